@@ -1,0 +1,191 @@
+/*
+ * match_oracle.cpp -- CPU restatement of the ORBmatcher inner kernels (TEST INFRASTRUCTURE ONLY).
+ * Follows /root/reference/src/ORBmatcher.cc: DescriptorDistance :2015-2031, best/second loop
+ * :208-231, accept + ratio :233-236, rotation histogram :241-251/:272-290, ComputeThreeMaxima
+ * :1969-2010, constants :57-59. PARITY UNPINNED (the reference has no tests); these functions are
+ * dependency-free integer code once cv::Mat is replaced by a pointer.
+ */
+#include "oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+const int TH_LOW = 50;          /* ORBmatcher.cc:58 */
+const int HISTO_LENGTH = 30;    /* ORBmatcher.cc:59 */
+
+/* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2015-2031): SWAR popcount over 8 x int32 */
+inline int descriptor_distance(const uint8_t* a, const uint8_t* b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4); memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+/* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:1969-2010) on bin sizes */
+void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; ++i) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+/* rotation bin (ORBmatcher.cc:243-248): rot = a_q - a_t (+360 if <0), bin = round(rot/30) mod 30.
+   `round` is C round() on a float promoted to double: half away from zero. */
+inline int rot_bin(float a_q, float a_t)
+{
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a_q - a_t;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)std::round(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+}  // namespace
+
+extern "C" {
+
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+
+void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* t_mask,
+              int32_t* best_idx, int32_t* best_d, int32_t* second_d)
+{
+    for (int i = 0; i < nq; ++i) {
+        int best1 = 256, best2 = 256, idx = -1;               /* ORBmatcher.cc:208-210 */
+        const uint8_t* dq = q + (size_t)i * 32;
+        for (int j = 0; j < nt; ++j) {
+            if (t_mask && t_mask[j]) continue;
+            const int dist = descriptor_distance(dq, t + (size_t)j * 32);
+            if (dist < best1) { best2 = best1; best1 = dist; idx = j; }
+            else if (dist < best2) { best2 = dist; }
+        }
+        best_idx[i] = idx; best_d[i] = best1; second_d[i] = best2;
+    }
+}
+
+void orc_knn2_grouped(const uint8_t* q, int nq, const uint8_t* t, int nt, int n_groups,
+                      const int32_t* q_off, const int32_t* q_idx, const int32_t* t_off, const int32_t* t_idx,
+                      int32_t* best_idx, int32_t* best_d, int32_t* second_d)
+{
+    (void)nt;
+    for (int i = 0; i < nq; ++i) { best_idx[i] = -1; best_d[i] = 256; second_d[i] = 256; }
+    for (int g = 0; g < n_groups; ++g) {
+        for (int a = q_off[g]; a < q_off[g + 1]; ++a) {
+            const int i = q_idx[a];
+            int best1 = 256, best2 = 256, idx = -1;
+            for (int b = t_off[g]; b < t_off[g + 1]; ++b) {
+                const int j = t_idx[b];
+                const int dist = descriptor_distance(q + (size_t)i * 32, t + (size_t)j * 32);
+                if (dist < best1) { best2 = best1; best1 = dist; idx = j; }
+                else if (dist < best2) { best2 = dist; }
+            }
+            best_idx[i] = idx; best_d[i] = best1; second_d[i] = best2;
+        }
+    }
+}
+
+int orc_ratio_rot_filter(int nq, const int32_t* best_idx, const int32_t* best_d, const int32_t* second_d,
+                         int th, int th_strict, float ratio, int check_ori,
+                         const float* q_angle, const float* t_angle, int32_t* match)
+{
+    int nmatches = 0;
+    std::vector<int> bin_of(nq, -1);
+    int histo[HISTO_LENGTH] = {0};
+    for (int i = 0; i < nq; ++i) {
+        match[i] = -1;
+        if (best_idx[i] < 0) continue;
+        const bool ok_th = th_strict ? (best_d[i] < th) : (best_d[i] <= th);
+        if (!ok_th) continue;
+        if (!(static_cast<float>(best_d[i]) < ratio * static_cast<float>(second_d[i]))) continue;
+        match[i] = best_idx[i];
+        if (check_ori) {
+            const int bin = rot_bin(q_angle[i], t_angle[best_idx[i]]);
+            bin_of[i] = bin;
+            ++histo[bin];
+        }
+        ++nmatches;
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < nq; ++i) {
+            const int b = bin_of[i];
+            if (b < 0 || b == ind1 || b == ind2 || b == ind3) continue;
+            match[i] = -1;
+            --nmatches;
+        }
+    }
+    return nmatches;
+}
+
+/* Faithful SearchByBoWCrossCam(F,cF,KF,cKF) (ORBmatcher.cc:162-294): sequential over KF features of
+   each shared vocabulary node; F candidates already claimed by an earlier query are skipped
+   (:216), so the result depends on processing order -- kept exactly. */
+int orc_search_by_bow_crosscam(const uint8_t* desc_kf, const float* ang_kf, const uint8_t* kf_valid, int n_kf,
+                               const uint8_t* desc_f, const float* ang_f, int n_f,
+                               const int32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx, int kf_n_nodes,
+                               const int32_t* f_nodes, const int32_t* f_off, const int32_t* f_idx, int f_n_nodes,
+                               float ratio, int check_ori, int32_t* match_f)
+{
+    (void)n_kf;
+    for (int j = 0; j < n_f; ++j) match_f[j] = -1;
+    int nmatches = 0;
+    std::vector<std::vector<int>> rot_hist(HISTO_LENGTH);
+    int a = 0, b = 0;
+    while (a < kf_n_nodes && b < f_n_nodes) {
+        if (kf_nodes[a] == f_nodes[b]) {
+            for (int ia = kf_off[a]; ia < kf_off[a + 1]; ++ia) {
+                const int ikf = kf_idx[ia];
+                if (!kf_valid[ikf]) continue;                       /* !pMP || pMP->isBad() */
+                int best1 = 256, best2 = 256, best_f = -1;
+                for (int ib = f_off[b]; ib < f_off[b + 1]; ++ib) {
+                    const int jf = f_idx[ib];
+                    if (match_f[jf] >= 0) continue;                 /* :216 */
+                    const int dist = descriptor_distance(desc_kf + (size_t)ikf * 32, desc_f + (size_t)jf * 32);
+                    if (dist < best1) { best2 = best1; best1 = dist; best_f = jf; }
+                    else if (dist < best2) { best2 = dist; }
+                }
+                if (best1 <= TH_LOW) {
+                    if (static_cast<float>(best1) < ratio * static_cast<float>(best2)) {
+                        match_f[best_f] = ikf;
+                        if (check_ori) rot_hist[rot_bin(ang_kf[ikf], ang_f[best_f])].push_back(best_f);
+                        ++nmatches;
+                    }
+                }
+            }
+            ++a; ++b;
+        } else if (kf_nodes[a] < f_nodes[b]) {
+            a = (int)(std::lower_bound(kf_nodes, kf_nodes + kf_n_nodes, f_nodes[b]) - kf_nodes);
+        } else {
+            b = (int)(std::lower_bound(f_nodes, f_nodes + f_n_nodes, kf_nodes[a]) - f_nodes);
+        }
+    }
+    if (check_ori) {
+        int histo[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; ++i) histo[i] = (int)rot_hist[i].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int jf : rot_hist[i]) { match_f[jf] = -1; --nmatches; }
+        }
+    }
+    return nmatches;
+}
+
+}  // extern "C"

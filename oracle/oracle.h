@@ -1,0 +1,149 @@
+/*
+ * oracle.h -- C interface of the CPU parity oracle (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * This directory is a dependency-free CPU restatement of the hot path of
+ * lixiny/ORB-SLAM2-DualCam (ORB extraction, Hamming matching, dual-camera local BA). It exists
+ * only as (1) the checker the HIP kernels are held to in tests/, __graft_entry__.smoke() and
+ * (2) the `cpu_baseline` leg of bench.py. Nothing under orb-slam2-dualcam_amd/ may include, link
+ * or call it.
+ *
+ * PARITY UNPINNED: the reference has no tests / golden vectors and cannot be built here (needs
+ * OpenCV >= 3.2 and Eigen3, both absent). The OpenCV/Eigen arithmetic the
+ * reference leans on (FAST, resize, GaussianBlur, fastAtan2, cvRound, SimplicialLDLT) is
+ * restated from the published OpenCV 3.3/3.4.0 non-IPP semantics written down in SURVEY.md
+ * Appendix A. Each function cites the reference file:line it follows.
+ */
+#ifndef ORB_DUALCAM_ORACLE_H
+#define ORB_DUALCAM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint layout (28 bytes), SURVEY.md Appendix E */
+typedef struct orc_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+/* pre-quadtree FAST candidate, level coordinates relative to minBorder (ORBextractor.cc:820-824) */
+typedef struct orc_candidate {
+    int16_t x, y;
+    int32_t score;
+} orc_candidate;
+
+typedef struct orc_orb orc_orb;
+
+/* ---- extraction (reference: src/ORBextractor.cc) ---- */
+orc_orb* orc_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th);
+void     orc_orb_destroy(orc_orb*);
+/* tables of the ctor (ORBextractor.cc:410-470); each array has nlevels entries (umax: 16) */
+void     orc_orb_tables(const orc_orb*, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                        int32_t* n_per_level, int32_t* umax16);
+/* ORBextractor::operator() (ORBextractor.cc:1043-1105). returns 0, or -1 if cap too small. */
+int      orc_orb_extract(orc_orb*, const uint8_t* img, int rows, int cols, int stride,
+                         orc_keypoint* kp, uint8_t* desc, int cap, int* n_out);
+/* stage accessors (valid after orc_orb_extract) for stage-by-stage parity tests */
+int      orc_orb_level_dims(const orc_orb*, int level, int* w, int* h);
+int      orc_orb_level_copy(const orc_orb*, int level, int blurred, uint8_t* dst /* w*h */);
+int      orc_orb_level_candidates(const orc_orb*, int level, orc_candidate* dst, int cap);
+int      orc_orb_level_keypoints(const orc_orb*, int level, orc_keypoint* dst, int cap);
+
+/* stand-alone stages */
+/* cv::resize INTER_LINEAR 8UC1 (OpenCV 3.3/3.4.0 non-IPP), SURVEY A.2 */
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+/* cv::GaussianBlur 7x7 sigma=2 BORDER_REFLECT_101, legacy 8-bit fixed point, SURVEY A.5 */
+void orc_gauss7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+/* cv::FAST(roi, T, nonmax=true) TYPE_9_16, SURVEY A.3. out: ROI-relative (x,y,score). returns count */
+int  orc_fast_roi(const uint8_t* roi, int w, int h, int stride, int threshold, orc_candidate* out, int cap);
+/* raw FAST-9/16 score of one pixel (max arc-min |diff| - 1; threshold independent) */
+int  orc_fast_score(const uint8_t* p, int stride);
+/* cv::fastAtan2 (OpenCV 3.x scalar polynomial), SURVEY A.4 */
+float orc_fast_atan2(float y, float x);
+/* IC_Angle (ORBextractor.cc:77-104) on an image with given stride, at integer (x,y) */
+float orc_ic_angle(const uint8_t* img, int stride, int x, int y);
+/* computeOrbDescriptor (ORBextractor.cc:108-147) */
+void orc_brief(const uint8_t* blurred, int stride, int x, int y, float angle_deg, uint8_t* desc32);
+/* DistributeOctTree (ORBextractor.cc:539-763) on candidates (in emission order); returns count */
+int  orc_distribute_octree(const orc_candidate* cand, int n, int minX, int maxX, int minY, int maxY,
+                           int N, orc_candidate* out, int cap);
+
+/* ---- matching (reference: src/ORBmatcher.cc) ---- */
+/* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2015-2031) */
+int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+/* best / second-best loop of ORBmatcher.cc:208-231 over ALL train descriptors (brute force);
+   t_mask[j] != 0 skips candidate j (may be NULL). best_idx = -1 when no candidate. */
+void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* t_mask,
+              int32_t* best_idx, int32_t* best_d, int32_t* second_d);
+/* same, restricted to CSR buckets: group g matches queries q_idx[q_off[g]..q_off[g+1]) against
+   candidates t_idx[t_off[g]..t_off[g+1]) (stateless variant: no "already matched" skipping) */
+void orc_knn2_grouped(const uint8_t* q, int nq, const uint8_t* t, int nt, int n_groups,
+                      const int32_t* q_off, const int32_t* q_idx, const int32_t* t_off, const int32_t* t_idx,
+                      int32_t* best_idx, int32_t* best_d, int32_t* second_d);
+/* accept test (ORBmatcher.cc:233-236) + rotation histogram (ORBmatcher.cc:241-251, 272-290,
+   1969-2010). match[i] = train index or -1. th_strict: use best < th (KF-KF variant :366). */
+int  orc_ratio_rot_filter(int nq, const int32_t* best_idx, const int32_t* best_d, const int32_t* second_d,
+                          int th, int th_strict, float ratio, int check_ori,
+                          const float* q_angle, const float* t_angle, int32_t* match);
+/* faithful greedy SearchByBoWCrossCam(F,cF,KF,cKF) (ORBmatcher.cc:162-294) on flat inputs.
+   KF side = queries (kf_valid[i] != 0 means "has a good MapPoint"), F side = candidates.
+   feature vectors as sorted node ids + CSR. match_f[j] = KF local index or -1. returns nmatches */
+int  orc_search_by_bow_crosscam(const uint8_t* desc_kf, const float* ang_kf, const uint8_t* kf_valid, int n_kf,
+                                const uint8_t* desc_f, const float* ang_f, int n_f,
+                                const int32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx, int kf_n_nodes,
+                                const int32_t* f_nodes, const int32_t* f_off, const int32_t* f_idx, int f_n_nodes,
+                                float ratio, int check_ori, int32_t* match_f);
+
+/* ---- local BA (reference: src/Optimizer.cc:407-696 + vendored g2o) ---- */
+typedef struct orc_ba_camera {
+    double fx, fy, cx, cy;
+    double ext[7];   /* extrinsic T_c (rig -> camera c): tx,ty,tz,qx,qy,qz,qw */
+    double adj[36];  /* row-major 6x6 "adjoint" as built by Cameras::setExtrinsics (Cameras.cc:27-37) */
+} orc_ba_camera;
+
+typedef struct orc_ba_problem {
+    int32_t n_poses, n_points, n_edges, n_cams;
+    const double*  poses;        /* [P][7] tx,ty,tz,qx,qy,qz,qw (world -> rig), ascending KF id */
+    const uint8_t* pose_fixed;   /* [P] */
+    const double*  points;       /* [L][3], ascending point id */
+    const int32_t* edge_pose;    /* [E] */
+    const int32_t* edge_point;   /* [E] */
+    const int32_t* edge_cam;     /* [E] */
+    const double*  obs;          /* [E][2] */
+    const double*  inv_sigma2;   /* [E] */
+    const orc_ba_camera* cams;   /* [n_cams] */
+    double huber_delta;          /* sqrt(5.991) (Optimizer.cc:515) */
+    double chi2_th;              /* 5.991 (Optimizer.cc:607) */
+    int32_t iters1, iters2;      /* 5, 10 (Optimizer.cc:587,619) */
+} orc_ba_problem;
+
+typedef struct orc_ba_result {
+    double*  poses;          /* [P][7] */
+    double*  points;         /* [L][3] */
+    double*  edge_chi2;      /* [E] chi2 of the last computeActiveErrors (inactive edges: stale value) */
+    uint8_t* edge_outlier;   /* [E] final check Optimizer.cc:653 */
+    uint8_t* edge_level1;    /* [E] excluded after round 1 (Optimizer.cc:607-610) */
+    int32_t  n_iters[2];     /* LM iterations run in each round */
+    int32_t  n_trials[2];    /* linear solves (trials) in each round */
+    double   lambda[2];      /* lambda at the end of each round */
+    double   chi2_trace[32]; /* robust chi2 at the end of each iteration (round1 then round2) */
+} orc_ba_result;
+
+int orc_ba_local(const orc_ba_problem* prob, const volatile uint8_t* stop_flag, orc_ba_result* res);
+
+/* edge pieces, for unit tests (types_six_dof_expmap.cpp:109-169) */
+void orc_ba_edge_error(const double pose[7], const double point[3], const orc_ba_camera* cam,
+                       const double obs[2], double err[2], double* depth);
+void orc_ba_edge_jacobian(const double pose[7], const double point[3], const orc_ba_camera* cam,
+                          double J_pose[12] /* 2x6 row-major */, double J_point[6] /* 2x3 */);
+/* SE3Quat::exp(update) * T (types_six_dof_expmap.h:73-76, se3quat.h:223-257) */
+void orc_se3_oplus(const double pose_in[7], const double update[6], double pose_out[7]);
+/* Cameras::setExtrinsics adjoint (Cameras.cc:27-37) from a float 4x4 T (row-major), LL block = 0 */
+void orc_rig_adjoint(const float T44[16], int exact, double adj36[36], double ext7[7]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,336 @@
+"""ctypes binding of the CPU parity oracle (TEST INFRASTRUCTURE -- see oracle/oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED: the reference has no golden vectors and cannot be built here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CANDIDATE = np.dtype([("x", "<i2"), ("y", "<i2"), ("score", "<i4")])
+assert KEYPOINT.itemsize == 28 and CANDIDATE.itemsize == 8
+
+
+def build(force=False):
+    """Compile oracle/*.cpp into oracle/_build/liboracle.so (g++ -O3, no -march=native)."""
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp",
+                                             "oracle.h", "brief_pattern.inc", "Makefile")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class BaCamera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("ext", C.c_double * 7), ("adj", C.c_double * 36)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32), ("n_cams", C.c_int32),
+                ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p),
+                ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p), ("edge_cam", C.c_void_p),
+                ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("cams", C.c_void_p),
+                ("huber_delta", C.c_double), ("chi2_th", C.c_double),
+                ("iters1", C.c_int32), ("iters2", C.c_int32)]
+
+
+class BaResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("edge_chi2", C.c_void_p),
+                ("edge_outlier", C.c_void_p), ("edge_level1", C.c_void_p),
+                ("n_iters", C.c_int32 * 2), ("n_trials", C.c_int32 * 2), ("lambda_", C.c_double * 2),
+                ("chi2_trace", C.c_double * 32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_orb_create.restype = C.c_void_p
+        L.orc_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_orb_destroy.argtypes = [C.c_void_p]
+        L.orc_orb_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_orb_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_orb_level_copy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_orb_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_orb_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_gauss7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_roi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_score.argtypes = [C.c_void_p, C.c_int]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_brief.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orc_distribute_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_knn2_grouped.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
+        L.orc_ratio_rot_filter.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_search_by_bow_crosscam.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_float, C.c_int, C.c_void_p]
+        L.orc_ba_local.argtypes = [C.POINTER(BaProblem), C.c_void_p, C.POINTER(BaResult)]
+        L.orc_ba_edge_error.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BaCamera), C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.orc_ba_edge_jacobian.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BaCamera), C.c_void_p, C.c_void_p]
+        L.orc_se3_oplus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_rig_adjoint.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class OrbOracle:
+    """Mirror of ORB_SLAM2::ORBextractor (include/ORBextractor.h:45-113) on the CPU restatement."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self._h = lib().orc_orb_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self._h:
+            raise ValueError("bad extractor parameters")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_orb_destroy(self._h)
+            self._h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        npl = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        lib().orc_orb_tables(self._h, _p(sc), _p(isc), _p(s2), _p(is2), _p(npl), _p(umax))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, n_per_level=npl, umax=umax)
+
+    def extract(self, img, cap=None):
+        """operator()(image) -> (keypoints[N] structured, descriptors[N,32] u8)."""
+        img = _c(img, np.uint8)
+        rows, cols = img.shape
+        cap = cap or max(self.nfeatures * 2 + 64, 64)
+        kp = np.zeros(cap, KEYPOINT)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        rc = lib().orc_orb_extract(self._h, _p(img), rows, cols, cols, _p(kp), _p(desc), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError("orc_orb_extract rc=%d (n=%d, cap=%d)" % (rc, n.value, cap))
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def level_dims(self, level):
+        w, h = C.c_int(), C.c_int()
+        lib().orc_orb_level_dims(self._h, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level_image(self, level, blurred=False):
+        w, h = self.level_dims(level)
+        out = np.zeros((h, w), np.uint8)
+        n = lib().orc_orb_level_copy(self._h, level, int(blurred), _p(out))
+        return out if n else None
+
+    def level_candidates(self, level):
+        n = lib().orc_orb_level_candidates(self._h, level, None, 0)
+        out = np.zeros(max(n, 1), CANDIDATE)
+        lib().orc_orb_level_candidates(self._h, level, _p(out), n)
+        return out[:n]
+
+    def level_keypoints(self, level):
+        n = lib().orc_orb_level_keypoints(self._h, level, None, 0)
+        out = np.zeros(max(n, 1), KEYPOINT)
+        lib().orc_orb_level_keypoints(self._h, level, _p(out), n)
+        return out[:n]
+
+
+def resize_linear_u8(src, dw, dh):
+    src = _c(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gauss7_u8(src):
+    src = _c(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().orc_gauss7_u8(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), src.shape[1])
+    return dst
+
+
+def fast_roi(roi, threshold):
+    roi = _c(roi, np.uint8)
+    cap = roi.size
+    out = np.zeros(max(cap, 1), CANDIDATE)
+    n = lib().orc_fast_roi(_p(roi), roi.shape[1], roi.shape[0], roi.shape[1], threshold, _p(out), cap)
+    return out[:n]
+
+
+def fast_score(img, x, y):
+    img = _c(img, np.uint8)
+    ptr = img.ctypes.data + y * img.shape[1] + x
+    return lib().orc_fast_score(C.c_void_p(ptr), img.shape[1])
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(float(y), float(x))
+
+
+def ic_angle(img, x, y):
+    img = _c(img, np.uint8)
+    return lib().orc_ic_angle(_p(img), img.shape[1], x, y)
+
+
+def brief(blurred, x, y, angle_deg):
+    blurred = _c(blurred, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orc_brief(_p(blurred), blurred.shape[1], x, y, float(angle_deg), _p(d))
+    return d
+
+
+def distribute_octree(cand, min_x, max_x, min_y, max_y, n_target):
+    cand = _c(cand, CANDIDATE)
+    out = np.zeros(max(len(cand), 1), CANDIDATE)
+    n = lib().orc_distribute_octree(_p(cand), len(cand), min_x, max_x, min_y, max_y, n_target, _p(out), len(out))
+    return out[:n]
+
+
+def descriptor_distance(a, b):
+    a, b = _c(a, np.uint8), _c(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def knn2(q, t, t_mask=None):
+    q, t = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
+    nq, nt = len(q), len(t)
+    bi, bd, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(3))
+    m = _c(t_mask, np.uint8) if t_mask is not None else None
+    lib().orc_knn2(_p(q), nq, _p(t), nt, _p(m), _p(bi), _p(bd), _p(sd))
+    return bi[:nq], bd[:nq], sd[:nq]
+
+
+def knn2_grouped(q, t, q_off, q_idx, t_off, t_idx):
+    q, t = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
+    q_off, q_idx, t_off, t_idx = (_c(a, np.int32) for a in (q_off, q_idx, t_off, t_idx))
+    nq = len(q)
+    bi, bd, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(3))
+    lib().orc_knn2_grouped(_p(q), nq, _p(t), len(t), len(q_off) - 1, _p(q_off), _p(q_idx), _p(t_off), _p(t_idx),
+                           _p(bi), _p(bd), _p(sd))
+    return bi[:nq], bd[:nq], sd[:nq]
+
+
+def ratio_rot_filter(best_idx, best_d, second_d, th=50, th_strict=False, ratio=0.75, check_ori=True,
+                     q_angle=None, t_angle=None):
+    best_idx, best_d, second_d = (_c(a, np.int32) for a in (best_idx, best_d, second_d))
+    nq = len(best_idx)
+    qa = _c(q_angle, np.float32) if q_angle is not None else np.zeros(max(nq, 1), np.float32)
+    ta = _c(t_angle, np.float32) if t_angle is not None else np.zeros(1, np.float32)
+    match = np.full(max(nq, 1), -1, np.int32)
+    n = lib().orc_ratio_rot_filter(nq, _p(best_idx), _p(best_d), _p(second_d), th, int(th_strict), float(ratio),
+                                   int(check_ori), _p(qa), _p(ta), _p(match))
+    return match[:nq], n
+
+
+def search_by_bow_crosscam(desc_kf, ang_kf, kf_valid, desc_f, ang_f, kf_fv, f_fv, ratio=0.75, check_ori=True):
+    """kf_fv / f_fv: (nodes, off, idx) CSR feature vectors with ascending node ids."""
+    desc_kf, desc_f = _c(desc_kf, np.uint8).reshape(-1, 32), _c(desc_f, np.uint8).reshape(-1, 32)
+    ang_kf, ang_f = _c(ang_kf, np.float32), _c(ang_f, np.float32)
+    kf_valid = _c(kf_valid, np.uint8)
+    kn, ko, ki = (_c(a, np.int32) for a in kf_fv)
+    fn, fo, fi = (_c(a, np.int32) for a in f_fv)
+    match = np.full(max(len(desc_f), 1), -1, np.int32)
+    n = lib().orc_search_by_bow_crosscam(_p(desc_kf), _p(ang_kf), _p(kf_valid), len(desc_kf),
+                                         _p(desc_f), _p(ang_f), len(desc_f),
+                                         _p(kn), _p(ko), _p(ki), len(kn), _p(fn), _p(fo), _p(fi), len(fn),
+                                         float(ratio), int(check_ori), _p(match))
+    return match[:len(desc_f)], n
+
+
+def make_camera(fx, fy, cx, cy, ext7, adj36):
+    c = BaCamera()
+    c.fx, c.fy, c.cx, c.cy = fx, fy, cx, cy
+    for i in range(7):
+        c.ext[i] = float(ext7[i])
+    for i in range(36):
+        c.adj[i] = float(np.asarray(adj36).reshape(-1)[i])
+    return c
+
+
+def rig_adjoint(T44_f32, exact=False):
+    T = _c(T44_f32, np.float32).reshape(16)
+    adj = np.zeros(36, np.float64)
+    ext = np.zeros(7, np.float64)
+    lib().orc_rig_adjoint(_p(T), int(exact), _p(adj), _p(ext))
+    return adj.reshape(6, 6), ext
+
+
+def ba_edge_error(pose7, point3, cam, obs2):
+    pose7, point3, obs2 = (_c(a, np.float64) for a in (pose7, point3, obs2))
+    e = np.zeros(2)
+    z = C.c_double()
+    lib().orc_ba_edge_error(_p(pose7), _p(point3), C.byref(cam), _p(obs2), _p(e), C.byref(z))
+    return e, z.value
+
+
+def ba_edge_jacobian(pose7, point3, cam):
+    pose7, point3 = _c(pose7, np.float64), _c(point3, np.float64)
+    jp, jx = np.zeros(12), np.zeros(6)
+    lib().orc_ba_edge_jacobian(_p(pose7), _p(point3), C.byref(cam), _p(jp), _p(jx))
+    return jp.reshape(2, 6), jx.reshape(2, 3)
+
+
+def se3_oplus(pose7, update6):
+    pose7, update6 = _c(pose7, np.float64), _c(update6, np.float64)
+    out = np.zeros(7)
+    lib().orc_se3_oplus(_p(pose7), _p(update6), _p(out))
+    return out
+
+
+def ba_local(prob, stop_flag=None):
+    """prob: dict with poses[P,7], pose_fixed[P], points[L,3], edge_pose/point/cam[E], obs[E,2],
+    inv_sigma2[E], cams (list of BaCamera), huber_delta, chi2_th, iters1, iters2."""
+    poses = _c(prob["poses"], np.float64)
+    fixed = _c(prob["pose_fixed"], np.uint8)
+    points = _c(prob["points"], np.float64)
+    ep, el, ec = (_c(prob[k], np.int32) for k in ("edge_pose", "edge_point", "edge_cam"))
+    obs = _c(prob["obs"], np.float64)
+    w = _c(prob["inv_sigma2"], np.float64)
+    cams = (BaCamera * len(prob["cams"]))(*prob["cams"])
+    P, L, E = len(poses), len(points), len(ep)
+    pb = BaProblem(P, L, E, len(prob["cams"]), _p(poses).value, _p(fixed).value, _p(points).value,
+                   _p(ep).value, _p(el).value, _p(ec).value, _p(obs).value, _p(w).value,
+                   C.cast(cams, C.c_void_p).value,
+                   float(prob.get("huber_delta", np.sqrt(5.991))), float(prob.get("chi2_th", 5.991)),
+                   int(prob.get("iters1", 5)), int(prob.get("iters2", 10)))
+    out_poses, out_points = np.zeros((P, 7)), np.zeros((L, 3))
+    chi2, outl, lvl1 = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+    res = BaResult(_p(out_poses).value, _p(out_points).value, _p(chi2).value, _p(outl).value, _p(lvl1).value)
+    sf = _p(stop_flag) if stop_flag is not None else None
+    rc = lib().orc_ba_local(C.byref(pb), sf, C.byref(res))
+    if rc != 0:
+        raise RuntimeError("orc_ba_local rc=%d" % rc)
+    return dict(poses=out_poses, points=out_points, edge_chi2=chi2, edge_outlier=outl, edge_level1=lvl1,
+                n_iters=list(res.n_iters), n_trials=list(res.n_trials), lambda_=list(res.lambda_),
+                chi2_trace=np.array(res.chi2_trace))

@@ -1,0 +1,7 @@
+"""orb-slam2-dualcam_amd: MI355X-native ORB extract + Hamming match + dual-camera local BA.
+
+Python side = thin ctypes mirror of the C ABI in include/dcs_abi.h (used by tests/ and bench.py).
+The product is the HIP library built from csrc/; there is NO CPU fallback: every entry point
+raises if the library is missing.
+"""
+from . import synth  # noqa: F401

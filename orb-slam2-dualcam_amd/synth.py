@@ -1,0 +1,302 @@
+"""Seeded synthetic inputs for the hot path: procedural dual-camera images,
+random descriptor sets with CSR vocabulary buckets, and the C4 local-BA problem.
+
+numpy only; used by tests/, bench.py and __graft_entry__.smoke(). The real sequence
+(indoor_lab_loop.avi) and vocabulary (ORBvoc) of the reference are external downloads and are
+not available, so every input is generated here and `data` is reported as "synthetic".
+"""
+import numpy as np
+
+# shipped rig calibration (reference Dual-LenaCV.yaml:12-47), parsed to float like Tracking.cc:109-160
+RIG = {
+    "cam0": dict(fx=558.4684, fy=560.0944, cx=326.7993, cy=262.9017),
+    "cam1": dict(fx=546.597961663159, fy=546.254254416417, cx=332.758939924785, cy=247.385425357685,
+                 q=(0.82351, -0.00262741, 0.567257, 0.00665084),   # qw, qx, qy, qz
+                 t=(0.069481, -0.000909887, -0.0713882)),
+}
+
+
+def _draw_scene(rng, width, height, n_rect, n_disc):
+    img = np.full((height, width), 128.0, np.float32)
+    for _ in range(n_rect):
+        w, h = rng.integers(8, 81, 2)
+        x, y = rng.integers(-20, width), rng.integers(-20, height)
+        img[max(y, 0):max(y + h, 0), max(x, 0):max(x + w, 0)] = float(rng.integers(0, 256))
+    for _ in range(n_disc):
+        r = int(rng.integers(4, 41))
+        cx, cy = int(rng.integers(0, width)), int(rng.integers(0, height))
+        x0, x1, y0, y1 = max(cx - r, 0), min(cx + r + 1, width), max(cy - r, 0), min(cy + r + 1, height)
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        mask = (xx - cx) ** 2 + (yy - cy) ** 2 <= r * r
+        img[y0:y1, x0:x1][mask] = float(rng.integers(0, 256))
+    gy, gx = np.mgrid[0:height, 0:width]
+    img += 20.0 * (gx / width - 0.5) + 12.0 * (gy / height - 0.5)
+    return img
+
+
+def _warp_h(img, H):
+    """bilinear warp: out(x,y) = img(H^-1 (x,y))."""
+    h, w = img.shape
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    Hi = np.linalg.inv(H)
+    d = Hi[2, 0] * xs + Hi[2, 1] * ys + Hi[2, 2]
+    sx = (Hi[0, 0] * xs + Hi[0, 1] * ys + Hi[0, 2]) / d
+    sy = (Hi[1, 0] * xs + Hi[1, 1] * ys + Hi[1, 2]) / d
+    sx = np.clip(sx, 0, w - 1.001)
+    sy = np.clip(sy, 0, h - 1.001)
+    x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+    fx, fy = sx - x0, sy - y0
+    a = img[y0, x0] * (1 - fx) + img[y0, x0 + 1] * fx
+    b = img[y0 + 1, x0] * (1 - fx) + img[y0 + 1, x0 + 1] * fx
+    return (a * (1 - fy) + b * fy).astype(np.float32)
+
+
+_SCENES = {}
+
+
+def frame_pair(width=640, height=480, stream=0, frame=0):
+    """Two u8 images (cam0, cam1) of stream `stream` at time `frame`.
+
+    Scene: mid-grey canvas + random filled rectangles / discs (sizes 8-80 px) + smooth gradient;
+    frame t = scene translated by (3t, t) px; cam1 = cam0's view warped by a fixed homography;
+    i.i.d. Gaussian noise sigma=3 with seed 1234 + stream*100 + cam*10 + frame.
+    """
+    big = max(width, height) >= 1000
+    key = (width, height, stream)
+    if key not in _SCENES:
+        rng = np.random.default_rng(1234 + stream * 100)
+        pad = 256
+        _SCENES.clear()
+        _SCENES[key] = _draw_scene(rng, width + pad, height + pad, 1200 if big else 400, 600 if big else 200)
+    scene = _SCENES[key]
+    ox, oy = (3 * frame) % 250, frame % 250
+    view = scene[oy:oy + height, ox:ox + width]
+    H = np.array([[0.96, 0.03, 14.0], [-0.025, 0.98, 9.0], [2.0e-5, -1.0e-5, 1.0]])
+    out = []
+    for cam in (0, 1):
+        base = view if cam == 0 else _warp_h(view, H)
+        rng = np.random.default_rng(1234 + stream * 100 + cam * 10 + frame)
+        noisy = base + rng.normal(0.0, 3.0, base.shape).astype(np.float32)
+        out.append(np.clip(np.rint(noisy), 0, 255).astype(np.uint8))
+    return out[0], out[1]
+
+
+def random_descriptors(n, seed=7):
+    return np.random.default_rng(seed).integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+def noisy_copy(desc, flip_bits=20, seed=11):
+    """descriptors with `flip_bits` random bits flipped per row (so knn2 finds real matches)."""
+    rng = np.random.default_rng(seed)
+    out = desc.copy()
+    for i in range(len(out)):
+        bits = rng.choice(256, flip_bits, replace=False)
+        for b in bits:
+            out[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return out
+
+
+def csr_buckets(n_items, n_buckets=100, seed=3):
+    """Random partition emulating a DBoW2 FeatureVector (Frame.cc:400-402): every item in exactly
+    one node; returns (node_ids ascending, off[n_nodes+1], idx) with idx ascending inside a node."""
+    rng = np.random.default_rng(seed)
+    node = rng.integers(0, n_buckets, n_items)
+    ids = np.unique(node)
+    off = [0]
+    idx = []
+    for k in ids:
+        members = np.nonzero(node == k)[0]
+        idx.extend(members.tolist())
+        off.append(len(idx))
+    return ids.astype(np.int32), np.asarray(off, np.int32), np.asarray(idx, np.int32)
+
+
+# ----------------------------------------------------------------------------- BA (C4)
+def _quat_from_R(R):
+    """Shoemake / Eigen quaternion from rotation matrix, returns (x,y,z,w) normalised, w >= 0."""
+    t = R[0, 0] + R[1, 1] + R[2, 2]
+    if t > 0:
+        s = np.sqrt(t + 1.0)
+        w = 0.5 * s
+        s = 0.5 / s
+        x, y, z = (R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s
+    else:
+        i = 0
+        if R[1, 1] > R[0, 0]:
+            i = 1
+        if R[2, 2] > R[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        v = np.zeros(3)
+        v[i] = 0.5 * s
+        s = 0.5 / s
+        w = (R[k, j] - R[j, k]) * s
+        v[j] = (R[j, i] + R[i, j]) * s
+        v[k] = (R[k, i] + R[i, k]) * s
+        x, y, z = v
+    q = np.array([x, y, z, w])
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def _rodrigues(rv):
+    th = np.linalg.norm(rv)
+    if th < 1e-12:
+        return np.eye(3)
+    k = rv / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+def rig_extrinsics_f32():
+    """4x4 float32 T_c (rig -> camera c) for the shipped rig, built like Tracking.cc:146-171."""
+    T0 = np.eye(4, dtype=np.float32)
+    qw, qx, qy, qz = (float(np.float32(v)) for v in RIG["cam1"]["q"])
+    t = [float(np.float32(v)) for v in RIG["cam1"]["t"]]
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                  [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                  [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    T1 = np.eye(4)
+    T1[:3, :3] = R
+    T1[:3, 3] = t
+    return T0, T1.astype(np.float32)
+
+
+def rig_adjoint_f32(T, exact=False):
+    """Cameras::setExtrinsics adjoint (Cameras.cc:27-37): [[R, R t^],[0, R]] in float32 (Q1: the
+    reference leaves the lower-left block uninitialised, 0 here); exact -> g2o adj() [[R,0],[t^R,R]].
+    Returns (adj 6x6 float64, ext7 = tx,ty,tz,qx,qy,qz,qw float64)."""
+    T = np.asarray(T, np.float32)
+    R32, t32 = T[:3, :3], T[:3, 3]
+    q = _quat_from_R(R32.astype(np.float64))
+    ext7 = np.concatenate([t32.astype(np.float64), q])
+    adj = np.zeros((6, 6))
+    if not exact:
+        th = np.array([[0, -t32[2], t32[1]], [t32[2], 0, -t32[0]], [-t32[1], t32[0], 0]], np.float32)
+        Rt = np.zeros((3, 3), np.float32)
+        for i in range(3):
+            for j in range(3):
+                acc = np.float32(0)
+                for k in range(3):
+                    acc = np.float32(acc + np.float32(R32[i, k] * th[k, j]))
+                Rt[i, j] = acc
+        adj[:3, :3] = R32
+        adj[3:, 3:] = R32
+        adj[:3, 3:] = Rt
+    else:
+        x, y, z, w = q
+        Rn = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        t = t32.astype(np.float64)
+        th = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        adj[:3, :3] = Rn
+        adj[3:, 3:] = Rn
+        adj[3:, :3] = th @ Rn
+    return adj, ext7
+
+
+def ba_problem(n_poses=50, n_fixed=10, n_points=2000, obs_per_point=10, seed=42, outlier_frac=0.05,
+               exact_adjoint=False, noise=True):
+    """poses on a loop, points in a 12x4x12 m box, dual-camera observations with
+    the shipped rig, octave-dependent pixel noise, 5 % gross outliers, perturbed initial state.
+    All state passes through float32 like the reference's cv::Mat CV_32F (Converter.cc:58-68).
+
+    Returns dict of numpy arrays (poses[P,7] = tx,ty,tz,qx,qy,qz,qw world->rig; cams = list of
+    (fx,fy,cx,cy,ext7,adj6x6)), plus ground truth under 'gt_*'.
+    """
+    rng = np.random.default_rng(seed)
+    P, L = n_poses, n_points
+    T0, T1 = rig_extrinsics_f32()
+    cams = []
+    for c, T in enumerate((T0, T1)):
+        k = RIG["cam%d" % c]
+        adj, ext7 = rig_adjoint_f32(T, exact_adjoint)
+        cams.append(dict(fx=float(np.float32(k["fx"])), fy=float(np.float32(k["fy"])),
+                         cx=float(np.float32(k["cx"])), cy=float(np.float32(k["cy"])),
+                         ext7=ext7, adj=adj, T=T.astype(np.float64)))
+    # ground-truth poses: centres on a circle of circumference ~10 m, small rotations (<= 10 deg)
+    R_gt, t_gt = [], []
+    radius = 10.0 / (2 * np.pi)
+    for i in range(P):
+        a = 2 * np.pi * i / P
+        centre = np.array([radius * np.cos(a), 0.1 * np.sin(3 * a), radius * np.sin(a)])
+        rv = rng.uniform(-1, 1, 3)
+        rv = rv / np.linalg.norm(rv) * np.deg2rad(rng.uniform(0, 10))
+        R = _rodrigues(rv)
+        R_gt.append(R)
+        t_gt.append(-R @ centre)
+    R_gt, t_gt = np.array(R_gt), np.array(t_gt)
+
+    def project_all(X):
+        """X[n,3] -> uv[n,P,2,2], z[n,P,2]"""
+        pr = np.einsum("pij,nj->npi", R_gt, X) + t_gt[None]
+        uv = np.zeros((len(X), P, 2, 2))
+        z = np.zeros((len(X), P, 2))
+        for c, cam in enumerate(cams):
+            pc = pr @ cam["T"][:3, :3].T + cam["T"][:3, 3]
+            z[:, :, c] = pc[:, :, 2]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                uv[:, :, c, 0] = cam["fx"] * pc[:, :, 0] / pc[:, :, 2] + cam["cx"]
+                uv[:, :, c, 1] = cam["fy"] * pc[:, :, 1] / pc[:, :, 2] + cam["cy"]
+        return uv, z
+
+    pts, e_pose, e_point, e_cam, e_uv = [], [], [], [], []
+    while len(pts) < L:
+        X = np.column_stack([rng.uniform(-6, 6, 4 * L), rng.uniform(-2, 2, 4 * L), rng.uniform(-6, 6, 4 * L)])
+        uv, z = project_all(X)
+        vis = (z > 0.1) & (uv[..., 0] >= 0) & (uv[..., 0] < 640) & (uv[..., 1] >= 0) & (uv[..., 1] < 480)
+        for n in range(len(X)):
+            if len(pts) >= L:
+                break
+            poses_ok = np.nonzero(vis[n].any(axis=1))[0]
+            if len(poses_ok) < obs_per_point:
+                continue
+            chosen = np.sort(rng.choice(poses_ok, obs_per_point, replace=False))
+            l = len(pts)
+            pts.append(X[n])
+            for p in chosen:
+                both = vis[n, p]
+                c = int(rng.integers(0, 2)) if both.all() else int(np.argmax(both))
+                e_pose.append(p); e_point.append(l); e_cam.append(c); e_uv.append(uv[n, p, c])
+    pts = np.array(pts)
+    e_pose, e_point, e_cam = (np.asarray(a, np.int32) for a in (e_pose, e_point, e_cam))
+    e_uv = np.array(e_uv)
+    E = len(e_pose)
+    octave = rng.integers(0, 8, E)
+    scale = np.ones(8, np.float32)
+    for i in range(1, 8):
+        scale[i] = np.float32(np.float64(scale[i - 1]) * np.float64(np.float32(1.2)))
+    inv_sigma2 = (np.float32(1.0) / (scale * scale)).astype(np.float32)
+    obs = e_uv.copy()
+    if noise:
+        obs += rng.normal(0, 1, (E, 2)) * scale[octave][:, None]
+        n_out = int(round(outlier_frac * E))
+        bad = rng.choice(E, n_out, replace=False)
+        obs[bad] += rng.choice([-50.0, 50.0], (n_out, 2))
+    obs = obs.astype(np.float32).astype(np.float64)
+    # fixed: pose 0 (fixId, Optimizer.cc:483) and the last n_fixed poses (fixed-camera set :489-500)
+    fixed = np.zeros(P, np.uint8)
+    fixed[0] = 1
+    fixed[P - n_fixed:] = 1
+    poses = np.zeros((P, 7))
+    for i in range(P):
+        R, t = R_gt[i], t_gt[i]
+        if noise and not fixed[i]:
+            R = _rodrigues(rng.normal(0, 0.02, 3)) @ R
+            t = t + rng.normal(0, 0.05, 3)
+        R32, t32 = R.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64)
+        poses[i, :3] = t32
+        poses[i, 3:] = _quat_from_R(R32)
+    gt_poses = np.zeros((P, 7))
+    for i in range(P):
+        gt_poses[i, :3] = t_gt[i]
+        gt_poses[i, 3:] = _quat_from_R(R_gt[i])
+    points = pts + (rng.normal(0, 0.05, pts.shape) if noise else 0.0)
+    points = points.astype(np.float32).astype(np.float64)
+    return dict(poses=poses, pose_fixed=fixed, points=points, edge_pose=e_pose, edge_point=e_point,
+                edge_cam=e_cam, obs=obs, inv_sigma2=inv_sigma2[octave].astype(np.float64), cams=cams,
+                huber_delta=float(np.float32(np.sqrt(5.991))), chi2_th=5.991, iters1=5, iters2=10,
+                gt_poses=gt_poses, gt_points=pts)

@@ -1,0 +1,144 @@
+"""Known-answer tests for the local-BA oracle (Optimizer.cc:407-696 + vendored g2o arithmetic)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _cams(oracle, synth, exact=False):
+    T0, T1 = synth.rig_extrinsics_f32()
+    out = []
+    for c, T in enumerate((T0, T1)):
+        k = synth.RIG["cam%d" % c]
+        adj, ext = synth.rig_adjoint_f32(T, exact)
+        out.append(oracle.make_camera(np.float32(k["fx"]), np.float32(k["fy"]), np.float32(k["cx"]), np.float32(k["cy"]), ext, adj))
+    return out
+
+
+def test_rig_adjoint_helper(oracle, synth):
+    T0, T1 = synth.rig_extrinsics_f32()
+    for exact in (False, True):
+        adj_py, ext_py = synth.rig_adjoint_f32(T1, exact)
+        adj_c, ext_c = oracle.rig_adjoint(T1, exact)
+        assert np.allclose(adj_py, adj_c, atol=1e-12) and np.allclose(ext_py, ext_c, atol=1e-12)
+    adj, ext = oracle.rig_adjoint(T0, False)
+    assert np.array_equal(adj, np.eye(6)) and ext.tolist() == [0, 0, 0, 0, 0, 0, 1]
+    adj, _ = oracle.rig_adjoint(T1, False)
+    assert np.all(adj[3:, :3] == 0)            # Q1: lower-left block (uninitialised in the reference) = 0
+    assert np.abs(adj[:3, 3:]).max() > 0.05    # UR = R * t^
+
+
+def test_edge_error_and_jacobian(oracle, synth):
+    cams = _cams(oracle, synth, exact=True)
+    cams_ref = _cams(oracle, synth, exact=False)
+    rng = np.random.default_rng(0)
+    pose = np.array([0.1, -0.2, 0.3, 0.05, -0.02, 0.03, 0.0])
+    pose[6] = np.sqrt(1 - np.sum(pose[3:6] ** 2))
+    for c in (0, 1):
+        X = np.array([0.4, -0.3, 5.0]) if c == 0 else np.array([-4.0, 0.2, 3.5])
+        e0, z = oracle.ba_edge_error(pose, X, cams[c], np.zeros(2))
+        assert z > 0.5
+        # error = obs - projection: a perfect observation gives 0
+        e, _ = oracle.ba_edge_error(pose, X, cams[c], -e0)
+        assert np.allclose(e, 0, atol=1e-12)
+        Jp, Jx = oracle.ba_edge_jacobian(pose, X, cams[c])
+        h = 1e-6
+        Jp_fd, Jx_fd = np.zeros((2, 6)), np.zeros((2, 3))
+        for k in range(6):
+            d = np.zeros(6); d[k] = h
+            ep, _ = oracle.ba_edge_error(oracle.se3_oplus(pose, d), X, cams[c], np.zeros(2))
+            em, _ = oracle.ba_edge_error(oracle.se3_oplus(pose, -d), X, cams[c], np.zeros(2))
+            Jp_fd[:, k] = (ep - em) / (2 * h)
+        for k in range(3):
+            d = np.zeros(3); d[k] = h
+            ep, _ = oracle.ba_edge_error(pose, X + d, cams[c], np.zeros(2))
+            em, _ = oracle.ba_edge_error(pose, X - d, cams[c], np.zeros(2))
+            Jx_fd[:, k] = (ep - em) / (2 * h)
+        assert np.allclose(Jx, Jx_fd, rtol=0, atol=2e-5 * np.abs(Jx_fd).max())
+        # with g2o's true adjoint the pose Jacobian IS the derivative (checked to ~1e-7)
+        assert np.allclose(Jp, Jp_fd, rtol=0, atol=2e-5 * np.abs(Jp_fd).max())
+        # with the reference's matrix (UR = R t^, LL = 0) it is exact for cam0 and an approximation for cam1 (Q2)
+        Jp_ref, Jx_ref = oracle.ba_edge_jacobian(pose, X, cams_ref[c])
+        assert np.allclose(Jx_ref, Jx)
+        dev = np.abs(Jp_ref - Jp_fd).max() / np.abs(Jp_fd).max()
+        assert dev < 1e-5 if c == 0 else 1e-3 < dev < 0.2
+
+
+def test_se3_oplus(oracle):
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    assert np.allclose(oracle.se3_oplus(ident, np.zeros(6)), ident)
+    out = oracle.se3_oplus(ident, np.array([0, 0, 0, 1.0, -2.0, 3.0]))       # pure translation (theta < 1e-5 branch)
+    assert np.allclose(out, [1, -2, 3, 0, 0, 0, 1])
+    th = 0.3
+    out = oracle.se3_oplus(ident, np.array([0, 0, th, 0, 0, 0]))              # rotation about z
+    assert np.allclose(out[3:], [0, 0, np.sin(th / 2), np.cos(th / 2)], atol=1e-14)
+    # left-multiplicative: exp(d) * T
+    T = np.array([1.0, 2.0, 3.0, 0, 0, 0, 1.0])
+    out = oracle.se3_oplus(T, np.array([0, 0, np.pi / 2, 0, 0, 0]))
+    assert np.allclose(out[:3], [-2, 1, 3], atol=1e-12)
+    # small-angle branch uses R = I + W + W^2 (se3quat.h:238-244), still ~ a rotation
+    out = oracle.se3_oplus(ident, np.array([1e-6, 0, 0, 0, 0, 0]))
+    assert abs(out[3] - 5e-7) < 1e-12 and abs(np.linalg.norm(out[3:]) - 1) < 1e-15
+
+
+def _run(oracle, pb, **kw):
+    prob = dict(pb); prob.update(kw)
+    prob["cams"] = [oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pb["cams"]]
+    return oracle.ba_local(prob)
+
+
+def test_ba_noise_free_converges_to_ground_truth(oracle, synth):
+    """noise-free problem must converge to ground truth within 1e-4."""
+    pb = synth.ba_problem(n_poses=10, n_fixed=3, n_points=120, obs_per_point=5, seed=3, noise=False)
+    rng = np.random.default_rng(1)
+    start = dict(pb)
+    start["points"] = pb["points"] + rng.normal(0, 0.03, pb["points"].shape)
+    poses = pb["poses"].copy()
+    for i in range(len(poses)):
+        if not pb["pose_fixed"][i]:
+            poses[i, :3] += rng.normal(0, 0.02, 3)
+    start["poses"] = poses
+    r = _run(oracle, start)
+    free = pb["pose_fixed"] == 0
+    assert np.abs(r["poses"][free, :3] - pb["gt_poses"][free, :3]).max() < 1e-4
+    assert np.abs(r["points"] - pb["gt_points"]).max() < 2e-3
+    assert r["edge_outlier"].sum() == 0 and r["edge_level1"].sum() == 0
+    assert np.array_equal(r["poses"][~free], pb["poses"][~free])           # fixed poses untouched
+    tr = r["chi2_trace"][:sum(r["n_iters"])]
+    assert tr[-1] < 1e-3 * tr[0] + 1e-3
+
+
+def test_ba_small_golden_and_outliers(oracle, synth):
+    g = np.load(os.path.join(GOLDEN, "ba_small.npz"))
+    pb = synth.ba_problem(n_poses=12, n_fixed=3, n_points=150, obs_per_point=6, seed=7)
+    assert np.array_equal(pb["poses"], g["in_poses"]) and np.array_equal(pb["obs"], g["obs"])
+    r = _run(oracle, pb)
+    assert np.allclose(r["poses"], g["poses"], atol=1e-9) and np.allclose(r["points"], g["points"], atol=1e-9)
+    assert np.array_equal(r["edge_outlier"], g["edge_outlier"]) and np.array_equal(r["edge_level1"], g["edge_level1"])
+    assert r["n_iters"] == g["n_iters"].tolist() and r["n_trials"] == g["n_trials"].tolist()
+    # 5 % gross outliers (+-50 px) are excluded from round 2, plus the ~5 % of inliers above the
+    # chi2 95 % quantile (5.991)
+    n_bad = int(round(0.05 * len(pb["obs"])))
+    assert n_bad * 0.9 <= r["edge_level1"].sum() <= n_bad * 2.4
+    free = pb["pose_fixed"] == 0
+    err0 = np.abs(pb["poses"][free, :3] - pb["gt_poses"][free, :3]).max()
+    err1 = np.abs(r["poses"][free, :3] - pb["gt_poses"][free, :3]).max()
+    assert err1 < 0.25 * err0
+    # robust chi2 decreases monotonically inside each round (accepted steps only)
+    k = r["n_iters"][0]
+    assert np.all(np.diff(r["chi2_trace"][:k]) <= 1e-9) and np.all(np.diff(r["chi2_trace"][k:k + r["n_iters"][1]]) <= 1e-9)
+
+
+def test_ba_stop_flag_and_degenerate(oracle, synth):
+    pb = synth.ba_problem(n_poses=8, n_fixed=2, n_points=60, obs_per_point=4, seed=5)
+    stop = np.ones(1, np.uint8)
+    prob = dict(pb)
+    prob["cams"] = [oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pb["cams"]]
+    r = oracle.ba_local(prob, stop_flag=stop)                      # Optimizer.cc:582-584: early return
+    assert r["n_iters"] == [0, 0] and np.array_equal(r["poses"], pb["poses"]) and np.array_equal(r["points"], pb["points"])
+    # all poses fixed: only points move (structure-only), still fine
+    allfix = dict(pb); allfix["pose_fixed"] = np.ones(8, np.uint8)
+    r = _run(oracle, allfix)
+    assert np.array_equal(r["poses"], pb["poses"]) and r["n_iters"][0] >= 1
+    assert not np.array_equal(r["points"], pb["points"])

@@ -1,0 +1,118 @@
+"""Known-answer tests for the matcher oracle (ORBmatcher.cc:57-59, 162-294, 1969-2031)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_hamming_kats(oracle, synth):
+    z, o = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert oracle.descriptor_distance(z, z) == 0 and oracle.descriptor_distance(z, o) == 256
+    for bit in (0, 7, 8, 100, 255):
+        a = z.copy()
+        a[bit >> 3] |= 1 << (bit & 7)
+        assert oracle.descriptor_distance(a, z) == 1
+    d = synth.random_descriptors(64, seed=7)
+    for i in range(0, 64, 2):
+        x = int.from_bytes(d[i].tobytes(), "little") ^ int.from_bytes(d[i + 1].tobytes(), "little")
+        assert oracle.descriptor_distance(d[i], d[i + 1]) == bin(x).count("1")
+
+
+def test_knn2_semantics(oracle, synth):
+    q = synth.random_descriptors(50, seed=1)
+    t = synth.random_descriptors(70, seed=2)
+    t[10] = q[3]; t[40] = q[3]                 # duplicate best: first index wins (strict <), second = same dist
+    bi, bd, sd = oracle.knn2(q, t)
+    D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    assert np.array_equal(bd, D.min(1)) and np.array_equal(bi, D.argmin(1))
+    srt = np.sort(D, axis=1)
+    assert np.array_equal(sd, srt[:, 1])
+    assert bi[3] == 10 and bd[3] == 0 and sd[3] == 0
+    # masked candidates are skipped; empty candidate set -> idx -1, dist 256/256 (ORBmatcher.cc:208-210)
+    mask = np.zeros(70, np.uint8); mask[10] = 1
+    assert oracle.knn2(q, t, mask)[0][3] == 40
+    bi0, bd0, sd0 = oracle.knn2(q, t[:0])
+    assert np.all(bi0 == -1) and np.all(bd0 == 256) and np.all(sd0 == 256)
+    bi1, bd1, sd1 = oracle.knn2(q, t[:1])
+    assert np.all(bi1 == 0) and np.all(sd1 == 256)
+    assert len(oracle.knn2(q[:0], t)[0]) == 0
+
+
+def test_knn2_grouped(oracle, synth):
+    q = synth.random_descriptors(200, seed=3)
+    t = synth.random_descriptors(300, seed=4)
+    qn, qo, qi = synth.csr_buckets(200, 20, seed=5)
+    tn, to, ti = synth.csr_buckets(300, 20, seed=6)
+    assert np.array_equal(qn, tn)              # all 20 nodes populated on both sides
+    bi, bd, sd = oracle.knn2_grouped(q, t, qo, qi, to, ti)
+    for g in range(len(qn)):
+        cand = ti[to[g]:to[g + 1]]
+        for i in qi[qo[g]:qo[g + 1]]:
+            b, d, s = oracle.knn2(q[i:i + 1], t[cand])
+            assert bi[i] == cand[b[0]] and bd[i] == d[0] and sd[i] == s[0]
+
+
+def test_ratio_rot_filter(oracle):
+    # accept: best <= 50 and best < ratio*second (ORBmatcher.cc:233-236); strict variant best < 50 (:366)
+    bi = np.array([0, 1, 2, 3, -1], np.int32)
+    bd = np.array([50, 51, 30, 30, 256], np.int32)
+    sd = np.array([100, 100, 40, 41, 256], np.int32)
+    m, n = oracle.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, False)
+    assert m.tolist() == [0, -1, -1, 3, -1] and n == 2       # 30 < 0.75*40 is false (30 < 30)
+    m, n = oracle.ratio_rot_filter(bi, bd, sd, 50, True, 0.75, False)
+    assert m.tolist() == [-1, -1, -1, 3, -1] and n == 1
+    # rotation histogram: bins of 12 deg... factor 1/30 on degrees -> bin = round(rot/30), 30 -> 0
+    nq = 40
+    bi = np.arange(nq, dtype=np.int32); bd = np.full(nq, 10, np.int32); sd = np.full(nq, 100, np.int32)
+    qa = np.zeros(nq, np.float32); ta = np.zeros(nq, np.float32)
+    qa[:20] = 100.0                     # rot 100 -> bin round(3.33) = 3   (20 votes)
+    qa[20:30] = 200.0                   # bin 7                            (10 votes)
+    qa[30:38] = 20.0; ta[30:38] = 30.0  # rot -10+360=350 -> round(11.67) = 12 (8 votes)
+    qa[38] = 355.0                      # round(11.83) = 12 ... 355/30 = 11.83 -> 12 (1 more)
+    qa[39] = 359.0                      # 359/30 = 11.97 -> 12
+    m, n = oracle.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, qa, ta)
+    assert n == 40 and np.all(m >= 0)   # exactly three populated bins: all kept
+    qa[39] = 50.0                       # a 4th bin (round(1.67)=2) with 1 vote: dropped
+    m, n = oracle.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, qa, ta)
+    assert n == 39 and m[39] == -1
+    # second/third maxima dropped when < 0.1 * max (ComputeThreeMaxima :2001-2009)
+    qa[:] = 100.0; qa[0] = 200.0
+    m, n = oracle.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, qa, ta)
+    assert n == 39 and m[0] == -1
+    # bin 30 wraps to 0: rot = 359.9 -> round(11.997)=12; rot 900? not reachable; test rot=345 -> 11.5 -> 12 (half away)
+    qa[:] = 345.0
+    assert oracle.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, qa, ta)[1] == 40
+
+
+def test_search_by_bow_greedy(oracle, synth):
+    """the faithful SearchByBoWCrossCam: already-claimed F features are skipped (:216)."""
+    base = synth.random_descriptors(3, seed=8)
+    kf = np.stack([base[0], base[0], base[1]])          # two identical KF queries, same node
+    f = np.stack([base[0], synth.noisy_copy(base[:1], 30, seed=1)[0], base[2]])
+    ang = np.zeros(3, np.float32)
+    fv_kf = (np.array([5], np.int32), np.array([0, 3], np.int32), np.array([0, 1, 2], np.int32))
+    fv_f = (np.array([5], np.int32), np.array([0, 3], np.int32), np.array([0, 1, 2], np.int32))
+    m, n = oracle.search_by_bow_crosscam(kf, ang, np.ones(3, np.uint8), f, ang, fv_kf, fv_f, ratio=0.9, check_ori=False)
+    # query 0 claims F0 (dist 0); query 1 cannot see F0 any more and takes F1 (dist 30) if it passes ratio
+    assert m[0] == 0 and m[1] == 1 and n == 2
+    # invalid KF features (no MapPoint) are skipped; disjoint nodes produce nothing
+    m, n = oracle.search_by_bow_crosscam(kf, ang, np.array([0, 1, 1], np.uint8), f, ang, fv_kf, fv_f, ratio=0.9, check_ori=False)
+    assert m[0] == 1 and n == 1
+    fv_f2 = (np.array([6], np.int32), fv_f[1], fv_f[2])
+    assert oracle.search_by_bow_crosscam(kf, ang, np.ones(3, np.uint8), f, ang, fv_kf, fv_f2, 0.9, False)[1] == 0
+    # merge-join over several nodes equals the stateless grouped knn2 + filter when no F is contested
+    q = synth.random_descriptors(120, seed=20)
+    t = synth.noisy_copy(q, 10, seed=21)
+    nodes, off, idx = synth.csr_buckets(120, 15, seed=22)
+    qa = np.zeros(120, np.float32)
+    m, n = oracle.search_by_bow_crosscam(q, qa, np.ones(120, np.uint8), t, qa, (nodes, off, idx), (nodes, off, idx), 0.75, True)
+    assert n == 120 and np.array_equal(m, np.arange(120))
+
+
+def test_match_golden(oracle):
+    g = np.load(os.path.join(GOLDEN, "match_small.npz"))
+    bi, bd, sd = oracle.knn2(g["q"], g["t"])
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_d"]) and np.array_equal(sd, g["second_d"])
+    m, n = oracle.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, g["q_angle"], g["t_angle"])
+    assert np.array_equal(m, g["match"]) and n == int(g["n_matches"])
