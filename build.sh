@@ -1,0 +1,26 @@
+#!/usr/bin/env bash
+# Builds libdcs_hip.so (gfx950) in-tree with hipcc. hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+PKG="orb-slam2-dualcam_amd"
+OUT="$PKG/lib"
+OBJ="$PKG/build"
+mkdir -p "$OUT" "$OBJ"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude"
+SRCS=(common.cpp orb_host.cpp octree.cpp orb_extract.cpp orb_kernels.hip match_kernels.hip ba_host.cpp ba_kernels.hip)
+OBJS=()
+pids=()
+for f in "${SRCS[@]}"; do
+  src="$PKG/csrc/$f"
+  [ -f "$src" ] || continue
+  o="$OBJ/${f%.*}.o"
+  OBJS+=("$o")
+  if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ -n "$(find "$PKG/csrc" include -newer "$o" \( -name '*.h' -o -name '*.inc' \) -print -quit)" ]; then
+    ( "$HIPCC" $FLAGS -x hip -c "$src" -o "$o" ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdcs_hip.so" "${OBJS[@]}"
+echo "built $OUT/libdcs_hip.so"

@@ -1,0 +1,212 @@
+/*
+ * dcs_abi.h -- C ABI of the MI355X-native dual-camera SLAM hot path ("dcs").
+ *
+ * Drop-in boundary for the three seams of lixiny/ORB-SLAM2-DualCam; the reference
+ * has no FFI layer, so each entry point cites the C++ member it replaces:
+ *   extraction : ORBextractor::ORBextractor / operator()     include/ORBextractor.h:51-61,
+ *                                                             src/ORBextractor.cc:410-470, 1043-1105
+ *   matching   : ORBmatcher::DescriptorDistance + the best/second-best/ratio/rot-hist kernel shared
+ *                by every Search... / Fuse member                include/ORBmatcher.h:49-281,
+ *                                                             src/ORBmatcher.cc:162-294, 1969-2031
+ *   local BA   : Optimizer::LocalBundleAdjustment             include/Optimizer.h:55,
+ *                                                             src/Optimizer.cc:407-696 (+ vendored g2o)
+ *
+ * Conventions: every function returns DCS_OK (0) or a negative dcs_status; nothing throws or
+ * exits across the boundary (the reference's exit() calls, ORBmatcher.cc:1168..., are not
+ * reproduced). Plain pointers + sizes only. Functions without a `_device` suffix take HOST
+ * buffers (what cv::Mat / std::vector hand over in the reference) and synchronise before
+ * returning; `_device` functions take HBM-resident buffers plus a hipStream_t (as void*) and
+ * only enqueue work (outputs are valid once the stream is synchronised).
+ * There is no CPU fallback: without a HIP device every compute entry point fails with
+ * DCS_ERR_NO_DEVICE.
+ *
+ * Threading contract (mirrors the reference): a dcs_orb handle is NOT thread-safe
+ * (ORBextractor is stateful, one per camera, Tracking thread only); dcs_match_* / dcs_hamming_*
+ * are re-entrant (ORBmatcher is stack-constructed concurrently on 3 threads); a dcs_ba handle
+ * has a single caller; `stop_flag` may be written asynchronously (LocalMapping.cc:141).
+ */
+#ifndef DCS_ABI_H
+#define DCS_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dcs_status {
+    DCS_OK = 0,
+    DCS_ERR_INVALID = -1,     /* bad argument */
+    DCS_ERR_CAPACITY = -2,    /* caller buffer too small; *n_out holds the required size */
+    DCS_ERR_HIP = -3,         /* HIP runtime error (dcs_last_error() has the text) */
+    DCS_ERR_NO_DEVICE = -4,   /* no gfx950 device visible: there is no CPU path */
+    DCS_ERR_UNSUPPORTED = -5
+} dcs_status;
+
+const char* dcs_last_error(void);          /* thread-local text of the last failure */
+const char* dcs_version(void);
+int dcs_device_count(void);
+
+/* cv::KeyPoint layout, 28 bytes: pt.x, pt.y, size, angle, response, octave, class_id */
+typedef struct dcs_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} dcs_keypoint;
+
+/* FAST candidate before the quadtree: level coordinates relative to minBorder (ORBextractor.cc:820-824) */
+typedef struct dcs_candidate {
+    int16_t x, y;
+    int32_t score;
+} dcs_candidate;
+
+/* ------------------------------------------------------------------ extraction */
+typedef struct dcs_orb dcs_orb;
+
+typedef struct dcs_orb_params {
+    int32_t nfeatures;        /* ORBextractor ctor args (ORBextractor.h:51-52) */
+    float   scale_factor;
+    int32_t nlevels;          /* 1..16 */
+    int32_t ini_th_fast;
+    int32_t min_th_fast;      /* >= 1 */
+    int32_t device;           /* HIP ordinal, -1 = current device */
+    int32_t max_images;       /* images per batched call this handle is sized for (>= 1) */
+    int32_t host_threads;     /* worker threads for the host-side quadtree stage, 0 = auto */
+} dcs_orb_params;
+
+int  dcs_orb_create(const dcs_orb_params* p, dcs_orb** out);
+void dcs_orb_destroy(dcs_orb* h);
+
+/* getters GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+   GetInverseScaleSigmaSquares (ORBextractor.h:63-83) + mnFeaturesPerLevel; arrays of nlevels */
+int  dcs_orb_tables(const dcs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* n_per_level);
+
+/* ORBextractor::operator()(image, mask (ignored), keypoints, descriptors).
+   image: 8-bit single channel, `stride` bytes per row. kp[cap], desc[cap*32] caller-owned.
+   rows/cols == 0 or image == NULL -> *n_out = 0, DCS_OK (ORBextractor.cc:1046-1047). */
+int  dcs_orb_extract(dcs_orb* h, const uint8_t* image, int rows, int cols, int stride,
+                     dcs_keypoint* kp, uint8_t* desc, int cap, int* n_out);
+
+/* n_images equally sized images in one pass (dual frame: n_images = 2; multi-stream: more).
+   Outputs are slotted: image i -> kp[i*cap ...], desc[i*cap*32 ...], n_out[i]. */
+int  dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images, int rows, int cols,
+                           int stride, dcs_keypoint* kp, uint8_t* desc, int cap, int* n_out);
+
+/* HBM-resident variant: d_images = n_images * rows * stride bytes; outputs in HBM, slotted as
+   above; d_n_out[n_images]. Work is enqueued on `stream` (hipStream_t). */
+int  dcs_orb_extract_batch_device(dcs_orb* h, const uint8_t* d_images, int n_images, int rows, int cols,
+                                  int stride, dcs_keypoint* d_kp, uint8_t* d_desc, int cap,
+                                  int32_t* d_n_out, void* stream);
+
+/* stage taps for parity tests (valid after an extract call on the same handle; host buffers) */
+int  dcs_orb_debug_level_dims(const dcs_orb* h, int level, int* w, int* h_out);
+int  dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t* dst /* w*h */);
+int  dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* dst, int cap, int* n);
+/* per-stage GPU time of the last extract call in microseconds: pyramid, fast, blur, quadtree(host),
+   describe, total (6 floats) */
+int  dcs_orb_last_timing(const dcs_orb* h, float* us6);
+
+/* DistributeOctTree (ORBextractor.cc:539-763) alone, host buffers (used by tests) */
+int  dcs_distribute_octree(const dcs_candidate* cand, int n, int min_x, int max_x, int min_y, int max_y,
+                           int n_target, dcs_candidate* out, int cap, int* n_out);
+
+/* ------------------------------------------------------------------ matching */
+#define DCS_TH_LOW 50          /* ORBmatcher.cc:58 */
+#define DCS_TH_HIGH 100        /* ORBmatcher.cc:57 */
+#define DCS_HISTO_LENGTH 30    /* ORBmatcher.cc:59 */
+
+/* best / second-best Hamming loop (ORBmatcher.cc:208-231) of every query against every train
+   descriptor (brute force). t_mask[j] != 0 skips j (NULL = none). best_idx = -1, best = second =
+   256 when there is no candidate. First minimum wins ties (strict <). Descriptors are 32-byte rows. */
+int  dcs_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* t_mask,
+                      int32_t* best_idx, int32_t* best_d, int32_t* second_d);
+
+/* same restricted to CSR buckets (a DBoW2 FeatureVector per side, Frame.cc:400-402): group g matches
+   queries q_idx[q_off[g]..q_off[g+1]) against t_idx[t_off[g]..t_off[g+1]). Queries in no group get -1/256/256. */
+int  dcs_hamming_knn2_grouped(const uint8_t* q, int nq, const uint8_t* t, int nt, int n_groups,
+                              const int32_t* q_off, const int32_t* q_idx, const int32_t* t_off, const int32_t* t_idx,
+                              int32_t* best_idx, int32_t* best_d, int32_t* second_d);
+
+/* accept test best <= th (th_strict: best < th) and (float)best < ratio*(float)second
+   (ORBmatcher.cc:233-236, :366) + 30-bin rotation histogram with ComputeThreeMaxima
+   (ORBmatcher.cc:241-251, 272-290, 1969-2010). match[i] = train index or -1. */
+int  dcs_match_filter(int nq, const int32_t* best_idx, const int32_t* best_d, const int32_t* second_d,
+                      int th, int th_strict, float ratio, int check_ori,
+                      const float* q_angle, const float* t_angle, int32_t* match, int* n_matches);
+
+/* fused brute-force matcher "Hamming BF + ratio test across the two camera streams": knn2 + filter.
+   Angles are taken from the keypoints. */
+int  dcs_match_bf(const uint8_t* q, const dcs_keypoint* q_kp, int nq,
+                  const uint8_t* t, const dcs_keypoint* t_kp, int nt,
+                  int th, float ratio, int check_ori, int32_t* match, int* n_matches);
+
+/* HBM-resident batch: feature slots as written by dcs_orb_extract_batch_device (slot s at
+   d_desc + s*cap*32, d_kp + s*cap, count d_n[s]). pair p matches slot pairs[2p] (queries) against
+   slot pairs[2p+1] (train). Outputs d_match[p*cap + i], d_n_matches[p], and the best / second-best
+   distances d_best_d / d_second_d [n_pairs*cap] (required; same slotting). */
+int  dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, const int32_t* d_n, int cap,
+                               const int32_t* d_pairs, int n_pairs, int th, float ratio, int check_ori,
+                               int32_t* d_match, int32_t* d_n_matches, int32_t* d_best_d, int32_t* d_second_d,
+                               void* stream);
+
+/* faithful SearchByBoWCrossCam(F,cF,KF,cKF) (ORBmatcher.cc:162-294): greedy, sequential over the KF
+   features of each shared vocabulary node (already-claimed F features are skipped, :216).
+   Feature vectors = ascending node ids + CSR. match_f[j] = KF index or -1. */
+int  dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_t* kf_valid, int n_kf,
+                       const uint8_t* desc_f, const float* ang_f, int n_f,
+                       const int32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx, int kf_n_nodes,
+                       const int32_t* f_nodes, const int32_t* f_off, const int32_t* f_idx, int f_n_nodes,
+                       float ratio, int check_ori, int32_t* match_f, int* n_matches);
+
+/* ------------------------------------------------------------------ local BA */
+typedef struct dcs_ba_camera {
+    double fx, fy, cx, cy;      /* e->fx.. (Optimizer.cc:561-564) */
+    double ext[7];              /* rig -> camera extrinsic SE3Quat: tx,ty,tz,qx,qy,qz,qw (:565-571) */
+    double adj[36];             /* row-major 6x6 mVertexSE3CamExtAdj (Cameras.cc:27-37) */
+} dcs_ba_camera;
+
+typedef struct dcs_ba_problem {
+    int32_t n_poses, n_points, n_edges, n_cams;
+    const double*  poses;        /* [P][7] tx,ty,tz,qx,qy,qz,qw world -> rig, ascending KF id */
+    const uint8_t* pose_fixed;   /* [P] setFixed (Optimizer.cc:483,496) */
+    const double*  points;       /* [L][3] ascending MapPoint id */
+    const int32_t* edge_pose;    /* [E] */
+    const int32_t* edge_point;   /* [E] at most one edge per (pose, point) pair */
+    const int32_t* edge_cam;     /* [E] */
+    const double*  obs;          /* [E][2] kpUn.pt */
+    const double*  inv_sigma2;   /* [E] mvInvLevelSigma2[octave] */
+    const dcs_ba_camera* cams;   /* [n_cams] */
+    double  huber_delta;         /* sqrt(5.991) */
+    double  chi2_th;             /* 5.991 */
+    int32_t iters1, iters2;      /* 5, 10 */
+} dcs_ba_problem;
+
+typedef struct dcs_ba_result {
+    double*  poses;          /* [P][7] */
+    double*  points;         /* [L][3] */
+    double*  edge_chi2;      /* [E] chi2 of the last error evaluation (NULL allowed) */
+    uint8_t* edge_outlier;   /* [E] chi2 > chi2_th || depth <= 0 after optimisation (Optimizer.cc:653) */
+    uint8_t* edge_level1;    /* [E] excluded after round 1 (:607-610) (NULL allowed) */
+    int32_t  n_iters[2];     /* LM iterations per round */
+    int32_t  n_trials[2];    /* linear solves per round */
+    double   lambda[2];
+    double   chi2_trace[32]; /* robust chi2 after each iteration */
+    float    gpu_ms;         /* device time of the optimise phase */
+} dcs_ba_result;
+
+/* Optimizer::LocalBundleAdjustment numerics on a flat problem (host buffers).
+   stop_flag (may be NULL) is polled between LM iterations and trials like g2o does. */
+int  dcs_ba_local(const dcs_ba_problem* prob, const volatile uint8_t* stop_flag, dcs_ba_result* res);
+
+/* Cameras::setExtrinsics (Cameras.cc:17-37) + Converter::toSE3Quat/toMatrix6d: float 4x4 (row-major)
+   -> ext[7], adj[36]. exact = 0: reference matrix [[R, R t^],[0, R]] in float;
+   exact = 1: g2o's SE3Quat::adj() [[R,0],[t^R,R]]. Pure host helper. */
+int  dcs_rig_adjoint(const float T44[16], int exact, double ext7[7], double adj36[36]);
+/* Converter::toSE3Quat (Converter.cc:58-68) / toCvMat(SE3Quat) (:70-74): 4x4 float <-> pose[7] */
+int  dcs_pose_from_matrix(const float T44[16], double pose7[7]);
+int  dcs_pose_to_matrix(const double pose7[7], float T44[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCS_ABI_H */

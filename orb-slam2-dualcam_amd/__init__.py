@@ -5,3 +5,5 @@ The product is the HIP library built from csrc/; there is NO CPU fallback: every
 raises if the library is missing.
 """
 from . import synth  # noqa: F401
+from . import abi  # noqa: F401,E402
+from .abi import ORBextractor, ORBmatcher, Optimizer, DcsError  # noqa: F401,E402

@@ -1,0 +1,353 @@
+"""ctypes binding of include/dcs_abi.h (libdcs_hip.so) -- the host-side Python mirror used by
+tests/ and bench.py. The reference is C++ (no Python), so this layer only exists to drive the C ABI:
+class / method names follow the reference's seams (ORBextractor, ORBmatcher, Optimizer).
+
+No CPU fallback: if the library is missing or no GPU is visible, calls raise DcsError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdcs_hip.so")
+
+KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CANDIDATE = np.dtype([("x", "<i2"), ("y", "<i2"), ("score", "<i4")])
+
+DCS_OK, DCS_ERR_INVALID, DCS_ERR_CAPACITY, DCS_ERR_HIP, DCS_ERR_NO_DEVICE, DCS_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+# every symbol include/dcs_abi.h declares (checked by tests/test_abi_symbols.py)
+SYMBOLS = [
+    "dcs_last_error", "dcs_version", "dcs_device_count",
+    "dcs_orb_create", "dcs_orb_destroy", "dcs_orb_tables", "dcs_orb_extract", "dcs_orb_extract_batch",
+    "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
+    "dcs_orb_debug_candidates", "dcs_orb_last_timing", "dcs_distribute_octree",
+    "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
+    "dcs_match_bf_batch_device", "dcs_search_by_bow",
+    "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
+]
+
+
+class DcsError(RuntimeError):
+    def __init__(self, rc, where):
+        self.rc = rc
+        msg = lib().dcs_last_error().decode() if _lib is not None else ""
+        super().__init__("%s failed: rc=%d %s" % (where, rc, msg))
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("device", C.c_int32),
+                ("max_images", C.c_int32), ("host_threads", C.c_int32)]
+
+
+class BaCamera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("ext", C.c_double * 7), ("adj", C.c_double * 36)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32), ("n_cams", C.c_int32),
+                ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p),
+                ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p), ("edge_cam", C.c_void_p),
+                ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("cams", C.c_void_p),
+                ("huber_delta", C.c_double), ("chi2_th", C.c_double),
+                ("iters1", C.c_int32), ("iters2", C.c_int32)]
+
+
+class BaResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("edge_chi2", C.c_void_p),
+                ("edge_outlier", C.c_void_p), ("edge_level1", C.c_void_p),
+                ("n_iters", C.c_int32 * 2), ("n_trials", C.c_int32 * 2), ("lambda_", C.c_double * 2),
+                ("chi2_trace", C.c_double * 32), ("gpu_ms", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libdcs_hip.so (raises if it was not built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libdcs_hip.so not built (run __graft_entry__.build() / ./build.sh); no CPU fallback exists")
+        L = C.CDLL(LIB_PATH)
+        L.dcs_last_error.restype = C.c_char_p
+        L.dcs_version.restype = C.c_char_p
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        pci = C.POINTER(ci)
+        sigs = {
+            "dcs_orb_create": [C.POINTER(OrbParams), C.POINTER(vp)],
+            "dcs_orb_destroy": [vp],
+            "dcs_orb_tables": [vp] * 6,
+            "dcs_orb_extract": [vp, vp, ci, ci, ci, vp, vp, ci, pci],
+            "dcs_orb_extract_batch": [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp],
+            "dcs_orb_extract_batch_device": [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp],
+            "dcs_orb_debug_level_dims": [vp, ci, pci, pci],
+            "dcs_orb_debug_level": [vp, ci, ci, ci, vp],
+            "dcs_orb_debug_candidates": [vp, ci, ci, vp, ci, pci],
+            "dcs_orb_last_timing": [vp, vp],
+            "dcs_distribute_octree": [vp, ci, ci, ci, ci, ci, ci, vp, ci, pci],
+            "dcs_hamming_knn2": [vp, ci, vp, ci, vp, vp, vp, vp],
+            "dcs_hamming_knn2_grouped": [vp, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp],
+            "dcs_match_filter": [ci, vp, vp, vp, ci, ci, cf, ci, vp, vp, vp, pci],
+            "dcs_match_bf": [vp, vp, ci, vp, vp, ci, ci, cf, ci, vp, pci],
+            "dcs_match_bf_batch_device": [vp, vp, vp, ci, vp, ci, ci, cf, ci, vp, vp, vp, vp, vp],
+            "dcs_search_by_bow": [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, vp, pci],
+            "dcs_ba_local": [C.POINTER(BaProblem), vp, C.POINTER(BaResult)],
+            "dcs_rig_adjoint": [vp, ci, vp, vp],
+            "dcs_pose_from_matrix": [vp, vp],
+            "dcs_pose_to_matrix": [vp, vp],
+        }
+        for name, argtypes in sigs.items():
+            fn = getattr(L, name, None)       # a missing symbol is reported by tests/test_abi_symbols.py
+            if fn is not None:
+                fn.argtypes = argtypes
+        if hasattr(L, "dcs_orb_destroy"):
+            L.dcs_orb_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _check(rc, where):
+    if rc != DCS_OK:
+        raise DcsError(rc, where)
+
+
+def device_count():
+    return lib().dcs_device_count()
+
+
+class ORBextractor:
+    """ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:45-113) on the HIP library."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7,
+                 device=-1, max_images=2, host_threads=0):
+        self.nfeatures, self.nlevels, self.max_images = nfeatures, nlevels, max_images
+        self._h = C.c_void_p()
+        prm = OrbParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, max_images, host_threads)
+        _check(lib().dcs_orb_create(C.byref(prm), C.byref(self._h)), "dcs_orb_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().dcs_orb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def default_cap(self):
+        return self.nfeatures + 4 * self.nlevels + 64
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        npl = np.zeros(n, np.int32)
+        _check(lib().dcs_orb_tables(self._h, _p(sc), _p(isc), _p(s2), _p(is2), _p(npl)), "dcs_orb_tables")
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, n_per_level=npl)
+
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactors(self):
+        return self.tables()["scale"]
+
+    def __call__(self, image, cap=None):
+        """operator()(image, mask, keypoints, descriptors) -> (keypoints[N], descriptors[N,32])."""
+        kps, descs = self.extract_batch([image], cap)
+        return kps[0], descs[0]
+
+    def extract_batch(self, images, cap=None):
+        images = [_c(im, np.uint8) for im in images]
+        n = len(images)
+        rows, cols = images[0].shape if images[0].ndim == 2 else (0, 0)
+        cap = cap or self.default_cap()
+        kp = np.zeros((n, cap), KEYPOINT)
+        desc = np.zeros((n, cap, 32), np.uint8)
+        n_out = np.zeros(n, np.int32)
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in images])
+        rc = lib().dcs_orb_extract_batch(self._h, C.cast(ptrs, C.c_void_p), n, rows, cols, cols, _p(kp), _p(desc), cap, _p(n_out))
+        _check(rc, "dcs_orb_extract_batch")
+        return [kp[i, :n_out[i]].copy() for i in range(n)], [desc[i, :n_out[i]].copy() for i in range(n)]
+
+    def extract_batch_device(self, d_images, d_kp, d_desc, d_n, cap, stream=None):
+        """d_images: torch uint8 [n, rows, stride] on the GPU; outputs torch buffers (slotted)."""
+        n, rows, stride = d_images.shape
+        rc = lib().dcs_orb_extract_batch_device(self._h, d_images.data_ptr(), n, rows, stride, stride, d_kp.data_ptr(),
+                                                d_desc.data_ptr(), cap, d_n.data_ptr(), stream)
+        _check(rc, "dcs_orb_extract_batch_device")
+
+    def level_dims(self, level):
+        w, h = C.c_int(), C.c_int()
+        _check(lib().dcs_orb_debug_level_dims(self._h, level, C.byref(w), C.byref(h)), "dcs_orb_debug_level_dims")
+        return w.value, h.value
+
+    def level_image(self, image, level, blurred=False):
+        w, h = self.level_dims(level)
+        out = np.zeros((h, w), np.uint8)
+        _check(lib().dcs_orb_debug_level(self._h, image, level, int(blurred), _p(out)), "dcs_orb_debug_level")
+        return out
+
+    def level_candidates(self, image, level):
+        n = C.c_int()
+        _check(lib().dcs_orb_debug_candidates(self._h, image, level, None, 0, C.byref(n)), "dcs_orb_debug_candidates")
+        out = np.zeros(max(n.value, 1), CANDIDATE)
+        _check(lib().dcs_orb_debug_candidates(self._h, image, level, _p(out), n.value, C.byref(n)), "dcs_orb_debug_candidates")
+        return out[:n.value]
+
+    def last_timing(self):
+        t = np.zeros(6, np.float32)
+        _check(lib().dcs_orb_last_timing(self._h, _p(t)), "dcs_orb_last_timing")
+        return dict(zip(("pyramid_us", "fast_us", "blur_us", "quadtree_host_us", "describe_us", "total_us"), t.tolist()))
+
+
+def distribute_octree(cand, min_x, max_x, min_y, max_y, n_target):
+    cand = _c(cand, CANDIDATE)
+    out = np.zeros(max(len(cand), 1), CANDIDATE)
+    n = C.c_int()
+    _check(lib().dcs_distribute_octree(_p(cand), len(cand), min_x, max_x, min_y, max_y, n_target, _p(out), len(out), C.byref(n)),
+           "dcs_distribute_octree")
+    return out[:n.value]
+
+
+class ORBmatcher:
+    """The inner kernels of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:45-309)."""
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True):
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+
+    @staticmethod
+    def knn2(q, t, t_mask=None):
+        q, t = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
+        nq = len(q)
+        bi, bd, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(3))
+        m = _c(t_mask, np.uint8) if t_mask is not None else None
+        _check(lib().dcs_hamming_knn2(_p(q), nq, _p(t), len(t), _p(m), _p(bi), _p(bd), _p(sd)), "dcs_hamming_knn2")
+        return bi[:nq], bd[:nq], sd[:nq]
+
+    @staticmethod
+    def knn2_grouped(q, t, q_off, q_idx, t_off, t_idx):
+        q, t = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
+        q_off, q_idx, t_off, t_idx = (_c(a, np.int32) for a in (q_off, q_idx, t_off, t_idx))
+        nq = len(q)
+        bi, bd, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(3))
+        _check(lib().dcs_hamming_knn2_grouped(_p(q), nq, _p(t), len(t), len(q_off) - 1, _p(q_off), _p(q_idx), _p(t_off),
+                                              _p(t_idx), _p(bi), _p(bd), _p(sd)), "dcs_hamming_knn2_grouped")
+        return bi[:nq], bd[:nq], sd[:nq]
+
+    def filter(self, best_idx, best_d, second_d, th=50, th_strict=False, q_angle=None, t_angle=None):
+        best_idx, best_d, second_d = (_c(a, np.int32) for a in (best_idx, best_d, second_d))
+        nq = len(best_idx)
+        qa = _c(q_angle, np.float32) if q_angle is not None else None
+        ta = _c(t_angle, np.float32) if t_angle is not None else None
+        match = np.full(max(nq, 1), -1, np.int32)
+        n = C.c_int()
+        _check(lib().dcs_match_filter(nq, _p(best_idx), _p(best_d), _p(second_d), th, int(th_strict), self.mfNNratio,
+                                      int(self.mbCheckOrientation and qa is not None), _p(qa), _p(ta), _p(match), C.byref(n)),
+               "dcs_match_filter")
+        return match[:nq], n.value
+
+    def match_bf(self, q, q_kp, t, t_kp, th=50):
+        q, t = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
+        q_kp, t_kp = _c(q_kp, KEYPOINT), _c(t_kp, KEYPOINT)
+        match = np.full(max(len(q), 1), -1, np.int32)
+        n = C.c_int()
+        _check(lib().dcs_match_bf(_p(q), _p(q_kp), len(q), _p(t), _p(t_kp), len(t), th, self.mfNNratio,
+                                  int(self.mbCheckOrientation), _p(match), C.byref(n)), "dcs_match_bf")
+        return match[:len(q)], n.value
+
+    def match_bf_batch_device(self, d_desc, d_kp, d_n, cap, d_pairs, n_pairs, d_match, d_n_matches, d_best, d_second,
+                              th=50, stream=None):
+        _check(lib().dcs_match_bf_batch_device(d_desc.data_ptr(), d_kp.data_ptr(), d_n.data_ptr(), cap, d_pairs.data_ptr(),
+                                               n_pairs, th, self.mfNNratio, int(self.mbCheckOrientation), d_match.data_ptr(),
+                                               d_n_matches.data_ptr(), d_best.data_ptr(), d_second.data_ptr(), stream),
+               "dcs_match_bf_batch_device")
+
+    def SearchByBoWCrossCam(self, desc_kf, ang_kf, kf_valid, desc_f, ang_f, kf_fv, f_fv):
+        """SearchByBoWCrossCam(F,cF,KF,cKF) (ORBmatcher.cc:162-294) on flat inputs; returns (match_f, n)."""
+        desc_kf, desc_f = _c(desc_kf, np.uint8).reshape(-1, 32), _c(desc_f, np.uint8).reshape(-1, 32)
+        ang_kf, ang_f, kf_valid = _c(ang_kf, np.float32), _c(ang_f, np.float32), _c(kf_valid, np.uint8)
+        kn, ko, ki = (_c(a, np.int32) for a in kf_fv)
+        fn, fo, fi = (_c(a, np.int32) for a in f_fv)
+        match = np.full(max(len(desc_f), 1), -1, np.int32)
+        n = C.c_int()
+        _check(lib().dcs_search_by_bow(_p(desc_kf), _p(ang_kf), _p(kf_valid), len(desc_kf), _p(desc_f), _p(ang_f), len(desc_f),
+                                       _p(kn), _p(ko), _p(ki), len(kn), _p(fn), _p(fo), _p(fi), len(fn),
+                                       self.mfNNratio, int(self.mbCheckOrientation), _p(match), C.byref(n)), "dcs_search_by_bow")
+        return match[:len(desc_f)], n.value
+
+
+def rig_adjoint(T44_f32, exact=False):
+    T = _c(T44_f32, np.float32).reshape(16)
+    ext, adj = np.zeros(7), np.zeros(36)
+    _check(lib().dcs_rig_adjoint(_p(T), int(exact), _p(ext), _p(adj)), "dcs_rig_adjoint")
+    return adj.reshape(6, 6), ext
+
+
+def pose_from_matrix(T44_f32):
+    T = _c(T44_f32, np.float32).reshape(16)
+    out = np.zeros(7)
+    _check(lib().dcs_pose_from_matrix(_p(T), _p(out)), "dcs_pose_from_matrix")
+    return out
+
+
+def pose_to_matrix(pose7):
+    p = _c(pose7, np.float64)
+    out = np.zeros(16, np.float32)
+    _check(lib().dcs_pose_to_matrix(_p(p), _p(out)), "dcs_pose_to_matrix")
+    return out.reshape(4, 4)
+
+
+def make_camera(fx, fy, cx, cy, ext7, adj36):
+    c = BaCamera()
+    c.fx, c.fy, c.cx, c.cy = float(fx), float(fy), float(cx), float(cy)
+    for i in range(7):
+        c.ext[i] = float(ext7[i])
+    a = np.asarray(adj36, np.float64).reshape(-1)
+    for i in range(36):
+        c.adj[i] = float(a[i])
+    return c
+
+
+class Optimizer:
+    """Optimizer::LocalBundleAdjustment (reference include/Optimizer.h:55) on a flat problem."""
+
+    @staticmethod
+    def LocalBundleAdjustment(prob, stop_flag=None):
+        poses = _c(prob["poses"], np.float64)
+        fixed = _c(prob["pose_fixed"], np.uint8)
+        points = _c(prob["points"], np.float64)
+        ep, el, ec = (_c(prob[k], np.int32) for k in ("edge_pose", "edge_point", "edge_cam"))
+        obs = _c(prob["obs"], np.float64)
+        w = _c(prob["inv_sigma2"], np.float64)
+        cam_list = [c if isinstance(c, BaCamera) else make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"])
+                    for c in prob["cams"]]
+        cams = (BaCamera * len(cam_list))(*cam_list)
+        P, L, E = len(poses), len(points), len(ep)
+        pb = BaProblem(P, L, E, len(cam_list), _p(poses).value, _p(fixed).value, _p(points).value,
+                       _p(ep).value, _p(el).value, _p(ec).value, _p(obs).value, _p(w).value,
+                       C.cast(cams, C.c_void_p).value,
+                       float(prob.get("huber_delta", np.sqrt(5.991))), float(prob.get("chi2_th", 5.991)),
+                       int(prob.get("iters1", 5)), int(prob.get("iters2", 10)))
+        out_poses, out_points = np.zeros((P, 7)), np.zeros((L, 3))
+        chi2, outl, lvl1 = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+        res = BaResult(_p(out_poses).value, _p(out_points).value, _p(chi2).value, _p(outl).value, _p(lvl1).value)
+        sf = _p(stop_flag) if stop_flag is not None else None
+        _check(lib().dcs_ba_local(C.byref(pb), sf, C.byref(res)), "dcs_ba_local")
+        return dict(poses=out_poses, points=out_points, edge_chi2=chi2, edge_outlier=outl, edge_level1=lvl1,
+                    n_iters=list(res.n_iters), n_trials=list(res.n_trials), lambda_=list(res.lambda_),
+                    chi2_trace=np.array(res.chi2_trace), gpu_ms=float(res.gpu_ms))

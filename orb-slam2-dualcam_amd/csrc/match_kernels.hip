@@ -1,0 +1,370 @@
+// match_kernels.hip -- Hamming matcher kernels for gfx950.
+//
+// Replaces the inner loop shared by every ORBmatcher::Search*/Fuse member of the reference
+// (src/ORBmatcher.cc): DescriptorDistance :2015-2031 (256-bit XOR + popcount), best / second-best
+// with strict "<" (:208-231), accept best <= TH and best < ratio * second (:233-236), 30-bin rotation
+// histogram + ComputeThreeMaxima (:241-251, :272-290, :1969-2010).
+//
+// knn2 layout: a workgroup = 64 queries x 4 train splits (one wave per split, one query per lane,
+// the query's 4 x u64 descriptor words live in VGPRs). Train descriptors are staged through LDS in
+// tiles of 256 (8 KB, coalesced 16-B loads); every lane of a wave reads the SAME train word, an LDS
+// broadcast, and spends 4 x (v_xor + popcount) per distance. The two smallest distances (with
+// multiplicity) and the first index of the minimum are order-independent quantities, so the four
+// partial results merge exactly into what the reference's sequential loop produces.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace dcs {
+
+struct Best { int b1, idx, b2; };
+
+__device__ __forceinline__ void best_update(Best& s, int dist, int j)
+{
+    if (dist < s.b1) { s.b2 = s.b1; s.b1 = dist; s.idx = j; }
+    else if (dist < s.b2) { s.b2 = dist; }
+}
+
+// merge of partial results over disjoint candidate sets (any order)
+__device__ __forceinline__ Best best_merge(const Best& a, const Best& b)
+{
+    Best r;
+    if (a.b1 < b.b1 || (a.b1 == b.b1 && (unsigned)a.idx <= (unsigned)b.idx)) { r.b1 = a.b1; r.idx = a.idx; r.b2 = min(a.b2, b.b1); }
+    else { r.b1 = b.b1; r.idx = b.idx; r.b2 = min(b.b2, a.b1); }
+    r.b2 = min(r.b2, min(a.b2, b.b2));
+    return r;
+}
+
+constexpr int kTile = 256;
+
+__device__ __forceinline__ void knn2_tile(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                          const uint8_t* __restrict__ t_mask, int q_tile, int32_t* __restrict__ best_idx,
+                                          int32_t* __restrict__ best_d, int32_t* __restrict__ second_d)
+{
+    __shared__ uint4 s_t[kTile * 2];                 // 256 descriptors x 32 B
+    __shared__ Best s_part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = q_tile * 64 + lane;
+    unsigned long long qw[4] = {0, 0, 0, 0};
+    if (qi < nq) {
+        const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
+        const uint4 a = qp[0], b = qp[1];
+        qw[0] = ((unsigned long long)a.y << 32) | a.x; qw[1] = ((unsigned long long)a.w << 32) | a.z;
+        qw[2] = ((unsigned long long)b.y << 32) | b.x; qw[3] = ((unsigned long long)b.w << 32) | b.z;
+    }
+    Best st{256, -1, 256};
+    for (int t0 = 0; t0 < nt; t0 += kTile) {
+        const int n_here = min(kTile, nt - t0);
+        __syncthreads();
+        {
+            const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)t0 * 32);
+            for (int i = tid; i < n_here * 2; i += 256) s_t[i] = tp[i];
+        }
+        __syncthreads();
+        const int jb = wave * 64, je = min(jb + 64, n_here);
+        for (int j = jb; j < je; ++j) {
+            if (t_mask && t_mask[t0 + j]) continue;                      // wave-uniform branch
+            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&s_t[2 * j]);
+            const int dist = __popcll(qw[0] ^ w[0]) + __popcll(qw[1] ^ w[1]) + __popcll(qw[2] ^ w[2]) + __popcll(qw[3] ^ w[3]);
+            best_update(st, dist, t0 + j);
+        }
+    }
+    s_part[wave][lane] = st;
+    __syncthreads();
+    if (wave == 0 && qi < nq) {
+        Best r = best_merge(best_merge(s_part[0][lane], s_part[1][lane]), best_merge(s_part[2][lane], s_part[3][lane]));
+        best_idx[qi] = r.idx; best_d[qi] = r.b1; second_d[qi] = r.b2;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                              const uint8_t* __restrict__ t_mask, int32_t* best_idx, int32_t* best_d, int32_t* second_d)
+{
+    knn2_tile(q, nq, t, nt, t_mask, blockIdx.x, best_idx, best_d, second_d);
+}
+
+// batch: grid (ceil(cap/64), n_pairs); feature slots as written by the extractor
+__global__ __launch_bounds__(256) void k_knn2_pairs(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_feat, int cap,
+                                                    const int32_t* __restrict__ pairs, int32_t* best_idx, int32_t* best_d, int32_t* second_d)
+{
+    const int p = blockIdx.y;
+    const int qs = pairs[2 * p], ts = pairs[2 * p + 1];
+    const int nq = min(n_feat[qs], cap), nt = min(n_feat[ts], cap);
+    if ((int)blockIdx.x * 64 >= nq) return;
+    knn2_tile(desc + (size_t)qs * cap * 32, nq, desc + (size_t)ts * cap * 32, nt, nullptr, blockIdx.x,
+              best_idx + (size_t)p * cap, best_d + (size_t)p * cap, second_d + (size_t)p * cap);
+}
+
+// grouped (CSR buckets): one wave per group, one query per lane, candidates read through t_idx
+__global__ __launch_bounds__(64) void k_knn2_grouped(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
+                                                     const int32_t* __restrict__ q_off, const int32_t* __restrict__ q_idx,
+                                                     const int32_t* __restrict__ t_off, const int32_t* __restrict__ t_idx,
+                                                     int32_t* best_idx, int32_t* best_d, int32_t* second_d)
+{
+    const int g = blockIdx.x;
+    const int qb = q_off[g], qe = q_off[g + 1], tb = t_off[g], te = t_off[g + 1];
+    for (int a = qb + threadIdx.x; a < qe; a += 64) {
+        const int qi = q_idx[a];
+        const unsigned long long* qp = reinterpret_cast<const unsigned long long*>(q + (size_t)qi * 32);
+        const unsigned long long q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+        Best st{256, -1, 256};
+        for (int b = tb; b < te; ++b) {
+            const int j = t_idx[b];
+            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(t + (size_t)j * 32);
+            const int dist = __popcll(q0 ^ w[0]) + __popcll(q1 ^ w[1]) + __popcll(q2 ^ w[2]) + __popcll(q3 ^ w[3]);
+            best_update(st, dist, j);
+        }
+        best_idx[qi] = st.idx; best_d[qi] = st.b1; second_d[qi] = st.b2;
+    }
+}
+
+__global__ void k_fill_knn(int32_t* best_idx, int32_t* best_d, int32_t* second_d, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { best_idx[i] = -1; best_d[i] = 256; second_d[i] = 256; }
+}
+
+// ---- accept + rotation histogram; one workgroup per problem
+__device__ __forceinline__ int rot_bin(float aq, float at)
+{
+    const float factor = 1.0f / 30;                      // 1.0f/HISTO_LENGTH (:181)
+    float rot = __fsub_rn(aq, at);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));       // round(): half away from zero (:246)
+    if (bin == 30) bin = 0;
+    return bin;
+}
+
+__device__ __forceinline__ bool accept(int idx, int b1, int b2, int th, int th_strict, float ratio)
+{
+    if (idx < 0) return false;
+    if (th_strict ? !(b1 < th) : !(b1 <= th)) return false;
+    return (float)b1 < __fmul_rn(ratio, (float)b2);
+}
+
+// note: `match` may alias `best_idx` (each thread reads best_idx[i] before it writes match[i])
+__device__ void filter_problem(int nq, const int32_t* best_idx, const int32_t* __restrict__ best_d,
+                               const int32_t* __restrict__ second_d, int th, int th_strict, float ratio, int check_ori,
+                               const float* __restrict__ q_ang, int q_stride, const float* __restrict__ t_ang, int t_stride,
+                               int32_t* match, int32_t* __restrict__ n_matches)
+{
+    __shared__ int s_hist[32];
+    __shared__ int s_ind[3];
+    __shared__ int s_count;
+    const int tid = threadIdx.x;
+    if (tid < 32) s_hist[tid] = 0;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    if (check_ori) {
+        for (int i = tid; i < nq; i += blockDim.x) {
+            if (accept(best_idx[i], best_d[i], second_d[i], th, th_strict, ratio))
+                atomicAdd(&s_hist[rot_bin(q_ang[(size_t)i * q_stride], t_ang[(size_t)best_idx[i] * t_stride])], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {                                  // ComputeThreeMaxima (:1969-2010)
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < 30; ++i) {
+                const int s = s_hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+            s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+        }
+        __syncthreads();
+    }
+    int local = 0;
+    for (int i = tid; i < nq; i += blockDim.x) {
+        int m = -1;
+        if (accept(best_idx[i], best_d[i], second_d[i], th, th_strict, ratio)) {
+            m = best_idx[i];
+            if (check_ori) {
+                const int b = rot_bin(q_ang[(size_t)i * q_stride], t_ang[(size_t)m * t_stride]);
+                if (b != s_ind[0] && b != s_ind[1] && b != s_ind[2]) m = -1;
+            }
+        }
+        match[i] = m;
+        local += m >= 0;
+    }
+    atomicAdd(&s_count, local);
+    __syncthreads();
+    if (tid == 0) *n_matches = s_count;
+}
+
+__global__ __launch_bounds__(256) void k_filter(int nq, const int32_t* best_idx, const int32_t* best_d, const int32_t* second_d,
+                                                int th, int th_strict, float ratio, int check_ori, const float* q_ang, int q_stride,
+                                                const float* t_ang, int t_stride, int32_t* match, int32_t* n_matches)
+{
+    filter_problem(nq, best_idx, best_d, second_d, th, th_strict, ratio, check_ori, q_ang, q_stride, t_ang, t_stride, match, n_matches);
+}
+
+__global__ __launch_bounds__(256) void k_filter_pairs(const dcs_keypoint* __restrict__ kp, const int32_t* __restrict__ n_feat, int cap,
+                                                      const int32_t* __restrict__ pairs, const int32_t* best_idx, const int32_t* best_d,
+                                                      const int32_t* second_d, int th, float ratio, int check_ori, int32_t* match,
+                                                      int32_t* n_matches)
+{
+    const int p = blockIdx.x;
+    const int qs = pairs[2 * p], ts = pairs[2 * p + 1];
+    const int nq = min(n_feat[qs], cap);
+    const size_t o = (size_t)p * cap;
+    filter_problem(nq, best_idx + o, best_d + o, second_d + o, th, 0, ratio, check_ori, &kp[(size_t)qs * cap].angle, 7,
+                   &kp[(size_t)ts * cap].angle, 7, match + o, n_matches + p);
+}
+
+}  // namespace dcs
+
+using namespace dcs;
+
+namespace {
+struct Scratch {                       // per-call device scratch for the host-buffer entry points (re-entrant)
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T> int alloc(T** out, size_t n) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) { set_error("hipMalloc: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
+        ptrs.push_back(p); *out = (T*)p; return DCS_OK;
+    }
+    template <typename T> int upload(T** out, const T* src, size_t n) {
+        int rc = alloc(out, n);
+        if (rc) return rc;
+        if (n) DCS_HIP(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice));
+        return DCS_OK;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int dcs_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* t_mask, int32_t* best_idx,
+                     int32_t* best_d, int32_t* second_d)
+{
+    if (nq < 0 || nt < 0 || (nq && (!q || !best_idx || !best_d || !second_d)) || (nt && !t)) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (nq == 0) return DCS_OK;
+    Scratch s;
+    uint8_t *dq, *dt, *dm = nullptr;
+    int32_t *bi, *bd, *sd;
+    if ((rc = s.upload(&dq, q, (size_t)nq * 32)) || (rc = s.upload(&dt, t, (size_t)nt * 32))) return rc;
+    if (t_mask && (rc = s.upload(&dm, t_mask, (size_t)nt))) return rc;
+    if ((rc = s.alloc(&bi, nq)) || (rc = s.alloc(&bd, nq)) || (rc = s.alloc(&sd, nq))) return rc;
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64), dim3(256), 0, 0, dq, nq, dt, nt, dm, bi, bd, sd);
+    DCS_CHECK_LAUNCH();
+    DCS_HIP(hipMemcpy(best_idx, bi, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(best_d, bd, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(second_d, sd, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    return DCS_OK;
+}
+
+int dcs_hamming_knn2_grouped(const uint8_t* q, int nq, const uint8_t* t, int nt, int n_groups, const int32_t* q_off,
+                             const int32_t* q_idx, const int32_t* t_off, const int32_t* t_idx, int32_t* best_idx,
+                             int32_t* best_d, int32_t* second_d)
+{
+    if (nq < 0 || nt < 0 || n_groups < 0 || (n_groups && (!q_off || !t_off)) || (nq && (!q || !best_idx || !best_d || !second_d))) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (nq == 0) return DCS_OK;
+    Scratch s;
+    uint8_t *dq, *dt;
+    int32_t *bi, *bd, *sd, *dqo, *dqi, *dto, *dti;
+    if ((rc = s.upload(&dq, q, (size_t)nq * 32)) || (rc = s.upload(&dt, t, (size_t)nt * 32))) return rc;
+    if ((rc = s.alloc(&bi, nq)) || (rc = s.alloc(&bd, nq)) || (rc = s.alloc(&sd, nq))) return rc;
+    hipLaunchKernelGGL(k_fill_knn, dim3((nq + 255) / 256), dim3(256), 0, 0, bi, bd, sd, nq);
+    DCS_CHECK_LAUNCH();
+    if (n_groups) {
+        const int nqi = q_off[n_groups], nti = t_off[n_groups];
+        if ((rc = s.upload(&dqo, q_off, (size_t)n_groups + 1)) || (rc = s.upload(&dto, t_off, (size_t)n_groups + 1))) return rc;
+        if ((rc = s.upload(&dqi, q_idx, (size_t)nqi)) || (rc = s.upload(&dti, t_idx, (size_t)nti))) return rc;
+        hipLaunchKernelGGL(k_knn2_grouped, dim3(n_groups), dim3(64), 0, 0, dq, dt, dqo, dqi, dto, dti, bi, bd, sd);
+        DCS_CHECK_LAUNCH();
+    }
+    DCS_HIP(hipMemcpy(best_idx, bi, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(best_d, bd, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(second_d, sd, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    return DCS_OK;
+}
+
+int dcs_match_filter(int nq, const int32_t* best_idx, const int32_t* best_d, const int32_t* second_d, int th, int th_strict,
+                     float ratio, int check_ori, const float* q_angle, const float* t_angle, int32_t* match, int* n_matches)
+{
+    if (nq < 0 || !n_matches || (nq && (!best_idx || !best_d || !second_d || !match)) || (check_ori && nq && (!q_angle || !t_angle))) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    *n_matches = 0;
+    if (nq == 0) return DCS_OK;
+    int max_t = 0;
+    for (int i = 0; i < nq; ++i) max_t = std::max(max_t, best_idx[i] + 1);
+    Scratch s;
+    int32_t *bi, *bd, *sd, *dm, *dn;
+    float *qa = nullptr, *ta = nullptr;
+    if ((rc = s.upload(&bi, best_idx, nq)) || (rc = s.upload(&bd, best_d, nq)) || (rc = s.upload(&sd, second_d, nq))) return rc;
+    if (check_ori && ((rc = s.upload(&qa, q_angle, nq)) || (rc = s.upload(&ta, t_angle, max_t)))) return rc;
+    if ((rc = s.alloc(&dm, nq)) || (rc = s.alloc(&dn, 1))) return rc;
+    hipLaunchKernelGGL(k_filter, dim3(1), dim3(256), 0, 0, nq, bi, bd, sd, th, th_strict, ratio, check_ori, qa, 1, ta, 1, dm, dn);
+    DCS_CHECK_LAUNCH();
+    DCS_HIP(hipMemcpy(match, dm, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    int32_t n32 = 0;
+    DCS_HIP(hipMemcpy(&n32, dn, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *n_matches = n32;
+    return DCS_OK;
+}
+
+int dcs_match_bf(const uint8_t* q, const dcs_keypoint* q_kp, int nq, const uint8_t* t, const dcs_keypoint* t_kp, int nt,
+                 int th, float ratio, int check_ori, int32_t* match, int* n_matches)
+{
+    if (nq < 0 || nt < 0 || !n_matches || (nq && (!q || !match)) || (nt && !t) || (check_ori && ((nq && !q_kp) || (nt && !t_kp)))) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    *n_matches = 0;
+    if (nq == 0) return DCS_OK;
+    Scratch s;
+    uint8_t *dq, *dt;
+    dcs_keypoint *kq = nullptr, *kt = nullptr;
+    int32_t *bi, *bd, *sd, *dm, *dn;
+    if ((rc = s.upload(&dq, q, (size_t)nq * 32)) || (rc = s.upload(&dt, t, (size_t)nt * 32))) return rc;
+    if (check_ori && ((rc = s.upload(&kq, q_kp, nq)) || (rc = s.upload(&kt, t_kp, nt)))) return rc;
+    if ((rc = s.alloc(&bi, nq)) || (rc = s.alloc(&bd, nq)) || (rc = s.alloc(&sd, nq)) || (rc = s.alloc(&dm, nq)) || (rc = s.alloc(&dn, 1))) return rc;
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64), dim3(256), 0, 0, dq, nq, dt, nt, (const uint8_t*)nullptr, bi, bd, sd);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_filter, dim3(1), dim3(256), 0, 0, nq, bi, bd, sd, th, 0, ratio, check_ori,
+                       kq ? &kq->angle : nullptr, 7, kt ? &kt->angle : nullptr, 7, dm, dn);
+    DCS_CHECK_LAUNCH();
+    DCS_HIP(hipMemcpy(match, dm, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    int32_t n32 = 0;
+    DCS_HIP(hipMemcpy(&n32, dn, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *n_matches = n32;
+    return DCS_OK;
+}
+
+int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, const int32_t* d_n, int cap, const int32_t* d_pairs,
+                              int n_pairs, int th, float ratio, int check_ori, int32_t* d_match, int32_t* d_n_matches,
+                              int32_t* d_best_d, int32_t* d_second_d, void* stream)
+{
+    if (!d_desc || !d_kp || !d_n || !d_pairs || !d_match || !d_n_matches || !d_best_d || !d_second_d || cap < 1 || n_pairs < 0) {
+        set_error("bad argument (d_best_d / d_second_d scratch is required)"); return DCS_ERR_INVALID;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_pairs == 0) return DCS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    // d_match doubles as the best-index buffer: the filter reads best_idx[i] and writes match[i] in the same thread
+    hipLaunchKernelGGL(k_knn2_pairs, dim3((cap + 63) / 64, n_pairs), dim3(256), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_filter_pairs, dim3(n_pairs), dim3(256), 0, s, d_kp, d_n, cap, d_pairs, d_match, d_best_d, d_second_d, th,
+                       ratio, check_ori, d_match, d_n_matches);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+}  // extern "C"

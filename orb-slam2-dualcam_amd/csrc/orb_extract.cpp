@@ -1,0 +1,500 @@
+// orb_extract.cpp -- extractor handle and per-call orchestration (HIP streams/events, no kernels here).
+//
+// Mirrors ORBextractor (reference include/ORBextractor.h:45-113, src/ORBextractor.cc:1043-1105) for a
+// BATCH of equally sized images. HBM layout per handle (sized for max_images B):
+//   pyramid slab   B x slab_bytes   u8, level l at lv[l].offset, row pitch = roundup64(w_l)
+//   blurred slab   B x slab_bytes   same geometry
+//   FAST slots     B x n_slots      dcs_candidate, fixed capacity per 30-px cell (no atomics: order matters)
+//   dense cands    one array for the whole batch, (image, level)-major, in the reference's emission order
+// Stream plan per call: [resize l=1..L-1] -> {FAST cells -> scan -> gather -> D2H} on the main stream,
+// Gaussian blur of all levels concurrently on an auxiliary stream, host quadtree (thread pool), then
+// one orientation+rBRIEF launch that waits for the blur event.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+#include "orb_host.h"
+#include "orb_kernels.h"
+
+namespace dcs {
+
+// ------------------------------------------------------------------ tiny persistent thread pool
+class Pool {
+public:
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; ++epoch_; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    // runs fn(i) for i in [0, n) on the workers + the calling thread
+    void parallel_for(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (workers_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)workers_.size(); ++epoch_;
+        }
+        cv_.notify_all();
+        run();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void run() { for (int i; (i = next_.fetch_add(1)) < n_;) (*fn_)(i); }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return epoch_ != seen; });
+                seen = epoch_;
+                if (stop_) return;
+            }
+            run();
+            { std::lock_guard<std::mutex> g(m_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace dcs
+
+using namespace dcs;
+
+struct dcs_orb {
+    OrbTables t;
+    dcs_orb_params prm;
+    int device = 0;
+    PyramidGeom g;
+    bool configured = false;
+
+    DevBuf<uint8_t> d_pyr, d_blur;
+    DevBuf<int16_t> d_rtab;
+    struct RTab { size_t xofs, xa, yofs, ya; } rtab[kMaxLevels];
+    std::vector<CellDesc> h_cells;
+    std::vector<int32_t> h_level_cell_begin;
+    DevBuf<CellDesc> d_cells;
+    DevBuf<int32_t> d_level_cell_begin;
+    DevBuf<dcs_candidate> d_slots, d_dense;
+    size_t dense_cap = 0;
+    DevBuf<int32_t> d_cell_count, d_cell_off, d_lvl_total, d_lvl_off;
+    PinnedBuf<int32_t> h_lvl_off;
+    PinnedBuf<dcs_candidate> h_dense;
+    PinnedBuf<SelKp> h_sel;
+    DevBuf<SelKp> d_sel;
+    PinnedBuf<int32_t> h_img_off;
+    DevBuf<int32_t> d_img_off;
+    // staging for the host-buffer API
+    DevBuf<dcs_keypoint> d_kp;
+    DevBuf<uint8_t> d_desc;
+    DevBuf<int32_t> d_n;
+    PinnedBuf<dcs_keypoint> h_kp;
+    PinnedBuf<uint8_t> h_desc;
+    PinnedBuf<int32_t> h_n;
+    PinnedBuf<uint8_t> h_img;
+
+    hipStream_t s_main = nullptr, s_aux = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr},
+               ev_b[2] = {nullptr, nullptr};
+    float host_us = 0;
+    bool timing_valid = false;
+    std::unique_ptr<Pool> pool;
+    std::vector<std::vector<dcs_candidate>> task_out;
+
+    // last call (debug taps)
+    LevelSet last_raw{}, last_blur{};
+    int last_n_images = 0;
+
+    ~dcs_orb() {
+        if (s_main) (void)hipStreamDestroy(s_main);
+        if (s_aux) (void)hipStreamDestroy(s_aux);
+        if (ev_pyr) (void)hipEventDestroy(ev_pyr);
+        if (ev_blur) (void)hipEventDestroy(ev_blur);
+        for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_b) if (e) (void)hipEventDestroy(e);
+    }
+
+    int configure(int rows, int cols);
+    LevelSet make_levels(const uint8_t* slab, const uint8_t* level0, size_t level0_img_stride, int level0_pitch) const;
+    int run(const uint8_t* d_level0, size_t level0_img_stride, int level0_pitch, int n_images,
+            dcs_keypoint* d_kp_out, uint8_t* d_desc_out, int cap, int32_t* d_n_out, hipStream_t stream,
+            int* h_counts /* may be null */);
+};
+
+int dcs_orb::configure(int rows, int cols)
+{
+    if (configured && g.rows == rows && g.cols == cols) return DCS_OK;
+    if (rows < 2 * kEdgeThreshold || cols < 2 * kEdgeThreshold || rows > 16384 || cols > 16384) {
+        set_error("image size %dx%d outside supported range", cols, rows);
+        return DCS_ERR_INVALID;
+    }
+    g.build(t, rows, cols);
+    const int B = prm.max_images, L = t.nlevels;
+    for (int l = 0; l < L; ++l) {
+        if (g.lv[l].w < 2 * kEdgeThreshold + 1 || g.lv[l].h < 2 * kEdgeThreshold + 1) {
+            set_error("pyramid level %d (%dx%d) is smaller than the 19-px border allows", l, g.lv[l].w, g.lv[l].h);
+            return DCS_ERR_INVALID;
+        }
+        if (g.lv[l].w_cell + 6 > 65 || g.lv[l].h_cell + 6 > 65) { set_error("cell too large"); return DCS_ERR_UNSUPPORTED; }
+    }
+    int rc;
+    if ((rc = d_pyr.resize((size_t)B * g.slab_bytes + 256))) return rc;
+    if ((rc = d_blur.resize((size_t)B * g.slab_bytes + 256))) return rc;
+    // resize coefficient tables, one set per level >= 1
+    std::vector<int16_t> tab;
+    for (int l = 1; l < L; ++l) {
+        ResizeTable rt;
+        rt.build(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h);
+        rtab[l].xofs = tab.size(); tab.insert(tab.end(), rt.xofs.begin(), rt.xofs.end());
+        rtab[l].xa = tab.size();   tab.insert(tab.end(), rt.xa.begin(), rt.xa.end());
+        rtab[l].yofs = tab.size(); tab.insert(tab.end(), rt.yofs.begin(), rt.yofs.end());
+        rtab[l].ya = tab.size();   tab.insert(tab.end(), rt.ya.begin(), rt.ya.end());
+    }
+    if ((rc = d_rtab.resize(std::max<size_t>(tab.size(), 1)))) return rc;
+    if (!tab.empty()) DCS_HIP(hipMemcpy(d_rtab.p, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    // FAST cells (ORBextractor.cc:789-806)
+    h_cells.clear(); h_level_cell_begin.assign(L + 1, 0);
+    for (int l = 0; l < L; ++l) {
+        const LevelGeom& lg = g.lv[l];
+        h_level_cell_begin[l] = (int)h_cells.size();
+        const int max_bx = lg.w - kEdgeThreshold + 3, max_by = lg.h - kEdgeThreshold + 3;
+        for (int i = 0; i < lg.n_rows; ++i) {
+            const int ini_y = kMinBorder + i * lg.h_cell;
+            int max_y = ini_y + lg.h_cell + 6;
+            const bool skip_row = ini_y >= max_by - 3;
+            if (max_y > max_by) max_y = max_by;
+            for (int j = 0; j < lg.n_cols; ++j) {
+                const int ini_x = kMinBorder + j * lg.w_cell;
+                int max_x = ini_x + lg.w_cell + 6;
+                const bool skip = skip_row || ini_x >= max_bx - 6;
+                if (max_x > max_bx) max_x = max_bx;
+                CellDesc c{};
+                c.level = (int16_t)l; c.x0 = (int16_t)ini_x; c.y0 = (int16_t)ini_y;
+                c.rw = (int16_t)(skip ? 0 : max_x - ini_x); c.rh = (int16_t)(skip ? 0 : max_y - ini_y);
+                c.ox = (int16_t)(j * lg.w_cell); c.oy = (int16_t)(i * lg.h_cell);
+                c.cap = (int16_t)lg.cell_cap;
+                c.slot_base = (int32_t)(lg.slot_base + (size_t)(i * lg.n_cols + j) * lg.cell_cap);
+                h_cells.push_back(c);
+            }
+        }
+    }
+    h_level_cell_begin[L] = (int)h_cells.size();
+    const int n_cells = (int)h_cells.size();
+    if ((rc = d_cells.resize(std::max(n_cells, 1)))) return rc;
+    if (n_cells) DCS_HIP(hipMemcpy(d_cells.p, h_cells.data(), sizeof(CellDesc) * n_cells, hipMemcpyHostToDevice));
+    if ((rc = d_level_cell_begin.resize(L + 1))) return rc;
+    DCS_HIP(hipMemcpy(d_level_cell_begin.p, h_level_cell_begin.data(), sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice));
+    if ((rc = d_slots.resize(std::max<size_t>((size_t)B * g.n_slots, 1)))) return rc;
+    if ((rc = d_cell_count.resize(std::max<size_t>((size_t)B * n_cells, 1)))) return rc;
+    if ((rc = d_cell_off.resize(std::max<size_t>((size_t)B * n_cells, 1)))) return rc;
+    if ((rc = d_lvl_total.resize((size_t)B * L))) return rc;
+    if ((rc = d_lvl_off.resize((size_t)B * L + 1))) return rc;
+    if ((rc = h_lvl_off.resize((size_t)B * L + 1))) return rc;
+    // dense candidates: generous (1/16 of the pixels), the call fails loudly if an image exceeds it
+    size_t px = 0;
+    for (int l = 0; l < L; ++l) px += (size_t)g.lv[l].w * g.lv[l].h;
+    dense_cap = std::min<size_t>((size_t)B * g.n_slots, (size_t)B * std::max<size_t>(px / 16, 4096));
+    dense_cap = std::max<size_t>(dense_cap, 1);
+    if ((rc = d_dense.resize(dense_cap))) return rc;
+    if ((rc = h_dense.resize(dense_cap))) return rc;
+    const size_t max_sel = (size_t)B * ((size_t)t.nfeatures + 4 * L + 64) * 2;
+    if ((rc = h_sel.resize(max_sel))) return rc;
+    if ((rc = d_sel.resize(max_sel))) return rc;
+    if ((rc = h_img_off.resize(B + 1))) return rc;
+    if ((rc = d_img_off.resize(B + 1))) return rc;
+    task_out.resize((size_t)B * L);
+    configured = true;
+    return DCS_OK;
+}
+
+LevelSet dcs_orb::make_levels(const uint8_t* slab, const uint8_t* level0, size_t level0_img_stride, int level0_pitch) const
+{
+    LevelSet s{};
+    s.nlevels = t.nlevels;
+    for (int l = 0; l < t.nlevels; ++l) {
+        s.lv[l].base = slab + g.lv[l].offset;
+        s.lv[l].img_stride = g.slab_bytes;
+        s.lv[l].w = g.lv[l].w; s.lv[l].h = g.lv[l].h; s.lv[l].pitch = g.lv[l].pitch;
+    }
+    if (level0) { s.lv[0].base = level0; s.lv[0].img_stride = level0_img_stride; s.lv[0].pitch = level0_pitch; }
+    return s;
+}
+
+int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_pitch, int n_images,
+                 dcs_keypoint* d_kp_out, uint8_t* d_desc_out, int cap, int32_t* d_n_out, hipStream_t stream, int* h_counts)
+{
+    const int L = t.nlevels, n_cells = (int)h_cells.size();
+    const LevelSet raw = make_levels(d_pyr.p, d_level0, level0_img_stride, level0_pitch);
+    const LevelSet blur = make_levels(d_blur.p, nullptr, 0, 0);
+    last_raw = raw; last_blur = blur; last_n_images = n_images;
+    timing_valid = false;
+    int rc;
+    DCS_HIP(hipEventRecord(ev_t[0], stream));
+    for (int l = 1; l < L; ++l) {
+        if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs, d_rtab.p + rtab[l].xa,
+                                d_rtab.p + rtab[l].yofs, d_rtab.p + rtab[l].ya, n_images, stream))) return rc;
+    }
+    DCS_HIP(hipEventRecord(ev_pyr, stream));
+    DCS_HIP(hipEventRecord(ev_t[1], stream));
+    // blur on the auxiliary stream, overlapping FAST + the host stage
+    DCS_HIP(hipStreamWaitEvent(s_aux, ev_pyr, 0));
+    DCS_HIP(hipEventRecord(ev_b[0], s_aux));
+    if ((rc = launch_blur(raw, blur, n_images, s_aux))) return rc;
+    DCS_HIP(hipEventRecord(ev_b[1], s_aux));
+    DCS_HIP(hipEventRecord(ev_blur, s_aux));
+
+    if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
+                                d_cell_count.p, stream))) return rc;
+    if ((rc = launch_compact(d_cells.p, d_level_cell_begin.p, L, n_images, n_cells, d_slots.p, g.n_slots, d_cell_count.p,
+                             d_cell_off.p, d_lvl_total.p, d_lvl_off.p, d_dense.p, dense_cap, stream))) return rc;
+    const int n_tasks = n_images * L;
+    DCS_HIP(hipMemcpyAsync(h_lvl_off.p, d_lvl_off.p, sizeof(int32_t) * (n_tasks + 1), hipMemcpyDeviceToHost, stream));
+    DCS_HIP(hipEventRecord(ev_t[2], stream));
+    DCS_HIP(hipStreamSynchronize(stream));
+    const size_t total = (size_t)h_lvl_off.p[n_tasks];
+    if (total > dense_cap) { set_error("FAST candidates (%zu) exceed the dense buffer (%zu)", total, dense_cap); return DCS_ERR_CAPACITY; }
+    if (total) {
+        DCS_HIP(hipMemcpyAsync(h_dense.p, d_dense.p, sizeof(dcs_candidate) * total, hipMemcpyDeviceToHost, stream));
+        DCS_HIP(hipStreamSynchronize(stream));
+    }
+    // host quadtree per (image, level)
+    const auto t0 = std::chrono::steady_clock::now();
+    pool->parallel_for(n_tasks, [&](int k) {
+        const int l = k % L;
+        const int b = h_lvl_off.p[k], e = h_lvl_off.p[k + 1];
+        const LevelGeom& lg = g.lv[l];
+        distribute_octree(h_dense.p + b, e - b, (lg.w - kEdgeThreshold + 3) - kMinBorder, (lg.h - kEdgeThreshold + 3) - kMinBorder,
+                          t.n_per_level[l], task_out[k]);
+    });
+    size_t n_sel = 0;
+    int max_per_image = 0;
+    bool over = false;
+    for (int i = 0; i < n_images; ++i) {
+        h_img_off.p[i] = (int32_t)n_sel;
+        for (int l = 0; l < L; ++l) {
+            for (const dcs_candidate& c : task_out[(size_t)i * L + l]) {
+                if (n_sel >= h_sel.n) { over = true; break; }
+                SelKp s;
+                s.x = (int16_t)(c.x + kMinBorder); s.y = (int16_t)(c.y + kMinBorder);
+                s.score = (int16_t)c.score; s.level = (int8_t)l; s.pad = 0;
+                h_sel.p[n_sel++] = s;
+            }
+        }
+        const int n_i = (int)(n_sel - h_img_off.p[i]);
+        if (h_counts) h_counts[i] = n_i;
+        max_per_image = std::max(max_per_image, n_i);
+    }
+    h_img_off.p[n_images] = (int32_t)n_sel;
+    host_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (over) { set_error("selected keypoints exceed internal capacity"); return DCS_ERR_CAPACITY; }
+    if (max_per_image > cap) {
+        set_error("an image yields %d keypoints but cap is %d", max_per_image, cap);
+        return DCS_ERR_CAPACITY;
+    }
+    if (n_sel) DCS_HIP(hipMemcpyAsync(d_sel.p, h_sel.p, sizeof(SelKp) * n_sel, hipMemcpyHostToDevice, stream));
+    DCS_HIP(hipMemcpyAsync(d_img_off.p, h_img_off.p, sizeof(int32_t) * (n_images + 1), hipMemcpyHostToDevice, stream));
+    DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
+    DCS_HIP(hipEventRecord(ev_t[3], stream));
+    DescribeParams dp{};
+    for (int l = 0; l < L; ++l) { dp.scale[l] = t.scale[l]; dp.scaled_patch[l] = g.lv[l].scaled_patch; }
+    for (int v = 0; v <= kHalfPatch; ++v) dp.umax[v] = t.umax[v];
+    if ((rc = launch_describe(raw, blur, dp, d_sel.p, d_img_off.p, n_images, max_per_image, d_kp_out, d_desc_out, cap,
+                              d_n_out, stream))) return rc;
+    DCS_HIP(hipEventRecord(ev_t[4], stream));
+    timing_valid = true;
+    return DCS_OK;
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
+{
+    if (!p || !out) { set_error("null argument"); return DCS_ERR_INVALID; }
+    *out = nullptr;
+    if (p->nlevels < 1 || p->nlevels > kMaxLevels || p->nfeatures < 1 || p->min_th_fast < 1 ||
+        p->ini_th_fast < p->min_th_fast || p->ini_th_fast > 254 || !(p->scale_factor > 1.0f)) {
+        set_error("bad ORB parameters");
+        return DCS_ERR_INVALID;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (p->device >= 0) DCS_HIP(hipSetDevice(p->device));
+    std::unique_ptr<dcs_orb> h(new dcs_orb);
+    h->prm = *p;
+    if (h->prm.max_images < 1) h->prm.max_images = 1;
+    DCS_HIP(hipGetDevice(&h->device));
+    h->t.build(p->nfeatures, p->scale_factor, p->nlevels, p->ini_th_fast, p->min_th_fast);
+    DCS_HIP(hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking));
+    DCS_HIP(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
+    DCS_HIP(hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming));
+    DCS_HIP(hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming));
+    for (auto& e : h->ev_t) DCS_HIP(hipEventCreate(&e));
+    for (auto& e : h->ev_b) DCS_HIP(hipEventCreate(&e));
+    int nthreads = p->host_threads;
+    if (nthreads <= 0) nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    h->pool.reset(new Pool(nthreads - 1));
+    *out = h.release();
+    return DCS_OK;
+}
+
+void dcs_orb_destroy(dcs_orb* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    delete h;
+}
+
+int dcs_orb_tables(const dcs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* n_per_level)
+{
+    if (!h) { set_error("null handle"); return DCS_ERR_INVALID; }
+    for (int i = 0; i < h->t.nlevels; ++i) {
+        if (scale) scale[i] = h->t.scale[i];
+        if (inv_scale) inv_scale[i] = h->t.inv_scale[i];
+        if (sigma2) sigma2[i] = h->t.sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->t.inv_sigma2[i];
+        if (n_per_level) n_per_level[i] = h->t.n_per_level[i];
+    }
+    return DCS_OK;
+}
+
+int dcs_orb_extract_batch_device(dcs_orb* h, const uint8_t* d_images, int n_images, int rows, int cols, int stride,
+                                 dcs_keypoint* d_kp, uint8_t* d_desc, int cap, int32_t* d_n_out, void* stream)
+{
+    if (!h || !d_images || !d_kp || !d_desc || !d_n_out || n_images < 1 || cap < 1 || stride < cols) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    if (n_images > h->prm.max_images) { set_error("n_images %d > max_images %d", n_images, h->prm.max_images); return DCS_ERR_INVALID; }
+    DCS_HIP(hipSetDevice(h->device));
+    int rc = h->configure(rows, cols);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : h->s_main;
+    return h->run(d_images, (size_t)rows * stride, stride, n_images, d_kp, d_desc, cap, d_n_out, s, nullptr);
+}
+
+int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images, int rows, int cols, int stride,
+                          dcs_keypoint* kp, uint8_t* desc, int cap, int* n_out)
+{
+    if (!h || !n_out || n_images < 1) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    for (int i = 0; i < n_images; ++i) n_out[i] = 0;
+    if (!images || rows <= 0 || cols <= 0) return DCS_OK;          // _image.empty() (:1046-1047)
+    for (int i = 0; i < n_images; ++i) if (!images[i]) return DCS_OK;
+    if (!kp || !desc || cap < 1 || stride < cols) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    if (n_images > h->prm.max_images) { set_error("n_images %d > max_images %d", n_images, h->prm.max_images); return DCS_ERR_INVALID; }
+    DCS_HIP(hipSetDevice(h->device));
+    int rc = h->configure(rows, cols);
+    if (rc) return rc;
+    const LevelGeom& l0 = h->g.lv[0];
+    // stage through pinned memory so the H2D copies are truly asynchronous
+    const size_t img_bytes = (size_t)rows * cols;
+    if ((rc = h->h_img.resize(img_bytes * n_images))) return rc;
+    for (int i = 0; i < n_images; ++i)
+        for (int y = 0; y < rows; ++y)
+            memcpy(h->h_img.p + i * img_bytes + (size_t)y * cols, images[i] + (size_t)y * stride, cols);
+    for (int i = 0; i < n_images; ++i)
+        DCS_HIP(hipMemcpy2DAsync(h->d_pyr.p + (size_t)i * h->g.slab_bytes + l0.offset, l0.pitch, h->h_img.p + i * img_bytes, cols,
+                                 cols, rows, hipMemcpyHostToDevice, h->s_main));
+    if ((rc = h->d_kp.resize((size_t)n_images * cap))) return rc;
+    if ((rc = h->d_desc.resize((size_t)n_images * cap * 32))) return rc;
+    if ((rc = h->d_n.resize(n_images))) return rc;
+    if ((rc = h->h_n.resize(n_images))) return rc;
+    std::vector<int> counts(n_images, 0);
+    rc = h->run(nullptr, 0, 0, n_images, h->d_kp.p, h->d_desc.p, cap, h->d_n.p, h->s_main, counts.data());
+    if (rc) { for (int i = 0; i < n_images; ++i) n_out[i] = counts[i]; return rc; }
+    for (int i = 0; i < n_images; ++i) {
+        if (!counts[i]) continue;
+        DCS_HIP(hipMemcpyAsync(kp + (size_t)i * cap, h->d_kp.p + (size_t)i * cap, sizeof(dcs_keypoint) * counts[i],
+                               hipMemcpyDeviceToHost, h->s_main));
+        DCS_HIP(hipMemcpyAsync(desc + (size_t)i * cap * 32, h->d_desc.p + (size_t)i * cap * 32, (size_t)32 * counts[i],
+                               hipMemcpyDeviceToHost, h->s_main));
+    }
+    DCS_HIP(hipStreamSynchronize(h->s_main));
+    for (int i = 0; i < n_images; ++i) n_out[i] = counts[i];
+    return DCS_OK;
+}
+
+int dcs_orb_extract(dcs_orb* h, const uint8_t* image, int rows, int cols, int stride, dcs_keypoint* kp, uint8_t* desc,
+                    int cap, int* n_out)
+{
+    const uint8_t* imgs[1] = {image};
+    return dcs_orb_extract_batch(h, imgs, 1, rows, cols, stride, kp, desc, cap, n_out);
+}
+
+int dcs_orb_debug_level_dims(const dcs_orb* h, int level, int* w, int* h_out)
+{
+    if (!h || !h->configured || level < 0 || level >= h->t.nlevels) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    *w = h->g.lv[level].w; *h_out = h->g.lv[level].h;
+    return DCS_OK;
+}
+
+int dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t* dst)
+{
+    if (!h || !h->configured || level < 0 || level >= h->t.nlevels || image < 0 || image >= h->last_n_images || !dst) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    DCS_HIP(hipSetDevice(h->device));
+    DCS_HIP(hipDeviceSynchronize());
+    const LevelView& v = blurred ? h->last_blur.lv[level] : h->last_raw.lv[level];
+    DCS_HIP(hipMemcpy2D(dst, v.w, v.base + (size_t)image * v.img_stride, v.pitch, v.w, v.h, hipMemcpyDeviceToHost));
+    return DCS_OK;
+}
+
+int dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* dst, int cap, int* n)
+{
+    if (!h || !h->configured || level < 0 || level >= h->t.nlevels || image < 0 || image >= h->last_n_images || !n) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    const int k = image * h->t.nlevels + level;
+    const int b = h->h_lvl_off.p[k], e = h->h_lvl_off.p[k + 1];
+    *n = e - b;
+    if (dst) memcpy(dst, h->h_dense.p + b, sizeof(dcs_candidate) * std::min(cap, e - b));
+    return DCS_OK;
+}
+
+int dcs_orb_last_timing(const dcs_orb* h, float* us6)
+{
+    if (!h || !us6 || !h->timing_valid) { set_error("no timing available"); return DCS_ERR_INVALID; }
+    DCS_HIP(hipEventSynchronize(h->ev_t[4]));
+    DCS_HIP(hipEventSynchronize(h->ev_b[1]));
+    float ms;
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[0], h->ev_t[1])); us6[0] = ms * 1000.f;
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[1], h->ev_t[2])); us6[1] = ms * 1000.f;
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_b[0], h->ev_b[1])); us6[2] = ms * 1000.f;
+    us6[3] = h->host_us;
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[3], h->ev_t[4])); us6[4] = ms * 1000.f;
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[0], h->ev_t[4])); us6[5] = ms * 1000.f;
+    return DCS_OK;
+}
+
+int dcs_distribute_octree(const dcs_candidate* cand, int n, int min_x, int max_x, int min_y, int max_y, int n_target,
+                          dcs_candidate* out, int cap, int* n_out)
+{
+    if (!n_out || n < 0 || (n && !cand)) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    std::vector<dcs_candidate> sel;
+    const int m = distribute_octree(cand, n, max_x - min_x, max_y - min_y, n_target, sel);
+    *n_out = m;
+    if (m > cap) return DCS_ERR_CAPACITY;
+    if (m && out) memcpy(out, sel.data(), sizeof(dcs_candidate) * m);
+    return DCS_OK;
+}
+
+}  // extern "C"

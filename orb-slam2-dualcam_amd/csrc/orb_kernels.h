@@ -1,0 +1,65 @@
+// orb_kernels.h -- launch interface of the extraction kernels (orb_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/dcs_abi.h"
+#include "orb_host.h"
+
+namespace dcs {
+
+// one pyramid level across a batch: image i lives at base + i * img_stride
+struct LevelView {
+    const uint8_t* base;
+    size_t img_stride;
+    int w, h, pitch;
+};
+
+struct LevelSet {                       // passed by value to kernels (<= 16 levels)
+    LevelView lv[kMaxLevels];
+    int nlevels;
+};
+
+// FAST cell descriptor (ORBextractor.cc:789-827): ROI origin/size in level coordinates, offset
+// added to ROI-relative keypoint coordinates (j*wCell, i*hCell), output slots.
+struct CellDesc {
+    int16_t level, x0, y0, rw, rh, ox, oy, cap;
+    int32_t slot_base;                  // first candidate slot of this cell inside one image
+};
+
+// keypoint selected by the quadtree, level coordinates (already + minBorder)
+struct SelKp {
+    int16_t x, y, score;
+    int8_t level, pad;
+};
+
+struct DescribeParams {
+    float scale[kMaxLevels];
+    int scaled_patch[kMaxLevels];
+    int umax[kHalfPatch + 1];
+};
+
+int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_xofs, const int16_t* d_xa,
+                  const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s);
+
+int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
+                      int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
+                      int32_t* d_cell_count, hipStream_t s);
+
+// per (image, level): scan the cell counts, then gather the slots into one dense array for the whole
+// batch. d_lvl_off[n_images*nlevels + 1] = exclusive offsets (image-major, level-minor).
+int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin /* nlevels+1 */, int nlevels,
+                   int n_images, int n_cells, const dcs_candidate* d_slots, size_t slots_per_image,
+                   const int32_t* d_cell_count, int32_t* d_cell_off, int32_t* d_lvl_total,
+                   int32_t* d_lvl_off, dcs_candidate* d_dense, size_t dense_cap, hipStream_t s);
+
+int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStream_t s);
+
+int launch_describe(const LevelSet& raw, const LevelSet& blurred, const DescribeParams& prm,
+                    const SelKp* d_sel, const int32_t* d_img_off /* n_images+1 */, int n_images, int max_per_image,
+                    dcs_keypoint* d_kp, uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s);
+
+int upload_pattern();   // copies the rBRIEF table to constant memory of the current device
+
+}  // namespace dcs

@@ -1,0 +1,443 @@
+// orb_kernels.hip -- hand-written gfx950 kernels of the ORB front end.
+//
+// What each kernel replaces in the reference (src/ORBextractor.cc) and the OpenCV call it restates
+// (OpenCV 3.3/3.4.0 non-IPP semantics):
+//   k_resize        ComputePyramid :1107-1132        cv::resize INTER_LINEAR 8UC1 (11-bit fixed point)
+//   k_fast_cells    ComputeKeyPointsOctTree :789-827  cv::FAST 9/16 + NMS per 30-px cell, iniTh -> minTh fallback
+//   k_level_scan / k_gather                           vToDistributeKeys in emission order (cell-major, row-major)
+//   k_blur          operator() :1085-1086             cv::GaussianBlur 7x7 sigma 2, REFLECT_101, legacy 8-bit path
+//   k_describe      IC_Angle :77-104, computeOrbDescriptor :108-147, keypoint assembly :837-847,1095-1101
+// All integer stages are bit-exact by construction; the float stages (fastAtan2 polynomial, rotated
+// pattern coordinates) use explicitly rounded mul/add (no FMA contraction) and RNE conversions.
+// Built with -ffp-contract=off.
+#include "orb_kernels.h"
+
+#include <cfloat>
+
+#include "common.h"
+
+namespace dcs {
+
+__constant__ int8_t c_pattern[1024] = {
+#include "brief_pattern.inc"
+};
+
+int upload_pattern() { return DCS_OK; }   // statically initialised __constant__ data: nothing to do
+
+// ------------------------------------------------------------------------------------- resize
+// one thread = 4 horizontally adjacent destination pixels (one packed dword store)
+__global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, const int16_t* __restrict__ xofs,
+                                                const int16_t* __restrict__ xa, const int16_t* __restrict__ yofs,
+                                                const int16_t* __restrict__ ya)
+{
+    const int img = blockIdx.z;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (dy >= dst.h || dx0 >= dst.w) return;
+    const uint8_t* S = src.base + (size_t)img * src.img_stride;
+    uint8_t* D = const_cast<uint8_t*>(dst.base) + (size_t)img * dst.img_stride + (size_t)dy * dst.pitch;
+    const int sy = yofs[dy];
+    const int sy0 = min(max(sy, 0), src.h - 1), sy1 = min(max(sy + 1, 0), src.h - 1);
+    const int b0 = ya[2 * dy], b1 = ya[2 * dy + 1];
+    const uint8_t* r0 = S + (size_t)sy0 * src.pitch;
+    const uint8_t* r1 = S + (size_t)sy1 * src.pitch;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = dx0 + k;
+        if (dx < dst.w) {
+            const int sx = xofs[dx], sx1 = min(sx + 1, src.w - 1);
+            const int a0 = xa[2 * dx], a1 = xa[2 * dx + 1];
+            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(D + dx0) = packed;     // pitch is a multiple of 64: always in-row
+}
+
+int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_xofs, const int16_t* d_xa,
+                  const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s)
+{
+    dim3 block(64, 4, 1);
+    dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, n_images);
+    hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, dst, d_xofs, d_xa, d_yofs, d_ya);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// ------------------------------------------------------------------------------------- FAST
+constexpr int kRoiMax = 66;      // w_cell <= 59 (n_cols = floor(width/30)) -> ROI <= 65
+constexpr int kRoiPitch = 68;
+
+// FAST-9/16 score of the pixel at c (LDS, row pitch kRoiPitch): max over the 16 contiguous 9-arcs of
+// the sign-consistent minimum |centre - ring|, minus 1 (== OpenCV cornerScore<16>; "corner at T"
+// <=> score >= T, so the score does not depend on the threshold).
+__device__ __forceinline__ int fast_score(const uint8_t* c)
+{
+    constexpr int P = kRoiPitch;
+    constexpr int off[16] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
+                             -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1};
+    const int v = c[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - (int)c[off[k]];
+    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
+    int dark = -256, bright = 256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        dark = max(dark, min(mn8[k], d[(k + 8) & 15]));        // all 9 ring pixels darker by > dark-1
+        bright = min(bright, max(mx8[k], d[(k + 8) & 15]));    // all 9 brighter by > -bright-1
+    }
+    return max(dark, -bright) - 1;
+}
+
+// one workgroup per (cell, image): ROI -> LDS, scores, strict 8-neighbour NMS inside the ROI's
+// detection area, per-cell threshold fallback, ordered (row-major) emission via wave ballots.
+__global__ __launch_bounds__(256) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells,
+                                                    int ini_th, int min_th, dcs_candidate* __restrict__ slots,
+                                                    size_t slots_per_image, int32_t* __restrict__ cell_count)
+{
+    __shared__ uint8_t s_px[kRoiMax * kRoiPitch];
+    __shared__ uint8_t s_sc[kRoiMax * kRoiPitch];
+    __shared__ int s_wave[4];
+    const int cell = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const CellDesc cd = cells[cell];
+    const int rw = cd.rw, rh = cd.rh;
+    if (rw < 7 || rh < 7) {
+        if (tid == 0) cell_count[(size_t)img * n_cells + cell] = 0;
+        return;
+    }
+    const LevelView lv = L.lv[cd.level];
+    const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)cd.y0 * lv.pitch + cd.x0;
+    for (int i = tid; i < rw * rh; i += 256) {
+        const int y = i / rw, x = i - y * rw;
+        s_px[y * kRoiPitch + x] = src[(size_t)y * lv.pitch + x];
+        s_sc[y * kRoiPitch + x] = 0;
+    }
+    __syncthreads();
+    const int dw = rw - 6, dh = rh - 6, ndet = dw * dh;
+    for (int p = tid; p < ndet; p += 256) {
+        const int y = 3 + p / dw, x = 3 + p % dw;
+        const int s = fast_score(&s_px[y * kRoiPitch + x]);
+        s_sc[y * kRoiPitch + x] = (uint8_t)max(s, 0);
+    }
+    __syncthreads();
+    // keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } -- neighbours below T lose anyway
+    uint32_t f_min = 0, f_ini = 0;
+    int it = 0;
+    for (int p = tid; p < ndet; p += 256, ++it) {
+        const int y = 3 + p / dw, x = 3 + p % dw;
+        const uint8_t* c = &s_sc[y * kRoiPitch + x];
+        const int s = c[0];
+        if (s >= min_th) {
+            const bool mx = s > c[-1] && s > c[1] && s > c[-kRoiPitch - 1] && s > c[-kRoiPitch] && s > c[-kRoiPitch + 1] &&
+                            s > c[kRoiPitch - 1] && s > c[kRoiPitch] && s > c[kRoiPitch + 1];
+            if (mx) { f_min |= 1u << it; if (s >= ini_th) f_ini |= 1u << it; }
+        }
+    }
+    const int any_ini = __syncthreads_or(f_ini != 0);     // vKeysCell.empty() after FAST(iniTh) ? (:812)
+    const uint32_t sel = any_ini ? f_ini : f_min;
+    const int n_it = (ndet + 255) >> 8;
+    const int wave = tid >> 6, lane = tid & 63;
+    dcs_candidate* out = slots + (size_t)img * slots_per_image + cd.slot_base;
+    int base = 0;
+    for (it = 0; it < n_it; ++it) {
+        const bool flag = (sel >> it) & 1u;
+        const unsigned long long m = __ballot(flag);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int off = base + __popcll(m & ((1ull << lane) - 1ull));
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = s_wave[w]; if (w < wave) off += c; tot += c; }
+        if (flag && off < cd.cap) {
+            const int p = it * 256 + tid;
+            const int y = 3 + p / dw, x = 3 + p % dw;
+            dcs_candidate o;
+            o.x = (int16_t)(x + cd.ox); o.y = (int16_t)(y + cd.oy); o.score = s_sc[y * kRoiPitch + x];
+            out[off] = o;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) cell_count[(size_t)img * n_cells + cell] = min(base, (int)cd.cap);
+}
+
+int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
+                      int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
+                      int32_t* d_cell_count, hipStream_t s)
+{
+    if (n_cells == 0) return DCS_OK;
+    hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, n_images), dim3(256), 0, s, levels, d_cells, n_cells,
+                       ini_th, min_th, d_slots, slots_per_image, d_cell_count);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// ------------------------------------------------------------------------------------- compaction
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* s_tmp /*[5]*/, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = s_tmp[w]; if (w < wave) off += c; tot += c; }
+    __syncthreads();
+    *total = tot;
+    return off + inc - v;
+}
+
+// grid (nlevels, n_images): exclusive offsets of the cells of one level + the level total
+__global__ __launch_bounds__(256) void k_level_scan(const int32_t* __restrict__ level_cell_begin, int nlevels, int n_cells,
+                                                    const int32_t* __restrict__ cell_count, int32_t* __restrict__ cell_off,
+                                                    int32_t* __restrict__ lvl_total)
+{
+    __shared__ int s_tmp[4];
+    const int l = blockIdx.x, img = blockIdx.y;
+    const int cb = level_cell_begin[l], ce = level_cell_begin[l + 1];
+    int running = 0;
+    for (int c0 = cb; c0 < ce; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        const int v = c < ce ? cell_count[(size_t)img * n_cells + c] : 0;
+        int tot;
+        const int ex = block_exclusive_scan_256(v, s_tmp, &tot);
+        if (c < ce) cell_off[(size_t)img * n_cells + c] = running + ex;
+        running += tot;
+    }
+    if (threadIdx.x == 0) lvl_total[img * nlevels + l] = running;
+}
+
+// grid (nlevels, n_images): global base of this (image, level) = sum of earlier totals, then gather
+__global__ __launch_bounds__(256) void k_gather(const CellDesc* __restrict__ cells, const int32_t* __restrict__ level_cell_begin,
+                                                int nlevels, int n_images, int n_cells, const dcs_candidate* __restrict__ slots,
+                                                size_t slots_per_image, const int32_t* __restrict__ cell_count,
+                                                const int32_t* __restrict__ cell_off, const int32_t* __restrict__ lvl_total,
+                                                int32_t* __restrict__ lvl_off, dcs_candidate* __restrict__ dense, size_t dense_cap)
+{
+    __shared__ int s_tmp[4];
+    const int l = blockIdx.x, img = blockIdx.y;
+    const int me = img * nlevels + l, n_all = n_images * nlevels;
+    int part = 0;
+    for (int j = threadIdx.x; j < me; j += 256) part += lvl_total[j];
+    int base;
+    (void)block_exclusive_scan_256(part, s_tmp, &base);
+    const int mine = lvl_total[me];
+    if (threadIdx.x == 0) {
+        lvl_off[me] = base;
+        if (me == n_all - 1) lvl_off[n_all] = base + mine;
+    }
+    const int cb = level_cell_begin[l], ce = level_cell_begin[l + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = cb + wave; c < ce; c += 4) {
+        const int n = cell_count[(size_t)img * n_cells + c];
+        const size_t dst0 = (size_t)base + cell_off[(size_t)img * n_cells + c];
+        const dcs_candidate* src = slots + (size_t)img * slots_per_image + cells[c].slot_base;
+        for (int k = lane; k < n; k += 64)
+            if (dst0 + k < dense_cap) dense[dst0 + k] = src[k];
+    }
+}
+
+int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, int nlevels, int n_images, int n_cells,
+                   const dcs_candidate* d_slots, size_t slots_per_image, const int32_t* d_cell_count,
+                   int32_t* d_cell_off, int32_t* d_lvl_total, int32_t* d_lvl_off, dcs_candidate* d_dense,
+                   size_t dense_cap, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_level_scan, dim3(nlevels, n_images), dim3(256), 0, s, d_level_cell_begin, nlevels, n_cells,
+                       d_cell_count, d_cell_off, d_lvl_total);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_gather, dim3(nlevels, n_images), dim3(256), 0, s, d_cells, d_level_cell_begin, nlevels,
+                       n_images, n_cells, d_slots, slots_per_image, d_cell_count, d_cell_off, d_lvl_total, d_lvl_off,
+                       d_dense, dense_cap);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// ------------------------------------------------------------------------------------- Gaussian blur
+constexpr int kBlurTW = 64, kBlurTH = 16;
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// separable 7-tap, integer kernel {18,34,49,55,49,34,18} (getGaussianKernel(7,2)*256 rounded), rows then
+// columns in int32, out = sat_u8((acc + 32768) >> 16). grid.x enumerates the tiles of all levels.
+__global__ __launch_bounds__(256) void k_blur(LevelSet src, LevelSet dst, int n_tiles_total)
+{
+    __shared__ uint8_t s_in[(kBlurTH + 6) * (kBlurTW + 8)];
+    __shared__ uint16_t s_h[(kBlurTH + 6) * kBlurTW];
+    int t = blockIdx.x, l = 0, tiles_x = 0;
+    for (; l < src.nlevels; ++l) {
+        tiles_x = (src.lv[l].w + kBlurTW - 1) / kBlurTW;
+        const int n = tiles_x * ((src.lv[l].h + kBlurTH - 1) / kBlurTH);
+        if (t < n) break;
+        t -= n;
+    }
+    if (l >= src.nlevels) return;
+    const LevelView sv = src.lv[l], dv = dst.lv[l];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int x0 = (t % tiles_x) * kBlurTW, y0 = (t / tiles_x) * kBlurTH;
+    const uint8_t* S = sv.base + (size_t)img * sv.img_stride;
+    constexpr int IW = kBlurTW + 6, IP = kBlurTW + 8;
+    for (int i = tid; i < (kBlurTH + 6) * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int sy = reflect101(y0 + r - 3, sv.h), sx = reflect101(x0 + c - 3, sv.w);
+        s_in[r * IP + c] = S[(size_t)sy * sv.pitch + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint8_t* p = &s_in[r * IP + c];
+        const int acc = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+        s_h[i] = (uint16_t)acc;                           // <= 255 * 257 = 65535
+    }
+    __syncthreads();
+    const int c = tid & 63, rq = tid >> 6;
+    uint8_t* D = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = rq * 4 + k;
+        const uint16_t* p = &s_h[r * kBlurTW + c];
+        const int acc = 18 * (p[0] + p[6 * kBlurTW]) + 34 * (p[kBlurTW] + p[5 * kBlurTW]) + 49 * (p[2 * kBlurTW] + p[4 * kBlurTW]) + 55 * p[3 * kBlurTW];
+        const int v = min(255, (acc + 32768) >> 16);
+        if (y0 + r < dv.h && x0 + c < dv.w) D[(size_t)(y0 + r) * dv.pitch + x0 + c] = (uint8_t)v;
+    }
+}
+
+int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStream_t s)
+{
+    int tiles = 0;
+    for (int l = 0; l < src.nlevels; ++l)
+        tiles += ((src.lv[l].w + kBlurTW - 1) / kBlurTW) * ((src.lv[l].h + kBlurTH - 1) / kBlurTH);
+    if (tiles == 0) return DCS_OK;
+    hipLaunchKernelGGL(k_blur, dim3(tiles, n_images), dim3(256), 0, s, src, dst, tiles);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// ------------------------------------------------------------------------------------- orientation + rBRIEF
+// cv::fastAtan2 (OpenCV 3.x): 7th-order odd polynomial on min/max, degrees in [0, 360)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+constexpr int kPatchR = 18;                 // rotated pattern reach: max radius 18.38 -> |coord| <= 18
+constexpr int kPatchRows = 2 * kPatchR + 1; // 37
+constexpr int kPatchDw = 11;                // dwords per staged row (44 bytes cover 37 + 3 alignment bytes)
+
+// one wave per keypoint; 4 keypoints per workgroup. grid (ceil(max_per_image/4), n_images)
+__global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
+                                                  const SelKp* __restrict__ sel, const int32_t* __restrict__ img_off,
+                                                  dcs_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int cap,
+                                                  int32_t* __restrict__ n_out)
+{
+    __shared__ uint32_t s_patch[4][kPatchRows * kPatchDw];
+    const int img = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int first = img_off[img], n_img = min(img_off[img + 1] - first, cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) n_out[img] = n_img;
+    const int i = blockIdx.x * 4 + wave;
+    if (blockIdx.x * 4 >= n_img) return;                     // block-uniform
+    const bool active = i < n_img;                           // wave-uniform; inactive waves only hit the barrier
+    const SelKp k = sel[first + (active ? i : 0)];
+    const int x = k.x, y = k.y, level = k.level;
+
+    // ---- IC_Angle on the unblurred level: moments over the umax disc (exact int32)
+    const LevelView rv = raw.lv[level];
+    const uint8_t* rc = rv.base + (size_t)img * rv.img_stride + (size_t)y * rv.pitch + x;
+    int m10 = 0, m01 = 0;
+    for (int idx = lane; idx < kPatchSize * kPatchSize; idx += 64) {
+        const int v = idx / kPatchSize - kHalfPatch, u = idx % kPatchSize - kHalfPatch;
+        if (abs(u) <= prm.umax[abs(v)]) {
+            const int val = rc[v * rv.pitch + u];
+            m10 += u * val; m01 += v * val;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- stage the 37x37 blurred neighbourhood in LDS with aligned dword loads
+    const LevelView bv = blurred.lv[level];
+    const uint8_t* bimg = bv.base + (size_t)img * bv.img_stride;
+    const int xs = (x - kPatchR) & ~3, shift = (x - kPatchR) & 3;
+    uint32_t* patch = s_patch[wave];
+    for (int idx = lane; idx < kPatchRows * kPatchDw; idx += 64) {
+        const int r = idx / kPatchDw, c = idx - r * kPatchDw;
+        patch[idx] = *reinterpret_cast<const uint32_t*>(bimg + (size_t)(y - kPatchR + r) * bv.pitch + xs + 4 * c);
+    }
+    __syncthreads();
+    if (!active) return;
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(patch) + kPatchR * (kPatchDw * 4) + kPatchR + shift;
+
+    // ---- steered BRIEF: a = (float)cos((double)rad), b = (float)sin((double)rad)   
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float rad = __fmul_rn(angle, factorPI);
+    const float a = (float)cos((double)rad), b = (float)sin((double)rad);
+    uint8_t* dout = desc_out + ((size_t)img * cap + i) * 32;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int t = it * 64 + lane;
+        const char4 pt = reinterpret_cast<const char4*>(c_pattern)[t];
+        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = pb[r0 * (kPatchDw * 4) + c0], t1 = pb[r1 * (kPatchDw * 4) + c1];
+        const unsigned long long m = __ballot(t0 < t1);      // bit j of m = test 64*it + j  (LSB-first bytes)
+        if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * it) = m;
+    }
+    if (lane == 0) {
+        dcs_keypoint o;
+        const float sc = prm.scale[level];
+        o.x = level ? __fmul_rn((float)x, sc) : (float)x;
+        o.y = level ? __fmul_rn((float)y, sc) : (float)y;
+        o.size = (float)prm.scaled_patch[level];
+        o.angle = angle; o.response = (float)k.score; o.octave = level; o.class_id = -1;
+        kp_out[(size_t)img * cap + i] = o;
+    }
+}
+
+int launch_describe(const LevelSet& raw, const LevelSet& blurred, const DescribeParams& prm, const SelKp* d_sel,
+                    const int32_t* d_img_off, int n_images, int max_per_image, dcs_keypoint* d_kp, uint8_t* d_desc,
+                    int cap, int32_t* d_n_out, hipStream_t s)
+{
+    const int gx = max_per_image > 0 ? (max_per_image + 3) / 4 : 1;
+    hipLaunchKernelGGL(k_describe, dim3(gx, n_images), dim3(256), 0, s, raw, blurred, prm, d_sel, d_img_off, d_kp, d_desc,
+                       cap, d_n_out);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+}  // namespace dcs

@@ -1,0 +1,146 @@
+"""GPU parity: HIP extraction (through the C ABI) vs the CPU oracle -- bit-exact keypoints and descriptors,
+stage by stage (pyramid, FAST candidates, blur) and end to end, plus golden fixtures and edge cases."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _same(kp_a, desc_a, kp_b, desc_b):
+    assert len(kp_a) == len(kp_b)
+    assert kp_a.tobytes() == kp_b.tobytes()
+    assert np.array_equal(desc_a, desc_b)
+
+
+@pytest.fixture(scope="module")
+def ext1000(pkg):
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=4)
+    yield e
+    e.close()
+
+
+def test_tables_match_oracle(pkg, oracle, ext1000):
+    t, o = ext1000.tables(), oracle.OrbOracle(1000, 1.2, 8, 20, 7).tables()
+    for k in ("scale", "inv_scale", "sigma2", "inv_sigma2", "n_per_level"):
+        assert np.array_equal(t[k], o[k]), k
+
+
+def test_stages_bit_exact_640x480(pkg, oracle, synth, ext1000):
+    img0, img1 = synth.frame_pair(640, 480, 0, 0)
+    kps, descs = ext1000.extract_batch([img0, img1])
+    for i, img in enumerate((img0, img1)):
+        o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+        okp, odesc = o.extract(img)
+        for l in range(8):
+            assert ext1000.level_dims(l) == o.level_dims(l)
+            assert np.array_equal(ext1000.level_image(i, l), o.level_image(l)), ("pyramid", i, l)
+            assert np.array_equal(ext1000.level_image(i, l, blurred=True), oracle.gauss7_u8(o.level_image(l))), ("blur", i, l)
+            assert ext1000.level_candidates(i, l).tobytes() == o.level_candidates(l).tobytes(), ("fast", i, l)
+        _same(kps[i], descs[i], okp, odesc)
+
+
+@pytest.mark.parametrize("w,h,n", [(640, 480, 1300), (1280, 720, 2000), (752, 480, 500), (333, 245, 300)])
+def test_end_to_end_bit_exact(pkg, oracle, synth, w, h, n):
+    imgs = synth.frame_pair(1280, 720, 1, 2) if (w, h) == (1280, 720) else synth.frame_pair(640, 480, 2, 1)
+    imgs = [np.ascontiguousarray(im[:h, :w]) if im.shape != (h, w) else im for im in imgs]
+    if imgs[0].shape != (h, w):                      # 752x480: pad from the big scene
+        big = synth.frame_pair(1280, 720, 1, 3)
+        imgs = [np.ascontiguousarray(b[:h, :w]) for b in big]
+    e = pkg.ORBextractor(n, 1.2, 8, 20, 7, max_images=2)
+    kps, descs = e.extract_batch(imgs, cap=n + 200)
+    for i in range(2):
+        okp, odesc = oracle.OrbOracle(n, 1.2, 8, 20, 7).extract(imgs[i], cap=n + 200)
+        _same(kps[i], descs[i], okp, odesc)
+    e.close()
+
+
+def test_single_image_operator_and_strided_input(pkg, oracle, synth, ext1000):
+    img, _ = synth.frame_pair(640, 480, 3, 0)
+    kp, desc = ext1000(img)
+    okp, odesc = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(img)
+    _same(kp, desc, okp, odesc)
+    # non-default FAST thresholds / levels / scale
+    e = pkg.ORBextractor(600, 1.5, 5, 30, 10, max_images=1)
+    kp, desc = e(img)
+    okp, odesc = oracle.OrbOracle(600, 1.5, 5, 30, 10).extract(img)
+    _same(kp, desc, okp, odesc)
+    e.close()
+
+
+def test_edge_cases(pkg, oracle, synth, ext1000):
+    # textureless image -> zero keypoints, no error (ORBextractor.cc:1064-1065)
+    kp, desc = ext1000(np.full((480, 640), 128, np.uint8))
+    assert len(kp) == 0 and desc.shape == (0, 32)
+    # saturated / extreme-contrast checkerboard: many equal scores (NMS ties) and saturating blur
+    yy, xx = np.mgrid[0:480, 0:640]
+    chk = (((xx // 16) + (yy // 16)) % 2 * 255).astype(np.uint8)
+    kp, desc = ext1000(chk)
+    okp, odesc = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(chk)
+    _same(kp, desc, okp, odesc)
+    # pure noise: every cell full of candidates (stress for per-cell slot capacity)
+    noise = np.random.default_rng(0).integers(0, 256, (480, 640), dtype=np.uint8)
+    kp, desc = ext1000(noise)
+    okp, odesc = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(noise)
+    _same(kp, desc, okp, odesc)
+    # capacity error is reported, not silently truncated
+    img, _ = synth.frame_pair(640, 480, 0, 0)
+    with pytest.raises(pkg.DcsError) as ei:
+        ext1000.extract_batch([img], cap=100)
+    assert ei.value.rc == pkg.abi.DCS_ERR_CAPACITY
+    # too many images for the handle
+    with pytest.raises(pkg.DcsError):
+        ext1000.extract_batch([img] * 5)
+    # image smaller than the border allows
+    with pytest.raises(pkg.DcsError):
+        ext1000(np.zeros((30, 30), np.uint8))
+
+
+def test_golden_fixture_and_hashes(pkg, synth):
+    g = np.load(os.path.join(GOLDEN, "extract_320x240_n300.npz"))
+    e = pkg.ORBextractor(300, 1.2, 8, 20, 7, max_images=1)
+    kp, desc = e(g["image"])
+    assert kp.tobytes() == g["keypoints"].tobytes() and np.array_equal(desc, g["descriptors"])
+    e.close()
+    gold = json.load(open(os.path.join(GOLDEN, "extract_hashes.json")))
+    for key, rec in gold.items():
+        img = synth.frame_pair(rec["width"], rec["height"], rec["stream"], rec["frame"])[rec["cam"]]
+        if hashlib.sha256(img.tobytes()).hexdigest() != rec["image_sha256"]:
+            pytest.skip("synthetic generator differs on this numpy build")
+        e = pkg.ORBextractor(rec["nfeatures"], 1.2, 8, 20, 7, max_images=1)
+        kp, desc = e(img, cap=rec["nfeatures"] + 200)
+        assert len(kp) == rec["n_keypoints"], key
+        assert hashlib.sha256(kp.tobytes()).hexdigest() == rec["keypoints_sha256"], key
+        assert hashlib.sha256(desc.tobytes()).hexdigest() == rec["descriptors_sha256"], key
+        e.close()
+
+
+def test_device_resident_batch_matches_host_api(pkg, oracle, synth):
+    import torch
+    B = 6
+    imgs = []
+    for f in range(B // 2):
+        imgs.extend(synth.frame_pair(640, 480, 0, f))
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=B)
+    cap = e.default_cap()
+    d_img = torch.from_numpy(np.stack(imgs)).cuda()
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_img, d_kp, d_desc, d_n, cap, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    kp_all = d_kp.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    desc_all = d_desc.cpu().numpy()
+    for i in range(B):
+        okp, odesc = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(imgs[i])
+        assert n[i] == len(okp)
+        assert kp_all[i, :n[i]].tobytes() == okp.tobytes()
+        assert np.array_equal(desc_all[i, :n[i]], odesc)
+    t = e.last_timing()
+    assert t["total_us"] > 0
+    e.close()

@@ -1,0 +1,106 @@
+"""GPU parity: Hamming knn2 / grouped knn2 / ratio + rotation filter through the C ABI vs the oracle
+(bit-exact: indices, distances, tie-breaking), golden fixture, edge cases."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _eq3(a, b):
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("nq,nt", [(1000, 1000), (2000, 2037), (1, 1), (63, 257), (65, 255), (300, 1)])
+def test_knn2_random(pkg, oracle, synth, nq, nt):
+    q = synth.random_descriptors(nq, seed=7)
+    t = synth.random_descriptors(nt, seed=8)
+    _eq3(pkg.ORBmatcher.knn2(q, t), oracle.knn2(q, t))
+
+
+def test_knn2_ties_masks_and_empty(pkg, oracle, synth):
+    q = synth.random_descriptors(200, seed=1)
+    t = np.concatenate([synth.noisy_copy(q, 12, seed=2), q[::-1], q])        # exact duplicates: distance-0 ties
+    _eq3(pkg.ORBmatcher.knn2(q, t), oracle.knn2(q, t))
+    few = np.tile(synth.random_descriptors(3, seed=3), (100, 1))             # heavy ties across LDS tiles / waves
+    _eq3(pkg.ORBmatcher.knn2(q, few), oracle.knn2(q, few))
+    mask = (np.random.default_rng(4).random(len(t)) < 0.5).astype(np.uint8)
+    _eq3(pkg.ORBmatcher.knn2(q, t, mask), oracle.knn2(q, t, mask))
+    _eq3(pkg.ORBmatcher.knn2(q, t, np.ones(len(t), np.uint8)), oracle.knn2(q, t, np.ones(len(t), np.uint8)))
+    bi, bd, sd = pkg.ORBmatcher.knn2(q, t[:0])
+    assert np.all(bi == -1) and np.all(bd == 256) and np.all(sd == 256)
+    assert len(pkg.ORBmatcher.knn2(q[:0], t)[0]) == 0
+
+
+def test_knn2_grouped(pkg, oracle, synth):
+    q = synth.random_descriptors(1000, seed=3)
+    t = synth.noisy_copy(q, 20, seed=4)[np.random.default_rng(5).permutation(1000)]
+    qn, qo, qi = synth.csr_buckets(1000, 100, seed=5)
+    tn, to, ti = synth.csr_buckets(1000, 100, seed=6)
+    assert np.array_equal(qn, tn)
+    _eq3(pkg.ORBmatcher.knn2_grouped(q, t, qo, qi, to, ti), oracle.knn2_grouped(q, t, qo, qi, to, ti))
+    # queries outside every group keep the sentinel
+    qo2, qi2 = qo[:11].copy(), qi[:qo[10]].copy()
+    got = pkg.ORBmatcher.knn2_grouped(q, t, qo2, qi2, to[:11], ti[:to[10]])
+    _eq3(got, oracle.knn2_grouped(q, t, qo2, qi2, to[:11], ti[:to[10]]))
+    assert np.sum(got[0] == -1) == 1000 - len(qi2)
+
+
+def test_filter_and_fused_bf_on_real_features(pkg, oracle, synth):
+    img0, img1 = synth.frame_pair(640, 480, 0, 0)
+    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    kp0, d0 = o.extract(img0)
+    kp1, d1 = o.extract(img1)
+    bi, bd, sd = oracle.knn2(d0, d1)
+    for ratio, ori, th, strict in [(0.75, True, 50, False), (0.6, True, 50, True), (0.9, False, 100, False), (0.75, True, 30, False)]:
+        exp_m, exp_n = oracle.ratio_rot_filter(bi, bd, sd, th, strict, ratio, ori, kp0["angle"], kp1["angle"])
+        m = pkg.ORBmatcher(ratio, ori)
+        got_m, got_n = m.filter(bi, bd, sd, th, strict, kp0["angle"], kp1["angle"])
+        assert np.array_equal(got_m, exp_m) and got_n == exp_n
+        if not strict:
+            fm, fn = m.match_bf(d0, kp0, d1, kp1, th)
+            assert np.array_equal(fm, exp_m) and fn == exp_n
+    assert exp_n > 20
+
+
+def test_match_golden(pkg):
+    g = np.load(os.path.join(GOLDEN, "match_small.npz"))
+    bi, bd, sd = pkg.ORBmatcher.knn2(g["q"], g["t"])
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_d"]) and np.array_equal(sd, g["second_d"])
+    m, n = pkg.ORBmatcher(0.75, True).filter(bi, bd, sd, 50, False, g["q_angle"], g["t_angle"])
+    assert np.array_equal(m, g["match"]) and n == int(g["n_matches"])
+
+
+def test_batch_device_pairs(pkg, oracle, synth):
+    import torch
+    B = 4
+    imgs = list(synth.frame_pair(640, 480, 0, 0)) + list(synth.frame_pair(640, 480, 0, 1))
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=B)
+    cap = e.default_cap()
+    d_img = torch.from_numpy(np.stack(imgs)).cuda()
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_img, d_kp, d_desc, d_n, cap, stream=torch.cuda.current_stream().cuda_stream)
+    pairs = np.array([[0, 1], [2, 3], [2, 0], [3, 1]], np.int32)        # cam0-cam1 at t0, t1; cam_c(t1) vs cam_c(t0)
+    d_pairs = torch.from_numpy(pairs).cuda()
+    P = len(pairs)
+    d_match = torch.full((P, cap), -7, dtype=torch.int32, device="cuda")
+    d_nm = torch.zeros(P, dtype=torch.int32, device="cuda")
+    d_b = torch.zeros((P, cap), dtype=torch.int32, device="cuda")
+    d_s = torch.zeros((P, cap), dtype=torch.int32, device="cuda")
+    pkg.ORBmatcher(0.75, True).match_bf_batch_device(d_desc, d_kp, d_n, cap, d_pairs, P, d_match, d_nm, d_b, d_s, 50,
+                                                     stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    feats = [oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(im) for im in imgs]
+    for p, (a, b) in enumerate(pairs):
+        (kq, dq), (kt, dt) = feats[a], feats[b]
+        bi, bd, sd = oracle.knn2(dq, dt)
+        m, n = oracle.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, kq["angle"], kt["angle"])
+        assert int(d_nm[p]) == n
+        assert np.array_equal(d_match[p, :len(dq)].cpu().numpy(), m)
+        assert np.array_equal(d_b[p, :len(dq)].cpu().numpy(), bd) and np.array_equal(d_s[p, :len(dq)].cpu().numpy(), sd)
+    e.close()
