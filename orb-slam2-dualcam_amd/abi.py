@@ -73,6 +73,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libdcs_hip.so not built (run __graft_entry__.build() / ./build.sh); no CPU fallback exists")
+        try:
+            # torch bundles its own libamdhip64.so.7 (ROCm 7.0); ours is linked against the same SONAME. Two HIP
+            # runtimes in one process cannot both own the GPU, so let torch's load first and share it.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.dcs_last_error.restype = C.c_char_p
         L.dcs_version.restype = C.c_char_p
