@@ -102,9 +102,9 @@ int  dcs_orb_extract_batch_device(dcs_orb* h, const uint8_t* d_images, int n_ima
 int  dcs_orb_debug_level_dims(const dcs_orb* h, int level, int* w, int* h_out);
 int  dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t* dst /* w*h */);
 int  dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* dst, int cap, int* n);
-/* per-stage GPU time of the last extract call in microseconds: pyramid, fast, blur, quadtree(host),
-   describe, total (6 floats) */
-int  dcs_orb_last_timing(const dcs_orb* h, float* us6);
+/* per-stage time of the last extract call in microseconds (hipEvents on the streams the kernels ran on):
+   resize chain, k_fast_cells, scan+gather, k_blur, host quadtree, k_describe, whole call (7 floats) */
+int  dcs_orb_last_timing(const dcs_orb* h, float* us7);
 
 /* DistributeOctTree (ORBextractor.cc:539-763) alone, host buffers (used by tests) */
 int  dcs_distribute_octree(const dcs_candidate* cand, int n, int min_x, int max_x, int min_y, int max_y,

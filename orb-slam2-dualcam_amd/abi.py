@@ -215,9 +215,10 @@ class ORBextractor:
         return out[:n.value]
 
     def last_timing(self):
-        t = np.zeros(6, np.float32)
+        t = np.zeros(7, np.float32)
         _check(lib().dcs_orb_last_timing(self._h, _p(t)), "dcs_orb_last_timing")
-        return dict(zip(("pyramid_us", "fast_us", "blur_us", "quadtree_host_us", "describe_us", "total_us"), t.tolist()))
+        return dict(zip(("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_host_us", "describe_us", "total_us"),
+                        t.tolist()))
 
 
 def distribute_octree(cand, min_x, max_x, min_y, max_y, n_target):

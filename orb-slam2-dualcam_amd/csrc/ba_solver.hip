@@ -1,0 +1,893 @@
+// ba_solver.hip -- Optimizer::LocalBundleAdjustment numerics on gfx950 (f64).
+//
+// Replaces (reference files): src/Optimizer.cc:582-621, 645-658 (two LM rounds, outlier flags) and the
+// g2o arithmetic they execute -- types/types_six_dof_expmap.cpp:109-169 (dual-camera edge error and
+// Jacobians with extrinsic + "adjoint"), core/base_binary_edge.hpp:55-120 + robust_kernel_impl.cpp:78-91
+// (Huber-weighted J^T W J blocks), core/block_solver.hpp:354-604 (Schur complement, lambda on every
+// diagonal, landmark back-substitution), solvers/linear_solver_eigen.h:94-124 (LDL^T of the reduced
+// camera system), core/optimization_algorithm_levenberg.cpp:61-189 (LM control), se3quat.h:223-257 (exp).
+//
+// Flat SoA problem in HBM, no graph objects. Per LM iteration:
+//   k_error      edge-parallel residual + chi2 + Huber rho, deterministic block partial sums
+//   k_linearize  edge-parallel Jacobians -> per-edge H_pl (6x3) and per-edge pose / point contributions
+//   k_reduce_point / k_reduce_pose   segmented sums in CSR order (no atomics: reproducible)
+//   per trial: k_point_prep (D^-1 = (H_ll + lambda I)^-1, H_pl D^-1), k_schur (one wave per pose pair over a
+//   precomputed (edge,edge) list), blocked LDL^T (16-column panels; trailing update on the f64 matrix
+//   cores, v_mfma_f64_16x16x4_f64), triangular solves, landmark back-substitution, manifold update,
+//   residuals again; the host reads back 3 doubles per trial and runs g2o's accept / reject logic.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace dcs {
+
+constexpr int kMaxCams = 4;
+constexpr int kNB = 16;
+
+struct DCam { double fx, fy, cx, cy, t[3], q[4], adj[36]; };
+struct DCams { DCam c[kMaxCams]; };
+
+// ------------------------------------------------------------------ small SE3 math (Eigen semantics)
+__host__ __device__ inline void cross3(const double a[3], const double b[3], double o[3])
+{ o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+
+// q = (x, y, z, w); Eigen QuaternionBase::_transformVector
+__host__ __device__ inline void qrot(const double q[4], const double v[3], double o[3])
+{
+    double uv[3]; cross3(q, v, uv);
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    double c[3]; cross3(q, uv, c);
+    o[0] = v[0] + q[3] * uv[0] + c[0]; o[1] = v[1] + q[3] * uv[1] + c[1]; o[2] = v[2] + q[3] * uv[2] + c[2];
+}
+__host__ __device__ inline void qmul(const double a[4], const double b[4], double o[4])
+{
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+__host__ __device__ inline void qnormalize(double q[4])      // SE3Quat::normalizeRotation
+{
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+__host__ __device__ inline void qtoR(const double q[4], double R[9])
+{
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+__host__ __device__ inline void qfromR(const double R[9], double q[4])
+{
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+        double v[3];
+        v[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+    }
+}
+// pose layout: tx,ty,tz,qx,qy,qz,qw
+__host__ __device__ inline void pose_map(const double* T, const double X[3], double o[3])
+{ qrot(T + 3, X, o); o[0] += T[0]; o[1] += T[1]; o[2] += T[2]; }
+
+__host__ __device__ inline void cam_point(const double* pose, const double* X, const DCam& c, double pc[3])
+{
+    double pm[3];
+    pose_map(pose, X, pm);
+    qrot(c.q, pm, pc);
+    pc[0] += c.t[0]; pc[1] += c.t[1]; pc[2] += c.t[2];
+}
+
+// exp(update) * T   (VertexSE3Expmap::oplusImpl, SE3Quat::exp, SE3Quat::operator*)
+__host__ __device__ inline void pose_oplus(const double* T, const double* u, double* out)
+{
+    const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double O2[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    double R[9], V[9];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
+        for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0 ? 1.0 : 0.0); R[i] = I + a * O[i] + b * O2[i]; V[i] = I + b * O[i] + c * O2[i]; }
+    }
+    double qe[4], te[3];
+    qfromR(R, qe); qnormalize(qe);
+    for (int i = 0; i < 3; ++i) te[i] = V[i * 3] * up[0] + V[i * 3 + 1] * up[1] + V[i * 3 + 2] * up[2];
+    double rt[3]; qrot(qe, T, rt);
+    out[0] = te[0] + rt[0]; out[1] = te[1] + rt[1]; out[2] = te[2] + rt[2];
+    double qo[4]; qmul(qe, T + 3, qo); qnormalize(qo);
+    out[3] = qo[0]; out[4] = qo[1]; out[5] = qo[2]; out[6] = qo[3];
+}
+
+__device__ inline void inv3(const double m[9], double o[9])     // Eigen cofactor inverse
+{
+    const double c00 = m[4] * m[8] - m[5] * m[7], c10 = m[5] * m[6] - m[3] * m[8], c20 = m[3] * m[7] - m[4] * m[6];
+    const double id = 1.0 / (c00 * m[0] + c10 * m[1] + c20 * m[2]);
+    o[0] = c00 * id; o[3] = c10 * id; o[6] = c20 * id;
+    o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    o[2] = (m[1] * m[5] - m[2] * m[4]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// deterministic block sum (256 threads): result valid in thread 0
+__device__ inline double block_sum_256(double v, double* s /*[256]*/)
+{
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d]; __syncthreads(); }
+    return s[0];
+}
+
+// ------------------------------------------------------------------ kernels
+struct EdgeArrays {
+    const int32_t *pose, *point, *cam;      // [E]
+    const double *obs, *w;                  // [E][2], [E]
+    const uint8_t* active;                  // [E]
+};
+
+// residuals (computeError), chi2, robust rho0; partial[blockIdx] = sum of rho0 over the block's active edges
+__global__ __launch_bounds__(256) void k_error(EdgeArrays ed, int E, const double* __restrict__ poses, const double* __restrict__ points,
+                                               DCams cams, int robust, double delta, double* __restrict__ err, double* __restrict__ chi2,
+                                               double* __restrict__ partial)
+{
+    __shared__ double s[256];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double rho0 = 0;
+    if (e < E && ed.active[e]) {
+        double pc[3];
+        const DCam& c = cams.c[ed.cam[e]];
+        cam_point(poses + 7 * ed.pose[e], points + 3 * ed.point[e], c, pc);
+        const double e0 = ed.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+        const double e1 = ed.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+        const double w = ed.w[e];
+        const double x2 = e0 * (w * e0) + e1 * (w * e1);
+        err[2 * e] = e0; err[2 * e + 1] = e1; chi2[e] = x2;
+        if (robust && x2 > delta * delta) rho0 = 2 * sqrt(x2) * delta - delta * delta; else rho0 = x2;
+    }
+    const double t = block_sum_256(rho0, s);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// out[slot] = sum(partial[0..n)) in index order (single block)
+__global__ __launch_bounds__(256) void k_final_sum(const double* __restrict__ partial, int n, double* __restrict__ out)
+{
+    __shared__ double s[256];
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
+    const double t = block_sum_256(v, s);
+    if (threadIdx.x == 0) *out = t;
+}
+
+// linearizeOplus + constructQuadraticForm, per edge. cpoint[e] = {Hll 00,01,02,11,12,22, bl0..2},
+// cpose[e] = {21 upper entries of Hpp row-major, bp0..5}, Hpl[e] = 6x3 row-major (pose rows, point cols)
+__global__ __launch_bounds__(256) void k_linearize(EdgeArrays ed, int E, const double* __restrict__ poses, const double* __restrict__ points,
+                                                   DCams cams, int robust, double delta, const double* __restrict__ err,
+                                                   const double* __restrict__ chi2, const int32_t* __restrict__ pose_idx,
+                                                   double* __restrict__ cpoint, double* __restrict__ cpose, double* __restrict__ Hpl)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E || !ed.active[e]) return;
+    const DCam& c = cams.c[ed.cam[e]];
+    const double* T = poses + 7 * ed.pose[e];
+    double pc[3];
+    cam_point(T, points + 3 * ed.point[e], c, pc);
+    const double x = pc[0], y = pc[1], z = pc[2];
+    const double s = -1. / z;
+    const double st[6] = {s * c.fx, s * 0.0, s * (-x / z * c.fx), s * 0.0, s * c.fy, s * (-y / z * c.fy)};
+    const double J3[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+    double A[12], Jp[12], Jx[6];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) A[i * 6 + j] = st[i * 3] * J3[j] + st[i * 3 + 1] * J3[6 + j] + st[i * 3 + 2] * J3[12 + j];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) {
+        double acc = 0;
+        for (int k = 0; k < 6; ++k) acc += A[i * 6 + k] * c.adj[k * 6 + j];
+        Jp[i * 6 + j] = acc;
+    }
+    double qt[4], R[9];
+    qmul(c.q, T + 3, qt); qnormalize(qt); qtoR(qt, R);         // rotation of T_ext * T_mcs
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Jx[i * 3 + j] = st[i * 3] * R[j] + st[i * 3 + 1] * R[3 + j] + st[i * 3 + 2] * R[6 + j];
+    double w = ed.w[e];
+    double r0 = -w * err[2 * e], r1 = -w * err[2 * e + 1];
+    if (robust) {
+        const double x2 = chi2[e];
+        const double rho1 = x2 <= delta * delta ? 1.0 : delta / sqrt(x2);
+        r0 *= rho1; r1 *= rho1; w = rho1 * w;
+    }
+    double* cp = cpoint + (size_t)e * 9;
+    int k = 0;
+    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) cp[k++] = Jx[i] * w * Jx[j] + Jx[3 + i] * w * Jx[3 + j];
+    for (int i = 0; i < 3; ++i) cp[6 + i] = Jx[i] * r0 + Jx[3 + i] * r1;
+    if (pose_idx[ed.pose[e]] >= 0) {
+        double* cq = cpose + (size_t)e * 27;
+        k = 0;
+        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) cq[k++] = Jp[i] * w * Jp[j] + Jp[6 + i] * w * Jp[6 + j];
+        for (int i = 0; i < 6; ++i) cq[21 + i] = Jp[i] * r0 + Jp[6 + i] * r1;
+        double* h = Hpl + (size_t)e * 18;
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) h[i * 3 + j] = Jp[i] * w * Jx[j] + Jp[6 + i] * w * Jx[3 + j];
+    }
+}
+
+// thread per point: sums its edges' contributions (CSR over active edges). Hll full 3x3, bl.
+__global__ __launch_bounds__(256) void k_reduce_point(int L, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
+                                                      const double* __restrict__ cpoint, double* __restrict__ Hll, double* __restrict__ bl)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
+        const double* c = cpoint + (size_t)pt_edges[k] * 9;
+        for (int i = 0; i < 9; ++i) a[i] += c[i];
+    }
+    double* H = Hll + (size_t)l * 9;
+    H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
+    bl[3 * l] = a[6]; bl[3 * l + 1] = a[7]; bl[3 * l + 2] = a[8];
+}
+
+// block (64 threads) per free pose: thread c < 27 sums component c over the pose's edges in CSR order
+__global__ __launch_bounds__(64) void k_reduce_pose(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
+                                                    const double* __restrict__ cpose, double* __restrict__ Hpp, double* __restrict__ bp)
+{
+    __shared__ double s[27];
+    const int i = blockIdx.x, c = threadIdx.x;
+    if (c < 27) {
+        double a = 0;
+        for (int k = ps_off[i]; k < ps_off[i + 1]; ++k) a += cpose[(size_t)ps_edges[k] * 27 + c];
+        s[c] = a;
+    }
+    __syncthreads();
+    if (c < 36) {
+        const int r = c / 6, q = c % 6, lo = min(r, q), hi = max(r, q);
+        Hpp[(size_t)i * 36 + c] = s[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+    }
+    if (c < 6) bp[i * 6 + c] = s[21 + c];
+}
+
+// max |diagonal| over pose and landmark blocks (computeLambdaInit). single block.
+__global__ __launch_bounds__(256) void k_max_diag(int np, const double* __restrict__ Hpp, int L, const int32_t* __restrict__ pt_off,
+                                                  const double* __restrict__ Hll, double* __restrict__ out)
+{
+    __shared__ double s[256];
+    double m = 0;
+    for (int i = threadIdx.x; i < np * 6; i += 256) m = fmax(m, fabs(Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+    for (int i = threadIdx.x; i < L * 3; i += 256) {
+        const int l = i / 3;
+        if (pt_off[l + 1] > pt_off[l]) m = fmax(m, fabs(Hll[(size_t)l * 9 + (i % 3) * 4]));
+    }
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + d]); __syncthreads(); }
+    if (threadIdx.x == 0) *out = s[0];
+}
+
+// thread per point: Dinv = (Hll + lambda I)^-1, db = Dinv bl, BD[e] = Hpl[e] Dinv for its free-pose edges
+__global__ __launch_bounds__(256) void k_point_prep(int L, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
+                                                    const int32_t* __restrict__ e_pose, const int32_t* __restrict__ pose_idx,
+                                                    const double* __restrict__ Hll, const double* __restrict__ bl, double lambda,
+                                                    const double* __restrict__ Hpl, double* __restrict__ Dinv, double* __restrict__ db,
+                                                    double* __restrict__ BD)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= L || pt_off[l + 1] == pt_off[l]) return;
+    double H[9], D[9];
+    for (int i = 0; i < 9; ++i) H[i] = Hll[(size_t)l * 9 + i];
+    H[0] += lambda; H[4] += lambda; H[8] += lambda;
+    inv3(H, D);
+    for (int i = 0; i < 9; ++i) Dinv[(size_t)l * 9 + i] = D[i];
+    for (int i = 0; i < 3; ++i) db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
+    for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
+        const int e = pt_edges[k];
+        if (pose_idx[e_pose[e]] < 0) continue;
+        const double* B = Hpl + (size_t)e * 18;
+        double* o = BD + (size_t)e * 18;
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = B[r * 3] * D[c] + B[r * 3 + 1] * D[3 + c] + B[r * 3 + 2] * D[6 + c];
+    }
+}
+
+// one wave per pose pair (i1 <= i2): S block = [i1==i2](Hpp + lambda I) - sum over shared points BD[e1] Hpl[e2]^T
+__global__ __launch_bounds__(64) void k_schur(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_off,
+                                              const int32_t* __restrict__ pair_e1, const int32_t* __restrict__ pair_e2,
+                                              const double* __restrict__ Hpp, double lambda, const double* __restrict__ BD,
+                                              const double* __restrict__ Hpl, double* __restrict__ S, int ld)
+{
+    const int p = blockIdx.x, t = threadIdx.x;
+    if (t >= 36) return;
+    const int i1 = pair_ij[2 * p], i2 = pair_ij[2 * p + 1];
+    const int r = t / 6, c = t % 6;
+    double acc = 0;
+    for (int k = pair_off[p]; k < pair_off[p + 1]; ++k) {
+        const double* a = BD + (size_t)pair_e1[k] * 18 + r * 3;
+        const double* b = Hpl + (size_t)pair_e2[k] * 18 + c * 3;
+        acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    }
+    double v = -acc;
+    if (i1 == i2) v += Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
+    S[(size_t)(i1 * 6 + r) * ld + i2 * 6 + c] = v;
+    if (i1 != i2) S[(size_t)(i2 * 6 + c) * ld + i1 * 6 + r] = v;
+}
+
+// block (64 threads) per free pose: bsch = bp - sum_e Hpl[e] db[point(e)]
+__global__ __launch_bounds__(64) void k_bschur(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
+                                               const int32_t* __restrict__ e_point, const double* __restrict__ Hpl,
+                                               const double* __restrict__ db, const double* __restrict__ bp, double* __restrict__ bsch)
+{
+    const int i = blockIdx.x, r = threadIdx.x;
+    if (r >= 6) return;
+    double a = 0;
+    for (int k = ps_off[i]; k < ps_off[i + 1]; ++k) {
+        const int e = ps_edges[k];
+        const double* B = Hpl + (size_t)e * 18 + r * 3;
+        const double* d = db + 3 * e_point[e];
+        a += B[0] * d[0] + B[1] * d[1] + B[2] * d[2];
+    }
+    bsch[i * 6 + r] = bp[i * 6 + r] - a;
+}
+
+// ---- blocked LDL^T of S (ld x ld, lower part used, n_pad multiple of 16) ----
+// panel step k0: factor the 16x16 diagonal block, then L rows below; W = L D kept for the trailing update
+__global__ __launch_bounds__(256) void k_ldlt_panel(double* __restrict__ S, int ld, int n_pad, int k0, double* __restrict__ W, int* __restrict__ ok)
+{
+    __shared__ double A[kNB][kNB + 1];
+    __shared__ double d[kNB];
+    const int t = threadIdx.x;
+    {
+        const int i = t / kNB, j = t % kNB;
+        A[i][j] = S[(size_t)(k0 + i) * ld + k0 + j];
+    }
+    __syncthreads();
+    for (int j = 0; j < kNB; ++j) {                         // right-looking LDL^T, thread i = row i
+        const double dj = A[j][j];
+        if (t == 0) { d[j] = dj; if (dj == 0.0 || !isfinite(dj)) *ok = 0; }
+        double col_i = 0;
+        if (t < kNB && t > j) col_i = A[t][j];
+        __syncthreads();
+        if (t < kNB && t > j) {
+            const double l = col_i / dj;
+            for (int c = j + 1; c <= t; ++c) A[t][c] -= l * A[c][j];    // A[c][j] still holds the unscaled column
+        }
+        __syncthreads();
+        if (t < kNB && t > j) A[t][j] = col_i / dj;
+        __syncthreads();
+    }
+    {
+        const int i = t / kNB, j = t % kNB;
+        if (i > j) S[(size_t)(k0 + i) * ld + k0 + j] = A[i][j];
+        else if (i == j) S[(size_t)(k0 + i) * ld + k0 + j] = d[i];
+    }
+    // rows below the diagonal block: L_r = A_r L_kk^-T D^-1
+    for (int r = k0 + kNB + t; r < n_pad; r += 256) {
+        double v[kNB];
+        double* row = S + (size_t)r * ld + k0;
+        for (int j = 0; j < kNB; ++j) {
+            double a = row[j];
+            for (int m = 0; m < j; ++m) a -= v[m] * A[j][m];          // v[m] = L_rm * d_m
+            v[j] = a;
+        }
+        for (int j = 0; j < kNB; ++j) { W[(size_t)r * kNB + j] = v[j]; row[j] = v[j] / d[j]; }
+    }
+}
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// trailing update of one 16x16 tile (ti >= tj > k) per wave: A_ij -= W_i L_j^T on the f64 matrix cores.
+// v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// C/D: col = l&15, row = (l>>4) + 4*reg.
+__global__ __launch_bounds__(64) void k_ldlt_update(double* __restrict__ S, int ld, int k0, const double* __restrict__ W)
+{
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj > ti) return;
+    const int i0 = k0 + kNB * (ti + 1), j0 = k0 + kNB * (tj + 1);
+    const int l = threadIdx.x, lo = l & 15, hi = l >> 4;
+    double4_t acc;
+    for (int r = 0; r < 4; ++r) acc[r] = S[(size_t)(i0 + hi + 4 * r) * ld + j0 + lo];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double a = -W[(size_t)(i0 + lo) * kNB + 4 * kk + hi];
+        const double b = S[(size_t)(j0 + lo) * ld + k0 + 4 * kk + hi];       // L_j[lo][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; ++r) S[(size_t)(i0 + hi + 4 * r) * ld + j0 + lo] = acc[r];
+}
+
+// x = S^-1 b with S = L D L^T already factored in place (unit lower L below the diagonal, D on it). single block.
+__global__ __launch_bounds__(256) void k_ldlt_solve(const double* __restrict__ S, int ld, int n_pad, const double* __restrict__ b, int n,
+                                                    double* __restrict__ x)
+{
+    extern __shared__ double y[];                  // n_pad
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    for (int i = t; i < n_pad; i += 256) y[i] = i < n ? b[i] : 0.0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n_pad; k0 += kNB) {      // forward: L y = b
+        if (t == 0) {
+            for (int i = 1; i < kNB; ++i) { double a = y[k0 + i]; for (int m = 0; m < i; ++m) a -= S[(size_t)(k0 + i) * ld + k0 + m] * y[k0 + m]; y[k0 + i] = a; }
+        }
+        __syncthreads();
+        for (int r = k0 + kNB + t; r < n_pad; r += 256) {
+            double a = y[r];
+            const double* row = S + (size_t)r * ld + k0;
+            for (int m = 0; m < kNB; ++m) a -= row[m] * y[k0 + m];
+            y[r] = a;
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < n_pad; i += 256) y[i] /= S[(size_t)i * ld + i];
+    __syncthreads();
+    for (int k0 = n_pad - kNB; k0 >= 0; k0 -= kNB) {   // backward: L^T x = z
+        // contributions of already solved rows below: 16 columns x 16 row-chunks
+        const int j = t & 15, ch = t >> 4;
+        double a = 0;
+        for (int r = k0 + kNB + ch; r < n_pad; r += 16) a += S[(size_t)r * ld + k0 + j] * y[r];
+        red[t] = a;
+        __syncthreads();
+        if (t < kNB) { double s = 0; for (int c = 0; c < 16; ++c) s += red[c * 16 + t]; y[k0 + t] -= s; }
+        __syncthreads();
+        if (t == 0) {
+            for (int i = kNB - 2; i >= 0; --i) { double a2 = y[k0 + i]; for (int m = i + 1; m < kNB; ++m) a2 -= S[(size_t)(k0 + m) * ld + k0 + i] * y[k0 + m]; y[k0 + i] = a2; }
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < n; i += 256) x[i] = y[i];
+}
+
+// thread per point: xl = Dinv (bl - sum_e Hpl[e]^T xp[pose(e)])
+__global__ __launch_bounds__(256) void k_back_subst(int L, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
+                                                    const int32_t* __restrict__ e_pose, const int32_t* __restrict__ pose_idx,
+                                                    const double* __restrict__ Hpl, const double* __restrict__ xp, const double* __restrict__ bl,
+                                                    const double* __restrict__ Dinv, double* __restrict__ xl)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    if (pt_off[l + 1] == pt_off[l]) { xl[3 * l] = xl[3 * l + 1] = xl[3 * l + 2] = 0; return; }
+    double c[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
+    for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
+        const int e = pt_edges[k], pi = pose_idx[e_pose[e]];
+        if (pi < 0) continue;
+        const double* B = Hpl + (size_t)e * 18;
+        const double* xq = xp + pi * 6;
+        for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) c[j] -= B[r * 3 + j] * xq[r];
+    }
+    const double* D = Dinv + (size_t)l * 9;
+    for (int i = 0; i < 3; ++i) xl[3 * l + i] = D[i * 3] * c[0] + D[i * 3 + 1] * c[1] + D[i * 3 + 2] * c[2];
+}
+
+// push + update: backup the estimates, then pose <- exp(dx) * pose, point += dx
+__global__ __launch_bounds__(256) void k_update(int P, int L, const int32_t* __restrict__ pose_idx, const double* __restrict__ xp,
+                                                const double* __restrict__ xl, double* __restrict__ poses, double* __restrict__ points,
+                                                double* __restrict__ poses_bk, double* __restrict__ points_bk)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P) {
+        double T[7];
+        for (int k = 0; k < 7; ++k) { T[k] = poses[7 * i + k]; poses_bk[7 * i + k] = T[k]; }
+        const int pi = pose_idx[i];
+        if (pi >= 0) { double o[7]; pose_oplus(T, xp + 6 * pi, o); for (int k = 0; k < 7; ++k) poses[7 * i + k] = o[k]; }
+    } else if (i < P + L) {
+        const int l = i - P;
+        for (int k = 0; k < 3; ++k) { const double v = points[3 * l + k]; points_bk[3 * l + k] = v; points[3 * l + k] = v + xl[3 * l + k]; }
+    }
+}
+
+// computeScale: sum_j x_j (lambda x_j + b_j) over pose and active landmark entries. single block.
+__global__ __launch_bounds__(256) void k_scale(int n, const double* __restrict__ xp, const double* __restrict__ bp, int L,
+                                               const int32_t* __restrict__ pt_off, const double* __restrict__ xl, const double* __restrict__ bl,
+                                               double lambda, double* __restrict__ out)
+{
+    __shared__ double s[256];
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += xp[i] * (lambda * xp[i] + bp[i]);
+    for (int i = threadIdx.x; i < 3 * L; i += 256) {
+        const int l = i / 3;
+        if (pt_off[l + 1] > pt_off[l]) v += xl[i] * (lambda * xl[i] + bl[i]);
+    }
+    const double t = block_sum_256(v, s);
+    if (threadIdx.x == 0) *out = t;
+}
+
+// outlier flags: chi2 (last evaluation) > th || depth <= 0 with the CURRENT estimates (Optimizer.cc:607, 653)
+__global__ __launch_bounds__(256) void k_flags(EdgeArrays ed, int E, const double* __restrict__ poses, const double* __restrict__ points,
+                                               DCams cams, const double* __restrict__ chi2, double th, uint8_t* __restrict__ flag)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    double pc[3];
+    cam_point(poses + 7 * ed.pose[e], points + 3 * ed.point[e], cams.c[ed.cam[e]], pc);
+    flag[e] = (chi2[e] > th || !(pc[2] > 0.0)) ? 1 : 0;
+}
+
+__global__ void k_pad_identity(double* S, int ld, int n, int n_pad)
+{
+    const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pad) S[(size_t)i * ld + i] = 1.0;
+}
+
+}  // namespace dcs
+
+using namespace dcs;
+
+namespace {
+
+struct Arena {                                 // one device allocation per solve
+    char* base = nullptr; size_t cap = 0, off = 0;
+    ~Arena() { if (base) (void)hipFree(base); }
+    int init(size_t bytes) { cap = bytes; DCS_HIP(hipMalloc((void**)&base, bytes)); return DCS_OK; }
+    template <typename T> T* get(size_t n) { off = (off + 255) & ~(size_t)255; T* p = (T*)(base + off); off += n * sizeof(T); return off <= cap ? p : nullptr; }
+};
+
+struct Round {                                  // structure of one optimisation round (buildIndexMapping + buildStructure)
+    std::vector<int32_t> pose_idx, pt_off, pt_edges, ps_off, ps_edges, pair_ij, pair_off, pair_e1, pair_e2;
+    int np = 0, n = 0, n_pad = 0, n_pairs = 0, n_active = 0;
+};
+
+void build_round(const dcs_ba_problem* pb, const std::vector<uint8_t>& active, Round& r)
+{
+    const int P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+    std::vector<uint8_t> pose_act(P, 0);
+    r.n_active = 0;
+    for (int e = 0; e < E; ++e) if (active[e]) { pose_act[pb->edge_pose[e]] = 1; ++r.n_active; }
+    r.pose_idx.assign(P, -1);
+    r.np = 0;
+    for (int p = 0; p < P; ++p) if (pose_act[p] && !pb->pose_fixed[p]) r.pose_idx[p] = r.np++;
+    r.n = r.np * 6; r.n_pad = ((r.n + kNB - 1) / kNB) * kNB;
+    // point -> active edges, sorted by pose index (fixed poses first: index -1), then edge id
+    r.pt_off.assign(L + 1, 0);
+    for (int e = 0; e < E; ++e) if (active[e]) ++r.pt_off[pb->edge_point[e] + 1];
+    for (int l = 0; l < L; ++l) r.pt_off[l + 1] += r.pt_off[l];
+    r.pt_edges.assign(r.n_active, 0);
+    {
+        std::vector<int32_t> cur(r.pt_off.begin(), r.pt_off.end() - 1);
+        for (int e = 0; e < E; ++e) if (active[e]) r.pt_edges[cur[pb->edge_point[e]]++] = e;
+        for (int l = 0; l < L; ++l)
+            std::stable_sort(r.pt_edges.begin() + r.pt_off[l], r.pt_edges.begin() + r.pt_off[l + 1],
+                             [&](int a, int b) { return r.pose_idx[pb->edge_pose[a]] < r.pose_idx[pb->edge_pose[b]]; });
+    }
+    // free pose -> active edges (edge id order)
+    r.ps_off.assign(r.np + 1, 0);
+    for (int e = 0; e < E; ++e) if (active[e] && r.pose_idx[pb->edge_pose[e]] >= 0) ++r.ps_off[r.pose_idx[pb->edge_pose[e]] + 1];
+    for (int i = 0; i < r.np; ++i) r.ps_off[i + 1] += r.ps_off[i];
+    r.ps_edges.assign(r.ps_off[r.np], 0);
+    {
+        std::vector<int32_t> cur(r.ps_off.begin(), r.ps_off.end() - 1);
+        for (int e = 0; e < E; ++e) if (active[e] && r.pose_idx[pb->edge_pose[e]] >= 0) r.ps_edges[cur[r.pose_idx[pb->edge_pose[e]]]++] = e;
+    }
+    // pose pairs (i1 <= i2) sharing a point, plus every diagonal pair; (e1, e2) lists in point order
+    const int np = r.np;
+    std::vector<int32_t> cnt((size_t)np * np, 0);
+    for (int l = 0; l < L; ++l)
+        for (int a = r.pt_off[l]; a < r.pt_off[l + 1]; ++a) {
+            const int i1 = r.pose_idx[pb->edge_pose[r.pt_edges[a]]];
+            if (i1 < 0) continue;
+            for (int b = a; b < r.pt_off[l + 1]; ++b) ++cnt[(size_t)i1 * np + r.pose_idx[pb->edge_pose[r.pt_edges[b]]]];
+        }
+    std::vector<int32_t> pid((size_t)np * np, -1);
+    r.pair_ij.clear(); r.pair_off.assign(1, 0);
+    for (int i1 = 0; i1 < np; ++i1)
+        for (int i2 = i1; i2 < np; ++i2)
+            if (cnt[(size_t)i1 * np + i2] || i1 == i2) {
+                pid[(size_t)i1 * np + i2] = (int)r.pair_ij.size() / 2;
+                r.pair_ij.push_back(i1); r.pair_ij.push_back(i2);
+                r.pair_off.push_back(r.pair_off.back() + cnt[(size_t)i1 * np + i2]);
+            }
+    r.n_pairs = (int)r.pair_ij.size() / 2;
+    r.pair_e1.assign(r.pair_off.back(), 0); r.pair_e2.assign(r.pair_off.back(), 0);
+    {
+        std::vector<int32_t> cur(r.pair_off.begin(), r.pair_off.end() - 1);
+        for (int l = 0; l < L; ++l)
+            for (int a = r.pt_off[l]; a < r.pt_off[l + 1]; ++a) {
+                const int e1 = r.pt_edges[a], i1 = r.pose_idx[pb->edge_pose[e1]];
+                if (i1 < 0) continue;
+                for (int b = a; b < r.pt_off[l + 1]; ++b) {
+                    const int e2 = r.pt_edges[b], p = pid[(size_t)i1 * np + r.pose_idx[pb->edge_pose[e2]]];
+                    r.pair_e1[cur[p]] = e1; r.pair_e2[cur[p]] = e2; ++cur[p];
+                }
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dcs_ba_result* res)
+{
+    if (!pb || !res || !res->poses || !res->points || !res->edge_outlier || pb->n_poses < 1 || pb->n_points < 1 || pb->n_edges < 1 ||
+        pb->n_cams < 1 || pb->n_cams > kMaxCams || !pb->poses || !pb->pose_fixed || !pb->points || !pb->edge_pose || !pb->edge_point ||
+        !pb->edge_cam || !pb->obs || !pb->inv_sigma2 || !pb->cams) {
+        set_error("bad BA problem (n_cams must be 1..%d)", kMaxCams); return DCS_ERR_INVALID;
+    }
+    const int P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+    for (int e = 0; e < E; ++e)
+        if (pb->edge_pose[e] < 0 || pb->edge_pose[e] >= P || pb->edge_point[e] < 0 || pb->edge_point[e] >= L || pb->edge_cam[e] < 0 ||
+            pb->edge_cam[e] >= pb->n_cams) { set_error("edge %d out of range", e); return DCS_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    res->n_iters[0] = res->n_iters[1] = 0; res->n_trials[0] = res->n_trials[1] = 0; res->lambda[0] = res->lambda[1] = 0; res->gpu_ms = 0;
+    for (int i = 0; i < 32; ++i) res->chi2_trace[i] = 0;
+    auto stopped = [&]() { return stop_flag && *stop_flag; };
+
+    DCams cams{};
+    for (int c = 0; c < pb->n_cams; ++c) {
+        DCam& d = cams.c[c];
+        const dcs_ba_camera& s = pb->cams[c];
+        d.fx = s.fx; d.fy = s.fy; d.cx = s.cx; d.cy = s.cy;
+        d.t[0] = s.ext[0]; d.t[1] = s.ext[1]; d.t[2] = s.ext[2];
+        d.q[0] = s.ext[3]; d.q[1] = s.ext[4]; d.q[2] = s.ext[5]; d.q[3] = s.ext[6];
+        memcpy(d.adj, s.adj, sizeof(d.adj));
+    }
+    const int nblk = (E + 255) / 256;
+    const int n_max = P * 6, n_pad_max = ((n_max + kNB - 1) / kNB) * kNB;
+    const size_t max_pairs_entries = [&] {            // upper bound of the (e1,e2) list: sum over points k(k+1)/2
+        std::vector<int> k(L, 0);
+        for (int e = 0; e < E; ++e) ++k[pb->edge_point[e]];
+        size_t s = 0;
+        for (int l = 0; l < L; ++l) s += (size_t)k[l] * (k[l] + 1) / 2;
+        return s;
+    }();
+    const size_t n_pairs_max = (size_t)P * (P + 1) / 2;
+    Arena ar;
+    size_t bytes = 0;
+    bytes += (size_t)(2 * P * 7 + 2 * L * 3) * 8 + (size_t)E * (12 + 8 * (2 + 1 + 2 + 1 + 18 + 18 + 27 + 9) + 2);
+    bytes += (size_t)L * 8 * (9 + 3 + 9 + 3 + 3) + (size_t)P * 8 * (36 + 6 + 6 + 6) + (size_t)n_pad_max * n_pad_max * 8 + (size_t)n_pad_max * kNB * 8;
+    bytes += (size_t)(P + L + 1 + E + P + 1 + E) * 4 + n_pairs_max * 12 + max_pairs_entries * 8 + (size_t)nblk * 8 + 64 * 256 + (1 << 16);
+    if ((rc = ar.init(bytes))) return rc;
+    double* d_poses = ar.get<double>(P * 7); double* d_poses_bk = ar.get<double>(P * 7);
+    double* d_points = ar.get<double>(L * 3); double* d_points_bk = ar.get<double>(L * 3);
+    int32_t* d_epose = ar.get<int32_t>(E); int32_t* d_epoint = ar.get<int32_t>(E); int32_t* d_ecam = ar.get<int32_t>(E);
+    double* d_obs = ar.get<double>(2 * (size_t)E); double* d_w = ar.get<double>(E);
+    uint8_t* d_active = ar.get<uint8_t>(E); uint8_t* d_flag = ar.get<uint8_t>(E);
+    double* d_err = ar.get<double>(2 * (size_t)E); double* d_chi2 = ar.get<double>(E);
+    double* d_Hpl = ar.get<double>(18 * (size_t)E); double* d_BD = ar.get<double>(18 * (size_t)E);
+    double* d_cpose = ar.get<double>(27 * (size_t)E); double* d_cpoint = ar.get<double>(9 * (size_t)E);
+    double* d_Hll = ar.get<double>(9 * (size_t)L); double* d_bl = ar.get<double>(3 * (size_t)L);
+    double* d_Dinv = ar.get<double>(9 * (size_t)L); double* d_db = ar.get<double>(3 * (size_t)L); double* d_xl = ar.get<double>(3 * (size_t)L);
+    double* d_Hpp = ar.get<double>(36 * (size_t)P); double* d_bp = ar.get<double>(6 * (size_t)P);
+    double* d_bsch = ar.get<double>(6 * (size_t)P); double* d_xp = ar.get<double>(6 * (size_t)P);
+    double* d_S = ar.get<double>((size_t)n_pad_max * n_pad_max); double* d_W = ar.get<double>((size_t)n_pad_max * kNB);
+    int32_t* d_pose_idx = ar.get<int32_t>(P); int32_t* d_pt_off = ar.get<int32_t>(L + 1); int32_t* d_pt_edges = ar.get<int32_t>(E);
+    int32_t* d_ps_off = ar.get<int32_t>(P + 1); int32_t* d_ps_edges = ar.get<int32_t>(E);
+    int32_t* d_pair_ij = ar.get<int32_t>(2 * n_pairs_max); int32_t* d_pair_off = ar.get<int32_t>(n_pairs_max + 1);
+    int32_t* d_pair_e1 = ar.get<int32_t>(max_pairs_entries + 1); int32_t* d_pair_e2 = ar.get<int32_t>(max_pairs_entries + 1);
+    double* d_partial = ar.get<double>(nblk);
+    double* d_scal = ar.get<double>(8);               // [0] chi2, [1] scale, [2] maxdiag
+    int* d_ok = ar.get<int>(4);
+    if (!d_ok) { set_error("BA arena too small"); return DCS_ERR_HIP; }
+    double* h_scal = nullptr;
+    DCS_HIP(hipHostMalloc((void**)&h_scal, 64));
+    struct HostFree { void* p; ~HostFree() { (void)hipHostFree(p); } } hf{h_scal};
+    int* h_ok = (int*)(h_scal + 4);
+
+    hipStream_t st;
+    DCS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{st};
+    DCS_HIP(hipMemcpyAsync(d_poses, pb->poses, sizeof(double) * 7 * P, hipMemcpyHostToDevice, st));
+    DCS_HIP(hipMemcpyAsync(d_points, pb->points, sizeof(double) * 3 * L, hipMemcpyHostToDevice, st));
+    DCS_HIP(hipMemcpyAsync(d_epose, pb->edge_pose, sizeof(int32_t) * E, hipMemcpyHostToDevice, st));
+    DCS_HIP(hipMemcpyAsync(d_epoint, pb->edge_point, sizeof(int32_t) * E, hipMemcpyHostToDevice, st));
+    DCS_HIP(hipMemcpyAsync(d_ecam, pb->edge_cam, sizeof(int32_t) * E, hipMemcpyHostToDevice, st));
+    DCS_HIP(hipMemcpyAsync(d_obs, pb->obs, sizeof(double) * 2 * E, hipMemcpyHostToDevice, st));
+    DCS_HIP(hipMemcpyAsync(d_w, pb->inv_sigma2, sizeof(double) * E, hipMemcpyHostToDevice, st));
+    DCS_HIP(hipMemsetAsync(d_chi2, 0, sizeof(double) * E, st));
+    DCS_HIP(hipMemsetAsync(d_err, 0, sizeof(double) * 2 * E, st));
+    EdgeArrays ed{d_epose, d_epoint, d_ecam, d_obs, d_w, d_active};
+    const double delta = pb->huber_delta;
+    std::vector<uint8_t> active(E, 1), level1(E, 0);
+    int trace = 0;
+    const auto t_opt0 = std::chrono::steady_clock::now();
+
+    auto eval_error = [&](int robust, double* chi_out) -> int {     // computeActiveErrors + activeRobustChi2
+        hipLaunchKernelGGL(k_error, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2, d_partial);
+        DCS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, st, d_partial, nblk, chi_out);
+        DCS_CHECK_LAUNCH();
+        return DCS_OK;
+    };
+
+    auto run_round = [&](int round, int iters, int robust) -> int {
+        Round r;
+        build_round(pb, active, r);
+        if (r.n_active == 0) return DCS_OK;
+        DCS_HIP(hipMemcpyAsync(d_active, active.data(), E, hipMemcpyHostToDevice, st));
+        DCS_HIP(hipMemcpyAsync(d_pose_idx, r.pose_idx.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+        DCS_HIP(hipMemcpyAsync(d_pt_off, r.pt_off.data(), sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice, st));
+        DCS_HIP(hipMemcpyAsync(d_pt_edges, r.pt_edges.data(), sizeof(int32_t) * r.pt_edges.size(), hipMemcpyHostToDevice, st));
+        DCS_HIP(hipMemcpyAsync(d_ps_off, r.ps_off.data(), sizeof(int32_t) * (r.np + 1), hipMemcpyHostToDevice, st));
+        if (!r.ps_edges.empty()) DCS_HIP(hipMemcpyAsync(d_ps_edges, r.ps_edges.data(), sizeof(int32_t) * r.ps_edges.size(), hipMemcpyHostToDevice, st));
+        if (r.n_pairs) {
+            DCS_HIP(hipMemcpyAsync(d_pair_ij, r.pair_ij.data(), sizeof(int32_t) * r.pair_ij.size(), hipMemcpyHostToDevice, st));
+            DCS_HIP(hipMemcpyAsync(d_pair_off, r.pair_off.data(), sizeof(int32_t) * r.pair_off.size(), hipMemcpyHostToDevice, st));
+            if (!r.pair_e1.empty()) {
+                DCS_HIP(hipMemcpyAsync(d_pair_e1, r.pair_e1.data(), sizeof(int32_t) * r.pair_e1.size(), hipMemcpyHostToDevice, st));
+                DCS_HIP(hipMemcpyAsync(d_pair_e2, r.pair_e2.data(), sizeof(int32_t) * r.pair_e2.size(), hipMemcpyHostToDevice, st));
+            }
+        }
+        DCS_HIP(hipStreamSynchronize(st));              // host vectors go out of scope with the round
+        const int n = r.n, n_pad = r.n_pad, ld = std::max(n_pad, kNB);
+        double lambda = 0, ni = 2, currentChi = 0;
+        int nBad = 0;
+        bool errors_current = false;
+        for (int it = 0; it < iters && !stopped(); ++it) {
+            int rc2;
+            if (!errors_current) {
+                if ((rc2 = eval_error(robust, d_scal))) return rc2;
+                DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 8, hipMemcpyDeviceToHost, st));
+                DCS_HIP(hipStreamSynchronize(st));
+                currentChi = h_scal[0];
+            }
+            const double iniChi = currentChi;
+            // buildSystem
+            hipLaunchKernelGGL(k_linearize, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2,
+                               d_pose_idx, d_cpoint, d_cpose, d_Hpl);
+            DCS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(k_reduce_point, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_cpoint, d_Hll, d_bl);
+            DCS_CHECK_LAUNCH();
+            if (r.np) { hipLaunchKernelGGL(k_reduce_pose, dim3(r.np), dim3(64), 0, st, d_ps_off, d_ps_edges, d_cpose, d_Hpp, d_bp); DCS_CHECK_LAUNCH(); }
+            if (it == 0) {
+                hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, r.np, d_Hpp, L, d_pt_off, d_Hll, d_scal + 2);
+                DCS_CHECK_LAUNCH();
+                DCS_HIP(hipMemcpyAsync(h_scal + 2, d_scal + 2, 8, hipMemcpyDeviceToHost, st));
+                DCS_HIP(hipStreamSynchronize(st));
+                lambda = 1e-5 * h_scal[2]; ni = 2; nBad = 0;        // computeLambdaInit, tau = 1e-5
+            }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                // setLambda + solve (Schur)
+                hipLaunchKernelGGL(k_point_prep, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx,
+                                   d_Hll, d_bl, lambda, d_Hpl, d_Dinv, d_db, d_BD);
+                DCS_CHECK_LAUNCH();
+                *h_ok = 1;
+                DCS_HIP(hipMemcpyAsync(d_ok, h_ok, sizeof(int), hipMemcpyHostToDevice, st));
+                if (r.np) {
+                    DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));
+                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs), dim3(64), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp, lambda,
+                                       d_BD, d_Hpl, d_S, ld);
+                    DCS_CHECK_LAUNCH();
+                    if (n_pad > n) { hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(64), 0, st, d_S, ld, n, n_pad); DCS_CHECK_LAUNCH(); }
+                    hipLaunchKernelGGL(k_bschur, dim3(r.np), dim3(64), 0, st, d_ps_off, d_ps_edges, d_epoint, d_Hpl, d_db, d_bp, d_bsch);
+                    DCS_CHECK_LAUNCH();
+                    for (int k0 = 0; k0 < n_pad; k0 += kNB) {
+                        hipLaunchKernelGGL(k_ldlt_panel, dim3(1), dim3(256), 0, st, d_S, ld, n_pad, k0, d_W, d_ok);
+                        DCS_CHECK_LAUNCH();
+                        const int m = (n_pad - k0) / kNB - 1;
+                        if (m > 0) { hipLaunchKernelGGL(k_ldlt_update, dim3(m, m), dim3(64), 0, st, d_S, ld, k0, d_W); DCS_CHECK_LAUNCH(); }
+                    }
+                    hipLaunchKernelGGL(k_ldlt_solve, dim3(1), dim3(256), sizeof(double) * n_pad, st, d_S, ld, n_pad, d_bsch, n, d_xp);
+                    DCS_CHECK_LAUNCH();
+                }
+                hipLaunchKernelGGL(k_back_subst, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx, d_Hpl,
+                                   d_xp, d_bl, d_Dinv, d_xl);
+                DCS_CHECK_LAUNCH();
+                hipLaunchKernelGGL(k_update, dim3((P + L + 255) / 256), dim3(256), 0, st, P, L, d_pose_idx, d_xp, d_xl, d_poses, d_points,
+                                   d_poses_bk, d_points_bk);
+                DCS_CHECK_LAUNCH();
+                int rc2;
+                if ((rc2 = eval_error(robust, d_scal))) return rc2;
+                hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, st, n, d_xp, d_bp, L, d_pt_off, d_xl, d_bl, lambda, d_scal + 1);
+                DCS_CHECK_LAUNCH();
+                DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 16, hipMemcpyDeviceToHost, st));
+                DCS_HIP(hipMemcpyAsync(h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, st));
+                DCS_HIP(hipStreamSynchronize(st));
+                ++res->n_trials[round];
+                double tempChi = h_scal[0];
+                if (!*h_ok) tempChi = std::numeric_limits<double>::max();
+                rho = currentChi - tempChi;
+                const double scale = h_scal[1] + 1e-3;
+                rho /= scale;
+                if (rho > 0 && std::isfinite(tempChi)) {
+                    double alpha = 1. - std::pow((2 * rho - 1), 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    lambda *= std::max(1. / 3., alpha);
+                    ni = 2; currentChi = tempChi; errors_current = true;
+                } else {
+                    lambda *= ni; ni *= 2;
+                    DCS_HIP(hipMemcpyAsync(d_poses, d_poses_bk, sizeof(double) * 7 * P, hipMemcpyDeviceToDevice, st));   // pop
+                    DCS_HIP(hipMemcpyAsync(d_points, d_points_bk, sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, st));
+                    errors_current = false;
+                }
+                ++qmax;
+            } while (rho < 0 && qmax < 10 && !stopped());
+            ++res->n_iters[round];
+            if (trace < 32) res->chi2_trace[trace++] = currentChi;
+            res->lambda[round] = lambda;
+            if (qmax == 10 || rho == 0) break;                         // Terminate
+            if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
+            if (nBad >= 3) break;
+        }
+        res->lambda[round] = lambda;
+        return DCS_OK;
+    };
+
+    if (!stopped()) {
+        if ((rc = run_round(0, pb->iters1, 1))) return rc;
+        if (!stopped()) {
+            hipLaunchKernelGGL(k_flags, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, d_chi2, pb->chi2_th, d_flag);
+            DCS_CHECK_LAUNCH();
+            DCS_HIP(hipMemcpyAsync(level1.data(), d_flag, E, hipMemcpyDeviceToHost, st));
+            DCS_HIP(hipStreamSynchronize(st));
+            for (int e = 0; e < E; ++e) active[e] = !level1[e];
+            if ((rc = run_round(1, pb->iters2, 0))) return rc;
+        }
+    }
+    hipLaunchKernelGGL(k_flags, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, d_chi2, pb->chi2_th, d_flag);
+    DCS_CHECK_LAUNCH();
+    DCS_HIP(hipMemcpyAsync(res->edge_outlier, d_flag, E, hipMemcpyDeviceToHost, st));
+    DCS_HIP(hipMemcpyAsync(res->poses, d_poses, sizeof(double) * 7 * P, hipMemcpyDeviceToHost, st));
+    DCS_HIP(hipMemcpyAsync(res->points, d_points, sizeof(double) * 3 * L, hipMemcpyDeviceToHost, st));
+    if (res->edge_chi2) DCS_HIP(hipMemcpyAsync(res->edge_chi2, d_chi2, sizeof(double) * E, hipMemcpyDeviceToHost, st));
+    DCS_HIP(hipStreamSynchronize(st));
+    if (res->edge_level1) memcpy(res->edge_level1, level1.data(), E);
+    res->gpu_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_opt0).count();
+    return DCS_OK;
+}
+
+int dcs_rig_adjoint(const float T[16], int exact, double ext7[7], double adj[36])
+{
+    if (!T || !ext7 || !adj) { set_error("null argument"); return DCS_ERR_INVALID; }
+    double R[9], t[3], q[4];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = T[i * 4 + j]; t[i] = T[i * 4 + 3]; }
+    qfromR(R, q); qnormalize(q);
+    ext7[0] = t[0]; ext7[1] = t[1]; ext7[2] = t[2]; ext7[3] = q[0]; ext7[4] = q[1]; ext7[5] = q[2]; ext7[6] = q[3];
+    for (int i = 0; i < 36; ++i) adj[i] = 0;
+    if (!exact) {                                      // Cameras::setExtrinsics: float [[R, R t^],[?, R]], LL := 0
+        const float th[9] = {0, -T[11], T[7], T[11], 0, -T[3], -T[7], T[3], 0};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            float acc = 0;
+            for (int k = 0; k < 3; ++k) acc += T[i * 4 + k] * th[k * 3 + j];
+            adj[i * 6 + j] = T[i * 4 + j]; adj[(i + 3) * 6 + j + 3] = T[i * 4 + j]; adj[i * 6 + j + 3] = acc;
+        }
+    } else {                                           // g2o SE3Quat::adj(): [[R, 0],[t^ R, R]]
+        double Rn[9]; qtoR(q, Rn);
+        const double th[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            adj[i * 6 + j] = Rn[i * 3 + j]; adj[(i + 3) * 6 + j + 3] = Rn[i * 3 + j];
+            adj[(i + 3) * 6 + j] = th[i * 3] * Rn[j] + th[i * 3 + 1] * Rn[3 + j] + th[i * 3 + 2] * Rn[6 + j];
+        }
+    }
+    return DCS_OK;
+}
+
+int dcs_pose_from_matrix(const float T[16], double p[7])      // Converter::toSE3Quat (Converter.cc:58-68)
+{
+    if (!T || !p) { set_error("null argument"); return DCS_ERR_INVALID; }
+    double R[9], q[4];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = T[i * 4 + j]; p[i] = T[i * 4 + 3]; }
+    qfromR(R, q); qnormalize(q);
+    p[3] = q[0]; p[4] = q[1]; p[5] = q[2]; p[6] = q[3];
+    return DCS_OK;
+}
+
+int dcs_pose_to_matrix(const double p[7], float T[16])        // Converter::toCvMat(SE3Quat) (Converter.cc:70-74)
+{
+    if (!T || !p) { set_error("null argument"); return DCS_ERR_INVALID; }
+    double R[9];
+    qtoR(p + 3, R);
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T[i * 4 + j] = (float)R[i * 3 + j]; T[i * 4 + 3] = (float)p[i]; }
+    T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+    return DCS_OK;
+}
+
+}  // extern "C"

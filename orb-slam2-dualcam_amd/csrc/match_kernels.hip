@@ -13,6 +13,7 @@
 // partial results merge exactly into what the reference's sequential loop produces.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -215,6 +216,104 @@ __global__ __launch_bounds__(256) void k_filter_pairs(const dcs_keypoint* __rest
                    &kp[(size_t)ts * cap].angle, 7, match + o, n_matches + p);
 }
 
+
+// ---- faithful SearchByBoWCrossCam (ORBmatcher.cc:162-294): one wave per shared vocabulary node. The
+// reference is sequential over the KF features of a node because a query skips F features already
+// claimed by an earlier query (:216); nodes are independent (every F feature lives in exactly one node),
+// so the wave walks the node's queries in order and spreads each query's candidates over its lanes.
+constexpr int kBowMaxCand = 4096;       // F features per node held as "claimed" bits in LDS
+
+__device__ __forceinline__ Best wave_merge(Best s)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Best o;
+        o.b1 = __shfl_xor(s.b1, d); o.idx = __shfl_xor(s.idx, d); o.b2 = __shfl_xor(s.b2, d);
+        s = best_merge(s, o);
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(64) void k_search_bow(const uint8_t* __restrict__ desc_kf, const float* __restrict__ ang_kf,
+                                                   const uint8_t* __restrict__ kf_valid, const uint8_t* __restrict__ desc_f,
+                                                   const float* __restrict__ ang_f, const int32_t* __restrict__ node_pairs,
+                                                   const int32_t* __restrict__ kf_off, const int32_t* __restrict__ kf_idx,
+                                                   const int32_t* __restrict__ f_off, const int32_t* __restrict__ f_idx, float ratio,
+                                                   int check_ori, int32_t* __restrict__ match_f, int32_t* __restrict__ bin_f,
+                                                   int32_t* __restrict__ hist, int32_t* __restrict__ overflow)
+{
+    __shared__ uint32_t s_claimed[kBowMaxCand / 32];
+    const int a = node_pairs[2 * blockIdx.x], b = node_pairs[2 * blockIdx.x + 1], lane = threadIdx.x;
+    const int qb = kf_off[a], qe = kf_off[a + 1], cb = f_off[b], ce = f_off[b + 1];
+    if (ce - cb > kBowMaxCand) { if (lane == 0) *overflow = 1; return; }
+    for (int i = lane; i < kBowMaxCand / 32; i += 64) s_claimed[i] = 0;
+    __syncthreads();
+    for (int qa = qb; qa < qe; ++qa) {
+        const int ikf = kf_idx[qa];
+        if (!kf_valid[ikf]) continue;                                      // wave-uniform
+        const unsigned long long* qp = reinterpret_cast<const unsigned long long*>(desc_kf + (size_t)ikf * 32);
+        const unsigned long long q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+        Best st{256, -1, 256};                                             // idx = position in the node's candidate list
+        for (int c = cb + lane; c < ce; c += 64) {
+            const int pos = c - cb;
+            if (s_claimed[pos >> 5] & (1u << (pos & 31))) continue;
+            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(desc_f + (size_t)f_idx[c] * 32);
+            const int dist = __popcll(q0 ^ w[0]) + __popcll(q1 ^ w[1]) + __popcll(q2 ^ w[2]) + __popcll(q3 ^ w[3]);
+            best_update(st, dist, pos);
+        }
+        st = wave_merge(st);                                               // first position of the minimum wins, like the loop
+        if (st.b1 <= 50 && (float)st.b1 < __fmul_rn(ratio, (float)st.b2)) {
+            if (lane == 0) {
+                const int jf = f_idx[cb + st.idx];
+                s_claimed[st.idx >> 5] |= 1u << (st.idx & 31);
+                match_f[jf] = ikf;
+                if (check_ori) { const int bn = rot_bin(ang_kf[ikf], ang_f[jf]); bin_f[jf] = bn; atomicAdd(&hist[bn], 1); }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ComputeThreeMaxima + removal of matches outside the three dominant rotation bins (:272-290); single block
+__global__ __launch_bounds__(256) void k_bow_finish(int n_f, int check_ori, const int32_t* __restrict__ hist, const int32_t* __restrict__ bin_f,
+                                                    int32_t* __restrict__ match_f, int32_t* __restrict__ n_matches)
+{
+    __shared__ int s_ind[3];
+    __shared__ int s_count;
+    if (threadIdx.x == 0) {
+        s_count = 0;
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < 30; ++i) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+    }
+    __syncthreads();
+    int local = 0;
+    for (int j = threadIdx.x; j < n_f; j += 256) {
+        int m = match_f[j];
+        if (m >= 0 && check_ori) {
+            const int b = bin_f[j];
+            if (b != s_ind[0] && b != s_ind[1] && b != s_ind[2]) { m = -1; match_f[j] = -1; }
+        }
+        local += m >= 0;
+    }
+    atomicAdd(&s_count, local);
+    __syncthreads();
+    if (threadIdx.x == 0) *n_matches = s_count;
+}
+
+__global__ void k_fill_i32(int32_t* p, int n, int32_t v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 }  // namespace dcs
 
 using namespace dcs;
@@ -364,6 +463,55 @@ int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, c
     hipLaunchKernelGGL(k_filter_pairs, dim3(n_pairs), dim3(256), 0, s, d_kp, d_n, cap, d_pairs, d_match, d_best_d, d_second_d, th,
                        ratio, check_ori, d_match, d_n_matches);
     DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+
+int dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_t* kf_valid, int n_kf, const uint8_t* desc_f,
+                      const float* ang_f, int n_f, const int32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx,
+                      int kf_n_nodes, const int32_t* f_nodes, const int32_t* f_off, const int32_t* f_idx, int f_n_nodes, float ratio,
+                      int check_ori, int32_t* match_f, int* n_matches)
+{
+    if (n_kf < 0 || n_f < 0 || kf_n_nodes < 0 || f_n_nodes < 0 || !n_matches || (n_f && (!match_f || !desc_f)) || (n_kf && (!desc_kf || !kf_valid)) ||
+        (kf_n_nodes && (!kf_nodes || !kf_off || !kf_idx)) || (f_n_nodes && (!f_nodes || !f_off || !f_idx)) || (check_ori && ((n_kf && !ang_kf) || (n_f && !ang_f)))) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    *n_matches = 0;
+    for (int j = 0; j < n_f; ++j) match_f[j] = -1;
+    // merge-join of the two sorted node lists (:189-269), on the host: O(nodes)
+    std::vector<int32_t> np;
+    for (int a = 0, b = 0; a < kf_n_nodes && b < f_n_nodes;) {
+        if (kf_nodes[a] == f_nodes[b]) { np.push_back(a); np.push_back(b); ++a; ++b; }
+        else if (kf_nodes[a] < f_nodes[b]) a = (int)(std::lower_bound(kf_nodes, kf_nodes + kf_n_nodes, f_nodes[b]) - kf_nodes);
+        else b = (int)(std::lower_bound(f_nodes, f_nodes + f_n_nodes, kf_nodes[a]) - f_nodes);
+    }
+    const int n_shared = (int)np.size() / 2;
+    if (n_shared == 0 || n_f == 0 || n_kf == 0) return DCS_OK;
+    Scratch s;
+    uint8_t *dkf, *df, *dval;
+    float *akf = nullptr, *af = nullptr;
+    int32_t *dnp, *dko, *dki, *dfo, *dfi, *dm, *dbin, *dhist, *dn;
+    if ((rc = s.upload(&dkf, desc_kf, (size_t)n_kf * 32)) || (rc = s.upload(&df, desc_f, (size_t)n_f * 32)) || (rc = s.upload(&dval, kf_valid, (size_t)n_kf))) return rc;
+    if (check_ori && ((rc = s.upload(&akf, ang_kf, n_kf)) || (rc = s.upload(&af, ang_f, n_f)))) return rc;
+    if ((rc = s.upload(&dnp, np.data(), np.size())) || (rc = s.upload(&dko, kf_off, (size_t)kf_n_nodes + 1)) || (rc = s.upload(&dki, kf_idx, (size_t)kf_off[kf_n_nodes])) ||
+        (rc = s.upload(&dfo, f_off, (size_t)f_n_nodes + 1)) || (rc = s.upload(&dfi, f_idx, (size_t)f_off[f_n_nodes]))) return rc;
+    if ((rc = s.alloc(&dm, n_f)) || (rc = s.alloc(&dbin, n_f)) || (rc = s.alloc(&dhist, 32)) || (rc = s.alloc(&dn, 2))) return rc;
+    hipLaunchKernelGGL(k_fill_i32, dim3((n_f + 255) / 256), dim3(256), 0, 0, dm, n_f, -1);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, 0, dhist, 32, 0);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, 0, dn, 2, 0);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_search_bow, dim3(n_shared), dim3(64), 0, 0, dkf, akf, dval, df, af, dnp, dko, dki, dfo, dfi, ratio, check_ori, dm, dbin,
+                       dhist, dn + 1);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, 0, n_f, check_ori, dhist, dbin, dm, dn);
+    DCS_CHECK_LAUNCH();
+    int32_t h[2] = {0, 0};
+    DCS_HIP(hipMemcpy(h, dn, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[1]) { set_error("a vocabulary node holds more than %d frame features", kBowMaxCand); return DCS_ERR_UNSUPPORTED; }
+    DCS_HIP(hipMemcpy(match_f, dm, sizeof(int32_t) * n_f, hipMemcpyDeviceToHost));
+    *n_matches = h[0];
     return DCS_OK;
 }
 

@@ -112,7 +112,7 @@ struct dcs_orb {
     PinnedBuf<uint8_t> h_img;
 
     hipStream_t s_main = nullptr, s_aux = nullptr;
-    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr},
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
                ev_b[2] = {nullptr, nullptr};
     float host_us = 0;
     bool timing_valid = false;
@@ -263,11 +263,12 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
 
     if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
                                 d_cell_count.p, stream))) return rc;
+    DCS_HIP(hipEventRecord(ev_t[2], stream));
     if ((rc = launch_compact(d_cells.p, d_level_cell_begin.p, L, n_images, n_cells, d_slots.p, g.n_slots, d_cell_count.p,
                              d_cell_off.p, d_lvl_total.p, d_lvl_off.p, d_dense.p, dense_cap, stream))) return rc;
     const int n_tasks = n_images * L;
+    DCS_HIP(hipEventRecord(ev_t[3], stream));
     DCS_HIP(hipMemcpyAsync(h_lvl_off.p, d_lvl_off.p, sizeof(int32_t) * (n_tasks + 1), hipMemcpyDeviceToHost, stream));
-    DCS_HIP(hipEventRecord(ev_t[2], stream));
     DCS_HIP(hipStreamSynchronize(stream));
     const size_t total = (size_t)h_lvl_off.p[n_tasks];
     if (total > dense_cap) { set_error("FAST candidates (%zu) exceed the dense buffer (%zu)", total, dense_cap); return DCS_ERR_CAPACITY; }
@@ -312,13 +313,13 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     if (n_sel) DCS_HIP(hipMemcpyAsync(d_sel.p, h_sel.p, sizeof(SelKp) * n_sel, hipMemcpyHostToDevice, stream));
     DCS_HIP(hipMemcpyAsync(d_img_off.p, h_img_off.p, sizeof(int32_t) * (n_images + 1), hipMemcpyHostToDevice, stream));
     DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
-    DCS_HIP(hipEventRecord(ev_t[3], stream));
+    DCS_HIP(hipEventRecord(ev_t[4], stream));
     DescribeParams dp{};
     for (int l = 0; l < L; ++l) { dp.scale[l] = t.scale[l]; dp.scaled_patch[l] = g.lv[l].scaled_patch; }
     for (int v = 0; v <= kHalfPatch; ++v) dp.umax[v] = t.umax[v];
     if ((rc = launch_describe(raw, blur, dp, d_sel.p, d_img_off.p, n_images, max_per_image, d_kp_out, d_desc_out, cap,
                               d_n_out, stream))) return rc;
-    DCS_HIP(hipEventRecord(ev_t[4], stream));
+    DCS_HIP(hipEventRecord(ev_t[5], stream));
     timing_valid = true;
     return DCS_OK;
 }
@@ -470,18 +471,19 @@ int dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* ds
     return DCS_OK;
 }
 
-int dcs_orb_last_timing(const dcs_orb* h, float* us6)
+int dcs_orb_last_timing(const dcs_orb* h, float* us7)
 {
-    if (!h || !us6 || !h->timing_valid) { set_error("no timing available"); return DCS_ERR_INVALID; }
-    DCS_HIP(hipEventSynchronize(h->ev_t[4]));
+    if (!h || !us7 || !h->timing_valid) { set_error("no timing available"); return DCS_ERR_INVALID; }
+    DCS_HIP(hipEventSynchronize(h->ev_t[5]));
     DCS_HIP(hipEventSynchronize(h->ev_b[1]));
     float ms;
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[0], h->ev_t[1])); us6[0] = ms * 1000.f;
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[1], h->ev_t[2])); us6[1] = ms * 1000.f;
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_b[0], h->ev_b[1])); us6[2] = ms * 1000.f;
-    us6[3] = h->host_us;
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[3], h->ev_t[4])); us6[4] = ms * 1000.f;
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[0], h->ev_t[4])); us6[5] = ms * 1000.f;
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[0], h->ev_t[1])); us7[0] = ms * 1000.f;   // resize chain
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[1], h->ev_t[2])); us7[1] = ms * 1000.f;   // k_fast_cells
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[2], h->ev_t[3])); us7[2] = ms * 1000.f;   // scan + gather
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_b[0], h->ev_b[1])); us7[3] = ms * 1000.f;   // k_blur (aux stream)
+    us7[4] = h->host_us;                                                               // host quadtree
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[4], h->ev_t[5])); us7[5] = ms * 1000.f;   // k_describe
+    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[0], h->ev_t[5])); us7[6] = ms * 1000.f;   // whole call on the main stream
     return DCS_OK;
 }
 
