@@ -1,0 +1,67 @@
+// ORBmatcher.h -- header-only C++ mirror of the numeric core of ORB_SLAM2::ORBmatcher (reference
+// include/ORBmatcher.h:45-309, src/ORBmatcher.cc) over the C ABI. The 14 Search*/Fuse members of the
+// reference differ in how they pick candidates (BoW node, grid window); what they share -- and what runs on
+// the GPU -- is the Hamming best/second-best loop, the TH_LOW/TH_HIGH + ratio accept test and the rotation
+// histogram. Stateless and re-entrant like the reference's stack-constructed matcher.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "dcs_abi.h"
+
+namespace ORB_SLAM2 {
+
+// flat DBoW2::FeatureVector (Thirdparty/DBoW2/DBoW2/FeatureVector.h:23-24): ascending node ids + CSR of local feature indices
+struct FeatureVectorCSR { std::vector<int32_t> nodes, off, idx; };
+
+class ORBmatcher {
+public:
+    static const int TH_LOW = DCS_TH_LOW, TH_HIGH = DCS_TH_HIGH, HISTO_LENGTH = DCS_HISTO_LENGTH;
+
+    ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    // SearchByBoWCrossCam(F, cF, KF, cKF, vpMapPointMatches) (ORBmatcher.cc:162-294) on flat per-camera arrays:
+    // kfValid[i] = "KF feature i has a good MapPoint"; matchF[j] = matched KF feature or -1. Returns nmatches.
+    int SearchByBoWCrossCam(const std::vector<uint8_t>& descF, const std::vector<float>& angF, const FeatureVectorCSR& fvF,
+                            const std::vector<uint8_t>& descKF, const std::vector<float>& angKF, const std::vector<uint8_t>& kfValid,
+                            const FeatureVectorCSR& fvKF, std::vector<int32_t>& matchF) const
+    {
+        const int nF = (int)angF.size(), nKF = (int)angKF.size();
+        matchF.assign(nF, -1);
+        int n = 0;
+        check(dcs_search_by_bow(descKF.data(), angKF.data(), kfValid.data(), nKF, descF.data(), angF.data(), nF,
+                                fvKF.nodes.data(), fvKF.off.data(), fvKF.idx.data(), (int)fvKF.nodes.size(),
+                                fvF.nodes.data(), fvF.off.data(), fvF.idx.data(), (int)fvF.nodes.size(),
+                                mfNNratio, mbCheckOrientation, matchF.data(), &n), "dcs_search_by_bow");
+        return n;
+    }
+
+    // brute-force "Hamming BF + ratio test across the two camera streams": knn2 + TH + ratio + rotation histogram
+    int MatchBruteForce(const std::vector<uint8_t>& descQ, const std::vector<dcs_keypoint>& kpQ, const std::vector<uint8_t>& descT,
+                        const std::vector<dcs_keypoint>& kpT, std::vector<int32_t>& match, int th = TH_LOW) const
+    {
+        match.assign(kpQ.size(), -1);
+        int n = 0;
+        check(dcs_match_bf(descQ.data(), kpQ.data(), (int)kpQ.size(), descT.data(), kpT.data(), (int)kpT.size(), th, mfNNratio,
+                           mbCheckOrientation, match.data(), &n), "dcs_match_bf");
+        return n;
+    }
+
+    // best / second-best distances of every query (the loop at ORBmatcher.cc:208-231 over all candidates)
+    static void Knn2(const std::vector<uint8_t>& q, const std::vector<uint8_t>& t, std::vector<int32_t>& bestIdx,
+                     std::vector<int32_t>& bestDist, std::vector<int32_t>& secondDist)
+    {
+        const int nq = (int)q.size() / 32, nt = (int)t.size() / 32;
+        bestIdx.assign(nq, -1); bestDist.assign(nq, 256); secondDist.assign(nq, 256);
+        check(dcs_hamming_knn2(q.data(), nq, t.data(), nt, nullptr, bestIdx.data(), bestDist.data(), secondDist.data()), "dcs_hamming_knn2");
+    }
+
+protected:
+    static void check(int rc, const char* what) { if (rc != DCS_OK) throw std::runtime_error(std::string(what) + ": " + dcs_last_error()); }
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+}  // namespace ORB_SLAM2

@@ -1,0 +1,54 @@
+// Optimizer.h -- header-only C++ mirror of Optimizer::LocalBundleAdjustment (reference include/Optimizer.h:55,
+// src/Optimizer.cc:407-696) over the C ABI. The reference gathers KeyFrames / MapPoints into a g2o graph
+// (:409-580), optimises (:586-621) and writes back (:641-693); the gather and write-back stay with the caller
+// (they walk the SLAM data model under its mutexes), the numerics run on the GPU from a flat problem.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "dcs_abi.h"
+
+namespace ORB_SLAM2 {
+
+struct LocalBAProblem {
+    std::vector<double> poses;        // [P][7] from dcs_pose_from_matrix(KF->GetPose()), ascending mnId
+    std::vector<uint8_t> poseFixed;   // mnId == fixId, or member of lFixedCameras (:483, :496)
+    std::vector<double> points;       // [L][3] MapPoint::GetWorldPos
+    std::vector<int32_t> edgePose, edgePoint, edgeCam;   // keypointToCam[idx] (:541)
+    std::vector<double> obs;          // [E][2] mvTotalKeysUn[idx].pt
+    std::vector<double> invSigma2;    // [E] mvInvLevelSigma2[octave]
+    std::vector<dcs_ba_camera> cams;  // per camera: mvfx.., dcs_rig_adjoint(getExtrinsici(c))
+};
+
+struct LocalBAResult {
+    std::vector<double> poses, points;
+    std::vector<uint8_t> edgeOutlier;  // -> vToErase (:653-657)
+    int iterations[2];
+};
+
+class Optimizer {
+public:
+    // pbStopFlag as in the reference (:471-472, :582-593); thHuber = sqrt(5.991), chi2 gate 5.991, 5 + 10 iterations
+    static void LocalBundleAdjustment(const LocalBAProblem& in, bool* pbStopFlag, LocalBAResult& out)
+    {
+        dcs_ba_problem p{};
+        p.n_poses = (int)in.poseFixed.size(); p.n_points = (int)in.points.size() / 3; p.n_edges = (int)in.edgePose.size();
+        p.n_cams = (int)in.cams.size();
+        p.poses = in.poses.data(); p.pose_fixed = in.poseFixed.data(); p.points = in.points.data();
+        p.edge_pose = in.edgePose.data(); p.edge_point = in.edgePoint.data(); p.edge_cam = in.edgeCam.data();
+        p.obs = in.obs.data(); p.inv_sigma2 = in.invSigma2.data(); p.cams = in.cams.data();
+        p.huber_delta = (double)(float)2.447651936;   // const float thHuberMono = sqrt(5.991) (:515)
+        p.chi2_th = 5.991; p.iters1 = 5; p.iters2 = 10;
+        out.poses.resize(in.poses.size()); out.points.resize(in.points.size()); out.edgeOutlier.resize(p.n_edges);
+        dcs_ba_result r{};
+        r.poses = out.poses.data(); r.points = out.points.data(); r.edge_outlier = out.edgeOutlier.data();
+        static_assert(sizeof(bool) == 1, "stop flag is polled as a byte");
+        const int rc = dcs_ba_local(&p, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), &r);
+        if (rc != DCS_OK) throw std::runtime_error(std::string("dcs_ba_local: ") + dcs_last_error());
+        out.iterations[0] = r.n_iters[0]; out.iterations[1] = r.n_iters[1];
+    }
+};
+
+}  // namespace ORB_SLAM2
