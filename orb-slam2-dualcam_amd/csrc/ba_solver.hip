@@ -20,7 +20,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <numeric>
 #include <vector>
 
@@ -151,12 +153,14 @@ struct EdgeArrays {
     const uint8_t* active;                  // [E]
 };
 
-// residuals (computeError), chi2, robust rho0; partial[blockIdx] = sum of rho0 over the block's active edges
+// residuals (computeError), chi2, robust rho0. Block partial sums go to partial[]; the last block to finish
+// (device-scope ticket) adds them in index order -> *chi_out, so the total is reproducible run to run.
 __global__ __launch_bounds__(256) void k_error(EdgeArrays ed, int E, const double* __restrict__ poses, const double* __restrict__ points,
                                                DCams cams, int robust, double delta, double* __restrict__ err, double* __restrict__ chi2,
-                                               double* __restrict__ partial)
+                                               double* __restrict__ partial, unsigned* __restrict__ ticket, double* __restrict__ chi_out)
 {
     __shared__ double s[256];
+    __shared__ bool last;
     const int e = blockIdx.x * 256 + threadIdx.x;
     double rho0 = 0;
     if (e < E && ed.active[e]) {
@@ -171,17 +175,21 @@ __global__ __launch_bounds__(256) void k_error(EdgeArrays ed, int E, const doubl
         if (robust && x2 > delta * delta) rho0 = 2 * sqrt(x2) * delta - delta * delta; else rho0 = x2;
     }
     const double t = block_sum_256(rho0, s);
-    if (threadIdx.x == 0) partial[blockIdx.x] = t;
-}
-
-// out[slot] = sum(partial[0..n)) in index order (single block)
-__global__ __launch_bounds__(256) void k_final_sum(const double* __restrict__ partial, int n, double* __restrict__ out)
-{
-    __shared__ double s[256];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (prev == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
     double v = 0;
-    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
-    const double t = block_sum_256(v, s);
-    if (threadIdx.x == 0) *out = t;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) v += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double tot = block_sum_256(v, s);
+    if (threadIdx.x == 0) { *chi_out = tot; __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // linearizeOplus + constructQuadraticForm, per edge. cpoint[e] = {Hll 00,01,02,11,12,22, bl0..2},
@@ -248,23 +256,27 @@ __global__ __launch_bounds__(256) void k_reduce_point(int L, const int32_t* __re
     bl[3 * l] = a[6]; bl[3 * l + 1] = a[7]; bl[3 * l + 2] = a[8];
 }
 
-// block (64 threads) per free pose: thread c < 27 sums component c over the pose's edges in CSR order
-__global__ __launch_bounds__(64) void k_reduce_pose(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
+// block (256 threads) per free pose: 9 edge chunks x 27 components, combined in chunk order (deterministic)
+__global__ __launch_bounds__(256) void k_reduce_pose(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
                                                     const double* __restrict__ cpose, double* __restrict__ Hpp, double* __restrict__ bp)
 {
+    __shared__ double part[9][27];
     __shared__ double s[27];
-    const int i = blockIdx.x, c = threadIdx.x;
-    if (c < 27) {
+    const int i = blockIdx.x, t = threadIdx.x;
+    const int c = t % 27, q = t / 27;
+    if (q < 9) {
         double a = 0;
-        for (int k = ps_off[i]; k < ps_off[i + 1]; ++k) a += cpose[(size_t)ps_edges[k] * 27 + c];
-        s[c] = a;
+        for (int k = ps_off[i] + q; k < ps_off[i + 1]; k += 9) a += cpose[(size_t)ps_edges[k] * 27 + c];
+        part[q][c] = a;
     }
     __syncthreads();
-    if (c < 36) {
-        const int r = c / 6, q = c % 6, lo = min(r, q), hi = max(r, q);
-        Hpp[(size_t)i * 36 + c] = s[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+    if (t < 27) { double a = 0; for (int q2 = 0; q2 < 9; ++q2) a += part[q2][t]; s[t] = a; }
+    __syncthreads();
+    if (t < 36) {
+        const int r = t / 6, qq = t % 6, lo = min(r, qq), hi = max(r, qq);
+        Hpp[(size_t)i * 36 + t] = s[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
     }
-    if (c < 6) bp[i * 6 + c] = s[21 + c];
+    if (t < 6) bp[i * 6 + t] = s[21 + t];
 }
 
 // max |diagonal| over pose and landmark blocks (computeLambdaInit). single block.
@@ -289,9 +301,10 @@ __global__ __launch_bounds__(256) void k_point_prep(int L, const int32_t* __rest
                                                     const int32_t* __restrict__ e_pose, const int32_t* __restrict__ pose_idx,
                                                     const double* __restrict__ Hll, const double* __restrict__ bl, double lambda,
                                                     const double* __restrict__ Hpl, double* __restrict__ Dinv, double* __restrict__ db,
-                                                    double* __restrict__ BD)
+                                                    double* __restrict__ BD, double* __restrict__ ok)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l == 0) *ok = 1.0;                                   // reset the "factorisation succeeded" flag of this trial
     if (l >= L || pt_off[l + 1] == pt_off[l]) return;
     double H[9], D[9];
     for (int i = 0; i < 9; ++i) H[i] = Hll[(size_t)l * 9 + i];
@@ -308,48 +321,178 @@ __global__ __launch_bounds__(256) void k_point_prep(int L, const int32_t* __rest
     }
 }
 
-// one wave per pose pair (i1 <= i2): S block = [i1==i2](Hpp + lambda I) - sum over shared points BD[e1] Hpl[e2]^T
-__global__ __launch_bounds__(64) void k_schur(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_off,
-                                              const int32_t* __restrict__ pair_e1, const int32_t* __restrict__ pair_e2,
-                                              const double* __restrict__ Hpp, double lambda, const double* __restrict__ BD,
-                                              const double* __restrict__ Hpl, double* __restrict__ S, int ld)
+// workgroup per pose pair (i1 <= i2): S block = [i1==i2](Hpp + lambda I) - sum over shared points BD[e1] Hpl[e2]^T.
+// 7 list chunks x 36 block entries; chunk partials combined in fixed order.
+__global__ __launch_bounds__(256) void k_schur(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_off,
+                                               const int32_t* __restrict__ pair_e1, const int32_t* __restrict__ pair_e2,
+                                               const double* __restrict__ Hpp, double lambda, const double* __restrict__ BD,
+                                               const double* __restrict__ Hpl, double* __restrict__ S, int ld)
 {
+    __shared__ double part[7][36];
     const int p = blockIdx.x, t = threadIdx.x;
+    const int el = t % 36, q = t / 36;
+    const int r = el / 6, c = el % 6;
+    if (q < 7) {
+        double acc = 0;
+        for (int k = pair_off[p] + q; k < pair_off[p + 1]; k += 7) {
+            const double* a = BD + (size_t)pair_e1[k] * 18 + r * 3;
+            const double* b = Hpl + (size_t)pair_e2[k] * 18 + c * 3;
+            acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+        }
+        part[q][el] = acc;
+    }
+    __syncthreads();
     if (t >= 36) return;
     const int i1 = pair_ij[2 * p], i2 = pair_ij[2 * p + 1];
-    const int r = t / 6, c = t % 6;
     double acc = 0;
-    for (int k = pair_off[p]; k < pair_off[p + 1]; ++k) {
-        const double* a = BD + (size_t)pair_e1[k] * 18 + r * 3;
-        const double* b = Hpl + (size_t)pair_e2[k] * 18 + c * 3;
-        acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
-    }
+    for (int q2 = 0; q2 < 7; ++q2) acc += part[q2][t];
     double v = -acc;
     if (i1 == i2) v += Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
     S[(size_t)(i1 * 6 + r) * ld + i2 * 6 + c] = v;
     if (i1 != i2) S[(size_t)(i2 * 6 + c) * ld + i1 * 6 + r] = v;
 }
 
-// block (64 threads) per free pose: bsch = bp - sum_e Hpl[e] db[point(e)]
-__global__ __launch_bounds__(64) void k_bschur(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
-                                               const int32_t* __restrict__ e_point, const double* __restrict__ Hpl,
-                                               const double* __restrict__ db, const double* __restrict__ bp, double* __restrict__ bsch)
+// workgroup per free pose: bsch = bp - sum_e Hpl[e] db[point(e)]; 42 edge chunks x 6 rows
+__global__ __launch_bounds__(256) void k_bschur(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
+                                                const int32_t* __restrict__ e_point, const double* __restrict__ Hpl,
+                                                const double* __restrict__ db, const double* __restrict__ bp, double* __restrict__ bsch)
 {
-    const int i = blockIdx.x, r = threadIdx.x;
-    if (r >= 6) return;
-    double a = 0;
-    for (int k = ps_off[i]; k < ps_off[i + 1]; ++k) {
-        const int e = ps_edges[k];
-        const double* B = Hpl + (size_t)e * 18 + r * 3;
-        const double* d = db + 3 * e_point[e];
-        a += B[0] * d[0] + B[1] * d[1] + B[2] * d[2];
+    __shared__ double part[42][6];
+    const int i = blockIdx.x, t = threadIdx.x;
+    const int r = t % 6, q = t / 6;
+    if (q < 42) {
+        double a = 0;
+        for (int k = ps_off[i] + q; k < ps_off[i + 1]; k += 42) {
+            const int e = ps_edges[k];
+            const double* B = Hpl + (size_t)e * 18 + r * 3;
+            const double* d = db + 3 * e_point[e];
+            a += B[0] * d[0] + B[1] * d[1] + B[2] * d[2];
+        }
+        part[q][r] = a;
     }
-    bsch[i * 6 + r] = bp[i * 6 + r] - a;
+    __syncthreads();
+    if (t < 6) { double a = 0; for (int q2 = 0; q2 < 42; ++q2) a += part[q2][t]; bsch[i * 6 + t] = bp[i * 6 + t] - a; }
+}
+
+// ---- register-resident LDL^T + solve (n_pad <= 256): the whole lower triangle lives in the VGPRs of ONE workgroup.
+// 1024 threads as a 32x32 grid; thread (ti, tj) owns A[32 bi + ti][32 bj + tj] for bj <= bi < 8 (36 doubles = 72 of its
+// 128 VGPRs; 16 waves x 128 VGPRs = the CU's whole 512 KB register file). Column k is broadcast through a double-buffered LDS
+// vector (one barrier per column), every thread applies the rank-1 update to its own elements, then the same
+// distribution does the forward / diagonal / backward substitutions. One launch replaces 2 * n/16 + 1.
+template <int NBLK>
+__global__ __launch_bounds__(1024) void k_ldlt_reg(const double* __restrict__ S, int ld, int n, const double* __restrict__ b,
+                                                   double* __restrict__ x, double* __restrict__ ok)
+{
+    constexpr int NS = NBLK * (NBLK + 1) / 2;
+#define SLOT(bi, bj) ((bi) * ((bi) + 1) / 2 + (bj))
+    __shared__ double col[2][NBLK * 32];
+    __shared__ double y[NBLK * 32];
+    __shared__ double Lkk[32][33];
+    __shared__ double part[16][NBLK * 32];
+    const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31, wave = tid >> 6, lane = tid & 63;
+    double a[NS];
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj) {
+            const int i = bi * 32 + ti, j = bj * 32 + tj;
+            a[SLOT(bi, bj)] = (i < n && j < n) ? S[(size_t)i * ld + j] : (i == j ? 1.0 : 0.0);
+        }
+    if (tid < NBLK * 32) y[tid] = tid < n ? b[tid] : 0.0;
+    bool good = true;
+    // Factorisation with the forward substitution L y = b fused in (b rides along as an extra column).
+    // kb (32-column block of the pivot) is a compile-time constant in every unrolled copy of the body, so all
+    // register-array indices are static; kt walks the columns of the block at run time. One barrier per column.
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+#pragma nounroll
+        for (int kt = 0; kt < 32; ++kt) {
+            const int k = kb * 32 + kt;
+            if (k >= n) break;
+            double* cb = col[k & 1];
+            if (tj == kt) {
+#pragma unroll
+                for (int bi = kb; bi < NBLK; ++bi) cb[bi * 32 + ti] = a[SLOT(bi, kb)];
+            }
+            __syncthreads();
+            const double d = cb[k];
+            if (d == 0.0 || !isfinite(d)) good = false;
+            const double invd = 1.0 / d;
+            double ci[NBLK], cj[NBLK];
+#pragma unroll
+            for (int bb = kb; bb < NBLK; ++bb) { ci[bb] = cb[bb * 32 + ti]; cj[bb] = cb[bb * 32 + tj] * invd; }
+            if (tj > kt) {                                // rest of the pivot's own column block
+                if (ti >= tj) a[SLOT(kb, kb)] -= ci[kb] * cj[kb];
+#pragma unroll
+                for (int bi = kb + 1; bi < NBLK; ++bi) a[SLOT(bi, kb)] -= ci[bi] * cj[kb];
+            }
+#pragma unroll
+            for (int bj = kb + 1; bj < NBLK; ++bj) {      // column blocks to the right: no column predicate needed
+                if (ti >= tj) a[SLOT(bj, bj)] -= ci[bj] * cj[bj];
+#pragma unroll
+                for (int bi = bj + 1; bi < NBLK; ++bi) a[SLOT(bi, bj)] -= ci[bi] * cj[bj];
+            }
+            if (tj == kt) {                               // column k becomes L[:,k]; apply it to y (rows below k)
+                const double yk = y[k];
+#pragma unroll
+                for (int bi = kb; bi < NBLK; ++bi) {
+                    if (bi * 32 + ti > k) { const double l = ci[bi] * invd; a[SLOT(bi, kb)] = l; y[bi * 32 + ti] -= l * yk; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (ti == tj) {
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) { const int i = bi * 32 + ti; if (i < n) y[i] /= a[SLOT(bi, bi)]; }
+    }
+    __syncthreads();
+    // Backward substitution L^T x = z, one 32-column block per round: diagonal triangle by a single wave in LDS,
+    // then the rows of this block are eliminated from all earlier blocks with a fixed-order reduction over the waves.
+    volatile double* yv = y;
+#pragma unroll
+    for (int kb = NBLK - 1; kb >= 0; --kb) {
+        if (kb * 32 >= n) continue;
+        Lkk[ti][tj] = a[SLOT(kb, kb)];
+        __syncthreads();
+        if (wave == 0) {
+            volatile double(*Lv)[33] = Lkk;
+            for (int kt = 31; kt >= 0; --kt) {
+                const int k = kb * 32 + kt;
+                if (k < n) {
+                    const double xk = yv[k];
+                    if (lane < kt) yv[kb * 32 + lane] -= Lv[kt][lane] * xk;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        if (kb > 0) {
+            const double xi = y[kb * 32 + ti];
+#pragma unroll
+            for (int bj = 0; bj < kb; ++bj) {
+                double pv = a[SLOT(kb, bj)] * xi;          // L[32 kb + ti][32 bj + tj] * x[32 kb + ti]
+                pv += __shfl_xor(pv, 32);                  // the wave's two rows
+                if (lane < 32) part[wave][bj * 32 + tj] = pv;
+            }
+            __syncthreads();
+            if (tid < kb * 32) {
+                double sacc = 0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) sacc += part[w][tid];
+                y[tid] -= sacc;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < n) x[tid] = y[tid];
+    if (!good && tid == 0) *ok = 0.0;
+#undef SLOT
 }
 
 // ---- blocked LDL^T of S (ld x ld, lower part used, n_pad multiple of 16) ----
 // panel step k0: factor the 16x16 diagonal block, then L rows below; W = L D kept for the trailing update
-__global__ __launch_bounds__(256) void k_ldlt_panel(double* __restrict__ S, int ld, int n_pad, int k0, double* __restrict__ W, int* __restrict__ ok)
+__global__ __launch_bounds__(256) void k_ldlt_panel(double* __restrict__ S, int ld, int n_pad, int k0, double* __restrict__ W, double* __restrict__ ok)
 {
     __shared__ double A[kNB][kNB + 1];
     __shared__ double d[kNB];
@@ -361,7 +504,7 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(double* __restrict__ S, int 
     __syncthreads();
     for (int j = 0; j < kNB; ++j) {                         // right-looking LDL^T, thread i = row i
         const double dj = A[j][j];
-        if (t == 0) { d[j] = dj; if (dj == 0.0 || !isfinite(dj)) *ok = 0; }
+        if (t == 0) { d[j] = dj; if (dj == 0.0 || !isfinite(dj)) *ok = 0.0; }
         double col_i = 0;
         if (t < kNB && t > j) col_i = A[t][j];
         __syncthreads();
@@ -674,11 +817,12 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     double* d_partial = ar.get<double>(nblk);
     double* d_scal = ar.get<double>(8);               // [0] chi2, [1] scale, [2] maxdiag
     int* d_ok = ar.get<int>(4);
-    if (!d_ok) { set_error("BA arena too small"); return DCS_ERR_HIP; }
+    unsigned* d_ticket = ar.get<unsigned>(4);
+    if (!d_ticket) { set_error("BA arena too small"); return DCS_ERR_HIP; }
     double* h_scal = nullptr;
     DCS_HIP(hipHostMalloc((void**)&h_scal, 64));
     struct HostFree { void* p; ~HostFree() { (void)hipHostFree(p); } } hf{h_scal};
-    int* h_ok = (int*)(h_scal + 4);
+    const bool force_blocked = getenv("DCS_BA_FORCE_BLOCKED_LDLT") != nullptr;   // test hook: exercise the MFMA fallback at small n
 
     hipStream_t st;
     DCS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -692,6 +836,7 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     DCS_HIP(hipMemcpyAsync(d_w, pb->inv_sigma2, sizeof(double) * E, hipMemcpyHostToDevice, st));
     DCS_HIP(hipMemsetAsync(d_chi2, 0, sizeof(double) * E, st));
     DCS_HIP(hipMemsetAsync(d_err, 0, sizeof(double) * 2 * E, st));
+    DCS_HIP(hipMemsetAsync(d_ticket, 0, 16, st));
     EdgeArrays ed{d_epose, d_epoint, d_ecam, d_obs, d_w, d_active};
     const double delta = pb->huber_delta;
     std::vector<uint8_t> active(E, 1), level1(E, 0);
@@ -699,9 +844,8 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     const auto t_opt0 = std::chrono::steady_clock::now();
 
     auto eval_error = [&](int robust, double* chi_out) -> int {     // computeActiveErrors + activeRobustChi2
-        hipLaunchKernelGGL(k_error, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2, d_partial);
-        DCS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, st, d_partial, nblk, chi_out);
+        hipLaunchKernelGGL(k_error, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2, d_partial,
+                           d_ticket, chi_out);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     };
@@ -726,6 +870,8 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
         }
         DCS_HIP(hipStreamSynchronize(st));              // host vectors go out of scope with the round
         const int n = r.n, n_pad = r.n_pad, ld = std::max(n_pad, kNB);
+        const bool use_reg = n <= 256 && !force_blocked;  // reduced camera system fits one workgroup's registers
+        if (r.np && use_reg) DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));   // pairs without shared points stay 0
         double lambda = 0, ni = 2, currentChi = 0;
         int nBad = 0;
         bool errors_current = false;
@@ -744,7 +890,7 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
             DCS_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_reduce_point, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_cpoint, d_Hll, d_bl);
             DCS_CHECK_LAUNCH();
-            if (r.np) { hipLaunchKernelGGL(k_reduce_pose, dim3(r.np), dim3(64), 0, st, d_ps_off, d_ps_edges, d_cpose, d_Hpp, d_bp); DCS_CHECK_LAUNCH(); }
+            if (r.np) { hipLaunchKernelGGL(k_reduce_pose, dim3(r.np), dim3(256), 0, st, d_ps_off, d_ps_edges, d_cpose, d_Hpp, d_bp); DCS_CHECK_LAUNCH(); }
             if (it == 0) {
                 hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, r.np, d_Hpp, L, d_pt_off, d_Hll, d_scal + 2);
                 DCS_CHECK_LAUNCH();
@@ -757,26 +903,31 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
             do {
                 // setLambda + solve (Schur)
                 hipLaunchKernelGGL(k_point_prep, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx,
-                                   d_Hll, d_bl, lambda, d_Hpl, d_Dinv, d_db, d_BD);
+                                   d_Hll, d_bl, lambda, d_Hpl, d_Dinv, d_db, d_BD, d_scal + 3);
                 DCS_CHECK_LAUNCH();
-                *h_ok = 1;
-                DCS_HIP(hipMemcpyAsync(d_ok, h_ok, sizeof(int), hipMemcpyHostToDevice, st));
                 if (r.np) {
-                    DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));
-                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs), dim3(64), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp, lambda,
+                    if (!use_reg) {                       // the blocked fallback factors S in place: rebuild it every trial
+                        DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));
+                        if (n_pad > n) { hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(64), 0, st, d_S, ld, n, n_pad); DCS_CHECK_LAUNCH(); }
+                    }
+                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs), dim3(256), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp, lambda,
                                        d_BD, d_Hpl, d_S, ld);
                     DCS_CHECK_LAUNCH();
-                    if (n_pad > n) { hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(64), 0, st, d_S, ld, n, n_pad); DCS_CHECK_LAUNCH(); }
-                    hipLaunchKernelGGL(k_bschur, dim3(r.np), dim3(64), 0, st, d_ps_off, d_ps_edges, d_epoint, d_Hpl, d_db, d_bp, d_bsch);
+                    hipLaunchKernelGGL(k_bschur, dim3(r.np), dim3(256), 0, st, d_ps_off, d_ps_edges, d_epoint, d_Hpl, d_db, d_bp, d_bsch);
                     DCS_CHECK_LAUNCH();
-                    for (int k0 = 0; k0 < n_pad; k0 += kNB) {
-                        hipLaunchKernelGGL(k_ldlt_panel, dim3(1), dim3(256), 0, st, d_S, ld, n_pad, k0, d_W, d_ok);
+                    if (use_reg) {
+                        hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(1), dim3(1024), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3);
                         DCS_CHECK_LAUNCH();
-                        const int m = (n_pad - k0) / kNB - 1;
-                        if (m > 0) { hipLaunchKernelGGL(k_ldlt_update, dim3(m, m), dim3(64), 0, st, d_S, ld, k0, d_W); DCS_CHECK_LAUNCH(); }
+                    } else {
+                        for (int k0 = 0; k0 < n_pad; k0 += kNB) {
+                            hipLaunchKernelGGL(k_ldlt_panel, dim3(1), dim3(256), 0, st, d_S, ld, n_pad, k0, d_W, d_scal + 3);
+                            DCS_CHECK_LAUNCH();
+                            const int m = (n_pad - k0) / kNB - 1;
+                            if (m > 0) { hipLaunchKernelGGL(k_ldlt_update, dim3(m, m), dim3(64), 0, st, d_S, ld, k0, d_W); DCS_CHECK_LAUNCH(); }
+                        }
+                        hipLaunchKernelGGL(k_ldlt_solve, dim3(1), dim3(256), sizeof(double) * n_pad, st, d_S, ld, n_pad, d_bsch, n, d_xp);
+                        DCS_CHECK_LAUNCH();
                     }
-                    hipLaunchKernelGGL(k_ldlt_solve, dim3(1), dim3(256), sizeof(double) * n_pad, st, d_S, ld, n_pad, d_bsch, n, d_xp);
-                    DCS_CHECK_LAUNCH();
                 }
                 hipLaunchKernelGGL(k_back_subst, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx, d_Hpl,
                                    d_xp, d_bl, d_Dinv, d_xl);
@@ -788,12 +939,11 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
                 if ((rc2 = eval_error(robust, d_scal))) return rc2;
                 hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, st, n, d_xp, d_bp, L, d_pt_off, d_xl, d_bl, lambda, d_scal + 1);
                 DCS_CHECK_LAUNCH();
-                DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 16, hipMemcpyDeviceToHost, st));
-                DCS_HIP(hipMemcpyAsync(h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, st));
+                DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 32, hipMemcpyDeviceToHost, st));
                 DCS_HIP(hipStreamSynchronize(st));
                 ++res->n_trials[round];
                 double tempChi = h_scal[0];
-                if (!*h_ok) tempChi = std::numeric_limits<double>::max();
+                if (h_scal[3] == 0.0) tempChi = std::numeric_limits<double>::max();
                 rho = currentChi - tempChi;
                 const double scale = h_scal[1] + 1e-3;
                 rho /= scale;
