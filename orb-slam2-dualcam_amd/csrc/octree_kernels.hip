@@ -1,0 +1,333 @@
+// octree_kernels.hip -- DistributeOctTree (reference src/ORBextractor.cc:481-763) on the GPU.
+//
+// Device version of the sort/scan formulation documented and validated on the host in octree.cpp
+// (tests/test_octree_host.py compares that formulation with the oracle's literal std::list restatement).
+// One workgroup per (image, level):
+//   1. path code per candidate (initial node, then one quadrant per depth; children use ceil(w/2))
+//   2. bitonic sort of (code << 20 | input index) -- in LDS when it fits, in HBM scratch otherwise
+//   3. lcp[i] = common path elements of sorted neighbours; two 16-bin LDS histograms give the list size and
+//      the number of multi-key nodes at every depth -> stopping depth D of the breadth-first phase and whether
+//      the "expand the fullest nodes first" tail (:673-738) runs
+//   4. tail passes: sort the expandable nodes by (size desc, list order | creation seq desc), prefix-sum the
+//      list growth, cut at the first node that reaches N
+//   5. final nodes -> (list-order key, best candidate = max response, first in input order) -> bitonic sort ->
+//      selected keypoints in the reference's list order.
+// Ties between equal-size nodes: creation sequence (Q3, same as the oracle). Output is bit-exact vs the oracle.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "orb_kernels.h"
+
+namespace dcs {
+
+namespace {
+
+constexpr int kT = 256;                 // threads per workgroup
+constexpr int kLdsKeys = 4096;          // sort in LDS up to this many (padded) keys
+constexpr int kMaxDepth = 14;           // 8-bit initial node + 14 x 2-bit quadrants = 36-bit path code
+constexpr unsigned long long kM20 = (1ull << 20) - 1;
+constexpr unsigned long long kM36 = (1ull << 36) - 1;
+
+__device__ __forceinline__ int common_prefix(unsigned long long a, unsigned long long b)
+{
+    const unsigned long long x = a ^ b;
+    if (x == 0) return kMaxDepth + 1;
+    const int hb = 63 - __clzll(x);
+    if (hb >= 2 * kMaxDepth) return 0;
+    return (2 * kMaxDepth + 1 - hb) / 2;
+}
+
+// list-order key of a depth-`depth` node: quadrant j complemented when (depth - j) is even, the initial-node
+// index complemented when depth is odd (derivation in octree.cpp)
+__device__ __forceinline__ unsigned long long order_key(unsigned long long code, int depth)
+{
+    const unsigned long long k = code >> (2 * kMaxDepth);
+    unsigned long long out = (depth & 1) ? (~k & 0xFF) : k;
+#pragma unroll
+    for (int j = 1; j <= kMaxDepth; ++j) {
+        unsigned long long q = 0;
+        if (j <= depth) {
+            q = (code >> (2 * (kMaxDepth - j))) & 3;
+            if (((depth - j) & 1) == 0) q = 3 - q;
+        }
+        out = (out << 2) | q;
+    }
+    return out;
+}
+
+__device__ __forceinline__ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// in-place ascending bitonic sort of npow2 keys (+ optional payload); every thread of the block calls it
+__device__ void bitonic_sort(unsigned long long* keys, unsigned* vals, int npow2)
+{
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (npow2 >> 1); t += kT) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) {
+                    keys[lo] = b; keys[hi] = a;
+                    if (vals) { const unsigned va = vals[lo]; vals[lo] = vals[hi]; vals[hi] = va; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// in-place exclusive scan of a[0..n); returns the total. Every thread of the block calls it.
+__device__ int block_scan_inplace(int* a, int n)
+{
+    __shared__ int s_run, s_w[kT / 64];
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += kT) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? a[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int off = s_run, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kT / 64; ++w) { const int c = s_w[w]; if (w < wave) off += c; tot += c; }
+        if (i < n) a[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += tot;
+        __syncthreads();
+    }
+    return s_run;
+}
+
+}  // namespace
+
+// All scratch arrays have 2 * dense_cap elements; the task whose candidates start at b0 uses [2*b0, 2*b0 + 2n).
+__global__ __launch_bounds__(kT) void k_octree(const dcs_candidate* __restrict__ dense, const int32_t* __restrict__ lvl_off,
+                                               OctLevels P, OctScratch G, int dense_cap, SelKp* __restrict__ sel, int32_t* __restrict__ lvl_cnt)
+{
+    __shared__ unsigned long long s_keys[kLdsKeys];
+    __shared__ unsigned s_vals[kLdsKeys];
+    __shared__ int s_hist[kMaxDepth + 2], s_exp[kMaxDepth + 3];
+    __shared__ int s_D, s_tail, s_size, s_nfin, s_nnext, s_rstar, s_seq;
+    const int task = blockIdx.x, tid = threadIdx.x;
+    const int l = task % P.nlevels, img = task / P.nlevels;
+    const OctLevel lp = P.lv[l];
+    const int b0 = lvl_off[task], n = min(lvl_off[task + 1], dense_cap) - b0;   // k_gather drops what does not fit
+    SelKp* out = sel + (size_t)img * P.out_per_image + lp.out_base;
+    if (n <= 0 || lp.height <= 0) { if (tid == 0) lvl_cnt[task] = 0; return; }
+    const int n_ini = (int)roundf(__fdiv_rn((float)lp.width, (float)lp.height));
+    if (n_ini < 1 || n_ini > 255) { if (tid == 0) lvl_cnt[task] = 0; return; }
+    const float hX = __fdiv_rn((float)lp.width, (float)n_ini);
+    const dcs_candidate* c = dense + b0;
+    const size_t o = (size_t)2 * b0;
+    unsigned long long* gk = G.keys + o;          // sorted keys
+    unsigned char* lcp = G.lcp + o;
+    int* A0 = G.i0 + o; int* A1 = G.i1 + o; int* A2 = G.i2 + o;
+    int* todo_b = G.i3 + o; int* todo_e = G.i4 + o; int* next_b = G.i5 + o; int* next_e = G.i6 + o; int* next_seq = G.i7 + o;
+    unsigned long long* fkey = G.fkey + o; unsigned* fbeg = G.fval + o;
+    unsigned long long* tkey = G.tkey + o; unsigned* tval = G.tval + o;
+
+    // ---- 1. path codes (same float arithmetic as the reference: kp.pt.x / hX, (int)(hX * i))
+    const int npow2 = next_pow2(n);
+    unsigned long long* keys = npow2 <= kLdsKeys ? s_keys : gk;
+    for (int i = tid; i < npow2; i += kT) {
+        unsigned long long key = ~0ull;
+        if (i < n) {
+            const int x = c[i].x, y = c[i].y;
+            int k = (int)__fdiv_rn((float)x, hX);
+            if (k >= n_ini) k = n_ini - 1;
+            int ulx = (int)__fmul_rn(hX, (float)k), urx = (int)__fmul_rn(hX, (float)(k + 1)), uly = 0, bry = lp.height;
+            unsigned long long code = (unsigned long long)k;
+#pragma unroll
+            for (int d = 1; d <= kMaxDepth; ++d) {
+                const int mx = ulx + (urx - ulx + 1) / 2, my = uly + (bry - uly + 1) / 2;
+                unsigned q = 0;
+                if (x < mx) urx = mx; else { ulx = mx; q |= 1; }
+                if (y < my) bry = my; else { uly = my; q |= 2; }
+                code = (code << 2) | q;
+            }
+            key = (code << 20) | (unsigned long long)i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    // ---- 2. sort by (path code, input index)
+    bitonic_sort(keys, nullptr, npow2);
+    if (keys != gk) for (int i = tid; i < n; i += kT) gk[i] = keys[i];
+    if (tid <= kMaxDepth + 1) s_hist[tid] = 0;
+    if (tid <= kMaxDepth + 2) s_exp[tid] = 0;
+    __syncthreads();
+    // ---- 3. common-prefix lengths, list size and expandable-node count per depth
+    for (int i = tid; i <= n; i += kT) {
+        int v = 0;
+        if (i > 0 && i < n) { v = common_prefix(gk[i - 1] >> 20, gk[i] >> 20); atomicAdd(&s_hist[v], 1); }
+        lcp[i] = (unsigned char)v;
+    }
+    __syncthreads();
+    for (int i = tid; i + 1 < n; i += kT) {        // the run starting at i is a multi-key node for depths [lcp[i], lcp[i+1])
+        const int a = lcp[i], b = lcp[i + 1];
+        if (a < b) { atomicAdd(&s_exp[a], 1); atomicSub(&s_exp[b], 1); }
+    }
+    __syncthreads();
+    if (tid == 0) {                                 // breadth-first phase (:594-673)
+        int cum = 1, e = 0, prev = 0, D = kMaxDepth, tail = 0, size_D = 0;
+        bool done = false;
+        for (int d = 0; d <= kMaxDepth; ++d) {
+            cum += s_hist[d]; e += s_exp[d];
+            if (done) continue;
+            if (d == 0) { prev = cum; size_D = cum; continue; }
+            size_D = cum; D = d;
+            if (cum >= lp.n_target || cum == prev) { done = true; }
+            else if (cum + 3 * e > lp.n_target) { tail = 1; done = true; }
+            prev = cum;
+        }
+        s_D = D; s_tail = tail; s_size = size_D; s_nfin = 0; s_nnext = 0; s_seq = 1;
+    }
+    __syncthreads();
+    const int D = s_D, tail = s_tail;
+    // ---- 4. nodes of the breadth-first list L_D = runs of keys sharing D+1 path elements
+    for (int i = tid; i < n; i += kT) A0[i] = (i == 0 || lcp[i] <= D) ? 1 : 0;
+    __syncthreads();
+    const int M0 = block_scan_inplace(A0, n);
+    for (int i = tid; i < n; i += kT) {
+        if (i == 0 || lcp[i] <= D) { const int m = A0[i]; A1[m] = i; if (m > 0) A2[m - 1] = i; }
+    }
+    if (tid == 0) A2[M0 - 1] = n;
+    __syncthreads();
+    int* fend = A0;                                  // scan flags are dead: A0 becomes the end index of final nodes
+    for (int m = tid; m < M0; m += kT) {
+        const int b = A1[m], e = A2[m];
+        const int depth = (e - b == 1) ? min(D, max((int)lcp[b], (int)lcp[e])) : D;   // single keys froze at a shallower depth
+        const unsigned long long ok = order_key(gk[b] >> 20, depth);
+        if (tail && e - b > 1) {
+            const int t = atomicAdd(&s_nnext, 1);
+            todo_b[t] = b; todo_e[t] = e;
+            tkey[t] = ((kM20 - (unsigned long long)(e - b)) << 36) | ok;      // fullest first, then list order
+            tval[t] = (unsigned)t;
+        } else {
+            const int f = atomicAdd(&s_nfin, 1);
+            fkey[f] = (1ull << 60) | ((unsigned long long)(D - depth) << 36) | ok;
+            fbeg[f] = (unsigned)b; fend[f] = e;
+        }
+    }
+    __syncthreads();
+    // ---- 5. "expand the fullest nodes first" passes (:673-738)
+    if (tail) {
+        int* nch = A1; int* inc = A2;               // node_b / node_e are dead from here on
+        int depth_cur = D;
+        bool first_pass = true;
+        for (;;) {
+            const int T = s_nnext, prev_size = s_size, seq_base = s_seq;
+            __syncthreads();
+            if (T == 0) break;
+            const int tp = next_pow2(T);
+            unsigned long long* sk = tp <= kLdsKeys ? s_keys : tkey;
+            unsigned* sv = tp <= kLdsKeys ? s_vals : tval;
+            for (int i = tid; i < tp; i += kT) {
+                if (sk != tkey) { sk[i] = i < T ? tkey[i] : ~0ull; sv[i] = i < T ? tval[i] : 0u; }
+                else if (i >= T) { sk[i] = ~0ull; sv[i] = 0u; }
+            }
+            __syncthreads();
+            bitonic_sort(sk, sv, tp);                // processing order r = 0..T-1
+            for (int r = tid; r < T; r += kT) {
+                const int t = (int)sv[r];
+                int cnt = 1;
+                for (int i = todo_b[t] + 1; i < todo_e[t]; ++i) cnt += (lcp[i] == depth_cur + 1);
+                nch[r] = cnt; inc[r] = cnt;
+            }
+            __syncthreads();
+            (void)block_scan_inplace(inc, T);        // inc[r] = children created before node r
+            if (tid == 0) s_rstar = T;
+            __syncthreads();
+            for (int r = tid; r < T; r += kT)
+                if (prev_size + inc[r] + nch[r] - (r + 1) >= lp.n_target) atomicMin(&s_rstar, r);
+            __syncthreads();
+            const bool full = s_rstar < T;
+            const int last_r = full ? s_rstar : T - 1;
+            const int created = inc[last_r] + nch[last_r];
+            const int new_size = prev_size + created - (last_r + 1);
+            const bool stop = full || new_size == prev_size;
+            __syncthreads();
+            if (tid == 0) { s_nnext = 0; s_size = new_size; s_seq = seq_base + created; }
+            __syncthreads();
+            for (int r = tid; r < T; r += kT) {
+                const int t = (int)sv[r];
+                const int b = todo_b[t], e = todo_e[t];
+                if (r > last_r) {                    // never reached: the node stays where it is in the list
+                    const int f = atomicAdd(&s_nfin, 1);
+                    fkey[f] = first_pass ? ((1ull << 60) | (sk[r] & kM36)) : ((sk[r] & kM20) << 36);
+                    fbeg[f] = (unsigned)b; fend[f] = e;
+                    continue;
+                }
+                int child = 0;
+                for (int cb = b; cb < e; ++child) {
+                    int ce = cb + 1;
+                    while (ce < e && lcp[ce] > depth_cur + 1) ++ce;
+                    const unsigned long long seq = (unsigned long long)(seq_base + inc[r] + child);
+                    if (!stop && ce - cb > 1 && depth_cur + 1 < kMaxDepth) {
+                        const int s2 = atomicAdd(&s_nnext, 1);
+                        next_b[s2] = cb; next_e[s2] = ce; next_seq[s2] = (int)seq;
+                    } else {
+                        const int f = atomicAdd(&s_nfin, 1);
+                        fkey[f] = (kM20 - seq) << 36;               // group 0: pushed to the front, latest first
+                        fbeg[f] = (unsigned)cb; fend[f] = ce;
+                    }
+                    cb = ce;
+                }
+            }
+            __syncthreads();
+            if (stop) break;
+            const int T2 = s_nnext;
+            for (int s2 = tid; s2 < T2; s2 += kT) {  // next pass: fullest first, then latest created first
+                todo_b[s2] = next_b[s2]; todo_e[s2] = next_e[s2];
+                tkey[s2] = ((kM20 - (unsigned long long)(next_e[s2] - next_b[s2])) << 36) | (kM20 - (unsigned long long)next_seq[s2]);
+                tval[s2] = (unsigned)s2;
+            }
+            depth_cur += 1;
+            first_pass = false;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- 6. best candidate per final node (max response, first in input order), sort into list order, emit
+    const int F = s_nfin;
+    const int fp = next_pow2(F);
+    unsigned long long* sk = fp <= kLdsKeys ? s_keys : fkey;
+    unsigned* sv = fp <= kLdsKeys ? s_vals : fbeg;
+    for (int f = tid; f < fp; f += kT) {
+        if (f < F) {
+            const int b = (int)fbeg[f], e = fend[f];
+            int best = (int)(gk[b] & kM20);
+            for (int i = b + 1; i < e; ++i) {
+                const int id = (int)(gk[i] & kM20);
+                if (c[id].score > c[best].score || (c[id].score == c[best].score && id < best)) best = id;
+            }
+            sk[f] = fkey[f]; sv[f] = (unsigned)best;
+        } else { sk[f] = ~0ull; sv[f] = 0u; }
+    }
+    __syncthreads();
+    bitonic_sort(sk, sv, fp);
+    const int n_out = min(F, lp.out_cap);
+    for (int f = tid; f < n_out; f += kT) {
+        const dcs_candidate cc = c[sv[f]];
+        SelKp s;
+        s.x = (int16_t)(cc.x + kMinBorder); s.y = (int16_t)(cc.y + kMinBorder); s.score = (int16_t)cc.score; s.level = (int8_t)l; s.pad = 0;
+        out[f] = s;
+    }
+    if (tid == 0) lvl_cnt[task] = n_out;
+}
+
+int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const OctLevels& levels, const OctScratch& scratch,
+                  int n_tasks, int dense_cap, SelKp* d_sel, int32_t* d_lvl_cnt, hipStream_t s)
+{
+    if (n_tasks <= 0) return DCS_OK;
+    hipLaunchKernelGGL(k_octree, dim3(n_tasks), dim3(kT), 0, s, d_dense, d_lvl_off, levels, scratch, dense_cap, d_sel, d_lvl_cnt);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+}  // namespace dcs

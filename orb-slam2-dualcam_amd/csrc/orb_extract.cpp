@@ -102,6 +102,16 @@ struct dcs_orb {
     DevBuf<SelKp> d_sel;
     PinnedBuf<int32_t> h_img_off;
     DevBuf<int32_t> d_img_off;
+    // device quadtree (default): per-(image, level) output slots + HBM scratch
+    bool device_octree = true;
+    OctLevels oct{};
+    DevBuf<int32_t> d_lvl_cnt;
+    DevBuf<unsigned long long> d_oct_u64[3];
+    DevBuf<unsigned> d_oct_u32[2];
+    DevBuf<int> d_oct_i32[8];
+    DevBuf<unsigned char> d_oct_u8;
+    bool host_copy_valid = false;       // h_lvl_off / h_dense mirror the last call (debug taps)
+    int last_tasks = 0;
     // staging for the host-buffer API
     DevBuf<dcs_keypoint> d_kp;
     DevBuf<uint8_t> d_desc;
@@ -112,7 +122,7 @@ struct dcs_orb {
     PinnedBuf<uint8_t> h_img;
 
     hipStream_t s_main = nullptr, s_aux = nullptr;
-    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_t[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
                ev_b[2] = {nullptr, nullptr};
     float host_us = 0;
     bool timing_valid = false;
@@ -215,7 +225,25 @@ int dcs_orb::configure(int rows, int cols)
     dense_cap = std::max<size_t>(dense_cap, 1);
     if ((rc = d_dense.resize(dense_cap))) return rc;
     if ((rc = h_dense.resize(dense_cap))) return rc;
-    const size_t max_sel = (size_t)B * ((size_t)t.nfeatures + 4 * L + 64) * 2;
+    oct = OctLevels();
+    oct.nlevels = L;
+    int out_total = 0;
+    for (int l = 0; l < L; ++l) {
+        OctLevel& ol = oct.lv[l];
+        ol.width = (g.lv[l].w - kEdgeThreshold + 3) - kMinBorder; ol.height = (g.lv[l].h - kEdgeThreshold + 3) - kMinBorder;
+        ol.n_target = t.n_per_level[l];
+        ol.out_base = out_total; ol.out_cap = t.n_per_level[l] + 8;     // the list never exceeds N + 3 (or 4 initial nodes)
+        out_total += ol.out_cap;
+    }
+    oct.out_per_image = out_total;
+    if (device_octree) {
+        if ((rc = d_lvl_cnt.resize((size_t)B * L))) return rc;
+        for (auto& b : d_oct_u64) if ((rc = b.resize(2 * dense_cap))) return rc;
+        for (auto& b : d_oct_u32) if ((rc = b.resize(2 * dense_cap))) return rc;
+        for (auto& b : d_oct_i32) if ((rc = b.resize(2 * dense_cap))) return rc;
+        if ((rc = d_oct_u8.resize(2 * dense_cap))) return rc;
+    }
+    const size_t max_sel = std::max((size_t)B * ((size_t)t.nfeatures + 4 * L + 64) * 2, (size_t)B * out_total);
     if ((rc = h_sel.resize(max_sel))) return rc;
     if ((rc = d_sel.resize(max_sel))) return rc;
     if ((rc = h_img_off.resize(B + 1))) return rc;
@@ -268,57 +296,75 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
                              d_cell_off.p, d_lvl_total.p, d_lvl_off.p, d_dense.p, dense_cap, stream))) return rc;
     const int n_tasks = n_images * L;
     DCS_HIP(hipEventRecord(ev_t[3], stream));
-    DCS_HIP(hipMemcpyAsync(h_lvl_off.p, d_lvl_off.p, sizeof(int32_t) * (n_tasks + 1), hipMemcpyDeviceToHost, stream));
-    DCS_HIP(hipStreamSynchronize(stream));
-    const size_t total = (size_t)h_lvl_off.p[n_tasks];
-    if (total > dense_cap) { set_error("FAST candidates (%zu) exceed the dense buffer (%zu)", total, dense_cap); return DCS_ERR_CAPACITY; }
-    if (total) {
-        DCS_HIP(hipMemcpyAsync(h_dense.p, d_dense.p, sizeof(dcs_candidate) * total, hipMemcpyDeviceToHost, stream));
-        DCS_HIP(hipStreamSynchronize(stream));
-    }
-    // host quadtree per (image, level)
-    const auto t0 = std::chrono::steady_clock::now();
-    pool->parallel_for(n_tasks, [&](int k) {
-        const int l = k % L;
-        const int b = h_lvl_off.p[k], e = h_lvl_off.p[k + 1];
-        const LevelGeom& lg = g.lv[l];
-        distribute_octree(h_dense.p + b, e - b, (lg.w - kEdgeThreshold + 3) - kMinBorder, (lg.h - kEdgeThreshold + 3) - kMinBorder,
-                          t.n_per_level[l], task_out[k]);
-    });
-    size_t n_sel = 0;
-    int max_per_image = 0;
-    bool over = false;
-    for (int i = 0; i < n_images; ++i) {
-        h_img_off.p[i] = (int32_t)n_sel;
-        for (int l = 0; l < L; ++l) {
-            for (const dcs_candidate& c : task_out[(size_t)i * L + l]) {
-                if (n_sel >= h_sel.n) { over = true; break; }
-                SelKp s;
-                s.x = (int16_t)(c.x + kMinBorder); s.y = (int16_t)(c.y + kMinBorder);
-                s.score = (int16_t)c.score; s.level = (int8_t)l; s.pad = 0;
-                h_sel.p[n_sel++] = s;
-            }
-        }
-        const int n_i = (int)(n_sel - h_img_off.p[i]);
-        if (h_counts) h_counts[i] = n_i;
-        max_per_image = std::max(max_per_image, n_i);
-    }
-    h_img_off.p[n_images] = (int32_t)n_sel;
-    host_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    if (over) { set_error("selected keypoints exceed internal capacity"); return DCS_ERR_CAPACITY; }
-    if (max_per_image > cap) {
-        set_error("an image yields %d keypoints but cap is %d", max_per_image, cap);
-        return DCS_ERR_CAPACITY;
-    }
-    if (n_sel) DCS_HIP(hipMemcpyAsync(d_sel.p, h_sel.p, sizeof(SelKp) * n_sel, hipMemcpyHostToDevice, stream));
-    DCS_HIP(hipMemcpyAsync(d_img_off.p, h_img_off.p, sizeof(int32_t) * (n_images + 1), hipMemcpyHostToDevice, stream));
-    DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
-    DCS_HIP(hipEventRecord(ev_t[4], stream));
+    last_tasks = n_tasks; host_copy_valid = false;
     DescribeParams dp{};
-    for (int l = 0; l < L; ++l) { dp.scale[l] = t.scale[l]; dp.scaled_patch[l] = g.lv[l].scaled_patch; }
+    for (int l = 0; l < L; ++l) { dp.scale[l] = t.scale[l]; dp.scaled_patch[l] = g.lv[l].scaled_patch; dp.out_base[l] = oct.lv[l].out_base; }
     for (int v = 0; v <= kHalfPatch; ++v) dp.umax[v] = t.umax[v];
-    if ((rc = launch_describe(raw, blur, dp, d_sel.p, d_img_off.p, n_images, max_per_image, d_kp_out, d_desc_out, cap,
-                              d_n_out, stream))) return rc;
+    dp.out_per_image = oct.out_per_image; dp.nlevels = L;
+    if (device_octree) {
+        // fully asynchronous: quadtree on the device, no host round trip
+        if (cap < oct.out_per_image) {
+            set_error("cap %d < %d (nfeatures + 8 per level): required by the device quadtree path", cap, oct.out_per_image);
+            return DCS_ERR_CAPACITY;
+        }
+        OctScratch sc{d_oct_u64[0].p, d_oct_u8.p, d_oct_i32[0].p, d_oct_i32[1].p, d_oct_i32[2].p, d_oct_i32[3].p, d_oct_i32[4].p,
+                      d_oct_i32[5].p, d_oct_i32[6].p, d_oct_i32[7].p, d_oct_u64[1].p, d_oct_u32[0].p, d_oct_u64[2].p, d_oct_u32[1].p};
+        if ((rc = launch_octree(d_dense.p, d_lvl_off.p, oct, sc, n_tasks, (int)dense_cap, d_sel.p, d_lvl_cnt.p, stream))) return rc;
+        DCS_HIP(hipEventRecord(ev_t[6], stream));
+        host_us = -1.f;
+        DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
+        DCS_HIP(hipEventRecord(ev_t[4], stream));
+        if ((rc = launch_describe(raw, blur, dp, d_sel.p, nullptr, d_lvl_cnt.p, n_images, oct.out_per_image, d_kp_out, d_desc_out, cap,
+                                  d_n_out, stream))) return rc;
+    } else {
+        DCS_HIP(hipMemcpyAsync(h_lvl_off.p, d_lvl_off.p, sizeof(int32_t) * (n_tasks + 1), hipMemcpyDeviceToHost, stream));
+        DCS_HIP(hipStreamSynchronize(stream));
+        const size_t total = (size_t)h_lvl_off.p[n_tasks];
+        if (total > dense_cap) { set_error("FAST candidates (%zu) exceed the dense buffer (%zu)", total, dense_cap); return DCS_ERR_CAPACITY; }
+        if (total) {
+            DCS_HIP(hipMemcpyAsync(h_dense.p, d_dense.p, sizeof(dcs_candidate) * total, hipMemcpyDeviceToHost, stream));
+            DCS_HIP(hipStreamSynchronize(stream));
+        }
+        host_copy_valid = true;
+        // host quadtree per (image, level)
+        const auto t0 = std::chrono::steady_clock::now();
+        pool->parallel_for(n_tasks, [&](int k) {
+            const int l = k % L;
+            const int b = h_lvl_off.p[k], e = h_lvl_off.p[k + 1];
+            distribute_octree(h_dense.p + b, e - b, oct.lv[l].width, oct.lv[l].height, t.n_per_level[l], task_out[k]);
+        });
+        size_t n_sel = 0;
+        int max_per_image = 0;
+        bool over = false;
+        for (int i = 0; i < n_images; ++i) {
+            h_img_off.p[i] = (int32_t)n_sel;
+            for (int l = 0; l < L; ++l) {
+                for (const dcs_candidate& c : task_out[(size_t)i * L + l]) {
+                    if (n_sel >= h_sel.n) { over = true; break; }
+                    SelKp sk;
+                    sk.x = (int16_t)(c.x + kMinBorder); sk.y = (int16_t)(c.y + kMinBorder);
+                    sk.score = (int16_t)c.score; sk.level = (int8_t)l; sk.pad = 0;
+                    h_sel.p[n_sel++] = sk;
+                }
+            }
+            const int n_i = (int)(n_sel - h_img_off.p[i]);
+            if (h_counts) h_counts[i] = n_i;
+            max_per_image = std::max(max_per_image, n_i);
+        }
+        h_img_off.p[n_images] = (int32_t)n_sel;
+        host_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (over) { set_error("selected keypoints exceed internal capacity"); return DCS_ERR_CAPACITY; }
+        if (max_per_image > cap) {
+            set_error("an image yields %d keypoints but cap is %d", max_per_image, cap);
+            return DCS_ERR_CAPACITY;
+        }
+        if (n_sel) DCS_HIP(hipMemcpyAsync(d_sel.p, h_sel.p, sizeof(SelKp) * n_sel, hipMemcpyHostToDevice, stream));
+        DCS_HIP(hipMemcpyAsync(d_img_off.p, h_img_off.p, sizeof(int32_t) * (n_images + 1), hipMemcpyHostToDevice, stream));
+        DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
+        DCS_HIP(hipEventRecord(ev_t[4], stream));
+        if ((rc = launch_describe(raw, blur, dp, d_sel.p, d_img_off.p, nullptr, n_images, max_per_image, d_kp_out, d_desc_out, cap,
+                                  d_n_out, stream))) return rc;
+    }
     DCS_HIP(hipEventRecord(ev_t[5], stream));
     timing_valid = true;
     return DCS_OK;
@@ -350,9 +396,8 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     DCS_HIP(hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming));
     for (auto& e : h->ev_t) DCS_HIP(hipEventCreate(&e));
     for (auto& e : h->ev_b) DCS_HIP(hipEventCreate(&e));
-    int nthreads = p->host_threads;
-    if (nthreads <= 0) nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    h->pool.reset(new Pool(nthreads - 1));
+    h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
+    h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
     *out = h.release();
     return DCS_OK;
 }
@@ -388,7 +433,7 @@ int dcs_orb_extract_batch_device(dcs_orb* h, const uint8_t* d_images, int n_imag
     DCS_HIP(hipSetDevice(h->device));
     int rc = h->configure(rows, cols);
     if (rc) return rc;
-    hipStream_t s = stream ? (hipStream_t)stream : h->s_main;
+    hipStream_t s = (hipStream_t)stream;            // NULL = the legacy default stream, exactly what the caller passed
     return h->run(d_images, (size_t)rows * stride, stride, n_images, d_kp, d_desc, cap, d_n_out, s, nullptr);
 }
 
@@ -421,6 +466,16 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     std::vector<int> counts(n_images, 0);
     rc = h->run(nullptr, 0, 0, n_images, h->d_kp.p, h->d_desc.p, cap, h->d_n.p, h->s_main, counts.data());
     if (rc) { for (int i = 0; i < n_images; ++i) n_out[i] = counts[i]; return rc; }
+    if (h->device_octree) {
+        DCS_HIP(hipMemcpyAsync(h->h_n.p, h->d_n.p, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost, h->s_main));
+        DCS_HIP(hipMemcpyAsync(h->h_lvl_off.p, h->d_lvl_off.p, sizeof(int32_t) * (n_images * h->t.nlevels + 1), hipMemcpyDeviceToHost, h->s_main));
+        DCS_HIP(hipStreamSynchronize(h->s_main));
+        if ((size_t)h->h_lvl_off.p[n_images * h->t.nlevels] > h->dense_cap) {
+            set_error("FAST candidates (%d) exceed the dense buffer (%zu)", h->h_lvl_off.p[n_images * h->t.nlevels], h->dense_cap);
+            return DCS_ERR_CAPACITY;
+        }
+        for (int i = 0; i < n_images; ++i) counts[i] = h->h_n.p[i];
+    }
     for (int i = 0; i < n_images; ++i) {
         if (!counts[i]) continue;
         DCS_HIP(hipMemcpyAsync(kp + (size_t)i * cap, h->d_kp.p + (size_t)i * cap, sizeof(dcs_keypoint) * counts[i],
@@ -464,6 +519,14 @@ int dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* ds
     if (!h || !h->configured || level < 0 || level >= h->t.nlevels || image < 0 || image >= h->last_n_images || !n) {
         set_error("bad argument"); return DCS_ERR_INVALID;
     }
+    if (!h->host_copy_valid) {
+        DCS_HIP(hipSetDevice(h->device));
+        DCS_HIP(hipDeviceSynchronize());
+        DCS_HIP(hipMemcpy(h->h_lvl_off.p, h->d_lvl_off.p, sizeof(int32_t) * (h->last_tasks + 1), hipMemcpyDeviceToHost));
+        const size_t total = std::min((size_t)h->h_lvl_off.p[h->last_tasks], h->dense_cap);
+        if (total) DCS_HIP(hipMemcpy(h->h_dense.p, h->d_dense.p, sizeof(dcs_candidate) * total, hipMemcpyDeviceToHost));
+        h->host_copy_valid = true;
+    }
     const int k = image * h->t.nlevels + level;
     const int b = h->h_lvl_off.p[k], e = h->h_lvl_off.p[k + 1];
     *n = e - b;
@@ -481,7 +544,8 @@ int dcs_orb_last_timing(const dcs_orb* h, float* us7)
     DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[1], h->ev_t[2])); us7[1] = ms * 1000.f;   // k_fast_cells
     DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[2], h->ev_t[3])); us7[2] = ms * 1000.f;   // scan + gather
     DCS_HIP(hipEventElapsedTime(&ms, h->ev_b[0], h->ev_b[1])); us7[3] = ms * 1000.f;   // k_blur (aux stream)
-    us7[4] = h->host_us;                                                               // host quadtree
+    if (h->device_octree) { DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[3], h->ev_t[6])); us7[4] = ms * 1000.f; }   // k_octree
+    else us7[4] = h->host_us;                                                          // host quadtree (wall)
     DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[4], h->ev_t[5])); us7[5] = ms * 1000.f;   // k_describe
     DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[0], h->ev_t[5])); us7[6] = ms * 1000.f;   // whole call on the main stream
     return DCS_OK;

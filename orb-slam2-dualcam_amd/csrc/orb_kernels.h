@@ -38,6 +38,19 @@ struct DescribeParams {
     float scale[kMaxLevels];
     int scaled_patch[kMaxLevels];
     int umax[kHalfPatch + 1];
+    // device-quadtree mode: keypoints of (image, level) live at sel[image * out_per_image + out_base[level] ...]
+    int out_base[kMaxLevels];
+    int out_per_image, nlevels;
+};
+
+// per-level parameters of the device quadtree (k_octree)
+struct OctLevel { int width, height, n_target, out_base, out_cap; };
+struct OctLevels { OctLevel lv[kMaxLevels]; int nlevels; int out_per_image; };
+// HBM scratch of k_octree: every array has 2 * dense_cap elements
+struct OctScratch {
+    unsigned long long* keys; unsigned char* lcp;
+    int *i0, *i1, *i2, *i3, *i4, *i5, *i6, *i7;
+    unsigned long long* fkey; unsigned* fval; unsigned long long* tkey; unsigned* tval;
 };
 
 int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_xofs, const int16_t* d_xa,
@@ -56,9 +69,14 @@ int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin /*
 
 int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStream_t s);
 
+// d_img_off != NULL: host-quadtree mode (sel dense, image i at [img_off[i], img_off[i+1]));
+// d_lvl_cnt != NULL: device-quadtree mode (per (image, level) counts, layout in prm.out_base)
 int launch_describe(const LevelSet& raw, const LevelSet& blurred, const DescribeParams& prm,
-                    const SelKp* d_sel, const int32_t* d_img_off /* n_images+1 */, int n_images, int max_per_image,
-                    dcs_keypoint* d_kp, uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s);
+                    const SelKp* d_sel, const int32_t* d_img_off /* n_images+1 */, const int32_t* d_lvl_cnt, int n_images,
+                    int max_per_image, dcs_keypoint* d_kp, uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s);
+
+int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const OctLevels& levels, const OctScratch& scratch,
+                  int n_tasks, int dense_cap, SelKp* d_sel, int32_t* d_lvl_cnt, hipStream_t s);
 
 int upload_pattern();   // copies the rBRIEF table to constant memory of the current device
 

@@ -359,17 +359,32 @@ constexpr int kPatchDw = 11;                // dwords per staged row (44 bytes c
 // one wave per keypoint; 4 keypoints per workgroup. grid (ceil(max_per_image/4), n_images)
 __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
                                                   const SelKp* __restrict__ sel, const int32_t* __restrict__ img_off,
-                                                  dcs_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int cap,
-                                                  int32_t* __restrict__ n_out)
+                                                  const int32_t* __restrict__ lvl_cnt, dcs_keypoint* __restrict__ kp_out,
+                                                  uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out)
 {
     __shared__ uint32_t s_patch[4][kPatchRows * kPatchDw];
     const int img = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int first = img_off[img], n_img = min(img_off[img + 1] - first, cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0) n_out[img] = n_img;
     const int i = blockIdx.x * 4 + wave;
+    int n_img, src = 0;
+    if (lvl_cnt) {                                           // device quadtree: per-level slots, level-major output order
+        int acc = 0;
+        src = -1;
+        for (int l = 0; l < prm.nlevels; ++l) {
+            const int cnt = lvl_cnt[img * prm.nlevels + l];
+            if (src < 0 && i < acc + cnt) src = img * prm.out_per_image + prm.out_base[l] + (i - acc);
+            acc += cnt;
+        }
+        n_img = min(acc, cap);
+        if (src < 0) src = img * prm.out_per_image;
+    } else {
+        const int first = img_off[img];
+        n_img = min(img_off[img + 1] - first, cap);
+        src = first + (i < n_img ? i : 0);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) n_out[img] = n_img;
     if (blockIdx.x * 4 >= n_img) return;                     // block-uniform
     const bool active = i < n_img;                           // wave-uniform; inactive waves only hit the barrier
-    const SelKp k = sel[first + (active ? i : 0)];
+    const SelKp k = sel[src];
     const int x = k.x, y = k.y, level = k.level;
 
     // ---- IC_Angle on the unblurred level: moments over the umax disc (exact int32)
@@ -430,12 +445,12 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
 }
 
 int launch_describe(const LevelSet& raw, const LevelSet& blurred, const DescribeParams& prm, const SelKp* d_sel,
-                    const int32_t* d_img_off, int n_images, int max_per_image, dcs_keypoint* d_kp, uint8_t* d_desc,
-                    int cap, int32_t* d_n_out, hipStream_t s)
+                    const int32_t* d_img_off, const int32_t* d_lvl_cnt, int n_images, int max_per_image, dcs_keypoint* d_kp,
+                    uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s)
 {
     const int gx = max_per_image > 0 ? (max_per_image + 3) / 4 : 1;
-    hipLaunchKernelGGL(k_describe, dim3(gx, n_images), dim3(256), 0, s, raw, blurred, prm, d_sel, d_img_off, d_kp, d_desc,
-                       cap, d_n_out);
+    hipLaunchKernelGGL(k_describe, dim3(gx, n_images), dim3(256), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
+                       d_desc, cap, d_n_out);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

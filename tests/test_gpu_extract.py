@@ -59,6 +59,18 @@ def test_end_to_end_bit_exact(pkg, oracle, synth, w, h, n):
     e.close()
 
 
+@pytest.mark.parametrize("host_threads", [1, 4])
+def test_host_quadtree_mode_matches_too(pkg, oracle, synth, host_threads):
+    """host_threads > 0 selects the host-side sort/scan quadtree (csrc/octree.cpp) instead of k_octree."""
+    imgs = list(synth.frame_pair(640, 480, 4, 0)) + [np.random.default_rng(1).integers(0, 256, (480, 640), dtype=np.uint8)]
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=3, host_threads=host_threads)
+    kps, descs = e.extract_batch(imgs)
+    for i in range(3):
+        okp, odesc = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(imgs[i])
+        _same(kps[i], descs[i], okp, odesc)
+    e.close()
+
+
 def test_single_image_operator_and_strided_input(pkg, oracle, synth, ext1000):
     img, _ = synth.frame_pair(640, 480, 3, 0)
     kp, desc = ext1000(img)
