@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -104,6 +105,7 @@ struct dcs_orb {
     DevBuf<int32_t> d_img_off;
     // device quadtree (default): per-(image, level) output slots + HBM scratch
     bool device_octree = true;
+    bool no_overlap = false;
     OctLevels oct{};
     DevBuf<int32_t> d_lvl_cnt;
     DevBuf<unsigned long long> d_oct_u64[3];
@@ -282,12 +284,14 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     }
     DCS_HIP(hipEventRecord(ev_pyr, stream));
     DCS_HIP(hipEventRecord(ev_t[1], stream));
-    // blur on the auxiliary stream, overlapping FAST + the host stage
-    DCS_HIP(hipStreamWaitEvent(s_aux, ev_pyr, 0));
-    DCS_HIP(hipEventRecord(ev_b[0], s_aux));
-    if ((rc = launch_blur(raw, blur, n_images, s_aux))) return rc;
-    DCS_HIP(hipEventRecord(ev_b[1], s_aux));
-    DCS_HIP(hipEventRecord(ev_blur, s_aux));
+    // blur on the auxiliary stream, overlapping FAST + quadtree (DCS_ORB_NO_OVERLAP=1 serialises it for clean timings)
+    hipStream_t sb = no_overlap ? stream : s_aux;
+    if (!no_overlap) DCS_HIP(hipStreamWaitEvent(s_aux, ev_pyr, 0));
+    DCS_HIP(hipEventRecord(ev_b[0], sb));
+    if ((rc = launch_blur(raw, blur, n_images, sb))) return rc;
+    DCS_HIP(hipEventRecord(ev_b[1], sb));
+    DCS_HIP(hipEventRecord(ev_blur, sb));
+    if (no_overlap) DCS_HIP(hipEventRecord(ev_t[1], stream));      // FAST timing starts after the blur
 
     if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
                                 d_cell_count.p, stream))) return rc;
@@ -396,6 +400,7 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     DCS_HIP(hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming));
     for (auto& e : h->ev_t) DCS_HIP(hipEventCreate(&e));
     for (auto& e : h->ev_b) DCS_HIP(hipEventCreate(&e));
+    h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
     h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
     *out = h.release();

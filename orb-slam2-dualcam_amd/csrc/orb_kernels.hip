@@ -265,7 +265,15 @@ int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, i
 }
 
 // ------------------------------------------------------------------------------------- Gaussian blur
-constexpr int kBlurTW = 64, kBlurTH = 16;
+// Separable 7-tap, integer kernel {18,34,49,55,49,34,18} (getGaussianKernel(7,2)*256 rounded), rows then columns in
+// int32, out = sat_u8((acc + 32768) >> 16), BORDER_REFLECT_101.
+// Streaming design, no LDS: a thread owns 4 horizontally adjacent output pixels (one dword) of a 16-row strip. For
+// every input row it loads the 12 source bytes as 3 aligned dwords, forms the four 7-byte windows with
+// v_alignbyte and reduces them with 2 x v_dot4_u32_u8 each; the last 7 horizontal results per pixel stay in
+// VGPRs (fully unrolled ring), so the vertical pass is 7 v_mad per pixel and one packed dword store per row.
+constexpr int kBlurW = 256;      // output pixels per workgroup row (64 lanes x 4 px)
+constexpr int kBlurR = 32;       // output rows per thread
+constexpr int kBlurWaves = 4;    // waves per workgroup (stacked in y)
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -274,58 +282,154 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-// separable 7-tap, integer kernel {18,34,49,55,49,34,18} (getGaussianKernel(7,2)*256 rounded), rows then
-// columns in int32, out = sat_u8((acc + 32768) >> 16). grid.x enumerates the tiles of all levels.
-__global__ __launch_bounds__(256) void k_blur(LevelSet src, LevelSet dst, int n_tiles_total)
+template <bool FAST>
+__device__ __forceinline__ void blur_hrow(const uint8_t* __restrict__ row, int x0, int w, unsigned (&h)[4])
 {
-    __shared__ uint8_t s_in[(kBlurTH + 6) * (kBlurTW + 8)];
-    __shared__ uint16_t s_h[(kBlurTH + 6) * kBlurTW];
+    unsigned d0, d1, d2;
+    if (FAST) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(row + x0 - 4);
+        d0 = p[0]; d1 = p[1]; d2 = p[2];
+    } else {                                       // image edge (or unaligned level 0): byte gathers with reflection
+        unsigned b[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) b[k] = row[reflect101(x0 - 4 + k, w)];
+        d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    }
+    constexpr unsigned KA = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3
+    constexpr unsigned KB = 49u | (34u << 8) | (18u << 16);                 // taps 4..6 (+0)
+    h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0u, false) +
+           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, 0u, false);
+    h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0u, false) +
+           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, 0u, false);
+    h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0u, false) +
+           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, 0u, false);
+    h[3] = __builtin_amdgcn_udot4(d1, KA, 0u, false) + __builtin_amdgcn_udot4(d2, KB, 0u, false);
+}
+
+// one 4-pixel-wide, kBlurR-row strip
+template <bool FAST>
+__device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ S, uint8_t* __restrict__ D, const LevelView& sv, const LevelView& dv,
+                                           int x0, int y0)
+{
+    unsigned ring[7][4];
+#pragma unroll
+    for (int r = 0; r < kBlurR + 6; ++r) {
+        const int yy = reflect101(y0 + r - 3, sv.h);
+        blur_hrow<FAST>(S + (size_t)yy * sv.pitch, x0, sv.w, ring[r % 7]);
+        if (r >= 6) {
+            const int y = y0 + r - 6;                 // output row: window = input rows r-6 .. r
+            unsigned packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // operands < 2^24: v_mad_u32_u24 chain (full-rate), 32-bit accumulate (max 257 * 65535)
+                unsigned acc = __umul24(55u, ring[(r - 3) % 7][i]);
+                acc = __umul24(18u, ring[(r - 6) % 7][i] + ring[r % 7][i]) + acc;
+                acc = __umul24(34u, ring[(r - 5) % 7][i] + ring[(r - 1) % 7][i]) + acc;
+                acc = __umul24(49u, ring[(r - 4) % 7][i] + ring[(r - 2) % 7][i]) + acc;
+                packed |= min(255u, (acc + 32768u) >> 16) << (8 * i);
+            }
+            if (y < dv.h) *reinterpret_cast<unsigned*>(D + (size_t)y * dv.pitch + x0) = packed;
+        }
+    }
+}
+
+__device__ __forceinline__ bool level_aligned(const LevelView& v, int img)
+{ return ((reinterpret_cast<uintptr_t>(v.base + (size_t)img * v.img_stride) | (uintptr_t)v.pitch) & 3) == 0; }
+
+// interior strips: all 12 source bytes of every row lie inside the image row -> divergence-free dword path.
+// (an unaligned caller-owned level 0 takes the byte path for every lane instead)
+__global__ __launch_bounds__(64 * kBlurWaves) void k_blur(LevelSet src, LevelSet dst, int n_tiles_total)
+{
     int t = blockIdx.x, l = 0, tiles_x = 0;
     for (; l < src.nlevels; ++l) {
-        tiles_x = (src.lv[l].w + kBlurTW - 1) / kBlurTW;
-        const int n = tiles_x * ((src.lv[l].h + kBlurTH - 1) / kBlurTH);
+        tiles_x = (src.lv[l].w + kBlurW - 1) / kBlurW;
+        const int n = tiles_x * ((src.lv[l].h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
         if (t < n) break;
         t -= n;
     }
     if (l >= src.nlevels) return;
     const LevelView sv = src.lv[l], dv = dst.lv[l];
-    const int img = blockIdx.y, tid = threadIdx.x;
-    const int x0 = (t % tiles_x) * kBlurTW, y0 = (t / tiles_x) * kBlurTH;
+    const int img = blockIdx.y;
+    const int x0 = (t % tiles_x) * kBlurW + 4 * (int)threadIdx.x;
+    const int y0 = (t / tiles_x) * (kBlurR * kBlurWaves) + kBlurR * (int)threadIdx.y;
+    if (x0 >= sv.w || y0 >= sv.h) return;
     const uint8_t* S = sv.base + (size_t)img * sv.img_stride;
-    constexpr int IW = kBlurTW + 6, IP = kBlurTW + 8;
-    for (int i = tid; i < (kBlurTH + 6) * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
-        const int sy = reflect101(y0 + r - 3, sv.h), sx = reflect101(x0 + c - 3, sv.w);
-        s_in[r * IP + c] = S[(size_t)sy * sv.pitch + sx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &s_in[r * IP + c];
-        const int acc = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-        s_h[i] = (uint16_t)acc;                           // <= 255 * 257 = 65535
-    }
-    __syncthreads();
-    const int c = tid & 63, rq = tid >> 6;
     uint8_t* D = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
+    if (!level_aligned(sv, img)) return;                                          // k_blur_unaligned_l0
+    if (x0 >= 4 && x0 + 7 <= sv.w - 1) blur_strip<true>(S, D, sv, dv, x0, y0);     // edge columns: k_blur_edges
+}
+
+// caller-owned level 0 whose base / stride is not 4-byte aligned: byte path for every strip (rare; correctness only)
+__global__ __launch_bounds__(64) void k_blur_unaligned_l0(LevelSet src, LevelSet dst)
+{
+    const LevelView sv = src.lv[0], dv = dst.lv[0];
+    const int img = blockIdx.z;
+    if (level_aligned(sv, img)) return;
+    const int x0 = 4 * (blockIdx.x * 64 + (int)threadIdx.x), y0 = kBlurR * (int)blockIdx.y;
+    if (x0 >= sv.w || y0 >= sv.h) return;
+    blur_strip<false>(sv.base + (size_t)img * sv.img_stride, const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride, sv, dv, x0, y0);
+}
+
+// the (at most 3) dword columns per level whose 7-tap window crosses the left / right image border. Workgroup =
+// 122 output rows of one column: 128 threads each reduce ONE input row with the reflecting byte path into LDS, then
+// 122 threads run the vertical pass. No divergence, short dependency chains (this is ~2 % of the pixels).
+constexpr int kEdgeRows = 122;
+__global__ __launch_bounds__(128) void k_blur_edges(LevelSet src, LevelSet dst)
+{
+    __shared__ unsigned s_h[kEdgeRows + 6][4];
+    const int l = blockIdx.z % src.nlevels, img = blockIdx.z / src.nlevels, col = blockIdx.y;
+    const LevelView sv = src.lv[l], dv = dst.lv[l];
+    if (!level_aligned(sv, img)) return;                  // handled entirely by k_blur_unaligned_l0
+    const int y0 = blockIdx.x * kEdgeRows;
+    if (y0 >= sv.h) return;
+    // edge columns: x0 = 0 and the multiples of 4 in (w - 8, w)
+    const int last = ((sv.w - 1) / 4) * 4;
+    const int x0 = col == 0 ? 0 : (col == 1 ? last : last - 4);
+    if (x0 < 0 || x0 >= sv.w) return;
+    if (col > 0 && (x0 == 0 || (x0 >= 4 && x0 + 7 <= sv.w - 1))) return;   // interior, or duplicate of column 0
+    const uint8_t* S = sv.base + (size_t)img * sv.img_stride;
+    uint8_t* D = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
+    const int t = threadIdx.x;
+    {
+        const int yy = reflect101(y0 + t - 3, sv.h);
+        unsigned h[4];
+        blur_hrow<false>(S + (size_t)yy * sv.pitch, x0, sv.w, h);
+        s_h[t][0] = h[0]; s_h[t][1] = h[1]; s_h[t][2] = h[2]; s_h[t][3] = h[3];
+    }
+    __syncthreads();
+    const int y = y0 + t;
+    if (t < kEdgeRows && y < dv.h) {
+        unsigned packed = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = rq * 4 + k;
-        const uint16_t* p = &s_h[r * kBlurTW + c];
-        const int acc = 18 * (p[0] + p[6 * kBlurTW]) + 34 * (p[kBlurTW] + p[5 * kBlurTW]) + 49 * (p[2 * kBlurTW] + p[4 * kBlurTW]) + 55 * p[3 * kBlurTW];
-        const int v = min(255, (acc + 32768) >> 16);
-        if (y0 + r < dv.h && x0 + c < dv.w) D[(size_t)(y0 + r) * dv.pitch + x0 + c] = (uint8_t)v;
+        for (int i = 0; i < 4; ++i) {
+            unsigned acc = __umul24(55u, s_h[t + 3][i]);
+            acc = __umul24(18u, s_h[t][i] + s_h[t + 6][i]) + acc;
+            acc = __umul24(34u, s_h[t + 1][i] + s_h[t + 5][i]) + acc;
+            acc = __umul24(49u, s_h[t + 2][i] + s_h[t + 4][i]) + acc;
+            packed |= min(255u, (acc + 32768u) >> 16) << (8 * i);
+        }
+        *reinterpret_cast<unsigned*>(D + (size_t)y * dv.pitch + x0) = packed;
     }
 }
 
 int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStream_t s)
 {
-    int tiles = 0;
-    for (int l = 0; l < src.nlevels; ++l)
-        tiles += ((src.lv[l].w + kBlurTW - 1) / kBlurTW) * ((src.lv[l].h + kBlurTH - 1) / kBlurTH);
+    int tiles = 0, max_chunks = 1;
+    for (int l = 0; l < src.nlevels; ++l) {
+        tiles += ((src.lv[l].w + kBlurW - 1) / kBlurW) * ((src.lv[l].h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
+        max_chunks = max(max_chunks, (src.lv[l].h + kEdgeRows - 1) / kEdgeRows);
+    }
     if (tiles == 0) return DCS_OK;
-    hipLaunchKernelGGL(k_blur, dim3(tiles, n_images), dim3(256), 0, s, src, dst, tiles);
+    hipLaunchKernelGGL(k_blur, dim3(tiles, n_images), dim3(64, kBlurWaves), 0, s, src, dst, tiles);
     DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_blur_edges, dim3(max_chunks, 3, src.nlevels * n_images), dim3(128), 0, s, src, dst);
+    DCS_CHECK_LAUNCH();
+    if (((reinterpret_cast<uintptr_t>(src.lv[0].base) | (uintptr_t)src.lv[0].pitch | (uintptr_t)src.lv[0].img_stride) & 3) != 0) {
+        hipLaunchKernelGGL(k_blur_unaligned_l0, dim3((src.lv[0].w + 255) / 256, (src.lv[0].h + kBlurR - 1) / kBlurR, n_images), dim3(64), 0, s, src, dst);
+        DCS_CHECK_LAUNCH();
+    }
     return DCS_OK;
 }
 
