@@ -175,8 +175,10 @@ int dcs_orb::configure(int rows, int cols)
     for (int l = 1; l < L; ++l) {
         ResizeTable rt;
         rt.build(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h);
-        rtab[l].xofs = tab.size(); tab.insert(tab.end(), rt.xofs.begin(), rt.xofs.end());
-        rtab[l].xa = tab.size();   tab.insert(tab.end(), rt.xa.begin(), rt.xa.end());
+        while (tab.size() % 4) tab.push_back(0);                 // 8-byte aligned packed columns {sx, 0, a0, a1}
+        rtab[l].xofs = tab.size();
+        for (size_t x = 0; x < rt.xofs.size(); ++x) { tab.push_back(rt.xofs[x]); tab.push_back(0); tab.push_back(rt.xa[2 * x]); tab.push_back(rt.xa[2 * x + 1]); }
+        rtab[l].xa = tab.size();
         rtab[l].yofs = tab.size(); tab.insert(tab.end(), rt.yofs.begin(), rt.yofs.end());
         rtab[l].ya = tab.size();   tab.insert(tab.end(), rt.ya.begin(), rt.ya.end());
     }
@@ -293,8 +295,10 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     DCS_HIP(hipEventRecord(ev_blur, sb));
     if (no_overlap) DCS_HIP(hipEventRecord(ev_t[1], stream));      // FAST timing starts after the blur
 
+    int max_rw = 7, max_rh = 7;
+    for (const CellDesc& c : h_cells) { max_rw = std::max(max_rw, (int)c.rw); max_rh = std::max(max_rh, (int)c.rh); }
     if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                d_cell_count.p, stream))) return rc;
+                                d_cell_count.p, max_rw, max_rh, stream))) return rc;
     DCS_HIP(hipEventRecord(ev_t[2], stream));
     if ((rc = launch_compact(d_cells.p, d_level_cell_begin.p, L, n_images, n_cells, d_slots.p, g.n_slots, d_cell_count.p,
                              d_cell_off.p, d_lvl_total.p, d_lvl_off.p, d_dense.p, dense_cap, stream))) return rc;

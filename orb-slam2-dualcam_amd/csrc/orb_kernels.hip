@@ -25,159 +25,252 @@ __constant__ int8_t c_pattern[1024] = {
 int upload_pattern() { return DCS_OK; }   // statically initialised __constant__ data: nothing to do
 
 // ------------------------------------------------------------------------------------- resize
-// one thread = 4 horizontally adjacent destination pixels (one packed dword store)
-__global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, const int16_t* __restrict__ xofs,
-                                                const int16_t* __restrict__ xa, const int16_t* __restrict__ yofs,
-                                                const int16_t* __restrict__ ya)
+// cv::resize INTER_LINEAR 8UC1 (11-bit fixed point), streaming like the blur: a thread owns 4 adjacent destination
+// pixels (one dword) of a strip of destination rows. Its 4 column taps {sx, a0, a1} are fixed for the whole strip, so
+// each source row costs ONE 12-byte load (3 aligned dwords containing all 8 taps) + v_alignbyte extraction; the
+// horizontally interpolated row (4 ints) is cached in VGPRs because consecutive destination rows share source rows
+// at scale 1.2. No LDS, no barriers, no dependent table lookups in the row loop (row tables are wave-uniform).
+constexpr int kRsRowsPerThread = 8;
+
+struct ResizeCol { int16_t sx, pad, a0, a1; };
+
+__device__ __forceinline__ void resize_hrow(const uint8_t* __restrict__ row, bool aligned, const int (&o)[4], const int (&a0)[4],
+                                            const int (&a1)[4], int (&h)[4])
 {
-    const int img = blockIdx.z;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (dy >= dst.h || dx0 >= dst.w) return;
-    const uint8_t* S = src.base + (size_t)img * src.img_stride;
-    uint8_t* D = const_cast<uint8_t*>(dst.base) + (size_t)img * dst.img_stride + (size_t)dy * dst.pitch;
-    const int sy = yofs[dy];
-    const int sy0 = min(max(sy, 0), src.h - 1), sy1 = min(max(sy + 1, 0), src.h - 1);
-    const int b0 = ya[2 * dy], b1 = ya[2 * dy + 1];
-    const uint8_t* r0 = S + (size_t)sy0 * src.pitch;
-    const uint8_t* r1 = S + (size_t)sy1 * src.pitch;
-    uint32_t packed = 0;
+    unsigned d0, d1, d2;
+    if (aligned) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(row);
+        d0 = p[0]; d1 = p[1]; d2 = p[2];
+    } else {
+        unsigned b[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) b[k] = row[k];
+        d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int dx = dx0 + k;
-        if (dx < dst.w) {
-            const int sx = xofs[dx], sx1 = min(sx + 1, src.w - 1);
-            const int a0 = xa[2 * dx], a1 = xa[2 * dx + 1];
-            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
-            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xff) << (8 * k);
-        }
+        const int q = o[k] >> 2;                      // 0..2: which dword holds the first tap (window offset <= 11)
+        const unsigned lo = q == 0 ? d0 : (q == 1 ? d1 : d2), hi = q == 0 ? d1 : (q == 1 ? d2 : 0u);
+        const unsigned w = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o[k] & 3));
+        h[k] = (int)__umul24(w & 0xffu, (unsigned)a0[k]) + (int)__umul24((w >> 8) & 0xffu, (unsigned)a1[k]);
     }
-    *reinterpret_cast<uint32_t*>(D + dx0) = packed;     // pitch is a multiple of 64: always in-row
 }
 
-int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_xofs, const int16_t* d_xa,
+__global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, const ResizeCol* __restrict__ cols,
+                                                const int16_t* __restrict__ yofs, const int16_t* __restrict__ ya)
+{
+    const int img = blockIdx.z;
+    const int dx0 = (blockIdx.x * 64 + (int)threadIdx.x) * 4;
+    const int dy0 = (blockIdx.y * 4 + (int)threadIdx.y) * kRsRowsPerThread;
+    if (dx0 >= dst.w || dy0 >= dst.h) return;
+    const uint8_t* S = src.base + (size_t)img * src.img_stride;
+    uint8_t* D = const_cast<uint8_t*>(dst.base) + (size_t)img * dst.img_stride;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(S) | (uintptr_t)src.pitch) & 3) == 0 && src.pitch >= 12;
+    int o[4], a0[4], a1[4];
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const ResizeCol cc = cols[min(dx0 + k, dst.w - 1)];
+        // 12-byte window [base, base + 12) must hold every tap (offsets <= 11) and stay inside the row's storage
+        if (k == 0) base = aligned ? min((int)cc.sx & ~3, src.pitch - 12) : max(0, min((int)cc.sx, src.w - 12));
+        o[k] = cc.sx - base; a0[k] = cc.a0; a1[k] = cc.a1;
+        // single-tap columns (sx == sw-1) carry a1 == 0: the second byte of the window is multiplied by 0
+    }
+    const uint8_t* colbase = S + base;
+    int hA[4], hB[4];
+    int rowA = -1, rowB = -1;                           // source rows currently held in hA / hB
+    const int dy_end = min(dy0 + kRsRowsPerThread, dst.h);
+    for (int dy = dy0; dy < dy_end; ++dy) {
+        const int sy = yofs[dy];
+        const int sy0 = min(max(sy, 0), src.h - 1), sy1 = min(max(sy + 1, 0), src.h - 1);
+        if (sy0 != rowA) {
+            if (sy0 == rowB) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int t = hA[k]; hA[k] = hB[k]; hB[k] = t; }
+                const int t = rowA; rowA = rowB; rowB = t;
+            } else { resize_hrow(colbase + (size_t)sy0 * src.pitch, aligned, o, a0, a1, hA); rowA = sy0; }
+        }
+        if (sy1 == rowA) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hB[k] = hA[k];
+            rowB = rowA;
+        } else if (sy1 != rowB) { resize_hrow(colbase + (size_t)sy1 * src.pitch, aligned, o, a0, a1, hB); rowB = sy1; }
+        const int b0 = ya[2 * dy], b1 = ya[2 * dy + 1];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = (((b0 * (hA[k] >> 4)) >> 16) + ((b1 * (hB[k] >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(D + (size_t)dy * dst.pitch + dx0) = packed;     // pitch is a multiple of 64: in-row
+    }
+}
+
+int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_cols, const int16_t* d_unused,
                   const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s)
 {
-    dim3 block(64, 4, 1);
-    dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, n_images);
-    hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, dst, d_xofs, d_xa, d_yofs, d_ya);
+    (void)d_unused;
+    if ((double)src.w / dst.w > 2.0) { set_error("pyramid scale factor > 2 not supported by the resize kernel"); return DCS_ERR_UNSUPPORTED; }
+    dim3 grid((dst.w + 255) / 256, (dst.h + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread), n_images);
+    hipLaunchKernelGGL(k_resize, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
 
 // ------------------------------------------------------------------------------------- FAST
-constexpr int kRoiMax = 66;      // w_cell <= 59 (n_cols = floor(width/30)) -> ROI <= 65
-constexpr int kRoiPitch = 68;
+typedef short short2_t __attribute__((ext_vector_type(2)));
 
-// FAST-9/16 score of the pixel at c (LDS, row pitch kRoiPitch): max over the 16 contiguous 9-arcs of
-// the sign-consistent minimum |centre - ring|, minus 1 (== OpenCV cornerScore<16>; "corner at T"
-// <=> score >= T, so the score does not depend on the threshold).
-__device__ __forceinline__ int fast_score(const uint8_t* c)
+// FAST-9/16 score of the pixel at c (LDS bytes, row pitch P): max over the 16 contiguous 9-arcs of the sign-consistent
+// minimum |centre - ring|, minus 1 (== OpenCV cornerScore<16>; "corner at T" <=> score >= T, so the score does not
+// depend on the threshold). Both polarities ride in one packed register: lo16 = c - ring ("darker"), hi16 = ring - c.
+__device__ __forceinline__ int fast_score(const uint8_t* c, int P)
 {
-    constexpr int P = kRoiPitch;
-    constexpr int off[16] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
-                             -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1};
+    const int off[16] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
+                         -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1};
     const int v = c[0];
-    int d[16];
+    short2_t d[16], m2[16], m4[16], m8[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - (int)c[off[k]];
-    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+    for (int k = 0; k < 16; ++k) { const int r = c[off[k]]; d[k] = short2_t{(short)(v - r), (short)(r - v)}; }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+    for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    for (int k = 0; k < 16; ++k) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
-    int dark = -256, bright = 256;
+    for (int k = 0; k < 16; ++k) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+    short2_t best = short2_t{-256, -256};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        dark = max(dark, min(mn8[k], d[(k + 8) & 15]));        // all 9 ring pixels darker by > dark-1
-        bright = min(bright, max(mx8[k], d[(k + 8) & 15]));    // all 9 brighter by > -bright-1
-    }
-    return max(dark, -bright) - 1;
+    for (int k = 0; k < 16; ++k) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
+    return max((int)best.x, (int)best.y) - 1;
 }
 
-// one workgroup per (cell, image): ROI -> LDS, scores, strict 8-neighbour NMS inside the ROI's
-// detection area, per-cell threshold fallback, ordered (row-major) emission via wave ballots.
-__global__ __launch_bounds__(256) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells,
-                                                    int ini_th, int min_th, dcs_candidate* __restrict__ slots,
-                                                    size_t slots_per_image, int32_t* __restrict__ cell_count)
+// One wave per (cell, image) -- the reference's per-cell cv::FAST call (ORBextractor.cc:789-827):
+//   1. ROI -> LDS with aligned dword loads (byte loads when the level is not 4-byte aligned)
+//   2. necessary test on the 4 compass ring pixels at minTh (a 9-arc always covers >= 2 of them); survivors are
+//      compacted IN ROW-MAJOR ORDER with ballot + popcount prefix
+//   3. exact score only for the survivors (packed 16-bit min/max), written to an LDS score map
+//   4. strict 8-neighbour NMS inside the ROI's detection area, iniTh -> minTh fallback when the cell has no
+//      iniTh keypoint (vKeysCell.empty(), :812), ordered emission into the cell's fixed slot range.
+// LDS: px[rh][P] + score[rh][P] bytes + survivor list (u16), sized by the host for the largest cell.
+__global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
+                                                   dcs_candidate* __restrict__ slots, size_t slots_per_image,
+                                                   int32_t* __restrict__ cell_count, int P, int map_bytes)
 {
-    __shared__ uint8_t s_px[kRoiMax * kRoiPitch];
-    __shared__ uint8_t s_sc[kRoiMax * kRoiPitch];
-    __shared__ int s_wave[4];
-    const int cell = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* s_px = smem;
+    uint8_t* s_sc = smem + map_bytes;
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(smem + 2 * map_bytes);
+    const int cell = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
     const CellDesc cd = cells[cell];
     const int rw = cd.rw, rh = cd.rh;
     if (rw < 7 || rh < 7) {
-        if (tid == 0) cell_count[(size_t)img * n_cells + cell] = 0;
+        if (lane == 0) cell_count[(size_t)img * n_cells + cell] = 0;
         return;
     }
     const LevelView lv = L.lv[cd.level];
-    const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)cd.y0 * lv.pitch + cd.x0;
-    for (int i = tid; i < rw * rh; i += 256) {
-        const int y = i / rw, x = i - y * rw;
-        s_px[y * kRoiPitch + x] = src[(size_t)y * lv.pitch + x];
-        s_sc[y * kRoiPitch + x] = 0;
+    const uint8_t* img_base = lv.base + (size_t)img * lv.img_stride;
+    const int shift = cd.x0 & 3;
+    {   // ---- 1. ROI rows into LDS (pixel (x, y) of the ROI at s_px[y * P + shift + x]) and a zeroed score map
+        const bool aligned = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 3) == 0;
+        const int ndw = (shift + rw + 3) >> 2;
+        uint32_t* px_dw = reinterpret_cast<uint32_t*>(s_px);
+        const int Pdw = P >> 2;
+        if (aligned && ndw <= 16) {                 // 4 rows x 16 dword columns per wave pass (no divisions)
+            const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
+            const int c = lane & 15;
+            for (int r = lane >> 4; r < rh; r += 4)
+                if (c < ndw) px_dw[r * Pdw + c] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * lv.pitch + 4 * c);
+        } else if (aligned) {
+            const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
+            for (int i = lane; i < rh * ndw; i += 64) {
+                const int r = i / ndw, c = i - r * ndw;
+                px_dw[r * Pdw + c] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * lv.pitch + 4 * c);
+            }
+        } else {
+            const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + cd.x0;
+            for (int i = lane; i < rh * rw; i += 64) { const int r = i / rw, c = i - r * rw; s_px[r * P + shift + c] = src[(size_t)r * lv.pitch + c]; }
+        }
+        uint32_t* sc_dw = reinterpret_cast<uint32_t*>(s_sc);
+        for (int i = lane; i < rh * Pdw; i += 64) sc_dw[i] = 0;
     }
     __syncthreads();
+    const uint8_t* px = s_px + shift;
+    uint8_t* sc = s_sc + shift;
     const int dw = rw - 6, dh = rh - 6, ndet = dw * dh;
-    for (int p = tid; p < ndet; p += 256) {
-        const int y = 3 + p / dw, x = 3 + p % dw;
-        const int s = fast_score(&s_px[y * kRoiPitch + x]);
-        s_sc[y * kRoiPitch + x] = (uint8_t)max(s, 0);
+    // ---- 2. compass test + ordered compaction; survivors are stored as (y << 8 | x), ROI coordinates
+    int n_list = 0;
+    {
+        int y = 3 + lane / dw, x = 3 + lane % dw;            // pixel p = p0 + lane, advanced by 64 per round without dividing
+        const int step_y = 64 / dw, step_x = 64 % dw;
+        for (int p0 = 0; p0 < ndet; p0 += 64) {
+            bool pass = false;
+            if (p0 + lane < ndet) {
+                const uint8_t* c = px + y * P + x;
+                const int v = c[0], hi = v + min_th, lo = v - min_th;
+                const int r0 = c[3 * P], r4 = c[3], r8 = c[-3 * P], r12 = c[-3];
+                const int nb = (r0 > hi) + (r4 > hi) + (r8 > hi) + (r12 > hi);
+                const int nd = (r0 < lo) + (r4 < lo) + (r8 < lo) + (r12 < lo);
+                pass = nb >= 2 || nd >= 2;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) s_list[n_list + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((y << 8) | x);
+            n_list += __popcll(m);
+            y += step_y; x += step_x;
+            if (x >= dw + 3) { x -= dw; ++y; }
+        }
     }
     __syncthreads();
-    // keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } -- neighbours below T lose anyway
-    uint32_t f_min = 0, f_ini = 0;
+    // ---- 3. exact scores of the survivors
+    for (int i = lane; i < n_list; i += 64) {
+        const int yx = s_list[i], y = yx >> 8, x = yx & 255;
+        const int s = fast_score(px + y * P + x, P);
+        sc[y * P + x] = (uint8_t)max(s, 0);
+    }
+    __syncthreads();
+    // ---- 4. NMS: keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } (neighbours below T lose anyway)
+    unsigned long long f_min = 0, f_ini = 0;       // one bit per list round of this lane
     int it = 0;
-    for (int p = tid; p < ndet; p += 256, ++it) {
-        const int y = 3 + p / dw, x = 3 + p % dw;
-        const uint8_t* c = &s_sc[y * kRoiPitch + x];
+    for (int i = lane; i < n_list; i += 64, ++it) {
+        const int yx = s_list[i], y = yx >> 8, x = yx & 255;
+        const uint8_t* c = sc + y * P + x;
         const int s = c[0];
         if (s >= min_th) {
-            const bool mx = s > c[-1] && s > c[1] && s > c[-kRoiPitch - 1] && s > c[-kRoiPitch] && s > c[-kRoiPitch + 1] &&
-                            s > c[kRoiPitch - 1] && s > c[kRoiPitch] && s > c[kRoiPitch + 1];
-            if (mx) { f_min |= 1u << it; if (s >= ini_th) f_ini |= 1u << it; }
+            const bool mx = s > c[-1] && s > c[1] && s > c[-P - 1] && s > c[-P] && s > c[-P + 1] && s > c[P - 1] && s > c[P] && s > c[P + 1];
+            if (mx) { f_min |= 1ull << it; if (s >= ini_th) f_ini |= 1ull << it; }
         }
     }
-    const int any_ini = __syncthreads_or(f_ini != 0);     // vKeysCell.empty() after FAST(iniTh) ? (:812)
-    const uint32_t sel = any_ini ? f_ini : f_min;
-    const int n_it = (ndet + 255) >> 8;
-    const int wave = tid >> 6, lane = tid & 63;
+    const bool any_ini = __any(f_ini != 0);
+    const unsigned long long sel = any_ini ? f_ini : f_min;
     dcs_candidate* out = slots + (size_t)img * slots_per_image + cd.slot_base;
     int base = 0;
-    for (it = 0; it < n_it; ++it) {
-        const bool flag = (sel >> it) & 1u;
+    it = 0;
+    for (int i0 = 0; i0 < n_list; i0 += 64, ++it) {
+        const bool flag = (sel >> it) & 1ull;
         const unsigned long long m = __ballot(flag);
-        if (lane == 0) s_wave[wave] = __popcll(m);
-        __syncthreads();
-        int off = base + __popcll(m & ((1ull << lane) - 1ull));
-        int tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { const int c = s_wave[w]; if (w < wave) off += c; tot += c; }
+        const int off = base + __popcll(m & ((1ull << lane) - 1ull));
         if (flag && off < cd.cap) {
-            const int p = it * 256 + tid;
-            const int y = 3 + p / dw, x = 3 + p % dw;
+            const int yx = s_list[i0 + lane], y = yx >> 8, x = yx & 255;
             dcs_candidate o;
-            o.x = (int16_t)(x + cd.ox); o.y = (int16_t)(y + cd.oy); o.score = s_sc[y * kRoiPitch + x];
+            o.x = (int16_t)(x + cd.ox); o.y = (int16_t)(y + cd.oy); o.score = sc[y * P + x];
             out[off] = o;
         }
-        base += tot;
-        __syncthreads();
+        base += __popcll(m);
     }
-    if (tid == 0) cell_count[(size_t)img * n_cells + cell] = min(base, (int)cd.cap);
+    if (lane == 0) cell_count[(size_t)img * n_cells + cell] = min(base, (int)cd.cap);
 }
 
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
-                      int32_t* d_cell_count, hipStream_t s)
+                      int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s)
 {
     if (n_cells == 0) return DCS_OK;
-    hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, n_images), dim3(256), 0, s, levels, d_cells, n_cells,
-                       ini_th, min_th, d_slots, slots_per_image, d_cell_count);
+    const int P = (max_rw + 3 + 3 + 3) & ~3;                     // shift (<= 3) + row + slack, dword multiple
+    const int map_bytes = ((max_rh * P) + 15) & ~15;
+    const int list_bytes = (((max_rw - 6) * (max_rh - 6) * 2) + 15) & ~15;
+    const size_t shmem = (size_t)2 * map_bytes + list_bytes;
+    hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, n_images), dim3(64), shmem, s, levels, d_cells, n_cells,
+                       ini_th, min_th, d_slots, slots_per_image, d_cell_count, P, map_bytes);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
