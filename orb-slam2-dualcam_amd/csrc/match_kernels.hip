@@ -22,10 +22,13 @@ namespace dcs {
 
 struct Best { int b1, idx, b2; };
 
+// branch-free form of: if (d < b1) { b2 = b1; b1 = d; idx = j; } else if (d < b2) b2 = d;   (ORBmatcher.cc:221-230)
 __device__ __forceinline__ void best_update(Best& s, int dist, int j)
 {
-    if (dist < s.b1) { s.b2 = s.b1; s.b1 = dist; s.idx = j; }
-    else if (dist < s.b2) { s.b2 = dist; }
+    const bool lt1 = dist < s.b1;
+    s.b2 = lt1 ? s.b1 : min(s.b2, dist);
+    s.idx = lt1 ? j : s.idx;
+    s.b1 = min(s.b1, dist);
 }
 
 // merge of partial results over disjoint candidate sets (any order)

@@ -38,6 +38,7 @@ struct DescribeParams {
     float scale[kMaxLevels];
     int scaled_patch[kMaxLevels];
     int umax[kHalfPatch + 1];
+    unsigned long long umax_packed;      // umax[v] in bits [4v, 4v+4)
     // device-quadtree mode: keypoints of (image, level) live at sel[image * out_per_image + out_base[level] ...]
     int out_base[kMaxLevels];
     int out_per_image, nlevels;

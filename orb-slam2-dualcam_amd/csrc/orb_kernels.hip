@@ -170,13 +170,19 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     }
     const LevelView lv = L.lv[cd.level];
     const uint8_t* img_base = lv.base + (size_t)img * lv.img_stride;
-    const int shift = cd.x0 & 3;
+    const int shift = cd.x0 & 15;                  // ROI columns start at byte `shift` of 16-byte aligned LDS rows
     {   // ---- 1. ROI rows into LDS (pixel (x, y) of the ROI at s_px[y * P + shift + x]) and a zeroed score map
         const bool aligned = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 3) == 0;
+        const bool aligned16 = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 15) == 0;
         const int ndw = (shift + rw + 3) >> 2;
         uint32_t* px_dw = reinterpret_cast<uint32_t*>(s_px);
         const int Pdw = P >> 2;
-        if (aligned && ndw <= 16) {                 // 4 rows x 16 dword columns per wave pass (no divisions)
+        if (aligned16 && shift + rw <= 64 && (P & 15) == 0) {        // 16 rows x 4 x 16-byte columns per wave pass
+            const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
+            const int c = lane & 3, nq = (shift + rw + 15) >> 4;
+            for (int r = lane >> 2; r < rh; r += 16)
+                if (c < nq) *reinterpret_cast<uint4*>(s_px + r * P + 16 * c) = *reinterpret_cast<const uint4*>(src + (size_t)r * lv.pitch + 16 * c);
+        } else if (aligned && ndw <= 16) {          // 4 rows x 16 dword columns per wave pass (no divisions)
             const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
             const int c = lane & 15;
             for (int r = lane >> 4; r < rh; r += 4)
@@ -265,7 +271,7 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
                       int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s)
 {
     if (n_cells == 0) return DCS_OK;
-    const int P = (max_rw + 3 + 3 + 3) & ~3;                     // shift (<= 3) + row + slack, dword multiple
+    const int P = (max_rw + 15 + 15) & ~15;                      // shift (<= 15) + row, rounded to 16 bytes
     const int map_bytes = ((max_rh * P) + 15) & ~15;
     const int list_bytes = (((max_rw - 6) * (max_rh - 6) * 2) + 15) & ~15;
     const size_t shmem = (size_t)2 * map_bytes + list_bytes;
@@ -312,34 +318,37 @@ __global__ __launch_bounds__(256) void k_level_scan(const int32_t* __restrict__ 
     if (threadIdx.x == 0) lvl_total[img * nlevels + l] = running;
 }
 
-// grid (nlevels, n_images): global base of this (image, level) = sum of earlier totals, then gather
-__global__ __launch_bounds__(256) void k_gather(const CellDesc* __restrict__ cells, const int32_t* __restrict__ level_cell_begin,
-                                                int nlevels, int n_images, int n_cells, const dcs_candidate* __restrict__ slots,
-                                                size_t slots_per_image, const int32_t* __restrict__ cell_count,
-                                                const int32_t* __restrict__ cell_off, const int32_t* __restrict__ lvl_total,
-                                                int32_t* __restrict__ lvl_off, dcs_candidate* __restrict__ dense, size_t dense_cap)
+// single block: exclusive scan of the (image, level) totals -> lvl_off[n_all + 1]
+__global__ __launch_bounds__(256) void k_lvl_offsets(const int32_t* __restrict__ lvl_total, int n_all, int32_t* __restrict__ lvl_off)
 {
     __shared__ int s_tmp[4];
-    const int l = blockIdx.x, img = blockIdx.y;
-    const int me = img * nlevels + l, n_all = n_images * nlevels;
-    int part = 0;
-    for (int j = threadIdx.x; j < me; j += 256) part += lvl_total[j];
-    int base;
-    (void)block_exclusive_scan_256(part, s_tmp, &base);
-    const int mine = lvl_total[me];
-    if (threadIdx.x == 0) {
-        lvl_off[me] = base;
-        if (me == n_all - 1) lvl_off[n_all] = base + mine;
+    int running = 0;
+    for (int c0 = 0; c0 < n_all; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        const int v = c < n_all ? lvl_total[c] : 0;
+        int tot;
+        const int ex = block_exclusive_scan_256(v, s_tmp, &tot);
+        if (c < n_all) lvl_off[c] = running + ex;
+        running += tot;
     }
-    const int cb = level_cell_begin[l], ce = level_cell_begin[l + 1];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c = cb + wave; c < ce; c += 4) {
-        const int n = cell_count[(size_t)img * n_cells + c];
-        const size_t dst0 = (size_t)base + cell_off[(size_t)img * n_cells + c];
-        const dcs_candidate* src = slots + (size_t)img * slots_per_image + cells[c].slot_base;
-        for (int k = lane; k < n; k += 64)
-            if (dst0 + k < dense_cap) dense[dst0 + k] = src[k];
-    }
+    if (threadIdx.x == 0) lvl_off[n_all] = running;
+}
+
+// one wave per (cell, image): copy the cell's slots to their place in the dense, emission-ordered array
+__global__ __launch_bounds__(256) void k_gather(const CellDesc* __restrict__ cells, int nlevels, int n_cells,
+                                                const dcs_candidate* __restrict__ slots, size_t slots_per_image,
+                                                const int32_t* __restrict__ cell_count, const int32_t* __restrict__ cell_off,
+                                                const int32_t* __restrict__ lvl_off, dcs_candidate* __restrict__ dense, size_t dense_cap)
+{
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), img = blockIdx.y, lane = threadIdx.x & 63;
+    if (c >= n_cells) return;
+    const int n = cell_count[(size_t)img * n_cells + c];
+    if (n == 0) return;
+    const CellDesc cd = cells[c];
+    const size_t dst0 = (size_t)lvl_off[img * nlevels + cd.level] + cell_off[(size_t)img * n_cells + c];
+    const dcs_candidate* src = slots + (size_t)img * slots_per_image + cd.slot_base;
+    for (int k = lane; k < n; k += 64)
+        if (dst0 + k < dense_cap) dense[dst0 + k] = src[k];
 }
 
 int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, int nlevels, int n_images, int n_cells,
@@ -350,10 +359,13 @@ int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, i
     hipLaunchKernelGGL(k_level_scan, dim3(nlevels, n_images), dim3(256), 0, s, d_level_cell_begin, nlevels, n_cells,
                        d_cell_count, d_cell_off, d_lvl_total);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_gather, dim3(nlevels, n_images), dim3(256), 0, s, d_cells, d_level_cell_begin, nlevels,
-                       n_images, n_cells, d_slots, slots_per_image, d_cell_count, d_cell_off, d_lvl_total, d_lvl_off,
-                       d_dense, dense_cap);
+    hipLaunchKernelGGL(k_lvl_offsets, dim3(1), dim3(256), 0, s, d_lvl_total, n_images * nlevels, d_lvl_off);
     DCS_CHECK_LAUNCH();
+    if (n_cells) {
+        hipLaunchKernelGGL(k_gather, dim3((n_cells + 3) / 4, n_images), dim3(256), 0, s, d_cells, nlevels, n_cells, d_slots, slots_per_image,
+                           d_cell_count, d_cell_off, d_lvl_off, d_dense, dense_cap);
+        DCS_CHECK_LAUNCH();
+    }
     return DCS_OK;
 }
 
@@ -551,7 +563,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 constexpr int kPatchR = 18;                 // rotated pattern reach: max radius 18.38 -> |coord| <= 18
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
-constexpr int kPatchDw = 11;                // dwords per staged row (44 bytes cover 37 + 3 alignment bytes)
+constexpr int kPatchDw = 16;                // dwords per staged row: 4 x 16 B cover 37 bytes + <= 15 alignment bytes
 
 // one wave per keypoint; 4 keypoints per workgroup. grid (ceil(max_per_image/4), n_images)
 __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
@@ -559,7 +571,9 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
                                                   const int32_t* __restrict__ lvl_cnt, dcs_keypoint* __restrict__ kp_out,
                                                   uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out)
 {
-    __shared__ uint32_t s_patch[4][kPatchRows * kPatchDw];
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][kPatchRows * kPatchDw];
+    __shared__ char4 s_pattern[256];
+    s_pattern[threadIdx.x] = reinterpret_cast<const char4*>(c_pattern)[threadIdx.x];    // 1 KB table, one coalesced load
     const int img = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     int n_img, src = 0;
@@ -584,15 +598,33 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
     const SelKp k = sel[src];
     const int x = k.x, y = k.y, level = k.level;
 
-    // ---- IC_Angle on the unblurred level: moments over the umax disc (exact int32)
+    // ---- IC_Angle on the unblurred level: moments over the umax disc (exact int32). Rows are read as aligned
+    // dwords (9 per row cover x-15..x+15); umax[] rides in a 64-bit immediate (4 bits per row).
     const LevelView rv = raw.lv[level];
-    const uint8_t* rc = rv.base + (size_t)img * rv.img_stride + (size_t)y * rv.pitch + x;
+    const uint8_t* rimg = rv.base + (size_t)img * rv.img_stride;
     int m10 = 0, m01 = 0;
-    for (int idx = lane; idx < kPatchSize * kPatchSize; idx += 64) {
-        const int v = idx / kPatchSize - kHalfPatch, u = idx % kPatchSize - kHalfPatch;
-        if (abs(u) <= prm.umax[abs(v)]) {
-            const int val = rc[v * rv.pitch + u];
-            m10 += u * val; m01 += v * val;
+    if (((reinterpret_cast<uintptr_t>(rimg) | (uintptr_t)rv.pitch) & 15) == 0) {
+        const int xs = (x - kHalfPatch) & ~15;               // 3 x 16 B cover x-15 .. x+15 (31 + <= 15 bytes)
+        for (int idx = lane; idx < kPatchSize * 3; idx += 64) {
+            const int r = idx / 3, c = idx - r * 3;
+            const int v = r - kHalfPatch, um = (int)((prm.umax_packed >> (4 * abs(v))) & 15ull);
+            const uint4 q = *reinterpret_cast<const uint4*>(rimg + (size_t)(y + v) * rv.pitch + xs + 16 * c);
+            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+            const int u0 = xs + 16 * c - x;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const int u = u0 + b, val = (int)((w4[b >> 2] >> (8 * (b & 3))) & 0xffu);
+                if (abs(u) <= um) { m10 += u * val; m01 += v * val; }
+            }
+        }
+    } else {
+        const uint8_t* rc = rimg + (size_t)y * rv.pitch + x;
+        for (int idx = lane; idx < kPatchSize * kPatchSize; idx += 64) {
+            const int v = idx / kPatchSize - kHalfPatch, u = idx % kPatchSize - kHalfPatch;
+            if (abs(u) <= (int)((prm.umax_packed >> (4 * abs(v))) & 15ull)) {
+                const int val = rc[v * rv.pitch + u];
+                m10 += u * val; m01 += v * val;
+            }
         }
     }
 #pragma unroll
@@ -602,11 +634,11 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
     // ---- stage the 37x37 blurred neighbourhood in LDS with aligned dword loads
     const LevelView bv = blurred.lv[level];
     const uint8_t* bimg = bv.base + (size_t)img * bv.img_stride;
-    const int xs = (x - kPatchR) & ~3, shift = (x - kPatchR) & 3;
+    const int xs = (x - kPatchR) & ~15, shift = (x - kPatchR) & 15;       // blurred slab: 256-B aligned levels, pitch % 64 == 0
     uint32_t* patch = s_patch[wave];
-    for (int idx = lane; idx < kPatchRows * kPatchDw; idx += 64) {
-        const int r = idx / kPatchDw, c = idx - r * kPatchDw;
-        patch[idx] = *reinterpret_cast<const uint32_t*>(bimg + (size_t)(y - kPatchR + r) * bv.pitch + xs + 4 * c);
+    for (int idx = lane; idx < kPatchRows * 4; idx += 64) {
+        const int r = idx >> 2, c = idx & 3;
+        reinterpret_cast<uint4*>(patch)[idx] = *reinterpret_cast<const uint4*>(bimg + (size_t)(y - kPatchR + r) * bv.pitch + xs + 16 * c);
     }
     __syncthreads();
     if (!active) return;
@@ -620,7 +652,7 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int t = it * 64 + lane;
-        const char4 pt = reinterpret_cast<const char4*>(c_pattern)[t];
+        const char4 pt = s_pattern[t];
         const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
