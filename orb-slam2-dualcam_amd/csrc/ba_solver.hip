@@ -379,28 +379,47 @@ __global__ __launch_bounds__(256) void k_bschur(const int32_t* __restrict__ ps_o
 // 128 VGPRs; 16 waves x 128 VGPRs = the CU's whole 512 KB register file). Column k is broadcast through a double-buffered LDS
 // vector (one barrier per column), every thread applies the rank-1 update to its own elements, then the same
 // distribution does the forward / diagonal / backward substitutions. One launch replaces 2 * n/16 + 1.
+// 1/d to full double precision without the IEEE division sequence: v_rcp_f64 + two Newton steps
+__device__ __forceinline__ double fast_recip(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 template <int NBLK>
 __global__ __launch_bounds__(1024) void k_ldlt_reg(const double* __restrict__ S, int ld, int n, const double* __restrict__ b,
-                                                   double* __restrict__ x, double* __restrict__ ok)
+                                                   double* __restrict__ x, double* __restrict__ ok, int dbg_skip)
 {
     constexpr int NS = NBLK * (NBLK + 1) / 2;
 #define SLOT(bi, bj) ((bi) * ((bi) + 1) / 2 + (bj))
     __shared__ double col[2][NBLK * 32];
     __shared__ double y[NBLK * 32];
+    __shared__ double s_invd[NBLK * 32 + 2];       // 1/d_k for every pivot (columns stay unscaled: L[i][k] = A[i][k] / d_k)
     __shared__ double Lkk[32][33];
-    __shared__ double part[16][NBLK * 32];
-    const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31, wave = tid >> 6, lane = tid & 63;
+    __shared__ double s_yk[2];
+    // thread (ti, tj): a wave holds TWO columns tj = 2 wave + (lane >> 5) and all 32 row residues ti = lane & 31, so a
+    // pivot column is published by a single wave (LDS instruction issue, not bytes, bounds each step)
+    const int tid = threadIdx.x, ti = tid & 31, tj = tid >> 5, wave = tid >> 6, lane = tid & 63;
     double a[NS];
 #pragma unroll
     for (int bi = 0; bi < NBLK; ++bi)
 #pragma unroll
         for (int bj = 0; bj <= bi; ++bj) {
             const int i = bi * 32 + ti, j = bj * 32 + tj;
-            a[SLOT(bi, bj)] = (i < n && j < n) ? S[(size_t)i * ld + j] : (i == j ? 1.0 : 0.0);
+            a[SLOT(bi, bj)] = (i < n && j < n) ? S[(size_t)j * ld + i] : (i == j ? 1.0 : 0.0);   // S is symmetric: coalesced along i
         }
-    if (tid < NBLK * 32) y[tid] = tid < n ? b[tid] : 0.0;
-    bool good = true;
-    // Factorisation with the forward substitution L y = b fused in (b rides along as an extra column).
+    // The right-hand side rides along in the registers of ONE wave (wave 15: lane l owns rows l, l+64, ...), so the
+    // forward substitution L y = b is fused into the factorisation and costs the other 15 waves nothing.
+    constexpr int NY = NBLK / 2;
+    double yr[NY];
+    const bool ywave = wave == 15;
+#pragma unroll
+    for (int q = 0; q < NY; ++q) { const int i = q * 64 + lane; yr[q] = (ywave && i < n) ? b[i] : 0.0; }
+    // Look-ahead: the owners of A[k+1][k+1] and y[k+1] publish 1/d and y right after their own update in step k.
+    if (tid == 0) { const double d0 = a[SLOT(0, 0)]; s_invd[0] = fast_recip(d0); if (d0 == 0.0 || !isfinite(d0)) *ok = 0.0; }
+    if (tid == 960) s_yk[0] = yr[0];
     // kb (32-column block of the pivot) is a compile-time constant in every unrolled copy of the body, so all
     // register-array indices are static; kt walks the columns of the block at run time. One barrier per column.
 #pragma unroll
@@ -408,85 +427,92 @@ __global__ __launch_bounds__(1024) void k_ldlt_reg(const double* __restrict__ S,
 #pragma nounroll
         for (int kt = 0; kt < 32; ++kt) {
             const int k = kb * 32 + kt;
-            if (k >= n) break;
+            if (k >= n || (dbg_skip & 1)) break;
             double* cb = col[k & 1];
             if (tj == kt) {
 #pragma unroll
                 for (int bi = kb; bi < NBLK; ++bi) cb[bi * 32 + ti] = a[SLOT(bi, kb)];
             }
             __syncthreads();
-            const double d = cb[k];
-            if (d == 0.0 || !isfinite(d)) good = false;
-            const double invd = 1.0 / d;
-            double ci[NBLK], cj[NBLK];
+            const double invd = s_invd[k];
+            double ci[NBLK], lj[NBLK];
 #pragma unroll
-            for (int bb = kb; bb < NBLK; ++bb) { ci[bb] = cb[bb * 32 + ti]; cj[bb] = cb[bb * 32 + tj] * invd; }
+            for (int bb = kb; bb < NBLK; ++bb) { ci[bb] = cb[bb * 32 + ti]; lj[bb] = cb[bb * 32 + tj] * invd; }
+            const int kn = k + 1, knt = kn & 31;
             if (tj > kt) {                                // rest of the pivot's own column block
-                if (ti >= tj) a[SLOT(kb, kb)] -= ci[kb] * cj[kb];
+                if (ti >= tj) a[SLOT(kb, kb)] = fma(-ci[kb], lj[kb], a[SLOT(kb, kb)]);
 #pragma unroll
-                for (int bi = kb + 1; bi < NBLK; ++bi) a[SLOT(bi, kb)] -= ci[bi] * cj[kb];
+                for (int bi = kb + 1; bi < NBLK; ++bi) a[SLOT(bi, kb)] = fma(-ci[bi], lj[kb], a[SLOT(bi, kb)]);
+            }
+            if (kn < n && kt < 31 && ti == knt && tj == knt) {          // next pivot lives in this block column
+                const double dn = a[SLOT(kb, kb)];
+                s_invd[kn] = fast_recip(dn);
+                if (dn == 0.0 || !isfinite(dn)) *ok = 0.0;
+            }
+            if (ywave) {                                  // forward substitution: y[i] -= (A[i][k] / d_k) y[k], rows below k
+                const double f = s_yk[k & 1] * invd;
+                double ynext = 0;
+#pragma unroll
+                for (int q = 0; q < NY; ++q) {
+                    const int i = q * 64 + lane;
+                    if (i > k && i < n) yr[q] = fma(-cb[i], f, yr[q]);
+                    if (i == kn) ynext = yr[q];
+                }
+                if ((kn & 63) == lane && kn < n) s_yk[kn & 1] = ynext;
             }
 #pragma unroll
             for (int bj = kb + 1; bj < NBLK; ++bj) {      // column blocks to the right: no column predicate needed
-                if (ti >= tj) a[SLOT(bj, bj)] -= ci[bj] * cj[bj];
+                if (ti >= tj) a[SLOT(bj, bj)] = fma(-ci[bj], lj[bj], a[SLOT(bj, bj)]);
 #pragma unroll
-                for (int bi = bj + 1; bi < NBLK; ++bi) a[SLOT(bi, bj)] -= ci[bi] * cj[bj];
+                for (int bi = bj + 1; bi < NBLK; ++bi) a[SLOT(bi, bj)] = fma(-ci[bi], lj[bj], a[SLOT(bi, bj)]);
             }
-            if (tj == kt) {                               // column k becomes L[:,k]; apply it to y (rows below k)
-                const double yk = y[k];
-#pragma unroll
-                for (int bi = kb; bi < NBLK; ++bi) {
-                    if (bi * 32 + ti > k) { const double l = ci[bi] * invd; a[SLOT(bi, kb)] = l; y[bi * 32 + ti] -= l * yk; }
-                }
+            if (kn < n && kt == 31 && kb + 1 < NBLK && ti == 0 && tj == 0) {   // next pivot heads the next block column
+                const double dn = a[SLOT(kb + 1 < NBLK ? kb + 1 : kb, kb + 1 < NBLK ? kb + 1 : kb)];
+                s_invd[kn] = fast_recip(dn);
+                if (dn == 0.0 || !isfinite(dn)) *ok = 0.0;
             }
         }
     }
-    __syncthreads();
-    if (ti == tj) {
+    if (ywave) {
 #pragma unroll
-        for (int bi = 0; bi < NBLK; ++bi) { const int i = bi * 32 + ti; if (i < n) y[i] /= a[SLOT(bi, bi)]; }
+        for (int q = 0; q < NY; ++q) y[q * 64 + lane] = yr[q];
     }
     __syncthreads();
-    // Backward substitution L^T x = z, one 32-column block per round: diagonal triangle by a single wave in LDS,
-    // then the rows of this block are eliminated from all earlier blocks with a fixed-order reduction over the waves.
-    volatile double* yv = y;
+    if (tid < n) y[tid] *= s_invd[tid];              // z = D^-1 y
+    __syncthreads();
+    // Backward substitution L^T x = z with L[i][j] = A[i][j] * invd[j], one 32-column block per round: the diagonal
+    // triangle is solved by wave 0 with x in registers (pivot broadcast by v_readlane, rows prefetched from LDS), then
+    // the rows of this block are eliminated from all earlier blocks with a fixed-order reduction over the waves.
 #pragma unroll
     for (int kb = NBLK - 1; kb >= 0; --kb) {
-        if (kb * 32 >= n) continue;
+        if (kb * 32 >= n || (dbg_skip & 2)) continue;
         Lkk[ti][tj] = a[SLOT(kb, kb)];
         __syncthreads();
         if (wave == 0) {
-            volatile double(*Lv)[33] = Lkk;
-            for (int kt = 31; kt >= 0; --kt) {
-                const int k = kb * 32 + kt;
-                if (k < n) {
-                    const double xk = yv[k];
-                    if (lane < kt) yv[kb * 32 + lane] -= Lv[kt][lane] * xk;
-                }
-                __builtin_amdgcn_wave_barrier();
+            double xv = lane < 32 ? y[kb * 32 + lane] : 0.0;
+            const double sc = lane < 32 ? s_invd[kb * 32 + lane] : 0.0;      // column scaling of L
+            for (int kt = 31; kt >= 1; --kt) {
+                const double lkj = lane < kt ? Lkk[kt][lane] * sc : 0.0;     // independent of x: the loads pipeline
+                const int lo = __builtin_amdgcn_readlane(__double2loint(xv), kt), hi = __builtin_amdgcn_readlane(__double2hiint(xv), kt);
+                const double xk = __hiloint2double(hi, lo);
+                if (kb * 32 + kt < n) xv = fma(-lkj, xk, xv);
             }
+            if (lane < 32) y[kb * 32 + lane] = xv;
         }
         __syncthreads();
         if (kb > 0) {
             const double xi = y[kb * 32 + ti];
 #pragma unroll
             for (int bj = 0; bj < kb; ++bj) {
-                double pv = a[SLOT(kb, bj)] * xi;          // L[32 kb + ti][32 bj + tj] * x[32 kb + ti]
-                pv += __shfl_xor(pv, 32);                  // the wave's two rows
-                if (lane < 32) part[wave][bj * 32 + tj] = pv;
-            }
-            __syncthreads();
-            if (tid < kb * 32) {
-                double sacc = 0;
+                double pv = a[SLOT(kb, bj)] * xi;          // A[32 kb + ti][32 bj + tj] * x[32 kb + ti]
 #pragma unroll
-                for (int w = 0; w < 16; ++w) sacc += part[w][tid];
-                y[tid] -= sacc;
+                for (int d = 1; d < 32; d <<= 1) pv += __shfl_xor(pv, d);     // sum over the 32 rows ti (one half-wave)
+                if (ti == 0) y[bj * 32 + tj] = fma(-pv, s_invd[bj * 32 + tj], y[bj * 32 + tj]);
             }
             __syncthreads();
         }
     }
     if (tid < n) x[tid] = y[tid];
-    if (!good && tid == 0) *ok = 0.0;
 #undef SLOT
 }
 
@@ -822,7 +848,13 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     double* h_scal = nullptr;
     DCS_HIP(hipHostMalloc((void**)&h_scal, 64));
     struct HostFree { void* p; ~HostFree() { (void)hipHostFree(p); } } hf{h_scal};
-    const bool force_blocked = getenv("DCS_BA_FORCE_BLOCKED_LDLT") != nullptr;   // test hook: exercise the MFMA fallback at small n
+    const bool force_blocked = getenv("DCS_BA_FORCE_BLOCKED_LDLT") != nullptr;
+    const bool trace_t = getenv("DCS_BA_TRACE") != nullptr;
+    const int dbg_skip = getenv("DCS_BA_DBG_SKIP") ? atoi(getenv("DCS_BA_DBG_SKIP")) : 0;   // timing experiments only
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    const auto t_call0 = now();
+    double t_build = 0, t_sync = 0;   // test hook: exercise the MFMA fallback at small n
 
     hipStream_t st;
     DCS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -852,7 +884,9 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
 
     auto run_round = [&](int round, int iters, int robust) -> int {
         Round r;
+        const auto tb0 = now();
         build_round(pb, active, r);
+        t_build += ms_since(tb0);
         if (r.n_active == 0) return DCS_OK;
         DCS_HIP(hipMemcpyAsync(d_active, active.data(), E, hipMemcpyHostToDevice, st));
         DCS_HIP(hipMemcpyAsync(d_pose_idx, r.pose_idx.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
@@ -916,7 +950,7 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
                     hipLaunchKernelGGL(k_bschur, dim3(r.np), dim3(256), 0, st, d_ps_off, d_ps_edges, d_epoint, d_Hpl, d_db, d_bp, d_bsch);
                     DCS_CHECK_LAUNCH();
                     if (use_reg) {
-                        hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(1), dim3(1024), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3);
+                        hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(1), dim3(1024), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3, dbg_skip);
                         DCS_CHECK_LAUNCH();
                     } else {
                         for (int k0 = 0; k0 < n_pad; k0 += kNB) {
@@ -940,7 +974,9 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
                 hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, st, n, d_xp, d_bp, L, d_pt_off, d_xl, d_bl, lambda, d_scal + 1);
                 DCS_CHECK_LAUNCH();
                 DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 32, hipMemcpyDeviceToHost, st));
+                const auto ts0 = now();
                 DCS_HIP(hipStreamSynchronize(st));
+                t_sync += ms_since(ts0);
                 ++res->n_trials[round];
                 double tempChi = h_scal[0];
                 if (h_scal[3] == 0.0) tempChi = std::numeric_limits<double>::max();
@@ -991,6 +1027,9 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     DCS_HIP(hipStreamSynchronize(st));
     if (res->edge_level1) memcpy(res->edge_level1, level1.data(), E);
     res->gpu_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_opt0).count();
+    if (trace_t)
+        fprintf(stderr, "[dcs_ba] total %.3f ms: setup %.3f, optimise %.3f (build_round %.3f, waiting on GPU in trial syncs %.3f)\n", ms_since(t_call0),
+                ms_since(t_call0) - res->gpu_ms, (double)res->gpu_ms, t_build, t_sync);
     return DCS_OK;
 }
 
