@@ -200,7 +200,18 @@ __global__ __launch_bounds__(256) void k_linearize(EdgeArrays ed, int E, const d
                                                    double* __restrict__ cpoint, double* __restrict__ cpose, double* __restrict__ Hpl)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E || !ed.active[e]) return;
+    if (e >= E) return;
+    if (!ed.active[e]) {                           // level-1 edge: adds nothing to any block (the CSR lists still name it)
+        double* cp = cpoint + (size_t)e * 9;
+        for (int i = 0; i < 9; ++i) cp[i] = 0;
+        if (pose_idx[ed.pose[e]] >= 0) {
+            double* cq = cpose + (size_t)e * 27;
+            for (int i = 0; i < 27; ++i) cq[i] = 0;
+            double* h = Hpl + (size_t)e * 18;
+            for (int i = 0; i < 18; ++i) h[i] = 0;
+        }
+        return;
+    }
     const DCam& c = cams.c[ed.cam[e]];
     const double* T = poses + 7 * ed.pose[e];
     double pc[3];
@@ -242,15 +253,20 @@ __global__ __launch_bounds__(256) void k_linearize(EdgeArrays ed, int E, const d
 
 // thread per point: sums its edges' contributions (CSR over active edges). Hll full 3x3, bl.
 __global__ __launch_bounds__(256) void k_reduce_point(int L, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
-                                                      const double* __restrict__ cpoint, double* __restrict__ Hll, double* __restrict__ bl)
+                                                      const uint8_t* __restrict__ e_active, const double* __restrict__ cpoint,
+                                                      double* __restrict__ Hll, double* __restrict__ bl, uint8_t* __restrict__ pt_active)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= L) return;
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int n_act = 0;
     for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
-        const double* c = cpoint + (size_t)pt_edges[k] * 9;
+        const int e = pt_edges[k];
+        n_act += e_active[e];
+        const double* c = cpoint + (size_t)e * 9;
         for (int i = 0; i < 9; ++i) a[i] += c[i];
     }
+    pt_active[l] = n_act > 0;                       // a landmark without active edges is not part of this round
     double* H = Hll + (size_t)l * 9;
     H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
     bl[3 * l] = a[6]; bl[3 * l + 1] = a[7]; bl[3 * l + 2] = a[8];
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(256) void k_reduce_pose(const int32_t* __restrict__
 }
 
 // max |diagonal| over pose and landmark blocks (computeLambdaInit). single block.
-__global__ __launch_bounds__(256) void k_max_diag(int np, const double* __restrict__ Hpp, int L, const int32_t* __restrict__ pt_off,
+__global__ __launch_bounds__(256) void k_max_diag(int np, const double* __restrict__ Hpp, int L, const uint8_t* __restrict__ pt_active,
                                                   const double* __restrict__ Hll, double* __restrict__ out)
 {
     __shared__ double s[256];
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(256) void k_max_diag(int np, const double* __restri
     for (int i = threadIdx.x; i < np * 6; i += 256) m = fmax(m, fabs(Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
     for (int i = threadIdx.x; i < L * 3; i += 256) {
         const int l = i / 3;
-        if (pt_off[l + 1] > pt_off[l]) m = fmax(m, fabs(Hll[(size_t)l * 9 + (i % 3) * 4]));
+        if (pt_active[l]) m = fmax(m, fabs(Hll[(size_t)l * 9 + (i % 3) * 4]));
     }
     s[threadIdx.x] = m;
     __syncthreads();
@@ -299,13 +315,15 @@ __global__ __launch_bounds__(256) void k_max_diag(int np, const double* __restri
 // thread per point: Dinv = (Hll + lambda I)^-1, db = Dinv bl, BD[e] = Hpl[e] Dinv for its free-pose edges
 __global__ __launch_bounds__(256) void k_point_prep(int L, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
                                                     const int32_t* __restrict__ e_pose, const int32_t* __restrict__ pose_idx,
-                                                    const double* __restrict__ Hll, const double* __restrict__ bl, double lambda,
+                                                    const double* __restrict__ Hll, const double* __restrict__ bl,
+                                                    const double* __restrict__ max_diag, double lam_mult, const uint8_t* __restrict__ pt_active,
                                                     const double* __restrict__ Hpl, double* __restrict__ Dinv, double* __restrict__ db,
                                                     double* __restrict__ BD, double* __restrict__ ok)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l == 0) *ok = 1.0;                                   // reset the "factorisation succeeded" flag of this trial
-    if (l >= L || pt_off[l + 1] == pt_off[l]) return;
+    if (l >= L || !pt_active[l]) return;
+    const double lambda = 1e-5 * *max_diag * lam_mult;       // computeLambdaInit (tau = 1e-5) x the host's LM multiplier
     double H[9], D[9];
     for (int i = 0; i < 9; ++i) H[i] = Hll[(size_t)l * 9 + i];
     H[0] += lambda; H[4] += lambda; H[8] += lambda;
@@ -325,10 +343,11 @@ __global__ __launch_bounds__(256) void k_point_prep(int L, const int32_t* __rest
 // 7 list chunks x 36 block entries; chunk partials combined in fixed order.
 __global__ __launch_bounds__(256) void k_schur(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_off,
                                                const int32_t* __restrict__ pair_e1, const int32_t* __restrict__ pair_e2,
-                                               const double* __restrict__ Hpp, double lambda, const double* __restrict__ BD,
-                                               const double* __restrict__ Hpl, double* __restrict__ S, int ld)
+                                               const double* __restrict__ Hpp, const double* __restrict__ max_diag, double lam_mult,
+                                               const double* __restrict__ BD, const double* __restrict__ Hpl, double* __restrict__ S, int ld)
 {
     __shared__ double part[7][36];
+    const double lambda = 1e-5 * *max_diag * lam_mult;
     const int p = blockIdx.x, t = threadIdx.x;
     const int el = t % 36, q = t / 36;
     const int r = el / 6, c = el % 6;
@@ -626,12 +645,13 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(const double* __restrict__ S
 // thread per point: xl = Dinv (bl - sum_e Hpl[e]^T xp[pose(e)])
 __global__ __launch_bounds__(256) void k_back_subst(int L, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
                                                     const int32_t* __restrict__ e_pose, const int32_t* __restrict__ pose_idx,
-                                                    const double* __restrict__ Hpl, const double* __restrict__ xp, const double* __restrict__ bl,
+                                                    const uint8_t* __restrict__ pt_active, const double* __restrict__ Hpl,
+                                                    const double* __restrict__ xp, const double* __restrict__ bl,
                                                     const double* __restrict__ Dinv, double* __restrict__ xl)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= L) return;
-    if (pt_off[l + 1] == pt_off[l]) { xl[3 * l] = xl[3 * l + 1] = xl[3 * l + 2] = 0; return; }
+    if (!pt_active[l]) { xl[3 * l] = xl[3 * l + 1] = xl[3 * l + 2] = 0; return; }
     double c[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
     for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
         const int e = pt_edges[k], pi = pose_idx[e_pose[e]];
@@ -663,15 +683,16 @@ __global__ __launch_bounds__(256) void k_update(int P, int L, const int32_t* __r
 
 // computeScale: sum_j x_j (lambda x_j + b_j) over pose and active landmark entries. single block.
 __global__ __launch_bounds__(256) void k_scale(int n, const double* __restrict__ xp, const double* __restrict__ bp, int L,
-                                               const int32_t* __restrict__ pt_off, const double* __restrict__ xl, const double* __restrict__ bl,
-                                               double lambda, double* __restrict__ out)
+                                               const uint8_t* __restrict__ pt_active, const double* __restrict__ xl, const double* __restrict__ bl,
+                                               const double* __restrict__ max_diag, double lam_mult, double* __restrict__ out)
 {
     __shared__ double s[256];
+    const double lambda = 1e-5 * *max_diag * lam_mult;
     double v = 0;
     for (int i = threadIdx.x; i < n; i += 256) v += xp[i] * (lambda * xp[i] + bp[i]);
     for (int i = threadIdx.x; i < 3 * L; i += 256) {
         const int l = i / 3;
-        if (pt_off[l + 1] > pt_off[l]) v += xl[i] * (lambda * xl[i] + bl[i]);
+        if (pt_active[l]) v += xl[i] * (lambda * xl[i] + bl[i]);
     }
     const double t = block_sum_256(v, s);
     if (threadIdx.x == 0) *out = t;
@@ -841,7 +862,8 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     int32_t* d_pair_ij = ar.get<int32_t>(2 * n_pairs_max); int32_t* d_pair_off = ar.get<int32_t>(n_pairs_max + 1);
     int32_t* d_pair_e1 = ar.get<int32_t>(max_pairs_entries + 1); int32_t* d_pair_e2 = ar.get<int32_t>(max_pairs_entries + 1);
     double* d_partial = ar.get<double>(nblk);
-    double* d_scal = ar.get<double>(8);               // [0] chi2, [1] scale, [2] maxdiag
+    uint8_t* d_pt_active = ar.get<uint8_t>(L);
+    double* d_scal = ar.get<double>(8);               // [0] chi2, [1] scale, [2] maxdiag, [3] ok, [4] chi2 before the trial
     int* d_ok = ar.get<int>(4);
     unsigned* d_ticket = ar.get<unsigned>(4);
     if (!d_ticket) { set_error("BA arena too small"); return DCS_ERR_HIP; }
@@ -882,13 +904,15 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
         return DCS_OK;
     };
 
-    auto run_round = [&](int round, int iters, int robust) -> int {
-        Round r;
+    // structure of the problem (index mapping, CSR lists, pose-pair lists): built ONCE from all edges. The second
+    // round only changes the per-edge active mask; inactive edges contribute exact zeros, landmarks without an active
+    // edge are skipped (pt_active) and poses without one see a decoupled lambda*I block (zero update), which is
+    // what g2o's re-indexing of the active subgraph amounts to.
+    Round r;
+    {
         const auto tb0 = now();
         build_round(pb, active, r);
         t_build += ms_since(tb0);
-        if (r.n_active == 0) return DCS_OK;
-        DCS_HIP(hipMemcpyAsync(d_active, active.data(), E, hipMemcpyHostToDevice, st));
         DCS_HIP(hipMemcpyAsync(d_pose_idx, r.pose_idx.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
         DCS_HIP(hipMemcpyAsync(d_pt_off, r.pt_off.data(), sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice, st));
         DCS_HIP(hipMemcpyAsync(d_pt_edges, r.pt_edges.data(), sizeof(int32_t) * r.pt_edges.size(), hipMemcpyHostToDevice, st));
@@ -902,50 +926,52 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
                 DCS_HIP(hipMemcpyAsync(d_pair_e2, r.pair_e2.data(), sizeof(int32_t) * r.pair_e2.size(), hipMemcpyHostToDevice, st));
             }
         }
-        DCS_HIP(hipStreamSynchronize(st));              // host vectors go out of scope with the round
-        const int n = r.n, n_pad = r.n_pad, ld = std::max(n_pad, kNB);
-        const bool use_reg = n <= 256 && !force_blocked;  // reduced camera system fits one workgroup's registers
-        if (r.np && use_reg) DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));   // pairs without shared points stay 0
-        double lambda = 0, ni = 2, currentChi = 0;
+    }
+    const int n = r.n, n_pad = r.n_pad, ld = std::max(n_pad, kNB);
+    const bool use_reg = n <= 256 && !force_blocked;      // reduced camera system fits one workgroup's registers
+    if (r.np && use_reg) DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));   // pairs without shared points stay 0
+    const double* d_maxdiag = d_scal + 2;
+
+    auto run_round = [&](int round, int iters, int robust) -> int {
+        int n_act = 0;
+        for (int e = 0; e < E; ++e) n_act += active[e];
+        if (n_act == 0) return DCS_OK;
+        DCS_HIP(hipMemcpyAsync(d_active, active.data(), E, hipMemcpyHostToDevice, st));
+        double mult = 1.0, ni = 2, currentChi = 0;        // lambda = 1e-5 * maxdiag (device) * mult (host)
         int nBad = 0;
         bool errors_current = false;
         for (int it = 0; it < iters && !stopped(); ++it) {
             int rc2;
-            if (!errors_current) {
-                if ((rc2 = eval_error(robust, d_scal))) return rc2;
-                DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 8, hipMemcpyDeviceToHost, st));
-                DCS_HIP(hipStreamSynchronize(st));
-                currentChi = h_scal[0];
-            }
-            const double iniChi = currentChi;
+            const bool need_chi = !errors_current;
+            if (need_chi && (rc2 = eval_error(robust, d_scal + 4))) return rc2;    // read back with the first trial
+            double iniChi = currentChi;
             // buildSystem
             hipLaunchKernelGGL(k_linearize, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2,
                                d_pose_idx, d_cpoint, d_cpose, d_Hpl);
             DCS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(k_reduce_point, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_cpoint, d_Hll, d_bl);
+            hipLaunchKernelGGL(k_reduce_point, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_active, d_cpoint, d_Hll, d_bl,
+                               d_pt_active);
             DCS_CHECK_LAUNCH();
             if (r.np) { hipLaunchKernelGGL(k_reduce_pose, dim3(r.np), dim3(256), 0, st, d_ps_off, d_ps_edges, d_cpose, d_Hpp, d_bp); DCS_CHECK_LAUNCH(); }
             if (it == 0) {
-                hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, r.np, d_Hpp, L, d_pt_off, d_Hll, d_scal + 2);
+                hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, r.np, d_Hpp, L, d_pt_active, d_Hll, d_scal + 2);
                 DCS_CHECK_LAUNCH();
-                DCS_HIP(hipMemcpyAsync(h_scal + 2, d_scal + 2, 8, hipMemcpyDeviceToHost, st));
-                DCS_HIP(hipStreamSynchronize(st));
-                lambda = 1e-5 * h_scal[2]; ni = 2; nBad = 0;        // computeLambdaInit, tau = 1e-5
+                mult = 1.0; ni = 2; nBad = 0;             // computeLambdaInit: lambda = tau * max diagonal, tau = 1e-5
             }
             double rho = 0;
             int qmax = 0;
             do {
                 // setLambda + solve (Schur)
                 hipLaunchKernelGGL(k_point_prep, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx,
-                                   d_Hll, d_bl, lambda, d_Hpl, d_Dinv, d_db, d_BD, d_scal + 3);
+                                   d_Hll, d_bl, d_maxdiag, mult, d_pt_active, d_Hpl, d_Dinv, d_db, d_BD, d_scal + 3);
                 DCS_CHECK_LAUNCH();
                 if (r.np) {
                     if (!use_reg) {                       // the blocked fallback factors S in place: rebuild it every trial
                         DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));
                         if (n_pad > n) { hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(64), 0, st, d_S, ld, n, n_pad); DCS_CHECK_LAUNCH(); }
                     }
-                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs), dim3(256), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp, lambda,
-                                       d_BD, d_Hpl, d_S, ld);
+                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs), dim3(256), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp, d_maxdiag,
+                                       mult, d_BD, d_Hpl, d_S, ld);
                     DCS_CHECK_LAUNCH();
                     hipLaunchKernelGGL(k_bschur, dim3(r.np), dim3(256), 0, st, d_ps_off, d_ps_edges, d_epoint, d_Hpl, d_db, d_bp, d_bsch);
                     DCS_CHECK_LAUNCH();
@@ -963,21 +989,21 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
                         DCS_CHECK_LAUNCH();
                     }
                 }
-                hipLaunchKernelGGL(k_back_subst, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx, d_Hpl,
-                                   d_xp, d_bl, d_Dinv, d_xl);
+                hipLaunchKernelGGL(k_back_subst, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx, d_pt_active,
+                                   d_Hpl, d_xp, d_bl, d_Dinv, d_xl);
                 DCS_CHECK_LAUNCH();
                 hipLaunchKernelGGL(k_update, dim3((P + L + 255) / 256), dim3(256), 0, st, P, L, d_pose_idx, d_xp, d_xl, d_poses, d_points,
                                    d_poses_bk, d_points_bk);
                 DCS_CHECK_LAUNCH();
-                int rc2;
                 if ((rc2 = eval_error(robust, d_scal))) return rc2;
-                hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, st, n, d_xp, d_bp, L, d_pt_off, d_xl, d_bl, lambda, d_scal + 1);
+                hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, st, n, d_xp, d_bp, L, d_pt_active, d_xl, d_bl, d_maxdiag, mult, d_scal + 1);
                 DCS_CHECK_LAUNCH();
-                DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 32, hipMemcpyDeviceToHost, st));
+                DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 40, hipMemcpyDeviceToHost, st));     // chi, scale, maxdiag, ok, initial chi
                 const auto ts0 = now();
                 DCS_HIP(hipStreamSynchronize(st));
                 t_sync += ms_since(ts0);
                 ++res->n_trials[round];
+                if (need_chi && qmax == 0) { currentChi = h_scal[4]; iniChi = currentChi; }
                 double tempChi = h_scal[0];
                 if (h_scal[3] == 0.0) tempChi = std::numeric_limits<double>::max();
                 rho = currentChi - tempChi;
@@ -986,10 +1012,10 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
                 if (rho > 0 && std::isfinite(tempChi)) {
                     double alpha = 1. - std::pow((2 * rho - 1), 3);
                     alpha = std::min(alpha, 2. / 3.);
-                    lambda *= std::max(1. / 3., alpha);
+                    mult *= std::max(1. / 3., alpha);
                     ni = 2; currentChi = tempChi; errors_current = true;
                 } else {
-                    lambda *= ni; ni *= 2;
+                    mult *= ni; ni *= 2;
                     DCS_HIP(hipMemcpyAsync(d_poses, d_poses_bk, sizeof(double) * 7 * P, hipMemcpyDeviceToDevice, st));   // pop
                     DCS_HIP(hipMemcpyAsync(d_points, d_points_bk, sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, st));
                     errors_current = false;
@@ -998,12 +1024,11 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
             } while (rho < 0 && qmax < 10 && !stopped());
             ++res->n_iters[round];
             if (trace < 32) res->chi2_trace[trace++] = currentChi;
-            res->lambda[round] = lambda;
+            res->lambda[round] = 1e-5 * h_scal[2] * mult;
             if (qmax == 10 || rho == 0) break;                         // Terminate
             if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
             if (nBad >= 3) break;
         }
-        res->lambda[round] = lambda;
         return DCS_OK;
     };
 
