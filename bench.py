@@ -88,53 +88,45 @@ def main():
     d_b = torch.zeros((n_pairs, cap), dtype=torch.int32, device=dev)
     d_s = torch.zeros((n_pairs, cap), dtype=torch.int32, device=dev)
     if world > 1:
-        rec = cap * 60 + 64                          # per camera: kp 28 B + desc 32 B per slot + count
+        from orb_slam2_dualcam_amd import sharding
+        rec = sharding.record_bytes(cap)             # per camera: kp 28 B + desc 32 B per slot + count
         g_send = torch.zeros((2, rec), dtype=torch.uint8, device=dev)
-        g_recv = torch.zeros((world, 2, rec), dtype=torch.uint8, device=dev)
+        g_recv = torch.zeros((2 * world, rec), dtype=torch.uint8, device=dev)
         g_kp = torch.zeros((2 * world, cap, 7), dtype=torch.float32, device=dev)
         g_desc = torch.zeros((2 * world, cap, 32), dtype=torch.uint8, device=dev)
         g_n = torch.zeros(2 * world, dtype=torch.int32, device=dev)
-        x_pairs = torch.tensor([(2 * rank, 2 * r + 1) for r in range(world) if r != rank], dtype=torch.int32, device=dev)
+        x_pairs = torch.tensor(sharding.reloc_pairs(rank, world), dtype=torch.int32, device=dev)
         x_match = torch.zeros((world - 1, cap), dtype=torch.int32, device=dev)
         x_nm = torch.zeros(world - 1, dtype=torch.int32, device=dev)
         x_b = torch.zeros((world - 1, cap), dtype=torch.int32, device=dev)
         x_s = torch.zeros((world - 1, cap), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    stage_keys = ("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_host_us", "describe_us", "total_us")
+    stage_keys = ("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us")
     acc = {k: 0.0 for k in stage_keys}
     acc["match_us"] = 0.0
     acc["allgather_us"] = 0.0
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    # per-step torch events (match, all-gather) are read AFTER the timed region so that nothing stalls the stream
+    ev_all = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps + args.warmup)]
+    step_no = [0]
 
     def step(timed):
+        ev = ev_all[step_no[0]]
+        step_no[0] += 1
         ext.extract_batch_device(d_img, d_kp[2:], d_desc[2:], d_n[2:], cap, stream=stream)
         ev[0].record()
         matcher.match_bf_batch_device(d_desc, d_kp, d_n, cap, d_pairs, n_pairs, d_match, d_nm, d_b, d_s, 50, stream=stream)
         ev[1].record()
         if world > 1:
             # exchange the newest dual frame: pack (kp | desc | n) per camera, one all-gather, cross-GPU reloc match
-            g_send[:, :cap * 28] = d_kp[S - 2:].reshape(2, -1).view(torch.uint8)
-            g_send[:, cap * 28:cap * 60] = d_desc[S - 2:].reshape(2, -1)
-            g_send[:, cap * 60:cap * 60 + 4] = d_n[S - 2:].view(torch.uint8).reshape(2, 4)
+            sharding.pack_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_send)
             ev[2].record()
             dist.all_gather_into_tensor(g_recv, g_send)
             ev[3].record()
-            flat = g_recv.reshape(2 * world, rec)
-            g_kp.copy_(flat[:, :cap * 28].contiguous().view(torch.float32).reshape(2 * world, cap, 7))
-            g_desc.copy_(flat[:, cap * 28:cap * 60].reshape(2 * world, cap, 32))
-            g_n.copy_(flat[:, cap * 60:cap * 60 + 4].contiguous().view(torch.int32).reshape(2 * world))
+            sharding.unpack_features(g_recv, cap, g_kp, g_desc, g_n)
             matcher.match_bf_batch_device(g_desc, g_kp, g_n, cap, x_pairs, world - 1, x_match, x_nm, x_b, x_s, 50, stream=stream)
         # newest dual frame becomes "t-1" of the next step
         d_kp[0:2].copy_(d_kp[S - 2:]); d_desc[0:2].copy_(d_desc[S - 2:]); d_n[0:2].copy_(d_n[S - 2:])
-        if timed:
-            t = ext.last_timing()
-            for k in stage_keys:
-                acc[k] += t[k]
-            ev[1].synchronize()
-            acc["match_us"] += ev[0].elapsed_time(ev[1]) * 1000.0
-            if world > 1:
-                ev[3].synchronize()
-                acc["allgather_us"] += ev[2].elapsed_time(ev[3]) * 1000.0
+        return None
 
     def barrier():
         if world > 1:
@@ -143,6 +135,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
+    ext.timing_totals(reset=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -152,6 +145,13 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sums, n_timed = ext.timing_totals()
+    for k in stage_keys:
+        acc[k] = sums[k]
+    for ev in ev_all[args.warmup:]:
+        acc["match_us"] += ev[0].elapsed_time(ev[1]) * 1000.0
+        if world > 1:
+            acc["allgather_us"] += ev[2].elapsed_time(ev[3]) * 1000.0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -171,14 +171,15 @@ def main():
         n_img = 2 * P
         n_avg = n_feat_step / n_img
         K = args.steps
+        n_cand = None
         algo = {                                     # algorithmic bytes per launch x images per launch
             "k_resize(x7)": ((sum_px - px7) + sum_17) * n_img,
             "k_fast_cells": sum_px * n_img,
-            "k_blur": 2 * sum_px * n_img,
+            "k_blur+k_blur_edges": 2 * sum_px * n_img,
             "k_describe": int((749 + 512 + 60) * n_avg * n_img),
             "k_knn2_pairs+k_filter_pairs": int((32 * 2 * n_avg + 12 * n_avg) * n_pairs),
         }
-        dur = {"k_resize(x7)": acc["pyramid_us"] / K, "k_fast_cells": acc["fast_us"] / K, "k_blur": acc["blur_us"] / K,
+        dur = {"k_resize(x7)": acc["pyramid_us"] / K, "k_fast_cells": acc["fast_us"] / K, "k_blur+k_blur_edges": acc["blur_us"] / K,
                "k_describe": acc["describe_us"] / K, "k_knn2_pairs+k_filter_pairs": acc["match_us"] / K}
         kernels = {k: dict(us=round(dur[k], 2), algo_bytes=int(algo[k]),
                            gbps=round(algo[k] / max(dur[k], 1e-3) / 1e3, 2)) for k in algo}

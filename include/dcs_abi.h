@@ -104,7 +104,10 @@ int  dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t*
 int  dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* dst, int cap, int* n);
 /* per-stage time of the last extract call in microseconds (hipEvents on the streams the kernels ran on):
    resize chain, k_fast_cells, scan+gather, k_blur, host quadtree, k_describe, whole call (7 floats) */
-int  dcs_orb_last_timing(const dcs_orb* h, float* us7);
+int  dcs_orb_last_timing(dcs_orb* h, float* us7);
+/* sums of the same 7 stage times over every extract call since the last reset. Event sets live in a ring and are read
+   lazily, so asynchronous (_device) callers are never stalled by the instrumentation. */
+int  dcs_orb_timing_totals(dcs_orb* h, double* sum_us7, int64_t* n_calls, int reset);
 
 /* DistributeOctTree (ORBextractor.cc:539-763) alone, host buffers (used by tests) */
 int  dcs_distribute_octree(const dcs_candidate* cand, int n, int min_x, int max_x, int min_y, int max_y,

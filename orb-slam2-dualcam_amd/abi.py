@@ -23,7 +23,7 @@ SYMBOLS = [
     "dcs_last_error", "dcs_version", "dcs_device_count",
     "dcs_orb_create", "dcs_orb_destroy", "dcs_orb_tables", "dcs_orb_extract", "dcs_orb_extract_batch",
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
-    "dcs_orb_debug_candidates", "dcs_orb_last_timing", "dcs_distribute_octree",
+    "dcs_orb_debug_candidates", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow",
     "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
@@ -95,6 +95,7 @@ def lib():
             "dcs_orb_debug_level": [vp, ci, ci, ci, vp],
             "dcs_orb_debug_candidates": [vp, ci, ci, vp, ci, pci],
             "dcs_orb_last_timing": [vp, vp],
+            "dcs_orb_timing_totals": [vp, vp, vp, ci],
             "dcs_distribute_octree": [vp, ci, ci, ci, ci, ci, ci, vp, ci, pci],
             "dcs_hamming_knn2": [vp, ci, vp, ci, vp, vp, vp, vp],
             "dcs_hamming_knn2_grouped": [vp, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp],
@@ -214,10 +215,19 @@ class ORBextractor:
         _check(lib().dcs_orb_debug_candidates(self._h, image, level, _p(out), n.value, C.byref(n)), "dcs_orb_debug_candidates")
         return out[:n.value]
 
+    STAGES = ("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us")
+
+    def timing_totals(self, reset=False):
+        """(dict of summed stage microseconds, number of calls) since the last reset; does not stall async callers."""
+        sums = np.zeros(7, np.float64)
+        n = C.c_int64()
+        _check(lib().dcs_orb_timing_totals(self._h, _p(sums), C.byref(n), int(reset)), "dcs_orb_timing_totals")
+        return dict(zip(self.STAGES, sums.tolist())), n.value
+
     def last_timing(self):
         t = np.zeros(7, np.float32)
         _check(lib().dcs_orb_last_timing(self._h, _p(t)), "dcs_orb_last_timing")
-        return dict(zip(("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_host_us", "describe_us", "total_us"),
+        return dict(zip(("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us"),
                         t.tolist()))
 
 

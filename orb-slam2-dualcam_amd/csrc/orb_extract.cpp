@@ -124,10 +124,19 @@ struct dcs_orb {
     PinnedBuf<uint8_t> h_img;
 
     hipStream_t s_main = nullptr, s_aux = nullptr;
-    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_t[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
-               ev_b[2] = {nullptr, nullptr};
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+    // per-call timing events live in a small ring so that asynchronous callers are never stalled: a set is harvested
+    // (elapsed times read and accumulated) only when it is about to be reused or when the totals are requested
+    static constexpr int kRing = 8;
+    struct EvSet { hipEvent_t t[7] = {}, b[2] = {}; float host_us = 0; bool pending = false, dev_oct = true; } ring[kRing];
+    hipEvent_t* ev_t = nullptr; hipEvent_t* ev_b = nullptr;     // the set of the call in flight
+    long n_calls = 0;
+    float last_us[7] = {0, 0, 0, 0, 0, 0, 0};
+    double sum_us[7] = {0, 0, 0, 0, 0, 0, 0};
+    long n_harvested = 0;
     float host_us = 0;
     bool timing_valid = false;
+    int harvest(EvSet& es);
     std::unique_ptr<Pool> pool;
     std::vector<std::vector<dcs_candidate>> task_out;
 
@@ -140,8 +149,7 @@ struct dcs_orb {
         if (s_aux) (void)hipStreamDestroy(s_aux);
         if (ev_pyr) (void)hipEventDestroy(ev_pyr);
         if (ev_blur) (void)hipEventDestroy(ev_blur);
-        for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
-        for (auto& e : ev_b) if (e) (void)hipEventDestroy(e);
+        for (auto& es : ring) { for (auto& e : es.t) if (e) (void)hipEventDestroy(e); for (auto& e : es.b) if (e) (void)hipEventDestroy(e); }
     }
 
     int configure(int rows, int cols);
@@ -279,6 +287,10 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     last_raw = raw; last_blur = blur; last_n_images = n_images;
     timing_valid = false;
     int rc;
+    EvSet& es = ring[n_calls % kRing];
+    if (es.pending && (rc = harvest(es))) return rc;
+    ev_t = es.t; ev_b = es.b; es.dev_oct = device_octree;
+    ++n_calls;
     DCS_HIP(hipEventRecord(ev_t[0], stream));
     for (int l = 1; l < L; ++l) {
         if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs, d_rtab.p + rtab[l].xa,
@@ -374,7 +386,27 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
                                   d_n_out, stream))) return rc;
     }
     DCS_HIP(hipEventRecord(ev_t[5], stream));
+    es.host_us = host_us; es.pending = true;
     timing_valid = true;
+    return DCS_OK;
+}
+
+int dcs_orb::harvest(EvSet& es)
+{
+    DCS_HIP(hipEventSynchronize(es.t[5]));
+    DCS_HIP(hipEventSynchronize(es.b[1]));
+    float ms, us[7];
+    DCS_HIP(hipEventElapsedTime(&ms, es.t[0], es.t[1])); us[0] = ms * 1000.f;   // resize chain
+    DCS_HIP(hipEventElapsedTime(&ms, es.t[1], es.t[2])); us[1] = ms * 1000.f;   // k_fast_cells
+    DCS_HIP(hipEventElapsedTime(&ms, es.t[2], es.t[3])); us[2] = ms * 1000.f;   // scan + offsets + gather
+    DCS_HIP(hipEventElapsedTime(&ms, es.b[0], es.b[1])); us[3] = ms * 1000.f;   // k_blur + k_blur_edges (aux stream)
+    if (es.dev_oct) { DCS_HIP(hipEventElapsedTime(&ms, es.t[3], es.t[6])); us[4] = ms * 1000.f; }   // k_octree
+    else us[4] = es.host_us;                                                    // host quadtree (wall)
+    DCS_HIP(hipEventElapsedTime(&ms, es.t[4], es.t[5])); us[5] = ms * 1000.f;   // k_describe
+    DCS_HIP(hipEventElapsedTime(&ms, es.t[0], es.t[5])); us[6] = ms * 1000.f;   // whole call on the main stream
+    for (int i = 0; i < 7; ++i) { last_us[i] = us[i]; sum_us[i] += us[i]; }
+    ++n_harvested;
+    es.pending = false;
     return DCS_OK;
 }
 
@@ -402,8 +434,7 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     DCS_HIP(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
     DCS_HIP(hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming));
     DCS_HIP(hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming));
-    for (auto& e : h->ev_t) DCS_HIP(hipEventCreate(&e));
-    for (auto& e : h->ev_b) DCS_HIP(hipEventCreate(&e));
+    for (auto& es : h->ring) { for (auto& e : es.t) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.b) DCS_HIP(hipEventCreate(&e)); }
     h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
     h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
@@ -543,20 +574,24 @@ int dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* ds
     return DCS_OK;
 }
 
-int dcs_orb_last_timing(const dcs_orb* h, float* us7)
+int dcs_orb_last_timing(dcs_orb* h, float* us7)
 {
     if (!h || !us7 || !h->timing_valid) { set_error("no timing available"); return DCS_ERR_INVALID; }
-    DCS_HIP(hipEventSynchronize(h->ev_t[5]));
-    DCS_HIP(hipEventSynchronize(h->ev_b[1]));
-    float ms;
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[0], h->ev_t[1])); us7[0] = ms * 1000.f;   // resize chain
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[1], h->ev_t[2])); us7[1] = ms * 1000.f;   // k_fast_cells
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[2], h->ev_t[3])); us7[2] = ms * 1000.f;   // scan + gather
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_b[0], h->ev_b[1])); us7[3] = ms * 1000.f;   // k_blur (aux stream)
-    if (h->device_octree) { DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[3], h->ev_t[6])); us7[4] = ms * 1000.f; }   // k_octree
-    else us7[4] = h->host_us;                                                          // host quadtree (wall)
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[4], h->ev_t[5])); us7[5] = ms * 1000.f;   // k_describe
-    DCS_HIP(hipEventElapsedTime(&ms, h->ev_t[0], h->ev_t[5])); us7[6] = ms * 1000.f;   // whole call on the main stream
+    dcs_orb::EvSet& es = h->ring[(h->n_calls - 1) % dcs_orb::kRing];
+    int rc;
+    if (es.pending && (rc = h->harvest(es))) return rc;
+    for (int i = 0; i < 7; ++i) us7[i] = h->last_us[i];
+    return DCS_OK;
+}
+
+int dcs_orb_timing_totals(dcs_orb* h, double* sum_us7, int64_t* n_calls, int reset)
+{
+    if (!h || !sum_us7 || !n_calls) { set_error("null argument"); return DCS_ERR_INVALID; }
+    int rc;
+    for (auto& es : h->ring) if (es.pending && (rc = h->harvest(es))) return rc;
+    for (int i = 0; i < 7; ++i) sum_us7[i] = h->sum_us[i];
+    *n_calls = h->n_harvested;
+    if (reset) { for (auto& v : h->sum_us) v = 0; h->n_harvested = 0; }
     return DCS_OK;
 }
 
