@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="independent extractor handles/streams the batch is split over (overlaps latency-bound kernels)")
     args = ap.parse_args()
 
     import torch
@@ -70,7 +71,13 @@ def main():
     imgs = np.stack([frames[(2 * (p % n_unique)) + c] for p in range(P) for c in (0, 1)])
     d_img = torch.from_numpy(imgs).to(dev)
 
-    ext = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local_rank, max_images=2 * P)
+    n_lanes = max(1, min(args.lanes, P))
+    lane_pairs = [P // n_lanes + (1 if i < P % n_lanes else 0) for i in range(n_lanes)]
+    exts = [pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local_rank, max_images=2 * lp) for lp in lane_pairs]
+    ext = exts[0]
+    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
+    lane_done = [torch.cuda.Event() for _ in range(n_lanes)]
+    lane_go = torch.cuda.Event()
     matcher = pkg.ORBmatcher(0.75, True)
     cap = ext.default_cap()
     S = 2 * P + 2                                   # feature slots: [prev cam0, prev cam1, batch ...]
@@ -112,7 +119,18 @@ def main():
     def step(timed):
         ev = ev_all[step_no[0]]
         step_no[0] += 1
-        ext.extract_batch_device(d_img, d_kp[2:], d_desc[2:], d_n[2:], cap, stream=stream)
+        # the batch is split over `n_lanes` extractor handles on their own streams; matching waits for all of them
+        lane_go.record()
+        first = 0
+        for li in range(n_lanes):
+            a, b = 2 * first, 2 * (first + lane_pairs[li])
+            lane_streams[li].wait_event(lane_go)
+            exts[li].extract_batch_device(d_img[a:b], d_kp[2 + a:2 + b], d_desc[2 + a:2 + b], d_n[2 + a:2 + b], cap,
+                                          stream=lane_streams[li].cuda_stream)
+            lane_done[li].record(lane_streams[li])
+            first += lane_pairs[li]
+        for li in range(n_lanes):
+            torch.cuda.current_stream().wait_event(lane_done[li])
         ev[0].record()
         matcher.match_bf_batch_device(d_desc, d_kp, d_n, cap, d_pairs, n_pairs, d_match, d_nm, d_b, d_s, 50, stream=stream)
         ev[1].record()
@@ -135,7 +153,8 @@ def main():
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
-    ext.timing_totals(reset=True)
+    for e_ in exts:
+        e_.timing_totals(reset=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -145,9 +164,10 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    sums, n_timed = ext.timing_totals()
-    for k in stage_keys:
-        acc[k] = sums[k]
+    for e_ in exts:                       # kernel times: summed over the lanes (each lane launches its own kernels)
+        sums, n_timed = e_.timing_totals()
+        for k in stage_keys:
+            acc[k] += sums[k]
     for ev in ev_all[args.warmup:]:
         acc["match_us"] += ev[0].elapsed_time(ev[1]) * 1000.0
         if world > 1:
@@ -171,21 +191,31 @@ def main():
         n_img = 2 * P
         n_avg = n_feat_step / n_img
         K = args.steps
-        n_cand = None
-        algo = {                                     # algorithmic bytes per launch x images per launch
-            "k_resize(x7)": ((sum_px - px7) + sum_17) * n_img,
-            "k_fast_cells": sum_px * n_img,
-            "k_blur+k_blur_edges": 2 * sum_px * n_img,
-            "k_describe": int((749 + 512 + 60) * n_avg * n_img),
+        LN = n_lanes                                 # every extraction kernel is launched once per lane per step
+        n_img_l = n_img / LN
+        algo = {                                     # algorithmic bytes per LAUNCH x images per launch
+            "k_resize(x7)": ((sum_px - px7) + sum_17) * n_img_l,
+            "k_fast_cells": sum_px * n_img_l,
+            "k_blur+k_blur_edges": 2 * sum_px * n_img_l,
+            "k_describe": int((749 + 512 + 60) * n_avg * n_img_l),
             "k_knn2_pairs+k_filter_pairs": int((32 * 2 * n_avg + 12 * n_avg) * n_pairs),
         }
-        dur = {"k_resize(x7)": acc["pyramid_us"] / K, "k_fast_cells": acc["fast_us"] / K, "k_blur+k_blur_edges": acc["blur_us"] / K,
-               "k_describe": acc["describe_us"] / K, "k_knn2_pairs+k_filter_pairs": acc["match_us"] / K}
+        dur = {"k_resize(x7)": acc["pyramid_us"] / (K * LN), "k_fast_cells": acc["fast_us"] / (K * LN),
+               "k_blur+k_blur_edges": acc["blur_us"] / (K * LN), "k_describe": acc["describe_us"] / (K * LN),
+               "k_knn2_pairs+k_filter_pairs": acc["match_us"] / K}
         kernels = {k: dict(us=round(dur[k], 2), algo_bytes=int(algo[k]),
                            gbps=round(algo[k] / max(dur[k], 1e-3) / 1e3, 2)) for k in algo}
         dom = max((k for k in dur if k != "k_knn2_pairs+k_filter_pairs"), key=lambda k: dur[k])
+        traffic = None                               # HBM bytes per launch from the committed PMC passes (profiles/), same workload only
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+            if (P, W, H, NF, LN) == tuple(pmc.get("bench_args", ())):
+                kk = pmc["kernels"][dom.split("(")[0].split("+")[0]]
+                traffic = int((kk["FETCH_SIZE_KB_avg_per_launch"] + kk["WRITE_SIZE_KB_avg_per_launch"]) * 1024)
+        except Exception:
+            traffic = None
         roofline = dict(kernel=dom, bound="hbm", achieved=kernels[dom]["gbps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(kernels[dom]["gbps"] / HBM_PEAK_GBS, 5), traffic=None,
+                        frac=round(kernels[dom]["gbps"] / HBM_PEAK_GBS, 5), traffic=traffic,
                         algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(dur[dom], 2))
         out = {
             "metric": "dual-frame ORB extract+match kfeatures/s; local-BA iters/s (50 KF / 2k MP)",
@@ -193,7 +223,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: dual %dx%d stream, %d feat/cam, 8 levels, extract + BF match (3 matches/dual frame)" % (W, H, NF),
-                       "dual_frames_per_step_per_gpu": P, "features_per_step_per_gpu": n_feat_step,
+                       "dual_frames_per_step_per_gpu": P, "extractor_lanes": n_lanes, "features_per_step_per_gpu": n_feat_step,
                        "matches_per_step_per_gpu": n_match_step, "parallelism": "frame-pair shard x%d" % world},
             "roofline": roofline,
             "stage_us_per_step": {k: round(v / K, 2) for k, v in acc.items()},
@@ -260,7 +290,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    ext.close()
+    for e_ in exts:
+        e_.close()
     if world > 1:
         dist.destroy_process_group()
 

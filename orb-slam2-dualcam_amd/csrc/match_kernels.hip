@@ -5,8 +5,8 @@
 // with strict "<" (:208-231), accept best <= TH and best < ratio * second (:233-236), 30-bin rotation
 // histogram + ComputeThreeMaxima (:241-251, :272-290, :1969-2010).
 //
-// knn2 layout: a workgroup = 64 queries x 4 train splits (one wave per split, one query per lane,
-// the query's 4 x u64 descriptor words live in VGPRs). Train descriptors are staged through LDS in
+// knn2 layout: a workgroup = 128 queries x 4 train splits (one wave per split, two queries per lane,
+// the queries' 4 x u64 descriptor words live in VGPRs). Train descriptors are staged through LDS in
 // tiles of 256 (8 KB, coalesced 16-B loads); every lane of a wave reads the SAME train word, an LDS
 // broadcast, and spends 4 x (v_xor + popcount) per distance. The two smallest distances (with
 // multiplicity) and the first index of the minimum are order-independent quantities, so the four
@@ -43,22 +43,31 @@ __device__ __forceinline__ Best best_merge(const Best& a, const Best& b)
 
 constexpr int kTile = 256;
 
-__device__ __forceinline__ void knn2_tile(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
-                                          const uint8_t* __restrict__ t_mask, int q_tile, int32_t* __restrict__ best_idx,
-                                          int32_t* __restrict__ best_d, int32_t* __restrict__ second_d)
+__device__ __forceinline__ void load_query(const uint8_t* __restrict__ q, int qi, int nq, unsigned long long (&qw)[4])
 {
-    __shared__ uint4 s_t[kTile * 2];                 // 256 descriptors x 32 B
-    __shared__ Best s_part[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qi = q_tile * 64 + lane;
-    unsigned long long qw[4] = {0, 0, 0, 0};
+    qw[0] = qw[1] = qw[2] = qw[3] = 0;
     if (qi < nq) {
         const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
         const uint4 a = qp[0], b = qp[1];
         qw[0] = ((unsigned long long)a.y << 32) | a.x; qw[1] = ((unsigned long long)a.w << 32) | a.z;
         qw[2] = ((unsigned long long)b.y << 32) | b.x; qw[3] = ((unsigned long long)b.w << 32) | b.z;
     }
-    Best st{256, -1, 256};
+}
+
+// workgroup = 128 queries x 4 train splits: every lane keeps TWO queries in VGPRs (q_tile*128 + lane and + 64), so each
+// LDS broadcast of a train descriptor (4 x ds_read_b64) feeds two distance computations.
+__device__ __forceinline__ void knn2_tile(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                          const uint8_t* __restrict__ t_mask, int q_tile, int32_t* __restrict__ best_idx,
+                                          int32_t* __restrict__ best_d, int32_t* __restrict__ second_d)
+{
+    __shared__ uint4 s_t[kTile * 2];                 // 256 descriptors x 32 B
+    __shared__ Best s_part[4][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qa = q_tile * 128 + lane, qb = qa + 64;
+    unsigned long long wa[4], wb[4];
+    load_query(q, qa, nq, wa);
+    load_query(q, qb, nq, wb);
+    Best sa{256, -1, 256}, sb{256, -1, 256};
     for (int t0 = 0; t0 < nt; t0 += kTile) {
         const int n_here = min(kTile, nt - t0);
         __syncthreads();
@@ -71,15 +80,21 @@ __device__ __forceinline__ void knn2_tile(const uint8_t* __restrict__ q, int nq,
         for (int j = jb; j < je; ++j) {
             if (t_mask && t_mask[t0 + j]) continue;                      // wave-uniform branch
             const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&s_t[2 * j]);
-            const int dist = __popcll(qw[0] ^ w[0]) + __popcll(qw[1] ^ w[1]) + __popcll(qw[2] ^ w[2]) + __popcll(qw[3] ^ w[3]);
-            best_update(st, dist, t0 + j);
+            const unsigned long long w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            const int da = __popcll(wa[0] ^ w0) + __popcll(wa[1] ^ w1) + __popcll(wa[2] ^ w2) + __popcll(wa[3] ^ w3);
+            const int db = __popcll(wb[0] ^ w0) + __popcll(wb[1] ^ w1) + __popcll(wb[2] ^ w2) + __popcll(wb[3] ^ w3);
+            best_update(sa, da, t0 + j);
+            best_update(sb, db, t0 + j);
         }
     }
-    s_part[wave][lane] = st;
+    s_part[wave][lane] = sa; s_part[wave][lane + 64] = sb;
     __syncthreads();
-    if (wave == 0 && qi < nq) {
-        Best r = best_merge(best_merge(s_part[0][lane], s_part[1][lane]), best_merge(s_part[2][lane], s_part[3][lane]));
-        best_idx[qi] = r.idx; best_d[qi] = r.b1; second_d[qi] = r.b2;
+    if (tid < 128) {
+        const int qi = q_tile * 128 + tid;
+        if (qi < nq) {
+            Best r = best_merge(best_merge(s_part[0][tid], s_part[1][tid]), best_merge(s_part[2][tid], s_part[3][tid]));
+            best_idx[qi] = r.idx; best_d[qi] = r.b1; second_d[qi] = r.b2;
+        }
     }
 }
 
@@ -96,7 +111,7 @@ __global__ __launch_bounds__(256) void k_knn2_pairs(const uint8_t* __restrict__ 
     const int p = blockIdx.y;
     const int qs = pairs[2 * p], ts = pairs[2 * p + 1];
     const int nq = min(n_feat[qs], cap), nt = min(n_feat[ts], cap);
-    if ((int)blockIdx.x * 64 >= nq) return;
+    if ((int)blockIdx.x * 128 >= nq) return;
     knn2_tile(desc + (size_t)qs * cap * 32, nq, desc + (size_t)ts * cap * 32, nt, nullptr, blockIdx.x,
               best_idx + (size_t)p * cap, best_d + (size_t)p * cap, second_d + (size_t)p * cap);
 }
@@ -355,7 +370,7 @@ int dcs_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const u
     if ((rc = s.upload(&dq, q, (size_t)nq * 32)) || (rc = s.upload(&dt, t, (size_t)nt * 32))) return rc;
     if (t_mask && (rc = s.upload(&dm, t_mask, (size_t)nt))) return rc;
     if ((rc = s.alloc(&bi, nq)) || (rc = s.alloc(&bd, nq)) || (rc = s.alloc(&sd, nq))) return rc;
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64), dim3(256), 0, 0, dq, nq, dt, nt, dm, bi, bd, sd);
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 127) / 128), dim3(256), 0, 0, dq, nq, dt, nt, dm, bi, bd, sd);
     DCS_CHECK_LAUNCH();
     DCS_HIP(hipMemcpy(best_idx, bi, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
     DCS_HIP(hipMemcpy(best_d, bd, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
@@ -437,7 +452,7 @@ int dcs_match_bf(const uint8_t* q, const dcs_keypoint* q_kp, int nq, const uint8
     if ((rc = s.upload(&dq, q, (size_t)nq * 32)) || (rc = s.upload(&dt, t, (size_t)nt * 32))) return rc;
     if (check_ori && ((rc = s.upload(&kq, q_kp, nq)) || (rc = s.upload(&kt, t_kp, nt)))) return rc;
     if ((rc = s.alloc(&bi, nq)) || (rc = s.alloc(&bd, nq)) || (rc = s.alloc(&sd, nq)) || (rc = s.alloc(&dm, nq)) || (rc = s.alloc(&dn, 1))) return rc;
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64), dim3(256), 0, 0, dq, nq, dt, nt, (const uint8_t*)nullptr, bi, bd, sd);
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 127) / 128), dim3(256), 0, 0, dq, nq, dt, nt, (const uint8_t*)nullptr, bi, bd, sd);
     DCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter, dim3(1), dim3(256), 0, 0, nq, bi, bd, sd, th, 0, ratio, check_ori,
                        kq ? &kq->angle : nullptr, 7, kt ? &kt->angle : nullptr, 7, dm, dn);
@@ -461,7 +476,7 @@ int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, c
     if (n_pairs == 0) return DCS_OK;
     hipStream_t s = (hipStream_t)stream;
     // d_match doubles as the best-index buffer: the filter reads best_idx[i] and writes match[i] in the same thread
-    hipLaunchKernelGGL(k_knn2_pairs, dim3((cap + 63) / 64, n_pairs), dim3(256), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
+    hipLaunchKernelGGL(k_knn2_pairs, dim3((cap + 127) / 128, n_pairs), dim3(256), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
     DCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter_pairs, dim3(n_pairs), dim3(256), 0, s, d_kp, d_n, cap, d_pairs, d_match, d_best_d, d_second_d, th,
                        ratio, check_ori, d_match, d_n_matches);

@@ -15,6 +15,8 @@
 // Ties between equal-size nodes: creation sequence (Q3, same as the oracle). Output is bit-exact vs the oracle.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "orb_kernels.h"
 
@@ -107,13 +109,15 @@ __device__ int block_scan_inplace(int* a, int n)
 
 // All scratch arrays have 2 * dense_cap elements; the task whose candidates start at b0 uses [2*b0, 2*b0 + 2n).
 __global__ __launch_bounds__(kT) void k_octree(const dcs_candidate* __restrict__ dense, const int32_t* __restrict__ lvl_off,
-                                               OctLevels P, OctScratch G, int dense_cap, SelKp* __restrict__ sel, int32_t* __restrict__ lvl_cnt)
+                                               OctLevels P, OctScratch G, int dense_cap, const int32_t* __restrict__ only_flagged, SelKp* __restrict__ sel,
+                                               int32_t* __restrict__ lvl_cnt)
 {
     __shared__ unsigned long long s_keys[kLdsKeys];
     __shared__ unsigned s_vals[kLdsKeys];
     __shared__ int s_hist[kMaxDepth + 2], s_exp[kMaxDepth + 3];
     __shared__ int s_D, s_tail, s_size, s_nfin, s_nnext, s_rstar, s_seq;
     const int task = blockIdx.x, tid = threadIdx.x;
+    if (only_flagged && !only_flagged[task]) return;          // the histogram fast path already did this task
     const int l = task % P.nlevels, img = task / P.nlevels;
     const OctLevel lp = P.lv[l];
     const int b0 = lvl_off[task], n = min(lvl_off[task + 1], dense_cap) - b0;   // k_gather drops what does not fit
@@ -321,11 +325,238 @@ __global__ __launch_bounds__(kT) void k_octree(const dcs_candidate* __restrict__
     if (tid == 0) lvl_cnt[task] = n_out;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Fast path: the quadtree as a histogram pyramid in LDS (no sort of the candidates at all).
+// A depth-d node is the bin "initial node, d quadrants"; bins of one depth are contiguous ranges of the depth-6 bins, so
+//   * key counts per bin: LDS atomics at depth 6, then a bottom-up pyramid (sum of 4 children),
+//   * the best candidate of any node = max over a contiguous range of a packed (response << 20 | ~index) word,
+//   * list size / expandable nodes per depth = non-empty / multi-key bins -> stopping depth D exactly as in k_octree,
+//   * the "fullest nodes first" tail only needs the 4 child counts of each expandable node.
+// Valid while everything the reference touches lies within 6 levels (true for the usual quotas); otherwise the task is
+// flagged and the general sort-based kernel k_octree redoes it. Output is identical by construction and by test.
+template <int NINI>
+__global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restrict__ dense, const int32_t* __restrict__ lvl_off,
+                                                    OctLevels P, int dense_cap, int force_general, SelKp* __restrict__ sel,
+                                                    int32_t* __restrict__ lvl_cnt, int32_t* __restrict__ need_general)
+{
+    constexpr int kHD = 6;                              // deepest histogram level
+    constexpr int NB6 = NINI << (2 * kHD);
+    constexpr int kCap = 1024;                          // final / expandable nodes handled in LDS
+    __shared__ unsigned s_cnt6[NB6];                    // depth 6 counts (32-bit for LDS atomics)
+    __shared__ unsigned short s_cnt[NINI * 1365 + 8];   // depths 0..5: NINI * (1 + 4 + ... + 1024)
+    __shared__ unsigned s_best[NB6];
+    __shared__ unsigned long long s_fkey[kCap], s_tkey[kCap];
+    __shared__ unsigned s_fval[kCap], s_tval[kCap];
+    __shared__ int s_size[kHD + 1], s_nexp[kHD + 1];
+    __shared__ int s_D, s_tail, s_cursize, s_nfin, s_nnext, s_rstar, s_seq, s_bail;
+    __shared__ int s_nch[kCap], s_inc[kCap];
+    const int task = blockIdx.x, tid = threadIdx.x;
+    const int l = task % P.nlevels, img = task / P.nlevels;
+    const OctLevel lp = P.lv[l];
+    const int b0 = lvl_off[task], n = min(lvl_off[task + 1], dense_cap) - b0;
+    SelKp* out = sel + (size_t)img * P.out_per_image + lp.out_base;
+    if (tid == 0) need_general[task] = 0;
+    if (n <= 0 || lp.height <= 0) { if (tid == 0) lvl_cnt[task] = 0; return; }
+    const int n_ini = (int)roundf(__fdiv_rn((float)lp.width, (float)lp.height));
+    if (n_ini < 1 || n_ini > 255) { if (tid == 0) lvl_cnt[task] = 0; return; }
+    if (n_ini > NINI || n >= (1 << 20) || force_general) { if (tid == 0) need_general[task] = 1; return; }
+    const float hX = __fdiv_rn((float)lp.width, (float)n_ini);
+    const dcs_candidate* c = dense + b0;
+    auto lvl_base = [](int d) { return NINI * (((1 << (2 * d)) - 1) / 3); };     // offset of depth d inside s_cnt
+    auto count_at = [&](int d, int bin) -> int { return d == kHD ? (int)s_cnt6[bin] : (int)s_cnt[lvl_base(d) + bin]; };
+
+    for (int i = tid; i < NB6; i += kT) { s_cnt6[i] = 0; s_best[i] = 0; }
+    if (tid == 0) { s_nfin = 0; s_nnext = 0; s_seq = 1; s_bail = 0; }
+    __syncthreads();
+    // ---- 1. histogram of the depth-6 bins + best candidate per bin
+    for (int i = tid; i < n; i += kT) {
+        const int x = c[i].x, y = c[i].y;
+        int k = (int)__fdiv_rn((float)x, hX);
+        if (k >= n_ini) k = n_ini - 1;
+        int ulx = (int)__fmul_rn(hX, (float)k), urx = (int)__fmul_rn(hX, (float)(k + 1)), uly = 0, bry = lp.height;
+        unsigned code = (unsigned)k;
+#pragma unroll
+        for (int d = 1; d <= kHD; ++d) {
+            const int mx = ulx + (urx - ulx + 1) / 2, my = uly + (bry - uly + 1) / 2;
+            unsigned q = 0;
+            if (x < mx) urx = mx; else { ulx = mx; q |= 1; }
+            if (y < my) bry = my; else { uly = my; q |= 2; }
+            code = (code << 2) | q;
+        }
+        atomicAdd(&s_cnt6[code], 1u);
+        atomicMax(&s_best[code], ((unsigned)c[i].score << 20) | (unsigned)(kM20 - (unsigned)i));   // max response, then first in input order
+    }
+    __syncthreads();
+    // ---- 2. pyramid of counts, list size and expandable nodes per depth
+    for (int d = kHD - 1; d >= 0; --d) {
+        const int nb = NINI << (2 * d);
+        for (int b = tid; b < nb; b += kT) {
+            int s4 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4 += count_at(d + 1, 4 * b + q);
+            s_cnt[lvl_base(d) + b] = (unsigned short)min(s4, 65535);
+        }
+        __syncthreads();
+    }
+    if (tid <= kHD) { s_size[tid] = 0; s_nexp[tid] = 0; }
+    __syncthreads();
+    for (int d = 0; d <= kHD; ++d) {
+        const int nb = NINI << (2 * d);
+        int ne = 0, nm = 0;
+        for (int b = tid; b < nb; b += kT) { const int cc = count_at(d, b); ne += cc > 0; nm += cc > 1; }
+        if (ne) atomicAdd(&s_size[d], ne);
+        if (nm) atomicAdd(&s_nexp[d], nm);
+    }
+    __syncthreads();
+    if (tid == 0) {                                     // breadth-first phase (:594-673), same decisions as k_octree
+        int prev = s_size[0], D = -1, tail = 0;
+        for (int d = 1; d <= kHD; ++d) {
+            const int sz = s_size[d];
+            if (sz >= lp.n_target || sz == prev) { D = d; break; }
+            if (sz + 3 * s_nexp[d] > lp.n_target) { D = d; tail = 1; break; }
+            prev = sz;
+        }
+        if (D < 0 || (tail && D + 1 > kHD) || n > 65535) s_bail = 1;     // deeper than the pyramid (or 16-bit counts): general kernel
+        s_D = D; s_tail = tail; s_cursize = D >= 0 ? s_size[D] : 0;
+    }
+    __syncthreads();
+    if (s_bail) { if (tid == 0) need_general[task] = 1; return; }
+    const int D = s_D, tail = s_tail;
+    auto code14 = [](unsigned bin, int d) -> unsigned long long { return (unsigned long long)bin << (2 * (kMaxDepth - d)); };
+    auto best_of = [&](int d, int bin) -> unsigned {    // best candidate index of a depth-d node
+        const int span = 1 << (2 * (kHD - d));
+        unsigned m = 0;
+        for (int q = 0; q < span; ++q) m = max(m, s_best[bin * span + q]);
+        return (unsigned)(kM20 - (m & kM20));
+    };
+    // ---- 3. nodes of the breadth-first list L_D
+    {
+        const int nb = NINI << (2 * D);
+        for (int b = tid; b < nb; b += kT) {
+            const int cc = count_at(D, b);
+            if (cc == 0) continue;
+            if (tail && cc > 1) {
+                const int t = atomicAdd(&s_nnext, 1);
+                if (t < kCap) { s_tkey[t] = ((kM20 - (unsigned long long)cc) << 36) | order_key(code14(b, D), D); s_tval[t] = (unsigned)b; }
+                else s_bail = 1;
+                continue;
+            }
+            int depth = D;
+            if (cc == 1) { while (depth > 0 && count_at(depth - 1, b >> (2 * (D - depth + 1))) == 1) --depth; }   // froze at the first depth it was alone
+            const int f = atomicAdd(&s_nfin, 1);
+            if (f < kCap) {
+                s_fkey[f] = (1ull << 60) | ((unsigned long long)(D - depth) << 36) | order_key(code14(b >> (2 * (D - depth)), depth), depth);
+                s_fval[f] = best_of(D, b);
+            } else s_bail = 1;
+        }
+    }
+    __syncthreads();
+    // ---- 4. "expand the fullest nodes first" passes (:673-738)
+    if (tail && !s_bail) {
+        int depth_cur = D;
+        bool first_pass = true;
+        for (;;) {
+            const int T = s_nnext, prev_size = s_cursize, seq_base = s_seq;
+            __syncthreads();
+            if (T == 0 || s_bail) break;
+            const int tp = next_pow2(T);
+            for (int i = T + tid; i < tp; i += kT) { s_tkey[i] = ~0ull; s_tval[i] = 0u; }
+            __syncthreads();
+            bitonic_sort(s_tkey, s_tval, tp);               // processing order
+            for (int r = tid; r < T; r += kT) {
+                int cnt = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cnt += count_at(depth_cur + 1, 4 * (int)s_tval[r] + q) > 0;
+                s_nch[r] = cnt; s_inc[r] = cnt;
+            }
+            __syncthreads();
+            (void)block_scan_inplace(s_inc, T);
+            if (tid == 0) s_rstar = T;
+            __syncthreads();
+            for (int r = tid; r < T; r += kT)
+                if (prev_size + s_inc[r] + s_nch[r] - (r + 1) >= lp.n_target) atomicMin(&s_rstar, r);
+            __syncthreads();
+            const bool full = s_rstar < T;
+            const int last_r = full ? s_rstar : T - 1;
+            const int created = s_inc[last_r] + s_nch[last_r];
+            const int new_size = prev_size + created - (last_r + 1);
+            const bool stop = full || new_size == prev_size;
+            __syncthreads();
+            if (tid == 0) { s_nnext = 0; s_cursize = new_size; s_seq = seq_base + created; }
+            // children of the processed nodes go to per-pass staging (s_nch/s_inc are dead after this loop's reads)
+            __shared__ unsigned s_nbin[kCap];
+            __shared__ int s_nseq[kCap], s_ncnt[kCap];
+            __syncthreads();
+            for (int r = tid; r < T; r += kT) {
+                const unsigned bin = s_tval[r];
+                if (r > last_r) {                            // never reached: stays where it is in the list
+                    const int f = atomicAdd(&s_nfin, 1);
+                    if (f < kCap) {
+                        s_fkey[f] = first_pass ? ((1ull << 60) | (s_tkey[r] & kM36)) : ((s_tkey[r] & kM20) << 36);
+                        s_fval[f] = best_of(depth_cur, (int)bin);
+                    } else s_bail = 1;
+                    continue;
+                }
+                int child = 0;
+                for (int q = 0; q < 4; ++q) {
+                    const int cb = 4 * (int)bin + q, cc = count_at(depth_cur + 1, cb);
+                    if (cc == 0) continue;
+                    const unsigned long long seq = (unsigned long long)(seq_base + s_inc[r] + child);
+                    ++child;
+                    if (!stop && cc > 1) {
+                        if (depth_cur + 2 > kHD) { s_bail = 1; continue; }       // grandchildren would leave the pyramid
+                        const int s2 = atomicAdd(&s_nnext, 1);
+                        if (s2 < kCap) { s_nbin[s2] = (unsigned)cb; s_nseq[s2] = (int)seq; s_ncnt[s2] = cc; } else s_bail = 1;
+                    } else {
+                        const int f = atomicAdd(&s_nfin, 1);
+                        if (f < kCap) { s_fkey[f] = (kM20 - seq) << 36; s_fval[f] = best_of(depth_cur + 1, cb); } else s_bail = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            if (stop || s_bail) break;
+            const int T2 = s_nnext;
+            for (int s2 = tid; s2 < T2; s2 += kT) {
+                s_tkey[s2] = ((kM20 - (unsigned long long)s_ncnt[s2]) << 36) | (kM20 - (unsigned long long)s_nseq[s2]);
+                s_tval[s2] = s_nbin[s2];
+            }
+            depth_cur += 1;
+            first_pass = false;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (s_bail) { if (tid == 0) need_general[task] = 1; return; }
+    // ---- 5. sort the final nodes into list order, emit
+    const int F = s_nfin;
+    const int fp = next_pow2(F);
+    for (int f = F + tid; f < fp; f += kT) { s_fkey[f] = ~0ull; s_fval[f] = 0u; }
+    __syncthreads();
+    bitonic_sort(s_fkey, s_fval, fp);
+    const int n_out = min(F, lp.out_cap);
+    for (int f = tid; f < n_out; f += kT) {
+        const dcs_candidate cc = c[s_fval[f]];
+        SelKp s;
+        s.x = (int16_t)(cc.x + kMinBorder); s.y = (int16_t)(cc.y + kMinBorder); s.score = (int16_t)cc.score; s.level = (int8_t)l; s.pad = 0;
+        out[f] = s;
+    }
+    if (tid == 0) lvl_cnt[task] = n_out;
+}
+
 int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const OctLevels& levels, const OctScratch& scratch,
-                  int n_tasks, int dense_cap, SelKp* d_sel, int32_t* d_lvl_cnt, hipStream_t s)
+                  int n_tasks, int dense_cap, SelKp* d_sel, int32_t* d_lvl_cnt, int32_t* d_need_general, hipStream_t s)
 {
     if (n_tasks <= 0) return DCS_OK;
-    hipLaunchKernelGGL(k_octree, dim3(n_tasks), dim3(kT), 0, s, d_dense, d_lvl_off, levels, scratch, dense_cap, d_sel, d_lvl_cnt);
+    static const int force_general = getenv("DCS_OCTREE_FORCE_GENERAL") ? 1 : 0;      // test hook: exercise the sort-based kernel
+    int max_ini = 1;
+    for (int l = 0; l < levels.nlevels; ++l)
+        if (levels.lv[l].height > 0) max_ini = max(max_ini, (int)roundf((float)levels.lv[l].width / (float)levels.lv[l].height));
+    if (max_ini <= 1)
+        hipLaunchKernelGGL(k_octree_hist<1>, dim3(n_tasks), dim3(kT), 0, s, d_dense, d_lvl_off, levels, dense_cap, force_general, d_sel, d_lvl_cnt, d_need_general);
+    else
+        hipLaunchKernelGGL(k_octree_hist<2>, dim3(n_tasks), dim3(kT), 0, s, d_dense, d_lvl_off, levels, dense_cap, force_general, d_sel, d_lvl_cnt, d_need_general);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_octree, dim3(n_tasks), dim3(kT), 0, s, d_dense, d_lvl_off, levels, scratch, dense_cap, d_need_general, d_sel, d_lvl_cnt);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

@@ -107,7 +107,7 @@ struct dcs_orb {
     bool device_octree = true;
     bool no_overlap = false;
     OctLevels oct{};
-    DevBuf<int32_t> d_lvl_cnt;
+    DevBuf<int32_t> d_lvl_cnt, d_oct_flag;
     DevBuf<unsigned long long> d_oct_u64[3];
     DevBuf<unsigned> d_oct_u32[2];
     DevBuf<int> d_oct_i32[8];
@@ -250,6 +250,7 @@ int dcs_orb::configure(int rows, int cols)
     oct.out_per_image = out_total;
     if (device_octree) {
         if ((rc = d_lvl_cnt.resize((size_t)B * L))) return rc;
+        if ((rc = d_oct_flag.resize((size_t)B * L))) return rc;
         for (auto& b : d_oct_u64) if ((rc = b.resize(2 * dense_cap))) return rc;
         for (auto& b : d_oct_u32) if ((rc = b.resize(2 * dense_cap))) return rc;
         for (auto& b : d_oct_i32) if ((rc = b.resize(2 * dense_cap))) return rc;
@@ -329,7 +330,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         }
         OctScratch sc{d_oct_u64[0].p, d_oct_u8.p, d_oct_i32[0].p, d_oct_i32[1].p, d_oct_i32[2].p, d_oct_i32[3].p, d_oct_i32[4].p,
                       d_oct_i32[5].p, d_oct_i32[6].p, d_oct_i32[7].p, d_oct_u64[1].p, d_oct_u32[0].p, d_oct_u64[2].p, d_oct_u32[1].p};
-        if ((rc = launch_octree(d_dense.p, d_lvl_off.p, oct, sc, n_tasks, (int)dense_cap, d_sel.p, d_lvl_cnt.p, stream))) return rc;
+        if ((rc = launch_octree(d_dense.p, d_lvl_off.p, oct, sc, n_tasks, (int)dense_cap, d_sel.p, d_lvl_cnt.p, d_oct_flag.p, stream))) return rc;
         DCS_HIP(hipEventRecord(ev_t[6], stream));
         host_us = -1.f;
         DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));

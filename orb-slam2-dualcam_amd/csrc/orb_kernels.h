@@ -77,7 +77,7 @@ int launch_describe(const LevelSet& raw, const LevelSet& blurred, const Describe
                     int max_per_image, dcs_keypoint* d_kp, uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s);
 
 int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const OctLevels& levels, const OctScratch& scratch,
-                  int n_tasks, int dense_cap, SelKp* d_sel, int32_t* d_lvl_cnt, hipStream_t s);
+                  int n_tasks, int dense_cap, SelKp* d_sel, int32_t* d_lvl_cnt, int32_t* d_need_general, hipStream_t s);
 
 int upload_pattern();   // copies the rBRIEF table to constant memory of the current device
 

@@ -125,9 +125,10 @@ typedef short short2_t __attribute__((ext_vector_type(2)));
 // FAST-9/16 score of the pixel at c (LDS bytes, row pitch P): max over the 16 contiguous 9-arcs of the sign-consistent
 // minimum |centre - ring|, minus 1 (== OpenCV cornerScore<16>; "corner at T" <=> score >= T, so the score does not
 // depend on the threshold). Both polarities ride in one packed register: lo16 = c - ring ("darker"), hi16 = ring - c.
-__device__ __forceinline__ int fast_score(const uint8_t* c, int P)
+template <int P>
+__device__ __forceinline__ int fast_score(const uint8_t* c)
 {
-    const int off[16] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
+    constexpr int off[16] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
                          -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1};
     const int v = c[0];
     short2_t d[16], m2[16], m4[16], m8[16];
@@ -153,9 +154,10 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, int P)
 //   4. strict 8-neighbour NMS inside the ROI's detection area, iniTh -> minTh fallback when the cell has no
 //      iniTh keypoint (vKeysCell.empty(), :812), ordered emission into the cell's fixed slot range.
 // LDS: px[rh][P] + score[rh][P] bytes + survivor list (u16), sized by the host for the largest cell.
+template <int P>           // LDS row pitch in bytes (64 or 128): compile-time so that the ring offsets are immediates
 __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
                                                    dcs_candidate* __restrict__ slots, size_t slots_per_image,
-                                                   int32_t* __restrict__ cell_count, int P, int map_bytes)
+                                                   int32_t* __restrict__ cell_count, int map_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_px = smem;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     // ---- 3. exact scores of the survivors
     for (int i = lane; i < n_list; i += 64) {
         const int yx = s_list[i], y = yx >> 8, x = yx & 255;
-        const int s = fast_score(px + y * P + x, P);
+        const int s = fast_score<P>(px + y * P + x);
         sc[y * P + x] = (uint8_t)max(s, 0);
     }
     __syncthreads();
@@ -271,12 +273,16 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
                       int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s)
 {
     if (n_cells == 0) return DCS_OK;
-    const int P = (max_rw + 15 + 15) & ~15;                      // shift (<= 15) + row, rounded to 16 bytes
+    const int P = (max_rw + 15 <= 64) ? 64 : 128;                // shift (<= 15) + row fits the pitch
     const int map_bytes = ((max_rh * P) + 15) & ~15;
     const int list_bytes = (((max_rw - 6) * (max_rh - 6) * 2) + 15) & ~15;
     const size_t shmem = (size_t)2 * map_bytes + list_bytes;
-    hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, n_images), dim3(64), shmem, s, levels, d_cells, n_cells,
-                       ini_th, min_th, d_slots, slots_per_image, d_cell_count, P, map_bytes);
+    if (P == 64)
+        hipLaunchKernelGGL(k_fast_cells<64>, dim3(n_cells, n_images), dim3(64), shmem, s, levels, d_cells, n_cells,
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes);
+    else
+        hipLaunchKernelGGL(k_fast_cells<128>, dim3(n_cells, n_images), dim3(64), shmem, s, levels, d_cells, n_cells,
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
