@@ -102,6 +102,9 @@ int  dcs_orb_extract_batch_device(dcs_orb* h, const uint8_t* d_images, int n_ima
 int  dcs_orb_debug_level_dims(const dcs_orb* h, int level, int* w, int* h_out);
 int  dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t* dst /* w*h */);
 int  dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* dst, int cap, int* n);
+/* number of (image, level) quadtrees of the last call that left the LDS histogram fast path for the general
+   sort-based kernel (device-quadtree mode; 0 in host-quadtree mode) */
+int  dcs_orb_debug_quadtree_fallbacks(dcs_orb* h, int* n);
 /* per-stage time of the last extract call in microseconds (hipEvents on the streams the kernels ran on):
    resize chain, k_fast_cells, scan+gather, k_blur, host quadtree, k_describe, whole call (7 floats) */
 int  dcs_orb_last_timing(dcs_orb* h, float* us7);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "dcs_last_error", "dcs_version", "dcs_device_count",
     "dcs_orb_create", "dcs_orb_destroy", "dcs_orb_tables", "dcs_orb_extract", "dcs_orb_extract_batch",
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
-    "dcs_orb_debug_candidates", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
+    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow",
     "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
@@ -94,6 +94,7 @@ def lib():
             "dcs_orb_debug_level_dims": [vp, ci, pci, pci],
             "dcs_orb_debug_level": [vp, ci, ci, ci, vp],
             "dcs_orb_debug_candidates": [vp, ci, ci, vp, ci, pci],
+            "dcs_orb_debug_quadtree_fallbacks": [vp, pci],
             "dcs_orb_last_timing": [vp, vp],
             "dcs_orb_timing_totals": [vp, vp, vp, ci],
             "dcs_distribute_octree": [vp, ci, ci, ci, ci, ci, ci, vp, ci, pci],
@@ -190,10 +191,11 @@ class ORBextractor:
         _check(rc, "dcs_orb_extract_batch")
         return [kp[i, :n_out[i]].copy() for i in range(n)], [desc[i, :n_out[i]].copy() for i in range(n)]
 
-    def extract_batch_device(self, d_images, d_kp, d_desc, d_n, cap, stream=None):
-        """d_images: torch uint8 [n, rows, stride] on the GPU; outputs torch buffers (slotted)."""
+    def extract_batch_device(self, d_images, d_kp, d_desc, d_n, cap, stream=None, cols=None):
+        """d_images: torch uint8 [n, rows, stride] on the GPU (cols <= stride valid bytes per row); outputs torch
+        buffers (slotted)."""
         n, rows, stride = d_images.shape
-        rc = lib().dcs_orb_extract_batch_device(self._h, d_images.data_ptr(), n, rows, stride, stride, d_kp.data_ptr(),
+        rc = lib().dcs_orb_extract_batch_device(self._h, d_images.data_ptr(), n, rows, cols or stride, stride, d_kp.data_ptr(),
                                                 d_desc.data_ptr(), cap, d_n.data_ptr(), stream)
         _check(rc, "dcs_orb_extract_batch_device")
 
@@ -214,6 +216,11 @@ class ORBextractor:
         out = np.zeros(max(n.value, 1), CANDIDATE)
         _check(lib().dcs_orb_debug_candidates(self._h, image, level, _p(out), n.value, C.byref(n)), "dcs_orb_debug_candidates")
         return out[:n.value]
+
+    def quadtree_fallbacks(self):
+        n = C.c_int()
+        _check(lib().dcs_orb_debug_quadtree_fallbacks(self._h, C.byref(n)), "dcs_orb_debug_quadtree_fallbacks")
+        return n.value
 
     STAGES = ("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us")
 

@@ -555,6 +555,19 @@ int dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t* 
     return DCS_OK;
 }
 
+int dcs_orb_debug_quadtree_fallbacks(dcs_orb* h, int* n)
+{
+    if (!h || !h->configured || !n) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    *n = 0;
+    if (!h->device_octree || h->last_tasks <= 0) return DCS_OK;
+    DCS_HIP(hipSetDevice(h->device));
+    DCS_HIP(hipDeviceSynchronize());
+    std::vector<int32_t> f((size_t)h->last_tasks);
+    DCS_HIP(hipMemcpy(f.data(), h->d_oct_flag.p, sizeof(int32_t) * f.size(), hipMemcpyDeviceToHost));
+    for (int32_t v : f) *n += v != 0;
+    return DCS_OK;
+}
+
 int dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* dst, int cap, int* n)
 {
     if (!h || !h->configured || level < 0 || level >= h->t.nlevels || image < 0 || image >= h->last_n_images || !n) {

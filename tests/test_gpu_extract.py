@@ -156,3 +156,53 @@ def test_device_resident_batch_matches_host_api(pkg, oracle, synth):
     t = e.last_timing()
     assert t["total_us"] > 0
     e.close()
+
+
+def test_deep_quadtree_leaves_the_histogram_fast_path(pkg, oracle, synth):
+    """Corner patches on a geometric diagonal: one node splits per level, so the quota drives the quadtree deeper
+    than the 6-level LDS histogram pyramid and the sort-based kernel redoes those (image, level) tasks. The usual
+    scene stays on the fast path. Both are bit-exact."""
+    rng = np.random.default_rng(0)
+    img = np.full((480, 640), 120, np.uint8)
+    for k in range(1, 10):
+        x, y, s = int(30 + 560 * (1 - 2.0 ** -k)), int(30 + 400 * (1 - 2.0 ** -k)), max(4, 12 - k // 2)
+        img[y:y + s, x:x + s] = rng.integers(0, 256, (s, s), dtype=np.uint8)
+    e = pkg.ORBextractor(1000, 1.2, 8, 12, 5, max_images=1)
+    kp, desc = e(img)
+    assert e.quadtree_fallbacks() >= 3
+    okp, odesc = oracle.OrbOracle(1000, 1.2, 8, 12, 5).extract(img)
+    assert len(okp) > 100
+    _same(kp, desc, okp, odesc)
+    e.close()
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=1)
+    e(synth.frame_pair(640, 480, 0, 0)[0])
+    assert e.quadtree_fallbacks() == 0
+    e.close()
+
+
+def test_device_api_unaligned_pointer_and_stride(pkg, oracle, synth):
+    """HBM-resident input that is neither 4-byte aligned nor 4-byte strided (byte-wise fallback loads)."""
+    import torch
+    B, rows, cols, stride = 2, 240, 317, 323
+    base = synth.frame_pair(640, 480, 1, 0)
+    imgs = [np.ascontiguousarray(b[100:100 + rows, 50:50 + cols]) for b in base]
+    buf = torch.zeros(B * rows * stride + 8, dtype=torch.uint8, device="cuda")
+    view = buf[1:1 + B * rows * stride].view(B, rows, stride)          # data_ptr() % 4 == 1
+    view[:, :, :cols] = torch.from_numpy(np.stack(imgs)).cuda()
+    view[:, :, cols:] = 255                                            # padding must never be read as image
+    e = pkg.ORBextractor(400, 1.2, 8, 20, 7, max_images=B)
+    cap = e.default_cap()
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    assert view.data_ptr() % 4 == 1
+    e.extract_batch_device(view, d_kp, d_desc, d_n, cap, stream=torch.cuda.current_stream().cuda_stream, cols=cols)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    kp_all = d_kp.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    for i in range(B):
+        okp, odesc = oracle.OrbOracle(400, 1.2, 8, 20, 7).extract(imgs[i])
+        assert n[i] == len(okp) and len(okp) > 50
+        assert kp_all[i, :n[i]].tobytes() == okp.tobytes()
+        assert np.array_equal(d_desc[i, :n[i]].cpu().numpy(), odesc)
+    e.close()
