@@ -41,17 +41,40 @@ __device__ __forceinline__ Best best_merge(const Best& a, const Best& b)
     return r;
 }
 
-constexpr int kTile = 256;
-
-__device__ __forceinline__ void load_query(const uint8_t* __restrict__ q, int qi, int nq, unsigned long long (&qw)[4])
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
 {
-    qw[0] = qw[1] = qw[2] = qw[3] = 0;
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+constexpr int kTile = 256;
+constexpr unsigned kKeyInit = (256u << 23) | 0x7FFFFFu;      // distance 256 = "none" (ORBmatcher.cc:218-219), index field all ones
+
+__device__ __forceinline__ void load_query(const uint8_t* __restrict__ q, int qi, int nq, unsigned (&qw)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qw[k] = 0;
     if (qi < nq) {
         const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
         const uint4 a = qp[0], b = qp[1];
-        qw[0] = ((unsigned long long)a.y << 32) | a.x; qw[1] = ((unsigned long long)a.w << 32) | a.z;
-        qw[2] = ((unsigned long long)b.y << 32) | b.x; qw[3] = ((unsigned long long)b.w << 32) | b.z;
+        qw[0] = a.x; qw[1] = a.y; qw[2] = a.z; qw[3] = a.w; qw[4] = b.x; qw[5] = b.y; qw[6] = b.z; qw[7] = b.w;
     }
+}
+
+// popcount(q ^ t) over 256 bits as one v_bcnt_u32_b32 accumulate chain (8 xor + 8 bcnt, no separate adds)
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc)
+{
+    unsigned r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ unsigned hamming256(const unsigned (&q)[8], const uint4& lo, const uint4& hi)
+{
+    unsigned d = bcnt_acc(q[0] ^ lo.x, 0u);
+    d = bcnt_acc(q[1] ^ lo.y, d); d = bcnt_acc(q[2] ^ lo.z, d); d = bcnt_acc(q[3] ^ lo.w, d);
+    d = bcnt_acc(q[4] ^ hi.x, d); d = bcnt_acc(q[5] ^ hi.y, d); d = bcnt_acc(q[6] ^ hi.z, d); d = bcnt_acc(q[7] ^ hi.w, d);
+    return d;
 }
 
 // workgroup = 128 queries x 4 train splits: every lane keeps TWO queries in VGPRs (q_tile*128 + lane and + 64), so each
@@ -61,13 +84,16 @@ __device__ __forceinline__ void knn2_tile(const uint8_t* __restrict__ q, int nq,
                                           int32_t* __restrict__ best_d, int32_t* __restrict__ second_d)
 {
     __shared__ uint4 s_t[kTile * 2];                 // 256 descriptors x 32 B
-    __shared__ Best s_part[4][128];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ unsigned s_k1[4][128], s_k2[4][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qa = q_tile * 128 + lane, qb = qa + 64;
-    unsigned long long wa[4], wb[4];
+    unsigned wa[8], wb[8];
     load_query(q, qa, nq, wa);
     load_query(q, qb, nq, wb);
-    Best sa{256, -1, 256}, sb{256, -1, 256};
+    // best / second-best as packed keys (distance << 23 | train index): keys are unique, so the two smallest keys carry
+    // exactly (smallest distance, first index attaining it) and (second-smallest distance counted with multiplicity) --
+    // the same triple as best_update(), in 3 instructions per distance: key = lshl_or, k2 = med3(k1, k2, key), k1 = min.
+    unsigned a1 = kKeyInit, a2 = kKeyInit, b1 = kKeyInit, b2 = kKeyInit;
     for (int t0 = 0; t0 < nt; t0 += kTile) {
         const int n_here = min(kTile, nt - t0);
         __syncthreads();
@@ -76,24 +102,30 @@ __device__ __forceinline__ void knn2_tile(const uint8_t* __restrict__ q, int nq,
             for (int i = tid; i < n_here * 2; i += 256) s_t[i] = tp[i];
         }
         __syncthreads();
-        const int jb = wave * 64, je = min(jb + 64, n_here);
+        const int jb = wave * 64, je = min(jb + 64, n_here);             // wave-uniform (scalar) loop bounds
+#pragma unroll 4
         for (int j = jb; j < je; ++j) {
-            if (t_mask && t_mask[t0 + j]) continue;                      // wave-uniform branch
-            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&s_t[2 * j]);
-            const unsigned long long w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-            const int da = __popcll(wa[0] ^ w0) + __popcll(wa[1] ^ w1) + __popcll(wa[2] ^ w2) + __popcll(wa[3] ^ w3);
-            const int db = __popcll(wb[0] ^ w0) + __popcll(wb[1] ^ w1) + __popcll(wb[2] ^ w2) + __popcll(wb[3] ^ w3);
-            best_update(sa, da, t0 + j);
-            best_update(sb, db, t0 + j);
+            if (t_mask && t_mask[t0 + j]) continue;
+            const uint4 lo = s_t[2 * j], hi = s_t[2 * j + 1];           // LDS broadcast
+            const unsigned da = hamming256(wa, lo, hi), db = hamming256(wb, lo, hi);
+            const unsigned ka = (da << 23) | (unsigned)(t0 + j), kb = (db << 23) | (unsigned)(t0 + j);
+            a2 = umed3(a1, a2, ka); a1 = min(a1, ka);
+            b2 = umed3(b1, b2, kb); b1 = min(b1, kb);
         }
     }
-    s_part[wave][lane] = sa; s_part[wave][lane + 64] = sb;
+    s_k1[wave][lane] = a1; s_k2[wave][lane] = a2; s_k1[wave][lane + 64] = b1; s_k2[wave][lane + 64] = b2;
     __syncthreads();
     if (tid < 128) {
         const int qi = q_tile * 128 + tid;
         if (qi < nq) {
-            Best r = best_merge(best_merge(s_part[0][tid], s_part[1][tid]), best_merge(s_part[2][tid], s_part[3][tid]));
-            best_idx[qi] = r.idx; best_d[qi] = r.b1; second_d[qi] = r.b2;
+            unsigned k1 = s_k1[0][tid], k2 = s_k2[0][tid];
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) {                             // two smallest of the union (keys are distinct)
+                const unsigned o1 = s_k1[wv][tid], o2 = s_k2[wv][tid];
+                k2 = min(min(k2, o2), max(k1, o1));
+                k1 = min(k1, o1);
+            }
+            best_idx[qi] = (k1 >> 23) >= 256u ? -1 : (int)(k1 & 0x7FFFFFu); best_d[qi] = (int)(k1 >> 23); second_d[qi] = (int)(k2 >> 23);
         }
     }
 }
@@ -364,6 +396,7 @@ int dcs_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const u
     int rc = ensure_device();
     if (rc) return rc;
     if (nq == 0) return DCS_OK;
+    if (nt >= (1 << 23)) { set_error("nt %d exceeds the 2^23 train descriptors of one knn2 problem", nt); return DCS_ERR_UNSUPPORTED; }
     Scratch s;
     uint8_t *dq, *dt, *dm = nullptr;
     int32_t *bi, *bd, *sd;
@@ -445,6 +478,7 @@ int dcs_match_bf(const uint8_t* q, const dcs_keypoint* q_kp, int nq, const uint8
     if (rc) return rc;
     *n_matches = 0;
     if (nq == 0) return DCS_OK;
+    if (nt >= (1 << 23)) { set_error("nt %d exceeds the 2^23 train descriptors of one knn2 problem", nt); return DCS_ERR_UNSUPPORTED; }
     Scratch s;
     uint8_t *dq, *dt;
     dcs_keypoint *kq = nullptr, *kt = nullptr;
@@ -474,6 +508,7 @@ int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, c
     int rc = ensure_device();
     if (rc) return rc;
     if (n_pairs == 0) return DCS_OK;
+    if (cap >= (1 << 23)) { set_error("cap %d exceeds the 2^23 descriptors of one knn2 problem", cap); return DCS_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     // d_match doubles as the best-index buffer: the filter reads best_idx[i] and writes match[i] in the same thread
     hipLaunchKernelGGL(k_knn2_pairs, dim3((cap + 127) / 128, n_pairs), dim3(256), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);

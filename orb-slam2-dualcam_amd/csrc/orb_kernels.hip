@@ -133,7 +133,10 @@ __device__ __forceinline__ int fast_score(const uint8_t* c)
     const int v = c[0];
     short2_t d[16], m2[16], m4[16], m8[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { const int r = c[off[k]]; d[k] = short2_t{(short)(v - r), (short)(r - v)}; }
+    for (int k = 0; k < 16; ++k) {
+        const unsigned vr = (unsigned)v | ((unsigned)c[off[k]] << 16);            // (lo = centre, hi = ring)
+        asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d[k]) : "v"(vr));   // lo = v - r, hi = r - v
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
 #pragma unroll
@@ -148,7 +151,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* c)
 
 // One wave per (cell, image) -- the reference's per-cell cv::FAST call (ORBextractor.cc:789-827):
 //   1. ROI -> LDS with aligned dword loads (byte loads when the level is not 4-byte aligned)
-//   2. necessary test on the 4 compass ring pixels at minTh (a 9-arc always covers >= 2 of them); survivors are
+//   2. necessary test on the 4 compass ring pixels at minTh (a 9-arc always covers 2 adjacent ones); survivors are
 //      compacted IN ROW-MAJOR ORDER with ballot + popcount prefix
 //   3. exact score only for the survivors (packed 16-bit min/max), written to an LDS score map
 //   4. strict 8-neighbour NMS inside the ROI's detection area, iniTh -> minTh fallback when the cell has no
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + cd.x0;
             for (int i = lane; i < rh * rw; i += 64) { const int r = i / rw, c = i - r * rw; s_px[r * P + shift + c] = src[(size_t)r * lv.pitch + c]; }
         }
-        uint32_t* sc_dw = reinterpret_cast<uint32_t*>(s_sc);
-        for (int i = lane; i < rh * Pdw; i += 64) sc_dw[i] = 0;
+        uint4* sc_q = reinterpret_cast<uint4*>(s_sc);
+        for (int i = lane; i < rh * (P >> 4); i += 64) sc_q[i] = uint4{0, 0, 0, 0};
     }
     __syncthreads();
     const uint8_t* px = s_px + shift;
@@ -208,21 +211,30 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     const int dw = rw - 6, dh = rh - 6, ndet = dw * dh;
     // ---- 2. compass test + ordered compaction; survivors are stored as (y << 8 | x), ROI coordinates
     int n_list = 0;
-    {
+    auto compass = [&](const uint8_t* c) -> bool {
+        // a 9-arc covers two ADJACENT compass pixels: (b0|b8)&(b4|b12) for "brighter", same for "darker"
+        const int v = c[0], hi = v + min_th, lo = v - min_th;
+        const int r0 = c[3 * P], r4 = c[3], r8 = c[-3 * P], r12 = c[-3];
+        return min(max(r0, r8), max(r4, r12)) > hi || max(min(r0, r8), min(r4, r12)) < lo;
+    };
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    if (dw <= 32) {                                  // two detection rows per round: lanes 0-31 row y, lanes 32-63 row y + 1
+        const int x = 3 + (lane & 31);
+        const bool col_ok = (lane & 31) < dw;
+        const uint8_t* c = px + (3 + (lane >> 5)) * P + x;
+        for (int y = 3 + (lane >> 5); y < 3 + dh + (lane >> 5); y += 2, c += 2 * P) {     // same trip count in both halves
+            const bool pass = col_ok && y < dh + 3 && compass(c);
+            const unsigned long long m = __ballot(pass);
+            if (pass) s_list[n_list + __popcll(m & lanes_below)] = (uint16_t)((y << 8) | x);
+            n_list += __popcll(m);
+        }
+    } else {
         int y = 3 + lane / dw, x = 3 + lane % dw;            // pixel p = p0 + lane, advanced by 64 per round without dividing
         const int step_y = 64 / dw, step_x = 64 % dw;
         for (int p0 = 0; p0 < ndet; p0 += 64) {
-            bool pass = false;
-            if (p0 + lane < ndet) {
-                const uint8_t* c = px + y * P + x;
-                const int v = c[0], hi = v + min_th, lo = v - min_th;
-                const int r0 = c[3 * P], r4 = c[3], r8 = c[-3 * P], r12 = c[-3];
-                const int nb = (r0 > hi) + (r4 > hi) + (r8 > hi) + (r12 > hi);
-                const int nd = (r0 < lo) + (r4 < lo) + (r8 < lo) + (r12 < lo);
-                pass = nb >= 2 || nd >= 2;
-            }
+            const bool pass = p0 + lane < ndet && compass(px + y * P + x);
             const unsigned long long m = __ballot(pass);
-            if (pass) s_list[n_list + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((y << 8) | x);
+            if (pass) s_list[n_list + __popcll(m & lanes_below)] = (uint16_t)((y << 8) | x);
             n_list += __popcll(m);
             y += step_y; x += step_x;
             if (x >= dw + 3) { x -= dw; ++y; }
@@ -244,8 +256,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         const uint8_t* c = sc + y * P + x;
         const int s = c[0];
         if (s >= min_th) {
-            const bool mx = s > c[-1] && s > c[1] && s > c[-P - 1] && s > c[-P] && s > c[-P + 1] && s > c[P - 1] && s > c[P] && s > c[P + 1];
-            if (mx) { f_min |= 1ull << it; if (s >= ini_th) f_ini |= 1ull << it; }
+            const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-P - 1], (int)c[-P])), max(max((int)c[-P + 1], (int)c[P - 1]), max((int)c[P], (int)c[P + 1])));
+            if (s > nb) { f_min |= 1ull << it; if (s >= ini_th) f_ini |= 1ull << it; }
         }
     }
     const bool any_ini = __any(f_ini != 0);
