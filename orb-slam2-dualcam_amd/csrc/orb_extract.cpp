@@ -108,6 +108,7 @@ struct dcs_orb {
     bool no_overlap = false;
     OctLevels oct{};
     DevBuf<int32_t> d_lvl_cnt, d_oct_flag;
+    DevBuf<uint32_t> d_ic_mask;
     DevBuf<unsigned long long> d_oct_u64[3];
     DevBuf<unsigned> d_oct_u32[2];
     DevBuf<int> d_oct_i32[8];
@@ -248,6 +249,12 @@ int dcs_orb::configure(int rows, int cols)
         out_total += ol.out_cap;
     }
     oct.out_per_image = out_total;
+    {
+        std::vector<uint32_t> mask(kIcMaskWords);
+        build_ic_mask(t.umax, mask.data());
+        if ((rc = d_ic_mask.resize(kIcMaskWords))) return rc;
+        DCS_HIP(hipMemcpy(d_ic_mask.p, mask.data(), sizeof(uint32_t) * kIcMaskWords, hipMemcpyHostToDevice));
+    }
     if (device_octree) {
         if ((rc = d_lvl_cnt.resize((size_t)B * L))) return rc;
         if ((rc = d_oct_flag.resize((size_t)B * L))) return rc;
@@ -321,7 +328,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     DescribeParams dp{};
     for (int l = 0; l < L; ++l) { dp.scale[l] = t.scale[l]; dp.scaled_patch[l] = g.lv[l].scaled_patch; dp.out_base[l] = oct.lv[l].out_base; }
     for (int v = 0; v <= kHalfPatch; ++v) { dp.umax[v] = t.umax[v]; dp.umax_packed |= (unsigned long long)(t.umax[v] & 15) << (4 * v); }
-    dp.out_per_image = oct.out_per_image; dp.nlevels = L;
+    dp.out_per_image = oct.out_per_image; dp.nlevels = L; dp.ic_mask = d_ic_mask.p; dp.dbg = getenv("DCS_DESC_DBG") ? atoi(getenv("DCS_DESC_DBG")) : 0;
     if (device_octree) {
         // fully asynchronous: quadtree on the device, no host round trip
         if (cap < oct.out_per_image) {

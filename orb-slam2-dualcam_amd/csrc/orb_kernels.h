@@ -42,7 +42,12 @@ struct DescribeParams {
     // device-quadtree mode: keypoints of (image, level) live at sel[image * out_per_image + out_base[level] ...]
     int out_base[kMaxLevels];
     int out_per_image, nlevels;
+    int dbg;
+    const uint32_t* ic_mask;             // device table built by build_ic_mask()
 };
+
+constexpr int kIcMaskWords = 4 * 288;    // 4 alignments x (31 rows x 9 dwords, padded to 288)
+void build_ic_mask(const int* umax, uint32_t* out /* kIcMaskWords */);
 
 // per-level parameters of the device quadtree (k_octree)
 struct OctLevel { int width, height, n_target, out_base, out_cap; };

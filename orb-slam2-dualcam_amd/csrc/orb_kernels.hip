@@ -119,6 +119,16 @@ int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_c
     return DCS_OK;
 }
 
+// XCD-aware block mapping: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
+// 4 MB L2). Map a 1-D grid of n_images * per_image blocks so that all blocks of one image have ids congruent mod 8:
+// neighbouring cells / tiles / keypoints of an image then share cache lines in ONE L2 instead of up to eight.
+__device__ __forceinline__ void xcd_image_block(int b, int n_images, int per_image, int& img, int& item)
+{
+    const int full = n_images & ~7;                          // images forming complete groups of 8
+    if (b < full * per_image) { const int j = b >> 3; img = (j / per_image) * 8 + (b & 7); item = j % per_image; }
+    else { const int r = b - full * per_image; img = full + r / per_image; item = r % per_image; }
+}
+
 // ------------------------------------------------------------------------------------- FAST
 typedef short short2_t __attribute__((ext_vector_type(2)));
 
@@ -131,21 +141,26 @@ __device__ __forceinline__ int fast_score(const uint8_t* c)
     constexpr int off[16] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
                          -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1};
     const int v = c[0];
-    short2_t d[16], m2[16], m4[16], m8[16];
+    short2_t d[16], g[16], h[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const unsigned vr = (unsigned)v | ((unsigned)c[off[k]] << 16);            // (lo = centre, hi = ring)
         asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d[k]) : "v"(vr));   // lo = v - r, hi = r - v
     }
+    // min over every circular window of 9 (van Herk / Gil-Werman with two blocks of 8): g = prefix minima and
+    // h = suffix minima inside blocks {0..7}, {8..15}; window k..k+8 = h[k] (k .. block end) + g[k+8] (next block start .. k+8)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+    for (int blk = 0; blk < 16; blk += 8) {
+        g[blk] = d[blk]; h[blk + 7] = d[blk + 7];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+        for (int j = 1; j < 8; ++j) {
+            g[blk + j] = __builtin_elementwise_min(g[blk + j - 1], d[blk + j]);
+            h[blk + 7 - j] = __builtin_elementwise_min(h[blk + 8 - j], d[blk + 7 - j]);
+        }
+    }
+    short2_t best = __builtin_elementwise_min(h[0], g[8]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-    short2_t best = short2_t{-256, -256};
-#pragma unroll
-    for (int k = 0; k < 16; ++k) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
+    for (int k = 1; k < 16; ++k) best = __builtin_elementwise_max(best, __builtin_elementwise_min(h[k], g[(k + 8) & 15]));
     return max((int)best.x, (int)best.y) - 1;
 }
 
@@ -160,13 +175,16 @@ __device__ __forceinline__ int fast_score(const uint8_t* c)
 template <int P>           // LDS row pitch in bytes (64 or 128): compile-time so that the ring offsets are immediates
 __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
                                                    dcs_candidate* __restrict__ slots, size_t slots_per_image,
-                                                   int32_t* __restrict__ cell_count, int map_bytes)
+                                                   int32_t* __restrict__ cell_count, int map_bytes, int n_images)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_px = smem;
     uint8_t* s_sc = smem + map_bytes;
     uint16_t* s_list = reinterpret_cast<uint16_t*>(smem + 2 * map_bytes);
-    const int cell = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    int img, cell;
+    if (n_images < 0) { img = blockIdx.x / n_cells; cell = blockIdx.x % n_cells; } else
+    xcd_image_block(blockIdx.x, n_images, n_cells, img, cell);
     const CellDesc cd = cells[cell];
     const int rw = cd.rw, rh = cd.rh;
     if (rw < 7 || rh < 7) {
@@ -290,11 +308,11 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
     const int list_bytes = (((max_rw - 6) * (max_rh - 6) * 2) + 15) & ~15;
     const size_t shmem = (size_t)2 * map_bytes + list_bytes;
     if (P == 64)
-        hipLaunchKernelGGL(k_fast_cells<64>, dim3(n_cells, n_images), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes);
+        hipLaunchKernelGGL(k_fast_cells<64>, dim3(n_cells * n_images), dim3(64), shmem, s, levels, d_cells, n_cells,
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, getenv("DCS_NO_XCD") ? -n_images : n_images);
     else
-        hipLaunchKernelGGL(k_fast_cells<128>, dim3(n_cells, n_images), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes);
+        hipLaunchKernelGGL(k_fast_cells<128>, dim3(n_cells * n_images), dim3(64), shmem, s, levels, d_cells, n_cells,
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, getenv("DCS_NO_XCD") ? -n_images : n_images);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -582,112 +600,191 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 constexpr int kPatchR = 18;                 // rotated pattern reach: max radius 18.38 -> |coord| <= 18
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
 constexpr int kPatchDw = 16;                // dwords per staged row: 4 x 16 B cover 37 bytes + <= 15 alignment bytes
+constexpr int kDescKp = 64;                 // keypoints per workgroup
+constexpr int kIcCols = 9;                  // aligned dwords covering x-15 .. x+15
+constexpr int kIcTasks = 288;                    // 31 x 9 = 279 dword tasks per keypoint, padded to 18 rounds of 16 lanes
 
-// one wave per keypoint; 4 keypoints per workgroup. grid (ceil(max_per_image/4), n_images)
+// byte masks of the umax disc for the IC_Angle dword tasks: entry [shift][row * 9 + col] selects the bytes b of the
+// aligned dword at u = -15 - shift + 4 * col + b (shift = (x - 15) & 3) with |u| <= umax[|row - 15|]
+void build_ic_mask(const int* umax, uint32_t* out /* kIcMaskWords */)
+{
+    for (int shift = 0; shift < 4; ++shift)
+        for (int row = 0; row < kPatchSize; ++row)
+            for (int col = 0; col < kIcCols; ++col) {
+                uint32_t m = 0;
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int u = -kHalfPatch - shift + 4 * col + bb;
+                    if (std::abs(u) <= umax[std::abs(row - kHalfPatch)]) m |= 0xffu << (8 * bb);
+                }
+                out[shift * kIcTasks + row * kIcCols + col] = m;
+            }
+    for (int shift = 0; shift < 4; ++shift)
+        for (int t = kPatchSize * kIcCols; t < kIcTasks; ++t) out[shift * kIcTasks + t] = 0;     // padding tasks contribute nothing
+}
+
+// Workgroup = 64 keypoints of one image, three phases:
+//   A. IC_Angle moments (exact int32). A 16-lane row of a wave owns one keypoint; its 279 dword tasks (31 rows x 9
+//      aligned dwords) are masked with the precomputed disc mask and reduced with v_dot4_u32_u8:
+//      sum(val) and sum((u + 32) * val) per dword, m01 += v * sum(val).
+//   B. one LANE per keypoint: fastAtan2 + (float)cos/sin((double)rad) -- the double-precision sincos is ~200
+//      instructions, so it is issued once per 64 keypoints instead of once per keypoint-wave -- and the cv::KeyPoint.
+//   C. one wave per keypoint: 37x64 B blurred neighbourhood -> LDS (16-byte loads), 4 rounds of 64 rBRIEF tests.
 __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
                                                   const SelKp* __restrict__ sel, const int32_t* __restrict__ img_off,
                                                   const int32_t* __restrict__ lvl_cnt, dcs_keypoint* __restrict__ kp_out,
-                                                  uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out)
+                                                  uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out, int n_images, int chunks)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][kPatchRows * kPatchDw];
-    __shared__ char4 s_pattern[256];
-    s_pattern[threadIdx.x] = reinterpret_cast<const char4*>(c_pattern)[threadIdx.x];    // 1 KB table, one coalesced load
-    const int img = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
-    int n_img, src = 0;
+    __shared__ float4 s_pattern[256];
+    __shared__ uint32_t s_mask[kIcMaskWords];
+    __shared__ SelKp s_sel[kDescKp];
+    __shared__ int s_m10[kDescKp], s_m01[kDescKp];
+    __shared__ float s_cos[kDescKp], s_sin[kDescKp];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int img, chunk;
+    xcd_image_block(blockIdx.x, n_images, chunks, img, chunk);
+    const int i0 = chunk * kDescKp;
+    int n_img;
     if (lvl_cnt) {                                           // device quadtree: per-level slots, level-major output order
         int acc = 0;
-        src = -1;
-        for (int l = 0; l < prm.nlevels; ++l) {
-            const int cnt = lvl_cnt[img * prm.nlevels + l];
-            if (src < 0 && i < acc + cnt) src = img * prm.out_per_image + prm.out_base[l] + (i - acc);
-            acc += cnt;
-        }
+        for (int l = 0; l < prm.nlevels; ++l) acc += lvl_cnt[img * prm.nlevels + l];
         n_img = min(acc, cap);
-        if (src < 0) src = img * prm.out_per_image;
-    } else {
-        const int first = img_off[img];
-        n_img = min(img_off[img + 1] - first, cap);
-        src = first + (i < n_img ? i : 0);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) n_out[img] = n_img;
-    if (blockIdx.x * 4 >= n_img) return;                     // block-uniform
-    const bool active = i < n_img;                           // wave-uniform; inactive waves only hit the barrier
-    const SelKp k = sel[src];
-    const int x = k.x, y = k.y, level = k.level;
-
-    // ---- IC_Angle on the unblurred level: moments over the umax disc (exact int32). Rows are read as aligned
-    // dwords (9 per row cover x-15..x+15); umax[] rides in a 64-bit immediate (4 bits per row).
-    const LevelView rv = raw.lv[level];
-    const uint8_t* rimg = rv.base + (size_t)img * rv.img_stride;
-    int m10 = 0, m01 = 0;
-    if (((reinterpret_cast<uintptr_t>(rimg) | (uintptr_t)rv.pitch) & 15) == 0) {
-        const int xs = (x - kHalfPatch) & ~15;               // 3 x 16 B cover x-15 .. x+15 (31 + <= 15 bytes)
-        for (int idx = lane; idx < kPatchSize * 3; idx += 64) {
-            const int r = idx / 3, c = idx - r * 3;
-            const int v = r - kHalfPatch, um = (int)((prm.umax_packed >> (4 * abs(v))) & 15ull);
-            const uint4 q = *reinterpret_cast<const uint4*>(rimg + (size_t)(y + v) * rv.pitch + xs + 16 * c);
-            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
-            const int u0 = xs + 16 * c - x;
-#pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const int u = u0 + b, val = (int)((w4[b >> 2] >> (8 * (b & 3))) & 0xffu);
-                if (abs(u) <= um) { m10 += u * val; m01 += v * val; }
-            }
+    } else n_img = min(img_off[img + 1] - img_off[img], cap);
+    if (chunk == 0 && tid == 0) n_out[img] = n_img;
+    if (i0 >= n_img) return;                                 // block-uniform
+    {
+        const char4 pt = reinterpret_cast<const char4*>(c_pattern)[tid];
+        s_pattern[tid] = float4{(float)pt.x, (float)pt.y, (float)pt.z, (float)pt.w};
+        for (int e = tid; e < kIcMaskWords; e += 256) s_mask[e] = prm.ic_mask[e];
+        if (tid < kDescKp) {
+            const int i = i0 + tid;
+            int src;
+            if (lvl_cnt) {
+                int acc = 0;
+                src = -1;
+                for (int l = 0; l < prm.nlevels; ++l) {
+                    const int cnt = lvl_cnt[img * prm.nlevels + l];
+                    if (src < 0 && i < acc + cnt) src = img * prm.out_per_image + prm.out_base[l] + (i - acc);
+                    acc += cnt;
+                }
+                if (src < 0) src = img * prm.out_per_image;
+            } else src = img_off[img] + (i < n_img ? i : 0);
+            s_sel[tid] = sel[src];
         }
-    } else {
-        const uint8_t* rc = rimg + (size_t)y * rv.pitch + x;
-        for (int idx = lane; idx < kPatchSize * kPatchSize; idx += 64) {
-            const int v = idx / kPatchSize - kHalfPatch, u = idx % kPatchSize - kHalfPatch;
-            if (abs(u) <= (int)((prm.umax_packed >> (4 * abs(v))) & 15ull)) {
-                const int val = rc[v * rv.pitch + u];
-                m10 += u * val; m01 += v * val;
-            }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    // ---- stage the 37x37 blurred neighbourhood in LDS with aligned dword loads
-    const LevelView bv = blurred.lv[level];
-    const uint8_t* bimg = bv.base + (size_t)img * bv.img_stride;
-    const int xs = (x - kPatchR) & ~15, shift = (x - kPatchR) & 15;       // blurred slab: 256-B aligned levels, pitch % 64 == 0
-    uint32_t* patch = s_patch[wave];
-    for (int idx = lane; idx < kPatchRows * 4; idx += 64) {
-        const int r = idx >> 2, c = idx & 3;
-        reinterpret_cast<uint4*>(patch)[idx] = *reinterpret_cast<const uint4*>(bimg + (size_t)(y - kPatchR + r) * bv.pitch + xs + 16 * c);
     }
     __syncthreads();
-    if (!active) return;
-    const uint8_t* pb = reinterpret_cast<const uint8_t*>(patch) + kPatchR * (kPatchDw * 4) + kPatchR + shift;
+    const int n_here = min(kDescKp, n_img - i0);             // keypoints of this workgroup
 
-    // ---- steered BRIEF: a = (float)cos((double)rad), b = (float)sin((double)rad)   
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    const float rad = __fmul_rn(angle, factorPI);
-    const float a = (float)cos((double)rad), b = (float)sin((double)rad);
-    uint8_t* dout = desc_out + ((size_t)img * cap + i) * 32;
+    // ---- A. IC_Angle moments on the unblurred level
+    if (!(prm.dbg & 1)) {
+        const int grp = lane >> 4, sub = lane & 15;
+#pragma unroll 1
+        for (int batch = 0; batch < 4; ++batch) {
+            const int kq = wave * 16 + batch * 4 + grp;
+            if (wave * 16 + batch * 4 >= n_here) break;      // wave-uniform
+            const SelKp k = s_sel[min(kq, n_here - 1)];
+            const int x = k.x, y = k.y;
+            const LevelView rv = raw.lv[k.level];
+            const uint8_t* rimg = rv.base + (size_t)img * rv.img_stride;
+            int m10 = 0, m01 = 0;
+            if (((reinterpret_cast<uintptr_t>(rimg) | (uintptr_t)rv.pitch) & 3) == 0) {
+                const int shift = (x - kHalfPatch) & 3;
+                const uint8_t* p0 = rimg + (size_t)(y - kHalfPatch) * rv.pitch + (x - kHalfPatch - shift);
+                const uint32_t* mk = s_mask + shift * kIcTasks;
+                unsigned s_all = 0, s_u = 0;                 // sum(val), sum((u + 32) * val)
+                int row = sub / kIcCols, col = sub - row * kIcCols;      // task t = sub + 16 * round
+#pragma unroll 6
+                for (int t = sub; t < kIcTasks; t += 16) {   // 18 rounds for every lane (padding tasks have an empty mask)
+                    const unsigned val = *reinterpret_cast<const uint32_t*>(p0 + (size_t)row * rv.pitch + 4 * col) & mk[t];
+                    const unsigned ub = (unsigned)(17 - shift + 4 * col);                        // u + 32 of byte 0 (<= 49)
+                    const unsigned w = (__umul24(ub, 0x010101u) + 0x03020100u) + (ub << 24);    // u + 32 per byte, no carries
+                    const unsigned rs = __builtin_amdgcn_udot4(val, 0x01010101u, 0u, false);
+                    s_u = __builtin_amdgcn_udot4(val, w, s_u, false);
+                    s_all += rs;
+                    m01 += (row - kHalfPatch) * (int)rs;
+                    col += 16 - kIcCols; row += 1;
+                    if (col >= kIcCols) { col -= kIcCols; row += 1; }
+                }
+                m10 = (int)s_u - 32 * (int)s_all;
+            } else {                                         // unaligned level-0 input: byte loads
+                const uint8_t* rc = rimg + (size_t)y * rv.pitch + x;
+                for (int idx = sub; idx < kPatchSize * kPatchSize; idx += 16) {
+                    const int v = idx / kPatchSize - kHalfPatch, u = idx % kPatchSize - kHalfPatch;
+                    if (abs(u) <= (int)((prm.umax_packed >> (4 * abs(v))) & 15ull)) {
+                        const int val = rc[v * rv.pitch + u];
+                        m10 += u * val; m01 += v * val;
+                    }
+                }
+            }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int t = it * 64 + lane;
-        const char4 pt = s_pattern[t];
-        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = pb[r0 * (kPatchDw * 4) + c0], t1 = pb[r1 * (kPatchDw * 4) + c1];
-        const unsigned long long m = __ballot(t0 < t1);      // bit j of m = test 64*it + j  (LSB-first bytes)
-        if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * it) = m;
+            for (int d = 8; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
+            if (sub == 0 && kq < n_here) { s_m10[kq] = m10; s_m01[kq] = m01; }
+        }
     }
-    if (lane == 0) {
+    __syncthreads();
+    // ---- B. orientation, steering coefficients a = (float)cos((double)rad), b = (float)sin((double)rad), keypoint
+    if (tid < n_here) {
+        const SelKp k = s_sel[tid];
+        const float angle = fast_atan2_deg((float)s_m01[tid], (float)s_m10[tid]);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        const float rad = __fmul_rn(angle, factorPI);
+        if (prm.dbg & 2) { s_cos[tid] = 1.f; s_sin[tid] = rad; } else {
+        s_cos[tid] = (float)cos((double)rad); s_sin[tid] = (float)sin((double)rad); }
         dcs_keypoint o;
+        const int level = k.level;
         const float sc = prm.scale[level];
-        o.x = level ? __fmul_rn((float)x, sc) : (float)x;
-        o.y = level ? __fmul_rn((float)y, sc) : (float)y;
+        o.x = level ? __fmul_rn((float)k.x, sc) : (float)k.x;
+        o.y = level ? __fmul_rn((float)k.y, sc) : (float)k.y;
         o.size = (float)prm.scaled_patch[level];
         o.angle = angle; o.response = (float)k.score; o.octave = level; o.class_id = -1;
-        kp_out[(size_t)img * cap + i] = o;
+        kp_out[(size_t)img * cap + i0 + tid] = o;
+    }
+    __syncthreads();
+    // ---- C. steered BRIEF, one wave per keypoint
+    uint32_t* patch = s_patch[wave];
+    const int r_lane = lane >> 2;                            // 16 rows x 4 x 16 B per wave pass; 37 rows = 3 passes (last: 5 rows)
+    uint4 q0, q1, q2;
+    int shift = 0;
+    auto fetch = [&](int kq) {                               // blurred neighbourhood of keypoint kq -> registers
+        const SelKp k = s_sel[kq];
+        const LevelView bv = blurred.lv[k.level];
+        const uint8_t* bimg = bv.base + (size_t)img * bv.img_stride;
+        const int xs = (k.x - kPatchR) & ~15;                // blurred slab: 256-B aligned levels, pitch % 64 == 0
+        shift = (k.x - kPatchR) & 15;
+        const uint8_t* bsrc = bimg + (size_t)(k.y - kPatchR) * bv.pitch + xs + 16 * (lane & 3);
+        q0 = *reinterpret_cast<const uint4*>(bsrc + (size_t)r_lane * bv.pitch);
+        q1 = *reinterpret_cast<const uint4*>(bsrc + (size_t)(r_lane + 16) * bv.pitch);
+        q2 = *reinterpret_cast<const uint4*>(bsrc + (size_t)min(r_lane + 32, kPatchRows - 1) * bv.pitch);
+    };
+    if (wave * 16 < n_here && !(prm.dbg & 4)) fetch(wave * 16);
+#pragma unroll 1
+    for (int kk = 0; kk < 16; ++kk) {
+        const int kq = wave * 16 + kk;
+        if (kq >= n_here || (prm.dbg & 4)) break;            // wave-uniform
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // previous keypoint's LDS reads are done
+        __builtin_amdgcn_wave_barrier();
+        reinterpret_cast<uint4*>(patch)[lane] = q0;
+        reinterpret_cast<uint4*>(patch)[lane + 64] = q1;
+        if (lane + 128 < kPatchRows * 4) reinterpret_cast<uint4*>(patch)[lane + 128] = q2;
+        const uint8_t* pb = reinterpret_cast<const uint8_t*>(patch) + kPatchR * (kPatchDw * 4) + kPatchR + shift;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (kq + 1 < min(n_here, wave * 16 + 16)) fetch(kq + 1);        // next keypoint's loads fly during this one's tests
+        const float a = s_cos[kq], b = s_sin[kq];
+        uint8_t* dout = desc_out + ((size_t)img * cap + i0 + kq) * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float4 pt = s_pattern[it * 64 + lane];
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+            const int t0 = pb[r0 * (kPatchDw * 4) + c0], t1 = pb[r1 * (kPatchDw * 4) + c1];
+            const unsigned long long m = __ballot(t0 < t1);  // bit j of m = test 64*it + j  (LSB-first bytes)
+            if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * it) = m;
+        }
     }
 }
 
@@ -695,9 +792,9 @@ int launch_describe(const LevelSet& raw, const LevelSet& blurred, const Describe
                     const int32_t* d_img_off, const int32_t* d_lvl_cnt, int n_images, int max_per_image, dcs_keypoint* d_kp,
                     uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s)
 {
-    const int gx = max_per_image > 0 ? (max_per_image + 3) / 4 : 1;
-    hipLaunchKernelGGL(k_describe, dim3(gx, n_images), dim3(256), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
-                       d_desc, cap, d_n_out);
+    const int gx = max_per_image > 0 ? (max_per_image + kDescKp - 1) / kDescKp : 1;
+    hipLaunchKernelGGL(k_describe, dim3(gx * n_images), dim3(256), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
+                       d_desc, cap, d_n_out, n_images, gx);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
