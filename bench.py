@@ -81,9 +81,12 @@ def main():
     matcher = pkg.ORBmatcher(0.75, True)
     cap = ext.default_cap()
     S = 2 * P + 2                                   # feature slots: [prev cam0, prev cam1, batch ...]
-    d_kp = torch.zeros((S, cap, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((S, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    # two slot sets: matching of step i (main stream) overlaps the extraction of step i + 1 (lane streams)
+    NB = 2
+    d_kp_b = [torch.zeros((S, cap, 7), dtype=torch.float32, device=dev) for _ in range(NB)]
+    d_desc_b = [torch.zeros((S, cap, 32), dtype=torch.uint8, device=dev) for _ in range(NB)]
+    d_n_b = [torch.zeros(S, dtype=torch.int32, device=dev) for _ in range(NB)]
+    match_done = [torch.cuda.Event() for _ in range(NB)]
     pairs = []
     for f in range(P):
         c0, c1 = 2 + 2 * f, 3 + 2 * f
@@ -117,20 +120,26 @@ def main():
     step_no = [0]
 
     def step(timed):
-        ev = ev_all[step_no[0]]
+        it = step_no[0]
+        ev = ev_all[it]
         step_no[0] += 1
-        # the batch is split over `n_lanes` extractor handles on their own streams; matching waits for all of them
-        lane_go.record()
+        cur, prv = it % NB, (it - 1) % NB
+        d_kp, d_desc, d_n = d_kp_b[cur], d_desc_b[cur], d_n_b[cur]
+        # the batch is split over `n_lanes` extractor handles on their own streams; they only wait for the matcher to
+        # be done with this slot set (step it - 2), so extraction of step it overlaps matching of step it - 1
         first = 0
         for li in range(n_lanes):
             a, b = 2 * first, 2 * (first + lane_pairs[li])
-            lane_streams[li].wait_event(lane_go)
+            if it >= NB:
+                lane_streams[li].wait_event(match_done[cur])
             exts[li].extract_batch_device(d_img[a:b], d_kp[2 + a:2 + b], d_desc[2 + a:2 + b], d_n[2 + a:2 + b], cap,
                                           stream=lane_streams[li].cuda_stream)
             lane_done[li].record(lane_streams[li])
             first += lane_pairs[li]
         for li in range(n_lanes):
             torch.cuda.current_stream().wait_event(lane_done[li])
+        # newest dual frame of the previous step is "t-1" of this one
+        d_kp[0:2].copy_(d_kp_b[prv][S - 2:]); d_desc[0:2].copy_(d_desc_b[prv][S - 2:]); d_n[0:2].copy_(d_n_b[prv][S - 2:])
         ev[0].record()
         matcher.match_bf_batch_device(d_desc, d_kp, d_n, cap, d_pairs, n_pairs, d_match, d_nm, d_b, d_s, 50, stream=stream)
         ev[1].record()
@@ -142,8 +151,7 @@ def main():
             ev[3].record()
             sharding.unpack_features(g_recv, cap, g_kp, g_desc, g_n)
             matcher.match_bf_batch_device(g_desc, g_kp, g_n, cap, x_pairs, world - 1, x_match, x_nm, x_b, x_s, 50, stream=stream)
-        # newest dual frame becomes "t-1" of the next step
-        d_kp[0:2].copy_(d_kp[S - 2:]); d_desc[0:2].copy_(d_desc[S - 2:]); d_n[0:2].copy_(d_n[S - 2:])
+        match_done[cur].record()
         return None
 
     def barrier():
@@ -176,7 +184,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    n_feat_step = int(d_n[2:].sum().item())
+    n_feat_step = int(d_n_b[(step_no[0] - 1) % NB][2:].sum().item())
     n_match_step = int(d_nm.sum().item())
     tot = torch.tensor([n_feat_step], dtype=torch.float64, device=dev)
     if world > 1:
@@ -196,12 +204,12 @@ def main():
         algo = {                                     # algorithmic bytes per LAUNCH x images per launch
             "k_resize(x7)": ((sum_px - px7) + sum_17) * n_img_l,
             "k_fast_cells": sum_px * n_img_l,
-            "k_blur+k_blur_edges": 2 * sum_px * n_img_l,
+            "k_blur": 2 * sum_px * n_img_l,
             "k_describe": int((749 + 512 + 60) * n_avg * n_img_l),
             "k_knn2_pairs+k_filter_pairs": int((32 * 2 * n_avg + 12 * n_avg) * n_pairs),
         }
         dur = {"k_resize(x7)": acc["pyramid_us"] / (K * LN), "k_fast_cells": acc["fast_us"] / (K * LN),
-               "k_blur+k_blur_edges": acc["blur_us"] / (K * LN), "k_describe": acc["describe_us"] / (K * LN),
+               "k_blur": acc["blur_us"] / (K * LN), "k_describe": acc["describe_us"] / (K * LN),
                "k_knn2_pairs+k_filter_pairs": acc["match_us"] / K}
         kernels = {k: dict(us=round(dur[k], 2), algo_bytes=int(algo[k]),
                            gbps=round(algo[k] / max(dur[k], 1e-3) / 1e3, 2)) for k in algo}

@@ -369,8 +369,12 @@ __global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restr
     if (tid == 0) { s_nfin = 0; s_nnext = 0; s_seq = 1; s_bail = 0; }
     __syncthreads();
     // ---- 1. histogram of the depth-6 bins + best candidate per bin
-    for (int i = tid; i < n; i += kT) {
-        const int x = c[i].x, y = c[i].y;
+    const unsigned long long* c8 = reinterpret_cast<const unsigned long long*>(c);        // {x, y, score}: one 8-byte load
+#pragma unroll 4
+    for (int i = tid; i < n; i += kT) {                      // unrolled: 4 independent loads in flight per thread
+        const unsigned long long cw = c8[i];
+        const int x = (int)(short)(cw & 0xffff), y = (int)(short)((cw >> 16) & 0xffff);
+        const unsigned score = (unsigned)(cw >> 32);
         int k = (int)__fdiv_rn((float)x, hX);
         if (k >= n_ini) k = n_ini - 1;
         int ulx = (int)__fmul_rn(hX, (float)k), urx = (int)__fmul_rn(hX, (float)(k + 1)), uly = 0, bry = lp.height;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restr
             code = (code << 2) | q;
         }
         atomicAdd(&s_cnt6[code], 1u);
-        atomicMax(&s_best[code], ((unsigned)c[i].score << 20) | (unsigned)(kM20 - (unsigned)i));   // max response, then first in input order
+        atomicMax(&s_best[code], (score << 20) | (unsigned)(kM20 - (unsigned)i));   // max response, then first in input order
     }
     __syncthreads();
     // ---- 2. pyramid of counts, list size and expandable nodes per depth

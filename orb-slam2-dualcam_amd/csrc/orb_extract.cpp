@@ -407,7 +407,7 @@ int dcs_orb::harvest(EvSet& es)
     DCS_HIP(hipEventElapsedTime(&ms, es.t[0], es.t[1])); us[0] = ms * 1000.f;   // resize chain
     DCS_HIP(hipEventElapsedTime(&ms, es.t[1], es.t[2])); us[1] = ms * 1000.f;   // k_fast_cells
     DCS_HIP(hipEventElapsedTime(&ms, es.t[2], es.t[3])); us[2] = ms * 1000.f;   // scan + offsets + gather
-    DCS_HIP(hipEventElapsedTime(&ms, es.b[0], es.b[1])); us[3] = ms * 1000.f;   // k_blur + k_blur_edges (aux stream)
+    DCS_HIP(hipEventElapsedTime(&ms, es.b[0], es.b[1])); us[3] = ms * 1000.f;   // k_blur (aux stream)
     if (es.dev_oct) { DCS_HIP(hipEventElapsedTime(&ms, es.t[3], es.t[6])); us[4] = ms * 1000.f; }   // k_octree
     else us[4] = es.host_us;                                                    // host quadtree (wall)
     DCS_HIP(hipEventElapsedTime(&ms, es.t[4], es.t[5])); us[5] = ms * 1000.f;   // k_describe

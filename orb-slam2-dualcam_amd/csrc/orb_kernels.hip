@@ -27,15 +27,23 @@ int upload_pattern() { return DCS_OK; }   // statically initialised __constant__
 // ------------------------------------------------------------------------------------- resize
 // cv::resize INTER_LINEAR 8UC1 (11-bit fixed point), streaming like the blur: a thread owns 4 adjacent destination
 // pixels (one dword) of a strip of destination rows. Its 4 column taps {sx, a0, a1} are fixed for the whole strip, so
-// each source row costs ONE 12-byte load (3 aligned dwords containing all 8 taps) + v_alignbyte extraction; the
-// horizontally interpolated row (4 ints) is cached in VGPRs because consecutive destination rows share source rows
-// at scale 1.2. No LDS, no barriers, no dependent table lookups in the row loop (row tables are wave-uniform).
+// each source row costs ONE 12-byte load (3 aligned dwords containing all 8 taps); per pixel the two taps are pulled
+// out with one v_perm_b32 (as two zero-extended u16) and weighted with one v_dot2_u32_u16. The horizontally
+// interpolated rows (already >> 4, as the vertical pass wants them) are cached in VGPRs because consecutive destination
+// rows share source rows at scale 1.2. All row bookkeeping is wave-uniform (scalar registers and branches); the
+// vertical pass is two 24-bit multiplies + one SDWA add of the high halves per pixel. No LDS, no barriers.
 constexpr int kRsRowsPerThread = 8;
 
 struct ResizeCol { int16_t sx, pad, a0, a1; };
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void resize_hrow(const uint8_t* __restrict__ row, bool aligned, const int (&o)[4], const int (&a0)[4],
-                                            const int (&a1)[4], int (&h)[4])
+struct ResizeTaps {                    // loop-invariant per thread
+    bool upper[4];                     // taps of pixel k live in dwords (d1, d2) instead of (d0, d1)
+    unsigned sel[4];                   // v_perm selector: byte0 = first tap, byte2 = second tap, bytes 1/3 = 0
+    unsigned wgt[4];                   // a0 | a1 << 16
+};
+
+__device__ __forceinline__ void resize_hrow(const uint8_t* __restrict__ row, bool aligned, const ResizeTaps& t, unsigned (&h)[4])
 {
     unsigned d0, d1, d2;
     if (aligned) {
@@ -51,10 +59,9 @@ __device__ __forceinline__ void resize_hrow(const uint8_t* __restrict__ row, boo
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int q = o[k] >> 2;                      // 0..2: which dword holds the first tap (window offset <= 11)
-        const unsigned lo = q == 0 ? d0 : (q == 1 ? d1 : d2), hi = q == 0 ? d1 : (q == 1 ? d2 : 0u);
-        const unsigned w = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o[k] & 3));
-        h[k] = (int)__umul24(w & 0xffu, (unsigned)a0[k]) + (int)__umul24((w >> 8) & 0xffu, (unsigned)a1[k]);
+        const unsigned lo = t.upper[k] ? d1 : d0, hi = t.upper[k] ? d2 : d1;
+        const unsigned taps = __builtin_amdgcn_perm(hi, lo, t.sel[k]);                  // (S0, S1) as two u16
+        h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, taps), __builtin_bit_cast(ushort2_t, t.wgt[k]), 0u, false) >> 4;
     }
 }
 
@@ -63,24 +70,28 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
 {
     const int img = blockIdx.z;
     const int dx0 = (blockIdx.x * 64 + (int)threadIdx.x) * 4;
-    const int dy0 = (blockIdx.y * 4 + (int)threadIdx.y) * kRsRowsPerThread;
+    const int dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * kRsRowsPerThread;   // wave-uniform
     if (dx0 >= dst.w || dy0 >= dst.h) return;
     const uint8_t* S = src.base + (size_t)img * src.img_stride;
     uint8_t* D = const_cast<uint8_t*>(dst.base) + (size_t)img * dst.img_stride;
     const bool aligned = ((reinterpret_cast<uintptr_t>(S) | (uintptr_t)src.pitch) & 3) == 0 && src.pitch >= 12;
-    int o[4], a0[4], a1[4];
+    ResizeTaps t;
     int base = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const ResizeCol cc = cols[min(dx0 + k, dst.w - 1)];
         // 12-byte window [base, base + 12) must hold every tap (offsets <= 11) and stay inside the row's storage
         if (k == 0) base = aligned ? min((int)cc.sx & ~3, src.pitch - 12) : max(0, min((int)cc.sx, src.w - 12));
-        o[k] = cc.sx - base; a0[k] = cc.a0; a1[k] = cc.a1;
-        // single-tap columns (sx == sw-1) carry a1 == 0: the second byte of the window is multiplied by 0
+        const int o = cc.sx - base;                          // 0..11
+        t.upper[k] = o > 6;
+        const unsigned o8 = (unsigned)(t.upper[k] ? o - 4 : o);              // offset inside the chosen 8-byte pair, 0..7
+        // single-tap columns (sx == sw-1) carry a1 == 0; a second tap beyond the pair reads as constant zero (0x0c)
+        t.sel[k] = 0x0c000c00u | o8 | ((o8 < 7 ? o8 + 1 : 0x0cu) << 16);
+        t.wgt[k] = (unsigned)(uint16_t)cc.a0 | ((unsigned)(uint16_t)cc.a1 << 16);
     }
     const uint8_t* colbase = S + base;
-    int hA[4], hB[4];
-    int rowA = -1, rowB = -1;                           // source rows currently held in hA / hB
+    unsigned hA[4], hB[4];
+    int rowA = -1, rowB = -1;                           // source rows currently held in hA / hB (wave-uniform)
     const int dy_end = min(dy0 + kRsRowsPerThread, dst.h);
     for (int dy = dy0; dy < dy_end; ++dy) {
         const int sy = yofs[dy];
@@ -88,21 +99,22 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
         if (sy0 != rowA) {
             if (sy0 == rowB) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const int t = hA[k]; hA[k] = hB[k]; hB[k] = t; }
-                const int t = rowA; rowA = rowB; rowB = t;
-            } else { resize_hrow(colbase + (size_t)sy0 * src.pitch, aligned, o, a0, a1, hA); rowA = sy0; }
+                for (int k = 0; k < 4; ++k) { const unsigned tt = hA[k]; hA[k] = hB[k]; hB[k] = tt; }
+                const int tt = rowA; rowA = rowB; rowB = tt;
+            } else { resize_hrow(colbase + (size_t)sy0 * src.pitch, aligned, t, hA); rowA = sy0; }
         }
         if (sy1 == rowA) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) hB[k] = hA[k];
             rowB = rowA;
-        } else if (sy1 != rowB) { resize_hrow(colbase + (size_t)sy1 * src.pitch, aligned, o, a0, a1, hB); rowB = sy1; }
-        const int b0 = ya[2 * dy], b1 = ya[2 * dy + 1];
+        } else if (sy1 != rowB) { resize_hrow(colbase + (size_t)sy1 * src.pitch, aligned, t, hB); rowB = sy1; }
+        const unsigned b0 = (unsigned)(int)ya[2 * dy], b1 = (unsigned)(int)ya[2 * dy + 1];       // 0..2048
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int v = (((b0 * (hA[k] >> 4)) >> 16) + ((b1 * (hB[k] >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xff) << (8 * k);
+            // hA, hB <= 32640 and b <= 2048: 24-bit multiplies are exact; each product is truncated (>> 16) on its own
+            const unsigned v = ((__umul24(b0, hA[k]) >> 16) + (__umul24(b1, hB[k]) >> 16) + 2u) >> 2;
+            packed |= (v & 0xffu) << (8 * k);
         }
         *reinterpret_cast<uint32_t*>(D + (size_t)dy * dst.pitch + dx0) = packed;     // pitch is a multiple of 64: in-row
     }
@@ -423,14 +435,62 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-template <bool FAST>
-__device__ __forceinline__ void blur_hrow(const uint8_t* __restrict__ row, int x0, int w, unsigned (&h)[4])
+// how a strip gets the 12 source bytes x0-4 .. x0+7 of a row:
+//   kBlurInterior  all of them lie inside the image row: three aligned dword loads
+//   kBlurEdge      the window crosses the left / right image border: the same three dword loads (shifted right by one
+//                  dword at x0 == 0, predicated against the row's storage), then BORDER_REFLECT_101 is applied in
+//                  registers with one v_perm_b32 per dword; the byte shuffle is fixed per lane for the whole strip
+//   kBlurBytes     unaligned caller-owned level 0: byte gathers
+enum { kBlurInterior = 0, kBlurEdge = 1, kBlurBytes = 2 };
+
+struct BlurEdgeMap {                   // loop-invariant per lane (kBlurEdge)
+    int ofs;                           // loaded window starts at x0 - 4 + ofs
+    bool ld[3], use_b[3];              // dword t is loaded; target dword t permutes (L2, L1) instead of (L1, L0)
+    unsigned sel[3];
+};
+
+__device__ __forceinline__ BlurEdgeMap blur_edge_map(int x0, int w, int pitch)
+{
+    BlurEdgeMap m;
+    m.ofs = x0 == 0 ? 4 : 0;
+    const int start = x0 - 4 + m.ofs;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        m.ld[t] = start + 4 * t >= 0 && start + 4 * t + 4 <= pitch;
+        int q[4], qmin = 99;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int p = x0 - 4 + 4 * t + k;                      // reflect101 (w >= 8 here: one bounce is enough)
+            p = p < 0 ? -p : (p >= w ? 2 * w - 2 - p : p);
+            q[k] = p - start;                                // byte index inside the loaded 12-byte window, if 0..11
+            if (q[k] >= 0 && q[k] <= 11) qmin = min(qmin, q[k]);
+        }
+        m.use_b[t] = qmin > 3 && qmin != 99;
+        unsigned sel = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int qq = m.use_b[t] ? q[k] - 4 : q[k];     // bytes a valid output never needs fall outside: constant 0
+            sel |= (unsigned)((q[k] >= 0 && q[k] <= 11 && qq >= 0 && qq <= 7) ? qq : 0x0c) << (8 * k);
+        }
+        m.sel[t] = sel;
+    }
+    return m;
+}
+
+template <int MODE>
+__device__ __forceinline__ void blur_hrow(const uint8_t* __restrict__ row, int x0, int w, const BlurEdgeMap& em, unsigned (&h)[4])
 {
     unsigned d0, d1, d2;
-    if (FAST) {
+    if (MODE == kBlurInterior) {
         const unsigned* p = reinterpret_cast<const unsigned*>(row + x0 - 4);
         d0 = p[0]; d1 = p[1]; d2 = p[2];
-    } else {                                       // image edge (or unaligned level 0): byte gathers with reflection
+    } else if (MODE == kBlurEdge) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(row + x0 - 4 + em.ofs);
+        const unsigned l0 = em.ld[0] ? p[0] : 0u, l1 = em.ld[1] ? p[1] : 0u, l2 = em.ld[2] ? p[2] : 0u;
+        d0 = __builtin_amdgcn_perm(em.use_b[0] ? l2 : l1, em.use_b[0] ? l1 : l0, em.sel[0]);
+        d1 = __builtin_amdgcn_perm(em.use_b[1] ? l2 : l1, em.use_b[1] ? l1 : l0, em.sel[1]);
+        d2 = __builtin_amdgcn_perm(em.use_b[2] ? l2 : l1, em.use_b[2] ? l1 : l0, em.sel[2]);
+    } else {                                       // unaligned level 0: byte gathers with reflection
         unsigned b[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) b[k] = row[reflect101(x0 - 4 + k, w)];
@@ -450,15 +510,17 @@ __device__ __forceinline__ void blur_hrow(const uint8_t* __restrict__ row, int x
 }
 
 // one 4-pixel-wide, kBlurR-row strip
-template <bool FAST>
+template <int MODE>
 __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ S, uint8_t* __restrict__ D, const LevelView& sv, const LevelView& dv,
                                            int x0, int y0)
 {
+    BlurEdgeMap em{};
+    if (MODE == kBlurEdge) em = blur_edge_map(x0, sv.w, sv.pitch);
     unsigned ring[7][4];
 #pragma unroll
     for (int r = 0; r < kBlurR + 6; ++r) {
         const int yy = reflect101(y0 + r - 3, sv.h);
-        blur_hrow<FAST>(S + (size_t)yy * sv.pitch, x0, sv.w, ring[r % 7]);
+        blur_hrow<MODE>(S + (size_t)yy * sv.pitch, x0, sv.w, em, ring[r % 7]);
         if (r >= 6) {
             const int y = y0 + r - 6;                 // output row: window = input rows r-6 .. r
             unsigned packed = 0;
@@ -495,11 +557,17 @@ __global__ __launch_bounds__(64 * kBlurWaves) void k_blur(LevelSet src, LevelSet
     const int img = blockIdx.y;
     const int x0 = (t % tiles_x) * kBlurW + 4 * (int)threadIdx.x;
     const int y0 = (t / tiles_x) * (kBlurR * kBlurWaves) + kBlurR * (int)threadIdx.y;
-    if (x0 >= sv.w || y0 >= sv.h) return;
+    if (y0 >= sv.h) return;                                                       // wave-uniform
     const uint8_t* S = sv.base + (size_t)img * sv.img_stride;
     uint8_t* D = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
     if (!level_aligned(sv, img)) return;                                          // k_blur_unaligned_l0
-    if (x0 >= 4 && x0 + 7 <= sv.w - 1) blur_strip<true>(S, D, sv, dv, x0, y0);     // edge columns: k_blur_edges
+    const bool inside = x0 < sv.w, interior = x0 >= 4 && x0 + 7 <= sv.w - 1;
+    if (__all(!inside || interior)) {                                             // wave-uniform choice of the code path
+        if (inside) blur_strip<kBlurInterior>(S, D, sv, dv, x0, y0);
+    } else if (inside) {
+        if (sv.w >= 8) blur_strip<kBlurEdge>(S, D, sv, dv, x0, y0);               // first / last 256-px tile of a row
+        else blur_strip<kBlurBytes>(S, D, sv, dv, x0, y0);
+    }
 }
 
 // caller-owned level 0 whose base / stride is not 4-byte aligned: byte path for every strip (rare; correctness only)
@@ -510,62 +578,16 @@ __global__ __launch_bounds__(64) void k_blur_unaligned_l0(LevelSet src, LevelSet
     if (level_aligned(sv, img)) return;
     const int x0 = 4 * (blockIdx.x * 64 + (int)threadIdx.x), y0 = kBlurR * (int)blockIdx.y;
     if (x0 >= sv.w || y0 >= sv.h) return;
-    blur_strip<false>(sv.base + (size_t)img * sv.img_stride, const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride, sv, dv, x0, y0);
-}
-
-// the (at most 3) dword columns per level whose 7-tap window crosses the left / right image border. Workgroup =
-// 122 output rows of one column: 128 threads each reduce ONE input row with the reflecting byte path into LDS, then
-// 122 threads run the vertical pass. No divergence, short dependency chains (this is ~2 % of the pixels).
-constexpr int kEdgeRows = 122;
-__global__ __launch_bounds__(128) void k_blur_edges(LevelSet src, LevelSet dst)
-{
-    __shared__ unsigned s_h[kEdgeRows + 6][4];
-    const int l = blockIdx.z % src.nlevels, img = blockIdx.z / src.nlevels, col = blockIdx.y;
-    const LevelView sv = src.lv[l], dv = dst.lv[l];
-    if (!level_aligned(sv, img)) return;                  // handled entirely by k_blur_unaligned_l0
-    const int y0 = blockIdx.x * kEdgeRows;
-    if (y0 >= sv.h) return;
-    // edge columns: x0 = 0 and the multiples of 4 in (w - 8, w)
-    const int last = ((sv.w - 1) / 4) * 4;
-    const int x0 = col == 0 ? 0 : (col == 1 ? last : last - 4);
-    if (x0 < 0 || x0 >= sv.w) return;
-    if (col > 0 && (x0 == 0 || (x0 >= 4 && x0 + 7 <= sv.w - 1))) return;   // interior, or duplicate of column 0
-    const uint8_t* S = sv.base + (size_t)img * sv.img_stride;
-    uint8_t* D = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
-    const int t = threadIdx.x;
-    {
-        const int yy = reflect101(y0 + t - 3, sv.h);
-        unsigned h[4];
-        blur_hrow<false>(S + (size_t)yy * sv.pitch, x0, sv.w, h);
-        s_h[t][0] = h[0]; s_h[t][1] = h[1]; s_h[t][2] = h[2]; s_h[t][3] = h[3];
-    }
-    __syncthreads();
-    const int y = y0 + t;
-    if (t < kEdgeRows && y < dv.h) {
-        unsigned packed = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned acc = __umul24(55u, s_h[t + 3][i]);
-            acc = __umul24(18u, s_h[t][i] + s_h[t + 6][i]) + acc;
-            acc = __umul24(34u, s_h[t + 1][i] + s_h[t + 5][i]) + acc;
-            acc = __umul24(49u, s_h[t + 2][i] + s_h[t + 4][i]) + acc;
-            packed |= min(255u, (acc + 32768u) >> 16) << (8 * i);
-        }
-        *reinterpret_cast<unsigned*>(D + (size_t)y * dv.pitch + x0) = packed;
-    }
+    blur_strip<kBlurBytes>(sv.base + (size_t)img * sv.img_stride, const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride, sv, dv, x0, y0);
 }
 
 int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStream_t s)
 {
-    int tiles = 0, max_chunks = 1;
-    for (int l = 0; l < src.nlevels; ++l) {
+    int tiles = 0;
+    for (int l = 0; l < src.nlevels; ++l)
         tiles += ((src.lv[l].w + kBlurW - 1) / kBlurW) * ((src.lv[l].h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
-        max_chunks = max(max_chunks, (src.lv[l].h + kEdgeRows - 1) / kEdgeRows);
-    }
     if (tiles == 0) return DCS_OK;
     hipLaunchKernelGGL(k_blur, dim3(tiles, n_images), dim3(64, kBlurWaves), 0, s, src, dst, tiles);
-    DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_blur_edges, dim3(max_chunks, 3, src.nlevels * n_images), dim3(128), 0, s, src, dst);
     DCS_CHECK_LAUNCH();
     if (((reinterpret_cast<uintptr_t>(src.lv[0].base) | (uintptr_t)src.lv[0].pitch | (uintptr_t)src.lv[0].img_stride) & 3) != 0) {
         hipLaunchKernelGGL(k_blur_unaligned_l0, dim3((src.lv[0].w + 255) / 256, (src.lv[0].h + kBlurR - 1) / kBlurR, n_images), dim3(64), 0, s, src, dst);
