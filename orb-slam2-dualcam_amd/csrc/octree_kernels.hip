@@ -15,6 +15,7 @@
 // Ties between equal-size nodes: creation sequence (Q3, same as the oracle). Output is bit-exact vs the oracle.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -60,7 +61,7 @@ __device__ __forceinline__ unsigned long long order_key(unsigned long long code,
 __device__ __forceinline__ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 // in-place ascending bitonic sort of npow2 keys (+ optional payload); every thread of the block calls it
-__device__ void bitonic_sort(unsigned long long* keys, unsigned* vals, int npow2)
+__device__ __forceinline__ void bitonic_sort(unsigned long long* keys, unsigned* vals, int npow2)
 {
     for (int k = 2; k <= npow2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -80,7 +81,7 @@ __device__ void bitonic_sort(unsigned long long* keys, unsigned* vals, int npow2
 }
 
 // in-place exclusive scan of a[0..n); returns the total. Every thread of the block calls it.
-__device__ int block_scan_inplace(int* a, int n)
+__device__ __forceinline__ int block_scan_inplace(int* a, int n)
 {
     __shared__ int s_run, s_w[kT / 64];
     if (threadIdx.x == 0) s_run = 0;
@@ -328,29 +329,74 @@ __global__ __launch_bounds__(kT) void k_octree(const dcs_candidate* __restrict__
 // ------------------------------------------------------------------------------------------------------------
 // Fast path: the quadtree as a histogram pyramid in LDS (no sort of the candidates at all).
 // A depth-d node is the bin "initial node, d quadrants"; bins of one depth are contiguous ranges of the depth-6 bins, so
-//   * key counts per bin: LDS atomics at depth 6, then a bottom-up pyramid (sum of 4 children),
+//   * key counts per bin: LDS atomics at depth 6, then a bottom-up pyramid (sum of 4 children, wave shuffles),
 //   * the best candidate of any node = max over a contiguous range of a packed (response << 20 | ~index) word,
 //   * list size / expandable nodes per depth = non-empty / multi-key bins -> stopping depth D exactly as in k_octree,
 //   * the "fullest nodes first" tail only needs the 4 child counts of each expandable node.
+// The kernel is latency-bound (a few thousand instructions per task), so it runs 1024 threads per task and keeps the
+// number of workgroup barriers small: node lists (<= 512 entries) are ordered by a rank sort (rank = number of smaller
+// keys, counted by all threads in parallel; keys are distinct) instead of a bitonic network.
 // Valid while everything the reference touches lies within 6 levels (true for the usual quotas); otherwise the task is
 // flagged and the general sort-based kernel k_octree redoes it. Output is identical by construction and by test.
-template <int NINI>
-__global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restrict__ dense, const int32_t* __restrict__ lvl_off,
-                                                    OctLevels P, int dense_cap, int force_general, SelKp* __restrict__ sel,
-                                                    int32_t* __restrict__ lvl_cnt, int32_t* __restrict__ need_general)
+constexpr int kTH = 512;
+constexpr int kHD = 6;                                  // deepest histogram level
+constexpr int kCapH = 512;                              // final / expandable nodes handled in LDS
+
+// out[rank] = in[i] for n <= kCapH distinct keys; every thread of the 1024-thread block calls it
+__device__ __forceinline__ void rank_sort(const unsigned long long* kin, const unsigned* vin, unsigned long long* kout, unsigned* vout, int n, int* s_rank)
 {
-    constexpr int kHD = 6;                              // deepest histogram level
-    constexpr int NB6 = NINI << (2 * kHD);
-    constexpr int kCap = 1024;                          // final / expandable nodes handled in LDS
-    __shared__ unsigned s_cnt6[NB6];                    // depth 6 counts (32-bit for LDS atomics)
+    const int tid = threadIdx.x;
+    const int np = next_pow2(max(n, 1)), parts = kTH / np;       // np <= 512: every element gets `parts` >= 2 threads
+    if (tid < n) s_rank[tid] = 0;
+    __syncthreads();
+    const int i = tid & (np - 1), part = tid / np;
+    if (i < n) {
+        const unsigned long long key = kin[i];
+        const int per = (n + parts - 1) / parts;
+        const int j0 = part * per, j1 = min(n, j0 + per);
+        int r = 0;
+#pragma unroll 8
+        for (int j = j0; j < j1; ++j) r += kin[j] < key;         // independent LDS reads: keep several in flight
+        if (r) atomicAdd(&s_rank[i], r);
+    }
+    __syncthreads();
+    if (tid < n) { const int r = s_rank[tid]; kout[r] = kin[tid]; vout[r] = vin[tid]; }
+    __syncthreads();
+}
+
+// in-place exclusive scan of a[0..n), n <= kTH; returns the total. Every thread calls it.
+__device__ __forceinline__ int scan_block(int* a, int n, int* s_w /* [kTH / 64] */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int v = tid < n ? a[tid] : 0;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kTH / 64; ++w) { const int c = s_w[w]; if (w < wave) off += c; tot += c; }
+    if (tid < n) a[tid] = off + inc - v;
+    __syncthreads();
+    return tot;
+}
+
+template <int NINI>
+__global__ __launch_bounds__(kTH) void k_octree_hist(const dcs_candidate* __restrict__ dense, const int32_t* __restrict__ lvl_off,
+                                                     OctLevels P, int dense_cap, int force_general, SelKp* __restrict__ sel,
+                                                     int32_t* __restrict__ lvl_cnt, int32_t* __restrict__ need_general)
+{
+    constexpr int NB6 = NINI << (2 * kHD), NB5 = NINI << (2 * kHD - 2);
+    // depth 6 bins: count (8 bits) | best candidate (response << 16 | ~index, 24 bits) in ONE word, updated with a CAS loop
+    __shared__ __attribute__((aligned(16))) unsigned s_bin6[NB6];
     __shared__ unsigned short s_cnt[NINI * 1365 + 8];   // depths 0..5: NINI * (1 + 4 + ... + 1024)
-    __shared__ unsigned s_best[NB6];
-    __shared__ unsigned long long s_fkey[kCap], s_tkey[kCap];
-    __shared__ unsigned s_fval[kCap], s_tval[kCap];
-    __shared__ int s_size[kHD + 1], s_nexp[kHD + 1];
+    __shared__ unsigned long long s_ka[kCapH], s_kb[kCapH], s_fkey[kCapH];    // expandable nodes (unsorted / sorted), final nodes
+    __shared__ unsigned s_va[kCapH], s_vb[kCapH], s_fval[kCapH];
+    __shared__ int s_nch[kCapH], s_inc[kCapH], s_rank[kCapH];
+    __shared__ int s_size[kHD + 2], s_nexp[kHD + 2], s_w[kTH / 64];
     __shared__ int s_D, s_tail, s_cursize, s_nfin, s_nnext, s_rstar, s_seq, s_bail;
-    __shared__ int s_nch[kCap], s_inc[kCap];
-    const int task = blockIdx.x, tid = threadIdx.x;
+    const int task = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int l = task % P.nlevels, img = task / P.nlevels;
     const OctLevel lp = P.lv[l];
     const int b0 = lvl_off[task], n = min(lvl_off[task + 1], dense_cap) - b0;
@@ -359,19 +405,20 @@ __global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restr
     if (n <= 0 || lp.height <= 0) { if (tid == 0) lvl_cnt[task] = 0; return; }
     const int n_ini = (int)roundf(__fdiv_rn((float)lp.width, (float)lp.height));
     if (n_ini < 1 || n_ini > 255) { if (tid == 0) lvl_cnt[task] = 0; return; }
-    if (n_ini > NINI || n >= (1 << 20) || force_general) { if (tid == 0) need_general[task] = 1; return; }
+    if (n_ini > NINI || n > 65535 || force_general) { if (tid == 0) need_general[task] = 1; return; }   // 16-bit counts above depth 6
     const float hX = __fdiv_rn((float)lp.width, (float)n_ini);
     const dcs_candidate* c = dense + b0;
     auto lvl_base = [](int d) { return NINI * (((1 << (2 * d)) - 1) / 3); };     // offset of depth d inside s_cnt
-    auto count_at = [&](int d, int bin) -> int { return d == kHD ? (int)s_cnt6[bin] : (int)s_cnt[lvl_base(d) + bin]; };
+    auto count_at = [&](int d, int bin) -> int { return d == kHD ? (int)(s_bin6[bin] & 255u) : (int)s_cnt[lvl_base(d) + bin]; };
 
-    for (int i = tid; i < NB6; i += kT) { s_cnt6[i] = 0; s_best[i] = 0; }
+    for (int i = tid; i < NB6; i += kTH) s_bin6[i] = 0;
+    if (tid < kHD + 2) { s_size[tid] = 0; s_nexp[tid] = 0; }
     if (tid == 0) { s_nfin = 0; s_nnext = 0; s_seq = 1; s_bail = 0; }
     __syncthreads();
     // ---- 1. histogram of the depth-6 bins + best candidate per bin
     const unsigned long long* c8 = reinterpret_cast<const unsigned long long*>(c);        // {x, y, score}: one 8-byte load
-#pragma unroll 4
-    for (int i = tid; i < n; i += kT) {                      // unrolled: 4 independent loads in flight per thread
+#pragma unroll 2
+    for (int i = tid; i < n; i += kTH) {
         const unsigned long long cw = c8[i];
         const int x = (int)(short)(cw & 0xffff), y = (int)(short)((cw >> 16) & 0xffff);
         const unsigned score = (unsigned)(cw >> 32);
@@ -387,29 +434,58 @@ __global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restr
             if (y < my) bry = my; else { uly = my; q |= 2; }
             code = (code << 2) | q;
         }
-        atomicAdd(&s_cnt6[code], 1u);
-        atomicMax(&s_best[code], (score << 20) | (unsigned)(kM20 - (unsigned)i));   // max response, then first in input order
-    }
-    __syncthreads();
-    // ---- 2. pyramid of counts, list size and expandable nodes per depth
-    for (int d = kHD - 1; d >= 0; --d) {
-        const int nb = NINI << (2 * d);
-        for (int b = tid; b < nb; b += kT) {
-            int s4 = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s4 += count_at(d + 1, 4 * b + q);
-            s_cnt[lvl_base(d) + b] = (unsigned short)min(s4, 65535);
+        const unsigned mine = (score << 16) | (0xFFFFu - (unsigned)i);           // max response, then first in input order
+        unsigned old = s_bin6[code];
+        for (;;) {
+            if ((old & 255u) == 255u) { s_bail = 1; break; }                    // cannot happen for FAST + NMS output; be safe
+            const unsigned nw = (max(old >> 8, mine) << 8) | ((old & 255u) + 1u);
+            const unsigned prev = atomicCAS(&s_bin6[code], old, nw);
+            if (prev == old) break;
+            old = prev;
         }
-        __syncthreads();
     }
-    if (tid <= kHD) { s_size[tid] = 0; s_nexp[tid] = 0; }
     __syncthreads();
-    for (int d = 0; d <= kHD; ++d) {
-        const int nb = NINI << (2 * d);
-        int ne = 0, nm = 0;
-        for (int b = tid; b < nb; b += kT) { const int cc = count_at(d, b); ne += cc > 0; nm += cc > 1; }
-        if (ne) atomicAdd(&s_size[d], ne);
-        if (nm) atomicAdd(&s_nexp[d], nm);
+    // ---- 2. pyramid of counts (depth 5..2 with wave shuffles: a wave owns 64 consecutive depth-5 bins = one depth-2 bin)
+    //         and, per depth, the list size (non-empty bins) and the expandable nodes (bins with more than one key)
+    for (int b5 = tid; b5 < NB5; b5 += kTH) {
+        int ne6 = 0, nm6 = 0, c5 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int v = (int)(s_bin6[4 * b5 + q] & 255u); c5 += v; ne6 += v > 0; nm6 += v > 1; }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { ne6 += __shfl_xor(ne6, d); nm6 += __shfl_xor(nm6, d); }
+        int c4 = c5 + __shfl_xor(c5, 1); c4 += __shfl_xor(c4, 2);
+        int c3 = c4 + __shfl_xor(c4, 4); c3 += __shfl_xor(c3, 8);
+        int c2 = c3 + __shfl_xor(c3, 16); c2 += __shfl_xor(c2, 32);
+        s_cnt[lvl_base(5) + b5] = (unsigned short)c5;
+        if ((lane & 3) == 0) s_cnt[lvl_base(4) + (b5 >> 2)] = (unsigned short)c4;
+        if ((lane & 15) == 0) s_cnt[lvl_base(3) + (b5 >> 4)] = (unsigned short)c3;
+        const int ne5 = __popcll(__ballot(c5 > 0)), nm5 = __popcll(__ballot(c5 > 1));
+        const int ne4 = __popcll(__ballot((lane & 3) == 0 && c4 > 0)), nm4 = __popcll(__ballot((lane & 3) == 0 && c4 > 1));
+        const int ne3 = __popcll(__ballot((lane & 15) == 0 && c3 > 0)), nm3 = __popcll(__ballot((lane & 15) == 0 && c3 > 1));
+        if (lane == 0) {
+            s_cnt[lvl_base(2) + (b5 >> 6)] = (unsigned short)c2;
+            atomicAdd(&s_size[6], ne6); atomicAdd(&s_nexp[6], nm6);
+            atomicAdd(&s_size[5], ne5); atomicAdd(&s_nexp[5], nm5);
+            atomicAdd(&s_size[4], ne4); atomicAdd(&s_nexp[4], nm4);
+            atomicAdd(&s_size[3], ne3); atomicAdd(&s_nexp[3], nm3);
+            atomicAdd(&s_size[2], c2 > 0); atomicAdd(&s_nexp[2], c2 > 1);
+        }
+    }
+    __syncthreads();
+    if (tid < NINI * 4) {                                // depth 1 (and depth 0 by its first child)
+        int c1 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c1 += (int)s_cnt[lvl_base(2) + 4 * tid + q];
+        s_cnt[lvl_base(1) + tid] = (unsigned short)c1;
+        atomicAdd(&s_size[1], c1 > 0); atomicAdd(&s_nexp[1], c1 > 1);
+    }
+    if (tid >= 64 && tid < 64 + NINI) {                  // depth 0 from the 16 depth-2 bins of the initial node
+        const int k0 = tid - 64;
+        int c0 = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c0 += (int)s_cnt[lvl_base(2) + 16 * k0 + q];
+        s_cnt[lvl_base(0) + k0] = (unsigned short)c0;
+        atomicAdd(&s_size[0], c0 > 0); atomicAdd(&s_nexp[0], c0 > 1);
     }
     __syncthreads();
     if (tid == 0) {                                     // breadth-first phase (:594-673), same decisions as k_octree
@@ -420,7 +496,7 @@ __global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restr
             if (sz + 3 * s_nexp[d] > lp.n_target) { D = d; tail = 1; break; }
             prev = sz;
         }
-        if (D < 0 || (tail && D + 1 > kHD) || n > 65535) s_bail = 1;     // deeper than the pyramid (or 16-bit counts): general kernel
+        if (D < 0 || (tail && D + 1 > kHD)) s_bail = 1;   // deeper than the pyramid: general kernel
         s_D = D; s_tail = tail; s_cursize = D >= 0 ? s_size[D] : 0;
     }
     __syncthreads();
@@ -430,25 +506,29 @@ __global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restr
     auto best_of = [&](int d, int bin) -> unsigned {    // best candidate index of a depth-d node
         const int span = 1 << (2 * (kHD - d));
         unsigned m = 0;
-        for (int q = 0; q < span; ++q) m = max(m, s_best[bin * span + q]);
-        return (unsigned)(kM20 - (m & kM20));
+        if (span >= 4) {                                 // 16-byte LDS reads, several in flight
+            const uint4* p4 = reinterpret_cast<const uint4*>(s_bin6 + bin * span);
+#pragma unroll 4
+            for (int q = 0; q < (span >> 2); ++q) { const uint4 v = p4[q]; m = max(max(m, max(v.x, v.y)), max(v.z, v.w)); }   // count bits are below the response
+        } else m = s_bin6[bin];
+        return 0xFFFFu - ((m >> 8) & 0xFFFFu);
     };
     // ---- 3. nodes of the breadth-first list L_D
     {
         const int nb = NINI << (2 * D);
-        for (int b = tid; b < nb; b += kT) {
+        for (int b = tid; b < nb; b += kTH) {
             const int cc = count_at(D, b);
             if (cc == 0) continue;
             if (tail && cc > 1) {
                 const int t = atomicAdd(&s_nnext, 1);
-                if (t < kCap) { s_tkey[t] = ((kM20 - (unsigned long long)cc) << 36) | order_key(code14(b, D), D); s_tval[t] = (unsigned)b; }
+                if (t < kCapH) { s_ka[t] = ((kM20 - (unsigned long long)cc) << 36) | order_key(code14(b, D), D); s_va[t] = (unsigned)b; }
                 else s_bail = 1;
                 continue;
             }
             int depth = D;
             if (cc == 1) { while (depth > 0 && count_at(depth - 1, b >> (2 * (D - depth + 1))) == 1) --depth; }   // froze at the first depth it was alone
             const int f = atomicAdd(&s_nfin, 1);
-            if (f < kCap) {
+            if (f < kCapH) {
                 s_fkey[f] = (1ull << 60) | ((unsigned long long)(D - depth) << 36) | order_key(code14(b >> (2 * (D - depth)), depth), depth);
                 s_fval[f] = best_of(D, b);
             } else s_bail = 1;
@@ -463,22 +543,17 @@ __global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restr
             const int T = s_nnext, prev_size = s_cursize, seq_base = s_seq;
             __syncthreads();
             if (T == 0 || s_bail) break;
-            const int tp = next_pow2(T);
-            for (int i = T + tid; i < tp; i += kT) { s_tkey[i] = ~0ull; s_tval[i] = 0u; }
-            __syncthreads();
-            bitonic_sort(s_tkey, s_tval, tp);               // processing order
-            for (int r = tid; r < T; r += kT) {
+            rank_sort(s_ka, s_va, s_kb, s_vb, T, s_rank);    // processing order: fullest first, then list order / latest first
+            if (tid < T) {
                 int cnt = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cnt += count_at(depth_cur + 1, 4 * (int)s_tval[r] + q) > 0;
-                s_nch[r] = cnt; s_inc[r] = cnt;
+                for (int q = 0; q < 4; ++q) cnt += count_at(depth_cur + 1, 4 * (int)s_vb[tid] + q) > 0;
+                s_nch[tid] = cnt; s_inc[tid] = cnt;
             }
-            __syncthreads();
-            (void)block_scan_inplace(s_inc, T);
             if (tid == 0) s_rstar = T;
             __syncthreads();
-            for (int r = tid; r < T; r += kT)
-                if (prev_size + s_inc[r] + s_nch[r] - (r + 1) >= lp.n_target) atomicMin(&s_rstar, r);
+            (void)scan_block(s_inc, T, s_w);                 // s_inc[r] = children created before node r
+            if (tid < T && prev_size + s_inc[tid] + s_nch[tid] - (tid + 1) >= lp.n_target) atomicMin(&s_rstar, tid);
             __syncthreads();
             const bool full = s_rstar < T;
             const int last_r = full ? s_rstar : T - 1;
@@ -487,62 +562,52 @@ __global__ __launch_bounds__(kT) void k_octree_hist(const dcs_candidate* __restr
             const bool stop = full || new_size == prev_size;
             __syncthreads();
             if (tid == 0) { s_nnext = 0; s_cursize = new_size; s_seq = seq_base + created; }
-            // children of the processed nodes go to per-pass staging (s_nch/s_inc are dead after this loop's reads)
-            __shared__ unsigned s_nbin[kCap];
-            __shared__ int s_nseq[kCap], s_ncnt[kCap];
             __syncthreads();
-            for (int r = tid; r < T; r += kT) {
-                const unsigned bin = s_tval[r];
+            if (tid < T) {
+                const int r = tid;
+                const unsigned bin = s_vb[r];
                 if (r > last_r) {                            // never reached: stays where it is in the list
                     const int f = atomicAdd(&s_nfin, 1);
-                    if (f < kCap) {
-                        s_fkey[f] = first_pass ? ((1ull << 60) | (s_tkey[r] & kM36)) : ((s_tkey[r] & kM20) << 36);
+                    if (f < kCapH) {
+                        s_fkey[f] = first_pass ? ((1ull << 60) | (s_kb[r] & kM36)) : ((s_kb[r] & kM20) << 36);
                         s_fval[f] = best_of(depth_cur, (int)bin);
                     } else s_bail = 1;
-                    continue;
-                }
-                int child = 0;
-                for (int q = 0; q < 4; ++q) {
-                    const int cb = 4 * (int)bin + q, cc = count_at(depth_cur + 1, cb);
-                    if (cc == 0) continue;
-                    const unsigned long long seq = (unsigned long long)(seq_base + s_inc[r] + child);
-                    ++child;
-                    if (!stop && cc > 1) {
-                        if (depth_cur + 2 > kHD) { s_bail = 1; continue; }       // grandchildren would leave the pyramid
-                        const int s2 = atomicAdd(&s_nnext, 1);
-                        if (s2 < kCap) { s_nbin[s2] = (unsigned)cb; s_nseq[s2] = (int)seq; s_ncnt[s2] = cc; } else s_bail = 1;
-                    } else {
-                        const int f = atomicAdd(&s_nfin, 1);
-                        if (f < kCap) { s_fkey[f] = (kM20 - seq) << 36; s_fval[f] = best_of(depth_cur + 1, cb); } else s_bail = 1;
+                } else {
+                    int child = 0;
+                    for (int q = 0; q < 4; ++q) {
+                        const int cb = 4 * (int)bin + q, cc = count_at(depth_cur + 1, cb);
+                        if (cc == 0) continue;
+                        const unsigned long long seq = (unsigned long long)(seq_base + s_inc[r] + child);
+                        ++child;
+                        if (!stop && cc > 1) {
+                            if (depth_cur + 2 > kHD) { s_bail = 1; continue; }       // grandchildren would leave the pyramid
+                            const int s2 = atomicAdd(&s_nnext, 1);                   // next pass: fullest first, then latest created first
+                            if (s2 < kCapH) { s_ka[s2] = ((kM20 - (unsigned long long)cc) << 36) | (kM20 - seq); s_va[s2] = (unsigned)cb; }
+                            else s_bail = 1;
+                        } else {
+                            const int f = atomicAdd(&s_nfin, 1);
+                            if (f < kCapH) { s_fkey[f] = (kM20 - seq) << 36; s_fval[f] = best_of(depth_cur + 1, cb); } else s_bail = 1;
+                        }
                     }
                 }
             }
             __syncthreads();
             if (stop || s_bail) break;
-            const int T2 = s_nnext;
-            for (int s2 = tid; s2 < T2; s2 += kT) {
-                s_tkey[s2] = ((kM20 - (unsigned long long)s_ncnt[s2]) << 36) | (kM20 - (unsigned long long)s_nseq[s2]);
-                s_tval[s2] = s_nbin[s2];
-            }
             depth_cur += 1;
             first_pass = false;
-            __syncthreads();
         }
     }
     __syncthreads();
     if (s_bail) { if (tid == 0) need_general[task] = 1; return; }
     // ---- 5. sort the final nodes into list order, emit
     const int F = s_nfin;
-    const int fp = next_pow2(F);
-    for (int f = F + tid; f < fp; f += kT) { s_fkey[f] = ~0ull; s_fval[f] = 0u; }
-    __syncthreads();
-    bitonic_sort(s_fkey, s_fval, fp);
+    rank_sort(s_fkey, s_fval, s_ka, s_va, F, s_rank);
     const int n_out = min(F, lp.out_cap);
-    for (int f = tid; f < n_out; f += kT) {
-        const dcs_candidate cc = c[s_fval[f]];
+    if (tid < n_out) {
+        const dcs_candidate cc = c[s_va[tid]];
         SelKp s;
         s.x = (int16_t)(cc.x + kMinBorder); s.y = (int16_t)(cc.y + kMinBorder); s.score = (int16_t)cc.score; s.level = (int8_t)l; s.pad = 0;
-        out[f] = s;
+        out[tid] = s;
     }
     if (tid == 0) lvl_cnt[task] = n_out;
 }
@@ -556,9 +621,9 @@ int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const 
     for (int l = 0; l < levels.nlevels; ++l)
         if (levels.lv[l].height > 0) max_ini = max(max_ini, (int)roundf((float)levels.lv[l].width / (float)levels.lv[l].height));
     if (max_ini <= 1)
-        hipLaunchKernelGGL(k_octree_hist<1>, dim3(n_tasks), dim3(kT), 0, s, d_dense, d_lvl_off, levels, dense_cap, force_general, d_sel, d_lvl_cnt, d_need_general);
+        hipLaunchKernelGGL(k_octree_hist<1>, dim3(n_tasks), dim3(kTH), 0, s, d_dense, d_lvl_off, levels, dense_cap, force_general, d_sel, d_lvl_cnt, d_need_general);
     else
-        hipLaunchKernelGGL(k_octree_hist<2>, dim3(n_tasks), dim3(kT), 0, s, d_dense, d_lvl_off, levels, dense_cap, force_general, d_sel, d_lvl_cnt, d_need_general);
+        hipLaunchKernelGGL(k_octree_hist<2>, dim3(n_tasks), dim3(kTH), 0, s, d_dense, d_lvl_off, levels, dense_cap, force_general, d_sel, d_lvl_cnt, d_need_general);
     DCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_octree, dim3(n_tasks), dim3(kT), 0, s, d_dense, d_lvl_off, levels, scratch, dense_cap, d_need_general, d_sel, d_lvl_cnt);
     DCS_CHECK_LAUNCH();

@@ -304,22 +304,32 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs, d_rtab.p + rtab[l].xa,
                                 d_rtab.p + rtab[l].yofs, d_rtab.p + rtab[l].ya, n_images, stream))) return rc;
     }
-    DCS_HIP(hipEventRecord(ev_pyr, stream));
     DCS_HIP(hipEventRecord(ev_t[1], stream));
-    // blur on the auxiliary stream, overlapping FAST + quadtree (DCS_ORB_NO_OVERLAP=1 serialises it for clean timings)
+    // blur on the auxiliary stream, overlapping FAST (DCS_ORB_NO_OVERLAP=1 serialises it for clean timings).
+    // DCS_ORB_BLUR_LATE=1 starts it after FAST instead (measured slower: it then collides with the latency-bound
+    // compaction + quadtree kernels, 1.64 vs 1.55 ms per 128 dual frames).
+    static const bool blur_early = getenv("DCS_ORB_BLUR_LATE") == nullptr;
     hipStream_t sb = no_overlap ? stream : s_aux;
-    if (!no_overlap) DCS_HIP(hipStreamWaitEvent(s_aux, ev_pyr, 0));
-    DCS_HIP(hipEventRecord(ev_b[0], sb));
-    if ((rc = launch_blur(raw, blur, n_images, sb))) return rc;
-    DCS_HIP(hipEventRecord(ev_b[1], sb));
-    DCS_HIP(hipEventRecord(ev_blur, sb));
-    if (no_overlap) DCS_HIP(hipEventRecord(ev_t[1], stream));      // FAST timing starts after the blur
+    auto blur_stage = [&]() -> int {
+        if (!no_overlap) { DCS_HIP(hipEventRecord(ev_pyr, stream)); DCS_HIP(hipStreamWaitEvent(s_aux, ev_pyr, 0)); }
+        DCS_HIP(hipEventRecord(ev_b[0], sb));
+        int r = launch_blur(raw, blur, n_images, sb);
+        if (r) return r;
+        DCS_HIP(hipEventRecord(ev_b[1], sb));
+        DCS_HIP(hipEventRecord(ev_blur, sb));
+        return DCS_OK;
+    };
+    if (no_overlap || blur_early) {
+        if ((rc = blur_stage())) return rc;
+        if (no_overlap) DCS_HIP(hipEventRecord(ev_t[1], stream));      // FAST timing starts after the blur
+    }
 
     int max_rw = 7, max_rh = 7;
     for (const CellDesc& c : h_cells) { max_rw = std::max(max_rw, (int)c.rw); max_rh = std::max(max_rh, (int)c.rh); }
     if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
                                 d_cell_count.p, max_rw, max_rh, stream))) return rc;
     DCS_HIP(hipEventRecord(ev_t[2], stream));
+    if (!(no_overlap || blur_early) && (rc = blur_stage())) return rc;
     if ((rc = launch_compact(d_cells.p, d_level_cell_begin.p, L, n_images, n_cells, d_slots.p, g.n_slots, d_cell_count.p,
                              d_cell_off.p, d_lvl_total.p, d_lvl_off.p, d_dense.p, dense_cap, stream))) return rc;
     const int n_tasks = n_images * L;

@@ -176,7 +176,8 @@ def test_deep_quadtree_leaves_the_histogram_fast_path(pkg, oracle, synth):
     e.close()
     e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=1)
     e(synth.frame_pair(640, 480, 0, 0)[0])
-    assert e.quadtree_fallbacks() == 0
+    if not os.environ.get("DCS_OCTREE_FORCE_GENERAL"):
+        assert e.quadtree_fallbacks() == 0
     e.close()
 
 
@@ -206,3 +207,26 @@ def test_device_api_unaligned_pointer_and_stride(pkg, oracle, synth):
         assert kp_all[i, :n[i]].tobytes() == okp.tobytes()
         assert np.array_equal(d_desc[i, :n[i]].cpu().numpy(), odesc)
     e.close()
+
+
+def test_general_quadtree_kernel_alone(tmp_path):
+    """DCS_OCTREE_FORCE_GENERAL=1 sends every (image, level) task to the sort-based kernel (the switch is read once per
+    process, hence the subprocess); the result must equal the oracle's as well."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import load_pkg\n"
+        "import oracle\n"
+        "pkg = load_pkg(); oracle.build(); oracle.lib()\n"
+        "imgs = list(pkg.synth.frame_pair(640, 480, 4, 1))\n"
+        "e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)\n"
+        "kps, descs = e.extract_batch(imgs)\n"
+        "assert e.quadtree_fallbacks() == 16\n"
+        "for i in range(2):\n"
+        "    okp, od = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(imgs[i])\n"
+        "    assert kps[i].tobytes() == okp.tobytes() and np.array_equal(descs[i], od)\n"
+        "print('general-ok')\n" % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, DCS_OCTREE_FORCE_GENERAL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "general-ok" in r.stdout, r.stdout + r.stderr
