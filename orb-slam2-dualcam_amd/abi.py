@@ -347,31 +347,51 @@ def make_camera(fx, fy, cx, cy, ext7, adj36):
     return c
 
 
+class PreparedBA:
+    """The flat problem marshalled once (contiguous arrays + dcs_ba_problem / dcs_ba_result structs); solve() is then a
+    bare dcs_ba_local call, like the C++ caller in INTEGRATION.md section 3."""
+
+    def __init__(self, prob):
+        self.poses = _c(prob["poses"], np.float64)
+        self.fixed = _c(prob["pose_fixed"], np.uint8)
+        self.points = _c(prob["points"], np.float64)
+        self.ep, self.el, self.ec = (_c(prob[k], np.int32) for k in ("edge_pose", "edge_point", "edge_cam"))
+        self.obs = _c(prob["obs"], np.float64)
+        self.w = _c(prob["inv_sigma2"], np.float64)
+        cam_list = [c if isinstance(c, BaCamera) else make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"])
+                    for c in prob["cams"]]
+        self.cams = (BaCamera * len(cam_list))(*cam_list)
+        P, L, E = len(self.poses), len(self.points), len(self.ep)
+        self.pb = BaProblem(P, L, E, len(cam_list), _p(self.poses).value, _p(self.fixed).value, _p(self.points).value,
+                            _p(self.ep).value, _p(self.el).value, _p(self.ec).value, _p(self.obs).value, _p(self.w).value,
+                            C.cast(self.cams, C.c_void_p).value,
+                            float(prob.get("huber_delta", np.sqrt(5.991))), float(prob.get("chi2_th", 5.991)),
+                            int(prob.get("iters1", 5)), int(prob.get("iters2", 10)))
+        self.out_poses, self.out_points = np.zeros((P, 7)), np.zeros((L, 3))
+        self.chi2, self.outl, self.lvl1 = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+        self.res = BaResult(_p(self.out_poses).value, _p(self.out_points).value, _p(self.chi2).value, _p(self.outl).value,
+                            _p(self.lvl1).value)
+
+    def solve(self, stop_flag=None):
+        sf = _p(stop_flag) if stop_flag is not None else None
+        _check(lib().dcs_ba_local(C.byref(self.pb), sf, C.byref(self.res)), "dcs_ba_local")
+        res = self.res
+        return dict(poses=self.out_poses, points=self.out_points, edge_chi2=self.chi2, edge_outlier=self.outl, edge_level1=self.lvl1,
+                    n_iters=list(res.n_iters), n_trials=list(res.n_trials), lambda_=list(res.lambda_),
+                    chi2_trace=np.array(res.chi2_trace), gpu_ms=float(res.gpu_ms))
+
+
 class Optimizer:
     """Optimizer::LocalBundleAdjustment (reference include/Optimizer.h:55) on a flat problem."""
 
     @staticmethod
+    def prepare(prob):
+        return PreparedBA(prob)
+
+    @staticmethod
     def LocalBundleAdjustment(prob, stop_flag=None):
-        poses = _c(prob["poses"], np.float64)
-        fixed = _c(prob["pose_fixed"], np.uint8)
-        points = _c(prob["points"], np.float64)
-        ep, el, ec = (_c(prob[k], np.int32) for k in ("edge_pose", "edge_point", "edge_cam"))
-        obs = _c(prob["obs"], np.float64)
-        w = _c(prob["inv_sigma2"], np.float64)
-        cam_list = [c if isinstance(c, BaCamera) else make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"])
-                    for c in prob["cams"]]
-        cams = (BaCamera * len(cam_list))(*cam_list)
-        P, L, E = len(poses), len(points), len(ep)
-        pb = BaProblem(P, L, E, len(cam_list), _p(poses).value, _p(fixed).value, _p(points).value,
-                       _p(ep).value, _p(el).value, _p(ec).value, _p(obs).value, _p(w).value,
-                       C.cast(cams, C.c_void_p).value,
-                       float(prob.get("huber_delta", np.sqrt(5.991))), float(prob.get("chi2_th", 5.991)),
-                       int(prob.get("iters1", 5)), int(prob.get("iters2", 10)))
-        out_poses, out_points = np.zeros((P, 7)), np.zeros((L, 3))
-        chi2, outl, lvl1 = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
-        res = BaResult(_p(out_poses).value, _p(out_points).value, _p(chi2).value, _p(outl).value, _p(lvl1).value)
-        sf = _p(stop_flag) if stop_flag is not None else None
-        _check(lib().dcs_ba_local(C.byref(pb), sf, C.byref(res)), "dcs_ba_local")
-        return dict(poses=out_poses, points=out_points, edge_chi2=chi2, edge_outlier=outl, edge_level1=lvl1,
-                    n_iters=list(res.n_iters), n_trials=list(res.n_trials), lambda_=list(res.lambda_),
-                    chi2_trace=np.array(res.chi2_trace), gpu_ms=float(res.gpu_ms))
+        prep = prob if isinstance(prob, PreparedBA) else PreparedBA(prob)
+        out = prep.solve(stop_flag)
+        if prep is not prob:                               # one-shot call: the caller owns the outputs
+            return out
+        return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in out.items()}

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_reduce_point(int L, const int32_t* __re
                                                       const uint8_t* __restrict__ e_active, const double* __restrict__ cpoint,
                                                       double* __restrict__ Hll, double* __restrict__ bl, uint8_t* __restrict__ pt_active)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= L) return;
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int n_act = 0;
@@ -272,21 +272,25 @@ __global__ __launch_bounds__(256) void k_reduce_point(int L, const int32_t* __re
     bl[3 * l] = a[6]; bl[3 * l + 1] = a[7]; bl[3 * l + 2] = a[8];
 }
 
-// block (256 threads) per free pose: 9 edge chunks x 27 components, combined in chunk order (deterministic)
-__global__ __launch_bounds__(256) void k_reduce_pose(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
-                                                    const double* __restrict__ cpose, double* __restrict__ Hpp, double* __restrict__ bp)
+// block (1024 threads) per free pose: 37 edge chunks x 27 components, combined in chunk order (deterministic). The
+// list walk is latency-bound (index load -> value load), so many short chunks with 4 loads in flight each.
+constexpr int kPoseChunks = 37;
+__global__ __launch_bounds__(1024) void k_reduce_pose(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
+                                                     const double* __restrict__ cpose, double* __restrict__ Hpp, double* __restrict__ bp)
 {
-    __shared__ double part[9][27];
+    __shared__ double part[kPoseChunks][27];
     __shared__ double s[27];
     const int i = blockIdx.x, t = threadIdx.x;
     const int c = t % 27, q = t / 27;
-    if (q < 9) {
+    if (q < kPoseChunks) {
         double a = 0;
-        for (int k = ps_off[i] + q; k < ps_off[i + 1]; k += 9) a += cpose[(size_t)ps_edges[k] * 27 + c];
+        const int k1 = ps_off[i + 1];
+#pragma unroll 4
+        for (int k = ps_off[i] + q; k < k1; k += kPoseChunks) a += cpose[(size_t)ps_edges[k] * 27 + c];
         part[q][c] = a;
     }
     __syncthreads();
-    if (t < 27) { double a = 0; for (int q2 = 0; q2 < 9; ++q2) a += part[q2][t]; s[t] = a; }
+    if (t < 27) { double a = 0; for (int q2 = 0; q2 < kPoseChunks; ++q2) a += part[q2][t]; s[t] = a; }
     __syncthreads();
     if (t < 36) {
         const int r = t / 6, qq = t % 6, lo = min(r, qq), hi = max(r, qq);
@@ -312,15 +316,12 @@ __global__ __launch_bounds__(256) void k_max_diag(int np, const double* __restri
     if (threadIdx.x == 0) *out = s[0];
 }
 
-// thread per point: Dinv = (Hll + lambda I)^-1, db = Dinv bl, BD[e] = Hpl[e] Dinv for its free-pose edges
-__global__ __launch_bounds__(256) void k_point_prep(int L, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
-                                                    const int32_t* __restrict__ e_pose, const int32_t* __restrict__ pose_idx,
-                                                    const double* __restrict__ Hll, const double* __restrict__ bl,
+// thread per point: Dinv = (Hll + lambda I)^-1, db = Dinv bl
+__global__ __launch_bounds__(256) void k_point_prep(int L, const double* __restrict__ Hll, const double* __restrict__ bl,
                                                     const double* __restrict__ max_diag, double lam_mult, const uint8_t* __restrict__ pt_active,
-                                                    const double* __restrict__ Hpl, double* __restrict__ Dinv, double* __restrict__ db,
-                                                    double* __restrict__ BD, double* __restrict__ ok)
+                                                    double* __restrict__ Dinv, double* __restrict__ db, double* __restrict__ ok)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l == 0) *ok = 1.0;                                   // reset the "factorisation succeeded" flag of this trial
     if (l >= L || !pt_active[l]) return;
     const double lambda = 1e-5 * *max_diag * lam_mult;       // computeLambdaInit (tau = 1e-5) x the host's LM multiplier
@@ -330,30 +331,43 @@ __global__ __launch_bounds__(256) void k_point_prep(int L, const int32_t* __rest
     inv3(H, D);
     for (int i = 0; i < 9; ++i) Dinv[(size_t)l * 9 + i] = D[i];
     for (int i = 0; i < 3; ++i) db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
-    for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
-        const int e = pt_edges[k];
-        if (pose_idx[e_pose[e]] < 0) continue;
-        const double* B = Hpl + (size_t)e * 18;
-        double* o = BD + (size_t)e * 18;
-        for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = B[r * 3] * D[c] + B[r * 3 + 1] * D[3 + c] + B[r * 3 + 2] * D[6 + c];
+}
+
+// thread per edge of a free pose: BD[e] = Hpl[e] Dinv[point(e)] (zero for level-1 edges)
+__global__ __launch_bounds__(256) void k_edge_bd(int E, const uint8_t* __restrict__ e_active, const int32_t* __restrict__ e_pose,
+                                                 const int32_t* __restrict__ e_point, const int32_t* __restrict__ pose_idx,
+                                                 const double* __restrict__ Hpl, const double* __restrict__ Dinv, double* __restrict__ BD)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E || pose_idx[e_pose[e]] < 0) return;
+    double* o = BD + (size_t)e * 18;
+    if (!e_active[e]) {                                      // level-1 edge: still named by the pair lists, contributes zero
+        for (int i = 0; i < 18; ++i) o[i] = 0.0;
+        return;
     }
+    const double* D = Dinv + (size_t)e_point[e] * 9;
+    const double* B = Hpl + (size_t)e * 18;
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = B[r * 3] * D[c] + B[r * 3 + 1] * D[3 + c] + B[r * 3 + 2] * D[6 + c];
 }
 
 // workgroup per pose pair (i1 <= i2): S block = [i1==i2](Hpp + lambda I) - sum over shared points BD[e1] Hpl[e2]^T.
-// 7 list chunks x 36 block entries; chunk partials combined in fixed order.
-__global__ __launch_bounds__(256) void k_schur(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_off,
-                                               const int32_t* __restrict__ pair_e1, const int32_t* __restrict__ pair_e2,
-                                               const double* __restrict__ Hpp, const double* __restrict__ max_diag, double lam_mult,
-                                               const double* __restrict__ BD, const double* __restrict__ Hpl, double* __restrict__ S, int ld)
+// 28 list chunks x 36 block entries (1024 threads, 4 list entries in flight per thread); partials combined in fixed order.
+constexpr int kSchurChunks = 28;
+__global__ __launch_bounds__(1024) void k_schur(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_off,
+                                                const int32_t* __restrict__ pair_e1, const int32_t* __restrict__ pair_e2,
+                                                const double* __restrict__ Hpp, const double* __restrict__ max_diag, double lam_mult,
+                                                const double* __restrict__ BD, const double* __restrict__ Hpl, double* __restrict__ S, int ld)
 {
-    __shared__ double part[7][36];
+    __shared__ double part[kSchurChunks][36];
     const double lambda = 1e-5 * *max_diag * lam_mult;
     const int p = blockIdx.x, t = threadIdx.x;
     const int el = t % 36, q = t / 36;
     const int r = el / 6, c = el % 6;
-    if (q < 7) {
+    if (q < kSchurChunks) {
         double acc = 0;
-        for (int k = pair_off[p] + q; k < pair_off[p + 1]; k += 7) {
+        const int k1 = pair_off[p + 1];
+#pragma unroll 4
+        for (int k = pair_off[p] + q; k < k1; k += kSchurChunks) {
             const double* a = BD + (size_t)pair_e1[k] * 18 + r * 3;
             const double* b = Hpl + (size_t)pair_e2[k] * 18 + c * 3;
             acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(256) void k_schur(const int32_t* __restrict__ pair_
     if (t >= 36) return;
     const int i1 = pair_ij[2 * p], i2 = pair_ij[2 * p + 1];
     double acc = 0;
-    for (int q2 = 0; q2 < 7; ++q2) acc += part[q2][t];
+    for (int q2 = 0; q2 < kSchurChunks; ++q2) acc += part[q2][t];
     double v = -acc;
     if (i1 == i2) v += Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
     S[(size_t)(i1 * 6 + r) * ld + i2 * 6 + c] = v;
@@ -381,7 +395,9 @@ __global__ __launch_bounds__(256) void k_bschur(const int32_t* __restrict__ ps_o
     const int r = t % 6, q = t / 6;
     if (q < 42) {
         double a = 0;
-        for (int k = ps_off[i] + q; k < ps_off[i + 1]; k += 42) {
+        const int k1 = ps_off[i + 1];
+#pragma unroll 4
+        for (int k = ps_off[i] + q; k < k1; k += 42) {
             const int e = ps_edges[k];
             const double* B = Hpl + (size_t)e * 18 + r * 3;
             const double* d = db + 3 * e_point[e];
@@ -601,6 +617,199 @@ __global__ __launch_bounds__(64) void k_ldlt_update(double* __restrict__ S, int 
     for (int r = 0; r < 4; ++r) S[(size_t)(i0 + hi + 4 * r) * ld + j0 + lo] = acc[r];
 }
 
+// ---- single-workgroup blocked LDL^T + solve on the f64 matrix cores (n <= 256) ---------------------------------------
+// The lower triangle lives in the VGPRs of 8 waves as 16x16 tiles in the MFMA accumulator layout (lane l, register r
+// holds element (row = (l >> 4) + 4 r, col = l & 15)); wave (p, q) = (wave >> 1, wave & 1) owns the tiles (I, J) with
+// I % 4 == p, J % 2 == q, I >= J (2-D block-cyclic: the work stays balanced while the trailing matrix shrinks).
+// Block step J:
+//   a. the owners of block column J publish their tiles to LDS (row-major panel rows of 16 doubles),
+//   b. wave 0 factors the 16x16 diagonal block with one ROW per lane (pivot column broadcast with v_readlane) and
+//      forward-substitutes the 16 right-hand-side entries,
+//   c. one thread per row below solves its 16 entries against L11 (broadcast LDS reads; w = l d kept for step d) and
+//      applies the 16 new y values to its own right-hand-side entry,
+//   d. every wave updates its remaining tiles C(I, K) -= L(I, J) W(K, J)^T with 4 v_mfma_f64_16x16x4_f64 each
+//      (operand maps: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]); the finished L tiles return to registers.
+// Back substitution L^T x = D^-1 y walks the block columns backwards: tile owners reduce L(I, J)^T x_I with two
+// cross-lane adds, wave 0 sums the four partial vectors in fixed order and solves the 16x16 triangle with readlane.
+// 4 barriers per 16 columns instead of 1 per column, and 16x fewer LDS operand reads per multiply-add than the VALU kernel.
+constexpr int kLS = 17;                        // padded LDS row stride of the 16-wide panels (doubles)
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ long long g_ldlt_dbg[8];
+#define LSTAMP(i) do { if (tid == 0) { const long long t_ = clock64(); g_ldlt_dbg[i] += t_ - t_prev; t_prev = t_; } } while (0)
+__global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S, int ld, int n, const double* __restrict__ b,
+                                                  double* __restrict__ x, double* __restrict__ ok)
+{
+    __shared__ double Lp[256 * kLS];           // panel: raw columns of block J, then the finished L rows
+    __shared__ double Wn[256 * kLS];           // -(L D) rows of the panel
+    __shared__ double Ud[16][16 * kLS];        // unit lower factor of every diagonal block
+    __shared__ double s_invd[256], s_y[256], s_x[256];
+    __shared__ double s_part[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = wave >> 1, q = wave & 1, lo = lane & 15, hi = lane >> 4;          // 4 x 2 wave grid
+    const int NT = (n + 15) >> 4, n_pad = NT << 4;
+    // every LDS address below is one of these lane bases + a compile-time constant (ds_read/ds_write immediate offset)
+    double* const LpC = Lp + (16 * p + hi) * kLS + lo;          // accumulator layout: element (16 I + hi + 4 r, lo), 16 I = 64 a + 16 p
+    const double* const LpA = Lp + (16 * p + lo) * kLS + hi;    // MFMA A operand of row block I: L[16 I + lo][4 sl + hi]
+    const double* const WnB = Wn + (16 * q + lo) * kLS + hi;    // MFMA B operand of row block K = 2 bb + q: W[16 K + lo][4 sl + hi]
+    // tile slots: (a, b) -> I = 4 a + p, J = 2 b + q, kept for b <= 2 a + 1 (20 slots); valid iff J <= I < NT
+#define LSLOT(a, b) ((a) * ((a) + 1) + (b))
+    double4_t acc[20];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb <= 2 * a + 1; ++bb) {
+            const int I = 4 * a + p, J = 2 * bb + q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + hi + 4 * r, j = 16 * J + lo;
+                double v = i == j ? 1.0 : 0.0;                                  // identity padding
+                if (J <= I && i < n && j < n) v = i >= j ? S[(size_t)j * ld + i] : S[(size_t)i * ld + j];
+                acc[LSLOT(a, bb)][r] = v;
+            }
+        }
+    if (tid < 256) s_y[tid] = tid < n ? b[tid] : 0.0;
+    __syncthreads();
+    long long t_prev = clock64();
+    for (int J = 0; J < NT; ++J) {
+        // ---- a. publish block column J
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bb = 0; bb <= 2 * a + 1; ++bb) {
+                const int I = 4 * a + p;
+                if (2 * bb + q == J && I >= J && I < NT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) LpC[(64 * a + 4 * r) * kLS] = acc[LSLOT(a, bb)][r];
+                }
+            }
+        __syncthreads();
+        LSTAMP(0);
+        // ---- b. diagonal block: lane = row (lanes >= 16 mirror rows 0..15 and write nothing)
+        if (wave == 0) {
+            int lo_ = lo;
+            asm volatile("" : "+v"(lo_));          // per-step lane predicates (lo > k): recompute them, do not hoist 16 masks out of the J loop
+            double ar[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ar[k] = Lp[(16 * J + lo) * kLS + k];
+            double yv = s_y[16 * J + lo];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const double dk = readlane_f64(ar[k], k);
+                const double invd = fast_recip(dk);
+                if (lane == 0) { s_invd[16 * J + k] = invd; if (dk == 0.0 || !isfinite(dk)) *ok = 0.0; }
+                const double yk = readlane_f64(yv, k);
+                const double lik = ar[k] * invd;                               // meaningful for rows below k
+#pragma unroll
+                for (int j = k + 1; j < 16; ++j) ar[j] = fma(-lik, readlane_f64(ar[k], j), ar[j]);   // a_ij -= l_ik (d_k l_jk)
+                if (lo_ > k) yv = fma(-lik, yk, yv);
+                ar[k] = lik;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) Ud[J][lo * kLS + k] = k < lo_ ? ar[k] : (k == lo_ ? 1.0 : 0.0);
+                s_y[16 * J + lo] = yv;
+            }
+        }
+        __syncthreads();
+        LSTAMP(1);
+        // ---- c. rows below the diagonal block: w_j = a_j - sum_{m<j} w_m U[j][m], l_j = w_j / d_j
+        {
+            const int row = 16 * (J + 1) + tid;
+            if (row < n_pad) {
+                double w[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = Lp[row * kLS + j];
+#pragma unroll
+                for (int m = 0; m < 15; ++m) {                                  // right-looking: w_m is final, 15 - m independent updates
+#pragma unroll
+                    for (int j = m + 1; j < 16; ++j) w[j] = fma(-w[m], Ud[J][j * kLS + m], w[j]);
+                    if ((m & 3) == 3) asm volatile("" ::: "memory");            // keep the LDS loads of later columns from piling up in VGPRs
+                }
+                double yacc = s_y[row];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const double l = w[j] * s_invd[16 * J + j];
+                    Lp[row * kLS + j] = l; Wn[row * kLS + j] = -w[j];
+                    yacc = fma(-l, s_y[16 * J + j], yacc);
+                }
+                s_y[row] = yacc;
+            }
+        }
+        __syncthreads();
+        LSTAMP(2);
+        // ---- d. finished L tiles back to registers, trailing update on the matrix cores
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int I = 4 * a + p;
+            if (I <= J || I >= NT) continue;                                   // wave-uniform
+            double av[4];
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) av[sl] = LpA[64 * a * kLS + 4 * sl];
+#pragma unroll
+            for (int bb = 0; bb <= 2 * a + 1; ++bb)
+                if (2 * bb + q == J) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[LSLOT(a, bb)][r] = LpC[(64 * a + 4 * r) * kLS];
+                }
+#pragma unroll
+            for (int bb = 0; bb <= 2 * a + 1; ++bb) {
+                const int K = 2 * bb + q;
+                if (K > J && K <= I) {
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl)
+                        acc[LSLOT(a, bb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sl], WnB[32 * bb * kLS + 4 * sl], acc[LSLOT(a, bb)], 0, 0, 0);
+                    asm volatile("" ::: "memory");
+                }
+            }
+        }
+        __syncthreads();
+        LSTAMP(3);
+    }
+    if (tid < n_pad) s_x[tid] = s_y[tid] * s_invd[tid];                       // z = D^-1 y
+    __syncthreads();
+    for (int J = NT - 1; J >= 0; --J) {
+        if (q == (J & 1)) {                                                   // owners of block column J
+            double c = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int bb = 0; bb <= 2 * a + 1; ++bb) {
+                    const int I = 4 * a + p;
+                    if (2 * bb + q == J && I > J && I < NT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) c = fma(acc[LSLOT(a, bb)][r], s_x[16 * p + hi + 64 * a + 4 * r], c);
+                    }
+                }
+            c += __shfl_xor(c, 16);
+            c += __shfl_xor(c, 32);
+            if (lane < 16) s_part[p][lane] = c;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double rhs = s_x[16 * J + lo] - (((s_part[0][lo] + s_part[1][lo]) + s_part[2][lo]) + s_part[3][lo]);
+            double uc[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) uc[k] = Ud[J][k * kLS + lo];          // U[k][lo]
+#pragma unroll
+            for (int k = 15; k >= 1; --k) {
+                const double xk = readlane_f64(rhs, k);
+                if (lo < k) rhs = fma(-uc[k], xk, rhs);
+            }
+            if (lane < 16) s_x[16 * J + lo] = rhs;
+        }
+        __syncthreads();
+    }
+    LSTAMP(4);
+    if (tid < n) x[tid] = s_x[tid];
+#undef LSLOT
+}
+
 // x = S^-1 b with S = L D L^T already factored in place (unit lower L below the diagonal, D on it). single block.
 __global__ __launch_bounds__(256) void k_ldlt_solve(const double* __restrict__ S, int ld, int n_pad, const double* __restrict__ b, int n,
                                                     double* __restrict__ x)
@@ -649,7 +858,7 @@ __global__ __launch_bounds__(256) void k_back_subst(int L, const int32_t* __rest
                                                     const double* __restrict__ xp, const double* __restrict__ bl,
                                                     const double* __restrict__ Dinv, double* __restrict__ xl)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= L) return;
     if (!pt_active[l]) { xl[3 * l] = xl[3 * l + 1] = xl[3 * l + 2] = 0; return; }
     double c[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
@@ -721,10 +930,39 @@ using namespace dcs;
 
 namespace {
 
-struct Arena {                                 // one device allocation per solve
+// Per host thread and device, kept across solves: the device arena (grow-only), the pinned read-back slot and the
+// stream. hipMalloc + hipFree of ~30 MB, hipHostMalloc/Free and stream create/destroy cost ~1.4 ms per call together --
+// a third of a local BA.
+struct BaContext {
+    char* base = nullptr; size_t cap = 0; int device = -1;
+    double* h_scal = nullptr; hipStream_t stream = nullptr;
+    void release()
+    {
+        if (base) (void)hipFree(base);
+        if (h_scal) (void)hipHostFree(h_scal);
+        if (stream) (void)hipStreamDestroy(stream);
+        base = nullptr; cap = 0; h_scal = nullptr; stream = nullptr; device = -1;
+    }
+    ~BaContext() { release(); }
+};
+inline BaContext& ba_context() { static thread_local BaContext c; return c; }
+
+struct Arena {
     char* base = nullptr; size_t cap = 0, off = 0;
-    ~Arena() { if (base) (void)hipFree(base); }
-    int init(size_t bytes) { cap = bytes; DCS_HIP(hipMalloc((void**)&base, bytes)); return DCS_OK; }
+    int init(size_t bytes)
+    {
+        BaContext& c = ba_context();
+        int dev = 0;
+        DCS_HIP(hipGetDevice(&dev));
+        if (c.device != dev) c.release();
+        if (c.base && c.cap < bytes) { (void)hipFree(c.base); c.base = nullptr; c.cap = 0; }
+        if (!c.base) { DCS_HIP(hipMalloc((void**)&c.base, bytes)); c.cap = bytes; }
+        if (!c.h_scal) DCS_HIP(hipHostMalloc((void**)&c.h_scal, 64));
+        if (!c.stream) DCS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        c.device = dev;
+        base = c.base; cap = c.cap; off = 0;
+        return DCS_OK;
+    }
     template <typename T> T* get(size_t n) { off = (off + 255) & ~(size_t)255; T* p = (T*)(base + off); off += n * sizeof(T); return off <= cap ? p : nullptr; }
 };
 
@@ -867,10 +1105,9 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     int* d_ok = ar.get<int>(4);
     unsigned* d_ticket = ar.get<unsigned>(4);
     if (!d_ticket) { set_error("BA arena too small"); return DCS_ERR_HIP; }
-    double* h_scal = nullptr;
-    DCS_HIP(hipHostMalloc((void**)&h_scal, 64));
-    struct HostFree { void* p; ~HostFree() { (void)hipHostFree(p); } } hf{h_scal};
+    double* h_scal = ba_context().h_scal;
     const bool force_blocked = getenv("DCS_BA_FORCE_BLOCKED_LDLT") != nullptr;
+    const bool ldlt_valu = getenv("DCS_BA_LDLT_VALU") != nullptr;       // previous register-resident column-by-column kernel
     const bool trace_t = getenv("DCS_BA_TRACE") != nullptr;
     const int dbg_skip = getenv("DCS_BA_DBG_SKIP") ? atoi(getenv("DCS_BA_DBG_SKIP")) : 0;   // timing experiments only
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -878,9 +1115,7 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     const auto t_call0 = now();
     double t_build = 0, t_sync = 0;   // test hook: exercise the MFMA fallback at small n
 
-    hipStream_t st;
-    DCS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{st};
+    hipStream_t st = ba_context().stream;
     DCS_HIP(hipMemcpyAsync(d_poses, pb->poses, sizeof(double) * 7 * P, hipMemcpyHostToDevice, st));
     DCS_HIP(hipMemcpyAsync(d_points, pb->points, sizeof(double) * 3 * L, hipMemcpyHostToDevice, st));
     DCS_HIP(hipMemcpyAsync(d_epose, pb->edge_pose, sizeof(int32_t) * E, hipMemcpyHostToDevice, st));
@@ -949,10 +1184,10 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
             hipLaunchKernelGGL(k_linearize, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2,
                                d_pose_idx, d_cpoint, d_cpose, d_Hpl);
             DCS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(k_reduce_point, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_active, d_cpoint, d_Hll, d_bl,
+            hipLaunchKernelGGL(k_reduce_point, dim3((L + 63) / 64), dim3(64), 0, st, L, d_pt_off, d_pt_edges, d_active, d_cpoint, d_Hll, d_bl,
                                d_pt_active);
             DCS_CHECK_LAUNCH();
-            if (r.np) { hipLaunchKernelGGL(k_reduce_pose, dim3(r.np), dim3(256), 0, st, d_ps_off, d_ps_edges, d_cpose, d_Hpp, d_bp); DCS_CHECK_LAUNCH(); }
+            if (r.np) { hipLaunchKernelGGL(k_reduce_pose, dim3(r.np), dim3(1024), 0, st, d_ps_off, d_ps_edges, d_cpose, d_Hpp, d_bp); DCS_CHECK_LAUNCH(); }
             if (it == 0) {
                 hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, r.np, d_Hpp, L, d_pt_active, d_Hll, d_scal + 2);
                 DCS_CHECK_LAUNCH();
@@ -962,21 +1197,25 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
             int qmax = 0;
             do {
                 // setLambda + solve (Schur)
-                hipLaunchKernelGGL(k_point_prep, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx,
-                                   d_Hll, d_bl, d_maxdiag, mult, d_pt_active, d_Hpl, d_Dinv, d_db, d_BD, d_scal + 3);
+                hipLaunchKernelGGL(k_point_prep, dim3((L + 63) / 64), dim3(64), 0, st, L, d_Hll, d_bl, d_maxdiag, mult, d_pt_active, d_Dinv, d_db, d_scal + 3);
                 DCS_CHECK_LAUNCH();
+                if (r.np) {
+                    hipLaunchKernelGGL(k_edge_bd, dim3(nblk), dim3(256), 0, st, E, d_active, d_epose, d_epoint, d_pose_idx, d_Hpl, d_Dinv, d_BD);
+                    DCS_CHECK_LAUNCH();
+                }
                 if (r.np) {
                     if (!use_reg) {                       // the blocked fallback factors S in place: rebuild it every trial
                         DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));
                         if (n_pad > n) { hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(64), 0, st, d_S, ld, n, n_pad); DCS_CHECK_LAUNCH(); }
                     }
-                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs), dim3(256), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp, d_maxdiag,
+                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs), dim3(1024), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp, d_maxdiag,
                                        mult, d_BD, d_Hpl, d_S, ld);
                     DCS_CHECK_LAUNCH();
                     hipLaunchKernelGGL(k_bschur, dim3(r.np), dim3(256), 0, st, d_ps_off, d_ps_edges, d_epoint, d_Hpl, d_db, d_bp, d_bsch);
                     DCS_CHECK_LAUNCH();
                     if (use_reg) {
-                        hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(1), dim3(1024), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3, dbg_skip);
+                        if (ldlt_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(1), dim3(1024), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3, dbg_skip);
+                        else hipLaunchKernelGGL(k_ldlt_mfma, dim3(1), dim3(512), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3);
                         DCS_CHECK_LAUNCH();
                     } else {
                         for (int k0 = 0; k0 < n_pad; k0 += kNB) {
@@ -989,7 +1228,7 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
                         DCS_CHECK_LAUNCH();
                     }
                 }
-                hipLaunchKernelGGL(k_back_subst, dim3((L + 255) / 256), dim3(256), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx, d_pt_active,
+                hipLaunchKernelGGL(k_back_subst, dim3((L + 63) / 64), dim3(64), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx, d_pt_active,
                                    d_Hpl, d_xp, d_bl, d_Dinv, d_xl);
                 DCS_CHECK_LAUNCH();
                 hipLaunchKernelGGL(k_update, dim3((P + L + 255) / 256), dim3(256), 0, st, P, L, d_pose_idx, d_xp, d_xl, d_poses, d_points,
@@ -1056,6 +1295,16 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
         fprintf(stderr, "[dcs_ba] total %.3f ms: setup %.3f, optimise %.3f (build_round %.3f, waiting on GPU in trial syncs %.3f)\n", ms_since(t_call0),
                 ms_since(t_call0) - res->gpu_ms, (double)res->gpu_ms, t_build, t_sync);
     return DCS_OK;
+}
+
+void dcs_dbg_ldlt_dump()
+{
+    long long h[8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(dcs::g_ldlt_dbg), sizeof(h));
+    printf("ldlt cycles: publish %lld diag %lld rows %lld update %lld backsubst %lld\n", h[0], h[1], h[2], h[3], h[4]);
+    memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dcs::g_ldlt_dbg), h, sizeof(h));
 }
 
 int dcs_rig_adjoint(const float T[16], int exact, double ext7[7], double adj[36])
