@@ -7,14 +7,22 @@
 // diagonal, landmark back-substitution), solvers/linear_solver_eigen.h:94-124 (LDL^T of the reduced
 // camera system), core/optimization_algorithm_levenberg.cpp:61-189 (LM control), se3quat.h:223-257 (exp).
 //
-// Flat SoA problem in HBM, no graph objects. Per LM iteration:
-//   k_error      edge-parallel residual + chi2 + Huber rho, deterministic block partial sums
-//   k_linearize  edge-parallel Jacobians -> per-edge H_pl (6x3) and per-edge pose / point contributions
-//   k_reduce_point / k_reduce_pose   segmented sums in CSR order (no atomics: reproducible)
-//   per trial: k_point_prep (D^-1 = (H_ll + lambda I)^-1, H_pl D^-1), k_schur (one wave per pose pair over a
-//   precomputed (edge,edge) list), blocked LDL^T (16-column panels; trailing update on the f64 matrix
-//   cores, v_mfma_f64_16x16x4_f64), triangular solves, landmark back-substitution, manifold update,
-//   residuals again; the host reads back 3 doubles per trial and runs g2o's accept / reject logic.
+// Flat SoA problem in HBM, no graph objects. Launches per LM iteration (every list walk is a latency chain, so each
+// reduction uses many short chunks with several loads in flight, and small kernels share launches):
+//   k_linearize     edge-parallel Jacobians -> per-edge H_pl (6x3) and per-edge pose / point contributions
+//   k_reduce_pose   one launch: segmented sums of the pose blocks (37 chunks per free pose) and of the landmark blocks,
+//                   CSR order, no atomics (reproducible)
+//   per trial (5 launches + one 40-byte read-back):
+//   k_prep          BD[e] = H_pl[e] (H_ll + lambda I)^-1 per edge, D^-1 and D^-1 b_l per landmark
+//   k_schur         workgroup per pose pair over a precomputed (edge, edge) list (28 chunks) + the reduced right-hand side
+//   k_ldlt_mfma     LDL^T + both triangular solves of the reduced camera system in ONE workgroup: 16x16 tiles in
+//                   registers, trailing updates on the f64 matrix cores (v_mfma_f64_16x16x4_f64)
+//                   (k_ldlt_reg: column-by-column VALU predecessor, DCS_BA_LDLT_VALU=1; k_ldlt_panel/_update/_solve:
+//                   multi-launch fallback for n > 256)
+//   k_solve_update  landmark back-substitution, push + manifold update of all estimates, computeScale partials
+//   k_error         edge-parallel residual + chi2 + Huber rho; the last block adds the block partials (and the scale
+//                   partials) in index order
+// The host reads back 5 doubles per trial and runs g2o's accept / reject logic.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -157,7 +165,8 @@ struct EdgeArrays {
 // (device-scope ticket) adds them in index order -> *chi_out, so the total is reproducible run to run.
 __global__ __launch_bounds__(256) void k_error(EdgeArrays ed, int E, const double* __restrict__ poses, const double* __restrict__ points,
                                                DCams cams, int robust, double delta, double* __restrict__ err, double* __restrict__ chi2,
-                                               double* __restrict__ partial, unsigned* __restrict__ ticket, double* __restrict__ chi_out)
+                                               double* __restrict__ partial, unsigned* __restrict__ ticket, double* __restrict__ chi_out,
+                                               const double* __restrict__ scale_partial, int n_scale_partial, double* __restrict__ scale_out)
 {
     __shared__ double s[256];
     __shared__ bool last;
@@ -190,6 +199,13 @@ __global__ __launch_bounds__(256) void k_error(EdgeArrays ed, int E, const doubl
     for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) v += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double tot = block_sum_256(v, s);
     if (threadIdx.x == 0) { *chi_out = tot; __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (n_scale_partial > 0) {                      // computeScale: block partials of k_solve_update (an earlier launch), fixed order
+        __syncthreads();
+        double w = 0;
+        for (int i = threadIdx.x; i < n_scale_partial; i += 256) w += scale_partial[i];
+        const double sc = block_sum_256(w, s);
+        if (threadIdx.x == 0) *scale_out = sc;
+    }
 }
 
 // linearizeOplus + constructQuadraticForm, per edge. cpoint[e] = {Hll 00,01,02,11,12,22, bl0..2},
@@ -251,35 +267,34 @@ __global__ __launch_bounds__(256) void k_linearize(EdgeArrays ed, int E, const d
     }
 }
 
-// thread per point: sums its edges' contributions (CSR over active edges). Hll full 3x3, bl.
-__global__ __launch_bounds__(256) void k_reduce_point(int L, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
-                                                      const uint8_t* __restrict__ e_active, const double* __restrict__ cpoint,
-                                                      double* __restrict__ Hll, double* __restrict__ bl, uint8_t* __restrict__ pt_active)
-{
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= L) return;
-    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int n_act = 0;
-    for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
-        const int e = pt_edges[k];
-        n_act += e_active[e];
-        const double* c = cpoint + (size_t)e * 9;
-        for (int i = 0; i < 9; ++i) a[i] += c[i];
-    }
-    pt_active[l] = n_act > 0;                       // a landmark without active edges is not part of this round
-    double* H = Hll + (size_t)l * 9;
-    H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
-    bl[3 * l] = a[6]; bl[3 * l + 1] = a[7]; bl[3 * l + 2] = a[8];
-}
-
 // block (1024 threads) per free pose: 37 edge chunks x 27 components, combined in chunk order (deterministic). The
 // list walk is latency-bound (index load -> value load), so many short chunks with 4 loads in flight each.
 constexpr int kPoseChunks = 37;
+struct ReducePointArgs { int L; const int32_t *pt_off, *pt_edges; const uint8_t* e_active; const double* cpoint; double *Hll, *bl; uint8_t* pt_active; };
 __global__ __launch_bounds__(1024) void k_reduce_pose(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
-                                                     const double* __restrict__ cpose, double* __restrict__ Hpp, double* __restrict__ bp)
+                                                     const double* __restrict__ cpose, double* __restrict__ Hpp, double* __restrict__ bp,
+                                                     int np, ReducePointArgs rp)
 {
     __shared__ double part[kPoseChunks][27];
     __shared__ double s[27];
+    if ((int)blockIdx.x >= np) {                             // blocks past the free poses: 64 landmarks each (thread per landmark)
+        if (threadIdx.x >= 64) return;
+        const int l = (blockIdx.x - np) * 64 + threadIdx.x;
+        if (l >= rp.L) return;
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int n_act = 0;
+        for (int k = rp.pt_off[l]; k < rp.pt_off[l + 1]; ++k) {
+            const int e = rp.pt_edges[k];
+            n_act += rp.e_active[e];
+            const double* c = rp.cpoint + (size_t)e * 9;
+            for (int i = 0; i < 9; ++i) a[i] += c[i];
+        }
+        rp.pt_active[l] = n_act > 0;                 // a landmark without active edges is not part of this round
+        double* H = rp.Hll + (size_t)l * 9;
+        H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
+        rp.bl[3 * l] = a[6]; rp.bl[3 * l + 1] = a[7]; rp.bl[3 * l + 2] = a[8];
+        return;
+    }
     const int i = blockIdx.x, t = threadIdx.x;
     const int c = t % 27, q = t / 27;
     if (q < kPoseChunks) {
@@ -316,15 +331,38 @@ __global__ __launch_bounds__(256) void k_max_diag(int np, const double* __restri
     if (threadIdx.x == 0) *out = s[0];
 }
 
-// thread per point: Dinv = (Hll + lambda I)^-1, db = Dinv bl
-__global__ __launch_bounds__(256) void k_point_prep(int L, const double* __restrict__ Hll, const double* __restrict__ bl,
-                                                    const double* __restrict__ max_diag, double lam_mult, const uint8_t* __restrict__ pt_active,
-                                                    double* __restrict__ Dinv, double* __restrict__ db, double* __restrict__ ok)
+// setLambda for the landmark blocks, one launch:
+//   blocks [0, nblk_e)  thread per edge of a free pose: BD[e] = Hpl[e] Dinv[point(e)] (zero for level-1 edges); the 3x3
+//                       inverse is recomputed per edge (40 flops) so that the edges do not wait for a per-point pass
+//   blocks [nblk_e, ..) thread per point: Dinv = (Hll + lambda I)^-1, db = Dinv bl (read by k_schur_all / k_solve_update)
+__global__ __launch_bounds__(256) void k_prep(int E, int nblk_e, const uint8_t* __restrict__ e_active, const int32_t* __restrict__ e_pose,
+                                              const int32_t* __restrict__ e_point, const int32_t* __restrict__ pose_idx,
+                                              const double* __restrict__ Hpl, double* __restrict__ BD, int L, const double* __restrict__ Hll,
+                                              const double* __restrict__ bl, const double* __restrict__ max_diag, double lam_mult,
+                                              const uint8_t* __restrict__ pt_active, double* __restrict__ Dinv, double* __restrict__ db,
+                                              double* __restrict__ ok)
 {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const double lambda = 1e-5 * *max_diag * lam_mult;       // computeLambdaInit (tau = 1e-5) x the host's LM multiplier
+    if ((int)blockIdx.x < nblk_e) {
+        const int e = blockIdx.x * 256 + threadIdx.x;
+        if (e >= E || pose_idx[e_pose[e]] < 0) return;
+        double* o = BD + (size_t)e * 18;
+        if (!e_active[e]) {                                  // level-1 edge: still named by the pair lists, contributes zero
+            for (int i = 0; i < 18; ++i) o[i] = 0.0;
+            return;
+        }
+        const int l = e_point[e];
+        double H[9], D[9];
+        for (int i = 0; i < 9; ++i) H[i] = Hll[(size_t)l * 9 + i];
+        H[0] += lambda; H[4] += lambda; H[8] += lambda;
+        inv3(H, D);
+        const double* B = Hpl + (size_t)e * 18;
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = B[r * 3] * D[c] + B[r * 3 + 1] * D[3 + c] + B[r * 3 + 2] * D[6 + c];
+        return;
+    }
+    const int l = (blockIdx.x - nblk_e) * 256 + threadIdx.x;
     if (l == 0) *ok = 1.0;                                   // reset the "factorisation succeeded" flag of this trial
     if (l >= L || !pt_active[l]) return;
-    const double lambda = 1e-5 * *max_diag * lam_mult;       // computeLambdaInit (tau = 1e-5) x the host's LM multiplier
     double H[9], D[9];
     for (int i = 0; i < 9; ++i) H[i] = Hll[(size_t)l * 9 + i];
     H[0] += lambda; H[4] += lambda; H[8] += lambda;
@@ -333,32 +371,38 @@ __global__ __launch_bounds__(256) void k_point_prep(int L, const double* __restr
     for (int i = 0; i < 3; ++i) db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
 }
 
-// thread per edge of a free pose: BD[e] = Hpl[e] Dinv[point(e)] (zero for level-1 edges)
-__global__ __launch_bounds__(256) void k_edge_bd(int E, const uint8_t* __restrict__ e_active, const int32_t* __restrict__ e_pose,
-                                                 const int32_t* __restrict__ e_point, const int32_t* __restrict__ pose_idx,
-                                                 const double* __restrict__ Hpl, const double* __restrict__ Dinv, double* __restrict__ BD)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E || pose_idx[e_pose[e]] < 0) return;
-    double* o = BD + (size_t)e * 18;
-    if (!e_active[e]) {                                      // level-1 edge: still named by the pair lists, contributes zero
-        for (int i = 0; i < 18; ++i) o[i] = 0.0;
-        return;
-    }
-    const double* D = Dinv + (size_t)e_point[e] * 9;
-    const double* B = Hpl + (size_t)e * 18;
-    for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = B[r * 3] * D[c] + B[r * 3 + 1] * D[3 + c] + B[r * 3 + 2] * D[6 + c];
-}
-
 // workgroup per pose pair (i1 <= i2): S block = [i1==i2](Hpp + lambda I) - sum over shared points BD[e1] Hpl[e2]^T.
 // 28 list chunks x 36 block entries (1024 threads, 4 list entries in flight per thread); partials combined in fixed order.
 constexpr int kSchurChunks = 28;
+struct BschurArgs { const int32_t *ps_off, *ps_edges, *e_point; const double *db, *bp; double* bsch; };
 __global__ __launch_bounds__(1024) void k_schur(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_off,
                                                 const int32_t* __restrict__ pair_e1, const int32_t* __restrict__ pair_e2,
                                                 const double* __restrict__ Hpp, const double* __restrict__ max_diag, double lam_mult,
-                                                const double* __restrict__ BD, const double* __restrict__ Hpl, double* __restrict__ S, int ld)
+                                                const double* __restrict__ BD, const double* __restrict__ Hpl, double* __restrict__ S, int ld,
+                                                int n_pairs, BschurArgs bs)
 {
     __shared__ double part[kSchurChunks][36];
+    if ((int)blockIdx.x >= n_pairs) {                        // blocks past the pair list: reduced right-hand side of one free pose
+        // bsch = bp - sum_e Hpl[e] db[point(e)]; 168 edge chunks x 6 rows, combined in chunk order
+        double (*bpart)[6] = reinterpret_cast<double (*)[6]>(&part[0][0]);         // 168 x 6 <= 28 x 36
+        const int i = blockIdx.x - n_pairs, t = threadIdx.x;
+        const int r = t % 6, q = t / 6;
+        if (q < 168) {
+            double a = 0;
+            const int k1 = bs.ps_off[i + 1];
+#pragma unroll 4
+            for (int k = bs.ps_off[i] + q; k < k1; k += 168) {
+                const int e = bs.ps_edges[k];
+                const double* B = Hpl + (size_t)e * 18 + r * 3;
+                const double* d = bs.db + 3 * bs.e_point[e];
+                a += B[0] * d[0] + B[1] * d[1] + B[2] * d[2];
+            }
+            bpart[q][r] = a;
+        }
+        __syncthreads();
+        if (t < 6) { double a = 0; for (int q2 = 0; q2 < 168; ++q2) a += bpart[q2][t]; bs.bsch[i * 6 + t] = bs.bp[i * 6 + t] - a; }
+        return;
+    }
     const double lambda = 1e-5 * *max_diag * lam_mult;
     const int p = blockIdx.x, t = threadIdx.x;
     const int el = t % 36, q = t / 36;
@@ -383,30 +427,6 @@ __global__ __launch_bounds__(1024) void k_schur(const int32_t* __restrict__ pair
     if (i1 == i2) v += Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
     S[(size_t)(i1 * 6 + r) * ld + i2 * 6 + c] = v;
     if (i1 != i2) S[(size_t)(i2 * 6 + c) * ld + i1 * 6 + r] = v;
-}
-
-// workgroup per free pose: bsch = bp - sum_e Hpl[e] db[point(e)]; 42 edge chunks x 6 rows
-__global__ __launch_bounds__(256) void k_bschur(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
-                                                const int32_t* __restrict__ e_point, const double* __restrict__ Hpl,
-                                                const double* __restrict__ db, const double* __restrict__ bp, double* __restrict__ bsch)
-{
-    __shared__ double part[42][6];
-    const int i = blockIdx.x, t = threadIdx.x;
-    const int r = t % 6, q = t / 6;
-    if (q < 42) {
-        double a = 0;
-        const int k1 = ps_off[i + 1];
-#pragma unroll 4
-        for (int k = ps_off[i] + q; k < k1; k += 42) {
-            const int e = ps_edges[k];
-            const double* B = Hpl + (size_t)e * 18 + r * 3;
-            const double* d = db + 3 * e_point[e];
-            a += B[0] * d[0] + B[1] * d[1] + B[2] * d[2];
-        }
-        part[q][r] = a;
-    }
-    __syncthreads();
-    if (t < 6) { double a = 0; for (int q2 = 0; q2 < 42; ++q2) a += part[q2][t]; bsch[i * 6 + t] = bp[i * 6 + t] - a; }
 }
 
 // ---- register-resident LDL^T + solve (n_pad <= 256): the whole lower triangle lives in the VGPRs of ONE workgroup.
@@ -851,60 +871,62 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(const double* __restrict__ S
     for (int i = t; i < n; i += 256) x[i] = y[i];
 }
 
-// thread per point: xl = Dinv (bl - sum_e Hpl[e]^T xp[pose(e)])
-__global__ __launch_bounds__(256) void k_back_subst(int L, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
+// Landmark back-substitution, push + oplus of every estimate and the block partials of computeScale, one launch of
+// 64-thread blocks: blocks [0, nb_pts) thread per landmark (xl = Dinv (bl - sum_e Hpl[e]^T xp[pose(e)]), backup, += xl),
+// blocks [nb_pts, ..) thread per pose (backup, pose <- exp(dx) * pose). scale = sum_j x_j (lambda x_j + b_j) over pose and
+// active landmark entries; the block sums are added in index order by k_error's finisher.
+__global__ __launch_bounds__(64) void k_solve_update(int L, int nb_pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
                                                     const int32_t* __restrict__ e_pose, const int32_t* __restrict__ pose_idx,
                                                     const uint8_t* __restrict__ pt_active, const double* __restrict__ Hpl,
-                                                    const double* __restrict__ xp, const double* __restrict__ bl,
-                                                    const double* __restrict__ Dinv, double* __restrict__ xl)
+                                                    const double* __restrict__ xp, const double* __restrict__ bl, const double* __restrict__ Dinv,
+                                                    double* __restrict__ xl, int P, const double* __restrict__ bp, double* __restrict__ poses,
+                                                    double* __restrict__ points, double* __restrict__ poses_bk, double* __restrict__ points_bk,
+                                                    const double* __restrict__ max_diag, double lam_mult, double* __restrict__ scale_partial)
 {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= L) return;
-    if (!pt_active[l]) { xl[3 * l] = xl[3 * l + 1] = xl[3 * l + 2] = 0; return; }
-    double c[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
-    for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
-        const int e = pt_edges[k], pi = pose_idx[e_pose[e]];
-        if (pi < 0) continue;
-        const double* B = Hpl + (size_t)e * 18;
-        const double* xq = xp + pi * 6;
-        for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) c[j] -= B[r * 3 + j] * xq[r];
-    }
-    const double* D = Dinv + (size_t)l * 9;
-    for (int i = 0; i < 3; ++i) xl[3 * l + i] = D[i * 3] * c[0] + D[i * 3 + 1] * c[1] + D[i * 3 + 2] * c[2];
-}
-
-// push + update: backup the estimates, then pose <- exp(dx) * pose, point += dx
-__global__ __launch_bounds__(256) void k_update(int P, int L, const int32_t* __restrict__ pose_idx, const double* __restrict__ xp,
-                                                const double* __restrict__ xl, double* __restrict__ poses, double* __restrict__ points,
-                                                double* __restrict__ poses_bk, double* __restrict__ points_bk)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < P) {
-        double T[7];
-        for (int k = 0; k < 7; ++k) { T[k] = poses[7 * i + k]; poses_bk[7 * i + k] = T[k]; }
-        const int pi = pose_idx[i];
-        if (pi >= 0) { double o[7]; pose_oplus(T, xp + 6 * pi, o); for (int k = 0; k < 7; ++k) poses[7 * i + k] = o[k]; }
-    } else if (i < P + L) {
-        const int l = i - P;
-        for (int k = 0; k < 3; ++k) { const double v = points[3 * l + k]; points_bk[3 * l + k] = v; points[3 * l + k] = v + xl[3 * l + k]; }
-    }
-}
-
-// computeScale: sum_j x_j (lambda x_j + b_j) over pose and active landmark entries. single block.
-__global__ __launch_bounds__(256) void k_scale(int n, const double* __restrict__ xp, const double* __restrict__ bp, int L,
-                                               const uint8_t* __restrict__ pt_active, const double* __restrict__ xl, const double* __restrict__ bl,
-                                               const double* __restrict__ max_diag, double lam_mult, double* __restrict__ out)
-{
-    __shared__ double s[256];
     const double lambda = 1e-5 * *max_diag * lam_mult;
-    double v = 0;
-    for (int i = threadIdx.x; i < n; i += 256) v += xp[i] * (lambda * xp[i] + bp[i]);
-    for (int i = threadIdx.x; i < 3 * L; i += 256) {
-        const int l = i / 3;
-        if (pt_active[l]) v += xl[i] * (lambda * xl[i] + bl[i]);
+    double sc = 0;
+    if ((int)blockIdx.x < nb_pts) {
+        const int l = blockIdx.x * 64 + threadIdx.x;
+        if (l < L) {
+            double x[3] = {0, 0, 0};
+            if (pt_active[l]) {
+                double c[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
+                for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
+                    const int e = pt_edges[k], pi = pose_idx[e_pose[e]];
+                    if (pi < 0) continue;
+                    const double* B = Hpl + (size_t)e * 18;
+                    const double* xq = xp + pi * 6;
+                    for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) c[j] -= B[r * 3 + j] * xq[r];
+                }
+                const double* D = Dinv + (size_t)l * 9;
+                for (int i = 0; i < 3; ++i) {
+                    x[i] = D[i * 3] * c[0] + D[i * 3 + 1] * c[1] + D[i * 3 + 2] * c[2];
+                    sc += x[i] * (lambda * x[i] + bl[3 * l + i]);
+                }
+            }
+            for (int k = 0; k < 3; ++k) {
+                xl[3 * l + k] = x[k];
+                const double v = points[3 * l + k];
+                points_bk[3 * l + k] = v; points[3 * l + k] = v + x[k];
+            }
+        }
+    } else {
+        const int i = (blockIdx.x - nb_pts) * 64 + threadIdx.x;
+        if (i < P) {
+            double T[7];
+            for (int k = 0; k < 7; ++k) { T[k] = poses[7 * i + k]; poses_bk[7 * i + k] = T[k]; }
+            const int pi = pose_idx[i];
+            if (pi >= 0) {
+                double o[7];
+                pose_oplus(T, xp + 6 * pi, o);
+                for (int k = 0; k < 7; ++k) poses[7 * i + k] = o[k];
+                for (int k = 0; k < 6; ++k) sc += xp[6 * pi + k] * (lambda * xp[6 * pi + k] + bp[6 * pi + k]);
+            }
+        }
     }
-    const double t = block_sum_256(v, s);
-    if (threadIdx.x == 0) *out = t;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sc += __shfl_xor(sc, d);
+    if (threadIdx.x == 0) scale_partial[blockIdx.x] = sc;
 }
 
 // outlier flags: chi2 (last evaluation) > th || depth <= 0 with the CURRENT estimates (Optimizer.cc:607, 653)
@@ -1100,6 +1122,8 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     int32_t* d_pair_ij = ar.get<int32_t>(2 * n_pairs_max); int32_t* d_pair_off = ar.get<int32_t>(n_pairs_max + 1);
     int32_t* d_pair_e1 = ar.get<int32_t>(max_pairs_entries + 1); int32_t* d_pair_e2 = ar.get<int32_t>(max_pairs_entries + 1);
     double* d_partial = ar.get<double>(nblk);
+    const int nb_pts = (L + 63) / 64, nb_pose = (P + 63) / 64;
+    double* d_scale_part = ar.get<double>(nb_pts + nb_pose);
     uint8_t* d_pt_active = ar.get<uint8_t>(L);
     double* d_scal = ar.get<double>(8);               // [0] chi2, [1] scale, [2] maxdiag, [3] ok, [4] chi2 before the trial
     int* d_ok = ar.get<int>(4);
@@ -1132,9 +1156,9 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     int trace = 0;
     const auto t_opt0 = std::chrono::steady_clock::now();
 
-    auto eval_error = [&](int robust, double* chi_out) -> int {     // computeActiveErrors + activeRobustChi2
+    auto eval_error = [&](int robust, double* chi_out, int n_scale = 0) -> int {     // computeActiveErrors + activeRobustChi2 (+ computeScale)
         hipLaunchKernelGGL(k_error, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2, d_partial,
-                           d_ticket, chi_out);
+                           d_ticket, chi_out, (const double*)d_scale_part, n_scale, d_scal + 1);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     };
@@ -1184,10 +1208,11 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
             hipLaunchKernelGGL(k_linearize, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2,
                                d_pose_idx, d_cpoint, d_cpose, d_Hpl);
             DCS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(k_reduce_point, dim3((L + 63) / 64), dim3(64), 0, st, L, d_pt_off, d_pt_edges, d_active, d_cpoint, d_Hll, d_bl,
-                               d_pt_active);
-            DCS_CHECK_LAUNCH();
-            if (r.np) { hipLaunchKernelGGL(k_reduce_pose, dim3(r.np), dim3(1024), 0, st, d_ps_off, d_ps_edges, d_cpose, d_Hpp, d_bp); DCS_CHECK_LAUNCH(); }
+            {
+                const ReducePointArgs rp{L, d_pt_off, d_pt_edges, d_active, d_cpoint, d_Hll, d_bl, d_pt_active};
+                hipLaunchKernelGGL(k_reduce_pose, dim3(r.np + nb_pts), dim3(1024), 0, st, d_ps_off, d_ps_edges, d_cpose, d_Hpp, d_bp, r.np, rp);
+                DCS_CHECK_LAUNCH();
+            }
             if (it == 0) {
                 hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, r.np, d_Hpp, L, d_pt_active, d_Hll, d_scal + 2);
                 DCS_CHECK_LAUNCH();
@@ -1197,21 +1222,17 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
             int qmax = 0;
             do {
                 // setLambda + solve (Schur)
-                hipLaunchKernelGGL(k_point_prep, dim3((L + 63) / 64), dim3(64), 0, st, L, d_Hll, d_bl, d_maxdiag, mult, d_pt_active, d_Dinv, d_db, d_scal + 3);
+                hipLaunchKernelGGL(k_prep, dim3((r.np ? nblk : 0) + (L + 255) / 256), dim3(256), 0, st, E, r.np ? nblk : 0, d_active, d_epose, d_epoint,
+                                   d_pose_idx, d_Hpl, d_BD, L, d_Hll, d_bl, d_maxdiag, mult, d_pt_active, d_Dinv, d_db, d_scal + 3);
                 DCS_CHECK_LAUNCH();
-                if (r.np) {
-                    hipLaunchKernelGGL(k_edge_bd, dim3(nblk), dim3(256), 0, st, E, d_active, d_epose, d_epoint, d_pose_idx, d_Hpl, d_Dinv, d_BD);
-                    DCS_CHECK_LAUNCH();
-                }
                 if (r.np) {
                     if (!use_reg) {                       // the blocked fallback factors S in place: rebuild it every trial
                         DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));
                         if (n_pad > n) { hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(64), 0, st, d_S, ld, n, n_pad); DCS_CHECK_LAUNCH(); }
                     }
-                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs), dim3(1024), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp, d_maxdiag,
-                                       mult, d_BD, d_Hpl, d_S, ld);
-                    DCS_CHECK_LAUNCH();
-                    hipLaunchKernelGGL(k_bschur, dim3(r.np), dim3(256), 0, st, d_ps_off, d_ps_edges, d_epoint, d_Hpl, d_db, d_bp, d_bsch);
+                    const BschurArgs bs{d_ps_off, d_ps_edges, d_epoint, d_db, d_bp, d_bsch};
+                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs + r.np), dim3(1024), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp,
+                                       d_maxdiag, mult, d_BD, d_Hpl, d_S, ld, r.n_pairs, bs);
                     DCS_CHECK_LAUNCH();
                     if (use_reg) {
                         if (ldlt_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(1), dim3(1024), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3, dbg_skip);
@@ -1228,15 +1249,11 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
                         DCS_CHECK_LAUNCH();
                     }
                 }
-                hipLaunchKernelGGL(k_back_subst, dim3((L + 63) / 64), dim3(64), 0, st, L, d_pt_off, d_pt_edges, d_epose, d_pose_idx, d_pt_active,
-                                   d_Hpl, d_xp, d_bl, d_Dinv, d_xl);
+                hipLaunchKernelGGL(k_solve_update, dim3(nb_pts + nb_pose), dim3(64), 0, st, L, nb_pts, d_pt_off, d_pt_edges, d_epose, d_pose_idx,
+                                   d_pt_active, d_Hpl, d_xp, d_bl, d_Dinv, d_xl, P, d_bp, d_poses, d_points, d_poses_bk, d_points_bk, d_maxdiag, mult,
+                                   d_scale_part);
                 DCS_CHECK_LAUNCH();
-                hipLaunchKernelGGL(k_update, dim3((P + L + 255) / 256), dim3(256), 0, st, P, L, d_pose_idx, d_xp, d_xl, d_poses, d_points,
-                                   d_poses_bk, d_points_bk);
-                DCS_CHECK_LAUNCH();
-                if ((rc2 = eval_error(robust, d_scal))) return rc2;
-                hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, st, n, d_xp, d_bp, L, d_pt_active, d_xl, d_bl, d_maxdiag, mult, d_scal + 1);
-                DCS_CHECK_LAUNCH();
+                if ((rc2 = eval_error(robust, d_scal, nb_pts + nb_pose))) return rc2;      // chi2 of the trial + computeScale
                 DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 40, hipMemcpyDeviceToHost, st));     // chi, scale, maxdiag, ok, initial chi
                 const auto ts0 = now();
                 DCS_HIP(hipStreamSynchronize(st));
