@@ -641,18 +641,19 @@ __global__ __launch_bounds__(64) void k_ldlt_update(double* __restrict__ S, int 
 // The lower triangle lives in the VGPRs of 8 waves as 16x16 tiles in the MFMA accumulator layout (lane l, register r
 // holds element (row = (l >> 4) + 4 r, col = l & 15)); wave (p, q) = (wave >> 1, wave & 1) owns the tiles (I, J) with
 // I % 4 == p, J % 2 == q, I >= J (2-D block-cyclic: the work stays balanced while the trailing matrix shrinks).
-// Block step J:
-//   a. the owners of block column J publish their tiles to LDS (row-major panel rows of 16 doubles),
-//   b. wave 0 factors the 16x16 diagonal block with one ROW per lane (pivot column broadcast with v_readlane) and
-//      forward-substitutes the 16 right-hand-side entries,
-//   c. one thread per row below solves its 16 entries against L11 (broadcast LDS reads; w = l d kept for step d) and
-//      applies the 16 new y values to its own right-hand-side entry,
-//   d. every wave updates its remaining tiles C(I, K) -= L(I, J) W(K, J)^T with 4 v_mfma_f64_16x16x4_f64 each
-//      (operand maps: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]); the finished L tiles return to registers.
+// Block step J, two workgroup barriers:
+//   rows    one thread per row below the diagonal block solves its 16 entries against L11 (broadcast LDS reads;
+//           w = l d is kept for the update) and applies the 16 new y values to its own right-hand-side entry
+//   update  every wave updates its tiles C(I, K) -= L(I, J) W(K, J)^T with 4 v_mfma_f64_16x16x4_f64 each (operand maps:
+//           A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]); the tiles of block column J + 1 go first and are
+//           published to the other panel buffer, and as soon as the diagonal tile (J + 1, J + 1) is out (LDS flag) the
+//           lightly loaded wave 1 factors it -- one ROW per lane, pivot column broadcast with v_readlane, right-hand side
+//           forward-substituted alongside -- while the other waves finish the update (look-ahead: the sequential
+//           16x16 factorisation is off the critical path). The finished L tiles of column J return to registers.
 // Back substitution L^T x = D^-1 y walks the block columns backwards: tile owners reduce L(I, J)^T x_I with two
-// cross-lane adds, wave 0 sums the four partial vectors in fixed order and solves the 16x16 triangle with readlane.
-// 4 barriers per 16 columns instead of 1 per column, and 16x fewer LDS operand reads per multiply-add than the VALU kernel.
+// cross-lane adds, wave 1 sums the four partial vectors in fixed order and solves the 16x16 triangle with readlane.
 constexpr int kLS = 17;                        // padded LDS row stride of the 16-wide panels (doubles)
+constexpr int kDiagWave = 1;                   // (p, q) = (0, 1): owns the fewest tiles, never owns a diagonal tile with I % 4 == 0, J odd
 
 __device__ __forceinline__ double readlane_f64(double v, int srclane)
 {
@@ -660,23 +661,46 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane)
     return __hiloint2double(hi, lo);
 }
 
-__device__ long long g_ldlt_dbg[8];
-#define LSTAMP(i) do { if (tid == 0) { const long long t_ = clock64(); g_ldlt_dbg[i] += t_ - t_prev; t_prev = t_; } } while (0)
+// factor the 16x16 diagonal block whose raw rows sit in P (row stride kLS), forward-substitute y[0..16); one wave
+__device__ __forceinline__ void ldlt_diag16(const double* P, double* U, double* invd_out, double* y, double* ok, int lane)
+{
+    int lo_ = lane & 15;
+    asm volatile("" : "+v"(lo_));              // per-step lane predicates (lo > k): recompute them, do not hoist 16 masks
+    double ar[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ar[k] = P[lo_ * kLS + k];
+    double yv = y[lo_];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double dk = readlane_f64(ar[k], k);
+        const double invd = fast_recip(dk);
+        if (lane == 0) { invd_out[k] = invd; if (dk == 0.0 || !isfinite(dk)) *ok = 0.0; }
+        const double yk = readlane_f64(yv, k);
+        const double lik = ar[k] * invd;                                   // meaningful for rows below k
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) ar[j] = fma(-lik, readlane_f64(ar[k], j), ar[j]);   // a_ij -= l_ik (d_k l_jk)
+        if (lo_ > k) yv = fma(-lik, yk, yv);
+        ar[k] = lik;
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) U[lo_ * kLS + k] = k < lo_ ? ar[k] : (k == lo_ ? 1.0 : 0.0);
+        y[lo_] = yv;
+    }
+}
+
 __global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S, int ld, int n, const double* __restrict__ b,
                                                   double* __restrict__ x, double* __restrict__ ok)
 {
-    __shared__ double Lp[256 * kLS];           // panel: raw columns of block J, then the finished L rows
+    __shared__ double Lp[2][256 * kLS];        // panel (double-buffered): raw columns of block J, then the finished L rows
     __shared__ double Wn[256 * kLS];           // -(L D) rows of the panel
     __shared__ double Ud[16][16 * kLS];        // unit lower factor of every diagonal block
     __shared__ double s_invd[256], s_y[256], s_x[256];
     __shared__ double s_part[4][16];
+    __shared__ int s_flag;                     // block column whose diagonal tile has been published
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = wave >> 1, q = wave & 1, lo = lane & 15, hi = lane >> 4;          // 4 x 2 wave grid
     const int NT = (n + 15) >> 4, n_pad = NT << 4;
-    // every LDS address below is one of these lane bases + a compile-time constant (ds_read/ds_write immediate offset)
-    double* const LpC = Lp + (16 * p + hi) * kLS + lo;          // accumulator layout: element (16 I + hi + 4 r, lo), 16 I = 64 a + 16 p
-    const double* const LpA = Lp + (16 * p + lo) * kLS + hi;    // MFMA A operand of row block I: L[16 I + lo][4 sl + hi]
-    const double* const WnB = Wn + (16 * q + lo) * kLS + hi;    // MFMA B operand of row block K = 2 bb + q: W[16 K + lo][4 sl + hi]
     // tile slots: (a, b) -> I = 4 a + p, J = 2 b + q, kept for b <= 2 a + 1 (20 slots); valid iff J <= I < NT
 #define LSLOT(a, b) ((a) * ((a) + 1) + (b))
     double4_t acc[20];
@@ -694,57 +718,34 @@ __global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S,
             }
         }
     if (tid < 256) s_y[tid] = tid < n ? b[tid] : 0.0;
-    __syncthreads();
-    long long t_prev = clock64();
-    for (int J = 0; J < NT; ++J) {
-        // ---- a. publish block column J
+    if (tid == 0) s_flag = -1;
+    // every LDS address below is a lane base + a compile-time constant (ds_read / ds_write immediate offset)
+    const int offC = (16 * p + hi) * kLS + lo;      // accumulator layout: element (16 I + hi + 4 r, lo), 16 I = 64 a + 16 p
+    const int offA = (16 * p + lo) * kLS + hi;      // MFMA A operand of row block I: L[16 I + lo][4 sl + hi]
+    const double* const WnB = Wn + (16 * q + lo) * kLS + hi;    // MFMA B operand of row block K = 2 bb + q: W[16 K + lo][4 sl + hi]
+    // ---- prologue: publish block column 0, factor its diagonal block
+    if (q == 0) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
+            if (4 * a + p < NT) {
 #pragma unroll
-            for (int bb = 0; bb <= 2 * a + 1; ++bb) {
-                const int I = 4 * a + p;
-                if (2 * bb + q == J && I >= J && I < NT) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) LpC[(64 * a + 4 * r) * kLS] = acc[LSLOT(a, bb)][r];
-                }
-            }
-        __syncthreads();
-        LSTAMP(0);
-        // ---- b. diagonal block: lane = row (lanes >= 16 mirror rows 0..15 and write nothing)
-        if (wave == 0) {
-            int lo_ = lo;
-            asm volatile("" : "+v"(lo_));          // per-step lane predicates (lo > k): recompute them, do not hoist 16 masks out of the J loop
-            double ar[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) ar[k] = Lp[(16 * J + lo) * kLS + k];
-            double yv = s_y[16 * J + lo];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double dk = readlane_f64(ar[k], k);
-                const double invd = fast_recip(dk);
-                if (lane == 0) { s_invd[16 * J + k] = invd; if (dk == 0.0 || !isfinite(dk)) *ok = 0.0; }
-                const double yk = readlane_f64(yv, k);
-                const double lik = ar[k] * invd;                               // meaningful for rows below k
-#pragma unroll
-                for (int j = k + 1; j < 16; ++j) ar[j] = fma(-lik, readlane_f64(ar[k], j), ar[j]);   // a_ij -= l_ik (d_k l_jk)
-                if (lo_ > k) yv = fma(-lik, yk, yv);
-                ar[k] = lik;
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) Ud[J][lo * kLS + k] = k < lo_ ? ar[k] : (k == lo_ ? 1.0 : 0.0);
-                s_y[16 * J + lo] = yv;
+                for (int r = 0; r < 4; ++r) Lp[0][offC + (64 * a + 4 * r) * kLS] = acc[LSLOT(a, 0)][r];
             }
         }
-        __syncthreads();
-        LSTAMP(1);
-        // ---- c. rows below the diagonal block: w_j = a_j - sum_{m<j} w_m U[j][m], l_j = w_j / d_j
+    }
+    __syncthreads();
+    if (wave == kDiagWave) ldlt_diag16(&Lp[0][0], &Ud[0][0], s_invd, s_y, ok, lane);
+    __syncthreads();
+    for (int J = 0; J < NT; ++J) {
+        double* const Lc = Lp[J & 1];              // panel of this step
+        double* const Ln = Lp[(J & 1) ^ 1];        // panel of the next step (raw columns of block J + 1)
+        // ---- rows below the diagonal block: w_j = a_j - sum_{m<j} w_m U[j][m], l_j = w_j / d_j
         {
             const int row = 16 * (J + 1) + tid;
             if (row < n_pad) {
                 double w[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) w[j] = Lp[row * kLS + j];
+                for (int j = 0; j < 16; ++j) w[j] = Lc[row * kLS + j];
 #pragma unroll
                 for (int m = 0; m < 15; ++m) {                                  // right-looking: w_m is final, 15 - m independent updates
 #pragma unroll
@@ -755,32 +756,53 @@ __global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S,
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const double l = w[j] * s_invd[16 * J + j];
-                    Lp[row * kLS + j] = l; Wn[row * kLS + j] = -w[j];
+                    Lc[row * kLS + j] = l; Wn[row * kLS + j] = -w[j];
                     yacc = fma(-l, s_y[16 * J + j], yacc);
                 }
                 s_y[row] = yacc;
             }
         }
         __syncthreads();
-        LSTAMP(2);
-        // ---- d. finished L tiles back to registers, trailing update on the matrix cores
+        // ---- update, pass 1: tiles of block column J + 1 (ascending I, so an owned diagonal tile goes first), published at once
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int I = 4 * a + p;
             if (I <= J || I >= NT) continue;                                   // wave-uniform
+#pragma unroll
+            for (int bb = 0; bb <= 2 * a + 1; ++bb) {
+                if (2 * bb + q != J + 1) continue;
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl)
+                    acc[LSLOT(a, bb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[offA + 64 * a * kLS + 4 * sl], WnB[32 * bb * kLS + 4 * sl], acc[LSLOT(a, bb)], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ln[offC + (64 * a + 4 * r) * kLS] = acc[LSLOT(a, bb)][r];
+                if (I == J + 1) {                                              // diagonal tile of the next step: release it to wave kDiagWave
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(&s_flag, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        // ---- look-ahead: factor the next diagonal block while the other waves run pass 2
+        if (wave == kDiagWave && J + 1 < NT) {
+            while (__hip_atomic_load(&s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            ldlt_diag16(Ln + 16 * (J + 1) * kLS, &Ud[J + 1][0], s_invd + 16 * (J + 1), s_y + 16 * (J + 1), ok, lane);
+        }
+        // ---- update, pass 2: finished L tiles of column J back to registers, all other tiles
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int I = 4 * a + p;
+            if (I <= J || I >= NT) continue;
             double av[4];
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) av[sl] = LpA[64 * a * kLS + 4 * sl];
-#pragma unroll
-            for (int bb = 0; bb <= 2 * a + 1; ++bb)
-                if (2 * bb + q == J) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[LSLOT(a, bb)][r] = LpC[(64 * a + 4 * r) * kLS];
-                }
+            for (int sl = 0; sl < 4; ++sl) av[sl] = Lc[offA + 64 * a * kLS + 4 * sl];
 #pragma unroll
             for (int bb = 0; bb <= 2 * a + 1; ++bb) {
                 const int K = 2 * bb + q;
-                if (K > J && K <= I) {
+                if (K == J) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[LSLOT(a, bb)][r] = Lc[offC + (64 * a + 4 * r) * kLS];
+                } else if (K > J + 1 && K <= I) {
 #pragma unroll
                     for (int sl = 0; sl < 4; ++sl)
                         acc[LSLOT(a, bb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sl], WnB[32 * bb * kLS + 4 * sl], acc[LSLOT(a, bb)], 0, 0, 0);
@@ -789,7 +811,6 @@ __global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S,
             }
         }
         __syncthreads();
-        LSTAMP(3);
     }
     if (tid < n_pad) s_x[tid] = s_y[tid] * s_invd[tid];                       // z = D^-1 y
     __syncthreads();
@@ -811,7 +832,7 @@ __global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S,
             if (lane < 16) s_part[p][lane] = c;
         }
         __syncthreads();
-        if (wave == 0) {
+        if (wave == kDiagWave) {
             double rhs = s_x[16 * J + lo] - (((s_part[0][lo] + s_part[1][lo]) + s_part[2][lo]) + s_part[3][lo]);
             double uc[16];
 #pragma unroll
@@ -825,7 +846,6 @@ __global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S,
         }
         __syncthreads();
     }
-    LSTAMP(4);
     if (tid < n) x[tid] = s_x[tid];
 #undef LSLOT
 }
@@ -1312,16 +1332,6 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
         fprintf(stderr, "[dcs_ba] total %.3f ms: setup %.3f, optimise %.3f (build_round %.3f, waiting on GPU in trial syncs %.3f)\n", ms_since(t_call0),
                 ms_since(t_call0) - res->gpu_ms, (double)res->gpu_ms, t_build, t_sync);
     return DCS_OK;
-}
-
-void dcs_dbg_ldlt_dump()
-{
-    long long h[8];
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(dcs::g_ldlt_dbg), sizeof(h));
-    printf("ldlt cycles: publish %lld diag %lld rows %lld update %lld backsubst %lld\n", h[0], h[1], h[2], h[3], h[4]);
-    memset(h, 0, sizeof(h));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(dcs::g_ldlt_dbg), h, sizeof(h));
 }
 
 int dcs_rig_adjoint(const float T[16], int exact, double ext7[7], double adj[36])
