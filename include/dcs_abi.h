@@ -142,6 +142,13 @@ int  dcs_match_filter(int nq, const int32_t* best_idx, const int32_t* best_d, co
 
 /* fused brute-force matcher "Hamming BF + ratio test across the two camera streams": knn2 + filter.
    Angles are taken from the keypoints. */
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:270-340), batched: map point p owns the descriptors
+   pool[idx[off[p] .. off[p+1])] (the rows the reference gathers from its observations, in that order); best[p] = position
+   inside that list of the descriptor with the least median Hamming distance to the others (median = sorted[(int)(0.5 (N-1))]
+   of its row including the zero self-distance, first minimum wins), or -1 for an empty list. */
+int  dcs_distinctive_descriptors(const uint8_t* pool, int n_pool, const int32_t* off, const int32_t* idx, int n_points,
+                                 int32_t* best);
+
 int  dcs_match_bf(const uint8_t* q, const dcs_keypoint* q_kp, int nq,
                   const uint8_t* t, const dcs_keypoint* t_kp, int nt,
                   int th, float ratio, int check_ori, int32_t* match, int* n_matches);
@@ -182,9 +189,9 @@ typedef struct dcs_ba_problem {
     const double*  obs;          /* [E][2] kpUn.pt */
     const double*  inv_sigma2;   /* [E] mvInvLevelSigma2[octave] */
     const dcs_ba_camera* cams;   /* [n_cams] */
-    double  huber_delta;         /* sqrt(5.991) */
+    double  huber_delta;         /* sqrt(5.991); <= 0: no robust kernel in round 1 (BundleAdjustment with bRobust = false) */
     double  chi2_th;             /* 5.991 */
-    int32_t iters1, iters2;      /* 5, 10 */
+    int32_t iters1, iters2;      /* 5, 10; iters2 = 0: single round (BundleAdjustment, Optimizer.cc:70-248) */
 } dcs_ba_problem;
 
 typedef struct dcs_ba_result {
@@ -201,7 +208,9 @@ typedef struct dcs_ba_result {
 } dcs_ba_result;
 
 /* Optimizer::LocalBundleAdjustment numerics on a flat problem (host buffers).
-   stop_flag (may be NULL) is polled between LM iterations and trials like g2o does. */
+   stop_flag (may be NULL) is polled between LM iterations and trials like g2o does.
+   Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (Optimizer.cc:61-248) is the same edge type and solver with one
+   round: iters1 = nIterations, iters2 = 0, huber_delta = sqrt(3.99) (:107) or <= 0 when bRobust is false, only fixId fixed. */
 int  dcs_ba_local(const dcs_ba_problem* prob, const volatile uint8_t* stop_flag, dcs_ba_result* res);
 
 /* Cameras::setExtrinsics (Cameras.cc:17-37) + Converter::toSE3Quat/toMatrix6d: float 4x4 (row-major)

@@ -463,7 +463,7 @@ int orc_ba_local(const orc_ba_problem* pb, const volatile uint8_t* stop_flag, or
     };
 
     if (!(stop_flag && *stop_flag)) {                              /* Optimizer.cc:582-584 */
-        s.robust = true;
+        s.robust = pb->huber_delta > 0.0;                          /* BundleAdjustment(bRobust = false): no kernel (:137-142) */
         run(0, pb->iters1);
         bool more = !(stop_flag && *stop_flag);                    /* :589-593 */
         if (more) {

@@ -8,6 +8,7 @@
 #include "oracle.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -186,6 +187,33 @@ int orc_search_by_bow_crosscam(const uint8_t* desc_kf, const float* ang_kf, cons
         }
     }
     return nmatches;
+}
+
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:270-340) for a batch of map points: point p owns the
+   descriptors pool[idx[off[p] .. off[p+1])]. Full N x N distance table, every row sorted, median = sorted[(int)(0.5 (N-1))],
+   first row with the least median wins (:318-331). */
+void orc_distinctive_descriptors(const uint8_t* pool, const int32_t* off, const int32_t* idx, int n_points, int32_t* best)
+{
+    std::vector<int> dist, row;
+    for (int p = 0; p < n_points; ++p) {
+        const int N = off[p + 1] - off[p];
+        if (N <= 0) { best[p] = -1; continue; }
+        const int32_t* id = idx + off[p];
+        dist.assign((size_t)N * N, 0);
+        for (int i = 0; i < N; ++i)
+            for (int j = i + 1; j < N; ++j) {
+                const int d = descriptor_distance(pool + (size_t)id[i] * 32, pool + (size_t)id[j] * 32);
+                dist[(size_t)i * N + j] = d; dist[(size_t)j * N + i] = d;
+            }
+        int best_median = INT_MAX, best_idx = 0;
+        for (int i = 0; i < N; ++i) {
+            row.assign(dist.begin() + (size_t)i * N, dist.begin() + (size_t)(i + 1) * N);
+            std::sort(row.begin(), row.end());
+            const int median = row[(size_t)(0.5 * (N - 1))];
+            if (median < best_median) { best_median = median; best_idx = i; }
+        }
+        best[p] = best_idx;
+    }
 }
 
 }  // extern "C"

@@ -75,6 +75,7 @@ int  orc_distribute_octree(const orc_candidate* cand, int n, int minX, int maxX,
 int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
 /* best / second-best loop of ORBmatcher.cc:208-231 over ALL train descriptors (brute force);
    t_mask[j] != 0 skips candidate j (may be NULL). best_idx = -1 when no candidate. */
+void orc_distinctive_descriptors(const uint8_t* pool, const int32_t* off, const int32_t* idx, int n_points, int32_t* best);
 void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* t_mask,
               int32_t* best_idx, int32_t* best_d, int32_t* second_d);
 /* same, restricted to CSR buckets: group g matches queries q_idx[q_off[g]..q_off[g+1]) against

@@ -231,6 +231,14 @@ def knn2(q, t, t_mask=None):
     return bi[:nq], bd[:nq], sd[:nq]
 
 
+def distinctive_descriptors(pool, off, idx):
+    pool = _c(pool, np.uint8).reshape(-1, 32)
+    off, idx = _c(off, np.int32), _c(idx, np.int32)
+    best = np.zeros(max(len(off) - 1, 1), np.int32)
+    lib().orc_distinctive_descriptors(_p(pool), _p(off), _p(idx), len(off) - 1, _p(best))
+    return best[:len(off) - 1]
+
+
 def knn2_grouped(q, t, q_off, q_idx, t_off, t_idx):
     q, t = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
     q_off, q_idx, t_off, t_idx = (_c(a, np.int32) for a in (q_off, q_idx, t_off, t_idx))

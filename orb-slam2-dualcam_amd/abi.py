@@ -25,7 +25,7 @@ SYMBOLS = [
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
-    "dcs_match_bf_batch_device", "dcs_search_by_bow",
+    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors",
     "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
 ]
 
@@ -104,6 +104,7 @@ def lib():
             "dcs_match_bf": [vp, vp, ci, vp, vp, ci, ci, cf, ci, vp, pci],
             "dcs_match_bf_batch_device": [vp, vp, vp, ci, vp, ci, ci, cf, ci, vp, vp, vp, vp, vp],
             "dcs_search_by_bow": [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, vp, pci],
+            "dcs_distinctive_descriptors": [vp, ci, vp, vp, ci, vp],
             "dcs_ba_local": [C.POINTER(BaProblem), vp, C.POINTER(BaResult)],
             "dcs_rig_adjoint": [vp, ci, vp, vp],
             "dcs_pose_from_matrix": [vp, vp],
@@ -315,6 +316,16 @@ class ORBmatcher:
         return match[:len(desc_f)], n.value
 
 
+def ComputeDistinctiveDescriptors(pool, off, idx):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:270-340) for a batch of map points (CSR lists into a
+    descriptor pool); returns the position of the chosen descriptor inside each list (-1 for empty lists)."""
+    pool = _c(pool, np.uint8).reshape(-1, 32)
+    off, idx = _c(off, np.int32), _c(idx, np.int32)
+    best = np.zeros(max(len(off) - 1, 1), np.int32)
+    _check(lib().dcs_distinctive_descriptors(_p(pool), len(pool), _p(off), _p(idx), len(off) - 1, _p(best)), "dcs_distinctive_descriptors")
+    return best[:len(off) - 1]
+
+
 def rig_adjoint(T44_f32, exact=False):
     T = _c(T44_f32, np.float32).reshape(16)
     ext, adj = np.zeros(7), np.zeros(36)
@@ -387,6 +398,15 @@ class Optimizer:
     @staticmethod
     def prepare(prob):
         return PreparedBA(prob)
+
+    @staticmethod
+    def BundleAdjustment(prob, nIterations=5, bRobust=True, stop_flag=None):
+        """Optimizer::BundleAdjustment (Optimizer.cc:70-248): one LM round of nIterations, Huber delta sqrt(3.99) when
+        bRobust; `prob` is the flat problem with only fixId marked fixed."""
+        p = dict(prob)
+        p["iters1"], p["iters2"] = int(nIterations), 0
+        p["huber_delta"] = float(np.float32(np.sqrt(3.99))) if bRobust else 0.0     # const float thHuber2D (:107)
+        return PreparedBA(p).solve(stop_flag)
 
     @staticmethod
     def LocalBundleAdjustment(prob, stop_flag=None):

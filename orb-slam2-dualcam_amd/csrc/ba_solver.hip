@@ -1309,7 +1309,7 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     };
 
     if (!stopped()) {
-        if ((rc = run_round(0, pb->iters1, 1))) return rc;
+        if ((rc = run_round(0, pb->iters1, pb->huber_delta > 0.0 ? 1 : 0))) return rc;   // BundleAdjustment(bRobust = false): no kernel
         if (!stopped()) {
             hipLaunchKernelGGL(k_flags, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, d_chi2, pb->chi2_th, d_flag);
             DCS_CHECK_LAUNCH();

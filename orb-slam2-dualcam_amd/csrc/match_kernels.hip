@@ -364,6 +364,41 @@ __global__ void k_fill_i32(int32_t* p, int n, int32_t v)
     if (i < n) p[i] = v;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:270-340), one wave per map point. Lane i owns row i of the N x N
+// distance table (rows i, i + 64, ... for N > 64) and never stores it: its descriptor sits in VGPRs, the others are
+// broadcast loads, and the row median sorted[(int)(0.5 (N - 1))] is found by bisection on the distance value
+// (9 counting passes over the row, distances in 0..256) instead of a sort. First row with the least median wins.
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ pool, const int32_t* __restrict__ off,
+                                                    const int32_t* __restrict__ idx, int32_t* __restrict__ best)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int b0 = off[p], N = off[p + 1] - b0;
+    if (N <= 0) { if (lane == 0) best[p] = -1; return; }
+    const int32_t* id = idx + b0;
+    const int k = (int)(0.5 * (N - 1));                      // rank of the median in the sorted row (:325)
+    unsigned best_key = 0xFFFFFFFFu;                         // (median << 20) | row: minimum = least median, first row
+    for (int i = lane; i < N; i += 64) {
+        const uint4* qp = reinterpret_cast<const uint4*>(pool + (size_t)id[i] * 32);
+        const uint4 qa = qp[0], qb = qp[1];
+        const unsigned qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        int lo = 0, hi = 256;                                // smallest v with #(d_ij <= v) >= k + 1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < N; ++j) {
+                const uint4* tp = reinterpret_cast<const uint4*>(pool + (size_t)id[j] * 32);
+                const uint4 lo4 = tp[0], hi4 = tp[1];
+                cnt += (int)hamming256(qw, lo4, hi4) <= mid;
+            }
+            if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+        }
+        best_key = min(best_key, ((unsigned)lo << 20) | (unsigned)i);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best_key = min(best_key, (unsigned)__shfl_xor((int)best_key, d));
+    if (lane == 0) best[p] = (int)(best_key & 0xFFFFFu);
+}
+
 }  // namespace dcs
 
 using namespace dcs;
@@ -519,6 +554,30 @@ int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, c
     return DCS_OK;
 }
 
+
+int dcs_distinctive_descriptors(const uint8_t* pool, int n_pool, const int32_t* off, const int32_t* idx, int n_points, int32_t* best)
+{
+    if (n_points < 0 || n_pool < 0 || (n_points && (!off || !best)) || (n_points && off[n_points] > 0 && (!idx || !pool))) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_points == 0) return DCS_OK;
+    const int total = off[n_points];
+    for (int p = 0; p < n_points; ++p) {
+        if (off[p + 1] < off[p]) { set_error("offsets not ascending at point %d", p); return DCS_ERR_INVALID; }
+        if (off[p + 1] - off[p] >= (1 << 20)) { set_error("more than 2^20 observations of one map point"); return DCS_ERR_UNSUPPORTED; }
+    }
+    for (int i = 0; i < total; ++i) if (idx[i] < 0 || idx[i] >= n_pool) { set_error("descriptor index %d out of range", idx[i]); return DCS_ERR_INVALID; }
+    Scratch s;
+    uint8_t* d_pool; int32_t *d_off, *d_idx, *d_best;
+    if ((rc = s.upload(&d_pool, pool, (size_t)n_pool * 32)) || (rc = s.upload(&d_off, off, (size_t)n_points + 1)) ||
+        (rc = s.upload(&d_idx, idx, (size_t)total)) || (rc = s.alloc(&d_best, n_points))) return rc;
+    hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), 0, 0, d_pool, d_off, d_idx, d_best);
+    DCS_CHECK_LAUNCH();
+    DCS_HIP(hipMemcpy(best, d_best, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost));
+    return DCS_OK;
+}
 
 int dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_t* kf_valid, int n_kf, const uint8_t* desc_f,
                       const float* ang_f, int n_f, const int32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx,

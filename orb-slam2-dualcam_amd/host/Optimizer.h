@@ -33,14 +33,28 @@ public:
     // pbStopFlag as in the reference (:471-472, :582-593); thHuber = sqrt(5.991), chi2 gate 5.991, 5 + 10 iterations
     static void LocalBundleAdjustment(const LocalBAProblem& in, bool* pbStopFlag, LocalBAResult& out)
     {
+        solve(in, pbStopFlag, out, (double)(float)2.447651936 /* const float thHuberMono = sqrt(5.991) (:515) */, 5, 10);
+    }
+
+    // Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (src/Optimizer.cc:61-248): same dual-camera edges and solver,
+    // ONE round of nIterations, Huber delta = (float)sqrt(3.99) (:107) when bRobust, no outlier re-classification.
+    // `in.poseFixed` marks only fixId; map points without observations are left out by the caller (:184-192).
+    static void BundleAdjustment(const LocalBAProblem& in, int nIterations, bool* pbStopFlag, bool bRobust, LocalBAResult& out)
+    {
+        solve(in, pbStopFlag, out, bRobust ? (double)(float)1.9974984 : 0.0, nIterations, 0);
+    }
+
+private:
+    static void solve(const LocalBAProblem& in, bool* pbStopFlag, LocalBAResult& out, double huber, int iters1, int iters2)
+    {
         dcs_ba_problem p{};
         p.n_poses = (int)in.poseFixed.size(); p.n_points = (int)in.points.size() / 3; p.n_edges = (int)in.edgePose.size();
         p.n_cams = (int)in.cams.size();
         p.poses = in.poses.data(); p.pose_fixed = in.poseFixed.data(); p.points = in.points.data();
         p.edge_pose = in.edgePose.data(); p.edge_point = in.edgePoint.data(); p.edge_cam = in.edgeCam.data();
         p.obs = in.obs.data(); p.inv_sigma2 = in.invSigma2.data(); p.cams = in.cams.data();
-        p.huber_delta = (double)(float)2.447651936;   // const float thHuberMono = sqrt(5.991) (:515)
-        p.chi2_th = 5.991; p.iters1 = 5; p.iters2 = 10;
+        p.huber_delta = huber;
+        p.chi2_th = 5.991; p.iters1 = iters1; p.iters2 = iters2;
         out.poses.resize(in.poses.size()); out.points.resize(in.points.size()); out.edgeOutlier.resize(p.n_edges);
         dcs_ba_result r{};
         r.poses = out.poses.data(); r.points = out.points.data(); r.edge_outlier = out.edgeOutlier.data();

@@ -110,3 +110,19 @@ def test_ba_blocked_mfma_ldlt_fallback(pkg, oracle, synth, monkeypatch):
     monkeypatch.delenv("DCS_BA_FORCE_BLOCKED_LDLT")
     big = synth.ba_problem(n_poses=60, n_fixed=4, n_points=800, obs_per_point=8, seed=13)      # 55 free poses -> n = 330 > 256
     _compare(pkg.Optimizer.LocalBundleAdjustment(big), _oracle_run(oracle, big), big)
+
+
+@pytest.mark.parametrize("robust,iters", [(True, 10), (False, 5)])
+def test_global_bundle_adjustment_vs_oracle(pkg, oracle, synth, robust, iters):
+    """Optimizer::BundleAdjustment (Optimizer.cc:70-248): one round of nIterations, Huber sqrt(3.99) or no kernel,
+    only fixId fixed, no outlier re-classification between rounds."""
+    pb = synth.ba_problem(n_poses=14, n_fixed=1, n_points=220, obs_per_point=6, seed=11)
+    got = pkg.Optimizer.BundleAdjustment(pb, nIterations=iters, bRobust=robust)
+    delta = float(np.float32(np.sqrt(3.99))) if robust else 0.0
+    exp = _oracle_run(oracle, pb, iters1=iters, iters2=0, huber_delta=delta)
+    assert exp["n_iters"][1] == 0 and got["n_iters"][1] == 0 and exp["n_iters"][0] >= 2
+    assert not got["edge_level1"].any() or got["n_iters"][1] == 0
+    _compare(got, exp, pb)
+    if not robust:                              # without the kernel the trace is the plain chi2: strictly larger on outliers
+        rob = _oracle_run(oracle, pb, iters1=iters, iters2=0, huber_delta=float(np.float32(np.sqrt(3.99))))
+        assert exp["chi2_trace"][0] > rob["chi2_trace"][0]

@@ -104,3 +104,22 @@ def test_batch_device_pairs(pkg, oracle, synth):
         assert np.array_equal(d_match[p, :len(dq)].cpu().numpy(), m)
         assert np.array_equal(d_b[p, :len(dq)].cpu().numpy(), bd) and np.array_equal(d_s[p, :len(dq)].cpu().numpy(), sd)
     e.close()
+
+
+def test_distinctive_descriptors(pkg, oracle, synth):
+    """MapPoint::ComputeDistinctiveDescriptors batched: lists of 0..90 observations, shared descriptors, ties."""
+    rng = np.random.default_rng(21)
+    pool = synth.random_descriptors(600, seed=5)
+    pool[100:140] = pool[100]                   # identical rows: all-zero distances, the first must win
+    pool[140:180] = synth.noisy_copy(np.repeat(pool[140:141], 40, 0), flip_bits=6, seed=3)   # tight cluster
+    sizes = [0, 1, 2, 3, 4, 5, 8, 13, 21, 34, 64, 65, 90] + list(rng.integers(1, 30, 80))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    idx = np.concatenate([rng.choice(600, n, replace=False) for n in sizes if n] or [[]]).astype(np.int32)
+    idx[off[5]:off[6]] = np.arange(100, 105)    # the all-identical case
+    idx[off[8]:off[9]] = np.arange(140, 161)    # the clustered case
+    got = pkg.ComputeDistinctiveDescriptors(pool, off, idx)
+    exp = oracle.distinctive_descriptors(pool, off, idx)
+    assert np.array_equal(got, exp)
+    assert got[0] == -1 and got[1] == 0 and got[5] == 0
+    with pytest.raises(pkg.DcsError):
+        pkg.ComputeDistinctiveDescriptors(pool, off, idx + 1000)

@@ -116,3 +116,22 @@ def test_match_golden(oracle):
     assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_d"]) and np.array_equal(sd, g["second_d"])
     m, n = oracle.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, g["q_angle"], g["t_angle"])
     assert np.array_equal(m, g["match"]) and n == int(g["n_matches"])
+
+
+def test_distinctive_descriptors_by_definition(oracle, synth):
+    """MapPoint.cc:270-340 restated with numpy: N x N Hamming table, sorted rows, median index (int)(0.5 (N-1))."""
+    rng = np.random.default_rng(4)
+    pool = synth.random_descriptors(200, seed=9)
+    sizes = [0, 1, 2, 3, 6, 7, 20, 33]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    idx = np.concatenate([rng.choice(200, n, replace=False) for n in sizes if n]).astype(np.int32)
+    best = oracle.distinctive_descriptors(pool, off, idx)
+    bits = np.unpackbits(pool, axis=1).astype(np.int32)
+    for p, n in enumerate(sizes):
+        if n == 0:
+            assert best[p] == -1
+            continue
+        b = bits[idx[off[p]:off[p + 1]]]
+        d = (b[:, None, :] != b[None, :, :]).sum(-1)
+        med = np.sort(d, axis=1)[:, int(0.5 * (n - 1))]
+        assert best[p] == int(np.argmin(med))
