@@ -213,6 +213,33 @@ typedef struct dcs_ba_result {
    round: iters1 = nIterations, iters2 = 0, huber_delta = sqrt(3.99) (:107) or <= 0 when bRobust is false, only fixId fixed. */
 int  dcs_ba_local(const dcs_ba_problem* prob, const volatile uint8_t* stop_flag, dcs_ba_result* res);
 
+/* Optimizer::PoseOptimization (src/Optimizer.cc:250-405) for a batch of independent frames (one per stream / camera
+   rig); the whole 4-round Levenberg-Marquardt procedure of a frame runs inside one workgroup, no host round trips.
+   Frame f owns the edges edge_off[f] .. edge_off[f+1] (features with a MapPoint, ascending feature index). */
+typedef struct dcs_pose_problem {
+    int32_t n_frames, n_cams;
+    const double*  poses;        /* [F][7] pFrame->mTcw (dcs_pose_from_matrix) */
+    const int32_t* edge_off;     /* [F+1] */
+    const double*  xw;           /* [E][3] MapPoint::GetWorldPos */
+    const double*  obs;          /* [E][2] mvTotalKeysUn[i].pt */
+    const double*  inv_sigma2;   /* [E] mvInvLevelSigma2[octave] */
+    const int32_t* edge_cam;     /* [E] keypointToCam[i] */
+    const dcs_ba_camera* cams;   /* [n_cams] */
+    double  huber_delta;         /* (float)sqrt(5.991) (:284) */
+    float   chi2_th[4];          /* {5.991f x 4} (:352), compared in float like the reference (:375-377) */
+    int32_t its[4];              /* {10,10,10,10} (:354) */
+} dcs_pose_problem;
+
+typedef struct dcs_pose_result {
+    double*  poses;          /* [F][7] */
+    uint8_t* outlier;        /* [E] pFrame->mvbOutlier of the edge's feature */
+    int32_t* n_inliers;      /* [F] the reference's return value (0 when fewer than 3 correspondences: pose untouched) */
+    double*  edge_chi2;      /* [E] NULL allowed */
+    int32_t* n_iters;        /* [F][4] LM iterations per round, NULL allowed */
+} dcs_pose_result;
+
+int  dcs_pose_optimization(const dcs_pose_problem* prob, dcs_pose_result* res);
+
 /* Cameras::setExtrinsics (Cameras.cc:17-37) + Converter::toSE3Quat/toMatrix6d: float 4x4 (row-major)
    -> ext[7], adj[36]. exact = 0: reference matrix [[R, R t^],[0, R]] in float;
    exact = 1: g2o's SE3Quat::adj() [[R,0],[t^R,R]]. Pure host helper. */

@@ -488,6 +488,119 @@ int orc_ba_local(const orc_ba_problem* pb, const volatile uint8_t* stop_flag, or
     return 0;
 }
 
+/* Optimizer::PoseOptimization (Optimizer.cc:250-405). Per frame: vertex = pose, unary edges; the LM driver is the same
+   optimization_algorithm_levenberg.cpp:61-164 as in orc_ba_local with a single 6x6 block and no Schur complement
+   (BlockSolver::solve non-Schur branch, block_solver.hpp:354-372; LinearSolverDense = dense LDL^T, isPositive check). */
+int orc_pose_optimization(const orc_pose_problem* pb, orc_pose_result* res)
+{
+    std::vector<Cam> cams(pb->n_cams);
+    for (int c = 0; c < pb->n_cams; ++c) cams[c] = cam_from(pb->cams[c]);
+    for (int f = 0; f < pb->n_frames; ++f) {
+        const int e0 = pb->edge_off[f], n = pb->edge_off[f + 1] - e0;
+        const Pose init = pose_from7(pb->poses + 7 * f);
+        Pose T = init;
+        for (int k = 0; k < n; ++k) res->outlier[e0 + k] = 0;                       /* :300 */
+        if (res->n_iters) for (int r = 0; r < 4; ++r) res->n_iters[4 * f + r] = 0;
+        if (n < 3) {                                                                  /* :343-344: pose untouched, returns 0 */
+            res->n_inliers[f] = 0;
+            pose_to7(T, res->poses + 7 * f);
+            if (res->edge_chi2) for (int k = 0; k < n; ++k) res->edge_chi2[e0 + k] = 0;
+            continue;
+        }
+        std::vector<uint8_t> level(n, 0);
+        std::vector<double> err(2 * (size_t)n, 0.0);                                   /* _error of every edge */
+        bool robust = true;                                                            /* kernels removed after round 3 (:388-389) */
+        auto chi2_of = [&](int k) { const double w = pb->inv_sigma2[e0 + k]; return err[2 * k] * (w * err[2 * k]) + err[2 * k + 1] * (w * err[2 * k + 1]); };
+        auto huber = [&](double e2, double rho[3]) {
+            const double delta = pb->huber_delta, dsqr = delta * delta;
+            if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; }
+            else { const double sq = std::sqrt(e2); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e2; }
+        };
+        int nBadEdges = 0;
+        for (int it = 0; it < 4; ++it) {
+            T = init;                                                                  /* :360 */
+            std::vector<int> act;
+            for (int k = 0; k < n; ++k) if (!level[k]) act.push_back(k);              /* initializeOptimization(0) */
+            auto compute_errors = [&]() {
+                for (int k : act) { double z; edge_error(T, pb->xw + 3 * (size_t)(e0 + k), cams[pb->edge_cam[e0 + k]], pb->obs + 2 * (size_t)(e0 + k), &err[2 * k], &z); }
+            };
+            auto robust_chi2 = [&]() {
+                double chi = 0, rho[3];
+                for (int k : act) { if (robust) { huber(chi2_of(k), rho); chi += rho[0]; } else chi += chi2_of(k); }
+                return chi;
+            };
+            double lambda = -1, ni = 2;
+            int nBad = 0;
+            if (!act.empty()) {                                                        /* optimize(): no active vertex -> nothing happens */
+                for (int i = 0; i < pb->its[it]; ++i) {
+                    compute_errors();
+                    double currentChi = robust_chi2(), tempChi = currentChi;
+                    const double iniChi = currentChi;
+                    double H[36], b[6], x[6];
+                    for (double& v : H) v = 0;
+                    for (double& v : b) v = 0;
+                    for (int k : act) {                                                /* linearizeOplus + constructQuadraticForm (base_unary_edge.hpp) */
+                        double Jp[12], Jx[6];
+                        edge_jacobian(T, pb->xw + 3 * (size_t)(e0 + k), cams[pb->edge_cam[e0 + k]], Jp, Jx);
+                        double w = pb->inv_sigma2[e0 + k];
+                        double r[2] = {-w * err[2 * k], -w * err[2 * k + 1]};
+                        if (robust) { double rho[3]; huber(chi2_of(k), rho); r[0] *= rho[1]; r[1] *= rho[1]; w = rho[1] * w; }
+                        for (int a = 0; a < 6; ++a) {
+                            b[a] += Jp[a] * r[0] + Jp[6 + a] * r[1];
+                            for (int c = 0; c < 6; ++c) H[a * 6 + c] += Jp[a] * w * Jp[c] + Jp[6 + a] * w * Jp[6 + c];
+                        }
+                    }
+                    if (i == 0) {                                                      /* computeLambdaInit */
+                        double maxDiag = 0;
+                        for (int d = 0; d < 6; ++d) maxDiag = std::max(std::fabs(H[d * 7]), maxDiag);
+                        lambda = 1e-5 * maxDiag; ni = 2; nBad = 0;
+                    }
+                    double rho = 0;
+                    int qmax = 0;
+                    do {
+                        const Pose bk = T;                                             /* push */
+                        std::vector<double> A(H, H + 36);
+                        for (int d = 0; d < 6; ++d) A[d * 7] += lambda;
+                        const bool ok2 = ldlt_solve(A, 6, b, x);
+                        T = pose_mul(pose_exp(x), T);
+                        compute_errors();
+                        tempChi = robust_chi2();
+                        if (!ok2) tempChi = DBL_MAX;
+                        rho = currentChi - tempChi;
+                        double scale = 0;
+                        for (int j = 0; j < 6; ++j) scale += x[j] * (lambda * x[j] + b[j]);
+                        scale += 1e-3;
+                        rho /= scale;
+                        if (rho > 0 && std::isfinite(tempChi)) {
+                            double alpha = 1. - std::pow((2 * rho - 1), 3);
+                            alpha = std::min(alpha, 2. / 3.);
+                            lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                        } else { lambda *= ni; ni *= 2; T = bk; }                      /* pop: errors stay stale, as in g2o */
+                        ++qmax;
+                    } while (rho < 0 && qmax < 10);
+                    if (res->n_iters) ++res->n_iters[4 * f + it];
+                    if (qmax == 10 || rho == 0) break;
+                    if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
+                    if (nBad >= 3) break;
+                }
+            }
+            nBadEdges = 0;
+            for (int k = 0; k < n; ++k) {                                              /* :365-390 */
+                if (res->outlier[e0 + k]) { double z; edge_error(T, pb->xw + 3 * (size_t)(e0 + k), cams[pb->edge_cam[e0 + k]], pb->obs + 2 * (size_t)(e0 + k), &err[2 * k], &z); }
+                const float chi2 = (float)chi2_of(k);
+                if (chi2 > pb->chi2_th[it]) { res->outlier[e0 + k] = 1; level[k] = 1; ++nBadEdges; }
+                else { res->outlier[e0 + k] = 0; level[k] = 0; }
+            }
+            if (it == 2) robust = false;
+            if (n < 10) break;                                                         /* optimizer.edges().size() < 10 (:392) */
+        }
+        pose_to7(T, res->poses + 7 * f);
+        res->n_inliers[f] = n - nBadEdges;
+        if (res->edge_chi2) for (int k = 0; k < n; ++k) res->edge_chi2[e0 + k] = chi2_of(k);
+    }
+    return 0;
+}
+
 void orc_ba_edge_error(const double pose[7], const double point[3], const orc_ba_camera* cam,
                        const double obs[2], double err[2], double* depth)
 { edge_error(pose_from7(pose), point, cam_from(*cam), obs, err, depth); }

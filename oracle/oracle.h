@@ -134,6 +134,33 @@ typedef struct orc_ba_result {
 
 int orc_ba_local(const orc_ba_problem* prob, const volatile uint8_t* stop_flag, orc_ba_result* res);
 
+/* ---- Optimizer::PoseOptimization (src/Optimizer.cc:250-405) for a batch of independent frames:
+   one pose vertex per frame, unary EdgeSE3ProjectXYZOnlyPose edges (types_six_dof_expmap.cpp:200-255), dense 6x6 solve,
+   4 rounds restarting from the initial pose, re-classification of every edge after each round. */
+typedef struct orc_pose_problem {
+    int32_t n_frames, n_cams;
+    const double*  poses;        /* [F][7] pFrame->mTcw as SE3Quat */
+    const int32_t* edge_off;     /* [F+1] edges of frame f: edge_off[f] .. edge_off[f+1] (features with a MapPoint, ascending i) */
+    const double*  xw;           /* [E][3] MapPoint world position (float in the reference) */
+    const double*  obs;          /* [E][2] mvTotalKeysUn[i].pt */
+    const double*  inv_sigma2;   /* [E] mvInvLevelSigma2[octave] */
+    const int32_t* edge_cam;     /* [E] keypointToCam[i] */
+    const orc_ba_camera* cams;   /* [n_cams] */
+    double  huber_delta;         /* (float)sqrt(5.991) (:284) */
+    float   chi2_th[4];          /* {5.991f x4} (:352); compared in float (:375-377) */
+    int32_t its[4];              /* {10,10,10,10} (:354) */
+} orc_pose_problem;
+
+typedef struct orc_pose_result {
+    double*  poses;          /* [F][7] */
+    uint8_t* outlier;        /* [E] pFrame->mvbOutlier of the edge's feature */
+    int32_t* n_inliers;      /* [F] return value: nInitialCorrespondences - nBad (0 when < 3 correspondences) */
+    double*  edge_chi2;      /* [E] e->chi2() as read by the last classification (NULL allowed) */
+    int32_t* n_iters;        /* [F][4] LM iterations per round (NULL allowed) */
+} orc_pose_result;
+
+int orc_pose_optimization(const orc_pose_problem* prob, orc_pose_result* res);
+
 /* edge pieces, for unit tests (types_six_dof_expmap.cpp:109-169) */
 void orc_ba_edge_error(const double pose[7], const double point[3], const orc_ba_camera* cam,
                        const double obs[2], double err[2], double* depth);

@@ -50,6 +50,17 @@ class BaResult(C.Structure):
                 ("chi2_trace", C.c_double * 32)]
 
 
+class PoseProblem(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_cams", C.c_int32), ("poses", C.c_void_p), ("edge_off", C.c_void_p),
+                ("xw", C.c_void_p), ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("edge_cam", C.c_void_p),
+                ("cams", C.c_void_p), ("huber_delta", C.c_double), ("chi2_th", C.c_float * 4), ("its", C.c_int32 * 4)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("outlier", C.c_void_p), ("n_inliers", C.c_void_p), ("edge_chi2", C.c_void_p),
+                ("n_iters", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -314,6 +325,25 @@ def se3_oplus(pose7, update6):
     out = np.zeros(7)
     lib().orc_se3_oplus(_p(pose7), _p(update6), _p(out))
     return out
+
+
+def pose_optimization(prob):
+    """prob: dict as made by synth.pose_problem (cams = list of BaCamera)."""
+    poses = _c(prob["poses"], np.float64)
+    off, cam = _c(prob["edge_off"], np.int32), _c(prob["edge_cam"], np.int32)
+    xw, obs, w = (_c(prob[k], np.float64) for k in ("xw", "obs", "inv_sigma2"))
+    cams = (BaCamera * len(prob["cams"]))(*prob["cams"])
+    F, E = len(poses), len(cam)
+    pb = PoseProblem(F, len(prob["cams"]), _p(poses).value, _p(off).value, _p(xw).value, _p(obs).value, _p(w).value,
+                     _p(cam).value, C.cast(cams, C.c_void_p).value, float(prob["huber_delta"]),
+                     (C.c_float * 4)(*prob["chi2_th"]), (C.c_int32 * 4)(*prob["its"]))
+    out_poses, outl, ninl = np.zeros((F, 7)), np.zeros(max(E, 1), np.uint8), np.zeros(F, np.int32)
+    chi2, nit = np.zeros(max(E, 1)), np.zeros((F, 4), np.int32)
+    res = PoseResult(_p(out_poses).value, _p(outl).value, _p(ninl).value, _p(chi2).value, _p(nit).value)
+    rc = lib().orc_pose_optimization(C.byref(pb), C.byref(res))
+    if rc != 0:
+        raise RuntimeError("orc_pose_optimization rc=%d" % rc)
+    return dict(poses=out_poses, outlier=outl[:E], n_inliers=ninl, edge_chi2=chi2[:E], n_iters=nit)
 
 
 def ba_local(prob, stop_flag=None):

@@ -25,7 +25,7 @@ SYMBOLS = [
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
-    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors",
+    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization",
     "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
 ]
 
@@ -106,6 +106,7 @@ def lib():
             "dcs_search_by_bow": [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, vp, pci],
             "dcs_distinctive_descriptors": [vp, ci, vp, vp, ci, vp],
             "dcs_ba_local": [C.POINTER(BaProblem), vp, C.POINTER(BaResult)],
+            "dcs_pose_optimization": [C.POINTER(PoseProblem), C.POINTER(PoseResult)],
             "dcs_rig_adjoint": [vp, ci, vp, vp],
             "dcs_pose_from_matrix": [vp, vp],
             "dcs_pose_to_matrix": [vp, vp],
@@ -358,6 +359,17 @@ def make_camera(fx, fy, cx, cy, ext7, adj36):
     return c
 
 
+class PoseProblem(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_cams", C.c_int32), ("poses", C.c_void_p), ("edge_off", C.c_void_p),
+                ("xw", C.c_void_p), ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("edge_cam", C.c_void_p),
+                ("cams", C.c_void_p), ("huber_delta", C.c_double), ("chi2_th", C.c_float * 4), ("its", C.c_int32 * 4)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("outlier", C.c_void_p), ("n_inliers", C.c_void_p), ("edge_chi2", C.c_void_p),
+                ("n_iters", C.c_void_p)]
+
+
 class PreparedBA:
     """The flat problem marshalled once (contiguous arrays + dcs_ba_problem / dcs_ba_result structs); solve() is then a
     bare dcs_ba_local call, like the C++ caller in INTEGRATION.md section 3."""
@@ -398,6 +410,25 @@ class Optimizer:
     @staticmethod
     def prepare(prob):
         return PreparedBA(prob)
+
+    @staticmethod
+    def PoseOptimization(prob):
+        """Optimizer::PoseOptimization (Optimizer.cc:250-405) for a batch of frames (flat problem, see dcs_pose_problem)."""
+        poses = _c(prob["poses"], np.float64)
+        off, cam = _c(prob["edge_off"], np.int32), _c(prob["edge_cam"], np.int32)
+        xw, obs, w = (_c(prob[k], np.float64) for k in ("xw", "obs", "inv_sigma2"))
+        cam_list = [c if isinstance(c, BaCamera) else make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"])
+                    for c in prob["cams"]]
+        cams = (BaCamera * len(cam_list))(*cam_list)
+        F, E = len(poses), len(cam)
+        pb = PoseProblem(F, len(cam_list), _p(poses).value, _p(off).value, _p(xw).value, _p(obs).value, _p(w).value,
+                         _p(cam).value, C.cast(cams, C.c_void_p).value, float(prob["huber_delta"]),
+                         (C.c_float * 4)(*prob["chi2_th"]), (C.c_int32 * 4)(*prob["its"]))
+        out_poses, outl, ninl = np.zeros((F, 7)), np.zeros(max(E, 1), np.uint8), np.zeros(F, np.int32)
+        chi2, nit = np.zeros(max(E, 1)), np.zeros((F, 4), np.int32)
+        res = PoseResult(_p(out_poses).value, _p(outl).value, _p(ninl).value, _p(chi2).value, _p(nit).value)
+        _check(lib().dcs_pose_optimization(C.byref(pb), C.byref(res)), "dcs_pose_optimization")
+        return dict(poses=out_poses, outlier=outl[:E], n_inliers=ninl, edge_chi2=chi2[:E], n_iters=nit)
 
     @staticmethod
     def BundleAdjustment(prob, nIterations=5, bRobust=True, stop_flag=None):

@@ -966,6 +966,227 @@ __global__ void k_pad_identity(double* S, int ld, int n, int n_pad)
     if (i < n_pad) S[(size_t)i * ld + i] = 1.0;
 }
 
+// ------------------------------------------------------------------ Optimizer::PoseOptimization (Optimizer.cc:250-405)
+// One workgroup per frame runs the whole procedure on the device: 4 rounds x <= 10 LM iterations x <= 10 trials, each
+// trial = edge-parallel residuals / Jacobians (threads stride over the frame's unary edges), a fixed-order block
+// reduction of the 21 + 6 entries of the 6x6 system, a dense LDL^T by thread 0, the manifold update and the chi2 of
+// the trial -- g2o's accept / reject logic is evaluated by thread 0 and broadcast through LDS. Frames are independent,
+// so a batch (one frame per stream) fills the GPU; a single frame costs a few hundred microseconds of latency.
+struct PoseArgs {
+    const double* poses; const int32_t* edge_off; const double* xw; const double* obs; const double* w; const int32_t* cam;
+    double huber; float chi2_th[4]; int its[4];
+    double* err; uint8_t* level;                 // scratch per edge
+    double* out_poses; uint8_t* outlier; int32_t* n_inliers; double* edge_chi2; int32_t* n_iters;
+};
+
+// Jacobian of the projection w.r.t. the rig pose (EdgeSE3ProjectXYZOnlyPose::linearizeOplus, types_six_dof_expmap.cpp:218-246)
+__device__ inline void pose_jacobian(const double* T, const double* X, const DCam& c, double Jp[12])
+{
+    double pc[3];
+    cam_point(T, X, c, pc);
+    const double x = pc[0], y = pc[1], z = pc[2];
+    const double s = -1. / z;
+    const double st[6] = {s * c.fx, s * 0.0, s * (-x / z * c.fx), s * 0.0, s * c.fy, s * (-y / z * c.fy)};
+    const double J3[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+    double A[12];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) A[i * 6 + j] = st[i * 3] * J3[j] + st[i * 3 + 1] * J3[6 + j] + st[i * 3 + 2] * J3[12 + j];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) {
+        double acc = 0;
+        for (int k = 0; k < 6; ++k) acc += A[i * 6 + k] * c.adj[k * 6 + j];
+        Jp[i * 6 + j] = acc;
+    }
+}
+
+// dense LDL^T solve of a 6x6 system (LinearSolverDense; fails like isPositive() on a non-positive pivot)
+__device__ inline bool solve6(const double* H, double lambda, const double* b, double* x)
+{
+    double A[36];
+    for (int i = 0; i < 36; ++i) A[i] = H[i];
+    for (int d = 0; d < 6; ++d) A[d * 7] += lambda;
+    double dd[6];
+    for (int j = 0; j < 6; ++j) {
+        double v = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) v -= A[j * 6 + k] * A[j * 6 + k] * dd[k];
+        if (!(v > 0.0) || !isfinite(v)) return false;
+        dd[j] = v;
+        for (int i = j + 1; i < 6; ++i) {
+            double a = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) a -= A[i * 6 + k] * A[j * 6 + k] * dd[k];
+            A[i * 6 + j] = a / v;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double a = b[i]; for (int k = 0; k < i; ++k) a -= A[i * 6 + k] * y[k]; y[i] = a; }
+    for (int i = 0; i < 6; ++i) y[i] /= dd[i];
+    for (int i = 5; i >= 0; --i) { double a = y[i]; for (int k = i + 1; k < 6; ++k) a -= A[k * 6 + i] * x[k]; x[i] = a; }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
+{
+    __shared__ double s_red[4][28];
+    __shared__ double s_T[7], s_x[6], s_tot[28];
+    __shared__ int s_ctl;                                    // decision of thread 0: 0 = next trial, 1 = iteration done, 2 = round done
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e0 = a.edge_off[f], n = a.edge_off[f + 1] - e0;
+    const double* Tin = a.poses + 7 * f;
+    for (int k = tid; k < n; k += 256) { a.outlier[e0 + k] = 0; a.level[e0 + k] = 0; if (a.edge_chi2) a.edge_chi2[e0 + k] = 0; }
+    if (tid < 4 && a.n_iters) a.n_iters[4 * f + tid] = 0;
+    if (n < 3) {                                              // :343-344
+        if (tid < 7) a.out_poses[7 * f + tid] = Tin[tid];
+        if (tid == 0) a.n_inliers[f] = 0;
+        return;
+    }
+    // fixed-order block sum of NV values per thread: wave shuffles, then the 4 wave partials in order; result in s_tot
+    auto block_sum = [&](double* v, int nv) {
+        for (int i = 0; i < nv; ++i) {
+            double t = v[i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+            if (lane == 0) s_red[wave][i] = t;
+        }
+        __syncthreads();
+        if (tid < nv) s_tot[tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+        __syncthreads();
+    };
+    const double delta = a.huber, dsqr = delta * delta;
+    auto chi2_of = [&](int k) { const double w = a.w[e0 + k]; const double ex = a.err[2 * (size_t)(e0 + k)], ey = a.err[2 * (size_t)(e0 + k) + 1]; return ex * (w * ex) + ey * (w * ey); };
+    bool robust = true;
+    int n_bad_edges = 0;
+    for (int it = 0; it < 4; ++it) {
+        if (tid < 7) s_T[tid] = Tin[tid];                      // :360 every round restarts from the frame's pose
+        __syncthreads();
+        // errors of the active edges at s_T + robust chi2 -> s_tot[0]; also the number of active edges in s_tot[1]
+        auto errors_and_chi = [&]() {
+            double v[2] = {0, 0};
+            for (int k = tid; k < n; k += 256) {
+                if (a.level[e0 + k]) continue;
+                const DCam& c = cams.c[a.cam[e0 + k]];
+                double pc[3];
+                cam_point(s_T, a.xw + 3 * (size_t)(e0 + k), c, pc);
+                const double ex = a.obs[2 * (size_t)(e0 + k)] - (pc[0] / pc[2] * c.fx + c.cx);
+                const double ey = a.obs[2 * (size_t)(e0 + k) + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+                a.err[2 * (size_t)(e0 + k)] = ex; a.err[2 * (size_t)(e0 + k) + 1] = ey;
+                const double w = a.w[e0 + k], x2 = ex * (w * ex) + ey * (w * ey);
+                v[0] += (robust && x2 > dsqr) ? 2 * sqrt(x2) * delta - dsqr : x2;
+                v[1] += 1.0;
+            }
+            block_sum(v, 2);
+        };
+        // LM state lives in thread 0's registers
+        double lambda = -1, ni = 2, currentChi = 0, iniChi = 0;
+        int nBad = 0, n_it = 0;
+        bool round_done = false;
+        errors_and_chi();
+        if (s_tot[1] == 0.0) round_done = true;                // no active edge: optimize() does nothing
+        for (int i = 0; i < a.its[it] && !round_done; ++i) {
+            if (i > 0) errors_and_chi();                        // computeActiveErrors at the top of every LM iteration
+            if (tid == 0) { currentChi = s_tot[0]; iniChi = currentChi; }
+            {   // build the 6x6 system
+                double v[27];
+                for (int q = 0; q < 27; ++q) v[q] = 0;
+                for (int k = tid; k < n; k += 256) {
+                    if (a.level[e0 + k]) continue;
+                    double Jp[12];
+                    pose_jacobian(s_T, a.xw + 3 * (size_t)(e0 + k), cams.c[a.cam[e0 + k]], Jp);
+                    double w = a.w[e0 + k];
+                    const double ex = a.err[2 * (size_t)(e0 + k)], ey = a.err[2 * (size_t)(e0 + k) + 1];
+                    double r0 = -w * ex, r1 = -w * ey;
+                    if (robust) {
+                        const double x2 = ex * (w * ex) + ey * (w * ey);
+                        const double rho1 = x2 <= dsqr ? 1.0 : delta / sqrt(x2);
+                        r0 *= rho1; r1 *= rho1; w = rho1 * w;
+                    }
+                    int q = 0;
+                    for (int r = 0; r < 6; ++r) for (int c2 = r; c2 < 6; ++c2) v[q++] += Jp[r] * w * Jp[c2] + Jp[6 + r] * w * Jp[6 + c2];
+                    for (int r = 0; r < 6; ++r) v[21 + r] += Jp[r] * r0 + Jp[6 + r] * r1;
+                }
+                block_sum(v, 27);
+            }
+            double H[36], b[6];
+            if (tid == 0) {
+                int q = 0;
+                for (int r = 0; r < 6; ++r) for (int c2 = r; c2 < 6; ++c2) { H[r * 6 + c2] = s_tot[q]; H[c2 * 6 + r] = s_tot[q]; ++q; }
+                for (int r = 0; r < 6; ++r) b[r] = s_tot[21 + r];
+                if (i == 0) {                                   // computeLambdaInit
+                    double md = 0;
+                    for (int d = 0; d < 6; ++d) md = fmax(fabs(H[d * 7]), md);
+                    lambda = 1e-5 * md; ni = 2; nBad = 0;
+                }
+            }
+            double rho = 0, bk[7];
+            int qmax = 0;
+            bool ok2 = true;
+            for (;;) {                                          // trials
+                if (tid == 0) {
+                    for (int d = 0; d < 7; ++d) bk[d] = s_T[d];                          // push
+                    double x[6];
+                    ok2 = solve6(H, lambda, b, x);
+                    if (!ok2) for (int d = 0; d < 6; ++d) x[d] = 0;
+                    double o[7];
+                    pose_oplus(s_T, x, o);
+                    for (int d = 0; d < 7; ++d) s_T[d] = o[d];
+                    for (int d = 0; d < 6; ++d) s_x[d] = x[d];
+                }
+                __syncthreads();
+                errors_and_chi();
+                if (tid == 0) {
+                    double tempChi = ok2 ? s_tot[0] : 1.7976931348623157e308;
+                    rho = currentChi - tempChi;
+                    double scale = 0;
+                    for (int j = 0; j < 6; ++j) scale += s_x[j] * (lambda * s_x[j] + b[j]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    if (rho > 0 && isfinite(tempChi)) {
+                        double alpha = 1. - pow((2 * rho - 1), 3);
+                        alpha = fmin(alpha, 2. / 3.);
+                        lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                    } else {
+                        lambda *= ni; ni *= 2;
+                        for (int d = 0; d < 7; ++d) s_T[d] = bk[d];                      // pop (errors stay stale, as in g2o)
+                    }
+                    ++qmax;
+                    int ctl = (rho < 0 && qmax < 10) ? 0 : 1;
+                    if (ctl == 1) {
+                        ++n_it;
+                        if (qmax == 10 || rho == 0) ctl = 2;
+                        else { if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0; if (nBad >= 3) ctl = 2; }
+                    }
+                    s_ctl = ctl;
+                }
+                __syncthreads();
+                if (s_ctl != 0) break;
+            }
+            if (s_ctl == 2) round_done = true;
+        }
+        if (tid == 0 && a.n_iters) a.n_iters[4 * f + it] = n_it;
+        __syncthreads();
+        // classification of every edge (:365-390): previous outliers are re-evaluated at the final pose, inliers keep the
+        // error of the last evaluation
+        double cnt[1] = {0};
+        for (int k = tid; k < n; k += 256) {
+            if (a.outlier[e0 + k]) {
+                const DCam& c = cams.c[a.cam[e0 + k]];
+                double pc[3];
+                cam_point(s_T, a.xw + 3 * (size_t)(e0 + k), c, pc);
+                a.err[2 * (size_t)(e0 + k)] = a.obs[2 * (size_t)(e0 + k)] - (pc[0] / pc[2] * c.fx + c.cx);
+                a.err[2 * (size_t)(e0 + k) + 1] = a.obs[2 * (size_t)(e0 + k) + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+            }
+            const float chi2 = (float)chi2_of(k);
+            const bool bad = chi2 > a.chi2_th[it];
+            a.outlier[e0 + k] = bad; a.level[e0 + k] = bad;
+            cnt[0] += bad;
+        }
+        block_sum(cnt, 1);
+        n_bad_edges = (int)s_tot[0];
+        if (it == 2) robust = false;                           // :388-389
+        if (n < 10) break;                                     // :392
+    }
+    if (tid < 7) a.out_poses[7 * f + tid] = s_T[tid];
+    if (tid == 0) a.n_inliers[f] = n - n_bad_edges;
+    if (a.edge_chi2) for (int k = tid; k < n; k += 256) a.edge_chi2[e0 + k] = chi2_of(k);
+}
+
 }  // namespace dcs
 
 using namespace dcs;
@@ -1331,6 +1552,62 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     if (trace_t)
         fprintf(stderr, "[dcs_ba] total %.3f ms: setup %.3f, optimise %.3f (build_round %.3f, waiting on GPU in trial syncs %.3f)\n", ms_since(t_call0),
                 ms_since(t_call0) - res->gpu_ms, (double)res->gpu_ms, t_build, t_sync);
+    return DCS_OK;
+}
+
+int dcs_pose_optimization(const dcs_pose_problem* pb, dcs_pose_result* res)
+{
+    if (!pb || !res || pb->n_frames < 0 || pb->n_cams < 1 || pb->n_cams > kMaxCams || !pb->cams || (pb->n_frames && (!pb->poses || !pb->edge_off ||
+        !res->poses || !res->n_inliers))) { set_error("bad pose-optimisation problem (n_cams must be 1..%d)", kMaxCams); return DCS_ERR_INVALID; }
+    const int F = pb->n_frames;
+    if (F == 0) return DCS_OK;
+    const int E = pb->edge_off[F];
+    for (int f = 0; f < F; ++f) if (pb->edge_off[f + 1] < pb->edge_off[f]) { set_error("edge_off not ascending at frame %d", f); return DCS_ERR_INVALID; }
+    if (E && (!pb->xw || !pb->obs || !pb->inv_sigma2 || !pb->edge_cam || !res->outlier)) { set_error("null edge array"); return DCS_ERR_INVALID; }
+    for (int e = 0; e < E; ++e) if (pb->edge_cam[e] < 0 || pb->edge_cam[e] >= pb->n_cams) { set_error("edge %d: camera out of range", e); return DCS_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    DCams cams{};
+    for (int c = 0; c < pb->n_cams; ++c) {
+        DCam& d = cams.c[c];
+        const dcs_ba_camera& s = pb->cams[c];
+        d.fx = s.fx; d.fy = s.fy; d.cx = s.cx; d.cy = s.cy;
+        d.t[0] = s.ext[0]; d.t[1] = s.ext[1]; d.t[2] = s.ext[2];
+        d.q[0] = s.ext[3]; d.q[1] = s.ext[4]; d.q[2] = s.ext[5]; d.q[3] = s.ext[6];
+        memcpy(d.adj, s.adj, sizeof(d.adj));
+    }
+    Arena ar;
+    const size_t Ee = std::max(E, 1);
+    if ((rc = ar.init((size_t)F * (7 * 8 * 2 + 4 + 4 + 16) + Ee * (8 * (3 + 2 + 1 + 2 + 1) + 4 + 2) + (1 << 14)))) return rc;
+    hipStream_t st = ba_context().stream;
+    double* d_poses = ar.get<double>(7 * (size_t)F); double* d_out = ar.get<double>(7 * (size_t)F);
+    int32_t* d_off = ar.get<int32_t>(F + 1); int32_t* d_ninl = ar.get<int32_t>(F); int32_t* d_nit = ar.get<int32_t>(4 * (size_t)F);
+    double* d_xw = ar.get<double>(3 * Ee); double* d_obs = ar.get<double>(2 * Ee); double* d_w = ar.get<double>(Ee);
+    double* d_err = ar.get<double>(2 * Ee); double* d_chi = ar.get<double>(Ee);
+    int32_t* d_cam = ar.get<int32_t>(Ee); uint8_t* d_level = ar.get<uint8_t>(Ee); uint8_t* d_outl = ar.get<uint8_t>(Ee);
+    if (!d_outl) { set_error("pose arena too small"); return DCS_ERR_HIP; }
+    DCS_HIP(hipMemcpyAsync(d_poses, pb->poses, sizeof(double) * 7 * F, hipMemcpyHostToDevice, st));
+    DCS_HIP(hipMemcpyAsync(d_off, pb->edge_off, sizeof(int32_t) * (F + 1), hipMemcpyHostToDevice, st));
+    if (E) {
+        DCS_HIP(hipMemcpyAsync(d_xw, pb->xw, sizeof(double) * 3 * E, hipMemcpyHostToDevice, st));
+        DCS_HIP(hipMemcpyAsync(d_obs, pb->obs, sizeof(double) * 2 * E, hipMemcpyHostToDevice, st));
+        DCS_HIP(hipMemcpyAsync(d_w, pb->inv_sigma2, sizeof(double) * E, hipMemcpyHostToDevice, st));
+        DCS_HIP(hipMemcpyAsync(d_cam, pb->edge_cam, sizeof(int32_t) * E, hipMemcpyHostToDevice, st));
+    }
+    PoseArgs a{};
+    a.poses = d_poses; a.edge_off = d_off; a.xw = d_xw; a.obs = d_obs; a.w = d_w; a.cam = d_cam;
+    a.huber = pb->huber_delta;
+    for (int i = 0; i < 4; ++i) { a.chi2_th[i] = pb->chi2_th[i]; a.its[i] = pb->its[i]; }
+    a.err = d_err; a.level = d_level; a.out_poses = d_out; a.outlier = d_outl; a.n_inliers = d_ninl;
+    a.edge_chi2 = res->edge_chi2 ? d_chi : nullptr; a.n_iters = res->n_iters ? d_nit : nullptr;
+    hipLaunchKernelGGL(k_pose_opt, dim3(F), dim3(256), 0, st, a, cams);
+    DCS_CHECK_LAUNCH();
+    DCS_HIP(hipMemcpyAsync(res->poses, d_out, sizeof(double) * 7 * F, hipMemcpyDeviceToHost, st));
+    DCS_HIP(hipMemcpyAsync(res->n_inliers, d_ninl, sizeof(int32_t) * F, hipMemcpyDeviceToHost, st));
+    if (E) DCS_HIP(hipMemcpyAsync(res->outlier, d_outl, E, hipMemcpyDeviceToHost, st));
+    if (E && res->edge_chi2) DCS_HIP(hipMemcpyAsync(res->edge_chi2, d_chi, sizeof(double) * E, hipMemcpyDeviceToHost, st));
+    if (res->n_iters) DCS_HIP(hipMemcpyAsync(res->n_iters, d_nit, sizeof(int32_t) * 4 * F, hipMemcpyDeviceToHost, st));
+    DCS_HIP(hipStreamSynchronize(st));
     return DCS_OK;
 }
 

@@ -28,8 +28,37 @@ struct LocalBAResult {
     int iterations[2];
 };
 
+// flat input of PoseOptimization for a batch of frames (one per stream); see dcs_pose_problem
+struct PoseProblem {
+    std::vector<double> poses;        // [F][7] dcs_pose_from_matrix(pFrame->mTcw)
+    std::vector<int32_t> edgeOff;     // [F+1]
+    std::vector<double> xw, obs, invSigma2;   // [E][3] MapPoint::GetWorldPos, [E][2] mvTotalKeysUn[i].pt, [E]
+    std::vector<int32_t> edgeCam;     // [E] keypointToCam[i]
+    std::vector<dcs_ba_camera> cams;
+};
+
 class Optimizer {
 public:
+    // Optimizer::PoseOptimization (src/Optimizer.cc:250-405), batched over frames. outlier[e] = pFrame->mvbOutlier of the
+    // edge's feature; returns per frame nInitialCorrespondences - nBad (0 and an untouched pose below 3 correspondences).
+    static std::vector<int> PoseOptimization(const PoseProblem& in, std::vector<double>& posesOut, std::vector<uint8_t>& outlier)
+    {
+        dcs_pose_problem p{};
+        p.n_frames = (int)in.poses.size() / 7; p.n_cams = (int)in.cams.size();
+        p.poses = in.poses.data(); p.edge_off = in.edgeOff.data(); p.xw = in.xw.data(); p.obs = in.obs.data();
+        p.inv_sigma2 = in.invSigma2.data(); p.edge_cam = in.edgeCam.data(); p.cams = in.cams.data();
+        p.huber_delta = (double)(float)2.447651936;                       // const float deltaMono = sqrt(5.991) (:284)
+        for (int i = 0; i < 4; ++i) { p.chi2_th[i] = 5.991f; p.its[i] = 10; }   // :352, :354
+        posesOut.resize(in.poses.size()); outlier.resize(in.edgeCam.size() ? in.edgeCam.size() : 1);
+        std::vector<int> inliers(p.n_frames);
+        dcs_pose_result r{};
+        r.poses = posesOut.data(); r.outlier = outlier.data(); r.n_inliers = inliers.data();
+        const int rc = dcs_pose_optimization(&p, &r);
+        if (rc != DCS_OK) throw std::runtime_error(std::string("dcs_pose_optimization: ") + dcs_last_error());
+        outlier.resize(in.edgeCam.size());
+        return inliers;
+    }
+
     // pbStopFlag as in the reference (:471-472, :582-593); thHuber = sqrt(5.991), chi2 gate 5.991, 5 + 10 iterations
     static void LocalBundleAdjustment(const LocalBAProblem& in, bool* pbStopFlag, LocalBAResult& out)
     {

@@ -300,3 +300,26 @@ def ba_problem(n_poses=50, n_fixed=10, n_points=2000, obs_per_point=10, seed=42,
                 edge_cam=e_cam, obs=obs, inv_sigma2=inv_sigma2[octave].astype(np.float64), cams=cams,
                 huber_delta=float(np.float32(np.sqrt(5.991))), chi2_th=5.991, iters1=5, iters2=10,
                 gt_poses=gt_poses, gt_points=pts)
+
+
+def pose_problem(n_frames=16, obs_per_frame=400, seed=5, outlier_frac=0.1, point_noise=0.01):
+    """Synthetic input of Optimizer::PoseOptimization (Optimizer.cc:250-405) for a batch of frames: frame f = ground-truth
+    pose f of a ba_problem scene, observing `obs_per_frame` map points with the dual-camera rig; map points carry a
+    small error (they are float32 state of the map), observations octave-dependent noise + gross outliers, the initial
+    pose is the motion-model guess (perturbed ground truth). Frames 0/1 are degenerate on purpose (2 and 9 edges)."""
+    per_point = 6
+    n_points = max(60, n_frames * obs_per_frame // per_point + 50)
+    ba = ba_problem(n_poses=n_frames, n_fixed=0, n_points=n_points, obs_per_point=per_point, seed=seed, outlier_frac=outlier_frac)
+    rng = np.random.default_rng(seed + 1000)
+    xw_all = (ba["gt_points"] + rng.normal(0, point_noise, ba["gt_points"].shape)).astype(np.float32).astype(np.float64)
+    off, xw, obs, w, cam = [0], [], [], [], []
+    for f in range(n_frames):
+        e = np.nonzero(ba["edge_pose"] == f)[0]
+        keep = obs_per_frame if f > 1 else (2 if f == 0 else 9)
+        e = e[:keep]
+        xw.append(xw_all[ba["edge_point"][e]]); obs.append(ba["obs"][e]); w.append(ba["inv_sigma2"][e]); cam.append(ba["edge_cam"][e])
+        off.append(off[-1] + len(e))
+    return dict(poses=ba["poses"].copy(), edge_off=np.asarray(off, np.int32), xw=np.concatenate(xw), obs=np.concatenate(obs),
+                inv_sigma2=np.concatenate(w), edge_cam=np.concatenate(cam).astype(np.int32), cams=ba["cams"],
+                huber_delta=float(np.float32(np.sqrt(5.991))), chi2_th=[float(np.float32(5.991))] * 4, its=[10, 10, 10, 10],
+                gt_poses=ba["gt_poses"])

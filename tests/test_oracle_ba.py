@@ -142,3 +142,29 @@ def test_ba_stop_flag_and_degenerate(oracle, synth):
     r = _run(oracle, allfix)
     assert np.array_equal(r["poses"], pb["poses"]) and r["n_iters"][0] >= 1
     assert not np.array_equal(r["points"], pb["points"])
+
+
+def test_pose_optimization_oracle(oracle, synth):
+    """Optimizer::PoseOptimization restatement: converges to the ground-truth pose from the motion-model guess, flags the
+    gross outliers, handles the degenerate frames (< 3 edges: untouched, returns 0; < 10 edges: one round)."""
+    pb = synth.pose_problem(n_frames=6, obs_per_frame=300, seed=3)
+    prob = dict(pb)
+    prob["cams"] = [oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pb["cams"]]
+    r = oracle.pose_optimization(prob)
+    off = pb["edge_off"]
+    # frame 0: 2 correspondences -> untouched
+    assert r["n_inliers"][0] == 0 and np.array_equal(r["poses"][0], pb["poses"][0]) and not r["outlier"][off[0]:off[1]].any()
+    # frame 1: 9 edges -> exactly one round of optimisation
+    assert r["n_iters"][1][0] > 0 and (r["n_iters"][1][1:] == 0).all()
+    for f in range(2, 6):
+        err0 = np.abs(pb["poses"][f, :3] - pb["gt_poses"][f, :3]).max()
+        err1 = np.abs(r["poses"][f, :3] - pb["gt_poses"][f, :3]).max()
+        assert err1 < 0.02 and err1 < 0.5 * err0, (f, err0, err1)
+        n = off[f + 1] - off[f]
+        n_out = int(r["outlier"][off[f]:off[f + 1]].sum())
+        assert r["n_inliers"][f] == n - n_out
+        assert 0.05 * n < n_out < 0.35 * n                     # ~10 % gross outliers + the chi2 tail
+        assert (r["n_iters"][f] > 0).all()
+    # classification is the chi2 gate on the reported chi2 (float compare, Optimizer.cc:375-377)
+    e = slice(off[2], off[6])
+    assert np.array_equal(r["outlier"][e] != 0, r["edge_chi2"][e].astype(np.float32) > np.float32(5.991))
