@@ -216,4 +216,108 @@ void orc_distinctive_descriptors(const uint8_t* pool, const int32_t* off, const 
     }
 }
 
+/* Frame::GetFeaturesInArea (Frame.cc:316-376) */
+static void features_in_area(const orc_proj_frame* f, int c, float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out)
+{
+    out.clear();
+    const int nMinCellX = std::max(0, (int)std::floor((x - f->min_x[c] - r) * f->grid_w_inv[c]));
+    if (nMinCellX >= ORC_GRID_COLS) return;
+    const int nMaxCellX = std::min((int)ORC_GRID_COLS - 1, (int)std::ceil((x - f->min_x[c] + r) * f->grid_w_inv[c]));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = std::max(0, (int)std::floor((y - f->min_y[c] - r) * f->grid_h_inv[c]));
+    if (nMinCellY >= ORC_GRID_ROWS) return;
+    const int nMaxCellY = std::min((int)ORC_GRID_ROWS - 1, (int)std::ceil((y - f->min_y[c] + r) * f->grid_h_inv[c]));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    const int base = f->cam_off[c];
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+        for (int iy = nMinCellY; iy <= nMaxCellY; ++iy) {
+            const int cell = (c * ORC_GRID_COLS + ix) * ORC_GRID_ROWS + iy;
+            for (int j = f->grid_off[cell]; j < f->grid_off[cell + 1]; ++j) {
+                const int local = f->grid_idx[j], g = base + local;
+                if (bCheckLevels) {
+                    if (f->kp_octave[g] < minLevel) continue;
+                    if (maxLevel >= 0 && f->kp_octave[g] > maxLevel) continue;
+                }
+                const float distx = f->kp_x[g] - x, disty = f->kp_y[g] - y;
+                if (std::fabs(distx) < r && std::fabs(disty) < r) out.push_back(local);
+            }
+        }
+}
+
+int orc_features_in_area(const orc_proj_frame* f, int c, float x, float y, float r, int min_level, int max_level, int32_t* out, int cap)
+{
+    std::vector<int> v;
+    features_in_area(f, c, x, y, r, min_level, max_level, v);
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+void orc_search_by_projection(const orc_proj_frame* f, const orc_proj_queries* q, int th_high, float nn_ratio, int check_orientation,
+                              int32_t* match_of_query, int32_t* query_of_feature, int32_t* n_matches)
+{
+    const int N = f->cam_off[f->n_cams];
+    std::vector<uint8_t> taken(f->taken, f->taken + N);
+    for (int i = 0; i < N; ++i) query_of_feature[i] = -1;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    std::vector<int> vIndices;
+    for (int i = 0; i < q->n; ++i) {
+        match_of_query[i] = -1;
+        if (!q->valid[i]) continue;
+        const int c = q->cam[i];
+        features_in_area(f, c, q->u[i], q->v[i], q->radius[i], q->min_level[i], q->max_level[i], vIndices);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = q->desc + (size_t)i * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int local : vIndices) {
+            const int g = f->cam_off[c] + local;
+            if (taken[g]) continue;                                        /* mvpMapPoints[g] && Observations() > 0 */
+            const int dist = descriptor_distance(dMP, f->desc + (size_t)g * 32);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = f->kp_octave[g]; bestIdx = g; }
+            else if (dist < bestDist2) { bestLevel2 = f->kp_octave[g]; bestDist2 = dist; }
+        }
+        if (bestDist <= th_high) {
+            if (nn_ratio > 0 && bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;   /* :609-610 */
+            taken[bestIdx] = 1; query_of_feature[bestIdx] = i; match_of_query[i] = bestIdx;
+            ++nmatches;
+            if (check_orientation) {                                       /* :1072-1084 */
+                float rot = q->angle[i] - f->kp_angle[bestIdx];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx);
+            }
+        }
+    }
+    if (check_orientation) {                                               /* :1087-1101 */
+        int histo[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int b = 0; b < HISTO_LENGTH; ++b) histo[b] = (int)rotHist[b].size();
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; ++b)
+            if (b != ind1 && b != ind2 && b != ind3)
+                for (int g : rotHist[b]) { match_of_query[query_of_feature[g]] = -1; query_of_feature[g] = -1; --nmatches; }
+    }
+    *n_matches = nmatches;
+}
+
+int orc_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const float* kp_y, const float* min_x, const float* min_y,
+                   const float* grid_w_inv, const float* grid_h_inv, int32_t* grid_off, int32_t* grid_idx)
+{
+    const int cells = n_cams * ORC_GRID_COLS * ORC_GRID_ROWS;
+    std::vector<std::vector<int>> g((size_t)cells);
+    for (int c = 0; c < n_cams; ++c)
+        for (int i = cam_off[c]; i < cam_off[c + 1]; ++i) {
+            const int px = (int)std::nearbyint((kp_x[i] - min_x[c]) * grid_w_inv[c]);      /* cvRound (RNE) */
+            const int py = (int)std::nearbyint((kp_y[i] - min_y[c]) * grid_h_inv[c]);
+            if (px < 0 || px >= ORC_GRID_COLS || py < 0 || py >= ORC_GRID_ROWS) continue;
+            g[(size_t)(c * ORC_GRID_COLS + px) * ORC_GRID_ROWS + py].push_back(i - cam_off[c]);
+        }
+    int n = 0;
+    for (int k = 0; k < cells; ++k) { grid_off[k] = n; for (int v : g[k]) grid_idx[n++] = v; }
+    grid_off[cells] = n;
+    return n;
+}
+
 }  // extern "C"

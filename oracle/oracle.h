@@ -97,6 +97,55 @@ int  orc_search_by_bow_crosscam(const uint8_t* desc_kf, const float* ang_kf, con
                                 const int32_t* f_nodes, const int32_t* f_off, const int32_t* f_idx, int f_n_nodes,
                                 float ratio, int check_ori, int32_t* match_f);
 
+/* ---- projection-guided matching: ORBmatcher::SearchByProjection(F, local map points, th) (ORBmatcher.cc:539-624) and
+   SearchByProjectionOnCam(Fcur, cam, Flast, th) (:954-1113), on top of Frame::GetFeaturesInArea (Frame.cc:316-376).
+   The geometry that produces the window of every query (isInFrustum, Frame.cc:244-312; the motion-model projection,
+   ORBmatcher.cc:990-1027) stays with the caller. Queries are processed IN ORDER: a feature matched by an earlier query
+   is no longer available (mvpMapPoints[idx] && Observations() > 0). */
+#define ORC_GRID_COLS 64   /* FRAME_GRID_COLS (Frame.h:40) */
+#define ORC_GRID_ROWS 48   /* FRAME_GRID_ROWS (Frame.h:39) */
+typedef struct orc_proj_frame {
+    int32_t n_cams;
+    const int32_t* cam_off;      /* [n_cams+1] global index of each camera's first feature */
+    const float*   kp_x;         /* [N] mvvkeysUnTemp[c][i].pt.x in global index order */
+    const float*   kp_y;
+    const int32_t* kp_octave;
+    const float*   kp_angle;     /* read when check_orientation */
+    const uint8_t* desc;         /* [N][32] */
+    const uint8_t* taken;        /* [N] mvpMapPoints[i] && Observations() > 0 before the call */
+    const float*   min_x;        /* [n_cams] mvMinX */
+    const float*   min_y;
+    const float*   grid_w_inv;   /* [n_cams] mvfGridElementWidthInv */
+    const float*   grid_h_inv;
+    const int32_t* grid_off;     /* [n_cams*64*48 + 1] CSR over (c, ix, iy) of mvGrids[c][ix][iy] */
+    const int32_t* grid_idx;     /* camera-local feature indices in insertion order */
+} orc_proj_frame;
+
+typedef struct orc_proj_queries {
+    int32_t n;
+    const uint8_t* valid;        /* [n] passes the caller's gating (mbTrackInView && !isBad / :994-1013) */
+    const int32_t* cam;          /* [n] mTrackProjCamera / query camera */
+    const float*   u;            /* [n] mTrackProjX */
+    const float*   v;
+    const float*   radius;       /* [n] r * mvScaleFactors[level] (:565) / th * mvScaleFactors[octave] (:1036) */
+    const int32_t* min_level;    /* [n] level - 1 */
+    const int32_t* max_level;    /* [n] level + 1 */
+    const uint8_t* desc;         /* [n][32] MapPoint::GetDescriptor */
+    const float*   angle;        /* [n] last frame's keypoint angle (check_orientation) */
+} orc_proj_queries;
+
+/* nn_ratio > 0: best/second + "same level" ratio rule of SearchByProjection (:606-613); nn_ratio <= 0: best only (OnCam).
+   check_orientation: rotation histogram + three maxima of the OnCam variant (:1072-1101).
+   match_of_query[n] = global feature index or -1; query_of_feature[N] = query index or -1. */
+void orc_search_by_projection(const orc_proj_frame* f, const orc_proj_queries* q, int th_high, float nn_ratio, int check_orientation,
+                              int32_t* match_of_query, int32_t* query_of_feature, int32_t* n_matches);
+/* Frame::PosInGrid + the grid fill of the Frame constructor (Frame.cc:180-196, 380-390): CSR over (c, ix, iy); features whose
+   cell falls outside the 64 x 48 grid are left out. grid_off[n_cams*64*48+1], grid_idx[<= N]; returns the entries written. */
+int orc_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const float* kp_y, const float* min_x, const float* min_y,
+                   const float* grid_w_inv, const float* grid_h_inv, int32_t* grid_off, int32_t* grid_idx);
+/* Frame::GetFeaturesInArea (Frame.cc:316-376): camera-local indices in visiting order; returns the count */
+int orc_features_in_area(const orc_proj_frame* f, int c, float x, float y, float r, int min_level, int max_level, int32_t* out, int cap);
+
 /* ---- local BA (reference: src/Optimizer.cc:407-696 + vendored g2o) ---- */
 typedef struct orc_ba_camera {
     double fx, fy, cx, cy;

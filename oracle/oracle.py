@@ -50,6 +50,68 @@ class BaResult(C.Structure):
                 ("chi2_trace", C.c_double * 32)]
 
 
+class ProjFrame(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("cam_off", C.c_void_p), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p),
+                ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p), ("desc", C.c_void_p), ("taken", C.c_void_p),
+                ("min_x", C.c_void_p), ("min_y", C.c_void_p), ("grid_w_inv", C.c_void_p), ("grid_h_inv", C.c_void_p),
+                ("grid_off", C.c_void_p), ("grid_idx", C.c_void_p)]
+
+
+class ProjQueries(C.Structure):
+    _fields_ = [("n", C.c_int32), ("valid", C.c_void_p), ("cam", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p),
+                ("radius", C.c_void_p), ("min_level", C.c_void_p), ("max_level", C.c_void_p), ("desc", C.c_void_p),
+                ("angle", C.c_void_p)]
+
+
+def _proj_structs(frame, queries):
+    """dicts (see synth.projection_problem) -> (ProjFrame, ProjQueries, keep-alive list)"""
+    keep = []
+
+    def a(x, dt):
+        arr = _c(x, dt)
+        keep.append(arr)
+        return _p(arr).value
+    f = ProjFrame(len(frame["cam_off"]) - 1, a(frame["cam_off"], np.int32), a(frame["kp_x"], np.float32), a(frame["kp_y"], np.float32),
+                  a(frame["kp_octave"], np.int32), a(frame["kp_angle"], np.float32), a(frame["desc"], np.uint8),
+                  a(frame["taken"], np.uint8), a(frame["min_x"], np.float32), a(frame["min_y"], np.float32),
+                  a(frame["grid_w_inv"], np.float32), a(frame["grid_h_inv"], np.float32), a(frame["grid_off"], np.int32),
+                  a(frame["grid_idx"], np.int32))
+    q = ProjQueries(len(queries["cam"]), a(queries["valid"], np.uint8), a(queries["cam"], np.int32), a(queries["u"], np.float32),
+                    a(queries["v"], np.float32), a(queries["radius"], np.float32), a(queries["min_level"], np.int32),
+                    a(queries["max_level"], np.int32), a(queries["desc"], np.uint8), a(queries["angle"], np.float32))
+    return f, q, keep
+
+
+def frame_grid(cam_off, kp_x, kp_y, min_x, min_y, w_inv, h_inv):
+    cam_off = _c(cam_off, np.int32)
+    n_cams, N = len(cam_off) - 1, int(cam_off[-1])
+    kx, ky = _c(kp_x, np.float32), _c(kp_y, np.float32)
+    mx, my, wi, hi = (_c(v, np.float32) for v in (min_x, min_y, w_inv, h_inv))
+    off = np.zeros(n_cams * 64 * 48 + 1, np.int32)
+    idx = np.zeros(max(N, 1), np.int32)
+    n = lib().orc_frame_grid(n_cams, _p(cam_off), _p(kx), _p(ky), _p(mx), _p(my), _p(wi), _p(hi), _p(off), _p(idx))
+    return off, idx[:n]
+
+
+def features_in_area(frame, c, x, y, r, min_level, max_level):
+    f, _, keep = _proj_structs(frame, dict(valid=[], cam=[], u=[], v=[], radius=[], min_level=[], max_level=[], desc=np.zeros((0, 32), np.uint8), angle=[]))
+    out = np.zeros(max(int(frame["cam_off"][-1]), 1), np.int32)
+    L = lib()
+    L.orc_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = L.orc_features_in_area(C.byref(f), int(c), float(x), float(y), float(r), int(min_level), int(max_level), _p(out), len(out))
+    return out[:n]
+
+
+def search_by_projection(frame, queries, th_high=100, nn_ratio=0.8, check_orientation=False):
+    f, q, keep = _proj_structs(frame, queries)
+    N, n = int(frame["cam_off"][-1]), len(queries["cam"])
+    mq, qf, nm = np.full(max(n, 1), -1, np.int32), np.full(max(N, 1), -1, np.int32), C.c_int32()
+    L = lib()
+    L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_search_by_projection(C.byref(f), C.byref(q), int(th_high), float(nn_ratio), int(check_orientation), _p(mq), _p(qf), C.byref(nm))
+    return mq[:n], qf[:N], nm.value
+
+
 class PoseProblem(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("n_cams", C.c_int32), ("poses", C.c_void_p), ("edge_off", C.c_void_p),
                 ("xw", C.c_void_p), ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("edge_cam", C.c_void_p),

@@ -323,3 +323,55 @@ def pose_problem(n_frames=16, obs_per_frame=400, seed=5, outlier_frac=0.1, point
                 inv_sigma2=np.concatenate(w), edge_cam=np.concatenate(cam).astype(np.int32), cams=ba["cams"],
                 huber_delta=float(np.float32(np.sqrt(5.991))), chi2_th=[float(np.float32(5.991))] * 4, its=[10, 10, 10, 10],
                 gt_poses=ba["gt_poses"])
+
+
+def projection_problem(n_per_cam=900, n_queries=700, seed=13, th=1.0, big_windows=0):
+    """Synthetic input of ORBmatcher::SearchByProjection / SearchByProjectionOnCam: a dual-camera frame (keypoints with
+    octaves / angles / descriptors, some features already holding a map point) and ordered queries (map points or the
+    last frame's features) that project near features of the frame: most carry a noisy copy of their feature's
+    descriptor, several target the SAME feature (exercises the "already matched" rule), some are invalid, some are
+    distractors. `big_windows` queries get a window covering most of the image (candidate lists beyond any fixed cap).
+    The grid (CSR) is NOT included: build it with dcs_frame_grid / oracle.frame_grid."""
+    rng = np.random.default_rng(seed)
+    n_cams = 2
+    cam_off = np.array([0, n_per_cam, 2 * n_per_cam], np.int32)
+    N = int(cam_off[-1])
+    scale = np.ones(8, np.float32)
+    for i in range(1, 8):
+        scale[i] = np.float32(np.float64(scale[i - 1]) * np.float64(np.float32(1.2)))
+    kp_x = rng.uniform(-3, 643, N).astype(np.float32)            # undistortion can push keypoints slightly outside
+    kp_y = rng.uniform(-3, 483, N).astype(np.float32)
+    kp_x[rng.choice(N, 40, replace=False)] = np.float32(320.5)   # crowded columns: several features per cell, exact ties in x
+    octave = np.minimum(rng.geometric(0.35, N) - 1, 7).astype(np.int32)
+    angle = rng.uniform(0, 360, N).astype(np.float32)
+    desc = random_descriptors(N, seed=seed + 1)
+    taken = (rng.random(N) < 0.08).astype(np.uint8)
+    min_x, max_x, min_y, max_y = np.float32(-2.5), np.float32(642.0), np.float32(-1.5), np.float32(481.0)
+    frame = dict(cam_off=cam_off, kp_x=kp_x, kp_y=kp_y, kp_octave=octave, kp_angle=angle, desc=desc, taken=taken,
+                 min_x=np.full(n_cams, min_x, np.float32), min_y=np.full(n_cams, min_y, np.float32),
+                 grid_w_inv=np.full(n_cams, np.float32(64) / np.float32(max_x - min_x), np.float32),
+                 grid_h_inv=np.full(n_cams, np.float32(48) / np.float32(max_y - min_y), np.float32))
+    target = rng.integers(0, N, n_queries)
+    target[1::9] = target[0::9][:len(target[1::9])]              # duplicates right after the original
+    cam = np.searchsorted(cam_off, target, side="right").astype(np.int32) - 1
+    level = np.clip(octave[target] + rng.integers(-1, 2, n_queries), 0, 7).astype(np.int32)
+    view_cos = rng.uniform(0.99, 1.0, n_queries)
+    r = np.where(view_cos > 0.998, np.float32(2.5), np.float32(4.0)).astype(np.float32)
+    if th != 1.0:
+        r = (r * np.float32(th)).astype(np.float32)
+    radius = (r * scale[level]).astype(np.float32)
+    u = (kp_x[target] + rng.normal(0, 1.5, n_queries)).astype(np.float32)
+    v = (kp_y[target] + rng.normal(0, 1.5, n_queries)).astype(np.float32)
+    qdesc = noisy_copy(desc[target], flip_bits=18, seed=seed + 2)
+    distract = rng.random(n_queries) < 0.15
+    qdesc[distract] = random_descriptors(int(distract.sum()), seed=seed + 3)
+    valid = (rng.random(n_queries) > 0.05).astype(np.uint8)
+    qangle = ((angle[target] + rng.normal(0, 4, n_queries)) % 360).astype(np.float32)
+    flip = rng.random(n_queries) < 0.2                          # rotation-inconsistent matches for the histogram test
+    qangle[flip] = rng.uniform(0, 360, int(flip.sum())).astype(np.float32)
+    if big_windows:
+        big = rng.choice(n_queries, big_windows, replace=False)
+        radius[big] = np.float32(400.0)
+    queries = dict(valid=valid, cam=cam, u=u, v=v, radius=radius, min_level=(level - 1).astype(np.int32),
+                   max_level=(level + 1).astype(np.int32), desc=qdesc, angle=qangle)
+    return frame, queries

@@ -135,3 +135,79 @@ def test_distinctive_descriptors_by_definition(oracle, synth):
         d = (b[:, None, :] != b[None, :, :]).sum(-1)
         med = np.sort(d, axis=1)[:, int(0.5 * (n - 1))]
         assert best[p] == int(np.argmin(med))
+
+
+def _grid_np(frame):
+    """Frame::PosInGrid restated with numpy (cvRound = round half to even)."""
+    cells = {}
+    co = frame["cam_off"]
+    for c in range(len(co) - 1):
+        for i in range(co[c], co[c + 1]):
+            px = int(np.rint(np.float32(np.float32(frame["kp_x"][i] - frame["min_x"][c]) * frame["grid_w_inv"][c])))
+            py = int(np.rint(np.float32(np.float32(frame["kp_y"][i] - frame["min_y"][c]) * frame["grid_h_inv"][c])))
+            if 0 <= px < 64 and 0 <= py < 48:
+                cells.setdefault((c, px, py), []).append(i - co[c])
+    return cells
+
+
+def test_projection_search_oracle(oracle, synth):
+    """GetFeaturesInArea + SearchByProjection restatement vs an independent numpy version of the same definitions."""
+    frame, q = synth.projection_problem(n_per_cam=300, n_queries=220, seed=4)
+    off, idx = oracle.frame_grid(frame["cam_off"], frame["kp_x"], frame["kp_y"], frame["min_x"], frame["min_y"],
+                                 frame["grid_w_inv"], frame["grid_h_inv"])
+    frame["grid_off"], frame["grid_idx"] = off, idx
+    cells = _grid_np(frame)
+    for (c, px, py), lst in cells.items():
+        k = (c * 64 + px) * 48 + py
+        assert list(idx[off[k]:off[k + 1]]) == lst
+    assert off[-1] == sum(len(v) for v in cells.values()) <= frame["cam_off"][-1]
+
+    def area(c, x, y, r, lo, hi):                          # Frame.cc:316-376 in float32
+        x, y, r = np.float32(x), np.float32(y), np.float32(r)
+        f32 = np.float32
+        x0 = max(0, int(np.floor(f32(f32(f32(x - frame["min_x"][c]) - r) * frame["grid_w_inv"][c]))))
+        x1 = min(63, int(np.ceil(f32(f32(f32(x - frame["min_x"][c]) + r) * frame["grid_w_inv"][c]))))
+        y0 = max(0, int(np.floor(f32(f32(f32(y - frame["min_y"][c]) - r) * frame["grid_h_inv"][c]))))
+        y1 = min(47, int(np.ceil(f32(f32(f32(y - frame["min_y"][c]) + r) * frame["grid_h_inv"][c]))))
+        if x0 >= 64 or x1 < 0 or y0 >= 48 or y1 < 0:
+            return []
+        out = []
+        for ix in range(x0, x1 + 1):
+            for iy in range(y0, y1 + 1):
+                for loc in cells.get((c, ix, iy), []):
+                    g = frame["cam_off"][c] + loc
+                    o = frame["kp_octave"][g]
+                    if (lo > 0 or hi >= 0) and (o < lo or (hi >= 0 and o > hi)):
+                        continue
+                    if abs(f32(frame["kp_x"][g] - x)) < r and abs(f32(frame["kp_y"][g] - y)) < r:
+                        out.append(loc)
+        return out
+    bits = np.unpackbits(frame["desc"], axis=1).astype(np.int32)
+    qbits = np.unpackbits(q["desc"], axis=1).astype(np.int32)
+    taken = frame["taken"].copy()
+    exp_mq = np.full(len(q["cam"]), -1)
+    for i in range(len(q["cam"])):
+        if not q["valid"][i]:
+            continue
+        c = q["cam"][i]
+        cand = area(c, q["u"][i], q["v"][i], q["radius"][i], q["min_level"][i], q["max_level"][i])
+        assert cand == list(oracle.features_in_area(frame, c, q["u"][i], q["v"][i], q["radius"][i], q["min_level"][i], q["max_level"][i]))
+        best = [256, -1, -1]; second = [256, -1]
+        for loc in cand:
+            g = frame["cam_off"][c] + loc
+            if taken[g]:
+                continue
+            d = int((bits[g] != qbits[i]).sum())
+            if d < best[0]:
+                second = [best[0], best[1]]; best = [d, frame["kp_octave"][g], g]
+            elif d < second[0]:
+                second = [d, frame["kp_octave"][g]]
+        if best[0] <= 100 and not (best[1] == second[1] and np.float32(best[0]) > np.float32(0.8) * np.float32(second[0])):
+            taken[best[2]] = 1; exp_mq[i] = best[2]
+    mq, qf, nm = oracle.search_by_projection(frame, q, 100, 0.8, False)
+    assert np.array_equal(mq, exp_mq) and nm == int((exp_mq >= 0).sum()) and nm > 60
+    assert all(qf[g] == i for i, g in enumerate(mq) if g >= 0)
+    # the OnCam variant: no ratio test, rotation histogram keeps the three dominant bins
+    mq2, qf2, nm2 = oracle.search_by_projection(frame, q, 100, 0.0, True)
+    mq3, _, nm3 = oracle.search_by_projection(frame, q, 100, 0.0, False)
+    assert nm2 < nm3 and set(np.nonzero(mq2 >= 0)[0]) <= set(np.nonzero(mq3 >= 0)[0])
