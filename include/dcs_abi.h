@@ -142,6 +142,53 @@ int  dcs_match_filter(int nq, const int32_t* best_idx, const int32_t* best_d, co
 
 /* fused brute-force matcher "Hamming BF + ratio test across the two camera streams": knn2 + filter.
    Angles are taken from the keypoints. */
+/* ---- projection-guided matching: ORBmatcher::SearchByProjection(F, local map points, th) (ORBmatcher.cc:539-624) and
+   SearchByProjectionOnCam(Fcur, cam, Flast, th) (:954-1113) on top of Frame::GetFeaturesInArea (Frame.cc:316-376).
+   The geometry that produces every query's window (Frame::isInFrustum, Frame.cc:244-312; the motion-model projection,
+   ORBmatcher.cc:990-1027) stays with the caller. Queries are honoured IN ORDER: a feature matched by an earlier query is no
+   longer available (mvpMapPoints[idx] && Observations() > 0), exactly like the reference's sequential loop. */
+#define DCS_GRID_COLS 64   /* FRAME_GRID_COLS (Frame.h:40) */
+#define DCS_GRID_ROWS 48   /* FRAME_GRID_ROWS (Frame.h:39) */
+typedef struct dcs_proj_frame {
+    int32_t n_cams;
+    const int32_t* cam_off;      /* [n_cams+1] global index of each camera's first feature (prefix of mvN) */
+    const float*   kp_x;         /* [N] mvvkeysUnTemp[c][i].pt.x, global index order */
+    const float*   kp_y;
+    const int32_t* kp_octave;
+    const float*   kp_angle;     /* read when check_orientation */
+    const uint8_t* desc;         /* [N][32] */
+    const uint8_t* taken;        /* [N] mvpMapPoints[i] && Observations() > 0 before the call */
+    const float*   min_x;        /* [n_cams] mvMinX */
+    const float*   min_y;
+    const float*   grid_w_inv;   /* [n_cams] mvfGridElementWidthInv */
+    const float*   grid_h_inv;
+    const int32_t* grid_off;     /* [n_cams*64*48 + 1] CSR over (c, ix, iy) of mvGrids[c][ix][iy] (dcs_frame_grid) */
+    const int32_t* grid_idx;     /* camera-local feature indices in insertion order */
+} dcs_proj_frame;
+
+typedef struct dcs_proj_queries {
+    int32_t n;
+    const uint8_t* valid;        /* [n] passes the caller's gating (mbTrackInView && !isBad / ORBmatcher.cc:994-1013) */
+    const int32_t* cam;          /* [n] mTrackProjCamera / the query camera */
+    const float*   u;            /* [n] mTrackProjX */
+    const float*   v;
+    const float*   radius;       /* [n] r * mvScaleFactors[level] (:565) / th * mvScaleFactors[octave] (:1036) */
+    const int32_t* min_level;    /* [n] level - 1 */
+    const int32_t* max_level;    /* [n] level + 1 */
+    const uint8_t* desc;         /* [n][32] MapPoint::GetDescriptor */
+    const float*   angle;        /* [n] the last frame's keypoint angle (check_orientation) */
+} dcs_proj_queries;
+
+/* Frame::PosInGrid + grid fill (Frame.cc:180-196, 380-390) as CSR; pure host helper. grid_off[n_cams*64*48+1],
+   grid_idx[N]; *n_entries = features that fell inside the grid. */
+int  dcs_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const float* kp_y, const float* min_x, const float* min_y,
+                    const float* grid_w_inv, const float* grid_h_inv, int32_t* grid_off, int32_t* grid_idx, int* n_entries);
+/* nn_ratio > 0: best / second + the "same level" ratio rule of SearchByProjection (:606-613), TH_HIGH = th_high;
+   nn_ratio <= 0: best only (SearchByProjectionOnCam). check_orientation: rotation histogram + three maxima (:1072-1101).
+   match_of_query[n] = global feature index or -1; query_of_feature[N] = query index or -1. */
+int  dcs_search_by_projection(const dcs_proj_frame* frame, const dcs_proj_queries* queries, int th_high, float nn_ratio,
+                              int check_orientation, int32_t* match_of_query, int32_t* query_of_feature, int* n_matches);
+
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:270-340), batched: map point p owns the descriptors
    pool[idx[off[p] .. off[p+1])] (the rows the reference gathers from its observations, in that order); best[p] = position
    inside that list of the descriptor with the least median Hamming distance to the others (median = sorted[(int)(0.5 (N-1))]

@@ -25,7 +25,7 @@ SYMBOLS = [
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
-    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization",
+    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
     "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
 ]
 
@@ -107,6 +107,8 @@ def lib():
             "dcs_distinctive_descriptors": [vp, ci, vp, vp, ci, vp],
             "dcs_ba_local": [C.POINTER(BaProblem), vp, C.POINTER(BaResult)],
             "dcs_pose_optimization": [C.POINTER(PoseProblem), C.POINTER(PoseResult)],
+            "dcs_frame_grid": [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, pci],
+            "dcs_search_by_projection": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, cf, ci, vp, vp, pci],
             "dcs_rig_adjoint": [vp, ci, vp, vp],
             "dcs_pose_from_matrix": [vp, vp],
             "dcs_pose_to_matrix": [vp, vp],
@@ -303,6 +305,30 @@ class ORBmatcher:
                                                d_n_matches.data_ptr(), d_best.data_ptr(), d_second.data_ptr(), stream),
                "dcs_match_bf_batch_device")
 
+    def SearchByProjection(self, frame, queries, th_high=100, use_ratio=True, check_orientation=False):
+        """ORBmatcher::SearchByProjection(F, map points, th) (ORBmatcher.cc:539-624; use_ratio) or
+        SearchByProjectionOnCam (:954-1113; use_ratio=False, check_orientation=mbCheckOrientation) on flat inputs
+        (dicts laid out like dcs_proj_frame / dcs_proj_queries). Returns (match_of_query, query_of_feature, n)."""
+        keep = []
+
+        def a(x, dt):
+            arr = _c(x, dt)
+            keep.append(arr)
+            return _p(arr).value
+        f = ProjFrame(len(frame["cam_off"]) - 1, a(frame["cam_off"], np.int32), a(frame["kp_x"], np.float32), a(frame["kp_y"], np.float32),
+                      a(frame["kp_octave"], np.int32), a(frame["kp_angle"], np.float32), a(frame["desc"], np.uint8),
+                      a(frame["taken"], np.uint8), a(frame["min_x"], np.float32), a(frame["min_y"], np.float32),
+                      a(frame["grid_w_inv"], np.float32), a(frame["grid_h_inv"], np.float32), a(frame["grid_off"], np.int32),
+                      a(frame["grid_idx"], np.int32))
+        q = ProjQueries(len(queries["cam"]), a(queries["valid"], np.uint8), a(queries["cam"], np.int32), a(queries["u"], np.float32),
+                        a(queries["v"], np.float32), a(queries["radius"], np.float32), a(queries["min_level"], np.int32),
+                        a(queries["max_level"], np.int32), a(queries["desc"], np.uint8), a(queries["angle"], np.float32))
+        N, n = int(frame["cam_off"][-1]), len(queries["cam"])
+        mq, qf, nm = np.full(max(n, 1), -1, np.int32), np.full(max(N, 1), -1, np.int32), C.c_int()
+        _check(lib().dcs_search_by_projection(C.byref(f), C.byref(q), int(th_high), float(self.mfNNratio) if use_ratio else 0.0,
+                                              int(check_orientation), _p(mq), _p(qf), C.byref(nm)), "dcs_search_by_projection")
+        return mq[:n], qf[:N], nm.value
+
     def SearchByBoWCrossCam(self, desc_kf, ang_kf, kf_valid, desc_f, ang_f, kf_fv, f_fv):
         """SearchByBoWCrossCam(F,cF,KF,cKF) (ORBmatcher.cc:162-294) on flat inputs; returns (match_f, n)."""
         desc_kf, desc_f = _c(desc_kf, np.uint8).reshape(-1, 32), _c(desc_f, np.uint8).reshape(-1, 32)
@@ -315,6 +341,18 @@ class ORBmatcher:
                                        _p(kn), _p(ko), _p(ki), len(kn), _p(fn), _p(fo), _p(fi), len(fn),
                                        self.mfNNratio, int(self.mbCheckOrientation), _p(match), C.byref(n)), "dcs_search_by_bow")
         return match[:len(desc_f)], n.value
+
+
+def frame_grid(cam_off, kp_x, kp_y, min_x, min_y, w_inv, h_inv):
+    """Frame::PosInGrid + grid fill (Frame.cc:180-196, 380-390) as CSR (grid_off, grid_idx)."""
+    cam_off = _c(cam_off, np.int32)
+    n_cams, N = len(cam_off) - 1, int(cam_off[-1])
+    kx, ky = _c(kp_x, np.float32), _c(kp_y, np.float32)
+    mx, my, wi, hi = (_c(v, np.float32) for v in (min_x, min_y, w_inv, h_inv))
+    off, idx, n = np.zeros(n_cams * 64 * 48 + 1, np.int32), np.zeros(max(N, 1), np.int32), C.c_int()
+    _check(lib().dcs_frame_grid(n_cams, _p(cam_off), _p(kx), _p(ky), _p(mx), _p(my), _p(wi), _p(hi), _p(off), _p(idx), C.byref(n)),
+           "dcs_frame_grid")
+    return off, idx[:n.value]
 
 
 def ComputeDistinctiveDescriptors(pool, off, idx):
@@ -357,6 +395,19 @@ def make_camera(fx, fy, cx, cy, ext7, adj36):
     for i in range(36):
         c.adj[i] = float(a[i])
     return c
+
+
+class ProjFrame(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("cam_off", C.c_void_p), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p),
+                ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p), ("desc", C.c_void_p), ("taken", C.c_void_p),
+                ("min_x", C.c_void_p), ("min_y", C.c_void_p), ("grid_w_inv", C.c_void_p), ("grid_h_inv", C.c_void_p),
+                ("grid_off", C.c_void_p), ("grid_idx", C.c_void_p)]
+
+
+class ProjQueries(C.Structure):
+    _fields_ = [("n", C.c_int32), ("valid", C.c_void_p), ("cam", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p),
+                ("radius", C.c_void_p), ("min_level", C.c_void_p), ("max_level", C.c_void_p), ("desc", C.c_void_p),
+                ("angle", C.c_void_p)]
 
 
 class PoseProblem(C.Structure):

@@ -1,0 +1,521 @@
+// proj_kernels.hip -- projection-guided matching on gfx950: ORBmatcher::SearchByProjection (src/ORBmatcher.cc:539-624),
+// SearchByProjectionOnCam (:954-1113) and Frame::GetFeaturesInArea (src/Frame.cc:316-376).
+//
+// The reference walks the queries (map points) one after the other; a feature matched by an earlier query is skipped by
+// the later ones, so the result depends on the order. Two kernels keep that semantics and still do the heavy part in
+// parallel:
+//   k_proj_collect  one wave per query: visits the grid cells of the window in the reference's (ix, iy, j) order, applies
+//                   the octave and |dx|,|dy| < r tests, drops features that were taken BEFORE the call, computes the
+//                   Hamming distance of the survivors (64 candidates per round, one per lane) and appends
+//                   (distance, octave, feature) words to the query's candidate list with an ordered ballot compaction
+//   k_proj_resolve  one wave per call: walks the queries in order; a query's candidates sit one per lane, the lanes whose
+//                   feature has been taken meanwhile (LDS byte map) drop out, best / second are the two smallest
+//                   (distance, position) keys of the wave -- the first two elements of a stable sort by distance, which
+//                   is what the reference's strict "<" updates produce -- then the TH_HIGH / same-level ratio rules,
+//                   the rotation histogram and ComputeThreeMaxima.
+// Candidate lists hold up to kProjCap entries; a query with a wider window (relocalisation-sized radii) is re-walked
+// inside the resolver with the same visiting code (correct, slower).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+
+namespace dcs {
+namespace {
+
+constexpr int kProjCap = 64;                    // candidates kept per query (one per lane of the resolver)
+constexpr int kHisto = 30;                      // HISTO_LENGTH (ORBmatcher.cc:59)
+
+struct ProjFrameD {
+    int n_cams, N;
+    const int32_t* cam_off; const float *kp_x, *kp_y; const int32_t* kp_octave; const float* kp_angle;
+    const uint8_t *desc, *taken; const float *min_x, *min_y, *w_inv, *h_inv; const int32_t *grid_off, *grid_idx;
+};
+struct ProjQueriesD {
+    int n;
+    const uint8_t* valid; const int32_t* cam; const float *u, *v, *radius; const int32_t *min_level, *max_level;
+    const uint8_t* desc; const float* angle;
+};
+
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc)
+{
+    unsigned r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+// Visits the window of query qi exactly like Frame::GetFeaturesInArea (Frame.cc:316-376) + the candidate loop of
+// ORBmatcher.cc:581-603: cells ix (outer), iy (inner), entries in insertion order, 64 entries per round (lane = entry).
+// For every round calls emit(pass, word, pos0): pass = this lane holds a candidate, word = packed (dist << 23 |
+// octave << 19 | camera-local index), pos0 = candidates emitted before this round. `taken` is the byte map to honour.
+// how the "already matched" byte of a feature is read: plain loads for a map nobody writes (k_proj_collect) or that lives
+// in LDS, device-coherent loads for the resolver's working copy in HBM (the L1 of the CU may hold a stale line)
+struct TakenPlain { const uint8_t* p; __device__ bool operator()(int g) const { return p[g] != 0; } };
+struct TakenCoherent {
+    const uint8_t* p;
+    __device__ bool operator()(int g) const { return __hip_atomic_load(p + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
+};
+
+template <typename Taken, typename Emit>
+__device__ __forceinline__ int proj_visit(const ProjFrameD& f, const ProjQueriesD& q, int qi, Taken taken, Emit emit)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = q.cam[qi];
+    const float x = q.u[qi], y = q.v[qi], r = q.radius[qi];
+    const int minLevel = q.min_level[qi], maxLevel = q.max_level[qi];
+    const float mx = f.min_x[c], my = f.min_y[c], wi = f.w_inv[c], hi = f.h_inv[c];
+    const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, mx), r), wi)));
+    if (x0 >= DCS_GRID_COLS) return 0;
+    const int x1 = min(DCS_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, mx), r), wi)));
+    if (x1 < 0) return 0;
+    const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, my), r), hi)));
+    if (y0 >= DCS_GRID_ROWS) return 0;
+    const int y1 = min(DCS_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, my), r), hi)));
+    if (y1 < 0) return 0;
+    const bool check_levels = (minLevel > 0) || (maxLevel >= 0);
+    const int base = f.cam_off[c];
+    const uint4* qp = reinterpret_cast<const uint4*>(q.desc + (size_t)qi * 32);
+    const uint4 qa = qp[0], qb = qp[1];
+    int count = 0;
+    for (int ix = x0; ix <= x1; ++ix) {
+        // the cells (ix, y0..y1) are adjacent in the CSR: one contiguous run of entries, already in (iy, j) order
+        const int cell0 = (c * DCS_GRID_COLS + ix) * DCS_GRID_ROWS + y0;
+        const int j0 = f.grid_off[cell0], j1 = f.grid_off[cell0 + (y1 - y0) + 1];
+        for (int jb = j0; jb < j1; jb += 64) {
+            const int j = jb + lane;
+            bool pass = false;
+            unsigned word = 0;
+            if (j < j1) {
+                const int local = f.grid_idx[j], g = base + local;
+                const int oct = f.kp_octave[g];
+                bool ok = true;
+                if (check_levels) ok = !(oct < minLevel) && !(maxLevel >= 0 && oct > maxLevel);
+                const float dx = __fsub_rn(f.kp_x[g], x), dy = __fsub_rn(f.kp_y[g], y);
+                ok = ok && fabsf(dx) < r && fabsf(dy) < r && !taken(g);
+                if (ok) {
+                    const uint4* tp = reinterpret_cast<const uint4*>(f.desc + (size_t)g * 32);
+                    const uint4 ta = tp[0], tb = tp[1];
+                    unsigned d = bcnt_acc(qa.x ^ ta.x, 0u);
+                    d = bcnt_acc(qa.y ^ ta.y, d); d = bcnt_acc(qa.z ^ ta.z, d); d = bcnt_acc(qa.w ^ ta.w, d);
+                    d = bcnt_acc(qb.x ^ tb.x, d); d = bcnt_acc(qb.y ^ tb.y, d); d = bcnt_acc(qb.z ^ tb.z, d); d = bcnt_acc(qb.w ^ tb.w, d);
+                    pass = true;
+                    word = (d << 23) | ((unsigned)oct << 19) | (unsigned)local;
+                }
+            }
+            const unsigned long long m = __ballot(pass);
+            emit(pass, word, count + __popcll(m & ((1ull << lane) - 1ull)));
+            count += __popcll(m);
+        }
+    }
+    return count;
+}
+
+__global__ __launch_bounds__(256) void k_proj_collect(ProjFrameD f, ProjQueriesD q, unsigned* __restrict__ cand, int32_t* __restrict__ cand_n)
+{
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= q.n) return;
+    if (!q.valid[qi]) { if ((threadIdx.x & 63) == 0) cand_n[qi] = 0; return; }
+    unsigned* out = cand + (size_t)qi * kProjCap;
+    const int n = proj_visit(f, q, qi, TakenPlain{f.taken}, [&](bool pass, unsigned word, int pos) { if (pass && pos < kProjCap) out[pos] = word; });
+    if ((threadIdx.x & 63) == 0) cand_n[qi] = n;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, d));
+    return v;
+}
+
+// one wave, queries in order. The live "taken" map sits in LDS when the frame has <= 64 K features (always, in practice);
+// otherwise in HBM with device-coherent accesses.
+template <bool LDS_MAP>
+__global__ __launch_bounds__(64) void k_proj_resolve(ProjFrameD f, ProjQueriesD q, const unsigned* __restrict__ cand,
+                                                    const int32_t* __restrict__ cand_n, uint8_t* __restrict__ taken_hbm /* [N] working copy */,
+                                                    int th_high, float nn_ratio, int check_ori, int32_t* __restrict__ match_of_query,
+                                                    int32_t* __restrict__ query_of_feature, int32_t* __restrict__ bin_of_query,
+                                                    int32_t* __restrict__ n_matches)
+{
+    __shared__ int s_hist[kHisto];
+    __shared__ int s_ind[3];
+    extern __shared__ uint8_t s_taken[];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < f.N; i += 64) { query_of_feature[i] = -1; if (LDS_MAP) s_taken[i] = f.taken[i]; }
+    if (lane < kHisto) s_hist[lane] = 0;
+    __syncthreads();
+    uint8_t* const taken = LDS_MAP ? s_taken : taken_hbm;
+    auto is_taken = [&](int g) -> bool {
+        if (LDS_MAP) return taken[g] != 0;
+        return __hip_atomic_load(taken + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    };
+    int nmatches = 0;
+    for (int qi = 0; qi < q.n; ++qi) {
+        int n = cand_n[qi];                                   // wave-uniform
+        unsigned best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;    // (dist << 23 | octave << 19 | local) of the two winners
+        if (n > 0 && n <= kProjCap) {
+            unsigned w = 0, key = 0xFFFFFFFFu;
+            if (lane < n) {
+                w = cand[(size_t)qi * kProjCap + lane];
+                const int g = f.cam_off[q.cam[qi]] + (int)(w & 0x7FFFFu);
+                if (!is_taken(g)) key = ((w >> 23) << 8) | (unsigned)lane;         // distance, then visiting order
+            }
+            const unsigned k1 = wave_min_u32(key);
+            if (k1 != 0xFFFFFFFFu) {
+                const unsigned k2 = wave_min_u32(key == k1 ? 0xFFFFFFFFu : key);
+                best = (unsigned)__builtin_amdgcn_readlane((int)w, (int)(k1 & 63u));
+                if (k2 != 0xFFFFFFFFu) second = (unsigned)__builtin_amdgcn_readlane((int)w, (int)(k2 & 63u));
+            }
+        } else if (n > kProjCap) {                           // window wider than the list: walk it again, honouring the live map
+            unsigned long long b1 = ~0ull, b2 = ~0ull;       // (dist << 40 | position << 8... ) keys: dist, then visiting position
+            unsigned w1 = 0, w2 = 0;
+            auto track = [&](bool pass, unsigned word, int pos) {
+                const unsigned long long key = pass ? (((unsigned long long)(word >> 23) << 32) | (unsigned)pos) : ~0ull;
+                if (key < b1) { b2 = b1; w2 = w1; b1 = key; w1 = word; }
+                else if (key < b2) { b2 = key; w2 = word; }
+            };
+            if (LDS_MAP) (void)proj_visit(f, q, qi, TakenPlain{taken}, track);
+            else (void)proj_visit(f, q, qi, TakenCoherent{taken}, track);
+            // merge the per-lane (best, second) pairs: two smallest keys of the wave
+            unsigned long long m1 = b1;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m1, d); m1 = o < m1 ? o : m1; }
+            unsigned long long c2 = (b1 == m1) ? b2 : b1, m2 = c2;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m2, d); m2 = o < m2 ? o : m2; }
+            if (m1 != ~0ull) {
+                const unsigned long long has1 = __ballot(b1 == m1);
+                best = (unsigned)__builtin_amdgcn_readlane((int)w1, __ffsll((long long)has1) - 1);
+                if (m2 != ~0ull) {
+                    const unsigned mine = (b1 == m2) ? w1 : w2;
+                    const unsigned long long has2 = __ballot(b1 == m2 || b2 == m2);
+                    second = (unsigned)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)has2) - 1);
+                }
+            }
+        }
+        int matched = -1;
+        if (best != 0xFFFFFFFFu) {
+            const int bestDist = (int)(best >> 23), bestLevel = (int)((best >> 19) & 15u);
+            const int bestDist2 = second != 0xFFFFFFFFu ? (int)(second >> 23) : 256;
+            const int bestLevel2 = second != 0xFFFFFFFFu ? (int)((second >> 19) & 15u) : -1;
+            if (bestDist <= th_high &&
+                !(nn_ratio > 0.f && bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nn_ratio, (float)bestDist2)))
+                matched = f.cam_off[q.cam[qi]] + (int)(best & 0x7FFFFu);
+        }
+        if (lane == 0) {
+            match_of_query[qi] = matched;
+            if (matched >= 0) {
+                if (LDS_MAP) taken[matched] = 1; else __hip_atomic_store(taken + matched, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                query_of_feature[matched] = qi;
+                if (check_ori) {                              // :1072-1084
+                    float rot = __fsub_rn(q.angle[qi], f.kp_angle[matched]);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, 1.0f / kHisto));
+                    if (bin == kHisto) bin = 0;
+                    bin_of_query[qi] = bin;
+                    ++s_hist[bin];
+                }
+            }
+        }
+        nmatches += matched >= 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the taken byte must be visible to the next query's lanes
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+    }
+    if (check_ori) {
+        __syncthreads();
+        if (lane == 0) {                                      // ComputeThreeMaxima (:1969-2010)
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < kHisto; ++i) {
+                const int s = s_hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+            s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int qi = lane; qi < q.n; qi += 64) {
+            const int g = match_of_query[qi];
+            if (g < 0) continue;
+            const int b = bin_of_query[qi];
+            if (b != s_ind[0] && b != s_ind[1] && b != s_ind[2]) { match_of_query[qi] = -1; query_of_feature[g] = -1; ++removed; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
+        nmatches -= removed;
+    }
+    if (lane == 0) *n_matches = nmatches;
+}
+
+// Parallel resolver with the same order-dependent result: thread = query, rounds until every query is final.
+// A query may only be decided once no EARLIER undecided query can still take one of its live candidates: per round every
+// undecided query posts its index with atomicMin on the features of its list (minq), and the queries that own all of their
+// live candidates (minq == own index) are decided together -- they cannot influence each other, and the earliest undecided
+// query always qualifies, so the rounds terminate. Windows of different map points rarely overlap, so a frame takes a
+// handful of rounds instead of one step per query. A query whose window overflowed its list is decided alone by wave 0
+// (re-walk of the window) when it becomes the earliest undecided one, and blocks the later ones until then.
+constexpr int kResT = 1024;
+constexpr int kResMaxN = 16384;                 // features whose minq / taken maps fit in LDS (80 KB)
+
+__global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f, ProjQueriesD q, const unsigned* __restrict__ cand,
+                                                           const int32_t* __restrict__ cand_n, uint8_t* __restrict__ state /* [n] 0 = undecided */,
+                                                           int th_high, float nn_ratio, int check_ori, int32_t* __restrict__ match_of_query,
+                                                           int32_t* __restrict__ query_of_feature, int32_t* __restrict__ bin_of_query,
+                                                           int32_t* __restrict__ n_matches)
+{
+    __shared__ int s_minq[kResMaxN];
+    __shared__ uint8_t s_taken[kResMaxN];
+    __shared__ int s_hist[kHisto], s_ind[3];
+    __shared__ int s_first, s_firstovf, s_undecided, s_nm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < f.N; i += kResT) { s_taken[i] = f.taken[i]; query_of_feature[i] = -1; }
+    for (int i = tid; i < q.n; i += kResT) { match_of_query[i] = -1; state[i] = cand_n[i] == 0; }   // empty window / invalid: decided
+    if (tid < kHisto) s_hist[tid] = 0;
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+    auto decide = [&](int qi, unsigned best, unsigned second) {      // ORBmatcher.cc:606-613 / :1066-1084
+        int matched = -1;
+        if (best != 0xFFFFFFFFu) {
+            const int bestDist = (int)(best >> 23), bestLevel = (int)((best >> 19) & 15u);
+            const int bestDist2 = second != 0xFFFFFFFFu ? (int)(second >> 23) : 256;
+            const int bestLevel2 = second != 0xFFFFFFFFu ? (int)((second >> 19) & 15u) : -1;
+            if (bestDist <= th_high &&
+                !(nn_ratio > 0.f && bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nn_ratio, (float)bestDist2)))
+                matched = f.cam_off[q.cam[qi]] + (int)(best & 0x7FFFFu);
+        }
+        match_of_query[qi] = matched;
+        if (matched >= 0) {
+            s_taken[matched] = 1; query_of_feature[matched] = qi;
+            atomicAdd(&s_nm, 1);
+            if (check_ori) {
+                float rot = __fsub_rn(q.angle[qi], f.kp_angle[matched]);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, 1.0f / kHisto));
+                if (bin == kHisto) bin = 0;
+                bin_of_query[qi] = bin;
+                atomicAdd(&s_hist[bin], 1);
+            }
+        }
+    };
+    for (;;) {
+        for (int i = tid; i < f.N; i += kResT) s_minq[i] = 0x7FFFFFFF;
+        if (tid == 0) { s_first = 0x7FFFFFFF; s_firstovf = 0x7FFFFFFF; s_undecided = 0; }
+        __syncthreads();
+        for (int qi = tid; qi < q.n; qi += kResT) {
+            if (state[qi]) continue;
+            atomicMin(&s_first, qi);
+            const int n = cand_n[qi];
+            if (n > kProjCap) { atomicMin(&s_firstovf, qi); continue; }
+            const int base = f.cam_off[q.cam[qi]];
+            for (int k = 0; k < n; ++k) {
+                const int g = base + (int)(cand[(size_t)qi * kProjCap + k] & 0x7FFFFu);
+                if (!s_taken[g]) atomicMin(&s_minq[g], qi);
+            }
+        }
+        __syncthreads();
+        if (s_first == 0x7FFFFFFF) break;                      // everything decided
+        const int first_ovf = s_firstovf;
+        for (int qi = tid; qi < q.n; qi += kResT) {
+            if (state[qi]) continue;
+            const int n = cand_n[qi];
+            if (n > kProjCap || qi > first_ovf) continue;
+            const int base = f.cam_off[q.cam[qi]];
+            bool safe = true;
+            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, w1 = 0, w2 = 0;        // two smallest (dist, position) keys
+            for (int k = 0; k < n; ++k) {
+                const unsigned w = cand[(size_t)qi * kProjCap + k];
+                const int g = base + (int)(w & 0x7FFFFu);
+                if (s_taken[g]) continue;                       // taken in an earlier round (this round's takers never share a live candidate)
+                if (s_minq[g] != qi) { safe = false; break; }
+                const unsigned key = ((w >> 23) << 8) | (unsigned)k;
+                if (key < k1) { k2 = k1; w2 = w1; k1 = key; w1 = w; }
+                else if (key < k2) { k2 = key; w2 = w; }
+            }
+            if (!safe) continue;
+            decide(qi, k1 != 0xFFFFFFFFu ? w1 : 0xFFFFFFFFu, k2 != 0xFFFFFFFFu ? w2 : 0xFFFFFFFFu);
+            state[qi] = 1;
+        }
+        __syncthreads();
+        if (first_ovf == s_first) {                             // the earliest undecided query has an oversized window: wave 0 walks it
+            if (tid < 64) {
+                const int qi = first_ovf;
+                unsigned long long b1 = ~0ull, b2 = ~0ull;
+                unsigned w1 = 0, w2 = 0;
+                (void)proj_visit(f, q, qi, TakenPlain{s_taken}, [&](bool pass, unsigned word, int pos) {
+                    const unsigned long long key = pass ? (((unsigned long long)(word >> 23) << 32) | (unsigned)pos) : ~0ull;
+                    if (key < b1) { b2 = b1; w2 = w1; b1 = key; w1 = word; }
+                    else if (key < b2) { b2 = key; w2 = word; }
+                });
+                unsigned long long m1 = b1;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m1, d); m1 = o < m1 ? o : m1; }
+                const unsigned long long c2 = (b1 == m1) ? b2 : b1;
+                unsigned long long m2 = c2;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m2, d); m2 = o < m2 ? o : m2; }
+                unsigned best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+                if (m1 != ~0ull) {
+                    const unsigned long long has1 = __ballot(b1 == m1);
+                    best = (unsigned)__builtin_amdgcn_readlane((int)w1, __ffsll((long long)has1) - 1);
+                    if (m2 != ~0ull) {
+                        const unsigned mine = (b1 == m2) ? w1 : w2;
+                        const unsigned long long has2 = __ballot(b1 == m2 || b2 == m2);
+                        second = (unsigned)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)has2) - 1);
+                    }
+                }
+                if (lane == 0) { decide(qi, best, second); state[qi] = 1; }
+            }
+            __syncthreads();
+        }
+    }
+    int nm = s_nm;
+    if (check_ori) {
+        __syncthreads();
+        if (tid == 0) {                                        // ComputeThreeMaxima (:1969-2010)
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < kHisto; ++i) {
+                const int sz = s_hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+            s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+            s_undecided = 0;                                    // reused: number of removed matches
+        }
+        __syncthreads();
+        for (int qi = tid; qi < q.n; qi += kResT) {
+            const int g = match_of_query[qi];
+            if (g < 0) continue;
+            const int b = bin_of_query[qi];
+            if (b != s_ind[0] && b != s_ind[1] && b != s_ind[2]) { match_of_query[qi] = -1; query_of_feature[g] = -1; atomicAdd(&s_undecided, 1); }
+        }
+        __syncthreads();
+        nm -= s_undecided;
+    }
+    if (tid == 0) *n_matches = nm;
+}
+
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T> int alloc(T** out, size_t n) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) { set_error("hipMalloc: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
+        ptrs.push_back(p); *out = (T*)p; return DCS_OK;
+    }
+    template <typename T> int upload(const T** out, const T* src, size_t n) {
+        T* d = nullptr;
+        int rc = alloc(&d, n);
+        if (rc) return rc;
+        if (n) DCS_HIP(hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
+        *out = d; return DCS_OK;
+    }
+};
+
+}  // namespace
+}  // namespace dcs
+
+using namespace dcs;
+
+extern "C" {
+
+int dcs_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const float* kp_y, const float* min_x, const float* min_y,
+                   const float* grid_w_inv, const float* grid_h_inv, int32_t* grid_off, int32_t* grid_idx, int* n_entries)
+{
+    if (n_cams < 1 || !cam_off || !min_x || !min_y || !grid_w_inv || !grid_h_inv || !grid_off || (cam_off[n_cams] > 0 && (!kp_x || !kp_y || !grid_idx))) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    const int cells = n_cams * DCS_GRID_COLS * DCS_GRID_ROWS, N = cam_off[n_cams];
+    std::vector<int32_t> cell_of((size_t)std::max(N, 1), -1), cnt((size_t)cells + 1, 0);
+    for (int c = 0; c < n_cams; ++c)
+        for (int i = cam_off[c]; i < cam_off[c + 1]; ++i) {
+            const int px = (int)nearbyintf((kp_x[i] - min_x[c]) * grid_w_inv[c]);      // cvRound: round half to even
+            const int py = (int)nearbyintf((kp_y[i] - min_y[c]) * grid_h_inv[c]);
+            if (px < 0 || px >= DCS_GRID_COLS || py < 0 || py >= DCS_GRID_ROWS) continue;   // PosInGrid (Frame.cc:386-388)
+            cell_of[i] = (c * DCS_GRID_COLS + px) * DCS_GRID_ROWS + py;
+            ++cnt[cell_of[i] + 1];
+        }
+    for (int k = 0; k < cells; ++k) cnt[k + 1] += cnt[k];
+    for (int k = 0; k <= cells; ++k) grid_off[k] = cnt[k];
+    std::vector<int32_t> cur(cnt.begin(), cnt.end() - 1);
+    for (int c = 0; c < n_cams; ++c)
+        for (int i = cam_off[c]; i < cam_off[c + 1]; ++i)
+            if (cell_of[i] >= 0) grid_idx[cur[cell_of[i]]++] = i - cam_off[c];         // ascending i inside a cell = push_back order
+    if (n_entries) *n_entries = cnt[cells];
+    return DCS_OK;
+}
+
+int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* qs, int th_high, float nn_ratio, int check_orientation,
+                             int32_t* match_of_query, int32_t* query_of_feature, int* n_matches)
+{
+    if (!fr || !qs || !n_matches || fr->n_cams < 1 || !fr->cam_off || qs->n < 0) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    const int C = fr->n_cams, N = fr->cam_off[C], nq = qs->n;
+    const int cells = C * DCS_GRID_COLS * DCS_GRID_ROWS;
+    if (N < 0 || N >= (1 << 19)) { set_error("feature count %d outside 0 .. 2^19", N); return DCS_ERR_UNSUPPORTED; }
+    if (!fr->min_x || !fr->min_y || !fr->grid_w_inv || !fr->grid_h_inv || !fr->grid_off || (N && (!fr->kp_x || !fr->kp_y || !fr->kp_octave ||
+        !fr->desc || !fr->taken || !fr->grid_idx || !query_of_feature)) || (check_orientation && N && !fr->kp_angle) ||
+        (nq && (!qs->valid || !qs->cam || !qs->u || !qs->v || !qs->radius || !qs->min_level || !qs->max_level || !qs->desc || !match_of_query)) ||
+        (check_orientation && nq && !qs->angle)) { set_error("null array"); return DCS_ERR_INVALID; }
+    const int n_entries = fr->grid_off[cells];
+    if (n_entries < 0 || n_entries > N) { set_error("grid CSR inconsistent"); return DCS_ERR_INVALID; }
+    for (int i = 0; i < N; ++i) if (fr->kp_octave[i] < 0 || fr->kp_octave[i] > 15) { set_error("octave of feature %d outside 0..15", i); return DCS_ERR_INVALID; }
+    for (int i = 0; i < nq; ++i) if (qs->valid[i] && (qs->cam[i] < 0 || qs->cam[i] >= C)) { set_error("query %d: camera out of range", i); return DCS_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    *n_matches = 0;
+    if (nq == 0) { for (int i = 0; i < N; ++i) query_of_feature[i] = -1; return DCS_OK; }
+    Scratch s;
+    ProjFrameD f{};
+    ProjQueriesD q{};
+    f.n_cams = C; f.N = N;
+    static const float zero_f = 0.f;
+    if ((rc = s.upload(&f.cam_off, fr->cam_off, (size_t)C + 1)) || (rc = s.upload(&f.kp_x, fr->kp_x, (size_t)N)) || (rc = s.upload(&f.kp_y, fr->kp_y, (size_t)N)) ||
+        (rc = s.upload(&f.kp_octave, fr->kp_octave, (size_t)N)) || (rc = s.upload(&f.kp_angle, check_orientation ? fr->kp_angle : &zero_f, check_orientation ? (size_t)N : 1)) ||
+        (rc = s.upload(&f.desc, fr->desc, (size_t)N * 32)) || (rc = s.upload(&f.taken, fr->taken, (size_t)N)) ||
+        (rc = s.upload(&f.min_x, fr->min_x, (size_t)C)) || (rc = s.upload(&f.min_y, fr->min_y, (size_t)C)) ||
+        (rc = s.upload(&f.w_inv, fr->grid_w_inv, (size_t)C)) || (rc = s.upload(&f.h_inv, fr->grid_h_inv, (size_t)C)) ||
+        (rc = s.upload(&f.grid_off, fr->grid_off, (size_t)cells + 1)) || (rc = s.upload(&f.grid_idx, fr->grid_idx, (size_t)n_entries))) return rc;
+    q.n = nq;
+    if ((rc = s.upload(&q.valid, qs->valid, (size_t)nq)) || (rc = s.upload(&q.cam, qs->cam, (size_t)nq)) || (rc = s.upload(&q.u, qs->u, (size_t)nq)) ||
+        (rc = s.upload(&q.v, qs->v, (size_t)nq)) || (rc = s.upload(&q.radius, qs->radius, (size_t)nq)) ||
+        (rc = s.upload(&q.min_level, qs->min_level, (size_t)nq)) || (rc = s.upload(&q.max_level, qs->max_level, (size_t)nq)) ||
+        (rc = s.upload(&q.desc, qs->desc, (size_t)nq * 32)) || (rc = s.upload(&q.angle, check_orientation ? qs->angle : &zero_f, check_orientation ? (size_t)nq : 1))) return rc;
+    unsigned* d_cand; int32_t *d_cn, *d_mq, *d_qf, *d_bin, *d_nm; uint8_t* d_taken;
+    if ((rc = s.alloc(&d_cand, (size_t)nq * kProjCap)) || (rc = s.alloc(&d_cn, (size_t)nq)) || (rc = s.alloc(&d_mq, (size_t)nq)) ||
+        (rc = s.alloc(&d_qf, (size_t)N)) || (rc = s.alloc(&d_bin, (size_t)nq)) || (rc = s.alloc(&d_nm, 1)) || (rc = s.alloc(&d_taken, (size_t)N))) return rc;
+    DCS_HIP(hipMemcpy(d_taken, fr->taken, (size_t)N, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_proj_collect, dim3((nq + 3) / 4), dim3(256), 0, 0, f, q, d_cand, d_cn);
+    DCS_CHECK_LAUNCH();
+    static const bool serial = getenv("DCS_PROJ_SERIAL") != nullptr;     // one-wave resolver (reference order, step by step)
+    if (N <= kResMaxN && !serial) {
+        uint8_t* d_state;
+        if ((rc = s.alloc(&d_state, (size_t)nq))) return rc;
+        hipLaunchKernelGGL(k_proj_resolve_par, dim3(1), dim3(kResT), 0, 0, f, q, d_cand, d_cn, d_state, th_high, nn_ratio, check_orientation,
+                           d_mq, d_qf, d_bin, d_nm);
+    } else if (N <= 65536)
+        hipLaunchKernelGGL(k_proj_resolve<true>, dim3(1), dim3(64), (size_t)std::max(N, 1), 0, f, q, d_cand, d_cn, d_taken, th_high, nn_ratio,
+                           check_orientation, d_mq, d_qf, d_bin, d_nm);
+    else
+        hipLaunchKernelGGL(k_proj_resolve<false>, dim3(1), dim3(64), 0, 0, f, q, d_cand, d_cn, d_taken, th_high, nn_ratio, check_orientation,
+                           d_mq, d_qf, d_bin, d_nm);
+    DCS_CHECK_LAUNCH();
+    DCS_HIP(hipMemcpy(match_of_query, d_mq, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    if (N) DCS_HIP(hipMemcpy(query_of_feature, d_qf, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    int32_t nm = 0;
+    DCS_HIP(hipMemcpy(&nm, d_nm, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *n_matches = nm;
+    return DCS_OK;
+}
+
+}  // extern "C"

@@ -49,6 +49,34 @@ public:
         return n;
     }
 
+    // SearchByProjection(pF, vpMapPoints, th) (ORBmatcher.cc:539-624): the caller fills `queries` from the map points that
+    // passed Frame::isInFrustum (cam = mTrackProjCamera, u/v = mTrackProjX/Y, radius = RadiusByViewingCos(mTrackViewCos) [* th]
+    // * mvScaleFactors[mnTrackScaleLevel], levels = mnTrackScaleLevel -/+ 1) and `frame` from pF (dcs_frame_grid builds the
+    // CSR of mvGrids). matchOfQuery[i] = global feature index that now holds map point i, or -1. Returns nmatches.
+    int SearchByProjection(const dcs_proj_frame& frame, const dcs_proj_queries& queries, std::vector<int32_t>& matchOfQuery,
+                           std::vector<int32_t>& queryOfFeature) const
+    {
+        matchOfQuery.assign(queries.n > 0 ? queries.n : 1, -1); queryOfFeature.assign(frame.cam_off[frame.n_cams] > 0 ? frame.cam_off[frame.n_cams] : 1, -1);
+        int n = 0;
+        check(dcs_search_by_projection(&frame, &queries, TH_HIGH, mfNNratio, 0, matchOfQuery.data(), queryOfFeature.data(), &n), "dcs_search_by_projection");
+        matchOfQuery.resize(queries.n); queryOfFeature.resize(frame.cam_off[frame.n_cams]);
+        return n;
+    }
+
+    // SearchByProjectionOnCam(pFcurt, query, pFlast, th) (ORBmatcher.cc:954-1113): queries = the last frame's features of
+    // camera `query` that hold a map point and project inside the image (:990-1013), radius = th * mvScaleFactors[octave],
+    // levels = octave -/+ 1, angle = the last frame's keypoint angle. Best candidate only, rotation histogram if enabled.
+    int SearchByProjectionOnCam(const dcs_proj_frame& frame, const dcs_proj_queries& queries, std::vector<int32_t>& matchOfQuery,
+                                std::vector<int32_t>& queryOfFeature) const
+    {
+        matchOfQuery.assign(queries.n > 0 ? queries.n : 1, -1); queryOfFeature.assign(frame.cam_off[frame.n_cams] > 0 ? frame.cam_off[frame.n_cams] : 1, -1);
+        int n = 0;
+        check(dcs_search_by_projection(&frame, &queries, TH_HIGH, 0.f, mbCheckOrientation, matchOfQuery.data(), queryOfFeature.data(), &n),
+              "dcs_search_by_projection");
+        matchOfQuery.resize(queries.n); queryOfFeature.resize(frame.cam_off[frame.n_cams]);
+        return n;
+    }
+
     // best / second-best distances of every query (the loop at ORBmatcher.cc:208-231 over all candidates)
     static void Knn2(const std::vector<uint8_t>& q, const std::vector<uint8_t>& t, std::vector<int32_t>& bestIdx,
                      std::vector<int32_t>& bestDist, std::vector<int32_t>& secondDist)

@@ -123,3 +123,33 @@ def test_distinctive_descriptors(pkg, oracle, synth):
     assert got[0] == -1 and got[1] == 0 and got[5] == 0
     with pytest.raises(pkg.DcsError):
         pkg.ComputeDistinctiveDescriptors(pool, off, idx + 1000)
+
+
+def _proj_problem(pkg, oracle, synth, **kw):
+    frame, q = synth.projection_problem(**kw)
+    off, idx = pkg.frame_grid(frame["cam_off"], frame["kp_x"], frame["kp_y"], frame["min_x"], frame["min_y"],
+                              frame["grid_w_inv"], frame["grid_h_inv"])
+    ooff, oidx = oracle.frame_grid(frame["cam_off"], frame["kp_x"], frame["kp_y"], frame["min_x"], frame["min_y"],
+                                   frame["grid_w_inv"], frame["grid_h_inv"])
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    frame["grid_off"], frame["grid_idx"] = off, idx
+    return frame, q
+
+
+@pytest.mark.parametrize("kw", [dict(n_per_cam=900, n_queries=700, seed=13),
+                                dict(n_per_cam=2000, n_queries=1500, seed=2, th=3.0),
+                                dict(n_per_cam=400, n_queries=300, seed=5, big_windows=25)])
+def test_search_by_projection(pkg, oracle, synth, kw):
+    """ORBmatcher::SearchByProjection (ratio rule) and SearchByProjectionOnCam (best only + rotation histogram): the
+    order-dependent greedy result must equal the sequential oracle exactly, including windows beyond the candidate cap."""
+    frame, q = _proj_problem(pkg, oracle, synth, **kw)
+    m = pkg.ORBmatcher(0.8, True)
+    for use_ratio, ori in ((True, False), (False, True), (False, False)):
+        mq, qf, n = m.SearchByProjection(frame, q, 100, use_ratio=use_ratio, check_orientation=ori)
+        emq, eqf, en = oracle.search_by_projection(frame, q, 100, 0.8 if use_ratio else 0.0, ori)
+        assert np.array_equal(mq, emq) and np.array_equal(qf, eqf) and n == en
+        assert n > 0.3 * len(mq)
+    # invalid queries and an empty query set
+    q0 = {k: v[:0] for k, v in q.items()}
+    mq, qf, n = m.SearchByProjection(frame, q0)
+    assert n == 0 and len(mq) == 0 and (qf == -1).all()
