@@ -500,40 +500,65 @@ __device__ __forceinline__ void blur_hrow(const uint8_t* __restrict__ row, int x
     }
     constexpr unsigned KA = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3
     constexpr unsigned KB = 49u | (34u << 8) | (18u << 16);                 // taps 4..6 (+0)
-    h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0u, false) +
-           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, 0u, false);
-    h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0u, false) +
-           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, 0u, false);
-    h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0u, false) +
-           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, 0u, false);
-    h[3] = __builtin_amdgcn_udot4(d1, KA, 0u, false) + __builtin_amdgcn_udot4(d2, KB, 0u, false);
+    // second dot4 accumulates onto the first: 2 instructions per pixel
+    h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0u, false), false);
+    h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0u, false), false);
+    h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0u, false), false);
+    h[3] = __builtin_amdgcn_udot4(d2, KB, __builtin_amdgcn_udot4(d1, KA, 0u, false), false);
 }
 
-// one 4-pixel-wide, kBlurR-row strip
-template <int MODE>
+// K * b + c with K an inline constant (the compiler splits this into v_mul_u32_u24 + v_add otherwise)
+template <int K>
+__device__ __forceinline__ unsigned kmad24(unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "n"(K), "v"(b), "v"(c));
+    return r;
+}
+template <int K>
+__device__ __forceinline__ unsigned kmad24s(unsigned b, unsigned c_uniform)      // addend in a scalar register
+{
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "n"(K), "v"(b), "s"(c_uniform));
+    return r;
+}
+
+// one 4-pixel-wide, kBlurR-row strip. YEDGE = the strip touches the top / bottom of the image (row reflection and the
+// y < h store predicate); interior strips walk a plain row pointer.
+template <int MODE, bool YEDGE>
 __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ S, uint8_t* __restrict__ D, const LevelView& sv, const LevelView& dv,
                                            int x0, int y0)
 {
     BlurEdgeMap em{};
     if (MODE == kBlurEdge) em = blur_edge_map(x0, sv.w, sv.pitch);
     unsigned ring[7][4];
+    const uint8_t* rowp = S + (ptrdiff_t)(y0 - 3) * sv.pitch;
+    uint8_t* outp = D + (size_t)y0 * dv.pitch + x0;
+    // The ring slot of every row must be a compile-time constant: hot strips (no row reflection) are unrolled completely,
+    // the strips at the top / bottom of an image roll the rows in groups of 7 (the ring period) to keep the code small.
+    constexpr int kGroup = YEDGE ? 7 : 42;
+#pragma unroll 1
+    for (int r0 = 0; r0 < kBlurR + 6; r0 += kGroup) {
 #pragma unroll
-    for (int r = 0; r < kBlurR + 6; ++r) {
-        const int yy = reflect101(y0 + r - 3, sv.h);
-        blur_hrow<MODE>(S + (size_t)yy * sv.pitch, x0, sv.w, em, ring[r % 7]);
-        if (r >= 6) {
-            const int y = y0 + r - 6;                 // output row: window = input rows r-6 .. r
-            unsigned packed = 0;
+        for (int kk = 0; kk < kGroup; ++kk) {
+            const int k = kk % 7;
+            const int r = r0 + kk;
+            if (r >= kBlurR + 6) break;
+            const uint8_t* row = YEDGE ? S + (size_t)reflect101(y0 + r - 3, sv.h) * sv.pitch : rowp + (size_t)r * sv.pitch;
+            blur_hrow<MODE>(row, x0, sv.w, em, ring[k]);
+            if (r >= 6) {                             // output row y0 + r - 6: window = input rows r-6 .. r
+                unsigned packed = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // operands < 2^24: v_mad_u32_u24 chain (full-rate), 32-bit accumulate (max 257 * 65535)
-                unsigned acc = __umul24(55u, ring[(r - 3) % 7][i]);
-                acc = __umul24(18u, ring[(r - 6) % 7][i] + ring[r % 7][i]) + acc;
-                acc = __umul24(34u, ring[(r - 5) % 7][i] + ring[(r - 1) % 7][i]) + acc;
-                acc = __umul24(49u, ring[(r - 4) % 7][i] + ring[(r - 2) % 7][i]) + acc;
-                packed |= min(255u, (acc + 32768u) >> 16) << (8 * i);
+                for (int i = 0; i < 4; ++i) {
+                    // operands < 2^24: v_mad_u32_u24 chain (full rate), 32-bit accumulate (max 257 * 65535); rounding folded in
+                    unsigned acc = kmad24s<55>(ring[(k + 4) % 7][i], 32768u);
+                    acc = kmad24<18>(ring[(k + 1) % 7][i] + ring[k][i], acc);
+                    acc = kmad24<34>(ring[(k + 2) % 7][i] + ring[(k + 6) % 7][i], acc);
+                    acc = kmad24<49>(ring[(k + 3) % 7][i] + ring[(k + 5) % 7][i], acc);
+                    packed |= min(255u, acc >> 16) << (8 * i);
+                }
+                if (!YEDGE || y0 + r - 6 < dv.h) *reinterpret_cast<unsigned*>(outp + (size_t)(r - 6) * dv.pitch) = packed;
             }
-            if (y < dv.h) *reinterpret_cast<unsigned*>(D + (size_t)y * dv.pitch + x0) = packed;
         }
     }
 }
@@ -562,11 +587,12 @@ __global__ __launch_bounds__(64 * kBlurWaves) void k_blur(LevelSet src, LevelSet
     uint8_t* D = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
     if (!level_aligned(sv, img)) return;                                          // k_blur_unaligned_l0
     const bool inside = x0 < sv.w, interior = x0 >= 4 && x0 + 7 <= sv.w - 1;
+    const bool yedge = y0 < 3 || y0 + kBlurR + 3 > sv.h;                          // wave-uniform
     if (__all(!inside || interior)) {                                             // wave-uniform choice of the code path
-        if (inside) blur_strip<kBlurInterior>(S, D, sv, dv, x0, y0);
+        if (inside) { if (yedge) blur_strip<kBlurInterior, true>(S, D, sv, dv, x0, y0); else blur_strip<kBlurInterior, false>(S, D, sv, dv, x0, y0); }
     } else if (inside) {
-        if (sv.w >= 8) blur_strip<kBlurEdge>(S, D, sv, dv, x0, y0);               // first / last 256-px tile of a row
-        else blur_strip<kBlurBytes>(S, D, sv, dv, x0, y0);
+        if (sv.w >= 8) { if (yedge) blur_strip<kBlurEdge, true>(S, D, sv, dv, x0, y0); else blur_strip<kBlurEdge, false>(S, D, sv, dv, x0, y0); }   // first / last 256-px tile of a row
+        else blur_strip<kBlurBytes, true>(S, D, sv, dv, x0, y0);
     }
 }
 
@@ -578,7 +604,7 @@ __global__ __launch_bounds__(64) void k_blur_unaligned_l0(LevelSet src, LevelSet
     if (level_aligned(sv, img)) return;
     const int x0 = 4 * (blockIdx.x * 64 + (int)threadIdx.x), y0 = kBlurR * (int)blockIdx.y;
     if (x0 >= sv.w || y0 >= sv.h) return;
-    blur_strip<kBlurBytes>(sv.base + (size_t)img * sv.img_stride, const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride, sv, dv, x0, y0);
+    blur_strip<kBlurBytes, true>(sv.base + (size_t)img * sv.img_stride, const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride, sv, dv, x0, y0);
 }
 
 int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStream_t s)
