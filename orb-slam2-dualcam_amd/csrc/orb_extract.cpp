@@ -109,6 +109,10 @@ struct dcs_orb {
     OctLevels oct{};
     DevBuf<int32_t> d_lvl_cnt, d_oct_flag;
     DevBuf<uint32_t> d_ic_mask;
+    std::unique_ptr<Pool> stage_pool;
+    DevBuf<uint8_t> d_stage;
+    PinnedBuf<dcs_keypoint> h_kp_out;
+    PinnedBuf<uint8_t> h_desc_out;
     DevBuf<unsigned long long> d_oct_u64[3];
     DevBuf<unsigned> d_oct_u32[2];
     DevBuf<int> d_oct_i32[8];
@@ -456,6 +460,11 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
     h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
+    {   // staging threads of the host-buffer API (DCS_ORB_STAGING_THREADS, default 4; 1 = pack on the calling thread)
+        const char* e = getenv("DCS_ORB_STAGING_THREADS");
+        const int nt = e ? atoi(e) : 4;
+        if (nt > 1 && h->prm.max_images > 2) h->stage_pool.reset(new Pool(nt - 1));
+    }
     *out = h.release();
     return DCS_OK;
 }
@@ -507,42 +516,71 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     DCS_HIP(hipSetDevice(h->device));
     int rc = h->configure(rows, cols);
     if (rc) return rc;
-    const LevelGeom& l0 = h->g.lv[0];
-    // stage through pinned memory so the H2D copies are truly asynchronous
-    const size_t img_bytes = (size_t)rows * cols;
-    if ((rc = h->h_img.resize(img_bytes * n_images))) return rc;
-    for (int i = 0; i < n_images; ++i)
-        for (int y = 0; y < rows; ++y)
-            memcpy(h->h_img.p + i * img_bytes + (size_t)y * cols, images[i] + (size_t)y * stride, cols);
-    for (int i = 0; i < n_images; ++i)
-        DCS_HIP(hipMemcpy2DAsync(h->d_pyr.p + (size_t)i * h->g.slab_bytes + l0.offset, l0.pitch, h->h_img.p + i * img_bytes, cols,
-                                 cols, rows, hipMemcpyHostToDevice, h->s_main));
-    if ((rc = h->d_kp.resize((size_t)n_images * cap))) return rc;
-    if ((rc = h->d_desc.resize((size_t)n_images * cap * 32))) return rc;
-    if ((rc = h->d_n.resize(n_images))) return rc;
-    if ((rc = h->h_n.resize(n_images))) return rc;
+    // Host images -> pinned staging (rows packed at a 4-byte aligned pitch) -> ONE device staging buffer that the kernels
+    // read in place as level 0, exactly like the _device entry point. Groups of 8 images are packed by the staging
+    // threads and their DMA (one copy per group) is enqueued while the next group is packed.
+    const int pitch_s = (cols + 3) & ~3;
+    const size_t img_bytes = (size_t)rows * pitch_s;
+    if ((rc = h->h_img.resize(img_bytes * n_images)) || (rc = h->d_stage.resize(img_bytes * n_images))) return rc;
+    auto pack = [&](int i) {
+        uint8_t* dst = h->h_img.p + i * img_bytes;
+        if (stride == cols && pitch_s == cols) memcpy(dst, images[i], img_bytes);
+        else for (int y = 0; y < rows; ++y) memcpy(dst + (size_t)y * pitch_s, images[i] + (size_t)y * stride, cols);
+    };
+    for (int i0 = 0; i0 < n_images; i0 += 8) {
+        const int m = std::min(8, n_images - i0);
+        if (m > 1 && h->stage_pool) h->stage_pool->parallel_for(m, [&](int k) { pack(i0 + k); });
+        else for (int k = 0; k < m; ++k) pack(i0 + k);
+        DCS_HIP(hipMemcpyAsync(h->d_stage.p + i0 * img_bytes, h->h_img.p + i0 * img_bytes, img_bytes * m, hipMemcpyHostToDevice, h->s_main));
+    }
+    const size_t slots = (size_t)n_images * cap;
+    if ((rc = h->d_kp.resize(slots)) || (rc = h->d_desc.resize(slots * 32)) || (rc = h->d_n.resize(n_images)) || (rc = h->h_n.resize(n_images))) return rc;
     std::vector<int> counts(n_images, 0);
-    rc = h->run(nullptr, 0, 0, n_images, h->d_kp.p, h->d_desc.p, cap, h->d_n.p, h->s_main, counts.data());
+    rc = h->run(h->d_stage.p, img_bytes, pitch_s, n_images, h->d_kp.p, h->d_desc.p, cap, h->d_n.p, h->s_main, counts.data());
     if (rc) { for (int i = 0; i < n_images; ++i) n_out[i] = counts[i]; return rc; }
     if (h->device_octree) {
+        // everything is still in flight: the slotted results follow in two copies, one synchronisation for the whole call
+        if ((rc = h->h_kp_out.resize(slots)) || (rc = h->h_desc_out.resize(slots * 32))) return rc;
         DCS_HIP(hipMemcpyAsync(h->h_n.p, h->d_n.p, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost, h->s_main));
         DCS_HIP(hipMemcpyAsync(h->h_lvl_off.p, h->d_lvl_off.p, sizeof(int32_t) * (n_images * h->t.nlevels + 1), hipMemcpyDeviceToHost, h->s_main));
+        DCS_HIP(hipMemcpyAsync(h->h_kp_out.p, h->d_kp.p, sizeof(dcs_keypoint) * slots, hipMemcpyDeviceToHost, h->s_main));
+        DCS_HIP(hipMemcpyAsync(h->h_desc_out.p, h->d_desc.p, slots * 32, hipMemcpyDeviceToHost, h->s_main));
         DCS_HIP(hipStreamSynchronize(h->s_main));
         if ((size_t)h->h_lvl_off.p[n_images * h->t.nlevels] > h->dense_cap) {
             set_error("FAST candidates (%d) exceed the dense buffer (%zu)", h->h_lvl_off.p[n_images * h->t.nlevels], h->dense_cap);
             return DCS_ERR_CAPACITY;
         }
-        for (int i = 0; i < n_images; ++i) counts[i] = h->h_n.p[i];
+        for (int i = 0; i < n_images; ++i) {
+            const int c = h->h_n.p[i];
+            if (c) {
+                memcpy(kp + (size_t)i * cap, h->h_kp_out.p + (size_t)i * cap, sizeof(dcs_keypoint) * c);
+                memcpy(desc + (size_t)i * cap * 32, h->h_desc_out.p + (size_t)i * cap * 32, (size_t)32 * c);
+            }
+            n_out[i] = c;
+        }
+        return DCS_OK;
     }
+    // host-quadtree mode: counts are known on the host already
+    size_t total = 0;
+    for (int i = 0; i < n_images; ++i) total += (size_t)counts[i];
+    if ((rc = h->h_kp_out.resize(total)) || (rc = h->h_desc_out.resize(total * 32))) return rc;
+    size_t at = 0;
     for (int i = 0; i < n_images; ++i) {
         if (!counts[i]) continue;
-        DCS_HIP(hipMemcpyAsync(kp + (size_t)i * cap, h->d_kp.p + (size_t)i * cap, sizeof(dcs_keypoint) * counts[i],
-                               hipMemcpyDeviceToHost, h->s_main));
-        DCS_HIP(hipMemcpyAsync(desc + (size_t)i * cap * 32, h->d_desc.p + (size_t)i * cap * 32, (size_t)32 * counts[i],
-                               hipMemcpyDeviceToHost, h->s_main));
+        DCS_HIP(hipMemcpyAsync(h->h_kp_out.p + at, h->d_kp.p + (size_t)i * cap, sizeof(dcs_keypoint) * counts[i], hipMemcpyDeviceToHost, h->s_main));
+        DCS_HIP(hipMemcpyAsync(h->h_desc_out.p + at * 32, h->d_desc.p + (size_t)i * cap * 32, (size_t)32 * counts[i], hipMemcpyDeviceToHost, h->s_main));
+        at += (size_t)counts[i];
     }
     DCS_HIP(hipStreamSynchronize(h->s_main));
-    for (int i = 0; i < n_images; ++i) n_out[i] = counts[i];
+    at = 0;
+    for (int i = 0; i < n_images; ++i) {
+        if (counts[i]) {
+            memcpy(kp + (size_t)i * cap, h->h_kp_out.p + at, sizeof(dcs_keypoint) * counts[i]);
+            memcpy(desc + (size_t)i * cap * 32, h->h_desc_out.p + at * 32, (size_t)32 * counts[i]);
+            at += (size_t)counts[i];
+        }
+        n_out[i] = counts[i];
+    }
     return DCS_OK;
 }
 
