@@ -13,6 +13,8 @@
 // partial results merge exactly into what the reference's sequential loop produces.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <vector>
 
@@ -146,6 +148,160 @@ __global__ __launch_bounds__(256) void k_knn2_pairs(const uint8_t* __restrict__ 
     if ((int)blockIdx.x * 128 >= nq) return;
     knn2_tile(desc + (size_t)qs * cap * 32, nq, desc + (size_t)ts * cap * 32, nt, nullptr, blockIdx.x,
               best_idx + (size_t)p * cap, best_d + (size_t)p * cap, second_d + (size_t)p * cap);
+}
+
+// ---- Hamming knn2 on the i8 matrix cores ------------------------------------------------------------------------------
+// popcount(q ^ t) = popcount(q) + popcount(t) - 2 <q, t> with the descriptors expanded to 256 bytes of 0 / 1: the inner
+// product is an i8 GEMM, 4 x v_mfma_i32_16x16x64_i8 per 16 x 16 block of distances, on a pipe the rest of the front end
+// leaves idle, and the vector ALU only keeps the best / second-best keys (5 instructions per distance instead of 19.5).
+// A operand = 16 train descriptors (rows), B operand = 16 queries (columns): lane (c = l & 15, g = l >> 4) feeds, for
+// K-slice s, the 16 bytes expanded from 16-bit chunk (4 s + g) of its row / column -- A and B use the same chunk-to-lane
+// rule, so the products pair up bit by bit whatever the hardware's k ordering inside the instruction is. The accumulator
+// puts <train 4 g + r, query c> in register r of lane (c, g): every lane tracks ITS query over its 4 train rows per block,
+// and the four lanes of a query merge at the end (exact: keys are distinct).
+// Workgroup = 4 waves x 64 queries (4 B fragments in VGPRs per wave); train tiles of 128 descriptors are expanded
+// cooperatively into LDS (272-byte rows: 16 B of padding against bank conflicts) together with their popcounts.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+constexpr int kMTile = 128;                    // train descriptors per LDS tile
+constexpr int kMRow = 272;                     // bytes per expanded descriptor in LDS (256 + 16 padding)
+
+__device__ __forceinline__ unsigned spread4(unsigned nib)      // 4 bits -> 4 bytes of 0 / 1
+{ return __umul24(nib, 0x204081u) & 0x01010101u; }
+
+__device__ __forceinline__ v4i_t expand16(unsigned h16)        // 16 bits -> 16 bytes of 0 / 1 (bit b -> byte b)
+{
+    v4i_t v;
+    v.x = (int)spread4(h16 & 15u); v.y = (int)spread4((h16 >> 4) & 15u); v.z = (int)spread4((h16 >> 8) & 15u); v.w = (int)spread4((h16 >> 12) & 15u);
+    return v;
+}
+
+template <int QG, int WAVES>
+__device__ __forceinline__ void knn2_tile_mfma(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt, int q_tile,
+                                               int32_t* __restrict__ best_idx, int32_t* __restrict__ best_d, int32_t* __restrict__ second_d)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[2][kMTile * kMRow];     // double-buffered: one barrier per tile
+    __shared__ __attribute__((aligned(16))) int s_pb[2][kMTile];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    constexpr int kParts = WAVES / 2;              // threads per train descriptor in the expansion (64 WAVES / 128)
+    const int qbase = (q_tile * WAVES + wave) * (16 * QG);
+    // B fragments + popcounts of this lane's 4 queries (query qbase + 16 qg + c, chunks 4 s + g)
+    v4i_t bf[QG][4];
+    int pa[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        const int qi = qbase + 16 * qg + c;
+        uint4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (qi < nq) { const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 32); lo = qp[0]; hi = qp[1]; }
+        const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        pa[qg] = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]) + __popc(w[4]) + __popc(w[5]) + __popc(w[6]) + __popc(w[7]);
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            // chunk 4 sl + g = halfword (g & 1) of dword 2 sl + (g >> 1)
+            const unsigned dw = (g >> 1) ? w[2 * sl + 1] : w[2 * sl];
+            // queries enter as bytes 0 / -1: the accumulator holds -<q, t>, and the key is one v_lshl_add_u32
+            const v4i_t e = expand16((g & 1) ? (dw >> 16) : (dw & 0xFFFFu));
+            bf[qg][sl] = v4i_t{(e.x << 8) - e.x, (e.y << 8) - e.y, (e.z << 8) - e.z, (e.w << 8) - e.w};
+        }
+    }
+    // Keys are tracked WITHOUT the query's own popcount (a constant per lane and query group that cannot change the order):
+    // key = (popcount(t) - 2 <q, t> + 512) << 22 | train index -- 4 instructions per distance (mad, lshl_or, med3, min).
+    constexpr unsigned kInitM = (0x3FFu << 22) | 0x3FFFFFu;
+    unsigned k1[QG], k2[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) { k1[qg] = kInitM; k2[qg] = kInitM; }
+    auto expand_tile = [&](int t0, int buf) {
+        // expand the tile: kParts threads per descriptor, 8 / kParts dwords (-> 16 bytes each per 16-bit chunk) per thread
+        {
+            constexpr int kDw = 8 / kParts;
+            const int d = tid / kParts, part = tid % kParts, ti = t0 + d;
+            unsigned w[kDw];
+#pragma unroll
+            for (int k = 0; k < kDw; ++k) w[k] = 0;
+            if (ti < nt) {
+                const unsigned* src = reinterpret_cast<const unsigned*>(t + (size_t)ti * 32) + part * kDw;
+#pragma unroll
+                for (int k = 0; k < kDw; ++k) w[k] = src[k];
+            }
+            uint8_t* row = s_t[buf] + d * kMRow + part * (32 * kDw);
+            int pc = 0;
+#pragma unroll
+            for (int k = 0; k < kDw; ++k) {                    // dword k -> two chunks
+                *reinterpret_cast<v4i_t*>(row + 32 * k) = expand16(w[k] & 0xFFFFu);
+                *reinterpret_cast<v4i_t*>(row + 32 * k + 16) = expand16(w[k] >> 16);
+                pc += __popc(w[k]);
+            }
+#pragma unroll
+            for (int sh = 1; sh < kParts; sh <<= 1) pc += __shfl_xor(pc, sh);
+            if (part == 0) s_pb[buf][d] = (ti < nt ? pc + 512 : 0x3FF) << 22;   // key high part; padding rows: largest biased distance
+        }
+    };
+    expand_tile(0, 0);
+    __syncthreads();
+    for (int t0 = 0, buf = 0; t0 < nt; t0 += kMTile, buf ^= 1) {
+        if (t0 + kMTile < nt) expand_tile(t0 + kMTile, buf ^ 1);   // next tile: its VALU / LDS work overlaps this tile's MFMAs
+        const int n_grp = (min(kMTile, nt - t0) + 15) >> 4;
+        v4i_t af[4], pb;
+        auto load_group = [&](int tg) {
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) af[sl] = *reinterpret_cast<const v4i_t*>(s_t[buf] + (16 * tg + c) * kMRow + 16 * (4 * sl + g));
+            pb = *reinterpret_cast<const v4i_t*>(&s_pb[buf][16 * tg + 4 * g]);              // biased popcounts of train rows 4 g + r
+        };
+        load_group(0);
+        for (int tg = 0; tg < n_grp; ++tg) {
+            v4i_t acc[QG];
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) acc[qg] = v4i_t{0, 0, 0, 0};
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)                       // slice-major: consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[sl], bf[qg][sl], acc[qg], 0, 0, 0);
+            const v4i_t pbc = pb;
+            const unsigned tbase = (unsigned)(t0 + 16 * tg + 4 * g);
+            if (tg + 1 < n_grp) load_group(tg + 1);              // next group's operands fly while this group's keys are ranked
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // (popcount(t) + 512 - 2 <q, t>) << 22 | index; padding rows of the last group: acc = 0, largest key, index >= nt
+                    const unsigned key = (((unsigned)acc[qg][r] << 23) + (unsigned)pbc[r]) | (tbase + (unsigned)r);
+                    k2[qg] = umed3(k1[qg], k2[qg], key); k1[qg] = min(k1[qg], key);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the 4 lanes (g = 0..3) of a query hold disjoint train rows: two smallest of the union
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        unsigned a1 = k1[qg], a2 = k2[qg];
+#pragma unroll
+        for (int d = 16; d <= 32; d <<= 1) {
+            const unsigned o1 = (unsigned)__shfl_xor((int)a1, d), o2 = (unsigned)__shfl_xor((int)a2, d);
+            a2 = min(min(a2, o2), max(a1, o1));
+            a1 = min(a1, o1);
+        }
+        const int qi = qbase + 16 * qg + c;
+        if (g == 0 && qi < nq) {
+            // un-bias: distance = key_distance - 512 + popcount(q); a key that never met a real train row keeps index >= nt
+            const int i1 = (int)(a1 & 0x3FFFFFu), i2 = (int)(a2 & 0x3FFFFFu);
+            const int d1 = i1 < nt ? (int)(a1 >> 22) - 512 + pa[qg] : 256, d2 = i2 < nt ? (int)(a2 >> 22) - 512 + pa[qg] : 256;
+            best_idx[qi] = d1 >= 256 ? -1 : i1;
+            best_d[qi] = min(d1, 256); second_d[qi] = min(d2, 256);
+        }
+    }
+}
+
+constexpr int kKnnQG = 2, kKnnWaves = 8, kKnnQ = 16 * kKnnQG * kKnnWaves;      // 256 queries per workgroup
+__global__ __launch_bounds__(64 * kKnnWaves) void k_knn2_pairs_mfma(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_feat, int cap,
+                                                         const int32_t* __restrict__ pairs, int32_t* best_idx, int32_t* best_d, int32_t* second_d)
+{
+    const int p = blockIdx.y;
+    const int qs = pairs[2 * p], ts = pairs[2 * p + 1];
+    const int nq = min(n_feat[qs], cap), nt = min(n_feat[ts], cap);
+    if ((int)blockIdx.x * kKnnQ >= nq) return;
+    knn2_tile_mfma<kKnnQG, kKnnWaves>(desc + (size_t)qs * cap * 32, nq, desc + (size_t)ts * cap * 32, nt, blockIdx.x,
+                   best_idx + (size_t)p * cap, best_d + (size_t)p * cap, second_d + (size_t)p * cap);
 }
 
 // grouped (CSR buckets): one wave per group, one query per lane, candidates read through t_idx
@@ -546,7 +702,9 @@ int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, c
     if (cap >= (1 << 23)) { set_error("cap %d exceeds the 2^23 descriptors of one knn2 problem", cap); return DCS_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     // d_match doubles as the best-index buffer: the filter reads best_idx[i] and writes match[i] in the same thread
-    hipLaunchKernelGGL(k_knn2_pairs, dim3((cap + 127) / 128, n_pairs), dim3(256), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
+    static const bool knn_valu = getenv("DCS_KNN2_VALU") != nullptr;      // xor + popcount kernel instead of the i8 matrix-core one
+    if (knn_valu) hipLaunchKernelGGL(k_knn2_pairs, dim3((cap + 127) / 128, n_pairs), dim3(256), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
+    else hipLaunchKernelGGL(k_knn2_pairs_mfma, dim3((cap + kKnnQ - 1) / kKnnQ, n_pairs), dim3(64 * kKnnWaves), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
     DCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter_pairs, dim3(n_pairs), dim3(256), 0, s, d_kp, d_n, cap, d_pairs, d_match, d_best_d, d_second_d, th,
                        ratio, check_ori, d_match, d_n_matches);
