@@ -206,14 +206,14 @@ def main():
             "k_fast_cells": sum_px * n_img_l,
             "k_blur": 2 * sum_px * n_img_l,
             "k_describe": int((749 + 512 + 60) * n_avg * n_img_l),
-            "k_knn2_pairs+k_filter_pairs": int((32 * 2 * n_avg + 12 * n_avg) * n_pairs),
+            "k_knn2_pairs_mfma+k_filter_pairs": int((32 * 2 * n_avg + 12 * n_avg) * n_pairs),
         }
         dur = {"k_resize(x7)": acc["pyramid_us"] / (K * LN), "k_fast_cells": acc["fast_us"] / (K * LN),
                "k_blur": acc["blur_us"] / (K * LN), "k_describe": acc["describe_us"] / (K * LN),
-               "k_knn2_pairs+k_filter_pairs": acc["match_us"] / K}
+               "k_knn2_pairs_mfma+k_filter_pairs": acc["match_us"] / K}
         kernels = {k: dict(us=round(dur[k], 2), algo_bytes=int(algo[k]),
                            gbps=round(algo[k] / max(dur[k], 1e-3) / 1e3, 2)) for k in algo}
-        dom = max((k for k in dur if k != "k_knn2_pairs+k_filter_pairs"), key=lambda k: dur[k])
+        dom = max((k for k in dur if k != "k_knn2_pairs_mfma+k_filter_pairs"), key=lambda k: dur[k])
         traffic = None                               # HBM bytes per launch from the committed PMC passes (profiles/), same workload only
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))

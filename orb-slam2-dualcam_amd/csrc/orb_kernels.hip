@@ -382,21 +382,23 @@ __global__ __launch_bounds__(256) void k_lvl_offsets(const int32_t* __restrict__
     if (threadIdx.x == 0) lvl_off[n_all] = running;
 }
 
-// one wave per (cell, image): copy the cell's slots to their place in the dense, emission-ordered array
+// 16 lanes per (cell, image) -- a cell rarely holds more than a dozen candidates: copy the cell's slots to their place in
+// the dense, emission-ordered array
 __global__ __launch_bounds__(256) void k_gather(const CellDesc* __restrict__ cells, int nlevels, int n_cells,
                                                 const dcs_candidate* __restrict__ slots, size_t slots_per_image,
                                                 const int32_t* __restrict__ cell_count, const int32_t* __restrict__ cell_off,
                                                 const int32_t* __restrict__ lvl_off, dcs_candidate* __restrict__ dense, size_t dense_cap)
 {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), img = blockIdx.y, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4), img = blockIdx.y, sub = threadIdx.x & 15;
     if (c >= n_cells) return;
     const int n = cell_count[(size_t)img * n_cells + c];
     if (n == 0) return;
     const CellDesc cd = cells[c];
     const size_t dst0 = (size_t)lvl_off[img * nlevels + cd.level] + cell_off[(size_t)img * n_cells + c];
-    const dcs_candidate* src = slots + (size_t)img * slots_per_image + cd.slot_base;
-    for (int k = lane; k < n; k += 64)
-        if (dst0 + k < dense_cap) dense[dst0 + k] = src[k];
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(slots + (size_t)img * slots_per_image + cd.slot_base);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(dense);
+    for (int k = sub; k < n; k += 16)
+        if (dst0 + k < dense_cap) dst[dst0 + k] = src[k];
 }
 
 int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, int nlevels, int n_images, int n_cells,
@@ -410,7 +412,7 @@ int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, i
     hipLaunchKernelGGL(k_lvl_offsets, dim3(1), dim3(256), 0, s, d_lvl_total, n_images * nlevels, d_lvl_off);
     DCS_CHECK_LAUNCH();
     if (n_cells) {
-        hipLaunchKernelGGL(k_gather, dim3((n_cells + 3) / 4, n_images), dim3(256), 0, s, d_cells, nlevels, n_cells, d_slots, slots_per_image,
+        hipLaunchKernelGGL(k_gather, dim3((n_cells + 15) / 16, n_images), dim3(256), 0, s, d_cells, nlevels, n_cells, d_slots, slots_per_image,
                            d_cell_count, d_cell_off, d_lvl_off, d_dense, dense_cap);
         DCS_CHECK_LAUNCH();
     }
