@@ -66,12 +66,16 @@ __device__ __forceinline__ void resize_hrow(const uint8_t* __restrict__ row, boo
 }
 
 __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, const ResizeCol* __restrict__ cols,
-                                                const int16_t* __restrict__ yofs, const int16_t* __restrict__ ya)
+                                                const int16_t* __restrict__ yofs, const int16_t* __restrict__ ya, int n_images)
 {
-    const int img = blockIdx.z;
-    const int dx0 = (blockIdx.x * 64 + (int)threadIdx.x) * 4;
+    // lanes run over (image, destination dword) pairs: every image of the batch has the same geometry and row tables, so a
+    // wave stays uniform in y while its 64 lanes are all busy whatever the level width is (widths are not multiples of 256)
+    const int n_x4 = (dst.w + 3) >> 2;
+    const int li = blockIdx.x * 64 + (int)threadIdx.x;
+    const int img = li / n_x4;
+    const int dx0 = (li - img * n_x4) * 4;
     const int dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * kRsRowsPerThread;   // wave-uniform
-    if (dx0 >= dst.w || dy0 >= dst.h) return;
+    if (img >= n_images || dy0 >= dst.h) return;
     const uint8_t* S = src.base + (size_t)img * src.img_stride;
     uint8_t* D = const_cast<uint8_t*>(dst.base) + (size_t)img * dst.img_stride;
     const bool aligned = ((reinterpret_cast<uintptr_t>(S) | (uintptr_t)src.pitch) & 3) == 0 && src.pitch >= 12;
@@ -125,8 +129,9 @@ int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_c
 {
     (void)d_unused;
     if ((double)src.w / dst.w > 2.0) { set_error("pyramid scale factor > 2 not supported by the resize kernel"); return DCS_ERR_UNSUPPORTED; }
-    dim3 grid((dst.w + 255) / 256, (dst.h + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread), n_images);
-    hipLaunchKernelGGL(k_resize, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya);
+    const int n_x4 = (dst.w + 3) / 4;
+    dim3 grid((n_images * n_x4 + 63) / 64, (dst.h + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread));
+    hipLaunchKernelGGL(k_resize, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
