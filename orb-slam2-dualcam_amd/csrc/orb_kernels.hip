@@ -575,32 +575,60 @@ __device__ __forceinline__ bool level_aligned(const LevelView& v, int img)
 
 // interior strips: all 12 source bytes of every row lie inside the image row -> divergence-free dword path.
 // (an unaligned caller-owned level 0 takes the byte path for every lane instead)
-__global__ __launch_bounds__(64 * kBlurWaves) void k_blur(LevelSet src, LevelSet dst, int n_tiles_total)
+// Interior dwords (the 7-tap window of all 4 pixels lies inside the row): x0 = 4, 8, .. 4 n_int with n_int = (w - 8) / 4.
+// Lanes run over (image, interior dword) pairs -- every image of the batch shares the geometry, so the waves are full at
+// every level width and stay uniform in y; workgroup = 4 waves stacked in y (32 rows each). One launch for all levels:
+// blockIdx.x -> (level, lane block, strip block).
+__device__ __forceinline__ int blur_n_int(int w) { return w >= 12 ? (w - 8) / 4 : 0; }
+
+__global__ __launch_bounds__(64 * kBlurWaves) void k_blur(LevelSet src, LevelSet dst, int n_images)
 {
-    int t = blockIdx.x, l = 0, tiles_x = 0;
+    int t = blockIdx.x, l = 0, nbx = 0;
     for (; l < src.nlevels; ++l) {
-        tiles_x = (src.lv[l].w + kBlurW - 1) / kBlurW;
-        const int n = tiles_x * ((src.lv[l].h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
+        nbx = (n_images * blur_n_int(src.lv[l].w) + 63) / 64;
+        const int n = nbx * ((src.lv[l].h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
         if (t < n) break;
         t -= n;
     }
     if (l >= src.nlevels) return;
     const LevelView sv = src.lv[l], dv = dst.lv[l];
-    const int img = blockIdx.y;
-    const int x0 = (t % tiles_x) * kBlurW + 4 * (int)threadIdx.x;
-    const int y0 = (t / tiles_x) * (kBlurR * kBlurWaves) + kBlurR * (int)threadIdx.y;
-    if (y0 >= sv.h) return;                                                       // wave-uniform
+    const int n_int = blur_n_int(sv.w);
+    const int li = (t % nbx) * 64 + (int)threadIdx.x;
+    const int img = li / n_int;
+    const int x0 = 4 + 4 * (li - img * n_int);
+    const int y0 = (t / nbx) * (kBlurR * kBlurWaves) + kBlurR * (int)threadIdx.y;
+    if (y0 >= sv.h || img >= n_images) return;
+    if (!level_aligned(sv, img)) return;                                          // k_blur_unaligned_l0
     const uint8_t* S = sv.base + (size_t)img * sv.img_stride;
     uint8_t* D = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
-    if (!level_aligned(sv, img)) return;                                          // k_blur_unaligned_l0
-    const bool inside = x0 < sv.w, interior = x0 >= 4 && x0 + 7 <= sv.w - 1;
-    const bool yedge = y0 < 3 || y0 + kBlurR + 3 > sv.h;                          // wave-uniform
-    if (__all(!inside || interior)) {                                             // wave-uniform choice of the code path
-        if (inside) { if (yedge) blur_strip<kBlurInterior, true>(S, D, sv, dv, x0, y0); else blur_strip<kBlurInterior, false>(S, D, sv, dv, x0, y0); }
-    } else if (inside) {
-        if (sv.w >= 8) { if (yedge) blur_strip<kBlurEdge, true>(S, D, sv, dv, x0, y0); else blur_strip<kBlurEdge, false>(S, D, sv, dv, x0, y0); }   // first / last 256-px tile of a row
-        else blur_strip<kBlurBytes, true>(S, D, sv, dv, x0, y0);
+    if (y0 < 3 || y0 + kBlurR + 3 > sv.h) blur_strip<kBlurInterior, true>(S, D, sv, dv, x0, y0);      // wave-uniform
+    else blur_strip<kBlurInterior, false>(S, D, sv, dv, x0, y0);
+}
+
+// The dword columns whose window crosses the left / right image border (x0 = 0 and the last one or two dwords of a row,
+// <= 2 % of the pixels): lane = (image, 32-row strip, edge column), the same streaming strip with the reflected window
+// assembled in registers (v_perm selectors fixed per lane). Rows narrower than 8 pixels take the byte path.
+__global__ __launch_bounds__(64) void k_blur_edge_cols(LevelSet src, LevelSet dst, int n_images)
+{
+    int t = blockIdx.x * 64 + threadIdx.x, l = 0, n_edge = 0, n_strip = 0;
+    for (; l < src.nlevels; ++l) {
+        const int w = src.lv[l].w, n_x4 = (w + 3) / 4;
+        n_edge = n_x4 - blur_n_int(w);
+        n_strip = (src.lv[l].h + kBlurR - 1) / kBlurR;
+        const int n = n_images * n_strip * n_edge;
+        if (t < n) break;
+        t -= n;
     }
+    if (l >= src.nlevels) return;
+    const LevelView sv = src.lv[l], dv = dst.lv[l];
+    const int e = t % n_edge, strip = (t / n_edge) % n_strip, img = t / (n_edge * n_strip);
+    const int n_int = blur_n_int(sv.w);
+    const int x0 = e == 0 ? 0 : 4 * (n_int + e);                                   // dwords after the interior run
+    if (!level_aligned(sv, img)) return;
+    const uint8_t* S = sv.base + (size_t)img * sv.img_stride;
+    uint8_t* D = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
+    if (sv.w >= 8) blur_strip<kBlurEdge, true>(S, D, sv, dv, x0, strip * kBlurR);
+    else blur_strip<kBlurBytes, true>(S, D, sv, dv, x0, strip * kBlurR);
 }
 
 // caller-owned level 0 whose base / stride is not 4-byte aligned: byte path for every strip (rare; correctness only)
@@ -616,12 +644,14 @@ __global__ __launch_bounds__(64) void k_blur_unaligned_l0(LevelSet src, LevelSet
 
 int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStream_t s)
 {
-    int tiles = 0;
-    for (int l = 0; l < src.nlevels; ++l)
-        tiles += ((src.lv[l].w + kBlurW - 1) / kBlurW) * ((src.lv[l].h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
-    if (tiles == 0) return DCS_OK;
-    hipLaunchKernelGGL(k_blur, dim3(tiles, n_images), dim3(64, kBlurWaves), 0, s, src, dst, tiles);
-    DCS_CHECK_LAUNCH();
+    int blocks = 0, edge_lanes = 0;
+    for (int l = 0; l < src.nlevels; ++l) {
+        const int w = src.lv[l].w, h = src.lv[l].h, n_int = w >= 12 ? (w - 8) / 4 : 0;
+        blocks += ((n_images * n_int + 63) / 64) * ((h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
+        edge_lanes += n_images * ((h + kBlurR - 1) / kBlurR) * ((w + 3) / 4 - n_int);
+    }
+    if (blocks) { hipLaunchKernelGGL(k_blur, dim3(blocks), dim3(64, kBlurWaves), 0, s, src, dst, n_images); DCS_CHECK_LAUNCH(); }
+    if (edge_lanes) { hipLaunchKernelGGL(k_blur_edge_cols, dim3((edge_lanes + 63) / 64), dim3(64), 0, s, src, dst, n_images); DCS_CHECK_LAUNCH(); }
     if (((reinterpret_cast<uintptr_t>(src.lv[0].base) | (uintptr_t)src.lv[0].pitch | (uintptr_t)src.lv[0].img_stride) & 3) != 0) {
         hipLaunchKernelGGL(k_blur_unaligned_l0, dim3((src.lv[0].w + 255) / 256, (src.lv[0].h + kBlurR - 1) / kBlurR, n_images), dim3(64), 0, s, src, dst);
         DCS_CHECK_LAUNCH();
