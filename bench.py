@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=128, help="dual frames per step per GPU")
+    ap.add_argument("--pairs", type=int, default=256, help="dual frames per step per GPU")
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
