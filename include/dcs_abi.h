@@ -81,6 +81,11 @@ void dcs_orb_destroy(dcs_orb* h);
 int  dcs_orb_tables(const dcs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
                     int32_t* n_per_level);
 
+/* Smallest `cap` the extract calls accept for rows x cols images: the reference returns up to
+   sum over levels of max(N_level + 3, 4 * round(w/h)) keypoints (DistributeOctTree splits every initial node once
+   before it looks at N, ORBextractor.cc:594-673); *cap is that bound with a little slack per level. */
+int  dcs_orb_required_cap(const dcs_orb* h, int rows, int cols, int* cap);
+
 /* ORBextractor::operator()(image, mask (ignored), keypoints, descriptors).
    image: 8-bit single channel, `stride` bytes per row. kp[cap], desc[cap*32] caller-owned.
    rows/cols == 0 or image == NULL -> *n_out = 0, DCS_OK (ORBextractor.cc:1046-1047). */

@@ -23,7 +23,7 @@ SYMBOLS = [
     "dcs_last_error", "dcs_version", "dcs_device_count",
     "dcs_orb_create", "dcs_orb_destroy", "dcs_orb_tables", "dcs_orb_extract", "dcs_orb_extract_batch",
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
-    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
+    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
     "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
@@ -95,6 +95,7 @@ def lib():
             "dcs_orb_debug_level": [vp, ci, ci, ci, vp],
             "dcs_orb_debug_candidates": [vp, ci, ci, vp, ci, pci],
             "dcs_orb_debug_quadtree_fallbacks": [vp, pci],
+            "dcs_orb_required_cap": [vp, ci, ci, pci],
             "dcs_orb_last_timing": [vp, vp],
             "dcs_orb_timing_totals": [vp, vp, vp, ci],
             "dcs_distribute_octree": [vp, ci, ci, ci, ci, ci, ci, vp, ci, pci],
@@ -161,8 +162,15 @@ class ORBextractor:
         except Exception:
             pass
 
-    def default_cap(self):
+    def default_cap(self, rows=None, cols=None):
+        if rows and cols:
+            return self.required_cap(rows, cols)
         return self.nfeatures + 4 * self.nlevels + 64
+
+    def required_cap(self, rows, cols):
+        n = C.c_int()
+        _check(lib().dcs_orb_required_cap(self._h, rows, cols, C.byref(n)), "dcs_orb_required_cap")
+        return n.value
 
     def tables(self):
         n = self.nlevels
@@ -186,7 +194,7 @@ class ORBextractor:
         images = [_c(im, np.uint8) for im in images]
         n = len(images)
         rows, cols = images[0].shape if images[0].ndim == 2 else (0, 0)
-        cap = cap or self.default_cap()
+        cap = cap or max(self.default_cap(), self.required_cap(rows, cols) if rows and cols else 0)
         kp = np.zeros((n, cap), KEYPOINT)
         desc = np.zeros((n, cap, 32), np.uint8)
         n_out = np.zeros(n, np.int32)

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,15 @@
 #include "orb_kernels.h"
 
 namespace dcs {
+
+// Upper bound of the quadtree's node list for one level: the first pass splits all nIni = round(w/h) initial nodes before N
+// is looked at (<= 4 nIni nodes, ORBextractor.cc:594-673); every later pass stops at N + 3 at the latest.
+static int octree_list_bound(int width, int height, int n_target)
+{
+    const int n_ini = height > 0 ? (int)std::round((float)width / (float)height) : 0;
+    return std::max(n_target + 8, 4 * std::min(std::max(n_ini, 1), 255));
+}
+
 
 // ------------------------------------------------------------------ tiny persistent thread pool
 class Pool {
@@ -249,7 +259,7 @@ int dcs_orb::configure(int rows, int cols)
         OctLevel& ol = oct.lv[l];
         ol.width = (g.lv[l].w - kEdgeThreshold + 3) - kMinBorder; ol.height = (g.lv[l].h - kEdgeThreshold + 3) - kMinBorder;
         ol.n_target = t.n_per_level[l];
-        ol.out_base = out_total; ol.out_cap = t.n_per_level[l] + 8;     // the list never exceeds N + 3 (or 4 initial nodes)
+        ol.out_base = out_total; ol.out_cap = octree_list_bound(ol.width, ol.height, ol.n_target);
         out_total += ol.out_cap;
     }
     oct.out_per_image = out_total;
@@ -346,7 +356,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     if (device_octree) {
         // fully asynchronous: quadtree on the device, no host round trip
         if (cap < oct.out_per_image) {
-            set_error("cap %d < %d (nfeatures + 8 per level): required by the device quadtree path", cap, oct.out_per_image);
+            set_error("cap %d < %d (sum over levels of max(N_level + 8, 4 * initial nodes)): required by the device quadtree path", cap, oct.out_per_image);
             return DCS_ERR_CAPACITY;
         }
         OctScratch sc{d_oct_u64[0].p, d_oct_u8.p, d_oct_i32[0].p, d_oct_i32[1].p, d_oct_i32[2].p, d_oct_i32[3].p, d_oct_i32[4].p,
@@ -487,6 +497,18 @@ int dcs_orb_tables(const dcs_orb* h, float* scale, float* inv_scale, float* sigm
         if (inv_sigma2) inv_sigma2[i] = h->t.inv_sigma2[i];
         if (n_per_level) n_per_level[i] = h->t.n_per_level[i];
     }
+    return DCS_OK;
+}
+
+int dcs_orb_required_cap(const dcs_orb* h, int rows, int cols, int* cap)
+{
+    if (!h || !cap || rows < 1 || cols < 1) { set_error("dcs_orb_required_cap: bad arguments"); return DCS_ERR_INVALID; }
+    PyramidGeom g;
+    g.build(h->t, rows, cols);
+    int total = 0;
+    for (int l = 0; l < h->t.nlevels; ++l)
+        total += octree_list_bound((g.lv[l].w - kEdgeThreshold + 3) - kMinBorder, (g.lv[l].h - kEdgeThreshold + 3) - kMinBorder, h->t.n_per_level[l]);
+    *cap = total;
     return DCS_OK;
 }
 

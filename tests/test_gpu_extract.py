@@ -181,6 +181,28 @@ def test_deep_quadtree_leaves_the_histogram_fast_path(pkg, oracle, synth):
     e.close()
 
 
+def test_wide_image_with_small_quota(pkg, oracle, synth):
+    """Wide, short images start the quadtree from round(w/h) >= 3 initial nodes and the reference splits all of them once
+    before it looks at the quota (ORBextractor.cc:594-673): with a small per-level quota a level keeps up to 4 * nIni
+    keypoints, more than N + 3. Found by scratch/stress_parity.py; the output slots are sized for it now."""
+    src = synth.frame_pair(1280, 720, 0, 0)[0]
+    exceeded = 0
+    for (w, h, nf, nl, sf, ini, mn) in [(836, 144, 68, 4, 1.27, 21, 17), (706, 199, 62, 9, 1.129, 37, 26), (650, 253, 73, 9, 1.174, 33, 20),
+                                        (757, 176, 258, 9, 1.1255, 29, 26)]:
+        img = np.ascontiguousarray(src[100:100 + h, 200:200 + w])
+        e = pkg.ORBextractor(nf, sf, nl, ini, mn, max_images=1)
+        need = e.required_cap(h, w)
+        assert need > nf + 8 * nl
+        with pytest.raises(pkg.DcsError):
+            e.extract_batch([img], cap=nf + 8 * nl)
+        kp, desc = e(img)
+        okp, odesc = oracle.OrbOracle(nf, sf, nl, ini, mn).extract(img, cap=need)
+        exceeded += len(okp) > nf + 8 * nl
+        _same(kp, desc, okp, odesc)
+        e.close()
+    assert exceeded >= 1
+
+
 def test_device_api_unaligned_pointer_and_stride(pkg, oracle, synth):
     """HBM-resident input that is neither 4-byte aligned nor 4-byte strided (byte-wise fallback loads)."""
     import torch
