@@ -279,6 +279,8 @@ class ORBmatcher:
     def knn2_grouped(q, t, q_off, q_idx, t_off, t_idx):
         q, t = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
         q_off, q_idx, t_off, t_idx = (_c(a, np.int32) for a in (q_off, q_idx, t_off, t_idx))
+        if len(q_off) != len(t_off) or len(q_off) < 1:
+            raise ValueError("q_off and t_off describe the same groups: equal lengths (n_groups + 1) expected")
         nq = len(q)
         bi, bd, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(3))
         _check(lib().dcs_hamming_knn2_grouped(_p(q), nq, _p(t), len(t), len(q_off) - 1, _p(q_off), _p(q_idx), _p(t_off),

@@ -602,12 +602,26 @@ int dcs_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const u
     return DCS_OK;
 }
 
+// CSR lists handed over by the caller (feature vectors, observation lists): offsets ascending from 0, indices inside [0, n_items)
+static bool valid_csr(const int32_t* off, int n_groups, const int32_t* idx, int n_items)
+{
+    if (n_groups == 0) return true;
+    if (off[0] != 0) return false;
+    for (int g = 0; g < n_groups; ++g) if (off[g + 1] < off[g]) return false;
+    if (off[n_groups] && !idx) return false;
+    for (int i = 0; i < off[n_groups]; ++i) if (idx[i] < 0 || idx[i] >= n_items) return false;
+    return true;
+}
+
 int dcs_hamming_knn2_grouped(const uint8_t* q, int nq, const uint8_t* t, int nt, int n_groups, const int32_t* q_off,
                              const int32_t* q_idx, const int32_t* t_off, const int32_t* t_idx, int32_t* best_idx,
                              int32_t* best_d, int32_t* second_d)
 {
     if (nq < 0 || nt < 0 || n_groups < 0 || (n_groups && (!q_off || !t_off)) || (nq && (!q || !best_idx || !best_d || !second_d))) {
         set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    if (!valid_csr(q_off, n_groups, q_idx, nq) || !valid_csr(t_off, n_groups, t_idx, nt)) {
+        set_error("dcs_hamming_knn2_grouped: offsets must ascend from 0 and indices lie inside the descriptor arrays"); return DCS_ERR_INVALID;
     }
     int rc = ensure_device();
     if (rc) return rc;
@@ -745,6 +759,9 @@ int dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_t
     if (n_kf < 0 || n_f < 0 || kf_n_nodes < 0 || f_n_nodes < 0 || !n_matches || (n_f && (!match_f || !desc_f)) || (n_kf && (!desc_kf || !kf_valid)) ||
         (kf_n_nodes && (!kf_nodes || !kf_off || !kf_idx)) || (f_n_nodes && (!f_nodes || !f_off || !f_idx)) || (check_ori && ((n_kf && !ang_kf) || (n_f && !ang_f)))) {
         set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    if (!valid_csr(kf_off, kf_n_nodes, kf_idx, n_kf) || !valid_csr(f_off, f_n_nodes, f_idx, n_f)) {
+        set_error("dcs_search_by_bow: feature-vector offsets must ascend from 0 and indices lie inside the descriptor arrays"); return DCS_ERR_INVALID;
     }
     int rc = ensure_device();
     if (rc) return rc;

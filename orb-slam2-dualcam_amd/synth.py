@@ -209,6 +209,8 @@ def ba_problem(n_poses=50, n_fixed=10, n_points=2000, obs_per_point=10, seed=42,
     """
     rng = np.random.default_rng(seed)
     P, L = n_poses, n_points
+    if obs_per_point > P:
+        raise ValueError("obs_per_point %d > n_poses %d" % (obs_per_point, P))
     T0, T1 = rig_extrinsics_f32()
     cams = []
     for c, T in enumerate((T0, T1)):
@@ -307,7 +309,7 @@ def pose_problem(n_frames=16, obs_per_frame=400, seed=5, outlier_frac=0.1, point
     pose f of a ba_problem scene, observing `obs_per_frame` map points with the dual-camera rig; map points carry a
     small error (they are float32 state of the map), observations octave-dependent noise + gross outliers, the initial
     pose is the motion-model guess (perturbed ground truth). Frames 0/1 are degenerate on purpose (2 and 9 edges)."""
-    per_point = 6
+    per_point = min(6, n_frames)
     n_points = max(60, n_frames * obs_per_frame // per_point + 50)
     ba = ba_problem(n_poses=n_frames, n_fixed=0, n_points=n_points, obs_per_point=per_point, seed=seed, outlier_frac=outlier_frac)
     rng = np.random.default_rng(seed + 1000)

@@ -62,3 +62,14 @@ def test_host_helpers_without_gpu(pkg, oracle, synth):
     h = C.c_void_p()
     assert pkg.abi.lib().dcs_orb_create(C.byref(bad), C.byref(h)) == pkg.abi.DCS_ERR_INVALID
     assert b"bad ORB parameters" in pkg.abi.lib().dcs_last_error()
+    # malformed CSR lists (feature vectors) are rejected before anything is sent to the GPU
+    q = np.zeros((4, 32), np.uint8)
+    out = [np.zeros(4, np.int32) for _ in range(3)]
+    good_off, idx = np.array([0, 2, 4], np.int32), np.array([0, 1, 2, 3], np.int32)
+    for off, ix in [(np.array([0, 3, 2], np.int32), idx), (np.array([1, 2, 4], np.int32), idx), (good_off, np.array([0, 1, 2, 4], np.int32)),
+                    (good_off, np.array([0, -1, 2, 3], np.int32))]:
+        rc = pkg.abi.lib().dcs_hamming_knn2_grouped(q.ctypes.data, 4, q.ctypes.data, 4, 2, good_off.ctypes.data, idx.ctypes.data, off.ctypes.data,
+                                                    ix.ctypes.data, *[o.ctypes.data for o in out])
+        assert rc == pkg.abi.DCS_ERR_INVALID
+    with pytest.raises(ValueError):
+        pkg.ORBmatcher.knn2_grouped(q, q, good_off, idx, good_off[:2], idx[:2])
