@@ -11,8 +11,8 @@ n_ext = n_match = bad = 0
 big = [synth.frame_pair(1280, 720, s, f) for s in range(2) for f in range(2)]
 while time.time() < t_end:
     # ---- extraction
-    w, h = int(rng.integers(120, 900)), int(rng.integers(100, 700))
-    nf = int(rng.integers(50, 2600)); nl = int(rng.integers(2, 11)); sf = float(np.float32(rng.uniform(1.08, 1.7)))
+    w, h = (int(rng.integers(120, 900)), int(rng.integers(100, 700))) if rng.random() < 0.9 else (int(rng.integers(900, 1281)), int(rng.integers(500, 721)))
+    nf = int(rng.integers(50, 2600)); nl = int(rng.integers(1, 13)); sf = float(np.float32(rng.uniform(1.03, 1.9)))
     ini = int(rng.integers(8, 40)); mn = int(rng.integers(2, ini + 1))
     src = big[int(rng.integers(0, 4))][int(rng.integers(0, 2))]
     y0, x0 = int(rng.integers(0, 720 - h + 1)), int(rng.integers(0, 1280 - w + 1))
@@ -21,15 +21,17 @@ while time.time() < t_end:
     if mode == 1: img = (img // 64 * 64).astype(np.uint8)              # posterised: many ties
     if mode == 2: img = rng.integers(0, 256, img.shape, dtype=np.uint8)  # noise
     try:
-        ext = pkg.ORBextractor(nf, sf, nl, ini, mn, max_images=2)
+        nb = int(rng.integers(1, 6))
+        ext = pkg.ORBextractor(nf, sf, nl, ini, mn, max_images=nb)
     except pkg.DcsError:
         continue
     try:
         cap = ext.required_cap(h, w)
-        kps, descs = ext.extract_batch([img, img[::-1].copy()], cap=cap)
+        imgs = [img, img[::-1].copy(), img[:, ::-1].copy(), (255 - img), np.roll(img, 7, axis=1)][:nb]
+        kps, descs = ext.extract_batch(imgs, cap=cap)
     except pkg.DcsError as ex:
         ext.close(); continue                                             # image too small for the pyramid etc.
-    for i, im in enumerate((img, img[::-1].copy())):
+    for i, im in enumerate(imgs):
         okp, od = oracle.OrbOracle(nf, sf, nl, ini, mn).extract(im, cap=cap)
         if kps[i].tobytes() != okp.tobytes() or not np.array_equal(descs[i], od):
             bad += 1; print("EXTRACT MISMATCH", w, h, nf, nl, sf, ini, mn, mode, i, len(kps[i]), len(okp), flush=True)
