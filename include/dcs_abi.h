@@ -300,6 +300,41 @@ int  dcs_rig_adjoint(const float T44[16], int exact, double ext7[7], double adj3
 int  dcs_pose_from_matrix(const float T44[16], double pose7[7]);
 int  dcs_pose_to_matrix(const double pose7[7], float T44[16]);
 
+/* ---------------------------------------------------------------------------------------------------------------
+   BoW front half: DBoW2 vocabulary tree in HBM, transform -> BowVector + FeatureVector, L1 score.
+   Replaces ORBVocabulary::transform as called by Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:393-406,
+   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1151-1283) and ORBVocabulary::score (ScoringObject.cpp:23-67) as called by
+   KeyFrameDatabase (src/KeyFrameDatabase.cc:250-372). */
+typedef struct dcs_vocab dcs_vocab;
+
+/* The vocabulary as the columns of the reference's text format (loadFromTextFile, TemplatedVocabulary.h:1362-1446): row i
+   describes node i + 1 (node 0 = root): parent id, leaf flag, 32-byte descriptor, weight. scoring / weighting are the DBoW2
+   enums (L1_NORM = 0 ..., TF_IDF = 0, TF, IDF, BINARY). A row's leaf flag must agree with "has no children". */
+int  dcs_vocab_create(int k, int L, int scoring, int weighting, int n_rows, const int32_t* parent, const uint8_t* is_leaf,
+                      const uint8_t* desc, const double* weight, dcs_vocab** out);
+void dcs_vocab_destroy(dcs_vocab* v);
+int  dcs_vocab_info(const dcs_vocab* v, int* k, int* L, int* n_nodes, int* n_words);
+
+/* transform(features, BowVector, FeatureVector, levelsup) for n_images images whose descriptors sit in HBM in the extractor's
+   slotted layout (image i: d_desc + i*cap*32, count d_n[i]); cap <= 4096. Outputs, slotted the same way:
+     d_word / d_node / d_weight [n_images*cap]   per feature: word id, node id at level L - levelsup, word weight
+                                                 (-1 / -1 for stopped words, weight <= 0)
+     d_bow_word / d_bow_val [n_images*cap], d_bow_n[n_images]            BowVector: ascending word ids, normalised values
+     d_fv_node [n_images*cap], d_fv_off [n_images*(cap+1)], d_fv_idx [n_images*cap], d_fv_n[n_images]
+                                                 FeatureVector as CSR: ascending node ids, feature indices ascending per node
+   (the input format of dcs_search_by_bow / dcs_hamming_knn2_grouped). Values are bit-identical to the reference's doubles. */
+int  dcs_bow_transform_device(const dcs_vocab* v, const uint8_t* d_desc, const int32_t* d_n, int n_images, int cap, int levelsup,
+                              int32_t* d_word, int32_t* d_node, double* d_weight, int32_t* d_bow_word, double* d_bow_val,
+                              int32_t* d_bow_n, int32_t* d_fv_node, int32_t* d_fv_off, int32_t* d_fv_idx, int32_t* d_fv_n,
+                              void* stream);
+/* one image from host memory; arrays sized n (fv_off n + 1); word / node may be NULL */
+int  dcs_bow_transform(const dcs_vocab* v, const uint8_t* desc, int n, int levelsup, int32_t* word, int32_t* node,
+                       int32_t* bow_word, double* bow_val, int* n_words, int32_t* fv_node, int32_t* fv_off, int32_t* fv_idx,
+                       int* n_nodes);
+/* L1Scoring::score of one BowVector against n_db BowVectors stored as CSR (db_off[n_db+1]); score[n_db] in [0, 1] */
+int  dcs_bow_score_l1(const int32_t* q_word, const double* q_val, int nq, const int32_t* db_off, const int32_t* db_word,
+                      const double* db_val, int n_db, double* score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,6 +220,26 @@ void orc_se3_oplus(const double pose_in[7], const double update[6], double pose_
 /* Cameras::setExtrinsics adjoint (Cameras.cc:27-37) from a float 4x4 T (row-major), LL block = 0 */
 void orc_rig_adjoint(const float T44[16], int exact, double adj36[36], double ext7[7]);
 
+/* ---------------------------------------------------------------------------------------------------------------
+   BoW front half: DBoW2 vocabulary tree, transform -> BowVector + FeatureVector, L1 score.
+   The vocabulary is given as the columns of the reference's text format (TemplatedVocabulary.h:1362-1446): row i
+   describes node i + 1 (node 0 = root): parent id, leaf flag, 32-byte descriptor, weight. Children of a node are
+   visited in row order (m_nodes[pid].children.push_back(nid), :1416); word ids count the leaves in row order (:1434). */
+typedef struct orc_vocab orc_vocab;
+orc_vocab* orc_vocab_create(int k, int L, int scoring, int weighting, int n_rows, const int32_t* parent, const uint8_t* is_leaf,
+                            const uint8_t* desc, const double* weight);
+void orc_vocab_destroy(orc_vocab* v);
+int  orc_vocab_words(const orc_vocab* v);
+/* TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) (:1151-1228) for one image.
+   word[n] / node[n]: per-feature word id and node id at level L - levelsup (-1 / -1 for a stopped word);
+   BowVector = (bow_word ascending, bow_val), FeatureVector = (fv_node ascending, fv_off[n_nodes+1], fv_idx).
+   All arrays sized n (fv_off n + 1). Returns 0, or -1 for an unsupported scoring type. */
+int  orc_bow_transform(const orc_vocab* v, const uint8_t* desc, int n, int levelsup, int32_t* word, int32_t* node,
+                       int32_t* bow_word, double* bow_val, int* n_words, int32_t* fv_node, int32_t* fv_off, int32_t* fv_idx, int* n_nodes);
+/* L1Scoring::score (ScoringObject.cpp:23-67) of one BowVector against n_db BowVectors stored as CSR */
+void orc_bow_score_l1(const int32_t* q_word, const double* q_val, int nq, const int32_t* db_off, const int32_t* db_word,
+                      const double* db_val, int n_db, double* score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,12 @@ def lib():
         L.orc_ba_edge_jacobian.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BaCamera), C.c_void_p, C.c_void_p]
         L.orc_se3_oplus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rig_adjoint.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_vocab_create.restype = C.c_void_p
+        L.orc_vocab_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_vocab_destroy.argtypes = [C.c_void_p]
+        L.orc_vocab_words.argtypes = [C.c_void_p]
+        L.orc_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + [C.POINTER(C.c_int)]
+        L.orc_bow_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -434,3 +440,47 @@ def ba_local(prob, stop_flag=None):
     return dict(poses=out_poses, points=out_points, edge_chi2=chi2, edge_outlier=outl, edge_level1=lvl1,
                 n_iters=list(res.n_iters), n_trials=list(res.n_trials), lambda_=list(res.lambda_),
                 chi2_trace=np.array(res.chi2_trace))
+
+
+class Vocabulary:
+    """DBoW2 vocabulary tree from the columns of the reference's text format (row i = node i + 1)."""
+
+    def __init__(self, k, L, parent, is_leaf, desc, weight, scoring=0, weighting=0):
+        parent, is_leaf = _c(parent, np.int32), _c(is_leaf, np.uint8)
+        desc, weight = _c(desc, np.uint8).reshape(-1, 32), _c(weight, np.float64)
+        self._h = lib().orc_vocab_create(k, L, scoring, weighting, len(parent), _p(parent), _p(is_leaf), _p(desc), _p(weight))
+        if not self._h:
+            raise ValueError("bad vocabulary")
+        self.k, self.L = k, L
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.orc_vocab_destroy(self._h)
+            self._h = None
+
+    def n_words(self):
+        return lib().orc_vocab_words(self._h)
+
+    def transform(self, desc, levelsup=4):
+        """-> dict(word[n], node[n], bow_word, bow_val, fv_node, fv_off, fv_idx)"""
+        desc = _c(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        m = max(n, 1)
+        word, node, bw, fn, fi = (np.zeros(m, np.int32) for _ in range(5))
+        fo = np.zeros(m + 1, np.int32)
+        bv = np.zeros(m)
+        nw, nn = C.c_int(), C.c_int()
+        rc = lib().orc_bow_transform(self._h, _p(desc), n, levelsup, _p(word), _p(node), _p(bw), _p(bv), C.byref(nw), _p(fn), _p(fo), _p(fi), C.byref(nn))
+        if rc != 0:
+            raise RuntimeError("orc_bow_transform rc=%d" % rc)
+        return dict(word=word[:n], node=node[:n], bow_word=bw[:nw.value].copy(), bow_val=bv[:nw.value].copy(), fv_node=fn[:nn.value].copy(),
+                    fv_off=fo[:nn.value + 1].copy(), fv_idx=fi[:fo[nn.value]].copy())
+
+
+def bow_score_l1(q_word, q_val, db_off, db_word, db_val):
+    q_word, q_val = _c(q_word, np.int32), _c(q_val, np.float64)
+    db_off, db_word, db_val = _c(db_off, np.int32), _c(db_word, np.int32), _c(db_val, np.float64)
+    n_db = len(db_off) - 1
+    score = np.zeros(max(n_db, 1))
+    lib().orc_bow_score_l1(_p(q_word), _p(q_val), len(q_word), _p(db_off), _p(db_word), _p(db_val), n_db, _p(score))
+    return score[:n_db]

@@ -27,6 +27,7 @@ SYMBOLS = [
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
     "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
+    "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
 ]
 
 
@@ -113,6 +114,12 @@ def lib():
             "dcs_rig_adjoint": [vp, ci, vp, vp],
             "dcs_pose_from_matrix": [vp, vp],
             "dcs_pose_to_matrix": [vp, vp],
+            "dcs_vocab_create": [ci, ci, ci, ci, ci, vp, vp, vp, vp, C.POINTER(vp)],
+            "dcs_vocab_destroy": [vp],
+            "dcs_vocab_info": [vp, pci, pci, pci, pci],
+            "dcs_bow_transform_device": [vp, vp, vp, ci, ci, ci] + [vp] * 11,
+            "dcs_bow_transform": [vp, vp, ci, ci, vp, vp, vp, vp, pci, vp, vp, vp, pci],
+            "dcs_bow_score_l1": [vp, vp, ci, vp, vp, vp, ci, vp],
         }
         for name, argtypes in sigs.items():
             fn = getattr(L, name, None)       # a missing symbol is reported by tests/test_abi_symbols.py
@@ -120,6 +127,8 @@ def lib():
                 fn.argtypes = argtypes
         if hasattr(L, "dcs_orb_destroy"):
             L.dcs_orb_destroy.restype = None
+        if hasattr(L, "dcs_vocab_destroy"):
+            L.dcs_vocab_destroy.restype = None
         _lib = L
     return _lib
 
@@ -507,3 +516,79 @@ class Optimizer:
         if prep is not prob:                               # one-shot call: the caller owns the outputs
             return out
         return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in out.items()}
+
+
+class ORBVocabulary:
+    """ORB_SLAM2::ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h:31-32) with the
+    tree resident in HBM: transform (Frame::ComputeBoW, src/Frame.cc:393-406) and score (KeyFrameDatabase.cc:250-372)."""
+    L1_NORM, TF_IDF = 0, 0
+
+    def __init__(self, k, L, parent, is_leaf, desc, weight, scoring=0, weighting=0):
+        parent, is_leaf = _c(parent, np.int32), _c(is_leaf, np.uint8)
+        desc, weight = _c(desc, np.uint8).reshape(-1, 32), _c(weight, np.float64)
+        if not (len(parent) == len(is_leaf) == len(desc) == len(weight)):
+            raise ValueError("vocabulary columns differ in length")
+        self._h = C.c_void_p()
+        _check(lib().dcs_vocab_create(k, L, scoring, weighting, len(parent), _p(parent), _p(is_leaf), _p(desc), _p(weight), C.byref(self._h)),
+               "dcs_vocab_create")
+
+    @classmethod
+    def loadFromTextFile(cls, path):
+        from . import synth
+        v = synth.vocabulary_from_text(path)
+        return cls(v["k"], v["L"], v["parent"], v["is_leaf"], v["desc"], v["weight"], v["scoring"], v["weighting"])
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.dcs_vocab_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def info(self):
+        k, L, nn, nw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(lib().dcs_vocab_info(self._h, C.byref(k), C.byref(L), C.byref(nn), C.byref(nw)), "dcs_vocab_info")
+        return dict(k=k.value, L=L.value, n_nodes=nn.value, n_words=nw.value)
+
+    def transform(self, desc, levelsup=4):
+        """one image -> dict(word[n], node[n], bow_word, bow_val, fv_node, fv_off, fv_idx)"""
+        desc = _c(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        m = max(n, 1)
+        word, node, bw, fn, fi = (np.zeros(m, np.int32) for _ in range(5))
+        fo = np.zeros(m + 1, np.int32)
+        bv = np.zeros(m)
+        nw, nn = C.c_int(), C.c_int()
+        _check(lib().dcs_bow_transform(self._h, _p(desc), n, levelsup, _p(word), _p(node), _p(bw), _p(bv), C.byref(nw), _p(fn), _p(fo), _p(fi),
+                                       C.byref(nn)), "dcs_bow_transform")
+        return dict(word=word[:n], node=node[:n], bow_word=bw[:nw.value].copy(), bow_val=bv[:nw.value].copy(), fv_node=fn[:nn.value].copy(),
+                    fv_off=fo[:nn.value + 1].copy(), fv_idx=fi[:fo[nn.value]].copy())
+
+    def transform_device(self, d_desc, d_n, cap, out, levelsup=4, stream=None):
+        """d_desc torch uint8 [n_images, cap, 32], d_n int32 [n_images]; `out` = dict of preallocated torch buffers
+        (see bow_buffers)."""
+        n_images = d_desc.shape[0]
+        _check(lib().dcs_bow_transform_device(self._h, d_desc.data_ptr(), d_n.data_ptr(), n_images, cap, levelsup, out["word"].data_ptr(),
+                                              out["node"].data_ptr(), out["weight"].data_ptr(), out["bow_word"].data_ptr(), out["bow_val"].data_ptr(),
+                                              out["bow_n"].data_ptr(), out["fv_node"].data_ptr(), out["fv_off"].data_ptr(), out["fv_idx"].data_ptr(),
+                                              out["fv_n"].data_ptr(), stream), "dcs_bow_transform_device")
+
+    @staticmethod
+    def bow_buffers(n_images, cap, device="cuda"):
+        import torch
+        i32 = dict(dtype=torch.int32, device=device)
+        f64 = dict(dtype=torch.float64, device=device)
+        return dict(word=torch.zeros((n_images, cap), **i32), node=torch.zeros((n_images, cap), **i32), weight=torch.zeros((n_images, cap), **f64),
+                    bow_word=torch.zeros((n_images, cap), **i32), bow_val=torch.zeros((n_images, cap), **f64), bow_n=torch.zeros(n_images, **i32),
+                    fv_node=torch.zeros((n_images, cap), **i32), fv_off=torch.zeros((n_images, cap + 1), **i32),
+                    fv_idx=torch.zeros((n_images, cap), **i32), fv_n=torch.zeros(n_images, **i32))
+
+    @staticmethod
+    def score(q_word, q_val, db_off, db_word, db_val):
+        """L1 score of one BowVector against a CSR database of BowVectors -> float64 [n_db]"""
+        q_word, q_val = _c(q_word, np.int32), _c(q_val, np.float64)
+        db_off, db_word, db_val = _c(db_off, np.int32), _c(db_word, np.int32), _c(db_val, np.float64)
+        n_db = len(db_off) - 1
+        score = np.zeros(max(n_db, 1))
+        _check(lib().dcs_bow_score_l1(_p(q_word), _p(q_val), len(q_word), _p(db_off), _p(db_word), _p(db_val), n_db, _p(score)), "dcs_bow_score_l1")
+        return score[:n_db]

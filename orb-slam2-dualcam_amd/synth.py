@@ -377,3 +377,103 @@ def projection_problem(n_per_cam=900, n_queries=700, seed=13, th=1.0, big_window
     queries = dict(valid=valid, cam=cam, u=u, v=v, radius=radius, min_level=(level - 1).astype(np.int32),
                    max_level=(level + 1).astype(np.int32), desc=qdesc, angle=qangle)
     return frame, queries
+
+
+# ----------------------------------------------------------------------------- BoW vocabulary
+def vocabulary(k=10, L=6, seed=1, flip=24, ragged=0.0, early_leaf=0.0, stop_frac=0.0, dup_frac=0.0):
+    """Synthetic DBoW2 vocabulary in the column form of the reference's text file (TemplatedVocabulary.h:1362-1446; the real
+    ORBvoc.txt is an external download, Vocabulary/download_link.txt): row i = node i + 1 -> (parent, is_leaf, desc[32], weight).
+    A k-ary tree of depth L built breadth-first (children of a node are consecutive rows, as DBoW2's k-means training numbers
+    them); a child's descriptor = the parent's with ~`flip`/depth random bits flipped, so the greedy descent is meaningful.
+    ragged: probability that an inner node has fewer than k children; early_leaf: probability that a node above depth L is a
+    leaf; stop_frac: leaves with weight 0 (stopped words); dup_frac: children that copy a sibling's descriptor (ties -> the
+    first child wins). Returns dict(k, L, parent, is_leaf, desc, weight, depth)."""
+    rng = np.random.default_rng(seed)
+    parent, is_leaf, desc, depth = [], [], [], []
+    frontier = [(0, np.zeros(32, np.uint8), 0)]                   # (node id, descriptor, depth); root descriptor unused
+    n_nodes = 1
+    while frontier:
+        nxt = []
+        for (nid, d, dep) in frontier:
+            n_kids = k if (dep == 0 or rng.random() >= ragged) else int(rng.integers(1, k + 1))
+            kids = []
+            for c in range(n_kids):
+                if dep == 0:
+                    cd = rng.integers(0, 256, 32, dtype=np.uint8)
+                elif kids and rng.random() < dup_frac:
+                    cd = kids[int(rng.integers(0, len(kids)))].copy()
+                else:
+                    bits = np.unpackbits(d)
+                    nflip = max(1, int(flip // (dep + 1)) + int(rng.integers(0, 4)))
+                    bits[rng.choice(256, nflip, replace=False)] ^= 1
+                    cd = np.packbits(bits)
+                kids.append(cd)
+                leaf = (dep + 1 == L) or (dep + 1 >= 2 and rng.random() < early_leaf)
+                parent.append(nid); is_leaf.append(1 if leaf else 0); desc.append(cd); depth.append(dep + 1)
+                if not leaf:
+                    nxt.append((n_nodes, cd, dep + 1))
+                n_nodes += 1
+        frontier = nxt
+    is_leaf = np.asarray(is_leaf, np.uint8)
+    weight = np.zeros(len(parent))
+    nl = int(is_leaf.sum())
+    w = rng.uniform(0.3, 9.0, nl)                                  # idf-like: -log(Ni/N)
+    w[rng.random(nl) < stop_frac] = 0.0
+    weight[is_leaf != 0] = w
+    return dict(k=k, L=L, parent=np.asarray(parent, np.int32), is_leaf=is_leaf, desc=np.asarray(desc, np.uint8).reshape(-1, 32),
+                weight=weight, depth=np.asarray(depth, np.int32))
+
+
+def vocabulary_fast(k=10, L=6, seed=1, flip=24):
+    """Full k-ary tree like vocabulary() but vectorised level by level (for the k = 10, L = 6 size: 1.1 M nodes)."""
+    rng = np.random.default_rng(seed)
+    parents, descs, leafs = [], [], []
+    prev_ids = np.zeros(1, np.int64); prev_desc = np.zeros((1, 32), np.uint8)
+    next_id = 1
+    for dep in range(L):
+        n_par = len(prev_ids)
+        par = np.repeat(prev_ids, k)
+        if dep == 0:
+            d = rng.integers(0, 256, (n_par * k, 32), dtype=np.uint8)
+        else:
+            bits = np.unpackbits(np.repeat(prev_desc, k, axis=0), axis=1)
+            nflip = max(1, flip // (dep + 1))
+            cols = rng.integers(0, 256, (n_par * k, nflip))
+            np.put_along_axis(bits, cols, 1 - np.take_along_axis(bits, cols, 1), 1)
+            d = np.packbits(bits, axis=1)
+        ids = np.arange(next_id, next_id + n_par * k)
+        next_id += n_par * k
+        parents.append(par); descs.append(d); leafs.append(np.full(n_par * k, 1 if dep + 1 == L else 0, np.uint8))
+        prev_ids, prev_desc = ids, d
+    # rows must be in node-id order: breadth-first numbering already is
+    parent = np.concatenate(parents).astype(np.int32); desc = np.concatenate(descs); is_leaf = np.concatenate(leafs)
+    weight = np.zeros(len(parent)); nl = int(is_leaf.sum()); weight[is_leaf != 0] = rng.uniform(0.3, 9.0, nl)
+    return dict(k=k, L=L, parent=parent, is_leaf=is_leaf, desc=desc, weight=weight)
+
+
+def vocabulary_to_text(voc, path, scoring=0, weighting=0):
+    """saveToTextFile (TemplatedVocabulary.h:1451-1480): 'k L  scoring weighting' then 'parent leaf b0 .. b31 weight' per node."""
+    with open(path, "w") as f:
+        f.write("%d %d  %d %d\n" % (voc["k"], voc["L"], scoring, weighting))
+        for i in range(len(voc["parent"])):
+            f.write("%d %d %s %r\n" % (voc["parent"][i], voc["is_leaf"][i], " ".join(str(int(b)) for b in voc["desc"][i]), float(voc["weight"][i])))
+
+
+def vocabulary_from_text(path):
+    """loadFromTextFile (TemplatedVocabulary.h:1362-1446) -> the column form."""
+    with open(path) as f:
+        k, L, n1, n2 = (int(x) for x in f.readline().split())
+        rows = [ln.split() for ln in f if ln.strip()]
+    parent = np.array([int(r[0]) for r in rows], np.int32)
+    is_leaf = np.array([1 if int(r[1]) > 0 else 0 for r in rows], np.uint8)
+    desc = np.array([[int(x) for x in r[2:34]] for r in rows], np.uint8).reshape(-1, 32)
+    weight = np.array([float(r[34]) for r in rows])
+    return dict(k=k, L=L, parent=parent, is_leaf=is_leaf, desc=desc, weight=weight, scoring=n1, weighting=n2)
+
+
+def descriptors_near_words(voc, n, seed=3, flip=10):
+    """n descriptors: noisy copies of random leaf descriptors (so the descent lands in populated parts of the tree)."""
+    rng = np.random.default_rng(seed)
+    leaves = np.nonzero(voc["is_leaf"])[0]
+    d = voc["desc"][leaves[rng.integers(0, len(leaves), n)]].copy()
+    return noisy_copy(d, flip_bits=flip, seed=seed + 1)
