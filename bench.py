@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-bow", action="store_true")
     ap.add_argument("--lanes", type=int, default=1, help="independent extractor handles/streams the batch is split over (overlaps latency-bound kernels)")
     args = ap.parse_args()
 
@@ -296,6 +297,39 @@ def main():
                                   "sample": "%d solves of the C4 problem in %.1f s, oracle -O3 single thread (dense LDLT)" % (n_c, tcb)}
             ba["speedup_vs_cpu_1thread"] = round(ba["value"] / max(ba["cpu_baseline"]["value"], 1e-9), 1)
         out["local_ba"] = ba
+
+    # ---- BoW front-half leg: transform of the step's descriptors with a full-size synthetic vocabulary
+    if rank == 0 and world == 1 and not args.no_bow and hasattr(pkg.abi.lib(), "dcs_bow_transform_device"):
+        voc = synth.vocabulary_fast(10, 6, seed=3)                   # k = 10, L = 6: 1.1 M nodes, 10^6 words (the shape of ORBvoc.txt)
+        V = pkg.ORBVocabulary(voc["k"], voc["L"], voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+        d_kp, d_desc, d_n = d_kp_b[(step_no[0] - 1) % NB], d_desc_b[(step_no[0] - 1) % NB], d_n_b[(step_no[0] - 1) % NB]
+        bufs = pkg.ORBVocabulary.bow_buffers(S, cap)
+        for _ in range(3):
+            V.transform_device(d_desc, d_n, cap, bufs, 4, stream)
+        torch.cuda.synchronize()
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        b0.record()
+        for _ in range(reps):
+            V.transform_device(d_desc, d_n, cap, bufs, 4, stream)
+        b1.record(); torch.cuda.synchronize()
+        bms = b0.elapsed_time(b1) / reps
+        n_desc = int(d_n.sum().item())
+        bow = {"metric": "BoW transform (10^6-word vocabulary, levelsup 4) Mdescriptors/s", "value": round(n_desc / bms / 1e3, 1), "unit": "Mdescriptors/s",
+               "images_per_call": S, "ms_per_call": round(bms, 4), "dtype": "u8 (Hamming) + f64 (word values)", "data": "synthetic vocabulary"}
+        if args.cpu_seconds > 0:
+            O = entry.load_oracle()
+            OV = O.Vocabulary(voc["k"], voc["L"], voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+            n0 = int(d_n[2].item()); h0 = d_desc[2, :n0].cpu().numpy()
+            tc0, n_c = time.perf_counter(), 0
+            while n_c < 1 or time.perf_counter() - tc0 < min(args.cpu_seconds, 2.0):
+                OV.transform(h0, 4); n_c += 1
+            tcb = time.perf_counter() - tc0
+            bow["cpu_baseline"] = {"value": round(n0 * n_c / tcb / 1e6, 3), "unit": "Mdescriptors/s", "cores": 1, "kind": "port",
+                                   "sample": "%d transforms of one image (%d descriptors) in %.1f s, oracle -O3 single thread" % (n_c, n0, tcb)}
+            bow["speedup_vs_cpu_1thread"] = round(bow["value"] / max(bow["cpu_baseline"]["value"], 1e-9), 1)
+        out["bow"] = bow
+        V.close()
 
     if rank == 0:
         print(json.dumps(out))

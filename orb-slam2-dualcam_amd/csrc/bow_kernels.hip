@@ -29,6 +29,7 @@ namespace {
 
 constexpr int kAsmT = 256;            // threads of k_bow_assemble
 constexpr int kAsmMax = 4096;         // features per image handled in LDS
+constexpr int kChunk = 10;            // children whose descriptors one lane loads before it compares (k = 10 in ORBvoc)
 
 struct VocabDev {
     const uint4* kid_desc;            // [n_slots][2]
@@ -64,15 +65,15 @@ __global__ __launch_bounds__(256) void k_bow_descend(VocabDev V, const uint8_t* 
         ++level;
         const int base = V.first_kid[cur];
         int best_d = 1 << 30, best = base;
-        for (int c0 = 0; c0 < nk; c0 += 5) {               // blocks of 5 children: 10 independent 16-byte loads in flight
-            uint4 k0[5], k1[5];
+        for (int c0 = 0; c0 < nk; c0 += kChunk) {          // blocks of kChunk children: 2 kChunk independent 16-byte loads in flight
+            uint4 k0[kChunk], k1[kChunk];
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
+            for (int u = 0; u < kChunk; ++u) {
                 const int c = min(c0 + u, nk - 1);
                 k0[u] = V.kid_desc[2 * (size_t)(base + c)]; k1[u] = V.kid_desc[2 * (size_t)(base + c) + 1];
             }
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
+            for (int u = 0; u < kChunk; ++u) {
                 const int d = hamming256(f0, f1, k0[u], k1[u]);
                 if (c0 + u < nk && d < best_d) { best_d = d; best = base + c0 + u; }      // strict <: the first child wins ties (:1266)
             }

@@ -1,11 +1,12 @@
 // Drives the header-only C++ mirrors (orb-slam2-dualcam_amd/host/*.h) the way the reference's call sites do
 // (Frame::ExtractORB, ORBmatcher, LocalMapping::Run -> LocalBundleAdjustment) and prints checksums that
-// tests/test_gpu_cpp_mirror.py compares with the oracle. usage: mirror_test image.raw rows cols nfeatures
+// tests/test_gpu_cpp_mirror.py compares with the oracle. usage: mirror_test image.raw rows cols nfeatures [vocabulary.txt]
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 #include "ORBextractor.h"
+#include "ORBVocabulary.h"
 #include "ORBmatcher.h"
 #include "Optimizer.h"
 
@@ -43,6 +44,20 @@ int main(int argc, char** argv)
         std::vector<dcs_keypoint> ke;
         ext(ORB_SLAM2::ImageView{nullptr, 0, 0, 0}, ke, empty_kp_desc);
         printf("empty %zu\n", ke.size());
+        if (argc > 5) {                                    // Frame::ComputeBoW: transform(descriptors, BowVec, FeatVec, 4)
+            ORB_SLAM2::ORBVocabulary voc;
+            if (!voc.loadFromTextFile(argv[5])) return 4;
+            ORB_SLAM2::BowVectorFlat b0, b1;
+            ORB_SLAM2::FeatureVectorCSR f0, f1;
+            voc.transform(d0, b0, f0, 4);
+            voc.transform(d1, b1, f1, 4);
+            printf("bow %u %zu %016llx %016llx\n", voc.size(), b0.words.size(), (unsigned long long)fnv(b0.words.data(), b0.words.size() * 4),
+                   (unsigned long long)fnv(b0.values.data(), b0.values.size() * 8));
+            printf("fv %zu %016llx %016llx %016llx\n", f0.nodes.size(), (unsigned long long)fnv(f0.nodes.data(), f0.nodes.size() * 4),
+                   (unsigned long long)fnv(f0.off.data(), f0.off.size() * 4), (unsigned long long)fnv(f0.idx.data(), f0.idx.size() * 4));
+            const double s01 = voc.score(b0, b1), s00 = voc.score(b0, b0);
+            printf("score %016llx %016llx\n", (unsigned long long)fnv(&s01, 8), (unsigned long long)fnv(&s00, 8));
+        }
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

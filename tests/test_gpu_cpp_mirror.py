@@ -44,7 +44,10 @@ def test_mirror_matches_oracle(tmp_path, pkg, oracle, synth):
     img0, img1 = synth.frame_pair(640, 480, 0, 0)
     raw = tmp_path / "pair.raw"
     raw.write_bytes(img0.tobytes() + img1.tobytes())
-    out = subprocess.run([exe, str(raw), "480", "640", "1000"], capture_output=True, text=True, timeout=120)
+    voc = synth.vocabulary(k=6, L=5, seed=4, ragged=0.2, stop_frac=0.05)
+    voc_path = str(tmp_path / "voc.txt")
+    synth.vocabulary_to_text(voc, voc_path)
+    out = subprocess.run([exe, str(raw), "480", "640", "1000", voc_path], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = dict((l.split()[0], l.split()[1:]) for l in out.stdout.strip().splitlines())
     feats = [oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(im) for im in (img0, img1)]
@@ -56,3 +59,14 @@ def test_mirror_matches_oracle(tmp_path, pkg, oracle, synth):
     m, n = oracle.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, feats[0][0]["angle"], feats[1][0]["angle"])
     assert int(lines["match"][0]) == n and int(lines["match"][1], 16) == _fnv(m.tobytes())
     assert lines["empty"] == ["0"]
+    # ORBVocabulary mirror: loadFromTextFile + transform(levelsup 4 -> level-1 nodes of this L = 5 tree) + score
+    import struct
+    V = oracle.Vocabulary(voc["k"], voc["L"], voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    r0, r1 = V.transform(feats[0][1], 4), V.transform(feats[1][1], 4)
+    assert int(lines["bow"][0]) == V.n_words() and int(lines["bow"][1]) == len(r0["bow_word"])
+    assert int(lines["bow"][2], 16) == _fnv(r0["bow_word"].tobytes()) and int(lines["bow"][3], 16) == _fnv(r0["bow_val"].tobytes())
+    assert int(lines["fv"][0]) == len(r0["fv_node"]) and int(lines["fv"][1], 16) == _fnv(r0["fv_node"].tobytes())
+    assert int(lines["fv"][2], 16) == _fnv(r0["fv_off"].tobytes()) and int(lines["fv"][3], 16) == _fnv(r0["fv_idx"].tobytes())
+    s01 = oracle.bow_score_l1(r0["bow_word"], r0["bow_val"], [0, len(r1["bow_word"])], r1["bow_word"], r1["bow_val"])[0]
+    s00 = oracle.bow_score_l1(r0["bow_word"], r0["bow_val"], [0, len(r0["bow_word"])], r0["bow_word"], r0["bow_val"])[0]
+    assert int(lines["score"][0], 16) == _fnv(struct.pack("<d", s01)) and int(lines["score"][1], 16) == _fnv(struct.pack("<d", s00))
