@@ -7,7 +7,7 @@ pkg = e.load_package(); oracle = e.load_oracle(); synth = pkg.synth
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
-cnt = dict(filter=0, grouped=0, bow=0, proj=0, distinct=0, ba=0, gba=0, pose=0); bad = 0
+cnt = dict(filter=0, grouped=0, bow=0, proj=0, distinct=0, ba=0, gba=0, pose=0, voc=0); bad = 0
 TRACE = os.environ.get("STRESS_TRACE")
 def tr(*a):
     if TRACE: print("..", *a, flush=True)
@@ -84,6 +84,27 @@ while time.time() < t_end:
     idxd = np.concatenate([rng.choice(len(pool), s, replace=False) for s in sizes] + [np.zeros(0, np.int64)]).astype(np.int32)
     if not np.array_equal(pkg.ComputeDistinctiveDescriptors(pool, offd, idxd), oracle.distinctive_descriptors(pool, offd, idxd)): report("distinctive", len(pool), len(sizes))
     cnt["distinct"] += 1
+    # ---- BoW front half: random vocabulary tree, transform, L1 scores
+    vk, vL = int(rng.integers(2, 11)), int(rng.integers(1, 6))
+    if vk ** vL <= 20000:
+        voc = synth.vocabulary(k=vk, L=vL, seed=seed % 100000, ragged=float(rng.choice([0, 0.3])), early_leaf=float(rng.choice([0, 0.15])),
+                               stop_frac=float(rng.choice([0, 0.1, 0.5])), dup_frac=float(rng.choice([0, 0.2])))
+        sc, wg, lu = int(rng.integers(0, 6)), int(rng.integers(0, 4)), int(rng.integers(0, vL + 2))
+        tr('voc', vk, vL, len(voc["parent"]), sc, wg, lu)
+        va = (voc["k"], voc["L"], voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"], sc, wg)
+        GV, OV = pkg.ORBVocabulary(*va), oracle.Vocabulary(*va)
+        res = []
+        for nfe in (int(rng.integers(0, 4097)), int(rng.integers(0, 300))):
+            fe = np.concatenate([synth.descriptors_near_words(voc, nfe, seed=seed, flip=int(rng.integers(0, 40))), synth.random_descriptors(8, seed=seed)])[:nfe]
+            g, x = GV.transform(fe, lu), OV.transform(fe, lu)
+            if not (all(np.array_equal(g[key], x[key]) for key in ("word", "node", "bow_word", "fv_node", "fv_off", "fv_idx")) and g["bow_val"].tobytes() == x["bow_val"].tobytes()):
+                report("bow_transform", vk, vL, sc, wg, lu, nfe, seed)
+            res.append(x)
+        dbo = np.array([0, len(res[0]["bow_word"]), len(res[0]["bow_word"]) + len(res[1]["bow_word"])], np.int32)
+        dbw, dbv = np.concatenate([r["bow_word"] for r in res]), np.concatenate([r["bow_val"] for r in res])
+        if pkg.ORBVocabulary.score(res[1]["bow_word"], res[1]["bow_val"], dbo, dbw, dbv).tobytes() != oracle.bow_score_l1(res[1]["bow_word"], res[1]["bow_val"], dbo, dbw, dbv).tobytes():
+            report("bow_score", vk, vL, seed)
+        GV.close(); cnt["voc"] += 1
     # ---- local BA, global BA
     P = int(rng.integers(3, 36)); F = int(rng.integers(1, max(2, P // 3))); L = int(rng.integers(20, 500)); O = int(rng.integers(2, min(P, 10) + 1))
     args = dict(n_poses=P, n_fixed=F, n_points=L, obs_per_point=O, seed=seed % 100000, outlier_frac=float(rng.choice([0.0, 0.05, 0.2])), exact_adjoint=bool(rng.integers(0, 2)))
