@@ -205,7 +205,8 @@ __device__ __forceinline__ void knn2_tile_mfma(const uint8_t* __restrict__ q, in
         }
     }
     // Keys are tracked WITHOUT the query's own popcount (a constant per lane and query group that cannot change the order):
-    // key = (popcount(t) - 2 <q, t> + 512) << 22 | train index -- 4 instructions per distance (mad, lshl_or, med3, min).
+    // key = (popcount(t) - 2 <q, t> + 512) << 22 | train index -- 3 instructions per distance (lshl_add, med3, min): the train's
+    // popcount and index are merged into one word when the tile is expanded.
     constexpr unsigned kInitM = (0x3FFu << 22) | 0x3FFFFFu;
     unsigned k1[QG], k2[QG];
 #pragma unroll
@@ -233,7 +234,8 @@ __device__ __forceinline__ void knn2_tile_mfma(const uint8_t* __restrict__ q, in
             }
 #pragma unroll
             for (int sh = 1; sh < kParts; sh <<= 1) pc += __shfl_xor(pc, sh);
-            if (part == 0) s_pb[buf][d] = (ti < nt ? pc + 512 : 0x3FF) << 22;   // key high part; padding rows: largest biased distance
+            // everything of the key that does not depend on the query: biased popcount | train index (padding rows: largest distance, index >= nt)
+            if (part == 0) s_pb[buf][d] = ((ti < nt ? pc + 512 : 0x3FF) << 22) | ti;
         }
     };
     expand_tile(0, 0);
@@ -257,14 +259,13 @@ __device__ __forceinline__ void knn2_tile_mfma(const uint8_t* __restrict__ q, in
 #pragma unroll
                 for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[sl], bf[qg][sl], acc[qg], 0, 0, 0);
             const v4i_t pbc = pb;
-            const unsigned tbase = (unsigned)(t0 + 16 * tg + 4 * g);
             if (tg + 1 < n_grp) load_group(tg + 1);              // next group's operands fly while this group's keys are ranked
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // (popcount(t) + 512 - 2 <q, t>) << 22 | index; padding rows of the last group: acc = 0, largest key, index >= nt
-                    const unsigned key = (((unsigned)acc[qg][r] << 23) + (unsigned)pbc[r]) | (tbase + (unsigned)r);
+                    const unsigned key = ((unsigned)acc[qg][r] << 23) + (unsigned)pbc[r];       // one v_lshl_add_u32
                     k2[qg] = umed3(k1[qg], k2[qg], key); k1[qg] = min(k1[qg], key);
                 }
             }
