@@ -203,6 +203,7 @@ int dcs_orb::configure(int rows, int cols)
         for (size_t x = 0; x < rt.xofs.size(); ++x) { tab.push_back(rt.xofs[x]); tab.push_back(0); tab.push_back(rt.xa[2 * x]); tab.push_back(rt.xa[2 * x + 1]); }
         rtab[l].xa = tab.size();
         rtab[l].yofs = tab.size(); tab.insert(tab.end(), rt.yofs.begin(), rt.yofs.end());
+        while (tab.size() % 2) tab.push_back(0);                 // k_resize reads a row's two coefficients as one dword
         rtab[l].ya = tab.size();   tab.insert(tab.end(), rt.ya.begin(), rt.ya.end());
     }
     if ((rc = d_rtab.resize(std::max<size_t>(tab.size(), 1)))) return rc;

@@ -43,28 +43,56 @@ struct ResizeTaps {                    // loop-invariant per thread
     unsigned wgt[4];                   // a0 | a1 << 16
 };
 
-__device__ __forceinline__ void resize_hrow(const uint8_t* __restrict__ row, bool aligned, const ResizeTaps& t, unsigned (&h)[4])
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct ResizeRaw { u32x4_t d; };                // x, y, z = the 12 source bytes one thread needs from one source row (one register tuple:
+                                                // a conditionally reloaded row stays in place instead of being copied after the load)
+
+__device__ __forceinline__ ResizeRaw resize_load(const uint8_t* __restrict__ row, bool aligned)
 {
-    unsigned d0, d1, d2;
+    ResizeRaw r;
     if (aligned) {
         const unsigned* p = reinterpret_cast<const unsigned*>(row);
-        d0 = p[0]; d1 = p[1]; d2 = p[2];
+        r.d = u32x4_t{p[0], p[1], p[2], 0u};
     } else {
         unsigned b[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) b[k] = row[k];
-        d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-        d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-        d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+        r.d = u32x4_t{b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24),
+                      b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24), 0u};
     }
+    return r;
+}
+
+// horizontal pass of one source row for 4 destination pixels: (S0 a0 + S1 a1) >> 4
+__device__ __forceinline__ void resize_hpass(const ResizeRaw& r, const ResizeTaps& t, unsigned (&h)[4])
+{
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const unsigned lo = t.upper[k] ? d1 : d0, hi = t.upper[k] ? d2 : d1;
+        const unsigned lo = t.upper[k] ? r.d.y : r.d.x, hi = t.upper[k] ? r.d.z : r.d.y;
         const unsigned taps = __builtin_amdgcn_perm(hi, lo, t.sel[k]);                  // (S0, S1) as two u16
         h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, taps), __builtin_bit_cast(ushort2_t, t.wgt[k]), 0u, false) >> 4;
     }
 }
 
+__device__ __forceinline__ void resize_hrow(const uint8_t* __restrict__ row, bool aligned, const ResizeTaps& t, unsigned (&h)[4])
+{
+    resize_hpass(resize_load(row, aligned), t, h);
+}
+
+// vertical pass + store of one destination row: hA, hB <= 32640 and b <= 2048, so the 24-bit multiplies are exact; each product is
+// truncated (>> 16) on its own like OpenCV's fixed-point VResizeLinear
+__device__ __forceinline__ void resize_emit(uint8_t* __restrict__ out, const unsigned (&hA)[4], const unsigned (&hB)[4], unsigned b0, unsigned b1)
+{
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned v = ((__umul24(b0, hA[k]) >> 16) + (__umul24(b1, hB[k]) >> 16) + 2u) >> 2;
+        packed |= (v & 0xffu) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(out) = packed;
+}
+
+template <bool ALIGNED>      // source rows readable as dwords (base, image stride and pitch multiples of 4): decided on the host
 __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, const ResizeCol* __restrict__ cols,
                                                 const int16_t* __restrict__ yofs, const int16_t* __restrict__ ya, int n_images)
 {
@@ -75,10 +103,22 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
     const int img = li / n_x4;
     const int dx0 = (li - img * n_x4) * 4;
     const int dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * kRsRowsPerThread;   // wave-uniform
-    if (img >= n_images || dy0 >= dst.h) return;
+    if (dy0 >= dst.h) return;
+    // row tables of this strip: lane k (mod 8) holds the entries of destination row dy0 + k; read back with v_readlane (the
+    // loads are issued by every lane, before the out-of-range lanes of the last block leave)
+    const int krow = min(dy0 + (int)(threadIdx.x & 7), dst.h - 1);
+    const int my_sy = yofs[krow];
+    const unsigned my_a = *reinterpret_cast<const unsigned*>(ya + 2 * krow);           // b0 | b1 << 16 (both 0..2048)
+    // the readlanes happen HERE, while all 64 lanes are still active: placed after the return below, the compiler sinks the two
+    // loads behind it too and the lanes that left never fetch their entries (a wave with < 8 surviving lanes then read garbage)
+    int sy_of[kRsRowsPerThread];
+    unsigned a_of[kRsRowsPerThread];
+#pragma unroll
+    for (int k = 0; k < kRsRowsPerThread; ++k) { sy_of[k] = __builtin_amdgcn_readlane(my_sy, k); a_of[k] = (unsigned)__builtin_amdgcn_readlane((int)my_a, k); }
+    if (img >= n_images) return;
     const uint8_t* S = src.base + (size_t)img * src.img_stride;
     uint8_t* D = const_cast<uint8_t*>(dst.base) + (size_t)img * dst.img_stride;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(S) | (uintptr_t)src.pitch) & 3) == 0 && src.pitch >= 12;
+    constexpr bool aligned = ALIGNED;
     ResizeTaps t;
     int base = 0;
 #pragma unroll
@@ -94,6 +134,38 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
         t.wgt[k] = (unsigned)(uint16_t)cc.a0 | ((unsigned)(uint16_t)cc.a1 << 16);
     }
     const uint8_t* colbase = S + base;
+    uint8_t* out = D + (size_t)dy0 * dst.pitch + dx0;                         // pitch is a multiple of 64: the dword stays in the row
+    const int sy_first = sy_of[0], sy_last = sy_of[kRsRowsPerThread - 1];
+    if (dy0 + kRsRowsPerThread <= dst.h && sy_first >= 0 && sy_last + 1 <= src.h - 1) {
+        // interior strip (no clamped source row): walk the source rows once. hP / hC = horizontal passes of rows p, p + 1; the
+        // raw bytes of row p + 2 are already in flight while the current destination row is produced. A destination row
+        // advances p by 0..2 (scale <= 2), all of it wave-uniform (SGPR compares, constant-lane readlanes).
+        int p = sy_first;
+        unsigned hP[4], hC[4];
+        const ResizeRaw r0 = resize_load(colbase + (size_t)p * src.pitch, aligned);
+        const ResizeRaw r1 = resize_load(colbase + (size_t)(p + 1) * src.pitch, aligned);
+        ResizeRaw nx = resize_load(colbase + (size_t)min(p + 2, src.h - 1) * src.pitch, aligned);
+        resize_hpass(r0, t, hP);
+        resize_hpass(r1, t, hC);
+#pragma unroll
+        for (int k = 0; k < kRsRowsPerThread; ++k) {
+            const int sy = sy_of[k];
+#pragma unroll
+            for (int adv = 0; adv < 2; ++adv) {
+                if (p < sy) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) hP[c] = hC[c];
+                    resize_hpass(nx, t, hC);
+                    ++p;
+                    nx = resize_load(colbase + (size_t)min(p + 2, src.h - 1) * src.pitch, aligned);
+                }
+            }
+            const unsigned a = a_of[k];
+            resize_emit(out + (size_t)k * dst.pitch, hP, hC, a & 0xffffu, a >> 16);
+        }
+        return;
+    }
+    // boundary strips (clamped rows at the bottom edge, a partial last strip): one destination row at a time
     unsigned hA[4], hB[4];
     int rowA = -1, rowB = -1;                           // source rows currently held in hA / hB (wave-uniform)
     const int dy_end = min(dy0 + kRsRowsPerThread, dst.h);
@@ -112,15 +184,7 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
             for (int k = 0; k < 4; ++k) hB[k] = hA[k];
             rowB = rowA;
         } else if (sy1 != rowB) { resize_hrow(colbase + (size_t)sy1 * src.pitch, aligned, t, hB); rowB = sy1; }
-        const unsigned b0 = (unsigned)(int)ya[2 * dy], b1 = (unsigned)(int)ya[2 * dy + 1];       // 0..2048
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // hA, hB <= 32640 and b <= 2048: 24-bit multiplies are exact; each product is truncated (>> 16) on its own
-            const unsigned v = ((__umul24(b0, hA[k]) >> 16) + (__umul24(b1, hB[k]) >> 16) + 2u) >> 2;
-            packed |= (v & 0xffu) << (8 * k);
-        }
-        *reinterpret_cast<uint32_t*>(D + (size_t)dy * dst.pitch + dx0) = packed;     // pitch is a multiple of 64: in-row
+        resize_emit(out + (size_t)(dy - dy0) * dst.pitch, hA, hB, (unsigned)(int)ya[2 * dy], (unsigned)(int)ya[2 * dy + 1]);
     }
 }
 
@@ -131,7 +195,9 @@ int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_c
     if ((double)src.w / dst.w > 2.0) { set_error("pyramid scale factor > 2 not supported by the resize kernel"); return DCS_ERR_UNSUPPORTED; }
     const int n_x4 = (dst.w + 3) / 4;
     dim3 grid((n_images * n_x4 + 63) / 64, (dst.h + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread));
-    hipLaunchKernelGGL(k_resize, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src.base) | (uintptr_t)src.img_stride | (uintptr_t)src.pitch) & 3) == 0 && src.pitch >= 12;
+    if (aligned) hipLaunchKernelGGL(k_resize<true>, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images);
+    else hipLaunchKernelGGL(k_resize<false>, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
