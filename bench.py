@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-bow", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2, help="independent extractor handles/streams the batch is split over (overlaps latency-bound kernels)")
+    ap.add_argument("--lanes", type=int, default=1, help="independent extractor handles/streams the batch is split over (overlaps latency-bound kernels)")
     args = ap.parse_args()
 
     import torch
