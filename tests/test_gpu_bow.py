@@ -107,3 +107,15 @@ def test_load_from_text_file(pkg, oracle, synth, tmp_path):
     feats = synth.descriptors_near_words(v, 300, seed=2)
     _same(G.transform(feats, 1), oracle.Vocabulary(v["k"], v["L"], v["parent"], v["is_leaf"], v["desc"], v["weight"]).transform(feats, 1))
     G.close()
+
+
+def test_bow_golden(pkg):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bow_small.npz"))
+    V = pkg.ORBVocabulary(int(g["k"]), int(g["L"]), g["parent"], g["is_leaf"], g["voc_desc"], g["weight"])
+    r = V.transform(g["feats"], int(g["levelsup"]))
+    _same(r, {k: g[k] for k in ("word", "node", "bow_word", "bow_val", "fv_node", "fv_off", "fv_idx")})
+    r2 = V.transform(g["feats"][::2], int(g["levelsup"]))
+    off = np.array([0, len(r["bow_word"]), len(r["bow_word"]) + len(r2["bow_word"])], np.int32)
+    s = pkg.ORBVocabulary.score(r2["bow_word"], r2["bow_val"], off, np.concatenate([r["bow_word"], r2["bow_word"]]), np.concatenate([r["bow_val"], r2["bow_val"]]))
+    assert s.tobytes() == g["score_half_vs_full_and_self"].tobytes()
+    V.close()

@@ -129,3 +129,16 @@ def test_text_format_round_trip(oracle, synth, tmp_path):
         assert np.array_equal(u[key], v[key]), key
     assert (u["k"], u["L"], u["scoring"], u["weighting"]) == (3, 3, 0, 0)
 
+
+
+def test_bow_golden(oracle):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bow_small.npz"))
+    V = oracle.Vocabulary(int(g["k"]), int(g["L"]), g["parent"], g["is_leaf"], g["voc_desc"], g["weight"])
+    r = V.transform(g["feats"], int(g["levelsup"]))
+    for key in ("word", "node", "bow_word", "fv_node", "fv_off", "fv_idx"):
+        assert np.array_equal(r[key], g[key]), key
+    assert r["bow_val"].tobytes() == g["bow_val"].tobytes()
+    r2 = V.transform(g["feats"][::2], int(g["levelsup"]))
+    off = np.array([0, len(r["bow_word"]), len(r["bow_word"]) + len(r2["bow_word"])], np.int32)
+    s = oracle.bow_score_l1(r2["bow_word"], r2["bow_val"], off, np.concatenate([r["bow_word"], r2["bow_word"]]), np.concatenate([r["bow_val"], r2["bow_val"]]))
+    assert s.tobytes() == g["score_half_vs_full_and_self"].tobytes() and abs(s[1] - 1.0) < 1e-12
