@@ -37,7 +37,7 @@ public:
     // Empty image -> returns with empty outputs (reference ORBextractor.cc:1046-1047).
     void operator()(const ImageView& image, std::vector<dcs_keypoint>& keypoints, std::vector<uint8_t>& descriptors)
     {
-        const int cap = nfeatures_ + 4 * nlevels_ + 64;
+        const int cap = capacity(image.rows, image.cols);
         keypoints.resize(cap); descriptors.resize((size_t)cap * 32);
         int n = 0;
         const int rc = dcs_orb_extract(h_, image.data, image.rows, image.cols, image.stride, keypoints.data(), descriptors.data(), cap, &n);
@@ -53,7 +53,7 @@ public:
         if (_image.empty()) return;
         cv::Mat image = _image.getMat();
         CV_Assert(image.type() == CV_8UC1);
-        const int cap = nfeatures_ + 4 * nlevels_ + 64;
+        const int cap = capacity(image.rows, image.cols);
         _keypoints.resize(cap);
         cv::Mat desc(cap, 32, CV_8U);
         int n = 0;
@@ -64,6 +64,15 @@ public:
         if (n == 0) _descriptors.release(); else desc.rowRange(0, n).copyTo(_descriptors);
     }
 #endif
+
+    // output slots one image may need: the quadtree keeps up to max(N_level + 3, 4 * round(w/h)) keypoints per level
+    int capacity(int rows, int cols) const
+    {
+        int cap = nfeatures_ + 4 * nlevels_ + 64;
+        int need = 0;
+        if (rows > 0 && cols > 0 && dcs_orb_required_cap(h_, rows, cols, &need) == DCS_OK && need > cap) cap = need;
+        return cap;
+    }
 
     int GetLevels() { return nlevels_; }
     float GetScaleFactor() { return (float)scaleFactor_; }
