@@ -194,6 +194,30 @@ int  dcs_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const
 int  dcs_search_by_projection(const dcs_proj_frame* frame, const dcs_proj_queries* queries, int th_high, float nn_ratio,
                               int check_orientation, int32_t* match_of_query, int32_t* query_of_feature, int* n_matches);
 
+/* Frame::isInFrustum (Frame.cc:244-312) for a batch of map points + the window of SearchByProjection (ORBmatcher.cc:557-565):
+   the geometry gate in front of dcs_search_by_projection. The caller supplies the per-camera matrices exactly as the reference
+   forms them with cv::Mat (Tsw = mvExtrinsics[c] * mTcw -> Rsw, tsw, Frame.cc:252-256; GetCameraCenter(c), :222-235);
+   cameras are tried in order and the first that sees the point wins (n_cams = 1 when bForAllCam is false). */
+typedef struct dcs_frustum_frame {
+    int32_t n_cams;
+    const float* Rsw;            /* [n_cams][9] row-major */
+    const float* tsw;            /* [n_cams][3] */
+    const float* Ow;             /* [n_cams][3] camera centres in the world */
+    const float* fx; const float* fy; const float* cx; const float* cy;          /* [n_cams] mvfx ... */
+    const float* min_x; const float* max_x; const float* min_y; const float* max_y;   /* [n_cams] mvMinX ... */
+    float   log_scale_factor;    /* mfLogScaleFactor */
+    int32_t n_scale_levels;      /* mnScaleLevels */
+    const float* scale_factors;  /* [n_scale_levels] mvScaleFactors */
+} dcs_frustum_frame;
+/* pos / normal [n][3] (GetWorldPos, GetNormal), min_dist / max_dist [n] (mfMinDistance, mfMaxDistance: the 0.8 / 1.2
+   invariance factors are applied inside, MapPoint.cc:411-421), candidate [n] or NULL (0 = skip: bad / already matched).
+   Outputs [n]: in_view (mbTrackInView), cam (mTrackProjCamera), u, v (mTrackProjX/Y), view_cos (mTrackViewCos), level
+   (mnTrackScaleLevel = PredictScale, MapPoint.cc:440-455), radius = RadiusByViewingCos(view_cos) [* th when th != 1] *
+   scale_factors[level] -- i.e. the valid / cam / u / v / radius / level -+ 1 columns of dcs_proj_queries. */
+int  dcs_is_in_frustum(const dcs_frustum_frame* frame, int n, const float* pos, const float* normal, const float* min_dist,
+                       const float* max_dist, const uint8_t* candidate, float viewing_cos_limit, float th, uint8_t* in_view,
+                       int32_t* cam, float* u, float* v, float* view_cos, int32_t* level, float* radius);
+
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:270-340), batched: map point p owns the descriptors
    pool[idx[off[p] .. off[p+1])] (the rows the reference gathers from its observations, in that order); best[p] = position
    inside that list of the descriptor with the least median Hamming distance to the others (median = sorted[(int)(0.5 (N-1))]

@@ -321,3 +321,59 @@ int orc_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Frame::isInFrustum (src/Frame.cc:244-312), one map point at a time, in the arithmetic the reference's cv::Mat expressions
+// perform (OpenCV 3.x, CV_32F; restated -- OpenCV is not in this image, parity unpinned):
+//   * Pic = Rsw * P + tsw (:258): MatExpr folds it into ONE gemm(Rsw, P, 1, tsw, 1); 3x3 by 3x1 takes gemm's small-matrix
+//     path (matmul.cpp, "len <= 4"): float dot products left to right, then d = (float)(t * alpha + c * beta) in double
+//   * u = fx * PicX * invz + cx (:271-272): float, left to right, invz = 1.0f / PicZ
+//   * PO = P - Ow (:286) float; dist = cv::norm(PO) (:287): L2 with double accumulation, sqrt in double, narrowed to float
+//   * viewCos = PO.dot(Pn) / dist (:294): Mat::dot accumulates (double)a * b; the quotient is double, narrowed to float
+//   * PredictScale (src/MapPoint.cc:440-455): ratio = mfMaxDistance / dist (float), ceil(log(ratio) / mfLogScaleFactor) with
+//     the float overloads (`using namespace std` is in scope: logf, float division, ceilf), clamped to [0, nScaleLevels - 1]
+//   * window (src/ORBmatcher.cc:65-71, 557-565): r = viewCos > 0.998 (double compare) ? 2.5f : 4.0f; r *= th when th != 1;
+//     radius = r * mvScaleFactors[level]
+extern "C" void orc_is_in_frustum(const orc_frustum_frame* f, int n, const float* pos, const float* normal, const float* min_dist,
+                                  const float* max_dist, const uint8_t* candidate, float viewing_cos_limit, float th, uint8_t* in_view,
+                                  int32_t* cam, float* u_out, float* v_out, float* view_cos, int32_t* level, float* radius)
+{
+    const bool bFactor = th != 1.0f;                                       // :545 (th is a float compared with 1.0)
+    for (int i = 0; i < n; ++i) {
+        in_view[i] = 0; cam[i] = -1; u_out[i] = 0; v_out[i] = 0; view_cos[i] = 0; level[i] = 0; radius[i] = 0;
+        if (candidate && !candidate[i]) continue;
+        const float* P = pos + 3 * i; const float* Pn = normal + 3 * i;
+        for (int ic = 0; ic < f->n_cams; ++ic) {
+            const float* R = f->Rsw + 9 * ic; const float* t = f->tsw + 3 * ic; const float* O = f->Ow + 3 * ic;
+            float Pic[3];
+            for (int r = 0; r < 3; ++r) {
+                const float t0 = R[3 * r] * P[0] + R[3 * r + 1] * P[1] + R[3 * r + 2] * P[2];
+                Pic[r] = (float)((double)t0 * 1.0 + (double)t[r] * 1.0);
+            }
+            if (Pic[2] < 0.0f) continue;                                   // :265
+            const float invz = 1.0f / Pic[2];
+            const float u = f->fx[ic] * Pic[0] * invz + f->cx[ic];
+            const float v = f->fy[ic] * Pic[1] * invz + f->cy[ic];
+            if (u < f->min_x[ic] || u > f->max_x[ic]) continue;            // :274 (NaN passes, like the reference)
+            if (v < f->min_y[ic] || v > f->max_y[ic]) continue;
+            const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+            const float PO[3] = {P[0] - O[0], P[1] - O[1], P[2] - O[2]};
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += (double)PO[k] * (double)PO[k];
+            const float dist = (float)std::sqrt(s);
+            if (dist < minDistance || dist > maxDistance) continue;       // :289
+            double dot = 0;
+            for (int k = 0; k < 3; ++k) dot += (double)PO[k] * (double)Pn[k];
+            const float viewCos = (float)(dot / (double)dist);
+            if (viewCos < viewing_cos_limit) continue;                     // :296
+            const float ratio = max_dist[i] / dist;
+            int nScale = (int)std::ceil(std::log(ratio) / f->log_scale_factor);      // float overloads
+            if (nScale < 0) nScale = 0; else if (nScale >= f->n_scale_levels) nScale = f->n_scale_levels - 1;
+            float r = ((double)viewCos > 0.998) ? 2.5f : 4.0f;
+            if (bFactor) r *= th;
+            in_view[i] = 1; cam[i] = ic; u_out[i] = u; v_out[i] = v; view_cos[i] = viewCos; level[i] = nScale;
+            radius[i] = r * f->scale_factors[nScale];
+            break;                                                         // return true (:307)
+        }
+    }
+}

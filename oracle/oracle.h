@@ -220,6 +220,19 @@ void orc_se3_oplus(const double pose_in[7], const double update[6], double pose_
 /* Cameras::setExtrinsics adjoint (Cameras.cc:27-37) from a float 4x4 T (row-major), LL block = 0 */
 void orc_rig_adjoint(const float T44[16], int exact, double adj36[36], double ext7[7]);
 
+/* Frame::isInFrustum (Frame.cc:244-312) + PredictScale (MapPoint.cc:440-455) + the search window of SearchByProjection
+   (ORBmatcher.cc:65-71, 557-565) for n map points; per-camera matrices as the caller's cv::Mat code forms them. */
+typedef struct orc_frustum_frame {
+    int32_t n_cams;
+    const float* Rsw; const float* tsw; const float* Ow;
+    const float* fx; const float* fy; const float* cx; const float* cy;
+    const float* min_x; const float* max_x; const float* min_y; const float* max_y;
+    float log_scale_factor; int32_t n_scale_levels; const float* scale_factors;
+} orc_frustum_frame;
+void orc_is_in_frustum(const orc_frustum_frame* f, int n, const float* pos, const float* normal, const float* min_dist,
+                       const float* max_dist, const uint8_t* candidate, float viewing_cos_limit, float th, uint8_t* in_view,
+                       int32_t* cam, float* u, float* v, float* view_cos, int32_t* level, float* radius);
+
 /* ---------------------------------------------------------------------------------------------------------------
    BoW front half: DBoW2 vocabulary tree, transform -> BowVector + FeatureVector, L1 score.
    The vocabulary is given as the columns of the reference's text format (TemplatedVocabulary.h:1362-1446): row i

@@ -123,6 +123,19 @@ class PoseResult(C.Structure):
                 ("n_iters", C.c_void_p)]
 
 
+class FrustumFrame(C.Structure):
+    _fields_ = [("n_cams", C.c_int32)] + [(k, C.c_void_p) for k in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y")] + \
+               [("log_scale_factor", C.c_float), ("n_scale_levels", C.c_int32), ("scale_factors", C.c_void_p)]
+
+
+def _frustum_frame(cls, fr, keep):
+    a = {k: _c(fr[k], np.float32) for k in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y", "scale_factors")}
+    keep.append(a)
+    n_cams = len(a["fx"])
+    return cls(n_cams, *[a[k].ctypes.data for k in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y")],
+               float(np.float32(fr["log_scale_factor"])), len(a["scale_factors"]), a["scale_factors"].ctypes.data)
+
+
 _lib = None
 
 
@@ -167,6 +180,7 @@ def lib():
         L.orc_ba_edge_jacobian.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BaCamera), C.c_void_p, C.c_void_p]
         L.orc_se3_oplus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rig_adjoint.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_is_in_frustum.argtypes = [C.POINTER(FrustumFrame), C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_float] + [C.c_void_p] * 7
         L.orc_vocab_create.restype = C.c_void_p
         L.orc_vocab_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vocab_destroy.argtypes = [C.c_void_p]
@@ -484,3 +498,19 @@ def bow_score_l1(q_word, q_val, db_off, db_word, db_val):
     score = np.zeros(max(n_db, 1))
     lib().orc_bow_score_l1(_p(q_word), _p(q_val), len(q_word), _p(db_off), _p(db_word), _p(db_val), n_db, _p(score))
     return score[:n_db]
+
+
+def is_in_frustum(frame, pts, viewing_cos_limit=0.5, th=1.0):
+    """Frame::isInFrustum + PredictScale + search window for pts = dict(pos[n,3], normal[n,3], min_dist[n], max_dist[n], candidate[n] or None)."""
+    keep = []
+    f = _frustum_frame(FrustumFrame, frame, keep)
+    pos, nrm = _c(pts["pos"], np.float32).reshape(-1, 3), _c(pts["normal"], np.float32).reshape(-1, 3)
+    mind, maxd = _c(pts["min_dist"], np.float32), _c(pts["max_dist"], np.float32)
+    cand = _c(pts["candidate"], np.uint8) if pts.get("candidate") is not None else None
+    n = len(pos)
+    m = max(n, 1)
+    out = dict(in_view=np.zeros(m, np.uint8), cam=np.zeros(m, np.int32), u=np.zeros(m, np.float32), v=np.zeros(m, np.float32),
+               view_cos=np.zeros(m, np.float32), level=np.zeros(m, np.int32), radius=np.zeros(m, np.float32))
+    lib().orc_is_in_frustum(C.byref(f), n, _p(pos), _p(nrm), _p(mind), _p(maxd), _p(cand), float(viewing_cos_limit), float(th),
+                            *[_p(out[k]) for k in ("in_view", "cam", "u", "v", "view_cos", "level", "radius")])
+    return {k: a[:n] for k, a in out.items()}

@@ -27,7 +27,7 @@ SYMBOLS = [
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
     "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
-    "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
+    "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
 ]
 
 
@@ -36,6 +36,11 @@ class DcsError(RuntimeError):
         self.rc = rc
         msg = lib().dcs_last_error().decode() if _lib is not None else ""
         super().__init__("%s failed: rc=%d %s" % (where, rc, msg))
+
+
+class FrustumFrame(C.Structure):
+    _fields_ = [("n_cams", C.c_int32)] + [(k, C.c_void_p) for k in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y")] + \
+               [("log_scale_factor", C.c_float), ("n_scale_levels", C.c_int32), ("scale_factors", C.c_void_p)]
 
 
 class OrbParams(C.Structure):
@@ -114,6 +119,7 @@ def lib():
             "dcs_rig_adjoint": [vp, ci, vp, vp],
             "dcs_pose_from_matrix": [vp, vp],
             "dcs_pose_to_matrix": [vp, vp],
+            "dcs_is_in_frustum": [C.POINTER(FrustumFrame), ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp],
             "dcs_vocab_create": [ci, ci, ci, ci, ci, vp, vp, vp, vp, C.POINTER(vp)],
             "dcs_vocab_destroy": [vp],
             "dcs_vocab_info": [vp, pci, pci, pci, pci],
@@ -592,3 +598,31 @@ class ORBVocabulary:
         score = np.zeros(max(n_db, 1))
         _check(lib().dcs_bow_score_l1(_p(q_word), _p(q_val), len(q_word), _p(db_off), _p(db_word), _p(db_val), n_db, _p(score)), "dcs_bow_score_l1")
         return score[:n_db]
+
+
+def isInFrustum(frame, pts, viewing_cos_limit=0.5, th=1.0):
+    """Frame::isInFrustum (Frame.cc:244-312) for a batch of map points + PredictScale + the SearchByProjection window.
+    frame: dict(Rsw[c,9], tsw[c,3], Ow[c,3], fx, fy, cx, cy, min_x, max_x, min_y, max_y [c], log_scale_factor, scale_factors[L]);
+    pts: dict(pos[n,3], normal[n,3], min_dist[n], max_dist[n], candidate[n] or None). Returns the per-point outputs; the columns
+    valid / cam / u / v / radius / min_level / max_level of the projection queries follow directly (see projection_queries)."""
+    a = {k: _c(frame[k], np.float32) for k in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y", "scale_factors")}
+    f = FrustumFrame(len(a["fx"]), *[a[k].ctypes.data for k in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y")],
+                     float(np.float32(frame["log_scale_factor"])), len(a["scale_factors"]), a["scale_factors"].ctypes.data)
+    pos, nrm = _c(pts["pos"], np.float32).reshape(-1, 3), _c(pts["normal"], np.float32).reshape(-1, 3)
+    mind, maxd = _c(pts["min_dist"], np.float32), _c(pts["max_dist"], np.float32)
+    cand = _c(pts["candidate"], np.uint8) if pts.get("candidate") is not None else None
+    n = len(pos)
+    m = max(n, 1)
+    out = dict(in_view=np.zeros(m, np.uint8), cam=np.zeros(m, np.int32), u=np.zeros(m, np.float32), v=np.zeros(m, np.float32),
+               view_cos=np.zeros(m, np.float32), level=np.zeros(m, np.int32), radius=np.zeros(m, np.float32))
+    _check(lib().dcs_is_in_frustum(C.byref(f), n, _p(pos), _p(nrm), _p(mind), _p(maxd), _p(cand), float(viewing_cos_limit), float(th),
+                                   *[_p(out[k]) for k in ("in_view", "cam", "u", "v", "view_cos", "level", "radius")]), "dcs_is_in_frustum")
+    return {k: v[:n] for k, v in out.items()}
+
+
+def projection_queries(fr, desc, angle=None):
+    """isInFrustum outputs + the map points' descriptors -> the query dict of ORBmatcher.SearchByProjection (ORBmatcher.cc:557-565)."""
+    n = len(fr["in_view"])
+    return dict(valid=fr["in_view"], cam=np.maximum(fr["cam"], 0).astype(np.int32), u=fr["u"], v=fr["v"], radius=fr["radius"],
+                min_level=(fr["level"] - 1).astype(np.int32), max_level=(fr["level"] + 1).astype(np.int32), desc=_c(desc, np.uint8).reshape(-1, 32),
+                angle=_c(angle, np.float32) if angle is not None else np.zeros(n, np.float32))

@@ -405,6 +405,64 @@ __global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f, ProjQu
     if (tid == 0) *n_matches = nm;
 }
 
+// ---- Frame::isInFrustum + PredictScale + search window, one lane per map point (Frame.cc:244-312, MapPoint.cc:440-455,
+// ORBmatcher.cc:65-71, 557-565). Same arithmetic as the reference's cv::Mat expressions (see oracle/match_oracle.cpp): float dot
+// products left to right without contraction, the translation added in double, norm / dot accumulated in double.
+constexpr int kFrMaxCams = 8;
+struct FrustumDev {
+    int n_cams, n_levels;
+    float R[kFrMaxCams][9], t[kFrMaxCams][3], O[kFrMaxCams][3];
+    float fx[kFrMaxCams], fy[kFrMaxCams], cx[kFrMaxCams], cy[kFrMaxCams], min_x[kFrMaxCams], max_x[kFrMaxCams], min_y[kFrMaxCams], max_y[kFrMaxCams];
+    float log_scale;
+    const float* scale_factors;
+};
+
+__global__ __launch_bounds__(256) void k_frustum(FrustumDev F, int n, const float* __restrict__ pos, const float* __restrict__ normal,
+                                                 const float* __restrict__ min_dist, const float* __restrict__ max_dist,
+                                                 const uint8_t* __restrict__ candidate, float cos_limit, float th, uint8_t* __restrict__ in_view,
+                                                 int32_t* __restrict__ cam, float* __restrict__ u_out, float* __restrict__ v_out,
+                                                 float* __restrict__ view_cos, int32_t* __restrict__ level, float* __restrict__ radius)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t ok = 0; int c_out = -1, lvl = 0; float uo = 0, vo = 0, vc = 0, rad = 0;
+    if (!candidate || candidate[i]) {
+        const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
+        const float N0 = normal[3 * i], N1 = normal[3 * i + 1], N2 = normal[3 * i + 2];
+        const float mind = __fmul_rn(0.8f, min_dist[i]), maxd = __fmul_rn(1.2f, max_dist[i]), maxd_raw = max_dist[i];
+        for (int ic = 0; ic < F.n_cams; ++ic) {
+            float Pic[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float t0 = __fadd_rn(__fadd_rn(__fmul_rn(F.R[ic][3 * r], P0), __fmul_rn(F.R[ic][3 * r + 1], P1)), __fmul_rn(F.R[ic][3 * r + 2], P2));
+                Pic[r] = (float)((double)t0 + (double)F.t[ic][r]);
+            }
+            if (Pic[2] < 0.0f) continue;
+            const float invz = __fdiv_rn(1.0f, Pic[2]);
+            const float u = __fadd_rn(__fmul_rn(__fmul_rn(F.fx[ic], Pic[0]), invz), F.cx[ic]);
+            const float v = __fadd_rn(__fmul_rn(__fmul_rn(F.fy[ic], Pic[1]), invz), F.cy[ic]);
+            if (u < F.min_x[ic] || u > F.max_x[ic]) continue;
+            if (v < F.min_y[ic] || v > F.max_y[ic]) continue;
+            const float d0 = __fsub_rn(P0, F.O[ic][0]), d1 = __fsub_rn(P1, F.O[ic][1]), d2 = __fsub_rn(P2, F.O[ic][2]);
+            const double s = __dadd_rn(__dadd_rn(__dmul_rn((double)d0, (double)d0), __dmul_rn((double)d1, (double)d1)), __dmul_rn((double)d2, (double)d2));
+            const float dist = (float)sqrt(s);
+            if (dist < mind || dist > maxd) continue;
+            const double dot = __dadd_rn(__dadd_rn(__dmul_rn((double)d0, (double)N0), __dmul_rn((double)d1, (double)N1)), __dmul_rn((double)d2, (double)N2));
+            const float viewCos = (float)(dot / (double)dist);
+            if (viewCos < cos_limit) continue;
+            const float ratio = __fdiv_rn(maxd_raw, dist);
+            const float lg = (float)log((double)ratio);                   // correctly rounded logf for all but ~2^-29 of the inputs
+            int nScale = (int)ceilf(__fdiv_rn(lg, F.log_scale));
+            nScale = nScale < 0 ? 0 : (nScale >= F.n_levels ? F.n_levels - 1 : nScale);
+            float r = ((double)viewCos > 0.998) ? 2.5f : 4.0f;
+            if (th != 1.0f) r = __fmul_rn(r, th);
+            ok = 1; c_out = ic; uo = u; vo = v; vc = viewCos; lvl = nScale; rad = __fmul_rn(r, F.scale_factors[nScale]);
+            break;
+        }
+    }
+    in_view[i] = ok; cam[i] = c_out; u_out[i] = uo; v_out[i] = vo; view_cos[i] = vc; level[i] = lvl; radius[i] = rad;
+}
+
 struct Scratch {
     std::vector<void*> ptrs;
     ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
@@ -515,6 +573,50 @@ int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* q
     int32_t nm = 0;
     DCS_HIP(hipMemcpy(&nm, d_nm, sizeof(int32_t), hipMemcpyDeviceToHost));
     *n_matches = nm;
+    return DCS_OK;
+}
+
+int dcs_is_in_frustum(const dcs_frustum_frame* f, int n, const float* pos, const float* normal, const float* min_dist, const float* max_dist,
+                      const uint8_t* candidate, float viewing_cos_limit, float th, uint8_t* in_view, int32_t* cam, float* u, float* v,
+                      float* view_cos, int32_t* level, float* radius)
+{
+    if (!f || n < 0 || f->n_cams < 1 || f->n_cams > kFrMaxCams || f->n_scale_levels < 1 || !f->Rsw || !f->tsw || !f->Ow || !f->fx || !f->fy || !f->cx ||
+        !f->cy || !f->min_x || !f->max_x || !f->min_y || !f->max_y || !f->scale_factors ||
+        (n && (!pos || !normal || !min_dist || !max_dist || !in_view || !cam || !u || !v || !view_cos || !level || !radius))) {
+        set_error("dcs_is_in_frustum: bad argument"); return DCS_ERR_INVALID;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) return DCS_OK;
+    FrustumDev F{};
+    F.n_cams = f->n_cams; F.n_levels = f->n_scale_levels; F.log_scale = f->log_scale_factor;
+    for (int c = 0; c < f->n_cams; ++c) {
+        for (int k = 0; k < 9; ++k) F.R[c][k] = f->Rsw[9 * c + k];
+        for (int k = 0; k < 3; ++k) { F.t[c][k] = f->tsw[3 * c + k]; F.O[c][k] = f->Ow[3 * c + k]; }
+        F.fx[c] = f->fx[c]; F.fy[c] = f->fy[c]; F.cx[c] = f->cx[c]; F.cy[c] = f->cy[c];
+        F.min_x[c] = f->min_x[c]; F.max_x[c] = f->max_x[c]; F.min_y[c] = f->min_y[c]; F.max_y[c] = f->max_y[c];
+    }
+    Scratch s;
+    const float *d_pos, *d_nrm, *d_min, *d_max, *d_sf;
+    float *d_u, *d_v, *d_vc, *d_rad;
+    const uint8_t* d_cand = nullptr;
+    uint8_t* d_in;
+    int32_t *d_cam, *d_lvl;
+    if ((rc = s.upload(&d_pos, pos, (size_t)3 * n)) || (rc = s.upload(&d_nrm, normal, (size_t)3 * n)) || (rc = s.upload(&d_min, min_dist, n)) ||
+        (rc = s.upload(&d_max, max_dist, n)) || (rc = s.upload(&d_sf, f->scale_factors, f->n_scale_levels)) || (candidate && (rc = s.upload(&d_cand, candidate, n))) ||
+        (rc = s.alloc(&d_in, n)) || (rc = s.alloc(&d_cam, n)) || (rc = s.alloc(&d_u, n)) || (rc = s.alloc(&d_v, n)) || (rc = s.alloc(&d_vc, n)) ||
+        (rc = s.alloc(&d_lvl, n)) || (rc = s.alloc(&d_rad, n))) return rc;
+    F.scale_factors = d_sf;
+    hipLaunchKernelGGL(k_frustum, dim3((n + 255) / 256), dim3(256), 0, 0, F, n, d_pos, d_nrm, d_min, d_max, d_cand, viewing_cos_limit, th, d_in, d_cam, d_u, d_v,
+                       d_vc, d_lvl, d_rad);
+    DCS_CHECK_LAUNCH();
+    DCS_HIP(hipMemcpy(in_view, d_in, n, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(cam, d_cam, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(u, d_u, sizeof(float) * n, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(v, d_v, sizeof(float) * n, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(view_cos, d_vc, sizeof(float) * n, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(level, d_lvl, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(radius, d_rad, sizeof(float) * n, hipMemcpyDeviceToHost));
     return DCS_OK;
 }
 

@@ -77,6 +77,23 @@ public:
         return n;
     }
 
+    // Frame::isInFrustum (Frame.cc:244-312) for all local map points of Tracking::SearchLocalPoints (Tracking.cc:1617-1680) in one
+    // call, fused with PredictScale and the window of SearchByProjection (:557-565). `frame` carries Tsw = mvExtrinsics[c] * mTcw
+    // and GetCameraCenter(c) as the caller's cv::Mat code forms them; the outputs fill the valid / cam / u / v / radius /
+    // level -+ 1 columns of dcs_proj_queries (and pMP->mbTrackInView, mTrackProjX/Y, mnTrackScaleLevel, mTrackViewCos).
+    struct FrustumResult { std::vector<uint8_t> inView; std::vector<int32_t> cam, level; std::vector<float> u, v, viewCos, radius; };
+    static void IsInFrustum(const dcs_frustum_frame& frame, const std::vector<float>& worldPos, const std::vector<float>& normal,
+                            const std::vector<float>& minDistance, const std::vector<float>& maxDistance, const std::vector<uint8_t>& candidate,
+                            float viewingCosLimit, float th, FrustumResult& r)
+    {
+        const int n = (int)minDistance.size();
+        const size_t m = n > 0 ? (size_t)n : 1;
+        r.inView.assign(m, 0); r.cam.assign(m, -1); r.level.assign(m, 0); r.u.assign(m, 0.f); r.v.assign(m, 0.f); r.viewCos.assign(m, 0.f); r.radius.assign(m, 0.f);
+        check(dcs_is_in_frustum(&frame, n, worldPos.data(), normal.data(), minDistance.data(), maxDistance.data(), candidate.empty() ? nullptr : candidate.data(),
+                                viewingCosLimit, th, r.inView.data(), r.cam.data(), r.u.data(), r.v.data(), r.viewCos.data(), r.level.data(), r.radius.data()),
+              "dcs_is_in_frustum");
+    }
+
     // best / second-best distances of every query (the loop at ORBmatcher.cc:208-231 over all candidates)
     static void Knn2(const std::vector<uint8_t>& q, const std::vector<uint8_t>& t, std::vector<int32_t>& bestIdx,
                      std::vector<int32_t>& bestDist, std::vector<int32_t>& secondDist)

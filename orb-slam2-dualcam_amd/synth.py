@@ -477,3 +477,51 @@ def descriptors_near_words(voc, n, seed=3, flip=10):
     leaves = np.nonzero(voc["is_leaf"])[0]
     d = voc["desc"][leaves[rng.integers(0, len(leaves), n)]].copy()
     return noisy_copy(d, flip_bits=flip, seed=seed + 1)
+
+
+# ----------------------------------------------------------------------------- isInFrustum
+def frustum_problem(n_points=3000, seed=4, n_cams=2):
+    """Synthetic input of Frame::isInFrustum (Frame.cc:244-312) as called by Tracking::SearchLocalPoints (Tracking.cc:1617-1680):
+    a frame pose, the rig's cameras (Tsw = Tsc * Tcw and the camera centres, formed in float32 like the caller's cv::Mat code),
+    and local map points all around the rig -- in front of cam0, only visible to cam1 (it looks ~69 deg to the side), behind
+    both, outside the image bounds, outside the scale-invariance distances, seen from a bad angle, and looked at head-on
+    (viewCos > 0.998 -> the narrow window). Returns (frame dict, points dict)."""
+    rng = np.random.default_rng(seed)
+    T0, T1 = rig_extrinsics_f32()
+    ext = [T0, T1][:n_cams]
+    rv = rng.normal(0, 0.2, 3)
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[:3, :3] = _rodrigues(rv).astype(np.float32)
+    Tcw[:3, 3] = rng.normal(0, 0.5, 3).astype(np.float32)
+    Rsw, tsw, Ow = [], [], []
+    for T in ext:
+        Tsw = (T.astype(np.float32) @ Tcw).astype(np.float32)
+        R, t = Tsw[:3, :3], Tsw[:3, 3]
+        Rsw.append(R.reshape(9)); tsw.append(t); Ow.append((-(R.T @ t)).astype(np.float32))
+    scale = np.ones(8, np.float32)
+    for i in range(1, 8):
+        scale[i] = np.float32(np.float64(scale[i - 1]) * np.float64(np.float32(1.2)))
+    k = [RIG["cam0"], RIG["cam1"]][:n_cams]
+    frame = dict(Rsw=np.array(Rsw, np.float32), tsw=np.array(tsw, np.float32), Ow=np.array(Ow, np.float32),
+                 fx=np.array([c["fx"] for c in k], np.float32), fy=np.array([c["fy"] for c in k], np.float32),
+                 cx=np.array([c["cx"] for c in k], np.float32), cy=np.array([c["cy"] for c in k], np.float32),
+                 min_x=np.full(n_cams, -2.5, np.float32), max_x=np.full(n_cams, 642.0, np.float32),
+                 min_y=np.full(n_cams, -1.5, np.float32), max_y=np.full(n_cams, 481.0, np.float32),
+                 log_scale_factor=np.float32(np.log(np.float32(1.2))), scale_factors=scale)
+    # points on a shell around the rig centre (all directions), 1..12 m
+    d = rng.normal(0, 1, (n_points, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = rng.uniform(1.0, 12.0, n_points)
+    centre = Ow[0].astype(np.float64)
+    pos = (centre + d * dist[:, None]).astype(np.float32)
+    # mean viewing direction: from the observing keyframes towards the point; mostly aligned with the current ray, some oblique,
+    # some exactly head-on
+    ray = pos.astype(np.float64) - centre; ray /= np.linalg.norm(ray, axis=1, keepdims=True)
+    jitter = rng.normal(0, 1, (n_points, 3)) * rng.choice([0.0, 0.05, 0.4, 1.5], n_points, p=[0.15, 0.45, 0.3, 0.1])[:, None]
+    nrm = ray + jitter; nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    # scale-invariance range: the point was created at distance d0 on level l0: max = d0 * s[l0], min = max / s[7]
+    d0 = dist * rng.uniform(0.4, 2.5, n_points)
+    l0 = rng.integers(0, 8, n_points)
+    max_dist = (d0 * scale[l0]).astype(np.float32)
+    min_dist = (max_dist / scale[7]).astype(np.float32)
+    cand = (rng.random(n_points) < 0.9).astype(np.uint8)
+    return frame, dict(pos=pos, normal=nrm.astype(np.float32), min_dist=min_dist, max_dist=max_dist, candidate=cand)

@@ -153,3 +153,49 @@ def test_search_by_projection(pkg, oracle, synth, kw):
     q0 = {k: v[:0] for k, v in q.items()}
     mq, qf, n = m.SearchByProjection(frame, q0)
     assert n == 0 and len(mq) == 0 and (qf == -1).all()
+
+
+def test_is_in_frustum_and_projection_chain(pkg, oracle, synth):
+    """Frame::isInFrustum + PredictScale + window (dcs_is_in_frustum) vs the oracle, float outputs bit for bit; then the chain of
+    Tracking::SearchLocalPoints: frustum gate -> projection queries -> SearchByProjection, GPU vs oracle end to end."""
+    frame, pts = synth.frustum_problem(n_points=20000, seed=3)
+    for cos_limit, th in ((0.5, 1.0), (0.5, 3.0), (0.8, 5.0)):
+        got, exp = pkg.isInFrustum(frame, pts, cos_limit, th), oracle.is_in_frustum(frame, pts, cos_limit, th)
+        for k in ("in_view", "cam"):
+            assert np.array_equal(got[k], exp[k]), k
+        for k in ("u", "v", "view_cos"):
+            assert got[k].tobytes() == exp[k].tobytes(), k
+        flips = int(np.sum(got["level"] != exp["level"]))        # logf (glibc) vs float(log(double)) on the GPU: an ulp can tip the ceil (Q13)
+        assert flips <= 1
+        same = got["level"] == exp["level"]
+        assert got["radius"][same].tobytes() == exp["radius"][same].tobytes()
+    assert exp["in_view"].sum() > 500 and (exp["cam"] == 1).sum() > 200
+    one = {k: (v[:1] if k not in ("scale_factors", "log_scale_factor") else v) for k, v in frame.items()}      # bForAllCam = false
+    g1, e1 = pkg.isInFrustum(one, pts), oracle.is_in_frustum(one, pts)
+    assert np.array_equal(g1["in_view"], e1["in_view"]) and (g1["cam"] <= 0).all() and g1["in_view"].sum() < exp["in_view"].sum()
+    empty = {k: v[:0] for k, v in pts.items()}
+    assert len(pkg.isInFrustum(frame, empty)["in_view"]) == 0
+    # chain: features of a synthetic frame placed where visible points project; queries built from the frustum outputs
+    fr = pkg.isInFrustum(frame, pts, 0.5, 1.0)
+    vis = np.nonzero(fr["in_view"])[0]
+    rng = np.random.default_rng(1)
+    n_cams = 2
+    per_cam = [vis[fr["cam"][vis] == c] for c in range(n_cams)]
+    cam_off = np.array([0, len(per_cam[0]), len(per_cam[0]) + len(per_cam[1])], np.int32)
+    order = np.concatenate(per_cam)
+    N = len(order)
+    desc_mp = synth.random_descriptors(len(pts["pos"]), seed=12)
+    kp_x = (fr["u"][order] + rng.normal(0, 1.0, N)).astype(np.float32)
+    kp_y = (fr["v"][order] + rng.normal(0, 1.0, N)).astype(np.float32)
+    octave = np.clip(fr["level"][order] + rng.integers(-1, 2, N), 0, 7).astype(np.int32)
+    fdesc = synth.noisy_copy(desc_mp[order], flip_bits=12, seed=4)
+    min_x, max_x, min_y, max_y = frame["min_x"], frame["max_x"], frame["min_y"], frame["max_y"]
+    pf = dict(cam_off=cam_off, kp_x=kp_x, kp_y=kp_y, kp_octave=octave, kp_angle=np.zeros(N, np.float32), desc=fdesc, taken=np.zeros(N, np.uint8),
+              min_x=min_x, min_y=min_y, grid_w_inv=(np.float32(64) / (max_x - min_x)).astype(np.float32),
+              grid_h_inv=(np.float32(48) / (max_y - min_y)).astype(np.float32))
+    pf["grid_off"], pf["grid_idx"] = pkg.frame_grid(cam_off, kp_x, kp_y, min_x, min_y, pf["grid_w_inv"], pf["grid_h_inv"])
+    q = pkg.projection_queries(fr, desc_mp)
+    qo = pkg.projection_queries(oracle.is_in_frustum(frame, pts, 0.5, 1.0), desc_mp)
+    mq, qf, n = pkg.ORBmatcher(0.8, False).SearchByProjection(pf, q, 100, use_ratio=True, check_orientation=False)
+    emq, eqf, en = oracle.search_by_projection(pf, qo, 100, 0.8, False)
+    assert np.array_equal(mq, emq) and np.array_equal(qf, eqf) and n == en and n > 0.6 * N

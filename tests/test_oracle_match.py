@@ -211,3 +211,77 @@ def test_projection_search_oracle(oracle, synth):
     mq2, qf2, nm2 = oracle.search_by_projection(frame, q, 100, 0.0, True)
     mq3, _, nm3 = oracle.search_by_projection(frame, q, 100, 0.0, False)
     assert nm2 < nm3 and set(np.nonzero(mq2 >= 0)[0]) <= set(np.nonzero(mq3 >= 0)[0])
+
+
+def _np_frustum(fr, pts, cos_limit, th):
+    """Frame::isInFrustum restated independently with numpy float32 / float64 element-wise arithmetic (vectorised over points)."""
+    f32, f64 = np.float32, np.float64
+    P, Pn = pts["pos"].astype(f32), pts["normal"].astype(f32)
+    n = len(P)
+    out = dict(in_view=np.zeros(n, np.uint8), cam=np.full(n, -1, np.int32), u=np.zeros(n, f32), v=np.zeros(n, f32), view_cos=np.zeros(n, f32),
+               level=np.zeros(n, np.int32), radius=np.zeros(n, f32))
+    todo = pts["candidate"].astype(bool).copy() if pts.get("candidate") is not None else np.ones(n, bool)
+    for c in range(len(fr["fx"])):
+        R, t, O = fr["Rsw"][c].reshape(3, 3), fr["tsw"][c], fr["Ow"][c]
+        pic = []
+        for r in range(3):
+            t0 = (R[r, 0] * P[:, 0] + R[r, 1] * P[:, 1]) + R[r, 2] * P[:, 2]          # float32, left to right
+            pic.append((t0.astype(f64) + f64(t[r])).astype(f32))
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            invz = f32(1.0) / pic[2]
+            u = fr["fx"][c] * pic[0] * invz + fr["cx"][c]
+            v = fr["fy"][c] * pic[1] * invz + fr["cy"][c]
+            po = P - O
+            dist = np.sqrt(po[:, 0].astype(f64) ** 2 + po[:, 1].astype(f64) ** 2 + po[:, 2].astype(f64) ** 2).astype(f32)
+            dot = po[:, 0].astype(f64) * Pn[:, 0] + po[:, 1].astype(f64) * Pn[:, 1] + po[:, 2].astype(f64) * Pn[:, 2]
+            vc = (dot / dist.astype(f64)).astype(f32)
+            ratio = pts["max_dist"].astype(f32) / dist
+            lvl = np.ceil(np.log(ratio.astype(f64)).astype(f32) / f32(fr["log_scale_factor"]))
+        ok = todo & ~(pic[2] < 0) & ~((u < fr["min_x"][c]) | (u > fr["max_x"][c])) & ~((v < fr["min_y"][c]) | (v > fr["max_y"][c]))
+        ok &= ~((dist < f32(0.8) * pts["min_dist"]) | (dist > f32(1.2) * pts["max_dist"])) & ~(vc < f32(cos_limit))
+        lv = np.clip(np.nan_to_num(lvl, nan=0, posinf=1e6, neginf=-1e6), 0, len(fr["scale_factors"]) - 1).astype(np.int32)
+        r = np.where(vc.astype(f64) > 0.998, f32(2.5), f32(4.0)).astype(f32)
+        if f32(th) != f32(1.0):
+            r = r * f32(th)
+        for k, val in (("cam", c), ("u", u), ("v", v), ("view_cos", vc), ("level", lv), ("radius", r * fr["scale_factors"][lv])):
+            out[k][ok] = val[ok] if isinstance(val, np.ndarray) else val
+        out["in_view"][ok] = 1
+        todo &= ~ok
+    return out
+
+
+def test_is_in_frustum_by_hand_and_vs_numpy(oracle, synth):
+    f32 = np.float32
+    scale = np.array([1, 1.2, 1.44, 1.728], f32)
+    eye = np.eye(3, dtype=f32).reshape(9)
+    side = np.array([[0, 0, -1], [0, 1, 0], [1, 0, 0]], f32).reshape(9)          # second camera looks along +x
+    fr = dict(Rsw=np.stack([eye, side]), tsw=np.zeros((2, 3), f32), Ow=np.zeros((2, 3), f32), fx=[500, 500], fy=[500, 500], cx=[320, 320],
+              cy=[240, 240], min_x=[0, 0], max_x=[640, 640], min_y=[0, 0], max_y=[480, 480], log_scale_factor=f32(np.log(f32(1.2))), scale_factors=scale)
+    pos = np.array([[0, 0, 5], [0.5, -0.25, 5], [0, 0, -5], [4, 0, 5], [0, 0, 5], [0, 0, 5], [0, 0, 5], [5, 0, 0.01], [0, 0, 5]], f32)
+    nrm = np.array([[0, 0, 1], [0, 0, 1], [0, 0, -1], [0, 0, 1], [0, 0, 1], [0, 0, 1], [1, 0, 0], [1, 0, 0], [0, 0, 1]], f32)
+    max_d = np.array([7.5, 7.5, 7.5, 7.5, 4.0, 100.0, 7.5, 7.5, 7.5], f32)
+    min_d = np.array([1, 1, 1, 1, 1, 80.0, 1, 1, 1], f32)
+    cand = np.array([1, 1, 1, 1, 1, 1, 1, 1, 0], np.uint8)
+    r = oracle.is_in_frustum(fr, dict(pos=pos, normal=nrm, min_dist=min_d, max_dist=max_d, candidate=cand), 0.5, 1.0)
+    # 0: straight ahead; 1: off-centre; 2: behind both cameras' ... (cam1 sees x > 0 only); 3: outside cam0's image; 4: too far (5 > 1.2 * 4);
+    # 5: too close (5 < 0.8 * 80); 6: normal perpendicular to the ray; 7: only the side camera sees it; 8: not a candidate
+    assert r["in_view"].tolist() == [1, 1, 0, 0, 0, 0, 0, 1, 0]
+    assert r["cam"].tolist() == [0, 0, -1, -1, -1, -1, -1, 1, -1]
+    assert r["u"][0] == 320 and r["v"][0] == 240 and r["view_cos"][0] == 1
+    assert r["u"][1] == f32(500) * f32(0.5) * (f32(1) / f32(5)) + f32(320) and r["v"][1] == f32(500) * f32(-0.25) * (f32(1) / f32(5)) + f32(240)
+    assert r["level"][0] == 3 and r["radius"][0] == f32(2.5) * scale[3]           # log(1.5) / log(1.2) = 2.22 -> 3; head-on -> 2.5
+    assert r["view_cos"][1] < 0.998 and r["radius"][1] == f32(4.0) * scale[r["level"][1]]
+    assert r["level"][7] == 3 and abs(r["u"][7] - (500 * -0.01 / 5 + 320)) < 1e-3 and r["v"][7] == 240      # side camera: x_cam = -z_world
+    r3 = oracle.is_in_frustum(fr, dict(pos=pos, normal=nrm, min_dist=min_d, max_dist=max_d, candidate=cand), 0.5, 3.0)
+    assert r3["radius"][0] == f32(2.5) * f32(3.0) * scale[3]
+    r1 = oracle.is_in_frustum({k: (v[:1] if isinstance(v, (list, np.ndarray)) and k != "scale_factors" else v) for k, v in fr.items()},
+                              dict(pos=pos, normal=nrm, min_dist=min_d, max_dist=max_d, candidate=cand), 0.5, 1.0)
+    assert r1["in_view"].tolist() == [1, 1, 0, 0, 0, 0, 0, 0, 0]                 # bForAllCam = false: only camera 0
+    # the synthetic rig problem against the independent numpy statement
+    frame, pts = synth.frustum_problem(n_points=4000, seed=9)
+    for cos_limit, th in ((0.5, 1.0), (0.5, 3.0), (0.9, 5.0)):
+        a, b = oracle.is_in_frustum(frame, pts, cos_limit, th), _np_frustum(frame, pts, cos_limit, th)
+        for k in ("in_view", "cam", "u", "v", "view_cos", "radius"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.sum(a["level"] != b["level"]) <= 1                            # logf vs rounded log: an ulp can tip a ceil (DESIGN.md Q13)
+    assert a["in_view"].sum() > 50 and (a["cam"] == 1).sum() > 20
