@@ -7,7 +7,7 @@ pkg = e.load_package(); oracle = e.load_oracle(); synth = pkg.synth
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
-cnt = dict(filter=0, grouped=0, bow=0, proj=0, distinct=0, ba=0, gba=0, pose=0, voc=0); bad = 0
+cnt = dict(filter=0, grouped=0, bow=0, proj=0, distinct=0, ba=0, gba=0, pose=0, voc=0, frustum=0); bad = 0
 TRACE = os.environ.get("STRESS_TRACE")
 def tr(*a):
     if TRACE: print("..", *a, flush=True)
@@ -84,6 +84,16 @@ while time.time() < t_end:
     idxd = np.concatenate([rng.choice(len(pool), s, replace=False) for s in sizes] + [np.zeros(0, np.int64)]).astype(np.int32)
     if not np.array_equal(pkg.ComputeDistinctiveDescriptors(pool, offd, idxd), oracle.distinctive_descriptors(pool, offd, idxd)): report("distinctive", len(pool), len(sizes))
     cnt["distinct"] += 1
+    # ---- isInFrustum + PredictScale + window
+    frf, ptf = synth.frustum_problem(n_points=int(rng.integers(1, 6000)), seed=seed % 100000, n_cams=int(rng.integers(1, 3)))
+    cl, thf = float(rng.choice([0.5, 0.0, 0.9])), float(rng.choice([1.0, 3.0, 5.0]))
+    tr('frustum', len(ptf["pos"]), cl, thf)
+    g, x = pkg.isInFrustum(frf, ptf, cl, thf), oracle.is_in_frustum(frf, ptf, cl, thf)
+    same = g["level"] == x["level"]
+    if not (all(g[k].tobytes() == x[k].tobytes() for k in ("in_view", "cam", "u", "v", "view_cos")) and (~same).sum() <= 1 and g["radius"][same].tobytes() == x["radius"][same].tobytes()):
+        report("frustum", len(ptf["pos"]), cl, thf, seed)
+    if (~same).any(): soft["frustum_level_ulp"] = soft.get("frustum_level_ulp", 0) + int((~same).sum())
+    cnt["frustum"] += 1
     # ---- BoW front half: random vocabulary tree, transform, L1 scores
     vk, vL = int(rng.integers(2, 11)), int(rng.integers(1, 6))
     if vk ** vL <= 20000:
