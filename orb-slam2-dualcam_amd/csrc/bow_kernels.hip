@@ -249,25 +249,6 @@ struct dcs_vocab {
     int norm_kind() const { return scoring == 5 ? 0 : (scoring == 1 ? 2 : 1); }      // mustNormalize, ScoringObject.h:76-91
 };
 
-namespace {
-struct Scratch {
-    std::vector<void*> ptrs;
-    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
-    template <typename T> int alloc(T** out, size_t n) {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
-        if (e != hipSuccess) { set_error("hipMalloc: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
-        ptrs.push_back(p); *out = (T*)p; return DCS_OK;
-    }
-    template <typename T> int upload(T** out, const T* src, size_t n) {
-        int rc = alloc(out, n);
-        if (rc) return rc;
-        if (n) DCS_HIP(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice));
-        return DCS_OK;
-    }
-};
-}  // namespace
-
 extern "C" {
 
 int dcs_vocab_create(int k, int L, int scoring, int weighting, int n_rows, const int32_t* parent, const uint8_t* is_leaf,

@@ -5,7 +5,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "../../include/dcs_abi.h"
 
@@ -51,6 +53,33 @@ struct PinnedBuf {
         DCS_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
         n = count;
         return DCS_OK;
+    }
+};
+
+// per-call device scratch of the host-buffer entry points (re-entrant: nothing is cached between calls)
+struct Scratch {
+    std::vector<void*> ptrs;
+    Scratch() = default;
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T> int alloc(T** out, size_t n) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) { set_error("hipMalloc: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
+        ptrs.push_back(p); *out = (T*)p; return DCS_OK;
+    }
+    template <typename T> int upload(T** out, const T* src, size_t n) {
+        int rc = alloc(out, n);
+        if (rc) return rc;
+        if (n) DCS_HIP(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice));
+        return DCS_OK;
+    }
+    template <typename T> int upload(const T** out, const T* src, size_t n) {
+        T* d = nullptr;
+        int rc = upload(&d, src, n);
+        *out = d;
+        return rc;
     }
 };
 

@@ -561,22 +561,6 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ 
 using namespace dcs;
 
 namespace {
-struct Scratch {                       // per-call device scratch for the host-buffer entry points (re-entrant)
-    std::vector<void*> ptrs;
-    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
-    template <typename T> int alloc(T** out, size_t n) {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
-        if (e != hipSuccess) { set_error("hipMalloc: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
-        ptrs.push_back(p); *out = (T*)p; return DCS_OK;
-    }
-    template <typename T> int upload(T** out, const T* src, size_t n) {
-        int rc = alloc(out, n);
-        if (rc) return rc;
-        if (n) DCS_HIP(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice));
-        return DCS_OK;
-    }
-};
 }  // namespace
 
 extern "C" {

@@ -463,23 +463,6 @@ __global__ __launch_bounds__(256) void k_frustum(FrustumDev F, int n, const floa
     in_view[i] = ok; cam[i] = c_out; u_out[i] = uo; v_out[i] = vo; view_cos[i] = vc; level[i] = lvl; radius[i] = rad;
 }
 
-struct Scratch {
-    std::vector<void*> ptrs;
-    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
-    template <typename T> int alloc(T** out, size_t n) {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
-        if (e != hipSuccess) { set_error("hipMalloc: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
-        ptrs.push_back(p); *out = (T*)p; return DCS_OK;
-    }
-    template <typename T> int upload(const T** out, const T* src, size_t n) {
-        T* d = nullptr;
-        int rc = alloc(&d, n);
-        if (rc) return rc;
-        if (n) DCS_HIP(hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
-        *out = d; return DCS_OK;
-    }
-};
 
 }  // namespace
 }  // namespace dcs
