@@ -445,7 +445,7 @@ __device__ __forceinline__ double fast_recip(double d)
 
 template <int NBLK>
 __global__ __launch_bounds__(1024) void k_ldlt_reg(const double* __restrict__ S, int ld, int n, const double* __restrict__ b,
-                                                   double* __restrict__ x, double* __restrict__ ok, int dbg_skip)
+                                                   double* __restrict__ x, double* __restrict__ ok)
 {
     constexpr int NS = NBLK * (NBLK + 1) / 2;
 #define SLOT(bi, bj) ((bi) * ((bi) + 1) / 2 + (bj))
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(1024) void k_ldlt_reg(const double* __restrict__ S,
 #pragma nounroll
         for (int kt = 0; kt < 32; ++kt) {
             const int k = kb * 32 + kt;
-            if (k >= n || (dbg_skip & 1)) break;
+            if (k >= n) break;
             double* cb = col[k & 1];
             if (tj == kt) {
 #pragma unroll
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(1024) void k_ldlt_reg(const double* __restrict__ S,
     // the rows of this block are eliminated from all earlier blocks with a fixed-order reduction over the waves.
 #pragma unroll
     for (int kb = NBLK - 1; kb >= 0; --kb) {
-        if (kb * 32 >= n || (dbg_skip & 2)) continue;
+        if (kb * 32 >= n) continue;
         Lkk[ti][tj] = a[SLOT(kb, kb)];
         __syncthreads();
         if (wave == 0) {
@@ -1374,7 +1374,6 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
     const bool force_blocked = getenv("DCS_BA_FORCE_BLOCKED_LDLT") != nullptr;
     const bool ldlt_valu = getenv("DCS_BA_LDLT_VALU") != nullptr;       // previous register-resident column-by-column kernel
     const bool trace_t = getenv("DCS_BA_TRACE") != nullptr;
-    const int dbg_skip = getenv("DCS_BA_DBG_SKIP") ? atoi(getenv("DCS_BA_DBG_SKIP")) : 0;   // timing experiments only
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     const auto t_call0 = now();
@@ -1476,7 +1475,7 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
                                        d_maxdiag, mult, d_BD, d_Hpl, d_S, ld, r.n_pairs, bs);
                     DCS_CHECK_LAUNCH();
                     if (use_reg) {
-                        if (ldlt_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(1), dim3(1024), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3, dbg_skip);
+                        if (ldlt_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(1), dim3(1024), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3);
                         else hipLaunchKernelGGL(k_ldlt_mfma, dim3(1), dim3(512), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3);
                         DCS_CHECK_LAUNCH();
                     } else {

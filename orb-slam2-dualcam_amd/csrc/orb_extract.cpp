@@ -353,7 +353,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     DescribeParams dp{};
     for (int l = 0; l < L; ++l) { dp.scale[l] = t.scale[l]; dp.scaled_patch[l] = g.lv[l].scaled_patch; dp.out_base[l] = oct.lv[l].out_base; }
     for (int v = 0; v <= kHalfPatch; ++v) { dp.umax[v] = t.umax[v]; dp.umax_packed |= (unsigned long long)(t.umax[v] & 15) << (4 * v); }
-    dp.out_per_image = oct.out_per_image; dp.nlevels = L; dp.ic_mask = d_ic_mask.p; dp.dbg = getenv("DCS_DESC_DBG") ? atoi(getenv("DCS_DESC_DBG")) : 0;
+    dp.out_per_image = oct.out_per_image; dp.nlevels = L; dp.ic_mask = d_ic_mask.p;
     if (device_octree) {
         // fully asynchronous: quadtree on the device, no host round trip
         if (cap < oct.out_per_image) {

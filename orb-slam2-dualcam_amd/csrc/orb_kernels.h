@@ -42,7 +42,6 @@ struct DescribeParams {
     // device-quadtree mode: keypoints of (image, level) live at sel[image * out_per_image + out_base[level] ...]
     int out_base[kMaxLevels];
     int out_per_image, nlevels;
-    int dbg;
     const uint32_t* ic_mask;             // device table built by build_ic_mask()
 };
 

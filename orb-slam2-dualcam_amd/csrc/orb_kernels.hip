@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
     const int n_here = min(kDescKp, n_img - i0);             // keypoints of this workgroup
 
     // ---- A. IC_Angle moments on the unblurred level
-    if (!(prm.dbg & 1)) {
+    {
         const int grp = lane >> 4, sub = lane & 15;
 #pragma unroll 1
         for (int batch = 0; batch < 4; ++batch) {
@@ -881,8 +881,7 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
         const float angle = fast_atan2_deg((float)s_m01[tid], (float)s_m10[tid]);
         const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
         const float rad = __fmul_rn(angle, factorPI);
-        if (prm.dbg & 2) { s_cos[tid] = 1.f; s_sin[tid] = rad; } else {
-        s_cos[tid] = (float)cos((double)rad); s_sin[tid] = (float)sin((double)rad); }
+        s_cos[tid] = (float)cos((double)rad); s_sin[tid] = (float)sin((double)rad);
         dcs_keypoint o;
         const int level = k.level;
         const float sc = prm.scale[level];
@@ -909,11 +908,11 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
         q1 = *reinterpret_cast<const uint4*>(bsrc + (size_t)(r_lane + 16) * bv.pitch);
         q2 = *reinterpret_cast<const uint4*>(bsrc + (size_t)min(r_lane + 32, kPatchRows - 1) * bv.pitch);
     };
-    if (wave * 16 < n_here && !(prm.dbg & 4)) fetch(wave * 16);
+    if (wave * 16 < n_here) fetch(wave * 16);
 #pragma unroll 1
     for (int kk = 0; kk < 16; ++kk) {
         const int kq = wave * 16 + kk;
-        if (kq >= n_here || (prm.dbg & 4)) break;            // wave-uniform
+        if (kq >= n_here) break;                              // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // previous keypoint's LDS reads are done
         __builtin_amdgcn_wave_barrier();
         reinterpret_cast<uint4*>(patch)[lane] = q0;
