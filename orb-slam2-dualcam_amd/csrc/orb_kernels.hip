@@ -313,30 +313,42 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     const int dw = rw - 6, dh = rh - 6, ndet = dw * dh;
     // ---- 2. compass test + ordered compaction; survivors are stored as (y << 8 | x), ROI coordinates
     int n_list = 0;
-    auto compass = [&](const uint8_t* c) -> bool {
-        // a 9-arc covers two ADJACENT compass pixels: (b0|b8)&(b4|b12) for "brighter", same for "darker"
+    // a 9-arc covers two ADJACENT compass pixels: (b0|b8)&(b4|b12) for "brighter", same for "darker". The two compares are
+    // balloted one by one (ballot of a plain compare IS the compare's SGPR mask; a ballot of their OR would be rebuilt through
+    // v_cndmask + v_cmp) and combined with scalar 64-bit logic.
+    auto compass = [&](const uint8_t* c, bool& brighter, bool& darker) {
         const int v = c[0], hi = v + min_th, lo = v - min_th;
         const int r0 = c[3 * P], r4 = c[3], r8 = c[-3 * P], r12 = c[-3];
-        return min(max(r0, r8), max(r4, r12)) > hi || max(min(r0, r8), min(r4, r12)) < lo;
+        brighter = min(max(r0, r8), max(r4, r12)) > hi;
+        darker = max(min(r0, r8), min(r4, r12)) < lo;
     };
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    // position of this lane among the set bits of a ballot: v_mbcnt_lo + v_mbcnt_hi
+    auto rank_in = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     if (dw <= 32) {                                  // two detection rows per round: lanes 0-31 row y, lanes 32-63 row y + 1
         const int x = 3 + (lane & 31);
         const bool col_ok = (lane & 31) < dw;
+        const unsigned long long m_col = __builtin_amdgcn_ballot_w64(col_ok);
         const uint8_t* c = px + (3 + (lane >> 5)) * P + x;
-        for (int y = 3 + (lane >> 5); y < 3 + dh + (lane >> 5); y += 2, c += 2 * P) {     // same trip count in both halves
-            const bool pass = col_ok && y < dh + 3 && compass(c);
-            const unsigned long long m = __ballot(pass);
-            if (pass) s_list[n_list + __popcll(m & lanes_below)] = (uint16_t)((y << 8) | x);
+        int y = 3 + (lane >> 5);
+        for (int yy = 0; yy < dh; yy += 2, y += 2, c += 2 * P) {                          // wave-uniform trip count
+            // every lane evaluates the test (a lane outside the detection area reads the zeroed score map at worst: still inside
+            // the LDS allocation)
+            bool br, dk;
+            compass(c, br, dk);
+            const bool y_ok = y < dh + 3;
+            const unsigned long long m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & m_col & __builtin_amdgcn_ballot_w64(y_ok);
+            if ((br | dk) & col_ok & y_ok) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
             n_list += __popcll(m);
         }
     } else {
         int y = 3 + lane / dw, x = 3 + lane % dw;            // pixel p = p0 + lane, advanced by 64 per round without dividing
         const int step_y = 64 / dw, step_x = 64 % dw;
         for (int p0 = 0; p0 < ndet; p0 += 64) {
-            const bool pass = p0 + lane < ndet && compass(px + y * P + x);
-            const unsigned long long m = __ballot(pass);
-            if (pass) s_list[n_list + __popcll(m & lanes_below)] = (uint16_t)((y << 8) | x);
+            bool br, dk;
+            compass(px + y * P + x, br, dk);
+            const bool in_range = p0 + lane < ndet;
+            const unsigned long long m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & __builtin_amdgcn_ballot_w64(in_range);
+            if ((br | dk) & in_range) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
             n_list += __popcll(m);
             y += step_y; x += step_x;
             if (x >= dw + 3) { x -= dw; ++y; }
