@@ -311,74 +311,86 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     const uint8_t* px = s_px + shift;
     uint8_t* sc = s_sc + shift;
     const int dw = rw - 6, dh = rh - 6, ndet = dw * dh;
-    // ---- 2. compass test + ordered compaction; survivors are stored as (y << 8 | x), ROI coordinates
+    // Steps 2-4 run for the reference's two thresholds in its own order (ORBextractor.cc:806-819): iniThFAST first; only a cell
+    // that yields NO keypoint there is redone at minThFAST. A pass at threshold T only needs the pixels that pass the compass
+    // test at T: every pixel with score >= T does, so the score map holds exactly what the non-maximum suppression at T compares
+    // (a neighbour whose score is missing has score < T <= s(p) and would lose anyway). 91 % of the cells of the benchmark
+    // scene stop after the first pass, which scores a third fewer pixels than the minThFAST pass.
     int n_list = 0;
-    // a 9-arc covers two ADJACENT compass pixels: (b0|b8)&(b4|b12) for "brighter", same for "darker". The two compares are
-    // balloted one by one (ballot of a plain compare IS the compare's SGPR mask; a ballot of their OR would be rebuilt through
-    // v_cndmask + v_cmp) and combined with scalar 64-bit logic.
-    auto compass = [&](const uint8_t* c, bool& brighter, bool& darker) {
-        const int v = c[0], hi = v + min_th, lo = v - min_th;
-        const int r0 = c[3 * P], r4 = c[3], r8 = c[-3 * P], r12 = c[-3];
-        brighter = min(max(r0, r8), max(r4, r12)) > hi;
-        darker = max(min(r0, r8), min(r4, r12)) < lo;
-    };
+    unsigned long long sel = 0;                    // one bit per list round of this lane: keypoints of the pass that produced some
     // position of this lane among the set bits of a ballot: v_mbcnt_lo + v_mbcnt_hi
     auto rank_in = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
-    if (dw <= 32) {                                  // two detection rows per round: lanes 0-31 row y, lanes 32-63 row y + 1
-        const int x = 3 + (lane & 31);
-        const bool col_ok = (lane & 31) < dw;
-        const unsigned long long m_col = __builtin_amdgcn_ballot_w64(col_ok);
-        const uint8_t* c = px + (3 + (lane >> 5)) * P + x;
-        int y = 3 + (lane >> 5);
-        for (int yy = 0; yy < dh; yy += 2, y += 2, c += 2 * P) {                          // wave-uniform trip count
-            // every lane evaluates the test (a lane outside the detection area reads the zeroed score map at worst: still inside
-            // the LDS allocation)
-            bool br, dk;
-            compass(c, br, dk);
-            const bool y_ok = y < dh + 3;
-            const unsigned long long m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & m_col & __builtin_amdgcn_ballot_w64(y_ok);
-            if ((br | dk) & col_ok & y_ok) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
-            n_list += __popcll(m);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int th = pass == 0 ? ini_th : min_th;
+        if (pass == 1 && min_th == ini_th) break;
+        // ---- 2. compass test + ordered compaction; survivors are stored as (y << 8 | x), ROI coordinates
+        // a 9-arc covers two ADJACENT compass pixels: (b0|b8)&(b4|b12) for "brighter", same for "darker". The two compares are
+        // balloted one by one (ballot of a plain compare IS the compare's SGPR mask; a ballot of their OR would be rebuilt through
+        // v_cndmask + v_cmp) and combined with scalar 64-bit logic.
+        auto compass = [&](const uint8_t* c, bool& brighter, bool& darker) {
+            const int v = c[0], hi = v + th, lo = v - th;
+            const int r0 = c[3 * P], r4 = c[3], r8 = c[-3 * P], r12 = c[-3];
+            brighter = min(max(r0, r8), max(r4, r12)) > hi;
+            darker = max(min(r0, r8), min(r4, r12)) < lo;
+        };
+        n_list = 0;
+        if (dw <= 32) {                                  // two detection rows per round: lanes 0-31 row y, lanes 32-63 row y + 1
+            const int x = 3 + (lane & 31);
+            const bool col_ok = (lane & 31) < dw;
+            const unsigned long long m_col = __builtin_amdgcn_ballot_w64(col_ok);
+            const uint8_t* c = px + (3 + (lane >> 5)) * P + x;
+            int y = 3 + (lane >> 5);
+            for (int yy = 0; yy < dh; yy += 2, y += 2, c += 2 * P) {                          // wave-uniform trip count
+                // every lane evaluates the test (a lane outside the detection area reads the score map at worst: still inside
+                // the LDS allocation)
+                bool br, dk;
+                compass(c, br, dk);
+                const bool y_ok = y < dh + 3;
+                const unsigned long long m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & m_col & __builtin_amdgcn_ballot_w64(y_ok);
+                if ((br | dk) & col_ok & y_ok) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
+                n_list += __popcll(m);
+            }
+        } else {
+            int y = 3 + lane / dw, x = 3 + lane % dw;            // pixel p = p0 + lane, advanced by 64 per round without dividing
+            const int step_y = 64 / dw, step_x = 64 % dw;
+            for (int p0 = 0; p0 < ndet; p0 += 64) {
+                bool br, dk;
+                compass(px + y * P + x, br, dk);
+                const bool in_range = p0 + lane < ndet;
+                const unsigned long long m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & __builtin_amdgcn_ballot_w64(in_range);
+                if ((br | dk) & in_range) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
+                n_list += __popcll(m);
+                y += step_y; x += step_x;
+                if (x >= dw + 3) { x -= dw; ++y; }
+            }
         }
-    } else {
-        int y = 3 + lane / dw, x = 3 + lane % dw;            // pixel p = p0 + lane, advanced by 64 per round without dividing
-        const int step_y = 64 / dw, step_x = 64 % dw;
-        for (int p0 = 0; p0 < ndet; p0 += 64) {
-            bool br, dk;
-            compass(px + y * P + x, br, dk);
-            const bool in_range = p0 + lane < ndet;
-            const unsigned long long m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & __builtin_amdgcn_ballot_w64(in_range);
-            if ((br | dk) & in_range) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
-            n_list += __popcll(m);
-            y += step_y; x += step_x;
-            if (x >= dw + 3) { x -= dw; ++y; }
+        __syncthreads();
+        // ---- 3. exact scores of the survivors (a second pass rewrites the first pass's entries with the same values)
+        for (int i = lane; i < n_list; i += 64) {
+            const int yx = s_list[i], y = yx >> 8, x = yx & 255;
+            const int s = fast_score<P>(px + y * P + x);
+            sc[y * P + x] = (uint8_t)max(s, 0);
         }
-    }
-    __syncthreads();
-    // ---- 3. exact scores of the survivors
-    for (int i = lane; i < n_list; i += 64) {
-        const int yx = s_list[i], y = yx >> 8, x = yx & 255;
-        const int s = fast_score<P>(px + y * P + x);
-        sc[y * P + x] = (uint8_t)max(s, 0);
-    }
-    __syncthreads();
-    // ---- 4. NMS: keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } (neighbours below T lose anyway)
-    unsigned long long f_min = 0, f_ini = 0;       // one bit per list round of this lane
-    int it = 0;
-    for (int i = lane; i < n_list; i += 64, ++it) {
-        const int yx = s_list[i], y = yx >> 8, x = yx & 255;
-        const uint8_t* c = sc + y * P + x;
-        const int s = c[0];
-        if (s >= min_th) {
-            const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-P - 1], (int)c[-P])), max(max((int)c[-P + 1], (int)c[P - 1]), max((int)c[P], (int)c[P + 1])));
-            if (s > nb) { f_min |= 1ull << it; if (s >= ini_th) f_ini |= 1ull << it; }
+        __syncthreads();
+        // ---- 4. NMS: keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } (neighbours below T lose anyway)
+        unsigned long long f = 0;
+        int it = 0;
+        for (int i = lane; i < n_list; i += 64, ++it) {
+            const int yx = s_list[i], y = yx >> 8, x = yx & 255;
+            const uint8_t* c = sc + y * P + x;
+            const int s = c[0];
+            if (s >= th) {
+                const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-P - 1], (int)c[-P])), max(max((int)c[-P + 1], (int)c[P - 1]), max((int)c[P], (int)c[P + 1])));
+                if (s > nb) f |= 1ull << it;
+            }
         }
+        sel = f;
+        if (__any(f != 0)) break;                      // vKeysCell not empty: no minThFAST retry (:812)
+        __syncthreads();                               // the list is rebuilt by the next pass
     }
-    const bool any_ini = __any(f_ini != 0);
-    const unsigned long long sel = any_ini ? f_ini : f_min;
     dcs_candidate* out = slots + (size_t)img * slots_per_image + cd.slot_base;
     int base = 0;
-    it = 0;
+    int it = 0;
     for (int i0 = 0; i0 < n_list; i0 += 64, ++it) {
         const bool flag = (sel >> it) & 1ull;
         const unsigned long long m = __ballot(flag);
