@@ -462,17 +462,22 @@ __global__ __launch_bounds__(256) void k_level_scan(const int32_t* __restrict__ 
     if (threadIdx.x == 0) lvl_total[img * nlevels + l] = running;
 }
 
-// single block: exclusive scan of the (image, level) totals -> lvl_off[n_all + 1]
+// single block: exclusive scan of the (image, level) totals -> lvl_off[n_all + 1]. Every thread scans a run of consecutive
+// entries in registers, so 4096 totals (512 images x 8 levels) take ONE block scan instead of sixteen
 __global__ __launch_bounds__(256) void k_lvl_offsets(const int32_t* __restrict__ lvl_total, int n_all, int32_t* __restrict__ lvl_off)
 {
     __shared__ int s_tmp[4];
+    constexpr int kRun = 16;
     int running = 0;
-    for (int c0 = 0; c0 < n_all; c0 += 256) {
-        const int c = c0 + threadIdx.x;
-        const int v = c < n_all ? lvl_total[c] : 0;
+    for (int c0 = 0; c0 < n_all; c0 += 256 * kRun) {
+        const int b = c0 + threadIdx.x * kRun;
+        int v[kRun], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kRun; ++k) { v[k] = b + k < n_all ? lvl_total[b + k] : 0; sum += v[k]; }
         int tot;
-        const int ex = block_exclusive_scan_256(v, s_tmp, &tot);
-        if (c < n_all) lvl_off[c] = running + ex;
+        int ex = running + block_exclusive_scan_256(sum, s_tmp, &tot);
+#pragma unroll
+        for (int k = 0; k < kRun; ++k) { if (b + k < n_all) lvl_off[b + k] = ex; ex += v[k]; }
         running += tot;
     }
     if (threadIdx.x == 0) lvl_off[n_all] = running;
