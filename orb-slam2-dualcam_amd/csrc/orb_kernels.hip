@@ -258,12 +258,12 @@ __device__ __forceinline__ int fast_score(const uint8_t* c)
 template <int P>           // LDS row pitch in bytes (64 or 128): compile-time so that the ring offsets are immediates
 __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
                                                    dcs_candidate* __restrict__ slots, size_t slots_per_image,
-                                                   int32_t* __restrict__ cell_count, int map_bytes, int n_images)
+                                                   int32_t* __restrict__ cell_count, int map_bytes, int n_images, int sc_pitch, int sc_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_px = smem;
     uint8_t* s_sc = smem + map_bytes;
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(smem + 2 * map_bytes);
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(smem + map_bytes + sc_bytes);
     // grid (8, n_cells, ceil(n_images / 8)): workgroups go to the 8 XCDs round-robin by linear id, so blockIdx.x IS the XCD and all
     // cells of an image run on one XCD -- neighbouring cells share their aprons' cache lines in ONE L2 (fabric fetches 1072 -> 219 MB
     // per 512-image launch) without any index arithmetic
@@ -277,14 +277,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     }
     const LevelView lv = L.lv[cd.level];
     const uint8_t* img_base = lv.base + (size_t)img * lv.img_stride;
-    const int shift = cd.x0 & 15;                  // ROI columns start at byte `shift` of 16-byte aligned LDS rows
+    // ROI columns start at byte `shift` of the LDS rows: global loads stay 16-byte (P = 64 / 128) or 8-byte (P = 48) aligned
+    const int shift = cd.x0 & (P == 48 ? 7 : 15);
     {   // ---- 1. ROI rows into LDS (pixel (x, y) of the ROI at s_px[y * P + shift + x]) and a zeroed score map
         const bool aligned = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 3) == 0;
         const bool aligned16 = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 15) == 0;
         const int ndw = (shift + rw + 3) >> 2;
         uint32_t* px_dw = reinterpret_cast<uint32_t*>(s_px);
         const int Pdw = P >> 2;
-        if (aligned16 && shift + rw <= 64 && (P & 15) == 0) {        // 16 rows x 4 x 16-byte columns per wave pass
+        const bool aligned8 = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 7) == 0;
+        if (P == 48 && aligned8) {                                    // 10 rows x 6 x 8-byte columns per wave pass (rows of 48 bytes)
+            const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
+            const int r0 = lane / 6, c = lane - 6 * r0, nq = (shift + rw + 7) >> 3;
+            if (lane < 60)
+                for (int r = r0; r < rh; r += 10)
+                    if (c < nq) *reinterpret_cast<uint2*>(s_px + r * P + 8 * c) = *reinterpret_cast<const uint2*>(src + (size_t)r * lv.pitch + 8 * c);
+        } else if (P != 48 && aligned16 && shift + rw <= 64 && (P & 15) == 0) {        // 16 rows x 4 x 16-byte columns per wave pass
             const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
             const int c = lane & 3, nq = (shift + rw + 15) >> 4;
             for (int r = lane >> 2; r < rh; r += 16)
@@ -305,11 +313,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             for (int i = lane; i < rh * rw; i += 64) { const int r = i / rw, c = i - r * rw; s_px[r * P + shift + c] = src[(size_t)r * lv.pitch + c]; }
         }
         uint4* sc_q = reinterpret_cast<uint4*>(s_sc);
-        for (int i = lane; i < rh * (P >> 4); i += 64) sc_q[i] = uint4{0, 0, 0, 0};
+        for (int i = lane; i < (sc_bytes >> 4); i += 64) sc_q[i] = uint4{0, 0, 0, 0};
     }
     __syncthreads();
     const uint8_t* px = s_px + shift;
-    uint8_t* sc = s_sc + shift;
+    // score map: only the detection area and its 1-px rim exist, pixel (x, y) of the ROI at s_sc[(y - 2) * sc_pitch + (x - 2)] (the
+    // smaller map buys LDS room for two more resident waves per SIMD, and FAST loses 13 % when it loses 1.25)
+    uint8_t* sc = s_sc - 2 * sc_pitch - 2;
     const int dw = rw - 6, dh = rh - 6, ndet = dw * dh;
     // Steps 2-4 run for the reference's two thresholds in its own order (ORBextractor.cc:806-819): iniThFAST first; only a cell
     // that yields NO keypoint there is redone at minThFAST. A pass at threshold T only needs the pixels that pass the compass
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         for (int i = lane; i < n_list; i += 64) {
             const int yx = s_list[i], y = yx >> 8, x = yx & 255;
             const int s = fast_score<P>(px + y * P + x);
-            sc[y * P + x] = (uint8_t)max(s, 0);
+            sc[y * sc_pitch + x] = (uint8_t)max(s, 0);
         }
         __syncthreads();
         // ---- 4. NMS: keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } (neighbours below T lose anyway)
@@ -377,10 +387,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         int it = 0;
         for (int i = lane; i < n_list; i += 64, ++it) {
             const int yx = s_list[i], y = yx >> 8, x = yx & 255;
-            const uint8_t* c = sc + y * P + x;
+            const uint8_t* c = sc + y * sc_pitch + x;
             const int s = c[0];
             if (s >= th) {
-                const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-P - 1], (int)c[-P])), max(max((int)c[-P + 1], (int)c[P - 1]), max((int)c[P], (int)c[P + 1])));
+                const uint8_t* cu = c - sc_pitch; const uint8_t* cd2 = c + sc_pitch;
+                const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)cu[-1], (int)cu[0])), max(max((int)cu[1], (int)cd2[-1]), max((int)cd2[0], (int)cd2[1])));
                 if (s > nb) f |= 1ull << it;
             }
         }
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         if (flag && off < cd.cap) {
             const int yx = s_list[i0 + lane], y = yx >> 8, x = yx & 255;
             dcs_candidate o;
-            o.x = (int16_t)(x + cd.ox); o.y = (int16_t)(y + cd.oy); o.score = sc[y * P + x];
+            o.x = (int16_t)(x + cd.ox); o.y = (int16_t)(y + cd.oy); o.score = sc[y * sc_pitch + x];
             out[off] = o;
         }
         base += __popcll(m);
@@ -411,16 +422,21 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
                       int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s)
 {
     if (n_cells == 0) return DCS_OK;
-    const int P = (max_rw + 15 <= 64) ? 64 : 128;                // shift (<= 15) + row fits the pitch
+    const int P = (max_rw + 7 <= 48) ? 48 : (max_rw + 15 <= 64) ? 64 : 128;      // shift (<= 7 or 15) + row fits the pitch
     const int map_bytes = ((max_rh * P) + 15) & ~15;
     const int list_bytes = (((max_rw - 6) * (max_rh - 6) * 2) + 15) & ~15;
-    const size_t shmem = (size_t)2 * map_bytes + list_bytes;
-    if (P == 64)
+    const int sc_pitch = ((max_rw - 6 + 2) + 3) & ~3;              // detection width + 1-px rim
+    const int sc_bytes = (sc_pitch * (max_rh - 6 + 2) + 15) & ~15;
+    const size_t shmem = (size_t)map_bytes + sc_bytes + list_bytes;
+    if (P == 48)
+        hipLaunchKernelGGL(k_fast_cells<48>, dim3(8, n_cells, (n_images + 7) / 8), dim3(64), shmem, s, levels, d_cells, n_cells,
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes);
+    else if (P == 64)
         hipLaunchKernelGGL(k_fast_cells<64>, dim3(8, n_cells, (n_images + 7) / 8), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images);
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes);
     else
         hipLaunchKernelGGL(k_fast_cells<128>, dim3(8, n_cells, (n_images + 7) / 8), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images);
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
