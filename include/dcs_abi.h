@@ -289,6 +289,16 @@ typedef struct dcs_ba_result {
    round: iters1 = nIterations, iters2 = 0, huber_delta = sqrt(3.99) (:107) or <= 0 when bRobust is false, only fixId fixed. */
 int  dcs_ba_local(const dcs_ba_problem* prob, const volatile uint8_t* stop_flag, dcs_ba_result* res);
 
+/* The same solver for n_problems INDEPENDENT problems at once -- BASELINE config C5: one LocalMapping thread per
+   dual-camera stream, each issuing Optimizer::LocalBundleAdjustment (src/LocalMapping.cc:97-104 -> src/Optimizer.cc:407-696).
+   Every kernel of an LM step covers all problems (one launch, blockIdx.y = problem; the reduced camera systems are factored
+   on n_problems compute units at once) and the accept / reject logic of optimization_algorithm_levenberg.cpp:104-164 runs on
+   the device, so the host never waits for a trial. dcs_ba_local IS this function with n_problems = 1: results are identical.
+   stop_flags may be NULL, and so may any stop_flags[b]; a flag already set at entry leaves that problem untouched
+   (estimates copied through, no outliers, zero iterations: Optimizer.cc:582-585). Problems may differ in every size. */
+int  dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* probs, const volatile uint8_t* const* stop_flags,
+                        dcs_ba_result* const* results);
+
 /* Optimizer::PoseOptimization (src/Optimizer.cc:250-405) for a batch of independent frames (one per stream / camera
    rig); the whole 4-round Levenberg-Marquardt procedure of a frame runs inside one workgroup, no host round trips.
    Frame f owns the edges edge_off[f] .. edge_off[f+1] (features with a MapPoint, ascending feature index). */

@@ -113,6 +113,7 @@ def lib():
             "dcs_search_by_bow": [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, vp, pci],
             "dcs_distinctive_descriptors": [vp, ci, vp, vp, ci, vp],
             "dcs_ba_local": [C.POINTER(BaProblem), vp, C.POINTER(BaResult)],
+            "dcs_ba_local_batch": [ci, vp, vp, vp],
             "dcs_pose_optimization": [C.POINTER(PoseProblem), C.POINTER(PoseResult)],
             "dcs_frame_grid": [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, pci],
             "dcs_search_by_projection": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, cf, ci, vp, vp, pci],
@@ -474,6 +475,9 @@ class PreparedBA:
     def solve(self, stop_flag=None):
         sf = _p(stop_flag) if stop_flag is not None else None
         _check(lib().dcs_ba_local(C.byref(self.pb), sf, C.byref(self.res)), "dcs_ba_local")
+        return self.result()
+
+    def result(self):
         res = self.res
         return dict(poses=self.out_poses, points=self.out_points, edge_chi2=self.chi2, edge_outlier=self.outl, edge_level1=self.lvl1,
                     n_iters=list(res.n_iters), n_trials=list(res.n_trials), lambda_=list(res.lambda_),
@@ -514,6 +518,26 @@ class Optimizer:
         p["iters1"], p["iters2"] = int(nIterations), 0
         p["huber_delta"] = float(np.float32(np.sqrt(3.99))) if bRobust else 0.0     # const float thHuber2D (:107)
         return PreparedBA(p).solve(stop_flag)
+
+    @staticmethod
+    def LocalBundleAdjustmentBatch(probs, stop_flags=None):
+        """dcs_ba_local_batch: one Optimizer::LocalBundleAdjustment per dual-camera stream (BASELINE config C5,
+        src/LocalMapping.cc:97-104), all problems in one call. `probs`: flat problems or PreparedBA objects;
+        `stop_flags`: None or a list of (uint8 array | None). Returns one result dict per problem."""
+        preps = [p if isinstance(p, PreparedBA) else PreparedBA(p) for p in probs]
+        n = len(preps)
+        pbs = (C.c_void_p * max(n, 1))(*[C.addressof(p.pb) for p in preps])
+        ress = (C.c_void_p * max(n, 1))(*[C.addressof(p.res) for p in preps])
+        sfs = None
+        if stop_flags is not None:
+            sfs = (C.c_void_p * max(n, 1))(*[(_p(f).value if f is not None else None) for f in stop_flags])
+        _check(lib().dcs_ba_local_batch(n, C.cast(pbs, C.c_void_p), C.cast(sfs, C.c_void_p) if sfs is not None else None,
+                                        C.cast(ress, C.c_void_p)), "dcs_ba_local_batch")
+        outs = []
+        for p in preps:
+            out = p.result()
+            outs.append({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in out.items()})
+        return outs
 
     @staticmethod
     def LocalBundleAdjustment(prob, stop_flag=None):

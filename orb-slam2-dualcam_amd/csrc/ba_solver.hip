@@ -32,6 +32,8 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -154,84 +156,178 @@ __device__ inline double block_sum_256(double v, double* s /*[256]*/)
     return s[0];
 }
 
-// ------------------------------------------------------------------ kernels
-struct EdgeArrays {
-    const int32_t *pose, *point, *cam;      // [E]
-    const double *obs, *w;                  // [E][2], [E]
-    const uint8_t* active;                  // [E]
+// ------------------------------------------------------------------ batched problem descriptors
+// Every BA kernel is launched once for a whole batch of independent problems: blockIdx.y = problem, blockIdx.x runs up
+// to the largest problem's block count (smaller problems exit). The Levenberg-Marquardt state of a problem (BaCtl)
+// lives in HBM and is advanced ON THE DEVICE -- by the finisher of the trial's error kernel and by k_round_ctl -- so
+// the host enqueues identical "steps" back to back and never waits for a trial (it only watches a progress word in
+// pinned memory). A kernel whose problem is not in a state that needs it returns at once.
+enum : int { ST_NEW_ITER = 0, ST_RETRY = 1, ST_ROUND_END = 2, ST_DONE = 3 };
+
+struct BaCtl {
+    int state, round, it, qmax, nBad, cur, errors_current, robust, trace, stopped, n_active, pad0;
+    double mult, ni, currentChi, iniChi, maxdiag, ok, scale, pad1;
+    int n_iters[2], n_trials[2];
+    double lambda[2], chi2_trace[32];
 };
 
-// residuals (computeError), chi2, robust rho0. Block partial sums go to partial[]; the last block to finish
-// (device-scope ticket) adds them in index order -> *chi_out, so the total is reproducible run to run.
-__global__ __launch_bounds__(256) void k_error(EdgeArrays ed, int E, const double* __restrict__ poses, const double* __restrict__ points,
-                                               DCams cams, int robust, double delta, double* __restrict__ err, double* __restrict__ chi2,
-                                               double* __restrict__ partial, unsigned* __restrict__ ticket, double* __restrict__ chi_out,
-                                               const double* __restrict__ scale_partial, int n_scale_partial, double* __restrict__ scale_out)
+struct BaProb {
+    int P, L, E, np, n, n_pad, ld, n_pairs, nblk, nb_pts, nb_pose, use_reg;
+    int iters[2], robust0, pad;
+    double delta, chi2_th;
+    double *poses[2], *points[2];                  // estimates are double-buffered: a trial writes [cur ^ 1], accept flips cur
+    const int32_t *epose, *epoint, *ecam;          // [E]
+    const double *obs, *w;                         // [E][2], [E]
+    uint8_t *active, *flag, *level1;               // [E]
+    double *err, *chi2;                            // [E][2], [E]
+    double *Hpl, *BD, *cpose, *cpoint;             // [E][18], [E][18], [E][27], [E][9]
+    double *Hll, *bl, *Dinv, *db, *xl;             // per landmark
+    double *Hpp, *bp, *bsch, *xp;                  // per free pose
+    double *S, *W;                                 // reduced camera system (ld x ld), panel scratch of the n > 256 fallback
+    const int32_t *pose_idx, *pt_off, *pt_edges, *ps_off, *ps_edges, *pair_ij, *pair_off, *pair_e1, *pair_e2;
+    double *partial, *scale_part;
+    uint8_t* pt_active;
+    unsigned* ticket;
+    const DCams* cams;
+    double *out_poses, *out_points;
+};
+
+__device__ __forceinline__ void load_cams(DCams* dst, const DCams* src)
+{
+    const double* s = reinterpret_cast<const double*>(src);
+    double* d = reinterpret_cast<double*>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(DCams) / sizeof(double)); i += blockDim.x) d[i] = s[i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ kernels
+// residuals (computeError), chi2, robust rho0. Block partial sums go to partial[]; the last block of the problem to
+// finish (device-scope ticket) adds them in index order, so the total is reproducible run to run. That finisher also
+// owns the LM control flow (OptimizationAlgorithmLevenberg::solve, optimization_algorithm_levenberg.cpp:61-164):
+//   TRIAL = 0  computeActiveErrors at the top of an LM iteration whose errors are stale (first iteration of a round, or
+//              after a rejected trial): evaluated at the current estimates, sets currentChi
+//   TRIAL = 1  errors of the trial estimates [cur ^ 1], + computeScale, then accept / reject, lambda update, termination
+template <int TRIAL>
+__global__ __launch_bounds__(256) void k_error(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, const volatile int* __restrict__ stop_words)
 {
     __shared__ double s[256];
+    __shared__ DCams cams;
     __shared__ bool last;
+    const BaProb& pb = probs[blockIdx.y];
+    BaCtl& ctl = ctls[blockIdx.y];
+    if ((int)blockIdx.x >= pb.nblk) return;
+    if (TRIAL ? ctl.state > ST_RETRY : (ctl.state != ST_NEW_ITER || ctl.errors_current)) return;
+    const int robust = ctl.robust, E = pb.E;
+    const double delta = pb.delta;
+    const double* __restrict__ poses = pb.poses[TRIAL ? ctl.cur ^ 1 : ctl.cur];
+    const double* __restrict__ points = pb.points[TRIAL ? ctl.cur ^ 1 : ctl.cur];
+    load_cams(&cams, pb.cams);
     const int e = blockIdx.x * 256 + threadIdx.x;
     double rho0 = 0;
-    if (e < E && ed.active[e]) {
+    if (e < E && pb.active[e]) {
         double pc[3];
-        const DCam& c = cams.c[ed.cam[e]];
-        cam_point(poses + 7 * ed.pose[e], points + 3 * ed.point[e], c, pc);
-        const double e0 = ed.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
-        const double e1 = ed.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
-        const double w = ed.w[e];
+        const DCam& c = cams.c[pb.ecam[e]];
+        cam_point(poses + 7 * pb.epose[e], points + 3 * pb.epoint[e], c, pc);
+        const double e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+        const double e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+        const double w = pb.w[e];
         const double x2 = e0 * (w * e0) + e1 * (w * e1);
-        err[2 * e] = e0; err[2 * e + 1] = e1; chi2[e] = x2;
+        pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
         if (robust && x2 > delta * delta) rho0 = 2 * sqrt(x2) * delta - delta * delta; else rho0 = x2;
     }
     const double t = block_sum_256(rho0, s);
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pb.partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = (prev == gridDim.x - 1);
+        const unsigned prev = __hip_atomic_fetch_add(pb.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (prev == (unsigned)pb.nblk - 1);
     }
     __syncthreads();
     if (!last) return;
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     double v = 0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) v += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < pb.nblk; i += 256) v += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double tot = block_sum_256(v, s);
-    if (threadIdx.x == 0) { *chi_out = tot; __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    if (n_scale_partial > 0) {                      // computeScale: block partials of k_solve_update (an earlier launch), fixed order
-        __syncthreads();
-        double w = 0;
-        for (int i = threadIdx.x; i < n_scale_partial; i += 256) w += scale_partial[i];
-        const double sc = block_sum_256(w, s);
-        if (threadIdx.x == 0) *scale_out = sc;
+    if (threadIdx.x == 0) __hip_atomic_store(pb.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!TRIAL) {
+        if (threadIdx.x == 0) { ctl.currentChi = tot; ctl.iniChi = tot; ctl.errors_current = 1; }
+        return;
     }
+    __syncthreads();
+    double w = 0;                                   // computeScale: block partials of k_solve_update (an earlier launch), fixed order
+    for (int i = threadIdx.x; i < pb.nb_pts + pb.nb_pose; i += 256) w += pb.scale_part[i];
+    const double sc = block_sum_256(w, s);
+    if (threadIdx.x != 0) return;
+    // ---- accept / reject (optimization_algorithm_levenberg.cpp:104-164)
+    ++ctl.n_trials[ctl.round];
+    double tempChi = tot;
+    if (ctl.ok == 0.0) tempChi = 1.7976931348623157e308;
+    double rho = ctl.currentChi - tempChi;
+    const double scale = sc + 1e-3;
+    rho /= scale;
+    double mult = ctl.mult, ni = ctl.ni, currentChi = ctl.currentChi;
+    if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        mult *= fmax(1. / 3., alpha);
+        ni = 2; currentChi = tempChi;
+        ctl.cur ^= 1; ctl.errors_current = 1;       // discardTop: the trial estimates become the current ones
+    } else {
+        mult *= ni; ni *= 2;
+        ctl.errors_current = 0;                     // pop: the other buffer still holds the estimates; err / chi2 stay stale like g2o's
+    }
+    ctl.mult = mult; ctl.ni = ni; ctl.currentChi = currentChi; ctl.scale = sc;
+    const int qmax = ++ctl.qmax;
+    const bool stop = stop_words && __hip_atomic_load(const_cast<const int*>(stop_words + blockIdx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+    if (stop) ctl.stopped = 1;
+    if (rho < 0 && qmax < 10 && !stop) { ctl.state = ST_RETRY; return; }
+    const int round = ctl.round;
+    ++ctl.n_iters[round];
+    if (ctl.trace < 32) ctl.chi2_trace[ctl.trace++] = currentChi;
+    ctl.lambda[round] = 1e-5 * ctl.maxdiag * mult;
+    bool term = (qmax == 10 || rho == 0);           // Terminate
+    if (!term) {
+        if ((ctl.iniChi - currentChi) * 1e3 < ctl.iniChi) ++ctl.nBad; else ctl.nBad = 0;
+        if (ctl.nBad >= 3) term = true;
+    }
+    const int it = ++ctl.it;
+    if (term || stop || it >= pb.iters[round]) ctl.state = ST_ROUND_END;
+    else { ctl.state = ST_NEW_ITER; ctl.qmax = 0; ctl.iniChi = currentChi; }
 }
 
 // linearizeOplus + constructQuadraticForm, per edge. cpoint[e] = {Hll 00,01,02,11,12,22, bl0..2},
 // cpose[e] = {21 upper entries of Hpp row-major, bp0..5}, Hpl[e] = 6x3 row-major (pose rows, point cols)
-__global__ __launch_bounds__(256) void k_linearize(EdgeArrays ed, int E, const double* __restrict__ poses, const double* __restrict__ points,
-                                                   DCams cams, int robust, double delta, const double* __restrict__ err,
-                                                   const double* __restrict__ chi2, const int32_t* __restrict__ pose_idx,
-                                                   double* __restrict__ cpoint, double* __restrict__ cpose, double* __restrict__ Hpl)
+__global__ __launch_bounds__(256) void k_linearize(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
+    __shared__ DCams cams;
+    const BaProb& pb = probs[blockIdx.y];
+    const BaCtl& ctl = ctls[blockIdx.y];
+    if ((int)blockIdx.x >= pb.nblk || ctl.state != ST_NEW_ITER) return;
+    const int robust = ctl.robust;
+    const double delta = pb.delta;
+    const double* __restrict__ poses = pb.poses[ctl.cur];
+    const double* __restrict__ points = pb.points[ctl.cur];
+    const int32_t* __restrict__ pose_idx = pb.pose_idx;
+    load_cams(&cams, pb.cams);
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E) return;
-    if (!ed.active[e]) {                           // level-1 edge: adds nothing to any block (the CSR lists still name it)
-        double* cp = cpoint + (size_t)e * 9;
+    if (e >= pb.E) return;
+    if (!pb.active[e]) {                           // level-1 edge: adds nothing to any block (the CSR lists still name it)
+        double* cp = pb.cpoint + (size_t)e * 9;
         for (int i = 0; i < 9; ++i) cp[i] = 0;
-        if (pose_idx[ed.pose[e]] >= 0) {
-            double* cq = cpose + (size_t)e * 27;
+        if (pose_idx[pb.epose[e]] >= 0) {
+            double* cq = pb.cpose + (size_t)e * 27;
             for (int i = 0; i < 27; ++i) cq[i] = 0;
-            double* h = Hpl + (size_t)e * 18;
+            double* h = pb.Hpl + (size_t)e * 18;
             for (int i = 0; i < 18; ++i) h[i] = 0;
         }
         return;
     }
-    const DCam& c = cams.c[ed.cam[e]];
-    const double* T = poses + 7 * ed.pose[e];
+    const DCam& c = cams.c[pb.ecam[e]];
+    const double* T = poses + 7 * pb.epose[e];
     double pc[3];
-    cam_point(T, points + 3 * ed.point[e], c, pc);
+    cam_point(T, points + 3 * pb.epoint[e], c, pc);
     const double x = pc[0], y = pc[1], z = pc[2];
     const double s = -1. / z;
     const double st[6] = {s * c.fx, s * 0.0, s * (-x / z * c.fx), s * 0.0, s * c.fy, s * (-y / z * c.fy)};
@@ -246,23 +342,23 @@ __global__ __launch_bounds__(256) void k_linearize(EdgeArrays ed, int E, const d
     double qt[4], R[9];
     qmul(c.q, T + 3, qt); qnormalize(qt); qtoR(qt, R);         // rotation of T_ext * T_mcs
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Jx[i * 3 + j] = st[i * 3] * R[j] + st[i * 3 + 1] * R[3 + j] + st[i * 3 + 2] * R[6 + j];
-    double w = ed.w[e];
-    double r0 = -w * err[2 * e], r1 = -w * err[2 * e + 1];
+    double w = pb.w[e];
+    double r0 = -w * pb.err[2 * e], r1 = -w * pb.err[2 * e + 1];
     if (robust) {
-        const double x2 = chi2[e];
+        const double x2 = pb.chi2[e];
         const double rho1 = x2 <= delta * delta ? 1.0 : delta / sqrt(x2);
         r0 *= rho1; r1 *= rho1; w = rho1 * w;
     }
-    double* cp = cpoint + (size_t)e * 9;
+    double* cp = pb.cpoint + (size_t)e * 9;
     int k = 0;
     for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) cp[k++] = Jx[i] * w * Jx[j] + Jx[3 + i] * w * Jx[3 + j];
     for (int i = 0; i < 3; ++i) cp[6 + i] = Jx[i] * r0 + Jx[3 + i] * r1;
-    if (pose_idx[ed.pose[e]] >= 0) {
-        double* cq = cpose + (size_t)e * 27;
+    if (pose_idx[pb.epose[e]] >= 0) {
+        double* cq = pb.cpose + (size_t)e * 27;
         k = 0;
         for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) cq[k++] = Jp[i] * w * Jp[j] + Jp[6 + i] * w * Jp[6 + j];
         for (int i = 0; i < 6; ++i) cq[21 + i] = Jp[i] * r0 + Jp[6 + i] * r1;
-        double* h = Hpl + (size_t)e * 18;
+        double* h = pb.Hpl + (size_t)e * 18;
         for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) h[i * 3 + j] = Jp[i] * w * Jx[j] + Jp[6 + i] * w * Jx[3 + j];
     }
 }
@@ -270,31 +366,35 @@ __global__ __launch_bounds__(256) void k_linearize(EdgeArrays ed, int E, const d
 // block (1024 threads) per free pose: 37 edge chunks x 27 components, combined in chunk order (deterministic). The
 // list walk is latency-bound (index load -> value load), so many short chunks with 4 loads in flight each.
 constexpr int kPoseChunks = 37;
-struct ReducePointArgs { int L; const int32_t *pt_off, *pt_edges; const uint8_t* e_active; const double* cpoint; double *Hll, *bl; uint8_t* pt_active; };
-__global__ __launch_bounds__(1024) void k_reduce_pose(const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
-                                                     const double* __restrict__ cpose, double* __restrict__ Hpp, double* __restrict__ bp,
-                                                     int np, ReducePointArgs rp)
+__global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
     __shared__ double part[kPoseChunks][27];
     __shared__ double s[27];
+    const BaProb& pb = probs[blockIdx.y];
+    if (ctls[blockIdx.y].state != ST_NEW_ITER) return;
+    const int np = pb.np;
+    if ((int)blockIdx.x >= np + pb.nb_pts) return;
     if ((int)blockIdx.x >= np) {                             // blocks past the free poses: 64 landmarks each (thread per landmark)
         if (threadIdx.x >= 64) return;
         const int l = (blockIdx.x - np) * 64 + threadIdx.x;
-        if (l >= rp.L) return;
+        if (l >= pb.L) return;
         double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         int n_act = 0;
-        for (int k = rp.pt_off[l]; k < rp.pt_off[l + 1]; ++k) {
-            const int e = rp.pt_edges[k];
-            n_act += rp.e_active[e];
-            const double* c = rp.cpoint + (size_t)e * 9;
+        for (int k = pb.pt_off[l]; k < pb.pt_off[l + 1]; ++k) {
+            const int e = pb.pt_edges[k];
+            n_act += pb.active[e];
+            const double* c = pb.cpoint + (size_t)e * 9;
             for (int i = 0; i < 9; ++i) a[i] += c[i];
         }
-        rp.pt_active[l] = n_act > 0;                 // a landmark without active edges is not part of this round
-        double* H = rp.Hll + (size_t)l * 9;
+        pb.pt_active[l] = n_act > 0;                 // a landmark without active edges is not part of this round
+        double* H = pb.Hll + (size_t)l * 9;
         H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
-        rp.bl[3 * l] = a[6]; rp.bl[3 * l + 1] = a[7]; rp.bl[3 * l + 2] = a[8];
+        pb.bl[3 * l] = a[6]; pb.bl[3 * l + 1] = a[7]; pb.bl[3 * l + 2] = a[8];
         return;
     }
+    const int32_t* __restrict__ ps_off = pb.ps_off;
+    const int32_t* __restrict__ ps_edges = pb.ps_edges;
+    const double* __restrict__ cpose = pb.cpose;
     const int i = blockIdx.x, t = threadIdx.x;
     const int c = t % 27, q = t / 27;
     if (q < kPoseChunks) {
@@ -309,101 +409,114 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const int32_t* __restrict_
     __syncthreads();
     if (t < 36) {
         const int r = t / 6, qq = t % 6, lo = min(r, qq), hi = max(r, qq);
-        Hpp[(size_t)i * 36 + t] = s[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+        pb.Hpp[(size_t)i * 36 + t] = s[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
     }
-    if (t < 6) bp[i * 6 + t] = s[21 + t];
+    if (t < 6) pb.bp[i * 6 + t] = s[21 + t];
 }
 
-// max |diagonal| over pose and landmark blocks (computeLambdaInit). single block.
-__global__ __launch_bounds__(256) void k_max_diag(int np, const double* __restrict__ Hpp, int L, const uint8_t* __restrict__ pt_active,
-                                                  const double* __restrict__ Hll, double* __restrict__ out)
+// max |diagonal| over pose and landmark blocks (computeLambdaInit) at the first iteration of a round; block per problem.
+__global__ __launch_bounds__(256) void k_max_diag(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
 {
     __shared__ double s[256];
+    const BaProb& pb = probs[blockIdx.y];
+    BaCtl& ctl = ctls[blockIdx.y];
+    if (ctl.state != ST_NEW_ITER || ctl.it != 0) return;
     double m = 0;
-    for (int i = threadIdx.x; i < np * 6; i += 256) m = fmax(m, fabs(Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
-    for (int i = threadIdx.x; i < L * 3; i += 256) {
+    for (int i = threadIdx.x; i < pb.np * 6; i += 256) m = fmax(m, fabs(pb.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+    for (int i = threadIdx.x; i < pb.L * 3; i += 256) {
         const int l = i / 3;
-        if (pt_active[l]) m = fmax(m, fabs(Hll[(size_t)l * 9 + (i % 3) * 4]));
+        if (pb.pt_active[l]) m = fmax(m, fabs(pb.Hll[(size_t)l * 9 + (i % 3) * 4]));
     }
     s[threadIdx.x] = m;
     __syncthreads();
     for (int d = 128; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + d]); __syncthreads(); }
-    if (threadIdx.x == 0) *out = s[0];
+    if (threadIdx.x == 0) { ctl.maxdiag = s[0]; ctl.mult = 1.0; ctl.ni = 2; ctl.nBad = 0; }   // lambda = tau * max diagonal, tau = 1e-5
 }
 
 // setLambda for the landmark blocks, one launch:
 //   blocks [0, nblk_e)  thread per edge of a free pose: BD[e] = Hpl[e] Dinv[point(e)] (zero for level-1 edges); the 3x3
 //                       inverse is recomputed per edge (40 flops) so that the edges do not wait for a per-point pass
-//   blocks [nblk_e, ..) thread per point: Dinv = (Hll + lambda I)^-1, db = Dinv bl (read by k_schur_all / k_solve_update)
-__global__ __launch_bounds__(256) void k_prep(int E, int nblk_e, const uint8_t* __restrict__ e_active, const int32_t* __restrict__ e_pose,
-                                              const int32_t* __restrict__ e_point, const int32_t* __restrict__ pose_idx,
-                                              const double* __restrict__ Hpl, double* __restrict__ BD, int L, const double* __restrict__ Hll,
-                                              const double* __restrict__ bl, const double* __restrict__ max_diag, double lam_mult,
-                                              const uint8_t* __restrict__ pt_active, double* __restrict__ Dinv, double* __restrict__ db,
-                                              double* __restrict__ ok)
+//   blocks [nblk_e, ..) thread per point: Dinv = (Hll + lambda I)^-1, db = Dinv bl (read by k_schur / k_solve_update)
+__global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
 {
-    const double lambda = 1e-5 * *max_diag * lam_mult;       // computeLambdaInit (tau = 1e-5) x the host's LM multiplier
+    const BaProb& pb = probs[blockIdx.y];
+    BaCtl& ctl = ctls[blockIdx.y];
+    if (ctl.state > ST_RETRY) return;
+    const int nblk_e = pb.np ? pb.nblk : 0, L = pb.L;
+    if ((int)blockIdx.x >= nblk_e + (L + 255) / 256) return;
+    const double lambda = 1e-5 * ctl.maxdiag * ctl.mult;     // computeLambdaInit (tau = 1e-5) x the LM multiplier
+    const double* __restrict__ Hll = pb.Hll;
     if ((int)blockIdx.x < nblk_e) {
         const int e = blockIdx.x * 256 + threadIdx.x;
-        if (e >= E || pose_idx[e_pose[e]] < 0) return;
-        double* o = BD + (size_t)e * 18;
-        if (!e_active[e]) {                                  // level-1 edge: still named by the pair lists, contributes zero
+        if (e >= pb.E || pb.pose_idx[pb.epose[e]] < 0) return;
+        double* o = pb.BD + (size_t)e * 18;
+        if (!pb.active[e]) {                                 // level-1 edge: still named by the pair lists, contributes zero
             for (int i = 0; i < 18; ++i) o[i] = 0.0;
             return;
         }
-        const int l = e_point[e];
+        const int l = pb.epoint[e];
         double H[9], D[9];
         for (int i = 0; i < 9; ++i) H[i] = Hll[(size_t)l * 9 + i];
         H[0] += lambda; H[4] += lambda; H[8] += lambda;
         inv3(H, D);
-        const double* B = Hpl + (size_t)e * 18;
+        const double* B = pb.Hpl + (size_t)e * 18;
         for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = B[r * 3] * D[c] + B[r * 3 + 1] * D[3 + c] + B[r * 3 + 2] * D[6 + c];
         return;
     }
     const int l = (blockIdx.x - nblk_e) * 256 + threadIdx.x;
-    if (l == 0) *ok = 1.0;                                   // reset the "factorisation succeeded" flag of this trial
-    if (l >= L || !pt_active[l]) return;
+    if (l == 0) ctl.ok = 1.0;                                // reset the "factorisation succeeded" flag of this trial
+    if (l >= L || !pb.pt_active[l]) return;
     double H[9], D[9];
     for (int i = 0; i < 9; ++i) H[i] = Hll[(size_t)l * 9 + i];
     H[0] += lambda; H[4] += lambda; H[8] += lambda;
     inv3(H, D);
-    for (int i = 0; i < 9; ++i) Dinv[(size_t)l * 9 + i] = D[i];
-    for (int i = 0; i < 3; ++i) db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
+    const double* bl = pb.bl;
+    for (int i = 0; i < 9; ++i) pb.Dinv[(size_t)l * 9 + i] = D[i];
+    for (int i = 0; i < 3; ++i) pb.db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
 }
 
 // workgroup per pose pair (i1 <= i2): S block = [i1==i2](Hpp + lambda I) - sum over shared points BD[e1] Hpl[e2]^T.
 // 28 list chunks x 36 block entries (1024 threads, 4 list entries in flight per thread); partials combined in fixed order.
 constexpr int kSchurChunks = 28;
-struct BschurArgs { const int32_t *ps_off, *ps_edges, *e_point; const double *db, *bp; double* bsch; };
-__global__ __launch_bounds__(1024) void k_schur(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_off,
-                                                const int32_t* __restrict__ pair_e1, const int32_t* __restrict__ pair_e2,
-                                                const double* __restrict__ Hpp, const double* __restrict__ max_diag, double lam_mult,
-                                                const double* __restrict__ BD, const double* __restrict__ Hpl, double* __restrict__ S, int ld,
-                                                int n_pairs, BschurArgs bs)
+__global__ __launch_bounds__(1024) void k_schur(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
     __shared__ double part[kSchurChunks][36];
+    const BaProb& pb = probs[blockIdx.y];
+    const BaCtl& ctl = ctls[blockIdx.y];
+    if (ctl.state > ST_RETRY || pb.np == 0) return;
+    const int n_pairs = pb.n_pairs;
+    if ((int)blockIdx.x >= n_pairs + pb.np) return;
+    const double* __restrict__ Hpl = pb.Hpl;
     if ((int)blockIdx.x >= n_pairs) {                        // blocks past the pair list: reduced right-hand side of one free pose
         // bsch = bp - sum_e Hpl[e] db[point(e)]; 168 edge chunks x 6 rows, combined in chunk order
         double (*bpart)[6] = reinterpret_cast<double (*)[6]>(&part[0][0]);         // 168 x 6 <= 28 x 36
+        const int32_t* __restrict__ ps_off = pb.ps_off;
+        const int32_t* __restrict__ ps_edges = pb.ps_edges;
+        const int32_t* __restrict__ e_point = pb.epoint;
+        const double* __restrict__ db = pb.db;
         const int i = blockIdx.x - n_pairs, t = threadIdx.x;
         const int r = t % 6, q = t / 6;
         if (q < 168) {
             double a = 0;
-            const int k1 = bs.ps_off[i + 1];
+            const int k1 = ps_off[i + 1];
 #pragma unroll 4
-            for (int k = bs.ps_off[i] + q; k < k1; k += 168) {
-                const int e = bs.ps_edges[k];
+            for (int k = ps_off[i] + q; k < k1; k += 168) {
+                const int e = ps_edges[k];
                 const double* B = Hpl + (size_t)e * 18 + r * 3;
-                const double* d = bs.db + 3 * bs.e_point[e];
+                const double* d = db + 3 * e_point[e];
                 a += B[0] * d[0] + B[1] * d[1] + B[2] * d[2];
             }
             bpart[q][r] = a;
         }
         __syncthreads();
-        if (t < 6) { double a = 0; for (int q2 = 0; q2 < 168; ++q2) a += bpart[q2][t]; bs.bsch[i * 6 + t] = bs.bp[i * 6 + t] - a; }
+        if (t < 6) { double a = 0; for (int q2 = 0; q2 < 168; ++q2) a += bpart[q2][t]; pb.bsch[i * 6 + t] = pb.bp[i * 6 + t] - a; }
         return;
     }
-    const double lambda = 1e-5 * *max_diag * lam_mult;
+    const double lambda = 1e-5 * ctl.maxdiag * ctl.mult;
+    const int32_t* __restrict__ pair_off = pb.pair_off;
+    const int32_t* __restrict__ pair_e1 = pb.pair_e1;
+    const int32_t* __restrict__ pair_e2 = pb.pair_e2;
+    const double* __restrict__ BD = pb.BD;
     const int p = blockIdx.x, t = threadIdx.x;
     const int el = t % 36, q = t / 36;
     const int r = el / 6, c = el % 6;
@@ -420,13 +533,13 @@ __global__ __launch_bounds__(1024) void k_schur(const int32_t* __restrict__ pair
     }
     __syncthreads();
     if (t >= 36) return;
-    const int i1 = pair_ij[2 * p], i2 = pair_ij[2 * p + 1];
+    const int i1 = pb.pair_ij[2 * p], i2 = pb.pair_ij[2 * p + 1], ld = pb.ld;
     double acc = 0;
     for (int q2 = 0; q2 < kSchurChunks; ++q2) acc += part[q2][t];
     double v = -acc;
-    if (i1 == i2) v += Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
-    S[(size_t)(i1 * 6 + r) * ld + i2 * 6 + c] = v;
-    if (i1 != i2) S[(size_t)(i2 * 6 + c) * ld + i1 * 6 + r] = v;
+    if (i1 == i2) v += pb.Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
+    pb.S[(size_t)(i1 * 6 + r) * ld + i2 * 6 + c] = v;
+    if (i1 != i2) pb.S[(size_t)(i2 * 6 + c) * ld + i1 * 6 + r] = v;
 }
 
 // ---- register-resident LDL^T + solve (n_pad <= 256): the whole lower triangle lives in the VGPRs of ONE workgroup.
@@ -443,10 +556,17 @@ __device__ __forceinline__ double fast_recip(double d)
     return r;
 }
 
+// (use_reg: 1 = k_ldlt_mfma, 2 = k_ldlt_reg, 0 = blocked multi-launch fallback; one workgroup per problem)
 template <int NBLK>
-__global__ __launch_bounds__(1024) void k_ldlt_reg(const double* __restrict__ S, int ld, int n, const double* __restrict__ b,
-                                                   double* __restrict__ x, double* __restrict__ ok)
+__global__ __launch_bounds__(1024) void k_ldlt_reg(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
 {
+    const BaProb& pb = probs[blockIdx.x];
+    if (ctls[blockIdx.x].state > ST_RETRY || pb.np == 0 || pb.use_reg != 2) return;
+    const double* __restrict__ S = pb.S;
+    const double* __restrict__ b = pb.bsch;
+    double* __restrict__ x = pb.xp;
+    double* __restrict__ ok = &ctls[blockIdx.x].ok;
+    const int ld = pb.ld, n = pb.n;
     constexpr int NS = NBLK * (NBLK + 1) / 2;
 #define SLOT(bi, bj) ((bi) * ((bi) + 1) / 2 + (bj))
     __shared__ double col[2][NBLK * 32];
@@ -573,8 +693,14 @@ __global__ __launch_bounds__(1024) void k_ldlt_reg(const double* __restrict__ S,
 
 // ---- blocked LDL^T of S (ld x ld, lower part used, n_pad multiple of 16) ----
 // panel step k0: factor the 16x16 diagonal block, then L rows below; W = L D kept for the trailing update
-__global__ __launch_bounds__(256) void k_ldlt_panel(double* __restrict__ S, int ld, int n_pad, int k0, double* __restrict__ W, double* __restrict__ ok)
+__global__ __launch_bounds__(256) void k_ldlt_panel(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int k0)
 {
+    const BaProb& pb = probs[blockIdx.x];
+    if (ctls[blockIdx.x].state > ST_RETRY || pb.np == 0 || pb.use_reg != 0 || k0 >= pb.n_pad) return;
+    double* __restrict__ S = pb.S;
+    double* __restrict__ W = pb.W;
+    double* __restrict__ ok = &ctls[blockIdx.x].ok;
+    const int ld = pb.ld, n_pad = pb.n_pad;
     __shared__ double A[kNB][kNB + 1];
     __shared__ double d[kNB];
     const int t = threadIdx.x;
@@ -620,10 +746,15 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // trailing update of one 16x16 tile (ti >= tj > k) per wave: A_ij -= W_i L_j^T on the f64 matrix cores.
 // v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
 // C/D: col = l&15, row = (l>>4) + 4*reg.
-__global__ __launch_bounds__(64) void k_ldlt_update(double* __restrict__ S, int ld, int k0, const double* __restrict__ W)
+__global__ __launch_bounds__(64) void k_ldlt_update(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls, int k0)
 {
+    const BaProb& pb = probs[blockIdx.z];
+    if (ctls[blockIdx.z].state > ST_RETRY || pb.np == 0 || pb.use_reg != 0) return;
     const int ti = blockIdx.x, tj = blockIdx.y;
-    if (tj > ti) return;
+    if (tj > ti || ti >= (pb.n_pad - k0) / kNB - 1) return;
+    double* __restrict__ S = pb.S;
+    const double* __restrict__ W = pb.W;
+    const int ld = pb.ld;
     const int i0 = k0 + kNB * (ti + 1), j0 = k0 + kNB * (tj + 1);
     const int l = threadIdx.x, lo = l & 15, hi = l >> 4;
     double4_t acc;
@@ -642,16 +773,17 @@ __global__ __launch_bounds__(64) void k_ldlt_update(double* __restrict__ S, int 
 // holds element (row = (l >> 4) + 4 r, col = l & 15)); wave (p, q) = (wave >> 1, wave & 1) owns the tiles (I, J) with
 // I % 4 == p, J % 2 == q, I >= J (2-D block-cyclic: the work stays balanced while the trailing matrix shrinks).
 // Block step J, two workgroup barriers:
-//   rows    one thread per row below the diagonal block solves its 16 entries against L11 (broadcast LDS reads;
-//           w = l d is kept for the update) and applies the 16 new y values to its own right-hand-side entry
-//   update  every wave updates its tiles C(I, K) -= L(I, J) W(K, J)^T with 4 v_mfma_f64_16x16x4_f64 each (operand maps:
-//           A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]); the tiles of block column J + 1 go first and are
-//           published to the other panel buffer, and as soon as the diagonal tile (J + 1, J + 1) is out (LDS flag) the
-//           lightly loaded wave 1 factors it -- one ROW per lane, pivot column broadcast with v_readlane, right-hand side
-//           forward-substituted alongside -- while the other waves finish the update (look-ahead: the sequential
-//           16x16 factorisation is off the critical path). The finished L tiles of column J return to registers.
+//   rows    the panel below the diagonal block is W = A U^-T, L = W D^-1 with the INVERSE of the unit factor of the
+//           diagonal block: 4 v_mfma_f64_16x16x4_f64 per 16-row tile (operand maps: A[i = l & 15][k = l >> 4],
+//           B[k = l >> 4][j = l & 15]), two tiles per wave; L and -W go to LDS in the operand layout of the update
+//   update  every wave updates its tiles C(I, K) -= L(I, J) W(K, J)^T with 4 MFMAs each; the tiles of block column J + 1
+//           go first and are published to the other panel buffer, and as soon as the diagonal tile (J + 1, J + 1) is out
+//           (LDS flag) wave 1 factors it while the other waves finish the update (look-ahead). The diagonal block is
+//           factored one ROW per lane, pivot row / column broadcast with DPP row_newbcast (v_mov_b64_dpp: no SGPR
+//           traffic); the same elimination applied to an identity yields U^-1 at the price of as many FMAs again, and
+//           the right-hand side is forward-substituted alongside. The finished L tiles of column J return to registers.
 // Back substitution L^T x = D^-1 y walks the block columns backwards: tile owners reduce L(I, J)^T x_I with two
-// cross-lane adds, wave 1 sums the four partial vectors in fixed order and solves the 16x16 triangle with readlane.
+// cross-lane adds, wave 1 sums the four partial vectors in fixed order and multiplies by U^-T (16 DPP broadcasts).
 constexpr int kLS = 17;                        // padded LDS row stride of the 16-wide panels (doubles)
 constexpr int kDiagWave = 1;                   // (p, q) = (0, 1): owns the fewest tiles, never owns a diagonal tile with I % 4 == 0, J odd
 
@@ -661,54 +793,133 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane)
     return __hiloint2double(hi, lo);
 }
 
-// factor the 16x16 diagonal block whose raw rows sit in P (row stride kLS), forward-substitute y[0..16); one wave
-__device__ __forceinline__ void ldlt_diag16(const double* P, double* U, double* invd_out, double* y, double* ok, int lane)
+// DPP row_newbcast: lane K of every 16-lane row feeds all lanes of that row. v_mov_b64_dpp broadcasts a double,
+// v_fmac_f64_dpp folds the broadcast into the FMA (acc += src[lane K of the row] * mul): no SGPR traffic, no temporaries.
+// Everything on the pivot chain is volatile asm so that the hand-made order below (and with it the register footprint)
+// survives the scheduler. The compiler does not track hazards inside asm: a VGPR written by one of the two preceding VALU
+// instructions must not be the DPP source (2 wait states), which the NOP variants / the op order take care of.
+template <int K, bool NOP> __device__ __forceinline__ double bcast16(double v)
 {
-    int lo_ = lane & 15;
-    asm volatile("" : "+v"(lo_));              // per-step lane predicates (lo > k): recompute them, do not hoist 16 masks
-    double ar[16];
+    double r;
+    if constexpr (NOP) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    else asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+template <int K, bool NOP> __device__ __forceinline__ void fmac_bcast16(double& acc, double src, double mul)      // acc += src[lane K of the row] * mul
+{
+    if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+}
+__device__ __forceinline__ double asm_rcp(double x) { double r; asm volatile("v_rcp_f64 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ double asm_fnma1(double d, double r) { double e; asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(d), "v"(r)); return e; }   // 1 - d r
+__device__ __forceinline__ double asm_fma(double a, double b, double c) { double r; asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ double asm_nmul(double a, double b) { double r; asm volatile("v_mul_f64 %0, -%1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }        // -(a b)
+
+// Factor the 16x16 diagonal block whose raw rows sit in P (row stride kLS): A = U D U^T, U unit lower. One wave, lane
+// (l & 15) = row (the four 16-lane rows of the wave work redundantly). Writes U^-1 (row-major, stride kLS) and 1/d, and
+// forward-substitutes the block's right-hand side yv (lane = row); returns it. ok is cleared on a zero / non-finite pivot.
+//
+// Pivot k = a dependent chain (broadcast d_k -> v_rcp_f64 -> two Newton steps -> -l_ik) followed by 16 independent
+// updates: a_ij -= l_ik (d_k l_jk) for j > k, y_i -= l_ik y_k, and row_i(U^-1) -= l_ik row_k(U^-1) (the elimination applied
+// to an identity). Only the update of a_{k+1,k+1} feeds the next pivot, so the other 15 are issued BETWEEN the chain
+// instructions of pivot k + 1, two per latency bubble (software pipeline, spelled out because a single wave issues in
+// order). Compile-time recursion instead of unrolled loops: every register index and DPP lane is a constant, and the code
+// is branch-free (with a branch per pivot the compiler sinks the updates into later blocks and keeps every broadcast
+// alive: 200+ VGPRs).
+struct Diag16 { double ar[16], xr[16], yv, nlik, nlikm, myinvd; int lo; };
+
+// the IDX-th of the 16 updates of pivot M: columns M+1 .. 15, then y, then U^-1 columns 0 .. M-1
+template <int M, int IDX> __device__ __forceinline__ void diag16_bulk(Diag16& d)
+{
+    if constexpr (IDX < 15 - M) fmac_bcast16<M + 1 + IDX, false>(d.ar[M + 1 + IDX], d.ar[M], d.nlik);
+    else if constexpr (IDX == 15 - M) fmac_bcast16<M, false>(d.yv, d.yv, d.nlikm);
+    else fmac_bcast16<M, (IDX - (16 - M) == M - 1)>(d.xr[IDX - (16 - M)], d.xr[IDX - (16 - M)], d.nlikm);   // xr[M-1] was set by plain VALU code: keep its distance
+}
+template <int M, int I0> __device__ __forceinline__ void diag16_bulk2(Diag16& d)
+{
+    if constexpr (M >= 0) { diag16_bulk<M, I0>(d); diag16_bulk<M, I0 + 1>(d); }
+}
+template <int K> __device__ __forceinline__ void diag16_pivot(Diag16& d)
+{
+    if constexpr (K > 0) { diag16_bulk<K - 1, 0>(d); diag16_bulk<K - 1, 1>(d); diag16_bulk<K - 1, 2>(d); }   // a_kk first; two more keep the DPP read of a_kk two slots away
+    const double dk = bcast16<K, K == 0>(d.ar[K]);
+    diag16_bulk2<K - 1, 3>(d);
+    double r = asm_rcp(dk);
+    diag16_bulk2<K - 1, 5>(d);
+    double e = asm_fnma1(dk, r);
+    diag16_bulk2<K - 1, 7>(d);
+    r = asm_fma(e, r, r);
+    diag16_bulk2<K - 1, 9>(d);
+    e = asm_fnma1(dk, r);
+    diag16_bulk2<K - 1, 11>(d);
+    const double invd = asm_fma(e, r, r);
+    diag16_bulk2<K - 1, 13>(d);
+    if constexpr (K > 0) diag16_bulk<K - 1, 15>(d);
+    d.myinvd = d.lo == K ? invd : d.myinvd;
+    d.nlik = asm_nmul(d.ar[K], invd);                                      // -l_ik, meaningful for rows below k
+    d.nlikm = d.lo > K ? d.nlik : 0.0;
+    d.xr[K] += d.nlikm;                                                    // column k of U^-1 starts as e_k (set before the loop)
+}
+template <int... Ks> __device__ __forceinline__ void diag16_pivots(Diag16& d, std::integer_sequence<int, Ks...>) { (diag16_pivot<Ks>(d), ...); }
+template <int... Is> __device__ __forceinline__ void diag16_tail(Diag16& d, std::integer_sequence<int, Is...>) { (diag16_bulk<15, Is>(d), ...); }
+
+__device__ __forceinline__ double ldlt_diag16(const double* P, double* Uinv, double* invd_out, double yv, double* ok, int lane)
+{
+    Diag16 d;
+    d.lo = lane & 15; d.yv = yv; d.nlik = 0.0; d.nlikm = 0.0; d.myinvd = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) ar[k] = P[lo_ * kLS + k];
-    double yv = y[lo_];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const double dk = readlane_f64(ar[k], k);
-        const double invd = fast_recip(dk);
-        if (lane == 0) { invd_out[k] = invd; if (dk == 0.0 || !isfinite(dk)) *ok = 0.0; }
-        const double yk = readlane_f64(yv, k);
-        const double lik = ar[k] * invd;                                   // meaningful for rows below k
-#pragma unroll
-        for (int j = k + 1; j < 16; ++j) ar[j] = fma(-lik, readlane_f64(ar[k], j), ar[j]);   // a_ij -= l_ik (d_k l_jk)
-        if (lo_ > k) yv = fma(-lik, yk, yv);
-        ar[k] = lik;
-    }
+    for (int k = 0; k < 16; ++k) { d.ar[k] = P[d.lo * kLS + k]; d.xr[k] = d.lo == k ? 1.0 : 0.0; }
+    diag16_pivots(d, std::make_integer_sequence<int, 16>{});
+    diag16_tail(d, std::make_integer_sequence<int, 16>{});
     if (lane < 16) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) U[lo_ * kLS + k] = k < lo_ ? ar[k] : (k == lo_ ? 1.0 : 0.0);
-        y[lo_] = yv;
+        for (int k = 0; k < 16; ++k) Uinv[d.lo * kLS + k] = d.xr[k];
+        invd_out[d.lo] = d.myinvd;
     }
+    // a zero / infinite / NaN pivot shows in its reciprocal (inf / 0 / NaN): one test per lane instead of one per pivot
+    if (__any(lane < 16 && (!isfinite(d.myinvd) || d.myinvd == 0.0)) && lane == 0) *ok = 0.0;
+    return d.yv;
 }
 
-__global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S, int ld, int n, const double* __restrict__ b,
-                                                  double* __restrict__ x, double* __restrict__ ok)
+// x_j = sum_k uc[k] rhs[lane k]: four chains of four v_fmac_f64_dpp instead of one of sixteen
+template <int K> __device__ __forceinline__ void bsub4(double& xa, double& xb, double& xc, double& xd, double rhs, const double* uc)
 {
+    fmac_bcast16<K, false>(xa, rhs, uc[K]); fmac_bcast16<K + 1, false>(xb, rhs, uc[K + 1]);
+    fmac_bcast16<K + 2, false>(xc, rhs, uc[K + 2]); fmac_bcast16<K + 3, false>(xd, rhs, uc[K + 3]);
+}
+
+#ifdef LDLT_PROF
+__device__ long long g_ldlt_prof[512];
+#define LP(J, k, w) do { if (blockIdx.x == 0 && lane == 0 && wave == (w)) g_ldlt_prof[(J) * 8 + (k)] = clock64(); } while (0)
+#else
+#define LP(J, k, w)
+#endif
+__global__ __launch_bounds__(256) void k_ldlt_mfma(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
+{
+    const BaProb& pb = probs[blockIdx.x];
+    if (ctls[blockIdx.x].state > ST_RETRY || pb.np == 0 || pb.use_reg != 1) return;
+    const double* __restrict__ S = pb.S;
+    const double* __restrict__ b = pb.bsch;
+    double* __restrict__ x = pb.xp;
+    double* __restrict__ ok = &ctls[blockIdx.x].ok;
+    const int ld = pb.ld, n = pb.n;
     __shared__ double Lp[2][256 * kLS];        // panel (double-buffered): raw columns of block J, then the finished L rows
     __shared__ double Wn[256 * kLS];           // -(L D) rows of the panel
-    __shared__ double Ud[16][16 * kLS];        // unit lower factor of every diagonal block
+    __shared__ double Ui[16][16 * kLS];        // inverse of the unit lower factor of every diagonal block
     __shared__ double s_invd[256], s_y[256], s_x[256];
-    __shared__ double s_part[4][16];
+    __shared__ double s_part[2][16];
     __shared__ int s_flag;                     // block column whose diagonal tile has been published
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = wave >> 1, q = wave & 1, lo = lane & 15, hi = lane >> 4;          // 4 x 2 wave grid
+    const int p = wave >> 1, q = wave & 1, lo = lane & 15, hi = lane >> 4;          // 2 x 2 wave grid
     const int NT = (n + 15) >> 4, n_pad = NT << 4;
-    // tile slots: (a, b) -> I = 4 a + p, J = 2 b + q, kept for b <= 2 a + 1 (20 slots); valid iff J <= I < NT
-#define LSLOT(a, b) ((a) * ((a) + 1) + (b))
-    double4_t acc[20];
+    // tile slots: (a, b) -> I = 2 a + p, J = 2 b + q, kept for b <= a (36 slots); valid iff J <= I < NT
+#define LSLOT(a, b) ((a) * ((a) + 1) / 2 + (b))
+    double4_t acc[36];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int bb = 0; bb <= 2 * a + 1; ++bb) {
-            const int I = 4 * a + p, J = 2 * bb + q;
+        for (int bb = 0; bb <= a; ++bb) {
+            const int I = 2 * a + p, J = 2 * bb + q;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * I + hi + 4 * r, j = 16 * J + lo;
@@ -717,114 +928,147 @@ __global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S,
                 acc[LSLOT(a, bb)][r] = v;
             }
         }
-    if (tid < 256) s_y[tid] = tid < n ? b[tid] : 0.0;
+    s_y[tid] = tid < n ? b[tid] : 0.0;
     if (tid == 0) s_flag = -1;
     // every LDS address below is a lane base + a compile-time constant (ds_read / ds_write immediate offset)
-    const int offC = (16 * p + hi) * kLS + lo;      // accumulator layout: element (16 I + hi + 4 r, lo), 16 I = 64 a + 16 p
+    const int offC = (16 * p + hi) * kLS + lo;      // accumulator layout: element (16 I + hi + 4 r, lo), 16 I = 32 a + 16 p
     const int offA = (16 * p + lo) * kLS + hi;      // MFMA A operand of row block I: L[16 I + lo][4 sl + hi]
     const double* const WnB = Wn + (16 * q + lo) * kLS + hi;    // MFMA B operand of row block K = 2 bb + q: W[16 K + lo][4 sl + hi]
     // ---- prologue: publish block column 0, factor its diagonal block
     if (q == 0) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            if (4 * a + p < NT) {
+        for (int a = 0; a < 8; ++a) {
+            if (2 * a + p < NT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Lp[0][offC + (64 * a + 4 * r) * kLS] = acc[LSLOT(a, 0)][r];
+                for (int r = 0; r < 4; ++r) Lp[0][offC + (32 * a + 4 * r) * kLS] = acc[LSLOT(a, 0)][r];
             }
         }
     }
     __syncthreads();
-    if (wave == kDiagWave) ldlt_diag16(&Lp[0][0], &Ud[0][0], s_invd, s_y, ok, lane);
+    if (wave == kDiagWave) {
+        const double yv = ldlt_diag16(&Lp[0][0], &Ui[0][0], s_invd, s_y[lo], ok, lane);
+        if (lane < 16) s_y[lo] = yv;
+    }
     __syncthreads();
     for (int J = 0; J < NT; ++J) {
         double* const Lc = Lp[J & 1];              // panel of this step
         double* const Ln = Lp[(J & 1) ^ 1];        // panel of the next step (raw columns of block J + 1)
-        // ---- rows below the diagonal block: w_j = a_j - sum_{m<j} w_m U[j][m], l_j = w_j / d_j
+        LP(J, 0, 0);
+        // ---- rows below the diagonal block: W = A U^-T on the matrix cores, L = W D^-1; wave (p, q) takes I = 2 a + p, a % 2 == q
         {
-            const int row = 16 * (J + 1) + tid;
-            if (row < n_pad) {
-                double w[16];
+            const double* const UiB = &Ui[J][lo * kLS + hi];                    // B[k = 4 sl + hi][j = lo] = U^-1[lo][4 sl + hi]
+            const double invd_c = s_invd[16 * J + lo];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) w[j] = Lc[row * kLS + j];
+            for (int a2 = 0; a2 < 4; ++a2) {
+                const int a = 2 * a2 + q, I = 2 * a + p;
+                if (I <= J || I >= NT) continue;                                // wave-uniform
+                double4_t w = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int m = 0; m < 15; ++m) {                                  // right-looking: w_m is final, 15 - m independent updates
+                for (int sl = 0; sl < 4; ++sl)
+                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[offA + 32 * a * kLS + 4 * sl], UiB[4 * sl], w, 0, 0, 0);
 #pragma unroll
-                    for (int j = m + 1; j < 16; ++j) w[j] = fma(-w[m], Ud[J][j * kLS + m], w[j]);
-                    if ((m & 3) == 3) asm volatile("" ::: "memory");            // keep the LDS loads of later columns from piling up in VGPRs
-                }
-                double yacc = s_y[row];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const double l = w[j] * s_invd[16 * J + j];
-                    Lc[row * kLS + j] = l; Wn[row * kLS + j] = -w[j];
-                    yacc = fma(-l, s_y[16 * J + j], yacc);
-                }
-                s_y[row] = yacc;
+                for (int r = 0; r < 4; ++r) { Lc[offC + (32 * a + 4 * r) * kLS] = w[r] * invd_c; Wn[offC + (32 * a + 4 * r) * kLS] = -w[r]; }
             }
         }
+        LP(J, 1, 0);
         __syncthreads();
+        LP(J, 2, 0);
+        // ---- B operands of the whole step (W rows of every owned column block), loaded once: with the A operands fetched per
+        // row block, the tile loops below wait on LDS once per row instead of twice per tile
+        double bv[8][4];
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            if (2 * bb + q <= J) continue;                                     // wave-uniform; rows past NT are identity padding inside the buffer
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) bv[bb][sl] = WnB[32 * bb * kLS + 4 * sl];
+        }
         // ---- update, pass 1: tiles of block column J + 1 (ascending I, so an owned diagonal tile goes first), published at once
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int I = 4 * a + p;
+        for (int a = 0; a < 8; ++a) {
+            const int I = 2 * a + p;
             if (I <= J || I >= NT) continue;                                   // wave-uniform
 #pragma unroll
-            for (int bb = 0; bb <= 2 * a + 1; ++bb) {
+            for (int bb = 0; bb <= a; ++bb) {
                 if (2 * bb + q != J + 1) continue;
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl)
-                    acc[LSLOT(a, bb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[offA + 64 * a * kLS + 4 * sl], WnB[32 * bb * kLS + 4 * sl], acc[LSLOT(a, bb)], 0, 0, 0);
+                    acc[LSLOT(a, bb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[offA + 32 * a * kLS + 4 * sl], bv[bb][sl], acc[LSLOT(a, bb)], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Ln[offC + (64 * a + 4 * r) * kLS] = acc[LSLOT(a, bb)][r];
+                for (int r = 0; r < 4; ++r) Ln[offC + (32 * a + 4 * r) * kLS] = acc[LSLOT(a, bb)][r];
                 if (I == J + 1) {                                              // diagonal tile of the next step: release it to wave kDiagWave
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) __hip_atomic_store(&s_flag, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
+        LP(J, 3, 0);
         // ---- look-ahead: factor the next diagonal block while the other waves run pass 2
         if (wave == kDiagWave && J + 1 < NT) {
+            // forward substitution of the next block's right-hand side with the L rows just finished: y -= L(J + 1, J) y_J
+            double yv = s_y[16 * (J + 1) + lo];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) yv = fma(-Lc[(16 * (J + 1) + lo) * kLS + j], s_y[16 * J + j], yv);
+            LP(J, 5, kDiagWave);
             while (__hip_atomic_load(&s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            ldlt_diag16(Ln + 16 * (J + 1) * kLS, &Ud[J + 1][0], s_invd + 16 * (J + 1), s_y + 16 * (J + 1), ok, lane);
+            LP(J, 6, kDiagWave);
+            yv = ldlt_diag16(Ln + 16 * (J + 1) * kLS, &Ui[J + 1][0], s_invd + 16 * (J + 1), yv, ok, lane);
+            if (lane < 16) s_y[16 * (J + 1) + lo] = yv;
+            LP(J, 7, kDiagWave);
+        }
+        // ---- right-hand side of the rows below block J + 1 (one thread per row)
+        {
+            const int row = 16 * (J + 2) + tid;
+            if (row < n_pad) {
+                double yacc = s_y[row];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) yacc = fma(-Lc[row * kLS + j], s_y[16 * J + j], yacc);
+                s_y[row] = yacc;
+            }
         }
         // ---- update, pass 2: finished L tiles of column J back to registers, all other tiles
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int I = 4 * a + p;
+        for (int a = 0; a < 8; ++a) {
+            const int I = 2 * a + p;
             if (I <= J || I >= NT) continue;
             double av[4];
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) av[sl] = Lc[offA + 64 * a * kLS + 4 * sl];
+            for (int sl = 0; sl < 4; ++sl) av[sl] = Lc[offA + 32 * a * kLS + 4 * sl];
 #pragma unroll
-            for (int bb = 0; bb <= 2 * a + 1; ++bb) {
+            for (int bb = 0; bb <= a; ++bb) {
                 const int K = 2 * bb + q;
                 if (K == J) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[LSLOT(a, bb)][r] = Lc[offC + (64 * a + 4 * r) * kLS];
+                    for (int r = 0; r < 4; ++r) acc[LSLOT(a, bb)][r] = Lc[offC + (32 * a + 4 * r) * kLS];
                 } else if (K > J + 1 && K <= I) {
 #pragma unroll
                     for (int sl = 0; sl < 4; ++sl)
-                        acc[LSLOT(a, bb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sl], WnB[32 * bb * kLS + 4 * sl], acc[LSLOT(a, bb)], 0, 0, 0);
-                    asm volatile("" ::: "memory");
+                        acc[LSLOT(a, bb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sl], bv[bb][sl], acc[LSLOT(a, bb)], 0, 0, 0);
                 }
             }
         }
+        LP(J, 4, 0);
         __syncthreads();
     }
+    LP(NT, 0, 0);
     if (tid < n_pad) s_x[tid] = s_y[tid] * s_invd[tid];                       // z = D^-1 y
     __syncthreads();
     for (int J = NT - 1; J >= 0; --J) {
+        double uc[16];
+        if (wave == kDiagWave) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) uc[k] = Ui[J][k * kLS + lo];          // U^-1[k][lo]: in flight while the owners reduce
+        }
         if (q == (J & 1)) {                                                   // owners of block column J
             double c = 0.0;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 8; ++a)
 #pragma unroll
-                for (int bb = 0; bb <= 2 * a + 1; ++bb) {
-                    const int I = 4 * a + p;
+                for (int bb = 0; bb <= a; ++bb) {
+                    const int I = 2 * a + p;
                     if (2 * bb + q == J && I > J && I < NT) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) c = fma(acc[LSLOT(a, bb)][r], s_x[16 * p + hi + 64 * a + 4 * r], c);
+                        for (int r = 0; r < 4; ++r) c = fma(acc[LSLOT(a, bb)][r], s_x[16 * p + hi + 32 * a + 4 * r], c);
                     }
                 }
             c += __shfl_xor(c, 16);
@@ -832,28 +1076,29 @@ __global__ __launch_bounds__(512) void k_ldlt_mfma(const double* __restrict__ S,
             if (lane < 16) s_part[p][lane] = c;
         }
         __syncthreads();
-        if (wave == kDiagWave) {
-            double rhs = s_x[16 * J + lo] - (((s_part[0][lo] + s_part[1][lo]) + s_part[2][lo]) + s_part[3][lo]);
-            double uc[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) uc[k] = Ud[J][k * kLS + lo];          // U[k][lo]
-#pragma unroll
-            for (int k = 15; k >= 1; --k) {
-                const double xk = readlane_f64(rhs, k);
-                if (lo < k) rhs = fma(-uc[k], xk, rhs);
-            }
-            if (lane < 16) s_x[16 * J + lo] = rhs;
+        if (wave == kDiagWave) {                                              // x_J = U^-T (z_J - sum_I L(I, J)^T x_I)
+            double rhs = s_x[16 * J + lo] - (s_part[0][lo] + s_part[1][lo]);
+            asm volatile("s_nop 1" : "+v"(rhs));                                // rhs is a DPP source right away
+            double xa = 0.0, xb = 0.0, xc = 0.0, xd = 0.0;
+            bsub4<0>(xa, xb, xc, xd, rhs, uc); bsub4<4>(xa, xb, xc, xd, rhs, uc); bsub4<8>(xa, xb, xc, xd, rhs, uc); bsub4<12>(xa, xb, xc, xd, rhs, uc);
+            if (lane < 16) s_x[16 * J + lo] = (xa + xb) + (xc + xd);
         }
         __syncthreads();
     }
+    LP(NT + 1, 0, 0);
     if (tid < n) x[tid] = s_x[tid];
 #undef LSLOT
 }
 
 // x = S^-1 b with S = L D L^T already factored in place (unit lower L below the diagonal, D on it). single block.
-__global__ __launch_bounds__(256) void k_ldlt_solve(const double* __restrict__ S, int ld, int n_pad, const double* __restrict__ b, int n,
-                                                    double* __restrict__ x)
+__global__ __launch_bounds__(256) void k_ldlt_solve(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
+    const BaProb& pb = probs[blockIdx.x];
+    if (ctls[blockIdx.x].state > ST_RETRY || pb.np == 0 || pb.use_reg != 0) return;
+    const double* __restrict__ S = pb.S;
+    const double* __restrict__ b = pb.bsch;
+    double* __restrict__ x = pb.xp;
+    const int ld = pb.ld, n_pad = pb.n_pad, n = pb.n;
     extern __shared__ double y[];                  // n_pad
     __shared__ double red[256];
     const int t = threadIdx.x;
@@ -891,79 +1136,144 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(const double* __restrict__ S
     for (int i = t; i < n; i += 256) x[i] = y[i];
 }
 
-// Landmark back-substitution, push + oplus of every estimate and the block partials of computeScale, one launch of
-// 64-thread blocks: blocks [0, nb_pts) thread per landmark (xl = Dinv (bl - sum_e Hpl[e]^T xp[pose(e)]), backup, += xl),
-// blocks [nb_pts, ..) thread per pose (backup, pose <- exp(dx) * pose). scale = sum_j x_j (lambda x_j + b_j) over pose and
-// active landmark entries; the block sums are added in index order by k_error's finisher.
-__global__ __launch_bounds__(64) void k_solve_update(int L, int nb_pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
-                                                    const int32_t* __restrict__ e_pose, const int32_t* __restrict__ pose_idx,
-                                                    const uint8_t* __restrict__ pt_active, const double* __restrict__ Hpl,
-                                                    const double* __restrict__ xp, const double* __restrict__ bl, const double* __restrict__ Dinv,
-                                                    double* __restrict__ xl, int P, const double* __restrict__ bp, double* __restrict__ poses,
-                                                    double* __restrict__ points, double* __restrict__ poses_bk, double* __restrict__ points_bk,
-                                                    const double* __restrict__ max_diag, double lam_mult, double* __restrict__ scale_partial)
+// Landmark back-substitution + oplus of every estimate into the OTHER estimate buffer (g2o's push + update: the current
+// buffer is the backup, nothing has to be copied back on a rejected trial) and the block partials of computeScale, one
+// launch of 64-thread blocks: blocks [0, nb_pts) thread per landmark (xl = Dinv (bl - sum_e Hpl[e]^T xp[pose(e)])),
+// blocks [nb_pts, ..) thread per pose (pose <- exp(dx) * pose). scale = sum_j x_j (lambda x_j + b_j) over pose and
+// active landmark entries; the block sums are added in index order by k_error<1>'s finisher.
+__global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
-    const double lambda = 1e-5 * *max_diag * lam_mult;
+    const BaProb& pb = probs[blockIdx.y];
+    const BaCtl& ctl = ctls[blockIdx.y];
+    if (ctl.state > ST_RETRY) return;
+    const int nb_pts = pb.nb_pts, L = pb.L, P = pb.P;
+    if ((int)blockIdx.x >= nb_pts + pb.nb_pose) return;
+    const double lambda = 1e-5 * ctl.maxdiag * ctl.mult;
+    const int32_t* __restrict__ pose_idx = pb.pose_idx;
+    const double* __restrict__ xp = pb.xp;
     double sc = 0;
     if ((int)blockIdx.x < nb_pts) {
         const int l = blockIdx.x * 64 + threadIdx.x;
         if (l < L) {
+            const double* __restrict__ bl = pb.bl;
             double x[3] = {0, 0, 0};
-            if (pt_active[l]) {
+            if (pb.pt_active[l]) {
                 double c[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
-                for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
-                    const int e = pt_edges[k], pi = pose_idx[e_pose[e]];
-                    if (pi < 0) continue;
-                    const double* B = Hpl + (size_t)e * 18;
-                    const double* xq = xp + pi * 6;
-                    for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) c[j] -= B[r * 3 + j] * xq[r];
+                if (pb.np) {
+                    for (int k = pb.pt_off[l]; k < pb.pt_off[l + 1]; ++k) {
+                        const int e = pb.pt_edges[k], pi = pose_idx[pb.epose[e]];
+                        if (pi < 0) continue;
+                        const double* B = pb.Hpl + (size_t)e * 18;
+                        const double* xq = xp + pi * 6;
+                        for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) c[j] -= B[r * 3 + j] * xq[r];
+                    }
                 }
-                const double* D = Dinv + (size_t)l * 9;
+                const double* D = pb.Dinv + (size_t)l * 9;
                 for (int i = 0; i < 3; ++i) {
                     x[i] = D[i * 3] * c[0] + D[i * 3 + 1] * c[1] + D[i * 3 + 2] * c[2];
                     sc += x[i] * (lambda * x[i] + bl[3 * l + i]);
                 }
             }
-            for (int k = 0; k < 3; ++k) {
-                xl[3 * l + k] = x[k];
-                const double v = points[3 * l + k];
-                points_bk[3 * l + k] = v; points[3 * l + k] = v + x[k];
-            }
+            const double* __restrict__ src = pb.points[ctl.cur];
+            double* __restrict__ dst = pb.points[ctl.cur ^ 1];
+            for (int k = 0; k < 3; ++k) { pb.xl[3 * l + k] = x[k]; dst[3 * l + k] = src[3 * l + k] + x[k]; }
         }
     } else {
         const int i = (blockIdx.x - nb_pts) * 64 + threadIdx.x;
         if (i < P) {
+            const double* __restrict__ src = pb.poses[ctl.cur];
+            double* __restrict__ dst = pb.poses[ctl.cur ^ 1];
             double T[7];
-            for (int k = 0; k < 7; ++k) { T[k] = poses[7 * i + k]; poses_bk[7 * i + k] = T[k]; }
+            for (int k = 0; k < 7; ++k) T[k] = src[7 * i + k];
             const int pi = pose_idx[i];
             if (pi >= 0) {
                 double o[7];
                 pose_oplus(T, xp + 6 * pi, o);
-                for (int k = 0; k < 7; ++k) poses[7 * i + k] = o[k];
-                for (int k = 0; k < 6; ++k) sc += xp[6 * pi + k] * (lambda * xp[6 * pi + k] + bp[6 * pi + k]);
+                for (int k = 0; k < 7; ++k) dst[7 * i + k] = o[k];
+                for (int k = 0; k < 6; ++k) sc += xp[6 * pi + k] * (lambda * xp[6 * pi + k] + pb.bp[6 * pi + k]);
+            } else {
+                for (int k = 0; k < 7; ++k) dst[7 * i + k] = T[k];
             }
         }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sc += __shfl_xor(sc, d);
-    if (threadIdx.x == 0) scale_partial[blockIdx.x] = sc;
+    if (threadIdx.x == 0) pb.scale_part[blockIdx.x] = sc;
 }
 
-// outlier flags: chi2 (last evaluation) > th || depth <= 0 with the CURRENT estimates (Optimizer.cc:607, 653)
-__global__ __launch_bounds__(256) void k_flags(EdgeArrays ed, int E, const double* __restrict__ poses, const double* __restrict__ points,
-                                               DCams cams, const double* __restrict__ chi2, double th, uint8_t* __restrict__ flag)
+// End of a round (state == ROUND_END): outlier flags chi2 (last evaluation) > th || depth <= 0 with the CURRENT estimates
+// (Optimizer.cc:607, 653). After round 0 they become the level-1 set of round 1 (:607-612) unless the stop flag was seen
+// (:597-600); the current estimates are copied to the output arrays either way.
+__global__ __launch_bounds__(256) void k_round_flags(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
 {
+    __shared__ DCams cams;
+    __shared__ int s_cnt;
+    const BaProb& pb = probs[blockIdx.y];
+    BaCtl& ctl = ctls[blockIdx.y];
+    if ((int)blockIdx.x >= pb.nblk || ctl.state != ST_ROUND_END) return;
+    const double* __restrict__ poses = pb.poses[ctl.cur];
+    const double* __restrict__ points = pb.points[ctl.cur];
+    const int round = ctl.round, stopped = ctl.stopped;
+    if (threadIdx.x == 0) s_cnt = 0;
+    load_cams(&cams, pb.cams);
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E) return;
-    double pc[3];
-    cam_point(poses + 7 * ed.pose[e], points + 3 * ed.point[e], cams.c[ed.cam[e]], pc);
-    flag[e] = (chi2[e] > th || !(pc[2] > 0.0)) ? 1 : 0;
+    if (e < pb.E) {
+        double pc[3];
+        cam_point(poses + 7 * pb.epose[e], points + 3 * pb.epoint[e], cams.c[pb.ecam[e]], pc);
+        const uint8_t f = (pb.chi2[e] > pb.chi2_th || !(pc[2] > 0.0)) ? 1 : 0;
+        pb.flag[e] = f;
+        if (round == 0) {
+            pb.level1[e] = stopped ? 0 : f;
+            if (!stopped) { pb.active[e] = !f; if (!f) atomicAdd(&s_cnt, 1); }
+        }
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 7 * pb.P; i += pb.nblk * 256) pb.out_poses[i] = poses[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * pb.L; i += pb.nblk * 256) pb.out_points[i] = points[i];
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(&ctl.n_active, s_cnt);
 }
 
-__global__ void k_pad_identity(double* S, int ld, int n, int n_pad)
+// one thread per problem: round 0 -> round 1 (robust kernel off, lambda re-initialised, Optimizer.cc:612-621) or done;
+// thread 0 then publishes {step, problems done} to the host's pinned progress words.
+__global__ __launch_bounds__(1024) void k_round_ctl(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int step, int* __restrict__ h_progress)
 {
-    const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_pad) S[(size_t)i * ld + i] = 1.0;
+    __shared__ int s_done;
+    if (threadIdx.x == 0) s_done = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        BaCtl& ctl = ctls[b];
+        if (ctl.state == ST_ROUND_END) {
+            if (ctl.round == 0 && !ctl.stopped && probs[b].iters[1] > 0 && ctl.n_active > 0) {
+                ctl.round = 1; ctl.it = 0; ctl.qmax = 0; ctl.nBad = 0; ctl.robust = 0; ctl.errors_current = 0; ctl.state = ST_NEW_ITER;
+            } else ctl.state = ST_DONE;
+        }
+        if (ctl.state == ST_DONE) atomicAdd(&s_done, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(h_progress + 1, s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(h_progress, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_ctl_init(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B)
+{
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        BaCtl c{};
+        c.state = probs[b].iters[0] > 0 ? ST_NEW_ITER : ST_ROUND_END;
+        c.robust = probs[b].robust0;
+        c.mult = 1.0; c.ni = 2; c.ok = 1.0;
+        ctls[b] = c;
+    }
+}
+
+// n > 256 fallback: the blocked factorisation works in place, so S is cleared and its padding rows get a unit diagonal
+__global__ void k_pad_identity(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
+{
+    const BaProb& pb = probs[blockIdx.y];
+    if (ctls[blockIdx.y].state > ST_RETRY || pb.np == 0 || pb.use_reg != 0) return;
+    const int i = pb.n + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pb.n_pad) pb.S[(size_t)i * pb.ld + i] = 1.0;
 }
 
 // ------------------------------------------------------------------ Optimizer::PoseOptimization (Optimizer.cc:250-405)
@@ -1193,40 +1503,55 @@ using namespace dcs;
 
 namespace {
 
-// Per host thread and device, kept across solves: the device arena (grow-only), the pinned read-back slot and the
-// stream. hipMalloc + hipFree of ~30 MB, hipHostMalloc/Free and stream create/destroy cost ~1.4 ms per call together --
-// a third of a local BA.
+// Per host thread and device, kept across solves: the device arena (grow-only), the pinned staging image of its
+// upload / download regions, the pinned progress + stop words and the stream. hipMalloc + hipFree of ~30 MB,
+// hipHostMalloc/Free and stream create/destroy cost ~1.4 ms per call together -- a third of a local BA.
 struct BaContext {
     char* base = nullptr; size_t cap = 0; int device = -1;
-    double* h_scal = nullptr; hipStream_t stream = nullptr;
+    char* h_stage = nullptr; size_t stage_cap = 0;
+    int* h_words = nullptr; size_t words_cap = 0;      // [0] last finished step, [1] problems done, [16 + b] stop word of problem b
+    hipStream_t stream = nullptr;
     void release()
     {
         if (base) (void)hipFree(base);
-        if (h_scal) (void)hipHostFree(h_scal);
+        if (h_stage) (void)hipHostFree(h_stage);
+        if (h_words) (void)hipHostFree(h_words);
         if (stream) (void)hipStreamDestroy(stream);
-        base = nullptr; cap = 0; h_scal = nullptr; stream = nullptr; device = -1;
+        base = nullptr; cap = 0; h_stage = nullptr; stage_cap = 0; h_words = nullptr; words_cap = 0; stream = nullptr; device = -1;
     }
     ~BaContext() { release(); }
+    int prepare(size_t arena_bytes, size_t stage_bytes, size_t n_words)
+    {
+        int dev = 0;
+        DCS_HIP(hipGetDevice(&dev));
+        if (device != dev) release();
+        device = dev;
+        if (base && cap < arena_bytes) { (void)hipFree(base); base = nullptr; cap = 0; }
+        if (!base) { DCS_HIP(hipMalloc((void**)&base, arena_bytes)); cap = arena_bytes; }
+        if (h_stage && stage_cap < stage_bytes) { (void)hipHostFree(h_stage); h_stage = nullptr; stage_cap = 0; }
+        if (!h_stage && stage_bytes) { DCS_HIP(hipHostMalloc((void**)&h_stage, stage_bytes, hipHostMallocDefault)); stage_cap = stage_bytes; }
+        if (h_words && words_cap < n_words) { (void)hipHostFree(h_words); h_words = nullptr; words_cap = 0; }
+        if (!h_words) {
+            const size_t w = std::max<size_t>(n_words, 64);
+            DCS_HIP(hipHostMalloc((void**)&h_words, w * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
+            words_cap = w;
+        }
+        if (!stream) DCS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return DCS_OK;
+    }
 };
 inline BaContext& ba_context() { static thread_local BaContext c; return c; }
 
-struct Arena {
-    char* base = nullptr; size_t cap = 0, off = 0;
-    int init(size_t bytes)
+// carves 256-byte aligned arrays out of [base, ...): run once with a null base to size the arena, once for real
+struct Carver {
+    char* base = nullptr; size_t off = 0;
+    template <typename T> T* get(size_t n)
     {
-        BaContext& c = ba_context();
-        int dev = 0;
-        DCS_HIP(hipGetDevice(&dev));
-        if (c.device != dev) c.release();
-        if (c.base && c.cap < bytes) { (void)hipFree(c.base); c.base = nullptr; c.cap = 0; }
-        if (!c.base) { DCS_HIP(hipMalloc((void**)&c.base, bytes)); c.cap = bytes; }
-        if (!c.h_scal) DCS_HIP(hipHostMalloc((void**)&c.h_scal, 64));
-        if (!c.stream) DCS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-        c.device = dev;
-        base = c.base; cap = c.cap; off = 0;
-        return DCS_OK;
+        off = (off + 255) & ~(size_t)255;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += std::max<size_t>(n, 1) * sizeof(T);
+        return p;
     }
-    template <typename T> T* get(size_t n) { off = (off + 255) & ~(size_t)255; T* p = (T*)(base + off); off += n * sizeof(T); return off <= cap ? p : nullptr; }
 };
 
 struct Round {                                  // structure of one optimisation round (buildIndexMapping + buildStructure)
@@ -1234,9 +1559,11 @@ struct Round {                                  // structure of one optimisation
     int np = 0, n = 0, n_pad = 0, n_pairs = 0, n_active = 0;
 };
 
-void build_round(const dcs_ba_problem* pb, const std::vector<uint8_t>& active, Round& r)
+// returns -1, or the id of an edge that repeats a (pose, point) pair (the pair lists assume at most one, like g2o's hash of Hpl blocks)
+int build_round(const dcs_ba_problem* pb, Round& r)
 {
     const int P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+    const std::vector<uint8_t> active(E, 1);
     std::vector<uint8_t> pose_act(P, 0);
     r.n_active = 0;
     for (int e = 0; e < E; ++e) if (active[e]) { pose_act[pb->edge_pose[e]] = 1; ++r.n_active; }
@@ -1252,9 +1579,15 @@ void build_round(const dcs_ba_problem* pb, const std::vector<uint8_t>& active, R
     {
         std::vector<int32_t> cur(r.pt_off.begin(), r.pt_off.end() - 1);
         for (int e = 0; e < E; ++e) if (active[e]) r.pt_edges[cur[pb->edge_point[e]]++] = e;
-        for (int l = 0; l < L; ++l)
+        std::vector<std::pair<int32_t, int32_t>> seen;
+        for (int l = 0; l < L; ++l) {
+            seen.clear();
+            for (int k = r.pt_off[l]; k < r.pt_off[l + 1]; ++k) seen.emplace_back(pb->edge_pose[r.pt_edges[k]], r.pt_edges[k]);
+            std::sort(seen.begin(), seen.end());
+            for (size_t k = 1; k < seen.size(); ++k) if (seen[k].first == seen[k - 1].first) return seen[k].second;
             std::stable_sort(r.pt_edges.begin() + r.pt_off[l], r.pt_edges.begin() + r.pt_off[l + 1],
                              [&](int a, int b) { return r.pose_idx[pb->edge_pose[a]] < r.pose_idx[pb->edge_pose[b]]; });
+        }
     }
     // free pose -> active edges (edge id order)
     r.ps_off.assign(r.np + 1, 0);
@@ -1297,261 +1630,300 @@ void build_round(const dcs_ba_problem* pb, const std::vector<uint8_t>& active, R
                 }
             }
     }
+    return -1;
 }
 
 }  // namespace
 
 extern "C" {
 
-int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dcs_ba_result* res)
+int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, const volatile uint8_t* const* stop_flags, dcs_ba_result* const* results)
 {
-    if (!pb || !res || !res->poses || !res->points || !res->edge_outlier || pb->n_poses < 1 || pb->n_points < 1 || pb->n_edges < 1 ||
-        pb->n_cams < 1 || pb->n_cams > kMaxCams || !pb->poses || !pb->pose_fixed || !pb->points || !pb->edge_pose || !pb->edge_point ||
-        !pb->edge_cam || !pb->obs || !pb->inv_sigma2 || !pb->cams) {
-        set_error("bad BA problem (n_cams must be 1..%d)", kMaxCams); return DCS_ERR_INVALID;
+    const int B = n_problems;
+    if (B < 0 || (B && (!problems || !results))) { set_error("bad BA batch"); return DCS_ERR_INVALID; }
+    if (B == 0) return DCS_OK;
+    for (int b = 0; b < B; ++b) {
+        const dcs_ba_problem* pb = problems[b];
+        const dcs_ba_result* res = results[b];
+        if (!pb || !res || !res->poses || !res->points || !res->edge_outlier || pb->n_poses < 1 || pb->n_points < 1 || pb->n_edges < 1 ||
+            pb->n_cams < 1 || pb->n_cams > kMaxCams || !pb->poses || !pb->pose_fixed || !pb->points || !pb->edge_pose || !pb->edge_point ||
+            !pb->edge_cam || !pb->obs || !pb->inv_sigma2 || !pb->cams) {
+            set_error("bad BA problem %d (n_cams must be 1..%d)", b, kMaxCams); return DCS_ERR_INVALID;
+        }
+        const int P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+        for (int e = 0; e < E; ++e)
+            if (pb->edge_pose[e] < 0 || pb->edge_pose[e] >= P || pb->edge_point[e] < 0 || pb->edge_point[e] >= L || pb->edge_cam[e] < 0 ||
+                pb->edge_cam[e] >= pb->n_cams) { set_error("problem %d: edge %d out of range", b, e); return DCS_ERR_INVALID; }
     }
-    const int P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
-    for (int e = 0; e < E; ++e)
-        if (pb->edge_pose[e] < 0 || pb->edge_pose[e] >= P || pb->edge_point[e] < 0 || pb->edge_point[e] >= L || pb->edge_cam[e] < 0 ||
-            pb->edge_cam[e] >= pb->n_cams) { set_error("edge %d out of range", e); return DCS_ERR_INVALID; }
     int rc = ensure_device();
     if (rc) return rc;
-    res->n_iters[0] = res->n_iters[1] = 0; res->n_trials[0] = res->n_trials[1] = 0; res->lambda[0] = res->lambda[1] = 0; res->gpu_ms = 0;
-    for (int i = 0; i < 32; ++i) res->chi2_trace[i] = 0;
-    auto stopped = [&]() { return stop_flag && *stop_flag; };
-
-    DCams cams{};
-    for (int c = 0; c < pb->n_cams; ++c) {
-        DCam& d = cams.c[c];
-        const dcs_ba_camera& s = pb->cams[c];
-        d.fx = s.fx; d.fy = s.fy; d.cx = s.cx; d.cy = s.cy;
-        d.t[0] = s.ext[0]; d.t[1] = s.ext[1]; d.t[2] = s.ext[2];
-        d.q[0] = s.ext[3]; d.q[1] = s.ext[4]; d.q[2] = s.ext[5]; d.q[3] = s.ext[6];
-        memcpy(d.adj, s.adj, sizeof(d.adj));
-    }
-    const int nblk = (E + 255) / 256;
-    const int n_max = P * 6, n_pad_max = ((n_max + kNB - 1) / kNB) * kNB;
-    const size_t max_pairs_entries = [&] {            // upper bound of the (e1,e2) list: sum over points k(k+1)/2
-        std::vector<int> k(L, 0);
-        for (int e = 0; e < E; ++e) ++k[pb->edge_point[e]];
-        size_t s = 0;
-        for (int l = 0; l < L; ++l) s += (size_t)k[l] * (k[l] + 1) / 2;
-        return s;
-    }();
-    const size_t n_pairs_max = (size_t)P * (P + 1) / 2;
-    Arena ar;
-    size_t bytes = 0;
-    bytes += (size_t)(2 * P * 7 + 2 * L * 3) * 8 + (size_t)E * (12 + 8 * (2 + 1 + 2 + 1 + 18 + 18 + 27 + 9) + 2);
-    bytes += (size_t)L * 8 * (9 + 3 + 9 + 3 + 3) + (size_t)P * 8 * (36 + 6 + 6 + 6) + (size_t)n_pad_max * n_pad_max * 8 + (size_t)n_pad_max * kNB * 8;
-    bytes += (size_t)(P + L + 1 + E + P + 1 + E) * 4 + n_pairs_max * 12 + max_pairs_entries * 8 + (size_t)nblk * 8 + 64 * 256 + (1 << 16);
-    if ((rc = ar.init(bytes))) return rc;
-    double* d_poses = ar.get<double>(P * 7); double* d_poses_bk = ar.get<double>(P * 7);
-    double* d_points = ar.get<double>(L * 3); double* d_points_bk = ar.get<double>(L * 3);
-    int32_t* d_epose = ar.get<int32_t>(E); int32_t* d_epoint = ar.get<int32_t>(E); int32_t* d_ecam = ar.get<int32_t>(E);
-    double* d_obs = ar.get<double>(2 * (size_t)E); double* d_w = ar.get<double>(E);
-    uint8_t* d_active = ar.get<uint8_t>(E); uint8_t* d_flag = ar.get<uint8_t>(E);
-    double* d_err = ar.get<double>(2 * (size_t)E); double* d_chi2 = ar.get<double>(E);
-    double* d_Hpl = ar.get<double>(18 * (size_t)E); double* d_BD = ar.get<double>(18 * (size_t)E);
-    double* d_cpose = ar.get<double>(27 * (size_t)E); double* d_cpoint = ar.get<double>(9 * (size_t)E);
-    double* d_Hll = ar.get<double>(9 * (size_t)L); double* d_bl = ar.get<double>(3 * (size_t)L);
-    double* d_Dinv = ar.get<double>(9 * (size_t)L); double* d_db = ar.get<double>(3 * (size_t)L); double* d_xl = ar.get<double>(3 * (size_t)L);
-    double* d_Hpp = ar.get<double>(36 * (size_t)P); double* d_bp = ar.get<double>(6 * (size_t)P);
-    double* d_bsch = ar.get<double>(6 * (size_t)P); double* d_xp = ar.get<double>(6 * (size_t)P);
-    double* d_S = ar.get<double>((size_t)n_pad_max * n_pad_max); double* d_W = ar.get<double>((size_t)n_pad_max * kNB);
-    int32_t* d_pose_idx = ar.get<int32_t>(P); int32_t* d_pt_off = ar.get<int32_t>(L + 1); int32_t* d_pt_edges = ar.get<int32_t>(E);
-    int32_t* d_ps_off = ar.get<int32_t>(P + 1); int32_t* d_ps_edges = ar.get<int32_t>(E);
-    int32_t* d_pair_ij = ar.get<int32_t>(2 * n_pairs_max); int32_t* d_pair_off = ar.get<int32_t>(n_pairs_max + 1);
-    int32_t* d_pair_e1 = ar.get<int32_t>(max_pairs_entries + 1); int32_t* d_pair_e2 = ar.get<int32_t>(max_pairs_entries + 1);
-    double* d_partial = ar.get<double>(nblk);
-    const int nb_pts = (L + 63) / 64, nb_pose = (P + 63) / 64;
-    double* d_scale_part = ar.get<double>(nb_pts + nb_pose);
-    uint8_t* d_pt_active = ar.get<uint8_t>(L);
-    double* d_scal = ar.get<double>(8);               // [0] chi2, [1] scale, [2] maxdiag, [3] ok, [4] chi2 before the trial
-    int* d_ok = ar.get<int>(4);
-    unsigned* d_ticket = ar.get<unsigned>(4);
-    if (!d_ticket) { set_error("BA arena too small"); return DCS_ERR_HIP; }
-    double* h_scal = ba_context().h_scal;
-    const bool force_blocked = getenv("DCS_BA_FORCE_BLOCKED_LDLT") != nullptr;
-    const bool ldlt_valu = getenv("DCS_BA_LDLT_VALU") != nullptr;       // previous register-resident column-by-column kernel
     const bool trace_t = getenv("DCS_BA_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     const auto t_call0 = now();
-    double t_build = 0, t_sync = 0;   // test hook: exercise the MFMA fallback at small n
+    auto stop_requested = [&](int b) { return stop_flags && stop_flags[b] && *stop_flags[b]; };
 
-    hipStream_t st = ba_context().stream;
-    DCS_HIP(hipMemcpyAsync(d_poses, pb->poses, sizeof(double) * 7 * P, hipMemcpyHostToDevice, st));
-    DCS_HIP(hipMemcpyAsync(d_points, pb->points, sizeof(double) * 3 * L, hipMemcpyHostToDevice, st));
-    DCS_HIP(hipMemcpyAsync(d_epose, pb->edge_pose, sizeof(int32_t) * E, hipMemcpyHostToDevice, st));
-    DCS_HIP(hipMemcpyAsync(d_epoint, pb->edge_point, sizeof(int32_t) * E, hipMemcpyHostToDevice, st));
-    DCS_HIP(hipMemcpyAsync(d_ecam, pb->edge_cam, sizeof(int32_t) * E, hipMemcpyHostToDevice, st));
-    DCS_HIP(hipMemcpyAsync(d_obs, pb->obs, sizeof(double) * 2 * E, hipMemcpyHostToDevice, st));
-    DCS_HIP(hipMemcpyAsync(d_w, pb->inv_sigma2, sizeof(double) * E, hipMemcpyHostToDevice, st));
-    DCS_HIP(hipMemsetAsync(d_chi2, 0, sizeof(double) * E, st));
-    DCS_HIP(hipMemsetAsync(d_err, 0, sizeof(double) * 2 * E, st));
-    DCS_HIP(hipMemsetAsync(d_ticket, 0, 16, st));
-    EdgeArrays ed{d_epose, d_epoint, d_ecam, d_obs, d_w, d_active};
-    const double delta = pb->huber_delta;
-    std::vector<uint8_t> active(E, 1), level1(E, 0);
-    int trace = 0;
-    const auto t_opt0 = std::chrono::steady_clock::now();
+    // A problem whose stop flag is already set is not optimised at all (Optimizer.cc:582-585: the reference returns before
+    // it touches anything): estimates pass through, no outlier is reported. The others form the device batch.
+    std::vector<int> live;
+    for (int b = 0; b < B; ++b) {
+        dcs_ba_result* res = results[b];
+        res->n_iters[0] = res->n_iters[1] = 0; res->n_trials[0] = res->n_trials[1] = 0; res->lambda[0] = res->lambda[1] = 0; res->gpu_ms = 0;
+        for (int i = 0; i < 32; ++i) res->chi2_trace[i] = 0;
+        if (stop_requested(b)) {
+            const dcs_ba_problem* pb = problems[b];
+            memcpy(res->poses, pb->poses, sizeof(double) * 7 * pb->n_poses);
+            memcpy(res->points, pb->points, sizeof(double) * 3 * pb->n_points);
+            memset(res->edge_outlier, 0, pb->n_edges);
+            if (res->edge_level1) memset(res->edge_level1, 0, pb->n_edges);
+            if (res->edge_chi2) memset(res->edge_chi2, 0, sizeof(double) * pb->n_edges);
+        } else live.push_back(b);
+    }
+    const int NB = (int)live.size();
+    if (NB == 0) return DCS_OK;
 
-    auto eval_error = [&](int robust, double* chi_out, int n_scale = 0) -> int {     // computeActiveErrors + activeRobustChi2 (+ computeScale)
-        hipLaunchKernelGGL(k_error, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2, d_partial,
-                           d_ticket, chi_out, (const double*)d_scale_part, n_scale, d_scal + 1);
+    // ---- structure of every problem (index mapping, CSR lists, pose-pair lists): built ONCE from all edges. The second
+    // round only changes the per-edge active mask; inactive edges contribute exact zeros, landmarks without an active
+    // edge are skipped (pt_active) and poses without one see a decoupled lambda*I block (zero update), which is
+    // what g2o's re-indexing of the active subgraph amounts to.
+    std::vector<Round> rounds(NB);
+    std::vector<int> dup(NB, -1);
+    {
+        auto work = [&](int i) { dup[i] = build_round(problems[live[i]], rounds[i]); };
+        if (NB == 1) work(0);
+        else {
+            const int nt = std::min(NB, 8);
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (int i = t; i < NB; i += nt) work(i); });
+            for (auto& t : th) t.join();
+        }
+        for (int i = 0; i < NB; ++i)
+            if (dup[i] >= 0) { set_error("problem %d: more than one edge between pose and point of edge %d", live[i], dup[i]); return DCS_ERR_INVALID; }
+    }
+    const double t_build = ms_since(t_call0);
+    const bool force_blocked = getenv("DCS_BA_FORCE_BLOCKED_LDLT") != nullptr;   // test hook: the n > 256 path at small n
+    const bool ldlt_valu = getenv("DCS_BA_LDLT_VALU") != nullptr;                // column-by-column VALU predecessor of k_ldlt_mfma
+
+    // ---- arena layout: [upload | zeroed | scratch | download]
+    struct Regions { size_t upload_end, zero_begin, zero_end, dl_begin, dl_end; };
+    std::vector<BaProb> hp(NB);
+    BaProb* d_probs = nullptr; BaCtl* d_ctls = nullptr;
+    auto layout = [&](Carver& c, Regions& rg) {
+        for (int i = 0; i < NB; ++i) {
+            const dcs_ba_problem* pb = problems[live[i]];
+            const Round& r = rounds[i];
+            BaProb& q = hp[i];
+            const size_t P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+            q.P = (int)P; q.L = (int)L; q.E = (int)E; q.np = r.np; q.n = r.n; q.n_pad = r.n_pad; q.ld = std::max(r.n_pad, kNB); q.n_pairs = r.n_pairs;
+            q.nblk = (int)((E + 255) / 256); q.nb_pts = (int)((L + 63) / 64); q.nb_pose = (int)((P + 63) / 64);
+            q.use_reg = (r.n <= 256 && !force_blocked) ? (ldlt_valu ? 2 : 1) : 0;
+            q.iters[0] = pb->iters1; q.iters[1] = pb->iters2; q.robust0 = pb->huber_delta > 0.0 ? 1 : 0; q.pad = 0;   // BundleAdjustment(bRobust = false): no kernel
+            q.delta = pb->huber_delta; q.chi2_th = pb->chi2_th;
+            q.poses[0] = c.get<double>(7 * P); q.points[0] = c.get<double>(3 * L);
+            q.epose = c.get<int32_t>(E); q.epoint = c.get<int32_t>(E); q.ecam = c.get<int32_t>(E);
+            q.obs = c.get<double>(2 * E); q.w = c.get<double>(E); q.active = c.get<uint8_t>(E);
+            q.pose_idx = c.get<int32_t>(P); q.pt_off = c.get<int32_t>(L + 1); q.pt_edges = c.get<int32_t>(r.pt_edges.size());
+            q.ps_off = c.get<int32_t>(r.ps_off.size()); q.ps_edges = c.get<int32_t>(r.ps_edges.size());
+            q.pair_ij = c.get<int32_t>(r.pair_ij.size()); q.pair_off = c.get<int32_t>(r.pair_off.size());
+            q.pair_e1 = c.get<int32_t>(r.pair_e1.size()); q.pair_e2 = c.get<int32_t>(r.pair_e2.size());
+            q.cams = c.get<DCams>(1);
+        }
+        d_probs = c.get<BaProb>(NB);
+        rg.upload_end = c.off;
+        c.off = (c.off + 255) & ~(size_t)255;
+        rg.zero_begin = c.off;
+        for (int i = 0; i < NB; ++i) {
+            BaProb& q = hp[i];
+            q.ticket = c.get<unsigned>(4);
+            q.S = q.use_reg ? c.get<double>((size_t)q.ld * q.ld) : nullptr;       // pairs without shared points stay 0
+        }
+        rg.zero_end = c.off;
+        for (int i = 0; i < NB; ++i) {
+            BaProb& q = hp[i];
+            const size_t P = q.P, L = q.L, E = q.E;
+            if (!q.use_reg) q.S = c.get<double>((size_t)q.ld * q.ld);
+            q.W = c.get<double>(q.use_reg ? 1 : (size_t)q.ld * kNB);
+            q.poses[1] = c.get<double>(7 * P); q.points[1] = c.get<double>(3 * L);
+            q.err = c.get<double>(2 * E);
+            q.Hpl = c.get<double>(18 * E); q.BD = c.get<double>(18 * E); q.cpose = c.get<double>(27 * E); q.cpoint = c.get<double>(9 * E);
+            q.Hll = c.get<double>(9 * L); q.bl = c.get<double>(3 * L); q.Dinv = c.get<double>(9 * L); q.db = c.get<double>(3 * L); q.xl = c.get<double>(3 * L);
+            q.Hpp = c.get<double>(36 * P); q.bp = c.get<double>(6 * P); q.bsch = c.get<double>(6 * P); q.xp = c.get<double>(6 * P);
+            q.partial = c.get<double>(q.nblk); q.scale_part = c.get<double>(q.nb_pts + q.nb_pose);
+            q.pt_active = c.get<uint8_t>(L);
+        }
+        c.off = (c.off + 255) & ~(size_t)255;
+        rg.dl_begin = c.off;
+        d_ctls = c.get<BaCtl>(NB);
+        for (int i = 0; i < NB; ++i) {
+            BaProb& q = hp[i];
+            const size_t P = q.P, L = q.L, E = q.E;
+            q.out_poses = c.get<double>(7 * P); q.out_points = c.get<double>(3 * L);
+            q.chi2 = c.get<double>(E); q.flag = c.get<uint8_t>(E); q.level1 = c.get<uint8_t>(E);
+        }
+        rg.dl_end = c.off;
+    };
+    Regions rg{};
+    { Carver dry; layout(dry, rg); }
+    const size_t arena_bytes = rg.dl_end + 256, dl_bytes = rg.dl_end - rg.dl_begin;
+    BaContext& ctx = ba_context();
+    if ((rc = ctx.prepare(arena_bytes, rg.upload_end + dl_bytes, 16 + (size_t)NB))) return rc;
+    Carver real; real.base = ctx.base;
+    layout(real, rg);
+    hipStream_t st = ctx.stream;
+    char* const hs = ctx.h_stage;
+    char* const h_dl = ctx.h_stage + rg.upload_end;
+    auto stage = [&](const void* dptr) { return hs + (reinterpret_cast<const char*>(dptr) - ctx.base); };
+    auto landed = [&](const void* dptr) { return h_dl + (reinterpret_cast<const char*>(dptr) - (ctx.base + rg.dl_begin)); };
+
+    // ---- one staging image, one copy
+    for (int i = 0; i < NB; ++i) {
+        const dcs_ba_problem* pb = problems[live[i]];
+        const Round& r = rounds[i];
+        const BaProb& q = hp[i];
+        const size_t P = q.P, L = q.L, E = q.E;
+        memcpy(stage(q.poses[0]), pb->poses, sizeof(double) * 7 * P);
+        memcpy(stage(q.points[0]), pb->points, sizeof(double) * 3 * L);
+        memcpy(stage(q.epose), pb->edge_pose, sizeof(int32_t) * E);
+        memcpy(stage(q.epoint), pb->edge_point, sizeof(int32_t) * E);
+        memcpy(stage(q.ecam), pb->edge_cam, sizeof(int32_t) * E);
+        memcpy(stage(q.obs), pb->obs, sizeof(double) * 2 * E);
+        memcpy(stage(q.w), pb->inv_sigma2, sizeof(double) * E);
+        memset(stage(q.active), 1, E);
+        auto put = [&](const int32_t* d, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage(d), v.data(), sizeof(int32_t) * v.size()); };
+        put(q.pose_idx, r.pose_idx); put(q.pt_off, r.pt_off); put(q.pt_edges, r.pt_edges); put(q.ps_off, r.ps_off); put(q.ps_edges, r.ps_edges);
+        put(q.pair_ij, r.pair_ij); put(q.pair_off, r.pair_off); put(q.pair_e1, r.pair_e1); put(q.pair_e2, r.pair_e2);
+        DCams* cams = reinterpret_cast<DCams*>(stage(q.cams));
+        memset(cams, 0, sizeof(DCams));
+        for (int c = 0; c < pb->n_cams; ++c) {
+            DCam& d = cams->c[c];
+            const dcs_ba_camera& sc = pb->cams[c];
+            d.fx = sc.fx; d.fy = sc.fy; d.cx = sc.cx; d.cy = sc.cy;
+            d.t[0] = sc.ext[0]; d.t[1] = sc.ext[1]; d.t[2] = sc.ext[2];
+            d.q[0] = sc.ext[3]; d.q[1] = sc.ext[4]; d.q[2] = sc.ext[5]; d.q[3] = sc.ext[6];
+            memcpy(d.adj, sc.adj, sizeof(d.adj));
+        }
+    }
+    memcpy(stage(d_probs), hp.data(), sizeof(BaProb) * NB);
+    int* const h_words = ctx.h_words;
+    h_words[0] = 0; h_words[1] = 0;
+    for (int i = 0; i < NB; ++i) h_words[16 + i] = 0;
+    const auto t_opt0 = now();
+    DCS_HIP(hipMemcpyAsync(ctx.base, hs, rg.upload_end, hipMemcpyHostToDevice, st));
+    DCS_HIP(hipMemsetAsync(ctx.base + rg.zero_begin, 0, rg.zero_end - rg.zero_begin, st));
+    for (int i = 0; i < NB; ++i)
+        if (hp[i].iters[0] <= 0) DCS_HIP(hipMemsetAsync(hp[i].chi2, 0, sizeof(double) * hp[i].E, st));    // no error evaluation will ever write it
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1024), 0, st, (const BaProb*)d_probs, d_ctls, NB);
+    DCS_CHECK_LAUNCH();
+
+    // ---- launch geometry of one step (largest problem decides; smaller ones exit early)
+    int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, max_steps = 0, max_npad_blocked = 0;
+    bool any_mfma = false, any_valu = false, any_blocked = false;
+    for (int i = 0; i < NB; ++i) {
+        const BaProb& q = hp[i];
+        g_edges = std::max(g_edges, q.nblk);
+        g_reduce = std::max(g_reduce, q.np + q.nb_pts);
+        g_prep = std::max(g_prep, (q.np ? q.nblk : 0) + (q.L + 255) / 256);
+        if (q.np) g_schur = std::max(g_schur, q.n_pairs + q.np);
+        g_update = std::max(g_update, q.nb_pts + q.nb_pose);
+        max_steps = std::max(max_steps, (std::max(q.iters[0], 0) + std::max(q.iters[1], 0)) * 10 + 2);
+        if (q.np) {
+            any_mfma |= q.use_reg == 1; any_valu |= q.use_reg == 2; any_blocked |= q.use_reg == 0;
+            if (q.use_reg == 0) max_npad_blocked = std::max(max_npad_blocked, q.n_pad);
+        }
+    }
+    const BaProb* dp = d_probs;
+    const volatile int* d_stop = h_words + 16;
+    auto enqueue_step = [&](int step) -> int {
+        hipLaunchKernelGGL(k_error<0>, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, (const volatile int*)nullptr);      // computeActiveErrors (stale errors only)
+        hipLaunchKernelGGL(k_linearize, dim3(g_edges, NB), dim3(256), 0, st, dp, (const BaCtl*)d_ctls);                    // buildSystem
+        hipLaunchKernelGGL(k_reduce_pose, dim3(g_reduce, NB), dim3(1024), 0, st, dp, (const BaCtl*)d_ctls);
+        hipLaunchKernelGGL(k_max_diag, dim3(1, NB), dim3(256), 0, st, dp, d_ctls);                                        // computeLambdaInit (first iteration)
+        hipLaunchKernelGGL(k_prep, dim3(g_prep, NB), dim3(256), 0, st, dp, d_ctls);                                       // setLambda + solve (Schur)
+        DCS_CHECK_LAUNCH();
+        if (any_blocked) {                                // the blocked fallback factors S in place: rebuild it every trial
+            for (int i = 0; i < NB; ++i)
+                if (hp[i].np && hp[i].use_reg == 0) DCS_HIP(hipMemsetAsync(hp[i].S, 0, sizeof(double) * (size_t)hp[i].ld * hp[i].ld, st));
+            hipLaunchKernelGGL(k_pad_identity, dim3(1, NB), dim3(64), 0, st, dp, (const BaCtl*)d_ctls);
+        }
+        if (g_schur) hipLaunchKernelGGL(k_schur, dim3(g_schur, NB), dim3(1024), 0, st, dp, (const BaCtl*)d_ctls);
+        if (any_mfma) hipLaunchKernelGGL(k_ldlt_mfma, dim3(NB), dim3(256), 0, st, dp, d_ctls);
+        if (any_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(NB), dim3(1024), 0, st, dp, d_ctls);
+        if (any_blocked) {
+            for (int k0 = 0; k0 < max_npad_blocked; k0 += kNB) {
+                hipLaunchKernelGGL(k_ldlt_panel, dim3(NB), dim3(256), 0, st, dp, d_ctls, k0);
+                const int m = (max_npad_blocked - k0) / kNB - 1;
+                if (m > 0) hipLaunchKernelGGL(k_ldlt_update, dim3(m, m, NB), dim3(64), 0, st, dp, (const BaCtl*)d_ctls, k0);
+            }
+            hipLaunchKernelGGL(k_ldlt_solve, dim3(NB), dim3(256), sizeof(double) * max_npad_blocked, st, dp, (const BaCtl*)d_ctls);
+        }
+        DCS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_solve_update, dim3(g_update, NB), dim3(64), 0, st, dp, (const BaCtl*)d_ctls);
+        hipLaunchKernelGGL(k_error<1>, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, d_stop);        // chi2 of the trial + computeScale + accept / reject
+        hipLaunchKernelGGL(k_round_flags, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls);
+        hipLaunchKernelGGL(k_round_ctl, dim3(1), dim3(1024), 0, st, dp, d_ctls, NB, step, h_words);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     };
 
-    // structure of the problem (index mapping, CSR lists, pose-pair lists): built ONCE from all edges. The second
-    // round only changes the per-edge active mask; inactive edges contribute exact zeros, landmarks without an active
-    // edge are skipped (pt_active) and poses without one see a decoupled lambda*I block (zero update), which is
-    // what g2o's re-indexing of the active subgraph amounts to.
-    Round r;
-    {
-        const auto tb0 = now();
-        build_round(pb, active, r);
-        t_build += ms_since(tb0);
-        DCS_HIP(hipMemcpyAsync(d_pose_idx, r.pose_idx.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
-        DCS_HIP(hipMemcpyAsync(d_pt_off, r.pt_off.data(), sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice, st));
-        DCS_HIP(hipMemcpyAsync(d_pt_edges, r.pt_edges.data(), sizeof(int32_t) * r.pt_edges.size(), hipMemcpyHostToDevice, st));
-        DCS_HIP(hipMemcpyAsync(d_ps_off, r.ps_off.data(), sizeof(int32_t) * (r.np + 1), hipMemcpyHostToDevice, st));
-        if (!r.ps_edges.empty()) DCS_HIP(hipMemcpyAsync(d_ps_edges, r.ps_edges.data(), sizeof(int32_t) * r.ps_edges.size(), hipMemcpyHostToDevice, st));
-        if (r.n_pairs) {
-            DCS_HIP(hipMemcpyAsync(d_pair_ij, r.pair_ij.data(), sizeof(int32_t) * r.pair_ij.size(), hipMemcpyHostToDevice, st));
-            DCS_HIP(hipMemcpyAsync(d_pair_off, r.pair_off.data(), sizeof(int32_t) * r.pair_off.size(), hipMemcpyHostToDevice, st));
-            if (!r.pair_e1.empty()) {
-                DCS_HIP(hipMemcpyAsync(d_pair_e1, r.pair_e1.data(), sizeof(int32_t) * r.pair_e1.size(), hipMemcpyHostToDevice, st));
-                DCS_HIP(hipMemcpyAsync(d_pair_e2, r.pair_e2.data(), sizeof(int32_t) * r.pair_e2.size(), hipMemcpyHostToDevice, st));
-            }
-        }
-    }
-    const int n = r.n, n_pad = r.n_pad, ld = std::max(n_pad, kNB);
-    const bool use_reg = n <= 256 && !force_blocked;      // reduced camera system fits one workgroup's registers
-    if (r.np && use_reg) DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));   // pairs without shared points stay 0
-    const double* d_maxdiag = d_scal + 2;
-
-    auto run_round = [&](int round, int iters, int robust) -> int {
-        int n_act = 0;
-        for (int e = 0; e < E; ++e) n_act += active[e];
-        if (n_act == 0) return DCS_OK;
-        DCS_HIP(hipMemcpyAsync(d_active, active.data(), E, hipMemcpyHostToDevice, st));
-        double mult = 1.0, ni = 2, currentChi = 0;        // lambda = 1e-5 * maxdiag (device) * mult (host)
-        int nBad = 0;
-        bool errors_current = false;
-        for (int it = 0; it < iters && !stopped(); ++it) {
-            int rc2;
-            const bool need_chi = !errors_current;
-            if (need_chi && (rc2 = eval_error(robust, d_scal + 4))) return rc2;    // read back with the first trial
-            double iniChi = currentChi;
-            // buildSystem
-            hipLaunchKernelGGL(k_linearize, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, robust, delta, d_err, d_chi2,
-                               d_pose_idx, d_cpoint, d_cpose, d_Hpl);
-            DCS_CHECK_LAUNCH();
-            {
-                const ReducePointArgs rp{L, d_pt_off, d_pt_edges, d_active, d_cpoint, d_Hll, d_bl, d_pt_active};
-                hipLaunchKernelGGL(k_reduce_pose, dim3(r.np + nb_pts), dim3(1024), 0, st, d_ps_off, d_ps_edges, d_cpose, d_Hpp, d_bp, r.np, rp);
-                DCS_CHECK_LAUNCH();
-            }
-            if (it == 0) {
-                hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, r.np, d_Hpp, L, d_pt_active, d_Hll, d_scal + 2);
-                DCS_CHECK_LAUNCH();
-                mult = 1.0; ni = 2; nBad = 0;             // computeLambdaInit: lambda = tau * max diagonal, tau = 1e-5
-            }
-            double rho = 0;
-            int qmax = 0;
-            do {
-                // setLambda + solve (Schur)
-                hipLaunchKernelGGL(k_prep, dim3((r.np ? nblk : 0) + (L + 255) / 256), dim3(256), 0, st, E, r.np ? nblk : 0, d_active, d_epose, d_epoint,
-                                   d_pose_idx, d_Hpl, d_BD, L, d_Hll, d_bl, d_maxdiag, mult, d_pt_active, d_Dinv, d_db, d_scal + 3);
-                DCS_CHECK_LAUNCH();
-                if (r.np) {
-                    if (!use_reg) {                       // the blocked fallback factors S in place: rebuild it every trial
-                        DCS_HIP(hipMemsetAsync(d_S, 0, sizeof(double) * (size_t)ld * ld, st));
-                        if (n_pad > n) { hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(64), 0, st, d_S, ld, n, n_pad); DCS_CHECK_LAUNCH(); }
-                    }
-                    const BschurArgs bs{d_ps_off, d_ps_edges, d_epoint, d_db, d_bp, d_bsch};
-                    hipLaunchKernelGGL(k_schur, dim3(r.n_pairs + r.np), dim3(1024), 0, st, d_pair_ij, d_pair_off, d_pair_e1, d_pair_e2, d_Hpp,
-                                       d_maxdiag, mult, d_BD, d_Hpl, d_S, ld, r.n_pairs, bs);
-                    DCS_CHECK_LAUNCH();
-                    if (use_reg) {
-                        if (ldlt_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(1), dim3(1024), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3);
-                        else hipLaunchKernelGGL(k_ldlt_mfma, dim3(1), dim3(512), 0, st, d_S, ld, n, d_bsch, d_xp, d_scal + 3);
-                        DCS_CHECK_LAUNCH();
-                    } else {
-                        for (int k0 = 0; k0 < n_pad; k0 += kNB) {
-                            hipLaunchKernelGGL(k_ldlt_panel, dim3(1), dim3(256), 0, st, d_S, ld, n_pad, k0, d_W, d_scal + 3);
-                            DCS_CHECK_LAUNCH();
-                            const int m = (n_pad - k0) / kNB - 1;
-                            if (m > 0) { hipLaunchKernelGGL(k_ldlt_update, dim3(m, m), dim3(64), 0, st, d_S, ld, k0, d_W); DCS_CHECK_LAUNCH(); }
-                        }
-                        hipLaunchKernelGGL(k_ldlt_solve, dim3(1), dim3(256), sizeof(double) * n_pad, st, d_S, ld, n_pad, d_bsch, n, d_xp);
-                        DCS_CHECK_LAUNCH();
-                    }
-                }
-                hipLaunchKernelGGL(k_solve_update, dim3(nb_pts + nb_pose), dim3(64), 0, st, L, nb_pts, d_pt_off, d_pt_edges, d_epose, d_pose_idx,
-                                   d_pt_active, d_Hpl, d_xp, d_bl, d_Dinv, d_xl, P, d_bp, d_poses, d_points, d_poses_bk, d_points_bk, d_maxdiag, mult,
-                                   d_scale_part);
-                DCS_CHECK_LAUNCH();
-                if ((rc2 = eval_error(robust, d_scal, nb_pts + nb_pose))) return rc2;      // chi2 of the trial + computeScale
-                DCS_HIP(hipMemcpyAsync(h_scal, d_scal, 40, hipMemcpyDeviceToHost, st));     // chi, scale, maxdiag, ok, initial chi
-                const auto ts0 = now();
-                DCS_HIP(hipStreamSynchronize(st));
-                t_sync += ms_since(ts0);
-                ++res->n_trials[round];
-                if (need_chi && qmax == 0) { currentChi = h_scal[4]; iniChi = currentChi; }
-                double tempChi = h_scal[0];
-                if (h_scal[3] == 0.0) tempChi = std::numeric_limits<double>::max();
-                rho = currentChi - tempChi;
-                const double scale = h_scal[1] + 1e-3;
-                rho /= scale;
-                if (rho > 0 && std::isfinite(tempChi)) {
-                    double alpha = 1. - std::pow((2 * rho - 1), 3);
-                    alpha = std::min(alpha, 2. / 3.);
-                    mult *= std::max(1. / 3., alpha);
-                    ni = 2; currentChi = tempChi; errors_current = true;
-                } else {
-                    mult *= ni; ni *= 2;
-                    DCS_HIP(hipMemcpyAsync(d_poses, d_poses_bk, sizeof(double) * 7 * P, hipMemcpyDeviceToDevice, st));   // pop
-                    DCS_HIP(hipMemcpyAsync(d_points, d_points_bk, sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, st));
-                    errors_current = false;
-                }
-                ++qmax;
-            } while (rho < 0 && qmax < 10 && !stopped());
-            ++res->n_iters[round];
-            if (trace < 32) res->chi2_trace[trace++] = currentChi;
-            res->lambda[round] = 1e-5 * h_scal[2] * mult;
-            if (qmax == 10 || rho == 0) break;                         // Terminate
-            if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
-            if (nBad >= 3) break;
-        }
-        return DCS_OK;
+    // ---- the host only feeds the queue: kLookahead steps ahead of what the device has reported finished
+    constexpr int kLookahead = 3;
+    auto load_words = [&](int& step_done, int& n_done) {
+        step_done = __atomic_load_n(h_words, __ATOMIC_ACQUIRE);
+        n_done = __atomic_load_n(h_words + 1, __ATOMIC_RELAXED);
     };
-
-    if (!stopped()) {
-        if ((rc = run_round(0, pb->iters1, pb->huber_delta > 0.0 ? 1 : 0))) return rc;   // BundleAdjustment(bRobust = false): no kernel
-        if (!stopped()) {
-            hipLaunchKernelGGL(k_flags, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, d_chi2, pb->chi2_th, d_flag);
-            DCS_CHECK_LAUNCH();
-            DCS_HIP(hipMemcpyAsync(level1.data(), d_flag, E, hipMemcpyDeviceToHost, st));
-            DCS_HIP(hipStreamSynchronize(st));
-            for (int e = 0; e < E; ++e) active[e] = !level1[e];
-            if ((rc = run_round(1, pb->iters2, 0))) return rc;
+    auto refresh_stop = [&] { for (int i = 0; i < NB; ++i) if (stop_requested(live[i])) __atomic_store_n(h_words + 16 + i, 1, __ATOMIC_RELAXED); };
+    int steps = 0;
+    bool finished = false;
+    double t_wait = 0;
+    while (!finished && steps < max_steps) {
+        refresh_stop();
+        ++steps;
+        if ((rc = enqueue_step(steps))) return rc;
+        const auto tw0 = now();
+        for (;;) {
+            int sd, nd;
+            load_words(sd, nd);
+            if (nd == NB) { finished = true; break; }
+            if (sd >= steps - kLookahead) break;
+            refresh_stop();
+            const hipError_t qe = hipStreamQuery(st);
+            if (qe == hipSuccess) {                       // queue drained: the words are final
+                load_words(sd, nd);
+                if (nd == NB) finished = true;
+                else if (sd < steps) { set_error("BA device loop lost step %d (reported %d)", steps, sd); return DCS_ERR_HIP; }
+                break;
+            }
+            if (qe != hipErrorNotReady) { set_error("BA stream: %s", hipGetErrorString(qe)); return DCS_ERR_HIP; }
         }
+        t_wait += ms_since(tw0);
     }
-    hipLaunchKernelGGL(k_flags, dim3(nblk), dim3(256), 0, st, ed, E, d_poses, d_points, cams, d_chi2, pb->chi2_th, d_flag);
-    DCS_CHECK_LAUNCH();
-    DCS_HIP(hipMemcpyAsync(res->edge_outlier, d_flag, E, hipMemcpyDeviceToHost, st));
-    DCS_HIP(hipMemcpyAsync(res->poses, d_poses, sizeof(double) * 7 * P, hipMemcpyDeviceToHost, st));
-    DCS_HIP(hipMemcpyAsync(res->points, d_points, sizeof(double) * 3 * L, hipMemcpyDeviceToHost, st));
-    if (res->edge_chi2) DCS_HIP(hipMemcpyAsync(res->edge_chi2, d_chi2, sizeof(double) * E, hipMemcpyDeviceToHost, st));
+    DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, st));
     DCS_HIP(hipStreamSynchronize(st));
-    if (res->edge_level1) memcpy(res->edge_level1, level1.data(), E);
-    res->gpu_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_opt0).count();
+    const float opt_ms = (float)ms_since(t_opt0);
+    const BaCtl* h_ctls = reinterpret_cast<const BaCtl*>(landed(d_ctls));
+    for (int i = 0; i < NB; ++i) {
+        const BaProb& q = hp[i];
+        dcs_ba_result* res = results[live[i]];
+        const BaCtl& c = h_ctls[i];
+        if (c.state != ST_DONE) { set_error("BA problem %d did not finish within %d steps", live[i], max_steps); return DCS_ERR_HIP; }
+        memcpy(res->poses, landed(q.out_poses), sizeof(double) * 7 * q.P);
+        memcpy(res->points, landed(q.out_points), sizeof(double) * 3 * q.L);
+        memcpy(res->edge_outlier, landed(q.flag), q.E);
+        if (res->edge_level1) memcpy(res->edge_level1, landed(q.level1), q.E);
+        if (res->edge_chi2) memcpy(res->edge_chi2, landed(q.chi2), sizeof(double) * q.E);
+        for (int k = 0; k < 2; ++k) { res->n_iters[k] = c.n_iters[k]; res->n_trials[k] = c.n_trials[k]; res->lambda[k] = c.lambda[k]; }
+        for (int k = 0; k < 32; ++k) res->chi2_trace[k] = c.chi2_trace[k];
+        res->gpu_ms = opt_ms;
+    }
     if (trace_t)
-        fprintf(stderr, "[dcs_ba] total %.3f ms: setup %.3f, optimise %.3f (build_round %.3f, waiting on GPU in trial syncs %.3f)\n", ms_since(t_call0),
-                ms_since(t_call0) - res->gpu_ms, (double)res->gpu_ms, t_build, t_sync);
+        fprintf(stderr, "[dcs_ba] %d problems, total %.3f ms: build_round %.3f, layout + staging %.3f, optimise %.3f (%d steps enqueued, host waited %.3f)\n",
+                NB, ms_since(t_call0), t_build, ms_since(t_call0) - t_build - opt_ms, (double)opt_ms, steps, t_wait);
     return DCS_OK;
+}
+
+int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dcs_ba_result* res)
+{
+    return dcs_ba_local_batch(1, &pb, &stop_flag, &res);
 }
 
 int dcs_pose_optimization(const dcs_pose_problem* pb, dcs_pose_result* res)
@@ -1575,16 +1947,25 @@ int dcs_pose_optimization(const dcs_pose_problem* pb, dcs_pose_result* res)
         d.q[0] = s.ext[3]; d.q[1] = s.ext[4]; d.q[2] = s.ext[5]; d.q[3] = s.ext[6];
         memcpy(d.adj, s.adj, sizeof(d.adj));
     }
-    Arena ar;
     const size_t Ee = std::max(E, 1);
-    if ((rc = ar.init((size_t)F * (7 * 8 * 2 + 4 + 4 + 16) + Ee * (8 * (3 + 2 + 1 + 2 + 1) + 4 + 2) + (1 << 14)))) return rc;
-    hipStream_t st = ba_context().stream;
-    double* d_poses = ar.get<double>(7 * (size_t)F); double* d_out = ar.get<double>(7 * (size_t)F);
-    int32_t* d_off = ar.get<int32_t>(F + 1); int32_t* d_ninl = ar.get<int32_t>(F); int32_t* d_nit = ar.get<int32_t>(4 * (size_t)F);
-    double* d_xw = ar.get<double>(3 * Ee); double* d_obs = ar.get<double>(2 * Ee); double* d_w = ar.get<double>(Ee);
-    double* d_err = ar.get<double>(2 * Ee); double* d_chi = ar.get<double>(Ee);
-    int32_t* d_cam = ar.get<int32_t>(Ee); uint8_t* d_level = ar.get<uint8_t>(Ee); uint8_t* d_outl = ar.get<uint8_t>(Ee);
-    if (!d_outl) { set_error("pose arena too small"); return DCS_ERR_HIP; }
+    auto carve = [&](Carver& ar, double*& d_poses, double*& d_out, int32_t*& d_off, int32_t*& d_ninl, int32_t*& d_nit, double*& d_xw, double*& d_obs,
+                     double*& d_w, double*& d_err, double*& d_chi, int32_t*& d_cam, uint8_t*& d_level, uint8_t*& d_outl) {
+        d_poses = ar.get<double>(7 * (size_t)F); d_out = ar.get<double>(7 * (size_t)F);
+        d_off = ar.get<int32_t>(F + 1); d_ninl = ar.get<int32_t>(F); d_nit = ar.get<int32_t>(4 * (size_t)F);
+        d_xw = ar.get<double>(3 * Ee); d_obs = ar.get<double>(2 * Ee); d_w = ar.get<double>(Ee);
+        d_err = ar.get<double>(2 * Ee); d_chi = ar.get<double>(Ee);
+        d_cam = ar.get<int32_t>(Ee); d_level = ar.get<uint8_t>(Ee); d_outl = ar.get<uint8_t>(Ee);
+    };
+    double *d_poses, *d_out, *d_xw, *d_obs, *d_w, *d_err, *d_chi;
+    int32_t *d_off, *d_ninl, *d_nit, *d_cam;
+    uint8_t *d_level, *d_outl;
+    Carver dry;
+    carve(dry, d_poses, d_out, d_off, d_ninl, d_nit, d_xw, d_obs, d_w, d_err, d_chi, d_cam, d_level, d_outl);
+    BaContext& ctx = ba_context();
+    if ((rc = ctx.prepare(dry.off + 256, 0, 16))) return rc;
+    Carver ar; ar.base = ctx.base;
+    carve(ar, d_poses, d_out, d_off, d_ninl, d_nit, d_xw, d_obs, d_w, d_err, d_chi, d_cam, d_level, d_outl);
+    hipStream_t st = ctx.stream;
     DCS_HIP(hipMemcpyAsync(d_poses, pb->poses, sizeof(double) * 7 * F, hipMemcpyHostToDevice, st));
     DCS_HIP(hipMemcpyAsync(d_off, pb->edge_off, sizeof(int32_t) * (F + 1), hipMemcpyHostToDevice, st));
     if (E) {

@@ -51,6 +51,47 @@ def test_ba_c4_vs_oracle_and_golden(pkg, oracle, synth):
     assert np.abs(got["poses"][free, :3] - pb["gt_poses"][free, :3]).max() < 0.02   # recovers from 5 cm / 0.02 rad noise
 
 
+def test_ba_batch_c5_eight_streams(pkg, oracle, synth):
+    """BASELINE config C5: 8 dual-camera streams, one LocalBundleAdjustment each (src/LocalMapping.cc:97-104), solved by ONE
+    dcs_ba_local_batch call with the LM control flow on the device. Every problem must equal its own dcs_ba_local solve
+    bit for bit (same kernels, same order of operations) and the oracle within the north star's 1e-4."""
+    pbs = [synth.ba_problem(seed=42 + s) for s in range(8)]             # 8 x (50 KF / 2000 MP / 20000 edges), different maps
+    got = pkg.Optimizer.LocalBundleAdjustmentBatch(pbs)
+    assert len(got) == 8
+    for s, pb in enumerate(pbs):
+        one = pkg.Optimizer.LocalBundleAdjustment(pb)
+        for k in ("poses", "points", "edge_chi2", "edge_outlier", "edge_level1", "chi2_trace"):
+            assert np.array_equal(got[s][k], one[k]), (s, k)
+        assert got[s]["n_iters"] == one["n_iters"] and got[s]["n_trials"] == one["n_trials"] and got[s]["lambda_"] == one["lambda_"]
+        if s < 3:                                                       # the oracle needs ~2 s per C4 problem
+            _compare(got[s], _oracle_run(oracle, pb), pb)
+
+
+def test_ba_batch_ragged_and_stop_flags(pkg, oracle, synth):
+    """Problems of different sizes and LDL^T paths in one batch (n <= 256 on one workgroup, n > 256 blocked), a problem
+    stopped at entry (Optimizer.cc:582-585: untouched) and an empty batch."""
+    kws = [dict(n_poses=12, n_fixed=3, n_points=150, obs_per_point=6, seed=7),
+           dict(n_poses=60, n_fixed=4, n_points=800, obs_per_point=8, seed=13),      # n = 330: blocked fallback
+           dict(n_poses=7, n_fixed=2, n_points=60, obs_per_point=4, seed=2),
+           dict(n_poses=20, n_fixed=4, n_points=500, obs_per_point=8, seed=9, exact_adjoint=True),
+           dict(n_poses=8, n_fixed=2, n_points=60, obs_per_point=4, seed=5)]
+    pbs = [synth.ba_problem(**kw) for kw in kws]
+    pbs[4] = dict(pbs[4]); pbs[4]["pose_fixed"] = np.ones(8, np.uint8)              # every pose fixed: structure-only
+    stop = [None, None, np.ones(1, np.uint8), np.zeros(1, np.uint8), None]
+    got = pkg.Optimizer.LocalBundleAdjustmentBatch(pbs, stop)
+    for i, pb in enumerate(pbs):
+        if i == 2:
+            assert got[i]["n_iters"] == [0, 0] and np.array_equal(got[i]["poses"], pb["poses"]) and np.array_equal(got[i]["points"], pb["points"])
+            assert not got[i]["edge_outlier"].any()
+            continue
+        _compare(got[i], _oracle_run(oracle, pb), pb)
+    assert pkg.Optimizer.LocalBundleAdjustmentBatch([]) == []
+    dup = dict(pbs[0]); dup["edge_pose"] = pbs[0]["edge_pose"].copy(); dup["edge_point"] = pbs[0]["edge_point"].copy()
+    dup["edge_pose"][1], dup["edge_point"][1] = dup["edge_pose"][0], dup["edge_point"][0]
+    with pytest.raises(pkg.DcsError):
+        pkg.Optimizer.LocalBundleAdjustment(dup)
+
+
 def test_ba_noise_free_ground_truth(pkg, synth):
     pb = synth.ba_problem(n_poses=10, n_fixed=3, n_points=120, obs_per_point=5, seed=3, noise=False)
     rng = np.random.default_rng(1)
