@@ -26,7 +26,7 @@ SYMBOLS = [
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
-    "dcs_ba_local", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
+    "dcs_ba_local", "dcs_ba_local_batch", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
 ]
 
