@@ -10,11 +10,23 @@ N > 1: one process per GPU (torch.distributed, RCCL), each rank owns its own str
 (weak scaling, no data-path collective inside extraction/matching); once per step the ranks all-gather
 the newest dual frame's features (the cross-camera relocalisation exchange of the north star) and
 match their cam0 against every other rank's cam1.
+
+`python bench.py --gpus N` launches its own N ranks (re-exec under torch.distributed.run) when it is not
+already running as a rank (RANK / WORLD_SIZE unset); under an external torchrun it just joins.
+
+Extra legs on rank 0 at N = 1 (each one can be switched off): cpu_baseline (oracle, 1 thread) and
+cpu_all_cores, latency (one dual frame through the host-buffer API, PCIe included), with_transfers
+(the default batch through the host-buffer API), matcher (solo, i8-MFMA TOPS), c3 (dual 1280x720, 2000
+features), local_ba (C4 + its MFMA / HBM roofline + the 8-problem batch), c5_one_gpu (8 streams of
+extraction + matching next to 8 concurrent local BAs, time-sliced on ONE GPU), bow.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -24,15 +36,12 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+I8_MFMA_PEAK_TOPS = 3944.0       # MI355X_MICROARCH.md: v_mfma_i32_16x16x64_i8 dense, measured ceiling
+F64_MFMA_PEAK_GFLOPS = 78600.0   # AMD's public MI355X figure for FP64 matrix (= FP64 vector); the in-container guide has no f64 row
+N_CU = 256
 
 
-def pyramid_px(pkg, ext):
-    dims = [ext.level_dims(l) for l in range(ext.nlevels)]
-    px = [w * h for w, h in dims]
-    return px
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -41,11 +50,265 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip every CPU leg)")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-bow", action="store_true")
+    ap.add_argument("--no-c3", action="store_true")
+    ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the latency / with_transfers legs")
     ap.add_argument("--lanes", type=int, default=1, help="independent extractor handles/streams the batch is split over (overlaps latency-bound kernels)")
-    args = ap.parse_args()
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="CPU check of the N > 1 entry: launcher -> ranks -> gloo process group -> the feature all-gather, then one JSON line")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a rank environment: become the launcher (one process per GPU under torch.distributed.run)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_rank(args):
+    """The N > 1 path up to and including its first collective, on CPU (gloo): same sharding code bench runs over RCCL."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    entry.load_package()
+    from orb_slam2_dualcam_amd import sharding
+    cap = 64
+    kp = torch.full((2, cap, 7), float(rank), dtype=torch.float32)
+    desc = torch.full((2, cap, 32), rank + 1, dtype=torch.uint8)
+    n = torch.tensor([10 + rank, 20 + rank], dtype=torch.int32)
+    g_kp, g_desc, g_n = sharding.allgather_features(kp, desc, n, cap)
+    ok = g_n.tolist() == [v for r in range(world) for v in (10 + r, 20 + r)] and \
+        all(int(g_desc[2 * r, 0, 0]) == r + 1 for r in range(world)) and all(q == 2 * rank for q, _ in sharding.reloc_pairs(rank, world))
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "backend": "gloo", "allgather_ok": bool(flag.item()),
+                          "units_of_rank0": sharding.shard_units(2 * world + 1, 0, world)}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if flag.item() else 1
+
+
+class Pipeline:
+    """extraction + matching of `streams` x `frames` dual frames per step, HBM-resident, double-buffered feature slots:
+    matching of step i (main stream) overlaps the extraction of step i + 1 (extractor streams)."""
+
+    def __init__(self, pkg, torch, dev, local_rank, W, H, NF, streams, frames, n_lanes, stream_base, n_events):
+        synth = pkg.synth
+        self.pkg, self.torch, self.dev = pkg, torch, dev
+        self.W, self.H, self.NF, self.streams, self.frames = W, H, NF, streams, frames
+        P = self.P = streams * frames
+        n_unique = min(frames, 8) if streams == 1 else min(frames, 2)
+        self.n_unique = n_unique
+        self.host_frames = {}
+        imgs = []
+        for s in range(streams):
+            for f in range(n_unique):
+                self.host_frames[(s, f)] = synth.frame_pair(W, H, stream_base + s, f)
+        for s in range(streams):
+            for f in range(frames):
+                imgs.extend(self.host_frames[(s, f % n_unique)])
+        self.host_imgs = np.stack(imgs)
+        self.d_img = torch.from_numpy(self.host_imgs).to(dev)
+        n_lanes = self.n_lanes = max(1, min(n_lanes, P))
+        self.lane_pairs = [P // n_lanes + (1 if i < P % n_lanes else 0) for i in range(n_lanes)]
+        self.exts = [pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local_rank, max_images=2 * lp) for lp in self.lane_pairs]
+        self.ext = self.exts[0]
+        self.lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
+        self.lane_done = [torch.cuda.Event() for _ in range(n_lanes)]
+        self.matcher = pkg.ORBmatcher(0.75, True)
+        cap = self.cap = self.ext.default_cap()
+        NP = self.NP = 2 * streams                     # "t-1" slots: the newest dual frame of every stream from the previous step
+        S = self.S = NP + 2 * P
+        self.NB = 2
+        self.d_kp_b = [torch.zeros((S, cap, 7), dtype=torch.float32, device=dev) for _ in range(self.NB)]
+        self.d_desc_b = [torch.zeros((S, cap, 32), dtype=torch.uint8, device=dev) for _ in range(self.NB)]
+        self.d_n_b = [torch.zeros(S, dtype=torch.int32, device=dev) for _ in range(self.NB)]
+        self.match_done = [torch.cuda.Event() for _ in range(self.NB)]
+        pairs = []
+        for s in range(streams):
+            for f in range(frames):
+                c0 = NP + 2 * (s * frames + f)
+                c1 = c0 + 1
+                p0 = (c0 - 2) if f > 0 else 2 * s
+                pairs += [(c0, c1), (c0, p0), (c1, p0 + 1)]
+        self.n_pairs = len(pairs)
+        self.pairs = pairs
+        self.d_pairs = torch.tensor(pairs, dtype=torch.int32, device=dev)
+        self.d_match = torch.zeros((self.n_pairs, cap), dtype=torch.int32, device=dev)
+        self.d_nm = torch.zeros(self.n_pairs, dtype=torch.int32, device=dev)
+        self.d_b = torch.zeros((self.n_pairs, cap), dtype=torch.int32, device=dev)
+        self.d_s = torch.zeros((self.n_pairs, cap), dtype=torch.int32, device=dev)
+        # newest dual frame of every stream inside the batch (source of the next step's "t-1" slots)
+        self.newest = torch.tensor([NP + 2 * (s * frames + frames - 1) + c for s in range(streams) for c in (0, 1)], dtype=torch.int64, device=dev)
+        self.ev_all = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_events)]
+        self.step_no = 0
+        self.post_match = None                          # hook: called inside step() after the matcher launch (all-gather leg)
+
+    def step(self):
+        torch = self.torch
+        it = self.step_no
+        ev = self.ev_all[it % len(self.ev_all)]
+        self.step_no += 1
+        cur, prv = it % self.NB, (it - 1) % self.NB
+        d_kp, d_desc, d_n = self.d_kp_b[cur], self.d_desc_b[cur], self.d_n_b[cur]
+        NP = self.NP
+        first = 0
+        for li in range(self.n_lanes):
+            a, b = 2 * first, 2 * (first + self.lane_pairs[li])
+            if it >= self.NB:
+                self.lane_streams[li].wait_event(self.match_done[cur])
+            self.exts[li].extract_batch_device(self.d_img[a:b], d_kp[NP + a:NP + b], d_desc[NP + a:NP + b], d_n[NP + a:NP + b], self.cap,
+                                               stream=self.lane_streams[li].cuda_stream)
+            self.lane_done[li].record(self.lane_streams[li])
+            first += self.lane_pairs[li]
+        for li in range(self.n_lanes):
+            torch.cuda.current_stream().wait_event(self.lane_done[li])
+        if self.streams == 1:
+            d_kp[0:2].copy_(self.d_kp_b[prv][self.S - 2:]); d_desc[0:2].copy_(self.d_desc_b[prv][self.S - 2:]); d_n[0:2].copy_(self.d_n_b[prv][self.S - 2:])
+        else:
+            d_kp[0:NP].copy_(self.d_kp_b[prv][self.newest]); d_desc[0:NP].copy_(self.d_desc_b[prv][self.newest]); d_n[0:NP].copy_(self.d_n_b[prv][self.newest])
+        ev[0].record()
+        self.matcher.match_bf_batch_device(d_desc, d_kp, d_n, self.cap, self.d_pairs, self.n_pairs, self.d_match, self.d_nm, self.d_b, self.d_s, 50,
+                                           stream=torch.cuda.current_stream().cuda_stream)
+        ev[1].record()
+        if self.post_match is not None:
+            self.post_match(d_kp, d_desc, d_n, ev)
+        self.match_done[cur].record()
+
+    def last_slots(self):
+        c = (self.step_no - 1) % self.NB
+        return self.d_kp_b[c], self.d_desc_b[c], self.d_n_b[c]
+
+    def features_per_step(self):
+        return int(self.last_slots()[2][self.NP:].sum().item())
+
+    def run(self, steps, warmup, barrier=None):
+        torch = self.torch
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        for e_ in self.exts:
+            e_.timing_totals(reset=True)
+        self.step_no_timed0 = self.step_no
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def close(self):
+        for e_ in self.exts:
+            e_.close()
+
+
+def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
+    """BASELINE config C5 on ONE GPU: 8 dual-camera streams (1280x720, 2000 features / camera), one new dual frame per stream per
+    step, next to one local BA per stream (dcs_ba_local_batch from a second host thread, its own HIP stream). The reference's
+    pattern: Tracking thread extracts / matches while the LocalMapping thread runs LocalBundleAdjustment (src/LocalMapping.cc:97-104)."""
+    synth = pkg.synth
+    pipe = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 8, 1, 1, 0, 64)
+    preps = [pkg.Optimizer.prepare(synth.ba_problem(seed=42 + s)) for s in range(n_ba)]
+    for _ in range(2):
+        pkg.Optimizer.LocalBundleAdjustmentBatch(preps)
+
+    def ba_calls(n):
+        its, t0 = 0, time.perf_counter()
+        for _ in range(n):
+            _check_batch(pkg, preps)
+            its += sum(sum(p.res.n_iters) for p in preps)
+        return its, time.perf_counter() - t0
+
+    steps = 40
+    dt_alone = pipe.run(steps, 3)
+    feats = pipe.features_per_step()
+    its_alone, t_ba_alone = ba_calls(10)
+    stop = threading.Event()
+    ba_stat = {"its": 0, "calls": 0, "t": 0.0}
+
+    def ba_worker():
+        t0 = time.perf_counter()
+        while not stop.is_set():
+            _check_batch(pkg, preps)
+            ba_stat["its"] += sum(sum(p.res.n_iters) for p in preps)
+            ba_stat["calls"] += 1
+        ba_stat["t"] = time.perf_counter() - t0
+
+    th = threading.Thread(target=ba_worker)
+    th.start()
+    time.sleep(0.02)
+    dt_both = pipe.run(3 * steps, 2)
+    stop.set()
+    th.join()
+    out = {"workload": "configs[4] on ONE GPU (time-sliced; C5 proper is one stream per GPU): 8 dual 1280x720 streams, 2000 feat/cam, "
+                       "1 new dual frame per stream per step (extract + 3 matches) next to 8 concurrent local BAs (50 KF / 2000 MP each, one dcs_ba_local_batch per round)",
+           "features_per_step": feats,
+           "concurrent": {"kfeatures_s": round(feats * 3 * steps / dt_both / 1e3, 1), "dual_frames_s": round(8 * 3 * steps / dt_both, 1),
+                          "ba_iters_s": round(ba_stat["its"] / max(ba_stat["t"], 1e-9), 1), "ba_rounds": ba_stat["calls"]},
+           "alone": {"kfeatures_s": round(feats * steps / dt_alone / 1e3, 1), "dual_frames_s": round(8 * steps / dt_alone, 1),
+                     "ba_iters_s": round(its_alone / t_ba_alone, 1)}}
+    pipe.close()
+    return out
+
+
+def _check_batch(pkg, preps):
+    import ctypes as C
+    n = len(preps)
+    pbs = (C.c_void_p * n)(*[C.addressof(p.pb) for p in preps])
+    ress = (C.c_void_p * n)(*[C.addressof(p.res) for p in preps])
+    rc = pkg.abi.lib().dcs_ba_local_batch(n, C.cast(pbs, C.c_void_p), None, C.cast(ress, C.c_void_p))
+    if rc:
+        raise RuntimeError("dcs_ba_local_batch -> %d: %s" % (rc, pkg.abi.lib().dcs_last_error().decode()))
+
+
+def cpu_frame_pair(O, o, a, b, prev):
+    """what one step does for one dual frame, on the oracle: 2 extractions + 3 knn2 / ratio / rot-hist matches"""
+    ka, da = o.extract(a)
+    kb, db = o.extract(b)
+    jobs = [(da, ka, db, kb)]
+    if prev is not None:
+        jobs += [(da, ka, prev[0], prev[1]), (db, kb, prev[2], prev[3])]
+    else:
+        jobs += [(da, ka, da, ka), (db, kb, db, kb)]
+    for (q, kq, t, kt) in jobs:
+        bi, bd, sd = O.knn2(q, t)
+        O.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, kq["angle"], kt["angle"])
+    return (da, ka, db, kb), len(ka) + len(kb)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    in_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_rank_env:
+        sys.exit(launch_ranks(args, argv))
+    if args.selftest_launch:
+        if not in_rank_env:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+        sys.exit(selftest_rank(args))
 
     import torch
     import torch.distributed as dist
@@ -64,40 +327,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     P, W, H, NF = args.pairs, args.width, args.height, args.nfeatures
-    # ---- HBM-resident synthetic input: stream = rank, n_unique distinct dual frames tiled to P
-    n_unique = min(P, 8)
-    frames = []
-    for f in range(n_unique):
-        frames.extend(synth.frame_pair(W, H, rank, f))
-    imgs = np.stack([frames[(2 * (p % n_unique)) + c] for p in range(P) for c in (0, 1)])
-    d_img = torch.from_numpy(imgs).to(dev)
-
-    n_lanes = max(1, min(args.lanes, P))
-    lane_pairs = [P // n_lanes + (1 if i < P % n_lanes else 0) for i in range(n_lanes)]
-    exts = [pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local_rank, max_images=2 * lp) for lp in lane_pairs]
-    ext = exts[0]
-    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
-    lane_done = [torch.cuda.Event() for _ in range(n_lanes)]
-    lane_go = torch.cuda.Event()
-    matcher = pkg.ORBmatcher(0.75, True)
-    cap = ext.default_cap()
-    S = 2 * P + 2                                   # feature slots: [prev cam0, prev cam1, batch ...]
-    # two slot sets: matching of step i (main stream) overlaps the extraction of step i + 1 (lane streams)
-    NB = 2
-    d_kp_b = [torch.zeros((S, cap, 7), dtype=torch.float32, device=dev) for _ in range(NB)]
-    d_desc_b = [torch.zeros((S, cap, 32), dtype=torch.uint8, device=dev) for _ in range(NB)]
-    d_n_b = [torch.zeros(S, dtype=torch.int32, device=dev) for _ in range(NB)]
-    match_done = [torch.cuda.Event() for _ in range(NB)]
-    pairs = []
-    for f in range(P):
-        c0, c1 = 2 + 2 * f, 3 + 2 * f
-        pairs += [(c0, c1), (c0, c0 - 2), (c1, c1 - 2)]
-    n_pairs = len(pairs)
-    d_pairs = torch.tensor(pairs, dtype=torch.int32, device=dev)
-    d_match = torch.zeros((n_pairs, cap), dtype=torch.int32, device=dev)
-    d_nm = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
-    d_b = torch.zeros((n_pairs, cap), dtype=torch.int32, device=dev)
-    d_s = torch.zeros((n_pairs, cap), dtype=torch.int32, device=dev)
+    n_ev = args.steps + args.warmup
+    pipe = Pipeline(pkg, torch, dev, local_rank, W, H, NF, 1, P, args.lanes, rank, n_ev)
+    ext, cap, S, n_pairs, n_lanes = pipe.ext, pipe.cap, pipe.S, pipe.n_pairs, pipe.n_lanes
+    matcher = pipe.matcher
+    stream = torch.cuda.current_stream().cuda_stream
     if world > 1:
         from orb_slam2_dualcam_amd import sharding
         rec = sharding.record_bytes(cap)             # per camera: kp 28 B + desc 32 B per slot + count
@@ -111,40 +345,8 @@ def main():
         x_nm = torch.zeros(world - 1, dtype=torch.int32, device=dev)
         x_b = torch.zeros((world - 1, cap), dtype=torch.int32, device=dev)
         x_s = torch.zeros((world - 1, cap), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    stage_keys = ("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us")
-    acc = {k: 0.0 for k in stage_keys}
-    acc["match_us"] = 0.0
-    acc["allgather_us"] = 0.0
-    # per-step torch events (match, all-gather) are read AFTER the timed region so that nothing stalls the stream
-    ev_all = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps + args.warmup)]
-    step_no = [0]
 
-    def step(timed):
-        it = step_no[0]
-        ev = ev_all[it]
-        step_no[0] += 1
-        cur, prv = it % NB, (it - 1) % NB
-        d_kp, d_desc, d_n = d_kp_b[cur], d_desc_b[cur], d_n_b[cur]
-        # the batch is split over `n_lanes` extractor handles on their own streams; they only wait for the matcher to
-        # be done with this slot set (step it - 2), so extraction of step it overlaps matching of step it - 1
-        first = 0
-        for li in range(n_lanes):
-            a, b = 2 * first, 2 * (first + lane_pairs[li])
-            if it >= NB:
-                lane_streams[li].wait_event(match_done[cur])
-            exts[li].extract_batch_device(d_img[a:b], d_kp[2 + a:2 + b], d_desc[2 + a:2 + b], d_n[2 + a:2 + b], cap,
-                                          stream=lane_streams[li].cuda_stream)
-            lane_done[li].record(lane_streams[li])
-            first += lane_pairs[li]
-        for li in range(n_lanes):
-            torch.cuda.current_stream().wait_event(lane_done[li])
-        # newest dual frame of the previous step is "t-1" of this one
-        d_kp[0:2].copy_(d_kp_b[prv][S - 2:]); d_desc[0:2].copy_(d_desc_b[prv][S - 2:]); d_n[0:2].copy_(d_n_b[prv][S - 2:])
-        ev[0].record()
-        matcher.match_bf_batch_device(d_desc, d_kp, d_n, cap, d_pairs, n_pairs, d_match, d_nm, d_b, d_s, 50, stream=stream)
-        ev[1].record()
-        if world > 1:
+        def exchange(d_kp, d_desc, d_n, ev):
             # exchange the newest dual frame: pack (kp | desc | n) per camera, one all-gather, cross-GPU reloc match
             sharding.pack_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_send)
             ev[2].record()
@@ -152,32 +354,22 @@ def main():
             ev[3].record()
             sharding.unpack_features(g_recv, cap, g_kp, g_desc, g_n)
             matcher.match_bf_batch_device(g_desc, g_kp, g_n, cap, x_pairs, world - 1, x_match, x_nm, x_b, x_s, 50, stream=stream)
-        match_done[cur].record()
-        return None
+        pipe.post_match = exchange
+    stage_keys = ("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us")
+    acc = {k: 0.0 for k in stage_keys}
+    acc["match_us"] = 0.0
+    acc["allgather_us"] = 0.0
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    for e_ in exts:
-        e_.timing_totals(reset=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    for e_ in exts:                       # kernel times: summed over the lanes (each lane launches its own kernels)
+    dt = pipe.run(args.steps, args.warmup, barrier)
+    for e_ in pipe.exts:                  # kernel times: summed over the lanes (each lane launches its own kernels)
         sums, n_timed = e_.timing_totals()
         for k in stage_keys:
             acc[k] += sums[k]
-    for ev in ev_all[args.warmup:]:
+    for ev in pipe.ev_all[args.warmup:]:
         acc["match_us"] += ev[0].elapsed_time(ev[1]) * 1000.0
         if world > 1:
             acc["allgather_us"] += ev[2].elapsed_time(ev[3]) * 1000.0
@@ -185,8 +377,8 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    n_feat_step = int(d_n_b[(step_no[0] - 1) % NB][2:].sum().item())
-    n_match_step = int(d_nm.sum().item())
+    n_feat_step = pipe.features_per_step()
+    n_match_step = int(pipe.d_nm.sum().item())
     tot = torch.tensor([n_feat_step], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tot)
@@ -195,7 +387,7 @@ def main():
 
     out = None
     if rank == 0:
-        px = pyramid_px(pkg, ext)
+        px = [w * h for w, h in (ext.level_dims(l) for l in range(ext.nlevels))]
         sum_px, px7, sum_17 = sum(px), px[-1], sum(px[1:])
         n_img = 2 * P
         n_avg = n_feat_step / n_img
@@ -207,22 +399,22 @@ def main():
             "k_fast_cells": sum_px * n_img_l,
             "k_blur": 2 * sum_px * n_img_l,
             "k_describe": int((749 + 512 + 60) * n_avg * n_img_l),
-            "k_knn2_pairs_mfma+k_filter_pairs": int((32 * 2 * n_avg + 12 * n_avg) * n_pairs),
         }
         dur = {"k_resize(x7)": acc["pyramid_us"] / (K * LN), "k_fast_cells": acc["fast_us"] / (K * LN),
-               "k_blur": acc["blur_us"] / (K * LN), "k_describe": acc["describe_us"] / (K * LN),
-               "k_knn2_pairs_mfma+k_filter_pairs": acc["match_us"] / K}
+               "k_blur": acc["blur_us"] / (K * LN), "k_describe": acc["describe_us"] / (K * LN)}
         kernels = {k: dict(us=round(dur[k], 2), algo_bytes=int(algo[k]),
                            gbps=round(algo[k] / max(dur[k], 1e-3) / 1e3, 2)) for k in algo}
-        dom = max((k for k in dur if k != "k_knn2_pairs_mfma+k_filter_pairs"), key=lambda k: dur[k])
+        dom = max(dur, key=lambda k: dur[k])
         traffic = None                               # HBM bytes per launch from the committed PMC passes (profiles/), same workload only
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-            if (P, W, H, NF, LN) == tuple(pmc.get("bench_args", ())):
-                kk = pmc["kernels"][dom.split("(")[0].split("+")[0]]
-                traffic = int((kk["FETCH_SIZE_KB_avg_per_launch"] + kk["WRITE_SIZE_KB_avg_per_launch"]) * 1024)
-        except Exception:
-            traffic = None
+        for prof in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                if (P, W, H, NF, LN) == tuple(pmc.get("bench_args", ())):
+                    kk = pmc["kernels"][dom.split("(")[0].split("+")[0]]
+                    traffic = int((kk["FETCH_SIZE_KB_avg_per_launch"] + kk["WRITE_SIZE_KB_avg_per_launch"]) * 1024)
+                    break
+            except Exception:
+                traffic = None
         roofline = dict(kernel=dom, bound="hbm", achieved=kernels[dom]["gbps"], peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(kernels[dom]["gbps"] / HBM_PEAK_GBS, 5), traffic=traffic,
                         algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(dur[dom], 2))
@@ -238,52 +430,162 @@ def main():
             "stage_us_per_step": {k: round(v / K, 2) for k, v in acc.items()},
             "kernels": kernels,
         }
+        if world > 1:
+            out["allgather_us"] = round(acc["allgather_us"] / K, 2)
+            out["allgather_bytes_per_rank"] = int(2 * rec)
 
-    # ---- CPU baseline (rank 0, N = 1 only): the oracle ("port"), single thread, bounded sample
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    solo = rank == 0 and world == 1
+    # ---- matcher alone (nothing else on the GPU): the i8 matrix-core Hamming kernel against its own peak
+    if solo:
+        d_kp, d_desc, d_n = pipe.last_slots()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            matcher.match_bf_batch_device(d_desc, d_kp, d_n, cap, pipe.d_pairs, n_pairs, pipe.d_match, pipe.d_nm, pipe.d_b, pipe.d_s, 50, stream=stream)
+        torch.cuda.synchronize()
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            matcher.match_bf_batch_device(d_desc, d_kp, d_n, cap, pipe.d_pairs, n_pairs, pipe.d_match, pipe.d_nm, pipe.d_b, pipe.d_s, 50, stream=stream)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        nn = pipe.last_slots()[2].cpu().numpy().astype(np.int64)
+        dist_count = int(sum(nn[a] * nn[b] for a, b in pipe.pairs))
+        tops = dist_count * 512 / us / 1e6            # 256 multiply-accumulates per Hamming distance on the i8 matrix cores
+        out["matcher"] = {"kernel": "k_knn2_pairs_mfma + k_filter_pairs", "solo_us_per_step": round(us, 2), "pairs": n_pairs,
+                          "distances": dist_count, "achieved": round(tops, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOPS (i8 MFMA)",
+                          "frac": round(tops / I8_MFMA_PEAK_TOPS, 4), "gdistances_s": round(dist_count / us / 1e3, 1),
+                          "algo_bytes": int((32 * 2 * n_avg + 12 * n_avg) * n_pairs)}
+        out["kernels"]["k_knn2_pairs_mfma+k_filter_pairs"] = dict(us=round(us, 2), note="solo; inside a step it runs underneath the next extraction (stage_us_per_step.match_us is that window)")
+
+    # ---- host-buffer API (what the reference's seams hand over): one dual frame per call (latency), the whole batch (throughput)
+    if solo and not args.no_host_api:
+        a, b = pipe.host_frames[(0, 0)]
+        ext1 = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local_rank, max_images=2)
+        m1 = pkg.ORBmatcher(0.75, True)
+        for _ in range(5):
+            kps, descs = ext1.extract_batch([a, b]); m1.match_bf(descs[0], kps[0], descs[1], kps[1], 50)
+        reps, t0, t_ext = 50, time.perf_counter(), 0.0
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            kps, descs = ext1.extract_batch([a, b])
+            t_ext += time.perf_counter() - t1
+            m1.match_bf(descs[0], kps[0], descs[1], kps[1], 50)
+        tl = (time.perf_counter() - t0) / reps
+        out["latency"] = {"workload": "1 dual frame per call: dcs_orb_extract_batch (2 host images in, keypoints + descriptors out) + dcs_match_bf (host buffers), "
+                                      "synchronous, PCIe included -- what Frame::ExtractORB issues per frame",
+                          "ms_per_dual_frame": round(tl * 1e3, 3), "ms_extract": round(t_ext / reps * 1e3, 3), "ms_match": round((tl - t_ext / reps) * 1e3, 3),
+                          "kfeatures_s": round((len(kps[0]) + len(kps[1])) / tl / 1e3, 2)}
+        ext1.close()
+        host_imgs = [pipe.host_imgs[i] for i in range(2 * P)]
+        ext.extract_batch(host_imgs)
+        reps, t0 = 3, time.perf_counter()
+        for _ in range(reps):
+            kps, descs = ext.extract_batch(host_imgs)
+        tt = (time.perf_counter() - t0) / reps
+        nf = sum(len(k) for k in kps)
+        out["with_transfers"] = {"workload": "the default batch (%d images) through dcs_orb_extract_batch: pageable host images in, keypoints + descriptors out, extraction only" % (2 * P),
+                                 "ms_per_call": round(tt * 1e3, 2), "kfeatures_s": round(nf / tt / 1e3, 1),
+                                 "image_GBps": round(2 * P * W * H / tt / 1e9, 2)}
+
+    # ---- CPU baseline (rank 0, N = 1 only): the oracle ("port"), single thread, bounded sample; then every host core
+    if solo and args.cpu_seconds > 0:
         O = entry.load_oracle()
         o = O.OrbOracle(NF, 1.2, 8, 20, 7)
-        prev = None
-        feats = 0
-        n_done = 0
+        prev, feats, n_done = None, 0, 0
         tc0 = time.perf_counter()
         while time.perf_counter() - tc0 < args.cpu_seconds and n_done < 400:
-            f = n_done % n_unique
-            a, b = frames[2 * f], frames[2 * f + 1]
-            ka, da = o.extract(a)
-            kb, db = o.extract(b)
-            jobs = [(da, ka, db, kb)]
-            if prev is not None:
-                jobs += [(da, ka, prev[0], prev[1]), (db, kb, prev[2], prev[3])]
-            else:
-                jobs += [(da, ka, da, ka), (db, kb, db, kb)]
-            for (q, kq, t, kt) in jobs:
-                bi, bd, sd = O.knn2(q, t)
-                O.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, kq["angle"], kt["angle"])
-            prev = (da, ka, db, kb)
-            feats += len(ka) + len(kb)
+            a, b = pipe.host_frames[(0, n_done % pipe.n_unique)]
+            prev, nf = cpu_frame_pair(O, o, a, b, prev)
+            feats += nf
             n_done += 1
         tc = time.perf_counter() - tc0
         out["cpu_baseline"] = {"value": round(feats / tc / 1000.0, 3), "unit": "kfeatures/s", "cores": 1, "kind": "port",
                                "sample": "%d dual %dx%d frames (extract x2 + 3 knn2/filter each) in %.1f s, oracle -O3 single thread; host has %d cores"
                                          % (n_done, W, H, tc, os.cpu_count())}
         out["speedup_vs_cpu_1thread"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        # all host cores: one stream of dual frames per thread (the oracle is C behind ctypes: the GIL is released inside)
+        n_thr = max(1, min(os.cpu_count() or 1, 256))
+        budget = min(args.cpu_seconds, 6.0)
+        counts = [0] * n_thr
+
+        def worker(t):
+            ot = O.OrbOracle(NF, 1.2, 8, 20, 7)
+            pv, k = None, 0
+            t_end = time.perf_counter() + budget
+            while time.perf_counter() < t_end:
+                a_, b_ = pipe.host_frames[(0, (t + k) % pipe.n_unique)]
+                pv, nf_ = cpu_frame_pair(O, ot, a_, b_, pv)
+                counts[t] += nf_
+                k += 1
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+        ta0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        ta = time.perf_counter() - ta0
+        out["cpu_all_cores"] = {"value": round(sum(counts) / ta / 1000.0, 2), "unit": "kfeatures/s", "cores": n_thr, "kind": "port",
+                                "sample": "%d threads x one dual-frame stream each for %.1f s (oracle -O3, one thread per host core)" % (n_thr, ta)}
+        out["speedup_vs_cpu_all_cores"] = round(out["value"] / max(out["cpu_all_cores"]["value"], 1e-9), 2)
+
+    # ---- C3 leg: dual 1280x720, 2000 features / camera (BASELINE configs[2]) on this GPU
+    if solo and not args.no_c3 and (W, H, NF) != (1280, 720, 2000):
+        p3 = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 1, 64, 1, 0, 16)
+        dt3 = p3.run(8, 2)
+        f3 = p3.features_per_step()
+        out["c3"] = {"workload": "configs[2] at 1 GPU: dual 1280x720 stream, 2000 feat/cam, extract + BF match, 64 dual frames per step",
+                     "kfeatures_s": round(f3 * 8 / dt3 / 1e3, 1), "ms_per_step": round(dt3 / 8 * 1e3, 3), "features_per_step": f3,
+                     "dual_frames_s": round(64 * 8 / dt3, 1)}
+        p3.close()
 
     # ---- local BA leg (C4: 50 KF / 2000 MP / 20k dual-camera edges), rank 0, N = 1
-    if rank == 0 and world == 1 and not args.no_ba and hasattr(pkg.abi.lib(), "dcs_ba_local"):
+    if solo and not args.no_ba and hasattr(pkg.abi.lib(), "dcs_ba_local"):
         pb = synth.ba_problem()
         prep = pkg.Optimizer.prepare(pb)                             # flat problem marshalled once, as a C++ caller holds it
         prep.solve()                                                 # warm-up (allocations, code objects)
-        reps, iters, tb0 = 10, 0, time.perf_counter()
+        reps, iters, tb0 = 30, 0, time.perf_counter()
         gpu_ms = 0.0
         for _ in range(reps):
             r = prep.solve()
             iters += sum(r["n_iters"])
             gpu_ms += r["gpu_ms"]
         tb = time.perf_counter() - tb0
-        ba = {"metric": "local-BA iters/s (50 KF / 2k MP / %d edges)" % len(pb["obs"]), "value": round(iters / tb, 1),
-              "unit": "LM iterations/s", "iters_per_solve": iters / reps, "ms_per_solve_wall": round(tb / reps * 1e3, 2),
-              "ms_per_solve_optimise_phase": round(gpu_ms / reps, 2), "dtype": "f64"}
+        n_free = int((np.asarray(pb["pose_fixed"]) == 0).sum())
+        E, L = len(pb["obs"]), len(pb["points"])
+        ba = {"metric": "local-BA iters/s (50 KF / 2k MP / %d edges)" % E, "value": round(iters / tb, 1),
+              "unit": "LM iterations/s", "solves": reps, "iters_per_solve": iters / reps, "trials_per_solve": sum(r["n_trials"]),
+              "ms_per_solve_wall": round(tb / reps * 1e3, 3), "ms_per_solve_optimise_phase": round(gpu_ms / reps, 3), "dtype": "f64"}
+        # roofline of the reduced-camera-system factorisation, timed live with hipEvents on the solver's own stream
+        pkg.Optimizer.timing(True)
+        for _ in range(10):
+            prep.solve()
+        tm = pkg.Optimizer.timing(False)
+        if tm["ldlt_launches"] > 0:
+            n_sys = 6 * n_free
+            flops = n_sys ** 3 / 3.0
+            us_l = tm["ldlt_us"] / tm["ldlt_launches"]
+            us_s = tm["step_us"] / max(tm["steps"], 1)
+            gf = flops / us_l / 1e3
+            bytes_trial = E * 144 + L * 96 + (n_sys ** 2) * 8 + E * (8 + 16 + 8 + 1 + 56 + 24)      # Schur reads + S write + residual pass
+            ba["roofline"] = {"kernel": "k_ldlt_mfma", "bound": "mfma", "achieved": round(gf / 1e3, 5), "peak": F64_MFMA_PEAK_GFLOPS / 1e3, "unit": "TFLOP/s",
+                              "frac": round(gf / F64_MFMA_PEAK_GFLOPS, 6), "traffic": None,
+                              "flops_per_launch": int(flops), "n": n_sys, "avg_launch_us": round(us_l, 2),
+                              "note": "one workgroup factors one reduced camera system: 1 of %d CUs is busy (frac_of_one_cu %.3f); f64 MFMA peak = public spec"
+                                      % (N_CU, gf / (F64_MFMA_PEAK_GFLOPS / N_CU)),
+                              "frac_of_one_cu": round(gf / (F64_MFMA_PEAK_GFLOPS / N_CU), 4),
+                              "hbm_per_trial": {"bound": "hbm", "algorithmic_bytes": int(bytes_trial), "avg_step_us": round(us_s, 2),
+                                                "achieved": round(bytes_trial / us_s / 1e3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": round(bytes_trial / us_s / 1e3 / HBM_PEAK_GBS, 5)}}
+        # the 8-problem batch (config C5's BA half alone): one dcs_ba_local_batch per round
+        preps8 = [prep] + [pkg.Optimizer.prepare(synth.ba_problem(seed=43 + s)) for s in range(7)]
+        _check_batch(pkg, preps8)
+        reps8, it8, t80 = 10, 0, time.perf_counter()
+        for _ in range(reps8):
+            _check_batch(pkg, preps8)
+            it8 += sum(sum(p.res.n_iters) for p in preps8)
+        t8 = time.perf_counter() - t80
+        ba["batch8"] = {"value": round(it8 / t8, 1), "unit": "LM iterations/s (8 problems per dcs_ba_local_batch call)", "ms_per_call": round(t8 / reps8 * 1e3, 3),
+                        "vs_single": round(it8 / t8 / max(ba["value"], 1e-9), 2)}
         if args.cpu_seconds > 0:
             O = entry.load_oracle()
             prob = dict(pb)
@@ -298,11 +600,15 @@ def main():
             ba["speedup_vs_cpu_1thread"] = round(ba["value"] / max(ba["cpu_baseline"]["value"], 1e-9), 1)
         out["local_ba"] = ba
 
+    # ---- C5 on one GPU
+    if solo and not args.no_c5 and not args.no_ba:
+        out["c5_one_gpu"] = run_c5(pkg, torch, dev, local_rank, args)
+
     # ---- BoW front-half leg: transform of the step's descriptors with a full-size synthetic vocabulary
-    if rank == 0 and world == 1 and not args.no_bow and hasattr(pkg.abi.lib(), "dcs_bow_transform_device"):
+    if solo and not args.no_bow and hasattr(pkg.abi.lib(), "dcs_bow_transform_device"):
         voc = synth.vocabulary_fast(10, 6, seed=3)                   # k = 10, L = 6: 1.1 M nodes, 10^6 words (the shape of ORBvoc.txt)
         V = pkg.ORBVocabulary(voc["k"], voc["L"], voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
-        d_kp, d_desc, d_n = d_kp_b[(step_no[0] - 1) % NB], d_desc_b[(step_no[0] - 1) % NB], d_n_b[(step_no[0] - 1) % NB]
+        d_kp, d_desc, d_n = pipe.last_slots()
         bufs = pkg.ORBVocabulary.bow_buffers(S, cap)
         for _ in range(3):
             V.transform_device(d_desc, d_n, cap, bufs, 4, stream)
@@ -331,10 +637,53 @@ def main():
         out["bow"] = bow
         V.close()
 
-    if rank == 0:
+    # ---- N > 1: the same exchange through the C ABI (dcs_features_allgather, RCCL bound by the library), after the timed region.
+    # A watchdog prints the line without this leg if the second communicator cannot be brought up.
+    if world > 1:
+        printed = threading.Event()
+
+        def emit():
+            if rank == 0 and not printed.is_set():
+                printed.set()
+                print(json.dumps(out), flush=True)
+
+        def watchdog():
+            if not done.wait(60.0):
+                if rank == 0:
+                    out["allgather_cabi"] = "timed out"
+                emit()
+                os._exit(0)
+        done = threading.Event()
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.from_numpy(pkg.abi.FeatureComm.unique_id()).to(dev))
+            dist.broadcast(uid, 0)
+            comm = pkg.abi.FeatureComm(uid.cpu().numpy(), rank, world)
+            d_kp, d_desc, d_n = pipe.last_slots()
+            c_kp, c_desc, c_n = torch.zeros_like(g_kp), torch.zeros_like(g_desc), torch.zeros_like(g_n)
+            for _ in range(3):
+                comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, c_kp, c_desc, c_n, stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, c_kp, c_desc, c_n, stream)
+            e1.record(); torch.cuda.synchronize()
+            same = bool(torch.equal(c_n, g_n) and torch.equal(c_desc, g_desc))
+            if rank == 0:
+                out["allgather_cabi"] = {"us": round(e0.elapsed_time(e1) * 1e3 / 20, 2), "equals_torch_distributed": same,
+                                         "impl": "dcs_features_allgather: 3 grouped ncclAllGather on the slot arrays in place"}
+            comm.close()
+        except Exception as e:                       # noqa: BLE001
+            if rank == 0:
+                out["allgather_cabi"] = "unavailable: %s" % e
+        done.set()
+        emit()
+    elif rank == 0:
         print(json.dumps(out))
-    for e_ in exts:
-        e_.close()
+    pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

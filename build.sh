@@ -8,7 +8,7 @@ OBJ="$PKG/build"
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude"
-SRCS=(common.cpp orb_host.cpp octree.cpp orb_extract.cpp orb_kernels.hip octree_kernels.hip match_kernels.hip proj_kernels.hip bow_kernels.hip ba_solver.hip)
+SRCS=(common.cpp comm.cpp orb_host.cpp octree.cpp orb_extract.cpp orb_kernels.hip octree_kernels.hip match_kernels.hip proj_kernels.hip bow_kernels.hip ba_solver.hip)
 OBJS=()
 pids=()
 for f in "${SRCS[@]}"; do
@@ -22,5 +22,5 @@ for f in "${SRCS[@]}"; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdcs_hip.so" "${OBJS[@]}"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdcs_hip.so" "${OBJS[@]}" -ldl
 echo "built $OUT/libdcs_hip.so"

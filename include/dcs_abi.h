@@ -247,6 +247,25 @@ int  dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_
                        const int32_t* f_nodes, const int32_t* f_off, const int32_t* f_idx, int f_n_nodes,
                        float ratio, int check_ori, int32_t* match_f, int* n_matches);
 
+/* ------------------------------------------------------------------ cross-GPU feature exchange
+   One process per GPU; frame pairs / streams are sharded with no data-path collective. The only exchange: every rank
+   contributes its newest feature slots and receives everybody's, so that it can match its cameras against features
+   extracted on the other GPUs -- the multi-GPU analogue of SearchByBoWCrossCam(curFrame, camS, KF, CAP) (reference
+   src/Tracking.cc:822; the reference itself has no collective). RCCL over xGMI, bound at run time (librccl.so.1).
+   Bootstrap like NCCL's: rank 0 calls dcs_comm_unique_id and hands the 128 bytes to the other ranks over whatever channel
+   the host has (file, socket, MPI ...); every rank then calls dcs_comm_create. */
+#define DCS_COMM_ID_BYTES 128
+typedef struct dcs_comm dcs_comm;
+int  dcs_comm_unique_id(uint8_t id[DCS_COMM_ID_BYTES]);
+int  dcs_comm_create(const uint8_t id[DCS_COMM_ID_BYTES], int rank, int world, dcs_comm** out);
+void dcs_comm_destroy(dcs_comm*);
+int  dcs_comm_info(const dcs_comm*, int* rank, int* world);
+/* d_kp [n_slots][cap], d_desc [n_slots][cap][32], d_n [n_slots] of this rank (device pointers, the extractor's slot layout)
+   -> *_all [world * n_slots] ..., rank-major: slot s of rank r lands at r * n_slots + s. Asynchronous on `stream`
+   (hipStream_t); three grouped ncclAllGather calls on the slot arrays in place, no packing. */
+int  dcs_features_allgather(dcs_comm*, const dcs_keypoint* d_kp, const uint8_t* d_desc, const int32_t* d_n, int n_slots, int cap,
+                            dcs_keypoint* d_kp_all, uint8_t* d_desc_all, int32_t* d_n_all, void* stream);
+
 /* ------------------------------------------------------------------ local BA */
 typedef struct dcs_ba_camera {
     double fx, fy, cx, cy;      /* e->fx.. (Optimizer.cc:561-564) */
@@ -298,6 +317,11 @@ int  dcs_ba_local(const dcs_ba_problem* prob, const volatile uint8_t* stop_flag,
    (estimates copied through, no outliers, zero iterations: Optimizer.cc:582-585). Problems may differ in every size. */
 int  dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* probs, const volatile uint8_t* const* stop_flags,
                         dcs_ba_result* const* results);
+/* Measurement hook for bench.py (per calling thread): on != 0 makes the following dcs_ba_local[_batch] calls of this thread
+   bracket every launch of the reduced-camera-system factorisation (k_ldlt_mfma, the reference's LinearSolverEigen::solve,
+   Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:94-124) and every LM step with hipEvents on the solver's stream.
+   out (may be NULL) receives and resets {factorisation us, launches timed, step us, steps timed}. */
+int  dcs_ba_timing(int on, double out[4]);
 
 /* Optimizer::PoseOptimization (src/Optimizer.cc:250-405) for a batch of independent frames (one per stream / camera
    rig); the whole 4-round Levenberg-Marquardt procedure of a frame runs inside one workgroup, no host round trips.

@@ -26,7 +26,8 @@ SYMBOLS = [
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
-    "dcs_ba_local", "dcs_ba_local_batch", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
+    "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
+    "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
 ]
 
@@ -114,6 +115,12 @@ def lib():
             "dcs_distinctive_descriptors": [vp, ci, vp, vp, ci, vp],
             "dcs_ba_local": [C.POINTER(BaProblem), vp, C.POINTER(BaResult)],
             "dcs_ba_local_batch": [ci, vp, vp, vp],
+            "dcs_ba_timing": [ci, vp],
+            "dcs_comm_unique_id": [vp],
+            "dcs_comm_create": [vp, ci, ci, C.POINTER(vp)],
+            "dcs_comm_destroy": [vp],
+            "dcs_comm_info": [vp, pci, pci],
+            "dcs_features_allgather": [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp],
             "dcs_pose_optimization": [C.POINTER(PoseProblem), C.POINTER(PoseResult)],
             "dcs_frame_grid": [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, pci],
             "dcs_search_by_projection": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, cf, ci, vp, vp, pci],
@@ -136,6 +143,8 @@ def lib():
             L.dcs_orb_destroy.restype = None
         if hasattr(L, "dcs_vocab_destroy"):
             L.dcs_vocab_destroy.restype = None
+        if hasattr(L, "dcs_comm_destroy"):
+            L.dcs_comm_destroy.restype = None
         _lib = L
     return _lib
 
@@ -369,6 +378,39 @@ class ORBmatcher:
         return match[:len(desc_f)], n.value
 
 
+class FeatureComm:
+    """dcs_comm: the RCCL communicator of the cross-GPU feature exchange (one per process / GPU)."""
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(128, np.uint8)
+        _check(lib().dcs_comm_unique_id(_p(buf)), "dcs_comm_unique_id")
+        return buf
+
+    def __init__(self, uid, rank, world):
+        uid = _c(uid, np.uint8)
+        self._h = C.c_void_p()
+        _check(lib().dcs_comm_create(_p(uid), int(rank), int(world), C.byref(self._h)), "dcs_comm_create")
+        self.rank, self.world = int(rank), int(world)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().dcs_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allgather_features(self, d_kp, d_desc, d_n, cap, g_kp, g_desc, g_n, stream=None):
+        """torch CUDA tensors: kp [S, cap, 7] f32, desc [S, cap, 32] u8, n [S] i32 -> g_* [world * S, ...] (rank-major)."""
+        S = int(d_kp.shape[0])
+        _check(lib().dcs_features_allgather(self._h, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), S, int(cap),
+                                            g_kp.data_ptr(), g_desc.data_ptr(), g_n.data_ptr(), stream), "dcs_features_allgather")
+
+
 def frame_grid(cam_off, kp_x, kp_y, min_x, min_y, w_inv, h_inv):
     """Frame::PosInGrid + grid fill (Frame.cc:180-196, 380-390) as CSR (grid_off, grid_idx)."""
     cam_off = _c(cam_off, np.int32)
@@ -518,6 +560,14 @@ class Optimizer:
         p["iters1"], p["iters2"] = int(nIterations), 0
         p["huber_delta"] = float(np.float32(np.sqrt(3.99))) if bRobust else 0.0     # const float thHuber2D (:107)
         return PreparedBA(p).solve(stop_flag)
+
+    @staticmethod
+    def timing(on):
+        """dcs_ba_timing: returns {ldlt_us, ldlt_launches, step_us, steps} accumulated since the last call and
+        switches the event timing of this thread's BA calls on / off."""
+        out = np.zeros(4)
+        _check(lib().dcs_ba_timing(int(bool(on)), _p(out)), "dcs_ba_timing")
+        return dict(ldlt_us=out[0], ldlt_launches=out[1], step_us=out[2], steps=out[3])
 
     @staticmethod
     def LocalBundleAdjustmentBatch(probs, stop_flags=None):

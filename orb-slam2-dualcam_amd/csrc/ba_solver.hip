@@ -1511,8 +1511,14 @@ struct BaContext {
     char* h_stage = nullptr; size_t stage_cap = 0;
     int* h_words = nullptr; size_t words_cap = 0;      // [0] last finished step, [1] problems done, [16 + b] stop word of problem b
     hipStream_t stream = nullptr;
+    // measurement hook (dcs_ba_timing): hipEvents around every LDL^T launch and every step of the device loop
+    bool timing = false;
+    std::vector<hipEvent_t> events;
+    double t_ldlt_us = 0, n_ldlt = 0, t_step_us = 0, n_step = 0;
     void release()
     {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        events.clear();
         if (base) (void)hipFree(base);
         if (h_stage) (void)hipHostFree(h_stage);
         if (h_words) (void)hipHostFree(h_words);
@@ -1833,7 +1839,14 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     }
     const BaProb* dp = d_probs;
     const volatile int* d_stop = h_words + 16;
+    const bool timing = ctx.timing;
+    auto event_at = [&](size_t i) -> hipEvent_t {
+        while (ctx.events.size() <= i) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ctx.events.push_back(e); }
+        return ctx.events[i];
+    };
+    auto mark = [&](int step, int k) { if (timing) { hipEvent_t e = event_at((size_t)(step - 1) * 4 + k); if (e) (void)hipEventRecord(e, st); } };
     auto enqueue_step = [&](int step) -> int {
+        mark(step, 0);
         hipLaunchKernelGGL(k_error<0>, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, (const volatile int*)nullptr);      // computeActiveErrors (stale errors only)
         hipLaunchKernelGGL(k_linearize, dim3(g_edges, NB), dim3(256), 0, st, dp, (const BaCtl*)d_ctls);                    // buildSystem
         hipLaunchKernelGGL(k_reduce_pose, dim3(g_reduce, NB), dim3(1024), 0, st, dp, (const BaCtl*)d_ctls);
@@ -1846,6 +1859,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             hipLaunchKernelGGL(k_pad_identity, dim3(1, NB), dim3(64), 0, st, dp, (const BaCtl*)d_ctls);
         }
         if (g_schur) hipLaunchKernelGGL(k_schur, dim3(g_schur, NB), dim3(1024), 0, st, dp, (const BaCtl*)d_ctls);
+        mark(step, 1);
         if (any_mfma) hipLaunchKernelGGL(k_ldlt_mfma, dim3(NB), dim3(256), 0, st, dp, d_ctls);
         if (any_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(NB), dim3(1024), 0, st, dp, d_ctls);
         if (any_blocked) {
@@ -1857,10 +1871,12 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             hipLaunchKernelGGL(k_ldlt_solve, dim3(NB), dim3(256), sizeof(double) * max_npad_blocked, st, dp, (const BaCtl*)d_ctls);
         }
         DCS_CHECK_LAUNCH();
+        mark(step, 2);
         hipLaunchKernelGGL(k_solve_update, dim3(g_update, NB), dim3(64), 0, st, dp, (const BaCtl*)d_ctls);
         hipLaunchKernelGGL(k_error<1>, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, d_stop);        // chi2 of the trial + computeScale + accept / reject
         hipLaunchKernelGGL(k_round_flags, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls);
         hipLaunchKernelGGL(k_round_ctl, dim3(1), dim3(1024), 0, st, dp, d_ctls, NB, step, h_words);
+        mark(step, 3);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     };
@@ -1901,6 +1917,17 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     DCS_HIP(hipStreamSynchronize(st));
     const float opt_ms = (float)ms_since(t_opt0);
     const BaCtl* h_ctls = reinterpret_cast<const BaCtl*>(landed(d_ctls));
+    if (timing) {                                         // only the steps in which at least one problem ran a trial
+        int real = 0;
+        for (int i = 0; i < NB; ++i) real = std::max(real, h_ctls[i].n_trials[0] + h_ctls[i].n_trials[1]);
+        for (int sidx = 0; sidx < std::min(real, steps); ++sidx) {
+            float a = 0, b = 0;
+            if ((size_t)sidx * 4 + 3 < ctx.events.size() && hipEventElapsedTime(&a, ctx.events[sidx * 4 + 1], ctx.events[sidx * 4 + 2]) == hipSuccess &&
+                hipEventElapsedTime(&b, ctx.events[sidx * 4], ctx.events[sidx * 4 + 3]) == hipSuccess) {
+                ctx.t_ldlt_us += 1e3 * a; ctx.n_ldlt += 1; ctx.t_step_us += 1e3 * b; ctx.n_step += 1;
+            }
+        }
+    }
     for (int i = 0; i < NB; ++i) {
         const BaProb& q = hp[i];
         dcs_ba_result* res = results[live[i]];
@@ -1918,6 +1945,15 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     if (trace_t)
         fprintf(stderr, "[dcs_ba] %d problems, total %.3f ms: build_round %.3f, layout + staging %.3f, optimise %.3f (%d steps enqueued, host waited %.3f)\n",
                 NB, ms_since(t_call0), t_build, ms_since(t_call0) - t_build - opt_ms, (double)opt_ms, steps, t_wait);
+    return DCS_OK;
+}
+
+int dcs_ba_timing(int on, double out[4])
+{
+    BaContext& c = ba_context();
+    if (out) { out[0] = c.t_ldlt_us; out[1] = c.n_ldlt; out[2] = c.t_step_us; out[3] = c.n_step; }
+    c.t_ldlt_us = c.n_ldlt = c.t_step_us = c.n_step = 0;
+    c.timing = on != 0;
     return DCS_OK;
 }
 

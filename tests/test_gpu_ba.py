@@ -92,6 +92,54 @@ def test_ba_batch_ragged_and_stop_flags(pkg, oracle, synth):
         pkg.Optimizer.LocalBundleAdjustment(dup)
 
 
+def test_ba_batch_concurrent_with_extraction(pkg, oracle, synth):
+    """The reference's threading: Tracking extracts while LocalMapping runs LocalBundleAdjustment (src/LocalMapping.cc:97-104).
+    A host thread solves a BA batch on the solver's own HIP stream while this thread runs dcs_orb_extract_batch_device on
+    another stream; both results must equal their solo runs bit for bit (and the oracle)."""
+    import threading
+    import torch
+    pbs = [synth.ba_problem(n_poses=30, n_fixed=5, n_points=900, obs_per_point=8, seed=60 + s) for s in range(4)]
+    solo = pkg.Optimizer.LocalBundleAdjustmentBatch(pbs)
+    imgs = [im for f in range(4) for im in synth.frame_pair(640, 480, 1, f)]
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=len(imgs))
+    cap, B = e.default_cap(), len(imgs)
+    d_img = torch.from_numpy(np.stack(imgs)).cuda()
+    bufs = [(torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"), torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+             torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(2)]
+    st = torch.cuda.Stream()
+    e.extract_batch_device(d_img, *bufs[0], cap, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    got, err = [], []
+
+    def ba_thread():
+        try:
+            for _ in range(6):
+                got.append(pkg.Optimizer.LocalBundleAdjustmentBatch(pbs))
+        except Exception as ex:            # noqa: BLE001
+            err.append(ex)
+    th = threading.Thread(target=ba_thread)
+    th.start()
+    n_ext = 0
+    while th.is_alive() or n_ext < 3:
+        e.extract_batch_device(d_img, *bufs[1], cap, stream=st.cuda_stream)
+        st.synchronize()
+        n_ext += 1
+        assert torch.equal(bufs[1][2], bufs[0][2]) and torch.equal(bufs[1][1], bufs[0][1])
+        assert torch.equal(bufs[1][0].view(torch.int32), bufs[0][0].view(torch.int32))
+    th.join()
+    assert not err, err
+    assert len(got) == 6 and n_ext >= 3
+    for r in got:
+        for s in range(4):
+            for k in ("poses", "points", "edge_outlier", "chi2_trace"):
+                assert np.array_equal(r[s][k], solo[s][k]), (s, k)
+    _compare(solo[0], _oracle_run(oracle, pbs[0]), pbs[0])
+    okp, odesc = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(imgs[3])
+    n3 = int(bufs[1][2][3])
+    assert n3 == len(okp) and np.array_equal(bufs[1][1][3, :n3].cpu().numpy(), odesc)
+    e.close()
+
+
 def test_ba_noise_free_ground_truth(pkg, synth):
     pb = synth.ba_problem(n_poses=10, n_fixed=3, n_points=120, obs_per_point=5, seed=3, noise=False)
     rng = np.random.default_rng(1)

@@ -73,3 +73,21 @@ def test_allgather_through_rccl_world_1(pkg, synth):
         assert torch.equal(g_kp.view(torch.int32), kp.view(torch.int32)) and torch.equal(g_desc, desc) and torch.equal(g_n, n)
     finally:
         dist.destroy_process_group()
+
+
+def test_cabi_allgather_world_1(pkg, synth):
+    """dcs_comm_* + dcs_features_allgather (the exchange a C++ host owns, include/dcs_abi.h): RCCL bound by the library, world
+    size 1 on the test box -- the slot arrays come back unchanged, in place, no packing."""
+    import torch
+    cap = 1096
+    _, kp, desc, n = _extract_rank(pkg, synth, 0, cap, torch)
+    comm = pkg.abi.FeatureComm(pkg.abi.FeatureComm.unique_id(), 0, 1)
+    g_kp, g_desc, g_n = torch.zeros_like(kp), torch.zeros_like(desc), torch.zeros_like(n)
+    for _ in range(2):
+        comm.allgather_features(kp, desc, n, cap, g_kp, g_desc, g_n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(g_kp.view(torch.int32), kp.view(torch.int32)) and torch.equal(g_desc, desc) and torch.equal(g_n, n)
+    assert int(g_n.min()) > 900
+    comm.close()
+    with pytest.raises(pkg.DcsError):
+        pkg.abi.FeatureComm(pkg.abi.FeatureComm.unique_id(), 3, 2)
