@@ -503,30 +503,18 @@ def main():
                                "sample": "%d dual %dx%d frames (extract x2 + 3 knn2/filter each) in %.1f s, oracle -O3 single thread; host has %d cores"
                                          % (n_done, W, H, tc, os.cpu_count())}
         out["speedup_vs_cpu_1thread"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
-        # all host cores: one stream of dual frames per thread (the oracle is C behind ctypes: the GIL is released inside)
-        n_thr = max(1, min(os.cpu_count() or 1, 256))
-        budget = min(args.cpu_seconds, 6.0)
-        counts = [0] * n_thr
-
-        def worker(t):
-            ot = O.OrbOracle(NF, 1.2, 8, 20, 7)
-            pv, k = None, 0
-            t_end = time.perf_counter() + budget
-            while time.perf_counter() < t_end:
-                a_, b_ = pipe.host_frames[(0, (t + k) % pipe.n_unique)]
-                pv, nf_ = cpu_frame_pair(O, ot, a_, b_, pv)
-                counts[t] += nf_
-                k += 1
-        ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
-        ta0 = time.perf_counter()
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        ta = time.perf_counter() - ta0
-        out["cpu_all_cores"] = {"value": round(sum(counts) / ta / 1000.0, 2), "unit": "kfeatures/s", "cores": n_thr, "kind": "port",
-                                "sample": "%d threads x one dual-frame stream each for %.1f s (oracle -O3, one thread per host core)" % (n_thr, ta)}
-        out["speedup_vs_cpu_all_cores"] = round(out["value"] / max(out["cpu_all_cores"]["value"], 1e-9), 2)
+        # all host cores: one stream of dual frames per worker PROCESS (tools/cpu_workers.py; a separate process tree, no GPU runtime in it)
+        n_proc = max(1, os.cpu_count() or 1)
+        try:
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_workers.py"), "--width", str(W), "--height", str(H), "--nfeatures", str(NF),
+                                 "--seconds", str(min(args.cpu_seconds, 6.0)), "--procs", str(n_proc)], capture_output=True, text=True, timeout=120)
+            res = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+            out["cpu_all_cores"] = {"value": round(res["kfeatures_s"], 2), "unit": "kfeatures/s", "cores": res["procs"], "kind": "port",
+                                    "sample": "%d processes x one dual-frame stream each, %.1f s wall incl. start-up (oracle -O3, one process per host core)"
+                                              % (res["procs"], res["seconds"])}
+            out["speedup_vs_cpu_all_cores"] = round(out["value"] / max(out["cpu_all_cores"]["value"], 1e-9), 2)
+        except Exception as e:                       # noqa: BLE001
+            out["cpu_all_cores"] = "unavailable: %s" % e
 
     # ---- C3 leg: dual 1280x720, 2000 features / camera (BASELINE configs[2]) on this GPU
     if solo and not args.no_c3 and (W, H, NF) != (1280, 720, 2000):

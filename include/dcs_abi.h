@@ -98,12 +98,19 @@ int  dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_image
                            int stride, dcs_keypoint* kp, uint8_t* desc, int cap, int* n_out);
 
 /* HBM-resident variant: d_images = n_images * rows * stride bytes; outputs in HBM, slotted as
-   above; d_n_out[n_images]. Work is enqueued on `stream` (hipStream_t). */
+   above; d_n_out[n_images]. Work is enqueued on `stream` (hipStream_t); nothing is read back, so the one
+   run-time failure -- the batch's FAST candidates exceed the handle's candidate buffer (1/16 of the pyramid pixels per
+   image, shared by the batch; a scene of pure salt-and-pepper corners) -- is reported in band: every d_n_out[i] of that
+   call is DCS_ERR_CAPACITY (negative) instead of a count, and no keypoint of the call is valid. The host-buffer entry points
+   return DCS_ERR_CAPACITY for the same condition. `cap` < dcs_orb_required_cap() is rejected before anything is enqueued. */
 int  dcs_orb_extract_batch_device(dcs_orb* h, const uint8_t* d_images, int n_images, int rows, int cols,
                                   int stride, dcs_keypoint* d_kp, uint8_t* d_desc, int cap,
                                   int32_t* d_n_out, void* stream);
 
 /* stage taps for parity tests (valid after an extract call on the same handle; host buffers) */
+/* test tap: the cosf / sinf the describe kernel evaluates for the steering coefficients (libm's float overloads, which is
+   what `cos(angle)` / `sin(angle)` on a float are in src/ORBextractor.cc:112-113), for n angles in radians (|x| < 120). */
+int  dcs_debug_sincosf(const float* x, int n, float* cos_out, float* sin_out);
 int  dcs_orb_debug_level_dims(const dcs_orb* h, int level, int* w, int* h_out);
 int  dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t* dst /* w*h */);
 int  dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* dst, int cap, int* n);

@@ -315,6 +315,18 @@ def descriptor_distance(a, b):
     return lib().orc_descriptor_distance(_p(a), _p(b))
 
 
+def sincosf(x, restated=False):
+    """cosf / sinf of float32 radians: the host libm's (what the reference calls, ORBextractor.cc:112-113) or the oracle's
+    restatement of glibc's algorithm (the expressions the GPU kernel evaluates)."""
+    x = _c(x, np.float32)
+    c, s = np.zeros(len(x), np.float32), np.zeros(len(x), np.float32)
+    fn = lib().orc_sincosf_restated if restated else lib().orc_libm_sincosf
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    fn.restype = None
+    fn(_p(x), len(x), _p(c), _p(s))
+    return c, s
+
+
 def knn2(q, t, t_mask=None):
     q, t = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
     nq, nt = len(q), len(t)

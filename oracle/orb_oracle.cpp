@@ -293,13 +293,63 @@ float ic_angle(const uint8_t* img, int stride, int x, int y, const int* umax)
     return fast_atan2((float)m_01, (float)m_10);
 }
 
-/* computeOrbDescriptor (ORBextractor.cc:108-147). cos/sin: double libm on the float angle,
-   narrowed. */
+/* glibc >= 2.28 sinf / cosf (sysdeps/ieee754/flt-32/s_sincosf.h, the ARM optimized-routines code) for |x| < 120: argument
+   reduction by pi/2 and two minimax polynomials, all in double. Exported so that the tests can hold it against the host's
+   libm (exhaustively equal on [0, 6.5) -- every angle an ORB keypoint can have -- with and without FMA contraction); the
+   GPU kernel evaluates the same expressions (csrc/orb_kernels.hip, glibc_sincosf). */
+namespace {
+struct SinCosTab { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+const SinCosTab kSinCos[2] = {
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5,
+     -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5,
+     0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}};
+inline uint32_t abstop12(float x) { uint32_t u; memcpy(&u, &x, 4); return (u >> 20) & 0x7ff; }
+inline float sincos_poly(double x, double x2, const SinCosTab& p, int n)
+{
+    if ((n & 1) == 0) { const double x3 = x * x2, s1 = p.s2 + x2 * p.s3, x7 = x3 * x2, s = x + x3 * p.s1; return (float)(s + x7 * s1); }
+    const double x4 = x2 * x2, c2 = p.c3 + x2 * p.c4, c1 = p.c0 + x2 * p.c1, x6 = x4 * x2, c = c1 + x4 * p.c2;
+    return (float)(c + x6 * c2);
+}
+}  // namespace
+
+extern "C" void orc_sincosf_restated(const float* x, int n, float* cos_out, float* sin_out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float y = x[i];
+        double xd = y;
+        if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {                           /* |y| < pi/4 */
+            const double x2 = xd * xd;
+            const bool tiny = abstop12(y) < abstop12(0x1p-12f);
+            cos_out[i] = tiny ? 1.0f : sincos_poly(xd, x2, kSinCos[0], 1);
+            sin_out[i] = tiny ? y : sincos_poly(xd, x2, kSinCos[0], 0);
+            continue;
+        }
+        const double r = xd * kSinCos[0].hpi_inv;                               /* valid for |y| < 120 */
+        const int q = ((int32_t)r + 0x800000) >> 24;
+        xd = xd - q * kSinCos[0].hpi;
+        const double sgn = kSinCos[0].sign[q & 3];
+        const SinCosTab& p = kSinCos[(q & 2) ? 1 : 0];
+        cos_out[i] = sincos_poly(xd * sgn, xd * xd, p, q ^ 1);
+        sin_out[i] = sincos_poly(xd * sgn, xd * xd, p, q);
+    }
+}
+
+/* the host libm's float overloads: what the reference's cos(angle) / sin(angle) call (ORBextractor.cc:112-113) */
+extern "C" void orc_libm_sincosf(const float* x, int n, float* cos_out, float* sin_out)
+{
+    for (int i = 0; i < n; ++i) { cos_out[i] = cosf(x[i]); sin_out[i] = sinf(x[i]); }
+}
+
+/* computeOrbDescriptor (ORBextractor.cc:108-147). `cos(angle)` / `sin(angle)` on a float with <cmath> and `using namespace
+   std` in scope (:66-67, :112-113) resolve to the float overloads, i.e. libm's cosf / sinf -- NOT a double cosine narrowed
+   to float as SURVEY A.5 has it (the two differ by one ulp for 0.3 % / 0.6 % of the angles). The oracle calls the same
+   functions the reference calls; sincosf_restated() below is glibc's (>= 2.28) algorithm spelled out, which the GPU runs. */
 void brief256(const uint8_t* img, int stride, int x, int y, float angle_deg, uint8_t* desc)
 {
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float angle = angle_deg * factorPI;
-    const float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+    const float a = cosf(angle), b = sinf(angle);
     const uint8_t* center = img + (size_t)y * stride + x;
     const int8_t* pat = kPattern;
     for (int i = 0; i < 32; ++i, pat += 32) {

@@ -23,7 +23,7 @@ SYMBOLS = [
     "dcs_last_error", "dcs_version", "dcs_device_count",
     "dcs_orb_create", "dcs_orb_destroy", "dcs_orb_tables", "dcs_orb_extract", "dcs_orb_extract_batch",
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
-    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
+    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
@@ -102,6 +102,7 @@ def lib():
             "dcs_orb_debug_level": [vp, ci, ci, ci, vp],
             "dcs_orb_debug_candidates": [vp, ci, ci, vp, ci, pci],
             "dcs_orb_debug_quadtree_fallbacks": [vp, pci],
+            "dcs_debug_sincosf": [vp, ci, vp, vp],
             "dcs_orb_required_cap": [vp, ci, ci, pci],
             "dcs_orb_last_timing": [vp, vp],
             "dcs_orb_timing_totals": [vp, vp, vp, ci],
@@ -273,6 +274,14 @@ class ORBextractor:
         _check(lib().dcs_orb_last_timing(self._h, _p(t)), "dcs_orb_last_timing")
         return dict(zip(("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us"),
                         t.tolist()))
+
+
+def debug_sincosf(x):
+    """the describe kernel's cosf / sinf (glibc's algorithm on the GPU) for float32 angles in radians"""
+    x = _c(x, np.float32)
+    c, s = np.zeros(len(x), np.float32), np.zeros(len(x), np.float32)
+    _check(lib().dcs_debug_sincosf(_p(x), len(x), _p(c), _p(s)), "dcs_debug_sincosf")
+    return c, s
 
 
 def distribute_octree(cand, min_x, max_x, min_y, max_y, n_target):

@@ -698,7 +698,7 @@ int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, c
     int rc = ensure_device();
     if (rc) return rc;
     if (n_pairs == 0) return DCS_OK;
-    if (cap >= (1 << 23)) { set_error("cap %d exceeds the 2^23 descriptors of one knn2 problem", cap); return DCS_ERR_UNSUPPORTED; }
+    if (cap >= (1 << 22)) { set_error("cap %d exceeds the 2^22 descriptors of one knn2 problem (22-bit index field of the matrix-core key)", cap); return DCS_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     // d_match doubles as the best-index buffer: the filter reads best_idx[i] and writes match[i] in the same thread
     static const bool knn_valu = getenv("DCS_KNN2_VALU") != nullptr;      // xor + popcount kernel instead of the i8 matrix-core one

@@ -251,6 +251,7 @@ int dcs_orb::configure(int rows, int cols)
     for (int l = 0; l < L; ++l) px += (size_t)g.lv[l].w * g.lv[l].h;
     dense_cap = std::min<size_t>((size_t)B * g.n_slots, (size_t)B * std::max<size_t>(px / 16, 4096));
     dense_cap = std::max<size_t>(dense_cap, 1);
+    if (const char* e = getenv("DCS_ORB_DENSE_CAP")) dense_cap = std::max<size_t>((size_t)atoll(e), 1);      // test hook: provoke the overflow path
     if ((rc = d_dense.resize(dense_cap))) return rc;
     if ((rc = h_dense.resize(dense_cap))) return rc;
     oct = OctLevels();
@@ -368,7 +369,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
         DCS_HIP(hipEventRecord(ev_t[4], stream));
         if ((rc = launch_describe(raw, blur, dp, d_sel.p, nullptr, d_lvl_cnt.p, n_images, oct.out_per_image, d_kp_out, d_desc_out, cap,
-                                  d_n_out, stream))) return rc;
+                                  d_n_out, stream, d_lvl_off.p + n_tasks, (int)dense_cap))) return rc;
     } else {
         DCS_HIP(hipMemcpyAsync(h_lvl_off.p, d_lvl_off.p, sizeof(int32_t) * (n_tasks + 1), hipMemcpyDeviceToHost, stream));
         DCS_HIP(hipStreamSynchronize(stream));
@@ -498,6 +499,20 @@ int dcs_orb_tables(const dcs_orb* h, float* scale, float* inv_scale, float* sigm
         if (inv_sigma2) inv_sigma2[i] = h->t.inv_sigma2[i];
         if (n_per_level) n_per_level[i] = h->t.n_per_level[i];
     }
+    return DCS_OK;
+}
+
+int dcs_debug_sincosf(const float* x, int n, float* cos_out, float* sin_out)
+{
+    if (n < 0 || (n && (!x || !cos_out || !sin_out))) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc || n == 0) return rc;
+    Scratch s;
+    const float* d_x; float *d_c, *d_s;
+    if ((rc = s.upload(&d_x, x, (size_t)n)) || (rc = s.alloc(&d_c, (size_t)n)) || (rc = s.alloc(&d_s, (size_t)n))) return rc;
+    if ((rc = launch_debug_sincosf(d_x, n, d_c, d_s, nullptr))) return rc;
+    DCS_HIP(hipMemcpy(cos_out, d_c, sizeof(float) * n, hipMemcpyDeviceToHost));
+    DCS_HIP(hipMemcpy(sin_out, d_s, sizeof(float) * n, hipMemcpyDeviceToHost));
     return DCS_OK;
 }
 

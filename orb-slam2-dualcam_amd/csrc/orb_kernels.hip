@@ -819,17 +819,69 @@ void build_ic_mask(const int* umax, uint32_t* out /* kIcMaskWords */)
         for (int t = kPatchSize * kIcCols; t < kIcTasks; ++t) out[shift * kIcTasks + t] = 0;     // padding tasks contribute nothing
 }
 
+// cosf / sinf of the keypoint angle, bit for bit what glibc (>= 2.28, sysdeps/ieee754/flt-32/s_sincosf.h) returns for
+// 0 <= x < 120: the reference's `cos(angle)` on a float resolves to the float overload (src/ORBextractor.cc:66-67, 112-113).
+// Reduction by pi/2 and two minimax polynomials in double, no FMA contraction (this file is built with -ffp-contract=off;
+// libm's contracted variant returns the same floats on this range). tests/test_oracle_extract.py holds the oracle's
+// restatement of the algorithm against the host's libm, tests/test_gpu_extract.py holds this function against both.
+// glibc's second table entry is the first with the cosine coefficients negated: every product and sum then flips its sign
+// exactly, so the value is negated at the end instead.
+__device__ __forceinline__ float glibc_sin_poly(double x, double x2)
+{
+    const double x3 = x * x2, s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13, x7 = x3 * x2, s = x + x3 * -0x1.555545995a603p-3;
+    return (float)(s + x7 * s1);
+}
+__device__ __forceinline__ float glibc_cos_poly(double x2, bool negate)
+{
+    const double x4 = x2 * x2, c2 = -0x1.6c087e89a359dp-10 + x2 * 0x1.99343027bf8c3p-16, c1 = 0x1p0 + x2 * -0x1.ffffffd0c621cp-2;
+    const double x6 = x4 * x2, c = c1 + x4 * 0x1.55553e1068f19p-5, r = c + x6 * c2;
+    return (float)(negate ? -r : r);
+}
+__device__ __forceinline__ void glibc_sincosf(float y, float& c_out, float& s_out)
+{
+    double x = (double)y;
+    const unsigned top = (__float_as_uint(y) >> 20) & 0x7ffu;
+    if (top < 0x3f4u) {                                      // abstop12(pi/4 as float 0x3f490fdb)
+        const double x2 = x * x;
+        const bool tiny = top < 0x398u;                      // abstop12(0x1p-12f)
+        c_out = tiny ? 1.0f : glibc_cos_poly(x2, false);
+        s_out = tiny ? y : glibc_sin_poly(x, x2);
+        return;
+    }
+    const double r = x * 0x1.45F306DC9C883p+23;              // 2/pi * 2^24
+    const int n = ((int)r + 0x800000) >> 24;
+    x = x - (double)n * 0x1.921FB54442D18p0;
+    const double xs = ((n & 3) == 1 || (n & 3) == 2) ? -x : x;   // sign[n & 3] = {1, -1, -1, 1}
+    const double x2 = x * x;
+    const bool neg = (n & 2) != 0;
+    // sinf: polynomial picked by n, cosf: by n ^ 1 (odd -> cosine polynomial)
+    s_out = (n & 1) ? glibc_cos_poly(x2, neg) : glibc_sin_poly(xs, x2);
+    c_out = (n & 1) ? glibc_sin_poly(xs, x2) : glibc_cos_poly(x2, neg);
+}
+__global__ void k_debug_sincosf(const float* __restrict__ x, int n, float* __restrict__ c, float* __restrict__ s)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) glibc_sincosf(x[i], c[i], s[i]);
+}
+int launch_debug_sincosf(const float* d_x, int n, float* d_c, float* d_s, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_debug_sincosf, dim3((n + 255) / 256), dim3(256), 0, st, d_x, n, d_c, d_s);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
 // Workgroup = 64 keypoints of one image, three phases:
 //   A. IC_Angle moments (exact int32). A 16-lane row of a wave owns one keypoint; its 279 dword tasks (31 rows x 9
 //      aligned dwords) are masked with the precomputed disc mask and reduced with v_dot4_u32_u8:
 //      sum(val) and sum((u + 32) * val) per dword, m01 += v * sum(val).
-//   B. one LANE per keypoint: fastAtan2 + (float)cos/sin((double)rad) -- the double-precision sincos is ~200
-//      instructions, so it is issued once per 64 keypoints instead of once per keypoint-wave -- and the cv::KeyPoint.
+//   B. one LANE per keypoint: fastAtan2 + libm's cosf / sinf (glibc_sincosf: the reference calls the float overloads,
+//      ORBextractor.cc:112-113) -- issued once per 64 keypoints instead of once per keypoint-wave -- and the cv::KeyPoint.
 //   C. one wave per keypoint: 37x64 B blurred neighbourhood -> LDS (16-byte loads), 4 rounds of 64 rBRIEF tests.
 __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
                                                   const SelKp* __restrict__ sel, const int32_t* __restrict__ img_off,
                                                   const int32_t* __restrict__ lvl_cnt, dcs_keypoint* __restrict__ kp_out,
-                                                  uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out, int n_images, int chunks)
+                                                  uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out, int n_images, int chunks,
+                                                  const int32_t* __restrict__ dense_total, int dense_cap)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][kPatchRows * kPatchDw];
     __shared__ float4 s_pattern[256];
@@ -842,6 +894,13 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
     int img, chunk;
     xcd_image_block(blockIdx.x, n_images, chunks, img, chunk);
     const int i0 = chunk * kDescKp;
+    // The batch's FAST candidates did not fit the handle's dense buffer (k_gather dropped the excess): nothing downstream of
+    // it is the reference's result, so every image of the call reports DCS_ERR_CAPACITY in place of a count -- the
+    // asynchronous API has no other way to fail, and a negative count cannot be mistaken for features.
+    if (dense_total && *dense_total > dense_cap) {
+        if (chunk == 0 && tid == 0) n_out[img] = DCS_ERR_CAPACITY;
+        return;
+    }
     int n_img;
     if (lvl_cnt) {                                           // device quadtree: per-level slots, level-major output order
         int acc = 0;
@@ -920,13 +979,13 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
         }
     }
     __syncthreads();
-    // ---- B. orientation, steering coefficients a = (float)cos((double)rad), b = (float)sin((double)rad), keypoint
+    // ---- B. orientation, steering coefficients a = cosf(rad), b = sinf(rad) exactly as libm computes them (glibc_sincosf), keypoint
     if (tid < n_here) {
         const SelKp k = s_sel[tid];
         const float angle = fast_atan2_deg((float)s_m01[tid], (float)s_m10[tid]);
         const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
         const float rad = __fmul_rn(angle, factorPI);
-        s_cos[tid] = (float)cos((double)rad); s_sin[tid] = (float)sin((double)rad);
+        glibc_sincosf(rad, s_cos[tid], s_sin[tid]);
         dcs_keypoint o;
         const int level = k.level;
         const float sc = prm.scale[level];
@@ -986,11 +1045,11 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
 
 int launch_describe(const LevelSet& raw, const LevelSet& blurred, const DescribeParams& prm, const SelKp* d_sel,
                     const int32_t* d_img_off, const int32_t* d_lvl_cnt, int n_images, int max_per_image, dcs_keypoint* d_kp,
-                    uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s)
+                    uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s, const int32_t* d_dense_total, int dense_cap)
 {
     const int gx = max_per_image > 0 ? (max_per_image + kDescKp - 1) / kDescKp : 1;
     hipLaunchKernelGGL(k_describe, dim3(gx * n_images), dim3(256), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
-                       d_desc, cap, d_n_out, n_images, gx);
+                       d_desc, cap, d_n_out, n_images, gx, d_dense_total, dense_cap);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

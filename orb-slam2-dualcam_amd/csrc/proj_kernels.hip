@@ -321,8 +321,10 @@ __global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f, ProjQu
             }
         }
         __syncthreads();
-        if (s_first == 0x7FFFFFFF) break;                      // everything decided
-        const int first_ovf = s_firstovf;
+        // both words are read HERE, between two barriers, by every thread: thread 0 resets them at the top of the next round
+        // without a barrier in between, so a later read could see the reset value and desynchronise the barrier phases
+        const int first = s_first, first_ovf = s_firstovf;
+        if (first == 0x7FFFFFFF) break;                        // everything decided
         for (int qi = tid; qi < q.n; qi += kResT) {
             if (state[qi]) continue;
             const int n = cand_n[qi];
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f, ProjQu
             state[qi] = 1;
         }
         __syncthreads();
-        if (first_ovf == s_first) {                             // the earliest undecided query has an oversized window: wave 0 walks it
+        if (first_ovf == first) {                               // the earliest undecided query has an oversized window: wave 0 walks it
             if (tid < 64) {
                 const int qi = first_ovf;
                 unsigned long long b1 = ~0ull, b2 = ~0ull;
@@ -510,6 +512,17 @@ int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* q
         (check_orientation && nq && !qs->angle)) { set_error("null array"); return DCS_ERR_INVALID; }
     const int n_entries = fr->grid_off[cells];
     if (n_entries < 0 || n_entries > N) { set_error("grid CSR inconsistent"); return DCS_ERR_INVALID; }
+    for (int c = 0; c <= C; ++c) if (fr->cam_off[c] < 0 || (c && fr->cam_off[c] < fr->cam_off[c - 1])) { set_error("cam_off not ascending"); return DCS_ERR_INVALID; }
+    // a malformed grid would index features / LDS maps out of bounds on the device: offsets ascending, every entry a local index of its camera
+    for (int c = 0; c < C; ++c) {
+        const int n_cam = fr->cam_off[c + 1] - fr->cam_off[c], c0 = c * DCS_GRID_COLS * DCS_GRID_ROWS;
+        for (int k = c0; k < c0 + DCS_GRID_COLS * DCS_GRID_ROWS; ++k) {
+            const int a = fr->grid_off[k], b = fr->grid_off[k + 1];
+            if (a < 0 || b < a || b > n_entries) { set_error("grid_off not ascending at cell %d", k); return DCS_ERR_INVALID; }
+            for (int e = a; e < b; ++e)
+                if (fr->grid_idx[e] < 0 || fr->grid_idx[e] >= n_cam) { set_error("grid_idx[%d] = %d outside camera %d (%d features)", e, fr->grid_idx[e], c, n_cam); return DCS_ERR_INVALID; }
+        }
+    }
     for (int i = 0; i < N; ++i) if (fr->kp_octave[i] < 0 || fr->kp_octave[i] > 15) { set_error("octave of feature %d outside 0..15", i); return DCS_ERR_INVALID; }
     for (int i = 0; i < nq; ++i) if (qs->valid[i] && (qs->cam[i] < 0 || qs->cam[i] >= C)) { set_error("query %d: camera out of range", i); return DCS_ERR_INVALID; }
     int rc = ensure_device();

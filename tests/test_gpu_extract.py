@@ -252,3 +252,45 @@ def test_general_quadtree_kernel_alone(tmp_path):
     env = dict(os.environ, DCS_OCTREE_FORCE_GENERAL="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "general-ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_candidate_buffer_overflow_is_reported_in_band(tmp_path):
+    """The asynchronous device API cannot return an error after the fact: when the FAST candidates of a batch exceed the
+    handle's dense buffer (provoked here with the DCS_ORB_DENSE_CAP test hook, read at handle creation, hence the subprocess)
+    every count of the call is DCS_ERR_CAPACITY (-2) instead of a number of keypoints, and the host-buffer API fails."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from conftest import load_pkg\n"
+        "pkg = load_pkg()\n"
+        "imgs = list(pkg.synth.frame_pair(640, 480, 4, 1))\n"
+        "e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)\n"
+        "cap = e.default_cap()\n"
+        "d_img = torch.from_numpy(np.stack(imgs)).cuda()\n"
+        "d_kp = torch.zeros((2, cap, 7), dtype=torch.float32, device='cuda'); d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device='cuda')\n"
+        "d_n = torch.full((2,), 7, dtype=torch.int32, device='cuda')\n"
+        "e.extract_batch_device(d_img, d_kp, d_desc, d_n, cap, stream=torch.cuda.current_stream().cuda_stream)\n"
+        "torch.cuda.synchronize()\n"
+        "assert d_n.tolist() == [-2, -2], d_n.tolist()\n"
+        "try:\n"
+        "    e.extract_batch(imgs)\n"
+        "    raise SystemExit('host API did not fail')\n"
+        "except pkg.DcsError as ex:\n"
+        "    assert ex.rc == -2, ex.rc\n"
+        "print('overflow reported')\n"
+    ) % os.path.join(root, "tests")
+    env = dict(os.environ, DCS_ORB_DENSE_CAP="3000")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "overflow reported" in p.stdout, p.stdout + p.stderr
+
+
+def test_gpu_sincosf_equals_libm(pkg, oracle):
+    """The describe kernel's steering coefficients: glibc's cosf / sinf evaluated on the GPU, bit for bit the host libm's
+    (the functions the reference calls, ORBextractor.cc:112-113), on 4 M angles of [0, 2 pi] and the quadrant boundaries."""
+    hi = np.float32(6.2832).view(np.uint32)
+    x = np.arange(0, int(hi), 263, dtype=np.uint32).view(np.float32)
+    x = np.concatenate([x, (np.linspace(0, 360, 100001, dtype=np.float32) * np.float32(np.float32(3.1415926535897932384626433832795) / np.float32(180.0)))])
+    gc, gs = pkg.abi.debug_sincosf(x)
+    hc, hs = oracle.sincosf(x)
+    assert np.array_equal(gc.view(np.uint32), hc.view(np.uint32)) and np.array_equal(gs.view(np.uint32), hs.view(np.uint32))
