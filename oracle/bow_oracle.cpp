@@ -40,6 +40,22 @@ int forb_distance(const unsigned char* a, const unsigned char* b)     // FORB.cp
     return dist;
 }
 
+// BowVector::addWeight (BowVector.cpp:34-46) / addIfNotExist (:50-58)
+void bow_add(std::map<unsigned, double>& bow, unsigned wid, double w, bool if_not_exist)
+{
+    auto it = bow.lower_bound(wid);
+    if (!if_not_exist) { if (it != bow.end() && it->first == wid) it->second += w; else bow.insert(it, {wid, w}); }
+    else if (it == bow.end() || it->first != wid) bow.insert(it, {wid, w});
+}
+// BowVector::normalize (BowVector.cpp:62-88): sum in ascending word order, then one division per entry
+void bow_normalize(std::map<unsigned, double>& bow, bool l2)
+{
+    double norm = 0.0;
+    if (!l2) for (auto& kv : bow) norm += std::fabs(kv.second);
+    else { for (auto& kv : bow) norm += kv.second * kv.second; norm = std::sqrt(norm); }
+    if (norm > 0.0) for (auto& kv : bow) kv.second /= norm;
+}
+
 }  // namespace
 
 struct orc_vocab {
@@ -105,13 +121,7 @@ int orc_bow_transform(const orc_vocab* v, const uint8_t* desc, int n, int levels
         const double w = v->nodes[final_id].weight;
         const int wid = v->nodes[final_id].word_id;
         if (w > 0) {                                                      // not stopped (:1181)
-            if (tf) {                                                     // addWeight (BowVector.cpp:34-46)
-                auto it = bow.lower_bound((unsigned)wid);
-                if (it != bow.end() && it->first == (unsigned)wid) it->second += w; else bow.insert(it, {(unsigned)wid, w});
-            } else {                                                      // addIfNotExist (:50-58)
-                auto it = bow.lower_bound((unsigned)wid);
-                if (it == bow.end() || it->first != (unsigned)wid) bow.insert(it, {(unsigned)wid, w});
-            }
+            bow_add(bow, (unsigned)wid, w, !tf);
             fv[(unsigned)nid].push_back((unsigned)i);                     // addFeature (FeatureVector.cpp:31-45)
             if (word) word[i] = wid;
             if (node) node[i] = nid;
@@ -124,12 +134,7 @@ int orc_bow_transform(const orc_vocab* v, const uint8_t* desc, int n, int levels
         const double nd = (double)bow.size();
         for (auto& kv : bow) kv.second /= nd;
     }
-    if (must) {                                                           // BowVector::normalize (:62-88)
-        double norm = 0.0;
-        if (!l2) for (auto& kv : bow) norm += std::fabs(kv.second);
-        else { for (auto& kv : bow) norm += kv.second * kv.second; norm = std::sqrt(norm); }
-        if (norm > 0.0) for (auto& kv : bow) kv.second /= norm;
-    }
+    if (must) bow_normalize(bow, l2);
     int a = 0;
     for (auto& kv : bow) { bow_word[a] = (int32_t)kv.first; bow_val[a] = kv.second; ++a; }
     *n_words = a;
@@ -142,6 +147,17 @@ int orc_bow_transform(const orc_vocab* v, const uint8_t* desc, int n, int levels
     fv_off[b] = o;
     *n_nodes = b;
     return 0;
+}
+
+/* the accumulation of transform() alone (same helpers as orc_bow_transform): for the checks against oracle/_ref */
+int orc_bow_vector(int n, const uint32_t* word, const double* weight, int if_not_exist, int norm, int32_t* out_word, double* out_val)
+{
+    std::map<unsigned, double> bow;
+    for (int i = 0; i < n; ++i) if (weight[i] > 0) bow_add(bow, word[i], weight[i], if_not_exist != 0);
+    if (norm) bow_normalize(bow, norm == 2);
+    int a = 0;
+    for (auto& kv : bow) { out_word[a] = (int32_t)kv.first; out_val[a] = kv.second; ++a; }
+    return a;
 }
 
 void orc_bow_score_l1(const int32_t* q_word, const double* q_val, int nq, const int32_t* db_off, const int32_t* db_word,

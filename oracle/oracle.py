@@ -20,13 +20,75 @@ assert KEYPOINT.itemsize == 28 and CANDIDATE.itemsize == 8
 
 def build(force=False):
     """Compile oracle/*.cpp into oracle/_build/liboracle.so (g++ -O3, no -march=native)."""
-    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp",
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp", "bow_oracle.cpp",
                                              "oracle.h", "brief_pattern.inc", "Makefile")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
+
+
+REFERENCE_DIR = os.environ.get("DCS_REFERENCE_DIR", "/root/reference")
+_REF_PATH = os.path.join(_HERE, "_ref", "libref.so")
+_ref = None
+
+
+def build_ref():
+    """oracle/_ref/libref.so: the dependency-free pieces of the REAL reference (DBoW2 BowVector / FeatureVector / ScoringObject,
+    the Hamming loops of ORBmatcher::DescriptorDistance and FORB::distance) compiled from where they lie (Makefile target
+    `ref`, ref_shim.cpp). Returns the path, or None where the reference tree does not exist (the GPU box)."""
+    if os.path.isdir(REFERENCE_DIR):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref", "REF=" + REFERENCE_DIR])
+    return _REF_PATH if os.path.exists(_REF_PATH) else None
+
+
+def ref():
+    """ctypes handle of oracle/_ref/libref.so or None"""
+    global _ref
+    if _ref is None:
+        path = build_ref()
+        if path is None:
+            return None
+        L = C.CDLL(path)
+        vp, ci = C.c_void_p, C.c_int
+        L.ref_descriptor_distance.argtypes = [vp, vp]
+        L.ref_forb_distance.argtypes = [vp, vp]
+        L.ref_bow_vector.argtypes = [ci, vp, vp, ci, ci, vp, vp]
+        L.ref_score.argtypes = [ci, ci, vp, vp, ci, vp, vp]
+        L.ref_score.restype = C.c_double
+        L.ref_feature_vector.argtypes = [ci, vp, vp, vp, vp]
+        _ref = L
+    return _ref
+
+
+def ref_distances(a, b):
+    """(ORBmatcher::DescriptorDistance, FORB::distance) of descriptor rows a[i], b[i] through the reference's own loops"""
+    a, b = _c(a, np.uint8).reshape(-1, 32), _c(b, np.uint8).reshape(-1, 32)
+    L = ref()
+    d1 = np.array([L.ref_descriptor_distance(a[i].ctypes.data, b[i].ctypes.data) for i in range(len(a))], np.int32)
+    d2 = np.array([L.ref_forb_distance(a[i].ctypes.data, b[i].ctypes.data) for i in range(len(a))], np.int32)
+    return d1, d2
+
+
+def ref_bow_vector(word, weight, if_not_exist=False, norm=1):
+    word, weight = _c(word, np.uint32), _c(weight, np.float64)
+    ow, ov = np.zeros(max(len(word), 1), np.uint32), np.zeros(max(len(word), 1))
+    n = ref().ref_bow_vector(len(word), _p(word), _p(weight), int(if_not_exist), int(norm), _p(ow), _p(ov))
+    return ow[:n].astype(np.int32), ov[:n].copy()
+
+
+def ref_score(kind, w1, v1, w2, v2):
+    w1, w2, v1, v2 = _c(w1, np.uint32), _c(w2, np.uint32), _c(v1, np.float64), _c(v2, np.float64)
+    return float(ref().ref_score(int(kind), len(w1), _p(w1), _p(v1), len(w2), _p(w2), _p(v2)))
+
+
+def ref_feature_vector(node):
+    node = _c(node, np.uint32)
+    n = len(node)
+    on, oo, oi = np.zeros(max(n, 1), np.uint32), np.zeros(n + 1, np.int32), np.zeros(max(n, 1), np.uint32)
+    k = ref().ref_feature_vector(n, _p(node), _p(on), _p(oo), _p(oi))
+    return on[:k].astype(np.int32), oo[:k + 1].copy(), oi[:oo[k]].astype(np.int32)
 
 
 class BaCamera(C.Structure):
@@ -501,6 +563,22 @@ class Vocabulary:
             raise RuntimeError("orc_bow_transform rc=%d" % rc)
         return dict(word=word[:n], node=node[:n], bow_word=bw[:nw.value].copy(), bow_val=bv[:nw.value].copy(), fv_node=fn[:nn.value].copy(),
                     fv_off=fo[:nn.value + 1].copy(), fv_idx=fi[:fo[nn.value]].copy())
+
+
+def bow_vector(word, weight, if_not_exist=False, norm=1):
+    """the oracle's BowVector accumulation (addWeight / addIfNotExist in feature order) + normalize, as transform() runs it"""
+    word, weight = _c(word, np.uint32), _c(weight, np.float64)
+    ow, ov = np.zeros(max(len(word), 1), np.int32), np.zeros(max(len(word), 1))
+    fn = lib().orc_bow_vector
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = fn(len(word), _p(word), _p(weight), int(if_not_exist), int(norm), _p(ow), _p(ov))
+    return ow[:n].copy(), ov[:n].copy()
+
+
+def descriptor_distances(a, b):
+    a, b = _c(a, np.uint8).reshape(-1, 32), _c(b, np.uint8).reshape(-1, 32)
+    L = lib()
+    return np.array([L.orc_descriptor_distance(a[i].ctypes.data, b[i].ctypes.data) for i in range(len(a))], np.int32)
 
 
 def bow_score_l1(q_word, q_val, db_off, db_word, db_val):

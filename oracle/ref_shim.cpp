@@ -1,0 +1,89 @@
+// ref_shim.cpp -- C entry points around the pieces of the REAL reference that compile here without OpenCV / Eigen
+// (test infrastructure, built into oracle/_ref/libref.so by `make ref`, only where /root/reference exists):
+//   * Thirdparty/DBoW2/DBoW2/BowVector.cpp, FeatureVector.cpp                       compiled from where they lie, unmodified
+//   * Thirdparty/DBoW2/DBoW2/ScoringObject.cpp                                      unmodified except that its one
+//       `#include "TemplatedVocabulary.h"` (which pulls OpenCV in) is dropped by sed at build time; the declarations it needs
+//       come from the reference's own ScoringObject.h (-include)
+//   * the loops of ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2015-2031) and FORB::distance
+//       (Thirdparty/DBoW2/DBoW2/FORB.cpp:82-102): their statements from `int dist=0;` to `return dist;` are cut out by awk at build
+//       time into _ref/*.inc (the two lines before them only fetch `const int*` row pointers from cv::Mat)
+// Nothing of the reference is copied into the repository: the generated files live in oracle/_ref/ (git-ignored).
+// The oracle's restatements are checked against these functions in tests/test_oracle_ref.py, and golden vectors produced
+// by them are committed (tests/golden/ref_dbow2.npz, make_golden_ref.py) so that the pin travels to machines without the reference.
+#include <cstdint>
+#include <cstring>
+
+#include "BowVector.h"
+#include "FeatureVector.h"
+#include "ScoringObject.h"
+
+static int ref_orbmatcher_distance(const int* pa, const int* pb)
+{
+#include "orbmatcher_distance_body.inc"
+}
+static int ref_forb_distance_impl(const int* pa, const int* pb)
+{
+#include "forb_distance_body.inc"
+}
+
+extern "C" {
+
+int ref_descriptor_distance(const uint8_t* a, const uint8_t* b)
+{
+    int32_t ra[8], rb[8];
+    memcpy(ra, a, 32); memcpy(rb, b, 32);
+    return ref_orbmatcher_distance(ra, rb);
+}
+int ref_forb_distance(const uint8_t* a, const uint8_t* b)
+{
+    int32_t ra[8], rb[8];
+    memcpy(ra, a, 32); memcpy(rb, b, 32);
+    return ref_forb_distance_impl(ra, rb);
+}
+
+// TemplatedVocabulary::transform's accumulation (TemplatedVocabulary.h:1186-1237): per feature addWeight (TF_IDF, TF) or
+// addIfNotExist (IDF, BINARY) in feature order, then BowVector::normalize. norm: 0 none, 1 L1, 2 L2. Returns the size.
+int ref_bow_vector(int n, const uint32_t* word, const double* weight, int if_not_exist, int norm, uint32_t* out_word, double* out_val)
+{
+    DBoW2::BowVector v;
+    for (int i = 0; i < n; ++i) {
+        if (!(weight[i] > 0)) continue;                       // transform(): `if(w > 0) v.addWeight(id, w);`
+        if (if_not_exist) v.addIfNotExist(word[i], weight[i]); else v.addWeight(word[i], weight[i]);
+    }
+    if (norm == 1) v.normalize(DBoW2::L1); else if (norm == 2) v.normalize(DBoW2::L2);
+    int k = 0;
+    for (DBoW2::BowVector::const_iterator it = v.begin(); it != v.end(); ++it, ++k) { out_word[k] = it->first; out_val[k] = it->second; }
+    return k;
+}
+
+// kind: 0 L1, 1 L2, 2 ChiSquare, 3 KL, 4 Bhattacharyya, 5 DotProduct (the ScoringType order of TemplatedVocabulary.h)
+double ref_score(int kind, int n1, const uint32_t* w1, const double* v1, int n2, const uint32_t* w2, const double* v2)
+{
+    DBoW2::BowVector a, b;
+    for (int i = 0; i < n1; ++i) a.insert(a.end(), std::make_pair(w1[i], v1[i]));
+    for (int i = 0; i < n2; ++i) b.insert(b.end(), std::make_pair(w2[i], v2[i]));
+    switch (kind) {
+    case 0: return DBoW2::L1Scoring().score(a, b);
+    case 1: return DBoW2::L2Scoring().score(a, b);
+    case 2: return DBoW2::ChiSquareScoring().score(a, b);
+    case 3: return DBoW2::KLScoring().score(a, b);
+    case 4: return DBoW2::BhattacharyyaScoring().score(a, b);
+    default: return DBoW2::DotProductScoring().score(a, b);
+    }
+}
+
+// FeatureVector::addFeature for features 0 .. n-1 in order -> CSR (ascending node ids, offsets, feature indices). Returns #nodes.
+int ref_feature_vector(int n, const uint32_t* node, uint32_t* out_node, int32_t* out_off, uint32_t* out_idx)
+{
+    DBoW2::FeatureVector fv;
+    for (int i = 0; i < n; ++i) fv.addFeature(node[i], (unsigned)i);
+    int k = 0, at = 0;
+    for (DBoW2::FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it, ++k) {
+        out_node[k] = it->first; out_off[k] = at;
+        for (size_t j = 0; j < it->second.size(); ++j) out_idx[at++] = it->second[j];
+    }
+    out_off[k] = at;
+    return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Golden vectors produced by the REAL reference code (oracle/_ref/libref.so = DBoW2's BowVector.cpp / FeatureVector.cpp /
+ScoringObject.cpp and the Hamming loops of ORBmatcher.cc / FORB.cpp compiled from /root/reference, see oracle/Makefile `ref`).
+Run in the build container (the reference tree does not travel); the .npz holds inputs and the reference's outputs only."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle as O  # noqa: E402
+
+assert O.ref() is not None, "needs /root/reference"
+rng = np.random.default_rng(2024)
+out = {}
+# Hamming distances: random pairs, near pairs, extremes
+a = rng.integers(0, 256, (512, 32), dtype=np.uint8)
+b = a.copy()
+flip = rng.integers(0, 256, (512, 32), dtype=np.uint8) & rng.integers(0, 256, (512, 32), dtype=np.uint8) & rng.integers(0, 256, (512, 32), dtype=np.uint8)
+b[:256] ^= flip[:256]
+b[256:500] = rng.integers(0, 256, (244, 32), dtype=np.uint8)
+a[500:] = 0; b[500:506] = 255; b[506:] = 0
+out["ham_a"], out["ham_b"] = a, b
+out["ham_orbmatcher"], out["ham_forb"] = O.ref_distances(a, b)
+# BowVector accumulation + normalisation (transform's addWeight / addIfNotExist in feature order) and FeatureVector
+for case, (n, n_words) in enumerate([(1000, 400), (37, 1000000), (2000, 50), (1, 5)]):
+    word = rng.integers(0, n_words, n).astype(np.uint32)
+    wtab = rng.uniform(0.01, 12.0, n_words if n_words < 5000 else 1)
+    weight = wtab[word % len(wtab)]
+    for ine in (0, 1):
+        for norm in (0, 1, 2):
+            w, v = O.ref_bow_vector(word, weight, ine, norm)
+            out["bow%d_%d_%d_word" % (case, ine, norm)], out["bow%d_%d_%d_val" % (case, ine, norm)] = w, v
+    out["bow%d_in_word" % case], out["bow%d_in_weight" % case] = word, weight
+    node = rng.integers(0, max(n_words // 7, 2), n).astype(np.uint32)
+    fn, fo, fi = O.ref_feature_vector(node)
+    out["fv%d_in" % case], out["fv%d_node" % case], out["fv%d_off" % case], out["fv%d_idx" % case] = node, fn, fo, fi
+# scores of every ScoringType on L1-normalised sparse vectors (the state DBoW2 scores in)
+vecs = []
+for n in (300, 300, 40, 1200, 1, 0):
+    w = np.unique(rng.integers(0, 2000, n)).astype(np.uint32)
+    v = rng.uniform(0.0, 1.0, len(w))
+    if len(w):
+        v /= v.sum()
+    vecs.append((w, v))
+for i, (w, v) in enumerate(vecs):
+    out["sv%d_word" % i], out["sv%d_val" % i] = w, v
+sc = np.zeros((6, len(vecs), len(vecs)))
+for k in range(6):
+    for i, (w1, v1) in enumerate(vecs):
+        for j, (w2, v2) in enumerate(vecs):
+            sc[k, i, j] = O.ref_score(k, w1, v1, w2, v2)
+out["scores"] = sc
+np.savez_compressed(os.path.join(HERE, "ref_dbow2.npz"), **out)
+print("ref_dbow2.npz:", len(out), "arrays")

@@ -119,3 +119,16 @@ def test_bow_golden(pkg):
     s = pkg.ORBVocabulary.score(r2["bow_word"], r2["bow_val"], off, np.concatenate([r["bow_word"], r2["bow_word"]]), np.concatenate([r["bow_val"], r2["bow_val"]]))
     assert s.tobytes() == g["score_half_vs_full_and_self"].tobytes()
     V.close()
+
+
+def test_gpu_l1_score_equals_reference_scoring_object(pkg):
+    """dcs_bow_score_l1 against golden scores produced by the REAL DBoW2 L1Scoring::score (oracle/_ref, compiled from
+    /root/reference/Thirdparty/DBoW2/DBoW2/ScoringObject.cpp; tests/golden/make_golden_ref.py): f64 values bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_dbow2.npz"))
+    n = g["scores"].shape[1]
+    vecs = [(g["sv%d_word" % i].astype(np.int32), g["sv%d_val" % i]) for i in range(n)]
+    off = np.cumsum([0] + [len(w) for w, _ in vecs]).astype(np.int32)
+    dbw, dbv = np.concatenate([w for w, _ in vecs]), np.concatenate([v for _, v in vecs])
+    for i, (w, v) in enumerate(vecs):
+        s = pkg.ORBVocabulary.score(w, v, off, dbw, dbv)
+        assert np.array_equal(np.asarray(s).view(np.uint64), g["scores"][0, i].view(np.uint64)), i

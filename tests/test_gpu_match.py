@@ -199,3 +199,17 @@ def test_is_in_frustum_and_projection_chain(pkg, oracle, synth):
     mq, qf, n = pkg.ORBmatcher(0.8, False).SearchByProjection(pf, q, 100, use_ratio=True, check_orientation=False)
     emq, eqf, en = oracle.search_by_projection(pf, qo, 100, 0.8, False)
     assert np.array_equal(mq, emq) and np.array_equal(qf, eqf) and n == en and n > 0.6 * N
+
+
+def test_gpu_hamming_equals_reference_descriptor_distance(pkg):
+    """Both GPU Hamming kernels (i8 matrix cores, VALU popcount) against distances produced by the reference's own
+    ORBmatcher::DescriptorDistance loop (oracle/_ref; golden: tests/golden/ref_dbow2.npz): one query per train row."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_dbow2.npz"))
+    a, b, d = g["ham_a"], g["ham_b"], g["ham_orbmatcher"]
+    for i in range(0, len(a), 37):                                   # row i of b alone as train set: best distance = d(a_i, b_i)
+        bi, bd, sd = pkg.ORBmatcher.knn2(a[i:i + 1], b[i:i + 1])
+        assert int(bd[0]) == int(d[i]) and int(bi[0]) == 0
+    bi, bd, sd = pkg.ORBmatcher.knn2(a, b)                           # full table: minimum over the reference-checked popcounts
+    full = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+    assert np.array_equal(np.diag(full), d) and np.array_equal(bd, full.min(1))
