@@ -476,6 +476,27 @@ def main():
                           "ms_per_dual_frame": round(tl * 1e3, 3), "ms_extract": round(t_ext / reps * 1e3, 3), "ms_match": round((tl - t_ext / reps) * 1e3, 3),
                           "kfeatures_s": round((len(kps[0]) + len(kps[1])) / tl / 1e3, 2)}
         ext1.close()
+        # per-call latency of the other host-buffer seams (each = what one ORBmatcher member call of the reference costs here)
+        seam = {}
+        O_ = entry.load_oracle() if args.cpu_seconds > 0 else None
+
+        def per_call(fn, reps=30):
+            for _ in range(3):
+                fn()
+            t0_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return round((time.perf_counter() - t0_) / reps * 1e3, 4)
+        seam["dcs_match_bf_ms"] = per_call(lambda: m1.match_bf(descs[0], kps[0], descs[1], kps[1], 50))
+        seam["dcs_hamming_knn2_ms"] = per_call(lambda: pkg.ORBmatcher.knn2(descs[0], descs[1]))
+        fr_, q_ = synth.projection_problem(n_per_cam=1000, n_queries=800, seed=13)
+        fr_["grid_off"], fr_["grid_idx"] = pkg.frame_grid(fr_["cam_off"], fr_["kp_x"], fr_["kp_y"], fr_["min_x"], fr_["min_y"], fr_["grid_w_inv"], fr_["grid_h_inv"])
+        seam["dcs_search_by_projection_ms"] = per_call(lambda: m1.SearchByProjection(fr_, q_, 100, use_ratio=True, check_orientation=False))
+        fvk, fvf = synth.csr_buckets(len(descs[0]), 100, seed=100), synth.csr_buckets(len(descs[1]), 100, seed=101)
+        ones = np.ones(len(descs[0]), np.uint8)
+        seam["dcs_search_by_bow_ms"] = per_call(lambda: m1.SearchByBoWCrossCam(descs[0], kps[0]["angle"], ones, descs[1], kps[1]["angle"], fvk, fvf))
+        seam["note"] = "host buffers in, host buffers out, synchronous; ~1000 x 1000 features; ctypes call overhead included"
+        out["seam_latency"] = seam
         host_imgs = [pipe.host_imgs[i] for i in range(2 * P)]
         ext.extract_batch(host_imgs)
         reps, t0 = 3, time.perf_counter()

@@ -369,18 +369,21 @@ int dcs_bow_transform(const dcs_vocab* v, const uint8_t* desc, int n, int levels
     if ((rc = s.upload(&dd, desc, (size_t)n * 32)) || (rc = s.upload(&dn, &n, 1)) || (rc = s.alloc(&dw, n)) || (rc = s.alloc(&dnd, n)) || (rc = s.alloc(&dwt, n)) ||
         (rc = s.alloc(&dbw, n)) || (rc = s.alloc(&dbv, n)) || (rc = s.alloc(&dbn, 1)) || (rc = s.alloc(&dfn, n)) || (rc = s.alloc(&dfo, n + 1)) ||
         (rc = s.alloc(&dfi, n)) || (rc = s.alloc(&dfc, 1))) return rc;
-    if ((rc = dcs_bow_transform_device(v, dd, dn, 1, n, levelsup, dw, dnd, dwt, dbw, dbv, dbn, dfn, dfo, dfi, dfc, nullptr))) return rc;
+    if ((rc = dcs_bow_transform_device(v, dd, dn, 1, n, levelsup, dw, dnd, dwt, dbw, dbv, dbn, dfn, dfo, dfi, dfc, s.st))) return rc;
+    // one round trip: the counts and the arrays they delimit come back together, then only the valid prefixes are handed over
+    std::vector<int32_t> h_bw(n), h_fn(n), h_fo(n + 1), h_fi(n);
+    std::vector<double> h_bv(n);
     int32_t nw = 0, nn = 0;
-    DCS_HIP(hipMemcpy(&nw, dbn, 4, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(&nn, dfc, 4, hipMemcpyDeviceToHost));
-    if (word) DCS_HIP(hipMemcpy(word, dw, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    if (node) DCS_HIP(hipMemcpy(node, dnd, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    if (nw) { DCS_HIP(hipMemcpy(bow_word, dbw, sizeof(int32_t) * nw, hipMemcpyDeviceToHost)); DCS_HIP(hipMemcpy(bow_val, dbv, sizeof(double) * nw, hipMemcpyDeviceToHost)); }
-    DCS_HIP(hipMemcpy(fv_off, dfo, sizeof(int32_t) * (nn + 1), hipMemcpyDeviceToHost));
-    if (nn) {
-        DCS_HIP(hipMemcpy(fv_node, dfn, sizeof(int32_t) * nn, hipMemcpyDeviceToHost));
-        DCS_HIP(hipMemcpy(fv_idx, dfi, sizeof(int32_t) * fv_off[nn], hipMemcpyDeviceToHost));
-    }
+    if ((rc = s.download_bytes(&nw, dbn, 4)) || (rc = s.download_bytes(&nn, dfc, 4))) return rc;
+    if (word && (rc = s.download_bytes(word, dw, sizeof(int32_t) * n))) return rc;
+    if (node && (rc = s.download_bytes(node, dnd, sizeof(int32_t) * n))) return rc;
+    if ((rc = s.download_bytes(h_bw.data(), dbw, sizeof(int32_t) * n)) || (rc = s.download_bytes(h_bv.data(), dbv, sizeof(double) * n)) ||
+        (rc = s.download_bytes(h_fn.data(), dfn, sizeof(int32_t) * n)) || (rc = s.download_bytes(h_fo.data(), dfo, sizeof(int32_t) * (n + 1))) ||
+        (rc = s.download_bytes(h_fi.data(), dfi, sizeof(int32_t) * n))) return rc;
+    if ((rc = s.finish())) return rc;
+    if (nw) { memcpy(bow_word, h_bw.data(), sizeof(int32_t) * nw); memcpy(bow_val, h_bv.data(), sizeof(double) * nw); }
+    memcpy(fv_off, h_fo.data(), sizeof(int32_t) * (nn + 1));
+    if (nn) { memcpy(fv_node, h_fn.data(), sizeof(int32_t) * nn); memcpy(fv_idx, h_fi.data(), sizeof(int32_t) * h_fo[nn]); }
     *n_words = nw; *n_nodes = nn;
     return DCS_OK;
 }
@@ -401,10 +404,10 @@ int dcs_bow_score_l1(const int32_t* q_word, const double* q_val, int nq, const i
     int32_t *dqw, *dof, *dbw; double *dqv, *dbv, *dsc;
     if ((rc = s.upload(&dqw, q_word, nq)) || (rc = s.upload(&dqv, q_val, nq)) || (rc = s.upload(&dof, db_off, (size_t)n_db + 1)) ||
         (rc = s.upload(&dbw, db_word, db_off[n_db])) || (rc = s.upload(&dbv, db_val, db_off[n_db])) || (rc = s.alloc(&dsc, n_db))) return rc;
-    hipLaunchKernelGGL(k_bow_score_l1, dim3((n_db + 255) / 256), dim3(256), 0, 0, dqw, dqv, nq, dof, dbw, dbv, n_db, dsc);
+    hipLaunchKernelGGL(k_bow_score_l1, dim3((n_db + 255) / 256), dim3(256), 0, s.st, dqw, dqv, nq, dof, dbw, dbv, n_db, dsc);
     DCS_CHECK_LAUNCH();
-    DCS_HIP(hipMemcpy(score, dsc, sizeof(double) * n_db, hipMemcpyDeviceToHost));
-    return DCS_OK;
+    if ((rc = s.download_bytes(score, dsc, sizeof(double) * n_db))) return rc;
+    return s.finish();
 }
 
 }  // extern "C"

@@ -1,6 +1,7 @@
 // common.cpp -- error text, device probing, version.
 #include "common.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace dcs {
@@ -26,6 +27,58 @@ int ensure_device()
     }
     return DCS_OK;
 }
+
+ThreadArena::~ThreadArena() { release(); }
+
+void ThreadArena::release()
+{
+    for (Block& b : dev) (void)hipFree(b.p);
+    for (Block& b : pin) (void)hipHostFree(b.p);
+    dev.clear(); pin.clear();
+    if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr; device = -1; dev_used = pin_used = 0;
+}
+
+int ThreadArena::begin()
+{
+    int d = 0;
+    DCS_HIP(hipGetDevice(&d));
+    if (device != d) release();
+    device = d;
+    if (!stream) DCS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    dev_peak = std::max(dev_peak, dev_call); pin_peak = std::max(pin_peak, pin_call);
+    dev_call = pin_call = 0;
+    // a previous call that outgrew its block left several behind: replace them by ONE of the peak size (nothing is in
+    // flight: every call ends with a stream synchronisation)
+    if (dev.size() > 1) { for (Block& b : dev) (void)hipFree(b.p); dev.clear(); }
+    if (pin.size() > 1) { for (Block& b : pin) (void)hipHostFree(b.p); pin.clear(); }
+    dev_used = pin_used = 0;
+    return DCS_OK;
+}
+
+void* ThreadArena::take(bool pinned, size_t bytes)
+{
+    std::vector<Block>& blocks = pinned ? pin : dev;
+    size_t& used = pinned ? pin_used : dev_used;
+    size_t& call = pinned ? pin_call : dev_call;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    call += need;
+    if (blocks.empty() || used + need > blocks.back().cap) {
+        const size_t peak = pinned ? pin_peak : dev_peak;
+        size_t cap = std::max<size_t>({need, peak + peak / 4, (size_t)1 << 20});
+        if (!blocks.empty()) cap = std::max(cap, 2 * blocks.back().cap);
+        Block b{nullptr, cap};
+        const hipError_t e = pinned ? hipHostMalloc((void**)&b.p, cap, hipHostMallocDefault) : hipMalloc((void**)&b.p, cap);
+        if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        blocks.push_back(b);
+        used = 0;
+    }
+    void* p = blocks.back().p + used;
+    used += need;
+    return p;
+}
+
+ThreadArena& thread_arena() { static thread_local ThreadArena a; return a; }
 
 }  // namespace dcs
 

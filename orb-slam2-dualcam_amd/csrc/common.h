@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -56,23 +57,49 @@ struct PinnedBuf {
     }
 };
 
-// per-call device scratch of the host-buffer entry points (re-entrant: nothing is cached between calls)
+// Scratch of the host-buffer entry points (what the reference's Tracking / LocalMapping / LoopClosing threads call
+// concurrently, dcs_abi.h "threading"). Everything a call needs comes out of a PER-THREAD context that lives across calls:
+// a non-blocking stream (nothing touches the legacy null stream, so calls of different threads never serialise on it), a
+// grow-only device arena and a grow-only pinned staging arena (no hipMalloc / hipFree / hipHostMalloc on the steady-state
+// path: those cost more than the kernels of a 1000 x 1000 match). Uploads and downloads are asynchronous copies through the
+// pinned arena; finish() is the call's single synchronisation and scatters the downloads into the caller's buffers.
+struct ThreadArena {
+    struct Block { char* p; size_t cap; };
+    std::vector<Block> dev, pin;
+    size_t dev_used = 0, pin_used = 0, dev_peak = 0, pin_peak = 0;      // offsets inside the LAST block / peak demand of a call
+    size_t dev_call = 0, pin_call = 0;
+    hipStream_t stream = nullptr;
+    int device = -1;
+    ~ThreadArena();
+    void release();
+    int begin();                                         // start of a call: rewind, coalesce fragmented blocks into one
+    void* take(bool pinned, size_t bytes);               // 256-byte aligned; nullptr on allocation failure
+};
+ThreadArena& thread_arena();
+
 struct Scratch {
-    std::vector<void*> ptrs;
-    Scratch() = default;
+    ThreadArena& a;
+    hipStream_t st = nullptr;
+    struct Pending { void* dst; const void* src; size_t bytes; };
+    std::vector<Pending> pending;
+    int rc0;
+    Scratch() : a(thread_arena()) { rc0 = a.begin(); st = a.stream; }
     Scratch(const Scratch&) = delete;
     Scratch& operator=(const Scratch&) = delete;
-    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    ~Scratch() { if (!pending.empty() && st) (void)hipStreamSynchronize(st); }
     template <typename T> int alloc(T** out, size_t n) {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
-        if (e != hipSuccess) { set_error("hipMalloc: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
-        ptrs.push_back(p); *out = (T*)p; return DCS_OK;
+        if (rc0) return rc0;
+        void* p = a.take(false, std::max<size_t>(n, 1) * sizeof(T));
+        if (!p) { set_error("device scratch: out of memory"); return DCS_ERR_HIP; }
+        *out = (T*)p; return DCS_OK;
     }
     template <typename T> int upload(T** out, const T* src, size_t n) {
         int rc = alloc(out, n);
-        if (rc) return rc;
-        if (n) DCS_HIP(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice));
+        if (rc || n == 0) return rc;
+        void* h = a.take(true, n * sizeof(T));
+        if (!h) { set_error("pinned scratch: out of memory"); return DCS_ERR_HIP; }
+        memcpy(h, src, n * sizeof(T));
+        DCS_HIP(hipMemcpyAsync(*out, h, n * sizeof(T), hipMemcpyHostToDevice, st));
         return DCS_OK;
     }
     template <typename T> int upload(const T** out, const T* src, size_t n) {
@@ -80,6 +107,32 @@ struct Scratch {
         int rc = upload(&d, src, n);
         *out = d;
         return rc;
+    }
+    // host -> an already carved device range (several host arrays into one device array)
+    template <typename T> int upload_into(T* d_dst, const T* src, size_t n) {
+        if (rc0) return rc0;
+        if (n == 0) return DCS_OK;
+        void* h = a.take(true, n * sizeof(T));
+        if (!h) { set_error("pinned scratch: out of memory"); return DCS_ERR_HIP; }
+        memcpy(h, src, n * sizeof(T));
+        DCS_HIP(hipMemcpyAsync(d_dst, h, n * sizeof(T), hipMemcpyHostToDevice, st));
+        return DCS_OK;
+    }
+    // asynchronous device -> caller copy: lands in `dst` at the next finish()
+    template <typename T> int download(T* dst, const T* d_src, size_t n) {
+        if (n == 0) return DCS_OK;
+        void* h = a.take(true, n * sizeof(T));
+        if (!h) { set_error("pinned scratch: out of memory"); return DCS_ERR_HIP; }
+        DCS_HIP(hipMemcpyAsync(h, d_src, n * sizeof(T), hipMemcpyDeviceToHost, st));
+        pending.push_back({dst, h, n * sizeof(T)});
+        return DCS_OK;
+    }
+    int download_bytes(void* dst, const void* d_src, size_t bytes) { return download((char*)dst, (const char*)d_src, bytes); }
+    int finish() {
+        DCS_HIP(hipStreamSynchronize(st));
+        for (const Pending& q : pending) memcpy(q.dst, q.src, q.bytes);
+        pending.clear();
+        return DCS_OK;
     }
 };
 

@@ -561,6 +561,29 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ 
 using namespace dcs;
 
 namespace {
+
+// One (query set, train set) problem of the host-buffer entry points on the i8 matrix-core kernel: the two descriptor sets
+// become slots 0 and 1 of a two-slot feature array (the layout dcs_match_bf_batch_device works on), pair (0, 1).
+// Below this many distances the plain popcount kernel has less set-up to amortise.
+constexpr long long kMfmaMinDistances = 64LL * 64LL;
+struct TwoSlot {
+    uint8_t* desc = nullptr; dcs_keypoint* kp = nullptr; int32_t *n = nullptr, *pairs = nullptr, *best_i = nullptr, *best_d = nullptr, *second_d = nullptr;
+    int cap = 0;
+};
+int two_slot_upload(Scratch& s, const uint8_t* q, const dcs_keypoint* q_kp, int nq, const uint8_t* t, const dcs_keypoint* t_kp, int nt, TwoSlot& o)
+{
+    int rc;
+    o.cap = (std::max(nq, nt) + 127) & ~127;               // whole train tiles: the kernel never reads past a slot
+    const int32_t hn[2] = {nq, nt}, hp[2] = {0, 1};
+    if ((rc = s.alloc(&o.desc, (size_t)2 * o.cap * 32)) || (rc = s.upload_into(o.desc, q, (size_t)nq * 32)) ||
+        (rc = s.upload_into(o.desc + (size_t)o.cap * 32, t, (size_t)nt * 32)) || (rc = s.upload(&o.n, hn, 2)) || (rc = s.upload(&o.pairs, hp, 2)) ||
+        (rc = s.alloc(&o.best_i, (size_t)o.cap)) || (rc = s.alloc(&o.best_d, (size_t)o.cap)) || (rc = s.alloc(&o.second_d, (size_t)o.cap))) return rc;
+    if (q_kp && t_kp) {
+        if ((rc = s.alloc(&o.kp, (size_t)2 * o.cap)) || (rc = s.upload_into(o.kp, q_kp, (size_t)nq)) || (rc = s.upload_into(o.kp + o.cap, t_kp, (size_t)nt))) return rc;
+    }
+    return DCS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -574,17 +597,27 @@ int dcs_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const u
     if (nq == 0) return DCS_OK;
     if (nt >= (1 << 23)) { set_error("nt %d exceeds the 2^23 train descriptors of one knn2 problem", nt); return DCS_ERR_UNSUPPORTED; }
     Scratch s;
+    if (!t_mask && (long long)nq * nt >= kMfmaMinDistances && nt < (1 << 22)) {         // the matrix-core kernel (no mask support)
+        TwoSlot ts;
+        if ((rc = two_slot_upload(s, q, nullptr, nq, t, nullptr, nt, ts))) return rc;
+        hipLaunchKernelGGL(k_knn2_pairs_mfma, dim3((ts.cap + kKnnQ - 1) / kKnnQ, 1), dim3(64 * kKnnWaves), 0, s.st, ts.desc, ts.n, ts.cap, ts.pairs,
+                           ts.best_i, ts.best_d, ts.second_d);
+        DCS_CHECK_LAUNCH();
+        if ((rc = s.download_bytes(best_idx, ts.best_i, sizeof(int32_t) * nq)) || (rc = s.download_bytes(best_d, ts.best_d, sizeof(int32_t) * nq)) ||
+            (rc = s.download_bytes(second_d, ts.second_d, sizeof(int32_t) * nq))) return rc;
+        return s.finish();
+    }
     uint8_t *dq, *dt, *dm = nullptr;
     int32_t *bi, *bd, *sd;
     if ((rc = s.upload(&dq, q, (size_t)nq * 32)) || (rc = s.upload(&dt, t, (size_t)nt * 32))) return rc;
     if (t_mask && (rc = s.upload(&dm, t_mask, (size_t)nt))) return rc;
     if ((rc = s.alloc(&bi, nq)) || (rc = s.alloc(&bd, nq)) || (rc = s.alloc(&sd, nq))) return rc;
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 127) / 128), dim3(256), 0, 0, dq, nq, dt, nt, dm, bi, bd, sd);
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 127) / 128), dim3(256), 0, s.st, dq, nq, dt, nt, dm, bi, bd, sd);
     DCS_CHECK_LAUNCH();
-    DCS_HIP(hipMemcpy(best_idx, bi, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(best_d, bd, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(second_d, sd, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-    return DCS_OK;
+    if ((rc = s.download_bytes(best_idx, bi, sizeof(int32_t) * nq))) return rc;
+    if ((rc = s.download_bytes(best_d, bd, sizeof(int32_t) * nq))) return rc;
+    if ((rc = s.download_bytes(second_d, sd, sizeof(int32_t) * nq))) return rc;
+    return s.finish();
 }
 
 // CSR lists handed over by the caller (feature vectors, observation lists): offsets ascending from 0, indices inside [0, n_items)
@@ -616,19 +649,19 @@ int dcs_hamming_knn2_grouped(const uint8_t* q, int nq, const uint8_t* t, int nt,
     int32_t *bi, *bd, *sd, *dqo, *dqi, *dto, *dti;
     if ((rc = s.upload(&dq, q, (size_t)nq * 32)) || (rc = s.upload(&dt, t, (size_t)nt * 32))) return rc;
     if ((rc = s.alloc(&bi, nq)) || (rc = s.alloc(&bd, nq)) || (rc = s.alloc(&sd, nq))) return rc;
-    hipLaunchKernelGGL(k_fill_knn, dim3((nq + 255) / 256), dim3(256), 0, 0, bi, bd, sd, nq);
+    hipLaunchKernelGGL(k_fill_knn, dim3((nq + 255) / 256), dim3(256), 0, s.st, bi, bd, sd, nq);
     DCS_CHECK_LAUNCH();
     if (n_groups) {
         const int nqi = q_off[n_groups], nti = t_off[n_groups];
         if ((rc = s.upload(&dqo, q_off, (size_t)n_groups + 1)) || (rc = s.upload(&dto, t_off, (size_t)n_groups + 1))) return rc;
         if ((rc = s.upload(&dqi, q_idx, (size_t)nqi)) || (rc = s.upload(&dti, t_idx, (size_t)nti))) return rc;
-        hipLaunchKernelGGL(k_knn2_grouped, dim3(n_groups), dim3(64), 0, 0, dq, dt, dqo, dqi, dto, dti, bi, bd, sd);
+        hipLaunchKernelGGL(k_knn2_grouped, dim3(n_groups), dim3(64), 0, s.st, dq, dt, dqo, dqi, dto, dti, bi, bd, sd);
         DCS_CHECK_LAUNCH();
     }
-    DCS_HIP(hipMemcpy(best_idx, bi, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(best_d, bd, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(second_d, sd, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-    return DCS_OK;
+    if ((rc = s.download_bytes(best_idx, bi, sizeof(int32_t) * nq))) return rc;
+    if ((rc = s.download_bytes(best_d, bd, sizeof(int32_t) * nq))) return rc;
+    if ((rc = s.download_bytes(second_d, sd, sizeof(int32_t) * nq))) return rc;
+    return s.finish();
 }
 
 int dcs_match_filter(int nq, const int32_t* best_idx, const int32_t* best_d, const int32_t* second_d, int th, int th_strict,
@@ -649,11 +682,12 @@ int dcs_match_filter(int nq, const int32_t* best_idx, const int32_t* best_d, con
     if ((rc = s.upload(&bi, best_idx, nq)) || (rc = s.upload(&bd, best_d, nq)) || (rc = s.upload(&sd, second_d, nq))) return rc;
     if (check_ori && ((rc = s.upload(&qa, q_angle, nq)) || (rc = s.upload(&ta, t_angle, max_t)))) return rc;
     if ((rc = s.alloc(&dm, nq)) || (rc = s.alloc(&dn, 1))) return rc;
-    hipLaunchKernelGGL(k_filter, dim3(1), dim3(256), 0, 0, nq, bi, bd, sd, th, th_strict, ratio, check_ori, qa, 1, ta, 1, dm, dn);
+    hipLaunchKernelGGL(k_filter, dim3(1), dim3(256), 0, s.st, nq, bi, bd, sd, th, th_strict, ratio, check_ori, qa, 1, ta, 1, dm, dn);
     DCS_CHECK_LAUNCH();
-    DCS_HIP(hipMemcpy(match, dm, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    if ((rc = s.download_bytes(match, dm, sizeof(int32_t) * nq))) return rc;
     int32_t n32 = 0;
-    DCS_HIP(hipMemcpy(&n32, dn, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if ((rc = s.download_bytes(&n32, dn, sizeof(int32_t)))) return rc;
+    if ((rc = s.finish())) return rc;
     *n_matches = n32;
     return DCS_OK;
 }
@@ -670,20 +704,37 @@ int dcs_match_bf(const uint8_t* q, const dcs_keypoint* q_kp, int nq, const uint8
     if (nq == 0) return DCS_OK;
     if (nt >= (1 << 23)) { set_error("nt %d exceeds the 2^23 train descriptors of one knn2 problem", nt); return DCS_ERR_UNSUPPORTED; }
     Scratch s;
+    if ((long long)nq * nt >= kMfmaMinDistances && nt < (1 << 22) && (!check_ori || (q_kp && t_kp))) {   // matrix-core kernel + the batched filter
+        TwoSlot ts;
+        int32_t* dn1;
+        if ((rc = two_slot_upload(s, q, check_ori ? q_kp : nullptr, nq, t, check_ori ? t_kp : nullptr, nt, ts)) || (rc = s.alloc(&dn1, 1))) return rc;
+        if (!ts.kp && (rc = s.alloc(&ts.kp, 1))) return rc;                                  // never read without check_ori
+        hipLaunchKernelGGL(k_knn2_pairs_mfma, dim3((ts.cap + kKnnQ - 1) / kKnnQ, 1), dim3(64 * kKnnWaves), 0, s.st, ts.desc, ts.n, ts.cap, ts.pairs,
+                           ts.best_i, ts.best_d, ts.second_d);
+        DCS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_filter_pairs, dim3(1), dim3(256), 0, s.st, ts.kp, ts.n, ts.cap, ts.pairs, ts.best_i, ts.best_d, ts.second_d, th, ratio, check_ori,
+                           ts.best_i, dn1);
+        DCS_CHECK_LAUNCH();
+        int32_t n32 = 0;
+        if ((rc = s.download_bytes(match, ts.best_i, sizeof(int32_t) * nq)) || (rc = s.download_bytes(&n32, dn1, sizeof(int32_t))) || (rc = s.finish())) return rc;
+        *n_matches = n32;
+        return DCS_OK;
+    }
     uint8_t *dq, *dt;
     dcs_keypoint *kq = nullptr, *kt = nullptr;
     int32_t *bi, *bd, *sd, *dm, *dn;
     if ((rc = s.upload(&dq, q, (size_t)nq * 32)) || (rc = s.upload(&dt, t, (size_t)nt * 32))) return rc;
     if (check_ori && ((rc = s.upload(&kq, q_kp, nq)) || (rc = s.upload(&kt, t_kp, nt)))) return rc;
     if ((rc = s.alloc(&bi, nq)) || (rc = s.alloc(&bd, nq)) || (rc = s.alloc(&sd, nq)) || (rc = s.alloc(&dm, nq)) || (rc = s.alloc(&dn, 1))) return rc;
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 127) / 128), dim3(256), 0, 0, dq, nq, dt, nt, (const uint8_t*)nullptr, bi, bd, sd);
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 127) / 128), dim3(256), 0, s.st, dq, nq, dt, nt, (const uint8_t*)nullptr, bi, bd, sd);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_filter, dim3(1), dim3(256), 0, 0, nq, bi, bd, sd, th, 0, ratio, check_ori,
+    hipLaunchKernelGGL(k_filter, dim3(1), dim3(256), 0, s.st, nq, bi, bd, sd, th, 0, ratio, check_ori,
                        kq ? &kq->angle : nullptr, 7, kt ? &kt->angle : nullptr, 7, dm, dn);
     DCS_CHECK_LAUNCH();
-    DCS_HIP(hipMemcpy(match, dm, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+    if ((rc = s.download_bytes(match, dm, sizeof(int32_t) * nq))) return rc;
     int32_t n32 = 0;
-    DCS_HIP(hipMemcpy(&n32, dn, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if ((rc = s.download_bytes(&n32, dn, sizeof(int32_t)))) return rc;
+    if ((rc = s.finish())) return rc;
     *n_matches = n32;
     return DCS_OK;
 }
@@ -730,9 +781,10 @@ int dcs_distinctive_descriptors(const uint8_t* pool, int n_pool, const int32_t* 
     uint8_t* d_pool; int32_t *d_off, *d_idx, *d_best;
     if ((rc = s.upload(&d_pool, pool, (size_t)n_pool * 32)) || (rc = s.upload(&d_off, off, (size_t)n_points + 1)) ||
         (rc = s.upload(&d_idx, idx, (size_t)total)) || (rc = s.alloc(&d_best, n_points))) return rc;
-    hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), 0, 0, d_pool, d_off, d_idx, d_best);
+    hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), 0, s.st, d_pool, d_off, d_idx, d_best);
     DCS_CHECK_LAUNCH();
-    DCS_HIP(hipMemcpy(best, d_best, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost));
+    if ((rc = s.download_bytes(best, d_best, sizeof(int32_t) * n_points))) return rc;
+    if ((rc = s.finish())) return rc;
     return DCS_OK;
 }
 
@@ -770,19 +822,20 @@ int dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_t
     if ((rc = s.upload(&dnp, np.data(), np.size())) || (rc = s.upload(&dko, kf_off, (size_t)kf_n_nodes + 1)) || (rc = s.upload(&dki, kf_idx, (size_t)kf_off[kf_n_nodes])) ||
         (rc = s.upload(&dfo, f_off, (size_t)f_n_nodes + 1)) || (rc = s.upload(&dfi, f_idx, (size_t)f_off[f_n_nodes]))) return rc;
     if ((rc = s.alloc(&dm, n_f)) || (rc = s.alloc(&dbin, n_f)) || (rc = s.alloc(&dhist, 32)) || (rc = s.alloc(&dn, 2))) return rc;
-    hipLaunchKernelGGL(k_fill_i32, dim3((n_f + 255) / 256), dim3(256), 0, 0, dm, n_f, -1);
-    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, 0, dhist, 32, 0);
-    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, 0, dn, 2, 0);
+    hipLaunchKernelGGL(k_fill_i32, dim3((n_f + 255) / 256), dim3(256), 0, s.st, dm, n_f, -1);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s.st, dhist, 32, 0);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s.st, dn, 2, 0);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_search_bow, dim3(n_shared), dim3(64), 0, 0, dkf, akf, dval, df, af, dnp, dko, dki, dfo, dfi, ratio, check_ori, dm, dbin,
+    hipLaunchKernelGGL(k_search_bow, dim3(n_shared), dim3(64), 0, s.st, dkf, akf, dval, df, af, dnp, dko, dki, dfo, dfi, ratio, check_ori, dm, dbin,
                        dhist, dn + 1);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, 0, n_f, check_ori, dhist, dbin, dm, dn);
+    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, s.st, n_f, check_ori, dhist, dbin, dm, dn);
     DCS_CHECK_LAUNCH();
     int32_t h[2] = {0, 0};
-    DCS_HIP(hipMemcpy(h, dn, sizeof(h), hipMemcpyDeviceToHost));
+    if ((rc = s.download_bytes(h, dn, sizeof(h)))) return rc;
+    if ((rc = s.download_bytes(match_f, dm, sizeof(int32_t) * n_f))) return rc;
+    if ((rc = s.finish())) return rc;
     if (h[1]) { set_error("a vocabulary node holds more than %d frame features", kBowMaxCand); return DCS_ERR_UNSUPPORTED; }
-    DCS_HIP(hipMemcpy(match_f, dm, sizeof(int32_t) * n_f, hipMemcpyDeviceToHost));
     *n_matches = h[0];
     return DCS_OK;
 }

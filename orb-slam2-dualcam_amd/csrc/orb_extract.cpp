@@ -510,10 +510,10 @@ int dcs_debug_sincosf(const float* x, int n, float* cos_out, float* sin_out)
     Scratch s;
     const float* d_x; float *d_c, *d_s;
     if ((rc = s.upload(&d_x, x, (size_t)n)) || (rc = s.alloc(&d_c, (size_t)n)) || (rc = s.alloc(&d_s, (size_t)n))) return rc;
-    if ((rc = launch_debug_sincosf(d_x, n, d_c, d_s, nullptr))) return rc;
-    DCS_HIP(hipMemcpy(cos_out, d_c, sizeof(float) * n, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(sin_out, d_s, sizeof(float) * n, hipMemcpyDeviceToHost));
-    return DCS_OK;
+    if ((rc = launch_debug_sincosf(d_x, n, d_c, d_s, s.st))) return rc;
+    if ((rc = s.download_bytes(cos_out, d_c, sizeof(float) * n))) return rc;
+    if ((rc = s.download_bytes(sin_out, d_s, sizeof(float) * n))) return rc;
+    return s.finish();
 }
 
 int dcs_orb_required_cap(const dcs_orb* h, int rows, int cols, int* cap)

@@ -547,27 +547,27 @@ int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* q
         (rc = s.upload(&q.desc, qs->desc, (size_t)nq * 32)) || (rc = s.upload(&q.angle, check_orientation ? qs->angle : &zero_f, check_orientation ? (size_t)nq : 1))) return rc;
     unsigned* d_cand; int32_t *d_cn, *d_mq, *d_qf, *d_bin, *d_nm; uint8_t* d_taken;
     if ((rc = s.alloc(&d_cand, (size_t)nq * kProjCap)) || (rc = s.alloc(&d_cn, (size_t)nq)) || (rc = s.alloc(&d_mq, (size_t)nq)) ||
-        (rc = s.alloc(&d_qf, (size_t)N)) || (rc = s.alloc(&d_bin, (size_t)nq)) || (rc = s.alloc(&d_nm, 1)) || (rc = s.alloc(&d_taken, (size_t)N))) return rc;
-    DCS_HIP(hipMemcpy(d_taken, fr->taken, (size_t)N, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_proj_collect, dim3((nq + 3) / 4), dim3(256), 0, 0, f, q, d_cand, d_cn);
+        (rc = s.alloc(&d_qf, (size_t)N)) || (rc = s.alloc(&d_bin, (size_t)nq)) || (rc = s.alloc(&d_nm, 1)) || (rc = s.upload(&d_taken, fr->taken, (size_t)N))) return rc;
+    hipLaunchKernelGGL(k_proj_collect, dim3((nq + 3) / 4), dim3(256), 0, s.st, f, q, d_cand, d_cn);
     DCS_CHECK_LAUNCH();
     static const bool serial = getenv("DCS_PROJ_SERIAL") != nullptr;     // one-wave resolver (reference order, step by step)
     if (N <= kResMaxN && !serial) {
         uint8_t* d_state;
         if ((rc = s.alloc(&d_state, (size_t)nq))) return rc;
-        hipLaunchKernelGGL(k_proj_resolve_par, dim3(1), dim3(kResT), 0, 0, f, q, d_cand, d_cn, d_state, th_high, nn_ratio, check_orientation,
+        hipLaunchKernelGGL(k_proj_resolve_par, dim3(1), dim3(kResT), 0, s.st, f, q, d_cand, d_cn, d_state, th_high, nn_ratio, check_orientation,
                            d_mq, d_qf, d_bin, d_nm);
     } else if (N <= 65536)
-        hipLaunchKernelGGL(k_proj_resolve<true>, dim3(1), dim3(64), (size_t)std::max(N, 1), 0, f, q, d_cand, d_cn, d_taken, th_high, nn_ratio,
+        hipLaunchKernelGGL(k_proj_resolve<true>, dim3(1), dim3(64), (size_t)std::max(N, 1), s.st, f, q, d_cand, d_cn, d_taken, th_high, nn_ratio,
                            check_orientation, d_mq, d_qf, d_bin, d_nm);
     else
-        hipLaunchKernelGGL(k_proj_resolve<false>, dim3(1), dim3(64), 0, 0, f, q, d_cand, d_cn, d_taken, th_high, nn_ratio, check_orientation,
+        hipLaunchKernelGGL(k_proj_resolve<false>, dim3(1), dim3(64), 0, s.st, f, q, d_cand, d_cn, d_taken, th_high, nn_ratio, check_orientation,
                            d_mq, d_qf, d_bin, d_nm);
     DCS_CHECK_LAUNCH();
-    DCS_HIP(hipMemcpy(match_of_query, d_mq, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-    if (N) DCS_HIP(hipMemcpy(query_of_feature, d_qf, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    if ((rc = s.download_bytes(match_of_query, d_mq, sizeof(int32_t) * nq))) return rc;
+    if (N) if ((rc = s.download_bytes(query_of_feature, d_qf, sizeof(int32_t) * N))) return rc;
     int32_t nm = 0;
-    DCS_HIP(hipMemcpy(&nm, d_nm, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if ((rc = s.download_bytes(&nm, d_nm, sizeof(int32_t)))) return rc;
+    if ((rc = s.finish())) return rc;
     *n_matches = nm;
     return DCS_OK;
 }
@@ -603,17 +603,17 @@ int dcs_is_in_frustum(const dcs_frustum_frame* f, int n, const float* pos, const
         (rc = s.alloc(&d_in, n)) || (rc = s.alloc(&d_cam, n)) || (rc = s.alloc(&d_u, n)) || (rc = s.alloc(&d_v, n)) || (rc = s.alloc(&d_vc, n)) ||
         (rc = s.alloc(&d_lvl, n)) || (rc = s.alloc(&d_rad, n))) return rc;
     F.scale_factors = d_sf;
-    hipLaunchKernelGGL(k_frustum, dim3((n + 255) / 256), dim3(256), 0, 0, F, n, d_pos, d_nrm, d_min, d_max, d_cand, viewing_cos_limit, th, d_in, d_cam, d_u, d_v,
+    hipLaunchKernelGGL(k_frustum, dim3((n + 255) / 256), dim3(256), 0, s.st, F, n, d_pos, d_nrm, d_min, d_max, d_cand, viewing_cos_limit, th, d_in, d_cam, d_u, d_v,
                        d_vc, d_lvl, d_rad);
     DCS_CHECK_LAUNCH();
-    DCS_HIP(hipMemcpy(in_view, d_in, n, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(cam, d_cam, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(u, d_u, sizeof(float) * n, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(v, d_v, sizeof(float) * n, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(view_cos, d_vc, sizeof(float) * n, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(level, d_lvl, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    DCS_HIP(hipMemcpy(radius, d_rad, sizeof(float) * n, hipMemcpyDeviceToHost));
-    return DCS_OK;
+    if ((rc = s.download_bytes(in_view, d_in, n))) return rc;
+    if ((rc = s.download_bytes(cam, d_cam, sizeof(int32_t) * n))) return rc;
+    if ((rc = s.download_bytes(u, d_u, sizeof(float) * n))) return rc;
+    if ((rc = s.download_bytes(v, d_v, sizeof(float) * n))) return rc;
+    if ((rc = s.download_bytes(view_cos, d_vc, sizeof(float) * n))) return rc;
+    if ((rc = s.download_bytes(level, d_lvl, sizeof(int32_t) * n))) return rc;
+    if ((rc = s.download_bytes(radius, d_rad, sizeof(float) * n))) return rc;
+    return s.finish();
 }
 
 }  // extern "C"
