@@ -140,6 +140,23 @@ def test_ba_batch_concurrent_with_extraction(pkg, oracle, synth):
     e.close()
 
 
+def test_ba_ill_conditioned_documented_bound(pkg, oracle, synth):
+    """A weakly constrained problem far from the C4 shape (31 poses, every point seen by only 3 of them, 20 % gross outliers; the
+    worst case of the round-1 random sweep, gpurun_out/stress2.log:23808). The chi2 traces of two IEEE-correct solvers with
+    different summation orders agree to 1e-15 at the start and separate ~10x per LM iteration; on the convergence plateau
+    rho ~ 0 changes sign with rounding, so one side may run one LM trial more. Documented bound for such problems:
+    translations within 2e-2, the first round's chi2 trace to 1e-6, trial counts within one. C4-shaped problems stay at 1e-9."""
+    pb = synth.ba_problem(n_poses=31, n_fixed=1, n_points=326, obs_per_point=3, seed=8141, outlier_frac=0.2, exact_adjoint=True)
+    got, exp = pkg.Optimizer.LocalBundleAdjustment(pb), _oracle_run(oracle, pb)
+    assert got["n_iters"][0] == exp["n_iters"][0] and abs(got["n_iters"][1] - exp["n_iters"][1]) <= 1
+    assert abs(sum(got["n_trials"]) - sum(exp["n_trials"])) <= 2
+    k = exp["n_iters"][0]
+    assert np.allclose(got["chi2_trace"][:k], exp["chi2_trace"][:k], rtol=1e-6)
+    assert np.abs(got["poses"][:, :3] - exp["poses"][:, :3]).max() < 2e-2
+    assert np.sum(got["edge_level1"] != exp["edge_level1"]) <= 2
+    assert np.isfinite(got["poses"]).all() and np.isfinite(got["points"]).all()
+
+
 def test_ba_noise_free_ground_truth(pkg, synth):
     pb = synth.ba_problem(n_poses=10, n_fixed=3, n_points=120, obs_per_point=5, seed=3, noise=False)
     rng = np.random.default_rng(1)

@@ -18,8 +18,8 @@ def _fnv(b):
     return h
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "mirror_test")
+def _build(tmp_path, name="mirror_test"):
+    exe = str(tmp_path / name)
     torch_lib = None
     try:
         import torch
@@ -27,7 +27,7 @@ def _build(tmp_path):
     except ImportError:
         pass
     cmd = ["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "host"),
-           os.path.join(ROOT, "tests", "cpp", "mirror_test.cpp"), "-L", os.path.join(PKG, "lib"), "-ldcs_hip",
+           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-L", os.path.join(PKG, "lib"), "-ldcs_hip",
            "-Wl,-rpath," + os.path.join(PKG, "lib"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     subprocess.check_call(cmd)
     return exe
@@ -36,6 +36,7 @@ def _build(tmp_path):
 def test_mirror_headers_compile(tmp_path, pkg):
     pkg.abi.lib()
     _build(tmp_path)
+    _build(tmp_path, "mirror_ba_test")
 
 
 @pytest.mark.gpu
@@ -70,3 +71,69 @@ def test_mirror_matches_oracle(tmp_path, pkg, oracle, synth):
     s01 = oracle.bow_score_l1(r0["bow_word"], r0["bow_val"], [0, len(r1["bow_word"])], r1["bow_word"], r1["bow_val"])[0]
     s00 = oracle.bow_score_l1(r0["bow_word"], r0["bow_val"], [0, len(r0["bow_word"])], r0["bow_word"], r0["bow_val"])[0]
     assert int(lines["score"][0], 16) == _fnv(struct.pack("<d", s01)) and int(lines["score"][1], 16) == _fnv(struct.pack("<d", s00))
+
+
+def _blob(path, arrays):
+    import struct
+    with open(path, "wb") as f:
+        for name, a in arrays.items():
+            raw = np.ascontiguousarray(a).tobytes()
+            f.write(struct.pack("<I", len(name))); f.write(name.encode()); f.write(struct.pack("<Q", len(raw))); f.write(raw)
+
+
+@pytest.mark.gpu
+def test_optimizer_and_projection_mirrors(tmp_path, pkg, oracle, synth):
+    """host/Optimizer.h (LocalBundleAdjustment, stop flag, BundleAdjustment, PoseOptimization) and host/ORBmatcher.h
+    (SearchByProjection, SearchByProjectionOnCam, IsInFrustum) driven from C++ like the reference's call sites: the results must
+    be the ctypes path's bit for bit (which the other GPU tests hold against the oracle) and the oracle's where that is exact."""
+    import ctypes as C
+    exe = _build(tmp_path, "mirror_ba_test")
+    ba = synth.ba_problem(n_poses=14, n_fixed=3, n_points=260, obs_per_point=6, seed=21)
+    cams = (pkg.abi.BaCamera * len(ba["cams"]))(*[pkg.abi.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in ba["cams"]])
+    po = synth.pose_problem(n_frames=6, obs_per_frame=200, seed=4)
+    frame, q = synth.projection_problem(n_per_cam=700, n_queries=500, seed=17)
+    ff, pts = synth.frustum_problem(n_points=3000, seed=5)
+    arrays = {"cams": np.frombuffer(bytes(cams), np.uint8),
+              "ba.poses": ba["poses"].astype(np.float64), "ba.fixed": ba["pose_fixed"].astype(np.uint8), "ba.points": ba["points"].astype(np.float64),
+              "ba.edge_pose": ba["edge_pose"].astype(np.int32), "ba.edge_point": ba["edge_point"].astype(np.int32), "ba.edge_cam": ba["edge_cam"].astype(np.int32),
+              "ba.obs": ba["obs"].astype(np.float64), "ba.inv_sigma2": ba["inv_sigma2"].astype(np.float64),
+              "po.poses": po["poses"].astype(np.float64), "po.edge_off": po["edge_off"].astype(np.int32), "po.xw": po["xw"].astype(np.float64),
+              "po.obs": po["obs"].astype(np.float64), "po.inv_sigma2": po["inv_sigma2"].astype(np.float64), "po.edge_cam": po["edge_cam"].astype(np.int32)}
+    for k, dt in (("cam_off", np.int32), ("kp_x", np.float32), ("kp_y", np.float32), ("kp_octave", np.int32), ("kp_angle", np.float32), ("desc", np.uint8),
+                  ("taken", np.uint8), ("min_x", np.float32), ("min_y", np.float32), ("grid_w_inv", np.float32), ("grid_h_inv", np.float32)):
+        arrays["pr." + k] = np.asarray(frame[k]).astype(dt)
+    for k, dt in (("valid", np.uint8), ("cam", np.int32), ("u", np.float32), ("v", np.float32), ("radius", np.float32), ("min_level", np.int32),
+                  ("max_level", np.int32), ("desc", np.uint8), ("angle", np.float32)):
+        arrays["q." + k] = np.asarray(q[k]).astype(dt)
+    for k in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y", "scale_factors"):
+        arrays["fr." + k] = np.asarray(ff[k]).astype(np.float32)
+    arrays["fr.log_scale_factor"] = np.float32([ff["log_scale_factor"]])
+    for k in ("pos", "normal", "min_dist", "max_dist"):
+        arrays["pt." + k] = np.asarray(pts[k]).astype(np.float32)
+    blob = str(tmp_path / "problem.blob")
+    _blob(blob, arrays)
+    out = subprocess.run([exe, blob], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    L = dict((l.split()[0], l.split()[1:]) for l in out.stdout.strip().splitlines())
+    h = lambda a: "%016x" % _fnv(np.ascontiguousarray(a).tobytes())            # noqa: E731
+    # LocalBundleAdjustment / stop flag / BundleAdjustment
+    g = pkg.Optimizer.LocalBundleAdjustment(ba)
+    assert [int(L["lba"][0]), int(L["lba"][1])] == g["n_iters"] and L["lba"][2:] == [h(g["poses"]), h(g["points"]), h(g["edge_outlier"])]
+    exp = oracle.ba_local(dict(ba, cams=[oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in ba["cams"]]))
+    assert g["n_iters"] == exp["n_iters"] and np.abs(g["poses"][:, :3] - exp["poses"][:, :3]).max() < 1e-4
+    assert L["lba_stopped"] == ["0", "0", "1"]
+    gb = pkg.Optimizer.BundleAdjustment(ba, nIterations=5, bRobust=True)
+    assert [int(L["gba"][0]), int(L["gba"][1])] == gb["n_iters"] and L["gba"][2] == h(gb["poses"])
+    # PoseOptimization
+    gp = pkg.Optimizer.PoseOptimization(po)
+    assert int(L["po"][0]) == 6 and L["po"][1:] == [h(gp["n_inliers"].astype(np.int32)), h(gp["poses"]), h(gp["outlier"])]
+    # projection-guided matching: the oracle is exact here
+    goff, gidx = oracle.frame_grid(frame["cam_off"], frame["kp_x"], frame["kp_y"], frame["min_x"], frame["min_y"], frame["grid_w_inv"], frame["grid_h_inv"])
+    frame["grid_off"], frame["grid_idx"] = goff, gidx
+    emq, eqf, en = oracle.search_by_projection(frame, q, 100, 0.8, False)
+    assert int(L["proj"][0]) == len(gidx) and int(L["proj"][1]) == en and L["proj"][2:] == [h(emq), h(eqf)]
+    emq, eqf, en = oracle.search_by_projection(frame, q, 100, 0.0, True)
+    assert int(L["proj_oncam"][0]) == en and L["proj_oncam"][1:] == [h(emq), h(eqf)]
+    # isInFrustum: in_view / cam / u / v / viewCos bit for bit
+    e = oracle.is_in_frustum(ff, dict(pts, candidate=None), 0.5, 1.0)
+    assert L["frustum"] == [h(e["in_view"]), h(e["cam"]), h(e["u"]), h(e["v"]), h(e["view_cos"])]
