@@ -273,6 +273,38 @@ int  dcs_comm_info(const dcs_comm*, int* rank, int* world);
 int  dcs_features_allgather(dcs_comm*, const dcs_keypoint* d_kp, const uint8_t* d_desc, const int32_t* d_n, int n_slots, int cap,
                             dcs_keypoint* d_kp_all, uint8_t* d_desc_all, int32_t* d_n_all, void* stream);
 
+/* SearchByBoWCrossCam(KF1, c1, KF2, c2, vpMatches12) (ORBmatcher.cc:297-414, LoopClosing.cc:300): like dcs_search_by_bow, but
+   both sides are key frames: valid1 / valid2 = "has a good MapPoint", a KF2 feature matched once stays claimed (vbMatched2,
+   also when the rotation histogram later drops the match), best < TH_LOW is STRICT. match12[i] = KF2 feature (camera-local)
+   whose MapPoint KF1 feature i takes, or -1. */
+int  dcs_search_by_bow_kf(const uint8_t* desc1, const float* ang1, const uint8_t* valid1, int n1,
+                          const uint8_t* desc2, const float* ang2, const uint8_t* valid2, int n2,
+                          const int32_t* nodes1, const int32_t* off1, const int32_t* idx1, int n_nodes1,
+                          const int32_t* nodes2, const int32_t* off2, const int32_t* idx2, int n_nodes2,
+                          float ratio, int check_ori, int32_t* match12, int* n_matches);
+
+/* SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, camS) (ORBmatcher.cc:1253-1427, LocalMapping.cc:321) with
+   CheckDistEpipolarLine (:74-91): features WITHOUT a MapPoint (free1 / free2) of camera camS, per shared vocabulary node, best
+   candidate only: distance <= TH_LOW, not within 10 * sqrt(scale) px of the epipole (ex, ey), on the epipolar line x1' F12
+   (3.84 * mvLevelSigma2[octave]); of equal distances the LAST one of the node list wins (`dist > bestDist` skips). The caller
+   computes F12 and the epipole with its cv::Mat code (:1262-1268). match12[i] = camera-local KF2 feature or -1; the global
+   index pairs of vMatchedPairs follow by adding the camera offsets (:1413-1424). */
+typedef struct dcs_epipolar {
+    float F12[9];                 /* row-major */
+    float ex, ey;                 /* epipole in the second image */
+    const float* kp1_x; const float* kp1_y;     /* [n1] pKF1->mvvkeysUnTemp[camS][i].pt */
+    const float* kp2_x; const float* kp2_y;     /* [n2] */
+    const int32_t* kp2_octave;    /* [n2] */
+    const float* level_sigma2;    /* [n_levels] pKF2->mvLevelSigma2 */
+    const float* scale_factors;   /* [n_levels] pKF2->mvScaleFactors */
+    int32_t n_levels;
+} dcs_epipolar;
+int  dcs_search_for_triangulation(const uint8_t* desc1, const float* ang1, const uint8_t* free1, int n1,
+                                  const uint8_t* desc2, const float* ang2, const uint8_t* free2, int n2,
+                                  const int32_t* nodes1, const int32_t* off1, const int32_t* idx1, int n_nodes1,
+                                  const int32_t* nodes2, const int32_t* off2, const int32_t* idx2, int n_nodes2,
+                                  const dcs_epipolar* epi, int check_ori, int32_t* match12, int* n_matches);
+
 /* ------------------------------------------------------------------ local BA */
 typedef struct dcs_ba_camera {
     double fx, fy, cx, cy;      /* e->fx.. (Optimizer.cc:561-564) */

@@ -189,6 +189,125 @@ int orc_search_by_bow_crosscam(const uint8_t* desc_kf, const float* ang_kf, cons
     return nmatches;
 }
 
+/* SearchByBoWCrossCam(KF1, c1, KF2, c2, vpMatches12) (ORBmatcher.cc:297-414): both sides key frames. valid = "has a MapPoint
+   that is not bad" (:336, :348); vbMatched2 stays set when the rotation histogram drops the match; best < TH_LOW is strict
+   (:364). match12[i] = camera-local KF2 feature or -1. */
+int orc_search_by_bow_kfkf(const uint8_t* desc1, const float* ang1, const uint8_t* valid1, int n1,
+                           const uint8_t* desc2, const float* ang2, const uint8_t* valid2, int n2,
+                           const int32_t* nodes1, const int32_t* off1, const int32_t* idx1, int n_nodes1,
+                           const int32_t* nodes2, const int32_t* off2, const int32_t* idx2, int n_nodes2,
+                           float ratio, int check_ori, int32_t* match12)
+{
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    std::vector<uint8_t> matched2((size_t)std::max(n2, 1), 0);
+    std::vector<std::vector<int>> rot_hist(HISTO_LENGTH);
+    int nmatches = 0, a = 0, b = 0;
+    while (a < n_nodes1 && b < n_nodes2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int ia = off1[a]; ia < off1[a + 1]; ++ia) {
+                const int i1 = idx1[ia];
+                if (!valid1[i1]) continue;
+                int best1 = 256, best2 = 256, best_i2 = -1;
+                for (int ib = off2[b]; ib < off2[b + 1]; ++ib) {
+                    const int i2 = idx2[ib];
+                    if (matched2[i2] || !valid2[i2]) continue;                                       /* :348 */
+                    const int dist = descriptor_distance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+                    if (dist < best1) { best2 = best1; best1 = dist; best_i2 = i2; }
+                    else if (dist < best2) { best2 = dist; }
+                }
+                if (best1 < TH_LOW) {                                                                /* :364 */
+                    if (static_cast<float>(best1) < ratio * static_cast<float>(best2)) {
+                        match12[i1] = best_i2;
+                        matched2[best_i2] = 1;
+                        if (check_ori) rot_hist[rot_bin(ang1[i1], ang2[best_i2])].push_back(i1);
+                        ++nmatches;
+                    }
+                }
+            }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) a = (int)(std::lower_bound(nodes1, nodes1 + n_nodes1, nodes2[b]) - nodes1);
+        else b = (int)(std::lower_bound(nodes2, nodes2 + n_nodes2, nodes1[a]) - nodes2);
+    }
+    if (check_ori) {
+        int histo[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; ++i) histo[i] = (int)rot_hist[i].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int i1 : rot_hist[i]) { match12[i1] = -1; --nmatches; }
+        }
+    }
+    return nmatches;
+}
+
+/* ORBmatcher::CheckDistEpipolarLine (ORBmatcher.cc:74-91): float arithmetic left to right, the final comparison against
+   3.84 * mvLevelSigma2[octave] in double (3.84 is a double literal). */
+static bool check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float* F12, float sigma2_oct)
+{
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2_oct;
+}
+
+/* SearchForTriangulation (ORBmatcher.cc:1253-1427) for one camera: features without a MapPoint (free1 / free2), per shared
+   vocabulary node, best candidate only; bestDist starts at TH_LOW and `dist > bestDist` skips (:1326), so of equal distances
+   the last accepted one wins; epipole gate (:1331-1334) and epipolar line gate (:1337) before a candidate may lower bestDist. */
+int orc_search_for_triangulation(const uint8_t* desc1, const float* ang1, const uint8_t* free1, int n1,
+                                 const uint8_t* desc2, const float* ang2, const uint8_t* free2, int n2,
+                                 const int32_t* nodes1, const int32_t* off1, const int32_t* idx1, int n_nodes1,
+                                 const int32_t* nodes2, const int32_t* off2, const int32_t* idx2, int n_nodes2,
+                                 const float* F12, float ex, float ey, const float* x1, const float* y1, const float* x2, const float* y2,
+                                 const int32_t* oct2, const float* level_sigma2, const float* scale_factors, int check_ori, int32_t* match12)
+{
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    std::vector<uint8_t> matched2((size_t)std::max(n2, 1), 0);
+    std::vector<std::vector<int>> rot_hist(HISTO_LENGTH);
+    int nmatches = 0, a = 0, b = 0;
+    while (a < n_nodes1 && b < n_nodes2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int ia = off1[a]; ia < off1[a + 1]; ++ia) {
+                const int i1 = idx1[ia];
+                if (!free1[i1]) continue;                                                            /* :1296-1297 */
+                int best_dist = TH_LOW, best_i2 = -1;
+                for (int ib = off2[b]; ib < off2[b + 1]; ++ib) {
+                    const int i2 = idx2[ib];
+                    if (matched2[i2] || !free2[i2]) continue;                                        /* :1314 */
+                    const int dist = descriptor_distance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+                    if (dist > TH_LOW || dist > best_dist) continue;                                 /* :1326 */
+                    const float distex = ex - x2[i2], distey = ey - y2[i2];
+                    if (distex * distex + distey * distey < 100 * scale_factors[oct2[i2]]) continue;  /* :1333 */
+                    if (check_dist_epipolar_line(x1[i1], y1[i1], x2[i2], y2[i2], F12, level_sigma2[oct2[i2]])) { best_i2 = i2; best_dist = dist; }
+                }
+                if (best_i2 >= 0) {
+                    match12[i1] = best_i2;
+                    matched2[best_i2] = 1;
+                    ++nmatches;
+                    if (check_ori) rot_hist[rot_bin(ang1[i1], ang2[best_i2])].push_back(i1);
+                }
+            }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) a = (int)(std::lower_bound(nodes1, nodes1 + n_nodes1, nodes2[b]) - nodes1);
+        else b = (int)(std::lower_bound(nodes2, nodes2 + n_nodes2, nodes1[a]) - nodes2);
+    }
+    if (check_ori) {
+        int histo[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; ++i) histo[i] = (int)rot_hist[i].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int i1 : rot_hist[i]) { match12[i1] = -1; --nmatches; }
+        }
+    }
+    return nmatches;
+}
+
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:270-340) for a batch of map points: point p owns the
    descriptors pool[idx[off[p] .. off[p+1])]. Full N x N distance table, every row sorted, median = sorted[(int)(0.5 (N-1))],
    first row with the least median wins (:318-331). */

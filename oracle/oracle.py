@@ -443,6 +443,40 @@ def search_by_bow_crosscam(desc_kf, ang_kf, kf_valid, desc_f, ang_f, kf_fv, f_fv
     return match[:len(desc_f)], n
 
 
+def search_by_bow_kfkf(desc1, ang1, valid1, desc2, ang2, valid2, fv1, fv2, ratio=0.75, check_ori=True):
+    """SearchByBoWCrossCam(KF1, c1, KF2, c2) (ORBmatcher.cc:297-414) -> (match12[n1], nmatches)"""
+    desc1, desc2 = _c(desc1, np.uint8).reshape(-1, 32), _c(desc2, np.uint8).reshape(-1, 32)
+    ang1, ang2, valid1, valid2 = _c(ang1, np.float32), _c(ang2, np.float32), _c(valid1, np.uint8), _c(valid2, np.uint8)
+    n1_, o1, i1 = (_c(a, np.int32) for a in fv1)
+    n2_, o2, i2 = (_c(a, np.int32) for a in fv2)
+    match = np.full(max(len(desc1), 1), -1, np.int32)
+    fn = lib().orc_search_by_bow_kfkf
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] * 2 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] * 2 + [C.c_float, C.c_int, C.c_void_p]
+    n = fn(_p(desc1), _p(ang1), _p(valid1), len(desc1), _p(desc2), _p(ang2), _p(valid2), len(desc2),
+           _p(n1_), _p(o1), _p(i1), len(n1_), _p(n2_), _p(o2), _p(i2), len(n2_), float(ratio), int(check_ori), _p(match))
+    return match[:len(desc1)], n
+
+
+def search_for_triangulation(desc1, ang1, free1, desc2, ang2, free2, fv1, fv2, epi, check_ori=True):
+    """SearchForTriangulation (ORBmatcher.cc:1253-1427) for one camera. epi = dict(F12[9], ex, ey, kp1_x, kp1_y, kp2_x, kp2_y,
+    kp2_octave, level_sigma2, scale_factors) -> (match12[n1], nmatches)"""
+    desc1, desc2 = _c(desc1, np.uint8).reshape(-1, 32), _c(desc2, np.uint8).reshape(-1, 32)
+    ang1, ang2, free1, free2 = _c(ang1, np.float32), _c(ang2, np.float32), _c(free1, np.uint8), _c(free2, np.uint8)
+    n1_, o1, i1 = (_c(a, np.int32) for a in fv1)
+    n2_, o2, i2 = (_c(a, np.int32) for a in fv2)
+    F = _c(epi["F12"], np.float32).reshape(9)
+    x1, y1, x2, y2 = (_c(epi[k], np.float32) for k in ("kp1_x", "kp1_y", "kp2_x", "kp2_y"))
+    oc, sg, sc = _c(epi["kp2_octave"], np.int32), _c(epi["level_sigma2"], np.float32), _c(epi["scale_factors"], np.float32)
+    match = np.full(max(len(desc1), 1), -1, np.int32)
+    fn = lib().orc_search_for_triangulation
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    fn.argtypes = [vp, vp, vp, ci] * 2 + [vp, vp, vp, ci] * 2 + [vp, cf, cf, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+    n = fn(_p(desc1), _p(ang1), _p(free1), len(desc1), _p(desc2), _p(ang2), _p(free2), len(desc2),
+           _p(n1_), _p(o1), _p(i1), len(n1_), _p(n2_), _p(o2), _p(i2), len(n2_), _p(F), float(np.float32(epi["ex"])), float(np.float32(epi["ey"])),
+           _p(x1), _p(y1), _p(x2), _p(y2), _p(oc), _p(sg), _p(sc), int(check_ori), _p(match))
+    return match[:len(desc1)], n
+
+
 def make_camera(fx, fy, cx, cy, ext7, adj36):
     c = BaCamera()
     c.fx, c.fy, c.cx, c.cy = fx, fy, cx, cy

@@ -25,7 +25,7 @@ SYMBOLS = [
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
-    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
+    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
@@ -42,6 +42,11 @@ class DcsError(RuntimeError):
 class FrustumFrame(C.Structure):
     _fields_ = [("n_cams", C.c_int32)] + [(k, C.c_void_p) for k in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y")] + \
                [("log_scale_factor", C.c_float), ("n_scale_levels", C.c_int32), ("scale_factors", C.c_void_p)]
+
+
+class Epipolar(C.Structure):
+    _fields_ = [("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float)] + \
+               [(k, C.c_void_p) for k in ("kp1_x", "kp1_y", "kp2_x", "kp2_y", "kp2_octave", "level_sigma2", "scale_factors")] + [("n_levels", C.c_int32)]
 
 
 class OrbParams(C.Structure):
@@ -113,6 +118,8 @@ def lib():
             "dcs_match_bf": [vp, vp, ci, vp, vp, ci, ci, cf, ci, vp, pci],
             "dcs_match_bf_batch_device": [vp, vp, vp, ci, vp, ci, ci, cf, ci, vp, vp, vp, vp, vp],
             "dcs_search_by_bow": [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, vp, pci],
+            "dcs_search_by_bow_kf": [vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, vp, pci],
+            "dcs_search_for_triangulation": [vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, C.POINTER(Epipolar), ci, vp, pci],
             "dcs_distinctive_descriptors": [vp, ci, vp, vp, ci, vp],
             "dcs_ba_local": [C.POINTER(BaProblem), vp, C.POINTER(BaResult)],
             "dcs_ba_local_batch": [ci, vp, vp, vp],
@@ -418,6 +425,39 @@ class FeatureComm:
         S = int(d_kp.shape[0])
         _check(lib().dcs_features_allgather(self._h, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), S, int(cap),
                                             g_kp.data_ptr(), g_desc.data_ptr(), g_n.data_ptr(), stream), "dcs_features_allgather")
+
+
+def SearchByBoWCrossCamKF(desc1, ang1, valid1, desc2, ang2, valid2, fv1, fv2, ratio=0.75, check_ori=True):
+    """ORBmatcher::SearchByBoWCrossCam(KF1, c1, KF2, c2, vpMatches12) (ORBmatcher.cc:297-414) -> (match12[n1], nmatches)"""
+    desc1, desc2 = _c(desc1, np.uint8).reshape(-1, 32), _c(desc2, np.uint8).reshape(-1, 32)
+    ang1, ang2, valid1, valid2 = _c(ang1, np.float32), _c(ang2, np.float32), _c(valid1, np.uint8), _c(valid2, np.uint8)
+    a1, a2 = [_c(a, np.int32) for a in fv1], [_c(a, np.int32) for a in fv2]
+    match, n = np.full(max(len(desc1), 1), -1, np.int32), C.c_int(0)
+    _check(lib().dcs_search_by_bow_kf(_p(desc1), _p(ang1), _p(valid1), len(desc1), _p(desc2), _p(ang2), _p(valid2), len(desc2),
+                                      _p(a1[0]), _p(a1[1]), _p(a1[2]), len(a1[0]), _p(a2[0]), _p(a2[1]), _p(a2[2]), len(a2[0]),
+                                      float(ratio), int(check_ori), _p(match), C.byref(n)), "dcs_search_by_bow_kf")
+    return match[:len(desc1)], n.value
+
+
+def SearchForTriangulation(desc1, ang1, free1, desc2, ang2, free2, fv1, fv2, epi, check_ori=True):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:1253-1427) for one camera; epi as in oracle.search_for_triangulation"""
+    desc1, desc2 = _c(desc1, np.uint8).reshape(-1, 32), _c(desc2, np.uint8).reshape(-1, 32)
+    ang1, ang2, free1, free2 = _c(ang1, np.float32), _c(ang2, np.float32), _c(free1, np.uint8), _c(free2, np.uint8)
+    a1, a2 = [_c(a, np.int32) for a in fv1], [_c(a, np.int32) for a in fv2]
+    keep = {k: _c(epi[k], np.float32) for k in ("kp1_x", "kp1_y", "kp2_x", "kp2_y", "level_sigma2", "scale_factors")}
+    keep["kp2_octave"] = _c(epi["kp2_octave"], np.int32)
+    e = Epipolar()
+    for i, v in enumerate(np.asarray(epi["F12"], np.float32).reshape(9)):
+        e.F12[i] = float(v)
+    e.ex, e.ey = float(np.float32(epi["ex"])), float(np.float32(epi["ey"]))
+    for k in ("kp1_x", "kp1_y", "kp2_x", "kp2_y", "kp2_octave", "level_sigma2", "scale_factors"):
+        setattr(e, k, keep[k].ctypes.data)
+    e.n_levels = len(keep["scale_factors"])
+    match, n = np.full(max(len(desc1), 1), -1, np.int32), C.c_int(0)
+    _check(lib().dcs_search_for_triangulation(_p(desc1), _p(ang1), _p(free1), len(desc1), _p(desc2), _p(ang2), _p(free2), len(desc2),
+                                              _p(a1[0]), _p(a1[1]), _p(a1[2]), len(a1[0]), _p(a2[0]), _p(a2[1]), _p(a2[2]), len(a2[0]),
+                                              C.byref(e), int(check_ori), _p(match), C.byref(n)), "dcs_search_for_triangulation")
+    return match[:len(desc1)], n.value
 
 
 def frame_grid(cam_off, kp_x, kp_y, min_x, min_y, w_inv, h_inv):

@@ -441,12 +441,30 @@ __device__ __forceinline__ Best wave_merge(Best s)
     return s;
 }
 
+// The three BoW-guided matchers of the reference share this loop (queries of a vocabulary node in list order, candidates of
+// the same node, candidates claimed by an earlier query are skipped); they differ in what is a valid candidate and when a
+// query accepts:
+//   kBowFKF   SearchByBoWCrossCam(F, cF, KF, cKF)        :162-294   best <= TH_LOW and best < ratio * second, first minimum
+//   kBowKFKF  SearchByBoWCrossCam(KF1, c1, KF2, c2)      :297-414   best <  TH_LOW (strict) and ratio; candidates need a good MapPoint
+//   kBowTri   SearchForTriangulation(KF1, KF2, F12, camS) :1253-1427 best only, dist <= TH_LOW, LAST minimum (`dist > bestDist` skips, a tie
+//             replaces), candidates without a MapPoint, farther than 10 * sqrt(scale) px from the epipole and on the epipolar
+//             line (CheckDistEpipolarLine :74-91, chi2 3.84 * sigma2 of the candidate's octave)
+enum { kBowFKF = 0, kBowKFKF = 1, kBowTri = 2 };
+struct EpipolarD {
+    float F[9], ex, ey;                               // F12 row-major, epipole of KF1's camera centre in KF2's image
+    const float *x1, *y1, *x2, *y2;                   // undistorted keypoint coordinates (mvvkeysUnTemp[camS])
+    const int32_t* oct2;
+    const float *sigma2, *scale;                      // mvLevelSigma2, mvScaleFactors
+};
+
+template <int MODE>
 __global__ __launch_bounds__(64) void k_search_bow(const uint8_t* __restrict__ desc_kf, const float* __restrict__ ang_kf,
                                                    const uint8_t* __restrict__ kf_valid, const uint8_t* __restrict__ desc_f,
-                                                   const float* __restrict__ ang_f, const int32_t* __restrict__ node_pairs,
+                                                   const float* __restrict__ ang_f, const uint8_t* __restrict__ f_valid,
+                                                   const int32_t* __restrict__ node_pairs,
                                                    const int32_t* __restrict__ kf_off, const int32_t* __restrict__ kf_idx,
                                                    const int32_t* __restrict__ f_off, const int32_t* __restrict__ f_idx, float ratio,
-                                                   int check_ori, int32_t* __restrict__ match_f, int32_t* __restrict__ bin_f,
+                                                   int check_ori, EpipolarD ep, int32_t* __restrict__ match_f, int32_t* __restrict__ bin_f,
                                                    int32_t* __restrict__ hist, int32_t* __restrict__ overflow)
 {
     __shared__ uint32_t s_claimed[kBowMaxCand / 32];
@@ -461,18 +479,50 @@ __global__ __launch_bounds__(64) void k_search_bow(const uint8_t* __restrict__ d
         const unsigned long long* qp = reinterpret_cast<const unsigned long long*>(desc_kf + (size_t)ikf * 32);
         const unsigned long long q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
         Best st{256, -1, 256};                                             // idx = position in the node's candidate list
+        unsigned tri_key = 0xFFFFFFFFu;                                    // kBowTri: (dist << 16) | (0xFFFF - position): least distance, last position
+        float la = 0.f, lb = 0.f, lc = 0.f;
+        if (MODE == kBowTri) {                                             // epipolar line in the second image l = x1' F12 (:77-79), float, left to right
+            const float x1 = ep.x1[ikf], y1 = ep.y1[ikf];
+            la = __fadd_rn(__fadd_rn(__fmul_rn(x1, ep.F[0]), __fmul_rn(y1, ep.F[3])), ep.F[6]);
+            lb = __fadd_rn(__fadd_rn(__fmul_rn(x1, ep.F[1]), __fmul_rn(y1, ep.F[4])), ep.F[7]);
+            lc = __fadd_rn(__fadd_rn(__fmul_rn(x1, ep.F[2]), __fmul_rn(y1, ep.F[5])), ep.F[8]);
+        }
         for (int c = cb + lane; c < ce; c += 64) {
             const int pos = c - cb;
             if (s_claimed[pos >> 5] & (1u << (pos & 31))) continue;
-            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(desc_f + (size_t)f_idx[c] * 32);
+            const int jf = f_idx[c];
+            if (MODE != kBowFKF && !f_valid[jf]) continue;
+            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(desc_f + (size_t)jf * 32);
             const int dist = __popcll(q0 ^ w[0]) + __popcll(q1 ^ w[1]) + __popcll(q2 ^ w[2]) + __popcll(q3 ^ w[3]);
-            best_update(st, dist, pos);
+            if (MODE != kBowTri) { best_update(st, dist, pos); continue; }
+            if (dist > 50) continue;                                       // :1326 (the running bestDist only matters for the order: see the key)
+            const float x2 = ep.x2[jf], y2 = ep.y2[jf];
+            const int o2 = ep.oct2[jf];
+            const float dex = __fsub_rn(ep.ex, x2), dey = __fsub_rn(ep.ey, y2);
+            if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.0f, ep.scale[o2])) continue;      // :1331-1334
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, x2), __fmul_rn(lb, y2)), lc);
+            const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+            if (den == 0.f) continue;
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < 3.84 * (double)ep.sigma2[o2])) continue;                                             // :90, compared in double
+            tri_key = min(tri_key, ((unsigned)dist << 16) | (unsigned)(0xFFFF - pos));
         }
-        st = wave_merge(st);                                               // first position of the minimum wins, like the loop
-        if (st.b1 <= 50 && (float)st.b1 < __fmul_rn(ratio, (float)st.b2)) {
+        bool accept;
+        int best_pos;
+        if (MODE == kBowTri) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) tri_key = min(tri_key, (unsigned)__shfl_xor((int)tri_key, d));
+            accept = tri_key != 0xFFFFFFFFu;
+            best_pos = 0xFFFF - (int)(tri_key & 0xFFFFu);
+        } else {
+            st = wave_merge(st);                                           // first position of the minimum wins, like the loop
+            accept = (MODE == kBowKFKF ? st.b1 < 50 : st.b1 <= 50) && (float)st.b1 < __fmul_rn(ratio, (float)st.b2);
+            best_pos = st.idx;
+        }
+        if (accept) {
             if (lane == 0) {
-                const int jf = f_idx[cb + st.idx];
-                s_claimed[st.idx >> 5] |= 1u << (st.idx & 31);
+                const int jf = f_idx[cb + best_pos];
+                s_claimed[best_pos >> 5] |= 1u << (best_pos & 31);
                 match_f[jf] = ikf;
                 if (check_ori) { const int bn = rot_bin(ang_kf[ikf], ang_f[jf]); bin_f[jf] = bn; atomicAdd(&hist[bn], 1); }
             }
@@ -788,17 +838,24 @@ int dcs_distinctive_descriptors(const uint8_t* pool, int n_pool, const int32_t* 
     return DCS_OK;
 }
 
-int dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_t* kf_valid, int n_kf, const uint8_t* desc_f,
-                      const float* ang_f, int n_f, const int32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx,
-                      int kf_n_nodes, const int32_t* f_nodes, const int32_t* f_off, const int32_t* f_idx, int f_n_nodes, float ratio,
-                      int check_ori, int32_t* match_f, int* n_matches)
+// shared host side of the three BoW-guided matchers: match_f[j] = query that took candidate j (or -1)
+static int search_bow_impl(int mode, const uint8_t* desc_kf, const float* ang_kf, const uint8_t* kf_valid, int n_kf, const uint8_t* desc_f,
+                           const float* ang_f, const uint8_t* f_valid, int n_f, const int32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx,
+                           int kf_n_nodes, const int32_t* f_nodes, const int32_t* f_off, const int32_t* f_idx, int f_n_nodes, float ratio,
+                           int check_ori, const dcs_epipolar* epi, int n_levels, int32_t* match_f, int* n_matches)
 {
     if (n_kf < 0 || n_f < 0 || kf_n_nodes < 0 || f_n_nodes < 0 || !n_matches || (n_f && (!match_f || !desc_f)) || (n_kf && (!desc_kf || !kf_valid)) ||
-        (kf_n_nodes && (!kf_nodes || !kf_off || !kf_idx)) || (f_n_nodes && (!f_nodes || !f_off || !f_idx)) || (check_ori && ((n_kf && !ang_kf) || (n_f && !ang_f)))) {
+        (kf_n_nodes && (!kf_nodes || !kf_off || !kf_idx)) || (f_n_nodes && (!f_nodes || !f_off || !f_idx)) || (check_ori && ((n_kf && !ang_kf) || (n_f && !ang_f))) ||
+        (mode != kBowFKF && n_f && !f_valid)) {
         set_error("bad argument"); return DCS_ERR_INVALID;
     }
     if (!valid_csr(kf_off, kf_n_nodes, kf_idx, n_kf) || !valid_csr(f_off, f_n_nodes, f_idx, n_f)) {
-        set_error("dcs_search_by_bow: feature-vector offsets must ascend from 0 and indices lie inside the descriptor arrays"); return DCS_ERR_INVALID;
+        set_error("feature-vector offsets must ascend from 0 and indices lie inside the descriptor arrays"); return DCS_ERR_INVALID;
+    }
+    if (mode == kBowTri) {
+        if (!epi || n_levels < 1 || n_levels > 16 || !epi->level_sigma2 || !epi->scale_factors || (n_kf && (!epi->kp1_x || !epi->kp1_y)) ||
+            (n_f && (!epi->kp2_x || !epi->kp2_y || !epi->kp2_octave))) { set_error("bad epipolar geometry"); return DCS_ERR_INVALID; }
+        for (int j = 0; j < n_f; ++j) if (epi->kp2_octave[j] < 0 || epi->kp2_octave[j] >= n_levels) { set_error("octave of feature %d outside the pyramid", j); return DCS_ERR_INVALID; }
     }
     int rc = ensure_device();
     if (rc) return rc;
@@ -814,20 +871,35 @@ int dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_t
     const int n_shared = (int)np.size() / 2;
     if (n_shared == 0 || n_f == 0 || n_kf == 0) return DCS_OK;
     Scratch s;
-    uint8_t *dkf, *df, *dval;
+    uint8_t *dkf, *df, *dval, *dfval = nullptr;
     float *akf = nullptr, *af = nullptr;
     int32_t *dnp, *dko, *dki, *dfo, *dfi, *dm, *dbin, *dhist, *dn;
     if ((rc = s.upload(&dkf, desc_kf, (size_t)n_kf * 32)) || (rc = s.upload(&df, desc_f, (size_t)n_f * 32)) || (rc = s.upload(&dval, kf_valid, (size_t)n_kf))) return rc;
+    if (mode != kBowFKF && (rc = s.upload(&dfval, f_valid, (size_t)n_f))) return rc;
     if (check_ori && ((rc = s.upload(&akf, ang_kf, n_kf)) || (rc = s.upload(&af, ang_f, n_f)))) return rc;
     if ((rc = s.upload(&dnp, np.data(), np.size())) || (rc = s.upload(&dko, kf_off, (size_t)kf_n_nodes + 1)) || (rc = s.upload(&dki, kf_idx, (size_t)kf_off[kf_n_nodes])) ||
         (rc = s.upload(&dfo, f_off, (size_t)f_n_nodes + 1)) || (rc = s.upload(&dfi, f_idx, (size_t)f_off[f_n_nodes]))) return rc;
     if ((rc = s.alloc(&dm, n_f)) || (rc = s.alloc(&dbin, n_f)) || (rc = s.alloc(&dhist, 32)) || (rc = s.alloc(&dn, 2))) return rc;
+    EpipolarD ep{};
+    if (mode == kBowTri) {
+        for (int i = 0; i < 9; ++i) ep.F[i] = epi->F12[i];
+        ep.ex = epi->ex; ep.ey = epi->ey;
+        float *x1, *y1, *x2, *y2, *sg, *sc; int32_t* o2;
+        if ((rc = s.upload(&x1, epi->kp1_x, n_kf)) || (rc = s.upload(&y1, epi->kp1_y, n_kf)) || (rc = s.upload(&x2, epi->kp2_x, n_f)) ||
+            (rc = s.upload(&y2, epi->kp2_y, n_f)) || (rc = s.upload(&o2, epi->kp2_octave, n_f)) || (rc = s.upload(&sg, epi->level_sigma2, n_levels)) ||
+            (rc = s.upload(&sc, epi->scale_factors, n_levels))) return rc;
+        ep.x1 = x1; ep.y1 = y1; ep.x2 = x2; ep.y2 = y2; ep.oct2 = o2; ep.sigma2 = sg; ep.scale = sc;
+    }
     hipLaunchKernelGGL(k_fill_i32, dim3((n_f + 255) / 256), dim3(256), 0, s.st, dm, n_f, -1);
     hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s.st, dhist, 32, 0);
     hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s.st, dn, 2, 0);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_search_bow, dim3(n_shared), dim3(64), 0, s.st, dkf, akf, dval, df, af, dnp, dko, dki, dfo, dfi, ratio, check_ori, dm, dbin,
-                       dhist, dn + 1);
+    if (mode == kBowFKF)
+        hipLaunchKernelGGL(k_search_bow<kBowFKF>, dim3(n_shared), dim3(64), 0, s.st, dkf, akf, dval, df, af, dfval, dnp, dko, dki, dfo, dfi, ratio, check_ori, ep, dm, dbin, dhist, dn + 1);
+    else if (mode == kBowKFKF)
+        hipLaunchKernelGGL(k_search_bow<kBowKFKF>, dim3(n_shared), dim3(64), 0, s.st, dkf, akf, dval, df, af, dfval, dnp, dko, dki, dfo, dfi, ratio, check_ori, ep, dm, dbin, dhist, dn + 1);
+    else
+        hipLaunchKernelGGL(k_search_bow<kBowTri>, dim3(n_shared), dim3(64), 0, s.st, dkf, akf, dval, df, af, dfval, dnp, dko, dki, dfo, dfi, ratio, check_ori, ep, dm, dbin, dhist, dn + 1);
     DCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, s.st, n_f, check_ori, dhist, dbin, dm, dn);
     DCS_CHECK_LAUNCH();
@@ -835,8 +907,52 @@ int dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_t
     if ((rc = s.download_bytes(h, dn, sizeof(h)))) return rc;
     if ((rc = s.download_bytes(match_f, dm, sizeof(int32_t) * n_f))) return rc;
     if ((rc = s.finish())) return rc;
-    if (h[1]) { set_error("a vocabulary node holds more than %d frame features", kBowMaxCand); return DCS_ERR_UNSUPPORTED; }
+    if (h[1]) { set_error("a vocabulary node holds more than %d candidate features", kBowMaxCand); return DCS_ERR_UNSUPPORTED; }
     *n_matches = h[0];
+    return DCS_OK;
+}
+
+// candidate-indexed result -> query-indexed (every query takes at most one candidate)
+static void invert_matches(const std::vector<int32_t>& match_f, int n_q, int32_t* match_q)
+{
+    for (int i = 0; i < n_q; ++i) match_q[i] = -1;
+    for (size_t j = 0; j < match_f.size(); ++j) if (match_f[j] >= 0) match_q[match_f[j]] = (int32_t)j;
+}
+
+int dcs_search_by_bow(const uint8_t* desc_kf, const float* ang_kf, const uint8_t* kf_valid, int n_kf, const uint8_t* desc_f,
+                      const float* ang_f, int n_f, const int32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx,
+                      int kf_n_nodes, const int32_t* f_nodes, const int32_t* f_off, const int32_t* f_idx, int f_n_nodes, float ratio,
+                      int check_ori, int32_t* match_f, int* n_matches)
+{
+    return search_bow_impl(kBowFKF, desc_kf, ang_kf, kf_valid, n_kf, desc_f, ang_f, nullptr, n_f, kf_nodes, kf_off, kf_idx, kf_n_nodes, f_nodes, f_off, f_idx,
+                           f_n_nodes, ratio, check_ori, nullptr, 0, match_f, n_matches);
+}
+
+int dcs_search_by_bow_kf(const uint8_t* desc1, const float* ang1, const uint8_t* valid1, int n1, const uint8_t* desc2, const float* ang2,
+                         const uint8_t* valid2, int n2, const int32_t* nodes1, const int32_t* off1, const int32_t* idx1, int n_nodes1,
+                         const int32_t* nodes2, const int32_t* off2, const int32_t* idx2, int n_nodes2, float ratio, int check_ori,
+                         int32_t* match12, int* n_matches)
+{
+    if (n1 < 0 || n2 < 0 || (n1 && !match12)) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    std::vector<int32_t> mf((size_t)std::max(n2, 0), -1);
+    const int rc = search_bow_impl(kBowKFKF, desc1, ang1, valid1, n1, desc2, ang2, valid2, n2, nodes1, off1, idx1, n_nodes1, nodes2, off2, idx2, n_nodes2,
+                                   ratio, check_ori, nullptr, 0, mf.data(), n_matches);
+    if (rc) return rc;
+    invert_matches(mf, n1, match12);
+    return DCS_OK;
+}
+
+int dcs_search_for_triangulation(const uint8_t* desc1, const float* ang1, const uint8_t* free1, int n1, const uint8_t* desc2, const float* ang2,
+                                 const uint8_t* free2, int n2, const int32_t* nodes1, const int32_t* off1, const int32_t* idx1, int n_nodes1,
+                                 const int32_t* nodes2, const int32_t* off2, const int32_t* idx2, int n_nodes2, const dcs_epipolar* epi,
+                                 int check_ori, int32_t* match12, int* n_matches)
+{
+    if (n1 < 0 || n2 < 0 || (n1 && !match12) || !epi) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    std::vector<int32_t> mf((size_t)std::max(n2, 0), -1);
+    const int rc = search_bow_impl(kBowTri, desc1, ang1, free1, n1, desc2, ang2, free2, n2, nodes1, off1, idx1, n_nodes1, nodes2, off2, idx2, n_nodes2,
+                                   0.f, check_ori, epi, epi->n_levels, mf.data(), n_matches);
+    if (rc) return rc;
+    invert_matches(mf, n1, match12);
     return DCS_OK;
 }
 

@@ -213,3 +213,60 @@ def test_gpu_hamming_equals_reference_descriptor_distance(pkg):
     bi, bd, sd = pkg.ORBmatcher.knn2(a, b)                           # full table: minimum over the reference-checked popcounts
     full = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
     assert np.array_equal(np.diag(full), d) and np.array_equal(bd, full.min(1))
+
+
+def _desc_buckets(desc, n_bits=6):
+    """feature vector in which similar descriptors share a node (first descriptor bits), ascending node ids, ascending indices"""
+    node = (desc[:, 0] >> (8 - n_bits)).astype(np.int64)
+    ids = np.unique(node)
+    off, idx = [0], []
+    for k in ids:
+        idx.extend(np.nonzero(node == k)[0].tolist()); off.append(len(idx))
+    return ids.astype(np.int32), np.asarray(off, np.int32), np.asarray(idx, np.int32)
+
+
+def test_kfkf_bow_and_triangulation_vs_oracle(pkg, oracle, synth):
+    """The two remaining BoW-guided matchers with their in-loop state -- SearchByBoWCrossCam(KF1, c1, KF2, c2) (ORBmatcher.cc:297-414:
+    strict threshold, sticky vbMatched2, MapPoint masks) and SearchForTriangulation (:1253-1427: best only, last tie, epipole and
+    epipolar-line gates of :74-91) -- on real ORB features of consecutive frames, GPU vs oracle, exact."""
+    o = oracle.OrbOracle(1500, 1.2, 8, 20, 7)
+    f0, f1 = synth.frame_pair(640, 480, 2, 0)[0], synth.frame_pair(640, 480, 2, 1)[0]       # same camera, frame t and t + 1 ((3, 1) px apart)
+    kp0, d0 = o.extract(f0)
+    kp1, d1 = o.extract(f1)
+    rng = np.random.default_rng(5)
+    a0, a1 = kp0["angle"].copy(), kp1["angle"].copy()
+    tested = 0
+    for n_bits, ratio, ori in ((6, 0.75, True), (4, 0.9, True), (8, 0.6, False), (2, 0.75, True)):
+        fv0, fv1 = _desc_buckets(d0, n_bits), _desc_buckets(d1, n_bits)
+        v0, v1 = (rng.random(len(d0)) < 0.8).astype(np.uint8), (rng.random(len(d1)) < 0.7).astype(np.uint8)
+        em, en = oracle.search_by_bow_kfkf(d0, a0, v0, d1, a1, v1, fv0, fv1, ratio, ori)
+        gm, gn = pkg.abi.SearchByBoWCrossCamKF(d0, a0, v0, d1, a1, v1, fv0, fv1, ratio, ori)
+        assert np.array_equal(gm, em) and gn == en, (n_bits, ratio, ori)
+        tested += en
+        # triangulation: pure image translation (3, 1) between the frames -> F12 = [t]x, plus noise-level slack from sigma2
+        for (tx, ty, ex, ey) in ((3.0, 1.0, -500.0, 240.0), (3.0, 1.2, 320.0, 240.0)):
+            F = np.float32([0, 0, ty, 0, 0, -tx, -ty, tx, 0])
+            lvl = np.arange(8)
+            epi = dict(F12=F, ex=ex, ey=ey, kp1_x=kp0["x"], kp1_y=kp0["y"], kp2_x=kp1["x"], kp2_y=kp1["y"], kp2_octave=kp1["octave"],
+                       level_sigma2=(np.float32(1.2) ** lvl).astype(np.float32) ** 2, scale_factors=(np.float32(1.2) ** lvl).astype(np.float32))
+            em, en = oracle.search_for_triangulation(d0, a0, 1 - v0, d1, a1, 1 - v1, fv0, fv1, epi, ori)
+            gm, gn = pkg.abi.SearchForTriangulation(d0, a0, 1 - v0, d1, a1, 1 - v1, fv0, fv1, epi, ori)
+            assert np.array_equal(gm, em) and gn == en, (n_bits, tx, ty, ori)
+            tested += en
+    assert tested > 200
+    # identical descriptors inside one node: order decides (first minimum with claims / last minimum)
+    base = synth.random_descriptors(30, seed=8)
+    q = np.repeat(base, 3, axis=0)
+    t = np.repeat(base, 4, axis=0)
+    fvq, fvt = synth.csr_buckets(len(q), 4, seed=1), synth.csr_buckets(len(t), 4, seed=2)
+    ones_q, ones_t = np.ones(len(q), np.uint8), np.ones(len(t), np.uint8)
+    zq, zt = np.zeros(len(q), np.float32), np.zeros(len(t), np.float32)
+    em, en = oracle.search_by_bow_kfkf(q, zq, ones_q, t, zt, ones_t, fvq, fvt, 0.95, False)
+    gm, gn = pkg.abi.SearchByBoWCrossCamKF(q, zq, ones_q, t, zt, ones_t, fvq, fvt, 0.95, False)
+    assert np.array_equal(gm, em) and gn == en
+    epi = dict(F12=np.zeros(9, np.float32) + np.float32([0, 0, 0, 0, 0, -1, 0, 1, 0]), ex=-1e4, ey=-1e4, kp1_x=np.full(len(q), 10, np.float32),
+               kp1_y=np.full(len(q), 20, np.float32), kp2_x=np.full(len(t), 30, np.float32), kp2_y=np.full(len(t), 20, np.float32),
+               kp2_octave=np.zeros(len(t), np.int32), level_sigma2=np.float32([1]), scale_factors=np.float32([1]))
+    em, en = oracle.search_for_triangulation(q, zq, ones_q, t, zt, ones_t, fvq, fvt, epi, False)
+    gm, gn = pkg.abi.SearchForTriangulation(q, zq, ones_q, t, zt, ones_t, fvq, fvt, epi, False)
+    assert np.array_equal(gm, em) and gn == en and en > 20

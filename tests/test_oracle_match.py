@@ -285,3 +285,46 @@ def test_is_in_frustum_by_hand_and_vs_numpy(oracle, synth):
             assert np.array_equal(a[k], b[k]), k
         assert np.sum(a["level"] != b["level"]) <= 1                            # logf vs rounded log: an ulp can tip a ceil
     assert a["in_view"].sum() > 50 and (a["cam"] == 1).sum() > 20
+
+
+def _one_node(n):
+    return (np.int32([7]), np.int32([0, n]), np.arange(n, dtype=np.int32))
+
+
+def test_kfkf_bow_strict_threshold_and_sticky_claims(oracle):
+    """SearchByBoWCrossCam(KF1, c1, KF2, c2) (ORBmatcher.cc:297-414): best < TH_LOW is strict (:364), candidates need a MapPoint,
+    and a KF2 feature stays claimed (vbMatched2) for later queries."""
+    z = np.zeros((1, 32), np.uint8)
+    def with_bits(k):
+        d = z.copy(); bits = np.zeros(256, np.uint8); bits[:k] = 1; d[0] = np.packbits(bits); return d
+    q = np.concatenate([z, z])                                   # two identical queries
+    t = np.concatenate([with_bits(50), with_bits(49), with_bits(10)])
+    ang = np.zeros(3, np.float32)
+    m, n = oracle.search_by_bow_kfkf(q, ang[:2], [1, 1], t, ang, [1, 1, 0], _one_node(2), _one_node(3), 0.99, False)
+    # candidate 2 (distance 10) has no MapPoint; query 0 takes candidate 1 (49 < 50, 49 < .99 * 50); query 1 is left with distance 50: not < TH_LOW
+    assert m.tolist() == [1, -1] and n == 1
+    m, n = oracle.search_by_bow_kfkf(q, ang[:2], [1, 1], t, ang, [1, 1, 1], _one_node(2), _one_node(3), 0.6, False)
+    assert m.tolist() == [2, -1] and n == 1                      # 10 < .6 * 49; then best 49, second 50: ratio fails
+
+
+def test_triangulation_last_tie_wins_and_epipolar_gates(oracle):
+    """SearchForTriangulation (ORBmatcher.cc:1253-1427): `dist > bestDist` skips, so of equal distances the LAST candidate of the node
+    list that passes the gates wins; candidates near the epipole (:1333) or off the epipolar line (:74-91) never lower bestDist."""
+    z = np.zeros((1, 32), np.uint8)
+    def with_bits(k):
+        d = z.copy(); bits = np.zeros(256, np.uint8); bits[:k] = 1; d[0] = np.packbits(bits); return d
+    t = np.concatenate([with_bits(20), with_bits(20), with_bits(5), with_bits(20), with_bits(51)])
+    F = np.float32([0, 0, 0, 0, 0, -1, 0, 1, 0])                   # pure x-translation: epipolar lines are the rows y2 = y1
+    epi = dict(F12=F, ex=-1000.0, ey=-1000.0, kp1_x=np.float32([100]), kp1_y=np.float32([50]),
+               kp2_x=np.float32([90, 80, 70, 300, 60]), kp2_y=np.float32([50, 50.5, 58, 50, 50]), kp2_octave=np.int32([0, 0, 0, 0, 0]),
+               level_sigma2=np.float32([1.0]), scale_factors=np.float32([1.0]))
+    ang = np.zeros(5, np.float32)
+    m, n = oracle.search_for_triangulation(z, ang[:1], [1], t, ang, [1, 1, 1, 1, 1], _one_node(1), _one_node(5), epi, False)
+    assert m.tolist() == [3] and n == 1                          # 0, 1, 3 tie at 20 (1 is 0.5 px off the line: 0.25 < 3.84); 2 is 8 px off; 4 is > TH_LOW
+    epi2 = dict(epi, ex=300.0, ey=50.0)                          # candidate 3 sits on the epipole
+    m, n = oracle.search_for_triangulation(z, ang[:1], [1], t, ang, [1, 1, 1, 1, 1], _one_node(1), _one_node(5), epi2, False)
+    assert m.tolist() == [1]
+    m, n = oracle.search_for_triangulation(z, ang[:1], [1], t, ang, [1, 0, 1, 0, 1], _one_node(1), _one_node(5), epi, False)
+    assert m.tolist() == [0]                                     # features that already hold a MapPoint are not candidates
+    m, n = oracle.search_for_triangulation(z, ang[:1], [0], t, ang, [1, 1, 1, 1, 1], _one_node(1), _one_node(5), epi, False)
+    assert m.tolist() == [-1] and n == 0
