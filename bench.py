@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the latency / with_transfers legs")
     ap.add_argument("--lanes", type=int, default=1, help="independent extractor handles/streams the batch is split over (overlaps latency-bound kernels)")
+    ap.add_argument("--serial", action="store_true", help="profiling aid: synchronise after the extraction and after the matching of every step (no kernel of one overlaps the other); with DCS_ORB_NO_OVERLAP=1 every kernel runs alone")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU check of the N > 1 entry: launcher -> ranks -> gloo process group -> the feature all-gather, then one JSON line")
     return ap.parse_args(argv)
@@ -160,6 +161,7 @@ class Pipeline:
         self.newest = torch.tensor([NP + 2 * (s * frames + frames - 1) + c for s in range(streams) for c in (0, 1)], dtype=torch.int64, device=dev)
         self.ev_all = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_events)]
         self.step_no = 0
+        self.serial = False
         self.post_match = None                          # hook: called inside step() after the matcher launch (all-gather leg)
 
     def step(self):
@@ -181,6 +183,8 @@ class Pipeline:
             first += self.lane_pairs[li]
         for li in range(self.n_lanes):
             torch.cuda.current_stream().wait_event(self.lane_done[li])
+        if self.serial:
+            torch.cuda.synchronize()
         if self.streams == 1:
             d_kp[0:2].copy_(self.d_kp_b[prv][self.S - 2:]); d_desc[0:2].copy_(self.d_desc_b[prv][self.S - 2:]); d_n[0:2].copy_(self.d_n_b[prv][self.S - 2:])
         else:
@@ -192,6 +196,8 @@ class Pipeline:
         if self.post_match is not None:
             self.post_match(d_kp, d_desc, d_n, ev)
         self.match_done[cur].record()
+        if self.serial:
+            torch.cuda.synchronize()
 
     def last_slots(self):
         c = (self.step_no - 1) % self.NB
@@ -329,6 +335,7 @@ def main():
     P, W, H, NF = args.pairs, args.width, args.height, args.nfeatures
     n_ev = args.steps + args.warmup
     pipe = Pipeline(pkg, torch, dev, local_rank, W, H, NF, 1, P, args.lanes, rank, n_ev)
+    pipe.serial = args.serial
     ext, cap, S, n_pairs, n_lanes = pipe.ext, pipe.cap, pipe.S, pipe.n_pairs, pipe.n_lanes
     matcher = pipe.matcher
     stream = torch.cuda.current_stream().cuda_stream
