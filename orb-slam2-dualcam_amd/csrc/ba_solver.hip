@@ -20,9 +20,11 @@
 //                   (k_ldlt_reg: column-by-column VALU predecessor, DCS_BA_LDLT_VALU=1; k_ldlt_panel/_update/_solve:
 //                   multi-launch fallback for n > 256)
 //   k_solve_update  landmark back-substitution, push + manifold update of all estimates, computeScale partials
-//   k_error         edge-parallel residual + chi2 + Huber rho; the last block adds the block partials (and the scale
-//                   partials) in index order
-// The host reads back 5 doubles per trial and runs g2o's accept / reject logic.
+//   k_error<1>      edge-parallel residual + chi2 + Huber rho of the trial estimates; the problem's last block adds the block
+//                   partials (and the scale partials) in index order and runs g2o's accept / reject logic ON THE DEVICE
+//   k_post          between iterations: round change (outlier flags, level-1 set, robust kernel off), errors of a stale state,
+//                   progress words for the host
+// Every kernel covers a whole batch of problems (blockIdx.y); the host only enqueues steps and watches a pinned progress word.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -185,9 +187,9 @@ struct BaProb {
     double *Hpp, *bp, *bsch, *xp;                  // per free pose
     double *S, *W;                                 // reduced camera system (ld x ld), panel scratch of the n > 256 fallback
     const int32_t *pose_idx, *pt_off, *pt_edges, *ps_off, *ps_edges, *pair_ij, *pair_off, *pair_e1, *pair_e2;
-    double *partial, *scale_part;
+    double *partial, *scale_part, *maxd_part;      // block partials: chi2, computeScale, max |diagonal| (np + nb_pts entries)
     uint8_t* pt_active;
-    unsigned* ticket;
+    unsigned* ticket;                              // [0] error kernels, [1] k_reduce_pose, [2] k_post
     const DCams* cams;
     double *out_poses, *out_points;
 };
@@ -366,7 +368,35 @@ __global__ __launch_bounds__(256) void k_linearize(const BaProb* __restrict__ pr
 // block (1024 threads) per free pose: 37 edge chunks x 27 components, combined in chunk order (deterministic). The
 // list walk is latency-bound (index load -> value load), so many short chunks with 4 loads in flight each.
 constexpr int kPoseChunks = 37;
-__global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
+// computeLambdaInit (optimization_algorithm_levenberg.cpp:170-181) rides along: every block leaves the max |diagonal| of its
+// Hessian blocks in maxd_part[], and at the first iteration of a round the last block to finish (ticket) takes the maximum of
+// those np + nb_pts numbers -- a max is order-independent, so the result is reproducible -- and resets the LM multipliers.
+// Called by the first wave of a block with a wave-uniform `md`.
+__device__ __forceinline__ void reduce_finish(const BaProb& pb, BaCtl& ctl, double md)
+{
+    if (ctl.it != 0) return;                                 // block-uniform: lambda is only initialised at the first iteration
+    const int lane = threadIdx.x & 63, n_blk = pb.np + pb.nb_pts;
+    int last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(&pb.maxd_part[blockIdx.x], md, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(pb.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)n_blk - 1;
+    }
+    last = __shfl(last, 0);
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double m = 0.0;
+    for (int i = lane; i < n_blk; i += 64) m = fmax(m, __hip_atomic_load(&pb.maxd_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d));
+    if (lane == 0) {
+        ctl.maxdiag = m; ctl.mult = 1.0; ctl.ni = 2; ctl.nBad = 0;       // lambda = tau * max diagonal, tau = 1e-5
+        __hip_atomic_store(pb.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
 {
     __shared__ double part[kPoseChunks][27];
     __shared__ double s[27];
@@ -377,19 +407,26 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__
     if ((int)blockIdx.x >= np) {                             // blocks past the free poses: 64 landmarks each (thread per landmark)
         if (threadIdx.x >= 64) return;
         const int l = (blockIdx.x - np) * 64 + threadIdx.x;
-        if (l >= pb.L) return;
         double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         int n_act = 0;
-        for (int k = pb.pt_off[l]; k < pb.pt_off[l + 1]; ++k) {
+        for (int k = l < pb.L ? pb.pt_off[l] : 0, k1 = l < pb.L ? pb.pt_off[l + 1] : 0; k < k1; ++k) {
             const int e = pb.pt_edges[k];
             n_act += pb.active[e];
             const double* c = pb.cpoint + (size_t)e * 9;
             for (int i = 0; i < 9; ++i) a[i] += c[i];
         }
+        // NOTE: threads of this branch must all reach the block's finisher below (no early return for l >= L)
+        double md = 0.0;
+        if (l < pb.L) {
         pb.pt_active[l] = n_act > 0;                 // a landmark without active edges is not part of this round
         double* H = pb.Hll + (size_t)l * 9;
         H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
         pb.bl[3 * l] = a[6]; pb.bl[3 * l + 1] = a[7]; pb.bl[3 * l + 2] = a[8];
+        if (n_act > 0) md = fmax(fmax(fabs(a[0]), fabs(a[3])), fabs(a[5]));
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) md = fmax(md, __shfl_xor(md, d));
+        reduce_finish(pb, ctls[blockIdx.y], md);
         return;
     }
     const int32_t* __restrict__ ps_off = pb.ps_off;
@@ -412,25 +449,10 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__
         pb.Hpp[(size_t)i * 36 + t] = s[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
     }
     if (t < 6) pb.bp[i * 6 + t] = s[21 + t];
-}
-
-// max |diagonal| over pose and landmark blocks (computeLambdaInit) at the first iteration of a round; block per problem.
-__global__ __launch_bounds__(256) void k_max_diag(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
-{
-    __shared__ double s[256];
-    const BaProb& pb = probs[blockIdx.y];
-    BaCtl& ctl = ctls[blockIdx.y];
-    if (ctl.state != ST_NEW_ITER || ctl.it != 0) return;
-    double m = 0;
-    for (int i = threadIdx.x; i < pb.np * 6; i += 256) m = fmax(m, fabs(pb.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
-    for (int i = threadIdx.x; i < pb.L * 3; i += 256) {
-        const int l = i / 3;
-        if (pb.pt_active[l]) m = fmax(m, fabs(pb.Hll[(size_t)l * 9 + (i % 3) * 4]));
+    if (t < 64) {                                            // wave 0: max |diagonal| of this pose block (entries 0, 6, 11, 15, 18, 20 of the packed upper triangle)
+        const double md = fmax(fmax(fmax(fabs(s[0]), fabs(s[6])), fmax(fabs(s[11]), fabs(s[15]))), fmax(fabs(s[18]), fabs(s[20])));
+        reduce_finish(pb, ctls[blockIdx.y], md);
     }
-    s[threadIdx.x] = m;
-    __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + d]); __syncthreads(); }
-    if (threadIdx.x == 0) { ctl.maxdiag = s[0]; ctl.mult = 1.0; ctl.ni = 2; ctl.nBad = 0; }   // lambda = tau * max diagonal, tau = 1e-5
 }
 
 // setLambda for the landmark blocks, one launch:
@@ -1201,57 +1223,105 @@ __global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ 
     if (threadIdx.x == 0) pb.scale_part[blockIdx.x] = sc;
 }
 
-// End of a round (state == ROUND_END): outlier flags chi2 (last evaluation) > th || depth <= 0 with the CURRENT estimates
-// (Optimizer.cc:607, 653). After round 0 they become the level-1 set of round 1 (:607-612) unless the stop flag was seen
-// (:597-600); the current estimates are copied to the output arrays either way.
-__global__ __launch_bounds__(256) void k_round_flags(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
+// Last kernel of every step (and once before the first): everything that happens BETWEEN LM iterations.
+//   state == ROUND_END   outlier flags chi2 (last evaluation) > th || depth <= 0 with the CURRENT estimates (Optimizer.cc:607,
+//                        653); after round 0 they become the level-1 set of round 1 (:607-612) unless the stop flag was seen
+//                        (:597-600), and the same thread evaluates the edge's error for round 1's first iteration (robust kernel
+//                        off); the current estimates are copied to the output arrays. The problem's last block (ticket) then
+//                        starts round 1 (lambda is re-initialised by k_reduce_pose) or marks the problem done.
+//   state == NEW_ITER with stale errors (first iteration of round 0; an iteration that ended on a rejected trial)
+//                        computeActiveErrors at the current estimates, chi2 total -> currentChi.
+// The last block of the whole grid publishes {step, problems done} to the host's pinned progress words.
+__global__ __launch_bounds__(256) void k_post(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int step, int* __restrict__ h_progress,
+                                              unsigned* __restrict__ grid_ticket)
 {
+    __shared__ double s[256];
     __shared__ DCams cams;
     __shared__ int s_cnt;
+    __shared__ bool last;
     const BaProb& pb = probs[blockIdx.y];
     BaCtl& ctl = ctls[blockIdx.y];
-    if ((int)blockIdx.x >= pb.nblk || ctl.state != ST_ROUND_END) return;
-    const double* __restrict__ poses = pb.poses[ctl.cur];
-    const double* __restrict__ points = pb.points[ctl.cur];
-    const int round = ctl.round, stopped = ctl.stopped;
-    if (threadIdx.x == 0) s_cnt = 0;
-    load_cams(&cams, pb.cams);
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < pb.E) {
-        double pc[3];
-        cam_point(poses + 7 * pb.epose[e], points + 3 * pb.epoint[e], cams.c[pb.ecam[e]], pc);
-        const uint8_t f = (pb.chi2[e] > pb.chi2_th || !(pc[2] > 0.0)) ? 1 : 0;
-        pb.flag[e] = f;
-        if (round == 0) {
-            pb.level1[e] = stopped ? 0 : f;
-            if (!stopped) { pb.active[e] = !f; if (!f) atomicAdd(&s_cnt, 1); }
+    const int state = ctl.state;
+    const bool round_end = state == ST_ROUND_END, pre = state == ST_NEW_ITER && !ctl.errors_current;
+    if ((int)blockIdx.x < pb.nblk && (round_end || pre)) {
+        const double* __restrict__ poses = pb.poses[ctl.cur];
+        const double* __restrict__ points = pb.points[ctl.cur];
+        const int round = ctl.round, stopped = ctl.stopped;
+        const bool next_round = round_end && round == 0 && !stopped && pb.iters[1] > 0;
+        const int robust = round_end ? 0 : ctl.robust;
+        const double delta = pb.delta;
+        if (threadIdx.x == 0) s_cnt = 0;
+        load_cams(&cams, pb.cams);
+        const int e = blockIdx.x * 256 + threadIdx.x;
+        double rho0 = 0;
+        if (e < pb.E) {
+            double pc[3];
+            const DCam& c = cams.c[pb.ecam[e]];
+            cam_point(poses + 7 * pb.epose[e], points + 3 * pb.epoint[e], c, pc);
+            bool act = pb.active[e] != 0;
+            if (round_end) {
+                const uint8_t f = (pb.chi2[e] > pb.chi2_th || !(pc[2] > 0.0)) ? 1 : 0;
+                pb.flag[e] = f;
+                if (round == 0) {
+                    pb.level1[e] = stopped ? 0 : f;
+                    if (!stopped) { act = !f; pb.active[e] = act; if (act) atomicAdd(&s_cnt, 1); }
+                }
+            }
+            if ((pre || next_round) && act) {
+                const double e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+                const double e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+                const double w = pb.w[e];
+                const double x2 = e0 * (w * e0) + e1 * (w * e1);
+                pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
+                if (robust && x2 > delta * delta) rho0 = 2 * sqrt(x2) * delta - delta * delta; else rho0 = x2;
+            }
+        }
+        if (round_end) {
+            for (int i = blockIdx.x * 256 + threadIdx.x; i < 7 * pb.P; i += pb.nblk * 256) pb.out_poses[i] = poses[i];
+            for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * pb.L; i += pb.nblk * 256) pb.out_points[i] = points[i];
+        }
+        const double t = block_sum_256(rho0, s);
+        if (threadIdx.x == 0) {
+            if (s_cnt) atomicAdd(&ctl.n_active, s_cnt);
+            __hip_atomic_store(&pb.partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            last = __hip_atomic_fetch_add(pb.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)pb.nblk - 1;
+        }
+        __syncthreads();
+        if (last) {                                           // block-uniform
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            double v = 0;
+            for (int i = threadIdx.x; i < pb.nblk; i += 256) v += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double tot = block_sum_256(v, s);
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(pb.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int n_act = __hip_atomic_load(&ctl.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pre || (next_round && n_act > 0)) {
+                    if (next_round) { ctl.round = 1; ctl.it = 0; ctl.qmax = 0; ctl.nBad = 0; ctl.robust = 0; }   // Optimizer.cc:612-621
+                    ctl.currentChi = tot; ctl.iniChi = tot; ctl.errors_current = 1; ctl.state = ST_NEW_ITER;
+                } else ctl.state = ST_DONE;
+            }
         }
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < 7 * pb.P; i += pb.nblk * 256) pb.out_poses[i] = poses[i];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * pb.L; i += pb.nblk * 256) pb.out_points[i] = points[i];
-    __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) atomicAdd(&ctl.n_active, s_cnt);
-}
-
-// one thread per problem: round 0 -> round 1 (robust kernel off, lambda re-initialised, Optimizer.cc:612-621) or done;
-// thread 0 then publishes {step, problems done} to the host's pinned progress words.
-__global__ __launch_bounds__(1024) void k_round_ctl(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int step, int* __restrict__ h_progress)
-{
-    __shared__ int s_done;
-    if (threadIdx.x == 0) s_done = 0;
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += 1024) {
-        BaCtl& ctl = ctls[b];
-        if (ctl.state == ST_ROUND_END) {
-            if (ctl.round == 0 && !ctl.stopped && probs[b].iters[1] > 0 && ctl.n_active > 0) {
-                ctl.round = 1; ctl.it = 0; ctl.qmax = 0; ctl.nBad = 0; ctl.robust = 0; ctl.errors_current = 0; ctl.state = ST_NEW_ITER;
-            } else ctl.state = ST_DONE;
-        }
-        if (ctl.state == ST_DONE) atomicAdd(&s_done, 1);
-    }
+    // ---- progress: the last block of the grid counts the finished problems
+    __shared__ bool glast;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_store(h_progress + 1, s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        glast = __hip_atomic_fetch_add(grid_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1;
+    }
+    __syncthreads();
+    if (!glast) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    int done = 0;
+    for (int b = threadIdx.x; b < B; b += 256) done += __hip_atomic_load(&ctls[b].state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ST_DONE;
+    const double nd = block_sum_256((double)done, s);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(grid_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(h_progress + 1, (int)nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(h_progress, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -1714,6 +1784,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     struct Regions { size_t upload_end, zero_begin, zero_end, dl_begin, dl_end; };
     std::vector<BaProb> hp(NB);
     BaProb* d_probs = nullptr; BaCtl* d_ctls = nullptr;
+    unsigned* d_grid_ticket = nullptr;
     auto layout = [&](Carver& c, Regions& rg) {
         for (int i = 0; i < NB; ++i) {
             const dcs_ba_problem* pb = problems[live[i]];
@@ -1741,6 +1812,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         for (int i = 0; i < NB; ++i) {
             BaProb& q = hp[i];
             q.ticket = c.get<unsigned>(4);
+            if (i == 0) d_grid_ticket = c.get<unsigned>(4);
             q.S = q.use_reg ? c.get<double>((size_t)q.ld * q.ld) : nullptr;       // pairs without shared points stay 0
         }
         rg.zero_end = c.off;
@@ -1754,7 +1826,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.Hpl = c.get<double>(18 * E); q.BD = c.get<double>(18 * E); q.cpose = c.get<double>(27 * E); q.cpoint = c.get<double>(9 * E);
             q.Hll = c.get<double>(9 * L); q.bl = c.get<double>(3 * L); q.Dinv = c.get<double>(9 * L); q.db = c.get<double>(3 * L); q.xl = c.get<double>(3 * L);
             q.Hpp = c.get<double>(36 * P); q.bp = c.get<double>(6 * P); q.bsch = c.get<double>(6 * P); q.xp = c.get<double>(6 * P);
-            q.partial = c.get<double>(q.nblk); q.scale_part = c.get<double>(q.nb_pts + q.nb_pose);
+            q.partial = c.get<double>(q.nblk); q.scale_part = c.get<double>(q.nb_pts + q.nb_pose); q.maxd_part = c.get<double>(q.np + q.nb_pts);
             q.pt_active = c.get<uint8_t>(L);
         }
         c.off = (c.off + 255) & ~(size_t)255;
@@ -1839,6 +1911,9 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     }
     const BaProb* dp = d_probs;
     const volatile int* d_stop = h_words + 16;
+    // before the first step: errors of the initial estimates (or, with iters1 <= 0, straight to the flags)
+    hipLaunchKernelGGL(k_post, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, NB, 0, h_words, d_grid_ticket);
+    DCS_CHECK_LAUNCH();
     const bool timing = ctx.timing;
     auto event_at = [&](size_t i) -> hipEvent_t {
         while (ctx.events.size() <= i) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ctx.events.push_back(e); }
@@ -1847,10 +1922,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     auto mark = [&](int step, int k) { if (timing) { hipEvent_t e = event_at((size_t)(step - 1) * 4 + k); if (e) (void)hipEventRecord(e, st); } };
     auto enqueue_step = [&](int step) -> int {
         mark(step, 0);
-        hipLaunchKernelGGL(k_error<0>, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, (const volatile int*)nullptr);      // computeActiveErrors (stale errors only)
         hipLaunchKernelGGL(k_linearize, dim3(g_edges, NB), dim3(256), 0, st, dp, (const BaCtl*)d_ctls);                    // buildSystem
-        hipLaunchKernelGGL(k_reduce_pose, dim3(g_reduce, NB), dim3(1024), 0, st, dp, (const BaCtl*)d_ctls);
-        hipLaunchKernelGGL(k_max_diag, dim3(1, NB), dim3(256), 0, st, dp, d_ctls);                                        // computeLambdaInit (first iteration)
+        hipLaunchKernelGGL(k_reduce_pose, dim3(g_reduce, NB), dim3(1024), 0, st, dp, d_ctls);                              // + computeLambdaInit (first iteration)
         hipLaunchKernelGGL(k_prep, dim3(g_prep, NB), dim3(256), 0, st, dp, d_ctls);                                       // setLambda + solve (Schur)
         DCS_CHECK_LAUNCH();
         if (any_blocked) {                                // the blocked fallback factors S in place: rebuild it every trial
@@ -1874,8 +1947,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         mark(step, 2);
         hipLaunchKernelGGL(k_solve_update, dim3(g_update, NB), dim3(64), 0, st, dp, (const BaCtl*)d_ctls);
         hipLaunchKernelGGL(k_error<1>, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, d_stop);        // chi2 of the trial + computeScale + accept / reject
-        hipLaunchKernelGGL(k_round_flags, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls);
-        hipLaunchKernelGGL(k_round_ctl, dim3(1), dim3(1024), 0, st, dp, d_ctls, NB, step, h_words);
+        hipLaunchKernelGGL(k_post, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, NB, step, h_words, d_grid_ticket);          // round change / stale errors / progress
         mark(step, 3);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
