@@ -3,11 +3,11 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 PKG="orb-slam2-dualcam_amd"
-OUT="$PKG/lib"
-OBJ="$PKG/build"
+OUT="${DCS_OUT_DIR:-$PKG/lib}"          # DCS_OUT_DIR / DCS_OBJ_DIR / DCS_EXTRA_FLAGS: side builds for A/B timing and profiling (scratch/)
+OBJ="${DCS_OBJ_DIR:-$PKG/build}"
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude ${DCS_EXTRA_FLAGS:-}"
 SRCS=(common.cpp comm.cpp orb_host.cpp octree.cpp orb_extract.cpp orb_kernels.hip octree_kernels.hip match_kernels.hip proj_kernels.hip bow_kernels.hip ba_solver.hip)
 OBJS=()
 pids=()

@@ -214,39 +214,80 @@ __device__ __forceinline__ void xcd_image_block(int b, int n_images, int per_ima
 
 // ------------------------------------------------------------------------------------- FAST
 typedef short short2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 
-// FAST-9/16 score of the pixel at c (LDS bytes, row pitch P): max over the 16 contiguous 9-arcs of the sign-consistent
-// minimum |centre - ring|, minus 1 (== OpenCV cornerScore<16>; "corner at T" <=> score >= T, so the score does not
-// depend on the threshold). Both polarities ride in one packed register: lo16 = c - ring ("darker"), hi16 = ring - c.
-template <int P>
-__device__ __forceinline__ int fast_score(const uint8_t* c)
+// FAST-9/16 score of ONE polarity of the pixel whose 7x7 neighbourhood starts at b (LDS bytes, row pitch P; the centre is
+// b[3P + 3]): max over the 16 contiguous 9-arcs of min(sign * (ring - centre)), minus 1 (== OpenCV cornerScore<16> when the
+// other polarity has no arc at the threshold, see k_fast_cells step 3). Ring pixel k and its opposite k + 8 share one
+// register (lo = k, hi = k + 8): the arc k .. k + 8 is "k .. 7" of the low halves + "8 .. k + 8" of the high halves and the arc
+// k + 8 .. k + 16 the same with the halves exchanged, so 7 suffix minima, 7 prefix minima and 8 half-swapped minima
+// (v_pk_min_i16 op_sel) give all 16 arcs: 31 packed instructions per polarity instead of 59 for both polarities side by side.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)p; }
+__device__ __forceinline__ unsigned pk_min_i16_swap(unsigned a, unsigned b)            // (min(a.lo, b.hi), min(a.hi, b.lo))
 {
-    constexpr int off[16] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
-                         -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1};
-    const int v = c[0];
-    short2_t d[16], g[16], h[16];
+    unsigned r;
+    asm("v_pk_min_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_min_i16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b)));
+}
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b)));
+}
+__device__ __forceinline__ int fast_arcs(const unsigned (&R)[8], unsigned sgn, unsigned vs)
+{
+    unsigned D[8], S[8], Q[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const unsigned vr = (unsigned)v | ((unsigned)c[off[k]] << 16);            // (lo = centre, hi = ring)
-        asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d[k]) : "v"(vr));   // lo = v - r, hi = r - v
+    for (int k = 0; k < 8; ++k) asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(D[k]) : "v"(R[k]), "v"(sgn), "v"(vs));    // sign * (ring - centre)
+    S[7] = D[7]; Q[0] = D[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { S[7 - k] = pk_min_i16(D[7 - k], S[8 - k]); Q[k] = pk_min_i16(Q[k - 1], D[k]); }
+    unsigned best = pk_min_i16_swap(S[0], Q[0]);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) best = pk_max_i16(best, pk_min_i16_swap(S[k], Q[k]));
+    const short2_t bb = __builtin_bit_cast(short2_t, best);
+    return max((int)bb.x, (int)bb.y);
+}
+template <int P>
+__device__ __forceinline__ int fast_score(const uint8_t* b, unsigned th_pk /* th in both halves */)
+{
+    constexpr int C = 3 * P + 3;
+    // ring pixel k (OpenCV's order, starting below the centre) at b[off[k]], its opposite k + 8 at b[2C - off[k]]
+    constexpr int off[8] = {C + 3 * P, C + 3 * P + 1, C + 2 * P + 2, C + P + 3, C + 3, C - P + 3, C - 2 * P + 2, C - 3 * P + 1};
+    unsigned R[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) R[k] = (unsigned)b[off[k]] | ((unsigned)b[2 * C - off[k]] << 16);
+    const unsigned v = b[C], V = v | (v << 16);
+    // which polarity can hold an arc at the threshold: a 9-arc covers two ADJACENT compass pixels (ring 0, 4, 8, 12)
+    unsigned a0, a4, c0, c4;
+    asm("v_pk_max_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(a0) : "v"(R[0]));       // max(r0, r8) in both halves
+    asm("v_pk_max_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(a4) : "v"(R[4]));
+    asm("v_pk_min_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(c0) : "v"(R[0]));
+    asm("v_pk_min_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(c4) : "v"(R[4]));
+    const ushort2_t Vv = __builtin_bit_cast(ushort2_t, V), Tv = __builtin_bit_cast(ushort2_t, th_pk);
+    const unsigned e = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, a0), __builtin_bit_cast(ushort2_t, a4)));
+    const unsigned f = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, c0), __builtin_bit_cast(ushort2_t, c4)));
+    const bool brighter = e > __builtin_bit_cast(unsigned, (ushort2_t)(Vv + Tv));              // equal halves on both sides: one 32-bit compare
+    const bool darker = f < __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(Vv, Tv));
+    const unsigned mV = __builtin_bit_cast(unsigned, (short2_t)(-__builtin_bit_cast(short2_t, V)));
+    // brighter: ring - centre = R * (+1) + (-V); darker: centre - ring = R * (-1) + V
+    int s = fast_arcs(R, brighter ? 0x00010001u : 0xffffffffu, brighter ? mV : V);
+    if (__any(brighter && darker)) {                    // both polarities pass the compass test (rare): the score is the larger one
+        if (brighter && darker) s = max(s, fast_arcs(R, 0xffffffffu, V));
     }
-    // min over every circular window of 9 (van Herk / Gil-Werman with two blocks of 8): g = prefix minima and
-    // h = suffix minima inside blocks {0..7}, {8..15}; window k..k+8 = h[k] (k .. block end) + g[k+8] (next block start .. k+8)
-#pragma unroll
-    for (int blk = 0; blk < 16; blk += 8) {
-        g[blk] = d[blk]; h[blk + 7] = d[blk + 7];
-#pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            g[blk + j] = __builtin_elementwise_min(g[blk + j - 1], d[blk + j]);
-            h[blk + 7 - j] = __builtin_elementwise_min(h[blk + 8 - j], d[blk + 7 - j]);
-        }
-    }
-    short2_t best = __builtin_elementwise_min(h[0], g[8]);
-#pragma unroll
-    for (int k = 1; k < 16; ++k) best = __builtin_elementwise_max(best, __builtin_elementwise_min(h[k], g[(k + 8) & 15]));
-    return max((int)best.x, (int)best.y) - 1;
+    return max(s, 1) - 1;
 }
 
+// Profiling builds (-DDCS_FAST_SECTIONS, scratch/fast_sections.sh) can end the kernel after a section to count the instructions
+// of each one with the PMC counters; product builds compile the hook away.
+#ifdef DCS_FAST_SECTIONS
+#define DCS_FAST_SECTION(n) do { if (dbg_stop == (n)) { if (lane == 0) cell_count[(size_t)img * n_cells + cell] = 0; return; } } while (0)
+#else
+#define DCS_FAST_SECTION(n) do { } while (0)
+#endif
 // One wave per (cell, image) -- the reference's per-cell cv::FAST call (ORBextractor.cc:789-827):
 //   1. ROI -> LDS with aligned dword loads (byte loads when the level is not 4-byte aligned)
 //   2. necessary test on the 4 compass ring pixels at minTh (a 9-arc always covers 2 adjacent ones); survivors are
@@ -258,7 +299,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* c)
 template <int P>           // LDS row pitch in bytes (64 or 128): compile-time so that the ring offsets are immediates
 __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
                                                    dcs_candidate* __restrict__ slots, size_t slots_per_image,
-                                                   int32_t* __restrict__ cell_count, int map_bytes, int n_images, int sc_pitch, int sc_bytes)
+                                                   int32_t* __restrict__ cell_count, int map_bytes, int n_images, int sc_pitch, int sc_bytes, int dbg_stop)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_px = smem;
@@ -316,6 +357,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         for (int i = lane; i < (sc_bytes >> 4); i += 64) sc_q[i] = uint4{0, 0, 0, 0};
     }
     __syncthreads();
+    DCS_FAST_SECTION(1);
     const uint8_t* px = s_px + shift;
     // score map: only the detection area and its 1-px rim exist, pixel (x, y) of the ROI at s_sc[(y - 2) * sc_pitch + (x - 2)] (the
     // smaller map buys LDS room for two more resident waves per SIMD, and FAST loses 13 % when it loses 1.25)
@@ -326,6 +368,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     // test at T: every pixel with score >= T does, so the score map holds exactly what the non-maximum suppression at T compares
     // (a neighbour whose score is missing has score < T <= s(p) and would lose anyway). 91 % of the cells of the benchmark
     // scene stop after the first pass, which scores a third fewer pixels than the minThFAST pass.
+    const int spare = dw * dh + 32;                // u16 slot behind the survivor list (and behind what an odd last row appends)
     int n_list = 0;
     unsigned long long sel = 0;                    // one bit per list round of this lane: keypoints of the pass that produced some
     // position of this lane among the set bits of a ballot: v_mbcnt_lo + v_mbcnt_hi
@@ -337,35 +380,46 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         // a 9-arc covers two ADJACENT compass pixels: (b0|b8)&(b4|b12) for "brighter", same for "darker". The two compares are
         // balloted one by one (ballot of a plain compare IS the compare's SGPR mask; a ballot of their OR would be rebuilt through
         // v_cndmask + v_cmp) and combined with scalar 64-bit logic.
-        auto compass = [&](const uint8_t* c, bool& brighter, bool& darker) {
-            const int v = c[0], hi = v + th, lo = v - th;
-            const int r0 = c[3 * P], r4 = c[3], r8 = c[-3 * P], r12 = c[-3];
+        // b = the pixel 3 up and 3 left of the centre: every LDS offset is a non-negative immediate
+        auto compass = [&](const uint8_t* b, bool& brighter, bool& darker) {
+            const int v = b[3 * P + 3], hi = v + th, lo = v - th;
+            const int r0 = b[6 * P + 3], r4 = b[3 * P + 6], r8 = b[3], r12 = b[3 * P];
             brighter = min(max(r0, r8), max(r4, r12)) > hi;
             darker = max(min(r0, r8), min(r4, r12)) < lo;
         };
         n_list = 0;
         if (dw <= 32) {                                  // two detection rows per round: lanes 0-31 row y, lanes 32-63 row y + 1
-            const int x = 3 + (lane & 31);
             const bool col_ok = (lane & 31) < dw;
             const unsigned long long m_col = __builtin_amdgcn_ballot_w64(col_ok);
-            const uint8_t* c = px + (3 + (lane >> 5)) * P + x;
-            int y = 3 + (lane >> 5);
-            for (int yy = 0; yy < dh; yy += 2, y += 2, c += 2 * P) {                          // wave-uniform trip count
-                // every lane evaluates the test (a lane outside the detection area reads the score map at worst: still inside
-                // the LDS allocation)
+            const uint8_t* b = px + (lane >> 5) * P + (lane & 31);
+            unsigned yx = (unsigned)(((3 + (lane >> 5)) << 8) | (3 + (lane & 31)));
+            unsigned long long m = 0;
+            const unsigned list_addr = lds_addr(s_list);
+            unsigned spare_addr = list_addr + 2u * (unsigned)spare, end_addr = list_addr;       // end_addr: scalar, behind the last entry
+            asm volatile("" : "+v"(spare_addr));                                                 // keep it in a VGPR across the loop
+            for (int yy = 0; yy < dh; yy += 2, yx += 0x200u, b += 2 * P) {                   // wave-uniform trip count
+                // Every lane evaluates the test (a lane outside the detection area reads the score map at worst: still inside
+                // the LDS allocation). The two compares are balloted one by one (the ballot of a plain compare IS its SGPR mask)
+                // and combined with scalar logic. No branch, no exec mask: a lane that has nothing to append writes the spare
+                // slot behind the list (v_cndmask on the lane's bit of m). When dh is odd the upper half-wave's last row lies
+                // below the detection area: whatever it appends comes after every valid entry and is cut off by the count below.
                 bool br, dk;
-                compass(c, br, dk);
-                const bool y_ok = y < dh + 3;
-                const unsigned long long m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & m_col & __builtin_amdgcn_ballot_w64(y_ok);
-                if ((br | dk) & col_ok & y_ok) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
-                n_list += __popcll(m);
+                compass(b, br, dk);
+                m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & m_col;
+                const unsigned at = ((unsigned)rank_in(m) << 1) + end_addr;
+                unsigned to;
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(to) : "v"(spare_addr), "v"(at), "s"(m));
+                *reinterpret_cast<__attribute__((address_space(3))) uint16_t*>((uintptr_t)to) = (uint16_t)yx;
+                end_addr += 2u * (unsigned)__popcll(m);
             }
+            n_list = (int)((end_addr - list_addr) >> 1);
+            if (dh & 1) n_list -= __popc((unsigned)(m >> 32));
         } else {
             int y = 3 + lane / dw, x = 3 + lane % dw;            // pixel p = p0 + lane, advanced by 64 per round without dividing
             const int step_y = 64 / dw, step_x = 64 % dw;
             for (int p0 = 0; p0 < ndet; p0 += 64) {
                 bool br, dk;
-                compass(px + y * P + x, br, dk);
+                compass(px + (y - 3) * P + (x - 3), br, dk);
                 const bool in_range = p0 + lane < ndet;
                 const unsigned long long m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & __builtin_amdgcn_ballot_w64(in_range);
                 if ((br | dk) & in_range) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
@@ -375,19 +429,28 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             }
         }
         __syncthreads();
-        // ---- 3. exact scores of the survivors (a second pass rewrites the first pass's entries with the same values)
+        DCS_FAST_SECTION(2);
+        // ---- 3. exact scores of the survivors. Only the polarity (or, rarely, both) that passed the compass test at this
+        // threshold is evaluated: the other one has no 9-arc at th, so its arc minimum is < th + 1 and cannot be the maximum of a
+        // pixel that scores >= th; a pixel that scores < th may be stored with a smaller value than cv::FAST's -- it is never
+        // emitted and loses every comparison against a neighbour that is (s(q) >= th > both values). A second pass rewrites the
+        // first pass's entries (its list is a superset), so every stored score >= min_th is exact then.
+        const unsigned th_pk = (unsigned)th * 0x10001u;
         for (int i = lane; i < n_list; i += 64) {
             const int yx = s_list[i], y = yx >> 8, x = yx & 255;
-            const int s = fast_score<P>(px + y * P + x);
-            sc[y * sc_pitch + x] = (uint8_t)max(s, 0);
+            int o = (y - 3) * P + (x - 3);
+            asm("" : "+v"(o));                          // opaque: keeps the 17 ring offsets non-negative immediates of ONE base address
+            const int s = fast_score<P>(px + o, th_pk);
+            sc[__mul24(y, sc_pitch) + x] = (uint8_t)s;
         }
         __syncthreads();
+        DCS_FAST_SECTION(3);
         // ---- 4. NMS: keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } (neighbours below T lose anyway)
         unsigned long long f = 0;
         int it = 0;
         for (int i = lane; i < n_list; i += 64, ++it) {
             const int yx = s_list[i], y = yx >> 8, x = yx & 255;
-            const uint8_t* c = sc + y * sc_pitch + x;
+            const uint8_t* c = sc + __mul24(y, sc_pitch) + x;
             const int s = c[0];
             if (s >= th) {
                 const uint8_t* cu = c - sc_pitch; const uint8_t* cd2 = c + sc_pitch;
@@ -396,6 +459,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             }
         }
         sel = f;
+        DCS_FAST_SECTION(4);
         if (__any(f != 0)) break;                      // vKeysCell not empty: no minThFAST retry (:812)
         __syncthreads();                               // the list is rebuilt by the next pass
     }
@@ -409,7 +473,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         if (flag && off < cd.cap) {
             const int yx = s_list[i0 + lane], y = yx >> 8, x = yx & 255;
             dcs_candidate o;
-            o.x = (int16_t)(x + cd.ox); o.y = (int16_t)(y + cd.oy); o.score = sc[y * sc_pitch + x];
+            o.x = (int16_t)(x + cd.ox); o.y = (int16_t)(y + cd.oy); o.score = sc[__mul24(y, sc_pitch) + x];
             out[off] = o;
         }
         base += __popcll(m);
@@ -424,19 +488,20 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
     if (n_cells == 0) return DCS_OK;
     const int P = (max_rw + 7 <= 48) ? 48 : (max_rw + 15 <= 64) ? 64 : 128;      // shift (<= 7 or 15) + row fits the pitch
     const int map_bytes = ((max_rh * P) + 15) & ~15;
-    const int list_bytes = (((max_rw - 6) * (max_rh - 6) * 2) + 15) & ~15;
+    const int list_bytes = ((((max_rw - 6) * (max_rh - 6) + 33) * 2) + 15) & ~15;      // + 32 entries of an odd last row + the spare slot
     const int sc_pitch = ((max_rw - 6 + 2) + 3) & ~3;              // detection width + 1-px rim
     const int sc_bytes = (sc_pitch * (max_rh - 6 + 2) + 15) & ~15;
     const size_t shmem = (size_t)map_bytes + sc_bytes + list_bytes;
+    static const int dbg_stop = getenv("DCS_FAST_STOP") ? atoi(getenv("DCS_FAST_STOP")) : 0;      // only read by -DDCS_FAST_SECTIONS builds
     if (P == 48)
         hipLaunchKernelGGL(k_fast_cells<48>, dim3(8, n_cells, (n_images + 7) / 8), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes);
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop);
     else if (P == 64)
         hipLaunchKernelGGL(k_fast_cells<64>, dim3(8, n_cells, (n_images + 7) / 8), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes);
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop);
     else
         hipLaunchKernelGGL(k_fast_cells<128>, dim3(8, n_cells, (n_images + 7) / 8), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes);
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

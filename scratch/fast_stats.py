@@ -4,7 +4,7 @@ import importlib
 synth = importlib.import_module('orb-slam2-dualcam_amd.synth')
 img,_ = synth.frame_pair(640,480,0,0)
 v = img.astype(np.int32)
-th=7
+th=int(sys.argv[1]) if len(sys.argv)>1 else 7
 c = v[3:-3,3:-3]
 r0=v[6:,3:-3]; r8=v[:-6,3:-3]; r4=v[3:-3,6:]; r12=v[3:-3,:-6]
 B=[r>c+th for r in (r0,r4,r8,r12)]; Dk=[r<c-th for r in (r0,r4,r8,r12)]

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
 pkg = e.load_package(); synth = pkg.synth
 import torch
-P = 128
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 imgs = []
 for f in range(P): imgs.extend(synth.frame_pair(640, 480, 0, f % 8))
 ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2 * P); cap = ext.default_cap()
@@ -13,4 +13,6 @@ st = torch.cuda.current_stream().cuda_stream
 for _ in range(3): ext.extract_batch_device(d_img, d_kp, d_desc, d_n, cap, stream=st)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): ext.extract_batch_device(d_img, d_kp, d_desc, d_n, cap, stream=st)
-torch.cuda.synchronize(); print("extract alone: %.1f us per %d images" % ((time.perf_counter() - t0) / 10 * 1e6, S), ext.timing_totals()[0])
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10 * 1e6
+tot, n = ext.timing_totals()
+print("extract alone: %.1f us per %d images; per call:" % (dt, S), {k: round(v / max(n, 1), 1) for k, v in tot.items()})
