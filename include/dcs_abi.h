@@ -201,6 +201,35 @@ int  dcs_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const
 int  dcs_search_by_projection(const dcs_proj_frame* frame, const dcs_proj_queries* queries, int th_high, float nn_ratio,
                               int check_orientation, int32_t* match_of_query, int32_t* query_of_feature, int* n_matches);
 
+/* The same call also is SearchByProjectionOnCam(F, query, KF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:812-951: best only,
+   taken = pF->mvpMapPoints[g] != NULL, th_high = ORBdist, levels nPredictedLevel -+ 1, check_orientation) and
+   SearchByProjection(KF, query, Scw, vpPoints, vpMatched, th) (:416-536: best only, taken = vpMatched[idxLocal] != NULL, TH_LOW,
+   levels nPredictedLevel - 1 .. nPredictedLevel) -- both mark the matched feature as taken for the queries that follow.
+
+   Window searches whose queries do NOT see each other's results -- the candidate loops of
+     Fuse(KF, vpMapPoints, th)                        ORBmatcher.cc:1431-1556  kf_area = 1, chi2 gate, levels pred - 1 .. pred, th = TH_LOW
+     Fuse(KF, Scw, vpPoints, th, vpReplacePoint)      :1560-1706               kf_area = 1, no chi2 gate, levels pred - 1 .. pred, TH_LOW
+     SearchBySim3CrossCam (each direction)            :1713-1965               kf_area = 1, levels pred - 1 .. pred, th = TH_HIGH
+     SearchByProjection(KF, vpMapPoints, sAlreadyFound, th, ORBdist)  :693-799 kf_area = 1, levels pred - 1 .. pred + 1, th = ORBdist
+   one wave per query. kf_area != 0: candidates as KeyFrame::GetFeaturesInArea returns them (KeyFrame.cc:728-765: no level
+   argument, and the |dx|,|dy| < r test reads mvTotalKeysUn[camera-LOCAL index], :756 -- reproduced); the octave gate is the
+   loop's own (min_level <= octave <= max_level). chi2_inv_sigma2 (NULL = off; n_levels entries = mvInvLevelSigma2): Fuse's
+   reprojection gate e2 * mvInvLevelSigma2[octave] > 5.99 (:1503-1509). frame->taken may be NULL (nothing to skip).
+   match_of_query[n] = GLOBAL feature index or -1 (bestDist <= th), best_dist[n] (NULL allowed) = bestDist (256: no candidate).
+   What the reference then does with a match (Replace / AddObservation / agreement check of the two Sim3 directions) is
+   bookkeeping on its map and stays with the caller. */
+int  dcs_search_in_window(const dcs_proj_frame* frame, const dcs_proj_queries* queries, int th, int kf_area,
+                          const float* chi2_inv_sigma2, int n_levels, int32_t* match_of_query, int32_t* best_dist, int* n_matches);
+
+/* ORBmatcher::SearchForInitialization (ORBmatcher.cc:1117-1251). frame2 = F2 (its grid; `taken` is ignored), queries = F1's key
+   points in global order: valid[i] = "camera CAP and octave 0" (:1142-1149), (u, v) = vbPrevMatched[i], radius = windowSize,
+   min_level = max_level = the key point's octave (:1152), desc / angle = F1's. In-loop state reproduced: a candidate held by an
+   earlier query with a distance <= this one's is skipped (vMatchedDistance, :1176), an accepted query takes the feature from
+   its previous owner (vnMatches21, :1194-1198), TH_LOW and bestDist < bestDist2 * nn_ratio (:1190-1192), and the rotation
+   histogram keeps robbed entries (:1206, 1228-1240). match12[n] = global F2 feature or -1, *n_matches = the return value. */
+int  dcs_search_for_initialization(const dcs_proj_frame* frame2, const dcs_proj_queries* queries, float nn_ratio, int check_orientation,
+                                   int32_t* match12, int* n_matches);
+
 /* Frame::isInFrustum (Frame.cc:244-312) for a batch of map points + the window of SearchByProjection (ORBmatcher.cc:557-565):
    the geometry gate in front of dcs_search_by_projection. The caller supplies the per-camera matrices exactly as the reference
    forms them with cv::Mat (Tsw = mvExtrinsics[c] * mTcw -> Rsw, tsw, Frame.cc:252-256; GetCameraCenter(c), :222-235);

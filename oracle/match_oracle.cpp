@@ -421,6 +421,129 @@ void orc_search_by_projection(const orc_proj_frame* f, const orc_proj_queries* q
     *n_matches = nmatches;
 }
 
+/* KeyFrame::GetFeaturesInArea (KeyFrame.cc:728-765): the cell arithmetic of the Frame version without the level test, and the
+   |dx|,|dy| < r test reads mvTotalKeysUn[vCell[j]] -- the camera-LOCAL index taken as a global one (:756), i.e. for c > 0 the
+   position of another keypoint decides. Kept: Fuse / SearchBySim3CrossCam / SearchByProjection(KF, ...) all go through it. */
+static void kf_features_in_area(const orc_proj_frame* f, int c, float x, float y, float r, std::vector<int>& out)
+{
+    out.clear();
+    const int nMinCellX = std::max(0, (int)std::floor((x - f->min_x[c] - r) * f->grid_w_inv[c]));
+    if (nMinCellX >= ORC_GRID_COLS) return;
+    const int nMaxCellX = std::min((int)ORC_GRID_COLS - 1, (int)std::ceil((x - f->min_x[c] + r) * f->grid_w_inv[c]));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = std::max(0, (int)std::floor((y - f->min_y[c] - r) * f->grid_h_inv[c]));
+    if (nMinCellY >= ORC_GRID_ROWS) return;
+    const int nMaxCellY = std::min((int)ORC_GRID_ROWS - 1, (int)std::ceil((y - f->min_y[c] + r) * f->grid_h_inv[c]));
+    if (nMaxCellY < 0) return;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+        for (int iy = nMinCellY; iy <= nMaxCellY; ++iy) {
+            const int cell = (c * ORC_GRID_COLS + ix) * ORC_GRID_ROWS + iy;
+            for (int j = f->grid_off[cell]; j < f->grid_off[cell + 1]; ++j) {
+                const int local = f->grid_idx[j];
+                const float distx = f->kp_x[local] - x, disty = f->kp_y[local] - y;          /* mvTotalKeysUn[vCell[j]] */
+                if (std::fabs(distx) < r && std::fabs(disty) < r) out.push_back(local);
+            }
+        }
+}
+
+/* The window searches whose queries do not see each other's results: Fuse(KF, vpMapPoints, th) (ORBmatcher.cc:1431-1556),
+   Fuse(KF, Scw, ...) (:1560-1706), both directions of SearchBySim3CrossCam (:1713-1965), SearchByProjection(KF, vpMapPoints,
+   sAlreadyFound, th, ORBdist) (:693-799). Per query: candidates = GetFeaturesInArea of a KeyFrame (kf_area != 0, see above) or
+   of a Frame; octave gate min_level <= octave <= max_level inside the loop (:1497, :1662, :1847, :757); Fuse's reprojection gate
+   e2 * mvInvLevelSigma2[octave] > 5.99 (:1503-1509; float product, double comparison) when chi2_inv_sigma2 != NULL; features
+   flagged in f->taken are skipped (vpMatched[idx] of :416-536 read as a snapshot; all zero for the others); strict `dist <
+   bestDist` from 256 / INT_MAX: the first of equal distances wins; accepted when bestDist <= th.
+   match_of_query[i] = GLOBAL feature index or -1. Returns the number of accepted queries. */
+int orc_search_in_window(const orc_proj_frame* f, const orc_proj_queries* q, int th, int kf_area, const float* chi2_inv_sigma2,
+                         int32_t* match_of_query, int32_t* best_dist)
+{
+    int n_acc = 0;
+    std::vector<int> cand;
+    for (int i = 0; i < q->n; ++i) {
+        match_of_query[i] = -1;
+        if (best_dist) best_dist[i] = 256;
+        if (!q->valid[i]) continue;
+        const int c = q->cam[i];
+        const float u = q->u[i], v = q->v[i];
+        if (kf_area) kf_features_in_area(f, c, u, v, q->radius[i], cand);
+        else features_in_area(f, c, u, v, q->radius[i], -1, -1, cand);
+        int bestDist = 256, bestIdx = -1;
+        for (int local : cand) {
+            const int g = f->cam_off[c] + local;
+            if (f->taken && f->taken[g]) continue;
+            const int lvl = f->kp_octave[g];
+            if (lvl < q->min_level[i] || lvl > q->max_level[i]) continue;
+            if (chi2_inv_sigma2) {
+                const float ex = u - f->kp_x[g], ey = v - f->kp_y[g];
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * chi2_inv_sigma2[lvl] > 5.99) continue;
+            }
+            const int dist = descriptor_distance(q->desc + (size_t)i * 32, f->desc + (size_t)g * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = g; }
+        }
+        if (best_dist) best_dist[i] = bestDist;
+        if (bestDist <= th) { match_of_query[i] = bestIdx; ++n_acc; }
+    }
+    return n_acc;
+}
+
+/* SearchForInitialization (ORBmatcher.cc:1117-1251). Queries = F1's key points in global order; valid[i] = "camera CAP and
+   octave 0" (:1142-1149); (u, v) = vbPrevMatched[i], radius = windowSize, min_level = max_level = the key point's octave
+   (GetFeaturesInArea(CAP, x, y, windowSize, level1, level1), :1152). In-loop state: vMatchedDistance[g] -- a candidate is skipped
+   when an earlier query holds it with a distance <= this one's (:1176) -- and vnMatches21: a later, closer query steals the
+   feature (:1194-1198). The rotation histogram keeps the entries of robbed queries (they still count in ComputeThreeMaxima,
+   :1228) and only live matches outside the three maxima are removed (:1236-1240). match12[i] = global F2 index or -1. */
+int orc_search_for_initialization(const orc_proj_frame* f2, const orc_proj_queries* q, float nn_ratio, int check_orientation,
+                                  int32_t* match12)
+{
+    const int N2 = f2->cam_off[f2->n_cams];
+    std::vector<int> vMatchedDistance((size_t)std::max(N2, 1), INT_MAX), vnMatches21((size_t)std::max(N2, 1), -1);
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    std::vector<int> vIndices2;
+    for (int i1 = 0; i1 < q->n; ++i1) match12[i1] = -1;
+    for (int i1 = 0; i1 < q->n; ++i1) {
+        if (!q->valid[i1]) continue;
+        const int c = q->cam[i1];
+        features_in_area(f2, c, q->u[i1], q->v[i1], q->radius[i1], q->min_level[i1], q->max_level[i1], vIndices2);
+        if (vIndices2.empty()) continue;
+        const uint8_t* d1 = q->desc + (size_t)i1 * 32;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int local : vIndices2) {
+            const int g = f2->cam_off[c] + local;
+            const int dist = descriptor_distance(d1, f2->desc + (size_t)g * 32);
+            if (vMatchedDistance[g] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = g; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nn_ratio) {
+                if (vnMatches21[bestIdx2] >= 0) { match12[vnMatches21[bestIdx2]] = -1; --nmatches; }
+                match12[i1] = bestIdx2; vnMatches21[bestIdx2] = i1; vMatchedDistance[bestIdx2] = bestDist;
+                ++nmatches;
+                if (check_orientation) {
+                    float rot = q->angle[i1] - f2->kp_angle[bestIdx2];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int histo[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int b = 0; b < HISTO_LENGTH; ++b) histo[b] = (int)rotHist[b].size();
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; ++b) {
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            for (int i1 : rotHist[b]) if (match12[i1] >= 0) { match12[i1] = -1; --nmatches; }
+        }
+    }
+    return nmatches;
+}
+
 int orc_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const float* kp_y, const float* min_x, const float* min_y,
                    const float* grid_w_inv, const float* grid_h_inv, int32_t* grid_off, int32_t* grid_idx)
 {

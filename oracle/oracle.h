@@ -139,6 +139,15 @@ typedef struct orc_proj_queries {
    match_of_query[n] = global feature index or -1; query_of_feature[N] = query index or -1. */
 void orc_search_by_projection(const orc_proj_frame* f, const orc_proj_queries* q, int th_high, float nn_ratio, int check_orientation,
                               int32_t* match_of_query, int32_t* query_of_feature, int32_t* n_matches);
+/* Window searches with independent queries: Fuse x2 (ORBmatcher.cc:1431-1556, 1560-1706), SearchBySim3CrossCam (:1713-1965),
+   SearchByProjection(KF, vpMapPoints, sAlreadyFound, th, ORBdist) (:693-799), and :416-536 with vpMatched as a snapshot.
+   kf_area: candidates come from KeyFrame::GetFeaturesInArea (KeyFrame.cc:728-765, local index read as global, :756);
+   chi2_inv_sigma2 (may be NULL): Fuse's e2 * mvInvLevelSigma2[octave] > 5.99 gate. best_dist may be NULL. */
+int orc_search_in_window(const orc_proj_frame* f, const orc_proj_queries* q, int th, int kf_area, const float* chi2_inv_sigma2,
+                         int32_t* match_of_query, int32_t* best_dist);
+/* SearchForInitialization (ORBmatcher.cc:1117-1251): vMatchedDistance gate + match stealing + the stale rotation histogram */
+int orc_search_for_initialization(const orc_proj_frame* f2, const orc_proj_queries* q, float nn_ratio, int check_orientation,
+                                  int32_t* match12);
 /* Frame::PosInGrid + the grid fill of the Frame constructor (Frame.cc:180-196, 380-390): CSR over (c, ix, iy); features whose
    cell falls outside the 64 x 48 grid are left out. grid_off[n_cams*64*48+1], grid_idx[<= N]; returns the entries written. */
 int orc_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const float* kp_y, const float* min_x, const float* min_y,

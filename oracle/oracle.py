@@ -174,6 +174,30 @@ def search_by_projection(frame, queries, th_high=100, nn_ratio=0.8, check_orient
     return mq[:n], qf[:N], nm.value
 
 
+def search_in_window(frame, queries, th=50, kf_area=True, chi2_inv_sigma2=None):
+    """Fuse x2 / SearchBySim3CrossCam / SearchByProjection(KF, ...) candidate loops (independent queries):
+    (match_of_query [global feature or -1], best_dist, accepted)"""
+    f, q, keep = _proj_structs(frame, queries)
+    n = len(queries["cam"])
+    mq, bd = np.full(max(n, 1), -1, np.int32), np.full(max(n, 1), 256, np.int32)
+    chi = None if chi2_inv_sigma2 is None else _c(chi2_inv_sigma2, np.float32)
+    L = lib()
+    L.orc_search_in_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    acc = L.orc_search_in_window(C.byref(f), C.byref(q), int(th), int(bool(kf_area)), None if chi is None else _p(chi), _p(mq), _p(bd))
+    return mq[:n], bd[:n], acc
+
+
+def search_for_initialization(frame2, queries, nn_ratio=0.9, check_orientation=True):
+    """SearchForInitialization (ORBmatcher.cc:1117-1251): (match12 [global F2 feature or -1], nmatches)"""
+    f, q, keep = _proj_structs(frame2, queries)
+    n = len(queries["cam"])
+    m12 = np.full(max(n, 1), -1, np.int32)
+    L = lib()
+    L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    nm = L.orc_search_for_initialization(C.byref(f), C.byref(q), float(nn_ratio), int(check_orientation), _p(m12))
+    return m12[:n], nm
+
+
 class PoseProblem(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("n_cams", C.c_int32), ("poses", C.c_void_p), ("edge_off", C.c_void_p),
                 ("xw", C.c_void_p), ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("edge_cam", C.c_void_p),

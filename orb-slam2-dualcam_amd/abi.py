@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdcs_hip.so")
+LIB_PATH = os.environ.get("DCS_LIB_PATH") or os.path.join(_HERE, "lib", "libdcs_hip.so")      # DCS_LIB_PATH: A/B timing of two builds (scratch/)
 
 KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -25,7 +25,7 @@ SYMBOLS = [
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
-    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection",
+    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_in_window", "dcs_search_for_initialization",
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
@@ -132,6 +132,8 @@ def lib():
             "dcs_pose_optimization": [C.POINTER(PoseProblem), C.POINTER(PoseResult)],
             "dcs_frame_grid": [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, pci],
             "dcs_search_by_projection": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, cf, ci, vp, vp, pci],
+            "dcs_search_in_window": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, ci, vp, ci, vp, vp, pci],
+            "dcs_search_for_initialization": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), cf, ci, vp, pci],
             "dcs_rig_adjoint": [vp, ci, vp, vp],
             "dcs_pose_from_matrix": [vp, vp],
             "dcs_pose_to_matrix": [vp, vp],
@@ -356,29 +358,79 @@ class ORBmatcher:
                                                d_n_matches.data_ptr(), d_best.data_ptr(), d_second.data_ptr(), stream),
                "dcs_match_bf_batch_device")
 
-    def SearchByProjection(self, frame, queries, th_high=100, use_ratio=True, check_orientation=False):
-        """ORBmatcher::SearchByProjection(F, map points, th) (ORBmatcher.cc:539-624; use_ratio) or
-        SearchByProjectionOnCam (:954-1113; use_ratio=False, check_orientation=mbCheckOrientation) on flat inputs
-        (dicts laid out like dcs_proj_frame / dcs_proj_queries). Returns (match_of_query, query_of_feature, n)."""
+    @staticmethod
+    def _proj_structs(frame, queries):
         keep = []
 
         def a(x, dt):
+            if x is None:
+                return None
             arr = _c(x, dt)
             keep.append(arr)
             return _p(arr).value
         f = ProjFrame(len(frame["cam_off"]) - 1, a(frame["cam_off"], np.int32), a(frame["kp_x"], np.float32), a(frame["kp_y"], np.float32),
                       a(frame["kp_octave"], np.int32), a(frame["kp_angle"], np.float32), a(frame["desc"], np.uint8),
-                      a(frame["taken"], np.uint8), a(frame["min_x"], np.float32), a(frame["min_y"], np.float32),
+                      a(frame.get("taken"), np.uint8), a(frame["min_x"], np.float32), a(frame["min_y"], np.float32),
                       a(frame["grid_w_inv"], np.float32), a(frame["grid_h_inv"], np.float32), a(frame["grid_off"], np.int32),
                       a(frame["grid_idx"], np.int32))
         q = ProjQueries(len(queries["cam"]), a(queries["valid"], np.uint8), a(queries["cam"], np.int32), a(queries["u"], np.float32),
                         a(queries["v"], np.float32), a(queries["radius"], np.float32), a(queries["min_level"], np.int32),
                         a(queries["max_level"], np.int32), a(queries["desc"], np.uint8), a(queries["angle"], np.float32))
+        return f, q, keep
+
+    def SearchByProjection(self, frame, queries, th_high=100, use_ratio=True, check_orientation=False):
+        """ORBmatcher::SearchByProjection(F, map points, th) (ORBmatcher.cc:539-624; use_ratio) or
+        SearchByProjectionOnCam (:954-1113 and :812-951; use_ratio=False, check_orientation=mbCheckOrientation) on flat inputs
+        (dicts laid out like dcs_proj_frame / dcs_proj_queries). Returns (match_of_query, query_of_feature, n)."""
+        f, q, keep = self._proj_structs(frame, queries)
         N, n = int(frame["cam_off"][-1]), len(queries["cam"])
         mq, qf, nm = np.full(max(n, 1), -1, np.int32), np.full(max(N, 1), -1, np.int32), C.c_int()
         _check(lib().dcs_search_by_projection(C.byref(f), C.byref(q), int(th_high), float(self.mfNNratio) if use_ratio else 0.0,
                                               int(check_orientation), _p(mq), _p(qf), C.byref(nm)), "dcs_search_by_projection")
         return mq[:n], qf[:N], nm.value
+
+    def SearchInWindow(self, frame, queries, th=50, kf_area=True, chi2_inv_sigma2=None):
+        """Candidate loops of Fuse x2 (ORBmatcher.cc:1431-1556, 1560-1706), SearchBySim3CrossCam (:1713-1965, one direction per call)
+        and SearchByProjection(KF, vpMapPoints, sAlreadyFound, th, ORBdist) (:693-799): independent queries, best only.
+        Returns (match_of_query [global feature or -1], best_dist, accepted)."""
+        f, q, keep = self._proj_structs(frame, queries)
+        n = len(queries["cam"])
+        mq, bd, nm = np.full(max(n, 1), -1, np.int32), np.full(max(n, 1), 256, np.int32), C.c_int()
+        chi = None if chi2_inv_sigma2 is None else _c(chi2_inv_sigma2, np.float32)
+        _check(lib().dcs_search_in_window(C.byref(f), C.byref(q), int(th), int(bool(kf_area)), None if chi is None else _p(chi),
+                                          0 if chi is None else len(chi), _p(mq), _p(bd), C.byref(nm)), "dcs_search_in_window")
+        return mq[:n], bd[:n], nm.value
+
+    def SearchBySim3(self, frame1, queries_1in2, frame2, queries_2in1, th=100):
+        """SearchBySim3CrossCam (ORBmatcher.cc:1713-1965) for one camera pair: queries_1in2 = KF1's map points projected into KF2
+        (searched in frame2), queries_2in1 the other way; both indexed by the camera-local feature of their own key frame.
+        Returns (match12 [local KF2 feature or -1], nFound) after the agreement check (:1950-1964)."""
+        m1, _, _ = self.SearchInWindow(frame2, queries_1in2, th=th, kf_area=True)
+        m2, _, _ = self.SearchInWindow(frame1, queries_2in1, th=th, kf_area=True)
+        c2 = np.asarray(queries_1in2["cam"], np.int32)
+        c1 = np.asarray(queries_2in1["cam"], np.int32)
+        off2, off1 = np.asarray(frame2["cam_off"]), np.asarray(frame1["cam_off"])
+        match12 = np.full(len(m1), -1, np.int32)
+        found = 0
+        for i1 in range(len(m1)):
+            if m1[i1] < 0:
+                continue
+            i2 = int(m1[i1] - off2[c2[i1]])                 # vnMatch1[i1] = bestIdx2local
+            if i2 < len(m2) and m2[i2] >= 0 and int(m2[i2] - off1[c1[i2]]) == i1:
+                match12[i1] = i2
+                found += 1
+        return match12, found
+
+    def SearchForInitialization(self, frame2, queries, check_orientation=None):
+        """ORBmatcher::SearchForInitialization (ORBmatcher.cc:1117-1251) on flat inputs (see dcs_search_for_initialization).
+        Returns (vnMatches12 [global F2 feature or -1], nmatches)."""
+        f, q, keep = self._proj_structs(frame2, queries)
+        n = len(queries["cam"])
+        m12, nm = np.full(max(n, 1), -1, np.int32), C.c_int()
+        co = self.mbCheckOrientation if check_orientation is None else check_orientation
+        _check(lib().dcs_search_for_initialization(C.byref(f), C.byref(q), float(self.mfNNratio), int(co), _p(m12), C.byref(nm)),
+               "dcs_search_for_initialization")
+        return m12[:n], nm.value
 
     def SearchByBoWCrossCam(self, desc_kf, ang_kf, kf_valid, desc_f, ang_f, kf_fv, f_fv):
         """SearchByBoWCrossCam(F,cF,KF,cKF) (ORBmatcher.cc:162-294) on flat inputs; returns (match_f, n)."""

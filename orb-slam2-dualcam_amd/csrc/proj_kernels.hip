@@ -34,6 +34,10 @@ struct ProjFrameD {
     int n_cams, N;
     const int32_t* cam_off; const float *kp_x, *kp_y; const int32_t* kp_octave; const float* kp_angle;
     const uint8_t *desc, *taken; const float *min_x, *min_y, *w_inv, *h_inv; const int32_t *grid_off, *grid_idx;
+    // window searches on a KeyFrame (dcs_search_in_window): KeyFrame::GetFeaturesInArea reads the position of
+    // mvTotalKeysUn[local index] (KeyFrame.cc:756) and has no level test -- the octave gate sits in the caller's loop
+    // (min <= octave <= max, ORBmatcher.cc:1497, 1662, 757) -- and Fuse adds e2 * mvInvLevelSigma2[octave] > 5.99 (:1503-1509)
+    int kf_area, loop_levels; const float* chi2_inv_sigma2;
 };
 struct ProjQueriesD {
     int n;
@@ -93,9 +97,16 @@ __device__ __forceinline__ int proj_visit(const ProjFrameD& f, const ProjQueries
                 const int local = f.grid_idx[j], g = base + local;
                 const int oct = f.kp_octave[g];
                 bool ok = true;
-                if (check_levels) ok = !(oct < minLevel) && !(maxLevel >= 0 && oct > maxLevel);
-                const float dx = __fsub_rn(f.kp_x[g], x), dy = __fsub_rn(f.kp_y[g], y);
+                if (f.loop_levels) ok = !(oct < minLevel || oct > maxLevel);
+                else if (check_levels) ok = !(oct < minLevel) && !(maxLevel >= 0 && oct > maxLevel);
+                const int gp = f.kf_area ? local : g;
+                const float dx = __fsub_rn(f.kp_x[gp], x), dy = __fsub_rn(f.kp_y[gp], y);
                 ok = ok && fabsf(dx) < r && fabsf(dy) < r && !taken(g);
+                if (ok && f.chi2_inv_sigma2) {
+                    const float ex = __fsub_rn(x, f.kp_x[g]), ey = __fsub_rn(y, f.kp_y[g]);
+                    const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                    ok = !((double)__fmul_rn(e2, f.chi2_inv_sigma2[oct]) > 5.99);
+                }
                 if (ok) {
                     const uint4* tp = reinterpret_cast<const uint4*>(f.desc + (size_t)g * 32);
                     const uint4 ta = tp[0], tb = tp[1];
@@ -410,6 +421,161 @@ __global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f, ProjQu
 // ---- Frame::isInFrustum + PredictScale + search window, one lane per map point (Frame.cc:244-312, MapPoint.cc:440-455,
 // ORBmatcher.cc:65-71, 557-565). Same arithmetic as the reference's cv::Mat expressions (see oracle/match_oracle.cpp): float dot
 // products left to right without contraction, the translation added in double, norm / dot accumulated in double.
+// Window searches whose queries do not see each other (Fuse x2, SearchBySim3CrossCam, SearchByProjection(KF, vpMapPoints, ...)):
+// one wave per query walks the window like the reference's loop and keeps the smallest (distance, visiting position) key -- strict
+// `dist < bestDist` updates keep the FIRST of equal distances.
+__global__ __launch_bounds__(256) void k_window_static(ProjFrameD f, ProjQueriesD q, int th, int32_t* __restrict__ match_of_query,
+                                                        int32_t* __restrict__ best_dist, int32_t* __restrict__ n_acc)
+{
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (qi >= q.n) return;
+    int matched = -1, bd = 256;
+    if (q.valid[qi]) {
+        unsigned long long b1 = ~0ull;
+        unsigned w1 = 0;
+        (void)proj_visit(f, q, qi, TakenPlain{f.taken}, [&](bool pass, unsigned word, int pos) {
+            const unsigned long long key = pass ? (((unsigned long long)(word >> 23) << 32) | (unsigned)pos) : ~0ull;
+            if (key < b1) { b1 = key; w1 = word; }
+        });
+        unsigned long long m1 = b1;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m1, d); m1 = o < m1 ? o : m1; }
+        if (m1 != ~0ull) {
+            const unsigned long long has = __ballot(b1 == m1);
+            const unsigned best = (unsigned)__builtin_amdgcn_readlane((int)w1, __ffsll((long long)has) - 1);
+            bd = (int)(best >> 23);
+            if (bd <= th) matched = f.cam_off[q.cam[qi]] + (int)(best & 0x7FFFFu);
+        }
+    }
+    if (lane == 0) {
+        match_of_query[qi] = matched; best_dist[qi] = bd;
+        if (matched >= 0) atomicAdd(n_acc, 1);
+    }
+}
+
+// SearchForInitialization (ORBmatcher.cc:1117-1251): one wave, queries in order. A candidate is skipped while an earlier query
+// holds its feature with a distance <= this one's (vMatchedDistance, :1176); an accepted query takes the feature away from its
+// previous owner (vnMatches21, :1194-1198). Candidate lists (distance, octave, feature) come from k_proj_collect (nothing taken).
+// The distance map lives in LDS as u16 (0xFFFF = INT_MAX) for frames of <= 30 000 features, else in HBM.
+template <bool LDS_MAP>
+__global__ __launch_bounds__(64) void k_init_resolve(ProjFrameD f, ProjQueriesD q, const unsigned* __restrict__ cand, const int32_t* __restrict__ cand_n,
+                                                    uint16_t* __restrict__ md_hbm /* [N] */, float nn_ratio, int check_ori,
+                                                    int32_t* __restrict__ match12, int32_t* __restrict__ owner /* [N] vnMatches21 */,
+                                                    int32_t* __restrict__ bin_of_query, int32_t* __restrict__ n_matches)
+{
+    __shared__ int s_hist[kHisto];
+    __shared__ int s_ind[3];
+    extern __shared__ uint16_t s_md[];
+    const int lane = threadIdx.x;
+    uint16_t* const md = LDS_MAP ? s_md : md_hbm;
+    for (int i = lane; i < f.N; i += 64) { owner[i] = -1; md[i] = 0xFFFFu; }
+    for (int i = lane; i < q.n; i += 64) { match12[i] = -1; bin_of_query[i] = -1; }
+    if (lane < kHisto) s_hist[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    auto held = [&](int g) -> unsigned {
+        if (LDS_MAP) return md[g];
+        return __hip_atomic_load(md + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    for (int qi = 0; qi < q.n; ++qi) {
+        const int n = cand_n[qi];                            // wave-uniform (0 for invalid queries)
+        if (n == 0) continue;
+        const int base = f.cam_off[q.cam[qi]];
+        unsigned best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+        if (n <= kProjCap) {
+            unsigned w = 0, key = 0xFFFFFFFFu;
+            if (lane < n) {
+                w = cand[(size_t)qi * kProjCap + lane];
+                const int g = base + (int)(w & 0x7FFFFu);
+                if (!(held(g) <= (w >> 23))) key = ((w >> 23) << 8) | (unsigned)lane;      // vMatchedDistance[g] <= dist: skip
+            }
+            const unsigned k1 = wave_min_u32(key);
+            if (k1 != 0xFFFFFFFFu) {
+                const unsigned k2 = wave_min_u32(key == k1 ? 0xFFFFFFFFu : key);
+                best = (unsigned)__builtin_amdgcn_readlane((int)w, (int)(k1 & 63u));
+                if (k2 != 0xFFFFFFFFu) second = (unsigned)__builtin_amdgcn_readlane((int)w, (int)(k2 & 63u));
+            }
+        } else {                                             // window wider than the list: walk it again
+            unsigned long long b1 = ~0ull, b2 = ~0ull;
+            unsigned w1 = 0, w2 = 0;
+            (void)proj_visit(f, q, qi, TakenPlain{f.taken}, [&](bool pass, unsigned word, int pos) {
+                if (pass && held(base + (int)(word & 0x7FFFFu)) <= (word >> 23)) pass = false;
+                const unsigned long long key = pass ? (((unsigned long long)(word >> 23) << 32) | (unsigned)pos) : ~0ull;
+                if (key < b1) { b2 = b1; w2 = w1; b1 = key; w1 = word; }
+                else if (key < b2) { b2 = key; w2 = word; }
+            });
+            unsigned long long m1 = b1;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m1, d); m1 = o < m1 ? o : m1; }
+            unsigned long long c2 = (b1 == m1) ? b2 : b1, m2 = c2;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m2, d); m2 = o < m2 ? o : m2; }
+            if (m1 != ~0ull) {
+                const unsigned long long has1 = __ballot(b1 == m1);
+                best = (unsigned)__builtin_amdgcn_readlane((int)w1, __ffsll((long long)has1) - 1);
+                if (m2 != ~0ull) {
+                    const unsigned mine = (b1 == m2) ? w1 : w2;
+                    const unsigned long long has2 = __ballot(b1 == m2 || b2 == m2);
+                    second = (unsigned)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)has2) - 1);
+                }
+            }
+        }
+        if (best != 0xFFFFFFFFu) {
+            const int bestDist = (int)(best >> 23);
+            const float d2 = second != 0xFFFFFFFFu ? (float)(int)(second >> 23) : 2147483648.0f;      // (float)INT_MAX
+            if (bestDist <= 50 && (float)bestDist < __fmul_rn(d2, nn_ratio)) {                       // TH_LOW, :1190-1192
+                const int g = base + (int)(best & 0x7FFFFu);
+                if (lane == 0) {
+                    const int prev = owner[g];
+                    if (prev >= 0) match12[prev] = -1;
+                    match12[qi] = g; owner[g] = qi;
+                    if (LDS_MAP) md[g] = (uint16_t)bestDist; else __hip_atomic_store(md + g, (uint16_t)bestDist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (check_ori) {
+                        float rot = __fsub_rn(q.angle[qi], f.kp_angle[g]);
+                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                        int bin = (int)roundf(__fmul_rn(rot, 1.0f / kHisto));
+                        if (bin == kHisto) bin = 0;
+                        bin_of_query[qi] = bin;
+                        ++s_hist[bin];                       // a robbed query stays in the histogram (:1206 vs :1194-1198)
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+    }
+    // the rotation filter removes the LIVE matches outside the three maxima (:1236-1240)
+    if (check_ori) {
+        if (lane == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < kHisto; ++i) {
+                const int sgm = s_hist[i];
+                if (sgm > max1) { max3 = max2; max2 = max1; max1 = sgm; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sgm > max2) { max3 = max2; max2 = sgm; ind3 = ind2; ind2 = i; }
+                else if (sgm > max3) { max3 = sgm; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+            s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+        }
+        __syncthreads();
+        for (int qi = lane; qi < q.n; qi += 64) {
+            const int b = bin_of_query[qi];
+            if (b >= 0 && match12[qi] >= 0 && b != s_ind[0] && b != s_ind[1] && b != s_ind[2]) match12[qi] = -1;
+        }
+        __syncthreads();
+    }
+    // nmatches of the reference = accepted - robbed - filtered = the queries that still hold a feature
+    int live = 0;
+    for (int qi = lane; qi < q.n; qi += 64) live += match12[qi] >= 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) live += __shfl_xor(live, d);
+    if (lane == 0) *n_matches = live;
+}
+
 constexpr int kFrMaxCams = 8;
 struct FrustumDev {
     int n_cams, n_levels;
@@ -499,22 +665,22 @@ int dcs_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const 
     return DCS_OK;
 }
 
-int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* qs, int th_high, float nn_ratio, int check_orientation,
-                             int32_t* match_of_query, int32_t* query_of_feature, int* n_matches)
+// validation + upload shared by the window searches: a malformed grid would index features / LDS maps out of bounds on the device
+struct ProjInputs { ProjFrameD f{}; ProjQueriesD q{}; int C = 0, N = 0, nq = 0; };
+static int proj_prepare(Scratch& s, const dcs_proj_frame* fr, const dcs_proj_queries* qs, bool need_taken, bool need_angles, ProjInputs& in)
 {
-    if (!fr || !qs || !n_matches || fr->n_cams < 1 || !fr->cam_off || qs->n < 0) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    if (!fr || !qs || fr->n_cams < 1 || !fr->cam_off || qs->n < 0) { set_error("bad argument"); return DCS_ERR_INVALID; }
     const int C = fr->n_cams, N = fr->cam_off[C], nq = qs->n;
     const int cells = C * DCS_GRID_COLS * DCS_GRID_ROWS;
     if (N < 0 || N >= (1 << 19)) { set_error("feature count %d outside 0 .. 2^19", N); return DCS_ERR_UNSUPPORTED; }
     if (!fr->min_x || !fr->min_y || !fr->grid_w_inv || !fr->grid_h_inv || !fr->grid_off || (N && (!fr->kp_x || !fr->kp_y || !fr->kp_octave ||
-        !fr->desc || !fr->taken || !fr->grid_idx || !query_of_feature)) || (check_orientation && N && !fr->kp_angle) ||
-        (nq && (!qs->valid || !qs->cam || !qs->u || !qs->v || !qs->radius || !qs->min_level || !qs->max_level || !qs->desc || !match_of_query)) ||
-        (check_orientation && nq && !qs->angle)) { set_error("null array"); return DCS_ERR_INVALID; }
+        !fr->desc || (need_taken && !fr->taken) || !fr->grid_idx)) || (need_angles && N && !fr->kp_angle) ||
+        (nq && (!qs->valid || !qs->cam || !qs->u || !qs->v || !qs->radius || !qs->min_level || !qs->max_level || !qs->desc)) ||
+        (need_angles && nq && !qs->angle)) { set_error("null array"); return DCS_ERR_INVALID; }
     const int n_entries = fr->grid_off[cells];
     if (n_entries < 0 || n_entries > N) { set_error("grid CSR inconsistent"); return DCS_ERR_INVALID; }
     for (int c = 0; c <= C; ++c) if (fr->cam_off[c] < 0 || (c && fr->cam_off[c] < fr->cam_off[c - 1])) { set_error("cam_off not ascending"); return DCS_ERR_INVALID; }
-    // a malformed grid would index features / LDS maps out of bounds on the device: offsets ascending, every entry a local index of its camera
-    for (int c = 0; c < C; ++c) {
+    for (int c = 0; c < C; ++c) {                       // offsets ascending, every entry a local index of its camera
         const int n_cam = fr->cam_off[c + 1] - fr->cam_off[c], c0 = c * DCS_GRID_COLS * DCS_GRID_ROWS;
         for (int k = c0; k < c0 + DCS_GRID_COLS * DCS_GRID_ROWS; ++k) {
             const int a = fr->grid_off[k], b = fr->grid_off[k + 1];
@@ -527,16 +693,16 @@ int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* q
     for (int i = 0; i < nq; ++i) if (qs->valid[i] && (qs->cam[i] < 0 || qs->cam[i] >= C)) { set_error("query %d: camera out of range", i); return DCS_ERR_INVALID; }
     int rc = ensure_device();
     if (rc) return rc;
-    *n_matches = 0;
-    if (nq == 0) { for (int i = 0; i < N; ++i) query_of_feature[i] = -1; return DCS_OK; }
-    Scratch s;
-    ProjFrameD f{};
-    ProjQueriesD q{};
+    in.C = C; in.N = N; in.nq = nq;
+    if (nq == 0) return DCS_OK;
+    ProjFrameD& f = in.f;
+    ProjQueriesD& q = in.q;
     f.n_cams = C; f.N = N;
     static const float zero_f = 0.f;
+    const std::vector<uint8_t> none(need_taken || fr->taken ? 0 : (size_t)std::max(N, 1), 0);        // "nothing taken" when the caller has no map
     if ((rc = s.upload(&f.cam_off, fr->cam_off, (size_t)C + 1)) || (rc = s.upload(&f.kp_x, fr->kp_x, (size_t)N)) || (rc = s.upload(&f.kp_y, fr->kp_y, (size_t)N)) ||
-        (rc = s.upload(&f.kp_octave, fr->kp_octave, (size_t)N)) || (rc = s.upload(&f.kp_angle, check_orientation ? fr->kp_angle : &zero_f, check_orientation ? (size_t)N : 1)) ||
-        (rc = s.upload(&f.desc, fr->desc, (size_t)N * 32)) || (rc = s.upload(&f.taken, fr->taken, (size_t)N)) ||
+        (rc = s.upload(&f.kp_octave, fr->kp_octave, (size_t)N)) || (rc = s.upload(&f.kp_angle, need_angles ? fr->kp_angle : &zero_f, need_angles ? (size_t)N : 1)) ||
+        (rc = s.upload(&f.desc, fr->desc, (size_t)N * 32)) || (rc = s.upload(&f.taken, fr->taken ? fr->taken : none.data(), (size_t)N)) ||
         (rc = s.upload(&f.min_x, fr->min_x, (size_t)C)) || (rc = s.upload(&f.min_y, fr->min_y, (size_t)C)) ||
         (rc = s.upload(&f.w_inv, fr->grid_w_inv, (size_t)C)) || (rc = s.upload(&f.h_inv, fr->grid_h_inv, (size_t)C)) ||
         (rc = s.upload(&f.grid_off, fr->grid_off, (size_t)cells + 1)) || (rc = s.upload(&f.grid_idx, fr->grid_idx, (size_t)n_entries))) return rc;
@@ -544,7 +710,25 @@ int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* q
     if ((rc = s.upload(&q.valid, qs->valid, (size_t)nq)) || (rc = s.upload(&q.cam, qs->cam, (size_t)nq)) || (rc = s.upload(&q.u, qs->u, (size_t)nq)) ||
         (rc = s.upload(&q.v, qs->v, (size_t)nq)) || (rc = s.upload(&q.radius, qs->radius, (size_t)nq)) ||
         (rc = s.upload(&q.min_level, qs->min_level, (size_t)nq)) || (rc = s.upload(&q.max_level, qs->max_level, (size_t)nq)) ||
-        (rc = s.upload(&q.desc, qs->desc, (size_t)nq * 32)) || (rc = s.upload(&q.angle, check_orientation ? qs->angle : &zero_f, check_orientation ? (size_t)nq : 1))) return rc;
+        (rc = s.upload(&q.desc, qs->desc, (size_t)nq * 32)) || (rc = s.upload(&q.angle, need_angles ? qs->angle : &zero_f, need_angles ? (size_t)nq : 1))) return rc;
+    return DCS_OK;
+}
+
+int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* qs, int th_high, float nn_ratio, int check_orientation,
+                             int32_t* match_of_query, int32_t* query_of_feature, int* n_matches)
+{
+    if (!n_matches || (fr && fr->cam_off && fr->n_cams >= 1 && fr->cam_off[fr->n_cams] > 0 && !query_of_feature) || (qs && qs->n > 0 && !match_of_query)) {
+        set_error("bad argument"); return DCS_ERR_INVALID;
+    }
+    Scratch s;
+    ProjInputs in;
+    int rc = proj_prepare(s, fr, qs, true, check_orientation != 0, in);
+    if (rc) return rc;
+    const int N = in.N, nq = in.nq;
+    const ProjFrameD& f = in.f;
+    const ProjQueriesD& q = in.q;
+    *n_matches = 0;
+    if (nq == 0) { for (int i = 0; i < N; ++i) query_of_feature[i] = -1; return DCS_OK; }
     unsigned* d_cand; int32_t *d_cn, *d_mq, *d_qf, *d_bin, *d_nm; uint8_t* d_taken;
     if ((rc = s.alloc(&d_cand, (size_t)nq * kProjCap)) || (rc = s.alloc(&d_cn, (size_t)nq)) || (rc = s.alloc(&d_mq, (size_t)nq)) ||
         (rc = s.alloc(&d_qf, (size_t)N)) || (rc = s.alloc(&d_bin, (size_t)nq)) || (rc = s.alloc(&d_nm, 1)) || (rc = s.upload(&d_taken, fr->taken, (size_t)N))) return rc;
@@ -566,6 +750,70 @@ int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* q
     if ((rc = s.download_bytes(match_of_query, d_mq, sizeof(int32_t) * nq))) return rc;
     if (N) if ((rc = s.download_bytes(query_of_feature, d_qf, sizeof(int32_t) * N))) return rc;
     int32_t nm = 0;
+    if ((rc = s.download_bytes(&nm, d_nm, sizeof(int32_t)))) return rc;
+    if ((rc = s.finish())) return rc;
+    *n_matches = nm;
+    return DCS_OK;
+}
+
+int dcs_search_in_window(const dcs_proj_frame* fr, const dcs_proj_queries* qs, int th, int kf_area, const float* chi2_inv_sigma2, int n_levels,
+                         int32_t* match_of_query, int32_t* best_dist, int* n_matches)
+{
+    if (!n_matches || (qs && qs->n > 0 && !match_of_query) || (chi2_inv_sigma2 && (n_levels < 1 || n_levels > 16))) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    Scratch s;
+    ProjInputs in;
+    int rc = proj_prepare(s, fr, qs, false, false, in);
+    if (rc) return rc;
+    *n_matches = 0;
+    const int nq = in.nq;
+    if (nq == 0) return DCS_OK;
+    if (chi2_inv_sigma2)
+        for (int i = 0; i < in.N; ++i) if (fr->kp_octave[i] >= n_levels) { set_error("octave of feature %d beyond the %d sigma levels", i, n_levels); return DCS_ERR_INVALID; }
+    in.f.kf_area = kf_area != 0; in.f.loop_levels = 1;
+    if (chi2_inv_sigma2 && (rc = s.upload(&in.f.chi2_inv_sigma2, chi2_inv_sigma2, (size_t)n_levels))) return rc;
+    int32_t *d_mq, *d_bd, *d_nm;
+    if ((rc = s.alloc(&d_mq, (size_t)nq)) || (rc = s.alloc(&d_bd, (size_t)nq)) || (rc = s.alloc(&d_nm, 1))) return rc;
+    DCS_HIP(hipMemsetAsync(d_nm, 0, sizeof(int32_t), s.st));
+    hipLaunchKernelGGL(k_window_static, dim3((nq + 3) / 4), dim3(256), 0, s.st, in.f, in.q, th, d_mq, d_bd, d_nm);
+    DCS_CHECK_LAUNCH();
+    int32_t nm = 0;
+    if ((rc = s.download_bytes(match_of_query, d_mq, sizeof(int32_t) * nq))) return rc;
+    if (best_dist && (rc = s.download_bytes(best_dist, d_bd, sizeof(int32_t) * nq))) return rc;
+    if ((rc = s.download_bytes(&nm, d_nm, sizeof(int32_t)))) return rc;
+    if ((rc = s.finish())) return rc;
+    *n_matches = nm;
+    return DCS_OK;
+}
+
+int dcs_search_for_initialization(const dcs_proj_frame* f2, const dcs_proj_queries* qs, float nn_ratio, int check_orientation,
+                                  int32_t* match12, int* n_matches)
+{
+    if (!n_matches || (qs && qs->n > 0 && !match12)) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    Scratch s;
+    ProjInputs in;
+    int rc = proj_prepare(s, f2, qs, false, check_orientation != 0, in);
+    if (rc) return rc;
+    *n_matches = 0;
+    const int N = in.N, nq = in.nq;
+    if (nq == 0) return DCS_OK;
+    if (f2->taken) {                                     // SearchForInitialization has no "already matched" input: ignore the caller's map
+        const std::vector<uint8_t> none((size_t)std::max(N, 1), 0);
+        if ((rc = s.upload(&in.f.taken, none.data(), (size_t)N))) return rc;
+    }
+    unsigned* d_cand; int32_t *d_cn, *d_m12, *d_owner, *d_bin, *d_nm; uint16_t* d_md;
+    if ((rc = s.alloc(&d_cand, (size_t)nq * kProjCap)) || (rc = s.alloc(&d_cn, (size_t)nq)) || (rc = s.alloc(&d_m12, (size_t)nq)) ||
+        (rc = s.alloc(&d_owner, (size_t)N)) || (rc = s.alloc(&d_bin, (size_t)nq)) || (rc = s.alloc(&d_nm, 1)) || (rc = s.alloc(&d_md, (size_t)N))) return rc;
+    hipLaunchKernelGGL(k_proj_collect, dim3((nq + 3) / 4), dim3(256), 0, s.st, in.f, in.q, d_cand, d_cn);
+    DCS_CHECK_LAUNCH();
+    if (N <= 30000)                                      // u16 distance map + the static arrays stay below 64 KB of LDS
+        hipLaunchKernelGGL(k_init_resolve<true>, dim3(1), dim3(64), sizeof(uint16_t) * (size_t)std::max(N, 1), s.st, in.f, in.q, d_cand, d_cn, d_md, nn_ratio,
+                           check_orientation, d_m12, d_owner, d_bin, d_nm);
+    else
+        hipLaunchKernelGGL(k_init_resolve<false>, dim3(1), dim3(64), 0, s.st, in.f, in.q, d_cand, d_cn, d_md, nn_ratio, check_orientation, d_m12, d_owner,
+                           d_bin, d_nm);
+    DCS_CHECK_LAUNCH();
+    int32_t nm = 0;
+    if ((rc = s.download_bytes(match12, d_m12, sizeof(int32_t) * nq))) return rc;
     if ((rc = s.download_bytes(&nm, d_nm, sizeof(int32_t)))) return rc;
     if ((rc = s.finish())) return rc;
     *n_matches = nm;

@@ -77,6 +77,96 @@ public:
         return n;
     }
 
+    // SearchByProjectionOnCam(pF, query, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:812-951): queries = pKF's map points that
+    // are not bad / not already found and project into camera `query` (:849-876), radius = th * mvScaleFactors[nPredictedLevel],
+    // levels = nPredictedLevel -/+ 1, angle = pKF->mvTotalKeysUn[i].angle, frame.taken = (pF->mvpMapPoints[g] != NULL).
+    int SearchByProjectionOnCam(const dcs_proj_frame& frame, const dcs_proj_queries& queries, int ORBdist, std::vector<int32_t>& matchOfQuery,
+                                std::vector<int32_t>& queryOfFeature) const
+    {
+        matchOfQuery.assign(queries.n > 0 ? queries.n : 1, -1); queryOfFeature.assign(frame.cam_off[frame.n_cams] > 0 ? frame.cam_off[frame.n_cams] : 1, -1);
+        int n = 0;
+        check(dcs_search_by_projection(&frame, &queries, ORBdist, 0.f, mbCheckOrientation, matchOfQuery.data(), queryOfFeature.data(), &n),
+              "dcs_search_by_projection");
+        matchOfQuery.resize(queries.n); queryOfFeature.resize(frame.cam_off[frame.n_cams]);
+        return n;
+    }
+
+    // SearchByProjection(pKF, query, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:416-536, loop closing): queries = the candidate
+    // map points that pass :448-490 (depth, IsInImage, distance range, viewing angle), radius = th * mvScaleFactors[nPredictedLevel],
+    // levels nPredictedLevel - 1 .. nPredictedLevel, frame.taken = (vpMatched[idxLocal] != NULL); best only, TH_LOW; a matched
+    // feature is taken for the queries that follow (:508-509, :527). The KeyFrame grid quirk (KeyFrame.cc:756) only differs from
+    // the Frame grid for cameras > 0.
+    int SearchByProjection(const dcs_proj_frame& keyFrame, const dcs_proj_queries& queries, int th, std::vector<int32_t>& matchOfQuery,
+                           std::vector<int32_t>& queryOfFeature) const
+    {
+        (void)th;                                            // folded into queries.radius by the caller
+        matchOfQuery.assign(queries.n > 0 ? queries.n : 1, -1); queryOfFeature.assign(keyFrame.cam_off[keyFrame.n_cams] > 0 ? keyFrame.cam_off[keyFrame.n_cams] : 1, -1);
+        int n = 0;
+        check(dcs_search_by_projection(&keyFrame, &queries, TH_LOW, 0.f, 0, matchOfQuery.data(), queryOfFeature.data(), &n), "dcs_search_by_projection");
+        matchOfQuery.resize(queries.n); queryOfFeature.resize(keyFrame.cam_off[keyFrame.n_cams]);
+        return n;
+    }
+
+    // The candidate loop of Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:1431-1556; reprojGate = true: e2 * mvInvLevelSigma2[octave]
+    // > 5.99 skips, :1503-1509) and of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1560-1706; reprojGate = false): queries = the
+    // map points that pass the projection tests of their camera (:1451-1480), levels nPredictedLevel - 1 .. nPredictedLevel.
+    // bestIdx[i] = global key point whose map point is to be replaced / that receives the observation (:1530-1552), or -1.
+    // Queries are independent of each other; the Replace / AddObservation bookkeeping stays with the caller. Returns nFused.
+    int Fuse(const dcs_proj_frame& keyFrame, const dcs_proj_queries& queries, const std::vector<float>& invLevelSigma2, bool reprojGate,
+             std::vector<int32_t>& bestIdx) const
+    {
+        bestIdx.assign(queries.n > 0 ? queries.n : 1, -1);
+        int n = 0;
+        check(dcs_search_in_window(&keyFrame, &queries, TH_LOW, 1, reprojGate ? invLevelSigma2.data() : nullptr, (int)invLevelSigma2.size(), bestIdx.data(),
+                                   nullptr, &n), "dcs_search_in_window");
+        bestIdx.resize(queries.n);
+        return n;
+    }
+
+    // SearchByProjection(pKF, vpMapPoints, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:693-799), one camera per call: levels
+    // nPredictedLevel -/+ 1, best only, bestDist <= ORBdist.
+    int SearchByProjection(const dcs_proj_frame& keyFrame, const dcs_proj_queries& queries, int ORBdist, std::vector<int32_t>& bestIdx) const
+    {
+        bestIdx.assign(queries.n > 0 ? queries.n : 1, -1);
+        int n = 0;
+        check(dcs_search_in_window(&keyFrame, &queries, ORBdist, 1, nullptr, 0, bestIdx.data(), nullptr, &n), "dcs_search_in_window");
+        bestIdx.resize(queries.n);
+        return n;
+    }
+
+    // SearchBySim3CrossCam(pKF1, cam1, pKF2, cam2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:1713-1965): queries1in2[i1] = map
+    // point of KF1's local feature i1 projected into KF2's camera (:1793-1832), queries2in1 the other way (:1872-1911); both carry
+    // levels nPredictedLevel - 1 .. nPredictedLevel and cam = the searched key frame's camera. match12[i1] = camera-local KF2
+    // feature after the agreement check (:1950-1964), or -1. Returns nFound.
+    int SearchBySim3CrossCam(const dcs_proj_frame& keyFrame1, const dcs_proj_queries& queries2in1, const dcs_proj_frame& keyFrame2,
+                             const dcs_proj_queries& queries1in2, std::vector<int32_t>& match12) const
+    {
+        std::vector<int32_t> m1(queries1in2.n > 0 ? queries1in2.n : 1, -1), m2(queries2in1.n > 0 ? queries2in1.n : 1, -1);
+        int n = 0;
+        check(dcs_search_in_window(&keyFrame2, &queries1in2, TH_HIGH, 1, nullptr, 0, m1.data(), nullptr, &n), "dcs_search_in_window");
+        check(dcs_search_in_window(&keyFrame1, &queries2in1, TH_HIGH, 1, nullptr, 0, m2.data(), nullptr, &n), "dcs_search_in_window");
+        match12.assign(queries1in2.n, -1);
+        int nFound = 0;
+        for (int i1 = 0; i1 < queries1in2.n; ++i1) {
+            if (m1[i1] < 0) continue;
+            const int i2 = m1[i1] - keyFrame2.cam_off[queries1in2.cam[i1]];              // vnMatch1[i1] = bestIdx2local
+            if (i2 < queries2in1.n && m2[i2] >= 0 && m2[i2] - keyFrame1.cam_off[queries2in1.cam[i2]] == i1) { match12[i1] = i2; ++nFound; }
+        }
+        return nFound;
+    }
+
+    // SearchForInitialization(pF1, pF2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:1117-1251): frame2 = pF2, queries =
+    // pF1's key points in global order (valid = camera CAP and octave 0; u, v = vbPrevMatched; radius = windowSize; min = max
+    // level = octave). vnMatches12[i] = global key point of pF2 or -1; the caller then refreshes vbPrevMatched (:1244-1246).
+    int SearchForInitialization(const dcs_proj_frame& frame2, const dcs_proj_queries& queries, std::vector<int>& vnMatches12) const
+    {
+        std::vector<int32_t> m(queries.n > 0 ? queries.n : 1, -1);
+        int n = 0;
+        check(dcs_search_for_initialization(&frame2, &queries, mfNNratio, mbCheckOrientation, m.data(), &n), "dcs_search_for_initialization");
+        vnMatches12.assign(m.begin(), m.begin() + queries.n);
+        return n;
+    }
+
     // Frame::isInFrustum (Frame.cc:244-312) for all local map points of Tracking::SearchLocalPoints (Tracking.cc:1617-1680) in one
     // call, fused with PredictScale and the window of SearchByProjection (:557-565). `frame` carries Tsw = mvExtrinsics[c] * mTcw
     // and GetCameraCenter(c) as the caller's cv::Mat code forms them; the outputs fill the valid / cam / u / v / radius /

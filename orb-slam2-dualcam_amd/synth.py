@@ -379,6 +379,52 @@ def projection_problem(n_per_cam=900, n_queries=700, seed=13, th=1.0, big_window
     return frame, queries
 
 
+def initialization_problem(n_per_cam=500, seed=21, window=100.0, crowd=0.3):
+    """Synthetic input of ORBmatcher::SearchForInitialization (ORBmatcher.cc:1117-1251): frame F2 (dual camera, grid NOT included)
+    and F1's key points as ordered queries. Most level-0 key points of F1's camera 0 have a moved, noisy copy in F2; a fraction
+    `crowd` of them are rivals of an earlier key point (same target, a few pixels away, another noise level), so that later
+    queries find features held by earlier ones with a smaller / equal / larger distance (the vMatchedDistance gate and the
+    stealing rule both fire). Angles are consistent up to noise except for a random 20 % (rotation histogram)."""
+    rng = np.random.default_rng(seed)
+    n_cams = 2
+    cam_off = np.array([0, n_per_cam, 2 * n_per_cam], np.int32)
+    N = int(cam_off[-1])
+    kp_x2 = rng.uniform(5, 635, N).astype(np.float32)
+    kp_y2 = rng.uniform(5, 475, N).astype(np.float32)
+    oct2 = np.where(rng.random(N) < 0.6, 0, np.minimum(rng.geometric(0.4, N), 7)).astype(np.int32)
+    ang2 = rng.uniform(0, 360, N).astype(np.float32)
+    desc2 = random_descriptors(N, seed=seed + 1)
+    min_x, max_x, min_y, max_y = np.float32(0.0), np.float32(640.0), np.float32(0.0), np.float32(480.0)
+    frame2 = dict(cam_off=cam_off, kp_x=kp_x2, kp_y=kp_y2, kp_octave=oct2, kp_angle=ang2, desc=desc2, taken=np.zeros(N, np.uint8),
+                  min_x=np.full(n_cams, min_x, np.float32), min_y=np.full(n_cams, min_y, np.float32),
+                  grid_w_inv=np.full(n_cams, np.float32(64) / np.float32(max_x - min_x), np.float32),
+                  grid_h_inv=np.full(n_cams, np.float32(48) / np.float32(max_y - min_y), np.float32))
+    # F1: global order = camera 0 then camera 1
+    n1 = N
+    cam1 = np.repeat(np.arange(n_cams, dtype=np.int32), n_per_cam)
+    lvl0_cam0 = np.nonzero((oct2[:n_per_cam] == 0))[0]
+    target = rng.choice(lvl0_cam0, n1)                                   # F2 feature each F1 key point derives from
+    rival = rng.random(n1) < crowd
+    prev = np.maximum(np.arange(n1) - rng.integers(1, 6, n1), 0)
+    target[rival] = target[prev[rival]]                                   # same target as a key point a few places earlier
+    kp_x1 = (kp_x2[target] + rng.uniform(-40, 40, n1)).astype(np.float32)
+    kp_y1 = (kp_y2[target] + rng.uniform(-40, 40, n1)).astype(np.float32)
+    oct1 = np.where(rng.random(n1) < 0.7, 0, rng.integers(1, 8, n1)).astype(np.int32)
+    desc1 = desc2[target].copy()
+    flips = rng.choice([4, 8, 8, 12, 16, 24, 40, 70], n1)                 # equal noise levels on purpose: distance ties
+    for i in range(n1):
+        bits = rng.choice(256, int(flips[i]), replace=False)
+        for b in bits:
+            desc1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    ang1 = ((ang2[target] + rng.normal(0, 5, n1)) % 360).astype(np.float32)
+    odd = rng.random(n1) < 0.2
+    ang1[odd] = rng.uniform(0, 360, int(odd.sum())).astype(np.float32)
+    valid = ((cam1 == 0) & (oct1 == 0)).astype(np.uint8)
+    queries = dict(valid=valid, cam=cam1, u=kp_x1, v=kp_y1, radius=np.full(n1, np.float32(window), np.float32),
+                   min_level=oct1.copy(), max_level=oct1.copy(), desc=desc1, angle=ang1)
+    return frame2, queries
+
+
 # ----------------------------------------------------------------------------- BoW vocabulary (SURVEY 8(f)-4)
 def vocabulary(k=10, L=6, seed=1, flip=24, ragged=0.0, early_leaf=0.0, stop_frac=0.0, dup_frac=0.0):
     """Synthetic DBoW2 vocabulary in the column form of the reference's text file (TemplatedVocabulary.h:1362-1446; the real

@@ -270,3 +270,88 @@ def test_kfkf_bow_and_triangulation_vs_oracle(pkg, oracle, synth):
     em, en = oracle.search_for_triangulation(q, zq, ones_q, t, zt, ones_t, fvq, fvt, epi, False)
     gm, gn = pkg.abi.SearchForTriangulation(q, zq, ones_q, t, zt, ones_t, fvq, fvt, epi, False)
     assert np.array_equal(gm, em) and gn == en and en > 20
+
+
+@pytest.mark.parametrize("kw", [dict(n_per_cam=900, n_queries=700, seed=31, th=3.0),
+                                dict(n_per_cam=2500, n_queries=2000, seed=32, th=6.0),
+                                dict(n_per_cam=400, n_queries=300, seed=33, big_windows=25)])
+def test_search_in_window_vs_oracle(pkg, oracle, synth, kw):
+    """Candidate loops of Fuse x2, SearchBySim3CrossCam and SearchByProjection(KF, vpMapPoints, ...) (ORBmatcher.cc:1431-1556,
+    1560-1706, 1713-1965, 693-799): independent queries, KeyFrame::GetFeaturesInArea's index quirk, the loop's octave gate,
+    Fuse's chi-square gate -- every combination exact against the oracle, matches and best distances."""
+    frame, q = _proj_problem(pkg, oracle, synth, **kw)
+    inv_sigma2 = (1.0 / (np.float32(1.2) ** (2 * np.arange(8)))).astype(np.float32)
+    m = pkg.ORBmatcher(0.8, True)
+    for levels in (0, 1):                                   # pred - 1 .. pred (Fuse, Sim3) / pred - 1 .. pred + 1 (:757)
+        q["max_level"] = (q["min_level"] + 1 + levels).astype(np.int32)
+        for taken in (False, True):
+            fr = dict(frame)
+            if not taken:
+                fr["taken"] = np.zeros_like(frame["taken"])
+            for kf in (True, False):
+                for chi in (None, inv_sigma2):
+                    for th in (50, 100):
+                        mq, bd, n = m.SearchInWindow(fr, q, th=th, kf_area=kf, chi2_inv_sigma2=chi)
+                        emq, ebd, en = oracle.search_in_window(fr, q, th, kf, chi)
+                        assert np.array_equal(mq, emq) and np.array_equal(bd, ebd) and n == en
+    assert en > 0.2 * len(mq)
+    fr = dict(frame); fr["taken"] = None                     # no "already matched" map at all
+    mq, bd, n = m.SearchInWindow(fr, q, th=100, kf_area=True)
+    fr["taken"] = np.zeros_like(frame["taken"])
+    emq, ebd, en = oracle.search_in_window(fr, q, 100, True, None)
+    assert np.array_equal(mq, emq) and n == en
+    q0 = {k: v[:0] for k, v in q.items()}
+    mq, bd, n = m.SearchInWindow(frame, q0)
+    assert n == 0 and len(mq) == 0
+    with pytest.raises(pkg.DcsError):                        # an octave beyond the sigma table must be refused, not read out of bounds
+        m.SearchInWindow(frame, q, chi2_inv_sigma2=inv_sigma2[:3])
+
+
+def test_search_by_sim3_agreement(pkg, oracle, synth):
+    """SearchBySim3CrossCam (ORBmatcher.cc:1713-1965): two window searches + the agreement check, against the oracle's two
+    directions combined the same way."""
+    f1, q21 = _proj_problem(pkg, oracle, synth, n_per_cam=600, n_queries=600, seed=41, th=4.0)      # queries aimed at f1's features
+    f2, q12 = _proj_problem(pkg, oracle, synth, n_per_cam=600, n_queries=600, seed=42, th=4.0)      # ... at f2's
+    # queries are indexed by the camera-local feature of their own key frame, all of camera 0 here
+    for q, fr_other, fr_own in ((q12, f2, f1), (q21, f1, f2)):
+        q["cam"][:] = 0; q["max_level"] = (q["min_level"] + 1).astype(np.int32)
+    # make direction 2 -> 1 the mirror image of 1 -> 2 for half of the queries so that agreements exist
+    m1, _, _ = oracle.search_in_window(f2, q12, 100, True, None)
+    for i1 in np.nonzero(m1 >= 0)[0][::2]:
+        i2 = int(m1[i1])
+        if i2 < len(q21["cam"]):
+            q21["u"][i2], q21["v"][i2] = f1["kp_x"][i1], f1["kp_y"][i1]
+            q21["desc"][i2] = f1["desc"][i1]; q21["min_level"][i2] = f1["kp_octave"][i1] - 1; q21["max_level"][i2] = f1["kp_octave"][i1]
+            q21["radius"][i2] = 12.0; q21["valid"][i2] = 1
+    m = pkg.ORBmatcher(0.8, True)
+    match12, found = m.SearchBySim3(f1, q12, f2, q21, th=100)
+    e1, _, _ = oracle.search_in_window(f2, q12, 100, True, None)
+    e2, _, _ = oracle.search_in_window(f1, q21, 100, True, None)
+    exp = np.full(len(e1), -1, np.int32)
+    for i1 in range(len(e1)):
+        if e1[i1] >= 0 and e1[i1] < len(e2) and e2[e1[i1]] == i1:
+            exp[i1] = e1[i1]
+    assert np.array_equal(match12, exp) and found == int((exp >= 0).sum()) and found > 20
+
+
+@pytest.mark.parametrize("kw", [dict(n_per_cam=500, seed=21), dict(n_per_cam=1500, seed=23, crowd=0.5),
+                                dict(n_per_cam=300, seed=24, window=400.0)])
+def test_search_for_initialization_vs_oracle(pkg, oracle, synth, kw):
+    """ORBmatcher::SearchForInitialization (ORBmatcher.cc:1117-1251) with its in-loop state -- vMatchedDistance gate, match
+    stealing, the stale rotation histogram -- exact against the sequential oracle; window = 400 px overflows the candidate lists."""
+    f2, q = synth.initialization_problem(**kw)
+    off, idx = pkg.frame_grid(f2["cam_off"], f2["kp_x"], f2["kp_y"], f2["min_x"], f2["min_y"], f2["grid_w_inv"], f2["grid_h_inv"])
+    f2["grid_off"], f2["grid_idx"] = off, idx
+    for ratio in (0.9, 0.7):
+        m = pkg.ORBmatcher(ratio, True)
+        for ori in (True, False):
+            m12, n = m.SearchForInitialization(f2, q, check_orientation=ori)
+            e12, en = oracle.search_for_initialization(f2, q, ratio, ori)
+            assert np.array_equal(m12, e12) and n == en
+            assert n == int((m12 >= 0).sum()) and n > 0.15 * int(q["valid"].sum())
+    f2t = dict(f2); f2t["taken"] = np.ones_like(f2["taken"])          # the frame's "taken" map is not part of this search
+    m12b, nb = m.SearchForInitialization(f2t, q, check_orientation=False)
+    assert np.array_equal(m12b, m12) and nb == n
+    q0 = {k: v[:0] for k, v in q.items()}
+    m12, n = m.SearchForInitialization(f2, q0)
+    assert n == 0 and len(m12) == 0

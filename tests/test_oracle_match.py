@@ -328,3 +328,198 @@ def test_triangulation_last_tie_wins_and_epipolar_gates(oracle):
     assert m.tolist() == [0]                                     # features that already hold a MapPoint are not candidates
     m, n = oracle.search_for_triangulation(z, ang[:1], [0], t, ang, [1, 1, 1, 1, 1], _one_node(1), _one_node(5), epi, False)
     assert m.tolist() == [-1] and n == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# row a10, the remaining variants: SearchForInitialization (in-loop vMatchedDistance / stealing) and the window searches with
+# independent queries (Fuse x2, SearchBySim3CrossCam, SearchByProjection(KF, ...)) incl. KeyFrame::GetFeaturesInArea's index quirk
+def _area_np(frame, cells, c, x, y, r, lo=None, hi=None, kf=False):
+    """Frame::GetFeaturesInArea (Frame.cc:316-376) / KeyFrame::GetFeaturesInArea (KeyFrame.cc:728-765, kf=True) in float32"""
+    f32 = np.float32
+    x, y, r = f32(x), f32(y), f32(r)
+    x0 = max(0, int(np.floor(f32(f32(f32(x - frame["min_x"][c]) - r) * frame["grid_w_inv"][c]))))
+    x1 = min(63, int(np.ceil(f32(f32(f32(x - frame["min_x"][c]) + r) * frame["grid_w_inv"][c]))))
+    y0 = max(0, int(np.floor(f32(f32(f32(y - frame["min_y"][c]) - r) * frame["grid_h_inv"][c]))))
+    y1 = min(47, int(np.ceil(f32(f32(f32(y - frame["min_y"][c]) + r) * frame["grid_h_inv"][c]))))
+    if x0 >= 64 or x1 < 0 or y0 >= 48 or y1 < 0:
+        return []
+    out = []
+    for ix in range(x0, x1 + 1):
+        for iy in range(y0, y1 + 1):
+            for loc in cells.get((c, ix, iy), []):
+                g = frame["cam_off"][c] + loc
+                if not kf:
+                    o = frame["kp_octave"][g]
+                    if (lo > 0 or hi >= 0) and (o < lo or (hi >= 0 and o > hi)):
+                        continue
+                p = loc if kf else g                                   # KeyFrame.cc:756: mvTotalKeysUn[vCell[j]]
+                if abs(f32(frame["kp_x"][p] - x)) < r and abs(f32(frame["kp_y"][p] - y)) < r:
+                    out.append(loc)
+    return out
+
+
+def _with_grid(oracle, frame):
+    off, idx = oracle.frame_grid(frame["cam_off"], frame["kp_x"], frame["kp_y"], frame["min_x"], frame["min_y"],
+                                 frame["grid_w_inv"], frame["grid_h_inv"])
+    frame["grid_off"], frame["grid_idx"] = off, idx
+    return frame
+
+
+def _init_np(frame2, cells, q, ratio, check_ori):
+    """SearchForInitialization (ORBmatcher.cc:1117-1251) written independently of the oracle: plain Python over numpy bits"""
+    f32 = np.float32
+    N2, n1 = int(frame2["cam_off"][-1]), len(q["cam"])
+    bits2 = np.unpackbits(frame2["desc"], axis=1).astype(np.int32)
+    bits1 = np.unpackbits(q["desc"], axis=1).astype(np.int32)
+    INT_MAX = 2 ** 31 - 1
+    m12 = np.full(n1, -1); m21 = np.full(N2, -1); md = np.full(N2, INT_MAX, np.int64)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    for i in range(n1):
+        if not q["valid"][i]:
+            continue
+        c = q["cam"][i]
+        best, best2, bi = INT_MAX, INT_MAX, -1
+        for loc in _area_np(frame2, cells, c, q["u"][i], q["v"][i], q["radius"][i], q["min_level"][i], q["max_level"][i]):
+            g = frame2["cam_off"][c] + loc
+            d = int((bits1[i] != bits2[g]).sum())
+            if md[g] <= d:
+                continue
+            if d < best:
+                best2, best, bi = best, d, g
+            elif d < best2:
+                best2 = d
+        if best <= 50 and f32(best) < f32(f32(best2) * f32(ratio)):
+            if m21[bi] >= 0:
+                m12[m21[bi]] = -1; nm -= 1
+            m12[i] = bi; m21[bi] = i; md[bi] = best; nm += 1
+            if check_ori:
+                rot = f32(q["angle"][i] - frame2["kp_angle"][bi])
+                if rot < 0:
+                    rot = f32(rot + f32(360))
+                t = float(f32(rot * f32(1.0 / 30)))
+                b = int(np.floor(t + 0.5))                             # round(): half away from zero, t >= 0
+                hist[0 if b == 30 else b].append(i)
+    if check_ori:
+        sizes = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda b: (-sizes[b], b))         # ComputeThreeMaxima: strict >, first bin wins ties
+        i1, i2, i3 = order[0], order[1], order[2]
+        if sizes[i1] == 0:
+            i1 = i2 = i3 = -1
+        else:
+            if sizes[i2] == 0 or f32(sizes[i2]) < f32(0.1) * f32(sizes[i1]):
+                i2 = i3 = -1
+            elif sizes[i3] == 0 or f32(sizes[i3]) < f32(0.1) * f32(sizes[i1]):
+                i3 = -1
+        for b in range(30):
+            if b in (i1, i2, i3):
+                continue
+            for i in hist[b]:
+                if m12[i] >= 0:
+                    m12[i] = -1; nm -= 1
+    return m12, nm
+
+
+def test_search_for_initialization_oracle(oracle, synth):
+    # --- hand-built: one F2 feature, rivals with distances 10, 10, 6, 8 in this order
+    f2 = dict(cam_off=np.array([0, 2, 2], np.int32), kp_x=np.array([100, 400], np.float32), kp_y=np.array([100, 300], np.float32),
+              kp_octave=np.zeros(2, np.int32), kp_angle=np.zeros(2, np.float32), desc=np.zeros((2, 32), np.uint8), taken=np.zeros(2, np.uint8),
+              min_x=np.zeros(2, np.float32), min_y=np.zeros(2, np.float32), grid_w_inv=np.full(2, 0.1, np.float32), grid_h_inv=np.full(2, 0.1, np.float32))
+    f2["desc"][1] = 255
+    _with_grid(oracle, f2)
+
+    def qdesc(nbits):
+        d = np.zeros(32, np.uint8)
+        for b in range(nbits):
+            d[b >> 3] |= 1 << (b & 7)
+        return d
+    dists = [10, 10, 6, 8, 60]
+    n = len(dists)
+    q = dict(valid=np.ones(n, np.uint8), cam=np.zeros(n, np.int32), u=np.full(n, 110, np.float32), v=np.full(n, 95, np.float32),
+             radius=np.full(n, 100, np.float32), min_level=np.zeros(n, np.int32), max_level=np.zeros(n, np.int32),
+             desc=np.stack([qdesc(d) for d in dists]), angle=np.zeros(n, np.float32))
+    m, nm = oracle.search_for_initialization(f2, q, 0.9, False)
+    # q0 takes feature 0 at 10; q1 (10 <= 10: candidate skipped, :1176) gets nothing; q2 steals at 6; q3 (8 > 6) skipped; q4 too far
+    assert list(m) == [-1, -1, 0, -1, -1] and nm == 1
+    # a non-CAP / non-level-0 key point never searches (:1142-1149)
+    q["valid"][2] = 0
+    m, nm = oracle.search_for_initialization(f2, q, 0.9, False)
+    assert list(m) == [-1, -1, -1, 0, -1] and nm == 1            # q0 took it at 10, q3 steals at 8
+    # the ratio test against the second-best candidate (:1192): features at distance 9 and 10 -> 9 < (float)10 * 0.9f = 9.0f fails
+    f2b = dict(f2); f2b["kp_x"] = np.array([100, 120], np.float32); f2b["kp_y"] = np.array([100, 100], np.float32)
+    f2b["desc"] = np.stack([np.zeros(32, np.uint8), qdesc(19)])
+    _with_grid(oracle, f2b)
+    q1 = {k: v[2:3].copy() for k, v in q.items()}; q1["valid"][:] = 1; q1["desc"] = qdesc(9)[None]
+    m, nm = oracle.search_for_initialization(f2b, q1, 0.9, False)   # dist to f0 = 9, to f1 = 10
+    assert list(m) == [-1] and nm == 0
+    m, nm = oracle.search_for_initialization(f2b, q1, 1.0, False)
+    assert list(m) == [0] and nm == 1
+    # --- against the independent restatement, with and without the rotation histogram
+    for seed in (21, 22):
+        f2, q = synth.initialization_problem(n_per_cam=260, seed=seed)
+        _with_grid(oracle, f2)
+        cells = _grid_np(f2)
+        for ori in (False, True):
+            m, nm = oracle.search_for_initialization(f2, q, 0.9, ori)
+            em, enm = _init_np(f2, cells, q, 0.9, ori)
+            assert np.array_equal(m, em) and nm == enm and nm == int((m >= 0).sum()) and nm > 20
+    # the stealing rule really fired: some valid queries found an acceptable feature and lost it again
+    m_no, _ = oracle.search_for_initialization(f2, q, 0.9, False)
+    assert int((m_no >= 0).sum()) < int(q["valid"].sum())
+
+
+def test_search_in_window_oracle(oracle, synth):
+    frame, q = synth.projection_problem(n_per_cam=300, n_queries=260, seed=8, th=3.0)
+    frame["taken"][:] = 0
+    _with_grid(oracle, frame)
+    cells = _grid_np(frame)
+    q["max_level"] = (q["min_level"] + 1).astype(np.int32)                   # nPredictedLevel - 1 .. nPredictedLevel
+    inv_sigma2 = (1.0 / (np.float32(1.2) ** (2 * np.arange(8)))).astype(np.float32)
+    bits = np.unpackbits(frame["desc"], axis=1).astype(np.int32)
+    qbits = np.unpackbits(q["desc"], axis=1).astype(np.int32)
+    f32 = np.float32
+
+    def expect(kf, chi, th):
+        out = np.full(len(q["cam"]), -1); bd = np.full(len(q["cam"]), 256)
+        for i in range(len(q["cam"])):
+            if not q["valid"][i]:
+                continue
+            c = q["cam"][i]
+            best, bi = 256, -1
+            for loc in _area_np(frame, cells, c, q["u"][i], q["v"][i], q["radius"][i], -1, -1, kf=kf):
+                g = frame["cam_off"][c] + loc
+                o = frame["kp_octave"][g]
+                if o < q["min_level"][i] or o > q["max_level"][i]:
+                    continue
+                if chi is not None:
+                    ex, ey = f32(q["u"][i] - frame["kp_x"][g]), f32(q["v"][i] - frame["kp_y"][g])
+                    e2 = f32(f32(ex * ex) + f32(ey * ey))
+                    if float(f32(e2 * chi[o])) > 5.99:
+                        continue
+                d = int((bits[g] != qbits[i]).sum())
+                if d < best:
+                    best, bi = d, g
+            bd[i] = best
+            if best <= th:
+                out[i] = bi
+        return out, bd
+    n_kf = {}
+    for kf in (False, True):
+        for chi in (None, inv_sigma2):
+            for th in (50, 100):
+                m, bd, acc = oracle.search_in_window(frame, q, th, kf, chi)
+                em, ebd = expect(kf, chi, th)
+                assert np.array_equal(m, em) and np.array_equal(bd, ebd) and acc == int((em >= 0).sum())
+                n_kf[(kf, chi is None, th)] = acc
+    assert n_kf[(False, True, 100)] > 100                                   # the searches find their targets ...
+    assert n_kf[(False, False, 100)] < n_kf[(False, True, 100)]             # ... the chi2 gate removes some ...
+    # ... and the KeyFrame quirk matters for camera 1 only (camera 0: local == global)
+    m0, _, _ = oracle.search_in_window(frame, q, 100, False, None)
+    m1, _, _ = oracle.search_in_window(frame, q, 100, True, None)
+    cam = q["cam"]
+    assert np.array_equal(m0[cam == 0], m1[cam == 0]) and not np.array_equal(m0[cam == 1], m1[cam == 1])
+    # features flagged in `taken` are skipped (vpMatched[idx] of ORBmatcher.cc:508-509 as a snapshot)
+    hit = m0[m0 >= 0][:20]
+    frame["taken"][hit] = 1
+    m2, _, _ = oracle.search_in_window(frame, q, 100, False, None)
+    assert not np.isin(m2[m2 >= 0], hit).any()
