@@ -14,7 +14,7 @@
 //                   CSR order, no atomics (reproducible)
 //   per trial (5 launches + one 40-byte read-back):
 //   k_prep          BD[e] = H_pl[e] (H_ll + lambda I)^-1 per edge, D^-1 and D^-1 b_l per landmark
-//   k_schur         workgroup per pose pair over a precomputed (edge, edge) list (28 chunks) + the reduced right-hand side
+//   k_schur         4-wave workgroup per pose pair over a precomputed (edge, edge) list (7 chunks x 36 entries) + the reduced right-hand side
 //   k_ldlt_mfma     LDL^T + both triangular solves of the reduced camera system in ONE workgroup: 16x16 tiles in
 //                   registers, trailing updates on the f64 matrix cores (v_mfma_f64_16x16x4_f64)
 //                   (k_ldlt_reg: column-by-column VALU predecessor, DCS_BA_LDLT_VALU=1; k_ldlt_panel/_update/_solve:
@@ -498,9 +498,13 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
 }
 
 // workgroup per pose pair (i1 <= i2): S block = [i1==i2](Hpp + lambda I) - sum over shared points BD[e1] Hpl[e2]^T.
-// 28 list chunks x 36 block entries (1024 threads, 4 list entries in flight per thread); partials combined in fixed order.
-constexpr int kSchurChunks = 28;
-__global__ __launch_bounds__(1024) void k_schur(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
+// kSchurChunks list chunks x 36 block entries per workgroup (4 list entries in flight per thread); partials combined in fixed
+// order. 7 chunks = 4 waves: a C4 problem has ~860 such workgroups per trial and a batch of 8 problems ~6 900 -- with 16-wave
+// workgroups (28 chunks) the batch needed 13 rounds of the chip's wave slots (97 us), with 4-wave ones it needs 4.
+constexpr int kSchurChunks = 7;
+constexpr int kSchurThreads = 256;
+constexpr int kSchurRhsChunks = 42;                      // 42 x 6 rows = 252 threads for the reduced right-hand side
+__global__ __launch_bounds__(kSchurThreads) void k_schur(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
     __shared__ double part[kSchurChunks][36];
     const BaProb& pb = probs[blockIdx.y];
@@ -510,19 +514,20 @@ __global__ __launch_bounds__(1024) void k_schur(const BaProb* __restrict__ probs
     if ((int)blockIdx.x >= n_pairs + pb.np) return;
     const double* __restrict__ Hpl = pb.Hpl;
     if ((int)blockIdx.x >= n_pairs) {                        // blocks past the pair list: reduced right-hand side of one free pose
-        // bsch = bp - sum_e Hpl[e] db[point(e)]; 168 edge chunks x 6 rows, combined in chunk order
-        double (*bpart)[6] = reinterpret_cast<double (*)[6]>(&part[0][0]);         // 168 x 6 <= 28 x 36
+        // bsch = bp - sum_e Hpl[e] db[point(e)]; kSchurRhsChunks edge chunks x 6 rows, combined in chunk order
+        static_assert(kSchurRhsChunks * 6 <= kSchurChunks * 36 && kSchurRhsChunks * 6 <= kSchurThreads, "rhs partials live in `part`");
+        double (*bpart)[6] = reinterpret_cast<double (*)[6]>(&part[0][0]);
         const int32_t* __restrict__ ps_off = pb.ps_off;
         const int32_t* __restrict__ ps_edges = pb.ps_edges;
         const int32_t* __restrict__ e_point = pb.epoint;
         const double* __restrict__ db = pb.db;
         const int i = blockIdx.x - n_pairs, t = threadIdx.x;
         const int r = t % 6, q = t / 6;
-        if (q < 168) {
+        if (q < kSchurRhsChunks) {
             double a = 0;
             const int k1 = ps_off[i + 1];
 #pragma unroll 4
-            for (int k = ps_off[i] + q; k < k1; k += 168) {
+            for (int k = ps_off[i] + q; k < k1; k += kSchurRhsChunks) {
                 const int e = ps_edges[k];
                 const double* B = Hpl + (size_t)e * 18 + r * 3;
                 const double* d = db + 3 * e_point[e];
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(1024) void k_schur(const BaProb* __restrict__ probs
             bpart[q][r] = a;
         }
         __syncthreads();
-        if (t < 6) { double a = 0; for (int q2 = 0; q2 < 168; ++q2) a += bpart[q2][t]; pb.bsch[i * 6 + t] = pb.bp[i * 6 + t] - a; }
+        if (t < 6) { double a = 0; for (int q2 = 0; q2 < kSchurRhsChunks; ++q2) a += bpart[q2][t]; pb.bsch[i * 6 + t] = pb.bp[i * 6 + t] - a; }
         return;
     }
     const double lambda = 1e-5 * ctl.maxdiag * ctl.mult;
@@ -1581,6 +1586,11 @@ struct BaContext {
     char* h_stage = nullptr; size_t stage_cap = 0;
     int* h_words = nullptr; size_t words_cap = 0;      // [0] last finished step, [1] problems done, [16 + b] stop word of problem b
     hipStream_t stream = nullptr;
+    // a batch is split into groups of problems, each fed through its own stream: while one group's reduced camera systems are
+    // factored (one workgroup per problem) the other groups' wide kernels have the rest of the chip
+    static constexpr int kMaxGroups = 4;
+    hipStream_t aux[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_up = nullptr, ev_done[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
     // measurement hook (dcs_ba_timing): hipEvents around every LDL^T launch and every step of the device loop
     bool timing = false;
     std::vector<hipEvent_t> events;
@@ -1593,6 +1603,10 @@ struct BaContext {
         if (h_stage) (void)hipHostFree(h_stage);
         if (h_words) (void)hipHostFree(h_words);
         if (stream) (void)hipStreamDestroy(stream);
+        for (hipStream_t& a : aux) { if (a) (void)hipStreamDestroy(a); a = nullptr; }
+        for (hipEvent_t& e : ev_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        if (ev_up) (void)hipEventDestroy(ev_up);
+        ev_up = nullptr;
         base = nullptr; cap = 0; h_stage = nullptr; stage_cap = 0; h_words = nullptr; words_cap = 0; stream = nullptr; device = -1;
     }
     ~BaContext() { release(); }
@@ -1613,6 +1627,15 @@ struct BaContext {
             words_cap = w;
         }
         if (!stream) DCS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return DCS_OK;
+    }
+    int prepare_groups(int n_groups)
+    {
+        if (n_groups > 1 && !ev_up) DCS_HIP(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
+        for (int g = 1; g < n_groups; ++g) {
+            if (!aux[g - 1]) DCS_HIP(hipStreamCreateWithFlags(&aux[g - 1], hipStreamNonBlocking));
+            if (!ev_done[g - 1]) DCS_HIP(hipEventCreateWithFlags(&ev_done[g - 1], hipEventDisableTiming));
+        }
         return DCS_OK;
     }
 };
@@ -1784,7 +1807,15 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     struct Regions { size_t upload_end, zero_begin, zero_end, dl_begin, dl_end; };
     std::vector<BaProb> hp(NB);
     BaProb* d_probs = nullptr; BaCtl* d_ctls = nullptr;
-    unsigned* d_grid_ticket = nullptr;
+    // groups of problems = contiguous ranges [g_begin[g], g_begin[g + 1]) of the live list, one stream each. The event timing
+    // of dcs_ba_timing brackets launches on ONE stream, so a timed call runs as a single group.
+    BaContext& ctx = ba_context();
+    int G = std::min({BaContext::kMaxGroups, std::max(NB / 2, 1), 8});
+    if (const char* e = getenv("DCS_BA_GROUPS")) G = std::max(1, std::min({atoi(e), (int)BaContext::kMaxGroups, NB}));
+    if (ctx.timing) G = 1;
+    int g_begin[BaContext::kMaxGroups + 1];
+    for (int g = 0; g <= G; ++g) g_begin[g] = (int)((long long)NB * g / G);
+    unsigned* d_grid_ticket[BaContext::kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
     auto layout = [&](Carver& c, Regions& rg) {
         for (int i = 0; i < NB; ++i) {
             const dcs_ba_problem* pb = problems[live[i]];
@@ -1812,7 +1843,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         for (int i = 0; i < NB; ++i) {
             BaProb& q = hp[i];
             q.ticket = c.get<unsigned>(4);
-            if (i == 0) d_grid_ticket = c.get<unsigned>(4);
+            for (int g = 0; g < G; ++g) if (i == g_begin[g]) d_grid_ticket[g] = c.get<unsigned>(4);
             q.S = q.use_reg ? c.get<double>((size_t)q.ld * q.ld) : nullptr;       // pairs without shared points stay 0
         }
         rg.zero_end = c.off;
@@ -1843,8 +1874,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     Regions rg{};
     { Carver dry; layout(dry, rg); }
     const size_t arena_bytes = rg.dl_end + 256, dl_bytes = rg.dl_end - rg.dl_begin;
-    BaContext& ctx = ba_context();
-    if ((rc = ctx.prepare(arena_bytes, rg.upload_end + dl_bytes, 16 + (size_t)NB))) return rc;
+    if ((rc = ctx.prepare(arena_bytes, rg.upload_end + dl_bytes, 16 + (size_t)NB)) || (rc = ctx.prepare_groups(G))) return rc;
     Carver real; real.base = ctx.base;
     layout(real, rg);
     hipStream_t st = ctx.stream;
@@ -1853,7 +1883,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     auto stage = [&](const void* dptr) { return hs + (reinterpret_cast<const char*>(dptr) - ctx.base); };
     auto landed = [&](const void* dptr) { return h_dl + (reinterpret_cast<const char*>(dptr) - (ctx.base + rg.dl_begin)); };
 
-    // ---- one staging image, one copy
+    // ---- one staging image, one copy (threads do not help here: the copies are short and the pinned buffer is one stream of writes)
     for (int i = 0; i < NB; ++i) {
         const dcs_ba_problem* pb = problems[live[i]];
         const Round& r = rounds[i];
@@ -1882,8 +1912,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
     }
     memcpy(stage(d_probs), hp.data(), sizeof(BaProb) * NB);
-    int* const h_words = ctx.h_words;
-    h_words[0] = 0; h_words[1] = 0;
+    int* const h_words = ctx.h_words;                   // [2g] last finished step of group g, [2g + 1] its finished problems, [16 + i] stop word of problem i
+    for (int k = 0; k < 16; ++k) h_words[k] = 0;
     for (int i = 0; i < NB; ++i) h_words[16 + i] = 0;
     const auto t_opt0 = now();
     DCS_HIP(hipMemcpyAsync(ctx.base, hs, rg.upload_end, hipMemcpyHostToDevice, st));
@@ -1892,98 +1922,123 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         if (hp[i].iters[0] <= 0) DCS_HIP(hipMemsetAsync(hp[i].chi2, 0, sizeof(double) * hp[i].E, st));    // no error evaluation will ever write it
     hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1024), 0, st, (const BaProb*)d_probs, d_ctls, NB);
     DCS_CHECK_LAUNCH();
+    if (G > 1) {
+        DCS_HIP(hipEventRecord(ctx.ev_up, st));
+        for (int g = 1; g < G; ++g) DCS_HIP(hipStreamWaitEvent(ctx.aux[g - 1], ctx.ev_up, 0));
+    }
 
-    // ---- launch geometry of one step (largest problem decides; smaller ones exit early)
-    int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, max_steps = 0, max_npad_blocked = 0;
-    bool any_mfma = false, any_valu = false, any_blocked = false;
-    for (int i = 0; i < NB; ++i) {
-        const BaProb& q = hp[i];
-        g_edges = std::max(g_edges, q.nblk);
-        g_reduce = std::max(g_reduce, q.np + q.nb_pts);
-        g_prep = std::max(g_prep, (q.np ? q.nblk : 0) + (q.L + 255) / 256);
-        if (q.np) g_schur = std::max(g_schur, q.n_pairs + q.np);
-        g_update = std::max(g_update, q.nb_pts + q.nb_pose);
-        max_steps = std::max(max_steps, (std::max(q.iters[0], 0) + std::max(q.iters[1], 0)) * 10 + 2);
-        if (q.np) {
-            any_mfma |= q.use_reg == 1; any_valu |= q.use_reg == 2; any_blocked |= q.use_reg == 0;
-            if (q.use_reg == 0) max_npad_blocked = std::max(max_npad_blocked, q.n_pad);
+    // ---- launch geometry of one step of a group (its largest problem decides; smaller ones exit early)
+    struct Group {
+        hipStream_t st; const BaProb* dp; BaCtl* ctls; int nb, off; int* words; unsigned* ticket;
+        int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, max_npad_blocked = 0;
+        bool any_mfma = false, any_valu = false, any_blocked = false, finished = false;
+    };
+    std::vector<Group> groups((size_t)G);
+    int max_steps = 0;
+    for (int g = 0; g < G; ++g) {
+        Group& gr = groups[g];
+        gr.st = g == 0 ? st : ctx.aux[g - 1]; gr.off = g_begin[g]; gr.nb = g_begin[g + 1] - g_begin[g];
+        gr.dp = d_probs + gr.off; gr.ctls = d_ctls + gr.off; gr.words = h_words + 2 * g; gr.ticket = d_grid_ticket[g];
+        for (int i = gr.off; i < gr.off + gr.nb; ++i) {
+            const BaProb& q = hp[i];
+            gr.g_edges = std::max(gr.g_edges, q.nblk);
+            gr.g_reduce = std::max(gr.g_reduce, q.np + q.nb_pts);
+            gr.g_prep = std::max(gr.g_prep, (q.np ? q.nblk : 0) + (q.L + 255) / 256);
+            if (q.np) gr.g_schur = std::max(gr.g_schur, q.n_pairs + q.np);
+            gr.g_update = std::max(gr.g_update, q.nb_pts + q.nb_pose);
+            max_steps = std::max(max_steps, (std::max(q.iters[0], 0) + std::max(q.iters[1], 0)) * 10 + 2);
+            if (q.np) {
+                gr.any_mfma |= q.use_reg == 1; gr.any_valu |= q.use_reg == 2; gr.any_blocked |= q.use_reg == 0;
+                if (q.use_reg == 0) gr.max_npad_blocked = std::max(gr.max_npad_blocked, q.n_pad);
+            }
         }
     }
-    const BaProb* dp = d_probs;
-    const volatile int* d_stop = h_words + 16;
     // before the first step: errors of the initial estimates (or, with iters1 <= 0, straight to the flags)
-    hipLaunchKernelGGL(k_post, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, NB, 0, h_words, d_grid_ticket);
-    DCS_CHECK_LAUNCH();
+    for (const Group& gr : groups) {
+        hipLaunchKernelGGL(k_post, dim3(gr.g_edges, gr.nb), dim3(256), 0, gr.st, gr.dp, gr.ctls, gr.nb, 0, gr.words, gr.ticket);
+        DCS_CHECK_LAUNCH();
+    }
     const bool timing = ctx.timing;
     auto event_at = [&](size_t i) -> hipEvent_t {
         while (ctx.events.size() <= i) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ctx.events.push_back(e); }
         return ctx.events[i];
     };
     auto mark = [&](int step, int k) { if (timing) { hipEvent_t e = event_at((size_t)(step - 1) * 4 + k); if (e) (void)hipEventRecord(e, st); } };
-    auto enqueue_step = [&](int step) -> int {
+    auto enqueue_step = [&](const Group& gr, int step) -> int {
+        hipStream_t gs = gr.st;
+        const BaProb* dp = gr.dp;
+        BaCtl* ctls = gr.ctls;
+        const int nb = gr.nb;
+        const volatile int* d_stop = h_words + 16 + gr.off;
         mark(step, 0);
-        hipLaunchKernelGGL(k_linearize, dim3(g_edges, NB), dim3(256), 0, st, dp, (const BaCtl*)d_ctls);                    // buildSystem
-        hipLaunchKernelGGL(k_reduce_pose, dim3(g_reduce, NB), dim3(1024), 0, st, dp, d_ctls);                              // + computeLambdaInit (first iteration)
-        hipLaunchKernelGGL(k_prep, dim3(g_prep, NB), dim3(256), 0, st, dp, d_ctls);                                       // setLambda + solve (Schur)
+        hipLaunchKernelGGL(k_linearize, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, (const BaCtl*)ctls);                   // buildSystem
+        hipLaunchKernelGGL(k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), 0, gs, dp, ctls);                             // + computeLambdaInit (first iteration)
+        hipLaunchKernelGGL(k_prep, dim3(gr.g_prep, nb), dim3(256), 0, gs, dp, ctls);                                      // setLambda + solve (Schur)
         DCS_CHECK_LAUNCH();
-        if (any_blocked) {                                // the blocked fallback factors S in place: rebuild it every trial
-            for (int i = 0; i < NB; ++i)
-                if (hp[i].np && hp[i].use_reg == 0) DCS_HIP(hipMemsetAsync(hp[i].S, 0, sizeof(double) * (size_t)hp[i].ld * hp[i].ld, st));
-            hipLaunchKernelGGL(k_pad_identity, dim3(1, NB), dim3(64), 0, st, dp, (const BaCtl*)d_ctls);
+        if (gr.any_blocked) {                             // the blocked fallback factors S in place: rebuild it every trial
+            for (int i = gr.off; i < gr.off + nb; ++i)
+                if (hp[i].np && hp[i].use_reg == 0) DCS_HIP(hipMemsetAsync(hp[i].S, 0, sizeof(double) * (size_t)hp[i].ld * hp[i].ld, gs));
+            hipLaunchKernelGGL(k_pad_identity, dim3(1, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
         }
-        if (g_schur) hipLaunchKernelGGL(k_schur, dim3(g_schur, NB), dim3(1024), 0, st, dp, (const BaCtl*)d_ctls);
+        if (gr.g_schur) hipLaunchKernelGGL(k_schur, dim3(gr.g_schur, nb), dim3(kSchurThreads), 0, gs, dp, (const BaCtl*)ctls);
         mark(step, 1);
-        if (any_mfma) hipLaunchKernelGGL(k_ldlt_mfma, dim3(NB), dim3(256), 0, st, dp, d_ctls);
-        if (any_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(NB), dim3(1024), 0, st, dp, d_ctls);
-        if (any_blocked) {
-            for (int k0 = 0; k0 < max_npad_blocked; k0 += kNB) {
-                hipLaunchKernelGGL(k_ldlt_panel, dim3(NB), dim3(256), 0, st, dp, d_ctls, k0);
-                const int m = (max_npad_blocked - k0) / kNB - 1;
-                if (m > 0) hipLaunchKernelGGL(k_ldlt_update, dim3(m, m, NB), dim3(64), 0, st, dp, (const BaCtl*)d_ctls, k0);
+        if (gr.any_mfma) hipLaunchKernelGGL(k_ldlt_mfma, dim3(nb), dim3(256), 0, gs, dp, ctls);
+        if (gr.any_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(nb), dim3(1024), 0, gs, dp, ctls);
+        if (gr.any_blocked) {
+            for (int k0 = 0; k0 < gr.max_npad_blocked; k0 += kNB) {
+                hipLaunchKernelGGL(k_ldlt_panel, dim3(nb), dim3(256), 0, gs, dp, ctls, k0);
+                const int m = (gr.max_npad_blocked - k0) / kNB - 1;
+                if (m > 0) hipLaunchKernelGGL(k_ldlt_update, dim3(m, m, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls, k0);
             }
-            hipLaunchKernelGGL(k_ldlt_solve, dim3(NB), dim3(256), sizeof(double) * max_npad_blocked, st, dp, (const BaCtl*)d_ctls);
+            hipLaunchKernelGGL(k_ldlt_solve, dim3(nb), dim3(256), sizeof(double) * gr.max_npad_blocked, gs, dp, (const BaCtl*)ctls);
         }
         DCS_CHECK_LAUNCH();
         mark(step, 2);
-        hipLaunchKernelGGL(k_solve_update, dim3(g_update, NB), dim3(64), 0, st, dp, (const BaCtl*)d_ctls);
-        hipLaunchKernelGGL(k_error<1>, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, d_stop);        // chi2 of the trial + computeScale + accept / reject
-        hipLaunchKernelGGL(k_post, dim3(g_edges, NB), dim3(256), 0, st, dp, d_ctls, NB, step, h_words, d_grid_ticket);          // round change / stale errors / progress
+        hipLaunchKernelGGL(k_solve_update, dim3(gr.g_update, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
+        hipLaunchKernelGGL(k_error<1>, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, d_stop);        // chi2 of the trial + computeScale + accept / reject
+        hipLaunchKernelGGL(k_post, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, nb, step, gr.words, gr.ticket);          // round change / stale errors / progress
         mark(step, 3);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     };
 
-    // ---- the host only feeds the queue: kLookahead steps ahead of what the device has reported finished
-    constexpr int kLookahead = 3;
-    auto load_words = [&](int& step_done, int& n_done) {
-        step_done = __atomic_load_n(h_words, __ATOMIC_ACQUIRE);
-        n_done = __atomic_load_n(h_words + 1, __ATOMIC_RELAXED);
+    // ---- the host only feeds the queues: kLookahead steps ahead of what the device has reported finished, group by group
+    constexpr int kLookahead = 2;                        // a step lasts 0.2 - 0.3 ms, enqueueing one 0.05 - 0.15 ms
+    auto load_words = [&](const Group& gr, int& step_done, int& n_done) {
+        step_done = __atomic_load_n(gr.words, __ATOMIC_ACQUIRE);
+        n_done = __atomic_load_n(gr.words + 1, __ATOMIC_RELAXED);
     };
     auto refresh_stop = [&] { for (int i = 0; i < NB; ++i) if (stop_requested(live[i])) __atomic_store_n(h_words + 16 + i, 1, __ATOMIC_RELAXED); };
-    int steps = 0;
-    bool finished = false;
+    int steps = 0, n_finished = 0;
     double t_wait = 0;
-    while (!finished && steps < max_steps) {
+    while (n_finished < G && steps < max_steps) {
         refresh_stop();
         ++steps;
-        if ((rc = enqueue_step(steps))) return rc;
+        for (Group& gr : groups) if (!gr.finished && (rc = enqueue_step(gr, steps))) return rc;
         const auto tw0 = now();
-        for (;;) {
-            int sd, nd;
-            load_words(sd, nd);
-            if (nd == NB) { finished = true; break; }
-            if (sd >= steps - kLookahead) break;
-            refresh_stop();
-            const hipError_t qe = hipStreamQuery(st);
-            if (qe == hipSuccess) {                       // queue drained: the words are final
-                load_words(sd, nd);
-                if (nd == NB) finished = true;
-                else if (sd < steps) { set_error("BA device loop lost step %d (reported %d)", steps, sd); return DCS_ERR_HIP; }
-                break;
+        for (Group& gr : groups) {
+            if (gr.finished) continue;
+            for (;;) {
+                int sd, nd;
+                load_words(gr, sd, nd);
+                if (nd == gr.nb) { gr.finished = true; ++n_finished; break; }
+                if (sd >= steps - kLookahead) break;
+                refresh_stop();
+                const hipError_t qe = hipStreamQuery(gr.st);
+                if (qe == hipSuccess) {                   // queue drained: the words are final
+                    load_words(gr, sd, nd);
+                    if (nd == gr.nb) { gr.finished = true; ++n_finished; }
+                    else if (sd < steps) { set_error("BA device loop lost step %d (reported %d)", steps, sd); return DCS_ERR_HIP; }
+                    break;
+                }
+                if (qe != hipErrorNotReady) { set_error("BA stream: %s", hipGetErrorString(qe)); return DCS_ERR_HIP; }
             }
-            if (qe != hipErrorNotReady) { set_error("BA stream: %s", hipGetErrorString(qe)); return DCS_ERR_HIP; }
         }
         t_wait += ms_since(tw0);
+    }
+    for (int g = 1; g < G; ++g) {                         // the download waits for every group
+        DCS_HIP(hipEventRecord(ctx.ev_done[g - 1], ctx.aux[g - 1]));
+        DCS_HIP(hipStreamWaitEvent(st, ctx.ev_done[g - 1], 0));
     }
     DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, st));
     DCS_HIP(hipStreamSynchronize(st));
