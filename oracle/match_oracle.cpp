@@ -63,6 +63,14 @@ extern "C" {
 
 int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
 
+/* ComputeThreeMaxima on a histogram given as bin sizes; ind[3] start at -1 like every caller's (ORBmatcher.cc:274-276) */
+void orc_three_maxima(const int32_t* sizes, int L, int32_t* ind)
+{
+    int i1 = -1, i2 = -1, i3 = -1;
+    three_maxima(sizes, L, i1, i2, i3);
+    ind[0] = i1; ind[1] = i2; ind[2] = i3;
+}
+
 void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* t_mask,
               int32_t* best_idx, int32_t* best_d, int32_t* second_d)
 {

@@ -71,6 +71,21 @@ def ref_distances(a, b):
     return d1, d2
 
 
+def ref_three_maxima(sizes):
+    """ORBmatcher::ComputeThreeMaxima (the reference's own statements) on a histogram given as bin sizes -> (ind1, ind2, ind3)"""
+    sizes = _c(sizes, np.int32)
+    ind = np.zeros(3, np.int32)
+    ref().ref_three_maxima(_p(sizes), len(sizes), _p(ind))
+    return tuple(int(v) for v in ind)
+
+
+def three_maxima(sizes):
+    sizes = _c(sizes, np.int32)
+    ind = np.zeros(3, np.int32)
+    lib().orc_three_maxima(_p(sizes), len(sizes), _p(ind))
+    return tuple(int(v) for v in ind)
+
+
 def ref_bow_vector(word, weight, if_not_exist=False, norm=1):
     word, weight = _c(word, np.uint32), _c(weight, np.float64)
     ow, ov = np.zeros(max(len(word), 1), np.uint32), np.zeros(max(len(word), 1))

@@ -7,11 +7,14 @@
 //   * the loops of ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2015-2031) and FORB::distance
 //       (Thirdparty/DBoW2/DBoW2/FORB.cpp:82-102): their statements from `int dist=0;` to `return dist;` are cut out by awk at build
 //       time into _ref/*.inc (the two lines before them only fetch `const int*` row pointers from cv::Mat)
+//   * ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1969-2010): the statements between the braces of its definition, cut out
+//       by awk the same way; the wrapper below repeats the reference's parameter list (histo, L, ind1, ind2, ind3)
 // Nothing of the reference is copied into the repository: the generated files live in oracle/_ref/ (git-ignored).
 // The oracle's restatements are checked against these functions in tests/test_oracle_ref.py, and golden vectors produced
 // by them are committed (tests/golden/ref_dbow2.npz, make_golden_ref.py) so that the pin travels to machines without the reference.
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "BowVector.h"
 #include "FeatureVector.h"
@@ -26,7 +29,23 @@ static int ref_forb_distance_impl(const int* pa, const int* pb)
 #include "forb_distance_body.inc"
 }
 
+static void ref_three_maxima_impl(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3)
+{
+    using namespace std;
+#include "three_maxima_body.inc"
+}
+
 extern "C" {
+
+// histogram given as bin sizes; ind[3] = {ind1, ind2, ind3} as the callers initialise them (-1) and the function leaves them
+void ref_three_maxima(const int32_t* sizes, int L, int32_t* ind)
+{
+    std::vector<std::vector<int>> h((size_t)L);
+    for (int i = 0; i < L; ++i) h[i].assign((size_t)sizes[i], 0);
+    int i1 = -1, i2 = -1, i3 = -1;
+    ref_three_maxima_impl(h.data(), L, i1, i2, i3);
+    ind[0] = i1; ind[1] = i2; ind[2] = i3;
+}
 
 int ref_descriptor_distance(const uint8_t* a, const uint8_t* b)
 {

@@ -55,3 +55,16 @@ for k in range(6):
 out["scores"] = sc
 np.savez_compressed(os.path.join(HERE, "ref_dbow2.npz"), **out)
 print("ref_dbow2.npz:", len(out), "arrays")
+
+# ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1969-2010, the reference's own statements) on rotation histograms:
+# random ones, ties, empty ones and the 0.1f * max1 boundaries
+tm = np.random.default_rng(2025)
+hist = [tm.integers(0, 40, 30), tm.integers(0, 3, 30), np.zeros(30, np.int64), np.full(30, 7), np.eye(1, 30, 4, dtype=np.int64)[0] * 9]
+for m1, m2, m3 in [(10, 1, 1), (10, 2, 1), (20, 2, 1), (20, 2, 2), (30, 3, 2), (100, 10, 9), (100, 11, 10), (50, 5, 5), (50, 6, 4)]:
+    h = np.zeros(30, np.int64); h[[3, 17, 29]] = (m1, m2, m3); hist.append(h)
+    h = np.zeros(30, np.int64); h[[29, 0, 1]] = (m1, m2, m3); hist.append(h)
+hist += [tm.integers(0, 12, 30) for _ in range(200)]
+hist = np.stack(hist).astype(np.int32)
+ind = np.array([O.ref_three_maxima(h) for h in hist], np.int32)
+np.savez_compressed(os.path.join(HERE, "ref_three_maxima.npz"), hist=hist, ind=ind)
+print("ref_three_maxima.npz:", hist.shape, "histograms")

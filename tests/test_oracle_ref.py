@@ -90,3 +90,18 @@ def test_transform_against_reference_containers(oracle, synth):
     assert np.array_equal(w, t["bow_word"]) and np.array_equal(_bits(v), _bits(t["bow_val"]))
     fn, fo, fi = oracle.ref_feature_vector(t["node"].astype(np.uint32))
     assert np.array_equal(fn, t["fv_node"]) and np.array_equal(fo, t["fv_off"]) and np.array_equal(fi, t["fv_idx"])
+
+
+def test_three_maxima_golden_and_live(oracle):
+    """ORBmatcher::ComputeThreeMaxima: the oracle's restatement against the reference's own statements (golden vectors made by
+    oracle/_ref, and live where the reference tree exists), including ties and the 0.1f * max1 boundaries."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_three_maxima.npz"))
+    for h, ind in zip(g["hist"], g["ind"]):
+        assert oracle.three_maxima(h) == tuple(int(v) for v in ind), h
+    assert tuple(g["ind"][2]) == (-1, -1, -1) and tuple(g["ind"][3]) == (0, 1, 2) and tuple(g["ind"][4]) == (4, -1, -1)   # empty / all equal (strict ">" keeps the first three bins) / single bin
+    if oracle.ref() is None:
+        return
+    rng = np.random.default_rng(int.from_bytes(os.urandom(4), "little"))
+    for _ in range(2000):
+        h = rng.integers(0, rng.integers(2, 60), 30).astype(np.int32)
+        assert oracle.three_maxima(h) == oracle.ref_three_maxima(h), h
