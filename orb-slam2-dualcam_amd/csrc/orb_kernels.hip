@@ -369,8 +369,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     // (a neighbour whose score is missing has score < T <= s(p) and would lose anyway). 91 % of the cells of the benchmark
     // scene stop after the first pass, which scores a third fewer pixels than the minThFAST pass.
     const int spare = dw * dh + 32;                // u16 slot behind the survivor list (and behind what an odd last row appends)
-    int n_list = 0;
-    unsigned long long sel = 0;                    // one bit per list round of this lane: keypoints of the pass that produced some
+    int n_list = 0, base = 0;                      // survivors of the compass test; keypoints emitted
+    dcs_candidate* const out = slots + (size_t)img * slots_per_image + cd.slot_base;
     // position of this lane among the set bits of a ballot: v_mbcnt_lo + v_mbcnt_hi
     auto rank_in = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     for (int pass = 0; pass < 2; ++pass) {
@@ -445,38 +445,38 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         }
         __syncthreads();
         DCS_FAST_SECTION(3);
-        // ---- 4. NMS: keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } (neighbours below T lose anyway)
-        unsigned long long f = 0;
-        int it = 0;
-        for (int i = lane; i < n_list; i += 64, ++it) {
-            const int yx = s_list[i], y = yx >> 8, x = yx & 255;
-            const uint8_t* c = sc + __mul24(y, sc_pitch) + x;
-            const int s = c[0];
-            if (s >= th) {
-                const uint8_t* cu = c - sc_pitch; const uint8_t* cd2 = c + sc_pitch;
-                const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)cu[-1], (int)cu[0])), max(max((int)cu[1], (int)cd2[-1]), max((int)cd2[0], (int)cd2[1])));
-                if (s > nb) f |= 1ull << it;
+        // ---- 4. NMS + ordered emission: keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } (neighbours below T
+        // lose anyway). Keypoints go straight to the cell's slot range: a pass that finds none has emitted nothing, and only such
+        // a pass is followed by another one (vKeysCell.empty(), :812).
+        for (int i0 = 0; i0 < n_list; i0 += 64) {               // wave-uniform
+            const int i = i0 + lane;
+            bool keep = false;
+            int y = 0, x = 0, s = 0;
+            if (i < n_list) {
+                const int yx = s_list[i];
+                y = yx >> 8; x = yx & 255;
+                const uint8_t* c = sc + __mul24(y, sc_pitch) + x;
+                s = c[0];
+                if (s >= th) {
+                    const uint8_t* cu = c - sc_pitch; const uint8_t* cd2 = c + sc_pitch;
+                    const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)cu[-1], (int)cu[0])), max(max((int)cu[1], (int)cd2[-1]), max((int)cd2[0], (int)cd2[1])));
+                    keep = s > nb;
+                }
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            if (m) {                                             // wave-uniform
+                const int off = base + rank_in(m);
+                if (keep && off < cd.cap) {
+                    dcs_candidate o;
+                    o.x = (int16_t)(x + cd.ox); o.y = (int16_t)(y + cd.oy); o.score = (uint8_t)s;
+                    out[off] = o;
+                }
+                base += __popcll(m);
             }
         }
-        sel = f;
         DCS_FAST_SECTION(4);
-        if (__any(f != 0)) break;                      // vKeysCell not empty: no minThFAST retry (:812)
+        if (base) break;                               // vKeysCell not empty: no minThFAST retry (:812)
         __syncthreads();                               // the list is rebuilt by the next pass
-    }
-    dcs_candidate* out = slots + (size_t)img * slots_per_image + cd.slot_base;
-    int base = 0;
-    int it = 0;
-    for (int i0 = 0; i0 < n_list; i0 += 64, ++it) {
-        const bool flag = (sel >> it) & 1ull;
-        const unsigned long long m = __ballot(flag);
-        const int off = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (flag && off < cd.cap) {
-            const int yx = s_list[i0 + lane], y = yx >> 8, x = yx & 255;
-            dcs_candidate o;
-            o.x = (int16_t)(x + cd.ox); o.y = (int16_t)(y + cd.oy); o.score = sc[__mul24(y, sc_pitch) + x];
-            out[off] = o;
-        }
-        base += __popcll(m);
     }
     if (lane == 0) cell_count[(size_t)img * n_cells + cell] = min(base, (int)cd.cap);
 }
