@@ -461,6 +461,29 @@ int  dcs_bow_transform(const dcs_vocab* v, const uint8_t* desc, int n, int level
 int  dcs_bow_score_l1(const int32_t* q_word, const double* q_val, int nq, const int32_t* db_off, const int32_t* db_word,
                       const double* db_val, int n_db, double* score);
 
+/* ---------------------------------------------------------------------------------------------------------------
+   KeyFrameDatabase of one camera (src/KeyFrameDatabase.cc:46-110: mvvInvertedFiles[c]) resident in HBM, and the query half of
+   DetectLoopCandidatesForCam (:111-235) / DetectRelocalizationCandidates (:237-372). The database keeps the entries' BowVectors in
+   order of insertion; an inverted list of the reference is "the live entries that hold the word, ascending entry id" (its
+   push_back order), so it is never materialised. One handle per camera; not thread-safe per handle (the reference holds mMutex). */
+typedef struct dcs_kfdb dcs_kfdb;
+int  dcs_kfdb_create(dcs_kfdb** out);
+void dcs_kfdb_destroy(dcs_kfdb* db);
+/* KeyFrameDatabase::add (:63-71): the BowVector (word ids strictly ascending, as a std::map iterates) of the new key frame;
+   *entry_id = its index (0, 1, 2 ... in order of insertion) */
+int  dcs_kfdb_add(dcs_kfdb* db, const int32_t* word, const double* val, int n, int* entry_id);
+/* KeyFrameDatabase::erase (:73-97): the entry leaves every inverted list; ids of the others do not change */
+int  dcs_kfdb_erase(dcs_kfdb* db, int entry_id);
+int  dcs_kfdb_clear(dcs_kfdb* db);                      /* :99-108 */
+int  dcs_kfdb_size(const dcs_kfdb* db, int* n_entries); /* entries ever added since the last clear (erased ones included) */
+/* For every entry (arrays of dcs_kfdb_size elements): common = words shared with the query = the value the walk over the
+   inverted files leaves in mnLoopWords / mnRelocWords (:128-149, :257-272; 0 for erased entries), first_word = the smallest shared
+   word id (-1 if none) -- entries enter lKFsSharingWords in (first_word, entry id) order -- and score = (float)L1Scoring::score
+   (query, entry), the `float si = mpVoc->score(...)` of :175, :305 (bit-identical to dcs_bow_score_l1). The thresholds
+   (0.8f * maxCommonWords, minScore), the covisibility accumulation and the 0.75f * bestAccScore cut work on these three arrays
+   and the caller's covisibility graph: KeyFrameDatabase::Detect*Candidates in orb-slam2-dualcam_amd/host/KeyFrameDatabase.h. */
+int  dcs_kfdb_query(dcs_kfdb* db, const int32_t* q_word, const double* q_val, int nq, int32_t* common, int32_t* first_word, float* score);
+
 #ifdef __cplusplus
 }
 #endif

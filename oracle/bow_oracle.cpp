@@ -10,6 +10,7 @@
 // Called from Frame::ComputeBoW with levelsup = 4 (src/Frame.cc:393-406). std::map is used exactly as DBoW2 does, so
 // the order of the floating-point additions (per-word accumulation, norm, score) is the reference's.
 // PARITY UNPINNED: the reference ships no vocabulary (Vocabulary/download_link.txt) and no test vectors for this path.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -175,6 +176,76 @@ void orc_bow_score_l1(const int32_t* q_word, const double* q_val, int nq, const 
         }
         score[k] = -s / 2.0;                                              // :64
     }
+}
+
+/* KeyFrameDatabase::DetectLoopCandidatesForCam (src/KeyFrameDatabase.cc:111-235, loop != 0) and DetectRelocalizationCandidates
+   (:237-372, loop == 0) for one camera pair on flat arrays, statement by statement, with REAL inverted files: the database is
+   given as the BowVectors of its entries in insertion order (CSR) + a dead flag per entry (erase()); the lists
+   mvvInvertedFiles[word] are built from it in push_back order. st_query / st_words / st_score are the key frames' members
+   (mnLoopQuery | mnRelocQuery, mnLoopWords | mnRelocWords, mLoopScore | mRelocScore): in/out, they persist across calls.
+   connected[k]: entry k is in pKF->GetConnectedKeyFrames() (loop only). covis: GetBestCovisibilityKeyFrames(10) of every entry
+   as CSR of entry ids. Returns the number of candidates written to out (entry ids, the reference's order). */
+int orc_detect_candidates(int loop, int query_id, const int32_t* q_word, const double* q_val, int nq, int n_db, const int32_t* db_off,
+                          const int32_t* db_word, const double* db_val, const uint8_t* dead, const uint8_t* connected, float minScore,
+                          const int32_t* covis_off, const int32_t* covis_idx, int32_t* st_query, int32_t* st_words, float* st_score,
+                          int32_t* out, int cap)
+{
+    std::map<int, std::vector<int>> inverted;                           /* word -> entries, insertion order */
+    for (int k = 0; k < n_db; ++k)
+        if (!dead[k]) for (int j = db_off[k]; j < db_off[k + 1]; ++j) inverted[db_word[j]].push_back(k);
+    std::vector<int> lKFsSharingWords;
+    for (int a = 0; a < nq; ++a) {                                      /* :128-149 / :257-272 */
+        auto it = inverted.find(q_word[a]);
+        if (it == inverted.end()) continue;
+        for (int pKFi : it->second) {
+            if (st_query[pKFi] != query_id) {
+                st_words[pKFi] = 0;
+                if (!loop || !connected[pKFi]) { st_query[pKFi] = query_id; lKFsSharingWords.push_back(pKFi); }
+            }
+            st_words[pKFi]++;
+        }
+    }
+    if (lKFsSharingWords.empty()) return 0;
+    int maxCommonWords = 0;
+    for (int k : lKFsSharingWords) if (st_words[k] > maxCommonWords) maxCommonWords = st_words[k];
+    const int minCommonWords = (int)(maxCommonWords * 0.8f);
+    std::vector<std::pair<float, int>> lScoreAndMatch;
+    for (int k : lKFsSharingWords) {
+        if (st_words[k] > minCommonWords) {
+            double sc;
+            orc_bow_score_l1(q_word, q_val, nq, db_off + k, db_word, db_val, 1, &sc);      /* db_off + k: entry k as a one-entry CSR */
+            const float si = (float)sc;
+            st_score[k] = si;
+            if (!loop || si >= minScore) lScoreAndMatch.push_back(std::make_pair(si, k));
+        }
+    }
+    if (lScoreAndMatch.empty()) return 0;
+    std::vector<std::pair<float, int>> lAccScoreAndMatch;
+    float bestAccScore = loop ? minScore : 0.0f;
+    for (auto& sm : lScoreAndMatch) {
+        const int pKFi = sm.second;
+        float bestScore = sm.first, accScore = sm.first;
+        int pBestKF = pKFi;
+        for (int j = covis_off[pKFi]; j < covis_off[pKFi + 1]; ++j) {
+            const int pKF2 = covis_idx[j];
+            if (loop) { if (!(st_query[pKF2] == query_id && st_words[pKF2] > minCommonWords)) continue; }
+            else if (st_query[pKF2] != query_id) continue;
+            accScore += st_score[pKF2];
+            if (st_score[pKF2] > bestScore) { pBestKF = pKF2; bestScore = st_score[pKF2]; }
+        }
+        lAccScoreAndMatch.push_back(std::make_pair(accScore, pBestKF));
+        if (accScore > bestAccScore) bestAccScore = accScore;
+    }
+    const float minScoreToRetain = 0.75f * bestAccScore;
+    std::vector<int> added;
+    int n_out = 0;
+    for (auto& am : lAccScoreAndMatch) {
+        if (am.first > minScoreToRetain) {
+            const int k = am.second;
+            if (std::find(added.begin(), added.end(), k) == added.end()) { if (n_out < cap) out[n_out] = k; ++n_out; added.push_back(k); }
+        }
+    }
+    return n_out;
 }
 
 }  // extern "C"

@@ -263,6 +263,13 @@ int  orc_bow_transform(const orc_vocab* v, const uint8_t* desc, int n, int level
 void orc_bow_score_l1(const int32_t* q_word, const double* q_val, int nq, const int32_t* db_off, const int32_t* db_word,
                       const double* db_val, int n_db, double* score);
 
+/* KeyFrameDatabase::DetectLoopCandidatesForCam (src/KeyFrameDatabase.cc:111-235) / DetectRelocalizationCandidates (:237-372) of one
+   camera pair on flat arrays with real inverted files; st_* = the key frames' mn*Query / mn*Words / m*Score members (in/out) */
+int orc_detect_candidates(int loop, int query_id, const int32_t* q_word, const double* q_val, int nq, int n_db, const int32_t* db_off,
+                          const int32_t* db_word, const double* db_val, const uint8_t* dead, const uint8_t* connected, float min_score,
+                          const int32_t* covis_off, const int32_t* covis_idx, int32_t* st_query, int32_t* st_words, float* st_score,
+                          int32_t* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

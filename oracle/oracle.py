@@ -663,6 +663,29 @@ def bow_score_l1(q_word, q_val, db_off, db_word, db_val):
     return score[:n_db]
 
 
+def detect_candidates(loop, query_id, q_word, q_val, db, dead, covis, state, connected=None, min_score=0.0):
+    """KeyFrameDatabase::DetectLoopCandidatesForCam / DetectRelocalizationCandidates on flat arrays. db = list of (word, val) BowVectors
+    in insertion order; covis = list of neighbour entry lists; state = dict(query=int32[n], words=int32[n], score=float32[n]), updated
+    in place. Returns the candidate entry ids in the reference's order."""
+    n = len(db)
+    off = np.cumsum([0] + [len(w) for w, _ in db]).astype(np.int32)
+    dbw = _c(np.concatenate([np.asarray(w, np.int32) for w, _ in db]) if n else np.zeros(0, np.int32), np.int32)
+    dbv = _c(np.concatenate([np.asarray(v, np.float64) for _, v in db]) if n else np.zeros(0), np.float64)
+    coff = np.cumsum([0] + [len(c) for c in covis]).astype(np.int32)
+    cidx = _c(np.concatenate([np.asarray(c, np.int32) for c in covis]) if sum(len(c) for c in covis) else np.zeros(1, np.int32), np.int32)
+    q_word, q_val = _c(q_word, np.int32), _c(q_val, np.float64)
+    dead = _c(dead, np.uint8)
+    conn = _c(connected if connected is not None else np.zeros(max(n, 1), np.uint8), np.uint8)
+    out = np.zeros(max(n, 1), np.int32)
+    L = lib()
+    L.orc_detect_candidates.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    assert state["query"].dtype == np.int32 and state["words"].dtype == np.int32 and state["score"].dtype == np.float32
+    k = L.orc_detect_candidates(int(bool(loop)), int(query_id), _p(q_word), _p(q_val), len(q_word), n, _p(off), _p(dbw), _p(dbv), _p(dead), _p(conn),
+                                float(min_score), _p(coff), _p(cidx), _p(state["query"]), _p(state["words"]), _p(state["score"]), _p(out), len(out))
+    return [int(v) for v in out[:k]]
+
+
 def is_in_frustum(frame, pts, viewing_cos_limit=0.5, th=1.0):
     """Frame::isInFrustum + PredictScale + search window for pts = dict(pos[n,3], normal[n,3], min_dist[n], max_dist[n], candidate[n] or None)."""
     keep = []

@@ -6,5 +6,5 @@ raises if the library is missing.
 """
 from . import synth  # noqa: F401
 from . import abi  # noqa: F401,E402
-from .abi import ORBextractor, ORBmatcher, Optimizer, DcsError, ComputeDistinctiveDescriptors, frame_grid, ORBVocabulary, isInFrustum, projection_queries  # noqa: F401,E402
+from .abi import ORBextractor, ORBmatcher, Optimizer, DcsError, ComputeDistinctiveDescriptors, frame_grid, ORBVocabulary, KeyFrameDatabase, isInFrustum, projection_queries  # noqa: F401,E402
 from . import sharding  # noqa: F401,E402

@@ -29,6 +29,7 @@ SYMBOLS = [
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
+    "dcs_kfdb_create", "dcs_kfdb_destroy", "dcs_kfdb_add", "dcs_kfdb_erase", "dcs_kfdb_clear", "dcs_kfdb_size", "dcs_kfdb_query",
 ]
 
 
@@ -132,6 +133,8 @@ def lib():
             "dcs_pose_optimization": [C.POINTER(PoseProblem), C.POINTER(PoseResult)],
             "dcs_frame_grid": [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, pci],
             "dcs_search_by_projection": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, cf, ci, vp, vp, pci],
+            "dcs_kfdb_create": [C.POINTER(vp)], "dcs_kfdb_destroy": [vp], "dcs_kfdb_add": [vp, vp, vp, ci, pci], "dcs_kfdb_erase": [vp, ci],
+            "dcs_kfdb_clear": [vp], "dcs_kfdb_size": [vp, pci], "dcs_kfdb_query": [vp, vp, vp, ci, vp, vp, vp],
             "dcs_search_in_window": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, ci, vp, ci, vp, vp, pci],
             "dcs_search_for_initialization": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), cf, ci, vp, pci],
             "dcs_rig_adjoint": [vp, ci, vp, vp],
@@ -153,6 +156,7 @@ def lib():
             L.dcs_orb_destroy.restype = None
         if hasattr(L, "dcs_vocab_destroy"):
             L.dcs_vocab_destroy.restype = None
+            L.dcs_kfdb_destroy.restype = None
         if hasattr(L, "dcs_comm_destroy"):
             L.dcs_comm_destroy.restype = None
         _lib = L
@@ -773,6 +777,113 @@ class ORBVocabulary:
         score = np.zeros(max(n_db, 1))
         _check(lib().dcs_bow_score_l1(_p(q_word), _p(q_val), len(q_word), _p(db_off), _p(db_word), _p(db_val), n_db, _p(score)), "dcs_bow_score_l1")
         return score[:n_db]
+
+
+class KeyFrameDatabase:
+    """KeyFrameDatabase of ONE camera (src/KeyFrameDatabase.cc) over dcs_kfdb_*: add / erase / clear and the two candidate
+    searches on flat inputs. Per-entry state the reference keeps in KeyFrame members (mnLoopQuery, mnLoopWords, mLoopScore,
+    mnRelocQuery, mnRelocWords, mRelocScore) lives in arrays here and persists across queries like the members do."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(lib().dcs_kfdb_create(C.byref(self._h)), "dcs_kfdb_create")
+        # q_id / words / score = mnLoopQuery|mnRelocQuery, mnLoopWords|mnRelocWords, mLoopScore|mRelocScore of the entries (one search
+        # kind per instance; databases of several cameras may share these arrays: assign the same objects)
+        self.q_id = np.zeros(0, np.int64); self.words = np.zeros(0, np.int32); self.score = np.zeros(0, np.float32)
+
+    def close(self):
+        if self._h:
+            lib().dcs_kfdb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = C.c_int()
+        _check(lib().dcs_kfdb_size(self._h, C.byref(n)), "dcs_kfdb_size")
+        return n.value
+
+    def add(self, word, val):
+        word, val = _c(word, np.int32), _c(val, np.float64)
+        e = C.c_int()
+        _check(lib().dcs_kfdb_add(self._h, _p(word), _p(val), len(word), C.byref(e)), "dcs_kfdb_add")
+        self.q_id = np.append(self.q_id, -1); self.words = np.append(self.words, 0).astype(np.int32); self.score = np.append(self.score, 0).astype(np.float32)
+        return e.value
+
+    def erase(self, entry):
+        _check(lib().dcs_kfdb_erase(self._h, int(entry)), "dcs_kfdb_erase")
+
+    def clear(self):
+        _check(lib().dcs_kfdb_clear(self._h), "dcs_kfdb_clear")
+        self.q_id = np.zeros(0, np.int64); self.words = np.zeros(0, np.int32); self.score = np.zeros(0, np.float32)
+
+    def query(self, q_word, q_val):
+        q_word, q_val = _c(q_word, np.int32), _c(q_val, np.float64)
+        n = len(self)
+        common, first, score = np.zeros(max(n, 1), np.int32), np.full(max(n, 1), -1, np.int32), np.zeros(max(n, 1), np.float32)
+        _check(lib().dcs_kfdb_query(self._h, _p(q_word), _p(q_val), len(q_word), _p(common), _p(first), _p(score)), "dcs_kfdb_query")
+        return common[:n], first[:n], score[:n]
+
+    def _detect(self, query_id, q_word, q_val, covis, connected, min_score, loop):
+        common, first, score = self.query(q_word, q_val)
+        n = len(common)
+        # the walk over the inverted files (:128-149, :257-272) leaves, per entry that shares a word: its place in lKFsSharingWords
+        # = (first shared word, entry id) order, and the members. An entry that already carries this query's id (the same key frame
+        # queried again for another camera pair: the members are per key frame, not per camera) is NOT listed again and its word
+        # count keeps growing; a connected key frame (loop search) never gets the id, so its count restarts at every word: 1.
+        sharing = []
+        for k in np.lexsort((np.arange(n), first)):
+            if common[k] <= 0:
+                continue
+            if self.q_id[k] != query_id:
+                if loop and connected[k]:
+                    self.words[k] = 1
+                else:
+                    self.q_id[k] = query_id; self.words[k] = common[k]; sharing.append(int(k))
+            else:
+                self.words[k] += common[k]
+        if not sharing:
+            return []
+        max_common = max(int(self.words[k]) for k in sharing)
+        min_common = int(np.float32(max_common) * np.float32(0.8))
+        score_and_match = []
+        for k in sharing:
+            if self.words[k] > min_common:
+                self.score[k] = score[k]
+                if not loop or score[k] >= np.float32(min_score):
+                    score_and_match.append((np.float32(score[k]), k))
+        if not score_and_match:
+            return []
+        acc_and_match, best_acc = [], (np.float32(min_score) if loop else np.float32(0))
+        for si, k in score_and_match:
+            best, acc, best_k = si, si, k
+            for k2 in covis[k]:
+                if self.q_id[k2] != query_id or (loop and not self.words[k2] > min_common):
+                    continue
+                acc = np.float32(acc + self.score[k2])
+                if self.score[k2] > best:
+                    best_k, best = k2, self.score[k2]
+            acc_and_match.append((acc, best_k))
+            if acc > best_acc:
+                best_acc = acc
+        keep = np.float32(np.float32(0.75) * best_acc)
+        out = []
+        for acc, k in acc_and_match:
+            if acc > keep and k not in out:
+                out.append(int(k))
+        return out
+
+    def DetectRelocalizationCandidates(self, frame_id, q_word, q_val, covis):
+        """src/KeyFrameDatabase.cc:237-372; covis[k] = GetBestCovisibilityKeyFrames(10) of entry k as entry ids"""
+        return self._detect(frame_id, q_word, q_val, covis, None, 0.0, False)
+
+    def DetectLoopCandidates(self, kf_id, q_word, q_val, covis, connected, min_score):
+        """DetectLoopCandidatesForCam (:111-235); connected[k] = entry k is in pKF->GetConnectedKeyFrames()"""
+        return self._detect(kf_id, q_word, q_val, covis, connected, min_score, True)
 
 
 def isInFrustum(frame, pts, viewing_cos_limit=0.5, th=1.0):

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "common.h"
@@ -234,10 +235,73 @@ __global__ __launch_bounds__(256) void k_bow_score_l1(const int32_t* __restrict_
     score[k] = -s / 2.0;
 }
 
+// KeyFrameDatabase query: one lane per database entry, the same merge-join as k_bow_score_l1 (identical order of additions) that
+// also counts the shared words -- what the walk over the inverted files accumulates in mnLoopWords / mnRelocWords
+// (src/KeyFrameDatabase.cc:128-149, 257-272) -- and remembers the first one, which fixes the entry's place in lKFsSharingWords.
+__global__ __launch_bounds__(256) void k_kfdb_query(const int32_t* __restrict__ q_word, const double* __restrict__ q_val, int nq,
+                                                    const int64_t* __restrict__ db_off, const int32_t* __restrict__ db_word,
+                                                    const double* __restrict__ db_val, const uint8_t* __restrict__ dead, int n_db,
+                                                    int32_t* __restrict__ common, int32_t* __restrict__ first_word, float* __restrict__ score)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_db) return;
+    int cnt = 0, first = -1;
+    double s = 0.0;
+    if (!dead[k]) {
+        int a = 0;
+        int64_t b = db_off[k];
+        const int64_t be = db_off[k + 1];
+        while (a < nq && b < be) {
+            const int wa = q_word[a], wb = db_word[b];
+            if (wa == wb) {
+                const double vi = q_val[a], wi = db_val[b];
+                s += fabs(vi - wi) - fabs(vi) - fabs(wi);
+                if (!cnt) first = wa;
+                ++cnt; ++a; ++b;
+            } else if (wa < wb) ++a;
+            else ++b;
+        }
+    }
+    common[k] = cnt; first_word[k] = first; score[k] = (float)(-s / 2.0);          // `float si = mpVoc->score(...)`
+}
+
 }  // namespace
 }  // namespace dcs
 
 using namespace dcs;
+
+// KeyFrameDatabase of ONE camera (mvvInvertedFiles[c], src/KeyFrameDatabase.cc:46-110) kept in HBM as the entries' BowVectors in
+// order of insertion: an inverted list is then "the entries that hold the word, ascending entry id" -- the reference's push_back
+// order -- without being stored. Grow-only arrays, erased entries stay as tombstones.
+struct dcs_kfdb {
+    int device = 0, n = 0;
+    int64_t n_words = 0;
+    std::vector<int64_t> h_off{0};
+    std::vector<uint8_t> h_dead;
+    int32_t* d_word = nullptr; double* d_val = nullptr; size_t cap_word = 0, cap_val = 0;
+    int64_t* d_off = nullptr; uint8_t* d_dead = nullptr; size_t cap_off = 0, cap_dead = 0;
+    hipStream_t st = nullptr;
+    ~dcs_kfdb()
+    {
+        if (d_word) (void)hipFree(d_word);
+        if (d_val) (void)hipFree(d_val);
+        if (d_off) (void)hipFree(d_off);
+        if (d_dead) (void)hipFree(d_dead);
+        if (st) (void)hipStreamDestroy(st);
+    }
+    template <typename T> int grow(T*& p, size_t& cap, size_t need, size_t used)
+    {
+        if (need <= cap) return DCS_OK;
+        size_t nc = std::max<size_t>(need, std::max<size_t>(2 * cap, 1024));
+        T* q = nullptr;
+        DCS_HIP(hipMalloc((void**)&q, nc * sizeof(T)));
+        if (p && used) DCS_HIP(hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, st));
+        DCS_HIP(hipStreamSynchronize(st));
+        if (p) (void)hipFree(p);
+        p = q; cap = nc;
+        return DCS_OK;
+    }
+};
 
 struct dcs_vocab {
     int k = 0, L = 0, scoring = 0, weighting = 0, n_nodes = 0, n_words = 0, n_slots = 0, device = 0;
@@ -407,6 +471,85 @@ int dcs_bow_score_l1(const int32_t* q_word, const double* q_val, int nq, const i
     hipLaunchKernelGGL(k_bow_score_l1, dim3((n_db + 255) / 256), dim3(256), 0, s.st, dqw, dqv, nq, dof, dbw, dbv, n_db, dsc);
     DCS_CHECK_LAUNCH();
     if ((rc = s.download_bytes(score, dsc, sizeof(double) * n_db))) return rc;
+    return s.finish();
+}
+
+int dcs_kfdb_create(dcs_kfdb** out)
+{
+    if (!out) { set_error("dcs_kfdb_create: bad argument"); return DCS_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    dcs_kfdb* d = new (std::nothrow) dcs_kfdb;
+    if (!d) { set_error("out of memory"); return DCS_ERR_HIP; }
+    if (hipGetDevice(&d->device) != hipSuccess || hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking) != hipSuccess) { delete d; set_error("dcs_kfdb_create: no stream"); return DCS_ERR_HIP; }
+    *out = d;
+    return DCS_OK;
+}
+
+void dcs_kfdb_destroy(dcs_kfdb* d) { delete d; }
+
+int dcs_kfdb_size(const dcs_kfdb* d, int* n_entries)
+{
+    if (!d || !n_entries) { set_error("dcs_kfdb_size: bad argument"); return DCS_ERR_INVALID; }
+    *n_entries = d->n;
+    return DCS_OK;
+}
+
+int dcs_kfdb_add(dcs_kfdb* d, const int32_t* word, const double* val, int n, int* entry_id)
+{
+    if (!d || n < 0 || (n && (!word || !val)) || !entry_id) { set_error("dcs_kfdb_add: bad argument"); return DCS_ERR_INVALID; }
+    for (int i = 1; i < n; ++i) if (word[i] <= word[i - 1]) { set_error("dcs_kfdb_add: word ids must ascend strictly (a BowVector is a std::map)"); return DCS_ERR_INVALID; }
+    if (n && word[0] < 0) { set_error("dcs_kfdb_add: negative word id"); return DCS_ERR_INVALID; }
+    int rc;
+    const bool first = d->cap_off == 0;
+    if ((rc = d->grow(d->d_off, d->cap_off, (size_t)d->n + 2, first ? 0 : (size_t)d->n + 1)) || (rc = d->grow(d->d_dead, d->cap_dead, (size_t)d->n + 1, (size_t)d->n)) ||
+        (rc = d->grow(d->d_word, d->cap_word, (size_t)d->n_words + n, (size_t)d->n_words)) || (rc = d->grow(d->d_val, d->cap_val, (size_t)d->n_words + n, (size_t)d->n_words))) return rc;
+    if (d->n == 0) { const int64_t z = 0; DCS_HIP(hipMemcpyAsync(d->d_off, &z, sizeof(z), hipMemcpyHostToDevice, d->st)); DCS_HIP(hipStreamSynchronize(d->st)); }
+    const int64_t end = d->n_words + n;
+    const uint8_t alive = 0;
+    if (n) {
+        DCS_HIP(hipMemcpyAsync(d->d_word + d->n_words, word, sizeof(int32_t) * n, hipMemcpyHostToDevice, d->st));
+        DCS_HIP(hipMemcpyAsync(d->d_val + d->n_words, val, sizeof(double) * n, hipMemcpyHostToDevice, d->st));
+    }
+    DCS_HIP(hipMemcpyAsync(d->d_off + d->n + 1, &end, sizeof(end), hipMemcpyHostToDevice, d->st));
+    DCS_HIP(hipMemcpyAsync(d->d_dead + d->n, &alive, 1, hipMemcpyHostToDevice, d->st));
+    DCS_HIP(hipStreamSynchronize(d->st));
+    d->h_off.push_back(end); d->h_dead.push_back(0);
+    *entry_id = d->n;
+    d->n += 1; d->n_words = end;
+    return DCS_OK;
+}
+
+int dcs_kfdb_erase(dcs_kfdb* d, int entry_id)
+{
+    if (!d || entry_id < 0 || entry_id >= d->n) { set_error("dcs_kfdb_erase: no such entry"); return DCS_ERR_INVALID; }
+    const uint8_t dead = 1;
+    DCS_HIP(hipMemcpyAsync(d->d_dead + entry_id, &dead, 1, hipMemcpyHostToDevice, d->st));
+    DCS_HIP(hipStreamSynchronize(d->st));
+    d->h_dead[entry_id] = 1;
+    return DCS_OK;
+}
+
+int dcs_kfdb_clear(dcs_kfdb* d)
+{
+    if (!d) { set_error("dcs_kfdb_clear: bad argument"); return DCS_ERR_INVALID; }
+    d->n = 0; d->n_words = 0; d->h_off.assign(1, 0); d->h_dead.clear();
+    return DCS_OK;
+}
+
+int dcs_kfdb_query(dcs_kfdb* d, const int32_t* q_word, const double* q_val, int nq, int32_t* common, int32_t* first_word, float* score)
+{
+    if (!d || nq < 0 || (nq && (!q_word || !q_val)) || (d->n && (!common || !first_word || !score))) { set_error("dcs_kfdb_query: bad argument"); return DCS_ERR_INVALID; }
+    for (int i = 1; i < nq; ++i) if (q_word[i] <= q_word[i - 1]) { set_error("dcs_kfdb_query: word ids must ascend strictly"); return DCS_ERR_INVALID; }
+    if (d->n == 0) return DCS_OK;
+    Scratch s;
+    int rc;
+    int32_t *dqw, *dcm, *dfw; double* dqv; float* dsc;
+    if ((rc = s.upload(&dqw, q_word, nq)) || (rc = s.upload(&dqv, q_val, nq)) || (rc = s.alloc(&dcm, d->n)) || (rc = s.alloc(&dfw, d->n)) || (rc = s.alloc(&dsc, d->n))) return rc;
+    hipLaunchKernelGGL(k_kfdb_query, dim3((d->n + 255) / 256), dim3(256), 0, s.st, dqw, dqv, nq, d->d_off, d->d_word, d->d_val, d->d_dead, d->n, dcm, dfw, dsc);
+    DCS_CHECK_LAUNCH();
+    if ((rc = s.download_bytes(common, dcm, sizeof(int32_t) * d->n)) || (rc = s.download_bytes(first_word, dfw, sizeof(int32_t) * d->n)) ||
+        (rc = s.download_bytes(score, dsc, sizeof(float) * d->n))) return rc;
     return s.finish();
 }
 

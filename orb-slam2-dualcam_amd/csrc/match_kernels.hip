@@ -293,7 +293,13 @@ __device__ __forceinline__ void knn2_tile_mfma(const uint8_t* __restrict__ q, in
     }
 }
 
-constexpr int kKnnQG = 2, kKnnWaves = 8, kKnnQ = 16 * kKnnQG * kKnnWaves;      // 256 queries per workgroup
+#ifndef DCS_KNN_QG                 // tuning hooks (scratch/ab builds): query groups of 16 per wave, waves per workgroup
+#define DCS_KNN_QG 2
+#endif
+#ifndef DCS_KNN_WAVES
+#define DCS_KNN_WAVES 8
+#endif
+constexpr int kKnnQG = DCS_KNN_QG, kKnnWaves = DCS_KNN_WAVES, kKnnQ = 16 * kKnnQG * kKnnWaves;      // 256 queries per workgroup
 __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2_pairs_mfma(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_feat, int cap,
                                                          const int32_t* __restrict__ pairs, int32_t* best_idx, int32_t* best_d, int32_t* second_d)
 {

@@ -526,6 +526,30 @@ def descriptors_near_words(voc, n, seed=3, flip=10):
 
 
 # ----------------------------------------------------------------------------- isInFrustum
+def keyframe_database(n_db=400, n_words=4000, words_per_kf=300, n_places=25, seed=9):
+    """Synthetic KeyFrameDatabase content (src/KeyFrameDatabase.cc): n_db key frames visiting n_places places in a loop; the BowVector of
+    a key frame = most of its place's words + some of its own (L1-normalised tf-idf-like values, ascending word ids), so that
+    revisits share many words. Returns dict(db=[(word, val)], place, covis=[neighbour entry ids, best-10 style], queries=[(word, val,
+    place)])."""
+    rng = np.random.default_rng(seed)
+    place_words = [np.sort(rng.choice(n_words, words_per_kf, replace=False)) for _ in range(n_places)]
+
+    def bow_of(place):
+        keep = place_words[place][rng.random(words_per_kf) < 0.7]
+        own = rng.choice(n_words, words_per_kf // 4, replace=False)
+        w = np.unique(np.concatenate([keep, own])).astype(np.int32)
+        v = rng.uniform(0.2, 3.0, len(w))
+        return w, (v / v.sum()).astype(np.float64)
+    place = (np.arange(n_db) * n_places * 2 // n_db) % n_places            # two laps
+    db = [bow_of(int(pl)) for pl in place]
+    covis = []
+    for k in range(n_db):
+        near = [j for j in range(max(0, k - 7), min(n_db, k + 8)) if j != k]
+        covis.append([int(j) for j in rng.permutation(near)[:10]])
+    queries = [bow_of(int(pl)) + (int(pl),) for pl in rng.integers(0, n_places, 12)]
+    return dict(db=db, place=place, covis=covis, queries=queries)
+
+
 def frustum_problem(n_points=3000, seed=4, n_cams=2):
     """Synthetic input of Frame::isInFrustum (Frame.cc:244-312) as called by Tracking::SearchLocalPoints (Tracking.cc:1617-1680):
     a frame pose, the rig's cameras (Tsw = Tsc * Tcw and the camera centres, formed in float32 like the caller's cv::Mat code),

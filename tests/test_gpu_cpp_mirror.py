@@ -37,6 +37,7 @@ def test_mirror_headers_compile(tmp_path, pkg):
     pkg.abi.lib()
     _build(tmp_path)
     _build(tmp_path, "mirror_ba_test")
+    _build(tmp_path, "mirror_kfdb_test")
 
 
 @pytest.mark.gpu
@@ -137,3 +138,77 @@ def test_optimizer_and_projection_mirrors(tmp_path, pkg, oracle, synth):
     # isInFrustum: in_view / cam / u / v / viewCos bit for bit
     e = oracle.is_in_frustum(ff, dict(pts, candidate=None), 0.5, 1.0)
     assert L["frustum"] == [h(e["in_view"]), h(e["cam"]), h(e["u"]), h(e["v"]), h(e["view_cos"])]
+
+
+def _kfdb_case(synth):
+    kd = synth.keyframe_database(n_db=300, n_words=4000, words_per_kf=250, n_places=20, seed=6)
+    n = len(kd["db"])
+    dead = np.zeros(n, np.uint8); dead[[7, 90, 91, 250]] = 1
+    queries = []
+    for qi, (qw, qv, pl) in enumerate(kd["queries"]):
+        conn = np.zeros(n, np.uint8)
+        conn[(kd["place"] == pl) & (np.arange(n) >= n // 2)] = 1
+        queries.append((2000 + qi // 2, qw, qv, conn))                 # pairs of queries share an id (two camera pairs of one key frame)
+    return kd, dead, queries
+
+
+@pytest.mark.gpu
+def test_kfdb_python_twin_and_cpp_mirror_vs_oracle(tmp_path, pkg, oracle, synth):
+    """KeyFrameDatabase::add / erase / DetectLoopCandidatesForCam / DetectRelocalizationCandidates (src/KeyFrameDatabase.cc:63-372):
+    the resident database + query kernel (dcs_kfdb_*) under the Python twin and under the C++ mirror give the candidate lists
+    of the oracle's statement-by-statement restatement with real inverted files; shared-word counts, first words and float
+    scores of the query are checked one by one as well."""
+    kd, dead, queries = _kfdb_case(synth)
+    db, covis, n = kd["db"], kd["covis"], len(kd["db"])
+    # ---- Python twin over the C ABI
+    for loop in (0, 1):
+        kf = pkg.KeyFrameDatabase()
+        for w, v in db:
+            kf.add(w, v)
+        for k in np.nonzero(dead)[0]:
+            kf.erase(int(k))
+        assert len(kf) == n
+        st = dict(query=np.full(n, -1, np.int32), words=np.zeros(n, np.int32), score=np.zeros(n, np.float32))
+        total = 0
+        for qid, qw, qv, conn in queries:
+            common, first, score = kf.query(qw, qv)
+            sc = oracle.bow_score_l1(qw, qv, np.cumsum([0] + [len(w) for w, _ in db]).astype(np.int32),
+                                     np.concatenate([w for w, _ in db]).astype(np.int32), np.concatenate([v for _, v in db]))
+            for k in range(n):
+                shared = np.intersect1d(qw, db[k][0])
+                assert common[k] == (0 if dead[k] else len(shared)) and first[k] == (-1 if dead[k] or not len(shared) else shared[0])
+                if not dead[k]:
+                    assert score[k] == np.float32(sc[k])
+            got = kf.DetectLoopCandidates(qid, qw, qv, covis, conn, 0.05) if loop else kf.DetectRelocalizationCandidates(qid, qw, qv, covis)
+            exp = oracle.detect_candidates(loop, qid, qw, qv, db, dead, covis, st, conn, 0.05)
+            assert got == exp
+            live = st["query"] >= 0
+            assert np.array_equal(kf.words[live], st["words"][live]) and np.array_equal(kf.score[live], st["score"][live])
+            total += len(got)
+        assert total > 10
+        kf.clear()
+        assert len(kf) == 0 and kf.DetectRelocalizationCandidates(1, queries[0][1], queries[0][2], covis) == []
+        kf.close()
+    # ---- C++ mirror
+    exe = _build(tmp_path, "mirror_kfdb_test")
+    path = tmp_path / "kfdb.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([n, len(queries), int(dead.sum())], np.int32).tobytes())
+        for k, (w, v) in enumerate(db):
+            f.write(np.array([len(w)], np.int32).tobytes()); f.write(np.asarray(w, np.int32).tobytes()); f.write(np.asarray(v, np.float64).tobytes())
+            f.write(np.array([len(covis[k])], np.int32).tobytes()); f.write(np.asarray(covis[k], np.int32).tobytes())
+        f.write(np.nonzero(dead)[0].astype(np.int32).tobytes())
+        for qid, qw, qv, conn in queries:
+            f.write(np.array([qid, len(qw)], np.int32).tobytes()); f.write(np.asarray(qw, np.int32).tobytes()); f.write(np.asarray(qv, np.float64).tobytes())
+            f.write(conn.tobytes())
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    for loop in (0, 1):
+        st = dict(query=np.full(n, -1, np.int32), words=np.zeros(n, np.int32), score=np.zeros(n, np.float32))
+        for qi, (qid, qw, qv, conn) in enumerate(queries):
+            exp = oracle.detect_candidates(loop, qid, qw, qv, db, dead, covis, st, conn, 0.05)
+            tag = "%s %d:" % ("loop" if loop else "reloc", qi)
+            line = [l for l in lines if l.startswith(tag)][0]
+            assert [int(x) for x in line[len(tag):].split()] == exp
+    assert lines[-1] == "size %d" % n

@@ -142,3 +142,95 @@ def test_bow_golden(oracle):
     off = np.array([0, len(r["bow_word"]), len(r["bow_word"]) + len(r2["bow_word"])], np.int32)
     s = oracle.bow_score_l1(r2["bow_word"], r2["bow_val"], off, np.concatenate([r["bow_word"], r2["bow_word"]]), np.concatenate([r["bow_val"], r2["bow_val"]]))
     assert s.tobytes() == g["score_half_vs_full_and_self"].tobytes() and abs(s[1] - 1.0) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# KeyFrameDatabase::DetectLoopCandidatesForCam / DetectRelocalizationCandidates (src/KeyFrameDatabase.cc:111-372)
+def _detect_np(loop, qid, qw, qv, db, dead, covis, st, connected, min_score):
+    """written from the reference text independently of the oracle: dict inverted files, python lists, numpy float32 scalars"""
+    f32 = np.float32
+    inv = {}
+    for k, (w, _) in enumerate(db):
+        if not dead[k]:
+            for x in w:
+                inv.setdefault(int(x), []).append(k)
+    sharing = []
+    for x in qw:
+        for k in inv.get(int(x), []):
+            if st["query"][k] != qid:
+                st["words"][k] = 0
+                if not (loop and connected[k]):
+                    st["query"][k] = qid
+                    sharing.append(k)
+            st["words"][k] += 1
+    if not sharing:
+        return []
+    mx = max(int(st["words"][k]) for k in sharing)
+    mn = int(f32(mx) * f32(0.8))
+
+    def l1(k):
+        w, v = db[k]
+        dq, dk = dict(zip(map(int, qw), qv)), dict(zip(map(int, w), v))
+        s = 0.0
+        for x in sorted(set(dq) & set(dk)):
+            s += abs(dq[x] - dk[x]) - abs(dq[x]) - abs(dk[x])
+        return f32(-s / 2.0)
+    sm = []
+    for k in sharing:
+        if st["words"][k] > mn:
+            si = l1(k)
+            st["score"][k] = si
+            if not loop or si >= f32(min_score):
+                sm.append((si, k))
+    if not sm:
+        return []
+    am, best_acc = [], (f32(min_score) if loop else f32(0))
+    for si, k in sm:
+        best, acc, bk = si, si, k
+        for k2 in covis[k]:
+            if loop:
+                if not (st["query"][k2] == qid and st["words"][k2] > mn):
+                    continue
+            elif st["query"][k2] != qid:
+                continue
+            acc = f32(acc + st["score"][k2])
+            if st["score"][k2] > best:
+                bk, best = k2, st["score"][k2]
+        am.append((acc, bk))
+        if acc > best_acc:
+            best_acc = acc
+    keep = f32(f32(0.75) * best_acc)
+    out = []
+    for acc, k in am:
+        if acc > keep and k not in out:
+            out.append(k)
+    return out
+
+
+def _fresh_state(n):
+    return dict(query=np.full(n, -1, np.int32), words=np.zeros(n, np.int32), score=np.zeros(n, np.float32))
+
+
+def test_detect_candidates_oracle(oracle, synth):
+    kd = synth.keyframe_database(n_db=160, n_words=2500, words_per_kf=150, n_places=12, seed=3)
+    db, covis, n = kd["db"], kd["covis"], len(kd["db"])
+    dead = np.zeros(n, np.uint8); dead[[5, 40, 41, 150]] = 1
+    for loop in (0, 1):
+        st_o, st_n = _fresh_state(n), _fresh_state(n)
+        total = 0
+        for qi, (qw, qv, pl) in enumerate(kd["queries"]):
+            connected = np.zeros(n, np.uint8)
+            connected[(kd["place"] == pl) & (np.arange(n) >= n // 2)] = 1            # the second lap's key frames of this place are "local"
+            qid = 1000 + qi // 2                                                  # pairs of queries share an id: the members are not reset (other camera pair)
+            exp = _detect_np(loop, qid, qw, qv, db, dead, covis, st_n, connected, 0.05)
+            got = oracle.detect_candidates(loop, qid, qw, qv, db, dead, covis, st_o, connected, 0.05)
+            assert got == exp
+            assert all(np.array_equal(st_o[k], st_n[k]) for k in st_o)
+            assert not any(dead[k] for k in got) and (not loop or not any(connected[k] for k in got))
+            if got and qi % 2 == 0:                                               # (a fresh id; the second query of a pair inherits marks)
+                assert (kd["place"][got] == pl).mean() > 0.5                      # the candidates are revisits of the query's place
+            total += len(got)
+        assert total > 10
+    # a query without any shared word, an empty database
+    assert oracle.detect_candidates(0, 1, np.array([2499], np.int32) + 1, np.array([1.0]), db, dead, covis, _fresh_state(n)) == []
+    assert oracle.detect_candidates(0, 1, kd["queries"][0][0], kd["queries"][0][1], [], np.zeros(0, np.uint8), [], _fresh_state(0)) == []
