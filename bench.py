@@ -44,8 +44,8 @@ N_CU = 256
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=256, help="dual frames per step per GPU")
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--width", type=int, default=640)
@@ -248,7 +248,7 @@ def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
             its += sum(sum(p.res.n_iters) for p in preps)
         return its, time.perf_counter() - t0
 
-    steps = 40
+    steps = 150                                   # the concurrent window is 3 x this: ~150 ms, 30+ BA rounds
     dt_alone = pipe.run(steps, 3)
     feats = pipe.features_per_step()
     its_alone, t_ba_alone = ba_calls(10)
