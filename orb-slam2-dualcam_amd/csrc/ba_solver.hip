@@ -1689,14 +1689,27 @@ int build_round(const dcs_ba_problem* pb, Round& r)
     {
         std::vector<int32_t> cur(r.pt_off.begin(), r.pt_off.end() - 1);
         for (int e = 0; e < E; ++e) if (active[e]) r.pt_edges[cur[pb->edge_point[e]]++] = e;
-        std::vector<std::pair<int32_t, int32_t>> seen;
+        // per point: ONE insertion sort of its (few) edges by (pose index, edge id) -- the order the kernels sum in (fixed poses
+        // first: index -1) -- and the duplicate test on the sorted run: equal indices are adjacent, the fixed prefix is compared
+        // pairwise by pose id (a handful of entries)
+        struct Key { int32_t idx, pose, edge; };
+        std::vector<Key> keys;
         for (int l = 0; l < L; ++l) {
-            seen.clear();
-            for (int k = r.pt_off[l]; k < r.pt_off[l + 1]; ++k) seen.emplace_back(pb->edge_pose[r.pt_edges[k]], r.pt_edges[k]);
-            std::sort(seen.begin(), seen.end());
-            for (size_t k = 1; k < seen.size(); ++k) if (seen[k].first == seen[k - 1].first) return seen[k].second;
-            std::stable_sort(r.pt_edges.begin() + r.pt_off[l], r.pt_edges.begin() + r.pt_off[l + 1],
-                             [&](int a, int b) { return r.pose_idx[pb->edge_pose[a]] < r.pose_idx[pb->edge_pose[b]]; });
+            const int k0 = r.pt_off[l], k1 = r.pt_off[l + 1], nk = k1 - k0;
+            keys.resize((size_t)nk);
+            for (int k = 0; k < nk; ++k) {
+                const int e = r.pt_edges[k0 + k], ps = pb->edge_pose[e];
+                const Key key{r.pose_idx[ps], ps, e};
+                int j = k;
+                while (j > 0 && (keys[j - 1].idx > key.idx || (keys[j - 1].idx == key.idx && keys[j - 1].edge > key.edge))) { keys[j] = keys[j - 1]; --j; }
+                keys[j] = key;
+            }
+            int n_fixed = 0;
+            while (n_fixed < nk && keys[n_fixed].idx < 0) ++n_fixed;
+            for (int a = 1; a < n_fixed; ++a)
+                for (int b2 = 0; b2 < a; ++b2) if (keys[a].pose == keys[b2].pose) return keys[a].edge;
+            for (int k = n_fixed + 1; k < nk; ++k) if (keys[k].idx == keys[k - 1].idx) return keys[k].edge;
+            for (int k = 0; k < nk; ++k) r.pt_edges[k0 + k] = keys[k].edge;
         }
     }
     // free pose -> active edges (edge id order)
