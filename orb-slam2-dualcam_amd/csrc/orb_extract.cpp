@@ -317,7 +317,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     ++n_calls;
     DCS_HIP(hipEventRecord(ev_t[0], stream));
     for (int l = 1; l < L; ++l) {
-        if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs, d_rtab.p + rtab[l].xa,
+        if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs,
                                 d_rtab.p + rtab[l].yofs, d_rtab.p + rtab[l].ya, n_images, stream))) return rc;
     }
     DCS_HIP(hipEventRecord(ev_t[1], stream));

@@ -58,7 +58,7 @@ struct OctScratch {
     unsigned long long* fkey; unsigned* fval; unsigned long long* tkey; unsigned* tval;
 };
 
-int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_xofs, const int16_t* d_xa,
+int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_cols /* {sx, 0, a0, a1} per destination column */,
                   const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s);
 
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,

@@ -188,10 +188,8 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
     }
 }
 
-int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_cols, const int16_t* d_unused,
-                  const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s)
+int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_cols, const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s)
 {
-    (void)d_unused;
     if ((double)src.w / dst.w > 2.0) { set_error("pyramid scale factor > 2 not supported by the resize kernel"); return DCS_ERR_UNSUPPORTED; }
     const int n_x4 = (dst.w + 3) / 4;
     dim3 grid((n_images * n_x4 + 63) / 64, (dst.h + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread));
@@ -998,6 +996,7 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
     const int n_here = min(kDescKp, n_img - i0);             // keypoints of this workgroup
 
     // ---- A. IC_Angle moments on the unblurred level
+#if !defined(DCS_DESCRIBE_SKIP) || DCS_DESCRIBE_SKIP != 1        // profiling side builds: 1 = without phase A, 2 = without phase C
     {
         const int grp = lane >> 4, sub = lane & 15;
 #pragma unroll 1
@@ -1015,6 +1014,8 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
                 const uint32_t* mk = s_mask + shift * kIcTasks;
                 unsigned s_all = 0, s_u = 0;                 // sum(val), sum((u + 32) * val)
                 int row = sub / kIcCols, col = sub - row * kIcCols;      // task t = sub + 16 * round
+                // unroll 6: fully unrolled (all 18 row loads in flight) the kernel is 5 % faster ALONE (441 -> 418 us) but needs 121 instead of
+                // 54 VGPRs, and next to the matcher that runs underneath it in the pipeline it is slower (446 -> 484 us as launched)
 #pragma unroll 6
                 for (int t = sub; t < kIcTasks; t += 16) {   // 18 rounds for every lane (padding tasks have an empty mask)
                     const unsigned val = *reinterpret_cast<const uint32_t*>(p0 + (size_t)row * rv.pitch + 4 * col) & mk[t];
@@ -1043,6 +1044,7 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
             if (sub == 0 && kq < n_here) { s_m10[kq] = m10; s_m01[kq] = m01; }
         }
     }
+#endif
     __syncthreads();
     // ---- B. orientation, steering coefficients a = cosf(rad), b = sinf(rad) exactly as libm computes them (glibc_sincosf), keypoint
     if (tid < n_here) {
@@ -1062,6 +1064,9 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
     }
     __syncthreads();
     // ---- C. steered BRIEF, one wave per keypoint
+#if defined(DCS_DESCRIBE_SKIP) && DCS_DESCRIBE_SKIP == 2
+    return;
+#endif
     uint32_t* patch = s_patch[wave];
     const int r_lane = lane >> 2;                            // 16 rows x 4 x 16 B per wave pass; 37 rows = 3 passes (last: 5 rows)
     uint4 q0, q1, q2;
