@@ -203,14 +203,18 @@ def test_wide_image_with_small_quota(pkg, oracle, synth):
     assert exceeded >= 1
 
 
-def test_device_api_unaligned_pointer_and_stride(pkg, oracle, synth):
-    """HBM-resident input that is neither 4-byte aligned nor 4-byte strided (byte-wise fallback loads)."""
+@pytest.mark.parametrize("lead,stride", [(1, 323), (4, 324), (16, 336), (0, 320)])
+def test_device_api_unaligned_pointer_and_stride(pkg, oracle, synth, lead, stride):
+    """HBM-resident input at every alignment class of the level-0 loads: neither 4-byte aligned nor 4-byte strided (byte-wise
+    fallbacks), 4-byte but not 16-byte aligned (dword path of IC_Angle), 16-byte aligned with padding and with a stride that
+    leaves only 3 bytes behind the last column (the 16-byte chunks of IC_Angle must stay inside the row)."""
     import torch
-    B, rows, cols, stride = 2, 240, 317, 323
+    B, rows, cols = 2, 240, 317
     base = synth.frame_pair(640, 480, 1, 0)
     imgs = [np.ascontiguousarray(b[100:100 + rows, 50:50 + cols]) for b in base]
-    buf = torch.zeros(B * rows * stride + 8, dtype=torch.uint8, device="cuda")
-    view = buf[1:1 + B * rows * stride].view(B, rows, stride)          # data_ptr() % 4 == 1
+    buf = torch.zeros(B * rows * stride + 64, dtype=torch.uint8, device="cuda")
+    assert buf.data_ptr() % 16 == 0
+    view = buf[lead:lead + B * rows * stride].view(B, rows, stride)
     view[:, :, :cols] = torch.from_numpy(np.stack(imgs)).cuda()
     view[:, :, cols:] = 255                                            # padding must never be read as image
     e = pkg.ORBextractor(400, 1.2, 8, 20, 7, max_images=B)
@@ -218,7 +222,7 @@ def test_device_api_unaligned_pointer_and_stride(pkg, oracle, synth):
     d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
     d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
-    assert view.data_ptr() % 4 == 1
+    assert view.data_ptr() % 16 == lead % 16
     e.extract_batch_device(view, d_kp, d_desc, d_n, cap, stream=torch.cuda.current_stream().cuda_stream, cols=cols)
     torch.cuda.synchronize()
     n = d_n.cpu().numpy()
