@@ -1237,7 +1237,10 @@ __global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ 
 //   state == NEW_ITER with stale errors (first iteration of round 0; an iteration that ended on a rejected trial)
 //                        computeActiveErrors at the current estimates, chi2 total -> currentChi.
 // The last block of the whole grid publishes {step, problems done} to the host's pinned progress words.
-__global__ __launch_bounds__(256) void k_post(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int step, int* __restrict__ h_progress,
+// grid_ticket[0] = arrival counter of the grid, grid_ticket[1] = number of k_post grids this group has finished = the step number the
+// host waits for (0 = the pass before the first step): kept on the device so that every launch of a step has the same arguments
+// and the step can be replayed as one hipGraph.
+__global__ __launch_bounds__(256) void k_post(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int* __restrict__ h_progress,
                                               unsigned* __restrict__ grid_ticket)
 {
     __shared__ double s[256];
@@ -1326,6 +1329,8 @@ __global__ __launch_bounds__(256) void k_post(const BaProb* __restrict__ probs, 
     const double nd = block_sum_256((double)done, s);
     if (threadIdx.x == 0) {
         __hip_atomic_store(grid_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int step = (int)grid_ticket[1];
+        grid_ticket[1] = (unsigned)step + 1u;
         __hip_atomic_store(h_progress + 1, (int)nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(h_progress, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1591,6 +1596,16 @@ struct BaContext {
     static constexpr int kMaxGroups = 4;
     hipStream_t aux[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_up = nullptr, ev_done[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+    // one LM step of a group = 8 dependent launches with the same arguments every time: optionally replayed as an executable hipGraph
+    // (DCS_BA_GRAPH=1, see dcs_ba_local_batch)
+    struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; std::vector<hipGraphNode_t> nodes; unsigned shape = 0; };
+    StepGraph step_graph[kMaxGroups];
+    void drop_graph(StepGraph& g)
+    {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        g.exec = nullptr; g.graph = nullptr; g.nodes.clear(); g.shape = 0;
+    }
     // measurement hook (dcs_ba_timing): hipEvents around every LDL^T launch and every step of the device loop
     bool timing = false;
     std::vector<hipEvent_t> events;
@@ -1603,6 +1618,7 @@ struct BaContext {
         if (h_stage) (void)hipHostFree(h_stage);
         if (h_words) (void)hipHostFree(h_words);
         if (stream) (void)hipStreamDestroy(stream);
+        for (StepGraph& g : step_graph) drop_graph(g);
         for (hipStream_t& a : aux) { if (a) (void)hipStreamDestroy(a); a = nullptr; }
         for (hipEvent_t& e : ev_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (ev_up) (void)hipEventDestroy(ev_up);
@@ -1981,7 +1997,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     }
     // before the first step: errors of the initial estimates (or, with iters1 <= 0, straight to the flags)
     for (const Group& gr : groups) {
-        hipLaunchKernelGGL(k_post, dim3(gr.g_edges, gr.nb), dim3(256), 0, gr.st, gr.dp, gr.ctls, gr.nb, 0, gr.words, gr.ticket);
+        hipLaunchKernelGGL(k_post, dim3(gr.g_edges, gr.nb), dim3(256), 0, gr.st, gr.dp, gr.ctls, gr.nb, gr.words, gr.ticket);
         DCS_CHECK_LAUNCH();
     }
     const bool timing = ctx.timing;
@@ -1990,12 +2006,61 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         return ctx.events[i];
     };
     auto mark = [&](int step, int k) { if (timing) { hipEvent_t e = event_at((size_t)(step - 1) * 4 + k); if (e) (void)hipEventRecord(e, st); } };
+    // ---- the step as a hipGraph: OPT-IN (DCS_BA_GRAPH=1). Measured on MI355X / ROCm 7.0: replaying the 8-kernel step as one
+    // hipGraphLaunch is SLOWER than 8 plain launches -- 2.36 vs 2.28 ms per C4 solve, 3.61 vs 3.39 ms for 8 problems -- because the host
+    // is not the bottleneck here (it feeds the queue two steps ahead and spends 80 % of a solve waiting) and the graph's kernel
+    // nodes are dispatched no faster than stream launches. The graph is rebuilt per call: hipGraphExecKernelNodeSetParams did not
+    // take new grid sizes reliably (a problem of another size then never finished).
+    static const bool use_graph_env = getenv("DCS_BA_GRAPH") && atoi(getenv("DCS_BA_GRAPH")) != 0;
+    std::vector<hipGraphExec_t> step_exec((size_t)G, nullptr);
+    if (use_graph_env && !timing) {
+        for (int g = 0; g < G; ++g) {
+            const Group& gr = groups[g];
+            if (gr.any_blocked) continue;
+            const BaProb* dp = gr.dp; BaCtl* ctls = gr.ctls; const BaCtl* cctls = gr.ctls; int nb = gr.nb;
+            const volatile int* d_stop = h_words + 16 + gr.off; int* words = gr.words; unsigned* ticket = gr.ticket;
+            void* a_cc[] = {(void*)&dp, (void*)&cctls};                                   // (probs, const ctls)
+            void* a_c[] = {(void*)&dp, (void*)&ctls};                                     // (probs, ctls)
+            void* a_err[] = {(void*)&dp, (void*)&ctls, (void*)&d_stop};
+            void* a_post[] = {(void*)&dp, (void*)&ctls, (void*)&nb, (void*)&words, (void*)&ticket};
+            struct Spec { void* fn; dim3 grid, block; void** args; };
+            std::vector<Spec> spec;
+            spec.push_back({(void*)k_linearize, dim3(gr.g_edges, nb), dim3(256), a_cc});
+            spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
+            spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
+            if (gr.g_schur) spec.push_back({(void*)k_schur, dim3(gr.g_schur, nb), dim3(kSchurThreads), a_cc});
+            if (gr.any_mfma) spec.push_back({(void*)k_ldlt_mfma, dim3(nb), dim3(256), a_c});
+            if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
+            spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
+            spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
+            spec.push_back({(void*)k_post, dim3(gr.g_edges, nb), dim3(256), a_post});
+            const unsigned shape = (gr.g_schur ? 1u : 0u) | (gr.any_mfma ? 2u : 0u) | (gr.any_valu ? 4u : 0u) | 8u;
+            BaContext::StepGraph& sg = ctx.step_graph[g];
+            auto params_of = [](const Spec& sp) { hipKernelNodeParams kp{}; kp.func = sp.fn; kp.gridDim = sp.grid; kp.blockDim = sp.block; kp.sharedMemBytes = 0; kp.kernelParams = sp.args; kp.extra = nullptr; return kp; };
+            bool ok = true;
+            {
+                ctx.drop_graph(sg);
+                ok = hipGraphCreate(&sg.graph, 0) == hipSuccess;
+                hipGraphNode_t prev = nullptr;
+                for (size_t k = 0; k < spec.size() && ok; ++k) {
+                    hipKernelNodeParams kp = params_of(spec[k]);
+                    hipGraphNode_t node = nullptr;
+                    ok = hipGraphAddKernelNode(&node, sg.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp) == hipSuccess;
+                    sg.nodes.push_back(node); prev = node;
+                }
+                ok = ok && hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0) == hipSuccess;
+                if (ok) sg.shape = shape; else { (void)hipGetLastError(); ctx.drop_graph(sg); }
+            }
+            step_exec[(size_t)g] = ok ? sg.exec : nullptr;            // nullptr: fall back to plain launches for this group
+        }
+    }
     auto enqueue_step = [&](const Group& gr, int step) -> int {
         hipStream_t gs = gr.st;
         const BaProb* dp = gr.dp;
         BaCtl* ctls = gr.ctls;
         const int nb = gr.nb;
         const volatile int* d_stop = h_words + 16 + gr.off;
+        if (hipGraphExec_t ge = step_exec[(size_t)(&gr - groups.data())]) { DCS_HIP(hipGraphLaunch(ge, gs)); return DCS_OK; }
         mark(step, 0);
         hipLaunchKernelGGL(k_linearize, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, (const BaCtl*)ctls);                   // buildSystem
         hipLaunchKernelGGL(k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), 0, gs, dp, ctls);                             // + computeLambdaInit (first iteration)
@@ -2022,7 +2087,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         mark(step, 2);
         hipLaunchKernelGGL(k_solve_update, dim3(gr.g_update, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
         hipLaunchKernelGGL(k_error<1>, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, d_stop);        // chi2 of the trial + computeScale + accept / reject
-        hipLaunchKernelGGL(k_post, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, nb, step, gr.words, gr.ticket);          // round change / stale errors / progress
+        hipLaunchKernelGGL(k_post, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, nb, gr.words, gr.ticket);                // round change / stale errors / progress
         mark(step, 3);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
