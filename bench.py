@@ -663,6 +663,29 @@ def main():
             bow["cpu_baseline"] = {"value": round(n0 * n_c / tcb / 1e6, 3), "unit": "Mdescriptors/s", "cores": 1, "kind": "port",
                                    "sample": "%d transforms of one image (%d descriptors) in %.1f s, oracle -O3 single thread" % (n_c, n0, tcb)}
             bow["speedup_vs_cpu_1thread"] = round(bow["value"] / max(bow["cpu_baseline"]["value"], 1e-9), 1)
+        # the key-frame database query behind loop detection / relocalisation (dcs_kfdb_query): 2000 key frames x ~330 words
+        if hasattr(pkg.abi.lib(), "dcs_kfdb_query"):
+            kd = synth.keyframe_database(n_db=2000, n_words=100000, words_per_kf=300, n_places=100, seed=5)
+            kf = pkg.KeyFrameDatabase()
+            for w_, v_ in kd["db"]:
+                kf.add(w_, v_)
+            qw_, qv_, _ = kd["queries"][0]
+            for _ in range(3):
+                kf.query(qw_, qv_)
+            tq0, nq_ = time.perf_counter(), 50
+            for _ in range(nq_):
+                kf.query(qw_, qv_)
+            tq = (time.perf_counter() - tq0) / nq_
+            bow["kfdb_query"] = {"workload": "shared-word counts + first shared word + L1 score of one BowVector (%d words) against %d resident key frames (host buffers out)" % (len(qw_), len(kf)),
+                                 "ms_per_query": round(tq * 1e3, 4)}
+            if args.cpu_seconds > 0:
+                O = entry.load_oracle()
+                st_ = dict(query=np.full(len(kf), -1, np.int32), words=np.zeros(len(kf), np.int32), score=np.zeros(len(kf), np.float32))
+                tq0 = time.perf_counter()
+                O.detect_candidates(0, 1, qw_, qv_, kd["db"], np.zeros(len(kf), np.uint8), kd["covis"], st_)
+                bow["kfdb_query"]["cpu_ms_per_detect_call"] = round((time.perf_counter() - tq0) * 1e3, 3)
+                bow["kfdb_query"]["cpu_note"] = "oracle DetectRelocalizationCandidates incl. building the inverted files from the flat database (kind: port, 1 core)"
+            kf.close()
         out["bow"] = bow
         V.close()
 
