@@ -812,7 +812,10 @@ __global__ __launch_bounds__(64) void k_ldlt_update(const BaProb* __restrict__ p
 // Back substitution L^T x = D^-1 y walks the block columns backwards: tile owners reduce L(I, J)^T x_I with two
 // cross-lane adds, wave 1 sums the four partial vectors in fixed order and multiplies by U^-T (16 DPP broadcasts).
 constexpr int kLS = 17;                        // padded LDS row stride of the 16-wide panels (doubles)
-constexpr int kDiagWave = 1;                   // (p, q) = (0, 1): owns the fewest tiles, never owns a diagonal tile with I % 4 == 0, J odd
+constexpr int kLdltWorkers = 7;                // waves that own tiles; one more wave runs the chain of diagonal blocks
+constexpr int kLdltThreads = 64 * (kLdltWorkers + 1);
+constexpr int kLdltSlots = 20;                 // ceil(136 tiles of a 16 x 16-tile triangle / 7 workers)
+constexpr int kDiagWave = kLdltWorkers;
 
 __device__ __forceinline__ double readlane_f64(double v, int srclane)
 {
@@ -853,7 +856,7 @@ __device__ __forceinline__ double asm_nmul(double a, double b) { double r; asm v
 // order). Compile-time recursion instead of unrolled loops: every register index and DPP lane is a constant, and the code
 // is branch-free (with a branch per pivot the compiler sinks the updates into later blocks and keeps every broadcast
 // alive: 200+ VGPRs).
-struct Diag16 { double ar[16], xr[16], yv, nlik, nlikm, myinvd; int lo; };
+struct Diag16 { double (&ar)[16]; double (&xr)[16]; double yv, nlik, nlikm, myinvd; int lo; };      // ar / xr: caller-provided registers
 
 // the IDX-th of the 16 updates of pivot M: columns M+1 .. 15, then y, then U^-1 columns 0 .. M-1
 template <int M, int IDX> __device__ __forceinline__ void diag16_bulk(Diag16& d)
@@ -890,10 +893,9 @@ template <int K> __device__ __forceinline__ void diag16_pivot(Diag16& d)
 template <int... Ks> __device__ __forceinline__ void diag16_pivots(Diag16& d, std::integer_sequence<int, Ks...>) { (diag16_pivot<Ks>(d), ...); }
 template <int... Is> __device__ __forceinline__ void diag16_tail(Diag16& d, std::integer_sequence<int, Is...>) { (diag16_bulk<15, Is>(d), ...); }
 
-__device__ __forceinline__ double ldlt_diag16(const double* P, double* Uinv, double* invd_out, double yv, double* ok, int lane)
+__device__ __forceinline__ double ldlt_diag16(double (&ar)[16], double (&xr)[16], const double* P, double* Uinv, double* invd_out, double yv, double* ok, int lane)
 {
-    Diag16 d;
-    d.lo = lane & 15; d.yv = yv; d.nlik = 0.0; d.nlikm = 0.0; d.myinvd = 0.0;
+    Diag16 d{ar, xr, yv, 0.0, 0.0, 0.0, lane & 15};
 #pragma unroll
     for (int k = 0; k < 16; ++k) { d.ar[k] = P[d.lo * kLS + k]; d.xr[k] = d.lo == k ? 1.0 : 0.0; }
     diag16_pivots(d, std::make_integer_sequence<int, 16>{});
@@ -921,7 +923,88 @@ __device__ long long g_ldlt_prof[512];
 #else
 #define LP(J, k, w)
 #endif
-__global__ __launch_bounds__(256) void k_ldlt_mfma(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
+struct LdltShared {
+    double Lp[2][256 * kLS];        // panel (double-buffered): raw columns of block J, then the finished L rows
+    double Wn[256 * kLS];           // -(L D) rows of the panel
+    double Ui[16][16 * kLS];        // inverse of the unit lower factor of every diagonal block
+    double Inb[2][2][16 * kLS];     // chain wave's inbox, [block & 1]: raw tile (K, K - 1) and diagonal tile (K, K) as of step K - 2
+    double Dsc[2][16 * kLS];        // chain wave's own panel tile: L(K, K - 1) and -W(K, K - 1)
+    double invd[256], y[256], x[256];
+    double part[kLdltWorkers][16];
+};
+
+// The chain wave: diagonal block J + 1 only needs panel tile (J + 1, J) and diagonal tile (J + 1, J + 1) as of step J - 1, which
+// the workers drop into its inbox one step early. It computes that panel tile itself, applies it to the diagonal tile, forward-
+// substitutes the block's right-hand side and factors the block while the workers are still busy with the trailing update of
+// step J: the only thing the workers ever wait for is U^-1 of the next block. Its barriers mirror the workers' one for one.
+__device__ __forceinline__ void ldlt_chain_wave(LdltShared& sh, int NT, double* ok, int lane)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+    const int offC = hi * kLS + lo, offA = lo * kLS + hi;
+    [[maybe_unused]] const int wave = kDiagWave;                                // LDLT_PROF builds
+    double ar[16], xr[16];
+    __syncthreads();                            // workers: tiles staged through Lp[1] / Wn
+    __syncthreads();                            // workers: block column 0 published
+    {
+        const double yv = ldlt_diag16(ar, xr, &sh.Lp[0][0], &sh.Ui[0][0], sh.invd, sh.y[lo], ok, lane);
+        if (lane < 16) sh.y[lo] = yv;
+    }
+    __syncthreads();
+    for (int J = 0; J + 1 < NT; ++J) {
+        const int par = (J + 1) & 1;
+        const double* const R = &sh.Inb[par][0][0];
+        double* const Dg = &sh.Inb[par][1][0];
+        const double* const UiB = &sh.Ui[J][offA];
+        const double invd_c = sh.invd[16 * J + lo];
+        double4_t w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) w = __builtin_amdgcn_mfma_f64_16x16x4f64(R[offA + 4 * sl], UiB[4 * sl], w, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sh.Dsc[0][offC + 4 * r * kLS] = w[r] * invd_c; sh.Dsc[1][offC + 4 * r * kLS] = -w[r]; }
+        double4_t dg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dg[r] = Dg[offC + 4 * r * kLS];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.Dsc[0][offA + 4 * sl], sh.Dsc[1][offA + 4 * sl], dg, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dg[offC + 4 * r * kLS] = dg[r];
+        double yv = sh.y[16 * (J + 1) + lo];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) yv = fma(-sh.Dsc[0][lo * kLS + j], sh.y[16 * J + j], yv);
+        LP(J, 5, kDiagWave);
+        __syncthreads();
+        LP(J, 6, kDiagWave);
+#ifdef LDLT_EXEC16
+        if (lane < 16) {
+            yv = ldlt_diag16(ar, xr, Dg, &sh.Ui[J + 1][0], sh.invd + 16 * (J + 1), yv, ok, lane);
+            sh.y[16 * (J + 1) + lo] = yv;
+        }
+#else
+        yv = ldlt_diag16(ar, xr, Dg, &sh.Ui[J + 1][0], sh.invd + 16 * (J + 1), yv, ok, lane);
+        if (lane < 16) sh.y[16 * (J + 1) + lo] = yv;
+#endif
+        LP(J, 7, kDiagWave);
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int J = NT - 1; J >= 0; --J) {                                       // x_J = U^-T (z_J - sum_I L(I, J)^T x_I)
+        double uc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) uc[k] = sh.Ui[J][k * kLS + lo];          // U^-1[k][lo]: in flight while the owners reduce
+        __syncthreads();
+        double sum = sh.part[0][lo];
+#pragma unroll
+        for (int w = 1; w < kLdltWorkers; ++w) sum += sh.part[w][lo];
+        double rhs = sh.x[16 * J + lo] - sum;
+        asm volatile("s_nop 1" : "+v"(rhs));                                    // rhs is a DPP source right away
+        double xa = 0.0, xb = 0.0, xc = 0.0, xd = 0.0;
+        bsub4<0>(xa, xb, xc, xd, rhs, uc); bsub4<4>(xa, xb, xc, xd, rhs, uc); bsub4<8>(xa, xb, xc, xd, rhs, uc); bsub4<12>(xa, xb, xc, xd, rhs, uc);
+        if (lane < 16) sh.x[16 * J + lo] = (xa + xb) + (xc + xd);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
 {
     const BaProb& pb = probs[blockIdx.x];
     if (ctls[blockIdx.x].state > ST_RETRY || pb.np == 0 || pb.use_reg != 1) return;
@@ -930,191 +1013,177 @@ __global__ __launch_bounds__(256) void k_ldlt_mfma(const BaProb* __restrict__ pr
     double* __restrict__ x = pb.xp;
     double* __restrict__ ok = &ctls[blockIdx.x].ok;
     const int ld = pb.ld, n = pb.n;
-    __shared__ double Lp[2][256 * kLS];        // panel (double-buffered): raw columns of block J, then the finished L rows
-    __shared__ double Wn[256 * kLS];           // -(L D) rows of the panel
-    __shared__ double Ui[16][16 * kLS];        // inverse of the unit lower factor of every diagonal block
-    __shared__ double s_invd[256], s_y[256], s_x[256];
-    __shared__ double s_part[2][16];
-    __shared__ int s_flag;                     // block column whose diagonal tile has been published
+    __shared__ LdltShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = wave >> 1, q = wave & 1, lo = lane & 15, hi = lane >> 4;          // 2 x 2 wave grid
     const int NT = (n + 15) >> 4, n_pad = NT << 4;
-    // tile slots: (a, b) -> I = 2 a + p, J = 2 b + q, kept for b <= a (36 slots); valid iff J <= I < NT
-#define LSLOT(a, b) ((a) * ((a) + 1) / 2 + (b))
-    double4_t acc[36];
+    LP(20, 0, 0);
+    if (wave == kDiagWave) { ldlt_chain_wave(sh, NT, ok, lane); return; }
+    // ---- workers
+    const int lo = lane & 15, hi = lane >> 4;
+    // every LDS address below is a lane base + a wave-uniform tile offset + a compile-time constant
+    const int offC = hi * kLS + lo;            // accumulator layout: element (hi + 4 r, lo) of a tile at offC + 4 r kLS
+    const int offA = lo * kLS + hi;            // MFMA operand layout: element (row lo, k = hi + 4 sl) at offA + 4 sl
+    // slot s of worker w holds tile t = 7 s + w of the row-major lower triangle, t = I (I + 1) / 2 + K
+    int tIK[kLdltSlots];                       // I | K << 8 (one SGPR per slot), -1 = no tile
+#define tI(s) (tIK[s] < 0 ? -1 : (tIK[s] & 255))
+#define tK(s) (tIK[s] >> 8)
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int s = 0; s < kLdltSlots; ++s) {
+        const int t = kLdltWorkers * s + wave;
+        int I = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+        if ((I + 1) * (I + 2) / 2 <= t) ++I;
+        if (I * (I + 1) / 2 > t) --I;
+        const int K = t - I * (I + 1) / 2;
+        tIK[s] = __builtin_amdgcn_readfirstlane(I >= NT ? -1 : (I | (K << 8)));
+    }
+    // Tiles come in with 16-byte loads along the contiguous index of S (lane = (row pair, column) of the stored triangle: two load
+    // instructions per tile, all of them in flight at once -- the loads are unconditional, a branch around them makes the compiler
+    // sink each one to its use) and are turned into the accumulator layout through a per-wave LDS tile (Wn is idle until the
+    // first panel). Diagonal tiles read the stored triangle mirrored.
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    LP(20, 2, 0);
+    double4_t acc[kLdltSlots];
+    const int li = 2 * (lane & 7), lj = lane >> 3;
 #pragma unroll
-        for (int bb = 0; bb <= a; ++bb) {
-            const int I = 2 * a + p, J = 2 * bb + q;
+    for (int s = 0; s < kLdltSlots; ++s) {
+        const int I = max(tI(s), 0), K = max(tK(s), 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * I + hi + 4 * r, j = 16 * J + lo;
-                double v = i == j ? 1.0 : 0.0;                                  // identity padding
-                if (J <= I && i < n && j < n) v = i >= j ? S[(size_t)j * ld + i] : S[(size_t)i * ld + j];
-                acc[LSLOT(a, bb)][r] = v;
-            }
-        }
-    s_y[tid] = tid < n ? b[tid] : 0.0;
-    if (tid == 0) s_flag = -1;
-    // every LDS address below is a lane base + a compile-time constant (ds_read / ds_write immediate offset)
-    const int offC = (16 * p + hi) * kLS + lo;      // accumulator layout: element (16 I + hi + 4 r, lo), 16 I = 32 a + 16 p
-    const int offA = (16 * p + lo) * kLS + hi;      // MFMA A operand of row block I: L[16 I + lo][4 sl + hi]
-    const double* const WnB = Wn + (16 * q + lo) * kLS + hi;    // MFMA B operand of row block K = 2 bb + q: W[16 K + lo][4 sl + hi]
-    // ---- prologue: publish block column 0, factor its diagonal block
-    if (q == 0) {
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            if (2 * a + p < NT) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Lp[0][offC + (32 * a + 4 * r) * kLS] = acc[LSLOT(a, 0)][r];
-            }
+        for (int r = 0; r < 2; ++r) {
+            const double2_t v = *reinterpret_cast<const double2_t*>(&S[(size_t)(16 * K + lj + 8 * r) * ld + 16 * I + li]);
+            acc[s][2 * r] = v.x; acc[s][2 * r + 1] = v.y;
         }
     }
-    __syncthreads();
-    if (wave == kDiagWave) {
-        const double yv = ldlt_diag16(&Lp[0][0], &Ui[0][0], s_invd, s_y[lo], ok, lane);
-        if (lane < 16) s_y[lo] = yv;
+    LP(20, 3, 0);
+    {   // four tiles per round trip: Lp[1] and Wn (contiguous, idle until the first panel) hold 4 tiles per wave
+        double* const T0 = &sh.Lp[1][0] + wave * 4 * 16 * kLS;
+#pragma unroll
+        for (int g = 0; g < kLdltSlots; g += 4) {
+#pragma unroll
+            for (int s = g; s < g + 4; ++s) {
+                double* const T = T0 + (s - g) * 16 * kLS;
+                const int I = max(tI(s), 0), K = max(tK(s), 0);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int j = 16 * K + lj + 8 * r, i = 16 * I + li;
+                    T[li * kLS + lj + 8 * r] = (i < n && j < n) ? acc[s][2 * r] : (i == j ? 1.0 : 0.0);                  // identity padding
+                    T[(li + 1) * kLS + lj + 8 * r] = (i + 1 < n && j < n) ? acc[s][2 * r + 1] : (i + 1 == j ? 1.0 : 0.0);
+                }
+            }
+#pragma unroll
+            for (int s = g; s < g + 4; ++s) {
+                const double* const T = T0 + (s - g) * 16 * kLS;
+                const bool diag = tI(s) == tK(s);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = hi + 4 * r;
+                    acc[s][r] = T[(diag && row < lo) ? lo * kLS + row : row * kLS + lo];
+                }
+            }
+        }
+        LP(20, 4, 0);
+        __syncthreads();                        // (chain wave: matching barrier) the staging area becomes Lp[1] / Wn again
+        LP(20, 5, 0);
     }
+    // ---- prologue: publish block column 0 and the chain wave's inputs for block 1; the chain wave factors diagonal block 0
+#pragma unroll
+    for (int s = 0; s < kLdltSlots; ++s) {
+        const int I = tI(s), K = tK(s);
+        if (K == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh.Lp[0][16 * I * kLS + offC + 4 * r * kLS] = acc[s][r];
+        }
+        if (I == 1) {                                                            // tiles (1, 0) and (1, 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh.Inb[1][K][offC + 4 * r * kLS] = acc[s][r];
+        }
+    }
+    if (tid < 256) sh.y[tid] = tid < n ? b[tid] : 0.0;
+    LP(20, 1, 0);
     __syncthreads();
-    for (int J = 0; J < NT; ++J) {
-        double* const Lc = Lp[J & 1];              // panel of this step
-        double* const Ln = Lp[(J & 1) ^ 1];        // panel of the next step (raw columns of block J + 1)
+    __syncthreads();
+    for (int J = 0; J + 1 < NT; ++J) {
+        double* const Lc = sh.Lp[J & 1];           // panel of this step
+        double* const Ln = sh.Lp[(J & 1) ^ 1];     // panel of the next step (raw columns of block J + 1)
         LP(J, 0, 0);
-        // ---- rows below the diagonal block: W = A U^-T on the matrix cores, L = W D^-1; wave (p, q) takes I = 2 a + p, a % 2 == q
-        {
-            const double* const UiB = &Ui[J][lo * kLS + hi];                    // B[k = 4 sl + hi][j = lo] = U^-1[lo][4 sl + hi]
-            const double invd_c = s_invd[16 * J + lo];
-#pragma unroll
-            for (int a2 = 0; a2 < 4; ++a2) {
-                const int a = 2 * a2 + q, I = 2 * a + p;
-                if (I <= J || I >= NT) continue;                                // wave-uniform
+        {   // ---- rows below the diagonal block: W = A U^-T on the matrix cores, L = W D^-1; tiles dealt round-robin to the workers
+            const double* const UiB = &sh.Ui[J][offA];                          // B[k = 4 sl + hi][j = lo] = U^-1[lo][4 sl + hi]
+            const double invd_c = sh.invd[16 * J + lo];
+            for (int I = J + 1 + wave; I < NT; I += kLdltWorkers) {            // wave-uniform
+                double* const T = Lc + 16 * I * kLS;
                 double4_t w = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl)
-                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[offA + 32 * a * kLS + 4 * sl], UiB[4 * sl], w, 0, 0, 0);
+                for (int sl = 0; sl < 4; ++sl) w = __builtin_amdgcn_mfma_f64_16x16x4f64(T[offA + 4 * sl], UiB[4 * sl], w, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { Lc[offC + (32 * a + 4 * r) * kLS] = w[r] * invd_c; Wn[offC + (32 * a + 4 * r) * kLS] = -w[r]; }
+                for (int r = 0; r < 4; ++r) { T[offC + 4 * r * kLS] = w[r] * invd_c; sh.Wn[16 * I * kLS + offC + 4 * r * kLS] = -w[r]; }
             }
         }
         LP(J, 1, 0);
         __syncthreads();
         LP(J, 2, 0);
-        // ---- B operands of the whole step (W rows of every owned column block), loaded once: with the A operands fetched per
-        // row block, the tile loops below wait on LDS once per row instead of twice per tile
-        double bv[8][4];
+        // ---- update: C(I, K) -= L(I, J) W(K, J)^T for every owned tile right of column J; the tiles of column J + 1 are
+        // published as the next panel, tiles (J + 2, J + 1) and (J + 2, J + 2) also to the chain wave's inbox; the finished L
+        // tiles of column J return to registers (back substitution)
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            if (2 * bb + q <= J) continue;                                     // wave-uniform; rows past NT are identity padding inside the buffer
+        for (int s = 0; s < kLdltSlots; ++s) {
+            const int I = tI(s), K = tK(s);                                      // wave-uniform
+            if (K == J) {
+                if (I > J) {
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) bv[bb][sl] = WnB[32 * bb * kLS + 4 * sl];
-        }
-        // ---- update, pass 1: tiles of block column J + 1 (ascending I, so an owned diagonal tile goes first), published at once
+                    for (int r = 0; r < 4; ++r) acc[s][r] = Lc[16 * I * kLS + offC + 4 * r * kLS];
+                }
+            } else if (K > J) {
+                const double* const Ar = Lc + 16 * I * kLS + offA;
+                const double* const Br = sh.Wn + 16 * K * kLS + offA;
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const int I = 2 * a + p;
-            if (I <= J || I >= NT) continue;                                   // wave-uniform
+                for (int sl = 0; sl < 4; ++sl) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[4 * sl], Br[4 * sl], acc[s], 0, 0, 0);
+                if (K == J + 1) {
 #pragma unroll
-            for (int bb = 0; bb <= a; ++bb) {
-                if (2 * bb + q != J + 1) continue;
+                    for (int r = 0; r < 4; ++r) Ln[16 * I * kLS + offC + 4 * r * kLS] = acc[s][r];
+                    if (I == J + 2) {
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl)
-                    acc[LSLOT(a, bb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[offA + 32 * a * kLS + 4 * sl], bv[bb][sl], acc[LSLOT(a, bb)], 0, 0, 0);
+                        for (int r = 0; r < 4; ++r) sh.Inb[J & 1][0][offC + 4 * r * kLS] = acc[s][r];
+                    }
+                } else if (I == J + 2) {                                         // K == J + 2: the diagonal tile after next
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Ln[offC + (32 * a + 4 * r) * kLS] = acc[LSLOT(a, bb)][r];
-                if (I == J + 1) {                                              // diagonal tile of the next step: release it to wave kDiagWave
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) __hip_atomic_store(&s_flag, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int r = 0; r < 4; ++r) sh.Inb[J & 1][1][offC + 4 * r * kLS] = acc[s][r];
                 }
             }
         }
-        LP(J, 3, 0);
-        // ---- look-ahead: factor the next diagonal block while the other waves run pass 2
-        if (wave == kDiagWave && J + 1 < NT) {
-            // forward substitution of the next block's right-hand side with the L rows just finished: y -= L(J + 1, J) y_J
-            double yv = s_y[16 * (J + 1) + lo];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) yv = fma(-Lc[(16 * (J + 1) + lo) * kLS + j], s_y[16 * J + j], yv);
-            LP(J, 5, kDiagWave);
-            while (__hip_atomic_load(&s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            LP(J, 6, kDiagWave);
-            yv = ldlt_diag16(Ln + 16 * (J + 1) * kLS, &Ui[J + 1][0], s_invd + 16 * (J + 1), yv, ok, lane);
-            if (lane < 16) s_y[16 * (J + 1) + lo] = yv;
-            LP(J, 7, kDiagWave);
-        }
-        // ---- right-hand side of the rows below block J + 1 (one thread per row)
-        {
+        {   // ---- right-hand side of the rows below block J + 1 (one thread per row)
             const int row = 16 * (J + 2) + tid;
-            if (row < n_pad) {
-                double yacc = s_y[row];
+            if (tid < 256 && row < n_pad) {
+                double yacc = sh.y[row];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) yacc = fma(-Lc[row * kLS + j], s_y[16 * J + j], yacc);
-                s_y[row] = yacc;
-            }
-        }
-        // ---- update, pass 2: finished L tiles of column J back to registers, all other tiles
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const int I = 2 * a + p;
-            if (I <= J || I >= NT) continue;
-            double av[4];
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) av[sl] = Lc[offA + 32 * a * kLS + 4 * sl];
-#pragma unroll
-            for (int bb = 0; bb <= a; ++bb) {
-                const int K = 2 * bb + q;
-                if (K == J) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[LSLOT(a, bb)][r] = Lc[offC + (32 * a + 4 * r) * kLS];
-                } else if (K > J + 1 && K <= I) {
-#pragma unroll
-                    for (int sl = 0; sl < 4; ++sl)
-                        acc[LSLOT(a, bb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sl], bv[bb][sl], acc[LSLOT(a, bb)], 0, 0, 0);
-                }
+                for (int j = 0; j < 16; ++j) yacc = fma(-Lc[row * kLS + j], sh.y[16 * J + j], yacc);
+                sh.y[row] = yacc;
             }
         }
         LP(J, 4, 0);
         __syncthreads();
     }
     LP(NT, 0, 0);
-    if (tid < n_pad) s_x[tid] = s_y[tid] * s_invd[tid];                       // z = D^-1 y
+    if (tid < n_pad) sh.x[tid] = sh.y[tid] * sh.invd[tid];                    // z = D^-1 y
     __syncthreads();
     for (int J = NT - 1; J >= 0; --J) {
-        double uc[16];
-        if (wave == kDiagWave) {
+        double c = 0.0;                                                       // owners of block column J: L(I, J)^T x_I
 #pragma unroll
-            for (int k = 0; k < 16; ++k) uc[k] = Ui[J][k * kLS + lo];          // U^-1[k][lo]: in flight while the owners reduce
+        for (int s = 0; s < kLdltSlots; ++s) {
+            const int I = tI(s);
+            if (tK(s) == J && I > J) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c = fma(acc[s][r], sh.x[16 * I + hi + 4 * r], c);
+            }
         }
-        if (q == (J & 1)) {                                                   // owners of block column J
-            double c = 0.0;
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-#pragma unroll
-                for (int bb = 0; bb <= a; ++bb) {
-                    const int I = 2 * a + p;
-                    if (2 * bb + q == J && I > J && I < NT) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) c = fma(acc[LSLOT(a, bb)][r], s_x[16 * p + hi + 32 * a + 4 * r], c);
-                    }
-                }
-            c += __shfl_xor(c, 16);
-            c += __shfl_xor(c, 32);
-            if (lane < 16) s_part[p][lane] = c;
-        }
+        c += __shfl_xor(c, 16);
+        c += __shfl_xor(c, 32);
+        if (lane < 16) sh.part[wave][lane] = c;
         __syncthreads();
-        if (wave == kDiagWave) {                                              // x_J = U^-T (z_J - sum_I L(I, J)^T x_I)
-            double rhs = s_x[16 * J + lo] - (s_part[0][lo] + s_part[1][lo]);
-            asm volatile("s_nop 1" : "+v"(rhs));                                // rhs is a DPP source right away
-            double xa = 0.0, xb = 0.0, xc = 0.0, xd = 0.0;
-            bsub4<0>(xa, xb, xc, xd, rhs, uc); bsub4<4>(xa, xb, xc, xd, rhs, uc); bsub4<8>(xa, xb, xc, xd, rhs, uc); bsub4<12>(xa, xb, xc, xd, rhs, uc);
-            if (lane < 16) s_x[16 * J + lo] = (xa + xb) + (xc + xd);
-        }
         __syncthreads();
     }
     LP(NT + 1, 0, 0);
-    if (tid < n) x[tid] = s_x[tid];
-#undef LSLOT
+    if (tid < n) x[tid] = sh.x[tid];
+#undef tI
+#undef tK
 }
 
 // x = S^-1 b with S = L D L^T already factored in place (unit lower L below the diagonal, D on it). single block.
@@ -2029,7 +2098,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
             spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
             if (gr.g_schur) spec.push_back({(void*)k_schur, dim3(gr.g_schur, nb), dim3(kSchurThreads), a_cc});
-            if (gr.any_mfma) spec.push_back({(void*)k_ldlt_mfma, dim3(nb), dim3(256), a_c});
+            if (gr.any_mfma) spec.push_back({(void*)k_ldlt_mfma, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
             spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
             spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
@@ -2073,7 +2142,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         if (gr.g_schur) hipLaunchKernelGGL(k_schur, dim3(gr.g_schur, nb), dim3(kSchurThreads), 0, gs, dp, (const BaCtl*)ctls);
         mark(step, 1);
-        if (gr.any_mfma) hipLaunchKernelGGL(k_ldlt_mfma, dim3(nb), dim3(256), 0, gs, dp, ctls);
+        if (gr.any_mfma) hipLaunchKernelGGL(k_ldlt_mfma, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
         if (gr.any_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(nb), dim3(1024), 0, gs, dp, ctls);
         if (gr.any_blocked) {
             for (int k0 = 0; k0 < gr.max_npad_blocked; k0 += kNB) {

@@ -31,7 +31,7 @@ int main(int argc, char** argv)
     hipMemcpy(dp, hp.data(), sizeof(BaProb) * B, hipMemcpyHostToDevice);
     hipMemcpy(dc, hc.data(), sizeof(BaCtl) * B, hipMemcpyHostToDevice);
     auto launch = [&] {
-        if (which == 1) hipLaunchKernelGGL(k_ldlt_mfma, dim3(B), dim3(256), 0, 0, (const BaProb*)dp, dc);
+        if (which == 1) hipLaunchKernelGGL(k_ldlt_mfma, dim3(B), dim3(kLdltThreads), 0, 0, (const BaProb*)dp, dc);
         else hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(B), dim3(1024), 0, 0, (const BaProb*)dp, dc);
     };
     launch();
@@ -52,7 +52,7 @@ int main(int argc, char** argv)
     printf("n=%d B=%d kernel=%s: %.2f us per launch, max |Sx-b| = %.3e, ok=%g\n", n, B, which == 1 ? "mfma" : "valu", ms * 1e3 / reps, worst, hc[0].ok);
 #ifdef LDLT_PROF
     long long h[512]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ldlt_prof), sizeof(h));
-    for (int i = 0; i < 64 && h[i * 8]; ++i) { printf("J=%2d:", i); for (int k = 0; k < 8; ++k) printf(" %7lld", h[i * 8 + k] - h[0]); printf("\n"); }
+    for (int i = 0; i < 24; ++i) { if (!h[i * 8]) continue; printf("J=%2d:", i); for (int k = 0; k < 8; ++k) printf(" %7lld", h[i * 8 + k] - h[0]); printf("\n"); }
 #endif
     return worst < 1e-8 ? 0 : 1;
 }
