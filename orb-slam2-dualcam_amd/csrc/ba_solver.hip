@@ -814,7 +814,6 @@ __global__ __launch_bounds__(64) void k_ldlt_update(const BaProb* __restrict__ p
 constexpr int kLS = 17;                        // padded LDS row stride of the 16-wide panels (doubles)
 constexpr int kLdltWorkers = 7;                // waves that own tiles; one more wave runs the chain of diagonal blocks
 constexpr int kLdltThreads = 64 * (kLdltWorkers + 1);
-constexpr int kLdltSlots = 20;                 // ceil(136 tiles of a 16 x 16-tile triangle / 7 workers)
 constexpr int kDiagWave = kLdltWorkers;
 
 __device__ __forceinline__ double readlane_f64(double v, int srclane)
@@ -937,19 +936,27 @@ struct LdltShared {
 // the workers drop into its inbox one step early. It computes that panel tile itself, applies it to the diagonal tile, forward-
 // substitutes the block's right-hand side and factors the block while the workers are still busy with the trailing update of
 // step J: the only thing the workers ever wait for is U^-1 of the next block. Its barriers mirror the workers' one for one.
-__device__ __forceinline__ void ldlt_chain_wave(LdltShared& sh, int NT, double* ok, int lane)
+__device__ __forceinline__ void ldlt_chain_wave(LdltShared& sh, int NT, double* ok, int lane, const double* __restrict__ S, const double* __restrict__ b, int ld, int n)
 {
     const int lo = lane & 15, hi = lane >> 4;
     const int offC = hi * kLS + lo, offA = lo * kLS + hi;
     [[maybe_unused]] const int wave = kDiagWave;                                // LDLT_PROF builds
     double ar[16], xr[16];
-    __syncthreads();                            // workers: tiles staged through Lp[1] / Wn
-    __syncthreads();                            // workers: block column 0 published
-    {
-        const double yv = ldlt_diag16(ar, xr, &sh.Lp[0][0], &sh.Ui[0][0], sh.invd, sh.y[lo], ok, lane);
+    {   // diagonal block 0 straight from memory (lane lo = row lo of the mirrored triangle) while the workers stage their tiles
+        double* const T = &sh.Inb[0][1][0];     // the inbox of block 2: first written in step 0
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = S[(size_t)min(min(lo, k), n - 1) * ld + min(max(lo, k), n - 1)];
+        const double yv0 = b[min(lo, n - 1)];
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) T[lo * kLS + k] = (lo < n && k < n) ? v[k] : (lo == k ? 1.0 : 0.0);
+        }
+        const double yv = ldlt_diag16(ar, xr, T, &sh.Ui[0][0], sh.invd, lo < n ? yv0 : 0.0, ok, lane);
         if (lane < 16) sh.y[lo] = yv;
     }
-    __syncthreads();
+    __syncthreads();                            // workers: tiles staged through Lp[1] / Wn
+    __syncthreads();                            // workers: block column 0 published
     for (int J = 0; J + 1 < NT; ++J) {
         const int par = (J + 1) & 1;
         const double* const R = &sh.Inb[par][0][0];
@@ -1004,6 +1011,7 @@ __device__ __forceinline__ void ldlt_chain_wave(LdltShared& sh, int NT, double* 
     }
 }
 
+template <int kLdltSlots>       // 18: at most 15 block rows (n <= 240, 120 tiles), 20: 16 block rows (136 tiles); 16 registers apart
 __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
 {
     const BaProb& pb = probs[blockIdx.x];
@@ -1016,8 +1024,11 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
     __shared__ LdltShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = (n + 15) >> 4, n_pad = NT << 4;
+#ifdef LDLT_PROF
+    if (blockIdx.x == 0 && lane == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_ldlt_prof[21 * 8 + wave] = 1000 + ((hw >> 4) & 3); }
+#endif
     LP(20, 0, 0);
-    if (wave == kDiagWave) { ldlt_chain_wave(sh, NT, ok, lane); return; }
+    if (wave == kDiagWave) { ldlt_chain_wave(sh, NT, ok, lane, S, b, ld, n); return; }
     // ---- workers
     const int lo = lane & 15, hi = lane >> 4;
     // every LDS address below is a lane base + a wave-uniform tile offset + a compile-time constant
@@ -1030,11 +1041,23 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
 #pragma unroll
     for (int s = 0; s < kLdltSlots; ++s) {
         const int t = kLdltWorkers * s + wave;
-        int I = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+        int I = (int)((__builtin_amdgcn_sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);      // raw v_sqrt_f32: the two corrections below absorb its error
         if ((I + 1) * (I + 2) / 2 <= t) ++I;
         if (I * (I + 1) / 2 > t) --I;
         const int K = t - I * (I + 1) / 2;
         tIK[s] = __builtin_amdgcn_readfirstlane(I >= NT ? -1 : (I | (K << 8)));
+    }
+    // slot sets per block column, one bit per slot, column k in lane k (fetched with v_readlane in step k): the tiles of column k
+    // below the diagonal, and every tile right of column k. A step only visits the slots it has work for -- walking all 20 slots
+    // with scalar tests cost more than the matrix-core instructions themselves.
+    unsigned colv = 0, gtv = 0;
+#pragma unroll
+    for (int s = 0; s < kLdltSlots; ++s) {
+        const int I = tI(s), K = tK(s);
+        if (K >= 0) {
+            if (K == lo && I > lo) colv |= 1u << s;
+            if (K > lo) gtv |= 1u << s;
+        }
     }
     // Tiles come in with 16-byte loads along the contiguous index of S (lane = (row pair, column) of the stored triangle: two load
     // instructions per tile, all of them in flight at once -- the loads are unconditional, a branch around them makes the compiler
@@ -1059,7 +1082,7 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
 #pragma unroll
         for (int g = 0; g < kLdltSlots; g += 4) {
 #pragma unroll
-            for (int s = g; s < g + 4; ++s) {
+            for (int s = g; s < g + 4 && s < kLdltSlots; ++s) {
                 double* const T = T0 + (s - g) * 16 * kLS;
                 const int I = max(tI(s), 0), K = max(tK(s), 0);
 #pragma unroll
@@ -1070,7 +1093,7 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
                 }
             }
 #pragma unroll
-            for (int s = g; s < g + 4; ++s) {
+            for (int s = g; s < g + 4 && s < kLdltSlots; ++s) {
                 const double* const T = T0 + (s - g) * 16 * kLS;
                 const bool diag = tI(s) == tK(s);
 #pragma unroll
@@ -1097,9 +1120,8 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
             for (int r = 0; r < 4; ++r) sh.Inb[1][K][offC + 4 * r * kLS] = acc[s][r];
         }
     }
-    if (tid < 256) sh.y[tid] = tid < n ? b[tid] : 0.0;
+    if (tid >= 16 && tid < 256) sh.y[tid] = tid < n ? b[tid] : 0.0;             // rows 0 .. 15 belong to the chain wave
     LP(20, 1, 0);
-    __syncthreads();
     __syncthreads();
     for (int J = 0; J + 1 < NT; ++J) {
         double* const Lc = sh.Lp[J & 1];           // panel of this step
@@ -1123,31 +1145,36 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
         // ---- update: C(I, K) -= L(I, J) W(K, J)^T for every owned tile right of column J; the tiles of column J + 1 are
         // published as the next panel, tiles (J + 2, J + 1) and (J + 2, J + 2) also to the chain wave's inbox; the finished L
         // tiles of column J return to registers (back substitution)
+        const unsigned m_eq = (unsigned)__builtin_amdgcn_readlane((int)colv, J), m_gt = (unsigned)__builtin_amdgcn_readlane((int)gtv, J);
+        // (two loops: with the reload and the update of a slot in one if / else the register allocator routes both through a
+        // temporary tile and drains the matrix pipe twice per tile to copy it. Requesting the next slot's operands ahead of this
+        // slot's matrix-core instructions was measured twice: the double buffer pushes the kernel into spills, 71 -> 89 us.)
 #pragma unroll
         for (int s = 0; s < kLdltSlots; ++s) {
+            if (!(m_gt >> s & 1)) continue;                                      // one scalar bit test per idle slot
             const int I = tI(s), K = tK(s);                                      // wave-uniform
-            if (K == J) {
-                if (I > J) {
+            const double* const Ar = Lc + 16 * I * kLS + offA;
+            const double* const Br = sh.Wn + 16 * K * kLS + offA;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[s][r] = Lc[16 * I * kLS + offC + 4 * r * kLS];
+            for (int sl = 0; sl < 4; ++sl) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[4 * sl], Br[4 * sl], acc[s], 0, 0, 0);
+            if (K == J + 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ln[16 * I * kLS + offC + 4 * r * kLS] = acc[s][r];
+                if (I == J + 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sh.Inb[J & 1][0][offC + 4 * r * kLS] = acc[s][r];
                 }
-            } else if (K > J) {
-                const double* const Ar = Lc + 16 * I * kLS + offA;
-                const double* const Br = sh.Wn + 16 * K * kLS + offA;
+            } else if (I == J + 2 && K == J + 2) {                               // the diagonal tile after next
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[4 * sl], Br[4 * sl], acc[s], 0, 0, 0);
-                if (K == J + 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Ln[16 * I * kLS + offC + 4 * r * kLS] = acc[s][r];
-                    if (I == J + 2) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sh.Inb[J & 1][0][offC + 4 * r * kLS] = acc[s][r];
-                    }
-                } else if (I == J + 2) {                                         // K == J + 2: the diagonal tile after next
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sh.Inb[J & 1][1][offC + 4 * r * kLS] = acc[s][r];
-                }
+                for (int r = 0; r < 4; ++r) sh.Inb[J & 1][1][offC + 4 * r * kLS] = acc[s][r];
             }
+        }
+#pragma unroll
+        for (int s = 0; s < kLdltSlots; ++s) {
+            if (!(m_eq >> s & 1)) continue;
+            const int I = tI(s);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s][r] = Lc[16 * I * kLS + offC + 4 * r * kLS];
         }
         {   // ---- right-hand side of the rows below block J + 1 (one thread per row)
             const int row = 16 * (J + 2) + tid;
@@ -1166,13 +1193,13 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
     __syncthreads();
     for (int J = NT - 1; J >= 0; --J) {
         double c = 0.0;                                                       // owners of block column J: L(I, J)^T x_I
+        const unsigned m_eq = (unsigned)__builtin_amdgcn_readlane((int)colv, J);
 #pragma unroll
         for (int s = 0; s < kLdltSlots; ++s) {
+            if (!(m_eq >> s & 1)) continue;
             const int I = tI(s);
-            if (tK(s) == J && I > J) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) c = fma(acc[s][r], sh.x[16 * I + hi + 4 * r], c);
-            }
+            for (int r = 0; r < 4; ++r) c = fma(acc[s][r], sh.x[16 * I + hi + 4 * r], c);
         }
         c += __shfl_xor(c, 16);
         c += __shfl_xor(c, 32);
@@ -2043,6 +2070,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         hipStream_t st; const BaProb* dp; BaCtl* ctls; int nb, off; int* words; unsigned* ticket;
         int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, max_npad_blocked = 0;
         bool any_mfma = false, any_valu = false, any_blocked = false, finished = false;
+        int max_n_mfma = 0;
     };
     std::vector<Group> groups((size_t)G);
     int max_steps = 0;
@@ -2059,6 +2087,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             gr.g_update = std::max(gr.g_update, q.nb_pts + q.nb_pose);
             max_steps = std::max(max_steps, (std::max(q.iters[0], 0) + std::max(q.iters[1], 0)) * 10 + 2);
             if (q.np) {
+                if (q.use_reg == 1) gr.max_n_mfma = std::max(gr.max_n_mfma, q.n);
                 gr.any_mfma |= q.use_reg == 1; gr.any_valu |= q.use_reg == 2; gr.any_blocked |= q.use_reg == 0;
                 if (q.use_reg == 0) gr.max_npad_blocked = std::max(gr.max_npad_blocked, q.n_pad);
             }
@@ -2098,7 +2127,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
             spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
             if (gr.g_schur) spec.push_back({(void*)k_schur, dim3(gr.g_schur, nb), dim3(kSchurThreads), a_cc});
-            if (gr.any_mfma) spec.push_back({(void*)k_ldlt_mfma, dim3(nb), dim3(kLdltThreads), a_c});
+            if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<18> : (void*)k_ldlt_mfma<20>, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
             spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
             spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
@@ -2142,7 +2171,10 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         if (gr.g_schur) hipLaunchKernelGGL(k_schur, dim3(gr.g_schur, nb), dim3(kSchurThreads), 0, gs, dp, (const BaCtl*)ctls);
         mark(step, 1);
-        if (gr.any_mfma) hipLaunchKernelGGL(k_ldlt_mfma, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
+        if (gr.any_mfma) {
+            if (gr.max_n_mfma <= 240) hipLaunchKernelGGL(k_ldlt_mfma<18>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
+            else hipLaunchKernelGGL(k_ldlt_mfma<20>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
+        }
         if (gr.any_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(nb), dim3(1024), 0, gs, dp, ctls);
         if (gr.any_blocked) {
             for (int k0 = 0; k0 < gr.max_npad_blocked; k0 += kNB) {
