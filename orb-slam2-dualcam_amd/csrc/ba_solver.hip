@@ -502,11 +502,16 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
 // order. 7 chunks = 4 waves: a C4 problem has ~860 such workgroups per trial and a batch of 8 problems ~6 900 -- with 16-wave
 // workgroups (28 chunks) the batch needed 13 rounds of the chip's wave slots (97 us), with 4-wave ones it needs 4.
 constexpr int kSchurChunks = 7;
+constexpr int kSchurFine = 28;                           // partial sums per S entry: list entry k belongs to partial k % 28, whatever the workgroup size
 constexpr int kSchurThreads = 256;
 constexpr int kSchurRhsChunks = 42;                      // 42 x 6 rows = 252 threads for the reduced right-hand side
-__global__ __launch_bounds__(kSchurThreads) void k_schur(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
+// WIDE = 0: 4 waves, thread (q, el) keeps the 4 partials q, q + 7, q + 14, q + 21 of entry el in 4 accumulators; WIDE = 1: 16 waves, one
+// partial per thread (a single problem has too few pose pairs to fill the chip with 4-wave workgroups). Both add the 28 partials in
+// index order: the same bits whichever one runs, so a batch still equals its problems solved one by one.
+template <int WIDE>
+__global__ __launch_bounds__(WIDE ? 1024 : kSchurThreads) void k_schur(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
-    __shared__ double part[kSchurChunks][36];
+    __shared__ double part[kSchurFine][36];
     const BaProb& pb = probs[blockIdx.y];
     const BaCtl& ctl = ctls[blockIdx.y];
     if (ctl.state > ST_RETRY || pb.np == 0) return;
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const BaProb* __restric
     const double* __restrict__ Hpl = pb.Hpl;
     if ((int)blockIdx.x >= n_pairs) {                        // blocks past the pair list: reduced right-hand side of one free pose
         // bsch = bp - sum_e Hpl[e] db[point(e)]; kSchurRhsChunks edge chunks x 6 rows, combined in chunk order
-        static_assert(kSchurRhsChunks * 6 <= kSchurChunks * 36 && kSchurRhsChunks * 6 <= kSchurThreads, "rhs partials live in `part`");
+        static_assert(kSchurRhsChunks * 6 <= kSchurFine * 36 && kSchurRhsChunks * 6 <= kSchurThreads, "rhs partials live in `part`");
         double (*bpart)[6] = reinterpret_cast<double (*)[6]>(&part[0][0]);
         const int32_t* __restrict__ ps_off = pb.ps_off;
         const int32_t* __restrict__ ps_edges = pb.ps_edges;
@@ -547,22 +552,36 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const BaProb* __restric
     const int p = blockIdx.x, t = threadIdx.x;
     const int el = t % 36, q = t / 36;
     const int r = el / 6, c = el % 6;
-    if (q < kSchurChunks) {
-        double acc = 0;
-        const int k1 = pair_off[p + 1];
+    const int k0 = pair_off[p], k1 = pair_off[p + 1];
+    auto term = [&](int k) {
+        const double* a = BD + (size_t)pair_e1[k] * 18 + r * 3;
+        const double* b = Hpl + (size_t)pair_e2[k] * 18 + c * 3;
+        return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    };
+    if (WIDE) {
+        if (q < kSchurFine) {
+            double acc = 0;
 #pragma unroll 4
-        for (int k = pair_off[p] + q; k < k1; k += kSchurChunks) {
-            const double* a = BD + (size_t)pair_e1[k] * 18 + r * 3;
-            const double* b = Hpl + (size_t)pair_e2[k] * 18 + c * 3;
-            acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+            for (int k = k0 + q; k < k1; k += kSchurFine) acc += term(k);
+            part[q][el] = acc;
         }
-        part[q][el] = acc;
+    } else if (q < kSchurChunks) {
+        double a4[4] = {0, 0, 0, 0};
+        int k = k0 + q;
+        for (; k + 3 * kSchurChunks < k1; k += kSchurFine) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a4[m] += term(k + kSchurChunks * m);
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) if (k + kSchurChunks * m < k1) a4[m] += term(k + kSchurChunks * m);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) part[q + kSchurChunks * m][el] = a4[m];
     }
     __syncthreads();
     if (t >= 36) return;
     const int i1 = pb.pair_ij[2 * p], i2 = pb.pair_ij[2 * p + 1], ld = pb.ld;
     double acc = 0;
-    for (int q2 = 0; q2 < kSchurChunks; ++q2) acc += part[q2][t];
+    for (int q2 = 0; q2 < kSchurFine; ++q2) acc += part[q2][t];
     double v = -acc;
     if (i1 == i2) v += pb.Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
     pb.S[(size_t)(i1 * 6 + r) * ld + i2 * 6 + c] = v;
@@ -1776,6 +1795,13 @@ struct Carver {
     }
 };
 
+// 16-wave k_schur workgroups for small groups (DCS_BA_SCHUR_WIDE = max problems per group that use them; default 2)
+static bool schur_wide(int nb)
+{
+    static const int lim = getenv("DCS_BA_SCHUR_WIDE") ? atoi(getenv("DCS_BA_SCHUR_WIDE")) : 2;
+    return nb <= lim;
+}
+
 struct Round {                                  // structure of one optimisation round (buildIndexMapping + buildStructure)
     std::vector<int32_t> pose_idx, pt_off, pt_edges, ps_off, ps_edges, pair_ij, pair_off, pair_e1, pair_e2;
     int np = 0, n = 0, n_pad = 0, n_pairs = 0, n_active = 0;
@@ -2126,7 +2152,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             spec.push_back({(void*)k_linearize, dim3(gr.g_edges, nb), dim3(256), a_cc});
             spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
             spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
-            if (gr.g_schur) spec.push_back({(void*)k_schur, dim3(gr.g_schur, nb), dim3(kSchurThreads), a_cc});
+            if (gr.g_schur) spec.push_back({schur_wide(nb) ? (void*)k_schur<1> : (void*)k_schur<0>, dim3(gr.g_schur, nb), dim3(schur_wide(nb) ? 1024 : kSchurThreads), a_cc});
             if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<18> : (void*)k_ldlt_mfma<20>, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
             spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
@@ -2169,7 +2195,10 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
                 if (hp[i].np && hp[i].use_reg == 0) DCS_HIP(hipMemsetAsync(hp[i].S, 0, sizeof(double) * (size_t)hp[i].ld * hp[i].ld, gs));
             hipLaunchKernelGGL(k_pad_identity, dim3(1, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
         }
-        if (gr.g_schur) hipLaunchKernelGGL(k_schur, dim3(gr.g_schur, nb), dim3(kSchurThreads), 0, gs, dp, (const BaCtl*)ctls);
+        if (gr.g_schur) {
+            if (schur_wide(nb)) hipLaunchKernelGGL(k_schur<1>, dim3(gr.g_schur, nb), dim3(1024), 0, gs, dp, (const BaCtl*)ctls);
+            else hipLaunchKernelGGL(k_schur<0>, dim3(gr.g_schur, nb), dim3(kSchurThreads), 0, gs, dp, (const BaCtl*)ctls);
+        }
         mark(step, 1);
         if (gr.any_mfma) {
             if (gr.max_n_mfma <= 240) hipLaunchKernelGGL(k_ldlt_mfma<18>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
