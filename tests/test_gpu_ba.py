@@ -260,3 +260,18 @@ def test_pose_optimization_vs_oracle(pkg, oracle, synth):
                inv_sigma2=pb["inv_sigma2"][e0:e1], edge_cam=pb["edge_cam"][e0:e1])
     got2 = pkg.Optimizer.PoseOptimization(sub)
     assert np.array_equal(got2["poses"], got["poses"][f0:f1]) and np.array_equal(got2["outlier"], got["outlier"][e0:e1])
+
+
+def test_ba_large_map_fits_the_arena(pkg, oracle, synth):
+    """Global-BA-sized map (> 65 000 points: the arena estimate of round 1 ran out there): the device arena is sized by a
+    dry run of the layout, so the call must succeed and agree with the oracle."""
+    pb = synth.ba_problem(n_poses=10, n_fixed=2, n_points=70000, obs_per_point=2, seed=3)
+    pb["iters1"], pb["iters2"] = 2, 0
+    _compare(pkg.Optimizer.LocalBundleAdjustment(pb), _oracle_run(oracle, pb), pb)
+
+
+@pytest.mark.parametrize("n_free", [37, 39, 40, 41, 42])
+def test_ba_reduced_system_sizes_around_the_slot_builds(pkg, oracle, synth, n_free):
+    """n = 6 * free poses = 222 ... 252: k_ldlt_mfma's 18-slot build (n <= 240, 15 block rows) and its 20-slot build (16 block rows)."""
+    pb = synth.ba_problem(n_poses=n_free + 3, n_fixed=3, n_points=400, obs_per_point=8, seed=100 + n_free)
+    _compare(pkg.Optimizer.LocalBundleAdjustment(pb), _oracle_run(oracle, pb), pb)
