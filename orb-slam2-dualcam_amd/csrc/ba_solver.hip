@@ -14,9 +14,11 @@
 //                   CSR order, no atomics (reproducible)
 //   per trial (5 launches + one 40-byte read-back):
 //   k_prep          BD[e] = H_pl[e] (H_ll + lambda I)^-1 per edge, D^-1 and D^-1 b_l per landmark
-//   k_schur         4-wave workgroup per pose pair over a precomputed (edge, edge) list (7 chunks x 36 entries) + the reduced right-hand side
-//   k_ldlt_mfma     LDL^T + both triangular solves of the reduced camera system in ONE workgroup: 16x16 tiles in
-//                   registers, trailing updates on the f64 matrix cores (v_mfma_f64_16x16x4_f64)
+//   k_schur         workgroup per pose pair over a precomputed (edge, edge) list: 28 partial sums x 36 entries (4 waves with 4
+//                   accumulators per thread, or 16 waves for groups of <= 2 problems; same bits) + the reduced right-hand side
+//   k_ldlt_mfma     LDL^T + both triangular solves of the reduced camera system in ONE workgroup: 16x16 tiles in the
+//                   registers of 7 worker waves, trailing updates on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the
+//                   diagonal blocks factored one step ahead by an eighth wave
 //                   (k_ldlt_reg: column-by-column VALU predecessor, DCS_BA_LDLT_VALU=1; k_ldlt_panel/_update/_solve:
 //                   multi-launch fallback for n > 256)
 //   k_solve_update  landmark back-substitution, push + manifold update of all estimates, computeScale partials
@@ -815,21 +817,28 @@ __global__ __launch_bounds__(64) void k_ldlt_update(const BaProb* __restrict__ p
 }
 
 // ---- single-workgroup blocked LDL^T + solve on the f64 matrix cores (n <= 256) ---------------------------------------
-// The lower triangle lives in the VGPRs of 8 waves as 16x16 tiles in the MFMA accumulator layout (lane l, register r
-// holds element (row = (l >> 4) + 4 r, col = l & 15)); wave (p, q) = (wave >> 1, wave & 1) owns the tiles (I, J) with
-// I % 4 == p, J % 2 == q, I >= J (2-D block-cyclic: the work stays balanced while the trailing matrix shrinks).
+// 8 waves: 7 WORKERS hold the lower triangle in their VGPRs as 16x16 tiles in the MFMA accumulator layout (lane l, register r
+// holds element (row = (l >> 4) + 4 r, col = l & 15)); tile t = I (I + 1) / 2 + K of the row-major triangle belongs to worker
+// t % 7, slot t / 7 (18 slots for <= 15 block rows, 20 for 16: two builds). The eighth wave is the CHAIN wave: it owns no tile
+// and runs the only sequential part, the diagonal blocks.
 // Block step J, two workgroup barriers:
-//   rows    the panel below the diagonal block is W = A U^-T, L = W D^-1 with the INVERSE of the unit factor of the
-//           diagonal block: 4 v_mfma_f64_16x16x4_f64 per 16-row tile (operand maps: A[i = l & 15][k = l >> 4],
-//           B[k = l >> 4][j = l & 15]), two tiles per wave; L and -W go to LDS in the operand layout of the update
-//   update  every wave updates its tiles C(I, K) -= L(I, J) W(K, J)^T with 4 MFMAs each; the tiles of block column J + 1
-//           go first and are published to the other panel buffer, and as soon as the diagonal tile (J + 1, J + 1) is out
-//           (LDS flag) wave 1 factors it while the other waves finish the update (look-ahead). The diagonal block is
-//           factored one ROW per lane, pivot row / column broadcast with DPP row_newbcast (v_mov_b64_dpp: no SGPR
-//           traffic); the same elimination applied to an identity yields U^-1 at the price of as many FMAs again, and
-//           the right-hand side is forward-substituted alongside. The finished L tiles of column J return to registers.
+//   workers, rows    the panel below the diagonal block is W = A U^-T, L = W D^-1 with the INVERSE of the unit factor of the
+//                    diagonal block: 4 v_mfma_f64_16x16x4_f64 per 16-row tile (operand maps: A[i = l & 15][k = l >> 4],
+//                    B[k = l >> 4][j = l & 15]), tiles dealt round-robin; L and -W go to LDS in the operand layout of the update
+//   workers, update  every worker updates its tiles C(I, K) -= L(I, J) W(K, J)^T with 4 MFMAs each (the slots that have work in
+//                    step J come from a per-column bit mask: one scalar test per idle slot); the tiles of block column J + 1 are
+//                    published as the next panel, tiles (J + 2, J + 1) and (J + 2, J + 2) also to the chain wave's inbox; the
+//                    finished L tiles of column J return to registers
+//   chain wave       diagonal block J + 1 needs only panel tile (J + 1, J) and diagonal tile (J + 1, J + 1) as of step J - 1 (its
+//                    inbox): it computes that panel tile itself, applies it, forward-substitutes the block's right-hand side
+//                    and factors the block -- one ROW per lane, pivot row / column broadcast with DPP row_newbcast
+//                    (v_mov_b64_dpp: no SGPR traffic); the same elimination applied to an identity yields U^-1 -- all of it
+//                    while the workers run step J. The workers only ever wait for U^-1 of the next block.
 // Back substitution L^T x = D^-1 y walks the block columns backwards: tile owners reduce L(I, J)^T x_I with two
-// cross-lane adds, wave 1 sums the four partial vectors in fixed order and multiplies by U^-T (16 DPP broadcasts).
+// cross-lane adds, the chain wave sums the seven partial vectors in fixed order and multiplies by U^-T (16 DPP broadcasts).
+// Measured (n = 234, scratch/ldlt): 67 us = staging 9 + 14 steps 52 (7 700 cycles each for the first steps, matrix-core bound at
+// ~70 % of one CU's rate; 5 200 for the last ones = the chain wave's 1 300 + 3 500) + back substitution 9. f64 MFMA 16x16x4 issues
+// every 64 cycles, dependent or not, 2 waves of a SIMD share the pipe (scratch/probe/mfma_f64_probe.hip).
 constexpr int kLS = 17;                        // padded LDS row stride of the 16-wide panels (doubles)
 constexpr int kLdltWorkers = 7;                // waves that own tiles; one more wave runs the chain of diagonal blocks
 constexpr int kLdltThreads = 64 * (kLdltWorkers + 1);
@@ -1000,15 +1009,9 @@ __device__ __forceinline__ void ldlt_chain_wave(LdltShared& sh, int NT, double* 
         LP(J, 5, kDiagWave);
         __syncthreads();
         LP(J, 6, kDiagWave);
-#ifdef LDLT_EXEC16
-        if (lane < 16) {
-            yv = ldlt_diag16(ar, xr, Dg, &sh.Ui[J + 1][0], sh.invd + 16 * (J + 1), yv, ok, lane);
-            sh.y[16 * (J + 1) + lo] = yv;
-        }
-#else
+        // (all 64 lanes run it: with only the 16 useful lanes active it takes the same 3 500 cycles -- EXEC does not shorten a pass)
         yv = ldlt_diag16(ar, xr, Dg, &sh.Ui[J + 1][0], sh.invd + 16 * (J + 1), yv, ok, lane);
         if (lane < 16) sh.y[16 * (J + 1) + lo] = yv;
-#endif
         LP(J, 7, kDiagWave);
         __syncthreads();
     }
