@@ -33,8 +33,11 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include <utility>
@@ -1805,6 +1808,56 @@ static bool schur_wide(int nb)
     return nb <= lim;
 }
 
+// A few persistent host threads for the per-problem list building of a batch. One job at a time: a second caller (the header
+// promises re-entrancy) that finds the pool busy simply does its own work inline. The workers are never joined (they sleep on a
+// condition variable until the process ends), so there is no destruction-order problem at exit.
+class HostPool {
+public:
+    template <class F> void run(int n, F&& f)
+    {
+        std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+        if (!job.owns_lock() || n < 2) { for (int i = 0; i < n; ++i) f(i); return; }
+        std::function<void(int)> fn = std::ref(f);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; n_ = n; next_ = 0; left_ = n; ++gen_;
+            while ((int)threads_.size() < std::min(n - 1, 7)) { threads_.emplace_back([this] { loop(); }); threads_.back().detach(); }
+        }
+        cv_.notify_all();
+        for (;;) {                                  // the caller works too
+            int i;
+            { std::lock_guard<std::mutex> lk(mu_); if (next_ >= n_) break; i = next_++; }
+            fn(i);
+            std::lock_guard<std::mutex> lk(mu_); --left_;
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void loop()
+    {
+        unsigned seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return gen_ != seen && fn_ && next_ < n_; });
+            seen = gen_;
+            while (fn_ && next_ < n_) {
+                const int i = next_++;
+                lk.unlock(); (*fn_)(i); lk.lock();
+                if (--left_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int n_ = 0, next_ = 0, left_ = 0;
+    unsigned gen_ = 0;
+};
+static HostPool& host_pool() { static HostPool* p = new HostPool; return *p; }
+
 struct Round {                                  // structure of one optimisation round (buildIndexMapping + buildStructure)
     std::vector<int32_t> pose_idx, pt_off, pt_edges, ps_off, ps_edges, pair_ij, pair_off, pair_e1, pair_e2;
     int np = 0, n = 0, n_pad = 0, n_pairs = 0, n_active = 0;
@@ -1955,12 +2008,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     {
         auto work = [&](int i) { dup[i] = build_round(problems[live[i]], rounds[i]); };
         if (NB == 1) work(0);
-        else {
-            const int nt = std::min(NB, 8);
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (int i = t; i < NB; i += nt) work(i); });
-            for (auto& t : th) t.join();
-        }
+        else host_pool().run(NB, work);            // persistent workers: creating 8 threads per call cost more than the lists themselves
         for (int i = 0; i < NB; ++i)
             if (dup[i] >= 0) { set_error("problem %d: more than one edge between pose and point of edge %d", live[i], dup[i]); return DCS_ERR_INVALID; }
     }

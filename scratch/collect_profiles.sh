@@ -8,6 +8,8 @@ rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 timeout 900 python $R/bench.py > $O/bench.json 2> $O/bench.err
 # the same command under the kernel tracer (CPU legs off: they only add wall time)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --cpu-seconds 0 > $O/bench_prof.json 2>/dev/null
+# the timed region alone (what roofline.achieved is checked against)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/headline -- python $R/bench.py --cpu-seconds 0 --no-ba --no-bow --no-c3 --no-c5 --no-host-api > $O/bench_headline.json 2>/dev/null
 # every kernel alone (no stream overlap inside the extractor, matcher not underneath): the durations DESIGN.md quotes as "solo"
 DCS_ORB_NO_OVERLAP=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/solo -- python $R/bench.py --serial --cpu-seconds 0 --no-ba --no-bow --no-c3 --no-c5 --no-host-api > /dev/null 2>&1
 # BA only: one C4 problem, then the batch of 8
@@ -19,6 +21,6 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLE
 cd $R
 python scratch/pmc_to_json.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json 256 640 480 1000 1 | tail -5
 python scratch/pmc_sum.py $O/pmc_sq > $O/pmc_sq_summary.txt
-for d in stats solo ba1 ba8; do cp $(ls $O/$d/*/*kernel_stats.csv | head -1) $O/${d}_kernel_stats.csv; done
-rm -rf $O/stats $O/solo $O/ba1 $O/ba8 $O/pmc_fetch $O/pmc_write $O/pmc_sq
+for d in stats headline solo ba1 ba8; do cp $(ls $O/$d/*/*kernel_stats.csv | head -1) $O/${d}_kernel_stats.csv; done
+rm -rf $O/stats $O/headline $O/solo $O/ba1 $O/ba8 $O/pmc_fetch $O/pmc_write $O/pmc_sq
 tail -c 1500 $O/bench.json; cat $O/ba8.log | tail -4
