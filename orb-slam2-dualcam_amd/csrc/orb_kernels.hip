@@ -860,7 +860,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 constexpr int kPatchR = 18;                 // rotated pattern reach: max radius 18.38 -> |coord| <= 18
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
 constexpr int kPatchDw = 16;                // dwords per staged row: 4 x 16 B cover 37 bytes + <= 15 alignment bytes
-constexpr int kDescKp = 64;                 // keypoints per workgroup
+#ifndef DCS_DESC_KP                          // tuning hook (scratch/ab builds)
+#define DCS_DESC_KP 16
+#endif
+constexpr int kDescKp = DCS_DESC_KP;        // keypoints per workgroup (4 waves)
+constexpr int kDescPerWave = kDescKp / 4;
+static_assert(kDescKp % 16 == 0 && kDescKp <= 64, "phase A works on 4 keypoints per wave at a time, phase B on one lane per keypoint");
 constexpr int kIcCols = 9;                  // aligned dwords covering x-15 .. x+15
 constexpr int kIcTasks = 288;                    // 31 x 9 = 279 dword tasks per keypoint, padded to 18 rounds of 16 lanes
 
@@ -1000,9 +1005,9 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
     {
         const int grp = lane >> 4, sub = lane & 15;
 #pragma unroll 1
-        for (int batch = 0; batch < 4; ++batch) {
-            const int kq = wave * 16 + batch * 4 + grp;
-            if (wave * 16 + batch * 4 >= n_here) break;      // wave-uniform
+        for (int batch = 0; batch < kDescPerWave / 4; ++batch) {
+            const int kq = wave * kDescPerWave + batch * 4 + grp;
+            if (wave * kDescPerWave + batch * 4 >= n_here) break;      // wave-uniform
             const SelKp k = s_sel[min(kq, n_here - 1)];
             const int x = k.x, y = k.y;
             const LevelView rv = raw.lv[k.level];
@@ -1084,10 +1089,10 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
         q1 = *reinterpret_cast<const uint4*>(bsrc + (size_t)(r_lane + 16) * bv.pitch);
         q2 = *reinterpret_cast<const uint4*>(bsrc + (size_t)min(r_lane + 32, kPatchRows - 1) * bv.pitch);
     };
-    if (wave * 16 < n_here) fetch(wave * 16);
+    if (wave * kDescPerWave < n_here) fetch(wave * kDescPerWave);
 #pragma unroll 1
-    for (int kk = 0; kk < 16; ++kk) {
-        const int kq = wave * 16 + kk;
+    for (int kk = 0; kk < kDescPerWave; ++kk) {
+        const int kq = wave * kDescPerWave + kk;
         if (kq >= n_here) break;                              // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // previous keypoint's LDS reads are done
         __builtin_amdgcn_wave_barrier();
@@ -1098,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (kq + 1 < min(n_here, wave * 16 + 16)) fetch(kq + 1);        // next keypoint's loads fly during this one's tests
+        if (kq + 1 < min(n_here, wave * kDescPerWave + kDescPerWave)) fetch(kq + 1);        // next keypoint's loads fly during this one's tests
         const float a = s_cos[kq], b = s_sin[kq];
         uint8_t* dout = desc_out + ((size_t)img * cap + i0 + kq) * 32;
 #pragma unroll
