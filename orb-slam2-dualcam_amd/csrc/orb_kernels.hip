@@ -863,9 +863,13 @@ constexpr int kPatchDw = 16;                // dwords per staged row: 4 x 16 B c
 #ifndef DCS_DESC_KP                          // tuning hook (scratch/ab builds)
 #define DCS_DESC_KP 16
 #endif
-constexpr int kDescKp = DCS_DESC_KP;        // keypoints per workgroup (4 waves)
-constexpr int kDescPerWave = kDescKp / 4;
-static_assert(kDescKp % 16 == 0 && kDescKp <= 64, "phase A works on 4 keypoints per wave at a time, phase B on one lane per keypoint");
+#ifndef DCS_DESC_WAVES
+#define DCS_DESC_WAVES 4
+#endif
+constexpr int kDescKp = DCS_DESC_KP;        // keypoints per workgroup
+constexpr int kDescWaves = DCS_DESC_WAVES;  // waves per workgroup
+constexpr int kDescPerWave = kDescKp / kDescWaves;
+static_assert(kDescKp % (4 * kDescWaves) == 0 && kDescKp <= 64, "phase A works on 4 keypoints per wave at a time, phase B on one lane per keypoint");
 constexpr int kIcCols = 9;                  // aligned dwords covering x-15 .. x+15
 constexpr int kIcTasks = 288;                    // 31 x 9 = 279 dword tasks per keypoint, padded to 18 rounds of 16 lanes
 
@@ -945,13 +949,13 @@ int launch_debug_sincosf(const float* d_x, int n, float* d_c, float* d_s, hipStr
 //   B. one LANE per keypoint: fastAtan2 + libm's cosf / sinf (glibc_sincosf: the reference calls the float overloads,
 //      ORBextractor.cc:112-113) -- issued once per 64 keypoints instead of once per keypoint-wave -- and the cv::KeyPoint.
 //   C. one wave per keypoint: 37x64 B blurred neighbourhood -> LDS (16-byte loads), 4 rounds of 64 rBRIEF tests.
-__global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
+__global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
                                                   const SelKp* __restrict__ sel, const int32_t* __restrict__ img_off,
                                                   const int32_t* __restrict__ lvl_cnt, dcs_keypoint* __restrict__ kp_out,
                                                   uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out, int n_images, int chunks,
                                                   const int32_t* __restrict__ dense_total, int dense_cap)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][kPatchRows * kPatchDw];
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[kDescWaves][kPatchRows * kPatchDw];
     __shared__ float4 s_pattern[256];
     __shared__ uint32_t s_mask[kIcMaskWords];
     __shared__ SelKp s_sel[kDescKp];
@@ -978,9 +982,11 @@ __global__ __launch_bounds__(256) void k_describe(LevelSet raw, LevelSet blurred
     if (chunk == 0 && tid == 0) n_out[img] = n_img;
     if (i0 >= n_img) return;                                 // block-uniform
     {
-        const char4 pt = reinterpret_cast<const char4*>(c_pattern)[tid];
-        s_pattern[tid] = float4{(float)pt.x, (float)pt.y, (float)pt.z, (float)pt.w};
-        for (int e = tid; e < kIcMaskWords; e += 256) s_mask[e] = prm.ic_mask[e];
+        for (int e = tid; e < 256; e += 64 * kDescWaves) {
+            const char4 pt = reinterpret_cast<const char4*>(c_pattern)[e];
+            s_pattern[e] = float4{(float)pt.x, (float)pt.y, (float)pt.z, (float)pt.w};
+        }
+        for (int e = tid; e < kIcMaskWords; e += 64 * kDescWaves) s_mask[e] = prm.ic_mask[e];
         if (tid < kDescKp) {
             const int i = i0 + tid;
             int src;
@@ -1125,7 +1131,7 @@ int launch_describe(const LevelSet& raw, const LevelSet& blurred, const Describe
                     uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s, const int32_t* d_dense_total, int dense_cap)
 {
     const int gx = max_per_image > 0 ? (max_per_image + kDescKp - 1) / kDescKp : 1;
-    hipLaunchKernelGGL(k_describe, dim3(gx * n_images), dim3(256), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
+    hipLaunchKernelGGL(k_describe, dim3(gx * n_images), dim3(64 * kDescWaves), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
                        d_desc, cap, d_n_out, n_images, gx, d_dense_total, dense_cap);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
