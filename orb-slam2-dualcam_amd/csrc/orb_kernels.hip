@@ -1025,11 +1025,14 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
                 const uint32_t* mk = s_mask + shift * kIcTasks;
                 unsigned s_all = 0, s_u = 0;                 // sum(val), sum((u + 32) * val)
                 int row = sub / kIcCols, col = sub - row * kIcCols;      // task t = sub + 16 * round
-                // unroll 6: fully unrolled (all 18 row loads in flight) the kernel is 5 % faster ALONE (441 -> 418 us) but needs 121 instead of
-                // 54 VGPRs, and next to the matcher that runs underneath it in the pipeline it is slower (446 -> 484 us as launched).
+                // unroll 9 (two batches of 9 row loads): measured in the pipeline with 16-keypoint workgroups, 6 / 9 / 18 -> 1.868 / 1.860 / 1.882 ms per
+                // step; fully unrolled the kernel needs 121 instead of 54 VGPRs and loses next to the matcher that runs underneath it.
                 // 16-byte loads (31 rows x 3 chunks, 6 rounds, masks from a byte table at any offset): bit-exact, 485 us -- the four
                 // unaligned mask reads and weight words per chunk cost more than the 12 saved load instructions
-#pragma unroll 6
+#ifndef DCS_IC_UNROLL
+#define DCS_IC_UNROLL 9
+#endif
+#pragma unroll DCS_IC_UNROLL
                 for (int t = sub; t < kIcTasks; t += 16) {   // 18 rounds for every lane (padding tasks have an empty mask)
                     const unsigned val = *reinterpret_cast<const uint32_t*>(p0 + (size_t)row * rv.pitch + 4 * col) & mk[t];
                     const unsigned ub = (unsigned)(17 - shift + 4 * col);                        // u + 32 of byte 0 (<= 49)
