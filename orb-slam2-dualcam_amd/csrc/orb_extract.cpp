@@ -157,6 +157,8 @@ struct dcs_orb {
 
     // last call (debug taps)
     LevelSet last_raw{}, last_blur{};
+    bool last_blur_valid = false;                  // fused describe: the blurred pyramid is only made when dcs_orb_debug_level asks for it
+    bool fused_blur = false;
     int last_n_images = 0;
 
     ~dcs_orb() {
@@ -324,9 +326,15 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // blur on the auxiliary stream, overlapping FAST (DCS_ORB_NO_OVERLAP=1 serialises it for clean timings).
     // DCS_ORB_BLUR_LATE=1 starts it after FAST instead (measured slower: it then collides with the latency-bound
     // compaction + quadtree kernels, 1.64 vs 1.55 ms per 128 dual frames).
+    // fused_blur (DCS_ORB_FUSED_BLUR=1 when the handle is created; OPT-IN): no blur kernels, no blurred pyramid -- k_describe blurs every
+    // keypoint's 43 x 43 raw patch itself (dcs_orb_debug_level makes the blurred level on demand). Bit-exact; measured: FAST runs at its
+    // solo 630 us once the blur no longer shares the vector ALUs with it, but k_describe grows from 403 to 740 us (the two passes cost
+    // ~390 wave-instructions per keypoint, 150 more than the idle issue slots of the kernel absorb): 1 860 vs 1 790 us per 512 images.
+    last_blur_valid = !fused_blur;
     static const bool blur_early = getenv("DCS_ORB_BLUR_LATE") == nullptr;
     hipStream_t sb = no_overlap ? stream : s_aux;
     auto blur_stage = [&]() -> int {
+        if (fused_blur) { DCS_HIP(hipEventRecord(ev_b[0], sb)); DCS_HIP(hipEventRecord(ev_b[1], sb)); return DCS_OK; }
         if (!no_overlap) { DCS_HIP(hipEventRecord(ev_pyr, stream)); DCS_HIP(hipStreamWaitEvent(s_aux, ev_pyr, 0)); }
         DCS_HIP(hipEventRecord(ev_b[0], sb));
         int r = launch_blur(raw, blur, n_images, sb);
@@ -366,10 +374,10 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         if ((rc = launch_octree(d_dense.p, d_lvl_off.p, oct, sc, n_tasks, (int)dense_cap, d_sel.p, d_lvl_cnt.p, d_oct_flag.p, stream))) return rc;
         DCS_HIP(hipEventRecord(ev_t[6], stream));
         host_us = -1.f;
-        DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
+        if (!fused_blur) DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
         DCS_HIP(hipEventRecord(ev_t[4], stream));
         if ((rc = launch_describe(raw, blur, dp, d_sel.p, nullptr, d_lvl_cnt.p, n_images, oct.out_per_image, d_kp_out, d_desc_out, cap,
-                                  d_n_out, stream, d_lvl_off.p + n_tasks, (int)dense_cap))) return rc;
+                                  d_n_out, stream, d_lvl_off.p + n_tasks, (int)dense_cap, fused_blur))) return rc;
     } else {
         DCS_HIP(hipMemcpyAsync(h_lvl_off.p, d_lvl_off.p, sizeof(int32_t) * (n_tasks + 1), hipMemcpyDeviceToHost, stream));
         DCS_HIP(hipStreamSynchronize(stream));
@@ -414,10 +422,10 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         }
         if (n_sel) DCS_HIP(hipMemcpyAsync(d_sel.p, h_sel.p, sizeof(SelKp) * n_sel, hipMemcpyHostToDevice, stream));
         DCS_HIP(hipMemcpyAsync(d_img_off.p, h_img_off.p, sizeof(int32_t) * (n_images + 1), hipMemcpyHostToDevice, stream));
-        DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
+        if (!fused_blur) DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
         DCS_HIP(hipEventRecord(ev_t[4], stream));
         if ((rc = launch_describe(raw, blur, dp, d_sel.p, d_img_off.p, nullptr, n_images, max_per_image, d_kp_out, d_desc_out, cap,
-                                  d_n_out, stream))) return rc;
+                                  d_n_out, stream, nullptr, 0, fused_blur))) return rc;
     }
     DCS_HIP(hipEventRecord(ev_t[5], stream));
     es.host_us = host_us; es.pending = true;
@@ -470,6 +478,7 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     DCS_HIP(hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming));
     for (auto& es : h->ring) { for (auto& e : es.t) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.b) DCS_HIP(hipEventCreate(&e)); }
     h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
+    h->fused_blur = getenv("DCS_ORB_FUSED_BLUR") && atoi(getenv("DCS_ORB_FUSED_BLUR")) != 0;
     h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
     {   // staging threads of the host-buffer API (DCS_ORB_STAGING_THREADS, default 4; 1 = pack on the calling thread)
@@ -643,6 +652,12 @@ int dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t* 
     }
     DCS_HIP(hipSetDevice(h->device));
     DCS_HIP(hipDeviceSynchronize());
+    if (blurred && !h->last_blur_valid) {           // the product path never needed it (the caller's level-0 buffer must still be alive)
+        int r = launch_blur(h->last_raw, h->last_blur, h->last_n_images, h->s_aux);
+        if (r) return r;
+        DCS_HIP(hipDeviceSynchronize());
+        h->last_blur_valid = true;
+    }
     const LevelView& v = blurred ? h->last_blur.lv[level] : h->last_raw.lv[level];
     DCS_HIP(hipMemcpy2D(dst, v.w, v.base + (size_t)image * v.img_stride, v.pitch, v.w, v.h, hipMemcpyDeviceToHost));
     return DCS_OK;

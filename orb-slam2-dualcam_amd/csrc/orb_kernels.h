@@ -79,7 +79,8 @@ int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStrea
 int launch_describe(const LevelSet& raw, const LevelSet& blurred, const DescribeParams& prm,
                     const SelKp* d_sel, const int32_t* d_img_off /* n_images+1 */, const int32_t* d_lvl_cnt, int n_images,
                     int max_per_image, dcs_keypoint* d_kp, uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s,
-                    const int32_t* d_dense_total = nullptr /* device quadtree: total candidates of the batch */, int dense_cap = 0);
+                    const int32_t* d_dense_total = nullptr /* device quadtree: total candidates of the batch */, int dense_cap = 0,
+                    bool fused = false /* no blurred pyramid: k_describe blurs every patch itself */);
 
 int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const OctLevels& levels, const OctScratch& scratch,
                   int n_tasks, int dense_cap, SelKp* d_sel, int32_t* d_lvl_cnt, int32_t* d_need_general, hipStream_t s);

@@ -860,6 +860,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 constexpr int kPatchR = 18;                 // rotated pattern reach: max radius 18.38 -> |coord| <= 18
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
 constexpr int kPatchDw = 16;                // dwords per staged row: 4 x 16 B cover 37 bytes + <= 15 alignment bytes
+// fused variant (the Gaussian blur of the patch inside k_describe): raw rows y - 21 .. y + 21 staged like the blurred ones were,
+// horizontal pass -> 16-bit sums packed as ROW PAIRS (lo = even row, hi = odd row: the vertical pass is 4 v_dot2_u32_u16 per pixel),
+// vertical pass -> the 37 x 37 blurred patch, 40-byte rows, in place of the raw rows
+constexpr int kRawR = kPatchR + 3;          // 21
+constexpr int kRawRows = 2 * kRawR + 1;     // 43 (+ 1 padding row: the odd half of the last row pair)
+constexpr int kHPairs = (kRawRows + 1) / 2; // 22
+constexpr int kHCols = 40;                  // columns of the horizontal sums / of the blurred patch (37 used)
 #ifndef DCS_DESC_KP                          // tuning hook (scratch/ab builds)
 #define DCS_DESC_KP 16
 #endif
@@ -949,13 +956,15 @@ int launch_debug_sincosf(const float* d_x, int n, float* d_c, float* d_s, hipStr
 //   B. one LANE per keypoint: fastAtan2 + libm's cosf / sinf (glibc_sincosf: the reference calls the float overloads,
 //      ORBextractor.cc:112-113) -- issued once per 64 keypoints instead of once per keypoint-wave -- and the cv::KeyPoint.
 //   C. one wave per keypoint: 37x64 B blurred neighbourhood -> LDS (16-byte loads), 4 rounds of 64 rBRIEF tests.
+template <bool FUSED>       // FUSED: no blurred pyramid exists, phase C blurs the raw patch itself
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
                                                   const SelKp* __restrict__ sel, const int32_t* __restrict__ img_off,
                                                   const int32_t* __restrict__ lvl_cnt, dcs_keypoint* __restrict__ kp_out,
                                                   uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out, int n_images, int chunks,
                                                   const int32_t* __restrict__ dense_total, int dense_cap)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_patch[kDescWaves][kPatchRows * kPatchDw];
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[kDescWaves][FUSED ? (kRawRows + 1) * kPatchDw : kPatchRows * kPatchDw];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hp[FUSED ? kDescWaves : 1][FUSED ? kHPairs * kHCols : 4];
     __shared__ float4 s_pattern[256];
     __shared__ uint32_t s_mask[kIcMaskWords];
     __shared__ SelKp s_sel[kDescKp];
@@ -1083,6 +1092,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
 #if defined(DCS_DESCRIBE_SKIP) && DCS_DESCRIBE_SKIP == 2
     return;
 #endif
+    if constexpr (!FUSED) {
     uint32_t* patch = s_patch[wave];
     const int r_lane = lane >> 2;                            // 16 rows x 4 x 16 B per wave pass; 37 rows = 3 passes (last: 5 rows)
     uint4 q0, q1, q2;
@@ -1127,15 +1137,145 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
             if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * it) = m;
         }
     }
+    } else {
+    uint32_t* patch = s_patch[wave];
+    uint32_t* hp = s_hp[wave];
+    const int r_lane = lane >> 2, c4 = lane & 3;             // 16 rows x 4 x 16 B per wave pass; 43 rows = 3 passes
+    uint4 q0, q1, q2;
+    int shift = 0;
+    bool wide = true, xedge = false;                         // this keypoint: 16-byte row loads possible; patch crosses the left / right border
+    int kx = 0, kw = 0;
+    auto fetch = [&](int kq) {                               // raw neighbourhood of keypoint kq -> registers (rows reflected at the level's top / bottom)
+        const SelKp k = s_sel[kq];
+        const LevelView rv = raw.lv[k.level];
+        const uint8_t* rimg = rv.base + (size_t)img * rv.img_stride;
+        kx = k.x; kw = rv.w;
+        wide = ((reinterpret_cast<uintptr_t>(rimg) | (uintptr_t)rv.pitch) & 15) == 0;       // a caller-owned level 0 may not be
+        xedge = k.x - kRawR < 0 || k.x + kRawR >= rv.w;
+        const int xs = (k.x - kRawR) & ~15;
+        shift = (k.x - kRawR) - xs;
+        if (!wide) return;
+        // 16-byte chunks that lie completely outside the row are loaded from the nearest chunk inside it (never used: the columns
+        // they stand for are rewritten by the reflection fix-up)
+        const int col = min(max(xs + 16 * c4, 0), (rv.w - 1) & ~15);
+        const uint8_t* src = rimg + col;
+        q0 = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(k.y - kRawR + r_lane, rv.h) * rv.pitch);
+        q1 = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(k.y - kRawR + r_lane + 16, rv.h) * rv.pitch);
+        q2 = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(k.y - kRawR + min(r_lane + 32, kRawRows - 1), rv.h) * rv.pitch);
+    };
+    if (wave * kDescPerWave < n_here) fetch(wave * kDescPerWave);
+    constexpr unsigned KA = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3 of the 7-tap kernel (k_blur's)
+    constexpr unsigned KB = 49u | (34u << 8) | (18u << 16);                 // taps 4..6
+#pragma unroll 1
+    for (int kk = 0; kk < kDescPerWave; ++kk) {
+        const int kq = wave * kDescPerWave + kk;
+        if (kq >= n_here) break;                              // wave-uniform
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // previous keypoint's LDS reads are done
+        __builtin_amdgcn_wave_barrier();
+        uint8_t* praw = reinterpret_cast<uint8_t*>(patch);
+        if (wide) {                                           // wave-uniform
+            reinterpret_cast<uint4*>(patch)[lane] = q0;
+            reinterpret_cast<uint4*>(patch)[lane + 64] = q1;
+            if (lane + 128 < kRawRows * 4) reinterpret_cast<uint4*>(patch)[lane + 128] = q2;
+            if (xedge) {                                      // at most 2 columns per side lie outside the row: BORDER_REFLECT_101
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (lane < kRawRows) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int jj = e < 2 ? e : kRawRows - 4 + e, g = kx - kRawR + jj;      // patch columns 0, 1, 41, 42
+                        if (g < 0 || g >= kw) praw[lane * 64 + shift + jj] = praw[lane * 64 + shift + (reflect101(g, kw) - (kx - kRawR))];
+                    }
+                }
+            }
+        } else {                                              // unaligned caller-owned level 0: byte loads, reflection applied on the way
+            const SelKp k = s_sel[kq];
+            const LevelView rv = raw.lv[k.level];
+            const uint8_t* rimg = rv.base + (size_t)img * rv.img_stride;
+            for (int i = lane; i < kRawRows * kRawRows; i += 64) {
+                const int r = i / kRawRows, j = i - r * kRawRows;
+                praw[r * 64 + shift + j] = rimg[(size_t)reflect101(k.y - kRawR + r, rv.h) * rv.pitch + reflect101(k.x - kRawR + j, rv.w)];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int shift_now = shift;
+        if (kq + 1 < min(n_here, wave * kDescPerWave + kDescPerWave)) fetch(kq + 1);        // next keypoint's loads fly during this one's work
+        // ---- horizontal pass: task = (row pair, 4 output columns); h[c] = sum_k K[k] raw[c + k] (<= 65 535)
+        {
+            const int a0 = shift_now >> 2, sh = shift_now & 3;
+#pragma unroll 1
+            for (int t = lane; t < kHPairs * (kHCols / 4); t += 64) {
+                const int rp = t / (kHCols / 4), d = t - rp * (kHCols / 4);
+                unsigned hh[2][4];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const uint32_t* row = patch + (2 * rp + half) * kPatchDw + a0 + d;
+                    const unsigned w0 = row[0], w1 = row[1], w2 = row[2], w3 = row[3];
+                    const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh), d1 = __builtin_amdgcn_alignbyte(w2, w1, sh), d2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+                    hh[half][0] = __builtin_amdgcn_udot4(d1, KB, __builtin_amdgcn_udot4(d0, KA, 0u, false), false);
+                    hh[half][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0u, false), false);
+                    hh[half][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0u, false), false);
+                    hh[half][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0u, false), false);
+                }
+                uint4 o;
+                o.x = hh[0][0] | (hh[1][0] << 16); o.y = hh[0][1] | (hh[1][1] << 16); o.z = hh[0][2] | (hh[1][2] << 16); o.w = hh[0][3] | (hh[1][3] << 16);
+                *reinterpret_cast<uint4*>(hp + rp * kHCols + 4 * d) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // ---- vertical pass: task = (output row q, 4 columns); rows q .. q + 6 = 4 row pairs, taps arranged by the parity of q
+#pragma unroll 1
+        for (int t = lane; t < kPatchRows * (kHCols / 4); t += 64) {
+            const int q = t / (kHCols / 4), d = t - q * (kHCols / 4);
+            const int m = q >> 1;
+            const bool odd = q & 1;
+            const unsigned W0 = odd ? (18u << 16) : (18u | (34u << 16)), W1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16)),
+                           W2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), W3 = odd ? (34u | (18u << 16)) : 18u;
+            const uint4 p0 = *reinterpret_cast<const uint4*>(hp + m * kHCols + 4 * d), p1 = *reinterpret_cast<const uint4*>(hp + (m + 1) * kHCols + 4 * d),
+                        p2 = *reinterpret_cast<const uint4*>(hp + (m + 2) * kHCols + 4 * d), p3 = *reinterpret_cast<const uint4*>(hp + (m + 3) * kHCols + 4 * d);
+            auto px = [&](unsigned a, unsigned b, unsigned c, unsigned e) {
+                unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, W0), 32768u, false);
+                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, b), __builtin_bit_cast(ushort2_t, W1), acc, false);
+                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, c), __builtin_bit_cast(ushort2_t, W2), acc, false);
+                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, e), __builtin_bit_cast(ushort2_t, W3), acc, false);
+                return min(255u, acc >> 16);
+            };
+            const unsigned o = px(p0.x, p1.x, p2.x, p3.x) | (px(p0.y, p1.y, p2.y, p3.y) << 8) | (px(p0.z, p1.z, p2.z, p3.z) << 16) | (px(p0.w, p1.w, p2.w, p3.w) << 24);
+            patch[q * (kHCols / 4) + d] = o;                 // the blurred patch replaces the raw rows (dead since the horizontal pass)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint8_t* pb = reinterpret_cast<const uint8_t*>(patch) + kPatchR * kHCols + kPatchR;
+        const float a = s_cos[kq], b = s_sin[kq];
+        uint8_t* dout = desc_out + ((size_t)img * cap + i0 + kq) * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float4 pt = s_pattern[it * 64 + lane];
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+            const int t0 = pb[r0 * kHCols + c0], t1 = pb[r1 * kHCols + c1];
+            const unsigned long long m = __ballot(t0 < t1);  // bit j of m = test 64*it + j  (LSB-first bytes)
+            if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * it) = m;
+        }
+    }
+    }
 }
 
 int launch_describe(const LevelSet& raw, const LevelSet& blurred, const DescribeParams& prm, const SelKp* d_sel,
                     const int32_t* d_img_off, const int32_t* d_lvl_cnt, int n_images, int max_per_image, dcs_keypoint* d_kp,
-                    uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s, const int32_t* d_dense_total, int dense_cap)
+                    uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s, const int32_t* d_dense_total, int dense_cap, bool fused)
 {
     const int gx = max_per_image > 0 ? (max_per_image + kDescKp - 1) / kDescKp : 1;
-    hipLaunchKernelGGL(k_describe, dim3(gx * n_images), dim3(64 * kDescWaves), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
-                       d_desc, cap, d_n_out, n_images, gx, d_dense_total, dense_cap);
+    if (fused) hipLaunchKernelGGL(k_describe<true>, dim3(gx * n_images), dim3(64 * kDescWaves), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
+                                  d_desc, cap, d_n_out, n_images, gx, d_dense_total, dense_cap);
+    else hipLaunchKernelGGL(k_describe<false>, dim3(gx * n_images), dim3(64 * kDescWaves), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
+                            d_desc, cap, d_n_out, n_images, gx, d_dense_total, dense_cap);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

@@ -298,3 +298,20 @@ def test_gpu_sincosf_equals_libm(pkg, oracle):
     gc, gs = pkg.abi.debug_sincosf(x)
     hc, hs = oracle.sincosf(x)
     assert np.array_equal(gc.view(np.uint32), hc.view(np.uint32)) and np.array_equal(gs.view(np.uint32), hs.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h,n", [(640, 480, 1000), (333, 245, 300)])
+def test_fused_blur_describe_is_bit_exact_too(pkg, oracle, synth, monkeypatch, w, h, n):
+    """DCS_ORB_FUSED_BLUR=1 (opt-in, read when the handle is created): no blur kernels, k_describe blurs every keypoint's raw patch
+    itself -- same descriptors, and the blurred debug level (made on demand then) is still the oracle's."""
+    monkeypatch.setenv("DCS_ORB_FUSED_BLUR", "1")
+    imgs = [np.ascontiguousarray(im[:h, :w]) for im in synth.frame_pair(640, 480, 2, 1)]
+    imgs.append(np.random.default_rng(5).integers(0, 256, (h, w), dtype=np.uint8))          # noise: keypoints everywhere, also at the borders
+    e = pkg.ORBextractor(n, 1.2, 8, 20, 7, max_images=3)
+    kps, descs = e.extract_batch(imgs, cap=n + 200)
+    for i in range(3):
+        o = oracle.OrbOracle(n, 1.2, 8, 20, 7)
+        okp, odesc = o.extract(imgs[i], cap=n + 200)
+        _same(kps[i], descs[i], okp, odesc)
+        assert np.array_equal(e.level_image(i, 2, blurred=True), oracle.gauss7_u8(o.level_image(2)))
+    e.close()
