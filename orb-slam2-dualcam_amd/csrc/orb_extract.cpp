@@ -158,7 +158,7 @@ struct dcs_orb {
     // last call (debug taps)
     LevelSet last_raw{}, last_blur{};
     bool last_blur_valid = false;                  // fused describe: the blurred pyramid is only made when dcs_orb_debug_level asks for it
-    bool fused_blur = false;
+    int fused_mode = -1;                           // DCS_ORB_FUSED_BLUR when the handle is created: 0 / 1, unset = choose per call
     int last_n_images = 0;
 
     ~dcs_orb() {
@@ -326,10 +326,16 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // blur on the auxiliary stream, overlapping FAST (DCS_ORB_NO_OVERLAP=1 serialises it for clean timings).
     // DCS_ORB_BLUR_LATE=1 starts it after FAST instead (measured slower: it then collides with the latency-bound
     // compaction + quadtree kernels, 1.64 vs 1.55 ms per 128 dual frames).
-    // fused_blur (DCS_ORB_FUSED_BLUR=1 when the handle is created; OPT-IN): no blur kernels, no blurred pyramid -- k_describe blurs every
-    // keypoint's 43 x 43 raw patch itself (dcs_orb_debug_level makes the blurred level on demand). Bit-exact; measured: FAST runs at its
-    // solo 630 us once the blur no longer shares the vector ALUs with it, but k_describe grows from 403 to 740 us (the two passes cost
-    // ~390 wave-instructions per keypoint, 150 more than the idle issue slots of the kernel absorb): 1 860 vs 1 790 us per 512 images.
+    // fused_blur: no blur kernels, no blurred pyramid -- k_describe blurs every keypoint's 43 x 43 raw patch itself
+    // (dcs_orb_debug_level makes the blurred level on demand). Bit-exact either way. The fused kernel costs a fixed amount per KEYPOINT
+    // (describe 400 -> 635 us per 512 x 1000 keypoints), the blur kernels a fixed amount per PIXEL and they slow FAST down while
+    // they run next to it (FAST 840 -> 630 us without them). Measured (kfeatures/s, fused vs separate): 640 x 480 / 1000 features
+    // 281 vs 282-286 k (950 pyramid pixels per feature), 1280 x 720 / 2000: 173 vs 166 k (1 425 pixels per feature), one dual frame
+    // per call 0.268 vs 0.286 ms (five launches fewer). Default: fused from 1 200 pyramid pixels per requested feature, and for
+    // calls too small to fill the chip; DCS_ORB_FUSED_BLUR=0 / 1 (read when the handle is created) forces one.
+    double pyr_px = 0;
+    for (int l = 0; l < L; ++l) pyr_px += (double)raw.lv[l].w * raw.lv[l].h;
+    const bool fused_blur = fused_mode >= 0 ? fused_mode != 0 : (pyr_px >= 1200.0 * t.nfeatures || n_images <= 8);
     last_blur_valid = !fused_blur;
     static const bool blur_early = getenv("DCS_ORB_BLUR_LATE") == nullptr;
     hipStream_t sb = no_overlap ? stream : s_aux;
@@ -478,7 +484,7 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     DCS_HIP(hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming));
     for (auto& es : h->ring) { for (auto& e : es.t) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.b) DCS_HIP(hipEventCreate(&e)); }
     h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
-    h->fused_blur = getenv("DCS_ORB_FUSED_BLUR") && atoi(getenv("DCS_ORB_FUSED_BLUR")) != 0;
+    h->fused_mode = getenv("DCS_ORB_FUSED_BLUR") ? (atoi(getenv("DCS_ORB_FUSED_BLUR")) != 0) : -1;
     h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
     {   // staging threads of the host-buffer API (DCS_ORB_STAGING_THREADS, default 4; 1 = pack on the calling thread)

@@ -867,6 +867,33 @@ constexpr int kRawR = kPatchR + 3;          // 21
 constexpr int kRawRows = 2 * kRawR + 1;     // 43 (+ 1 padding row: the odd half of the last row pair)
 constexpr int kHPairs = (kRawRows + 1) / 2; // 22
 constexpr int kHCols = 40;                  // columns of the horizontal sums / of the blurred patch (37 used)
+// Horizontal-pass tasks (row pair, dword column) that a test can reach: a rotated pattern point lies within 18.385 + 0.7072 < 19.1 of
+// the keypoint (rounding adds at most half a pixel per axis), so blurred pixel (r, c) is read only if r^2 + c^2 <= 364, and the sum
+// of raw row rho feeds the blurred rows rho - 3 .. rho + 3: 189 of the 220 tasks -- three rounds of a wave instead of four.
+struct HTaskTable { uint16_t t[192]; int n; };
+constexpr HTaskTable make_h_tasks()
+{
+    HTaskTable tb{};
+    tb.n = 0;
+    for (int rp = 0; rp < kHPairs; ++rp) {
+        int best = -1;
+        for (int half = 0; half < 2; ++half) {
+            const int rho = 2 * rp + half - kRawR;
+            if (rho > kRawR) continue;
+            for (int r = (rho - 3 < -kPatchR ? -kPatchR : rho - 3); r <= (rho + 3 > kPatchR ? kPatchR : rho + 3); ++r) {
+                int cm = 0;
+                while (cm < kPatchR && (cm + 1) * (cm + 1) + r * r <= 364) ++cm;
+                if (r * r <= 364 && cm > best) best = cm;
+            }
+        }
+        if (best < 0) continue;
+        for (int d = (kPatchR - best) >> 2; d <= (kPatchR + best) >> 2; ++d) tb.t[tb.n++] = (uint16_t)(rp | (d << 8));
+    }
+    for (int i = tb.n; i < 192; ++i) tb.t[i] = 0xFFFFu;
+    return tb;
+}
+__device__ const HTaskTable c_h_tasks = make_h_tasks();
+static_assert(make_h_tasks().n <= 192, "three rounds of 64 lanes");
 #ifndef DCS_DESC_KP                          // tuning hook (scratch/ab builds)
 #define DCS_DESC_KP 16
 #endif
@@ -1164,6 +1191,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         q2 = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(k.y - kRawR + min(r_lane + 32, kRawRows - 1), rv.h) * rv.pitch);
     };
     if (wave * kDescPerWave < n_here) fetch(wave * kDescPerWave);
+    const unsigned ht[3] = {c_h_tasks.t[lane], c_h_tasks.t[lane + 64], c_h_tasks.t[lane + 128]};      // this lane's horizontal-pass tasks
     constexpr unsigned KA = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3 of the 7-tap kernel (k_blur's)
     constexpr unsigned KB = 49u | (34u << 8) | (18u << 16);                 // taps 4..6
 #pragma unroll 1
@@ -1204,9 +1232,11 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         // ---- horizontal pass: task = (row pair, 4 output columns); h[c] = sum_k K[k] raw[c + k] (<= 65 535)
         {
             const int a0 = shift_now >> 2, sh = shift_now & 3;
-#pragma unroll 1
-            for (int t = lane; t < kHPairs * (kHCols / 4); t += 64) {
-                const int rp = t / (kHCols / 4), d = t - rp * (kHCols / 4);
+#pragma unroll
+            for (int round = 0; round < 3; ++round) {
+                const unsigned task = ht[round];
+                if (task == 0xFFFFu) continue;
+                const int rp = task & 255, d = task >> 8;
                 unsigned hh[2][4];
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -1226,32 +1256,22 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // ---- vertical pass: task = (output row q, 4 columns); rows q .. q + 6 = 4 row pairs, taps arranged by the parity of q
-#pragma unroll 1
-        for (int t = lane; t < kPatchRows * (kHCols / 4); t += 64) {
-            const int q = t / (kHCols / 4), d = t - q * (kHCols / 4);
-            const int m = q >> 1;
+        // ---- vertical pass ON DEMAND: only the (at most) 512 pixels the tests read are blurred -- rows q .. q + 6 of the horizontal
+        // sums = 4 row pairs, taps arranged by the parity of q: 4 v_dot2_u32_u16 per pixel
+        const float a = s_cos[kq], b = s_sin[kq];
+        uint8_t* dout = desc_out + ((size_t)img * cap + i0 + kq) * 32;
+        auto blurred_at = [&](int r, int c) {                // r, c in -18 .. 18
+            const int q = r + kPatchR, m = q >> 1;
             const bool odd = q & 1;
             const unsigned W0 = odd ? (18u << 16) : (18u | (34u << 16)), W1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16)),
                            W2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), W3 = odd ? (34u | (18u << 16)) : 18u;
-            const uint4 p0 = *reinterpret_cast<const uint4*>(hp + m * kHCols + 4 * d), p1 = *reinterpret_cast<const uint4*>(hp + (m + 1) * kHCols + 4 * d),
-                        p2 = *reinterpret_cast<const uint4*>(hp + (m + 2) * kHCols + 4 * d), p3 = *reinterpret_cast<const uint4*>(hp + (m + 3) * kHCols + 4 * d);
-            auto px = [&](unsigned a, unsigned b, unsigned c, unsigned e) {
-                unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, W0), 32768u, false);
-                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, b), __builtin_bit_cast(ushort2_t, W1), acc, false);
-                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, c), __builtin_bit_cast(ushort2_t, W2), acc, false);
-                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, e), __builtin_bit_cast(ushort2_t, W3), acc, false);
-                return min(255u, acc >> 16);
-            };
-            const unsigned o = px(p0.x, p1.x, p2.x, p3.x) | (px(p0.y, p1.y, p2.y, p3.y) << 8) | (px(p0.z, p1.z, p2.z, p3.z) << 16) | (px(p0.w, p1.w, p2.w, p3.w) << 24);
-            patch[q * (kHCols / 4) + d] = o;                 // the blurred patch replaces the raw rows (dead since the horizontal pass)
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint8_t* pb = reinterpret_cast<const uint8_t*>(patch) + kPatchR * kHCols + kPatchR;
-        const float a = s_cos[kq], b = s_sin[kq];
-        uint8_t* dout = desc_out + ((size_t)img * cap + i0 + kq) * 32;
+            const uint32_t* col = hp + m * kHCols + (c + kPatchR);
+            unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[0]), __builtin_bit_cast(ushort2_t, W0), 32768u, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[kHCols]), __builtin_bit_cast(ushort2_t, W1), acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[2 * kHCols]), __builtin_bit_cast(ushort2_t, W2), acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[3 * kHCols]), __builtin_bit_cast(ushort2_t, W3), acc, false);
+            return min(255u, acc >> 16);
+        };
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const float4 pt = s_pattern[it * 64 + lane];
@@ -1259,7 +1279,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
             const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
             const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
-            const int t0 = pb[r0 * kHCols + c0], t1 = pb[r1 * kHCols + c1];
+            const unsigned t0 = blurred_at(r0, c0), t1 = blurred_at(r1, c1);
             const unsigned long long m = __ballot(t0 < t1);  // bit j of m = test 64*it + j  (LSB-first bytes)
             if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * it) = m;
         }

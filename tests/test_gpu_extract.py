@@ -8,6 +8,13 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["separate blur kernels", "blur fused into k_describe"])
+def blur_mode(request, monkeypatch):
+    """Every test of this file runs with both pipelines (DCS_ORB_FUSED_BLUR is read when an extractor handle is created): the library
+    picks one per call from the pyramid pixels per feature and the batch size, so small test batches would only ever see the fused one."""
+    monkeypatch.setenv("DCS_ORB_FUSED_BLUR", "0" if request.param.startswith("separate") else "1")
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -17,7 +24,7 @@ def _same(kp_a, desc_a, kp_b, desc_b):
     assert np.array_equal(desc_a, desc_b)
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def ext1000(pkg):
     e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=4)
     yield e
@@ -300,18 +307,15 @@ def test_gpu_sincosf_equals_libm(pkg, oracle):
     assert np.array_equal(gc.view(np.uint32), hc.view(np.uint32)) and np.array_equal(gs.view(np.uint32), hs.view(np.uint32))
 
 
-@pytest.mark.parametrize("w,h,n", [(640, 480, 1000), (333, 245, 300)])
-def test_fused_blur_describe_is_bit_exact_too(pkg, oracle, synth, monkeypatch, w, h, n):
-    """DCS_ORB_FUSED_BLUR=1 (opt-in, read when the handle is created): no blur kernels, k_describe blurs every keypoint's raw patch
-    itself -- same descriptors, and the blurred debug level (made on demand then) is still the oracle's."""
+def test_fused_blur_describe_keeps_the_blurred_debug_level(pkg, oracle, synth, monkeypatch):
+    """With the fused describe no blur kernel runs in the product path: the blurred debug level is made on demand and is still the oracle's."""
     monkeypatch.setenv("DCS_ORB_FUSED_BLUR", "1")
-    imgs = [np.ascontiguousarray(im[:h, :w]) for im in synth.frame_pair(640, 480, 2, 1)]
-    imgs.append(np.random.default_rng(5).integers(0, 256, (h, w), dtype=np.uint8))          # noise: keypoints everywhere, also at the borders
-    e = pkg.ORBextractor(n, 1.2, 8, 20, 7, max_images=3)
-    kps, descs = e.extract_batch(imgs, cap=n + 200)
+    imgs = list(synth.frame_pair(640, 480, 2, 1)) + [np.random.default_rng(5).integers(0, 256, (480, 640), dtype=np.uint8)]
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=3)
+    kps, descs = e.extract_batch(imgs)
     for i in range(3):
-        o = oracle.OrbOracle(n, 1.2, 8, 20, 7)
-        okp, odesc = o.extract(imgs[i], cap=n + 200)
+        o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+        okp, odesc = o.extract(imgs[i])
         _same(kps[i], descs[i], okp, odesc)
         assert np.array_equal(e.level_image(i, 2, blurred=True), oracle.gauss7_u8(o.level_image(2)))
     e.close()
