@@ -112,6 +112,9 @@ int  dcs_orb_extract_batch_device(dcs_orb* h, const uint8_t* d_images, int n_ima
    what `cos(angle)` / `sin(angle)` on a float are in src/ORBextractor.cc:112-113), for n angles in radians (|x| < 120). */
 int  dcs_debug_sincosf(const float* x, int n, float* cos_out, float* sin_out);
 int  dcs_orb_debug_level_dims(const dcs_orb* h, int level, int* w, int* h_out);
+/* blurred = 1: the GaussianBlur'ed level (src/ORBextractor.cc:1081-1083). When the last call described its keypoints with the fused
+   kernel (no blurred pyramid exists in the product path then) the level is blurred on demand from the raw pyramid -- for level 0
+   of the _device API that is the caller's buffer, which must still be alive. */
 int  dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t* dst /* w*h */);
 int  dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* dst, int cap, int* n);
 /* number of (image, level) quadtrees of the last call that left the LDS histogram fast path for the general
