@@ -63,7 +63,8 @@ int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_c
 
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
-                      int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s);
+                      int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s,
+                      int cell0 = 0, int n_launch = -1 /* the launch covers cells [cell0, cell0 + n_launch); -1: to the end */);
 
 // per (image, level): scan the cell counts, then gather the slots into one dense array for the whole
 // batch. d_lvl_off[n_images*nlevels + 1] = exclusive offsets (image-major, level-minor).

@@ -297,7 +297,8 @@ __device__ __forceinline__ int fast_score(const uint8_t* b, unsigned th_pk /* th
 template <int P>           // LDS row pitch in bytes (64 or 128): compile-time so that the ring offsets are immediates
 __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
                                                    dcs_candidate* __restrict__ slots, size_t slots_per_image,
-                                                   int32_t* __restrict__ cell_count, int map_bytes, int n_images, int sc_pitch, int sc_bytes, int dbg_stop)
+                                                   int32_t* __restrict__ cell_count, int map_bytes, int n_images, int sc_pitch, int sc_bytes, int dbg_stop,
+                                                   int cell0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_px = smem;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     // grid (8, n_cells, ceil(n_images / 8)): workgroups go to the 8 XCDs round-robin by linear id, so blockIdx.x IS the XCD and all
     // cells of an image run on one XCD -- neighbouring cells share their aprons' cache lines in ONE L2 (fabric fetches 1072 -> 219 MB
     // per 512-image launch) without any index arithmetic
-    const int lane = threadIdx.x, cell = blockIdx.y, img = blockIdx.z * 8 + blockIdx.x;
+    const int lane = threadIdx.x, cell = blockIdx.y + cell0, img = blockIdx.z * 8 + blockIdx.x;       // cell0: first cell of this launch
     if (img >= n_images) return;
     const CellDesc cd = cells[cell];
     const int rw = cd.rw, rh = cd.rh;
@@ -481,9 +482,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
 
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
-                      int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s)
+                      int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s, int cell0, int n_launch)
 {
-    if (n_cells == 0) return DCS_OK;
+    if (n_launch < 0) n_launch = n_cells - cell0;             // cells [cell0, cell0 + n_launch) of the n_cells of the pyramid
+    if (n_launch <= 0) return DCS_OK;
     const int P = (max_rw + 7 <= 48) ? 48 : (max_rw + 15 <= 64) ? 64 : 128;      // shift (<= 7 or 15) + row fits the pitch
     const int map_bytes = ((max_rh * P) + 15) & ~15;
     const int list_bytes = ((((max_rw - 6) * (max_rh - 6) + 33) * 2) + 15) & ~15;      // + 32 entries of an odd last row + the spare slot
@@ -491,15 +493,16 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
     const int sc_bytes = (sc_pitch * (max_rh - 6 + 2) + 15) & ~15;
     const size_t shmem = (size_t)map_bytes + sc_bytes + list_bytes;
     static const int dbg_stop = getenv("DCS_FAST_STOP") ? atoi(getenv("DCS_FAST_STOP")) : 0;      // only read by -DDCS_FAST_SECTIONS builds
+    const dim3 grid(8, n_launch, (n_images + 7) / 8);
     if (P == 48)
-        hipLaunchKernelGGL(k_fast_cells<48>, dim3(8, n_cells, (n_images + 7) / 8), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop);
+        hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), shmem, s, levels, d_cells, n_cells,
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop, cell0);
     else if (P == 64)
-        hipLaunchKernelGGL(k_fast_cells<64>, dim3(8, n_cells, (n_images + 7) / 8), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop);
+        hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), shmem, s, levels, d_cells, n_cells,
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop, cell0);
     else
-        hipLaunchKernelGGL(k_fast_cells<128>, dim3(8, n_cells, (n_images + 7) / 8), dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop);
+        hipLaunchKernelGGL(k_fast_cells<128>, grid, dim3(64), shmem, s, levels, d_cells, n_cells,
+                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop, cell0);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

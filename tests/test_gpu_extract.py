@@ -10,11 +10,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["separate blur kernels", "blur fused into k_describe"])
-def blur_mode(request, monkeypatch):
-    """Every test of this file runs with both pipelines (DCS_ORB_FUSED_BLUR is read when an extractor handle is created): the library
-    picks one per call from the pyramid pixels per feature and the batch size, so small test batches would only ever see the fused one."""
+@pytest.fixture(autouse=True, params=["separate blur kernels", "blur fused into k_describe", "fused + early FAST of levels 0-1"])
+def pipeline_mode(request, monkeypatch):
+    """Every test of this file runs with every pipeline variant (DCS_ORB_FUSED_BLUR / DCS_ORB_FAST_SPLIT are read when an extractor
+    handle is created): the library picks the blur variant per call from the pyramid pixels per feature and the batch size, so small
+    test batches would only ever see the fused one; the early FAST launch (two k_fast_cells launches on two streams) is opt-in."""
     monkeypatch.setenv("DCS_ORB_FUSED_BLUR", "0" if request.param.startswith("separate") else "1")
+    monkeypatch.setenv("DCS_ORB_FAST_SPLIT", "2" if "early" in request.param else "0")
+
+
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
