@@ -32,7 +32,10 @@ int upload_pattern() { return DCS_OK; }   // statically initialised __constant__
 // interpolated rows (already >> 4, as the vertical pass wants them) are cached in VGPRs because consecutive destination
 // rows share source rows at scale 1.2. All row bookkeeping is wave-uniform (scalar registers and branches); the
 // vertical pass is two 24-bit multiplies + one SDWA add of the high halves per pixel. No LDS, no barriers.
-constexpr int kRsRowsPerThread = 8;
+#ifndef DCS_RS_ROWS                          // tuning hook (scratch/ab builds); a power of two <= 64
+#define DCS_RS_ROWS 16
+#endif
+constexpr int kRsRowsPerThread = DCS_RS_ROWS;
 
 struct ResizeCol { int16_t sx, pad, a0, a1; };
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
@@ -104,9 +107,9 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
     const int dx0 = (li - img * n_x4) * 4;
     const int dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * kRsRowsPerThread;   // wave-uniform
     if (dy0 >= dst.h) return;
-    // row tables of this strip: lane k (mod 8) holds the entries of destination row dy0 + k; read back with v_readlane (the
+    // row tables of this strip: lane k (mod rows per thread) holds the entries of destination row dy0 + k; read back with v_readlane (the
     // loads are issued by every lane, before the out-of-range lanes of the last block leave)
-    const int krow = min(dy0 + (int)(threadIdx.x & 7), dst.h - 1);
+    const int krow = min(dy0 + (int)(threadIdx.x & (kRsRowsPerThread - 1)), dst.h - 1);
     const int my_sy = yofs[krow];
     const unsigned my_a = *reinterpret_cast<const unsigned*>(ya + 2 * krow);           // b0 | b1 << 16 (both 0..2048)
     // the readlanes happen HERE, while all 64 lanes are still active: placed after the return below, the compiler sinks the two
@@ -610,8 +613,14 @@ int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, i
 // v_alignbyte and reduces them with 2 x v_dot4_u32_u8 each; the last 7 horizontal results per pixel stay in
 // VGPRs (fully unrolled ring), so the vertical pass is 7 v_mad per pixel and one packed dword store per row.
 constexpr int kBlurW = 256;      // output pixels per workgroup row (64 lanes x 4 px)
-constexpr int kBlurR = 32;       // output rows per thread
-constexpr int kBlurWaves = 4;    // waves per workgroup (stacked in y)
+#ifndef DCS_BLUR_ROWS                        // tuning hooks (scratch/ab builds)
+#define DCS_BLUR_ROWS 32
+#endif
+#ifndef DCS_BLUR_WAVES
+#define DCS_BLUR_WAVES 4
+#endif
+constexpr int kBlurR = DCS_BLUR_ROWS;       // output rows per thread
+constexpr int kBlurWaves = DCS_BLUR_WAVES;    // waves per workgroup (stacked in y)
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
