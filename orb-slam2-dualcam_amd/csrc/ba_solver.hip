@@ -17,8 +17,8 @@
 //   k_schur         workgroup per pose pair over a precomputed (edge, edge) list: 28 partial sums x 36 entries (4 waves with 4
 //                   accumulators per thread, or 16 waves for groups of <= 2 problems; same bits) + the reduced right-hand side
 //   k_ldlt_mfma     LDL^T + both triangular solves of the reduced camera system in ONE workgroup: 16x16 tiles in the
-//                   registers of 7 worker waves, trailing updates on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the
-//                   diagonal blocks factored one step ahead by an eighth wave
+//                   registers of 11 worker waves, trailing updates on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the
+//                   diagonal blocks factored one step ahead by a twelfth wave
 //                   (k_ldlt_reg: column-by-column VALU predecessor, DCS_BA_LDLT_VALU=1; k_ldlt_panel/_update/_solve:
 //                   multi-launch fallback for n > 256)
 //   k_solve_update  landmark back-substitution, push + manifold update of all estimates, computeScale partials
@@ -820,9 +820,9 @@ __global__ __launch_bounds__(64) void k_ldlt_update(const BaProb* __restrict__ p
 }
 
 // ---- single-workgroup blocked LDL^T + solve on the f64 matrix cores (n <= 256) ---------------------------------------
-// 8 waves: 7 WORKERS hold the lower triangle in their VGPRs as 16x16 tiles in the MFMA accumulator layout (lane l, register r
+// 12 waves: 11 WORKERS hold the lower triangle in their VGPRs as 16x16 tiles in the MFMA accumulator layout (lane l, register r
 // holds element (row = (l >> 4) + 4 r, col = l & 15)); tile t = I (I + 1) / 2 + K of the row-major triangle belongs to worker
-// t % 7, slot t / 7 (18 slots for <= 15 block rows, 20 for 16: two builds). The eighth wave is the CHAIN wave: it owns no tile
+// t % 11, slot t / 11 (11 slots for <= 15 block rows, 13 for 16: two builds; 7 workers with 18 / 20 slots: 67 instead of 64 us, 15: 64). The twelfth wave is the CHAIN wave: it owns no tile
 // and runs the only sequential part, the diagonal blocks.
 // Block step J, two workgroup barriers:
 //   workers, rows    the panel below the diagonal block is W = A U^-T, L = W D^-1 with the INVERSE of the unit factor of the
@@ -838,12 +838,19 @@ __global__ __launch_bounds__(64) void k_ldlt_update(const BaProb* __restrict__ p
 //                    (v_mov_b64_dpp: no SGPR traffic); the same elimination applied to an identity yields U^-1 -- all of it
 //                    while the workers run step J. The workers only ever wait for U^-1 of the next block.
 // Back substitution L^T x = D^-1 y walks the block columns backwards: tile owners reduce L(I, J)^T x_I with two
-// cross-lane adds, the chain wave sums the seven partial vectors in fixed order and multiplies by U^-T (16 DPP broadcasts).
-// Measured (n = 234, scratch/ldlt): 67 us = staging 9 + 14 steps 52 (7 700 cycles each for the first steps, matrix-core bound at
+// cross-lane adds, the chain wave sums the workers' partial vectors in fixed order and multiplies by U^-T (16 DPP broadcasts).
+// Measured (n = 234, scratch/ldlt, 7 workers): 67 us = staging 9 + 14 steps 52 (7 700 cycles each for the first steps, matrix-core bound at
 // ~70 % of one CU's rate; 5 200 for the last ones = the chain wave's 1 300 + 3 500) + back substitution 9. f64 MFMA 16x16x4 issues
-// every 64 cycles, dependent or not, 2 waves of a SIMD share the pipe (scratch/probe/mfma_f64_probe.hip).
+// every 64 cycles, dependent or not, the waves of a SIMD share the pipe (scratch/probe/mfma_f64_probe.hip): with 3 instead of 2 waves
+// per SIMD the operand loads of one wave hide behind the others' MFMAs (64 us).
 constexpr int kLS = 17;                        // padded LDS row stride of the 16-wide panels (doubles)
-constexpr int kLdltWorkers = 7;                // waves that own tiles; one more wave runs the chain of diagonal blocks
+#ifndef DCS_LDLT_WORKERS                       // tuning hook (scratch/ldlt)
+#define DCS_LDLT_WORKERS 11
+#endif
+constexpr int kLdltWorkers = DCS_LDLT_WORKERS; // waves that own tiles; one more wave runs the chain of diagonal blocks
+constexpr int kLdltSlotsSmall = (120 + kLdltWorkers - 1) / kLdltWorkers;       // <= 15 block rows (n <= 240): 120 tiles
+constexpr int kLdltSlotsBig = (136 + kLdltWorkers - 1) / kLdltWorkers;         // 16 block rows: 136 tiles
+constexpr int kLdltStage = (2 * 256 * kLS) / (kLdltWorkers * 16 * kLS) >= 4 ? 4 : (2 * 256 * kLS) / (kLdltWorkers * 16 * kLS);   // tiles per wave staged at once in Lp[1] + Wn
 constexpr int kLdltThreads = 64 * (kLdltWorkers + 1);
 constexpr int kDiagWave = kLdltWorkers;
 
@@ -1036,7 +1043,7 @@ __device__ __forceinline__ void ldlt_chain_wave(LdltShared& sh, int NT, double* 
     }
 }
 
-template <int kLdltSlots>       // 18: at most 15 block rows (n <= 240, 120 tiles), 20: 16 block rows (136 tiles); 16 registers apart
+template <int kLdltSlots>       // kLdltSlotsSmall: at most 15 block rows (n <= 240, 120 tiles), kLdltSlotsBig: 16 block rows (136 tiles)
 __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
 {
     const BaProb& pb = probs[blockIdx.x];
@@ -1059,7 +1066,7 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
     // every LDS address below is a lane base + a wave-uniform tile offset + a compile-time constant
     const int offC = hi * kLS + lo;            // accumulator layout: element (hi + 4 r, lo) of a tile at offC + 4 r kLS
     const int offA = lo * kLS + hi;            // MFMA operand layout: element (row lo, k = hi + 4 sl) at offA + 4 sl
-    // slot s of worker w holds tile t = 7 s + w of the row-major lower triangle, t = I (I + 1) / 2 + K
+    // slot s of worker w holds tile t = kLdltWorkers s + w of the row-major lower triangle, t = I (I + 1) / 2 + K
     int tIK[kLdltSlots];                       // I | K << 8 (one SGPR per slot), -1 = no tile
 #define tI(s) (tIK[s] < 0 ? -1 : (tIK[s] & 255))
 #define tK(s) (tIK[s] >> 8)
@@ -1102,12 +1109,12 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
         }
     }
     LP(20, 3, 0);
-    {   // four tiles per round trip: Lp[1] and Wn (contiguous, idle until the first panel) hold 4 tiles per wave
-        double* const T0 = &sh.Lp[1][0] + wave * 4 * 16 * kLS;
+    {   // kLdltStage tiles per round trip: Lp[1] and Wn (contiguous, idle until the first panel) hold that many tiles per wave
+        double* const T0 = &sh.Lp[1][0] + wave * kLdltStage * 16 * kLS;
 #pragma unroll
-        for (int g = 0; g < kLdltSlots; g += 4) {
+        for (int g = 0; g < kLdltSlots; g += kLdltStage) {
 #pragma unroll
-            for (int s = g; s < g + 4 && s < kLdltSlots; ++s) {
+            for (int s = g; s < g + kLdltStage && s < kLdltSlots; ++s) {
                 double* const T = T0 + (s - g) * 16 * kLS;
                 const int I = max(tI(s), 0), K = max(tK(s), 0);
 #pragma unroll
@@ -1118,7 +1125,7 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
                 }
             }
 #pragma unroll
-            for (int s = g; s < g + 4 && s < kLdltSlots; ++s) {
+            for (int s = g; s < g + kLdltStage && s < kLdltSlots; ++s) {
                 const double* const T = T0 + (s - g) * 16 * kLS;
                 const bool diag = tI(s) == tK(s);
 #pragma unroll
@@ -2204,7 +2211,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
             spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
             if (gr.g_schur) spec.push_back({schur_wide(nb) ? (void*)k_schur<1> : (void*)k_schur<0>, dim3(gr.g_schur, nb), dim3(schur_wide(nb) ? 1024 : kSchurThreads), a_cc});
-            if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<18> : (void*)k_ldlt_mfma<20>, dim3(nb), dim3(kLdltThreads), a_c});
+            if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<kLdltSlotsSmall> : (void*)k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
             spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
             spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
@@ -2252,8 +2259,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         mark(step, 1);
         if (gr.any_mfma) {
-            if (gr.max_n_mfma <= 240) hipLaunchKernelGGL(k_ldlt_mfma<18>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
-            else hipLaunchKernelGGL(k_ldlt_mfma<20>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
+            if (gr.max_n_mfma <= 240) hipLaunchKernelGGL(k_ldlt_mfma<kLdltSlotsSmall>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
+            else hipLaunchKernelGGL(k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
         }
         if (gr.any_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(nb), dim3(1024), 0, gs, dp, ctls);
         if (gr.any_blocked) {
