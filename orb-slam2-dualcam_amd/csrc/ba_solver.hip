@@ -503,19 +503,21 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
 }
 
 // workgroup per pose pair (i1 <= i2): S block = [i1==i2](Hpp + lambda I) - sum over shared points BD[e1] Hpl[e2]^T.
-// kSchurChunks list chunks x 36 block entries per workgroup (4 list entries in flight per thread); partials combined in fixed
-// order. 7 chunks = 4 waves: a C4 problem has ~860 such workgroups per trial and a batch of 8 problems ~6 900 -- with 16-wave
-// workgroups (28 chunks) the batch needed 13 rounds of the chip's wave slots (97 us), with 4-wave ones it needs 4.
+// C list chunks x 36 block entries per workgroup (4 list entries in flight per thread); partials combined in fixed order. A C4 problem
+// has ~860 such workgroups per trial and a batch of 8 problems ~6 900: 16-wave workgroups (C = 28) for every group size needed 13
+// rounds of the chip's wave slots for 8 problems (97 us), 4-wave ones (C = 7) 4 rounds (65 us); a single problem is the other way round.
 constexpr int kSchurChunks = 7;
 constexpr int kSchurFine = 28;                           // partial sums per S entry: list entry k belongs to partial k % 28, whatever the workgroup size
 constexpr int kSchurThreads = 256;
 constexpr int kSchurRhsChunks = 42;                      // 42 x 6 rows = 252 threads for the reduced right-hand side
-// WIDE = 0: 4 waves, thread (q, el) keeps the 4 partials q, q + 7, q + 14, q + 21 of entry el in 4 accumulators; WIDE = 1: 16 waves, one
-// partial per thread (a single problem has too few pose pairs to fill the chip with 4-wave workgroups). Both add the 28 partials in
-// index order: the same bits whichever one runs, so a batch still equals its problems solved one by one.
-template <int WIDE>
-__global__ __launch_bounds__(WIDE ? 1024 : kSchurThreads) void k_schur(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
+// C = list chunks per workgroup: 7 (4 waves, thread (q, el) keeps the partials q, q + 7, q + 14, q + 21 of entry el in 4 accumulators), 14 (8
+// waves, 2 accumulators) or 28 (16 waves, one partial per thread: a single problem has too few pose pairs to fill the chip with 4-wave
+// workgroups). All of them add the 28 partials in index order: the same bits whichever one runs, so a batch still equals its
+// problems solved one by one.
+template <int C>
+__global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
+    static_assert(C == 7 || C == 14 || C == 28, "28 fine partials split evenly");
     __shared__ double part[kSchurFine][36];
     const BaProb& pb = probs[blockIdx.y];
     const BaCtl& ctl = ctls[blockIdx.y];
@@ -563,24 +565,20 @@ __global__ __launch_bounds__(WIDE ? 1024 : kSchurThreads) void k_schur(const BaP
         const double* b = Hpl + (size_t)pair_e2[k] * 18 + c * 3;
         return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
     };
-    if (WIDE) {
-        if (q < kSchurFine) {
-            double acc = 0;
-#pragma unroll 4
-            for (int k = k0 + q; k < k1; k += kSchurFine) acc += term(k);
-            part[q][el] = acc;
-        }
-    } else if (q < kSchurChunks) {
-        double a4[4] = {0, 0, 0, 0};
+    if (q < C) {
+        constexpr int A = kSchurFine / C;                    // accumulators per thread
+        double acc[A];
+#pragma unroll
+        for (int m = 0; m < A; ++m) acc[m] = 0;
         int k = k0 + q;
-        for (; k + 3 * kSchurChunks < k1; k += kSchurFine) {
+        for (; k + (A - 1) * C < k1; k += kSchurFine) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a4[m] += term(k + kSchurChunks * m);
+            for (int m = 0; m < A; ++m) acc[m] += term(k + C * m);
         }
 #pragma unroll
-        for (int m = 0; m < 3; ++m) if (k + kSchurChunks * m < k1) a4[m] += term(k + kSchurChunks * m);
+        for (int m = 0; m < A - 1; ++m) if (k + C * m < k1) acc[m] += term(k + C * m);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) part[q + kSchurChunks * m][el] = a4[m];
+        for (int m = 0; m < A; ++m) part[q + C * m][el] = acc[m];
     }
     __syncthreads();
     if (t >= 36) return;
@@ -1808,12 +1806,15 @@ struct Carver {
     }
 };
 
-// 16-wave k_schur workgroups for small groups (DCS_BA_SCHUR_WIDE = max problems per group that use them; default 2)
-static bool schur_wide(int nb)
+// list chunks per k_schur workgroup by group size: 28 (16 waves) for 1-2 problems, DCS_BA_SCHUR_MID (8 waves) up to that many, else 7
+static int schur_chunks(int nb)
 {
-    static const int lim = getenv("DCS_BA_SCHUR_WIDE") ? atoi(getenv("DCS_BA_SCHUR_WIDE")) : 2;
-    return nb <= lim;
+    static const int wide = getenv("DCS_BA_SCHUR_WIDE") ? atoi(getenv("DCS_BA_SCHUR_WIDE")) : 2;
+    static const int mid = getenv("DCS_BA_SCHUR_MID") ? atoi(getenv("DCS_BA_SCHUR_MID")) : 4;
+    return nb <= wide ? 28 : nb <= mid ? 14 : 7;
 }
+static void* schur_fn(int c) { return c == 28 ? (void*)k_schur<28> : c == 14 ? (void*)k_schur<14> : (void*)k_schur<7>; }
+static int schur_threads(int c) { return c == 28 ? 1024 : c == 14 ? 512 : 256; }
 
 // A few persistent host threads for the per-problem list building of a batch. One job at a time: a second caller (the header
 // promises re-entrancy) that finds the pool busy simply does its own work inline. The workers are never joined (they sleep on a
@@ -2210,7 +2211,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             spec.push_back({(void*)k_linearize, dim3(gr.g_edges, nb), dim3(256), a_cc});
             spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
             spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
-            if (gr.g_schur) spec.push_back({schur_wide(nb) ? (void*)k_schur<1> : (void*)k_schur<0>, dim3(gr.g_schur, nb), dim3(schur_wide(nb) ? 1024 : kSchurThreads), a_cc});
+            if (gr.g_schur) spec.push_back({schur_fn(schur_chunks(nb)), dim3(gr.g_schur, nb), dim3(schur_threads(schur_chunks(nb))), a_cc});
             if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<kLdltSlotsSmall> : (void*)k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
             spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
@@ -2254,8 +2255,10 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             hipLaunchKernelGGL(k_pad_identity, dim3(1, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
         }
         if (gr.g_schur) {
-            if (schur_wide(nb)) hipLaunchKernelGGL(k_schur<1>, dim3(gr.g_schur, nb), dim3(1024), 0, gs, dp, (const BaCtl*)ctls);
-            else hipLaunchKernelGGL(k_schur<0>, dim3(gr.g_schur, nb), dim3(kSchurThreads), 0, gs, dp, (const BaCtl*)ctls);
+            const int sc = schur_chunks(nb);
+            if (sc == 28) hipLaunchKernelGGL(k_schur<28>, dim3(gr.g_schur, nb), dim3(1024), 0, gs, dp, (const BaCtl*)ctls);
+            else if (sc == 14) hipLaunchKernelGGL(k_schur<14>, dim3(gr.g_schur, nb), dim3(512), 0, gs, dp, (const BaCtl*)ctls);
+            else hipLaunchKernelGGL(k_schur<7>, dim3(gr.g_schur, nb), dim3(256), 0, gs, dp, (const BaCtl*)ctls);
         }
         mark(step, 1);
         if (gr.any_mfma) {
