@@ -2285,7 +2285,11 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     };
 
     // ---- the host only feeds the queues: kLookahead steps ahead of what the device has reported finished, group by group
-    constexpr int kLookahead = 2;                        // a step lasts 0.2 - 0.3 ms, enqueueing one 0.05 - 0.15 ms
+    // Steps already in the queue when the device reports the last problem done still run, as 8 no-op launches of ~5 us each, in front
+    // of the download (75 us of a 2 ms C4 solve at two steps ahead). One step ahead (DCS_BA_LOOKAHEAD=1) measured +1 % for one C4 problem
+    // and nothing for a batch; two stays the default because small problems (a step of 50 us) need the slack: enqueueing a step
+    // costs the host 30 - 50 us per group.
+    static const int kLookahead = getenv("DCS_BA_LOOKAHEAD") ? std::max(1, atoi(getenv("DCS_BA_LOOKAHEAD"))) : 2;
     auto load_words = [&](const Group& gr, int& step_done, int& n_done) {
         step_done = __atomic_load_n(gr.words, __ATOMIC_ACQUIRE);
         n_done = __atomic_load_n(gr.words + 1, __ATOMIC_RELAXED);
