@@ -1721,6 +1721,25 @@ struct BaContext {
     // factored (one workgroup per problem) the other groups' wide kernels have the rest of the chip
     static constexpr int kMaxGroups = 4;
     hipStream_t aux[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+    hipStream_t dl = nullptr;                          // results come down on their own stream once every problem has reported done
+    // A call that took its results down on `dl` returns while the steps it had queued ahead (no-ops on a finished batch) are still in
+    // the solver's queues -- and the last block of each of their k_post launches still stores to the pinned progress words. Nothing
+    // may reset those words, or free / reuse what the queues reference, before they have drained: drain() is the first thing prepare()
+    // and release() do (by then the tail has long run under the caller's own work; found as a bug of the first version of the dl path:
+    // the next call zeroed the words on the host, a late k_post of the previous call reported "all problems done", and the next call
+    // would have downloaded results before running a step).
+    bool tail_pending = false;
+    void drain()
+    {
+        if (!tail_pending) return;
+#ifdef DCS_BA_NO_DRAIN                                  // side builds only: shows that tests/test_gpu_ba.py catches the missing drain
+        tail_pending = false;
+        return;
+#endif
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (hipStream_t a : aux) if (a) (void)hipStreamSynchronize(a);
+        tail_pending = false;
+    }
     hipEvent_t ev_up = nullptr, ev_done[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
     // one LM step of a group = 8 dependent launches with the same arguments every time: optionally replayed as an executable hipGraph
     // (DCS_BA_GRAPH=1, see dcs_ba_local_batch)
@@ -1738,6 +1757,7 @@ struct BaContext {
     double t_ldlt_us = 0, n_ldlt = 0, t_step_us = 0, n_step = 0;
     void release()
     {
+        drain();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         events.clear();
         if (base) (void)hipFree(base);
@@ -1746,6 +1766,8 @@ struct BaContext {
         if (stream) (void)hipStreamDestroy(stream);
         for (StepGraph& g : step_graph) drop_graph(g);
         for (hipStream_t& a : aux) { if (a) (void)hipStreamDestroy(a); a = nullptr; }
+        if (dl) (void)hipStreamDestroy(dl);
+        dl = nullptr;
         for (hipEvent_t& e : ev_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (ev_up) (void)hipEventDestroy(ev_up);
         ev_up = nullptr;
@@ -1754,6 +1776,7 @@ struct BaContext {
     ~BaContext() { release(); }
     int prepare(size_t arena_bytes, size_t stage_bytes, size_t n_words)
     {
+        drain();                                            // queued-ahead steps of the previous call (see tail_pending)
         int dev = 0;
         DCS_HIP(hipGetDevice(&dev));
         if (device != dev) release();
@@ -2322,12 +2345,25 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         t_wait += ms_since(tw0);
     }
-    for (int g = 1; g < G; ++g) {                         // the download waits for every group
-        DCS_HIP(hipEventRecord(ctx.ev_done[g - 1], ctx.aux[g - 1]));
-        DCS_HIP(hipStreamWaitEvent(st, ctx.ev_done[g - 1], 0));
+    // When every group has REPORTED its problems done (the progress words are stored with a system-scope release by the last block
+    // of k_post, after every result array and every BaCtl of the step), the steps still in the queues are no-ops: they return on
+    // state > ST_RETRY before they write anything but the progress words. The results then come down on a stream of their own
+    // instead of behind those 2 x 8 launches (~75 us of a 2 ms C4 solve). DCS_BA_DL_STREAM=0, or a batch that ran into max_steps,
+    // takes the ordered path: the download behind everything on the solver's streams.
+    static const bool dl_own = !(getenv("DCS_BA_DL_STREAM") && atoi(getenv("DCS_BA_DL_STREAM")) == 0);
+    if (dl_own && n_finished == G) {
+        if (!ctx.dl) DCS_HIP(BaContext::create_stream(&ctx.dl));
+        ctx.tail_pending = true;                            // set before anything can fail: the queues are not empty from here on
+        DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, ctx.dl));
+        DCS_HIP(hipStreamSynchronize(ctx.dl));
+    } else {
+        for (int g = 1; g < G; ++g) {                     // the download waits for every group
+            DCS_HIP(hipEventRecord(ctx.ev_done[g - 1], ctx.aux[g - 1]));
+            DCS_HIP(hipStreamWaitEvent(st, ctx.ev_done[g - 1], 0));
+        }
+        DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, st));
+        DCS_HIP(hipStreamSynchronize(st));
     }
-    DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, st));
-    DCS_HIP(hipStreamSynchronize(st));
     const float opt_ms = (float)ms_since(t_opt0);
     const BaCtl* h_ctls = reinterpret_cast<const BaCtl*>(landed(d_ctls));
     if (timing) {                                         // only the steps in which at least one problem ran a trial

@@ -275,3 +275,33 @@ def test_ba_reduced_system_sizes_around_the_slot_builds(pkg, oracle, synth, n_fr
     """n = 6 * free poses = 222 ... 252: k_ldlt_mfma's 18-slot build (n <= 240, 15 block rows) and its 20-slot build (16 block rows)."""
     pb = synth.ba_problem(n_poses=n_free + 3, n_fixed=3, n_points=400, obs_per_point=8, seed=100 + n_free)
     _compare(pkg.Optimizer.LocalBundleAdjustment(pb), _oracle_run(oracle, pb), pb)
+
+
+def test_ba_back_to_back_calls_do_not_inherit_the_previous_calls_progress(pkg, synth):
+    """A finished call returns while the steps it had queued ahead are still in the solver's streams (its results come down on a stream
+    of their own); those steps' k_post launches still store to the pinned progress words. The next call on the thread must drain them
+    before it resets the words -- otherwise it reads 'all problems done' from its predecessor and downloads before running a step.
+    Two different problems of the same size, alternated 40 times (single and as batches of 2): every result equals the first, isolated
+    solve of that problem bit for bit. The race is timing-dependent: against a side build without the drain (-DDCS_BA_NO_DRAIN) this
+    test failed in 2 of 3 runs on the MI355X box (through the library's own 'lost step' error both times, which nothing guarantees),
+    so a pass is evidence, not proof; the ordering argument is in BaContext::drain()."""
+    pa = pkg.Optimizer.prepare(synth.ba_problem(n_poses=14, n_fixed=3, n_points=220, obs_per_point=6, seed=301))
+    pb = pkg.Optimizer.prepare(synth.ba_problem(n_poses=14, n_fixed=3, n_points=220, obs_per_point=6, seed=302))
+    keys = ("poses", "points", "edge_chi2", "edge_outlier", "chi2_trace")
+    ref = {}
+    for name, p in (("a", pa), ("b", pb)):
+        r = p.solve()
+        ref[name] = ({k: np.array(r[k], copy=True) for k in keys}, list(r["n_iters"]), list(r["n_trials"]))
+    assert not np.array_equal(ref["a"][0]["poses"], ref["b"][0]["poses"])
+    for it in range(40):
+        for name, p in (("a", pa), ("b", pb)):
+            r = p.solve()
+            for k in keys:
+                assert np.array_equal(r[k], ref[name][0][k]), (it, name, k)
+            assert list(r["n_iters"]) == ref[name][1] and list(r["n_trials"]) == ref[name][2]
+    for it in range(10):
+        out = pkg.Optimizer.LocalBundleAdjustmentBatch([pa, pb] if it % 2 == 0 else [pb, pa])
+        names = ("a", "b") if it % 2 == 0 else ("b", "a")
+        for r, name in zip(out, names):
+            for k in keys:
+                assert np.array_equal(r[k], ref[name][0][k]), ("batch", it, name, k)
