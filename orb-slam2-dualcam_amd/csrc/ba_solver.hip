@@ -1457,8 +1457,11 @@ __global__ __launch_bounds__(256) void k_post(const BaProb* __restrict__ probs, 
         __hip_atomic_store(grid_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int step = (int)grid_ticket[1];
         grid_ticket[1] = (unsigned)step + 1u;
-        __hip_atomic_store(h_progress + 1, (int)nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(h_progress, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // ONE 64-bit word {finished problems : step}: the host decides from a single acquire load, so "all done" can never be seen
+        // ahead of the release that publishes the results (the blocks' agent-scope releases are acquired above, this release is
+        // system-scope and cumulative)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(h_progress), ((unsigned long long)(unsigned)(int)nd << 32) | (unsigned)step, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -2162,6 +2165,10 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     for (int k = 0; k < 16; ++k) h_words[k] = 0;
     for (int i = 0; i < NB; ++i) h_words[16 + i] = 0;
     const auto t_opt0 = now();
+    // From here on the solver's queues hold work that references the arena and the pinned words: EVERY return below -- the error
+    // returns of the feed loop included -- leaves the context marked, and the next prepare() / release() drains the streams before it
+    // resets or frees anything. Only the ordered download path, which ends with the queues empty, clears the mark.
+    ctx.tail_pending = true;
     DCS_HIP(hipMemcpyAsync(ctx.base, hs, rg.upload_end, hipMemcpyHostToDevice, st));
     DCS_HIP(hipMemsetAsync(ctx.base + rg.zero_begin, 0, rg.zero_end - rg.zero_begin, st));
     for (int i = 0; i < NB; ++i)
@@ -2314,8 +2321,9 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // costs the host 30 - 50 us per group.
     static const int kLookahead = getenv("DCS_BA_LOOKAHEAD") ? std::max(1, atoi(getenv("DCS_BA_LOOKAHEAD"))) : 2;
     auto load_words = [&](const Group& gr, int& step_done, int& n_done) {
-        step_done = __atomic_load_n(gr.words, __ATOMIC_ACQUIRE);
-        n_done = __atomic_load_n(gr.words + 1, __ATOMIC_RELAXED);
+        const unsigned long long w = __atomic_load_n(reinterpret_cast<const unsigned long long*>(gr.words), __ATOMIC_ACQUIRE);   // {done : step}, one word
+        step_done = (int)(unsigned)w;
+        n_done = (int)(w >> 32);
     };
     auto refresh_stop = [&] { for (int i = 0; i < NB; ++i) if (stop_requested(live[i])) __atomic_store_n(h_words + 16 + i, 1, __ATOMIC_RELAXED); };
     int steps = 0, n_finished = 0;
@@ -2353,7 +2361,6 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     static const bool dl_own = !(getenv("DCS_BA_DL_STREAM") && atoi(getenv("DCS_BA_DL_STREAM")) == 0);
     if (dl_own && n_finished == G) {
         if (!ctx.dl) DCS_HIP(BaContext::create_stream(&ctx.dl));
-        ctx.tail_pending = true;                            // set before anything can fail: the queues are not empty from here on
         DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, ctx.dl));
         DCS_HIP(hipStreamSynchronize(ctx.dl));
     } else {
@@ -2363,6 +2370,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, st));
         DCS_HIP(hipStreamSynchronize(st));
+        ctx.tail_pending = false;                           // every group's queue was waited for: nothing is in flight
     }
     const float opt_ms = (float)ms_since(t_opt0);
     const BaCtl* h_ctls = reinterpret_cast<const BaCtl*>(landed(d_ctls));

@@ -370,7 +370,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     // test at T: every pixel with score >= T does, so the score map holds exactly what the non-maximum suppression at T compares
     // (a neighbour whose score is missing has score < T <= s(p) and would lose anyway). 91 % of the cells of the benchmark
     // scene stop after the first pass, which scores a third fewer pixels than the minThFAST pass.
-    const int spare = dw * dh + 32;                // u16 slot behind the survivor list (and behind what an odd last row appends)
     int n_list = 0, base = 0;                      // survivors of the compass test; keypoints emitted
     dcs_candidate* const out = slots + (size_t)img * slots_per_image + cd.slot_base;
     // position of this lane among the set bits of a ballot: v_mbcnt_lo + v_mbcnt_hi
@@ -383,11 +382,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         // balloted one by one (ballot of a plain compare IS the compare's SGPR mask; a ballot of their OR would be rebuilt through
         // v_cndmask + v_cmp) and combined with scalar 64-bit logic.
         // b = the pixel 3 up and 3 left of the centre: every LDS offset is a non-negative immediate
-        auto compass = [&](const uint8_t* b, bool& brighter, bool& darker) {
-            const int v = b[3 * P + 3], hi = v + th, lo = v - th;
-            const int r0 = b[6 * P + 3], r4 = b[3 * P + 6], r8 = b[3], r12 = b[3 * P];
-            brighter = min(max(r0, r8), max(r4, r12)) > hi;
-            darker = max(min(r0, r8), min(r4, r12)) < lo;
+        // 16-bit VOP2 min / max / sub issue at twice the rate of their 32-bit forms on gfx950 (profiles/r03_valu_rate_probe.txt), and the
+        // two polarities fold into ONE compare: brighter <=> e - v > th, darker <=> v - f > th, so pass <=> max(e - v, v - f) > th.
+        auto compass = [&](const uint8_t* b) -> bool {
+            const uint16_t v = b[3 * P + 3];
+            const uint16_t r0 = b[6 * P + 3], r4 = b[3 * P + 6], r8 = b[3], r12 = b[3 * P];
+            const uint16_t e = min(max(r0, r8), max(r4, r12)), f = max(min(r0, r8), min(r4, r12));
+            const int16_t up = (int16_t)(uint16_t)(e - v), down = (int16_t)(uint16_t)(v - f);
+            return max(up, down) > (int16_t)th;
         };
         n_list = 0;
         if (dw <= 32) {                                  // two detection rows per round: lanes 0-31 row y, lanes 32-63 row y + 1
@@ -397,21 +399,18 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             unsigned yx = (unsigned)(((3 + (lane >> 5)) << 8) | (3 + (lane & 31)));
             unsigned long long m = 0;
             const unsigned list_addr = lds_addr(s_list);
-            unsigned spare_addr = list_addr + 2u * (unsigned)spare, end_addr = list_addr;       // end_addr: scalar, behind the last entry
-            asm volatile("" : "+v"(spare_addr));                                                 // keep it in a VGPR across the loop
+            unsigned end_addr = list_addr;                                                       // scalar, behind the last entry
             for (int yy = 0; yy < dh; yy += 2, yx += 0x200u, b += 2 * P) {                   // wave-uniform trip count
                 // Every lane evaluates the test (a lane outside the detection area reads the score map at worst: still inside
-                // the LDS allocation). The two compares are balloted one by one (the ballot of a plain compare IS its SGPR mask)
-                // and combined with scalar logic. No branch, no exec mask: a lane that has nothing to append writes the spare
-                // slot behind the list (v_cndmask on the lane's bit of m). When dh is odd the upper half-wave's last row lies
-                // below the detection area: whatever it appends comes after every valid entry and is cut off by the count below.
-                bool br, dk;
-                compass(b, br, dk);
-                m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & m_col;
+                // the LDS allocation); its ballot IS the compare's SGPR mask. No branch: the append is one LDS store under exec = m.
+                // When dh is odd the upper half-wave's last row lies below the detection area: whatever it appends comes after
+                // every valid entry and is cut off by the count below.
+                m = __builtin_amdgcn_ballot_w64(compass(b)) & m_col;
                 const unsigned at = ((unsigned)rank_in(m) << 1) + end_addr;
-                unsigned to;
-                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(to) : "v"(spare_addr), "v"(at), "s"(m));
-                *reinterpret_cast<__attribute__((address_space(3))) uint16_t*>((uintptr_t)to) = (uint16_t)yx;
+                // the store runs under exec = m (two scalar moves around it) instead of steering idle lanes to a spare slot with a
+                // v_cndmask: one vector instruction less per round, still no branch
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(m), "v"(at), "v"(yx) : "memory");
                 end_addr += 2u * (unsigned)__popcll(m);
             }
             n_list = (int)((end_addr - list_addr) >> 1);
@@ -420,11 +419,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             int y = 3 + lane / dw, x = 3 + lane % dw;            // pixel p = p0 + lane, advanced by 64 per round without dividing
             const int step_y = 64 / dw, step_x = 64 % dw;
             for (int p0 = 0; p0 < ndet; p0 += 64) {
-                bool br, dk;
-                compass(px + (y - 3) * P + (x - 3), br, dk);
+                const bool pass_c = compass(px + (y - 3) * P + (x - 3));
                 const bool in_range = p0 + lane < ndet;
-                const unsigned long long m = (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & __builtin_amdgcn_ballot_w64(in_range);
-                if ((br | dk) & in_range) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass_c) & __builtin_amdgcn_ballot_w64(in_range);
+                if (pass_c & in_range) s_list[n_list + rank_in(m)] = (uint16_t)((y << 8) | x);
                 n_list += __popcll(m);
                 y += step_y; x += step_x;
                 if (x >= dw + 3) { x -= dw; ++y; }
@@ -872,40 +870,19 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 constexpr int kPatchR = 18;                 // rotated pattern reach: max radius 18.38 -> |coord| <= 18
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
 constexpr int kPatchDw = 16;                // dwords per staged row: 4 x 16 B cover 37 bytes + <= 15 alignment bytes
-// fused variant (the Gaussian blur of the patch inside k_describe): raw rows y - 21 .. y + 21 staged like the blurred ones were,
-// horizontal pass -> 16-bit sums packed as ROW PAIRS (lo = even row, hi = odd row: the vertical pass is 4 v_dot2_u32_u16 per pixel),
-// vertical pass -> the 37 x 37 blurred patch, 40-byte rows, in place of the raw rows
+// fused variant (the Gaussian blur of the patch inside k_describe): the raw rows y - 21 .. y + 21 are staged in LDS like the blurred ones
+// were, the HORIZONTAL 7-tap pass is an i8 GEMM H = Raw x T on the matrix cores (v_mfma_i32_16x16x64_i8: one K-window of 64 input
+// columns covers the patch at any alignment; T = banded Toeplitz matrix of the taps, shifted by the patch's offset in its 16-byte
+// aligned rows), its 16-bit sums land in LDS packed as ROW PAIRS (lo = even row, hi = odd row), and the VERTICAL pass runs on demand at
+// the <= 512 pixels the tests read (4 v_dot2_u32_u16 each).
 constexpr int kRawR = kPatchR + 3;          // 21
-constexpr int kRawRows = 2 * kRawR + 1;     // 43 (+ 1 padding row: the odd half of the last row pair)
-constexpr int kHPairs = (kRawRows + 1) / 2; // 22
-constexpr int kHCols = 40;                  // columns of the horizontal sums / of the blurred patch (37 used)
-// Horizontal-pass tasks (row pair, dword column) that a test can reach: a rotated pattern point lies within 18.385 + 0.7072 < 19.1 of
-// the keypoint (rounding adds at most half a pixel per axis), so blurred pixel (r, c) is read only if r^2 + c^2 <= 364, and the sum
-// of raw row rho feeds the blurred rows rho - 3 .. rho + 3: 189 of the 220 tasks -- three rounds of a wave instead of four.
-struct HTaskTable { uint16_t t[192]; int n; };
-constexpr HTaskTable make_h_tasks()
-{
-    HTaskTable tb{};
-    tb.n = 0;
-    for (int rp = 0; rp < kHPairs; ++rp) {
-        int best = -1;
-        for (int half = 0; half < 2; ++half) {
-            const int rho = 2 * rp + half - kRawR;
-            if (rho > kRawR) continue;
-            for (int r = (rho - 3 < -kPatchR ? -kPatchR : rho - 3); r <= (rho + 3 > kPatchR ? kPatchR : rho + 3); ++r) {
-                int cm = 0;
-                while (cm < kPatchR && (cm + 1) * (cm + 1) + r * r <= 364) ++cm;
-                if (r * r <= 364 && cm > best) best = cm;
-            }
-        }
-        if (best < 0) continue;
-        for (int d = (kPatchR - best) >> 2; d <= (kPatchR + best) >> 2; ++d) tb.t[tb.n++] = (uint16_t)(rp | (d << 8));
-    }
-    for (int i = tb.n; i < 192; ++i) tb.t[i] = 0xFFFFu;
-    return tb;
-}
-__device__ const HTaskTable c_h_tasks = make_h_tasks();
-static_assert(make_h_tasks().n <= 192, "three rounds of 64 lanes");
+constexpr int kRawRows = 2 * kRawR + 1;     // 43
+constexpr int kRawTileRows = 48;            // 3 GEMM row tiles (rows 43 .. 47: whatever LDS holds, never read back)
+constexpr int kRawPitch = 80;               // bytes per staged raw row: 64 + 16, so that the 16-byte A-operand reads of 8 consecutive rows hit 8 different bank groups
+constexpr int kHPairs = 25;                 // row pairs of the 3 x 16 rows the GEMM produces (22 used) + 1: the last tile's third store spills 8 dwords
+constexpr int kHCols = 40;                  // columns of the horizontal sums (37 used); 2 * 40 dwords = 16 banks: the (g, g + 1) halves of a wave's store miss each other
+constexpr int kBTabEntries = 24;            // B operand rows: the 7 taps at byte offset d = -7 .. 16 of a 16-byte k-group (d = -7 and 16: all zero)
+typedef int v4i_t __attribute__((ext_vector_type(4)));
 #ifndef DCS_DESC_KP                          // tuning hook (scratch/ab builds)
 #define DCS_DESC_KP 16
 #endif
@@ -1002,8 +979,9 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
                                                   uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out, int n_images, int chunks,
                                                   const int32_t* __restrict__ dense_total, int dense_cap)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_patch[kDescWaves][FUSED ? (kRawRows + 1) * kPatchDw : kPatchRows * kPatchDw];
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[kDescWaves][FUSED ? kRawTileRows * kRawPitch / 4 : kPatchRows * kPatchDw];
     __shared__ __attribute__((aligned(16))) uint32_t s_hp[FUSED ? kDescWaves : 1][FUSED ? kHPairs * kHCols : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_btab[FUSED ? kBTabEntries * 4 : 4];
     __shared__ float4 s_pattern[256];
     __shared__ uint32_t s_mask[kIcMaskWords];
     __shared__ SelKp s_sel[kDescKp];
@@ -1035,6 +1013,19 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
             s_pattern[e] = float4{(float)pt.x, (float)pt.y, (float)pt.z, (float)pt.w};
         }
         for (int e = tid; e < kIcMaskWords; e += 64 * kDescWaves) s_mask[e] = prm.ic_mask[e];
+        if constexpr (FUSED) {
+            if (tid < kBTabEntries * 4) {                    // dword w of entry e: byte j = 4 w + b holds tap[j - d], d = e - 7
+                const int d = (tid >> 2) - 7;
+                unsigned v = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int t = 4 * (tid & 3) + bb - d;
+                    const unsigned tap = t == 0 || t == 6 ? 18u : t == 1 || t == 5 ? 34u : t == 2 || t == 4 ? 49u : t == 3 ? 55u : 0u;
+                    v |= tap << (8 * bb);
+                }
+                s_btab[tid] = v;
+            }
+        }
         if (tid < kDescKp) {
             const int i = i0 + tid;
             int src;
@@ -1179,7 +1170,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
     } else {
     uint32_t* patch = s_patch[wave];
     uint32_t* hp = s_hp[wave];
-    const int r_lane = lane >> 2, c4 = lane & 3;             // 16 rows x 4 x 16 B per wave pass; 43 rows = 3 passes
+    const int r_lane = lane >> 2, c4 = lane & 3;             // staging: 16 rows x 4 x 16 B per wave pass; 43 rows = 3 passes
+    const int mc = lane & 15, mg = lane >> 4;                // GEMM: A row / B column mc, k-group mg (k = 16 mg + byte); D: column mc, rows 4 mg + r
     uint4 q0, q1, q2;
     int shift = 0;
     bool wide = true, xedge = false;                         // this keypoint: 16-byte row loads possible; patch crosses the left / right border
@@ -1203,9 +1195,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         q2 = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(k.y - kRawR + min(r_lane + 32, kRawRows - 1), rv.h) * rv.pitch);
     };
     if (wave * kDescPerWave < n_here) fetch(wave * kDescPerWave);
-    const unsigned ht[3] = {c_h_tasks.t[lane], c_h_tasks.t[lane + 64], c_h_tasks.t[lane + 128]};      // this lane's horizontal-pass tasks
-    constexpr unsigned KA = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3 of the 7-tap kernel (k_blur's)
-    constexpr unsigned KB = 49u | (34u << 8) | (18u << 16);                 // taps 4..6
+    // u8 -> i8: x ^ 0x80 = x - 128, and sum_k tap[k] * 128 = 257 * 128 = 32896 comes back through the accumulator's initial value
+    const v4i_t c_init = {32896, 32896, 32896, 32896};
 #pragma unroll 1
     for (int kk = 0; kk < kDescPerWave; ++kk) {
         const int kq = wave * kDescPerWave + kk;
@@ -1214,16 +1205,16 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         __builtin_amdgcn_wave_barrier();
         uint8_t* praw = reinterpret_cast<uint8_t*>(patch);
         if (wide) {                                           // wave-uniform
-            reinterpret_cast<uint4*>(patch)[lane] = q0;
-            reinterpret_cast<uint4*>(patch)[lane + 64] = q1;
-            if (lane + 128 < kRawRows * 4) reinterpret_cast<uint4*>(patch)[lane + 128] = q2;
-            if (xedge) {                                      // at most 2 columns per side lie outside the row: BORDER_REFLECT_101
+            *reinterpret_cast<uint4*>(praw + r_lane * kRawPitch + 16 * c4) = q0;
+            *reinterpret_cast<uint4*>(praw + (r_lane + 16) * kRawPitch + 16 * c4) = q1;
+            if (r_lane + 32 < kRawRows) *reinterpret_cast<uint4*>(praw + (r_lane + 32) * kRawPitch + 16 * c4) = q2;
+            if (xedge) {                                      // at most 2 columns per side lie outside the row (19 <= x <= w - 20): BORDER_REFLECT_101
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (lane < kRawRows) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int jj = e < 2 ? e : kRawRows - 4 + e, g = kx - kRawR + jj;      // patch columns 0, 1, 41, 42
-                        if (g < 0 || g >= kw) praw[lane * 64 + shift + jj] = praw[lane * 64 + shift + (reflect101(g, kw) - (kx - kRawR))];
+                        if (g < 0 || g >= kw) praw[lane * kRawPitch + shift + jj] = praw[lane * kRawPitch + shift + (reflect101(g, kw) - (kx - kRawR))];
                     }
                 }
             }
@@ -1233,7 +1224,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
             const uint8_t* rimg = rv.base + (size_t)img * rv.img_stride;
             for (int i = lane; i < kRawRows * kRawRows; i += 64) {
                 const int r = i / kRawRows, j = i - r * kRawRows;
-                praw[r * 64 + shift + j] = rimg[(size_t)reflect101(k.y - kRawR + r, rv.h) * rv.pitch + reflect101(k.x - kRawR + j, rv.w)];
+                praw[r * kRawPitch + shift + j] = rimg[(size_t)reflect101(k.y - kRawR + r, rv.h) * rv.pitch + reflect101(k.x - kRawR + j, rv.w)];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1241,28 +1232,32 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int shift_now = shift;
         if (kq + 1 < min(n_here, wave * kDescPerWave + kDescPerWave)) fetch(kq + 1);        // next keypoint's loads fly during this one's work
-        // ---- horizontal pass: task = (row pair, 4 output columns); h[c] = sum_k K[k] raw[c + k] (<= 65 535)
+        // ---- horizontal pass: h[row][c] = sum_k tap[k] raw[row][c + k] (<= 65 535) for 48 rows x 37 columns as 3 x 3 matrix instructions.
+        // A = 16 staged bytes of row 16 mt + mc, k-group mg; B (column tile nt) = the taps at byte offset shift + 16 nt + mc - 16 mg of that
+        // k-group, read from the 24-entry table. Register r of lane (mc, mg) holds row 16 mt + 4 mg + r, column 16 nt + mc: rows
+        // (4 mg, 4 mg + 1) and (4 mg + 2, 4 mg + 3) are two row pairs, stored with one ds_write2_b32. Column tile 2 (columns 32 .. 47, 32 .. 36
+        // used) is stored FIRST: its columns 40 .. 47 spill into columns 0 .. 7 of the next row pair, which tile 0's store -- later in
+        // program order, LDS operations of a wave complete in order -- overwrites (the very last spill lands in the padding pair).
         {
-            const int a0 = shift_now >> 2, sh = shift_now & 3;
+            v4i_t bt[3];
 #pragma unroll
-            for (int round = 0; round < 3; ++round) {
-                const unsigned task = ht[round];
-                if (task == 0xFFFFu) continue;
-                const int rp = task & 255, d = task >> 8;
-                unsigned hh[2][4];
+            for (int nt = 0; nt < 3; ++nt) {
+                const int e = min(max(shift_now + 16 * nt + mc - 16 * mg + 7, 0), kBTabEntries - 1);
+                bt[nt] = *reinterpret_cast<const v4i_t*>(s_btab + 4 * e);
+            }
+            uint32_t* hrow = hp + (2 * mg) * kHCols + mc;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const uint32_t* row = patch + (2 * rp + half) * kPatchDw + a0 + d;
-                    const unsigned w0 = row[0], w1 = row[1], w2 = row[2], w3 = row[3];
-                    const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh), d1 = __builtin_amdgcn_alignbyte(w2, w1, sh), d2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
-                    hh[half][0] = __builtin_amdgcn_udot4(d1, KB, __builtin_amdgcn_udot4(d0, KA, 0u, false), false);
-                    hh[half][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0u, false), false);
-                    hh[half][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0u, false), false);
-                    hh[half][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0u, false), false);
-                }
-                uint4 o;
-                o.x = hh[0][0] | (hh[1][0] << 16); o.y = hh[0][1] | (hh[1][1] << 16); o.z = hh[0][2] | (hh[1][2] << 16); o.w = hh[0][3] | (hh[1][3] << 16);
-                *reinterpret_cast<uint4*>(hp + rp * kHCols + 4 * d) = o;
+            for (int mt = 0; mt < 3; ++mt) {
+                v4i_t a = *reinterpret_cast<const v4i_t*>(praw + (16 * mt + mc) * kRawPitch + 16 * mg);
+                a ^= (v4i_t){(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+                const v4i_t d2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[2], c_init, 0, 0, 0);
+                const v4i_t d0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[0], c_init, 0, 0, 0);
+                const v4i_t d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[1], c_init, 0, 0, 0);
+                uint32_t* o = hrow + (8 * mt) * kHCols;
+                o[32] = (unsigned)d2.x | ((unsigned)d2.y << 16); o[32 + kHCols] = (unsigned)d2.z | ((unsigned)d2.w << 16);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // keeps the spilling store ahead of the ones that overwrite its spill
+                o[0] = (unsigned)d0.x | ((unsigned)d0.y << 16); o[kHCols] = (unsigned)d0.z | ((unsigned)d0.w << 16);
+                o[16] = (unsigned)d1.x | ((unsigned)d1.y << 16); o[16 + kHCols] = (unsigned)d1.z | ((unsigned)d1.w << 16);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
