@@ -351,16 +351,13 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // blur on the auxiliary stream, overlapping FAST (DCS_ORB_NO_OVERLAP=1 serialises it for clean timings).
     // DCS_ORB_BLUR_LATE=1 starts it after FAST instead (measured slower: it then collides with the latency-bound
     // compaction + quadtree kernels, 1.64 vs 1.55 ms per 128 dual frames).
-    // fused_blur: no blur kernels, no blurred pyramid -- k_describe blurs every keypoint's 43 x 43 raw patch itself
-    // (dcs_orb_debug_level makes the blurred level on demand). Bit-exact either way. The fused kernel costs a fixed amount per KEYPOINT
-    // (describe 400 -> 635 us per 512 x 1000 keypoints), the blur kernels a fixed amount per PIXEL and they slow FAST down while
-    // they run next to it (FAST 840 -> 630 us without them). Measured (kfeatures/s, fused vs separate): 640 x 480 / 1000 features
-    // 281 vs 282-286 k (950 pyramid pixels per feature), 1280 x 720 / 2000: 173 vs 166 k (1 425 pixels per feature), one dual frame
-    // per call 0.268 vs 0.286 ms (five launches fewer). Default: fused from 1 200 pyramid pixels per requested feature, and for
-    // calls too small to fill the chip; DCS_ORB_FUSED_BLUR=0 / 1 (read when the handle is created) forces one.
-    double pyr_px = 0;
-    for (int l = 0; l < L; ++l) pyr_px += (double)raw.lv[l].w * raw.lv[l].h;
-    const bool fused_blur = fused_mode >= 0 ? fused_mode != 0 : (pyr_px >= 1200.0 * t.nfeatures || n_images <= 8);
+    // fused_blur (the DEFAULT since round 3): no blur kernels, no blurred pyramid, no auxiliary stream -- k_describe<FUSED> blurs every
+    // keypoint's 43 x 43 raw patch itself (horizontal pass on the matrix cores, vertical pass at the tested pixels only;
+    // dcs_orb_debug_level makes the blurred level on demand). Bit-exact either way. Measured on the headline workload (640 x 480 / 1000
+    // features, 512 images per step): 313 k kfeatures/s fused against 289 k with the separate kernels -- FAST runs at its solo speed once
+    // the blur no longer competes for the vector ALUs (800 -> 619 us) and the fused describe costs 455 instead of 388 us.
+    // DCS_ORB_FUSED_BLUR=0 (read when the handle is created) selects the separate blur kernels (the debug / A-B path).
+    const bool fused_blur = fused_mode >= 0 ? fused_mode != 0 : true;
     last_blur_valid = !fused_blur;
     static const bool blur_early = getenv("DCS_ORB_BLUR_LATE") == nullptr;
     hipStream_t sb = no_overlap ? stream : s_aux;

@@ -867,6 +867,17 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+// cvRound of a steered pattern coordinate (|x| < 2^22) WITHOUT leaving the float pipe: x + 1.5 * 2^23 rounds to the integer grid with the
+// FPU's round-to-nearest-even -- v_rndne_f32's rule -- and its bit pattern is kRnBias + rint(x). The callers fold kRnBias into their
+// LDS base addresses (32-bit wrap-around arithmetic), so the rounding costs one v_add_f32 instead of v_rndne_f32 + v_cvt_i32_f32.
+constexpr unsigned kRnBias = 0x4B400000u;
+#ifdef DCS_EXP_RN
+__device__ __forceinline__ unsigned rn_biased(float x) { return (unsigned)__float2int_rn(x) + kRnBias; }
+#else
+__device__ __forceinline__ unsigned rn_biased(float x) { return __float_as_uint(__fadd_rn(x, 12582912.0f)); }
+#endif
+typedef __attribute__((address_space(3))) const uint8_t* lds_u8_ptr;
+typedef __attribute__((address_space(3))) const uint32_t* lds_u32_ptr;
 constexpr int kPatchR = 18;                 // rotated pattern reach: max radius 18.38 -> |coord| <= 18
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
 constexpr int kPatchDw = 16;                // dwords per staged row: 4 x 16 B cover 37 bytes + <= 15 alignment bytes
@@ -879,7 +890,7 @@ constexpr int kRawR = kPatchR + 3;          // 21
 constexpr int kRawRows = 2 * kRawR + 1;     // 43
 constexpr int kRawTileRows = 48;            // 3 GEMM row tiles (rows 43 .. 47: whatever LDS holds, never read back)
 constexpr int kRawPitch = 80;               // bytes per staged raw row: 64 + 16, so that the 16-byte A-operand reads of 8 consecutive rows hit 8 different bank groups
-constexpr int kHPairs = 25;                 // row pairs of the 3 x 16 rows the GEMM produces (22 used) + 1: the last tile's third store spills 8 dwords
+constexpr int kHPairs = 24;                 // row pairs of the 3 x 16 rows the GEMM produces (22 used)
 constexpr int kHCols = 40;                  // columns of the horizontal sums (37 used); 2 * 40 dwords = 16 banks: the (g, g + 1) halves of a wave's store miss each other
 constexpr int kBTabEntries = 24;            // B operand rows: the 7 taps at byte offset d = -7 .. 16 of a 16-byte k-group (d = -7 and 16: all zero)
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -972,15 +983,15 @@ int launch_debug_sincosf(const float* d_x, int n, float* d_c, float* d_s, hipStr
 //   B. one LANE per keypoint: fastAtan2 + libm's cosf / sinf (glibc_sincosf: the reference calls the float overloads,
 //      ORBextractor.cc:112-113) -- issued once per 64 keypoints instead of once per keypoint-wave -- and the cv::KeyPoint.
 //   C. one wave per keypoint: 37x64 B blurred neighbourhood -> LDS (16-byte loads), 4 rounds of 64 rBRIEF tests.
+// FUSED keeps four workgroups per CU: <= 40 960 B of LDS each and <= 128 registers per lane (amdgpu_waves_per_eu makes that the compiler's budget)
 template <bool FUSED>       // FUSED: no blurred pyramid exists, phase C blurs the raw patch itself
-__global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
+__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(4))) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
                                                   const SelKp* __restrict__ sel, const int32_t* __restrict__ img_off,
                                                   const int32_t* __restrict__ lvl_cnt, dcs_keypoint* __restrict__ kp_out,
                                                   uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out, int n_images, int chunks,
                                                   const int32_t* __restrict__ dense_total, int dense_cap)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_patch[kDescWaves][FUSED ? kRawTileRows * kRawPitch / 4 : kPatchRows * kPatchDw];
-    __shared__ __attribute__((aligned(16))) uint32_t s_hp[FUSED ? kDescWaves : 1][FUSED ? kHPairs * kHCols : 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_btab[FUSED ? kBTabEntries * 4 : 4];
     __shared__ float4 s_pattern[256];
     __shared__ uint32_t s_mask[kIcMaskWords];
@@ -1014,16 +1025,16 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         }
         for (int e = tid; e < kIcMaskWords; e += 64 * kDescWaves) s_mask[e] = prm.ic_mask[e];
         if constexpr (FUSED) {
-            if (tid < kBTabEntries * 4) {                    // dword w of entry e: byte j = 4 w + b holds tap[j - d], d = e - 7
-                const int d = (tid >> 2) - 7;
+            for (int e = tid; e < kBTabEntries * 4; e += 64 * kDescWaves) {      // dword w of entry e: byte j = 4 w + b holds tap[j - d], d = e - 7
+                const int d = (e >> 2) - 7;
                 unsigned v = 0;
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) {
-                    const int t = 4 * (tid & 3) + bb - d;
+                    const int t = 4 * (e & 3) + bb - d;
                     const unsigned tap = t == 0 || t == 6 ? 18u : t == 1 || t == 5 ? 34u : t == 2 || t == 4 ? 49u : t == 3 ? 55u : 0u;
                     v |= tap << (8 * bb);
                 }
-                s_btab[tid] = v;
+                s_btab[e] = v;
             }
         }
         if (tid < kDescKp) {
@@ -1148,7 +1159,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         reinterpret_cast<uint4*>(patch)[lane] = q0;
         reinterpret_cast<uint4*>(patch)[lane + 64] = q1;
         if (lane + 128 < kPatchRows * 4) reinterpret_cast<uint4*>(patch)[lane + 128] = q2;
-        const uint8_t* pb = reinterpret_cast<const uint8_t*>(patch) + kPatchR * (kPatchDw * 4) + kPatchR + shift;
+        // address of patch pixel (r, c) = pb + 64 r + c; with biased coordinates the two biases go into the base
+        const unsigned pb = lds_addr(patch) + (unsigned)(kPatchR * (kPatchDw * 4) + kPatchR + shift) - (kPatchDw * 4 + 1) * kRnBias;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1158,18 +1170,19 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const float4 pt = s_pattern[it * 64 + lane];
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
-            const int t0 = pb[r0 * (kPatchDw * 4) + c0], t1 = pb[r1 * (kPatchDw * 4) + c1];
+            const unsigned r0 = rn_biased(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+            const unsigned c0 = rn_biased(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+            const unsigned r1 = rn_biased(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+            const unsigned c1 = rn_biased(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+            const int t0 = *(lds_u8_ptr)(uintptr_t)(pb + r0 * (kPatchDw * 4) + c0), t1 = *(lds_u8_ptr)(uintptr_t)(pb + r1 * (kPatchDw * 4) + c1);
             const unsigned long long m = __ballot(t0 < t1);  // bit j of m = test 64*it + j  (LSB-first bytes)
             if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * it) = m;
         }
     }
     } else {
     uint32_t* patch = s_patch[wave];
-    uint32_t* hp = s_hp[wave];
+    uint32_t* hp = patch;                                    // the GEMM works in place: 16 staged rows (16 x 80 B) become 8 row pairs (8 x 160 B)
+    static_assert(16 * kRawPitch == 8 * kHCols * 4 && kRawTileRows * kRawPitch == kHPairs * kHCols * 4, "in-place horizontal pass");
     const int r_lane = lane >> 2, c4 = lane & 3;             // staging: 16 rows x 4 x 16 B per wave pass; 43 rows = 3 passes
     const int mc = lane & 15, mg = lane >> 4;                // GEMM: A row / B column mc, k-group mg (k = 16 mg + byte); D: column mc, rows 4 mg + r
     uint4 q0, q1, q2;
@@ -1235,29 +1248,27 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         // ---- horizontal pass: h[row][c] = sum_k tap[k] raw[row][c + k] (<= 65 535) for 48 rows x 37 columns as 3 x 3 matrix instructions.
         // A = 16 staged bytes of row 16 mt + mc, k-group mg; B (column tile nt) = the taps at byte offset shift + 16 nt + mc - 16 mg of that
         // k-group, read from the 24-entry table. Register r of lane (mc, mg) holds row 16 mt + 4 mg + r, column 16 nt + mc: rows
-        // (4 mg, 4 mg + 1) and (4 mg + 2, 4 mg + 3) are two row pairs, stored with one ds_write2_b32. Column tile 2 (columns 32 .. 47, 32 .. 36
-        // used) is stored FIRST: its columns 40 .. 47 spill into columns 0 .. 7 of the next row pair, which tile 0's store -- later in
-        // program order, LDS operations of a wave complete in order -- overwrites (the very last spill lands in the padding pair).
+        // (4 mg, 4 mg + 1) and (4 mg + 2, 4 mg + 3) are two row pairs, stored with one ds_write2_b32 -- IN PLACE: the 8 row pairs of a
+        // row tile take exactly the bytes of its 16 staged rows, every lane has read its A operand by then (LDS operations of a wave
+        // complete in order), and column tile 2 (columns 32 .. 47) stores only its first 8 columns, so nothing reaches the next tile's rows.
         {
             v4i_t bt[3];
+            // (a 111-entry table without the clamps costs 1.4 KB of LDS: 42.2 KB per workgroup = three workgroups per CU instead of four, +15 % kernel time)
+            const int e0 = shift_now + mc - 16 * mg + 7;
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) {
-                const int e = min(max(shift_now + 16 * nt + mc - 16 * mg + 7, 0), kBTabEntries - 1);
-                bt[nt] = *reinterpret_cast<const v4i_t*>(s_btab + 4 * e);
-            }
+            for (int nt = 0; nt < 3; ++nt) bt[nt] = *reinterpret_cast<const v4i_t*>(s_btab + 4 * min(max(e0 + 16 * nt, 0), kBTabEntries - 1));
             uint32_t* hrow = hp + (2 * mg) * kHCols + mc;
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) {
                 v4i_t a = *reinterpret_cast<const v4i_t*>(praw + (16 * mt + mc) * kRawPitch + 16 * mg);
                 a ^= (v4i_t){(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
-                const v4i_t d2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[2], c_init, 0, 0, 0);
                 const v4i_t d0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[0], c_init, 0, 0, 0);
                 const v4i_t d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[1], c_init, 0, 0, 0);
+                const v4i_t d2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[2], c_init, 0, 0, 0);
                 uint32_t* o = hrow + (8 * mt) * kHCols;
-                o[32] = (unsigned)d2.x | ((unsigned)d2.y << 16); o[32 + kHCols] = (unsigned)d2.z | ((unsigned)d2.w << 16);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // keeps the spilling store ahead of the ones that overwrite its spill
                 o[0] = (unsigned)d0.x | ((unsigned)d0.y << 16); o[kHCols] = (unsigned)d0.z | ((unsigned)d0.w << 16);
                 o[16] = (unsigned)d1.x | ((unsigned)d1.y << 16); o[16 + kHCols] = (unsigned)d1.z | ((unsigned)d1.w << 16);
+                if (mc < 8) { o[32] = (unsigned)d2.x | ((unsigned)d2.y << 16); o[32 + kHCols] = (unsigned)d2.z | ((unsigned)d2.w << 16); }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1267,12 +1278,14 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
         // sums = 4 row pairs, taps arranged by the parity of q: 4 v_dot2_u32_u16 per pixel
         const float a = s_cos[kq], b = s_sin[kq];
         uint8_t* dout = desc_out + ((size_t)img * cap + i0 + kq) * 32;
-        auto blurred_at = [&](int r, int c) {                // r, c in -18 .. 18
-            const int q = r + kPatchR, m = q >> 1;
-            const bool odd = q & 1;
+        // biased coordinates (kRnBias + r, kRnBias + c; kRnBias is even): row pair (r + 18) >> 1 = (rb >> 1) - kRnBias / 2 + 9, parity = rb & 1,
+        // column c + 18; the constants go into the base address
+        const unsigned hp_base = lds_addr(hp) + (unsigned)(9 * kHCols * 4 + kPatchR * 4) - (kRnBias / 2) * (kHCols * 4) - kRnBias * 4;
+        auto blurred_at = [&](unsigned rb, unsigned cb) {
+            const bool odd = rb & 1;
             const unsigned W0 = odd ? (18u << 16) : (18u | (34u << 16)), W1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16)),
                            W2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), W3 = odd ? (34u | (18u << 16)) : 18u;
-            const uint32_t* col = hp + m * kHCols + (c + kPatchR);
+            const lds_u32_ptr col = (lds_u32_ptr)(uintptr_t)(hp_base + (rb >> 1) * (kHCols * 4) + (cb << 2));
             unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[0]), __builtin_bit_cast(ushort2_t, W0), 32768u, false);
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[kHCols]), __builtin_bit_cast(ushort2_t, W1), acc, false);
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[2 * kHCols]), __builtin_bit_cast(ushort2_t, W2), acc, false);
@@ -1282,10 +1295,10 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(LevelSet raw, Leve
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const float4 pt = s_pattern[it * 64 + lane];
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+            const unsigned r0 = rn_biased(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+            const unsigned c0 = rn_biased(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+            const unsigned r1 = rn_biased(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+            const unsigned c1 = rn_biased(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
             const unsigned t0 = blurred_at(r0, c0), t1 = blurred_at(r1, c1);
             const unsigned long long m = __ballot(t0 < t1);  // bit j of m = test 64*it + j  (LSB-first bytes)
             if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * it) = m;
