@@ -376,8 +376,32 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         if (no_overlap) DCS_HIP(hipEventRecord(ev_t[1], stream));      // FAST timing starts after the blur
     }
 
-    if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                d_cell_count.p, max_rw, max_rh, stream, cells_early, n_cells - cells_early))) return rc;
+    if (cells_early > 0) {
+        if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
+                                    d_cell_count.p, max_rw, max_rh, stream, cells_early, n_cells - cells_early))) return rc;
+    } else {
+        // One launch per LDS size class: a cell's workgroup (one wave) holds its ROI, score map and survivor list in LDS, sized for the
+        // largest ROI of the LAUNCH, and that footprint decides how many cells a CU holds -- 5 104 B for the 38 x 38 ROIs of levels 0-3 of
+        // the 640 x 480 pyramid = 32 waves per CU, 5.5 KB for levels 4-6 = 29, 6.6 KB for the 43-wide cells of level 7 = 24. One launch
+        // sized for level 7's twelve cells held every level at 24 (DCS_ORB_FAST_GROUPS=0 restores it).
+        static const bool grouped = !(getenv("DCS_ORB_FAST_GROUPS") && atoi(getenv("DCS_ORB_FAST_GROUPS")) == 0);
+        auto wg_per_cu = [](int rw, int rh) { return std::min(32, 163840 / std::max(fast_cells_lds_bytes(rw, rh), 1)); };
+        int l0 = 0;
+        while (l0 < L) {
+            int grw = 7, grh = 7, l1 = l0;
+            for (; l1 < L; ++l1) {
+                int lrw = 7, lrh = 7;
+                for (int c = h_level_cell_begin[l1]; c < h_level_cell_begin[l1 + 1]; ++c) { lrw = std::max(lrw, (int)h_cells[c].rw); lrh = std::max(lrh, (int)h_cells[c].rh); }
+                const int mrw = std::max(grw, lrw), mrh = std::max(grh, lrh);
+                if (grouped && l1 > l0 && !(wg_per_cu(lrw, lrh) == wg_per_cu(grw, grh) && wg_per_cu(mrw, mrh) == wg_per_cu(grw, grh))) break;
+                grw = mrw; grh = mrh;
+            }
+            const int c0 = h_level_cell_begin[l0], c1 = h_level_cell_begin[l1];
+            if (c1 > c0 && (rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
+                                                   d_cell_count.p, grw, grh, stream, c0, c1 - c0))) return rc;
+            l0 = l1;
+        }
+    }
     DCS_HIP(hipEventRecord(ev_t[2], stream));
     if (cells_early > 0) DCS_HIP(hipStreamWaitEvent(stream, ev_fast_early, 0));      // the compaction needs every cell's count
     if (!(no_overlap || blur_early) && (rc = blur_stage())) return rc;

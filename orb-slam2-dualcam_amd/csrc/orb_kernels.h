@@ -61,6 +61,7 @@ struct OctScratch {
 int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_cols /* {sx, 0, a0, a1} per destination column */,
                   const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s);
 
+int fast_cells_lds_bytes(int max_rw, int max_rh);       // LDS of one cell's workgroup when the launch's largest ROI is max_rw x max_rh
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
                       int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s,

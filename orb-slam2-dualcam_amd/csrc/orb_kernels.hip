@@ -481,6 +481,16 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     if (lane == 0) cell_count[(size_t)img * n_cells + cell] = min(base, (int)cd.cap);
 }
 
+// LDS of one cell's workgroup for a launch whose largest ROI is max_rw x max_rh (the host groups levels by this figure, orb_extract.cpp)
+int fast_cells_lds_bytes(int max_rw, int max_rh)
+{
+    const int P = (max_rw + 7 <= 48) ? 48 : (max_rw + 15 <= 64) ? 64 : 128;      // shift (<= 7 or 15) + row fits the pitch
+    const int map_bytes = ((max_rh * P) + 15) & ~15;
+    const int list_bytes = ((((max_rw - 6) * (max_rh - 6) + 32) * 2) + 15) & ~15;      // + 32 entries of an odd last row
+    const int sc_bytes = ((max_rw - 6 + 2) * (max_rh - 6 + 2) + 15) & ~15;             // detection area + 1-px rim, rows packed (byte accesses only)
+    return map_bytes + sc_bytes + list_bytes;
+}
+
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
                       int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s, int cell0, int n_launch)
@@ -489,8 +499,8 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
     if (n_launch <= 0) return DCS_OK;
     const int P = (max_rw + 7 <= 48) ? 48 : (max_rw + 15 <= 64) ? 64 : 128;      // shift (<= 7 or 15) + row fits the pitch
     const int map_bytes = ((max_rh * P) + 15) & ~15;
-    const int list_bytes = ((((max_rw - 6) * (max_rh - 6) + 33) * 2) + 15) & ~15;      // + 32 entries of an odd last row + the spare slot
-    const int sc_pitch = ((max_rw - 6 + 2) + 3) & ~3;              // detection width + 1-px rim
+    const int list_bytes = ((((max_rw - 6) * (max_rh - 6) + 32) * 2) + 15) & ~15;      // + 32 entries of an odd last row
+    const int sc_pitch = max_rw - 6 + 2;                           // detection width + 1-px rim
     const int sc_bytes = (sc_pitch * (max_rh - 6 + 2) + 15) & ~15;
     const size_t shmem = (size_t)map_bytes + sc_bytes + list_bytes;
     static const int dbg_stop = getenv("DCS_FAST_STOP") ? atoi(getenv("DCS_FAST_STOP")) : 0;      // only read by -DDCS_FAST_SECTIONS builds
