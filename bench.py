@@ -58,6 +58,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-host-api", action="store_true", help="skip the latency / with_transfers legs")
     ap.add_argument("--lanes", type=int, default=1, help="independent extractor handles/streams the batch is split over (overlaps latency-bound kernels)")
     ap.add_argument("--serial", action="store_true", help="profiling aid: synchronise after the extraction and after the matching of every step (no kernel of one overlaps the other); with DCS_ORB_NO_OVERLAP=1 every kernel runs alone")
+    ap.add_argument("--exchange", choices=("cabi", "torch"), default="cabi",
+                    help="N > 1 (or any run under a rank environment): the per-step feature all-gather goes through the library's own RCCL communicator "
+                         "(dcs_features_allgather, default) or through torch.distributed + pack / unpack")
+    ap.add_argument("--input-sets", type=int, default=3, help="distinct HBM-resident input batches rotated across steps (3 x 157 MB > the 256 MB Infinity Cache)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU check of the N > 1 entry: launcher -> ranks -> gloo process group -> the feature all-gather, then one JSON line")
     return ap.parse_args(argv)
@@ -111,23 +115,32 @@ class Pipeline:
     """extraction + matching of `streams` x `frames` dual frames per step, HBM-resident, double-buffered feature slots:
     matching of step i (main stream) overlaps the extraction of step i + 1 (extractor streams)."""
 
-    def __init__(self, pkg, torch, dev, local_rank, W, H, NF, streams, frames, n_lanes, stream_base, n_events):
+    def __init__(self, pkg, torch, dev, local_rank, W, H, NF, streams, frames, n_lanes, stream_base, n_events, n_sets=1):
         synth = pkg.synth
         self.pkg, self.torch, self.dev = pkg, torch, dev
         self.W, self.H, self.NF, self.streams, self.frames = W, H, NF, streams, frames
         P = self.P = streams * frames
         n_unique = min(frames, 8) if streams == 1 else min(frames, 2)
         self.n_unique = n_unique
+        # `n_sets` distinct input batches, rotated step by step: set r holds the synthetic frames r * n_unique .. (r + 1) * n_unique - 1 of
+        # every stream, so no step re-reads the images of the step before it out of the Infinity Cache
+        self.n_sets = n_sets = max(1, n_sets)
         self.host_frames = {}
-        imgs = []
-        for s in range(streams):
-            for f in range(n_unique):
-                self.host_frames[(s, f)] = synth.frame_pair(W, H, stream_base + s, f)
-        for s in range(streams):
-            for f in range(frames):
-                imgs.extend(self.host_frames[(s, f % n_unique)])
-        self.host_imgs = np.stack(imgs)
-        self.d_img = torch.from_numpy(self.host_imgs).to(dev)
+        self.d_imgs = []
+        for r in range(n_sets):
+            imgs = []
+            for s in range(streams):
+                for f in range(n_unique):
+                    self.host_frames[(s, r * n_unique + f)] = synth.frame_pair(W, H, stream_base + s, r * n_unique + f)
+            for s in range(streams):
+                for f in range(frames):
+                    imgs.extend(self.host_frames[(s, r * n_unique + f % n_unique)])
+            host = np.stack(imgs)
+            if r == 0:
+                self.host_imgs = host
+            self.d_imgs.append(torch.from_numpy(host).to(dev))
+        self.d_img = self.d_imgs[0]
+        self.set_features = [None] * n_sets           # keypoints one step returns for input set r (filled by run())
         n_lanes = self.n_lanes = max(1, min(n_lanes, P))
         self.lane_pairs = [P // n_lanes + (1 if i < P % n_lanes else 0) for i in range(n_lanes)]
         self.exts = [pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local_rank, max_images=2 * lp) for lp in self.lane_pairs]
@@ -177,7 +190,7 @@ class Pipeline:
             a, b = 2 * first, 2 * (first + self.lane_pairs[li])
             if it >= self.NB:
                 self.lane_streams[li].wait_event(self.match_done[cur])
-            self.exts[li].extract_batch_device(self.d_img[a:b], d_kp[NP + a:NP + b], d_desc[NP + a:NP + b], d_n[NP + a:NP + b], self.cap,
+            self.exts[li].extract_batch_device(self.d_imgs[it % self.n_sets][a:b], d_kp[NP + a:NP + b], d_desc[NP + a:NP + b], d_n[NP + a:NP + b], self.cap,
                                                stream=self.lane_streams[li].cuda_stream)
             self.lane_done[li].record(self.lane_streams[li])
             first += self.lane_pairs[li]
@@ -206,8 +219,21 @@ class Pipeline:
     def features_per_step(self):
         return int(self.last_slots()[2][self.NP:].sum().item())
 
+    def features_in_steps(self, first_step, n_steps):
+        """keypoints returned by steps [first_step, first_step + n_steps) (input set = step number mod n_sets)"""
+        return sum(self.set_features[(first_step + i) % self.n_sets] for i in range(n_steps))
+
     def run(self, steps, warmup, barrier=None):
         torch = self.torch
+        # set-up, outside warm-up and timing: one step per input set to learn how many keypoints each set yields (the step counter is
+        # realigned to a multiple of n_sets afterwards, so "set = step mod n_sets" holds for every later step)
+        if self.set_features[0] is None:
+            while self.step_no % self.n_sets:
+                self.step()
+            for r in range(self.n_sets):
+                self.step()
+                torch.cuda.synchronize()
+                self.set_features[r] = self.features_per_step()
         for _ in range(warmup):
             self.step()
         torch.cuda.synchronize()
@@ -325,42 +351,81 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # Under a rank environment (the driver's torchrun, bench.py's own launcher, or the GPU test that sets RANK / WORLD_SIZE for one rank)
+    # the run is "distributed" even at world size 1: RCCL is initialised and the per-step feature exchange runs inside the timed region.
+    distributed = in_rank_env
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     pkg = entry.load_package()
     synth = pkg.synth
     dev = torch.device("cuda", local_rank)
 
     P, W, H, NF = args.pairs, args.width, args.height, args.nfeatures
-    n_ev = args.steps + args.warmup
-    pipe = Pipeline(pkg, torch, dev, local_rank, W, H, NF, 1, P, args.lanes, rank, n_ev)
+    n_ev = args.steps + args.warmup + 2 * args.input_sets
+    pipe = Pipeline(pkg, torch, dev, local_rank, W, H, NF, 1, P, args.lanes, rank, n_ev, n_sets=args.input_sets)
     pipe.serial = args.serial
     ext, cap, S, n_pairs, n_lanes = pipe.ext, pipe.cap, pipe.S, pipe.n_pairs, pipe.n_lanes
     matcher = pipe.matcher
     stream = torch.cuda.current_stream().cuda_stream
-    if world > 1:
+    exchange_impl = None
+    if distributed:
         from orb_slam2_dualcam_amd import sharding
         rec = sharding.record_bytes(cap)             # per camera: kp 28 B + desc 32 B per slot + count
-        g_send = torch.zeros((2, rec), dtype=torch.uint8, device=dev)
-        g_recv = torch.zeros((2 * world, rec), dtype=torch.uint8, device=dev)
         g_kp = torch.zeros((2 * world, cap, 7), dtype=torch.float32, device=dev)
         g_desc = torch.zeros((2 * world, cap, 32), dtype=torch.uint8, device=dev)
         g_n = torch.zeros(2 * world, dtype=torch.int32, device=dev)
-        x_pairs = torch.tensor(sharding.reloc_pairs(rank, world), dtype=torch.int32, device=dev)
-        x_match = torch.zeros((world - 1, cap), dtype=torch.int32, device=dev)
-        x_nm = torch.zeros(world - 1, dtype=torch.int32, device=dev)
-        x_b = torch.zeros((world - 1, cap), dtype=torch.int32, device=dev)
-        x_s = torch.zeros((world - 1, cap), dtype=torch.int32, device=dev)
+        nx = max(world - 1, 1)
+        x_pairs = torch.tensor(sharding.reloc_pairs(rank, world) or [(0, 1)], dtype=torch.int32, device=dev)
+        x_match = torch.zeros((nx, cap), dtype=torch.int32, device=dev)
+        x_nm = torch.zeros(nx, dtype=torch.int32, device=dev)
+        x_b = torch.zeros((nx, cap), dtype=torch.int32, device=dev)
+        x_s = torch.zeros((nx, cap), dtype=torch.int32, device=dev)
+        # the exchange of the north star through the library's own communicator (dcs_comm_*, csrc/comm.cpp): brought up once, here,
+        # with the unique id broadcast over the process group; every rank must agree on the path, so a failure anywhere (or a bring-up
+        # that does not return within 60 s) sends ALL ranks to the torch.distributed path and the line says so
+        comm, comm_err = None, None
+        if args.exchange == "cabi":
+            box = {}
+
+            def bring_up():
+                try:
+                    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+                    if rank == 0:
+                        uid.copy_(torch.from_numpy(pkg.abi.FeatureComm.unique_id()).to(dev))
+                    dist.broadcast(uid, 0)
+                    box["comm"] = pkg.abi.FeatureComm(uid.cpu().numpy(), rank, world)
+                except Exception as e:               # noqa: BLE001
+                    box["err"] = str(e)
+            th = threading.Thread(target=bring_up, daemon=True)
+            th.start()
+            th.join(60.0)
+            comm, comm_err = box.get("comm"), box.get("err", "bring-up timed out" if th.is_alive() else None)
+            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()):
+                comm = None
+        exchange_impl = "dcs_features_allgather (library-owned RCCL communicator, slot arrays in place)" if comm is not None else \
+            "torch.distributed all_gather_into_tensor + pack / unpack" + (" (C-ABI communicator unavailable: %s)" % comm_err if args.exchange == "cabi" else "")
+        g_send = torch.zeros((2, rec), dtype=torch.uint8, device=dev)
+        g_recv = torch.zeros((2 * world, rec), dtype=torch.uint8, device=dev)
 
         def exchange(d_kp, d_desc, d_n, ev):
-            # exchange the newest dual frame: pack (kp | desc | n) per camera, one all-gather, cross-GPU reloc match
-            sharding.pack_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_send)
-            ev[2].record()
-            dist.all_gather_into_tensor(g_recv, g_send)
-            ev[3].record()
-            sharding.unpack_features(g_recv, cap, g_kp, g_desc, g_n)
-            matcher.match_bf_batch_device(g_desc, g_kp, g_n, cap, x_pairs, world - 1, x_match, x_nm, x_b, x_s, 50, stream=stream)
+            # exchange the newest dual frame (2 camera slots per rank), then the cross-GPU relocalisation match: this rank's cam0 against
+            # every other rank's cam1
+            if comm is not None:
+                ev[2].record()
+                comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_kp, g_desc, g_n, stream)
+                ev[3].record()
+            else:
+                sharding.pack_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_send)
+                ev[2].record()
+                dist.all_gather_into_tensor(g_recv, g_send)
+                ev[3].record()
+                sharding.unpack_features(g_recv, cap, g_kp, g_desc, g_n)
+            if world > 1:
+                matcher.match_bf_batch_device(g_desc, g_kp, g_n, cap, x_pairs, world - 1, x_match, x_nm, x_b, x_s, 50, stream=stream)
         pipe.post_match = exchange
     stage_keys = ("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us")
     acc = {k: 0.0 for k in stage_keys}
@@ -368,7 +433,7 @@ def main():
     acc["allgather_us"] = 0.0
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
 
     dt = pipe.run(args.steps, args.warmup, barrier)
@@ -376,21 +441,23 @@ def main():
         sums, n_timed = e_.timing_totals()
         for k in stage_keys:
             acc[k] += sums[k]
-    for ev in pipe.ev_all[args.warmup:]:
+    for i in range(args.steps):
+        ev = pipe.ev_all[(pipe.step_no_timed0 + i) % len(pipe.ev_all)]
         acc["match_us"] += ev[0].elapsed_time(ev[1]) * 1000.0
-        if world > 1:
+        if distributed:
             acc["allgather_us"] += ev[2].elapsed_time(ev[3]) * 1000.0
-    if world > 1:
+    if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    n_feat_step = pipe.features_per_step()
+    feats_timed = pipe.features_in_steps(pipe.step_no_timed0, args.steps)     # keypoints this rank returned inside the timed region
+    n_feat_step = int(round(feats_timed / args.steps))
     n_match_step = int(pipe.d_nm.sum().item())
-    tot = torch.tensor([n_feat_step], dtype=torch.float64, device=dev)
-    if world > 1:
+    tot = torch.tensor([feats_timed], dtype=torch.float64, device=dev)
+    if distributed:
         dist.all_reduce(tot)
     feats_all = float(tot.item())
-    value = feats_all * args.steps / dt / 1000.0
+    value = feats_all / dt / 1000.0
 
     out = None
     if rank == 0:
@@ -412,19 +479,32 @@ def main():
         kernels = {k: dict(us=round(dur[k], 2), algo_bytes=int(algo[k]),
                            gbps=round(algo[k] / max(dur[k], 1e-3) / 1e3, 2)) for k in algo}
         dom = max(dur, key=lambda k: dur[k])
-        traffic = None                               # HBM bytes per launch from the committed PMC passes (profiles/), same workload only
-        for prof in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        # Hardware counters cannot be read inside this process: the HBM traffic and the instruction counts come from the committed
+        # rocprofv3 --pmc passes of this same command (profiles/, produced by tools/collect_profiles.sh) and are labelled "imported";
+        # they are used only when the workload matches. A "launch" of the roofline kernel = its launches of ONE step (FAST runs one
+        # launch per LDS size class), timed together by the hipEvents around the stage.
+        traffic, counters_src, pmc_k = None, None, {}
+        for prof in ("r03_pmc_counters.json",):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if (P, W, H, NF, LN) == tuple(pmc.get("bench_args", ())):
-                    kk = pmc["kernels"][dom.split("(")[0].split("+")[0]]
-                    traffic = int((kk["FETCH_SIZE_KB_avg_per_launch"] + kk["WRITE_SIZE_KB_avg_per_launch"]) * 1024)
+                    pmc_k = pmc["kernels"]
+                    kk = pmc_k[dom.split("(")[0].split("+")[0]]
+                    traffic = int((kk["FETCH_SIZE_per_step"] + kk["WRITE_SIZE_per_step"]) * 1024 / LN)
+                    counters_src = "imported: profiles/%s (rocprofv3 --pmc passes of this command, collected in a separate run)" % prof
                     break
             except Exception:
                 traffic = None
+        # share of the vector-ALU issue slots a kernel's instructions take while it runs: SQ_INSTS_VALU x 4 cycles (one wave64 instruction
+        # occupies a SIMD for 4 cycles, profiles/r03_valu_rate_probe.txt) / (1024 SIMDs x stage duration x 2.4 GHz)
+        for k in kernels:
+            kk = pmc_k.get(k.split("(")[0].split("+")[0])
+            if kk and "SQ_INSTS_VALU_per_step" in kk and dur[k] > 0:
+                kernels[k]["valu_issue_frac"] = round(kk["SQ_INSTS_VALU_per_step"] / LN * 4.0 / (4 * N_CU * dur[k] * 1e-6 * 2.4e9), 4)
         roofline = dict(kernel=dom, bound="hbm", achieved=kernels[dom]["gbps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(kernels[dom]["gbps"] / HBM_PEAK_GBS, 5), traffic=traffic,
-                        algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(dur[dom], 2))
+                        frac=round(kernels[dom]["gbps"] / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=counters_src,
+                        algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(dur[dom], 2),
+                        valu_issue_frac=kernels[dom].get("valu_issue_frac"))
         out = {
             "metric": "dual-frame ORB extract+match kfeatures/s; local-BA iters/s (50 KF / 2k MP)",
             "value": round(value, 2), "unit": "kfeatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -437,9 +517,11 @@ def main():
             "stage_us_per_step": {k: round(v / K, 2) for k, v in acc.items()},
             "kernels": kernels,
         }
-        if world > 1:
+        out["config"]["input_sets_rotated"] = pipe.n_sets
+        if distributed:
             out["allgather_us"] = round(acc["allgather_us"] / K, 2)
             out["allgather_bytes_per_rank"] = int(2 * rec)
+            out["exchange"] = exchange_impl
 
     solo = rank == 0 and world == 1
     # ---- matcher alone (nothing else on the GPU): the i8 matrix-core Hamming kernel against its own peak
@@ -533,6 +615,9 @@ def main():
         O = entry.load_oracle()
         o = O.OrbOracle(NF, 1.2, 8, 20, 7)
         prev, feats, n_done = None, 0, 0
+        aff0 = os.sched_getaffinity(0)
+        core = sorted(aff0)[len(aff0) // 2]          # the single-thread baseline stays on ONE core (taskset -c)
+        os.sched_setaffinity(0, {core})
         tc0 = time.perf_counter()
         while time.perf_counter() - tc0 < args.cpu_seconds and n_done < 400:
             a, b = pipe.host_frames[(0, n_done % pipe.n_unique)]
@@ -540,9 +625,10 @@ def main():
             feats += nf
             n_done += 1
         tc = time.perf_counter() - tc0
-        out["cpu_baseline"] = {"value": round(feats / tc / 1000.0, 3), "unit": "kfeatures/s", "cores": 1, "kind": "port",
-                               "sample": "%d dual %dx%d frames (extract x2 + 3 knn2/filter each) in %.1f s, oracle -O3 single thread; host has %d cores"
-                                         % (n_done, W, H, tc, os.cpu_count())}
+        os.sched_setaffinity(0, aff0)
+        out["cpu_baseline"] = {"value": round(feats / tc / 1000.0, 3), "unit": "kfeatures/s", "cores": 1, "kind": "port", "pinned_core": core,
+                               "sample": "%d dual %dx%d frames (extract x2 + 3 knn2/filter each) in %.1f s, oracle -O3 single thread pinned to core %d; host has %d cores"
+                                         % (n_done, W, H, tc, core, os.cpu_count())}
         out["speedup_vs_cpu_1thread"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
         # all host cores: one stream of dual frames per worker PROCESS (tools/cpu_workers.py; a separate process tree, no GPU runtime in it)
         n_proc = max(1, os.cpu_count() or 1)
@@ -619,13 +705,17 @@ def main():
             O = entry.load_oracle()
             prob = dict(pb)
             prob["cams"] = [O.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pb["cams"]]
+            aff0 = os.sched_getaffinity(0)
+            core = sorted(aff0)[len(aff0) // 2]
+            os.sched_setaffinity(0, {core})
             tc0, it_c, n_c = time.perf_counter(), 0, 0
             while n_c < 1 or (time.perf_counter() - tc0 < min(args.cpu_seconds, 8.0) and n_c < 20):
                 rc = O.ba_local(prob)
                 it_c += sum(rc["n_iters"]); n_c += 1
             tcb = time.perf_counter() - tc0
-            ba["cpu_baseline"] = {"value": round(it_c / tcb, 2), "unit": "LM iterations/s", "cores": 1, "kind": "port",
-                                  "sample": "%d solves of the C4 problem in %.1f s, oracle -O3 single thread (dense LDLT)" % (n_c, tcb)}
+            os.sched_setaffinity(0, aff0)
+            ba["cpu_baseline"] = {"value": round(it_c / tcb, 2), "unit": "LM iterations/s", "cores": 1, "kind": "port", "pinned_core": core,
+                                  "sample": "%d solves of the C4 problem in %.1f s, oracle -O3 single thread pinned to core %d (dense LDLT)" % (n_c, tcb, core)}
             ba["speedup_vs_cpu_1thread"] = round(ba["value"] / max(ba["cpu_baseline"]["value"], 1e-9), 1)
         out["local_ba"] = ba
 
@@ -689,9 +779,9 @@ def main():
         out["bow"] = bow
         V.close()
 
-    # ---- N > 1: the same exchange through the C ABI (dcs_features_allgather, RCCL bound by the library), after the timed region.
-    # A watchdog prints the line without this leg if the second communicator cannot be brought up.
-    if world > 1:
+    # ---- distributed runs: the OTHER exchange path once after the timed region, as a cross-check of the gathered slot arrays
+    # (a watchdog prints the line without this leg if a collective does not come back)
+    if distributed:
         printed = threading.Event()
 
         def emit():
@@ -702,41 +792,34 @@ def main():
         def watchdog():
             if not done.wait(60.0):
                 if rank == 0:
-                    out["allgather_cabi"] = "timed out"
+                    out["exchange_crosscheck"] = "timed out"
                 emit()
                 os._exit(0)
         done = threading.Event()
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                uid.copy_(torch.from_numpy(pkg.abi.FeatureComm.unique_id()).to(dev))
-            dist.broadcast(uid, 0)
-            comm = pkg.abi.FeatureComm(uid.cpu().numpy(), rank, world)
             d_kp, d_desc, d_n = pipe.last_slots()
-            c_kp, c_desc, c_n = torch.zeros_like(g_kp), torch.zeros_like(g_desc), torch.zeros_like(g_n)
-            for _ in range(3):
-                comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, c_kp, c_desc, c_n, stream)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, c_kp, c_desc, c_n, stream)
-            e1.record(); torch.cuda.synchronize()
-            same = bool(torch.equal(c_n, g_n) and torch.equal(c_desc, g_desc))
-            if rank == 0:
-                out["allgather_cabi"] = {"us": round(e0.elapsed_time(e1) * 1e3 / 20, 2), "equals_torch_distributed": same,
-                                         "impl": "dcs_features_allgather: 3 grouped ncclAllGather on the slot arrays in place"}
-            comm.close()
+            if comm is not None:                     # timed region used the C ABI: compare with torch.distributed
+                sharding.pack_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_send)
+                dist.all_gather_into_tensor(g_recv, g_send)
+                t_kp, t_desc, t_n = sharding.unpack_features(g_recv, cap)
+                comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_kp, g_desc, g_n, stream)
+                torch.cuda.synchronize()
+                same = bool(torch.equal(t_n, g_n) and torch.equal(t_desc, g_desc) and torch.equal(t_kp.view(torch.int32), g_kp.view(torch.int32)))
+                if rank == 0:
+                    out["exchange_crosscheck"] = {"other_path": "torch.distributed all_gather_into_tensor + pack / unpack", "slot_arrays_equal": same}
+                comm.close()
+            elif rank == 0:
+                out["exchange_crosscheck"] = "skipped (the C-ABI communicator is not up)"
         except Exception as e:                       # noqa: BLE001
             if rank == 0:
-                out["allgather_cabi"] = "unavailable: %s" % e
+                out["exchange_crosscheck"] = "unavailable: %s" % e
         done.set()
         emit()
     elif rank == 0:
         print(json.dumps(out))
     pipe.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

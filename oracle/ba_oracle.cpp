@@ -23,6 +23,14 @@
 #include <cstring>
 #include <vector>
 
+/* RobustKernelHuber::robustify with dsqr = delta * delta as setDelta leaves it (robust_kernel_impl.cpp:65-69, 78-91) */
+extern "C" void orc_robust_huber(double delta, double e, double rho[3])
+{
+    const double dsqr = delta * delta;
+    if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
+    else { const double sqrte = std::sqrt(e); rho[0] = 2 * sqrte * delta - dsqr; rho[1] = delta / sqrte; rho[2] = -0.5 * rho[1] / e; }
+}
+
 namespace {
 
 struct Quat { double x, y, z, w; };
@@ -248,13 +256,7 @@ struct Solver {
         }
     }
     double chi2(int e) const { const double w = pb->inv_sigma2[e]; return err[2 * e] * (w * err[2 * e]) + err[2 * e + 1] * (w * err[2 * e + 1]); }
-    /* RobustKernelHuber::robustify (robust_kernel_impl.cpp:78-91) */
-    void huber(double e2, double rho[3]) const
-    {
-        const double delta = pb->huber_delta, dsqr = delta * delta;
-        if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; }
-        else { const double s = std::sqrt(e2); rho[0] = 2 * s * delta - dsqr; rho[1] = delta / s; rho[2] = -0.5 * rho[1] / e2; }
-    }
+    void huber(double e2, double rho[3]) const { orc_robust_huber(pb->huber_delta, e2, rho); }
     double robust_chi2() const
     {
         double chi = 0.0, rho[3];
@@ -511,11 +513,7 @@ int orc_pose_optimization(const orc_pose_problem* pb, orc_pose_result* res)
         std::vector<double> err(2 * (size_t)n, 0.0);                                   /* _error of every edge */
         bool robust = true;                                                            /* kernels removed after round 3 (:388-389) */
         auto chi2_of = [&](int k) { const double w = pb->inv_sigma2[e0 + k]; return err[2 * k] * (w * err[2 * k]) + err[2 * k + 1] * (w * err[2 * k + 1]); };
-        auto huber = [&](double e2, double rho[3]) {
-            const double delta = pb->huber_delta, dsqr = delta * delta;
-            if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; }
-            else { const double sq = std::sqrt(e2); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e2; }
-        };
+        auto huber = [&](double e2, double rho[3]) { orc_robust_huber(pb->huber_delta, e2, rho); };
         int nBadEdges = 0;
         for (int it = 0; it < 4; ++it) {
             T = init;                                                                  /* :360 */

@@ -192,6 +192,9 @@ typedef struct orc_ba_result {
 } orc_ba_result;
 
 int orc_ba_local(const orc_ba_problem* prob, const volatile uint8_t* stop_flag, orc_ba_result* res);
+/* RobustKernelHuber::setDelta(delta) + ::robustify (Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp:65-91): rho = {rho(e), rho'(e), rho''(e)} of
+   an edge's chi2 e. The one Huber every solver of the oracle uses; pinned against the reference's own statements (oracle/_ref, tests/test_oracle_ref.py). */
+void orc_robust_huber(double delta, double e, double rho[3]);
 
 /* ---- Optimizer::PoseOptimization (src/Optimizer.cc:250-405) for a batch of independent frames:
    one pose vertex per frame, unary EdgeSE3ProjectXYZOnlyPose edges (types_six_dof_expmap.cpp:200-255), dense 6x6 solve,

@@ -58,6 +58,8 @@ def ref():
         L.ref_score.argtypes = [ci, ci, vp, vp, ci, vp, vp]
         L.ref_score.restype = C.c_double
         L.ref_feature_vector.argtypes = [ci, vp, vp, vp, vp]
+        L.ref_huber.argtypes = [C.c_double, C.c_double, vp]
+        L.ref_huber.restype = None
         _ref = L
     return _ref
 
@@ -69,6 +71,23 @@ def ref_distances(a, b):
     d1 = np.array([L.ref_descriptor_distance(a[i].ctypes.data, b[i].ctypes.data) for i in range(len(a))], np.int32)
     d2 = np.array([L.ref_forb_distance(a[i].ctypes.data, b[i].ctypes.data) for i in range(len(a))], np.int32)
     return d1, d2
+
+
+def ref_huber(delta, e):
+    """g2o's RobustKernelHuber (the reference's own statements): setDelta(delta), robustify(e) -> (rho, rho', rho'')"""
+    rho = np.zeros(3)
+    ref().ref_huber(float(delta), float(e), _p(rho))
+    return rho
+
+
+def robust_huber(delta, e):
+    """the oracle's Huber kernel (orc_robust_huber)"""
+    rho = np.zeros(3)
+    fn = lib().orc_robust_huber
+    fn.argtypes = [C.c_double, C.c_double, C.c_void_p]
+    fn.restype = None
+    fn(float(delta), float(e), _p(rho))
+    return rho
 
 
 def ref_three_maxima(sizes):

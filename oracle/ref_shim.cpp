@@ -9,6 +9,9 @@
 //       time into _ref/*.inc (the two lines before them only fetch `const int*` row pointers from cv::Mat)
 //   * ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1969-2010): the statements between the braces of its definition, cut out
 //       by awk the same way; the wrapper below repeats the reference's parameter list (histo, L, ind1, ind2, ind3)
+//   * RobustKernelHuber::setDelta / ::robustify (Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp:65-91): the statements between the
+//       braces of the two definitions, cut out by awk; the struct below supplies the two members they use (dsqr, _delta) and the
+//       parameter list (double e, rho indexable 0..2 like Eigen::Vector3d)
 // Nothing of the reference is copied into the repository: the generated files live in oracle/_ref/ (git-ignored).
 // The oracle's restatements are checked against these functions in tests/test_oracle_ref.py, and golden vectors produced
 // by them are committed (tests/golden/ref_dbow2.npz, make_golden_ref.py) so that the pin travels to machines without the reference.
@@ -35,7 +38,27 @@ static void ref_three_maxima_impl(std::vector<int>* histo, const int L, int& ind
 #include "three_maxima_body.inc"
 }
 
+struct RefHuber {
+    double dsqr = 0, _delta = 0;
+    void setDelta(double delta)
+    {
+#include "huber_setdelta_body.inc"
+    }
+    void robustify(double e, double* rho) const
+    {
+#include "huber_robustify_body.inc"
+    }
+};
+
 extern "C" {
+
+// rho[3] = {rho(e), rho'(e), rho''(e)} of g2o's Huber kernel with setDelta(delta), e = chi2 of the edge
+void ref_huber(double delta, double e, double* rho)
+{
+    RefHuber k;
+    k.setDelta(delta);
+    k.robustify(e, rho);
+}
 
 // histogram given as bin sizes; ind[3] = {ind1, ind2, ind3} as the callers initialise them (-1) and the function leaves them
 void ref_three_maxima(const int32_t* sizes, int L, int32_t* ind)

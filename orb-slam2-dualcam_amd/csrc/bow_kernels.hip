@@ -281,6 +281,15 @@ struct dcs_kfdb {
     int32_t* d_word = nullptr; double* d_val = nullptr; size_t cap_word = 0, cap_val = 0;
     int64_t* d_off = nullptr; uint8_t* d_dead = nullptr; size_t cap_off = 0, cap_dead = 0;
     hipStream_t st = nullptr;
+    PinnedBuf<char> stage;                           // one add = one pinned image of {words, values, end offset, alive byte}
+    // the arrays live on the device the handle was created on; the calling thread's scratch arena lives on ITS current device
+    int check_device(const char* who) const
+    {
+        int cur = -1;
+        DCS_HIP(hipGetDevice(&cur));
+        if (cur != device) { set_error("%s: the database lives on device %d, the calling thread's current device is %d", who, device, cur); return DCS_ERR_INVALID; }
+        return DCS_OK;
+    }
     ~dcs_kfdb()
     {
         if (d_word) (void)hipFree(d_word);
@@ -501,18 +510,26 @@ int dcs_kfdb_add(dcs_kfdb* d, const int32_t* word, const double* val, int n, int
     for (int i = 1; i < n; ++i) if (word[i] <= word[i - 1]) { set_error("dcs_kfdb_add: word ids must ascend strictly (a BowVector is a std::map)"); return DCS_ERR_INVALID; }
     if (n && word[0] < 0) { set_error("dcs_kfdb_add: negative word id"); return DCS_ERR_INVALID; }
     int rc;
+    if ((rc = d->check_device("dcs_kfdb_add"))) return rc;
     const bool first = d->cap_off == 0;
     if ((rc = d->grow(d->d_off, d->cap_off, (size_t)d->n + 2, first ? 0 : (size_t)d->n + 1)) || (rc = d->grow(d->d_dead, d->cap_dead, (size_t)d->n + 1, (size_t)d->n)) ||
         (rc = d->grow(d->d_word, d->cap_word, (size_t)d->n_words + n, (size_t)d->n_words)) || (rc = d->grow(d->d_val, d->cap_val, (size_t)d->n_words + n, (size_t)d->n_words))) return rc;
-    if (d->n == 0) { const int64_t z = 0; DCS_HIP(hipMemcpyAsync(d->d_off, &z, sizeof(z), hipMemcpyHostToDevice, d->st)); DCS_HIP(hipStreamSynchronize(d->st)); }
+    // one pinned staging image per add: [val (8 n) | off[n_entries], off[n_entries + 1] (16) | word (4 n) | alive byte], asynchronous copies into
+    // the four arrays, ONE synchronisation (the first offset is rewritten with every add: it also initialises off[0] = 0)
     const int64_t end = d->n_words + n;
-    const uint8_t alive = 0;
+    const size_t o_off = sizeof(double) * (size_t)n, o_word = o_off + 16, o_alive = o_word + sizeof(int32_t) * (size_t)n;
+    if ((rc = d->stage.resize(o_alive + 16))) return rc;
+    char* h = d->stage.p;
+    if (n) { memcpy(h, val, sizeof(double) * n); memcpy(h + o_word, word, sizeof(int32_t) * n); }
+    const int64_t offs[2] = {d->n_words, end};
+    memcpy(h + o_off, offs, 16);
+    h[o_alive] = 0;
     if (n) {
-        DCS_HIP(hipMemcpyAsync(d->d_word + d->n_words, word, sizeof(int32_t) * n, hipMemcpyHostToDevice, d->st));
-        DCS_HIP(hipMemcpyAsync(d->d_val + d->n_words, val, sizeof(double) * n, hipMemcpyHostToDevice, d->st));
+        DCS_HIP(hipMemcpyAsync(d->d_word + d->n_words, h + o_word, sizeof(int32_t) * n, hipMemcpyHostToDevice, d->st));
+        DCS_HIP(hipMemcpyAsync(d->d_val + d->n_words, h, sizeof(double) * n, hipMemcpyHostToDevice, d->st));
     }
-    DCS_HIP(hipMemcpyAsync(d->d_off + d->n + 1, &end, sizeof(end), hipMemcpyHostToDevice, d->st));
-    DCS_HIP(hipMemcpyAsync(d->d_dead + d->n, &alive, 1, hipMemcpyHostToDevice, d->st));
+    DCS_HIP(hipMemcpyAsync(d->d_off + d->n, h + o_off, 16, hipMemcpyHostToDevice, d->st));
+    DCS_HIP(hipMemcpyAsync(d->d_dead + d->n, h + o_alive, 1, hipMemcpyHostToDevice, d->st));
     DCS_HIP(hipStreamSynchronize(d->st));
     d->h_off.push_back(end); d->h_dead.push_back(0);
     *entry_id = d->n;
@@ -523,6 +540,7 @@ int dcs_kfdb_add(dcs_kfdb* d, const int32_t* word, const double* val, int n, int
 int dcs_kfdb_erase(dcs_kfdb* d, int entry_id)
 {
     if (!d || entry_id < 0 || entry_id >= d->n) { set_error("dcs_kfdb_erase: no such entry"); return DCS_ERR_INVALID; }
+    if (int rc = d->check_device("dcs_kfdb_erase")) return rc;
     const uint8_t dead = 1;
     DCS_HIP(hipMemcpyAsync(d->d_dead + entry_id, &dead, 1, hipMemcpyHostToDevice, d->st));
     DCS_HIP(hipStreamSynchronize(d->st));
@@ -542,8 +560,9 @@ int dcs_kfdb_query(dcs_kfdb* d, const int32_t* q_word, const double* q_val, int 
     if (!d || nq < 0 || (nq && (!q_word || !q_val)) || (d->n && (!common || !first_word || !score))) { set_error("dcs_kfdb_query: bad argument"); return DCS_ERR_INVALID; }
     for (int i = 1; i < nq; ++i) if (q_word[i] <= q_word[i - 1]) { set_error("dcs_kfdb_query: word ids must ascend strictly"); return DCS_ERR_INVALID; }
     if (d->n == 0) return DCS_OK;
-    Scratch s;
     int rc;
+    if ((rc = d->check_device("dcs_kfdb_query"))) return rc;
+    Scratch s;
     int32_t *dqw, *dcm, *dfw; double* dqv; float* dsc;
     if ((rc = s.upload(&dqw, q_word, nq)) || (rc = s.upload(&dqv, q_val, nq)) || (rc = s.alloc(&dcm, d->n)) || (rc = s.alloc(&dfw, d->n)) || (rc = s.alloc(&dsc, d->n))) return rc;
     hipLaunchKernelGGL(k_kfdb_query, dim3((d->n + 255) / 256), dim3(256), 0, s.st, dqw, dqv, nq, d->d_off, d->d_word, d->d_val, d->d_dead, d->n, dcm, dfw, dsc);

@@ -11,6 +11,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "common.h"
 
@@ -25,16 +26,21 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;                                 // why the library is unusable (written once, inside the call_once)
 };
+
+Rccl& rccl_state() { static Rccl r; return r; }
+std::string rccl_why() { const Rccl& r = rccl_state(); return r.why.empty() ? std::string("unknown reason") : r.why; }
 
 Rccl* rccl()
 {
-    static Rccl r;
+    Rccl& r = rccl_state();
     static std::once_flag once;
-    std::call_once(once, [] {
+    std::call_once(once, [&r] {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.so) break;
+            if (const char* e = dlerror()) r.why = e;           // dlerror() clears itself: read ONCE, here, on the loading thread
         }
         if (!r.so) return;
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.so, "ncclGetUniqueId");
@@ -44,7 +50,11 @@ Rccl* rccl()
         r.GroupStart = (decltype(r.GroupStart))dlsym(r.so, "ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.so, "ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
-        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd) r.so = nullptr;
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd) {
+            r.why = "a required nccl* symbol is missing";
+            dlclose(r.so);
+            r.so = nullptr;
+        }
     });
     return r.so ? &r : nullptr;
 }
@@ -52,7 +62,7 @@ Rccl* rccl()
 int need_rccl(Rccl*& r)
 {
     r = rccl();
-    if (!r) { dcs::set_error("librccl.so.1 could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"); return DCS_ERR_HIP; }
+    if (!r) { dcs::set_error("librccl.so.1 could not be loaded: %s", rccl_why().c_str()); return DCS_ERR_HIP; }
     return DCS_OK;
 }
 

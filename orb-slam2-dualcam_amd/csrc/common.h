@@ -70,6 +70,7 @@ struct ThreadArena {
     size_t dev_call = 0, pin_call = 0;
     hipStream_t stream = nullptr;
     int device = -1;
+    bool in_call = false;                                // a Scratch of this thread is alive: a second begin() would rewind ITS arena
     ~ThreadArena();
     void release();
     int begin();                                         // start of a call: rewind, coalesce fragmented blocks into one
@@ -83,12 +84,29 @@ struct Scratch {
     struct Pending { void* dst; const void* src; size_t bytes; };
     std::vector<Pending> pending;
     int rc0;
-    Scratch() : a(thread_arena()) { rc0 = a.begin(); st = a.stream; }
+    bool owner = false, finished = false, touched = false;       // touched: something was enqueued on the stream
+    // One Scratch per thread at a time: a nested one (an entry point calling another entry point) would rewind the outer call's arena
+    // under its in-flight copies -- it fails with DCS_ERR_INVALID instead.
+    Scratch() : a(thread_arena())
+    {
+        if (a.in_call) { set_error("nested scratch arena on one thread"); rc0 = DCS_ERR_INVALID; return; }
+        a.in_call = owner = true;
+        rc0 = a.begin(); st = a.stream;
+    }
     Scratch(const Scratch&) = delete;
     Scratch& operator=(const Scratch&) = delete;
-    ~Scratch() { if (!pending.empty() && st) (void)hipStreamSynchronize(st); }
+    // A call that returns early -- a failed launch, a late validation error, an allocation failure -- has not run finish(): its uploads
+    // and kernels may still be reading the pinned staging and the arena that the thread's NEXT call rewinds, so the stream is drained here.
+    ~Scratch()
+    {
+        if (owner) {
+            if (!finished && touched && st) (void)hipStreamSynchronize(st);
+            a.in_call = false;
+        }
+    }
     template <typename T> int alloc(T** out, size_t n) {
         if (rc0) return rc0;
+        touched = true;                                   // the caller is about to launch on / copy through this memory
         void* p = a.take(false, std::max<size_t>(n, 1) * sizeof(T));
         if (!p) { set_error("device scratch: out of memory"); return DCS_ERR_HIP; }
         *out = (T*)p; return DCS_OK;
@@ -112,6 +130,7 @@ struct Scratch {
     template <typename T> int upload_into(T* d_dst, const T* src, size_t n) {
         if (rc0) return rc0;
         if (n == 0) return DCS_OK;
+        touched = true;
         void* h = a.take(true, n * sizeof(T));
         if (!h) { set_error("pinned scratch: out of memory"); return DCS_ERR_HIP; }
         memcpy(h, src, n * sizeof(T));
@@ -120,7 +139,9 @@ struct Scratch {
     }
     // asynchronous device -> caller copy: lands in `dst` at the next finish()
     template <typename T> int download(T* dst, const T* d_src, size_t n) {
+        if (rc0) return rc0;
         if (n == 0) return DCS_OK;
+        touched = true;
         void* h = a.take(true, n * sizeof(T));
         if (!h) { set_error("pinned scratch: out of memory"); return DCS_ERR_HIP; }
         DCS_HIP(hipMemcpyAsync(h, d_src, n * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -129,9 +150,11 @@ struct Scratch {
     }
     int download_bytes(void* dst, const void* d_src, size_t bytes) { return download((char*)dst, (const char*)d_src, bytes); }
     int finish() {
+        if (rc0) return rc0;
         DCS_HIP(hipStreamSynchronize(st));
         for (const Pending& q : pending) memcpy(q.dst, q.src, q.bytes);
         pending.clear();
+        finished = true; touched = false;                 // a call may go on after a finish() (two-phase entry points): tracked again from here
         return DCS_OK;
     }
 };

@@ -139,6 +139,9 @@ struct dcs_orb {
     PinnedBuf<uint8_t> h_img;
 
     hipStream_t s_main = nullptr, s_aux = nullptr, s_fast = nullptr;
+    // host-buffer batches run as a pipeline of image chunks: upload of chunk k + 1 || kernels of chunk k || download of chunk k - 1
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    std::vector<hipEvent_t> ev_chunk;              // 3 per chunk: uploaded, computed, downloaded
     hipEvent_t ev_lvl = nullptr, ev_fast_early = nullptr;
     int fast_split = 0;                            // DCS_ORB_FAST_SPLIT: FAST of levels [0, fast_split) starts on its own stream as soon as they exist
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
@@ -165,6 +168,9 @@ struct dcs_orb {
 
     ~dcs_orb() {
         if (s_main) (void)hipStreamDestroy(s_main);
+        if (s_h2d) (void)hipStreamDestroy(s_h2d);
+        if (s_d2h) (void)hipStreamDestroy(s_d2h);
+        for (hipEvent_t e : ev_chunk) (void)hipEventDestroy(e);
         if (s_aux) (void)hipStreamDestroy(s_aux);
         if (s_fast) (void)hipStreamDestroy(s_fast);
         if (ev_lvl) (void)hipEventDestroy(ev_lvl);
@@ -540,7 +546,7 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
     {   // staging threads of the host-buffer API (DCS_ORB_STAGING_THREADS, default 4; 1 = pack on the calling thread)
         const char* e = getenv("DCS_ORB_STAGING_THREADS");
-        const int nt = e ? atoi(e) : 4;
+        const int nt = e ? atoi(e) : (h->prm.max_images >= 64 ? 8 : 4);    // 8 packers keep up with PCIe 5 (~45 GB/s of image bytes) on large batches
         if (nt > 1 && h->prm.max_images > 2) h->stage_pool.reset(new Pool(nt - 1));
     }
     *out = h.release();
@@ -621,16 +627,129 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     int rc = h->configure(rows, cols);
     if (rc) return rc;
     // Host images -> pinned staging (rows packed at a 4-byte aligned pitch) -> ONE device staging buffer that the kernels
-    // read in place as level 0, exactly like the _device entry point. Groups of 8 images are packed by the staging
-    // threads and their DMA (one copy per group) is enqueued while the next group is packed.
+    // read in place as level 0, exactly like the _device entry point.
     const int pitch_s = (cols + 3) & ~3;
     const size_t img_bytes = (size_t)rows * pitch_s;
     if ((rc = h->h_img.resize(img_bytes * n_images)) || (rc = h->d_stage.resize(img_bytes * n_images))) return rc;
+    const bool nopack = getenv("DCS_ORB_HOST_NOPACK") != nullptr;   // measurement aid: the pinned staging keeps the previous call's images
     auto pack = [&](int i) {
+        if (nopack) return;
         uint8_t* dst = h->h_img.p + i * img_bytes;
         if (stride == cols && pitch_s == cols) memcpy(dst, images[i], img_bytes);
         else for (int y = 0; y < rows; ++y) memcpy(dst + (size_t)y * pitch_s, images[i] + (size_t)y * stride, cols);
     };
+    // ---- large batches (what a host that buffers frames hands over): a three-stage pipeline over chunks of images. While the staging
+    // threads pack chunk k + 1 into pinned memory and its DMA runs on the upload stream, the kernels of chunk k run on the main stream
+    // and the slots of chunk k - 1 come down on the download stream and are scattered into the caller's arrays: the call costs the
+    // slowest stage (PCIe: 157 MB of images per 512) instead of the sum. Results are the same bytes as the one-shot path (every chunk
+    // is an ordinary extraction of its images).
+    const char* chunk_s = getenv("DCS_ORB_HOST_CHUNK");           // images per chunk (default 64; 0 = one-shot path); read per call: tests compare the two paths
+    const int chunk_env = chunk_s ? atoi(chunk_s) : 64;
+    if (h->device_octree && chunk_env > 0 && n_images >= 2 * chunk_env) {
+        const int C = chunk_env;
+        const size_t slots = (size_t)n_images * cap;
+        if ((rc = h->d_kp.resize(slots)) || (rc = h->d_desc.resize(slots * 32)) || (rc = h->d_n.resize(n_images)) || (rc = h->h_n.resize(n_images)) ||
+            (rc = h->h_kp_out.resize(slots)) || (rc = h->h_desc_out.resize(slots * 32))) return rc;
+        if (!h->s_h2d) DCS_HIP(hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking));
+        if (!h->s_d2h) DCS_HIP(hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking));
+        // Chunk boundaries: a short first chunk starts the DMA early, a short last one keeps the tail (kernels + download + scatter of
+        // the final chunk, which nothing overlaps) small.
+        std::vector<int> c_begin;
+        {
+            int i = 0;
+            const int head = std::max(8, C / 4);
+            c_begin.push_back(0);
+            if (n_images > 4 * C) { i = head; c_begin.push_back(i); }
+            while (n_images - i > C + head) { i += C; c_begin.push_back(i); }
+            if (n_images - i > head && n_images > 4 * C) { c_begin.push_back(n_images - head); }
+            c_begin.push_back(n_images);
+        }
+        const int NC = (int)c_begin.size() - 1;
+        while (h->ev_chunk.size() < (size_t)3 * NC) { hipEvent_t e; DCS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_chunk.push_back(e); }
+        const bool trace = getenv("DCS_ORB_HOST_TRACE") != nullptr;           // stderr: host time per stage of this call
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t_call = now();
+        // The calling thread only ENQUEUES (copies, ~25 launches and 3 events per chunk: ~0.13 ms of API time each). A helper thread owns
+        // the staging pool: it packs the chunks in order into pinned memory (flag packed[k]), then scatters every chunk that has landed
+        // (flag enqueued[k] -> its download event) into the caller's arrays -- packing, DMA, kernels and scattering all overlap.
+        std::vector<std::atomic<int>> packed(NC), enqueued(NC);
+        for (int k = 0; k < NC; ++k) { packed[k].store(0); enqueued[k].store(0); }
+        std::atomic<int> failed{DCS_OK}, abort_flag{0};
+        double t_pack = 0, t_scatter = 0;
+        auto scatter = [&](int k) {                                // chunk k has landed in pinned memory: hand its valid prefixes to the caller
+            const int i0 = c_begin[k], m = c_begin[k + 1] - i0;
+            auto one = [&](int j) {
+                const int i = i0 + j, c = h->h_n.p[i];
+                if (c > 0) {
+                    memcpy(kp + (size_t)i * cap, h->h_kp_out.p + (size_t)i * cap, sizeof(dcs_keypoint) * std::min(c, cap));
+                    memcpy(desc + (size_t)i * cap * 32, h->h_desc_out.p + (size_t)i * cap * 32, (size_t)32 * std::min(c, cap));
+                }
+                n_out[i] = std::max(c, 0);
+            };
+            for (int j = 0; j < m; ++j) if (h->h_n.p[i0 + j] < 0) failed.store(h->h_n.p[i0 + j]);     // k_describe reports DCS_ERR_CAPACITY in place of a count
+            if (h->stage_pool) h->stage_pool->parallel_for(m, one); else for (int j = 0; j < m; ++j) one(j);
+        };
+        const int dev = h->device;
+        std::thread helper([&] {
+            (void)hipSetDevice(dev);
+            const auto tp0 = now();
+            for (int k = 0; k < NC && !abort_flag.load(); ++k) {
+                const int i0 = c_begin[k], m = c_begin[k + 1] - i0;
+                if (h->stage_pool) h->stage_pool->parallel_for(m, [&](int j) { pack(i0 + j); }); else for (int j = 0; j < m; ++j) pack(i0 + j);
+                packed[k].store(1, std::memory_order_release);
+            }
+            const auto tp1 = now();
+            t_pack = ms(tp0, tp1);
+            for (int k = 0; k < NC; ++k) {
+                while (!enqueued[k].load(std::memory_order_acquire)) { if (abort_flag.load()) return; std::this_thread::yield(); }
+                if (hipEventSynchronize(h->ev_chunk[3 * k + 2]) != hipSuccess) { failed.store(DCS_ERR_HIP); return; }
+                scatter(k);
+            }
+            t_scatter = ms(tp1, now());
+        });
+        // on any error: the helper stops, and nothing may stay in flight that reads the pinned / device staging of this handle
+        auto bail = [&](int code) {
+            abort_flag.store(1);
+            helper.join();
+            (void)hipStreamSynchronize(h->s_h2d); (void)hipStreamSynchronize(h->s_main); (void)hipStreamSynchronize(h->s_d2h);
+            return code;
+        };
+#define DCS_PIPE(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return bail(DCS_ERR_HIP); } } while (0)
+        double t_enq = 0, t_wait_pack = 0;
+        for (int k = 0; k < NC; ++k) {
+            const int i0 = c_begin[k], m = c_begin[k + 1] - i0;
+            hipEvent_t e_up = h->ev_chunk[3 * k], e_done = h->ev_chunk[3 * k + 1], e_dl = h->ev_chunk[3 * k + 2];
+            const auto tw0 = now();
+            while (!packed[k].load(std::memory_order_acquire)) std::this_thread::yield();
+            const auto tw1 = now();
+            t_wait_pack += ms(tw0, tw1);
+            DCS_PIPE(hipMemcpyAsync(h->d_stage.p + i0 * img_bytes, h->h_img.p + i0 * img_bytes, img_bytes * m, hipMemcpyHostToDevice, h->s_h2d));
+            DCS_PIPE(hipEventRecord(e_up, h->s_h2d));
+            DCS_PIPE(hipStreamWaitEvent(h->s_main, e_up, 0));
+            if ((rc = h->run(h->d_stage.p + i0 * img_bytes, img_bytes, pitch_s, m, h->d_kp.p + (size_t)i0 * cap, h->d_desc.p + (size_t)i0 * cap * 32, cap,
+                             h->d_n.p + i0, h->s_main, nullptr))) return bail(rc);
+            DCS_PIPE(hipEventRecord(e_done, h->s_main));
+            DCS_PIPE(hipStreamWaitEvent(h->s_d2h, e_done, 0));
+            DCS_PIPE(hipMemcpyAsync(h->h_n.p + i0, h->d_n.p + i0, sizeof(int32_t) * m, hipMemcpyDeviceToHost, h->s_d2h));
+            DCS_PIPE(hipMemcpyAsync(h->h_kp_out.p + (size_t)i0 * cap, h->d_kp.p + (size_t)i0 * cap, sizeof(dcs_keypoint) * (size_t)m * cap, hipMemcpyDeviceToHost, h->s_d2h));
+            DCS_PIPE(hipMemcpyAsync(h->h_desc_out.p + (size_t)i0 * cap * 32, h->d_desc.p + (size_t)i0 * cap * 32, (size_t)m * cap * 32, hipMemcpyDeviceToHost, h->s_d2h));
+            DCS_PIPE(hipEventRecord(e_dl, h->s_d2h));
+            enqueued[k].store(1, std::memory_order_release);
+            t_enq += ms(tw1, now());
+        }
+#undef DCS_PIPE
+        const auto t_loop = now();
+        helper.join();
+        DCS_HIP(hipStreamSynchronize(h->s_main));                  // timing events of the last chunk
+        if (trace) fprintf(stderr, "[dcs_orb_extract_batch] %d images in %d chunks: %.3f ms (calling thread: enqueue %.3f, waited for packing %.3f, loop done at %.3f; "
+                                   "helper: pack %.3f, then scatter + waiting for downloads %.3f)\n", n_images, NC, ms(t_call, now()), t_enq, t_wait_pack, ms(t_call, t_loop), t_pack, t_scatter);
+        if (failed.load() == DCS_ERR_CAPACITY) { set_error("FAST candidates exceed the dense buffer of the handle"); return DCS_ERR_CAPACITY; }
+        if (failed.load()) { set_error("host pipeline: a download did not complete"); return failed.load(); }
+        return DCS_OK;
+    }
+    // ---- small batches: groups of 8 images are packed by the staging threads and their DMA (one copy per group) is enqueued while the
+    // next group is packed; one launch sequence, one synchronisation.
     for (int i0 = 0; i0 < n_images; i0 += 8) {
         const int m = std::min(8, n_images - i0);
         if (m > 1 && h->stage_pool) h->stage_pool->parallel_for(m, [&](int k) { pack(i0 + k); });

@@ -68,3 +68,17 @@ hist = np.stack(hist).astype(np.int32)
 ind = np.array([O.ref_three_maxima(h) for h in hist], np.int32)
 np.savez_compressed(os.path.join(HERE, "ref_three_maxima.npz"), hist=hist, ind=ind)
 print("ref_three_maxima.npz:", hist.shape, "histograms")
+
+# g2o's RobustKernelHuber (Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp:65-91, the reference's own statements): the deltas the reference
+# sets (sqrt(5.991) in LocalBundleAdjustment / PoseOptimization, sqrt(7.815) stereo, the float sqrt(3.99) of BundleAdjustment) and chi2
+# values around delta^2, tiny, huge and exactly on the boundary
+hk = np.random.default_rng(2026)
+deltas = np.array([np.sqrt(5.991), np.sqrt(7.815), float(np.float32(np.sqrt(3.99))), 1.0, 0.25, 12.5])
+es = []
+for d in deltas:
+    es.append(np.concatenate([[0.0, 1e-300, 1e-12, d * d, np.nextafter(d * d, 0), np.nextafter(d * d, 1e9), 1e12, 1e300],
+                              hk.uniform(0, 3 * d * d, 40), d * d * np.exp(hk.uniform(-8, 8, 40))]))
+es = np.stack(es)
+rho = np.array([[O.ref_huber(d, e) for e in row] for d, row in zip(deltas, es)])
+np.savez_compressed(os.path.join(HERE, "ref_huber.npz"), delta=deltas, e=es, rho=rho)
+print("ref_huber.npz:", rho.shape)

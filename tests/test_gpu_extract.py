@@ -323,3 +323,29 @@ def test_fused_blur_describe_keeps_the_blurred_debug_level(pkg, oracle, synth, m
         _same(kps[i], descs[i], okp, odesc)
         assert np.array_equal(e.level_image(i, 2, blurred=True), oracle.gauss7_u8(o.level_image(2)))
     e.close()
+
+
+def test_host_batch_pipeline_equals_one_shot(pkg, oracle, synth, monkeypatch):
+    """dcs_orb_extract_batch on a large host batch runs as a pipeline of image chunks (upload || kernels || download + scatter,
+    csrc/orb_extract.cpp); DCS_ORB_HOST_CHUNK=0 selects the one-shot path. Same bytes either way, and the oracle's for sampled images;
+    a ragged last chunk is covered."""
+    W, H = 320, 240
+    base = [synth.frame_pair(640, 480, 0, f) for f in range(5)]
+    imgs = []
+    for i in range(75):                                        # 75 images: chunks of 16 -> 4 full + 11
+        a = base[i % 5][i % 2]
+        y0, x0 = (7 * i) % 200, (13 * i) % 300
+        imgs.append(np.ascontiguousarray(a[y0:y0 + H, x0:x0 + W]))
+    outs = []
+    for chunk in ("16", "0"):
+        monkeypatch.setenv("DCS_ORB_HOST_CHUNK", chunk)
+        ext = pkg.ORBextractor(300, 1.2, 8, 20, 7, max_images=75)
+        outs.append(ext.extract_batch(imgs))
+        ext.close()
+    (kp_a, d_a), (kp_b, d_b) = outs
+    for i in range(75):
+        assert kp_a[i].tobytes() == kp_b[i].tobytes() and np.array_equal(d_a[i], d_b[i]), i
+    o = oracle.OrbOracle(300, 1.2, 8, 20, 7)
+    for i in (0, 15, 16, 63, 64, 74):
+        ek, ed = o.extract(imgs[i])
+        assert kp_a[i].tobytes() == ek.tobytes() and np.array_equal(d_a[i], ed), i

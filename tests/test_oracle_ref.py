@@ -105,3 +105,19 @@ def test_three_maxima_golden_and_live(oracle):
     for _ in range(2000):
         h = rng.integers(0, rng.integers(2, 60), 30).astype(np.int32)
         assert oracle.three_maxima(h) == oracle.ref_three_maxima(h), h
+
+
+def test_huber_kernel_golden_and_live(oracle):
+    """row a15: the Huber kernel every solver of the oracle uses (orc_robust_huber; through it the rho_1 of the GPU's k_linearize /
+    k_pose_opt, which the BA parity tests hold against the oracle) against RobustKernelHuber::setDelta + ::robustify of the reference
+    (Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp:65-91, its own statements): golden vectors everywhere, live where the reference exists."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_huber.npz"))
+    for d, es, rhos in zip(g["delta"], g["e"], g["rho"]):
+        for e, rho in zip(es, rhos):
+            assert np.array_equal(_bits(oracle.robust_huber(d, e)), _bits(rho)), (d, e)
+    if oracle.ref() is not None:
+        rng = np.random.default_rng(77)
+        for _ in range(2000):
+            d = float(rng.uniform(0.05, 20.0))
+            e = float(d * d * np.exp(rng.uniform(-10, 10)))
+            assert np.array_equal(_bits(oracle.robust_huber(d, e)), _bits(oracle.ref_huber(d, e))), (d, e)
