@@ -624,19 +624,33 @@ namespace {
 constexpr long long kMfmaMinDistances = 64LL * 64LL;
 struct TwoSlot {
     uint8_t* desc = nullptr; dcs_keypoint* kp = nullptr; int32_t *n = nullptr, *pairs = nullptr, *best_i = nullptr, *best_d = nullptr, *second_d = nullptr;
+    int32_t* count = nullptr;                              // 16 spare ints right in front of best_i (a match count comes down in the same copy)
     int cap = 0;
 };
 int two_slot_upload(Scratch& s, const uint8_t* q, const dcs_keypoint* q_kp, int nq, const uint8_t* t, const dcs_keypoint* t_kp, int nt, TwoSlot& o)
 {
     int rc;
     o.cap = (std::max(nq, nt) + 127) & ~127;               // whole train tiles: the kernel never reads past a slot
-    const int32_t hn[2] = {nq, nt}, hp[2] = {0, 1};
-    if ((rc = s.alloc(&o.desc, (size_t)2 * o.cap * 32)) || (rc = s.upload_into(o.desc, q, (size_t)nq * 32)) ||
-        (rc = s.upload_into(o.desc + (size_t)o.cap * 32, t, (size_t)nt * 32)) || (rc = s.upload(&o.n, hn, 2)) || (rc = s.upload(&o.pairs, hp, 2)) ||
-        (rc = s.alloc(&o.best_i, (size_t)o.cap)) || (rc = s.alloc(&o.best_d, (size_t)o.cap)) || (rc = s.alloc(&o.second_d, (size_t)o.cap))) return rc;
-    if (q_kp && t_kp) {
-        if ((rc = s.alloc(&o.kp, (size_t)2 * o.cap)) || (rc = s.upload_into(o.kp, q_kp, (size_t)nq)) || (rc = s.upload_into(o.kp + o.cap, t_kp, (size_t)nt))) return rc;
+    // ONE staging image [descriptors slot 0 | slot 1 | counts, pair | key points slot 0 | slot 1] = one DMA operation; the unused tails
+    // of the slots travel along (whatever the pinned block holds: the kernels read a slot only up to its count / mask the rest)
+    const bool with_kp = q_kp && t_kp;
+    const size_t desc_bytes = (size_t)2 * o.cap * 32, kp_bytes = with_kp ? sizeof(dcs_keypoint) * 2 * (size_t)o.cap : 0;
+    uint8_t *d = nullptr, *h = nullptr;
+    if ((rc = s.stage(&d, &h, desc_bytes + 16 + kp_bytes))) return rc;
+    memcpy(h, q, (size_t)nq * 32);
+    memcpy(h + (size_t)o.cap * 32, t, (size_t)nt * 32);
+    const int32_t ints[4] = {nq, nt, 0, 1};
+    memcpy(h + desc_bytes, ints, 16);
+    o.desc = d; o.n = reinterpret_cast<int32_t*>(d + desc_bytes); o.pairs = o.n + 2;
+    if (with_kp) {
+        memcpy(h + desc_bytes + 16, q_kp, sizeof(dcs_keypoint) * (size_t)nq);
+        memcpy(h + desc_bytes + 16 + sizeof(dcs_keypoint) * (size_t)o.cap, t_kp, sizeof(dcs_keypoint) * (size_t)nt);
+        o.kp = reinterpret_cast<dcs_keypoint*>(d + desc_bytes + 16);
     }
+    // results side by side: one download
+    int32_t* res = nullptr;
+    if ((rc = s.alloc(&res, (size_t)3 * o.cap + 16))) return rc;
+    o.count = res; o.best_i = res + 16; o.best_d = o.best_i + o.cap; o.second_d = o.best_i + 2 * o.cap;
     return DCS_OK;
 }
 
@@ -762,8 +776,8 @@ int dcs_match_bf(const uint8_t* q, const dcs_keypoint* q_kp, int nq, const uint8
     Scratch s;
     if ((long long)nq * nt >= kMfmaMinDistances && nt < (1 << 22) && (!check_ori || (q_kp && t_kp))) {   // matrix-core kernel + the batched filter
         TwoSlot ts;
-        int32_t* dn1;
-        if ((rc = two_slot_upload(s, q, check_ori ? q_kp : nullptr, nq, t, check_ori ? t_kp : nullptr, nt, ts)) || (rc = s.alloc(&dn1, 1))) return rc;
+        if ((rc = two_slot_upload(s, q, check_ori ? q_kp : nullptr, nq, t, check_ori ? t_kp : nullptr, nt, ts))) return rc;
+        int32_t* dn1 = ts.count;
         if (!ts.kp && (rc = s.alloc(&ts.kp, 1))) return rc;                                  // never read without check_ori
         hipLaunchKernelGGL(k_knn2_pairs_mfma, dim3((ts.cap + kKnnQ - 1) / kKnnQ, 1), dim3(64 * kKnnWaves), 0, s.st, ts.desc, ts.n, ts.cap, ts.pairs,
                            ts.best_i, ts.best_d, ts.second_d);

@@ -132,6 +132,8 @@ struct dcs_orb {
     // staging for the host-buffer API
     DevBuf<dcs_keypoint> d_kp;
     DevBuf<uint8_t> d_desc;
+    DevBuf<uint8_t> d_out;               // one-shot host calls: [counts | key points | descriptors] in one block, one download
+    PinnedBuf<uint8_t> h_out;
     DevBuf<int32_t> d_n;
     PinnedBuf<dcs_keypoint> h_kp;
     PinnedBuf<uint8_t> h_desc;
@@ -328,7 +330,12 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     if (es.pending && (rc = harvest(es))) return rc;
     ev_t = es.t; ev_b = es.b; ev_f = es.f; es.dev_oct = device_octree;
     ++n_calls;
-    DCS_HIP(hipEventRecord(ev_t[0], stream));
+    // Stage timing (dcs_orb_timing_totals) brackets every stage with hipEvents; each record is a marker packet between two kernels and
+    // costs 5 - 10 us of queue latency -- 45 us of a 220-us dual-frame call. Calls of one or two images (a frame per call) skip them (DCS_ORB_TIMING=1 keeps them).
+    static const bool timing_always = getenv("DCS_ORB_TIMING") && atoi(getenv("DCS_ORB_TIMING")) != 0;
+    const bool timed = n_images > 2 || timing_always || no_overlap;
+#define DCS_MARK(e, s) do { if (timed) DCS_HIP(hipEventRecord(e, s)); } while (0)
+    DCS_MARK(ev_t[0], stream);
     int max_rw = 7, max_rh = 7;
     for (const CellDesc& c : h_cells) { max_rw = std::max(max_rw, (int)c.rw); max_rh = std::max(max_rh, (int)c.rh); }
     // Early FAST (DCS_ORB_FAST_SPLIT=k when the handle is created; OPT-IN): the cells of levels [0, k) -- most of the pixels -- start on
@@ -345,15 +352,15 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         if (cells_early > 0 && l == std::max(split - 1, 1)) {              // levels 0 .. split - 1 are complete (split == 1: level 0 needs no resize)
             DCS_HIP(hipEventRecord(ev_lvl, stream));
             DCS_HIP(hipStreamWaitEvent(s_fast, ev_lvl, 0));
-            DCS_HIP(hipEventRecord(ev_f[0], s_fast));
+            DCS_MARK(ev_f[0], s_fast);
             if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
                                         d_cell_count.p, max_rw, max_rh, s_fast, 0, cells_early))) return rc;
-            DCS_HIP(hipEventRecord(ev_f[1], s_fast));
+            DCS_MARK(ev_f[1], s_fast);
             DCS_HIP(hipEventRecord(ev_fast_early, s_fast));
         }
     }
-    if (cells_early == 0) { DCS_HIP(hipEventRecord(ev_f[0], stream)); DCS_HIP(hipEventRecord(ev_f[1], stream)); }
-    DCS_HIP(hipEventRecord(ev_t[1], stream));
+    if (cells_early == 0) { DCS_MARK(ev_f[0], stream); DCS_MARK(ev_f[1], stream); }
+    DCS_MARK(ev_t[1], stream);
     // blur on the auxiliary stream, overlapping FAST (DCS_ORB_NO_OVERLAP=1 serialises it for clean timings).
     // DCS_ORB_BLUR_LATE=1 starts it after FAST instead (measured slower: it then collides with the latency-bound
     // compaction + quadtree kernels, 1.64 vs 1.55 ms per 128 dual frames).
@@ -368,18 +375,18 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     static const bool blur_early = getenv("DCS_ORB_BLUR_LATE") == nullptr;
     hipStream_t sb = no_overlap ? stream : s_aux;
     auto blur_stage = [&]() -> int {
-        if (fused_blur) { DCS_HIP(hipEventRecord(ev_b[0], sb)); DCS_HIP(hipEventRecord(ev_b[1], sb)); return DCS_OK; }
+        if (fused_blur) { DCS_MARK(ev_b[0], sb); DCS_MARK(ev_b[1], sb); return DCS_OK; }
         if (!no_overlap) { DCS_HIP(hipEventRecord(ev_pyr, stream)); DCS_HIP(hipStreamWaitEvent(s_aux, ev_pyr, 0)); }
-        DCS_HIP(hipEventRecord(ev_b[0], sb));
+        DCS_MARK(ev_b[0], sb);
         int r = launch_blur(raw, blur, n_images, sb);
         if (r) return r;
-        DCS_HIP(hipEventRecord(ev_b[1], sb));
+        DCS_MARK(ev_b[1], sb);
         DCS_HIP(hipEventRecord(ev_blur, sb));
         return DCS_OK;
     };
     if (no_overlap || blur_early) {
         if ((rc = blur_stage())) return rc;
-        if (no_overlap) DCS_HIP(hipEventRecord(ev_t[1], stream));      // FAST timing starts after the blur
+        if (no_overlap) DCS_MARK(ev_t[1], stream);      // FAST timing starts after the blur
     }
 
     if (cells_early > 0) {
@@ -390,7 +397,9 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         // largest ROI of the LAUNCH, and that footprint decides how many cells a CU holds -- 5 104 B for the 38 x 38 ROIs of levels 0-3 of
         // the 640 x 480 pyramid = 32 waves per CU, 5.5 KB for levels 4-6 = 29, 6.6 KB for the 43-wide cells of level 7 = 24. One launch
         // sized for level 7's twelve cells held every level at 24 (DCS_ORB_FAST_GROUPS=0 restores it).
-        static const bool grouped = !(getenv("DCS_ORB_FAST_GROUPS") && atoi(getenv("DCS_ORB_FAST_GROUPS")) == 0);
+        // (calls of a few images are latency-bound: one launch there)
+        static const bool grouped_env = !(getenv("DCS_ORB_FAST_GROUPS") && atoi(getenv("DCS_ORB_FAST_GROUPS")) == 0);
+        const bool grouped = grouped_env && n_images > 8;
         auto wg_per_cu = [](int rw, int rh) { return std::min(32, 163840 / std::max(fast_cells_lds_bytes(rw, rh), 1)); };
         int l0 = 0;
         while (l0 < L) {
@@ -408,13 +417,13 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
             l0 = l1;
         }
     }
-    DCS_HIP(hipEventRecord(ev_t[2], stream));
+    DCS_MARK(ev_t[2], stream);
     if (cells_early > 0) DCS_HIP(hipStreamWaitEvent(stream, ev_fast_early, 0));      // the compaction needs every cell's count
     if (!(no_overlap || blur_early) && (rc = blur_stage())) return rc;
     if ((rc = launch_compact(d_cells.p, d_level_cell_begin.p, L, n_images, n_cells, d_slots.p, g.n_slots, d_cell_count.p,
                              d_cell_off.p, d_lvl_total.p, d_lvl_off.p, d_dense.p, dense_cap, stream))) return rc;
     const int n_tasks = n_images * L;
-    DCS_HIP(hipEventRecord(ev_t[3], stream));
+    DCS_MARK(ev_t[3], stream);
     last_tasks = n_tasks; host_copy_valid = false;
     DescribeParams dp{};
     for (int l = 0; l < L; ++l) { dp.scale[l] = t.scale[l]; dp.scaled_patch[l] = g.lv[l].scaled_patch; dp.out_base[l] = oct.lv[l].out_base; }
@@ -429,10 +438,10 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         OctScratch sc{d_oct_u64[0].p, d_oct_u8.p, d_oct_i32[0].p, d_oct_i32[1].p, d_oct_i32[2].p, d_oct_i32[3].p, d_oct_i32[4].p,
                       d_oct_i32[5].p, d_oct_i32[6].p, d_oct_i32[7].p, d_oct_u64[1].p, d_oct_u32[0].p, d_oct_u64[2].p, d_oct_u32[1].p};
         if ((rc = launch_octree(d_dense.p, d_lvl_off.p, oct, sc, n_tasks, (int)dense_cap, d_sel.p, d_lvl_cnt.p, d_oct_flag.p, stream))) return rc;
-        DCS_HIP(hipEventRecord(ev_t[6], stream));
+        DCS_MARK(ev_t[6], stream);
         host_us = -1.f;
         if (!fused_blur) DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
-        DCS_HIP(hipEventRecord(ev_t[4], stream));
+        DCS_MARK(ev_t[4], stream);
         if ((rc = launch_describe(raw, blur, dp, d_sel.p, nullptr, d_lvl_cnt.p, n_images, oct.out_per_image, d_kp_out, d_desc_out, cap,
                                   d_n_out, stream, d_lvl_off.p + n_tasks, (int)dense_cap, fused_blur))) return rc;
     } else {
@@ -480,14 +489,15 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         if (n_sel) DCS_HIP(hipMemcpyAsync(d_sel.p, h_sel.p, sizeof(SelKp) * n_sel, hipMemcpyHostToDevice, stream));
         DCS_HIP(hipMemcpyAsync(d_img_off.p, h_img_off.p, sizeof(int32_t) * (n_images + 1), hipMemcpyHostToDevice, stream));
         if (!fused_blur) DCS_HIP(hipStreamWaitEvent(stream, ev_blur, 0));
-        DCS_HIP(hipEventRecord(ev_t[4], stream));
+        DCS_MARK(ev_t[4], stream);
         if ((rc = launch_describe(raw, blur, dp, d_sel.p, d_img_off.p, nullptr, n_images, max_per_image, d_kp_out, d_desc_out, cap,
                                   d_n_out, stream, nullptr, 0, fused_blur))) return rc;
     }
-    DCS_HIP(hipEventRecord(ev_t[5], stream));
-    es.host_us = host_us; es.pending = true;
-    timing_valid = true;
+    DCS_MARK(ev_t[5], stream);
+    es.host_us = host_us; es.pending = timed;
+    timing_valid = timed;
     return DCS_OK;
+#undef DCS_MARK
 }
 
 int dcs_orb::harvest(EvSet& es)
@@ -757,32 +767,35 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
         DCS_HIP(hipMemcpyAsync(h->d_stage.p + i0 * img_bytes, h->h_img.p + i0 * img_bytes, img_bytes * m, hipMemcpyHostToDevice, h->s_main));
     }
     const size_t slots = (size_t)n_images * cap;
-    if ((rc = h->d_kp.resize(slots)) || (rc = h->d_desc.resize(slots * 32)) || (rc = h->d_n.resize(n_images)) || (rc = h->h_n.resize(n_images))) return rc;
-    std::vector<int> counts(n_images, 0);
-    rc = h->run(h->d_stage.p, img_bytes, pitch_s, n_images, h->d_kp.p, h->d_desc.p, cap, h->d_n.p, h->s_main, counts.data());
-    if (rc) { for (int i = 0; i < n_images; ++i) n_out[i] = counts[i]; return rc; }
     if (h->device_octree) {
-        // everything is still in flight: the slotted results follow in two copies, one synchronisation for the whole call
-        if ((rc = h->h_kp_out.resize(slots)) || (rc = h->h_desc_out.resize(slots * 32))) return rc;
-        DCS_HIP(hipMemcpyAsync(h->h_n.p, h->d_n.p, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost, h->s_main));
-        DCS_HIP(hipMemcpyAsync(h->h_lvl_off.p, h->d_lvl_off.p, sizeof(int32_t) * (n_images * h->t.nlevels + 1), hipMemcpyDeviceToHost, h->s_main));
-        DCS_HIP(hipMemcpyAsync(h->h_kp_out.p, h->d_kp.p, sizeof(dcs_keypoint) * slots, hipMemcpyDeviceToHost, h->s_main));
-        DCS_HIP(hipMemcpyAsync(h->h_desc_out.p, h->d_desc.p, slots * 32, hipMemcpyDeviceToHost, h->s_main));
+        // The results of the call live in ONE device block [counts | key points | descriptors] and come down in ONE copy behind the
+        // kernels: one synchronisation for the whole call (a dual frame per call is latency-bound: every DMA operation counts).
+        const size_t o_kp = ((sizeof(int32_t) * n_images + 255) & ~(size_t)255), o_desc = o_kp + ((sizeof(dcs_keypoint) * slots + 255) & ~(size_t)255),
+                     total = o_desc + slots * 32;
+        if ((rc = h->d_out.resize(total)) || (rc = h->h_out.resize(total))) return rc;
+        int32_t* d_cnt = reinterpret_cast<int32_t*>(h->d_out.p);
+        dcs_keypoint* d_kps = reinterpret_cast<dcs_keypoint*>(h->d_out.p + o_kp);
+        uint8_t* d_dsc = h->d_out.p + o_desc;
+        if ((rc = h->run(h->d_stage.p, img_bytes, pitch_s, n_images, d_kps, d_dsc, cap, d_cnt, h->s_main, nullptr))) return rc;
+        DCS_HIP(hipMemcpyAsync(h->h_out.p, h->d_out.p, total, hipMemcpyDeviceToHost, h->s_main));
         DCS_HIP(hipStreamSynchronize(h->s_main));
-        if ((size_t)h->h_lvl_off.p[n_images * h->t.nlevels] > h->dense_cap) {
-            set_error("FAST candidates (%d) exceed the dense buffer (%zu)", h->h_lvl_off.p[n_images * h->t.nlevels], h->dense_cap);
-            return DCS_ERR_CAPACITY;
-        }
+        const int32_t* cnt = reinterpret_cast<const int32_t*>(h->h_out.p);
+        for (int i = 0; i < n_images; ++i)
+            if (cnt[i] < 0) { set_error("FAST candidates exceed the dense buffer of the handle (%zu)", h->dense_cap); return cnt[i]; }      // k_describe reports DCS_ERR_CAPACITY in place of a count
         for (int i = 0; i < n_images; ++i) {
-            const int c = h->h_n.p[i];
+            const int c = std::min(cnt[i], cap);
             if (c) {
-                memcpy(kp + (size_t)i * cap, h->h_kp_out.p + (size_t)i * cap, sizeof(dcs_keypoint) * c);
-                memcpy(desc + (size_t)i * cap * 32, h->h_desc_out.p + (size_t)i * cap * 32, (size_t)32 * c);
+                memcpy(kp + (size_t)i * cap, h->h_out.p + o_kp + sizeof(dcs_keypoint) * (size_t)i * cap, sizeof(dcs_keypoint) * c);
+                memcpy(desc + (size_t)i * cap * 32, h->h_out.p + o_desc + (size_t)i * cap * 32, (size_t)32 * c);
             }
             n_out[i] = c;
         }
         return DCS_OK;
     }
+    if ((rc = h->d_kp.resize(slots)) || (rc = h->d_desc.resize(slots * 32)) || (rc = h->d_n.resize(n_images)) || (rc = h->h_n.resize(n_images))) return rc;
+    std::vector<int> counts(n_images, 0);
+    rc = h->run(h->d_stage.p, img_bytes, pitch_s, n_images, h->d_kp.p, h->d_desc.p, cap, h->d_n.p, h->s_main, counts.data());
+    if (rc) { for (int i = 0; i < n_images; ++i) n_out[i] = counts[i]; return rc; }
     // host-quadtree mode: counts are known on the host already
     size_t total = 0;
     for (int i = 0; i < n_images; ++i) total += (size_t)counts[i];
