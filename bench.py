@@ -115,7 +115,7 @@ class Pipeline:
     """extraction + matching of `streams` x `frames` dual frames per step, HBM-resident, double-buffered feature slots:
     matching of step i (main stream) overlaps the extraction of step i + 1 (extractor streams)."""
 
-    def __init__(self, pkg, torch, dev, local_rank, W, H, NF, streams, frames, n_lanes, stream_base, n_events, n_sets=1):
+    def __init__(self, pkg, torch, dev, local_rank, W, H, NF, streams, frames, n_lanes, stream_base, n_events, n_sets=1, stream_factory=None):
         synth = pkg.synth
         self.pkg, self.torch, self.dev = pkg, torch, dev
         self.W, self.H, self.NF, self.streams, self.frames = W, H, NF, streams, frames
@@ -145,7 +145,7 @@ class Pipeline:
         self.lane_pairs = [P // n_lanes + (1 if i < P % n_lanes else 0) for i in range(n_lanes)]
         self.exts = [pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local_rank, max_images=2 * lp) for lp in self.lane_pairs]
         self.ext = self.exts[0]
-        self.lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
+        self.lane_streams = [(stream_factory() if stream_factory else torch.cuda.Stream(device=dev)) for _ in range(n_lanes)]
         self.lane_done = [torch.cuda.Event() for _ in range(n_lanes)]
         self.matcher = pkg.ORBmatcher(0.75, True)
         cap = self.cap = self.ext.default_cap()
@@ -259,50 +259,80 @@ class Pipeline:
 
 def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
     """BASELINE config C5 on ONE GPU: 8 dual-camera streams (1280x720, 2000 features / camera), one new dual frame per stream per
-    step, next to one local BA per stream (dcs_ba_local_batch from a second host thread, its own HIP stream). The reference's
-    pattern: Tracking thread extracts / matches while the LocalMapping thread runs LocalBundleAdjustment (src/LocalMapping.cc:97-104)."""
+    step, next to one local BA per stream (dcs_ba_local_batch from a second host thread, its own HIP streams). The reference's
+    pattern: Tracking thread extracts / matches while the LocalMapping thread runs LocalBundleAdjustment (src/LocalMapping.cc:97-104).
+    Measured time-sliced (both sides on every CU) and PARTITIONED: the solver's streams on `ba_cus` compute units, the front end's on
+    the others (CU masks; sweep over the split)."""
     synth = pkg.synth
-    pipe = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 8, 1, 1, 0, 64)
     preps = [pkg.Optimizer.prepare(synth.ba_problem(seed=42 + s)) for s in range(n_ba)]
-    for _ in range(2):
-        pkg.Optimizer.LocalBundleAdjustmentBatch(preps)
-
-    def ba_calls(n):
-        its, t0 = 0, time.perf_counter()
-        for _ in range(n):
-            _check_batch(pkg, preps)
-            its += sum(sum(p.res.n_iters) for p in preps)
-        return its, time.perf_counter() - t0
-
     steps = 150                                   # the concurrent window is 3 x this: ~150 ms, 30+ BA rounds
-    dt_alone = pipe.run(steps, 3)
-    feats = pipe.features_per_step()
-    its_alone, t_ba_alone = ba_calls(10)
-    stop = threading.Event()
-    ba_stat = {"its": 0, "calls": 0, "t": 0.0}
 
-    def ba_worker():
-        t0 = time.perf_counter()
-        while not stop.is_set():
-            _check_batch(pkg, preps)
-            ba_stat["its"] += sum(sum(p.res.n_iters) for p in preps)
-            ba_stat["calls"] += 1
-        ba_stat["t"] = time.perf_counter() - t0
+    def one_config(ba_cus):
+        ext_streams = []
 
-    th = threading.Thread(target=ba_worker)
-    th.start()
-    time.sleep(0.02)
-    dt_both = pipe.run(3 * steps, 2)
-    stop.set()
-    th.join()
-    out = {"workload": "configs[4] on ONE GPU (time-sliced; C5 proper is one stream per GPU): 8 dual 1280x720 streams, 2000 feat/cam, "
-                       "1 new dual frame per stream per step (extract + 3 matches) next to 8 concurrent local BAs (50 KF / 2000 MP each, one dcs_ba_local_batch per round)",
-           "features_per_step": feats,
-           "concurrent": {"kfeatures_s": round(feats * 3 * steps / dt_both / 1e3, 1), "dual_frames_s": round(8 * 3 * steps / dt_both, 1),
-                          "ba_iters_s": round(ba_stat["its"] / max(ba_stat["t"], 1e-9), 1), "ba_rounds": ba_stat["calls"]},
-           "alone": {"kfeatures_s": round(feats * steps / dt_alone / 1e3, 1), "dual_frames_s": round(8 * steps / dt_alone, 1),
-                     "ba_iters_s": round(its_alone / t_ba_alone, 1)}}
-    pipe.close()
+        def masked_stream():
+            ext_streams.append(pkg.abi.cu_range_stream(ba_cus, N_CU - ba_cus))
+            return torch.cuda.ExternalStream(ext_streams[-1], device=dev)
+        pkg.abi.ba_release_thread()
+        pkg.abi.ba_set_cu_range(0, ba_cus)          # 0 CUs = no restriction
+        main = masked_stream() if ba_cus else torch.cuda.current_stream()
+        with torch.cuda.stream(main):
+            pipe = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 8, 1, 1, 0, 64, stream_factory=masked_stream if ba_cus else None)
+            for _ in range(2):
+                pkg.Optimizer.LocalBundleAdjustmentBatch(preps)
+
+            def ba_calls(n):
+                its, t0 = 0, time.perf_counter()
+                for _ in range(n):
+                    _check_batch(pkg, preps)
+                    its += sum(sum(p.res.n_iters) for p in preps)
+                return its, time.perf_counter() - t0
+            dt_alone = pipe.run(steps, 3)
+            feats = pipe.features_per_step()
+            its_alone, t_ba_alone = ba_calls(10)
+            stop = threading.Event()
+            ba_stat = {"its": 0, "calls": 0, "t": 0.0}
+
+            def ba_worker():
+                t0 = time.perf_counter()
+                while not stop.is_set():
+                    _check_batch(pkg, preps)
+                    ba_stat["its"] += sum(sum(p.res.n_iters) for p in preps)
+                    ba_stat["calls"] += 1
+                ba_stat["t"] = time.perf_counter() - t0
+                pkg.abi.ba_release_thread()
+
+            th = threading.Thread(target=ba_worker)
+            th.start()
+            time.sleep(0.02)
+            dt_both = pipe.run(3 * steps, 2)
+            stop.set()
+            th.join()
+            pipe.close()
+        torch.cuda.synchronize()
+        for s_ in ext_streams:
+            pkg.abi.lib().dcs_stream_destroy(s_)
+        return {"ba_cus": ba_cus, "front_end_cus": N_CU - ba_cus if ba_cus else N_CU, "features_per_step": feats,
+                "concurrent": {"kfeatures_s": round(feats * 3 * steps / dt_both / 1e3, 1), "dual_frames_s": round(8 * 3 * steps / dt_both, 1),
+                               "ba_iters_s": round(ba_stat["its"] / max(ba_stat["t"], 1e-9), 1), "ba_rounds": ba_stat["calls"]},
+                "alone": {"kfeatures_s": round(feats * steps / dt_alone / 1e3, 1), "dual_frames_s": round(8 * steps / dt_alone, 1),
+                          "ba_iters_s": round(its_alone / t_ba_alone, 1)}}
+
+    sliced = one_config(0)
+    sweep = [one_config(c) for c in ((16, 32, 48, 64) if not os.environ.get("DCS_BENCH_C5_NO_SWEEP") else (32,))]
+    pkg.abi.ba_release_thread()
+    pkg.abi.ba_set_cu_range(0, 0)
+    # the split that keeps the most of BOTH sides relative to the unrestricted stand-alone rates
+    ref_f, ref_b = sliced["alone"]["kfeatures_s"], sliced["alone"]["ba_iters_s"]
+    for r in sweep:
+        r["vs_unrestricted_alone"] = {"front_end": round(r["concurrent"]["kfeatures_s"] / max(ref_f, 1e-9), 3), "ba": round(r["concurrent"]["ba_iters_s"] / max(ref_b, 1e-9), 3)}
+    best = max(sweep, key=lambda r: min(r["vs_unrestricted_alone"]["front_end"] / 0.9, r["vs_unrestricted_alone"]["ba"] / 0.7))
+    out = {"workload": "configs[4] on ONE GPU (C5 proper is one stream per GPU): 8 dual 1280x720 streams, 2000 feat/cam, 1 new dual frame per stream per step "
+                       "(extract + 3 matches) next to 8 concurrent local BAs (50 KF / 2000 MP each, one dcs_ba_local_batch per round)",
+           "features_per_step": sliced["features_per_step"],
+           "concurrent": sliced["concurrent"], "alone": sliced["alone"],
+           "time_sliced_vs_alone": {"front_end": round(sliced["concurrent"]["kfeatures_s"] / max(ref_f, 1e-9), 3), "ba": round(sliced["concurrent"]["ba_iters_s"] / max(ref_b, 1e-9), 3)},
+           "partitioned": best, "partition_sweep": sweep}
     return out
 
 

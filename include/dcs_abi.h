@@ -47,6 +47,21 @@ const char* dcs_last_error(void);          /* thread-local text of the last fail
 const char* dcs_version(void);
 int dcs_device_count(void);
 
+/* ---- chip partitioning for config C5 (one dual-camera stream extracting / matching next to its LocalMapping thread's local BA,
+ * src/LocalMapping.cc:97-104 beside src/Tracking.cc:236-269). The bundle adjustment is a chain of short kernels around a one-workgroup
+ * factorisation that needs a CU's whole LDS; time-sliced against a front end that fills every CU it waits for CUs to drain. A CU mask
+ * gives each side its own compute units (hipExtStreamCreateWithCUMask; mask bit k selects a CU of XCD k mod 8, so a prefix of the bits
+ * spreads evenly over the eight XCDs).
+ *   dcs_stream_create_cu_range  a stream restricted to the CUs [first_cu, first_cu + n_cus) of the mask order, for the caller's front-end
+ *                               launches (the _device entry points run on the caller's stream)
+ *   dcs_ba_set_cu_range         every solver stream created AFTER the call (new host threads, or after dcs_ba_release_thread) is
+ *                               restricted to that range; n_cus = 0 removes the restriction. Environment: DCS_BA_CUS="first:count".
+ *   dcs_ba_release_thread       frees the calling thread's solver context (arena, pinned words, streams); the next call rebuilds it */
+int  dcs_stream_create_cu_range(int first_cu, int n_cus, void** stream);
+void dcs_stream_destroy(void* stream);
+int  dcs_ba_set_cu_range(int first_cu, int n_cus);
+int  dcs_ba_release_thread(void);
+
 /* cv::KeyPoint layout, 28 bytes: pt.x, pt.y, size, angle, response, octave, class_id */
 typedef struct dcs_keypoint {
     float x, y, size, angle, response;

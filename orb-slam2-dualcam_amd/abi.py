@@ -28,6 +28,7 @@ SYMBOLS = [
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_in_window", "dcs_search_for_initialization",
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
+    "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
     "dcs_kfdb_create", "dcs_kfdb_destroy", "dcs_kfdb_add", "dcs_kfdb_erase", "dcs_kfdb_clear", "dcs_kfdb_size", "dcs_kfdb_query",
 ]
@@ -125,6 +126,9 @@ def lib():
             "dcs_ba_local": [C.POINTER(BaProblem), vp, C.POINTER(BaResult)],
             "dcs_ba_local_batch": [ci, vp, vp, vp],
             "dcs_ba_timing": [ci, vp],
+            "dcs_stream_create_cu_range": [ci, ci, C.POINTER(vp)],
+            "dcs_ba_set_cu_range": [ci, ci],
+            "dcs_ba_release_thread": [],
             "dcs_comm_unique_id": [vp],
             "dcs_comm_create": [vp, ci, ci, C.POINTER(vp)],
             "dcs_comm_destroy": [vp],
@@ -159,6 +163,9 @@ def lib():
             L.dcs_kfdb_destroy.restype = None
         if hasattr(L, "dcs_comm_destroy"):
             L.dcs_comm_destroy.restype = None
+        if hasattr(L, "dcs_stream_destroy"):
+            L.dcs_stream_destroy.restype = None
+            L.dcs_stream_destroy.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -912,3 +919,18 @@ def projection_queries(fr, desc, angle=None):
     return dict(valid=fr["in_view"], cam=np.maximum(fr["cam"], 0).astype(np.int32), u=fr["u"], v=fr["v"], radius=fr["radius"],
                 min_level=(fr["level"] - 1).astype(np.int32), max_level=(fr["level"] + 1).astype(np.int32), desc=_c(desc, np.uint8).reshape(-1, 32),
                 angle=_c(angle, np.float32) if angle is not None else np.zeros(n, np.float32))
+
+
+def cu_range_stream(first_cu, n_cus):
+    """dcs_stream_create_cu_range: raw hipStream_t (int) restricted to CUs [first_cu, first_cu + n_cus) of the CU-mask order"""
+    h = C.c_void_p()
+    _check(lib().dcs_stream_create_cu_range(int(first_cu), int(n_cus), C.byref(h)), "dcs_stream_create_cu_range")
+    return h.value
+
+
+def ba_set_cu_range(first_cu, n_cus):
+    _check(lib().dcs_ba_set_cu_range(int(first_cu), int(n_cus)), "dcs_ba_set_cu_range")
+
+
+def ba_release_thread():
+    _check(lib().dcs_ba_release_thread(), "dcs_ba_release_thread")

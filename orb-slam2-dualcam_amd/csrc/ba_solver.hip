@@ -1712,6 +1712,20 @@ using namespace dcs;
 
 namespace {
 
+// CU range of the solver's streams: process-wide, set by dcs_ba_set_cu_range or DCS_BA_CUS="first:count" (read once)
+static void ba_cu_range(int& first, int& count, bool set)
+{
+    static std::mutex mu;
+    static int s_first = 0, s_count = -1;
+    std::lock_guard<std::mutex> lk(mu);
+    if (set) { s_first = first; s_count = count; return; }
+    if (s_count < 0) {
+        s_first = 0; s_count = 0;
+        if (const char* e = getenv("DCS_BA_CUS")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && b > 0) { s_first = a; s_count = b; } }
+    }
+    first = s_first; count = s_count;
+}
+
 // Per host thread and device, kept across solves: the device arena (grow-only), the pinned staging image of its
 // upload / download regions, the pinned progress + stop words and the stream. hipMalloc + hipFree of ~30 MB,
 // hipHostMalloc/Free and stream create/destroy cost ~1.4 ms per call together -- a third of a local BA.
@@ -1802,10 +1816,13 @@ struct BaContext {
     // the short, gap-ridden kernels of the solver keep preempting the dispatch of the front end's waves.
     static hipError_t create_stream(hipStream_t* s)
     {
-        static const bool high = getenv("DCS_BA_STREAM_PRIORITY") && atoi(getenv("DCS_BA_STREAM_PRIORITY")) != 0;
+        int first = 0, count = 0;
+        ba_cu_range(first, count, false);
+        if (count > 0) return create_cu_range_stream(s, first, count);      // config C5: the solver keeps its own compute units (dcs_ba_set_cu_range)
+        static const int prio = getenv("DCS_BA_STREAM_PRIORITY") ? atoi(getenv("DCS_BA_STREAM_PRIORITY")) : 0;      // 1: highest, -1: lowest
         int least = 0, greatest = 0;
-        if (high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-            return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+        if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio > 0 ? greatest : least);
         return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     }
     int prepare_groups(int n_groups)
@@ -2402,6 +2419,19 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     if (trace_t)
         fprintf(stderr, "[dcs_ba] %d problems, total %.3f ms: build_round %.3f, layout + staging %.3f, optimise %.3f (%d steps enqueued, host waited %.3f)\n",
                 NB, ms_since(t_call0), t_build, ms_since(t_call0) - t_build - opt_ms, (double)opt_ms, steps, t_wait);
+    return DCS_OK;
+}
+
+int dcs_ba_set_cu_range(int first_cu, int n_cus)
+{
+    if (first_cu < 0 || n_cus < 0) { set_error("dcs_ba_set_cu_range: bad range"); return DCS_ERR_INVALID; }
+    ba_cu_range(first_cu, n_cus, true);
+    return DCS_OK;
+}
+
+int dcs_ba_release_thread(void)
+{
+    ba_context().release();
     return DCS_OK;
 }
 

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 namespace dcs {
 
@@ -80,12 +81,38 @@ void* ThreadArena::take(bool pinned, size_t bytes)
 
 ThreadArena& thread_arena() { static thread_local ThreadArena a; return a; }
 
+// stream restricted to CUs [first, first + count) of the CU-mask bit order (bit k -> a CU of XCD k mod 8 on gfx950: a prefix spreads evenly)
+hipError_t create_cu_range_stream(hipStream_t* s, int first, int count)
+{
+    int n_cu = 0, dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    if (count <= 0 || first < 0 || first + count > n_cu) return hipErrorInvalidValue;
+    std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+    for (int k = first; k < first + count; ++k) mask[(size_t)k >> 5] |= 1u << (k & 31);
+    return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+}
+
 }  // namespace dcs
 
 extern "C" {
 
 const char* dcs_last_error(void) { return dcs::g_err; }
 const char* dcs_version(void) { return "dcs-hip 0.1 (gfx950)"; }
+int dcs_stream_create_cu_range(int first_cu, int n_cus, void** stream)
+{
+    if (!stream) { dcs::set_error("null stream pointer"); return DCS_ERR_INVALID; }
+    int rc = dcs::ensure_device();
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    const hipError_t e = dcs::create_cu_range_stream(&s, first_cu, n_cus);
+    if (e != hipSuccess) { dcs::set_error("dcs_stream_create_cu_range(%d, %d): %s", first_cu, n_cus, hipGetErrorString(e)); (void)hipGetLastError(); return e == hipErrorInvalidValue ? DCS_ERR_INVALID : DCS_ERR_HIP; }
+    *stream = s;
+    return DCS_OK;
+}
+void dcs_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
+
 int dcs_device_count(void)
 {
     int n = 0;

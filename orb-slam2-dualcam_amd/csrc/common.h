@@ -77,6 +77,7 @@ struct ThreadArena {
     void* take(bool pinned, size_t bytes);               // 256-byte aligned; nullptr on allocation failure
 };
 ThreadArena& thread_arena();
+hipError_t create_cu_range_stream(hipStream_t* s, int first, int count);   // CUs [first, first + count) of the CU-mask bit order
 
 struct Scratch {
     ThreadArena& a;

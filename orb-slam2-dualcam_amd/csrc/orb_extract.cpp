@@ -397,9 +397,10 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         // largest ROI of the LAUNCH, and that footprint decides how many cells a CU holds -- 5 104 B for the 38 x 38 ROIs of levels 0-3 of
         // the 640 x 480 pyramid = 32 waves per CU, 5.5 KB for levels 4-6 = 29, 6.6 KB for the 43-wide cells of level 7 = 24. One launch
         // sized for level 7's twelve cells held every level at 24 (DCS_ORB_FAST_GROUPS=0 restores it).
-        // (calls of a few images are latency-bound: one launch there)
+        // Small batches are latency-bound -- one launch there: 16 images of 1280 x 720 (config C5's step) run at 89 k kfeatures/s with
+        // one launch against 80 k with three.
         static const bool grouped_env = !(getenv("DCS_ORB_FAST_GROUPS") && atoi(getenv("DCS_ORB_FAST_GROUPS")) == 0);
-        const bool grouped = grouped_env && n_images > 8;
+        const bool grouped = grouped_env && n_images >= 64;
         auto wg_per_cu = [](int rw, int rh) { return std::min(32, 163840 / std::max(fast_cells_lds_bytes(rw, rh), 1)); };
         int l0 = 0;
         while (l0 < L) {

@@ -92,21 +92,26 @@ def test_ba_batch_ragged_and_stop_flags(pkg, oracle, synth):
         pkg.Optimizer.LocalBundleAdjustment(dup)
 
 
-def test_ba_batch_concurrent_with_extraction(pkg, oracle, synth):
+@pytest.mark.parametrize("ba_cus", [0, 32], ids=["time-sliced", "solver on 32 CUs, front end on 224"])
+def test_ba_batch_concurrent_with_extraction(pkg, oracle, synth, ba_cus):
     """The reference's threading: Tracking extracts while LocalMapping runs LocalBundleAdjustment (src/LocalMapping.cc:97-104).
     A host thread solves a BA batch on the solver's own HIP stream while this thread runs dcs_orb_extract_batch_device on
-    another stream; both results must equal their solo runs bit for bit (and the oracle)."""
+    another stream; both results must equal their solo runs bit for bit (and the oracle). Second variant: the chip partitioned with CU
+    masks (dcs_ba_set_cu_range / dcs_stream_create_cu_range) -- where the kernels run must not change a bit of what they compute."""
     import threading
     import torch
     pbs = [synth.ba_problem(n_poses=30, n_fixed=5, n_points=900, obs_per_point=8, seed=60 + s) for s in range(4)]
     solo = pkg.Optimizer.LocalBundleAdjustmentBatch(pbs)
+    pkg.abi.ba_release_thread()
+    pkg.abi.ba_set_cu_range(0, ba_cus)
+    raw_stream = pkg.abi.cu_range_stream(ba_cus, 256 - ba_cus) if ba_cus else None
     imgs = [im for f in range(4) for im in synth.frame_pair(640, 480, 1, f)]
     e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=len(imgs))
     cap, B = e.default_cap(), len(imgs)
     d_img = torch.from_numpy(np.stack(imgs)).cuda()
     bufs = [(torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"), torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
              torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(2)]
-    st = torch.cuda.Stream()
+    st = torch.cuda.ExternalStream(raw_stream) if ba_cus else torch.cuda.Stream()
     e.extract_batch_device(d_img, *bufs[0], cap, stream=st.cuda_stream)
     torch.cuda.synchronize()
     got, err = [], []
@@ -117,6 +122,8 @@ def test_ba_batch_concurrent_with_extraction(pkg, oracle, synth):
                 got.append(pkg.Optimizer.LocalBundleAdjustmentBatch(pbs))
         except Exception as ex:            # noqa: BLE001
             err.append(ex)
+        finally:
+            pkg.abi.ba_release_thread()
     th = threading.Thread(target=ba_thread)
     th.start()
     n_ext = 0
@@ -138,6 +145,12 @@ def test_ba_batch_concurrent_with_extraction(pkg, oracle, synth):
     n3 = int(bufs[1][2][3])
     assert n3 == len(okp) and np.array_equal(bufs[1][1][3, :n3].cpu().numpy(), odesc)
     e.close()
+    pkg.abi.ba_set_cu_range(0, 0)
+    if raw_stream:
+        torch.cuda.synchronize()
+        pkg.abi.lib().dcs_stream_destroy(raw_stream)
+    with pytest.raises(pkg.DcsError):
+        pkg.abi.cu_range_stream(250, 16)                      # beyond the chip's 256 CUs
 
 
 def test_ba_ill_conditioned_documented_bound(pkg, oracle, synth):
