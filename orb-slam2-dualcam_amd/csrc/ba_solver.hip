@@ -7,9 +7,10 @@
 // diagonal, landmark back-substitution), solvers/linear_solver_eigen.h:94-124 (LDL^T of the reduced
 // camera system), core/optimization_algorithm_levenberg.cpp:61-189 (LM control), se3quat.h:223-257 (exp).
 //
-// Flat SoA problem in HBM, no graph objects. Launches per LM iteration (every list walk is a latency chain, so each
+// Flat SoA problem in HBM, no graph objects. Launches per LM step, 7 (every list walk is a latency chain, so each
 // reduction uses many short chunks with several loads in flight, and small kernels share launches):
-//   k_linearize     edge-parallel Jacobians -> per-edge H_pl (6x3) and per-edge pose / point contributions
+//   k_begin         edge-parallel: what happens BETWEEN iterations (round change: outlier flags, level-1 set, robust kernel off;
+//                   errors of a stale state), then the Jacobians -> per-edge H_pl (6x3) and per-edge pose / point contributions
 //   k_reduce_pose   one launch: segmented sums of the pose blocks (37 chunks per free pose) and of the landmark blocks,
 //                   CSR order, no atomics (reproducible)
 //   per trial (5 launches + one 40-byte read-back):
@@ -23,9 +24,8 @@
 //                   multi-launch fallback for n > 256)
 //   k_solve_update  landmark back-substitution, push + manifold update of all estimates, computeScale partials
 //   k_error<1>      edge-parallel residual + chi2 + Huber rho of the trial estimates; the problem's last block adds the block
-//                   partials (and the scale partials) in index order and runs g2o's accept / reject logic ON THE DEVICE
-//   k_post          between iterations: round change (outlier flags, level-1 set, robust kernel off), errors of a stale state,
-//                   progress words for the host
+//                   partials (and the scale partials) in index order and runs g2o's accept / reject logic ON THE DEVICE;
+//                   the grid's last block publishes the step to the host's pinned progress word
 // Every kernel covers a whole batch of problems (blockIdx.y); the host only enqueues steps and watches a pinned progress word.
 #include <hip/hip_runtime.h>
 
@@ -191,10 +191,10 @@ struct BaProb {
     double *Hll, *bl, *Dinv, *db, *xl;             // per landmark
     double *Hpp, *bp, *bsch, *xp;                  // per free pose
     double *S, *W;                                 // reduced camera system (ld x ld), panel scratch of the n > 256 fallback
-    const int32_t *pose_idx, *pt_off, *pt_edges, *ps_off, *ps_edges, *pair_ij, *pair_off, *pair_e1, *pair_e2;
+    const int32_t *pose_idx, *pt_off, *pt_edges, *ps_off, *ps_edges, *pair_ij, *pair_off, *pair_e;      // pair_e: (e1, e2) interleaved, one 8-byte load per list entry
     double *partial, *scale_part, *maxd_part;      // block partials: chi2, computeScale, max |diagonal| (np + nb_pts entries)
     uint8_t* pt_active;
-    unsigned* ticket;                              // [0] error kernels, [1] k_reduce_pose, [2] k_post
+    unsigned* ticket;                              // [0] error kernels, [1] k_reduce_pose, [2] k_begin
     const DCams* cams;
     double *out_poses, *out_points;
 };
@@ -214,16 +214,55 @@ __device__ __forceinline__ void load_cams(DCams* dst, const DCams* src)
 //   TRIAL = 0  computeActiveErrors at the top of an LM iteration whose errors are stale (first iteration of a round, or
 //              after a rejected trial): evaluated at the current estimates, sets currentChi
 //   TRIAL = 1  errors of the trial estimates [cur ^ 1], + computeScale, then accept / reject, lambda update, termination
-template <int TRIAL>
-__global__ __launch_bounds__(256) void k_error(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, const volatile int* __restrict__ stop_words)
+// Progress for the host, ONE pinned 64-bit word {finished problems : step} per group of problems, written with a system-scope release
+// store, so the host decides from a single acquire load and "all done" can never be seen ahead of the results. Only the threads that
+// END something publish -- no grid-wide arrival counter, no extra barrier in the other blocks (a grid-wide ticket in every block cost
+// 2 us per kernel):
+//   * a problem ends in k_begin: its finisher (the problem's last block, which has acquired every other block's release) bumps
+//     grid_ticket[2] = finished problems of the group and publishes it under the current step number;
+//   * a step ends in k_error<1>: the problems still live (B - finished: none of them can be in ROUND_END there) each have exactly one
+//     finisher thread, the last of THOSE to arrive (grid_ticket[0]) advances grid_ticket[1] = steps finished and publishes.
+// The counters live on the device so that every launch of a step has the same arguments (the step can be replayed as one hipGraph).
+__device__ __forceinline__ void publish_word(int* __restrict__ h_progress, unsigned done, unsigned step)
 {
-    __shared__ double s[256];
-    __shared__ DCams cams;
-    __shared__ bool last;
-    const BaProb& pb = probs[blockIdx.y];
-    BaCtl& ctl = ctls[blockIdx.y];
-    if ((int)blockIdx.x >= pb.nblk) return;
-    if (TRIAL ? ctl.state > ST_RETRY : (ctl.state != ST_NEW_ITER || ctl.errors_current)) return;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(h_progress), ((unsigned long long)done << 32) | step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void publish_step_end(int B, int* __restrict__ h_progress, unsigned* __restrict__ grid_ticket)      // one thread per live problem
+{
+    const unsigned done = __hip_atomic_load(grid_ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned live = (unsigned)B - done;
+    if (live > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (__hip_atomic_fetch_add(grid_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != live - 1) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(grid_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned step = grid_ticket[1] + 1;
+    grid_ticket[1] = step;
+    publish_word(h_progress, done, step);
+}
+__device__ __forceinline__ void publish_problem_end(int* __restrict__ h_progress, unsigned* __restrict__ grid_ticket)          // the finisher of a problem that ended
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(grid_ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Several problems may end in the same launch: every finisher publishes the count it READS and repeats until the count has not moved
+    // after its store has completed -- the store of the largest count is then the last one to land, whatever order the finishers ran in
+    // (without the re-check a batch whose problems all end in one launch could leave the word one problem short for ever: the no-op
+    // steps behind it publish nothing).
+    const unsigned step = grid_ticket[1];
+    unsigned v;
+    do {
+        v = __hip_atomic_load(grid_ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish_word(h_progress, v, step);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } while (__hip_atomic_load(grid_ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != v);
+}
+
+template <int TRIAL>
+__device__ __forceinline__ bool error_body(const BaProb& pb, BaCtl& ctl, const volatile int* __restrict__ stop_words, double* s /*[256]*/, DCams& cams, bool& last)
+{   // returns true in the ONE thread of the problem that ran the accept / reject logic
+    if ((int)blockIdx.x >= pb.nblk) return false;
+    if (TRIAL ? ctl.state > ST_RETRY : (ctl.state != ST_NEW_ITER || ctl.errors_current)) return false;
     const int robust = ctl.robust, E = pb.E;
     const double delta = pb.delta;
     const double* __restrict__ poses = pb.poses[TRIAL ? ctl.cur ^ 1 : ctl.cur];
@@ -251,7 +290,7 @@ __global__ __launch_bounds__(256) void k_error(const BaProb* __restrict__ probs,
         last = (prev == (unsigned)pb.nblk - 1);
     }
     __syncthreads();
-    if (!last) return;
+    if (!last) return false;
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     double v = 0;
@@ -260,13 +299,13 @@ __global__ __launch_bounds__(256) void k_error(const BaProb* __restrict__ probs,
     if (threadIdx.x == 0) __hip_atomic_store(pb.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!TRIAL) {
         if (threadIdx.x == 0) { ctl.currentChi = tot; ctl.iniChi = tot; ctl.errors_current = 1; }
-        return;
+        return false;
     }
     __syncthreads();
     double w = 0;                                   // computeScale: block partials of k_solve_update (an earlier launch), fixed order
     for (int i = threadIdx.x; i < pb.nb_pts + pb.nb_pose; i += 256) w += pb.scale_part[i];
     const double sc = block_sum_256(w, s);
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0) return false;
     // ---- accept / reject (optimization_algorithm_levenberg.cpp:104-164)
     ++ctl.n_trials[ctl.round];
     double tempChi = tot;
@@ -289,7 +328,7 @@ __global__ __launch_bounds__(256) void k_error(const BaProb* __restrict__ probs,
     const int qmax = ++ctl.qmax;
     const bool stop = stop_words && __hip_atomic_load(const_cast<const int*>(stop_words + blockIdx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
     if (stop) ctl.stopped = 1;
-    if (rho < 0 && qmax < 10 && !stop) { ctl.state = ST_RETRY; return; }
+    if (rho < 0 && qmax < 10 && !stop) { ctl.state = ST_RETRY; return true; }
     const int round = ctl.round;
     ++ctl.n_iters[round];
     if (ctl.trace < 32) ctl.chi2_trace[ctl.trace++] = currentChi;
@@ -302,71 +341,173 @@ __global__ __launch_bounds__(256) void k_error(const BaProb* __restrict__ probs,
     const int it = ++ctl.it;
     if (term || stop || it >= pb.iters[round]) ctl.state = ST_ROUND_END;
     else { ctl.state = ST_NEW_ITER; ctl.qmax = 0; ctl.iniChi = currentChi; }
+    return true;
 }
 
-// linearizeOplus + constructQuadraticForm, per edge. cpoint[e] = {Hll 00,01,02,11,12,22, bl0..2},
-// cpose[e] = {21 upper entries of Hpp row-major, bp0..5}, Hpl[e] = 6x3 row-major (pose rows, point cols)
-__global__ __launch_bounds__(256) void k_linearize(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
+// k_error<1> is the LAST kernel of a step: the last problem to finish its trial publishes the step to the host (publish_step_end).
+template <int TRIAL>
+__global__ __launch_bounds__(256) void k_error(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, const volatile int* __restrict__ stop_words, int B,
+                                               int* __restrict__ h_progress, unsigned* __restrict__ grid_ticket)
 {
+    __shared__ double s[256];
     __shared__ DCams cams;
+    __shared__ bool last;
+    const bool finisher = error_body<TRIAL>(probs[blockIdx.y], ctls[blockIdx.y], stop_words, s, cams, last);
+    if (TRIAL && finisher) publish_step_end(B, h_progress, grid_ticket);
+}
+
+// FIRST kernel of every step, thread per edge: (1) everything that happens BETWEEN LM iterations, then (2) the linearisation of the
+// iteration the step starts -- one launch, because both are edge-parallel over the same edges (until round 3 part 1 was a kernel of
+// its own, k_post, at the END of the step: a no-op launch in 10 of 13 steps of a C4 solve).
+// (1) state == ROUND_END   outlier flags chi2 (last evaluation) > th || depth <= 0 with the CURRENT estimates (Optimizer.cc:607,
+//                          653); after round 0 they become the level-1 set of round 1 (:607-612) unless the stop flag was seen
+//                          (:597-600), and the same thread evaluates the edge's error for round 1's first iteration (robust kernel
+//                          off); the current estimates are copied to the output arrays. The problem's last block (ticket) then
+//                          starts round 1 (lambda is re-initialised by k_reduce_pose) or marks the problem done.
+//     state == NEW_ITER with stale errors (first iteration of round 0; an iteration that ended on a rejected trial)
+//                          computeActiveErrors at the current estimates, chi2 total -> currentChi.
+// (2) linearizeOplus + constructQuadraticForm of the edge if the problem is (or has just been put) at the top of an LM iteration:
+//     cpoint[e] = {Hll 00,01,02,11,12,22, bl0..2}, cpose[e] = {21 upper entries of Hpp row-major, bp0..5}, Hpl[e] = 6x3 row-major
+//     (pose rows, point cols). A block cannot wait for the problem's last block, so it PREDICTS what that block will write from the
+//     control word it read on entry: round 1 starts after round 0 unless stopped (robust kernel off). The one case it cannot see --
+//     round 1 without a single active edge, which ends the problem -- leaves a linearisation nobody reads: every later kernel of the
+//     step tests ctl.state.
+// The end of a problem is decided here: its last block publishes it to the host (publish_problem_end).
+__global__ __launch_bounds__(256) void k_begin(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int* __restrict__ h_progress,
+                                               unsigned* __restrict__ grid_ticket)
+{
+    __shared__ double s[256];
+    __shared__ DCams cams;
+    __shared__ int s_cnt;
+    __shared__ bool last;
     const BaProb& pb = probs[blockIdx.y];
-    const BaCtl& ctl = ctls[blockIdx.y];
-    if ((int)blockIdx.x >= pb.nblk || ctl.state != ST_NEW_ITER) return;
-    const int robust = ctl.robust;
-    const double delta = pb.delta;
-    const double* __restrict__ poses = pb.poses[ctl.cur];
-    const double* __restrict__ points = pb.points[ctl.cur];
-    const int32_t* __restrict__ pose_idx = pb.pose_idx;
-    load_cams(&cams, pb.cams);
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= pb.E) return;
-    if (!pb.active[e]) {                           // level-1 edge: adds nothing to any block (the CSR lists still name it)
-        double* cp = pb.cpoint + (size_t)e * 9;
-        for (int i = 0; i < 9; ++i) cp[i] = 0;
-        if (pose_idx[pb.epose[e]] >= 0) {
-            double* cq = pb.cpose + (size_t)e * 27;
-            for (int i = 0; i < 27; ++i) cq[i] = 0;
-            double* h = pb.Hpl + (size_t)e * 18;
-            for (int i = 0; i < 18; ++i) h[i] = 0;
+    BaCtl& ctl = ctls[blockIdx.y];
+    if ((int)blockIdx.x < pb.nblk) {
+        // the control word as of the end of the previous step: read ONCE -- the problem's last block rewrites it while other blocks
+        // are still in part (2)
+        const int state = ctl.state, round = ctl.round, stopped = ctl.stopped, cur = ctl.cur, robust_in = ctl.robust;
+        const bool round_end = state == ST_ROUND_END, pre = state == ST_NEW_ITER && !ctl.errors_current;
+        const bool next_round = round_end && round == 0 && !stopped && pb.iters[1] > 0;
+        const bool lin = state == ST_NEW_ITER || next_round;           // (2) runs
+        const int robust = round_end ? 0 : robust_in;
+        if (round_end || pre || lin) {                                   // block-uniform
+            const double* __restrict__ poses = pb.poses[cur];
+            const double* __restrict__ points = pb.points[cur];
+            const double delta = pb.delta;
+            if (threadIdx.x == 0) s_cnt = 0;
+            load_cams(&cams, pb.cams);
+            const int e = blockIdx.x * 256 + threadIdx.x;
+            const bool in = e < pb.E;
+            double rho0 = 0, pc[3] = {0, 0, 1}, err0 = 0, err1 = 0, x2 = 0;
+            bool act = false;
+            int ps = 0, cam_id = 0;
+            if (in) {
+                ps = pb.epose[e]; cam_id = pb.ecam[e];
+                cam_point(poses + 7 * ps, points + 3 * pb.epoint[e], cams.c[cam_id], pc);
+                act = pb.active[e] != 0;
+            }
+            if (round_end || pre) {
+                if (in) {
+                    const DCam& c = cams.c[cam_id];
+                    if (round_end) {
+                        const uint8_t f = (pb.chi2[e] > pb.chi2_th || !(pc[2] > 0.0)) ? 1 : 0;
+                        pb.flag[e] = f;
+                        if (round == 0) {
+                            pb.level1[e] = stopped ? 0 : f;
+                            if (!stopped) { act = !f; pb.active[e] = act; if (act) atomicAdd(&s_cnt, 1); }
+                        }
+                    }
+                    if ((pre || next_round) && act) {
+                        err0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+                        err1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+                        const double w = pb.w[e];
+                        x2 = err0 * (w * err0) + err1 * (w * err1);
+                        pb.err[2 * e] = err0; pb.err[2 * e + 1] = err1; pb.chi2[e] = x2;
+                        if (robust && x2 > delta * delta) rho0 = 2 * sqrt(x2) * delta - delta * delta; else rho0 = x2;
+                    }
+                }
+                if (round_end) {
+                    for (int i = blockIdx.x * 256 + threadIdx.x; i < 7 * pb.P; i += pb.nblk * 256) pb.out_poses[i] = poses[i];
+                    for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * pb.L; i += pb.nblk * 256) pb.out_points[i] = points[i];
+                }
+                const double t = block_sum_256(rho0, s);
+                if (threadIdx.x == 0) {
+                    if (s_cnt) atomicAdd(&ctl.n_active, s_cnt);
+                    __hip_atomic_store(&pb.partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    last = __hip_atomic_fetch_add(pb.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)pb.nblk - 1;
+                }
+                __syncthreads();
+                if (last) {                                           // block-uniform
+                    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __syncthreads();
+                    double v = 0;
+                    for (int i = threadIdx.x; i < pb.nblk; i += 256) v += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double tot = block_sum_256(v, s);
+                    if (threadIdx.x == 0) {
+                        __hip_atomic_store(pb.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int n_act = __hip_atomic_load(&ctl.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (pre || (next_round && n_act > 0)) {
+                            if (next_round) { ctl.round = 1; ctl.it = 0; ctl.qmax = 0; ctl.nBad = 0; ctl.robust = 0; }   // Optimizer.cc:612-621
+                            ctl.currentChi = tot; ctl.iniChi = tot; ctl.errors_current = 1; ctl.state = ST_NEW_ITER;
+                        } else { ctl.state = ST_DONE; publish_problem_end(h_progress, grid_ticket); }
+                    }
+                }
+            } else if (in && act) {                                    // errors are current (written by the accepted trial's k_error<1>)
+                err0 = pb.err[2 * e]; err1 = pb.err[2 * e + 1]; x2 = pb.chi2[e];
+            }
+            // ---- (2) linearizeOplus + constructQuadraticForm
+            if (lin && in) {
+                const int32_t* __restrict__ pose_idx = pb.pose_idx;
+                const bool free_pose = pose_idx[ps] >= 0;
+                if (!act) {                                            // level-1 edge: adds nothing to any block (the CSR lists still name it)
+                    double* cp = pb.cpoint + (size_t)e * 9;
+                    for (int i = 0; i < 9; ++i) cp[i] = 0;
+                    if (free_pose) {
+                        double* cq = pb.cpose + (size_t)e * 27;
+                        for (int i = 0; i < 27; ++i) cq[i] = 0;
+                        double* h = pb.Hpl + (size_t)e * 18;
+                        for (int i = 0; i < 18; ++i) h[i] = 0;
+                    }
+                } else {
+                    const DCam& c = cams.c[cam_id];
+                    const double* T = poses + 7 * ps;
+                    const double x = pc[0], y = pc[1], z = pc[2];
+                    const double sz = -1. / z;
+                    const double st[6] = {sz * c.fx, sz * 0.0, sz * (-x / z * c.fx), sz * 0.0, sz * c.fy, sz * (-y / z * c.fy)};
+                    const double J3[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+                    double A[12], Jp[12], Jx[6];
+                    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) A[i * 6 + j] = st[i * 3] * J3[j] + st[i * 3 + 1] * J3[6 + j] + st[i * 3 + 2] * J3[12 + j];
+                    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) {
+                        double acc = 0;
+                        for (int k = 0; k < 6; ++k) acc += A[i * 6 + k] * c.adj[k * 6 + j];
+                        Jp[i * 6 + j] = acc;
+                    }
+                    double qt[4], R[9];
+                    qmul(c.q, T + 3, qt); qnormalize(qt); qtoR(qt, R);         // rotation of T_ext * T_mcs
+                    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Jx[i * 3 + j] = st[i * 3] * R[j] + st[i * 3 + 1] * R[3 + j] + st[i * 3 + 2] * R[6 + j];
+                    double w = pb.w[e];
+                    double r0 = -w * err0, r1 = -w * err1;
+                    if (robust) {
+                        const double rho1 = x2 <= delta * delta ? 1.0 : delta / sqrt(x2);
+                        r0 *= rho1; r1 *= rho1; w = rho1 * w;
+                    }
+                    double* cp = pb.cpoint + (size_t)e * 9;
+                    int k = 0;
+                    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) cp[k++] = Jx[i] * w * Jx[j] + Jx[3 + i] * w * Jx[3 + j];
+                    for (int i = 0; i < 3; ++i) cp[6 + i] = Jx[i] * r0 + Jx[3 + i] * r1;
+                    if (free_pose) {
+                        double* cq = pb.cpose + (size_t)e * 27;
+                        k = 0;
+                        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) cq[k++] = Jp[i] * w * Jp[j] + Jp[6 + i] * w * Jp[6 + j];
+                        for (int i = 0; i < 6; ++i) cq[21 + i] = Jp[i] * r0 + Jp[6 + i] * r1;
+                        double* h = pb.Hpl + (size_t)e * 18;
+                        for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) h[i * 3 + j] = Jp[i] * w * Jx[j] + Jp[6 + i] * w * Jx[3 + j];
+                    }
+                }
+            }
         }
-        return;
-    }
-    const DCam& c = cams.c[pb.ecam[e]];
-    const double* T = poses + 7 * pb.epose[e];
-    double pc[3];
-    cam_point(T, points + 3 * pb.epoint[e], c, pc);
-    const double x = pc[0], y = pc[1], z = pc[2];
-    const double s = -1. / z;
-    const double st[6] = {s * c.fx, s * 0.0, s * (-x / z * c.fx), s * 0.0, s * c.fy, s * (-y / z * c.fy)};
-    const double J3[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
-    double A[12], Jp[12], Jx[6];
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) A[i * 6 + j] = st[i * 3] * J3[j] + st[i * 3 + 1] * J3[6 + j] + st[i * 3 + 2] * J3[12 + j];
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) {
-        double acc = 0;
-        for (int k = 0; k < 6; ++k) acc += A[i * 6 + k] * c.adj[k * 6 + j];
-        Jp[i * 6 + j] = acc;
-    }
-    double qt[4], R[9];
-    qmul(c.q, T + 3, qt); qnormalize(qt); qtoR(qt, R);         // rotation of T_ext * T_mcs
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Jx[i * 3 + j] = st[i * 3] * R[j] + st[i * 3 + 1] * R[3 + j] + st[i * 3 + 2] * R[6 + j];
-    double w = pb.w[e];
-    double r0 = -w * pb.err[2 * e], r1 = -w * pb.err[2 * e + 1];
-    if (robust) {
-        const double x2 = pb.chi2[e];
-        const double rho1 = x2 <= delta * delta ? 1.0 : delta / sqrt(x2);
-        r0 *= rho1; r1 *= rho1; w = rho1 * w;
-    }
-    double* cp = pb.cpoint + (size_t)e * 9;
-    int k = 0;
-    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) cp[k++] = Jx[i] * w * Jx[j] + Jx[3 + i] * w * Jx[3 + j];
-    for (int i = 0; i < 3; ++i) cp[6 + i] = Jx[i] * r0 + Jx[3 + i] * r1;
-    if (pose_idx[pb.epose[e]] >= 0) {
-        double* cq = pb.cpose + (size_t)e * 27;
-        k = 0;
-        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) cq[k++] = Jp[i] * w * Jp[j] + Jp[6 + i] * w * Jp[6 + j];
-        for (int i = 0; i < 6; ++i) cq[21 + i] = Jp[i] * r0 + Jp[6 + i] * r1;
-        double* h = pb.Hpl + (size_t)e * 18;
-        for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) h[i * 3 + j] = Jp[i] * w * Jx[j] + Jp[6 + i] * w * Jx[3 + j];
     }
 }
 
@@ -553,16 +694,16 @@ __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(c
     }
     const double lambda = 1e-5 * ctl.maxdiag * ctl.mult;
     const int32_t* __restrict__ pair_off = pb.pair_off;
-    const int32_t* __restrict__ pair_e1 = pb.pair_e1;
-    const int32_t* __restrict__ pair_e2 = pb.pair_e2;
+    const int2* __restrict__ pair_e = reinterpret_cast<const int2*>(pb.pair_e);
     const double* __restrict__ BD = pb.BD;
     const int p = blockIdx.x, t = threadIdx.x;
     const int el = t % 36, q = t / 36;
     const int r = el / 6, c = el % 6;
     const int k0 = pair_off[p], k1 = pair_off[p + 1];
     auto term = [&](int k) {
-        const double* a = BD + (size_t)pair_e1[k] * 18 + r * 3;
-        const double* b = Hpl + (size_t)pair_e2[k] * 18 + c * 3;
+        const int2 pe = pair_e[k];
+        const double* a = BD + (size_t)pe.x * 18 + r * 3;
+        const double* b = Hpl + (size_t)pe.y * 18 + c * 3;
         return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
     };
     if (q < C) {
@@ -1354,117 +1495,6 @@ __global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ 
     if (threadIdx.x == 0) pb.scale_part[blockIdx.x] = sc;
 }
 
-// Last kernel of every step (and once before the first): everything that happens BETWEEN LM iterations.
-//   state == ROUND_END   outlier flags chi2 (last evaluation) > th || depth <= 0 with the CURRENT estimates (Optimizer.cc:607,
-//                        653); after round 0 they become the level-1 set of round 1 (:607-612) unless the stop flag was seen
-//                        (:597-600), and the same thread evaluates the edge's error for round 1's first iteration (robust kernel
-//                        off); the current estimates are copied to the output arrays. The problem's last block (ticket) then
-//                        starts round 1 (lambda is re-initialised by k_reduce_pose) or marks the problem done.
-//   state == NEW_ITER with stale errors (first iteration of round 0; an iteration that ended on a rejected trial)
-//                        computeActiveErrors at the current estimates, chi2 total -> currentChi.
-// The last block of the whole grid publishes {step, problems done} to the host's pinned progress words.
-// grid_ticket[0] = arrival counter of the grid, grid_ticket[1] = number of k_post grids this group has finished = the step number the
-// host waits for (0 = the pass before the first step): kept on the device so that every launch of a step has the same arguments
-// and the step can be replayed as one hipGraph.
-__global__ __launch_bounds__(256) void k_post(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int* __restrict__ h_progress,
-                                              unsigned* __restrict__ grid_ticket)
-{
-    __shared__ double s[256];
-    __shared__ DCams cams;
-    __shared__ int s_cnt;
-    __shared__ bool last;
-    const BaProb& pb = probs[blockIdx.y];
-    BaCtl& ctl = ctls[blockIdx.y];
-    const int state = ctl.state;
-    const bool round_end = state == ST_ROUND_END, pre = state == ST_NEW_ITER && !ctl.errors_current;
-    if ((int)blockIdx.x < pb.nblk && (round_end || pre)) {
-        const double* __restrict__ poses = pb.poses[ctl.cur];
-        const double* __restrict__ points = pb.points[ctl.cur];
-        const int round = ctl.round, stopped = ctl.stopped;
-        const bool next_round = round_end && round == 0 && !stopped && pb.iters[1] > 0;
-        const int robust = round_end ? 0 : ctl.robust;
-        const double delta = pb.delta;
-        if (threadIdx.x == 0) s_cnt = 0;
-        load_cams(&cams, pb.cams);
-        const int e = blockIdx.x * 256 + threadIdx.x;
-        double rho0 = 0;
-        if (e < pb.E) {
-            double pc[3];
-            const DCam& c = cams.c[pb.ecam[e]];
-            cam_point(poses + 7 * pb.epose[e], points + 3 * pb.epoint[e], c, pc);
-            bool act = pb.active[e] != 0;
-            if (round_end) {
-                const uint8_t f = (pb.chi2[e] > pb.chi2_th || !(pc[2] > 0.0)) ? 1 : 0;
-                pb.flag[e] = f;
-                if (round == 0) {
-                    pb.level1[e] = stopped ? 0 : f;
-                    if (!stopped) { act = !f; pb.active[e] = act; if (act) atomicAdd(&s_cnt, 1); }
-                }
-            }
-            if ((pre || next_round) && act) {
-                const double e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
-                const double e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
-                const double w = pb.w[e];
-                const double x2 = e0 * (w * e0) + e1 * (w * e1);
-                pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
-                if (robust && x2 > delta * delta) rho0 = 2 * sqrt(x2) * delta - delta * delta; else rho0 = x2;
-            }
-        }
-        if (round_end) {
-            for (int i = blockIdx.x * 256 + threadIdx.x; i < 7 * pb.P; i += pb.nblk * 256) pb.out_poses[i] = poses[i];
-            for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * pb.L; i += pb.nblk * 256) pb.out_points[i] = points[i];
-        }
-        const double t = block_sum_256(rho0, s);
-        if (threadIdx.x == 0) {
-            if (s_cnt) atomicAdd(&ctl.n_active, s_cnt);
-            __hip_atomic_store(&pb.partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            last = __hip_atomic_fetch_add(pb.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)pb.nblk - 1;
-        }
-        __syncthreads();
-        if (last) {                                           // block-uniform
-            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __syncthreads();
-            double v = 0;
-            for (int i = threadIdx.x; i < pb.nblk; i += 256) v += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double tot = block_sum_256(v, s);
-            if (threadIdx.x == 0) {
-                __hip_atomic_store(pb.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int n_act = __hip_atomic_load(&ctl.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (pre || (next_round && n_act > 0)) {
-                    if (next_round) { ctl.round = 1; ctl.it = 0; ctl.qmax = 0; ctl.nBad = 0; ctl.robust = 0; }   // Optimizer.cc:612-621
-                    ctl.currentChi = tot; ctl.iniChi = tot; ctl.errors_current = 1; ctl.state = ST_NEW_ITER;
-                } else ctl.state = ST_DONE;
-            }
-        }
-    }
-    // ---- progress: the last block of the grid counts the finished problems
-    __shared__ bool glast;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        glast = __hip_atomic_fetch_add(grid_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1;
-    }
-    __syncthreads();
-    if (!glast) return;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    int done = 0;
-    for (int b = threadIdx.x; b < B; b += 256) done += __hip_atomic_load(&ctls[b].state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ST_DONE;
-    const double nd = block_sum_256((double)done, s);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(grid_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int step = (int)grid_ticket[1];
-        grid_ticket[1] = (unsigned)step + 1u;
-        // ONE 64-bit word {finished problems : step}: the host decides from a single acquire load, so "all done" can never be seen
-        // ahead of the release that publishes the results (the blocks' agent-scope releases are acquired above, this release is
-        // system-scope and cumulative)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(h_progress), ((unsigned long long)(unsigned)(int)nd << 32) | (unsigned)step, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 __global__ __launch_bounds__(1024) void k_ctl_init(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B)
 {
     for (int b = threadIdx.x; b < B; b += 1024) {
@@ -1740,10 +1770,10 @@ struct BaContext {
     hipStream_t aux[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
     hipStream_t dl = nullptr;                          // results come down on their own stream once every problem has reported done
     // A call that took its results down on `dl` returns while the steps it had queued ahead (no-ops on a finished batch) are still in
-    // the solver's queues -- and the last block of each of their k_post launches still stores to the pinned progress words. Nothing
+    // the solver's queues -- and the last block of each of their k_begin / k_error launches still stores to the pinned progress words. Nothing
     // may reset those words, or free / reuse what the queues reference, before they have drained: drain() is the first thing prepare()
     // and release() do (by then the tail has long run under the caller's own work; found as a bug of the first version of the dl path:
-    // the next call zeroed the words on the host, a late k_post of the previous call reported "all problems done", and the next call
+    // the next call zeroed the words on the host, a late progress store of the previous call reported "all problems done", and the next call
     // would have downloaded results before running a step).
     bool tail_pending = false;
     void drain()
@@ -1910,93 +1940,112 @@ private:
 static HostPool& host_pool() { static HostPool* p = new HostPool; return *p; }
 
 struct Round {                                  // structure of one optimisation round (buildIndexMapping + buildStructure)
-    std::vector<int32_t> pose_idx, pt_off, pt_edges, ps_off, ps_edges, pair_ij, pair_off, pair_e1, pair_e2;
+    std::vector<int32_t> pose_idx, pt_off, pt_edges, ps_off, ps_edges, pair_ij, pair_off, pair_e;      // pair_e: (e1, e2) interleaved
+    struct Key { int32_t idx, edge; };              // (free-pose index or -1, edge id): scratch of build_round, kept for its capacity
+    std::vector<Key> keys;
+    std::vector<int32_t> cnt, cur_pt, cur_ps;
+    std::vector<uint8_t> pose_act;
     int np = 0, n = 0, n_pad = 0, n_pairs = 0, n_active = 0;
 };
 
 // returns -1, or the id of an edge that repeats a (pose, point) pair (the pair lists assume at most one, like g2o's hash of Hpl blocks)
+//
+// Host cost matters: the lists are rebuilt on every call (the local map changes between calls) and were 0.26 ms of a 1.95 ms C4 solve.
+// Everything below works on ONE packed record per CSR entry -- (free-pose index, edge) of a point's edges, sorted by pose index -- so
+// the two passes over the ~L * obs^2 / 2 pose pairs (count, fill) touch only that array and the np x np count / cursor matrix: no
+// per-pair chase through edge_pose / pose_idx.
 int build_round(const dcs_ba_problem* pb, Round& r)
 {
     const int P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
-    const std::vector<uint8_t> active(E, 1);
-    std::vector<uint8_t> pose_act(P, 0);
-    r.n_active = 0;
-    for (int e = 0; e < E; ++e) if (active[e]) { pose_act[pb->edge_pose[e]] = 1; ++r.n_active; }
+    const int32_t* __restrict__ e_pose = pb->edge_pose;
+    const int32_t* __restrict__ e_point = pb->edge_point;
+    r.n_active = E;                                           // round 0 structure: every edge (the second round only masks edges)
     r.pose_idx.assign(P, -1);
+    r.pose_act.assign(P, 0);
+    for (int e = 0; e < E; ++e) r.pose_act[e_pose[e]] = 1;
     r.np = 0;
-    for (int p = 0; p < P; ++p) if (pose_act[p] && !pb->pose_fixed[p]) r.pose_idx[p] = r.np++;
-    r.n = r.np * 6; r.n_pad = ((r.n + kNB - 1) / kNB) * kNB;
-    // point -> active edges, sorted by pose index (fixed poses first: index -1), then edge id
-    r.pt_off.assign(L + 1, 0);
-    for (int e = 0; e < E; ++e) if (active[e]) ++r.pt_off[pb->edge_point[e] + 1];
-    for (int l = 0; l < L; ++l) r.pt_off[l + 1] += r.pt_off[l];
-    r.pt_edges.assign(r.n_active, 0);
-    {
-        std::vector<int32_t> cur(r.pt_off.begin(), r.pt_off.end() - 1);
-        for (int e = 0; e < E; ++e) if (active[e]) r.pt_edges[cur[pb->edge_point[e]]++] = e;
-        // per point: ONE insertion sort of its (few) edges by (pose index, edge id) -- the order the kernels sum in (fixed poses
-        // first: index -1) -- and the duplicate test on the sorted run: equal indices are adjacent, the fixed prefix is compared
-        // pairwise by pose id (a handful of entries)
-        struct Key { int32_t idx, pose, edge; };
-        std::vector<Key> keys;
-        for (int l = 0; l < L; ++l) {
-            const int k0 = r.pt_off[l], k1 = r.pt_off[l + 1], nk = k1 - k0;
-            keys.resize((size_t)nk);
-            for (int k = 0; k < nk; ++k) {
-                const int e = r.pt_edges[k0 + k], ps = pb->edge_pose[e];
-                const Key key{r.pose_idx[ps], ps, e};
-                int j = k;
-                while (j > 0 && (keys[j - 1].idx > key.idx || (keys[j - 1].idx == key.idx && keys[j - 1].edge > key.edge))) { keys[j] = keys[j - 1]; --j; }
-                keys[j] = key;
-            }
-            int n_fixed = 0;
-            while (n_fixed < nk && keys[n_fixed].idx < 0) ++n_fixed;
-            for (int a = 1; a < n_fixed; ++a)
-                for (int b2 = 0; b2 < a; ++b2) if (keys[a].pose == keys[b2].pose) return keys[a].edge;
-            for (int k = n_fixed + 1; k < nk; ++k) if (keys[k].idx == keys[k - 1].idx) return keys[k].edge;
-            for (int k = 0; k < nk; ++k) r.pt_edges[k0 + k] = keys[k].edge;
-        }
-    }
-    // free pose -> active edges (edge id order)
-    r.ps_off.assign(r.np + 1, 0);
-    for (int e = 0; e < E; ++e) if (active[e] && r.pose_idx[pb->edge_pose[e]] >= 0) ++r.ps_off[r.pose_idx[pb->edge_pose[e]] + 1];
-    for (int i = 0; i < r.np; ++i) r.ps_off[i + 1] += r.ps_off[i];
-    r.ps_edges.assign(r.ps_off[r.np], 0);
-    {
-        std::vector<int32_t> cur(r.ps_off.begin(), r.ps_off.end() - 1);
-        for (int e = 0; e < E; ++e) if (active[e] && r.pose_idx[pb->edge_pose[e]] >= 0) r.ps_edges[cur[r.pose_idx[pb->edge_pose[e]]]++] = e;
-    }
-    // pose pairs (i1 <= i2) sharing a point, plus every diagonal pair; (e1, e2) lists in point order
+    for (int p = 0; p < P; ++p) if (r.pose_act[p] && !pb->pose_fixed[p]) r.pose_idx[p] = r.np++;
     const int np = r.np;
-    std::vector<int32_t> cnt((size_t)np * np, 0);
-    for (int l = 0; l < L; ++l)
-        for (int a = r.pt_off[l]; a < r.pt_off[l + 1]; ++a) {
-            const int i1 = r.pose_idx[pb->edge_pose[r.pt_edges[a]]];
-            if (i1 < 0) continue;
-            for (int b = a; b < r.pt_off[l + 1]; ++b) ++cnt[(size_t)i1 * np + r.pose_idx[pb->edge_pose[r.pt_edges[b]]]];
-        }
-    std::vector<int32_t> pid((size_t)np * np, -1);
-    r.pair_ij.clear(); r.pair_off.assign(1, 0);
-    for (int i1 = 0; i1 < np; ++i1)
-        for (int i2 = i1; i2 < np; ++i2)
-            if (cnt[(size_t)i1 * np + i2] || i1 == i2) {
-                pid[(size_t)i1 * np + i2] = (int)r.pair_ij.size() / 2;
-                r.pair_ij.push_back(i1); r.pair_ij.push_back(i2);
-                r.pair_off.push_back(r.pair_off.back() + cnt[(size_t)i1 * np + i2]);
-            }
-    r.n_pairs = (int)r.pair_ij.size() / 2;
-    r.pair_e1.assign(r.pair_off.back(), 0); r.pair_e2.assign(r.pair_off.back(), 0);
+    const int32_t* __restrict__ pose_idx = r.pose_idx.data();
+    r.n = np * 6; r.n_pad = ((r.n + kNB - 1) / kNB) * kNB;
+    // point -> edges and free pose -> edges (edge id order) in one counting pass
+    r.pt_off.assign(L + 1, 0);
+    r.ps_off.assign(np + 1, 0);
+    for (int e = 0; e < E; ++e) {
+        ++r.pt_off[e_point[e] + 1];
+        const int pi = pose_idx[e_pose[e]];
+        if (pi >= 0) ++r.ps_off[pi + 1];
+    }
+    for (int l = 0; l < L; ++l) r.pt_off[l + 1] += r.pt_off[l];
+    for (int i = 0; i < np; ++i) r.ps_off[i + 1] += r.ps_off[i];
+    r.pt_edges.resize(E);
+    r.ps_edges.resize(r.ps_off[np]);
+    using Key = Round::Key;
+    std::vector<Key>& keys = r.keys;
+    keys.resize((size_t)E);
     {
-        std::vector<int32_t> cur(r.pair_off.begin(), r.pair_off.end() - 1);
-        for (int l = 0; l < L; ++l)
-            for (int a = r.pt_off[l]; a < r.pt_off[l + 1]; ++a) {
-                const int e1 = r.pt_edges[a], i1 = r.pose_idx[pb->edge_pose[e1]];
-                if (i1 < 0) continue;
-                for (int b = a; b < r.pt_off[l + 1]; ++b) {
-                    const int e2 = r.pt_edges[b], p = pid[(size_t)i1 * np + r.pose_idx[pb->edge_pose[e2]]];
-                    r.pair_e1[cur[p]] = e1; r.pair_e2[cur[p]] = e2; ++cur[p];
-                }
+        std::vector<int32_t>& cur_pt = r.cur_pt;
+        std::vector<int32_t>& cur_ps = r.cur_ps;
+        cur_pt.assign(r.pt_off.begin(), r.pt_off.end() - 1); cur_ps.assign(r.ps_off.begin(), r.ps_off.end() - 1);
+        for (int e = 0; e < E; ++e) {
+            const int pi = pose_idx[e_pose[e]];
+            keys[cur_pt[e_point[e]]++] = Key{pi, e};
+            if (pi >= 0) r.ps_edges[cur_ps[pi]++] = e;
+        }
+    }
+    // per point: ONE insertion sort of its (few) edges by (pose index, edge id) -- the order the kernels sum in (fixed poses first:
+    // index -1; the counting pass already left them in edge order) -- and the duplicate test on the sorted run: equal indices are
+    // adjacent, the fixed prefix is compared pairwise by pose id (a handful of entries). Pairs (i1 <= i2) are counted on the way.
+    r.cnt.assign((size_t)np * np, 0);
+    int32_t* __restrict__ cntp = r.cnt.data();
+    for (int l = 0; l < L; ++l) {
+        const int k0 = r.pt_off[l], k1 = r.pt_off[l + 1];
+        Key* __restrict__ kk = keys.data() + k0;
+        const int nk = k1 - k0;
+        for (int k = 1; k < nk; ++k) {
+            const Key key = kk[k];
+            int j = k;
+            while (j > 0 && kk[j - 1].idx > key.idx) { kk[j] = kk[j - 1]; --j; }      // stable: equal indices keep their edge order
+            kk[j] = key;
+        }
+        int n_fixed = 0;
+        while (n_fixed < nk && kk[n_fixed].idx < 0) ++n_fixed;
+        for (int a = 1; a < n_fixed; ++a)
+            for (int b2 = 0; b2 < a; ++b2) if (e_pose[kk[a].edge] == e_pose[kk[b2].edge]) return kk[a].edge;
+        for (int k = n_fixed + 1; k < nk; ++k) if (kk[k].idx == kk[k - 1].idx) return kk[k].edge;
+        for (int k = 0; k < nk; ++k) r.pt_edges[k0 + k] = kk[k].edge;
+        for (int a = n_fixed; a < nk; ++a) {
+            int32_t* __restrict__ row = cntp + (size_t)kk[a].idx * np;
+            for (int b = a; b < nk; ++b) ++row[kk[b].idx];
+        }
+    }
+    // pose pairs (i1 <= i2) sharing a point, plus every diagonal pair; (e1, e2) lists in point order. The count matrix becomes the
+    // cursor matrix of the fill pass.
+    r.pair_ij.clear(); r.pair_off.assign(1, 0);
+    r.pair_ij.reserve((size_t)np * (np + 1)); r.pair_off.reserve((size_t)np * (np + 1) / 2 + 1);
+    for (int i1 = 0; i1 < np; ++i1)
+        for (int i2 = i1; i2 < np; ++i2) {
+            const int c = cntp[(size_t)i1 * np + i2];
+            if (c || i1 == i2) {
+                r.pair_ij.push_back(i1); r.pair_ij.push_back(i2);
+                cntp[(size_t)i1 * np + i2] = r.pair_off.back();
+                r.pair_off.push_back(r.pair_off.back() + c);
             }
+        }
+    r.n_pairs = (int)r.pair_ij.size() / 2;
+    r.pair_e.resize((size_t)2 * r.pair_off.back());
+    int2* __restrict__ pe = reinterpret_cast<int2*>(r.pair_e.data());
+    for (int l = 0; l < L; ++l) {
+        const int k0 = r.pt_off[l], k1 = r.pt_off[l + 1];
+        const Key* __restrict__ kk = keys.data() + k0;
+        const int nk = k1 - k0;
+        int a = 0;
+        while (a < nk && kk[a].idx < 0) ++a;
+        for (; a < nk; ++a) {
+            int32_t* __restrict__ row = cntp + (size_t)kk[a].idx * np;
+            const int32_t e1 = kk[a].edge;
+            for (int b = a; b < nk; ++b) pe[row[kk[b].idx]++] = int2{e1, kk[b].edge};
+        }
     }
     return -1;
 }
@@ -2054,7 +2103,10 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // round only changes the per-edge active mask; inactive edges contribute exact zeros, landmarks without an active
     // edge are skipped (pt_active) and poses without one see a decoupled lambda*I block (zero update), which is
     // what g2o's re-indexing of the active subgraph amounts to.
-    std::vector<Round> rounds(NB);
+    // (one list set per slot of the calling thread, kept across calls: fresh vectors of this size are mmap'ed and page-faulted on every call)
+    thread_local std::vector<Round> tl_rounds;
+    if ((int)tl_rounds.size() < NB) tl_rounds.resize(NB);
+    std::vector<Round>& rounds = tl_rounds;
     std::vector<int> dup(NB, -1);
     {
         auto work = [&](int i) { dup[i] = build_round(problems[live[i]], rounds[i]); };
@@ -2099,7 +2151,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.pose_idx = c.get<int32_t>(P); q.pt_off = c.get<int32_t>(L + 1); q.pt_edges = c.get<int32_t>(r.pt_edges.size());
             q.ps_off = c.get<int32_t>(r.ps_off.size()); q.ps_edges = c.get<int32_t>(r.ps_edges.size());
             q.pair_ij = c.get<int32_t>(r.pair_ij.size()); q.pair_off = c.get<int32_t>(r.pair_off.size());
-            q.pair_e1 = c.get<int32_t>(r.pair_e1.size()); q.pair_e2 = c.get<int32_t>(r.pair_e2.size());
+            q.pair_e = c.get<int32_t>(r.pair_e.size());
             q.cams = c.get<DCams>(1);
         }
         d_probs = c.get<BaProb>(NB);
@@ -2165,7 +2217,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         memset(stage(q.active), 1, E);
         auto put = [&](const int32_t* d, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage(d), v.data(), sizeof(int32_t) * v.size()); };
         put(q.pose_idx, r.pose_idx); put(q.pt_off, r.pt_off); put(q.pt_edges, r.pt_edges); put(q.ps_off, r.ps_off); put(q.ps_edges, r.ps_edges);
-        put(q.pair_ij, r.pair_ij); put(q.pair_off, r.pair_off); put(q.pair_e1, r.pair_e1); put(q.pair_e2, r.pair_e2);
+        put(q.pair_ij, r.pair_ij); put(q.pair_off, r.pair_off); put(q.pair_e, r.pair_e);
         DCams* cams = reinterpret_cast<DCams*>(stage(q.cams));
         memset(cams, 0, sizeof(DCams));
         for (int c = 0; c < pb->n_cams; ++c) {
@@ -2225,11 +2277,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             }
         }
     }
-    // before the first step: errors of the initial estimates (or, with iters1 <= 0, straight to the flags)
-    for (const Group& gr : groups) {
-        hipLaunchKernelGGL(k_post, dim3(gr.g_edges, gr.nb), dim3(256), 0, gr.st, gr.dp, gr.ctls, gr.nb, gr.words, gr.ticket);
-        DCS_CHECK_LAUNCH();
-    }
+    // (the errors of the initial estimates -- or, with iters1 <= 0, the flags straight away -- are the first thing k_begin of step 1 does)
     const bool timing = ctx.timing;
     auto event_at = [&](size_t i) -> hipEvent_t {
         while (ctx.events.size() <= i) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ctx.events.push_back(e); }
@@ -2251,11 +2299,11 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             const volatile int* d_stop = h_words + 16 + gr.off; int* words = gr.words; unsigned* ticket = gr.ticket;
             void* a_cc[] = {(void*)&dp, (void*)&cctls};                                   // (probs, const ctls)
             void* a_c[] = {(void*)&dp, (void*)&ctls};                                     // (probs, ctls)
-            void* a_err[] = {(void*)&dp, (void*)&ctls, (void*)&d_stop};
-            void* a_post[] = {(void*)&dp, (void*)&ctls, (void*)&nb, (void*)&words, (void*)&ticket};
+            void* a_err[] = {(void*)&dp, (void*)&ctls, (void*)&d_stop, (void*)&nb, (void*)&words, (void*)&ticket};
+            void* a_begin[] = {(void*)&dp, (void*)&ctls, (void*)&nb, (void*)&words, (void*)&ticket};
             struct Spec { void* fn; dim3 grid, block; void** args; };
             std::vector<Spec> spec;
-            spec.push_back({(void*)k_linearize, dim3(gr.g_edges, nb), dim3(256), a_cc});
+            spec.push_back({(void*)k_begin, dim3(gr.g_edges, nb), dim3(256), a_begin});
             spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
             spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
             if (gr.g_schur) spec.push_back({schur_fn(schur_chunks(nb)), dim3(gr.g_schur, nb), dim3(schur_threads(schur_chunks(nb))), a_cc});
@@ -2263,7 +2311,6 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
             spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
             spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
-            spec.push_back({(void*)k_post, dim3(gr.g_edges, nb), dim3(256), a_post});
             const unsigned shape = (gr.g_schur ? 1u : 0u) | (gr.any_mfma ? 2u : 0u) | (gr.any_valu ? 4u : 0u) | 8u;
             BaContext::StepGraph& sg = ctx.step_graph[g];
             auto params_of = [](const Spec& sp) { hipKernelNodeParams kp{}; kp.func = sp.fn; kp.gridDim = sp.grid; kp.blockDim = sp.block; kp.sharedMemBytes = 0; kp.kernelParams = sp.args; kp.extra = nullptr; return kp; };
@@ -2292,7 +2339,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         const volatile int* d_stop = h_words + 16 + gr.off;
         if (hipGraphExec_t ge = step_exec[(size_t)(&gr - groups.data())]) { DCS_HIP(hipGraphLaunch(ge, gs)); return DCS_OK; }
         mark(step, 0);
-        hipLaunchKernelGGL(k_linearize, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, (const BaCtl*)ctls);                   // buildSystem
+        hipLaunchKernelGGL(k_begin, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, nb, gr.words, gr.ticket);            // round change / stale errors, then buildSystem
         hipLaunchKernelGGL(k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), 0, gs, dp, ctls);                             // + computeLambdaInit (first iteration)
         hipLaunchKernelGGL(k_prep, dim3(gr.g_prep, nb), dim3(256), 0, gs, dp, ctls);                                      // setLambda + solve (Schur)
         DCS_CHECK_LAUNCH();
@@ -2324,8 +2371,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         DCS_CHECK_LAUNCH();
         mark(step, 2);
         hipLaunchKernelGGL(k_solve_update, dim3(gr.g_update, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
-        hipLaunchKernelGGL(k_error<1>, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, d_stop);        // chi2 of the trial + computeScale + accept / reject
-        hipLaunchKernelGGL(k_post, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, nb, gr.words, gr.ticket);                // round change / stale errors / progress
+        hipLaunchKernelGGL(k_error<1>, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // chi2 of the trial + computeScale + accept / reject, progress
         mark(step, 3);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
@@ -2371,7 +2417,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         t_wait += ms_since(tw0);
     }
     // When every group has REPORTED its problems done (the progress words are stored with a system-scope release by the last block
-    // of k_post, after every result array and every BaCtl of the step), the steps still in the queues are no-ops: they return on
+    // of k_begin / k_error<1>, after every result array and every BaCtl of the step), the steps still in the queues are no-ops: they return on
     // state > ST_RETRY before they write anything but the progress words. The results then come down on a stream of their own
     // instead of behind those 2 x 8 launches (~75 us of a 2 ms C4 solve). DCS_BA_DL_STREAM=0, or a batch that ran into max_steps,
     // takes the ordered path: the download behind everything on the solver's streams.
@@ -2420,6 +2466,16 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         fprintf(stderr, "[dcs_ba] %d problems, total %.3f ms: build_round %.3f, layout + staging %.3f, optimise %.3f (%d steps enqueued, host waited %.3f)\n",
                 NB, ms_since(t_call0), t_build, ms_since(t_call0) - t_build - opt_ms, (double)opt_ms, steps, t_wait);
     return DCS_OK;
+}
+
+// diagnostic (not part of the public header): average host time in ms of the structure build of one problem, no GPU needed
+double dcs_debug_ba_build_ms(const dcs_ba_problem* pb, int reps)
+{
+    if (!pb || reps < 1) return -1.0;
+    Round r;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; ++i) if (build_round(pb, r) >= 0) return -2.0;
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 
 int dcs_ba_set_cu_range(int first_cu, int n_cus)
