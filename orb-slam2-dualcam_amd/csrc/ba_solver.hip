@@ -191,7 +191,8 @@ struct BaProb {
     double *Hll, *bl, *Dinv, *db, *xl;             // per landmark
     double *Hpp, *bp, *bsch, *xp;                  // per free pose
     double *S, *W;                                 // reduced camera system (ld x ld), panel scratch of the n > 256 fallback
-    const int32_t *pose_idx, *pt_off, *pt_edges, *ps_off, *ps_edges, *pair_ij, *pair_off, *pair_e;      // pair_e: (e1, e2) interleaved, one 8-byte load per list entry
+    const int32_t *pose_idx, *pt_off, *pt_edges, *pt_pi, *ps_off, *ps_edges;   // pt_pi[k] = free-pose index (or -1) of edge pt_edges[k]
+    const int32_t *pair_ij, *pair_off, *pair_e;      // pair_e: (e1, e2) interleaved, one 8-byte load per list entry
     double *partial, *scale_part, *maxd_part;      // block partials: chi2, computeScale, max |diagonal| (np + nb_pts entries)
     uint8_t* pt_active;
     unsigned* ticket;                              // [0] error kernels, [1] k_reduce_pose, [2] k_begin
@@ -643,6 +644,17 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
     for (int i = 0; i < 3; ++i) pb.db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
 }
 
+// Storage of the reduced camera system for k_ldlt_mfma (use_reg == 1): the lower triangle as 16x16 TILES in the order and the register
+// layout the factorisation keeps them in -- tile t = I (I + 1) / 2 + K (block row I >= block column K), 256 doubles, element (row, col)
+// of the tile at (row >> 2) * 64 + (row & 3) * 16 + col = register row >> 2 of lane (row & 3) * 16 + col in the MFMA accumulator
+// layout -- so that a worker wave loads a tile with four fully coalesced 512-byte reads and no transposition through LDS. Diagonal
+// tiles hold both triangles. (The other two solvers read S row-major, ld x ld.)
+__host__ __device__ inline size_t s_tile_off(int x, int y)       // element (x, y) of the matrix, block(x) >= block(y)
+{
+    const int I = x >> 4, K = y >> 4, row = x & 15, col = y & 15;
+    return (size_t)(I * (I + 1) / 2 + K) * 256 + (row >> 2) * 64 + (row & 3) * 16 + col;
+}
+
 // workgroup per pose pair (i1 <= i2): S block = [i1==i2](Hpp + lambda I) - sum over shared points BD[e1] Hpl[e2]^T.
 // C list chunks x 36 block entries per workgroup (4 list entries in flight per thread); partials combined in fixed order. A C4 problem
 // has ~860 such workgroups per trial and a batch of 8 problems ~6 900: 16-wave workgroups (C = 28) for every group size needed 13
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(c
     const int n_pairs = pb.n_pairs;
     if ((int)blockIdx.x >= n_pairs + pb.np) return;
     const double* __restrict__ Hpl = pb.Hpl;
-    if ((int)blockIdx.x >= n_pairs) {                        // blocks past the pair list: reduced right-hand side of one free pose
+    if ((int)blockIdx.x >= n_pairs) {                        // blocks past the pair list: reduced right-hand side of one free pose (dispatching them FIRST was measured: 20.4 vs 19.6 us)
         // bsch = bp - sum_e Hpl[e] db[point(e)]; kSchurRhsChunks edge chunks x 6 rows, combined in chunk order
         static_assert(kSchurRhsChunks * 6 <= kSchurFine * 36 && kSchurRhsChunks * 6 <= kSchurThreads, "rhs partials live in `part`");
         double (*bpart)[6] = reinterpret_cast<double (*)[6]>(&part[0][0]);
@@ -728,8 +740,14 @@ __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(c
     for (int q2 = 0; q2 < kSchurFine; ++q2) acc += part[q2][t];
     double v = -acc;
     if (i1 == i2) v += pb.Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
-    pb.S[(size_t)(i1 * 6 + r) * ld + i2 * 6 + c] = v;
-    if (i1 != i2) pb.S[(size_t)(i2 * 6 + c) * ld + i1 * 6 + r] = v;
+    const int xa = i1 * 6 + r, ya = i2 * 6 + c;              // xa <= ya + 5; the mirrored entry (ya, xa) belongs to this thread only when i1 != i2
+    if (pb.use_reg == 1) {                                   // tiles of the lower triangle (diagonal tiles: both triangles)
+        if ((xa >> 4) >= (ya >> 4)) pb.S[s_tile_off(xa, ya)] = v;
+        if (i1 != i2 && (ya >> 4) >= (xa >> 4)) pb.S[s_tile_off(ya, xa)] = v;
+        return;
+    }
+    pb.S[(size_t)xa * ld + ya] = v;
+    if (i1 != i2) pb.S[(size_t)ya * ld + xa] = v;
 }
 
 // ---- register-resident LDL^T + solve (n_pad <= 256): the whole lower triangle lives in the VGPRs of ONE workgroup.
@@ -1123,7 +1141,7 @@ __device__ __forceinline__ void ldlt_chain_wave(LdltShared& sh, int NT, double* 
         double* const T = &sh.Inb[0][1][0];     // the inbox of block 2: first written in step 0
         double v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = S[(size_t)min(min(lo, k), n - 1) * ld + min(max(lo, k), n - 1)];
+        for (int k = 0; k < 16; ++k) v[k] = S[(lo >> 2) * 64 + (lo & 3) * 16 + k];          // tile 0, row lo: 128 contiguous bytes per lane
         const double yv0 = b[min(lo, n - 1)];
         if (lane < 16) {
 #pragma unroll
@@ -1132,7 +1150,6 @@ __device__ __forceinline__ void ldlt_chain_wave(LdltShared& sh, int NT, double* 
         const double yv = ldlt_diag16(ar, xr, T, &sh.Ui[0][0], sh.invd, lo < n ? yv0 : 0.0, ok, lane);
         if (lane < 16) sh.y[lo] = yv;
     }
-    __syncthreads();                            // workers: tiles staged through Lp[1] / Wn
     __syncthreads();                            // workers: block column 0 published
     for (int J = 0; J + 1 < NT; ++J) {
         const int par = (J + 1) & 1;
@@ -1230,54 +1247,33 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
             if (K > lo) gtv |= 1u << s;
         }
     }
-    // Tiles come in with 16-byte loads along the contiguous index of S (lane = (row pair, column) of the stored triangle: two load
-    // instructions per tile, all of them in flight at once -- the loads are unconditional, a branch around them makes the compiler
-    // sink each one to its use) and are turned into the accumulator layout through a per-wave LDS tile (Wn is idle until the
-    // first panel). Diagonal tiles read the stored triangle mirrored.
-    typedef double double2_t __attribute__((ext_vector_type(2)));
+    // Tiles come in straight from the tile storage k_schur writes (s_tile_off): register r of a tile = 64 consecutive doubles, all loads
+    // in flight at once (unconditional: a branch around them makes the compiler sink each one to its use; slots without a tile read
+    // tile 0). Rows / columns past n become the identity.
     LP(20, 2, 0);
     double4_t acc[kLdltSlots];
-    const int li = 2 * (lane & 7), lj = lane >> 3;
 #pragma unroll
     for (int s = 0; s < kLdltSlots; ++s) {
         const int I = max(tI(s), 0), K = max(tK(s), 0);
+        const double* const T = S + (size_t)(I * (I + 1) / 2 + K) * 256 + lane;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const double2_t v = *reinterpret_cast<const double2_t*>(&S[(size_t)(16 * K + lj + 8 * r) * ld + 16 * I + li]);
-            acc[s][2 * r] = v.x; acc[s][2 * r + 1] = v.y;
-        }
+        for (int r = 0; r < 4; ++r) acc[s][r] = T[64 * r];
     }
     LP(20, 3, 0);
-    {   // kLdltStage tiles per round trip: Lp[1] and Wn (contiguous, idle until the first panel) hold that many tiles per wave
-        double* const T0 = &sh.Lp[1][0] + wave * kLdltStage * 16 * kLS;
+    if (n < n_pad) {                                                             // wave-uniform: only a padded system has tiles to fix up
 #pragma unroll
-        for (int g = 0; g < kLdltSlots; g += kLdltStage) {
+        for (int s = 0; s < kLdltSlots; ++s) {
+            const int I = max(tI(s), 0), K = max(tK(s), 0);
+            if (I < NT - 1) continue;                                            // padding lives in the last block row
 #pragma unroll
-            for (int s = g; s < g + kLdltStage && s < kLdltSlots; ++s) {
-                double* const T = T0 + (s - g) * 16 * kLS;
-                const int I = max(tI(s), 0), K = max(tK(s), 0);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int j = 16 * K + lj + 8 * r, i = 16 * I + li;
-                    T[li * kLS + lj + 8 * r] = (i < n && j < n) ? acc[s][2 * r] : (i == j ? 1.0 : 0.0);                  // identity padding
-                    T[(li + 1) * kLS + lj + 8 * r] = (i + 1 < n && j < n) ? acc[s][2 * r + 1] : (i + 1 == j ? 1.0 : 0.0);
-                }
-            }
-#pragma unroll
-            for (int s = g; s < g + kLdltStage && s < kLdltSlots; ++s) {
-                const double* const T = T0 + (s - g) * 16 * kLS;
-                const bool diag = tI(s) == tK(s);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = hi + 4 * r;
-                    acc[s][r] = T[(diag && row < lo) ? lo * kLS + row : row * kLS + lo];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + hi + 4 * r, j = 16 * K + lo;
+                if (!(i < n && j < n)) acc[s][r] = i == j ? 1.0 : 0.0;
             }
         }
-        LP(20, 4, 0);
-        __syncthreads();                        // (chain wave: matching barrier) the staging area becomes Lp[1] / Wn again
-        LP(20, 5, 0);
     }
+    LP(20, 4, 0);
+    LP(20, 5, 0);
     // ---- prologue: publish block column 0 and the chain wave's inputs for block 1; the chain wave factors diagonal block 0
 #pragma unroll
     for (int s = 0; s < kLdltSlots; ++s) {
@@ -1454,12 +1450,21 @@ __global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ 
             if (pb.pt_active[l]) {
                 double c[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
                 if (pb.np) {
-                    for (int k = pb.pt_off[l]; k < pb.pt_off[l + 1]; ++k) {
-                        const int e = pb.pt_edges[k], pi = pose_idx[pb.epose[e]];
-                        if (pi < 0) continue;
-                        const double* B = pb.Hpl + (size_t)e * 18;
-                        const double* xq = xp + pi * 6;
-                        for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) c[j] -= B[r * 3 + j] * xq[r];
+                    // (edge, free-pose index) come from two parallel CSR arrays: one hop to the operands instead of three through
+                    // epose / pose_idx; the index pair of the next entry is already in flight while this one is applied
+                    const int32_t* __restrict__ pt_edges = pb.pt_edges;
+                    const int32_t* __restrict__ pt_pi = pb.pt_pi;
+                    const int k1 = pb.pt_off[l + 1];
+                    int k = pb.pt_off[l];
+                    int e = k < k1 ? pt_edges[k] : 0, pi = k < k1 ? pt_pi[k] : -1;
+                    for (; k < k1; ++k) {
+                        const int e_n = k + 1 < k1 ? pt_edges[k + 1] : 0, pi_n = k + 1 < k1 ? pt_pi[k + 1] : -1;
+                        if (pi >= 0) {
+                            const double* B = pb.Hpl + (size_t)e * 18;
+                            const double* xq = xp + pi * 6;
+                            for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) c[j] -= B[r * 3 + j] * xq[r];
+                        }
+                        e = e_n; pi = pi_n;
                     }
                 }
                 const double* D = pb.Dinv + (size_t)l * 9;
@@ -1940,7 +1945,7 @@ private:
 static HostPool& host_pool() { static HostPool* p = new HostPool; return *p; }
 
 struct Round {                                  // structure of one optimisation round (buildIndexMapping + buildStructure)
-    std::vector<int32_t> pose_idx, pt_off, pt_edges, ps_off, ps_edges, pair_ij, pair_off, pair_e;      // pair_e: (e1, e2) interleaved
+    std::vector<int32_t> pose_idx, pt_off, pt_edges, pt_pi, ps_off, ps_edges, pair_ij, pair_off, pair_e;      // pair_e: (e1, e2) interleaved
     struct Key { int32_t idx, edge; };              // (free-pose index or -1, edge id): scratch of build_round, kept for its capacity
     std::vector<Key> keys;
     std::vector<int32_t> cnt, cur_pt, cur_ps;
@@ -1978,7 +1983,7 @@ int build_round(const dcs_ba_problem* pb, Round& r)
     }
     for (int l = 0; l < L; ++l) r.pt_off[l + 1] += r.pt_off[l];
     for (int i = 0; i < np; ++i) r.ps_off[i + 1] += r.ps_off[i];
-    r.pt_edges.resize(E);
+    r.pt_edges.resize(E); r.pt_pi.resize(E);
     r.ps_edges.resize(r.ps_off[np]);
     using Key = Round::Key;
     std::vector<Key>& keys = r.keys;
@@ -2013,7 +2018,7 @@ int build_round(const dcs_ba_problem* pb, Round& r)
         for (int a = 1; a < n_fixed; ++a)
             for (int b2 = 0; b2 < a; ++b2) if (e_pose[kk[a].edge] == e_pose[kk[b2].edge]) return kk[a].edge;
         for (int k = n_fixed + 1; k < nk; ++k) if (kk[k].idx == kk[k - 1].idx) return kk[k].edge;
-        for (int k = 0; k < nk; ++k) r.pt_edges[k0 + k] = kk[k].edge;
+        for (int k = 0; k < nk; ++k) { r.pt_edges[k0 + k] = kk[k].edge; r.pt_pi[k0 + k] = kk[k].idx; }
         for (int a = n_fixed; a < nk; ++a) {
             int32_t* __restrict__ row = cntp + (size_t)kk[a].idx * np;
             for (int b = a; b < nk; ++b) ++row[kk[b].idx];
@@ -2148,7 +2153,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.poses[0] = c.get<double>(7 * P); q.points[0] = c.get<double>(3 * L);
             q.epose = c.get<int32_t>(E); q.epoint = c.get<int32_t>(E); q.ecam = c.get<int32_t>(E);
             q.obs = c.get<double>(2 * E); q.w = c.get<double>(E); q.active = c.get<uint8_t>(E);
-            q.pose_idx = c.get<int32_t>(P); q.pt_off = c.get<int32_t>(L + 1); q.pt_edges = c.get<int32_t>(r.pt_edges.size());
+            q.pose_idx = c.get<int32_t>(P); q.pt_off = c.get<int32_t>(L + 1); q.pt_edges = c.get<int32_t>(r.pt_edges.size()); q.pt_pi = c.get<int32_t>(r.pt_pi.size());
             q.ps_off = c.get<int32_t>(r.ps_off.size()); q.ps_edges = c.get<int32_t>(r.ps_edges.size());
             q.pair_ij = c.get<int32_t>(r.pair_ij.size()); q.pair_off = c.get<int32_t>(r.pair_off.size());
             q.pair_e = c.get<int32_t>(r.pair_e.size());
@@ -2216,7 +2221,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         memcpy(stage(q.w), pb->inv_sigma2, sizeof(double) * E);
         memset(stage(q.active), 1, E);
         auto put = [&](const int32_t* d, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage(d), v.data(), sizeof(int32_t) * v.size()); };
-        put(q.pose_idx, r.pose_idx); put(q.pt_off, r.pt_off); put(q.pt_edges, r.pt_edges); put(q.ps_off, r.ps_off); put(q.ps_edges, r.ps_edges);
+        put(q.pose_idx, r.pose_idx); put(q.pt_off, r.pt_off); put(q.pt_edges, r.pt_edges); put(q.pt_pi, r.pt_pi); put(q.ps_off, r.ps_off); put(q.ps_edges, r.ps_edges);
         put(q.pair_ij, r.pair_ij); put(q.pair_off, r.pair_off); put(q.pair_e, r.pair_e);
         DCams* cams = reinterpret_cast<DCams*>(stage(q.cams));
         memset(cams, 0, sizeof(DCams));

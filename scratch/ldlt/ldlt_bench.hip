@@ -16,12 +16,14 @@ int main(int argc, char** argv)
         S[(size_t)i * ld + j] = s; S[(size_t)j * ld + i] = s;
     }
     for (auto& v : b) v = N(rng);
+    std::vector<double> St((size_t)ld * ld, 0.0);              // what k_schur writes for k_ldlt_mfma: 16x16 tiles of the lower triangle (s_tile_off)
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if ((i >> 4) >= (j >> 4)) St[s_tile_off(i, j)] = S[(size_t)i * ld + j];
     double *dS, *db, *dx; BaProb* dp; BaCtl* dc;
     hipMalloc(&dS, sizeof(double) * ld * ld * B); hipMalloc(&db, sizeof(double) * n_pad * B); hipMalloc(&dx, sizeof(double) * n_pad * B);
     hipMalloc(&dp, sizeof(BaProb) * B); hipMalloc(&dc, sizeof(BaCtl) * B);
     std::vector<BaProb> hp(B); std::vector<BaCtl> hc(B);
     for (int i = 0; i < B; ++i) {
-        hipMemcpy(dS + (size_t)i * ld * ld, S.data(), sizeof(double) * ld * ld, hipMemcpyHostToDevice);
+        hipMemcpy(dS + (size_t)i * ld * ld, which == 1 ? St.data() : S.data(), sizeof(double) * ld * ld, hipMemcpyHostToDevice);
         hipMemcpy(db + (size_t)i * n_pad, b.data(), sizeof(double) * n, hipMemcpyHostToDevice);
         memset(&hp[i], 0, sizeof(BaProb)); memset(&hc[i], 0, sizeof(BaCtl));
         hp[i].np = n / 6 ? n / 6 : 1; hp[i].n = n; hp[i].n_pad = n_pad; hp[i].ld = ld; hp[i].use_reg = which;
