@@ -740,10 +740,15 @@ __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(c
     for (int q2 = 0; q2 < kSchurFine; ++q2) acc += part[q2][t];
     double v = -acc;
     if (i1 == i2) v += pb.Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
-    const int xa = i1 * 6 + r, ya = i2 * 6 + c;              // xa <= ya + 5; the mirrored entry (ya, xa) belongs to this thread only when i1 != i2
-    if (pb.use_reg == 1) {                                   // tiles of the lower triangle (diagonal tiles: both triangles)
-        if ((xa >> 4) >= (ya >> 4)) pb.S[s_tile_off(xa, ya)] = v;
-        if (i1 != i2 && (ya >> 4) >= (xa >> 4)) pb.S[s_tile_off(ya, xa)] = v;
+    const int xa = i1 * 6 + r, ya = i2 * 6 + c;
+    if (pb.use_reg == 1) {
+        // Tiles of the lower triangle (diagonal tiles: both triangles), filled from the UPPER entries only -- like g2o, which hands
+        // Eigen the upper triangle (linear_solver_eigen.h:94-124, selfadjointView<Upper>): entry (r, c) and entry (c, r) of a diagonal
+        // pose block are the same number on paper but two differently rounded sums here.
+        if (xa <= ya) {
+            pb.S[s_tile_off(ya, xa)] = v;
+            if (xa != ya && (xa >> 4) == (ya >> 4)) pb.S[s_tile_off(xa, ya)] = v;
+        }
         return;
     }
     pb.S[(size_t)xa * ld + ya] = v;
