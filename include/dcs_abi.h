@@ -220,9 +220,19 @@ int  dcs_search_by_projection(const dcs_proj_frame* frame, const dcs_proj_querie
                               int check_orientation, int32_t* match_of_query, int32_t* query_of_feature, int* n_matches);
 
 /* The same call also is SearchByProjectionOnCam(F, query, KF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:812-951: best only,
-   taken = pF->mvpMapPoints[g] != NULL, th_high = ORBdist, levels nPredictedLevel -+ 1, check_orientation) and
-   SearchByProjection(KF, query, Scw, vpPoints, vpMatched, th) (:416-536: best only, taken = vpMatched[idxLocal] != NULL, TH_LOW,
-   levels nPredictedLevel - 1 .. nPredictedLevel) -- both mark the matched feature as taken for the queries that follow.
+   taken = pF->mvpMapPoints[g] != NULL, th_high = ORBdist, levels nPredictedLevel -+ 1, check_orientation); it marks the matched
+   feature as taken for the queries that follow.
+
+   SearchByProjection(KF, query, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:416-536, loop closing) searches a KEY FRAME: its
+   candidates come from KeyFrame::GetFeaturesInArea (KeyFrame.cc:728-765: no level argument, and the |dx|,|dy| < r test reads
+   mvTotalKeysUn[camera-LOCAL index], :756 -- for cameras > 0 the position of another key point decides; reproduced), the octave
+   gate nPredictedLevel - 1 <= octave <= nPredictedLevel sits in the loop (:510-513: min_level / max_level of the queries), best
+   only, bestDist <= th (TH_LOW), a matched feature is taken for the queries that follow (:506, :527). frame->taken[g] =
+   (vpMatched[g - cam_off[query]] != NULL): the reference indexes vpMatched with the camera-local index. */
+int  dcs_search_by_projection_kf(const dcs_proj_frame* frame, const dcs_proj_queries* queries, int th,
+                                 int32_t* match_of_query, int32_t* query_of_feature, int* n_matches);
+
+/*
 
    Window searches whose queries do NOT see each other's results -- the candidate loops of
      Fuse(KF, vpMapPoints, th)                        ORBmatcher.cc:1431-1556  kf_area = 1, chi2 gate, levels pred - 1 .. pred, th = TH_LOW

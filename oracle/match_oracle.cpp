@@ -454,6 +454,40 @@ static void kf_features_in_area(const orc_proj_frame* f, int c, float x, float y
         }
 }
 
+/* ORBmatcher::SearchByProjection(KF, query, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:416-536, loop closing), the candidate
+   loop :494-529 on flat inputs: candidates = KeyFrame::GetFeaturesInArea (kf_features_in_area above, with its index quirk),
+   vpMatched[idxLocal] skips (:506; taken[] is indexed globally here, the caller maps the reference's camera-local vpMatched), the
+   octave gate nPredictedLevel - 1 .. nPredictedLevel (:510-513) = min_level .. max_level of the query, dist < bestDist (:519),
+   bestDist <= th accepts and marks the feature for the queries that follow (:525-529). */
+void orc_search_by_projection_kf(const orc_proj_frame* f, const orc_proj_queries* q, int th, int32_t* match_of_query, int32_t* query_of_feature,
+                                 int32_t* n_matches)
+{
+    const int N = f->cam_off[f->n_cams];
+    std::vector<uint8_t> taken(f->taken, f->taken + N);
+    for (int i = 0; i < N; ++i) query_of_feature[i] = -1;
+    int nmatches = 0;
+    std::vector<int> cand;
+    for (int i = 0; i < q->n; ++i) {
+        match_of_query[i] = -1;
+        if (!q->valid[i]) continue;
+        const int c = q->cam[i];
+        kf_features_in_area(f, c, q->u[i], q->v[i], q->radius[i], cand);
+        if (cand.empty()) continue;
+        const uint8_t* dMP = q->desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (int local : cand) {
+            const int g = f->cam_off[c] + local;
+            if (taken[g]) continue;
+            const int kpLevel = f->kp_octave[g];
+            if (kpLevel < q->min_level[i] || kpLevel > q->max_level[i]) continue;
+            const int dist = descriptor_distance(dMP, f->desc + (size_t)g * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = g; }
+        }
+        if (bestDist <= th) { taken[bestIdx] = 1; query_of_feature[bestIdx] = i; match_of_query[i] = bestIdx; ++nmatches; }
+    }
+    *n_matches = nmatches;
+}
+
 /* The window searches whose queries do not see each other's results: Fuse(KF, vpMapPoints, th) (ORBmatcher.cc:1431-1556),
    Fuse(KF, Scw, ...) (:1560-1706), both directions of SearchBySim3CrossCam (:1713-1965), SearchByProjection(KF, vpMapPoints,
    sAlreadyFound, th, ORBdist) (:693-799). Per query: candidates = GetFeaturesInArea of a KeyFrame (kf_area != 0, see above) or

@@ -140,6 +140,11 @@ typedef struct orc_proj_queries {
 void orc_search_by_projection(const orc_proj_frame* f, const orc_proj_queries* q, int th_high, float nn_ratio, int check_orientation,
                               int32_t* match_of_query, int32_t* query_of_feature, int32_t* n_matches);
 void orc_three_maxima(const int32_t* sizes, int L, int32_t* ind /* [3] */);
+/* ORBmatcher::SearchByProjection(KF, query, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:416-536): sequential, KeyFrame window
+   (KeyFrame.cc:728-765 incl. :756), octave gate in the loop, best only. */
+void orc_search_by_projection_kf(const orc_proj_frame* f, const orc_proj_queries* q, int th, int32_t* match_of_query, int32_t* query_of_feature,
+                                 int32_t* n_matches);
+
 /* Window searches with independent queries: Fuse x2 (ORBmatcher.cc:1431-1556, 1560-1706), SearchBySim3CrossCam (:1713-1965),
    SearchByProjection(KF, vpMapPoints, sAlreadyFound, th, ORBdist) (:693-799), and :416-536 with vpMatched as a snapshot.
    kf_area: candidates come from KeyFrame::GetFeaturesInArea (KeyFrame.cc:728-765, local index read as global, :756);

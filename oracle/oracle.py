@@ -208,6 +208,17 @@ def search_by_projection(frame, queries, th_high=100, nn_ratio=0.8, check_orient
     return mq[:n], qf[:N], nm.value
 
 
+def search_by_projection_kf(frame, queries, th=50):
+    """SearchByProjection(KF, query, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:416-536): (match_of_query, query_of_feature, n)"""
+    f, q, keep = _proj_structs(frame, queries)
+    N, n = int(frame["cam_off"][-1]), len(queries["cam"])
+    mq, qf, nm = np.full(max(n, 1), -1, np.int32), np.full(max(N, 1), -1, np.int32), C.c_int32()
+    L = lib()
+    L.orc_search_by_projection_kf.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_search_by_projection_kf(C.byref(f), C.byref(q), int(th), _p(mq), _p(qf), C.byref(nm))
+    return mq[:n], qf[:N], nm.value
+
+
 def search_in_window(frame, queries, th=50, kf_area=True, chi2_inv_sigma2=None):
     """Fuse x2 / SearchBySim3CrossCam / SearchByProjection(KF, ...) candidate loops (independent queries):
     (match_of_query [global feature or -1], best_dist, accepted)"""

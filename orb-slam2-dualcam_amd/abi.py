@@ -25,7 +25,7 @@ SYMBOLS = [
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
-    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_in_window", "dcs_search_for_initialization",
+    "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_by_projection_kf", "dcs_search_in_window", "dcs_search_for_initialization",
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
     "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
@@ -137,6 +137,7 @@ def lib():
             "dcs_pose_optimization": [C.POINTER(PoseProblem), C.POINTER(PoseResult)],
             "dcs_frame_grid": [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, pci],
             "dcs_search_by_projection": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, cf, ci, vp, vp, pci],
+            "dcs_search_by_projection_kf": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, vp, vp, pci],
             "dcs_kfdb_create": [C.POINTER(vp)], "dcs_kfdb_destroy": [vp], "dcs_kfdb_add": [vp, vp, vp, ci, pci], "dcs_kfdb_erase": [vp, ci],
             "dcs_kfdb_clear": [vp], "dcs_kfdb_size": [vp, pci], "dcs_kfdb_query": [vp, vp, vp, ci, vp, vp, vp],
             "dcs_search_in_window": [C.POINTER(ProjFrame), C.POINTER(ProjQueries), ci, ci, vp, ci, vp, vp, pci],
@@ -398,6 +399,16 @@ class ORBmatcher:
         mq, qf, nm = np.full(max(n, 1), -1, np.int32), np.full(max(N, 1), -1, np.int32), C.c_int()
         _check(lib().dcs_search_by_projection(C.byref(f), C.byref(q), int(th_high), float(self.mfNNratio) if use_ratio else 0.0,
                                               int(check_orientation), _p(mq), _p(qf), C.byref(nm)), "dcs_search_by_projection")
+        return mq[:n], qf[:N], nm.value
+
+    def SearchByProjectionKF(self, frame, queries, th=50):
+        """ORBmatcher::SearchByProjection(KF, query, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:416-536, loop closing): the key
+        frame's own window (KeyFrame::GetFeaturesInArea incl. its index quirk), octave gate in the loop, best only, sequential
+        `taken` chain. Returns (match_of_query, query_of_feature, n)."""
+        f, q, keep = self._proj_structs(frame, queries)
+        N, n = int(frame["cam_off"][-1]), len(queries["cam"])
+        mq, qf, nm = np.full(max(n, 1), -1, np.int32), np.full(max(N, 1), -1, np.int32), C.c_int()
+        _check(lib().dcs_search_by_projection_kf(C.byref(f), C.byref(q), int(th), _p(mq), _p(qf), C.byref(nm)), "dcs_search_by_projection_kf")
         return mq[:n], qf[:N], nm.value
 
     def SearchInWindow(self, frame, queries, th=50, kf_area=True, chi2_inv_sigma2=None):

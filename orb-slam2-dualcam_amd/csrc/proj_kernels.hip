@@ -714,8 +714,10 @@ static int proj_prepare(Scratch& s, const dcs_proj_frame* fr, const dcs_proj_que
     return DCS_OK;
 }
 
-int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* qs, int th_high, float nn_ratio, int check_orientation,
-                             int32_t* match_of_query, int32_t* query_of_feature, int* n_matches)
+// kf_area: the window of KeyFrame::GetFeaturesInArea (camera-local index read as a global one, KeyFrame.cc:756; no level argument: the
+// octave gate min <= octave <= max sits in the caller's loop, ORBmatcher.cc:510-513) instead of Frame::GetFeaturesInArea
+static int search_by_projection_impl(const dcs_proj_frame* fr, const dcs_proj_queries* qs, int th_high, float nn_ratio, int check_orientation, int kf_area,
+                                     int32_t* match_of_query, int32_t* query_of_feature, int* n_matches)
 {
     if (!n_matches || (fr && fr->cam_off && fr->n_cams >= 1 && fr->cam_off[fr->n_cams] > 0 && !query_of_feature) || (qs && qs->n > 0 && !match_of_query)) {
         set_error("bad argument"); return DCS_ERR_INVALID;
@@ -725,6 +727,7 @@ int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* q
     int rc = proj_prepare(s, fr, qs, true, check_orientation != 0, in);
     if (rc) return rc;
     const int N = in.N, nq = in.nq;
+    in.f.kf_area = kf_area != 0; in.f.loop_levels = kf_area != 0;
     const ProjFrameD& f = in.f;
     const ProjQueriesD& q = in.q;
     *n_matches = 0;
@@ -754,6 +757,17 @@ int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* q
     if ((rc = s.finish())) return rc;
     *n_matches = nm;
     return DCS_OK;
+}
+
+int dcs_search_by_projection(const dcs_proj_frame* fr, const dcs_proj_queries* qs, int th_high, float nn_ratio, int check_orientation,
+                             int32_t* match_of_query, int32_t* query_of_feature, int* n_matches)
+{
+    return search_by_projection_impl(fr, qs, th_high, nn_ratio, check_orientation, 0, match_of_query, query_of_feature, n_matches);
+}
+
+int dcs_search_by_projection_kf(const dcs_proj_frame* fr, const dcs_proj_queries* qs, int th, int32_t* match_of_query, int32_t* query_of_feature, int* n_matches)
+{
+    return search_by_projection_impl(fr, qs, th, 0.f, 0, 1, match_of_query, query_of_feature, n_matches);
 }
 
 int dcs_search_in_window(const dcs_proj_frame* fr, const dcs_proj_queries* qs, int th, int kf_area, const float* chi2_inv_sigma2, int n_levels,

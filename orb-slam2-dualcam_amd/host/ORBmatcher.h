@@ -93,16 +93,17 @@ public:
 
     // SearchByProjection(pKF, query, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:416-536, loop closing): queries = the candidate
     // map points that pass :448-490 (depth, IsInImage, distance range, viewing angle), radius = th * mvScaleFactors[nPredictedLevel],
-    // levels nPredictedLevel - 1 .. nPredictedLevel, frame.taken = (vpMatched[idxLocal] != NULL); best only, TH_LOW; a matched
-    // feature is taken for the queries that follow (:508-509, :527). The KeyFrame grid quirk (KeyFrame.cc:756) only differs from
-    // the Frame grid for cameras > 0.
+    // levels nPredictedLevel - 1 .. nPredictedLevel, best only, TH_LOW; a matched feature is taken for the queries that follow
+    // (:506, :527). The window is the key frame's own (KeyFrame::GetFeaturesInArea with its camera-local index quirk, KeyFrame.cc:756,
+    // reproduced by dcs_search_by_projection_kf). keyFrame.taken[cam_off[query] + l] = (vpMatched[l] != NULL): the reference indexes
+    // vpMatched with the camera-local index l, and vpMatched[l] = the query matched to queryOfFeature[cam_off[query] + l].
     int SearchByProjection(const dcs_proj_frame& keyFrame, const dcs_proj_queries& queries, int th, std::vector<int32_t>& matchOfQuery,
                            std::vector<int32_t>& queryOfFeature) const
     {
         (void)th;                                            // folded into queries.radius by the caller
         matchOfQuery.assign(queries.n > 0 ? queries.n : 1, -1); queryOfFeature.assign(keyFrame.cam_off[keyFrame.n_cams] > 0 ? keyFrame.cam_off[keyFrame.n_cams] : 1, -1);
         int n = 0;
-        check(dcs_search_by_projection(&keyFrame, &queries, TH_LOW, 0.f, 0, matchOfQuery.data(), queryOfFeature.data(), &n), "dcs_search_by_projection");
+        check(dcs_search_by_projection_kf(&keyFrame, &queries, TH_LOW, matchOfQuery.data(), queryOfFeature.data(), &n), "dcs_search_by_projection_kf");
         matchOfQuery.resize(queries.n); queryOfFeature.resize(keyFrame.cam_off[keyFrame.n_cams]);
         return n;
     }

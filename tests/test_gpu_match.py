@@ -155,6 +155,36 @@ def test_search_by_projection(pkg, oracle, synth, kw):
     assert n == 0 and len(mq) == 0 and (qf == -1).all()
 
 
+@pytest.mark.parametrize("kw", [dict(n_per_cam=900, n_queries=700, seed=21), dict(n_per_cam=1500, n_queries=1200, seed=4, th=3.0),
+                                dict(n_per_cam=400, n_queries=300, seed=6, big_windows=25)])
+def test_search_by_projection_kf(pkg, oracle, synth, kw):
+    """SearchByProjection(KF, query, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:416-536, loop closing): the key frame's own window
+    -- KeyFrame::GetFeaturesInArea tests the position of mvTotalKeysUn[camera-LOCAL index] (KeyFrame.cc:756), so for the second camera
+    another key point's position decides -- with the octave gate in the loop and the sequential vpMatched chain: exact vs the oracle,
+    and different from the Frame-window search on the two-camera problem (otherwise the test would not see the quirk)."""
+    frame, q = _proj_problem(pkg, oracle, synth, **kw)
+    assert len(frame["cam_off"]) == 3 and (q["cam"] == 1).sum() > 50
+    q = dict(q)
+    q["min_level"] = np.maximum(q["max_level"] - 1, 0).astype(np.int32)                  # nPredictedLevel - 1 .. nPredictedLevel
+    m = pkg.ORBmatcher(0.8, True)
+    for th in (50, 100):
+        mq, qf, n = m.SearchByProjectionKF(frame, q, th)
+        emq, eqf, en = oracle.search_by_projection_kf(frame, q, th)
+        assert np.array_equal(mq, emq) and np.array_equal(qf, eqf) and n == en
+    assert n > 0
+    fq, _, _ = m.SearchByProjection(frame, q, 100, use_ratio=False, check_orientation=False)
+    cam1 = q["cam"] == 1
+    assert not np.array_equal(fq[cam1], mq[cam1])
+    # already matched features are skipped and an empty query set clears the map
+    fr2 = dict(frame); fr2["taken"] = frame["taken"].copy(); fr2["taken"][emq[emq >= 0][::2]] = 1
+    mq2, qf2, n2 = m.SearchByProjectionKF(fr2, q, 100)
+    e2 = oracle.search_by_projection_kf(fr2, q, 100)
+    assert np.array_equal(mq2, e2[0]) and np.array_equal(qf2, e2[1]) and n2 == e2[2] and not set(mq2[mq2 >= 0]) & set(np.nonzero(fr2["taken"])[0])
+    q0 = {k: v[:0] for k, v in q.items()}
+    mq, qf, n = m.SearchByProjectionKF(frame, q0)
+    assert n == 0 and len(mq) == 0 and (qf == -1).all()
+
+
 def test_is_in_frustum_and_projection_chain(pkg, oracle, synth):
     """Frame::isInFrustum + PredictScale + window (dcs_is_in_frustum) vs the oracle, float outputs bit for bit; then the chain of
     Tracking::SearchLocalPoints: frustum gate -> projection queries -> SearchByProjection, GPU vs oracle end to end."""

@@ -523,3 +523,39 @@ def test_search_in_window_oracle(oracle, synth):
     frame["taken"][hit] = 1
     m2, _, _ = oracle.search_in_window(frame, q, 100, False, None)
     assert not np.isin(m2[m2 >= 0], hit).any()
+
+
+def test_search_by_projection_kf_oracle(oracle, synth):
+    """SearchByProjection(KF, query, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:416-536): the oracle against an independent
+    restatement of the loop :494-529 -- KeyFrame window with the local-as-global index, vpMatched skip, octave gate, strict
+    dist < bestDist, bestDist <= th, the match taken for the queries that follow."""
+    frame, q = synth.projection_problem(n_per_cam=350, n_queries=420, seed=17, th=3.0)
+    _with_grid(oracle, frame)
+    cells = _grid_np(frame)
+    q["max_level"] = (q["min_level"] + 1).astype(np.int32)                   # nPredictedLevel - 1 .. nPredictedLevel
+    bits = np.unpackbits(frame["desc"], axis=1).astype(np.int32)
+    qbits = np.unpackbits(q["desc"], axis=1).astype(np.int32)
+    for th in (50, 100):
+        matched = frame["taken"].copy()
+        out = np.full(len(q["cam"]), -1)
+        who = np.full(len(matched), -1)
+        for i in range(len(q["cam"])):
+            if not q["valid"][i]:
+                continue
+            c = q["cam"][i]
+            best, bi = 256, -1
+            for loc in _area_np(frame, cells, c, q["u"][i], q["v"][i], q["radius"][i], kf=True):
+                g = frame["cam_off"][c] + loc
+                if matched[g]:
+                    continue
+                o = frame["kp_octave"][g]
+                if o < q["min_level"][i] or o > q["max_level"][i]:
+                    continue
+                d = int((bits[g] != qbits[i]).sum())
+                if d < best:
+                    best, bi = d, g
+            if best <= th:
+                matched[bi] = 1; out[i] = bi; who[bi] = i
+        mq, qf, n = oracle.search_by_projection_kf(frame, q, th)
+        assert np.array_equal(mq, out) and np.array_equal(qf, who) and n == int((out >= 0).sum())
+    assert n > 40 and len(set(out[out >= 0])) == n                           # every feature matched at most once
