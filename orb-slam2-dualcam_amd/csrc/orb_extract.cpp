@@ -657,7 +657,10 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     // images per chunk: 96 from 192 images, half the call from 128 (0 = one-shot path; read per call: tests compare the two paths).
     // Measured per 512 images of 640 x 480 on one box, three alternating rounds: 64 -> 4.90 / 4.94 / 6.04 ms, 96 -> 4.22 / 4.24 / 5.79,
     // 80 -> 5.77 / 4.63 / 5.33, 128 -> 6.6, 170 -> 5.2, 32 -> 8.4 (the compute stream is the slow stage: every chunk is a complete
-    // extraction, and small ones fill the chip badly; large ones start late and leave a long tail).
+    // extraction, and small ones fill the chip badly; large ones start late and leave a long tail). A second extraction lane (odd
+    // chunks on a twin handle with its own scratch and stream, underneath the even ones) was measured and changes nothing -- 4.24 / 4.75 /
+    // 4.65 ms with two lanes against 5.13 / 4.72 / 4.68 with one: what the call waits for after the last image is packed (2.1 of
+    // 4.3 ms) is the image DMA, 157 MB at an effective ~45 GB/s next to the packing threads' traffic, then one chunk's kernels, download and scatter.
     const char* chunk_s = getenv("DCS_ORB_HOST_CHUNK");
     const int chunk_env = chunk_s ? atoi(chunk_s) : std::min(96, n_images / 2);
     if (h->device_octree && chunk_env > 0 && n_images >= 2 * chunk_env && (chunk_s || n_images >= 128)) {
