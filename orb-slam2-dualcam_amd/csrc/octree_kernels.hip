@@ -343,7 +343,8 @@ constexpr int kHD = 6;                                  // deepest histogram lev
 constexpr int kCapH = 512;                              // final / expandable nodes handled in LDS
 
 // out[rank] = in[i] for n <= kCapH distinct keys; every thread of the 1024-thread block calls it
-__device__ __forceinline__ void rank_sort(const unsigned long long* kin, const unsigned* vin, unsigned long long* kout, unsigned* vout, int n, int* s_rank)
+template <typename V>
+__device__ __forceinline__ void rank_sort(const unsigned long long* kin, const V* vin, unsigned long long* kout, V* vout, int n, int* s_rank)
 {
     const int tid = threadIdx.x;
     const int np = next_pow2(max(n, 1)), parts = kTH / np;       // np <= 512: every element gets `parts` >= 2 threads
@@ -383,7 +384,7 @@ __device__ __forceinline__ int scan_block(int* a, int n, int* s_w /* [kTH / 64] 
 }
 
 template <int NINI>
-__global__ __launch_bounds__(kTH) void k_octree_hist(const dcs_candidate* __restrict__ dense, const int32_t* __restrict__ lvl_off,
+__global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dcs_candidate* __restrict__ dense, const int32_t* __restrict__ lvl_off,
                                                      OctLevels P, int dense_cap, int force_general, SelKp* __restrict__ sel,
                                                      int32_t* __restrict__ lvl_cnt, int32_t* __restrict__ need_general)
 {
@@ -392,8 +393,11 @@ __global__ __launch_bounds__(kTH) void k_octree_hist(const dcs_candidate* __rest
     __shared__ __attribute__((aligned(16))) unsigned s_bin6[NB6];
     __shared__ unsigned short s_cnt[NINI * 1365 + 8];   // depths 0..5: NINI * (1 + 4 + ... + 1024)
     __shared__ unsigned long long s_ka[kCapH], s_kb[kCapH], s_fkey[kCapH];    // expandable nodes (unsorted / sorted), final nodes
-    __shared__ unsigned s_va[kCapH], s_vb[kCapH], s_fval[kCapH];
-    __shared__ int s_nch[kCapH], s_inc[kCapH], s_rank[kCapH];
+    // bins (< 8192) and candidate indices (< 65536) as 16-bit values, child counts as bytes: 39.2 KB for NINI = 1 = FOUR tasks per CU
+    // (43.8 KB held three; the kernel is latency-bound, so resident tasks are what counts)
+    __shared__ unsigned short s_va[kCapH], s_vb[kCapH], s_fval[kCapH];
+    __shared__ unsigned char s_nch[kCapH];
+    __shared__ int s_inc[kCapH], s_rank[kCapH];
     __shared__ int s_size[kHD + 2], s_nexp[kHD + 2], s_w[kTH / 64];
     __shared__ int s_D, s_tail, s_cursize, s_nfin, s_nnext, s_rstar, s_seq, s_bail;
     const int task = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(kTH) void k_octree_hist(const dcs_candidate* __rest
             if (cc == 0) continue;
             if (tail && cc > 1) {
                 const int t = atomicAdd(&s_nnext, 1);
-                if (t < kCapH) { s_ka[t] = ((kM20 - (unsigned long long)cc) << 36) | order_key(code14(b, D), D); s_va[t] = (unsigned)b; }
+                if (t < kCapH) { s_ka[t] = ((kM20 - (unsigned long long)cc) << 36) | order_key(code14(b, D), D); s_va[t] = (unsigned short)b; }
                 else s_bail = 1;
                 continue;
             }
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(kTH) void k_octree_hist(const dcs_candidate* __rest
             const int f = atomicAdd(&s_nfin, 1);
             if (f < kCapH) {
                 s_fkey[f] = (1ull << 60) | ((unsigned long long)(D - depth) << 36) | order_key(code14(b >> (2 * (D - depth)), depth), depth);
-                s_fval[f] = best_of(D, b);
+                s_fval[f] = (unsigned short)best_of(D, b);
             } else s_bail = 1;
         }
     }
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(kTH) void k_octree_hist(const dcs_candidate* __rest
                 int cnt = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) cnt += count_at(depth_cur + 1, 4 * (int)s_vb[tid] + q) > 0;
-                s_nch[tid] = cnt; s_inc[tid] = cnt;
+                s_nch[tid] = (unsigned char)cnt; s_inc[tid] = cnt;
             }
             if (tid == 0) s_rstar = T;
             __syncthreads();
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(kTH) void k_octree_hist(const dcs_candidate* __rest
                     const int f = atomicAdd(&s_nfin, 1);
                     if (f < kCapH) {
                         s_fkey[f] = first_pass ? ((1ull << 60) | (s_kb[r] & kM36)) : ((s_kb[r] & kM20) << 36);
-                        s_fval[f] = best_of(depth_cur, (int)bin);
+                        s_fval[f] = (unsigned short)best_of(depth_cur, (int)bin);
                     } else s_bail = 1;
                 } else {
                     int child = 0;
@@ -582,11 +586,11 @@ __global__ __launch_bounds__(kTH) void k_octree_hist(const dcs_candidate* __rest
                         if (!stop && cc > 1) {
                             if (depth_cur + 2 > kHD) { s_bail = 1; continue; }       // grandchildren would leave the pyramid
                             const int s2 = atomicAdd(&s_nnext, 1);                   // next pass: fullest first, then latest created first
-                            if (s2 < kCapH) { s_ka[s2] = ((kM20 - (unsigned long long)cc) << 36) | (kM20 - seq); s_va[s2] = (unsigned)cb; }
+                            if (s2 < kCapH) { s_ka[s2] = ((kM20 - (unsigned long long)cc) << 36) | (kM20 - seq); s_va[s2] = (unsigned short)cb; }
                             else s_bail = 1;
                         } else {
                             const int f = atomicAdd(&s_nfin, 1);
-                            if (f < kCapH) { s_fkey[f] = (kM20 - seq) << 36; s_fval[f] = best_of(depth_cur + 1, cb); } else s_bail = 1;
+                            if (f < kCapH) { s_fkey[f] = (kM20 - seq) << 36; s_fval[f] = (unsigned short)best_of(depth_cur + 1, cb); } else s_bail = 1;
                         }
                     }
                 }
