@@ -407,10 +407,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
                 // every valid entry and is cut off by the count below.
                 m = __builtin_amdgcn_ballot_w64(compass(b)) & m_col;
                 const unsigned at = ((unsigned)rank_in(m) << 1) + end_addr;
-                // the store runs under exec = m (two scalar moves around it) instead of steering idle lanes to a spare slot with a
-                // v_cndmask: one vector instruction less per round, still no branch
+                // the store runs under exec = m (s_and_saveexec before, one scalar move after: every lane is active here) instead of steering
+                // idle lanes to a spare slot with a v_cndmask: one vector instruction less per round, still no branch
                 unsigned long long saved;
-                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(m), "v"(at), "v"(yx) : "memory");
+                asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(m), "v"(at), "v"(yx) : "memory", "scc");
                 end_addr += 2u * (unsigned)__popcll(m);
             }
             n_list = (int)((end_addr - list_addr) >> 1);
@@ -1290,12 +1290,20 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         uint8_t* dout = desc_out + ((size_t)img * cap + i0 + kq) * 32;
         // biased coordinates (kRnBias + r, kRnBias + c; kRnBias is even): row pair (r + 18) >> 1 = (rb >> 1) - kRnBias / 2 + 9, parity = rb & 1,
         // column c + 18; the constants go into the base address
-        const unsigned hp_base = lds_addr(hp) + (unsigned)(9 * kHCols * 4 + kPatchR * 4) - (kRnBias / 2) * (kHCols * 4) - kRnBias * 4;
+        // (the row-pair index goes through a 24-bit multiply-add: only the low 24 bits of kRnBias / 2 take part in the product)
+        const unsigned hp_base = lds_addr(hp) + (unsigned)(9 * kHCols * 4 + kPatchR * 4) - ((kRnBias / 2) & 0xFFFFFFu) * (kHCols * 4) - kRnBias * 4;
+        unsigned hp_pitch_v = (unsigned)(kHCols * 4), hp_base_v = hp_base;
+        asm volatile("" : "+v"(hp_pitch_v), "+v"(hp_base_v));                  // loop-invariant VGPR copies
         auto blurred_at = [&](unsigned rb, unsigned cb) {
             const bool odd = rb & 1;
             const unsigned W0 = odd ? (18u << 16) : (18u | (34u << 16)), W1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16)),
                            W2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), W3 = odd ? (34u | (18u << 16)) : 18u;
-            const lds_u32_ptr col = (lds_u32_ptr)(uintptr_t)(hp_base + (rb >> 1) * (kHCols * 4) + (cb << 2));
+            // two instructions, spelled out (the compiler's own choice is v_mul_u32_u24 + v_lshlrev + v_add3): pitch and base sit in VGPRs
+            // because a VOP3 instruction reads at most one scalar register on gfx9
+            unsigned rowaddr, coladdr;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rowaddr) : "v"(rb >> 1), "v"(hp_pitch_v), "v"(hp_base_v));
+            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(coladdr) : "v"(cb), "v"(rowaddr));
+            const lds_u32_ptr col = (lds_u32_ptr)(uintptr_t)coladdr;
             unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[0]), __builtin_bit_cast(ushort2_t, W0), 32768u, false);
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[kHCols]), __builtin_bit_cast(ushort2_t, W1), acc, false);
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[2 * kHCols]), __builtin_bit_cast(ushort2_t, W2), acc, false);
