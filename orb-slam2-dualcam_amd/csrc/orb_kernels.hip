@@ -400,19 +400,27 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             unsigned long long m = 0;
             const unsigned list_addr = lds_addr(s_list);
             unsigned end_addr = list_addr;                                                       // scalar, behind the last entry
-            for (int yy = 0; yy < dh; yy += 2, yx += 0x200u, b += 2 * P) {                   // wave-uniform trip count
-                // Every lane evaluates the test (a lane outside the detection area reads the score map at worst: still inside
-                // the LDS allocation); its ballot IS the compare's SGPR mask. No branch: the append is one LDS store under exec = m.
-                // When dh is odd the upper half-wave's last row lies below the detection area: whatever it appends comes after
-                // every valid entry and is cut off by the count below.
-                m = __builtin_amdgcn_ballot_w64(compass(b)) & m_col;
+            // Every lane evaluates the test (a lane outside the detection area reads the score map at worst: still inside
+            // the LDS allocation); its ballot IS the compare's SGPR mask. No branch: the append is one LDS store under exec = m.
+            // When dh is odd the upper half-wave's last row lies below the detection area: whatever it appends comes after
+            // every valid entry and is cut off by the count below.
+            auto round = [&](const uint8_t* bb, unsigned yxr) {
+                m = __builtin_amdgcn_ballot_w64(compass(bb)) & m_col;
                 const unsigned at = ((unsigned)rank_in(m) << 1) + end_addr;
                 // the store runs under exec = m (s_and_saveexec before, one scalar move after: every lane is active here) instead of steering
                 // idle lanes to a spare slot with a v_cndmask: one vector instruction less per round, still no branch
                 unsigned long long saved;
-                asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(m), "v"(at), "v"(yx) : "memory", "scc");
-                end_addr += 2u * (unsigned)__popcll(m);
+                asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(m), "v"(at), "v"(yxr) : "memory", "scc");
+                const unsigned cnt = (unsigned)__popcll(m);
+                asm("s_lshl1_add_u32 %0, %1, %0" : "+s"(end_addr) : "s"(cnt) : "scc");      // end_addr += 2 cnt in one scalar instruction
+            };
+            // four rounds per trip: the later ones' LDS reads are immediate offsets of the first one's address, and the loop's
+            // scalar bookkeeping is paid once per eight rows
+            int yy = 0;
+            for (; yy + 6 < dh; yy += 8, yx += 0x800u, b += 8 * P) {                          // wave-uniform trip counts
+                round(b, yx); round(b + 2 * P, yx + 0x200u); round(b + 4 * P, yx + 0x400u); round(b + 6 * P, yx + 0x600u);
             }
+            for (; yy < dh; yy += 2, yx += 0x200u, b += 2 * P) round(b, yx);
             n_list = (int)((end_addr - list_addr) >> 1);
             if (dh & 1) n_list -= __popc((unsigned)(m >> 32));
         } else {
