@@ -1318,6 +1318,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, col[3 * kHCols]), __builtin_bit_cast(ushort2_t, W3), acc, false);
             return min(255u, acc >> 16);
         };
+        unsigned long long bits[4];                          // bit j of bits[it] = test 64 it + j (LSB-first bytes)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const float4 pt = s_pattern[it * 64 + lane];
@@ -1326,8 +1327,12 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
             const unsigned r1 = rn_biased(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
             const unsigned c1 = rn_biased(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
             const unsigned t0 = blurred_at(r0, c0), t1 = blurred_at(r1, c1);
-            const unsigned long long m = __ballot(t0 < t1);  // bit j of m = test 64*it + j  (LSB-first bytes)
-            if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * it) = m;
+            bits[it] = __ballot(t0 < t1);
+        }
+        if (lane == 0) {                                     // the 32 bytes in two 16-byte stores under ONE exec region (one store per ballot cost 3 scalar instructions each)
+            uint4* d4 = reinterpret_cast<uint4*>(dout);
+            d4[0] = uint4{(unsigned)bits[0], (unsigned)(bits[0] >> 32), (unsigned)bits[1], (unsigned)(bits[1] >> 32)};
+            d4[1] = uint4{(unsigned)bits[2], (unsigned)(bits[2] >> 32), (unsigned)bits[3], (unsigned)(bits[3] >> 32)};
         }
     }
     }
