@@ -243,14 +243,15 @@ __device__ __forceinline__ void knn2_tile_mfma(const uint8_t* __restrict__ q, in
     for (int t0 = 0, buf = 0; t0 < nt; t0 += kMTile, buf ^= 1) {
         if (t0 + kMTile < nt) expand_tile(t0 + kMTile, buf ^ 1);   // next tile: its VALU / LDS work overlaps this tile's MFMAs
         const int n_grp = (min(kMTile, nt - t0) + 15) >> 4;
-        v4i_t af[4], pb;
-        auto load_group = [&](int tg) {
+        v4i_t af[4], pbA, pbB;
+        auto load_group = [&](int tg, v4i_t& pb) {
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) af[sl] = *reinterpret_cast<const v4i_t*>(s_t[buf] + (16 * tg + c) * kMRow + 16 * (4 * sl + g));
             pb = *reinterpret_cast<const v4i_t*>(&s_pb[buf][16 * tg + 4 * g]);              // biased popcounts of train rows 4 g + r
         };
-        load_group(0);
-        for (int tg = 0; tg < n_grp; ++tg) {
+        // one group of 16 train rows: 4 x QG matrix instructions, the NEXT group's operands requested behind them (into the other
+        // popcount register set: the loop is unrolled by two so that no register copy is needed), then the keys of this group
+        auto group = [&](int tg, const v4i_t& pb_now, v4i_t& pb_next) {
             v4i_t acc[QG];
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg) acc[qg] = v4i_t{0, 0, 0, 0};
@@ -258,17 +259,21 @@ __device__ __forceinline__ void knn2_tile_mfma(const uint8_t* __restrict__ q, in
             for (int sl = 0; sl < 4; ++sl)                       // slice-major: consecutive MFMAs hit different accumulators
 #pragma unroll
                 for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[sl], bf[qg][sl], acc[qg], 0, 0, 0);
-            const v4i_t pbc = pb;
-            if (tg + 1 < n_grp) load_group(tg + 1);              // next group's operands fly while this group's keys are ranked
+            if (tg + 1 < n_grp) load_group(tg + 1, pb_next);     // next group's operands fly while this group's keys are ranked
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // (popcount(t) + 512 - 2 <q, t>) << 22 | index; padding rows of the last group: acc = 0, largest key, index >= nt
-                    const unsigned key = ((unsigned)acc[qg][r] << 23) + (unsigned)pbc[r];       // one v_lshl_add_u32
+                    const unsigned key = ((unsigned)acc[qg][r] << 23) + (unsigned)pb_now[r];       // one v_lshl_add_u32
                     k2[qg] = umed3(k1[qg], k2[qg], key); k1[qg] = min(k1[qg], key);
                 }
             }
+        };
+        load_group(0, pbA);
+        for (int tg = 0; tg < n_grp; tg += 2) {
+            group(tg, pbA, pbB);
+            if (tg + 1 < n_grp) group(tg + 1, pbB, pbA);
         }
         __syncthreads();
     }
