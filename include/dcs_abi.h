@@ -117,7 +117,8 @@ int  dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_image
    run-time failure -- the batch's FAST candidates exceed the handle's candidate buffer (1/16 of the pyramid pixels per
    image, shared by the batch; a scene of pure salt-and-pepper corners) -- is reported in band: every d_n_out[i] of that
    call is DCS_ERR_CAPACITY (negative) instead of a count, and no keypoint of the call is valid. The host-buffer entry points
-   return DCS_ERR_CAPACITY for the same condition. `cap` < dcs_orb_required_cap() is rejected before anything is enqueued. */
+   return DCS_ERR_CAPACITY for the same condition. d_images may have any alignment and stride; d_desc must be 16-byte aligned and
+   d_kp / d_n_out 4-byte aligned (descriptors are written and later read as 16-byte words; hipMalloc returns 256-byte alignment). `cap` < dcs_orb_required_cap() is rejected before anything is enqueued. */
 int  dcs_orb_extract_batch_device(dcs_orb* h, const uint8_t* d_images, int n_images, int rows, int cols,
                                   int stride, dcs_keypoint* d_kp, uint8_t* d_desc, int cap,
                                   int32_t* d_n_out, void* stream);
