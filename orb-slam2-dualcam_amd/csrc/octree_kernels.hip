@@ -338,6 +338,12 @@ __global__ __launch_bounds__(kT) void k_octree(const dcs_candidate* __restrict__
 // keys, counted by all threads in parallel; keys are distinct) instead of a bitonic network.
 // Valid while everything the reference touches lies within 6 levels (true for the usual quotas); otherwise the task is
 // flagged and the general sort-based kernel k_octree redoes it. Output is identical by construction and by test.
+#ifdef DCS_OCT_PROF                           // phase timestamps of one task (scratch: -DDCS_OCT_PROF side build + dcs_debug_oct_prof)
+__device__ long long g_oct_prof[64];
+#define OP(k) do { if (blockIdx.x == DCS_OCT_PROF && threadIdx.x == 0) g_oct_prof[k] = clock64(); } while (0)
+#else
+#define OP(k)
+#endif
 constexpr int kTH = 512;
 constexpr int kHD = 6;                                  // deepest histogram level
 constexpr int kCapH = 512;                              // final / expandable nodes handled in LDS
@@ -415,10 +421,12 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
     auto lvl_base = [](int d) { return NINI * (((1 << (2 * d)) - 1) / 3); };     // offset of depth d inside s_cnt
     auto count_at = [&](int d, int bin) -> int { return d == kHD ? (int)(s_bin6[bin] & 255u) : (int)s_cnt[lvl_base(d) + bin]; };
 
+    OP(0);
     for (int i = tid; i < NB6; i += kTH) s_bin6[i] = 0;
     if (tid < kHD + 2) { s_size[tid] = 0; s_nexp[tid] = 0; }
     if (tid == 0) { s_nfin = 0; s_nnext = 0; s_seq = 1; s_bail = 0; }
     __syncthreads();
+    OP(1);
     // ---- 1. histogram of the depth-6 bins + best candidate per bin
     const unsigned long long* c8 = reinterpret_cast<const unsigned long long*>(c);        // {x, y, score}: one 8-byte load
 #pragma unroll 2
@@ -449,6 +457,7 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
         }
     }
     __syncthreads();
+    OP(2);
     // ---- 2. pyramid of counts (depth 5..2 with wave shuffles: a wave owns 64 consecutive depth-5 bins = one depth-2 bin)
     //         and, per depth, the list size (non-empty bins) and the expandable nodes (bins with more than one key)
     for (int b5 = tid; b5 < NB5; b5 += kTH) {
@@ -476,6 +485,7 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
         }
     }
     __syncthreads();
+    OP(3);
     if (tid < NINI * 4) {                                // depth 1 (and depth 0 by its first child)
         int c1 = 0;
 #pragma unroll
@@ -492,6 +502,7 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
         atomicAdd(&s_size[0], c0 > 0); atomicAdd(&s_nexp[0], c0 > 1);
     }
     __syncthreads();
+    OP(4);
     if (tid == 0) {                                     // breadth-first phase (:594-673), same decisions as k_octree
         int prev = s_size[0], D = -1, tail = 0;
         for (int d = 1; d <= kHD; ++d) {
@@ -517,6 +528,7 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
         } else m = s_bin6[bin];
         return 0xFFFFu - ((m >> 8) & 0xFFFFu);
     };
+    OP(5);
     // ---- 3. nodes of the breadth-first list L_D
     {
         const int nb = NINI << (2 * D);
@@ -539,6 +551,7 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
         }
     }
     __syncthreads();
+    OP(6);
     // ---- 4. "expand the fullest nodes first" passes (:673-738)
     if (tail && !s_bail) {
         int depth_cur = D;
@@ -603,9 +616,11 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
     }
     __syncthreads();
     if (s_bail) { if (tid == 0) need_general[task] = 1; return; }
+    OP(7);
     // ---- 5. sort the final nodes into list order, emit
     const int F = s_nfin;
     rank_sort(s_fkey, s_fval, s_ka, s_va, F, s_rank);
+    OP(8);
     const int n_out = min(F, lp.out_cap);
     if (tid < n_out) {
         const dcs_candidate cc = c[s_va[tid]];
@@ -614,6 +629,10 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
         out[tid] = s;
     }
     if (tid == 0) lvl_cnt[task] = n_out;
+    OP(9);
+#ifdef DCS_OCT_PROF
+    if (blockIdx.x == DCS_OCT_PROF && threadIdx.x == 0) { g_oct_prof[10] = n; g_oct_prof[11] = F; g_oct_prof[12] = s_D; g_oct_prof[13] = s_tail; }
+#endif
 }
 
 int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const OctLevels& levels, const OctScratch& scratch,
@@ -635,3 +654,7 @@ int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const 
 }
 
 }  // namespace dcs
+
+#ifdef DCS_OCT_PROF
+extern "C" int dcs_debug_oct_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dcs::g_oct_prof), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+#endif
