@@ -1105,25 +1105,33 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
                 const uint8_t* p0 = rimg + (size_t)(y - kHalfPatch) * rv.pitch + (x - kHalfPatch - shift);
                 const uint32_t* mk = s_mask + shift * kIcTasks;
                 unsigned s_all = 0, s_u = 0;                 // sum(val), sum((u + 32) * val)
-                int row = sub / kIcCols, col = sub - row * kIcCols;      // task t = sub + 16 * round
+                const int row0 = sub / kIcCols, col0 = sub - row0 * kIcCols;      // task t = sub + 16 * round
                 // unroll 9 (two batches of 9 row loads): measured in the pipeline with 16-keypoint workgroups, 6 / 9 / 18 -> 1.868 / 1.860 / 1.882 ms per
                 // step; fully unrolled the kernel needs 121 instead of 54 VGPRs and loses next to the matcher that runs underneath it.
                 // 16-byte loads (31 rows x 3 chunks, 6 rounds, masks from a byte table at any offset): bit-exact, 485 us -- the four
                 // unaligned mask reads and weight words per chunk cost more than the 12 saved load instructions
+                // Everything that walks with the task is kept INCREMENTALLY (round 3: the phase was 120 vector instructions per keypoint,
+                // a quarter of them recomputing row * pitch + 4 col and the weight word): t + 16 = one row further and seven columns to the
+                // right, or -- from column 2 on -- two rows further and two columns back.
+                const uint8_t* pp = p0 + (size_t)row0 * rv.pitch + 4 * col0;
+                const long stepA = (long)rv.pitch + 28, stepB = 2 * (long)rv.pitch - 8;
+                int col = col0, rowm = row0 - kHalfPatch;
+                const unsigned ub0 = (unsigned)(17 - shift + 4 * col0);                        // u + 32 of byte 0 (<= 49)
+                unsigned w = (__umul24(ub0, 0x010101u) + 0x03020100u) + (ub0 << 24);          // u + 32 per byte; the steps below never carry between bytes
 #ifndef DCS_IC_UNROLL
 #define DCS_IC_UNROLL 9
 #endif
 #pragma unroll DCS_IC_UNROLL
                 for (int t = sub; t < kIcTasks; t += 16) {   // 18 rounds for every lane (padding tasks have an empty mask)
-                    const unsigned val = *reinterpret_cast<const uint32_t*>(p0 + (size_t)row * rv.pitch + 4 * col) & mk[t];
-                    const unsigned ub = (unsigned)(17 - shift + 4 * col);                        // u + 32 of byte 0 (<= 49)
-                    const unsigned w = (__umul24(ub, 0x010101u) + 0x03020100u) + (ub << 24);    // u + 32 per byte, no carries
+                    const unsigned val = *reinterpret_cast<const uint32_t*>(pp) & mk[t];
                     const unsigned rs = __builtin_amdgcn_udot4(val, 0x01010101u, 0u, false);
                     s_u = __builtin_amdgcn_udot4(val, w, s_u, false);
                     s_all += rs;
-                    m01 += (row - kHalfPatch) * (int)rs;
-                    col += 16 - kIcCols; row += 1;
-                    if (col >= kIcCols) { col -= kIcCols; row += 1; }
+                    m01 += __mul24(rowm, (int)rs);
+                    const bool wrap = col >= 2;
+                    col += wrap ? -2 : 7; rowm += wrap ? 2 : 1;
+                    pp += wrap ? stepB : stepA;
+                    w += wrap ? (0u - 0x08080808u) : 0x1C1C1C1Cu;    // every byte -8 or +28: the bytes stay in 14 .. 52, so neither step borrows / carries across bytes
                 }
                 m10 = (int)s_u - 32 * (int)s_all;
             } else {                                         // unaligned level-0 input: byte loads
