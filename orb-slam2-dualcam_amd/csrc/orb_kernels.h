@@ -45,7 +45,7 @@ struct DescribeParams {
     const uint32_t* ic_mask;             // device table built by build_ic_mask()
 };
 
-constexpr int kIcMaskWords = 4 * 288;    // 4 alignments x (31 rows x 9 dwords, padded to 288)
+constexpr int kIcMaskWords = 256;        // 32 rows (31 + one empty) x 8 dwords: byte b of dword c of row r covers u = -15 + 4 c + b, v = r - 15
 void build_ic_mask(const int* umax, uint32_t* out /* kIcMaskWords */);
 
 // per-level parameters of the device quadtree (k_octree)

@@ -935,25 +935,21 @@ constexpr int kDescKp = DCS_DESC_KP;        // keypoints per workgroup
 constexpr int kDescWaves = DCS_DESC_WAVES;  // waves per workgroup
 constexpr int kDescPerWave = kDescKp / kDescWaves;
 static_assert(kDescKp % (4 * kDescWaves) == 0 && kDescKp <= 64, "phase A works on 4 keypoints per wave at a time, phase B on one lane per keypoint");
-constexpr int kIcCols = 9;                  // aligned dwords covering x-15 .. x+15
-constexpr int kIcTasks = 288;                    // 31 x 9 = 279 dword tasks per keypoint, padded to 18 rounds of 16 lanes
+constexpr int kIcCols = 8;                  // dwords covering x-15 .. x+16, read at the keypoint's own byte alignment (the 32nd byte is masked out)
 
-// byte masks of the umax disc for the IC_Angle dword tasks: entry [shift][row * 9 + col] selects the bytes b of the
-// aligned dword at u = -15 - shift + 4 * col + b (shift = (x - 15) & 3) with |u| <= umax[|row - 15|]
+// byte masks of the umax disc for the IC_Angle dword tasks: entry [row * 8 + col] selects the bytes b of the dword at
+// u = -15 + 4 * col + b with |u| <= umax[|row - 15|]; row 31 (the partner of row 30 in the last round) is empty
 void build_ic_mask(const int* umax, uint32_t* out /* kIcMaskWords */)
 {
-    for (int shift = 0; shift < 4; ++shift)
-        for (int row = 0; row < kPatchSize; ++row)
-            for (int col = 0; col < kIcCols; ++col) {
-                uint32_t m = 0;
-                for (int bb = 0; bb < 4; ++bb) {
-                    const int u = -kHalfPatch - shift + 4 * col + bb;
-                    if (std::abs(u) <= umax[std::abs(row - kHalfPatch)]) m |= 0xffu << (8 * bb);
-                }
-                out[shift * kIcTasks + row * kIcCols + col] = m;
+    for (int row = 0; row < 32; ++row)
+        for (int col = 0; col < kIcCols; ++col) {
+            uint32_t m = 0;
+            for (int bb = 0; bb < 4; ++bb) {
+                const int u = -kHalfPatch + 4 * col + bb;
+                if (row < kPatchSize && std::abs(u) <= umax[std::abs(row - kHalfPatch)]) m |= 0xffu << (8 * bb);
             }
-    for (int shift = 0; shift < 4; ++shift)
-        for (int t = kPatchSize * kIcCols; t < kIcTasks; ++t) out[shift * kIcTasks + t] = 0;     // padding tasks contribute nothing
+            out[row * kIcCols + col] = m;
+        }
 }
 
 // cosf / sinf of the keypoint angle, bit for bit what glibc (>= 2.28, sysdeps/ieee754/flt-32/s_sincosf.h) returns for
@@ -1100,49 +1096,33 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
             const LevelView rv = raw.lv[k.level];
             const uint8_t* rimg = rv.base + (size_t)img * rv.img_stride;
             int m10 = 0, m01 = 0;
-            if (((reinterpret_cast<uintptr_t>(rimg) | (uintptr_t)rv.pitch) & 3) == 0) {
-                const int shift = (x - kHalfPatch) & 3;
-                const uint8_t* p0 = rimg + (size_t)(y - kHalfPatch) * rv.pitch + (x - kHalfPatch - shift);
-                const uint32_t* mk = s_mask + shift * kIcTasks;
+            {
+                // Round 3: the 31 x 31 disc is read as 8 dwords per row AT THE KEYPOINT'S OWN BYTE ALIGNMENT (global loads need none; the
+                // level may even be a caller-owned, unaligned level 0): a 16-lane group is two rows x eight dwords, so a lane keeps its
+                // column -- its weight word (u + 32 per byte) is a constant, its mask a fixed stride through the table, its pointer two
+                // rows further every round; 16 rounds of 8 vector instructions. (Until then: aligned dwords, 9 per row, 18 rounds of 16
+                // with the column / row / weight bookkeeping of a 9-column walk on 16 lanes, and a byte-load path for unaligned input:
+                // 120 vector instructions per keypoint in this phase.)
+                const int r2 = sub >> 3, col = sub & 7;
+                const uint8_t* pp = rimg + (size_t)(y - kHalfPatch + r2) * rv.pitch + (x - kHalfPatch + 4 * col);
+                const long step = 2 * (long)rv.pitch;
+                const unsigned ub = (unsigned)(17 + 4 * col);                                  // u + 32 of byte 0
+                const unsigned w = (__umul24(ub, 0x010101u) + 0x03020100u) + (ub << 24);      // u + 32 per byte, no carries
+                const uint32_t* mk = s_mask + sub;                                             // entry (2 j + r2) * 8 + col = sub + 16 j
                 unsigned s_all = 0, s_u = 0;                 // sum(val), sum((u + 32) * val)
-                const int row0 = sub / kIcCols, col0 = sub - row0 * kIcCols;      // task t = sub + 16 * round
-                // unroll 9 (two batches of 9 row loads): measured in the pipeline with 16-keypoint workgroups, 6 / 9 / 18 -> 1.868 / 1.860 / 1.882 ms per
-                // step; fully unrolled the kernel needs 121 instead of 54 VGPRs and loses next to the matcher that runs underneath it.
-                // 16-byte loads (31 rows x 3 chunks, 6 rounds, masks from a byte table at any offset): bit-exact, 485 us -- the four
-                // unaligned mask reads and weight words per chunk cost more than the 12 saved load instructions
-                // Everything that walks with the task is kept INCREMENTALLY (round 3: the phase was 120 vector instructions per keypoint,
-                // a quarter of them recomputing row * pitch + 4 col and the weight word): t + 16 = one row further and seven columns to the
-                // right, or -- from column 2 on -- two rows further and two columns back.
-                const uint8_t* pp = p0 + (size_t)row0 * rv.pitch + 4 * col0;
-                const long stepA = (long)rv.pitch + 28, stepB = 2 * (long)rv.pitch - 8;
-                int col = col0, rowm = row0 - kHalfPatch;
-                const unsigned ub0 = (unsigned)(17 - shift + 4 * col0);                        // u + 32 of byte 0 (<= 49)
-                unsigned w = (__umul24(ub0, 0x010101u) + 0x03020100u) + (ub0 << 24);          // u + 32 per byte; the steps below never carry between bytes
-#ifndef DCS_IC_UNROLL
-#define DCS_IC_UNROLL 9
-#endif
-#pragma unroll DCS_IC_UNROLL
-                for (int t = sub; t < kIcTasks; t += 16) {   // 18 rounds for every lane (padding tasks have an empty mask)
-                    const unsigned val = *reinterpret_cast<const uint32_t*>(pp) & mk[t];
+                int rowm = r2 - kHalfPatch;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {               // row 31 (j = 15, r2 = 1) lies inside the image (y + 16 <= h - 4) and has an empty mask
+                    unsigned val;
+                    __builtin_memcpy(&val, pp, 4);
+                    val &= mk[16 * j];
                     const unsigned rs = __builtin_amdgcn_udot4(val, 0x01010101u, 0u, false);
                     s_u = __builtin_amdgcn_udot4(val, w, s_u, false);
                     s_all += rs;
                     m01 += __mul24(rowm, (int)rs);
-                    const bool wrap = col >= 2;
-                    col += wrap ? -2 : 7; rowm += wrap ? 2 : 1;
-                    pp += wrap ? stepB : stepA;
-                    w += wrap ? (0u - 0x08080808u) : 0x1C1C1C1Cu;    // every byte -8 or +28: the bytes stay in 14 .. 52, so neither step borrows / carries across bytes
+                    pp += step; rowm += 2;
                 }
                 m10 = (int)s_u - 32 * (int)s_all;
-            } else {                                         // unaligned level-0 input: byte loads
-                const uint8_t* rc = rimg + (size_t)y * rv.pitch + x;
-                for (int idx = sub; idx < kPatchSize * kPatchSize; idx += 16) {
-                    const int v = idx / kPatchSize - kHalfPatch, u = idx % kPatchSize - kHalfPatch;
-                    if (abs(u) <= (int)((prm.umax_packed >> (4 * abs(v))) & 15ull)) {
-                        const int val = rc[v * rv.pitch + u];
-                        m10 += u * val; m01 += v * val;
-                    }
-                }
             }
 #pragma unroll
             for (int d = 8; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
