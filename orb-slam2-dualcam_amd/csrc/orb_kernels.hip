@@ -1222,9 +1222,13 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         // they stand for are rewritten by the reflection fix-up)
         const int col = min(max(xs + 16 * c4, 0), (rv.w - 1) & ~15);
         const uint8_t* src = rimg + col;
-        q0 = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(k.y - kRawR + r_lane, rv.h) * rv.pitch);
-        q1 = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(k.y - kRawR + r_lane + 16, rv.h) * rv.pitch);
-        q2 = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(k.y - kRawR + min(r_lane + 32, kRawRows - 1), rv.h) * rv.pitch);
+        // rows: reflected only when the neighbourhood crosses the level's top / bottom (y within two rows of the 19-px border) -- a
+        // wave-uniform test instead of three reflections per lane
+        int ra = k.y - kRawR + r_lane, rb = ra + 16, rc = k.y - kRawR + min(r_lane + 32, kRawRows - 1);
+        if (k.y - kRawR < 0 || k.y + kRawR >= rv.h) { ra = reflect101(ra, rv.h); rb = reflect101(rb, rv.h); rc = reflect101(rc, rv.h); }
+        q0 = *reinterpret_cast<const uint4*>(src + (size_t)ra * rv.pitch);
+        q1 = *reinterpret_cast<const uint4*>(src + (size_t)rb * rv.pitch);
+        q2 = *reinterpret_cast<const uint4*>(src + (size_t)rc * rv.pitch);
     };
     if (wave * kDescPerWave < n_here) fetch(wave * kDescPerWave);
     // u8 -> i8: x ^ 0x80 = x - 128, and sum_k tap[k] * 128 = 257 * 128 = 32896 comes back through the accumulator's initial value
