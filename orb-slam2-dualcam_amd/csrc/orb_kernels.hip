@@ -36,6 +36,13 @@ int upload_pattern() { return DCS_OK; }   // statically initialised __constant__
 #define DCS_RS_ROWS 16
 #endif
 constexpr int kRsRowsPerThread = DCS_RS_ROWS;
+#ifndef DCS_RS_UPFRONT                       // tuning hook: request every source row of an interior strip before the first is used
+#define DCS_RS_UPFRONT 1
+#endif
+#ifndef DCS_RS_SRCMAX
+#define DCS_RS_SRCMAX 22
+#endif
+constexpr int kRsSrcMax = DCS_RS_SRCMAX;     // source rows of a strip held in registers (16 rows at scale <= 1.25: 21)
 
 struct ResizeCol { int16_t sx, pad, a0, a1; };
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
@@ -139,6 +146,39 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
     const uint8_t* colbase = S + base;
     uint8_t* out = D + (size_t)dy0 * dst.pitch + dx0;                         // pitch is a multiple of 64: the dword stays in the row
     const int sy_first = sy_of[0], sy_last = sy_of[kRsRowsPerThread - 1];
+#if DCS_RS_UPFRONT
+    if (dy0 + kRsRowsPerThread <= dst.h && sy_first >= 0 && sy_last + 1 <= src.h - 1 && sy_last + 2 - sy_first <= kRsSrcMax) {
+        // interior strip whose source rows fit the register window (every strip at scale <= 1.25): ALL of them are requested before the
+        // first one is used -- the one-row look-ahead of the walk below keeps two loads in flight per wave, and with eight waves per SIMD
+        // that is what bounded the kernel (Little: 8 x 2 x 768 B per ~1 us and SIMD = ~3 TB/s of requested bytes). The rows are consumed
+        // in order (compile-time register names); the destination row that sits on source rows (j, j + 1) is emitted when j comes by --
+        // its table entries fetched with v_readlane at the run-time row counter.
+        ResizeRaw raw[kRsSrcMax];
+#pragma unroll
+        for (int j = 0; j < kRsSrcMax; ++j) raw[j] = resize_load(colbase + (size_t)min(sy_first + j, src.h - 1) * src.pitch, aligned);
+        unsigned hP[4], hC[4];
+        resize_hpass(raw[0], t, hP);
+        int k = 0, sy_k = sy_first;
+        unsigned a_k = a_of[0];
+        uint8_t* o = out;
+#pragma unroll
+        for (int j = 0; j + 1 < kRsSrcMax; ++j) {
+            resize_hpass(raw[j + 1], t, hC);
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                if (k < kRsRowsPerThread && sy_k == sy_first + j) {          // wave-uniform
+                    resize_emit(o, hP, hC, a_k & 0xffffu, a_k >> 16);
+                    o += dst.pitch; ++k;
+                    sy_k = __builtin_amdgcn_readlane(my_sy, k & (kRsRowsPerThread - 1));
+                    a_k = (unsigned)__builtin_amdgcn_readlane((int)my_a, k & (kRsRowsPerThread - 1));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hP[c] = hC[c];
+        }
+        return;
+    }
+#endif
     if (dy0 + kRsRowsPerThread <= dst.h && sy_first >= 0 && sy_last + 1 <= src.h - 1) {
         // interior strip (no clamped source row): walk the source rows once. hP / hC = horizontal passes of rows p, p + 1; the
         // raw bytes of row p + 2 are already in flight while the current destination row is produced. A destination row
