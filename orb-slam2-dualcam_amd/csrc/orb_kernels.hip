@@ -147,12 +147,16 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
     uint8_t* out = D + (size_t)dy0 * dst.pitch + dx0;                         // pitch is a multiple of 64: the dword stays in the row
     const int sy_first = sy_of[0], sy_last = sy_of[kRsRowsPerThread - 1];
 #if DCS_RS_UPFRONT
-    if (dy0 + kRsRowsPerThread <= dst.h && sy_first >= 0 && sy_last + 1 <= src.h - 1 && sy_last + 2 - sy_first <= kRsSrcMax) {
-        // interior strip whose source rows fit the register window (every strip at scale <= 1.25): ALL of them are requested before the
+    if (sy_first >= 0 && sy_last + 2 - sy_first <= kRsSrcMax) {
+        // strip whose source rows fit the register window (every strip at scale <= 1.25): ALL of them are requested before the
         // first one is used -- the one-row look-ahead of the walk below keeps two loads in flight per wave, and with eight waves per SIMD
         // that is what bounded the kernel (Little: 8 x 2 x 768 B per ~1 us and SIMD = ~3 TB/s of requested bytes). The rows are consumed
         // in order (compile-time register names); the destination row that sits on source rows (j, j + 1) is emitted when j comes by --
-        // its table entries fetched with v_readlane at the run-time row counter.
+        // its table entries fetched with v_readlane at the run-time row counter. The partial last strip of a level (its table entries
+        // beyond the last row repeat that row's and are not emitted) and a strip that ends on the clamped last source row (the loads clamp the
+        // row index: row j + 1 then IS row j) take this path too: the row-at-a-time loop below, one dependent load per destination row, made
+        // the last workgroups of every launch its tail.
+        const int n_rows = min(kRsRowsPerThread, dst.h - dy0);
         ResizeRaw raw[kRsSrcMax];
 #pragma unroll
         for (int j = 0; j < kRsSrcMax; ++j) raw[j] = resize_load(colbase + (size_t)min(sy_first + j, src.h - 1) * src.pitch, aligned);
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
             resize_hpass(raw[j + 1], t, hC);
 #pragma unroll
             for (int rep = 0; rep < 2; ++rep) {
-                if (k < kRsRowsPerThread && sy_k == sy_first + j) {          // wave-uniform
+                if (k < n_rows && sy_k == sy_first + j) {                    // wave-uniform
                     resize_emit(o, hP, hC, a_k & 0xffffu, a_k >> 16);
                     o += dst.pitch; ++k;
                     sy_k = __builtin_amdgcn_readlane(my_sy, k & (kRsRowsPerThread - 1));
