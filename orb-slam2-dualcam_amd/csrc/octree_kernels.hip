@@ -406,8 +406,13 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
     __shared__ int s_inc[kCapH], s_rank[kCapH];
     __shared__ int s_size[kHD + 2], s_nexp[kHD + 2], s_w[kTH / 64];
     __shared__ int s_D, s_tail, s_cursize, s_nfin, s_nnext, s_rstar, s_seq, s_bail;
-    const int task = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int l = task % P.nlevels, img = task / P.nlevels;
+    // Workgroup ids are dealt round-robin to the 8 XCDs: with task = blockIdx and 8 levels, XCD k would run ALL tasks of level k -- a third
+    // of the kernel's work (level 0) on an eighth of the chip. Level-major order instead: a level's tasks spread over the XCDs by image, and
+    // the long tasks (level 0: most candidates, largest quota) start first while the short ones fill in behind them.
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_img = (int)gridDim.x / P.nlevels;
+    const int l = (int)blockIdx.x / n_img, img = (int)blockIdx.x - l * n_img;
+    const int task = img * P.nlevels + l;
     const OctLevel lp = P.lv[l];
     const int b0 = lvl_off[task], n = min(lvl_off[task + 1], dense_cap) - b0;
     SelKp* out = sel + (size_t)img * P.out_per_image + lp.out_base;
