@@ -338,6 +338,12 @@ __global__ __launch_bounds__(kT) void k_octree(const dcs_candidate* __restrict__
 // keys, counted by all threads in parallel; keys are distinct) instead of a bitonic network.
 // Valid while everything the reference touches lies within 6 levels (true for the usual quotas); otherwise the task is
 // flagged and the general sort-based kernel k_octree redoes it. Output is identical by construction and by test.
+#ifdef DCS_OCT_PROF_ALL                       // schedule of every task (scratch/oct_sched.py): start / end on the 100 MHz wall clock, HW_ID, XCC_ID
+__device__ long long g_oct_all[4 * 8192];
+#define OPA(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_oct_all[4 * blockIdx.x + (k)] = (v); } while (0)
+#else
+#define OPA(k, v) do { } while (0)
+#endif
 #ifdef DCS_OCT_PROF                           // phase timestamps of one task (scratch: -DDCS_OCT_PROF side build + dcs_debug_oct_prof)
 __device__ long long g_oct_prof[64];
 #define OP(k) do { if (blockIdx.x == DCS_OCT_PROF && threadIdx.x == 0) g_oct_prof[k] = clock64(); } while (0)
@@ -413,6 +419,7 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
     const int n_img = (int)gridDim.x / P.nlevels;
     const int l = (int)blockIdx.x / n_img, img = (int)blockIdx.x - l * n_img;
     const int task = img * P.nlevels + l;
+    OPA(0, (long long)wall_clock64()); OPA(2, (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))); OPA(3, (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)));
     const OctLevel lp = P.lv[l];
     const int b0 = lvl_off[task], n = min(lvl_off[task + 1], dense_cap) - b0;
     SelKp* out = sel + (size_t)img * P.out_per_image + lp.out_base;
@@ -635,6 +642,7 @@ __global__ __launch_bounds__(kTH, NINI == 1 ? 8 : 4) void k_octree_hist(const dc
     }
     if (tid == 0) lvl_cnt[task] = n_out;
     OP(9);
+    OPA(1, (long long)wall_clock64());
 #ifdef DCS_OCT_PROF
     if (blockIdx.x == DCS_OCT_PROF && threadIdx.x == 0) { g_oct_prof[10] = n; g_oct_prof[11] = F; g_oct_prof[12] = s_D; g_oct_prof[13] = s_tail; }
 #endif
@@ -660,6 +668,9 @@ int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const 
 
 }  // namespace dcs
 
+#ifdef DCS_OCT_PROF_ALL
+extern "C" int dcs_debug_oct_all(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dcs::g_oct_all), sizeof(long long) * 4 * 8192) == hipSuccess ? 0 : -1; }
+#endif
 #ifdef DCS_OCT_PROF
 extern "C" int dcs_debug_oct_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dcs::g_oct_prof), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
 #endif
