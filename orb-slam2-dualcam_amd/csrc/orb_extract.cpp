@@ -393,25 +393,52 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
                                     d_cell_count.p, max_rw, max_rh, stream, cells_early, n_cells - cells_early))) return rc;
     } else {
-        // One launch per LDS size class: a cell's workgroup (one wave) holds its ROI, score map and survivor list in LDS, sized for the
+        // Launches by LDS footprint: a cell's workgroup (one wave) holds its ROI, score map and survivor list in LDS, sized for the
         // largest ROI of the LAUNCH, and that footprint decides how many cells a CU holds -- 5 104 B for the 38 x 38 ROIs of levels 0-3 of
-        // the 640 x 480 pyramid = 32 waves per CU, 5.5 KB for levels 4-6 = 29, 6.6 KB for the 43-wide cells of level 7 = 24. One launch
-        // sized for level 7's twelve cells held every level at 24 (DCS_ORB_FAST_GROUPS=0 restores it).
+        // the 640 x 480 pyramid = 32 waves per CU, 5.2-5.4 KB for levels 4 / 5 / 6 = 30 / 30 / 31, 6.6 KB for the 43-wide cells of level 7
+        // = 24. One launch sized for level 7's twelve cells held every level at 24 (DCS_ORB_FAST_GROUPS=0 restores it: 603 us per 512
+        // images); one launch per footprint class (five) ran in 547 us, but three of them were 1.5-3.6 rounds of the chip long and paid
+        // ramp, tail and launch gap for that. The partition of the levels into consecutive groups is now chosen by cost: a group costs
+        // its cells / (waves the chip holds at the group's footprint), each level's share raised by TWICE its relative loss of occupancy
+        // against a launch of its own (a level running below its own occupancy loses more than the proportion: [0-4] at 30 per CU
+        // measured 558 us), plus a fixed 1.3 rounds per launch. Headline pyramid: [0-3] 32, [4-6] 29, [7] 24 = 525 us.
         // Small batches are latency-bound -- one launch there: 16 images of 1280 x 720 (config C5's step) run at 89 k kfeatures/s with
         // one launch against 80 k with three.
         static const bool grouped_env = !(getenv("DCS_ORB_FAST_GROUPS") && atoi(getenv("DCS_ORB_FAST_GROUPS")) == 0);
         const bool grouped = grouped_env && n_images >= 64;
         auto wg_per_cu = [](int rw, int rh) { return std::min(32, 163840 / std::max(fast_cells_lds_bytes(rw, rh), 1)); };
-        int l0 = 0;
-        while (l0 < L) {
-            int grw = 7, grh = 7, l1 = l0;
-            for (; l1 < L; ++l1) {
-                int lrw = 7, lrh = 7;
-                for (int c = h_level_cell_begin[l1]; c < h_level_cell_begin[l1 + 1]; ++c) { lrw = std::max(lrw, (int)h_cells[c].rw); lrh = std::max(lrh, (int)h_cells[c].rh); }
-                const int mrw = std::max(grw, lrw), mrh = std::max(grh, lrh);
-                if (grouped && l1 > l0 && !(wg_per_cu(lrw, lrh) == wg_per_cu(grw, grh) && wg_per_cu(mrw, mrh) == wg_per_cu(grw, grh))) break;
-                grw = mrw; grh = mrh;
+        int lrw[kMaxLevels], lrh[kMaxLevels], start_of[kMaxLevels + 1];
+        for (int l = 0; l < L; ++l) {
+            lrw[l] = 7; lrh[l] = 7;
+            for (int c = h_level_cell_begin[l]; c < h_level_cell_begin[l + 1]; ++c) { lrw[l] = std::max(lrw[l], (int)h_cells[c].rw); lrh[l] = std::max(lrh[l], (int)h_cells[c].rh); }
+        }
+        if (!grouped) { for (int i = 0; i <= L; ++i) start_of[i] = 0; }
+        else {
+            double best[kMaxLevels + 1];
+            best[0] = 0;
+            for (int i = 1; i <= L; ++i) {                   // best[i] = cheapest partition of levels [0, i); the last group is [start_of[i], i)
+                best[i] = 1e300; start_of[i] = 0;
+                int grw = 7, grh = 7;
+                for (int j = i - 1; j >= 0; --j) {
+                    grw = std::max(grw, lrw[j]); grh = std::max(grh, lrh[j]);
+                    const double occ = wg_per_cu(grw, grh);
+                    double cost = 1.3;
+                    for (int l = j; l < i; ++l) {
+                        const double own = wg_per_cu(lrw[l], lrh[l]);
+                        const double rounds = (double)(h_level_cell_begin[l + 1] - h_level_cell_begin[l]) * n_images / (256.0 * occ);
+                        cost += rounds * (1.0 + 2.0 * (own - occ) / own);
+                    }
+                    if (best[j] + cost < best[i]) { best[i] = best[j] + cost; start_of[i] = j; }
+                }
             }
+        }
+        int bounds[kMaxLevels + 1], nb = 0;                  // group boundaries, last to first
+        for (int i = L; i > 0; i = start_of[i]) bounds[nb++] = i;
+        int l0 = 0;
+        for (int k = nb - 1; k >= 0; --k) {
+            const int l1 = bounds[k];
+            int grw = 7, grh = 7;
+            for (int l = l0; l < l1; ++l) { grw = std::max(grw, lrw[l]); grh = std::max(grh, lrh[l]); }
             const int c0 = h_level_cell_begin[l0], c1 = h_level_cell_begin[l1];
             if (c1 > c0 && (rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
                                                    d_cell_count.p, grw, grh, stream, c0, c1 - c0))) return rc;
