@@ -37,6 +37,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 I8_MFMA_PEAK_TOPS = 3944.0       # MI355X_MICROARCH.md: v_mfma_i32_16x16x64_i8 dense, measured ceiling
+FP4_MFMA_PEAK_TOPS = 7228.0      # cdna_hip_programming.md: v_mfma_scale_f32_16x16x128_f8f6f4 with FP4 operands, measured floor of the 16x16 shape (spec ~10 PF dense)
 F64_MFMA_PEAK_GFLOPS = 78600.0   # AMD's public MI355X figure for FP64 matrix (= FP64 vector); the in-container guide has no f64 row
 N_CU = 256
 
@@ -569,12 +570,16 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / reps
         nn = pipe.last_slots()[2].cpu().numpy().astype(np.int64)
         dist_count = int(sum(nn[a] * nn[b] for a, b in pipe.pairs))
-        tops = dist_count * 512 / us / 1e6            # 256 multiply-accumulates per Hamming distance on the i8 matrix cores
-        out["matcher"] = {"kernel": "k_knn2_pairs_mfma + k_filter_pairs", "solo_us_per_step": round(us, 2), "pairs": n_pairs,
-                          "distances": dist_count, "achieved": round(tops, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOPS (i8 MFMA)",
-                          "frac": round(tops / I8_MFMA_PEAK_TOPS, 4), "gdistances_s": round(dist_count / us / 1e3, 1),
-                          "algo_bytes": int((32 * 2 * n_avg + 12 * n_avg) * n_pairs)}
-        out["kernels"]["k_knn2_pairs_mfma+k_filter_pairs"] = dict(us=round(us, 2), note="solo; inside a step it runs underneath the next extraction (stage_us_per_step.match_us is that window)")
+        tops = dist_count * 512 / us / 1e6            # 256 multiply-accumulates per Hamming distance on the matrix cores
+        # which form the library launches (match_kernels.hip, launch_knn2_pairs_mfma): FP4 block-scaled when the slot fits its 14-bit index field
+        fp4 = cap <= 16383 and os.environ.get("DCS_KNN2_I8", "0") in ("", "0")
+        kname, peak, unit = ("k_knn2_pairs_fp4", FP4_MFMA_PEAK_TOPS, "TOPS (FP4 block-scaled MFMA 16x16x128)") if fp4 else ("k_knn2_pairs_mfma", I8_MFMA_PEAK_TOPS, "TOPS (i8 MFMA)")
+        out["matcher"] = {"kernel": kname + " + k_filter_pairs", "solo_us_per_step": round(us, 2), "pairs": n_pairs,
+                          "distances": dist_count, "achieved": round(tops, 1), "peak": peak, "unit": unit,
+                          "frac": round(tops / peak, 4), "gdistances_s": round(dist_count / us / 1e3, 1),
+                          "algo_bytes": int((32 * 2 * n_avg + 12 * n_avg) * n_pairs),
+                          "note": "not bound by the matrix pipe: ranking the keys, re-expanding the train tiles and the matrix instructions each cost about a third (DESIGN.md section 4)"}
+        out["kernels"][kname + "+k_filter_pairs"] = dict(us=round(us, 2), note="solo; inside a step it runs underneath the next extraction (stage_us_per_step.match_us is that window)")
 
     # ---- host-buffer API (what the reference's seams hand over): one dual frame per call (latency), the whole batch (throughput)
     if solo and not args.no_host_api:

@@ -298,6 +298,163 @@ __device__ __forceinline__ void knn2_tile_mfma(const uint8_t* __restrict__ q, in
     }
 }
 
+// ---- the same knn2 on the block-scaled FP4 matrix instruction (gfx950) --------------------------------------------------------
+// v_mfma_scale_f32_16x16x128_f8f6f4 with E2M1 operands is an exact AND-popcount engine that also FINISHES the key
+// (scratch/probe/fp4_probe.hip pins the operand maps and the exactness): a train bit enters as the nibble 0x2 (+1.0), a query bit as
+// 0xC (-2.0), the A scale is 2^14, and the accumulator starts from the train row's key base (popcount(t) + 512) * 2^14 + index as a
+// float -- so D = key base - 2 <q, t> * 2^14 = the finished key (< 2^24: exact in f32; positive floats order like integers). Against
+// the i8 form: TWO instructions of K = 128 per 16 x 16 block of distances instead of four of K = 64 at about the same issue time each,
+// no v_lshl_add per distance (2 vector instructions per distance: v_med3_f32 + v_min_f32), 128 instead of 256 operand bytes per
+// descriptor in LDS (36 KB per workgroup instead of 70). The index field has 14 bits: problems of more than 16 383 descriptors per slot
+// keep the i8 kernel.
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+constexpr int kIdxBits = 14;
+constexpr int kMRow4 = 144;                    // bytes per expanded descriptor in LDS (128 + 16 padding: rows 36 banks apart)
+constexpr int kFp4MaxCap = (1 << kIdxBits) - 1;
+
+__device__ __forceinline__ unsigned spread8n(unsigned b)       // 8 bits -> 8 nibbles of 0 / 1 (bit i -> nibble i); b < 256
+{
+    unsigned x = (b | (b << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    return (x | (x << 3)) & 0x11111111u;
+}
+template <bool QUERY>
+__device__ __forceinline__ v4i_t expand32_fp4(unsigned w)       // 32 bits -> 32 E2M1 nibbles: +1.0 (train) or -2.0 (query) per set bit
+{
+    v4i_t v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned x = spread8n((w >> (8 * j)) & 0xFFu);
+        v[j] = (int)(QUERY ? (x << 2) | (x << 3) : x << 1);
+    }
+    return v;
+}
+
+template <int QG, int WAVES>
+__device__ __forceinline__ void knn2_tile_fp4(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt, int q_tile,
+                                              int32_t* __restrict__ best_idx, int32_t* __restrict__ best_d, int32_t* __restrict__ second_d)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[2][kMTile * kMRow4];    // double-buffered: one barrier per tile
+    __shared__ __attribute__((aligned(16))) float s_pb[2][kMTile];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    constexpr int kParts = WAVES / 2;              // threads per train descriptor in the expansion (64 WAVES / 128)
+    const int qbase = (q_tile * WAVES + wave) * (16 * QG);
+    // B fragments + popcounts of this lane's queries: K-slice sl of lane group g = dword 4 sl + g of the descriptor (A uses the same rule)
+    v8i_t bf[QG][2];
+    int pa[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        const int qi = qbase + 16 * qg + c;
+        uint4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (qi < nq) { const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 32); lo = qp[0]; hi = qp[1]; }
+        pa[qg] = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
+        const unsigned w0 = g == 0 ? lo.x : g == 1 ? lo.y : g == 2 ? lo.z : lo.w, w1 = g == 0 ? hi.x : g == 1 ? hi.y : g == 2 ? hi.z : hi.w;
+        const v4i_t e0 = expand32_fp4<true>(w0), e1 = expand32_fp4<true>(w1);
+        bf[qg][0] = v8i_t{e0.x, e0.y, e0.z, e0.w, 0, 0, 0, 0};
+        bf[qg][1] = v8i_t{e1.x, e1.y, e1.z, e1.w, 0, 0, 0, 0};
+    }
+    // keys as floats, WITHOUT the query's own popcount (a constant per lane and query group that cannot change the order)
+    constexpr float kInit = 16777215.0f;           // (1023 << 14) | 16383: index >= nt for every problem this kernel takes
+    float k1[QG], k2[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) { k1[qg] = kInit; k2[qg] = kInit; }
+    auto expand_tile = [&](int t0, int buf) {
+        constexpr int kDw = 8 / kParts;
+        const int d = tid / kParts, part = tid % kParts, ti = t0 + d;
+        unsigned w[kDw];
+#pragma unroll
+        for (int k = 0; k < kDw; ++k) w[k] = 0;
+        if (ti < nt) {
+            const unsigned* src = reinterpret_cast<const unsigned*>(t + (size_t)ti * 32) + part * kDw;
+#pragma unroll
+            for (int k = 0; k < kDw; ++k) w[k] = src[k];
+        }
+        uint8_t* row = s_t[buf] + d * kMRow4 + part * (16 * kDw);
+        int pc = 0;
+#pragma unroll
+        for (int k = 0; k < kDw; ++k) {                        // dword k -> 16 operand bytes
+            *reinterpret_cast<v4i_t*>(row + 16 * k) = expand32_fp4<false>(w[k]);
+            pc += __popc(w[k]);
+        }
+#pragma unroll
+        for (int sh = 1; sh < kParts; sh <<= 1) pc += __shfl_xor(pc, sh);
+        // everything of the key that does not depend on the query (padding rows: largest distance, index >= nt)
+        if (part == 0) s_pb[buf][d] = (float)((((ti < nt ? pc + 512 : 0x3FF) << kIdxBits) | ti));
+    };
+    constexpr int kScaleA = 127 + kIdxBits, kScaleB = 127;      // E8M0 scales 2^14 and 2^0 (byte 0 of the scale operands: op_sel 0)
+    expand_tile(0, 0);
+    __syncthreads();
+    for (int t0 = 0, buf = 0; t0 < nt; t0 += kMTile, buf ^= 1) {
+#if !defined(DCS_KNN4_SKIP) || DCS_KNN4_SKIP != 1                  // timing-only side builds (wrong results): 1 = tiles are not re-expanded, 2 = no key ranking, 3 = no matrix instructions
+        if (t0 + kMTile < nt) expand_tile(t0 + kMTile, buf ^ 1);   // next tile: its VALU / LDS work overlaps this tile's MFMAs
+#endif
+        const int n_grp = (min(kMTile, nt - t0) + 15) >> 4;
+        v8i_t af[2];
+        v4f_t pbA, pbB;
+        auto load_group = [&](int tg, v4f_t& pb) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const v4i_t a = *reinterpret_cast<const v4i_t*>(s_t[buf] + (16 * tg + c) * kMRow4 + 16 * (4 * sl + g));
+                af[sl] = v8i_t{a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+            }
+            pb = *reinterpret_cast<const v4f_t*>(&s_pb[buf][16 * tg + 4 * g]);               // key bases of train rows 4 g + r
+        };
+        auto group = [&](int tg, const v4f_t& pb_now, v4f_t& pb_next) {
+            v4f_t acc[QG];
+#if defined(DCS_KNN4_SKIP) && DCS_KNN4_SKIP == 3
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) acc[qg] = pb_now + v4f_t{(float)af[0][qg], (float)af[1][qg], (float)bf[qg][0][0], (float)bf[qg][1][1]};
+#else
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[0], bf[qg][0], pb_now, 4, 4, 0, kScaleA, 0, kScaleB);
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[1], bf[qg][1], acc[qg], 4, 4, 0, kScaleA, 0, kScaleB);
+#endif
+            if (tg + 1 < n_grp) load_group(tg + 1, pb_next);     // next group's operands fly while this group's keys are ranked
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float key = acc[qg][r];
+#if defined(DCS_KNN4_SKIP) && DCS_KNN4_SKIP == 2
+                    if (r == 0) k1[qg] = fminf(k1[qg], (acc[qg][0] + acc[qg][1]) + (acc[qg][2] + acc[qg][3]));
+#else
+                    k2[qg] = __builtin_amdgcn_fmed3f(k1[qg], k2[qg], key); k1[qg] = fminf(k1[qg], key);
+#endif
+                }
+            }
+        };
+        load_group(0, pbA);
+        for (int tg = 0; tg < n_grp; tg += 2) {
+            group(tg, pbA, pbB);
+            if (tg + 1 < n_grp) group(tg + 1, pbB, pbA);
+        }
+        __syncthreads();
+    }
+    // the 4 lanes (g = 0..3) of a query hold disjoint train rows: two smallest of the union
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        float a1 = k1[qg], a2 = k2[qg];
+#pragma unroll
+        for (int d = 16; d <= 32; d <<= 1) {
+            const float o1 = __shfl_xor(a1, d), o2 = __shfl_xor(a2, d);
+            a2 = fminf(fminf(a2, o2), fmaxf(a1, o1));
+            a1 = fminf(a1, o1);
+        }
+        const int qi = qbase + 16 * qg + c;
+        if (g == 0 && qi < nq) {
+            // un-bias: distance = key_distance - 512 + popcount(q); a key that never met a real train row keeps index >= nt
+            const int u1 = (int)a1, u2 = (int)a2;
+            const int i1 = u1 & ((1 << kIdxBits) - 1), i2 = u2 & ((1 << kIdxBits) - 1);
+            const int d1 = i1 < nt ? (u1 >> kIdxBits) - 512 + pa[qg] : 256, d2 = i2 < nt ? (u2 >> kIdxBits) - 512 + pa[qg] : 256;
+            best_idx[qi] = d1 >= 256 ? -1 : i1;
+            best_d[qi] = min(d1, 256); second_d[qi] = min(d2, 256);
+        }
+    }
+}
+
 #ifndef DCS_KNN_QG                 // tuning hooks (scratch/ab builds): query groups of 16 per wave, waves per workgroup
 #define DCS_KNN_QG 2
 #endif
@@ -314,6 +471,33 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2_pairs_mfma(const uint8_
     if ((int)blockIdx.x * kKnnQ >= nq) return;
     knn2_tile_mfma<kKnnQG, kKnnWaves>(desc + (size_t)qs * cap * 32, nq, desc + (size_t)ts * cap * 32, nt, blockIdx.x,
                    best_idx + (size_t)p * cap, best_d + (size_t)p * cap, second_d + (size_t)p * cap);
+}
+
+#ifndef DCS_KNN4_QG
+#define DCS_KNN4_QG 2
+#endif
+constexpr int kKnn4QG = DCS_KNN4_QG, kKnn4Q = 16 * kKnn4QG * kKnnWaves;
+__global__ __launch_bounds__(64 * kKnnWaves) void k_knn2_pairs_fp4(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_feat, int cap,
+                                                        const int32_t* __restrict__ pairs, int32_t* best_idx, int32_t* best_d, int32_t* second_d)
+{
+    const int p = blockIdx.y;
+    const int qs = pairs[2 * p], ts = pairs[2 * p + 1];
+    const int nq = min(n_feat[qs], cap), nt = min(n_feat[ts], cap);
+    if ((int)blockIdx.x * kKnn4Q >= nq) return;
+    knn2_tile_fp4<kKnn4QG, kKnnWaves>(desc + (size_t)qs * cap * 32, nq, desc + (size_t)ts * cap * 32, nt, blockIdx.x,
+                  best_idx + (size_t)p * cap, best_d + (size_t)p * cap, second_d + (size_t)p * cap);
+}
+
+// the matrix-core knn2 of n_pairs (query slot, train slot) problems: FP4 form when the 14-bit index field holds the slot, i8 form otherwise
+// (DCS_KNN2_I8=1 forces the i8 form: the A/B and test hook)
+static void launch_knn2_pairs_mfma(const uint8_t* desc, const int32_t* n_feat, int cap, const int32_t* pairs, int n_pairs, int32_t* best_idx,
+                                   int32_t* best_d, int32_t* second_d, hipStream_t s)
+{
+    static const bool force_i8 = getenv("DCS_KNN2_I8") && atoi(getenv("DCS_KNN2_I8")) != 0;
+    if (cap <= kFp4MaxCap && !force_i8)
+        hipLaunchKernelGGL(k_knn2_pairs_fp4, dim3((cap + kKnn4Q - 1) / kKnn4Q, n_pairs), dim3(64 * kKnnWaves), 0, s, desc, n_feat, cap, pairs, best_idx, best_d, second_d);
+    else
+        hipLaunchKernelGGL(k_knn2_pairs_mfma, dim3((cap + kKnnQ - 1) / kKnnQ, n_pairs), dim3(64 * kKnnWaves), 0, s, desc, n_feat, cap, pairs, best_idx, best_d, second_d);
 }
 
 // grouped (CSR buckets): one wave per group, one query per lane, candidates read through t_idx
@@ -675,8 +859,7 @@ int dcs_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const u
     if (!t_mask && (long long)nq * nt >= kMfmaMinDistances && nt < (1 << 22)) {         // the matrix-core kernel (no mask support)
         TwoSlot ts;
         if ((rc = two_slot_upload(s, q, nullptr, nq, t, nullptr, nt, ts))) return rc;
-        hipLaunchKernelGGL(k_knn2_pairs_mfma, dim3((ts.cap + kKnnQ - 1) / kKnnQ, 1), dim3(64 * kKnnWaves), 0, s.st, ts.desc, ts.n, ts.cap, ts.pairs,
-                           ts.best_i, ts.best_d, ts.second_d);
+        launch_knn2_pairs_mfma(ts.desc, ts.n, ts.cap, ts.pairs, 1, ts.best_i, ts.best_d, ts.second_d, s.st);
         DCS_CHECK_LAUNCH();
         if ((rc = s.download_bytes(best_idx, ts.best_i, sizeof(int32_t) * nq)) || (rc = s.download_bytes(best_d, ts.best_d, sizeof(int32_t) * nq)) ||
             (rc = s.download_bytes(second_d, ts.second_d, sizeof(int32_t) * nq))) return rc;
@@ -784,8 +967,7 @@ int dcs_match_bf(const uint8_t* q, const dcs_keypoint* q_kp, int nq, const uint8
         if ((rc = two_slot_upload(s, q, check_ori ? q_kp : nullptr, nq, t, check_ori ? t_kp : nullptr, nt, ts))) return rc;
         int32_t* dn1 = ts.count;
         if (!ts.kp && (rc = s.alloc(&ts.kp, 1))) return rc;                                  // never read without check_ori
-        hipLaunchKernelGGL(k_knn2_pairs_mfma, dim3((ts.cap + kKnnQ - 1) / kKnnQ, 1), dim3(64 * kKnnWaves), 0, s.st, ts.desc, ts.n, ts.cap, ts.pairs,
-                           ts.best_i, ts.best_d, ts.second_d);
+        launch_knn2_pairs_mfma(ts.desc, ts.n, ts.cap, ts.pairs, 1, ts.best_i, ts.best_d, ts.second_d, s.st);
         DCS_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_filter_pairs, dim3(1), dim3(256), 0, s.st, ts.kp, ts.n, ts.cap, ts.pairs, ts.best_i, ts.best_d, ts.second_d, th, ratio, check_ori,
                            ts.best_i, dn1);
@@ -829,7 +1011,7 @@ int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, c
     // d_match doubles as the best-index buffer: the filter reads best_idx[i] and writes match[i] in the same thread
     static const bool knn_valu = getenv("DCS_KNN2_VALU") != nullptr;      // xor + popcount kernel instead of the i8 matrix-core one
     if (knn_valu) hipLaunchKernelGGL(k_knn2_pairs, dim3((cap + 127) / 128, n_pairs), dim3(256), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
-    else hipLaunchKernelGGL(k_knn2_pairs_mfma, dim3((cap + kKnnQ - 1) / kKnnQ, n_pairs), dim3(64 * kKnnWaves), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
+    else launch_knn2_pairs_mfma(d_desc, d_n, cap, d_pairs, n_pairs, d_match, d_best_d, d_second_d, s);
     DCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter_pairs, dim3(n_pairs), dim3(256), 0, s, d_kp, d_n, cap, d_pairs, d_match, d_best_d, d_second_d, th,
                        ratio, check_ori, d_match, d_n_matches);
