@@ -477,7 +477,15 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2_pairs_mfma(const uint8_
 #define DCS_KNN4_QG 2
 #endif
 constexpr int kKnn4QG = DCS_KNN4_QG, kKnn4Q = 16 * kKnn4QG * kKnnWaves;
-__global__ __launch_bounds__(64 * kKnnWaves) void k_knn2_pairs_fp4(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_feat, int cap,
+#ifndef DCS_KNN4_WPE               // tuning hook: minimum waves per SIMD the register allocation must allow (0 = compiler's choice)
+#define DCS_KNN4_WPE 0
+#endif
+#if DCS_KNN4_WPE
+__global__ __launch_bounds__(64 * kKnnWaves) __attribute__((amdgpu_waves_per_eu(DCS_KNN4_WPE))) void k_knn2_pairs_fp4(
+#else
+__global__ __launch_bounds__(64 * kKnnWaves) void k_knn2_pairs_fp4(
+#endif
+    const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_feat, int cap,
                                                         const int32_t* __restrict__ pairs, int32_t* best_idx, int32_t* best_d, int32_t* second_d)
 {
     const int p = blockIdx.y;
