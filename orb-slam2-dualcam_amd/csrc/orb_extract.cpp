@@ -336,8 +336,8 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     const bool timed = n_images > 2 || timing_always || no_overlap;
 #define DCS_MARK(e, s) do { if (timed) DCS_HIP(hipEventRecord(e, s)); } while (0)
     DCS_MARK(ev_t[0], stream);
-    int max_rw = 7, max_rh = 7;
-    for (const CellDesc& c : h_cells) { max_rw = std::max(max_rw, (int)c.rw); max_rh = std::max(max_rh, (int)c.rh); }
+    FastFootprint fp_all;                                    // every cell of the pyramid in one launch
+    for (const CellDesc& c : h_cells) fast_footprint_add(fp_all, c.rw, c.rh);
     // Early FAST (DCS_ORB_FAST_SPLIT=k when the handle is created; OPT-IN): the cells of levels [0, k) -- most of the pixels -- start on
     // their own stream as soon as those levels exist and run next to the rest of the resize chain (7 dependent launches at half the
     // chip's issue rate) instead of after it. Measured: an extraction running ALONE gains 6 % with the fused describe (k = 2: 1 740 ->
@@ -354,7 +354,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
             DCS_HIP(hipStreamWaitEvent(s_fast, ev_lvl, 0));
             DCS_MARK(ev_f[0], s_fast);
             if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                        d_cell_count.p, max_rw, max_rh, s_fast, 0, cells_early))) return rc;
+                                        d_cell_count.p, fp_all, s_fast, 0, cells_early))) return rc;
             DCS_MARK(ev_f[1], s_fast);
             DCS_HIP(hipEventRecord(ev_fast_early, s_fast));
         }
@@ -391,12 +391,12 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
 
     if (cells_early > 0) {
         if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                    d_cell_count.p, max_rw, max_rh, stream, cells_early, n_cells - cells_early))) return rc;
+                                    d_cell_count.p, fp_all, stream, cells_early, n_cells - cells_early))) return rc;
     } else {
         // Launches by LDS footprint: a cell's workgroup (one wave) holds its ROI, score map and survivor list in LDS, sized for the
         // largest ROI of the LAUNCH, and that footprint decides how many cells a CU holds -- 5 104 B for the 38 x 38 ROIs of levels 0-3 of
-        // the 640 x 480 pyramid = 32 waves per CU, 5.2-5.4 KB for levels 4 / 5 / 6 = 30 / 30 / 31, 6.6 KB for the 43-wide cells of level 7
-        // = 24. One launch sized for level 7's twelve cells held every level at 24 (DCS_ORB_FAST_GROUPS=0 restores it: 603 us per 512
+        // the 640 x 480 pyramid = 32 waves per CU, 5.2-5.4 KB for levels 4 / 5 / 6 = 30 / 30 / 31, 5.7 KB for the 43-wide cells of level 7
+        // = 28 (survivor list and score map sized for the largest CELL of the launch, not for the largest width x the largest height). One launch sized for level 7's twelve cells held every level at 24 (DCS_ORB_FAST_GROUPS=0 restores it: 603 us per 512
         // images); one launch per footprint class (five) ran in 547 us, but three of them were 1.5-3.6 rounds of the chip long and paid
         // ramp, tail and launch gap for that. The partition of the levels into consecutive groups is now chosen by cost: a group costs
         // its cells / (waves the chip holds at the group's footprint), each level's share raised by TWICE its relative loss of occupancy
@@ -406,25 +406,29 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         // one launch against 80 k with three.
         static const bool grouped_env = !(getenv("DCS_ORB_FAST_GROUPS") && atoi(getenv("DCS_ORB_FAST_GROUPS")) == 0);
         const bool grouped = grouped_env && n_images >= 64;
-        auto wg_per_cu = [](int rw, int rh) { return std::min(32, 163840 / std::max(fast_cells_lds_bytes(rw, rh), 1)); };
-        int lrw[kMaxLevels], lrh[kMaxLevels], start_of[kMaxLevels + 1];
-        for (int l = 0; l < L; ++l) {
-            lrw[l] = 7; lrh[l] = 7;
-            for (int c = h_level_cell_begin[l]; c < h_level_cell_begin[l + 1]; ++c) { lrw[l] = std::max(lrw[l], (int)h_cells[c].rw); lrh[l] = std::max(lrh[l], (int)h_cells[c].rh); }
-        }
+        auto wg_per_cu = [](const FastFootprint& f) { return std::min(32, 163840 / std::max(fast_cells_lds_bytes(f), 1)); };
+        FastFootprint lfp[kMaxLevels];
+        int start_of[kMaxLevels + 1];
+        auto merged = [](FastFootprint a, const FastFootprint& b) {
+            a.max_rw = std::max(a.max_rw, b.max_rw); a.max_rh = std::max(a.max_rh, b.max_rh);
+            a.list_entries = std::max(a.list_entries, b.list_entries); a.sc_bytes = std::max(a.sc_bytes, b.sc_bytes);
+            return a;
+        };
+        for (int l = 0; l < L; ++l)
+            for (int c = h_level_cell_begin[l]; c < h_level_cell_begin[l + 1]; ++c) fast_footprint_add(lfp[l], h_cells[c].rw, h_cells[c].rh);
         if (!grouped) { for (int i = 0; i <= L; ++i) start_of[i] = 0; }
         else {
             double best[kMaxLevels + 1];
             best[0] = 0;
             for (int i = 1; i <= L; ++i) {                   // best[i] = cheapest partition of levels [0, i); the last group is [start_of[i], i)
                 best[i] = 1e300; start_of[i] = 0;
-                int grw = 7, grh = 7;
+                FastFootprint gf;
                 for (int j = i - 1; j >= 0; --j) {
-                    grw = std::max(grw, lrw[j]); grh = std::max(grh, lrh[j]);
-                    const double occ = wg_per_cu(grw, grh);
+                    gf = merged(gf, lfp[j]);
+                    const double occ = wg_per_cu(gf);
                     double cost = 1.3;
                     for (int l = j; l < i; ++l) {
-                        const double own = wg_per_cu(lrw[l], lrh[l]);
+                        const double own = wg_per_cu(lfp[l]);
                         const double rounds = (double)(h_level_cell_begin[l + 1] - h_level_cell_begin[l]) * n_images / (256.0 * occ);
                         cost += rounds * (1.0 + 2.0 * (own - occ) / own);
                     }
@@ -437,11 +441,11 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         int l0 = 0;
         for (int k = nb - 1; k >= 0; --k) {
             const int l1 = bounds[k];
-            int grw = 7, grh = 7;
-            for (int l = l0; l < l1; ++l) { grw = std::max(grw, lrw[l]); grh = std::max(grh, lrh[l]); }
+            FastFootprint gf;
+            for (int l = l0; l < l1; ++l) gf = merged(gf, lfp[l]);
             const int c0 = h_level_cell_begin[l0], c1 = h_level_cell_begin[l1];
             if (c1 > c0 && (rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                                   d_cell_count.p, grw, grh, stream, c0, c1 - c0))) return rc;
+                                                   d_cell_count.p, gf, stream, c0, c1 - c0))) return rc;
             l0 = l1;
         }
     }

@@ -61,10 +61,14 @@ struct OctScratch {
 int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_cols /* {sx, 0, a0, a1} per destination column */,
                   const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s);
 
-int fast_cells_lds_bytes(int max_rw, int max_rh);       // LDS of one cell's workgroup when the launch's largest ROI is max_rw x max_rh
+// what decides the LDS of a cell's workgroup in a launch: the largest ROI (pixel map: max_rh rows at the pitch class of max_rw), the
+// longest survivor list and the largest score map among the launch's cells
+struct FastFootprint { int max_rw = 7, max_rh = 7, list_entries = 0, sc_bytes = 0; };
+void fast_footprint_add(FastFootprint& f, int rw, int rh);
+int fast_cells_lds_bytes(const FastFootprint& f);
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
-                      int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s,
+                      int32_t* d_cell_count, const FastFootprint& fp, hipStream_t s,
                       int cell0 = 0, int n_launch = -1 /* the launch covers cells [cell0, cell0 + n_launch); -1: to the end */);
 
 // per (image, level): scan the cell counts, then gather the slots into one dense array for the whole

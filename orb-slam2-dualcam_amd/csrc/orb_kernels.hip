@@ -341,10 +341,10 @@ __device__ __forceinline__ int fast_score(const uint8_t* b, unsigned th_pk /* th
 //   4. strict 8-neighbour NMS inside the ROI's detection area, iniTh -> minTh fallback when the cell has no
 //      iniTh keypoint (vKeysCell.empty(), :812), ordered emission into the cell's fixed slot range.
 // LDS: px[rh][P] + score[rh][P] bytes + survivor list (u16), sized by the host for the largest cell.
-template <int P>           // LDS row pitch in bytes (64 or 128): compile-time so that the ring offsets are immediates
+template <int P>           // LDS row pitch in bytes (40 / 44: the ROI's own bytes; 48 / 64 / 128: aligned rows): compile-time so that the ring offsets are immediates
 __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
                                                    dcs_candidate* __restrict__ slots, size_t slots_per_image,
-                                                   int32_t* __restrict__ cell_count, int map_bytes, int n_images, int sc_pitch, int sc_bytes, int dbg_stop,
+                                                   int32_t* __restrict__ cell_count, int map_bytes, int n_images, int sc_bytes, int dbg_stop,
                                                    int cell0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -364,8 +364,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     }
     const LevelView lv = L.lv[cd.level];
     const uint8_t* img_base = lv.base + (size_t)img * lv.img_stride;
-    // ROI columns start at byte `shift` of the LDS rows: global loads stay 16-byte (P = 64 / 128) or 8-byte (P = 48) aligned
-    const int shift = cd.x0 & (P == 48 ? 7 : 15);
+    // ROI columns start at byte `shift` of the LDS rows: global loads stay 16-byte (P = 64 / 128) or 8-byte (P = 48) aligned; the
+    // exact classes (P = 40 / 44) read the ROI's own bytes with dword loads at its byte address (global loads need no alignment)
+    constexpr bool kExact = P < 48;
+    const int shift = kExact ? 0 : cd.x0 & (P == 48 ? 7 : 15);
+    const int sc_pitch = rw - 4;                             // score map of THIS cell: detection width + 1-px rim, rows packed
     {   // ---- 1. ROI rows into LDS (pixel (x, y) of the ROI at s_px[y * P + shift + x]) and a zeroed score map
         const bool aligned = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 3) == 0;
         const bool aligned16 = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 15) == 0;
@@ -373,7 +376,26 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         uint32_t* px_dw = reinterpret_cast<uint32_t*>(s_px);
         const int Pdw = P >> 2;
         const bool aligned8 = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 7) == 0;
-        if (P == 48 && aligned8) {                                    // 10 rows x 6 x 8-byte columns per wave pass (rows of 48 bytes)
+        if (kExact) {
+            // P / 4 dwords per row, 64 / (P / 4) rows per wave pass; the dword that holds the ROI's last byte reads at most 3 bytes past it:
+            // inside the image row (the ROI ends 13 pixels before the row does). All of a lane's loads are requested before its first store.
+            constexpr int kDw = P / 4, kRows = 64 / kDw, kPasses = (44 + kRows - 1) / kRows;
+            const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + cd.x0;
+            const int r0 = lane / kDw, c = lane - kDw * r0, nd = (rw + 3) >> 2;
+            uint32_t v[kPasses];
+            bool ok[kPasses];
+#pragma unroll
+            for (int i = 0; i < kPasses; ++i) {
+                const int r = r0 + kRows * i;
+                ok[i] = lane < kRows * kDw && c < nd && r < rh;
+                if (ok[i]) __builtin_memcpy(&v[i], src + (size_t)r * lv.pitch + 4 * c, 4);
+            }
+#pragma unroll
+            for (int i = 0; i < kPasses; ++i) if (ok[i]) px_dw[(r0 + kRows * i) * Pdw + c] = v[i];
+            if (rh > kRows * kPasses && lane < kRows * kDw)    // taller cells (odd aspect ratios): the rest, row by row
+                for (int r = r0 + kRows * kPasses; r < rh; r += kRows)
+                    if (c < nd) { uint32_t w; __builtin_memcpy(&w, src + (size_t)r * lv.pitch + 4 * c, 4); px_dw[r * Pdw + c] = w; }
+        } else if (P == 48 && aligned8) {                             // 10 rows x 6 x 8-byte columns per wave pass (rows of 48 bytes)
             const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
             const int r0 = lane / 6, c = lane - 6 * r0, nq = (shift + rw + 7) >> 3;
             // the ROI has at most 44 rows (38 in this size class): all of a lane's row loads are requested before the first LDS store
@@ -546,39 +568,50 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     if (lane == 0) cell_count[(size_t)img * n_cells + cell] = min(base, (int)cd.cap);
 }
 
-// LDS of one cell's workgroup for a launch whose largest ROI is max_rw x max_rh (the host groups levels by this figure, orb_extract.cpp)
-int fast_cells_lds_bytes(int max_rw, int max_rh)
+// LDS of one cell's workgroup for a launch with the given footprint (the host groups levels by this figure, orb_extract.cpp)
+static int fast_pitch(int max_rw)                                // exact rows, or shift (<= 7 / 15) + row
 {
-    const int P = (max_rw + 7 <= 48) ? 48 : (max_rw + 15 <= 64) ? 64 : 128;      // shift (<= 7 or 15) + row fits the pitch
-    const int map_bytes = ((max_rh * P) + 15) & ~15;
-    const int list_bytes = ((((max_rw - 6) * (max_rh - 6) + 32) * 2) + 15) & ~15;      // + 32 entries of an odd last row
-    const int sc_bytes = ((max_rw - 6 + 2) * (max_rh - 6 + 2) + 15) & ~15;             // detection area + 1-px rim, rows packed (byte accesses only)
-    return map_bytes + sc_bytes + list_bytes;
+    // the exact classes (the ROI's own bytes, dword loads at its byte address): 44-byte rows for ROIs 41..44 wide instead of 64 (level 7 of
+    // the 640 x 480 pyramid: 28 instead of 24 cells per CU, -3 us per 512 images); 40-byte rows for everything narrower would lift levels
+    // 4-6 into the 32-per-CU class of levels 0-3 (one launch less), but seven dword loads per lane instead of five 8-byte ones cost more
+    // than that gives back: FAST 530 vs 503 us. DCS_FAST_EXACT: bit 0 = P 40, bit 1 = P 44 (default 2).
+    static const int exact = getenv("DCS_FAST_EXACT") ? atoi(getenv("DCS_FAST_EXACT")) : 2;
+    if ((exact & 1) && max_rw <= 40) return 40;
+    if ((exact & 2) && max_rw > 40 && max_rw <= 44) return 44;
+    return max_rw + 7 <= 48 ? 48 : max_rw + 15 <= 64 ? 64 : 128;
+}
+void fast_footprint_add(FastFootprint& f, int rw, int rh)
+{
+    f.max_rw = std::max(f.max_rw, rw); f.max_rh = std::max(f.max_rh, rh);
+    f.list_entries = std::max(f.list_entries, (rw - 6) * (rh - 6) + 32);          // every detection pixel + 32 entries of an odd last row
+    f.sc_bytes = std::max(f.sc_bytes, (rw - 4) * (rh - 4));                       // detection area + 1-px rim, rows packed at the CELL's width
+}
+int fast_cells_lds_bytes(const FastFootprint& f)
+{
+    const int map_bytes = ((f.max_rh * fast_pitch(f.max_rw)) + 15) & ~15;
+    return map_bytes + ((f.sc_bytes + 15) & ~15) + ((2 * f.list_entries + 15) & ~15);
 }
 
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
-                      int32_t* d_cell_count, int max_rw, int max_rh, hipStream_t s, int cell0, int n_launch)
+                      int32_t* d_cell_count, const FastFootprint& fp, hipStream_t s, int cell0, int n_launch)
 {
     if (n_launch < 0) n_launch = n_cells - cell0;             // cells [cell0, cell0 + n_launch) of the n_cells of the pyramid
     if (n_launch <= 0) return DCS_OK;
-    const int P = (max_rw + 7 <= 48) ? 48 : (max_rw + 15 <= 64) ? 64 : 128;      // shift (<= 7 or 15) + row fits the pitch
-    const int map_bytes = ((max_rh * P) + 15) & ~15;
-    const int list_bytes = ((((max_rw - 6) * (max_rh - 6) + 32) * 2) + 15) & ~15;      // + 32 entries of an odd last row
-    const int sc_pitch = max_rw - 6 + 2;                           // detection width + 1-px rim
-    const int sc_bytes = (sc_pitch * (max_rh - 6 + 2) + 15) & ~15;
-    const size_t shmem = (size_t)map_bytes + sc_bytes + list_bytes;
+    const int P = fast_pitch(fp.max_rw);
+    const int map_bytes = ((fp.max_rh * P) + 15) & ~15;
+    const int sc_bytes = (fp.sc_bytes + 15) & ~15;
+    const size_t shmem = (size_t)fast_cells_lds_bytes(fp);
     static const int dbg_stop = getenv("DCS_FAST_STOP") ? atoi(getenv("DCS_FAST_STOP")) : 0;      // only read by -DDCS_FAST_SECTIONS builds
     const dim3 grid(8, n_launch, (n_images + 7) / 8);
-    if (P == 48)
-        hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop, cell0);
-    else if (P == 64)
-        hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop, cell0);
-    else
-        hipLaunchKernelGGL(k_fast_cells<128>, grid, dim3(64), shmem, s, levels, d_cells, n_cells,
-                           ini_th, min_th, d_slots, slots_per_image, d_cell_count, map_bytes, n_images, sc_pitch, sc_bytes, dbg_stop, cell0);
+#define DCS_FAST_LAUNCH(PP) hipLaunchKernelGGL(k_fast_cells<PP>, grid, dim3(64), shmem, s, levels, d_cells, n_cells, ini_th, min_th, d_slots, slots_per_image, \
+                                               d_cell_count, map_bytes, n_images, sc_bytes, dbg_stop, cell0)
+    if (P == 40) DCS_FAST_LAUNCH(40);
+    else if (P == 44) DCS_FAST_LAUNCH(44);
+    else if (P == 48) DCS_FAST_LAUNCH(48);
+    else if (P == 64) DCS_FAST_LAUNCH(64);
+    else DCS_FAST_LAUNCH(128);
+#undef DCS_FAST_LAUNCH
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
