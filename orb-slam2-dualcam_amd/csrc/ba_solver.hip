@@ -2033,15 +2033,19 @@ int build_round(const dcs_ba_problem* pb, Round& r)
     // cursor matrix of the fill pass.
     r.pair_ij.clear(); r.pair_off.assign(1, 0);
     r.pair_ij.reserve((size_t)np * (np + 1)); r.pair_off.reserve((size_t)np * (np + 1) / 2 + 1);
-    for (int i1 = 0; i1 < np; ++i1)
-        for (int i2 = i1; i2 < np; ++i2) {
-            const int c = cntp[(size_t)i1 * np + i2];
-            if (c || i1 == i2) {
-                r.pair_ij.push_back(i1); r.pair_ij.push_back(i2);
-                cntp[(size_t)i1 * np + i2] = r.pair_off.back();
-                r.pair_off.push_back(r.pair_off.back() + c);
+    // The DIAGONAL pairs come first: a pose's own list (every edge of the pose) is several times longer than any list it shares with another
+    // pose, k_schur runs one workgroup per pair in list order, and a long workgroup that starts in the second round of the chip's wave slots
+    // is the kernel's tail. (The order of the pairs decides nothing else: every pair writes its own block of S.)
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i1 = 0; i1 < np; ++i1)
+            for (int i2 = pass == 0 ? i1 : i1 + 1, i2e = pass == 0 ? i1 + 1 : np; i2 < i2e; ++i2) {
+                const int c = cntp[(size_t)i1 * np + i2];
+                if (c || i1 == i2) {
+                    r.pair_ij.push_back(i1); r.pair_ij.push_back(i2);
+                    cntp[(size_t)i1 * np + i2] = r.pair_off.back();
+                    r.pair_off.push_back(r.pair_off.back() + c);
+                }
             }
-        }
     r.n_pairs = (int)r.pair_ij.size() / 2;
     r.pair_e.resize((size_t)2 * r.pair_off.back());
     int2* __restrict__ pe = reinterpret_cast<int2*>(r.pair_e.data());
