@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the latency / with_transfers legs")
+    ap.add_argument("--stage-timing", choices=("sampled", "all"), default="sampled",
+                    help="sampled: only the FAST stage is bracketed by events inside the timed region, the others in extra steps after it; all: every stage inside the timed region")
     ap.add_argument("--lanes", type=int, default=1, help="independent extractor handles/streams the batch is split over (overlaps latency-bound kernels)")
     ap.add_argument("--serial", action="store_true", help="profiling aid: synchronise after the extraction and after the matching of every step (no kernel of one overlaps the other); with DCS_ORB_NO_OVERLAP=1 every kernel runs alone")
     ap.add_argument("--exchange", choices=("cabi", "torch"), default="cabi",
@@ -279,6 +281,8 @@ def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
         main = masked_stream() if ba_cus else torch.cuda.current_stream()
         with torch.cuda.stream(main):
             pipe = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 8, 1, 1, 0, 64, stream_factory=masked_stream if ba_cus else None)
+            for e_ in pipe.exts:
+                e_.set_timing(0)
             for _ in range(2):
                 pkg.Optimizer.LocalBundleAdjustmentBatch(preps)
 
@@ -467,6 +471,12 @@ def main():
         if distributed:
             dist.barrier()
 
+    # Stage markers: every hipEventRecord is a packet between two kernels on the extraction stream; with all seven stages bracketed they cost
+    # 2.7 % of a step (1.405 vs 1.443 ms). Inside the timed region only the FAST stage -- the roofline kernel -- is bracketed
+    # (dcs_orb_set_timing mode 1: two markers per step); the other stages are sampled in extra steps after it with every marker on.
+    all_markers = args.stage_timing == "all"
+    for e_ in pipe.exts:
+        e_.set_timing(2 if all_markers else 1)
     dt = pipe.run(args.steps, args.warmup, barrier)
     for e_ in pipe.exts:                  # kernel times: summed over the lanes (each lane launches its own kernels)
         sums, n_timed = e_.timing_totals()
@@ -477,6 +487,19 @@ def main():
         acc["match_us"] += ev[0].elapsed_time(ev[1]) * 1000.0
         if distributed:
             acc["allgather_us"] += ev[2].elapsed_time(ev[3]) * 1000.0
+    n_sample = 0
+    if not all_markers:                   # the other stages: extra steps with every marker on (same pipeline, all ranks; not part of `value`)
+        n_sample = min(args.steps, 10)
+        for e_ in pipe.exts:
+            e_.set_timing(2); e_.timing_totals(reset=True)
+        for _ in range(n_sample):
+            pipe.step()
+        torch.cuda.synchronize()
+        for e_ in pipe.exts:
+            sums, _n = e_.timing_totals()
+            for k in stage_keys:
+                if k != "fast_us":
+                    acc[k] += sums[k] * (args.steps / n_sample)      # scaled to the K timed steps the report divides by
     if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -546,6 +569,9 @@ def main():
                        "matches_per_step_per_gpu": n_match_step, "parallelism": "frame-pair shard x%d" % world},
             "roofline": roofline,
             "stage_us_per_step": {k: round(v / K, 2) for k, v in acc.items()},
+            "stage_timing": ("every stage bracketed by hipEvents inside the timed region (--stage-timing all; the markers cost ~2.7 % of a step)" if all_markers else
+                             "fast_us (the roofline kernel) and match_us: hipEvents inside the timed region, every step; the other stages: %d extra steps after it with "
+                             "every stage marker on (seven markers per step cost ~2.7 %% of a step, so the timed region carries only the two around FAST)" % n_sample),
             "kernels": kernels,
         }
         out["config"]["input_sets_rotated"] = pipe.n_sets
@@ -702,6 +728,8 @@ def main():
     # ---- C3 leg: dual 1280x720, 2000 features / camera (BASELINE configs[2]) on this GPU
     if solo and not args.no_c3 and (W, H, NF) != (1280, 720, 2000):
         p3 = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 1, 64, 1, 0, 16)
+        for e_ in p3.exts:
+            e_.set_timing(0)                                  # no stage figures are reported for this leg: no markers on its stream
         dt3 = p3.run(8, 2)
         f3 = p3.features_per_step()
         out["c3"] = {"workload": "configs[2] at 1 GPU: dual 1280x720 stream, 2000 feat/cam, extract + BF match, 64 dual frames per step",

@@ -142,6 +142,11 @@ int  dcs_orb_last_timing(dcs_orb* h, float* us7);
 /* sums of the same 7 stage times over every extract call since the last reset. Event sets live in a ring and are read
    lazily, so asynchronous (_device) callers are never stalled by the instrumentation. */
 int  dcs_orb_timing_totals(dcs_orb* h, double* sum_us7, int64_t* n_calls, int reset);
+/* what the stage markers above cost: every hipEventRecord is a packet between two kernels on the stream, a call of more than two images
+   records 7 of them, and on the 512-image benchmark step that is 2.7 % of the step (1.405 instead of 1.443 ms without them). mode 2 (the
+   default): every stage; mode 1: only the FAST stage (the roofline kernel of bench.py) is bracketed, the other entries of the timing
+   arrays read 0; mode 0: no markers (dcs_orb_last_timing then fails with "no timing available"). Pending event sets are read first. */
+int  dcs_orb_set_timing(dcs_orb* h, int mode);
 
 /* DistributeOctTree (ORBextractor.cc:539-763) alone, host buffers (used by tests) */
 int  dcs_distribute_octree(const dcs_candidate* cand, int n, int min_x, int max_x, int min_y, int max_y,

@@ -23,7 +23,7 @@ SYMBOLS = [
     "dcs_last_error", "dcs_version", "dcs_device_count",
     "dcs_orb_create", "dcs_orb_destroy", "dcs_orb_tables", "dcs_orb_extract", "dcs_orb_extract_batch",
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
-    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_distribute_octree",
+    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_orb_set_timing", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_by_projection_kf", "dcs_search_in_window", "dcs_search_for_initialization",
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
@@ -113,6 +113,7 @@ def lib():
             "dcs_orb_required_cap": [vp, ci, ci, pci],
             "dcs_orb_last_timing": [vp, vp],
             "dcs_orb_timing_totals": [vp, vp, vp, ci],
+            "dcs_orb_set_timing": [vp, ci],
             "dcs_distribute_octree": [vp, ci, ci, ci, ci, ci, ci, vp, ci, pci],
             "dcs_hamming_knn2": [vp, ci, vp, ci, vp, vp, vp, vp],
             "dcs_hamming_knn2_grouped": [vp, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp],
@@ -282,6 +283,10 @@ class ORBextractor:
         return n.value
 
     STAGES = ("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us")
+
+    def set_timing(self, mode):
+        """stage markers of later calls: 0 none, 1 the FAST stage only, 2 every stage (the default); dcs_orb_set_timing"""
+        _check(lib().dcs_orb_set_timing(self._h, int(mode)), "dcs_orb_set_timing")
 
     def timing_totals(self, reset=False):
         """(dict of summed stage microseconds, number of calls) since the last reset; does not stall async callers."""

@@ -150,7 +150,8 @@ struct dcs_orb {
     // per-call timing events live in a small ring so that asynchronous callers are never stalled: a set is harvested
     // (elapsed times read and accumulated) only when it is about to be reused or when the totals are requested
     static constexpr int kRing = 8;
-    struct EvSet { hipEvent_t t[7] = {}, b[2] = {}, f[2] = {}; float host_us = 0; bool pending = false, dev_oct = true; } ring[kRing];
+    struct EvSet { hipEvent_t t[7] = {}, b[2] = {}, f[2] = {}; float host_us = 0; bool pending = false, dev_oct = true, has_f = false, has_b = false, all = true; } ring[kRing];
+    int timing_mode = 2;                                     // dcs_orb_set_timing: 0 no stage markers, 1 the FAST stage only, 2 every stage
     hipEvent_t* ev_t = nullptr; hipEvent_t* ev_b = nullptr; hipEvent_t* ev_f = nullptr;     // the set of the call in flight
     long n_calls = 0;
     float last_us[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -333,8 +334,11 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // Stage timing (dcs_orb_timing_totals) brackets every stage with hipEvents; each record is a marker packet between two kernels and
     // costs 5 - 10 us of queue latency -- 45 us of a 220-us dual-frame call. Calls of one or two images (a frame per call) skip them (DCS_ORB_TIMING=1 keeps them).
     static const bool timing_always = getenv("DCS_ORB_TIMING") && atoi(getenv("DCS_ORB_TIMING")) != 0;
-    const bool timed = n_images > 2 || timing_always || no_overlap;
-#define DCS_MARK(e, s) do { if (timed) DCS_HIP(hipEventRecord(e, s)); } while (0)
+    const bool timed = timing_mode > 0 && (n_images > 2 || timing_always || no_overlap);
+    const bool timed_all = timed && timing_mode >= 2;        // mode 1: only the two markers around FAST (the roofline kernel) are recorded
+    es.all = timed_all; es.has_f = false; es.has_b = false;
+#define DCS_MARK(e, s) do { if (timed_all) DCS_HIP(hipEventRecord(e, s)); } while (0)
+#define DCS_MARK_FAST(e, s) do { if (timed) DCS_HIP(hipEventRecord(e, s)); } while (0)
     DCS_MARK(ev_t[0], stream);
     FastFootprint fp_all;                                    // every cell of the pyramid in one launch
     for (const CellDesc& c : h_cells) fast_footprint_add(fp_all, c.rw, c.rh);
@@ -352,6 +356,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         if (cells_early > 0 && l == std::max(split - 1, 1)) {              // levels 0 .. split - 1 are complete (split == 1: level 0 needs no resize)
             DCS_HIP(hipEventRecord(ev_lvl, stream));
             DCS_HIP(hipStreamWaitEvent(s_fast, ev_lvl, 0));
+            es.has_f = timed_all;
             DCS_MARK(ev_f[0], s_fast);
             if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
                                         d_cell_count.p, fp_all, s_fast, 0, cells_early))) return rc;
@@ -359,8 +364,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
             DCS_HIP(hipEventRecord(ev_fast_early, s_fast));
         }
     }
-    if (cells_early == 0) { DCS_MARK(ev_f[0], stream); DCS_MARK(ev_f[1], stream); }
-    DCS_MARK(ev_t[1], stream);
+    DCS_MARK_FAST(ev_t[1], stream);
     // blur on the auxiliary stream, overlapping FAST (DCS_ORB_NO_OVERLAP=1 serialises it for clean timings).
     // DCS_ORB_BLUR_LATE=1 starts it after FAST instead (measured slower: it then collides with the latency-bound
     // compaction + quadtree kernels, 1.64 vs 1.55 ms per 128 dual frames).
@@ -375,7 +379,8 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     static const bool blur_early = getenv("DCS_ORB_BLUR_LATE") == nullptr;
     hipStream_t sb = no_overlap ? stream : s_aux;
     auto blur_stage = [&]() -> int {
-        if (fused_blur) { DCS_MARK(ev_b[0], sb); DCS_MARK(ev_b[1], sb); return DCS_OK; }
+        if (fused_blur) return DCS_OK;                       // no blur kernels, no markers (every record is a packet on the stream)
+        es.has_b = timed_all;
         if (!no_overlap) { DCS_HIP(hipEventRecord(ev_pyr, stream)); DCS_HIP(hipStreamWaitEvent(s_aux, ev_pyr, 0)); }
         DCS_MARK(ev_b[0], sb);
         int r = launch_blur(raw, blur, n_images, sb);
@@ -386,7 +391,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     };
     if (no_overlap || blur_early) {
         if ((rc = blur_stage())) return rc;
-        if (no_overlap) DCS_MARK(ev_t[1], stream);      // FAST timing starts after the blur
+        if (no_overlap) DCS_MARK_FAST(ev_t[1], stream);      // FAST timing starts after the blur
     }
 
     if (cells_early > 0) {
@@ -449,7 +454,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
             l0 = l1;
         }
     }
-    DCS_MARK(ev_t[2], stream);
+    DCS_MARK_FAST(ev_t[2], stream);
     if (cells_early > 0) DCS_HIP(hipStreamWaitEvent(stream, ev_fast_early, 0));      // the compaction needs every cell's count
     if (!(no_overlap || blur_early) && (rc = blur_stage())) return rc;
     if ((rc = launch_compact(d_cells.p, d_level_cell_begin.p, L, n_images, n_cells, d_slots.p, g.n_slots, d_cell_count.p,
@@ -530,23 +535,33 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     timing_valid = timed;
     return DCS_OK;
 #undef DCS_MARK
+#undef DCS_MARK_FAST
 }
 
 int dcs_orb::harvest(EvSet& es)
 {
-    DCS_HIP(hipEventSynchronize(es.t[5]));
-    DCS_HIP(hipEventSynchronize(es.b[1]));
-    float ms, us[7];
-    DCS_HIP(hipEventElapsedTime(&ms, es.t[0], es.t[1])); us[0] = ms * 1000.f;   // resize chain
-    DCS_HIP(hipEventElapsedTime(&ms, es.t[1], es.t[2])); us[1] = ms * 1000.f;   // k_fast_cells
-    DCS_HIP(hipEventSynchronize(es.f[1]));
-    DCS_HIP(hipEventElapsedTime(&ms, es.f[0], es.f[1])); us[1] += ms * 1000.f;  // + its early launch (levels [0, fast_split)) on s_fast
-    DCS_HIP(hipEventElapsedTime(&ms, es.t[2], es.t[3])); us[2] = ms * 1000.f;   // scan + offsets + gather
-    DCS_HIP(hipEventElapsedTime(&ms, es.b[0], es.b[1])); us[3] = ms * 1000.f;   // k_blur (aux stream)
-    if (es.dev_oct) { DCS_HIP(hipEventElapsedTime(&ms, es.t[3], es.t[6])); us[4] = ms * 1000.f; }   // k_octree
-    else us[4] = es.host_us;                                                    // host quadtree (wall)
-    DCS_HIP(hipEventElapsedTime(&ms, es.t[4], es.t[5])); us[5] = ms * 1000.f;   // k_describe
-    DCS_HIP(hipEventElapsedTime(&ms, es.t[0], es.t[5])); us[6] = ms * 1000.f;   // whole call on the main stream
+    float ms, us[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (!es.all) {                                           // timing mode 1: only the FAST stage was bracketed
+        DCS_HIP(hipEventSynchronize(es.t[2]));
+        DCS_HIP(hipEventElapsedTime(&ms, es.t[1], es.t[2])); us[1] = ms * 1000.f;
+    } else {
+        DCS_HIP(hipEventSynchronize(es.t[5]));
+        DCS_HIP(hipEventElapsedTime(&ms, es.t[0], es.t[1])); us[0] = ms * 1000.f;   // resize chain
+        DCS_HIP(hipEventElapsedTime(&ms, es.t[1], es.t[2])); us[1] = ms * 1000.f;   // k_fast_cells
+        if (es.has_f) {
+            DCS_HIP(hipEventSynchronize(es.f[1]));
+            DCS_HIP(hipEventElapsedTime(&ms, es.f[0], es.f[1])); us[1] += ms * 1000.f;  // + its early launch (levels [0, fast_split)) on s_fast
+        }
+        DCS_HIP(hipEventElapsedTime(&ms, es.t[2], es.t[3])); us[2] = ms * 1000.f;   // scan + offsets + gather
+        if (es.has_b) {
+            DCS_HIP(hipEventSynchronize(es.b[1]));
+            DCS_HIP(hipEventElapsedTime(&ms, es.b[0], es.b[1])); us[3] = ms * 1000.f;   // k_blur (aux stream)
+        }
+        if (es.dev_oct) { DCS_HIP(hipEventElapsedTime(&ms, es.t[3], es.t[6])); us[4] = ms * 1000.f; }   // k_octree
+        else us[4] = es.host_us;                                                    // host quadtree (wall)
+        DCS_HIP(hipEventElapsedTime(&ms, es.t[4], es.t[5])); us[5] = ms * 1000.f;   // k_describe
+        DCS_HIP(hipEventElapsedTime(&ms, es.t[0], es.t[5])); us[6] = ms * 1000.f;   // whole call on the main stream
+    }
     for (int i = 0; i < 7; ++i) { last_us[i] = us[i]; sum_us[i] += us[i]; }
     ++n_harvested;
     es.pending = false;
@@ -931,6 +946,15 @@ int dcs_orb_last_timing(dcs_orb* h, float* us7)
     int rc;
     if (es.pending && (rc = h->harvest(es))) return rc;
     for (int i = 0; i < 7; ++i) us7[i] = h->last_us[i];
+    return DCS_OK;
+}
+
+int dcs_orb_set_timing(dcs_orb* h, int mode)
+{
+    if (!h || mode < 0 || mode > 2) { set_error("timing mode must be 0 (off), 1 (FAST stage only) or 2 (every stage)"); return DCS_ERR_INVALID; }
+    int rc;
+    for (auto& es : h->ring) if (es.pending && (rc = h->harvest(es))) return rc;      // sets recorded under the old mode are read under it
+    h->timing_mode = mode;
     return DCS_OK;
 }
 

@@ -165,7 +165,24 @@ def test_device_resident_batch_matches_host_api(pkg, oracle, synth):
         assert kp_all[i, :n[i]].tobytes() == okp.tobytes()
         assert np.array_equal(desc_all[i, :n[i]], odesc)
     t = e.last_timing()
-    assert t["total_us"] > 0
+    assert t["total_us"] > 0 and t["fast_us"] > 0 and t["describe_us"] > 0
+    # dcs_orb_set_timing: 1 = only the FAST stage is bracketed (same results, the other entries read 0), 0 = no markers
+    ref = (n.copy(), kp_all.copy(), desc_all.copy())
+    for mode in (1, 0, 2):
+        e.set_timing(mode)
+        d_kp.zero_(); d_desc.zero_(); d_n.zero_()
+        e.extract_batch_device(d_img, d_kp, d_desc, d_n, cap, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_n.cpu().numpy(), ref[0]) and np.array_equal(d_desc.cpu().numpy(), ref[2])
+        assert d_kp.cpu().numpy().view(np.uint8).reshape(B, cap, 28).tobytes() == ref[1].tobytes()
+        if mode == 0:
+            with pytest.raises(Exception):
+                e.last_timing()
+        else:
+            t = e.last_timing()
+            assert t["fast_us"] > 0 and (t["describe_us"] > 0) == (mode == 2) and (t["total_us"] > 0) == (mode == 2)
+    with pytest.raises(Exception):
+        e.set_timing(3)
     e.close()
 
 
