@@ -790,6 +790,17 @@ __device__ __forceinline__ BlurEdgeMap blur_edge_map(int x0, int w, int pitch)
     return m;
 }
 
+// horizontal pass of the four pixels of a dword: the 7-byte windows by v_alignbyte, 2 x v_dot4_u32_u8 each (the second accumulates onto the first)
+__device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2, unsigned (&h)[4])
+{
+    constexpr unsigned KA = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3
+    constexpr unsigned KB = 49u | (34u << 8) | (18u << 16);                 // taps 4..6 (+0)
+    h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0u, false), false);
+    h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0u, false), false);
+    h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0u, false), false);
+    h[3] = __builtin_amdgcn_udot4(d2, KB, __builtin_amdgcn_udot4(d1, KA, 0u, false), false);
+}
+
 template <int MODE>
 __device__ __forceinline__ void blur_hrow(const uint8_t* __restrict__ row, int x0, int w, const BlurEdgeMap& em, unsigned (&h)[4])
 {
@@ -811,13 +822,7 @@ __device__ __forceinline__ void blur_hrow(const uint8_t* __restrict__ row, int x
         d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
         d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
     }
-    constexpr unsigned KA = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3
-    constexpr unsigned KB = 49u | (34u << 8) | (18u << 16);                 // taps 4..6 (+0)
-    // second dot4 accumulates onto the first: 2 instructions per pixel
-    h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0u, false), false);
-    h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0u, false), false);
-    h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0u, false), false);
-    h[3] = __builtin_amdgcn_udot4(d2, KB, __builtin_amdgcn_udot4(d1, KA, 0u, false), false);
+    blur_hsum(d0, d1, d2, h);
 }
 
 // K * b + c with K an inline constant (the compiler splits this into v_mul_u32_u24 + v_add otherwise)
@@ -834,6 +839,16 @@ __device__ __forceinline__ unsigned kmad24s(unsigned b, unsigned c_uniform)     
     unsigned r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "n"(K), "v"(b), "s"(c_uniform));
     return r;
+}
+
+// 55 * centre row + rounding. The centre row's horizontal sum is a v_dot4 RESULT read directly, and gfx950 needs three wait states between
+// a dot instruction's write and another VALU's read of it: the compiler pads its own instructions with s_nop but does not look inside
+// an asm statement. From the second output row on the centre row is three rows old; in the FIRST output row of a strip (kk == 6) all
+// seven rows have just been computed and the scheduler may place the dot right before the asm -- k_blur_fold returned pixels 100 too
+// bright there, in runs that depended on the timing -- so that one row uses the plain expression (v_mul + v_add, hazards handled).
+__device__ __forceinline__ unsigned blur_centre_term(unsigned centre, bool first_output_row)
+{
+    return first_output_row ? __umul24(centre, 55u) + 32768u : kmad24s<55>(centre, 32768u);
 }
 
 // one 4-pixel-wide, kBlurR-row strip. YEDGE = the strip touches the top / bottom of the image (row reflection and the
@@ -864,7 +879,7 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ S, uint8_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     // operands < 2^24: v_mad_u32_u24 chain (full rate), 32-bit accumulate (max 257 * 65535); rounding folded in
-                    unsigned acc = kmad24s<55>(ring[(k + 4) % 7][i], 32768u);
+                    unsigned acc = blur_centre_term(ring[(k + 4) % 7][i], kk == 6);
                     acc = kmad24<18>(ring[(k + 1) % 7][i] + ring[k][i], acc);
                     acc = kmad24<34>(ring[(k + 2) % 7][i] + ring[(k + 6) % 7][i], acc);
                     acc = kmad24<49>(ring[(k + 3) % 7][i] + ring[(k + 5) % 7][i], acc);
@@ -937,6 +952,125 @@ __global__ __launch_bounds__(64) void k_blur_edge_cols(LevelSet src, LevelSet ds
     else blur_strip<kBlurBytes, true>(S, D, sv, dv, x0, strip * kBlurR);
 }
 
+// ---- folded form (the default when every level is >= 16 pixels wide and a level's images span < 4 GB): ONE launch, lanes run over
+// (image, dword) pairs of ALL dwords of a row, the border dwords included, so the lines that hold a row's first and last bytes are
+// fetched once, by the waves that stream the row anyway (k_blur_edge_cols fetched one line per 12 useful bytes: 8-16 x its algorithmic
+// traffic, 30 % of the blur's time). A wave without a border dword runs the plain path; a wave with one (41 % of the waves of a
+// 640-wide level, all of them from 256 pixels down) pays three v_perm_b32 per row: every lane loads three dwords la, lb, lc at
+// per-lane offsets and forms d0 = perm(lb, la, s0), d1 = perm(lc, lb, s1), d2 = perm(lc, lb, s2) -- the operand assignment is the
+// same for every lane, only offsets and selectors differ:
+//   interior   (la, lb, lc) = dwords at x0 - 4, x0, x0 + 4, identity selectors
+//   x0 == 0    (0, 4, 0): d0 = pixels (4, 3, 2, 1) out of (lb, la); d1 = lc, d2 = lb
+//   right edge (x0 - 4, x0, x0 + 4 or, for the row's last dword, x0 - 4 again): BORDER_REFLECT_101 of the pixels >= w always lands
+//              inside the pair (lc, lb); window bytes no valid output reads select constant zero
+// Addresses are buffer-resource addresses: the level's base in a descriptor, the row offset in an SGPR (scalar arithmetic only) and a
+// 32-bit per-lane offset that never changes -- no vector address arithmetic per row at all (the plain kernel above spends two 64-bit
+// adds per row on it).
+struct BlurFold { unsigned oa, ob, oc, s0, s1, s2; };
+
+__device__ __forceinline__ BlurFold blur_fold_consts(int x0, int w, int last)          // wave-uniform arguments: scalar code
+{
+    BlurFold f;
+    if (x0 == 0) { f.oa = 0; f.ob = 4; f.oc = 0; }
+    else { f.oa = (unsigned)(x0 - 4); f.ob = (unsigned)x0; f.oc = (unsigned)(x0 + 4 <= last ? x0 + 4 : x0 - 4); }
+    auto sel = [&](int t, int lo, int hi) {
+        unsigned s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int p = x0 - 4 + 4 * t + k;
+            p = p < 0 ? -p : (p >= w ? 2 * w - 2 - p : p);                              // w >= 16: one bounce
+            const unsigned idx = (p >= lo && p < lo + 4) ? (unsigned)(p - lo) : (p >= hi && p < hi + 4) ? (unsigned)(4 + p - hi) : 0x0cu;
+            s |= idx << (8 * k);
+        }
+        return s;
+    };
+    f.s0 = sel(0, (int)f.oa, (int)f.ob); f.s1 = sel(1, (int)f.ob, (int)f.oc); f.s2 = sel(2, (int)f.ob, (int)f.oc);
+    return f;
+}
+
+// srs / drs: descriptors of the level's source / destination storage (wave-uniform); va / vb / vc / vd: per-lane byte offsets of the
+// three source dwords and of the destination dword inside row 0 of the lane's image; y0 wave-uniform
+typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
+template <bool EDGE, bool YEDGE>
+__device__ __forceinline__ void blur_strip_fold(__amdgpu_buffer_rsrc_t srs, __amdgpu_buffer_rsrc_t drs, const LevelView& sv, const LevelView& dv,
+                                                unsigned va, unsigned vb, unsigned vc, unsigned s0, unsigned s1, unsigned s2, unsigned vd, int y0)
+{
+    unsigned ring[7][4];
+    constexpr int kGroup = YEDGE ? 7 : 42;
+#pragma unroll 1
+    for (int r0 = 0; r0 < kBlurR + 6; r0 += kGroup) {
+#pragma unroll
+        for (int kk = 0; kk < kGroup; ++kk) {
+            const int k = kk % 7;
+            const int r = r0 + kk;
+            if (r >= kBlurR + 6) break;
+            const int ry = YEDGE ? reflect101(y0 + r - 3, sv.h) : y0 + r - 3;
+            const int row = ry * sv.pitch;                                            // scalar (soffset of the loads)
+            unsigned d0, d1, d2;
+            if (!EDGE) {
+                const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(srs, (int)va, row, 0);
+                d0 = v.x; d1 = v.y; d2 = v.z;
+            } else {
+                const unsigned la = __builtin_amdgcn_raw_buffer_load_b32(srs, (int)va, row, 0), lb = __builtin_amdgcn_raw_buffer_load_b32(srs, (int)vb, row, 0),
+                               lc = __builtin_amdgcn_raw_buffer_load_b32(srs, (int)vc, row, 0);
+                d0 = __builtin_amdgcn_perm(lb, la, s0); d1 = __builtin_amdgcn_perm(lc, lb, s1); d2 = __builtin_amdgcn_perm(lc, lb, s2);
+            }
+            blur_hsum(d0, d1, d2, ring[k]);
+            if (r >= 6) {
+                unsigned packed = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    unsigned acc = blur_centre_term(ring[(k + 4) % 7][i], kk == 6);
+                    acc = kmad24<18>(ring[(k + 1) % 7][i] + ring[k][i], acc);
+                    acc = kmad24<34>(ring[(k + 2) % 7][i] + ring[(k + 6) % 7][i], acc);
+                    acc = kmad24<49>(ring[(k + 3) % 7][i] + ring[(k + 5) % 7][i], acc);
+                    packed |= min(255u, acc >> 16) << (8 * i);
+                }
+                if (!YEDGE || y0 + r - 6 < dv.h) __builtin_amdgcn_raw_buffer_store_b32(packed, drs, (int)vd, (y0 + r - 6) * dv.pitch, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * kBlurWaves) void k_blur_fold(LevelSet src, LevelSet dst, int n_images)
+{
+    int t = blockIdx.x, l = 0, nbx = 0;
+    for (; l < src.nlevels; ++l) {
+        nbx = (n_images * ((src.lv[l].w + 3) >> 2) + 63) / 64;
+        const int n = nbx * ((src.lv[l].h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
+        if (t < n) break;
+        t -= n;
+    }
+    if (l >= src.nlevels) return;
+    const LevelView sv = src.lv[l], dv = dst.lv[l];
+    const int n_x4 = (sv.w + 3) >> 2, last = 4 * (n_x4 - 1);
+    const int li = (t % nbx) * 64 + (int)threadIdx.x;
+    const int img = li / n_x4;
+    const int x0 = 4 * (li - img * n_x4);
+    const int y0 = (t / nbx) * (kBlurR * kBlurWaves) + kBlurR * __builtin_amdgcn_readfirstlane((int)threadIdx.y);       // wave-uniform
+    if (y0 >= sv.h) return;
+    const bool valid = img < n_images;
+    const bool any_edge = __builtin_amdgcn_ballot_w64(valid && (x0 == 0 || x0 >= last - 4)) != 0;
+    if (!valid || !level_aligned(sv, img)) return;                                   // unaligned images: k_blur_unaligned_l0
+    const unsigned so = (unsigned)img * (unsigned)sv.img_stride, vd = (unsigned)img * (unsigned)dv.img_stride + (unsigned)x0;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sv.base), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dv.base), 0, 0xffffffffu, 0x00020000);
+    const bool yedge = y0 < 3 || y0 + kBlurR + 3 > sv.h;                             // wave-uniform
+    if (!any_edge) {
+        const unsigned va = so + (unsigned)(x0 - 4);
+        if (yedge) blur_strip_fold<false, true>(srs, drs, sv, dv, va, 0, 0, 0, 0, 0, vd, y0);
+        else blur_strip_fold<false, false>(srs, drs, sv, dv, va, 0, 0, 0, 0, 0, vd, y0);
+        return;
+    }
+    const BlurFold f0 = blur_fold_consts(0, sv.w, last), f1 = blur_fold_consts(last - 4, sv.w, last), f2 = blur_fold_consts(last, sv.w, last);
+    BlurFold f{(unsigned)(x0 - 4), (unsigned)x0, (unsigned)(x0 + 4), 0x03020100u, 0x03020100u, 0x07060504u};
+    if (x0 == 0) f = f0;
+    if (x0 == last - 4) f = f1;
+    if (x0 == last) f = f2;
+    if (yedge) blur_strip_fold<true, true>(srs, drs, sv, dv, so + f.oa, so + f.ob, so + f.oc, f.s0, f.s1, f.s2, vd, y0);
+    else blur_strip_fold<true, false>(srs, drs, sv, dv, so + f.oa, so + f.ob, so + f.oc, f.s0, f.s1, f.s2, vd, y0);
+}
+
 // caller-owned level 0 whose base / stride is not 4-byte aligned: byte path for every strip (rare; correctness only)
 __global__ __launch_bounds__(64) void k_blur_unaligned_l0(LevelSet src, LevelSet dst)
 {
@@ -950,14 +1084,31 @@ __global__ __launch_bounds__(64) void k_blur_unaligned_l0(LevelSet src, LevelSet
 
 int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStream_t s)
 {
-    int blocks = 0, edge_lanes = 0;
-    for (int l = 0; l < src.nlevels; ++l) {
-        const int w = src.lv[l].w, h = src.lv[l].h, n_int = w >= 12 ? (w - 8) / 4 : 0;
-        blocks += ((n_images * n_int + 63) / 64) * ((h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
-        edge_lanes += n_images * ((h + kBlurR - 1) / kBlurR) * ((w + 3) / 4 - n_int);
+    // folded form (k_blur_fold): every level >= 16 pixels wide (one reflection bounce, the three border classes distinct) and 32-bit
+    // per-lane offsets (a level's images span < 4 GB); DCS_BLUR_FOLD=0 keeps the round-2 pair k_blur + k_blur_edge_cols
+    const char* fold_env = getenv("DCS_BLUR_FOLD");                 // read per launch: the blur is not on the default pipeline's path
+    bool fold = !(fold_env && atoi(fold_env) == 0) && n_images > 0;
+    int fold_blocks = 0;
+    for (int l = 0; l < src.nlevels && fold; ++l) {
+        const LevelView& a = src.lv[l];
+        const LevelView& b = dst.lv[l];
+        const unsigned long long span_a = (unsigned long long)n_images * a.img_stride + (unsigned long long)a.h * a.pitch + 16;
+        const unsigned long long span_b = (unsigned long long)n_images * b.img_stride + (unsigned long long)b.h * b.pitch + 16;
+        if (a.w < 16 || span_a >= (1ull << 32) || span_b >= (1ull << 32)) fold = false;
+        fold_blocks += ((n_images * ((a.w + 3) / 4) + 63) / 64) * ((a.h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
     }
-    if (blocks) { hipLaunchKernelGGL(k_blur, dim3(blocks), dim3(64, kBlurWaves), 0, s, src, dst, n_images); DCS_CHECK_LAUNCH(); }
-    if (edge_lanes) { hipLaunchKernelGGL(k_blur_edge_cols, dim3((edge_lanes + 63) / 64), dim3(64), 0, s, src, dst, n_images); DCS_CHECK_LAUNCH(); }
+    if (fold) {
+        hipLaunchKernelGGL(k_blur_fold, dim3(fold_blocks), dim3(64, kBlurWaves), 0, s, src, dst, n_images); DCS_CHECK_LAUNCH();
+    } else {
+        int blocks = 0, edge_lanes = 0;
+        for (int l = 0; l < src.nlevels; ++l) {
+            const int w = src.lv[l].w, h = src.lv[l].h, n_int = w >= 12 ? (w - 8) / 4 : 0;
+            blocks += ((n_images * n_int + 63) / 64) * ((h + kBlurR * kBlurWaves - 1) / (kBlurR * kBlurWaves));
+            edge_lanes += n_images * ((h + kBlurR - 1) / kBlurR) * ((w + 3) / 4 - n_int);
+        }
+        if (blocks) { hipLaunchKernelGGL(k_blur, dim3(blocks), dim3(64, kBlurWaves), 0, s, src, dst, n_images); DCS_CHECK_LAUNCH(); }
+        if (edge_lanes) { hipLaunchKernelGGL(k_blur_edge_cols, dim3((edge_lanes + 63) / 64), dim3(64), 0, s, src, dst, n_images); DCS_CHECK_LAUNCH(); }
+    }
     if (((reinterpret_cast<uintptr_t>(src.lv[0].base) | (uintptr_t)src.lv[0].pitch | (uintptr_t)src.lv[0].img_stride) & 3) != 0) {
         hipLaunchKernelGGL(k_blur_unaligned_l0, dim3((src.lv[0].w + 255) / 256, (src.lv[0].h + kBlurR - 1) / kBlurR, n_images), dim3(64), 0, s, src, dst);
         DCS_CHECK_LAUNCH();

@@ -342,6 +342,26 @@ def test_fused_blur_describe_keeps_the_blurred_debug_level(pkg, oracle, synth, m
     e.close()
 
 
+@pytest.mark.parametrize("fold", ["1", "0"])
+def test_blurred_levels_every_width_class(pkg, oracle, monkeypatch, fold):
+    """cv::GaussianBlur 7x7 (ORBextractor.cc:1085-1086) on all 8 levels for level-0 widths 400..407: every w mod 4 class of the border
+    dwords (BORDER_REFLECT_101 assembled in registers), through the folded kernel (k_blur_fold, DCS_BLUR_FOLD=1, the default) and
+    through the round-2 pair k_blur + k_blur_edge_cols (=0)."""
+    monkeypatch.setenv("DCS_BLUR_FOLD", fold)
+    rng = np.random.default_rng(11)
+    for w in range(400, 408):
+        h = 300 + (w & 3)
+        imgs = [rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(3)]
+        e = pkg.ORBextractor(500, 1.2, 8, 20, 7, max_images=3)
+        e.extract_batch(imgs)
+        for i in (0, 2):
+            o = oracle.OrbOracle(500, 1.2, 8, 20, 7)
+            o.extract(imgs[i])
+            for l in range(8):
+                assert np.array_equal(e.level_image(i, l, blurred=True), oracle.gauss7_u8(o.level_image(l))), (w, i, l)
+        e.close()
+
+
 def test_host_batch_pipeline_equals_one_shot(pkg, oracle, synth, monkeypatch):
     """dcs_orb_extract_batch on a large host batch runs as a pipeline of image chunks (upload || kernels || download + scatter,
     csrc/orb_extract.cpp); DCS_ORB_HOST_CHUNK=0 selects the one-shot path. Same bytes either way, and the oracle's for sampled images;
