@@ -692,6 +692,48 @@ def main():
                                  "ms_per_call": round(tt * 1e3, 2), "ms_per_call_mean": round(tt_mean * 1e3, 2), "kfeatures_s": round(nf / tt / 1e3, 1),
                                  "image_GBps": round(nb_ * W * H / tt / 1e9, 2)}
 
+        # the same batch out of a page-locked frame ring (dcs_host_alloc): the DMA reads the caller's frames in place, no staging copy
+        hf = pkg.abi.HostFrames(nb_, H, W)
+        for i_ in range(nb_):
+            hf.frames[i_][:] = host_imgs[i_]
+        ptrs_l = (C.c_void_p * nb_)(*[f_.ctypes.data for f_ in hf.frames])
+        kp_l = np.zeros_like(kp_h); desc_l = np.zeros_like(desc_h); n_l = np.zeros_like(n_h)
+
+        def locked_call(n_=nb_):
+            rc_ = pkg.abi.lib().dcs_orb_extract_batch(ext._h, C.cast(ptrs_l, C.c_void_p), n_, H, W, hf.stride, kp_l.ctypes.data_as(C.c_void_p),
+                                                      desc_l.ctypes.data_as(C.c_void_p), cap, n_l.ctypes.data_as(C.c_void_p))
+            if rc_:
+                raise RuntimeError("dcs_orb_extract_batch (page-locked frames) rc=%d" % rc_)
+        for _ in range(3):
+            locked_call()
+        same = bool(np.array_equal(n_l, n_h) and kp_l.tobytes() == kp_h.tobytes() and np.array_equal(desc_l, desc_h))
+        tls = []
+        for _ in range(15):
+            t0 = time.perf_counter()
+            locked_call()
+            tls.append(time.perf_counter() - t0)
+        tl_, tl_mean = sorted(tls)[len(tls) // 2], sum(tls) / len(tls)
+        nf_l = int(n_l.sum())
+        ext2 = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local_rank, max_images=2)       # like the latency leg's handle: one dual frame per call
+
+        def locked_pair():
+            rc_ = pkg.abi.lib().dcs_orb_extract_batch(ext2._h, C.cast(ptrs_l, C.c_void_p), 2, H, W, hf.stride, kp_l.ctypes.data_as(C.c_void_p),
+                                                      desc_l.ctypes.data_as(C.c_void_p), cap, n_l.ctypes.data_as(C.c_void_p))
+            if rc_:
+                raise RuntimeError("dcs_orb_extract_batch (page-locked dual frame) rc=%d" % rc_)
+        t2s = []
+        for it_ in range(110):
+            t0 = time.perf_counter()
+            locked_pair()
+            if it_ >= 10:
+                t2s.append(time.perf_counter() - t0)
+        ext2.close()
+        out["with_transfers_page_locked"] = {"workload": "the same %d images in a page-locked frame ring (dcs_host_alloc): read in place by the DMA, no staging copy on the host; median of 15 calls" % nb_,
+                                             "ms_per_call": round(tl_ * 1e3, 2), "ms_per_call_mean": round(tl_mean * 1e3, 2), "kfeatures_s": round(nf_l / tl_ / 1e3, 1),
+                                             "image_GBps": round(nb_ * W * H / tl_ / 1e9, 2), "same_bytes_as_pageable": same,
+                                             "ms_extract_one_dual_frame": round(sorted(t2s)[50] * 1e3, 3)}
+        hf.close()
+
     # ---- CPU baseline (rank 0, N = 1 only): the oracle ("port"), single thread, bounded sample; then every host core
     if solo and args.cpu_seconds > 0:
         O = entry.load_oracle()

@@ -56,9 +56,15 @@ int dcs_device_count(void);
  *                               launches (the _device entry points run on the caller's stream)
  *   dcs_ba_set_cu_range         every solver stream created AFTER the call (new host threads, or after dcs_ba_release_thread) is
  *                               restricted to that range; n_cus = 0 removes the restriction. Environment: DCS_BA_CUS="first:count".
- *   dcs_ba_release_thread       frees the calling thread's solver context (arena, pinned words, streams); the next call rebuilds it */
+ *   dcs_ba_release_thread       frees the calling thread's solver context (arena, pinned words, streams); the next call rebuilds it
+ *   dcs_host_alloc / _free      page-locked host memory for the caller's frame ring (the cv::Mat headers of src/Frame.cc:141-149 can wrap it:
+ *                               cv::Mat(rows, cols, CV_8UC1, ptr, stride)). dcs_orb_extract_batch recognises images that lie in page-locked
+ *                               memory (this call, hipHostMalloc or hipHostRegister) at equal spacing with a 4-byte aligned stride and lets
+ *                               the DMA read them in place -- no staging copy on the host */
 int  dcs_stream_create_cu_range(int first_cu, int n_cus, void** stream);
 void dcs_stream_destroy(void* stream);
+int  dcs_host_alloc(void** ptr, size_t bytes);
+int  dcs_host_free(void* ptr);
 int  dcs_ba_set_cu_range(int first_cu, int n_cus);
 int  dcs_ba_release_thread(void);
 

@@ -28,7 +28,7 @@ SYMBOLS = [
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_by_projection_kf", "dcs_search_in_window", "dcs_search_for_initialization",
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
-    "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
+    "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_host_alloc", "dcs_host_free", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
     "dcs_kfdb_create", "dcs_kfdb_destroy", "dcs_kfdb_add", "dcs_kfdb_erase", "dcs_kfdb_clear", "dcs_kfdb_size", "dcs_kfdb_query",
 ]
@@ -128,6 +128,8 @@ def lib():
             "dcs_ba_local_batch": [ci, vp, vp, vp],
             "dcs_ba_timing": [ci, vp],
             "dcs_stream_create_cu_range": [ci, ci, C.POINTER(vp)],
+            "dcs_host_alloc": [C.POINTER(vp), C.c_size_t],
+            "dcs_host_free": [vp],
             "dcs_ba_set_cu_range": [ci, ci],
             "dcs_ba_release_thread": [],
             "dcs_comm_unique_id": [vp],
@@ -238,8 +240,9 @@ class ORBextractor:
         kps, descs = self.extract_batch([image], cap)
         return kps[0], descs[0]
 
-    def extract_batch(self, images, cap=None):
-        images = [_c(im, np.uint8) for im in images]
+    def extract_batch(self, images, cap=None, stride=None):
+        """images: [rows, cols] uint8 arrays; with `stride` they are passed as they lie (rows `stride` bytes apart, e.g. HostFrames.frames)"""
+        images = [_c(im, np.uint8) for im in images] if stride is None else list(images)
         n = len(images)
         rows, cols = images[0].shape if images[0].ndim == 2 else (0, 0)
         cap = cap or max(self.default_cap(), self.required_cap(rows, cols) if rows and cols else 0)
@@ -247,7 +250,7 @@ class ORBextractor:
         desc = np.zeros((n, cap, 32), np.uint8)
         n_out = np.zeros(n, np.int32)
         ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in images])
-        rc = lib().dcs_orb_extract_batch(self._h, C.cast(ptrs, C.c_void_p), n, rows, cols, cols, _p(kp), _p(desc), cap, _p(n_out))
+        rc = lib().dcs_orb_extract_batch(self._h, C.cast(ptrs, C.c_void_p), n, rows, cols, stride or cols, _p(kp), _p(desc), cap, _p(n_out))
         _check(rc, "dcs_orb_extract_batch")
         return [kp[i, :n_out[i]].copy() for i in range(n)], [desc[i, :n_out[i]].copy() for i in range(n)]
 
@@ -942,6 +945,26 @@ def cu_range_stream(first_cu, n_cus):
     h = C.c_void_p()
     _check(lib().dcs_stream_create_cu_range(int(first_cu), int(n_cus), C.byref(h)), "dcs_stream_create_cu_range")
     return h.value
+
+
+class HostFrames:
+    """dcs_host_alloc: n page-locked frames of rows x cols bytes at a 4-byte aligned stride, as numpy views (frames[i] is [rows, cols]);
+    dcs_orb_extract_batch reads such frames in place (no staging copy). close() frees the block."""
+
+    def __init__(self, n, rows, cols):
+        self.n, self.rows, self.cols, self.stride = n, rows, cols, (cols + 3) & ~3
+        h = C.c_void_p()
+        _check(lib().dcs_host_alloc(C.byref(h), n * rows * self.stride), "dcs_host_alloc")
+        self._p = h.value
+        buf = (C.c_uint8 * (n * rows * self.stride)).from_address(self._p)
+        self._block = np.frombuffer(buf, np.uint8).reshape(n, rows, self.stride)
+        self.frames = [self._block[i, :, :cols] for i in range(n)]
+
+    def close(self):
+        if self._p:
+            self.frames, self._block = None, None
+            _check(lib().dcs_host_free(self._p), "dcs_host_free")
+            self._p = None
 
 
 def ba_set_cu_range(first_cu, n_cus):

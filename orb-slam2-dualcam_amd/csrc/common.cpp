@@ -113,6 +113,19 @@ int dcs_stream_create_cu_range(int first_cu, int n_cus, void** stream)
 }
 void dcs_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 
+int dcs_host_alloc(void** ptr, size_t bytes)
+{
+    if (!ptr || !bytes) { dcs::set_error("dcs_host_alloc: bad argument"); return DCS_ERR_INVALID; }
+    *ptr = nullptr;
+    if (hipHostMalloc(ptr, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); dcs::set_error("dcs_host_alloc: %zu bytes of page-locked memory refused", bytes); return DCS_ERR_HIP; }
+    return DCS_OK;
+}
+int dcs_host_free(void* ptr)
+{
+    if (ptr && hipHostFree(ptr) != hipSuccess) { (void)hipGetLastError(); dcs::set_error("dcs_host_free: not a dcs_host_alloc block"); return DCS_ERR_INVALID; }
+    return DCS_OK;
+}
+
 int dcs_device_count(void)
 {
     int n = 0;

@@ -166,6 +166,8 @@ struct dcs_orb {
     // last call (debug taps)
     LevelSet last_raw{}, last_blur{};
     bool last_blur_valid = false;                  // fused describe: the blurred pyramid is only made when dcs_orb_debug_level asks for it
+    const uint8_t* locked_lo = nullptr;            // host range last found page-locked by dcs_orb_extract_batch (read in place by the DMA)
+    const uint8_t* locked_hi = nullptr;
     int fused_mode = -1;                           // DCS_ORB_FUSED_BLUR when the handle is created: 0 / 1, unset = choose per call
     int last_n_images = 0;
 
@@ -685,10 +687,42 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     if (rc) return rc;
     // Host images -> pinned staging (rows packed at a 4-byte aligned pitch) -> ONE device staging buffer that the kernels
     // read in place as level 0, exactly like the _device entry point.
-    const int pitch_s = (cols + 3) & ~3;
-    const size_t img_bytes = (size_t)rows * pitch_s;
-    if ((rc = h->h_img.resize(img_bytes * n_images)) || (rc = h->d_stage.resize(img_bytes * n_images))) return rc;
-    const bool nopack = getenv("DCS_ORB_HOST_NOPACK") != nullptr;   // measurement aid: the pinned staging keeps the previous call's images
+    // Images that already sit in page-locked memory (dcs_host_alloc, hipHostMalloc / hipHostRegister of the caller's frame ring) at equal
+    // spacing and a 4-byte aligned stride need no staging copy: the DMA reads the caller's memory and the kernels take the caller's
+    // stride as the pitch of level 0. One pointer query per call; pageable images take the packing path below. DCS_ORB_HOST_DIRECT=0 disables.
+    bool direct = false;
+    size_t spacing = (size_t)rows * stride;
+    if (stride % 4 == 0 && (reinterpret_cast<uintptr_t>(images[0]) & 3) == 0 && !(getenv("DCS_ORB_HOST_DIRECT") && atoi(getenv("DCS_ORB_HOST_DIRECT")) == 0)) {
+        bool even = true;
+        if (n_images > 1) {
+            even = images[1] > images[0] && (size_t)(images[1] - images[0]) >= spacing && ((images[1] - images[0]) & 3) == 0;
+            const size_t d = even ? (size_t)(images[1] - images[0]) : 0;
+            for (int i = 2; i < n_images && even; ++i) even = images[i] == images[0] + (size_t)i * d;
+            if (even) spacing = d;
+        }
+        if (even) {
+            auto locked = [](const void* q) {
+                hipPointerAttribute_t a;
+                if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+                return a.type == hipMemoryTypeHost;
+            };
+            // the query costs tens of microseconds (more for a large block): the handle remembers the last range it found page-locked -- a
+            // frame ring is handed over again and again. (A stale entry -- the block freed and the addresses reused by pageable memory --
+            // costs speed only: hipMemcpyAsync stages pageable sources itself.)
+            const uint8_t* lo = images[0];
+            const uint8_t* hi = images[n_images - 1] + (size_t)rows * stride;
+            if (lo >= h->locked_lo && hi <= h->locked_hi) direct = true;
+            else if ((direct = locked(lo) && locked(hi - 1))) { h->locked_lo = lo; h->locked_hi = hi; }
+        }
+    }
+    const int pitch_s = direct ? stride : (cols + 3) & ~3;
+    const size_t img_bytes = direct ? spacing : (size_t)rows * pitch_s;
+    // (direct: the last image is copied up to its last row only -- the caller's block need not extend to a full spacing behind it)
+    const size_t last_img_bytes = direct ? (size_t)rows * stride : img_bytes;
+    if ((!direct && (rc = h->h_img.resize(img_bytes * n_images))) || (rc = h->d_stage.resize(img_bytes * n_images))) return rc;
+    const uint8_t* const up_src = direct ? images[0] : h->h_img.p;
+    auto up_bytes = [&](int i0, int m) { return img_bytes * (size_t)(m - 1) + (i0 + m == n_images ? last_img_bytes : img_bytes); };
+    const bool nopack = direct || getenv("DCS_ORB_HOST_NOPACK") != nullptr;   // (the variable alone: measurement aid, the pinned staging keeps the previous call's images)
     auto pack = [&](int i) {
         if (nopack) return;
         uint8_t* dst = h->h_img.p + i * img_bytes;
@@ -788,7 +822,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
             while (!packed[k].load(std::memory_order_acquire)) std::this_thread::yield();
             const auto tw1 = now();
             t_wait_pack += ms(tw0, tw1);
-            DCS_PIPE(hipMemcpyAsync(h->d_stage.p + i0 * img_bytes, h->h_img.p + i0 * img_bytes, img_bytes * m, hipMemcpyHostToDevice, h->s_h2d));
+            DCS_PIPE(hipMemcpyAsync(h->d_stage.p + i0 * img_bytes, up_src + i0 * img_bytes, up_bytes(i0, m), hipMemcpyHostToDevice, h->s_h2d));
             DCS_PIPE(hipEventRecord(e_up, h->s_h2d));
             DCS_PIPE(hipStreamWaitEvent(h->s_main, e_up, 0));
             if ((rc = h->run(h->d_stage.p + i0 * img_bytes, img_bytes, pitch_s, m, h->d_kp.p + (size_t)i0 * cap, h->d_desc.p + (size_t)i0 * cap * 32, cap,
@@ -818,7 +852,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
         const int m = std::min(8, n_images - i0);
         if (m > 1 && h->stage_pool) h->stage_pool->parallel_for(m, [&](int k) { pack(i0 + k); });
         else for (int k = 0; k < m; ++k) pack(i0 + k);
-        DCS_HIP(hipMemcpyAsync(h->d_stage.p + i0 * img_bytes, h->h_img.p + i0 * img_bytes, img_bytes * m, hipMemcpyHostToDevice, h->s_main));
+        DCS_HIP(hipMemcpyAsync(h->d_stage.p + i0 * img_bytes, up_src + i0 * img_bytes, up_bytes(i0, m), hipMemcpyHostToDevice, h->s_main));
     }
     const size_t slots = (size_t)n_images * cap;
     if (h->device_octree) {

@@ -386,3 +386,41 @@ def test_host_batch_pipeline_equals_one_shot(pkg, oracle, synth, monkeypatch):
     for i in (0, 15, 16, 63, 64, 74):
         ek, ed = o.extract(imgs[i])
         assert kp_a[i].tobytes() == ek.tobytes() and np.array_equal(d_a[i], ed), i
+
+
+@pytest.mark.parametrize("W", [320, 322])
+def test_page_locked_frames_are_read_in_place(pkg, oracle, synth, monkeypatch, W):
+    """Frames in page-locked memory (dcs_host_alloc) at equal spacing and a 4-byte aligned stride go up without the staging copy
+    (csrc/orb_extract.cpp: `direct`) -- one dual frame per call, a one-shot batch and the chunked pipeline; same bytes as pageable
+    arrays of the same pixels (DCS_ORB_HOST_DIRECT=0: the packing path on the very same pointers) and the oracle's. W = 322: the
+    stride (324) is wider than the rows."""
+    H = 240
+    base = [synth.frame_pair(640, 480, 0, f) for f in range(5)]
+    hf = pkg.abi.HostFrames(40, H, W)
+    assert hf.stride % 4 == 0 and hf.stride >= W
+    imgs = []
+    for i in range(40):
+        a = base[i % 5][i % 2]
+        y0, x0 = (11 * i) % 200, (17 * i) % 300
+        hf.frames[i][:] = a[y0:y0 + H, x0:x0 + W]
+        imgs.append(hf.frames[i].copy())
+    ext = pkg.ORBextractor(300, 1.2, 8, 20, 7, max_images=40)
+    ref = ext.extract_batch(imgs)                                             # pageable copies: the packing path
+    for chunk, n in (("0", 2), ("0", 40), ("8", 40)):
+        monkeypatch.setenv("DCS_ORB_HOST_CHUNK", chunk)
+        for direct in ("1", "0"):
+            monkeypatch.setenv("DCS_ORB_HOST_DIRECT", direct)
+            kp, d = ext.extract_batch(hf.frames[:n], stride=hf.stride)
+            for i in range(n):
+                assert kp[i].tobytes() == ref[0][i].tobytes() and np.array_equal(d[i], ref[1][i]), (chunk, n, direct, i)
+    # frames that are NOT equally spaced (a reordered ring) fall back to the packing path
+    order = [3, 1, 2]
+    kp, d = ext.extract_batch([hf.frames[i] for i in order], stride=hf.stride)
+    for j, i in enumerate(order):
+        assert kp[j].tobytes() == ref[0][i].tobytes() and np.array_equal(d[j], ref[1][i])
+    ext.close()
+    o = oracle.OrbOracle(300, 1.2, 8, 20, 7)
+    for i in (0, 1, 39):
+        ek, ed = o.extract(imgs[i])
+        assert ref[0][i].tobytes() == ek.tobytes() and np.array_equal(ref[1][i], ed), i
+    hf.close()
