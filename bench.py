@@ -148,6 +148,17 @@ class Pipeline:
         self.lane_pairs = [P // n_lanes + (1 if i < P % n_lanes else 0) for i in range(n_lanes)]
         self.exts = [pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local_rank, max_images=2 * lp) for lp in self.lane_pairs]
         self.ext = self.exts[0]
+        # the extraction lanes run next to the matcher (the caller's current stream): every lane stream is created on a hardware queue of
+        # its own (dcs_stream_create_apart; torch.cuda.Stream() hands out pooled streams whose queue is an accident of the pool's state)
+        self.own_streams = []
+        self.main_raw = torch.cuda.current_stream().cuda_stream
+
+        def apart_stream():
+            raw, _ = pkg.abi.stream_apart([self.main_raw] + self.own_streams)
+            self.own_streams.append(raw)
+            return torch.cuda.ExternalStream(raw, device=dev)
+        if stream_factory is None and not os.environ.get("DCS_BENCH_POOLED_STREAMS"):
+            stream_factory = apart_stream
         self.lane_streams = [(stream_factory() if stream_factory else torch.cuda.Stream(device=dev)) for _ in range(n_lanes)]
         self.lane_done = [torch.cuda.Event() for _ in range(n_lanes)]
         self.matcher = pkg.ORBmatcher(0.75, True)
@@ -258,6 +269,11 @@ class Pipeline:
     def close(self):
         for e_ in self.exts:
             e_.close()
+        self.torch.cuda.synchronize()
+        self.lane_streams = []
+        for raw in self.own_streams:
+            self.pkg.abi.lib().dcs_stream_destroy(raw)
+        self.own_streams = []
 
 
 def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
@@ -270,7 +286,7 @@ def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
     preps = [pkg.Optimizer.prepare(synth.ba_problem(seed=42 + s)) for s in range(n_ba)]
     steps = 150                                   # the concurrent window is 3 x this: ~150 ms, 30+ BA rounds
 
-    def one_config(ba_cus):
+    def one_config(ba_cus, mask_front=True):
         ext_streams = []
 
         def masked_stream():
@@ -278,11 +294,14 @@ def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
             return torch.cuda.ExternalStream(ext_streams[-1], device=dev)
         pkg.abi.ba_release_thread()
         pkg.abi.ba_set_cu_range(0, ba_cus)          # 0 CUs = no restriction
-        main = masked_stream() if ba_cus else torch.cuda.current_stream()
+        front_masked = bool(ba_cus) and mask_front
+        main = masked_stream() if front_masked else torch.cuda.current_stream()
         with torch.cuda.stream(main):
-            pipe = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 8, 1, 1, 0, 64, stream_factory=masked_stream if ba_cus else None)
+            pipe = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 8, 1, 1, 0, 64, stream_factory=masked_stream if front_masked else None)
             for e_ in pipe.exts:
                 e_.set_timing(0)
+            if not ba_cus:
+                pkg.abi.ba_avoid_streams([pipe.main_raw] + [s_.cuda_stream for s_ in pipe.lane_streams])     # the solver's streams: other hardware queues
             for _ in range(2):
                 pkg.Optimizer.LocalBundleAdjustmentBatch(preps)
 
@@ -317,7 +336,7 @@ def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
         torch.cuda.synchronize()
         for s_ in ext_streams:
             pkg.abi.lib().dcs_stream_destroy(s_)
-        return {"ba_cus": ba_cus, "front_end_cus": N_CU - ba_cus if ba_cus else N_CU, "features_per_step": feats,
+        return {"ba_cus": ba_cus, "front_end_cus": N_CU - ba_cus if front_masked else N_CU, "features_per_step": feats,
                 "concurrent": {"kfeatures_s": round(feats * 3 * steps / dt_both / 1e3, 1), "dual_frames_s": round(8 * 3 * steps / dt_both, 1),
                                "ba_iters_s": round(ba_stat["its"] / max(ba_stat["t"], 1e-9), 1), "ba_rounds": ba_stat["calls"]},
                 "alone": {"kfeatures_s": round(feats * steps / dt_alone / 1e3, 1), "dual_frames_s": round(8 * steps / dt_alone, 1),
@@ -325,6 +344,10 @@ def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
 
     sliced = one_config(0)
     sweep = [one_config(c) for c in ((16, 32, 48, 64) if not os.environ.get("DCS_BENCH_C5_NO_SWEEP") else (32,))]
+    # only the solver restricted, the front end on every CU (its streams unmasked)
+    sweep += [one_config(c, mask_front=False) for c in ((64, 128) if not os.environ.get("DCS_BENCH_C5_NO_SWEEP") else ())]
+    again = [one_config(0) for _ in range(int(os.environ.get("DCS_BENCH_C5_REPEAT", "1")))]       # the first configuration once more, now warm
+    pkg.abi.ba_avoid_streams([])
     pkg.abi.ba_release_thread()
     pkg.abi.ba_set_cu_range(0, 0)
     # the split that keeps the most of BOTH sides relative to the unrestricted stand-alone rates
@@ -337,7 +360,7 @@ def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
            "features_per_step": sliced["features_per_step"],
            "concurrent": sliced["concurrent"], "alone": sliced["alone"],
            "time_sliced_vs_alone": {"front_end": round(sliced["concurrent"]["kfeatures_s"] / max(ref_f, 1e-9), 3), "ba": round(sliced["concurrent"]["ba_iters_s"] / max(ref_b, 1e-9), 3)},
-           "partitioned": best, "partition_sweep": sweep}
+           "partitioned": best, "partition_sweep": sweep, "time_sliced_repeat": again}
     return out
 
 

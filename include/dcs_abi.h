@@ -60,7 +60,18 @@ int dcs_device_count(void);
  *   dcs_host_alloc / _free      page-locked host memory for the caller's frame ring (the cv::Mat headers of src/Frame.cc:141-149 can wrap it:
  *                               cv::Mat(rows, cols, CV_8UC1, ptr, stride)). dcs_orb_extract_batch recognises images that lie in page-locked
  *                               memory (this call, hipHostMalloc or hipHostRegister) at equal spacing with a 4-byte aligned stride and lets
- *                               the DMA read them in place -- no staging copy on the host */
+ *                               the DMA read them in place -- no staging copy on the host
+ *   dcs_streams_share_queue     HIP maps a process's streams onto a few hardware queues (four per priority by default), and two streams on one
+ *                               queue run strictly one after the other. *shared = 1 when work on b waits for work on a (measured with two
+ *                               probe kernels, ~0.1 ms; both streams are synchronised first)
+ *   dcs_stream_create_apart     a non-blocking stream that shares its hardware queue with none of avoid[] (*apart = 0 when the process has
+ *                               fewer queues than that needs): for the stream the matcher / a second extraction lane / the solver runs on
+ *                               next to the caller's front-end stream. The library's own streams are created this way.
+ *   dcs_ba_avoid_streams        the solver's streams created AFTER the call (new host threads, or after dcs_ba_release_thread) keep off the
+ *                               hardware queues of these streams (the Tracking thread's extraction and matcher streams; n = 0 clears) */
+int  dcs_streams_share_queue(void* stream_a, void* stream_b, int* shared);
+int  dcs_stream_create_apart(void* const* avoid, int n_avoid, void** stream, int* apart);
+int  dcs_ba_avoid_streams(void* const* avoid, int n_avoid);
 int  dcs_stream_create_cu_range(int first_cu, int n_cus, void** stream);
 void dcs_stream_destroy(void* stream);
 int  dcs_host_alloc(void** ptr, size_t bytes);

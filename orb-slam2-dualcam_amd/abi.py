@@ -28,7 +28,7 @@ SYMBOLS = [
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_by_projection_kf", "dcs_search_in_window", "dcs_search_for_initialization",
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
-    "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_host_alloc", "dcs_host_free", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
+    "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_host_alloc", "dcs_host_free", "dcs_streams_share_queue", "dcs_stream_create_apart", "dcs_ba_avoid_streams", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
     "dcs_kfdb_create", "dcs_kfdb_destroy", "dcs_kfdb_add", "dcs_kfdb_erase", "dcs_kfdb_clear", "dcs_kfdb_size", "dcs_kfdb_query",
 ]
@@ -128,6 +128,9 @@ def lib():
             "dcs_ba_local_batch": [ci, vp, vp, vp],
             "dcs_ba_timing": [ci, vp],
             "dcs_stream_create_cu_range": [ci, ci, C.POINTER(vp)],
+            "dcs_streams_share_queue": [vp, vp, pci],
+            "dcs_stream_create_apart": [vp, ci, C.POINTER(vp), pci],
+            "dcs_ba_avoid_streams": [vp, ci],
             "dcs_host_alloc": [C.POINTER(vp), C.c_size_t],
             "dcs_host_free": [vp],
             "dcs_ba_set_cu_range": [ci, ci],
@@ -945,6 +948,27 @@ def cu_range_stream(first_cu, n_cus):
     h = C.c_void_p()
     _check(lib().dcs_stream_create_cu_range(int(first_cu), int(n_cus), C.byref(h)), "dcs_stream_create_cu_range")
     return h.value
+
+
+def streams_share_queue(a, b):
+    """dcs_streams_share_queue: does work on raw stream b wait for work on raw stream a (one hardware queue)? a / b: hipStream_t as int (0 = legacy default stream)"""
+    sh = C.c_int(0)
+    _check(lib().dcs_streams_share_queue(C.c_void_p(a or None), C.c_void_p(b or None), C.byref(sh)), "dcs_streams_share_queue")
+    return bool(sh.value)
+
+
+def stream_apart(avoid):
+    """dcs_stream_create_apart: (raw non-blocking hipStream_t as int, apart?) on another hardware queue than the raw streams in `avoid`"""
+    arr = (C.c_void_p * max(1, len(avoid)))(*[C.c_void_p(a or None) for a in avoid])
+    h, ok = C.c_void_p(), C.c_int(0)
+    _check(lib().dcs_stream_create_apart(C.cast(arr, C.c_void_p), len(avoid), C.byref(h), C.byref(ok)), "dcs_stream_create_apart")
+    return h.value, bool(ok.value)
+
+
+def ba_avoid_streams(avoid):
+    """dcs_ba_avoid_streams: solver streams created from now on keep off the hardware queues of these raw streams ([] clears)"""
+    arr = (C.c_void_p * max(1, len(avoid)))(*[C.c_void_p(a or None) for a in avoid])
+    _check(lib().dcs_ba_avoid_streams(C.cast(arr, C.c_void_p), len(avoid)), "dcs_ba_avoid_streams")
 
 
 class HostFrames:

@@ -1766,6 +1766,15 @@ static void ba_cu_range(int& first, int& count, bool set)
     first = s_first; count = s_count;
 }
 
+// streams of the front end the solver's compute streams keep off (dcs_ba_avoid_streams): process-wide
+static void ba_avoid_list(std::vector<hipStream_t>& v, bool set)
+{
+    static std::mutex mu;
+    static std::vector<hipStream_t> s_list;
+    std::lock_guard<std::mutex> lk(mu);
+    if (set) s_list = v; else v = s_list;
+}
+
 // Per host thread and device, kept across solves: the device arena (grow-only), the pinned staging image of its
 // upload / download regions, the pinned progress + stop words and the stream. hipMalloc + hipFree of ~30 MB,
 // hipHostMalloc/Free and stream create/destroy cost ~1.4 ms per call together -- a third of a local BA.
@@ -1848,28 +1857,42 @@ struct BaContext {
             DCS_HIP(hipHostMalloc((void**)&h_words, w * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
             words_cap = w;
         }
-        if (!stream) DCS_HIP(create_stream(&stream));
+        if (!stream) { const int rc_s = create_stream(&stream, true); if (rc_s) return rc_s; }
         return DCS_OK;
     }
     // Default priority. DCS_BA_STREAM_PRIORITY=1 (measurement aid) creates the solver's streams with the highest priority: next to a
     // front end that fills the chip (config C5) that HALVES the extraction rate (85 -> 41 kfeatures/s) for +20 % BA iterations --
     // the short, gap-ridden kernels of the solver keep preempting the dispatch of the front end's waves.
-    static hipError_t create_stream(hipStream_t* s)
+    // The streams of one context run CONCURRENTLY (groups of a batch, the result download over the queued-ahead steps), and so do the
+    // solver and the front end of config C5: each new stream is created on a hardware queue of its own -- apart from the context's
+    // other streams and, for the compute streams, from the streams named with dcs_ba_avoid_streams (common.cpp: create_stream_apart).
+    int create_stream(hipStream_t* s, bool keep_off_front_end)
     {
         int first = 0, count = 0;
         ba_cu_range(first, count, false);
-        if (count > 0) return create_cu_range_stream(s, first, count);      // config C5: the solver keeps its own compute units (dcs_ba_set_cu_range)
-        static const int prio = getenv("DCS_BA_STREAM_PRIORITY") ? atoi(getenv("DCS_BA_STREAM_PRIORITY")) : 0;      // 1: highest, -1: lowest
-        int least = 0, greatest = 0;
-        if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-            return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio > 0 ? greatest : least);
-        return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        hipError_t e = hipSuccess;
+        if (count > 0) e = create_cu_range_stream(s, first, count);      // config C5: the solver keeps its own compute units (dcs_ba_set_cu_range)
+        else {
+            static const int prio = getenv("DCS_BA_STREAM_PRIORITY") ? atoi(getenv("DCS_BA_STREAM_PRIORITY")) : 0;      // 1: highest, -1: lowest
+            int least = 0, greatest = 0;
+            if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+                e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio > 0 ? greatest : least);
+            else {
+                std::vector<hipStream_t> avoid;
+                if (keep_off_front_end) ba_avoid_list(avoid, false);
+                if (stream) avoid.push_back(stream);
+                for (hipStream_t a : aux) if (a) avoid.push_back(a);
+                return create_stream_apart(s, avoid.data(), (int)avoid.size(), nullptr);
+            }
+        }
+        if (e != hipSuccess) { set_error("solver stream: %s", hipGetErrorString(e)); (void)hipGetLastError(); return DCS_ERR_HIP; }
+        return DCS_OK;
     }
     int prepare_groups(int n_groups)
     {
         if (n_groups > 1 && !ev_up) DCS_HIP(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
         for (int g = 1; g < n_groups; ++g) {
-            if (!aux[g - 1]) DCS_HIP(create_stream(&aux[g - 1]));
+            if (!aux[g - 1]) { const int rc_s = create_stream(&aux[g - 1], true); if (rc_s) return rc_s; }
             if (!ev_done[g - 1]) DCS_HIP(hipEventCreateWithFlags(&ev_done[g - 1], hipEventDisableTiming));
         }
         return DCS_OK;
@@ -2437,7 +2460,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // takes the ordered path: the download behind everything on the solver's streams.
     static const bool dl_own = !(getenv("DCS_BA_DL_STREAM") && atoi(getenv("DCS_BA_DL_STREAM")) == 0);
     if (dl_own && n_finished == G) {
-        if (!ctx.dl) DCS_HIP(BaContext::create_stream(&ctx.dl));
+        if (!ctx.dl) { const int rc_s = ctx.create_stream(&ctx.dl, false); if (rc_s) return rc_s; }
         DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, ctx.dl));
         DCS_HIP(hipStreamSynchronize(ctx.dl));
     } else {
@@ -2496,6 +2519,15 @@ int dcs_ba_set_cu_range(int first_cu, int n_cus)
 {
     if (first_cu < 0 || n_cus < 0) { set_error("dcs_ba_set_cu_range: bad range"); return DCS_ERR_INVALID; }
     ba_cu_range(first_cu, n_cus, true);
+    return DCS_OK;
+}
+
+int dcs_ba_avoid_streams(void* const* avoid, int n_avoid)
+{
+    if (n_avoid < 0 || (n_avoid && !avoid)) { set_error("dcs_ba_avoid_streams: bad argument"); return DCS_ERR_INVALID; }
+    std::vector<hipStream_t> v;
+    for (int i = 0; i < n_avoid; ++i) if (avoid[i]) v.push_back((hipStream_t)avoid[i]);
+    ba_avoid_list(v, true);
     return DCS_OK;
 }
 

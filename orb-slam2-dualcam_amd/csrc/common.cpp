@@ -2,6 +2,8 @@
 #include "common.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -94,6 +96,80 @@ hipError_t create_cu_range_stream(hipStream_t* s, int first, int count)
     return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
 }
 
+// ---- hardware queues. HIP maps the streams of a process onto a handful of hardware queues (four per priority by default,
+// GPU_MAX_HW_QUEUES; a new stream takes the queue with the fewest users), and two streams on ONE queue run strictly one after the other:
+// whether the matcher runs underneath the next extraction, the solver next to the front end or an upload next to the kernels then
+// depends on how many streams the process happened to have alive (bench.py's C5 leg measured three states from the same code: front end
+// alone 106 k or 136 k kfeatures/s, the solver next to it at 0.85 or at 0.2 of its rate). There is no API to ask for a stream's queue,
+// so it is measured: a one-wave kernel that waits for a host flag is parked on stream a, a one-thread kernel that sets a second flag is
+// launched on stream b -- if b's flag does not arrive within a millisecond while a is parked, b sits behind a.
+__global__ void k_queue_probe_wait(volatile int* go, int* parked)
+{
+    __hip_atomic_store(parked, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long t0 = wall_clock64();                                  // 100 MHz: give up after 20 ms whatever happens
+    while (__hip_atomic_load(const_cast<int*>(go), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < 2000000) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void k_queue_probe_set(int* arrived) { __hip_atomic_store(arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared)
+{
+    *shared = false;
+    if (a == b) { *shared = true; return DCS_OK; }
+    int* w = nullptr;                                                      // [0] go, [1] parked, [2] arrived
+    DCS_HIP(hipHostMalloc((void**)&w, 64, hipHostMallocDefault));
+    w[0] = w[1] = w[2] = 0;
+    auto rd = [&](int i) { return __atomic_load_n(&w[i], __ATOMIC_ACQUIRE); };
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(now() - t).count(); };
+    hipError_t e = hipStreamSynchronize(a);
+    if (e == hipSuccess) e = hipStreamSynchronize(b);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_queue_probe_wait, dim3(1), dim3(64), 0, a, (volatile int*)w, w + 1); e = hipGetLastError(); }
+    if (e == hipSuccess) {
+        auto t0 = now();
+        while (!rd(1) && us_since(t0) < 10000.0) { }                      // the parked kernel is running
+        hipLaunchKernelGGL(k_queue_probe_set, dim3(1), dim3(1), 0, b, w + 2);
+        e = hipGetLastError();
+        t0 = now();
+        while (!rd(2) && us_since(t0) < 1000.0) { }
+        *shared = rd(1) && !rd(2);
+    }
+    __atomic_store_n(&w[0], 1, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+    (void)hipHostFree(w);
+    if (e != hipSuccess) { set_error("hardware-queue probe: %s", hipGetErrorString(e)); (void)hipGetLastError(); return DCS_ERR_HIP; }
+    return DCS_OK;
+}
+
+// A non-blocking stream that shares its hardware queue with none of avoid[0 .. n_avoid): candidates are created (each new one lands on the
+// least used queue) and probed until one is apart; the rejected ones are destroyed afterwards. With more streams to avoid than the
+// process has queues there is no such stream: the last candidate is returned and *apart (optional) reports 0.
+int create_stream_apart(hipStream_t* out, const hipStream_t* avoid, int n_avoid, bool* apart)
+{
+    static const bool probing = !(getenv("DCS_STREAM_PROBE") && atoi(getenv("DCS_STREAM_PROBE")) == 0);
+    std::vector<hipStream_t> rejected;
+    hipStream_t s = nullptr;
+    bool ok = false;
+    int rc = DCS_OK;
+    for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
+        hipStream_t c = nullptr;
+        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); set_error("hipStreamCreateWithFlags failed"); rc = DCS_ERR_HIP; break; }
+        if (s) rejected.push_back(s);
+        s = c;
+        ok = true;
+        for (int i = 0; i < n_avoid && ok && probing; ++i) {
+            bool sh = false;
+            if ((rc = streams_share_queue(avoid[i], s, &sh))) break;
+            if (sh) ok = false;
+        }
+        if (rc) break;
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    if (rc) { if (s) (void)hipStreamDestroy(s); return rc; }
+    *out = s;
+    if (apart) *apart = ok;
+    return DCS_OK;
+}
+
 }  // namespace dcs
 
 extern "C" {
@@ -109,6 +185,29 @@ int dcs_stream_create_cu_range(int first_cu, int n_cus, void** stream)
     const hipError_t e = dcs::create_cu_range_stream(&s, first_cu, n_cus);
     if (e != hipSuccess) { dcs::set_error("dcs_stream_create_cu_range(%d, %d): %s", first_cu, n_cus, hipGetErrorString(e)); (void)hipGetLastError(); return e == hipErrorInvalidValue ? DCS_ERR_INVALID : DCS_ERR_HIP; }
     *stream = s;
+    return DCS_OK;
+}
+int dcs_streams_share_queue(void* a, void* b, int* shared)
+{
+    if (!shared) { dcs::set_error("null output"); return DCS_ERR_INVALID; }
+    int rc = dcs::ensure_device();
+    if (rc) return rc;
+    bool sh = false;
+    rc = dcs::streams_share_queue((hipStream_t)a, (hipStream_t)b, &sh);
+    *shared = sh ? 1 : 0;
+    return rc;
+}
+int dcs_stream_create_apart(void* const* avoid, int n_avoid, void** stream, int* apart)
+{
+    if (!stream || n_avoid < 0 || (n_avoid && !avoid)) { dcs::set_error("bad argument"); return DCS_ERR_INVALID; }
+    int rc = dcs::ensure_device();
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    bool ok = false;
+    rc = dcs::create_stream_apart(&s, reinterpret_cast<const hipStream_t*>(avoid), n_avoid, &ok);
+    if (rc) return rc;
+    *stream = s;
+    if (apart) *apart = ok ? 1 : 0;
     return DCS_OK;
 }
 void dcs_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }

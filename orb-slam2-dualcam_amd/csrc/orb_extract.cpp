@@ -143,6 +143,15 @@ struct dcs_orb {
     hipStream_t s_main = nullptr, s_aux = nullptr, s_fast = nullptr;
     // host-buffer batches run as a pipeline of image chunks: upload of chunk k + 1 || kernels of chunk k || download of chunk k - 1
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    // side streams are made on first use, each on a hardware queue of its own next to the streams it runs beside (common.cpp:
+    // create_stream_apart -- two streams on one hardware queue run one after the other, and which streams share one is an accident of how
+    // many the process has alive)
+    int side_stream(hipStream_t& s, hipStream_t beside_a, hipStream_t beside_b = nullptr)
+    {
+        if (s) return DCS_OK;
+        const hipStream_t avoid[2] = {beside_a, beside_b};                 // beside_a may be the legacy default stream (0): it has a queue too
+        return create_stream_apart(&s, avoid, beside_b ? 2 : 1, nullptr);
+    }
     std::vector<hipEvent_t> ev_chunk;              // 3 per chunk: uploaded, computed, downloaded
     hipEvent_t ev_lvl = nullptr, ev_fast_early = nullptr;
     int fast_split = 0;                            // DCS_ORB_FAST_SPLIT: FAST of levels [0, fast_split) starts on its own stream as soon as they exist
@@ -351,6 +360,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // the matcher of the previous step already fills those idle issue slots, it LOSES 3-7 % (fused + 2: 277 k, separate + 3: 267 k
     // against 287 k kfeatures/s): the steady state is bound by the number of vector instructions, not by idle time.
     const int split = (no_overlap || L < 3) ? 0 : std::min(fast_split, L - 1);
+    if (split > 0 && (rc = side_stream(s_fast, stream))) return rc;
     const int cells_early = split > 0 ? h_level_cell_begin[split] : 0;
     for (int l = 1; l < L; ++l) {
         if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs,
@@ -379,6 +389,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     const bool fused_blur = fused_mode >= 0 ? fused_mode != 0 : true;
     last_blur_valid = !fused_blur;
     static const bool blur_early = getenv("DCS_ORB_BLUR_LATE") == nullptr;
+    if (!fused_blur && !no_overlap && (rc = side_stream(s_aux, stream, s_fast))) return rc;
     hipStream_t sb = no_overlap ? stream : s_aux;
     auto blur_stage = [&]() -> int {
         if (fused_blur) return DCS_OK;                       // no blur kernels, no markers (every record is a packet on the stream)
@@ -591,12 +602,10 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     DCS_HIP(hipGetDevice(&h->device));
     h->t.build(p->nfeatures, p->scale_factor, p->nlevels, p->ini_th_fast, p->min_th_fast);
     DCS_HIP(hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking));
-    DCS_HIP(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
     DCS_HIP(hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming));
     DCS_HIP(hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming));
     DCS_HIP(hipEventCreateWithFlags(&h->ev_lvl, hipEventDisableTiming));
     DCS_HIP(hipEventCreateWithFlags(&h->ev_fast_early, hipEventDisableTiming));
-    DCS_HIP(hipStreamCreateWithFlags(&h->s_fast, hipStreamNonBlocking));
     h->fast_split = getenv("DCS_ORB_FAST_SPLIT") ? atoi(getenv("DCS_ORB_FAST_SPLIT")) : 0;
     for (auto& es : h->ring) { for (auto& e : es.t) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.b) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.f) DCS_HIP(hipEventCreate(&e)); }
     h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
@@ -748,8 +757,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
         const size_t slots = (size_t)n_images * cap;
         if ((rc = h->d_kp.resize(slots)) || (rc = h->d_desc.resize(slots * 32)) || (rc = h->d_n.resize(n_images)) || (rc = h->h_n.resize(n_images)) ||
             (rc = h->h_kp_out.resize(slots)) || (rc = h->h_desc_out.resize(slots * 32))) return rc;
-        if (!h->s_h2d) DCS_HIP(hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking));
-        if (!h->s_d2h) DCS_HIP(hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking));
+        if ((rc = h->side_stream(h->s_h2d, h->s_main)) || (rc = h->side_stream(h->s_d2h, h->s_main, h->s_h2d))) return rc;
         // Chunk boundaries: a short first chunk starts the DMA early, a short last one keeps the tail (kernels + download + scatter of
         // the final chunk, which nothing overlaps) small.
         std::vector<int> c_begin;
@@ -930,7 +938,7 @@ int dcs_orb_debug_level(dcs_orb* h, int image, int level, int blurred, uint8_t* 
     DCS_HIP(hipSetDevice(h->device));
     DCS_HIP(hipDeviceSynchronize());
     if (blurred && !h->last_blur_valid) {           // the product path never needed it (the caller's level-0 buffer must still be alive)
-        int r = launch_blur(h->last_raw, h->last_blur, h->last_n_images, h->s_aux);
+        int r = launch_blur(h->last_raw, h->last_blur, h->last_n_images, h->s_main);
         if (r) return r;
         DCS_HIP(hipDeviceSynchronize());
         h->last_blur_valid = true;
