@@ -1857,7 +1857,7 @@ struct BaContext {
             DCS_HIP(hipHostMalloc((void**)&h_words, w * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
             words_cap = w;
         }
-        if (!stream) { const int rc_s = create_stream(&stream, true); if (rc_s) return rc_s; }
+        if (!stream) { const int rc_s = create_stream(&stream); if (rc_s) return rc_s; }
         return DCS_OK;
     }
     // Default priority. DCS_BA_STREAM_PRIORITY=1 (measurement aid) creates the solver's streams with the highest priority: next to a
@@ -1865,8 +1865,8 @@ struct BaContext {
     // the short, gap-ridden kernels of the solver keep preempting the dispatch of the front end's waves.
     // The streams of one context run CONCURRENTLY (groups of a batch, the result download over the queued-ahead steps), and so do the
     // solver and the front end of config C5: each new stream is created on a hardware queue of its own -- apart from the context's
-    // other streams and, for the compute streams, from the streams named with dcs_ba_avoid_streams (common.cpp: create_stream_apart).
-    int create_stream(hipStream_t* s, bool keep_off_front_end)
+    // other streams and from the streams named with dcs_ba_avoid_streams (common.cpp: create_stream_apart).
+    int create_stream(hipStream_t* s)
     {
         int first = 0, count = 0;
         ba_cu_range(first, count, false);
@@ -1878,11 +1878,20 @@ struct BaContext {
             if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
                 e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio > 0 ? greatest : least);
             else {
-                std::vector<hipStream_t> avoid;
-                if (keep_off_front_end) ba_avoid_list(avoid, false);
-                if (stream) avoid.push_back(stream);
-                for (hipStream_t a : aux) if (a) avoid.push_back(a);
-                return create_stream_apart(s, avoid.data(), (int)avoid.size(), nullptr);
+                // first choice: a queue shared with nobody; when the process has too few (three besides the legacy default stream's), a queue
+                // shared with one of the context's OWN streams -- never the front end's: a download or a group's kernels queued behind an
+                // extraction that the Tracking thread enqueues steps ahead would wait for all of it
+                std::vector<hipStream_t> front, all;
+                ba_avoid_list(front, false);
+                all = front;
+                if (stream) all.push_back(stream);
+                for (hipStream_t a : aux) if (a) all.push_back(a);
+                bool apart = false;
+                int rc_a = create_stream_apart(s, all.data(), (int)all.size(), &apart);
+                if (rc_a || apart || front.empty() || front.size() == all.size()) return rc_a;
+                (void)hipStreamDestroy(*s);
+                *s = nullptr;
+                return create_stream_apart(s, front.data(), (int)front.size(), nullptr);
             }
         }
         if (e != hipSuccess) { set_error("solver stream: %s", hipGetErrorString(e)); (void)hipGetLastError(); return DCS_ERR_HIP; }
@@ -1892,7 +1901,7 @@ struct BaContext {
     {
         if (n_groups > 1 && !ev_up) DCS_HIP(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
         for (int g = 1; g < n_groups; ++g) {
-            if (!aux[g - 1]) { const int rc_s = create_stream(&aux[g - 1], true); if (rc_s) return rc_s; }
+            if (!aux[g - 1]) { const int rc_s = create_stream(&aux[g - 1]); if (rc_s) return rc_s; }
             if (!ev_done[g - 1]) DCS_HIP(hipEventCreateWithFlags(&ev_done[g - 1], hipEventDisableTiming));
         }
         return DCS_OK;
@@ -2460,7 +2469,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // takes the ordered path: the download behind everything on the solver's streams.
     static const bool dl_own = !(getenv("DCS_BA_DL_STREAM") && atoi(getenv("DCS_BA_DL_STREAM")) == 0);
     if (dl_own && n_finished == G) {
-        if (!ctx.dl) { const int rc_s = ctx.create_stream(&ctx.dl, false); if (rc_s) return rc_s; }
+        if (!ctx.dl) { const int rc_s = ctx.create_stream(&ctx.dl); if (rc_s) return rc_s; }
         DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, ctx.dl));
         DCS_HIP(hipStreamSynchronize(ctx.dl));
     } else {
