@@ -63,7 +63,7 @@ int dcs_device_count(void);
  *                               the DMA read them in place -- no staging copy on the host
  *   dcs_streams_share_queue     HIP maps a process's streams onto a few hardware queues (four per priority by default), and two streams on one
  *                               queue run strictly one after the other. *shared = 1 when work on b waits for work on a (measured with two
- *                               probe kernels, ~0.1 ms; both streams are synchronised first)
+ *                               probe kernels, ~0.1 ms on idle streams; b is synchronised first, the probe takes its turn behind a's backlog)
  *   dcs_stream_create_apart     a non-blocking stream that shares its hardware queue with none of avoid[] (*apart = 0 when the process has
  *                               fewer queues than that needs): for the stream the matcher / a second extraction lane / the solver runs on
  *                               next to the caller's front-end stream. The library's own streams are created this way.

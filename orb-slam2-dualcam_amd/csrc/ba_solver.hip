@@ -2535,7 +2535,7 @@ int dcs_ba_avoid_streams(void* const* avoid, int n_avoid)
 {
     if (n_avoid < 0 || (n_avoid && !avoid)) { set_error("dcs_ba_avoid_streams: bad argument"); return DCS_ERR_INVALID; }
     std::vector<hipStream_t> v;
-    for (int i = 0; i < n_avoid; ++i) if (avoid[i]) v.push_back((hipStream_t)avoid[i]);
+    for (int i = 0; i < n_avoid; ++i) v.push_back((hipStream_t)avoid[i]);          // a null entry = the legacy default stream: it has a queue too
     ba_avoid_list(v, true);
     return DCS_OK;
 }

@@ -121,12 +121,13 @@ int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared)
     auto rd = [&](int i) { return __atomic_load_n(&w[i], __ATOMIC_ACQUIRE); };
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(now() - t).count(); };
-    hipError_t e = hipStreamSynchronize(a);
-    if (e == hipSuccess) e = hipStreamSynchronize(b);
+    // b is drained first (its own backlog must not read as "waits for a"); a is NOT: it may be a stream another thread keeps feeding
+    // (the Tracking thread's, while a LocalMapping thread builds its solver context) -- the parked kernel simply takes its turn there
+    hipError_t e = hipStreamSynchronize(b);
     if (e == hipSuccess) { hipLaunchKernelGGL(k_queue_probe_wait, dim3(1), dim3(64), 0, a, (volatile int*)w, w + 1); e = hipGetLastError(); }
     if (e == hipSuccess) {
         auto t0 = now();
-        while (!rd(1) && us_since(t0) < 10000.0) { }                      // the parked kernel is running
+        while (!rd(1) && us_since(t0) < 50000.0) { }                      // the parked kernel is running
         hipLaunchKernelGGL(k_queue_probe_set, dim3(1), dim3(1), 0, b, w + 2);
         e = hipGetLastError();
         t0 = now();
@@ -150,7 +151,10 @@ int create_stream_apart(hipStream_t* out, const hipStream_t* avoid, int n_avoid,
     hipStream_t s = nullptr;
     bool ok = false;
     int rc = DCS_OK;
-    for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
+    // every candidate lands on the queue with the fewest users and stays alive until the search ends, so the search walks towards a free
+    // queue even when idle streams of the process have left the counts lopsided (a rejected candidate costs the probe's 1 ms time-out)
+    const int max_attempts = n_avoid >= 4 ? 10 : 24;               // the default stream's queue + three more: four streams to avoid rarely leave one
+    for (int attempt = 0; attempt < max_attempts && !ok; ++attempt) {
         hipStream_t c = nullptr;
         if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); set_error("hipStreamCreateWithFlags failed"); rc = DCS_ERR_HIP; break; }
         if (s) rejected.push_back(s);
@@ -163,6 +167,9 @@ int create_stream_apart(hipStream_t* out, const hipStream_t* avoid, int n_avoid,
         }
         if (rc) break;
     }
+    static const bool trace = getenv("DCS_STREAM_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[create_stream_apart] %d streams to keep off, %zu candidates rejected, result %p %s\n", n_avoid, rejected.size(), (void*)s,
+                       rc ? "(error)" : ok ? "apart" : "SHARES a queue");
     for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
     if (rc) { if (s) (void)hipStreamDestroy(s); return rc; }
     *out = s;
