@@ -706,6 +706,7 @@ def main():
                                                       desc_h.ctypes.data_as(C.c_void_p), cap, n_h.ctypes.data_as(C.c_void_p))
             if rc_:
                 raise RuntimeError("dcs_orb_extract_batch rc=%d" % rc_)
+        ext.set_timing(0)                 # no stage figures are reported for the host-buffer legs: no markers on their streams
         for _ in range(3):
             host_call()
         tts = []
