@@ -124,7 +124,11 @@ int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared)
     // b is drained first (its own backlog must not read as "waits for a"); a is NOT: it may be a stream another thread keeps feeding
     // (the Tracking thread's, while a LocalMapping thread builds its solver context) -- the parked kernel simply takes its turn there
     hipError_t e = hipStreamSynchronize(b);
+    hipEvent_t parked_done = nullptr;                                      // behind the parked kernel: the probe waits for ITS end, not for what another thread enqueues on a afterwards
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&parked_done, hipEventDisableTiming);
     if (e == hipSuccess) { hipLaunchKernelGGL(k_queue_probe_wait, dim3(1), dim3(64), 0, a, (volatile int*)w, w + 1); e = hipGetLastError(); }
+    bool recorded = false;
+    if (e == hipSuccess) { e = hipEventRecord(parked_done, a); recorded = e == hipSuccess; }
     if (e == hipSuccess) {
         auto t0 = now();
         while (!rd(1) && us_since(t0) < 50000.0) { }                      // the parked kernel is running
@@ -135,7 +139,9 @@ int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared)
         *shared = rd(1) && !rd(2);
     }
     __atomic_store_n(&w[0], 1, __ATOMIC_RELEASE);
-    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+    if (!recorded || hipEventSynchronize(parked_done) != hipSuccess) (void)hipStreamSynchronize(a);     // the parked kernel reads w: it must have ended
+    if (parked_done) (void)hipEventDestroy(parked_done);
+    (void)hipStreamSynchronize(b);
     (void)hipHostFree(w);
     if (e != hipSuccess) { set_error("hardware-queue probe: %s", hipGetErrorString(e)); (void)hipGetLastError(); return DCS_ERR_HIP; }
     return DCS_OK;

@@ -698,7 +698,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     // read in place as level 0, exactly like the _device entry point.
     // Images that already sit in page-locked memory (dcs_host_alloc, hipHostMalloc / hipHostRegister of the caller's frame ring) at equal
     // spacing and a 4-byte aligned stride need no staging copy: the DMA reads the caller's memory and the kernels take the caller's
-    // stride as the pitch of level 0. One pointer query per call; pageable images take the packing path below. DCS_ORB_HOST_DIRECT=0 disables.
+    // stride as the pitch of level 0. Two pointer queries, remembered per handle; pageable images take the packing path below. DCS_ORB_HOST_DIRECT=0 disables.
     bool direct = false;
     size_t spacing = (size_t)rows * stride;
     if (stride % 4 == 0 && (reinterpret_cast<uintptr_t>(images[0]) & 3) == 0 && !(getenv("DCS_ORB_HOST_DIRECT") && atoi(getenv("DCS_ORB_HOST_DIRECT")) == 0)) {
