@@ -28,6 +28,7 @@
 #ifndef DCS_ABI_H
 #define DCS_ABI_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

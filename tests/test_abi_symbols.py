@@ -28,6 +28,17 @@ def test_header_symbols_exported(pkg):
     assert lib.dcs_version().decode().startswith("dcs-hip")
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/dcs_abi.h is what a cgo / JNI / ctypes binding compiles against: it must stand alone as C99 (no C++, every type it
+    names declared by its own includes)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "dcs_abi.h"\nint main(void) { dcs_keypoint k; (void)k; return 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_struct_layouts_match_header(pkg):
     assert pkg.abi.KEYPOINT.itemsize == 28 and pkg.abi.CANDIDATE.itemsize == 8
     assert C.sizeof(pkg.abi.OrbParams) == 32
