@@ -177,6 +177,8 @@ struct dcs_orb {
     bool last_blur_valid = false;                  // fused describe: the blurred pyramid is only made when dcs_orb_debug_level asks for it
     const uint8_t* locked_lo = nullptr;            // host range last found page-locked by dcs_orb_extract_batch (read in place by the DMA)
     const uint8_t* locked_hi = nullptr;
+    const uint8_t* pageable_lo = nullptr;          // ... and the last range found pageable (no second query for a caller that re-uses its buffers)
+    const uint8_t* pageable_hi = nullptr;
     int fused_mode = -1;                           // DCS_ORB_FUSED_BLUR when the handle is created: 0 / 1, unset = choose per call
     int last_n_images = 0;
 
@@ -721,7 +723,9 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
             const uint8_t* lo = images[0];
             const uint8_t* hi = images[n_images - 1] + (size_t)rows * stride;
             if (lo >= h->locked_lo && hi <= h->locked_hi) direct = true;
+            else if (lo == h->pageable_lo && hi == h->pageable_hi) direct = false;           // asked before: pageable (a caller that re-uses its buffers)
             else if ((direct = locked(lo) && locked(hi - 1))) { h->locked_lo = lo; h->locked_hi = hi; }
+            else { h->pageable_lo = lo; h->pageable_hi = hi; }
         }
     }
     const int pitch_s = direct ? stride : (cols + 3) & ~3;
