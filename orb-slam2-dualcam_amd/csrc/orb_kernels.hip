@@ -706,11 +706,84 @@ __global__ __launch_bounds__(256) void k_gather(const CellDesc* __restrict__ cel
     }
 }
 
+// Small batches (what Frame::ExtractORB hands over: one or two images per call, src/Frame.cc:141-149): the three launches above are 4 us of
+// work and 15 us of launch latency. ONE launch does all of it -- the dense, emission-ordered array is laid out (image, level, cell), which
+// is exactly the order of the (image, cell) entries, so ONE exclusive scan over all n_images * n_cells counts gives every cell its place;
+// the per-level offsets, totals and the (image, level) offsets the quadtree reads are differences of that scan. Same bytes in every
+// output array as k_level_scan + k_lvl_offsets + k_gather.
+constexpr int kCompactSmallThreads = 1024;
+constexpr int kCompactSmallRun = 16;                                       // entries per thread: up to 16 384 (image, cell) entries
+__global__ __launch_bounds__(kCompactSmallThreads) void k_compact_small(const CellDesc* __restrict__ cells, const int32_t* __restrict__ level_cell_begin, int nlevels,
+                                                                        int n_images, int n_cells, const dcs_candidate* __restrict__ slots, size_t slots_per_image,
+                                                                        const int32_t* __restrict__ cell_count, int32_t* __restrict__ cell_off,
+                                                                        int32_t* __restrict__ lvl_total, int32_t* __restrict__ lvl_off,
+                                                                        dcs_candidate* __restrict__ dense, size_t dense_cap)
+{
+    __shared__ int s_wave[kCompactSmallThreads / 64];
+    extern __shared__ int s_pos[];                                         // [n_entries + 1]: exclusive prefix of every (image, cell) entry
+    const int n_entries = n_images * n_cells, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = t * kCompactSmallRun;
+    int v[kCompactSmallRun], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactSmallRun; ++k) { v[k] = b + k < n_entries ? cell_count[b + k] : 0; sum += v[k]; }
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kCompactSmallThreads / 64; ++w) { const int c = s_wave[w]; if (w < wave) off += c; total += c; }
+    int ex = off + inc - sum;
+#pragma unroll
+    for (int k = 0; k < kCompactSmallRun; ++k) { if (b + k < n_entries) s_pos[b + k] = ex; ex += v[k]; }
+    if (t == 0) s_pos[n_entries] = total;
+    __syncthreads();
+    // (image, level) offsets and totals, per-level cell offsets: written by workgroup 0 (every workgroup repeats the scan -- 16 loads per
+    // thread -- and gathers its own share of the entries: the gather is two dependent loads per entry, one workgroup alone would walk them
+    // 64 at a time)
+    const int n_all = n_images * nlevels;
+    if (blockIdx.x == 0) {
+    for (int i = t; i <= n_all; i += kCompactSmallThreads) {
+        if (i == n_all) { lvl_off[n_all] = total; break; }
+        const int img = i / nlevels, l = i - img * nlevels;
+        const int first = s_pos[img * n_cells + level_cell_begin[l]], end = s_pos[img * n_cells + level_cell_begin[l + 1]];
+        lvl_off[i] = first;
+        lvl_total[i] = end - first;
+    }
+    for (int i = t; i < n_entries; i += kCompactSmallThreads) {
+        const int img = i / n_cells, c = i - img * n_cells;
+        cell_off[i] = s_pos[i] - s_pos[img * n_cells + level_cell_begin[cells[c].level]];
+    }
+    }
+    // gather: 16 lanes per entry, like k_gather
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(dense);
+    const int sub = t & 15;
+    for (int i = blockIdx.x * (kCompactSmallThreads / 16) + (t >> 4); i < n_entries; i += gridDim.x * (kCompactSmallThreads / 16)) {
+        const int n = s_pos[i + 1] - s_pos[i];
+        if (n == 0) continue;
+        const int img = i / n_cells, c = i - img * n_cells;
+        const size_t dst0 = (size_t)s_pos[i];
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(slots + (size_t)img * slots_per_image + cells[c].slot_base);
+        for (int k = sub; k < n; k += 16)
+            if (dst0 + k < dense_cap) dst[dst0 + k] = src[k];
+    }
+}
+
 int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, int nlevels, int n_images, int n_cells,
                    const dcs_candidate* d_slots, size_t slots_per_image, const int32_t* d_cell_count,
                    int32_t* d_cell_off, int32_t* d_lvl_total, int32_t* d_lvl_off, dcs_candidate* d_dense,
                    size_t dense_cap, hipStream_t s)
 {
+    static const bool small_on = !(getenv("DCS_ORB_COMPACT_SMALL") && atoi(getenv("DCS_ORB_COMPACT_SMALL")) == 0);
+    const long long n_entries = (long long)n_images * n_cells;
+    if (small_on && n_cells > 0 && n_entries <= kCompactSmallThreads * kCompactSmallRun && (n_entries + 1) * sizeof(int) <= 64 * 1024) {
+        const int n_wg = (int)std::min<long long>(64, (n_entries + 127) / 128);
+        hipLaunchKernelGGL(k_compact_small, dim3(n_wg), dim3(kCompactSmallThreads), (size_t)(n_entries + 1) * sizeof(int), s, d_cells, d_level_cell_begin, nlevels,
+                           n_images, n_cells, d_slots, slots_per_image, d_cell_count, d_cell_off, d_lvl_total, d_lvl_off, d_dense, dense_cap);
+        DCS_CHECK_LAUNCH();
+        return DCS_OK;
+    }
     hipLaunchKernelGGL(k_level_scan, dim3(nlevels, n_images), dim3(256), 0, s, d_level_cell_begin, nlevels, n_cells,
                        d_cell_count, d_cell_off, d_lvl_total);
     DCS_CHECK_LAUNCH();
