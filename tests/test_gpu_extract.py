@@ -424,3 +424,29 @@ def test_page_locked_frames_are_read_in_place(pkg, oracle, synth, monkeypatch, W
         ek, ed = o.extract(imgs[i])
         assert ref[0][i].tobytes() == ek.tobytes() and np.array_equal(ref[1][i], ed), i
     hf.close()
+
+
+def test_one_frame_calls_replayed_as_a_graph(pkg, oracle, synth, monkeypatch):
+    """A handle that is called with one or two host images again and again (Frame::ExtractORB, src/Frame.cc:141-149) replays the call's
+    launches as one executable graph from the third call of a shape on (DCS_ORB_SMALL_GRAPH=1): every call still returns the features
+    of ITS images -- different frames every call, compared with a fresh handle without the graph and with the oracle."""
+    frames = [synth.frame_pair(640, 480, 1, f) for f in range(7)]
+    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "0")
+    ref_ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)
+    ref = [ref_ext.extract_batch(list(fp)) for fp in frames]
+    ref_ext.close()
+    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "1")
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)
+    for rep in range(2):
+        for i, fp in enumerate(frames):
+            kps, descs = e.extract_batch(list(fp))
+            for c in range(2):
+                assert kps[c].tobytes() == ref[i][0][c].tobytes() and np.array_equal(descs[c], ref[i][1][c]), (rep, i, c)
+    one = e.extract_batch([frames[3][1]])                         # another shape of call on the same handle: single image
+    assert one[0][0].tobytes() == ref[3][0][1].tobytes()
+    kps, descs = e.extract_batch(list(frames[5]))                  # and back
+    assert kps[0].tobytes() == ref[5][0][0].tobytes() and np.array_equal(descs[1], ref[5][1][1])
+    e.close()
+    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    ek, ed = o.extract(frames[2][0])
+    assert ref[2][0][0].tobytes() == ek.tobytes() and np.array_equal(ref[2][1][0], ed)
