@@ -895,7 +895,8 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
         // plain launches). DCS_ORB_SMALL_GRAPH=0 / 1 forces it off / on.
         const char* graph_s = getenv("DCS_ORB_SMALL_GRAPH");                 // read per call (tests switch it)
         const int graph_env = graph_s ? atoi(graph_s) : -1;
-        const bool graph_ok = (graph_env < 0 ? kSmallGraphDefault : graph_env != 0) && n_images <= 2 && !h->no_overlap && !h->small_graph_broken;
+        static const bool timing_always = getenv("DCS_ORB_TIMING") && atoi(getenv("DCS_ORB_TIMING")) != 0;   // stage markers even on small calls: no graph (the events would become graph nodes)
+        const bool graph_ok = (graph_env < 0 ? kSmallGraphDefault : graph_env != 0) && n_images <= 2 && !h->no_overlap && !timing_always && !h->small_graph_broken;
         const dcs_orb::SmallGraphKey key{h->d_stage.p, h->d_out.p, h->h_out.p, img_bytes, total, n_images, rows, cols, pitch_s, cap};
         bool replayed = false;
         if (graph_ok && h->small_graph_exec && key == h->small_graph_key) {
