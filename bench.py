@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-bow", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-two-lanes", action="store_true", help="skip the two-extraction-lanes leg")
     ap.add_argument("--no-host-api", action="store_true", help="skip the latency / with_transfers legs")
     ap.add_argument("--stage-timing", choices=("sampled", "all"), default="sampled",
                     help="sampled: only the FAST stage is bracketed by events inside the timed region, the others in extra steps after it; all: every stage inside the timed region")
@@ -799,7 +800,7 @@ def main():
     # ---- the headline workload with the batch split over TWO extraction lanes (two handles, two streams on hardware queues of their own,
     # the same 256 dual frames per step): kernels of one lane fill the ramps, tails and latency-bound stretches of the other's. Reported
     # beside `value`, which stays on one lane so that a launch of the roofline kernel has the chip to itself.
-    if solo and not args.no_c3 and args.lanes == 1:
+    if solo and not args.no_two_lanes and not args.no_c3 and args.lanes == 1:
         p2 = Pipeline(pkg, torch, dev, local_rank, W, H, NF, 1, P, 2, rank, 8, n_sets=args.input_sets)
         for e_ in p2.exts:
             e_.set_timing(0)
