@@ -19,6 +19,11 @@ cpu_all_cores, latency (one dual frame through the host-buffer API, PCIe include
 (the default batch through the host-buffer API), matcher (solo, i8-MFMA TOPS), c3 (dual 1280x720, 2000
 features), local_ba (C4 + its MFMA / HBM roofline + the 8-problem batch), c5_one_gpu (8 streams of
 extraction + matching next to 8 concurrent local BAs, time-sliced on ONE GPU), bow.
+
+Under a rank environment (any N, every rank takes part, rank 0 reports node sums) two legs follow the headline:
+c3_scaled = BASELINE configs[2] (64 dual 1280x720 / 2000-feature frames per step per rank + the per-step feature
+all-gather + cross-rank match) and c5_node = configs[4] (per rank ONE dual-camera sequence on the main thread next
+to ONE local-BA loop on a second thread). `--no-rank-legs` skips them.
 """
 import argparse
 import json
@@ -66,6 +71,8 @@ def parse_args(argv=None):
                     help="N > 1 (or any run under a rank environment): the per-step feature all-gather goes through the library's own RCCL communicator "
                          "(dcs_features_allgather, default) or through torch.distributed + pack / unpack")
     ap.add_argument("--input-sets", type=int, default=3, help="distinct HBM-resident input batches rotated across steps (3 x 157 MB > the 256 MB Infinity Cache)")
+    ap.add_argument("--no-rank-legs", action="store_true", help="runs under a rank environment: skip the c3_scaled / c5_node legs that follow the headline")
+    ap.add_argument("--rank-leg-seconds", type=float, default=1.5, help="length of each window of the c5_node leg (front end alone, then front end next to the solver)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU check of the N > 1 entry: launcher -> ranks -> gloo process group -> the feature all-gather, then one JSON line")
     return ap.parse_args(argv)
@@ -90,7 +97,9 @@ def launch_ranks(args, argv):
 
 
 def selftest_rank(args):
-    """The N > 1 path up to and including its first collective, on CPU (gloo): same sharding code bench runs over RCCL."""
+    """The N > 1 path on CPU (gloo): the sharding code bench runs over RCCL up to and including its first collective, then the two
+    rank-path legs (c3_scaled, c5_node) with the GPU work replaced by stand-ins of the same SHAPES -- the collectives, the two-thread
+    structure of c5_node, the node sums and the JSON keys are the code the GPU run executes."""
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -107,12 +116,180 @@ def selftest_rank(args):
         all(int(g_desc[2 * r, 0, 0]) == r + 1 for r in range(world)) and all(q == 2 * rank for q, _ in sharding.reloc_pairs(rank, world))
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    env = RankEnv(torch, dist, torch.device("cpu"), rank, world)
+    legs = {}
+    if not args.no_rank_legs:
+        legs["c3_scaled"] = leg_c3_scaled(env, StandInC3(torch, sharding, rank, world), steps=3, warmup=1)
+        legs["c5_node"] = leg_c5_node(env, *stand_in_c5(rank), seconds=0.2)
     if rank == 0:
         print(json.dumps({"selftest": "launch", "n_gpus": world, "backend": "gloo", "allgather_ok": bool(flag.item()),
-                          "units_of_rank0": sharding.shard_units(2 * world + 1, 0, world)}))
+                          "units_of_rank0": sharding.shard_units(2 * world + 1, 0, world), **legs}))
     dist.barrier()
     dist.destroy_process_group()
     return 0 if flag.item() else 1
+
+
+# ---------------------------------------------------------------------------------------------------------------- rank-path legs
+# What an N-GPU run measures beyond the headline: BASELINE configs[2] ("dual 1280x720, 2000 feat/cam, 1 -> 8 GPUs frame-sharded with RCCL
+# descriptor all-gather") and configs[4] ("8 concurrent dual-camera sequences, one per GPU, + per-stream local BA, whole-node throughput").
+# Every rank runs the same leg on its own GPU; rank 0 reports per-rank figures and node sums. The GPU work is behind small objects so that
+# tests/test_bench_launcher.py can drive the very same collectives / threads / report code at world size 2 on gloo.
+C3_FRAMES_PER_STEP = 64
+C3_CAP_STAND_IN = 2096                              # slot capacity of a 2000-feature, 8-level handle: nfeatures + 4 x levels + 64 (abi.py default_cap)
+
+
+class RankEnv:
+    def __init__(self, torch, dist, dev, rank, world, distributed=True):
+        self.torch, self.dist, self.dev, self.rank, self.world, self.distributed = torch, dist, dev, rank, world, distributed
+
+    def barrier(self):
+        if self.distributed:
+            self.dist.barrier()
+
+    def gather(self, values):
+        """every rank's list of floats -> [world][len] on every rank"""
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=self.dev)
+        if not self.distributed:
+            return [t.tolist()]
+        out = self.torch.zeros(self.world * len(values), dtype=self.torch.float64, device=self.dev)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.reshape(self.world, len(values)).tolist()
+
+
+def leg_c3_scaled(env, work, steps, warmup):
+    """configs[2] on every rank: `C3_FRAMES_PER_STEP` dual 1280x720 / 2000-feature frames per step per rank (extract + 3 matches per dual
+    frame) + the per-step all-gather of the newest dual frame's features + the cross-rank relocalisation match. Weak scaling: the node's
+    rate = features of all ranks / the slowest rank's time."""
+    dt = work.run(steps, warmup, env.barrier)
+    rows = env.gather([dt, work.features_timed(), work.allgather_us(), work.features_per_step()])
+    work.close()
+    dt_max = max(r[0] for r in rows)
+    per_rank = [round(r[1] / r[0] / 1e3, 1) for r in rows]
+    return {"workload": "configs[2] on every rank: dual 1280x720 stream, 2000 feat/cam, %d dual frames per step per rank (extract + 3 BF matches each) "
+                        "+ per-step all-gather of the newest dual frame's features + cross-rank match" % work.frames_per_step,
+            "n_gpus": env.world, "steps": steps, "warmup": warmup,
+            "kfeatures_s": round(sum(r[1] for r in rows) / dt_max / 1e3, 1),
+            "dual_frames_s": round(env.world * work.frames_per_step * steps / dt_max, 1),
+            "ms_per_step": round(dt_max / steps * 1e3, 3),
+            "per_rank_kfeatures_s": per_rank, "per_rank_features_per_step": [int(r[3]) for r in rows],
+            "allgather_us": round(max(r[2] for r in rows), 2), "allgather_bytes_per_rank": int(work.allgather_bytes()),
+            "exchange": work.exchange_name()}
+
+
+def leg_c5_node(env, front_step, front_sync, front_features, ba_solve, ba_release, seconds):
+    """configs[4] as specified: per rank ONE dual-camera sequence -- the main thread extracts + matches one new dual 1280x720 frame per
+    step, the per-frame pattern of the Tracking thread (src/Tracking.cc:236-269) -- next to ONE local BA loop on a second host thread, the
+    LocalMapping thread's Optimizer::LocalBundleAdjustment (src/LocalMapping.cc:97-104). Two windows of `seconds`: the front end alone,
+    then both; the solver alone is timed over a few solves in between."""
+    def front_window(stop_after):
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < stop_after:
+            for _ in range(8):
+                front_step()
+            n += 8
+        front_sync()
+        return n, time.perf_counter() - t0
+    for _ in range(8):
+        front_step()
+    front_sync()
+    env.barrier()
+    n_alone, t_alone = front_window(seconds)
+    ba_solve()
+    it_alone, tb0 = 0, time.perf_counter()
+    while time.perf_counter() - tb0 < min(seconds, 0.5) or it_alone == 0:
+        it_alone += ba_solve()
+    tb_alone = time.perf_counter() - tb0
+    stop, ready = threading.Event(), threading.Event()
+    stat = {"its": 0, "solves": 0, "t": 0.0, "err": None}
+
+    def ba_worker():                                  # the LocalMapping thread: its own solver context (arena, streams) is built by its first solve
+        try:
+            ba_solve()
+            ready.set()
+            t0 = time.perf_counter()
+            while not stop.is_set():
+                stat["its"] += ba_solve()
+                stat["solves"] += 1
+            stat["t"] = time.perf_counter() - t0
+            ba_release()
+        except Exception as e:                        # noqa: BLE001
+            stat["err"] = str(e)
+            ready.set()
+    th = threading.Thread(target=ba_worker)
+    th.start()
+    ready.wait()
+    env.barrier()
+    n_both, t_both = front_window(seconds)
+    stop.set()
+    th.join()
+    if stat["err"]:
+        raise RuntimeError("c5_node solver thread: %s" % stat["err"])
+    f = front_features()
+    rows = env.gather([n_both / t_both, f * n_both / t_both / 1e3, stat["its"] / max(stat["t"], 1e-9), n_alone / t_alone, it_alone / tb_alone, stat["solves"]])
+    return {"workload": "configs[4]: per rank ONE dual 1280x720 sequence (2000 feat/cam, one new dual frame per step: extract + 3 matches, main thread, at most two frames in flight) "
+                        "next to ONE local BA loop (50 KF / 2000 MP / 20k edges, dcs_ba_local on a second host thread)",
+            "n_gpus": env.world, "window_s": seconds,
+            "concurrent": {"dual_frames_s": round(sum(r[0] for r in rows), 1), "kfeatures_s": round(sum(r[1] for r in rows), 1), "ba_iters_s": round(sum(r[2] for r in rows), 1),
+                           "per_rank_dual_frames_s": [round(r[0], 1) for r in rows], "per_rank_ba_iters_s": [round(r[2], 1) for r in rows],
+                           "ba_solves_per_rank": [int(r[5]) for r in rows]},
+            "alone": {"dual_frames_s": round(sum(r[3] for r in rows), 1), "ba_iters_s": round(sum(r[4] for r in rows), 1),
+                      "per_rank_dual_frames_s": [round(r[3], 1) for r in rows], "per_rank_ba_iters_s": [round(r[4], 1) for r in rows]},
+            "concurrent_vs_alone": {"front_end": round(sum(r[0] for r in rows) / max(sum(r[3] for r in rows), 1e-9), 3),
+                                    "ba": round(sum(r[2] for r in rows) / max(sum(r[4] for r in rows), 1e-9), 3)}}
+
+
+class StandInC3:
+    """CPU stand-in of the c3_scaled work for the gloo self-test: slots of the C3 shape, the all-gather of sharding.py, no extraction."""
+    frames_per_step = C3_FRAMES_PER_STEP
+
+    def __init__(self, torch, sharding, rank, world):
+        self.torch, self.sharding, self.rank, self.world, self.cap = torch, sharding, rank, world, C3_CAP_STAND_IN
+        self.kp = torch.full((2, self.cap, 7), float(rank), dtype=torch.float32)
+        self.desc = torch.full((2, self.cap, 32), rank + 1, dtype=torch.uint8)
+        self.n = torch.tensor([1900 + rank, 1950 + rank], dtype=torch.int32)
+        self.ag, self.timed = [], 0
+
+    def run(self, steps, warmup, barrier):
+        for i in range(warmup + steps):
+            if i == warmup:
+                barrier()
+                t0 = time.perf_counter()
+            ta = time.perf_counter()
+            g_kp, g_desc, g_n = self.sharding.allgather_features(self.kp, self.desc, self.n, self.cap)
+            assert g_n.tolist() == [v for r in range(self.world) for v in (1900 + r, 1950 + r)] and tuple(g_desc.shape) == (2 * self.world, self.cap, 32)
+            if i >= warmup:
+                self.ag.append((time.perf_counter() - ta) * 1e6)
+        barrier()
+        self.timed = steps
+        return time.perf_counter() - t0
+
+    def features_per_step(self):
+        return 2 * self.frames_per_step * 1950
+
+    def features_timed(self):
+        return self.features_per_step() * self.timed
+
+    def allgather_us(self):
+        return sum(self.ag) / max(len(self.ag), 1)
+
+    def allgather_bytes(self):
+        return 2 * self.sharding.record_bytes(self.cap)
+
+    def exchange_name(self):
+        return "stand-in: torch.distributed all_gather_into_tensor on gloo"
+
+    def close(self):
+        pass
+
+
+def stand_in_c5(rank):
+    def front_step():
+        time.sleep(0.0005)
+
+    def ba_solve():
+        time.sleep(0.002)
+        return 15
+    return front_step, (lambda: None), (lambda: 3900 + rank), ba_solve, (lambda: None)
 
 
 class Pipeline:
@@ -277,6 +454,112 @@ class Pipeline:
         self.own_streams = []
 
 
+class FeatureExchange:
+    """The per-step exchange of the north star, bound to one Pipeline: all-gather of the newest dual frame's features (2 camera slots per
+    rank) through the library's own RCCL communicator (dcs_features_allgather) or through torch.distributed + pack / unpack, then the
+    cross-GPU relocalisation match: this rank's cam0 against every other rank's cam1. Installed as Pipeline.post_match."""
+
+    def __init__(self, pkg, torch, dist, sharding, dev, rank, world, comm, pipe, stream):
+        self.torch, self.dist, self.sharding, self.comm, self.pipe, self.stream, self.world = torch, dist, sharding, comm, pipe, stream, world
+        cap = self.cap = pipe.cap
+        self.rec = sharding.record_bytes(cap)        # per camera: kp 28 B + desc 32 B per slot + count
+        self.g_kp = torch.zeros((2 * world, cap, 7), dtype=torch.float32, device=dev)
+        self.g_desc = torch.zeros((2 * world, cap, 32), dtype=torch.uint8, device=dev)
+        self.g_n = torch.zeros(2 * world, dtype=torch.int32, device=dev)
+        nx = max(world - 1, 1)
+        self.x_pairs = torch.tensor(sharding.reloc_pairs(rank, world) or [(0, 1)], dtype=torch.int32, device=dev)
+        self.x_match = torch.zeros((nx, cap), dtype=torch.int32, device=dev)
+        self.x_nm = torch.zeros(nx, dtype=torch.int32, device=dev)
+        self.x_b = torch.zeros((nx, cap), dtype=torch.int32, device=dev)
+        self.x_s = torch.zeros((nx, cap), dtype=torch.int32, device=dev)
+        self.g_send = torch.zeros((2, self.rec), dtype=torch.uint8, device=dev)
+        self.g_recv = torch.zeros((2 * world, self.rec), dtype=torch.uint8, device=dev)
+
+    def __call__(self, d_kp, d_desc, d_n, ev):
+        S, cap = self.pipe.S, self.cap
+        if self.comm is not None:
+            ev[2].record()
+            self.comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, self.g_kp, self.g_desc, self.g_n, self.stream)
+            ev[3].record()
+        else:
+            self.sharding.pack_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, self.g_send)
+            ev[2].record()
+            self.dist.all_gather_into_tensor(self.g_recv, self.g_send)
+            ev[3].record()
+            self.sharding.unpack_features(self.g_recv, cap, self.g_kp, self.g_desc, self.g_n)
+        if self.world > 1:
+            self.pipe.matcher.match_bf_batch_device(self.g_desc, self.g_kp, self.g_n, cap, self.x_pairs, self.world - 1, self.x_match, self.x_nm, self.x_b, self.x_s, 50,
+                                                    stream=self.stream)
+
+
+class GpuC3:
+    """the c3_scaled work of one rank: a Pipeline of 64 dual 1280x720 / 2000-feature frames per step + the FeatureExchange"""
+    frames_per_step = C3_FRAMES_PER_STEP
+
+    def __init__(self, pkg, torch, dist, sharding, dev, local_rank, rank, world, comm, stream, exchange_name, n_events):
+        self.torch = torch
+        self.pipe = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 1, self.frames_per_step, 1, rank, n_events, n_sets=2)
+        for e_ in self.pipe.exts:
+            e_.set_timing(0)                          # no stage figures on this leg: no markers on its stream
+        self.x = FeatureExchange(pkg, torch, dist, sharding, dev, rank, world, comm, self.pipe, stream)
+        self.pipe.post_match = self.x
+        self._name, self.steps = exchange_name, 0
+
+    def run(self, steps, warmup, barrier):
+        self.steps = steps
+        return self.pipe.run(steps, warmup, barrier)
+
+    def features_per_step(self):
+        return self.pipe.features_per_step()
+
+    def features_timed(self):
+        return self.pipe.features_in_steps(self.pipe.step_no_timed0, self.steps)
+
+    def allgather_us(self):
+        p = self.pipe
+        evs = [p.ev_all[(p.step_no_timed0 + i) % len(p.ev_all)] for i in range(self.steps)]
+        return sum(e[2].elapsed_time(e[3]) for e in evs) * 1e3 / max(self.steps, 1)
+
+    def allgather_bytes(self):
+        return 2 * self.x.rec
+
+    def exchange_name(self):
+        return self._name
+
+    def close(self):
+        self.pipe.close()
+        del self.x, self.pipe
+        self.torch.cuda.empty_cache()
+
+
+def gpu_c5(pkg, torch, dev, local_rank, rank, n_events=64):
+    """the leaves of leg_c5_node on one GPU: one dual 1280x720 / 2000-feature frame per step (extract + 3 matches) and one C4 local BA"""
+    pipe = Pipeline(pkg, torch, dev, local_rank, 1280, 720, 2000, 1, 1, 1, rank, n_events, n_sets=1)
+    for e_ in pipe.exts:
+        e_.set_timing(0)
+    pkg.abi.ba_avoid_streams([pipe.main_raw] + [s_.cuda_stream for s_ in pipe.lane_streams])      # the solver's streams: other hardware queues
+    prep = pkg.Optimizer.prepare(pkg.synth.ba_problem(seed=42 + rank))
+    pipe.step()
+    torch.cuda.synchronize()
+
+    def front_step():                                 # at most two frames in flight (the two feature slot sets): frame i is enqueued once frame i - 2 is done
+        it = pipe.step_no
+        if it >= pipe.NB:
+            pipe.match_done[it % pipe.NB].synchronize()
+        pipe.step()
+
+    def ba_solve():
+        return int(sum(prep.solve()["n_iters"]))
+
+    def release():
+        pkg.abi.ba_release_thread()
+
+    def close():
+        pipe.close()
+        pkg.abi.ba_avoid_streams([])
+    return front_step, torch.cuda.synchronize, pipe.features_per_step, ba_solve, release, close
+
+
 def run_c5(pkg, torch, dev, local_rank, args, n_ba=8):
     """BASELINE config C5 on ONE GPU: 8 dual-camera streams (1280x720, 2000 features / camera), one new dual frame per stream per
     step, next to one local BA per stream (dcs_ba_local_batch from a second host thread, its own HIP streams). The reference's
@@ -436,16 +719,6 @@ def main():
     exchange_impl = None
     if distributed:
         from orb_slam2_dualcam_amd import sharding
-        rec = sharding.record_bytes(cap)             # per camera: kp 28 B + desc 32 B per slot + count
-        g_kp = torch.zeros((2 * world, cap, 7), dtype=torch.float32, device=dev)
-        g_desc = torch.zeros((2 * world, cap, 32), dtype=torch.uint8, device=dev)
-        g_n = torch.zeros(2 * world, dtype=torch.int32, device=dev)
-        nx = max(world - 1, 1)
-        x_pairs = torch.tensor(sharding.reloc_pairs(rank, world) or [(0, 1)], dtype=torch.int32, device=dev)
-        x_match = torch.zeros((nx, cap), dtype=torch.int32, device=dev)
-        x_nm = torch.zeros(nx, dtype=torch.int32, device=dev)
-        x_b = torch.zeros((nx, cap), dtype=torch.int32, device=dev)
-        x_s = torch.zeros((nx, cap), dtype=torch.int32, device=dev)
         # the exchange of the north star through the library's own communicator (dcs_comm_*, csrc/comm.cpp): brought up once, here,
         # with the unique id broadcast over the process group; every rank must agree on the path, so a failure anywhere (or a bring-up
         # that does not return within 60 s) sends ALL ranks to the torch.distributed path and the line says so
@@ -472,25 +745,9 @@ def main():
                 comm = None
         exchange_impl = "dcs_features_allgather (library-owned RCCL communicator, slot arrays in place)" if comm is not None else \
             "torch.distributed all_gather_into_tensor + pack / unpack" + (" (C-ABI communicator unavailable: %s)" % comm_err if args.exchange == "cabi" else "")
-        g_send = torch.zeros((2, rec), dtype=torch.uint8, device=dev)
-        g_recv = torch.zeros((2 * world, rec), dtype=torch.uint8, device=dev)
-
-        def exchange(d_kp, d_desc, d_n, ev):
-            # exchange the newest dual frame (2 camera slots per rank), then the cross-GPU relocalisation match: this rank's cam0 against
-            # every other rank's cam1
-            if comm is not None:
-                ev[2].record()
-                comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_kp, g_desc, g_n, stream)
-                ev[3].record()
-            else:
-                sharding.pack_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_send)
-                ev[2].record()
-                dist.all_gather_into_tensor(g_recv, g_send)
-                ev[3].record()
-                sharding.unpack_features(g_recv, cap, g_kp, g_desc, g_n)
-            if world > 1:
-                matcher.match_bf_batch_device(g_desc, g_kp, g_n, cap, x_pairs, world - 1, x_match, x_nm, x_b, x_s, 50, stream=stream)
-        pipe.post_match = exchange
+        xchg = FeatureExchange(pkg, torch, dist, sharding, dev, rank, world, comm, pipe, stream)
+        rec = xchg.rec
+        pipe.post_match = xchg
     stage_keys = ("pyramid_us", "fast_us", "compact_us", "blur_us", "quadtree_us", "describe_us", "total_us")
     acc = {k: 0.0 for k in stage_keys}
     acc["match_us"] = 0.0
@@ -593,7 +850,8 @@ def main():
             "value": round(value, 2), "unit": "kfeatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: dual %dx%d stream, %d feat/cam, 8 levels, extract + BF match (3 matches/dual frame)" % (W, H, NF),
+            "config": {"workload": "%s: dual %dx%d stream, %d feat/cam, 8 levels, extract + BF match (3 matches/dual frame)"
+                                   % ({(640, 480, 1000): "configs[1]", (1280, 720, 2000): "configs[2] shape"}.get((W, H, NF), "custom shape (not a BASELINE config)"), W, H, NF),
                        "dual_frames_per_step_per_gpu": P, "extractor_lanes": n_lanes, "features_per_step_per_gpu": n_feat_step,
                        "matches_per_step_per_gpu": n_match_step, "parallelism": "frame-pair shard x%d" % world},
             "roofline": roofline,
@@ -950,8 +1208,9 @@ def main():
         out["bow"] = bow
         V.close()
 
-    # ---- distributed runs: the OTHER exchange path once after the timed region, as a cross-check of the gathered slot arrays
-    # (a watchdog prints the line without this leg if a collective does not come back)
+    # ---- distributed runs: the rank-path legs (configs[2] and configs[4] as an N-GPU run measures them), then the OTHER exchange path once
+    # as a cross-check of the gathered slot arrays. RCCL has never run with more than one rank on the builder's side, so a watchdog prints
+    # the line with whatever is complete if a collective does not come back.
     if distributed:
         printed = threading.Event()
 
@@ -960,23 +1219,44 @@ def main():
                 printed.set()
                 print(json.dumps(out), flush=True)
 
+        done = threading.Event()
+        phase = {"name": "rank legs"}
+
         def watchdog():
-            if not done.wait(60.0):
+            if not done.wait(240.0):
                 if rank == 0:
-                    out["exchange_crosscheck"] = "timed out"
+                    out["watchdog"] = "timed out in: %s" % phase["name"]
                 emit()
                 os._exit(0)
-        done = threading.Event()
         threading.Thread(target=watchdog, daemon=True).start()
+        env = RankEnv(torch, dist, dev, rank, world)
+        if not args.no_rank_legs:
+            res = {}
+            try:
+                phase["name"] = "c3_scaled"
+                res["c3_scaled"] = leg_c3_scaled(env, GpuC3(pkg, torch, dist, sharding, dev, local_rank, rank, world, comm, stream, exchange_impl, 16), steps=8, warmup=2)
+            except Exception as e:                   # noqa: BLE001
+                res["c3_scaled"] = "unavailable: %s" % e
+            if not args.no_ba:
+                try:
+                    phase["name"] = "c5_node"
+                    leaves = gpu_c5(pkg, torch, dev, local_rank, rank)
+                    res["c5_node"] = leg_c5_node(env, *leaves[:5], seconds=args.rank_leg_seconds)
+                    leaves[5]()
+                except Exception as e:               # noqa: BLE001
+                    res["c5_node"] = "unavailable: %s" % e
+            if rank == 0:
+                out.update(res)
+        phase["name"] = "exchange cross-check"
         try:
             d_kp, d_desc, d_n = pipe.last_slots()
             if comm is not None:                     # timed region used the C ABI: compare with torch.distributed
-                sharding.pack_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_send)
-                dist.all_gather_into_tensor(g_recv, g_send)
-                t_kp, t_desc, t_n = sharding.unpack_features(g_recv, cap)
-                comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, g_kp, g_desc, g_n, stream)
+                sharding.pack_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, xchg.g_send)
+                dist.all_gather_into_tensor(xchg.g_recv, xchg.g_send)
+                t_kp, t_desc, t_n = sharding.unpack_features(xchg.g_recv, cap)
+                comm.allgather_features(d_kp[S - 2:], d_desc[S - 2:], d_n[S - 2:], cap, xchg.g_kp, xchg.g_desc, xchg.g_n, stream)
                 torch.cuda.synchronize()
-                same = bool(torch.equal(t_n, g_n) and torch.equal(t_desc, g_desc) and torch.equal(t_kp.view(torch.int32), g_kp.view(torch.int32)))
+                same = bool(torch.equal(t_n, xchg.g_n) and torch.equal(t_desc, xchg.g_desc) and torch.equal(t_kp.view(torch.int32), xchg.g_kp.view(torch.int32)))
                 if rank == 0:
                     out["exchange_crosscheck"] = {"other_path": "torch.distributed all_gather_into_tensor + pack / unpack", "slot_arrays_equal": same}
                 comm.close()

@@ -64,9 +64,14 @@ int dcs_device_count(void);
  *                               the DMA read them in place -- no staging copy on the host
  *   dcs_streams_share_queue     HIP maps a process's streams onto a few hardware queues (four per priority by default), and two streams on one
  *                               queue run strictly one after the other. *shared = 1 when work on b waits for work on a (measured with two
- *                               probe kernels, ~0.1 ms on idle streams; b is synchronised first, the probe takes its turn behind a's backlog)
+ *                               probe kernels, ~0.1 ms on idle streams; b is synchronised first, the probe takes its turn behind a's backlog);
+ *                               *shared = -1 when a's backlog kept the probe kernel from starting within 50 ms: nothing was measured.
+ *                               BOTH calls ENQUEUE WORK on the streams they probe -- a one-wave kernel is parked on stream_a / on every
+ *                               avoid[] stream for up to a millisecond (a null entry = the legacy default stream: every blocking stream of
+ *                               the process waits with it): never call them while one of those streams is being captured into a graph, and
+ *                               create streams at set-up time, not inside a latency-critical section
  *   dcs_stream_create_apart     a non-blocking stream that shares its hardware queue with none of avoid[] (*apart = 0 when the process has
- *                               fewer queues than that needs): for the stream the matcher / a second extraction lane / the solver runs on
+ *                               fewer queues than that needs, or when a backlogged avoid[] stream could not be probed): for the stream the matcher / a second extraction lane / the solver runs on
  *                               next to the caller's front-end stream. The library's own streams are created this way.
  *   dcs_ba_avoid_streams        the solver's streams created AFTER the call (new host threads, or after dcs_ba_release_thread) keep off the
  *                               hardware queues of these streams (the Tracking thread's extraction and matcher streams; n = 0 clears) */
@@ -154,10 +159,15 @@ int  dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* d
 /* number of (image, level) quadtrees of the last call that left the LDS histogram fast path for the general
    sort-based kernel (device-quadtree mode; 0 in host-quadtree mode) */
 int  dcs_orb_debug_quadtree_fallbacks(dcs_orb* h, int* n);
-/* per-stage time of the last extract call in microseconds (hipEvents on the streams the kernels ran on):
-   resize chain, k_fast_cells, scan+gather, k_blur, host quadtree, k_describe, whole call (7 floats) */
+/* per-stage time of the last TIMED extraction in microseconds (hipEvents on the streams the kernels ran on):
+   resize chain, k_fast_cells, scan+gather, k_blur, quadtree, k_describe, whole call (7 floats).
+   Which extractions are timed: calls of MORE than two images under timing mode 1 / 2 (dcs_orb_set_timing). A call of one or two images
+   records no markers (they would cost 45 us of a 160-us dual-frame call) unless the process runs with DCS_ORB_TIMING=1, so after such a
+   call this function fails with DCS_ERR_INVALID "no timing available". A host-buffer call of >= 128 images runs as a pipeline of chunks,
+   each chunk an extraction of its own: the figures describe the LAST CHUNK only. */
 int  dcs_orb_last_timing(dcs_orb* h, float* us7);
-/* sums of the same 7 stage times over every extract call since the last reset. Event sets live in a ring and are read
+/* sums of the same 7 stage times over every TIMED extraction since the last reset; *n_calls counts extractions, i.e. CHUNKS for a
+   chunked host-buffer call (sum / n_calls = per chunk; the sums themselves cover the whole call). Event sets live in a ring and are read
    lazily, so asynchronous (_device) callers are never stalled by the instrumentation. */
 int  dcs_orb_timing_totals(dcs_orb* h, double* sum_us7, int64_t* n_calls, int reset);
 /* what the stage markers above cost: every hipEventRecord is a packet between two kernels on the stream, a call of more than two images

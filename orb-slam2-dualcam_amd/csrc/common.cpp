@@ -111,9 +111,10 @@ __global__ void k_queue_probe_wait(volatile int* go, int* parked)
 }
 __global__ void k_queue_probe_set(int* arrived) { __hip_atomic_store(arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared)
+int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared, bool* conclusive)
 {
     *shared = false;
+    if (conclusive) *conclusive = true;
     if (a == b) { *shared = true; return DCS_OK; }
     int* w = nullptr;                                                      // [0] go, [1] parked, [2] arrived
     DCS_HIP(hipHostMalloc((void**)&w, 64, hipHostMallocDefault));
@@ -137,6 +138,9 @@ int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared)
         t0 = now();
         while (!rd(2) && us_since(t0) < 1000.0) { }
         *shared = rd(1) && !rd(2);
+        // the parked kernel never started (stream a has a backlog of more than 50 ms): nothing was measured -- b's flag arriving says
+        // nothing about the queues. Reported as inconclusive, never as "apart".
+        if (!rd(1) && conclusive) *conclusive = false;
     }
     __atomic_store_n(&w[0], 1, __ATOMIC_RELEASE);
     if (!recorded || hipEventSynchronize(parked_done) != hipSuccess) (void)hipStreamSynchronize(a);     // the parked kernel reads w: it must have ended
@@ -166,12 +170,14 @@ int create_stream_apart(hipStream_t* out, const hipStream_t* avoid, int n_avoid,
         if (s) rejected.push_back(s);
         s = c;
         ok = true;
+        bool undecided = false;
         for (int i = 0; i < n_avoid && ok && probing; ++i) {
-            bool sh = false;
-            if ((rc = streams_share_queue(avoid[i], s, &sh))) break;
-            if (sh) ok = false;
+            bool sh = false, sure = true;
+            if ((rc = streams_share_queue(avoid[i], s, &sh, &sure))) break;
+            if (!sure) { undecided = true; ok = false; }          // a backlogged stream cannot be probed: the candidate is NOT reported apart,
+            else if (sh) ok = false;                              // and more candidates would only wait out the same backlog
         }
-        if (rc) break;
+        if (rc || undecided) break;
     }
     static const bool trace = getenv("DCS_STREAM_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[create_stream_apart] %d streams to keep off, %zu candidates rejected, result %p %s\n", n_avoid, rejected.size(), (void*)s,
@@ -205,9 +211,9 @@ int dcs_streams_share_queue(void* a, void* b, int* shared)
     if (!shared) { dcs::set_error("null output"); return DCS_ERR_INVALID; }
     int rc = dcs::ensure_device();
     if (rc) return rc;
-    bool sh = false;
-    rc = dcs::streams_share_queue((hipStream_t)a, (hipStream_t)b, &sh);
-    *shared = sh ? 1 : 0;
+    bool sh = false, sure = true;
+    rc = dcs::streams_share_queue((hipStream_t)a, (hipStream_t)b, &sh, &sure);
+    *shared = !sure ? -1 : sh ? 1 : 0;
     return rc;
 }
 int dcs_stream_create_apart(void* const* avoid, int n_avoid, void** stream, int* apart)

@@ -77,7 +77,7 @@ struct ThreadArena {
     void* take(bool pinned, size_t bytes);               // 256-byte aligned; nullptr on allocation failure
 };
 ThreadArena& thread_arena();
-int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared);            // measured: does work on b wait for work on a? (common.cpp)
+int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared, bool* conclusive = nullptr);   // measured: does work on b wait for work on a? *conclusive = false when a's backlog kept the probe from starting (common.cpp)
 int create_stream_apart(hipStream_t* out, const hipStream_t* avoid, int n_avoid, bool* apart);   // non-blocking stream on another hardware queue than avoid[]
 hipError_t create_cu_range_stream(hipStream_t* s, int first, int count);   // CUs [first, first + count) of the CU-mask bit order
 
@@ -114,7 +114,7 @@ struct Scratch {
     ~Scratch()
     {
         if (owner) {
-            if (!finished && touched && raw_st) (void)hipStreamSynchronize(raw_st);
+            if (touched && raw_st) (void)hipStreamSynchronize(raw_st);      // finish() clears `touched`; work enqueued after a finish() sets it again
             a.in_call = false;
         }
     }

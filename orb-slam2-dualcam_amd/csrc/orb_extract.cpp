@@ -183,14 +183,15 @@ struct dcs_orb {
     const uint8_t* pageable_hi = nullptr;
     // one or two host images per call: the call's launches replayed as one executable graph (dcs_orb_extract_batch)
     struct SmallGraphKey {
-        const void* stage; const void* d_out; const void* h_out; size_t img_bytes, total; int n, rows, cols, pitch, cap;
+        const void* stage; const void* d_out; const void* h_out; size_t img_bytes, total; int n, rows, cols, pitch, cap; long generation;
         bool operator==(const SmallGraphKey& o) const
-        { return stage == o.stage && d_out == o.d_out && h_out == o.h_out && img_bytes == o.img_bytes && total == o.total && n == o.n && rows == o.rows && cols == o.cols && pitch == o.pitch && cap == o.cap; }
+        { return generation == o.generation && stage == o.stage && d_out == o.d_out && h_out == o.h_out && img_bytes == o.img_bytes && total == o.total && n == o.n && rows == o.rows && cols == o.cols && pitch == o.pitch && cap == o.cap; }
     };
     SmallGraphKey small_graph_key{};
     hipGraphExec_t small_graph_exec = nullptr;
     int small_graph_seen = 0;
     bool small_graph_broken = false;
+    long config_generation = 0;                    // bumped by every configure() that rebuilds the buffers (part of the graph key)
     int fused_mode = -1;                           // DCS_ORB_FUSED_BLUR when the handle is created: 0 / 1, unset = choose per call
     int last_n_images = 0;
 
@@ -223,6 +224,13 @@ int dcs_orb::configure(int rows, int cols)
         set_error("image size %dx%d outside supported range", cols, rows);
         return DCS_ERR_INVALID;
     }
+    // Everything below frees and reallocates the handle's buffers: an executable graph captured for the previous shape holds their old
+    // addresses (d_pyr, d_cells, d_slots, d_dense, d_sel, d_rtab, d_ic_mask ...) and must never be replayed again -- the key of the small-call
+    // graph only covers the staging / output blocks, and a shape change can arrive through dcs_orb_extract_batch_device, which never looks at it.
+    if (small_graph_exec) { (void)hipGraphExecDestroy(small_graph_exec); small_graph_exec = nullptr; }
+    small_graph_seen = 0; small_graph_key = SmallGraphKey{};
+    ++config_generation;
+    configured = false;
     g.build(t, rows, cols);
     const int B = prm.max_images, L = t.nlevels;
     for (int l = 0; l < L; ++l) {
@@ -719,25 +727,40 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     if (stride % 4 == 0 && (reinterpret_cast<uintptr_t>(images[0]) & 3) == 0 && !(getenv("DCS_ORB_HOST_DIRECT") && atoi(getenv("DCS_ORB_HOST_DIRECT")) == 0)) {
         bool even = true;
         if (n_images > 1) {
-            even = images[1] > images[0] && (size_t)(images[1] - images[0]) >= spacing && ((images[1] - images[0]) & 3) == 0;
+            // equally spaced AND close: the spacing decides the size of the device staging and of the one DMA that reads the whole range,
+            // so it is capped at two images' worth (side-by-side frames, a ring with a header per frame); anything wider is packed
+            even = images[1] > images[0] && (size_t)(images[1] - images[0]) >= spacing && (size_t)(images[1] - images[0]) <= 2 * spacing &&
+                   ((images[1] - images[0]) & 3) == 0;
             const size_t d = even ? (size_t)(images[1] - images[0]) : 0;
             for (int i = 2; i < n_images && even; ++i) even = images[i] == images[0] + (size_t)i * d;
             if (even) spacing = d;
         }
         if (even) {
-            auto locked = [](const void* q) {
+            // The WHOLE range [first byte of image 0, last byte of the last image] must lie inside ONE page-locked allocation: the DMA reads
+            // the gaps between the images too, and two frames that were pinned separately (two hipHostRegister'd cv::Mats, two dcs_host_alloc
+            // blocks) are "equally spaced" by construction while the memory between them may be unregistered or unmapped. The allocation's
+            // base and size come from the runtime; a range it cannot vouch for is packed like pageable memory.
+            auto locked_range = [](const uint8_t* lo, const uint8_t* hi) {
                 hipPointerAttribute_t a;
-                if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
-                return a.type == hipMemoryTypeHost;
+                if (hipPointerGetAttributes(&a, lo) != hipSuccess) { (void)hipGetLastError(); return false; }
+                if (a.type != hipMemoryTypeHost) return false;
+                void* base = nullptr; size_t size = 0;
+                if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)lo) != hipSuccess ||
+                    hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)lo) != hipSuccess || !base) {
+                    (void)hipGetLastError();
+                    return false;
+                }
+                const uint8_t* b = static_cast<const uint8_t*>(base);
+                return lo >= b && hi <= b + size;
             };
-            // the query costs tens of microseconds (more for a large block): the handle remembers the last range it found page-locked -- a
+            // the queries cost tens of microseconds (more for a large block): the handle remembers the last range it found page-locked -- a
             // frame ring is handed over again and again. (A stale entry -- the block freed and the addresses reused by pageable memory --
             // costs speed only: hipMemcpyAsync stages pageable sources itself.)
             const uint8_t* lo = images[0];
             const uint8_t* hi = images[n_images - 1] + (size_t)rows * stride;
             if (lo >= h->locked_lo && hi <= h->locked_hi) direct = true;
             else if (lo == h->pageable_lo && hi == h->pageable_hi) direct = false;           // asked before: pageable (a caller that re-uses its buffers)
-            else if ((direct = locked(lo) && locked(hi - 1))) { h->locked_lo = lo; h->locked_hi = hi; }
+            else if ((direct = locked_range(lo, hi))) { h->locked_lo = lo; h->locked_hi = hi; }
             else { h->pageable_lo = lo; h->pageable_hi = hi; }
         }
     }
@@ -897,7 +920,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
         const int graph_env = graph_s ? atoi(graph_s) : -1;
         static const bool timing_always = getenv("DCS_ORB_TIMING") && atoi(getenv("DCS_ORB_TIMING")) != 0;   // stage markers even on small calls: no graph (the events would become graph nodes)
         const bool graph_ok = (graph_env < 0 ? kSmallGraphDefault : graph_env != 0) && n_images <= 2 && !h->no_overlap && !timing_always && !h->small_graph_broken;
-        const dcs_orb::SmallGraphKey key{h->d_stage.p, h->d_out.p, h->h_out.p, img_bytes, total, n_images, rows, cols, pitch_s, cap};
+        const dcs_orb::SmallGraphKey key{h->d_stage.p, h->d_out.p, h->h_out.p, img_bytes, total, n_images, rows, cols, pitch_s, cap, h->config_generation};
         bool replayed = false;
         if (graph_ok && h->small_graph_exec && key == h->small_graph_key) {
             DCS_HIP(hipGraphLaunch(h->small_graph_exec, h->s_main));

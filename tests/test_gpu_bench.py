@@ -26,7 +26,7 @@ def _bench_as_rank(extra):
     env = dict(os.environ)
     env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--pairs", "8", "--cpu-seconds", "0",
-           "--no-ba", "--no-bow", "--no-c3", "--no-c5", "--no-host-api"] + extra
+           "--no-bow", "--no-c3", "--no-c5", "--no-host-api"] + (["--no-ba"] if "--rank-legs-with-ba" not in extra else []) + [e for e in extra if e != "--rank-legs-with-ba"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -35,7 +35,7 @@ def _bench_as_rank(extra):
 
 
 def test_bench_under_rank_env_exchanges_through_the_c_abi():
-    out = _bench_as_rank([])
+    out = _bench_as_rank(["--no-rank-legs"])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["exchange"].startswith("dcs_features_allgather"), out["exchange"]
     assert out["allgather_us"] > 0 and out["allgather_bytes_per_rank"] > 100000
@@ -44,5 +44,20 @@ def test_bench_under_rank_env_exchanges_through_the_c_abi():
 
 
 def test_bench_under_rank_env_torch_exchange():
-    out = _bench_as_rank(["--exchange", "torch"])
+    out = _bench_as_rank(["--exchange", "torch", "--no-rank-legs"])
     assert out["exchange"].startswith("torch.distributed") and out["allgather_us"] > 0 and out["value"] > 0
+
+
+def test_bench_rank_legs_c3_scaled_and_c5_node():
+    """what an N-GPU run measures after the headline -- BASELINE configs[2] (c3_scaled) and configs[4] (c5_node) -- on RCCL at world size 1:
+    the real extraction / matching / exchange / solver behind the same leg code tests/test_bench_launcher.py drives at world size 2 on gloo"""
+    out = _bench_as_rank(["--rank-legs-with-ba", "--rank-leg-seconds", "0.5"])
+    assert out["config"]["workload"].startswith("configs[1]")
+    c3, c5 = out["c3_scaled"], out["c5_node"]
+    assert isinstance(c3, dict) and isinstance(c5, dict), (c3, c5)
+    assert c3["n_gpus"] == 1 and c3["kfeatures_s"] > 0 and c3["exchange"].startswith("dcs_features_allgather")
+    assert 3000 * 128 < c3["per_rank_features_per_step"][0] <= 4000 * 128 // 2 * 2     # 64 dual frames x ~2000 features per camera
+    assert c3["allgather_us"] > 0 and c3["allgather_bytes_per_rank"] == 2 * (2096 * 60 + 64)
+    assert c5["concurrent"]["dual_frames_s"] > 0 and c5["concurrent"]["ba_iters_s"] > 0 and c5["concurrent"]["ba_solves_per_rank"][0] > 0
+    assert c5["alone"]["dual_frames_s"] > 0 and c5["alone"]["ba_iters_s"] > 0
+    assert "watchdog" not in out and out["exchange_crosscheck"]["slot_arrays_equal"] is True
