@@ -159,6 +159,9 @@ int  dcs_orb_debug_candidates(dcs_orb* h, int image, int level, dcs_candidate* d
 /* number of (image, level) quadtrees of the last call that left the LDS histogram fast path for the general
    sort-based kernel (device-quadtree mode; 0 in host-quadtree mode) */
 int  dcs_orb_debug_quadtree_fallbacks(dcs_orb* h, int* n);
+/* which way the last dcs_orb_extract_batch went: *direct = 1 when the DMA read the caller's page-locked frames in place (0: packed into the
+   library's staging), *graph_replayed = 1 when a 1-2 image call was replayed as the handle's executable graph (either may be NULL) */
+int  dcs_orb_debug_host_path(const dcs_orb* h, int* direct, int* graph_replayed);
 /* per-stage time of the last TIMED extraction in microseconds (hipEvents on the streams the kernels ran on):
    resize chain, k_fast_cells, scan+gather, k_blur, quadtree, k_describe, whole call (7 floats).
    Which extractions are timed: calls of MORE than two images under timing mode 1 / 2 (dcs_orb_set_timing). A call of one or two images

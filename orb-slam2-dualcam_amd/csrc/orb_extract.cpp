@@ -191,6 +191,8 @@ struct dcs_orb {
     hipGraphExec_t small_graph_exec = nullptr;
     int small_graph_seen = 0;
     bool small_graph_broken = false;
+    int last_host_path = -1;                       // dcs_orb_debug_host_path: 1 = the last host-buffer call let the DMA read the caller's page-locked frames in place, 0 = packed
+    int last_small_graph = 0;                      // ... and 1 = it was replayed as the small-call graph
     long config_generation = 0;                    // bumped by every configure() that rebuilds the buffers (part of the graph key)
     int fused_mode = -1;                           // DCS_ORB_FUSED_BLUR when the handle is created: 0 / 1, unset = choose per call
     int last_n_images = 0;
@@ -764,6 +766,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
             else { h->pageable_lo = lo; h->pageable_hi = hi; }
         }
     }
+    h->last_host_path = direct ? 1 : 0; h->last_small_graph = 0;
     const int pitch_s = direct ? stride : (cols + 3) & ~3;
     const size_t img_bytes = direct ? spacing : (size_t)rows * pitch_s;
     // (direct: the last image is copied up to its last row only -- the caller's block need not extend to a full spacing behind it)
@@ -948,6 +951,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
             h->small_graph_key = key; h->small_graph_seen = 0;
             if (h->small_graph_exec) { (void)hipGraphExecDestroy(h->small_graph_exec); h->small_graph_exec = nullptr; }
         }
+        h->last_small_graph = replayed ? 1 : 0;
         if (!replayed) {
             if ((rc = h->run(h->d_stage.p, img_bytes, pitch_s, n_images, d_kps, d_dsc, cap, d_cnt, h->s_main, nullptr))) return rc;
             DCS_HIP(hipMemcpyAsync(h->h_out.p, h->d_out.p, total, hipMemcpyDeviceToHost, h->s_main));
@@ -1036,6 +1040,14 @@ int dcs_orb_debug_quadtree_fallbacks(dcs_orb* h, int* n)
     std::vector<int32_t> f((size_t)h->last_tasks);
     DCS_HIP(hipMemcpy(f.data(), h->d_oct_flag.p, sizeof(int32_t) * f.size(), hipMemcpyDeviceToHost));
     for (int32_t v : f) *n += v != 0;
+    return DCS_OK;
+}
+
+int dcs_orb_debug_host_path(const dcs_orb* h, int* direct, int* graph_replayed)
+{
+    if (!h || h->last_host_path < 0) { set_error("dcs_orb_debug_host_path: no host-buffer call yet"); return DCS_ERR_INVALID; }
+    if (direct) *direct = h->last_host_path;
+    if (graph_replayed) *graph_replayed = h->last_small_graph;
     return DCS_OK;
 }
 

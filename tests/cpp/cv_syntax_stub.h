@@ -1,0 +1,70 @@
+// cv_syntax_stub.h -- SYNTAX STAND-IN, PINS NOTHING.
+//
+// A declaration-only sketch of the handful of OpenCV 3.x names that the DCS_WITH_OPENCV half of orb-slam2-dualcam_amd/host/ORBextractor.h
+// touches (cv::Mat, cv::KeyPoint, cv::InputArray, cv::OutputArray, CV_8U / CV_8UC1, CV_Assert), written from the public OpenCV 3 API so
+// that `g++ -fsyntax-only -DDCS_WITH_OPENCV` can parse and type-check that block in an image that has no OpenCV
+// (tests/test_cv_boundary_syntax.py). Nothing here is defined, nothing links, nothing computes: it is not an OpenCV replacement, it is
+// never part of libdcs_hip.so or of the oracle, and no parity claim rests on it. What it does catch: a member the mirror uses that
+// cv::Mat does not have, an argument list that differs from the reference's ORBextractor::operator() (include/ORBextractor.h:59-61), a
+// cv::KeyPoint whose layout is not the 28-byte record of dcs_keypoint.
+#pragma once
+#include <cstddef>
+#include <vector>
+
+#define CV_8U 0
+#define CV_8UC1 0
+#define CV_Assert(expr) do { if (!(expr)) ::cv::error_stub(#expr); } while (0)
+
+namespace cv {
+
+void error_stub(const char* what);
+
+struct Point2f { float x, y; };
+
+// public data members of cv::KeyPoint in declaration order (opencv2/core/types.hpp): pt, size, angle, response, octave, class_id
+struct KeyPoint {
+    Point2f pt;
+    float size, angle, response;
+    int octave, class_id;
+#ifdef DCS_STUB_BREAK_LAYOUT                      // tests/test_cv_boundary_syntax.py::test_the_check_has_teeth: the static_asserts must notice
+    double extra;
+#endif
+};
+
+class _InputArray;
+class _OutputArray;
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
+
+struct MatStep {
+    operator size_t() const;
+};
+
+class Mat {
+public:
+    Mat();
+    Mat(int rows, int cols, int type);
+    Mat(int rows, int cols, int type, void* data, size_t step = 0);
+    int type() const;
+    bool empty() const;
+    Mat rowRange(int startrow, int endrow) const;
+    void copyTo(OutputArray m) const;
+    int rows, cols;
+    unsigned char* data;
+    MatStep step;
+};
+
+class _InputArray {
+public:
+    _InputArray(const Mat& m);
+    bool empty() const;
+    Mat getMat(int idx = -1) const;
+};
+
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray(Mat& m);
+    void release() const;
+};
+
+}  // namespace cv

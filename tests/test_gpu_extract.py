@@ -426,6 +426,70 @@ def test_page_locked_frames_are_read_in_place(pkg, oracle, synth, monkeypatch, W
     hf.close()
 
 
+def test_separately_pinned_frames_are_not_read_as_one_range(pkg, synth, monkeypatch):
+    """A left and a right frame that were pinned SEPARATELY (two dcs_host_alloc blocks, two hipHostRegister'd cv::Mats) are 'equally spaced'
+    by construction, but the memory between them belongs to neither: the in-place path (one DMA over the whole range) is only taken when
+    the range lies inside ONE page-locked allocation, anything else is packed. Same features either way."""
+    H, W = 240, 320
+    a, b = synth.frame_pair(640, 480, 2, 0)
+    one = pkg.abi.HostFrames(2, H, W)
+    left, right = pkg.abi.HostFrames(1, H, W), pkg.abi.HostFrames(1, H, W)
+    pad = pkg.abi.HostFrames(1, 7 * H, W)                                # (keeps the allocator from handing out two adjacent blocks)
+    for dst, src in ((one.frames[0], a), (one.frames[1], b), (left.frames[0], a), (right.frames[0], b)):
+        dst[:] = src[100:100 + H, 150:150 + W]
+    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "0")
+    ext = pkg.ORBextractor(400, 1.2, 8, 20, 7, max_images=2)
+    ref = ext.extract_batch([one.frames[0].copy(), one.frames[1].copy()])
+    assert ext.host_path()[0] == 0                                        # pageable copies: packed
+    kp, d = ext.extract_batch(one.frames, stride=one.stride)
+    assert ext.host_path()[0] == 1                                        # one block: read in place
+    for c in range(2):
+        assert kp[c].tobytes() == ref[0][c].tobytes() and np.array_equal(d[c], ref[1][c])
+    for pair in ([left.frames[0], right.frames[0]], [right.frames[0], left.frames[0]]):
+        order = (0, 1) if pair[0] is left.frames[0] else (1, 0)
+        kp, d = ext.extract_batch(pair, stride=left.stride)
+        assert ext.host_path()[0] == 0, "two allocations were read as one range"
+        for j, c in enumerate(order):
+            assert kp[j].tobytes() == ref[0][c].tobytes() and np.array_equal(d[j], ref[1][c])
+    ext.close()
+    for hf in (one, left, right, pad):
+        hf.close()
+
+
+def test_small_call_graph_is_dropped_when_the_handle_is_reconfigured(pkg, synth, monkeypatch):
+    """The executable graph of a 1-2 image call holds the addresses of the handle's internal buffers; a call of ANOTHER shape through the
+    _device entry point rebuilds them. The next host call of the first shape must not replay the old graph: it is captured
+    anew and every call returns the features of its own frames."""
+    import torch
+    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "1")
+    frames = [synth.frame_pair(640, 480, 3, f) for f in range(4)]
+    small = [[np.ascontiguousarray(im[60:300, 80:400]) for im in fp] for fp in frames]
+    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "0")
+    r = pkg.ORBextractor(500, 1.2, 8, 20, 7, max_images=2)
+    ref = [r.extract_batch(s_) for s_ in small]
+    r.close()
+    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "1")
+    e = pkg.ORBextractor(500, 1.2, 8, 20, 7, max_images=2)
+    for i in range(4):
+        kp, d = e.extract_batch(small[i])
+    assert e.host_path()[1] == 1                                          # replayed by now
+    cap = e.default_cap()
+    big = torch.from_numpy(np.stack(frames[0])).cuda()                    # 640 x 480: every internal buffer grows
+    d_kp = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda"); d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(2, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(big, d_kp, d_desc, d_n, cap)
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for i in range(4):
+            kp, d = e.extract_batch(small[i])
+            if rep == 0 and i == 0:
+                assert e.host_path()[1] == 0, "a graph captured before the reconfiguration was replayed"
+            for c in range(2):
+                assert kp[c].tobytes() == ref[i][0][c].tobytes() and np.array_equal(d[c], ref[i][1][c]), (rep, i, c)
+    assert e.host_path()[1] == 1
+    e.close()
+
+
 def test_one_frame_calls_replayed_as_a_graph(pkg, oracle, synth, monkeypatch):
     """A handle that is called with one or two host images again and again (Frame::ExtractORB, src/Frame.cc:141-149) replays the call's
     launches as one executable graph from the third call of a shape on (DCS_ORB_SMALL_GRAPH=1): every call still returns the features
