@@ -450,6 +450,13 @@ int  dcs_ba_local(const dcs_ba_problem* prob, const volatile uint8_t* stop_flag,
    (estimates copied through, no outliers, zero iterations: Optimizer.cc:582-585). Problems may differ in every size. */
 int  dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* probs, const volatile uint8_t* const* stop_flags,
                         dcs_ba_result* const* results);
+/* Parity tap for rows a14 / a15 (like dcs_orb_debug_level for the extraction stages): the blocks the solver holds after the FIRST
+   linearisation of the problem -- computeActiveErrors, linearizeOplus (Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:123-161) and
+   constructQuadraticForm with the robust kernel (g2o/core/base_binary_edge.hpp:55-120) at the initial estimates, no lambda added, no
+   solve. Hpp [n_free][36] and bp [n_free][6] in free-pose order (pose_idx[p] = index of pose p or -1: fixed poses and poses without an
+   edge), Hll [n_points][9] and bl [n_points][3], Hpl [n_edges][18] = 6 x 3 row-major (pose rows, point columns; zero for edges of fixed
+   poses). Caller-owned arrays sized for n_poses / n_points / n_edges. */
+int  dcs_ba_debug_linearize(const dcs_ba_problem* prob, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, int32_t* pose_idx, int* n_free);
 /* Measurement hook for bench.py (per calling thread): on != 0 makes the following dcs_ba_local[_batch] calls of this thread
    bracket every launch of the reduced-camera-system factorisation (k_ldlt_mfma, the reference's LinearSolverEigen::solve,
    Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:94-124) and every LM step with hipEvents on the solver's stream.

@@ -490,6 +490,41 @@ int orc_ba_local(const orc_ba_problem* pb, const volatile uint8_t* stop_flag, or
     return 0;
 }
 
+/* Parity tap: the blocks of the first linearisation of orc_ba_local -- initializeOptimization, computeActiveErrors, then buildSystem =
+   linearizeOplus (types_six_dof_expmap.cpp:123-161) + constructQuadraticForm with robustInformation (base_binary_edge.hpp:55-120,
+   base_edge.h:96-102) at the initial estimates; no lambda, no solve. Outputs by GLOBAL ids: Hpp / bp in free-pose order with
+   pose_idx[p] = index or -1, Hll / bl per point, Hpl per edge (6 x 3 row-major, zero where the edge's pose is fixed). */
+int orc_ba_linearize(const orc_ba_problem* pb, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, int32_t* pose_idx, int* n_free)
+{
+    Solver s;
+    s.pb = pb; s.stop = nullptr;
+    const int P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+    s.poses.resize(P);
+    for (int p = 0; p < P; ++p) s.poses[p] = pose_from7(pb->poses + 7 * p);
+    s.points.assign(pb->points, pb->points + 3 * (size_t)L);
+    s.cams.resize(pb->n_cams);
+    for (int c = 0; c < pb->n_cams; ++c) s.cams[c] = cam_from(pb->cams[c]);
+    s.level1.assign(E, 0);
+    s.err.assign(2 * (size_t)E, 0.0);
+    s.robust = pb->huber_delta > 0.0;
+    if (!s.init_round()) return -1;
+    s.compute_errors();
+    s.build_system();
+    *n_free = s.np;
+    for (int p = 0; p < P; ++p) pose_idx[p] = s.pose_idx[p];
+    memcpy(Hpp, s.Hpp.data(), sizeof(double) * 36 * (size_t)s.np);
+    memcpy(bp, s.b.data(), sizeof(double) * 6 * (size_t)s.np);
+    memset(Hll, 0, sizeof(double) * 9 * (size_t)L); memset(bl, 0, sizeof(double) * 3 * (size_t)L);
+    for (int li = 0; li < s.nl; ++li) {
+        const int l = s.idx_point[li];
+        memcpy(Hll + 9 * (size_t)l, &s.Hll[(size_t)li * 9], sizeof(double) * 9);
+        memcpy(bl + 3 * (size_t)l, &s.b[(size_t)s.np * 6 + (size_t)li * 3], sizeof(double) * 3);
+    }
+    memset(Hpl, 0, sizeof(double) * 18 * (size_t)E);
+    for (int e = 0; e < E; ++e) if (s.hpl_of_edge[e] >= 0) memcpy(Hpl + 18 * (size_t)e, &s.Hpl[(size_t)s.hpl_of_edge[e] * 18], sizeof(double) * 18);
+    return 0;
+}
+
 /* Optimizer::PoseOptimization (Optimizer.cc:250-405). Per frame: vertex = pose, unary edges; the LM driver is the same
    optimization_algorithm_levenberg.cpp:61-164 as in orc_ba_local with a single 6x6 block and no Schur complement
    (BlockSolver::solve non-Schur branch, block_solver.hpp:354-372; LinearSolverDense = dense LDL^T, isPositive check). */

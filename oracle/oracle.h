@@ -197,6 +197,8 @@ typedef struct orc_ba_result {
 } orc_ba_result;
 
 int orc_ba_local(const orc_ba_problem* prob, const volatile uint8_t* stop_flag, orc_ba_result* res);
+/* the H / b blocks of the first linearisation (parity tap for linearizeOplus + constructQuadraticForm); see ba_oracle.cpp */
+int orc_ba_linearize(const orc_ba_problem* prob, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, int32_t* pose_idx, int* n_free);
 /* RobustKernelHuber::setDelta(delta) + ::robustify (Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp:65-91): rho = {rho(e), rho'(e), rho''(e)} of
    an edge's chi2 e. The one Huber every solver of the oracle uses; pinned against the reference's own statements (oracle/_ref, tests/test_oracle_ref.py). */
 void orc_robust_huber(double delta, double e, double rho[3]);

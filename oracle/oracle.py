@@ -633,6 +633,32 @@ def ba_local(prob, stop_flag=None):
                 chi2_trace=np.array(res.chi2_trace))
 
 
+def ba_linearize(prob):
+    """orc_ba_linearize: H / b blocks after the first linearisation of ba_local's problem (no lambda, no solve)"""
+    poses = _c(prob["poses"], np.float64)
+    fixed = _c(prob["pose_fixed"], np.uint8)
+    points = _c(prob["points"], np.float64)
+    ep, el, ec = (_c(prob[k], np.int32) for k in ("edge_pose", "edge_point", "edge_cam"))
+    obs = _c(prob["obs"], np.float64)
+    w = _c(prob["inv_sigma2"], np.float64)
+    cams = (BaCamera * len(prob["cams"]))(*prob["cams"])
+    P, L, E = len(poses), len(points), len(ep)
+    pb = BaProblem(P, L, E, len(prob["cams"]), _p(poses).value, _p(fixed).value, _p(points).value,
+                   _p(ep).value, _p(el).value, _p(ec).value, _p(obs).value, _p(w).value,
+                   C.cast(cams, C.c_void_p).value,
+                   float(prob.get("huber_delta", np.sqrt(5.991))), float(prob.get("chi2_th", 5.991)),
+                   int(prob.get("iters1", 5)), int(prob.get("iters2", 10)))
+    Hpp, bp, Hll, bl, Hpl = np.zeros((P, 6, 6)), np.zeros((P, 6)), np.zeros((L, 3, 3)), np.zeros((L, 3)), np.zeros((E, 6, 3))
+    pose_idx, n_free = np.zeros(P, np.int32), C.c_int()
+    f = lib().orc_ba_linearize
+    f.restype = C.c_int
+    rc = f(C.byref(pb), _p(Hpp), _p(bp), _p(Hll), _p(bl), _p(Hpl), _p(pose_idx), C.byref(n_free))
+    if rc != 0:
+        raise RuntimeError("orc_ba_linearize rc=%d" % rc)
+    n = n_free.value
+    return dict(Hpp=Hpp[:n], bp=bp[:n], Hll=Hll, bl=bl, Hpl=Hpl, pose_idx=pose_idx, n_free=n)
+
+
 class Vocabulary:
     """DBoW2 vocabulary tree from the columns of the reference's text format (row i = node i + 1)."""
 

@@ -26,7 +26,7 @@ SYMBOLS = [
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_debug_host_path", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_orb_set_timing", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_by_projection_kf", "dcs_search_in_window", "dcs_search_for_initialization",
-    "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
+    "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_debug_linearize", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
     "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_host_alloc", "dcs_host_free", "dcs_streams_share_queue", "dcs_stream_create_apart", "dcs_ba_avoid_streams", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
@@ -127,6 +127,7 @@ def lib():
             "dcs_distinctive_descriptors": [vp, ci, vp, vp, ci, vp],
             "dcs_ba_local": [C.POINTER(BaProblem), vp, C.POINTER(BaResult)],
             "dcs_ba_local_batch": [ci, vp, vp, vp],
+            "dcs_ba_debug_linearize": [C.POINTER(BaProblem), vp, vp, vp, vp, vp, vp, pci],
             "dcs_ba_timing": [ci, vp],
             "dcs_stream_create_cu_range": [ci, ci, C.POINTER(vp)],
             "dcs_streams_share_queue": [vp, vp, pci],
@@ -659,6 +660,15 @@ class PreparedBA:
         sf = _p(stop_flag) if stop_flag is not None else None
         _check(lib().dcs_ba_local(C.byref(self.pb), sf, C.byref(self.res)), "dcs_ba_local")
         return self.result()
+
+    def linearize(self):
+        """dcs_ba_debug_linearize: the H / b blocks after the first linearisation (no lambda, no solve)"""
+        P, L, E = len(self.poses), len(self.points), len(self.ep)
+        Hpp, bp, Hll, bl, Hpl = np.zeros((P, 6, 6)), np.zeros((P, 6)), np.zeros((L, 3, 3)), np.zeros((L, 3)), np.zeros((E, 6, 3))
+        pose_idx, n_free = np.zeros(P, np.int32), C.c_int()
+        _check(lib().dcs_ba_debug_linearize(C.byref(self.pb), _p(Hpp), _p(bp), _p(Hll), _p(bl), _p(Hpl), _p(pose_idx), C.byref(n_free)), "dcs_ba_debug_linearize")
+        n = n_free.value
+        return dict(Hpp=Hpp[:n], bp=bp[:n], Hll=Hll, bl=bl, Hpl=Hpl, pose_idx=pose_idx, n_free=n)
 
     def result(self):
         res = self.res

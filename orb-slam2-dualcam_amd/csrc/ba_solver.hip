@@ -2096,6 +2096,10 @@ int build_round(const dcs_ba_problem* pb, Round& r)
     return -1;
 }
 
+// dcs_ba_debug_linearize: the blocks of the FIRST linearisation (rows a14 / a15) handed back instead of a solve
+struct BaTap { double *Hpp, *bp, *Hll, *bl, *Hpl; int32_t* pose_idx; int* np; };
+thread_local const BaTap* tl_tap = nullptr;
+
 }  // namespace
 
 extern "C" {
@@ -2293,6 +2297,30 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     if (G > 1) {
         DCS_HIP(hipEventRecord(ctx.ev_up, st));
         for (int g = 1; g < G; ++g) DCS_HIP(hipStreamWaitEvent(ctx.aux[g - 1], ctx.ev_up, 0));
+    }
+
+    if (const BaTap* tap = tl_tap) {
+        // parity tap: the first two launches of step 1 -- k_begin (errors of the initial estimates, linearizeOplus, constructQuadraticForm per
+        // edge) and k_reduce_pose (the per-vertex sums) -- then the blocks come down as they lie in the arena and the call ends
+        const BaProb& q = hp[0];
+        hipLaunchKernelGGL(k_begin, dim3(q.nblk, 1), dim3(256), 0, st, (const BaProb*)d_probs, d_ctls, 1, h_words, d_grid_ticket[0]);
+        hipLaunchKernelGGL(k_reduce_pose, dim3(q.np + q.nb_pts, 1), dim3(1024), 0, st, (const BaProb*)d_probs, d_ctls);
+        DCS_CHECK_LAUNCH();
+        DCS_HIP(hipStreamSynchronize(st));
+        ctx.tail_pending = false;
+        if (q.np) {
+            DCS_HIP(hipMemcpy(tap->Hpp, q.Hpp, sizeof(double) * 36 * q.np, hipMemcpyDeviceToHost));
+            DCS_HIP(hipMemcpy(tap->bp, q.bp, sizeof(double) * 6 * q.np, hipMemcpyDeviceToHost));
+        }
+        DCS_HIP(hipMemcpy(tap->Hll, q.Hll, sizeof(double) * 9 * q.L, hipMemcpyDeviceToHost));
+        DCS_HIP(hipMemcpy(tap->bl, q.bl, sizeof(double) * 3 * q.L, hipMemcpyDeviceToHost));
+        DCS_HIP(hipMemcpy(tap->Hpl, q.Hpl, sizeof(double) * 18 * q.E, hipMemcpyDeviceToHost));
+        const dcs_ba_problem* pb0 = problems[live[0]];
+        for (int e = 0; e < q.E; ++e)                          // edges of fixed poses have no H_pl block (the kernel never writes their slot)
+            if (rounds[0].pose_idx[pb0->edge_pose[e]] < 0) for (int k = 0; k < 18; ++k) tap->Hpl[(size_t)e * 18 + k] = 0.0;
+        memcpy(tap->pose_idx, rounds[0].pose_idx.data(), sizeof(int32_t) * q.P);
+        *tap->np = q.np;
+        return DCS_OK;
     }
 
     // ---- launch geometry of one step of a group (its largest problem decides; smaller ones exit early)
@@ -2558,6 +2586,21 @@ int dcs_ba_timing(int on, double out[4])
 int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dcs_ba_result* res)
 {
     return dcs_ba_local_batch(1, &pb, &stop_flag, &res);
+}
+
+int dcs_ba_debug_linearize(const dcs_ba_problem* pb, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, int32_t* pose_idx, int* n_free)
+{
+    if (!pb || !Hpp || !bp || !Hll || !bl || !Hpl || !pose_idx || !n_free) { set_error("dcs_ba_debug_linearize: null argument"); return DCS_ERR_INVALID; }
+    std::vector<double> poses((size_t)7 * std::max(pb->n_poses, 1)), points((size_t)3 * std::max(pb->n_points, 1));
+    std::vector<uint8_t> flags((size_t)std::max(pb->n_edges, 1));
+    dcs_ba_result res{};
+    res.poses = poses.data(); res.points = points.data(); res.edge_outlier = flags.data();
+    dcs_ba_result* rp = &res;
+    const BaTap tap{Hpp, bp, Hll, bl, Hpl, pose_idx, n_free};
+    tl_tap = &tap;
+    const int rc = dcs_ba_local_batch(1, &pb, nullptr, &rp);
+    tl_tap = nullptr;
+    return rc;
 }
 
 int dcs_pose_optimization(const dcs_pose_problem* pb, dcs_pose_result* res)

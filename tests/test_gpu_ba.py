@@ -318,3 +318,45 @@ def test_ba_back_to_back_calls_do_not_inherit_the_previous_calls_progress(pkg, s
         for r, name in zip(out, names):
             for k in keys:
                 assert np.array_equal(r[k], ref[name][0][k]), ("batch", it, name, k)
+
+
+@pytest.mark.parametrize("kw", [dict(n_poses=9, n_fixed=3, n_points=80, obs_per_point=5, seed=21),
+                                dict(n_poses=9, n_fixed=3, n_points=80, obs_per_point=5, seed=21, exact_adjoint=True),
+                                dict(n_poses=14, n_fixed=0, n_points=200, obs_per_point=7, seed=23),
+                                dict(n_poses=50, n_fixed=10, n_points=2000, obs_per_point=10, seed=42)])
+def test_first_linearisation_blocks_vs_oracle(pkg, oracle, synth, kw):
+    """Rows a14 / a15 tapped directly (dcs_ba_debug_linearize): H_pp, H_ll, H_pl, b_p, b_l after ONE linearisation -- computeError,
+    linearizeOplus (types_six_dof_expmap.cpp:123-161: J_pose through the rig's 'adjoint', exact or the reference's with the zero block;
+    J_point through R(T_ext T_mcs)) and constructQuadraticForm with Huber's rho' (base_binary_edge.hpp:55-120) -- block by block against
+    the oracle's buildSystem at rtol 1e-12. A Jacobian sign or a swapped row that Levenberg-Marquardt would still converge through cannot
+    hide here; fixed poses own no block and their edges no H_pl. 5 % of the edges are gross outliers, so both Huber branches are hit."""
+    pb = synth.ba_problem(**kw)
+    if kw.get("n_fixed") == 0:
+        pb = dict(pb); pb["pose_fixed"] = pb["pose_fixed"].copy(); pb["pose_fixed"][4] = 1      # one fixed pose in the middle of the index range
+    got = pkg.Optimizer.prepare(pb).linearize()
+    prob = dict(pb)
+    prob["cams"] = [oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pb["cams"]]
+    exp = oracle.ba_linearize(prob)
+    assert got["n_free"] == exp["n_free"] == int((pb["pose_fixed"] == 0).sum()) and np.array_equal(got["pose_idx"], exp["pose_idx"])
+    for k in ("Hpp", "bp", "Hll", "bl", "Hpl"):
+        g, e = got[k], exp[k]
+        assert g.shape == e.shape
+        scale = np.abs(e).reshape(len(e), -1).max(axis=1).reshape((-1,) + (1,) * (e.ndim - 1))      # per block: entries relative to the block's largest
+        assert np.all(np.abs(g - e) <= 1e-12 * np.maximum(scale, 1e-300)), (k, float(np.abs(g - e).max()))
+    fixed_edges = pb["pose_fixed"][pb["edge_pose"]] != 0
+    assert fixed_edges.any() and not np.any(got["Hpl"][fixed_edges]) and np.any(got["Hpl"][~fixed_edges])
+    assert np.array_equal(got["Hpp"], np.transpose(got["Hpp"], (0, 2, 1)))                         # symmetric by construction (upper entries mirrored)
+    # and the oracle's blocks are what the per-edge Jacobians say (numpy recomposition of one pose block and one point block)
+    i = 0
+    p_of = int(np.nonzero(exp["pose_idx"] == i)[0][0])
+    H, b = np.zeros((6, 6)), np.zeros(6)
+    delta = float(pb["huber_delta"])                           # the float-rounded sqrt(5.991) of Optimizer.cc:515
+    for e_ in np.nonzero(pb["edge_pose"] == p_of)[0]:
+        cam = prob["cams"][int(pb["edge_cam"][e_])]
+        Jp, Jx = oracle.ba_edge_jacobian(pb["poses"][p_of], pb["points"][pb["edge_point"][e_]], cam)
+        err, _z = oracle.ba_edge_error(pb["poses"][p_of], pb["points"][pb["edge_point"][e_]], cam, pb["obs"][e_])
+        w = float(pb["inv_sigma2"][e_])
+        chi2 = w * float(err @ err)
+        rho1 = 1.0 if chi2 <= delta * delta else delta / np.sqrt(chi2)
+        H += rho1 * w * (Jp.T @ Jp); b += -rho1 * w * (Jp.T @ err)
+    assert np.allclose(exp["Hpp"][i], H, rtol=1e-10, atol=1e-9) and np.allclose(exp["bp"][i], b, rtol=1e-10, atol=1e-9)

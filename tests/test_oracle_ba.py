@@ -168,3 +168,37 @@ def test_pose_optimization_oracle(oracle, synth):
     # classification is the chi2 gate on the reported chi2 (float compare, Optimizer.cc:375-377)
     e = slice(off[2], off[6])
     assert np.array_equal(r["outlier"][e] != 0, r["edge_chi2"][e].astype(np.float32) > np.float32(5.991))
+
+
+def test_linearize_blocks_are_the_sums_of_the_edge_jacobians(oracle, synth):
+    """orc_ba_linearize (the checker of the GPU's first-linearisation tap, tests/test_gpu_ba.py) against an independent numpy
+    recomposition: every block of H and b = sum over the vertex's edges of J^T (rho' Omega) J and -J^T (rho' Omega) e with the Jacobians
+    of orc_ba_edge_jacobian (themselves held against central differences above) and g2o's Huber rho' (pinned to its own statements in
+    test_oracle_ref.py); fixed poses own no block, their edges no H_pl."""
+    for exact in (False, True):
+        pb = synth.ba_problem(n_poses=8, n_fixed=2, n_points=50, obs_per_point=4, seed=31, exact_adjoint=exact)
+        prob = dict(pb)
+        prob["cams"] = [oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pb["cams"]]
+        lin = oracle.ba_linearize(prob)
+        P, L, E = len(pb["poses"]), len(pb["points"]), len(pb["obs"])
+        free = np.nonzero(pb["pose_fixed"] == 0)[0]
+        assert lin["n_free"] == len(free) and np.array_equal(np.nonzero(lin["pose_idx"] >= 0)[0], free)
+        Hpp, bp, Hll, bl, Hpl = np.zeros((P, 6, 6)), np.zeros((P, 6)), np.zeros((L, 3, 3)), np.zeros((L, 3)), np.zeros((E, 6, 3))
+        delta = float(pb["huber_delta"])                           # the float-rounded sqrt(5.991) of Optimizer.cc:515
+        n_sat = 0
+        for e in range(E):
+            p, l, cam = int(pb["edge_pose"][e]), int(pb["edge_point"][e]), prob["cams"][int(pb["edge_cam"][e])]
+            Jp, Jx = oracle.ba_edge_jacobian(pb["poses"][p], pb["points"][l], cam)
+            err, _z = oracle.ba_edge_error(pb["poses"][p], pb["points"][l], cam, pb["obs"][e])
+            w = float(pb["inv_sigma2"][e])
+            chi2 = w * float(err @ err)
+            rho1 = 1.0 if chi2 <= delta * delta else delta / np.sqrt(chi2)
+            n_sat += chi2 > delta * delta
+            Hll[l] += rho1 * w * (Jx.T @ Jx); bl[l] += -rho1 * w * (Jx.T @ err)
+            if not pb["pose_fixed"][p]:
+                Hpp[p] += rho1 * w * (Jp.T @ Jp); bp[p] += -rho1 * w * (Jp.T @ err); Hpl[e] = rho1 * w * (Jp.T @ Jx)
+        assert 0 < n_sat < E                                      # both Huber branches
+        tol = dict(rtol=1e-10, atol=1e-8)
+        assert np.allclose(lin["Hpp"], Hpp[free], **tol) and np.allclose(lin["bp"], bp[free], **tol)
+        assert np.allclose(lin["Hll"], Hll, **tol) and np.allclose(lin["bl"], bl, **tol) and np.allclose(lin["Hpl"], Hpl, **tol)
+        assert not np.any(lin["Hpl"][pb["pose_fixed"][pb["edge_pose"]] != 0])
