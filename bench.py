@@ -162,6 +162,7 @@ def leg_c3_scaled(env, work, steps, warmup):
     rate = features of all ranks / the slowest rank's time."""
     dt = work.run(steps, warmup, env.barrier)
     rows = env.gather([dt, work.features_timed(), work.allgather_us(), work.features_per_step()])
+    ag_bytes, x_name = int(work.allgather_bytes()), work.exchange_name()
     work.close()
     dt_max = max(r[0] for r in rows)
     per_rank = [round(r[1] / r[0] / 1e3, 1) for r in rows]
@@ -172,8 +173,8 @@ def leg_c3_scaled(env, work, steps, warmup):
             "dual_frames_s": round(env.world * work.frames_per_step * steps / dt_max, 1),
             "ms_per_step": round(dt_max / steps * 1e3, 3),
             "per_rank_kfeatures_s": per_rank, "per_rank_features_per_step": [int(r[3]) for r in rows],
-            "allgather_us": round(max(r[2] for r in rows), 2), "allgather_bytes_per_rank": int(work.allgather_bytes()),
-            "exchange": work.exchange_name()}
+            "allgather_us": round(max(r[2] for r in rows), 2), "allgather_bytes_per_rank": ag_bytes,
+            "exchange": x_name}
 
 
 def leg_c5_node(env, front_step, front_sync, front_features, ba_solve, ba_release, seconds):

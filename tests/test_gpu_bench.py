@@ -56,7 +56,7 @@ def test_bench_rank_legs_c3_scaled_and_c5_node():
     c3, c5 = out["c3_scaled"], out["c5_node"]
     assert isinstance(c3, dict) and isinstance(c5, dict), (c3, c5)
     assert c3["n_gpus"] == 1 and c3["kfeatures_s"] > 0 and c3["exchange"].startswith("dcs_features_allgather")
-    assert 3000 * 128 < c3["per_rank_features_per_step"][0] <= 4000 * 128 // 2 * 2     # 64 dual frames x ~2000 features per camera
+    assert 1500 * 128 < c3["per_rank_features_per_step"][0] <= 2096 * 128            # 64 dual frames = 128 images x ~2000 features
     assert c3["allgather_us"] > 0 and c3["allgather_bytes_per_rank"] == 2 * (2096 * 60 + 64)
     assert c5["concurrent"]["dual_frames_s"] > 0 and c5["concurrent"]["ba_iters_s"] > 0 and c5["concurrent"]["ba_solves_per_rank"][0] > 0
     assert c5["alone"]["dual_frames_s"] > 0 and c5["alone"]["ba_iters_s"] > 0
