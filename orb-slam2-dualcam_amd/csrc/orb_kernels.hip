@@ -282,46 +282,77 @@ __device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b)));
 }
-__device__ __forceinline__ int fast_arcs(const unsigned (&R)[8], unsigned sgn, unsigned vs)
+// max over the 16 contiguous 9-arcs of the arc's minimum, for ring values X[k] = (x_k, x_{k+8}) in the (lo, hi) halves: 7 suffix + 7 prefix
+// minima, 8 half-swapped minima, 7 maxima (all values are bytes: the signed packed forms order them like the unsigned ones)
+__device__ __forceinline__ unsigned fast_arcs(const unsigned (&X)[8])
 {
-    unsigned D[8], S[8], Q[8];
+    unsigned S[8], Q[8];
+    S[7] = X[7]; Q[0] = X[0];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(D[k]) : "v"(R[k]), "v"(sgn), "v"(vs));    // sign * (ring - centre)
-    S[7] = D[7]; Q[0] = D[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { S[7 - k] = pk_min_i16(D[7 - k], S[8 - k]); Q[k] = pk_min_i16(Q[k - 1], D[k]); }
+    for (int k = 1; k < 8; ++k) { S[7 - k] = pk_min_i16(X[7 - k], S[8 - k]); Q[k] = pk_min_i16(Q[k - 1], X[k]); }
     unsigned best = pk_min_i16_swap(S[0], Q[0]);
 #pragma unroll
     for (int k = 1; k < 8; ++k) best = pk_max_i16(best, pk_min_i16_swap(S[k], Q[k]));
-    const short2_t bb = __builtin_bit_cast(short2_t, best);
-    return max((int)bb.x, (int)bb.y);
+    return best;                                         // (best over the arcs that start at 0..7, at 8..15): the caller takes the larger half
 }
-template <int P>
-__device__ __forceinline__ int fast_score(const uint8_t* b, unsigned th_pk /* th in both halves */)
+// Round 4: no subtraction per ring pixel and no packed compare. min over an arc of (r - v) = (min over the arc of r) - v, so the
+// "brighter" score needs the arc minima of the RAW ring bytes; "darker" is the same on the complemented bytes x = 255 - r = r ^ 0xff
+// (v - r = x - (255 - v)): the polarity enters as ONE xor per packed pair -- a plain 32-bit op, which issues at twice the rate of the
+// v_pk_mad_i16 it replaces (profiles/r03_valu_rate_probe.txt) -- and the score is best(X) - (v ^ mask). Which polarity can hold an arc
+// at the threshold is decided on the raw bytes with 16-bit min / max / sub (the fast class again) before anything is packed.
+// D16Z: the eight "opposite" ring bytes come in through ds_read_u8_d16_hi, which on this hardware (gfx950 with SRAM ECC: "sramecc+" in the
+// architecture string, scratch/probe/lds_probe.hip) writes the byte to bits 16-23 AND zeroes the low half -- the value arrives already
+// shifted, and pack + polarity is ONE v_bitop3_b32 ((hi | lo) ^ mask, a fast-class op) per pair instead of a shift and a merge. The
+// compiler neither emits that form by itself nor tracks the loads of an asm statement, so the 17 loads and their wait are one statement.
+// The host picks D16Z = false (plain byte loads, shift + merge) on a device that does not report sramecc+.
+template <int P, bool D16Z>
+__device__ __forceinline__ int fast_score(const uint8_t* b, int th)
 {
     constexpr int C = 3 * P + 3;
     // ring pixel k (OpenCV's order, starting below the centre) at b[off[k]], its opposite k + 8 at b[2C - off[k]]
     constexpr int off[8] = {C + 3 * P, C + 3 * P + 1, C + 2 * P + 2, C + P + 3, C + 3, C - P + 3, C - 2 * P + 2, C - 3 * P + 1};
-    unsigned R[8];
+    unsigned lo[8], hs[8], v;                            // hs[k] = ring byte k + 8, << 16
+    if (D16Z) {
+        const unsigned a = lds_addr(b);
+        asm volatile("ds_read_u8 %0, %17 offset:%18\n\tds_read_u8 %1, %17 offset:%19\n\tds_read_u8 %2, %17 offset:%20\n\tds_read_u8 %3, %17 offset:%21\n\t"
+                     "ds_read_u8 %4, %17 offset:%22\n\tds_read_u8 %5, %17 offset:%23\n\tds_read_u8 %6, %17 offset:%24\n\tds_read_u8 %7, %17 offset:%25\n\t"
+                     "ds_read_u8_d16_hi %8, %17 offset:%26\n\tds_read_u8_d16_hi %9, %17 offset:%27\n\tds_read_u8_d16_hi %10, %17 offset:%28\n\tds_read_u8_d16_hi %11, %17 offset:%29\n\t"
+                     "ds_read_u8_d16_hi %12, %17 offset:%30\n\tds_read_u8_d16_hi %13, %17 offset:%31\n\tds_read_u8_d16_hi %14, %17 offset:%32\n\tds_read_u8_d16_hi %15, %17 offset:%33\n\t"
+                     "ds_read_u8 %16, %17 offset:%34\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]), "=&v"(lo[6]), "=&v"(lo[7]),
+                       "=&v"(hs[0]), "=&v"(hs[1]), "=&v"(hs[2]), "=&v"(hs[3]), "=&v"(hs[4]), "=&v"(hs[5]), "=&v"(hs[6]), "=&v"(hs[7]), "=&v"(v)
+                     : "v"(a), "n"(off[0]), "n"(off[1]), "n"(off[2]), "n"(off[3]), "n"(off[4]), "n"(off[5]), "n"(off[6]), "n"(off[7]),
+                       "n"(2 * C - off[0]), "n"(2 * C - off[1]), "n"(2 * C - off[2]), "n"(2 * C - off[3]), "n"(2 * C - off[4]), "n"(2 * C - off[5]),
+                       "n"(2 * C - off[6]), "n"(2 * C - off[7]), "n"(C)
+                     : "memory");
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) R[k] = (unsigned)b[off[k]] | ((unsigned)b[2 * C - off[k]] << 16);
-    const unsigned v = b[C], V = v | (v << 16);
-    // which polarity can hold an arc at the threshold: a 9-arc covers two ADJACENT compass pixels (ring 0, 4, 8, 12)
-    unsigned a0, a4, c0, c4;
-    asm("v_pk_max_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(a0) : "v"(R[0]));       // max(r0, r8) in both halves
-    asm("v_pk_max_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(a4) : "v"(R[4]));
-    asm("v_pk_min_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(c0) : "v"(R[0]));
-    asm("v_pk_min_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(c4) : "v"(R[4]));
-    const ushort2_t Vv = __builtin_bit_cast(ushort2_t, V), Tv = __builtin_bit_cast(ushort2_t, th_pk);
-    const unsigned e = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, a0), __builtin_bit_cast(ushort2_t, a4)));
-    const unsigned f = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, c0), __builtin_bit_cast(ushort2_t, c4)));
-    const bool brighter = e > __builtin_bit_cast(unsigned, (ushort2_t)(Vv + Tv));              // equal halves on both sides: one 32-bit compare
-    const bool darker = f < __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(Vv, Tv));
-    const unsigned mV = __builtin_bit_cast(unsigned, (short2_t)(-__builtin_bit_cast(short2_t, V)));
-    // brighter: ring - centre = R * (+1) + (-V); darker: centre - ring = R * (-1) + V
-    int s = fast_arcs(R, brighter ? 0x00010001u : 0xffffffffu, brighter ? mV : V);
-    if (__any(brighter && darker)) {                    // both polarities pass the compass test (rare): the score is the larger one
-        if (brighter && darker) s = max(s, fast_arcs(R, 0xffffffffu, V));
+        for (int k = 0; k < 8; ++k) { lo[k] = b[off[k]]; hs[k] = (unsigned)b[2 * C - off[k]] << 16; }
+        v = b[C];
+    }
+    // a 9-arc covers two ADJACENT compass pixels (ring 0, 4, 8, 12): the test of k_fast_cells step 2, per polarity, on 16-bit lanes
+    const uint16_t r0 = (uint16_t)lo[0], r4 = (uint16_t)lo[4], r8 = (uint16_t)(hs[0] >> 16), r12 = (uint16_t)(hs[4] >> 16), vc = (uint16_t)v;
+    const uint16_t e = min(max(r0, r8), max(r4, r12)), f = max(min(r0, r8), min(r4, r12));
+    // the two compares as SGPR masks (a ballot of the C++ bools is rebuilt by the compiler through v_cndmask + v_cmp_ne: two more vector
+    // instructions per polarity); the selects below read those masks directly
+    const uint16_t up = (uint16_t)(e - vc), down = (uint16_t)(vc - f);
+    unsigned long long m_b, m_d;
+    asm("v_cmp_gt_i16_e64 %0, %1, %2" : "=s"(m_b) : "v"(up), "v"((uint16_t)th));
+    asm("v_cmp_gt_i16_e64 %0, %1, %2" : "=s"(m_d) : "v"(down), "v"((uint16_t)th));
+    const unsigned long long m_both = m_b & m_d;
+    unsigned m;
+    asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(m) : "v"(0x00ff00ffu), "s"(m_b));       // brighter ? 0 : 0x00ff00ff
+    unsigned X[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) X[k] = (hs[k] | lo[k]) ^ m;
+    const short2_t bb = __builtin_bit_cast(short2_t, fast_arcs(X));
+    int s = max((int)bb.x, (int)bb.y) - (int)(v ^ (m & 0xffu));
+    if (m_both != 0) {                                   // wave-uniform, rare: some pixel passes the compass test in BOTH polarities -- its score is the larger one
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[k] ^= 0x00ff00ffu;                                  // (lanes that took the darker polarity above compute the brighter one here: unused)
+        const short2_t dd = __builtin_bit_cast(short2_t, fast_arcs(X));
+        const int s2 = max(s, max((int)dd.x, (int)dd.y) - (int)(v ^ 0xffu));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(s) : "v"(s), "v"(s2), "s"(m_both));
     }
     return max(s, 1) - 1;
 }
@@ -341,7 +372,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* b, unsigned th_pk /* th
 //   4. strict 8-neighbour NMS inside the ROI's detection area, iniTh -> minTh fallback when the cell has no
 //      iniTh keypoint (vKeysCell.empty(), :812), ordered emission into the cell's fixed slot range.
 // LDS: px[rh][P] + score[rh][P] bytes + survivor list (u16), sized by the host for the largest cell.
-template <int P>           // LDS row pitch in bytes (40 / 44: the ROI's own bytes; 48 / 64 / 128: aligned rows): compile-time so that the ring offsets are immediates
+template <int P, bool D16Z>           // P: LDS row pitch in bytes (40 / 44: the ROI's own bytes; 48 / 64 / 128: aligned rows), compile-time so that the ring offsets are immediates; D16Z: see fast_score
 __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
                                                    dcs_candidate* __restrict__ slots, size_t slots_per_image,
                                                    int32_t* __restrict__ cell_count, int map_bytes, int n_images, int sc_bytes, int dbg_stop,
@@ -396,29 +427,45 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
                 for (int r = r0 + kRows * kPasses; r < rh; r += kRows)
                     if (c < nd) { uint32_t w; __builtin_memcpy(&w, src + (size_t)r * lv.pitch + 4 * c, 4); px_dw[r * Pdw + c] = w; }
         } else if (P == 48 && aligned8) {                             // 10 rows x 6 x 8-byte columns per wave pass (rows of 48 bytes)
-            const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
+            // Round 4: buffer loads. The level image is a raw buffer of its valid bytes, a lane's address is ONE 32-bit offset (row r0 of the
+            // ROI, 8-byte column c) that advances by 10 rows per pass with a scalar addend -- no 64-bit multiply-add per row -- and the loads need
+            // no predicates: a lane without a column (lane >= 60, c beyond the ROI) starts out of range, a pass below the ROI reads image rows
+            // that are simply not stored, and anything past the image's last byte returns 0 without touching memory. All five requests are
+            // in flight before the first LDS store (the ROI has at most 44 rows, 38 in this size class); only the stores are predicated.
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img_base), 0, (lv.h - 1) * lv.pitch + lv.w, 0x00020000);
             const int r0 = lane / 6, c = lane - 6 * r0, nq = (shift + rw + 7) >> 3;
-            // the ROI has at most 44 rows (38 in this size class): all of a lane's row loads are requested before the first LDS store
-            // (the loop over a per-lane row count waited for every load in turn)
-            uint2 v[5];
-            bool ok[5];
+            const bool lane_ok = lane < 60 && c < nq;
+            const unsigned voff = lane_ok ? (unsigned)((cd.y0 + r0) * lv.pitch + (cd.x0 - shift) + 8 * c) : 0x80000000u;
+            const unsigned step = 10u * (unsigned)lv.pitch;
+            const int rr = lane_ok ? r0 : 0x10000;                   // "row" of a lane that stores nothing
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            u32x2_t v[5];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int r = r0 + 10 * i;
-                ok[i] = lane < 60 && c < nq && r < rh;
-                if (ok[i]) v[i] = *reinterpret_cast<const uint2*>(src + (size_t)r * lv.pitch + 8 * c);
-            }
+            for (int i = 0; i < 5; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(voff + (unsigned)i * step), 0, 0);
+            uint8_t* const dst = s_px + r0 * P + 8 * c;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) if (ok[i]) *reinterpret_cast<uint2*>(s_px + (r0 + 10 * i) * P + 8 * c) = v[i];
-            if (rh > 50 && lane < 60)                           // taller cells (odd aspect ratios): the rest, row by row
-                for (int r = r0 + 50; r < rh; r += 10)
-                    if (c < nq) *reinterpret_cast<uint2*>(s_px + r * P + 8 * c) = *reinterpret_cast<const uint2*>(src + (size_t)r * lv.pitch + 8 * c);
+            for (int i = 0; i < 5; ++i) if (rr < rh - 10 * i) *reinterpret_cast<u32x2_t*>(dst + 10 * i * P) = v[i];
+            if (rh > 50)                                             // taller cells (odd aspect ratios): the rest, row by row
+                for (int r = r0 + 50; r < rh && lane_ok; r += 10)
+                    *reinterpret_cast<u32x2_t*>(s_px + r * P + 8 * c) = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(voff + (unsigned)(r - r0) * (unsigned)lv.pitch), 0, 0);
         } else if (P != 48 && aligned16 && shift + rw <= 64 && (P & 15) == 0) {        // 16 rows x 4 x 16-byte columns per wave pass
-            const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
-            const int c = lane & 3, nq = (shift + rw + 15) >> 4;
-            // (the five-loads-upfront form of the 8-byte path measured here too: FAST 547.5 vs 543 us on the headline -- not kept)
-            for (int r = lane >> 2; r < rh; r += 16)
-                if (c < nq) *reinterpret_cast<uint4*>(s_px + r * P + 16 * c) = *reinterpret_cast<const uint4*>(src + (size_t)r * lv.pitch + 16 * c);
+            // the same form for the 64-byte class: three passes of 16 rows requested together (ROIs of up to 48 rows), buffer addressing
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img_base), 0, (lv.h - 1) * lv.pitch + lv.w, 0x00020000);
+            const int r0 = lane >> 2, c = lane & 3, nq = (shift + rw + 15) >> 4;
+            const bool lane_ok = c < nq;
+            const unsigned voff = lane_ok ? (unsigned)((cd.y0 + r0) * lv.pitch + (cd.x0 - shift) + 16 * c) : 0x80000000u;
+            const unsigned step = 16u * (unsigned)lv.pitch;
+            const int rr = lane_ok ? r0 : 0x10000;
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t v[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + (unsigned)i * step), 0, 0);
+            uint8_t* const dst = s_px + r0 * P + 16 * c;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (rr < rh - 16 * i) *reinterpret_cast<u32x4_t*>(dst + 16 * i * P) = v[i];
+            if (rh > 48)
+                for (int r = r0 + 48; r < rh && lane_ok; r += 16)
+                    *reinterpret_cast<u32x4_t*>(s_px + r * P + 16 * c) = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + (unsigned)(r - r0) * (unsigned)lv.pitch), 0, 0);
         } else if (aligned && ndw <= 16) {          // 4 rows x 16 dword columns per wave pass (no divisions)
             const uint8_t* src = img_base + (size_t)cd.y0 * lv.pitch + (cd.x0 - shift);
             const int c = lane & 15;
@@ -522,12 +569,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         // pixel that scores >= th; a pixel that scores < th may be stored with a smaller value than cv::FAST's -- it is never
         // emitted and loses every comparison against a neighbour that is (s(q) >= th > both values). A second pass rewrites the
         // first pass's entries (its list is a superset), so every stored score >= min_th is exact then.
-        const unsigned th_pk = (unsigned)th * 0x10001u;
         for (int i = lane; i < n_list; i += 64) {
             const int yx = s_list[i], y = yx >> 8, x = yx & 255;
             int o = (y - 3) * P + (x - 3);
             asm("" : "+v"(o));                          // opaque: keeps the 17 ring offsets non-negative immediates of ONE base address
-            const int s = fast_score<P>(px + o, th_pk);
+            const int s = fast_score<P, D16Z>(px + o, th);
             sc[__mul24(y, sc_pitch) + x] = (uint8_t)s;
         }
         __syncthreads();
@@ -546,8 +592,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
                 s = c[0];
                 if (s >= th) {
                     const uint8_t* cu = c - sc_pitch; const uint8_t* cd2 = c + sc_pitch;
-                    const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)cu[-1], (int)cu[0])), max(max((int)cu[1], (int)cd2[-1]), max((int)cd2[0], (int)cd2[1])));
-                    keep = s > nb;
+                    // seven two-input 16-bit maxima: the compiler's own choice, v_max3_u16, occupies the SIMD 3.3 x as long as a v_max_u16
+                    // (profiles/r04_valu_rate_probe.txt: 2.47 vs 0.75 ticks), so the pairs are pinned with asm
+                    auto mx = [](unsigned a, unsigned b) { unsigned r; asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+                    const unsigned nb = mx(mx(mx(c[-1], c[1]), mx(cu[-1], cu[0])), mx(mx(cu[1], cd2[-1]), mx(cd2[0], cd2[1])));
+                    keep = (unsigned)s > nb;
                 }
             }
             const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
@@ -604,8 +653,17 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
     const size_t shmem = (size_t)fast_cells_lds_bytes(fp);
     static const int dbg_stop = getenv("DCS_FAST_STOP") ? atoi(getenv("DCS_FAST_STOP")) : 0;      // only read by -DDCS_FAST_SECTIONS builds
     const dim3 grid(8, n_launch, (n_images + 7) / 8);
-#define DCS_FAST_LAUNCH(PP) hipLaunchKernelGGL(k_fast_cells<PP>, grid, dim3(64), shmem, s, levels, d_cells, n_cells, ini_th, min_th, d_slots, slots_per_image, \
-                                               d_cell_count, map_bytes, n_images, sc_bytes, dbg_stop, cell0)
+    // the d16_hi form of the score's ring loads needs the zeroing semantics of SRAM-ECC parts (every MI355X): asked once per process
+    static const bool d16z = [] {
+        hipDeviceProp_t pr;
+        int dev = 0;
+        if (getenv("DCS_FAST_D16Z") && atoi(getenv("DCS_FAST_D16Z")) == 0) return false;
+        return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && strstr(pr.gcnArchName, "sramecc+") != nullptr;
+    }();
+#define DCS_FAST_LAUNCH(PP) do { if (d16z) hipLaunchKernelGGL((k_fast_cells<PP, true>), grid, dim3(64), shmem, s, levels, d_cells, n_cells, ini_th, min_th, d_slots, slots_per_image, \
+                                               d_cell_count, map_bytes, n_images, sc_bytes, dbg_stop, cell0); \
+                                 else hipLaunchKernelGGL((k_fast_cells<PP, false>), grid, dim3(64), shmem, s, levels, d_cells, n_cells, ini_th, min_th, d_slots, slots_per_image, \
+                                               d_cell_count, map_bytes, n_images, sc_bytes, dbg_stop, cell0); } while (0)
     if (P == 40) DCS_FAST_LAUNCH(40);
     else if (P == 44) DCS_FAST_LAUNCH(44);
     else if (P == 48) DCS_FAST_LAUNCH(48);

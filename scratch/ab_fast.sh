@@ -2,7 +2,7 @@
 # GPU box: A/B of two builds of the library (scratch/ab/libdcs_hip_base.so vs the in-tree one): stage times solo and overlapped,
 # then PMC instruction counts of k_fast_cells for both
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/abfast; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-BASE=$R/scratch/ab/libdcs_hip_base.so
+BASE=${BASE:-$R/scratch/ab/base/libdcs_hip.so}
 for i in 1 2; do
   for L in $BASE ""; do
     echo "lib=${L:-new} solo: $(DCS_LIB_PATH=$L DCS_ORB_NO_OVERLAP=1 python $R/scratch/time_extract.py 2>&1 | tail -1 | cut -c1-200)"

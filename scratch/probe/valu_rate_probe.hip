@@ -130,6 +130,18 @@ DEF_OP(v_fma_f64, asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(dd) : "v"(ww)))
 DEF_OP(v_add_f64, asm volatile("v_add_f64 %0, %0, %1" : "+v"(dd) : "v"(ww)))
 DEF_OP(v_mul_f64, asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dd) : "v"(ww)))
 DEF_OP(v_lshlrev_b64, asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(dd)))
+// round 4 additions: what the rewritten k_fast_cells / k_describe loops are made of
+DEF_OP(v_bitop3_b32, A3("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x1e"))
+DEF_OP(v_max_i16, A2("v_max_i16 %0, %0, %1"))
+DEF_OP(v_max3_u16, A3("v_max3_u16 %0, %0, %1, %2"))
+DEF_OP(v_mad_i32_i24, A3("v_mad_i32_i24 %0, %0, %1, %2"))
+DEF_OP(v_mul_i32_i24, A2("v_mul_i32_i24 %0, %0, %1"))
+DEF_OP(v_pk_min_i16_plain, A2("v_pk_min_i16 %0, %0, %1"))
+DEF_OP(v_cmp_lt_i32_sdwa, { unsigned long long m; asm volatile("v_cmp_lt_i32_sdwa %0, %1, sext(%2) src0_sel:DWORD src1_sel:WORD_0" : "=s"(m) : "v"(w), "v"(d)); })
+DEF_OP(v_cmp_gt_i16_sgpr, { unsigned long long m; asm volatile("v_cmp_gt_i16_e64 %0, %1, %2" : "=s"(m) : "v"(d), "v"(w)); })
+DEF_OP(v_cmp_gt_u16_vcc, asm volatile("v_cmp_gt_u16 vcc, %0, %1" : : "v"(d), "v"(w) : "vcc"))
+DEF_OP(v_add_u32_sgpr, asm volatile("v_add_u32 %0, %1, %0" : "+v"(d) : "s"(0x200u)))
+DEF_OP(v_xor_b32_lit, asm volatile("v_xor_b32 %0, 0xff00ff, %0" : "+v"(d)))
 DEF_OP(ds_read_b32, { unsigned r_; asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(r_) : "v"((d & 0xffcu))); d ^= r_ & 4; })
 DEF_OP(ds_read_u8, { unsigned r_; asm volatile("ds_read_u8 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(r_) : "v"((d & 0xfffu))); d ^= r_ & 4; })
 
@@ -214,6 +226,8 @@ int main()
     REPORT(v_cvt_f32_u32); REPORT(v_cvt_i32_f32); REPORT(v_cvt_f32_ubyte0); REPORT(v_rndne_f32); REPORT(v_add_f32); REPORT(v_mul_f32); REPORT(v_fma_f32); REPORT(v_mac_f32); REPORT(v_rcp_f32);
     REPORT(v_pk_fma_f32); REPORT(v_pk_add_f32); REPORT(v_pk_mul_f32); REPORT(v_fma_f64); REPORT(v_add_f64); REPORT(v_mul_f64); REPORT(v_lshlrev_b64);
     REPORT(ds_read_b32); REPORT(ds_read_u8);
+    REPORT(v_bitop3_b32); REPORT(v_max_i16); REPORT(v_max3_u16); REPORT(v_mad_i32_i24); REPORT(v_mul_i32_i24); REPORT(v_pk_min_i16_plain);
+    REPORT(v_cmp_lt_i32_sdwa); REPORT(v_cmp_gt_i16_sgpr); REPORT(v_cmp_gt_u16_vcc); REPORT(v_add_u32_sgpr); REPORT(v_xor_b32_lit);
     // what the fp32 peak works out to from the measured issue cost
     {
         const size_t lds = 96 * 1024;
