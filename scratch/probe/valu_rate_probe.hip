@@ -142,6 +142,14 @@ DEF_OP(v_cmp_gt_i16_sgpr, { unsigned long long m; asm volatile("v_cmp_gt_i16_e64
 DEF_OP(v_cmp_gt_u16_vcc, asm volatile("v_cmp_gt_u16 vcc, %0, %1" : : "v"(d), "v"(w) : "vcc"))
 DEF_OP(v_add_u32_sgpr, asm volatile("v_add_u32 %0, %1, %0" : "+v"(d) : "s"(0x200u)))
 DEF_OP(v_xor_b32_lit, asm volatile("v_xor_b32 %0, 0xff00ff, %0" : "+v"(d)))
+// scalar unit: alone, and interleaved with vector instructions of the same wave (do they overlap across the waves of a SIMD?)
+DEF_OP(s_add_u32, { unsigned s_ = 1; asm volatile("s_add_u32 %0, %0, 3" : "+s"(s_) : : "scc"); })
+DEF_OP(s_and_b64, { unsigned long long s_ = 5; asm volatile("s_and_b64 %0, %0, exec" : "+s"(s_) : : "scc"); })
+DEF_OP(s_bcnt1_i32_b64, { unsigned s_; asm volatile("s_bcnt1_i32_b64 %0, exec" : "=s"(s_) : : "scc"); })
+DEF_OP(mix_vslow_s, { unsigned s_ = 1; asm volatile("v_mad_u32_u24 %0, %0, %2, %3\n\ts_add_u32 %1, %1, 3" : "+v"(d), "+s"(s_) : "v"(w), "v"(x) : "scc"); })
+DEF_OP(mix_vfast_s, { unsigned s_ = 1; asm volatile("v_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, 3" : "+v"(d), "+s"(s_) : "v"(w) : "scc"); })
+DEF_OP(mix_vfast_s_s, { unsigned s_ = 1; asm volatile("v_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, 3\n\ts_lshl_b32 %1, %1, 1" : "+v"(d), "+s"(s_) : "v"(w) : "scc"); })
+DEF_OP(mix_vslow_lds, { unsigned r_; asm volatile("v_mad_u32_u24 %0, %0, %2, %3\n\tds_read_u8 %1, %4" : "+v"(d), "=v"(r_) : "v"(w), "v"(x), "v"(x & 0xfffu)); })
 DEF_OP(ds_read_b32, { unsigned r_; asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(r_) : "v"((d & 0xffcu))); d ^= r_ & 4; })
 DEF_OP(ds_read_u8, { unsigned r_; asm volatile("ds_read_u8 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(r_) : "v"((d & 0xfffu))); d ^= r_ & 4; })
 
@@ -226,6 +234,11 @@ int main()
     REPORT(v_cvt_f32_u32); REPORT(v_cvt_i32_f32); REPORT(v_cvt_f32_ubyte0); REPORT(v_rndne_f32); REPORT(v_add_f32); REPORT(v_mul_f32); REPORT(v_fma_f32); REPORT(v_mac_f32); REPORT(v_rcp_f32);
     REPORT(v_pk_fma_f32); REPORT(v_pk_add_f32); REPORT(v_pk_mul_f32); REPORT(v_fma_f64); REPORT(v_add_f64); REPORT(v_mul_f64); REPORT(v_lshlrev_b64);
     REPORT(ds_read_b32); REPORT(ds_read_u8);
+    REPORT(s_add_u32); REPORT(s_and_b64); REPORT(s_bcnt1_i32_b64);
+    report(ctx, "v_mad + s_add (per pair)", k_mix_vslow_s<1>, k_mix_vslow_s<4>, 1);
+    report(ctx, "v_add + s_add (per pair)", k_mix_vfast_s<1>, k_mix_vfast_s<4>, 1);
+    report(ctx, "v_add + 2 s (per triple)", k_mix_vfast_s_s<1>, k_mix_vfast_s_s<4>, 1);
+    report(ctx, "v_mad + ds_read_u8 (pair)", k_mix_vslow_lds<1>, k_mix_vslow_lds<4>, 1);
     REPORT(v_bitop3_b32); REPORT(v_max_i16); REPORT(v_max3_u16); REPORT(v_mad_i32_i24); REPORT(v_mul_i32_i24); REPORT(v_pk_min_i16_plain);
     REPORT(v_cmp_lt_i32_sdwa); REPORT(v_cmp_gt_i16_sgpr); REPORT(v_cmp_gt_u16_vcc); REPORT(v_add_u32_sgpr); REPORT(v_xor_b32_lit);
     // what the fp32 peak works out to from the measured issue cost
