@@ -510,35 +510,55 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         // b = the pixel 3 up and 3 left of the centre: every LDS offset is a non-negative immediate
         // 16-bit VOP2 min / max / sub issue at twice the rate of their 32-bit forms on gfx950 (profiles/r03_valu_rate_probe.txt), and the
         // two polarities fold into ONE compare: brighter <=> e - v > th, darker <=> v - f > th, so pass <=> max(e - v, v - f) > th.
-        auto compass = [&](const uint8_t* b) -> bool {
+        // max(e - v, v - f) of the pixel whose 7 x 7 neighbourhood starts at b: the pixel passes when it exceeds th
+        auto compass_margin = [&](const uint8_t* b) -> uint16_t {
             const uint16_t v = b[3 * P + 3];
             const uint16_t r0 = b[6 * P + 3], r4 = b[3 * P + 6], r8 = b[3], r12 = b[3 * P];
             const uint16_t e = min(max(r0, r8), max(r4, r12)), f = max(min(r0, r8), min(r4, r12));
             const int16_t up = (int16_t)(uint16_t)(e - v), down = (int16_t)(uint16_t)(v - f);
-            return max(up, down) > (int16_t)th;
+            return (uint16_t)max(up, down);
         };
+        auto compass = [&](const uint8_t* b) -> bool { return (int16_t)compass_margin(b) > (int16_t)th; };
         n_list = 0;
         if (dw <= 32) {                                  // two detection rows per round: lanes 0-31 row y, lanes 32-63 row y + 1
-            const bool col_ok = (lane & 31) < dw;
-            const unsigned long long m_col = __builtin_amdgcn_ballot_w64(col_ok);
+            // Round 4: the CU's SCALAR unit is the kernel's second wall (profiles/r04_valu_rate_probe.txt: a two-operand scalar instruction
+            // costs 2.4 ticks of SIMD time, 1.8 x a slow-class vector one; a v_mad + s_add pair runs at the scalar rate), and this loop spent
+            // six scalar instructions per round on the append. Now: the columns outside the detection area are switched off through a per-lane
+            // threshold (no mask to AND), and the compare is a v_cmpx -- it writes the result to EXEC itself, so the rank (v_mbcnt of exec), the
+            // store and the count run on it directly and ONE s_mov restores the full wave: s_bcnt1 + s_lshl1_add + s_mov instead of
+            // s_and + s_bcnt1 + s_lshl1_add + s_and_saveexec + s_mov.
+            const uint16_t th_lane = (lane & 31) < dw ? (uint16_t)th : (uint16_t)0x7fff;
             const uint8_t* b = px + (lane >> 5) * P + (lane & 31);
             unsigned yx = (unsigned)(((3 + (lane >> 5)) << 8) | (3 + (lane & 31)));
             unsigned long long m = 0;
             const unsigned list_addr = lds_addr(s_list);
             unsigned end_addr = list_addr;                                                       // scalar, behind the last entry
+            unsigned long long exec_full;                                                       // the wave's execution mask in this region (restored after every append)
+            asm volatile("s_mov_b64 %0, exec" : "=s"(exec_full));
             // Every lane evaluates the test (a lane outside the detection area reads the score map at worst: still inside
-            // the LDS allocation); its ballot IS the compare's SGPR mask. No branch: the append is one LDS store under exec = m.
+            // the LDS allocation). No branch: the append is one LDS store under exec = the lanes that pass.
             // When dh is odd the upper half-wave's last row lies below the detection area: whatever it appends comes after
             // every valid entry and is cut off by the count below.
             auto round = [&](const uint8_t* bb, unsigned yxr) {
-                m = __builtin_amdgcn_ballot_w64(compass(bb)) & m_col;
-                const unsigned at = ((unsigned)rank_in(m) << 1) + end_addr;
-                // the store runs under exec = m (s_and_saveexec before, one scalar move after: every lane is active here) instead of steering
-                // idle lanes to a spare slot with a v_cndmask: one vector instruction less per round, still no branch
-                unsigned long long saved;
-                asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(m), "v"(at), "v"(yxr) : "memory", "scc");
-                const unsigned cnt = (unsigned)__popcll(m);
-                asm("s_lshl1_add_u32 %0, %1, %0" : "+s"(end_addr) : "s"(cnt) : "scc");      // end_addr += 2 cnt in one scalar instruction
+                const uint16_t mg = compass_margin(bb);
+                unsigned at, cnt;
+                asm volatile("v_cmpx_gt_i16_e64 %[m], %[mg], %[thl]\n\t"
+#ifndef DCS_FAST_CMPX_NOP
+#define DCS_FAST_CMPX_NOP 4
+#endif
+#define DCS_STR2(x) #x
+#define DCS_STR(x) DCS_STR2(x)
+                             "s_nop " DCS_STR(DCS_FAST_CMPX_NOP) "\n\t"      // v_cmpx writes EXEC, the v_mbcnt behind it reads exec_lo as DATA: wait states the assembler does not insert
+                             "v_mbcnt_lo_u32_b32 %[at], exec_lo, 0\n\t"
+                             "v_mbcnt_hi_u32_b32 %[at], exec_hi, %[at]\n\t"
+                             "v_lshl_add_u32 %[at], %[at], 1, %[end]\n\t"
+                             "ds_write_b16 %[at], %[yx]\n\t"
+                             "s_bcnt1_i32_b64 %[cnt], exec\n\t"
+                             "s_lshl1_add_u32 %[end], %[cnt], %[end]\n\t"
+                             "s_mov_b64 exec, %[full]"
+                             : [m] "=&s"(m), [at] "=&v"(at), [cnt] "=&s"(cnt), [end] "+s"(end_addr)
+                             : [mg] "v"(mg), [thl] "v"(th_lane), [yx] "v"(yxr), [full] "s"(exec_full)
+                             : "memory", "scc");
             };
             // four rounds per trip: the later ones' LDS reads are immediate offsets of the first one's address, and the loop's
             // scalar bookkeeping is paid once per eight rows

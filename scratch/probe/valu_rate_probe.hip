@@ -146,6 +146,12 @@ DEF_OP(v_xor_b32_lit, asm volatile("v_xor_b32 %0, 0xff00ff, %0" : "+v"(d)))
 DEF_OP(s_add_u32, { unsigned s_ = 1; asm volatile("s_add_u32 %0, %0, 3" : "+s"(s_) : : "scc"); })
 DEF_OP(s_and_b64, { unsigned long long s_ = 5; asm volatile("s_and_b64 %0, %0, exec" : "+s"(s_) : : "scc"); })
 DEF_OP(s_bcnt1_i32_b64, { unsigned s_; asm volatile("s_bcnt1_i32_b64 %0, exec" : "=s"(s_) : : "scc"); })
+DEF_OP(s_waitcnt_idle, asm volatile("s_waitcnt lgkmcnt(0)"))
+DEF_OP(s_nop_0, asm volatile("s_nop 0"))
+DEF_OP(s_saveexec_pair, { unsigned long long s_; asm volatile("s_and_saveexec_b64 %0, exec\n\ts_mov_b64 exec, %0" : "=&s"(s_) : : "scc"); })
+DEF_OP(s_cmp_cbranch, asm volatile("s_cmp_eq_u32 s0, s0\n\ts_cbranch_scc0 1f\n\ts_nop 0\n1:" : : : "scc"))
+DEF_OP(s_mov_b32, { unsigned s_; asm volatile("s_mov_b32 %0, 7" : "=s"(s_)); })
+DEF_OP(s_add_indep4, { unsigned a_ = 1, b_ = 2, c_ = 3, e_ = 4; asm volatile("s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 3\n\ts_add_u32 %2, %2, 3\n\ts_add_u32 %3, %3, 3" : "+s"(a_), "+s"(b_), "+s"(c_), "+s"(e_) : : "scc"); })
 DEF_OP(mix_vslow_s, { unsigned s_ = 1; asm volatile("v_mad_u32_u24 %0, %0, %2, %3\n\ts_add_u32 %1, %1, 3" : "+v"(d), "+s"(s_) : "v"(w), "v"(x) : "scc"); })
 DEF_OP(mix_vfast_s, { unsigned s_ = 1; asm volatile("v_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, 3" : "+v"(d), "+s"(s_) : "v"(w) : "scc"); })
 DEF_OP(mix_vfast_s_s, { unsigned s_ = 1; asm volatile("v_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, 3\n\ts_lshl_b32 %1, %1, 1" : "+v"(d), "+s"(s_) : "v"(w) : "scc"); })
@@ -234,7 +240,10 @@ int main()
     REPORT(v_cvt_f32_u32); REPORT(v_cvt_i32_f32); REPORT(v_cvt_f32_ubyte0); REPORT(v_rndne_f32); REPORT(v_add_f32); REPORT(v_mul_f32); REPORT(v_fma_f32); REPORT(v_mac_f32); REPORT(v_rcp_f32);
     REPORT(v_pk_fma_f32); REPORT(v_pk_add_f32); REPORT(v_pk_mul_f32); REPORT(v_fma_f64); REPORT(v_add_f64); REPORT(v_mul_f64); REPORT(v_lshlrev_b64);
     REPORT(ds_read_b32); REPORT(ds_read_u8);
-    REPORT(s_add_u32); REPORT(s_and_b64); REPORT(s_bcnt1_i32_b64);
+    REPORT(s_add_u32); REPORT(s_and_b64); REPORT(s_bcnt1_i32_b64); REPORT(s_waitcnt_idle); REPORT(s_nop_0); REPORT(s_mov_b32);
+    report(ctx, "s_and_saveexec + s_mov exec (pair)", k_s_saveexec_pair<1>, k_s_saveexec_pair<4>, 1);
+    report(ctx, "s_cmp + s_cbranch + s_nop (triple)", k_s_cmp_cbranch<1>, k_s_cmp_cbranch<4>, 1);
+    report(ctx, "4 independent s_add (per four)", k_s_add_indep4<1>, k_s_add_indep4<4>, 1);
     report(ctx, "v_mad + s_add (per pair)", k_mix_vslow_s<1>, k_mix_vslow_s<4>, 1);
     report(ctx, "v_add + s_add (per pair)", k_mix_vfast_s<1>, k_mix_vfast_s<4>, 1);
     report(ctx, "v_add + 2 s (per triple)", k_mix_vfast_s_s<1>, k_mix_vfast_s_s<4>, 1);
