@@ -824,28 +824,66 @@ def main():
         # rocprofv3 --pmc passes of this same command (profiles/, produced by tools/collect_profiles.sh) and are labelled "imported";
         # they are used only when the workload matches. A "launch" of the roofline kernel = its launches of ONE step (FAST runs one
         # launch per LDS size class), timed together by the hipEvents around the stage.
-        traffic, counters_src, pmc_k = None, None, {}
-        for prof in ("r03_pmc_counters.json",):
+        traffic, traffic_raw, counters_src, pmc_k = None, None, None, {}
+        for prof in ("r04_pmc_counters.json", "r03_pmc_counters.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if (P, W, H, NF, LN) == tuple(pmc.get("bench_args", ())):
                     pmc_k = pmc["kernels"]
                     kk = pmc_k[dom.split("(")[0].split("+")[0]]
-                    traffic = int((kk["FETCH_SIZE_per_step"] + kk["WRITE_SIZE_per_step"]) * 1024 / LN)
-                    counters_src = "imported: profiles/%s (rocprofv3 --pmc passes of this command, collected in a separate run)" % prof
+                    # FETCH_SIZE counts the L2's line requests at 64 B each; the lines are 128 B: a kernel that reads a known number of bytes with
+                    # 4- / 8- / 12- / 16-byte loads per lane is reported at exactly half (profiles/r04_fetch_calibration.json,
+                    # scratch/probe/fetch_calib.hip), so the corrected figure is 2 x FETCH_SIZE. WRITE_SIZE is taken as reported (not calibrated;
+                    # a tenth of the total here). Below the algorithmic bytes = part of the pyramid (written by k_resize just before) is still
+                    # in the 256 MB Infinity Cache / the L2s when it is read.
+                    traffic_raw = int((kk["FETCH_SIZE_per_step"] + kk["WRITE_SIZE_per_step"]) * 1024 / LN)
+                    traffic = int((2 * kk["FETCH_SIZE_per_step"] + kk["WRITE_SIZE_per_step"]) * 1024 / LN)
+                    counters_src = "imported: profiles/%s (rocprofv3 --pmc passes of this command, collected in a separate run); traffic = 2 x FETCH_SIZE + WRITE_SIZE " \
+                                   "(128-byte lines counted at 64 B: profiles/r04_fetch_calibration.json), traffic_raw = as reported" % prof
                     break
             except Exception:
                 traffic = None
-        # share of the vector-ALU issue slots a kernel's instructions take while it runs: SQ_INSTS_VALU x 4 cycles (one wave64 instruction
-        # occupies a SIMD for 4 cycles, profiles/r03_valu_rate_probe.txt) / (1024 SIMDs x stage duration x 2.4 GHz)
+        # Issue pressure per unit while a kernel runs, each as [lo, hi] (profiles/r04_valu_rate_probe.txt, r03_lds_rate_probe.txt; 1 tick = 1 / 720 MHz):
+        #   valu  SQ_INSTS_VALU x cost / (1024 SIMDs x duration); hi prices every instruction at the slow class (1.33 ticks = 4.3 shader cycles), lo
+        #         at the fast / slow mix of the kernel's loop code (tools/isa_class_mix.py -> profiles/r04_isa_class_mix.json; fast = 0.8 ticks)
+        #   lds   SQ_INSTS_LDS x 2.5 (reads) .. 4.2 (writes, wide reads) CU-cycles / (256 CUs x duration x 2.39 GHz)
+        #   salu  SQ_INSTS_SALU x cost / (1024 x duration): lo prices the loop code's static mix of two-operand (2.4 ticks), one-operand (1.3) and
+        #         wait / branch / compare (0.4) scalar instructions, hi every instruction at 1.3 ticks -- the scalar unit is shared by the CU's four SIMDs
+        try:
+            mix = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_class_mix.json")))["kernels"]
+        except Exception:
+            mix = {}
+        mix_key = {"k_resize": "k_resize<true>", "k_fast_cells": "k_fast_cells<48, true>", "k_describe": "k_describe<true>", "k_blur": "k_blur_fold"}
+        TICK_NS = 1.0 / 0.72
         for k in kernels:
-            kk = pmc_k.get(k.split("(")[0].split("+")[0])
-            if kk and "SQ_INSTS_VALU_per_step" in kk and dur[k] > 0:
-                kernels[k]["valu_issue_frac"] = round(kk["SQ_INSTS_VALU_per_step"] / LN * 4.0 / (4 * N_CU * dur[k] * 1e-6 * 2.4e9), 4)
+            base = k.split("(")[0].split("+")[0]
+            kk = pmc_k.get(base)
+            if not kk or dur[k] <= 0:
+                continue
+            simd_ns = 4 * N_CU * dur[k] * 1e3
+            m = mix.get(mix_key.get(base, base), {})
+            loops = m.get("loops") or {}
+            scope = loops if loops.get("valu_fast", 0) + loops.get("valu_slow", 0) >= 60 else (m.get("all") or {})
+            if "SQ_INSTS_VALU_per_step" in kk:
+                nv = kk["SQ_INSTS_VALU_per_step"] / LN
+                lo_t = scope.get("ticks_per_valu_instruction", 1.33)
+                kernels[k]["valu_issue_frac"] = [round(nv * lo_t * TICK_NS / simd_ns, 4), round(nv * 1.33 * TICK_NS / simd_ns, 4)]
+                kernels[k]["valu_fast_class_share"] = scope.get("valu_fast_share")
+            if "SQ_INSTS_LDS_per_step" in kk:
+                nl = kk["SQ_INSTS_LDS_per_step"] / LN
+                kernels[k]["lds_issue_frac"] = [round(nl * c_ / (N_CU * dur[k] * 1e-6 * 2.39e9), 4) for c_ in (2.5, 4.2)]
+            if "SQ_INSTS_SALU_per_step" in kk:
+                ns_ = kk["SQ_INSTS_SALU_per_step"] / LN
+                n_sc = scope.get("sop2", 0) + scope.get("sop1", 0) + scope.get("s_other", 0)
+                lo_c = (2.4 * scope.get("sop2", 0) + 1.3 * scope.get("sop1", 0) + 0.4 * scope.get("s_other", 0)) / n_sc if n_sc else 1.3
+                kernels[k]["salu_issue_frac"] = sorted([round(ns_ * lo_c * TICK_NS / simd_ns, 4), round(ns_ * 1.3 * TICK_NS / simd_ns, 4)])
         roofline = dict(kernel=dom, bound="hbm", achieved=kernels[dom]["gbps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(kernels[dom]["gbps"] / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=counters_src,
+                        frac=round(kernels[dom]["gbps"] / HBM_PEAK_GBS, 5), traffic=traffic, traffic_raw=traffic_raw, traffic_source=counters_src,
                         algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(dur[dom], 2),
-                        valu_issue_frac=kernels[dom].get("valu_issue_frac"))
+                        valu_issue_frac=kernels[dom].get("valu_issue_frac"), lds_issue_frac=kernels[dom].get("lds_issue_frac"),
+                        salu_issue_frac=kernels[dom].get("salu_issue_frac"),
+                        note="an integer stencil at ~38 vector + 23 scalar + 11 LDS operations per pixel: the byte roof is not its wall; the three issue fractions are -- "
+                             "no unit is saturated, each carries 0.6-0.8 of its rate (DESIGN.md section 4)")
         out = {
             "metric": "dual-frame ORB extract+match kfeatures/s; local-BA iters/s (50 KF / 2k MP)",
             "value": round(value, 2), "unit": "kfeatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -502,8 +502,11 @@ static void launch_knn2_pairs_mfma(const uint8_t* desc, const int32_t* n_feat, i
                                    int32_t* best_d, int32_t* second_d, hipStream_t s)
 {
     static const bool force_i8 = getenv("DCS_KNN2_I8") && atoi(getenv("DCS_KNN2_I8")) != 0;
+    // DCS_KNN2_LDS_PAD: extra dynamic LDS per workgroup = fewer matcher workgroups per CU (measurement aid: the matcher runs underneath the
+    // next step's resize chain, whose waves then find fewer registers taken)
+    static const int lds_pad = getenv("DCS_KNN2_LDS_PAD") ? atoi(getenv("DCS_KNN2_LDS_PAD")) : 0;
     if (cap <= kFp4MaxCap && !force_i8)
-        hipLaunchKernelGGL(k_knn2_pairs_fp4, dim3((cap + kKnn4Q - 1) / kKnn4Q, n_pairs), dim3(64 * kKnnWaves), 0, s, desc, n_feat, cap, pairs, best_idx, best_d, second_d);
+        hipLaunchKernelGGL(k_knn2_pairs_fp4, dim3((cap + kKnn4Q - 1) / kKnn4Q, n_pairs), dim3(64 * kKnnWaves), (size_t)lds_pad, s, desc, n_feat, cap, pairs, best_idx, best_d, second_d);
     else
         hipLaunchKernelGGL(k_knn2_pairs_mfma, dim3((cap + kKnnQ - 1) / kKnnQ, n_pairs), dim3(64 * kKnnWaves), 0, s, desc, n_feat, cap, pairs, best_idx, best_d, second_d);
 }
