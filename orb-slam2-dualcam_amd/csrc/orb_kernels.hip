@@ -1632,6 +1632,12 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // previous keypoint's LDS reads are done
         __builtin_amdgcn_wave_barrier();
         uint8_t* praw = reinterpret_cast<uint8_t*>(patch);
+#ifdef DCS_DESC_SHARE_BOUND       // measurement aid (wrong descriptors): staging + horizontal pass only for a wave's FIRST keypoint = the bound of any scheme that shares horizontal sums
+        const bool do_h = kk == 0;
+#else
+        constexpr bool do_h = true;
+#endif
+        if (do_h) {
         if (wide) {                                           // wave-uniform
             *reinterpret_cast<uint4*>(praw + r_lane * kRawPitch + 16 * c4) = q0;
             *reinterpret_cast<uint4*>(praw + (r_lane + 16) * kRawPitch + 16 * c4) = q1;
@@ -1659,7 +1665,9 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int shift_now = shift;
+#ifndef DCS_DESC_SHARE_BOUND
         if (kq + 1 < min(n_here, wave * kDescPerWave + kDescPerWave)) fetch(kq + 1);        // next keypoint's loads fly during this one's work
+#endif
         // ---- horizontal pass: h[row][c] = sum_k tap[k] raw[row][c + k] (<= 65 535) for 48 rows x 37 columns as 3 x 3 matrix instructions.
         // A = 16 staged bytes of row 16 mt + mc, k-group mg; B (column tile nt) = the taps at byte offset shift + 16 nt + mc - 16 mg of that
         // k-group, read from the 24-entry table. Register r of lane (mc, mg) holds row 16 mt + 4 mg + r, column 16 nt + mc: rows
@@ -1686,6 +1694,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
                 if (mc < 8) { o[32] = (unsigned)d2.x | ((unsigned)d2.y << 16); o[32 + kHCols] = (unsigned)d2.z | ((unsigned)d2.w << 16); }
             }
         }
+        }       // do_h
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
