@@ -1103,7 +1103,7 @@ def main():
             e_.set_timing(0)
         dt2 = p2.run(args.steps, args.warmup)
         f2 = p2.features_in_steps(p2.step_no_timed0, args.steps)
-        out["two_lanes"] = {"workload": "the headline batch split over 2 extraction lanes (DESIGN.md section 7)", "kfeatures_s": round(f2 / dt2 / 1e3, 2),
+        out["two_lanes"] = {"workload": "the headline batch split over 2 extraction lanes (NOTES.md section 7 item 11)", "kfeatures_s": round(f2 / dt2 / 1e3, 2),
                             "ms_per_step": round(dt2 / args.steps * 1e3, 3), "vs_one_lane": round(f2 / dt2 / 1e3 / max(out["value"], 1e-9), 4)}
         p2.close()
         del p2

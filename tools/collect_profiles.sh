@@ -3,7 +3,7 @@
 # bench line, rocprofv3 kernel stats of the same command and of the timed region alone, every kernel ALONE (--serial + DCS_ORB_NO_OVERLAP=1),
 # BA-only traces, and the FETCH_SIZE / WRITE_SIZE / SQ PMC passes (separate runs, --kernel-trace only) -> gpurun_out/<tag>/;
 # the files DESIGN.md cites are copied from there into profiles/ (tracked).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 HEAD="--cpu-seconds 0 --no-ba --no-bow --no-c3 --no-c5 --no-host-api"
