@@ -846,7 +846,8 @@ def main():
         # Issue pressure per unit while a kernel runs, each as [lo, hi] (profiles/r04_valu_rate_probe.txt, r03_lds_rate_probe.txt; 1 tick = 1 / 720 MHz):
         #   valu  SQ_INSTS_VALU x cost / (1024 SIMDs x duration); hi prices every instruction at the slow class (1.33 ticks = 4.3 shader cycles), lo
         #         at the fast / slow mix of the kernel's loop code (tools/isa_class_mix.py -> profiles/r04_isa_class_mix.json; fast = 0.8 ticks)
-        #   lds   SQ_INSTS_LDS x 2.5 (reads) .. 4.2 (writes, wide reads) CU-cycles / (256 CUs x duration x 2.39 GHz)
+        #   lds   SQ_INSTS_LDS x cost / (256 CUs x duration x 2.39 GHz); lo: every instruction a plain read (2.5 CU-cycles), hi: the loop code's static mix of
+        #         reads (2.5) and writes / wide reads / permutes (4.2)
         #   salu  SQ_INSTS_SALU x cost / (1024 x duration): lo prices the loop code's static mix of two-operand (2.4 ticks), one-operand (1.3) and
         #         wait / branch / compare (0.4) scalar instructions, hi every instruction at 1.3 ticks -- the scalar unit is shared by the CU's four SIMDs
         try:
@@ -871,7 +872,9 @@ def main():
                 kernels[k]["valu_fast_class_share"] = scope.get("valu_fast_share")
             if "SQ_INSTS_LDS_per_step" in kk:
                 nl = kk["SQ_INSTS_LDS_per_step"] / LN
-                kernels[k]["lds_issue_frac"] = [round(nl * c_ / (N_CU * dur[k] * 1e-6 * 2.39e9), 4) for c_ in (2.5, 4.2)]
+                n_r, n_w = scope.get("lds_read", 0), scope.get("lds_write", 0)
+                c_mix = (2.5 * n_r + 4.2 * n_w) / (n_r + n_w) if n_r + n_w else 4.2          # static read / write mix of the kernel's loop code
+                kernels[k]["lds_issue_frac"] = [round(nl * c_ / (N_CU * dur[k] * 1e-6 * 2.39e9), 4) for c_ in (2.5, c_mix)]
             if "SQ_INSTS_SALU_per_step" in kk:
                 ns_ = kk["SQ_INSTS_SALU_per_step"] / LN
                 n_sc = scope.get("sop2", 0) + scope.get("sop1", 0) + scope.get("s_other", 0)

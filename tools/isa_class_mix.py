@@ -6,7 +6,7 @@ separately for ALL basic blocks and for the blocks LLVM marks as part of a loop 
               (0.75-0.85 ticks of 720 MHz per wave instruction and SIMD = 2.5 shader cycles) -- unless an operand is an SGPR or the
               instruction is an SDWA / DPP form: those issue at the slow rate
   valu_slow   everything else on the vector ALU (1.25-1.4 ticks = 4.3 cycles); v_max3/min3/med3_*16 and v_rcp/rsq/sqrt count double (2.5 ticks)
-  mfma, lds (ds_*), vmem (buffer_/global_/flat_/scratch_), sop2 (two-operand scalar: 2.4 ticks), sop1_other (1.3), s_wait_nop (0.3-0.4)
+  mfma, lds_read / lds_write (ds_*: plain reads 2.5 CU-cycles; writes, atomics, permutes and 12-/16-byte reads 4.2), vmem (buffer_/global_/flat_/scratch_), sop2 (two-operand scalar: 2.4 ticks), sop1_other (1.3), s_wait_nop (0.3-0.4)
 usage: tools/isa_class_mix.py <out.json>"""
 import json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +27,7 @@ def classify(line):
         sgpr_src = re.search(r"\b(s\d+|s\[\d+:\d+\]|vcc|exec)", srcs) is not None
         if base in FAST and not m.endswith(("_sdwa", "_dpp")) and "dpp" not in ops and "sel:" not in ops and not sgpr_src: return "valu_fast"
         return "valu_slow"
-    if m.startswith("ds_"): return "lds"
+    if m.startswith("ds_"): return "lds_write" if m.startswith(("ds_write", "ds_add", "ds_min", "ds_max", "ds_or", "ds_and", "ds_cmpst", "ds_bpermute", "ds_permute", "ds_swizzle")) or "b128" in m or "b96" in m else "lds_read"
     if m.startswith(("buffer_", "global_", "flat_", "scratch_")): return "vmem"
     if m.startswith("s_"):
         if m in ("s_waitcnt", "s_nop", "s_endpgm", "s_barrier", "s_sleep") or m.startswith(("s_branch", "s_cbranch", "s_cmp", "s_load", "s_buffer_load", "s_setprio", "s_sendmsg", "s_setreg", "s_getreg")): return "s_other"
