@@ -868,7 +868,7 @@ def main():
             if "SQ_INSTS_VALU_per_step" in kk:
                 nv = kk["SQ_INSTS_VALU_per_step"] / LN
                 lo_t = scope.get("ticks_per_valu_instruction", 1.33)
-                kernels[k]["valu_issue_frac"] = [round(nv * lo_t * TICK_NS / simd_ns, 4), round(nv * 1.33 * TICK_NS / simd_ns, 4)]
+                kernels[k]["valu_issue_frac"] = [round(nv * lo_t * TICK_NS / simd_ns, 4), round(min(1.0, nv * 1.33 * TICK_NS / simd_ns), 4)]      # (hi is a bound: capped at the time there is)
                 kernels[k]["valu_fast_class_share"] = scope.get("valu_fast_share")
             if "SQ_INSTS_LDS_per_step" in kk:
                 nl = kk["SQ_INSTS_LDS_per_step"] / LN
@@ -885,8 +885,8 @@ def main():
                         algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(dur[dom], 2),
                         valu_issue_frac=kernels[dom].get("valu_issue_frac"), lds_issue_frac=kernels[dom].get("lds_issue_frac"),
                         salu_issue_frac=kernels[dom].get("salu_issue_frac"),
-                        note="an integer stencil at ~38 vector + 23 scalar + 11 LDS operations per pixel: the byte roof is not its wall; the three issue fractions are -- "
-                             "no unit is saturated, each carries 0.6-0.8 of its rate (DESIGN.md section 4)")
+                        note="an integer stencil at ~45 vector + 21 scalar + 12 LDS wave-instructions per 64 pixels-in-flight (669 / 308 / 178 per 30-px cell): the byte roof is "
+                             "not its wall, vector issue is (>= 0.92 of the SIMDs' issue time priced by instruction class), with the LDS pipe at ~0.7 and the CU's scalar unit at ~0.45 beside it (DESIGN.md section 4)")
         out = {
             "metric": "dual-frame ORB extract+match kfeatures/s; local-BA iters/s (50 KF / 2k MP)",
             "value": round(value, 2), "unit": "kfeatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
