@@ -490,6 +490,53 @@ typedef struct dcs_pose_result {
 
 int  dcs_pose_optimization(const dcs_pose_problem* prob, dcs_pose_result* res);
 
+/* ---- the steady-state per-frame chain of the Tracking thread, device-resident and batched over frames (one per stream / rig):
+   Tracking::SearchLocalPoints (src/Tracking.cc:1617-1680) = Frame::isInFrustum for every local map point (Frame.cc:244-312, viewing
+   cosine limit 0.5) + ORBmatcher(0.8).SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th) (ORBmatcher.cc:539-624), then
+   Optimizer::PoseOptimization (src/Optimizer.cc:250-405; Tracking.cc:1321) over every feature that holds a map point afterwards.
+   The three stages are dcs_is_in_frustum -> dcs_search_by_projection -> dcs_pose_optimization with the intermediate arrays kept in HBM:
+   the frustum stage writes the search's queries (valid = in view, camera, u, v, radius, level -+ 1), the search's assignment
+   (F.mvpMapPoints[bestIdx] = pMP, :617) becomes the optimiser's edge list (ascending feature index, Optimizer.cc:288-350: obs = the
+   undistorted key point, Xw = the map point's position as double, information = mvInvLevelSigma2[octave], camera = keypointToCam[i]).
+   Results equal the three calls issued one after the other (tests/test_gpu_track.py). */
+typedef struct dcs_track_frame {
+    dcs_proj_frame    features;     /* the frame: key points, descriptors, grid; taken[i] = mvpMapPoints[i] && Observations() > 0 before the call */
+    const uint8_t*    has_point;    /* [N] mvpMapPoints[i] != NULL before the call (NULL: same as features.taken) */
+    const float*      point_xw;     /* [N][3] GetWorldPos of the map point feature i holds (read where has_point) */
+    dcs_frustum_frame view;         /* the matrices of the pose guess exactly as for dcs_is_in_frustum; view.n_cams == features.n_cams */
+    const double*     pose;         /* [7] mTcw: the optimiser's initial estimate (dcs_pose_from_matrix) */
+    int32_t           n_points;     /* local map points offered to the search */
+    const float*      pos;          /* [n_points][3] */
+    const float*      normal;       /* [n_points][3] */
+    const float*      min_dist;     /* [n_points] */
+    const float*      max_dist;
+    const uint8_t*    candidate;    /* [n_points] or NULL: 0 = skip (bad, or already matched in this frame: Tracking.cc:1625-1640) */
+    const uint8_t*    desc;         /* [n_points][32] MapPoint::GetDescriptor */
+} dcs_track_frame;
+typedef struct dcs_track_params {
+    float   viewing_cos_limit;      /* 0.5 (Tracking.cc:1655) */
+    float   th;                     /* 1; 3 / 5 right after a relocalisation (Tracking.cc:1667-1672) */
+    int32_t th_high;                /* TH_HIGH = 100 */
+    float   nn_ratio;               /* 0.8 (:1664) */
+    int32_t n_levels;
+    const float* inv_level_sigma2;  /* [n_levels] mvInvLevelSigma2 */
+    int32_t n_cams;
+    const dcs_ba_camera* cams;      /* [n_cams] as for dcs_pose_optimization */
+    double  huber_delta;            /* (float)sqrt(5.991) */
+    float   chi2_th[4];
+    int32_t its[4];
+} dcs_track_params;
+typedef struct dcs_track_result {
+    double*  poses;                   /* [F][7] */
+    int32_t* n_inliers;               /* [F] PoseOptimization's return value */
+    int32_t* n_matches;               /* [F] SearchByProjection's return value */
+    int32_t* const* match_of_point;   /* [F] -> [n_points]: global feature index the map point was assigned to, or -1 */
+    int32_t* const* point_of_feature; /* [F] -> [N]: >= 0 local map point assigned by this call, -2 the feature keeps the map point it held, -1 none */
+    uint8_t* const* outlier;          /* [F] -> [N]: mvbOutlier[i] after the optimisation (0 for features without a map point) */
+} dcs_track_result;
+int  dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_track_params* prm, dcs_track_result* res);
+
+
 /* Cameras::setExtrinsics (Cameras.cc:17-37) + Converter::toSE3Quat/toMatrix6d: float 4x4 (row-major)
    -> ext[7], adj[36]. exact = 0: reference matrix [[R, R t^],[0, R]] in float;
    exact = 1: g2o's SE3Quat::adj() [[R,0],[t^R,R]]. Pure host helper. */

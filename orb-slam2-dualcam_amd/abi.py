@@ -26,7 +26,7 @@ SYMBOLS = [
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_debug_host_path", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_orb_set_timing", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_by_projection_kf", "dcs_search_in_window", "dcs_search_for_initialization",
-    "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_debug_linearize", "dcs_ba_timing", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
+    "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_debug_linearize", "dcs_ba_timing", "dcs_track_local_map", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
     "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_host_alloc", "dcs_host_free", "dcs_streams_share_queue", "dcs_stream_create_apart", "dcs_ba_avoid_streams", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
@@ -129,6 +129,7 @@ def lib():
             "dcs_ba_local_batch": [ci, vp, vp, vp],
             "dcs_ba_debug_linearize": [C.POINTER(BaProblem), vp, vp, vp, vp, vp, vp, pci],
             "dcs_ba_timing": [ci, vp],
+            "dcs_track_local_map": [ci, vp, vp, vp],
             "dcs_stream_create_cu_range": [ci, ci, C.POINTER(vp)],
             "dcs_streams_share_queue": [vp, vp, pci],
             "dcs_stream_create_apart": [vp, ci, C.POINTER(vp), pci],
@@ -1014,3 +1015,82 @@ def ba_set_cu_range(first_cu, n_cus):
 
 def ba_release_thread():
     _check(lib().dcs_ba_release_thread(), "dcs_ba_release_thread")
+
+
+class TrackFrame(C.Structure):
+    _fields_ = [("features", ProjFrame), ("has_point", C.c_void_p), ("point_xw", C.c_void_p), ("view", FrustumFrame), ("pose", C.c_void_p),
+                ("n_points", C.c_int32), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_dist", C.c_void_p), ("max_dist", C.c_void_p),
+                ("candidate", C.c_void_p), ("desc", C.c_void_p)]
+
+
+class TrackParams(C.Structure):
+    _fields_ = [("viewing_cos_limit", C.c_float), ("th", C.c_float), ("th_high", C.c_int32), ("nn_ratio", C.c_float), ("n_levels", C.c_int32),
+                ("inv_level_sigma2", C.c_void_p), ("n_cams", C.c_int32), ("cams", C.c_void_p), ("huber_delta", C.c_double),
+                ("chi2_th", C.c_float * 4), ("its", C.c_int32 * 4)]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("n_inliers", C.c_void_p), ("n_matches", C.c_void_p), ("match_of_point", C.c_void_p),
+                ("point_of_feature", C.c_void_p), ("outlier", C.c_void_p)]
+
+
+class PreparedTracking:
+    """dcs_track_local_map on a batch of frames laid out like synth.tracking_problem (every frame's features carry their grid): the flat
+    problem marshalled once, track() is then the bare C call."""
+
+    def __init__(self, frames, params):
+        self.keep = []
+
+        def a(x, dt):
+            if x is None:
+                return None
+            arr = _c(x, dt)
+            self.keep.append(arr)
+            return _p(arr).value
+        F = len(frames)
+        self.F = F
+        arr = (TrackFrame * max(F, 1))()
+        self.N, self.np_ = [], []
+        for k, fr in enumerate(frames):
+            ft, vw, pt = fr["features"], fr["view"], fr["points"]
+            t = arr[k]
+            t.features = ProjFrame(len(ft["cam_off"]) - 1, a(ft["cam_off"], np.int32), a(ft["kp_x"], np.float32), a(ft["kp_y"], np.float32),
+                                   a(ft["kp_octave"], np.int32), a(ft.get("kp_angle"), np.float32), a(ft["desc"], np.uint8), a(ft["taken"], np.uint8),
+                                   a(ft["min_x"], np.float32), a(ft["min_y"], np.float32), a(ft["grid_w_inv"], np.float32), a(ft["grid_h_inv"], np.float32),
+                                   a(ft["grid_off"], np.int32), a(ft["grid_idx"], np.int32))
+            t.has_point = a(fr.get("has_point"), np.uint8)
+            t.point_xw = a(fr["point_xw"], np.float32)
+            v = FrustumFrame()
+            v.n_cams = len(vw["fx"])
+            for key in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y"):
+                setattr(v, key, a(vw[key], np.float32))
+            v.log_scale_factor = float(vw["log_scale_factor"]); v.n_scale_levels = len(vw["scale_factors"]); v.scale_factors = a(vw["scale_factors"], np.float32)
+            t.view = v
+            t.pose = a(fr["pose"], np.float64)
+            t.n_points = len(pt["pos"])
+            t.pos, t.normal = a(pt["pos"], np.float32), a(pt["normal"], np.float32)
+            t.min_dist, t.max_dist = a(pt["min_dist"], np.float32), a(pt["max_dist"], np.float32)
+            t.candidate = a(pt.get("candidate"), np.uint8)
+            t.desc = a(fr["desc"], np.uint8)
+            self.N.append(int(ft["cam_off"][-1])); self.np_.append(len(pt["pos"]))
+        self.frames = arr
+        cam_list = [c if isinstance(c, BaCamera) else make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in params["cams"]]
+        self.cams = (BaCamera * len(cam_list))(*cam_list)
+        sig = a(params["inv_level_sigma2"], np.float32)
+        self.prm = TrackParams(float(params["viewing_cos_limit"]), float(params["th"]), int(params["th_high"]), float(params["nn_ratio"]),
+                               len(params["inv_level_sigma2"]), sig, len(cam_list), C.cast(self.cams, C.c_void_p).value, float(params["huber_delta"]),
+                               (C.c_float * 4)(*params["chi2_th"]), (C.c_int32 * 4)(*params["its"]))
+        self.poses = np.zeros((max(F, 1), 7)); self.n_inl = np.zeros(max(F, 1), np.int32); self.n_match = np.zeros(max(F, 1), np.int32)
+        self.mop = [np.full(max(n, 1), -1, np.int32) for n in self.np_]
+        self.pof = [np.full(max(n, 1), -1, np.int32) for n in self.N]
+        self.outl = [np.zeros(max(n, 1), np.uint8) for n in self.N]
+        self.p_mop = (C.c_void_p * max(F, 1))(*[_p(x).value for x in self.mop])
+        self.p_pof = (C.c_void_p * max(F, 1))(*[_p(x).value for x in self.pof])
+        self.p_outl = (C.c_void_p * max(F, 1))(*[_p(x).value for x in self.outl])
+        self.res = TrackResult(_p(self.poses).value, _p(self.n_inl).value, _p(self.n_match).value, C.cast(self.p_mop, C.c_void_p).value,
+                               C.cast(self.p_pof, C.c_void_p).value, C.cast(self.p_outl, C.c_void_p).value)
+
+    def track(self):
+        _check(lib().dcs_track_local_map(self.F, C.cast(self.frames, C.c_void_p), C.byref(self.prm), C.byref(self.res)), "dcs_track_local_map")
+        return [dict(pose=self.poses[k].copy(), n_inliers=int(self.n_inl[k]), n_matches=int(self.n_match[k]), match_of_point=self.mop[k][:self.np_[k]].copy(),
+                     point_of_feature=self.pof[k][:self.N[k]].copy(), outlier=self.outl[k][:self.N[k]].copy()) for k in range(self.F)]

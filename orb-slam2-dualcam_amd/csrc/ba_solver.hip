@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "common.h"
+#include "track.h"
 
 namespace dcs {
 
@@ -1533,6 +1534,7 @@ __global__ void k_pad_identity(const BaProb* __restrict__ probs, const BaCtl* __
 // so a batch (one frame per stream) fills the GPU; a single frame costs a few hundred microseconds of latency.
 struct PoseArgs {
     const double* poses; const int32_t* edge_off; const double* xw; const double* obs; const double* w; const int32_t* cam;
+    const int32_t* edge_cnt;                     // optional: frame f owns edge_cnt[f] edges from edge_off[f] (slotted layout of the tracking chain) instead of a CSR
     double huber; float chi2_th[4]; int its[4];
     double* err; uint8_t* level;                 // scratch per edge
     double* out_poses; uint8_t* outlier; int32_t* n_inliers; double* edge_chi2; int32_t* n_iters;
@@ -1587,7 +1589,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
     __shared__ double s_T[7], s_x[6], s_tot[28];
     __shared__ int s_ctl;                                    // decision of thread 0: 0 = next trial, 1 = iteration done, 2 = round done
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int e0 = a.edge_off[f], n = a.edge_off[f + 1] - e0;
+    const int e0 = a.edge_off[f], n = a.edge_cnt ? a.edge_cnt[f] : a.edge_off[f + 1] - e0;
     const double* Tin = a.poses + 7 * f;
     for (int k = tid; k < n; k += 256) { a.outlier[e0 + k] = 0; a.level[e0 + k] = 0; if (a.edge_chi2) a.edge_chi2[e0 + k] = 0; }
     if (tid < 4 && a.n_iters) a.n_iters[4 * f + tid] = 0;
@@ -2096,11 +2098,40 @@ int build_round(const dcs_ba_problem* pb, Round& r)
     return -1;
 }
 
+// k_pose_opt on arrays that already live in HBM (the tracking chain of proj_kernels.hip): declared in track.h
+static DCams pose_cams_of(const dcs_ba_camera* cams_in, int n_cams)
+{
+    DCams cams{};
+    for (int c = 0; c < n_cams; ++c) {
+        DCam& d = cams.c[c];
+        const dcs_ba_camera& s = cams_in[c];
+        d.fx = s.fx; d.fy = s.fy; d.cx = s.cx; d.cy = s.cy;
+        d.t[0] = s.ext[0]; d.t[1] = s.ext[1]; d.t[2] = s.ext[2];
+        d.q[0] = s.ext[3]; d.q[1] = s.ext[4]; d.q[2] = s.ext[5]; d.q[3] = s.ext[6];
+        memcpy(d.adj, s.adj, sizeof(d.adj));
+    }
+    return cams;
+}
+
 // dcs_ba_debug_linearize: the blocks of the FIRST linearisation (rows a14 / a15) handed back instead of a solve
 struct BaTap { double *Hpp, *bp, *Hll, *bl, *Hpl; int32_t* pose_idx; int* np; };
 thread_local const BaTap* tl_tap = nullptr;
 
 }  // namespace
+
+int dcs::launch_pose_opt_device(const PoseOptDevice& p, const dcs_ba_camera* cams_in, int n_cams, int n_frames, hipStream_t st)
+{
+    if (n_cams < 1 || n_cams > kMaxCams) { set_error("pose optimisation: n_cams must be 1..%d", kMaxCams); return DCS_ERR_INVALID; }
+    if (n_frames <= 0) return DCS_OK;
+    PoseArgs a{};
+    a.poses = p.poses; a.edge_off = p.edge_off; a.edge_cnt = p.edge_cnt; a.xw = p.xw; a.obs = p.obs; a.w = p.w; a.cam = p.cam;
+    a.huber = p.huber;
+    for (int i = 0; i < 4; ++i) { a.chi2_th[i] = p.chi2_th[i]; a.its[i] = p.its[i]; }
+    a.err = p.err; a.level = p.level; a.out_poses = p.out_poses; a.outlier = p.outlier; a.n_inliers = p.n_inliers; a.edge_chi2 = p.edge_chi2; a.n_iters = p.n_iters;
+    hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, st, a, pose_cams_of(cams_in, n_cams));
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
 
 extern "C" {
 

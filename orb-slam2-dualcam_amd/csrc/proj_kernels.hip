@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.h"
+#include "track.h"
 
 namespace dcs {
 namespace {
@@ -276,11 +277,11 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjFrameD f, ProjQueriesD 
 constexpr int kResT = 1024;
 constexpr int kResMaxN = 16384;                 // features whose minq / taken maps fit in LDS (80 KB)
 
-__global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f, ProjQueriesD q, const unsigned* __restrict__ cand,
-                                                           const int32_t* __restrict__ cand_n, uint8_t* __restrict__ state /* [n] 0 = undecided */,
-                                                           int th_high, float nn_ratio, int check_ori, int32_t* __restrict__ match_of_query,
-                                                           int32_t* __restrict__ query_of_feature, int32_t* __restrict__ bin_of_query,
-                                                           int32_t* __restrict__ n_matches)
+__device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const ProjQueriesD& q, const unsigned* __restrict__ cand,
+                                                      const int32_t* __restrict__ cand_n, uint8_t* __restrict__ state /* [n] 0 = undecided */,
+                                                      int th_high, float nn_ratio, int check_ori, int32_t* __restrict__ match_of_query,
+                                                      int32_t* __restrict__ query_of_feature, int32_t* __restrict__ bin_of_query,
+                                                      int32_t* __restrict__ n_matches)
 {
     __shared__ int s_minq[kResMaxN];
     __shared__ uint8_t s_taken[kResMaxN];
@@ -416,6 +417,13 @@ __global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f, ProjQu
         nm -= s_undecided;
     }
     if (tid == 0) *n_matches = nm;
+}
+__global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f, ProjQueriesD q, const unsigned* __restrict__ cand,
+                                                           const int32_t* __restrict__ cand_n, uint8_t* __restrict__ state, int th_high, float nn_ratio,
+                                                           int check_ori, int32_t* __restrict__ match_of_query, int32_t* __restrict__ query_of_feature,
+                                                           int32_t* __restrict__ bin_of_query, int32_t* __restrict__ n_matches)
+{
+    proj_resolve_par_body(f, q, cand, cand_n, state, th_high, nn_ratio, check_ori, match_of_query, query_of_feature, bin_of_query, n_matches);
 }
 
 // ---- Frame::isInFrustum + PredictScale + search window, one lane per map point (Frame.cc:244-312, MapPoint.cc:440-455,
@@ -585,14 +593,12 @@ struct FrustumDev {
     const float* scale_factors;
 };
 
-__global__ __launch_bounds__(256) void k_frustum(FrustumDev F, int n, const float* __restrict__ pos, const float* __restrict__ normal,
-                                                 const float* __restrict__ min_dist, const float* __restrict__ max_dist,
-                                                 const uint8_t* __restrict__ candidate, float cos_limit, float th, uint8_t* __restrict__ in_view,
-                                                 int32_t* __restrict__ cam, float* __restrict__ u_out, float* __restrict__ v_out,
-                                                 float* __restrict__ view_cos, int32_t* __restrict__ level, float* __restrict__ radius)
+__device__ __forceinline__ void frustum_point(const FrustumDev& F, int i, const float* __restrict__ pos, const float* __restrict__ normal,
+                                              const float* __restrict__ min_dist, const float* __restrict__ max_dist,
+                                              const uint8_t* __restrict__ candidate, float cos_limit, float th, uint8_t* __restrict__ in_view,
+                                              int32_t* __restrict__ cam, float* __restrict__ u_out, float* __restrict__ v_out,
+                                              float* __restrict__ view_cos, int32_t* __restrict__ level, float* __restrict__ radius)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     uint8_t ok = 0; int c_out = -1, lvl = 0; float uo = 0, vo = 0, vc = 0, rad = 0;
     if (!candidate || candidate[i]) {
         const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
@@ -628,8 +634,106 @@ __global__ __launch_bounds__(256) void k_frustum(FrustumDev F, int n, const floa
             break;
         }
     }
-    in_view[i] = ok; cam[i] = c_out; u_out[i] = uo; v_out[i] = vo; view_cos[i] = vc; level[i] = lvl; radius[i] = rad;
+    in_view[i] = ok; cam[i] = c_out; u_out[i] = uo; v_out[i] = vo; if (view_cos) view_cos[i] = vc; level[i] = lvl; radius[i] = rad;
 }
+__global__ __launch_bounds__(256) void k_frustum(FrustumDev F, int n, const float* __restrict__ pos, const float* __restrict__ normal,
+                                                 const float* __restrict__ min_dist, const float* __restrict__ max_dist,
+                                                 const uint8_t* __restrict__ candidate, float cos_limit, float th, uint8_t* __restrict__ in_view,
+                                                 int32_t* __restrict__ cam, float* __restrict__ u_out, float* __restrict__ v_out,
+                                                 float* __restrict__ view_cos, int32_t* __restrict__ level, float* __restrict__ radius)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) frustum_point(F, i, pos, normal, min_dist, max_dist, candidate, cos_limit, th, in_view, cam, u_out, v_out, view_cos, level, radius);
+}
+
+// ---- the tracking chain, batched over frames (dcs_track_local_map): blockIdx.y = frame, every per-frame pointer in a TrackItem in HBM
+struct TrackItem {
+    FrustumDev F;
+    ProjFrameD f; ProjQueriesD q;                  // q.* = what the frustum stage writes (the mutable aliases follow)
+    int n_points;
+    const float *pos, *normal, *min_dist, *max_dist; const uint8_t* candidate;
+    uint8_t* q_valid; int32_t *q_cam, *q_level, *q_min, *q_max; float *q_u, *q_v, *q_radius;
+    unsigned* cand; int32_t* cand_n; uint8_t* state; int32_t *mq, *qf, *bin, *nm;
+    const uint8_t* has_point; const float* point_xw;
+    int edge_base;                                  // first edge slot of this frame (= its first feature's global number in the batch)
+    int32_t *edge_feature, *point_of_feature; uint8_t* feat_outlier;
+};
+__global__ __launch_bounds__(256) void k_track_frustum(const TrackItem* __restrict__ items, float cos_limit, float th)
+{
+    const TrackItem& it = items[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= it.n_points) return;
+    frustum_point(it.F, i, it.pos, it.normal, it.min_dist, it.max_dist, it.candidate, cos_limit, th, it.q_valid, it.q_cam, it.q_u, it.q_v, nullptr, it.q_level, it.q_radius);
+    const int lvl = it.q_level[i];
+    it.q_min[i] = lvl - 1; it.q_max[i] = lvl + 1;                    // ORBmatcher.cc:567-569: GetFeaturesInArea(..., nPredictedLevel - 1, nPredictedLevel + 1)
+}
+__global__ __launch_bounds__(256) void k_track_collect(const TrackItem* __restrict__ items)
+{
+    const TrackItem& it = items[blockIdx.y];
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= it.q.n) return;
+    if (!it.q.valid[qi]) { if ((threadIdx.x & 63) == 0) it.cand_n[qi] = 0; return; }
+    unsigned* out = it.cand + (size_t)qi * kProjCap;
+    const int n = proj_visit(it.f, it.q, qi, TakenPlain{it.f.taken}, [&](bool pass, unsigned word, int pos) { if (pass && pos < kProjCap) out[pos] = word; });
+    if ((threadIdx.x & 63) == 0) it.cand_n[qi] = n;
+}
+__global__ __launch_bounds__(kResT) void k_track_resolve(const TrackItem* __restrict__ items, int th_high, float nn_ratio)
+{
+    const TrackItem& it = items[blockIdx.x];
+    proj_resolve_par_body(it.f, it.q, it.cand, it.cand_n, it.state, th_high, nn_ratio, 0, it.mq, it.qf, it.bin, it.nm);
+}
+// Optimizer::PoseOptimization's edge list (Optimizer.cc:288-350): every feature that holds a map point, ascending feature index -- the
+// point the search has just assigned (ORBmatcher.cc:617: F.mvpMapPoints[bestIdx] = pMP), else the one it held before the call.
+__global__ __launch_bounds__(256) void k_track_edges(const TrackItem* __restrict__ items, const float* __restrict__ inv_level_sigma2, int n_levels,
+                                                     double* __restrict__ xw, double* __restrict__ obs, double* __restrict__ w, int32_t* __restrict__ ecam,
+                                                     int32_t* __restrict__ edge_cnt)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_run;
+    const TrackItem& it = items[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, N = it.f.N;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += 256) {
+        const int i = i0 + tid;
+        int src = -1;                                              // >= 0: local map point of the new match, -2: the point held before, -1: none
+        if (i < N) {
+            const int qn = it.qf[i];
+            src = qn >= 0 ? qn : (it.has_point[i] ? -2 : -1);
+            it.point_of_feature[i] = src;
+            it.feat_outlier[i] = 0;
+        }
+        const bool has = src != -1;
+        const unsigned long long m = __ballot(has);
+        const int rank_w = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int before = s_run;
+        for (int k = 0; k < wave; ++k) before += s_wave[k];
+        if (has) {
+            const int e = it.edge_base + before + rank_w;
+            const float* X = src >= 0 ? it.pos + 3 * (size_t)src : it.point_xw + 3 * (size_t)i;
+            xw[3 * (size_t)e] = (double)X[0]; xw[3 * (size_t)e + 1] = (double)X[1]; xw[3 * (size_t)e + 2] = (double)X[2];   // Converter::toVector3d
+            obs[2 * (size_t)e] = (double)it.f.kp_x[i]; obs[2 * (size_t)e + 1] = (double)it.f.kp_y[i];
+            const int oct = min(max(it.f.kp_octave[i], 0), n_levels - 1);
+            w[e] = (double)inv_level_sigma2[oct];
+            int c = 0;
+            while (c + 1 < it.f.n_cams && i >= it.f.cam_off[c + 1]) ++c;                                                  // keypointToCam
+            ecam[e] = c;
+            it.edge_feature[before + rank_w] = i;
+        }
+        __syncthreads();
+        if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) edge_cnt[blockIdx.x] = s_run;
+}
+__global__ __launch_bounds__(256) void k_track_finish(const TrackItem* __restrict__ items, const int32_t* __restrict__ edge_cnt, const uint8_t* __restrict__ outlier)
+{
+    const TrackItem& it = items[blockIdx.x];
+    for (int k = threadIdx.x; k < edge_cnt[blockIdx.x]; k += 256) it.feat_outlier[it.edge_feature[k]] = outlier[it.edge_base + k];   // mvbOutlier[i]
+}
+
 
 
 }  // namespace
@@ -667,16 +771,15 @@ int dcs_frame_grid(int n_cams, const int32_t* cam_off, const float* kp_x, const 
 
 // validation + upload shared by the window searches: a malformed grid would index features / LDS maps out of bounds on the device
 struct ProjInputs { ProjFrameD f{}; ProjQueriesD q{}; int C = 0, N = 0, nq = 0; };
-static int proj_prepare(Scratch& s, const dcs_proj_frame* fr, const dcs_proj_queries* qs, bool need_taken, bool need_angles, ProjInputs& in)
+// the frame half of every projection search: validation of the caller's arrays (the kernels index with them) and upload
+static int proj_frame_check(const dcs_proj_frame* fr, bool need_taken, bool need_angles)
 {
-    if (!fr || !qs || fr->n_cams < 1 || !fr->cam_off || qs->n < 0) { set_error("bad argument"); return DCS_ERR_INVALID; }
-    const int C = fr->n_cams, N = fr->cam_off[C], nq = qs->n;
+    if (!fr || fr->n_cams < 1 || !fr->cam_off) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    const int C = fr->n_cams, N = fr->cam_off[C];
     const int cells = C * DCS_GRID_COLS * DCS_GRID_ROWS;
     if (N < 0 || N >= (1 << 19)) { set_error("feature count %d outside 0 .. 2^19", N); return DCS_ERR_UNSUPPORTED; }
     if (!fr->min_x || !fr->min_y || !fr->grid_w_inv || !fr->grid_h_inv || !fr->grid_off || (N && (!fr->kp_x || !fr->kp_y || !fr->kp_octave ||
-        !fr->desc || (need_taken && !fr->taken) || !fr->grid_idx)) || (need_angles && N && !fr->kp_angle) ||
-        (nq && (!qs->valid || !qs->cam || !qs->u || !qs->v || !qs->radius || !qs->min_level || !qs->max_level || !qs->desc)) ||
-        (need_angles && nq && !qs->angle)) { set_error("null array"); return DCS_ERR_INVALID; }
+        !fr->desc || (need_taken && !fr->taken) || !fr->grid_idx)) || (need_angles && N && !fr->kp_angle)) { set_error("null array"); return DCS_ERR_INVALID; }
     const int n_entries = fr->grid_off[cells];
     if (n_entries < 0 || n_entries > N) { set_error("grid CSR inconsistent"); return DCS_ERR_INVALID; }
     for (int c = 0; c <= C; ++c) if (fr->cam_off[c] < 0 || (c && fr->cam_off[c] < fr->cam_off[c - 1])) { set_error("cam_off not ascending"); return DCS_ERR_INVALID; }
@@ -690,13 +793,13 @@ static int proj_prepare(Scratch& s, const dcs_proj_frame* fr, const dcs_proj_que
         }
     }
     for (int i = 0; i < N; ++i) if (fr->kp_octave[i] < 0 || fr->kp_octave[i] > 15) { set_error("octave of feature %d outside 0..15", i); return DCS_ERR_INVALID; }
-    for (int i = 0; i < nq; ++i) if (qs->valid[i] && (qs->cam[i] < 0 || qs->cam[i] >= C)) { set_error("query %d: camera out of range", i); return DCS_ERR_INVALID; }
-    int rc = ensure_device();
-    if (rc) return rc;
-    in.C = C; in.N = N; in.nq = nq;
-    if (nq == 0) return DCS_OK;
-    ProjFrameD& f = in.f;
-    ProjQueriesD& q = in.q;
+    return DCS_OK;
+}
+static int proj_frame_upload(Scratch& s, const dcs_proj_frame* fr, bool need_taken, bool need_angles, ProjFrameD& f)
+{
+    const int C = fr->n_cams, N = fr->cam_off[C];
+    const int cells = C * DCS_GRID_COLS * DCS_GRID_ROWS, n_entries = fr->grid_off[cells];
+    int rc;
     f.n_cams = C; f.N = N;
     static const float zero_f = 0.f;
     const std::vector<uint8_t> none(need_taken || fr->taken ? 0 : (size_t)std::max(N, 1), 0);        // "nothing taken" when the caller has no map
@@ -706,6 +809,23 @@ static int proj_prepare(Scratch& s, const dcs_proj_frame* fr, const dcs_proj_que
         (rc = s.upload(&f.min_x, fr->min_x, (size_t)C)) || (rc = s.upload(&f.min_y, fr->min_y, (size_t)C)) ||
         (rc = s.upload(&f.w_inv, fr->grid_w_inv, (size_t)C)) || (rc = s.upload(&f.h_inv, fr->grid_h_inv, (size_t)C)) ||
         (rc = s.upload(&f.grid_off, fr->grid_off, (size_t)cells + 1)) || (rc = s.upload(&f.grid_idx, fr->grid_idx, (size_t)n_entries))) return rc;
+    return DCS_OK;
+}
+
+static int proj_prepare(Scratch& s, const dcs_proj_frame* fr, const dcs_proj_queries* qs, bool need_taken, bool need_angles, ProjInputs& in)
+{
+    if (!fr || !qs || fr->n_cams < 1 || !fr->cam_off || qs->n < 0) { set_error("bad argument"); return DCS_ERR_INVALID; }
+    const int C = fr->n_cams, N = fr->cam_off[C], nq = qs->n;
+    if ((nq && (!qs->valid || !qs->cam || !qs->u || !qs->v || !qs->radius || !qs->min_level || !qs->max_level || !qs->desc)) ||
+        (need_angles && nq && !qs->angle)) { set_error("null array"); return DCS_ERR_INVALID; }
+    for (int i = 0; i < nq; ++i) if (qs->valid[i] && (qs->cam[i] < 0 || qs->cam[i] >= C)) { set_error("query %d: camera out of range", i); return DCS_ERR_INVALID; }
+    int rc;
+    if ((rc = proj_frame_check(fr, need_taken, need_angles)) || (rc = ensure_device())) return rc;
+    in.C = C; in.N = N; in.nq = nq;
+    if (nq == 0) return DCS_OK;
+    if ((rc = proj_frame_upload(s, fr, need_taken, need_angles, in.f))) return rc;
+    ProjQueriesD& q = in.q;
+    static const float zero_f = 0.f;
     q.n = nq;
     if ((rc = s.upload(&q.valid, qs->valid, (size_t)nq)) || (rc = s.upload(&q.cam, qs->cam, (size_t)nq)) || (rc = s.upload(&q.u, qs->u, (size_t)nq)) ||
         (rc = s.upload(&q.v, qs->v, (size_t)nq)) || (rc = s.upload(&q.radius, qs->radius, (size_t)nq)) ||
@@ -875,6 +995,111 @@ int dcs_is_in_frustum(const dcs_frustum_frame* f, int n, const float* pos, const
     if ((rc = s.download_bytes(view_cos, d_vc, sizeof(float) * n))) return rc;
     if ((rc = s.download_bytes(level, d_lvl, sizeof(int32_t) * n))) return rc;
     if ((rc = s.download_bytes(radius, d_rad, sizeof(float) * n))) return rc;
+    return s.finish();
+}
+
+// The steady-state per-frame chain of the Tracking thread -- SearchLocalPoints (src/Tracking.cc:1617-1680: isInFrustum for every local map
+// point, then SearchByProjection) followed by PoseOptimization (:1321) -- for a BATCH of frames (one per stream / rig), device-resident:
+// the frustum stage writes the queries of the search, the search's assignment becomes the optimiser's edge list, nothing returns to the
+// host in between. Five launches for the whole batch (blockIdx.y / .x = frame) + k_pose_opt.
+int dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_track_params* prm, dcs_track_result* res)
+{
+    const int F = n_frames;
+    if (F < 0 || (F && (!frames || !prm || !res || !res->poses || !res->n_inliers || !res->n_matches || !res->match_of_point || !res->point_of_feature ||
+        !res->outlier)) || (F && (prm->n_levels < 1 || !prm->inv_level_sigma2 || !prm->cams))) { set_error("dcs_track_local_map: bad argument"); return DCS_ERR_INVALID; }
+    if (F == 0) return DCS_OK;
+    int rc;
+    long long n_feat = 0;
+    int max_pts = 0, max_q4 = 0;
+    for (int k = 0; k < F; ++k) {
+        const dcs_track_frame& t = frames[k];
+        const dcs_frustum_frame* v = &t.view;
+        if ((rc = proj_frame_check(&t.features, true, false))) return rc;
+        const int N = t.features.cam_off[t.features.n_cams];
+        if (N > kResMaxN) { set_error("frame %d: %d features (the chain's resolver holds %d)", k, N, kResMaxN); return DCS_ERR_UNSUPPORTED; }
+        if (t.n_points < 0 || !t.pose || v->n_cams != t.features.n_cams || v->n_cams > kFrMaxCams || v->n_scale_levels < 1 || !v->Rsw || !v->tsw || !v->Ow ||
+            !v->fx || !v->fy || !v->cx || !v->cy || !v->min_x || !v->max_x || !v->min_y || !v->max_y || !v->scale_factors ||
+            (t.n_points && (!t.pos || !t.normal || !t.min_dist || !t.max_dist || !t.desc)) || (N && !t.point_xw) ||
+            !res->match_of_point[k] || !res->point_of_feature[k] || !res->outlier[k]) { set_error("dcs_track_local_map: frame %d: bad argument", k); return DCS_ERR_INVALID; }
+        n_feat += N;
+        max_pts = std::max(max_pts, t.n_points); max_q4 = std::max(max_q4, (t.n_points + 3) / 4);
+    }
+    if ((rc = ensure_device())) return rc;
+    Scratch s;
+    std::vector<TrackItem> items((size_t)F);
+    std::vector<int32_t> edge_off((size_t)F);
+    const size_t Etot = (size_t)std::max<long long>(n_feat, 1);
+    int base = 0;
+    for (int k = 0; k < F; ++k) {
+        const dcs_track_frame& t = frames[k];
+        TrackItem& it = items[(size_t)k];
+        const dcs_frustum_frame* v = &t.view;
+        FrustumDev& Fd = it.F;
+        Fd = FrustumDev{};
+        Fd.n_cams = v->n_cams; Fd.n_levels = v->n_scale_levels; Fd.log_scale = v->log_scale_factor;
+        for (int c = 0; c < v->n_cams; ++c) {
+            for (int j = 0; j < 9; ++j) Fd.R[c][j] = v->Rsw[9 * c + j];
+            for (int j = 0; j < 3; ++j) { Fd.t[c][j] = v->tsw[3 * c + j]; Fd.O[c][j] = v->Ow[3 * c + j]; }
+            Fd.fx[c] = v->fx[c]; Fd.fy[c] = v->fy[c]; Fd.cx[c] = v->cx[c]; Fd.cy[c] = v->cy[c];
+            Fd.min_x[c] = v->min_x[c]; Fd.max_x[c] = v->max_x[c]; Fd.min_y[c] = v->min_y[c]; Fd.max_y[c] = v->max_y[c];
+        }
+        if ((rc = s.upload(&Fd.scale_factors, v->scale_factors, (size_t)v->n_scale_levels))) return rc;
+        if ((rc = proj_frame_upload(s, &t.features, true, false, it.f))) return rc;
+        it.f.kf_area = 0; it.f.loop_levels = 0; it.f.chi2_inv_sigma2 = nullptr;
+        const int N = it.f.N, np = t.n_points;
+        const size_t npe = (size_t)std::max(np, 1), Ne = (size_t)std::max(N, 1);
+        it.n_points = np;
+        const uint8_t* hp = t.has_point ? t.has_point : t.features.taken;
+        if ((rc = s.upload(&it.pos, t.pos, 3 * npe)) || (rc = s.upload(&it.normal, t.normal, 3 * npe)) || (rc = s.upload(&it.min_dist, t.min_dist, npe)) ||
+            (rc = s.upload(&it.max_dist, t.max_dist, npe)) || (rc = s.upload(&it.has_point, hp, Ne)) || (rc = s.upload(&it.point_xw, t.point_xw, 3 * Ne))) return rc;
+        it.candidate = nullptr;
+        if (t.candidate && (rc = s.upload(&it.candidate, t.candidate, npe))) return rc;
+        ProjQueriesD& q = it.q;
+        q.n = np;
+        if ((rc = s.upload(&q.desc, t.desc, 32 * npe))) return rc;
+        q.angle = nullptr;
+        if ((rc = s.alloc(&it.q_valid, npe)) || (rc = s.alloc(&it.q_cam, npe)) || (rc = s.alloc(&it.q_level, npe)) || (rc = s.alloc(&it.q_min, npe)) ||
+            (rc = s.alloc(&it.q_max, npe)) || (rc = s.alloc(&it.q_u, npe)) || (rc = s.alloc(&it.q_v, npe)) || (rc = s.alloc(&it.q_radius, npe)) ||
+            (rc = s.alloc(&it.cand, npe * kProjCap)) || (rc = s.alloc(&it.cand_n, npe)) || (rc = s.alloc(&it.state, npe)) || (rc = s.alloc(&it.mq, npe)) ||
+            (rc = s.alloc(&it.qf, Ne)) || (rc = s.alloc(&it.bin, npe)) || (rc = s.alloc(&it.nm, 1)) || (rc = s.alloc(&it.edge_feature, Ne)) ||
+            (rc = s.alloc(&it.point_of_feature, Ne)) || (rc = s.alloc(&it.feat_outlier, Ne))) return rc;
+        q.valid = it.q_valid; q.cam = it.q_cam; q.u = it.q_u; q.v = it.q_v; q.radius = it.q_radius; q.min_level = it.q_min; q.max_level = it.q_max;
+        it.edge_base = base; edge_off[(size_t)k] = base;
+        base += N;
+    }
+    const TrackItem* d_items; const int32_t* d_edge_off; const float* d_sig; const double* d_pose_in;
+    std::vector<double> poses_in((size_t)7 * F);
+    for (int k = 0; k < F; ++k) memcpy(&poses_in[(size_t)7 * k], frames[k].pose, sizeof(double) * 7);
+    double *d_xw, *d_obs, *d_w, *d_err, *d_out; int32_t *d_ecam, *d_cnt, *d_ninl; uint8_t *d_level, *d_outl;
+    if ((rc = s.upload(&d_items, items.data(), (size_t)F)) || (rc = s.upload(&d_edge_off, edge_off.data(), (size_t)F)) ||
+        (rc = s.upload(&d_sig, prm->inv_level_sigma2, (size_t)prm->n_levels)) || (rc = s.upload(&d_pose_in, poses_in.data(), poses_in.size())) ||
+        (rc = s.alloc(&d_xw, 3 * Etot)) || (rc = s.alloc(&d_obs, 2 * Etot)) || (rc = s.alloc(&d_w, Etot)) || (rc = s.alloc(&d_err, 2 * Etot)) ||
+        (rc = s.alloc(&d_out, (size_t)7 * F)) || (rc = s.alloc(&d_ecam, Etot)) || (rc = s.alloc(&d_cnt, (size_t)F)) || (rc = s.alloc(&d_ninl, (size_t)F)) ||
+        (rc = s.alloc(&d_level, Etot)) || (rc = s.alloc(&d_outl, Etot))) return rc;
+    hipStream_t st = s.st;
+    if (max_pts > 0) {
+        hipLaunchKernelGGL(k_track_frustum, dim3((max_pts + 255) / 256, F), dim3(256), 0, st, d_items, prm->viewing_cos_limit, prm->th);
+        hipLaunchKernelGGL(k_track_collect, dim3(max_q4, F), dim3(256), 0, st, d_items);
+    }
+    hipLaunchKernelGGL(k_track_resolve, dim3(F), dim3(kResT), 0, st, d_items, prm->th_high, prm->nn_ratio);
+    hipLaunchKernelGGL(k_track_edges, dim3(F), dim3(256), 0, st, d_items, d_sig, prm->n_levels, d_xw, d_obs, d_w, d_ecam, d_cnt);
+    DCS_CHECK_LAUNCH();
+    PoseOptDevice po{};
+    po.poses = d_pose_in; po.edge_off = d_edge_off; po.edge_cnt = d_cnt; po.xw = d_xw; po.obs = d_obs; po.w = d_w; po.cam = d_ecam;
+    po.huber = prm->huber_delta;
+    for (int i = 0; i < 4; ++i) { po.chi2_th[i] = prm->chi2_th[i]; po.its[i] = prm->its[i]; }
+    po.err = d_err; po.level = d_level; po.out_poses = d_out; po.outlier = d_outl; po.n_inliers = d_ninl; po.edge_chi2 = nullptr; po.n_iters = nullptr;
+    if ((rc = launch_pose_opt_device(po, prm->cams, prm->n_cams, F, st))) return rc;
+    hipLaunchKernelGGL(k_track_finish, dim3(F), dim3(256), 0, st, d_items, (const int32_t*)d_cnt, (const uint8_t*)d_outl);
+    DCS_CHECK_LAUNCH();
+    if ((rc = s.download_bytes(res->poses, d_out, sizeof(double) * 7 * F)) || (rc = s.download_bytes(res->n_inliers, d_ninl, sizeof(int32_t) * F))) return rc;
+    for (int k = 0; k < F; ++k) {
+        const TrackItem& it = items[(size_t)k];
+        if (it.n_points && (rc = s.download_bytes(res->match_of_point[k], it.mq, sizeof(int32_t) * it.n_points))) return rc;
+        if (it.f.N && ((rc = s.download_bytes(res->point_of_feature[k], it.point_of_feature, sizeof(int32_t) * it.f.N)) ||
+                       (rc = s.download_bytes(res->outlier[k], it.feat_outlier, (size_t)it.f.N)))) return rc;
+        if ((rc = s.download_bytes(&res->n_matches[k], it.nm, sizeof(int32_t)))) return rc;
+    }
     return s.finish();
 }
 

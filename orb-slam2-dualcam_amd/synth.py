@@ -595,3 +595,111 @@ def frustum_problem(n_points=3000, seed=4, n_cams=2):
     min_dist = (max_dist / scale[7]).astype(np.float32)
     cand = (rng.random(n_points) < 0.9).astype(np.uint8)
     return frame, dict(pos=pos, normal=nrm.astype(np.float32), min_dist=min_dist, max_dist=max_dist, candidate=cand)
+
+
+def tracking_problem(n_frames=6, n_points=1500, n_features=1000, seed=17, th=1.0, pre_matched=0.25):
+    """Synthetic input of the Tracking thread's steady-state chain -- SearchLocalPoints (Tracking.cc:1617-1680) + PoseOptimization
+    (:1321) -- for a batch of frames, laid out like dcs_track_frame: per frame a rig pose guess (motion model: perturbed truth) with the
+    view matrices the reference forms in float (Tsw = Tsc * Tcw, camera centres), a local map (points all around the rig: visible to
+    cam0, only to cam1, behind, out of range, oblique), and frame features = noisy projections of a subset of the visible map points
+    (+ distractor features); `pre_matched` of the features that stem from a map point already hold it (from TrackWithMotionModel:
+    has_point / taken, point_xw), and their map points are no candidates. The grid is NOT included (dcs_frame_grid / oracle.frame_grid)."""
+    rng = np.random.default_rng(seed)
+    T0, T1 = rig_extrinsics_f32()
+    ext = [T0, T1]
+    kk = [RIG["cam0"], RIG["cam1"]]
+    cams = []
+    for c, T in enumerate(ext):
+        adj, ext7 = rig_adjoint_f32(T, False)
+        cams.append(dict(fx=float(np.float32(kk[c]["fx"])), fy=float(np.float32(kk[c]["fy"])), cx=float(np.float32(kk[c]["cx"])),
+                         cy=float(np.float32(kk[c]["cy"])), ext7=ext7, adj=adj))
+    scale = np.ones(8, np.float32)
+    for i in range(1, 8):
+        scale[i] = np.float32(np.float64(scale[i - 1]) * np.float64(np.float32(1.2)))
+    inv_sigma2 = (np.float32(1.0) / (scale * scale)).astype(np.float32)
+    min_x, max_x, min_y, max_y = np.float32(-2.5), np.float32(642.0), np.float32(-1.5), np.float32(481.0)
+    frames = []
+    for f in range(n_frames):
+        # ground truth and guess (float 4 x 4 like mTcw)
+        rv = rng.normal(0, 0.2, 3)
+        Tgt = np.eye(4, dtype=np.float32)
+        Tgt[:3, :3] = _rodrigues(rv).astype(np.float32); Tgt[:3, 3] = rng.normal(0, 0.5, 3).astype(np.float32)
+        Tg = np.eye(4, dtype=np.float32)
+        Tg[:3, :3] = (_rodrigues(rng.normal(0, 0.004, 3)) @ Tgt[:3, :3].astype(np.float64)).astype(np.float32)
+        Tg[:3, 3] = (Tgt[:3, 3] + rng.normal(0, 0.01, 3)).astype(np.float32)
+        Rsw, tsw, Ow, Tsw_gt = [], [], [], []
+        for T in ext:
+            Tsw = (T.astype(np.float32) @ Tg).astype(np.float32)
+            R, t = Tsw[:3, :3], Tsw[:3, 3]
+            Rsw.append(R.reshape(9)); tsw.append(t); Ow.append((-(R.T @ t)).astype(np.float32))
+            Tsw_gt.append(T.astype(np.float64) @ Tgt.astype(np.float64))
+        view = dict(Rsw=np.array(Rsw, np.float32), tsw=np.array(tsw, np.float32), Ow=np.array(Ow, np.float32),
+                    fx=np.array([c["fx"] for c in cams], np.float32), fy=np.array([c["fy"] for c in cams], np.float32),
+                    cx=np.array([c["cx"] for c in cams], np.float32), cy=np.array([c["cy"] for c in cams], np.float32),
+                    min_x=np.full(2, min_x, np.float32), max_x=np.full(2, max_x, np.float32), min_y=np.full(2, min_y, np.float32),
+                    max_y=np.full(2, max_y, np.float32), log_scale_factor=np.float32(np.log(np.float32(1.2))), scale_factors=scale)
+        # local map: a shell around the rig centre, biased towards the two viewing directions
+        centre = (-(Tgt[:3, :3].astype(np.float64).T @ Tgt[:3, 3].astype(np.float64)))
+        d = rng.normal(0, 1, (n_points, 3))
+        for c in (0, 1):                                           # half of the points in front of each camera
+            sel = slice(c * n_points // 3, (c + 1) * n_points // 3)
+            zc = Tsw_gt[c][2, :3]
+            d[sel] = zc + rng.normal(0, 0.35, (n_points // 3, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        dist = rng.uniform(1.5, 10.0, n_points)
+        pos = (centre + d * dist[:, None]).astype(np.float32)
+        ray = pos.astype(np.float64) - centre; ray /= np.linalg.norm(ray, axis=1, keepdims=True)
+        nrm = ray + rng.normal(0, 1, (n_points, 3)) * rng.choice([0.0, 0.05, 0.4, 1.5], n_points, p=[0.1, 0.6, 0.25, 0.05])[:, None]
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        l0 = rng.integers(0, 6, n_points)
+        max_dist = (dist * rng.uniform(0.9, 1.6, n_points) * scale[l0]).astype(np.float32)
+        min_dist = (max_dist / scale[7]).astype(np.float32)
+        pdesc = random_descriptors(n_points, seed=seed * 100 + f)
+        # features: project with the TRUE pose, keep what lands in an image, noisy pixel + octave
+        feats = []                                                  # (cam, u, v, octave, point)
+        for p in range(n_points):
+            for c in (0, 1):
+                Pc = Tsw_gt[c][:3, :3] @ pos[p].astype(np.float64) + Tsw_gt[c][:3, 3]
+                if Pc[2] <= 0.2: continue
+                u = cams[c]["fx"] * Pc[0] / Pc[2] + cams[c]["cx"]; v = cams[c]["fy"] * Pc[1] / Pc[2] + cams[c]["cy"]
+                if 5 < u < 635 and 5 < v < 475:
+                    lvl = int(np.clip(np.ceil(np.log(max_dist[p] / np.linalg.norm(pos[p].astype(np.float64) - Ow[c].astype(np.float64))) / np.log(1.2)), 0, 7))
+                    feats.append((c, u, v, lvl, p)); break
+        order = rng.permutation(len(feats))[:int(n_features * 0.8)]
+        feats = [feats[i] for i in order]
+        n_dis = n_features - len(feats)
+        per_cam = [[ft for ft in feats if ft[0] == c] for c in (0, 1)]
+        kp_x, kp_y, octv, fdesc, src, cam_off = [], [], [], [], [], [0]
+        for c in (0, 1):
+            k_dis = n_dis // 2 if c == 0 else n_dis - n_dis // 2
+            ent = [(u + rng.normal(0, 0.8 * float(scale[l])), v + rng.normal(0, 0.8 * float(scale[l])), int(np.clip(l + rng.integers(-1, 2), 0, 7)), p) for (_, u, v, l, p) in per_cam[c]]
+            ent += [(rng.uniform(0, 640), rng.uniform(0, 480), int(min(rng.geometric(0.35) - 1, 7)), -1) for _ in range(k_dis)]
+            for i in rng.permutation(len(ent)):
+                u, v, l, p = ent[i]
+                kp_x.append(u); kp_y.append(v); octv.append(l); src.append(p)
+            cam_off.append(len(kp_x))
+        N = len(kp_x)
+        src = np.asarray(src, np.int64)
+        fdesc = random_descriptors(N, seed=seed * 100 + 50 + f)
+        from_map = src >= 0
+        fdesc[from_map] = noisy_copy(pdesc[src[from_map]], flip_bits=16, seed=seed * 100 + 70 + f)
+        has_point = (from_map & (rng.random(N) < pre_matched)).astype(np.uint8)
+        taken = (has_point.astype(bool) & (rng.random(N) < 0.9)).astype(np.uint8)          # a few hold a point without observations: searchable, and the search may replace it
+        point_xw = np.zeros((N, 3), np.float32)
+        point_xw[has_point != 0] = (pos[src[has_point != 0]].astype(np.float64) + rng.normal(0, 0.01, (int(has_point.sum()), 3))).astype(np.float32)
+        candidate = np.ones(n_points, np.uint8)
+        candidate[src[taken != 0]] = 0                                                     # already matched in this frame (Tracking.cc:1625-1640)
+        candidate[rng.random(n_points) < 0.03] = 0                                         # bad points
+        features = dict(cam_off=np.asarray(cam_off, np.int32), kp_x=np.asarray(kp_x, np.float32), kp_y=np.asarray(kp_y, np.float32),
+                        kp_octave=np.asarray(octv, np.int32), kp_angle=np.zeros(N, np.float32), desc=fdesc, taken=taken,
+                        min_x=np.full(2, min_x, np.float32), min_y=np.full(2, min_y, np.float32),
+                        grid_w_inv=np.full(2, np.float32(64) / np.float32(max_x - min_x), np.float32),
+                        grid_h_inv=np.full(2, np.float32(48) / np.float32(max_y - min_y), np.float32))
+        q = _quat_from_R(Tg[:3, :3].astype(np.float64))
+        pose = np.concatenate([Tg[:3, 3].astype(np.float64), q])
+        frames.append(dict(features=features, has_point=has_point, point_xw=point_xw, view=view, pose=pose, Tcw_guess=Tg, Tcw_gt=Tgt,
+                           points=dict(pos=pos, normal=nrm.astype(np.float32), min_dist=min_dist, max_dist=max_dist, candidate=candidate), desc=pdesc,
+                           feature_source=src))
+    params = dict(viewing_cos_limit=0.5, th=float(th), th_high=100, nn_ratio=0.8, inv_level_sigma2=inv_sigma2, cams=cams,
+                  huber_delta=float(np.float32(np.sqrt(5.991))), chi2_th=[float(np.float32(5.991))] * 4, its=[10, 10, 10, 10])
+    return frames, params
