@@ -18,7 +18,8 @@ Extra legs on rank 0 at N = 1 (each one can be switched off): cpu_baseline (orac
 cpu_all_cores, latency (one dual frame through the host-buffer API, PCIe included), with_transfers
 (the default batch through the host-buffer API), matcher (solo, i8-MFMA TOPS), c3 (dual 1280x720, 2000
 features), local_ba (C4 + its MFMA / HBM roofline + the 8-problem batch), c5_one_gpu (8 streams of
-extraction + matching next to 8 concurrent local BAs, time-sliced on ONE GPU), bow.
+extraction + matching next to 8 concurrent local BAs, time-sliced on ONE GPU), bow, per_frame_chain (SearchLocalPoints +
+PoseOptimization per frame: dcs_track_local_map against the three host-buffer calls it replaces).
 
 Under a rank environment (any N, every rank takes part, rank 0 reports node sums) two legs follow the headline:
 c3_scaled = BASELINE configs[2] (64 dual 1280x720 / 2000-feature frames per step per rank + the per-step feature
@@ -1249,6 +1250,66 @@ def main():
             kf.close()
         out["bow"] = bow
         V.close()
+
+    # ---- the Tracking thread's steady-state chain per frame: SearchLocalPoints + PoseOptimization, device-resident and
+    # batched (dcs_track_local_map) against the three host-buffer calls per frame it replaces, and the oracle on one host core
+    if solo and not args.no_host_api and hasattr(pkg.abi.lib(), "dcs_track_local_map"):
+        fr_t, prm_t = synth.tracking_problem(n_frames=16, n_points=2000, n_features=2000, seed=23)
+        for f_ in fr_t:
+            ft_ = f_["features"]
+            ft_["grid_off"], ft_["grid_idx"] = pkg.frame_grid(ft_["cam_off"], ft_["kp_x"], ft_["kp_y"], ft_["min_x"], ft_["min_y"], ft_["grid_w_inv"], ft_["grid_h_inv"])
+
+        def med(fn, reps=30):
+            for _ in range(3):
+                fn()
+            ts_ = []
+            for _ in range(reps):
+                t0_ = time.perf_counter(); fn(); ts_.append(time.perf_counter() - t0_)
+            return sorted(ts_)[reps // 2]
+        chain = {"workload": "per frame: isInFrustum of 2000 local map points -> SearchByProjection into ~2000 features (dual camera) -> PoseOptimization over the "
+                             "features that hold a map point (4 x 10 LM iterations); host buffers in, pose + assignment + outlier flags out"}
+        for nf_ in (1, 16):
+            pt_ = pkg.abi.PreparedTracking(fr_t[:nf_], prm_t)
+            chain["chained_ms_per_frame_batch_of_%d" % nf_] = round(med(pt_.track) / nf_ * 1e3, 4)
+        m_t = pkg.ORBmatcher(prm_t["nn_ratio"], False)
+
+        def three_calls():
+            f_ = fr_t[0]
+            ft_, pts_ = f_["features"], f_["points"]
+            fru_ = pkg.isInFrustum(f_["view"], pts_, prm_t["viewing_cos_limit"], prm_t["th"])
+            q_ = pkg.projection_queries(fru_, f_["desc"])
+            mq_, qf_, _nm = m_t.SearchByProjection(ft_, q_, prm_t["th_high"], use_ratio=True, check_orientation=False)
+            src_ = np.where(qf_ >= 0, qf_, np.where(f_["has_point"] != 0, -2, -1))
+            feat_ = np.nonzero(src_ != -1)[0]
+            xw_ = np.where((src_[feat_] >= 0)[:, None], pts_["pos"][np.maximum(src_[feat_], 0)], f_["point_xw"][feat_]).astype(np.float64)
+            pkg.Optimizer.PoseOptimization(dict(poses=f_["pose"][None, :], edge_off=np.array([0, len(feat_)], np.int32), xw=xw_,
+                                                obs=np.stack([ft_["kp_x"][feat_], ft_["kp_y"][feat_]], 1).astype(np.float64),
+                                                inv_sigma2=prm_t["inv_level_sigma2"][ft_["kp_octave"][feat_]].astype(np.float64),
+                                                edge_cam=(np.searchsorted(ft_["cam_off"], feat_, side="right") - 1).astype(np.int32), cams=prm_t["cams"],
+                                                huber_delta=prm_t["huber_delta"], chi2_th=prm_t["chi2_th"], its=prm_t["its"]))
+        chain["three_calls_ms_per_frame"] = round(med(three_calls) * 1e3, 4)
+        chain["note"] = "median of 30 calls incl. ctypes / numpy marshalling of the Python harness on both sides"
+        if args.cpu_seconds > 0:
+            O_ = entry.load_oracle()
+            cams_o = [O_.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in prm_t["cams"]]
+
+            def oracle_chain():
+                f_ = fr_t[0]
+                ft_, pts_ = f_["features"], f_["points"]
+                fru_ = O_.is_in_frustum(f_["view"], pts_, prm_t["viewing_cos_limit"], prm_t["th"])
+                q_ = pkg.projection_queries(fru_, f_["desc"])
+                mq_, qf_, _nm = O_.search_by_projection(ft_, q_, prm_t["th_high"], prm_t["nn_ratio"], False)
+                src_ = np.where(qf_ >= 0, qf_, np.where(f_["has_point"] != 0, -2, -1))
+                feat_ = np.nonzero(src_ != -1)[0]
+                xw_ = np.where((src_[feat_] >= 0)[:, None], pts_["pos"][np.maximum(src_[feat_], 0)], f_["point_xw"][feat_]).astype(np.float64)
+                O_.pose_optimization(dict(poses=f_["pose"][None, :], edge_off=np.array([0, len(feat_)], np.int32), xw=xw_,
+                                          obs=np.stack([ft_["kp_x"][feat_], ft_["kp_y"][feat_]], 1).astype(np.float64),
+                                          inv_sigma2=prm_t["inv_level_sigma2"][ft_["kp_octave"][feat_]].astype(np.float64),
+                                          edge_cam=(np.searchsorted(ft_["cam_off"], feat_, side="right") - 1).astype(np.int32), cams=cams_o,
+                                          huber_delta=prm_t["huber_delta"], chi2_th=prm_t["chi2_th"], its=prm_t["its"]))
+            chain["cpu_baseline"] = {"value": round(med(oracle_chain, 10) * 1e3, 4), "unit": "ms per frame", "cores": 1, "kind": "port",
+                                     "sample": "median of 10 frames, oracle -O3 single thread (same marshalling)"}
+        out["per_frame_chain"] = chain
 
     # ---- distributed runs: the rank-path legs (configs[2] and configs[4] as an N-GPU run measures them), then the OTHER exchange path once
     # as a cross-check of the gathered slot arrays. RCCL has never run with more than one rank on the builder's side, so a watchdog prints

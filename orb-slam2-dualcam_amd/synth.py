@@ -642,7 +642,7 @@ def tracking_problem(n_frames=6, n_points=1500, n_features=1000, seed=17, th=1.0
         centre = (-(Tgt[:3, :3].astype(np.float64).T @ Tgt[:3, 3].astype(np.float64)))
         d = rng.normal(0, 1, (n_points, 3))
         for c in (0, 1):                                           # half of the points in front of each camera
-            sel = slice(c * n_points // 3, (c + 1) * n_points // 3)
+            sel = slice(c * (n_points // 3), (c + 1) * (n_points // 3))
             zc = Tsw_gt[c][2, :3]
             d[sel] = zc + rng.normal(0, 0.35, (n_points // 3, 3))
         d /= np.linalg.norm(d, axis=1, keepdims=True)
