@@ -193,7 +193,11 @@ struct BaProb {
     double *Hpp, *bp, *bsch, *xp;                  // per free pose
     double *S, *W;                                 // reduced camera system (ld x ld), panel scratch of the n > 256 fallback
     const int32_t *pose_idx, *pt_off, *pt_edges, *pt_pi, *ps_off, *ps_edges;   // pt_pi[k] = free-pose index (or -1) of edge pt_edges[k]
-    const int32_t *pair_ij, *pair_off, *pair_e;      // pair_e: (e1, e2) interleaved, one 8-byte load per list entry
+    const int32_t* pair_ij;                          // [n_pairs][2]: every pair i1 <= i2 of free poses, the np diagonal pairs first
+    int32_t *pair_off, *pair_e;                      // lists of the pairs, BUILT ON THE DEVICE (k_pairs_*); pair_e: (e1, e2) interleaved, one 8-byte load per entry
+    uint32_t* pt_bits;                               // [np][pt_words] bit l of row i: free pose i observes point l (zeroed region)
+    int32_t* edge_of;                                // [np][L] the edge of (free pose, point), valid where the bit is set
+    int pt_words, pad2;
     double *partial, *scale_part, *maxd_part;      // block partials: chi2, computeScale, max |diagonal| (np + nb_pts entries)
     uint8_t* pt_active;
     unsigned* ticket;                              // [0] error kernels, [1] k_reduce_pose, [2] k_begin
@@ -260,6 +264,47 @@ __device__ __forceinline__ void publish_problem_end(int* __restrict__ h_progress
     } while (__hip_atomic_load(grid_ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != v);
 }
 
+// accept / reject of a trial (optimization_algorithm_levenberg.cpp:104-164): ONE thread of the problem, after the chi2 of the trial
+// estimates (tot) and computeScale (sc) are known. Always returns true.
+__device__ __forceinline__ bool lm_accept(const BaProb& pb, BaCtl& ctl, const volatile int* __restrict__ stop_words, double tot, double sc)
+{
+    ++ctl.n_trials[ctl.round];
+    double tempChi = tot;
+    if (ctl.ok == 0.0) tempChi = 1.7976931348623157e308;
+    double rho = ctl.currentChi - tempChi;
+    const double scale = sc + 1e-3;
+    rho /= scale;
+    double mult = ctl.mult, ni = ctl.ni, currentChi = ctl.currentChi;
+    if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        mult *= fmax(1. / 3., alpha);
+        ni = 2; currentChi = tempChi;
+        ctl.cur ^= 1; ctl.errors_current = 1;       // discardTop: the trial estimates become the current ones
+    } else {
+        mult *= ni; ni *= 2;
+        ctl.errors_current = 0;                     // pop: the other buffer still holds the estimates; err / chi2 stay stale like g2o's
+    }
+    ctl.mult = mult; ctl.ni = ni; ctl.currentChi = currentChi; ctl.scale = sc;
+    const int qmax = ++ctl.qmax;
+    const bool stop = stop_words && __hip_atomic_load(const_cast<const int*>(stop_words + blockIdx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+    if (stop) ctl.stopped = 1;
+    if (rho < 0 && qmax < 10 && !stop) { ctl.state = ST_RETRY; return true; }
+    const int round = ctl.round;
+    ++ctl.n_iters[round];
+    if (ctl.trace < 32) ctl.chi2_trace[ctl.trace++] = currentChi;
+    ctl.lambda[round] = 1e-5 * ctl.maxdiag * mult;
+    bool term = (qmax == 10 || rho == 0);           // Terminate
+    if (!term) {
+        if ((ctl.iniChi - currentChi) * 1e3 < ctl.iniChi) ++ctl.nBad; else ctl.nBad = 0;
+        if (ctl.nBad >= 3) term = true;
+    }
+    const int it = ++ctl.it;
+    if (term || stop || it >= pb.iters[round]) ctl.state = ST_ROUND_END;
+    else { ctl.state = ST_NEW_ITER; ctl.qmax = 0; ctl.iniChi = currentChi; }
+    return true;
+}
+
 template <int TRIAL>
 __device__ __forceinline__ bool error_body(const BaProb& pb, BaCtl& ctl, const volatile int* __restrict__ stop_words, double* s /*[256]*/, DCams& cams, bool& last)
 {   // returns true in the ONE thread of the problem that ran the accept / reject logic
@@ -308,42 +353,7 @@ __device__ __forceinline__ bool error_body(const BaProb& pb, BaCtl& ctl, const v
     for (int i = threadIdx.x; i < pb.nb_pts + pb.nb_pose; i += 256) w += pb.scale_part[i];
     const double sc = block_sum_256(w, s);
     if (threadIdx.x != 0) return false;
-    // ---- accept / reject (optimization_algorithm_levenberg.cpp:104-164)
-    ++ctl.n_trials[ctl.round];
-    double tempChi = tot;
-    if (ctl.ok == 0.0) tempChi = 1.7976931348623157e308;
-    double rho = ctl.currentChi - tempChi;
-    const double scale = sc + 1e-3;
-    rho /= scale;
-    double mult = ctl.mult, ni = ctl.ni, currentChi = ctl.currentChi;
-    if (rho > 0 && isfinite(tempChi)) {
-        double alpha = 1. - pow((2 * rho - 1), 3);
-        alpha = fmin(alpha, 2. / 3.);
-        mult *= fmax(1. / 3., alpha);
-        ni = 2; currentChi = tempChi;
-        ctl.cur ^= 1; ctl.errors_current = 1;       // discardTop: the trial estimates become the current ones
-    } else {
-        mult *= ni; ni *= 2;
-        ctl.errors_current = 0;                     // pop: the other buffer still holds the estimates; err / chi2 stay stale like g2o's
-    }
-    ctl.mult = mult; ctl.ni = ni; ctl.currentChi = currentChi; ctl.scale = sc;
-    const int qmax = ++ctl.qmax;
-    const bool stop = stop_words && __hip_atomic_load(const_cast<const int*>(stop_words + blockIdx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-    if (stop) ctl.stopped = 1;
-    if (rho < 0 && qmax < 10 && !stop) { ctl.state = ST_RETRY; return true; }
-    const int round = ctl.round;
-    ++ctl.n_iters[round];
-    if (ctl.trace < 32) ctl.chi2_trace[ctl.trace++] = currentChi;
-    ctl.lambda[round] = 1e-5 * ctl.maxdiag * mult;
-    bool term = (qmax == 10 || rho == 0);           // Terminate
-    if (!term) {
-        if ((ctl.iniChi - currentChi) * 1e3 < ctl.iniChi) ++ctl.nBad; else ctl.nBad = 0;
-        if (ctl.nBad >= 3) term = true;
-    }
-    const int it = ++ctl.it;
-    if (term || stop || it >= pb.iters[round]) ctl.state = ST_ROUND_END;
-    else { ctl.state = ST_NEW_ITER; ctl.qmax = 0; ctl.iniChi = currentChi; }
-    return true;
+    return lm_accept(pb, ctl, stop_words, tot, sc);
 }
 
 // k_error<1> is the LAST kernel of a step: the last problem to finish its trial publishes the step to the host (publish_step_end).
@@ -713,6 +723,7 @@ __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(c
     const int el = t % 36, q = t / 36;
     const int r = el / 6, c = el % 6;
     const int k0 = pair_off[p], k1 = pair_off[p + 1];
+    if (k0 == k1 && p >= pb.np) return;                      // two poses without a common point: their block of S stays zero (the arena's zeroed region)
     auto term = [&](int k) {
         const int2 pe = pair_e[k];
         const double* a = BD + (size_t)pe.x * 18 + r * 3;
@@ -754,6 +765,88 @@ __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(c
     }
     pb.S[(size_t)xa * ld + ya] = v;
     if (i1 != i2) pb.S[(size_t)ya * ld + xa] = v;
+}
+
+// ---- pose-pair lists on the device, once per call (until round 4 the host built and uploaded them: 0.8 of the 1.25 MB a C4 problem
+// uploads, and two passes over ~100 k (point, pose, pose) triples per problem on the host).
+// List of the pair (i1 <= i2) = the points both poses observe, in POINT order, as (edge of i1, edge of i2): the AND of two bit rows.
+//   k_pairs_mark   thread per edge of a free pose: bit (pose, point), edge_of[pose][point]   (at most one edge per (pose, point):
+//                  build_round's duplicate test)
+//   k_pairs_scan   one workgroup per problem: popcount of every pair's AND, exclusive scan in pair order -> pair_off
+//   k_pairs_fill   one wave per pair: the set bits of the AND in ascending order -> pair_e
+__global__ __launch_bounds__(256) void k_pairs_mark(const BaProb* __restrict__ probs)
+{
+    const BaProb& pb = probs[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= pb.E) return;
+    const int pi = pb.pose_idx[pb.epose[e]];
+    if (pi < 0) return;
+    const int l = pb.epoint[e];
+    atomicOr(pb.pt_bits + (size_t)pi * pb.pt_words + (l >> 5), 1u << (l & 31));
+    pb.edge_of[(size_t)pi * pb.L + l] = e;
+}
+
+__global__ __launch_bounds__(1024) void k_pairs_scan(const BaProb* __restrict__ probs)
+{
+    __shared__ int s_w[16];
+    const BaProb& pb = probs[blockIdx.x];
+    const int n_pairs = pb.n_pairs, W = pb.pt_words, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int running = 0;
+    for (int p0 = 0; p0 < n_pairs; p0 += 1024) {
+        const int p = p0 + t;
+        int c = 0;
+        if (p < n_pairs) {
+            const uint4* a = reinterpret_cast<const uint4*>(pb.pt_bits + (size_t)pb.pair_ij[2 * p] * W);        // pt_words is a multiple of 4
+            const uint4* b = reinterpret_cast<const uint4*>(pb.pt_bits + (size_t)pb.pair_ij[2 * p + 1] * W);
+#pragma unroll 4
+            for (int w = 0; w < W / 4; ++w) {
+                const uint4 x = a[w], y = b[w];
+                c += __popc(x.x & y.x) + __popc(x.y & y.y) + __popc(x.z & y.z) + __popc(x.w & y.w);
+            }
+        }
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int v = s_w[w]; if (w < wave) off += v; tot += v; }
+        if (p < n_pairs) pb.pair_off[p] = running + off + inc - c;
+        running += tot;
+        __syncthreads();
+    }
+    if (t == 0) pb.pair_off[n_pairs] = running;
+}
+
+__global__ __launch_bounds__(64) void k_pairs_fill(const BaProb* __restrict__ probs)
+{
+    const BaProb& pb = probs[blockIdx.y];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= pb.n_pairs) return;
+    const int W = pb.pt_words, L = pb.L;
+    const int i1 = pb.pair_ij[2 * p], i2 = pb.pair_ij[2 * p + 1];
+    const uint32_t* a = pb.pt_bits + (size_t)i1 * W;
+    const uint32_t* b = pb.pt_bits + (size_t)i2 * W;
+    const int32_t* e1 = pb.edge_of + (size_t)i1 * L;
+    const int32_t* e2 = pb.edge_of + (size_t)i2 * L;
+    int2* out = reinterpret_cast<int2*>(pb.pair_e);
+    int base = pb.pair_off[p];
+    for (int w0 = 0; w0 < W; w0 += 64) {
+        const int w = w0 + lane;
+        uint32_t m = w < W ? (a[w] & b[w]) : 0u;
+        const int c = __popc(m);
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+        int pos = base + inc - c;
+        while (m) {
+            const int l = w * 32 + __builtin_ctz(m);
+            m &= m - 1;
+            out[pos++] = make_int2(e1[l], e2[l]);
+        }
+        base += __shfl(inc, 63);
+    }
 }
 
 // ---- register-resident LDL^T + solve (n_pad <= 256): the whole lower triangle lives in the VGPRs of ONE workgroup.
@@ -1506,6 +1599,158 @@ __global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ 
     if (threadIdx.x == 0) pb.scale_part[blockIdx.x] = sc;
 }
 
+// k_solve_update + k_error<1> in ONE launch (a launch boundary costs a step ~4 us plus the second kernel's ramp; the step was 7 launches):
+// workgroup per 64 landmarks, 320 threads.
+//   (a) wave 4 of every workgroup maps ALL poses into LDS (pose <- exp(dx) * pose: a few hundred flops per pose, cheaper than a pass through HBM and a
+//       launch boundary); workgroup 0 also stores them and owns the poses' computeScale terms
+//   (b) waves 0-3, four lanes per landmark: the back-substitution of k_solve_update; the new point goes to LDS and to the other buffer
+//   (c) all threads: the edges of the workgroup's landmarks are ONE contiguous run of the point CSR -- residuals and chi2 of the trial
+//       estimates, thread per entry (k_error<1>'s arithmetic per edge; only the ORDER of the chi2 sum differs: CSR order, partial per
+//       workgroup, partials added in index order by the finisher)
+//   (d) the problem's last workgroup (ticket) runs the accept / reject logic and publishes the step like k_error<1>.
+// Problems with more than kFusedMaxPoses poses keep the two launches.
+constexpr int kFusedMaxPoses = 512;
+constexpr int kFusedThreads = 320;                       // waves 0-3: four lanes per landmark, wave 4: the poses
+// two sums at once over a workgroup of kFusedThreads threads (fixed tree; the totals come back in thread 0)
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* s /*[512]*/, double* s2 /*[512]*/)
+{
+    const int t = threadIdx.x;
+    s[t] = a; s2[t] = b;
+    if (t < 512 - kFusedThreads) { s[kFusedThreads + t] = 0; s2[kFusedThreads + t] = 0; }
+    __syncthreads();
+    for (int d = 256; d >= 1; d >>= 1) { if (t < d) { s[t] += s[t + d]; s2[t] += s2[t + d]; } __syncthreads(); }
+    a = s[0]; b = s2[0];
+}
+__global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, const volatile int* __restrict__ stop_words, int B,
+                                                      int* __restrict__ h_progress, unsigned* __restrict__ grid_ticket)
+{
+    __shared__ double s[512], s2[512];
+    __shared__ DCams cams;
+    __shared__ double s_pose[kFusedMaxPoses * 7];
+    __shared__ double s_pt[64 * 3];
+    __shared__ bool last;
+    const BaProb& pb = probs[blockIdx.y];
+    BaCtl& ctl = ctls[blockIdx.y];
+    if (ctl.state > ST_RETRY) return;
+    const int nb_pts = pb.nb_pts, L = pb.L, P = pb.P, t = threadIdx.x;
+    if ((int)blockIdx.x >= nb_pts) return;
+    // the control word as of the start of the launch: the finisher rewrites it, but only after every workgroup of the problem has arrived
+    const int cur = ctl.cur, robust = ctl.robust;
+    const double lambda = 1e-5 * ctl.maxdiag * ctl.mult, delta = pb.delta;
+    const int32_t* __restrict__ pose_idx = pb.pose_idx;
+    const double* __restrict__ xp = pb.xp;
+    load_cams(&cams, pb.cams);
+    // ---- (a)
+    double sc_pose = 0;
+    if (t >= 256) {                                          // wave 4, while waves 0-3 back-substitute
+        const double* __restrict__ src = pb.poses[cur];
+        double* __restrict__ dst = pb.poses[cur ^ 1];
+        for (int i = t - 256; i < P; i += 64) {
+            double T[7], o[7];
+            for (int k = 0; k < 7; ++k) T[k] = src[7 * i + k];
+            const int pi = pose_idx[i];
+            if (pi >= 0) {
+                pose_oplus(T, xp + 6 * pi, o);
+                for (int k = 0; k < 6; ++k) sc_pose += xp[6 * pi + k] * (lambda * xp[6 * pi + k] + pb.bp[6 * pi + k]);
+            } else {
+                for (int k = 0; k < 7; ++k) o[k] = T[k];
+            }
+            for (int k = 0; k < 7; ++k) s_pose[7 * i + k] = o[k];
+            if (blockIdx.x == 0) for (int k = 0; k < 7; ++k) dst[7 * i + k] = o[k];
+        }
+    }
+    // ---- (b) four lanes per landmark: a thread of its own walks a landmark's ~15 edges one dependent load pair at a time (index -> block
+    //      of H_pl), which was most of k_solve_update's 9.7 us; lane `sub` takes the entries k = sub (mod 4) and the four partial
+    //      sums are added as (p0 + p1) + (p2 + p3)
+    double sc = 0;
+    if (t < 256) {
+        const int lt = t >> 2, sub = t & 3;
+        const int l = blockIdx.x * 64 + lt;
+        const bool on = l < L && pb.pt_active[l];
+        double acc[3] = {0, 0, 0};
+        if (on && pb.np) {
+            const int32_t* __restrict__ pt_edges = pb.pt_edges;
+            const int32_t* __restrict__ pt_pi = pb.pt_pi;
+            const int k1 = pb.pt_off[l + 1];
+            for (int k = pb.pt_off[l] + sub; k < k1; k += 4) {
+                const int pi = pt_pi[k];
+                if (pi < 0) continue;
+                const double* Bm = pb.Hpl + (size_t)pt_edges[k] * 18;
+                const double* xq = xp + pi * 6;
+                for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) acc[j] += Bm[r * 3 + j] * xq[r];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { acc[j] += __shfl_xor(acc[j], 1); acc[j] += __shfl_xor(acc[j], 2); }
+        if (sub == 0 && l < L) {
+            const double* __restrict__ bl = pb.bl;
+            double x[3] = {0, 0, 0};
+            if (on) {
+                const double c[3] = {bl[3 * l] - acc[0], bl[3 * l + 1] - acc[1], bl[3 * l + 2] - acc[2]};
+                const double* D = pb.Dinv + (size_t)l * 9;
+                for (int i = 0; i < 3; ++i) {
+                    x[i] = D[i * 3] * c[0] + D[i * 3 + 1] * c[1] + D[i * 3 + 2] * c[2];
+                    sc += x[i] * (lambda * x[i] + bl[3 * l + i]);
+                }
+            }
+            const double* __restrict__ src = pb.points[cur];
+            double* __restrict__ dst = pb.points[cur ^ 1];
+            for (int k = 0; k < 3; ++k) {
+                const double v = src[3 * l + k] + x[k];
+                pb.xl[3 * l + k] = x[k]; dst[3 * l + k] = v; s_pt[3 * lt + k] = v;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && t >= 256) {                       // the poses' share of computeScale: wave 4's lanes in a fixed tree
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sc_pose += __shfl_xor(sc_pose, d);
+        if (t == 256) pb.scale_part[nb_pts] = sc_pose;
+    }
+    __syncthreads();
+    // ---- (c)
+    double rho0 = 0;
+    {
+        const int l0 = blockIdx.x * 64, l1 = min(l0 + 64, L);
+        const int k0 = pb.pt_off[l0], k1 = pb.pt_off[l1];
+        const int32_t* __restrict__ pt_edges = pb.pt_edges;
+        for (int k = k0 + t; k < k1; k += kFusedThreads) {
+            const int e = pt_edges[k];
+            if (!pb.active[e]) continue;
+            double pc[3];
+            const DCam& c = cams.c[pb.ecam[e]];
+            cam_point(s_pose + 7 * pb.epose[e], s_pt + 3 * (pb.epoint[e] - l0), c, pc);
+            const double e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+            const double e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+            const double w = pb.w[e];
+            const double x2 = e0 * (w * e0) + e1 * (w * e1);
+            pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
+            rho0 += (robust && x2 > delta * delta) ? 2 * sqrt(x2) * delta - delta * delta : x2;
+        }
+    }
+    block_sum2(rho0, sc, s, s2);                             // thread 0: chi2 and computeScale partials of this workgroup
+    // ---- (d)
+    if (t == 0) {
+        pb.scale_part[blockIdx.x] = sc;
+        __hip_atomic_store(&pb.partial[blockIdx.x], rho0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(pb.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (prev == (unsigned)nb_pts - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    double tot = 0, sc_tot = 0;
+    for (int i = t; i < nb_pts; i += kFusedThreads) tot += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = t; i <= nb_pts; i += kFusedThreads) sc_tot += __hip_atomic_load(&pb.scale_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    block_sum2(tot, sc_tot, s, s2);
+    if (t != 0) return;
+    __hip_atomic_store(pb.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lm_accept(pb, ctl, stop_words, tot, sc_tot);
+    publish_step_end(B, h_progress, grid_ticket);
+}
+
 __global__ __launch_bounds__(1024) void k_ctl_init(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B)
 {
     for (int b = threadIdx.x; b < B; b += 1024) {
@@ -1806,9 +2051,11 @@ struct BaContext {
 #endif
         if (stream) (void)hipStreamSynchronize(stream);
         for (hipStream_t a : aux) if (a) (void)hipStreamSynchronize(a);
+        if (dl) (void)hipStreamSynchronize(dl);             // the pair-list kernels of a call that ended before its first k_schur
         tail_pending = false;
     }
     hipEvent_t ev_up = nullptr, ev_done[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_staged = nullptr, ev_pairs = nullptr;   // pair lists on the side stream: upload done -> lists done
     // one LM step of a group = 8 dependent launches with the same arguments every time: optionally replayed as an executable hipGraph
     // (DCS_BA_GRAPH=1, see dcs_ba_local_batch)
     struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; std::vector<hipGraphNode_t> nodes; unsigned shape = 0; };
@@ -1839,6 +2086,9 @@ struct BaContext {
         for (hipEvent_t& e : ev_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (ev_up) (void)hipEventDestroy(ev_up);
         ev_up = nullptr;
+        if (ev_staged) (void)hipEventDestroy(ev_staged);
+        if (ev_pairs) (void)hipEventDestroy(ev_pairs);
+        ev_staged = ev_pairs = nullptr;
         base = nullptr; cap = 0; h_stage = nullptr; stage_cap = 0; h_words = nullptr; words_cap = 0; stream = nullptr; device = -1;
     }
     ~BaContext() { release(); }
@@ -1984,20 +2234,20 @@ private:
 static HostPool& host_pool() { static HostPool* p = new HostPool; return *p; }
 
 struct Round {                                  // structure of one optimisation round (buildIndexMapping + buildStructure)
-    std::vector<int32_t> pose_idx, pt_off, pt_edges, pt_pi, ps_off, ps_edges, pair_ij, pair_off, pair_e;      // pair_e: (e1, e2) interleaved
+    std::vector<int32_t> pose_idx, pt_off, pt_edges, pt_pi, ps_off, ps_edges, pair_ij;
     struct Key { int32_t idx, edge; };              // (free-pose index or -1, edge id): scratch of build_round, kept for its capacity
     std::vector<Key> keys;
-    std::vector<int32_t> cnt, cur_pt, cur_ps;
+    std::vector<int32_t> cur_pt, cur_ps;
     std::vector<uint8_t> pose_act;
     int np = 0, n = 0, n_pad = 0, n_pairs = 0, n_active = 0;
+    size_t n_pair_entries = 0;                      // total length of the pose-pair lists (the device builds them: k_pairs_*)
 };
 
 // returns -1, or the id of an edge that repeats a (pose, point) pair (the pair lists assume at most one, like g2o's hash of Hpl blocks)
 //
 // Host cost matters: the lists are rebuilt on every call (the local map changes between calls) and were 0.26 ms of a 1.95 ms C4 solve.
-// Everything below works on ONE packed record per CSR entry -- (free-pose index, edge) of a point's edges, sorted by pose index -- so
-// the two passes over the ~L * obs^2 / 2 pose pairs (count, fill) touch only that array and the np x np count / cursor matrix: no
-// per-pair chase through edge_pose / pose_idx.
+// The host keeps the two counting sorts over the edges and the per-point ordering + duplicate test; the pose-pair lists of k_schur
+// (~L * obs^2 / 2 entries) are built on the device from the uploaded edges (k_pairs_mark / _scan / _fill) -- the host only sizes them.
 int build_round(const dcs_ba_problem* pb, Round& r)
 {
     const int P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
@@ -2039,9 +2289,9 @@ int build_round(const dcs_ba_problem* pb, Round& r)
     }
     // per point: ONE insertion sort of its (few) edges by (pose index, edge id) -- the order the kernels sum in (fixed poses first:
     // index -1; the counting pass already left them in edge order) -- and the duplicate test on the sorted run: equal indices are
-    // adjacent, the fixed prefix is compared pairwise by pose id (a handful of entries). Pairs (i1 <= i2) are counted on the way.
-    r.cnt.assign((size_t)np * np, 0);
-    int32_t* __restrict__ cntp = r.cnt.data();
+    // adjacent, the fixed prefix is compared pairwise by pose id (a handful of entries). A point seen by f free poses adds one entry to
+    // f (f + 1) / 2 pair lists.
+    size_t entries = 0;
     for (int l = 0; l < L; ++l) {
         const int k0 = r.pt_off[l], k1 = r.pt_off[l + 1];
         Key* __restrict__ kk = keys.data() + k0;
@@ -2058,42 +2308,21 @@ int build_round(const dcs_ba_problem* pb, Round& r)
             for (int b2 = 0; b2 < a; ++b2) if (e_pose[kk[a].edge] == e_pose[kk[b2].edge]) return kk[a].edge;
         for (int k = n_fixed + 1; k < nk; ++k) if (kk[k].idx == kk[k - 1].idx) return kk[k].edge;
         for (int k = 0; k < nk; ++k) { r.pt_edges[k0 + k] = kk[k].edge; r.pt_pi[k0 + k] = kk[k].idx; }
-        for (int a = n_fixed; a < nk; ++a) {
-            int32_t* __restrict__ row = cntp + (size_t)kk[a].idx * np;
-            for (int b = a; b < nk; ++b) ++row[kk[b].idx];
-        }
+        const size_t f = (size_t)(nk - n_fixed);
+        entries += f * (f + 1) / 2;
     }
-    // pose pairs (i1 <= i2) sharing a point, plus every diagonal pair; (e1, e2) lists in point order. The count matrix becomes the
-    // cursor matrix of the fill pass.
-    r.pair_ij.clear(); r.pair_off.assign(1, 0);
-    r.pair_ij.reserve((size_t)np * (np + 1)); r.pair_off.reserve((size_t)np * (np + 1) / 2 + 1);
-    // The DIAGONAL pairs come first: a pose's own list (every edge of the pose) is several times longer than any list it shares with another
-    // pose, k_schur runs one workgroup per pair in list order, and a long workgroup that starts in the second round of the chip's wave slots
-    // is the kernel's tail. (The order of the pairs decides nothing else: every pair writes its own block of S.)
-    for (int pass = 0; pass < 2; ++pass)
+    r.n_pair_entries = entries;
+    // EVERY pose pair (i1 <= i2) gets a workgroup of k_schur; one without a common point finds an empty list and leaves its block of S
+    // zero. The DIAGONAL pairs come first: a pose's own list (every edge of the pose) is several times longer than any list it shares
+    // with another pose, k_schur runs one workgroup per pair in list order, and a long workgroup that starts in the second round of
+    // the chip's wave slots is the kernel's tail. (The order of the pairs decides nothing else: every pair writes its own block of S.)
+    r.n_pairs = np * (np + 1) / 2;
+    r.pair_ij.resize((size_t)2 * r.n_pairs);
+    {
+        int32_t* ij = r.pair_ij.data();
+        for (int i = 0; i < np; ++i) { *ij++ = i; *ij++ = i; }
         for (int i1 = 0; i1 < np; ++i1)
-            for (int i2 = pass == 0 ? i1 : i1 + 1, i2e = pass == 0 ? i1 + 1 : np; i2 < i2e; ++i2) {
-                const int c = cntp[(size_t)i1 * np + i2];
-                if (c || i1 == i2) {
-                    r.pair_ij.push_back(i1); r.pair_ij.push_back(i2);
-                    cntp[(size_t)i1 * np + i2] = r.pair_off.back();
-                    r.pair_off.push_back(r.pair_off.back() + c);
-                }
-            }
-    r.n_pairs = (int)r.pair_ij.size() / 2;
-    r.pair_e.resize((size_t)2 * r.pair_off.back());
-    int2* __restrict__ pe = reinterpret_cast<int2*>(r.pair_e.data());
-    for (int l = 0; l < L; ++l) {
-        const int k0 = r.pt_off[l], k1 = r.pt_off[l + 1];
-        const Key* __restrict__ kk = keys.data() + k0;
-        const int nk = k1 - k0;
-        int a = 0;
-        while (a < nk && kk[a].idx < 0) ++a;
-        for (; a < nk; ++a) {
-            int32_t* __restrict__ row = cntp + (size_t)kk[a].idx * np;
-            const int32_t e1 = kk[a].edge;
-            for (int b = a; b < nk; ++b) pe[row[kk[b].idx]++] = int2{e1, kk[b].edge};
-        }
+            for (int i2 = i1 + 1; i2 < np; ++i2) { *ij++ = i1; *ij++ = i2; }
     }
     return -1;
 }
@@ -2231,8 +2460,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.obs = c.get<double>(2 * E); q.w = c.get<double>(E); q.active = c.get<uint8_t>(E);
             q.pose_idx = c.get<int32_t>(P); q.pt_off = c.get<int32_t>(L + 1); q.pt_edges = c.get<int32_t>(r.pt_edges.size()); q.pt_pi = c.get<int32_t>(r.pt_pi.size());
             q.ps_off = c.get<int32_t>(r.ps_off.size()); q.ps_edges = c.get<int32_t>(r.ps_edges.size());
-            q.pair_ij = c.get<int32_t>(r.pair_ij.size()); q.pair_off = c.get<int32_t>(r.pair_off.size());
-            q.pair_e = c.get<int32_t>(r.pair_e.size());
+            q.pair_ij = c.get<int32_t>(r.pair_ij.size());
+            q.pt_words = (int)(((L + 31) / 32 + 3) & ~(size_t)3); q.pad2 = 0;      // rows are read 16 bytes at a time
             q.cams = c.get<DCams>(1);
         }
         d_probs = c.get<BaProb>(NB);
@@ -2243,6 +2472,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             BaProb& q = hp[i];
             q.ticket = c.get<unsigned>(4);
             for (int g = 0; g < G; ++g) if (i == g_begin[g]) d_grid_ticket[g] = c.get<unsigned>(4);
+            q.pt_bits = c.get<uint32_t>((size_t)q.np * q.pt_words);
             q.S = q.use_reg ? c.get<double>((size_t)q.ld * q.ld) : nullptr;       // pairs without shared points stay 0
         }
         rg.zero_end = c.off;
@@ -2256,8 +2486,10 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.Hpl = c.get<double>(18 * E); q.BD = c.get<double>(18 * E); q.cpose = c.get<double>(27 * E); q.cpoint = c.get<double>(9 * E);
             q.Hll = c.get<double>(9 * L); q.bl = c.get<double>(3 * L); q.Dinv = c.get<double>(9 * L); q.db = c.get<double>(3 * L); q.xl = c.get<double>(3 * L);
             q.Hpp = c.get<double>(36 * P); q.bp = c.get<double>(6 * P); q.bsch = c.get<double>(6 * P); q.xp = c.get<double>(6 * P);
-            q.partial = c.get<double>(q.nblk); q.scale_part = c.get<double>(q.nb_pts + q.nb_pose); q.maxd_part = c.get<double>(q.np + q.nb_pts);
+            q.partial = c.get<double>(std::max(q.nblk, q.nb_pts)); q.scale_part = c.get<double>(q.nb_pts + q.nb_pose); q.maxd_part = c.get<double>(q.np + q.nb_pts);
             q.pt_active = c.get<uint8_t>(L);
+            q.edge_of = c.get<int32_t>((size_t)q.np * L);
+            q.pair_off = c.get<int32_t>((size_t)q.n_pairs + 1); q.pair_e = c.get<int32_t>(2 * rounds[i].n_pair_entries);
         }
         c.off = (c.off + 255) & ~(size_t)255;
         rg.dl_begin = c.off;
@@ -2298,7 +2530,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         memset(stage(q.active), 1, E);
         auto put = [&](const int32_t* d, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage(d), v.data(), sizeof(int32_t) * v.size()); };
         put(q.pose_idx, r.pose_idx); put(q.pt_off, r.pt_off); put(q.pt_edges, r.pt_edges); put(q.pt_pi, r.pt_pi); put(q.ps_off, r.ps_off); put(q.ps_edges, r.ps_edges);
-        put(q.pair_ij, r.pair_ij); put(q.pair_off, r.pair_off); put(q.pair_e, r.pair_e);
+        put(q.pair_ij, r.pair_ij);
         DCams* cams = reinterpret_cast<DCams*>(stage(q.cams));
         memset(cams, 0, sizeof(DCams));
         for (int c = 0; c < pb->n_cams; ++c) {
@@ -2324,6 +2556,30 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     for (int i = 0; i < NB; ++i)
         if (hp[i].iters[0] <= 0) DCS_HIP(hipMemsetAsync(hp[i].chi2, 0, sizeof(double) * hp[i].E, st));    // no error evaluation will ever write it
     hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1024), 0, st, (const BaProb*)d_probs, d_ctls, NB);
+    // The pose-pair lists of k_schur, built where the edges already are. Nothing before the first k_schur reads them, so they are built on
+    // the context's side stream (the one the results come down on) UNDER k_begin / k_reduce_pose / k_prep of step 1: three short launches
+    // in front of the step cost a C4 solve 35 us. (A timed call and the parity tap keep to one stream.)
+    bool pairs_on_side = false;
+    {
+        int max_nblk = 0, max_pairs = 0;
+        for (int i = 0; i < NB; ++i) { max_nblk = std::max(max_nblk, hp[i].nblk); if (hp[i].np) max_pairs = std::max(max_pairs, hp[i].n_pairs); }
+        if (max_pairs) {
+            static const bool side_env = !(getenv("DCS_BA_PAIRS_SIDE") && atoi(getenv("DCS_BA_PAIRS_SIDE")) == 0);
+            hipStream_t ps = st;
+            if (side_env && !ctx.timing && !tl_tap) {
+                if (!ctx.dl) { const int rc_s = ctx.create_stream(&ctx.dl); if (rc_s) return rc_s; }
+                if (!ctx.ev_staged) DCS_HIP(hipEventCreateWithFlags(&ctx.ev_staged, hipEventDisableTiming));
+                if (!ctx.ev_pairs) DCS_HIP(hipEventCreateWithFlags(&ctx.ev_pairs, hipEventDisableTiming));
+                DCS_HIP(hipEventRecord(ctx.ev_staged, st));
+                DCS_HIP(hipStreamWaitEvent(ctx.dl, ctx.ev_staged, 0));
+                ps = ctx.dl; pairs_on_side = true;
+            }
+            hipLaunchKernelGGL(k_pairs_mark, dim3(max_nblk, NB), dim3(256), 0, ps, (const BaProb*)d_probs);
+            hipLaunchKernelGGL(k_pairs_scan, dim3(NB), dim3(1024), 0, ps, (const BaProb*)d_probs);
+            hipLaunchKernelGGL(k_pairs_fill, dim3(max_pairs, NB), dim3(64), 0, ps, (const BaProb*)d_probs);
+            if (pairs_on_side) DCS_HIP(hipEventRecord(ctx.ev_pairs, ps));
+        }
+    }
     DCS_CHECK_LAUNCH();
     if (G > 1) {
         DCS_HIP(hipEventRecord(ctx.ev_up, st));
@@ -2357,10 +2613,11 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // ---- launch geometry of one step of a group (its largest problem decides; smaller ones exit early)
     struct Group {
         hipStream_t st; const BaProb* dp; BaCtl* ctls; int nb, off; int* words; unsigned* ticket;
-        int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, max_npad_blocked = 0;
-        bool any_mfma = false, any_valu = false, any_blocked = false, finished = false;
+        int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, g_pts = 0, max_npad_blocked = 0;
+        bool any_mfma = false, any_valu = false, any_blocked = false, finished = false, fused_update = true;
         int max_n_mfma = 0;
     };
+    static const bool no_fused_update = getenv("DCS_BA_FUSED_UPDATE") && atoi(getenv("DCS_BA_FUSED_UPDATE")) == 0;   // A/B: the two launches
     std::vector<Group> groups((size_t)G);
     int max_steps = 0;
     for (int g = 0; g < G; ++g) {
@@ -2374,6 +2631,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             gr.g_prep = std::max(gr.g_prep, (q.np ? q.nblk : 0) + (q.L + 255) / 256);
             if (q.np) gr.g_schur = std::max(gr.g_schur, q.n_pairs + q.np);
             gr.g_update = std::max(gr.g_update, q.nb_pts + q.nb_pose);
+            gr.g_pts = std::max(gr.g_pts, q.nb_pts);
+            if (q.P > kFusedMaxPoses || no_fused_update) gr.fused_update = false;
             max_steps = std::max(max_steps, (std::max(q.iters[0], 0) + std::max(q.iters[1], 0)) * 10 + 2);
             if (q.np) {
                 if (q.use_reg == 1) gr.max_n_mfma = std::max(gr.max_n_mfma, q.n);
@@ -2414,8 +2673,11 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             if (gr.g_schur) spec.push_back({schur_fn(schur_chunks(nb)), dim3(gr.g_schur, nb), dim3(schur_threads(schur_chunks(nb))), a_cc});
             if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<kLdltSlotsSmall> : (void*)k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
-            spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
-            spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
+            if (gr.fused_update) spec.push_back({(void*)k_update_error, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
+            else {
+                spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
+                spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
+            }
             const unsigned shape = (gr.g_schur ? 1u : 0u) | (gr.any_mfma ? 2u : 0u) | (gr.any_valu ? 4u : 0u) | 8u;
             BaContext::StepGraph& sg = ctx.step_graph[g];
             auto params_of = [](const Spec& sp) { hipKernelNodeParams kp{}; kp.func = sp.fn; kp.gridDim = sp.grid; kp.blockDim = sp.block; kp.sharedMemBytes = 0; kp.kernelParams = sp.args; kp.extra = nullptr; return kp; };
@@ -2442,7 +2704,11 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         BaCtl* ctls = gr.ctls;
         const int nb = gr.nb;
         const volatile int* d_stop = h_words + 16 + gr.off;
-        if (hipGraphExec_t ge = step_exec[(size_t)(&gr - groups.data())]) { DCS_HIP(hipGraphLaunch(ge, gs)); return DCS_OK; }
+        if (hipGraphExec_t ge = step_exec[(size_t)(&gr - groups.data())]) {
+            if (step == 1 && pairs_on_side) DCS_HIP(hipStreamWaitEvent(gs, ctx.ev_pairs, 0));
+            DCS_HIP(hipGraphLaunch(ge, gs));
+            return DCS_OK;
+        }
         mark(step, 0);
         hipLaunchKernelGGL(k_begin, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, nb, gr.words, gr.ticket);            // round change / stale errors, then buildSystem
         hipLaunchKernelGGL(k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), 0, gs, dp, ctls);                             // + computeLambdaInit (first iteration)
@@ -2454,6 +2720,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             hipLaunchKernelGGL(k_pad_identity, dim3(1, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
         }
         if (gr.g_schur) {
+            if (step == 1 && pairs_on_side) DCS_HIP(hipStreamWaitEvent(gs, ctx.ev_pairs, 0));      // the pair lists (side stream)
             const int sc = schur_chunks(nb);
             if (sc == 28) hipLaunchKernelGGL(k_schur<28>, dim3(gr.g_schur, nb), dim3(1024), 0, gs, dp, (const BaCtl*)ctls);
             else if (sc == 14) hipLaunchKernelGGL(k_schur<14>, dim3(gr.g_schur, nb), dim3(512), 0, gs, dp, (const BaCtl*)ctls);
@@ -2475,8 +2742,12 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         DCS_CHECK_LAUNCH();
         mark(step, 2);
-        hipLaunchKernelGGL(k_solve_update, dim3(gr.g_update, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
-        hipLaunchKernelGGL(k_error<1>, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // chi2 of the trial + computeScale + accept / reject, progress
+        if (gr.fused_update) {
+            hipLaunchKernelGGL(k_update_error, dim3(gr.g_pts, nb), dim3(kFusedThreads), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // back-substitution, oplus, chi2 of the trial + computeScale + accept / reject, progress
+        } else {
+            hipLaunchKernelGGL(k_solve_update, dim3(gr.g_update, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
+            hipLaunchKernelGGL(k_error<1>, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // chi2 of the trial + computeScale + accept / reject, progress
+        }
         mark(step, 3);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
@@ -2538,6 +2809,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, st));
         DCS_HIP(hipStreamSynchronize(st));
+        if (pairs_on_side) DCS_HIP(hipStreamSynchronize(ctx.dl));
         ctx.tail_pending = false;                           // every group's queue was waited for: nothing is in flight
     }
     const float opt_ms = (float)ms_since(t_opt0);
