@@ -39,6 +39,28 @@ def test_ba_small_vs_oracle(pkg, oracle, synth, kw):
     _compare(pkg.Optimizer.LocalBundleAdjustment(pb), _oracle_run(oracle, pb), pb)
 
 
+def _restrict(pb, keep):
+    """the problem with only the edges keep[e] (same poses and points)"""
+    q = dict(pb)
+    for k in ("edge_pose", "edge_point", "edge_cam", "obs", "inv_sigma2"):
+        q[k] = np.ascontiguousarray(np.asarray(pb[k])[keep])
+    return q
+
+
+def test_ba_sparse_covisibility_vs_oracle(pkg, oracle, synth):
+    """Pose pairs WITHOUT a common point (their block of the reduced camera system stays zero: the pair lists are built on the
+    device from per-pose bit rows, and an empty list must leave the block alone) and points seen by fixed poses only: two clusters
+    of key frames that share no map point, then a chain in which a key frame only shares points with its neighbours."""
+    pb = synth.ba_problem(n_poses=24, n_fixed=4, n_points=700, obs_per_point=8, seed=12)
+    ep, el = np.asarray(pb["edge_pose"]), np.asarray(pb["edge_point"])
+    P = len(pb["poses"])
+    clusters = _restrict(pb, (ep < P // 2) == (el % 2 == 0))
+    chain = _restrict(pb, np.abs((ep * 7) % P - (el % P)) <= 2)
+    for q in (clusters, chain):
+        assert len(q["edge_pose"]) > 200
+        _compare(pkg.Optimizer.LocalBundleAdjustment(q), _oracle_run(oracle, q), q)
+
+
 def test_ba_c4_vs_oracle_and_golden(pkg, oracle, synth):
     pb = synth.ba_problem()                     # 50 KF / 2000 MP / 20000 edges
     got = pkg.Optimizer.LocalBundleAdjustment(pb)

@@ -1,6 +1,7 @@
 """The opt-in paths of the BA solver (read from the environment once per process) still give the default path's results:
-the LM step as one hipGraph, one step of look-ahead, the ordered download, one stream group (bit for bit), and the
-column-by-column VALU factorisation (another summation order: to 1e-9)."""
+the LM step as one hipGraph, one step of look-ahead, the ordered download, one stream group, the pose-pair lists built on the main
+stream instead of the side stream (bit for bit), and -- other summation orders, to 1e-9 -- the column-by-column VALU factorisation and
+the two-launch update + error evaluation (k_solve_update + k_error<1>, the path of problems with more than 512 poses)."""
 import json, os, subprocess, sys
 import numpy as np
 import pytest
@@ -41,10 +42,12 @@ def _run(extra):
 
 def test_ba_opt_in_paths_equal_default():
     base = _run({})
-    for extra in ({"DCS_BA_GRAPH": "1"}, {"DCS_BA_LOOKAHEAD": "1"}, {"DCS_BA_DL_STREAM": "0"}, {"DCS_BA_GROUPS": "1"}, {"DCS_BA_GROUPS": "4"}):
+    for extra in ({"DCS_BA_GRAPH": "1"}, {"DCS_BA_LOOKAHEAD": "1"}, {"DCS_BA_DL_STREAM": "0"}, {"DCS_BA_GROUPS": "1"}, {"DCS_BA_GROUPS": "4"},
+                  {"DCS_BA_PAIRS_SIDE": "0"}):
         got = _run(extra)
         assert got["digest"] == base["digest"], extra
-    valu = _run({"DCS_BA_LDLT_VALU": "1"})
-    for a, b in zip(valu["solves"], base["solves"]):
-        assert a["iters"] == b["iters"] and a["trials"] == b["trials"]
-        assert np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-9
+    for extra in ({"DCS_BA_LDLT_VALU": "1"}, {"DCS_BA_FUSED_UPDATE": "0"}, {"DCS_BA_FUSED_UPDATE": "0", "DCS_BA_GRAPH": "1"}):
+        other = _run(extra)
+        for a, b in zip(other["solves"], base["solves"]):
+            assert a["iters"] == b["iters"] and a["trials"] == b["trials"], extra
+            assert np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-9, extra
