@@ -1312,6 +1312,9 @@ constexpr int kPatchDw = 16;                // dwords per staged row: 4 x 16 B c
 constexpr int kRawR = kPatchR + 3;          // 21
 constexpr int kRawRows = 2 * kRawR + 1;     // 43
 constexpr int kRawTileRows = 48;            // 3 GEMM row tiles (rows 43 .. 47: whatever LDS holds, never read back)
+constexpr int kRawStoreRows = 44;           // rows a wave's LDS region really has: the last tile's rows 44 .. 47 are read from whatever follows it (the next wave's
+                                            // region, the tables behind s_patch) and their row pairs 22 / 23 are not stored -- 1 280 B less per workgroup: 19 968 B = EIGHT
+                                            // workgroups per CU instead of seven (the kernel gains with every resident workgroup: 565 / 479 / 399 / 382 us at 3 / 4 / 6 / 7)
 constexpr int kRawPitch = 80;               // bytes per staged raw row: 64 + 16, so that the 16-byte A-operand reads of 8 consecutive rows hit 8 different bank groups
 constexpr int kHPairs = 24;                 // row pairs of the 3 x 16 rows the GEMM produces (22 used)
 constexpr int kHCols = 40;                  // columns of the horizontal sums (37 used); 2 * 40 dwords = 16 banks: the (g, g + 1) halves of a wave's store miss each other
@@ -1322,6 +1325,9 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 #endif
 #ifndef DCS_DESC_WAVES
 #define DCS_DESC_WAVES 4
+#endif
+#ifndef DCS_DESC_WPE                         // minimum waves per SIMD the register allocation must allow
+#define DCS_DESC_WPE 8
 #endif
 constexpr int kDescKp = DCS_DESC_KP;        // keypoints per workgroup
 constexpr int kDescWaves = DCS_DESC_WAVES;  // waves per workgroup
@@ -1404,13 +1410,13 @@ int launch_debug_sincosf(const float* d_x, int n, float* d_c, float* d_s, hipStr
 //   C. one wave per keypoint: 37x64 B blurred neighbourhood -> LDS (16-byte loads), 4 rounds of 64 rBRIEF tests.
 // FUSED keeps four workgroups per CU: <= 40 960 B of LDS each and <= 128 registers per lane (amdgpu_waves_per_eu makes that the compiler's budget)
 template <bool FUSED>       // FUSED: no blurred pyramid exists, phase C blurs the raw patch itself
-__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(4))) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
+__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(DCS_DESC_WPE))) void k_describe(LevelSet raw, LevelSet blurred, DescribeParams prm,
                                                   const SelKp* __restrict__ sel, const int32_t* __restrict__ img_off,
                                                   const int32_t* __restrict__ lvl_cnt, dcs_keypoint* __restrict__ kp_out,
                                                   uint8_t* __restrict__ desc_out, int cap, int32_t* __restrict__ n_out, int n_images, int chunks,
                                                   const int32_t* __restrict__ dense_total, int dense_cap)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_patch[kDescWaves][FUSED ? kRawTileRows * kRawPitch / 4 : kPatchRows * kPatchDw];
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[kDescWaves][FUSED ? kRawStoreRows * kRawPitch / 4 : kPatchRows * kPatchDw];
     __shared__ __attribute__((aligned(16))) uint32_t s_btab[FUSED ? kBTabEntries * 4 : 4];
     __shared__ float4 s_pattern[256];
     __shared__ uint32_t s_mask[kIcMaskWords];
@@ -1593,7 +1599,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     } else {
     uint32_t* patch = s_patch[wave];
     uint32_t* hp = patch;                                    // the GEMM works in place: 16 staged rows (16 x 80 B) become 8 row pairs (8 x 160 B)
-    static_assert(16 * kRawPitch == 8 * kHCols * 4 && kRawTileRows * kRawPitch == kHPairs * kHCols * 4, "in-place horizontal pass");
+    static_assert(16 * kRawPitch == 8 * kHCols * 4 && kRawTileRows * kRawPitch == kHPairs * kHCols * 4 && kRawStoreRows >= kRawRows && kRawStoreRows % 2 == 0, "in-place horizontal pass");
     const int r_lane = lane >> 2, c4 = lane & 3;             // staging: 16 rows x 4 x 16 B per wave pass; 43 rows = 3 passes
     const int mc = lane & 15, mg = lane >> 4;                // GEMM: A row / B column mc, k-group mg (k = 16 mg + byte); D: column mc, rows 4 mg + r
     uint4 q0, q1, q2;
@@ -1689,6 +1695,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
                 const v4i_t d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[1], c_init, 0, 0, 0);
                 const v4i_t d2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[2], c_init, 0, 0, 0);
                 uint32_t* o = hrow + (8 * mt) * kHCols;
+                if (mt == 2 && mg == 3) continue;                // row pairs 22 / 23 (rows 44 .. 47): beyond the wave's region, never read
                 o[0] = (unsigned)d0.x | ((unsigned)d0.y << 16); o[kHCols] = (unsigned)d0.z | ((unsigned)d0.w << 16);
                 o[16] = (unsigned)d1.x | ((unsigned)d1.y << 16); o[16 + kHCols] = (unsigned)d1.z | ((unsigned)d1.w << 16);
                 if (mc < 8) { o[32] = (unsigned)d2.x | ((unsigned)d2.y << 16); o[32 + kHCols] = (unsigned)d2.z | ((unsigned)d2.w << 16); }
@@ -1749,7 +1756,8 @@ int launch_describe(const LevelSet& raw, const LevelSet& blurred, const Describe
                     uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s, const int32_t* d_dense_total, int dense_cap, bool fused)
 {
     const int gx = max_per_image > 0 ? (max_per_image + kDescKp - 1) / kDescKp : 1;
-    if (fused) hipLaunchKernelGGL(k_describe<true>, dim3(gx * n_images), dim3(64 * kDescWaves), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
+    static const size_t lds_pad = getenv("DCS_DESC_LDS_PAD") ? (size_t)atoi(getenv("DCS_DESC_LDS_PAD")) : 0;      // measurement aid: extra LDS per workgroup = fewer of them per CU
+    if (fused) hipLaunchKernelGGL(k_describe<true>, dim3(gx * n_images), dim3(64 * kDescWaves), lds_pad, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
                                   d_desc, cap, d_n_out, n_images, gx, d_dense_total, dense_cap);
     else hipLaunchKernelGGL(k_describe<false>, dim3(gx * n_images), dim3(64 * kDescWaves), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
                             d_desc, cap, d_n_out, n_images, gx, d_dense_total, dense_cap);
