@@ -670,7 +670,6 @@ __host__ __device__ inline size_t s_tile_off(int x, int y)       // element (x, 
 // C list chunks x 36 block entries per workgroup (4 list entries in flight per thread); partials combined in fixed order. A C4 problem
 // has ~860 such workgroups per trial and a batch of 8 problems ~6 900: 16-wave workgroups (C = 28) for every group size needed 13
 // rounds of the chip's wave slots for 8 problems (97 us), 4-wave ones (C = 7) 4 rounds (65 us); a single problem is the other way round.
-constexpr int kSchurChunks = 7;
 constexpr int kSchurFine = 28;                           // partial sums per S entry: list entry k belongs to partial k % 28, whatever the workgroup size
 constexpr int kSchurThreads = 256;
 constexpr int kSchurRhsChunks = 42;                      // 42 x 6 rows = 252 threads for the reduced right-hand side
@@ -1106,7 +1105,6 @@ constexpr int kLS = 17;                        // padded LDS row stride of the 1
 constexpr int kLdltWorkers = DCS_LDLT_WORKERS; // waves that own tiles; one more wave runs the chain of diagonal blocks
 constexpr int kLdltSlotsSmall = (120 + kLdltWorkers - 1) / kLdltWorkers;       // <= 15 block rows (n <= 240): 120 tiles
 constexpr int kLdltSlotsBig = (136 + kLdltWorkers - 1) / kLdltWorkers;         // 16 block rows: 136 tiles
-constexpr int kLdltStage = (2 * 256 * kLS) / (kLdltWorkers * 16 * kLS) >= 4 ? 4 : (2 * 256 * kLS) / (kLdltWorkers * 16 * kLS);   // tiles per wave staged at once in Lp[1] + Wn
 constexpr int kLdltThreads = 64 * (kLdltWorkers + 1);
 constexpr int kDiagWave = kLdltWorkers;
 
