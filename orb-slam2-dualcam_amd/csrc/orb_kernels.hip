@@ -615,13 +615,23 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         // pixel that scores >= th; a pixel that scores < th may be stored with a smaller value than cv::FAST's -- it is never
         // emitted and loses every comparison against a neighbour that is (s(q) >= th > both values). A second pass rewrites the
         // first pass's entries (its list is a superset), so every stored score >= min_th is exact then.
-        for (int i = lane; i < n_list; i += 64) {
-            const int yx = s_list[i], y = yx >> 8, x = yx & 255;
+        // The list shrinks once more on the way: only the pixels that score >= th go on to the suppression (every entry of a round is read before
+        // the round's survivors are written back, to positions that were read already).
+        int n_nms = 0;
+        for (int i0 = 0; i0 < n_list; i0 += 64) {                // wave-uniform
+            const int i = i0 + lane;
+            const bool valid = i < n_list;
+            const int yx = valid ? s_list[i] : ((3 << 8) | 3), y = yx >> 8, x = yx & 255;
             int o = (y - 3) * P + (x - 3);
             asm("" : "+v"(o));                          // opaque: keeps the 17 ring offsets non-negative immediates of ONE base address
             const int s = fast_score<P, D16Z>(px + o, th);
-            sc[__mul24(y, sc_pitch) + x] = (uint8_t)s;
+            if (valid) sc[__mul24(y, sc_pitch) + x] = (uint8_t)s;
+            const bool corner = valid && s >= th;
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(corner);
+            if (corner) s_list[n_nms + rank_in(mk)] = (uint16_t)yx;
+            n_nms += __popcll(mk);
         }
+        n_list = n_nms;
         __syncthreads();
         DCS_FAST_SECTION(3);
         // ---- 4. NMS + ordered emission: keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } (neighbours below T
@@ -635,8 +645,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
                 const int yx = s_list[i];
                 y = yx >> 8; x = yx & 255;
                 const uint8_t* c = sc + __mul24(y, sc_pitch) + x;
-                s = c[0];
-                if (s >= th) {
+                s = c[0];                                          // >= th: the scoring loop kept only those
+                {
                     const uint8_t* cu = c - sc_pitch; const uint8_t* cd2 = c + sc_pitch;
                     // seven two-input 16-bit maxima: the compiler's own choice, v_max3_u16, occupies the SIMD 3.3 x as long as a v_max_u16
                     // (profiles/r04_valu_rate_probe.txt: 2.47 vs 0.75 ticks), so the pairs are pinned with asm
