@@ -372,6 +372,33 @@ __device__ __forceinline__ int fast_score(const uint8_t* b, int th)
 //   4. strict 8-neighbour NMS inside the ROI's detection area, iniTh -> minTh fallback when the cell has no
 //      iniTh keypoint (vKeysCell.empty(), :812), ordered emission into the cell's fixed slot range.
 // LDS: px[rh][P] + score[rh][P] bytes + survivor list (u16), sized by the host for the largest cell.
+#ifndef DCS_FAST_CMPX_NOP
+#define DCS_FAST_CMPX_NOP 4
+#endif
+#define DCS_STR2(x) #x
+#define DCS_STR(x) DCS_STR2(x)
+// ordered append of `yx` to a 16-bit list in LDS for the lanes with (int16) value > (int16) limit; end_addr = LDS byte address behind the
+// last entry (scalar, advanced here). The compare is a v_cmpx: it writes EXEC itself, so the rank (v_mbcnt of exec), the store and the
+// count run on it directly and ONE s_mov restores the wave (exec_full). Returns the compare's mask.
+__device__ __forceinline__ unsigned long long fast_append_gt(unsigned value, unsigned limit, unsigned yx, unsigned& end_addr, unsigned long long exec_full)
+{
+    unsigned long long m;
+    unsigned at, cnt;
+    asm volatile("v_cmpx_gt_i16_e64 %[m], %[v], %[lim]\n\t"
+                 "s_nop " DCS_STR(DCS_FAST_CMPX_NOP) "\n\t"      // v_cmpx writes EXEC, the v_mbcnt behind it reads exec_lo as DATA: wait states the assembler does not insert
+                 "v_mbcnt_lo_u32_b32 %[at], exec_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[at], exec_hi, %[at]\n\t"
+                 "v_lshl_add_u32 %[at], %[at], 1, %[end]\n\t"
+                 "ds_write_b16 %[at], %[yx]\n\t"
+                 "s_bcnt1_i32_b64 %[cnt], exec\n\t"
+                 "s_lshl1_add_u32 %[end], %[cnt], %[end]\n\t"
+                 "s_mov_b64 exec, %[full]"
+                 : [m] "=&s"(m), [at] "=&v"(at), [cnt] "=&s"(cnt), [end] "+s"(end_addr)
+                 : [v] "v"(value), [lim] "v"(limit), [yx] "v"(yx), [full] "s"(exec_full)
+                 : "memory", "scc");
+    return m;
+}
+
 template <int P, bool D16Z>           // P: LDS row pitch in bytes (40 / 44: the ROI's own bytes; 48 / 64 / 128: aligned rows), compile-time so that the ring offsets are immediates; D16Z: see fast_score
 __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
                                                    dcs_candidate* __restrict__ slots, size_t slots_per_image,
@@ -520,6 +547,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         };
         auto compass = [&](const uint8_t* b) -> bool { return (int16_t)compass_margin(b) > (int16_t)th; };
         n_list = 0;
+        const unsigned list_addr = lds_addr(s_list);
+        unsigned long long exec_full;                                                           // the wave's execution mask in this region (restored after every append)
+        asm volatile("s_mov_b64 %0, exec" : "=s"(exec_full));
         if (dw <= 32) {                                  // two detection rows per round: lanes 0-31 row y, lanes 32-63 row y + 1
             // Round 4: the CU's SCALAR unit is the kernel's second wall (profiles/r04_valu_rate_probe.txt: a two-operand scalar instruction
             // costs 2.4 ticks of SIMD time, 1.8 x a slow-class vector one; a v_mad + s_add pair runs at the scalar rate), and this loop spent
@@ -531,35 +561,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             const uint8_t* b = px + (lane >> 5) * P + (lane & 31);
             unsigned yx = (unsigned)(((3 + (lane >> 5)) << 8) | (3 + (lane & 31)));
             unsigned long long m = 0;
-            const unsigned list_addr = lds_addr(s_list);
             unsigned end_addr = list_addr;                                                       // scalar, behind the last entry
-            unsigned long long exec_full;                                                       // the wave's execution mask in this region (restored after every append)
-            asm volatile("s_mov_b64 %0, exec" : "=s"(exec_full));
             // Every lane evaluates the test (a lane outside the detection area reads the score map at worst: still inside
             // the LDS allocation). No branch: the append is one LDS store under exec = the lanes that pass.
             // When dh is odd the upper half-wave's last row lies below the detection area: whatever it appends comes after
             // every valid entry and is cut off by the count below.
-            auto round = [&](const uint8_t* bb, unsigned yxr) {
-                const uint16_t mg = compass_margin(bb);
-                unsigned at, cnt;
-                asm volatile("v_cmpx_gt_i16_e64 %[m], %[mg], %[thl]\n\t"
-#ifndef DCS_FAST_CMPX_NOP
-#define DCS_FAST_CMPX_NOP 4
-#endif
-#define DCS_STR2(x) #x
-#define DCS_STR(x) DCS_STR2(x)
-                             "s_nop " DCS_STR(DCS_FAST_CMPX_NOP) "\n\t"      // v_cmpx writes EXEC, the v_mbcnt behind it reads exec_lo as DATA: wait states the assembler does not insert
-                             "v_mbcnt_lo_u32_b32 %[at], exec_lo, 0\n\t"
-                             "v_mbcnt_hi_u32_b32 %[at], exec_hi, %[at]\n\t"
-                             "v_lshl_add_u32 %[at], %[at], 1, %[end]\n\t"
-                             "ds_write_b16 %[at], %[yx]\n\t"
-                             "s_bcnt1_i32_b64 %[cnt], exec\n\t"
-                             "s_lshl1_add_u32 %[end], %[cnt], %[end]\n\t"
-                             "s_mov_b64 exec, %[full]"
-                             : [m] "=&s"(m), [at] "=&v"(at), [cnt] "=&s"(cnt), [end] "+s"(end_addr)
-                             : [mg] "v"(mg), [thl] "v"(th_lane), [yx] "v"(yxr), [full] "s"(exec_full)
-                             : "memory", "scc");
-            };
+            auto round = [&](const uint8_t* bb, unsigned yxr) { m = fast_append_gt(compass_margin(bb), th_lane, yxr, end_addr, exec_full); };
             // four rounds per trip: the later ones' LDS reads are immediate offsets of the first one's address, and the loop's
             // scalar bookkeeping is paid once per eight rows
             int yy = 0;
@@ -590,22 +597,21 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         // still holds everything the non-maximum suppression at th compares, and the minThFAST pass's list is still a superset of this one.
 #ifndef DCS_FAST_NO_DIAG
         {
-            int n2 = 0;
-            for (int i0 = 0; i0 < n_list; i0 += 64) {           // wave-uniform
+            const int n_in = __builtin_amdgcn_readfirstlane(n_list);
+            unsigned end2 = list_addr;
+            for (int i0 = 0; i0 < n_in; i0 += 64) {              // wave-uniform
                 const int i = i0 + lane;
-                const bool valid = i < n_list;
-                const int yx = valid ? s_list[i] : ((3 << 8) | 3);
-                const uint8_t* b = px + __mul24((yx >> 8) - 3, P) + ((yx & 255) - 3);
+                const unsigned lim = i < n_in ? (unsigned)th : 0x7fffu;           // a lane past the end reads the last entry and appends nothing
+                const unsigned yx = s_list[min(i, n_in - 1)];
+                const uint8_t* b = px + __mul24((int)(yx >> 8) - 3, P) + ((int)(yx & 255u) - 3);
                 const uint16_t v = b[3 * P + 3];
                 const uint16_t r2 = b[5 * P + 5], r6 = b[P + 5], r10 = b[P + 1], r14 = b[5 * P + 1];
                 const uint16_t e = min(max(r2, r10), max(r6, r14)), f = max(min(r2, r10), min(r6, r14));
                 const int16_t up = (int16_t)(uint16_t)(e - v), down = (int16_t)(uint16_t)(v - f);
-                const bool keep = valid && (int16_t)max(up, down) > (int16_t)th;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-                if (keep) s_list[n2 + rank_in(m)] = (uint16_t)yx;   // n2 + rank <= i: never ahead of an entry not read yet (a wave's LDS operations complete in order)
-                n2 += __popcll(m);
+                // in place: the write position is never ahead of an entry not read yet (a wave's LDS operations complete in order)
+                (void)fast_append_gt((unsigned)(uint16_t)max(up, down), lim, yx, end2, exec_full);
             }
-            n_list = n2;
+            n_list = (int)((end2 - list_addr) >> 1);
         }
         __syncthreads();
 #endif
@@ -617,21 +623,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         // first pass's entries (its list is a superset), so every stored score >= min_th is exact then.
         // The list shrinks once more on the way: only the pixels that score >= th go on to the suppression (every entry of a round is read before
         // the round's survivors are written back, to positions that were read already).
-        int n_nms = 0;
-        for (int i0 = 0; i0 < n_list; i0 += 64) {                // wave-uniform
-            const int i = i0 + lane;
-            const bool valid = i < n_list;
-            const int yx = valid ? s_list[i] : ((3 << 8) | 3), y = yx >> 8, x = yx & 255;
-            int o = (y - 3) * P + (x - 3);
-            asm("" : "+v"(o));                          // opaque: keeps the 17 ring offsets non-negative immediates of ONE base address
-            const int s = fast_score<P, D16Z>(px + o, th);
-            if (valid) sc[__mul24(y, sc_pitch) + x] = (uint8_t)s;
-            const bool corner = valid && s >= th;
-            const unsigned long long mk = __builtin_amdgcn_ballot_w64(corner);
-            if (corner) s_list[n_nms + rank_in(mk)] = (uint16_t)yx;
-            n_nms += __popcll(mk);
+        {
+            const int n_in = __builtin_amdgcn_readfirstlane(n_list);
+            unsigned end3 = list_addr;
+            for (int i0 = 0; i0 < n_in; i0 += 64) {              // wave-uniform
+                const int i = i0 + lane;
+                const bool valid = i < n_in;
+                const unsigned yx = s_list[min(i, n_in - 1)];
+                const int y = (int)(yx >> 8), x = (int)(yx & 255u);
+                int o = (y - 3) * P + (x - 3);
+                asm("" : "+v"(o));                          // opaque: keeps the 17 ring offsets non-negative immediates of ONE base address
+                const int s = fast_score<P, D16Z>(px + o, th);
+                if (valid) sc[__mul24(y, sc_pitch) + x] = (uint8_t)s;
+                (void)fast_append_gt((unsigned)s, valid ? (unsigned)(th - 1) : 0x7fffu, yx, end3, exec_full);       // s >= th
+            }
+            n_list = (int)((end3 - list_addr) >> 1);
         }
-        n_list = n_nms;
         __syncthreads();
         DCS_FAST_SECTION(3);
         // ---- 4. NMS + ordered emission: keep(T) = { p : s(p) >= T and s(p) > s(q) for the 8 neighbours q } (neighbours below T
