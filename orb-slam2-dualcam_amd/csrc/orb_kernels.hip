@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         // a round of this test (mean scoring rounds per cell 2.3 -> 1.6). Every pixel that scores >= th passes both tests, so the score map
         // still holds everything the non-maximum suppression at th compares, and the minThFAST pass's list is still a superset of this one.
 #ifndef DCS_FAST_NO_DIAG
-        {
+        if (__builtin_amdgcn_readfirstlane(n_list) > 64) {      // a list that already fits ONE scoring round gains nothing from being shorter
             const int n_in = __builtin_amdgcn_readfirstlane(n_list);
             unsigned end2 = list_addr;
             for (int i0 = 0; i0 < n_in; i0 += 64) {              // wave-uniform
