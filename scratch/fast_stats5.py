@@ -11,6 +11,7 @@ ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -
 th = 20
 SCORE, FILT, FILT2 = 110, 21, 30
 tot = dict(cells=0, s0=0, s1=0, s2=0, r0=0, r1=0, r2=0)
+band = {T: 0 for T in (88, 92, 96, 100, 104, 108, 112)}       # policy: no diagonal test for T < n <= 128
 for l in range(8):
     v = orc.level_image(l).astype(np.int32); H, W = v.shape
     c = v[3:-3, 3:-3]
@@ -41,8 +42,10 @@ for l in range(8):
             if n0 > 64 and n1 > 64 and (n1 - 1) % 64 < 17:
                 n2 = nC; c2 += FILT2 * r1
             r2 = math.ceil(n2 / 64)
+            for T in band: band[T] += (SCORE * r0 if (n0 <= 64 or T < n0 <= 128) else SCORE * math.ceil(nA / 64) + FILT * r0)
             tot["cells"] += 1; tot["r0"] += r0; tot["r1"] += r1; tot["r2"] += r2
             tot["s0"] += SCORE * r0; tot["s1"] += SCORE * r1 + c1; tot["s2"] += SCORE * r2 + c2
 n = tot["cells"]
 print("cells %d; scoring rounds per cell: none %.2f, diagonal %.2f, + odd quads %.2f; filter + scoring instructions per cell: %.0f / %.0f / %.0f"
       % (n, tot["r0"] / n, tot["r1"] / n, tot["r2"] / n, tot["s0"] / n, tot["s1"] / n, tot["s2"] / n))
+print("no diagonal test for T < n <= 128:", {T: round(v / n, 1) for T, v in band.items()})
