@@ -102,6 +102,13 @@ struct dcs_orb {
     DevBuf<uint8_t> d_pyr, d_blur;
     DevBuf<int16_t> d_rtab;
     struct RTab { size_t xofs, xa, yofs, ya; } rtab[kMaxLevels];
+    // Round 5, "FAST emits the next level": per level l < L - 1 the packed row table {sy, b0 | b1 << 16} of level l + 1 and the frame of
+    // level l + 1 that no cell of level l produces (k_resize on four rectangles). emit_ok: the geometry allows it (every cell's taps inside its ROI).
+    DevBuf<int32_t> d_erows;
+    size_t erows_off[kMaxLevels] = {};
+    ResizeRects frame[kMaxLevels] = {};
+    bool emit_ok = false;
+    int emit_mode = -1;                            // DCS_ORB_EMIT when the handle is created: 0 / 1, unset = choose per call
     std::vector<CellDesc> h_cells;
     std::vector<int32_t> h_level_cell_begin;
     DevBuf<CellDesc> d_cells;
@@ -250,7 +257,7 @@ int dcs_orb::configure(int rows, int cols)
     for (int l = 1; l < L; ++l) {
         ResizeTable rt;
         rt.build(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h);
-        while (tab.size() % 4) tab.push_back(0);                 // 8-byte aligned packed columns {sx, 0, a0, a1}
+        while (tab.size() % 8) tab.push_back(0);                 // 16-byte aligned packed columns {sx, 0, a0, a1}: an emitting FAST cell reads four of them as two 16-byte loads
         rtab[l].xofs = tab.size();
         for (size_t x = 0; x < rt.xofs.size(); ++x) { tab.push_back(rt.xofs[x]); tab.push_back(0); tab.push_back(rt.xa[2 * x]); tab.push_back(rt.xa[2 * x + 1]); }
         rtab[l].xa = tab.size();
@@ -287,6 +294,90 @@ int dcs_orb::configure(int rows, int cols)
         }
     }
     h_level_cell_begin[L] = (int)h_cells.size();
+    // ---- which part of level l + 1 each cell of level l produces (k_fast_cells<EMIT>), and the frame left to k_resize.
+    // Columns: cell column j owns the destination dwords k whose first source column sx(4k) lies in [x0_j, x0_{j+1}) (the last emitting column:
+    // up to its ROI's end), provided every tap of the dword's four pixels lies inside the ROI; rows likewise with the upper source row. The ROI
+    // reaches 6 pixels into the next cell, a dword's taps span <= 3 * scale + 2 columns: always inside for scale <= 1.33; anything else
+    // (a cell that cannot hold its share, skipped or degenerate cells inside the grid) switches the mode off for this image size.
+    emit_ok = L > 1;
+    std::vector<int32_t> erows;
+    for (int l = 0; l + 1 < L && emit_ok; ++l) {
+        const LevelGeom& lg = g.lv[l];
+        const LevelGeom& ld = g.lv[l + 1];
+        ResizeTable rt;
+        rt.build(lg.w, lg.h, ld.w, ld.h);
+        erows_off[l] = erows.size();
+        for (int dy = 0; dy < ld.h; ++dy) { erows.push_back(rt.yofs[dy]); erows.push_back((int32_t)((uint32_t)(uint16_t)rt.ya[2 * dy] | ((uint32_t)(uint16_t)rt.ya[2 * dy + 1] << 16))); }
+        const int n_x4 = (ld.w + 3) / 4;
+        const int c0 = h_level_cell_begin[l];
+        // emitting columns / rows: the leading run of cells with a usable ROI
+        int ncol = 0, nrow = 0;
+        while (ncol < lg.n_cols && h_cells[c0 + ncol].rw >= 7) ++ncol;
+        while (nrow < lg.n_rows && h_cells[c0 + nrow * lg.n_cols].rh >= 7) ++nrow;
+        for (int j = ncol; j < lg.n_cols; ++j) if (h_cells[c0 + j].rw >= 7) emit_ok = false;                     // a gap inside the grid
+        for (int i = nrow; i < lg.n_rows; ++i) if (h_cells[c0 + i * lg.n_cols].rh >= 7) emit_ok = false;
+        if (ncol == 0 || nrow == 0) emit_ok = false;
+        if (!emit_ok) break;
+        std::vector<int> kx_begin(ncol + 1), dy_begin(nrow + 1);
+        auto dword_fits = [&](int k, int lo, int hi) {           // all taps of destination pixels 4k .. 4k + 3 inside source columns [lo, hi)
+            if (4 * k + 3 >= ld.w) return false;                 // a partial last dword belongs to the frame
+            for (int i = 0; i < 4; ++i) {
+                const int sx = rt.xofs[4 * k + i];
+                if (sx < lo || sx + 1 >= hi || sx < rt.xofs[4 * k]) return false;
+            }
+            return rt.xofs[4 * k + 3] + 1 - rt.xofs[4 * k] <= 8;
+        };
+        {
+            int k = 0;
+            for (int j = 0; j < ncol; ++j) {
+                const CellDesc& c = h_cells[c0 + j];
+                const int own_hi = j + 1 < ncol ? h_cells[c0 + j + 1].x0 : c.x0 + c.rw;
+                while (k < n_x4 && 4 * k < ld.w && rt.xofs[4 * k] < c.x0) ++k;           // (only before the first column: the frame's left part)
+                kx_begin[j] = k;
+                while (k < n_x4 && 4 * k < ld.w && rt.xofs[4 * k] < own_hi) {
+                    if (!dword_fits(k, c.x0, c.x0 + c.rw)) { if (j + 1 < ncol) emit_ok = false; break; }   // the last column simply stops here
+                    ++k;
+                }
+                if (j + 1 < ncol && (4 * k >= ld.w || rt.xofs[4 * k] < own_hi)) emit_ok = false;
+            }
+            kx_begin[ncol] = k;
+        }
+        {
+            int d = 0;
+            for (int i = 0; i < nrow; ++i) {
+                const CellDesc& c = h_cells[c0 + i * lg.n_cols];
+                const int own_hi = i + 1 < nrow ? h_cells[c0 + (i + 1) * lg.n_cols].y0 : c.y0 + c.rh;
+                while (d < ld.h && rt.yofs[d] < c.y0) ++d;
+                dy_begin[i] = d;
+                while (d < ld.h && rt.yofs[d] < own_hi) {
+                    if (rt.yofs[d] + 1 >= c.y0 + c.rh) { if (i + 1 < nrow) emit_ok = false; break; }
+                    ++d;
+                }
+                if (i + 1 < nrow && (d >= ld.h || rt.yofs[d] < own_hi)) emit_ok = false;
+            }
+            dy_begin[nrow] = d;
+        }
+        for (int j = 0; j + 1 < ncol && emit_ok; ++j) if (kx_begin[j + 1] - kx_begin[j] > 64) emit_ok = false;
+        if (!emit_ok) break;
+        for (int i = 0; i < nrow; ++i)
+            for (int j = 0; j < ncol; ++j) {
+                CellDesc& c = h_cells[c0 + i * lg.n_cols + j];
+                const int nkx = kx_begin[j + 1] - kx_begin[j], ndy = dy_begin[i + 1] - dy_begin[i];
+                if (nkx <= 0 || ndy <= 0 || nkx > 64) continue;
+                c.ekx0 = (int16_t)kx_begin[j]; c.enkx = (int16_t)nkx; c.edy0 = (int16_t)dy_begin[i]; c.endy = (int16_t)ndy;
+                c.eG = (int16_t)(64 / nkx); c.emul = (65536 + nkx - 1) / nkx;
+            }
+        ResizeRects& fr = frame[l];
+        const int KX0 = kx_begin[0], KX1 = kx_begin[ncol], DY0 = dy_begin[0], DY1 = dy_begin[nrow];
+        fr.n = 4;
+        fr.r[0] = ResizeRect{0, n_x4, 0, DY0};                   // top
+        fr.r[1] = ResizeRect{0, n_x4, DY1, ld.h};                // bottom
+        fr.r[2] = ResizeRect{0, KX0, DY0, DY1};                  // left
+        fr.r[3] = ResizeRect{KX1, n_x4 - KX1, DY0, DY1};         // right
+    }
+    if (!emit_ok) for (CellDesc& c : h_cells) { c.enkx = 0; c.endy = 0; }
+    if ((rc = d_erows.resize(std::max<size_t>(erows.size(), 2)))) return rc;
+    if (!erows.empty()) DCS_HIP(hipMemcpy(d_erows.p, erows.data(), erows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     const int n_cells = (int)h_cells.size();
     if ((rc = d_cells.resize(std::max(n_cells, 1)))) return rc;
     if (n_cells) DCS_HIP(hipMemcpy(d_cells.p, h_cells.data(), sizeof(CellDesc) * n_cells, hipMemcpyHostToDevice));
@@ -387,7 +478,12 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     const int split = (no_overlap || L < 3) ? 0 : std::min(fast_split, L - 1);
     if (split > 0 && (rc = side_stream(s_fast, stream))) return rc;
     const int cells_early = split > 0 ? h_level_cell_begin[split] : 0;
-    for (int l = 1; l < L; ++l) {
+    const bool fused_blur = fused_mode >= 0 ? fused_mode != 0 : true;
+    // Round 5: no resize chain -- the FAST cells of level l write level l + 1 from their LDS tiles (k_fast_cells<EMIT>), k_resize only the
+    // frame around them; one FAST launch per level, each behind the one that produced its level. Needs the fused describe (the separate blur
+    // kernels want the whole pyramid before FAST starts). DCS_ORB_EMIT=0 (read when the handle is created) keeps the round-4 pipeline.
+    const bool emit = emit_ok && split == 0 && fused_blur && (emit_mode >= 0 ? emit_mode != 0 : true);
+    for (int l = 1; l < L && !emit; ++l) {
         if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs,
                                 d_rtab.p + rtab[l].yofs, d_rtab.p + rtab[l].ya, n_images, stream))) return rc;
         if (cells_early > 0 && l == std::max(split - 1, 1)) {              // levels 0 .. split - 1 are complete (split == 1: level 0 needs no resize)
@@ -411,7 +507,6 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // features, 512 images per step): 313 k kfeatures/s fused against 289 k with the separate kernels -- FAST runs at its solo speed once
     // the blur no longer competes for the vector ALUs (800 -> 619 us) and the fused describe costs 455 instead of 388 us.
     // DCS_ORB_FUSED_BLUR=0 (read when the handle is created) selects the separate blur kernels (the debug / A-B path).
-    const bool fused_blur = fused_mode >= 0 ? fused_mode != 0 : true;
     last_blur_valid = !fused_blur;
     static const bool blur_early = getenv("DCS_ORB_BLUR_LATE") == nullptr;
     if (!fused_blur && !no_overlap && (rc = side_stream(s_aux, stream, s_fast))) return rc;
@@ -432,7 +527,22 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         if (no_overlap) DCS_MARK_FAST(ev_t[1], stream);      // FAST timing starts after the blur
     }
 
-    if (cells_early > 0) {
+    if (emit) {
+        for (int l = 0; l < L; ++l) {
+            FastFootprint lf;
+            const int c0 = h_level_cell_begin[l], c1 = h_level_cell_begin[l + 1];
+            for (int c = c0; c < c1; ++c) fast_footprint_add(lf, h_cells[c].rw, h_cells[c].rh);
+            FastEmit fe{};
+            if (l + 1 < L) {
+                // the frame first: it only needs level l, and it is the shorter of the two
+                if ((rc = launch_resize(raw.lv[l], raw.lv[l + 1], d_rtab.p + rtab[l + 1].xofs, d_rtab.p + rtab[l + 1].yofs, d_rtab.p + rtab[l + 1].ya,
+                                        n_images, stream, &frame[l]))) return rc;
+                fe.dst = raw.lv[l + 1]; fe.cols = d_rtab.p + rtab[l + 1].xofs; fe.rows = d_erows.p + erows_off[l];
+            }
+            if (c1 > c0 && (rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
+                                                   d_cell_count.p, lf, stream, c0, c1 - c0, l + 1 < L ? &fe : nullptr))) return rc;
+        }
+    } else if (cells_early > 0) {
         if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
                                     d_cell_count.p, fp_all, stream, cells_early, n_cells - cells_early))) return rc;
     } else {
@@ -635,6 +745,7 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     for (auto& es : h->ring) { for (auto& e : es.t) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.b) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.f) DCS_HIP(hipEventCreate(&e)); }
     h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
     h->fused_mode = getenv("DCS_ORB_FUSED_BLUR") ? (atoi(getenv("DCS_ORB_FUSED_BLUR")) != 0) : -1;
+    h->emit_mode = getenv("DCS_ORB_EMIT") ? (atoi(getenv("DCS_ORB_EMIT")) != 0) : -1;
     h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
     {   // staging threads of the host-buffer API (DCS_ORB_STAGING_THREADS, default 4; 1 = pack on the calling thread)

@@ -26,7 +26,24 @@ struct LevelSet {                       // passed by value to kernels (<= 16 lev
 struct CellDesc {
     int16_t level, x0, y0, rw, rh, ox, oy, cap;
     int32_t slot_base;                  // first candidate slot of this cell inside one image
+    // Round 5: the part of pyramid level `level + 1` this cell produces from its ROI in LDS (ComputePyramid :1107-1132 fused into the per-cell
+    // FAST of :789-827): destination dwords [ekx0, ekx0 + enkx) x rows [edy0, edy0 + endy). A cell owns the destination dword whose FIRST
+    // source column lies in [x0, next cell's x0) and the rows whose upper source row lies in [y0, next cell's y0): all taps then fall inside
+    // its ROI (the ROI overlaps the next cell by 6 pixels). enkx == 0: nothing to emit. eG = 64 / enkx row groups per round, emul = ceil(65536 / enkx).
+    int16_t ekx0, enkx, edy0, endy, eG, epad;
+    int32_t emul;
 };
+
+// what an emitting FAST launch needs besides its cells: the level it writes and that level's resize tables
+struct FastEmit {
+    LevelView dst;
+    const int16_t* cols;                // {sx, 0, a0, a1} per destination column (16-byte aligned)
+    const int32_t* rows;                // {sy, b0 | b1 << 16} per destination row
+};
+
+// destination rectangle of a k_resize launch, in dwords (4 pixels) x rows
+struct ResizeRect { int x4_begin, x4_count, row_begin, row_end; };
+struct ResizeRects { ResizeRect r[4]; int n; };
 
 // keypoint selected by the quadtree, level coordinates (already + minBorder)
 struct SelKp {
@@ -59,7 +76,8 @@ struct OctScratch {
 };
 
 int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_cols /* {sx, 0, a0, a1} per destination column */,
-                  const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s);
+                  const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s,
+                  const ResizeRects* rects = nullptr /* NULL: the whole level; else only these rectangles (the frame no FAST cell produces) */);
 
 // what decides the LDS of a cell's workgroup in a launch: the largest ROI (pixel map: max_rh rows at the pitch class of max_rw), the
 // longest survivor list and the largest score map among the launch's cells
@@ -69,7 +87,8 @@ int fast_cells_lds_bytes(const FastFootprint& f);
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
                       int32_t* d_cell_count, const FastFootprint& fp, hipStream_t s,
-                      int cell0 = 0, int n_launch = -1 /* the launch covers cells [cell0, cell0 + n_launch); -1: to the end */);
+                      int cell0 = 0, int n_launch = -1 /* the launch covers cells [cell0, cell0 + n_launch); -1: to the end */,
+                      const FastEmit* emit = nullptr /* the cells of this launch (ONE level) also write their part of the next level */);
 
 // per (image, level): scan the cell counts, then gather the slots into one dense array for the whole
 // batch. d_lvl_off[n_images*nlevels + 1] = exclusive offsets (image-major, level-minor).

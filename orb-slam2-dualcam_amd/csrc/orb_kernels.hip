@@ -104,16 +104,19 @@ __device__ __forceinline__ void resize_emit(uint8_t* __restrict__ out, const uns
 
 template <bool ALIGNED>      // source rows readable as dwords (base, image stride and pitch multiples of 4): decided on the host
 __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, const ResizeCol* __restrict__ cols,
-                                                const int16_t* __restrict__ yofs, const int16_t* __restrict__ ya, int n_images)
+                                                const int16_t* __restrict__ yofs, const int16_t* __restrict__ ya, int n_images, ResizeRects rects)
 {
     // lanes run over (image, destination dword) pairs: every image of the batch has the same geometry and row tables, so a
-    // wave stays uniform in y while its 64 lanes are all busy whatever the level width is (widths are not multiples of 256)
-    const int n_x4 = (dst.w + 3) >> 2;
+    // wave stays uniform in y while its 64 lanes are all busy whatever the level width is (widths are not multiples of 256).
+    // Round 5: the launch covers a list of destination rectangles (blockIdx.z; the whole level = one rectangle) -- with the FAST cells of
+    // level l - 1 producing the inside of level l from their LDS tiles, this kernel only writes the frame no cell's ROI reaches.
+    const ResizeRect rc = rects.r[blockIdx.z];
+    const int n_x4 = rc.x4_count, row_end = rc.row_end;
     const int li = blockIdx.x * 64 + (int)threadIdx.x;
-    const int img = li / n_x4;
-    const int dx0 = (li - img * n_x4) * 4;
-    const int dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * kRsRowsPerThread;   // wave-uniform
-    if (dy0 >= dst.h) return;
+    const int img = li / max(n_x4, 1);
+    const int dx0 = (rc.x4_begin + li - img * n_x4) * 4;
+    const int dy0 = rc.row_begin + (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * kRsRowsPerThread;   // wave-uniform
+    if (dy0 >= row_end || n_x4 <= 0) return;
     // row tables of this strip: lane k (mod rows per thread) holds the entries of destination row dy0 + k; read back with v_readlane (the
     // loads are issued by every lane, before the out-of-range lanes of the last block leave)
     const int krow = min(dy0 + (int)(threadIdx.x & (kRsRowsPerThread - 1)), dst.h - 1);
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
         // beyond the last row repeat that row's and are not emitted) and a strip that ends on the clamped last source row (the loads clamp the
         // row index: row j + 1 then IS row j) take this path too: the row-at-a-time loop below, one dependent load per destination row, made
         // the last workgroups of every launch its tail.
-        const int n_rows = min(kRsRowsPerThread, dst.h - dy0);
+        const int n_rows = min(kRsRowsPerThread, row_end - dy0);
         ResizeRaw raw[kRsSrcMax];
 #pragma unroll
         for (int j = 0; j < kRsSrcMax; ++j) raw[j] = resize_load(colbase + (size_t)min(sy_first + j, src.h - 1) * src.pitch, aligned);
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
         return;
     }
 #endif
-    if (dy0 + kRsRowsPerThread <= dst.h && sy_first >= 0 && sy_last + 1 <= src.h - 1) {
+    if (dy0 + kRsRowsPerThread <= row_end && sy_first >= 0 && sy_last + 1 <= src.h - 1) {
         // interior strip (no clamped source row): walk the source rows once. hP / hC = horizontal passes of rows p, p + 1; the
         // raw bytes of row p + 2 are already in flight while the current destination row is produced. A destination row
         // advances p by 0..2 (scale <= 2), all of it wave-uniform (SGPR compares, constant-lane readlanes).
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
     // boundary strips (clamped rows at the bottom edge, a partial last strip): one destination row at a time
     unsigned hA[4], hB[4];
     int rowA = -1, rowB = -1;                           // source rows currently held in hA / hB (wave-uniform)
-    const int dy_end = min(dy0 + kRsRowsPerThread, dst.h);
+    const int dy_end = min(dy0 + kRsRowsPerThread, row_end);
     for (int dy = dy0; dy < dy_end; ++dy) {
         const int sy = yofs[dy];
         const int sy0 = min(max(sy, 0), src.h - 1), sy1 = min(max(sy + 1, 0), src.h - 1);
@@ -235,14 +238,25 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
     }
 }
 
-int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_cols, const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s)
+int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_cols, const int16_t* d_yofs, const int16_t* d_ya, int n_images, hipStream_t s,
+                  const ResizeRects* rects)
 {
     if ((double)src.w / dst.w > 2.0) { set_error("pyramid scale factor > 2 not supported by the resize kernel"); return DCS_ERR_UNSUPPORTED; }
-    const int n_x4 = (dst.w + 3) / 4;
-    dim3 grid((n_images * n_x4 + 63) / 64, (dst.h + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread));
+    ResizeRects rr{};
+    if (rects) rr = *rects;
+    else { rr.n = 1; rr.r[0] = ResizeRect{0, (dst.w + 3) / 4, 0, dst.h}; }
+    int gx = 0, gy = 0;
+    for (int i = 0; i < rr.n; ++i) {
+        const int rows = rr.r[i].row_end - rr.r[i].row_begin;
+        if (rr.r[i].x4_count <= 0 || rows <= 0) continue;
+        gx = std::max(gx, (n_images * rr.r[i].x4_count + 63) / 64);
+        gy = std::max(gy, (rows + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread));
+    }
+    if (gx == 0 || gy == 0 || rr.n <= 0) return DCS_OK;
+    dim3 grid(gx, gy, rr.n);
     const bool aligned = ((reinterpret_cast<uintptr_t>(src.base) | (uintptr_t)src.img_stride | (uintptr_t)src.pitch) & 3) == 0 && src.pitch >= 12;
-    if (aligned) hipLaunchKernelGGL(k_resize<true>, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images);
-    else hipLaunchKernelGGL(k_resize<false>, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images);
+    if (aligned) hipLaunchKernelGGL(k_resize<true>, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images, rr);
+    else hipLaunchKernelGGL(k_resize<false>, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images, rr);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -399,11 +413,15 @@ __device__ __forceinline__ unsigned long long fast_append_gt(unsigned value, uns
     return m;
 }
 
-template <int P, bool D16Z>           // P: LDS row pitch in bytes (40 / 44: the ROI's own bytes; 48 / 64 / 128: aligned rows), compile-time so that the ring offsets are immediates; D16Z: see fast_score
+// EMIT (round 5): the cell also produces its part of the NEXT pyramid level from the ROI it holds in LDS -- cv::resize INTER_LINEAR with the
+// tables and the per-pixel arithmetic of k_resize (resize_hpass / resize_emit), bit for bit. A lane owns one destination dword (4 pixels): its
+// column taps are fixed, it walks the cell's destination rows in steps of eG rows (lane = column + enkx * row group). The 12 source bytes of a row
+// come from LDS as three aligned dwords (the ROI row pitch P is a multiple of 4), the taps are picked out with the same v_perm selectors.
+template <int P, bool D16Z, bool EMIT> // P: LDS row pitch in bytes (40 / 44: the ROI's own bytes; 48 / 64 / 128: aligned rows), compile-time so that the ring offsets are immediates; D16Z: see fast_score
 __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* __restrict__ cells, int n_cells, int ini_th, int min_th,
                                                    dcs_candidate* __restrict__ slots, size_t slots_per_image,
                                                    int32_t* __restrict__ cell_count, int map_bytes, int n_images, int sc_bytes, int dbg_stop,
-                                                   int cell0)
+                                                   int cell0, FastEmit em)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_px = smem;
@@ -427,6 +445,24 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     constexpr bool kExact = P < 48;
     const int shift = kExact ? 0 : cd.x0 & (P == 48 ? 7 : 15);
     const int sc_pitch = rw - 4;                             // score map of THIS cell: detection width + 1-px rim, rows packed
+    // ---- 0. (EMIT) this lane's column taps and the table entries of its first three destination rows: requested with the ROI
+    constexpr int kEmitPre = 3;                              // rounds whose row entries are requested up front (a 30-px cell at scale 1.2: 25 rows, 9-10 groups)
+    typedef int i32x2_t __attribute__((ext_vector_type(2)));
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    int e_g = 0, e_kx = 0;
+    bool e_lane = false;
+    i32x4_t e_c01 = {0, 0, 0, 0}, e_c23 = {0, 0, 0, 0};
+    i32x2_t e_row[kEmitPre] = {};
+    if (EMIT && cd.enkx > 0) {
+        e_g = (int)(((unsigned)lane * (unsigned)cd.emul) >> 16);                  // lane / enkx
+        e_kx = lane - e_g * cd.enkx;
+        e_lane = e_g < cd.eG;
+        const i32x4_t* cp = reinterpret_cast<const i32x4_t*>(em.cols) + 2 * (cd.ekx0 + e_kx);   // 4 x {sx, 0, a0, a1}: 32 bytes
+        e_c01 = cp[0]; e_c23 = cp[1];
+#pragma unroll
+        for (int r = 0; r < kEmitPre; ++r)
+            e_row[r] = reinterpret_cast<const i32x2_t*>(em.rows)[cd.edy0 + min(e_g + r * cd.eG, cd.endy - 1)];
+    }
     {   // ---- 1. ROI rows into LDS (pixel (x, y) of the ROI at s_px[y * P + shift + x]) and a zeroed score map
         const bool aligned = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 3) == 0;
         const bool aligned16 = ((reinterpret_cast<uintptr_t>(img_base) | (uintptr_t)lv.pitch) & 15) == 0;
@@ -513,6 +549,41 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     }
     __syncthreads();
     DCS_FAST_SECTION(1);
+    if (EMIT && cd.enkx > 0) {   // ---- 1b. this cell's part of level `level + 1` (ComputePyramid :1120): see the comment above the kernel
+        ResizeTaps t;
+        const int sx[4] = {(int)(short)e_c01.x, (int)(short)e_c01.z, (int)(short)e_c23.x, (int)(short)e_c23.z};
+        const unsigned wg[4] = {(unsigned)e_c01.y, (unsigned)e_c01.w, (unsigned)e_c23.y, (unsigned)e_c23.w};      // a0 | a1 << 16
+        const int col0 = shift + sx[0] - cd.x0;                                    // byte of the first tap inside an LDS row
+        const int cbase = col0 & ~3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = shift + sx[k] - cd.x0 - cbase;                           // 0 .. 3 + 3 * scale: <= 9 for scale <= 2
+            t.upper[k] = o > 6;
+            const unsigned o8 = (unsigned)(t.upper[k] ? o - 4 : o);
+            t.sel[k] = 0x0c000c00u | o8 | ((o8 + 1) << 16);
+            t.wgt[k] = wg[k];
+        }
+        uint8_t* const D = const_cast<uint8_t*>(em.dst.base) + (size_t)img * em.dst.img_stride + 4 * (cd.ekx0 + e_kx);
+        const int G = cd.eG, rounds = (cd.endy + G - 1) / G;
+        auto one = [&](int r, i32x2_t ent) {
+            const int dyr = e_g + r * G;                                           // row inside the cell's rectangle
+            const bool ok = e_lane && dyr < cd.endy;
+            const uint8_t* row = s_px + ((int)ent.x - cd.y0) * P + cbase;          // entries of lanes past the end were clamped to the last row: in range
+            ResizeRaw ra, rb;
+            const unsigned* pa = reinterpret_cast<const unsigned*>(row);
+            const unsigned* pb = reinterpret_cast<const unsigned*>(row + P);
+            ra.d = u32x4_t{pa[0], pa[1], pa[2], 0u};
+            rb.d = u32x4_t{pb[0], pb[1], pb[2], 0u};
+            unsigned hA[4], hB[4];
+            resize_hpass(ra, t, hA);
+            resize_hpass(rb, t, hB);
+            if (ok) resize_emit(D + (size_t)(cd.edy0 + dyr) * em.dst.pitch, hA, hB, (unsigned)ent.y & 0xffffu, (unsigned)ent.y >> 16);
+        };
+#pragma unroll
+        for (int r = 0; r < kEmitPre; ++r) if (r < rounds) one(r, e_row[r]);       // wave-uniform
+        for (int r = kEmitPre; r < rounds; ++r)
+            one(r, reinterpret_cast<const i32x2_t*>(em.rows)[cd.edy0 + min(e_g + r * G, cd.endy - 1)]);
+    }
     const uint8_t* px = s_px + shift;
     // score map: only the detection area and its 1-px rim exist, pixel (x, y) of the ROI at s_sc[(y - 2) * sc_pitch + (x - 2)] (the
     // smaller map buys LDS room for two more resident waves per SIMD, and FAST loses 13 % when it loses 1.25)
@@ -706,7 +777,7 @@ int fast_cells_lds_bytes(const FastFootprint& f)
 
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
-                      int32_t* d_cell_count, const FastFootprint& fp, hipStream_t s, int cell0, int n_launch)
+                      int32_t* d_cell_count, const FastFootprint& fp, hipStream_t s, int cell0, int n_launch, const FastEmit* emit)
 {
     if (n_launch < 0) n_launch = n_cells - cell0;             // cells [cell0, cell0 + n_launch) of the n_cells of the pyramid
     if (n_launch <= 0) return DCS_OK;
@@ -723,16 +794,18 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
         if (getenv("DCS_FAST_D16Z") && atoi(getenv("DCS_FAST_D16Z")) == 0) return false;
         return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && strstr(pr.gcnArchName, "sramecc+") != nullptr;
     }();
-#define DCS_FAST_LAUNCH(PP) do { if (d16z) hipLaunchKernelGGL((k_fast_cells<PP, true>), grid, dim3(64), shmem, s, levels, d_cells, n_cells, ini_th, min_th, d_slots, slots_per_image, \
-                                               d_cell_count, map_bytes, n_images, sc_bytes, dbg_stop, cell0); \
-                                 else hipLaunchKernelGGL((k_fast_cells<PP, false>), grid, dim3(64), shmem, s, levels, d_cells, n_cells, ini_th, min_th, d_slots, slots_per_image, \
-                                               d_cell_count, map_bytes, n_images, sc_bytes, dbg_stop, cell0); } while (0)
+    const FastEmit em = emit ? *emit : FastEmit{};
+#define DCS_FAST_LAUNCH2(PP, ZZ, EE) hipLaunchKernelGGL((k_fast_cells<PP, ZZ, EE>), grid, dim3(64), shmem, s, levels, d_cells, n_cells, ini_th, min_th, d_slots, slots_per_image, \
+                                               d_cell_count, map_bytes, n_images, sc_bytes, dbg_stop, cell0, em)
+#define DCS_FAST_LAUNCH(PP) do { if (d16z) { if (emit) DCS_FAST_LAUNCH2(PP, true, true); else DCS_FAST_LAUNCH2(PP, true, false); } \
+                                 else { if (emit) DCS_FAST_LAUNCH2(PP, false, true); else DCS_FAST_LAUNCH2(PP, false, false); } } while (0)
     if (P == 40) DCS_FAST_LAUNCH(40);
     else if (P == 44) DCS_FAST_LAUNCH(44);
     else if (P == 48) DCS_FAST_LAUNCH(48);
     else if (P == 64) DCS_FAST_LAUNCH(64);
     else DCS_FAST_LAUNCH(128);
 #undef DCS_FAST_LAUNCH
+#undef DCS_FAST_LAUNCH2
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

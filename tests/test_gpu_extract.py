@@ -10,13 +10,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["separate blur kernels", "blur fused into k_describe", "fused + early FAST of levels 0-1"])
+@pytest.fixture(autouse=True, params=["separate blur kernels", "blur fused into k_describe", "fused + early FAST of levels 0-1",
+                                      "fused + resize chain (FAST cells do not emit the next level)"])
 def pipeline_mode(request, monkeypatch):
     """Every test of this file runs with every pipeline variant (DCS_ORB_FUSED_BLUR / DCS_ORB_FAST_SPLIT are read when an extractor
     handle is created): the library picks the blur variant per call from the pyramid pixels per feature and the batch size, so small
     test batches would only ever see the fused one; the early FAST launch (two k_fast_cells launches on two streams) is opt-in."""
     monkeypatch.setenv("DCS_ORB_FUSED_BLUR", "0" if request.param.startswith("separate") else "1")
     monkeypatch.setenv("DCS_ORB_FAST_SPLIT", "2" if "early" in request.param else "0")
+    # round 5: by default the FAST cells of level l write level l + 1 (k_fast_cells<EMIT>) -- whenever the blur is fused and no early FAST launch
+    # is asked for, i.e. in the second variant; the fourth keeps the fused describe on the round-4 resize chain
+    monkeypatch.setenv("DCS_ORB_EMIT", "0" if "resize chain" in request.param else "1")
 
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
