@@ -107,8 +107,10 @@ struct dcs_orb {
     DevBuf<int32_t> d_erows;
     size_t erows_off[kMaxLevels] = {};
     ResizeRects frame[kMaxLevels] = {};
+    FastEmit femit[kMaxLevels] = {};               // frame rectangles + block counts per emitting level (pointers filled per call)
     bool emit_ok = false;
-    int emit_mode = -1;                            // DCS_ORB_EMIT when the handle is created: 0 / 1, unset = choose per call
+    int emit_mode = -1;                            // DCS_ORB_EMIT when the handle is created: 0 = off, n > 0 = levels [0, n) emit whatever the batch; unset = all levels, from emit_min_pixels level-0 pixels per call
+    double emit_min_pixels = 2.5e7;
     std::vector<CellDesc> h_cells;
     std::vector<int32_t> h_level_cell_begin;
     DevBuf<CellDesc> d_cells;
@@ -325,7 +327,7 @@ int dcs_orb::configure(int rows, int cols)
                 const int sx = rt.xofs[4 * k + i];
                 if (sx < lo || sx + 1 >= hi || sx < rt.xofs[4 * k]) return false;
             }
-            return rt.xofs[4 * k + 3] + 1 - rt.xofs[4 * k] <= 8;
+            return rt.xofs[4 * k + 3] + 1 - rt.xofs[4 * k] <= 7;          // one 8-byte LDS window per source row holds every tap
         };
         {
             int k = 0;
@@ -365,7 +367,7 @@ int dcs_orb::configure(int rows, int cols)
                 const int nkx = kx_begin[j + 1] - kx_begin[j], ndy = dy_begin[i + 1] - dy_begin[i];
                 if (nkx <= 0 || ndy <= 0 || nkx > 64) continue;
                 c.ekx0 = (int16_t)kx_begin[j]; c.enkx = (int16_t)nkx; c.edy0 = (int16_t)dy_begin[i]; c.endy = (int16_t)ndy;
-                c.eG = (int16_t)(64 / nkx); c.emul = (65536 + nkx - 1) / nkx;
+                c.eG = (int16_t)(64 / nkx); c.erounds = (int16_t)((ndy + c.eG - 1) / c.eG); c.emul = (65536 + nkx - 1) / nkx;
             }
         ResizeRects& fr = frame[l];
         const int KX0 = kx_begin[0], KX1 = kx_begin[ncol], DY0 = dy_begin[0], DY1 = dy_begin[nrow];
@@ -374,6 +376,19 @@ int dcs_orb::configure(int rows, int cols)
         fr.r[1] = ResizeRect{0, n_x4, DY1, ld.h};                // bottom
         fr.r[2] = ResizeRect{0, KX0, DY0, DY1};                  // left
         fr.r[3] = ResizeRect{KX1, n_x4 - KX1, DY0, DY1};         // right
+        FastEmit& fe = femit[l];
+        fe = FastEmit{};
+        int blocks = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int nx = std::max(fr.r[k].x4_count, 0), nr = std::max(fr.r[k].row_end - fr.r[k].row_begin, 0);
+            FrameRect& q = fe.fr[k];
+            q.x4_begin = fr.r[k].x4_begin; q.x4_count = std::max(nx, 1); q.row_begin = fr.r[k].row_begin; q.row_end = fr.r[k].row_end;
+            q.count = nx * ((nr + 3) / 4); q.blk_begin = blocks;                     // a lane = one dword column x 4 rows
+            q.magic = nx > 1 ? (unsigned)((0x100000000ull + (unsigned)nx - 1) / (unsigned)nx) : 0u;
+            if (nx == 1 && nr > 0) emit_ok = false;                                   // (i / 1 needs a 33-bit magic; never seen: the frame is ~3 dwords wide)
+            blocks += (q.count + 63) / 64;
+        }
+        fe.n_frame_blocks = blocks; fe.src_level = l;
     }
     if (!emit_ok) for (CellDesc& c : h_cells) { c.enkx = 0; c.endy = 0; }
     if ((rc = d_erows.resize(std::max<size_t>(erows.size(), 2)))) return rc;
@@ -482,7 +497,14 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // Round 5: no resize chain -- the FAST cells of level l write level l + 1 from their LDS tiles (k_fast_cells<EMIT>), k_resize only the
     // frame around them; one FAST launch per level, each behind the one that produced its level. Needs the fused describe (the separate blur
     // kernels want the whole pyramid before FAST starts). DCS_ORB_EMIT=0 (read when the handle is created) keeps the round-4 pipeline.
-    const bool emit = emit_ok && split == 0 && fused_blur && (emit_mode >= 0 ? emit_mode != 0 : true);
+    // (the frame workgroups read level 0 as aligned dwords like k_resize<true>: a caller's buffer that is not 4-byte aligned keeps the resize chain)
+    const bool level0_aligned = ((reinterpret_cast<uintptr_t>(raw.lv[0].base) | (uintptr_t)raw.lv[0].img_stride | (uintptr_t)raw.lv[0].pitch) & 3) == 0 && raw.lv[0].pitch >= 12;
+    // Small batches keep the chain as well: they are bound by launch latency, and eight dependent FAST launches whose waves each run ~12 us are no
+    // shorter than seven small resizes + one FAST launch (per call alone, 640 x 480: 2 images 114 against 103 us, 16 images 168 / 159, 64 images
+    // 265 / 260; 512 images 1 253 / 1 331 and 128 images of 1280 x 720 1 075 / 1 130 the other way). DCS_ORB_EMIT=n forces the mode on for any batch.
+    const bool emit = emit_ok && split == 0 && fused_blur && emit_mode != 0 && level0_aligned &&
+                      (emit_mode > 0 || (double)n_images * g.rows * g.cols >= emit_min_pixels);
+    const int E = emit ? (emit_mode > 0 ? std::min(emit_mode, L - 1) : L - 1) : 0;      // levels [0, E) emit levels [1, E]; the rest of the chain is k_resize
     for (int l = 1; l < L && !emit; ++l) {
         if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs,
                                 d_rtab.p + rtab[l].yofs, d_rtab.p + rtab[l].ya, n_images, stream))) return rc;
@@ -528,21 +550,19 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     }
 
     if (emit) {
-        for (int l = 0; l < L; ++l) {
+        for (int l = 0; l < E; ++l) {
             FastFootprint lf;
             const int c0 = h_level_cell_begin[l], c1 = h_level_cell_begin[l + 1];
             for (int c = c0; c < c1; ++c) fast_footprint_add(lf, h_cells[c].rw, h_cells[c].rh);
-            FastEmit fe{};
-            if (l + 1 < L) {
-                // the frame first: it only needs level l, and it is the shorter of the two
-                if ((rc = launch_resize(raw.lv[l], raw.lv[l + 1], d_rtab.p + rtab[l + 1].xofs, d_rtab.p + rtab[l + 1].yofs, d_rtab.p + rtab[l + 1].ya,
-                                        n_images, stream, &frame[l]))) return rc;
-                fe.dst = raw.lv[l + 1]; fe.cols = d_rtab.p + rtab[l + 1].xofs; fe.rows = d_erows.p + erows_off[l];
-            }
+            FastEmit fe = femit[l];
+            fe.dst = raw.lv[l + 1]; fe.cols = d_rtab.p + rtab[l + 1].xofs; fe.rows = d_erows.p + erows_off[l];
             if (c1 > c0 && (rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                                   d_cell_count.p, lf, stream, c0, c1 - c0, l + 1 < L ? &fe : nullptr))) return rc;
+                                                   d_cell_count.p, lf, stream, c0, c1 - c0, &fe))) return rc;
         }
-    } else if (cells_early > 0) {
+        for (int l = E + 1; l < L; ++l)
+            if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs, d_rtab.p + rtab[l].yofs, d_rtab.p + rtab[l].ya, n_images, stream))) return rc;
+    }
+    if (cells_early > 0) {
         if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
                                     d_cell_count.p, fp_all, stream, cells_early, n_cells - cells_early))) return rc;
     } else {
@@ -569,14 +589,14 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         };
         for (int l = 0; l < L; ++l)
             for (int c = h_level_cell_begin[l]; c < h_level_cell_begin[l + 1]; ++c) fast_footprint_add(lfp[l], h_cells[c].rw, h_cells[c].rh);
-        if (!grouped) { for (int i = 0; i <= L; ++i) start_of[i] = 0; }
+        if (!grouped) { for (int i = 0; i <= L; ++i) start_of[i] = E; }
         else {
             double best[kMaxLevels + 1];
-            best[0] = 0;
-            for (int i = 1; i <= L; ++i) {                   // best[i] = cheapest partition of levels [0, i); the last group is [start_of[i], i)
-                best[i] = 1e300; start_of[i] = 0;
+            best[E] = 0;
+            for (int i = E + 1; i <= L; ++i) {               // best[i] = cheapest partition of levels [E, i); the last group is [start_of[i], i)
+                best[i] = 1e300; start_of[i] = E;
                 FastFootprint gf;
-                for (int j = i - 1; j >= 0; --j) {
+                for (int j = i - 1; j >= E; --j) {
                     gf = merged(gf, lfp[j]);
                     const double occ = wg_per_cu(gf);
                     double cost = 1.3;
@@ -590,8 +610,8 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
             }
         }
         int bounds[kMaxLevels + 1], nb = 0;                  // group boundaries, last to first
-        for (int i = L; i > 0; i = start_of[i]) bounds[nb++] = i;
-        int l0 = 0;
+        for (int i = L; i > E; i = start_of[i]) bounds[nb++] = i;
+        int l0 = E;
         for (int k = nb - 1; k >= 0; --k) {
             const int l1 = bounds[k];
             FastFootprint gf;
@@ -745,7 +765,8 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     for (auto& es : h->ring) { for (auto& e : es.t) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.b) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.f) DCS_HIP(hipEventCreate(&e)); }
     h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
     h->fused_mode = getenv("DCS_ORB_FUSED_BLUR") ? (atoi(getenv("DCS_ORB_FUSED_BLUR")) != 0) : -1;
-    h->emit_mode = getenv("DCS_ORB_EMIT") ? (atoi(getenv("DCS_ORB_EMIT")) != 0) : -1;
+    if (getenv("DCS_ORB_EMIT_MIN")) h->emit_min_pixels = atof(getenv("DCS_ORB_EMIT_MIN"));
+    h->emit_mode = getenv("DCS_ORB_EMIT") ? atoi(getenv("DCS_ORB_EMIT")) : -1;     // 0: round-4 resize chain; n > 0: the cells of levels [0, n) emit; unset: all of them
     h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
     {   // staging threads of the host-buffer API (DCS_ORB_STAGING_THREADS, default 4; 1 = pack on the calling thread)

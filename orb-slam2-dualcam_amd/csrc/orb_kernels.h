@@ -29,20 +29,26 @@ struct CellDesc {
     // Round 5: the part of pyramid level `level + 1` this cell produces from its ROI in LDS (ComputePyramid :1107-1132 fused into the per-cell
     // FAST of :789-827): destination dwords [ekx0, ekx0 + enkx) x rows [edy0, edy0 + endy). A cell owns the destination dword whose FIRST
     // source column lies in [x0, next cell's x0) and the rows whose upper source row lies in [y0, next cell's y0): all taps then fall inside
-    // its ROI (the ROI overlaps the next cell by 6 pixels). enkx == 0: nothing to emit. eG = 64 / enkx row groups per round, emul = ceil(65536 / enkx).
-    int16_t ekx0, enkx, edy0, endy, eG, epad;
+    // its ROI (the ROI overlaps the next cell by 6 pixels). enkx == 0: nothing to emit. eG = 64 / enkx row groups per round, erounds = ceil(endy / eG), emul = ceil(65536 / enkx).
+    int16_t ekx0, enkx, edy0, endy, eG, erounds;
     int32_t emul;
 };
 
 // what an emitting FAST launch needs besides its cells: the level it writes and that level's resize tables
+// The frame of the next level that no cell's ROI reaches (its outer ~11 pixels: sources in the 13-pixel band FAST never loads) is written by
+// extra workgroups of the same launch, one destination dword per lane straight from global memory (blockIdx.y >= n_cell_blocks): a separate
+// k_resize launch for it costs a wave's latency (>= 13 us) per level whatever its size. Four rectangles; a block belongs to one of them.
+struct FrameRect { int x4_begin, x4_count, row_begin, row_end, count, blk_begin; unsigned magic; };   // count = lanes (a lane = one dword column x 4 rows); magic = ceil(2^32 / x4_count)
 struct FastEmit {
     LevelView dst;
     const int16_t* cols;                // {sx, 0, a0, a1} per destination column (16-byte aligned)
     const int32_t* rows;                // {sy, b0 | b1 << 16} per destination row
+    FrameRect fr[4];
+    int n_cell_blocks, n_frame_blocks, src_level;
 };
 
 // destination rectangle of a k_resize launch, in dwords (4 pixels) x rows
-struct ResizeRect { int x4_begin, x4_count, row_begin, row_end; };
+struct ResizeRect { int x4_begin, x4_count, row_begin, row_end; int blk_begin, nbx; };   // blk_begin / nbx: filled by launch_resize (first block of the rectangle in the 1-D grid, blocks per strip row)
 struct ResizeRects { ResizeRect r[4]; int n; };
 
 // keypoint selected by the quadtree, level coordinates (already + minBorder)

@@ -110,12 +110,19 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelView dst, co
     // wave stays uniform in y while its 64 lanes are all busy whatever the level width is (widths are not multiples of 256).
     // Round 5: the launch covers a list of destination rectangles (blockIdx.z; the whole level = one rectangle) -- with the FAST cells of
     // level l - 1 producing the inside of level l from their LDS tiles, this kernel only writes the frame no cell's ROI reaches.
-    const ResizeRect rc = rects.r[blockIdx.z];
+    // (several rectangles: a 1-D grid, rectangle i owns blocks [blk_begin_i, blk_begin_{i+1}), nbx_i of them per 64-row strip group)
+    int ri = 0, bx = blockIdx.x, by = blockIdx.y;
+    if (rects.n > 1) {
+        for (int i = 1; i < rects.n; ++i) if ((int)blockIdx.x >= rects.r[i].blk_begin) ri = i;
+        const int b = (int)blockIdx.x - rects.r[ri].blk_begin;
+        by = b / rects.r[ri].nbx; bx = b - by * rects.r[ri].nbx;
+    }
+    const ResizeRect rc = rects.r[ri];
     const int n_x4 = rc.x4_count, row_end = rc.row_end;
-    const int li = blockIdx.x * 64 + (int)threadIdx.x;
+    const int li = bx * 64 + (int)threadIdx.x;
     const int img = li / max(n_x4, 1);
     const int dx0 = (rc.x4_begin + li - img * n_x4) * 4;
-    const int dy0 = rc.row_begin + (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * kRsRowsPerThread;   // wave-uniform
+    const int dy0 = rc.row_begin + (by * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * kRsRowsPerThread;   // wave-uniform
     if (dy0 >= row_end || n_x4 <= 0) return;
     // row tables of this strip: lane k (mod rows per thread) holds the entries of destination row dy0 + k; read back with v_readlane (the
     // loads are issued by every lane, before the out-of-range lanes of the last block leave)
@@ -245,15 +252,22 @@ int launch_resize(const LevelView& src, const LevelView& dst, const int16_t* d_c
     ResizeRects rr{};
     if (rects) rr = *rects;
     else { rr.n = 1; rr.r[0] = ResizeRect{0, (dst.w + 3) / 4, 0, dst.h}; }
-    int gx = 0, gy = 0;
-    for (int i = 0; i < rr.n; ++i) {
-        const int rows = rr.r[i].row_end - rr.r[i].row_begin;
-        if (rr.r[i].x4_count <= 0 || rows <= 0) continue;
-        gx = std::max(gx, (n_images * rr.r[i].x4_count + 63) / 64);
-        gy = std::max(gy, (rows + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread));
+    dim3 grid;
+    if (rr.n == 1) {
+        grid = dim3((n_images * rr.r[0].x4_count + 63) / 64, (rr.r[0].row_end - rr.r[0].row_begin + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread));
+        if (rr.r[0].x4_count <= 0 || rr.r[0].row_end <= rr.r[0].row_begin) return DCS_OK;
+    } else {
+        int total = 0;
+        for (int i = 0; i < rr.n; ++i) {
+            const int rows = rr.r[i].row_end - rr.r[i].row_begin;
+            const bool empty = rr.r[i].x4_count <= 0 || rows <= 0;
+            rr.r[i].blk_begin = total;
+            rr.r[i].nbx = empty ? 1 : (n_images * rr.r[i].x4_count + 63) / 64;
+            if (!empty) total += rr.r[i].nbx * ((rows + 4 * kRsRowsPerThread - 1) / (4 * kRsRowsPerThread));
+        }
+        if (total == 0) return DCS_OK;
+        grid = dim3(total);
     }
-    if (gx == 0 || gy == 0 || rr.n <= 0) return DCS_OK;
-    dim3 grid(gx, gy, rr.n);
     const bool aligned = ((reinterpret_cast<uintptr_t>(src.base) | (uintptr_t)src.img_stride | (uintptr_t)src.pitch) & 3) == 0 && src.pitch >= 12;
     if (aligned) hipLaunchKernelGGL(k_resize<true>, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images, rr);
     else hipLaunchKernelGGL(k_resize<false>, grid, dim3(64, 4), 0, s, src, dst, reinterpret_cast<const ResizeCol*>(d_cols), d_yofs, d_ya, n_images, rr);
@@ -432,6 +446,56 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     // per 512-image launch) without any index arithmetic
     const int lane = threadIdx.x, cell = blockIdx.y + cell0, img = blockIdx.z * 8 + blockIdx.x;       // cell0: first cell of this launch
     if (img >= n_images) return;
+    if (EMIT && (int)blockIdx.y >= em.n_cell_blocks) {
+        // ---- the frame of the next level: one destination dword per lane, taps from global memory with k_resize's own column logic (12-byte
+        // window of aligned dwords clamped into the row's storage, single-tap last column) and clamped source rows
+        const int fb = (int)blockIdx.y - em.n_cell_blocks;
+        int ri = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (fb >= em.fr[k].blk_begin) ri = k;                              // scalar
+        const FrameRect fr = em.fr[ri];
+        const int i = (fb - fr.blk_begin) * 64 + lane;
+        if (i >= fr.count) return;
+        const int q = (int)__umulhi((unsigned)i, fr.magic);                                           // i / x4_count (exact: i * x4_count < 2^32)
+        constexpr int kFrameRows = 4;                                                                 // destination rows per lane: a frame wave costs its start-up and two load latencies whatever it does
+        const int dy0 = fr.row_begin + kFrameRows * q, kx = fr.x4_begin + i - q * fr.x4_count;
+        const int n_rows = min(kFrameRows, fr.row_end - dy0);
+        const LevelView sv = L.lv[em.src_level];
+        const uint8_t* S = sv.base + (size_t)img * sv.img_stride;
+        const ResizeCol* cols = reinterpret_cast<const ResizeCol*>(em.cols);
+        int sy[kFrameRows];
+        unsigned ab[kFrameRows];
+#pragma unroll
+        for (int r = 0; r < kFrameRows; ++r) { const int dy = min(dy0 + r, fr.row_end - 1); sy[r] = em.rows[2 * dy]; ab[r] = (unsigned)em.rows[2 * dy + 1]; }
+        ResizeTaps t;
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const ResizeCol cc = cols[min(4 * kx + k, em.dst.w - 1)];
+            if (k == 0) base = min((int)cc.sx & ~3, sv.pitch - 12);
+            const int o = cc.sx - base;                          // 0..11
+            t.upper[k] = o > 6;
+            const unsigned o8 = (unsigned)(t.upper[k] ? o - 4 : o);
+            t.sel[k] = 0x0c000c00u | o8 | ((o8 < 7 ? o8 + 1 : 0x0cu) << 16);
+            t.wgt[k] = (unsigned)(uint16_t)cc.a0 | ((unsigned)(uint16_t)cc.a1 << 16);
+        }
+        ResizeRaw ra[kFrameRows], rb[kFrameRows];
+#pragma unroll
+        for (int r = 0; r < kFrameRows; ++r) {
+            const int sy0 = min(max(sy[r], 0), sv.h - 1), sy1 = min(max(sy[r] + 1, 0), sv.h - 1);
+            ra[r] = resize_load(S + (size_t)sy0 * sv.pitch + base, true);
+            rb[r] = resize_load(S + (size_t)sy1 * sv.pitch + base, true);
+        }
+        uint8_t* out = const_cast<uint8_t*>(em.dst.base) + (size_t)img * em.dst.img_stride + (size_t)dy0 * em.dst.pitch + 4 * kx;
+#pragma unroll
+        for (int r = 0; r < kFrameRows; ++r) {
+            unsigned hA[4], hB[4];
+            resize_hpass(ra[r], t, hA);
+            resize_hpass(rb[r], t, hB);
+            if (r < n_rows) resize_emit(out + (size_t)r * em.dst.pitch, hA, hB, ab[r] & 0xffffu, ab[r] >> 16);
+        }
+        return;
+    }
     const CellDesc cd = cells[cell];
     const int rw = cd.rw, rh = cd.rh;
     if (rw < 7 || rh < 7) {
@@ -550,34 +614,61 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     __syncthreads();
     DCS_FAST_SECTION(1);
     if (EMIT && cd.enkx > 0) {   // ---- 1b. this cell's part of level `level + 1` (ComputePyramid :1120): see the comment above the kernel
-        ResizeTaps t;
-        const int sx[4] = {(int)(short)e_c01.x, (int)(short)e_c01.z, (int)(short)e_c23.x, (int)(short)e_c23.z};
+        // The four pixels' taps span <= 7 source bytes (scale <= 1.33: the host checks it), so ONE 8-byte window per source row that starts
+        // at the first tap holds them all, and pixel k's pair is one v_perm with a per-lane selector -- no choice between dword pairs as in k_resize.
+        const int sx0 = (int)(short)e_c01.x;
+        const int sxk[4] = {sx0, (int)(short)e_c01.z, (int)(short)e_c23.x, (int)(short)e_c23.z};
         const unsigned wg[4] = {(unsigned)e_c01.y, (unsigned)e_c01.w, (unsigned)e_c23.y, (unsigned)e_c23.w};      // a0 | a1 << 16
-        const int col0 = shift + sx[0] - cd.x0;                                    // byte of the first tap inside an LDS row
-        const int cbase = col0 & ~3;
+        unsigned sel[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int o = shift + sx[k] - cd.x0 - cbase;                           // 0 .. 3 + 3 * scale: <= 9 for scale <= 2
-            t.upper[k] = o > 6;
-            const unsigned o8 = (unsigned)(t.upper[k] ? o - 4 : o);
-            t.sel[k] = 0x0c000c00u | o8 | ((o8 + 1) << 16);
-            t.wgt[k] = wg[k];
-        }
-        uint8_t* const D = const_cast<uint8_t*>(em.dst.base) + (size_t)img * em.dst.img_stride + 4 * (cd.ekx0 + e_kx);
-        const int G = cd.eG, rounds = (cd.endy + G - 1) / G;
+        for (int k = 0; k < 4; ++k) { const unsigned o = (unsigned)(sxk[k] - sx0); sel[k] = 0x0c000c00u | o | ((o + 1) << 16); }   // o <= 6
+        const int col0 = shift + sx0 - cd.x0;                                     // byte of the first tap inside an LDS row
+        const unsigned mis = (unsigned)col0 & 3u;
+#ifdef DCS_EMIT_UNALIGNED_LDS
+        const unsigned col_addr = lds_addr(s_px) + (unsigned)(col0 - cd.y0 * P);
+#else
+        const uint8_t* const col_ptr = s_px + (col0 & ~3) - cd.y0 * P;
+#endif
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(em.dst.base) + (size_t)img * em.dst.img_stride, 0,
+                                                                              em.dst.h * em.dst.pitch, 0x00020000);
+        const int G = cd.eG, rounds = cd.erounds;
+        const unsigned dcol = (unsigned)(4 * (cd.ekx0 + e_kx) + cd.edy0 * em.dst.pitch);
         auto one = [&](int r, i32x2_t ent) {
             const int dyr = e_g + r * G;                                           // row inside the cell's rectangle
-            const bool ok = e_lane && dyr < cd.endy;
-            const uint8_t* row = s_px + ((int)ent.x - cd.y0) * P + cbase;          // entries of lanes past the end were clamped to the last row: in range
-            ResizeRaw ra, rb;
-            const unsigned* pa = reinterpret_cast<const unsigned*>(row);
-            const unsigned* pb = reinterpret_cast<const unsigned*>(row + P);
-            ra.d = u32x4_t{pa[0], pa[1], pa[2], 0u};
-            rb.d = u32x4_t{pb[0], pb[1], pb[2], 0u};
-            unsigned hA[4], hB[4];
-            resize_hpass(ra, t, hA);
-            resize_hpass(rb, t, hB);
-            if (ok) resize_emit(D + (size_t)(cd.edy0 + dyr) * em.dst.pitch, hA, hB, (unsigned)ent.y & 0xffffu, (unsigned)ent.y >> 16);
+            const bool ok = e_lane && dyr < cd.endy;                               // (entries of lanes past the end were clamped to the last row: LDS reads stay in range)
+            unsigned a0, a1, b0, b1;
+#ifdef DCS_EMIT_UNALIGNED_LDS
+            // measured: 299 us for level 0 against 184 with aligned reads -- a misaligned ds_read_b32 is not one access
+            const unsigned a = col_addr + (unsigned)__mul24((int)ent.x, P);
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:%5\n\tds_read_b32 %3, %4 offset:%6\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(a), "n"(P), "n"(P + 4) : "memory");
+#else
+            // three aligned dwords per source row, realigned to the first tap's byte with two v_alignbyte (per-lane shift)
+            const unsigned* pa = reinterpret_cast<const unsigned*>(col_ptr + __mul24((int)ent.x, P));
+            const unsigned* pb = reinterpret_cast<const unsigned*>(reinterpret_cast<const uint8_t*>(pa) + P);
+            const unsigned ra0 = pa[0], ra1 = pa[1], ra2 = pa[2], rb0 = pb[0], rb1 = pb[1], rb2 = pb[2];
+            a0 = __builtin_amdgcn_alignbyte(ra1, ra0, mis); a1 = __builtin_amdgcn_alignbyte(ra2, ra1, mis);
+            b0 = __builtin_amdgcn_alignbyte(rb1, rb0, mis); b1 = __builtin_amdgcn_alignbyte(rb2, rb1, mis);
+#endif
+            const unsigned wb0 = (unsigned)ent.y & 0xffffu, wb1 = (unsigned)ent.y >> 16;
+            unsigned p0[4], p1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned hA = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, __builtin_amdgcn_perm(a1, a0, sel[k])), __builtin_bit_cast(ushort2_t, wg[k]), 0u, false) >> 4;
+                const unsigned hB = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, __builtin_amdgcn_perm(b1, b0, sel[k])), __builtin_bit_cast(ushort2_t, wg[k]), 0u, false) >> 4;
+                p0[k] = __umul24(wb0, hA) + 0x20000u;                              // the "+ 2" of the rounding rides on the first product's high half
+                p1[k] = __umul24(wb1, hB);
+            }
+            // ((p0 >> 16) + (p1 >> 16) + 2) >> 2 for four pixels: the high halves are added by SDWA straight into the halves of two registers, one
+            // 32-bit shift each (the bits that leak across the halves land above the byte that is kept), one v_perm packs the four bytes
+            unsigned s01, s23;
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(s01) : "v"(p0[0]), "v"(p1[0]));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(s01) : "v"(p0[1]), "v"(p1[1]));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(s23) : "v"(p0[2]), "v"(p1[2]));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(s23) : "v"(p0[3]), "v"(p1[3]));
+            const unsigned packed = __builtin_amdgcn_perm(s23 >> 2, s01 >> 2, 0x06040200u);
+            // a lane without a row stores out of range: dropped by the buffer unit, no branch
+            __builtin_amdgcn_raw_buffer_store_b32(packed, drs, ok ? (int)(dcol + (unsigned)__mul24(dyr, em.dst.pitch)) : (int)0x80000000u, 0, 0);
         };
 #pragma unroll
         for (int r = 0; r < kEmitPre; ++r) if (r < rounds) one(r, e_row[r]);       // wave-uniform
@@ -786,7 +877,9 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
     const int sc_bytes = (fp.sc_bytes + 15) & ~15;
     const size_t shmem = (size_t)fast_cells_lds_bytes(fp);
     static const int dbg_stop = getenv("DCS_FAST_STOP") ? atoi(getenv("DCS_FAST_STOP")) : 0;      // only read by -DDCS_FAST_SECTIONS builds
-    const dim3 grid(8, n_launch, (n_images + 7) / 8);
+    FastEmit em = emit ? *emit : FastEmit{};
+    em.n_cell_blocks = n_launch;
+    const dim3 grid(8, n_launch + (emit ? em.n_frame_blocks : 0), (n_images + 7) / 8);
     // the d16_hi form of the score's ring loads needs the zeroing semantics of SRAM-ECC parts (every MI355X): asked once per process
     static const bool d16z = [] {
         hipDeviceProp_t pr;
@@ -794,7 +887,6 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
         if (getenv("DCS_FAST_D16Z") && atoi(getenv("DCS_FAST_D16Z")) == 0) return false;
         return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && strstr(pr.gcnArchName, "sramecc+") != nullptr;
     }();
-    const FastEmit em = emit ? *emit : FastEmit{};
 #define DCS_FAST_LAUNCH2(PP, ZZ, EE) hipLaunchKernelGGL((k_fast_cells<PP, ZZ, EE>), grid, dim3(64), shmem, s, levels, d_cells, n_cells, ini_th, min_th, d_slots, slots_per_image, \
                                                d_cell_count, map_bytes, n_images, sc_bytes, dbg_stop, cell0, em)
 #define DCS_FAST_LAUNCH(PP) do { if (d16z) { if (emit) DCS_FAST_LAUNCH2(PP, true, true); else DCS_FAST_LAUNCH2(PP, true, false); } \
