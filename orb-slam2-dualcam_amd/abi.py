@@ -1038,11 +1038,12 @@ class PreparedTracking:
     """dcs_track_local_map on a batch of frames laid out like synth.tracking_problem (every frame's features carry their grid): the flat
     problem marshalled once, track() is then the bare C call."""
 
-    def __init__(self, frames, params):
+    def __init__(self, frames, params, null_empty=False):
+        """null_empty: empty arrays go over as NULL pointers (what a C caller with an empty local map passes)"""
         self.keep = []
 
         def a(x, dt):
-            if x is None:
+            if x is None or (null_empty and np.size(x) == 0):
                 return None
             arr = _c(x, dt)
             self.keep.append(arr)

@@ -49,6 +49,7 @@
 namespace dcs {
 
 constexpr int kMaxCams = 4;
+static_assert(kMaxCams == dcs::kPoseMaxCams, "track.h and ba_solver.hip disagree on the cameras per rig");
 constexpr int kNB = 16;
 
 struct DCam { double fx, fy, cx, cy, t[3], q[4], adj[36]; };
@@ -1781,6 +1782,7 @@ struct PoseArgs {
     double huber; float chi2_th[4]; int its[4];
     double* err; uint8_t* level;                 // scratch per edge
     double* out_poses; uint8_t* outlier; int32_t* n_inliers; double* edge_chi2; int32_t* n_iters;
+    int fast_max;                                // frames of up to fast_max edges belong to k_pose_opt2, larger ones to k_pose_opt (-1: every frame to k_pose_opt)
 };
 
 // Jacobian of the projection w.r.t. the rig pose (EdgeSE3ProjectXYZOnlyPose::linearizeOplus, types_six_dof_expmap.cpp:218-246)
@@ -1833,6 +1835,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
     __shared__ int s_ctl;                                    // decision of thread 0: 0 = next trial, 1 = iteration done, 2 = round done
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e0 = a.edge_off[f], n = a.edge_cnt ? a.edge_cnt[f] : a.edge_off[f + 1] - e0;
+    if (n <= a.fast_max) return;                              // k_pose_opt2's frame
     const double* Tin = a.poses + 7 * f;
     for (int k = tid; k < n; k += 256) { a.outlier[e0 + k] = 0; a.level[e0 + k] = 0; if (a.edge_chi2) a.edge_chi2[e0 + k] = 0; }
     if (tid < 4 && a.n_iters) a.n_iters[4 * f + tid] = 0;
@@ -1989,6 +1992,581 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
     if (tid < 7) a.out_poses[7 * f + tid] = s_T[tid];
     if (tid == 0) a.n_inliers[f] = n - n_bad_edges;
     if (a.edge_chi2) for (int k = tid; k < n; k += 256) a.edge_chi2[e0 + k] = chi2_of(k);
+}
+
+
+// ------------------------------------------------------------------ k_pose_opt2 (round 5): PoseOptimization, engineered
+// The same procedure (Optimizer.cc:250-405, types_six_dof_expmap.cpp:200-255) for frames of up to kPoseFastMax edges, one workgroup of 512
+// threads per frame. What changed against k_pose_opt (which stays for larger frames: 18 us per LM iteration of a 2 000-edge frame):
+//  * the edges live in REGISTERS for the whole call (<= 8 per thread: point, observation, weight, last error), grouped by camera once at the
+//    start (counting sort in LDS) so that every WAVE works on one camera: intrinsics and the composed world -> camera transform
+//    M_c = R_c R(T), m_c = R_c t(T) + t_c are wave-uniform, an edge's point costs 9 FMAs instead of two quaternion rotations;
+//  * J = A adj_c with A the 2 x 6 projection Jacobian in the camera frame (two structural zeros): the wave accumulates A^T W A (21) and
+//    A^T r (6) of its camera, and adj_c^T ( . ) adj_c is applied ONCE per pass to the per-camera totals (36 lanes) instead of 72 multiply-adds
+//    per edge -- the same sums, associated differently;
+//  * ONE pass per trial: the errors of a trial and the linearisation at the trial's pose are one sweep over the registers. g2o recomputes the
+//    errors at the top of the next iteration at exactly that pose when the trial is accepted (and a rejected trial ends the iteration's loop
+//    only together with the round), so the speculative system IS the next iteration's system; a rejection re-solves the kept system;
+//  * the 29 sums (21 + 6 + robust chi2 + active edges) of a pass cross the wave as ONE transposed reduction (32 shuffles, not 29 x 6) in a
+//    fixed tree, the 8 wave partials are added in wave order per camera: results do not depend on the batch the frame is part of;
+//  * wave 0 runs the scalar part (adjoint products on 42 lanes, LDL^T + exp map + LM rule on lane 0, the cameras' transforms on n_cams lanes)
+//    between two workgroup barriers.
+// Parity bar unchanged (tests/test_gpu_ba.py::test_pose_optimization_vs_oracle, tests/test_gpu_track.py): poses 1e-7 / 1e-8, flags, counts +-1.
+constexpr int kPoT = 512, kPoW = kPoT / 64, kPoWork = kPoW - 1, kPoEpt = 8;   // 7 worker waves + the control wave
+constexpr int kPoseFastMax = (kPoWork - (kMaxCams - 1)) * 64 * kPoEpt;          // 2 048: every camera split leaves the largest camera >= 4 waves x 8 edges per lane
+constexpr int kPoChunks = (kPoseFastMax + kPoT - 1) / kPoT;
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over the 64 lanes of each of 32 values: lanes 2q and 2q + 1 return the total of v[q]. One fixed tree: halves are exchanged, so every
+// step moves half as many values as the one before (16 + 8 + 4 + 2 + 1 + 1 exchanges). The two widest levels -- 24 of the 32 exchanges -- are
+// gfx950's v_permlane32_swap / v_permlane16_swap (the upper half of one register trades places with the lower half of the other: exactly
+// this step, no LDS round trip, no selects); the narrow ones are ds_bpermute shuffles.
+__device__ __forceinline__ double dbl_of(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ double swap_add32(double p, double q)
+{
+    const auto a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(p), (unsigned)__double2loint(q), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(p), (unsigned)__double2hiint(q), false, false);
+    return dbl_of(a[0], b[0]) + dbl_of(a[1], b[1]);
+}
+__device__ __forceinline__ double swap_add16(double p, double q)
+{
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(p), (unsigned)__double2loint(q), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(p), (unsigned)__double2hiint(q), false, false);
+    return dbl_of(a[0], b[0]) + dbl_of(a[1], b[1]);
+}
+__device__ __forceinline__ double wave_sum32(double (&v)[32], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = swap_add32(v[i], v[i + 16]);     // lanes 0-31: v[i] over (l, l + 32); lanes 32-63: v[i + 16]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = swap_add16(v[i], v[i + 8]);
+#define DCS_PO_STEP(N, BIT) _Pragma("unroll") for (int i = 0; i < N; ++i) { const bool hi = (lane & BIT) != 0; const double send = hi ? v[i] : v[i + N], keep = hi ? v[i + N] : v[i]; v[i] = keep + __shfl_xor(send, BIT); }
+    DCS_PO_STEP(4, 8)
+    DCS_PO_STEP(2, 4)
+    DCS_PO_STEP(1, 2)
+#undef DCS_PO_STEP
+    return v[0] + __shfl_xor(v[0], 1);
+}
+// value of lane `src` (a compile-time lane) in every lane: two v_readlane, no LDS
+__device__ __forceinline__ double bcast_lane(double x, int src)
+{
+    return dbl_of((unsigned)__builtin_amdgcn_readlane(__double2loint(x), src), (unsigned)__builtin_amdgcn_readlane(__double2hiint(x), src));
+}
+
+struct PoseShared {
+    uint16_t list[kPoseFastMax];
+    int cnt[kMaxCams][kPoChunks * kPoW];
+    int ncam[kMaxCams], off[kMaxCams], W[kMaxCams], wcam[kPoWork], wu[kPoWork], ctl, bad[kPoWork];
+    double part[kPoWork][32], HA[kMaxCams][32], Tm[kMaxCams][36], Hn[36], bn[6], Hc[36], bc[6], T[7], M[kMaxCams][12], lam;
+    DCam cam[kMaxCams];                    // the rig's cameras: lanes index them (a by-value kernel argument indexed per lane would be copied to scratch)
+    double ed[3][kPoEpt][kPoWork * 64];    // observation (x, y) and weight of every resident edge: the registers hold the point and the last chi2 (84 KB; one workgroup per CU anyway)
+};
+
+// world -> camera of rig camera c at the pose S.T: M = R_c R(T) column by column through the very rotations cam_point() applies, m = R_c t(T) + t_c
+__device__ __forceinline__ void pose_compose(PoseShared& S, int c)
+{
+    const DCam& cc = S.cam[c];
+    double* M = S.M[c];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double ei[3] = {i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0};
+        double r1[3], r2[3];
+        qrot(S.T + 3, ei, r1); qrot(cc.q, r1, r2);
+        M[i] = r2[0]; M[3 + i] = r2[1]; M[6 + i] = r2[2];
+    }
+    double tt[3];
+    qrot(cc.q, S.T, tt);
+    M[9] = tt[0] + cc.t[0]; M[10] = tt[1] + cc.t[1]; M[11] = tt[2] + cc.t[2];
+}
+
+// exp(update) * T like pose_oplus(), with the two libm calls that dominate it on one lane replaced: sin and cos of theta come from ONE sincos,
+// theta^3 is two multiplications (g2o calls pow(theta, 3): <= 1 ulp apart, the update itself is ~1e-3 rad)
+__device__ inline void pose_oplus_fast(const double* T, const double* u, double* out)
+{
+    const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double O2[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    double R[9], V[9];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    } else {
+        double sn, cs;
+        sincos(theta, &sn, &cs);
+        const double a = sn / theta, b = (1 - cs) / (theta * theta), c = (theta - sn) / (theta * theta * theta);
+        for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0 ? 1.0 : 0.0); R[i] = I + a * O[i] + b * O2[i]; V[i] = I + b * O[i] + c * O2[i]; }
+    }
+    double qe[4], te[3];
+    qfromR(R, qe); qnormalize(qe);
+    for (int i = 0; i < 3; ++i) te[i] = V[i * 3] * up[0] + V[i * 3 + 1] * up[1] + V[i * 3 + 2] * up[2];
+    double rt[3]; qrot(qe, T, rt);
+    out[0] = te[0] + rt[0]; out[1] = te[1] + rt[1]; out[2] = te[2] + rt[2];
+    double qo[4]; qmul(qe, T + 3, qo); qnormalize(qo);
+    out[3] = qo[0]; out[4] = qo[1]; out[5] = qo[2]; out[6] = qo[3];
+}
+
+// The control wave: everything between two passes. Barrier for barrier the mirror image of pose_worker(). Every stage is spread over the
+// lanes as far as its dependences allow -- a single lane runs dependent f64 code at ~9 ticks per operation, and all of this is on the
+// critical path of every trial (in-kernel timeline, -DDCS_POSE_PROF: the first version spent 11 800 of a pass's 18 600 ticks here).
+template <int NC>        // cameras 0 .. NC - 1 can hold edges (the loops over cameras are unrolled and branch-free: a rig of two does half the loads of kMaxCams)
+__device__ __forceinline__ void pose_control(PoseShared& S, const PoseArgs& a, int f, int n, int lane)
+{
+    const double* Tin = a.poses + 7 * f;
+    double lambda = -1, ni = 2, currentChi = 0, iniChi = 0, bk[7] = {0, 0, 0, 0, 0, 0, 0}, xs[6] = {0, 0, 0, 0, 0, 0};   // LM state: lane 0
+    int nBad = 0, n_it = 0, qmax = 0, it_i = 0, phase = 0, n_bad_edges = 0;
+    bool ok2 = true;
+#ifdef DCS_POSE_PROF
+    unsigned long long prof_c[5] = {0, 0, 0, 0, 0};
+#endif
+    // Loop invariants of this lane, read once: every stage below first LOADS what it needs (independent LDS reads in flight together), then
+    // computes -- a load per operand between the multiply-adds costs an LDS round trip each (the first version: 68 waits in the adjoint stage alone)
+    const int li = lane < 36 ? lane / 6 : 0, lj = lane < 36 ? lane - 6 * (lane / 6) : (lane < 42 ? lane - 36 : 0);
+    double adjA[NC][6], adjB[NC][6];               // adj_c[m][lj] (column lj), adj_c[k][li] (column li; lanes 36..41: column lane - 36 via lj)
+    int wcam_r[kPoWork];
+#pragma unroll
+    for (int w = 0; w < kPoWork; ++w) wcam_r[w] = S.wcam[w];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { adjA[c][m] = S.cam[c].adj[m * 6 + lj]; adjB[c][m] = S.cam[c].adj[m * 6 + (lane < 36 ? li : lj)]; }
+    const int cc_c = (lane >> 2) & (kMaxCams - 1), cc_i = lane & 3;
+    const bool cc_on = lane < 4 * kMaxCams && S.ncam[cc_c] > 0;
+    double cq[4], ct[3];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) cq[d] = S.cam[cc_c].q[d];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) ct[d] = S.cam[cc_c].t[d];
+    // lane (c, i), i = 0..2: column i of M_c = R_c R(T); i = 3: m_c = R_c t(T) + t_c -- the very rotations cam_point() applies
+    auto compose16 = [&]() {
+        double T[7];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) T[d] = S.T[d];
+        const double ei[3] = {cc_i == 0 ? 1.0 : 0.0, cc_i == 1 ? 1.0 : 0.0, cc_i == 2 ? 1.0 : 0.0};
+        double r1[3], r2[3], tt[3];
+        qrot(T + 3, ei, r1); qrot(cq, r1, r2);
+        qrot(cq, T, tt);
+        if (cc_on) {
+            double* M = S.M[cc_c];
+            if (cc_i < 3) { M[cc_i] = r2[0]; M[3 + cc_i] = r2[1]; M[6 + cc_i] = r2[2]; }
+            else { M[9] = tt[0] + ct[0]; M[10] = tt[1] + ct[1]; M[11] = tt[2] + ct[2]; }
+        }
+    };
+    for (int it = 0; it < 4; ++it) {
+        if (lane < 7) S.T[lane] = Tin[lane];                    // :360 every round restarts from the frame's pose
+        wave_sync();
+        compose16();
+        lambda = -1; ni = 2; nBad = 0; n_it = 0; qmax = 0; it_i = 0; phase = 0; ok2 = true;
+        __syncthreads();                                        // B1
+        for (;;) {
+            __syncthreads();                                    // B2: the workers' partial sums are in S.part
+#ifdef DCS_POSE_PROF
+            const unsigned long long tp0 = __builtin_readcyclecounter();
+#endif
+            {   // per-camera totals: the 7 wave partials in wave order, each to its wave's camera (the others add an exact zero)
+                double pw[kPoWork];
+#pragma unroll
+                for (int w = 0; w < kPoWork; ++w) pw[w] = S.part[w][lane & 31];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    double t = 0;
+#pragma unroll
+                    for (int w = 0; w < kPoWork; ++w) t += wcam_r[w] == c ? pw[w] : 0.0;
+                    if (lane < 32) S.HA[c][lane] = t;
+                }
+            }
+            wave_sync();
+            // H = sum_c adj_c^T (A^T W A)_c adj_c as two 6-term products per camera: lane (k, j) forms T_c[k][j] = sum_m HA_c(k, m) adj_c[m][j],
+            // then lane (i, j) sums adj_c[k][i] T_c[k][j] over k, the cameras added in index order; b = sum_c adj_c^T (A^T r)_c on lanes 36..41.
+            // (A camera without edges has zero totals: no branches.)
+            {
+                double ha[NC][6];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) { const int lo = li < m ? li : m, hi = li < m ? m : li; ha[c][m] = S.HA[c][lo * 6 - lo * (lo - 1) / 2 + (hi - lo)]; }
+                double hb[NC][6];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) hb[c][k] = S.HA[c][21 + k];
+                double tk[NC], bsum[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    tk[c] = 0; bsum[c] = 0;
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) { tk[c] = fma(ha[c][m], adjA[c][m], tk[c]); bsum[c] = fma(adjB[c][m], hb[c][m], bsum[c]); }
+                }
+                if (lane < 36) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) S.Tm[c][lane] = tk[c];
+                } else if (lane < 42) { double t = bsum[0];
+#pragma unroll
+                    for (int c = 1; c < NC; ++c) t += bsum[c]; S.bn[lane - 36] = t; }
+                wave_sync();
+                double tm[NC][6];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) tm[c][k] = S.Tm[c][k * 6 + lj];
+                double hs[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    hs[c] = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) hs[c] = fma(adjB[c][k], tm[c][k], hs[c]);
+                }
+                if (lane < 36) { double t = hs[0];
+#pragma unroll
+                    for (int c = 1; c < NC; ++c) t += hs[c]; S.Hn[lane] = t; }
+            }
+            wave_sync();
+#ifdef DCS_POSE_PROF
+            const unsigned long long tp1 = __builtin_readcyclecounter();
+#endif
+            if (lane == 0) {
+                int ctl = 0, adopt = 0, solve = 0;
+                double chi = 0, cnt = 0, bcv[6], hd[6];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { chi += S.HA[c][27]; cnt += S.HA[c][28]; }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { bcv[j] = S.bc[j]; hd[j] = S.Hn[j * 7]; }
+                if (phase == 0) {                               // evaluation at the current pose (round start, or after a rejected trial that did not end the round)
+                    if ((it_i == 0 && cnt == 0.0) || it_i >= a.its[it]) ctl = 2;          // no active edge / no iterations: optimize() does nothing
+                    else { currentChi = chi; iniChi = chi; adopt = 1; solve = 1; qmax = 0; }
+                } else {
+                    const double tempChi = ok2 ? chi : 1.7976931348623157e308;
+                    double rho = currentChi - tempChi, scale = 0;
+                    for (int j = 0; j < 6; ++j) scale += xs[j] * (lambda * xs[j] + bcv[j]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    bool accepted = false;
+                    if (rho > 0 && isfinite(tempChi)) {
+                        const double t = 2 * rho - 1;
+                        double alpha = 1. - t * t * t;          // g2o: pow(2 rho - 1, 3)
+                        alpha = fmin(alpha, 2. / 3.);
+                        lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi; accepted = true;
+                    } else {
+                        lambda *= ni; ni *= 2;
+                        for (int d = 0; d < 7; ++d) S.T[d] = bk[d];                       // pop (the edges keep the rejected trial's errors, as in g2o)
+                    }
+                    ++qmax;
+                    if (rho < 0 && qmax < 10) solve = 1;                                  // next trial of this iteration: same system, larger lambda
+                    else {
+                        ++n_it;
+                        if (qmax == 10 || rho == 0) ctl = 2;
+                        else { if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0; if (nBad >= 3) ctl = 2; }
+                        ++it_i;
+                        if (it_i >= a.its[it]) ctl = 2;
+                        if (ctl != 2) {
+                            if (accepted) { adopt = 1; solve = 1; iniChi = currentChi; qmax = 0; }   // the trial's pass IS computeActiveErrors + the next linearisation
+                            else phase = 0;                                               // (rho is NaN) re-evaluate at the restored pose
+                        }
+                    }
+                }
+                if (solve && it_i == 0 && phase == 0) {         // computeLambdaInit on the system about to be adopted
+                    double md = 0;
+                    for (int d = 0; d < 6; ++d) md = fmax(fabs(hd[d]), md);
+                    lambda = 1e-5 * md; ni = 2; nBad = 0;
+                }
+                if (solve) S.lam = lambda;
+                S.ctl = ctl | (adopt << 2) | (solve << 3);
+            }
+            wave_sync();
+#ifdef DCS_POSE_PROF
+            const unsigned long long tp2 = __builtin_readcyclecounter();
+#endif
+            const int flags = S.ctl;
+            if ((flags & 4) && lane < 42) { if (lane < 36) S.Hc[lane] = S.Hn[lane]; else S.bc[lane - 36] = S.bn[lane - 36]; }
+            wave_sync();
+            if (flags & 8) {
+                // LDL^T of H + lambda I with ROW i ON LANE i (right-looking; the terms (L_ik L_jk) d_k leave every entry in ascending k exactly as
+                // solve6()'s inner products do: same bits), forward substitution likewise; the back substitution runs on lane 0 in solve6()'s order
+                const int r = lane < 6 ? lane : 5;
+                double A[6], y = S.bc[r];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) A[m] = S.Hc[r * 6 + m];
+                const double lam = S.lam;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) if (m == r) A[m] += lam;
+                double dd[6];
+                bool okf = true;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double dj = bcast_lane(A[j], j);      // the pivot, every earlier column already subtracted
+                    dd[j] = dj;
+                    if (!(dj > 0.0) || !isfinite(dj)) okf = false;
+                    const double l = A[j] / dj;                 // L[r][j] (meaningful on lanes r > j)
+                    A[j] = l;
+#pragma unroll
+                    for (int m = j + 1; m < 6; ++m) {
+                        const double lm = bcast_lane(l, m);     // L[m][j]
+                        if (r >= m) A[m] -= l * lm * dj;
+                    }
+                }
+                // forward: y_r -= L[r][k] y_k in ascending k; y_k is final once step k - 1 is done
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { const double yk = bcast_lane(y, k); if (r > k) y -= A[k] * yk; }
+                y /= dd[r];
+                // L's lower triangle and y for the backward pass (v_readlane: every lane holds them, lane 0 uses them)
+                double Lk[6][6], yy[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { yy[k] = bcast_lane(y, k);
+#pragma unroll
+                    for (int i2 = 0; i2 < k; ++i2) Lk[k][i2] = bcast_lane(A[i2], k); }
+                if (lane == 0) {
+                    ok2 = okf;
+                    for (int d = 0; d < 7; ++d) bk[d] = S.T[d];                           // push
+                    if (ok2) {
+#pragma unroll
+                        for (int i2 = 5; i2 >= 0; --i2) { double acc = yy[i2];
+#pragma unroll
+                            for (int k = i2 + 1; k < 6; ++k) acc -= Lk[k][i2] * xs[k]; xs[i2] = acc; }
+                    } else for (int d = 0; d < 6; ++d) xs[d] = 0;
+                    double o[7];
+                    pose_oplus_fast(bk, xs, o);
+                    for (int d = 0; d < 7; ++d) S.T[d] = o[d];
+                    phase = 1;
+                }
+            }
+            wave_sync();
+#ifdef DCS_POSE_PROF
+            const unsigned long long tp3 = __builtin_readcyclecounter();
+#endif
+            compose16();
+#ifdef DCS_POSE_PROF
+            prof_c[0] += tp1 - tp0; prof_c[1] += tp2 - tp1; prof_c[2] += tp3 - tp2; prof_c[3] += (unsigned long long)__builtin_readcyclecounter() - tp3; ++prof_c[4];
+#endif
+            __syncthreads();                                    // B3
+            if ((flags & 3) == 2) break;
+        }
+        if (lane == 0 && a.n_iters) a.n_iters[4 * f + it] = n_it;
+        __syncthreads();                                        // B4: the workers' outlier counts
+        n_bad_edges = 0;
+        for (int w = 0; w < kPoWork; ++w) n_bad_edges += S.bad[w];
+        if (n < 10) break;                                      // :392
+    }
+#ifdef DCS_POSE_PROF
+    if (lane == 0 && f == 0) printf("control: %llu passes; per pass: totals + adjoint %llu, decision %llu, solve + oplus %llu, compose %llu ticks\n", prof_c[4], prof_c[0] / prof_c[4],
+                                    prof_c[1] / prof_c[4], prof_c[2] / prof_c[4], prof_c[3] / prof_c[4]);
+#endif
+    if (lane < 7) a.out_poses[7 * f + lane] = S.T[lane];
+    if (lane == 0) a.n_inliers[f] = n - n_bad_edges;
+}
+
+// A worker wave: its camera's share of the edges in registers; one pass per barrier pair.
+__device__ __forceinline__ void pose_worker(PoseShared& S, const PoseArgs& a, int e0, int n, int wave, int lane)
+{
+    const int wc = __builtin_amdgcn_readfirstlane(S.wcam[wave]), wu = __builtin_amdgcn_readfirstlane(S.wu[wave]), wW = __builtin_amdgcn_readfirstlane(S.W[wc]);
+    const int nc = __builtin_amdgcn_readfirstlane(S.ncam[wc]), coff = __builtin_amdgcn_readfirstlane(S.off[wc]);
+    const int ept = (nc + 64 * wW - 1) / (64 * wW);           // <= kPoEpt by the choice of kPoseFastMax
+    const double fx = S.cam[wc].fx, fy = S.cam[wc].fy, cx = S.cam[wc].cx, cy = S.cam[wc].cy;
+    double X[kPoEpt][3], c2[kPoEpt];                          // point, chi2 of the last evaluation (observation and weight: S.ed)
+    const int sl = wave * 64 + lane;
+    unsigned valid = 0, outl = 0;
+#pragma unroll
+    for (int j = 0; j < kPoEpt; ++j) {
+        const int p = (j * wW + wu) * 64 + lane;
+        const bool v = j < ept && p < nc;
+        const size_t e = (size_t)e0 + (v ? S.list[coff + p] : 0);
+        X[j][0] = v ? a.xw[3 * e] : 0.0; X[j][1] = v ? a.xw[3 * e + 1] : 0.0; X[j][2] = v ? a.xw[3 * e + 2] : 1.0;
+        S.ed[0][j][sl] = v ? a.obs[2 * e] : 0.0; S.ed[1][j][sl] = v ? a.obs[2 * e + 1] : 0.0; S.ed[2][j][sl] = v ? a.w[e] : 0.0;
+        c2[j] = 0;
+        valid |= (v ? 1u : 0u) << j;
+    }
+    const double delta = a.huber, dsqr = delta * delta;
+    bool robust = true;
+#ifdef DCS_POSE_PROF
+    unsigned long long prof_w[4] = {0, 0, 0, 0};
+    const unsigned long long tw_begin = __builtin_readcyclecounter();
+#endif
+    for (int it = 0; it < 4; ++it) {
+        __syncthreads();                                        // B1
+        for (;;) {
+            // ---- one pass: errors of the active edges at S.T, robust chi2, and the linearisation there
+#ifdef DCS_POSE_PROF
+            const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
+            double v[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = 0;
+            {
+                const double* Mc = S.M[wc];
+                const double M0 = Mc[0], M1 = Mc[1], M2 = Mc[2], M3 = Mc[3], M4 = Mc[4], M5 = Mc[5], M6 = Mc[6], M7 = Mc[7], M8 = Mc[8], m0 = Mc[9], m1 = Mc[10], m2 = Mc[11];
+#pragma unroll
+                for (int j = 0; j < kPoEpt; ++j) {
+                    if (j >= ept) break;                        // wave-uniform
+                    const bool act = ((valid & ~outl) >> j) & 1u;
+                    double x = fma(M0, X[j][0], fma(M1, X[j][1], fma(M2, X[j][2], m0)));
+                    double y = fma(M3, X[j][0], fma(M4, X[j][1], fma(M5, X[j][2], m1)));
+                    double z = fma(M6, X[j][0], fma(M7, X[j][1], fma(M8, X[j][2], m2)));
+                    if (!act) { x = 0; y = 0; z = 1; }          // an excluded edge contributes exact zeros below, whatever its point does
+                    const double iz = 1.0 / z, xz = x * iz, yz = y * iz;
+                    const double ex = S.ed[0][j][sl] - fma(xz, fx, cx), ey = S.ed[1][j][sl] - fma(yz, fy, cy);
+                    const double w = act ? S.ed[2][j][sl] : 0.0;
+                    const double x2 = ex * (w * ex) + ey * (w * ey);
+                    if (act) c2[j] = x2;
+                    const bool big = robust && x2 > dsqr;
+                    double rho0 = x2, we = w;
+                    if (__builtin_amdgcn_ballot_w64(big)) {        // wave-uniform: the square root and the division only when some edge of the wave is beyond the Huber width
+                        const double sq = sqrt(x2);
+                        if (big) { rho0 = 2 * sq * delta - dsqr; we = (delta / sq) * w; }
+                    }
+                    v[27] += rho0;
+                    v[28] += act ? 1.0 : 0.0;
+                    const double r0 = -(we * ex), r1 = -(we * ey);
+                    // A = -(1/z) [fx 0 -x/z fx; 0 fy -y/z fy] [-[p]x | I]  (types_six_dof_expmap.cpp:218-246 before the adjoint)
+                    const double st0 = -(fx * iz), st2 = (fx * xz) * iz, st4 = -(fy * iz), st5 = (fy * yz) * iz;
+                    const double a00 = st2 * y, a01 = fma(st0, z, -(st2 * x)), a02 = -(st0 * y), a03 = st0, a05 = st2;
+                    const double a10 = fma(st5, y, -(st4 * z)), a11 = -(st5 * x), a12 = st4 * x, a14 = st4, a15 = st5;
+                    const double p00 = we * a00, p01 = we * a01, p02 = we * a02, p03 = we * a03, p05 = we * a05;
+                    const double p10 = we * a10, p11 = we * a11, p12 = we * a12, p14 = we * a14, p15 = we * a15;
+                    v[0] = fma(p00, a00, fma(p10, a10, v[0]));   v[1] = fma(p00, a01, fma(p10, a11, v[1]));   v[2] = fma(p00, a02, fma(p10, a12, v[2]));
+                    v[3] = fma(p00, a03, v[3]);                  v[4] = fma(p10, a14, v[4]);                  v[5] = fma(p00, a05, fma(p10, a15, v[5]));
+                    v[6] = fma(p01, a01, fma(p11, a11, v[6]));   v[7] = fma(p01, a02, fma(p11, a12, v[7]));   v[8] = fma(p01, a03, v[8]);
+                    v[9] = fma(p11, a14, v[9]);                  v[10] = fma(p01, a05, fma(p11, a15, v[10]));
+                    v[11] = fma(p02, a02, fma(p12, a12, v[11])); v[12] = fma(p02, a03, v[12]);                v[13] = fma(p12, a14, v[13]);
+                    v[14] = fma(p02, a05, fma(p12, a15, v[14]));
+                    v[15] = fma(p03, a03, v[15]);                v[17] = fma(p03, a05, v[17]);
+                    v[18] = fma(p14, a14, v[18]);                v[19] = fma(p14, a15, v[19]);
+                    v[20] = fma(p05, a05, fma(p15, a15, v[20]));
+                    v[21] = fma(a00, r0, fma(a10, r1, v[21]));   v[22] = fma(a01, r0, fma(a11, r1, v[22]));   v[23] = fma(a02, r0, fma(a12, r1, v[23]));
+                    v[24] = fma(a03, r0, v[24]);                 v[25] = fma(a14, r1, v[25]);                 v[26] = fma(a05, r0, fma(a15, r1, v[26]));
+                }
+            }
+#ifdef DCS_POSE_PROF
+            const unsigned long long tw1 = __builtin_readcyclecounter();
+#endif
+            const double tot = wave_sum32(v, lane);
+            if (!(lane & 1)) S.part[wave][lane >> 1] = tot;
+#ifdef DCS_POSE_PROF
+            const unsigned long long tw2 = __builtin_readcyclecounter();
+#endif
+            __syncthreads();                                    // B2
+            __syncthreads();                                    // B3: the control wave has decided; S.T / S.M hold the next pose to evaluate (or the final one)
+#ifdef DCS_POSE_PROF
+            prof_w[0] += tw1 - tw0; prof_w[1] += tw2 - tw1; prof_w[2] += (unsigned long long)__builtin_readcyclecounter() - tw2; ++prof_w[3];
+#endif
+            if ((S.ctl & 3) == 2) break;
+        }
+        // ---- classification of every edge (:365-390): previous outliers are re-evaluated at the final pose, inliers keep the chi2 of the last evaluation
+        {
+            const double* Mc = S.M[wc];
+            const double M0 = Mc[0], M1 = Mc[1], M2 = Mc[2], M3 = Mc[3], M4 = Mc[4], M5 = Mc[5], M6 = Mc[6], M7 = Mc[7], M8 = Mc[8], m0 = Mc[9], m1 = Mc[10], m2 = Mc[11];
+            unsigned bad = 0;
+#pragma unroll
+            for (int j = 0; j < kPoEpt; ++j) {
+                if (j >= ept) break;
+                if ((outl >> j) & 1u) {
+                    const double x = fma(M0, X[j][0], fma(M1, X[j][1], fma(M2, X[j][2], m0)));
+                    const double y = fma(M3, X[j][0], fma(M4, X[j][1], fma(M5, X[j][2], m1)));
+                    const double z = fma(M6, X[j][0], fma(M7, X[j][1], fma(M8, X[j][2], m2)));
+                    const double iz = 1.0 / z;
+                    const double ex = S.ed[0][j][sl] - fma(x * iz, fx, cx), ey = S.ed[1][j][sl] - fma(y * iz, fy, cy), w = S.ed[2][j][sl];
+                    c2[j] = ex * (w * ex) + ey * (w * ey);
+                }
+                if (((valid >> j) & 1u) && (float)c2[j] > a.chi2_th[it]) bad |= 1u << j;
+            }
+            outl = bad;
+            int cnt = __popc(bad);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+            if (lane == 0) S.bad[wave] = cnt;
+        }
+        __syncthreads();                                        // B4
+        if (it == 2) robust = false;                            // :388-389
+        if (n < 10) break;                                      // :392
+    }
+#ifdef DCS_POSE_PROF
+    if (lane == 0 && blockIdx.x == 0 && wave == 0) printf("worker 0 (ept %d, n %d): %llu passes; per pass: sweep %llu, reduce %llu, wait for control %llu ticks; loop total %llu ticks\n", ept, n, prof_w[3],
+                                                           prof_w[0] / prof_w[3], prof_w[1] / prof_w[3], prof_w[2] / prof_w[3], (unsigned long long)__builtin_readcyclecounter() - tw_begin);
+#endif
+#pragma unroll
+    for (int j = 0; j < kPoEpt; ++j) {
+        if (j >= ept) break;
+        if ((valid >> j) & 1u) {
+            const size_t e = (size_t)e0 + S.list[coff + (j * wW + wu) * 64 + lane];
+            a.outlier[e] = (outl >> j) & 1u;
+            if (a.edge_chi2) a.edge_chi2[e] = c2[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
+{
+    __shared__ PoseShared S;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e0 = a.edge_off[f], n = a.edge_cnt ? a.edge_cnt[f] : a.edge_off[f + 1] - e0;
+    if (n > a.fast_max) return;                               // k_pose_opt's frame (the host launches it when a frame can be that large)
+    const double* Tin = a.poses + 7 * f;
+    for (int k = tid; k < n; k += kPoT) { a.outlier[e0 + k] = 0; if (a.edge_chi2) a.edge_chi2[e0 + k] = 0; }
+    if (tid < 4 && a.n_iters) a.n_iters[4 * f + tid] = 0;
+    if (n < 3) {                                              // :343-344
+        if (tid < 7) a.out_poses[7 * f + tid] = Tin[tid];
+        if (tid == 0) a.n_inliers[f] = 0;
+        return;
+    }
+    // ---- edges by camera: stable counting sort of the edge indices into S.list (camera c at [S.off[c], S.off[c] + S.ncam[c])), all 8 waves
+    {
+        int my_pos[kPoChunks];
+        for (int i = tid; i < kMaxCams * kPoChunks * kPoW; i += kPoT) (&S.cnt[0][0])[i] = 0;
+        {
+            constexpr int kCamWords = (int)(sizeof(DCams) / sizeof(double));
+            const double* src = reinterpret_cast<const double*>(&cams);               // (constant indices after unrolling: scalar loads of the kernel argument)
+            double* dst = reinterpret_cast<double*>(&S.cam[0]);
+#pragma unroll
+            for (int i = 0; i < kCamWords; ++i) if (tid == (i & (kPoT - 1))) dst[i] = src[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kPoChunks; ++m) {
+            const int k = m * kPoT + tid;
+            const int c = k < n ? a.cam[e0 + k] : -1;
+            my_pos[m] = -1;
+#pragma unroll
+            for (int cc = 0; cc < kMaxCams; ++cc) {
+                const unsigned long long mk = __ballot(c == cc);
+                if (c == cc) my_pos[m] = (cc << 16) | __popcll(mk & ((1ull << lane) - 1ull));
+                if (lane == 0) S.cnt[cc][m * kPoW + wave] = __popcll(mk);
+            }
+        }
+        __syncthreads();
+        if (tid < kMaxCams) {                                 // exclusive prefix over (chunk, wave) in edge order
+            int run = 0;
+            for (int i = 0; i < kPoChunks * kPoW; ++i) { const int v = S.cnt[tid][i]; S.cnt[tid][i] = run; run += v; }
+            S.ncam[tid] = run;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int off = 0, active = 0;
+            for (int c = 0; c < kMaxCams; ++c) { S.off[c] = off; off += S.ncam[c]; S.W[c] = S.ncam[c] > 0 ? 1 : 0; active += S.W[c]; }
+            // the remaining worker waves go, one at a time, to the camera with the most edges per wave (ties: the lower index)
+            for (int r = active; r < kPoWork; ++r) {
+                int best = 0; long long bn = -1, bd = 1;
+                for (int c = 0; c < kMaxCams; ++c) if (S.W[c] > 0 && (long long)S.ncam[c] * bd > bn * S.W[c]) { best = c; bn = S.ncam[c]; bd = S.W[c]; }
+                ++S.W[best];
+            }
+            int w = 0;
+            for (int c = 0; c < kMaxCams; ++c) for (int u = 0; u < S.W[c]; ++u) { S.wcam[w] = c; S.wu[w] = u; ++w; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kPoChunks; ++m)
+            if (my_pos[m] >= 0) { const int cc = my_pos[m] >> 16; S.list[S.off[cc] + S.cnt[cc][m * kPoW + wave] + (my_pos[m] & 0xffff)] = (uint16_t)(m * kPoT + tid); }
+        __syncthreads();
+    }
+    if (wave == kPoWork) {
+        const int ncu = S.ncam[3] > 0 || S.ncam[2] > 0 ? 4 : (S.ncam[1] > 0 ? 2 : 1);      // (the sums over the cameras keep their index order: same bits as the general form)
+        if (ncu == 1) pose_control<1>(S, a, f, n, lane);
+        else if (ncu == 2) pose_control<2>(S, a, f, n, lane);
+        else pose_control<kMaxCams>(S, a, f, n, lane);
+    } else pose_worker(S, a, e0, n, wave, lane);
 }
 
 }  // namespace dcs
@@ -2346,7 +2924,20 @@ thread_local const BaTap* tl_tap = nullptr;
 
 }  // namespace
 
-int dcs::launch_pose_opt_device(const PoseOptDevice& p, const dcs_ba_camera* cams_in, int n_cams, int n_frames, hipStream_t st)
+// both kernels over the frames: k_pose_opt2 takes the frames of up to kPoseFastMax edges, k_pose_opt the rest (launched only when the host's
+// bound on a frame's edges says one may exist). DCS_POSE_FAST=0: every frame to k_pose_opt (the round-4 kernel: A/B and tests).
+static int launch_pose_kernels(PoseArgs a, const DCams& cams, int n_frames, int max_edges_bound, hipStream_t st)
+{
+    const char* e = getenv("DCS_POSE_FAST");
+    const bool fast = !(e && atoi(e) == 0);
+    a.fast_max = fast ? kPoseFastMax : -1;
+    if (fast) hipLaunchKernelGGL(k_pose_opt2, dim3(n_frames), dim3(kPoT), 0, st, a, cams);
+    if (!fast || max_edges_bound > kPoseFastMax) hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, st, a, cams);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+int dcs::launch_pose_opt_device(const PoseOptDevice& p, const dcs_ba_camera* cams_in, int n_cams, int n_frames, int max_edges_bound, hipStream_t st)
 {
     if (n_cams < 1 || n_cams > kMaxCams) { set_error("pose optimisation: n_cams must be 1..%d", kMaxCams); return DCS_ERR_INVALID; }
     if (n_frames <= 0) return DCS_OK;
@@ -2355,9 +2946,7 @@ int dcs::launch_pose_opt_device(const PoseOptDevice& p, const dcs_ba_camera* cam
     a.huber = p.huber;
     for (int i = 0; i < 4; ++i) { a.chi2_th[i] = p.chi2_th[i]; a.its[i] = p.its[i]; }
     a.err = p.err; a.level = p.level; a.out_poses = p.out_poses; a.outlier = p.outlier; a.n_inliers = p.n_inliers; a.edge_chi2 = p.edge_chi2; a.n_iters = p.n_iters;
-    hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, st, a, pose_cams_of(cams_in, n_cams));
-    DCS_CHECK_LAUNCH();
-    return DCS_OK;
+    return launch_pose_kernels(a, pose_cams_of(cams_in, n_cams), n_frames, max_edges_bound, st);
 }
 
 extern "C" {
@@ -2897,10 +3486,15 @@ int dcs_ba_debug_linearize(const dcs_ba_problem* pb, double* Hpp, double* bp, do
     dcs_ba_result res{};
     res.poses = poses.data(); res.points = points.data(); res.edge_outlier = flags.data();
     dcs_ba_result* rp = &res;
+    // a problem the batch call answers without linearising (no free pose, no live edge: estimates copied through) never fires the tap: the
+    // caller then reads a defined "nothing" instead of whatever its buffers held
+    *n_free = -1;
+    for (int i = 0; i < pb->n_poses; ++i) pose_idx[i] = -1;
     const BaTap tap{Hpp, bp, Hll, bl, Hpl, pose_idx, n_free};
     tl_tap = &tap;
     const int rc = dcs_ba_local_batch(1, &pb, nullptr, &rp);
     tl_tap = nullptr;
+    if (rc == DCS_OK && *n_free < 0) { *n_free = 0; set_error("dcs_ba_debug_linearize: the problem has nothing to linearise (no free pose or no edge)"); return DCS_ERR_INVALID; }
     return rc;
 }
 
@@ -2958,8 +3552,9 @@ int dcs_pose_optimization(const dcs_pose_problem* pb, dcs_pose_result* res)
     for (int i = 0; i < 4; ++i) { a.chi2_th[i] = pb->chi2_th[i]; a.its[i] = pb->its[i]; }
     a.err = d_err; a.level = d_level; a.out_poses = d_out; a.outlier = d_outl; a.n_inliers = d_ninl;
     a.edge_chi2 = res->edge_chi2 ? d_chi : nullptr; a.n_iters = res->n_iters ? d_nit : nullptr;
-    hipLaunchKernelGGL(k_pose_opt, dim3(F), dim3(256), 0, st, a, cams);
-    DCS_CHECK_LAUNCH();
+    int max_edges = 0;
+    for (int f = 0; f < F; ++f) max_edges = std::max(max_edges, pb->edge_off[f + 1] - pb->edge_off[f]);
+    if ((rc = launch_pose_kernels(a, cams, F, max_edges, st))) return rc;
     DCS_HIP(hipMemcpyAsync(res->poses, d_out, sizeof(double) * 7 * F, hipMemcpyDeviceToHost, st));
     DCS_HIP(hipMemcpyAsync(res->n_inliers, d_ninl, sizeof(int32_t) * F, hipMemcpyDeviceToHost, st));
     if (E) DCS_HIP(hipMemcpyAsync(res->outlier, d_outl, E, hipMemcpyDeviceToHost, st));

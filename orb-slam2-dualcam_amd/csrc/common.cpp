@@ -137,10 +137,11 @@ int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared, bool* conclu
         e = hipGetLastError();
         t0 = now();
         while (!rd(2) && us_since(t0) < 1000.0) { }
-        *shared = rd(1) && !rd(2);
+        const bool parked = rd(1) != 0, passed = rd(2) != 0;                 // each flag read ONCE: it may flip between two reads
+        *shared = parked && !passed;
         // the parked kernel never started (stream a has a backlog of more than 50 ms): nothing was measured -- b's flag arriving says
         // nothing about the queues. Reported as inconclusive, never as "apart".
-        if (!rd(1) && conclusive) *conclusive = false;
+        if (!parked && conclusive) *conclusive = false;
     }
     __atomic_store_n(&w[0], 1, __ATOMIC_RELEASE);
     if (!recorded || hipEventSynchronize(parked_done) != hipSuccess) (void)hipStreamSynchronize(a);     // the parked kernel reads w: it must have ended

@@ -1008,20 +1008,24 @@ int dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_t
     if (F < 0 || (F && (!frames || !prm || !res || !res->poses || !res->n_inliers || !res->n_matches || !res->match_of_point || !res->point_of_feature ||
         !res->outlier)) || (F && (prm->n_levels < 1 || !prm->inv_level_sigma2 || !prm->cams))) { set_error("dcs_track_local_map: bad argument"); return DCS_ERR_INVALID; }
     if (F == 0) return DCS_OK;
+    // the optimiser holds its cameras by value (DCams, ba_solver.hip): checked here, before anything is enqueued
+    if (prm->n_cams < 1 || prm->n_cams > kPoseMaxCams) { set_error("dcs_track_local_map: prm->n_cams must be 1..%d", kPoseMaxCams); return DCS_ERR_INVALID; }
     int rc;
     long long n_feat = 0;
-    int max_pts = 0, max_q4 = 0;
+    int max_pts = 0, max_q4 = 0, max_feat = 0;
     for (int k = 0; k < F; ++k) {
         const dcs_track_frame& t = frames[k];
         const dcs_frustum_frame* v = &t.view;
         if ((rc = proj_frame_check(&t.features, true, false))) return rc;
+        // k_track_edges labels an edge with its feature's camera: every one of them must have intrinsics in prm->cams
+        if (t.features.n_cams > prm->n_cams) { set_error("dcs_track_local_map: frame %d has %d cameras, prm->cams holds %d", k, t.features.n_cams, prm->n_cams); return DCS_ERR_INVALID; }
         const int N = t.features.cam_off[t.features.n_cams];
         if (N > kResMaxN) { set_error("frame %d: %d features (the chain's resolver holds %d)", k, N, kResMaxN); return DCS_ERR_UNSUPPORTED; }
         if (t.n_points < 0 || !t.pose || v->n_cams != t.features.n_cams || v->n_cams > kFrMaxCams || v->n_scale_levels < 1 || !v->Rsw || !v->tsw || !v->Ow ||
             !v->fx || !v->fy || !v->cx || !v->cy || !v->min_x || !v->max_x || !v->min_y || !v->max_y || !v->scale_factors ||
-            (t.n_points && (!t.pos || !t.normal || !t.min_dist || !t.max_dist || !t.desc)) || (N && !t.point_xw) ||
+            (t.n_points && (!t.pos || !t.normal || !t.min_dist || !t.max_dist || !t.desc)) || (N && (!t.point_xw || !(t.has_point || t.features.taken))) ||
             !res->match_of_point[k] || !res->point_of_feature[k] || !res->outlier[k]) { set_error("dcs_track_local_map: frame %d: bad argument", k); return DCS_ERR_INVALID; }
-        n_feat += N;
+        n_feat += N; max_feat = std::max(max_feat, N);
         max_pts = std::max(max_pts, t.n_points); max_q4 = std::max(max_q4, (t.n_points + 3) / 4);
     }
     if ((rc = ensure_device())) return rc;
@@ -1050,13 +1054,15 @@ int dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_t
         const size_t npe = (size_t)std::max(np, 1), Ne = (size_t)std::max(N, 1);
         it.n_points = np;
         const uint8_t* hp = t.has_point ? t.has_point : t.features.taken;
-        if ((rc = s.upload(&it.pos, t.pos, 3 * npe)) || (rc = s.upload(&it.normal, t.normal, 3 * npe)) || (rc = s.upload(&it.min_dist, t.min_dist, npe)) ||
-            (rc = s.upload(&it.max_dist, t.max_dist, npe)) || (rc = s.upload(&it.has_point, hp, Ne)) || (rc = s.upload(&it.point_xw, t.point_xw, 3 * Ne))) return rc;
+        // uploads copy the REAL counts (an empty local map / a frame without features may pass NULL arrays: upload() of 0 elements only reserves)
+        const size_t npu = (size_t)np, Nu = (size_t)N;
+        if ((rc = s.upload(&it.pos, t.pos, 3 * npu)) || (rc = s.upload(&it.normal, t.normal, 3 * npu)) || (rc = s.upload(&it.min_dist, t.min_dist, npu)) ||
+            (rc = s.upload(&it.max_dist, t.max_dist, npu)) || (rc = s.upload(&it.has_point, hp, Nu)) || (rc = s.upload(&it.point_xw, t.point_xw, 3 * Nu))) return rc;
         it.candidate = nullptr;
-        if (t.candidate && (rc = s.upload(&it.candidate, t.candidate, npe))) return rc;
+        if (t.candidate && np && (rc = s.upload(&it.candidate, t.candidate, npu))) return rc;
         ProjQueriesD& q = it.q;
         q.n = np;
-        if ((rc = s.upload(&q.desc, t.desc, 32 * npe))) return rc;
+        if ((rc = s.upload(&q.desc, t.desc, 32 * npu))) return rc;
         q.angle = nullptr;
         if ((rc = s.alloc(&it.q_valid, npe)) || (rc = s.alloc(&it.q_cam, npe)) || (rc = s.alloc(&it.q_level, npe)) || (rc = s.alloc(&it.q_min, npe)) ||
             (rc = s.alloc(&it.q_max, npe)) || (rc = s.alloc(&it.q_u, npe)) || (rc = s.alloc(&it.q_v, npe)) || (rc = s.alloc(&it.q_radius, npe)) ||
@@ -1089,7 +1095,7 @@ int dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_t
     po.huber = prm->huber_delta;
     for (int i = 0; i < 4; ++i) { po.chi2_th[i] = prm->chi2_th[i]; po.its[i] = prm->its[i]; }
     po.err = d_err; po.level = d_level; po.out_poses = d_out; po.outlier = d_outl; po.n_inliers = d_ninl; po.edge_chi2 = nullptr; po.n_iters = nullptr;
-    if ((rc = launch_pose_opt_device(po, prm->cams, prm->n_cams, F, st))) return rc;
+    if ((rc = launch_pose_opt_device(po, prm->cams, prm->n_cams, F, max_feat, st))) return rc;      // a frame's edges <= its features
     hipLaunchKernelGGL(k_track_finish, dim3(F), dim3(256), 0, st, d_items, (const int32_t*)d_cnt, (const uint8_t*)d_outl);
     DCS_CHECK_LAUNCH();
     if ((rc = s.download_bytes(res->poses, d_out, sizeof(double) * 7 * F)) || (rc = s.download_bytes(res->n_inliers, d_ninl, sizeof(int32_t) * F))) return rc;

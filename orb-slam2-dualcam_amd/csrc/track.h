@@ -9,6 +9,8 @@
 
 namespace dcs {
 
+constexpr int kPoseMaxCams = 4;      // cameras of a rig the optimiser kernels hold by value (== kMaxCams of ba_solver.hip)
+
 struct PoseOptDevice {
     const double* poses;          // [F][7]
     const int32_t* edge_off;      // [F] first edge of frame f
@@ -19,6 +21,6 @@ struct PoseOptDevice {
     double* err; uint8_t* level;  // scratch [E][2], [E]
     double* out_poses; uint8_t* outlier; int32_t* n_inliers; double* edge_chi2 /* may be NULL */; int32_t* n_iters /* [F][4], may be NULL */;
 };
-int launch_pose_opt_device(const PoseOptDevice& p, const dcs_ba_camera* cams, int n_cams, int n_frames, hipStream_t st);
+int launch_pose_opt_device(const PoseOptDevice& p, const dcs_ba_camera* cams, int n_cams, int n_frames, int max_edges_bound /* no frame has more edges than this */, hipStream_t st);
 
 }  // namespace dcs

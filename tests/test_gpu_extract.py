@@ -20,7 +20,7 @@ def pipeline_mode(request, monkeypatch):
     monkeypatch.setenv("DCS_ORB_FAST_SPLIT", "2" if "early" in request.param else "0")
     # round 5: by default the FAST cells of level l write level l + 1 (k_fast_cells<EMIT>) -- whenever the blur is fused and no early FAST launch
     # is asked for, i.e. in the second variant; the fourth keeps the fused describe on the round-4 resize chain
-    monkeypatch.setenv("DCS_ORB_EMIT", "0" if "resize chain" in request.param else "1")
+    monkeypatch.setenv("DCS_ORB_EMIT", "0" if "resize chain" in request.param else "15")     # n > 0: the cells of levels [0, n) emit, whatever the batch size
 
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")

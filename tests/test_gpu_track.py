@@ -99,3 +99,29 @@ def test_track_local_map_edge_cases(pkg, synth):
     assert got[1]["n_matches"] == 0 and not np.any(got[1]["point_of_feature"] >= 0)
     assert np.array_equal(got[1]["point_of_feature"] == -2, frames[1]["has_point"] != 0)
     assert pkg.abi.PreparedTracking([], prm).track() == []
+
+
+def test_track_local_map_null_arrays_for_an_empty_local_map(pkg, synth):
+    """a C caller passes NULL for the arrays of an empty local map (n_points = 0): the uploads copy the real counts, nothing reads the pointers"""
+    frames, prm = synth.tracking_problem(n_frames=2, n_points=300, n_features=200, seed=3)
+    _with_grid(pkg, frames)
+    frames[0]["points"] = {k: v[:0] for k, v in frames[0]["points"].items()}
+    frames[0]["desc"] = frames[0]["desc"][:0]
+    ref = pkg.abi.PreparedTracking(frames, prm).track()
+    got = pkg.abi.PreparedTracking(frames, prm, null_empty=True).track()
+    for a, b in zip(ref, got):
+        assert a["n_matches"] == b["n_matches"] and a["n_inliers"] == b["n_inliers"]
+        assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["point_of_feature"], b["point_of_feature"]) and np.array_equal(a["outlier"], b["outlier"])
+    assert got[0]["n_matches"] == 0
+
+
+def test_track_local_map_rejects_more_cameras_than_intrinsics(pkg, synth):
+    """features.n_cams > prm->n_cams would index the optimiser's by-value camera table out of range: refused before anything is enqueued"""
+    frames, prm = synth.tracking_problem(n_frames=1, n_points=200, n_features=150, seed=9)
+    _with_grid(pkg, frames)
+    prm = dict(prm)
+    prm["cams"] = prm["cams"][:1]
+    assert len(frames[0]["features"]["cam_off"]) - 1 == 2
+    with pytest.raises(Exception) as ei:
+        pkg.abi.PreparedTracking(frames, prm).track()
+    assert "cameras" in str(ei.value)
