@@ -536,6 +536,50 @@ typedef struct dcs_track_result {
 } dcs_track_result;
 int  dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_track_params* prm, dcs_track_result* res);
 
+/* ---- the same chain FED FROM THE EXTRACTOR'S SLOTS (round 5): the frame's key points and descriptors stay where
+   dcs_orb_extract_batch_device left them in HBM one call earlier; what the Frame constructor does with them on the host
+   (src/Frame.cc:141-196: concatenate the cameras' key points into mvTotalKeysUn, PosInGrid + the 64 x 48 grid per camera) runs on
+   the device. Two modes, the two per-frame stages of the reference's steady state:
+     mode 0  Tracking::TrackLocalMap's search + optimisation: exactly dcs_track_local_map (isInFrustum -> SearchByProjection(F,
+             local map points, th) -> PoseOptimization);
+     mode 1  Tracking::TrackWithMotionModel (src/Tracking.cc:1384-1427): ORBmatcher(0.8, true).SearchByProjection(mCurrentFrame,
+             mpLastFrame, th) = SearchByProjectionOnCam per camera (src/ORBmatcher.cc:954-1113: project the last frame's map points with
+             the predicted pose, window th * mvScaleFactors[last octave], levels octave -+ 1, best distance <= TH_HIGH, a rotation
+             histogram per camera), then PoseOptimization over the new matches. The queries are the last frame's features that hold
+             a good map point, in ascending feature order: pos = GetWorldPos, desc = MapPoint::GetDescriptor, q_cam = keypointToCam[i],
+             q_octave / q_angle = the last frame's key point. mvpMapPoints of the current frame is empty in this stage (Tracking.cc:1396).
+   Key points are taken as they are (pt.x, pt.y = the undistorted position: Frame::UndistortKeyPoints is the identity for the zero
+   distortion the reference's rig files use, Frame.cc:UndistortKeyPoints first branch; a rig with distortion undistorts on the host and
+   uses dcs_track_local_map). Feature g of the outputs = the frame's compact index: camera c's features at [off_c, off_c + n_c) with
+   n_c = min(count of slot first_slot + c, cap) -- n_features reports n_c. Map-side arrays come from the host (they live in the reference's
+   map). One synchronisation, at the end. `stream` = the stream the extraction was enqueued on (the chain waits for it; NULL = legacy stream). */
+typedef struct dcs_dev_frame {
+    int32_t n_cams, cap, first_slot;    /* camera c = slot first_slot + c of the arrays below */
+    const dcs_keypoint* d_kp;           /* DEVICE [slots][cap] */
+    const uint8_t*      d_desc;         /* DEVICE [slots][cap][32] */
+    const int32_t*      d_n;            /* DEVICE [slots] */
+    const float* min_x; const float* min_y; const float* grid_w_inv; const float* grid_h_inv;   /* host [n_cams]: mvMinX, mvMinY, mvfGridElementWidthInv / HeightInv */
+} dcs_dev_frame;
+typedef struct dcs_track_dev_frame {
+    dcs_dev_frame     features;
+    dcs_frustum_frame view;         /* the matrices of the pose guess (mode 1 reads Rsw, tsw, fx .. cy, min / max, scale_factors) */
+    const double*     pose;         /* [7] */
+    int32_t           n_held;       /* entries of the three arrays below (the frame's feature count as an earlier stage reported it; 0 with NULL arrays: nothing held) */
+    const uint8_t*    taken;        /* host [n_held] as dcs_proj_frame.taken */
+    const uint8_t*    has_point;    /* host [n_held] or NULL (= taken) */
+    const float*      point_xw;     /* host [n_held][3] */
+    int32_t           n_points;     /* queries: local map points (mode 0) / the last frame's features with a map point (mode 1) */
+    const float* pos; const float* normal; const float* min_dist; const float* max_dist; const uint8_t* candidate;   /* normal .. candidate: mode 0 only */
+    const uint8_t* desc;            /* [n_points][32] */
+    const int32_t* q_cam; const int32_t* q_octave; const float* q_angle;   /* mode 1 only, [n_points] */
+} dcs_track_dev_frame;
+typedef struct dcs_track_dev_result {
+    dcs_track_result r;             /* arrays per frame sized for n_cams * cap features / n_points queries */
+    int32_t* n_features;            /* [F][n_cams] features per camera as assembled */
+} dcs_track_dev_result;
+int  dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, const dcs_track_params* prm, int mode, int check_orientation,
+                            dcs_track_dev_result* res, void* stream);
+
 
 /* Cameras::setExtrinsics (Cameras.cc:17-37) + Converter::toSE3Quat/toMatrix6d: float 4x4 (row-major)
    -> ext[7], adj[36]. exact = 0: reference matrix [[R, R t^],[0, R]] in float;

@@ -661,3 +661,40 @@ extern "C" void orc_is_in_frustum(const orc_frustum_frame* f, int n, const float
         }
     }
 }
+
+
+// ---- ORBmatcher::SearchByProjectionOnCam (src/ORBmatcher.cc:954-1113), the geometry in front of its candidate loop, for every feature i of
+// the last frame that holds a good map point (the caller passes those, in ascending feature order: :989-995 skip the rest):
+//   * Tsw = Tsc * Tcw, Rsw / tsw its blocks (:962-968) come from the caller as cv::Mat forms them (orc_frustum_frame);
+//   * x3Ds = Rsw * x3Dw + tsw (:997): cv::gemm's small-matrix path for CV_32F -- a float dot product left to right, then
+//     (float)(t0 * alpha + c * beta) with double alpha = beta = 1 (the arithmetic orc_is_in_frustum restates);
+//   * zs < 0 -> skip (:1002); invzs = 1.0 / zs, a DOUBLE division narrowed to float (:1003); u = fx * xs * invzs + cx in float (:1005-1006);
+//   * outside [mvMinX, mvMaxX] x [mvMinY, mvMaxY] -> skip (:1008-1011);
+//   * radius = th * mvScaleFactors[nLastOctave] (:1031), GetFeaturesInArea(query, u, v, radius, nLastOctave - 1, nLastOctave + 1) (:1036).
+// zs == 0 (a point in the camera's focal plane) projects to infinity in the reference; here it is reported as not visible.
+extern "C" void orc_motion_model_queries(const orc_frustum_frame* f, int n, const float* pos, const int32_t* q_cam, const int32_t* q_octave, float th,
+                                         uint8_t* valid, float* u_out, float* v_out, float* radius, int32_t* min_level, int32_t* max_level)
+{
+    for (int i = 0; i < n; ++i) {
+        const int c = q_cam[i];
+        const float* R = f->Rsw + 9 * c; const float* t = f->tsw + 3 * c; const float* P = pos + 3 * i;
+        float Ps[3];
+        for (int r = 0; r < 3; ++r) {
+            const float t0 = R[3 * r] * P[0] + R[3 * r + 1] * P[1] + R[3 * r + 2] * P[2];
+            Ps[r] = (float)((double)t0 * 1.0 + (double)t[r] * 1.0);
+        }
+        int oct = q_octave[i];
+        if (oct < 0) oct = 0; else if (oct >= f->n_scale_levels) oct = f->n_scale_levels - 1;
+        valid[i] = 0; u_out[i] = 0; v_out[i] = 0;
+        radius[i] = th * f->scale_factors[oct];
+        min_level[i] = q_octave[i] - 1; max_level[i] = q_octave[i] + 1;
+        if (Ps[2] < 0.0f || Ps[2] == 0.0f) continue;
+        const float invzs = (float)(1.0 / (double)Ps[2]);
+        const float u = f->fx[c] * Ps[0] * invzs + f->cx[c];
+        const float v = f->fy[c] * Ps[1] * invzs + f->cy[c];
+        u_out[i] = u; v_out[i] = v;
+        if (u < f->min_x[c] || u > f->max_x[c]) continue;
+        if (v < f->min_y[c] || v > f->max_y[c]) continue;
+        valid[i] = 1;
+    }
+}

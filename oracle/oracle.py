@@ -742,6 +742,22 @@ def detect_candidates(loop, query_id, q_word, q_val, db, dead, covis, state, con
     return [int(v) for v in out[:k]]
 
 
+def motion_model_queries(frame, pos, q_cam, q_octave, th):
+    """the query columns (valid, u, v, radius, min_level, max_level) of SearchByProjectionOnCam for the last frame's features with a map point"""
+    keep = []
+    f = _frustum_frame(FrustumFrame, frame, keep)
+    pos, q_cam, q_octave = _c(pos, np.float32).reshape(-1, 3), _c(q_cam, np.int32), _c(q_octave, np.int32)
+    n = len(pos)
+    m = max(n, 1)
+    out = dict(valid=np.zeros(m, np.uint8), u=np.zeros(m, np.float32), v=np.zeros(m, np.float32), radius=np.zeros(m, np.float32),
+               min_level=np.zeros(m, np.int32), max_level=np.zeros(m, np.int32))
+    L = lib()
+    L.orc_motion_model_queries.restype = None
+    L.orc_motion_model_queries.argtypes = [C.POINTER(FrustumFrame), C.c_int] + [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 6
+    L.orc_motion_model_queries(C.byref(f), n, _p(pos), _p(q_cam), _p(q_octave), float(th), *[_p(out[k]) for k in ("valid", "u", "v", "radius", "min_level", "max_level")])
+    return {k: a[:n] for k, a in out.items()}
+
+
 def is_in_frustum(frame, pts, viewing_cos_limit=0.5, th=1.0):
     """Frame::isInFrustum + PredictScale + search window for pts = dict(pos[n,3], normal[n,3], min_dist[n], max_dist[n], candidate[n] or None)."""
     keep = []

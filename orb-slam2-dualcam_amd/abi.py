@@ -1095,3 +1095,91 @@ class PreparedTracking:
         _check(lib().dcs_track_local_map(self.F, C.cast(self.frames, C.c_void_p), C.byref(self.prm), C.byref(self.res)), "dcs_track_local_map")
         return [dict(pose=self.poses[k].copy(), n_inliers=int(self.n_inl[k]), n_matches=int(self.n_match[k]), match_of_point=self.mop[k][:self.np_[k]].copy(),
                      point_of_feature=self.pof[k][:self.N[k]].copy(), outlier=self.outl[k][:self.N[k]].copy()) for k in range(self.F)]
+
+
+class DevFrame(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("cap", C.c_int32), ("first_slot", C.c_int32), ("d_kp", C.c_void_p), ("d_desc", C.c_void_p), ("d_n", C.c_void_p),
+                ("min_x", C.c_void_p), ("min_y", C.c_void_p), ("grid_w_inv", C.c_void_p), ("grid_h_inv", C.c_void_p)]
+
+
+class TrackDevFrame(C.Structure):
+    _fields_ = [("features", DevFrame), ("view", FrustumFrame), ("pose", C.c_void_p), ("n_held", C.c_int32), ("taken", C.c_void_p), ("has_point", C.c_void_p),
+                ("point_xw", C.c_void_p), ("n_points", C.c_int32), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_dist", C.c_void_p), ("max_dist", C.c_void_p),
+                ("candidate", C.c_void_p), ("desc", C.c_void_p), ("q_cam", C.c_void_p), ("q_octave", C.c_void_p), ("q_angle", C.c_void_p)]
+
+
+class TrackDevResult(C.Structure):
+    _fields_ = [("r", TrackResult), ("n_features", C.c_void_p)]
+
+
+class PreparedTrackingDevice:
+    """dcs_track_frame_device: the tracking chain on frames whose features are where dcs_orb_extract_batch_device left them. frames[k] = dict(
+    dev = dict(d_kp, d_desc, d_n: device pointers (ints); cap, first_slot, n_cams; min_x, min_y, grid_w_inv, grid_h_inv: per camera), view, pose,
+    held = None or dict(taken, has_point, point_xw) in the frame's compact feature order, points = dict(pos[, normal, min_dist, max_dist, candidate]),
+    desc, and for mode 1 q_cam, q_octave, q_angle). track() -> per frame dict incl. n_features[n_cams]; arrays cut to the real feature count."""
+
+    def __init__(self, frames, params, mode, check_orientation=False, stream=None):
+        self.keep = []
+
+        def a(x, dt):
+            if x is None:
+                return None
+            arr = _c(x, dt)
+            self.keep.append(arr)
+            return _p(arr).value
+        F = len(frames)
+        self.F, self.mode, self.check, self.stream = F, int(mode), int(bool(check_orientation)), stream
+        arr = (TrackDevFrame * max(F, 1))()
+        self.Ncap, self.np_, self.C = [], [], []
+        for k, fr in enumerate(frames):
+            dv, vw, pt = fr["dev"], fr["view"], fr["points"]
+            t = arr[k]
+            C_ = int(dv["n_cams"])
+            t.features = DevFrame(C_, int(dv["cap"]), int(dv["first_slot"]), int(dv["d_kp"]), int(dv["d_desc"]), int(dv["d_n"]), a(dv["min_x"], np.float32),
+                                  a(dv["min_y"], np.float32), a(dv["grid_w_inv"], np.float32), a(dv["grid_h_inv"], np.float32))
+            v = FrustumFrame()
+            v.n_cams = len(vw["fx"])
+            for key in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y"):
+                setattr(v, key, a(vw[key], np.float32))
+            v.log_scale_factor = float(vw["log_scale_factor"]); v.n_scale_levels = len(vw["scale_factors"]); v.scale_factors = a(vw["scale_factors"], np.float32)
+            t.view = v
+            t.pose = a(fr["pose"], np.float64)
+            held = fr.get("held")
+            t.n_held = 0 if held is None else len(held["taken"])
+            if held is not None:
+                t.taken, t.has_point, t.point_xw = a(held["taken"], np.uint8), a(held.get("has_point"), np.uint8), a(held["point_xw"], np.float32)
+            t.n_points = len(pt["pos"])
+            t.pos = a(pt["pos"], np.float32)
+            t.normal, t.min_dist, t.max_dist = a(pt.get("normal"), np.float32), a(pt.get("min_dist"), np.float32), a(pt.get("max_dist"), np.float32)
+            t.candidate = a(pt.get("candidate"), np.uint8)
+            t.desc = a(fr["desc"], np.uint8)
+            t.q_cam, t.q_octave, t.q_angle = a(fr.get("q_cam"), np.int32), a(fr.get("q_octave"), np.int32), a(fr.get("q_angle"), np.float32)
+            self.Ncap.append(C_ * int(dv["cap"])); self.np_.append(len(pt["pos"])); self.C.append(C_)
+        self.frames = arr
+        cam_list = [c if isinstance(c, BaCamera) else make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in params["cams"]]
+        self.cams = (BaCamera * len(cam_list))(*cam_list)
+        sig = a(params["inv_level_sigma2"], np.float32)
+        self.prm = TrackParams(float(params["viewing_cos_limit"]), float(params["th"]), int(params["th_high"]), float(params["nn_ratio"]),
+                               len(params["inv_level_sigma2"]), sig, len(cam_list), C.cast(self.cams, C.c_void_p).value, float(params["huber_delta"]),
+                               (C.c_float * 4)(*params["chi2_th"]), (C.c_int32 * 4)(*params["its"]))
+        self.poses = np.zeros((max(F, 1), 7)); self.n_inl = np.zeros(max(F, 1), np.int32); self.n_match = np.zeros(max(F, 1), np.int32)
+        self.nfeat = np.zeros(max(sum(self.C), 1), np.int32)
+        self.mop = [np.full(max(n, 1), -1, np.int32) for n in self.np_]
+        self.pof = [np.full(max(n, 1), -1, np.int32) for n in self.Ncap]
+        self.outl = [np.zeros(max(n, 1), np.uint8) for n in self.Ncap]
+        self.p_mop = (C.c_void_p * max(F, 1))(*[_p(x).value for x in self.mop])
+        self.p_pof = (C.c_void_p * max(F, 1))(*[_p(x).value for x in self.pof])
+        self.p_outl = (C.c_void_p * max(F, 1))(*[_p(x).value for x in self.outl])
+        self.res = TrackDevResult(TrackResult(_p(self.poses).value, _p(self.n_inl).value, _p(self.n_match).value, C.cast(self.p_mop, C.c_void_p).value,
+                                              C.cast(self.p_pof, C.c_void_p).value, C.cast(self.p_outl, C.c_void_p).value), _p(self.nfeat).value)
+
+    def track(self):
+        _check(lib().dcs_track_frame_device(self.F, C.cast(self.frames, C.c_void_p), C.byref(self.prm), self.mode, self.check, C.byref(self.res),
+                                            C.c_void_p(self.stream or 0)), "dcs_track_frame_device")
+        out, at = [], 0
+        for k in range(self.F):
+            nf = self.nfeat[at:at + self.C[k]].copy(); at += self.C[k]
+            N = int(nf.sum())
+            out.append(dict(pose=self.poses[k].copy(), n_inliers=int(self.n_inl[k]), n_matches=int(self.n_match[k]), match_of_point=self.mop[k][:self.np_[k]].copy(),
+                            point_of_feature=self.pof[k][:N].copy(), outlier=self.outl[k][:N].copy(), n_features=nf))
+        return out

@@ -281,15 +281,20 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
                                                       const int32_t* __restrict__ cand_n, uint8_t* __restrict__ state /* [n] 0 = undecided */,
                                                       int th_high, float nn_ratio, int check_ori, int32_t* __restrict__ match_of_query,
                                                       int32_t* __restrict__ query_of_feature, int32_t* __restrict__ bin_of_query,
-                                                      int32_t* __restrict__ n_matches)
+                                                      int32_t* __restrict__ n_matches, int cam_filter = -1)
 {
+    // cam_filter >= 0 (round 5): only the queries and the features of ONE camera -- ORBmatcher::SearchByProjection(Fcur, Flast, th) is a loop of
+    // SearchByProjectionOnCam calls (ORBmatcher.cc:954-1113), each with a rotation histogram of its own and each confined to its camera's features;
+    // the workgroups of a frame's cameras then run side by side and touch disjoint entries of every array.
     __shared__ int s_minq[kResMaxN];
     __shared__ uint8_t s_taken[kResMaxN];
     __shared__ int s_hist[kHisto], s_ind[3];
     __shared__ int s_first, s_firstovf, s_undecided, s_nm;
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < f.N; i += kResT) { s_taken[i] = f.taken[i]; query_of_feature[i] = -1; }
-    for (int i = tid; i < q.n; i += kResT) { match_of_query[i] = -1; state[i] = cand_n[i] == 0; }   // empty window / invalid: decided
+    const int f_lo = cam_filter >= 0 ? f.cam_off[cam_filter] : 0, f_hi = cam_filter >= 0 ? f.cam_off[cam_filter + 1] : f.N;
+    auto mine = [&](int qi) { return cam_filter < 0 || q.cam[qi] == cam_filter; };
+    for (int i = f_lo + tid; i < f_hi; i += kResT) { s_taken[i] = f.taken[i]; query_of_feature[i] = -1; }
+    for (int i = tid; i < q.n; i += kResT) if (mine(i)) { match_of_query[i] = -1; state[i] = cand_n[i] == 0; }   // empty window / invalid: decided
     if (tid < kHisto) s_hist[tid] = 0;
     if (tid == 0) s_nm = 0;
     __syncthreads();
@@ -318,11 +323,11 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
         }
     };
     for (;;) {
-        for (int i = tid; i < f.N; i += kResT) s_minq[i] = 0x7FFFFFFF;
+        for (int i = f_lo + tid; i < f_hi; i += kResT) s_minq[i] = 0x7FFFFFFF;
         if (tid == 0) { s_first = 0x7FFFFFFF; s_firstovf = 0x7FFFFFFF; s_undecided = 0; }
         __syncthreads();
         for (int qi = tid; qi < q.n; qi += kResT) {
-            if (state[qi]) continue;
+            if (!mine(qi) || state[qi]) continue;
             atomicMin(&s_first, qi);
             const int n = cand_n[qi];
             if (n > kProjCap) { atomicMin(&s_firstovf, qi); continue; }
@@ -338,7 +343,7 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
         const int first = s_first, first_ovf = s_firstovf;
         if (first == 0x7FFFFFFF) break;                        // everything decided
         for (int qi = tid; qi < q.n; qi += kResT) {
-            if (state[qi]) continue;
+            if (!mine(qi) || state[qi]) continue;
             const int n = cand_n[qi];
             if (n > kProjCap || qi > first_ovf) continue;
             const int base = f.cam_off[q.cam[qi]];
@@ -408,6 +413,7 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
         }
         __syncthreads();
         for (int qi = tid; qi < q.n; qi += kResT) {
+            if (!mine(qi)) continue;
             const int g = match_of_query[qi];
             if (g < 0) continue;
             const int b = bin_of_query[qi];
@@ -732,6 +738,127 @@ __global__ __launch_bounds__(256) void k_track_finish(const TrackItem* __restric
 {
     const TrackItem& it = items[blockIdx.x];
     for (int k = threadIdx.x; k < edge_cnt[blockIdx.x]; k += 256) it.feat_outlier[it.edge_feature[k]] = outlier[it.edge_base + k];   // mvbOutlier[i]
+}
+
+// ---- device-resident frames (dcs_track_frame_device): what the Frame constructor does with the extractor's output (src/Frame.cc:141-196)
+struct DevAsm {                                    // one per frame: where the extractor left the features, and the assembled arrays
+    const dcs_keypoint* kp; const uint8_t* desc; const int32_t* n; int cap, first_slot, n_cams;
+    int32_t* cam_off; float *kp_x, *kp_y, *kp_angle; int32_t* kp_octave; uint8_t* desc_out; int32_t *grid_off, *grid_idx;
+    const float *min_x, *min_y, *w_inv, *h_inv;    // device copies of the per-camera grid constants
+    int32_t* n_features;                           // [n_cams] output
+    const int32_t *q_cam_in, *q_octave_in;         // mode 1: camera and octave of every query (the last frame's key point)
+};
+// mvTotalKeysUn / mvDescriptors concatenated over the cameras (Frame.cc:166-181): feature i of camera c at cam_off[c] + i
+__global__ __launch_bounds__(256) void k_dev_assemble(const DevAsm* __restrict__ das)
+{
+    const DevAsm& d = das[blockIdx.y];
+    int off[kFrMaxCams + 1];
+    off[0] = 0;
+    for (int c = 0; c < d.n_cams; ++c) off[c + 1] = off[c] + min(max(d.n[d.first_slot + c], 0), d.cap);      // (a negative count is the extractor's error code: no features)
+    if (blockIdx.x == 0 && threadIdx.x <= d.n_cams) {
+        d.cam_off[threadIdx.x] = off[threadIdx.x];
+        if (threadIdx.x < d.n_cams) d.n_features[threadIdx.x] = off[threadIdx.x + 1] - off[threadIdx.x];
+    }
+    const int t = blockIdx.x * 256 + threadIdx.x;               // thread = (feature slot, 8-byte piece of its descriptor): 4 threads per feature
+    const int s = t >> 2, piece = t & 3;
+    const int c = s / d.cap, i = s - c * d.cap;
+    if (c >= d.n_cams || i >= off[c + 1] - off[c]) return;
+    const size_t src = (size_t)(d.first_slot + c) * d.cap + i;
+    const int g = off[c] + i;
+    reinterpret_cast<unsigned long long*>(d.desc_out + (size_t)g * 32)[piece] = reinterpret_cast<const unsigned long long*>(d.desc + src * 32)[piece];
+    if (piece == 0) {
+        const dcs_keypoint k = d.kp[src];
+        d.kp_x[g] = k.x; d.kp_y[g] = k.y; d.kp_angle[g] = k.angle; d.kp_octave[g] = k.octave;
+    }
+}
+// Frame::PosInGrid + the grid fill (Frame.cc:183-190, 380-390) as the CSR dcs_frame_grid builds on the host: cells (c, ix, iy), entries =
+// camera-local indices in insertion (= ascending) order. One workgroup per frame: counts in LDS, scan, placement, then every cell orders
+// its (few) entries.
+constexpr int kGridT = 1024;
+__global__ __launch_bounds__(kGridT) void k_dev_grid(const DevAsm* __restrict__ das)
+{
+    extern __shared__ int s_cell[];                             // [cells]: counts, then write cursors
+    __shared__ int s_scan[kGridT / 64];
+    const DevAsm& d = das[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cells = d.n_cams * DCS_GRID_COLS * DCS_GRID_ROWS, N = d.cam_off[d.n_cams];
+    for (int i = tid; i < cells; i += kGridT) s_cell[i] = 0;
+    __syncthreads();
+    auto cell_of = [&](int g, int c) {
+        const int px = __float2int_rn(__fmul_rn(__fsub_rn(d.kp_x[g], d.min_x[c]), d.w_inv[c]));              // cvRound: round half to even
+        const int py = __float2int_rn(__fmul_rn(__fsub_rn(d.kp_y[g], d.min_y[c]), d.h_inv[c]));
+        return (px < 0 || px >= DCS_GRID_COLS || py < 0 || py >= DCS_GRID_ROWS) ? -1 : (c * DCS_GRID_COLS + px) * DCS_GRID_ROWS + py;
+    };
+    auto cam_of = [&](int g) { int c = 0; while (c + 1 < d.n_cams && g >= d.cam_off[c + 1]) ++c; return c; };
+    for (int g = tid; g < N; g += kGridT) { const int cl = cell_of(g, cam_of(g)); if (cl >= 0) atomicAdd(&s_cell[cl], 1); }
+    __syncthreads();
+    // exclusive scan over the cells: every thread owns a run of consecutive cells
+    const int per = (cells + kGridT - 1) / kGridT, c0 = tid * per, c1 = min(c0 + per, cells);
+    int sum = 0;
+    for (int i = c0; i < c1; ++i) sum += s_cell[i];
+    int inc = sum;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const int t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
+    if (lane == 63) s_scan[wave] = inc;
+    __syncthreads();
+    int before = inc - sum;
+    for (int w = 0; w < wave; ++w) before += s_scan[w];
+    for (int i = c0; i < c1; ++i) { const int n = s_cell[i]; d.grid_off[i] = before; s_cell[i] = before; before += n; }
+    if (tid == kGridT - 1) d.grid_off[cells] = before;
+    __syncthreads();
+    for (int g = tid; g < N; g += kGridT) {
+        const int c = cam_of(g), cl = cell_of(g, c);
+        if (cl >= 0) d.grid_idx[atomicAdd(&s_cell[cl], 1)] = g - d.cam_off[c];
+    }
+    __syncthreads();
+    for (int i = c0; i < c1; ++i) {                             // s_cell[i] is now the END of cell i; insertion sort of its entries (ascending local index)
+        const int b = d.grid_off[i], e = s_cell[i];
+        for (int a = b + 1; a < e; ++a) {
+            const int v = d.grid_idx[a];
+            int k = a - 1;
+            while (k >= b && d.grid_idx[k] > v) { d.grid_idx[k + 1] = d.grid_idx[k]; --k; }
+            d.grid_idx[k + 1] = v;
+        }
+    }
+}
+// The geometry of SearchByProjectionOnCam (ORBmatcher.cc:962-968, 990-1036) for every query (a feature of the last frame with a good map
+// point): x3Ds = Rsw x3Dw + tsw in the reference's cv::Mat arithmetic (float dot product left to right, the translation added through
+// double: the small-matrix path of cv::gemm, as in frustum_point), zs < 0 -> skip, invzs = 1.0 / zs (a DOUBLE division narrowed to float,
+// :1003), u, v, the image-bounds test, radius = th * mvScaleFactors[last octave], levels octave - 1 .. octave + 1.
+__global__ __launch_bounds__(256) void k_track_mm_queries(const TrackItem* __restrict__ items, const DevAsm* __restrict__ das, float th)
+{
+    const TrackItem& it = items[blockIdx.y];
+    const DevAsm& d = das[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= it.n_points) return;
+    const FrustumDev& F = it.F;
+    const int c = d.q_cam_in[i], oct = min(max(d.q_octave_in[i], 0), F.n_levels - 1);
+    const float P0 = it.pos[3 * i], P1 = it.pos[3 * i + 1], P2 = it.pos[3 * i + 2];
+    float Ps[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float t0 = __fadd_rn(__fadd_rn(__fmul_rn(F.R[c][3 * r], P0), __fmul_rn(F.R[c][3 * r + 1], P1)), __fmul_rn(F.R[c][3 * r + 2], P2));
+        Ps[r] = (float)((double)t0 + (double)F.t[c][r]);
+    }
+    uint8_t ok = 0;
+    float u = 0, v = 0;
+    if (!(Ps[2] < 0.0f) && Ps[2] != 0.0f) {                       // (zs == 0 would project to infinity: treated as not visible)
+        const float invz = (float)(1.0 / (double)Ps[2]);
+        u = __fadd_rn(__fmul_rn(__fmul_rn(F.fx[c], Ps[0]), invz), F.cx[c]);
+        v = __fadd_rn(__fmul_rn(__fmul_rn(F.fy[c], Ps[1]), invz), F.cy[c]);
+        ok = !(u < F.min_x[c] || u > F.max_x[c]) && !(v < F.min_y[c] || v > F.max_y[c]);
+    }
+    it.q_valid[i] = ok; it.q_cam[i] = c; it.q_u[i] = u; it.q_v[i] = v;
+    it.q_radius[i] = __fmul_rn(th, F.scale_factors[oct]);
+    it.q_level[i] = oct; it.q_min[i] = d.q_octave_in[i] - 1; it.q_max[i] = d.q_octave_in[i] + 1;
+}
+// mode 1: one workgroup per (camera, frame) -- the SearchByProjectionOnCam calls of SearchByProjection(Fcur, Flast, th)
+__global__ __launch_bounds__(kResT) void k_track_resolve_cam(const TrackItem* __restrict__ items, int th_high, int check_ori)
+{
+    const TrackItem& it = items[blockIdx.y];
+    if ((int)blockIdx.x >= it.f.n_cams) return;
+    if (blockIdx.x == 0) for (int i = it.f.cam_off[it.f.n_cams] + (int)threadIdx.x; i < it.f.N; i += kResT) it.qf[i] = -1;      // the slots behind the last real feature (k_track_edges walks the capacity)
+    proj_resolve_par_body(it.f, it.q, it.cand, it.cand_n, it.state, th_high, 0.f, check_ori, it.mq, it.qf, it.bin, it.nm + blockIdx.x, (int)blockIdx.x);
 }
 
 
@@ -1107,6 +1234,169 @@ int dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_t
         if ((rc = s.download_bytes(&res->n_matches[k], it.nm, sizeof(int32_t)))) return rc;
     }
     return s.finish();
+}
+
+
+int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, const dcs_track_params* prm, int mode, int check_orientation,
+                           dcs_track_dev_result* res, void* stream)
+{
+    const int F = n_frames;
+    if (F < 0 || (mode != 0 && mode != 1) || (F && (!frames || !prm || !res || !res->n_features || !res->r.poses || !res->r.n_inliers || !res->r.n_matches ||
+        !res->r.match_of_point || !res->r.point_of_feature || !res->r.outlier)) || (F && (prm->n_levels < 1 || !prm->inv_level_sigma2 || !prm->cams))) {
+        set_error("dcs_track_frame_device: bad argument"); return DCS_ERR_INVALID;
+    }
+    if (F == 0) return DCS_OK;
+    if (prm->n_cams < 1 || prm->n_cams > kPoseMaxCams) { set_error("dcs_track_frame_device: prm->n_cams must be 1..%d", kPoseMaxCams); return DCS_ERR_INVALID; }
+    int rc, max_pts = 0, max_q4 = 0, max_cap = 0, max_cams = 0;
+    long long n_feat = 0;
+    for (int k = 0; k < F; ++k) {
+        const dcs_track_dev_frame& t = frames[k];
+        const dcs_dev_frame& df = t.features;
+        const dcs_frustum_frame* v = &t.view;
+        const int Ncap = df.n_cams * df.cap;
+        if (df.n_cams < 1 || df.n_cams > prm->n_cams || df.cap < 1 || df.first_slot < 0 || !df.d_kp || !df.d_desc || !df.d_n || !df.min_x || !df.min_y || !df.grid_w_inv ||
+            !df.grid_h_inv || Ncap > kResMaxN || t.n_points < 0 || !t.pose || v->n_cams != df.n_cams || v->n_scale_levels < 1 || !v->Rsw || !v->tsw || !v->Ow || !v->fx || !v->fy ||
+            !v->cx || !v->cy || !v->min_x || !v->max_x || !v->min_y || !v->max_y || !v->scale_factors || t.n_held < 0 || t.n_held > Ncap ||
+            (t.n_held && (!t.taken || !t.point_xw)) || (t.n_points && (!t.pos || !t.desc)) ||
+            (mode == 0 && t.n_points && (!t.normal || !t.min_dist || !t.max_dist)) || (mode == 1 && t.n_points && (!t.q_cam || !t.q_octave || (check_orientation && !t.q_angle))) ||
+            !res->r.match_of_point[k] || !res->r.point_of_feature[k] || !res->r.outlier[k]) { set_error("dcs_track_frame_device: frame %d: bad argument", k); return DCS_ERR_INVALID; }
+        if (mode == 1) for (int i = 0; i < t.n_points; ++i) if (t.q_cam[i] < 0 || t.q_cam[i] >= df.n_cams) { set_error("frame %d: query %d: camera out of range", k, i); return DCS_ERR_INVALID; }
+        n_feat += Ncap; max_cap = std::max(max_cap, Ncap); max_cams = std::max(max_cams, df.n_cams);
+        max_pts = std::max(max_pts, t.n_points); max_q4 = std::max(max_q4, (t.n_points + 3) / 4);
+    }
+    if ((rc = ensure_device())) return rc;
+    Scratch s;
+    std::vector<TrackItem> items((size_t)F);
+    std::vector<DevAsm> das((size_t)F);
+    std::vector<int32_t> edge_off((size_t)F);
+    const size_t Etot = (size_t)std::max<long long>(n_feat, 1);
+    int base = 0;
+    int32_t* d_nfeat;
+    if ((rc = s.alloc(&d_nfeat, (size_t)F * kFrMaxCams))) return rc;
+    hipStream_t raw = s.raw_st;
+    // arrays the kernels read past the frame's real feature count (its capacity is all the host knows) start out as zeros
+    auto zeroed = [&](auto** p, size_t n) -> int {
+        int r = s.alloc(p, n);
+        if (r) return r;
+        return hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(**p), raw) == hipSuccess ? DCS_OK : DCS_ERR_HIP;
+    };
+    for (int k = 0; k < F; ++k) {
+        const dcs_track_dev_frame& t = frames[k];
+        const dcs_dev_frame& df = t.features;
+        TrackItem& it = items[(size_t)k];
+        DevAsm& d = das[(size_t)k];
+        const dcs_frustum_frame* v = &t.view;
+        const int C = df.n_cams, Ncap = C * df.cap, cells = C * DCS_GRID_COLS * DCS_GRID_ROWS, np = t.n_points;
+        FrustumDev& Fd = it.F;
+        Fd = FrustumDev{};
+        Fd.n_cams = C; Fd.n_levels = v->n_scale_levels; Fd.log_scale = v->log_scale_factor;
+        for (int c = 0; c < C; ++c) {
+            for (int j = 0; j < 9; ++j) Fd.R[c][j] = v->Rsw[9 * c + j];
+            for (int j = 0; j < 3; ++j) { Fd.t[c][j] = v->tsw[3 * c + j]; Fd.O[c][j] = v->Ow[3 * c + j]; }
+            Fd.fx[c] = v->fx[c]; Fd.fy[c] = v->fy[c]; Fd.cx[c] = v->cx[c]; Fd.cy[c] = v->cy[c];
+            Fd.min_x[c] = v->min_x[c]; Fd.max_x[c] = v->max_x[c]; Fd.min_y[c] = v->min_y[c]; Fd.max_y[c] = v->max_y[c];
+        }
+        if ((rc = s.upload(&Fd.scale_factors, v->scale_factors, (size_t)v->n_scale_levels))) return rc;
+        d = DevAsm{};
+        d.kp = df.d_kp; d.desc = df.d_desc; d.n = df.d_n; d.cap = df.cap; d.first_slot = df.first_slot; d.n_cams = C;
+        d.n_features = d_nfeat + (size_t)k * kFrMaxCams;
+        uint8_t *taken_w, *hasp_w; float* pxw_w;
+        if ((rc = s.alloc(&d.cam_off, (size_t)C + 1)) || (rc = zeroed(&d.kp_x, (size_t)Ncap)) || (rc = zeroed(&d.kp_y, (size_t)Ncap)) || (rc = zeroed(&d.kp_angle, (size_t)Ncap)) ||
+            (rc = zeroed(&d.kp_octave, (size_t)Ncap)) || (rc = s.alloc(&d.desc_out, (size_t)Ncap * 32)) || (rc = s.alloc(&d.grid_off, (size_t)cells + 1)) ||
+            (rc = s.alloc(&d.grid_idx, (size_t)Ncap)) || (rc = s.upload(&d.min_x, df.min_x, (size_t)C)) || (rc = s.upload(&d.min_y, df.min_y, (size_t)C)) ||
+            (rc = s.upload(&d.w_inv, df.grid_w_inv, (size_t)C)) || (rc = s.upload(&d.h_inv, df.grid_h_inv, (size_t)C)) ||
+            (rc = zeroed(&taken_w, (size_t)Ncap)) || (rc = zeroed(&hasp_w, (size_t)Ncap)) || (rc = zeroed(&pxw_w, (size_t)3 * Ncap))) return rc;
+        if (t.n_held) {
+            if ((rc = s.upload_into(taken_w, t.taken, (size_t)t.n_held)) || (rc = s.upload_into(hasp_w, t.has_point ? t.has_point : t.taken, (size_t)t.n_held)) ||
+                (rc = s.upload_into(pxw_w, t.point_xw, (size_t)3 * t.n_held))) return rc;
+        }
+        ProjFrameD& f = it.f;
+        f = ProjFrameD{};
+        f.n_cams = C; f.N = Ncap;                                   // (the real count lives in cam_off on the device; entries beyond it are inert zeros)
+        f.cam_off = d.cam_off; f.kp_x = d.kp_x; f.kp_y = d.kp_y; f.kp_octave = d.kp_octave; f.kp_angle = d.kp_angle; f.desc = d.desc_out; f.taken = taken_w;
+        f.min_x = d.min_x; f.min_y = d.min_y; f.w_inv = d.w_inv; f.h_inv = d.h_inv; f.grid_off = d.grid_off; f.grid_idx = d.grid_idx;
+        it.has_point = hasp_w; it.point_xw = pxw_w;
+        it.n_points = np;
+        const size_t npe = (size_t)std::max(np, 1), Ne = (size_t)std::max(Ncap, 1), npu = (size_t)np;
+        it.normal = it.min_dist = it.max_dist = nullptr; it.candidate = nullptr;
+        if ((rc = s.upload(&it.pos, t.pos, 3 * npu))) return rc;
+        if (mode == 0) {
+            if ((rc = s.upload(&it.normal, t.normal, 3 * npu)) || (rc = s.upload(&it.min_dist, t.min_dist, npu)) || (rc = s.upload(&it.max_dist, t.max_dist, npu))) return rc;
+            if (t.candidate && np && (rc = s.upload(&it.candidate, t.candidate, npu))) return rc;
+        } else {
+            if ((rc = s.upload(&d.q_cam_in, t.q_cam, npu)) || (rc = s.upload(&d.q_octave_in, t.q_octave, npu))) return rc;
+        }
+        ProjQueriesD& q = it.q;
+        q.n = np;
+        if ((rc = s.upload(&q.desc, t.desc, 32 * npu))) return rc;
+        q.angle = nullptr;
+        if (mode == 1 && check_orientation && (rc = s.upload(&q.angle, t.q_angle, npu))) return rc;
+        if ((rc = s.alloc(&it.q_valid, npe)) || (rc = s.alloc(&it.q_cam, npe)) || (rc = s.alloc(&it.q_level, npe)) || (rc = s.alloc(&it.q_min, npe)) ||
+            (rc = s.alloc(&it.q_max, npe)) || (rc = s.alloc(&it.q_u, npe)) || (rc = s.alloc(&it.q_v, npe)) || (rc = s.alloc(&it.q_radius, npe)) ||
+            (rc = s.alloc(&it.cand, npe * kProjCap)) || (rc = s.alloc(&it.cand_n, npe)) || (rc = s.alloc(&it.state, npe)) || (rc = s.alloc(&it.mq, npe)) ||
+            (rc = s.alloc(&it.qf, Ne)) || (rc = s.alloc(&it.bin, npe)) || (rc = zeroed(&it.nm, (size_t)kFrMaxCams)) || (rc = s.alloc(&it.edge_feature, Ne)) ||
+            (rc = s.alloc(&it.point_of_feature, Ne)) || (rc = s.alloc(&it.feat_outlier, Ne))) return rc;
+        q.valid = it.q_valid; q.cam = it.q_cam; q.u = it.q_u; q.v = it.q_v; q.radius = it.q_radius; q.min_level = it.q_min; q.max_level = it.q_max;
+        it.edge_base = base; edge_off[(size_t)k] = base;
+        base += Ncap;
+    }
+    const TrackItem* d_items; const DevAsm* d_das; const int32_t* d_edge_off; const float* d_sig; const double* d_pose_in;
+    std::vector<double> poses_in((size_t)7 * F);
+    for (int k = 0; k < F; ++k) memcpy(&poses_in[(size_t)7 * k], frames[k].pose, sizeof(double) * 7);
+    double *d_xw, *d_obs, *d_w, *d_err, *d_out; int32_t *d_ecam, *d_cnt, *d_ninl; uint8_t *d_level, *d_outl;
+    if ((rc = s.upload(&d_items, items.data(), (size_t)F)) || (rc = s.upload(&d_das, das.data(), (size_t)F)) || (rc = s.upload(&d_edge_off, edge_off.data(), (size_t)F)) ||
+        (rc = s.upload(&d_sig, prm->inv_level_sigma2, (size_t)prm->n_levels)) || (rc = s.upload(&d_pose_in, poses_in.data(), poses_in.size())) ||
+        (rc = s.alloc(&d_xw, 3 * Etot)) || (rc = s.alloc(&d_obs, 2 * Etot)) || (rc = s.alloc(&d_w, Etot)) || (rc = s.alloc(&d_err, 2 * Etot)) ||
+        (rc = s.alloc(&d_out, (size_t)7 * F)) || (rc = s.alloc(&d_ecam, Etot)) || (rc = s.alloc(&d_cnt, (size_t)F)) || (rc = s.alloc(&d_ninl, (size_t)F)) ||
+        (rc = s.alloc(&d_level, Etot)) || (rc = s.alloc(&d_outl, Etot))) return rc;
+    hipStream_t st = s.st;                                          // (flushes the staged uploads)
+    {   // the features were produced on the caller's stream: this call's stream waits for it
+        hipEvent_t ev;
+        DCS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+        (void)hipEventDestroy(ev);
+        if (e != hipSuccess) { set_error("dcs_track_frame_device: cannot order behind the caller's stream: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
+    }
+    const int cells_max = max_cams * DCS_GRID_COLS * DCS_GRID_ROWS;
+    hipLaunchKernelGGL(k_dev_assemble, dim3((4 * max_cap + 255) / 256, F), dim3(256), 0, st, d_das);
+    hipLaunchKernelGGL(k_dev_grid, dim3(F), dim3(kGridT), sizeof(int) * (size_t)cells_max, st, d_das);
+    if (max_pts > 0) {
+        if (mode == 0) hipLaunchKernelGGL(k_track_frustum, dim3((max_pts + 255) / 256, F), dim3(256), 0, st, d_items, prm->viewing_cos_limit, prm->th);
+        else hipLaunchKernelGGL(k_track_mm_queries, dim3((max_pts + 255) / 256, F), dim3(256), 0, st, d_items, d_das, prm->th);
+        hipLaunchKernelGGL(k_track_collect, dim3(max_q4, F), dim3(256), 0, st, d_items);
+    }
+    if (mode == 0) hipLaunchKernelGGL(k_track_resolve, dim3(F), dim3(kResT), 0, st, d_items, prm->th_high, prm->nn_ratio);
+    else hipLaunchKernelGGL(k_track_resolve_cam, dim3(max_cams, F), dim3(kResT), 0, st, d_items, prm->th_high, check_orientation ? 1 : 0);
+    hipLaunchKernelGGL(k_track_edges, dim3(F), dim3(256), 0, st, d_items, d_sig, prm->n_levels, d_xw, d_obs, d_w, d_ecam, d_cnt);
+    DCS_CHECK_LAUNCH();
+    PoseOptDevice po{};
+    po.poses = d_pose_in; po.edge_off = d_edge_off; po.edge_cnt = d_cnt; po.xw = d_xw; po.obs = d_obs; po.w = d_w; po.cam = d_ecam;
+    po.huber = prm->huber_delta;
+    for (int i = 0; i < 4; ++i) { po.chi2_th[i] = prm->chi2_th[i]; po.its[i] = prm->its[i]; }
+    po.err = d_err; po.level = d_level; po.out_poses = d_out; po.outlier = d_outl; po.n_inliers = d_ninl; po.edge_chi2 = nullptr; po.n_iters = nullptr;
+    if ((rc = launch_pose_opt_device(po, prm->cams, prm->n_cams, F, max_cap, st))) return rc;
+    hipLaunchKernelGGL(k_track_finish, dim3(F), dim3(256), 0, st, d_items, (const int32_t*)d_cnt, (const uint8_t*)d_outl);
+    DCS_CHECK_LAUNCH();
+    std::vector<int32_t> nfeat((size_t)F * kFrMaxCams), nm((size_t)F * kFrMaxCams);
+    if ((rc = s.download_bytes(res->r.poses, d_out, sizeof(double) * 7 * F)) || (rc = s.download_bytes(res->r.n_inliers, d_ninl, sizeof(int32_t) * F)) ||
+        (rc = s.download_bytes(nfeat.data(), d_nfeat, sizeof(int32_t) * nfeat.size()))) return rc;
+    for (int k = 0; k < F; ++k) {
+        const TrackItem& it = items[(size_t)k];
+        if (it.n_points && (rc = s.download_bytes(res->r.match_of_point[k], it.mq, sizeof(int32_t) * it.n_points))) return rc;
+        if ((rc = s.download_bytes(res->r.point_of_feature[k], it.point_of_feature, sizeof(int32_t) * it.f.N)) ||
+            (rc = s.download_bytes(res->r.outlier[k], it.feat_outlier, (size_t)it.f.N))) return rc;
+        if ((rc = s.download_bytes(&nm[(size_t)k * kFrMaxCams], it.nm, sizeof(int32_t) * kFrMaxCams))) return rc;
+    }
+    if ((rc = s.finish())) return rc;
+    for (int k = 0; k < F; ++k) {
+        const int C = frames[k].features.n_cams;
+        for (int c = 0; c < C; ++c) res->n_features[(size_t)k * C + c] = nfeat[(size_t)k * kFrMaxCams + c];
+        int total = 0;
+        for (int c = 0; c < (mode == 1 ? C : 1); ++c) total += nm[(size_t)k * kFrMaxCams + c];
+        res->r.n_matches[k] = total;
+    }
+    return DCS_OK;
 }
 
 }  // extern "C"

@@ -703,3 +703,38 @@ def tracking_problem(n_frames=6, n_points=1500, n_features=1000, seed=17, th=1.0
     params = dict(viewing_cos_limit=0.5, th=float(th), th_high=100, nn_ratio=0.8, inv_level_sigma2=inv_sigma2, cams=cams,
                   huber_delta=float(np.float32(np.sqrt(5.991))), chi2_th=[float(np.float32(5.991))] * 4, its=[10, 10, 10, 10])
     return frames, params
+
+
+def motion_model_problem(n_frames=3, n_points=1200, n_features=900, seed=31, th=7.0, seen=0.85, lost=0.1):
+    """Input of Tracking::TrackWithMotionModel's search (src/Tracking.cc:1384-1427): tracking_problem's frames with nothing held yet
+    (mvpMapPoints is cleared, :1396), key-point angles, and per frame the LAST frame's features that hold a good map point as queries
+    (fr["mm"]: pos = GetWorldPos, desc = the map point's descriptor, q_cam = keypointToCam, q_octave / q_angle = the last key point), in the
+    last frame's feature order (camera-major). `seen` of this frame's map-born features were also seen by the last frame (octave -+ 1,
+    angle = this frame's + a common rotation + noise, a tenth of them arbitrary); `lost` adds map points this frame does not see."""
+    frames, prm = tracking_problem(n_frames=n_frames, n_points=n_points, n_features=n_features, seed=seed, pre_matched=0.0)
+    rng = np.random.default_rng(seed + 4099)
+    for fr in frames:
+        ft, src = fr["features"], fr["feature_source"]
+        N = len(src)
+        ft["kp_angle"] = rng.uniform(0, 360, N).astype(np.float32)
+        ft["taken"] = np.zeros(N, np.uint8); fr["has_point"] = np.zeros(N, np.uint8); fr["point_xw"] = np.zeros((N, 3), np.float32)
+        cam_of = (np.searchsorted(ft["cam_off"], np.arange(N), side="right") - 1).astype(np.int32)
+        born = np.nonzero(src >= 0)[0]
+        keep = born[rng.random(len(born)) < seen]
+        rot = float(rng.uniform(0, 30))
+        ang = (ft["kp_angle"][keep].astype(np.float64) + rot + rng.normal(0, 2.0, len(keep))) % 360.0
+        wild = rng.random(len(keep)) < 0.1
+        ang[wild] = rng.uniform(0, 360, int(wild.sum()))
+        pts = src[keep]
+        qc, qo = cam_of[keep], np.clip(ft["kp_octave"][keep] + rng.integers(-1, 2, len(keep)), 0, 7).astype(np.int32)
+        n_lost = int(lost * len(keep))
+        others = rng.choice(len(fr["points"]["pos"]), n_lost, replace=False) if n_lost else np.zeros(0, np.int64)
+        pts = np.concatenate([pts, others]); qc = np.concatenate([qc, rng.integers(0, 2, n_lost).astype(np.int32)])
+        qo = np.concatenate([qo, rng.integers(0, 8, n_lost).astype(np.int32)]); ang = np.concatenate([ang, rng.uniform(0, 360, n_lost)])
+        truth = np.concatenate([keep, np.full(n_lost, -1)])
+        order = np.lexsort((rng.random(len(pts)), qc))                  # the last frame's features: camera-major, arbitrary inside a camera
+        fr["mm"] = dict(pos=fr["points"]["pos"][pts][order].astype(np.float32), desc=fr["desc"][pts][order], q_cam=qc[order].astype(np.int32),
+                        q_octave=qo[order].astype(np.int32), q_angle=ang[order].astype(np.float32), truth_feature=truth[order])
+    prm = dict(prm)
+    prm["th"] = float(th); prm["nn_ratio"] = 0.0
+    return frames, prm

@@ -125,3 +125,117 @@ def test_track_local_map_rejects_more_cameras_than_intrinsics(pkg, synth):
     with pytest.raises(Exception) as ei:
         pkg.abi.PreparedTracking(frames, prm).track()
     assert "cameras" in str(ei.value)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# dcs_track_frame_device: the chain fed from the extractor's slots in HBM (frame assembly + the 64 x 48 grid on the device), both modes
+
+def _to_slots(ft, cap, first_slot=1, n_slots=None):
+    """a frame's features laid out like dcs_orb_extract_batch_device's outputs: dcs_keypoint[slot][cap], u8[slot][cap][32], int32[slot]"""
+    C_ = len(ft["cam_off"]) - 1
+    n_slots = n_slots or first_slot + C_ + 1
+    kp = np.zeros((n_slots, cap, 7), np.float32)
+    kp[..., 2] = 31.0
+    desc = np.zeros((n_slots, cap, 32), np.uint8)
+    n = np.zeros(n_slots, np.int32)
+    kpi = kp.view(np.int32)
+    for c in range(C_):
+        a, b = int(ft["cam_off"][c]), int(ft["cam_off"][c + 1])
+        m = b - a
+        assert m <= cap
+        kp[first_slot + c, :m, 0] = ft["kp_x"][a:b]; kp[first_slot + c, :m, 1] = ft["kp_y"][a:b]; kp[first_slot + c, :m, 3] = ft["kp_angle"][a:b]
+        kpi[first_slot + c, :m, 5] = ft["kp_octave"][a:b]; kpi[first_slot + c, :m, 6] = -1
+        kp[first_slot + c, m:, 0] = 1e6                      # stale slot contents behind the count must never be looked at
+        desc[first_slot + c, :m] = ft["desc"][a:b]; desc[first_slot + c, m:] = 0xA5
+        n[first_slot + c] = m
+    return kp, desc, n
+
+
+def _device_frames(frames, cap, mode):
+    import torch
+    out, keep = [], []
+    for fr in frames:
+        ft = fr["features"]
+        kp, desc, n = _to_slots(ft, cap)
+        d_kp, d_desc, d_n = torch.from_numpy(kp).cuda(), torch.from_numpy(desc).cuda(), torch.from_numpy(n).cuda()
+        keep += [d_kp, d_desc, d_n]
+        dev = dict(d_kp=d_kp.data_ptr(), d_desc=d_desc.data_ptr(), d_n=d_n.data_ptr(), cap=cap, first_slot=1, n_cams=len(ft["cam_off"]) - 1,
+                   min_x=ft["min_x"], min_y=ft["min_y"], grid_w_inv=ft["grid_w_inv"], grid_h_inv=ft["grid_h_inv"])
+        d = dict(dev=dev, view=fr["view"], pose=fr["pose"])
+        if mode == 0:
+            d.update(held=dict(taken=ft["taken"], has_point=fr["has_point"], point_xw=fr["point_xw"]), points=fr["points"], desc=fr["desc"])
+        else:
+            mm = fr["mm"]
+            d.update(held=None, points=dict(pos=mm["pos"]), desc=mm["desc"], q_cam=mm["q_cam"], q_octave=mm["q_octave"], q_angle=mm["q_angle"])
+        out.append(d)
+    torch.cuda.synchronize()
+    return out, keep
+
+
+def test_track_frame_device_mode0_equals_the_host_buffer_chain(pkg, synth):
+    """features taken from the extractor's slot layout in HBM, assembled and gridded on the device: bit for bit dcs_track_local_map"""
+    frames, prm = synth.tracking_problem(n_frames=3, n_points=1300, n_features=1000, seed=57)
+    _with_grid(pkg, frames)
+    ref = pkg.abi.PreparedTracking(frames, prm).track()
+    dfr, keep = _device_frames(frames, cap=700, mode=0)
+    got = pkg.abi.PreparedTrackingDevice(dfr, prm, mode=0).track()
+    for k, (a, b) in enumerate(zip(ref, got)):
+        ft = frames[k]["features"]
+        assert np.array_equal(b["n_features"], np.diff(ft["cam_off"])), k
+        assert np.array_equal(a["match_of_point"], b["match_of_point"]) and np.array_equal(a["point_of_feature"], b["point_of_feature"]), k
+        assert a["n_matches"] == b["n_matches"] and a["n_inliers"] == b["n_inliers"] and np.array_equal(a["outlier"], b["outlier"]), k
+        assert np.array_equal(a["pose"], b["pose"]), k
+
+
+def _oracle_motion_model(oracle, fr, prm, check_ori):
+    ft, mm = fr["features"], fr["mm"]
+    q = oracle.motion_model_queries(fr["view"], mm["pos"], mm["q_cam"], mm["q_octave"], prm["th"])
+    nq, N = len(mm["pos"]), int(ft["cam_off"][-1])
+    mq, qf, nm = np.full(nq, -1, np.int32), np.full(N, -1, np.int32), 0
+    for c in range(len(ft["cam_off"]) - 1):                 # SearchByProjection(Fcur, Flast, th) = one SearchByProjectionOnCam per camera, a histogram each
+        qc = dict(valid=(q["valid"] & (mm["q_cam"] == c)).astype(np.uint8), cam=mm["q_cam"], u=q["u"], v=q["v"], radius=q["radius"], min_level=q["min_level"],
+                  max_level=q["max_level"], desc=mm["desc"], angle=mm["q_angle"])
+        mq_c, qf_c, nm_c = oracle.search_by_projection(ft, qc, prm["th_high"], 0.0, check_ori)
+        sel = mm["q_cam"] == c
+        mq[sel] = mq_c[sel]; qf = np.maximum(qf, qf_c); nm += nm_c
+    feat = np.nonzero(qf >= 0)[0]
+    cam = (np.searchsorted(ft["cam_off"], feat, side="right") - 1).astype(np.int32)
+    prob = dict(poses=fr["pose"][None, :], edge_off=np.array([0, len(feat)], np.int32), xw=mm["pos"][qf[feat]].astype(np.float64),
+                obs=np.stack([ft["kp_x"][feat], ft["kp_y"][feat]], 1).astype(np.float64),
+                inv_sigma2=prm["inv_level_sigma2"][ft["kp_octave"][feat]].astype(np.float64), edge_cam=cam,
+                cams=[oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in prm["cams"]],
+                huber_delta=prm["huber_delta"], chi2_th=prm["chi2_th"], its=prm["its"])
+    po = oracle.pose_optimization(prob)
+    outl = np.zeros(N, np.uint8)
+    outl[feat] = po["outlier"][:len(feat)]
+    return dict(match_of_point=mq, point_of_feature=qf, n_matches=nm, pose=po["poses"][0], n_inliers=int(po["n_inliers"][0]), outlier=outl)
+
+
+@pytest.mark.parametrize("kw", [dict(n_frames=3, n_points=1200, n_features=900, seed=31, th=7.0, check_ori=True),
+                                dict(n_frames=2, n_points=2000, n_features=1500, seed=77, th=14.0, check_ori=True),
+                                dict(n_frames=2, n_points=600, n_features=500, seed=5, th=7.0, check_ori=False)])
+def test_track_frame_device_mode1_motion_model_vs_oracle(pkg, oracle, synth, kw):
+    """TrackWithMotionModel's search + optimisation (SearchByProjectionOnCam per camera with its rotation histogram, then PoseOptimization)
+    on device-resident features, against the oracle's stages composed: geometry -> per-camera ordered search -> optimiser"""
+    kw = dict(kw)
+    check = kw.pop("check_ori")
+    frames, prm = synth.motion_model_problem(**kw)
+    _with_grid(pkg, frames)
+    dfr, keep = _device_frames(frames, cap=1200, mode=1)
+    got = pkg.abi.PreparedTrackingDevice(dfr, prm, mode=1, check_orientation=check).track()
+    n_new = 0
+    for k, fr in enumerate(frames):
+        exp = _oracle_motion_model(oracle, fr, prm, check)
+        g = got[k]
+        assert np.array_equal(g["n_features"], np.diff(fr["features"]["cam_off"])), k
+        assert np.array_equal(g["match_of_point"], exp["match_of_point"]), k
+        assert np.array_equal(g["point_of_feature"], exp["point_of_feature"]), k
+        assert g["n_matches"] == exp["n_matches"] and g["n_inliers"] == exp["n_inliers"], (k, g["n_matches"], exp["n_matches"], g["n_inliers"], exp["n_inliers"])
+        assert np.array_equal(g["outlier"], exp["outlier"]), k
+        assert np.abs(g["pose"] - exp["pose"]).max() < 1e-9, (k, float(np.abs(g["pose"] - exp["pose"]).max()))
+        # the scene means something: most queries the last frame shared with this one find their feature
+        truth = fr["mm"]["truth_feature"]
+        hit = (exp["match_of_point"] == truth) & (truth >= 0)
+        assert hit.sum() > 0.5 * (truth >= 0).sum(), (k, int(hit.sum()), int((truth >= 0).sum()))
+        n_new += int(exp["n_matches"])
+    assert n_new > 100
