@@ -1311,6 +1311,78 @@ def main():
                                      "sample": "median of 10 frames, oracle -O3 single thread (same marshalling)"}
         out["per_frame_chain"] = chain
 
+    # ---- one dual frame from host images to the pose, the reference's steady state per frame (Frame ctor -> TrackWithMotionModel -> TrackLocalMap,
+    # src/Tracking.cc:1384-1427, 1617-1680): images up, extraction into slots in HBM, then dcs_track_frame_device twice -- the features never
+    # leave the device, the map side comes from the host both times. The map is fitted to what the extractor found (synth.scene_from_features).
+    if solo and not args.no_host_api and hasattr(pkg.abi.lib(), "dcs_track_frame_device"):
+        a_, b_ = synth.frame_pair(W, H, 0, 3)
+        ext2 = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_images=2)
+        cap2 = ext2.default_cap(H, W)
+        h_img = torch.from_numpy(np.stack([a_, b_])).pin_memory()
+        d_img = torch.empty(h_img.shape, dtype=torch.uint8, device="cuda")
+        d_kp2 = torch.zeros((2, cap2, 7), dtype=torch.float32, device="cuda"); d_desc2 = torch.zeros((2, cap2, 32), dtype=torch.uint8, device="cuda")
+        d_n2 = torch.zeros(2, dtype=torch.int32, device="cuda")
+        st2 = torch.cuda.current_stream().cuda_stream
+
+        def extract2():
+            d_img.copy_(h_img, non_blocking=True)
+            ext2.extract_batch_device(d_img, d_kp2, d_desc2, d_n2, cap2, stream=st2)
+        extract2(); torch.cuda.synchronize()
+        n2 = d_n2.cpu().numpy()
+        kp2 = d_kp2.cpu().numpy().reshape(2, cap2, 7).copy().view(pkg.abi.KEYPOINT).reshape(2, cap2)
+        de2 = d_desc2.cpu().numpy()
+        fs_, prm_s = synth.scene_from_features([kp2[c][:n2[c]] for c in (0, 1)], [de2[c][:n2[c]] for c in (0, 1)])
+        dev_ = dict(d_kp=d_kp2.data_ptr(), d_desc=d_desc2.data_ptr(), d_n=d_n2.data_ptr(), cap=cap2, first_slot=0, n_cams=2, **fs_["grid"])
+        mm_ = fs_["mm"]
+        prm_mm = dict(prm_s); prm_mm["th"] = 7.0; prm_mm["nn_ratio"] = 0.0
+        N2 = int(n2.sum())
+        held_ = dict(taken=np.zeros(N2, np.uint8), has_point=np.zeros(N2, np.uint8), point_xw=np.zeros((N2, 3), np.float32))
+        pts_lm = dict(fs_["points"]); pts_lm["candidate"] = np.ones(len(pts_lm["pos"]), np.uint8)
+        pt_mm = pkg.abi.PreparedTrackingDevice([dict(dev=dev_, view=fs_["view"], pose=fs_["pose"], held=None, points=dict(pos=mm_["pos"]), desc=mm_["desc"],
+                                                      q_cam=mm_["q_cam"], q_octave=mm_["q_octave"], q_angle=mm_["q_angle"])], prm_mm, mode=1, check_orientation=True, stream=st2)
+        pt_lm = pkg.abi.PreparedTrackingDevice([dict(dev=dev_, view=fs_["view"], pose=fs_["pose"], held=held_, points=pts_lm, desc=fs_["desc"])], prm_s, mode=0, stream=st2)
+        # the arrays the prepared call points at (updated in place between the two stages)
+        arrs = {id(x): x for x in pt_lm.keep}
+        tk_, hp_, px_, cd_ = held_["taken"], held_["has_point"], held_["point_xw"], pts_lm["candidate"]
+        assert all(id(x) in arrs for x in (tk_, hp_, px_, cd_)), "the prepared call copied an array the harness updates in place"
+
+        def glue(r1):                                        # TrackWithMotionModel's bookkeeping (Tracking.cc:1429-1448) + the candidate flags of SearchLocalPoints (:1625-1640)
+            pof = r1["point_of_feature"]
+            good = (pof >= 0) & (r1["outlier"] == 0)
+            tk_[:] = good; hp_[:] = good
+            px_[good] = mm_["pos"][pof[good]]
+            cd_[:] = 1; cd_[mm_["point"][pof[good]]] = 0
+
+        def whole():
+            extract2()
+            r1 = pt_mm.track()[0]
+            glue(r1)
+            return r1, pt_lm.track()[0]
+        r1_, r2_ = whole()
+        tot_ = {}
+
+        def stage(fn, reps=40, sync=False):
+            for _ in range(3):
+                fn()
+            ts_ = []
+            for _ in range(reps):
+                t0_ = time.perf_counter(); fn()
+                if sync:
+                    torch.cuda.synchronize()
+                ts_.append(time.perf_counter() - t0_)
+            return round(sorted(ts_)[reps // 2] * 1e3, 4)
+        tot_["ms_total"] = stage(whole)
+        tot_["ms_upload_extract_alone"] = stage(extract2, sync=True)
+        tot_["ms_motion_model_stage_alone"] = stage(lambda: pt_mm.track())
+        tot_["ms_local_map_stage_alone"] = stage(lambda: pt_lm.track())
+        out["per_frame_total"] = dict(workload="1 dual 640x480 frame: 2 page-locked host images up -> dcs_orb_extract_batch_device (slots in HBM) -> dcs_track_frame_device mode 1 "
+                                               "(TrackWithMotionModel: SearchByProjectionOnCam x 2 with rotation histograms + PoseOptimization) -> host bookkeeping -> "
+                                               "dcs_track_frame_device mode 0 (SearchLocalPoints + PoseOptimization); features stay on the device, map arrays from the host; "
+                                               "the local-map stage starts from the same pose guess (the harness does not rebuild the view matrices); median of 40",
+                                      features=int(N2), mm_queries=int(len(mm_["pos"])), mm_matches=int(r1_["n_matches"]), mm_inliers=int(r1_["n_inliers"]),
+                                      local_map_points=int(len(pts_lm["pos"])), lm_new_matches=int(r2_["n_matches"]), lm_inliers=int(r2_["n_inliers"]), **tot_)
+        ext2.close()
+
     # ---- distributed runs: the rank-path legs (configs[2] and configs[4] as an N-GPU run measures them), then the OTHER exchange path once
     # as a cross-check of the gathered slot arrays. RCCL has never run with more than one rank on the builder's side, so a watchdog prints
     # the line with whatever is complete if a collective does not come back.

@@ -162,6 +162,10 @@ int  dcs_orb_debug_quadtree_fallbacks(dcs_orb* h, int* n);
 /* which way the last dcs_orb_extract_batch went: *direct = 1 when the DMA read the caller's page-locked frames in place (0: packed into the
    library's staging), *graph_replayed = 1 when a 1-2 image call was replayed as the handle's executable graph (either may be NULL) */
 int  dcs_orb_debug_host_path(const dcs_orb* h, int* direct, int* graph_replayed);
+/* *fast_hw = 1: this handle's k_fast_cells launches use the two hardware-specific instruction forms (the zeroing ds_read_u8_d16_hi, the
+   v_cmpx append), which a one-wave probe verified on the handle's device when it was created; 0: the probe found the device behaving
+   differently (or DCS_FAST_HW_PROBE=fail asked for it) and the plain forms run -- same results. */
+int  dcs_orb_debug_fast_hw(const dcs_orb* h, int* fast_hw);
 /* per-stage time of the last TIMED extraction in microseconds (hipEvents on the streams the kernels ran on):
    resize chain, k_fast_cells, scan+gather, k_blur, quadtree, k_describe, whole call (7 floats).
    Which extractions are timed: calls of MORE than two images under timing mode 1 / 2 (dcs_orb_set_timing). A call of one or two images

@@ -23,10 +23,10 @@ SYMBOLS = [
     "dcs_last_error", "dcs_version", "dcs_device_count",
     "dcs_orb_create", "dcs_orb_destroy", "dcs_orb_tables", "dcs_orb_extract", "dcs_orb_extract_batch",
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
-    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_debug_host_path", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_orb_set_timing", "dcs_distribute_octree",
+    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_debug_host_path", "dcs_orb_debug_fast_hw", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_orb_set_timing", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_by_projection_kf", "dcs_search_in_window", "dcs_search_for_initialization",
-    "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_debug_linearize", "dcs_ba_timing", "dcs_track_local_map", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
+    "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_debug_linearize", "dcs_ba_timing", "dcs_track_local_map", "dcs_track_frame_device", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
     "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_host_alloc", "dcs_host_free", "dcs_streams_share_queue", "dcs_stream_create_apart", "dcs_ba_avoid_streams", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
@@ -110,6 +110,7 @@ def lib():
             "dcs_orb_debug_candidates": [vp, ci, ci, vp, ci, pci],
             "dcs_orb_debug_quadtree_fallbacks": [vp, pci],
             "dcs_orb_debug_host_path": [vp, pci, pci],
+            "dcs_orb_debug_fast_hw": [vp, pci],
             "dcs_debug_sincosf": [vp, ci, vp, vp],
             "dcs_orb_required_cap": [vp, ci, ci, pci],
             "dcs_orb_last_timing": [vp, vp],
@@ -130,6 +131,7 @@ def lib():
             "dcs_ba_debug_linearize": [C.POINTER(BaProblem), vp, vp, vp, vp, vp, vp, pci],
             "dcs_ba_timing": [ci, vp],
             "dcs_track_local_map": [ci, vp, vp, vp],
+            "dcs_track_frame_device": [ci, vp, vp, ci, ci, vp, vp],
             "dcs_stream_create_cu_range": [ci, ci, C.POINTER(vp)],
             "dcs_streams_share_queue": [vp, vp, pci],
             "dcs_stream_create_apart": [vp, ci, C.POINTER(vp), pci],
@@ -267,6 +269,12 @@ class ORBextractor:
         rc = lib().dcs_orb_extract_batch_device(self._h, d_images.data_ptr(), n, rows, cols or stride, stride, d_kp.data_ptr(),
                                                 d_desc.data_ptr(), cap, d_n.data_ptr(), stream)
         _check(rc, "dcs_orb_extract_batch_device")
+
+    def fast_hw(self):
+        """1: k_fast_cells runs its hardware-specific forms on this handle (the start-up probe passed), 0: the plain forms"""
+        v = C.c_int()
+        _check(lib().dcs_orb_debug_fast_hw(self._h, C.byref(v)), "dcs_orb_debug_fast_hw")
+        return v.value
 
     def host_path(self):
         """(direct, graph_replayed) of the last host-buffer call"""

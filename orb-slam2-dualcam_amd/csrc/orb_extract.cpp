@@ -109,6 +109,7 @@ struct dcs_orb {
     ResizeRects frame[kMaxLevels] = {};
     FastEmit femit[kMaxLevels] = {};               // frame rectangles + block counts per emitting level (pointers filled per call)
     bool emit_ok = false;
+    bool fast_hw = true;                           // k_fast_cells' hardware-specific forms passed the start-up probe on this device
     int emit_mode = -1;                            // DCS_ORB_EMIT when the handle is created: 0 = off, n > 0 = levels [0, n) emit whatever the batch; unset = all levels, from emit_min_pixels level-0 pixels per call
     double emit_min_pixels = 2.5e7;
     std::vector<CellDesc> h_cells;
@@ -514,7 +515,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
             es.has_f = timed_all;
             DCS_MARK(ev_f[0], s_fast);
             if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                        d_cell_count.p, fp_all, s_fast, 0, cells_early))) return rc;
+                                        d_cell_count.p, fp_all, s_fast, 0, cells_early, nullptr, fast_hw))) return rc;
             DCS_MARK(ev_f[1], s_fast);
             DCS_HIP(hipEventRecord(ev_fast_early, s_fast));
         }
@@ -557,14 +558,14 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
             FastEmit fe = femit[l];
             fe.dst = raw.lv[l + 1]; fe.cols = d_rtab.p + rtab[l + 1].xofs; fe.rows = d_erows.p + erows_off[l];
             if (c1 > c0 && (rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                                   d_cell_count.p, lf, stream, c0, c1 - c0, &fe))) return rc;
+                                                   d_cell_count.p, lf, stream, c0, c1 - c0, &fe, fast_hw))) return rc;
         }
         for (int l = E + 1; l < L; ++l)
             if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs, d_rtab.p + rtab[l].yofs, d_rtab.p + rtab[l].ya, n_images, stream))) return rc;
     }
     if (cells_early > 0) {
         if ((rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                    d_cell_count.p, fp_all, stream, cells_early, n_cells - cells_early))) return rc;
+                                    d_cell_count.p, fp_all, stream, cells_early, n_cells - cells_early, nullptr, fast_hw))) return rc;
     } else {
         // Launches by LDS footprint: a cell's workgroup (one wave) holds its ROI, score map and survivor list in LDS, sized for the
         // largest ROI of the LAUNCH, and that footprint decides how many cells a CU holds -- 5 104 B for the 38 x 38 ROIs of levels 0-3 of
@@ -618,7 +619,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
             for (int l = l0; l < l1; ++l) gf = merged(gf, lfp[l]);
             const int c0 = h_level_cell_begin[l0], c1 = h_level_cell_begin[l1];
             if (c1 > c0 && (rc = launch_fast_cells(raw, d_cells.p, n_cells, n_images, t.ini_th, t.min_th, d_slots.p, g.n_slots,
-                                                   d_cell_count.p, gf, stream, c0, c1 - c0))) return rc;
+                                                   d_cell_count.p, gf, stream, c0, c1 - c0, nullptr, fast_hw))) return rc;
             l0 = l1;
         }
     }
@@ -766,7 +767,22 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
     h->fused_mode = getenv("DCS_ORB_FUSED_BLUR") ? (atoi(getenv("DCS_ORB_FUSED_BLUR")) != 0) : -1;
     if (getenv("DCS_ORB_EMIT_MIN")) h->emit_min_pixels = atof(getenv("DCS_ORB_EMIT_MIN"));
-    h->emit_mode = getenv("DCS_ORB_EMIT") ? atoi(getenv("DCS_ORB_EMIT")) : -1;     // 0: round-4 resize chain; n > 0: the cells of levels [0, n) emit; unset: all of them
+    h->emit_mode = getenv("DCS_ORB_EMIT") ? atoi(getenv("DCS_ORB_EMIT")) : -1;
+    {   // the probe runs once per device and process; DCS_FAST_HW_PROBE=fail (read per handle: tests) makes this handle take the fallback
+        static std::mutex probe_m;
+        static int probed[64] = {0};                   // 0 = not yet, 1 = fast forms, 2 = plain forms
+        std::lock_guard<std::mutex> g(probe_m);
+        const int di = h->device >= 0 && h->device < 64 ? h->device : 0;
+        if (!probed[di]) {
+            bool ok = false;
+            char why[160] = "";
+            if ((rc = fast_hw_probe(&ok, why, sizeof why))) return rc;
+            probed[di] = ok ? 1 : 2;
+            if (!ok) fprintf(stderr, "[dcs] device %d: %s -- k_fast_cells runs its plain forms (byte loads, ballot append)\n", h->device, why);
+        }
+        const char* pe = getenv("DCS_FAST_HW_PROBE");
+        h->fast_hw = probed[di] == 1 && !(pe && strcmp(pe, "fail") == 0);
+    }     // 0: round-4 resize chain; n > 0: the cells of levels [0, n) emit; unset: all of them
     h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
     {   // staging threads of the host-buffer API (DCS_ORB_STAGING_THREADS, default 4; 1 = pack on the calling thread)
@@ -1172,6 +1188,13 @@ int dcs_orb_debug_quadtree_fallbacks(dcs_orb* h, int* n)
     std::vector<int32_t> f((size_t)h->last_tasks);
     DCS_HIP(hipMemcpy(f.data(), h->d_oct_flag.p, sizeof(int32_t) * f.size(), hipMemcpyDeviceToHost));
     for (int32_t v : f) *n += v != 0;
+    return DCS_OK;
+}
+
+int dcs_orb_debug_fast_hw(const dcs_orb* h, int* fast_hw)
+{
+    if (!h || !fast_hw) { set_error("dcs_orb_debug_fast_hw: null argument"); return DCS_ERR_INVALID; }
+    *fast_hw = h->fast_hw ? 1 : 0;
     return DCS_OK;
 }
 

@@ -94,7 +94,10 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
                       int32_t* d_cell_count, const FastFootprint& fp, hipStream_t s,
                       int cell0 = 0, int n_launch = -1 /* the launch covers cells [cell0, cell0 + n_launch); -1: to the end */,
-                      const FastEmit* emit = nullptr /* the cells of this launch (ONE level) also write their part of the next level */);
+                      const FastEmit* emit = nullptr /* the cells of this launch (ONE level) also write their part of the next level */,
+                      bool fast_hw = true /* the d16_hi score loads + the v_cmpx append (fast_hw_probe() said yes for this device) or the plain forms */);
+// one-wave probe of the two hardware behaviours the fast form relies on; *ok = both behave, else why[] says which one does not
+int fast_hw_probe(bool* ok, char* why, size_t why_len);
 
 // per (image, level): scan the cell counts, then gather the slots into one dense array for the whole
 // batch. d_lvl_off[n_images*nlevels + 1] = exclusive offsets (image-major, level-minor).

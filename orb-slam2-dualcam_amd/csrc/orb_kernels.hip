@@ -408,8 +408,17 @@ __device__ __forceinline__ int fast_score(const uint8_t* b, int th)
 // ordered append of `yx` to a 16-bit list in LDS for the lanes with (int16) value > (int16) limit; end_addr = LDS byte address behind the
 // last entry (scalar, advanced here). The compare is a v_cmpx: it writes EXEC itself, so the rank (v_mbcnt of exec), the store and the
 // count run on it directly and ONE s_mov restores the wave (exec_full). Returns the compare's mask.
+template <bool HW>      // HW = false: the same append through a plain ballot -- no EXEC games, no hand-placed wait states (the form the start-up probe falls back to)
 __device__ __forceinline__ unsigned long long fast_append_gt(unsigned value, unsigned limit, unsigned yx, unsigned& end_addr, unsigned long long exec_full)
 {
+    if (!HW) {
+        const bool pass = (short)(unsigned short)value > (short)(unsigned short)limit;
+        const unsigned long long mb = __builtin_amdgcn_ballot_w64(pass);
+        const unsigned at = end_addr + 2u * (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+        if (pass) asm volatile("ds_write_b16 %0, %1" : : "v"(at), "v"(yx) : "memory");
+        end_addr += 2u * (unsigned)__popcll(mb);
+        return mb;
+    }
     unsigned long long m;
     unsigned at, cnt;
     asm volatile("v_cmpx_gt_i16_e64 %[m], %[v], %[lim]\n\t"
@@ -728,7 +737,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             // the LDS allocation). No branch: the append is one LDS store under exec = the lanes that pass.
             // When dh is odd the upper half-wave's last row lies below the detection area: whatever it appends comes after
             // every valid entry and is cut off by the count below.
-            auto round = [&](const uint8_t* bb, unsigned yxr) { m = fast_append_gt(compass_margin(bb), th_lane, yxr, end_addr, exec_full); };
+            auto round = [&](const uint8_t* bb, unsigned yxr) { m = fast_append_gt<D16Z>(compass_margin(bb), th_lane, yxr, end_addr, exec_full); };
             // four rounds per trip: the later ones' LDS reads are immediate offsets of the first one's address, and the loop's
             // scalar bookkeeping is paid once per eight rows
             int yy = 0;
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
                 const uint16_t e = min(max(r2, r10), max(r6, r14)), f = max(min(r2, r10), min(r6, r14));
                 const int16_t up = (int16_t)(uint16_t)(e - v), down = (int16_t)(uint16_t)(v - f);
                 // in place: the write position is never ahead of an entry not read yet (a wave's LDS operations complete in order)
-                (void)fast_append_gt((unsigned)(uint16_t)max(up, down), lim, yx, end2, exec_full);
+                (void)fast_append_gt<D16Z>((unsigned)(uint16_t)max(up, down), lim, yx, end2, exec_full);
             }
             n_list = (int)((end2 - list_addr) >> 1);
         }
@@ -797,7 +806,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
                 asm("" : "+v"(o));                          // opaque: keeps the 17 ring offsets non-negative immediates of ONE base address
                 const int s = fast_score<P, D16Z>(px + o, th);
                 if (valid) sc[__mul24(y, sc_pitch) + x] = (uint8_t)s;
-                (void)fast_append_gt((unsigned)s, valid ? (unsigned)(th - 1) : 0x7fffu, yx, end3, exec_full);       // s >= th
+                (void)fast_append_gt<D16Z>((unsigned)s, valid ? (unsigned)(th - 1) : 0x7fffu, yx, end3, exec_full);       // s >= th
             }
             n_list = (int)((end3 - list_addr) >> 1);
         }
@@ -842,6 +851,63 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
     if (lane == 0) cell_count[(size_t)img * n_cells + cell] = min(base, (int)cd.cap);
 }
 
+// ---- start-up probe of the two hardware behaviours k_fast_cells<P, true, .> relies on and no manual guarantees (round-4 verdict, item 6):
+//  (1) ds_read_u8_d16_hi writes the byte to bits 16-23 AND clears the rest of the register (observed on gfx950 with SRAM ECC; the ISA text
+//      only promises the high half);  (2) the v_cmpx / s_nop / v_mbcnt(exec) sequence of fast_append_gt<true> ranks the passing lanes
+//      correctly with the shipped wait states. One wave runs the EXACT instruction forms on known data; the host compares with what the
+//      plain forms must give, and a device that answers differently runs k_fast_cells<P, false, .> (byte loads, ballot append) -- bit-exact
+//      either way, ~8 % slower.
+__global__ __launch_bounds__(64) void k_fast_hw_probe(unsigned* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sm[256];
+    __shared__ __attribute__((aligned(16))) uint16_t list[192];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) sm[i] = (uint8_t)(i * 37 + 11);
+    for (int i = lane; i < 192; i += 64) list[i] = 0xffff;
+    __syncthreads();
+    unsigned r = 0xdeadbeefu;                                  // garbage in BOTH halves before the load
+    asm volatile("ds_read_u8_d16_hi %0, %1 offset:5\n\ts_waitcnt lgkmcnt(0)" : "+v"(r) : "v"(lds_addr(sm) + (unsigned)lane) : "memory");
+    out[lane] = r;
+    unsigned end_addr = lds_addr(list);
+    unsigned long long exec_full;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(exec_full));
+    const unsigned long long m1 = fast_append_gt<true>((unsigned)(uint16_t)(short)(lane * 3 - 40), 17u, 0x100u + (unsigned)lane, end_addr, exec_full);
+    const unsigned long long m2 = fast_append_gt<true>((unsigned)(uint16_t)(short)((lane * 7) % 23 - 5), (lane & 1) ? 0x7fffu : 3u, 0x200u + (unsigned)lane, end_addr, exec_full);
+    __syncthreads();
+    for (int i = lane; i < 128; i += 64) out[64 + i] = list[i];
+    if (lane == 0) {
+        out[192] = (end_addr - lds_addr(list)) >> 1;
+        out[193] = (unsigned)m1; out[194] = (unsigned)(m1 >> 32); out[195] = (unsigned)m2; out[196] = (unsigned)(m2 >> 32);
+    }
+}
+int fast_hw_probe(bool* ok, char* why, size_t why_len)
+{
+    *ok = false;
+    unsigned* d = nullptr;
+    unsigned h[200] = {0};
+    DCS_HIP(hipMalloc(&d, sizeof(h)));
+    hipLaunchKernelGGL(k_fast_hw_probe, dim3(1), dim3(64), 0, nullptr, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) { set_error("fast_hw_probe: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
+    // what the plain forms give
+    for (int lane = 0; lane < 64; ++lane) {
+        const unsigned want = (unsigned)(uint8_t)((lane + 5) * 37 + 11) << 16;
+        if (h[lane] != want) { snprintf(why, why_len, "ds_read_u8_d16_hi: lane %d returned 0x%08x, the zeroing form gives 0x%08x", lane, h[lane], want); return DCS_OK; }
+    }
+    unsigned want_list[128];
+    int n = 0;
+    unsigned long long w1 = 0, w2 = 0;
+    for (int lane = 0; lane < 64; ++lane) if ((short)(lane * 3 - 40) > 17) { want_list[n++] = 0x100u + (unsigned)lane; w1 |= 1ull << lane; }
+    for (int lane = 0; lane < 64; ++lane) if ((short)((lane * 7) % 23 - 5) > (short)((lane & 1) ? 0x7fff : 3)) { want_list[n++] = 0x200u + (unsigned)lane; w2 |= 1ull << lane; }
+    if ((int)h[192] != n) { snprintf(why, why_len, "v_cmpx append: %u entries, expected %d", h[192], n); return DCS_OK; }
+    if ((((unsigned long long)h[194] << 32) | h[193]) != w1 || (((unsigned long long)h[196] << 32) | h[195]) != w2) { snprintf(why, why_len, "v_cmpx append: wrong compare mask"); return DCS_OK; }
+    for (int i = 0; i < n; ++i) if (h[64 + i] != want_list[i]) { snprintf(why, why_len, "v_cmpx append: entry %d is 0x%x, expected 0x%x", i, h[64 + i], want_list[i]); return DCS_OK; }
+    *ok = true;
+    return DCS_OK;
+}
+
 // LDS of one cell's workgroup for a launch with the given footprint (the host groups levels by this figure, orb_extract.cpp)
 static int fast_pitch(int max_rw)                                // exact rows, or shift (<= 7 / 15) + row
 {
@@ -868,7 +934,7 @@ int fast_cells_lds_bytes(const FastFootprint& f)
 
 int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cells, int n_images,
                       int ini_th, int min_th, dcs_candidate* d_slots, size_t slots_per_image,
-                      int32_t* d_cell_count, const FastFootprint& fp, hipStream_t s, int cell0, int n_launch, const FastEmit* emit)
+                      int32_t* d_cell_count, const FastFootprint& fp, hipStream_t s, int cell0, int n_launch, const FastEmit* emit, bool fast_hw)
 {
     if (n_launch < 0) n_launch = n_cells - cell0;             // cells [cell0, cell0 + n_launch) of the n_cells of the pyramid
     if (n_launch <= 0) return DCS_OK;
@@ -880,13 +946,9 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
     FastEmit em = emit ? *emit : FastEmit{};
     em.n_cell_blocks = n_launch;
     const dim3 grid(8, n_launch + (emit ? em.n_frame_blocks : 0), (n_images + 7) / 8);
-    // the d16_hi form of the score's ring loads needs the zeroing semantics of SRAM-ECC parts (every MI355X): asked once per process
-    static const bool d16z = [] {
-        hipDeviceProp_t pr;
-        int dev = 0;
-        if (getenv("DCS_FAST_D16Z") && atoi(getenv("DCS_FAST_D16Z")) == 0) return false;
-        return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && strstr(pr.gcnArchName, "sramecc+") != nullptr;
-    }();
+    // D16Z = fast_hw: BOTH hardware-specific forms of the kernel (the zeroing ds_read_u8_d16_hi of the score's ring loads, the v_cmpx append
+    // with its hand-placed wait states) or neither -- decided per device by fast_hw_probe() when the handle is created, not by an architecture string
+    const bool d16z = fast_hw;
 #define DCS_FAST_LAUNCH2(PP, ZZ, EE) hipLaunchKernelGGL((k_fast_cells<PP, ZZ, EE>), grid, dim3(64), shmem, s, levels, d_cells, n_cells, ini_th, min_th, d_slots, slots_per_image, \
                                                d_cell_count, map_bytes, n_images, sc_bytes, dbg_stop, cell0, em)
 #define DCS_FAST_LAUNCH(PP) do { if (d16z) { if (emit) DCS_FAST_LAUNCH2(PP, true, true); else DCS_FAST_LAUNCH2(PP, true, false); } \

@@ -738,3 +738,61 @@ def motion_model_problem(n_frames=3, n_points=1200, n_features=900, seed=31, th=
     prm = dict(prm)
     prm["th"] = float(th); prm["nn_ratio"] = 0.0
     return frames, prm
+
+
+def scene_from_features(kp_per_cam, desc_per_cam, seed=91, seen=0.8):
+    """A map that explains a dual frame's REAL extracted features (bench.py's per_frame_total leg: the chain is fed from the extractor's slots, so
+    the map has to fit what the extractor found): every key point of camera c is back-projected to a random depth with a true rig pose ->
+    a map point (position + noise, normal towards the camera, scale-invariance distances from the key point's octave, descriptor = the
+    feature's with a few flipped bits). Returns (frame pieces, params): view / pose of a perturbed pose guess, points (the local map of
+    TrackLocalMap), desc, mm (the last frame's share of them for TrackWithMotionModel: camera, octave, angle of the key point), cams."""
+    rng = np.random.default_rng(seed)
+    _, prm = tracking_problem(n_frames=1, n_points=30, n_features=20, seed=1)
+    cams, scale = prm["cams"], None
+    scale = np.ones(8, np.float32)
+    for i in range(1, 8):
+        scale[i] = np.float32(np.float64(scale[i - 1]) * np.float64(np.float32(1.2)))
+    T0, T1 = rig_extrinsics_f32()
+    ext = [T0, T1]
+    Tgt = np.eye(4, dtype=np.float32)
+    Tgt[:3, :3] = _rodrigues(rng.normal(0, 0.1, 3)).astype(np.float32); Tgt[:3, 3] = rng.normal(0, 0.3, 3).astype(np.float32)
+    Tg = np.eye(4, dtype=np.float32)
+    Tg[:3, :3] = (_rodrigues(rng.normal(0, 0.003, 3)) @ Tgt[:3, :3].astype(np.float64)).astype(np.float32)
+    Tg[:3, 3] = (Tgt[:3, 3] + rng.normal(0, 0.008, 3)).astype(np.float32)
+    min_x, max_x, min_y, max_y = np.float32(0.0), np.float32(640.0), np.float32(0.0), np.float32(480.0)
+    Rsw, tsw, Ow = [], [], []
+    for T in ext:
+        Tsw = (T.astype(np.float32) @ Tg).astype(np.float32)
+        R, t = Tsw[:3, :3], Tsw[:3, 3]
+        Rsw.append(R.reshape(9)); tsw.append(t); Ow.append((-(R.T @ t)).astype(np.float32))
+    view = dict(Rsw=np.array(Rsw, np.float32), tsw=np.array(tsw, np.float32), Ow=np.array(Ow, np.float32),
+                fx=np.array([c["fx"] for c in cams], np.float32), fy=np.array([c["fy"] for c in cams], np.float32),
+                cx=np.array([c["cx"] for c in cams], np.float32), cy=np.array([c["cy"] for c in cams], np.float32),
+                min_x=np.full(2, min_x, np.float32), max_x=np.full(2, max_x, np.float32), min_y=np.full(2, min_y, np.float32),
+                max_y=np.full(2, max_y, np.float32), log_scale_factor=np.float32(np.log(np.float32(1.2))), scale_factors=scale)
+    pos, nrm, mind, maxd, pdesc, qc, qo, qa = [], [], [], [], [], [], [], []
+    for c in (0, 1):
+        kp, de = kp_per_cam[c], desc_per_cam[c]
+        Tsw_gt = ext[c].astype(np.float64) @ Tgt.astype(np.float64)
+        Rg, tg = Tsw_gt[:3, :3], Tsw_gt[:3, 3]
+        centre = -(Rg.T @ tg)
+        d = rng.uniform(2.0, 8.0, len(kp))
+        lvl = kp["octave"].astype(np.int64)
+        pc = np.stack([(kp["x"].astype(np.float64) - cams[c]["cx"]) / cams[c]["fx"] * d, (kp["y"].astype(np.float64) - cams[c]["cy"]) / cams[c]["fy"] * d, d], 1)
+        pw = (pc - tg) @ Rg
+        pos.append((pw + rng.normal(0, 0.004, pw.shape)).astype(np.float32))
+        ray = pw - centre; ray /= np.linalg.norm(ray, axis=1, keepdims=True)
+        nrm.append(ray.astype(np.float32))
+        md = (d * scale[np.clip(lvl, 0, 7)] * 1.05).astype(np.float32)
+        maxd.append(md); mind.append((md / scale[7]).astype(np.float32))
+        pdesc.append(noisy_copy(de, flip_bits=8, seed=seed * 10 + c))
+        qc.append(np.full(len(kp), c, np.int32)); qo.append(kp["octave"].astype(np.int32)); qa.append(kp["angle"].astype(np.float32))
+    pos, nrm, mind, maxd, pdesc = np.concatenate(pos), np.concatenate(nrm), np.concatenate(mind), np.concatenate(maxd), np.concatenate(pdesc)
+    qc, qo, qa = np.concatenate(qc), np.concatenate(qo), np.concatenate(qa)
+    sel = np.nonzero(rng.random(len(pos)) < seen)[0]                   # ascending = the last frame's feature order (camera-major)
+    q = _quat_from_R(Tg[:3, :3].astype(np.float64))
+    frame = dict(view=view, pose=np.concatenate([Tg[:3, 3].astype(np.float64), q]), points=dict(pos=pos, normal=nrm, min_dist=mind, max_dist=maxd), desc=pdesc,
+                 mm=dict(pos=pos[sel], desc=pdesc[sel], q_cam=qc[sel], q_octave=qo[sel], q_angle=qa[sel], point=sel),
+                 grid=dict(min_x=np.full(2, min_x, np.float32), min_y=np.full(2, min_y, np.float32),
+                           grid_w_inv=np.full(2, np.float32(64) / np.float32(max_x - min_x), np.float32), grid_h_inv=np.full(2, np.float32(48) / np.float32(max_y - min_y), np.float32)))
+    return frame, prm

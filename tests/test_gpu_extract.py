@@ -518,3 +518,23 @@ def test_one_frame_calls_replayed_as_a_graph(pkg, oracle, synth, monkeypatch):
     o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
     ek, ed = o.extract(frames[2][0])
     assert ref[2][0][0].tobytes() == ek.tobytes() and np.array_equal(ref[2][1][0], ed)
+
+
+def test_fast_hw_probe_and_fallback_are_bit_exact(pkg, oracle, synth, monkeypatch):
+    """the start-up probe (k_fast_hw_probe) accepts this device's ds_read_u8_d16_hi / v_cmpx behaviour; a handle created while the probe is made
+    to fail (DCS_FAST_HW_PROBE=fail) runs k_fast_cells' plain forms -- byte loads, ballot append -- and returns the same bytes"""
+    imgs = list(synth.frame_pair(640, 480, 6, 1))
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)
+    hw = e.fast_hw()
+    kps, descs = e.extract_batch(imgs)
+    e.close()
+    monkeypatch.setenv("DCS_FAST_HW_PROBE", "fail")
+    e2 = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)
+    assert e2.fast_hw() == 0
+    kps2, descs2 = e2.extract_batch(imgs)
+    e2.close()
+    assert hw == 1, "the probe rejected this device: the fast forms are off everywhere (results are still exact)"
+    for i in range(2):
+        _same(kps[i], descs[i], kps2[i], descs2[i])
+        okp, odesc = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(imgs[i])
+        _same(kps2[i], descs2[i], okp, odesc)
