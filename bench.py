@@ -766,6 +766,14 @@ def main():
     for e_ in pipe.exts:
         e_.set_timing(2 if all_markers else 1)
     dt = pipe.run(args.steps, args.warmup, barrier)
+    # What did the timed region produce? The first four images of the LAST timed step and the three matches among them are copied out here
+    # (the clock has stopped) and held against the oracle in the CPU leg below: "parity_sample" on the line.
+    parity_snap = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and pipe.frames >= 2 and pipe.streams == 1:
+        kp_l, de_l, n_l = pipe.last_slots()
+        a0 = pipe.NP
+        parity_snap = dict(kp=kp_l[a0:a0 + 4].cpu().numpy(), desc=de_l[a0:a0 + 4].cpu().numpy(), n=n_l[a0:a0 + 4].cpu().numpy(),
+                           match=pipe.d_match[3:6].cpu().numpy(), nm=pipe.d_nm[3:6].cpu().numpy(), set=(pipe.step_no - 1) % pipe.n_sets)
     for e_ in pipe.exts:                  # kernel times: summed over the lanes (each lane launches its own kernels)
         sums, n_timed = e_.timing_totals()
         for k in stage_keys:
@@ -1085,6 +1093,27 @@ def main():
                                "sample": "%d dual %dx%d frames (extract x2 + 3 knn2/filter each) in %.1f s, oracle -O3 single thread pinned to core %d; host has %d cores"
                                          % (n_done, W, H, tc, core, os.cpu_count())}
         out["speedup_vs_cpu_1thread"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        if parity_snap is not None:
+            # images 0..3 of the last timed step = the two dual frames f = 0, 1 of its input set; matches 3..5 of the step = (cam0(1), cam1(1)),
+            # (cam0(1), cam0(0)), (cam1(1), cam1(0)) -- every operand among the four images
+            bad = []
+            r_ = parity_snap["set"]
+            imgs4 = list(pipe.host_frames[(0, r_ * pipe.n_unique)]) + list(pipe.host_frames[(0, r_ * pipe.n_unique + 1 % pipe.n_unique)])
+            ok_, od_ = [], []
+            for i4, im in enumerate(imgs4):
+                k4, d4 = o.extract(im, cap=cap)
+                ok_.append(k4); od_.append(d4)
+                n4 = int(parity_snap["n"][i4])
+                g_k = parity_snap["kp"][i4][:n4].copy().view(pkg.abi.KEYPOINT).reshape(-1)
+                if n4 != len(k4) or g_k.tobytes() != k4.tobytes() or not np.array_equal(parity_snap["desc"][i4][:n4], d4):
+                    bad.append("image %d" % i4)
+            for j4, (q4, t4) in enumerate(((2, 3), (2, 0), (3, 1))):
+                bi, bd, sd = O.knn2(od_[q4], od_[t4])
+                m4, nm4 = O.ratio_rot_filter(bi, bd, sd, 50, False, 0.75, True, ok_[q4]["angle"], ok_[t4]["angle"])
+                if nm4 != int(parity_snap["nm"][j4]) or not np.array_equal(parity_snap["match"][j4][:len(m4)], m4):
+                    bad.append("match %d" % j4)
+            out["parity_sample"] = "ok" if not bad else "MISMATCH: " + ", ".join(bad)
+            out["parity_sample_what"] = "4 images (key points + descriptors, byte for byte) and the 3 matches among them of the last timed step vs the oracle, after the clock stopped"
         # all host cores: one stream of dual frames per worker PROCESS (tools/cpu_workers.py; a separate process tree, no GPU runtime in it)
         n_proc = max(1, os.cpu_count() or 1)
         try:
