@@ -936,7 +936,7 @@ def main():
         dist_count = int(sum(nn[a] * nn[b] for a, b in pipe.pairs))
         tops = dist_count * 512 / us / 1e6            # 256 multiply-accumulates per Hamming distance on the matrix cores
         # which form the library launches (match_kernels.hip, launch_knn2_pairs_mfma): FP4 block-scaled when the slot fits its 14-bit index field
-        fp4 = cap <= 16383 and os.environ.get("DCS_KNN2_I8", "0") in ("", "0")
+        fp4 = cap <= 16383 and pkg.abi.get_option("DCS_KNN2_I8") == 0
         kname, peak, unit = ("k_knn2_pairs_fp4", FP4_MFMA_PEAK_TOPS, "TOPS (FP4 block-scaled MFMA 16x16x128)") if fp4 else ("k_knn2_pairs_mfma", I8_MFMA_PEAK_TOPS, "TOPS (i8 MFMA)")
         out["matcher"] = {"kernel": kname + " + k_filter_pairs", "solo_us_per_step": round(us, 2), "pairs": n_pairs,
                           "distances": dist_count, "achieved": round(tops, 1), "peak": peak, "unit": unit,

@@ -8,7 +8,7 @@ OBJ="${DCS_OBJ_DIR:-$PKG/build}"
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude ${DCS_EXTRA_FLAGS:-}"
-SRCS=(common.cpp comm.cpp orb_host.cpp octree.cpp orb_extract.cpp orb_kernels.hip octree_kernels.hip match_kernels.hip proj_kernels.hip bow_kernels.hip ba_solver.hip)
+SRCS=(common.cpp config.cpp comm.cpp orb_host.cpp octree.cpp orb_extract.cpp orb_kernels.hip octree_kernels.hip match_kernels.hip proj_kernels.hip bow_kernels.hip ba_solver.hip)
 OBJS=()
 pids=()
 for f in "${SRCS[@]}"; do

@@ -97,6 +97,17 @@ typedef struct dcs_candidate {
     int32_t score;
 } dcs_candidate;
 
+/* ------------------------------------------------------------------ options
+   The library's tuning and A/B switches (fused blur, FAST launch grouping, emitting FAST, quadtree mode, LDL^T variant, small-call graph, host
+   chunk size, ...: the table in csrc/config.h). An option is named like the environment variable that seeds it ("DCS_ORB_FUSED_BLUR"; the
+   prefix may be omitted) and holds an integer. The environment is read once per process; dcs_option_set changes the process-wide value from
+   then on: handle-less entry points (matcher, solver, tracking chain) read it per call, an extractor handle copies the extraction-pipeline
+   options when it is created -- set, create handle A, set again, create handle B gives two handles that differ. Unknown name: DCS_ERR_INVALID. */
+int  dcs_option_count(void);
+const char* dcs_option_name(int index);
+int  dcs_option_get(const char* name, int64_t* value);
+int  dcs_option_set(const char* name, int64_t value);
+
 /* ------------------------------------------------------------------ extraction */
 typedef struct dcs_orb dcs_orb;
 

@@ -20,7 +20,7 @@ DCS_OK, DCS_ERR_INVALID, DCS_ERR_CAPACITY, DCS_ERR_HIP, DCS_ERR_NO_DEVICE, DCS_E
 
 # every symbol include/dcs_abi.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
-    "dcs_last_error", "dcs_version", "dcs_device_count",
+    "dcs_last_error", "dcs_version", "dcs_device_count", "dcs_option_count", "dcs_option_name", "dcs_option_get", "dcs_option_set",
     "dcs_orb_create", "dcs_orb_destroy", "dcs_orb_tables", "dcs_orb_extract", "dcs_orb_extract_batch",
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_debug_host_path", "dcs_orb_debug_fast_hw", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_orb_set_timing", "dcs_distribute_octree",
@@ -193,6 +193,40 @@ def _c(a, dtype):
 def _check(rc, where):
     if rc != DCS_OK:
         raise DcsError(rc, where)
+
+
+def set_option(name, value):
+    """process-wide value of a library option (include/dcs_abi.h "options"): read per call by the handle-less entry points, copied by an
+    extractor handle when it is created"""
+    L = lib()
+    L.dcs_option_set.argtypes = [C.c_char_p, C.c_int64]
+    _check(L.dcs_option_set(name.encode(), int(value)), "dcs_option_set(%s)" % name)
+
+
+def get_option(name):
+    L = lib()
+    L.dcs_option_get.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
+    v = C.c_int64()
+    _check(L.dcs_option_get(name.encode(), C.byref(v)), "dcs_option_get(%s)" % name)
+    return v.value
+
+
+class options:
+    """with options(DCS_ORB_FUSED_BLUR=0, ...): the values inside the block, the previous ones restored afterwards"""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def device_count():

@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "common.h"
+#include "config.h"
 #include "track.h"
 
 namespace dcs {
@@ -2584,7 +2585,7 @@ static void ba_cu_range(int& first, int& count, bool set)
     if (set) { s_first = first; s_count = count; return; }
     if (s_count < 0) {
         s_first = 0; s_count = 0;
-        if (const char* e = getenv("DCS_BA_CUS")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && b > 0) { s_first = a; s_count = b; } }
+        if (opt(OPT_BA_CU_COUNT) > 0) { s_first = (int)opt(OPT_BA_CU_FIRST); s_count = (int)opt(OPT_BA_CU_COUNT); }      // (DCS_BA_CUS=first:count in the environment)
     }
     first = s_first; count = s_count;
 }
@@ -2701,7 +2702,7 @@ struct BaContext {
         hipError_t e = hipSuccess;
         if (count > 0) e = create_cu_range_stream(s, first, count);      // config C5: the solver keeps its own compute units (dcs_ba_set_cu_range)
         else {
-            static const int prio = getenv("DCS_BA_STREAM_PRIORITY") ? atoi(getenv("DCS_BA_STREAM_PRIORITY")) : 0;      // 1: highest, -1: lowest
+            const int prio = (int)opt(OPT_BA_STREAM_PRIORITY);      // 1: highest, -1: lowest
             int least = 0, greatest = 0;
             if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
                 e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio > 0 ? greatest : least);
@@ -2752,8 +2753,8 @@ struct Carver {
 // list chunks per k_schur workgroup by group size: 28 (16 waves) for 1-2 problems, DCS_BA_SCHUR_MID (8 waves) up to that many, else 7
 static int schur_chunks(int nb)
 {
-    static const int wide = getenv("DCS_BA_SCHUR_WIDE") ? atoi(getenv("DCS_BA_SCHUR_WIDE")) : 2;
-    static const int mid = getenv("DCS_BA_SCHUR_MID") ? atoi(getenv("DCS_BA_SCHUR_MID")) : 4;
+    const int wide = (int)opt(OPT_BA_SCHUR_WIDE);
+    const int mid = (int)opt(OPT_BA_SCHUR_MID);
     return nb <= wide ? 28 : nb <= mid ? 14 : 7;
 }
 static void* schur_fn(int c) { return c == 28 ? (void*)k_schur<28> : c == 14 ? (void*)k_schur<14> : (void*)k_schur<7>; }
@@ -2928,8 +2929,7 @@ thread_local const BaTap* tl_tap = nullptr;
 // bound on a frame's edges says one may exist). DCS_POSE_FAST=0: every frame to k_pose_opt (the round-4 kernel: A/B and tests).
 static int launch_pose_kernels(PoseArgs a, const DCams& cams, int n_frames, int max_edges_bound, hipStream_t st)
 {
-    const char* e = getenv("DCS_POSE_FAST");
-    const bool fast = !(e && atoi(e) == 0);
+    const bool fast = opt(OPT_POSE_FAST) != 0;
     a.fast_max = fast ? kPoseFastMax : -1;
     if (fast) hipLaunchKernelGGL(k_pose_opt2, dim3(n_frames), dim3(kPoT), 0, st, a, cams);
     if (!fast || max_edges_bound > kPoseFastMax) hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, st, a, cams);
@@ -2971,7 +2971,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     }
     int rc = ensure_device();
     if (rc) return rc;
-    const bool trace_t = getenv("DCS_BA_TRACE") != nullptr;
+    const bool trace_t = opt(OPT_BA_TRACE) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     const auto t_call0 = now();
@@ -3013,8 +3013,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             if (dup[i] >= 0) { set_error("problem %d: more than one edge between pose and point of edge %d", live[i], dup[i]); return DCS_ERR_INVALID; }
     }
     const double t_build = ms_since(t_call0);
-    const bool force_blocked = getenv("DCS_BA_FORCE_BLOCKED_LDLT") != nullptr;   // test hook: the n > 256 path at small n
-    const bool ldlt_valu = getenv("DCS_BA_LDLT_VALU") != nullptr;                // column-by-column VALU predecessor of k_ldlt_mfma
+    const bool force_blocked = opt(OPT_BA_FORCE_BLOCKED_LDLT) != 0;   // test hook: the n > 256 path at small n
+    const bool ldlt_valu = opt(OPT_BA_LDLT_VALU) != 0;                // column-by-column VALU predecessor of k_ldlt_mfma
 
     // ---- arena layout: [upload | zeroed | scratch | download]
     struct Regions { size_t upload_end, zero_begin, zero_end, dl_begin, dl_end; };
@@ -3026,7 +3026,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // Two groups by default: alone, 4 groups of 2 are as fast (18.8 k LM iterations/s for 8 C4 problems, 17.5 k with one group), but
     // next to a busy front end (config C5) four queues of short kernels lose against its long ones (9 k vs 16 k iterations/s).
     int G = NB >= 4 ? 2 : 1;
-    if (const char* e = getenv("DCS_BA_GROUPS")) G = std::max(1, std::min({atoi(e), (int)BaContext::kMaxGroups, NB}));
+    if (opt(OPT_BA_GROUPS) > 0) G = std::max(1, std::min({(int)opt(OPT_BA_GROUPS), (int)BaContext::kMaxGroups, NB}));
     if (ctx.timing) G = 1;
     int g_begin[BaContext::kMaxGroups + 1];
     for (int g = 0; g <= G; ++g) g_begin[g] = (int)((long long)NB * g / G);
@@ -3151,7 +3151,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         int max_nblk = 0, max_pairs = 0;
         for (int i = 0; i < NB; ++i) { max_nblk = std::max(max_nblk, hp[i].nblk); if (hp[i].np) max_pairs = std::max(max_pairs, hp[i].n_pairs); }
         if (max_pairs) {
-            static const bool side_env = !(getenv("DCS_BA_PAIRS_SIDE") && atoi(getenv("DCS_BA_PAIRS_SIDE")) == 0);
+            const bool side_env = opt(OPT_BA_PAIRS_SIDE) != 0;
             hipStream_t ps = st;
             if (side_env && !ctx.timing && !tl_tap) {
                 if (!ctx.dl) { const int rc_s = ctx.create_stream(&ctx.dl); if (rc_s) return rc_s; }
@@ -3204,7 +3204,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         bool any_mfma = false, any_valu = false, any_blocked = false, finished = false, fused_update = true;
         int max_n_mfma = 0;
     };
-    static const bool no_fused_update = getenv("DCS_BA_FUSED_UPDATE") && atoi(getenv("DCS_BA_FUSED_UPDATE")) == 0;   // A/B: the two launches
+    const bool no_fused_update = opt(OPT_BA_FUSED_UPDATE) == 0;   // A/B: the two launches
     std::vector<Group> groups((size_t)G);
     int max_steps = 0;
     for (int g = 0; g < G; ++g) {
@@ -3240,7 +3240,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // is not the bottleneck here (it feeds the queue two steps ahead and spends 80 % of a solve waiting) and the graph's kernel
     // nodes are dispatched no faster than stream launches. The graph is rebuilt per call: hipGraphExecKernelNodeSetParams did not
     // take new grid sizes reliably (a problem of another size then never finished).
-    static const bool use_graph_env = getenv("DCS_BA_GRAPH") && atoi(getenv("DCS_BA_GRAPH")) != 0;
+    const bool use_graph_env = opt(OPT_BA_GRAPH) != 0;
     std::vector<hipGraphExec_t> step_exec((size_t)G, nullptr);
     if (use_graph_env && !timing) {
         for (int g = 0; g < G; ++g) {
@@ -3345,7 +3345,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // of the download (75 us of a 2 ms C4 solve at two steps ahead). One step ahead (DCS_BA_LOOKAHEAD=1) measured +1 % for one C4 problem
     // and nothing for a batch; two stays the default because small problems (a step of 50 us) need the slack: enqueueing a step
     // costs the host 30 - 50 us per group.
-    static const int kLookahead = getenv("DCS_BA_LOOKAHEAD") ? std::max(1, atoi(getenv("DCS_BA_LOOKAHEAD"))) : 2;
+    const int kLookahead = std::max(1, (int)opt(OPT_BA_LOOKAHEAD));
     auto load_words = [&](const Group& gr, int& step_done, int& n_done) {
         const unsigned long long w = __atomic_load_n(reinterpret_cast<const unsigned long long*>(gr.words), __ATOMIC_ACQUIRE);   // {done : step}, one word
         step_done = (int)(unsigned)w;
@@ -3384,7 +3384,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // state > ST_RETRY before they write anything but the progress words. The results then come down on a stream of their own
     // instead of behind those 2 x 8 launches (~75 us of a 2 ms C4 solve). DCS_BA_DL_STREAM=0, or a batch that ran into max_steps,
     // takes the ordered path: the download behind everything on the solver's streams.
-    static const bool dl_own = !(getenv("DCS_BA_DL_STREAM") && atoi(getenv("DCS_BA_DL_STREAM")) == 0);
+    const bool dl_own = opt(OPT_BA_DL_STREAM) != 0;
     if (dl_own && n_finished == G) {
         if (!ctx.dl) { const int rc_s = ctx.create_stream(&ctx.dl); if (rc_s) return rc_s; }
         DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, ctx.dl));

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "config.h"
 
 namespace dcs {
 
@@ -501,10 +502,10 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2_pairs_fp4(
 static void launch_knn2_pairs_mfma(const uint8_t* desc, const int32_t* n_feat, int cap, const int32_t* pairs, int n_pairs, int32_t* best_idx,
                                    int32_t* best_d, int32_t* second_d, hipStream_t s)
 {
-    static const bool force_i8 = getenv("DCS_KNN2_I8") && atoi(getenv("DCS_KNN2_I8")) != 0;
+    const bool force_i8 = opt(OPT_KNN2_I8) != 0;
     // DCS_KNN2_LDS_PAD: extra dynamic LDS per workgroup = fewer matcher workgroups per CU (measurement aid: the matcher runs underneath the
     // next step's resize chain, whose waves then find fewer registers taken)
-    static const int lds_pad = getenv("DCS_KNN2_LDS_PAD") ? atoi(getenv("DCS_KNN2_LDS_PAD")) : 0;
+    const int lds_pad = (int)opt(OPT_KNN2_LDS_PAD);
     if (cap <= kFp4MaxCap && !force_i8)
         hipLaunchKernelGGL(k_knn2_pairs_fp4, dim3((cap + kKnn4Q - 1) / kKnn4Q, n_pairs), dim3(64 * kKnnWaves), (size_t)lds_pad, s, desc, n_feat, cap, pairs, best_idx, best_d, second_d);
     else
@@ -1020,7 +1021,7 @@ int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, c
     if (cap >= (1 << 22)) { set_error("cap %d exceeds the 2^22 descriptors of one knn2 problem (22-bit index field of the matrix-core key)", cap); return DCS_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     // d_match doubles as the best-index buffer: the filter reads best_idx[i] and writes match[i] in the same thread
-    static const bool knn_valu = getenv("DCS_KNN2_VALU") != nullptr;      // xor + popcount kernel instead of the i8 matrix-core one
+    const bool knn_valu = opt(OPT_KNN2_VALU) != 0;      // xor + popcount kernel instead of the i8 matrix-core one
     if (knn_valu) hipLaunchKernelGGL(k_knn2_pairs, dim3((cap + 127) / 128, n_pairs), dim3(256), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
     else launch_knn2_pairs_mfma(d_desc, d_n, cap, d_pairs, n_pairs, d_match, d_best_d, d_second_d, s);
     DCS_CHECK_LAUNCH();

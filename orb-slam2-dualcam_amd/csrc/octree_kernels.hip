@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "config.h"
 #include "orb_kernels.h"
 
 namespace dcs {
@@ -652,7 +653,7 @@ int launch_octree(const dcs_candidate* d_dense, const int32_t* d_lvl_off, const 
                   int n_tasks, int dense_cap, SelKp* d_sel, int32_t* d_lvl_cnt, int32_t* d_need_general, hipStream_t s)
 {
     if (n_tasks <= 0) return DCS_OK;
-    static const int force_general = getenv("DCS_OCTREE_FORCE_GENERAL") ? 1 : 0;      // test hook: exercise the sort-based kernel
+    const int force_general = opt(OPT_OCTREE_FORCE_GENERAL) != 0 ? 1 : 0;      // test hook: exercise the sort-based kernel
     int max_ini = 1;
     for (int l = 0; l < levels.nlevels; ++l)
         if (levels.lv[l].height > 0) max_ini = max(max_ini, (int)roundf((float)levels.lv[l].width / (float)levels.lv[l].height));

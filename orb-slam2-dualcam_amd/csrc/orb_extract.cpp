@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.h"
+#include "config.h"
 #include "orb_host.h"
 #include "orb_kernels.h"
 
@@ -109,6 +110,7 @@ struct dcs_orb {
     ResizeRects frame[kMaxLevels] = {};
     FastEmit femit[kMaxLevels] = {};               // frame rectangles + block counts per emitting level (pointers filled per call)
     bool emit_ok = false;
+    long long opt_dense_cap = 0;
     bool fast_hw = true;                           // k_fast_cells' hardware-specific forms passed the start-up probe on this device
     int emit_mode = -1;                            // DCS_ORB_EMIT when the handle is created: 0 = off, n > 0 = levels [0, n) emit whatever the batch; unset = all levels, from emit_min_pixels level-0 pixels per call
     double emit_min_pixels = 2.5e7;
@@ -410,7 +412,7 @@ int dcs_orb::configure(int rows, int cols)
     for (int l = 0; l < L; ++l) px += (size_t)g.lv[l].w * g.lv[l].h;
     dense_cap = std::min<size_t>((size_t)B * g.n_slots, (size_t)B * std::max<size_t>(px / 16, 4096));
     dense_cap = std::max<size_t>(dense_cap, 1);
-    if (const char* e = getenv("DCS_ORB_DENSE_CAP")) dense_cap = std::max<size_t>((size_t)atoll(e), 1);      // test hook: provoke the overflow path
+    if (opt_dense_cap > 0) dense_cap = (size_t)opt_dense_cap;      // test hook (option DCS_ORB_DENSE_CAP when the handle was created): provoke the overflow path
     if ((rc = d_dense.resize(dense_cap))) return rc;
     if ((rc = h_dense.resize(dense_cap))) return rc;
     oct = OctLevels();
@@ -476,7 +478,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     ++n_calls;
     // Stage timing (dcs_orb_timing_totals) brackets every stage with hipEvents; each record is a marker packet between two kernels and
     // costs 5 - 10 us of queue latency -- 45 us of a 220-us dual-frame call. Calls of one or two images (a frame per call) skip them (DCS_ORB_TIMING=1 keeps them).
-    static const bool timing_always = getenv("DCS_ORB_TIMING") && atoi(getenv("DCS_ORB_TIMING")) != 0;
+    const bool timing_always = opt(OPT_ORB_TIMING) != 0;
     const bool timed = timing_mode > 0 && (n_images > 2 || timing_always || no_overlap);
     const bool timed_all = timed && timing_mode >= 2;        // mode 1: only the two markers around FAST (the roofline kernel) are recorded
     es.all = timed_all; es.has_f = false; es.has_b = false;
@@ -531,7 +533,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // the blur no longer competes for the vector ALUs (800 -> 619 us) and the fused describe costs 455 instead of 388 us.
     // DCS_ORB_FUSED_BLUR=0 (read when the handle is created) selects the separate blur kernels (the debug / A-B path).
     last_blur_valid = !fused_blur;
-    static const bool blur_early = getenv("DCS_ORB_BLUR_LATE") == nullptr;
+    const bool blur_early = opt(OPT_ORB_BLUR_LATE) == 0;
     if (!fused_blur && !no_overlap && (rc = side_stream(s_aux, stream, s_fast))) return rc;
     hipStream_t sb = no_overlap ? stream : s_aux;
     auto blur_stage = [&]() -> int {
@@ -578,7 +580,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         // measured 558 us), plus a fixed 1.3 rounds per launch. Headline pyramid: [0-3] 32, [4-6] 29, [7] 24 = 525 us.
         // Small batches are latency-bound -- one launch there: 16 images of 1280 x 720 (config C5's step) run at 89 k kfeatures/s with
         // one launch against 80 k with three.
-        static const bool grouped_env = !(getenv("DCS_ORB_FAST_GROUPS") && atoi(getenv("DCS_ORB_FAST_GROUPS")) == 0);
+        const bool grouped_env = opt(OPT_ORB_FAST_GROUPS) != 0;
         const bool grouped = grouped_env && n_images >= 64;
         auto wg_per_cu = [](const FastFootprint& f) { return std::min(32, 163840 / std::max(fast_cells_lds_bytes(f), 1)); };
         FastFootprint lfp[kMaxLevels];
@@ -762,12 +764,14 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     DCS_HIP(hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming));
     DCS_HIP(hipEventCreateWithFlags(&h->ev_lvl, hipEventDisableTiming));
     DCS_HIP(hipEventCreateWithFlags(&h->ev_fast_early, hipEventDisableTiming));
-    h->fast_split = getenv("DCS_ORB_FAST_SPLIT") ? atoi(getenv("DCS_ORB_FAST_SPLIT")) : 0;
+    // options are copied when the handle is created (config.h): dcs_option_set between two dcs_orb_create calls gives two handles that differ
+    h->fast_split = (int)opt(OPT_ORB_FAST_SPLIT);
     for (auto& es : h->ring) { for (auto& e : es.t) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.b) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.f) DCS_HIP(hipEventCreate(&e)); }
-    h->no_overlap = getenv("DCS_ORB_NO_OVERLAP") != nullptr;
-    h->fused_mode = getenv("DCS_ORB_FUSED_BLUR") ? (atoi(getenv("DCS_ORB_FUSED_BLUR")) != 0) : -1;
-    if (getenv("DCS_ORB_EMIT_MIN")) h->emit_min_pixels = atof(getenv("DCS_ORB_EMIT_MIN"));
-    h->emit_mode = getenv("DCS_ORB_EMIT") ? atoi(getenv("DCS_ORB_EMIT")) : -1;
+    h->no_overlap = opt(OPT_ORB_NO_OVERLAP) != 0;
+    h->fused_mode = opt(OPT_ORB_FUSED_BLUR) < 0 ? -1 : (opt(OPT_ORB_FUSED_BLUR) != 0);
+    h->emit_min_pixels = (double)opt(OPT_ORB_EMIT_MIN);
+    h->opt_dense_cap = opt(OPT_ORB_DENSE_CAP);
+    h->emit_mode = (int)opt(OPT_ORB_EMIT);
     {   // the probe runs once per device and process; DCS_FAST_HW_PROBE=fail (read per handle: tests) makes this handle take the fallback
         static std::mutex probe_m;
         static int probed[64] = {0};                   // 0 = not yet, 1 = fast forms, 2 = plain forms
@@ -780,14 +784,12 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
             probed[di] = ok ? 1 : 2;
             if (!ok) fprintf(stderr, "[dcs] device %d: %s -- k_fast_cells runs its plain forms (byte loads, ballot append)\n", h->device, why);
         }
-        const char* pe = getenv("DCS_FAST_HW_PROBE");
-        h->fast_hw = probed[di] == 1 && !(pe && strcmp(pe, "fail") == 0);
+        h->fast_hw = probed[di] == 1 && opt(OPT_FAST_HW_PROBE_FAIL) == 0;
     }     // 0: round-4 resize chain; n > 0: the cells of levels [0, n) emit; unset: all of them
     h->device_octree = p->host_threads <= 0;          // host_threads > 0 selects the host quadtree with that many workers
     h->pool.reset(new Pool(std::max(0, p->host_threads - 1)));
     {   // staging threads of the host-buffer API (DCS_ORB_STAGING_THREADS, default 4; 1 = pack on the calling thread)
-        const char* e = getenv("DCS_ORB_STAGING_THREADS");
-        const int nt = e ? atoi(e) : (h->prm.max_images >= 64 ? 8 : 4);    // 8 packers keep up with PCIe 5 (~45 GB/s of image bytes) on large batches
+        const int nt = opt(OPT_ORB_STAGING_THREADS) > 0 ? (int)opt(OPT_ORB_STAGING_THREADS) : (h->prm.max_images >= 64 ? 8 : 4);    // 8 packers keep up with PCIe 5 (~45 GB/s of image bytes) on large batches
         if (nt > 1 && h->prm.max_images > 2) h->stage_pool.reset(new Pool(nt - 1));
     }
     *out = h.release();
@@ -874,7 +876,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     // stride as the pitch of level 0. Two pointer queries, remembered per handle; pageable images take the packing path below. DCS_ORB_HOST_DIRECT=0 disables.
     bool direct = false;
     size_t spacing = (size_t)rows * stride;
-    if (stride % 4 == 0 && (reinterpret_cast<uintptr_t>(images[0]) & 3) == 0 && !(getenv("DCS_ORB_HOST_DIRECT") && atoi(getenv("DCS_ORB_HOST_DIRECT")) == 0)) {
+    if (stride % 4 == 0 && (reinterpret_cast<uintptr_t>(images[0]) & 3) == 0 && opt(OPT_ORB_HOST_DIRECT) != 0) {
         bool even = true;
         if (n_images > 1) {
             // equally spaced AND close: the spacing decides the size of the device staging and of the one DMA that reads the whole range,
@@ -922,7 +924,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     if ((!direct && (rc = h->h_img.resize(img_bytes * n_images))) || (rc = h->d_stage.resize(img_bytes * n_images))) return rc;
     const uint8_t* const up_src = direct ? images[0] : h->h_img.p;
     auto up_bytes = [&](int i0, int m) { return img_bytes * (size_t)(m - 1) + (i0 + m == n_images ? last_img_bytes : img_bytes); };
-    const bool nopack = direct || getenv("DCS_ORB_HOST_NOPACK") != nullptr;   // (the variable alone: measurement aid, the pinned staging keeps the previous call's images)
+    const bool nopack = direct || opt(OPT_ORB_HOST_NOPACK) != 0;   // (the variable alone: measurement aid, the pinned staging keeps the previous call's images)
     auto pack = [&](int i) {
         if (nopack) return;
         uint8_t* dst = h->h_img.p + i * img_bytes;
@@ -941,8 +943,8 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     // chunks on a twin handle with its own scratch and stream, underneath the even ones) was measured and changes nothing -- 4.24 / 4.75 /
     // 4.65 ms with two lanes against 5.13 / 4.72 / 4.68 with one: what the call waits for after the last image is packed (2.1 of
     // 4.3 ms) is the image DMA, 157 MB at an effective ~45 GB/s next to the packing threads' traffic, then one chunk's kernels, download and scatter.
-    const char* chunk_s = getenv("DCS_ORB_HOST_CHUNK");
-    const int chunk_env = chunk_s ? atoi(chunk_s) : std::min(96, n_images / 2);
+    const bool chunk_s = opt(OPT_ORB_HOST_CHUNK) >= 0;                      // set explicitly (read per call)
+    const int chunk_env = chunk_s ? (int)opt(OPT_ORB_HOST_CHUNK) : std::min(96, n_images / 2);
     if (h->device_octree && chunk_env > 0 && n_images >= 2 * chunk_env && (chunk_s || n_images >= 128)) {
         const int C = chunk_env;
         const size_t slots = (size_t)n_images * cap;
@@ -963,7 +965,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
         }
         const int NC = (int)c_begin.size() - 1;
         while (h->ev_chunk.size() < (size_t)3 * NC) { hipEvent_t e; DCS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_chunk.push_back(e); }
-        const bool trace = getenv("DCS_ORB_HOST_TRACE") != nullptr;           // stderr: host time per stage of this call
+        const bool trace = opt(OPT_ORB_HOST_TRACE) != 0;           // stderr: host time per stage of this call
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         const auto t_call = now();
@@ -1067,9 +1069,8 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
         // between them. The launches of such a call are the same every time (same buffers, same shapes), so from the third call of a shape on
         // they are replayed as one executable graph (captured from the very code below; any failure to capture switches the handle back to
         // plain launches). DCS_ORB_SMALL_GRAPH=0 / 1 forces it off / on.
-        const char* graph_s = getenv("DCS_ORB_SMALL_GRAPH");                 // read per call (tests switch it)
-        const int graph_env = graph_s ? atoi(graph_s) : -1;
-        static const bool timing_always = getenv("DCS_ORB_TIMING") && atoi(getenv("DCS_ORB_TIMING")) != 0;   // stage markers even on small calls: no graph (the events would become graph nodes)
+        const int graph_env = (int)opt(OPT_ORB_SMALL_GRAPH);                 // read per call (tests switch it)
+        const bool timing_always = opt(OPT_ORB_TIMING) != 0;   // stage markers even on small calls: no graph (the events would become graph nodes)
         const bool graph_ok = (graph_env < 0 ? kSmallGraphDefault : graph_env != 0) && n_images <= 2 && !h->no_overlap && !timing_always && !h->small_graph_broken;
         const dcs_orb::SmallGraphKey key{h->d_stage.p, h->d_out.p, h->h_out.p, img_bytes, total, n_images, rows, cols, pitch_s, cap, h->config_generation};
         bool replayed = false;

@@ -15,6 +15,7 @@
 #include <cfloat>
 
 #include "common.h"
+#include "config.h"
 
 namespace dcs {
 
@@ -915,7 +916,7 @@ static int fast_pitch(int max_rw)                                // exact rows, 
     // the 640 x 480 pyramid: 28 instead of 24 cells per CU, -3 us per 512 images); 40-byte rows for everything narrower would lift levels
     // 4-6 into the 32-per-CU class of levels 0-3 (one launch less), but seven dword loads per lane instead of five 8-byte ones cost more
     // than that gives back: FAST 530 vs 503 us. DCS_FAST_EXACT: bit 0 = P 40, bit 1 = P 44 (default 2).
-    static const int exact = getenv("DCS_FAST_EXACT") ? atoi(getenv("DCS_FAST_EXACT")) : 2;
+    const int exact = (int)opt(OPT_FAST_EXACT);
     if ((exact & 1) && max_rw <= 40) return 40;
     if ((exact & 2) && max_rw > 40 && max_rw <= 44) return 44;
     return max_rw + 7 <= 48 ? 48 : max_rw + 15 <= 64 ? 64 : 128;
@@ -942,7 +943,7 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
     const int map_bytes = ((fp.max_rh * P) + 15) & ~15;
     const int sc_bytes = (fp.sc_bytes + 15) & ~15;
     const size_t shmem = (size_t)fast_cells_lds_bytes(fp);
-    static const int dbg_stop = getenv("DCS_FAST_STOP") ? atoi(getenv("DCS_FAST_STOP")) : 0;      // only read by -DDCS_FAST_SECTIONS builds
+    const int dbg_stop = (int)opt(OPT_FAST_STOP);      // only read by -DDCS_FAST_SECTIONS builds
     FastEmit em = emit ? *emit : FastEmit{};
     em.n_cell_blocks = n_launch;
     const dim3 grid(8, n_launch + (emit ? em.n_frame_blocks : 0), (n_images + 7) / 8);
@@ -1123,7 +1124,7 @@ int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, i
                    int32_t* d_cell_off, int32_t* d_lvl_total, int32_t* d_lvl_off, dcs_candidate* d_dense,
                    size_t dense_cap, hipStream_t s)
 {
-    static const bool small_on = !(getenv("DCS_ORB_COMPACT_SMALL") && atoi(getenv("DCS_ORB_COMPACT_SMALL")) == 0);
+    const bool small_on = opt(OPT_ORB_COMPACT_SMALL) != 0;
     const long long n_entries = (long long)n_images * n_cells;
     if (small_on && n_cells > 0 && n_entries <= kCompactSmallThreads * kCompactSmallRun && (n_entries + 1) * sizeof(int) <= 64 * 1024) {
         const int n_wg = (int)std::min<long long>(64, (n_entries + 127) / 128);
@@ -1507,8 +1508,7 @@ int launch_blur(const LevelSet& src, const LevelSet& dst, int n_images, hipStrea
 {
     // folded form (k_blur_fold): every level >= 16 pixels wide (one reflection bounce, the three border classes distinct) and 32-bit
     // per-lane offsets (a level's images span < 4 GB); DCS_BLUR_FOLD=0 keeps the round-2 pair k_blur + k_blur_edge_cols
-    const char* fold_env = getenv("DCS_BLUR_FOLD");                 // read per launch: the blur is not on the default pipeline's path
-    bool fold = !(fold_env && atoi(fold_env) == 0) && n_images > 0;
+    bool fold = opt(OPT_BLUR_FOLD) != 0 && n_images > 0;            // read per launch: the blur is not on the default pipeline's path
     int fold_blocks = 0;
     for (int l = 0; l < src.nlevels && fold; ++l) {
         const LevelView& a = src.lv[l];
@@ -2026,7 +2026,7 @@ int launch_describe(const LevelSet& raw, const LevelSet& blurred, const Describe
                     uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s, const int32_t* d_dense_total, int dense_cap, bool fused)
 {
     const int gx = max_per_image > 0 ? (max_per_image + kDescKp - 1) / kDescKp : 1;
-    static const size_t lds_pad = getenv("DCS_DESC_LDS_PAD") ? (size_t)atoi(getenv("DCS_DESC_LDS_PAD")) : 0;      // measurement aid: extra LDS per workgroup = fewer of them per CU
+    const size_t lds_pad = (size_t)std::max<long long>(opt(OPT_DESC_LDS_PAD), 0);      // measurement aid: extra LDS per workgroup = fewer of them per CU
     if (fused) hipLaunchKernelGGL(k_describe<true>, dim3(gx * n_images), dim3(64 * kDescWaves), lds_pad, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
                                   d_desc, cap, d_n_out, n_images, gx, d_dense_total, dense_cap);
     else hipLaunchKernelGGL(k_describe<false>, dim3(gx * n_images), dim3(64 * kDescWaves), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,

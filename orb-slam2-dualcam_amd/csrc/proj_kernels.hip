@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.h"
+#include "config.h"
 #include "track.h"
 
 namespace dcs {
@@ -984,7 +985,7 @@ static int search_by_projection_impl(const dcs_proj_frame* fr, const dcs_proj_qu
         (rc = s.alloc(&d_qf, (size_t)N)) || (rc = s.alloc(&d_bin, (size_t)nq)) || (rc = s.alloc(&d_nm, 1)) || (rc = s.upload(&d_taken, fr->taken, (size_t)N))) return rc;
     hipLaunchKernelGGL(k_proj_collect, dim3((nq + 3) / 4), dim3(256), 0, s.st, f, q, d_cand, d_cn);
     DCS_CHECK_LAUNCH();
-    static const bool serial = getenv("DCS_PROJ_SERIAL") != nullptr;     // one-wave resolver (reference order, step by step)
+    const bool serial = opt(OPT_PROJ_SERIAL) != 0;     // one-wave resolver (reference order, step by step)
     if (N <= kResMaxN && !serial) {
         uint8_t* d_state;
         if ((rc = s.alloc(&d_state, (size_t)nq))) return rc;

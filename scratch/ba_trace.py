@@ -16,7 +16,7 @@ def batch(preps):
     rc = pkg.abi.lib().dcs_ba_local_batch(n, C.cast(pbs, C.c_void_p), None, C.cast(ress, C.c_void_p))
     assert rc == 0
 for g in (os.environ.get("BA_GROUP_LIST", "2").split(",")):
-    os.environ["DCS_BA_GROUPS"] = g
+    pkg.abi.set_option("DCS_BA_GROUPS", int(g))
     print("groups", g, file=sys.stderr)
     for _ in range(5):
         batch(preps8)

@@ -14,7 +14,7 @@ ptrs = (C.c_void_p * B)(*[f.ctypes.data for f in hf.frames])
 call = lambda: pkg.abi.lib().dcs_orb_extract_batch(ext._h, C.cast(ptrs, C.c_void_p), B, H, W, hf.stride, kp.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap, n_out.ctypes.data_as(C.c_void_p))
 for rnd in range(2):
     for chunk in (96, 64, 128, 170, 48, 256):
-        os.environ["DCS_ORB_HOST_CHUNK"] = str(chunk)
+        pkg.abi.set_option("DCS_ORB_HOST_CHUNK", chunk)
         for _ in range(3): assert call() == 0
         ts = []
         for _ in range(15):

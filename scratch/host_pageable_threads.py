@@ -8,7 +8,7 @@ pairs = [synth.frame_pair(W, H, 0, f) for f in range(8)]
 imgs = [np.ascontiguousarray(pairs[(i // 2) % 8][i % 2]).copy() for i in range(B)]
 for rnd in range(2):
     for nt in (8, 16, 32, 12, 4):
-        os.environ["DCS_ORB_STAGING_THREADS"] = str(nt)
+        pkg.abi.set_option("DCS_ORB_STAGING_THREADS", nt)
         ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=B); ext.set_timing(0)
         cap = ext.default_cap()
         kp = np.zeros((B, cap), pkg.abi.KEYPOINT); desc = np.zeros((B, cap, 32), np.uint8); n_out = np.zeros(B, np.int32)

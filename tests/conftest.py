@@ -53,3 +53,19 @@ def gpu_available():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture
+def opts(pkg):
+    """opts(name, value): set a library option (include/dcs_abi.h "options") for the rest of the test; the previous values come back afterwards.
+    Options replaced the environment switches of rounds 1-4: they are read per call (matcher, solver, tracking) or when an extractor handle
+    is created, so one process can exercise every path -- no child processes."""
+    old = {}
+
+    def set_(name, value):
+        if name not in old:
+            old[name] = pkg.abi.get_option(name)
+        pkg.abi.set_option(name, int(value))
+    yield set_
+    for k, v in old.items():
+        pkg.abi.set_option(k, v)

@@ -242,13 +242,13 @@ def test_search_by_bow_greedy_vs_oracle(pkg, oracle, synth):
     assert np.array_equal(got_m, exp_m) and got_n == exp_n and exp_n > 40
 
 
-def test_ba_blocked_mfma_ldlt_fallback(pkg, oracle, synth, monkeypatch):
+def test_ba_blocked_mfma_ldlt_fallback(pkg, oracle, synth, opts):
     """n > 256 (or the test hook) uses the multi-launch blocked LDL^T whose trailing update runs on
     v_mfma_f64_16x16x4_f64; both solvers must agree with the oracle."""
     pb = synth.ba_problem(n_poses=12, n_fixed=3, n_points=150, obs_per_point=6, seed=7)
-    monkeypatch.setenv("DCS_BA_FORCE_BLOCKED_LDLT", "1")
+    opts("DCS_BA_FORCE_BLOCKED_LDLT", 1)
     _compare(pkg.Optimizer.LocalBundleAdjustment(pb), _oracle_run(oracle, pb), pb)
-    monkeypatch.delenv("DCS_BA_FORCE_BLOCKED_LDLT")
+    opts("DCS_BA_FORCE_BLOCKED_LDLT", 0)
     big = synth.ba_problem(n_poses=60, n_fixed=4, n_points=800, obs_per_point=8, seed=13)      # 55 free poses -> n = 330 > 256
     _compare(pkg.Optimizer.LocalBundleAdjustment(big), _oracle_run(oracle, big), big)
 

@@ -12,15 +12,15 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=["separate blur kernels", "blur fused into k_describe", "fused + early FAST of levels 0-1",
                                       "fused + resize chain (FAST cells do not emit the next level)"])
-def pipeline_mode(request, monkeypatch):
-    """Every test of this file runs with every pipeline variant (DCS_ORB_FUSED_BLUR / DCS_ORB_FAST_SPLIT are read when an extractor
+def pipeline_mode(request, opts):
+    """Every test of this file runs with every pipeline variant (the options DCS_ORB_FUSED_BLUR / DCS_ORB_FAST_SPLIT / DCS_ORB_EMIT are copied when an extractor
     handle is created): the library picks the blur variant per call from the pyramid pixels per feature and the batch size, so small
     test batches would only ever see the fused one; the early FAST launch (two k_fast_cells launches on two streams) is opt-in."""
-    monkeypatch.setenv("DCS_ORB_FUSED_BLUR", "0" if request.param.startswith("separate") else "1")
-    monkeypatch.setenv("DCS_ORB_FAST_SPLIT", "2" if "early" in request.param else "0")
+    opts("DCS_ORB_FUSED_BLUR", 0 if request.param.startswith("separate") else 1)
+    opts("DCS_ORB_FAST_SPLIT", int("2" if "early" in request.param else "0"))
     # round 5: by default the FAST cells of level l write level l + 1 (k_fast_cells<EMIT>) -- whenever the blur is fused and no early FAST launch
     # is asked for, i.e. in the second variant; the fourth keeps the fused describe on the round-4 resize chain
-    monkeypatch.setenv("DCS_ORB_EMIT", "0" if "resize chain" in request.param else "15")     # n > 0: the cells of levels [0, n) emit, whatever the batch size
+    opts("DCS_ORB_EMIT", int("0" if "resize chain" in request.param else "15"))     # n > 0: the cells of levels [0, n) emit, whatever the batch size
 
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -208,8 +208,7 @@ def test_deep_quadtree_leaves_the_histogram_fast_path(pkg, oracle, synth):
     e.close()
     e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=1)
     e(synth.frame_pair(640, 480, 0, 0)[0])
-    if not os.environ.get("DCS_OCTREE_FORCE_GENERAL"):
-        assert e.quadtree_fallbacks() == 0
+    assert e.quadtree_fallbacks() == 0
     e.close()
 
 
@@ -267,58 +266,39 @@ def test_device_api_unaligned_pointer_and_stride(pkg, oracle, synth, lead, strid
     e.close()
 
 
-def test_general_quadtree_kernel_alone(tmp_path):
-    """DCS_OCTREE_FORCE_GENERAL=1 sends every (image, level) task to the sort-based kernel (the switch is read once per
-    process, hence the subprocess); the result must equal the oracle's as well."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "from conftest import load_pkg\n"
-        "import oracle\n"
-        "pkg = load_pkg(); oracle.build(); oracle.lib()\n"
-        "imgs = list(pkg.synth.frame_pair(640, 480, 4, 1))\n"
-        "e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)\n"
-        "kps, descs = e.extract_batch(imgs)\n"
-        "assert e.quadtree_fallbacks() == 16\n"
-        "for i in range(2):\n"
-        "    okp, od = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(imgs[i])\n"
-        "    assert kps[i].tobytes() == okp.tobytes() and np.array_equal(descs[i], od)\n"
-        "print('general-ok')\n" % (root, os.path.join(root, "tests")))
-    env = dict(os.environ, DCS_OCTREE_FORCE_GENERAL="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "general-ok" in r.stdout, r.stdout + r.stderr
+def test_general_quadtree_kernel_alone(pkg, oracle, synth, opts):
+    """option DCS_OCTREE_FORCE_GENERAL = 1 sends every (image, level) task to the sort-based kernel (read per call); the result must
+    equal the oracle's as well."""
+    opts("DCS_OCTREE_FORCE_GENERAL", 1)
+    imgs = list(synth.frame_pair(640, 480, 4, 1))
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)
+    kps, descs = e.extract_batch(imgs)
+    assert e.quadtree_fallbacks() == 16
+    for i in range(2):
+        okp, od = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(imgs[i])
+        assert kps[i].tobytes() == okp.tobytes() and np.array_equal(descs[i], od)
+    e.close()
 
 
-def test_candidate_buffer_overflow_is_reported_in_band(tmp_path):
+def test_candidate_buffer_overflow_is_reported_in_band(pkg, synth, opts):
     """The asynchronous device API cannot return an error after the fact: when the FAST candidates of a batch exceed the
-    handle's dense buffer (provoked here with the DCS_ORB_DENSE_CAP test hook, read at handle creation, hence the subprocess)
+    handle's dense buffer (provoked here with the option DCS_ORB_DENSE_CAP, copied when the handle is created)
     every count of the call is DCS_ERR_CAPACITY (-2) instead of a number of keypoints, and the host-buffer API fails."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "from conftest import load_pkg\n"
-        "pkg = load_pkg()\n"
-        "imgs = list(pkg.synth.frame_pair(640, 480, 4, 1))\n"
-        "e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)\n"
-        "cap = e.default_cap()\n"
-        "d_img = torch.from_numpy(np.stack(imgs)).cuda()\n"
-        "d_kp = torch.zeros((2, cap, 7), dtype=torch.float32, device='cuda'); d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device='cuda')\n"
-        "d_n = torch.full((2,), 7, dtype=torch.int32, device='cuda')\n"
-        "e.extract_batch_device(d_img, d_kp, d_desc, d_n, cap, stream=torch.cuda.current_stream().cuda_stream)\n"
-        "torch.cuda.synchronize()\n"
-        "assert d_n.tolist() == [-2, -2], d_n.tolist()\n"
-        "try:\n"
-        "    e.extract_batch(imgs)\n"
-        "    raise SystemExit('host API did not fail')\n"
-        "except pkg.DcsError as ex:\n"
-        "    assert ex.rc == -2, ex.rc\n"
-        "print('overflow reported')\n"
-    ) % os.path.join(root, "tests")
-    env = dict(os.environ, DCS_ORB_DENSE_CAP="3000")
-    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "overflow reported" in p.stdout, p.stdout + p.stderr
+    import torch
+    opts("DCS_ORB_DENSE_CAP", 3000)
+    imgs = list(synth.frame_pair(640, 480, 4, 1))
+    e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)
+    cap = e.default_cap()
+    d_img = torch.from_numpy(np.stack(imgs)).cuda()
+    d_kp = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda"); d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.full((2,), 7, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_img, d_kp, d_desc, d_n, cap, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert d_n.tolist() == [-2, -2], d_n.tolist()
+    with pytest.raises(pkg.DcsError) as ei:
+        e.extract_batch(imgs)
+    assert ei.value.rc == -2
+    e.close()
 
 
 def test_gpu_sincosf_equals_libm(pkg, oracle):
@@ -332,9 +312,9 @@ def test_gpu_sincosf_equals_libm(pkg, oracle):
     assert np.array_equal(gc.view(np.uint32), hc.view(np.uint32)) and np.array_equal(gs.view(np.uint32), hs.view(np.uint32))
 
 
-def test_fused_blur_describe_keeps_the_blurred_debug_level(pkg, oracle, synth, monkeypatch):
+def test_fused_blur_describe_keeps_the_blurred_debug_level(pkg, oracle, synth, opts):
     """With the fused describe no blur kernel runs in the product path: the blurred debug level is made on demand and is still the oracle's."""
-    monkeypatch.setenv("DCS_ORB_FUSED_BLUR", "1")
+    opts("DCS_ORB_FUSED_BLUR", int("1"))
     imgs = list(synth.frame_pair(640, 480, 2, 1)) + [np.random.default_rng(5).integers(0, 256, (480, 640), dtype=np.uint8)]
     e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=3)
     kps, descs = e.extract_batch(imgs)
@@ -347,11 +327,11 @@ def test_fused_blur_describe_keeps_the_blurred_debug_level(pkg, oracle, synth, m
 
 
 @pytest.mark.parametrize("fold", ["1", "0"])
-def test_blurred_levels_every_width_class(pkg, oracle, monkeypatch, fold):
+def test_blurred_levels_every_width_class(pkg, oracle, opts, fold):
     """cv::GaussianBlur 7x7 (ORBextractor.cc:1085-1086) on all 8 levels for level-0 widths 400..407: every w mod 4 class of the border
     dwords (BORDER_REFLECT_101 assembled in registers), through the folded kernel (k_blur_fold, DCS_BLUR_FOLD=1, the default) and
     through the round-2 pair k_blur + k_blur_edge_cols (=0)."""
-    monkeypatch.setenv("DCS_BLUR_FOLD", fold)
+    opts("DCS_BLUR_FOLD", int(fold))
     rng = np.random.default_rng(11)
     for w in range(400, 408):
         h = 300 + (w & 3)
@@ -366,7 +346,7 @@ def test_blurred_levels_every_width_class(pkg, oracle, monkeypatch, fold):
         e.close()
 
 
-def test_host_batch_pipeline_equals_one_shot(pkg, oracle, synth, monkeypatch):
+def test_host_batch_pipeline_equals_one_shot(pkg, oracle, synth, opts):
     """dcs_orb_extract_batch on a large host batch runs as a pipeline of image chunks (upload || kernels || download + scatter,
     csrc/orb_extract.cpp); DCS_ORB_HOST_CHUNK=0 selects the one-shot path. Same bytes either way, and the oracle's for sampled images;
     a ragged last chunk is covered."""
@@ -379,7 +359,7 @@ def test_host_batch_pipeline_equals_one_shot(pkg, oracle, synth, monkeypatch):
         imgs.append(np.ascontiguousarray(a[y0:y0 + H, x0:x0 + W]))
     outs = []
     for chunk in ("16", "0"):
-        monkeypatch.setenv("DCS_ORB_HOST_CHUNK", chunk)
+        opts("DCS_ORB_HOST_CHUNK", int(chunk))
         ext = pkg.ORBextractor(300, 1.2, 8, 20, 7, max_images=75)
         outs.append(ext.extract_batch(imgs))
         ext.close()
@@ -393,7 +373,7 @@ def test_host_batch_pipeline_equals_one_shot(pkg, oracle, synth, monkeypatch):
 
 
 @pytest.mark.parametrize("W", [320, 322])
-def test_page_locked_frames_are_read_in_place(pkg, oracle, synth, monkeypatch, W):
+def test_page_locked_frames_are_read_in_place(pkg, oracle, synth, opts, W):
     """Frames in page-locked memory (dcs_host_alloc) at equal spacing and a 4-byte aligned stride go up without the staging copy
     (csrc/orb_extract.cpp: `direct`) -- one dual frame per call, a one-shot batch and the chunked pipeline; same bytes as pageable
     arrays of the same pixels (DCS_ORB_HOST_DIRECT=0: the packing path on the very same pointers) and the oracle's. W = 322: the
@@ -411,9 +391,9 @@ def test_page_locked_frames_are_read_in_place(pkg, oracle, synth, monkeypatch, W
     ext = pkg.ORBextractor(300, 1.2, 8, 20, 7, max_images=40)
     ref = ext.extract_batch(imgs)                                             # pageable copies: the packing path
     for chunk, n in (("0", 2), ("0", 40), ("8", 40)):
-        monkeypatch.setenv("DCS_ORB_HOST_CHUNK", chunk)
+        opts("DCS_ORB_HOST_CHUNK", int(chunk))
         for direct in ("1", "0"):
-            monkeypatch.setenv("DCS_ORB_HOST_DIRECT", direct)
+            opts("DCS_ORB_HOST_DIRECT", int(direct))
             kp, d = ext.extract_batch(hf.frames[:n], stride=hf.stride)
             for i in range(n):
                 assert kp[i].tobytes() == ref[0][i].tobytes() and np.array_equal(d[i], ref[1][i]), (chunk, n, direct, i)
@@ -430,7 +410,7 @@ def test_page_locked_frames_are_read_in_place(pkg, oracle, synth, monkeypatch, W
     hf.close()
 
 
-def test_separately_pinned_frames_are_not_read_as_one_range(pkg, synth, monkeypatch):
+def test_separately_pinned_frames_are_not_read_as_one_range(pkg, synth, opts):
     """A left and a right frame that were pinned SEPARATELY (two dcs_host_alloc blocks, two hipHostRegister'd cv::Mats) are 'equally spaced'
     by construction, but the memory between them belongs to neither: the in-place path (one DMA over the whole range) is only taken when
     the range lies inside ONE page-locked allocation, anything else is packed. Same features either way."""
@@ -441,7 +421,7 @@ def test_separately_pinned_frames_are_not_read_as_one_range(pkg, synth, monkeypa
     pad = pkg.abi.HostFrames(1, 7 * H, W)                                # (keeps the allocator from handing out two adjacent blocks)
     for dst, src in ((one.frames[0], a), (one.frames[1], b), (left.frames[0], a), (right.frames[0], b)):
         dst[:] = src[100:100 + H, 150:150 + W]
-    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "0")
+    opts("DCS_ORB_SMALL_GRAPH", int("0"))
     ext = pkg.ORBextractor(400, 1.2, 8, 20, 7, max_images=2)
     ref = ext.extract_batch([one.frames[0].copy(), one.frames[1].copy()])
     assert ext.host_path()[0] == 0                                        # pageable copies: packed
@@ -460,19 +440,19 @@ def test_separately_pinned_frames_are_not_read_as_one_range(pkg, synth, monkeypa
         hf.close()
 
 
-def test_small_call_graph_is_dropped_when_the_handle_is_reconfigured(pkg, synth, monkeypatch):
+def test_small_call_graph_is_dropped_when_the_handle_is_reconfigured(pkg, synth, opts):
     """The executable graph of a 1-2 image call holds the addresses of the handle's internal buffers; a call of ANOTHER shape through the
     _device entry point rebuilds them. The next host call of the first shape must not replay the old graph: it is captured
     anew and every call returns the features of its own frames."""
     import torch
-    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "1")
+    opts("DCS_ORB_SMALL_GRAPH", int("1"))
     frames = [synth.frame_pair(640, 480, 3, f) for f in range(4)]
     small = [[np.ascontiguousarray(im[60:300, 80:400]) for im in fp] for fp in frames]
-    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "0")
+    opts("DCS_ORB_SMALL_GRAPH", int("0"))
     r = pkg.ORBextractor(500, 1.2, 8, 20, 7, max_images=2)
     ref = [r.extract_batch(s_) for s_ in small]
     r.close()
-    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "1")
+    opts("DCS_ORB_SMALL_GRAPH", int("1"))
     e = pkg.ORBextractor(500, 1.2, 8, 20, 7, max_images=2)
     for i in range(4):
         kp, d = e.extract_batch(small[i])
@@ -494,16 +474,16 @@ def test_small_call_graph_is_dropped_when_the_handle_is_reconfigured(pkg, synth,
     e.close()
 
 
-def test_one_frame_calls_replayed_as_a_graph(pkg, oracle, synth, monkeypatch):
+def test_one_frame_calls_replayed_as_a_graph(pkg, oracle, synth, opts):
     """A handle that is called with one or two host images again and again (Frame::ExtractORB, src/Frame.cc:141-149) replays the call's
     launches as one executable graph from the third call of a shape on (DCS_ORB_SMALL_GRAPH=1): every call still returns the features
     of ITS images -- different frames every call, compared with a fresh handle without the graph and with the oracle."""
     frames = [synth.frame_pair(640, 480, 1, f) for f in range(7)]
-    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "0")
+    opts("DCS_ORB_SMALL_GRAPH", int("0"))
     ref_ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)
     ref = [ref_ext.extract_batch(list(fp)) for fp in frames]
     ref_ext.close()
-    monkeypatch.setenv("DCS_ORB_SMALL_GRAPH", "1")
+    opts("DCS_ORB_SMALL_GRAPH", int("1"))
     e = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)
     for rep in range(2):
         for i, fp in enumerate(frames):
@@ -520,7 +500,7 @@ def test_one_frame_calls_replayed_as_a_graph(pkg, oracle, synth, monkeypatch):
     assert ref[2][0][0].tobytes() == ek.tobytes() and np.array_equal(ref[2][1][0], ed)
 
 
-def test_fast_hw_probe_and_fallback_are_bit_exact(pkg, oracle, synth, monkeypatch):
+def test_fast_hw_probe_and_fallback_are_bit_exact(pkg, oracle, synth, opts):
     """the start-up probe (k_fast_hw_probe) accepts this device's ds_read_u8_d16_hi / v_cmpx behaviour; a handle created while the probe is made
     to fail (DCS_FAST_HW_PROBE=fail) runs k_fast_cells' plain forms -- byte loads, ballot append -- and returns the same bytes"""
     imgs = list(synth.frame_pair(640, 480, 6, 1))
@@ -528,7 +508,7 @@ def test_fast_hw_probe_and_fallback_are_bit_exact(pkg, oracle, synth, monkeypatc
     hw = e.fast_hw()
     kps, descs = e.extract_batch(imgs)
     e.close()
-    monkeypatch.setenv("DCS_FAST_HW_PROBE", "fail")
+    opts("DCS_FAST_HW_PROBE_FAIL", 1)
     e2 = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_images=2)
     assert e2.fast_hw() == 0
     kps2, descs2 = e2.extract_batch(imgs)

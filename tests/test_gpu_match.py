@@ -21,24 +21,23 @@ def test_knn2_random(pkg, oracle, synth, nq, nt):
     _eq3(pkg.ORBmatcher.knn2(q, t), oracle.knn2(q, t))
 
 
-def test_knn2_index_field_boundary_and_i8_form(pkg, oracle, synth):
+def test_knn2_index_field_boundary_and_i8_form(pkg, oracle, synth, opts):
     """the FP4 matrix-core kernel keeps a 14-bit train index inside its float keys: 16 383 descriptors per slot is its largest problem,
-    anything above runs the i8 form (22-bit index); the i8 form on the ordinary sizes (DCS_KNN2_I8=1, read once per process) in a child"""
+    anything above runs the i8 form (22-bit index); the i8 form on the ordinary sizes (option DCS_KNN2_I8 = 1) gives the same arrays"""
     q = synth.random_descriptors(300, seed=11)
     for nt in (16383, 16384, 16500):
         t = synth.random_descriptors(nt, seed=12)
         t[nt - 1] = q[5]; t[nt - 2] = q[5]                       # the best match sits in the last rows, with a tie
         _eq3(pkg.ORBmatcher.knn2(q, t), oracle.knn2(q, t))
-    import subprocess, sys
-    script = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); import __graft_entry__ as e; pkg = e.load_package(); s = pkg.synth; h = hashlib.sha1()\n"
-              "for nq, nt in ((1000, 1000), (2000, 2037), (65, 255), (257, 4000)):\n"
-              "    for a in pkg.ORBmatcher.knn2(s.random_descriptors(nq, seed=7), s.random_descriptors(nt, seed=8)): h.update(np.ascontiguousarray(a).tobytes())\n"
-              "print('DIGEST', h.hexdigest())") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import hashlib
     digests = []
-    for i8 in ("0", "1"):
-        p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, DCS_KNN2_I8=i8), capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
-        digests.append([l for l in p.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    for i8 in (0, 1):                                            # option DCS_KNN2_I8, read per call
+        opts("DCS_KNN2_I8", i8)
+        h = hashlib.sha1()
+        for nq, nt in ((1000, 1000), (2000, 2037), (65, 255), (257, 4000)):
+            for a in pkg.ORBmatcher.knn2(synth.random_descriptors(nq, seed=7), synth.random_descriptors(nt, seed=8)):
+                h.update(np.ascontiguousarray(a).tobytes())
+        digests.append(h.hexdigest())
     assert digests[0] == digests[1]
 
 
