@@ -818,14 +818,24 @@ def main():
         K = args.steps
         LN = n_lanes                                 # every extraction kernel is launched once per lane per step
         n_img_l = n_img / LN
+        # Round 5: with the emitting FAST (k_fast_cells<EMIT>, the default for batches like this one) the cells of level l write level l + 1 --
+        # SURVEY.md 8(d)'s pyramid row (levels read + levels written) and its FAST row (every level read) are ONE stage, bracketed by the FAST
+        # markers; its algorithmic bytes are the sum of the two rows restricted to the levels that were emitted. The resize chain's entry then
+        # covers the levels it still produced (none by default).
+        E_lv = ext.emit_levels()
+        pyr_fused = (sum(px[:E_lv]) + sum(px[1:E_lv + 1])) if E_lv else 0
+        pyr_chain = (sum(px[E_lv:-1]) + sum(px[E_lv + 1:])) if E_lv < len(px) - 1 else 0
+        fast_key = "k_fast_cells+pyramid" if E_lv else "k_fast_cells"
         algo = {                                     # algorithmic bytes per LAUNCH x images per launch
-            "k_resize(x7)": ((sum_px - px7) + sum_17) * n_img_l,
-            "k_fast_cells": sum_px * n_img_l,
+            "k_resize(x%d)" % (len(px) - 1 - E_lv): pyr_chain * n_img_l,
+            fast_key: (sum_px + pyr_fused) * n_img_l,
             "k_blur": 2 * sum_px * n_img_l,
             "k_describe": int((749 + 512 + 60) * n_avg * n_img_l),
         }
-        dur = {"k_resize(x7)": acc["pyramid_us"] / (K * LN), "k_fast_cells": acc["fast_us"] / (K * LN),
+        dur = {"k_resize(x%d)" % (len(px) - 1 - E_lv): acc["pyramid_us"] / (K * LN), fast_key: acc["fast_us"] / (K * LN),
                "k_blur": acc["blur_us"] / (K * LN), "k_describe": acc["describe_us"] / (K * LN)}
+        if pyr_chain == 0:
+            del algo["k_resize(x0)"], dur["k_resize(x0)"]
         kernels = {k: dict(us=round(dur[k], 2), algo_bytes=int(algo[k]),
                            gbps=round(algo[k] / max(dur[k], 1e-3) / 1e3, 2)) for k in algo}
         dom = max(dur, key=lambda k: dur[k])
@@ -834,7 +844,7 @@ def main():
         # they are used only when the workload matches. A "launch" of the roofline kernel = its launches of ONE step (FAST runs one
         # launch per LDS size class), timed together by the hipEvents around the stage.
         traffic, traffic_raw, counters_src, pmc_k = None, None, None, {}
-        for prof in ("r04_pmc_counters.json", "r03_pmc_counters.json"):
+        for prof in ("r05_pmc_counters.json", "r04_pmc_counters.json", "r03_pmc_counters.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if (P, W, H, NF, LN) == tuple(pmc.get("bench_args", ())):
@@ -860,10 +870,10 @@ def main():
         #   salu  SQ_INSTS_SALU x cost / (1024 x duration): lo prices the loop code's static mix of two-operand (2.4 ticks), one-operand (1.3) and
         #         wait / branch / compare (0.4) scalar instructions, hi every instruction at 1.3 ticks -- the scalar unit is shared by the CU's four SIMDs
         try:
-            mix = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_class_mix.json")))["kernels"]
+            mix = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_class_mix.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_isa_class_mix.json")) else "r04_isa_class_mix.json")))["kernels"]
         except Exception:
             mix = {}
-        mix_key = {"k_resize": "k_resize<true>", "k_fast_cells": "k_fast_cells<48, true>", "k_describe": "k_describe<true>", "k_blur": "k_blur_fold"}
+        mix_key = {"k_resize": "k_resize<true>", "k_fast_cells": "k_fast_cells<48, true, true>" if E_lv else "k_fast_cells<48, true, false>", "k_describe": "k_describe<true>", "k_blur": "k_blur_fold"}
         TICK_NS = 1.0 / 0.72
         for k in kernels:
             base = k.split("(")[0].split("+")[0]
@@ -894,8 +904,12 @@ def main():
                         algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(dur[dom], 2),
                         valu_issue_frac=kernels[dom].get("valu_issue_frac"), lds_issue_frac=kernels[dom].get("lds_issue_frac"),
                         salu_issue_frac=kernels[dom].get("salu_issue_frac"),
-                        note="an integer stencil at ~45 vector + 21 scalar + 12 LDS wave-instructions per 64 pixels-in-flight (669 / 308 / 178 per 30-px cell): the byte roof is "
-                             "not its wall, vector issue is (>= 0.92 of the SIMDs' issue time priced by instruction class), with the LDS pipe at ~0.7 and the CU's scalar unit at ~0.45 beside it (DESIGN.md section 4)")
+                        stage=("FAST + ComputePyramid in one stage: the cells of level l write level l + 1 from LDS (levels 1..%d); algorithmic bytes = SURVEY 8(d)'s FAST row "
+                               "(%d B / image) + its pyramid row for those levels (%d B / image)" % (E_lv, sum_px, pyr_fused)) if E_lv else "FAST alone (the k_resize chain made the pyramid)",
+                        frac_fast_row_only=round(sum_px * n_img_l / max(dur[dom], 1e-3) / 1e3 / HBM_PEAK_GBS, 5) if E_lv and dom == fast_key else None,
+                        note="an integer stencil (round 4: 601 vector + 289 scalar + 171 LDS wave-instructions per 30-px cell; the emitting form adds ~200 vector instructions per cell "
+                             "for the next level's pixels): the byte roof is not its wall, vector issue is (>= 0.92 of the SIMDs' issue time priced by instruction class), with the "
+                             "LDS pipe and the CU's scalar unit beside it (DESIGN.md section 4)")
         out = {
             "metric": "dual-frame ORB extract+match kfeatures/s; local-BA iters/s (50 KF / 2k MP)",
             "value": round(value, 2), "unit": "kfeatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -177,6 +177,10 @@ int  dcs_orb_debug_host_path(const dcs_orb* h, int* direct, int* graph_replayed)
    v_cmpx append), which a one-wave probe verified on the handle's device when it was created; 0: the probe found the device behaving
    differently (or DCS_FAST_HW_PROBE=fail asked for it) and the plain forms run -- same results. */
 int  dcs_orb_debug_fast_hw(const dcs_orb* h, int* fast_hw);
+/* *levels = pyramid levels 1 .. *levels of the handle's LAST call were written by the FAST cells of the level below (k_fast_cells<EMIT>:
+   ComputePyramid fused into the per-cell FAST pass); 0: the k_resize chain produced the pyramid (small batches, unaligned level 0, separate
+   blur kernels, option DCS_ORB_EMIT = 0). */
+int  dcs_orb_debug_emit_levels(const dcs_orb* h, int* levels);
 /* per-stage time of the last TIMED extraction in microseconds (hipEvents on the streams the kernels ran on):
    resize chain, k_fast_cells, scan+gather, k_blur, quadtree, k_describe, whole call (7 floats).
    Which extractions are timed: calls of MORE than two images under timing mode 1 / 2 (dcs_orb_set_timing). A call of one or two images

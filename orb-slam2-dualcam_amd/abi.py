@@ -23,7 +23,7 @@ SYMBOLS = [
     "dcs_last_error", "dcs_version", "dcs_device_count", "dcs_option_count", "dcs_option_name", "dcs_option_get", "dcs_option_set",
     "dcs_orb_create", "dcs_orb_destroy", "dcs_orb_tables", "dcs_orb_extract", "dcs_orb_extract_batch",
     "dcs_orb_extract_batch_device", "dcs_orb_debug_level_dims", "dcs_orb_debug_level",
-    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_debug_host_path", "dcs_orb_debug_fast_hw", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_orb_set_timing", "dcs_distribute_octree",
+    "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_debug_host_path", "dcs_orb_debug_fast_hw", "dcs_orb_debug_emit_levels", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_orb_set_timing", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_by_projection_kf", "dcs_search_in_window", "dcs_search_for_initialization",
     "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_debug_linearize", "dcs_ba_timing", "dcs_track_local_map", "dcs_track_frame_device", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
@@ -111,6 +111,7 @@ def lib():
             "dcs_orb_debug_quadtree_fallbacks": [vp, pci],
             "dcs_orb_debug_host_path": [vp, pci, pci],
             "dcs_orb_debug_fast_hw": [vp, pci],
+            "dcs_orb_debug_emit_levels": [vp, pci],
             "dcs_debug_sincosf": [vp, ci, vp, vp],
             "dcs_orb_required_cap": [vp, ci, ci, pci],
             "dcs_orb_last_timing": [vp, vp],
@@ -303,6 +304,12 @@ class ORBextractor:
         rc = lib().dcs_orb_extract_batch_device(self._h, d_images.data_ptr(), n, rows, cols or stride, stride, d_kp.data_ptr(),
                                                 d_desc.data_ptr(), cap, d_n.data_ptr(), stream)
         _check(rc, "dcs_orb_extract_batch_device")
+
+    def emit_levels(self):
+        """pyramid levels the FAST cells of the last call produced (0: the k_resize chain did)"""
+        v = C.c_int()
+        _check(lib().dcs_orb_debug_emit_levels(self._h, C.byref(v)), "dcs_orb_debug_emit_levels")
+        return v.value
 
     def fast_hw(self):
         """1: k_fast_cells runs its hardware-specific forms on this handle (the start-up probe passed), 0: the plain forms"""

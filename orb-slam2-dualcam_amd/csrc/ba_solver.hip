@@ -2609,7 +2609,7 @@ struct BaContext {
     hipStream_t stream = nullptr;
     // a batch is split into groups of problems, each fed through its own stream: while one group's reduced camera systems are
     // factored (one workgroup per problem) the other groups' wide kernels have the rest of the chip
-    static constexpr int kMaxGroups = 4;
+    static constexpr int kMaxGroups = 8;
     hipStream_t aux[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
     hipStream_t dl = nullptr;                          // results come down on their own stream once every problem has reported done
     // A call that took its results down on `dl` returns while the steps it had queued ahead (no-ops on a finished batch) are still in

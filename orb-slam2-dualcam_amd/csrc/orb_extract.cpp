@@ -208,6 +208,7 @@ struct dcs_orb {
     long config_generation = 0;                    // bumped by every configure() that rebuilds the buffers (part of the graph key)
     int fused_mode = -1;                           // DCS_ORB_FUSED_BLUR when the handle is created: 0 / 1, unset = choose per call
     int last_n_images = 0;
+    int last_emit_levels = 0;                      // pyramid levels the FAST cells of the last call produced (0: the resize chain did)
 
     ~dcs_orb() {
         if (s_main) (void)hipStreamDestroy(s_main);
@@ -507,7 +508,8 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // 265 / 260; 512 images 1 253 / 1 331 and 128 images of 1280 x 720 1 075 / 1 130 the other way). DCS_ORB_EMIT=n forces the mode on for any batch.
     const bool emit = emit_ok && split == 0 && fused_blur && emit_mode != 0 && level0_aligned &&
                       (emit_mode > 0 || (double)n_images * g.rows * g.cols >= emit_min_pixels);
-    const int E = emit ? (emit_mode > 0 ? std::min(emit_mode, L - 1) : L - 1) : 0;      // levels [0, E) emit levels [1, E]; the rest of the chain is k_resize
+    const int E = emit ? (emit_mode > 0 ? std::min(emit_mode, L - 1) : L - 1) : 0;
+    last_emit_levels = E;      // levels [0, E) emit levels [1, E]; the rest of the chain is k_resize
     for (int l = 1; l < L && !emit; ++l) {
         if ((rc = launch_resize(raw.lv[l - 1], raw.lv[l], d_rtab.p + rtab[l].xofs,
                                 d_rtab.p + rtab[l].yofs, d_rtab.p + rtab[l].ya, n_images, stream))) return rc;
@@ -1189,6 +1191,13 @@ int dcs_orb_debug_quadtree_fallbacks(dcs_orb* h, int* n)
     std::vector<int32_t> f((size_t)h->last_tasks);
     DCS_HIP(hipMemcpy(f.data(), h->d_oct_flag.p, sizeof(int32_t) * f.size(), hipMemcpyDeviceToHost));
     for (int32_t v : f) *n += v != 0;
+    return DCS_OK;
+}
+
+int dcs_orb_debug_emit_levels(const dcs_orb* h, int* levels)
+{
+    if (!h || !levels) { set_error("dcs_orb_debug_emit_levels: null argument"); return DCS_ERR_INVALID; }
+    *levels = h->last_emit_levels;
     return DCS_OK;
 }
 

@@ -70,6 +70,6 @@ for f in sorted(os.listdir(SRC)):
             m["ticks_per_valu_instruction"] = round((0.8 * fast + 1.33 * slow) / max(fast + m.get("valu_slow", 0) + m.get("valu_slow2", 0), 1), 3)
         res[name] = dict(file=f, **v)
 json.dump({"tool": "tools/isa_class_mix.py (static counts from hipcc -S; 'loops' = basic blocks inside a loop)", "kernels": res}, open(sys.argv[1], "w"), indent=1)
-for n in ("k_fast_cells<48, true>", "k_describe<true>", "k_resize<true>", "k_knn2_pairs_fp4", "k_octree_hist<2>"):
+for n in ("k_fast_cells<48, true, true>", "k_fast_cells<48, true, false>", "k_describe<true>", "k_pose_opt2", "k_resize<true>", "k_knn2_pairs_fp4", "k_octree_hist<2>"):
     for k, v in res.items():
         if k.startswith(n.split("<")[0]) and (n in k or "<" not in n): print(k, v["loops"]); break
