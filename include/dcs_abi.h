@@ -466,7 +466,10 @@ int  dcs_ba_local(const dcs_ba_problem* prob, const volatile uint8_t* stop_flag,
    on n_problems compute units at once) and the accept / reject logic of optimization_algorithm_levenberg.cpp:104-164 runs on
    the device, so the host never waits for a trial. dcs_ba_local IS this function with n_problems = 1: results are identical.
    stop_flags may be NULL, and so may any stop_flags[b]; a flag already set at entry leaves that problem untouched
-   (estimates copied through, no outliers, zero iterations: Optimizer.cc:582-585). Problems may differ in every size. */
+   (estimates copied through, no outliers, zero iterations: Optimizer.cc:582-585). Problems may differ in every size.
+   Bit-for-bit equality with a solo call holds as long as no problem of the call has more than 512 poses: such a problem moves the
+   problems that share its stream group to the two-launch update + error path, whose sums are ordered differently (same values to ~1e-15
+   relative; tests: 1e-9 on the translations). A problem whose pose-pair tables would exceed 1 GB / 4 M workgroups: DCS_ERR_UNSUPPORTED. */
 int  dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* probs, const volatile uint8_t* const* stop_flags,
                         dcs_ba_result* const* results);
 /* Parity tap for rows a14 / a15 (like dcs_orb_debug_level for the extraction stages): the blocks the solver holds after the FIRST

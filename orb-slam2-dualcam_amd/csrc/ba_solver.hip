@@ -3011,6 +3011,17 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         else host_pool().run(NB, work);            // persistent workers: creating 8 threads per call cost more than the lists themselves
         for (int i = 0; i < NB; ++i)
             if (dup[i] >= 0) { set_error("problem %d: more than one edge between pose and point of edge %d", live[i], dup[i]); return DCS_ERR_INVALID; }
+        // The device-built pair lists take edge_of[free poses][points] (int32) and one k_schur workgroup per pose PAIR, whatever the
+        // covisibility: fine for local BA (tens of poses) and the global BA sizes tested (10 x 70 000, 60 x 800), quadratic beyond. A problem
+        // that would need more than 1 GB or 4 M workgroups per step is refused instead of growing silently.
+        for (int i = 0; i < NB; ++i) {
+            const size_t cells = (size_t)rounds[i].np * (size_t)std::max(problems[live[i]]->n_points, 1);
+            if (cells * sizeof(int32_t) > ((size_t)1 << 30) || rounds[i].n_pairs > (4 << 20)) {
+                set_error("problem %d: %d free poses x %d points exceeds the pose-pair tables of this solver (edge_of %zu MB, %d pair workgroups)", live[i], rounds[i].np,
+                          problems[live[i]]->n_points, cells * sizeof(int32_t) >> 20, rounds[i].n_pairs);
+                return DCS_ERR_UNSUPPORTED;
+            }
+        }
     }
     const double t_build = ms_since(t_call0);
     const bool force_blocked = opt(OPT_BA_FORCE_BLOCKED_LDLT) != 0;   // test hook: the n > 256 path at small n
