@@ -685,6 +685,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         for (int r = kEmitPre; r < rounds; ++r)
             one(r, reinterpret_cast<const i32x2_t*>(em.rows)[cd.edy0 + min(e_g + r * G, cd.endy - 1)]);
     }
+    DCS_FAST_SECTION(11);
     const uint8_t* px = s_px + shift;
     // score map: only the detection area and its 1-px rim exist, pixel (x, y) of the ROI at s_sc[(y - 2) * sc_pitch + (x - 2)] (the
     // smaller map buys LDS room for two more resident waves per SIMD, and FAST loses 13 % when it loses 1.25)
