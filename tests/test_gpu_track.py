@@ -239,3 +239,44 @@ def test_track_frame_device_mode1_motion_model_vs_oracle(pkg, oracle, synth, kw)
         assert hit.sum() > 0.5 * (truth >= 0).sum(), (k, int(hit.sum()), int((truth >= 0).sum()))
         n_new += int(exp["n_matches"])
     assert n_new > 100
+
+
+def test_track_frame_device_edge_cases(pkg, oracle, synth):
+    """slots whose count exceeds the capacity are clamped to it, an error code in place of a count (the extractor's DCS_ERR_CAPACITY) means
+    no features, a frame without queries only assembles, and several frames of different sizes share one call"""
+    import torch
+    frames, prm = synth.motion_model_problem(n_frames=3, n_points=500, n_features=400, seed=12)
+    _with_grid(pkg, frames)
+    dfr, keep = _device_frames(frames, cap=600, mode=1)
+    # frame 1: no queries at all; frame 2: camera 1 reports an error code instead of a count
+    dfr[1]["points"] = dict(pos=np.zeros((0, 3), np.float32)); dfr[1]["desc"] = np.zeros((0, 32), np.uint8)
+    for k in ("q_cam", "q_octave"):
+        dfr[1][k] = np.zeros(0, np.int32)
+    dfr[1]["q_angle"] = np.zeros(0, np.float32)
+    d_n2 = keep[3 * 2 + 2]
+    n_before = d_n2.cpu().numpy().copy()
+    d_n2[2] = -2
+    torch.cuda.synchronize()
+    got = pkg.abi.PreparedTrackingDevice(dfr, prm, mode=1, check_orientation=True).track()
+    exp0 = _oracle_motion_model(oracle, frames[0], prm, True)
+    assert np.array_equal(got[0]["match_of_point"], exp0["match_of_point"]) and np.abs(got[0]["pose"] - exp0["pose"]).max() < 1e-9
+    assert got[1]["n_matches"] == 0 and got[1]["n_inliers"] == 0 and np.array_equal(got[1]["pose"], frames[1]["pose"])       # fewer than 3 edges: pose untouched
+    assert np.array_equal(got[1]["n_features"], np.diff(frames[1]["features"]["cam_off"]))
+    assert list(got[2]["n_features"]) == [int(n_before[1]), 0]
+    cam1 = frames[2]["mm"]["q_cam"] == 1
+    assert np.all(got[2]["match_of_point"][cam1] == -1)                                                                      # nothing to match in the empty camera
+    assert np.all(got[2]["match_of_point"][~cam1] < int(n_before[1]))
+    # a capacity below the count: the frame is what fits
+    ft = frames[0]["features"]
+    small = int(min(np.diff(ft["cam_off"]))) - 7
+    kp, desc, n = _to_slots(dict(ft, cam_off=np.array([0, small, 2 * small], np.int32), kp_x=np.concatenate([ft["kp_x"][ft["cam_off"][c]:ft["cam_off"][c] + small] for c in (0, 1)]),
+                                 kp_y=np.concatenate([ft["kp_y"][ft["cam_off"][c]:ft["cam_off"][c] + small] for c in (0, 1)]),
+                                 kp_angle=np.concatenate([ft["kp_angle"][ft["cam_off"][c]:ft["cam_off"][c] + small] for c in (0, 1)]),
+                                 kp_octave=np.concatenate([ft["kp_octave"][ft["cam_off"][c]:ft["cam_off"][c] + small] for c in (0, 1)]),
+                                 desc=np.concatenate([ft["desc"][ft["cam_off"][c]:ft["cam_off"][c] + small] for c in (0, 1)])), small)
+    n[1:3] = small + 50                                                                                                      # the extractor found more than the slot holds
+    t = [torch.from_numpy(a).cuda() for a in (kp, desc, n)]
+    d0 = dict(dfr[0]); d0["dev"] = dict(dfr[0]["dev"], d_kp=t[0].data_ptr(), d_desc=t[1].data_ptr(), d_n=t[2].data_ptr(), cap=small)
+    torch.cuda.synchronize()
+    g = pkg.abi.PreparedTrackingDevice([d0], prm, mode=1, check_orientation=True).track()[0]
+    assert list(g["n_features"]) == [small, small] and len(g["point_of_feature"]) == 2 * small
