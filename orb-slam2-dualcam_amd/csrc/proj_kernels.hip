@@ -1305,11 +1305,18 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
         if ((rc = s.alloc(&d.cam_off, (size_t)C + 1)) || (rc = zeroed(&d.kp_x, (size_t)Ncap)) || (rc = zeroed(&d.kp_y, (size_t)Ncap)) || (rc = zeroed(&d.kp_angle, (size_t)Ncap)) ||
             (rc = zeroed(&d.kp_octave, (size_t)Ncap)) || (rc = s.alloc(&d.desc_out, (size_t)Ncap * 32)) || (rc = s.alloc(&d.grid_off, (size_t)cells + 1)) ||
             (rc = s.alloc(&d.grid_idx, (size_t)Ncap)) || (rc = s.upload(&d.min_x, df.min_x, (size_t)C)) || (rc = s.upload(&d.min_y, df.min_y, (size_t)C)) ||
-            (rc = s.upload(&d.w_inv, df.grid_w_inv, (size_t)C)) || (rc = s.upload(&d.h_inv, df.grid_h_inv, (size_t)C)) ||
-            (rc = zeroed(&taken_w, (size_t)Ncap)) || (rc = zeroed(&hasp_w, (size_t)Ncap)) || (rc = zeroed(&pxw_w, (size_t)3 * Ncap))) return rc;
-        if (t.n_held) {
-            if ((rc = s.upload_into(taken_w, t.taken, (size_t)t.n_held)) || (rc = s.upload_into(hasp_w, t.has_point ? t.has_point : t.taken, (size_t)t.n_held)) ||
-                (rc = s.upload_into(pxw_w, t.point_xw, (size_t)3 * t.n_held))) return rc;
+            (rc = s.upload(&d.w_inv, df.grid_w_inv, (size_t)C)) || (rc = s.upload(&d.h_inv, df.grid_h_inv, (size_t)C))) return rc;
+        {   // what the features hold: the WHOLE capacity goes up from a zero-filled host image. (Uploading only n_held entries into a zeroed device
+            // array is not enough: Scratch merges staged uploads that are adjacent at their 256-byte padded sizes into one copy, and the padding of
+            // the pinned block -- stale bytes -- would land on the zeros behind a short array: frames of < 256 features then grew phantom edges.)
+            std::vector<uint8_t> h_tk((size_t)Ncap, 0), h_hp((size_t)Ncap, 0);
+            std::vector<float> h_xw((size_t)3 * Ncap, 0.f);
+            if (t.n_held) {
+                memcpy(h_tk.data(), t.taken, (size_t)t.n_held);
+                memcpy(h_hp.data(), t.has_point ? t.has_point : t.taken, (size_t)t.n_held);
+                memcpy(h_xw.data(), t.point_xw, sizeof(float) * 3 * (size_t)t.n_held);
+            }
+            if ((rc = s.upload(&taken_w, h_tk.data(), h_tk.size())) || (rc = s.upload(&hasp_w, h_hp.data(), h_hp.size())) || (rc = s.upload(&pxw_w, h_xw.data(), h_xw.size()))) return rc;
         }
         ProjFrameD& f = it.f;
         f = ProjFrameD{};

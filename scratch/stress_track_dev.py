@@ -23,6 +23,7 @@ while time.time() - t0 < budget:
         for a, b in zip(ref, got):
             ok = all(np.array_equal(a[k], b[k]) for k in ("match_of_point", "point_of_feature", "outlier", "pose")) and a["n_matches"] == b["n_matches"] and a["n_inliers"] == b["n_inliers"]
             bad += not ok; f0 += 1
+            if not ok: print('MISMATCH mode 0', nf, npts, nfeat, seed, cap, [k for k in ('match_of_point', 'point_of_feature', 'outlier', 'pose') if not np.array_equal(a[k], b[k])], a['n_matches'], b['n_matches'], a['n_inliers'], b['n_inliers'])
         n0 += 1
     else:
         check = bool(rng.integers(0, 2))

@@ -172,12 +172,15 @@ def _device_frames(frames, cap, mode):
     return out, keep
 
 
-def test_track_frame_device_mode0_equals_the_host_buffer_chain(pkg, synth):
-    """features taken from the extractor's slot layout in HBM, assembled and gridded on the device: bit for bit dcs_track_local_map"""
-    frames, prm = synth.tracking_problem(n_frames=3, n_points=1300, n_features=1000, seed=57)
+@pytest.mark.parametrize("kw,cap", [(dict(n_frames=3, n_points=1300, n_features=1000, seed=57), 700),
+                                    (dict(n_frames=3, n_points=1677, n_features=90, seed=976754755 % 100000, pre_matched=0.6), 118)])
+def test_track_frame_device_mode0_equals_the_host_buffer_chain(pkg, synth, kw, cap):
+    """features taken from the extractor's slot layout in HBM, assembled and gridded on the device: bit for bit dcs_track_local_map.
+    (Second case: frames of fewer than 256 features -- the randomised sweep found stale staging bytes behind their `has_point` arrays.)"""
+    frames, prm = synth.tracking_problem(**kw)
     _with_grid(pkg, frames)
     ref = pkg.abi.PreparedTracking(frames, prm).track()
-    dfr, keep = _device_frames(frames, cap=700, mode=0)
+    dfr, keep = _device_frames(frames, cap=cap, mode=0)
     got = pkg.abi.PreparedTrackingDevice(dfr, prm, mode=0).track()
     for k, (a, b) in enumerate(zip(ref, got)):
         ft = frames[k]["features"]
