@@ -389,7 +389,14 @@ __device__ __forceinline__ void knn2_tile_fp4(const uint8_t* __restrict__ q, int
     __syncthreads();
     for (int t0 = 0, buf = 0; t0 < nt; t0 += kMTile, buf ^= 1) {
 #if !defined(DCS_KNN4_SKIP) || DCS_KNN4_SKIP != 1                  // timing-only side builds (wrong results): 1 = tiles are not re-expanded, 2 = no key ranking, 3 = no matrix instructions
+#ifdef DCS_KNN4_DEPHASE
+        // the two waves that share a SIMD (w and w + 4) work in opposite order inside a tile: one re-expands the next tile (vector + LDS writes) while
+        // the other runs this tile's matrix instructions and key ranking -- the barrier per tile otherwise keeps every wave in the same phase
+        const bool expand_late = ((wave >> 2) & 1) != 0;
+        if (!expand_late && t0 + kMTile < nt) expand_tile(t0 + kMTile, buf ^ 1);
+#else
         if (t0 + kMTile < nt) expand_tile(t0 + kMTile, buf ^ 1);   // next tile: its VALU / LDS work overlaps this tile's MFMAs
+#endif
 #endif
         const int n_grp = (min(kMTile, nt - t0) + 15) >> 4;
         v8i_t af[2];
@@ -432,6 +439,9 @@ __device__ __forceinline__ void knn2_tile_fp4(const uint8_t* __restrict__ q, int
             group(tg, pbA, pbB);
             if (tg + 1 < n_grp) group(tg + 1, pbB, pbA);
         }
+#if defined(DCS_KNN4_DEPHASE) && (!defined(DCS_KNN4_SKIP) || DCS_KNN4_SKIP != 1)
+        if (expand_late && t0 + kMTile < nt) expand_tile(t0 + kMTile, buf ^ 1);
+#endif
         __syncthreads();
     }
     // the 4 lanes (g = 0..3) of a query hold disjoint train rows: two smallest of the union

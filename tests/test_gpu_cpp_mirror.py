@@ -212,3 +212,79 @@ def test_kfdb_python_twin_and_cpp_mirror_vs_oracle(tmp_path, pkg, oracle, synth)
             line = [l for l in lines if l.startswith(tag)][0]
             assert [int(x) for x in line[len(tag):].split()] == exp
     assert lines[-1] == "size %d" % n
+
+
+def _build_hip(tmp_path, name):
+    """a C++ host program that owns device memory itself (hipMalloc / streams through the HIP runtime API) and reaches the library through the C ABI only"""
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-L", os.path.join(PKG, "lib"), "-ldcs_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(PKG, "lib"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_frame_pipeline_program_compiles(tmp_path, pkg):
+    pkg.abi.lib()
+    _build_hip(tmp_path, "frame_pipeline_test")
+
+
+@pytest.mark.gpu
+def test_frame_pipeline_from_cpp_equals_the_ctypes_path(tmp_path, pkg, synth):
+    """images -> dcs_orb_extract_batch_device -> dcs_track_frame_device (TrackWithMotionModel's stage, host bookkeeping, TrackLocalMap's stage) from a
+    C++ program that holds the device buffers itself: counts, assignments, outlier flags and poses equal the ctypes path's on the same scene bit for bit
+    (which tests/test_gpu_track.py holds against the oracle)."""
+    import torch
+    exe = _build_hip(tmp_path, "frame_pipeline_test")
+    H, W, NF = 480, 640, 1000
+    a, b_ = synth.frame_pair(W, H, 0, 5)
+    ext = pkg.ORBextractor(NF, 1.2, 8, 20, 7, max_images=2)
+    cap = ext.default_cap(H, W)
+    d_img = torch.from_numpy(np.stack([a, b_])).cuda()
+    d_kp = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda"); d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(2, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ext.extract_batch_device(d_img, d_kp, d_desc, d_n, cap, stream=st)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    kp = d_kp.cpu().numpy().reshape(2, cap, 7).copy().view(pkg.abi.KEYPOINT).reshape(2, cap)
+    de = d_desc.cpu().numpy()
+    fs, prm = synth.scene_from_features([kp[c][:n[c]] for c in (0, 1)], [de[c][:n[c]] for c in (0, 1)], seed=33)
+    mm, vw = fs["mm"], fs["view"]
+    # ---- the ctypes path
+    dev = dict(d_kp=d_kp.data_ptr(), d_desc=d_desc.data_ptr(), d_n=d_n.data_ptr(), cap=cap, first_slot=0, n_cams=2, **fs["grid"])
+    prm_mm = dict(prm); prm_mm["th"] = 7.0; prm_mm["nn_ratio"] = 0.0
+    r1 = pkg.abi.PreparedTrackingDevice([dict(dev=dev, view=vw, pose=fs["pose"], held=None, points=dict(pos=mm["pos"]), desc=mm["desc"], q_cam=mm["q_cam"],
+                                              q_octave=mm["q_octave"], q_angle=mm["q_angle"])], prm_mm, mode=1, check_orientation=True, stream=st).track()[0]
+    N = int(n.sum())
+    pof = r1["point_of_feature"]
+    good = (pof >= 0) & (r1["outlier"] == 0)
+    held = good.astype(np.uint8)
+    xw = np.zeros((N, 3), np.float32); xw[good] = mm["pos"][pof[good]]
+    pts = dict(fs["points"]); pts["candidate"] = np.ones(len(pts["pos"]), np.uint8); pts["candidate"][mm["point"][pof[good]]] = 0
+    prm_lm = dict(prm); prm_lm["th"] = 1.0; prm_lm["nn_ratio"] = 0.8
+    r2 = pkg.abi.PreparedTrackingDevice([dict(dev=dev, view=vw, pose=fs["pose"], held=dict(taken=held, has_point=held, point_xw=xw), points=pts, desc=fs["desc"])],
+                                        prm_lm, mode=0, stream=st).track()[0]
+    assert r1["n_matches"] > 500 and r1["n_inliers"] > 500 and r2["n_inliers"] >= r1["n_inliers"]
+    # ---- the same scene through the C++ program
+    cam_bytes = b"".join(bytes(pkg.abi.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"])) for c in prm["cams"])
+    arrays = {"dims": np.array([H, W, NF], np.int32), "images": np.stack([a, b_]), "cams": np.frombuffer(cam_bytes, np.uint8),
+              "pose": fs["pose"].astype(np.float64), "huber_delta": np.array([prm["huber_delta"]], np.float64), "inv_level_sigma2": prm["inv_level_sigma2"].astype(np.float32),
+              "log_scale_factor": np.array([vw["log_scale_factor"]], np.float32), "grid_w_inv": fs["grid"]["grid_w_inv"], "grid_h_inv": fs["grid"]["grid_h_inv"],
+              "mm.pos": mm["pos"], "mm.desc": mm["desc"], "mm.q_cam": mm["q_cam"], "mm.q_octave": mm["q_octave"], "mm.q_angle": mm["q_angle"], "mm.point": mm["point"].astype(np.int32),
+              "lm.pos": fs["points"]["pos"], "lm.normal": fs["points"]["normal"], "lm.min_dist": fs["points"]["min_dist"], "lm.max_dist": fs["points"]["max_dist"], "lm.desc": fs["desc"]}
+    for k in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y", "scale_factors"):
+        arrays[k] = np.asarray(vw[k], np.float32)
+    blob = str(tmp_path / "scene.blob")
+    _blob(blob, arrays)
+    ext.close()
+    out = subprocess.run([exe, blob], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = dict((l.split()[0], l.split()[1:]) for l in out.stdout.strip().splitlines())
+    assert [int(v) for v in lines["features"]] == list(n)
+    for tag, r, nq in (("mm", r1, len(mm["pos"])), ("lm", r2, len(pts["pos"]))):
+        v = lines[tag]
+        assert int(v[0]) == r["n_matches"] and int(v[1]) == r["n_inliers"], (tag, v[:2], r["n_matches"], r["n_inliers"])
+        assert int(v[2], 16) == _fnv(r["match_of_point"][:nq].astype(np.int32).tobytes()), tag
+        assert int(v[3], 16) == _fnv(r["point_of_feature"].astype(np.int32).tobytes()) and int(v[4], 16) == _fnv(r["outlier"].tobytes()), tag
+        assert np.array_equal(np.array([float(x) for x in v[5:12]]), r["pose"]), tag
