@@ -1374,8 +1374,21 @@ def main():
         n2 = d_n2.cpu().numpy()
         kp2 = d_kp2.cpu().numpy().reshape(2, cap2, 7).copy().view(pkg.abi.KEYPOINT).reshape(2, cap2)
         de2 = d_desc2.cpu().numpy()
-        fs_, prm_s = synth.scene_from_features([kp2[c][:n2[c]] for c in (0, 1)], [de2[c][:n2[c]] for c in (0, 1)])
-        dev_ = dict(d_kp=d_kp2.data_ptr(), d_desc=d_desc2.data_ptr(), d_n=d_n2.data_ptr(), cap=cap2, first_slot=0, n_cams=2, **fs_["grid"])
+        # the shipped rig's intrinsics and distortion (Dual-LenaCV.yaml:12-35, k1 = -0.37): Frame::UndistortKeyPoints runs inside dcs_track_frame_device; the map
+        # is fitted to the UNDISTORTED key points and the image bounds are the undistorted corners (Frame::ComputeImageBounds, Frame.cc:454-476)
+        K_rig = np.array([[synth.RIG["cam%d" % c][k] for k in ("fx", "fy", "cx", "cy")] for c in (0, 1)], np.float32)
+        dist_rig = np.array([[-0.3689, 0.1627, 0.0, 0.0, 0.0], [-0.361851421593862, 0.140443638558527, 0.0, 0.0, 0.0]], np.float32)
+        kp_u, bnd = [], [[], [], [], []]
+        for c in (0, 1):
+            kc = kp2[c][:n2[c]].copy()
+            u_ = pkg.abi.undistort_points(np.stack([kc["x"], kc["y"]], 1), K_rig[c], dist_rig[c])
+            kc["x"], kc["y"] = u_[:, 0], u_[:, 1]
+            kp_u.append(kc)
+            cr = pkg.abi.undistort_points(np.array([[0, 0], [W, 0], [0, H], [W, H]], np.float32), K_rig[c], dist_rig[c])
+            for b_, v_ in zip(bnd, (min(cr[0, 0], cr[2, 0]), max(cr[1, 0], cr[3, 0]), min(cr[0, 1], cr[1, 1]), max(cr[2, 1], cr[3, 1]))):
+                b_.append(v_)
+        fs_, prm_s = synth.scene_from_features(kp_u, [de2[c][:n2[c]] for c in (0, 1)], bounds=bnd)
+        dev_ = dict(d_kp=d_kp2.data_ptr(), d_desc=d_desc2.data_ptr(), d_n=d_n2.data_ptr(), cap=cap2, first_slot=0, n_cams=2, K=K_rig, dist=dist_rig, **fs_["grid"])
         mm_ = fs_["mm"]
         prm_mm = dict(prm_s); prm_mm["th"] = 7.0; prm_mm["nn_ratio"] = 0.0
         N2 = int(n2.sum())
@@ -1419,7 +1432,7 @@ def main():
         tot_["ms_motion_model_stage_alone"] = stage(lambda: pt_mm.track())
         tot_["ms_local_map_stage_alone"] = stage(lambda: pt_lm.track())
         out["per_frame_total"] = dict(workload="1 dual 640x480 frame: 2 page-locked host images up -> dcs_orb_extract_batch_device (slots in HBM) -> dcs_track_frame_device mode 1 "
-                                               "(TrackWithMotionModel: SearchByProjectionOnCam x 2 with rotation histograms + PoseOptimization) -> host bookkeeping -> "
+                                               "(Frame::UndistortKeyPoints with the rig file's k1 = -0.37, TrackWithMotionModel: SearchByProjectionOnCam x 2 with rotation histograms + PoseOptimization) -> host bookkeeping -> "
                                                "dcs_track_frame_device mode 0 (SearchLocalPoints + PoseOptimization); features stay on the device, map arrays from the host; "
                                                "the local-map stage starts from the same pose guess (the harness does not rebuild the view matrices); median of 40",
                                       features=int(N2), mm_queries=int(len(mm_["pos"])), mm_matches=int(r1_["n_matches"]), mm_inliers=int(r1_["n_inliers"]),

@@ -570,9 +570,9 @@ int  dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_
              histogram per camera), then PoseOptimization over the new matches. The queries are the last frame's features that hold
              a good map point, in ascending feature order: pos = GetWorldPos, desc = MapPoint::GetDescriptor, q_cam = keypointToCam[i],
              q_octave / q_angle = the last frame's key point. mvpMapPoints of the current frame is empty in this stage (Tracking.cc:1396).
-   Key points are taken as they are (pt.x, pt.y = the undistorted position: Frame::UndistortKeyPoints is the identity for the zero
-   distortion the reference's rig files use, Frame.cc:UndistortKeyPoints first branch; a rig with distortion undistorts on the host and
-   uses dcs_track_local_map). Feature g of the outputs = the frame's compact index: camera c's features at [off_c, off_c + n_c) with
+   Frame::UndistortKeyPoints (Frame.cc:410-441) runs on the device too: with K and dist given (the rig file's fx fy cx cy and k1 k2 p1 p2 k3;
+   Dual-LenaCV.yaml has k1 = -0.37) every key point goes through cv::undistortPoints' arithmetic (dcs_undistort_points below) when the camera's
+   k1 != 0, exactly the reference's test (:414); dist == NULL: the key points are taken as they are. Feature g of the outputs = the frame's compact index: camera c's features at [off_c, off_c + n_c) with
    n_c = min(count of slot first_slot + c, cap) -- n_features reports n_c. Map-side arrays come from the host (they live in the reference's
    map). One synchronisation, at the end. `stream` = the stream the extraction was enqueued on (the chain waits for it; NULL = legacy stream). */
 typedef struct dcs_dev_frame {
@@ -581,6 +581,8 @@ typedef struct dcs_dev_frame {
     const uint8_t*      d_desc;         /* DEVICE [slots][cap][32] */
     const int32_t*      d_n;            /* DEVICE [slots] */
     const float* min_x; const float* min_y; const float* grid_w_inv; const float* grid_h_inv;   /* host [n_cams]: mvMinX, mvMinY, mvfGridElementWidthInv / HeightInv */
+    const float* K;                     /* host [n_cams][4] fx, fy, cx, cy of the rig file (read with dist) */
+    const float* dist;                  /* host [n_cams][5] k1, k2, p1, p2, k3 (0 when the file has no k3), or NULL: no undistortion */
 } dcs_dev_frame;
 typedef struct dcs_track_dev_frame {
     dcs_dev_frame     features;
@@ -599,6 +601,10 @@ typedef struct dcs_track_dev_result {
     dcs_track_result r;             /* arrays per frame sized for n_cams * cap features / n_points queries */
     int32_t* n_features;            /* [F][n_cams] features per camera as assembled */
 } dcs_track_dev_result;
+/* cv::undistortPoints(xy, out, K, dist, cv::Mat(), K) on n float points, the call of Frame::UndistortKeyPoints and Frame::ComputeImageBounds (Frame.cc:430,
+   468): OpenCV 3.3 / 3.4.0's five fixed-point iterations in double. dist5[0] == 0: copied through like the reference does (:414). Pure host helper (the
+   host-buffer chain dcs_track_local_map takes undistorted key points; the image bounds are four such points); the device chain runs the same arithmetic. */
+int  dcs_undistort_points(int n, const float* xy, const float K4[4], const float dist5[5], float* out);
 int  dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, const dcs_track_params* prm, int mode, int check_orientation,
                             dcs_track_dev_result* res, void* stream);
 

@@ -698,3 +698,34 @@ extern "C" void orc_motion_model_queries(const orc_frustum_frame* f, int n, cons
         valid[i] = 1;
     }
 }
+
+
+// ---- cv::undistortPoints(src, dst, K, distCoeffs, cv::Mat(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call it (src/Frame.cc:410-441, 454-476).
+// EXT: OpenCV 3.3 / 3.4.0 modules/imgproc/src/undistort.cpp, cvUndistortPoints (not under /root/reference: parity unpinned): everything in double --
+// A = K and the coefficients widened from float, ifx = 1 / fx, (x, y) = ((u - cx) ifx, (v - cy) ify), the tilt compensation with the identity matrix
+// (x0 = x = invProj * x with invProj = 1 / 1), FIVE fixed-point iterations
+//   r2 = x x + y y;  icdist = (1 + ((k7 r2 + k6) r2 + k5) r2) / (1 + ((k4 r2 + k1) r2 + k0) r2)
+//   dX = 2 k2 x y + k3 (r2 + 2 x x) + k8 r2 + k9 r2 r2;  dY = k2 (r2 + 2 y y) + 2 k3 x y + k10 r2 + k11 r2 r2;  x = (x0 - dX) icdist; y = (y0 - dY) icdist
+// (k0 k1 k2 k3 k4 = k1 k2 p1 p2 k3 of the rig file, the rest 0), then RR = P * R = K: xx = fx x + 0 y + cx, ww = 1 / (0 x + 0 y + 1), (float)(xx ww).
+extern "C" void orc_undistort_points(int n, const float* xy, const float K4[4], const float* dist, int n_dist, float* out)
+{
+    double k[14] = {0};
+    for (int i = 0; i < n_dist && i < 14; ++i) k[i] = (double)dist[i];
+    const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3], ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < n; ++i) {
+        double x = xy[2 * i], y = xy[2 * i + 1];
+        x = (x - cx) * ifx; y = (y - cy) * ify;
+        const double invProj = 1. / 1.0;
+        const double x0 = x = invProj * x, y0 = y = invProj * y;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = fx * x + 0.0 * y + cx, yy = 0.0 * x + fy * y + cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+        out[2 * i] = (float)(xx * ww); out[2 * i + 1] = (float)(yy * ww);
+    }
+}

@@ -252,6 +252,8 @@ typedef struct orc_frustum_frame {
 void orc_is_in_frustum(const orc_frustum_frame* f, int n, const float* pos, const float* normal, const float* min_dist,
                        const float* max_dist, const uint8_t* candidate, float viewing_cos_limit, float th, uint8_t* in_view,
                        int32_t* cam, float* u, float* v, float* view_cos, int32_t* level, float* radius);
+/* cv::undistortPoints(src, dst, K, dist, Mat(), K) as Frame::UndistortKeyPoints calls it (Frame.cc:410-441); OpenCV 3.3 / 3.4.0 cvUndistortPoints restated */
+void orc_undistort_points(int n, const float* xy, const float K4[4], const float* dist, int n_dist, float* out);
 /* the geometry of ORBmatcher::SearchByProjectionOnCam (ORBmatcher.cc:962-968, 990-1036) for the last frame's features that hold a good map point */
 void orc_motion_model_queries(const orc_frustum_frame* f, int n, const float* pos, const int32_t* q_cam, const int32_t* q_octave, float th,
                               uint8_t* valid, float* u, float* v, float* radius, int32_t* min_level, int32_t* max_level);

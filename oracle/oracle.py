@@ -742,6 +742,18 @@ def detect_candidates(loop, query_id, q_word, q_val, db, dead, covis, state, con
     return [int(v) for v in out[:k]]
 
 
+def undistort_points(xy, K4, dist):
+    """cv::undistortPoints(xy, K, dist, noArray(), K) on float points [n, 2] (Frame::UndistortKeyPoints); K4 = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])"""
+    xy = _c(xy, np.float32).reshape(-1, 2)
+    K4, dist = _c(K4, np.float32), _c(dist, np.float32)
+    out = np.zeros((max(len(xy), 1), 2), np.float32)
+    L = lib()
+    L.orc_undistort_points.restype = None
+    L.orc_undistort_points.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_undistort_points(len(xy), _p(xy), _p(K4), _p(dist), len(dist), _p(out))
+    return out[:len(xy)]
+
+
 def motion_model_queries(frame, pos, q_cam, q_octave, th):
     """the query columns (valid, u, v, radius, min_level, max_level) of SearchByProjectionOnCam for the last frame's features with a map point"""
     keep = []

@@ -26,7 +26,7 @@ SYMBOLS = [
     "dcs_orb_debug_candidates", "dcs_orb_debug_quadtree_fallbacks", "dcs_orb_debug_host_path", "dcs_orb_debug_fast_hw", "dcs_orb_debug_emit_levels", "dcs_debug_sincosf", "dcs_orb_required_cap", "dcs_orb_last_timing", "dcs_orb_timing_totals", "dcs_orb_set_timing", "dcs_distribute_octree",
     "dcs_hamming_knn2", "dcs_hamming_knn2_grouped", "dcs_match_filter", "dcs_match_bf",
     "dcs_match_bf_batch_device", "dcs_search_by_bow", "dcs_search_by_bow_kf", "dcs_search_for_triangulation", "dcs_distinctive_descriptors", "dcs_pose_optimization", "dcs_frame_grid", "dcs_search_by_projection", "dcs_search_by_projection_kf", "dcs_search_in_window", "dcs_search_for_initialization",
-    "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_debug_linearize", "dcs_ba_timing", "dcs_track_local_map", "dcs_track_frame_device", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
+    "dcs_ba_local", "dcs_ba_local_batch", "dcs_ba_debug_linearize", "dcs_ba_timing", "dcs_track_local_map", "dcs_track_frame_device", "dcs_undistort_points", "dcs_rig_adjoint", "dcs_pose_from_matrix", "dcs_pose_to_matrix",
     "dcs_comm_unique_id", "dcs_comm_create", "dcs_comm_destroy", "dcs_comm_info", "dcs_features_allgather",
     "dcs_stream_create_cu_range", "dcs_stream_destroy", "dcs_host_alloc", "dcs_host_free", "dcs_streams_share_queue", "dcs_stream_create_apart", "dcs_ba_avoid_streams", "dcs_ba_set_cu_range", "dcs_ba_release_thread",
     "dcs_is_in_frustum", "dcs_vocab_create", "dcs_vocab_destroy", "dcs_vocab_info", "dcs_bow_transform_device", "dcs_bow_transform", "dcs_bow_score_l1",
@@ -1148,7 +1148,7 @@ class PreparedTracking:
 
 class DevFrame(C.Structure):
     _fields_ = [("n_cams", C.c_int32), ("cap", C.c_int32), ("first_slot", C.c_int32), ("d_kp", C.c_void_p), ("d_desc", C.c_void_p), ("d_n", C.c_void_p),
-                ("min_x", C.c_void_p), ("min_y", C.c_void_p), ("grid_w_inv", C.c_void_p), ("grid_h_inv", C.c_void_p)]
+                ("min_x", C.c_void_p), ("min_y", C.c_void_p), ("grid_w_inv", C.c_void_p), ("grid_h_inv", C.c_void_p), ("K", C.c_void_p), ("dist", C.c_void_p)]
 
 
 class TrackDevFrame(C.Structure):
@@ -1159,6 +1159,18 @@ class TrackDevFrame(C.Structure):
 
 class TrackDevResult(C.Structure):
     _fields_ = [("r", TrackResult), ("n_features", C.c_void_p)]
+
+
+def undistort_points(xy, K4, dist5):
+    """dcs_undistort_points: cv::undistortPoints(xy, K, dist, noArray(), K) as Frame::UndistortKeyPoints calls it"""
+    xy = _c(xy, np.float32).reshape(-1, 2)
+    K4, d5 = _c(K4, np.float32), np.zeros(5, np.float32)
+    d5[:len(dist5)] = dist5
+    out = np.zeros((max(len(xy), 1), 2), np.float32)
+    L = lib()
+    L.dcs_undistort_points.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(L.dcs_undistort_points(len(xy), _p(xy), _p(K4), _p(d5), _p(out)), "dcs_undistort_points")
+    return out[:len(xy)]
 
 
 class PreparedTrackingDevice:
@@ -1185,7 +1197,7 @@ class PreparedTrackingDevice:
             t = arr[k]
             C_ = int(dv["n_cams"])
             t.features = DevFrame(C_, int(dv["cap"]), int(dv["first_slot"]), int(dv["d_kp"]), int(dv["d_desc"]), int(dv["d_n"]), a(dv["min_x"], np.float32),
-                                  a(dv["min_y"], np.float32), a(dv["grid_w_inv"], np.float32), a(dv["grid_h_inv"], np.float32))
+                                  a(dv["min_y"], np.float32), a(dv["grid_w_inv"], np.float32), a(dv["grid_h_inv"], np.float32), a(dv.get("K"), np.float32), a(dv.get("dist"), np.float32))
             v = FrustumFrame()
             v.n_cams = len(vw["fx"])
             for key in ("Rsw", "tsw", "Ow", "fx", "fy", "cx", "cy", "min_x", "max_x", "min_y", "max_y"):

@@ -741,6 +741,29 @@ __global__ __launch_bounds__(256) void k_track_finish(const TrackItem* __restric
     for (int k = threadIdx.x; k < edge_cnt[blockIdx.x]; k += 256) it.feat_outlier[it.edge_feature[k]] = outlier[it.edge_base + k];   // mvbOutlier[i]
 }
 
+// cv::undistortPoints(src, dst, K, distCoeffs, cv::Mat(), K) for ONE point, as Frame::UndistortKeyPoints calls it (src/Frame.cc:410-441): OpenCV 3.3 / 3.4.0
+// cvUndistortPoints (modules/imgproc/src/undistort.cpp) in its own order of double operations -- normalise with ifx = 1 / fx, the identity tilt
+// compensation, five fixed-point iterations of the radial / tangential model, re-projection with RR = K (the zero products stay in: they add exact zeros).
+// c = {fx, fy, cx, cy, k1, k2, p1, p2, k3}. Built without contraction (-ffp-contract=off) on both sides of the compiler.
+__host__ __device__ inline void undistort_point(const double c[9], float u, float v, float& uo, float& vo)
+{
+    const double fx = c[0], fy = c[1], cx = c[2], cy = c[3], k0 = c[4], k1 = c[5], k2 = c[6], k3 = c[7], k4 = c[8];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = u, y = v;
+    x = (x - cx) * ifx; y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+        const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x) + 0.0 * r2 + 0.0 * r2 * r2;
+        const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y + 0.0 * r2 + 0.0 * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0.0 * y + cx, yy = 0.0 * x + fy * y + cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    uo = (float)(xx * ww); vo = (float)(yy * ww);
+}
+
 // ---- device-resident frames (dcs_track_frame_device): what the Frame constructor does with the extractor's output (src/Frame.cc:141-196)
 struct DevAsm {                                    // one per frame: where the extractor left the features, and the assembled arrays
     const dcs_keypoint* kp; const uint8_t* desc; const int32_t* n; int cap, first_slot, n_cams;
@@ -748,6 +771,8 @@ struct DevAsm {                                    // one per frame: where the e
     const float *min_x, *min_y, *w_inv, *h_inv;    // device copies of the per-camera grid constants
     int32_t* n_features;                           // [n_cams] output
     const int32_t *q_cam_in, *q_octave_in;         // mode 1: camera and octave of every query (the last frame's key point)
+    double und[kFrMaxCams][9];                     // {fx, fy, cx, cy, k1, k2, p1, p2, k3} per camera
+    uint8_t und_on[kFrMaxCams];                    // Frame::UndistortKeyPoints: distCoef[0] != 0 (Frame.cc:414)
 };
 // mvTotalKeysUn / mvDescriptors concatenated over the cameras (Frame.cc:166-181): feature i of camera c at cam_off[c] + i
 __global__ __launch_bounds__(256) void k_dev_assemble(const DevAsm* __restrict__ das)
@@ -769,7 +794,9 @@ __global__ __launch_bounds__(256) void k_dev_assemble(const DevAsm* __restrict__
     reinterpret_cast<unsigned long long*>(d.desc_out + (size_t)g * 32)[piece] = reinterpret_cast<const unsigned long long*>(d.desc + src * 32)[piece];
     if (piece == 0) {
         const dcs_keypoint k = d.kp[src];
-        d.kp_x[g] = k.x; d.kp_y[g] = k.y; d.kp_angle[g] = k.angle; d.kp_octave[g] = k.octave;
+        float ux = k.x, uy = k.y;
+        if (d.und_on[c]) undistort_point(d.und[c], k.x, k.y, ux, uy);            // mvvkeysUnTemp (Frame.cc:410-441)
+        d.kp_x[g] = ux; d.kp_y[g] = uy; d.kp_angle[g] = k.angle; d.kp_octave[g] = k.octave;
     }
 }
 // Frame::PosInGrid + the grid fill (Frame.cc:183-190, 380-390) as the CSR dcs_frame_grid builds on the host: cells (c, ix, iy), entries =
@@ -1238,6 +1265,17 @@ int dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_t
 }
 
 
+int dcs_undistort_points(int n, const float* xy, const float K4[4], const float dist5[5], float* out)
+{
+    if (n < 0 || (n && (!xy || !out)) || !K4 || !dist5) { set_error("dcs_undistort_points: bad argument"); return DCS_ERR_INVALID; }
+    const double c[9] = {K4[0], K4[1], K4[2], K4[3], dist5[0], dist5[1], dist5[2], dist5[3], dist5[4]};
+    for (int i = 0; i < n; ++i) {
+        if (dist5[0] == 0.0f) { out[2 * i] = xy[2 * i]; out[2 * i + 1] = xy[2 * i + 1]; }       // Frame.cc:414-418: the key points are taken as they are
+        else undistort_point(c, xy[2 * i], xy[2 * i + 1], out[2 * i], out[2 * i + 1]);
+    }
+    return DCS_OK;
+}
+
 int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, const dcs_track_params* prm, int mode, int check_orientation,
                            dcs_track_dev_result* res, void* stream)
 {
@@ -1301,6 +1339,10 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
         d = DevAsm{};
         d.kp = df.d_kp; d.desc = df.d_desc; d.n = df.d_n; d.cap = df.cap; d.first_slot = df.first_slot; d.n_cams = C;
         d.n_features = d_nfeat + (size_t)k * kFrMaxCams;
+        for (int c = 0; c < C; ++c) {
+            d.und_on[c] = df.dist && df.K && df.dist[5 * c] != 0.0f;
+            if (d.und_on[c]) { for (int j = 0; j < 4; ++j) d.und[c][j] = (double)df.K[4 * c + j]; for (int j = 0; j < 5; ++j) d.und[c][4 + j] = (double)df.dist[5 * c + j]; }
+        }
         uint8_t *taken_w, *hasp_w; float* pxw_w;
         if ((rc = s.alloc(&d.cam_off, (size_t)C + 1)) || (rc = zeroed(&d.kp_x, (size_t)Ncap)) || (rc = zeroed(&d.kp_y, (size_t)Ncap)) || (rc = zeroed(&d.kp_angle, (size_t)Ncap)) ||
             (rc = zeroed(&d.kp_octave, (size_t)Ncap)) || (rc = s.alloc(&d.desc_out, (size_t)Ncap * 32)) || (rc = s.alloc(&d.grid_off, (size_t)cells + 1)) ||

@@ -740,7 +740,7 @@ def motion_model_problem(n_frames=3, n_points=1200, n_features=900, seed=31, th=
     return frames, prm
 
 
-def scene_from_features(kp_per_cam, desc_per_cam, seed=91, seen=0.8):
+def scene_from_features(kp_per_cam, desc_per_cam, seed=91, seen=0.8, bounds=None):
     """A map that explains a dual frame's REAL extracted features (bench.py's per_frame_total leg: the chain is fed from the extractor's slots, so
     the map has to fit what the extractor found): every key point of camera c is back-projected to a random depth with a true rig pose ->
     a map point (position + noise, normal towards the camera, scale-invariance distances from the key point's octave, descriptor = the
@@ -759,7 +759,10 @@ def scene_from_features(kp_per_cam, desc_per_cam, seed=91, seen=0.8):
     Tg = np.eye(4, dtype=np.float32)
     Tg[:3, :3] = (_rodrigues(rng.normal(0, 0.003, 3)) @ Tgt[:3, :3].astype(np.float64)).astype(np.float32)
     Tg[:3, 3] = (Tgt[:3, 3] + rng.normal(0, 0.008, 3)).astype(np.float32)
-    min_x, max_x, min_y, max_y = np.float32(0.0), np.float32(640.0), np.float32(0.0), np.float32(480.0)
+    # image bounds per camera (Frame::ComputeImageBounds): the image itself, or what the caller derived from the undistorted corners
+    if bounds is None:
+        bounds = (np.zeros(2, np.float32), np.full(2, 640.0, np.float32), np.zeros(2, np.float32), np.full(2, 480.0, np.float32))
+    bmin_x, bmax_x, bmin_y, bmax_y = (np.asarray(v, np.float32) for v in bounds)
     Rsw, tsw, Ow = [], [], []
     for T in ext:
         Tsw = (T.astype(np.float32) @ Tg).astype(np.float32)
@@ -768,8 +771,7 @@ def scene_from_features(kp_per_cam, desc_per_cam, seed=91, seen=0.8):
     view = dict(Rsw=np.array(Rsw, np.float32), tsw=np.array(tsw, np.float32), Ow=np.array(Ow, np.float32),
                 fx=np.array([c["fx"] for c in cams], np.float32), fy=np.array([c["fy"] for c in cams], np.float32),
                 cx=np.array([c["cx"] for c in cams], np.float32), cy=np.array([c["cy"] for c in cams], np.float32),
-                min_x=np.full(2, min_x, np.float32), max_x=np.full(2, max_x, np.float32), min_y=np.full(2, min_y, np.float32),
-                max_y=np.full(2, max_y, np.float32), log_scale_factor=np.float32(np.log(np.float32(1.2))), scale_factors=scale)
+                min_x=bmin_x, max_x=bmax_x, min_y=bmin_y, max_y=bmax_y, log_scale_factor=np.float32(np.log(np.float32(1.2))), scale_factors=scale)
     pos, nrm, mind, maxd, pdesc, qc, qo, qa = [], [], [], [], [], [], [], []
     for c in (0, 1):
         kp, de = kp_per_cam[c], desc_per_cam[c]
@@ -793,6 +795,6 @@ def scene_from_features(kp_per_cam, desc_per_cam, seed=91, seen=0.8):
     q = _quat_from_R(Tg[:3, :3].astype(np.float64))
     frame = dict(view=view, pose=np.concatenate([Tg[:3, 3].astype(np.float64), q]), points=dict(pos=pos, normal=nrm, min_dist=mind, max_dist=maxd), desc=pdesc,
                  mm=dict(pos=pos[sel], desc=pdesc[sel], q_cam=qc[sel], q_octave=qo[sel], q_angle=qa[sel], point=sel),
-                 grid=dict(min_x=np.full(2, min_x, np.float32), min_y=np.full(2, min_y, np.float32),
-                           grid_w_inv=np.full(2, np.float32(64) / np.float32(max_x - min_x), np.float32), grid_h_inv=np.full(2, np.float32(48) / np.float32(max_y - min_y), np.float32)))
+                 grid=dict(min_x=bmin_x, min_y=bmin_y, grid_w_inv=(np.float32(64) / (bmax_x - bmin_x)).astype(np.float32),
+                           grid_h_inv=(np.float32(48) / (bmax_y - bmin_y)).astype(np.float32)))
     return frame, prm

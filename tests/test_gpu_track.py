@@ -283,3 +283,34 @@ def test_track_frame_device_edge_cases(pkg, oracle, synth):
     torch.cuda.synchronize()
     g = pkg.abi.PreparedTrackingDevice([d0], prm, mode=1, check_orientation=True).track()[0]
     assert list(g["n_features"]) == [small, small] and len(g["point_of_feature"]) == 2 * small
+
+
+def test_track_frame_device_undistorts_key_points_like_the_frame_constructor(pkg, oracle, synth):
+    """the shipped rig has k1 = -0.37 (Dual-LenaCV.yaml:17, 30): Frame::UndistortKeyPoints (Frame.cc:410-441) runs on the device when K / dist are given.
+    The chain fed with DISTORTED key points in the slots + the coefficients equals the host-buffer chain fed with the oracle's cv::undistortPoints of them."""
+    frames, prm = synth.tracking_problem(n_frames=2, n_points=900, n_features=700, seed=71)
+    K = np.array([[558.4684, 560.0944, 326.7993, 262.9017], [546.598, 546.254, 332.759, 247.385]], np.float32)
+    dist = np.array([[-0.3689, 0.1627, 0.0, 0.0, 0.0], [-0.361851421593862, 0.140443638558527, 0.0, 0.0, 0.0]], np.float32)
+    und = []
+    for fr in frames:                                           # the synthetic key points play the distorted ones; the host-buffer chain gets their undistorted positions
+        ft = dict(fr["features"])
+        x, y = ft["kp_x"].copy(), ft["kp_y"].copy()
+        for c in (0, 1):
+            a, b = int(ft["cam_off"][c]), int(ft["cam_off"][c + 1])
+            u = oracle.undistort_points(np.stack([x[a:b], y[a:b]], 1), K[c], dist[c])
+            x[a:b], y[a:b] = u[:, 0], u[:, 1]
+        ft["kp_x"], ft["kp_y"] = x, y
+        f2 = dict(fr); f2["features"] = ft
+        und.append(f2)
+        assert np.abs(x - fr["features"]["kp_x"]).max() > 3.0    # the distortion moves key points by pixels
+    _with_grid(pkg, und)
+    ref = pkg.abi.PreparedTracking(und, prm).track()
+    dfr, keep = _device_frames(frames, cap=500, mode=0)
+    for d in dfr:
+        d["dev"]["K"], d["dev"]["dist"] = K, dist
+    got = pkg.abi.PreparedTrackingDevice(dfr, prm, mode=0).track()
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(a["match_of_point"], b["match_of_point"]) and np.array_equal(a["point_of_feature"], b["point_of_feature"]), k
+        assert a["n_matches"] == b["n_matches"] and a["n_inliers"] == b["n_inliers"] and np.array_equal(a["outlier"], b["outlier"]), k
+        assert np.array_equal(a["pose"], b["pose"]), k
+    # dist == NULL / k1 == 0: taken as they are (the other tests of this file)

@@ -559,3 +559,20 @@ def test_search_by_projection_kf_oracle(oracle, synth):
         mq, qf, n = oracle.search_by_projection_kf(frame, q, th)
         assert np.array_equal(mq, out) and np.array_equal(qf, who) and n == int((out >= 0).sum())
     assert n > 40 and len(set(out[out >= 0])) == n                           # every feature matched at most once
+
+
+def test_undistort_points_host_helper_equals_the_oracle(pkg, oracle):
+    """dcs_undistort_points (pure host; the arithmetic the device chain runs per key point) against the oracle's restatement of cv::undistortPoints,
+    bit for bit: the shipped rig's coefficients (Dual-LenaCV.yaml:12-35), one with tangential terms and k3, and k1 == 0 (copied through, Frame.cc:414)."""
+    rng = np.random.default_rng(5)
+    xy = np.concatenate([rng.uniform(-20, 680, (5000, 2)), [[0, 0], [640, 0], [0, 480], [640, 480], [326.7993, 262.9017]]]).astype(np.float32)
+    for K4, dist in (((558.4684, 560.0944, 326.7993, 262.9017), (-0.3689, 0.1627, 0.0, 0.0)),
+                     ((546.598, 546.254, 332.759, 247.385), (-0.361851421593862, 0.140443638558527, 0.0, 0.0)),
+                     ((520.9, 521.0, 325.1, 249.7), (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)),
+                     ((500.0, 500.0, 320.0, 240.0), (0.0, 0.1, 0.0, 0.0))):
+        got = pkg.abi.undistort_points(xy, K4, dist)
+        exp = oracle.undistort_points(xy, K4, list(dist) + [0.0] * (5 - len(dist))) if dist[0] != 0.0 else xy
+        assert np.array_equal(got.view(np.uint32), np.asarray(exp, np.float32).view(np.uint32)), (K4, dist)
+    # the undistorted corners are what Frame::ComputeImageBounds takes its bounds from (Frame.cc:454-476): outside the image for k1 < 0
+    c = pkg.abi.undistort_points(np.array([[0, 0], [640, 0], [0, 480], [640, 480]], np.float32), (558.4684, 560.0944, 326.7993, 262.9017), (-0.3689, 0.1627, 0, 0))
+    assert c[0, 0] < -50 and c[3, 0] > 690 and c[0, 1] < -40 and c[3, 1] > 500
