@@ -175,7 +175,12 @@ __device__ inline double block_sum_256(double v, double* s /*[256]*/)
 enum : int { ST_NEW_ITER = 0, ST_RETRY = 1, ST_ROUND_END = 2, ST_DONE = 3 };
 
 struct BaCtl {
-    int state, round, it, qmax, nBad, cur, errors_current, robust, trace, stopped, n_active, pad0;
+    int state, round, it, qmax, nBad, cur, errors_current, robust, trace, stopped, n_active, fault;
+    // k_front's hand-overs inside one launch (written with release, read with acquire; reset by the trial's finisher in k_update_error):
+    //   need_begin    the step starts with the edge pass of k_begin (round change, stale errors): decided by the PREVIOUS step's finisher
+    //   begin_done    that pass has finished and the control word is final
+    //   lambda_ready  computeLambdaInit of the first iteration of a round has run
+    int need_begin, begin_done, lambda_ready, pad0;
     double mult, ni, currentChi, iniChi, maxdiag, ok, scale, pad1;
     int n_iters[2], n_trials[2];
     double lambda[2], chi2_trace[32];
@@ -190,7 +195,8 @@ struct BaProb {
     const double *obs, *w;                         // [E][2], [E]
     uint8_t *active, *flag, *level1;               // [E]
     double *err, *chi2;                            // [E][2], [E]
-    double *Hpl, *BD, *cpose, *cpoint;             // [E][18], [E][18], [E][27], [E][9]
+    double *Hpl[2], *BD, *cpose[2], *cpoint[2];    // [E][18], [E][18], [E][27], [E][9]; the linearisation is double-buffered like the estimates: [b] belongs to poses[b] / points[b]
+                                                   // (k_update_error linearises the trial estimates it has just evaluated; [1] == [0] when a group runs the six-launch step)
     double *Hll, *bl, *Dinv, *db, *xl;             // per landmark
     double *Hpp, *bp, *bsch, *xp;                  // per free pose
     double *S, *W;                                 // reduced camera system (ld x ld), panel scratch of the n > 256 fallback
@@ -266,6 +272,15 @@ __device__ __forceinline__ void publish_problem_end(int* __restrict__ h_progress
     } while (__hip_atomic_load(grid_ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != v);
 }
 
+// what the NEXT step's k_front needs to know before any of its workgroups has run: does the step start with k_begin's edge pass (round change,
+// or an iteration that ended on a rejected trial and left the errors stale)? After an accepted trial it does not -- the trial kernel has
+// linearised the new estimates already.
+__device__ __forceinline__ void front_handover(BaCtl& ctl)
+{
+    ctl.need_begin = (ctl.state == ST_ROUND_END || (ctl.state == ST_NEW_ITER && !ctl.errors_current)) ? 1 : 0;
+    ctl.begin_done = 0; ctl.lambda_ready = 0;
+}
+
 // accept / reject of a trial (optimization_algorithm_levenberg.cpp:104-164): ONE thread of the problem, after the chi2 of the trial
 // estimates (tot) and computeScale (sc) are known. Always returns true.
 __device__ __forceinline__ bool lm_accept(const BaProb& pb, BaCtl& ctl, const volatile int* __restrict__ stop_words, double tot, double sc)
@@ -291,7 +306,7 @@ __device__ __forceinline__ bool lm_accept(const BaProb& pb, BaCtl& ctl, const vo
     const int qmax = ++ctl.qmax;
     const bool stop = stop_words && __hip_atomic_load(const_cast<const int*>(stop_words + blockIdx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
     if (stop) ctl.stopped = 1;
-    if (rho < 0 && qmax < 10 && !stop) { ctl.state = ST_RETRY; return true; }
+    if (rho < 0 && qmax < 10 && !stop) { ctl.state = ST_RETRY; front_handover(ctl); return true; }
     const int round = ctl.round;
     ++ctl.n_iters[round];
     if (ctl.trace < 32) ctl.chi2_trace[ctl.trace++] = currentChi;
@@ -304,6 +319,7 @@ __device__ __forceinline__ bool lm_accept(const BaProb& pb, BaCtl& ctl, const vo
     const int it = ++ctl.it;
     if (term || stop || it >= pb.iters[round]) ctl.state = ST_ROUND_END;
     else { ctl.state = ST_NEW_ITER; ctl.qmax = 0; ctl.iniChi = currentChi; }
+    front_handover(ctl);
     return true;
 }
 
@@ -387,6 +403,167 @@ __global__ __launch_bounds__(256) void k_error(const BaProb* __restrict__ probs,
 //     round 1 without a single active edge, which ends the problem -- leaves a linearisation nobody reads: every later kernel of the
 //     step tests ctl.state.
 // The end of a problem is decided here: its last block publishes it to the host (publish_problem_end).
+// linearizeOplus + constructQuadraticForm of ONE edge at the estimates of buffer `lb` (the pose T, the camera-frame point pc, the edge's
+// error / chi2 there): cpoint[e] = {Hll 00,01,02,11,12,22, bl0..2}, cpose[e] = {21 upper entries of Hpp row-major, bp0..5}, Hpl[e] = 6x3
+// row-major (pose rows, point cols). Shared by k_begin and by the trial kernel (which linearises the estimates it has just evaluated).
+__device__ __forceinline__ void linearize_edge(const BaProb& pb, int lb, int e, bool act, bool free_pose, const DCam& c, const double* T, const double* pc,
+                                               double err0, double err1, double x2, int robust, double delta)
+{
+    if (!act) {                                            // level-1 edge: adds nothing to any block (the CSR lists still name it)
+        double* cp = pb.cpoint[lb] + (size_t)e * 9;
+        for (int i = 0; i < 9; ++i) cp[i] = 0;
+        if (free_pose) {
+            double* cq = pb.cpose[lb] + (size_t)e * 27;
+            for (int i = 0; i < 27; ++i) cq[i] = 0;
+            double* h = pb.Hpl[lb] + (size_t)e * 18;
+            for (int i = 0; i < 18; ++i) h[i] = 0;
+        }
+        return;
+    }
+    const double x = pc[0], y = pc[1], z = pc[2];
+    const double sz = -1. / z;
+    const double st[6] = {sz * c.fx, sz * 0.0, sz * (-x / z * c.fx), sz * 0.0, sz * c.fy, sz * (-y / z * c.fy)};
+    const double J3[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+    double A[12], Jp[12], Jx[6];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) A[i * 6 + j] = st[i * 3] * J3[j] + st[i * 3 + 1] * J3[6 + j] + st[i * 3 + 2] * J3[12 + j];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) {
+        double acc = 0;
+        for (int k = 0; k < 6; ++k) acc += A[i * 6 + k] * c.adj[k * 6 + j];
+        Jp[i * 6 + j] = acc;
+    }
+    double qt[4], R[9];
+    qmul(c.q, T + 3, qt); qnormalize(qt); qtoR(qt, R);         // rotation of T_ext * T_mcs
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Jx[i * 3 + j] = st[i * 3] * R[j] + st[i * 3 + 1] * R[3 + j] + st[i * 3 + 2] * R[6 + j];
+    double w = pb.w[e];
+    double r0 = -w * err0, r1 = -w * err1;
+    if (robust) {
+        const double rho1 = x2 <= delta * delta ? 1.0 : delta / sqrt(x2);
+        r0 *= rho1; r1 *= rho1; w = rho1 * w;
+    }
+    double* cp = pb.cpoint[lb] + (size_t)e * 9;
+    int k = 0;
+    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) cp[k++] = Jx[i] * w * Jx[j] + Jx[3 + i] * w * Jx[3 + j];
+    for (int i = 0; i < 3; ++i) cp[6 + i] = Jx[i] * r0 + Jx[3 + i] * r1;
+    if (free_pose) {
+        double* cq = pb.cpose[lb] + (size_t)e * 27;
+        k = 0;
+        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) cq[k++] = Jp[i] * w * Jp[j] + Jp[6 + i] * w * Jp[6 + j];
+        for (int i = 0; i < 6; ++i) cq[21 + i] = Jp[i] * r0 + Jp[6 + i] * r1;
+        double* h = pb.Hpl[lb] + (size_t)e * 18;
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) h[i * 3 + j] = Jp[i] * w * Jx[j] + Jp[6 + i] * w * Jx[3 + j];
+    }
+}
+
+// sums over the 256-thread sub-blocks of a workgroup of 256 VB threads, each with block_sum_256's tree (the same bits): the total of the
+// caller's sub-block comes back in all of its threads
+template <int VB>
+__device__ __forceinline__ double vblock_sum_256(double v, double* s /*[256 VB]*/)
+{
+    const int t = threadIdx.x;
+    s[t] = v;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) { if ((t & 255) < d) s[t] += s[t + d]; __syncthreads(); }
+    const double r = s[t & ~255];
+    __syncthreads();
+    return r;
+}
+
+// The body of k_begin for a workgroup of 256 VB threads = VB of its 256-edge blocks (VB = 1: k_begin itself; VB = 4: the first workgroups of
+// k_front). bx = the workgroup's index among the problem's ceil(nblk / VB). The chi2 partials stay per 256-edge block and are added in the same
+// order, so both forms produce the same bits. Returns in its threads after everything the workgroup had to do.
+template <int VB>
+__device__ __forceinline__ void begin_body(const BaProb& pb, BaCtl& ctl, int bx, double* s /*[256 VB]*/, DCams& cams, int& s_cnt, bool& last, int* __restrict__ h_progress,
+                                           unsigned* __restrict__ grid_ticket, bool front)
+{
+    const int nwg = (pb.nblk + VB - 1) / VB, t = threadIdx.x;
+    // the control word as of the end of the previous step: read ONCE -- the problem's last block rewrites it while other blocks
+    // are still in part (2)
+    const int state = ctl.state, round = ctl.round, stopped = ctl.stopped, cur = ctl.cur, robust_in = ctl.robust;
+    const bool round_end = state == ST_ROUND_END, pre = state == ST_NEW_ITER && !ctl.errors_current;
+    const bool next_round = round_end && round == 0 && !stopped && pb.iters[1] > 0;
+    const bool lin = state == ST_NEW_ITER || next_round;           // (2) runs
+    const int robust = round_end ? 0 : robust_in;
+    if (!(round_end || pre || lin)) return;                          // workgroup-uniform
+    const double* __restrict__ poses = pb.poses[cur];
+    const double* __restrict__ points = pb.points[cur];
+    const double delta = pb.delta;
+    if (t == 0) s_cnt = 0;
+    load_cams(&cams, pb.cams);
+    const int vb = bx * VB + (t >> 8);                               // the 256-edge block of this thread
+    const int e = bx * (256 * VB) + t;
+    const bool in = e < pb.E;
+    double rho0 = 0, pc[3] = {0, 0, 1}, err0 = 0, err1 = 0, x2 = 0;
+    bool act = false;
+    int ps = 0, cam_id = 0;
+    if (in) {
+        ps = pb.epose[e]; cam_id = pb.ecam[e];
+        cam_point(poses + 7 * ps, points + 3 * pb.epoint[e], cams.c[cam_id], pc);
+        act = pb.active[e] != 0;
+    }
+    if (round_end || pre) {
+        if (in) {
+            const DCam& c = cams.c[cam_id];
+            if (round_end) {
+                const uint8_t f = (pb.chi2[e] > pb.chi2_th || !(pc[2] > 0.0)) ? 1 : 0;
+                pb.flag[e] = f;
+                if (round == 0) {
+                    pb.level1[e] = stopped ? 0 : f;
+                    if (!stopped) { act = !f; pb.active[e] = act; if (act) atomicAdd(&s_cnt, 1); }
+                }
+            }
+            if ((pre || next_round) && act) {
+                err0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+                err1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+                const double w = pb.w[e];
+                x2 = err0 * (w * err0) + err1 * (w * err1);
+                pb.err[2 * e] = err0; pb.err[2 * e + 1] = err1; pb.chi2[e] = x2;
+                if (robust && x2 > delta * delta) rho0 = 2 * sqrt(x2) * delta - delta * delta; else rho0 = x2;
+            }
+        }
+        if (round_end) {
+            for (int i = bx * (256 * VB) + t; i < 7 * pb.P; i += nwg * (256 * VB)) pb.out_poses[i] = poses[i];
+            for (int i = bx * (256 * VB) + t; i < 3 * pb.L; i += nwg * (256 * VB)) pb.out_points[i] = points[i];
+        }
+    } else if (in && act) {                                    // errors are current (written by the accepted trial's k_error<1>)
+        err0 = pb.err[2 * e]; err1 = pb.err[2 * e + 1]; x2 = pb.chi2[e];
+    }
+    // ---- (2) linearizeOplus + constructQuadraticForm. In FRONT of the ticket: in k_front the pass is over for the rest of the launch as soon as
+    // the last workgroup has arrived there
+    if (lin && in) linearize_edge(pb, cur, e, act, pb.pose_idx[ps] >= 0, cams.c[cam_id], poses + 7 * ps, pc, err0, err1, x2, robust, delta);
+    if (!(round_end || pre)) return;                                 // workgroup-uniform
+    const double tsum = vblock_sum_256<VB>(rho0, s);                 // (its barriers also order every thread's stores before thread 0's release)
+    if ((t & 255) == 0 && vb < pb.nblk) __hip_atomic_store(&pb.partial[vb], tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (VB > 1) __syncthreads();                                     // the sub-blocks' partials are stored before thread 0 releases them
+    if (t == 0) {
+        if (s_cnt) atomicAdd(&ctl.n_active, s_cnt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(pb.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nwg - 1;
+    }
+    __syncthreads();
+    if (!last) return;                                               // workgroup-uniform
+    // ---- the problem's last workgroup: the chi2 total in block order, the round change / the end of the problem
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    double v = 0;
+    if (t < 256) for (int i = t; i < pb.nblk; i += 256) v += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double tot = vblock_sum_256<VB>(v, s);                     // sub-block 0 = block_sum_256 over threads 0..255
+    if (t == 0) {
+        __hip_atomic_store(pb.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int n_act = __hip_atomic_load(&ctl.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool done = false;
+        if (pre || (next_round && n_act > 0)) {
+            if (next_round) { ctl.round = 1; ctl.it = 0; ctl.qmax = 0; ctl.nBad = 0; ctl.robust = 0; }   // Optimizer.cc:612-621
+            ctl.currentChi = tot; ctl.iniChi = tot; ctl.errors_current = 1; ctl.state = ST_NEW_ITER;
+        } else { ctl.state = ST_DONE; done = true; }
+        if (front) {                                                 // the rest of k_front's workgroups wait for this word
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(&ctl.begin_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (done) publish_problem_end(h_progress, grid_ticket);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_begin(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int* __restrict__ h_progress,
                                                unsigned* __restrict__ grid_ticket)
 {
@@ -395,134 +572,7 @@ __global__ __launch_bounds__(256) void k_begin(const BaProb* __restrict__ probs,
     __shared__ int s_cnt;
     __shared__ bool last;
     const BaProb& pb = probs[blockIdx.y];
-    BaCtl& ctl = ctls[blockIdx.y];
-    if ((int)blockIdx.x < pb.nblk) {
-        // the control word as of the end of the previous step: read ONCE -- the problem's last block rewrites it while other blocks
-        // are still in part (2)
-        const int state = ctl.state, round = ctl.round, stopped = ctl.stopped, cur = ctl.cur, robust_in = ctl.robust;
-        const bool round_end = state == ST_ROUND_END, pre = state == ST_NEW_ITER && !ctl.errors_current;
-        const bool next_round = round_end && round == 0 && !stopped && pb.iters[1] > 0;
-        const bool lin = state == ST_NEW_ITER || next_round;           // (2) runs
-        const int robust = round_end ? 0 : robust_in;
-        if (round_end || pre || lin) {                                   // block-uniform
-            const double* __restrict__ poses = pb.poses[cur];
-            const double* __restrict__ points = pb.points[cur];
-            const double delta = pb.delta;
-            if (threadIdx.x == 0) s_cnt = 0;
-            load_cams(&cams, pb.cams);
-            const int e = blockIdx.x * 256 + threadIdx.x;
-            const bool in = e < pb.E;
-            double rho0 = 0, pc[3] = {0, 0, 1}, err0 = 0, err1 = 0, x2 = 0;
-            bool act = false;
-            int ps = 0, cam_id = 0;
-            if (in) {
-                ps = pb.epose[e]; cam_id = pb.ecam[e];
-                cam_point(poses + 7 * ps, points + 3 * pb.epoint[e], cams.c[cam_id], pc);
-                act = pb.active[e] != 0;
-            }
-            if (round_end || pre) {
-                if (in) {
-                    const DCam& c = cams.c[cam_id];
-                    if (round_end) {
-                        const uint8_t f = (pb.chi2[e] > pb.chi2_th || !(pc[2] > 0.0)) ? 1 : 0;
-                        pb.flag[e] = f;
-                        if (round == 0) {
-                            pb.level1[e] = stopped ? 0 : f;
-                            if (!stopped) { act = !f; pb.active[e] = act; if (act) atomicAdd(&s_cnt, 1); }
-                        }
-                    }
-                    if ((pre || next_round) && act) {
-                        err0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
-                        err1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
-                        const double w = pb.w[e];
-                        x2 = err0 * (w * err0) + err1 * (w * err1);
-                        pb.err[2 * e] = err0; pb.err[2 * e + 1] = err1; pb.chi2[e] = x2;
-                        if (robust && x2 > delta * delta) rho0 = 2 * sqrt(x2) * delta - delta * delta; else rho0 = x2;
-                    }
-                }
-                if (round_end) {
-                    for (int i = blockIdx.x * 256 + threadIdx.x; i < 7 * pb.P; i += pb.nblk * 256) pb.out_poses[i] = poses[i];
-                    for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * pb.L; i += pb.nblk * 256) pb.out_points[i] = points[i];
-                }
-                const double t = block_sum_256(rho0, s);
-                if (threadIdx.x == 0) {
-                    if (s_cnt) atomicAdd(&ctl.n_active, s_cnt);
-                    __hip_atomic_store(&pb.partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    last = __hip_atomic_fetch_add(pb.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)pb.nblk - 1;
-                }
-                __syncthreads();
-                if (last) {                                           // block-uniform
-                    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    __syncthreads();
-                    double v = 0;
-                    for (int i = threadIdx.x; i < pb.nblk; i += 256) v += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double tot = block_sum_256(v, s);
-                    if (threadIdx.x == 0) {
-                        __hip_atomic_store(pb.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int n_act = __hip_atomic_load(&ctl.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (pre || (next_round && n_act > 0)) {
-                            if (next_round) { ctl.round = 1; ctl.it = 0; ctl.qmax = 0; ctl.nBad = 0; ctl.robust = 0; }   // Optimizer.cc:612-621
-                            ctl.currentChi = tot; ctl.iniChi = tot; ctl.errors_current = 1; ctl.state = ST_NEW_ITER;
-                        } else { ctl.state = ST_DONE; publish_problem_end(h_progress, grid_ticket); }
-                    }
-                }
-            } else if (in && act) {                                    // errors are current (written by the accepted trial's k_error<1>)
-                err0 = pb.err[2 * e]; err1 = pb.err[2 * e + 1]; x2 = pb.chi2[e];
-            }
-            // ---- (2) linearizeOplus + constructQuadraticForm
-            if (lin && in) {
-                const int32_t* __restrict__ pose_idx = pb.pose_idx;
-                const bool free_pose = pose_idx[ps] >= 0;
-                if (!act) {                                            // level-1 edge: adds nothing to any block (the CSR lists still name it)
-                    double* cp = pb.cpoint + (size_t)e * 9;
-                    for (int i = 0; i < 9; ++i) cp[i] = 0;
-                    if (free_pose) {
-                        double* cq = pb.cpose + (size_t)e * 27;
-                        for (int i = 0; i < 27; ++i) cq[i] = 0;
-                        double* h = pb.Hpl + (size_t)e * 18;
-                        for (int i = 0; i < 18; ++i) h[i] = 0;
-                    }
-                } else {
-                    const DCam& c = cams.c[cam_id];
-                    const double* T = poses + 7 * ps;
-                    const double x = pc[0], y = pc[1], z = pc[2];
-                    const double sz = -1. / z;
-                    const double st[6] = {sz * c.fx, sz * 0.0, sz * (-x / z * c.fx), sz * 0.0, sz * c.fy, sz * (-y / z * c.fy)};
-                    const double J3[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
-                    double A[12], Jp[12], Jx[6];
-                    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) A[i * 6 + j] = st[i * 3] * J3[j] + st[i * 3 + 1] * J3[6 + j] + st[i * 3 + 2] * J3[12 + j];
-                    for (int i = 0; i < 2; ++i) for (int j = 0; j < 6; ++j) {
-                        double acc = 0;
-                        for (int k = 0; k < 6; ++k) acc += A[i * 6 + k] * c.adj[k * 6 + j];
-                        Jp[i * 6 + j] = acc;
-                    }
-                    double qt[4], R[9];
-                    qmul(c.q, T + 3, qt); qnormalize(qt); qtoR(qt, R);         // rotation of T_ext * T_mcs
-                    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Jx[i * 3 + j] = st[i * 3] * R[j] + st[i * 3 + 1] * R[3 + j] + st[i * 3 + 2] * R[6 + j];
-                    double w = pb.w[e];
-                    double r0 = -w * err0, r1 = -w * err1;
-                    if (robust) {
-                        const double rho1 = x2 <= delta * delta ? 1.0 : delta / sqrt(x2);
-                        r0 *= rho1; r1 *= rho1; w = rho1 * w;
-                    }
-                    double* cp = pb.cpoint + (size_t)e * 9;
-                    int k = 0;
-                    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) cp[k++] = Jx[i] * w * Jx[j] + Jx[3 + i] * w * Jx[3 + j];
-                    for (int i = 0; i < 3; ++i) cp[6 + i] = Jx[i] * r0 + Jx[3 + i] * r1;
-                    if (free_pose) {
-                        double* cq = pb.cpose + (size_t)e * 27;
-                        k = 0;
-                        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) cq[k++] = Jp[i] * w * Jp[j] + Jp[6 + i] * w * Jp[6 + j];
-                        for (int i = 0; i < 6; ++i) cq[21 + i] = Jp[i] * r0 + Jp[6 + i] * r1;
-                        double* h = pb.Hpl + (size_t)e * 18;
-                        for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) h[i * 3 + j] = Jp[i] * w * Jx[j] + Jp[6 + i] * w * Jx[3 + j];
-                    }
-                }
-            }
-        }
-    }
+    if ((int)blockIdx.x < pb.nblk) begin_body<1>(pb, ctls[blockIdx.y], blockIdx.x, s, cams, s_cnt, last, h_progress, grid_ticket, false);
 }
 
 // block (1024 threads) per free pose: 37 edge chunks x 27 components, combined in chunk order (deterministic). The
@@ -532,13 +582,13 @@ constexpr int kPoseChunks = 37;
 // Hessian blocks in maxd_part[], and at the first iteration of a round the last block to finish (ticket) takes the maximum of
 // those np + nb_pts numbers -- a max is order-independent, so the result is reproducible -- and resets the LM multipliers.
 // Called by the first wave of a block with a wave-uniform `md`.
-__device__ __forceinline__ void reduce_finish(const BaProb& pb, BaCtl& ctl, double md)
+__device__ __forceinline__ void reduce_finish(const BaProb& pb, BaCtl& ctl, double md, int slot, int n_blk, bool front)
 {
     if (ctl.it != 0) return;                                 // block-uniform: lambda is only initialised at the first iteration
-    const int lane = threadIdx.x & 63, n_blk = pb.np + pb.nb_pts;
+    const int lane = threadIdx.x & 63;
     int last = 0;
     if (lane == 0) {
-        __hip_atomic_store(&pb.maxd_part[blockIdx.x], md, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pb.maxd_part[slot], md, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         last = __hip_atomic_fetch_add(pb.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)n_blk - 1;
@@ -553,6 +603,10 @@ __device__ __forceinline__ void reduce_finish(const BaProb& pb, BaCtl& ctl, doub
     if (lane == 0) {
         ctl.maxdiag = m; ctl.mult = 1.0; ctl.ni = 2; ctl.nBad = 0;       // lambda = tau * max diagonal, tau = 1e-5
         __hip_atomic_store(pb.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (front) {                                         // k_front: the landmark and edge workgroups of this launch wait for lambda
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(&ctl.lambda_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -562,7 +616,7 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__
     __shared__ double s[27];
     const BaProb& pb = probs[blockIdx.y];
     if (ctls[blockIdx.y].state != ST_NEW_ITER) return;
-    const int np = pb.np;
+    const int np = pb.np, cur = ctls[blockIdx.y].cur;
     if ((int)blockIdx.x >= np + pb.nb_pts) return;
     if ((int)blockIdx.x >= np) {                             // blocks past the free poses: 64 landmarks each (thread per landmark)
         if (threadIdx.x >= 64) return;
@@ -572,7 +626,7 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__
         for (int k = l < pb.L ? pb.pt_off[l] : 0, k1 = l < pb.L ? pb.pt_off[l + 1] : 0; k < k1; ++k) {
             const int e = pb.pt_edges[k];
             n_act += pb.active[e];
-            const double* c = pb.cpoint + (size_t)e * 9;
+            const double* c = pb.cpoint[cur] + (size_t)e * 9;
             for (int i = 0; i < 9; ++i) a[i] += c[i];
         }
         // NOTE: threads of this branch must all reach the block's finisher below (no early return for l >= L)
@@ -586,12 +640,12 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) md = fmax(md, __shfl_xor(md, d));
-        reduce_finish(pb, ctls[blockIdx.y], md);
+        reduce_finish(pb, ctls[blockIdx.y], md, blockIdx.x, pb.np + pb.nb_pts, false);
         return;
     }
     const int32_t* __restrict__ ps_off = pb.ps_off;
     const int32_t* __restrict__ ps_edges = pb.ps_edges;
-    const double* __restrict__ cpose = pb.cpose;
+    const double* __restrict__ cpose = pb.cpose[cur];
     const int i = blockIdx.x, t = threadIdx.x;
     const int c = t % 27, q = t / 27;
     if (q < kPoseChunks) {
@@ -611,7 +665,7 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__
     if (t < 6) pb.bp[i * 6 + t] = s[21 + t];
     if (t < 64) {                                            // wave 0: max |diagonal| of this pose block (entries 0, 6, 11, 15, 18, 20 of the packed upper triangle)
         const double md = fmax(fmax(fmax(fabs(s[0]), fabs(s[6])), fmax(fabs(s[11]), fabs(s[15]))), fmax(fabs(s[18]), fabs(s[20])));
-        reduce_finish(pb, ctls[blockIdx.y], md);
+        reduce_finish(pb, ctls[blockIdx.y], md, blockIdx.x, pb.np + pb.nb_pts, false);
     }
 }
 
@@ -641,7 +695,7 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
         for (int i = 0; i < 9; ++i) H[i] = Hll[(size_t)l * 9 + i];
         H[0] += lambda; H[4] += lambda; H[8] += lambda;
         inv3(H, D);
-        const double* B = pb.Hpl + (size_t)e * 18;
+        const double* B = pb.Hpl[ctl.cur] + (size_t)e * 18;
         for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = B[r * 3] * D[c] + B[r * 3 + 1] * D[3 + c] + B[r * 3 + 2] * D[6 + c];
         return;
     }
@@ -655,6 +709,223 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
     const double* bl = pb.bl;
     for (int i = 0; i < 9; ++i) pb.Dinv[(size_t)l * 9 + i] = D[i];
     for (int i = 0; i < 3; ++i) pb.db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
+}
+
+// ---- k_front: k_begin + k_reduce_pose + k_prep as ONE launch (round 5; a launch boundary costs an LM step ~5 us and the step had six).
+// What makes it possible: k_update_error linearises the trial estimates it has just evaluated into the other half of the double-buffered
+// blocks, so a step that follows an accepted trial has nothing left to do per edge -- k_begin's edge pass only runs at the start of a round
+// and after an iteration that ended on a rejected trial (ctl.need_begin, decided by the previous step's finisher). Workgroups of 1024 threads,
+// by index:
+//   [0, nwg_b)            begin_body<4> -- returns at once unless need_begin
+//   [.., + np)            one free pose each: k_reduce_pose's pose blocks
+//   [.., + nb_l)          1024 landmarks each: H_ll / b_l sums (k_reduce_pose), then (H_ll + lambda I)^-1 and D^-1 b_l (k_prep)
+//   [.., + nwg_b)         thread per edge: BD[e] = H_pl[e] (H_ll + lambda I)^-1 with the landmark's H_ll summed again in the same order (no wait for
+//                         the landmark workgroups)
+// Two hand-overs inside the launch, both from workgroups of LOWER index (dispatched earlier) to workgroups that have already done what others
+// wait for -- so nobody waits for a workgroup that cannot start: (1) need_begin: everyone behind the edge pass waits for begin_done; (2) first
+// iteration of a round: lambda comes from computeLambdaInit, i.e. from the last of the pose + landmark workgroups (lambda_ready); landmark
+// workgroups arrive there BEFORE they wait. The waits are bounded (kFrontSpin polls): on expiry the problem is marked (ctl.fault) and the call
+// fails instead of hanging the queue. The host only picks this launch for problems whose landmark workgroups are all resident at once.
+#ifndef DCS_FRONT_AB
+#define DCS_FRONT_AB 0
+#endif
+constexpr int kFrontThreads = 512;                      // 8 waves: 256 VGPRs per thread (begin_body needs 134; 1024 threads = 128 = spills)
+constexpr int kFrontVB = kFrontThreads / 256;
+constexpr int kFrontSpin = 1 << 22;
+constexpr int kFrontMaxPoints = 128 * kFrontThreads;    // 128 landmark workgroups of one problem: resident together on any part of the chip the solver may be confined to
+__device__ __forceinline__ bool front_wait(const int* flag, BaCtl& ctl, int& s_flag)      // whole workgroup; true = the word was seen
+{
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int i = 0; i < kFrontSpin; ++i) {
+            if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!ok) __hip_atomic_store(&ctl.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // every wave: what the other workgroups wrote before the word
+    return s_flag != 0;
+}
+
+#ifdef DCS_FRONT_PROF
+__device__ long long g_front_prof[4096];                     // [launch % 16][workgroup < 128][start, end] in 100 MHz ticks
+__device__ int g_front_launch;
+struct FrontProf {
+    int slot;
+    __device__ FrontProf() { slot = -1; if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 128) { slot = ((g_front_launch & 15) * 128 + blockIdx.x) * 2; g_front_prof[slot] = (long long)__builtin_amdgcn_s_memrealtime(); } }
+    __device__ ~FrontProf() { if (slot >= 0) g_front_prof[slot + 1] = (long long)__builtin_amdgcn_s_memrealtime(); }
+};
+#endif
+__global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int* __restrict__ h_progress,
+                                                         unsigned* __restrict__ grid_ticket)
+{
+#ifdef DCS_FRONT_PROF
+    FrontProf prof_scope;
+#endif
+    __shared__ double s[kPoseChunks * 27 + 27 > kFrontThreads ? kPoseChunks * 27 + 27 : kFrontThreads];   // begin_body's sums | the pose workgroup's part[37][27] + s[27]
+    __shared__ DCams cams;
+    __shared__ int s_cnt, s_flag;
+    __shared__ bool last;
+    __shared__ double s_md[kFrontThreads / 64];
+    const BaProb& pb = probs[blockIdx.y];
+    BaCtl& ctl = ctls[blockIdx.y];
+    const int t = threadIdx.x, L = pb.L, np = pb.np;
+    const int nwg_b = (pb.nblk + kFrontVB - 1) / kFrontVB, nb_l = (L + kFrontThreads - 1) / kFrontThreads, nwg_e = np ? nwg_b : 0;
+    int bx = blockIdx.x;
+    if (bx >= nwg_b + np + nb_l + nwg_e) return;
+    if (ctl.state == ST_DONE) return;                        // (only begin_body ends a problem: a later look at the word can only see it MORE advanced)
+    const int need_begin = ctl.need_begin;                   // written by the previous step (or k_ctl_init): the same in every workgroup
+    if (bx < nwg_b) {
+        if (need_begin) begin_body<kFrontVB>(pb, ctl, bx, s, cams, s_cnt, last, h_progress, grid_ticket, true);
+        return;
+    }
+    bx -= nwg_b;
+    if (need_begin && !front_wait(&ctl.begin_done, ctl, s_flag)) return;
+    const int state = __hip_atomic_load(&ctl.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // final now: begin_body's last workgroup may have rewritten the word
+    if (state > ST_RETRY) return;
+    const int cur = ctl.cur;
+    const bool new_iter = state == ST_NEW_ITER, first = new_iter && __hip_atomic_load(&ctl.it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    if (bx < np) {                                           // ---- one free pose (k_reduce_pose)
+#if DCS_FRONT_AB == 2
+        return;
+#endif
+        if (!new_iter) return;
+        double (*part)[27] = reinterpret_cast<double (*)[27]>(s);
+        double* const s27 = s + kPoseChunks * 27;
+        const int32_t* __restrict__ ps_off = pb.ps_off;
+        const int32_t* __restrict__ ps_edges = pb.ps_edges;
+        const double* __restrict__ cpose = pb.cpose[cur];
+        const int i = bx;
+        // k_reduce_pose's 37 chunk sums with 18 thread rows: row q keeps the chunks q, q + 18 and (row 0) 36 in accumulators of their own and walks them
+        // together -- the same sums in the same order, as many loads in flight per thread
+        constexpr int kRows = kFrontThreads / 27;
+        static_assert(kRows * 3 >= kPoseChunks && kRows * 2 < kPoseChunks + kRows, "three chunks per thread row cover the 37");
+        const int c = t % 27, q = t / 27;
+        if (q < kRows) {
+            double a0 = 0, a1 = 0, a2 = 0;
+            const int k1 = ps_off[i + 1];
+            const bool has1 = q + kRows < kPoseChunks, has2 = q + 2 * kRows < kPoseChunks;
+#pragma unroll 2
+            for (int k = ps_off[i] + q; k < k1; k += kPoseChunks) {
+                a0 += cpose[(size_t)ps_edges[k] * 27 + c];
+                if (has1 && k + kRows < k1) a1 += cpose[(size_t)ps_edges[k + kRows] * 27 + c];
+                if (has2 && k + 2 * kRows < k1) a2 += cpose[(size_t)ps_edges[k + 2 * kRows] * 27 + c];
+            }
+            // a chunk whose first entry lies past the end never enters the loop above when chunk q is empty too: chunks are nested (q < q + 18 < q + 36), so an
+            // empty chunk q means empty q + 18 and q + 36
+            part[q][c] = a0;
+            if (has1) part[q + kRows][c] = a1;
+            if (has2) part[q + 2 * kRows][c] = a2;
+        }
+        __syncthreads();
+        if (t < 27) { double a = 0; for (int q2 = 0; q2 < kPoseChunks; ++q2) a += part[q2][t]; s27[t] = a; }
+        __syncthreads();
+        if (t < 36) {
+            const int r = t / 6, qq = t % 6, lo = min(r, qq), hi = max(r, qq);
+            pb.Hpp[(size_t)i * 36 + t] = s27[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+        }
+        if (t < 6) pb.bp[i * 6 + t] = s27[21 + t];
+        if (t < 64 && first) {
+            const double md = fmax(fmax(fmax(fabs(s27[0]), fabs(s27[6])), fmax(fabs(s27[11]), fabs(s27[15]))), fmax(fabs(s27[18]), fabs(s27[20])));
+            reduce_finish(pb, ctl, md, bx, np + nb_l, true);
+        }
+        return;
+    }
+    bx -= np;
+    const double* __restrict__ cpoint = pb.cpoint[cur];
+    if (bx < nb_l) {                                         // ---- 1024 landmarks: thread per landmark
+#if DCS_FRONT_AB == 3
+        return;
+#endif
+        const int l = bx * kFrontThreads + t;
+        double H[9];
+        bool on = false;
+        if (new_iter) {
+            double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            int n_act = 0;
+            for (int k = l < L ? pb.pt_off[l] : 0, k1 = l < L ? pb.pt_off[l + 1] : 0; k < k1; ++k) {
+                const int e = pb.pt_edges[k];
+                n_act += pb.active[e];
+                const double* c = cpoint + (size_t)e * 9;
+                for (int i = 0; i < 9; ++i) a[i] += c[i];
+            }
+            double md = 0.0;
+            if (l < L) {
+                on = n_act > 0;
+                pb.pt_active[l] = on;                        // a landmark without active edges is not part of this round
+                H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
+                double* Hg = pb.Hll + (size_t)l * 9;
+                for (int i = 0; i < 9; ++i) Hg[i] = H[i];
+                pb.bl[3 * l] = a[6]; pb.bl[3 * l + 1] = a[7]; pb.bl[3 * l + 2] = a[8];
+                if (on) md = fmax(fmax(fabs(a[0]), fabs(a[3])), fabs(a[5]));
+            }
+            if (first) {                                     // workgroup-uniform
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) md = fmax(md, __shfl_xor(md, d));
+                if ((t & 63) == 0) s_md[t >> 6] = md;
+                __syncthreads();
+                if (t < 64) {
+                    double m = t < kFrontThreads / 64 ? s_md[t] : 0.0;
+#pragma unroll
+                    for (int d = 8; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d));
+                    m = __shfl(m, 0);
+                    reduce_finish(pb, ctl, m, np + bx, np + nb_l, true);
+                }
+            }
+        } else if (l < L) {
+            on = pb.pt_active[l];
+            if (on) for (int i = 0; i < 9; ++i) H[i] = pb.Hll[(size_t)l * 9 + i];
+        }
+        if (first && !front_wait(&ctl.lambda_ready, ctl, s_flag)) return;
+        const double lambda = 1e-5 * __hip_atomic_load(&ctl.maxdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * __hip_atomic_load(&ctl.mult, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // computeLambdaInit (tau = 1e-5) x the LM multiplier
+        if (l == 0) ctl.ok = 1.0;                            // reset the "factorisation succeeded" flag of this trial
+        if (l >= L || !on) return;
+        double D[9];
+        H[0] += lambda; H[4] += lambda; H[8] += lambda;
+        inv3(H, D);
+        const double* bl = pb.bl;
+        for (int i = 0; i < 9; ++i) pb.Dinv[(size_t)l * 9 + i] = D[i];
+        for (int i = 0; i < 3; ++i) pb.db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
+        return;
+    }
+    bx -= nb_l;
+    {                                                        // ---- 1024 edges: BD[e] = Hpl[e] (Hll + lambda I)^-1
+#if DCS_FRONT_AB == 4
+        return;
+#endif
+        const int e = bx * kFrontThreads + t;
+        const bool mine = e < pb.E && pb.pose_idx[pb.epose[e]] >= 0;
+        const bool act = mine && pb.active[e];
+        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (act) {
+            const int l = pb.epoint[e];
+            if (new_iter && DCS_FRONT_AB != 1) {
+                double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int k = pb.pt_off[l], k1 = pb.pt_off[l + 1]; k < k1; ++k) {
+                    const double* c = cpoint + (size_t)pb.pt_edges[k] * 9;
+                    for (int i = 0; i < 9; ++i) a[i] += c[i];
+                }
+                H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
+            } else {
+                for (int i = 0; i < 9; ++i) H[i] = pb.Hll[(size_t)l * 9 + i];
+            }
+        }
+        if (first && !front_wait(&ctl.lambda_ready, ctl, s_flag)) return;
+        if (!mine) return;
+        double* o = pb.BD + (size_t)e * 18;
+        if (!act) {                                          // level-1 edge: still named by the pair lists, contributes zero
+            for (int i = 0; i < 18; ++i) o[i] = 0.0;
+            return;
+        }
+        const double lambda = 1e-5 * __hip_atomic_load(&ctl.maxdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * __hip_atomic_load(&ctl.mult, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double D[9];
+        H[0] += lambda; H[4] += lambda; H[8] += lambda;
+        inv3(H, D);
+        const double* Bm = pb.Hpl[cur] + (size_t)e * 18;
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = Bm[r * 3] * D[c] + Bm[r * 3 + 1] * D[3 + c] + Bm[r * 3 + 2] * D[6 + c];
+    }
 }
 
 // Storage of the reduced camera system for k_ldlt_mfma (use_reg == 1): the lower triangle as 16x16 TILES in the order and the register
@@ -689,7 +960,7 @@ __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(c
     if (ctl.state > ST_RETRY || pb.np == 0) return;
     const int n_pairs = pb.n_pairs;
     if ((int)blockIdx.x >= n_pairs + pb.np) return;
-    const double* __restrict__ Hpl = pb.Hpl;
+    const double* __restrict__ Hpl = pb.Hpl[ctl.cur];
     if ((int)blockIdx.x >= n_pairs) {                        // blocks past the pair list: reduced right-hand side of one free pose (dispatching them FIRST was measured: 20.4 vs 19.6 us)
         // bsch = bp - sum_e Hpl[e] db[point(e)]; kSchurRhsChunks edge chunks x 6 rows, combined in chunk order
         static_assert(kSchurRhsChunks * 6 <= kSchurFine * 36 && kSchurRhsChunks * 6 <= kSchurThreads, "rhs partials live in `part`");
@@ -1559,7 +1830,7 @@ __global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ 
                     for (; k < k1; ++k) {
                         const int e_n = k + 1 < k1 ? pt_edges[k + 1] : 0, pi_n = k + 1 < k1 ? pt_pi[k + 1] : -1;
                         if (pi >= 0) {
-                            const double* B = pb.Hpl + (size_t)e * 18;
+                            const double* B = pb.Hpl[ctl.cur] + (size_t)e * 18;
                             const double* xq = xp + pi * 6;
                             for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) c[j] -= B[r * 3 + j] * xq[r];
                         }
@@ -1621,6 +1892,7 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* s /*[51
     for (int d = 256; d >= 1; d >>= 1) { if (t < d) { s[t] += s[t + d]; s2[t] += s2[t + d]; } __syncthreads(); }
     a = s[0]; b = s2[0];
 }
+template <bool SPEC>      // SPEC: also linearise the trial estimates into the other half of the double-buffered blocks (the step of k_front)
 __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, const volatile int* __restrict__ stop_words, int B,
                                                       int* __restrict__ h_progress, unsigned* __restrict__ grid_ticket)
 {
@@ -1675,7 +1947,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __
             for (int k = pb.pt_off[l] + sub; k < k1; k += 4) {
                 const int pi = pt_pi[k];
                 if (pi < 0) continue;
-                const double* Bm = pb.Hpl + (size_t)pt_edges[k] * 18;
+                const double* Bm = pb.Hpl[cur] + (size_t)pt_edges[k] * 18;
                 const double* xq = xp + pi * 6;
                 for (int j = 0; j < 3; ++j) for (int r = 0; r < 6; ++r) acc[j] += Bm[r * 3 + j] * xq[r];
             }
@@ -1715,16 +1987,23 @@ __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __
         const int32_t* __restrict__ pt_edges = pb.pt_edges;
         for (int k = k0 + t; k < k1; k += kFusedThreads) {
             const int e = pt_edges[k];
-            if (!pb.active[e]) continue;
+            const bool act = pb.active[e] != 0;
+            if (!SPEC && !act) continue;
             double pc[3];
+            const int ps = pb.epose[e];
             const DCam& c = cams.c[pb.ecam[e]];
-            cam_point(s_pose + 7 * pb.epose[e], s_pt + 3 * (pb.epoint[e] - l0), c, pc);
-            const double e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
-            const double e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
-            const double w = pb.w[e];
-            const double x2 = e0 * (w * e0) + e1 * (w * e1);
-            pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
-            rho0 += (robust && x2 > delta * delta) ? 2 * sqrt(x2) * delta - delta * delta : x2;
+            cam_point(s_pose + 7 * ps, s_pt + 3 * (pb.epoint[e] - l0), c, pc);
+            double e0 = 0, e1 = 0, x2 = 0;
+            if (act) {
+                e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+                e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+                const double w = pb.w[e];
+                x2 = e0 * (w * e0) + e1 * (w * e1);
+                pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
+                rho0 += (robust && x2 > delta * delta) ? 2 * sqrt(x2) * delta - delta * delta : x2;
+            }
+            // the accepted trial's estimates are the next iteration's linearisation point: the blocks go to the half that belongs to them
+            if (SPEC) linearize_edge(pb, cur ^ 1, e, act, pose_idx[ps] >= 0, c, s_pose + 7 * ps, pc, e0, e1, x2, robust, delta);
         }
     }
     block_sum2(rho0, sc, s, s2);                             // thread 0: chi2 and computeScale partials of this workgroup
@@ -1758,6 +2037,7 @@ __global__ __launch_bounds__(1024) void k_ctl_init(const BaProb* __restrict__ pr
         c.state = probs[b].iters[0] > 0 ? ST_NEW_ITER : ST_ROUND_END;
         c.robust = probs[b].robust0;
         c.mult = 1.0; c.ni = 2; c.ok = 1.0;
+        c.need_begin = 1;                                    // the first step: errors of the initial estimates (or the flags straight away)
         ctls[b] = c;
     }
 }
@@ -3042,6 +3322,18 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     int g_begin[BaContext::kMaxGroups + 1];
     for (int g = 0; g <= G; ++g) g_begin[g] = (int)((long long)NB * g / G);
     unsigned* d_grid_ticket[BaContext::kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+    // The four-launch step (k_front, k_schur, LDL^T, k_update_error<true>) per GROUP: every problem of the group must fit the fused trial kernel
+    // (poses in LDS) and have few enough landmark workgroups that all of them are resident at once (k_front's lambda hand-over).
+    const bool front_opt = opt(OPT_BA_FRONT) != 0 && opt(OPT_BA_FUSED_UPDATE) != 0 && !tl_tap;
+    bool group_front[BaContext::kMaxGroups];
+    std::vector<char> front_of((size_t)NB, 0);
+    for (int g = 0; g < G; ++g) {
+        bool f = front_opt;
+        for (int i = g_begin[g]; i < g_begin[g + 1]; ++i)
+            if (problems[live[i]]->n_poses > kFusedMaxPoses || problems[live[i]]->n_points > kFrontMaxPoints) f = false;
+        group_front[g] = f;
+        for (int i = g_begin[g]; i < g_begin[g + 1]; ++i) front_of[(size_t)i] = f;
+    }
     auto layout = [&](Carver& c, Regions& rg) {
         for (int i = 0; i < NB; ++i) {
             const dcs_ba_problem* pb = problems[live[i]];
@@ -3081,7 +3373,9 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.W = c.get<double>(q.use_reg ? 1 : (size_t)q.ld * kNB);
             q.poses[1] = c.get<double>(7 * P); q.points[1] = c.get<double>(3 * L);
             q.err = c.get<double>(2 * E);
-            q.Hpl = c.get<double>(18 * E); q.BD = c.get<double>(18 * E); q.cpose = c.get<double>(27 * E); q.cpoint = c.get<double>(9 * E);
+            q.Hpl[0] = c.get<double>(18 * E); q.BD = c.get<double>(18 * E); q.cpose[0] = c.get<double>(27 * E); q.cpoint[0] = c.get<double>(9 * E);
+            if (front_of[i]) { q.Hpl[1] = c.get<double>(18 * E); q.cpose[1] = c.get<double>(27 * E); q.cpoint[1] = c.get<double>(9 * E); }
+            else { q.Hpl[1] = q.Hpl[0]; q.cpose[1] = q.cpose[0]; q.cpoint[1] = q.cpoint[0]; }
             q.Hll = c.get<double>(9 * L); q.bl = c.get<double>(3 * L); q.Dinv = c.get<double>(9 * L); q.db = c.get<double>(3 * L); q.xl = c.get<double>(3 * L);
             q.Hpp = c.get<double>(36 * P); q.bp = c.get<double>(6 * P); q.bsch = c.get<double>(6 * P); q.xp = c.get<double>(6 * P);
             q.partial = c.get<double>(std::max(q.nblk, q.nb_pts)); q.scale_part = c.get<double>(q.nb_pts + q.nb_pose); q.maxd_part = c.get<double>(q.np + q.nb_pts);
@@ -3199,7 +3493,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         DCS_HIP(hipMemcpy(tap->Hll, q.Hll, sizeof(double) * 9 * q.L, hipMemcpyDeviceToHost));
         DCS_HIP(hipMemcpy(tap->bl, q.bl, sizeof(double) * 3 * q.L, hipMemcpyDeviceToHost));
-        DCS_HIP(hipMemcpy(tap->Hpl, q.Hpl, sizeof(double) * 18 * q.E, hipMemcpyDeviceToHost));
+        DCS_HIP(hipMemcpy(tap->Hpl, q.Hpl[0], sizeof(double) * 18 * q.E, hipMemcpyDeviceToHost));
         const dcs_ba_problem* pb0 = problems[live[0]];
         for (int e = 0; e < q.E; ++e)                          // edges of fixed poses have no H_pl block (the kernel never writes their slot)
             if (rounds[0].pose_idx[pb0->edge_pose[e]] < 0) for (int k = 0; k < 18; ++k) tap->Hpl[(size_t)e * 18 + k] = 0.0;
@@ -3212,7 +3506,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     struct Group {
         hipStream_t st; const BaProb* dp; BaCtl* ctls; int nb, off; int* words; unsigned* ticket;
         int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, g_pts = 0, max_npad_blocked = 0;
-        bool any_mfma = false, any_valu = false, any_blocked = false, finished = false, fused_update = true;
+        bool any_mfma = false, any_valu = false, any_blocked = false, finished = false, fused_update = true, front = false;
+        int g_front = 0;
         int max_n_mfma = 0;
     };
     const bool no_fused_update = opt(OPT_BA_FUSED_UPDATE) == 0;   // A/B: the two launches
@@ -3222,11 +3517,13 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         Group& gr = groups[g];
         gr.st = g == 0 ? st : ctx.aux[g - 1]; gr.off = g_begin[g]; gr.nb = g_begin[g + 1] - g_begin[g];
         gr.dp = d_probs + gr.off; gr.ctls = d_ctls + gr.off; gr.words = h_words + 2 * g; gr.ticket = d_grid_ticket[g];
+        gr.front = group_front[g];
         for (int i = gr.off; i < gr.off + gr.nb; ++i) {
             const BaProb& q = hp[i];
             gr.g_edges = std::max(gr.g_edges, q.nblk);
             gr.g_reduce = std::max(gr.g_reduce, q.np + q.nb_pts);
             gr.g_prep = std::max(gr.g_prep, (q.np ? q.nblk : 0) + (q.L + 255) / 256);
+            gr.g_front = std::max(gr.g_front, (q.nblk + kFrontVB - 1) / kFrontVB * (q.np ? 2 : 1) + q.np + (q.L + kFrontThreads - 1) / kFrontThreads);
             if (q.np) gr.g_schur = std::max(gr.g_schur, q.n_pairs + q.np);
             gr.g_update = std::max(gr.g_update, q.nb_pts + q.nb_pose);
             gr.g_pts = std::max(gr.g_pts, q.nb_pts);
@@ -3265,13 +3562,16 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             void* a_begin[] = {(void*)&dp, (void*)&ctls, (void*)&nb, (void*)&words, (void*)&ticket};
             struct Spec { void* fn; dim3 grid, block; void** args; };
             std::vector<Spec> spec;
-            spec.push_back({(void*)k_begin, dim3(gr.g_edges, nb), dim3(256), a_begin});
-            spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
-            spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
+            if (gr.front) spec.push_back({(void*)k_front, dim3(gr.g_front, nb), dim3(kFrontThreads), a_begin});
+            else {
+                spec.push_back({(void*)k_begin, dim3(gr.g_edges, nb), dim3(256), a_begin});
+                spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
+                spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
+            }
             if (gr.g_schur) spec.push_back({schur_fn(schur_chunks(nb)), dim3(gr.g_schur, nb), dim3(schur_threads(schur_chunks(nb))), a_cc});
             if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<kLdltSlotsSmall> : (void*)k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
-            if (gr.fused_update) spec.push_back({(void*)k_update_error, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
+            if (gr.fused_update) spec.push_back({gr.front ? (void*)k_update_error<true> : (void*)k_update_error<false>, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
             else {
                 spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
                 spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
@@ -3308,9 +3608,12 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             return DCS_OK;
         }
         mark(step, 0);
+        if (gr.front) hipLaunchKernelGGL(k_front, dim3(gr.g_front, nb), dim3(kFrontThreads), 0, gs, dp, ctls, nb, gr.words, gr.ticket);   // the three below as one launch
+        else {
         hipLaunchKernelGGL(k_begin, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, nb, gr.words, gr.ticket);            // round change / stale errors, then buildSystem
         hipLaunchKernelGGL(k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), 0, gs, dp, ctls);                             // + computeLambdaInit (first iteration)
         hipLaunchKernelGGL(k_prep, dim3(gr.g_prep, nb), dim3(256), 0, gs, dp, ctls);                                      // setLambda + solve (Schur)
+        }
         DCS_CHECK_LAUNCH();
         if (gr.any_blocked) {                             // the blocked fallback factors S in place: rebuild it every trial
             for (int i = gr.off; i < gr.off + nb; ++i)
@@ -3341,7 +3644,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         DCS_CHECK_LAUNCH();
         mark(step, 2);
         if (gr.fused_update) {
-            hipLaunchKernelGGL(k_update_error, dim3(gr.g_pts, nb), dim3(kFusedThreads), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // back-substitution, oplus, chi2 of the trial + computeScale + accept / reject, progress
+            if (gr.front) hipLaunchKernelGGL(k_update_error<true>, dim3(gr.g_pts, nb), dim3(kFusedThreads), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);
+            else hipLaunchKernelGGL(k_update_error<false>, dim3(gr.g_pts, nb), dim3(kFusedThreads), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // back-substitution, oplus, chi2 of the trial + computeScale + accept / reject, progress
         } else {
             hipLaunchKernelGGL(k_solve_update, dim3(gr.g_update, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
             hipLaunchKernelGGL(k_error<1>, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // chi2 of the trial + computeScale + accept / reject, progress
@@ -3427,6 +3731,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         const BaProb& q = hp[i];
         dcs_ba_result* res = results[live[i]];
         const BaCtl& c = h_ctls[i];
+        if (c.fault) { set_error("BA problem %d: a hand-over inside k_front timed out (workgroups of one launch did not run together)", live[i]); return DCS_ERR_HIP; }
         if (c.state != ST_DONE) { set_error("BA problem %d did not finish within %d steps", live[i], max_steps); return DCS_ERR_HIP; }
         memcpy(res->poses, landed(q.out_poses), sizeof(double) * 7 * q.P);
         memcpy(res->points, landed(q.out_points), sizeof(double) * 3 * q.L);
