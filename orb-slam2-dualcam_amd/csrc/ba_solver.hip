@@ -197,7 +197,7 @@ struct BaProb {
     double *err, *chi2;                            // [E][2], [E]
     double *Hpl[2], *BD, *cpose[2], *cpoint[2];    // [E][18], [E][18], [E][27], [E][9]; the linearisation is double-buffered like the estimates: [b] belongs to poses[b] / points[b]
                                                    // (k_update_error linearises the trial estimates it has just evaluated; [1] == [0] when a group runs the six-launch step)
-    double *Hll, *bl, *Dinv, *db, *xl;             // per landmark
+    double *Hll[2], *bl[2], *Dinv, *db, *xl;       // per landmark; H_ll / b_l / pt_active belong to a linearisation: [b] like Hpl[b]
     double *Hpp, *bp, *bsch, *xp;                  // per free pose
     double *S, *W;                                 // reduced camera system (ld x ld), panel scratch of the n > 256 fallback
     const int32_t *pose_idx, *pt_off, *pt_edges, *pt_pi, *ps_off, *ps_edges;   // pt_pi[k] = free-pose index (or -1) of edge pt_edges[k]
@@ -205,9 +205,9 @@ struct BaProb {
     int32_t *pair_off, *pair_e;                      // lists of the pairs, BUILT ON THE DEVICE (k_pairs_*); pair_e: (e1, e2) interleaved, one 8-byte load per entry
     uint32_t* pt_bits;                               // [np][pt_words] bit l of row i: free pose i observes point l (zeroed region)
     int32_t* edge_of;                                // [np][L] the edge of (free pose, point), valid where the bit is set
-    int pt_words, pad2;
+    int pt_words, spec_cap;                        // spec_cap: entries of k_update_error<true>'s dynamic LDS (the launch's, not the problem's)
     double *partial, *scale_part, *maxd_part;      // block partials: chi2, computeScale, max |diagonal| (np + nb_pts entries)
-    uint8_t* pt_active;
+    uint8_t* pt_active[2];
     unsigned* ticket;                              // [0] error kernels, [1] k_reduce_pose, [2] k_begin
     const DCams* cams;
     double *out_poses, *out_points;
@@ -407,10 +407,9 @@ __global__ __launch_bounds__(256) void k_error(const BaProb* __restrict__ probs,
 // error / chi2 there): cpoint[e] = {Hll 00,01,02,11,12,22, bl0..2}, cpose[e] = {21 upper entries of Hpp row-major, bp0..5}, Hpl[e] = 6x3
 // row-major (pose rows, point cols). Shared by k_begin and by the trial kernel (which linearises the estimates it has just evaluated).
 __device__ __forceinline__ void linearize_edge(const BaProb& pb, int lb, int e, bool act, bool free_pose, const DCam& c, const double* T, const double* pc,
-                                               double err0, double err1, double x2, int robust, double delta)
+                                               double err0, double err1, double x2, int robust, double delta, double* cp /* the edge's 9 landmark terms: cpoint[lb] + 9 e, or LDS */)
 {
     if (!act) {                                            // level-1 edge: adds nothing to any block (the CSR lists still name it)
-        double* cp = pb.cpoint[lb] + (size_t)e * 9;
         for (int i = 0; i < 9; ++i) cp[i] = 0;
         if (free_pose) {
             double* cq = pb.cpose[lb] + (size_t)e * 27;
@@ -440,7 +439,6 @@ __device__ __forceinline__ void linearize_edge(const BaProb& pb, int lb, int e, 
         const double rho1 = x2 <= delta * delta ? 1.0 : delta / sqrt(x2);
         r0 *= rho1; r1 *= rho1; w = rho1 * w;
     }
-    double* cp = pb.cpoint[lb] + (size_t)e * 9;
     int k = 0;
     for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) cp[k++] = Jx[i] * w * Jx[j] + Jx[3 + i] * w * Jx[3 + j];
     for (int i = 0; i < 3; ++i) cp[6 + i] = Jx[i] * r0 + Jx[3 + i] * r1;
@@ -529,7 +527,7 @@ __device__ __forceinline__ void begin_body(const BaProb& pb, BaCtl& ctl, int bx,
     }
     // ---- (2) linearizeOplus + constructQuadraticForm. In FRONT of the ticket: in k_front the pass is over for the rest of the launch as soon as
     // the last workgroup has arrived there
-    if (lin && in) linearize_edge(pb, cur, e, act, pb.pose_idx[ps] >= 0, cams.c[cam_id], poses + 7 * ps, pc, err0, err1, x2, robust, delta);
+    if (lin && in) linearize_edge(pb, cur, e, act, pb.pose_idx[ps] >= 0, cams.c[cam_id], poses + 7 * ps, pc, err0, err1, x2, robust, delta, pb.cpoint[cur] + (size_t)e * 9);
     if (!(round_end || pre)) return;                                 // workgroup-uniform
     const double tsum = vblock_sum_256<VB>(rho0, s);                 // (its barriers also order every thread's stores before thread 0's release)
     if ((t & 255) == 0 && vb < pb.nblk) __hip_atomic_store(&pb.partial[vb], tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -632,10 +630,10 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__
         // NOTE: threads of this branch must all reach the block's finisher below (no early return for l >= L)
         double md = 0.0;
         if (l < pb.L) {
-        pb.pt_active[l] = n_act > 0;                 // a landmark without active edges is not part of this round
-        double* H = pb.Hll + (size_t)l * 9;
+        pb.pt_active[cur][l] = n_act > 0;            // a landmark without active edges is not part of this round
+        double* H = pb.Hll[cur] + (size_t)l * 9;
         H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
-        pb.bl[3 * l] = a[6]; pb.bl[3 * l + 1] = a[7]; pb.bl[3 * l + 2] = a[8];
+        pb.bl[cur][3 * l] = a[6]; pb.bl[cur][3 * l + 1] = a[7]; pb.bl[cur][3 * l + 2] = a[8];
         if (n_act > 0) md = fmax(fmax(fabs(a[0]), fabs(a[3])), fabs(a[5]));
         }
 #pragma unroll
@@ -681,7 +679,7 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
     const int nblk_e = pb.np ? pb.nblk : 0, L = pb.L;
     if ((int)blockIdx.x >= nblk_e + (L + 255) / 256) return;
     const double lambda = 1e-5 * ctl.maxdiag * ctl.mult;     // computeLambdaInit (tau = 1e-5) x the LM multiplier
-    const double* __restrict__ Hll = pb.Hll;
+    const double* __restrict__ Hll = pb.Hll[ctl.cur];
     if ((int)blockIdx.x < nblk_e) {
         const int e = blockIdx.x * 256 + threadIdx.x;
         if (e >= pb.E || pb.pose_idx[pb.epose[e]] < 0) return;
@@ -701,12 +699,12 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
     }
     const int l = (blockIdx.x - nblk_e) * 256 + threadIdx.x;
     if (l == 0) ctl.ok = 1.0;                                // reset the "factorisation succeeded" flag of this trial
-    if (l >= L || !pb.pt_active[l]) return;
+    if (l >= L || !pb.pt_active[ctl.cur][l]) return;
     double H[9], D[9];
     for (int i = 0; i < 9; ++i) H[i] = Hll[(size_t)l * 9 + i];
     H[0] += lambda; H[4] += lambda; H[8] += lambda;
     inv3(H, D);
-    const double* bl = pb.bl;
+    const double* bl = pb.bl[ctl.cur];
     for (int i = 0; i < 9; ++i) pb.Dinv[(size_t)l * 9 + i] = D[i];
     for (int i = 0; i < 3; ++i) pb.db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
 }
@@ -726,9 +724,6 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
 // iteration of a round: lambda comes from computeLambdaInit, i.e. from the last of the pose + landmark workgroups (lambda_ready); landmark
 // workgroups arrive there BEFORE they wait. The waits are bounded (kFrontSpin polls): on expiry the problem is marked (ctl.fault) and the call
 // fails instead of hanging the queue. The host only picks this launch for problems whose landmark workgroups are all resident at once.
-#ifndef DCS_FRONT_AB
-#define DCS_FRONT_AB 0
-#endif
 constexpr int kFrontThreads = 512;                      // 8 waves: 256 VGPRs per thread (begin_body needs 134; 1024 threads = 128 = spills)
 constexpr int kFrontVB = kFrontThreads / 256;
 constexpr int kFrontSpin = 1 << 22;
@@ -738,32 +733,23 @@ __device__ __forceinline__ bool front_wait(const int* flag, BaCtl& ctl, int& s_f
     if (threadIdx.x == 0) {
         int ok = 0;
         for (int i = 0; i < kFrontSpin; ++i) {
-            if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; break; }
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(4);
         }
         if (!ok) __hip_atomic_store(&ctl.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_flag = ok;
     }
+    // The acquire belongs to the thread that saw the word; on gfx950 it invalidates the CU's vector L1 and the stale lines of the XCD's L2, which is
+    // what every wave of this workgroup reads through -- one invalidation per workgroup, not one per wave (with eight per workgroup the step of a
+    // round change took 93 us, with one 57)
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // every wave: what the other workgroups wrote before the word
     return s_flag != 0;
 }
 
-#ifdef DCS_FRONT_PROF
-__device__ long long g_front_prof[4096];                     // [launch % 16][workgroup < 128][start, end] in 100 MHz ticks
-__device__ int g_front_launch;
-struct FrontProf {
-    int slot;
-    __device__ FrontProf() { slot = -1; if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 128) { slot = ((g_front_launch & 15) * 128 + blockIdx.x) * 2; g_front_prof[slot] = (long long)__builtin_amdgcn_s_memrealtime(); } }
-    __device__ ~FrontProf() { if (slot >= 0) g_front_prof[slot + 1] = (long long)__builtin_amdgcn_s_memrealtime(); }
-};
-#endif
 __global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int* __restrict__ h_progress,
                                                          unsigned* __restrict__ grid_ticket)
 {
-#ifdef DCS_FRONT_PROF
-    FrontProf prof_scope;
-#endif
     __shared__ double s[kPoseChunks * 27 + 27 > kFrontThreads ? kPoseChunks * 27 + 27 : kFrontThreads];   // begin_body's sums | the pose workgroup's part[37][27] + s[27]
     __shared__ DCams cams;
     __shared__ int s_cnt, s_flag;
@@ -786,11 +772,9 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restric
     const int state = __hip_atomic_load(&ctl.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // final now: begin_body's last workgroup may have rewritten the word
     if (state > ST_RETRY) return;
     const int cur = ctl.cur;
-    const bool new_iter = state == ST_NEW_ITER, first = new_iter && __hip_atomic_load(&ctl.it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    // (the first iteration of a round always follows the edge pass, in this launch or -- step 1 -- in k_begin: computeLambdaInit then finds the landmark maxima here)
+    const bool new_iter = state == ST_NEW_ITER, first = new_iter && need_begin && __hip_atomic_load(&ctl.it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
     if (bx < np) {                                           // ---- one free pose (k_reduce_pose)
-#if DCS_FRONT_AB == 2
-        return;
-#endif
         if (!new_iter) return;
         double (*part)[27] = reinterpret_cast<double (*)[27]>(s);
         double* const s27 = s + kPoseChunks * 27;
@@ -807,14 +791,32 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restric
             double a0 = 0, a1 = 0, a2 = 0;
             const int k1 = ps_off[i + 1];
             const bool has1 = q + kRows < kPoseChunks, has2 = q + 2 * kRows < kPoseChunks;
-#pragma unroll 2
-            for (int k = ps_off[i] + q; k < k1; k += kPoseChunks) {
-                a0 += cpose[(size_t)ps_edges[k] * 27 + c];
-                if (has1 && k + kRows < k1) a1 += cpose[(size_t)ps_edges[k + kRows] * 27 + c];
-                if (has2 && k + 2 * kRows < k1) a2 += cpose[(size_t)ps_edges[k + 2 * kRows] * 27 + c];
+            // The walk is a chain of dependent loads (list entry -> block), so eight entries of each chunk are in flight at once: all their indices first,
+            // then all their blocks; the additions stay in list order
+            constexpr int kU = 8;
+            for (int kb = ps_off[i] + q; kb < k1; kb += kU * kPoseChunks) {
+                int e0[kU], e1[kU], e2[kU];
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    const int k = kb + j * kPoseChunks;
+                    e0[j] = k < k1 ? ps_edges[k] : -1;
+                    e1[j] = (has1 && k + kRows < k1) ? ps_edges[k + kRows] : -1;
+                    e2[j] = (has2 && k + 2 * kRows < k1) ? ps_edges[k + 2 * kRows] : -1;
+                }
+                double v0[kU], v1[kU], v2[kU];
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    v0[j] = e0[j] >= 0 ? cpose[(size_t)e0[j] * 27 + c] : 0.0;
+                    v1[j] = e1[j] >= 0 ? cpose[(size_t)e1[j] * 27 + c] : 0.0;
+                    v2[j] = e2[j] >= 0 ? cpose[(size_t)e2[j] * 27 + c] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    if (e0[j] >= 0) a0 += v0[j];
+                    if (e1[j] >= 0) a1 += v1[j];
+                    if (e2[j] >= 0) a2 += v2[j];
+                }
             }
-            // a chunk whose first entry lies past the end never enters the loop above when chunk q is empty too: chunks are nested (q < q + 18 < q + 36), so an
-            // empty chunk q means empty q + 18 and q + 36
             part[q][c] = a0;
             if (has1) part[q + kRows][c] = a1;
             if (has2) part[q + 2 * kRows][c] = a2;
@@ -836,13 +838,10 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restric
     bx -= np;
     const double* __restrict__ cpoint = pb.cpoint[cur];
     if (bx < nb_l) {                                         // ---- 1024 landmarks: thread per landmark
-#if DCS_FRONT_AB == 3
-        return;
-#endif
         const int l = bx * kFrontThreads + t;
         double H[9];
         bool on = false;
-        if (new_iter) {
+        if (new_iter && need_begin) {                        // the edge pass of this launch produced the terms; after an accepted trial k_update_error<true> left the sums
             double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             int n_act = 0;
             for (int k = l < L ? pb.pt_off[l] : 0, k1 = l < L ? pb.pt_off[l + 1] : 0; k < k1; ++k) {
@@ -854,11 +853,11 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restric
             double md = 0.0;
             if (l < L) {
                 on = n_act > 0;
-                pb.pt_active[l] = on;                        // a landmark without active edges is not part of this round
+                pb.pt_active[cur][l] = on;                   // a landmark without active edges is not part of this round
                 H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
-                double* Hg = pb.Hll + (size_t)l * 9;
+                double* Hg = pb.Hll[cur] + (size_t)l * 9;
                 for (int i = 0; i < 9; ++i) Hg[i] = H[i];
-                pb.bl[3 * l] = a[6]; pb.bl[3 * l + 1] = a[7]; pb.bl[3 * l + 2] = a[8];
+                pb.bl[cur][3 * l] = a[6]; pb.bl[cur][3 * l + 1] = a[7]; pb.bl[cur][3 * l + 2] = a[8];
                 if (on) md = fmax(fmax(fabs(a[0]), fabs(a[3])), fabs(a[5]));
             }
             if (first) {                                     // workgroup-uniform
@@ -875,8 +874,8 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restric
                 }
             }
         } else if (l < L) {
-            on = pb.pt_active[l];
-            if (on) for (int i = 0; i < 9; ++i) H[i] = pb.Hll[(size_t)l * 9 + i];
+            on = pb.pt_active[cur][l];
+            if (on) for (int i = 0; i < 9; ++i) H[i] = pb.Hll[cur][(size_t)l * 9 + i];
         }
         if (first && !front_wait(&ctl.lambda_ready, ctl, s_flag)) return;
         const double lambda = 1e-5 * __hip_atomic_load(&ctl.maxdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * __hip_atomic_load(&ctl.mult, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // computeLambdaInit (tau = 1e-5) x the LM multiplier
@@ -885,23 +884,20 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restric
         double D[9];
         H[0] += lambda; H[4] += lambda; H[8] += lambda;
         inv3(H, D);
-        const double* bl = pb.bl;
+        const double* bl = pb.bl[cur];
         for (int i = 0; i < 9; ++i) pb.Dinv[(size_t)l * 9 + i] = D[i];
         for (int i = 0; i < 3; ++i) pb.db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
         return;
     }
     bx -= nb_l;
     {                                                        // ---- 1024 edges: BD[e] = Hpl[e] (Hll + lambda I)^-1
-#if DCS_FRONT_AB == 4
-        return;
-#endif
         const int e = bx * kFrontThreads + t;
         const bool mine = e < pb.E && pb.pose_idx[pb.epose[e]] >= 0;
         const bool act = mine && pb.active[e];
         double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (act) {
             const int l = pb.epoint[e];
-            if (new_iter && DCS_FRONT_AB != 1) {
+            if (new_iter && need_begin) {
                 double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
                 for (int k = pb.pt_off[l], k1 = pb.pt_off[l + 1]; k < k1; ++k) {
                     const double* c = cpoint + (size_t)pb.pt_edges[k] * 9;
@@ -909,7 +905,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restric
                 }
                 H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
             } else {
-                for (int i = 0; i < 9; ++i) H[i] = pb.Hll[(size_t)l * 9 + i];
+                for (int i = 0; i < 9; ++i) H[i] = pb.Hll[cur][(size_t)l * 9 + i];
             }
         }
         if (first && !front_wait(&ctl.lambda_ready, ctl, s_flag)) return;
@@ -1815,9 +1811,9 @@ __global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ 
     if ((int)blockIdx.x < nb_pts) {
         const int l = blockIdx.x * 64 + threadIdx.x;
         if (l < L) {
-            const double* __restrict__ bl = pb.bl;
+            const double* __restrict__ bl = pb.bl[ctl.cur];
             double x[3] = {0, 0, 0};
-            if (pb.pt_active[l]) {
+            if (pb.pt_active[ctl.cur][l]) {
                 double c[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
                 if (pb.np) {
                     // (edge, free-pose index) come from two parallel CSR arrays: one hop to the operands instead of three through
@@ -1883,17 +1879,26 @@ __global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ 
 constexpr int kFusedMaxPoses = 512;
 constexpr int kFusedThreads = 320;                       // waves 0-3: four lanes per landmark, wave 4: the poses
 // two sums at once over a workgroup of kFusedThreads threads (fixed tree; the totals come back in thread 0)
+template <bool WIDE>      // WIDE: called by kSpecThreads threads, of which the first kFusedThreads carry values (the same tree, the same bits)
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* s /*[512]*/, double* s2 /*[512]*/)
 {
     const int t = threadIdx.x;
-    s[t] = a; s2[t] = b;
+    if (!WIDE || t < kFusedThreads) { s[t] = a; s2[t] = b; }
     if (t < 512 - kFusedThreads) { s[kFusedThreads + t] = 0; s2[kFusedThreads + t] = 0; }
     __syncthreads();
     for (int d = 256; d >= 1; d >>= 1) { if (t < d) { s[t] += s[t + d]; s2[t] += s2[t + d]; } __syncthreads(); }
     a = s[0]; b = s2[0];
 }
-template <bool SPEC>      // SPEC: also linearise the trial estimates into the other half of the double-buffered blocks (the step of k_front)
-__global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, const volatile int* __restrict__ stop_words, int B,
+// SPEC (the step of k_front): the workgroup also LINEARISES the trial estimates -- H_pl and the pose terms of every edge go to the other half of the
+// double-buffered blocks, the landmark terms stay in LDS and are summed per landmark right here (H_ll, b_l, pt_active of the other half, in
+// k_reduce_pose's order) -- so that the step after an accepted trial starts without an edge pass. 640 threads: one edge per thread for the usual
+// ~640 entries of 64 landmarks; each entry's chi2 goes through LDS so that thread t < 320 still adds the entries t, t + 320, ... in this order (the
+// same bits as the 320-thread kernel). Dynamic LDS: 81 bytes per entry of the largest 64-landmark run (the host sizes it and keeps groups with
+// longer runs on the six-launch step).
+constexpr int kSpecThreads = 640;
+constexpr int kSpecMaxEntries = 1280;
+template <bool SPEC>
+__global__ __launch_bounds__(SPEC ? kSpecThreads : kFusedThreads) void k_update_error(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, const volatile int* __restrict__ stop_words, int B,
                                                       int* __restrict__ h_progress, unsigned* __restrict__ grid_ticket)
 {
     __shared__ double s[512], s2[512];
@@ -1901,6 +1906,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __
     __shared__ double s_pose[kFusedMaxPoses * 7];
     __shared__ double s_pt[64 * 3];
     __shared__ bool last;
+    extern __shared__ double s_dyn[];                        // SPEC: [cap][9] landmark terms, [cap] chi2 terms, [cap] active bytes
     const BaProb& pb = probs[blockIdx.y];
     BaCtl& ctl = ctls[blockIdx.y];
     if (ctl.state > ST_RETRY) return;
@@ -1914,7 +1920,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __
     load_cams(&cams, pb.cams);
     // ---- (a)
     double sc_pose = 0;
-    if (t >= 256) {                                          // wave 4, while waves 0-3 back-substitute
+    if (t >= 256 && t < kFusedThreads) {                     // wave 4, while waves 0-3 back-substitute
         const double* __restrict__ src = pb.poses[cur];
         double* __restrict__ dst = pb.poses[cur ^ 1];
         for (int i = t - 256; i < P; i += 64) {
@@ -1938,7 +1944,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __
     if (t < 256) {
         const int lt = t >> 2, sub = t & 3;
         const int l = blockIdx.x * 64 + lt;
-        const bool on = l < L && pb.pt_active[l];
+        const bool on = l < L && pb.pt_active[cur][l];
         double acc[3] = {0, 0, 0};
         if (on && pb.np) {
             const int32_t* __restrict__ pt_edges = pb.pt_edges;
@@ -1955,7 +1961,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __
 #pragma unroll
         for (int j = 0; j < 3; ++j) { acc[j] += __shfl_xor(acc[j], 1); acc[j] += __shfl_xor(acc[j], 2); }
         if (sub == 0 && l < L) {
-            const double* __restrict__ bl = pb.bl;
+            const double* __restrict__ bl = pb.bl[cur];
             double x[3] = {0, 0, 0};
             if (on) {
                 const double c[3] = {bl[3 * l] - acc[0], bl[3 * l + 1] - acc[1], bl[3 * l + 2] - acc[2]};
@@ -1973,7 +1979,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __
             }
         }
     }
-    if (blockIdx.x == 0 && t >= 256) {                       // the poses' share of computeScale: wave 4's lanes in a fixed tree
+    if (blockIdx.x == 0 && t >= 256 && t < kFusedThreads) {  // the poses' share of computeScale: wave 4's lanes in a fixed tree
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) sc_pose += __shfl_xor(sc_pose, d);
         if (t == 256) pb.scale_part[nb_pts] = sc_pose;
@@ -1985,28 +1991,68 @@ __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __
         const int l0 = blockIdx.x * 64, l1 = min(l0 + 64, L);
         const int k0 = pb.pt_off[l0], k1 = pb.pt_off[l1];
         const int32_t* __restrict__ pt_edges = pb.pt_edges;
-        for (int k = k0 + t; k < k1; k += kFusedThreads) {
-            const int e = pt_edges[k];
-            const bool act = pb.active[e] != 0;
-            if (!SPEC && !act) continue;
-            double pc[3];
-            const int ps = pb.epose[e];
-            const DCam& c = cams.c[pb.ecam[e]];
-            cam_point(s_pose + 7 * ps, s_pt + 3 * (pb.epoint[e] - l0), c, pc);
-            double e0 = 0, e1 = 0, x2 = 0;
-            if (act) {
-                e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
-                e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+        if (!SPEC) {
+            for (int k = k0 + t; k < k1; k += kFusedThreads) {
+                const int e = pt_edges[k];
+                if (!pb.active[e]) continue;
+                double pc[3];
+                const DCam& c = cams.c[pb.ecam[e]];
+                cam_point(s_pose + 7 * pb.epose[e], s_pt + 3 * (pb.epoint[e] - l0), c, pc);
+                const double e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+                const double e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
                 const double w = pb.w[e];
-                x2 = e0 * (w * e0) + e1 * (w * e1);
+                const double x2 = e0 * (w * e0) + e1 * (w * e1);
                 pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
                 rho0 += (robust && x2 > delta * delta) ? 2 * sqrt(x2) * delta - delta * delta : x2;
             }
-            // the accepted trial's estimates are the next iteration's linearisation point: the blocks go to the half that belongs to them
-            if (SPEC) linearize_edge(pb, cur ^ 1, e, act, pose_idx[ps] >= 0, c, s_pose + 7 * ps, pc, e0, e1, x2, robust, delta);
+        } else {
+            const int cap = k1 - k0;                             // (<= the launch's dynamic LDS: the host checked every run of the group)
+            double* const s_cp = s_dyn;
+            double* const s_rho = s_dyn + (size_t)9 * pb.spec_cap;
+            uint8_t* const s_act = reinterpret_cast<uint8_t*>(s_rho + pb.spec_cap);
+            for (int k = k0 + t; k < k1; k += kSpecThreads) {
+                const int e = pt_edges[k];
+                const bool act = pb.active[e] != 0;
+                double pc[3];
+                const int ps = pb.epose[e];
+                const DCam& c = cams.c[pb.ecam[e]];
+                cam_point(s_pose + 7 * ps, s_pt + 3 * (pb.epoint[e] - l0), c, pc);
+                double e0 = 0, e1 = 0, x2 = 0, rho = 0;
+                if (act) {
+                    e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+                    e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+                    const double w = pb.w[e];
+                    x2 = e0 * (w * e0) + e1 * (w * e1);
+                    pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
+                    rho = (robust && x2 > delta * delta) ? 2 * sqrt(x2) * delta - delta * delta : x2;
+                }
+                s_rho[k - k0] = rho; s_act[k - k0] = act;
+                // the accepted trial's estimates are the next iteration's linearisation point: the blocks go to the half that belongs to them
+                linearize_edge(pb, cur ^ 1, e, act, pose_idx[ps] >= 0, c, s_pose + 7 * ps, pc, e0, e1, x2, robust, delta, s_cp + (size_t)9 * (k - k0));
+            }
+            __syncthreads();
+            if (t < kFusedThreads) {                             // the chi2 terms in the 320-thread kernel's order (an inactive edge adds +0.0: no change)
+                for (int j = t; j < cap; j += kFusedThreads) rho0 += s_rho[j];
+            } else if (t < kFusedThreads + 64) {                 // wave 5: H_ll / b_l / pt_active of the other half, thread per landmark, CSR order (k_reduce_pose's sums)
+                const int l = l0 + (t - kFusedThreads);
+                if (l < L) {
+                    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    int n_act = 0;
+                    for (int k = pb.pt_off[l], kk1 = pb.pt_off[l + 1]; k < kk1; ++k) {
+                        n_act += s_act[k - k0];
+                        const double* c9 = s_cp + (size_t)9 * (k - k0);
+                        for (int i = 0; i < 9; ++i) a[i] += c9[i];
+                    }
+                    pb.pt_active[cur ^ 1][l] = n_act > 0;
+                    double* H = pb.Hll[cur ^ 1] + (size_t)l * 9;
+                    H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
+                    double* bo = pb.bl[cur ^ 1];
+                    bo[3 * l] = a[6]; bo[3 * l + 1] = a[7]; bo[3 * l + 2] = a[8];
+                }
+            }
         }
     }
-    block_sum2(rho0, sc, s, s2);                             // thread 0: chi2 and computeScale partials of this workgroup
+    block_sum2<SPEC>(rho0, sc, s, s2);                       // thread 0: chi2 and computeScale partials of this workgroup
     // ---- (d)
     if (t == 0) {
         pb.scale_part[blockIdx.x] = sc;
@@ -2021,9 +2067,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __
     if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     double tot = 0, sc_tot = 0;
-    for (int i = t; i < nb_pts; i += kFusedThreads) tot += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = t; i <= nb_pts; i += kFusedThreads) sc_tot += __hip_atomic_load(&pb.scale_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    block_sum2(tot, sc_tot, s, s2);
+    if (t < kFusedThreads) {
+        for (int i = t; i < nb_pts; i += kFusedThreads) tot += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = t; i <= nb_pts; i += kFusedThreads) sc_tot += __hip_atomic_load(&pb.scale_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    block_sum2<SPEC>(tot, sc_tot, s, s2);
     if (t != 0) return;
     __hip_atomic_store(pb.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lm_accept(pb, ctl, stop_words, tot, sc_tot);
@@ -3325,14 +3373,25 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // The four-launch step (k_front, k_schur, LDL^T, k_update_error<true>) per GROUP: every problem of the group must fit the fused trial kernel
     // (poses in LDS) and have few enough landmark workgroups that all of them are resident at once (k_front's lambda hand-over).
     const bool front_opt = opt(OPT_BA_FRONT) != 0 && opt(OPT_BA_FUSED_UPDATE) != 0 && !tl_tap;
-    bool group_front[BaContext::kMaxGroups];
+    if (front_opt) {
+        static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_error<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kSpecMaxEntries * 81 + 16);
+        if (attr_rc != hipSuccess) { set_error("hipFuncSetAttribute(k_update_error<true>): %s", hipGetErrorString(attr_rc)); return DCS_ERR_HIP; }
+    }
+    bool group_front[BaContext::kMaxGroups]; int group_cap[BaContext::kMaxGroups];
     std::vector<char> front_of((size_t)NB, 0);
+    std::vector<int> cap_of((size_t)NB, 1);
     for (int g = 0; g < G; ++g) {
         bool f = front_opt;
-        for (int i = g_begin[g]; i < g_begin[g + 1]; ++i)
-            if (problems[live[i]]->n_poses > kFusedMaxPoses || problems[live[i]]->n_points > kFrontMaxPoints) f = false;
-        group_front[g] = f;
-        for (int i = g_begin[g]; i < g_begin[g + 1]; ++i) front_of[(size_t)i] = f;
+        int cap = 0;
+        for (int i = g_begin[g]; i < g_begin[g + 1]; ++i) {
+            const dcs_ba_problem* pb = problems[live[i]];
+            if (pb->n_poses > kFusedMaxPoses || pb->n_points > kFrontMaxPoints) f = false;
+            const std::vector<int32_t>& off = rounds[i].pt_off;                   // the longest run of 64 landmarks' entries: one workgroup of k_update_error<true> keeps it in LDS
+            for (int l0 = 0; l0 < pb->n_points; l0 += 64) cap = std::max(cap, off[(size_t)std::min(l0 + 64, pb->n_points)] - off[(size_t)l0]);
+        }
+        if (cap > kSpecMaxEntries) f = false;
+        group_front[g] = f; group_cap[g] = std::max(cap, 1);
+        for (int i = g_begin[g]; i < g_begin[g + 1]; ++i) { front_of[(size_t)i] = f; cap_of[(size_t)i] = group_cap[g]; }
     }
     auto layout = [&](Carver& c, Regions& rg) {
         for (int i = 0; i < NB; ++i) {
@@ -3351,7 +3410,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.pose_idx = c.get<int32_t>(P); q.pt_off = c.get<int32_t>(L + 1); q.pt_edges = c.get<int32_t>(r.pt_edges.size()); q.pt_pi = c.get<int32_t>(r.pt_pi.size());
             q.ps_off = c.get<int32_t>(r.ps_off.size()); q.ps_edges = c.get<int32_t>(r.ps_edges.size());
             q.pair_ij = c.get<int32_t>(r.pair_ij.size());
-            q.pt_words = (int)(((L + 31) / 32 + 3) & ~(size_t)3); q.pad2 = 0;      // rows are read 16 bytes at a time
+            q.pt_words = (int)(((L + 31) / 32 + 3) & ~(size_t)3); q.spec_cap = cap_of[(size_t)i];      // rows are read 16 bytes at a time
             q.cams = c.get<DCams>(1);
         }
         d_probs = c.get<BaProb>(NB);
@@ -3374,12 +3433,15 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.poses[1] = c.get<double>(7 * P); q.points[1] = c.get<double>(3 * L);
             q.err = c.get<double>(2 * E);
             q.Hpl[0] = c.get<double>(18 * E); q.BD = c.get<double>(18 * E); q.cpose[0] = c.get<double>(27 * E); q.cpoint[0] = c.get<double>(9 * E);
-            if (front_of[i]) { q.Hpl[1] = c.get<double>(18 * E); q.cpose[1] = c.get<double>(27 * E); q.cpoint[1] = c.get<double>(9 * E); }
-            else { q.Hpl[1] = q.Hpl[0]; q.cpose[1] = q.cpose[0]; q.cpoint[1] = q.cpoint[0]; }
-            q.Hll = c.get<double>(9 * L); q.bl = c.get<double>(3 * L); q.Dinv = c.get<double>(9 * L); q.db = c.get<double>(3 * L); q.xl = c.get<double>(3 * L);
+            q.cpoint[1] = q.cpoint[0];                     // (only k_begin's edge pass writes them to memory, and its readers run in the same step)
+            if (front_of[i]) { q.Hpl[1] = c.get<double>(18 * E); q.cpose[1] = c.get<double>(27 * E); }
+            else { q.Hpl[1] = q.Hpl[0]; q.cpose[1] = q.cpose[0]; }
+            q.Hll[0] = c.get<double>(9 * L); q.bl[0] = c.get<double>(3 * L); q.Dinv = c.get<double>(9 * L); q.db = c.get<double>(3 * L); q.xl = c.get<double>(3 * L);
             q.Hpp = c.get<double>(36 * P); q.bp = c.get<double>(6 * P); q.bsch = c.get<double>(6 * P); q.xp = c.get<double>(6 * P);
             q.partial = c.get<double>(std::max(q.nblk, q.nb_pts)); q.scale_part = c.get<double>(q.nb_pts + q.nb_pose); q.maxd_part = c.get<double>(q.np + q.nb_pts);
-            q.pt_active = c.get<uint8_t>(L);
+            q.pt_active[0] = c.get<uint8_t>(L);
+            if (front_of[i]) { q.Hll[1] = c.get<double>(9 * L); q.bl[1] = c.get<double>(3 * L); q.pt_active[1] = c.get<uint8_t>(L); }
+            else { q.Hll[1] = q.Hll[0]; q.bl[1] = q.bl[0]; q.pt_active[1] = q.pt_active[0]; }
             q.edge_of = c.get<int32_t>((size_t)q.np * L);
             q.pair_off = c.get<int32_t>((size_t)q.n_pairs + 1); q.pair_e = c.get<int32_t>(2 * rounds[i].n_pair_entries);
         }
@@ -3491,8 +3553,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             DCS_HIP(hipMemcpy(tap->Hpp, q.Hpp, sizeof(double) * 36 * q.np, hipMemcpyDeviceToHost));
             DCS_HIP(hipMemcpy(tap->bp, q.bp, sizeof(double) * 6 * q.np, hipMemcpyDeviceToHost));
         }
-        DCS_HIP(hipMemcpy(tap->Hll, q.Hll, sizeof(double) * 9 * q.L, hipMemcpyDeviceToHost));
-        DCS_HIP(hipMemcpy(tap->bl, q.bl, sizeof(double) * 3 * q.L, hipMemcpyDeviceToHost));
+        DCS_HIP(hipMemcpy(tap->Hll, q.Hll[0], sizeof(double) * 9 * q.L, hipMemcpyDeviceToHost));
+        DCS_HIP(hipMemcpy(tap->bl, q.bl[0], sizeof(double) * 3 * q.L, hipMemcpyDeviceToHost));
         DCS_HIP(hipMemcpy(tap->Hpl, q.Hpl[0], sizeof(double) * 18 * q.E, hipMemcpyDeviceToHost));
         const dcs_ba_problem* pb0 = problems[live[0]];
         for (int e = 0; e < q.E; ++e)                          // edges of fixed poses have no H_pl block (the kernel never writes their slot)
@@ -3507,7 +3569,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         hipStream_t st; const BaProb* dp; BaCtl* ctls; int nb, off; int* words; unsigned* ticket;
         int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, g_pts = 0, max_npad_blocked = 0;
         bool any_mfma = false, any_valu = false, any_blocked = false, finished = false, fused_update = true, front = false;
-        int g_front = 0;
+        int g_front = 0, spec_cap = 1;
         int max_n_mfma = 0;
     };
     const bool no_fused_update = opt(OPT_BA_FUSED_UPDATE) == 0;   // A/B: the two launches
@@ -3517,7 +3579,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         Group& gr = groups[g];
         gr.st = g == 0 ? st : ctx.aux[g - 1]; gr.off = g_begin[g]; gr.nb = g_begin[g + 1] - g_begin[g];
         gr.dp = d_probs + gr.off; gr.ctls = d_ctls + gr.off; gr.words = h_words + 2 * g; gr.ticket = d_grid_ticket[g];
-        gr.front = group_front[g];
+        gr.front = group_front[g]; gr.spec_cap = group_cap[g];
         for (int i = gr.off; i < gr.off + gr.nb; ++i) {
             const BaProb& q = hp[i];
             gr.g_edges = std::max(gr.g_edges, q.nblk);
@@ -3553,7 +3615,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     if (use_graph_env && !timing) {
         for (int g = 0; g < G; ++g) {
             const Group& gr = groups[g];
-            if (gr.any_blocked) continue;
+            if (gr.any_blocked || gr.front) continue;             // (the four-launch step differs in its first step: plain launches)
             const BaProb* dp = gr.dp; BaCtl* ctls = gr.ctls; const BaCtl* cctls = gr.ctls; int nb = gr.nb;
             const volatile int* d_stop = h_words + 16 + gr.off; int* words = gr.words; unsigned* ticket = gr.ticket;
             void* a_cc[] = {(void*)&dp, (void*)&cctls};                                   // (probs, const ctls)
@@ -3571,7 +3633,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             if (gr.g_schur) spec.push_back({schur_fn(schur_chunks(nb)), dim3(gr.g_schur, nb), dim3(schur_threads(schur_chunks(nb))), a_cc});
             if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<kLdltSlotsSmall> : (void*)k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
-            if (gr.fused_update) spec.push_back({gr.front ? (void*)k_update_error<true> : (void*)k_update_error<false>, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
+            if (gr.fused_update) spec.push_back({(void*)k_update_error<false>, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
             else {
                 spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
                 spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
@@ -3608,7 +3670,9 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             return DCS_OK;
         }
         mark(step, 0);
-        if (gr.front) hipLaunchKernelGGL(k_front, dim3(gr.g_front, nb), dim3(kFrontThreads), 0, gs, dp, ctls, nb, gr.words, gr.ticket);   // the three below as one launch
+        // (step 1 always starts with the edge pass -- the errors of the initial estimates -- and the host knows it: the three launches are cheaper
+        // than k_front's hand-overs inside one)
+        if (gr.front && step > 1) hipLaunchKernelGGL(k_front, dim3(gr.g_front, nb), dim3(kFrontThreads), 0, gs, dp, ctls, nb, gr.words, gr.ticket);   // the three below as one launch
         else {
         hipLaunchKernelGGL(k_begin, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, nb, gr.words, gr.ticket);            // round change / stale errors, then buildSystem
         hipLaunchKernelGGL(k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), 0, gs, dp, ctls);                             // + computeLambdaInit (first iteration)
@@ -3644,7 +3708,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         DCS_CHECK_LAUNCH();
         mark(step, 2);
         if (gr.fused_update) {
-            if (gr.front) hipLaunchKernelGGL(k_update_error<true>, dim3(gr.g_pts, nb), dim3(kFusedThreads), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);
+            if (gr.front) hipLaunchKernelGGL(k_update_error<true>, dim3(gr.g_pts, nb), dim3(kSpecThreads), (size_t)gr.spec_cap * 81 + 16, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);
             else hipLaunchKernelGGL(k_update_error<false>, dim3(gr.g_pts, nb), dim3(kFusedThreads), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // back-substitution, oplus, chi2 of the trial + computeScale + accept / reject, progress
         } else {
             hipLaunchKernelGGL(k_solve_update, dim3(gr.g_update, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
