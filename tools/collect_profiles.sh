@@ -15,6 +15,8 @@ DCS_ORB_NO_OVERLAP=1 timeout 400 rocprofv3 --kernel-trace --stats --output-forma
 DCS_ORB_FUSED_BLUR=0 DCS_ORB_NO_OVERLAP=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/solo_separate_blur -- python $R/bench.py $HEAD --serial > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ba1 -- python $R/scratch/time_ba_batch.py 1 20 > $O/ba1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ba8 -- python $R/scratch/time_ba_batch.py 8 20 > $O/ba8.log 2>&1
+# round 5: the same solve as the four-launch step (k_front + k_update_error<true>; opt-in, bit-identical)
+DCS_BA_FRONT=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ba1_front -- python $R/scratch/time_ba_batch.py 1 20 > $O/ba1_front.log 2>&1
 # round 5: the per-frame tracking chain alone (dcs_track_local_map at batch 1 and 16: k_pose_opt2 + the five chain kernels), the C3 shape (configs[2] at one GPU)
 # as a headline-only run, the emitting FAST launch by launch (in the pipeline and alone, emitting FAST and resize chain), k_pose_opt2's in-kernel timeline
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/track -- python $R/scratch/time_track.py > $O/track.log 2>&1
@@ -30,8 +32,8 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BU
 cd $R
 python scratch/pmc_to_json.py $O/pmc_counters.json 256 640 480 1000 1 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_mfma | tail -40
 python scratch/pmc_sum.py $O/pmc_sq > $O/pmc_sq_summary.txt
-for d in stats headline solo solo_separate_blur ba1 ba8 track c3; do cp $(ls $O/$d/*/*kernel_stats.csv | head -1) $O/${d}_kernel_stats.csv; done
-rm -rf $O/stats $O/headline $O/solo $O/solo_separate_blur $O/ba1 $O/ba8 $O/track $O/c3 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_mfma
+for d in stats headline solo solo_separate_blur ba1 ba8 ba1_front track c3; do cp $(ls $O/$d/*/*kernel_stats.csv | head -1) $O/${d}_kernel_stats.csv; done
+rm -rf $O/stats $O/headline $O/solo $O/solo_separate_blur $O/ba1 $O/ba8 $O/ba1_front $O/track $O/c3 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_mfma
 echo "== headline"; python scratch/kstats.py $O/headline_kernel_stats.csv 16
 echo "== solo"; python scratch/kstats.py $O/solo_kernel_stats.csv 16
 echo "== ba"; python scratch/kstats.py $O/ba1_kernel_stats.csv 12
