@@ -2416,28 +2416,70 @@ __device__ __forceinline__ void pose_compose(PoseShared& S, int c)
 
 // exp(update) * T like pose_oplus(), with the two libm calls that dominate it on one lane replaced: sin and cos of theta come from ONE sincos,
 // theta^3 is two multiplications (g2o calls pow(theta, 3): <= 1 ulp apart, the update itself is ~1e-3 rad)
+// 1 / sqrt(x) to full double precision: v_rsq_f64 + two Newton steps (x > 0)
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+// exp(update) * T like pose_oplus(), shaped for ONE lane on the control wave's critical path (round 5: ~2 000 of a pass's 12 700 ticks were this
+// function's dependent sqrt -> sincos -> divide -> sqrt -> divide -> sqrt -> divide chain):
+//   * the three coefficients sin(t)/t, (1 - cos t)/t^2, (t - sin t)/t^3 as even series in t^2 (an LM step rotates by far less than 0.5 rad: 11
+//     terms leave < 1e-17; no square root, no sincos, no division -- and no cancellation, which the closed forms have at small t);
+//     t >= 0.5 takes the closed forms
+//   * normalisations multiply by 1 / sqrt (v_rsq_f64 + two Newton steps) instead of sqrt followed by four IEEE divisions
+// Differences to pose_oplus() are of the order of an ulp per operation: the estimates agree to ~1e-15, which moves an accept / reject decision on a
+// plateau no more often than the reduction order does (tests: poses 1e-7 / 1e-8, flags exact, iteration counts +- 1).
+__device__ inline void quat_normalize_fast(double q[4])
+{
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double r = fast_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
+}
 __device__ inline void pose_oplus_fast(const double* T, const double* u, double* out)
 {
     const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
-    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double t2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
     const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
     double O2[9];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
     double R[9], V[9];
-    if (theta < 0.00001) {
+    if (t2 < 1e-10) {                                         // theta < 0.00001 (pose_oplus's first-order branch)
         for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
     } else {
-        double sn, cs;
-        sincos(theta, &sn, &cs);
-        const double a = sn / theta, b = (1 - cs) / (theta * theta), c = (theta - sn) / (theta * theta * theta);
+        double a, b, c;
+        if (t2 < 0.25) {
+            // a = sum (-1)^k t2^k / (2k+1)!,  b = sum (-1)^k t2^k / (2k+2)!,  c = sum (-1)^k t2^k / (2k+3)!   (Horner, k = 10 .. 0)
+            a = 1.0 / 51090942171709440000.0; b = 1.0 / 1124000727777607680000.0; c = 1.0 / 25852016738884976640000.0;
+            const double ia[10] = {1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, 1.0 / 1307674368000.0, 1.0 / 6227020800.0, 1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0, 1.0};
+            const double ib[10] = {1.0 / 2432902008176640000.0, 1.0 / 6402373705728000.0, 1.0 / 20922789888000.0, 1.0 / 87178291200.0, 1.0 / 479001600.0, 1.0 / 3628800.0, 1.0 / 40320.0, 1.0 / 720.0, 1.0 / 24.0, 1.0 / 2.0};
+            const double ic[10] = {1.0 / 51090942171709440000.0, 1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, 1.0 / 1307674368000.0, 1.0 / 6227020800.0, 1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0};
+#pragma unroll
+            for (int k = 0; k < 10; ++k) { a = fma(-t2, a, ia[k]); b = fma(-t2, b, ib[k]); c = fma(-t2, c, ic[k]); }
+        } else {
+            const double theta = sqrt(t2);
+            double sn, cs;
+            sincos(theta, &sn, &cs);
+            a = sn / theta; b = (1 - cs) / t2; c = (theta - sn) / (t2 * theta);
+        }
         for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0 ? 1.0 : 0.0); R[i] = I + a * O[i] + b * O2[i]; V[i] = I + b * O[i] + c * O2[i]; }
     }
     double qe[4], te[3];
-    qfromR(R, qe); qnormalize(qe);
+    {   // qfromR with 1 / sqrt in place of sqrt + 0.5 / t
+        double tr = R[0] + R[4] + R[8];
+        if (tr > 0) {
+            const double r = fast_rsqrt(tr + 1.0), t = (tr + 1.0) * r, h = 0.5 * r;
+            qe[3] = 0.5 * t;
+            qe[0] = (R[7] - R[5]) * h; qe[1] = (R[2] - R[6]) * h; qe[2] = (R[3] - R[1]) * h;
+        } else qfromR(R, qe);
+    }
+    quat_normalize_fast(qe);
     for (int i = 0; i < 3; ++i) te[i] = V[i * 3] * up[0] + V[i * 3 + 1] * up[1] + V[i * 3 + 2] * up[2];
     double rt[3]; qrot(qe, T, rt);
     out[0] = te[0] + rt[0]; out[1] = te[1] + rt[1]; out[2] = te[2] + rt[2];
-    double qo[4]; qmul(qe, T + 3, qo); qnormalize(qo);
+    double qo[4]; qmul(qe, T + 3, qo); quat_normalize_fast(qo);
     out[3] = qo[0]; out[4] = qo[1]; out[5] = qo[2]; out[6] = qo[3];
 }
 
@@ -2616,7 +2658,8 @@ __device__ __forceinline__ void pose_control(PoseShared& S, const PoseArgs& a, i
             wave_sync();
             if (flags & 8) {
                 // LDL^T of H + lambda I with ROW i ON LANE i (right-looking; the terms (L_ik L_jk) d_k leave every entry in ascending k exactly as
-                // solve6()'s inner products do: same bits), forward substitution likewise; the back substitution runs on lane 0 in solve6()'s order
+                // solve6()'s inner products do), forward substitution likewise; the back substitution runs on lane 0 in solve6()'s order. Divisions by a
+                // pivot are multiplications by its reciprocal (fast_recip): an ulp apart from solve6() at most
                 const int r = lane < 6 ? lane : 5;
                 double A[6], y = S.bc[r];
 #pragma unroll
@@ -2624,14 +2667,16 @@ __device__ __forceinline__ void pose_control(PoseShared& S, const PoseArgs& a, i
                 const double lam = S.lam;
 #pragma unroll
                 for (int m = 0; m < 6; ++m) if (m == r) A[m] += lam;
-                double dd[6];
+                double dd[6], myinv = 0.0;
                 bool okf = true;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const double dj = bcast_lane(A[j], j);      // the pivot, every earlier column already subtracted
                     dd[j] = dj;
                     if (!(dj > 0.0) || !isfinite(dj)) okf = false;
-                    const double l = A[j] / dj;                 // L[r][j] (meaningful on lanes r > j)
+                    const double inv = fast_recip(dj);          // (v_rcp_f64 + two Newton steps: the IEEE division sequence is ~3 x as long, six times in a row)
+                    if (j == r) myinv = inv;
+                    const double l = A[j] * inv;                // L[r][j] (meaningful on lanes r > j)
                     A[j] = l;
 #pragma unroll
                     for (int m = j + 1; m < 6; ++m) {
@@ -2642,7 +2687,7 @@ __device__ __forceinline__ void pose_control(PoseShared& S, const PoseArgs& a, i
                 // forward: y_r -= L[r][k] y_k in ascending k; y_k is final once step k - 1 is done
 #pragma unroll
                 for (int k = 0; k < 5; ++k) { const double yk = bcast_lane(y, k); if (r > k) y -= A[k] * yk; }
-                y /= dd[r];
+                y *= myinv;
                 // L's lower triangle and y for the backward pass (v_readlane: every lane holds them, lane 0 uses them)
                 double Lk[6][6], yy[6];
 #pragma unroll
