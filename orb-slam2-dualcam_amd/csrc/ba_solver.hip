@@ -1125,10 +1125,8 @@ __global__ __launch_bounds__(64) void k_pairs_fill(const BaProb* __restrict__ pr
 // 1/d to full double precision without the IEEE division sequence: v_rcp_f64 + two Newton steps
 __device__ __forceinline__ double fast_recip(double d)
 {
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(d), e = fma(-d, r, 1.0);       // v_rcp_f64: 2^-24.4; r (1 + e + e^2): error e^3 (scratch/probe/rcp_probe.hip)
+    return fma(r, fma(e, e, e), r);
 }
 
 // (use_reg: 1 = k_ldlt_mfma, 2 = k_ldlt_reg, 0 = blocked multi-launch fallback; one workgroup per problem)
@@ -1377,6 +1375,7 @@ constexpr int kLdltSlotsBig = (136 + kLdltWorkers - 1) / kLdltWorkers;         /
 constexpr int kLdltThreads = 64 * (kLdltWorkers + 1);
 constexpr int kDiagWave = kLdltWorkers;
 
+__device__ __forceinline__ double dbl_of(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
 __device__ __forceinline__ double readlane_f64(double v, int srclane)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
@@ -1434,15 +1433,16 @@ template <int K> __device__ __forceinline__ void diag16_pivot(Diag16& d)
     if constexpr (K > 0) { diag16_bulk<K - 1, 0>(d); diag16_bulk<K - 1, 1>(d); diag16_bulk<K - 1, 2>(d); }   // a_kk first; two more keep the DPP read of a_kk two slots away
     const double dk = bcast16<K, K == 0>(d.ar[K]);
     diag16_bulk2<K - 1, 3>(d);
-    double r = asm_rcp(dk);
+    const double r = asm_rcp(dk);
     diag16_bulk2<K - 1, 5>(d);
-    double e = asm_fnma1(dk, r);
+    // ONE correction of third order instead of two Newton steps: v_rcp_f64 is good to 2^-24.4 (scratch/probe/rcp_probe.hip), e = 1 - d r, and
+    // r (1 + e + e^2) leaves e^3 ~ 1e-22 -- a dependent operation less on the pivot chain, which is what a diagonal block's time is made of
+    const double e = asm_fnma1(dk, r);
     diag16_bulk2<K - 1, 7>(d);
-    r = asm_fma(e, r, r);
     diag16_bulk2<K - 1, 9>(d);
-    e = asm_fnma1(dk, r);
+    const double t = asm_fma(e, e, e);
     diag16_bulk2<K - 1, 11>(d);
-    const double invd = asm_fma(e, r, r);
+    const double invd = asm_fma(r, t, r);
     diag16_bulk2<K - 1, 13>(d);
     if constexpr (K > 0) diag16_bulk<K - 1, 15>(d);
     d.myinvd = d.lo == K ? invd : d.myinvd;
@@ -2356,7 +2356,6 @@ __device__ __forceinline__ void wave_sync()
 // step moves half as many values as the one before (16 + 8 + 4 + 2 + 1 + 1 exchanges). The two widest levels -- 24 of the 32 exchanges -- are
 // gfx950's v_permlane32_swap / v_permlane16_swap (the upper half of one register trades places with the lower half of the other: exactly
 // this step, no LDS round trip, no selects); the narrow ones are ds_bpermute shuffles.
-__device__ __forceinline__ double dbl_of(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
 __device__ __forceinline__ double swap_add32(double p, double q)
 {
     const auto a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(p), (unsigned)__double2loint(q), false, false);
