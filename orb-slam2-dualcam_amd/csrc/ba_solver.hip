@@ -20,7 +20,7 @@
 //   k_ldlt_mfma     LDL^T + both triangular solves of the reduced camera system in ONE workgroup: 16x16 tiles in the
 //                   registers of 11 worker waves, trailing updates on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the
 //                   diagonal blocks factored one step ahead by a twelfth wave
-//                   (k_ldlt_reg: column-by-column VALU predecessor, DCS_BA_LDLT_VALU=1; k_ldlt_panel/_update/_solve:
+//                   (k_ldlt_panel/_update/_solve:
 //                   multi-launch fallback for n > 256)
 //   k_solve_update  landmark back-substitution, push + manifold update of all estimates, computeScale partials
 //   k_error<1>      edge-parallel residual + chi2 + Huber rho of the trial estimates; the problem's last block adds the block
@@ -1117,152 +1117,15 @@ __global__ __launch_bounds__(64) void k_pairs_fill(const BaProb* __restrict__ pr
     }
 }
 
-// ---- register-resident LDL^T + solve (n_pad <= 256): the whole lower triangle lives in the VGPRs of ONE workgroup.
-// 1024 threads as a 32x32 grid; thread (ti, tj) owns A[32 bi + ti][32 bj + tj] for bj <= bi < 8 (36 doubles = 72 of its
-// 128 VGPRs; 16 waves x 128 VGPRs = the CU's whole 512 KB register file). Column k is broadcast through a double-buffered LDS
-// vector (one barrier per column), every thread applies the rank-1 update to its own elements, then the same
-// distribution does the forward / diagonal / backward substitutions. One launch replaces 2 * n/16 + 1.
-// 1/d to full double precision without the IEEE division sequence: v_rcp_f64 + two Newton steps
+// 1/d to full double precision without the IEEE division sequence: v_rcp_f64 + one third-order correction
 __device__ __forceinline__ double fast_recip(double d)
 {
     const double r = __builtin_amdgcn_rcp(d), e = fma(-d, r, 1.0);       // v_rcp_f64: 2^-24.4; r (1 + e + e^2): error e^3 (scratch/probe/rcp_probe.hip)
     return fma(r, fma(e, e, e), r);
 }
 
-// (use_reg: 1 = k_ldlt_mfma, 2 = k_ldlt_reg, 0 = blocked multi-launch fallback; one workgroup per problem)
-template <int NBLK>
-__global__ __launch_bounds__(1024) void k_ldlt_reg(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls)
-{
-    const BaProb& pb = probs[blockIdx.x];
-    if (ctls[blockIdx.x].state > ST_RETRY || pb.np == 0 || pb.use_reg != 2) return;
-    const double* __restrict__ S = pb.S;
-    const double* __restrict__ b = pb.bsch;
-    double* __restrict__ x = pb.xp;
-    double* __restrict__ ok = &ctls[blockIdx.x].ok;
-    const int ld = pb.ld, n = pb.n;
-    constexpr int NS = NBLK * (NBLK + 1) / 2;
-#define SLOT(bi, bj) ((bi) * ((bi) + 1) / 2 + (bj))
-    __shared__ double col[2][NBLK * 32];
-    __shared__ double y[NBLK * 32];
-    __shared__ double s_invd[NBLK * 32 + 2];       // 1/d_k for every pivot (columns stay unscaled: L[i][k] = A[i][k] / d_k)
-    __shared__ double Lkk[32][33];
-    __shared__ double s_yk[2];
-    // thread (ti, tj): a wave holds TWO columns tj = 2 wave + (lane >> 5) and all 32 row residues ti = lane & 31, so a
-    // pivot column is published by a single wave (LDS instruction issue, not bytes, bounds each step)
-    const int tid = threadIdx.x, ti = tid & 31, tj = tid >> 5, wave = tid >> 6, lane = tid & 63;
-    double a[NS];
-#pragma unroll
-    for (int bi = 0; bi < NBLK; ++bi)
-#pragma unroll
-        for (int bj = 0; bj <= bi; ++bj) {
-            const int i = bi * 32 + ti, j = bj * 32 + tj;
-            a[SLOT(bi, bj)] = (i < n && j < n) ? S[(size_t)j * ld + i] : (i == j ? 1.0 : 0.0);   // S is symmetric: coalesced along i
-        }
-    // The right-hand side rides along in the registers of ONE wave (wave 15: lane l owns rows l, l+64, ...), so the
-    // forward substitution L y = b is fused into the factorisation and costs the other 15 waves nothing.
-    constexpr int NY = NBLK / 2;
-    double yr[NY];
-    const bool ywave = wave == 15;
-#pragma unroll
-    for (int q = 0; q < NY; ++q) { const int i = q * 64 + lane; yr[q] = (ywave && i < n) ? b[i] : 0.0; }
-    // Look-ahead: the owners of A[k+1][k+1] and y[k+1] publish 1/d and y right after their own update in step k.
-    if (tid == 0) { const double d0 = a[SLOT(0, 0)]; s_invd[0] = fast_recip(d0); if (d0 == 0.0 || !isfinite(d0)) *ok = 0.0; }
-    if (tid == 960) s_yk[0] = yr[0];
-    // kb (32-column block of the pivot) is a compile-time constant in every unrolled copy of the body, so all
-    // register-array indices are static; kt walks the columns of the block at run time. One barrier per column.
-#pragma unroll
-    for (int kb = 0; kb < NBLK; ++kb) {
-#pragma nounroll
-        for (int kt = 0; kt < 32; ++kt) {
-            const int k = kb * 32 + kt;
-            if (k >= n) break;
-            double* cb = col[k & 1];
-            if (tj == kt) {
-#pragma unroll
-                for (int bi = kb; bi < NBLK; ++bi) cb[bi * 32 + ti] = a[SLOT(bi, kb)];
-            }
-            __syncthreads();
-            const double invd = s_invd[k];
-            double ci[NBLK], lj[NBLK];
-#pragma unroll
-            for (int bb = kb; bb < NBLK; ++bb) { ci[bb] = cb[bb * 32 + ti]; lj[bb] = cb[bb * 32 + tj] * invd; }
-            const int kn = k + 1, knt = kn & 31;
-            if (tj > kt) {                                // rest of the pivot's own column block
-                if (ti >= tj) a[SLOT(kb, kb)] = fma(-ci[kb], lj[kb], a[SLOT(kb, kb)]);
-#pragma unroll
-                for (int bi = kb + 1; bi < NBLK; ++bi) a[SLOT(bi, kb)] = fma(-ci[bi], lj[kb], a[SLOT(bi, kb)]);
-            }
-            if (kn < n && kt < 31 && ti == knt && tj == knt) {          // next pivot lives in this block column
-                const double dn = a[SLOT(kb, kb)];
-                s_invd[kn] = fast_recip(dn);
-                if (dn == 0.0 || !isfinite(dn)) *ok = 0.0;
-            }
-            if (ywave) {                                  // forward substitution: y[i] -= (A[i][k] / d_k) y[k], rows below k
-                const double f = s_yk[k & 1] * invd;
-                double ynext = 0;
-#pragma unroll
-                for (int q = 0; q < NY; ++q) {
-                    const int i = q * 64 + lane;
-                    if (i > k && i < n) yr[q] = fma(-cb[i], f, yr[q]);
-                    if (i == kn) ynext = yr[q];
-                }
-                if ((kn & 63) == lane && kn < n) s_yk[kn & 1] = ynext;
-            }
-#pragma unroll
-            for (int bj = kb + 1; bj < NBLK; ++bj) {      // column blocks to the right: no column predicate needed
-                if (ti >= tj) a[SLOT(bj, bj)] = fma(-ci[bj], lj[bj], a[SLOT(bj, bj)]);
-#pragma unroll
-                for (int bi = bj + 1; bi < NBLK; ++bi) a[SLOT(bi, bj)] = fma(-ci[bi], lj[bj], a[SLOT(bi, bj)]);
-            }
-            if (kn < n && kt == 31 && kb + 1 < NBLK && ti == 0 && tj == 0) {   // next pivot heads the next block column
-                const double dn = a[SLOT(kb + 1 < NBLK ? kb + 1 : kb, kb + 1 < NBLK ? kb + 1 : kb)];
-                s_invd[kn] = fast_recip(dn);
-                if (dn == 0.0 || !isfinite(dn)) *ok = 0.0;
-            }
-        }
-    }
-    if (ywave) {
-#pragma unroll
-        for (int q = 0; q < NY; ++q) y[q * 64 + lane] = yr[q];
-    }
-    __syncthreads();
-    if (tid < n) y[tid] *= s_invd[tid];              // z = D^-1 y
-    __syncthreads();
-    // Backward substitution L^T x = z with L[i][j] = A[i][j] * invd[j], one 32-column block per round: the diagonal
-    // triangle is solved by wave 0 with x in registers (pivot broadcast by v_readlane, rows prefetched from LDS), then
-    // the rows of this block are eliminated from all earlier blocks with a fixed-order reduction over the waves.
-#pragma unroll
-    for (int kb = NBLK - 1; kb >= 0; --kb) {
-        if (kb * 32 >= n) continue;
-        Lkk[ti][tj] = a[SLOT(kb, kb)];
-        __syncthreads();
-        if (wave == 0) {
-            double xv = lane < 32 ? y[kb * 32 + lane] : 0.0;
-            const double sc = lane < 32 ? s_invd[kb * 32 + lane] : 0.0;      // column scaling of L
-            for (int kt = 31; kt >= 1; --kt) {
-                const double lkj = lane < kt ? Lkk[kt][lane] * sc : 0.0;     // independent of x: the loads pipeline
-                const int lo = __builtin_amdgcn_readlane(__double2loint(xv), kt), hi = __builtin_amdgcn_readlane(__double2hiint(xv), kt);
-                const double xk = __hiloint2double(hi, lo);
-                if (kb * 32 + kt < n) xv = fma(-lkj, xk, xv);
-            }
-            if (lane < 32) y[kb * 32 + lane] = xv;
-        }
-        __syncthreads();
-        if (kb > 0) {
-            const double xi = y[kb * 32 + ti];
-#pragma unroll
-            for (int bj = 0; bj < kb; ++bj) {
-                double pv = a[SLOT(kb, bj)] * xi;          // A[32 kb + ti][32 bj + tj] * x[32 kb + ti]
-#pragma unroll
-                for (int d = 1; d < 32; d <<= 1) pv += __shfl_xor(pv, d);     // sum over the 32 rows ti (one half-wave)
-                if (ti == 0) y[bj * 32 + tj] = fma(-pv, s_invd[bj * 32 + tj], y[bj * 32 + tj]);
-            }
-            __syncthreads();
-        }
-    }
-    if (tid < n) x[tid] = y[tid];
-#undef SLOT
-}
+// (use_reg: 1 = k_ldlt_mfma, 0 = blocked multi-launch fallback; one workgroup per problem. The column-by-column VALU predecessor of k_ldlt_mfma,
+// k_ldlt_reg, was deleted in round 5: nothing selected it but an A/B switch.)
 
 // ---- blocked LDL^T of S (ld x ld, lower part used, n_pad multiple of 16) ----
 // panel step k0: factor the 16x16 diagonal block, then L rows below; W = L D kept for the trailing update
@@ -2673,7 +2536,7 @@ __device__ __forceinline__ void pose_control(PoseShared& S, const PoseArgs& a, i
                     const double dj = bcast_lane(A[j], j);      // the pivot, every earlier column already subtracted
                     dd[j] = dj;
                     if (!(dj > 0.0) || !isfinite(dj)) okf = false;
-                    const double inv = fast_recip(dj);          // (v_rcp_f64 + two Newton steps: the IEEE division sequence is ~3 x as long, six times in a row)
+                    const double inv = fast_recip(dj);          // (v_rcp_f64 + one third-order correction: the IEEE division sequence is ~3 x as long, six times in a row)
                     if (j == r) myinv = inv;
                     const double l = A[j] * inv;                // L[r][j] (meaningful on lanes r > j)
                     A[j] = l;
@@ -3397,7 +3260,6 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     }
     const double t_build = ms_since(t_call0);
     const bool force_blocked = opt(OPT_BA_FORCE_BLOCKED_LDLT) != 0;   // test hook: the n > 256 path at small n
-    const bool ldlt_valu = opt(OPT_BA_LDLT_VALU) != 0;                // column-by-column VALU predecessor of k_ldlt_mfma
 
     // ---- arena layout: [upload | zeroed | scratch | download]
     struct Regions { size_t upload_end, zero_begin, zero_end, dl_begin, dl_end; };
@@ -3445,7 +3307,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             const size_t P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
             q.P = (int)P; q.L = (int)L; q.E = (int)E; q.np = r.np; q.n = r.n; q.n_pad = r.n_pad; q.ld = std::max(r.n_pad, kNB); q.n_pairs = r.n_pairs;
             q.nblk = (int)((E + 255) / 256); q.nb_pts = (int)((L + 63) / 64); q.nb_pose = (int)((P + 63) / 64);
-            q.use_reg = (r.n <= 256 && !force_blocked) ? (ldlt_valu ? 2 : 1) : 0;
+            q.use_reg = (r.n <= 256 && !force_blocked) ? 1 : 0;
             q.iters[0] = pb->iters1; q.iters[1] = pb->iters2; q.robust0 = pb->huber_delta > 0.0 ? 1 : 0; q.pad = 0;   // BundleAdjustment(bRobust = false): no kernel
             q.delta = pb->huber_delta; q.chi2_th = pb->chi2_th;
             q.poses[0] = c.get<double>(7 * P); q.points[0] = c.get<double>(3 * L);
@@ -3612,7 +3474,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     struct Group {
         hipStream_t st; const BaProb* dp; BaCtl* ctls; int nb, off; int* words; unsigned* ticket;
         int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, g_pts = 0, max_npad_blocked = 0;
-        bool any_mfma = false, any_valu = false, any_blocked = false, finished = false, fused_update = true, front = false;
+        bool any_mfma = false, any_blocked = false, finished = false, fused_update = true, front = false;
         int g_front = 0, spec_cap = 1;
         int max_n_mfma = 0;
     };
@@ -3637,7 +3499,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             max_steps = std::max(max_steps, (std::max(q.iters[0], 0) + std::max(q.iters[1], 0)) * 10 + 2);
             if (q.np) {
                 if (q.use_reg == 1) gr.max_n_mfma = std::max(gr.max_n_mfma, q.n);
-                gr.any_mfma |= q.use_reg == 1; gr.any_valu |= q.use_reg == 2; gr.any_blocked |= q.use_reg == 0;
+                gr.any_mfma |= q.use_reg == 1; gr.any_blocked |= q.use_reg == 0;
                 if (q.use_reg == 0) gr.max_npad_blocked = std::max(gr.max_npad_blocked, q.n_pad);
             }
         }
@@ -3676,13 +3538,12 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             }
             if (gr.g_schur) spec.push_back({schur_fn(schur_chunks(nb)), dim3(gr.g_schur, nb), dim3(schur_threads(schur_chunks(nb))), a_cc});
             if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<kLdltSlotsSmall> : (void*)k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), a_c});
-            if (gr.any_valu) spec.push_back({(void*)k_ldlt_reg<8>, dim3(nb), dim3(1024), a_c});
             if (gr.fused_update) spec.push_back({(void*)k_update_error<false>, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
             else {
                 spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
                 spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
             }
-            const unsigned shape = (gr.g_schur ? 1u : 0u) | (gr.any_mfma ? 2u : 0u) | (gr.any_valu ? 4u : 0u) | 8u;
+            const unsigned shape = (gr.g_schur ? 1u : 0u) | (gr.any_mfma ? 2u : 0u) | 8u;
             BaContext::StepGraph& sg = ctx.step_graph[g];
             auto params_of = [](const Spec& sp) { hipKernelNodeParams kp{}; kp.func = sp.fn; kp.gridDim = sp.grid; kp.blockDim = sp.block; kp.sharedMemBytes = 0; kp.kernelParams = sp.args; kp.extra = nullptr; return kp; };
             bool ok = true;
@@ -3740,7 +3601,6 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             if (gr.max_n_mfma <= 240) hipLaunchKernelGGL(k_ldlt_mfma<kLdltSlotsSmall>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
             else hipLaunchKernelGGL(k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
         }
-        if (gr.any_valu) hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(nb), dim3(1024), 0, gs, dp, ctls);
         if (gr.any_blocked) {
             for (int k0 = 0; k0 < gr.max_npad_blocked; k0 += kNB) {
                 hipLaunchKernelGGL(k_ldlt_panel, dim3(nb), dim3(256), 0, gs, dp, ctls, k0);

@@ -45,7 +45,6 @@ namespace dcs {
     X(BA_SCHUR_MID,                4)                                                                                                    \
     X(BA_TRACE,                    0)   /* 1: host time per phase of dcs_ba_local_batch on stderr */                                     \
     X(BA_FORCE_BLOCKED_LDLT,       0)   /* test hook: the n > 256 factorisation at small n */                                            \
-    X(BA_LDLT_VALU,                0)   /* 1: the column-by-column predecessor of k_ldlt_mfma */                                         \
     X(BA_GROUPS,                   0)   /* > 0: stream groups of a batch */                                                              \
     X(BA_PAIRS_SIDE,               1)   /* 0: pose-pair lists built in front of the first step instead of beside it */                   \
     X(BA_FUSED_UPDATE,             1)   /* 0: k_solve_update + k_error<1> as two launches */                                             \

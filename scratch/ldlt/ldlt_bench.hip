@@ -34,8 +34,7 @@ int main(int argc, char** argv)
     hipMemcpy(dc, hc.data(), sizeof(BaCtl) * B, hipMemcpyHostToDevice);
     auto launch = [&] {
         if (which == 1 && n <= 240) hipLaunchKernelGGL(k_ldlt_mfma<kLdltSlotsSmall>, dim3(B), dim3(kLdltThreads), 0, 0, (const BaProb*)dp, dc);
-        else if (which == 1) hipLaunchKernelGGL(k_ldlt_mfma<kLdltSlotsBig>, dim3(B), dim3(kLdltThreads), 0, 0, (const BaProb*)dp, dc);
-        else hipLaunchKernelGGL(k_ldlt_reg<8>, dim3(B), dim3(1024), 0, 0, (const BaProb*)dp, dc);
+        else hipLaunchKernelGGL(k_ldlt_mfma<kLdltSlotsBig>, dim3(B), dim3(kLdltThreads), 0, 0, (const BaProb*)dp, dc);
     };
     launch();
     hipDeviceSynchronize();

@@ -1,6 +1,6 @@
 """The opt-in paths of the BA solver (library options, read per call) still give the default path's results: the LM step as one
 hipGraph, one step of look-ahead, the ordered download, one stream group, the pose-pair lists built on the main stream instead of the side
-stream (bit for bit), and -- other summation orders, to 1e-9 -- the column-by-column VALU factorisation and the two-launch update + error
+stream (bit for bit), and -- other summation orders, to 1e-9 -- the two-launch update + error
 evaluation (k_solve_update + k_error<1>, the path of problems with more than 512 poses). Round 5: options instead of environment switches,
 so every variant runs in THIS process."""
 import hashlib
@@ -39,7 +39,7 @@ def test_ba_opt_in_paths_equal_default(pkg, synth):
         with pkg.abi.options(**extra):
             got = _run(pkg, synth)
         assert got["digest"] == base["digest"], extra
-    for extra in ({"DCS_BA_LDLT_VALU": 1}, {"DCS_BA_FUSED_UPDATE": 0}, {"DCS_BA_FUSED_UPDATE": 0, "DCS_BA_GRAPH": 1}):
+    for extra in ({"DCS_BA_FUSED_UPDATE": 0}, {"DCS_BA_FUSED_UPDATE": 0, "DCS_BA_GRAPH": 1}):
         with pkg.abi.options(**extra):
             other = _run(pkg, synth)
         for a, b in zip(other["solves"], base["solves"]):
