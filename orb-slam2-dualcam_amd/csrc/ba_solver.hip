@@ -942,10 +942,38 @@ __host__ __device__ inline size_t s_tile_off(int x, int y)       // element (x, 
 constexpr int kSchurFine = 28;                           // partial sums per S entry: list entry k belongs to partial k % 28, whatever the workgroup size
 constexpr int kSchurThreads = 256;
 constexpr int kSchurRhsChunks = 42;                      // 42 x 6 rows = 252 threads for the reduced right-hand side
-// C = list chunks per workgroup: 7 (4 waves, thread (q, el) keeps the partials q, q + 7, q + 14, q + 21 of entry el in 4 accumulators), 14 (8
-// waves, 2 accumulators) or 28 (16 waves, one partial per thread: a single problem has too few pose pairs to fill the chip with 4-wave
-// workgroups). All of them add the 28 partials in index order: the same bits whichever one runs, so a batch still equals its
-// problems solved one by one.
+// C = list chunks per workgroup: 28 (16 waves, one partial per thread) is the form that runs -- for one or two problems, where the pose pairs are too
+// few to fill the chip and the shortest chain per thread wins; k_schur_w below takes the larger groups. (C = 7 / 14, 4 / 8 waves with several partials
+// per thread, were the round-4 forms for batches.) Every form adds the 28 partials in index order: the same bits whichever one runs, so a batch still
+// equals its problems solved one by one.
+// one partial of a pose's reduced right-hand side row: sum over the list entries k0, k0 + kSchurRhsChunks, ... of H_pl[e] row . db[point(e)], in list order.
+// Three dependent loads per entry (list -> edge -> point -> db): eight entries go through each level together (one at a time the ~11 entries of a
+// C4 pose made this row the longest chain of the whole Schur launch).
+__device__ __forceinline__ double schur_rhs_partial(int k0, int k1, const int32_t* __restrict__ ps_edges, const int32_t* __restrict__ e_point,
+                                                    const double* __restrict__ Hrow /* Hpl + 3 r */, const double* __restrict__ db)
+{
+    constexpr int kU = 8;
+    double a = 0;
+    for (int kb = k0; kb < k1; kb += kU * kSchurRhsChunks) {
+        int e[kU], pt[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const int k = kb + u * kSchurRhsChunks; e[u] = ps_edges[k < k1 ? k : k0]; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) pt[u] = e_point[e[u]];
+        double B[kU][3], d[kU][3];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const double* Bp = Hrow + (size_t)e[u] * 18;
+            const double* dp = db + 3 * pt[u];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { B[u][j] = Bp[j]; d[u][j] = dp[j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) if (kb + u * kSchurRhsChunks < k1) a += B[u][0] * d[u][0] + B[u][1] * d[u][1] + B[u][2] * d[u][2];
+    }
+    return a;
+}
+
 template <int C>
 __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
@@ -967,18 +995,7 @@ __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(c
         const double* __restrict__ db = pb.db;
         const int i = blockIdx.x - n_pairs, t = threadIdx.x;
         const int r = t % 6, q = t / 6;
-        if (q < kSchurRhsChunks) {
-            double a = 0;
-            const int k1 = ps_off[i + 1];
-#pragma unroll 4
-            for (int k = ps_off[i] + q; k < k1; k += kSchurRhsChunks) {
-                const int e = ps_edges[k];
-                const double* B = Hpl + (size_t)e * 18 + r * 3;
-                const double* d = db + 3 * e_point[e];
-                a += B[0] * d[0] + B[1] * d[1] + B[2] * d[2];
-            }
-            bpart[q][r] = a;
-        }
+        if (q < kSchurRhsChunks) bpart[q][r] = schur_rhs_partial(ps_off[i] + q, ps_off[i + 1], ps_edges, e_point, Hpl + r * 3, db);
         __syncthreads();
         if (t < 6) { double a = 0; for (int q2 = 0; q2 < kSchurRhsChunks; ++q2) a += bpart[q2][t]; pb.bsch[i * 6 + t] = pb.bp[i * 6 + t] - a; }
         return;
@@ -1025,6 +1042,106 @@ __global__ __launch_bounds__(C == 7 ? 256 : C == 14 ? 512 : 1024) void k_schur(c
         // Tiles of the lower triangle (diagonal tiles: both triangles), filled from the UPPER entries only -- like g2o, which hands
         // Eigen the upper triangle (linear_solver_eigen.h:94-124, selfadjointView<Upper>): entry (r, c) and entry (c, r) of a diagonal
         // pose block are the same number on paper but two differently rounded sums here.
+        if (xa <= ya) {
+            pb.S[s_tile_off(ya, xa)] = v;
+            if (xa != ya && (xa >> 4) == (ya >> 4)) pb.S[s_tile_off(xa, ya)] = v;
+        }
+        return;
+    }
+    pb.S[(size_t)xa * ld + ya] = v;
+    if (i1 != i2) pb.S[(size_t)ya * ld + xa] = v;
+}
+
+// ---- k_schur_w (round 5): TWO WAVES per pose pair, a lane per (partial, 3 x 3 quarter of the 6 x 6 block). k_schur gives every list entry to 36 threads that
+// each load 7 values for 3 multiply-adds (an int2, a row of BD, a row of H_pl): 16 waves per pair, and a batch of 4 problems is 3 440 pairs = 27 500 waves, 3.8
+// rounds of the chip at 11 us. Here lane (q, hr, hc) walks the entries of partial q (k = q, q + 28, ...: k_schur's own partials, so the sums keep their order and
+// their BITS) with rows 3 hr .., columns 3 hc .. of the block in 9 accumulators: an entry costs it 18 loads (three rows of BD[e1], three of H_pl[e2]) for 27
+// multiply-adds. The walk is a chain of dependent loads (list entry -> blocks), and the diagonal pairs hold ~16 entries per partial, so FOUR entries' blocks
+// are requested together and the next four index pairs ahead of them. The 28 partials are added in index order through LDS (rows of 37 doubles), the block goes
+// to S exactly as k_schur writes it. Workgroups of 4 waves = 2 pairs; the workgroups behind the pairs are k_schur's right-hand-side rows.
+constexpr int kSchurWPairs = 2;
+__global__ __launch_bounds__(128 * kSchurWPairs) void k_schur_w(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
+{
+    __shared__ double s_part[kSchurWPairs][kSchurFine][37];
+    const BaProb& pb = probs[blockIdx.y];
+    const BaCtl& ctl = ctls[blockIdx.y];
+    if (ctl.state > ST_RETRY || pb.np == 0) return;
+    const int n_pairs = pb.n_pairs, n_pb = (n_pairs + kSchurWPairs - 1) / kSchurWPairs;
+    if ((int)blockIdx.x >= n_pb + pb.np) return;
+    const double* __restrict__ Hpl = pb.Hpl[ctl.cur];
+    if ((int)blockIdx.x >= n_pb) {                           // the reduced right-hand side of one free pose: k_schur's code (kSchurRhsChunks x 6 threads)
+        double (*bpart)[6] = reinterpret_cast<double (*)[6]>(&s_part[0][0][0]);
+        static_assert(kSchurRhsChunks * 6 <= 128 * kSchurWPairs && kSchurRhsChunks * 6 <= kSchurFine * 37, "rhs partials live in s_part");
+        const int32_t* __restrict__ ps_off = pb.ps_off;
+        const int32_t* __restrict__ ps_edges = pb.ps_edges;
+        const int32_t* __restrict__ e_point = pb.epoint;
+        const double* __restrict__ db = pb.db;
+        const int i = blockIdx.x - n_pb, t = threadIdx.x;
+        const int r = t % 6, q = t / 6;
+        if (q < kSchurRhsChunks) bpart[q][r] = schur_rhs_partial(ps_off[i] + q, ps_off[i + 1], ps_edges, e_point, Hpl + r * 3, db);
+        __syncthreads();
+        if (t < 6) { double a = 0; for (int q2 = 0; q2 < kSchurRhsChunks; ++q2) a += bpart[q2][t]; pb.bsch[i * 6 + t] = pb.bp[i * 6 + t] - a; }
+        return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, pl = wave >> 1;
+    const int p = min(blockIdx.x * kSchurWPairs + pl, n_pairs - 1);                  // (an odd pair count: the last workgroup's second half repeats its pair and stores nothing)
+    const bool real = (int)(blockIdx.x * kSchurWPairs + pl) < n_pairs;
+    const int k0 = pb.pair_off[p], k1 = pb.pair_off[p + 1];
+    const bool skip = !real || (k0 == k1 && p >= pb.np);     // two poses without a common point: their block of S stays zero (the arena's zeroed region)
+    const int2* __restrict__ pair_e = reinterpret_cast<const int2*>(pb.pair_e);
+    const double* __restrict__ BD = pb.BD;
+    const int ql = lane >> 2, hr = (lane >> 1) & 1, hc = lane & 1, q = 14 * (wave & 1) + ql;
+    double (*part)[37] = s_part[pl];
+    if (!skip && ql < 14) {
+        double acc[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i] = 0;
+        constexpr int kD = 4;                                // entries in flight per lane
+        auto idx = [&](int k) { return pair_e[k < k1 ? k : k0]; };
+        int2 pn[kD];
+        int k = k0 + q;
+#pragma unroll
+        for (int d = 0; d < kD; ++d) pn[d] = idx(k + kSchurFine * d);
+        while (k < k1) {
+            int2 pc[kD];
+#pragma unroll
+            for (int d = 0; d < kD; ++d) { pc[d] = pn[d]; pn[d] = idx(k + kSchurFine * (kD + d)); }
+            double av[kD][9], bv[kD][9];
+#pragma unroll
+            for (int d = 0; d < kD; ++d) {
+                const double* a = BD + (size_t)pc[d].x * 18 + 9 * hr;          // rows 3 hr .. 3 hr + 2 of BD[e1]
+                const double* b = Hpl + (size_t)pc[d].y * 18 + 9 * hc;         // rows 3 hc .. 3 hc + 2 of H_pl[e2]
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { av[d][i] = a[i]; bv[d][i] = b[i]; }
+            }
+#pragma unroll
+            for (int d = 0; d < kD; ++d) {
+                if (k + kSchurFine * d < k1) {
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc)
+                            acc[rr * 3 + cc] += av[d][rr * 3] * bv[d][cc * 3] + av[d][rr * 3 + 1] * bv[d][cc * 3 + 1] + av[d][rr * 3 + 2] * bv[d][cc * 3 + 2];
+                }
+            }
+            k += kSchurFine * kD;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) part[q][(3 * hr + rr) * 6 + 3 * hc + cc] = acc[rr * 3 + cc];
+    }
+    __syncthreads();
+    if (skip || (wave & 1) || lane >= 36) return;
+    const int t = lane, r = t / 6, c = t % 6;
+    const int i1 = pb.pair_ij[2 * p], i2 = pb.pair_ij[2 * p + 1], ld = pb.ld;
+    double acc = 0;
+    for (int q2 = 0; q2 < kSchurFine; ++q2) acc += part[q2][t];
+    double v = -acc;
+    const double lambda = 1e-5 * ctl.maxdiag * ctl.mult;
+    if (i1 == i2) v += pb.Hpp[(size_t)i1 * 36 + t] + (r == c ? lambda : 0.0);
+    const int xa = i1 * 6 + r, ya = i2 * 6 + c;
+    if (pb.use_reg == 1) {                                   // (tiles of the lower triangle, filled from the upper entries: see k_schur)
         if (xa <= ya) {
             pb.S[s_tile_off(ya, xa)] = v;
             if (xa != ya && (xa >> 4) == (ya >> 4)) pb.S[s_tile_off(xa, ya)] = v;
@@ -2985,15 +3102,13 @@ struct Carver {
     }
 };
 
-// list chunks per k_schur workgroup by group size: 28 (16 waves) for 1-2 problems, DCS_BA_SCHUR_MID (8 waves) up to that many, else 7
-static int schur_chunks(int nb)
+// the Schur launch by group size: k_schur<28> (16 waves per pose pair: the shortest chains) for 1-2 problems, k_schur_w (2 waves per pair: a batch fits
+// the chip in one round) beyond; DCS_BA_SCHUR_WAVE = 0 / 2 forces one of them (same bits)
+static bool schur_use_wave(int nb)
 {
-    const int wide = (int)opt(OPT_BA_SCHUR_WIDE);
-    const int mid = (int)opt(OPT_BA_SCHUR_MID);
-    return nb <= wide ? 28 : nb <= mid ? 14 : 7;
+    const int m = (int)opt(OPT_BA_SCHUR_WAVE);
+    return m == 2 || (m == 1 && nb > 2);
 }
-static void* schur_fn(int c) { return c == 28 ? (void*)k_schur<28> : c == 14 ? (void*)k_schur<14> : (void*)k_schur<7>; }
-static int schur_threads(int c) { return c == 28 ? 1024 : c == 14 ? 512 : 256; }
 
 // A few persistent host threads for the per-problem list building of a batch. One job at a time: a second caller (the header
 // promises re-entrancy) that finds the pool busy simply does its own work inline. The workers are never joined (they sleep on a
@@ -3475,7 +3590,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         hipStream_t st; const BaProb* dp; BaCtl* ctls; int nb, off; int* words; unsigned* ticket;
         int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, g_pts = 0, max_npad_blocked = 0;
         bool any_mfma = false, any_blocked = false, finished = false, fused_update = true, front = false;
-        int g_front = 0, spec_cap = 1;
+        int g_front = 0, spec_cap = 1, g_schur_w = 0;
         int max_n_mfma = 0;
     };
     const bool no_fused_update = opt(OPT_BA_FUSED_UPDATE) == 0;   // A/B: the two launches
@@ -3492,7 +3607,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             gr.g_reduce = std::max(gr.g_reduce, q.np + q.nb_pts);
             gr.g_prep = std::max(gr.g_prep, (q.np ? q.nblk : 0) + (q.L + 255) / 256);
             gr.g_front = std::max(gr.g_front, (q.nblk + kFrontVB - 1) / kFrontVB * (q.np ? 2 : 1) + q.np + (q.L + kFrontThreads - 1) / kFrontThreads);
-            if (q.np) gr.g_schur = std::max(gr.g_schur, q.n_pairs + q.np);
+            if (q.np) { gr.g_schur = std::max(gr.g_schur, q.n_pairs + q.np); gr.g_schur_w = std::max(gr.g_schur_w, (q.n_pairs + kSchurWPairs - 1) / kSchurWPairs + q.np); }
             gr.g_update = std::max(gr.g_update, q.nb_pts + q.nb_pose);
             gr.g_pts = std::max(gr.g_pts, q.nb_pts);
             if (q.P > kFusedMaxPoses || no_fused_update) gr.fused_update = false;
@@ -3536,7 +3651,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
                 spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
                 spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
             }
-            if (gr.g_schur) spec.push_back({schur_fn(schur_chunks(nb)), dim3(gr.g_schur, nb), dim3(schur_threads(schur_chunks(nb))), a_cc});
+            if (gr.g_schur && schur_use_wave(nb)) spec.push_back({(void*)k_schur_w, dim3(gr.g_schur_w, nb), dim3(128 * kSchurWPairs), a_cc});
+            else if (gr.g_schur) spec.push_back({(void*)k_schur<28>, dim3(gr.g_schur, nb), dim3(1024), a_cc});
             if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<kLdltSlotsSmall> : (void*)k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.fused_update) spec.push_back({(void*)k_update_error<false>, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
             else {
@@ -3591,10 +3707,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         if (gr.g_schur) {
             if (step == 1 && pairs_on_side) DCS_HIP(hipStreamWaitEvent(gs, ctx.ev_pairs, 0));      // the pair lists (side stream)
-            const int sc = schur_chunks(nb);
-            if (sc == 28) hipLaunchKernelGGL(k_schur<28>, dim3(gr.g_schur, nb), dim3(1024), 0, gs, dp, (const BaCtl*)ctls);
-            else if (sc == 14) hipLaunchKernelGGL(k_schur<14>, dim3(gr.g_schur, nb), dim3(512), 0, gs, dp, (const BaCtl*)ctls);
-            else hipLaunchKernelGGL(k_schur<7>, dim3(gr.g_schur, nb), dim3(256), 0, gs, dp, (const BaCtl*)ctls);
+            if (schur_use_wave(nb)) hipLaunchKernelGGL(k_schur_w, dim3(gr.g_schur_w, nb), dim3(128 * kSchurWPairs), 0, gs, dp, (const BaCtl*)ctls);
+            else hipLaunchKernelGGL(k_schur<28>, dim3(gr.g_schur, nb), dim3(1024), 0, gs, dp, (const BaCtl*)ctls);
         }
         mark(step, 1);
         if (gr.any_mfma) {

@@ -41,8 +41,7 @@ namespace dcs {
     X(BA_CU_FIRST,                 0)   /* with BA_CU_COUNT > 0: the solver's streams are confined to CUs [first, first + count) */      \
     X(BA_CU_COUNT,                 0)                                                                                                    \
     X(BA_STREAM_PRIORITY,          0)   /* 1 highest, -1 lowest */                                                                       \
-    X(BA_SCHUR_WIDE,               2)                                                                                                    \
-    X(BA_SCHUR_MID,                4)                                                                                                    \
+    X(BA_SCHUR_WAVE,               1)   /* Schur launch: 1 = by group size (k_schur<28> for 1-2 problems, k_schur_w beyond), 0 / 2 = always the former / the latter */ \
     X(BA_TRACE,                    0)   /* 1: host time per phase of dcs_ba_local_batch on stderr */                                     \
     X(BA_FORCE_BLOCKED_LDLT,       0)   /* test hook: the n > 256 factorisation at small n */                                            \
     X(BA_GROUPS,                   0)   /* > 0: stream groups of a batch */                                                              \
