@@ -3183,7 +3183,17 @@ int build_round(const dcs_ba_problem* pb, Round& r)
     r.n_active = E;                                           // round 0 structure: every edge (the second round only masks edges)
     r.pose_idx.assign(P, -1);
     r.pose_act.assign(P, 0);
-    for (int e = 0; e < E; ++e) r.pose_act[e_pose[e]] = 1;
+    // (the range check of every edge rides on this first pass -- one pass per problem on the worker that builds its lists, instead of a serial
+    // loop over the whole batch in front of everything: 0.1 ms of a 2.9-ms batch of 8)
+    {
+        const int32_t* __restrict__ e_cam = pb->edge_cam;
+        const int n_cams = pb->n_cams;
+        for (int e = 0; e < E; ++e) {
+            const int ps = e_pose[e];
+            if ((unsigned)ps >= (unsigned)P || (unsigned)e_point[e] >= (unsigned)L || (unsigned)e_cam[e] >= (unsigned)n_cams) return -2 - e;
+            r.pose_act[ps] = 1;
+        }
+    }
     r.np = 0;
     for (int p = 0; p < P; ++p) if (r.pose_act[p] && !pb->pose_fixed[p]) r.pose_idx[p] = r.np++;
     const int np = r.np;
@@ -3314,10 +3324,6 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             !pb->edge_cam || !pb->obs || !pb->inv_sigma2 || !pb->cams) {
             set_error("bad BA problem %d (n_cams must be 1..%d)", b, kMaxCams); return DCS_ERR_INVALID;
         }
-        const int P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
-        for (int e = 0; e < E; ++e)
-            if (pb->edge_pose[e] < 0 || pb->edge_pose[e] >= P || pb->edge_point[e] < 0 || pb->edge_point[e] >= L || pb->edge_cam[e] < 0 ||
-                pb->edge_cam[e] >= pb->n_cams) { set_error("problem %d: edge %d out of range", b, e); return DCS_ERR_INVALID; }
     }
     int rc = ensure_device();
     if (rc) return rc;
@@ -3359,8 +3365,10 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         auto work = [&](int i) { dup[i] = build_round(problems[live[i]], rounds[i]); };
         if (NB == 1) work(0);
         else host_pool().run(NB, work);            // persistent workers: creating 8 threads per call cost more than the lists themselves
-        for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i) {                       // build_round: -1 fine, e >= 0 a duplicate at edge e, -2 - e edge e out of range
+            if (dup[i] <= -2) { set_error("problem %d: edge %d out of range", live[i], -2 - dup[i]); return DCS_ERR_INVALID; }
             if (dup[i] >= 0) { set_error("problem %d: more than one edge between pose and point of edge %d", live[i], dup[i]); return DCS_ERR_INVALID; }
+        }
         // The device-built pair lists take edge_of[free poses][points] (int32) and one k_schur workgroup per pose PAIR, whatever the
         // covisibility: fine for local BA (tens of poses) and the global BA sizes tested (10 x 70 000, 60 x 800), quadratic beyond. A problem
         // that would need more than 1 GB or 4 M workgroups per step is refused instead of growing silently.
@@ -3836,7 +3844,7 @@ double dcs_debug_ba_build_ms(const dcs_ba_problem* pb, int reps)
     if (!pb || reps < 1) return -1.0;
     Round r;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < reps; ++i) if (build_round(pb, r) >= 0) return -2.0;
+    for (int i = 0; i < reps; ++i) if (build_round(pb, r) != -1) return -2.0;
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 

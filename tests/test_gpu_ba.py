@@ -213,9 +213,14 @@ def test_ba_stop_flag_all_fixed_and_bad_input(pkg, oracle, synth):
     allfix = dict(pb); allfix["pose_fixed"] = np.ones(8, np.uint8)
     got, exp = pkg.Optimizer.LocalBundleAdjustment(allfix), _oracle_run(oracle, allfix)
     assert np.array_equal(got["poses"], pb["poses"]) and np.abs(got["points"] - exp["points"]).max() < 1e-6
-    bad = dict(pb); bad["edge_pose"] = pb["edge_pose"].copy(); bad["edge_pose"][0] = 99
-    with pytest.raises(pkg.DcsError):
-        pkg.Optimizer.LocalBundleAdjustment(bad)
+    # an edge out of range (pose, point, camera; first and last edge): refused by the list build's first pass, before anything is indexed with it
+    for key, at, val in (("edge_pose", 0, 99), ("edge_pose", -1, -1), ("edge_point", 3, 60), ("edge_point", -1, -7), ("edge_cam", 5, 2), ("edge_cam", 0, -1)):
+        bad = dict(pb); bad[key] = pb[key].copy(); bad[key][at] = val
+        with pytest.raises(pkg.DcsError, match="out of range"):
+            pkg.Optimizer.LocalBundleAdjustment(bad)
+    with pytest.raises(pkg.DcsError, match="out of range"):                      # inside a batch: the error names the problem
+        bad = dict(pb); bad["edge_point"] = pb["edge_point"].copy(); bad["edge_point"][7] = 1 << 20
+        pkg.Optimizer.LocalBundleAdjustmentBatch([pb, bad, pb])
 
 
 def test_search_by_bow_greedy_vs_oracle(pkg, oracle, synth):
