@@ -1206,7 +1206,6 @@ int dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_t
         if ((rc = proj_frame_upload(s, &t.features, true, false, it.f))) return rc;
         it.f.kf_area = 0; it.f.loop_levels = 0; it.f.chi2_inv_sigma2 = nullptr;
         const int N = it.f.N, np = t.n_points;
-        const size_t npe = (size_t)std::max(np, 1), Ne = (size_t)std::max(N, 1);
         it.n_points = np;
         const uint8_t* hp = t.has_point ? t.has_point : t.features.taken;
         // uploads copy the REAL counts (an empty local map / a frame without features may pass NULL arrays: upload() of 0 elements only reserves)
@@ -1219,24 +1218,38 @@ int dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_t
         q.n = np;
         if ((rc = s.upload(&q.desc, t.desc, 32 * npu))) return rc;
         q.angle = nullptr;
-        if ((rc = s.alloc(&it.q_valid, npe)) || (rc = s.alloc(&it.q_cam, npe)) || (rc = s.alloc(&it.q_level, npe)) || (rc = s.alloc(&it.q_min, npe)) ||
-            (rc = s.alloc(&it.q_max, npe)) || (rc = s.alloc(&it.q_u, npe)) || (rc = s.alloc(&it.q_v, npe)) || (rc = s.alloc(&it.q_radius, npe)) ||
-            (rc = s.alloc(&it.cand, npe * kProjCap)) || (rc = s.alloc(&it.cand_n, npe)) || (rc = s.alloc(&it.state, npe)) || (rc = s.alloc(&it.mq, npe)) ||
-            (rc = s.alloc(&it.qf, Ne)) || (rc = s.alloc(&it.bin, npe)) || (rc = s.alloc(&it.nm, 1)) || (rc = s.alloc(&it.edge_feature, Ne)) ||
-            (rc = s.alloc(&it.point_of_feature, Ne)) || (rc = s.alloc(&it.feat_outlier, Ne))) return rc;
-        q.valid = it.q_valid; q.cam = it.q_cam; q.u = it.q_u; q.v = it.q_v; q.radius = it.q_radius; q.min_level = it.q_min; q.max_level = it.q_max;
         it.edge_base = base; edge_off[(size_t)k] = base;
         base += N;
     }
-    const TrackItem* d_items; const int32_t* d_edge_off; const float* d_sig; const double* d_pose_in;
-    std::vector<double> poses_in((size_t)7 * F);
-    for (int k = 0; k < F; ++k) memcpy(&poses_in[(size_t)7 * k], frames[k].pose, sizeof(double) * 7);
+    // Everything that goes UP is carved first and back to back (the frames' arrays above, then the four small tables, staged here and filled once the
+    // device pointers they hold are known), everything that comes DOWN last and back to back: one DMA operation each way whatever the number of frames
+    // (with the scratch arrays in between a batch of 16 frames cost ~100 copies of 4 us each: a third of its time)
+    TrackItem* d_items; TrackItem* h_items; int32_t* d_edge_off; int32_t* h_edge_off; float* d_sig; float* h_sig; double* d_pose_in; double* h_pose_in;
+    if ((rc = s.stage(&d_items, &h_items, (size_t)F)) || (rc = s.stage(&d_edge_off, &h_edge_off, (size_t)F)) || (rc = s.stage(&d_sig, &h_sig, (size_t)prm->n_levels)) ||
+        (rc = s.stage(&d_pose_in, &h_pose_in, (size_t)7 * F))) return rc;
+    for (int k = 0; k < F; ++k) {                             // scratch of the searches
+        TrackItem& it = items[(size_t)k];
+        const size_t npe = (size_t)std::max(it.n_points, 1), Ne = (size_t)std::max(it.f.N, 1);
+        if ((rc = s.alloc(&it.q_valid, npe)) || (rc = s.alloc(&it.q_cam, npe)) || (rc = s.alloc(&it.q_level, npe)) || (rc = s.alloc(&it.q_min, npe)) ||
+            (rc = s.alloc(&it.q_max, npe)) || (rc = s.alloc(&it.q_u, npe)) || (rc = s.alloc(&it.q_v, npe)) || (rc = s.alloc(&it.q_radius, npe)) ||
+            (rc = s.alloc(&it.cand, npe * kProjCap)) || (rc = s.alloc(&it.cand_n, npe)) || (rc = s.alloc(&it.state, npe)) ||
+            (rc = s.alloc(&it.qf, Ne)) || (rc = s.alloc(&it.bin, npe)) || (rc = s.alloc(&it.edge_feature, Ne))) return rc;
+        ProjQueriesD& q = it.q;
+        q.valid = it.q_valid; q.cam = it.q_cam; q.u = it.q_u; q.v = it.q_v; q.radius = it.q_radius; q.min_level = it.q_min; q.max_level = it.q_max;
+    }
     double *d_xw, *d_obs, *d_w, *d_err, *d_out; int32_t *d_ecam, *d_cnt, *d_ninl; uint8_t *d_level, *d_outl;
-    if ((rc = s.upload(&d_items, items.data(), (size_t)F)) || (rc = s.upload(&d_edge_off, edge_off.data(), (size_t)F)) ||
-        (rc = s.upload(&d_sig, prm->inv_level_sigma2, (size_t)prm->n_levels)) || (rc = s.upload(&d_pose_in, poses_in.data(), poses_in.size())) ||
-        (rc = s.alloc(&d_xw, 3 * Etot)) || (rc = s.alloc(&d_obs, 2 * Etot)) || (rc = s.alloc(&d_w, Etot)) || (rc = s.alloc(&d_err, 2 * Etot)) ||
-        (rc = s.alloc(&d_out, (size_t)7 * F)) || (rc = s.alloc(&d_ecam, Etot)) || (rc = s.alloc(&d_cnt, (size_t)F)) || (rc = s.alloc(&d_ninl, (size_t)F)) ||
-        (rc = s.alloc(&d_level, Etot)) || (rc = s.alloc(&d_outl, Etot))) return rc;
+    if ((rc = s.alloc(&d_xw, 3 * Etot)) || (rc = s.alloc(&d_obs, 2 * Etot)) || (rc = s.alloc(&d_w, Etot)) || (rc = s.alloc(&d_err, 2 * Etot)) ||
+        (rc = s.alloc(&d_ecam, Etot)) || (rc = s.alloc(&d_cnt, (size_t)F)) || (rc = s.alloc(&d_level, Etot)) || (rc = s.alloc(&d_outl, Etot))) return rc;
+    if ((rc = s.alloc(&d_out, (size_t)7 * F)) || (rc = s.alloc(&d_ninl, (size_t)F))) return rc;      // results: from here to the end of the arena
+    for (int k = 0; k < F; ++k) {
+        TrackItem& it = items[(size_t)k];
+        const size_t npe = (size_t)std::max(it.n_points, 1), Ne = (size_t)std::max(it.f.N, 1);
+        if ((rc = s.alloc(&it.mq, npe)) || (rc = s.alloc(&it.point_of_feature, Ne)) || (rc = s.alloc(&it.feat_outlier, Ne)) || (rc = s.alloc(&it.nm, 1))) return rc;
+    }
+    memcpy(h_items, items.data(), sizeof(TrackItem) * (size_t)F);
+    memcpy(h_edge_off, edge_off.data(), sizeof(int32_t) * (size_t)F);
+    memcpy(h_sig, prm->inv_level_sigma2, sizeof(float) * (size_t)prm->n_levels);
+    for (int k = 0; k < F; ++k) memcpy(h_pose_in + (size_t)7 * k, frames[k].pose, sizeof(double) * 7);
     hipStream_t st = s.st;
     if (max_pts > 0) {
         hipLaunchKernelGGL(k_track_frustum, dim3((max_pts + 255) / 256, F), dim3(256), 0, st, d_items, prm->viewing_cos_limit, prm->th);
@@ -1310,15 +1323,11 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
     std::vector<int32_t> edge_off((size_t)F);
     const size_t Etot = (size_t)std::max<long long>(n_feat, 1);
     int base = 0;
-    int32_t* d_nfeat;
-    if ((rc = s.alloc(&d_nfeat, (size_t)F * kFrMaxCams))) return rc;
+    int32_t* d_nfeat = nullptr;
     hipStream_t raw = s.raw_st;
-    // arrays the kernels read past the frame's real feature count (its capacity is all the host knows) start out as zeros
-    auto zeroed = [&](auto** p, size_t n) -> int {
-        int r = s.alloc(p, n);
-        if (r) return r;
-        return hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(**p), raw) == hipSuccess ? DCS_OK : DCS_ERR_HIP;
-    };
+    // The arena is carved in four runs so that a call costs one DMA operation up, one down and two fills whatever the number of frames: (1) everything
+    // that goes up, (2) the arrays the kernels read past a frame's real feature count (its capacity is all the host knows: they start out as zeros --
+    // ONE fill), (3) scratch, (4) everything that comes down, the per-camera match counters (zeroed: the second fill) first.
     for (int k = 0; k < F; ++k) {
         const dcs_track_dev_frame& t = frames[k];
         const dcs_dev_frame& df = t.features;
@@ -1338,15 +1347,12 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
         if ((rc = s.upload(&Fd.scale_factors, v->scale_factors, (size_t)v->n_scale_levels))) return rc;
         d = DevAsm{};
         d.kp = df.d_kp; d.desc = df.d_desc; d.n = df.d_n; d.cap = df.cap; d.first_slot = df.first_slot; d.n_cams = C;
-        d.n_features = d_nfeat + (size_t)k * kFrMaxCams;
         for (int c = 0; c < C; ++c) {
             d.und_on[c] = df.dist && df.K && df.dist[5 * c] != 0.0f;
             if (d.und_on[c]) { for (int j = 0; j < 4; ++j) d.und[c][j] = (double)df.K[4 * c + j]; for (int j = 0; j < 5; ++j) d.und[c][4 + j] = (double)df.dist[5 * c + j]; }
         }
         uint8_t *taken_w, *hasp_w; float* pxw_w;
-        if ((rc = s.alloc(&d.cam_off, (size_t)C + 1)) || (rc = zeroed(&d.kp_x, (size_t)Ncap)) || (rc = zeroed(&d.kp_y, (size_t)Ncap)) || (rc = zeroed(&d.kp_angle, (size_t)Ncap)) ||
-            (rc = zeroed(&d.kp_octave, (size_t)Ncap)) || (rc = s.alloc(&d.desc_out, (size_t)Ncap * 32)) || (rc = s.alloc(&d.grid_off, (size_t)cells + 1)) ||
-            (rc = s.alloc(&d.grid_idx, (size_t)Ncap)) || (rc = s.upload(&d.min_x, df.min_x, (size_t)C)) || (rc = s.upload(&d.min_y, df.min_y, (size_t)C)) ||
+        if ((rc = s.upload(&d.min_x, df.min_x, (size_t)C)) || (rc = s.upload(&d.min_y, df.min_y, (size_t)C)) ||
             (rc = s.upload(&d.w_inv, df.grid_w_inv, (size_t)C)) || (rc = s.upload(&d.h_inv, df.grid_h_inv, (size_t)C))) return rc;
         {   // what the features hold: the WHOLE capacity goes up from a zero-filled host image. (Uploading only n_held entries into a zeroed device
             // array is not enough: Scratch merges staged uploads that are adjacent at their 256-byte padded sizes into one copy, and the padding of
@@ -1363,11 +1369,11 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
         ProjFrameD& f = it.f;
         f = ProjFrameD{};
         f.n_cams = C; f.N = Ncap;                                   // (the real count lives in cam_off on the device; entries beyond it are inert zeros)
-        f.cam_off = d.cam_off; f.kp_x = d.kp_x; f.kp_y = d.kp_y; f.kp_octave = d.kp_octave; f.kp_angle = d.kp_angle; f.desc = d.desc_out; f.taken = taken_w;
-        f.min_x = d.min_x; f.min_y = d.min_y; f.w_inv = d.w_inv; f.h_inv = d.h_inv; f.grid_off = d.grid_off; f.grid_idx = d.grid_idx;
+        f.taken = taken_w; f.min_x = d.min_x; f.min_y = d.min_y; f.w_inv = d.w_inv; f.h_inv = d.h_inv;
         it.has_point = hasp_w; it.point_xw = pxw_w;
         it.n_points = np;
-        const size_t npe = (size_t)std::max(np, 1), Ne = (size_t)std::max(Ncap, 1), npu = (size_t)np;
+        const size_t npu = (size_t)np;
+        (void)cells;
         it.normal = it.min_dist = it.max_dist = nullptr; it.candidate = nullptr;
         if ((rc = s.upload(&it.pos, t.pos, 3 * npu))) return rc;
         if (mode == 0) {
@@ -1381,24 +1387,62 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
         if ((rc = s.upload(&q.desc, t.desc, 32 * npu))) return rc;
         q.angle = nullptr;
         if (mode == 1 && check_orientation && (rc = s.upload(&q.angle, t.q_angle, npu))) return rc;
-        if ((rc = s.alloc(&it.q_valid, npe)) || (rc = s.alloc(&it.q_cam, npe)) || (rc = s.alloc(&it.q_level, npe)) || (rc = s.alloc(&it.q_min, npe)) ||
-            (rc = s.alloc(&it.q_max, npe)) || (rc = s.alloc(&it.q_u, npe)) || (rc = s.alloc(&it.q_v, npe)) || (rc = s.alloc(&it.q_radius, npe)) ||
-            (rc = s.alloc(&it.cand, npe * kProjCap)) || (rc = s.alloc(&it.cand_n, npe)) || (rc = s.alloc(&it.state, npe)) || (rc = s.alloc(&it.mq, npe)) ||
-            (rc = s.alloc(&it.qf, Ne)) || (rc = s.alloc(&it.bin, npe)) || (rc = zeroed(&it.nm, (size_t)kFrMaxCams)) || (rc = s.alloc(&it.edge_feature, Ne)) ||
-            (rc = s.alloc(&it.point_of_feature, Ne)) || (rc = s.alloc(&it.feat_outlier, Ne))) return rc;
-        q.valid = it.q_valid; q.cam = it.q_cam; q.u = it.q_u; q.v = it.q_v; q.radius = it.q_radius; q.min_level = it.q_min; q.max_level = it.q_max;
         it.edge_base = base; edge_off[(size_t)k] = base;
         base += Ncap;
     }
-    const TrackItem* d_items; const DevAsm* d_das; const int32_t* d_edge_off; const float* d_sig; const double* d_pose_in;
-    std::vector<double> poses_in((size_t)7 * F);
-    for (int k = 0; k < F; ++k) memcpy(&poses_in[(size_t)7 * k], frames[k].pose, sizeof(double) * 7);
+    TrackItem* d_items; TrackItem* h_items; DevAsm* d_das; DevAsm* h_das; int32_t* d_edge_off; int32_t* h_edge_off; float* d_sig; float* h_sig; double* d_pose_in; double* h_pose_in;
+    if ((rc = s.stage(&d_items, &h_items, (size_t)F)) || (rc = s.stage(&d_das, &h_das, (size_t)F)) || (rc = s.stage(&d_edge_off, &h_edge_off, (size_t)F)) ||
+        (rc = s.stage(&d_sig, &h_sig, (size_t)prm->n_levels)) || (rc = s.stage(&d_pose_in, &h_pose_in, (size_t)7 * F))) return rc;
+    char *z0 = nullptr, *z1 = nullptr;                              // (2) the zero-filled run
+    for (int k = 0; k < F; ++k) {
+        DevAsm& d = das[(size_t)k];
+        const size_t Ncap = (size_t)frames[k].features.n_cams * frames[k].features.cap;
+        if ((rc = s.alloc(&d.kp_x, Ncap)) || (rc = s.alloc(&d.kp_y, Ncap)) || (rc = s.alloc(&d.kp_angle, Ncap)) || (rc = s.alloc(&d.kp_octave, Ncap))) return rc;
+        if (k == 0) z0 = reinterpret_cast<char*>(d.kp_x);
+        z1 = reinterpret_cast<char*>(d.kp_octave + std::max<size_t>(Ncap, 1));
+    }
+    if (hipMemsetAsync(z0, 0, (size_t)(z1 - z0), raw) != hipSuccess) { set_error("dcs_track_frame_device: hipMemsetAsync failed"); return DCS_ERR_HIP; }
+    for (int k = 0; k < F; ++k) {                                   // (3) scratch
+        TrackItem& it = items[(size_t)k];
+        DevAsm& d = das[(size_t)k];
+        const int C = frames[k].features.n_cams, Ncap = C * frames[k].features.cap, cells = C * DCS_GRID_COLS * DCS_GRID_ROWS;
+        const size_t npe = (size_t)std::max(it.n_points, 1), Ne = (size_t)std::max(Ncap, 1);
+        if ((rc = s.alloc(&d.cam_off, (size_t)C + 1)) || (rc = s.alloc(&d.desc_out, (size_t)Ncap * 32)) || (rc = s.alloc(&d.grid_off, (size_t)cells + 1)) || (rc = s.alloc(&d.grid_idx, (size_t)Ncap)) ||
+            (rc = s.alloc(&it.q_valid, npe)) || (rc = s.alloc(&it.q_cam, npe)) || (rc = s.alloc(&it.q_level, npe)) || (rc = s.alloc(&it.q_min, npe)) ||
+            (rc = s.alloc(&it.q_max, npe)) || (rc = s.alloc(&it.q_u, npe)) || (rc = s.alloc(&it.q_v, npe)) || (rc = s.alloc(&it.q_radius, npe)) ||
+            (rc = s.alloc(&it.cand, npe * kProjCap)) || (rc = s.alloc(&it.cand_n, npe)) || (rc = s.alloc(&it.state, npe)) ||
+            (rc = s.alloc(&it.qf, Ne)) || (rc = s.alloc(&it.bin, npe)) || (rc = s.alloc(&it.edge_feature, Ne))) return rc;
+        ProjFrameD& f = it.f;
+        f.cam_off = d.cam_off; f.kp_x = d.kp_x; f.kp_y = d.kp_y; f.kp_octave = d.kp_octave; f.kp_angle = d.kp_angle; f.desc = d.desc_out;
+        f.grid_off = d.grid_off; f.grid_idx = d.grid_idx;
+        ProjQueriesD& q = it.q;
+        q.valid = it.q_valid; q.cam = it.q_cam; q.u = it.q_u; q.v = it.q_v; q.radius = it.q_radius; q.min_level = it.q_min; q.max_level = it.q_max;
+    }
     double *d_xw, *d_obs, *d_w, *d_err, *d_out; int32_t *d_ecam, *d_cnt, *d_ninl; uint8_t *d_level, *d_outl;
-    if ((rc = s.upload(&d_items, items.data(), (size_t)F)) || (rc = s.upload(&d_das, das.data(), (size_t)F)) || (rc = s.upload(&d_edge_off, edge_off.data(), (size_t)F)) ||
-        (rc = s.upload(&d_sig, prm->inv_level_sigma2, (size_t)prm->n_levels)) || (rc = s.upload(&d_pose_in, poses_in.data(), poses_in.size())) ||
-        (rc = s.alloc(&d_xw, 3 * Etot)) || (rc = s.alloc(&d_obs, 2 * Etot)) || (rc = s.alloc(&d_w, Etot)) || (rc = s.alloc(&d_err, 2 * Etot)) ||
-        (rc = s.alloc(&d_out, (size_t)7 * F)) || (rc = s.alloc(&d_ecam, Etot)) || (rc = s.alloc(&d_cnt, (size_t)F)) || (rc = s.alloc(&d_ninl, (size_t)F)) ||
-        (rc = s.alloc(&d_level, Etot)) || (rc = s.alloc(&d_outl, Etot))) return rc;
+    if ((rc = s.alloc(&d_xw, 3 * Etot)) || (rc = s.alloc(&d_obs, 2 * Etot)) || (rc = s.alloc(&d_w, Etot)) || (rc = s.alloc(&d_err, 2 * Etot)) ||
+        (rc = s.alloc(&d_ecam, Etot)) || (rc = s.alloc(&d_cnt, (size_t)F)) || (rc = s.alloc(&d_level, Etot)) || (rc = s.alloc(&d_outl, Etot))) return rc;
+    {   // (4) what comes down: the match counters of every frame (zeroed) first, then the rest
+        char *n0 = nullptr, *n1 = nullptr;
+        for (int k = 0; k < F; ++k) {
+            TrackItem& it = items[(size_t)k];
+            if ((rc = s.alloc(&it.nm, (size_t)kFrMaxCams))) return rc;
+            if (k == 0) n0 = reinterpret_cast<char*>(it.nm);
+            n1 = reinterpret_cast<char*>(it.nm + kFrMaxCams);
+        }
+        if (hipMemsetAsync(n0, 0, (size_t)(n1 - n0), raw) != hipSuccess) { set_error("dcs_track_frame_device: hipMemsetAsync failed"); return DCS_ERR_HIP; }
+        if ((rc = s.alloc(&d_nfeat, (size_t)F * kFrMaxCams)) || (rc = s.alloc(&d_out, (size_t)7 * F)) || (rc = s.alloc(&d_ninl, (size_t)F))) return rc;
+        for (int k = 0; k < F; ++k) {
+            TrackItem& it = items[(size_t)k];
+            const size_t npe = (size_t)std::max(it.n_points, 1), Ne = (size_t)std::max(it.f.N, 1);
+            if ((rc = s.alloc(&it.mq, npe)) || (rc = s.alloc(&it.point_of_feature, Ne)) || (rc = s.alloc(&it.feat_outlier, Ne))) return rc;
+        }
+    }
+    for (int k = 0; k < F; ++k) das[(size_t)k].n_features = d_nfeat + (size_t)k * kFrMaxCams;
+    memcpy(h_items, items.data(), sizeof(TrackItem) * (size_t)F);
+    memcpy(h_das, das.data(), sizeof(DevAsm) * (size_t)F);
+    memcpy(h_edge_off, edge_off.data(), sizeof(int32_t) * (size_t)F);
+    memcpy(h_sig, prm->inv_level_sigma2, sizeof(float) * (size_t)prm->n_levels);
+    for (int k = 0; k < F; ++k) memcpy(h_pose_in + (size_t)7 * k, frames[k].pose, sizeof(double) * 7);
     hipStream_t st = s.st;                                          // (flushes the staged uploads)
     {   // the features were produced on the caller's stream: this call's stream waits for it
         hipEvent_t ev;
