@@ -99,17 +99,23 @@ __host__ __device__ inline void qfromR(const double R[9], double q[4])
         q[3] = 0.5 * t; t = 0.5 / t;
         q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
     } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 4]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
-        double v[3];
-        v[i] = 0.5 * t; t = 0.5 / t;
-        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
-        q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+        // Eigen: i = the largest diagonal entry (first wins ties), j = i + 1, k = j + 1 cyclic. Written out per case: indexing a local array
+        // with i at run time sends it to scratch memory on the device.
+        const bool b1 = R[4] > R[0];
+        const bool b2 = R[8] > (b1 ? R[4] : R[0]);
+        if (b2) {                                             // i = 2, j = 0, k = 1
+            t = sqrt(R[8] - R[0] - R[4] + 1.0);
+            q[2] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[3] - R[1]) * t; q[0] = (R[2] + R[6]) * t; q[1] = (R[5] + R[7]) * t;
+        } else if (b1) {                                      // i = 1, j = 2, k = 0
+            t = sqrt(R[4] - R[8] - R[0] + 1.0);
+            q[1] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[2] - R[6]) * t; q[2] = (R[7] + R[5]) * t; q[0] = (R[1] + R[3]) * t;
+        } else {                                              // i = 0, j = 1, k = 2
+            t = sqrt(R[0] - R[4] - R[8] + 1.0);
+            q[0] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[7] - R[5]) * t; q[1] = (R[3] + R[1]) * t; q[2] = (R[6] + R[2]) * t;
+        }
     }
 }
 // pose layout: tx,ty,tz,qx,qy,qz,qw
@@ -2304,26 +2310,32 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
 }
 
 
-// ------------------------------------------------------------------ k_pose_opt2 (round 5): PoseOptimization, engineered
+// ------------------------------------------------------------------ k_pose_opt2 (round 6: rebuilt as a compact kernel)
 // The same procedure (Optimizer.cc:250-405, types_six_dof_expmap.cpp:200-255) for frames of up to kPoseFastMax edges, one workgroup of 512
-// threads per frame. What changed against k_pose_opt (which stays for larger frames: 18 us per LM iteration of a 2 000-edge frame):
-//  * the edges live in REGISTERS for the whole call (<= 8 per thread: point, observation, weight, last error), grouped by camera once at the
-//    start (counting sort in LDS) so that every WAVE works on one camera: intrinsics and the composed world -> camera transform
-//    M_c = R_c R(T), m_c = R_c t(T) + t_c are wave-uniform, an edge's point costs 9 FMAs instead of two quaternion rotations;
-//  * J = A adj_c with A the 2 x 6 projection Jacobian in the camera frame (two structural zeros): the wave accumulates A^T W A (21) and
-//    A^T r (6) of its camera, and adj_c^T ( . ) adj_c is applied ONCE per pass to the per-camera totals (36 lanes) instead of 72 multiply-adds
-//    per edge -- the same sums, associated differently;
-//  * ONE pass per trial: the errors of a trial and the linearisation at the trial's pose are one sweep over the registers. g2o recomputes the
-//    errors at the top of the next iteration at exactly that pose when the trial is accepted (and a rejected trial ends the iteration's loop
-//    only together with the round), so the speculative system IS the next iteration's system; a rejection re-solves the kept system;
-//  * the 29 sums (21 + 6 + robust chi2 + active edges) of a pass cross the wave as ONE transposed reduction (32 shuffles, not 29 x 6) in a
-//    fixed tree, the 8 wave partials are added in wave order per camera: results do not depend on the batch the frame is part of;
-//  * wave 0 runs the scalar part (adjoint products on 42 lanes, LDL^T + exp map + LM rule on lane 0, the cameras' transforms on n_cams lanes)
-//    between two workgroup barriers.
+// threads per frame; k_pose_opt stays for larger frames. Round 5's version of this kernel compiled to 940 KB of code with 13 375 spilled SGPRs
+// (a control wave whose every stage was force-inlined three times and broadcast through v_readlane): its passes waited on the instruction cache,
+// not on arithmetic. This one has ONE code path that every wave runs:
+//  * the edges live in registers (point) and LDS (observation, weight, last chi2), grouped by camera once at the start (counting sort in LDS)
+//    so that a WAVE works on one camera: intrinsics and the composed world -> camera transform M_c = R_c R(T), m_c = R_c t(T) + t_c are
+//    wave-uniform, an edge's point costs 9 FMAs;
+//  * J = A adj_c with A the 2 x 6 projection Jacobian in the camera frame (two structural zeros). adj_c is the reference's 6 x 6 matrix as
+//    given (NOT the SE3 adjoint, so it cannot be folded into the geometry): the wave accumulates A^T W A (21) and A^T r (6), reduces
+//    them across its lanes (one transposed reduction on v_permlane32/16_swap), and applies adj_c^T ( . ) adj_c to its own 27 sums as ONE constant
+//    27 x 27 linear map (row q on lane q, built once per call in LDS) before they meet the other waves' -- the same sums as 72 multiply-adds
+//    per edge, associated differently;
+//  * ONE sweep per trial: a trial's errors and the linearisation at the trial's pose. g2o recomputes exactly those when it accepts (and a
+//    rejection re-solves the kept system with a larger lambda);
+//  * NO control wave: after the one workgroup barrier of a pass every wave adds the 8 partial systems in wave order and then runs the scalar part
+//    -- LM rule, 6 x 6 LDL^T, exp map, the cameras' transforms -- itself, every lane the same arithmetic on the same numbers (a wave64 f64
+//    instruction costs the same for one lane as for 64, and two waves per SIMD hide each other's latency). Nothing is broadcast, no second
+//    barrier, no v_readlane; the partial sums are double-buffered so that a fast wave's next pass cannot overwrite what a slow one still reads.
 // Parity bar unchanged (tests/test_gpu_ba.py::test_pose_optimization_vs_oracle, tests/test_gpu_track.py): poses 1e-7 / 1e-8, flags, counts +-1.
-constexpr int kPoT = 512, kPoW = kPoT / 64, kPoWork = kPoW - 1, kPoEpt = 8;   // 7 worker waves + the control wave
-constexpr int kPoseFastMax = (kPoWork - (kMaxCams - 1)) * 64 * kPoEpt;          // 2 048: every camera split leaves the largest camera >= 4 waves x 8 edges per lane
+constexpr int kPoT = 512, kPoW = kPoT / 64, kPoEpt = 7;
+constexpr int kPoseFastMax = 2048;
+// the greedy wave split below leaves no camera more than n / (kPoW - (cameras - 1)) edges per wave (each extra wave goes to the largest ratio)
+static_assert((kPoW - (kMaxCams - 1)) * 64 * kPoEpt >= kPoseFastMax, "a camera's share of the edges must fit its waves' registers");
 constexpr int kPoChunks = (kPoseFastMax + kPoT - 1) / kPoT;
+constexpr int kPoLine = 48;          // a wave's exchange line: H 0..20, b 22..27, zeros 28..43, chi2 44, active edges 45
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -2361,40 +2373,31 @@ __device__ __forceinline__ double wave_sum32(double (&v)[32], int lane)
 #undef DCS_PO_STEP
     return v[0] + __shfl_xor(v[0], 1);
 }
-// value of lane `src` (a compile-time lane) in every lane: two v_readlane, no LDS
-__device__ __forceinline__ double bcast_lane(double x, int src)
+
+// entry q of the upper triangle of a 6 x 6 matrix, rows first: (0,0) (0,1) .. (0,5) (1,1) .. (5,5)
+__device__ inline void tri6(int q, int& r, int& c)
 {
-    return dbl_of((unsigned)__builtin_amdgcn_readlane(__double2loint(x), src), (unsigned)__builtin_amdgcn_readlane(__double2hiint(x), src));
+    r = 0;
+    int base = 0;
+    while (q >= base + (6 - r)) { base += 6 - r; ++r; }
+    c = r + (q - base);
 }
 
-struct PoseShared {
+struct alignas(16) PoseShared {
+    double part[2][kPoW][32];               // a pass's partial systems, wave by wave (double-buffered)
+    double line[kPoW][kPoLine];             // per wave: its own sums of a pass, laid out for the adjoint map
+    double tot[kPoW][32];                   // per wave: the totals of a pass for its own lanes
+    double keep[kPoW][36];                  // per wave: the adopted system (21 + 6 at 0..26) and the pushed pose (28..34)
+    double K[kMaxCams][27][22];             // adj_c^T ( . ) adj_c as a linear map on the 21 + 6 sums: row = output entry
+    double ed[4][kPoEpt][kPoT];             // observation (x, y), weight, chi2 of the last evaluation of every resident edge (112 KB; one workgroup per CU anyway)
+    DCam cam[kMaxCams];                     // the rig's cameras (a by-value kernel argument indexed at run time would be copied to scratch)
+    double rc[kMaxCams][12];                // their rotation matrices + translations
+    double series[34];                      // kPoSeries
     uint16_t list[kPoseFastMax];
     int cnt[kMaxCams][kPoChunks * kPoW];
-    int ncam[kMaxCams], off[kMaxCams], W[kMaxCams], wcam[kPoWork], wu[kPoWork], ctl, bad[kPoWork];
-    double part[kPoWork][32], HA[kMaxCams][32], Tm[kMaxCams][36], Hn[36], bn[6], Hc[36], bc[6], T[7], M[kMaxCams][12], lam;
-    DCam cam[kMaxCams];                    // the rig's cameras: lanes index them (a by-value kernel argument indexed per lane would be copied to scratch)
-    double ed[3][kPoEpt][kPoWork * 64];    // observation (x, y) and weight of every resident edge: the registers hold the point and the last chi2 (84 KB; one workgroup per CU anyway)
+    int ncam[kMaxCams], off[kMaxCams], W[kMaxCams], wcam[kPoW], wu[kPoW], bad[2][kPoW];
 };
 
-// world -> camera of rig camera c at the pose S.T: M = R_c R(T) column by column through the very rotations cam_point() applies, m = R_c t(T) + t_c
-__device__ __forceinline__ void pose_compose(PoseShared& S, int c)
-{
-    const DCam& cc = S.cam[c];
-    double* M = S.M[c];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double ei[3] = {i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0};
-        double r1[3], r2[3];
-        qrot(S.T + 3, ei, r1); qrot(cc.q, r1, r2);
-        M[i] = r2[0]; M[3 + i] = r2[1]; M[6 + i] = r2[2];
-    }
-    double tt[3];
-    qrot(cc.q, S.T, tt);
-    M[9] = tt[0] + cc.t[0]; M[10] = tt[1] + cc.t[1]; M[11] = tt[2] + cc.t[2];
-}
-
-// exp(update) * T like pose_oplus(), with the two libm calls that dominate it on one lane replaced: sin and cos of theta come from ONE sincos,
-// theta^3 is two multiplications (g2o calls pow(theta, 3): <= 1 ulp apart, the update itself is ~1e-3 rad)
 // 1 / sqrt(x) to full double precision: v_rsq_f64 + two Newton steps (x > 0)
 __device__ __forceinline__ double fast_rsqrt(double x)
 {
@@ -2403,8 +2406,7 @@ __device__ __forceinline__ double fast_rsqrt(double x)
     r = r * fma(-0.5 * x * r, r, 1.5);
     return r;
 }
-// exp(update) * T like pose_oplus(), shaped for ONE lane on the control wave's critical path (round 5: ~2 000 of a pass's 12 700 ticks were this
-// function's dependent sqrt -> sincos -> divide -> sqrt -> divide -> sqrt -> divide chain):
+// exp(update) * T like pose_oplus(), shaped for the dependent chain between two sweeps:
 //   * the three coefficients sin(t)/t, (1 - cos t)/t^2, (t - sin t)/t^3 as even series in t^2 (an LM step rotates by far less than 0.5 rad: 11
 //     terms leave < 1e-17; no square root, no sincos, no division -- and no cancellation, which the closed forms have at small t);
 //     t >= 0.5 takes the closed forms
@@ -2417,7 +2419,21 @@ __device__ inline void quat_normalize_fast(double q[4])
     const double r = fast_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
 }
-__device__ inline void pose_oplus_fast(const double* T, const double* u, double* out)
+// coefficients of the three series, highest power first: 1 / (2k+1)!, 1 / (2k+2)!, 1 / (2k+3)! for k = 10 .. 0. The kernel copies them to LDS and
+// reads them where it needs them: as literals the compiler hoists all 33 out of the trial loop into scalar register pairs and spills them.
+__device__ const double kPoSeries[33] = {
+    1.0 / 51090942171709440000.0, 1.0 / 1124000727777607680000.0, 1.0 / 25852016738884976640000.0,
+    1.0 / 121645100408832000.0, 1.0 / 2432902008176640000.0, 1.0 / 51090942171709440000.0,
+    1.0 / 355687428096000.0, 1.0 / 6402373705728000.0, 1.0 / 121645100408832000.0,
+    1.0 / 1307674368000.0, 1.0 / 20922789888000.0, 1.0 / 355687428096000.0,
+    1.0 / 6227020800.0, 1.0 / 87178291200.0, 1.0 / 1307674368000.0,
+    1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0,
+    1.0 / 362880.0, 1.0 / 3628800.0, 1.0 / 39916800.0,
+    1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0,
+    1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0,
+    1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0,
+    1.0, 1.0 / 2.0, 1.0 / 6.0};
+__device__ inline void pose_oplus_fast(const double* T, const double* u, double* out, const double* series)
 {
     const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
     const double t2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
@@ -2428,19 +2444,25 @@ __device__ inline void pose_oplus_fast(const double* T, const double* u, double*
     if (t2 < 1e-10) {                                         // theta < 0.00001 (pose_oplus's first-order branch)
         for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
     } else {
-        double a, b, c;
-        if (t2 < 0.25) {
+        double a, b, c, h = 1.0, ts = t2;                     // ts = (theta h)^2 < 0.25 with h = 2^-halvings
+        int halvings = 0;
+        while (!(ts < 0.25) && halvings < 1100) { ts *= 0.25; h *= 0.5; ++halvings; }
+        {
             // a = sum (-1)^k t2^k / (2k+1)!,  b = sum (-1)^k t2^k / (2k+2)!,  c = sum (-1)^k t2^k / (2k+3)!   (Horner, k = 10 .. 0)
-            a = 1.0 / 51090942171709440000.0; b = 1.0 / 1124000727777607680000.0; c = 1.0 / 25852016738884976640000.0;
-            const double ia[10] = {1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, 1.0 / 1307674368000.0, 1.0 / 6227020800.0, 1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0, 1.0};
-            const double ib[10] = {1.0 / 2432902008176640000.0, 1.0 / 6402373705728000.0, 1.0 / 20922789888000.0, 1.0 / 87178291200.0, 1.0 / 479001600.0, 1.0 / 3628800.0, 1.0 / 40320.0, 1.0 / 720.0, 1.0 / 24.0, 1.0 / 2.0};
-            const double ic[10] = {1.0 / 51090942171709440000.0, 1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, 1.0 / 1307674368000.0, 1.0 / 6227020800.0, 1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0};
+            double sc[33];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) { a = fma(-t2, a, ia[k]); b = fma(-t2, b, ib[k]); c = fma(-t2, c, ic[k]); }
-        } else {
+            for (int k = 0; k < 33; ++k) sc[k] = series[k];
+            a = sc[0]; b = sc[1]; c = sc[2];
+#pragma unroll
+            for (int k = 1; k < 11; ++k) { a = fma(-ts, a, sc[3 * k]); b = fma(-ts, b, sc[3 * k + 1]); c = fma(-ts, c, sc[3 * k + 2]); }
+        }
+        if (!(t2 < 0.25)) {
+            // a rotation of half a radian or more in ONE LM step (never seen; kept exact): sine and cosine of theta / 2^k from the series above,
+            // doubled k times, then the closed forms. (libm's sincos here costs 6 KB of code and two dozen scalar constants for a branch that
+            // does not run.)
             const double theta = sqrt(t2);
-            double sn, cs;
-            sincos(theta, &sn, &cs);
+            double sn = a * (theta * h), cs = 1.0 - b * (t2 * (h * h));
+            for (; halvings > 0; --halvings) { const double s2 = 2.0 * sn * cs; cs = 1.0 - 2.0 * sn * sn; sn = s2; }
             a = sn / theta; b = (1 - cs) / t2; c = (theta - sn) / (t2 * theta);
         }
         for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0 ? 1.0 : 0.0); R[i] = I + a * O[i] + b * O2[i]; V[i] = I + b * O[i] + c * O2[i]; }
@@ -2462,419 +2484,115 @@ __device__ inline void pose_oplus_fast(const double* T, const double* u, double*
     out[3] = qo[0]; out[4] = qo[1]; out[5] = qo[2]; out[6] = qo[3];
 }
 
-// The control wave: everything between two passes. Barrier for barrier the mirror image of pose_worker(). Every stage is spread over the
-// lanes as far as its dependences allow -- a single lane runs dependent f64 code at ~9 ticks per operation, and all of this is on the
-// critical path of every trial (in-kernel timeline, -DDCS_POSE_PROF: the first version spent 11 800 of a pass's 18 600 ticks here).
-template <int NC>        // cameras 0 .. NC - 1 can hold edges (the loops over cameras are unrolled and branch-free: a rig of two does half the loads of kMaxCams)
-__device__ __forceinline__ void pose_control(PoseShared& S, const PoseArgs& a, int f, int n, int lane)
+// (H + lambda I) x = b by LDL^T, H given as the 21 entries of its upper triangle. The terms (L_ik L_jk) d_k leave every entry in ascending k,
+// exactly as solve6()'s inner products do; a division by a pivot is a multiplication by its reciprocal (fast_recip: an ulp apart from solve6()
+// at most, a third of the dependent chain). false = a pivot that is not positive and finite (LinearSolverDense's isPositive()).
+__device__ __forceinline__ bool solve6_fast(const double (&Hs)[21], const double (&b)[6], double lambda, double (&x)[6])
 {
-    const double* Tin = a.poses + 7 * f;
-    double lambda = -1, ni = 2, currentChi = 0, iniChi = 0, bk[7] = {0, 0, 0, 0, 0, 0, 0}, xs[6] = {0, 0, 0, 0, 0, 0};   // LM state: lane 0
-    int nBad = 0, n_it = 0, qmax = 0, it_i = 0, phase = 0, n_bad_edges = 0;
-    bool ok2 = true;
-#ifdef DCS_POSE_PROF
-    unsigned long long prof_c[5] = {0, 0, 0, 0, 0};
-#endif
-    // Loop invariants of this lane, read once: every stage below first LOADS what it needs (independent LDS reads in flight together), then
-    // computes -- a load per operand between the multiply-adds costs an LDS round trip each (the first version: 68 waits in the adjoint stage alone)
-    const int li = lane < 36 ? lane / 6 : 0, lj = lane < 36 ? lane - 6 * (lane / 6) : (lane < 42 ? lane - 36 : 0);
-    double adjA[NC][6], adjB[NC][6];               // adj_c[m][lj] (column lj), adj_c[k][li] (column li; lanes 36..41: column lane - 36 via lj)
-    int wcam_r[kPoWork];
+    double A[6][6];
+    {
+        int q = 0;
 #pragma unroll
-    for (int w = 0; w < kPoWork; ++w) wcam_r[w] = S.wcam[w];
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int m = 0; m < 6; ++m) { adjA[c][m] = S.cam[c].adj[m * 6 + lj]; adjB[c][m] = S.cam[c].adj[m * 6 + (lane < 36 ? li : lj)]; }
-    const int cc_c = (lane >> 2) & (kMaxCams - 1), cc_i = lane & 3;
-    const bool cc_on = lane < 4 * kMaxCams && S.ncam[cc_c] > 0;
-    double cq[4], ct[3];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) cq[d] = S.cam[cc_c].q[d];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) ct[d] = S.cam[cc_c].t[d];
-    // lane (c, i), i = 0..2: column i of M_c = R_c R(T); i = 3: m_c = R_c t(T) + t_c -- the very rotations cam_point() applies
-    auto compose16 = [&]() {
-        double T[7];
-#pragma unroll
-        for (int d = 0; d < 7; ++d) T[d] = S.T[d];
-        const double ei[3] = {cc_i == 0 ? 1.0 : 0.0, cc_i == 1 ? 1.0 : 0.0, cc_i == 2 ? 1.0 : 0.0};
-        double r1[3], r2[3], tt[3];
-        qrot(T + 3, ei, r1); qrot(cq, r1, r2);
-        qrot(cq, T, tt);
-        if (cc_on) {
-            double* M = S.M[cc_c];
-            if (cc_i < 3) { M[cc_i] = r2[0]; M[3 + cc_i] = r2[1]; M[6 + cc_i] = r2[2]; }
-            else { M[9] = tt[0] + ct[0]; M[10] = tt[1] + ct[1]; M[11] = tt[2] + ct[2]; }
-        }
-    };
-    for (int it = 0; it < 4; ++it) {
-        if (lane < 7) S.T[lane] = Tin[lane];                    // :360 every round restarts from the frame's pose
-        wave_sync();
-        compose16();
-        lambda = -1; ni = 2; nBad = 0; n_it = 0; qmax = 0; it_i = 0; phase = 0; ok2 = true;
-        __syncthreads();                                        // B1
-        for (;;) {
-            __syncthreads();                                    // B2: the workers' partial sums are in S.part
-#ifdef DCS_POSE_PROF
-            const unsigned long long tp0 = __builtin_readcyclecounter();
-#endif
-            {   // per-camera totals: the 7 wave partials in wave order, each to its wave's camera (the others add an exact zero)
-                double pw[kPoWork];
-#pragma unroll
-                for (int w = 0; w < kPoWork; ++w) pw[w] = S.part[w][lane & 31];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    double t = 0;
-#pragma unroll
-                    for (int w = 0; w < kPoWork; ++w) t += wcam_r[w] == c ? pw[w] : 0.0;
-                    if (lane < 32) S.HA[c][lane] = t;
-                }
-            }
-            wave_sync();
-            // H = sum_c adj_c^T (A^T W A)_c adj_c as two 6-term products per camera: lane (k, j) forms T_c[k][j] = sum_m HA_c(k, m) adj_c[m][j],
-            // then lane (i, j) sums adj_c[k][i] T_c[k][j] over k, the cameras added in index order; b = sum_c adj_c^T (A^T r)_c on lanes 36..41.
-            // (A camera without edges has zero totals: no branches.)
-            {
-                double ha[NC][6];
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) { const int lo = li < m ? li : m, hi = li < m ? m : li; ha[c][m] = S.HA[c][lo * 6 - lo * (lo - 1) / 2 + (hi - lo)]; }
-                double hb[NC][6];
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) hb[c][k] = S.HA[c][21 + k];
-                double tk[NC], bsum[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    tk[c] = 0; bsum[c] = 0;
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) { tk[c] = fma(ha[c][m], adjA[c][m], tk[c]); bsum[c] = fma(adjB[c][m], hb[c][m], bsum[c]); }
-                }
-                if (lane < 36) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) S.Tm[c][lane] = tk[c];
-                } else if (lane < 42) { double t = bsum[0];
-#pragma unroll
-                    for (int c = 1; c < NC; ++c) t += bsum[c]; S.bn[lane - 36] = t; }
-                wave_sync();
-                double tm[NC][6];
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) tm[c][k] = S.Tm[c][k * 6 + lj];
-                double hs[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    hs[c] = 0;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) hs[c] = fma(adjB[c][k], tm[c][k], hs[c]);
-                }
-                if (lane < 36) { double t = hs[0];
-#pragma unroll
-                    for (int c = 1; c < NC; ++c) t += hs[c]; S.Hn[lane] = t; }
-            }
-            wave_sync();
-#ifdef DCS_POSE_PROF
-            const unsigned long long tp1 = __builtin_readcyclecounter();
-#endif
-            if (lane == 0) {
-                int ctl = 0, adopt = 0, solve = 0;
-                double chi = 0, cnt = 0, bcv[6], hd[6];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { chi += S.HA[c][27]; cnt += S.HA[c][28]; }
-#pragma unroll
-                for (int j = 0; j < 6; ++j) { bcv[j] = S.bc[j]; hd[j] = S.Hn[j * 7]; }
-                if (phase == 0) {                               // evaluation at the current pose (round start, or after a rejected trial that did not end the round)
-                    if ((it_i == 0 && cnt == 0.0) || it_i >= a.its[it]) ctl = 2;          // no active edge / no iterations: optimize() does nothing
-                    else { currentChi = chi; iniChi = chi; adopt = 1; solve = 1; qmax = 0; }
-                } else {
-                    const double tempChi = ok2 ? chi : 1.7976931348623157e308;
-                    double rho = currentChi - tempChi, scale = 0;
-                    for (int j = 0; j < 6; ++j) scale += xs[j] * (lambda * xs[j] + bcv[j]);
-                    scale += 1e-3;
-                    rho /= scale;
-                    bool accepted = false;
-                    if (rho > 0 && isfinite(tempChi)) {
-                        const double t = 2 * rho - 1;
-                        double alpha = 1. - t * t * t;          // g2o: pow(2 rho - 1, 3)
-                        alpha = fmin(alpha, 2. / 3.);
-                        lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi; accepted = true;
-                    } else {
-                        lambda *= ni; ni *= 2;
-                        for (int d = 0; d < 7; ++d) S.T[d] = bk[d];                       // pop (the edges keep the rejected trial's errors, as in g2o)
-                    }
-                    ++qmax;
-                    if (rho < 0 && qmax < 10) solve = 1;                                  // next trial of this iteration: same system, larger lambda
-                    else {
-                        ++n_it;
-                        if (qmax == 10 || rho == 0) ctl = 2;
-                        else { if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0; if (nBad >= 3) ctl = 2; }
-                        ++it_i;
-                        if (it_i >= a.its[it]) ctl = 2;
-                        if (ctl != 2) {
-                            if (accepted) { adopt = 1; solve = 1; iniChi = currentChi; qmax = 0; }   // the trial's pass IS computeActiveErrors + the next linearisation
-                            else phase = 0;                                               // (rho is NaN) re-evaluate at the restored pose
-                        }
-                    }
-                }
-                if (solve && it_i == 0 && phase == 0) {         // computeLambdaInit on the system about to be adopted
-                    double md = 0;
-                    for (int d = 0; d < 6; ++d) md = fmax(fabs(hd[d]), md);
-                    lambda = 1e-5 * md; ni = 2; nBad = 0;
-                }
-                if (solve) S.lam = lambda;
-                S.ctl = ctl | (adopt << 2) | (solve << 3);
-            }
-            wave_sync();
-#ifdef DCS_POSE_PROF
-            const unsigned long long tp2 = __builtin_readcyclecounter();
-#endif
-            const int flags = S.ctl;
-            if ((flags & 4) && lane < 42) { if (lane < 36) S.Hc[lane] = S.Hn[lane]; else S.bc[lane - 36] = S.bn[lane - 36]; }
-            wave_sync();
-            if (flags & 8) {
-                // LDL^T of H + lambda I with ROW i ON LANE i (right-looking; the terms (L_ik L_jk) d_k leave every entry in ascending k exactly as
-                // solve6()'s inner products do), forward substitution likewise; the back substitution runs on lane 0 in solve6()'s order. Divisions by a
-                // pivot are multiplications by its reciprocal (fast_recip): an ulp apart from solve6() at most
-                const int r = lane < 6 ? lane : 5;
-                double A[6], y = S.bc[r];
-#pragma unroll
-                for (int m = 0; m < 6; ++m) A[m] = S.Hc[r * 6 + m];
-                const double lam = S.lam;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) if (m == r) A[m] += lam;
-                double dd[6], myinv = 0.0;
-                bool okf = true;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const double dj = bcast_lane(A[j], j);      // the pivot, every earlier column already subtracted
-                    dd[j] = dj;
-                    if (!(dj > 0.0) || !isfinite(dj)) okf = false;
-                    const double inv = fast_recip(dj);          // (v_rcp_f64 + one third-order correction: the IEEE division sequence is ~3 x as long, six times in a row)
-                    if (j == r) myinv = inv;
-                    const double l = A[j] * inv;                // L[r][j] (meaningful on lanes r > j)
-                    A[j] = l;
-#pragma unroll
-                    for (int m = j + 1; m < 6; ++m) {
-                        const double lm = bcast_lane(l, m);     // L[m][j]
-                        if (r >= m) A[m] -= l * lm * dj;
-                    }
-                }
-                // forward: y_r -= L[r][k] y_k in ascending k; y_k is final once step k - 1 is done
-#pragma unroll
-                for (int k = 0; k < 5; ++k) { const double yk = bcast_lane(y, k); if (r > k) y -= A[k] * yk; }
-                y *= myinv;
-                // L's lower triangle and y for the backward pass (v_readlane: every lane holds them, lane 0 uses them)
-                double Lk[6][6], yy[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { yy[k] = bcast_lane(y, k);
-#pragma unroll
-                    for (int i2 = 0; i2 < k; ++i2) Lk[k][i2] = bcast_lane(A[i2], k); }
-                if (lane == 0) {
-                    ok2 = okf;
-                    for (int d = 0; d < 7; ++d) bk[d] = S.T[d];                           // push
-                    if (ok2) {
-#pragma unroll
-                        for (int i2 = 5; i2 >= 0; --i2) { double acc = yy[i2];
-#pragma unroll
-                            for (int k = i2 + 1; k < 6; ++k) acc -= Lk[k][i2] * xs[k]; xs[i2] = acc; }
-                    } else for (int d = 0; d < 6; ++d) xs[d] = 0;
-                    double o[7];
-                    pose_oplus_fast(bk, xs, o);
-                    for (int d = 0; d < 7; ++d) S.T[d] = o[d];
-                    phase = 1;
-                }
-            }
-            wave_sync();
-#ifdef DCS_POSE_PROF
-            const unsigned long long tp3 = __builtin_readcyclecounter();
-#endif
-            compose16();
-#ifdef DCS_POSE_PROF
-            prof_c[0] += tp1 - tp0; prof_c[1] += tp2 - tp1; prof_c[2] += tp3 - tp2; prof_c[3] += (unsigned long long)__builtin_readcyclecounter() - tp3; ++prof_c[4];
-#endif
-            __syncthreads();                                    // B3
-            if ((flags & 3) == 2) break;
-        }
-        if (lane == 0 && a.n_iters) a.n_iters[4 * f + it] = n_it;
-        __syncthreads();                                        // B4: the workers' outlier counts
-        n_bad_edges = 0;
-        for (int w = 0; w < kPoWork; ++w) n_bad_edges += S.bad[w];
-        if (n < 10) break;                                      // :392
+            for (int c = r; c < 6; ++c) A[c][r] = Hs[q++];                           // lower triangle: A[i][j], j <= i
     }
-#ifdef DCS_POSE_PROF
-    if (lane == 0 && f == 0) printf("control: %llu passes; per pass: totals + adjoint %llu, decision %llu, solve + oplus %llu, compose %llu ticks\n", prof_c[4], prof_c[0] / prof_c[4],
-                                    prof_c[1] / prof_c[4], prof_c[2] / prof_c[4], prof_c[3] / prof_c[4]);
-#endif
-    if (lane < 7) a.out_poses[7 * f + lane] = S.T[lane];
-    if (lane == 0) a.n_inliers[f] = n - n_bad_edges;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) A[d][d] += lambda;
+    double dd[6], inv[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double dj = A[j][j];
+        dd[j] = dj;
+        if (!(dj > 0.0) || !isfinite(dj)) ok = false;
+        inv[j] = fast_recip(dj);
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) A[i][j] *= inv[j];                           // L[i][j]
+#pragma unroll
+        for (int m = j + 1; m < 6; ++m)
+#pragma unroll
+            for (int i = m; i < 6; ++i) A[i][m] -= A[i][j] * A[m][j] * dj;
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { double acc = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) acc -= A[i][k] * y[k]; y[i] = acc; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] *= inv[i];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) { double acc = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) acc -= A[k][i] * x[k]; x[i] = acc; }
+    return ok;
 }
 
-// A worker wave: its camera's share of the edges in registers; one pass per barrier pair.
-__device__ __forceinline__ void pose_worker(PoseShared& S, const PoseArgs& a, int e0, int n, int wave, int lane)
+// a value every lane holds, moved to a scalar register pair (v_readfirstlane): the sweep's wave-uniform operands then cost no vector registers
+__device__ __forceinline__ double uniform_f64(double x)
 {
-    const int wc = __builtin_amdgcn_readfirstlane(S.wcam[wave]), wu = __builtin_amdgcn_readfirstlane(S.wu[wave]), wW = __builtin_amdgcn_readfirstlane(S.W[wc]);
-    const int nc = __builtin_amdgcn_readfirstlane(S.ncam[wc]), coff = __builtin_amdgcn_readfirstlane(S.off[wc]);
-    const int ept = (nc + 64 * wW - 1) / (64 * wW);           // <= kPoEpt by the choice of kPoseFastMax
-    const double fx = S.cam[wc].fx, fy = S.cam[wc].fy, cx = S.cam[wc].cx, cy = S.cam[wc].cy;
-    double X[kPoEpt][3], c2[kPoEpt];                          // point, chi2 of the last evaluation (observation and weight: S.ed)
-    const int sl = wave * 64 + lane;
-    unsigned valid = 0, outl = 0;
+    return dbl_of((unsigned)__builtin_amdgcn_readfirstlane(__double2loint(x)), (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x)));
+}
+
+// world -> camera at the pose T for the camera whose rotation matrix and translation sit at rc[0..8], rc[9..11] (LDS: twelve loads per pass are
+// cheaper than 24 registers held across the sweep): M = Rc R(T), m = Rc t(T) + tc
+__device__ __forceinline__ void pose_compose(const double (&T)[7], const double* rc, double (&M)[12])
+{
+    double Rc[12];
 #pragma unroll
-    for (int j = 0; j < kPoEpt; ++j) {
-        const int p = (j * wW + wu) * 64 + lane;
-        const bool v = j < ept && p < nc;
-        const size_t e = (size_t)e0 + (v ? S.list[coff + p] : 0);
-        X[j][0] = v ? a.xw[3 * e] : 0.0; X[j][1] = v ? a.xw[3 * e + 1] : 0.0; X[j][2] = v ? a.xw[3 * e + 2] : 1.0;
-        S.ed[0][j][sl] = v ? a.obs[2 * e] : 0.0; S.ed[1][j][sl] = v ? a.obs[2 * e + 1] : 0.0; S.ed[2][j][sl] = v ? a.w[e] : 0.0;
-        c2[j] = 0;
-        valid |= (v ? 1u : 0u) << j;
-    }
-    const double delta = a.huber, dsqr = delta * delta;
-    bool robust = true;
-#ifdef DCS_POSE_PROF
-    unsigned long long prof_w[4] = {0, 0, 0, 0};
-    const unsigned long long tw_begin = __builtin_readcyclecounter();
-#endif
-    for (int it = 0; it < 4; ++it) {
-        __syncthreads();                                        // B1
-        for (;;) {
-            // ---- one pass: errors of the active edges at S.T, robust chi2, and the linearisation there
-#ifdef DCS_POSE_PROF
-            const unsigned long long tw0 = __builtin_readcyclecounter();
-#endif
-            double v[32];
+    for (int i = 0; i < 12; ++i) Rc[i] = rc[i];
+    double R[9];
+    qtoR(&T[3], R);
 #pragma unroll
-            for (int q = 0; q < 32; ++q) v[q] = 0;
-            {
-                const double* Mc = S.M[wc];
-                const double M0 = Mc[0], M1 = Mc[1], M2 = Mc[2], M3 = Mc[3], M4 = Mc[4], M5 = Mc[5], M6 = Mc[6], M7 = Mc[7], M8 = Mc[8], m0 = Mc[9], m1 = Mc[10], m2 = Mc[11];
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int j = 0; j < kPoEpt; ++j) {
-                    if (j >= ept) break;                        // wave-uniform
-                    const bool act = ((valid & ~outl) >> j) & 1u;
-                    double x = fma(M0, X[j][0], fma(M1, X[j][1], fma(M2, X[j][2], m0)));
-                    double y = fma(M3, X[j][0], fma(M4, X[j][1], fma(M5, X[j][2], m1)));
-                    double z = fma(M6, X[j][0], fma(M7, X[j][1], fma(M8, X[j][2], m2)));
-                    if (!act) { x = 0; y = 0; z = 1; }          // an excluded edge contributes exact zeros below, whatever its point does
-                    const double iz = 1.0 / z, xz = x * iz, yz = y * iz;
-                    const double ex = S.ed[0][j][sl] - fma(xz, fx, cx), ey = S.ed[1][j][sl] - fma(yz, fy, cy);
-                    const double w = act ? S.ed[2][j][sl] : 0.0;
-                    const double x2 = ex * (w * ex) + ey * (w * ey);
-                    if (act) c2[j] = x2;
-                    const bool big = robust && x2 > dsqr;
-                    double rho0 = x2, we = w;
-                    if (__builtin_amdgcn_ballot_w64(big)) {        // wave-uniform: the square root and the division only when some edge of the wave is beyond the Huber width
-                        const double sq = sqrt(x2);
-                        if (big) { rho0 = 2 * sq * delta - dsqr; we = (delta / sq) * w; }
-                    }
-                    v[27] += rho0;
-                    v[28] += act ? 1.0 : 0.0;
-                    const double r0 = -(we * ex), r1 = -(we * ey);
-                    // A = -(1/z) [fx 0 -x/z fx; 0 fy -y/z fy] [-[p]x | I]  (types_six_dof_expmap.cpp:218-246 before the adjoint)
-                    const double st0 = -(fx * iz), st2 = (fx * xz) * iz, st4 = -(fy * iz), st5 = (fy * yz) * iz;
-                    const double a00 = st2 * y, a01 = fma(st0, z, -(st2 * x)), a02 = -(st0 * y), a03 = st0, a05 = st2;
-                    const double a10 = fma(st5, y, -(st4 * z)), a11 = -(st5 * x), a12 = st4 * x, a14 = st4, a15 = st5;
-                    const double p00 = we * a00, p01 = we * a01, p02 = we * a02, p03 = we * a03, p05 = we * a05;
-                    const double p10 = we * a10, p11 = we * a11, p12 = we * a12, p14 = we * a14, p15 = we * a15;
-                    v[0] = fma(p00, a00, fma(p10, a10, v[0]));   v[1] = fma(p00, a01, fma(p10, a11, v[1]));   v[2] = fma(p00, a02, fma(p10, a12, v[2]));
-                    v[3] = fma(p00, a03, v[3]);                  v[4] = fma(p10, a14, v[4]);                  v[5] = fma(p00, a05, fma(p10, a15, v[5]));
-                    v[6] = fma(p01, a01, fma(p11, a11, v[6]));   v[7] = fma(p01, a02, fma(p11, a12, v[7]));   v[8] = fma(p01, a03, v[8]);
-                    v[9] = fma(p11, a14, v[9]);                  v[10] = fma(p01, a05, fma(p11, a15, v[10]));
-                    v[11] = fma(p02, a02, fma(p12, a12, v[11])); v[12] = fma(p02, a03, v[12]);                v[13] = fma(p12, a14, v[13]);
-                    v[14] = fma(p02, a05, fma(p12, a15, v[14]));
-                    v[15] = fma(p03, a03, v[15]);                v[17] = fma(p03, a05, v[17]);
-                    v[18] = fma(p14, a14, v[18]);                v[19] = fma(p14, a15, v[19]);
-                    v[20] = fma(p05, a05, fma(p15, a15, v[20]));
-                    v[21] = fma(a00, r0, fma(a10, r1, v[21]));   v[22] = fma(a01, r0, fma(a11, r1, v[22]));   v[23] = fma(a02, r0, fma(a12, r1, v[23]));
-                    v[24] = fma(a03, r0, v[24]);                 v[25] = fma(a14, r1, v[25]);                 v[26] = fma(a05, r0, fma(a15, r1, v[26]));
-                }
-            }
-#ifdef DCS_POSE_PROF
-            const unsigned long long tw1 = __builtin_readcyclecounter();
-#endif
-            const double tot = wave_sum32(v, lane);
-            if (!(lane & 1)) S.part[wave][lane >> 1] = tot;
-#ifdef DCS_POSE_PROF
-            const unsigned long long tw2 = __builtin_readcyclecounter();
-#endif
-            __syncthreads();                                    // B2
-            __syncthreads();                                    // B3: the control wave has decided; S.T / S.M hold the next pose to evaluate (or the final one)
-#ifdef DCS_POSE_PROF
-            prof_w[0] += tw1 - tw0; prof_w[1] += tw2 - tw1; prof_w[2] += (unsigned long long)__builtin_readcyclecounter() - tw2; ++prof_w[3];
-#endif
-            if ((S.ctl & 3) == 2) break;
-        }
-        // ---- classification of every edge (:365-390): previous outliers are re-evaluated at the final pose, inliers keep the chi2 of the last evaluation
-        {
-            const double* Mc = S.M[wc];
-            const double M0 = Mc[0], M1 = Mc[1], M2 = Mc[2], M3 = Mc[3], M4 = Mc[4], M5 = Mc[5], M6 = Mc[6], M7 = Mc[7], M8 = Mc[8], m0 = Mc[9], m1 = Mc[10], m2 = Mc[11];
-            unsigned bad = 0;
-#pragma unroll
-            for (int j = 0; j < kPoEpt; ++j) {
-                if (j >= ept) break;
-                if ((outl >> j) & 1u) {
-                    const double x = fma(M0, X[j][0], fma(M1, X[j][1], fma(M2, X[j][2], m0)));
-                    const double y = fma(M3, X[j][0], fma(M4, X[j][1], fma(M5, X[j][2], m1)));
-                    const double z = fma(M6, X[j][0], fma(M7, X[j][1], fma(M8, X[j][2], m2)));
-                    const double iz = 1.0 / z;
-                    const double ex = S.ed[0][j][sl] - fma(x * iz, fx, cx), ey = S.ed[1][j][sl] - fma(y * iz, fy, cy), w = S.ed[2][j][sl];
-                    c2[j] = ex * (w * ex) + ey * (w * ey);
-                }
-                if (((valid >> j) & 1u) && (float)c2[j] > a.chi2_th[it]) bad |= 1u << j;
-            }
-            outl = bad;
-            int cnt = __popc(bad);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-            if (lane == 0) S.bad[wave] = cnt;
-        }
-        __syncthreads();                                        // B4
-        if (it == 2) robust = false;                            // :388-389
-        if (n < 10) break;                                      // :392
-    }
-#ifdef DCS_POSE_PROF
-    if (lane == 0 && blockIdx.x == 0 && wave == 0) printf("worker 0 (ept %d, n %d): %llu passes; per pass: sweep %llu, reduce %llu, wait for control %llu ticks; loop total %llu ticks\n", ept, n, prof_w[3],
-                                                           prof_w[0] / prof_w[3], prof_w[1] / prof_w[3], prof_w[2] / prof_w[3], (unsigned long long)__builtin_readcyclecounter() - tw_begin);
-#endif
-#pragma unroll
-    for (int j = 0; j < kPoEpt; ++j) {
-        if (j >= ept) break;
-        if ((valid >> j) & 1u) {
-            const size_t e = (size_t)e0 + S.list[coff + (j * wW + wu) * 64 + lane];
-            a.outlier[e] = (outl >> j) & 1u;
-            if (a.edge_chi2) a.edge_chi2[e] = c2[j];
-        }
+        for (int j = 0; j < 3; ++j) M[i * 3 + j] = fma(Rc[i * 3], R[j], fma(Rc[i * 3 + 1], R[3 + j], Rc[i * 3 + 2] * R[6 + j]));
+        M[9 + i] = fma(Rc[i * 3], T[0], fma(Rc[i * 3 + 1], T[1], fma(Rc[i * 3 + 2], T[2], Rc[9 + i])));
     }
 }
 
+#ifdef DCS_POSE_PROF
+// side builds only (-DDCS_POSE_PROF, tools/pose_timeline.py): frame 0 leaves, per wave, the clock at every stage boundary of ONE pass and the kernel's
+// span on both clocks (s_memtime = shader clock, s_memrealtime = 100 MHz) in a global array that dcs_debug_pose_prof() copies out -- no printf in
+// the kernel: its code and registers would distort what is measured
+__device__ unsigned long long g_pose_prof[kPoT / 64][16];
+#define DCS_PO_TICK(k) { if (prof_on) prof_t[k] = __builtin_readcyclecounter(); }
+#else
+#define DCS_PO_TICK(k)
+#endif
+
+struct PoseKernargs { PoseArgs a; DCams cams; };          // the kernel's argument list as the kernarg segment lays it out
 __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
 {
     __shared__ PoseShared S;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e0 = a.edge_off[f], n = a.edge_cnt ? a.edge_cnt[f] : a.edge_off[f + 1] - e0;
     if (n > a.fast_max) return;                               // k_pose_opt's frame (the host launches it when a frame can be that large)
-    const double* Tin = a.poses + 7 * f;
     for (int k = tid; k < n; k += kPoT) { a.outlier[e0 + k] = 0; if (a.edge_chi2) a.edge_chi2[e0 + k] = 0; }
     if (tid < 4 && a.n_iters) a.n_iters[4 * f + tid] = 0;
     if (n < 3) {                                              // :343-344
-        if (tid < 7) a.out_poses[7 * f + tid] = Tin[tid];
-        if (tid == 0) a.n_inliers[f] = 0;
+        const __attribute__((address_space(4))) char* k0 = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(k0));
+        const __attribute__((address_space(4))) PoseArgs& early = *(const __attribute__((address_space(4))) PoseArgs*)k0;
+        if (tid < 7) early.out_poses[7 * f + tid] = early.poses[7 * f + tid];
+        if (tid == 0) early.n_inliers[f] = 0;
         return;
     }
-    // ---- edges by camera: stable counting sort of the edge indices into S.list (camera c at [S.off[c], S.off[c] + S.ncam[c])), all 8 waves
+    // ---- edges by camera: stable counting sort of the edge indices into S.list (camera c at [S.off[c], S.off[c] + S.ncam[c]))
     {
         int my_pos[kPoChunks];
         for (int i = tid; i < kMaxCams * kPoChunks * kPoW; i += kPoT) (&S.cnt[0][0])[i] = 0;
-        {
+        for (int i = tid; i < kPoW * kPoLine; i += kPoT) (&S.line[0][0])[i] = 0.0;
+        if (tid < 33) S.series[tid] = kPoSeries[tid];
+        {   // the rig's cameras: thread i copies word i of the kernel argument straight from the kernarg segment (indexing the by-value argument at run
+            // time would copy it to scratch; round 5's "if (tid == i) dst[i] = src[i]" over constant i compiled to 900 KB of exec-mask bookkeeping)
             constexpr int kCamWords = (int)(sizeof(DCams) / sizeof(double));
-            const double* src = reinterpret_cast<const double*>(&cams);               // (constant indices after unrolling: scalar loads of the kernel argument)
+            static_assert(kCamWords <= kPoT, "one thread per word");
+            typedef const __attribute__((address_space(4))) double* KernargWords;
+            static_assert(offsetof(PoseKernargs, cams) % sizeof(double) == 0, "word offset");
+            const KernargWords src = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PoseKernargs, cams) / sizeof(double);
             double* dst = reinterpret_cast<double*>(&S.cam[0]);
-#pragma unroll
-            for (int i = 0; i < kCamWords; ++i) if (tid == (i & (kPoT - 1))) dst[i] = src[i];
+            if (tid < kCamWords) dst[tid] = src[tid];
         }
         __syncthreads();
 #pragma unroll
@@ -2889,6 +2607,24 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
                 if (lane == 0) S.cnt[cc][m * kPoW + wave] = __popcll(mk);
             }
         }
+        // the adjoint map of every camera: H'(i, j) = sum_{k <= m} K[(i, j)][(k, m)] HA(k, m), b'(r) = sum_k adj[k][r] ba(k)
+        for (int idx = tid; idx < kMaxCams * 27 * 22; idx += kPoT) {
+            const int c = idx / (27 * 22), r = (idx / 22) % 27, t = idx % 22;
+            const double* adj = S.cam[c].adj;
+            double val = 0.0;
+            if (r < 21 && t < 21) {
+                int i, j, k, m;
+                tri6(r, i, j); tri6(t, k, m);
+                val = k == m ? adj[k * 6 + i] * adj[k * 6 + j] : adj[k * 6 + i] * adj[m * 6 + j] + adj[m * 6 + i] * adj[k * 6 + j];
+            } else if (r >= 21 && t < 6) val = adj[t * 6 + (r - 21)];
+            S.K[c][r][t] = val;
+        }
+        if (tid < kMaxCams) {
+            double Rc[9];
+            qtoR(S.cam[tid].q, Rc);
+            for (int i = 0; i < 9; ++i) S.rc[tid][i] = Rc[i];
+            for (int i = 0; i < 3; ++i) S.rc[tid][9 + i] = S.cam[tid].t[i];
+        }
         __syncthreads();
         if (tid < kMaxCams) {                                 // exclusive prefix over (chunk, wave) in edge order
             int run = 0;
@@ -2899,8 +2635,8 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
         if (tid == 0) {
             int off = 0, active = 0;
             for (int c = 0; c < kMaxCams; ++c) { S.off[c] = off; off += S.ncam[c]; S.W[c] = S.ncam[c] > 0 ? 1 : 0; active += S.W[c]; }
-            // the remaining worker waves go, one at a time, to the camera with the most edges per wave (ties: the lower index)
-            for (int r = active; r < kPoWork; ++r) {
+            // the remaining waves go, one at a time, to the camera with the most edges per wave (ties: the lower index)
+            for (int r = active; r < kPoW; ++r) {
                 int best = 0; long long bn = -1, bd = 1;
                 for (int c = 0; c < kMaxCams; ++c) if (S.W[c] > 0 && (long long)S.ncam[c] * bd > bn * S.W[c]) { best = c; bn = S.ncam[c]; bd = S.W[c]; }
                 ++S.W[best];
@@ -2914,12 +2650,303 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
             if (my_pos[m] >= 0) { const int cc = my_pos[m] >> 16; S.list[S.off[cc] + S.cnt[cc][m * kPoW + wave] + (my_pos[m] & 0xffff)] = (uint16_t)(m * kPoT + tid); }
         __syncthreads();
     }
-    if (wave == kPoWork) {
-        const int ncu = S.ncam[3] > 0 || S.ncam[2] > 0 ? 4 : (S.ncam[1] > 0 ? 2 : 1);      // (the sums over the cameras keep their index order: same bits as the general form)
-        if (ncu == 1) pose_control<1>(S, a, f, n, lane);
-        else if (ncu == 2) pose_control<2>(S, a, f, n, lane);
-        else pose_control<kMaxCams>(S, a, f, n, lane);
-    } else pose_worker(S, a, e0, n, wave, lane);
+    // ---- this wave's camera and its share of the camera's edges
+    const int wc = __builtin_amdgcn_readfirstlane(S.wcam[wave]), wu = __builtin_amdgcn_readfirstlane(S.wu[wave]), wW = __builtin_amdgcn_readfirstlane(S.W[wc]);
+    const int nc = __builtin_amdgcn_readfirstlane(S.ncam[wc]), coff = __builtin_amdgcn_readfirstlane(S.off[wc]);
+    const int ept = (nc + 64 * wW - 1) / (64 * wW);           // <= kPoEpt by the choice of kPoseFastMax
+    const double fx = uniform_f64(S.cam[wc].fx), fy = uniform_f64(S.cam[wc].fy), cx = uniform_f64(S.cam[wc].cx), cy = uniform_f64(S.cam[wc].cy);
+    const double* const my_rc = S.rc[wc];
+    double X[kPoEpt][3];                                      // the points (observation, weight, last chi2: S.ed)
+    unsigned valid = 0, outl = 0;
+#pragma unroll
+    for (int j = 0; j < kPoEpt; ++j) {
+        const int p = (j * wW + wu) * 64 + lane;
+        const bool v = j < ept && p < nc;
+        const size_t e = (size_t)e0 + (v ? S.list[coff + p] : 0);
+        X[j][0] = v ? a.xw[3 * e] : 0.0; X[j][1] = v ? a.xw[3 * e + 1] : 0.0; X[j][2] = v ? a.xw[3 * e + 2] : 1.0;
+        S.ed[0][j][tid] = v ? a.obs[2 * e] : 0.0; S.ed[1][j][tid] = v ? a.obs[2 * e + 1] : 0.0; S.ed[2][j][tid] = v ? a.w[e] : 0.0; S.ed[3][j][tid] = 0.0;
+        valid |= (v ? 1u : 0u) << j;
+    }
+    const double delta = a.huber, dsqr = uniform_f64(delta * delta);
+    const double2* const my_line = reinterpret_cast<const double2*>(S.line[wave]) + (lane < 21 ? 0 : 11);     // lanes 21..26 read b (22..27) and zeros
+    const double2* const my_krow = reinterpret_cast<const double2*>(S.K[wc][lane < 27 ? lane : 0]);
+    const int line_slot = (lane >> 1) < 21 ? (lane >> 1) : ((lane >> 1) < 27 ? (lane >> 1) + 1 : (lane >> 1) + 17);   // where the sum of v[lane / 2] goes
+    bool robust = true;
+    int n_bad_edges = 0, buf = 0, n_its = 0;
+    double T[7], M[12];
+#ifdef DCS_POSE_PROF
+    unsigned long long prof_t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int n_pass = 0;
+    bool prof_on = false;
+    const unsigned long long t_begin = __builtin_readcyclecounter(), r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int it = 0; it < 4; ++it) {
+        // (the round's iteration limit and chi2 gate are read from the kernarg segment when the round starts: eight values held from the top
+        // of the kernel are eight scalar registers too many)
+        const __attribute__((address_space(4))) char* kr = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kr));
+        const int its_it = ((const __attribute__((address_space(4))) PoseArgs*)kr)->its[it];
+        const float th_it = ((const __attribute__((address_space(4))) PoseArgs*)kr)->chi2_th[it];
+        const double* const Tin = ((const __attribute__((address_space(4))) PoseArgs*)kr)->poses + 7 * f;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) T[d] = Tin[d];            // :360 every round restarts from the frame's pose
+        pose_compose(T, my_rc, M);
+        // LM state: the same in every lane of every wave
+        double lambda = -1, ni = 2, currentChi = 0, iniChi = 0, scale = 1;
+        int nBad = 0, n_it = 0, qmax = 0, it_i = 0, phase = 0;
+        bool ok2 = true;
+        for (;;) {
+#ifdef DCS_POSE_PROF
+            ++n_pass;
+            prof_on = f == 0 && n_pass == DCS_POSE_PROF;          // the pass to record: -DDCS_POSE_PROF=<pass number>
+            if (prof_on) prof_t[8] = __builtin_readcyclecounter();
+#endif
+            // ---- one sweep: errors of the active edges at T, robust chi2, and the linearisation there
+            double v[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = 0;
+            int ept_l = ept;
+            unsigned live_l = valid & ~outl;
+            asm volatile("" : "+s"(ept_l), "+v"(live_l));       // (tested afresh per slot: hoisted out of the loop the slots' comparisons and masks hold 28 scalar registers)
+#pragma unroll
+            for (int j = 0; j < kPoEpt; ++j) {
+                if (j >= ept_l) break;                          // wave-uniform
+                const bool act = (live_l >> j) & 1u;
+                double x = fma(M[0], X[j][0], fma(M[1], X[j][1], fma(M[2], X[j][2], M[9])));
+                double y = fma(M[3], X[j][0], fma(M[4], X[j][1], fma(M[5], X[j][2], M[10])));
+                double z = fma(M[6], X[j][0], fma(M[7], X[j][1], fma(M[8], X[j][2], M[11])));
+                if (!act) { x = 0; y = 0; z = 1; }              // an excluded edge contributes exact zeros below, whatever its point does
+                const double iz = 1.0 / z, xz = x * iz, yz = y * iz;
+                const double ex = S.ed[0][j][tid] - fma(xz, fx, cx), ey = S.ed[1][j][tid] - fma(yz, fy, cy);
+                const double w = act ? S.ed[2][j][tid] : 0.0;
+                const double x2 = ex * (w * ex) + ey * (w * ey);
+                if (act) S.ed[3][j][tid] = x2;
+                const bool big = robust && x2 > dsqr;
+                double rho0 = x2, we = w;
+                if (__builtin_amdgcn_ballot_w64(big)) {        // wave-uniform: the square root and the division only when some edge of the wave is beyond the Huber width
+                    const double sq = sqrt(x2);
+                    if (big) { rho0 = 2 * sq * delta - dsqr; we = (delta / sq) * w; }
+                }
+                v[27] += rho0;
+                v[28] += act ? 1.0 : 0.0;
+                const double r0 = -(we * ex), r1 = -(we * ey);
+                // A = -(1/z) [fx 0 -x/z fx; 0 fy -y/z fy] [-[p]x | I]  (types_six_dof_expmap.cpp:218-246 before the adjoint)
+                const double st0 = -(fx * iz), st2 = (fx * xz) * iz, st4 = -(fy * iz), st5 = (fy * yz) * iz;
+                const double a00 = st2 * y, a01 = fma(st0, z, -(st2 * x)), a02 = -(st0 * y), a03 = st0, a05 = st2;
+                const double a10 = fma(st5, y, -(st4 * z)), a11 = -(st5 * x), a12 = st4 * x, a14 = st4, a15 = st5;
+                const double p00 = we * a00, p01 = we * a01, p02 = we * a02, p03 = we * a03, p05 = we * a05;
+                const double p10 = we * a10, p11 = we * a11, p12 = we * a12, p14 = we * a14, p15 = we * a15;
+                v[0] = fma(p00, a00, fma(p10, a10, v[0]));   v[1] = fma(p00, a01, fma(p10, a11, v[1]));   v[2] = fma(p00, a02, fma(p10, a12, v[2]));
+                v[3] = fma(p00, a03, v[3]);                  v[4] = fma(p10, a14, v[4]);                  v[5] = fma(p00, a05, fma(p10, a15, v[5]));
+                v[6] = fma(p01, a01, fma(p11, a11, v[6]));   v[7] = fma(p01, a02, fma(p11, a12, v[7]));   v[8] = fma(p01, a03, v[8]);
+                v[9] = fma(p11, a14, v[9]);                  v[10] = fma(p01, a05, fma(p11, a15, v[10]));
+                v[11] = fma(p02, a02, fma(p12, a12, v[11])); v[12] = fma(p02, a03, v[12]);                v[13] = fma(p12, a14, v[13]);
+                v[14] = fma(p02, a05, fma(p12, a15, v[14]));
+                v[15] = fma(p03, a03, v[15]);                v[17] = fma(p03, a05, v[17]);
+                v[18] = fma(p14, a14, v[18]);                v[19] = fma(p14, a15, v[19]);
+                v[20] = fma(p05, a05, fma(p15, a15, v[20]));
+                v[21] = fma(a00, r0, fma(a10, r1, v[21]));   v[22] = fma(a01, r0, fma(a11, r1, v[22]));   v[23] = fma(a02, r0, fma(a12, r1, v[23]));
+                v[24] = fma(a03, r0, v[24]);                 v[25] = fma(a14, r1, v[25]);                 v[26] = fma(a05, r0, fma(a15, r1, v[26]));
+            }
+            DCS_PO_TICK(0)
+            // ---- the wave's 29 sums, then adj^T ( . ) adj on them: lane q < 21 forms entry q of H, lanes 21..26 the entries of b
+            {
+                const double2 k0 = my_krow[0], k1 = my_krow[1], k2 = my_krow[2], k3 = my_krow[3], k4 = my_krow[4], k5 = my_krow[5], k6 = my_krow[6], k7 = my_krow[7], k8 = my_krow[8],
+                              k9 = my_krow[9], k10 = my_krow[10];        // this lane's row of the adjoint map: asked for now, needed after the reduction
+                const double sum = wave_sum32(v, lane);         // lanes 2q, 2q + 1: total of v[q]
+                if (!(lane & 1) && lane < 58) S.line[wave][line_slot] = sum;
+                DCS_PO_TICK(1)
+                wave_sync();
+                const double2 d0 = my_line[0], d1 = my_line[1], d2 = my_line[2], d3 = my_line[3], d4 = my_line[4], d5 = my_line[5], d6 = my_line[6], d7 = my_line[7], d8 = my_line[8],
+                              d9 = my_line[9], d10 = my_line[10];
+                const double pass_through = S.line[wave][lane == 28 ? 45 : 44];
+                double c0 = k0.x * d0.x, c1 = k0.y * d0.y, c2 = k1.x * d1.x, c3 = k1.y * d1.y;
+                c0 = fma(k2.x, d2.x, c0); c1 = fma(k2.y, d2.y, c1); c2 = fma(k3.x, d3.x, c2); c3 = fma(k3.y, d3.y, c3);
+                c0 = fma(k4.x, d4.x, c0); c1 = fma(k4.y, d4.y, c1); c2 = fma(k5.x, d5.x, c2); c3 = fma(k5.y, d5.y, c3);
+                c0 = fma(k6.x, d6.x, c0); c1 = fma(k6.y, d6.y, c1); c2 = fma(k7.x, d7.x, c2); c3 = fma(k7.y, d7.y, c3);
+                c0 = fma(k8.x, d8.x, c0); c1 = fma(k8.y, d8.y, c1); c2 = fma(k9.x, d9.x, c2); c3 = fma(k9.y, d9.y, c3);
+                c0 = fma(k10.x, d10.x, c0); c1 = fma(k10.y, d10.y, c1);
+                const double mine = lane < 27 ? (c0 + c1) + (c2 + c3) : pass_through;
+                if (lane < 29) S.part[buf][wave][lane] = mine;
+            }
+            DCS_PO_TICK(2)
+            __syncthreads();                                    // the one barrier of a pass
+            DCS_PO_TICK(3)
+            double Hn[21], bn[6], chi, cnt;
+            {
+                double t = S.part[buf][0][lane & 31];
+#pragma unroll
+                for (int w = 1; w < kPoW; ++w) t += S.part[buf][w][lane & 31];          // wave order
+                buf ^= 1;
+                if (lane < 32) S.tot[wave][lane] = t;
+                wave_sync();
+                const double2* src = reinterpret_cast<const double2*>(S.tot[wave]);
+                double2 u[15];
+#pragma unroll
+                for (int i = 0; i < 15; ++i) u[i] = src[i];
+#pragma unroll
+                for (int i = 0; i < 21; ++i) Hn[i] = (i & 1) ? u[i >> 1].y : u[i >> 1].x;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bn[i] = ((21 + i) & 1) ? u[(21 + i) >> 1].y : u[(21 + i) >> 1].x;
+                chi = u[13].y; cnt = u[14].x;
+            }
+            DCS_PO_TICK(4)
+            // ---- the LM rule (optimization_algorithm_levenberg.cpp:61-164 as Optimizer.cc:360-364 drives it). The floating-point side is
+            // branch-free (both outcomes, then selects); its five comparisons become bits of a SCALAR register, so that the counters and the
+            // control flow below live on the scalar unit: every lane holds the same values, but only this tells the compiler
+            const double tempChi = ok2 ? chi : 1.7976931348623157e308;
+            const double rho = (currentChi - tempChi) / scale;
+            const bool acc_v = rho > 0 && isfinite(tempChi);
+            const double t3 = 2 * rho - 1;
+            const double alpha = fmin(1. - t3 * t3 * t3, 2. / 3.);      // g2o: pow(2 rho - 1, 3)
+            const double lam_acc = lambda * fmax(1. / 3., alpha), lam_rej = lambda * ni;
+            const double chi_after = acc_v ? tempChi : currentChi;
+            const int bits = __builtin_amdgcn_readfirstlane((acc_v ? 1 : 0) | (rho < 0 ? 2 : 0) | (rho == 0 ? 4 : 0) | ((iniChi - chi_after) * 1e3 < iniChi ? 8 : 0) | (cnt == 0.0 ? 16 : 0));
+            int ctl = 0, adopt = 0, solve = 0;
+            if (phase == 0) {                                   // evaluation at the current pose (round start, or after a rejected trial that did not end the round)
+                if ((it_i == 0 && (bits & 16)) || it_i >= its_it) ctl = 2;                // no active edge / no iterations: optimize() does nothing
+                else { currentChi = chi; iniChi = chi; adopt = 1; solve = 1; qmax = 0; }
+            } else {
+                const bool accepted = bits & 1;
+                if (accepted) { lambda = lam_acc; ni = 2; currentChi = tempChi; }
+                else {
+                    lambda = lam_rej; ni *= 2;
+#pragma unroll
+                    for (int d = 0; d < 7; ++d) T[d] = S.keep[wave][28 + d];               // pop (the edges keep the rejected trial's errors, as in g2o)
+                }
+                ++qmax;
+                if ((bits & 2) && qmax < 10) solve = 1;                                   // next trial of this iteration: same system, larger lambda
+                else {
+                    ++n_it;
+                    if (qmax == 10 || (bits & 4)) ctl = 2;
+                    else { if (bits & 8) ++nBad; else nBad = 0; if (nBad >= 3) ctl = 2; }
+                    ++it_i;
+                    if (it_i >= its_it) ctl = 2;
+                    if (ctl != 2) {
+                        if (accepted) { adopt = 1; solve = 1; iniChi = currentChi; qmax = 0; }   // the trial's sweep IS computeActiveErrors + the next linearisation
+                        else phase = 0;                                                   // (rho is NaN) re-evaluate at the restored pose
+                    }
+                }
+            }
+            if (solve && it_i == 0 && phase == 0) {             // computeLambdaInit on the system about to be adopted
+                double md = 0;
+                md = fmax(fabs(Hn[0]), md); md = fmax(fabs(Hn[6]), md); md = fmax(fabs(Hn[11]), md);
+                md = fmax(fabs(Hn[15]), md); md = fmax(fabs(Hn[18]), md); md = fmax(fabs(Hn[20]), md);
+                lambda = 1e-5 * md; ni = 2; nBad = 0;
+            }
+            const int flags = ctl | (adopt << 2) | (solve << 3);
+            DCS_PO_TICK(5)
+            if (flags & 8) {
+                if (flags & 4) {                                // adopt: the wave keeps its copy for the re-solves after rejected trials
+                    if (lane < 27) S.keep[wave][lane] = S.tot[wave][lane];
+                } else {
+                    wave_sync();
+#pragma unroll
+                    for (int i = 0; i < 21; ++i) Hn[i] = S.keep[wave][i];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) bn[i] = S.keep[wave][21 + i];
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int d = 0; d < 7; ++d) S.keep[wave][28 + d] = T[d];              // push
+                }
+                double xs[6];
+                ok2 = __builtin_amdgcn_readfirstlane(solve6_fast(Hn, bn, lambda, xs) ? 1 : 0) != 0;
+                if (!ok2) {
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) xs[d] = 0;
+                }
+                scale = 0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) scale += xs[j] * (lambda * xs[j] + bn[j]);
+                scale += 1e-3;
+                DCS_PO_TICK(6)
+                double o[7];
+                pose_oplus_fast(T, xs, o, S.series);
+#pragma unroll
+                for (int d = 0; d < 7; ++d) T[d] = o[d];
+                phase = 1;
+            }
+            pose_compose(T, my_rc, M);
+            DCS_PO_TICK(7)
+            if ((flags & 3) == 2) break;
+        }
+        n_its = it == 0 ? n_it : n_its | (n_it << (8 * it));                          // (<= 10 each: a byte per round)
+        // ---- classification of every edge (:365-390): previous outliers are re-evaluated at the final pose, inliers keep the chi2 of the last evaluation
+        {
+            unsigned bad = 0, valid_l = valid, outl_l = outl;
+            int ept_l = ept;
+            asm volatile("" : "+s"(ept_l), "+v"(valid_l), "+v"(outl_l));
+#pragma unroll
+            for (int j = 0; j < kPoEpt; ++j) {
+                if (j >= ept_l) break;
+                double c2 = S.ed[3][j][tid];
+                if ((outl_l >> j) & 1u) {
+                    const double x = fma(M[0], X[j][0], fma(M[1], X[j][1], fma(M[2], X[j][2], M[9])));
+                    const double y = fma(M[3], X[j][0], fma(M[4], X[j][1], fma(M[5], X[j][2], M[10])));
+                    const double z = fma(M[6], X[j][0], fma(M[7], X[j][1], fma(M[8], X[j][2], M[11])));
+                    const double iz = 1.0 / z;
+                    const double ex = S.ed[0][j][tid] - fma(x * iz, fx, cx), ey = S.ed[1][j][tid] - fma(y * iz, fy, cy), w = S.ed[2][j][tid];
+                    c2 = ex * (w * ex) + ey * (w * ey);
+                    S.ed[3][j][tid] = c2;
+                }
+                if (((valid_l >> j) & 1u) && (float)c2 > th_it) bad |= 1u << j;
+            }
+            outl = bad;
+            int cnt = __popc(bad);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+            if (lane == 0) S.bad[it & 1][wave] = cnt;
+        }
+        __syncthreads();
+        n_bad_edges = 0;
+#pragma unroll
+        for (int w = 0; w < kPoW; ++w) n_bad_edges += S.bad[it & 1][w];
+        if (it == 2) robust = false;                            // :388-389
+        if (n < 10) break;                                      // :392
+    }
+#ifdef DCS_POSE_PROF
+    if (lane == 0 && f == 0) {
+        for (int k = 0; k < 9; ++k) g_pose_prof[wave][k] = prof_t[k];
+        g_pose_prof[wave][9] = t_begin; g_pose_prof[wave][10] = __builtin_readcyclecounter();
+        g_pose_prof[wave][11] = r_begin; g_pose_prof[wave][12] = __builtin_amdgcn_s_memrealtime();
+        g_pose_prof[wave][13] = (unsigned long long)n_pass; g_pose_prof[wave][14] = (unsigned long long)n; g_pose_prof[wave][15] = (unsigned long long)ept;
+    }
+#endif
+    // the output pointers are read from the kernarg segment again here (through a pointer the compiler cannot connect to the argument list): held
+    // from the top of the kernel they would sit in scalar registers across the whole trial loop, and spill
+    const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const __attribute__((address_space(4))) PoseArgs& late = *(const __attribute__((address_space(4))) PoseArgs*)ka;
+    int tid_l = tid, f_l = f, wave_l = wave;
+    asm volatile("" : "+v"(tid_l), "+s"(f_l), "+s"(wave_l));
+    if (tid_l == 0) {
+        double* out_poses = late.out_poses;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) out_poses[7 * f_l + d] = T[d];
+        late.n_inliers[f_l] = n - n_bad_edges;
+        int32_t* n_iters = late.n_iters;
+        if (n_iters) { n_iters[4 * f_l] = n_its & 255; n_iters[4 * f_l + 1] = (n_its >> 8) & 255; n_iters[4 * f_l + 2] = (n_its >> 16) & 255; n_iters[4 * f_l + 3] = (n_its >> 24) & 255; }
+    }
+    uint8_t* const outlier = late.outlier;
+    double* const edge_chi2 = late.edge_chi2;
+    {   // (the wave's share again from LDS and the masks from their bits, for the same reason)
+        const int wc2 = __builtin_amdgcn_readfirstlane(S.wcam[wave_l]), wu2 = __builtin_amdgcn_readfirstlane(S.wu[wave_l]), wW2 = __builtin_amdgcn_readfirstlane(S.W[wc2]);
+        const int nc2 = __builtin_amdgcn_readfirstlane(S.ncam[wc2]), coff2 = __builtin_amdgcn_readfirstlane(S.off[wc2]);
+        const int ept2 = (nc2 + 64 * wW2 - 1) / (64 * wW2);
+        const int e0_2 = late.edge_off[f_l];
+        unsigned valid_l = valid, outl_l = outl;
+        asm volatile("" : "+v"(valid_l), "+v"(outl_l));
+#pragma unroll
+        for (int j = 0; j < kPoEpt; ++j) {
+            if (j >= ept2) break;
+            if ((valid_l >> j) & 1u) {
+                const size_t e = (size_t)e0_2 + S.list[coff2 + (j * wW2 + wu2) * 64 + lane];
+                outlier[e] = (outl_l >> j) & 1u;
+                if (edge_chi2) edge_chi2[e] = S.ed[3][j][tid];
+            }
+        }
+    }
 }
 
 }  // namespace dcs
@@ -3883,6 +3910,14 @@ int dcs_ba_local(const dcs_ba_problem* pb, const volatile uint8_t* stop_flag, dc
 {
     return dcs_ba_local_batch(1, &pb, &stop_flag, &res);
 }
+
+#ifdef DCS_POSE_PROF
+// side builds only: the timeline k_pose_opt2 left for frame 0 of its last launch ([8 waves][16] clock values, see g_pose_prof)
+extern "C" int dcs_debug_pose_prof(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_prof), sizeof(unsigned long long) * (kPoT / 64) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int dcs_ba_debug_linearize(const dcs_ba_problem* pb, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, int32_t* pose_idx, int* n_free)
 {
