@@ -599,7 +599,8 @@ typedef struct dcs_track_dev_frame {
 } dcs_track_dev_frame;
 typedef struct dcs_track_dev_result {
     dcs_track_result r;             /* arrays per frame sized for n_cams * cap features / n_points queries */
-    int32_t* n_features;            /* [F][n_cams] features per camera as assembled */
+    int32_t* n_features;            /* features per camera as assembled, frame after frame: frame k's n_cams counts start at the sum of n_cams of frames 0..k-1
+                                       (= [F][n_cams] when every frame has the same number of cameras) */
 } dcs_track_dev_result;
 /* cv::undistortPoints(xy, out, K, dist, cv::Mat(), K) on n float points, the call of Frame::UndistortKeyPoints and Frame::ComputeImageBounds (Frame.cc:430,
    468): OpenCV 3.3 / 3.4.0's five fixed-point iterations in double. dist5[0] == 0: copied through like the reference does (:414). Pure host helper (the

@@ -2150,7 +2150,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
     __shared__ int s_ctl;                                    // decision of thread 0: 0 = next trial, 1 = iteration done, 2 = round done
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e0 = a.edge_off[f], n = a.edge_cnt ? a.edge_cnt[f] : a.edge_off[f + 1] - e0;
-    if (n <= a.fast_max) return;                              // k_pose_opt2's frame
+    if (n <= a.fast_max && a.n_inliers[f] != INT_MIN) return;   // k_pose_opt2's frame, unless that kernel declined it (kPoseDeclined: a camera share beyond its registers)
     const double* Tin = a.poses + 7 * f;
     for (int k = tid; k < n; k += 256) { a.outlier[e0 + k] = 0; a.level[e0 + k] = 0; if (a.edge_chi2) a.edge_chi2[e0 + k] = 0; }
     if (tid < 4 && a.n_iters) a.n_iters[4 * f + tid] = 0;
@@ -2330,10 +2330,11 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
 //    instruction costs the same for one lane as for 64, and two waves per SIMD hide each other's latency). Nothing is broadcast, no second
 //    barrier, no v_readlane; the partial sums are double-buffered so that a fast wave's next pass cannot overwrite what a slow one still reads.
 // Parity bar unchanged (tests/test_gpu_ba.py::test_pose_optimization_vs_oracle, tests/test_gpu_track.py): poses 1e-7 / 1e-8, flags, counts +-1.
-constexpr int kPoT = 512, kPoW = kPoT / 64, kPoEpt = 7;
+constexpr int kPoT = 256, kPoW = kPoT / 64, kPoEpt = 16;     // ONE wave per SIMD: two waves on a SIMD run this f64 code one after the other, not interleaved (tools/pose_timeline.py)
 constexpr int kPoseFastMax = 2048;
-// the greedy wave split below leaves no camera more than n / (kPoW - (cameras - 1)) edges per wave (each extra wave goes to the largest ratio)
-static_assert((kPoW - (kMaxCams - 1)) * 64 * kPoEpt >= kPoseFastMax, "a camera's share of the edges must fit its waves' registers");
+// A camera's edges are shared by the waves the greedy split below gives it; a frame whose largest share does not fit kPoEpt slots per lane is left to
+// k_pose_opt (a rig of up to three cameras always fits: the extra wave goes to the largest camera; four cameras fit when none has more than 1 024 edges)
+static_assert(2 * 64 * kPoEpt >= kPoseFastMax, "two cameras, two waves each");
 constexpr int kPoChunks = (kPoseFastMax + kPoT - 1) / kPoT;
 constexpr int kPoLine = 48;          // a wave's exchange line: H 0..20, b 22..27, zeros 28..43, chi2 44, active edges 45
 
@@ -2347,7 +2348,7 @@ __device__ __forceinline__ void wave_sync()
 // sum over the 64 lanes of each of 32 values: lanes 2q and 2q + 1 return the total of v[q]. One fixed tree: halves are exchanged, so every
 // step moves half as many values as the one before (16 + 8 + 4 + 2 + 1 + 1 exchanges). The two widest levels -- 24 of the 32 exchanges -- are
 // gfx950's v_permlane32_swap / v_permlane16_swap (the upper half of one register trades places with the lower half of the other: exactly
-// this step, no LDS round trip, no selects); the narrow ones are ds_bpermute shuffles.
+// this step, no LDS round trip, no selects); the narrow ones are DPP moves inside a row of 16 lanes (round 6; ds_bpermute before: four LDS round trips).
 __device__ __forceinline__ double swap_add32(double p, double q)
 {
     const auto a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(p), (unsigned)__double2loint(q), false, false);
@@ -2360,18 +2361,29 @@ __device__ __forceinline__ double swap_add16(double p, double q)
     const auto b = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(p), (unsigned)__double2hiint(q), false, false);
     return dbl_of(a[0], b[0]) + dbl_of(a[1], b[1]);
 }
+// the value of lane (l ^ 8), (l ^ 4), (l ^ 2), (l ^ 1): DPP moves inside a row of 16 lanes (no LDS round trip as ds_bpermute has)
+template <int CTRL, int BANKS = 0xf>
+__device__ __forceinline__ double dpp_f64(double old, double x)
+{
+    return dbl_of((unsigned)__builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, BANKS, false),
+                  (unsigned)__builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, BANKS, false));
+}
+__device__ __forceinline__ double lane_xor8(double x) { return dpp_f64<0x128>(x, x); }                    // row_ror:8
+__device__ __forceinline__ double lane_xor4(double x) { return dpp_f64<0x114, 0xa>(dpp_f64<0x104, 0x5>(x, x), x); }   // row_shl:4 into lanes 0-3, 8-11; row_shr:4 into 4-7, 12-15
+__device__ __forceinline__ double lane_xor2(double x) { return dpp_f64<0x4e>(x, x); }                     // quad_perm [2, 3, 0, 1]
+__device__ __forceinline__ double lane_xor1(double x) { return dpp_f64<0xb1>(x, x); }                     // quad_perm [1, 0, 3, 2]
 __device__ __forceinline__ double wave_sum32(double (&v)[32], int lane)
 {
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = swap_add32(v[i], v[i + 16]);     // lanes 0-31: v[i] over (l, l + 32); lanes 32-63: v[i + 16]
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = swap_add16(v[i], v[i + 8]);
-#define DCS_PO_STEP(N, BIT) _Pragma("unroll") for (int i = 0; i < N; ++i) { const bool hi = (lane & BIT) != 0; const double send = hi ? v[i] : v[i + N], keep = hi ? v[i + N] : v[i]; v[i] = keep + __shfl_xor(send, BIT); }
-    DCS_PO_STEP(4, 8)
-    DCS_PO_STEP(2, 4)
-    DCS_PO_STEP(1, 2)
+#define DCS_PO_STEP(N, BIT, XOR) _Pragma("unroll") for (int i = 0; i < N; ++i) { const bool hi = (lane & BIT) != 0; const double send = hi ? v[i] : v[i + N], keep = hi ? v[i + N] : v[i]; v[i] = keep + XOR(send); }
+    DCS_PO_STEP(4, 8, lane_xor8)
+    DCS_PO_STEP(2, 4, lane_xor4)
+    DCS_PO_STEP(1, 2, lane_xor2)
 #undef DCS_PO_STEP
-    return v[0] + __shfl_xor(v[0], 1);
+    return v[0] + lane_xor1(v[0]);
 }
 
 // entry q of the upper triangle of a 6 x 6 matrix, rows first: (0,0) (0,1) .. (0,5) (1,1) .. (5,5)
@@ -2389,7 +2401,7 @@ struct alignas(16) PoseShared {
     double tot[kPoW][32];                   // per wave: the totals of a pass for its own lanes
     double keep[kPoW][36];                  // per wave: the adopted system (21 + 6 at 0..26) and the pushed pose (28..34)
     double K[kMaxCams][27][22];             // adj_c^T ( . ) adj_c as a linear map on the 21 + 6 sums: row = output entry
-    double ed[4][kPoEpt][kPoT];             // observation (x, y), weight, chi2 of the last evaluation of every resident edge (112 KB; one workgroup per CU anyway)
+    double ed[3][kPoEpt][kPoT];             // observation (x, y) and weight of every resident edge (96 KB; one workgroup per CU anyway)
     DCam cam[kMaxCams];                     // the rig's cameras (a by-value kernel argument indexed at run time would be copied to scratch)
     double rc[kMaxCams][12];                // their rotation matrices + translations
     double series[34];                      // kPoSeries
@@ -2437,12 +2449,14 @@ __device__ inline void pose_oplus_fast(const double* T, const double* u, double*
 {
     const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
     const double t2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    // O = [om]x and O2 = O O with the structural zeros written out (pose_oplus() multiplies and adds them: the same values -- a product with an
+    // exact zero adds nothing -- for 9 instructions instead of 45; likewise R and V below)
     const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
-    double O2[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    const double s00 = om[0] * om[0], s11 = om[1] * om[1], s22 = om[2] * om[2], p01 = om[1] * om[0], p02 = om[2] * om[0], p12 = om[2] * om[1];
+    const double O2[9] = {-s22 - s11, p01, p02, p01, -s22 - s00, p12, p02, p12, -s11 - s00};
     double R[9], V[9];
     if (t2 < 1e-10) {                                         // theta < 0.00001 (pose_oplus's first-order branch)
-        for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+        for (int i = 0; i < 9; ++i) { R[i] = i % 4 == 0 ? 1.0 + O2[i] : O[i] + O2[i]; V[i] = R[i]; }
     } else {
         double a, b, c, h = 1.0, ts = t2;                     // ts = (theta h)^2 < 0.25 with h = 2^-halvings
         int halvings = 0;
@@ -2465,7 +2479,10 @@ __device__ inline void pose_oplus_fast(const double* T, const double* u, double*
             for (; halvings > 0; --halvings) { const double s2 = 2.0 * sn * cs; cs = 1.0 - 2.0 * sn * sn; sn = s2; }
             a = sn / theta; b = (1 - cs) / t2; c = (theta - sn) / (t2 * theta);
         }
-        for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0 ? 1.0 : 0.0); R[i] = I + a * O[i] + b * O2[i]; V[i] = I + b * O[i] + c * O2[i]; }
+        for (int i = 0; i < 9; ++i) {
+            if (i % 4 == 0) { R[i] = 1.0 + b * O2[i]; V[i] = 1.0 + c * O2[i]; }
+            else { R[i] = a * O[i] + b * O2[i]; V[i] = b * O[i] + c * O2[i]; }
+        }
     }
     double qe[4], te[3];
     {   // qfromR with 1 / sqrt in place of sqrt + 0.5 / t
@@ -2484,9 +2501,11 @@ __device__ inline void pose_oplus_fast(const double* T, const double* u, double*
     out[3] = qo[0]; out[4] = qo[1]; out[5] = qo[2]; out[6] = qo[3];
 }
 
-// (H + lambda I) x = b by LDL^T, H given as the 21 entries of its upper triangle. The terms (L_ik L_jk) d_k leave every entry in ascending k,
-// exactly as solve6()'s inner products do; a division by a pivot is a multiplication by its reciprocal (fast_recip: an ulp apart from solve6()
-// at most, a third of the dependent chain). false = a pivot that is not positive and finite (LinearSolverDense's isPositive()).
+// (H + lambda I) x = b by LDL^T, H given as the 21 entries of its upper triangle; right-looking, the terms of every entry subtracted in
+// ascending k as solve6()'s inner products are. Column j before its scaling holds W_ij = L_ij d_j, so the update of entry (i, m) is ONE fused
+// multiply-add  A_im -= L_ij W_mj  (solve6(): (L_ij L_mj) d_j in three roundings), a division by a pivot is a multiplication by its reciprocal
+// (fast_recip), the substitutions are fused multiply-adds: 110 f64 instructions instead of 210 on the chain between two sweeps, the solution an ulp or
+// two from solve6()'s. false = a pivot that is not positive and finite (LinearSolverDense's isPositive()).
 __device__ __forceinline__ bool solve6_fast(const double (&Hs)[21], const double (&b)[6], double lambda, double (&x)[6])
 {
     double A[6][6];
@@ -2499,32 +2518,32 @@ __device__ __forceinline__ bool solve6_fast(const double (&Hs)[21], const double
     }
 #pragma unroll
     for (int d = 0; d < 6; ++d) A[d][d] += lambda;
-    double dd[6], inv[6];
+    double inv[6];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const double dj = A[j][j];
-        dd[j] = dj;
         if (!(dj > 0.0) || !isfinite(dj)) ok = false;
         inv[j] = fast_recip(dj);
+        double W[6];
 #pragma unroll
-        for (int i = j + 1; i < 6; ++i) A[i][j] *= inv[j];                           // L[i][j]
+        for (int i = j + 1; i < 6; ++i) { W[i] = A[i][j]; A[i][j] = W[i] * inv[j]; }   // L[i][j]
 #pragma unroll
         for (int m = j + 1; m < 6; ++m)
 #pragma unroll
-            for (int i = m; i < 6; ++i) A[i][m] -= A[i][j] * A[m][j] * dj;
+            for (int i = m; i < 6; ++i) A[i][m] = fma(-A[i][j], W[m], A[i][m]);
     }
     double y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { double acc = b[i];
 #pragma unroll
-        for (int k = 0; k < i; ++k) acc -= A[i][k] * y[k]; y[i] = acc; }
+        for (int k = 0; k < i; ++k) acc = fma(-A[i][k], y[k], acc); y[i] = acc; }
 #pragma unroll
     for (int i = 0; i < 6; ++i) y[i] *= inv[i];
 #pragma unroll
     for (int i = 5; i >= 0; --i) { double acc = y[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; ++k) acc -= A[k][i] * x[k]; x[i] = acc; }
+        for (int k = i + 1; k < 6; ++k) acc = fma(-A[k][i], x[k], acc); x[i] = acc; }
     return ok;
 }
 
@@ -2561,6 +2580,7 @@ __device__ unsigned long long g_pose_prof[kPoT / 64][16];
 #define DCS_PO_TICK(k)
 #endif
 
+constexpr int kPoseDeclined = INT_MIN;                    // n_inliers of a frame k_pose_opt2 left to k_pose_opt
 struct PoseKernargs { PoseArgs a; DCams cams; };          // the kernel's argument list as the kernarg segment lays it out
 __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
 {
@@ -2574,8 +2594,10 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
         const __attribute__((address_space(4))) char* k0 = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(k0));
         const __attribute__((address_space(4))) PoseArgs& early = *(const __attribute__((address_space(4))) PoseArgs*)k0;
-        if (tid < 7) early.out_poses[7 * f + tid] = early.poses[7 * f + tid];
-        if (tid == 0) early.n_inliers[f] = 0;
+        int f_e = f;
+        asm volatile("" : "+s"(f_e));
+        if (tid < 7) early.out_poses[7 * f_e + tid] = early.poses[7 * f_e + tid];
+        if (tid == 0) early.n_inliers[f_e] = 0;
         return;
     }
     // ---- edges by camera: stable counting sort of the edge indices into S.list (camera c at [S.off[c], S.off[c] + S.ncam[c]))
@@ -2653,10 +2675,21 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
     // ---- this wave's camera and its share of the camera's edges
     const int wc = __builtin_amdgcn_readfirstlane(S.wcam[wave]), wu = __builtin_amdgcn_readfirstlane(S.wu[wave]), wW = __builtin_amdgcn_readfirstlane(S.W[wc]);
     const int nc = __builtin_amdgcn_readfirstlane(S.ncam[wc]), coff = __builtin_amdgcn_readfirstlane(S.off[wc]);
-    const int ept = (nc + 64 * wW - 1) / (64 * wW);           // <= kPoEpt by the choice of kPoseFastMax
+    const int ept = (nc + 64 * wW - 1) / (64 * wW);
+    {   // a camera whose share does not fit the registers (only a four-camera rig with more than 1 024 edges on one camera can do that): the
+        // frame is k_pose_opt's, told by the sentinel in n_inliers (the host launches k_pose_opt behind this kernel for such rigs)
+        int worst = 0;
+        for (int c = 0; c < kMaxCams; ++c) if (S.W[c] > 0) worst = max(worst, (S.ncam[c] + 64 * S.W[c] - 1) / (64 * S.W[c]));
+        if (worst > kPoEpt) {
+            int tid_d = tid, f_d = f;
+            asm volatile("" : "+v"(tid_d), "+s"(f_d));
+            if (tid_d == 0) a.n_inliers[f_d] = kPoseDeclined;
+            return;
+        }
+    }
     const double fx = uniform_f64(S.cam[wc].fx), fy = uniform_f64(S.cam[wc].fy), cx = uniform_f64(S.cam[wc].cx), cy = uniform_f64(S.cam[wc].cy);
     const double* const my_rc = S.rc[wc];
-    double X[kPoEpt][3];                                      // the points (observation, weight, last chi2: S.ed)
+    double X[kPoEpt][3], c2[kPoEpt];                          // the points and the chi2 of their last evaluation (observation, weight: S.ed)
     unsigned valid = 0, outl = 0;
 #pragma unroll
     for (int j = 0; j < kPoEpt; ++j) {
@@ -2664,7 +2697,7 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
         const bool v = j < ept && p < nc;
         const size_t e = (size_t)e0 + (v ? S.list[coff + p] : 0);
         X[j][0] = v ? a.xw[3 * e] : 0.0; X[j][1] = v ? a.xw[3 * e + 1] : 0.0; X[j][2] = v ? a.xw[3 * e + 2] : 1.0;
-        S.ed[0][j][tid] = v ? a.obs[2 * e] : 0.0; S.ed[1][j][tid] = v ? a.obs[2 * e + 1] : 0.0; S.ed[2][j][tid] = v ? a.w[e] : 0.0; S.ed[3][j][tid] = 0.0;
+        S.ed[0][j][tid] = v ? a.obs[2 * e] : 0.0; S.ed[1][j][tid] = v ? a.obs[2 * e + 1] : 0.0; S.ed[2][j][tid] = v ? a.w[e] : 0.0; c2[j] = 0.0;
         valid |= (v ? 1u : 0u) << j;
     }
     const double delta = a.huber, dsqr = uniform_f64(delta * delta);
@@ -2688,11 +2721,13 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
         const int its_it = ((const __attribute__((address_space(4))) PoseArgs*)kr)->its[it];
         const float th_it = ((const __attribute__((address_space(4))) PoseArgs*)kr)->chi2_th[it];
         const double* const Tin = ((const __attribute__((address_space(4))) PoseArgs*)kr)->poses + 7 * f;
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));                      // (lane == 0 as a mask held since the sort would be a scalar register pair across the loop)
 #pragma unroll
         for (int d = 0; d < 7; ++d) T[d] = Tin[d];            // :360 every round restarts from the frame's pose
         pose_compose(T, my_rc, M);
         // LM state: the same in every lane of every wave
-        double lambda = -1, ni = 2, currentChi = 0, iniChi = 0, scale = 1;
+        double lambda = -1, ni = 2, currentChi = 0, iniChi = 0, inv_scale = 1;
         int nBad = 0, n_it = 0, qmax = 0, it_i = 0, phase = 0;
         bool ok2 = true;
         for (;;) {
@@ -2710,22 +2745,31 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
             asm volatile("" : "+s"(ept_l), "+v"(live_l));       // (tested afresh per slot: hoisted out of the loop the slots' comparisons and masks hold 28 scalar registers)
 #pragma unroll
             for (int j = 0; j < kPoEpt; ++j) {
-                if (j >= ept_l) break;                          // wave-uniform
+                if (j >= ept_l) continue;                       // wave-uniform (no early exit: a 16-fold unrolled loop with 16 exits is not unrolled at all)
                 const bool act = (live_l >> j) & 1u;
                 double x = fma(M[0], X[j][0], fma(M[1], X[j][1], fma(M[2], X[j][2], M[9])));
                 double y = fma(M[3], X[j][0], fma(M[4], X[j][1], fma(M[5], X[j][2], M[10])));
                 double z = fma(M[6], X[j][0], fma(M[7], X[j][1], fma(M[8], X[j][2], M[11])));
                 if (!act) { x = 0; y = 0; z = 1; }              // an excluded edge contributes exact zeros below, whatever its point does
+#ifdef DCS_PO_EXACT_SWEEP                                        // side builds (scratch/pose_flip_stats.py): what each shortcut costs in LM iterations apart from the oracle
                 const double iz = 1.0 / z, xz = x * iz, yz = y * iz;
+#else
+                const double iz = fast_recip(z), xz = x * iz, yz = y * iz;     // (v_rcp_f64 + a third-order correction: an ulp from the IEEE quotient, a quarter of its instructions)
+#endif
                 const double ex = S.ed[0][j][tid] - fma(xz, fx, cx), ey = S.ed[1][j][tid] - fma(yz, fy, cy);
                 const double w = act ? S.ed[2][j][tid] : 0.0;
                 const double x2 = ex * (w * ex) + ey * (w * ey);
-                if (act) S.ed[3][j][tid] = x2;
+                if (act) c2[j] = x2;
                 const bool big = robust && x2 > dsqr;
                 double rho0 = x2, we = w;
-                if (__builtin_amdgcn_ballot_w64(big)) {        // wave-uniform: the square root and the division only when some edge of the wave is beyond the Huber width
+                if (__builtin_amdgcn_ballot_w64(big)) {        // wave-uniform: only when some edge of the wave is beyond the Huber width
+#ifdef DCS_PO_EXACT_SWEEP
                     const double sq = sqrt(x2);
                     if (big) { rho0 = 2 * sq * delta - dsqr; we = (delta / sq) * w; }
+#else
+                    const double rs = fast_rsqrt(big ? x2 : 1.0);                      // sqrt(x2) = x2 rs, delta / sqrt(x2) = delta rs: no IEEE square root, no division
+                    if (big) { rho0 = 2 * (x2 * rs) * delta - dsqr; we = (delta * rs) * w; }
+#endif
                 }
                 v[27] += rho0;
                 v[28] += act ? 1.0 : 0.0;
@@ -2795,7 +2839,11 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
             // branch-free (both outcomes, then selects); its five comparisons become bits of a SCALAR register, so that the counters and the
             // control flow below live on the scalar unit: every lane holds the same values, but only this tells the compiler
             const double tempChi = ok2 ? chi : 1.7976931348623157e308;
-            const double rho = (currentChi - tempChi) / scale;
+#ifdef DCS_PO_EXACT_RULE
+            const double rho = (currentChi - tempChi) / (1.0 / inv_scale);
+#else
+            const double rho = (currentChi - tempChi) * inv_scale;   // (1 / scale: divided when the trial was made, off this chain)
+#endif
             const bool acc_v = rho > 0 && isfinite(tempChi);
             const double t3 = 2 * rho - 1;
             const double alpha = fmin(1. - t3 * t3 * t3, 2. / 3.);      // g2o: pow(2 rho - 1, 3)
@@ -2846,23 +2894,37 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
 #pragma unroll
                     for (int i = 0; i < 6; ++i) bn[i] = S.keep[wave][21 + i];
                 }
-                if (lane == 0) {
+                if (lane_l == 0) {
 #pragma unroll
                     for (int d = 0; d < 7; ++d) S.keep[wave][28 + d] = T[d];              // push
                 }
                 double xs[6];
+#ifdef DCS_PO_EXACT_SOLVE
+                {
+                    double Hf[36];
+                    int q = 0;
+                    for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { Hf[r * 6 + c] = Hn[q]; Hf[c * 6 + r] = Hn[q]; ++q; }
+                    ok2 = __builtin_amdgcn_readfirstlane(solve6(Hf, lambda, bn, xs) ? 1 : 0) != 0;
+                }
+#else
                 ok2 = __builtin_amdgcn_readfirstlane(solve6_fast(Hn, bn, lambda, xs) ? 1 : 0) != 0;
+#endif
                 if (!ok2) {
 #pragma unroll
                     for (int d = 0; d < 6; ++d) xs[d] = 0;
                 }
-                scale = 0;
+                double scale = 0;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) scale += xs[j] * (lambda * xs[j] + bn[j]);
                 scale += 1e-3;
+                inv_scale = 1.0 / scale;
                 DCS_PO_TICK(6)
                 double o[7];
+#ifdef DCS_PO_EXACT_EXP
+                pose_oplus(T, xs, o);
+#else
                 pose_oplus_fast(T, xs, o, S.series);
+#endif
 #pragma unroll
                 for (int d = 0; d < 7; ++d) T[d] = o[d];
                 phase = 1;
@@ -2879,24 +2941,22 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
             asm volatile("" : "+s"(ept_l), "+v"(valid_l), "+v"(outl_l));
 #pragma unroll
             for (int j = 0; j < kPoEpt; ++j) {
-                if (j >= ept_l) break;
-                double c2 = S.ed[3][j][tid];
+                if (j >= ept_l) continue;
                 if ((outl_l >> j) & 1u) {
                     const double x = fma(M[0], X[j][0], fma(M[1], X[j][1], fma(M[2], X[j][2], M[9])));
                     const double y = fma(M[3], X[j][0], fma(M[4], X[j][1], fma(M[5], X[j][2], M[10])));
                     const double z = fma(M[6], X[j][0], fma(M[7], X[j][1], fma(M[8], X[j][2], M[11])));
-                    const double iz = 1.0 / z;
+                    const double iz = fast_recip(z);
                     const double ex = S.ed[0][j][tid] - fma(x * iz, fx, cx), ey = S.ed[1][j][tid] - fma(y * iz, fy, cy), w = S.ed[2][j][tid];
-                    c2 = ex * (w * ex) + ey * (w * ey);
-                    S.ed[3][j][tid] = c2;
+                    c2[j] = ex * (w * ex) + ey * (w * ey);
                 }
-                if (((valid_l >> j) & 1u) && (float)c2 > th_it) bad |= 1u << j;
+                if (((valid_l >> j) & 1u) && (float)c2[j] > th_it) bad |= 1u << j;
             }
             outl = bad;
             int cnt = __popc(bad);
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-            if (lane == 0) S.bad[it & 1][wave] = cnt;
+            if (lane_l == 0) S.bad[it & 1][wave] = cnt;
         }
         __syncthreads();
         n_bad_edges = 0;
@@ -2939,11 +2999,11 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
         asm volatile("" : "+v"(valid_l), "+v"(outl_l));
 #pragma unroll
         for (int j = 0; j < kPoEpt; ++j) {
-            if (j >= ept2) break;
+            if (j >= ept2) continue;
             if ((valid_l >> j) & 1u) {
                 const size_t e = (size_t)e0_2 + S.list[coff2 + (j * wW2 + wu2) * 64 + lane];
                 outlier[e] = (outl_l >> j) & 1u;
-                if (edge_chi2) edge_chi2[e] = S.ed[3][j][tid];
+                if (edge_chi2) edge_chi2[e] = c2[j];
             }
         }
     }
@@ -3314,12 +3374,14 @@ thread_local const BaTap* tl_tap = nullptr;
 
 // both kernels over the frames: k_pose_opt2 takes the frames of up to kPoseFastMax edges, k_pose_opt the rest (launched only when the host's
 // bound on a frame's edges says one may exist). DCS_POSE_FAST=0: every frame to k_pose_opt (the round-4 kernel: A/B and tests).
-static int launch_pose_kernels(PoseArgs a, const DCams& cams, int n_frames, int max_edges_bound, hipStream_t st)
+static int launch_pose_kernels(PoseArgs a, const DCams& cams, int n_cams, int n_frames, int max_edges_bound, hipStream_t st)
 {
     const bool fast = opt(OPT_POSE_FAST) != 0;
     a.fast_max = fast ? kPoseFastMax : -1;
     if (fast) hipLaunchKernelGGL(k_pose_opt2, dim3(n_frames), dim3(kPoT), 0, st, a, cams);
-    if (!fast || max_edges_bound > kPoseFastMax) hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, st, a, cams);
+    // k_pose_opt behind it when a frame can be beyond k_pose_opt2: more edges than kPoseFastMax, or a four-camera rig with more than 64 * kPoEpt edges
+    // on one camera (k_pose_opt2 marks such a frame: kPoseDeclined)
+    if (!fast || max_edges_bound > kPoseFastMax || (n_cams > 3 && max_edges_bound > 64 * kPoEpt)) hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, st, a, cams);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -3333,7 +3395,7 @@ int dcs::launch_pose_opt_device(const PoseOptDevice& p, const dcs_ba_camera* cam
     a.huber = p.huber;
     for (int i = 0; i < 4; ++i) { a.chi2_th[i] = p.chi2_th[i]; a.its[i] = p.its[i]; }
     a.err = p.err; a.level = p.level; a.out_poses = p.out_poses; a.outlier = p.outlier; a.n_inliers = p.n_inliers; a.edge_chi2 = p.edge_chi2; a.n_iters = p.n_iters;
-    return launch_pose_kernels(a, pose_cams_of(cams_in, n_cams), n_frames, max_edges_bound, st);
+    return launch_pose_kernels(a, pose_cams_of(cams_in, n_cams), n_cams, n_frames, max_edges_bound, st);
 }
 
 extern "C" {
@@ -3995,7 +4057,7 @@ int dcs_pose_optimization(const dcs_pose_problem* pb, dcs_pose_result* res)
     a.edge_chi2 = res->edge_chi2 ? d_chi : nullptr; a.n_iters = res->n_iters ? d_nit : nullptr;
     int max_edges = 0;
     for (int f = 0; f < F; ++f) max_edges = std::max(max_edges, pb->edge_off[f + 1] - pb->edge_off[f]);
-    if ((rc = launch_pose_kernels(a, cams, F, max_edges, st))) return rc;
+    if ((rc = launch_pose_kernels(a, cams, pb->n_cams, F, max_edges, st))) return rc;
     DCS_HIP(hipMemcpyAsync(res->poses, d_out, sizeof(double) * 7 * F, hipMemcpyDeviceToHost, st));
     DCS_HIP(hipMemcpyAsync(res->n_inliers, d_ninl, sizeof(int32_t) * F, hipMemcpyDeviceToHost, st));
     if (E) DCS_HIP(hipMemcpyAsync(res->outlier, d_outl, E, hipMemcpyDeviceToHost, st));

@@ -82,6 +82,34 @@ void* ThreadArena::take(bool pinned, size_t bytes)
     return p;
 }
 
+bool ThreadArena::reserve(bool pinned, size_t bytes)
+{
+    std::vector<Block>& blocks = pinned ? pin : dev;
+    size_t& used = pinned ? pin_used : dev_used;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (!blocks.empty() && used + need <= blocks.back().cap) return true;
+    // the same growth rule as take(), without handing anything out: the run starts at the top of a fresh block
+    const size_t peak = pinned ? pin_peak : dev_peak;
+    size_t cap = std::max<size_t>({need, peak + peak / 4, (size_t)1 << 20});
+    if (!blocks.empty()) cap = std::max(cap, 2 * blocks.back().cap);
+    Block b{nullptr, cap};
+    const hipError_t e = pinned ? hipHostMalloc((void**)&b.p, cap, hipHostMallocDefault) : hipMalloc((void**)&b.p, cap);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    blocks.push_back(b);
+    used = 0;
+    return true;
+}
+
+bool ThreadArena::same_block(bool pinned, const void* p, const void* q) const
+{
+    const std::vector<Block>& blocks = pinned ? pin : dev;
+    for (const Block& b : blocks) {
+        const bool in_p = (const char*)p >= b.p && (const char*)p < b.p + b.cap, in_q = (const char*)q >= b.p && (const char*)q < b.p + b.cap;
+        if (in_p || in_q) return in_p && in_q;
+    }
+    return false;                                            // memory that is not the arena's (a caller's own device array): never merged
+}
+
 ThreadArena& thread_arena() { static thread_local ThreadArena a; return a; }
 
 // stream restricted to CUs [first, first + count) of the CU-mask bit order (bit k -> a CU of XCD k mod 8 on gfx950: a prefix spreads evenly)

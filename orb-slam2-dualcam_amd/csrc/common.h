@@ -75,6 +75,11 @@ struct ThreadArena {
     void release();
     int begin();                                         // start of a call: rewind, coalesce fragmented blocks into one
     void* take(bool pinned, size_t bytes);               // 256-byte aligned; nullptr on allocation failure
+    // take() opens a NEW hipMalloc block whenever the current one is full: consecutive take()s are contiguous only inside one block. A caller
+    // that treats a run of arrays as one range (one memset, one copy) reserves the run first: after reserve(n) the next take()s whose 256-byte
+    // padded sizes add up to at most n come from ONE block, back to back. false = allocation failure
+    bool reserve(bool pinned, size_t bytes);
+    bool same_block(bool pinned, const void* p, const void* q) const;   // both inside one block of the arena
 };
 ThreadArena& thread_arena();
 int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared, bool* conclusive = nullptr);   // measured: does work on b wait for work on a? *conclusive = false when a's backlog kept the probe from starting (common.cpp)
@@ -119,6 +124,12 @@ struct Scratch {
         }
     }
     static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    // the next alloc()s of `bytes` in all (each padded to 256) are carved back to back from one block of the device arena
+    int reserve(size_t bytes) {
+        if (rc0) return rc0;
+        if (!a.reserve(false, bytes)) { set_error("device scratch: out of memory"); return DCS_ERR_HIP; }
+        return DCS_OK;
+    }
     template <typename T> int alloc(T** out, size_t n) {
         if (rc0) return rc0;
         touched = true;                                   // the caller is about to launch on / copy through this memory
@@ -199,7 +210,8 @@ struct Scratch {
         std::vector<size_t> seg_of(downs.size());
         for (size_t k = 0; k < order.size(); ++k) {
             const Down& q = downs[order[k]];
-            if (!segs.empty() && q.d_src <= segs.back().d1 + 4096) segs.back().d1 = std::max(segs.back().d1, q.d_src + q.bytes);
+            // (ranges of two arena blocks never merge: what lies between two hipMalloc allocations is not ours to read)
+            if (!segs.empty() && q.d_src <= segs.back().d1 + 4096 && a.same_block(false, segs.back().d0, q.d_src)) segs.back().d1 = std::max(segs.back().d1, q.d_src + q.bytes);
             else segs.push_back({q.d_src, q.d_src + q.bytes, nullptr});
             seg_of[order[k]] = segs.size() - 1;
         }

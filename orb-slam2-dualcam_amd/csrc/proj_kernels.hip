@@ -1393,15 +1393,26 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
     TrackItem* d_items; TrackItem* h_items; DevAsm* d_das; DevAsm* h_das; int32_t* d_edge_off; int32_t* h_edge_off; float* d_sig; float* h_sig; double* d_pose_in; double* h_pose_in;
     if ((rc = s.stage(&d_items, &h_items, (size_t)F)) || (rc = s.stage(&d_das, &h_das, (size_t)F)) || (rc = s.stage(&d_edge_off, &h_edge_off, (size_t)F)) ||
         (rc = s.stage(&d_sig, &h_sig, (size_t)prm->n_levels)) || (rc = s.stage(&d_pose_in, &h_pose_in, (size_t)7 * F))) return rc;
-    char *z0 = nullptr, *z1 = nullptr;                              // (2) the zero-filled run
-    for (int k = 0; k < F; ++k) {
-        DevAsm& d = das[(size_t)k];
-        const size_t Ncap = (size_t)frames[k].features.n_cams * frames[k].features.cap;
-        if ((rc = s.alloc(&d.kp_x, Ncap)) || (rc = s.alloc(&d.kp_y, Ncap)) || (rc = s.alloc(&d.kp_angle, Ncap)) || (rc = s.alloc(&d.kp_octave, Ncap))) return rc;
-        if (k == 0) z0 = reinterpret_cast<char*>(d.kp_x);
-        z1 = reinterpret_cast<char*>(d.kp_octave + std::max<size_t>(Ncap, 1));
+    // (2) the zero-filled run: ONE fill over every frame's key-point arrays. The arena opens a new hipMalloc block whenever the current one is full
+    // (a thread's first call, a call that outgrows the previous ones), so the run is RESERVED first: after reserve() its arrays are carved from
+    // one block, back to back; the fill is checked against the sum of what was carved all the same. (Round 5 filled [first array, end of last
+    // array) without either: a cold thread with 5+ frames crossed the first 1-MB block inside the run and the fill covered foreign memory.)
+    {
+        size_t run = 0;
+        for (int k = 0; k < F; ++k) run += Scratch::padded(std::max<size_t>((size_t)frames[k].features.n_cams * frames[k].features.cap, 1) * sizeof(float)) * 3 +
+                                           Scratch::padded(std::max<size_t>((size_t)frames[k].features.n_cams * frames[k].features.cap, 1) * sizeof(int32_t));
+        if ((rc = s.reserve(run))) return rc;
+        char *z0 = nullptr, *z1 = nullptr;
+        for (int k = 0; k < F; ++k) {
+            DevAsm& d = das[(size_t)k];
+            const size_t Ncap = (size_t)frames[k].features.n_cams * frames[k].features.cap;
+            if ((rc = s.alloc(&d.kp_x, Ncap)) || (rc = s.alloc(&d.kp_y, Ncap)) || (rc = s.alloc(&d.kp_angle, Ncap)) || (rc = s.alloc(&d.kp_octave, Ncap))) return rc;
+            if (k == 0) z0 = reinterpret_cast<char*>(d.kp_x);
+            z1 = reinterpret_cast<char*>(d.kp_octave) + Scratch::padded(std::max<size_t>(Ncap, 1) * sizeof(*d.kp_octave));
+        }
+        if ((size_t)(z1 - z0) != run || !s.a.same_block(false, z0, z1 - 1)) { set_error("dcs_track_frame_device: the key-point run is not contiguous"); return DCS_ERR_HIP; }
+        if (hipMemsetAsync(z0, 0, run, raw) != hipSuccess) { set_error("dcs_track_frame_device: hipMemsetAsync failed"); return DCS_ERR_HIP; }
     }
-    if (hipMemsetAsync(z0, 0, (size_t)(z1 - z0), raw) != hipSuccess) { set_error("dcs_track_frame_device: hipMemsetAsync failed"); return DCS_ERR_HIP; }
     for (int k = 0; k < F; ++k) {                                   // (3) scratch
         TrackItem& it = items[(size_t)k];
         DevAsm& d = das[(size_t)k];
@@ -1423,13 +1434,16 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
         (rc = s.alloc(&d_ecam, Etot)) || (rc = s.alloc(&d_cnt, (size_t)F)) || (rc = s.alloc(&d_level, Etot)) || (rc = s.alloc(&d_outl, Etot))) return rc;
     {   // (4) what comes down: the match counters of every frame (zeroed) first, then the rest
         char *n0 = nullptr, *n1 = nullptr;
+        const size_t nm_run = (size_t)F * Scratch::padded(sizeof(*items[0].nm) * (size_t)kFrMaxCams);
+        if ((rc = s.reserve(nm_run))) return rc;                    // (one block, like the key-point run above)
         for (int k = 0; k < F; ++k) {
             TrackItem& it = items[(size_t)k];
             if ((rc = s.alloc(&it.nm, (size_t)kFrMaxCams))) return rc;
             if (k == 0) n0 = reinterpret_cast<char*>(it.nm);
-            n1 = reinterpret_cast<char*>(it.nm + kFrMaxCams);
+            n1 = reinterpret_cast<char*>(it.nm) + Scratch::padded(sizeof(*it.nm) * (size_t)kFrMaxCams);
         }
-        if (hipMemsetAsync(n0, 0, (size_t)(n1 - n0), raw) != hipSuccess) { set_error("dcs_track_frame_device: hipMemsetAsync failed"); return DCS_ERR_HIP; }
+        if ((size_t)(n1 - n0) != nm_run || !s.a.same_block(false, n0, n1 - 1)) { set_error("dcs_track_frame_device: the counter run is not contiguous"); return DCS_ERR_HIP; }
+        if (hipMemsetAsync(n0, 0, nm_run, raw) != hipSuccess) { set_error("dcs_track_frame_device: hipMemsetAsync failed"); return DCS_ERR_HIP; }
         if ((rc = s.alloc(&d_nfeat, (size_t)F * kFrMaxCams)) || (rc = s.alloc(&d_out, (size_t)7 * F)) || (rc = s.alloc(&d_ninl, (size_t)F))) return rc;
         for (int k = 0; k < F; ++k) {
             TrackItem& it = items[(size_t)k];
@@ -1483,9 +1497,11 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
         if ((rc = s.download_bytes(&nm[(size_t)k * kFrMaxCams], it.nm, sizeof(int32_t) * kFrMaxCams))) return rc;
     }
     if ((rc = s.finish())) return rc;
+    size_t nf_at = 0;                                               // n_features: the frames' counts one after the other (frame k at the sum of n_cams of frames 0..k-1)
     for (int k = 0; k < F; ++k) {
         const int C = frames[k].features.n_cams;
-        for (int c = 0; c < C; ++c) res->n_features[(size_t)k * C + c] = nfeat[(size_t)k * kFrMaxCams + c];
+        for (int c = 0; c < C; ++c) res->n_features[nf_at + c] = nfeat[(size_t)k * kFrMaxCams + c];
+        nf_at += (size_t)C;
         int total = 0;
         for (int c = 0; c < (mode == 1 ? C : 1); ++c) total += nm[(size_t)k * kFrMaxCams + c];
         res->r.n_matches[k] = total;

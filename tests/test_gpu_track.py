@@ -190,6 +190,49 @@ def test_track_frame_device_mode0_equals_the_host_buffer_chain(pkg, synth, kw, c
         assert np.array_equal(a["pose"], b["pose"]), k
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_track_frame_device_first_call_of_a_cold_thread(pkg, synth, mode):
+    """The arena of a host thread starts with one 1-MB block and opens a new hipMalloc block whenever a call outgrows the current one; round 5's
+    dcs_track_frame_device zero-filled [first key-point array, end of the last one) as ONE range, which on a thread's first call (or a call four
+    times larger than the one before) spanned two unrelated allocations. Every case here runs on a FRESH thread whose first call is
+    dcs_track_frame_device, with F x cap chosen on both sides of the 1-MB boundary; then a second call on the same thread that is several times
+    larger. All equal to the same frames through a warm thread's call (bit for bit: the chain is deterministic)."""
+    import threading
+    make = synth.tracking_problem if mode == 0 else synth.motion_model_problem
+    frames, prm = make(n_frames=40, n_points=500, n_features=600, seed=91)
+    _with_grid(pkg, frames)
+    keys = ("match_of_point", "point_of_feature", "outlier", "pose", "n_features")
+    ref = {}
+    for cap in (700, 1096, 2096):                               # warm reference on this thread (its arena has seen larger calls already)
+        dfr, keep = _device_frames(frames, cap=cap, mode=mode)
+        pt = pkg.abi.PreparedTrackingDevice(dfr, prm, mode=mode)
+        pt.track()
+        ref[cap] = (dfr, keep, pt.track())
+    errors = []
+
+    def same(a, b):
+        return a["n_matches"] == b["n_matches"] and a["n_inliers"] == b["n_inliers"] and all(np.array_equal(a[k], b[k]) for k in keys)
+
+    def cold(F, cap, grow_to):
+        try:
+            dfr = ref[cap][0]
+            got = pkg.abi.PreparedTrackingDevice(dfr[:F], prm, mode=mode).track()             # the thread's FIRST call
+            for k in range(F):
+                if not same(got[k], ref[cap][2][k]): errors.append(("first call", F, cap, k))
+            if grow_to:
+                got = pkg.abi.PreparedTrackingDevice(dfr[:grow_to], prm, mode=mode).track()    # outgrows the block the first call left
+                for k in range(grow_to):
+                    if not same(got[k], ref[cap][2][k]): errors.append(("grown call", F, grow_to, cap, k))
+        except Exception as ex:                                 # noqa: BLE001 -- reported with the case
+            errors.append((F, cap, grow_to, repr(ex)))
+
+    for cap in (700, 1096, 2096):
+        for F, grow_to in ((1, 0), (5, 0), (6, 24), (16, 0), (40, 0), (2, 9)):
+            t = threading.Thread(target=cold, args=(F, cap, grow_to))
+            t.start(); t.join()
+    assert not errors, errors[:5]
+
+
 def _oracle_motion_model(oracle, fr, prm, check_ori):
     ft, mm = fr["features"], fr["mm"]
     q = oracle.motion_model_queries(fr["view"], mm["pos"], mm["q_cam"], mm["q_octave"], prm["th"])

@@ -20,19 +20,19 @@ for f in fr:
 pt = pkg.abi.PreparedTracking(fr, prm)
 for _ in range(5): r = pt.track()
 lib = pkg.abi.lib() if callable(getattr(pkg.abi, "lib", None)) else ctypes.CDLL(pkg.abi.LIB_PATH)
-buf = (ctypes.c_ulonglong * (8 * 16))()
+buf = (ctypes.c_ulonglong * (4 * 16))()
 fn = lib.dcs_debug_pose_prof
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 assert fn(buf) == 0
-t = np.array(list(buf), dtype=np.uint64).reshape(8, 16).astype(np.int64)
+t = np.array(list(buf), dtype=np.uint64).reshape(4, 16).astype(np.int64)
 names = ["sweep", "reduce", "adjoint map + partials out", "barrier", "totals in", "LM rule", "solve", "exp map + compose"]
 span_clk = (t[:, 10] - t[:, 9]).max(); span_rt = (t[:, 12] - t[:, 11]).max()
 print("frame 0: %d edges, %d slots per lane (wave 0), %d passes; kernel span %d shader ticks = %.1f us on the 100 MHz clock -> %.0f MHz; %.0f ticks per pass"
       % (t[0, 14], t[0, 15], t[0, 13], span_clk, span_rt / 100.0, span_clk / (span_rt / 100.0), span_clk / max(1, t[0, 13])))
 t0 = t[:, 8].min()
 print("pass recorded: stage ends per wave, ticks after the earliest wave entered the pass")
-print("%-28s" % "wave (slots)" + "".join("%8d" % w for w in range(8)))
-print("%-28s" % "  slots per lane" + "".join("%8d" % t[w, 15] for w in range(8)))
-print("%-28s" % "  enters the pass" + "".join("%8d" % (t[w, 8] - t0) for w in range(8)))
+print("%-28s" % "wave (slots)" + "".join("%8d" % w for w in range(4)))
+print("%-28s" % "  slots per lane" + "".join("%8d" % t[w, 15] for w in range(4)))
+print("%-28s" % "  enters the pass" + "".join("%8d" % (t[w, 8] - t0) for w in range(4)))
 for k, nm in enumerate(names):
-    print("%-28s" % ("  " + nm) + "".join("%8d" % (t[w, k] - t0) for w in range(8)))
+    print("%-28s" % ("  " + nm) + "".join("%8d" % (t[w, k] - t0) for w in range(4)))
