@@ -24,3 +24,10 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdcs_hip.so" "${OBJS[@]}" -ldl
 echo "built $OUT/libdcs_hip.so"
+# Build gate (tools/check_codeobj.py): every kernel's code size, registers, spills and scratch from the code object's own metadata. The build FAILS
+# on a spilled vector register, on scratch memory, on a kernel larger than 48 KB -- and on spilled scalar registers except for the kernels
+# listed in tools/codeobj_allow.txt (a few scalar spills to lanes of a vector register, never to memory, in set-up code outside inner loops).
+# DCS_SKIP_CODEOBJ_GATE=1 skips it (side builds with profiling hooks); DCS_CODEOBJ_TABLE=<file> keeps the table.
+if [ -z "${DCS_SKIP_CODEOBJ_GATE:-}" ]; then
+  python3 tools/check_codeobj.py "$OUT/libdcs_hip.so" --sgpr-only-allow-file tools/codeobj_allow.txt ${DCS_CODEOBJ_TABLE:+--out "$DCS_CODEOBJ_TABLE"}
+fi

@@ -199,7 +199,9 @@ __device__ __forceinline__ void knn2_tile_mfma(const uint8_t* __restrict__ q, in
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
             // chunk 4 sl + g = halfword (g & 1) of dword 2 sl + (g >> 1)
-            const unsigned dw = (g >> 1) ? w[2 * sl + 1] : w[2 * sl];
+            // (two arrays and a select: written as w[2 sl + (g >> 1)] -- which is what the compiler makes of a select inside ONE array -- the words go to scratch memory)
+            const unsigned w_even[4] = {lo.x, lo.z, hi.x, hi.z}, w_odd[4] = {lo.y, lo.w, hi.y, hi.w};
+            const unsigned dw = (g >> 1) ? w_odd[sl] : w_even[sl];
             // queries enter as bytes 0 / -1: the accumulator holds -<q, t>, and the key is one v_lshl_add_u32
             const v4i_t e = expand16((g & 1) ? (dw >> 16) : (dw & 0xFFFFu));
             bf[qg][sl] = v4i_t{(e.x << 8) - e.x, (e.y << 8) - e.y, (e.z << 8) - e.z, (e.w << 8) - e.w};

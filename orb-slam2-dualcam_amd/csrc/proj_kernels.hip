@@ -47,6 +47,16 @@ struct ProjQueriesD {
     const uint8_t* desc; const float* angle;
 };
 
+// A kernel whose first two arguments are the frame and query descriptors reads them through the kernarg segment, where they are used: as
+// by-value arguments they are 30 + 21 scalar registers loaded at the top and held to the end, and the register allocator spills
+// (tools/check_codeobj.py: 18-36 spilled scalar registers per resolver before, none after).
+struct ProjArgsFQ { ProjFrameD f; ProjQueriesD q; };
+#define DCS_PROJ_ARGS_FROM_KERNARG(f, q)                                                                                                        \
+    const __attribute__((address_space(4))) char* ka_ = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr(); \
+    asm volatile("" : "+s"(ka_));                                                                                                               \
+    const ProjFrameD& f = ((const ProjArgsFQ*)ka_)->f;                                                                                          \
+    const ProjQueriesD& q = ((const ProjArgsFQ*)ka_)->q;
+
 __device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc)
 {
     unsigned r;
@@ -147,12 +157,13 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 // one wave, queries in order. The live "taken" map sits in LDS when the frame has <= 64 K features (always, in practice);
 // otherwise in HBM with device-coherent accesses.
 template <bool LDS_MAP>
-__global__ __launch_bounds__(64) void k_proj_resolve(ProjFrameD f, ProjQueriesD q, const unsigned* __restrict__ cand,
+__global__ __launch_bounds__(64) void k_proj_resolve(ProjFrameD f_arg, ProjQueriesD q_arg, const unsigned* __restrict__ cand,
                                                     const int32_t* __restrict__ cand_n, uint8_t* __restrict__ taken_hbm /* [N] working copy */,
                                                     int th_high, float nn_ratio, int check_ori, int32_t* __restrict__ match_of_query,
                                                     int32_t* __restrict__ query_of_feature, int32_t* __restrict__ bin_of_query,
                                                     int32_t* __restrict__ n_matches)
 {
+    DCS_PROJ_ARGS_FROM_KERNARG(f, q)
     __shared__ int s_hist[kHisto];
     __shared__ int s_ind[3];
     extern __shared__ uint8_t s_taken[];
@@ -187,8 +198,9 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjFrameD f, ProjQueriesD 
             unsigned w1 = 0, w2 = 0;
             auto track = [&](bool pass, unsigned word, int pos) {
                 const unsigned long long key = pass ? (((unsigned long long)(word >> 23) << 32) | (unsigned)pos) : ~0ull;
-                if (key < b1) { b2 = b1; w2 = w1; b1 = key; w1 = word; }
-                else if (key < b2) { b2 = key; w2 = word; }
+                const bool lt1 = key < b1, lt2 = key < b2;             // (selects, not branches: as if / else-if the compiler chose between the ADDRESSES of the four values and kept them in scratch memory)
+                b2 = lt1 ? b1 : (lt2 ? key : b2); w2 = lt1 ? w1 : (lt2 ? word : w2);
+                b1 = lt1 ? key : b1; w1 = lt1 ? word : w1;
             };
             if (LDS_MAP) (void)proj_visit(f, q, qi, TakenPlain{taken}, track);
             else (void)proj_visit(f, q, qi, TakenCoherent{taken}, track);
@@ -371,8 +383,9 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
                 unsigned w1 = 0, w2 = 0;
                 (void)proj_visit(f, q, qi, TakenPlain{s_taken}, [&](bool pass, unsigned word, int pos) {
                     const unsigned long long key = pass ? (((unsigned long long)(word >> 23) << 32) | (unsigned)pos) : ~0ull;
-                    if (key < b1) { b2 = b1; w2 = w1; b1 = key; w1 = word; }
-                    else if (key < b2) { b2 = key; w2 = word; }
+                    const bool lt1 = key < b1, lt2 = key < b2;             // (selects, not branches: as if / else-if the compiler chose between the ADDRESSES of the four values and kept them in scratch memory)
+                    b2 = lt1 ? b1 : (lt2 ? key : b2); w2 = lt1 ? w1 : (lt2 ? word : w2);
+                    b1 = lt1 ? key : b1; w1 = lt1 ? word : w1;
                 });
                 unsigned long long m1 = b1;
 #pragma unroll
@@ -425,11 +438,12 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
     }
     if (tid == 0) *n_matches = nm;
 }
-__global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f, ProjQueriesD q, const unsigned* __restrict__ cand,
+__global__ __launch_bounds__(kResT) void k_proj_resolve_par(ProjFrameD f_arg, ProjQueriesD q_arg, const unsigned* __restrict__ cand,
                                                            const int32_t* __restrict__ cand_n, uint8_t* __restrict__ state, int th_high, float nn_ratio,
                                                            int check_ori, int32_t* __restrict__ match_of_query, int32_t* __restrict__ query_of_feature,
                                                            int32_t* __restrict__ bin_of_query, int32_t* __restrict__ n_matches)
 {
+    DCS_PROJ_ARGS_FROM_KERNARG(f, q)
     proj_resolve_par_body(f, q, cand, cand_n, state, th_high, nn_ratio, check_ori, match_of_query, query_of_feature, bin_of_query, n_matches);
 }
 
@@ -473,11 +487,12 @@ __global__ __launch_bounds__(256) void k_window_static(ProjFrameD f, ProjQueries
 // previous owner (vnMatches21, :1194-1198). Candidate lists (distance, octave, feature) come from k_proj_collect (nothing taken).
 // The distance map lives in LDS as u16 (0xFFFF = INT_MAX) for frames of <= 30 000 features, else in HBM.
 template <bool LDS_MAP>
-__global__ __launch_bounds__(64) void k_init_resolve(ProjFrameD f, ProjQueriesD q, const unsigned* __restrict__ cand, const int32_t* __restrict__ cand_n,
+__global__ __launch_bounds__(64) void k_init_resolve(ProjFrameD f_arg, ProjQueriesD q_arg, const unsigned* __restrict__ cand, const int32_t* __restrict__ cand_n,
                                                     uint16_t* __restrict__ md_hbm /* [N] */, float nn_ratio, int check_ori,
                                                     int32_t* __restrict__ match12, int32_t* __restrict__ owner /* [N] vnMatches21 */,
                                                     int32_t* __restrict__ bin_of_query, int32_t* __restrict__ n_matches)
 {
+    DCS_PROJ_ARGS_FROM_KERNARG(f, q)
     __shared__ int s_hist[kHisto];
     __shared__ int s_ind[3];
     extern __shared__ uint16_t s_md[];
@@ -517,8 +532,9 @@ __global__ __launch_bounds__(64) void k_init_resolve(ProjFrameD f, ProjQueriesD 
             (void)proj_visit(f, q, qi, TakenPlain{f.taken}, [&](bool pass, unsigned word, int pos) {
                 if (pass && held(base + (int)(word & 0x7FFFFu)) <= (word >> 23)) pass = false;
                 const unsigned long long key = pass ? (((unsigned long long)(word >> 23) << 32) | (unsigned)pos) : ~0ull;
-                if (key < b1) { b2 = b1; w2 = w1; b1 = key; w1 = word; }
-                else if (key < b2) { b2 = key; w2 = word; }
+                const bool lt1 = key < b1, lt2 = key < b2;             // (selects, not branches: as if / else-if the compiler chose between the ADDRESSES of the four values and kept them in scratch memory)
+                b2 = lt1 ? b1 : (lt2 ? key : b2); w2 = lt1 ? w1 : (lt2 ? word : w2);
+                b1 = lt1 ? key : b1; w1 = lt1 ? word : w1;
             });
             unsigned long long m1 = b1;
 #pragma unroll
