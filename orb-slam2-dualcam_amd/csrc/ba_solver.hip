@@ -20,7 +20,7 @@
 //   k_ldlt_mfma     LDL^T + both triangular solves of the reduced camera system in ONE workgroup: 16x16 tiles in the
 //                   registers of 11 worker waves, trailing updates on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the
 //                   diagonal blocks factored one step ahead by a twelfth wave
-//                   (k_ldlt_panel/_update/_solve:
+//                   (k_ldlt_step / k_ldlt_back, one launch per block column:
 //                   multi-launch fallback for n > 256)
 //   k_solve_update  landmark back-substitution, push + manifold update of all estimates, computeScale partials
 //   k_error<1>      edge-parallel residual + chi2 + Huber rho of the trial estimates; the problem's last block adds the block
@@ -205,7 +205,7 @@ struct BaProb {
                                                    // (k_update_error linearises the trial estimates it has just evaluated; [1] == [0] when a group runs the six-launch step)
     double *Hll[2], *bl[2], *Dinv, *db, *xl;       // per landmark; H_ll / b_l / pt_active belong to a linearisation: [b] like Hpl[b]
     double *Hpp, *bp, *bsch, *xp;                  // per free pose
-    double *S, *W;                                 // reduced camera system (ld x ld), panel scratch of the n > 256 fallback
+    double *S, *W, *Dgf;                           // reduced camera system (ld x ld; n > 256: (n_pad + 16) x ld with the right-hand side below), the panels L D of two block columns, U^-1 and 1 / d of the diagonal blocks
     const int32_t *pose_idx, *pt_off, *pt_edges, *pt_pi, *ps_off, *ps_edges;   // pt_pi[k] = free-pose index (or -1) of edge pt_edges[k]
     const int32_t* pair_ij;                          // [n_pairs][2]: every pair i1 <= i2 of free poses, the np diagonal pairs first
     int32_t *pair_off, *pair_e;                      // lists of the pairs, BUILT ON THE DEVICE (k_pairs_*); pair_e: (e1, e2) interleaved, one 8-byte load per entry
@@ -1250,82 +1250,7 @@ __device__ __forceinline__ double fast_recip(double d)
 // (use_reg: 1 = k_ldlt_mfma, 0 = blocked multi-launch fallback; one workgroup per problem. The column-by-column VALU predecessor of k_ldlt_mfma,
 // k_ldlt_reg, was deleted in round 5: nothing selected it but an A/B switch.)
 
-// ---- blocked LDL^T of S (ld x ld, lower part used, n_pad multiple of 16) ----
-// panel step k0: factor the 16x16 diagonal block, then L rows below; W = L D kept for the trailing update
-__global__ __launch_bounds__(256) void k_ldlt_panel(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int k0)
-{
-    const BaProb& pb = probs[blockIdx.x];
-    if (ctls[blockIdx.x].state > ST_RETRY || pb.np == 0 || pb.use_reg != 0 || k0 >= pb.n_pad) return;
-    double* __restrict__ S = pb.S;
-    double* __restrict__ W = pb.W;
-    double* __restrict__ ok = &ctls[blockIdx.x].ok;
-    const int ld = pb.ld, n_pad = pb.n_pad;
-    __shared__ double A[kNB][kNB + 1];
-    __shared__ double d[kNB];
-    const int t = threadIdx.x;
-    {
-        const int i = t / kNB, j = t % kNB;
-        A[i][j] = S[(size_t)(k0 + i) * ld + k0 + j];
-    }
-    __syncthreads();
-    for (int j = 0; j < kNB; ++j) {                         // right-looking LDL^T, thread i = row i
-        const double dj = A[j][j];
-        if (t == 0) { d[j] = dj; if (dj == 0.0 || !isfinite(dj)) *ok = 0.0; }
-        double col_i = 0;
-        if (t < kNB && t > j) col_i = A[t][j];
-        __syncthreads();
-        if (t < kNB && t > j) {
-            const double l = col_i / dj;
-            for (int c = j + 1; c <= t; ++c) A[t][c] -= l * A[c][j];    // A[c][j] still holds the unscaled column
-        }
-        __syncthreads();
-        if (t < kNB && t > j) A[t][j] = col_i / dj;
-        __syncthreads();
-    }
-    {
-        const int i = t / kNB, j = t % kNB;
-        if (i > j) S[(size_t)(k0 + i) * ld + k0 + j] = A[i][j];
-        else if (i == j) S[(size_t)(k0 + i) * ld + k0 + j] = d[i];
-    }
-    // rows below the diagonal block: L_r = A_r L_kk^-T D^-1
-    for (int r = k0 + kNB + t; r < n_pad; r += 256) {
-        double v[kNB];
-        double* row = S + (size_t)r * ld + k0;
-        for (int j = 0; j < kNB; ++j) {
-            double a = row[j];
-            for (int m = 0; m < j; ++m) a -= v[m] * A[j][m];          // v[m] = L_rm * d_m
-            v[j] = a;
-        }
-        for (int j = 0; j < kNB; ++j) { W[(size_t)r * kNB + j] = v[j]; row[j] = v[j] / d[j]; }
-    }
-}
-
 typedef double double4_t __attribute__((ext_vector_type(4)));
-
-// trailing update of one 16x16 tile (ti >= tj > k) per wave: A_ij -= W_i L_j^T on the f64 matrix cores.
-// v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
-// C/D: col = l&15, row = (l>>4) + 4*reg.
-__global__ __launch_bounds__(64) void k_ldlt_update(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls, int k0)
-{
-    const BaProb& pb = probs[blockIdx.z];
-    if (ctls[blockIdx.z].state > ST_RETRY || pb.np == 0 || pb.use_reg != 0) return;
-    const int ti = blockIdx.x, tj = blockIdx.y;
-    if (tj > ti || ti >= (pb.n_pad - k0) / kNB - 1) return;
-    double* __restrict__ S = pb.S;
-    const double* __restrict__ W = pb.W;
-    const int ld = pb.ld;
-    const int i0 = k0 + kNB * (ti + 1), j0 = k0 + kNB * (tj + 1);
-    const int l = threadIdx.x, lo = l & 15, hi = l >> 4;
-    double4_t acc;
-    for (int r = 0; r < 4; ++r) acc[r] = S[(size_t)(i0 + hi + 4 * r) * ld + j0 + lo];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const double a = -W[(size_t)(i0 + lo) * kNB + 4 * kk + hi];
-        const double b = S[(size_t)(j0 + lo) * ld + k0 + 4 * kk + hi];       // L_j[lo][k]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    for (int r = 0; r < 4; ++r) S[(size_t)(i0 + hi + 4 * r) * ld + j0 + lo] = acc[r];
-}
 
 // ---- single-workgroup blocked LDL^T + solve on the f64 matrix cores (n <= 256) ---------------------------------------
 // 12 waves: 11 WORKERS hold the lower triangle in their VGPRs as 16x16 tiles in the MFMA accumulator layout (lane l, register r
@@ -1733,49 +1658,140 @@ __global__ __launch_bounds__(kLdltThreads) void k_ldlt_mfma(const BaProb* __rest
 }
 
 // x = S^-1 b with S = L D L^T already factored in place (unit lower L below the diagonal, D on it). single block.
-__global__ __launch_bounds__(256) void k_ldlt_solve(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
+// ---- n > 256 (more than 42 free poses: Optimizer.cc:415-422 takes EVERY covisible key frame, BundleAdjustment the whole map): blocked LDL^T
+// over many workgroups, ONE launch per block column and no hand-over between workgroups of a launch (round 6). S is a row-major (n_pad + 16) x ld
+// array of 16 x 16 tiles: block rows 0 .. m - 1 the matrix (both triangles filled by k_schur), block row m the right-hand side in its first
+// row (the factorisation of [S b; b^T .] leaves z = D^-1 L^-1 b there: the forward substitution costs one more tile row).
+// Launch s makes block column s final; one wave per tile (I, J), s <= J <= I <= m:
+//   every tile     C(I, J) -= W(I, s - 1) L(J, s - 1)^T          the update of column s - 1: 4 v_mfma_f64_16x16x4_f64
+//   tiles J == s   additionally: the wave forms the updated DIAGONAL tile (s, s) itself (4 more MFMAs on three tiles every such wave reads anyway),
+//                  factors it (ldlt_diag16: one row per lane, DPP broadcasts, ~1.5 us; gives U^-1 and 1 / d) and finishes its own tile:
+//                  W(I, s) = C(I, s) U^-T (4 MFMAs), L(I, s) = W D^-1. The m - s waves of the column repeat the same diagonal factorisation
+//                  instead of waiting for one another: a hand-over inside a launch costs 1 - 4 us (MI355X_MICROARCH.md price list), the
+//                  redundant factorisation 1.5 us and no ordering assumption. Wave (s, s) stores U^-1 and 1 / d for the back substitution
+//                  and owns the pivot test; it never writes S(s, s), which the others read.
+// W is double-buffered by the parity of s (launch s reads column s - 1 and writes column s). The predecessor (one 256-thread workgroup per
+// panel + one tile update launch per panel + a one-workgroup substitution) spent 21 us per panel in its panel kernel and 1.35 ms in the
+// substitution at n = 1 188: 3.76 ms per trial against ~0.6 ms here (scratch/time_ba_large.py).
+struct StepShared { double R[16 * kLS], Dg[16 * kLS], Ui[16 * kLS], invd[16], ok_other; };
+constexpr int kDiagRec = 16 * 16 + 16;             // per diagonal block: U^-1 (row-major 16 x 16), 1 / d
+
+__global__ __launch_bounds__(64) void k_ldlt_step(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int s)
+{
+    const BaProb& pb = probs[blockIdx.z];
+    if (ctls[blockIdx.z].state > ST_RETRY || pb.np == 0 || pb.use_reg != 0) return;
+    const int m = pb.n_pad / kNB;
+    const int I = s + (int)blockIdx.x, J = s + (int)blockIdx.y;
+    if (s >= m || J > I || I > m || J >= m) return;
+    __shared__ StepShared sh;
+    double* __restrict__ S = pb.S;
+    const int ld = pb.ld, n = pb.n, lane = threadIdx.x, lo = lane & 15, hi = lane >> 4;
+    const size_t w_rows = (size_t)pb.n_pad + kNB;
+    const double* __restrict__ Wprev = pb.W + (size_t)((s + 1) & 1) * w_rows * kNB;      // column s - 1
+    double* __restrict__ Wnext = pb.W + (size_t)(s & 1) * w_rows * kNB;
+    const int i0 = kNB * I, j0 = kNB * J, k0 = kNB * (s - 1);
+    // C(I, J) as the matrix cores hold it: lane l, register r = element (row (l >> 4) + 4 r, column l & 15). The right-hand side's tile row is
+    // read from bsch until it has been written once (launch 0 touches column 0 only, launch 1 every column)
+    auto load_tile = [&](int ti0, int tj0, bool rhs_fresh) {
+        double4_t c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (rhs_fresh) c[r] = (hi + 4 * r == 0 && tj0 + lo < n) ? pb.bsch[tj0 + lo] : 0.0;
+            else c[r] = S[(size_t)(ti0 + hi + 4 * r) * ld + tj0 + lo];
+        }
+        return c;
+    };
+    auto update = [&](double4_t c, int ti0, int tj0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double a = -Wprev[(size_t)(ti0 + lo) * kNB + 4 * kk + hi];
+            const double b = S[(size_t)(tj0 + lo) * ld + k0 + 4 * kk + hi];             // L(J, s - 1)[lo][k]
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        }
+        return c;
+    };
+    double4_t acc = load_tile(i0, j0, I == m && s <= 1);
+    if (s > 0) acc = update(acc, i0, j0);
+    if (J > s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(size_t)(i0 + hi + 4 * r) * ld + j0 + lo] = acc[r];
+        return;
+    }
+    // ---- column s: the diagonal tile (formed here unless this IS its wave), its factorisation, this wave's panel tile
+    const int offC = hi * kLS + lo, offA = lo * kLS + hi;
+    double4_t dg = acc;
+    if (I != s) { dg = load_tile(j0, j0, false); if (s > 0) dg = update(dg, j0, j0); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sh.R[offC + 4 * r * kLS] = acc[r]; sh.Dg[offC + 4 * r * kLS] = dg[r]; }
+    __syncthreads();
+    double ar[16], xr[16];
+    (void)ldlt_diag16(ar, xr, sh.Dg, sh.Ui, sh.invd, 0.0, I == s ? &ctls[blockIdx.z].ok : &sh.ok_other, lane);
+    __syncthreads();
+    if (I == s) {
+        double* rec = pb.Dgf + (size_t)s * kDiagRec;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rec[(hi + 4 * r) * 16 + lo] = sh.Ui[offC + 4 * r * kLS];
+        if (lane < 16) rec[256 + lane] = sh.invd[lane];
+        return;
+    }
+    double4_t w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) w = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.R[offA + 4 * sl], sh.Ui[offA + 4 * sl], w, 0, 0, 0);   // W = C U^-T
+    const double invd_c = sh.invd[lo];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        S[(size_t)(i0 + hi + 4 * r) * ld + j0 + lo] = w[r] * invd_c;                     // L(I, s)
+        Wnext[(size_t)(i0 + hi + 4 * r) * kNB + lo] = w[r];
+    }
+}
+
+// L^T x = z, block columns backwards, one workgroup per problem: z (the first row of S's last block row) sits in LDS; step J forms
+// x_J = U_J^-T z_J on 16 lanes and every thread takes x_J out of its columns of z: z_c -= sum_r L(16 J + r, c) x_J[r] (tile row J of S, read
+// along the rows: coalesced). What a step reads from memory does not depend on the steps before it and is requested before the step's barriers.
+constexpr int kBackT = 1024;
+__global__ __launch_bounds__(kBackT) void k_ldlt_back(const BaProb* __restrict__ probs, const BaCtl* __restrict__ ctls)
 {
     const BaProb& pb = probs[blockIdx.x];
     if (ctls[blockIdx.x].state > ST_RETRY || pb.np == 0 || pb.use_reg != 0) return;
     const double* __restrict__ S = pb.S;
-    const double* __restrict__ b = pb.bsch;
     double* __restrict__ x = pb.xp;
-    const int ld = pb.ld, n_pad = pb.n_pad, n = pb.n;
-    extern __shared__ double y[];                  // n_pad
-    __shared__ double red[256];
+    const int ld = pb.ld, n_pad = pb.n_pad, n = pb.n, m = n_pad / kNB;
+    extern __shared__ double zz[];                 // n_pad
+    __shared__ double xj[kNB];
     const int t = threadIdx.x;
-    for (int i = t; i < n_pad; i += 256) y[i] = i < n ? b[i] : 0.0;
-    __syncthreads();
-    for (int k0 = 0; k0 < n_pad; k0 += kNB) {      // forward: L y = b
-        if (t == 0) {
-            for (int i = 1; i < kNB; ++i) { double a = y[k0 + i]; for (int m = 0; m < i; ++m) a -= S[(size_t)(k0 + i) * ld + k0 + m] * y[k0 + m]; y[k0 + i] = a; }
+    for (int c = t; c < n_pad; c += kBackT) zz[c] = S[(size_t)n_pad * ld + c];
+    for (int J = m - 1; J >= 0; --J) {
+        const int r0 = kNB * J, c0 = t, c1 = t + kBackT;
+        const bool h0 = c0 < r0, h1 = c1 < r0;
+        double u[kNB], l0[kNB], l1[kNB];
+        if (t < kNB) {
+            const double* rec = pb.Dgf + (size_t)J * kDiagRec;
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) u[k] = rec[k * 16 + t];                        // U^-1[k][t]
+        }
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) { l0[r] = h0 ? S[(size_t)(r0 + r) * ld + c0] : 0.0; l1[r] = h1 ? S[(size_t)(r0 + r) * ld + c1] : 0.0; }
+        __syncthreads();                           // z_J is final: every earlier step has taken its x out
+        if (t < kNB) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) a = fma(u[k], zz[r0 + k], a);
+            xj[t] = a;
+            if (r0 + t < n) x[r0 + t] = a;
         }
         __syncthreads();
-        for (int r = k0 + kNB + t; r < n_pad; r += 256) {
-            double a = y[r];
-            const double* row = S + (size_t)r * ld + k0;
-            for (int m = 0; m < kNB; ++m) a -= row[m] * y[k0 + m];
-            y[r] = a;
+        if (h0) { double a = zz[c0];
+#pragma unroll
+            for (int r = 0; r < kNB; ++r) a = fma(-l0[r], xj[r], a); zz[c0] = a; }
+        if (h1) { double a = zz[c1];
+#pragma unroll
+            for (int r = 0; r < kNB; ++r) a = fma(-l1[r], xj[r], a); zz[c1] = a; }
+        for (int c = t + 2 * kBackT; c < r0; c += kBackT) {                              // (more than 2 048 columns: 341 free poses)
+            double a = zz[c];
+            for (int r = 0; r < kNB; ++r) a = fma(-S[(size_t)(r0 + r) * ld + c], xj[r], a);
+            zz[c] = a;
         }
-        __syncthreads();
     }
-    for (int i = t; i < n_pad; i += 256) y[i] /= S[(size_t)i * ld + i];
-    __syncthreads();
-    for (int k0 = n_pad - kNB; k0 >= 0; k0 -= kNB) {   // backward: L^T x = z
-        // contributions of already solved rows below: 16 columns x 16 row-chunks
-        const int j = t & 15, ch = t >> 4;
-        double a = 0;
-        for (int r = k0 + kNB + ch; r < n_pad; r += 16) a += S[(size_t)r * ld + k0 + j] * y[r];
-        red[t] = a;
-        __syncthreads();
-        if (t < kNB) { double s = 0; for (int c = 0; c < 16; ++c) s += red[c * 16 + t]; y[k0 + t] -= s; }
-        __syncthreads();
-        if (t == 0) {
-            for (int i = kNB - 2; i >= 0; --i) { double a2 = y[k0 + i]; for (int m = i + 1; m < kNB; ++m) a2 -= S[(size_t)(k0 + m) * ld + k0 + i] * y[k0 + m]; y[k0 + i] = a2; }
-        }
-        __syncthreads();
-    }
-    for (int i = t; i < n; i += 256) x[i] = y[i];
 }
 
 // Landmark back-substitution + oplus of every estimate into the OTHER estimate buffer (g2o's push + update: the current
@@ -3546,8 +3562,9 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         for (int i = 0; i < NB; ++i) {
             BaProb& q = hp[i];
             const size_t P = q.P, L = q.L, E = q.E;
-            if (!q.use_reg) q.S = c.get<double>((size_t)q.ld * q.ld);
-            q.W = c.get<double>(q.use_reg ? 1 : (size_t)q.ld * kNB);
+            if (!q.use_reg) q.S = c.get<double>(((size_t)q.n_pad + kNB) * q.ld);
+            q.W = c.get<double>(q.use_reg ? 1 : 2 * ((size_t)q.n_pad + kNB) * kNB);
+            q.Dgf = c.get<double>(q.use_reg ? 1 : (size_t)(q.n_pad / kNB) * kDiagRec);
             q.poses[1] = c.get<double>(7 * P); q.points[1] = c.get<double>(3 * L);
             q.err = c.get<double>(2 * E);
             q.Hpl[0] = c.get<double>(18 * E); q.BD = c.get<double>(18 * E); q.cpose[0] = c.get<double>(27 * E); q.cpoint[0] = c.get<double>(9 * E);
@@ -3799,7 +3816,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         DCS_CHECK_LAUNCH();
         if (gr.any_blocked) {                             // the blocked fallback factors S in place: rebuild it every trial
             for (int i = gr.off; i < gr.off + nb; ++i)
-                if (hp[i].np && hp[i].use_reg == 0) DCS_HIP(hipMemsetAsync(hp[i].S, 0, sizeof(double) * (size_t)hp[i].ld * hp[i].ld, gs));
+                if (hp[i].np && hp[i].use_reg == 0) DCS_HIP(hipMemsetAsync(hp[i].S, 0, sizeof(double) * ((size_t)hp[i].n_pad + kNB) * hp[i].ld, gs));
             hipLaunchKernelGGL(k_pad_identity, dim3(1, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
         }
         if (gr.g_schur) {
@@ -3813,12 +3830,9 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             else hipLaunchKernelGGL(k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), 0, gs, dp, ctls);
         }
         if (gr.any_blocked) {
-            for (int k0 = 0; k0 < gr.max_npad_blocked; k0 += kNB) {
-                hipLaunchKernelGGL(k_ldlt_panel, dim3(nb), dim3(256), 0, gs, dp, ctls, k0);
-                const int m = (gr.max_npad_blocked - k0) / kNB - 1;
-                if (m > 0) hipLaunchKernelGGL(k_ldlt_update, dim3(m, m, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls, k0);
-            }
-            hipLaunchKernelGGL(k_ldlt_solve, dim3(nb), dim3(256), sizeof(double) * gr.max_npad_blocked, gs, dp, (const BaCtl*)ctls);
+            const int m = gr.max_npad_blocked / kNB;      // block columns; launch s: tiles (I, J), s <= J < m, J <= I <= m (block row m = the right-hand side)
+            for (int s2 = 0; s2 < m; ++s2) hipLaunchKernelGGL(k_ldlt_step, dim3(m - s2 + 1, s2 == 0 ? 1 : m - s2, nb), dim3(64), 0, gs, dp, ctls, s2);
+            hipLaunchKernelGGL(k_ldlt_back, dim3(nb), dim3(kBackT), sizeof(double) * gr.max_npad_blocked, gs, dp, (const BaCtl*)ctls);
         }
         DCS_CHECK_LAUNCH();
         mark(step, 2);

@@ -304,6 +304,25 @@ def test_pose_optimization_vs_oracle(pkg, oracle, synth, seed, obs):
     assert np.array_equal(got2["poses"], got["poses"][f0:f1]) and np.array_equal(got2["outlier"], got["outlier"][e0:e1])
 
 
+def test_ba_window_of_sixty_free_poses_vs_oracle(pkg, oracle, synth):
+    """Optimizer::LocalBundleAdjustment takes EVERY covisible key frame (Optimizer.cc:415-422: the window is unbounded). 60 free poses:
+    reduced camera system n = 360 > 256, beyond the one-workgroup factorisation -- both rounds, against the oracle."""
+    pb = synth.ba_problem(n_poses=67, n_fixed=6, n_points=2400, obs_per_point=8, seed=61)       # + fixId, the oldest free pose
+    assert int((pb["pose_fixed"] == 0).sum()) == 60
+    _compare(pkg.Optimizer.LocalBundleAdjustment(pb), _oracle_run(oracle, pb), pb)
+
+
+def test_global_bundle_adjustment_at_map_size_vs_oracle(pkg, oracle, synth):
+    """Optimizer::BundleAdjustment over a whole map (Optimizer.cc:70-248): 200 key frames, 20 000 map points, 160 000 dual-camera edges,
+    only the first pose fixed -> reduced camera system n = 1 194; one round of 4 iterations with the Huber kernel, against the oracle."""
+    pb = synth.ba_problem(n_poses=200, n_fixed=1, n_points=20000, obs_per_point=8, seed=5)
+    assert len(pb["edge_pose"]) >= 150000
+    got = pkg.Optimizer.BundleAdjustment(pb, nIterations=4, bRobust=True)
+    exp = _oracle_run(oracle, pb, iters1=4, iters2=0, huber_delta=float(np.float32(np.sqrt(3.99))))
+    assert exp["n_iters"][0] >= 2
+    _compare(got, exp, pb)
+
+
 def test_pose_optimization_four_camera_rig_with_one_crowded_camera(pkg, oracle, synth):
     """k_pose_opt2 keeps a camera's edges in the registers of the waves the camera gets: a four-camera rig with more than 1 024 edges on ONE
     camera does not fit (each camera has one wave), the kernel declines the frame and k_pose_opt takes it in the same call. Frames of the
