@@ -1232,7 +1232,48 @@ def main():
             ba["cpu_baseline"] = {"value": round(it_c / tcb, 2), "unit": "LM iterations/s", "cores": 1, "kind": "port", "pinned_core": core,
                                   "sample": "%d solves of the C4 problem in %.1f s, oracle -O3 single thread pinned to core %d (dense LDLT)" % (n_c, tcb, core)}
             ba["speedup_vs_cpu_1thread"] = round(ba["value"] / max(ba["cpu_baseline"]["value"], 1e-9), 1)
+        # ---- windows beyond the one-workgroup factorisation (the reference's window is unbounded: Optimizer.cc:415-422 takes every covisible key frame,
+        # Optimizer::BundleAdjustment :70-248 the whole map): 60 free poses (n = 360) and a global-BA map (200 KF / 20 000 MP, one round), each with
+        # its own single-thread oracle baseline on a bounded sample
+        def large_leg(name, kw, gba_iters, reps_l, cpu_cap):
+            pbl = synth.ba_problem(**kw)
+            if gba_iters:
+                pbl = dict(pbl); pbl["iters1"], pbl["iters2"] = gba_iters, 0; pbl["huber_delta"] = float(np.float32(np.sqrt(3.99)))
+            prl = pkg.Optimizer.prepare(pbl)
+            prl.solve()
+            itl, tl0 = 0, time.perf_counter()
+            for _ in range(reps_l):
+                itl += sum(prl.solve()["n_iters"])
+            tl = time.perf_counter() - tl0
+            pkg.Optimizer.timing(True)
+            rl = prl.solve()
+            tml = pkg.Optimizer.timing(False)
+            nl = 6 * int((np.asarray(pbl["pose_fixed"]) == 0).sum())
+            leg = {"workload": name, "n_reduced_system": nl, "edges": len(pbl["obs"]), "value": round(itl / tl, 1), "unit": "LM iterations/s",
+                   "ms_per_solve": round(tl / reps_l * 1e3, 3), "iters_per_solve": itl / reps_l,
+                   "factorisation_us_per_trial": round(tml["ldlt_us"] / max(sum(rl["n_trials"]), 1), 1),
+                   "factorisation": "k_ldlt_step x %d launches + k_ldlt_back per trial (blocked LDL^T over many workgroups)" % ((nl + 15) // 16)}
+            if args.cpu_seconds > 0:
+                O2 = entry.load_oracle()
+                probl = dict(pbl)
+                probl["cams"] = [O2.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pbl["cams"]]
+                aff = os.sched_getaffinity(0)
+                core2 = sorted(aff)[len(aff) // 2]
+                os.sched_setaffinity(0, {core2})
+                tq0, it_q, n_q = time.perf_counter(), 0, 0
+                while n_q < 1 or (time.perf_counter() - tq0 < min(args.cpu_seconds, cpu_cap) and n_q < 10):
+                    it_q += sum(O2.ba_local(probl)["n_iters"]); n_q += 1
+                tq = time.perf_counter() - tq0
+                os.sched_setaffinity(0, aff)
+                leg["cpu_baseline"] = {"value": round(it_q / tq, 2), "unit": "LM iterations/s", "cores": 1, "kind": "port", "pinned_core": core2,
+                                       "sample": "%d solves of the same problem in %.1f s, oracle -O3 single thread (dense LDLT)" % (n_q, tq)}
+                leg["speedup_vs_cpu_1thread"] = round(leg["value"] / max(leg["cpu_baseline"]["value"], 1e-9), 1)
+            return leg
+        ba["p60"] = large_leg("LocalBundleAdjustment, 60 free + 7 fixed key frames / 2 400 MP (reduced camera system n = 360)",
+                              dict(n_poses=67, n_fixed=6, n_points=2400, obs_per_point=8, seed=61), 0, 10, 4.0)
         out["local_ba"] = ba
+        out["global_ba"] = large_leg("Optimizer::BundleAdjustment shape: 200 KF / 20 000 MP / 160 000 edges, one round of 5 iterations (n = 1 194)",
+                                     dict(n_poses=200, n_fixed=1, n_points=20000, obs_per_point=8, seed=5), 5, 3, 6.0)
 
     # ---- C5 on one GPU
     if solo and not args.no_c5 and not args.no_ba:

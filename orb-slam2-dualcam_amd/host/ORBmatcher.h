@@ -22,6 +22,15 @@ public:
 
     ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
+#ifdef DCS_WITH_REFERENCE_MODEL
+    // The reference's own signatures (include/ORBmatcher.h:65-67, 79-82, 121-124, 196-200), bodies in ReferenceAdapters.h: the reference's gating per
+    // map point, one call into the library for the candidate loops, the reference's assignment of the matches.
+    int SearchByProjection(FramePtr pF, const std::vector<MapPointPtr>& vpMapPoints, const float th = 3);
+    int SearchByProjection(FramePtr pCurrentFrame, const FramePtr pLastFrame, const float th, bool bMapScaled);
+    int SearchByProjectionOnCam(FramePtr pFcur, const int& query, FramePtr pFlast, const float th);
+    int SearchByBoWCrossCam(FramePtr F, const int& cF, KeyFramePtr pKF, const int& cKF, std::vector<MapPointPtr>& vpMapPointMatches);
+#endif
+
     // SearchByBoWCrossCam(F, cF, KF, cKF, vpMapPointMatches) (ORBmatcher.cc:162-294) on flat per-camera arrays:
     // kfValid[i] = "KF feature i has a good MapPoint"; matchF[j] = matched KF feature or -1. Returns nmatches.
     int SearchByBoWCrossCam(const std::vector<uint8_t>& descF, const std::vector<float>& angF, const FeatureVectorCSR& fvF,

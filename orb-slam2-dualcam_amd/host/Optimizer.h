@@ -59,6 +59,17 @@ public:
         return inliers;
     }
 
+#ifdef DCS_WITH_REFERENCE_MODEL
+    // The reference's own signatures (include/Optimizer.h:49-56), bodies in ReferenceAdapters.h: the reference's gather, one call into the library,
+    // the reference's write-back. Needs Frame.h / KeyFrame.h / MapPoint.h / Map.h / Cameras.h included first.
+    void static BundleAdjustment(const std::vector<KeyFramePtr>& vpKF, const std::vector<MapPointPtr>& vpMP, unsigned long fixId, int nIterations = 5,
+                                 bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true);
+    void static GlobalBundleAdjustemnt(MapPtr pMap, int nIterations = 5, unsigned long fixId = 0, bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0,
+                                       const bool bRobust = true);
+    void static LocalBundleAdjustment(KeyFramePtr pKF, bool* pbStopFlag, MapPtr pMap, size_t fixId);
+    int static PoseOptimization(FramePtr pFrame);
+#endif
+
     // pbStopFlag as in the reference (:471-472, :582-593); thHuber = sqrt(5.991), chi2 gate 5.991, 5 + 10 iterations
     static void LocalBundleAdjustment(const LocalBAProblem& in, bool* pbStopFlag, LocalBAResult& out)
     {

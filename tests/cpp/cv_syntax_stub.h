@@ -40,6 +40,12 @@ struct MatStep {
     operator size_t() const;
 };
 
+class Mat;
+class MatExpr {                                   // (a lazy expression in OpenCV; here only something a Mat is made from)
+public:
+    operator Mat() const;
+};
+
 class Mat {
 public:
     Mat();
@@ -48,11 +54,21 @@ public:
     int type() const;
     bool empty() const;
     Mat rowRange(int startrow, int endrow) const;
+    Mat colRange(int startcol, int endcol) const;    // the members below: host/ReferenceAdapters.h keeps the reference's own cv::Mat lines (ORBmatcher.cc:962-968, 997-1004)
+    Mat col(int x) const;
+    Mat row(int y) const;
+    Mat clone() const;
+    MatExpr t() const;
+    template <typename T> T& at(int i0);
+    template <typename T> const T& at(int i0) const;
     void copyTo(OutputArray m) const;
     int rows, cols;
     unsigned char* data;
     MatStep step;
 };
+MatExpr operator*(const Mat& a, const Mat& b);
+MatExpr operator+(const MatExpr& a, const Mat& b);
+MatExpr operator-(const MatExpr& a);
 
 class _InputArray {
 public:
