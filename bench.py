@@ -46,6 +46,7 @@ I8_MFMA_PEAK_TOPS = 3944.0       # MI355X_MICROARCH.md: v_mfma_i32_16x16x64_i8 d
 FP4_MFMA_PEAK_TOPS = 7228.0      # cdna_hip_programming.md: v_mfma_scale_f32_16x16x128_f8f6f4 with FP4 operands, measured floor of the 16x16 shape (spec ~10 PF dense)
 F64_MFMA_PEAK_GFLOPS = 78600.0   # AMD's public MI355X figure for FP64 matrix (= FP64 vector); the in-container guide has no f64 row
 N_CU = 256
+F64_VECTOR_PEAK_GFLOPS = 78600.0   # FP64 vector = FP64 matrix on MI355X (public spec): 16 FMA lanes per SIMD per cycle at 2.4 GHz
 
 
 def parse_args(argv=None):
@@ -838,13 +839,21 @@ def main():
             del algo["k_resize(x0)"], dur["k_resize(x0)"]
         kernels = {k: dict(us=round(dur[k], 2), algo_bytes=int(algo[k]),
                            gbps=round(algo[k] / max(dur[k], 1e-3) / 1e3, 2)) for k in algo}
+        # roofline-style entry of the second-largest stage, so that it has a number to beat: SURVEY 8(d)'s orientation + BRIEF + output rows per key
+        # point, PLUS its blur row (2 x pyramid pixels) when the fused form runs -- k_describe<true> blurs the 512 tested pixels of each patch itself and
+        # never reads or writes a blurred pyramid, which is what those bytes would have been
+        kd = kernels["k_describe"]
+        d_bytes = algo["k_describe"] + (2 * sum_px * n_img_l if acc["blur_us"] == 0 else 0)
+        kd["roofline"] = {"bound": "hbm", "achieved": round(d_bytes / max(dur["k_describe"], 1e-3) / 1e3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(d_bytes / max(dur["k_describe"], 1e-3) / 1e3 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(d_bytes),
+                          "note": "vector + matrix + LDS issue bound (8 workgroups per CU), not byte bound: DESIGN.md section 4"}
         dom = max(dur, key=lambda k: dur[k])
         # Hardware counters cannot be read inside this process: the HBM traffic and the instruction counts come from the committed
         # rocprofv3 --pmc passes of this same command (profiles/, produced by tools/collect_profiles.sh) and are labelled "imported";
         # they are used only when the workload matches. A "launch" of the roofline kernel = its launches of ONE step (FAST runs one
         # launch per LDS size class), timed together by the hipEvents around the stage.
         traffic, traffic_raw, counters_src, pmc_k = None, None, None, {}
-        for prof in ("r05_pmc_counters.json", "r04_pmc_counters.json", "r03_pmc_counters.json"):
+        for prof in ("r06_pmc_counters.json", "r05_pmc_counters.json", "r04_pmc_counters.json", "r03_pmc_counters.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if (P, W, H, NF, LN) == tuple(pmc.get("bench_args", ())):
@@ -1393,6 +1402,23 @@ def main():
                                           huber_delta=prm_t["huber_delta"], chi2_th=prm_t["chi2_th"], its=prm_t["its"]))
             chain["cpu_baseline"] = {"value": round(med(oracle_chain, 10) * 1e3, 4), "unit": "ms per frame", "cores": 1, "kind": "port",
                                      "sample": "median of 10 frames, oracle -O3 single thread (same marshalling)"}
+        # roofline-style entry of the chain's dominant kernel (k_pose_opt2: one workgroup per frame, 60 dependent passes): f64 operations of the sweeps
+        # + the scalar part per pass against the f64 vector peak of ONE CU; its duration is imported from the committed rocprofv3 trace of
+        # scratch/time_track.py (profiles/r06_track_kernel_stats.csv), the same frames as this leg
+        try:
+            import csv as _csv
+            with open(os.path.join(ROOT, "profiles", "r06_track_kernel_stats.csv")) as fh:
+                row = next(r for r in _csv.DictReader(fh) if "k_pose_opt2" in r["Name"])
+            us_k = float(row["MinNs"]) / 1e3                   # batch-of-1 launches (one workgroup) are the minimum of the trace
+            edges = int((pkg.abi.PreparedTracking(fr_t[:1], prm_t).track()[0]["point_of_feature"] != -1).sum())
+            passes, f64_per_edge, f64_scalar = 60, 2 * 107, 2 * 400      # measured passes of this frame; FMA = 2 flops
+            flops = passes * (edges * f64_per_edge + 4 * f64_scalar)
+            peak_cu = F64_VECTOR_PEAK_GFLOPS / N_CU
+            chain["pose_kernel"] = {"kernel": "k_pose_opt2", "edges": edges, "us_batch_of_1": round(us_k, 1), "bound": "latency (dependent f64 chain on one CU)",
+                                    "achieved": round(flops / us_k / 1e3, 2), "peak": round(peak_cu, 1), "unit": "GFLOP/s of ONE CU (f64 vector)",
+                                    "frac": round(flops / us_k / 1e3 / peak_cu, 4), "source": "imported: profiles/r06_track_kernel_stats.csv"}
+        except Exception:
+            pass
         out["per_frame_chain"] = chain
 
     # ---- one dual frame from host images to the pose, the reference's steady state per frame (Frame ctor -> TrackWithMotionModel -> TrackLocalMap,
