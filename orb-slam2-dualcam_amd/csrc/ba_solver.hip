@@ -181,12 +181,7 @@ __device__ inline double block_sum_256(double v, double* s /*[256]*/)
 enum : int { ST_NEW_ITER = 0, ST_RETRY = 1, ST_ROUND_END = 2, ST_DONE = 3 };
 
 struct BaCtl {
-    int state, round, it, qmax, nBad, cur, errors_current, robust, trace, stopped, n_active, fault;
-    // k_front's hand-overs inside one launch (written with release, read with acquire; reset by the trial's finisher in k_update_error):
-    //   need_begin    the step starts with the edge pass of k_begin (round change, stale errors): decided by the PREVIOUS step's finisher
-    //   begin_done    that pass has finished and the control word is final
-    //   lambda_ready  computeLambdaInit of the first iteration of a round has run
-    int need_begin, begin_done, lambda_ready, pad0;
+    int state, round, it, qmax, nBad, cur, errors_current, robust, trace, stopped, n_active, pad0;
     double mult, ni, currentChi, iniChi, maxdiag, ok, scale, pad1;
     int n_iters[2], n_trials[2];
     double lambda[2], chi2_trace[32];
@@ -211,7 +206,7 @@ struct BaProb {
     int32_t *pair_off, *pair_e;                      // lists of the pairs, BUILT ON THE DEVICE (k_pairs_*); pair_e: (e1, e2) interleaved, one 8-byte load per entry
     uint32_t* pt_bits;                               // [np][pt_words] bit l of row i: free pose i observes point l (zeroed region)
     int32_t* edge_of;                                // [np][L] the edge of (free pose, point), valid where the bit is set
-    int pt_words, spec_cap;                        // spec_cap: entries of k_update_error<true>'s dynamic LDS (the launch's, not the problem's)
+    int pt_words, pad2;
     double *partial, *scale_part, *maxd_part;      // block partials: chi2, computeScale, max |diagonal| (np + nb_pts entries)
     uint8_t* pt_active[2];
     unsigned* ticket;                              // [0] error kernels, [1] k_reduce_pose, [2] k_begin
@@ -278,15 +273,6 @@ __device__ __forceinline__ void publish_problem_end(int* __restrict__ h_progress
     } while (__hip_atomic_load(grid_ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != v);
 }
 
-// what the NEXT step's k_front needs to know before any of its workgroups has run: does the step start with k_begin's edge pass (round change,
-// or an iteration that ended on a rejected trial and left the errors stale)? After an accepted trial it does not -- the trial kernel has
-// linearised the new estimates already.
-__device__ __forceinline__ void front_handover(BaCtl& ctl)
-{
-    ctl.need_begin = (ctl.state == ST_ROUND_END || (ctl.state == ST_NEW_ITER && !ctl.errors_current)) ? 1 : 0;
-    ctl.begin_done = 0; ctl.lambda_ready = 0;
-}
-
 // accept / reject of a trial (optimization_algorithm_levenberg.cpp:104-164): ONE thread of the problem, after the chi2 of the trial
 // estimates (tot) and computeScale (sc) are known. Always returns true.
 __device__ __forceinline__ bool lm_accept(const BaProb& pb, BaCtl& ctl, const volatile int* __restrict__ stop_words, double tot, double sc)
@@ -312,7 +298,7 @@ __device__ __forceinline__ bool lm_accept(const BaProb& pb, BaCtl& ctl, const vo
     const int qmax = ++ctl.qmax;
     const bool stop = stop_words && __hip_atomic_load(const_cast<const int*>(stop_words + blockIdx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
     if (stop) ctl.stopped = 1;
-    if (rho < 0 && qmax < 10 && !stop) { ctl.state = ST_RETRY; front_handover(ctl); return true; }
+    if (rho < 0 && qmax < 10 && !stop) { ctl.state = ST_RETRY; return true; }
     const int round = ctl.round;
     ++ctl.n_iters[round];
     if (ctl.trace < 32) ctl.chi2_trace[ctl.trace++] = currentChi;
@@ -325,7 +311,6 @@ __device__ __forceinline__ bool lm_accept(const BaProb& pb, BaCtl& ctl, const vo
     const int it = ++ctl.it;
     if (term || stop || it >= pb.iters[round]) ctl.state = ST_ROUND_END;
     else { ctl.state = ST_NEW_ITER; ctl.qmax = 0; ctl.iniChi = currentChi; }
-    front_handover(ctl);
     return true;
 }
 
@@ -472,12 +457,11 @@ __device__ __forceinline__ double vblock_sum_256(double v, double* s /*[256 VB]*
     return r;
 }
 
-// The body of k_begin for a workgroup of 256 VB threads = VB of its 256-edge blocks (VB = 1: k_begin itself; VB = 4: the first workgroups of
-// k_front). bx = the workgroup's index among the problem's ceil(nblk / VB). The chi2 partials stay per 256-edge block and are added in the same
-// order, so both forms produce the same bits. Returns in its threads after everything the workgroup had to do.
+// The body of k_begin for a workgroup of 256 VB threads = VB of its 256-edge blocks (VB = 1 is the only form left: round 5's k_front, which ran it with
+// VB = 2 inside a fused launch, was bit-identical, slower and is gone). bx = the workgroup's index among the problem's ceil(nblk / VB).
 template <int VB>
 __device__ __forceinline__ void begin_body(const BaProb& pb, BaCtl& ctl, int bx, double* s /*[256 VB]*/, DCams& cams, int& s_cnt, bool& last, int* __restrict__ h_progress,
-                                           unsigned* __restrict__ grid_ticket, bool front)
+                                           unsigned* __restrict__ grid_ticket)
 {
     const int nwg = (pb.nblk + VB - 1) / VB, t = threadIdx.x;
     // the control word as of the end of the previous step: read ONCE -- the problem's last block rewrites it while other blocks
@@ -531,8 +515,7 @@ __device__ __forceinline__ void begin_body(const BaProb& pb, BaCtl& ctl, int bx,
     } else if (in && act) {                                    // errors are current (written by the accepted trial's k_error<1>)
         err0 = pb.err[2 * e]; err1 = pb.err[2 * e + 1]; x2 = pb.chi2[e];
     }
-    // ---- (2) linearizeOplus + constructQuadraticForm. In FRONT of the ticket: in k_front the pass is over for the rest of the launch as soon as
-    // the last workgroup has arrived there
+    // ---- (2) linearizeOplus + constructQuadraticForm
     if (lin && in) linearize_edge(pb, cur, e, act, pb.pose_idx[ps] >= 0, cams.c[cam_id], poses + 7 * ps, pc, err0, err1, x2, robust, delta, pb.cpoint[cur] + (size_t)e * 9);
     if (!(round_end || pre)) return;                                 // workgroup-uniform
     const double tsum = vblock_sum_256<VB>(rho0, s);                 // (its barriers also order every thread's stores before thread 0's release)
@@ -560,10 +543,6 @@ __device__ __forceinline__ void begin_body(const BaProb& pb, BaCtl& ctl, int bx,
             if (next_round) { ctl.round = 1; ctl.it = 0; ctl.qmax = 0; ctl.nBad = 0; ctl.robust = 0; }   // Optimizer.cc:612-621
             ctl.currentChi = tot; ctl.iniChi = tot; ctl.errors_current = 1; ctl.state = ST_NEW_ITER;
         } else { ctl.state = ST_DONE; done = true; }
-        if (front) {                                                 // the rest of k_front's workgroups wait for this word
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_store(&ctl.begin_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
         if (done) publish_problem_end(h_progress, grid_ticket);
     }
 }
@@ -576,7 +555,7 @@ __global__ __launch_bounds__(256) void k_begin(const BaProb* __restrict__ probs,
     __shared__ int s_cnt;
     __shared__ bool last;
     const BaProb& pb = probs[blockIdx.y];
-    if ((int)blockIdx.x < pb.nblk) begin_body<1>(pb, ctls[blockIdx.y], blockIdx.x, s, cams, s_cnt, last, h_progress, grid_ticket, false);
+    if ((int)blockIdx.x < pb.nblk) begin_body<1>(pb, ctls[blockIdx.y], blockIdx.x, s, cams, s_cnt, last, h_progress, grid_ticket);
 }
 
 // block (1024 threads) per free pose: 37 edge chunks x 27 components, combined in chunk order (deterministic). The
@@ -586,7 +565,7 @@ constexpr int kPoseChunks = 37;
 // Hessian blocks in maxd_part[], and at the first iteration of a round the last block to finish (ticket) takes the maximum of
 // those np + nb_pts numbers -- a max is order-independent, so the result is reproducible -- and resets the LM multipliers.
 // Called by the first wave of a block with a wave-uniform `md`.
-__device__ __forceinline__ void reduce_finish(const BaProb& pb, BaCtl& ctl, double md, int slot, int n_blk, bool front)
+__device__ __forceinline__ void reduce_finish(const BaProb& pb, BaCtl& ctl, double md, int slot, int n_blk)
 {
     if (ctl.it != 0) return;                                 // block-uniform: lambda is only initialised at the first iteration
     const int lane = threadIdx.x & 63;
@@ -607,10 +586,6 @@ __device__ __forceinline__ void reduce_finish(const BaProb& pb, BaCtl& ctl, doub
     if (lane == 0) {
         ctl.maxdiag = m; ctl.mult = 1.0; ctl.ni = 2; ctl.nBad = 0;       // lambda = tau * max diagonal, tau = 1e-5
         __hip_atomic_store(pb.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (front) {                                         // k_front: the landmark and edge workgroups of this launch wait for lambda
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_store(&ctl.lambda_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -644,7 +619,7 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) md = fmax(md, __shfl_xor(md, d));
-        reduce_finish(pb, ctls[blockIdx.y], md, blockIdx.x, pb.np + pb.nb_pts, false);
+        reduce_finish(pb, ctls[blockIdx.y], md, blockIdx.x, pb.np + pb.nb_pts);
         return;
     }
     const int32_t* __restrict__ ps_off = pb.ps_off;
@@ -669,7 +644,7 @@ __global__ __launch_bounds__(1024) void k_reduce_pose(const BaProb* __restrict__
     if (t < 6) pb.bp[i * 6 + t] = s[21 + t];
     if (t < 64) {                                            // wave 0: max |diagonal| of this pose block (entries 0, 6, 11, 15, 18, 20 of the packed upper triangle)
         const double md = fmax(fmax(fmax(fabs(s[0]), fabs(s[6])), fmax(fabs(s[11]), fabs(s[15]))), fmax(fabs(s[18]), fabs(s[20])));
-        reduce_finish(pb, ctls[blockIdx.y], md, blockIdx.x, pb.np + pb.nb_pts, false);
+        reduce_finish(pb, ctls[blockIdx.y], md, blockIdx.x, pb.np + pb.nb_pts);
     }
 }
 
@@ -713,221 +688,6 @@ __global__ __launch_bounds__(256) void k_prep(const BaProb* __restrict__ probs, 
     const double* bl = pb.bl[ctl.cur];
     for (int i = 0; i < 9; ++i) pb.Dinv[(size_t)l * 9 + i] = D[i];
     for (int i = 0; i < 3; ++i) pb.db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
-}
-
-// ---- k_front: k_begin + k_reduce_pose + k_prep as ONE launch (round 5; a launch boundary costs an LM step ~5 us and the step had six).
-// What makes it possible: k_update_error linearises the trial estimates it has just evaluated into the other half of the double-buffered
-// blocks, so a step that follows an accepted trial has nothing left to do per edge -- k_begin's edge pass only runs at the start of a round
-// and after an iteration that ended on a rejected trial (ctl.need_begin, decided by the previous step's finisher). Workgroups of 1024 threads,
-// by index:
-//   [0, nwg_b)            begin_body<4> -- returns at once unless need_begin
-//   [.., + np)            one free pose each: k_reduce_pose's pose blocks
-//   [.., + nb_l)          1024 landmarks each: H_ll / b_l sums (k_reduce_pose), then (H_ll + lambda I)^-1 and D^-1 b_l (k_prep)
-//   [.., + nwg_b)         thread per edge: BD[e] = H_pl[e] (H_ll + lambda I)^-1 with the landmark's H_ll summed again in the same order (no wait for
-//                         the landmark workgroups)
-// Two hand-overs inside the launch, both from workgroups of LOWER index (dispatched earlier) to workgroups that have already done what others
-// wait for -- so nobody waits for a workgroup that cannot start: (1) need_begin: everyone behind the edge pass waits for begin_done; (2) first
-// iteration of a round: lambda comes from computeLambdaInit, i.e. from the last of the pose + landmark workgroups (lambda_ready); landmark
-// workgroups arrive there BEFORE they wait. The waits are bounded (kFrontSpin polls): on expiry the problem is marked (ctl.fault) and the call
-// fails instead of hanging the queue. The host only picks this launch for problems whose landmark workgroups are all resident at once.
-constexpr int kFrontThreads = 512;                      // 8 waves: 256 VGPRs per thread (begin_body needs 134; 1024 threads = 128 = spills)
-constexpr int kFrontVB = kFrontThreads / 256;
-constexpr int kFrontSpin = 1 << 22;
-constexpr int kFrontMaxPoints = 128 * kFrontThreads;    // 128 landmark workgroups of one problem: resident together on any part of the chip the solver may be confined to
-__device__ __forceinline__ bool front_wait(const int* flag, BaCtl& ctl, int& s_flag)      // whole workgroup; true = the word was seen
-{
-    if (threadIdx.x == 0) {
-        int ok = 0;
-        for (int i = 0; i < kFrontSpin; ++i) {
-            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (!ok) __hip_atomic_store(&ctl.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_flag = ok;
-    }
-    // The acquire belongs to the thread that saw the word; on gfx950 it invalidates the CU's vector L1 and the stale lines of the XCD's L2, which is
-    // what every wave of this workgroup reads through -- one invalidation per workgroup, not one per wave (with eight per workgroup the step of a
-    // round change took 93 us, with one 57)
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    return s_flag != 0;
-}
-
-__global__ __launch_bounds__(kFrontThreads) void k_front(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, int B, int* __restrict__ h_progress,
-                                                         unsigned* __restrict__ grid_ticket)
-{
-    __shared__ double s[kPoseChunks * 27 + 27 > kFrontThreads ? kPoseChunks * 27 + 27 : kFrontThreads];   // begin_body's sums | the pose workgroup's part[37][27] + s[27]
-    __shared__ DCams cams;
-    __shared__ int s_cnt, s_flag;
-    __shared__ bool last;
-    __shared__ double s_md[kFrontThreads / 64];
-    const BaProb& pb = probs[blockIdx.y];
-    BaCtl& ctl = ctls[blockIdx.y];
-    const int t = threadIdx.x, L = pb.L, np = pb.np;
-    const int nwg_b = (pb.nblk + kFrontVB - 1) / kFrontVB, nb_l = (L + kFrontThreads - 1) / kFrontThreads, nwg_e = np ? nwg_b : 0;
-    int bx = blockIdx.x;
-    if (bx >= nwg_b + np + nb_l + nwg_e) return;
-    if (ctl.state == ST_DONE) return;                        // (only begin_body ends a problem: a later look at the word can only see it MORE advanced)
-    const int need_begin = ctl.need_begin;                   // written by the previous step (or k_ctl_init): the same in every workgroup
-    if (bx < nwg_b) {
-        if (need_begin) begin_body<kFrontVB>(pb, ctl, bx, s, cams, s_cnt, last, h_progress, grid_ticket, true);
-        return;
-    }
-    bx -= nwg_b;
-    if (need_begin && !front_wait(&ctl.begin_done, ctl, s_flag)) return;
-    const int state = __hip_atomic_load(&ctl.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // final now: begin_body's last workgroup may have rewritten the word
-    if (state > ST_RETRY) return;
-    const int cur = ctl.cur;
-    // (the first iteration of a round always follows the edge pass, in this launch or -- step 1 -- in k_begin: computeLambdaInit then finds the landmark maxima here)
-    const bool new_iter = state == ST_NEW_ITER, first = new_iter && need_begin && __hip_atomic_load(&ctl.it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-    if (bx < np) {                                           // ---- one free pose (k_reduce_pose)
-        if (!new_iter) return;
-        double (*part)[27] = reinterpret_cast<double (*)[27]>(s);
-        double* const s27 = s + kPoseChunks * 27;
-        const int32_t* __restrict__ ps_off = pb.ps_off;
-        const int32_t* __restrict__ ps_edges = pb.ps_edges;
-        const double* __restrict__ cpose = pb.cpose[cur];
-        const int i = bx;
-        // k_reduce_pose's 37 chunk sums with 18 thread rows: row q keeps the chunks q, q + 18 and (row 0) 36 in accumulators of their own and walks them
-        // together -- the same sums in the same order, as many loads in flight per thread
-        constexpr int kRows = kFrontThreads / 27;
-        static_assert(kRows * 3 >= kPoseChunks && kRows * 2 < kPoseChunks + kRows, "three chunks per thread row cover the 37");
-        const int c = t % 27, q = t / 27;
-        if (q < kRows) {
-            double a0 = 0, a1 = 0, a2 = 0;
-            const int k1 = ps_off[i + 1];
-            const bool has1 = q + kRows < kPoseChunks, has2 = q + 2 * kRows < kPoseChunks;
-            // The walk is a chain of dependent loads (list entry -> block), so eight entries of each chunk are in flight at once: all their indices first,
-            // then all their blocks; the additions stay in list order
-            constexpr int kU = 8;
-            for (int kb = ps_off[i] + q; kb < k1; kb += kU * kPoseChunks) {
-                int e0[kU], e1[kU], e2[kU];
-#pragma unroll
-                for (int j = 0; j < kU; ++j) {
-                    const int k = kb + j * kPoseChunks;
-                    e0[j] = k < k1 ? ps_edges[k] : -1;
-                    e1[j] = (has1 && k + kRows < k1) ? ps_edges[k + kRows] : -1;
-                    e2[j] = (has2 && k + 2 * kRows < k1) ? ps_edges[k + 2 * kRows] : -1;
-                }
-                double v0[kU], v1[kU], v2[kU];
-#pragma unroll
-                for (int j = 0; j < kU; ++j) {
-                    v0[j] = e0[j] >= 0 ? cpose[(size_t)e0[j] * 27 + c] : 0.0;
-                    v1[j] = e1[j] >= 0 ? cpose[(size_t)e1[j] * 27 + c] : 0.0;
-                    v2[j] = e2[j] >= 0 ? cpose[(size_t)e2[j] * 27 + c] : 0.0;
-                }
-#pragma unroll
-                for (int j = 0; j < kU; ++j) {
-                    if (e0[j] >= 0) a0 += v0[j];
-                    if (e1[j] >= 0) a1 += v1[j];
-                    if (e2[j] >= 0) a2 += v2[j];
-                }
-            }
-            part[q][c] = a0;
-            if (has1) part[q + kRows][c] = a1;
-            if (has2) part[q + 2 * kRows][c] = a2;
-        }
-        __syncthreads();
-        if (t < 27) { double a = 0; for (int q2 = 0; q2 < kPoseChunks; ++q2) a += part[q2][t]; s27[t] = a; }
-        __syncthreads();
-        if (t < 36) {
-            const int r = t / 6, qq = t % 6, lo = min(r, qq), hi = max(r, qq);
-            pb.Hpp[(size_t)i * 36 + t] = s27[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
-        }
-        if (t < 6) pb.bp[i * 6 + t] = s27[21 + t];
-        if (t < 64 && first) {
-            const double md = fmax(fmax(fmax(fabs(s27[0]), fabs(s27[6])), fmax(fabs(s27[11]), fabs(s27[15]))), fmax(fabs(s27[18]), fabs(s27[20])));
-            reduce_finish(pb, ctl, md, bx, np + nb_l, true);
-        }
-        return;
-    }
-    bx -= np;
-    const double* __restrict__ cpoint = pb.cpoint[cur];
-    if (bx < nb_l) {                                         // ---- 1024 landmarks: thread per landmark
-        const int l = bx * kFrontThreads + t;
-        double H[9];
-        bool on = false;
-        if (new_iter && need_begin) {                        // the edge pass of this launch produced the terms; after an accepted trial k_update_error<true> left the sums
-            double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            int n_act = 0;
-            for (int k = l < L ? pb.pt_off[l] : 0, k1 = l < L ? pb.pt_off[l + 1] : 0; k < k1; ++k) {
-                const int e = pb.pt_edges[k];
-                n_act += pb.active[e];
-                const double* c = cpoint + (size_t)e * 9;
-                for (int i = 0; i < 9; ++i) a[i] += c[i];
-            }
-            double md = 0.0;
-            if (l < L) {
-                on = n_act > 0;
-                pb.pt_active[cur][l] = on;                   // a landmark without active edges is not part of this round
-                H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
-                double* Hg = pb.Hll[cur] + (size_t)l * 9;
-                for (int i = 0; i < 9; ++i) Hg[i] = H[i];
-                pb.bl[cur][3 * l] = a[6]; pb.bl[cur][3 * l + 1] = a[7]; pb.bl[cur][3 * l + 2] = a[8];
-                if (on) md = fmax(fmax(fabs(a[0]), fabs(a[3])), fabs(a[5]));
-            }
-            if (first) {                                     // workgroup-uniform
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) md = fmax(md, __shfl_xor(md, d));
-                if ((t & 63) == 0) s_md[t >> 6] = md;
-                __syncthreads();
-                if (t < 64) {
-                    double m = t < kFrontThreads / 64 ? s_md[t] : 0.0;
-#pragma unroll
-                    for (int d = 8; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d));
-                    m = __shfl(m, 0);
-                    reduce_finish(pb, ctl, m, np + bx, np + nb_l, true);
-                }
-            }
-        } else if (l < L) {
-            on = pb.pt_active[cur][l];
-            if (on) for (int i = 0; i < 9; ++i) H[i] = pb.Hll[cur][(size_t)l * 9 + i];
-        }
-        if (first && !front_wait(&ctl.lambda_ready, ctl, s_flag)) return;
-        const double lambda = 1e-5 * __hip_atomic_load(&ctl.maxdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * __hip_atomic_load(&ctl.mult, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // computeLambdaInit (tau = 1e-5) x the LM multiplier
-        if (l == 0) ctl.ok = 1.0;                            // reset the "factorisation succeeded" flag of this trial
-        if (l >= L || !on) return;
-        double D[9];
-        H[0] += lambda; H[4] += lambda; H[8] += lambda;
-        inv3(H, D);
-        const double* bl = pb.bl[cur];
-        for (int i = 0; i < 9; ++i) pb.Dinv[(size_t)l * 9 + i] = D[i];
-        for (int i = 0; i < 3; ++i) pb.db[3 * l + i] = D[i * 3] * bl[3 * l] + D[i * 3 + 1] * bl[3 * l + 1] + D[i * 3 + 2] * bl[3 * l + 2];
-        return;
-    }
-    bx -= nb_l;
-    {                                                        // ---- 1024 edges: BD[e] = Hpl[e] (Hll + lambda I)^-1
-        const int e = bx * kFrontThreads + t;
-        const bool mine = e < pb.E && pb.pose_idx[pb.epose[e]] >= 0;
-        const bool act = mine && pb.active[e];
-        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (act) {
-            const int l = pb.epoint[e];
-            if (new_iter && need_begin) {
-                double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                for (int k = pb.pt_off[l], k1 = pb.pt_off[l + 1]; k < k1; ++k) {
-                    const double* c = cpoint + (size_t)pb.pt_edges[k] * 9;
-                    for (int i = 0; i < 9; ++i) a[i] += c[i];
-                }
-                H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
-            } else {
-                for (int i = 0; i < 9; ++i) H[i] = pb.Hll[cur][(size_t)l * 9 + i];
-            }
-        }
-        if (first && !front_wait(&ctl.lambda_ready, ctl, s_flag)) return;
-        if (!mine) return;
-        double* o = pb.BD + (size_t)e * 18;
-        if (!act) {                                          // level-1 edge: still named by the pair lists, contributes zero
-            for (int i = 0; i < 18; ++i) o[i] = 0.0;
-            return;
-        }
-        const double lambda = 1e-5 * __hip_atomic_load(&ctl.maxdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * __hip_atomic_load(&ctl.mult, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double D[9];
-        H[0] += lambda; H[4] += lambda; H[8] += lambda;
-        inv3(H, D);
-        const double* Bm = pb.Hpl[cur] + (size_t)e * 18;
-        for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = Bm[r * 3] * D[c] + Bm[r * 3 + 1] * D[3 + c] + Bm[r * 3 + 2] * D[6 + c];
-    }
 }
 
 // Storage of the reduced camera system for k_ldlt_mfma (use_reg == 1): the lower triangle as 16x16 TILES in the order and the register
@@ -1881,26 +1641,16 @@ __global__ __launch_bounds__(64) void k_solve_update(const BaProb* __restrict__ 
 constexpr int kFusedMaxPoses = 512;
 constexpr int kFusedThreads = 320;                       // waves 0-3: four lanes per landmark, wave 4: the poses
 // two sums at once over a workgroup of kFusedThreads threads (fixed tree; the totals come back in thread 0)
-template <bool WIDE>      // WIDE: called by kSpecThreads threads, of which the first kFusedThreads carry values (the same tree, the same bits)
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* s /*[512]*/, double* s2 /*[512]*/)
 {
     const int t = threadIdx.x;
-    if (!WIDE || t < kFusedThreads) { s[t] = a; s2[t] = b; }
+    s[t] = a; s2[t] = b;
     if (t < 512 - kFusedThreads) { s[kFusedThreads + t] = 0; s2[kFusedThreads + t] = 0; }
     __syncthreads();
     for (int d = 256; d >= 1; d >>= 1) { if (t < d) { s[t] += s[t + d]; s2[t] += s2[t + d]; } __syncthreads(); }
     a = s[0]; b = s2[0];
 }
-// SPEC (the step of k_front): the workgroup also LINEARISES the trial estimates -- H_pl and the pose terms of every edge go to the other half of the
-// double-buffered blocks, the landmark terms stay in LDS and are summed per landmark right here (H_ll, b_l, pt_active of the other half, in
-// k_reduce_pose's order) -- so that the step after an accepted trial starts without an edge pass. 640 threads: one edge per thread for the usual
-// ~640 entries of 64 landmarks; each entry's chi2 goes through LDS so that thread t < 320 still adds the entries t, t + 320, ... in this order (the
-// same bits as the 320-thread kernel). Dynamic LDS: 81 bytes per entry of the largest 64-landmark run (the host sizes it and keeps groups with
-// longer runs on the six-launch step).
-constexpr int kSpecThreads = 640;
-constexpr int kSpecMaxEntries = 1280;
-template <bool SPEC>
-__global__ __launch_bounds__(SPEC ? kSpecThreads : kFusedThreads) void k_update_error(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, const volatile int* __restrict__ stop_words, int B,
+__global__ __launch_bounds__(kFusedThreads) void k_update_error(const BaProb* __restrict__ probs, BaCtl* __restrict__ ctls, const volatile int* __restrict__ stop_words, int B,
                                                       int* __restrict__ h_progress, unsigned* __restrict__ grid_ticket)
 {
     __shared__ double s[512], s2[512];
@@ -1908,7 +1658,6 @@ __global__ __launch_bounds__(SPEC ? kSpecThreads : kFusedThreads) void k_update_
     __shared__ double s_pose[kFusedMaxPoses * 7];
     __shared__ double s_pt[64 * 3];
     __shared__ bool last;
-    extern __shared__ double s_dyn[];                        // SPEC: [cap][9] landmark terms, [cap] chi2 terms, [cap] active bytes
     const BaProb& pb = probs[blockIdx.y];
     BaCtl& ctl = ctls[blockIdx.y];
     if (ctl.state > ST_RETRY) return;
@@ -1993,68 +1742,21 @@ __global__ __launch_bounds__(SPEC ? kSpecThreads : kFusedThreads) void k_update_
         const int l0 = blockIdx.x * 64, l1 = min(l0 + 64, L);
         const int k0 = pb.pt_off[l0], k1 = pb.pt_off[l1];
         const int32_t* __restrict__ pt_edges = pb.pt_edges;
-        if (!SPEC) {
-            for (int k = k0 + t; k < k1; k += kFusedThreads) {
-                const int e = pt_edges[k];
-                if (!pb.active[e]) continue;
-                double pc[3];
-                const DCam& c = cams.c[pb.ecam[e]];
-                cam_point(s_pose + 7 * pb.epose[e], s_pt + 3 * (pb.epoint[e] - l0), c, pc);
-                const double e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
-                const double e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
-                const double w = pb.w[e];
-                const double x2 = e0 * (w * e0) + e1 * (w * e1);
-                pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
-                rho0 += (robust && x2 > delta * delta) ? 2 * sqrt(x2) * delta - delta * delta : x2;
-            }
-        } else {
-            const int cap = k1 - k0;                             // (<= the launch's dynamic LDS: the host checked every run of the group)
-            double* const s_cp = s_dyn;
-            double* const s_rho = s_dyn + (size_t)9 * pb.spec_cap;
-            uint8_t* const s_act = reinterpret_cast<uint8_t*>(s_rho + pb.spec_cap);
-            for (int k = k0 + t; k < k1; k += kSpecThreads) {
-                const int e = pt_edges[k];
-                const bool act = pb.active[e] != 0;
-                double pc[3];
-                const int ps = pb.epose[e];
-                const DCam& c = cams.c[pb.ecam[e]];
-                cam_point(s_pose + 7 * ps, s_pt + 3 * (pb.epoint[e] - l0), c, pc);
-                double e0 = 0, e1 = 0, x2 = 0, rho = 0;
-                if (act) {
-                    e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
-                    e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
-                    const double w = pb.w[e];
-                    x2 = e0 * (w * e0) + e1 * (w * e1);
-                    pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
-                    rho = (robust && x2 > delta * delta) ? 2 * sqrt(x2) * delta - delta * delta : x2;
-                }
-                s_rho[k - k0] = rho; s_act[k - k0] = act;
-                // the accepted trial's estimates are the next iteration's linearisation point: the blocks go to the half that belongs to them
-                linearize_edge(pb, cur ^ 1, e, act, pose_idx[ps] >= 0, c, s_pose + 7 * ps, pc, e0, e1, x2, robust, delta, s_cp + (size_t)9 * (k - k0));
-            }
-            __syncthreads();
-            if (t < kFusedThreads) {                             // the chi2 terms in the 320-thread kernel's order (an inactive edge adds +0.0: no change)
-                for (int j = t; j < cap; j += kFusedThreads) rho0 += s_rho[j];
-            } else if (t < kFusedThreads + 64) {                 // wave 5: H_ll / b_l / pt_active of the other half, thread per landmark, CSR order (k_reduce_pose's sums)
-                const int l = l0 + (t - kFusedThreads);
-                if (l < L) {
-                    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    int n_act = 0;
-                    for (int k = pb.pt_off[l], kk1 = pb.pt_off[l + 1]; k < kk1; ++k) {
-                        n_act += s_act[k - k0];
-                        const double* c9 = s_cp + (size_t)9 * (k - k0);
-                        for (int i = 0; i < 9; ++i) a[i] += c9[i];
-                    }
-                    pb.pt_active[cur ^ 1][l] = n_act > 0;
-                    double* H = pb.Hll[cur ^ 1] + (size_t)l * 9;
-                    H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[3] = a[1]; H[4] = a[3]; H[5] = a[4]; H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
-                    double* bo = pb.bl[cur ^ 1];
-                    bo[3 * l] = a[6]; bo[3 * l + 1] = a[7]; bo[3 * l + 2] = a[8];
-                }
-            }
+        for (int k = k0 + t; k < k1; k += kFusedThreads) {
+            const int e = pt_edges[k];
+            if (!pb.active[e]) continue;
+            double pc[3];
+            const DCam& c = cams.c[pb.ecam[e]];
+            cam_point(s_pose + 7 * pb.epose[e], s_pt + 3 * (pb.epoint[e] - l0), c, pc);
+            const double e0 = pb.obs[2 * e] - (pc[0] / pc[2] * c.fx + c.cx);
+            const double e1 = pb.obs[2 * e + 1] - (pc[1] / pc[2] * c.fy + c.cy);
+            const double w = pb.w[e];
+            const double x2 = e0 * (w * e0) + e1 * (w * e1);
+            pb.err[2 * e] = e0; pb.err[2 * e + 1] = e1; pb.chi2[e] = x2;
+            rho0 += (robust && x2 > delta * delta) ? 2 * sqrt(x2) * delta - delta * delta : x2;
         }
     }
-    block_sum2<SPEC>(rho0, sc, s, s2);                       // thread 0: chi2 and computeScale partials of this workgroup
+    block_sum2(rho0, sc, s, s2);                       // thread 0: chi2 and computeScale partials of this workgroup
     // ---- (d)
     if (t == 0) {
         pb.scale_part[blockIdx.x] = sc;
@@ -2073,7 +1775,7 @@ __global__ __launch_bounds__(SPEC ? kSpecThreads : kFusedThreads) void k_update_
         for (int i = t; i < nb_pts; i += kFusedThreads) tot += __hip_atomic_load(&pb.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = t; i <= nb_pts; i += kFusedThreads) sc_tot += __hip_atomic_load(&pb.scale_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    block_sum2<SPEC>(tot, sc_tot, s, s2);
+    block_sum2(tot, sc_tot, s, s2);
     if (t != 0) return;
     __hip_atomic_store(pb.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lm_accept(pb, ctl, stop_words, tot, sc_tot);
@@ -2087,7 +1789,6 @@ __global__ __launch_bounds__(1024) void k_ctl_init(const BaProb* __restrict__ pr
         c.state = probs[b].iters[0] > 0 ? ST_NEW_ITER : ST_ROUND_END;
         c.robust = probs[b].robust0;
         c.mult = 1.0; c.ni = 2; c.ok = 1.0;
-        c.need_begin = 1;                                    // the first step: errors of the initial estimates (or the flags straight away)
         ctls[b] = c;
     }
 }
@@ -3504,29 +3205,6 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     int g_begin[BaContext::kMaxGroups + 1];
     for (int g = 0; g <= G; ++g) g_begin[g] = (int)((long long)NB * g / G);
     unsigned* d_grid_ticket[BaContext::kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
-    // The four-launch step (k_front, k_schur, LDL^T, k_update_error<true>) per GROUP: every problem of the group must fit the fused trial kernel
-    // (poses in LDS) and have few enough landmark workgroups that all of them are resident at once (k_front's lambda hand-over).
-    const bool front_opt = opt(OPT_BA_FRONT) != 0 && opt(OPT_BA_FUSED_UPDATE) != 0 && !tl_tap;
-    if (front_opt) {
-        static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_error<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kSpecMaxEntries * 81 + 16);
-        if (attr_rc != hipSuccess) { set_error("hipFuncSetAttribute(k_update_error<true>): %s", hipGetErrorString(attr_rc)); return DCS_ERR_HIP; }
-    }
-    bool group_front[BaContext::kMaxGroups]; int group_cap[BaContext::kMaxGroups];
-    std::vector<char> front_of((size_t)NB, 0);
-    std::vector<int> cap_of((size_t)NB, 1);
-    for (int g = 0; g < G; ++g) {
-        bool f = front_opt;
-        int cap = 0;
-        for (int i = g_begin[g]; i < g_begin[g + 1]; ++i) {
-            const dcs_ba_problem* pb = problems[live[i]];
-            if (pb->n_poses > kFusedMaxPoses || pb->n_points > kFrontMaxPoints) f = false;
-            const std::vector<int32_t>& off = rounds[i].pt_off;                   // the longest run of 64 landmarks' entries: one workgroup of k_update_error<true> keeps it in LDS
-            for (int l0 = 0; l0 < pb->n_points; l0 += 64) cap = std::max(cap, off[(size_t)std::min(l0 + 64, pb->n_points)] - off[(size_t)l0]);
-        }
-        if (cap > kSpecMaxEntries) f = false;
-        group_front[g] = f; group_cap[g] = std::max(cap, 1);
-        for (int i = g_begin[g]; i < g_begin[g + 1]; ++i) { front_of[(size_t)i] = f; cap_of[(size_t)i] = group_cap[g]; }
-    }
     auto layout = [&](Carver& c, Regions& rg) {
         for (int i = 0; i < NB; ++i) {
             const dcs_ba_problem* pb = problems[live[i]];
@@ -3544,7 +3222,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.pose_idx = c.get<int32_t>(P); q.pt_off = c.get<int32_t>(L + 1); q.pt_edges = c.get<int32_t>(r.pt_edges.size()); q.pt_pi = c.get<int32_t>(r.pt_pi.size());
             q.ps_off = c.get<int32_t>(r.ps_off.size()); q.ps_edges = c.get<int32_t>(r.ps_edges.size());
             q.pair_ij = c.get<int32_t>(r.pair_ij.size());
-            q.pt_words = (int)(((L + 31) / 32 + 3) & ~(size_t)3); q.spec_cap = cap_of[(size_t)i];      // rows are read 16 bytes at a time
+            q.pt_words = (int)(((L + 31) / 32 + 3) & ~(size_t)3);      // rows are read 16 bytes at a time
             q.cams = c.get<DCams>(1);
         }
         d_probs = c.get<BaProb>(NB);
@@ -3569,14 +3247,12 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.err = c.get<double>(2 * E);
             q.Hpl[0] = c.get<double>(18 * E); q.BD = c.get<double>(18 * E); q.cpose[0] = c.get<double>(27 * E); q.cpoint[0] = c.get<double>(9 * E);
             q.cpoint[1] = q.cpoint[0];                     // (only k_begin's edge pass writes them to memory, and its readers run in the same step)
-            if (front_of[i]) { q.Hpl[1] = c.get<double>(18 * E); q.cpose[1] = c.get<double>(27 * E); }
-            else { q.Hpl[1] = q.Hpl[0]; q.cpose[1] = q.cpose[0]; }
+            q.Hpl[1] = q.Hpl[0]; q.cpose[1] = q.cpose[0];          // (one linearisation at a time: [1] is [0]; the two indices are what is left of round 5's trial kernel that linearised ahead)
             q.Hll[0] = c.get<double>(9 * L); q.bl[0] = c.get<double>(3 * L); q.Dinv = c.get<double>(9 * L); q.db = c.get<double>(3 * L); q.xl = c.get<double>(3 * L);
             q.Hpp = c.get<double>(36 * P); q.bp = c.get<double>(6 * P); q.bsch = c.get<double>(6 * P); q.xp = c.get<double>(6 * P);
             q.partial = c.get<double>(std::max(q.nblk, q.nb_pts)); q.scale_part = c.get<double>(q.nb_pts + q.nb_pose); q.maxd_part = c.get<double>(q.np + q.nb_pts);
             q.pt_active[0] = c.get<uint8_t>(L);
-            if (front_of[i]) { q.Hll[1] = c.get<double>(9 * L); q.bl[1] = c.get<double>(3 * L); q.pt_active[1] = c.get<uint8_t>(L); }
-            else { q.Hll[1] = q.Hll[0]; q.bl[1] = q.bl[0]; q.pt_active[1] = q.pt_active[0]; }
+            q.Hll[1] = q.Hll[0]; q.bl[1] = q.bl[0]; q.pt_active[1] = q.pt_active[0];
             q.edge_of = c.get<int32_t>((size_t)q.np * L);
             q.pair_off = c.get<int32_t>((size_t)q.n_pairs + 1); q.pair_e = c.get<int32_t>(2 * rounds[i].n_pair_entries);
         }
@@ -3703,8 +3379,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     struct Group {
         hipStream_t st; const BaProb* dp; BaCtl* ctls; int nb, off; int* words; unsigned* ticket;
         int g_edges = 0, g_reduce = 0, g_prep = 0, g_schur = 0, g_update = 0, g_pts = 0, max_npad_blocked = 0;
-        bool any_mfma = false, any_blocked = false, finished = false, fused_update = true, front = false;
-        int g_front = 0, spec_cap = 1, g_schur_w = 0;
+        bool any_mfma = false, any_blocked = false, finished = false, fused_update = true;
+        int g_schur_w = 0;
         int max_n_mfma = 0;
     };
     const bool no_fused_update = opt(OPT_BA_FUSED_UPDATE) == 0;   // A/B: the two launches
@@ -3714,13 +3390,11 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         Group& gr = groups[g];
         gr.st = g == 0 ? st : ctx.aux[g - 1]; gr.off = g_begin[g]; gr.nb = g_begin[g + 1] - g_begin[g];
         gr.dp = d_probs + gr.off; gr.ctls = d_ctls + gr.off; gr.words = h_words + 2 * g; gr.ticket = d_grid_ticket[g];
-        gr.front = group_front[g]; gr.spec_cap = group_cap[g];
         for (int i = gr.off; i < gr.off + gr.nb; ++i) {
             const BaProb& q = hp[i];
             gr.g_edges = std::max(gr.g_edges, q.nblk);
             gr.g_reduce = std::max(gr.g_reduce, q.np + q.nb_pts);
             gr.g_prep = std::max(gr.g_prep, (q.np ? q.nblk : 0) + (q.L + 255) / 256);
-            gr.g_front = std::max(gr.g_front, (q.nblk + kFrontVB - 1) / kFrontVB * (q.np ? 2 : 1) + q.np + (q.L + kFrontThreads - 1) / kFrontThreads);
             if (q.np) { gr.g_schur = std::max(gr.g_schur, q.n_pairs + q.np); gr.g_schur_w = std::max(gr.g_schur_w, (q.n_pairs + kSchurWPairs - 1) / kSchurWPairs + q.np); }
             gr.g_update = std::max(gr.g_update, q.nb_pts + q.nb_pose);
             gr.g_pts = std::max(gr.g_pts, q.nb_pts);
@@ -3750,7 +3424,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     if (use_graph_env && !timing) {
         for (int g = 0; g < G; ++g) {
             const Group& gr = groups[g];
-            if (gr.any_blocked || gr.front) continue;             // (the four-launch step differs in its first step: plain launches)
+            if (gr.any_blocked) continue;
             const BaProb* dp = gr.dp; BaCtl* ctls = gr.ctls; const BaCtl* cctls = gr.ctls; int nb = gr.nb;
             const volatile int* d_stop = h_words + 16 + gr.off; int* words = gr.words; unsigned* ticket = gr.ticket;
             void* a_cc[] = {(void*)&dp, (void*)&cctls};                                   // (probs, const ctls)
@@ -3759,16 +3433,13 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             void* a_begin[] = {(void*)&dp, (void*)&ctls, (void*)&nb, (void*)&words, (void*)&ticket};
             struct Spec { void* fn; dim3 grid, block; void** args; };
             std::vector<Spec> spec;
-            if (gr.front) spec.push_back({(void*)k_front, dim3(gr.g_front, nb), dim3(kFrontThreads), a_begin});
-            else {
-                spec.push_back({(void*)k_begin, dim3(gr.g_edges, nb), dim3(256), a_begin});
-                spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
-                spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
-            }
+            spec.push_back({(void*)k_begin, dim3(gr.g_edges, nb), dim3(256), a_begin});
+            spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
+            spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
             if (gr.g_schur && schur_use_wave(nb)) spec.push_back({(void*)k_schur_w, dim3(gr.g_schur_w, nb), dim3(128 * kSchurWPairs), a_cc});
             else if (gr.g_schur) spec.push_back({(void*)k_schur<28>, dim3(gr.g_schur, nb), dim3(1024), a_cc});
             if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<kLdltSlotsSmall> : (void*)k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), a_c});
-            if (gr.fused_update) spec.push_back({(void*)k_update_error<false>, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
+            if (gr.fused_update) spec.push_back({(void*)k_update_error, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
             else {
                 spec.push_back({(void*)k_solve_update, dim3(gr.g_update, nb), dim3(64), a_cc});
                 spec.push_back({(void*)k_error<1>, dim3(gr.g_edges, nb), dim3(256), a_err});
@@ -3805,14 +3476,9 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             return DCS_OK;
         }
         mark(step, 0);
-        // (step 1 always starts with the edge pass -- the errors of the initial estimates -- and the host knows it: the three launches are cheaper
-        // than k_front's hand-overs inside one)
-        if (gr.front && step > 1) hipLaunchKernelGGL(k_front, dim3(gr.g_front, nb), dim3(kFrontThreads), 0, gs, dp, ctls, nb, gr.words, gr.ticket);   // the three below as one launch
-        else {
         hipLaunchKernelGGL(k_begin, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, nb, gr.words, gr.ticket);            // round change / stale errors, then buildSystem
         hipLaunchKernelGGL(k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), 0, gs, dp, ctls);                             // + computeLambdaInit (first iteration)
         hipLaunchKernelGGL(k_prep, dim3(gr.g_prep, nb), dim3(256), 0, gs, dp, ctls);                                      // setLambda + solve (Schur)
-        }
         DCS_CHECK_LAUNCH();
         if (gr.any_blocked) {                             // the blocked fallback factors S in place: rebuild it every trial
             for (int i = gr.off; i < gr.off + nb; ++i)
@@ -3837,8 +3503,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         DCS_CHECK_LAUNCH();
         mark(step, 2);
         if (gr.fused_update) {
-            if (gr.front) hipLaunchKernelGGL(k_update_error<true>, dim3(gr.g_pts, nb), dim3(kSpecThreads), (size_t)gr.spec_cap * 81 + 16, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);
-            else hipLaunchKernelGGL(k_update_error<false>, dim3(gr.g_pts, nb), dim3(kFusedThreads), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // back-substitution, oplus, chi2 of the trial + computeScale + accept / reject, progress
+            hipLaunchKernelGGL(k_update_error, dim3(gr.g_pts, nb), dim3(kFusedThreads), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // back-substitution, oplus, chi2 of the trial + computeScale + accept / reject, progress
         } else {
             hipLaunchKernelGGL(k_solve_update, dim3(gr.g_update, nb), dim3(64), 0, gs, dp, (const BaCtl*)ctls);
             hipLaunchKernelGGL(k_error<1>, dim3(gr.g_edges, nb), dim3(256), 0, gs, dp, ctls, d_stop, nb, gr.words, gr.ticket);   // chi2 of the trial + computeScale + accept / reject, progress
@@ -3924,7 +3589,6 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         const BaProb& q = hp[i];
         dcs_ba_result* res = results[live[i]];
         const BaCtl& c = h_ctls[i];
-        if (c.fault) { set_error("BA problem %d: a hand-over inside k_front timed out (workgroups of one launch did not run together)", live[i]); return DCS_ERR_HIP; }
         if (c.state != ST_DONE) { set_error("BA problem %d did not finish within %d steps", live[i], max_steps); return DCS_ERR_HIP; }
         memcpy(res->poses, landed(q.out_poses), sizeof(double) * 7 * q.P);
         memcpy(res->points, landed(q.out_points), sizeof(double) * 3 * q.L);

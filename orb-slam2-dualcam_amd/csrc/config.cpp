@@ -26,16 +26,23 @@ void seed_from_environment()
 {
     for (int i = 0; i < OPT_COUNT; ++i) {
         long long v = kDefs[i].def;
-        if (const char* e = getenv(kDefs[i].name)) {          // the library's only getenv
+        if (const char* e = getenv(kDefs[i].name)) {          // the library's only getenv (+ the legacy spellings below)
             char* end = nullptr;
-            const double d = strtod(e, &end);                 // "2.5e7" style values too; a variable that is set but not a number means "on"
-            v = end != e ? (long long)d : 1;
+            const double d = strtod(e, &end);                 // "2.5e7" style values too
+            if (end != e) v = (long long)d;
+            else if (*e) v = 1;                               // set, not a number ("on", "yes"): on. An EMPTY value leaves the default (atoi gave 0 before round 5, "on" in round 5: neither was meant)
         }
         g_val[i].store(v, std::memory_order_relaxed);
     }
     // two historical spellings: DCS_BA_CUS=first:count, DCS_FAST_HW_PROBE=fail
     if (const char* e = getenv("DCS_BA_CUS")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && b > 0) { g_val[OPT_BA_CU_FIRST] = a; g_val[OPT_BA_CU_COUNT] = b; } }
     if (const char* e = getenv("DCS_FAST_HW_PROBE")) if (strcmp(e, "fail") == 0) g_val[OPT_FAST_HW_PROBE_FAIL] = 1;
+    // switches of earlier rounds that no longer exist: the documented safety fallback keeps its meaning, the others are named once on stderr instead of
+    // being dropped silently
+    if (const char* e = getenv("DCS_FAST_D16Z")) if (*e && atoi(e) == 0) g_val[OPT_FAST_HW_PROBE_FAIL] = 1;     // "plain byte loads" = the probe-failed forms
+    static const char* const kGone[] = {"DCS_BA_LDLT_VALU", "DCS_BA_SCHUR_WIDE", "DCS_BA_SCHUR_MID", "DCS_BA_FRONT"};
+    for (const char* name : kGone)
+        if (getenv(name)) fprintf(stderr, "[dcs] %s is no longer an option of this library and is ignored (dcs_option_count / dcs_option_name list the current ones)\n", name);
 }
 
 }  // namespace

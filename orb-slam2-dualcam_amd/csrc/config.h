@@ -47,7 +47,6 @@ namespace dcs {
     X(BA_GROUPS,                   0)   /* > 0: stream groups of a batch */                                                              \
     X(BA_PAIRS_SIDE,               1)   /* 0: pose-pair lists built in front of the first step instead of beside it */                   \
     X(BA_FUSED_UPDATE,             1)   /* 0: k_solve_update + k_error<1> as two launches */                                             \
-    X(BA_FRONT,                    0)   /* 1: the four-launch LM step (k_front = k_begin + k_reduce_pose + k_prep, linearisation in the trial kernel): same bits, measured SLOWER (NOTES round 5) */ \
     X(BA_GRAPH,                    0)   /* 1: an LM step replayed as an executable graph */                                              \
     X(BA_LOOKAHEAD,                2)   /* LM steps enqueued ahead of the progress word */                                               \
     X(BA_DL_STREAM,                1)   /* 0: results come down on the solver's stream */                                                \

@@ -32,11 +32,9 @@ def _run(pkg, synth):
 
 def test_ba_opt_in_paths_equal_default(pkg, synth):
     base = _run(pkg, synth)
-    # DCS_BA_FRONT: the four-launch LM step (k_front with hand-overs inside one launch, the trial kernel linearising the estimates it evaluated, double-
-    # buffered blocks) is arithmetic-for-arithmetic the six-launch step: same bits, alone, with the graph switch (ignored by it) and in 4 groups
+    # (round 6: the four-launch step DCS_BA_FRONT -- k_front + the linearising trial kernel, bit-identical and slower -- was deleted with its option)
     for extra in ({"DCS_BA_GRAPH": 1}, {"DCS_BA_LOOKAHEAD": 1}, {"DCS_BA_DL_STREAM": 0}, {"DCS_BA_GROUPS": 1}, {"DCS_BA_GROUPS": 4}, {"DCS_BA_PAIRS_SIDE": 0},
-                  {"DCS_BA_SCHUR_WAVE": 0}, {"DCS_BA_SCHUR_WAVE": 2}, {"DCS_BA_SCHUR_WAVE": 2, "DCS_BA_GRAPH": 1},
-                  {"DCS_BA_FRONT": 1}, {"DCS_BA_FRONT": 1, "DCS_BA_GRAPH": 1}, {"DCS_BA_FRONT": 1, "DCS_BA_GROUPS": 4}, {"DCS_BA_FRONT": 1, "DCS_BA_LOOKAHEAD": 1}):
+                  {"DCS_BA_SCHUR_WAVE": 0}, {"DCS_BA_SCHUR_WAVE": 2}, {"DCS_BA_SCHUR_WAVE": 2, "DCS_BA_GRAPH": 1}):
         with pkg.abi.options(**extra):
             got = _run(pkg, synth)
         assert got["digest"] == base["digest"], extra
