@@ -56,7 +56,7 @@ int dcs_device_count(void);
  *   dcs_stream_create_cu_range  a stream restricted to the CUs [first_cu, first_cu + n_cus) of the mask order, for the caller's front-end
  *                               launches (the _device entry points run on the caller's stream)
  *   dcs_ba_set_cu_range         every solver stream created AFTER the call (new host threads, or after dcs_ba_release_thread) is
- *                               restricted to that range; n_cus = 0 removes the restriction. Environment: DCS_BA_CUS="first:count".
+ *                               restricted to that range; n_cus = 0 removes the restriction.
  *   dcs_ba_release_thread       frees the calling thread's solver context (arena, pinned words, streams); the next call rebuilds it
  *   dcs_host_alloc / _free      page-locked host memory for the caller's frame ring (the cv::Mat headers of src/Frame.cc:141-149 can wrap it:
  *                               cv::Mat(rows, cols, CV_8UC1, ptr, stride)). dcs_orb_extract_batch recognises images that lie in page-locked
@@ -184,7 +184,7 @@ int  dcs_orb_debug_emit_levels(const dcs_orb* h, int* levels);
 /* per-stage time of the last TIMED extraction in microseconds (hipEvents on the streams the kernels ran on):
    resize chain, k_fast_cells, scan+gather, k_blur, quadtree, k_describe, whole call (7 floats).
    Which extractions are timed: calls of MORE than two images under timing mode 1 / 2 (dcs_orb_set_timing). A call of one or two images
-   records no markers (they would cost 45 us of a 160-us dual-frame call) unless the process runs with DCS_ORB_TIMING=1, so after such a
+   records no markers (they would cost 45 us of a 160-us dual-frame call) so after such a
    call this function fails with DCS_ERR_INVALID "no timing available". A host-buffer call of >= 128 images runs as a pipeline of chunks,
    each chunk an extraction of its own: the figures describe the LAST CHUNK only. */
 int  dcs_orb_last_timing(dcs_orb* h, float* us7);

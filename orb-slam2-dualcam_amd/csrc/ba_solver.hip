@@ -2741,7 +2741,6 @@ static void ba_cu_range(int& first, int& count, bool set)
     if (set) { s_first = first; s_count = count; return; }
     if (s_count < 0) {
         s_first = 0; s_count = 0;
-        if (opt(OPT_BA_CU_COUNT) > 0) { s_first = (int)opt(OPT_BA_CU_FIRST); s_count = (int)opt(OPT_BA_CU_COUNT); }      // (DCS_BA_CUS=first:count in the environment)
     }
     first = s_first; count = s_count;
 }
@@ -2858,11 +2857,7 @@ struct BaContext {
         hipError_t e = hipSuccess;
         if (count > 0) e = create_cu_range_stream(s, first, count);      // config C5: the solver keeps its own compute units (dcs_ba_set_cu_range)
         else {
-            const int prio = (int)opt(OPT_BA_STREAM_PRIORITY);      // 1: highest, -1: lowest
-            int least = 0, greatest = 0;
-            if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-                e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio > 0 ? greatest : least);
-            else {
+            {
                 // first choice: a queue shared with nobody; when the process has too few (three besides the legacy default stream's), a queue
                 // shared with one of the context's OWN streams -- never the front end's: a download or a group's kernels queued behind an
                 // extraction that the Tracking thread enqueues steps ahead would wait for all of it

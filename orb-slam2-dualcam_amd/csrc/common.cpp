@@ -186,7 +186,7 @@ int streams_share_queue(hipStream_t a, hipStream_t b, bool* shared, bool* conclu
 // process has queues there is no such stream: the last candidate is returned and *apart (optional) reports 0.
 int create_stream_apart(hipStream_t* out, const hipStream_t* avoid, int n_avoid, bool* apart)
 {
-    const bool probing = opt(OPT_STREAM_PROBE) != 0;
+    const bool probing = true;
     std::vector<hipStream_t> rejected;
     hipStream_t s = nullptr;
     bool ok = false;
@@ -209,9 +209,6 @@ int create_stream_apart(hipStream_t* out, const hipStream_t* avoid, int n_avoid,
         }
         if (rc || undecided) break;
     }
-    const bool trace = opt(OPT_STREAM_TRACE) != 0;
-    if (trace) fprintf(stderr, "[create_stream_apart] %d streams to keep off, %zu candidates rejected, result %p %s\n", n_avoid, rejected.size(), (void*)s,
-                       rc ? "(error)" : ok ? "apart" : "SHARES a queue");
     for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
     if (rc) { if (s) (void)hipStreamDestroy(s); return rc; }
     *out = s;

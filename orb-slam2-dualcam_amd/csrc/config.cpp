@@ -35,12 +35,11 @@ void seed_from_environment()
         g_val[i].store(v, std::memory_order_relaxed);
     }
     // two historical spellings: DCS_BA_CUS=first:count, DCS_FAST_HW_PROBE=fail
-    if (const char* e = getenv("DCS_BA_CUS")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && b > 0) { g_val[OPT_BA_CU_FIRST] = a; g_val[OPT_BA_CU_COUNT] = b; } }
     if (const char* e = getenv("DCS_FAST_HW_PROBE")) if (strcmp(e, "fail") == 0) g_val[OPT_FAST_HW_PROBE_FAIL] = 1;
     // switches of earlier rounds that no longer exist: the documented safety fallback keeps its meaning, the others are named once on stderr instead of
     // being dropped silently
     if (const char* e = getenv("DCS_FAST_D16Z")) if (*e && atoi(e) == 0) g_val[OPT_FAST_HW_PROBE_FAIL] = 1;     // "plain byte loads" = the probe-failed forms
-    static const char* const kGone[] = {"DCS_BA_LDLT_VALU", "DCS_BA_SCHUR_WIDE", "DCS_BA_SCHUR_MID", "DCS_BA_FRONT"};
+    static const char* const kGone[] = {"DCS_BA_LDLT_VALU", "DCS_BA_SCHUR_WIDE", "DCS_BA_SCHUR_MID", "DCS_BA_FRONT", "DCS_BA_CUS" /* dcs_ba_set_cu_range */, "DCS_BA_STREAM_PRIORITY", "DCS_KNN2_VALU", "DCS_PROJ_SERIAL"};
     for (const char* name : kGone)
         if (getenv(name)) fprintf(stderr, "[dcs] %s is no longer an option of this library and is ignored (dcs_option_count / dcs_option_name list the current ones)\n", name);
 }

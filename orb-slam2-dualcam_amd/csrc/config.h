@@ -14,33 +14,19 @@ namespace dcs {
     X(ORB_FUSED_BLUR,             -1)   /* -1 auto (fused), 0 separate blur kernels + k_describe<false>, 1 k_describe<FUSED> */          \
     X(ORB_FAST_SPLIT,              0)   /* k > 0: FAST of levels [0, k) starts on a stream of its own next to the resize chain */        \
     X(ORB_EMIT,                   -1)   /* 0 resize chain; n > 0 cells of levels [0, n) emit the next level whatever the batch; -1 auto */ \
-    X(ORB_EMIT_MIN,         25000000)   /* level-0 pixels per call from which the emitting FAST is chosen (auto) */                      \
     X(ORB_NO_OVERLAP,              0)   /* 1: every extraction kernel alone on the main stream (profiling) */                            \
-    X(ORB_BLUR_LATE,               0)   /* 1: separate blur kernels start after FAST */                                                  \
-    X(ORB_FAST_GROUPS,             1)   /* 0: one k_fast_cells launch for all levels */                                                  \
     X(ORB_DENSE_CAP,               0)   /* > 0: candidates the handle's dense buffer holds (test hook: provokes the overflow path) */    \
     X(ORB_HOST_CHUNK,             -1)   /* images per chunk of the host-image pipeline; 0 one-shot; -1 auto */                           \
     X(ORB_HOST_DIRECT,             1)   /* 0: page-locked frames are packed like pageable ones */                                        \
-    X(ORB_HOST_NOPACK,             0)   /* measurement aid: skip the packing copies */                                                   \
     X(ORB_HOST_TRACE,              0)   /* 1: per-stage host times of dcs_orb_extract_batch on stderr */                                 \
     X(ORB_SMALL_GRAPH,            -1)   /* 0 / 1: one-or-two-image calls replayed as an executable graph; -1 auto (on) */                \
     X(ORB_STAGING_THREADS,         0)   /* > 0: packing threads of the host-image pipeline; 0 auto */                                    \
-    X(ORB_TIMING,                  0)   /* 1: stage markers on small calls too */                                                        \
-    X(ORB_COMPACT_SMALL,           1)   /* 0: small batches use the three compaction launches */                                         \
     X(FAST_HW_PROBE_FAIL,          0)   /* 1: new handles behave as if the start-up probe had failed (plain k_fast_cells forms) */       \
     X(FAST_EXACT,                  2)   /* bit 0: 40-byte LDS rows, bit 1: 44-byte rows */                                               \
-    X(FAST_STOP,                   0)   /* -DDCS_FAST_SECTIONS builds: end k_fast_cells after this section */                            \
     X(BLUR_FOLD,                  -1)   /* separate blur: 1 k_blur_fold, 0 k_blur + k_blur_edge_cols, -1 auto */                         \
-    X(DESC_LDS_PAD,                0)   /* measurement aid: extra LDS bytes per k_describe workgroup */                                  \
     X(OCTREE_FORCE_GENERAL,        0)   /* 1: the sort-based k_octree for every task (test hook) */                                      \
     X(KNN2_I8,                     0)   /* 1: the i8 matrix-core matcher instead of the FP4 one */                                       \
-    X(KNN2_LDS_PAD,                0)   /* measurement aid: extra LDS bytes per matcher workgroup */                                     \
-    X(KNN2_VALU,                   0)   /* 1: xor + popcount matcher (dcs_hamming_knn2) */                                               \
-    X(PROJ_SERIAL,                 0)   /* 1: the one-wave in-order resolver of the projection searches */                               \
     X(POSE_FAST,                   1)   /* 0: every frame to the round-4 k_pose_opt */                                                   \
-    X(BA_CU_FIRST,                 0)   /* with BA_CU_COUNT > 0: the solver's streams are confined to CUs [first, first + count) */      \
-    X(BA_CU_COUNT,                 0)                                                                                                    \
-    X(BA_STREAM_PRIORITY,          0)   /* 1 highest, -1 lowest */                                                                       \
     X(BA_SCHUR_WAVE,               1)   /* Schur launch: 1 = by group size (k_schur<28> for 1-2 problems, k_schur_w beyond), 0 / 2 = always the former / the latter */ \
     X(BA_TRACE,                    0)   /* 1: host time per phase of dcs_ba_local_batch on stderr */                                     \
     X(BA_FORCE_BLOCKED_LDLT,       0)   /* test hook: the n > 256 factorisation at small n */                                            \
@@ -50,8 +36,6 @@ namespace dcs {
     X(BA_GRAPH,                    0)   /* 1: an LM step replayed as an executable graph */                                              \
     X(BA_LOOKAHEAD,                2)   /* LM steps enqueued ahead of the progress word */                                               \
     X(BA_DL_STREAM,                1)   /* 0: results come down on the solver's stream */                                                \
-    X(STREAM_PROBE,                1)   /* 0: dcs_stream_create_apart takes the first stream it gets */                                  \
-    X(STREAM_TRACE,                0)
 
 enum Opt : int {
 #define DCS_OPT_ENUM(name, def) OPT_##name,

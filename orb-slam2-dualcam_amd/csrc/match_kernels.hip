@@ -139,18 +139,6 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
     knn2_tile(q, nq, t, nt, t_mask, blockIdx.x, best_idx, best_d, second_d);
 }
 
-// batch: grid (ceil(cap/64), n_pairs); feature slots as written by the extractor
-__global__ __launch_bounds__(256) void k_knn2_pairs(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_feat, int cap,
-                                                    const int32_t* __restrict__ pairs, int32_t* best_idx, int32_t* best_d, int32_t* second_d)
-{
-    const int p = blockIdx.y;
-    const int qs = pairs[2 * p], ts = pairs[2 * p + 1];
-    const int nq = min(n_feat[qs], cap), nt = min(n_feat[ts], cap);
-    if ((int)blockIdx.x * 128 >= nq) return;
-    knn2_tile(desc + (size_t)qs * cap * 32, nq, desc + (size_t)ts * cap * 32, nt, nullptr, blockIdx.x,
-              best_idx + (size_t)p * cap, best_d + (size_t)p * cap, second_d + (size_t)p * cap);
-}
-
 // ---- Hamming knn2 on the i8 matrix cores ------------------------------------------------------------------------------
 // popcount(q ^ t) = popcount(q) + popcount(t) - 2 <q, t> with the descriptors expanded to 256 bytes of 0 / 1: the inner
 // product is an i8 GEMM, 4 x v_mfma_i32_16x16x64_i8 per 16 x 16 block of distances, on a pipe the rest of the front end
@@ -515,9 +503,7 @@ static void launch_knn2_pairs_mfma(const uint8_t* desc, const int32_t* n_feat, i
                                    int32_t* best_d, int32_t* second_d, hipStream_t s)
 {
     const bool force_i8 = opt(OPT_KNN2_I8) != 0;
-    // DCS_KNN2_LDS_PAD: extra dynamic LDS per workgroup = fewer matcher workgroups per CU (measurement aid: the matcher runs underneath the
-    // next step's resize chain, whose waves then find fewer registers taken)
-    const int lds_pad = (int)opt(OPT_KNN2_LDS_PAD);
+    const int lds_pad = 0;
     if (cap <= kFp4MaxCap && !force_i8)
         hipLaunchKernelGGL(k_knn2_pairs_fp4, dim3((cap + kKnn4Q - 1) / kKnn4Q, n_pairs), dim3(64 * kKnnWaves), (size_t)lds_pad, s, desc, n_feat, cap, pairs, best_idx, best_d, second_d);
     else
@@ -1033,9 +1019,7 @@ int dcs_match_bf_batch_device(const uint8_t* d_desc, const dcs_keypoint* d_kp, c
     if (cap >= (1 << 22)) { set_error("cap %d exceeds the 2^22 descriptors of one knn2 problem (22-bit index field of the matrix-core key)", cap); return DCS_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     // d_match doubles as the best-index buffer: the filter reads best_idx[i] and writes match[i] in the same thread
-    const bool knn_valu = opt(OPT_KNN2_VALU) != 0;      // xor + popcount kernel instead of the i8 matrix-core one
-    if (knn_valu) hipLaunchKernelGGL(k_knn2_pairs, dim3((cap + 127) / 128, n_pairs), dim3(256), 0, s, d_desc, d_n, cap, d_pairs, d_match, d_best_d, d_second_d);
-    else launch_knn2_pairs_mfma(d_desc, d_n, cap, d_pairs, n_pairs, d_match, d_best_d, d_second_d, s);
+    launch_knn2_pairs_mfma(d_desc, d_n, cap, d_pairs, n_pairs, d_match, d_best_d, d_second_d, s);
     DCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter_pairs, dim3(n_pairs), dim3(256), 0, s, d_kp, d_n, cap, d_pairs, d_match, d_best_d, d_second_d, th,
                        ratio, check_ori, d_match, d_n_matches);

@@ -479,8 +479,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     ++n_calls;
     // Stage timing (dcs_orb_timing_totals) brackets every stage with hipEvents; each record is a marker packet between two kernels and
     // costs 5 - 10 us of queue latency -- 45 us of a 220-us dual-frame call. Calls of one or two images (a frame per call) skip them (DCS_ORB_TIMING=1 keeps them).
-    const bool timing_always = opt(OPT_ORB_TIMING) != 0;
-    const bool timed = timing_mode > 0 && (n_images > 2 || timing_always || no_overlap);
+    const bool timed = timing_mode > 0 && (n_images > 2 || no_overlap);
     const bool timed_all = timed && timing_mode >= 2;        // mode 1: only the two markers around FAST (the roofline kernel) are recorded
     es.all = timed_all; es.has_f = false; es.has_b = false;
 #define DCS_MARK(e, s) do { if (timed_all) DCS_HIP(hipEventRecord(e, s)); } while (0)
@@ -535,7 +534,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
     // the blur no longer competes for the vector ALUs (800 -> 619 us) and the fused describe costs 455 instead of 388 us.
     // DCS_ORB_FUSED_BLUR=0 (read when the handle is created) selects the separate blur kernels (the debug / A-B path).
     last_blur_valid = !fused_blur;
-    const bool blur_early = opt(OPT_ORB_BLUR_LATE) == 0;
+    const bool blur_early = true;                            // (separate blur kernels start beside FAST; the "late" placement of round 2 lost and its switch is gone)
     if (!fused_blur && !no_overlap && (rc = side_stream(s_aux, stream, s_fast))) return rc;
     hipStream_t sb = no_overlap ? stream : s_aux;
     auto blur_stage = [&]() -> int {
@@ -582,8 +581,7 @@ int dcs_orb::run(const uint8_t* d_level0, size_t level0_img_stride, int level0_p
         // measured 558 us), plus a fixed 1.3 rounds per launch. Headline pyramid: [0-3] 32, [4-6] 29, [7] 24 = 525 us.
         // Small batches are latency-bound -- one launch there: 16 images of 1280 x 720 (config C5's step) run at 89 k kfeatures/s with
         // one launch against 80 k with three.
-        const bool grouped_env = opt(OPT_ORB_FAST_GROUPS) != 0;
-        const bool grouped = grouped_env && n_images >= 64;
+        const bool grouped = n_images >= 64;
         auto wg_per_cu = [](const FastFootprint& f) { return std::min(32, 163840 / std::max(fast_cells_lds_bytes(f), 1)); };
         FastFootprint lfp[kMaxLevels];
         int start_of[kMaxLevels + 1];
@@ -771,7 +769,6 @@ int dcs_orb_create(const dcs_orb_params* p, dcs_orb** out)
     for (auto& es : h->ring) { for (auto& e : es.t) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.b) DCS_HIP(hipEventCreate(&e)); for (auto& e : es.f) DCS_HIP(hipEventCreate(&e)); }
     h->no_overlap = opt(OPT_ORB_NO_OVERLAP) != 0;
     h->fused_mode = opt(OPT_ORB_FUSED_BLUR) < 0 ? -1 : (opt(OPT_ORB_FUSED_BLUR) != 0);
-    h->emit_min_pixels = (double)opt(OPT_ORB_EMIT_MIN);
     h->opt_dense_cap = opt(OPT_ORB_DENSE_CAP);
     h->emit_mode = (int)opt(OPT_ORB_EMIT);
     {   // the probe runs once per device and process; DCS_FAST_HW_PROBE=fail (read per handle: tests) makes this handle take the fallback
@@ -926,7 +923,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
     if ((!direct && (rc = h->h_img.resize(img_bytes * n_images))) || (rc = h->d_stage.resize(img_bytes * n_images))) return rc;
     const uint8_t* const up_src = direct ? images[0] : h->h_img.p;
     auto up_bytes = [&](int i0, int m) { return img_bytes * (size_t)(m - 1) + (i0 + m == n_images ? last_img_bytes : img_bytes); };
-    const bool nopack = direct || opt(OPT_ORB_HOST_NOPACK) != 0;   // (the variable alone: measurement aid, the pinned staging keeps the previous call's images)
+    const bool nopack = direct;
     auto pack = [&](int i) {
         if (nopack) return;
         uint8_t* dst = h->h_img.p + i * img_bytes;
@@ -1072,8 +1069,7 @@ int dcs_orb_extract_batch(dcs_orb* h, const uint8_t* const* images, int n_images
         // they are replayed as one executable graph (captured from the very code below; any failure to capture switches the handle back to
         // plain launches). DCS_ORB_SMALL_GRAPH=0 / 1 forces it off / on.
         const int graph_env = (int)opt(OPT_ORB_SMALL_GRAPH);                 // read per call (tests switch it)
-        const bool timing_always = opt(OPT_ORB_TIMING) != 0;   // stage markers even on small calls: no graph (the events would become graph nodes)
-        const bool graph_ok = (graph_env < 0 ? kSmallGraphDefault : graph_env != 0) && n_images <= 2 && !h->no_overlap && !timing_always && !h->small_graph_broken;
+        const bool graph_ok = (graph_env < 0 ? kSmallGraphDefault : graph_env != 0) && n_images <= 2 && !h->no_overlap && !h->small_graph_broken;
         const dcs_orb::SmallGraphKey key{h->d_stage.p, h->d_out.p, h->h_out.p, img_bytes, total, n_images, rows, cols, pitch_s, cap, h->config_generation};
         bool replayed = false;
         if (graph_ok && h->small_graph_exec && key == h->small_graph_key) {

@@ -944,7 +944,12 @@ int launch_fast_cells(const LevelSet& levels, const CellDesc* d_cells, int n_cel
     const int map_bytes = ((fp.max_rh * P) + 15) & ~15;
     const int sc_bytes = (fp.sc_bytes + 15) & ~15;
     const size_t shmem = (size_t)fast_cells_lds_bytes(fp);
-    const int dbg_stop = (int)opt(OPT_FAST_STOP);      // only read by -DDCS_FAST_SECTIONS builds
+#ifdef DCS_FAST_SECTIONS
+    const char* stop_env = getenv("DCS_FAST_STOP");          // -DDCS_FAST_SECTIONS side builds only (scratch/fast_sections.sh): not an option of the library
+    const int dbg_stop = stop_env ? atoi(stop_env) : 0;
+#else
+    const int dbg_stop = 0;
+#endif
     FastEmit em = emit ? *emit : FastEmit{};
     em.n_cell_blocks = n_launch;
     const dim3 grid(8, n_launch + (emit ? em.n_frame_blocks : 0), (n_images + 7) / 8);
@@ -1125,7 +1130,7 @@ int launch_compact(const CellDesc* d_cells, const int32_t* d_level_cell_begin, i
                    int32_t* d_cell_off, int32_t* d_lvl_total, int32_t* d_lvl_off, dcs_candidate* d_dense,
                    size_t dense_cap, hipStream_t s)
 {
-    const bool small_on = opt(OPT_ORB_COMPACT_SMALL) != 0;
+    const bool small_on = true;
     const long long n_entries = (long long)n_images * n_cells;
     if (small_on && n_cells > 0 && n_entries <= kCompactSmallThreads * kCompactSmallRun && (n_entries + 1) * sizeof(int) <= 64 * 1024) {
         const int n_wg = (int)std::min<long long>(64, (n_entries + 127) / 128);
@@ -2027,7 +2032,7 @@ int launch_describe(const LevelSet& raw, const LevelSet& blurred, const Describe
                     uint8_t* d_desc, int cap, int32_t* d_n_out, hipStream_t s, const int32_t* d_dense_total, int dense_cap, bool fused)
 {
     const int gx = max_per_image > 0 ? (max_per_image + kDescKp - 1) / kDescKp : 1;
-    const size_t lds_pad = (size_t)std::max<long long>(opt(OPT_DESC_LDS_PAD), 0);      // measurement aid: extra LDS per workgroup = fewer of them per CU
+    const size_t lds_pad = 0;
     if (fused) hipLaunchKernelGGL(k_describe<true>, dim3(gx * n_images), dim3(64 * kDescWaves), lds_pad, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,
                                   d_desc, cap, d_n_out, n_images, gx, d_dense_total, dense_cap);
     else hipLaunchKernelGGL(k_describe<false>, dim3(gx * n_images), dim3(64 * kDescWaves), 0, s, raw, blurred, prm, d_sel, d_img_off, d_lvl_cnt, d_kp,

@@ -1028,8 +1028,7 @@ static int search_by_projection_impl(const dcs_proj_frame* fr, const dcs_proj_qu
         (rc = s.alloc(&d_qf, (size_t)N)) || (rc = s.alloc(&d_bin, (size_t)nq)) || (rc = s.alloc(&d_nm, 1)) || (rc = s.upload(&d_taken, fr->taken, (size_t)N))) return rc;
     hipLaunchKernelGGL(k_proj_collect, dim3((nq + 3) / 4), dim3(256), 0, s.st, f, q, d_cand, d_cn);
     DCS_CHECK_LAUNCH();
-    const bool serial = opt(OPT_PROJ_SERIAL) != 0;     // one-wave resolver (reference order, step by step)
-    if (N <= kResMaxN && !serial) {
+    if (N <= kResMaxN) {                               // (larger frames: the one-wave resolver, reference order step by step)
         uint8_t* d_state;
         if ((rc = s.alloc(&d_state, (size_t)nq))) return rc;
         hipLaunchKernelGGL(k_proj_resolve_par, dim3(1), dim3(kResT), 0, s.st, f, q, d_cand, d_cn, d_state, th_high, nn_ratio, check_orientation,
