@@ -265,6 +265,29 @@ def test_gpu_hamming_equals_reference_descriptor_distance(pkg):
     assert np.array_equal(np.diag(full), d) and np.array_equal(bd, full.min(1))
 
 
+def test_gpu_hamming_against_the_reference_library_live(pkg, oracle):
+    """The binary compiled from the reference's own statements (oracle/_ref/libref.so: ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:2015-2031,
+    and FORB::distance) travels to the GPU box with the snapshot: fresh random descriptors on every run, the matrix-core matcher's best distances
+    against the reference's distances themselves (no golden file in between). Skipped where the binary was not built."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libref.so is not on this machine")
+    import os
+    rng = np.random.default_rng(int.from_bytes(os.urandom(4), "little"))
+    a = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    b = a ^ (rng.integers(0, 256, (300, 32), dtype=np.uint8) & rng.integers(0, 256, (300, 32), dtype=np.uint8) & rng.integers(0, 256, (300, 32), dtype=np.uint8))
+    d_ref, d_forb = oracle.ref_distances(a, b)                      # d(a_i, b_i) by the reference's two loops
+    assert np.array_equal(d_ref, d_forb)
+    for i in range(0, len(a), 7):
+        bi, bd, sd = pkg.ORBmatcher.knn2(a[i:i + 1], b[i:i + 1])
+        assert int(bd[0]) == int(d_ref[i]) and int(bi[0]) == 0, i
+    # the full table: every entry of row i is a reference distance d(a_i, b_j) -- computed pair by pair through the library
+    bi, bd, sd = pkg.ORBmatcher.knn2(a, b)
+    for i in range(0, len(a), 29):
+        row = oracle.ref_distances(np.repeat(a[i:i + 1], len(b), 0), b)[0]
+        order = np.sort(row)
+        assert int(bd[i]) == int(order[0]) and int(sd[i]) == int(order[1]) and int(row[bi[i]]) == int(order[0]), i
+
+
 def _desc_buckets(desc, n_bits=6):
     """feature vector in which similar descriptors share a node (first descriptor bits), ascending node ids, ascending indices"""
     node = (desc[:, 0] >> (8 - n_bits)).astype(np.int64)
