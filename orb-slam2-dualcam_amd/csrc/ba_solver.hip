@@ -923,7 +923,8 @@ __global__ __launch_bounds__(128 * kSchurWPairs) void k_schur_w(const BaProb* __
 // List of the pair (i1 <= i2) = the points both poses observe, in POINT order, as (edge of i1, edge of i2): the AND of two bit rows.
 //   k_pairs_mark   thread per edge of a free pose: bit (pose, point), edge_of[pose][point]   (at most one edge per (pose, point):
 //                  build_round's duplicate test)
-//   k_pairs_scan   one workgroup per problem: popcount of every pair's AND, exclusive scan in pair order -> pair_off
+//   k_pairs_count  thread per pair: popcount of the pair's AND
+//   k_pairs_scan   one workgroup per problem: exclusive scan of the counts in pair order -> pair_off
 //   k_pairs_fill   one wave per pair: the set bits of the AND in ascending order -> pair_e
 __global__ __launch_bounds__(256) void k_pairs_mark(const BaProb* __restrict__ probs)
 {
@@ -937,24 +938,33 @@ __global__ __launch_bounds__(256) void k_pairs_mark(const BaProb* __restrict__ p
     pb.edge_of[(size_t)pi * pb.L + l] = e;
 }
 
+// entries of every pair's list = popcount of the AND of the two poses' point rows: thread per pair over the whole chip (round 6: k_pairs_scan counted them
+// itself, one workgroup reading 100 MB of rows at the global-BA shape -- 1.28 ms of a 7.6-ms solve), left in pair_off for the scan
+__global__ __launch_bounds__(256) void k_pairs_count(const BaProb* __restrict__ probs)
+{
+    const BaProb& pb = probs[blockIdx.y];
+    const int p = blockIdx.x * 256 + threadIdx.x, W = pb.pt_words;
+    if (p >= pb.n_pairs) return;
+    const uint4* a = reinterpret_cast<const uint4*>(pb.pt_bits + (size_t)pb.pair_ij[2 * p] * W);        // pt_words is a multiple of 4
+    const uint4* b = reinterpret_cast<const uint4*>(pb.pt_bits + (size_t)pb.pair_ij[2 * p + 1] * W);
+    int c = 0;
+#pragma unroll 4
+    for (int w = 0; w < W / 4; ++w) {
+        const uint4 x = a[w], y = b[w];
+        c += __popc(x.x & y.x) + __popc(x.y & y.y) + __popc(x.z & y.z) + __popc(x.w & y.w);
+    }
+    pb.pair_off[p] = c;
+}
+
 __global__ __launch_bounds__(1024) void k_pairs_scan(const BaProb* __restrict__ probs)
 {
     __shared__ int s_w[16];
     const BaProb& pb = probs[blockIdx.x];
-    const int n_pairs = pb.n_pairs, W = pb.pt_words, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n_pairs = pb.n_pairs, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int running = 0;
     for (int p0 = 0; p0 < n_pairs; p0 += 1024) {
         const int p = p0 + t;
-        int c = 0;
-        if (p < n_pairs) {
-            const uint4* a = reinterpret_cast<const uint4*>(pb.pt_bits + (size_t)pb.pair_ij[2 * p] * W);        // pt_words is a multiple of 4
-            const uint4* b = reinterpret_cast<const uint4*>(pb.pt_bits + (size_t)pb.pair_ij[2 * p + 1] * W);
-#pragma unroll 4
-            for (int w = 0; w < W / 4; ++w) {
-                const uint4 x = a[w], y = b[w];
-                c += __popc(x.x & y.x) + __popc(x.y & y.y) + __popc(x.z & y.z) + __popc(x.w & y.w);
-            }
-        }
+        const int c = p < n_pairs ? pb.pair_off[p] : 0;          // k_pairs_count's result, replaced by the exclusive sum
         int inc = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
@@ -2901,12 +2911,13 @@ struct Carver {
     }
 };
 
-// the Schur launch by group size: k_schur<28> (16 waves per pose pair: the shortest chains) for 1-2 problems, k_schur_w (2 waves per pair: a batch fits
-// the chip in one round) beyond; DCS_BA_SCHUR_WAVE = 0 / 2 forces one of them (same bits)
-static bool schur_use_wave(int nb)
+// the Schur launch by group size: k_schur<28> (16 waves per pose pair: the shortest chains) for 1-2 problems of C4 size, k_schur_w (2 waves per pair: a batch
+// fits the chip in one round) beyond; DCS_BA_SCHUR_WAVE = 0 / 2 forces one of them (same bits)
+static bool schur_use_wave(int nb, int pairs_per_problem)
 {
     const int m = (int)opt(OPT_BA_SCHUR_WAVE);
-    return m == 2 || (m == 1 && nb > 2);
+    // (round 6: also for ONE problem with many pose pairs -- 60 free poses = 1 830 pairs +3 %, the 200-KF map = 19 900 pairs +9 %)
+    return m == 2 || (m == 1 && (nb > 2 || (long long)nb * pairs_per_problem >= 1800));
 }
 
 // A few persistent host threads for the per-problem list building of a batch. One job at a time: a second caller (the header
@@ -3335,6 +3346,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
                 ps = ctx.dl; pairs_on_side = true;
             }
             hipLaunchKernelGGL(k_pairs_mark, dim3(max_nblk, NB), dim3(256), 0, ps, (const BaProb*)d_probs);
+            hipLaunchKernelGGL(k_pairs_count, dim3((max_pairs + 255) / 256, NB), dim3(256), 0, ps, (const BaProb*)d_probs);
             hipLaunchKernelGGL(k_pairs_scan, dim3(NB), dim3(1024), 0, ps, (const BaProb*)d_probs);
             hipLaunchKernelGGL(k_pairs_fill, dim3(max_pairs, NB), dim3(64), 0, ps, (const BaProb*)d_probs);
             if (pairs_on_side) DCS_HIP(hipEventRecord(ctx.ev_pairs, ps));
@@ -3431,7 +3443,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             spec.push_back({(void*)k_begin, dim3(gr.g_edges, nb), dim3(256), a_begin});
             spec.push_back({(void*)k_reduce_pose, dim3(gr.g_reduce, nb), dim3(1024), a_c});
             spec.push_back({(void*)k_prep, dim3(gr.g_prep, nb), dim3(256), a_c});
-            if (gr.g_schur && schur_use_wave(nb)) spec.push_back({(void*)k_schur_w, dim3(gr.g_schur_w, nb), dim3(128 * kSchurWPairs), a_cc});
+            if (gr.g_schur && schur_use_wave(nb, gr.g_schur)) spec.push_back({(void*)k_schur_w, dim3(gr.g_schur_w, nb), dim3(128 * kSchurWPairs), a_cc});
             else if (gr.g_schur) spec.push_back({(void*)k_schur<28>, dim3(gr.g_schur, nb), dim3(1024), a_cc});
             if (gr.any_mfma) spec.push_back({gr.max_n_mfma <= 240 ? (void*)k_ldlt_mfma<kLdltSlotsSmall> : (void*)k_ldlt_mfma<kLdltSlotsBig>, dim3(nb), dim3(kLdltThreads), a_c});
             if (gr.fused_update) spec.push_back({(void*)k_update_error, dim3(gr.g_pts, nb), dim3(kFusedThreads), a_err});
@@ -3482,7 +3494,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         }
         if (gr.g_schur) {
             if (step == 1 && pairs_on_side) DCS_HIP(hipStreamWaitEvent(gs, ctx.ev_pairs, 0));      // the pair lists (side stream)
-            if (schur_use_wave(nb)) hipLaunchKernelGGL(k_schur_w, dim3(gr.g_schur_w, nb), dim3(128 * kSchurWPairs), 0, gs, dp, (const BaCtl*)ctls);
+            if (schur_use_wave(nb, gr.g_schur)) hipLaunchKernelGGL(k_schur_w, dim3(gr.g_schur_w, nb), dim3(128 * kSchurWPairs), 0, gs, dp, (const BaCtl*)ctls);
             else hipLaunchKernelGGL(k_schur<28>, dim3(gr.g_schur, nb), dim3(1024), 0, gs, dp, (const BaCtl*)ctls);
         }
         mark(step, 1);
