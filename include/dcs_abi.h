@@ -570,6 +570,10 @@ int  dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_
              histogram per camera), then PoseOptimization over the new matches. The queries are the last frame's features that hold
              a good map point, in ascending feature order: pos = GetWorldPos, desc = MapPoint::GetDescriptor, q_cam = keypointToCam[i],
              q_octave / q_angle = the last frame's key point. mvpMapPoints of the current frame is empty in this stage (Tracking.cc:1396).
+             PRECONDITION: every query's map point has Observations() > 0 (true of the points Tracking keeps in the last frame outside
+             localisation-only mode): a matched feature is then taken for the queries that follow, as :1046-1048 skips it. For a point WITHOUT
+             observations the reference lets a later query overwrite the feature and counts the match twice (:1062); that is not reproduced.
+             A query with zs == 0 is treated as not visible (the reference continues with inf / NaN coordinates, which fail its bounds test too).
    Frame::UndistortKeyPoints (Frame.cc:410-441) runs on the device too: with K and dist given (the rig file's fx fy cx cy and k1 k2 p1 p2 k3;
    Dual-LenaCV.yaml has k1 = -0.37) every key point goes through cv::undistortPoints' arithmetic (dcs_undistort_points below) when the camera's
    k1 != 0, exactly the reference's test (:414); dist == NULL: the key points are taken as they are. Feature g of the outputs = the frame's compact index: camera c's features at [off_c, off_c + n_c) with

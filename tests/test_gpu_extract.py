@@ -74,6 +74,32 @@ def test_end_to_end_bit_exact(pkg, oracle, synth, w, h, n):
     e.close()
 
 
+@pytest.mark.parametrize("w,h", [(333, 245), (642, 479), (701, 350), (1277, 719)])
+def test_emitting_fast_equals_the_resize_chain_on_odd_sizes(pkg, opts, synth, w, h):
+    """The default large-batch path -- the FAST cells of level l write level l + 1 (k_fast_cells<EMIT>: buffer-resource stores, per-cell tap windows,
+    the frame no cell's ROI reaches as extra workgroups) -- is chosen automatically only from 2.5e7 level-0 pixels per call, which no test batch
+    reaches: here it is FORCED (DCS_ORB_EMIT = all levels) on image sizes that are not multiples of 4 / 30 and held against the resize chain
+    (DCS_ORB_EMIT = 0) of the same images: every pyramid level, key point and descriptor bit for bit. emit_levels() > 0 is asserted so that a
+    silent fallback to the chain cannot make the comparison vacuous."""
+    big = synth.frame_pair(1280, 720, 1, 5)
+    imgs = [np.ascontiguousarray(b[:h, :w]) for b in big]
+    opts("DCS_ORB_FUSED_BLUR", 1); opts("DCS_ORB_FAST_SPLIT", 0)
+    opts("DCS_ORB_EMIT", 15)
+    e1 = pkg.ORBextractor(800, 1.2, 8, 20, 7, max_images=2)
+    k1, d1 = e1.extract_batch(imgs, cap=1000)
+    assert e1.emit_levels() > 0, "the emitting FAST did not run"
+    lv1 = [[e1.level_image(i, l) for l in range(8)] for i in range(2)]
+    opts("DCS_ORB_EMIT", 0)
+    e0 = pkg.ORBextractor(800, 1.2, 8, 20, 7, max_images=2)
+    k0, d0 = e0.extract_batch(imgs, cap=1000)
+    assert e0.emit_levels() == 0
+    for i in range(2):
+        for l in range(8):
+            assert np.array_equal(lv1[i][l], e0.level_image(i, l)), ("level", i, l)
+        _same(k1[i], d1[i], k0[i], d0[i])
+    e1.close(); e0.close()
+
+
 @pytest.mark.parametrize("host_threads", [1, 4])
 def test_host_quadtree_mode_matches_too(pkg, oracle, synth, host_threads):
     """host_threads > 0 selects the host-side sort/scan quadtree (csrc/octree.cpp) instead of k_octree."""
