@@ -664,8 +664,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
             unsigned p0[4], p1[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+#ifdef DCS_EMIT_SKIP_H      // timing-only side build (WRONG pixels): the horizontal pass costs nothing -- an upper bound on what moving it to the matrix cores could save (NOTES R6.6)
+                const unsigned hA = (k & 1 ? a1 : a0) & 0x7fffu, hB = (k & 1 ? b1 : b0) & 0x7fffu;
+#else
                 const unsigned hA = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, __builtin_amdgcn_perm(a1, a0, sel[k])), __builtin_bit_cast(ushort2_t, wg[k]), 0u, false) >> 4;
                 const unsigned hB = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, __builtin_amdgcn_perm(b1, b0, sel[k])), __builtin_bit_cast(ushort2_t, wg[k]), 0u, false) >> 4;
+#endif
                 p0[k] = __umul24(wb0, hA) + 0x20000u;                              // the "+ 2" of the rounding rides on the first product's high half
                 p1[k] = __umul24(wb1, hB);
             }

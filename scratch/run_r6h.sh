@@ -1,6 +1,9 @@
-cd $GRAFT_REPO_ROOT
-O=gpurun_out/r6h; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_ba.py tests/test_gpu_ba_threads.py tests/test_gpu_ba_variants.py tests/test_gpu_match.py -q -m gpu 2>&1 | tail -5 > $O/tests.log
-python scratch/time_ba_large.py 5 2>/dev/null | grep "it/s" > $O/large.log
-python scratch/time_ba_batch.py 8 20 2>/dev/null | grep "B=1\|B=8" >> $O/large.log
-cat $O/tests.log $O/large.log
+cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+HEAD="--cpu-seconds 0 --no-ba --no-bow --no-c3 --no-c5 --no-host-api --no-two-lanes --steps 6 --warmup 2"
+for lib in lib scratch/ab/emit_skip_h; do
+  L=$R/orb-slam2-dualcam_amd/lib/libdcs_hip.so; [ $lib != lib ] && L=$R/$lib/libdcs_hip.so
+  rm -rf $R/gpurun_out/tr_x; echo "== alone, $lib"
+  DCS_LIB_PATH=$L DCS_ORB_NO_OVERLAP=1 DCS_ORB_EMIT=15 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tr_x -o t -- python $R/bench.py $HEAD --serial > /dev/null 2>&1
+  python $R/scratch/trace_by_grid.py $R/gpurun_out/tr_x k_fast_cells | head -2
+  rm -rf $R/gpurun_out/tr_x
+done
