@@ -801,7 +801,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(LevelSet L, const CellDesc* _
         // The list shrinks once more on the way: only the pixels that score >= th go on to the suppression (every entry of a round is read before
         // the round's survivors are written back, to positions that were read already).
         {
+#ifdef DCS_FAST_ONE_ROUND    // timing-only side build (WRONG candidates): at most one scoring round per cell -- more than any packing of survivor lists across cells could save (NOTES R6.6)
+            const int n_in = min(__builtin_amdgcn_readfirstlane(n_list), 64);
+#else
             const int n_in = __builtin_amdgcn_readfirstlane(n_list);
+#endif
             unsigned end3 = list_addr;
             for (int i0 = 0; i0 < n_in; i0 += 64) {              // wave-uniform
                 const int i = i0 + lane;
