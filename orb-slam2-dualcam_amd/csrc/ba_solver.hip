@@ -3185,6 +3185,11 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         // covisibility: fine for local BA (tens of poses) and the global BA sizes tested (10 x 70 000, 60 x 800), quadratic beyond. A problem
         // that would need more than 1 GB or 4 M workgroups per step is refused instead of growing silently.
         for (int i = 0; i < NB; ++i) {
+            // (the substitution of the n > 256 path keeps z in the 64 KB of dynamic LDS every launch may ask for: n <= 8 192 = 1 365 free poses)
+            if ((size_t)rounds[i].n_pad * sizeof(double) > 65536) {
+                set_error("problem %d: %d free poses (reduced camera system n = %d) exceed the 8 192 rows of this solver's substitution kernel", live[i], rounds[i].np, rounds[i].n);
+                return DCS_ERR_UNSUPPORTED;
+            }
             const size_t cells = (size_t)rounds[i].np * (size_t)std::max(problems[live[i]]->n_points, 1);
             if (cells * sizeof(int32_t) > ((size_t)1 << 30) || rounds[i].n_pairs > (4 << 20)) {
                 set_error("problem %d: %d free poses x %d points exceeds the pose-pair tables of this solver (edge_of %zu MB, %d pair workgroups)", live[i], rounds[i].np,
