@@ -2038,13 +2038,13 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
 
 
 // ------------------------------------------------------------------ k_pose_opt2 (round 6: rebuilt as a compact kernel)
-// The same procedure (Optimizer.cc:250-405, types_six_dof_expmap.cpp:200-255) for frames of up to kPoseFastMax edges, one workgroup of 512
-// threads per frame; k_pose_opt stays for larger frames. Round 5's version of this kernel compiled to 940 KB of code with 13 375 spilled SGPRs
+// The same procedure (Optimizer.cc:250-405, types_six_dof_expmap.cpp:200-255) for frames of up to kPoseFastMax edges, one workgroup of 256
+// threads (one wave per SIMD) per frame; k_pose_opt stays for larger frames. Round 5's version of this kernel compiled to 940 KB of code with 13 375 spilled SGPRs
 // (a control wave whose every stage was force-inlined three times and broadcast through v_readlane): its passes waited on the instruction cache,
 // not on arithmetic. This one has ONE code path that every wave runs:
-//  * the edges live in registers (point) and LDS (observation, weight, last chi2), grouped by camera once at the start (counting sort in LDS)
-//    so that a WAVE works on one camera: intrinsics and the composed world -> camera transform M_c = R_c R(T), m_c = R_c t(T) + t_c are
-//    wave-uniform, an edge's point costs 9 FMAs;
+//  * the edges live in registers (point, last chi2) and LDS (observation, weight), grouped by camera once at the start (counting sort in LDS)
+//    so that a WAVE works on one camera: its intrinsics and rig -> camera transform are wave-uniform. An edge's camera-frame point and residual
+//    go through the oracle's own operations (cam_point_regs(), quotient(): see there for why the composed 3 x 4 transform was given up);
 //  * J = A adj_c with A the 2 x 6 projection Jacobian in the camera frame (two structural zeros). adj_c is the reference's 6 x 6 matrix as
 //    given (NOT the SE3 adjoint, so it cannot be folded into the geometry): the wave accumulates A^T W A (21) and A^T r (6), reduces
 //    them across its lanes (one transposed reduction on v_permlane32/16_swap), and applies adj_c^T ( . ) adj_c to its own 27 sums as ONE constant
@@ -2052,16 +2052,20 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
 //    per edge, associated differently;
 //  * ONE sweep per trial: a trial's errors and the linearisation at the trial's pose. g2o recomputes exactly those when it accepts (and a
 //    rejection re-solves the kept system with a larger lambda);
-//  * NO control wave: after the one workgroup barrier of a pass every wave adds the 8 partial systems in wave order and then runs the scalar part
-//    -- LM rule, 6 x 6 LDL^T, exp map, the cameras' transforms -- itself, every lane the same arithmetic on the same numbers (a wave64 f64
-//    instruction costs the same for one lane as for 64, and two waves per SIMD hide each other's latency). Nothing is broadcast, no second
-//    barrier, no v_readlane; the partial sums are double-buffered so that a fast wave's next pass cannot overwrite what a slow one still reads.
+//  * NO control wave: after the one workgroup barrier of a pass every wave adds the 4 partial systems in wave order and then runs the scalar part
+//    -- LM rule, 6 x 6 LDL^T, exp map -- itself, every lane the same arithmetic on the same numbers (a wave64 f64 instruction costs the same
+//    for one lane as for 64). Nothing is broadcast, no second
+//    barrier, no v_readlane; the partial sums are double-buffered so that a fast wave's next pass cannot overwrite what a slow one still reads;
+//  * a round's classification of the edges (:365-390) is one more pass of the same sweep code at the round's final pose, told by a flag.
 // Parity bar unchanged (tests/test_gpu_ba.py::test_pose_optimization_vs_oracle, tests/test_gpu_track.py): poses 1e-7 / 1e-8, flags, counts +-1.
-constexpr int kPoT = 256, kPoW = kPoT / 64, kPoEpt = 16;     // ONE wave per SIMD: two waves on a SIMD run this f64 code one after the other, not interleaved (tools/pose_timeline.py)
+constexpr int kPoT = 256, kPoW = kPoT / 64, kPoEpt = 12;     // ONE wave per SIMD: two waves on a SIMD run this f64 code one after the other, not interleaved (tools/pose_timeline.py)
 constexpr int kPoseFastMax = 2048;
 // A camera's edges are shared by the waves the greedy split below gives it; a frame whose largest share does not fit kPoEpt slots per lane is left to
-// k_pose_opt (a rig of up to three cameras always fits: the extra wave goes to the largest camera; four cameras fit when none has more than 1 024 edges)
-static_assert(2 * 64 * kPoEpt >= kPoseFastMax, "two cameras, two waves each");
+// k_pose_opt. The dual rig always fits (the split is 2 + 2 waves when the smaller camera has at least half the larger one's edges, else 3 + 1: 11 slots
+// at most over every split of up to 2 048 edges, tests/test_pose_split.py walks them all); a third or fourth camera fits while no camera that is left
+// with one wave holds more than 64 * kPoEpt = 768 edges. The slot count is the kernel's code size: the sweep is unrolled over it, 2.8 KB a slot.
+static_assert(128 * kPoEpt >= (2 * kPoseFastMax + 2) / 3, "two cameras, two waves each: the larger has at most two thirds of the edges");
+static_assert(192 * kPoEpt >= kPoseFastMax && 64 * kPoEpt >= (kPoseFastMax + 2) / 3, "two cameras, three waves and one: the smaller has less than a third");
 constexpr int kPoChunks = (kPoseFastMax + kPoT - 1) / kPoT;
 constexpr int kPoLine = 48;          // a wave's exchange line: H 0..20, b 22..27, zeros 28..43, chi2 44, active edges 45
 
@@ -2128,9 +2132,8 @@ struct alignas(16) PoseShared {
     double tot[kPoW][32];                   // per wave: the totals of a pass for its own lanes
     double keep[kPoW][36];                  // per wave: the adopted system (21 + 6 at 0..26) and the pushed pose (28..34)
     double K[kMaxCams][27][22];             // adj_c^T ( . ) adj_c as a linear map on the 21 + 6 sums: row = output entry
-    double ed[3][kPoEpt][kPoT];             // observation (x, y) and weight of every resident edge (96 KB; one workgroup per CU anyway)
+    double ed[3][kPoEpt][kPoT];             // observation (x, y) and weight of every resident edge (72 KB; one workgroup per CU anyway)
     DCam cam[kMaxCams];                     // the rig's cameras (a by-value kernel argument indexed at run time would be copied to scratch)
-    double rc[kMaxCams][12];                // their rotation matrices + translations
     double series[34];                      // kPoSeries
     uint16_t list[kPoseFastMax];
     int cnt[kMaxCams][kPoChunks * kPoW];
@@ -2280,21 +2283,30 @@ __device__ __forceinline__ double uniform_f64(double x)
     return dbl_of((unsigned)__builtin_amdgcn_readfirstlane(__double2loint(x)), (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x)));
 }
 
-// world -> camera at the pose T for the camera whose rotation matrix and translation sit at rc[0..8], rc[9..11] (LDS: twelve loads per pass are
-// cheaper than 24 registers held across the sweep): M = Rc R(T), m = Rc t(T) + tc
-__device__ __forceinline__ void pose_compose(const double (&T)[7], const double* rc, double (&M)[12])
+// The camera-frame point through the oracle's own operations (cam_point(): two quaternion rotations, 66 f64 instructions instead of the 9 of a composed
+// matrix), and the residual's quotients x / z, y / z, the Huber kernel's square root and quotient as values that equal the IEEE results in all but
+// vanishingly rare halfway cases, for a third of the IEEE sequences' instructions: v_rcp_f64 / v_rsq_f64 seeds, a correction, ONE remainder step.
+// Why (round 6, scratch/pose_flip_stats.py, profiles/r06_pose_flip_stats.txt): an accept / reject decision on the convergence plateau follows the
+// rounding of chi2. With per-edge terms that differ from the oracle's at 1e-14 (composed matrix, reciprocal-multiply quotients) 16.8 % of random
+// batches ended a round one LM iteration apart; with the oracle's point 12.2 %, with its residual arithmetic as well 9.2 % (the per-edge kernel
+// k_pose_opt: 8.2 %; what remains is the order of the sums). Costs 37 us of a 253-us frame (898 edges).
+__device__ __forceinline__ void cam_point_regs(const double (&T)[7], const double (&X)[3], const double (&cq)[4], const double (&ct)[3], double (&pc)[3])
 {
-    double Rc[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) Rc[i] = rc[i];
-    double R[9];
-    qtoR(&T[3], R);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) M[i * 3 + j] = fma(Rc[i * 3], R[j], fma(Rc[i * 3 + 1], R[3 + j], Rc[i * 3 + 2] * R[6 + j]));
-        M[9 + i] = fma(Rc[i * 3], T[0], fma(Rc[i * 3 + 1], T[1], fma(Rc[i * 3 + 2], T[2], Rc[9 + i])));
-    }
+    double pm[3];
+    qrot(&T[3], X, pm);
+    pm[0] += T[0]; pm[1] += T[1]; pm[2] += T[2];
+    qrot(cq, pm, pc);
+    pc[0] += ct[0]; pc[1] += ct[1]; pc[2] += ct[2];
+}
+__device__ __forceinline__ double quotient(double x, double r /* ~ 1 / z to an ulp */, double z)
+{
+    const double q0 = x * r;
+    return fma(fma(-q0, z, x), r, q0);
+}
+__device__ __forceinline__ double sqrt_seeded(double x, double rs /* ~ 1 / sqrt(x) to an ulp */)
+{
+    const double s0 = x * rs;
+    return fma(fma(-s0, s0, x), 0.5 * rs, s0);
 }
 
 #ifdef DCS_POSE_PROF
@@ -2368,12 +2380,6 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
             } else if (r >= 21 && t < 6) val = adj[t * 6 + (r - 21)];
             S.K[c][r][t] = val;
         }
-        if (tid < kMaxCams) {
-            double Rc[9];
-            qtoR(S.cam[tid].q, Rc);
-            for (int i = 0; i < 9; ++i) S.rc[tid][i] = Rc[i];
-            for (int i = 0; i < 3; ++i) S.rc[tid][9 + i] = S.cam[tid].t[i];
-        }
         __syncthreads();
         if (tid < kMaxCams) {                                 // exclusive prefix over (chunk, wave) in edge order
             int run = 0;
@@ -2403,7 +2409,7 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
     const int wc = __builtin_amdgcn_readfirstlane(S.wcam[wave]), wu = __builtin_amdgcn_readfirstlane(S.wu[wave]), wW = __builtin_amdgcn_readfirstlane(S.W[wc]);
     const int nc = __builtin_amdgcn_readfirstlane(S.ncam[wc]), coff = __builtin_amdgcn_readfirstlane(S.off[wc]);
     const int ept = (nc + 64 * wW - 1) / (64 * wW);
-    {   // a camera whose share does not fit the registers (only a four-camera rig with more than 1 024 edges on one camera can do that): the
+    {   // a camera whose share does not fit the registers (only a rig of three or four cameras with more than 768 edges on one of them can do that): the
         // frame is k_pose_opt's, told by the sentinel in n_inliers (the host launches k_pose_opt behind this kernel for such rigs)
         int worst = 0;
         for (int c = 0; c < kMaxCams; ++c) if (S.W[c] > 0) worst = max(worst, (S.ncam[c] + 64 * S.W[c] - 1) / (64 * S.W[c]));
@@ -2415,7 +2421,6 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
         }
     }
     const double fx = uniform_f64(S.cam[wc].fx), fy = uniform_f64(S.cam[wc].fy), cx = uniform_f64(S.cam[wc].cx), cy = uniform_f64(S.cam[wc].cy);
-    const double* const my_rc = S.rc[wc];
     double X[kPoEpt][3], c2[kPoEpt];                          // the points and the chi2 of their last evaluation (observation, weight: S.ed)
     unsigned valid = 0, outl = 0;
 #pragma unroll
@@ -2433,7 +2438,7 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
     const int line_slot = (lane >> 1) < 21 ? (lane >> 1) : ((lane >> 1) < 27 ? (lane >> 1) + 1 : (lane >> 1) + 17);   // where the sum of v[lane / 2] goes
     bool robust = true;
     int n_bad_edges = 0, buf = 0, n_its = 0;
-    double T[7], M[12];
+    double T[7];
 #ifdef DCS_POSE_PROF
     unsigned long long prof_t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int n_pass = 0;
@@ -2452,11 +2457,10 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
         asm volatile("" : "+v"(lane_l));                      // (lane == 0 as a mask held since the sort would be a scalar register pair across the loop)
 #pragma unroll
         for (int d = 0; d < 7; ++d) T[d] = Tin[d];            // :360 every round restarts from the frame's pose
-        pose_compose(T, my_rc, M);
         // LM state: the same in every lane of every wave
         double lambda = -1, ni = 2, currentChi = 0, iniChi = 0, inv_scale = 1;
         int nBad = 0, n_it = 0, qmax = 0, it_i = 0, phase = 0;
-        bool ok2 = true;
+        bool ok2 = true, classify = false;
         for (;;) {
 #ifdef DCS_POSE_PROF
             ++n_pass;
@@ -2467,36 +2471,35 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
             double v[32];
 #pragma unroll
             for (int q = 0; q < 32; ++q) v[q] = 0;
+            double cq[4], ct[3];                                // the wave's camera, rig -> camera (vector registers, read per sweep: as scalars they spill)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) cq[d] = S.cam[wc].q[d];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) ct[d] = S.cam[wc].t[d];
             int ept_l = ept;
-            unsigned live_l = valid & ~outl;
-            asm volatile("" : "+s"(ept_l), "+v"(live_l));       // (tested afresh per slot: hoisted out of the loop the slots' comparisons and masks hold 28 scalar registers)
+            unsigned live_l = classify ? outl : valid & ~outl, valid_l = valid, bad = 0;      // (classifying: only the previous outliers are evaluated)
+            asm volatile("" : "+s"(ept_l), "+v"(live_l), "+v"(valid_l));   // (tested afresh per slot: hoisted out of the loop the slots' comparisons and masks hold 28 scalar registers)
 #pragma unroll
             for (int j = 0; j < kPoEpt; ++j) {
                 if (j >= ept_l) continue;                       // wave-uniform (no early exit: a 16-fold unrolled loop with 16 exits is not unrolled at all)
                 const bool act = (live_l >> j) & 1u;
-                double x = fma(M[0], X[j][0], fma(M[1], X[j][1], fma(M[2], X[j][2], M[9])));
-                double y = fma(M[3], X[j][0], fma(M[4], X[j][1], fma(M[5], X[j][2], M[10])));
-                double z = fma(M[6], X[j][0], fma(M[7], X[j][1], fma(M[8], X[j][2], M[11])));
+                double pcv[3];
+                cam_point_regs(T, X[j], cq, ct, pcv);
+                double x = pcv[0], y = pcv[1], z = pcv[2];
                 if (!act) { x = 0; y = 0; z = 1; }              // an excluded edge contributes exact zeros below, whatever its point does
-#ifdef DCS_PO_EXACT_SWEEP                                        // side builds (scratch/pose_flip_stats.py): what each shortcut costs in LM iterations apart from the oracle
-                const double iz = 1.0 / z, xz = x * iz, yz = y * iz;
-#else
-                const double iz = fast_recip(z), xz = x * iz, yz = y * iz;     // (v_rcp_f64 + a third-order correction: an ulp from the IEEE quotient, a quarter of its instructions)
-#endif
-                const double ex = S.ed[0][j][tid] - fma(xz, fx, cx), ey = S.ed[1][j][tid] - fma(yz, fy, cy);
+                const double iz = fast_recip(z), xz = quotient(x, iz, z), yz = quotient(y, iz, z);
+                const double ex = S.ed[0][j][tid] - (xz * fx + cx), ey = S.ed[1][j][tid] - (yz * fy + cy);     // (unfused: the oracle's obs - (x / z * fx + cx))
                 const double w = act ? S.ed[2][j][tid] : 0.0;
                 const double x2 = ex * (w * ex) + ey * (w * ey);
                 if (act) c2[j] = x2;
+                // (the classifying pass runs on through the accumulation, whose sums nobody reads: a skip here is a second way into the next slot,
+                // and the compiler then copies all 28 accumulators at the end of every slot)
+                if (classify && ((valid_l >> j) & 1u) && (float)c2[j] > th_it) bad |= 1u << j;
                 const bool big = robust && x2 > dsqr;
                 double rho0 = x2, we = w;
                 if (__builtin_amdgcn_ballot_w64(big)) {        // wave-uniform: only when some edge of the wave is beyond the Huber width
-#ifdef DCS_PO_EXACT_SWEEP
-                    const double sq = sqrt(x2);
-                    if (big) { rho0 = 2 * sq * delta - dsqr; we = (delta / sq) * w; }
-#else
-                    const double rs = fast_rsqrt(big ? x2 : 1.0);                      // sqrt(x2) = x2 rs, delta / sqrt(x2) = delta rs: no IEEE square root, no division
-                    if (big) { rho0 = 2 * (x2 * rs) * delta - dsqr; we = (delta * rs) * w; }
-#endif
+                    const double rs = fast_rsqrt(big ? x2 : 1.0), sq = sqrt_seeded(big ? x2 : 1.0, rs);
+                    if (big) { rho0 = 2 * sq * delta - dsqr; we = quotient(delta, rs, sq) * w; }     // (delta / sqrt(x2)) * w
                 }
                 v[27] += rho0;
                 v[28] += act ? 1.0 : 0.0;
@@ -2518,6 +2521,14 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
                 v[20] = fma(p05, a05, fma(p15, a15, v[20]));
                 v[21] = fma(a00, r0, fma(a10, r1, v[21]));   v[22] = fma(a01, r0, fma(a11, r1, v[22]));   v[23] = fma(a02, r0, fma(a12, r1, v[23]));
                 v[24] = fma(a03, r0, v[24]);                 v[25] = fma(a14, r1, v[25]);                 v[26] = fma(a05, r0, fma(a15, r1, v[26]));
+            }
+            if (classify) {
+                outl = bad;
+                int cnt = __popc(bad);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+                if (lane_l == 0) S.bad[it & 1][wave] = cnt;
+                break;
             }
             DCS_PO_TICK(0)
             // ---- the wave's 29 sums, then adj^T ( . ) adj on them: lane q < 21 forms entry q of H, lanes 21..26 the entries of b
@@ -2656,35 +2667,13 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
                 for (int d = 0; d < 7; ++d) T[d] = o[d];
                 phase = 1;
             }
-            pose_compose(T, my_rc, M);
             DCS_PO_TICK(7)
-            if ((flags & 3) == 2) break;
+            // ---- the round is over: classification of every edge (:365-390) is one more pass of the sweep's evaluation at the final pose, in which
+            // the previous outliers are re-evaluated and the inliers keep the chi2 of their last evaluation (a second copy of the evaluation for
+            // it would be another 17 KB of code)
+            if ((flags & 3) == 2) classify = true;
         }
         n_its = it == 0 ? n_it : n_its | (n_it << (8 * it));                          // (<= 10 each: a byte per round)
-        // ---- classification of every edge (:365-390): previous outliers are re-evaluated at the final pose, inliers keep the chi2 of the last evaluation
-        {
-            unsigned bad = 0, valid_l = valid, outl_l = outl;
-            int ept_l = ept;
-            asm volatile("" : "+s"(ept_l), "+v"(valid_l), "+v"(outl_l));
-#pragma unroll
-            for (int j = 0; j < kPoEpt; ++j) {
-                if (j >= ept_l) continue;
-                if ((outl_l >> j) & 1u) {
-                    const double x = fma(M[0], X[j][0], fma(M[1], X[j][1], fma(M[2], X[j][2], M[9])));
-                    const double y = fma(M[3], X[j][0], fma(M[4], X[j][1], fma(M[5], X[j][2], M[10])));
-                    const double z = fma(M[6], X[j][0], fma(M[7], X[j][1], fma(M[8], X[j][2], M[11])));
-                    const double iz = fast_recip(z);
-                    const double ex = S.ed[0][j][tid] - fma(x * iz, fx, cx), ey = S.ed[1][j][tid] - fma(y * iz, fy, cy), w = S.ed[2][j][tid];
-                    c2[j] = ex * (w * ex) + ey * (w * ey);
-                }
-                if (((valid_l >> j) & 1u) && (float)c2[j] > th_it) bad |= 1u << j;
-            }
-            outl = bad;
-            int cnt = __popc(bad);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-            if (lane_l == 0) S.bad[it & 1][wave] = cnt;
-        }
         __syncthreads();
         n_bad_edges = 0;
 #pragma unroll
@@ -3102,9 +3091,9 @@ static int launch_pose_kernels(PoseArgs a, const DCams& cams, int n_cams, int n_
     const bool fast = opt(OPT_POSE_FAST) != 0;
     a.fast_max = fast ? kPoseFastMax : -1;
     if (fast) hipLaunchKernelGGL(k_pose_opt2, dim3(n_frames), dim3(kPoT), 0, st, a, cams);
-    // k_pose_opt behind it when a frame can be beyond k_pose_opt2: more edges than kPoseFastMax, or a four-camera rig with more than 64 * kPoEpt edges
-    // on one camera (k_pose_opt2 marks such a frame: kPoseDeclined)
-    if (!fast || max_edges_bound > kPoseFastMax || (n_cams > 3 && max_edges_bound > 64 * kPoEpt)) hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, st, a, cams);
+    // k_pose_opt behind it when a frame can be beyond k_pose_opt2: more edges than kPoseFastMax, or a rig of more than two cameras with more than
+    // 64 * kPoEpt edges on one of them (k_pose_opt2 marks such a frame: kPoseDeclined)
+    if (!fast || max_edges_bound > kPoseFastMax || (n_cams > 2 && max_edges_bound > 64 * kPoEpt)) hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, st, a, cams);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

@@ -1,9 +1,14 @@
-cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-HEAD="--cpu-seconds 0 --no-ba --no-bow --no-c3 --no-c5 --no-host-api --no-two-lanes --steps 6 --warmup 2"
-for lib in lib scratch/ab/one_round; do
-  L=$R/orb-slam2-dualcam_amd/lib/libdcs_hip.so; [ $lib != lib ] && L=$R/$lib/libdcs_hip.so
-  rm -rf $R/gpurun_out/tr_x; echo "== alone, $lib"
-  DCS_LIB_PATH=$L DCS_ORB_NO_OVERLAP=1 DCS_ORB_EMIT=15 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tr_x -o t -- python $R/bench.py $HEAD --serial > /dev/null 2>&1
-  python $R/scratch/trace_by_grid.py $R/gpurun_out/tr_x k_fast_cells | head -9
-  rm -rf $R/gpurun_out/tr_x
-done
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+python -m pytest tests/test_gpu_ba.py tests/test_gpu_track.py -m gpu -q 2>&1 | tail -3
+python scratch/pose_flip_stats.py 400 1 2>/dev/null | tail -1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tt -o tt -- python scratch/time_track.py > gpurun_out/tt.log 2>&1
+grep DCS_POSE gpurun_out/tt.log
+python - <<'PY'
+import csv,glob
+f=glob.glob('gpurun_out/tt/**/*kernel_stats.csv',recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if 'pose' in r['Name']: print(r['Name'][:40], r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'])
+PY
+python scratch/time_track.py 2>/dev/null | tail -1
+DCS_LIB_PATH=$GRAFT_REPO_ROOT/scratch/ab/pose_prof/libdcs_hip.so python tools/pose_timeline.py 2>&1 | tail -12

@@ -324,8 +324,8 @@ def test_global_bundle_adjustment_at_map_size_vs_oracle(pkg, oracle, synth):
 
 
 def test_pose_optimization_four_camera_rig_with_one_crowded_camera(pkg, oracle, synth):
-    """k_pose_opt2 keeps a camera's edges in the registers of the waves the camera gets: a four-camera rig with more than 1 024 edges on ONE
-    camera does not fit (each camera has one wave), the kernel declines the frame and k_pose_opt takes it in the same call. Frames of the
+    """k_pose_opt2 keeps a camera's edges in the registers of the waves the camera gets: a four-camera rig with more than 768 edges on ONE
+    camera does not fit (each camera has one wave of 64 lanes x 12 slots), the kernel declines the frame and k_pose_opt takes it in the same call. Frames of the
     same call that do fit stay with k_pose_opt2; both against the oracle. Cameras 2, 3 are copies of camera 1 (same model, other id)."""
     pb = synth.pose_problem(n_frames=6, obs_per_frame=5000, seed=41)
     rng = np.random.default_rng(7)
@@ -336,7 +336,7 @@ def test_pose_optimization_four_camera_rig_with_one_crowded_camera(pkg, oracle, 
         idx = np.arange(e0, e1)
         c = pb["edge_cam"][e0:e1]
         i0, i1 = idx[c == 0], idx[c == 1]
-        if f in (2, 3):   i0, i1 = i0[:1100], i1[:600]          # camera 0: 1 100 edges > 64 x 16 -> declined
+        if f in (2, 3):   i0, i1 = i0[:1100], i1[:600]          # camera 0: 1 100 edges > 64 x 12 -> declined
         elif f >= 4:      i0, i1 = i0[:500], i1[:900]           # fits: 500 / 300 / 300 / 300
         sel = np.sort(np.concatenate([i0, i1]))
         cn = pb["edge_cam"][sel].copy()
@@ -351,6 +351,36 @@ def test_pose_optimization_four_camera_rig_with_one_crowded_camera(pkg, oracle, 
     prob["cams"] = [oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pb4["cams"]]
     exp = oracle.pose_optimization(prob)
     got = pkg.Optimizer.PoseOptimization(pb4)
+    assert np.abs(got["n_iters"] - exp["n_iters"]).max() <= 1
+    assert np.abs(got["poses"][:, :3] - exp["poses"][:, :3]).max() < 1e-7 and np.abs(got["poses"][:, 3:] - exp["poses"][:, 3:]).max() < 1e-8
+    flips = int(np.sum(got["outlier"] != exp["outlier"]))
+    assert flips <= 2 and np.abs(got["n_inliers"] - exp["n_inliers"]).max() <= flips
+    assert (got["n_inliers"][2:] > 100).all()
+
+
+def test_pose_optimization_dual_rig_at_every_uneven_split_of_the_largest_frame(pkg, oracle, synth):
+    """k_pose_opt2 gives the rig's two cameras 2 + 2 or 3 + 1 waves; the dual rig must fit its 12 register slots per lane at ANY split of a
+    2 048-edge frame (worst cases: one third / two thirds, where the split changes, and a frame seen by one camera only). No frame may fall
+    back to k_pose_opt (DCS_POSE_FAST stays on; n_iters etc. are compared with the oracle like everywhere)."""
+    splits = [(1365, 683), (1366, 682), (2048, 0), (1536, 512), (0, 2048), (1024, 1024), (683, 1365)]      # (in an order the scene's frames can supply)
+    pb = synth.pose_problem(n_frames=2 + len(splits), obs_per_frame=8000, seed=43)
+    keep, off = [], [0]
+    for f in range(2 + len(splits)):
+        e0, e1 = int(pb["edge_off"][f]), int(pb["edge_off"][f + 1])
+        idx = np.arange(e0, e1)
+        if f >= 2:
+            c = pb["edge_cam"][e0:e1]
+            k0, k1 = splits[f - 2]
+            i0, i1 = idx[c == 0], idx[c == 1]
+            assert len(i0) >= k0 and len(i1) >= k1
+            idx = np.sort(np.concatenate([i0[:k0], i1[:k1]]))
+        keep.append(idx); off.append(off[-1] + len(idx))
+    keep = np.concatenate(keep)
+    pb2 = dict(pb, edge_off=np.asarray(off, np.int32), xw=pb["xw"][keep], obs=pb["obs"][keep], inv_sigma2=pb["inv_sigma2"][keep], edge_cam=pb["edge_cam"][keep])
+    prob = dict(pb2)
+    prob["cams"] = [oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pb2["cams"]]
+    exp = oracle.pose_optimization(prob)
+    got = pkg.Optimizer.PoseOptimization(pb2)
     assert np.abs(got["n_iters"] - exp["n_iters"]).max() <= 1
     assert np.abs(got["poses"][:, :3] - exp["poses"][:, :3]).max() < 1e-7 and np.abs(got["poses"][:, 3:] - exp["poses"][:, 3:]).max() < 1e-8
     flips = int(np.sum(got["outlier"] != exp["outlier"]))

@@ -1,0 +1,46 @@
+"""The wave split of k_pose_opt2 (orb-slam2-dualcam_amd/csrc/ba_solver.hip: the greedy rule after the camera sort) restated on the host, walked
+over EVERY split of a dual-rig frame: the kernel is unrolled over kPoEpt = 12 register slots per lane, and the claim its static_asserts and
+DESIGN.md make -- a two-camera frame of up to 2 048 edges never needs more than 11 -- is checked here by enumeration (CPU, no GPU)."""
+import numpy as np
+
+K_WAVES, K_SLOTS, K_FAST_MAX = 4, 12, 2048
+
+
+def slots_needed(n_per_cam):
+    """Waves: one per camera that has edges, the rest one at a time to the camera with the most edges per wave (ties: lower index);
+    slots = the largest ceil(edges / (64 * waves)) over the cameras."""
+    waves = [1 if n > 0 else 0 for n in n_per_cam]
+    for _ in range(sum(waves), K_WAVES):
+        best, bn, bd = 0, -1, 1
+        for c, n in enumerate(n_per_cam):
+            if waves[c] > 0 and n * bd > bn * waves[c]:
+                best, bn, bd = c, n, waves[c]
+        waves[best] += 1
+    return max((n + 64 * w - 1) // (64 * w) for n, w in zip(n_per_cam, waves) if w > 0)
+
+
+def test_every_dual_rig_split_fits_the_register_slots():
+    worst = 0
+    for n in range(3, K_FAST_MAX + 1):
+        n0 = np.arange(0, n + 1)
+        # vectorised form of slots_needed for two cameras: (2, 2) waves when the smaller camera has at least half the larger one's edges,
+        # else (3, 1); one camera alone gets all four
+        big, small = np.maximum(n0, n - n0), np.minimum(n0, n - n0)
+        need = np.where(small == 0, (big + 255) // 256, np.where(2 * small >= big, (big + 127) // 128, np.maximum((big + 191) // 192, (small + 63) // 64)))
+        worst = max(worst, int(need.max()))
+    assert worst == 11 and worst <= K_SLOTS
+
+
+def test_vectorised_rule_is_the_greedy_rule():
+    rng = np.random.default_rng(3)
+    for _ in range(3000):
+        n = int(rng.integers(3, K_FAST_MAX + 1)); n0 = int(rng.integers(0, n + 1))
+        big, small = max(n0, n - n0), min(n0, n - n0)
+        need = (big + 255) // 256 if small == 0 else ((big + 127) // 128 if 2 * small >= big else max((big + 191) // 192, (small + 63) // 64))
+        assert slots_needed([n0, n - n0]) == need, (n0, n - n0)
+
+
+def test_more_cameras_fit_until_a_one_wave_camera_exceeds_768_edges():
+    assert slots_needed([500, 300, 300, 300]) <= K_SLOTS          # tests/test_gpu_ba.py's fitting four-camera frames
+    assert slots_needed([1100, 200, 200, 200]) > K_SLOTS          # ... and its declined ones (k_pose_opt takes them)
+    assert slots_needed([900, 768, 380]) <= K_SLOTS and slots_needed([900, 800, 348]) > K_SLOTS

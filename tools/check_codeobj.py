@@ -90,6 +90,12 @@ def demangle(names):
         return names
 
 
+def names(entry, kernel):
+    """True when an allow-list entry names this kernel: the whole demangled name, or the name before its template arguments
+    (k_octree does not name k_octree_hist<1>, k_pose_opt does not name k_pose_opt2)."""
+    return kernel == entry or ("<" not in entry and kernel.startswith(entry + "<"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("lib", nargs="?", default=os.path.join(os.path.dirname(__file__), "..", "orb-slam2-dualcam_amd", "lib", "libdcs_hip.so"))
@@ -97,7 +103,7 @@ def main():
     ap.add_argument("--out")
     ap.add_argument("--sgpr-only-allow-file", help="file of NAME=REASON lines (tools/codeobj_allow.txt)")
     ap.add_argument("--verbose", action="store_true", help="print the whole table even when every kernel passes")
-    ap.add_argument("--allow", action="append", default=[], help="NAME=REASON (substring of the demangled name): anything goes for this kernel")
+    ap.add_argument("--allow", action="append", default=[], help="NAME=REASON (the demangled name, with or without its template arguments): anything goes for this kernel")
     ap.add_argument("--sgpr-only-allow", nargs="*", default=[], help="NAME=REASON ...: spilled SCALAR registers (to VGPR lanes) are tolerated for these kernels; vector spills, scratch and size still fail")
     a = ap.parse_args()
     fat = section_bytes(a.lib, ".hip_fatbin")
@@ -131,9 +137,9 @@ def main():
             why.append("code size")
         mark = ""
         if why:
-            reason = next((r for n, r in allow.items() if n in k["name"]), None)
+            reason = next((r for n, r in allow.items() if names(n, k["name"])), None)
             if reason is None and why == ["spills"] and not k["vspill"]:
-                reason = next((r for n, r in allow_s.items() if n in k["name"]), None)
+                reason = next((r for n, r in allow_s.items() if names(n, k["name"])), None)
             if reason is None:
                 bad += 1
                 mark = "   <-- FAIL: " + ", ".join(why)
