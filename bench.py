@@ -1364,6 +1364,11 @@ def main():
         for nf_ in (1, 16):
             pt_ = pkg.abi.PreparedTracking(fr_t[:nf_], prm_t)
             chain["chained_ms_per_frame_batch_of_%d" % nf_] = round(med(pt_.track) / nf_ * 1e3, 4)
+        with pkg.abi.options(DCS_POSE_EXACT_EDGE=1):            # the other build of k_pose_opt2 (every edge's point and residual through the oracle's own operations)
+            pt_ = pkg.abi.PreparedTracking(fr_t[:1], prm_t)
+            chain["exact_edge_build"] = {"chained_ms_per_frame_batch_of_1": round(med(pt_.track) * 1e3, 4),
+                                         "what": "option DCS_POSE_EXACT_EDGE=1: rounds of PoseOptimization one LM iteration from the oracle in 9.2 % of random batches "
+                                                 "instead of 16.8 % (profiles/r06_pose_flip_stats.txt)"}
         m_t = pkg.ORBmatcher(prm_t["nn_ratio"], False)
 
         def three_calls():
@@ -1411,7 +1416,7 @@ def main():
                 row = next(r for r in _csv.DictReader(fh) if "k_pose_opt2" in r["Name"])
             us_k = float(row["MinNs"]) / 1e3                   # batch-of-1 launches (one workgroup) are the minimum of the trace
             edges = int((pkg.abi.PreparedTracking(fr_t[:1], prm_t).track()[0]["point_of_feature"] != -1).sum())
-            passes, f64_per_edge, f64_scalar = 60, 2 * 107, 2 * 400      # measured passes of this frame; FMA = 2 flops
+            passes, f64_per_edge, f64_scalar = 66, 2 * 107, 2 * 400      # measured passes of this frame (62 trials + 4 classifying passes); FMA = 2 flops
             flops = passes * (edges * f64_per_edge + 4 * f64_scalar)
             peak_cu = F64_VECTOR_PEAK_GFLOPS / N_CU
             chain["pose_kernel"] = {"kernel": "k_pose_opt2", "edges": edges, "us_batch_of_1": round(us_k, 1), "bound": "latency (dependent f64 chain on one CU)",

@@ -490,7 +490,10 @@ int  dcs_ba_timing(int on, double out[4]);
 
 /* Optimizer::PoseOptimization (src/Optimizer.cc:250-405) for a batch of independent frames (one per stream / camera
    rig); the whole 4-round Levenberg-Marquardt procedure of a frame runs inside one workgroup, no host round trips.
-   Frame f owns the edges edge_off[f] .. edge_off[f+1] (features with a MapPoint, ascending feature index). */
+   Frame f owns the edges edge_off[f] .. edge_off[f+1] (features with a MapPoint, ascending feature index).
+   Poses agree with the reference's arithmetic to ~1e-11, flags and inlier counts exactly; a round's LM iteration count can be one off where
+   two trials differ by rounding only (the convergence plateau). Option DCS_POSE_EXACT_EDGE = 1 selects the build that forms every edge's
+   camera-frame point and residual with the reference's own operations: such rounds become about half as frequent, for 17-30 % more time. */
 typedef struct dcs_pose_problem {
     int32_t n_frames, n_cams;
     const double*  poses;        /* [F][7] pFrame->mTcw (dcs_pose_from_matrix) */

@@ -2043,8 +2043,9 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
 // (a control wave whose every stage was force-inlined three times and broadcast through v_readlane): its passes waited on the instruction cache,
 // not on arithmetic. This one has ONE code path that every wave runs:
 //  * the edges live in registers (point, last chi2) and LDS (observation, weight), grouped by camera once at the start (counting sort in LDS)
-//    so that a WAVE works on one camera: its intrinsics and rig -> camera transform are wave-uniform. An edge's camera-frame point and residual
-//    go through the oracle's own operations (cam_point_regs(), quotient(): see there for why the composed 3 x 4 transform was given up);
+//    so that a WAVE works on one camera: its intrinsics and rig -> camera transform are wave-uniform. Two builds of the per-edge arithmetic
+//    (template argument, option DCS_POSE_EXACT_EDGE): the composed world -> camera transform M_c = R_c R(T), m_c = R_c t(T) + t_c, an edge's
+//    point 9 FMAs (default); or the point and the residual through the oracle's own operations (cam_point_regs(), quotient(): see there);
 //  * J = A adj_c with A the 2 x 6 projection Jacobian in the camera frame (two structural zeros). adj_c is the reference's 6 x 6 matrix as
 //    given (NOT the SE3 adjoint, so it cannot be folded into the geometry): the wave accumulates A^T W A (21) and A^T r (6), reduces
 //    them across its lanes (one transposed reduction on v_permlane32/16_swap), and applies adj_c^T ( . ) adj_c to its own 27 sums as ONE constant
@@ -2134,6 +2135,7 @@ struct alignas(16) PoseShared {
     double K[kMaxCams][27][22];             // adj_c^T ( . ) adj_c as a linear map on the 21 + 6 sums: row = output entry
     double ed[3][kPoEpt][kPoT];             // observation (x, y) and weight of every resident edge (72 KB; one workgroup per CU anyway)
     DCam cam[kMaxCams];                     // the rig's cameras (a by-value kernel argument indexed at run time would be copied to scratch)
+    double rc[kMaxCams][12];                // (composed-transform build) rig -> camera: rotation matrix, translation
     double series[34];                      // kPoSeries
     uint16_t list[kPoseFastMax];
     int cnt[kMaxCams][kPoChunks * kPoW];
@@ -2283,13 +2285,31 @@ __device__ __forceinline__ double uniform_f64(double x)
     return dbl_of((unsigned)__builtin_amdgcn_readfirstlane(__double2loint(x)), (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x)));
 }
 
+// (kExactEdge = false) world -> camera at the pose T for the camera whose rotation matrix and translation sit at rc[0..8], rc[9..11] (LDS: twelve
+// loads per pass are cheaper than 24 registers held across the sweep): M = Rc R(T), m = Rc t(T) + tc; an edge's point is then 9 FMAs
+__device__ __forceinline__ void pose_compose(const double (&T)[7], const double* rc, double (&M)[12])
+{
+    double Rc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Rc[i] = rc[i];
+    double R[9];
+    qtoR(&T[3], R);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[i * 3 + j] = fma(Rc[i * 3], R[j], fma(Rc[i * 3 + 1], R[3 + j], Rc[i * 3 + 2] * R[6 + j]));
+        M[9 + i] = fma(Rc[i * 3], T[0], fma(Rc[i * 3 + 1], T[1], fma(Rc[i * 3 + 2], T[2], Rc[9 + i])));
+    }
+}
+
 // The camera-frame point through the oracle's own operations (cam_point(): two quaternion rotations, 66 f64 instructions instead of the 9 of a composed
 // matrix), and the residual's quotients x / z, y / z, the Huber kernel's square root and quotient as values that equal the IEEE results in all but
 // vanishingly rare halfway cases, for a third of the IEEE sequences' instructions: v_rcp_f64 / v_rsq_f64 seeds, a correction, ONE remainder step.
 // Why (round 6, scratch/pose_flip_stats.py, profiles/r06_pose_flip_stats.txt): an accept / reject decision on the convergence plateau follows the
 // rounding of chi2. With per-edge terms that differ from the oracle's at 1e-14 (composed matrix, reciprocal-multiply quotients) 16.8 % of random
 // batches ended a round one LM iteration apart; with the oracle's point 12.2 %, with its residual arithmetic as well 9.2 % (the per-edge kernel
-// k_pose_opt: 8.2 %; what remains is the order of the sums). Costs 37 us of a 253-us frame (898 edges).
+// k_pose_opt: 8.2 %; what remains is the order of the sums). Costs 37 us of a 253-us frame (898 edges), 80 of 344 at 1 781: the sweep is bound by
+// the f64 issue rate. Hence kExactEdge: the default build keeps the composed transform, option DCS_POSE_EXACT_EDGE selects this arithmetic.
 __device__ __forceinline__ void cam_point_regs(const double (&T)[7], const double (&X)[3], const double (&cq)[4], const double (&ct)[3], double (&pc)[3])
 {
     double pm[3];
@@ -2314,13 +2334,15 @@ __device__ __forceinline__ double sqrt_seeded(double x, double rs /* ~ 1 / sqrt(
 // span on both clocks (s_memtime = shader clock, s_memrealtime = 100 MHz) in a global array that dcs_debug_pose_prof() copies out -- no printf in
 // the kernel: its code and registers would distort what is measured
 __device__ unsigned long long g_pose_prof[kPoT / 64][16];
-#define DCS_PO_TICK(k) { if (prof_on) prof_t[k] = __builtin_readcyclecounter(); }
+// (the stamps go straight to memory: nine of them held to the kernel's end were 18 scalar registers, spilled, and the spills stretched every stage)
+#define DCS_PO_TICK(k) { if (prof_on) { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane_l == 0) g_pose_prof[wave][k] = now_; } }
 #else
 #define DCS_PO_TICK(k)
 #endif
 
 constexpr int kPoseDeclined = INT_MIN;                    // n_inliers of a frame k_pose_opt2 left to k_pose_opt
 struct PoseKernargs { PoseArgs a; DCams cams; };          // the kernel's argument list as the kernarg segment lays it out
+template <bool kExactEdge>
 __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
 {
     __shared__ PoseShared S;
@@ -2379,6 +2401,14 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
                 val = k == m ? adj[k * 6 + i] * adj[k * 6 + j] : adj[k * 6 + i] * adj[m * 6 + j] + adj[m * 6 + i] * adj[k * 6 + j];
             } else if (r >= 21 && t < 6) val = adj[t * 6 + (r - 21)];
             S.K[c][r][t] = val;
+        }
+        if constexpr (!kExactEdge) {
+            if (tid < kMaxCams) {
+                double Rc[9];
+                qtoR(S.cam[tid].q, Rc);
+                for (int i = 0; i < 9; ++i) S.rc[tid][i] = Rc[i];
+                for (int i = 0; i < 3; ++i) S.rc[tid][9 + i] = S.cam[tid].t[i];
+            }
         }
         __syncthreads();
         if (tid < kMaxCams) {                                 // exclusive prefix over (chunk, wave) in edge order
@@ -2440,10 +2470,9 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
     int n_bad_edges = 0, buf = 0, n_its = 0;
     double T[7];
 #ifdef DCS_POSE_PROF
-    unsigned long long prof_t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int n_pass = 0;
     bool prof_on = false;
-    const unsigned long long t_begin = __builtin_readcyclecounter(), r_begin = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && f == 0) { g_pose_prof[wave][9] = __builtin_readcyclecounter(); g_pose_prof[wave][11] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     for (int it = 0; it < 4; ++it) {
         // (the round's iteration limit and chi2 gate are read from the kernarg segment when the round starts: eight values held from the top
@@ -2465,17 +2494,19 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
 #ifdef DCS_POSE_PROF
             ++n_pass;
             prof_on = f == 0 && n_pass == DCS_POSE_PROF;          // the pass to record: -DDCS_POSE_PROF=<pass number>
-            if (prof_on) prof_t[8] = __builtin_readcyclecounter();
+            DCS_PO_TICK(8)
 #endif
             // ---- one sweep: errors of the active edges at T, robust chi2, and the linearisation there
             double v[32];
 #pragma unroll
             for (int q = 0; q < 32; ++q) v[q] = 0;
-            double cq[4], ct[3];                                // the wave's camera, rig -> camera (vector registers, read per sweep: as scalars they spill)
+            double cq[4], ct[3], M[12];                         // the wave's camera, rig -> camera (vector registers, read per sweep: as scalars they spill)
+            if constexpr (kExactEdge) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) cq[d] = S.cam[wc].q[d];
+                for (int d = 0; d < 4; ++d) cq[d] = S.cam[wc].q[d];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) ct[d] = S.cam[wc].t[d];
+                for (int d = 0; d < 3; ++d) ct[d] = S.cam[wc].t[d];
+            } else pose_compose(T, S.rc[wc], M);
             int ept_l = ept;
             unsigned live_l = classify ? outl : valid & ~outl, valid_l = valid, bad = 0;      // (classifying: only the previous outliers are evaluated)
             asm volatile("" : "+s"(ept_l), "+v"(live_l), "+v"(valid_l));   // (tested afresh per slot: hoisted out of the loop the slots' comparisons and masks hold 28 scalar registers)
@@ -2483,12 +2514,26 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
             for (int j = 0; j < kPoEpt; ++j) {
                 if (j >= ept_l) continue;                       // wave-uniform (no early exit: a 16-fold unrolled loop with 16 exits is not unrolled at all)
                 const bool act = (live_l >> j) & 1u;
-                double pcv[3];
-                cam_point_regs(T, X[j], cq, ct, pcv);
-                double x = pcv[0], y = pcv[1], z = pcv[2];
+                double x, y, z;
+                if constexpr (kExactEdge) {
+                    double pcv[3];
+                    cam_point_regs(T, X[j], cq, ct, pcv);
+                    x = pcv[0]; y = pcv[1]; z = pcv[2];
+                } else {
+                    x = fma(M[0], X[j][0], fma(M[1], X[j][1], fma(M[2], X[j][2], M[9])));
+                    y = fma(M[3], X[j][0], fma(M[4], X[j][1], fma(M[5], X[j][2], M[10])));
+                    z = fma(M[6], X[j][0], fma(M[7], X[j][1], fma(M[8], X[j][2], M[11])));
+                }
                 if (!act) { x = 0; y = 0; z = 1; }              // an excluded edge contributes exact zeros below, whatever its point does
-                const double iz = fast_recip(z), xz = quotient(x, iz, z), yz = quotient(y, iz, z);
-                const double ex = S.ed[0][j][tid] - (xz * fx + cx), ey = S.ed[1][j][tid] - (yz * fy + cy);     // (unfused: the oracle's obs - (x / z * fx + cx))
+                const double iz = fast_recip(z);                // (v_rcp_f64 + a third-order correction: an ulp from the IEEE reciprocal, a quarter of its instructions)
+                double xz, yz, ex, ey;
+                if constexpr (kExactEdge) {
+                    xz = quotient(x, iz, z); yz = quotient(y, iz, z);
+                    ex = S.ed[0][j][tid] - (xz * fx + cx); ey = S.ed[1][j][tid] - (yz * fy + cy);     // (unfused: the oracle's obs - (x / z * fx + cx))
+                } else {
+                    xz = x * iz; yz = y * iz;
+                    ex = S.ed[0][j][tid] - fma(xz, fx, cx); ey = S.ed[1][j][tid] - fma(yz, fy, cy);
+                }
                 const double w = act ? S.ed[2][j][tid] : 0.0;
                 const double x2 = ex * (w * ex) + ey * (w * ey);
                 if (act) c2[j] = x2;
@@ -2498,8 +2543,11 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
                 const bool big = robust && x2 > dsqr;
                 double rho0 = x2, we = w;
                 if (__builtin_amdgcn_ballot_w64(big)) {        // wave-uniform: only when some edge of the wave is beyond the Huber width
-                    const double rs = fast_rsqrt(big ? x2 : 1.0), sq = sqrt_seeded(big ? x2 : 1.0, rs);
-                    if (big) { rho0 = 2 * sq * delta - dsqr; we = quotient(delta, rs, sq) * w; }     // (delta / sqrt(x2)) * w
+                    const double rs = fast_rsqrt(big ? x2 : 1.0);
+                    if constexpr (kExactEdge) {
+                        const double sq = sqrt_seeded(big ? x2 : 1.0, rs);
+                        if (big) { rho0 = 2 * sq * delta - dsqr; we = quotient(delta, rs, sq) * w; }     // (delta / sqrt(x2)) * w
+                    } else if (big) { rho0 = 2 * (x2 * rs) * delta - dsqr; we = (delta * rs) * w; }       // sqrt(x2) = x2 rs, delta / sqrt(x2) = delta rs
                 }
                 v[27] += rho0;
                 v[28] += act ? 1.0 : 0.0;
@@ -2683,9 +2731,8 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
     }
 #ifdef DCS_POSE_PROF
     if (lane == 0 && f == 0) {
-        for (int k = 0; k < 9; ++k) g_pose_prof[wave][k] = prof_t[k];
-        g_pose_prof[wave][9] = t_begin; g_pose_prof[wave][10] = __builtin_readcyclecounter();
-        g_pose_prof[wave][11] = r_begin; g_pose_prof[wave][12] = __builtin_amdgcn_s_memrealtime();
+        g_pose_prof[wave][10] = __builtin_readcyclecounter();
+        g_pose_prof[wave][12] = __builtin_amdgcn_s_memrealtime();
         g_pose_prof[wave][13] = (unsigned long long)n_pass; g_pose_prof[wave][14] = (unsigned long long)n; g_pose_prof[wave][15] = (unsigned long long)ept;
     }
 #endif
@@ -3090,7 +3137,10 @@ static int launch_pose_kernels(PoseArgs a, const DCams& cams, int n_cams, int n_
 {
     const bool fast = opt(OPT_POSE_FAST) != 0;
     a.fast_max = fast ? kPoseFastMax : -1;
-    if (fast) hipLaunchKernelGGL(k_pose_opt2, dim3(n_frames), dim3(kPoT), 0, st, a, cams);
+    if (fast) {
+        if (opt(OPT_POSE_EXACT_EDGE) != 0) hipLaunchKernelGGL(k_pose_opt2<true>, dim3(n_frames), dim3(kPoT), 0, st, a, cams);
+        else hipLaunchKernelGGL(k_pose_opt2<false>, dim3(n_frames), dim3(kPoT), 0, st, a, cams);
+    }
     // k_pose_opt behind it when a frame can be beyond k_pose_opt2: more edges than kPoseFastMax, or a rig of more than two cameras with more than
     // 64 * kPoEpt edges on one of them (k_pose_opt2 marks such a frame: kPoseDeclined)
     if (!fast || max_edges_bound > kPoseFastMax || (n_cams > 2 && max_edges_bound > 64 * kPoEpt)) hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, st, a, cams);

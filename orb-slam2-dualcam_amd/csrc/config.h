@@ -27,6 +27,7 @@ namespace dcs {
     X(OCTREE_FORCE_GENERAL,        0)   /* 1: the sort-based k_octree for every task (test hook) */                                      \
     X(KNN2_I8,                     0)   /* 1: the i8 matrix-core matcher instead of the FP4 one */                                       \
     X(POSE_FAST,                   1)   /* 0: every frame to the round-4 k_pose_opt */                                                   \
+    X(POSE_EXACT_EDGE,             0)   /* 1: k_pose_opt2 forms every edge's point and residual with the oracle's own operations: rounds one LM iteration from the oracle 16.8 -> 9.2 % of batches, +17 % time (NOTES R6.3) */ \
     X(BA_SCHUR_WAVE,               1)   /* Schur launch: 1 = by group size (k_schur<28> for 1-2 problems, k_schur_w beyond), 0 / 2 = always the former / the latter */ \
     X(BA_TRACE,                    0)   /* 1: host time per phase of dcs_ba_local_batch on stderr */                                     \
     X(BA_FORCE_BLOCKED_LDLT,       0)   /* test hook: the n > 256 factorisation at small n */                                            \

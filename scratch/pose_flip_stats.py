@@ -1,5 +1,6 @@
 """How often does k_pose_opt2 end a round of Optimizer::PoseOptimization one LM iteration away from the oracle? (GPU box)
-usage: pose_flip_stats.py [n_problems] [seed0]     DCS_LIB_PATH selects a side build, DCS_POSE_FAST=0 the general kernel k_pose_opt.
+usage: pose_flip_stats.py [n_problems] [seed0]     DCS_LIB_PATH selects a side build, DCS_POSE_FAST=0 the general kernel k_pose_opt,
+DCS_POSE_EXACT_EDGE=1 the build of k_pose_opt2 with the oracle's per-edge arithmetic.
 Random batches as scratch/stress_parity2.py draws them (2..19 frames, 10..599 observations per frame, 0 / 10 / 30 % outliers) plus larger
 frames (600..1900). Reports: batches with any round apart, (frame, round) entries apart, largest pose difference, outlier-flag flips."""
 import os, sys, numpy as np
@@ -22,6 +23,6 @@ for i in range(n):
     frames += got["poses"].shape[0]
     flips += int(np.sum(got["outlier"] != exp["outlier"]))
     dmax = max(dmax, float(np.abs(got["poses"] - exp["poses"]).max()))
-print("%s DCS_POSE_FAST=%s: %d batches (%d frames): %d batches with a round apart (%.1f %%), %d of %d (frame, round) counts apart (%.2f %%), %d by more than one, %d outlier flags differ, largest pose difference %.2e"
-      % (os.path.basename(os.path.dirname(os.environ.get("DCS_LIB_PATH", "default/lib"))), os.environ.get("DCS_POSE_FAST", "1"), batches, frames, bad_batches, 100.0 * bad_batches / batches,
+print("%s DCS_POSE_FAST=%s DCS_POSE_EXACT_EDGE=%s: %d batches (%d frames): %d batches with a round apart (%.1f %%), %d of %d (frame, round) counts apart (%.2f %%), %d by more than one, %d outlier flags differ, largest pose difference %.2e"
+      % (os.path.basename(os.path.dirname(os.environ.get("DCS_LIB_PATH", "default/lib"))), os.environ.get("DCS_POSE_FAST", "1"), os.environ.get("DCS_POSE_EXACT_EDGE", "0"), batches, frames, bad_batches, 100.0 * bad_batches / batches,
          bad_entries, entries, 100.0 * bad_entries / entries, two_apart, flips, dmax))

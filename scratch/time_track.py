@@ -23,4 +23,4 @@ for nf in (1, 16):
     r = pt.track()
     out[nf] = round(med(pt.track) / nf * 1e3, 4)
     if nf == 1: edges = int((r[0]["point_of_feature"] != -1).sum())
-print("DCS_POSE_FAST=%s edges(frame 0)=%d ms per frame: batch 1 %.4f, batch 16 %.4f" % (os.environ.get("DCS_POSE_FAST", "1"), edges, out[1], out[16]))
+print("DCS_POSE_FAST=%s DCS_POSE_EXACT_EDGE=%s edges(frame 0)=%d ms per frame: batch 1 %.4f, batch 16 %.4f" % (os.environ.get("DCS_POSE_FAST", "1"), os.environ.get("DCS_POSE_EXACT_EDGE", "0"), edges, out[1], out[16]))

@@ -274,10 +274,18 @@ def test_global_bundle_adjustment_vs_oracle(pkg, oracle, synth, robust, iters):
         assert exp["chi2_trace"][0] > rob["chi2_trace"][0]
 
 
+@pytest.fixture(params=[0, 1], ids=["composed transform", "oracle's per-edge arithmetic"])
+def exact_edge(request, pkg):
+    """both builds of k_pose_opt2 (option DCS_POSE_EXACT_EDGE: 0 = the default, an edge's point through the composed world -> camera matrix;
+    1 = through the oracle's own operations, NOTES R6.3)"""
+    with pkg.abi.options(DCS_POSE_EXACT_EDGE=request.param):
+        yield request.param
+
+
 @pytest.mark.parametrize("seed,obs", [(8, 350), (21, 350), (22, 120), (23, 700), (24, 1000), (25, 1900), (26, 2048), (27, 2300)])
-def test_pose_optimization_vs_oracle(pkg, oracle, synth, seed, obs):
+def test_pose_optimization_vs_oracle(pkg, oracle, synth, seed, obs, exact_edge):
     """Optimizer::PoseOptimization batched on the GPU (one workgroup per frame, LM loop on the device) vs the oracle:
-    same outlier flags, iteration counts and inlier counts; poses to rounding. Eight seeds; 120 .. 2 048 observations per frame = 1 .. 16
+    same outlier flags, iteration counts and inlier counts; poses to rounding. Eight seeds; 120 .. 2 048 observations per frame = 1 .. 8
     register slots per lane of k_pose_opt2, 2 300 = k_pose_opt (the general kernel) beside it in one call."""
     pb = synth.pose_problem(n_frames=24 if obs <= 1000 else 8, obs_per_frame=obs, seed=seed)
     prob = dict(pb)
@@ -323,7 +331,7 @@ def test_global_bundle_adjustment_at_map_size_vs_oracle(pkg, oracle, synth):
     _compare(got, exp, pb)
 
 
-def test_pose_optimization_four_camera_rig_with_one_crowded_camera(pkg, oracle, synth):
+def test_pose_optimization_four_camera_rig_with_one_crowded_camera(pkg, oracle, synth, exact_edge):
     """k_pose_opt2 keeps a camera's edges in the registers of the waves the camera gets: a four-camera rig with more than 768 edges on ONE
     camera does not fit (each camera has one wave of 64 lanes x 12 slots), the kernel declines the frame and k_pose_opt takes it in the same call. Frames of the
     same call that do fit stay with k_pose_opt2; both against the oracle. Cameras 2, 3 are copies of camera 1 (same model, other id)."""
@@ -358,7 +366,7 @@ def test_pose_optimization_four_camera_rig_with_one_crowded_camera(pkg, oracle, 
     assert (got["n_inliers"][2:] > 100).all()
 
 
-def test_pose_optimization_dual_rig_at_every_uneven_split_of_the_largest_frame(pkg, oracle, synth):
+def test_pose_optimization_dual_rig_at_every_uneven_split_of_the_largest_frame(pkg, oracle, synth, exact_edge):
     """k_pose_opt2 gives the rig's two cameras 2 + 2 or 3 + 1 waves; the dual rig must fit its 12 register slots per lane at ANY split of a
     2 048-edge frame (worst cases: one third / two thirds, where the split changes, and a frame seen by one camera only). No frame may fall
     back to k_pose_opt (DCS_POSE_FAST stays on; n_iters etc. are compared with the oracle like everywhere)."""

@@ -19,12 +19,14 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ba8 -- py
 # as a headline-only run, the emitting FAST launch by launch (in the pipeline and alone, emitting FAST and resize chain), k_pose_opt2's in-kernel timeline
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/track -- python $R/scratch/time_track.py > $O/track.log 2>&1
 DCS_POSE_FAST=0 timeout 300 python $R/scratch/time_track.py >> $O/track.log 2>&1
+DCS_POSE_EXACT_EDGE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/track_exact -- python $R/scratch/time_track.py >> $O/track.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -- python $R/bench.py $HEAD --no-two-lanes --width 1280 --height 720 --nfeatures 2000 --pairs 64 > $O/bench_c3_shape.json 2>/dev/null
 ( cd $R && bash scratch/emit_trace.sh ) > $O/fast_emit_by_level.txt 2>&1
 # round 6: k_pose_opt2's in-kernel timeline (side build -DDCS_POSE_PROF=20, tools/pose_timeline.py), the windows beyond 42 free poses (scratch/time_ba_large.py) and
 # a PMC pass of the tracking chain alone (k_pose_opt2's instruction counts)
 if [ -f $R/scratch/ab/pose_prof/libdcs_hip.so ]; then
-  ( DCS_LIB_PATH=$R/scratch/ab/pose_prof/libdcs_hip.so timeout 120 python $R/tools/pose_timeline.py 2000 2000; DCS_LIB_PATH=$R/scratch/ab/pose_prof/libdcs_hip.so timeout 120 python $R/tools/pose_timeline.py 4000 4000 ) 2>/dev/null | grep -v amdgpu > $O/pose_timeline.txt
+  ( export DCS_LIB_PATH=$R/scratch/ab/pose_prof/libdcs_hip.so; timeout 120 python $R/tools/pose_timeline.py 2000 2000; timeout 120 python $R/tools/pose_timeline.py 4000 4000
+    echo "---- DCS_POSE_EXACT_EDGE=1"; DCS_POSE_EXACT_EDGE=1 timeout 120 python $R/tools/pose_timeline.py 2000 2000; DCS_POSE_EXACT_EDGE=1 timeout 120 python $R/tools/pose_timeline.py 4000 4000 ) 2>/dev/null | grep -v amdgpu > $O/pose_timeline.txt
 fi
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ba_large -- python $R/scratch/time_ba_large.py 3 > $O/ba_large.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA --output-format csv -d $O/pmc_track -- python $R/scratch/time_track.py 2000 2000 10 > /dev/null 2>&1
@@ -37,8 +39,8 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BU
 cd $R
 python scratch/pmc_to_json.py $O/pmc_counters.json 256 640 480 1000 1 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_mfma | tail -40
 python scratch/pmc_sum.py $O/pmc_sq > $O/pmc_sq_summary.txt
-for d in stats headline solo solo_separate_blur ba1 ba8 track c3 ba_large; do cp $(ls $O/$d/*/*kernel_stats.csv | head -1) $O/${d}_kernel_stats.csv; done
-rm -rf $O/stats $O/headline $O/solo $O/solo_separate_blur $O/ba1 $O/ba8 $O/track $O/c3 $O/ba_large $O/pmc_track $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_mfma
+for d in stats headline solo solo_separate_blur ba1 ba8 track track_exact c3 ba_large; do cp $(ls $O/$d/*/*kernel_stats.csv | head -1) $O/${d}_kernel_stats.csv; done
+rm -rf $O/stats $O/headline $O/solo $O/solo_separate_blur $O/ba1 $O/ba8 $O/track $O/track_exact $O/c3 $O/ba_large $O/pmc_track $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_mfma
 echo "== headline"; python scratch/kstats.py $O/headline_kernel_stats.csv 16
 echo "== solo"; python scratch/kstats.py $O/solo_kernel_stats.csv 16
 echo "== ba"; python scratch/kstats.py $O/ba1_kernel_stats.csv 12

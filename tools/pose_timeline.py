@@ -25,7 +25,7 @@ fn = lib.dcs_debug_pose_prof
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 assert fn(buf) == 0
 t = np.array(list(buf), dtype=np.uint64).reshape(4, 16).astype(np.int64)
-names = ["sweep", "reduce", "adjoint map + partials out", "barrier", "totals in", "LM rule", "solve", "exp map + compose"]
+names = ["(compose +) sweep", "reduce", "adjoint map + partials out", "barrier", "totals in", "LM rule", "solve", "exp map"]
 span_clk = (t[:, 10] - t[:, 9]).max(); span_rt = (t[:, 12] - t[:, 11]).max()
 print("frame 0: %d edges, %d slots per lane (wave 0), %d passes; kernel span %d shader ticks = %.1f us on the 100 MHz clock -> %.0f MHz; %.0f ticks per pass"
       % (t[0, 14], t[0, 15], t[0, 13], span_clk, span_rt / 100.0, span_clk / (span_rt / 100.0), span_clk / max(1, t[0, 13])))
