@@ -2870,6 +2870,18 @@ struct BaContext {
         base = nullptr; cap = 0; h_stage = nullptr; stage_cap = 0; h_words = nullptr; words_cap = 0; stream = nullptr; device = -1;
     }
     ~BaContext() { release(); }
+    // the pinned staging image alone, before the lists (and so the arena's size) exist: the caller's arrays are copied into it while the lists are built
+    int prepare_stage(size_t stage_bytes)
+    {
+        drain();
+        int dev = 0;
+        DCS_HIP(hipGetDevice(&dev));
+        if (device != dev) release();
+        device = dev;
+        if (h_stage && stage_cap < stage_bytes) { (void)hipHostFree(h_stage); h_stage = nullptr; stage_cap = 0; }
+        if (!h_stage) { DCS_HIP(hipHostMalloc((void**)&h_stage, stage_bytes, hipHostMallocDefault)); stage_cap = stage_bytes; }
+        return DCS_OK;
+    }
     int prepare(size_t arena_bytes, size_t stage_bytes, size_t n_words)
     {
         drain();                                            // queued-ahead steps of the previous call (see tail_pending)
@@ -3008,8 +3020,6 @@ static HostPool& host_pool() { static HostPool* p = new HostPool; return *p; }
 
 struct Round {                                  // structure of one optimisation round (buildIndexMapping + buildStructure)
     std::vector<int32_t> pose_idx, pt_off, pt_edges, pt_pi, ps_off, ps_edges, pair_ij;
-    struct Key { int32_t idx, edge; };              // (free-pose index or -1, edge id): scratch of build_round, kept for its capacity
-    std::vector<Key> keys;
     std::vector<int32_t> cur_pt, cur_ps;
     std::vector<uint8_t> pose_act;
     int np = 0, n = 0, n_pad = 0, n_pairs = 0, n_active = 0;
@@ -3027,72 +3037,69 @@ int build_round(const dcs_ba_problem* pb, Round& r)
     const int32_t* __restrict__ e_pose = pb->edge_pose;
     const int32_t* __restrict__ e_point = pb->edge_point;
     r.n_active = E;                                           // round 0 structure: every edge (the second round only masks edges)
-    r.pose_idx.assign(P, -1);
-    r.pose_act.assign(P, 0);
-    // (the range check of every edge rides on this first pass -- one pass per problem on the worker that builds its lists, instead of a serial
-    // loop over the whole batch in front of everything: 0.1 ms of a 2.9-ms batch of 8)
+    // ONE pass over the edges for the range check, the edges per point and the edges per pose (by pose id: which poses are free is only known
+    // once every edge has named its pose); then the free poses' counts are packed. (Round 6: the check, the activity flags and the two counts
+    // were two passes, and the sorted runs went through a scratch array: 0.086 of a 1.67-ms C4 solve on the host before the first upload.)
+    r.pt_off.assign(L + 1, 0);
+    std::vector<int32_t>& pose_cnt = r.cur_ps;                // (scratch: P counts now, the free poses' write cursors below)
+    pose_cnt.assign((size_t)P + 1, 0);
     {
         const int32_t* __restrict__ e_cam = pb->edge_cam;
         const int n_cams = pb->n_cams;
+        int32_t* __restrict__ pt_cnt = r.pt_off.data() + 1;
+        int32_t* __restrict__ ps_cnt = pose_cnt.data();
         for (int e = 0; e < E; ++e) {
-            const int ps = e_pose[e];
-            if ((unsigned)ps >= (unsigned)P || (unsigned)e_point[e] >= (unsigned)L || (unsigned)e_cam[e] >= (unsigned)n_cams) return -2 - e;
-            r.pose_act[ps] = 1;
+            const int ps = e_pose[e], pt = e_point[e];
+            if ((unsigned)ps >= (unsigned)P || (unsigned)pt >= (unsigned)L || (unsigned)e_cam[e] >= (unsigned)n_cams) return -2 - e;
+            ++pt_cnt[pt];
+            ++ps_cnt[ps];
         }
     }
+    r.pose_idx.assign(P, -1);
+    r.pose_act.assign(P, 0);
     r.np = 0;
-    for (int p = 0; p < P; ++p) if (r.pose_act[p] && !pb->pose_fixed[p]) r.pose_idx[p] = r.np++;
+    r.ps_off.assign(1, 0);
+    for (int p = 0; p < P; ++p) {
+        r.pose_act[p] = pose_cnt[p] > 0;
+        if (pose_cnt[p] > 0 && !pb->pose_fixed[p]) { r.pose_idx[p] = r.np++; r.ps_off.push_back(r.ps_off.back() + pose_cnt[p]); }
+    }
     const int np = r.np;
     const int32_t* __restrict__ pose_idx = r.pose_idx.data();
     r.n = np * 6; r.n_pad = ((r.n + kNB - 1) / kNB) * kNB;
-    // point -> edges and free pose -> edges (edge id order) in one counting pass
-    r.pt_off.assign(L + 1, 0);
-    r.ps_off.assign(np + 1, 0);
-    for (int e = 0; e < E; ++e) {
-        ++r.pt_off[e_point[e] + 1];
-        const int pi = pose_idx[e_pose[e]];
-        if (pi >= 0) ++r.ps_off[pi + 1];
-    }
     for (int l = 0; l < L; ++l) r.pt_off[l + 1] += r.pt_off[l];
-    for (int i = 0; i < np; ++i) r.ps_off[i + 1] += r.ps_off[i];
     r.pt_edges.resize(E); r.pt_pi.resize(E);
     r.ps_edges.resize(r.ps_off[np]);
-    using Key = Round::Key;
-    std::vector<Key>& keys = r.keys;
-    keys.resize((size_t)E);
+    // A point's run is ordered by (free-pose index, edge id), fixed poses (index -1) first: the order the kernels sum in. No sort: the edges of
+    // fixed poses go into the runs first, in edge order, while the free poses' edges are bucketed by pose (ps_edges: edge order inside a pose);
+    // then the buckets are emptied into the runs pose by pose. A repeated (pose, point) pair shows up as two neighbours with the same index
+    // (free poses) or, in the short fixed prefix, by comparing pose ids pairwise.
+    size_t entries = 0;
     {
         std::vector<int32_t>& cur_pt = r.cur_pt;
         std::vector<int32_t>& cur_ps = r.cur_ps;
         cur_pt.assign(r.pt_off.begin(), r.pt_off.end() - 1); cur_ps.assign(r.ps_off.begin(), r.ps_off.end() - 1);
+        int32_t* __restrict__ pe = r.pt_edges.data();
+        int32_t* __restrict__ pp = r.pt_pi.data();
+        int32_t* __restrict__ ps_edges = r.ps_edges.data();
+        int32_t* __restrict__ cpt = cur_pt.data();
         for (int e = 0; e < E; ++e) {
             const int pi = pose_idx[e_pose[e]];
-            keys[cur_pt[e_point[e]]++] = Key{pi, e};
-            if (pi >= 0) r.ps_edges[cur_ps[pi]++] = e;
+            if (pi >= 0) ps_edges[cur_ps[pi]++] = e;
+            else { const int k = cpt[e_point[e]]++; pe[k] = e; pp[k] = -1; }
         }
-    }
-    // per point: ONE insertion sort of its (few) edges by (pose index, edge id) -- the order the kernels sum in (fixed poses first:
-    // index -1; the counting pass already left them in edge order) -- and the duplicate test on the sorted run: equal indices are
-    // adjacent, the fixed prefix is compared pairwise by pose id (a handful of entries). A point seen by f free poses adds one entry to
-    // f (f + 1) / 2 pair lists.
-    size_t entries = 0;
-    for (int l = 0; l < L; ++l) {
-        const int k0 = r.pt_off[l], k1 = r.pt_off[l + 1];
-        Key* __restrict__ kk = keys.data() + k0;
-        const int nk = k1 - k0;
-        for (int k = 1; k < nk; ++k) {
-            const Key key = kk[k];
-            int j = k;
-            while (j > 0 && kk[j - 1].idx > key.idx) { kk[j] = kk[j - 1]; --j; }      // stable: equal indices keep their edge order
-            kk[j] = key;
+        for (int l = 0; l < L; ++l) {                         // the fixed prefix of every run: duplicates by pose id
+            const int k0 = r.pt_off[l], nf = cpt[l] - k0;
+            for (int a = 1; a < nf; ++a)
+                for (int b2 = 0; b2 < a; ++b2) if (e_pose[pe[k0 + a]] == e_pose[pe[k0 + b2]]) return pe[k0 + a];
+            const size_t f = (size_t)(r.pt_off[l + 1] - cpt[l]);
+            entries += f * (f + 1) / 2;
         }
-        int n_fixed = 0;
-        while (n_fixed < nk && kk[n_fixed].idx < 0) ++n_fixed;
-        for (int a = 1; a < n_fixed; ++a)
-            for (int b2 = 0; b2 < a; ++b2) if (e_pose[kk[a].edge] == e_pose[kk[b2].edge]) return kk[a].edge;
-        for (int k = n_fixed + 1; k < nk; ++k) if (kk[k].idx == kk[k - 1].idx) return kk[k].edge;
-        for (int k = 0; k < nk; ++k) { r.pt_edges[k0 + k] = kk[k].edge; r.pt_pi[k0 + k] = kk[k].idx; }
-        const size_t f = (size_t)(nk - n_fixed);
-        entries += f * (f + 1) / 2;
+        for (int pi = 0; pi < np; ++pi)
+            for (int q = r.ps_off[pi], q1 = r.ps_off[pi + 1]; q < q1; ++q) {
+                const int e = ps_edges[q], l = e_point[e], k = cpt[l]++;
+                if (k > r.pt_off[l] && pp[k - 1] == pi) return e;                  // the same free pose twice on this point
+                pe[k] = e; pp[k] = pi;
+            }
     }
     r.n_pair_entries = entries;
     // EVERY pose pair (i1 <= i2) gets a workgroup of k_schur; one without a common point finds an empty list and leaves its block of S
@@ -3212,8 +3219,73 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     if ((int)tl_rounds.size() < NB) tl_rounds.resize(NB);
     std::vector<Round>& rounds = tl_rounds;
     std::vector<int> dup(NB, -1);
+    // The arrays that go up as the caller gave them (estimates, edges, observations, cameras) lie at the FRONT of the upload image, every problem's
+    // before any problem's lists: their places depend on the problem sizes alone, so the worker that builds a problem's lists also copies its arrays
+    // into the pinned image -- 0.79 MB per C4 problem, 0.25 ms of a 3-ms batch of 8 when one thread copied them after the builds. The pinned
+    // buffer is sized beforehand for the worst case of the lists (every pose free, every edge in a pose list).
+    // Their LISTS follow, in slots sized for the worst case (every pose free, every edge in a pose list: a few per cent more than a round needs),
+    // so that those places do not wait for the builds either: a worker puts its lists into the image as soon as it has built them.
+    auto raw_layout = [&](Carver& c, int i, BaProb& q) {
+        const dcs_ba_problem* pb = problems[live[i]];
+        const size_t P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+        q.poses[0] = c.get<double>(7 * P); q.points[0] = c.get<double>(3 * L);
+        q.epose = c.get<int32_t>(E); q.epoint = c.get<int32_t>(E); q.ecam = c.get<int32_t>(E);
+        q.obs = c.get<double>(2 * E); q.w = c.get<double>(E); q.active = c.get<uint8_t>(E);
+        q.cams = c.get<DCams>(1);
+    };
+    auto list_layout = [&](Carver& c, int i, BaProb& q) {
+        const dcs_ba_problem* pb = problems[live[i]];
+        const size_t P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+        q.pose_idx = c.get<int32_t>(P); q.pt_off = c.get<int32_t>(L + 1); q.pt_edges = c.get<int32_t>(E); q.pt_pi = c.get<int32_t>(E);
+        q.ps_off = c.get<int32_t>(P + 1); q.ps_edges = c.get<int32_t>(E);
+        q.pair_ij = c.get<int32_t>(P * (P + 1));
+    };
+    BaContext& ctx = ba_context();
+    std::vector<BaProb> at(NB);                              // the same places as offsets into the image (Carver with a null base)
     {
-        auto work = [&](int i) { dup[i] = build_round(problems[live[i]], rounds[i]); };
+        Carver c0;
+        size_t dl_bound = 512 + sizeof(BaCtl) * (size_t)NB;
+        for (int i = 0; i < NB; ++i) raw_layout(c0, i, at[i]);
+        for (int i = 0; i < NB; ++i) {
+            list_layout(c0, i, at[i]);
+            const dcs_ba_problem* pb = problems[live[i]];
+            const size_t P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+            dl_bound += sizeof(double) * (7 * P + 3 * L + E) + 2 * E + 5 * 256;                          // out_poses, out_points, chi2, flag, level1
+        }
+        const size_t stage_bound = c0.off + sizeof(BaProb) * (size_t)NB + 1024 + dl_bound;
+        if ((rc = ctx.prepare_stage(stage_bound))) return rc;
+    }
+    char* const hs0 = ctx.h_stage;
+    {
+        auto work = [&](int i) {
+            const dcs_ba_problem* pb = problems[live[i]];
+            const BaProb& a = at[i];
+            auto img = [&](const void* off) { return hs0 + reinterpret_cast<size_t>(off); };
+            const size_t P = pb->n_poses, L = pb->n_points, E = pb->n_edges;
+            memcpy(img(a.poses[0]), pb->poses, sizeof(double) * 7 * P);
+            memcpy(img(a.points[0]), pb->points, sizeof(double) * 3 * L);
+            memcpy(img(a.epose), pb->edge_pose, sizeof(int32_t) * E);
+            memcpy(img(a.epoint), pb->edge_point, sizeof(int32_t) * E);
+            memcpy(img(a.ecam), pb->edge_cam, sizeof(int32_t) * E);
+            memcpy(img(a.obs), pb->obs, sizeof(double) * 2 * E);
+            memcpy(img(a.w), pb->inv_sigma2, sizeof(double) * E);
+            memset(img(a.active), 1, E);
+            DCams* cams = reinterpret_cast<DCams*>(img(a.cams));
+            memset(cams, 0, sizeof(DCams));
+            for (int c = 0; c < pb->n_cams; ++c) {
+                DCam& d = cams->c[c];
+                const dcs_ba_camera& sc = pb->cams[c];
+                d.fx = sc.fx; d.fy = sc.fy; d.cx = sc.cx; d.cy = sc.cy;
+                d.t[0] = sc.ext[0]; d.t[1] = sc.ext[1]; d.t[2] = sc.ext[2];
+                d.q[0] = sc.ext[3]; d.q[1] = sc.ext[4]; d.q[2] = sc.ext[5]; d.q[3] = sc.ext[6];
+                memcpy(d.adj, sc.adj, sizeof(d.adj));
+            }
+            const Round& r = rounds[i];
+            if ((dup[i] = build_round(pb, rounds[i])) != -1) return;
+            auto put = [&](const int32_t* off, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(img(off), v.data(), sizeof(int32_t) * v.size()); };
+            put(a.pose_idx, r.pose_idx); put(a.pt_off, r.pt_off); put(a.pt_edges, r.pt_edges); put(a.pt_pi, r.pt_pi); put(a.ps_off, r.ps_off); put(a.ps_edges, r.ps_edges);
+            put(a.pair_ij, r.pair_ij);
+        };
         if (NB == 1) work(0);
         else host_pool().run(NB, work);            // persistent workers: creating 8 threads per call cost more than the lists themselves
         for (int i = 0; i < NB; ++i) {                       // build_round: -1 fine, e >= 0 a duplicate at edge e, -2 - e edge e out of range
@@ -3246,7 +3318,6 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     BaProb* d_probs = nullptr; BaCtl* d_ctls = nullptr;
     // groups of problems = contiguous ranges [g_begin[g], g_begin[g + 1]) of the live list, one stream each. The event timing
     // of dcs_ba_timing brackets launches on ONE stream, so a timed call runs as a single group.
-    BaContext& ctx = ba_context();
     // Two groups by default: alone, 4 groups of 2 are as fast (18.8 k LM iterations/s for 8 C4 problems, 17.5 k with one group), but
     // next to a busy front end (config C5) four queues of short kernels lose against its long ones (9 k vs 16 k iterations/s).
     int G = NB >= 4 ? 2 : 1;
@@ -3256,6 +3327,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     for (int g = 0; g <= G; ++g) g_begin[g] = (int)((long long)NB * g / G);
     unsigned* d_grid_ticket[BaContext::kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
     auto layout = [&](Carver& c, Regions& rg) {
+        for (int i = 0; i < NB; ++i) raw_layout(c, i, hp[i]);           // (first, and by the same function as the places the workers copied to)
         for (int i = 0; i < NB; ++i) {
             const dcs_ba_problem* pb = problems[live[i]];
             const Round& r = rounds[i];
@@ -3266,14 +3338,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
             q.use_reg = (r.n <= 256 && !force_blocked) ? 1 : 0;
             q.iters[0] = pb->iters1; q.iters[1] = pb->iters2; q.robust0 = pb->huber_delta > 0.0 ? 1 : 0; q.pad = 0;   // BundleAdjustment(bRobust = false): no kernel
             q.delta = pb->huber_delta; q.chi2_th = pb->chi2_th;
-            q.poses[0] = c.get<double>(7 * P); q.points[0] = c.get<double>(3 * L);
-            q.epose = c.get<int32_t>(E); q.epoint = c.get<int32_t>(E); q.ecam = c.get<int32_t>(E);
-            q.obs = c.get<double>(2 * E); q.w = c.get<double>(E); q.active = c.get<uint8_t>(E);
-            q.pose_idx = c.get<int32_t>(P); q.pt_off = c.get<int32_t>(L + 1); q.pt_edges = c.get<int32_t>(r.pt_edges.size()); q.pt_pi = c.get<int32_t>(r.pt_pi.size());
-            q.ps_off = c.get<int32_t>(r.ps_off.size()); q.ps_edges = c.get<int32_t>(r.ps_edges.size());
-            q.pair_ij = c.get<int32_t>(r.pair_ij.size());
+            list_layout(c, i, q);
             q.pt_words = (int)(((L + 31) / 32 + 3) & ~(size_t)3);      // rows are read 16 bytes at a time
-            q.cams = c.get<DCams>(1);
         }
         d_probs = c.get<BaProb>(NB);
         rg.upload_end = c.off;
@@ -3329,34 +3395,13 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     auto stage = [&](const void* dptr) { return hs + (reinterpret_cast<const char*>(dptr) - ctx.base); };
     auto landed = [&](const void* dptr) { return h_dl + (reinterpret_cast<const char*>(dptr) - (ctx.base + rg.dl_begin)); };
 
-    // ---- one staging image, one copy (threads do not help here: the copies are short and the pinned buffer is one stream of writes)
-    for (int i = 0; i < NB; ++i) {
-        const dcs_ba_problem* pb = problems[live[i]];
-        const Round& r = rounds[i];
-        const BaProb& q = hp[i];
-        const size_t P = q.P, L = q.L, E = q.E;
-        memcpy(stage(q.poses[0]), pb->poses, sizeof(double) * 7 * P);
-        memcpy(stage(q.points[0]), pb->points, sizeof(double) * 3 * L);
-        memcpy(stage(q.epose), pb->edge_pose, sizeof(int32_t) * E);
-        memcpy(stage(q.epoint), pb->edge_point, sizeof(int32_t) * E);
-        memcpy(stage(q.ecam), pb->edge_cam, sizeof(int32_t) * E);
-        memcpy(stage(q.obs), pb->obs, sizeof(double) * 2 * E);
-        memcpy(stage(q.w), pb->inv_sigma2, sizeof(double) * E);
-        memset(stage(q.active), 1, E);
-        auto put = [&](const int32_t* d, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage(d), v.data(), sizeof(int32_t) * v.size()); };
-        put(q.pose_idx, r.pose_idx); put(q.pt_off, r.pt_off); put(q.pt_edges, r.pt_edges); put(q.pt_pi, r.pt_pi); put(q.ps_off, r.ps_off); put(q.ps_edges, r.ps_edges);
-        put(q.pair_ij, r.pair_ij);
-        DCams* cams = reinterpret_cast<DCams*>(stage(q.cams));
-        memset(cams, 0, sizeof(DCams));
-        for (int c = 0; c < pb->n_cams; ++c) {
-            DCam& d = cams->c[c];
-            const dcs_ba_camera& sc = pb->cams[c];
-            d.fx = sc.fx; d.fy = sc.fy; d.cx = sc.cx; d.cy = sc.cy;
-            d.t[0] = sc.ext[0]; d.t[1] = sc.ext[1]; d.t[2] = sc.ext[2];
-            d.q[0] = sc.ext[3]; d.q[1] = sc.ext[4]; d.q[2] = sc.ext[5]; d.q[3] = sc.ext[6];
-            memcpy(d.adj, sc.adj, sizeof(d.adj));
+    // ---- the table of the problems completes the staging image (the workers have filled the rest), then ONE copy
+    if (hs != hs0 || rg.upload_end + dl_bytes > ctx.stage_cap) { set_error("BA staging image: bound exceeded"); return DCS_ERR_HIP; }    // (cannot happen: prepare_stage's bound)
+    for (int i = 0; i < NB; ++i)
+        if ((size_t)(reinterpret_cast<const char*>(hp[i].poses[0]) - ctx.base) != reinterpret_cast<size_t>(at[i].poses[0]) ||
+            (size_t)(reinterpret_cast<const char*>(hp[i].pair_ij) - ctx.base) != reinterpret_cast<size_t>(at[i].pair_ij)) {
+            set_error("BA staging image: layout changed between the two passes"); return DCS_ERR_HIP;
         }
-    }
     memcpy(stage(d_probs), hp.data(), sizeof(BaProb) * NB);
     int* const h_words = ctx.h_words;                   // [2g] last finished step of group g, [2g + 1] its finished problems, [16 + i] stop word of problem i
     for (int k = 0; k < 16; ++k) h_words[k] = 0;
