@@ -3614,7 +3614,10 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // of the download (75 us of a 2 ms C4 solve at two steps ahead). One step ahead (DCS_BA_LOOKAHEAD=1) measured +1 % for one C4 problem
     // and nothing for a batch; two stays the default because small problems (a step of 50 us) need the slack: enqueueing a step
     // costs the host 30 - 50 us per group.
-    const int kLookahead = std::max(1, (int)opt(OPT_BA_LOOKAHEAD));
+    // (0 = by batch size. Round 6, after the host side stopped dominating a batch: the steps of four or more problems are long enough -- 200 us
+    // for eight C4 problems against 80 us of enqueueing for two groups -- that ONE step ahead keeps the queues fed, and the call behind this one
+    // waits for one no-op step less: 2.86 -> 2.77 ms per batch of 8. One problem: 1.61 vs 1.62 ms, stays at two.)
+    const int kLookahead = opt(OPT_BA_LOOKAHEAD) > 0 ? (int)opt(OPT_BA_LOOKAHEAD) : (NB >= 4 ? 1 : 2);
     auto load_words = [&](const Group& gr, int& step_done, int& n_done) {
         const unsigned long long w = __atomic_load_n(reinterpret_cast<const unsigned long long*>(gr.words), __ATOMIC_ACQUIRE);   // {done : step}, one word
         step_done = (int)(unsigned)w;

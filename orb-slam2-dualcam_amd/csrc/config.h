@@ -35,7 +35,7 @@ namespace dcs {
     X(BA_PAIRS_SIDE,               1)   /* 0: pose-pair lists built in front of the first step instead of beside it */                   \
     X(BA_FUSED_UPDATE,             1)   /* 0: k_solve_update + k_error<1> as two launches */                                             \
     X(BA_GRAPH,                    0)   /* 1: an LM step replayed as an executable graph */                                              \
-    X(BA_LOOKAHEAD,                2)   /* LM steps enqueued ahead of the progress word */                                               \
+    X(BA_LOOKAHEAD,                0)   /* LM steps enqueued ahead of the progress word; 0 = auto (2, or 1 for batches of four or more problems) */ \
     X(BA_DL_STREAM,                1)   /* 0: results come down on the solver's stream */                                                \
 
 enum Opt : int {

@@ -33,7 +33,7 @@ def _run(pkg, synth):
 def test_ba_opt_in_paths_equal_default(pkg, synth):
     base = _run(pkg, synth)
     # (round 6: the four-launch step DCS_BA_FRONT -- k_front + the linearising trial kernel, bit-identical and slower -- was deleted with its option)
-    for extra in ({"DCS_BA_GRAPH": 1}, {"DCS_BA_LOOKAHEAD": 1}, {"DCS_BA_DL_STREAM": 0}, {"DCS_BA_GROUPS": 1}, {"DCS_BA_GROUPS": 4}, {"DCS_BA_PAIRS_SIDE": 0},
+    for extra in ({"DCS_BA_GRAPH": 1}, {"DCS_BA_LOOKAHEAD": 1}, {"DCS_BA_LOOKAHEAD": 2}, {"DCS_BA_LOOKAHEAD": 3}, {"DCS_BA_DL_STREAM": 0}, {"DCS_BA_GROUPS": 1}, {"DCS_BA_GROUPS": 4}, {"DCS_BA_PAIRS_SIDE": 0},
                   {"DCS_BA_SCHUR_WAVE": 0}, {"DCS_BA_SCHUR_WAVE": 2}, {"DCS_BA_SCHUR_WAVE": 2, "DCS_BA_GRAPH": 1}):
         with pkg.abi.options(**extra):
             got = _run(pkg, synth)
