@@ -3657,6 +3657,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
     // instead of behind those 2 x 8 launches (~75 us of a 2 ms C4 solve). DCS_BA_DL_STREAM=0, or a batch that ran into max_steps,
     // takes the ordered path: the download behind everything on the solver's streams.
     const bool dl_own = opt(OPT_BA_DL_STREAM) != 0;
+    const auto t_dl0 = now();
     if (dl_own && n_finished == G) {
         if (!ctx.dl) { const int rc_s = ctx.create_stream(&ctx.dl); if (rc_s) return rc_s; }
         DCS_HIP(hipMemcpyAsync(h_dl, ctx.base + rg.dl_begin, dl_bytes, hipMemcpyDeviceToHost, ctx.dl));
@@ -3672,6 +3673,7 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         ctx.tail_pending = false;                           // every group's queue was waited for: nothing is in flight
     }
     const float opt_ms = (float)ms_since(t_opt0);
+    const double dl_ms = ms_since(t_dl0);
     const BaCtl* h_ctls = reinterpret_cast<const BaCtl*>(landed(d_ctls));
     if (timing) {                                         // only the steps in which at least one problem ran a trial
         int real = 0;
@@ -3699,8 +3701,8 @@ int dcs_ba_local_batch(int n_problems, const dcs_ba_problem* const* problems, co
         res->gpu_ms = opt_ms;
     }
     if (trace_t)
-        fprintf(stderr, "[dcs_ba] %d problems, total %.3f ms: build_round %.3f, layout + staging %.3f, optimise %.3f (%d steps enqueued, host waited %.3f)\n",
-                NB, ms_since(t_call0), t_build, ms_since(t_call0) - t_build - opt_ms, (double)opt_ms, steps, t_wait);
+        fprintf(stderr, "[dcs_ba] %d problems, total %.3f ms: build_round %.3f, layout + staging %.3f, optimise %.3f (%d steps enqueued, host waited %.3f, download %.3f)\n",
+                NB, ms_since(t_call0), t_build, ms_since(t_call0) - t_build - opt_ms, (double)opt_ms, steps, t_wait, dl_ms);
     return DCS_OK;
 }
 
