@@ -281,14 +281,17 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjFrameD f_arg, ProjQueri
 }
 
 // Parallel resolver with the same order-dependent result: thread = query, rounds until every query is final.
-// A query may only be decided once no EARLIER undecided query can still take one of its live candidates: per round every
-// undecided query posts its index with atomicMin on the features of its list (minq), and the queries that own all of their
-// live candidates (minq == own index) are decided together -- they cannot influence each other, and the earliest undecided
-// query always qualifies, so the rounds terminate. Windows of different map points rarely overlap, so a frame takes a
+// A query may be decided once no EARLIER undecided query can still take a candidate its decision depends on: per round every
+// undecided query posts its index with atomicMin on the features of its list (minq), and the queries that own their best live
+// candidate (and, under the ratio test, their second: minq == own index) are decided together -- two of them never take the same
+// feature, none can be overtaken by an earlier one, and the earliest undecided query always qualifies, so the rounds terminate.
+// (Round 6: "owns EVERY live candidate" before; and the first kResOwn queries of a thread now keep their state and their first kResReg
+// candidate words in registers -- a round touched global memory five times per query, 4.5 us a round, 76 us for a motion-model frame.) Windows of different map points rarely overlap, so a frame takes a
 // handful of rounds instead of one step per query. A query whose window overflowed its list is decided alone by wave 0
 // (re-walk of the window) when it becomes the earliest undecided one, and blocks the later ones until then.
 constexpr int kResT = 1024;
 constexpr int kResMaxN = 16384;                 // features whose minq / taken maps fit in LDS (80 KB)
+constexpr int kResOwn = 2, kResReg = 8;         // queries per thread whose state stays on chip (frames of up to 2 048 queries entirely): list length and base in registers, the first kResReg candidate words in LDS (64 KB)
 
 __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const ProjQueriesD& q, const unsigned* __restrict__ cand,
                                                       const int32_t* __restrict__ cand_n, uint8_t* __restrict__ state /* [n] 0 = undecided */,
@@ -301,17 +304,32 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
     // the workgroups of a frame's cameras then run side by side and touch disjoint entries of every array.
     __shared__ int s_minq[kResMaxN];
     __shared__ uint8_t s_taken[kResMaxN];
+    __shared__ unsigned s_w[kResReg][kResOwn * kResT];        // candidate word k of query qi < kResOwn * kResT at [k][qi]: a thread's reads fall on its own bank
     __shared__ int s_hist[kHisto], s_ind[3];
     __shared__ int s_first, s_firstovf, s_undecided, s_nm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int f_lo = cam_filter >= 0 ? f.cam_off[cam_filter] : 0, f_hi = cam_filter >= 0 ? f.cam_off[cam_filter + 1] : f.N;
     auto mine = [&](int qi) { return cam_filter < 0 || q.cam[qi] == cam_filter; };
     for (int i = f_lo + tid; i < f_hi; i += kResT) { s_taken[i] = f.taken[i]; query_of_feature[i] = -1; }
-    for (int i = tid; i < q.n; i += kResT) if (mine(i)) { match_of_query[i] = -1; state[i] = cand_n[i] == 0; }   // empty window / invalid: decided
+    // thread t owns the queries t, t + kResT, ...: the first kResOwn of them keep their state on chip (n = -1: none / not this camera's / decided),
+    // the rest -- frames with more than kResOwn * kResT queries -- in the global arrays as before
+    int own_n[kResOwn], own_base[kResOwn];
+#pragma unroll
+    for (int u = 0; u < kResOwn; ++u) {
+        const int qi = tid + u * kResT;
+        own_n[u] = -1; own_base[u] = 0;
+        if (qi < q.n && mine(qi)) {
+            match_of_query[qi] = -1;
+            const int n = cand_n[qi];
+            if (n > 0) { own_n[u] = n; own_base[u] = f.cam_off[q.cam[qi]]; }                 // (empty window / invalid: decided)
+        }
+        for (int k = 0; k < min(min(own_n[u], kProjCap), kResReg); ++k) s_w[k][qi] = cand[(size_t)qi * kProjCap + k];
+    }
+    for (int i = tid + kResOwn * kResT; i < q.n; i += kResT) if (mine(i)) { match_of_query[i] = -1; state[i] = cand_n[i] == 0; }
     if (tid < kHisto) s_hist[tid] = 0;
     if (tid == 0) s_nm = 0;
     __syncthreads();
-    auto decide = [&](int qi, unsigned best, unsigned second) {      // ORBmatcher.cc:606-613 / :1066-1084
+    auto decide = [&](int qi, int base, unsigned best, unsigned second) {      // ORBmatcher.cc:606-613 / :1066-1084 (the rotation histogram: after the rounds)
         int matched = -1;
         if (best != 0xFFFFFFFFu) {
             const int bestDist = (int)(best >> 23), bestLevel = (int)((best >> 19) & 15u);
@@ -319,61 +337,101 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
             const int bestLevel2 = second != 0xFFFFFFFFu ? (int)((second >> 19) & 15u) : -1;
             if (bestDist <= th_high &&
                 !(nn_ratio > 0.f && bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nn_ratio, (float)bestDist2)))
-                matched = f.cam_off[q.cam[qi]] + (int)(best & 0x7FFFFu);
+                matched = base + (int)(best & 0x7FFFFu);
         }
         match_of_query[qi] = matched;
-        if (matched >= 0) {
-            s_taken[matched] = 1; query_of_feature[matched] = qi;
-            atomicAdd(&s_nm, 1);
-            if (check_ori) {
-                float rot = __fsub_rn(q.angle[qi], f.kp_angle[matched]);
-                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                int bin = (int)roundf(__fmul_rn(rot, 1.0f / kHisto));
-                if (bin == kHisto) bin = 0;
-                bin_of_query[qi] = bin;
-                atomicAdd(&s_hist[bin], 1);
-            }
-        }
+        if (matched >= 0) { s_taken[matched] = 1; query_of_feature[matched] = qi; }
     };
     for (;;) {
         for (int i = f_lo + tid; i < f_hi; i += kResT) s_minq[i] = 0x7FFFFFFF;
         if (tid == 0) { s_first = 0x7FFFFFFF; s_firstovf = 0x7FFFFFFF; s_undecided = 0; }
         __syncthreads();
-        for (int qi = tid; qi < q.n; qi += kResT) {
+        auto post = [&](int qi, int base, unsigned w) { const int g = base + (int)(w & 0x7FFFFu); if (!s_taken[g]) atomicMin(&s_minq[g], qi); };
+        {   // the earliest undecided query: one atomic per wave (a wave's earliest is in its slot 0 if any lane has one there: the lowest such lane)
+            int mine_first = 0x7FFFFFFF;
+#pragma unroll
+            for (int u = kResOwn - 1; u >= 0; --u) if (own_n[u] >= 0) mine_first = tid + u * kResT;
+            const unsigned wf = wave_min_u32((unsigned)mine_first);
+            if (lane == 0 && wf != 0x7FFFFFFFu) atomicMin(&s_first, (int)wf);
+        }
+#pragma unroll
+        for (int u = 0; u < kResOwn; ++u) {
+            const int qi = tid + u * kResT, n = own_n[u];
+            if (n < 0) continue;
+            if (n > kProjCap) { atomicMin(&s_firstovf, qi); continue; }
+            {   // (loads first, all of them, then the tests, then the atomics: one LDS latency per stage instead of three per candidate)
+                unsigned w[kResReg]; int g[kResReg]; bool lv[kResReg];
+#pragma unroll
+                for (int k = 0; k < kResReg; ++k) w[k] = s_w[k][qi];
+#pragma unroll
+                for (int k = 0; k < kResReg; ++k) g[k] = k < n ? own_base[u] + (int)(w[k] & 0x7FFFFu) : f_lo;
+#pragma unroll
+                for (int k = 0; k < kResReg; ++k) lv[k] = !s_taken[g[k]] && k < n;
+#pragma unroll
+                for (int k = 0; k < kResReg; ++k) if (lv[k]) atomicMin(&s_minq[g[k]], qi);
+            }
+            for (int k = kResReg; k < n; ++k) post(qi, own_base[u], cand[(size_t)qi * kProjCap + k]);
+        }
+        for (int qi = tid + kResOwn * kResT; qi < q.n; qi += kResT) {
             if (!mine(qi) || state[qi]) continue;
             atomicMin(&s_first, qi);
             const int n = cand_n[qi];
             if (n > kProjCap) { atomicMin(&s_firstovf, qi); continue; }
             const int base = f.cam_off[q.cam[qi]];
-            for (int k = 0; k < n; ++k) {
-                const int g = base + (int)(cand[(size_t)qi * kProjCap + k] & 0x7FFFFu);
-                if (!s_taken[g]) atomicMin(&s_minq[g], qi);
-            }
+            for (int k = 0; k < n; ++k) post(qi, base, cand[(size_t)qi * kProjCap + k]);
         }
         __syncthreads();
         // both words are read HERE, between two barriers, by every thread: thread 0 resets them at the top of the next round
         // without a barrier in between, so a later read could see the reset value and desynchronise the barrier phases
         const int first = s_first, first_ovf = s_firstovf;
         if (first == 0x7FFFFFFF) break;                        // everything decided
-        for (int qi = tid; qi < q.n; qi += kResT) {
+        // the two smallest (dist, position) keys among the live candidates, then: final as soon as the candidates the decision READS cannot be
+        // taken before this query's turn -- the live set only shrinks, so the best live candidate stays the best if no earlier undecided query
+        // lists it, and with it the decision when there is no ratio test (SearchByProjectionOnCam); the ratio test also reads the second
+        struct Two { unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, w1 = 0, w2 = 0; };
+        auto rank = [&](Two& t, int base, unsigned w, int k) {
+            if (s_taken[base + (int)(w & 0x7FFFFu)]) return;   // taken in an earlier round
+            const unsigned key = ((w >> 23) << 8) | (unsigned)k;
+            const bool lt1 = key < t.k1, lt2 = key < t.k2;
+            t.k2 = lt1 ? t.k1 : (lt2 ? key : t.k2); t.w2 = lt1 ? t.w1 : (lt2 ? w : t.w2);
+            t.k1 = lt1 ? key : t.k1; t.w1 = lt1 ? w : t.w1;
+        };
+        auto settle = [&](const Two& t, int qi, int base) -> bool {
+            bool safe = t.k1 == 0xFFFFFFFFu || s_minq[base + (int)(t.w1 & 0x7FFFFu)] == qi;
+            if (safe && nn_ratio > 0.f && t.k2 != 0xFFFFFFFFu) safe = s_minq[base + (int)(t.w2 & 0x7FFFFu)] == qi;
+            if (safe) decide(qi, base, t.k1 != 0xFFFFFFFFu ? t.w1 : 0xFFFFFFFFu, t.k2 != 0xFFFFFFFFu ? t.w2 : 0xFFFFFFFFu);
+            return safe;
+        };
+#pragma unroll
+        for (int u = 0; u < kResOwn; ++u) {
+            const int qi = tid + u * kResT, n = own_n[u];
+            if (n < 0 || n > kProjCap || qi > first_ovf) continue;
+            Two t;
+            {
+                unsigned w[kResReg]; bool lv[kResReg];
+#pragma unroll
+                for (int k = 0; k < kResReg; ++k) w[k] = s_w[k][qi];
+#pragma unroll
+                for (int k = 0; k < kResReg; ++k) lv[k] = !s_taken[k < n ? own_base[u] + (int)(w[k] & 0x7FFFFu) : f_lo] && k < n;
+#pragma unroll
+                for (int k = 0; k < kResReg; ++k) {
+                    const unsigned key = lv[k] ? ((w[k] >> 23) << 8) | (unsigned)k : 0xFFFFFFFFu;
+                    const bool lt1 = key < t.k1, lt2 = key < t.k2;
+                    t.k2 = lt1 ? t.k1 : (lt2 ? key : t.k2); t.w2 = lt1 ? t.w1 : (lt2 ? w[k] : t.w2);
+                    t.k1 = lt1 ? key : t.k1; t.w1 = lt1 ? w[k] : t.w1;
+                }
+            }
+            for (int k = kResReg; k < n; ++k) rank(t, own_base[u], cand[(size_t)qi * kProjCap + k], k);
+            if (settle(t, qi, own_base[u])) own_n[u] = -1;
+        }
+        for (int qi = tid + kResOwn * kResT; qi < q.n; qi += kResT) {
             if (!mine(qi) || state[qi]) continue;
             const int n = cand_n[qi];
             if (n > kProjCap || qi > first_ovf) continue;
             const int base = f.cam_off[q.cam[qi]];
-            bool safe = true;
-            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, w1 = 0, w2 = 0;        // two smallest (dist, position) keys
-            for (int k = 0; k < n; ++k) {
-                const unsigned w = cand[(size_t)qi * kProjCap + k];
-                const int g = base + (int)(w & 0x7FFFFu);
-                if (s_taken[g]) continue;                       // taken in an earlier round (this round's takers never share a live candidate)
-                if (s_minq[g] != qi) { safe = false; break; }
-                const unsigned key = ((w >> 23) << 8) | (unsigned)k;
-                if (key < k1) { k2 = k1; w2 = w1; k1 = key; w1 = w; }
-                else if (key < k2) { k2 = key; w2 = w; }
-            }
-            if (!safe) continue;
-            decide(qi, k1 != 0xFFFFFFFFu ? w1 : 0xFFFFFFFFu, k2 != 0xFFFFFFFFu ? w2 : 0xFFFFFFFFu);
-            state[qi] = 1;
+            Two t;
+            for (int k = 0; k < n; ++k) rank(t, base, cand[(size_t)qi * kProjCap + k], k);
+            if (settle(t, qi, base)) state[qi] = 1;
         }
         __syncthreads();
         if (first_ovf == first) {                               // the earliest undecided query has an oversized window: wave 0 walks it
@@ -404,14 +462,37 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
                         second = (unsigned)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)has2) - 1);
                     }
                 }
-                if (lane == 0) { decide(qi, best, second); state[qi] = 1; }
+                if (lane == 0) { decide(qi, f.cam_off[q.cam[qi]], best, second); if (qi >= kResOwn * kResT) state[qi] = 1; }
             }
+#pragma unroll
+            for (int u = 0; u < kResOwn; ++u) if (tid + u * kResT == first_ovf) own_n[u] = -1;       // (its owner: decided)
             __syncthreads();
         }
     }
+    // the matches and, with the orientation check, their rotation histogram (:1072-1084): counted here, once, for every match -- inside the rounds
+    // the two angle loads of a decided query were on every round's critical path
+    __syncthreads();
+    int my_matches = 0;
+    for (int qi = tid; qi < q.n; qi += kResT) {
+        if (!mine(qi)) continue;
+        const int g = match_of_query[qi];
+        if (g < 0) continue;
+        ++my_matches;
+        if (check_ori) {
+            float rot = __fsub_rn(q.angle[qi], f.kp_angle[g]);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / kHisto));
+            if (bin == kHisto) bin = 0;
+            bin_of_query[qi] = bin;
+            atomicAdd(&s_hist[bin], 1);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) my_matches += __shfl_xor(my_matches, d);
+    if (lane == 0 && my_matches) atomicAdd(&s_nm, my_matches);
+    __syncthreads();
     int nm = s_nm;
     if (check_ori) {
-        __syncthreads();
         if (tid == 0) {                                        // ComputeThreeMaxima (:1969-2010)
             int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
             for (int i = 0; i < kHisto; ++i) {
@@ -786,6 +867,7 @@ struct DevAsm {                                    // one per frame: where the e
     int32_t* cam_off; float *kp_x, *kp_y, *kp_angle; int32_t* kp_octave; uint8_t* desc_out; int32_t *grid_off, *grid_idx;
     const float *min_x, *min_y, *w_inv, *h_inv;    // device copies of the per-camera grid constants
     int32_t* n_features;                           // [n_cams] output
+    int32_t* n_matches;                            // [kFrMaxCams] the frame's match counters (TrackItem::nm): zeroed by k_dev_assemble
     const int32_t *q_cam_in, *q_octave_in;         // mode 1: camera and octave of every query (the last frame's key point)
     double und[kFrMaxCams][9];                     // {fx, fy, cx, cy, k1, k2, p1, p2, k3} per camera
     uint8_t und_on[kFrMaxCams];                    // Frame::UndistortKeyPoints: distCoef[0] != 0 (Frame.cc:414)
@@ -801,8 +883,13 @@ __global__ __launch_bounds__(256) void k_dev_assemble(const DevAsm* __restrict__
         d.cam_off[threadIdx.x] = off[threadIdx.x];
         if (threadIdx.x < d.n_cams) d.n_features[threadIdx.x] = off[threadIdx.x + 1] - off[threadIdx.x];
     }
+    if (blockIdx.x == 0 && threadIdx.x < kFrMaxCams) d.n_matches[threadIdx.x] = 0;
     const int t = blockIdx.x * 256 + threadIdx.x;               // thread = (feature slot, 8-byte piece of its descriptor): 4 threads per feature
     const int s = t >> 2, piece = t & 3;
+    // the key-point arrays are read up to the frame's CAPACITY (all the host knows): the slots behind the last real feature are zeros. Written here,
+    // by the threads that have no feature to copy (round 6: two hipMemsetAsync in front of the upload before -- each a dispatch of its own with
+    // ~10 us of idle queue around it, 25 us of a 0.45-ms frame)
+    if (piece == 0 && s >= off[d.n_cams] && s < d.n_cams * d.cap) { d.kp_x[s] = 0.f; d.kp_y[s] = 0.f; d.kp_angle[s] = 0.f; d.kp_octave[s] = 0; }
     const int c = s / d.cap, i = s - c * d.cap;
     if (c >= d.n_cams || i >= off[c + 1] - off[c]) return;
     const size_t src = (size_t)(d.first_slot + c) * d.cap + i;
@@ -1339,10 +1426,9 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
     const size_t Etot = (size_t)std::max<long long>(n_feat, 1);
     int base = 0;
     int32_t* d_nfeat = nullptr;
-    hipStream_t raw = s.raw_st;
-    // The arena is carved in four runs so that a call costs one DMA operation up, one down and two fills whatever the number of frames: (1) everything
-    // that goes up, (2) the arrays the kernels read past a frame's real feature count (its capacity is all the host knows: they start out as zeros --
-    // ONE fill), (3) scratch, (4) everything that comes down, the per-camera match counters (zeroed: the second fill) first.
+    // The arena is carved in four runs so that a call costs one DMA operation up and one down whatever the number of frames: (1) everything
+    // that goes up, (2) the arrays the kernels read past a frame's real feature count (its capacity is all the host knows: k_dev_assemble zeroes
+    // the slots behind it), (3) scratch, (4) everything that comes down, the per-camera match counters (zeroed by k_dev_assemble too) first.
     for (int k = 0; k < F; ++k) {
         const dcs_track_dev_frame& t = frames[k];
         const dcs_dev_frame& df = t.features;
@@ -1408,25 +1494,13 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
     TrackItem* d_items; TrackItem* h_items; DevAsm* d_das; DevAsm* h_das; int32_t* d_edge_off; int32_t* h_edge_off; float* d_sig; float* h_sig; double* d_pose_in; double* h_pose_in;
     if ((rc = s.stage(&d_items, &h_items, (size_t)F)) || (rc = s.stage(&d_das, &h_das, (size_t)F)) || (rc = s.stage(&d_edge_off, &h_edge_off, (size_t)F)) ||
         (rc = s.stage(&d_sig, &h_sig, (size_t)prm->n_levels)) || (rc = s.stage(&d_pose_in, &h_pose_in, (size_t)7 * F))) return rc;
-    // (2) the zero-filled run: ONE fill over every frame's key-point arrays. The arena opens a new hipMalloc block whenever the current one is full
-    // (a thread's first call, a call that outgrows the previous ones), so the run is RESERVED first: after reserve() its arrays are carved from
-    // one block, back to back; the fill is checked against the sum of what was carved all the same. (Round 5 filled [first array, end of last
-    // array) without either: a cold thread with 5+ frames crossed the first 1-MB block inside the run and the fill covered foreign memory.)
-    {
-        size_t run = 0;
-        for (int k = 0; k < F; ++k) run += Scratch::padded(std::max<size_t>((size_t)frames[k].features.n_cams * frames[k].features.cap, 1) * sizeof(float)) * 3 +
-                                           Scratch::padded(std::max<size_t>((size_t)frames[k].features.n_cams * frames[k].features.cap, 1) * sizeof(int32_t));
-        if ((rc = s.reserve(run))) return rc;
-        char *z0 = nullptr, *z1 = nullptr;
-        for (int k = 0; k < F; ++k) {
-            DevAsm& d = das[(size_t)k];
-            const size_t Ncap = (size_t)frames[k].features.n_cams * frames[k].features.cap;
-            if ((rc = s.alloc(&d.kp_x, Ncap)) || (rc = s.alloc(&d.kp_y, Ncap)) || (rc = s.alloc(&d.kp_angle, Ncap)) || (rc = s.alloc(&d.kp_octave, Ncap))) return rc;
-            if (k == 0) z0 = reinterpret_cast<char*>(d.kp_x);
-            z1 = reinterpret_cast<char*>(d.kp_octave) + Scratch::padded(std::max<size_t>(Ncap, 1) * sizeof(*d.kp_octave));
-        }
-        if ((size_t)(z1 - z0) != run || !s.a.same_block(false, z0, z1 - 1)) { set_error("dcs_track_frame_device: the key-point run is not contiguous"); return DCS_ERR_HIP; }
-        if (hipMemsetAsync(z0, 0, run, raw) != hipSuccess) { set_error("dcs_track_frame_device: hipMemsetAsync failed"); return DCS_ERR_HIP; }
+    // (2) the key-point arrays: read up to a frame's capacity, so the slots behind its last real feature must be zeros -- k_dev_assemble writes them
+    // (round 5 filled the run with a hipMemsetAsync, and filled foreign memory when a cold thread's arena opened a second block inside the run; round 6
+    // reserved the run; now there is no fill)
+    for (int k = 0; k < F; ++k) {
+        DevAsm& d = das[(size_t)k];
+        const size_t Ncap = (size_t)frames[k].features.n_cams * frames[k].features.cap;
+        if ((rc = s.alloc(&d.kp_x, Ncap)) || (rc = s.alloc(&d.kp_y, Ncap)) || (rc = s.alloc(&d.kp_angle, Ncap)) || (rc = s.alloc(&d.kp_octave, Ncap))) return rc;
     }
     for (int k = 0; k < F; ++k) {                                   // (3) scratch
         TrackItem& it = items[(size_t)k];
@@ -1447,18 +1521,8 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
     double *d_xw, *d_obs, *d_w, *d_err, *d_out; int32_t *d_ecam, *d_cnt, *d_ninl; uint8_t *d_level, *d_outl;
     if ((rc = s.alloc(&d_xw, 3 * Etot)) || (rc = s.alloc(&d_obs, 2 * Etot)) || (rc = s.alloc(&d_w, Etot)) || (rc = s.alloc(&d_err, 2 * Etot)) ||
         (rc = s.alloc(&d_ecam, Etot)) || (rc = s.alloc(&d_cnt, (size_t)F)) || (rc = s.alloc(&d_level, Etot)) || (rc = s.alloc(&d_outl, Etot))) return rc;
-    {   // (4) what comes down: the match counters of every frame (zeroed) first, then the rest
-        char *n0 = nullptr, *n1 = nullptr;
-        const size_t nm_run = (size_t)F * Scratch::padded(sizeof(*items[0].nm) * (size_t)kFrMaxCams);
-        if ((rc = s.reserve(nm_run))) return rc;                    // (one block, like the key-point run above)
-        for (int k = 0; k < F; ++k) {
-            TrackItem& it = items[(size_t)k];
-            if ((rc = s.alloc(&it.nm, (size_t)kFrMaxCams))) return rc;
-            if (k == 0) n0 = reinterpret_cast<char*>(it.nm);
-            n1 = reinterpret_cast<char*>(it.nm) + Scratch::padded(sizeof(*it.nm) * (size_t)kFrMaxCams);
-        }
-        if ((size_t)(n1 - n0) != nm_run || !s.a.same_block(false, n0, n1 - 1)) { set_error("dcs_track_frame_device: the counter run is not contiguous"); return DCS_ERR_HIP; }
-        if (hipMemsetAsync(n0, 0, nm_run, raw) != hipSuccess) { set_error("dcs_track_frame_device: hipMemsetAsync failed"); return DCS_ERR_HIP; }
+    {   // (4) what comes down: the match counters of every frame (zeroed by k_dev_assemble) first, then the rest
+        for (int k = 0; k < F; ++k) if ((rc = s.alloc(&items[(size_t)k].nm, (size_t)kFrMaxCams))) return rc;
         if ((rc = s.alloc(&d_nfeat, (size_t)F * kFrMaxCams)) || (rc = s.alloc(&d_out, (size_t)7 * F)) || (rc = s.alloc(&d_ninl, (size_t)F))) return rc;
         for (int k = 0; k < F; ++k) {
             TrackItem& it = items[(size_t)k];
@@ -1466,7 +1530,7 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
             if ((rc = s.alloc(&it.mq, npe)) || (rc = s.alloc(&it.point_of_feature, Ne)) || (rc = s.alloc(&it.feat_outlier, Ne))) return rc;
         }
     }
-    for (int k = 0; k < F; ++k) das[(size_t)k].n_features = d_nfeat + (size_t)k * kFrMaxCams;
+    for (int k = 0; k < F; ++k) { das[(size_t)k].n_features = d_nfeat + (size_t)k * kFrMaxCams; das[(size_t)k].n_matches = items[(size_t)k].nm; }
     memcpy(h_items, items.data(), sizeof(TrackItem) * (size_t)F);
     memcpy(h_das, das.data(), sizeof(DevAsm) * (size_t)F);
     memcpy(h_edge_off, edge_off.data(), sizeof(int32_t) * (size_t)F);
