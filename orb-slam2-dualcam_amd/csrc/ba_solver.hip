@@ -2060,10 +2060,10 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs a, DCams cams)
 //  * a round's classification of the edges (:365-390) is one more pass of the same sweep code at the round's final pose, told by a flag.
 // Parity bar unchanged (tests/test_gpu_ba.py::test_pose_optimization_vs_oracle, tests/test_gpu_track.py): poses 1e-7 / 1e-8, flags, counts +-1.
 constexpr int kPoT = 256, kPoW = kPoT / 64, kPoEpt = 12;     // ONE wave per SIMD: two waves on a SIMD run this f64 code one after the other, not interleaved (tools/pose_timeline.py)
-constexpr int kPoseFastMax = 2048;
+constexpr int kPoseFastMax = 2304;      // (the most a dual rig can split over 12 slots: see the static_asserts; a frame of 2 x 1 048 feature slots stays below it)
 // A camera's edges are shared by the waves the greedy split below gives it; a frame whose largest share does not fit kPoEpt slots per lane is left to
 // k_pose_opt. The dual rig always fits (the split is 2 + 2 waves when the smaller camera has at least half the larger one's edges, else 3 + 1: 11 slots
-// at most over every split of up to 2 048 edges, tests/test_pose_split.py walks them all); a third or fourth camera fits while no camera that is left
+// for up to 2 048 edges, 12 for up to 2 304, tests/test_pose_split.py walks them all); a third or fourth camera fits while no camera that is left
 // with one wave holds more than 64 * kPoEpt = 768 edges. The slot count is the kernel's code size: the sweep is unrolled over it, 2.8 KB a slot.
 static_assert(128 * kPoEpt >= (2 * kPoseFastMax + 2) / 3, "two cameras, two waves each: the larger has at most two thirds of the edges");
 static_assert(192 * kPoEpt >= kPoseFastMax && 64 * kPoEpt >= (kPoseFastMax + 2) / 3, "two cameras, three waves and one: the smaller has less than a third");
@@ -2389,6 +2389,7 @@ __global__ __launch_bounds__(kPoT) void k_pose_opt2(PoseArgs a, DCams cams)
                 if (c == cc) my_pos[m] = (cc << 16) | __popcll(mk & ((1ull << lane) - 1ull));
                 if (lane == 0) S.cnt[cc][m * kPoW + wave] = __popcll(mk);
             }
+            asm volatile("" : "+v"(my_pos[m]));                // (computed HERE: sunk below the table set-up, the 36 ballot masks it is made from stay in scalar registers, and spill)
         }
         // the adjoint map of every camera: H'(i, j) = sum_{k <= m} K[(i, j)][(k, m)] HA(k, m), b'(r) = sum_k adj[k][r] ba(k)
         for (int idx = tid; idx < kMaxCams * 27 * 22; idx += kPoT) {

@@ -1,9 +1,6 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-python -m pytest tests/test_gpu_track.py tests/test_gpu_match.py tests/test_gpu_cpp_mirror.py tests/test_gpu_threads.py -m gpu -q 2>&1 | tail -3
-( timeout 200 python scratch/stress_track.py 70 801 2>/dev/null | tail -1 ) &
-( timeout 200 python scratch/stress_track_dev.py 70 802 2>/dev/null | tail -1 ) &
-wait
+python -m pytest tests/test_gpu_ba.py tests/test_gpu_track.py -m gpu -q 2>&1 | tail -3
+python scratch/pose_flip_stats.py 200 1 2>/dev/null | tail -1
 python bench.py --cpu-seconds 0 --no-ba --no-bow --no-c3 --no-c5 --no-two-lanes --steps 3 --warmup 1 > gpurun_out/pf.log 2>/dev/null
 python - <<'PY'
 import json

@@ -282,11 +282,11 @@ def exact_edge(request, pkg):
         yield request.param
 
 
-@pytest.mark.parametrize("seed,obs", [(8, 350), (21, 350), (22, 120), (23, 700), (24, 1000), (25, 1900), (26, 2048), (27, 2300)])
+@pytest.mark.parametrize("seed,obs", [(8, 350), (21, 350), (22, 120), (23, 700), (24, 1000), (25, 1900), (26, 2048), (27, 2300), (28, 2500)])
 def test_pose_optimization_vs_oracle(pkg, oracle, synth, seed, obs, exact_edge):
     """Optimizer::PoseOptimization batched on the GPU (one workgroup per frame, LM loop on the device) vs the oracle:
-    same outlier flags, iteration counts and inlier counts; poses to rounding. Eight seeds; 120 .. 2 048 observations per frame = 1 .. 8
-    register slots per lane of k_pose_opt2, 2 300 = k_pose_opt (the general kernel) beside it in one call."""
+    same outlier flags, iteration counts and inlier counts; poses to rounding. Nine seeds; 120 .. 2 300 observations per frame = 1 .. 9
+    register slots per lane of k_pose_opt2, 2 500 = k_pose_opt (the general kernel) beside it in one call."""
     pb = synth.pose_problem(n_frames=24 if obs <= 1000 else 8, obs_per_frame=obs, seed=seed)
     prob = dict(pb)
     prob["cams"] = [oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in pb["cams"]]
@@ -368,9 +368,9 @@ def test_pose_optimization_four_camera_rig_with_one_crowded_camera(pkg, oracle, 
 
 def test_pose_optimization_dual_rig_at_every_uneven_split_of_the_largest_frame(pkg, oracle, synth, exact_edge):
     """k_pose_opt2 gives the rig's two cameras 2 + 2 or 3 + 1 waves; the dual rig must fit its 12 register slots per lane at ANY split of a
-    2 048-edge frame (worst cases: one third / two thirds, where the split changes, and a frame seen by one camera only). No frame may fall
+    frame of up to 2 304 edges (worst cases: one third / two thirds, where the split changes, and a frame seen by one camera only). No frame may fall
     back to k_pose_opt (DCS_POSE_FAST stays on; n_iters etc. are compared with the oracle like everywhere)."""
-    splits = [(1365, 683), (1366, 682), (2048, 0), (1536, 512), (0, 2048), (1024, 1024), (683, 1365)]      # (in an order the scene's frames can supply)
+    splits = [(1365, 683), (1366, 682), (2048, 0), (1536, 768), (0, 2304), (1152, 1152), (767, 1537)]      # (in an order the scene's frames can supply)
     pb = synth.pose_problem(n_frames=2 + len(splits), obs_per_frame=8000, seed=43)
     keep, off = [], [0]
     for f in range(2 + len(splits)):
