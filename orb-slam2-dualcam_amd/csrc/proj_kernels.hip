@@ -17,6 +17,7 @@
 // inside the resolver with the same visiting code (correct, slower).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -788,17 +789,18 @@ __global__ __launch_bounds__(kResT) void k_track_resolve(const TrackItem* __rest
 }
 // Optimizer::PoseOptimization's edge list (Optimizer.cc:288-350): every feature that holds a map point, ascending feature index -- the
 // point the search has just assigned (ORBmatcher.cc:617: F.mvpMapPoints[bestIdx] = pMP), else the one it held before the call.
-__global__ __launch_bounds__(256) void k_track_edges(const TrackItem* __restrict__ items, const float* __restrict__ inv_level_sigma2, int n_levels,
+constexpr int kEdgesT = 1024;                   // (round 6: 256 before -- a 2 096-slot frame took nine passes of three barriers each, 16 us; now three)
+__global__ __launch_bounds__(kEdgesT) void k_track_edges(const TrackItem* __restrict__ items, const float* __restrict__ inv_level_sigma2, int n_levels,
                                                      double* __restrict__ xw, double* __restrict__ obs, double* __restrict__ w, int32_t* __restrict__ ecam,
                                                      int32_t* __restrict__ edge_cnt)
 {
-    __shared__ int s_wave[4];
+    __shared__ int s_wave[kEdgesT / 64];
     __shared__ int s_run;
     const TrackItem& it = items[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, N = it.f.N;
     if (tid == 0) s_run = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < N; i0 += 256) {
+    for (int i0 = 0; i0 < N; i0 += kEdgesT) {
         const int i = i0 + tid;
         int src = -1;                                              // >= 0: local map point of the new match, -2: the point held before, -1: none
         if (i < N) {
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(256) void k_track_edges(const TrackItem* __restrict
             it.edge_feature[before + rank_w] = i;
         }
         __syncthreads();
-        if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (tid == 0) { int t = 0; for (int k = 0; k < kEdgesT / 64; ++k) t += s_wave[k]; s_run += t; }
         __syncthreads();
     }
     if (tid == 0) edge_cnt[blockIdx.x] = s_run;
@@ -906,11 +908,13 @@ __global__ __launch_bounds__(256) void k_dev_assemble(const DevAsm* __restrict__
 // camera-local indices in insertion (= ascending) order. One workgroup per frame: counts in LDS, scan, placement, then every cell orders
 // its (few) entries.
 constexpr int kGridT = 1024;
-__global__ __launch_bounds__(kGridT) void k_dev_grid(const DevAsm* __restrict__ das)
+__global__ __launch_bounds__(kGridT) void k_dev_grid(const DevAsm* __restrict__ das, int cells_max)
 {
-    extern __shared__ int s_cell[];                             // [cells]: counts, then write cursors
+    extern __shared__ int s_dyn[];                              // [cells_max] counts, then write cursors; [capacity] the cells' entries until they are ordered
     __shared__ int s_scan[kGridT / 64];
     const DevAsm& d = das[blockIdx.x];
+    int* const s_cell = s_dyn;
+    int* const s_idx = s_dyn + cells_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cells = d.n_cams * DCS_GRID_COLS * DCS_GRID_ROWS, N = d.cam_off[d.n_cams];
     for (int i = tid; i < cells; i += kGridT) s_cell[i] = 0;
@@ -921,7 +925,15 @@ __global__ __launch_bounds__(kGridT) void k_dev_grid(const DevAsm* __restrict__ 
         return (px < 0 || px >= DCS_GRID_COLS || py < 0 || py >= DCS_GRID_ROWS) ? -1 : (c * DCS_GRID_COLS + px) * DCS_GRID_ROWS + py;
     };
     auto cam_of = [&](int g) { int c = 0; while (c + 1 < d.n_cams && g >= d.cam_off[c + 1]) ++c; return c; };
-    for (int g = tid; g < N; g += kGridT) { const int cl = cell_of(g, cam_of(g)); if (cl >= 0) atomicAdd(&s_cell[cl], 1); }
+    // (round 6: a thread keeps the cell and the local index of its first two features -- every feature of a frame of up to 2 048 -- from the count to
+    // the placement, and the entries are placed and ordered in LDS: the cells' insertion sorts ran on global memory, a round trip per step, 20 us)
+    int my_cl[2] = {-1, -1}, my_loc[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int g = tid + u * kGridT;
+        if (g < N) { const int c = cam_of(g); my_cl[u] = cell_of(g, c); my_loc[u] = g - d.cam_off[c]; if (my_cl[u] >= 0) atomicAdd(&s_cell[my_cl[u]], 1); }
+    }
+    for (int g = tid + 2 * kGridT; g < N; g += kGridT) { const int cl = cell_of(g, cam_of(g)); if (cl >= 0) atomicAdd(&s_cell[cl], 1); }
     __syncthreads();
     // exclusive scan over the cells: every thread owns a run of consecutive cells
     const int per = (cells + kGridT - 1) / kGridT, c0 = tid * per, c1 = min(c0 + per, cells);
@@ -934,23 +946,30 @@ __global__ __launch_bounds__(kGridT) void k_dev_grid(const DevAsm* __restrict__ 
     __syncthreads();
     int before = inc - sum;
     for (int w = 0; w < wave; ++w) before += s_scan[w];
+    const int run_begin = before;                               // first entry of this thread's run of cells
     for (int i = c0; i < c1; ++i) { const int n = s_cell[i]; d.grid_off[i] = before; s_cell[i] = before; before += n; }
     if (tid == kGridT - 1) d.grid_off[cells] = before;
     __syncthreads();
-    for (int g = tid; g < N; g += kGridT) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (my_cl[u] >= 0) s_idx[atomicAdd(&s_cell[my_cl[u]], 1)] = my_loc[u];
+    for (int g = tid + 2 * kGridT; g < N; g += kGridT) {
         const int c = cam_of(g), cl = cell_of(g, c);
-        if (cl >= 0) d.grid_idx[atomicAdd(&s_cell[cl], 1)] = g - d.cam_off[c];
+        if (cl >= 0) s_idx[atomicAdd(&s_cell[cl], 1)] = g - d.cam_off[c];
     }
     __syncthreads();
-    for (int i = c0; i < c1; ++i) {                             // s_cell[i] is now the END of cell i; insertion sort of its entries (ascending local index)
-        const int b = d.grid_off[i], e = s_cell[i];
+    for (int i = c0, b = run_begin; i < c1; ++i) {              // s_cell[i] is now the END of cell i; insertion sort of its entries (ascending local index)
+        const int e = s_cell[i];
         for (int a = b + 1; a < e; ++a) {
-            const int v = d.grid_idx[a];
+            const int v = s_idx[a];
             int k = a - 1;
-            while (k >= b && d.grid_idx[k] > v) { d.grid_idx[k + 1] = d.grid_idx[k]; --k; }
-            d.grid_idx[k + 1] = v;
+            while (k >= b && s_idx[k] > v) { s_idx[k + 1] = s_idx[k]; --k; }
+            s_idx[k + 1] = v;
         }
+        b = e;
     }
+    __syncthreads();
+    const int placed = s_cell[cells - 1];                       // (the last cell's end = entries placed: features outside the grid have none)
+    for (int k = tid; k < placed; k += kGridT) d.grid_idx[k] = s_idx[k];
 }
 // The geometry of SearchByProjectionOnCam (ORBmatcher.cc:962-968, 990-1036) for every query (a feature of the last frame with a good map
 // point): x3Ds = Rsw x3Dw + tsw in the reference's cv::Mat arithmetic (float dot product left to right, the translation added through
@@ -1358,7 +1377,7 @@ int dcs_track_local_map(int n_frames, const dcs_track_frame* frames, const dcs_t
         hipLaunchKernelGGL(k_track_collect, dim3(max_q4, F), dim3(256), 0, st, d_items);
     }
     hipLaunchKernelGGL(k_track_resolve, dim3(F), dim3(kResT), 0, st, d_items, prm->th_high, prm->nn_ratio);
-    hipLaunchKernelGGL(k_track_edges, dim3(F), dim3(256), 0, st, d_items, d_sig, prm->n_levels, d_xw, d_obs, d_w, d_ecam, d_cnt);
+    hipLaunchKernelGGL(k_track_edges, dim3(F), dim3(kEdgesT), 0, st, d_items, d_sig, prm->n_levels, d_xw, d_obs, d_w, d_ecam, d_cnt);
     DCS_CHECK_LAUNCH();
     PoseOptDevice po{};
     po.poses = d_pose_in; po.edge_off = d_edge_off; po.edge_cnt = d_cnt; po.xw = d_xw; po.obs = d_obs; po.w = d_w; po.cam = d_ecam;
@@ -1547,7 +1566,15 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
     }
     const int cells_max = max_cams * DCS_GRID_COLS * DCS_GRID_ROWS;
     hipLaunchKernelGGL(k_dev_assemble, dim3((4 * max_cap + 255) / 256, F), dim3(256), 0, st, d_das);
-    hipLaunchKernelGGL(k_dev_grid, dim3(F), dim3(kGridT), sizeof(int) * (size_t)cells_max, st, d_das);
+    {
+        const size_t grid_lds = sizeof(int) * ((size_t)cells_max + (size_t)max_cap);
+        static std::atomic<size_t> grid_lds_set{65536};            // what every launch may ask for without saying so
+        if (grid_lds > grid_lds_set.load()) {
+            DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dev_grid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)grid_lds));
+            grid_lds_set.store(grid_lds);
+        }
+        hipLaunchKernelGGL(k_dev_grid, dim3(F), dim3(kGridT), grid_lds, st, d_das, cells_max);
+    }
     if (max_pts > 0) {
         if (mode == 0) hipLaunchKernelGGL(k_track_frustum, dim3((max_pts + 255) / 256, F), dim3(256), 0, st, d_items, prm->viewing_cos_limit, prm->th);
         else hipLaunchKernelGGL(k_track_mm_queries, dim3((max_pts + 255) / 256, F), dim3(256), 0, st, d_items, d_das, prm->th);
@@ -1555,7 +1582,7 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
     }
     if (mode == 0) hipLaunchKernelGGL(k_track_resolve, dim3(F), dim3(kResT), 0, st, d_items, prm->th_high, prm->nn_ratio);
     else hipLaunchKernelGGL(k_track_resolve_cam, dim3(max_cams, F), dim3(kResT), 0, st, d_items, prm->th_high, check_orientation ? 1 : 0);
-    hipLaunchKernelGGL(k_track_edges, dim3(F), dim3(256), 0, st, d_items, d_sig, prm->n_levels, d_xw, d_obs, d_w, d_ecam, d_cnt);
+    hipLaunchKernelGGL(k_track_edges, dim3(F), dim3(kEdgesT), 0, st, d_items, d_sig, prm->n_levels, d_xw, d_obs, d_w, d_ecam, d_cnt);
     DCS_CHECK_LAUNCH();
     PoseOptDevice po{};
     po.poses = d_pose_in; po.edge_off = d_edge_off; po.edge_cnt = d_cnt; po.xw = d_xw; po.obs = d_obs; po.w = d_w; po.cam = d_ecam;
