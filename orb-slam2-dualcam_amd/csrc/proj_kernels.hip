@@ -307,7 +307,7 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
     __shared__ uint8_t s_taken[kResMaxN];
     __shared__ unsigned s_w[kResReg][kResOwn * kResT];        // candidate word k of query qi < kResOwn * kResT at [k][qi]: a thread's reads fall on its own bank
     __shared__ int s_hist[kHisto], s_ind[3];
-    __shared__ int s_first, s_firstovf, s_undecided, s_nm;
+    __shared__ int s_first[2], s_firstovf[2], s_undecided, s_nm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int f_lo = cam_filter >= 0 ? f.cam_off[cam_filter] : 0, f_hi = cam_filter >= 0 ? f.cam_off[cam_filter + 1] : f.N;
     auto mine = [&](int qi) { return cam_filter < 0 || q.cam[qi] == cam_filter; };
@@ -324,7 +324,12 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
             const int n = cand_n[qi];
             if (n > 0) { own_n[u] = n; own_base[u] = f.cam_off[q.cam[qi]]; }                 // (empty window / invalid: decided)
         }
-        for (int k = 0; k < min(min(own_n[u], kProjCap), kResReg); ++k) s_w[k][qi] = cand[(size_t)qi * kProjCap + k];
+        if (own_n[u] > 0) {                                   // the first kResReg words of the query's 64-word row, two 16-byte loads (words past the list's end are never read back)
+            static_assert(kResReg == 8 && kProjCap % 4 == 0, "two uint4 per row");
+            const uint4* row = reinterpret_cast<const uint4*>(cand + (size_t)qi * kProjCap);
+            const uint4 a = row[0], b = row[1];
+            s_w[0][qi] = a.x; s_w[1][qi] = a.y; s_w[2][qi] = a.z; s_w[3][qi] = a.w; s_w[4][qi] = b.x; s_w[5][qi] = b.y; s_w[6][qi] = b.z; s_w[7][qi] = b.w;
+        }
     }
     for (int i = tid + kResOwn * kResT; i < q.n; i += kResT) if (mine(i)) { match_of_query[i] = -1; state[i] = cand_n[i] == 0; }
     if (tid < kHisto) s_hist[tid] = 0;
@@ -343,23 +348,35 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
         match_of_query[qi] = matched;
         if (matched >= 0) { s_taken[matched] = 1; query_of_feature[matched] = qi; }
     };
-    for (;;) {
-        for (int i = f_lo + tid; i < f_hi; i += kResT) s_minq[i] = 0x7FFFFFFF;
-        if (tid == 0) { s_first = 0x7FFFFFFF; s_firstovf = 0x7FFFFFFF; s_undecided = 0; }
-        __syncthreads();
-        auto post = [&](int qi, int base, unsigned w) { const int g = base + (int)(w & 0x7FFFFu); if (!s_taken[g]) atomicMin(&s_minq[g], qi); };
-        {   // the earliest undecided query: one atomic per wave (a wave's earliest is in its slot 0 if any lane has one there: the lowest such lane)
+    // A round = rank + post | barrier | check + decide | barrier. s_minq is never reset: a post carries the round in its upper bits, counting DOWN, so
+    // that this round's posts win every atomicMin against older ones (a feature nobody posts on this round keeps a stale word nobody reads); the two
+    // "earliest undecided" words alternate between two copies, the one of the next round being reset between this round's barriers. (Round 6: three
+    // barriers, a reset pass and every list read twice per round before: 4 500 cycles a round, now ~1 500.)
+    struct Two { unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, w1 = 0, w2 = 0; };
+    auto rank = [&](Two& t, unsigned w, int k, bool live) {
+        const unsigned key = live ? ((w >> 23) << 8) | (unsigned)k : 0xFFFFFFFFu;           // (dist, position): strict "<" keeps the first of equal distances
+        const bool lt1 = key < t.k1, lt2 = key < t.k2;
+        t.k2 = lt1 ? t.k1 : (lt2 ? key : t.k2); t.w2 = lt1 ? t.w1 : (lt2 ? w : t.w2);
+        t.k1 = lt1 ? key : t.k1; t.w1 = lt1 ? w : t.w1;
+    };
+    for (int i = f_lo + tid; i < f_hi; i += kResT) s_minq[i] = 0x7FFFFFFF;
+    if (tid == 0) { s_first[0] = s_first[1] = 0x7FFFFFFF; s_firstovf[0] = s_firstovf[1] = 0x7FFFFFFF; s_undecided = 0; }
+    __syncthreads();
+    for (int round = 0;; ++round) {
+        const int par = round & 1, tag = (0x7FFF - round) << 16;
+        Two own_t[kResOwn];
+        {   // the earliest undecided query: one atomic per wave
             int mine_first = 0x7FFFFFFF;
 #pragma unroll
             for (int u = kResOwn - 1; u >= 0; --u) if (own_n[u] >= 0) mine_first = tid + u * kResT;
             const unsigned wf = wave_min_u32((unsigned)mine_first);
-            if (lane == 0 && wf != 0x7FFFFFFFu) atomicMin(&s_first, (int)wf);
+            if (lane == 0 && wf != 0x7FFFFFFFu) atomicMin(&s_first[par], (int)wf);
         }
 #pragma unroll
         for (int u = 0; u < kResOwn; ++u) {
             const int qi = tid + u * kResT, n = own_n[u];
             if (n < 0) continue;
-            if (n > kProjCap) { atomicMin(&s_firstovf, qi); continue; }
+            if (n > kProjCap) { atomicMin(&s_firstovf[par], qi); continue; }
             {   // (loads first, all of them, then the tests, then the atomics: one LDS latency per stage instead of three per candidate)
                 unsigned w[kResReg]; int g[kResReg]; bool lv[kResReg];
 #pragma unroll
@@ -369,37 +386,36 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
 #pragma unroll
                 for (int k = 0; k < kResReg; ++k) lv[k] = !s_taken[g[k]] && k < n;
 #pragma unroll
-                for (int k = 0; k < kResReg; ++k) if (lv[k]) atomicMin(&s_minq[g[k]], qi);
+                for (int k = 0; k < kResReg; ++k) if (lv[k]) atomicMin(&s_minq[g[k]], tag | qi);
+#pragma unroll
+                for (int k = 0; k < kResReg; ++k) rank(own_t[u], w[k], k, lv[k]);
             }
-            for (int k = kResReg; k < n; ++k) post(qi, own_base[u], cand[(size_t)qi * kProjCap + k]);
+            for (int k = kResReg; k < n; ++k) {
+                const unsigned w = cand[(size_t)qi * kProjCap + k];
+                const int g = own_base[u] + (int)(w & 0x7FFFFu);
+                const bool live = !s_taken[g];
+                if (live) atomicMin(&s_minq[g], tag | qi);
+                rank(own_t[u], w, k, live);
+            }
         }
         for (int qi = tid + kResOwn * kResT; qi < q.n; qi += kResT) {
             if (!mine(qi) || state[qi]) continue;
-            atomicMin(&s_first, qi);
+            atomicMin(&s_first[par], qi);
             const int n = cand_n[qi];
-            if (n > kProjCap) { atomicMin(&s_firstovf, qi); continue; }
+            if (n > kProjCap) { atomicMin(&s_firstovf[par], qi); continue; }
             const int base = f.cam_off[q.cam[qi]];
-            for (int k = 0; k < n; ++k) post(qi, base, cand[(size_t)qi * kProjCap + k]);
+            for (int k = 0; k < n; ++k) { const int g = base + (int)(cand[(size_t)qi * kProjCap + k] & 0x7FFFFu); if (!s_taken[g]) atomicMin(&s_minq[g], tag | qi); }
         }
         __syncthreads();
-        // both words are read HERE, between two barriers, by every thread: thread 0 resets them at the top of the next round
-        // without a barrier in between, so a later read could see the reset value and desynchronise the barrier phases
-        const int first = s_first, first_ovf = s_firstovf;
+        const int first = s_first[par], first_ovf = s_firstovf[par];
+        if (tid == 0) { s_first[par ^ 1] = 0x7FFFFFFF; s_firstovf[par ^ 1] = 0x7FFFFFFF; }     // (the next round's copies: nobody touches them before the barrier below)
         if (first == 0x7FFFFFFF) break;                        // everything decided
-        // the two smallest (dist, position) keys among the live candidates, then: final as soon as the candidates the decision READS cannot be
-        // taken before this query's turn -- the live set only shrinks, so the best live candidate stays the best if no earlier undecided query
-        // lists it, and with it the decision when there is no ratio test (SearchByProjectionOnCam); the ratio test also reads the second
-        struct Two { unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, w1 = 0, w2 = 0; };
-        auto rank = [&](Two& t, int base, unsigned w, int k) {
-            if (s_taken[base + (int)(w & 0x7FFFFu)]) return;   // taken in an earlier round
-            const unsigned key = ((w >> 23) << 8) | (unsigned)k;
-            const bool lt1 = key < t.k1, lt2 = key < t.k2;
-            t.k2 = lt1 ? t.k1 : (lt2 ? key : t.k2); t.w2 = lt1 ? t.w1 : (lt2 ? w : t.w2);
-            t.k1 = lt1 ? key : t.k1; t.w1 = lt1 ? w : t.w1;
-        };
+        // final as soon as the candidates the decision READS cannot be taken before this query's turn: the live set only shrinks, so the best live
+        // candidate stays the best if no earlier undecided query lists it, and with it the decision when there is no ratio test
+        // (SearchByProjectionOnCam); the ratio test also reads the second
         auto settle = [&](const Two& t, int qi, int base) -> bool {
-            bool safe = t.k1 == 0xFFFFFFFFu || s_minq[base + (int)(t.w1 & 0x7FFFFu)] == qi;
-            if (safe && nn_ratio > 0.f && t.k2 != 0xFFFFFFFFu) safe = s_minq[base + (int)(t.w2 & 0x7FFFFu)] == qi;
+            bool safe = t.k1 == 0xFFFFFFFFu || s_minq[base + (int)(t.w1 & 0x7FFFFu)] == (tag | qi);
+            if (safe && nn_ratio > 0.f && t.k2 != 0xFFFFFFFFu) safe = s_minq[base + (int)(t.w2 & 0x7FFFFu)] == (tag | qi);
             if (safe) decide(qi, base, t.k1 != 0xFFFFFFFFu ? t.w1 : 0xFFFFFFFFu, t.k2 != 0xFFFFFFFFu ? t.w2 : 0xFFFFFFFFu);
             return safe;
         };
@@ -407,23 +423,7 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
         for (int u = 0; u < kResOwn; ++u) {
             const int qi = tid + u * kResT, n = own_n[u];
             if (n < 0 || n > kProjCap || qi > first_ovf) continue;
-            Two t;
-            {
-                unsigned w[kResReg]; bool lv[kResReg];
-#pragma unroll
-                for (int k = 0; k < kResReg; ++k) w[k] = s_w[k][qi];
-#pragma unroll
-                for (int k = 0; k < kResReg; ++k) lv[k] = !s_taken[k < n ? own_base[u] + (int)(w[k] & 0x7FFFFu) : f_lo] && k < n;
-#pragma unroll
-                for (int k = 0; k < kResReg; ++k) {
-                    const unsigned key = lv[k] ? ((w[k] >> 23) << 8) | (unsigned)k : 0xFFFFFFFFu;
-                    const bool lt1 = key < t.k1, lt2 = key < t.k2;
-                    t.k2 = lt1 ? t.k1 : (lt2 ? key : t.k2); t.w2 = lt1 ? t.w1 : (lt2 ? w[k] : t.w2);
-                    t.k1 = lt1 ? key : t.k1; t.w1 = lt1 ? w[k] : t.w1;
-                }
-            }
-            for (int k = kResReg; k < n; ++k) rank(t, own_base[u], cand[(size_t)qi * kProjCap + k], k);
-            if (settle(t, qi, own_base[u])) own_n[u] = -1;
+            if (settle(own_t[u], qi, own_base[u])) own_n[u] = -1;
         }
         for (int qi = tid + kResOwn * kResT; qi < q.n; qi += kResT) {
             if (!mine(qi) || state[qi]) continue;
@@ -431,7 +431,7 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
             if (n > kProjCap || qi > first_ovf) continue;
             const int base = f.cam_off[q.cam[qi]];
             Two t;
-            for (int k = 0; k < n; ++k) rank(t, base, cand[(size_t)qi * kProjCap + k], k);
+            for (int k = 0; k < n; ++k) { const unsigned w = cand[(size_t)qi * kProjCap + k]; rank(t, w, k, !s_taken[base + (int)(w & 0x7FFFFu)]); }
             if (settle(t, qi, base)) state[qi] = 1;
         }
         __syncthreads();
