@@ -1556,12 +1556,15 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
     memcpy(h_sig, prm->inv_level_sigma2, sizeof(float) * (size_t)prm->n_levels);
     for (int k = 0; k < F; ++k) memcpy(h_pose_in + (size_t)7 * k, frames[k].pose, sizeof(double) * 7);
     hipStream_t st = s.st;                                          // (flushes the staged uploads)
-    {   // the features were produced on the caller's stream: this call's stream waits for it
-        hipEvent_t ev;
-        DCS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        hipError_t e = hipEventRecord(ev, (hipStream_t)stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
-        (void)hipEventDestroy(ev);
+    // the features were produced on the caller's stream: this call's stream waits for it -- when there is something to wait for. A stream that has
+    // drained (the second stage of a frame: the extraction ended a stage ago) needs no event: recording one and waiting for it put 8 us of idle queue in
+    // front of the first kernel and four runtime calls on the host's way to it. The event is the calling thread's own, made once.
+    if (hipStreamQuery((hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();                                // (hipErrorNotReady is what the query is for)
+        thread_local hipEvent_t tl_ev = nullptr;
+        if (!tl_ev) DCS_HIP(hipEventCreateWithFlags(&tl_ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(tl_ev, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, tl_ev, 0);
         if (e != hipSuccess) { set_error("dcs_track_frame_device: cannot order behind the caller's stream: %s", hipGetErrorString(e)); return DCS_ERR_HIP; }
     }
     const int cells_max = max_cams * DCS_GRID_COLS * DCS_GRID_ROWS;
