@@ -763,14 +763,16 @@ struct TrackItem {
     int edge_base;                                  // first edge slot of this frame (= its first feature's global number in the batch)
     int32_t *edge_feature, *point_of_feature; uint8_t* feat_outlier;
 };
-__global__ __launch_bounds__(256) void k_track_frustum(const TrackItem* __restrict__ items, float cos_limit, float th)
+__device__ __forceinline__ void track_frustum_query(const TrackItem& it, int i, float cos_limit, float th)
 {
-    const TrackItem& it = items[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= it.n_points) return;
     frustum_point(it.F, i, it.pos, it.normal, it.min_dist, it.max_dist, it.candidate, cos_limit, th, it.q_valid, it.q_cam, it.q_u, it.q_v, nullptr, it.q_level, it.q_radius);
     const int lvl = it.q_level[i];
     it.q_min[i] = lvl - 1; it.q_max[i] = lvl + 1;                    // ORBmatcher.cc:567-569: GetFeaturesInArea(..., nPredictedLevel - 1, nPredictedLevel + 1)
+}
+__global__ __launch_bounds__(256) void k_track_frustum(const TrackItem* __restrict__ items, float cos_limit, float th)
+{
+    track_frustum_query(items[blockIdx.y], blockIdx.x * 256 + threadIdx.x, cos_limit, th);
 }
 __global__ __launch_bounds__(256) void k_track_collect(const TrackItem* __restrict__ items)
 {
@@ -904,12 +906,52 @@ __global__ __launch_bounds__(256) void k_dev_assemble(const DevAsm* __restrict__
         d.kp_x[g] = ux; d.kp_y[g] = uy; d.kp_angle[g] = k.angle; d.kp_octave[g] = k.octave;
     }
 }
+// The geometry of SearchByProjectionOnCam (ORBmatcher.cc:962-968, 990-1036) for every query (a feature of the last frame with a good map
+// point): x3Ds = Rsw x3Dw + tsw in the reference's cv::Mat arithmetic (float dot product left to right, the translation added through
+// double: the small-matrix path of cv::gemm, as in frustum_point), zs < 0 -> skip, invzs = 1.0 / zs (a DOUBLE division narrowed to float,
+// :1003), u, v, the image-bounds test, radius = th * mvScaleFactors[last octave], levels octave - 1 .. octave + 1.
+__device__ __forceinline__ void track_mm_query(const TrackItem& it, const DevAsm& d, int i, float th)
+{
+    if (i >= it.n_points) return;
+    const FrustumDev& F = it.F;
+    const int c = d.q_cam_in[i], oct = min(max(d.q_octave_in[i], 0), F.n_levels - 1);
+    const float P0 = it.pos[3 * i], P1 = it.pos[3 * i + 1], P2 = it.pos[3 * i + 2];
+    float Ps[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float t0 = __fadd_rn(__fadd_rn(__fmul_rn(F.R[c][3 * r], P0), __fmul_rn(F.R[c][3 * r + 1], P1)), __fmul_rn(F.R[c][3 * r + 2], P2));
+        Ps[r] = (float)((double)t0 + (double)F.t[c][r]);
+    }
+    uint8_t ok = 0;
+    float u = 0, v = 0;
+    if (!(Ps[2] < 0.0f) && Ps[2] != 0.0f) {                       // (zs == 0 would project to infinity: treated as not visible)
+        const float invz = (float)(1.0 / (double)Ps[2]);
+        u = __fadd_rn(__fmul_rn(__fmul_rn(F.fx[c], Ps[0]), invz), F.cx[c]);
+        v = __fadd_rn(__fmul_rn(__fmul_rn(F.fy[c], Ps[1]), invz), F.cy[c]);
+        ok = !(u < F.min_x[c] || u > F.max_x[c]) && !(v < F.min_y[c] || v > F.max_y[c]);
+    }
+    it.q_valid[i] = ok; it.q_cam[i] = c; it.q_u[i] = u; it.q_v[i] = v;
+    it.q_radius[i] = __fmul_rn(th, F.scale_factors[oct]);
+    it.q_level[i] = oct; it.q_min[i] = d.q_octave_in[i] - 1; it.q_max[i] = d.q_octave_in[i] + 1;
+}
+__global__ __launch_bounds__(256) void k_track_mm_queries(const TrackItem* __restrict__ items, const DevAsm* __restrict__ das, float th)
+{
+    track_mm_query(items[blockIdx.y], das[blockIdx.y], blockIdx.x * 256 + threadIdx.x, th);
+}
 // Frame::PosInGrid + the grid fill (Frame.cc:183-190, 380-390) as the CSR dcs_frame_grid builds on the host: cells (c, ix, iy), entries =
 // camera-local indices in insertion (= ascending) order. One workgroup per frame: counts in LDS, scan, placement, then every cell orders
 // its (few) entries.
 constexpr int kGridT = 1024;
-__global__ __launch_bounds__(kGridT) void k_dev_grid(const DevAsm* __restrict__ das, int cells_max)
+// (round 6: the launch also carries the frame's QUERIES -- blocks y >= 1, a thread per map point: isInFrustum (mode 0) or SearchByProjectionOnCam's
+// geometry (mode 1). They depend on nothing the grid build does; as a launch of their own they were 5-8 us plus a kernel boundary on a 0.39-ms chain.)
+__global__ __launch_bounds__(kGridT) void k_dev_grid(const DevAsm* __restrict__ das, int cells_max, const TrackItem* __restrict__ items, int mode, float cos_limit, float th)
 {
+    if (blockIdx.y > 0) {
+        const int i = ((int)blockIdx.y - 1) * kGridT + (int)threadIdx.x;
+        if (mode == 0) track_frustum_query(items[blockIdx.x], i, cos_limit, th);
+        else track_mm_query(items[blockIdx.x], das[blockIdx.x], i, th);
+        return;
+    }
     extern __shared__ int s_dyn[];                              // [cells_max] counts, then write cursors; [capacity] the cells' entries until they are ordered
     __shared__ int s_scan[kGridT / 64];
     const DevAsm& d = das[blockIdx.x];
@@ -970,37 +1012,6 @@ __global__ __launch_bounds__(kGridT) void k_dev_grid(const DevAsm* __restrict__ 
     __syncthreads();
     const int placed = s_cell[cells - 1];                       // (the last cell's end = entries placed: features outside the grid have none)
     for (int k = tid; k < placed; k += kGridT) d.grid_idx[k] = s_idx[k];
-}
-// The geometry of SearchByProjectionOnCam (ORBmatcher.cc:962-968, 990-1036) for every query (a feature of the last frame with a good map
-// point): x3Ds = Rsw x3Dw + tsw in the reference's cv::Mat arithmetic (float dot product left to right, the translation added through
-// double: the small-matrix path of cv::gemm, as in frustum_point), zs < 0 -> skip, invzs = 1.0 / zs (a DOUBLE division narrowed to float,
-// :1003), u, v, the image-bounds test, radius = th * mvScaleFactors[last octave], levels octave - 1 .. octave + 1.
-__global__ __launch_bounds__(256) void k_track_mm_queries(const TrackItem* __restrict__ items, const DevAsm* __restrict__ das, float th)
-{
-    const TrackItem& it = items[blockIdx.y];
-    const DevAsm& d = das[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= it.n_points) return;
-    const FrustumDev& F = it.F;
-    const int c = d.q_cam_in[i], oct = min(max(d.q_octave_in[i], 0), F.n_levels - 1);
-    const float P0 = it.pos[3 * i], P1 = it.pos[3 * i + 1], P2 = it.pos[3 * i + 2];
-    float Ps[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const float t0 = __fadd_rn(__fadd_rn(__fmul_rn(F.R[c][3 * r], P0), __fmul_rn(F.R[c][3 * r + 1], P1)), __fmul_rn(F.R[c][3 * r + 2], P2));
-        Ps[r] = (float)((double)t0 + (double)F.t[c][r]);
-    }
-    uint8_t ok = 0;
-    float u = 0, v = 0;
-    if (!(Ps[2] < 0.0f) && Ps[2] != 0.0f) {                       // (zs == 0 would project to infinity: treated as not visible)
-        const float invz = (float)(1.0 / (double)Ps[2]);
-        u = __fadd_rn(__fmul_rn(__fmul_rn(F.fx[c], Ps[0]), invz), F.cx[c]);
-        v = __fadd_rn(__fmul_rn(__fmul_rn(F.fy[c], Ps[1]), invz), F.cy[c]);
-        ok = !(u < F.min_x[c] || u > F.max_x[c]) && !(v < F.min_y[c] || v > F.max_y[c]);
-    }
-    it.q_valid[i] = ok; it.q_cam[i] = c; it.q_u[i] = u; it.q_v[i] = v;
-    it.q_radius[i] = __fmul_rn(th, F.scale_factors[oct]);
-    it.q_level[i] = oct; it.q_min[i] = d.q_octave_in[i] - 1; it.q_max[i] = d.q_octave_in[i] + 1;
 }
 // mode 1: one workgroup per (camera, frame) -- the SearchByProjectionOnCam calls of SearchByProjection(Fcur, Flast, th)
 __global__ __launch_bounds__(kResT) void k_track_resolve_cam(const TrackItem* __restrict__ items, int th_high, int check_ori)
@@ -1576,13 +1587,10 @@ int dcs_track_frame_device(int n_frames, const dcs_track_dev_frame* frames, cons
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dev_grid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)grid_lds));
             grid_lds_set.store(grid_lds);
         }
-        hipLaunchKernelGGL(k_dev_grid, dim3(F), dim3(kGridT), grid_lds, st, d_das, cells_max);
+        hipLaunchKernelGGL(k_dev_grid, dim3(F, 1 + (max_pts + kGridT - 1) / kGridT), dim3(kGridT), grid_lds, st, d_das, cells_max, (const TrackItem*)d_items, mode,
+                           prm->viewing_cos_limit, prm->th);                      // the grids (y = 0) and the queries (y >= 1) in one launch
     }
-    if (max_pts > 0) {
-        if (mode == 0) hipLaunchKernelGGL(k_track_frustum, dim3((max_pts + 255) / 256, F), dim3(256), 0, st, d_items, prm->viewing_cos_limit, prm->th);
-        else hipLaunchKernelGGL(k_track_mm_queries, dim3((max_pts + 255) / 256, F), dim3(256), 0, st, d_items, d_das, prm->th);
-        hipLaunchKernelGGL(k_track_collect, dim3(max_q4, F), dim3(256), 0, st, d_items);
-    }
+    if (max_pts > 0) hipLaunchKernelGGL(k_track_collect, dim3(max_q4, F), dim3(256), 0, st, d_items);
     if (mode == 0) hipLaunchKernelGGL(k_track_resolve, dim3(F), dim3(kResT), 0, st, d_items, prm->th_high, prm->nn_ratio);
     else hipLaunchKernelGGL(k_track_resolve_cam, dim3(max_cams, F), dim3(kResT), 0, st, d_items, prm->th_high, check_orientation ? 1 : 0);
     hipLaunchKernelGGL(k_track_edges, dim3(F), dim3(kEdgesT), 0, st, d_items, d_sig, prm->n_levels, d_xw, d_obs, d_w, d_ecam, d_cnt);
