@@ -202,3 +202,23 @@ def test_linearize_blocks_are_the_sums_of_the_edge_jacobians(oracle, synth):
         assert np.allclose(lin["Hpp"], Hpp[free], **tol) and np.allclose(lin["bp"], bp[free], **tol)
         assert np.allclose(lin["Hll"], Hll, **tol) and np.allclose(lin["bl"], bl, **tol) and np.allclose(lin["Hpl"], Hpl, **tol)
         assert not np.any(lin["Hpl"][pb["pose_fixed"][pb["edge_pose"]] != 0])
+
+
+def test_weakly_constrained_draw_is_chaotic_in_the_oracle_itself(oracle, synth):
+    """The one hard mismatch of round 6's random sweeps (profiles/r06_parity_sweeps.txt): 29 poses, every point seen 4 times, 20 % gross outliers --
+    GPU and oracle run the same LM iterations and trials and end 9.5e-4 apart in a pose translation, where north_star's bar is 1e-4. The bar has no
+    meaning on this draw: the oracle ALONE moves by more than 1e-4 when its observations change in the sixteenth digit (below the rounding of one
+    projection). What such problems are held to instead: tests/test_gpu_ba.py::test_ba_ill_conditioned_documented_bound."""
+    pb = synth.ba_problem(n_poses=29, n_fixed=5, n_points=384, obs_per_point=4, seed=9455, outlier_frac=0.2, exact_adjoint=True)
+
+    def run(q):
+        prob = dict(q)
+        prob["cams"] = [oracle.make_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["ext7"], c["adj"]) for c in q["cams"]]
+        return oracle.ba_local(prob)
+    base = run(pb)
+    rng = np.random.default_rng(1)
+    nudged = dict(pb)
+    nudged["obs"] = pb["obs"] * (1 + 1e-15 * rng.standard_normal(pb["obs"].shape))
+    other = run(nudged)
+    assert other["n_iters"] == base["n_iters"] and other["n_trials"] == base["n_trials"]
+    assert np.abs(other["poses"][:, :3] - base["poses"][:, :3]).max() > 1e-4
