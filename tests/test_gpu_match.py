@@ -158,10 +158,14 @@ def _proj_problem(pkg, oracle, synth, **kw):
 
 @pytest.mark.parametrize("kw", [dict(n_per_cam=900, n_queries=700, seed=13),
                                 dict(n_per_cam=2000, n_queries=1500, seed=2, th=3.0),
-                                dict(n_per_cam=400, n_queries=300, seed=5, big_windows=25)])
+                                dict(n_per_cam=400, n_queries=300, seed=5, big_windows=25),
+                                dict(n_per_cam=2000, n_queries=2600, seed=31),
+                                dict(n_per_cam=1800, n_queries=3300, seed=32, th=3.0, big_windows=12)])
 def test_search_by_projection(pkg, oracle, synth, kw):
     """ORBmatcher::SearchByProjection (ratio rule) and SearchByProjectionOnCam (best only + rotation histogram): the
-    order-dependent greedy result must equal the sequential oracle exactly, including windows beyond the candidate cap."""
+    order-dependent greedy result must equal the sequential oracle exactly, including windows beyond the candidate cap -- and queries
+    beyond the 2 048 whose state the parallel resolver keeps on chip (round 6: the later ones go through its global-memory path, next to
+    on-chip ones whose lists are longer than the 8 words held in LDS)."""
     frame, q = _proj_problem(pkg, oracle, synth, **kw)
     m = pkg.ORBmatcher(0.8, True)
     for use_ratio, ori in ((True, False), (False, True), (False, False)):
