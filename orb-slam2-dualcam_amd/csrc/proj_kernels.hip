@@ -312,26 +312,52 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
     const int f_lo = cam_filter >= 0 ? f.cam_off[cam_filter] : 0, f_hi = cam_filter >= 0 ? f.cam_off[cam_filter + 1] : f.N;
     auto mine = [&](int qi) { return cam_filter < 0 || q.cam[qi] == cam_filter; };
     for (int i = f_lo + tid; i < f_hi; i += kResT) { s_taken[i] = f.taken[i]; query_of_feature[i] = -1; }
-    // thread t owns the queries t, t + kResT, ...: the first kResOwn of them keep their state on chip (n = -1: none / not this camera's / decided),
-    // the rest -- frames with more than kResOwn * kResT queries -- in the global arrays as before
-    int own_n[kResOwn], own_base[kResOwn];
+    // The queries that have anything to decide -- this camera's, with a non-empty list -- are counted off in index order; the first kResOwn * kResT of
+    // them keep their state on chip: thread t owns ranks t, t + kResT (query index, list length and base in registers; n = -1: none / decided), the
+    // first kResReg words of their lists in LDS at [k][rank]. Later ones (a local map of many thousand points IN VIEW) stay in the global arrays.
+    // (Round 6, late: the on-chip slots went to the first 2 048 query INDICES before -- of a 6 000-point local map two thirds of the visible points
+    // sat behind them, on the slow path: 60 us instead of 27; 148 instead of 50 at 12 000.)
+    __shared__ int s_act[kResOwn * kResT];
+    __shared__ int s_wcnt[kResT / 64];
+    __shared__ int s_run, s_rest;
+    if (tid == 0) { s_run = 0; s_rest = q.n; }
+    __syncthreads();
+    for (int base = 0; base < q.n; base += kResT) {
+        const int qi = base + tid;
+        const bool m = qi < q.n && mine(qi);
+        const int n = m ? cand_n[qi] : 0;
+        if (m) { match_of_query[qi] = -1; if (n <= 0) state[qi] = 1; }      // (empty window / invalid: decided)
+        const bool act = n > 0;
+        const unsigned long long bal = __ballot(act);
+        if (lane == 0) s_wcnt[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        int before = s_run;
+        for (int w = 0; w < (tid >> 6); ++w) before += s_wcnt[w];
+        if (act) {
+            const int r = before + __popcll(bal & ((1ull << lane) - 1ull));
+            if (r < kResOwn * kResT) s_act[r] = qi;
+            else { state[qi] = 0; atomicMin(&s_rest, qi); }
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < kResT / 64; ++w) t += s_wcnt[w]; s_run += t; }
+        __syncthreads();
+    }
+    const int n_on = min(s_run, kResOwn * kResT), rest = s_rest;      // on-chip ranks [0, n_on); the global path takes the queries from index `rest` on
+    int own_n[kResOwn], own_base[kResOwn], own_qi[kResOwn];
 #pragma unroll
     for (int u = 0; u < kResOwn; ++u) {
-        const int qi = tid + u * kResT;
-        own_n[u] = -1; own_base[u] = 0;
-        if (qi < q.n && mine(qi)) {
-            match_of_query[qi] = -1;
-            const int n = cand_n[qi];
-            if (n > 0) { own_n[u] = n; own_base[u] = f.cam_off[q.cam[qi]]; }                 // (empty window / invalid: decided)
-        }
-        if (own_n[u] > 0) {                                   // the first kResReg words of the query's 64-word row, two 16-byte loads (words past the list's end are never read back)
+        const int k = tid + u * kResT;
+        own_n[u] = -1; own_base[u] = 0; own_qi[u] = 0x7FFFFFFF;
+        if (k < n_on) {
+            const int qi = s_act[k];
+            own_qi[u] = qi; own_n[u] = cand_n[qi]; own_base[u] = f.cam_off[q.cam[qi]];
+            // the first kResReg words of the query's 64-word row, two 16-byte loads (words past the list's end are never read back)
             static_assert(kResReg == 8 && kProjCap % 4 == 0, "two uint4 per row");
             const uint4* row = reinterpret_cast<const uint4*>(cand + (size_t)qi * kProjCap);
             const uint4 a = row[0], b = row[1];
-            s_w[0][qi] = a.x; s_w[1][qi] = a.y; s_w[2][qi] = a.z; s_w[3][qi] = a.w; s_w[4][qi] = b.x; s_w[5][qi] = b.y; s_w[6][qi] = b.z; s_w[7][qi] = b.w;
+            s_w[0][k] = a.x; s_w[1][k] = a.y; s_w[2][k] = a.z; s_w[3][k] = a.w; s_w[4][k] = b.x; s_w[5][k] = b.y; s_w[6][k] = b.z; s_w[7][k] = b.w;
         }
     }
-    for (int i = tid + kResOwn * kResT; i < q.n; i += kResT) if (mine(i)) { match_of_query[i] = -1; state[i] = cand_n[i] == 0; }
     if (tid < kHisto) s_hist[tid] = 0;
     if (tid == 0) s_nm = 0;
     __syncthreads();
@@ -362,25 +388,31 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
     for (int i = f_lo + tid; i < f_hi; i += kResT) s_minq[i] = 0x7FFFFFFF;
     if (tid == 0) { s_first[0] = s_first[1] = 0x7FFFFFFF; s_firstovf[0] = s_firstovf[1] = 0x7FFFFFFF; s_undecided = 0; }
     __syncthreads();
+    const bool tagged = q.n <= 0x7FFF;                         // (a round decides at least one query: at most q.n rounds, and a query index fits the lower 16 bits)
     for (int round = 0;; ++round) {
-        const int par = round & 1, tag = (0x7FFF - round) << 16;
+        const int par = round & 1, tag = tagged ? (0x7FFF - round) << 16 : 0;
+        if (!tagged) {                                          // more queries than the tag holds (never seen): the reset pass of before
+            __syncthreads();
+            for (int i = f_lo + tid; i < f_hi; i += kResT) s_minq[i] = 0x7FFFFFFF;
+            __syncthreads();
+        }
         Two own_t[kResOwn];
         {   // the earliest undecided query: one atomic per wave
             int mine_first = 0x7FFFFFFF;
 #pragma unroll
-            for (int u = kResOwn - 1; u >= 0; --u) if (own_n[u] >= 0) mine_first = tid + u * kResT;
+            for (int u = kResOwn - 1; u >= 0; --u) if (own_n[u] >= 0) mine_first = own_qi[u];
             const unsigned wf = wave_min_u32((unsigned)mine_first);
             if (lane == 0 && wf != 0x7FFFFFFFu) atomicMin(&s_first[par], (int)wf);
         }
 #pragma unroll
         for (int u = 0; u < kResOwn; ++u) {
-            const int qi = tid + u * kResT, n = own_n[u];
+            const int qi = own_qi[u], n = own_n[u], slot = tid + u * kResT;
             if (n < 0) continue;
             if (n > kProjCap) { atomicMin(&s_firstovf[par], qi); continue; }
             {   // (loads first, all of them, then the tests, then the atomics: one LDS latency per stage instead of three per candidate)
                 unsigned w[kResReg]; int g[kResReg]; bool lv[kResReg];
 #pragma unroll
-                for (int k = 0; k < kResReg; ++k) w[k] = s_w[k][qi];
+                for (int k = 0; k < kResReg; ++k) w[k] = s_w[k][slot];
 #pragma unroll
                 for (int k = 0; k < kResReg; ++k) g[k] = k < n ? own_base[u] + (int)(w[k] & 0x7FFFFu) : f_lo;
 #pragma unroll
@@ -398,7 +430,7 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
                 rank(own_t[u], w, k, live);
             }
         }
-        for (int qi = tid + kResOwn * kResT; qi < q.n; qi += kResT) {
+        for (int qi = rest + tid; qi < q.n; qi += kResT) {
             if (!mine(qi) || state[qi]) continue;
             atomicMin(&s_first[par], qi);
             const int n = cand_n[qi];
@@ -421,11 +453,11 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
         };
 #pragma unroll
         for (int u = 0; u < kResOwn; ++u) {
-            const int qi = tid + u * kResT, n = own_n[u];
+            const int qi = own_qi[u], n = own_n[u];
             if (n < 0 || n > kProjCap || qi > first_ovf) continue;
             if (settle(own_t[u], qi, own_base[u])) own_n[u] = -1;
         }
-        for (int qi = tid + kResOwn * kResT; qi < q.n; qi += kResT) {
+        for (int qi = rest + tid; qi < q.n; qi += kResT) {
             if (!mine(qi) || state[qi]) continue;
             const int n = cand_n[qi];
             if (n > kProjCap || qi > first_ovf) continue;
@@ -463,10 +495,10 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
                         second = (unsigned)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)has2) - 1);
                     }
                 }
-                if (lane == 0) { decide(qi, f.cam_off[q.cam[qi]], best, second); if (qi >= kResOwn * kResT) state[qi] = 1; }
+                if (lane == 0) { decide(qi, f.cam_off[q.cam[qi]], best, second); if (qi >= rest) state[qi] = 1; }
             }
 #pragma unroll
-            for (int u = 0; u < kResOwn; ++u) if (tid + u * kResT == first_ovf) own_n[u] = -1;       // (its owner: decided)
+            for (int u = 0; u < kResOwn; ++u) if (own_qi[u] == first_ovf) own_n[u] = -1;             // (its owner: decided)
             __syncthreads();
         }
     }
