@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjFrameD f_arg, ProjQueri
 // (re-walk of the window) when it becomes the earliest undecided one, and blocks the later ones until then.
 constexpr int kResT = 1024;
 constexpr int kResMaxN = 16384;                 // features whose minq / taken maps fit in LDS (80 KB)
-constexpr int kResOwn = 2, kResReg = 8;         // queries per thread whose state stays on chip (frames of up to 2 048 queries entirely): list length and base in registers, the first kResReg candidate words in LDS (64 KB)
+constexpr int kResOwn = 4, kResReg = 4;         // queries per thread whose state stays on chip (the first 4 096 with anything to decide): index, list length and base in registers, the first kResReg candidate words in LDS (64 KB; 2 x 8 measured the same at 2 000 queries and slower beyond)
 
 __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const ProjQueriesD& q, const unsigned* __restrict__ cand,
                                                       const int32_t* __restrict__ cand_n, uint8_t* __restrict__ state /* [n] 0 = undecided */,
@@ -316,32 +316,58 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
     // them keep their state on chip: thread t owns ranks t, t + kResT (query index, list length and base in registers; n = -1: none / decided), the
     // first kResReg words of their lists in LDS at [k][rank]. Later ones (a local map of many thousand points IN VIEW) stay in the global arrays.
     // (Round 6, late: the on-chip slots went to the first 2 048 query INDICES before -- of a 6 000-point local map two thirds of the visible points
-    // sat behind them, on the slow path: 60 us instead of 27; 148 instead of 50 at 12 000.)
-    __shared__ int s_act[kResOwn * kResT];
-    __shared__ int s_wcnt[kResT / 64];
+    // sat behind them, on the slow path: 60 us instead of 23; 148 instead of 40 at 12 000.)
+    int* const s_act = reinterpret_cast<int*>(&s_w[0][0]);        // (rank k's query index: read by the thread that then writes s_w[.][k], nobody else)
+    constexpr int kResChunks = 64;                              // chunks of kResT queries whose activity bits a thread holds (65 536 queries)
+    __shared__ int s_pre[kResChunks * (kResT / 64)];            // active queries per (chunk, wave), then their exclusive prefix in index order
+    __shared__ int s_part[kResT / 64];
     __shared__ int s_run, s_rest;
+    const int chunks = (q.n + kResT - 1) / kResT, wave_id = tid >> 6;
     if (tid == 0) { s_run = 0; s_rest = q.n; }
-    __syncthreads();
-    for (int base = 0; base < q.n; base += kResT) {
-        const int qi = base + tid;
-        const bool m = qi < q.n && mine(qi);
-        const int n = m ? cand_n[qi] : 0;
-        if (m) { match_of_query[qi] = -1; if (n <= 0) state[qi] = 1; }      // (empty window / invalid: decided)
-        const bool act = n > 0;
-        const unsigned long long bal = __ballot(act);
-        if (lane == 0) s_wcnt[tid >> 6] = __popcll(bal);
+    // (three barriers per chunk before: a 12 000-point local map spent a dozen barrier-and-load round trips here. Now: every thread reads the
+    // activity of ALL its queries, the per-(chunk, wave) counts are scanned as one table, and the ranks follow from the ballots.)
+    unsigned long long act_bits = 0;                            // bit c: query c * kResT + tid has something to decide
+    if (chunks <= kResChunks) {
+#pragma unroll 8
+        for (int c = 0; c < chunks; ++c) {                      // (nothing in this loop waits for a load but the bit it sets: eight chunks' loads fly together)
+            const int qi = c * kResT + tid;
+            const bool m = qi < q.n && mine(qi);
+            const int n = m ? cand_n[qi] : 0;
+            if (m) { match_of_query[qi] = -1; if (n <= 0) state[qi] = 1; }   // (empty window / invalid: decided)
+            if (n > 0) act_bits |= 1ull << c;
+        }
+        for (int c = 0; c < chunks; ++c) {
+            const unsigned long long bal = __ballot((act_bits >> c) & 1ull);
+            if (lane == 0) s_pre[c * (kResT / 64) + wave_id] = __popcll(bal);
+        }
         __syncthreads();
-        int before = s_run;
-        for (int w = 0; w < (tid >> 6); ++w) before += s_wcnt[w];
-        if (act) {
-            const int r = before + __popcll(bal & ((1ull << lane) - 1ull));
+        {   // exclusive scan of the table (chunk-major, wave-minor = query index order), one entry per thread
+            const int n_ent = chunks * (kResT / 64);
+            const int v = tid < n_ent ? s_pre[tid] : 0;
+            int inc = v;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { const int t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
+            if (lane == 63) s_part[wave_id] = inc;
+            __syncthreads();
+            int before = inc - v;
+            for (int w = 0; w < wave_id; ++w) before += s_part[w];
+            if (tid < n_ent) s_pre[tid] = before;
+            if (tid == n_ent - 1) s_run = before + v;
+        }
+        __syncthreads();
+        for (int c = 0; c < chunks; ++c) {
+            const bool act = (act_bits >> c) & 1ull;
+            const unsigned long long bal = __ballot(act);
+            if (!act) continue;
+            const int qi = c * kResT + tid, r = s_pre[c * (kResT / 64) + wave_id] + __popcll(bal & ((1ull << lane) - 1ull));
             if (r < kResOwn * kResT) s_act[r] = qi;
             else { state[qi] = 0; atomicMin(&s_rest, qi); }
         }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int w = 0; w < kResT / 64; ++w) t += s_wcnt[w]; s_run += t; }
-        __syncthreads();
+    } else {                                                    // more queries than the bits hold (never seen): everything on the global path
+        for (int qi = tid; qi < q.n; qi += kResT) if (mine(qi)) { match_of_query[qi] = -1; state[qi] = cand_n[qi] == 0; }
+        if (tid == 0) s_rest = 0;
     }
+    __syncthreads();
     const int n_on = min(s_run, kResOwn * kResT), rest = s_rest;      // on-chip ranks [0, n_on); the global path takes the queries from index `rest` on
     int own_n[kResOwn], own_base[kResOwn], own_qi[kResOwn];
 #pragma unroll
@@ -352,10 +378,9 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
             const int qi = s_act[k];
             own_qi[u] = qi; own_n[u] = cand_n[qi]; own_base[u] = f.cam_off[q.cam[qi]];
             // the first kResReg words of the query's 64-word row, two 16-byte loads (words past the list's end are never read back)
-            static_assert(kResReg == 8 && kProjCap % 4 == 0, "two uint4 per row");
-            const uint4* row = reinterpret_cast<const uint4*>(cand + (size_t)qi * kProjCap);
-            const uint4 a = row[0], b = row[1];
-            s_w[0][k] = a.x; s_w[1][k] = a.y; s_w[2][k] = a.z; s_w[3][k] = a.w; s_w[4][k] = b.x; s_w[5][k] = b.y; s_w[6][k] = b.z; s_w[7][k] = b.w;
+            static_assert(kResReg == 4 && kProjCap % 4 == 0, "one uint4 per row");
+            const uint4 a = *reinterpret_cast<const uint4*>(cand + (size_t)qi * kProjCap);
+            s_w[0][k] = a.x; s_w[1][k] = a.y; s_w[2][k] = a.z; s_w[3][k] = a.w;
         }
     }
     if (tid < kHisto) s_hist[tid] = 0;
@@ -504,12 +529,12 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
     }
     // the matches and, with the orientation check, their rotation histogram (:1072-1084): counted here, once, for every match -- inside the rounds
     // the two angle loads of a decided query were on every round's critical path
+    // (only queries that had something to decide can hold a match: a thread's on-chip ones -- their results read back together -- and the global
+    // path's from index `rest` on; a walk over every query of a 12 000-point local map was a dozen dependent global loads)
     __syncthreads();
     int my_matches = 0;
-    for (int qi = tid; qi < q.n; qi += kResT) {
-        if (!mine(qi)) continue;
-        const int g = match_of_query[qi];
-        if (g < 0) continue;
+    auto count = [&](int qi, int g) {
+        if (g < 0) return;
         ++my_matches;
         if (check_ori) {
             float rot = __fsub_rn(q.angle[qi], f.kp_angle[g]);
@@ -519,7 +544,13 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
             bin_of_query[qi] = bin;
             atomicAdd(&s_hist[bin], 1);
         }
-    }
+    };
+    int own_g[kResOwn];
+#pragma unroll
+    for (int u = 0; u < kResOwn; ++u) own_g[u] = own_qi[u] != 0x7FFFFFFF ? match_of_query[own_qi[u]] : -1;
+#pragma unroll
+    for (int u = 0; u < kResOwn; ++u) count(own_qi[u], own_g[u]);
+    for (int qi = rest + tid; qi < q.n; qi += kResT) if (mine(qi)) count(qi, match_of_query[qi]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) my_matches += __shfl_xor(my_matches, d);
     if (lane == 0 && my_matches) atomicAdd(&s_nm, my_matches);
@@ -540,13 +571,14 @@ __device__ __forceinline__ void proj_resolve_par_body(const ProjFrameD& f, const
             s_undecided = 0;                                    // reused: number of removed matches
         }
         __syncthreads();
-        for (int qi = tid; qi < q.n; qi += kResT) {
-            if (!mine(qi)) continue;
-            const int g = match_of_query[qi];
-            if (g < 0) continue;
+        auto prune = [&](int qi, int g) {
+            if (g < 0) return;
             const int b = bin_of_query[qi];
             if (b != s_ind[0] && b != s_ind[1] && b != s_ind[2]) { match_of_query[qi] = -1; query_of_feature[g] = -1; atomicAdd(&s_undecided, 1); }
-        }
+        };
+#pragma unroll
+        for (int u = 0; u < kResOwn; ++u) prune(own_qi[u], own_g[u]);
+        for (int qi = rest + tid; qi < q.n; qi += kResT) if (mine(qi)) prune(qi, match_of_query[qi]);
         __syncthreads();
         nm -= s_undecided;
     }
