@@ -41,7 +41,9 @@ def _oracle_chain(oracle, fr, prm):
 
 @pytest.mark.parametrize("kw", [dict(n_frames=5, n_points=1200, n_features=900, seed=17),
                                 dict(n_frames=3, n_points=2500, n_features=1600, seed=29, th=3.0),
-                                dict(n_frames=2, n_points=400, n_features=300, seed=5, pre_matched=0.6)])
+                                dict(n_frames=2, n_points=400, n_features=300, seed=5, pre_matched=0.6),
+                                dict(n_frames=2, n_points=9000, n_features=2000, seed=61),                 # a local map of the reference's size: more points in
+                                dict(n_frames=1, n_points=14000, n_features=2000, seed=62, th=3.0)])      # view than the resolver keeps on chip (4 096)
 def test_track_local_map_equals_the_three_stages(pkg, oracle, synth, kw):
     frames, prm = synth.tracking_problem(**kw)
     _with_grid(pkg, frames)
