@@ -1,10 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python scratch/time_seam.py 2>/dev/null | tail -1
-python - <<'PY' 2>/dev/null | tail -1
-import torch
-torch.zeros(4, device="cuda")
-exec(open("scratch/time_seam.py").read())
-PY
-python bench.py --cpu-seconds 0 --no-ba --no-bow --no-c3 --no-c5 --no-two-lanes --steps 2 --warmup 1 2>/dev/null | python -c "
-import sys,json
-lines=[l for l in sys.stdin.read().splitlines() if l.startswith('{')]; d=json.loads(lines[-1]); print(d['seam_latency'])"
+for i in 1 2 3; do python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|error" | tail -1; done
+for i in 1 2 3 4 5 6; do python -m pytest tests/test_gpu_track.py tests/test_gpu_match.py -m gpu -q -x 2>&1 | grep -E "passed|failed|error" | tail -1; done
